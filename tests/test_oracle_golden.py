@@ -1,0 +1,208 @@
+"""Pins oracle/cpu_ref.py against the golden vectors the REFERENCE produced (tests/golden/make_goldens.py).
+
+CPU only.  Tolerances: the oracle replays the reference's torch op sequence, so forward values are
+expected bit-identical or within a few ulp (1e-6 rel); integer outputs (ranked ids, ranks, hits) exact.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cpu_ref as O
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+T = lambda a: torch.from_numpy(np.asarray(a))
+RTOL, ATOL = 1e-5, 1e-6
+
+
+def close(a, b, rtol=RTOL, atol=ATOL):
+    a = a.detach().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol)
+
+
+def leaf(g, key):
+    return T(g[key]).clone().requires_grad_(True)
+
+
+@pytest.mark.parametrize('d', [36, 64, 100])
+def test_bprmf_scores_loss_grads(golden, d):
+    g = golden('score_d%d' % d)
+    U, I = leaf(g, 'bprmf.user_embeddings.weight'), leaf(g, 'bprmf.item_embeddings.weight')
+    u, pi, ni = T(g['u']), T(g['pi']), T(g['ni'])
+    pos, neg = O.score_bprmf(U, I, u, pi), O.score_bprmf(U, I, u, ni)
+    close(pos, g['bprmf.pos']); close(neg, g['bprmf.neg'])
+    loss = O.bpr_loss(pos, neg, 1.0)
+    close(loss, g['bprmf.loss'])
+    loss.backward()
+    close(U.grad, g['bprmf.grad.user_embeddings.weight']); close(I.grad, g['bprmf.grad.item_embeddings.weight'])
+
+
+@pytest.mark.parametrize('d', [36, 64, 100])
+@pytest.mark.parametrize('l1', [False, True])
+@pytest.mark.parametrize('name', ['transe', 'transh', 'transr'])
+def test_kg_scorers(golden, d, l1, name):
+    g = golden('score_d%d' % d)
+    tag = '%s.%s.' % (name, 'L1' if l1 else 'L2')
+    E, R = leaf(g, name + '.ent_embeddings.weight'), leaf(g, name + '.rel_embeddings.weight')
+    ph, pt, pr, nh, nt = (T(g[k]) for k in ('ph', 'pt', 'pr', 'nh', 'nt'))
+    extra = None
+    if name == 'transe':
+        f = lambda h, t, r: O.score_transe(E, R, h, t, r, l1)
+    elif name == 'transh':
+        extra = leaf(g, 'transh.norm_embeddings.weight')
+        f = lambda h, t, r: O.score_transh(E, R, extra, h, t, r, l1)
+    else:
+        extra = leaf(g, 'transr.proj_embeddings.weight')
+        f = lambda h, t, r: O.score_transr(E, R, extra, h, t, r, l1)
+    pos, neg = f(ph, pt, pr), f(nh, nt, pr)
+    close(pos, g[tag + 'pos']); close(neg, g[tag + 'neg'])
+    loss = O.margin_loss(pos, neg, 1.0)
+    rel = R[torch.cat([pr, pr])]
+    if name == 'transh':
+        loss = loss + O.orthogonal_loss(rel, extra[torch.cat([pr, pr])])
+    loss = loss + O.norm_loss(E[torch.cat([ph, pt, nh, nt])]) + O.norm_loss(rel)
+    close(loss, g[tag + 'loss'], rtol=1e-5)
+    loss.backward()
+    close(E.grad, g[tag + 'grad.ent_embeddings.weight'], atol=1e-5)
+    close(R.grad, g[tag + 'grad.rel_embeddings.weight'], atol=1e-5)
+    if name == 'transh':
+        close(extra.grad, g[tag + 'grad.norm_embeddings.weight'], atol=1e-5)
+    if name == 'transr':
+        close(extra.grad, g[tag + 'grad.proj_embeddings.weight'], atol=1e-5)
+
+
+@pytest.mark.parametrize('d', [36, 64, 100])
+@pytest.mark.parametrize('l1', [False, True])
+@pytest.mark.parametrize('gum', [False, True])
+def test_tup(golden, d, l1, gum):
+    g = golden('score_d%d' % d)
+    tag = 'tup.%s.%s.' % ('L1' if l1 else 'L2', 'hard' if gum else 'soft')
+    U, I = leaf(g, 'tup.user_embeddings.weight'), leaf(g, 'tup.item_embeddings.weight')
+    P, Pn = leaf(g, 'tup.pref_embeddings.weight'), leaf(g, 'tup.pref_norm_embeddings.weight')
+    u, pi, ni = T(g['u']), T(g['pi']), T(g['ni'])
+    up = T(g[tag + 'uni_pos']) if gum else None
+    un = T(g[tag + 'uni_neg']) if gum else None
+    pos, neg = O.score_tup(U, I, P, Pn, u, pi, l1, up), O.score_tup(U, I, P, Pn, u, ni, l1, un)
+    close(pos, g[tag + 'pos']); close(neg, g[tag + 'neg'])
+    loss = O.bpr_loss(pos, neg, -1.0) + O.orthogonal_loss(P, Pn) + O.norm_loss(U[u]) \
+        + O.norm_loss(I[torch.cat([pi, ni])]) + O.norm_loss(P)
+    close(loss, g[tag + 'loss'])
+    loss.backward()
+    for w, k in ((U, 'user_embeddings'), (I, 'item_embeddings'), (P, 'pref_embeddings'), (Pn, 'pref_norm_embeddings')):
+        close(w.grad, g[tag + 'grad.%s.weight' % k], atol=1e-5)
+    if not gum:
+        pr_, re_, no_ = O.tup_preferences(U[u], I[pi], P, Pn)
+        close(pr_, g[tag + 'pref.probs']); close(re_, g[tag + 'pref.r_e']); close(no_, g[tag + 'pref.norm'])
+
+
+@pytest.mark.parametrize('d', [36, 64, 100])
+@pytest.mark.parametrize('l1', [False, True])
+@pytest.mark.parametrize('gum', [False, True])
+def test_ktup(golden, d, l1, gum):
+    g = golden('score_d%d' % d)
+    tag = 'ktup.%s.%s.' % ('L1' if l1 else 'L2', 'hard' if gum else 'soft')
+    names = ['user_embeddings', 'item_embeddings', 'ent_embeddings', 'pref_embeddings', 'pref_norm_embeddings',
+             'rel_embeddings', 'norm_embeddings']
+    W = {k: leaf(g, 'ktup.%s.weight' % k) for k in names}
+    i2e = T(g['ktup.item2ent'])
+    u, pi, ni = T(g['u']), T(g['pi']), T(g['ni'])
+    up = T(g[tag + 'uni_pos']) if gum else None
+    un = T(g[tag + 'uni_neg']) if gum else None
+    rec = lambda i, uni: O.score_ktup_rec(W['user_embeddings'], W['item_embeddings'], W['ent_embeddings'],
+                                          W['pref_embeddings'], W['pref_norm_embeddings'], W['rel_embeddings'],
+                                          W['norm_embeddings'], i2e, u, i, l1, uni)
+    pos, neg = rec(pi, up), rec(ni, un)
+    close(pos, g[tag + 'rec.pos']); close(neg, g[tag + 'rec.neg'])
+    loss = O.bpr_loss(pos, neg, -1.0) + O.orthogonal_loss(W['pref_embeddings'], W['pref_norm_embeddings'])
+    close(loss, g[tag + 'rec.loss'])
+    loss.backward()
+    for k in names:
+        key = tag + 'rec.grad.%s.weight' % k
+        if key in g:
+            got = W[k].grad.clone()
+            if k == 'ent_embeddings':
+                got[-1].zero_()          # nn.Embedding(padding_idx=...) never accumulates a grad for the pad row
+            close(got, g[key], atol=1e-5)
+    if not gum:
+        for w in W.values():
+            w.grad = None
+        ph, pt, pr, nh, nt = (T(g[k]) for k in ('ph', 'pt', 'pr', 'nh', 'nt'))
+        kg = lambda h, t: O.score_ktup_kg(W['ent_embeddings'], W['rel_embeddings'], W['norm_embeddings'], h, t, pr, l1)
+        pos, neg = kg(ph, pt), kg(nh, nt)
+        close(pos, g[tag + 'kg.pos']); close(neg, g[tag + 'kg.neg'])
+        rel = W['rel_embeddings'][torch.cat([pr, pr])]
+        loss = O.margin_loss(pos, neg, 1.0) + O.orthogonal_loss(rel, W['norm_embeddings'][torch.cat([pr, pr])]) \
+            + O.norm_loss(W['ent_embeddings'][torch.cat([ph, pt, nh, nt])]) + O.norm_loss(rel)
+        close(loss, g[tag + 'kg.loss'])
+        loss.backward()
+        for k in ('ent_embeddings', 'rel_embeddings', 'norm_embeddings'):
+            close(W[k].grad, g[tag + 'kg.grad.%s.weight' % k], atol=1e-5)
+
+
+def test_eval_matrices(golden):
+    g = golden('eval_small')
+    uq, eq, rq = T(g['uq']), T(g['eq']), T(g['rq'])
+    close(O.eval_bprmf(T(g['bprmf.user_embeddings.weight']), T(g['bprmf.item_embeddings.weight']), uq), g['bprmf.eval'])
+    for l1 in (False, True):
+        L = 'L1' if l1 else 'L2'
+        E, R = T(g['transe.ent_embeddings.weight']), T(g['transe.rel_embeddings.weight'])
+        close(O.eval_transe(E, R, eq, rq, l1, True), g['transe.%s.head' % L])
+        close(O.eval_transe(E, R, eq, rq, l1, False), g['transe.%s.tail' % L])
+        E, R, N = (T(g['transh.%s.weight' % k]) for k in ('ent_embeddings', 'rel_embeddings', 'norm_embeddings'))
+        close(O.eval_transh(E, R, N, eq, rq, l1, True), g['transh.%s.head' % L])
+        close(O.eval_transh(E, R, N, eq, rq, l1, False), g['transh.%s.tail' % L])
+        E, R, M = (T(g['transr.%s.weight' % k]) for k in ('ent_embeddings', 'rel_embeddings', 'proj_embeddings'))
+        close(O.eval_transr(E, R, M, eq, rq, l1, True), g['transr.%s.head' % L], rtol=1e-4, atol=1e-5)
+        close(O.eval_transr(E, R, M, eq, rq, l1, False), g['transr.%s.tail' % L], rtol=1e-4, atol=1e-5)
+        for gum in (False, True):
+            H = 'hard' if gum else 'soft'
+            U, I, P, Pn = (T(g['tup.%s.weight' % k]) for k in ('user_embeddings', 'item_embeddings', 'pref_embeddings', 'pref_norm_embeddings'))
+            uni = T(g['tup.%s.%s.uni' % (L, H)]) if gum else None
+            close(O.eval_tup(U, I, P, Pn, uq, l1, uni), g['tup.%s.%s.eval' % (L, H)])
+            K = {k: T(g['ktup.%s.weight' % k]) for k in ('user_embeddings', 'item_embeddings', 'ent_embeddings', 'pref_embeddings',
+                                                         'pref_norm_embeddings', 'rel_embeddings', 'norm_embeddings')}
+            uni = T(g['ktup.%s.%s.uni' % (L, H)]) if gum else None
+            got = O.eval_ktup_rec(K['user_embeddings'], K['item_embeddings'], K['ent_embeddings'], K['pref_embeddings'],
+                                  K['pref_norm_embeddings'], K['rel_embeddings'], K['norm_embeddings'], T(g['ktup.item2ent']), uq, l1, uni)
+            close(got, g['ktup.%s.%s.evalRec' % (L, H)])
+            if not gum:
+                close(O.eval_transh(K['ent_embeddings'], K['rel_embeddings'], K['norm_embeddings'], eq, rq, l1, True), g['ktup.%s.soft.evalHead' % L])
+                close(O.eval_transh(K['ent_embeddings'], K['rel_embeddings'], K['norm_embeddings'], eq, rq, l1, False), g['ktup.%s.soft.evalTail' % L])
+
+
+def test_ranking_exact(golden):
+    g = golden('ranking')
+    J = json.load(open(os.path.join(GOLDEN, 'ranking.json')))
+    nrec = g['rec.rows'].shape[0]
+    for b, c in enumerate(J['rec']):
+        desc = c.get('descending', False)
+        row = -g['rec.bprmf_rows'][b - nrec] if desc else g['rec.rows'][b]
+        filt = set(c['filter']) if c['filter'] is not None else None
+        f1, p, r, hit, ndcg, top = O.rec_performance(row, set(c['gold']), filt, 10)
+        assert top == c['top_ids']
+        assert hit == c['hit']
+        np.testing.assert_allclose([f1, p, r, ndcg], [c['f1'], c['p'], c['r'], c['ndcg']], rtol=1e-12, atol=0)
+    for b, c in enumerate(J['kg']):
+        hits, ranks, ids = O.kg_performance(g['kg.rows'][b], set(c['gold']), set(c['filter']), 10)
+        assert (hits, ranks, ids) == (c['hits'], c['ranks'], c['ids'])
+    for r, k, method, val in J['known']['ndcg']:
+        assert O.ndcg_at_k(r, k, method) == pytest.approx(val, rel=1e-14, abs=0)
+    # the reference's still-valid doc examples (jTransUP/utils/evaluation.py:88-96)
+    assert O.ndcg_at_k([2, 1, 2, 0], 4) == pytest.approx(0.9203032077642922, rel=1e-15)
+    assert O.ndcg_at_k([2, 1, 2, 0], 4, method=1) == pytest.approx(0.96519546960144276, rel=1e-15)
+    assert O.ndcg_at_k([0], 1) == 0.0 and O.ndcg_at_k([1], 2) == 1.0
+
+
+def test_alignment_and_schedule():
+    J = json.load(open(os.path.join(GOLDEN, 'alignment.json')))
+    new_map, e_remap, i_remap, n = O.rebuild_entity_item_vocab(dict(map(tuple, J['e_vocab'])), dict(map(tuple, J['i_vocab'])), J['kg2i'])
+    assert n == J['n_aligned']
+    assert {str(k): list(v) for k, v in new_map.items()} == J['new_map']
+    assert {str(k): v for k, v in e_remap.items()} == J['e_remap']
+    assert {str(k): v for k, v in i_remap.items()} == J['i_remap']
+    # joint schedule (knowledgable_recommendation.py:209,320): 0.7 -> 7 rec : 3 kg per 10 steps
+    for ratio, nrec in ((0.5, 5), (0.7, 7), (0.9, 9)):
+        assert sum(O.is_rec_step(s, ratio) for s in range(10)) == nrec
+        assert [O.is_rec_step(s, ratio) for s in range(10)] == [s < nrec for s in range(10)]

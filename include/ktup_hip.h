@@ -1,0 +1,112 @@
+/* libktup_hip.so -- C ABI of the MI355X (gfx950) joint KG + recommender scoring engine.
+ *
+ * The reference (TaoMiner/joint-kg-recommender) has no FFI layer: its hot path is the torch-op
+ * compositions inside jTransUP/models/{bprmf,transE,transH,transR,transUP,jTransUP}.py,
+ * jTransUP/utils/loss.py and the ranking walk in jTransUP/utils/misc.py.  Each entry point below
+ * replaces one of those compositions and cites it (paths relative to the reference checkout).
+ * INTEGRATION.md shows the ctypes binding a reference maintainer would add.
+ *
+ * Conventions (all entry points):
+ *   - every pointer is a DEVICE pointer unless stated; tables are row-major fp32 with a row pitch
+ *     `ld*` given in ELEMENTS; index arrays are int64 (the reference's LongTensor) unless stated;
+ *   - `stream` is a hipStream_t passed as void*; calls are asynchronous and stream-ordered;
+ *   - nothing is allocated or freed: outputs and scratch are caller-owned (see *_workspace_bytes);
+ *   - gradient outputs are ACCUMULATED with atomics (caller zero-fills, like a dense .grad);
+ *   - return 0 on success, <0 on error; ktup_last_error() gives the thread-local message;
+ *   - no global mutable state: callable from any host thread.
+ */
+#ifndef KTUP_HIP_H
+#define KTUP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KTUP_OK 0
+#define KTUP_ERR_INVALID_ARG (-1)
+#define KTUP_ERR_LAUNCH (-2)
+#define KTUP_ERR_UNSUPPORTED (-3)
+
+/* Gumbel modes for the preference gate (transUP.py:143-170, jTransUP.py:288-315). */
+#define KTUP_GUMBEL_OFF 0     /* soft: raw logits are the mixture weights (transUP.py:108-113)      */
+#define KTUP_GUMBEL_INPUT 1   /* hard, uniforms supplied by the caller (parity mode)                 */
+#define KTUP_GUMBEL_PHILOX 2  /* hard, uniforms drawn on device from Philox4x32-10(seed, offset)     */
+
+int ktup_version(void);
+const char* ktup_last_error(void);
+
+/* ------------------------------------------------------------------ K1  BPRMF  bprmf.py:46-49 */
+int ktup_score_bprmf_fwd(const float* U, int64_t ldu, const float* I, int64_t ldi, int d,
+                         const int64_t* u_ids, const int64_t* i_ids, int64_t n, float* score, void* stream);
+int ktup_score_bprmf_bwd(const float* U, int64_t ldu, const float* I, int64_t ldi, int d,
+                         const int64_t* u_ids, const int64_t* i_ids, int64_t n, const float* gscore,
+                         float* gU, float* gI, void* stream);
+
+/* ------------------------------------------------------------------ K2  TransE  transE.py:51-63 */
+int ktup_score_transe_fwd(const float* E, int64_t lde, const float* R, int64_t ldr, int d,
+                          const int64_t* h, const int64_t* t, const int64_t* r, int64_t n, int l1,
+                          float* score, void* stream);
+int ktup_score_transe_bwd(const float* E, int64_t lde, const float* R, int64_t ldr, int d,
+                          const int64_t* h, const int64_t* t, const int64_t* r, int64_t n, int l1,
+                          const float* gscore, float* gE, float* gR, void* stream);
+
+/* ------------------------------------------- K3  TransH  transH.py:58-71 + utils/misc.py:18-19
+ * (also the KG branch of KTUP, jTransUP.py:144-157, on its ent/rel/norm tables)                  */
+int ktup_score_transh_fwd(const float* E, int64_t lde, const float* R, int64_t ldr, const float* Nrm, int64_t ldn,
+                          int d, const int64_t* h, const int64_t* t, const int64_t* r, int64_t n, int l1,
+                          float* score, void* stream);
+int ktup_score_transh_bwd(const float* E, int64_t lde, const float* R, int64_t ldr, const float* Nrm, int64_t ldn,
+                          int d, const int64_t* h, const int64_t* t, const int64_t* r, int64_t n, int l1,
+                          const float* gscore, float* gE, float* gR, float* gN, void* stream);
+
+/* ------------------------------------------- K4  TransR  transR.py:65-78 + utils/misc.py:21-26
+ * M is the (n_rel x d*d) projection table, row r reshaped (d_rel=d) x (d_ent=d), row-major.       */
+int ktup_score_transr_fwd(const float* E, int64_t lde, const float* R, int64_t ldr, const float* M, int64_t ldm,
+                          int d, const int64_t* h, const int64_t* t, const int64_t* r, int64_t n, int l1,
+                          float* score, void* stream);
+int ktup_score_transr_bwd(const float* E, int64_t lde, const float* R, int64_t ldr, const float* M, int64_t ldm,
+                          int d, const int64_t* h, const int64_t* t, const int64_t* r, int64_t n, int l1,
+                          const float* gscore, float* gE, float* gR, float* gM, void* stream);
+
+/* ------------------------------------------- K5/K6/K7  TUP and KTUP preference-gated translation
+ * transUP.py:69-82,105-170 ; jTransUP.py:122-143,250-315.
+ *
+ * ktup_pref_prepare mixes and pre-scales the (tiny) preference tables once per table version into
+ * caller scratch `ws` (ktup_pref_workspace_bytes): A = pref (+ rel), C = pref_norm (+ norm);
+ * it stores A/2 (logit table), beta*A and beta*C with beta = 1 for TUP (rel == NULL) and 1/2 for
+ * KTUP (jTransUP.py:253,257,258), zero-padded so the score kernels run without bounds checks.     */
+size_t ktup_pref_workspace_bytes(int d, int n_pref);
+int ktup_pref_prepare(const float* pref, const float* pref_norm, const float* rel, const float* norm, int64_t ld,
+                      int n_pref, int d, float* ws, void* stream);
+
+/* TUP: E == NULL and item2ent == NULL.  KTUP: ie = I[i] + E[item2ent[i]] (int32 table; the pad row
+ * of E is all-zero, jTransUP.py:46,100).  `uniform` is (n x n_pref) for KTUP_GUMBEL_INPUT.         */
+int ktup_score_tup_fwd(const float* U, int64_t ldu, const float* I, int64_t ldi, const float* pref_ws, int n_pref,
+                       int d, const int64_t* u_ids, const int64_t* i_ids, int64_t n, int l1, int gumbel_mode,
+                       const float* uniform, uint64_t seed, uint64_t offset, float* score, void* stream);
+int ktup_score_ktup_fwd(const float* U, int64_t ldu, const float* I, int64_t ldi, const float* E, int64_t lde,
+                        const int32_t* item2ent, const float* pref_ws, int n_pref, int d, const int64_t* u_ids,
+                        const int64_t* i_ids, int64_t n, int l1, int gumbel_mode, const float* uniform,
+                        uint64_t seed, uint64_t offset, float* score, void* stream);
+
+/* Backward: gU/gI/gE are dense table grads (atomics); gA and gC are (n_pref x d, pitch d) grads of the
+ * MIXED tables A = pref(+rel), C = pref_norm(+norm): the caller adds gA to pref.grad (and rel.grad),
+ * gC to pref_norm.grad (and norm.grad).  ent_pad >= 0 names the E row that never receives a gradient
+ * (nn.Embedding(padding_idx=...), jTransUP.py:96).                                                  */
+int ktup_score_tup_bwd(const float* U, int64_t ldu, const float* I, int64_t ldi, const float* pref_ws, int n_pref,
+                       int d, const int64_t* u_ids, const int64_t* i_ids, int64_t n, int l1, int gumbel_mode,
+                       const float* uniform, uint64_t seed, uint64_t offset, const float* gscore, float* gU,
+                       float* gI, float* gA, float* gC, void* stream);
+int ktup_score_ktup_bwd(const float* U, int64_t ldu, const float* I, int64_t ldi, const float* E, int64_t lde,
+                        const int32_t* item2ent, int64_t ent_pad, const float* pref_ws, int n_pref, int d,
+                        const int64_t* u_ids, const int64_t* i_ids, int64_t n, int l1, int gumbel_mode,
+                        const float* uniform, uint64_t seed, uint64_t offset, const float* gscore, float* gU,
+                        float* gI, float* gE, float* gA, float* gC, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KTUP_HIP_H */

@@ -1,0 +1,86 @@
+// Shared host/device helpers for libktup_hip.so (gfx950 / CDNA4 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/ktup_hip.h"
+
+namespace ktup {
+
+// ---- host side -------------------------------------------------------------------------------
+int set_error(int code, const char* fmt, ...);  // records a thread-local message, returns `code`
+int check_launch(const char* what);             // hipGetLastError() -> KTUP_OK / KTUP_ERR_LAUNCH
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// Memory-bound launches: enough workgroups to fill 256 CUs x several resident blocks, grid-stride the rest.
+inline int grid_for(int64_t work_blocks, int max_blocks = 256 * 8) {
+  if (work_blocks < 1) work_blocks = 1;
+  return (int)(work_blocks < max_blocks ? work_blocks : max_blocks);
+}
+
+#define KTUP_REQUIRE(cond, ...) \
+  do {                          \
+    if (!(cond)) return ::ktup::set_error(KTUP_ERR_INVALID_ARG, __VA_ARGS__); \
+  } while (0)
+
+// ---- device side -----------------------------------------------------------------------------
+#define KTUP_DEV __device__ __forceinline__
+
+// Sum across G consecutive lanes (G = 16/32/64); every lane of the group gets the total.
+template <int G>
+KTUP_DEV float group_sum(float v) {
+#pragma unroll
+  for (int m = G / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+
+KTUP_DEV float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+KTUP_DEV float4 operator+(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+KTUP_DEV float4 operator-(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+KTUP_DEV float4 operator*(float s, float4 a) { return make_float4(s * a.x, s * a.y, s * a.z, s * a.w); }
+KTUP_DEV float dot4(float4 a, float4 b) { return fmaf(a.x, b.x, fmaf(a.y, b.y, fmaf(a.z, b.z, a.w * b.w))); }
+KTUP_DEV float4 fma4(float s, float4 a, float4 c) {  // c + s*a
+  return make_float4(fmaf(s, a.x, c.x), fmaf(s, a.y, c.y), fmaf(s, a.z, c.z), fmaf(s, a.w, c.w));
+}
+
+// The reference's two dissimilarities: L1 = sum|z|, "L2" = sum z^2 (SQUARED, no sqrt; transE.py:57-61).
+KTUP_DEV float dist1(float z, bool l1) { return l1 ? fabsf(z) : z * z; }
+KTUP_DEV float dist4(float4 z, bool l1) { return dist1(z.x, l1) + dist1(z.y, l1) + dist1(z.z, l1) + dist1(z.w, l1); }
+// d dist / dz : torch's abs backward is sign(z) with sign(0) = 0; pow(2) backward is 2z.
+KTUP_DEV float ddist1(float z, bool l1) { return l1 ? (z > 0.f ? 1.f : (z < 0.f ? -1.f : 0.f)) : 2.f * z; }
+KTUP_DEV float4 ddist4(float4 z, bool l1) { return make_float4(ddist1(z.x, l1), ddist1(z.y, l1), ddist1(z.z, l1), ddist1(z.w, l1)); }
+
+KTUP_DEV void atomic_add4(float* p, float4 v) {
+  atomicAdd(p + 0, v.x);
+  atomicAdd(p + 1, v.y);
+  atomicAdd(p + 2, v.z);
+  atomicAdd(p + 3, v.w);
+}
+
+// ST-Gumbel noise, transUP.py:159-162 : g = -log(-log(u + 1e-20) + 1e-20)
+KTUP_DEV float gumbel_from_uniform(float u) { return -logf(-logf(u + 1e-20f) + 1e-20f); }
+
+// Philox4x32-10 (counter-based; production Gumbel / negative-sampling draws).
+struct Philox {
+  uint32_t k0, k1;
+  KTUP_DEV Philox(uint64_t seed) : k0((uint32_t)seed), k1((uint32_t)(seed >> 32)) {}
+  KTUP_DEV uint4 operator()(uint64_t ctr_lo, uint64_t ctr_hi) const {
+    uint32_t c0 = (uint32_t)ctr_lo, c1 = (uint32_t)(ctr_lo >> 32), c2 = (uint32_t)ctr_hi, c3 = (uint32_t)(ctr_hi >> 32);
+    uint32_t a = k0, b = k1;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+      const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+      const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+      const uint32_t n0 = hi1 ^ c1 ^ a, n1 = lo1, n2 = hi0 ^ c3 ^ b, n3 = lo0;
+      c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+      a += 0x9E3779B9u; b += 0xBB67AE85u;
+    }
+    return make_uint4(c0, c1, c2, c3);
+  }
+};
+// 24-bit uniform in [0, 1), the same lattice torch's uniform_() draws from.
+KTUP_DEV float u01(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
+
+}  // namespace ktup

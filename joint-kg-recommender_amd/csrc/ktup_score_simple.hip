@@ -1,0 +1,408 @@
+// K1-K4: fused gather + score (and its backward) for BPRMF, TransE, TransH, TransR.
+//
+// Layout / mapping (gather-bound, HBM roofline): a row of d fp32 is d/4 16-byte chunks.  G = 16/32/64
+// consecutive lanes of a wave own one scored row (d=64 -> 16 lanes, d=100 -> 25 of 32 lanes, d=256 -> 64),
+// so every wave-level load is a run of contiguous 16-B pieces per row; the L1/L2 sum is reduced with
+// xor-shuffles inside the lane group and one 4-byte score is stored per row.  The reference instead runs
+// index_select x3 + ~4-10 elementwise kernels, each materialising a (B x d) temporary.
+// When a pointer or pitch is not 16-B aligned (or d % 4 != 0) the same code runs with 4-byte lanes.
+#include "ktup_common.h"
+
+using namespace ktup;
+
+namespace {
+
+// ---- tiny vector abstraction: V = float4 (fast path) or float --------------------------------
+KTUP_DEV void vzero(float& a) { a = 0.f; }
+KTUP_DEV void vzero(float4& a) { a = f4zero(); }
+KTUP_DEV float vadd(float a, float b) { return a + b; }
+KTUP_DEV float4 vadd(float4 a, float4 b) { return a + b; }
+KTUP_DEV float vsub(float a, float b) { return a - b; }
+KTUP_DEV float4 vsub(float4 a, float4 b) { return a - b; }
+KTUP_DEV float vscale(float s, float a) { return s * a; }
+KTUP_DEV float4 vscale(float s, float4 a) { return s * a; }
+KTUP_DEV float vfma(float s, float a, float c) { return fmaf(s, a, c); }
+KTUP_DEV float4 vfma(float s, float4 a, float4 c) { return fma4(s, a, c); }
+KTUP_DEV float vdot(float a, float b) { return a * b; }
+KTUP_DEV float vdot(float4 a, float4 b) { return dot4(a, b); }
+KTUP_DEV float vdist(float z, bool l1) { return dist1(z, l1); }
+KTUP_DEV float vdist(float4 z, bool l1) { return dist4(z, l1); }
+KTUP_DEV float vddist(float z, bool l1) { return ddist1(z, l1); }
+KTUP_DEV float4 vddist(float4 z, bool l1) { return ddist4(z, l1); }
+KTUP_DEV void vatomic(float* p, float v) { atomicAdd(p, v); }
+KTUP_DEV void vatomic(float* p, float4 v) { atomic_add4(p, v); }
+template <typename V> struct VW;
+template <> struct VW<float> { static constexpr int W = 1; };
+template <> struct VW<float4> { static constexpr int W = 4; };
+
+template <typename V, int G, int CPL>
+struct RowCtx {
+  int nch;   // chunks of V per row
+  int lane;  // lane inside the G-lane group
+  KTUP_DEV void load(V (&x)[CPL], const float* row) const {
+    const V* p = reinterpret_cast<const V*>(row);
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+      const int c = lane + j * G;
+      if (c < nch) x[j] = p[c]; else vzero(x[j]);
+    }
+  }
+  KTUP_DEV void scatter_add(float* row, const V (&g)[CPL]) const {
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+      const int c = lane + j * G;
+      if (c < nch) vatomic(row + (int64_t)c * VW<V>::W, g[j]);
+    }
+  }
+};
+
+template <typename V, int G, int CPL, typename Op>
+__global__ __launch_bounds__(256) void row_kernel(Op op, int nch, int64_t n) {
+  RowCtx<V, G, CPL> cx{nch, (int)(threadIdx.x % G)};
+  constexpr int GPB = 256 / G;  // rows in flight per workgroup
+  for (int64_t row = (int64_t)blockIdx.x * GPB + threadIdx.x / G; row < n; row += (int64_t)gridDim.x * GPB)
+    op.template run<V, G, CPL>(cx, row);
+}
+
+template <typename Op>
+int launch_rows(const Op& op, int d, bool vec4, int64_t n, hipStream_t st, const char* name) {
+  if (n == 0) return KTUP_OK;
+  const int nch = vec4 ? d / 4 : d;
+#define KTUP_L(V, G, CPL)                                                                          \
+  {                                                                                                \
+    const int grid = grid_for((n + (256 / G) - 1) / (256 / G));                                   \
+    hipLaunchKernelGGL((row_kernel<V, G, CPL, Op>), dim3(grid), dim3(256), 0, st, op, nch, n);    \
+    return check_launch(name);                                                                     \
+  }
+  if (vec4) {
+    if (nch <= 16) KTUP_L(float4, 16, 1)
+    if (nch <= 32) KTUP_L(float4, 32, 1)
+    if (nch <= 64) KTUP_L(float4, 64, 1)
+    if (nch <= 128) KTUP_L(float4, 64, 2)
+    if (nch <= 256) KTUP_L(float4, 64, 4)
+  } else {
+    if (nch <= 16) KTUP_L(float, 16, 1)
+    if (nch <= 32) KTUP_L(float, 32, 1)
+    if (nch <= 64) KTUP_L(float, 64, 1)
+    if (nch <= 128) KTUP_L(float, 64, 2)
+    if (nch <= 256) KTUP_L(float, 64, 4)
+  }
+#undef KTUP_L
+  return set_error(KTUP_ERR_UNSUPPORTED, "%s: embedding_size %d too large for the row kernels", name, d);
+}
+
+inline bool can_vec4(int d, std::initializer_list<const void*> ptrs, std::initializer_list<int64_t> lds) {
+  if (d % 4) return false;
+  for (const void* p : ptrs) if (p && !aligned16(p)) return false;
+  for (int64_t l : lds) if (l % 4) return false;
+  return true;
+}
+
+// ------------------------------------------------------------------------------ K1 BPRMF
+struct BprmfFwd {
+  const float *U, *I; int64_t ldu, ldi; const int64_t *u, *i; float* score;
+  template <typename V, int G, int CPL>
+  KTUP_DEV void run(const RowCtx<V, G, CPL>& cx, int64_t row) const {
+    V a[CPL], b[CPL];
+    cx.load(a, U + u[row] * ldu);
+    cx.load(b, I + i[row] * ldi);
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) s += vdot(a[j], b[j]);
+    s = group_sum<G>(s);
+    if (cx.lane == 0) score[row] = s;
+  }
+};
+struct BprmfBwd {
+  const float *U, *I; int64_t ldu, ldi; const int64_t *u, *i; const float* gs; float *gU, *gI;
+  template <typename V, int G, int CPL>
+  KTUP_DEV void run(const RowCtx<V, G, CPL>& cx, int64_t row) const {
+    const int64_t ur = u[row], ir = i[row];
+    V a[CPL], b[CPL];
+    cx.load(a, U + ur * ldu);
+    cx.load(b, I + ir * ldi);
+    const float g = gs[row];
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) { V t = a[j]; a[j] = vscale(g, b[j]); b[j] = vscale(g, t); }
+    cx.scatter_add(gU + ur * ldu, a);
+    cx.scatter_add(gI + ir * ldi, b);
+  }
+};
+
+// ------------------------------------------------------------------------------ K2 TransE
+struct TranseFwd {
+  const float *E, *R; int64_t lde, ldr; const int64_t *h, *t, *r; bool l1; float* score;
+  template <typename V, int G, int CPL>
+  KTUP_DEV void run(const RowCtx<V, G, CPL>& cx, int64_t row) const {
+    V a[CPL], b[CPL], c[CPL];
+    cx.load(a, E + h[row] * lde);
+    cx.load(b, E + t[row] * lde);
+    cx.load(c, R + r[row] * ldr);
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) s += vdist(vsub(vadd(a[j], c[j]), b[j]), l1);  // (h + r) - t, transE.py:57
+    s = group_sum<G>(s);
+    if (cx.lane == 0) score[row] = s;
+  }
+};
+struct TranseBwd {
+  const float *E, *R; int64_t lde, ldr; const int64_t *h, *t, *r; bool l1; const float* gs; float *gE, *gR;
+  template <typename V, int G, int CPL>
+  KTUP_DEV void run(const RowCtx<V, G, CPL>& cx, int64_t row) const {
+    const int64_t hr = h[row], tr = t[row], rr = r[row];
+    V a[CPL], b[CPL], c[CPL];
+    cx.load(a, E + hr * lde);
+    cx.load(b, E + tr * lde);
+    cx.load(c, R + rr * ldr);
+    const float g = gs[row];
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+      a[j] = vscale(g, vddist(vsub(vadd(a[j], c[j]), b[j]), l1));  // gz
+      b[j] = vscale(-1.f, a[j]);
+    }
+    cx.scatter_add(gE + hr * lde, a);
+    cx.scatter_add(gE + tr * lde, b);
+    cx.scatter_add(gR + rr * ldr, a);
+  }
+};
+
+// ------------------------------------------------------------------------------ K3 TransH
+// z = (h - (h.w)w) + r - (t - (t.w)w),  w = norm row of the relation (NOT re-normalised, misc.py:18-19)
+struct TranshFwd {
+  const float *E, *R, *Nm; int64_t lde, ldr, ldn; const int64_t *h, *t, *r; bool l1; float* score;
+  template <typename V, int G, int CPL>
+  KTUP_DEV void run(const RowCtx<V, G, CPL>& cx, int64_t row) const {
+    const int64_t rr = r[row];
+    V a[CPL], b[CPL], c[CPL], w[CPL];
+    cx.load(a, E + h[row] * lde);
+    cx.load(b, E + t[row] * lde);
+    cx.load(c, R + rr * ldr);
+    cx.load(w, Nm + rr * ldn);
+    float dh = 0.f, dt = 0.f;
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) { dh += vdot(a[j], w[j]); dt += vdot(b[j], w[j]); }
+    dh = group_sum<G>(dh);
+    dt = group_sum<G>(dt);
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+      const V ph = vfma(-dh, w[j], a[j]), pt = vfma(-dt, w[j], b[j]);
+      s += vdist(vsub(vadd(ph, c[j]), pt), l1);
+    }
+    s = group_sum<G>(s);
+    if (cx.lane == 0) score[row] = s;
+  }
+};
+// With q = h - t, s = q.w, a = gz.w :  gh = gz - a w, gt = -gh, gr = gz, gw = -s gz - a q.
+struct TranshBwd {
+  const float *E, *R, *Nm; int64_t lde, ldr, ldn; const int64_t *h, *t, *r; bool l1; const float* gs;
+  float *gE, *gR, *gN;
+  template <typename V, int G, int CPL>
+  KTUP_DEV void run(const RowCtx<V, G, CPL>& cx, int64_t row) const {
+    const int64_t hr = h[row], tr = t[row], rr = r[row];
+    V a[CPL], b[CPL], c[CPL], w[CPL];
+    cx.load(a, E + hr * lde);
+    cx.load(b, E + tr * lde);
+    cx.load(c, R + rr * ldr);
+    cx.load(w, Nm + rr * ldn);
+    float dh = 0.f, dt = 0.f;
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) { dh += vdot(a[j], w[j]); dt += vdot(b[j], w[j]); }
+    dh = group_sum<G>(dh);
+    dt = group_sum<G>(dt);
+    const float g = gs[row];
+    float aw = 0.f;
+    V gz[CPL];
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+      const V ph = vfma(-dh, w[j], a[j]), pt = vfma(-dt, w[j], b[j]);
+      gz[j] = vscale(g, vddist(vsub(vadd(ph, c[j]), pt), l1));
+      aw += vdot(gz[j], w[j]);
+    }
+    aw = group_sum<G>(aw);
+    const float sq = dh - dt;
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+      const V q = vsub(a[j], b[j]);
+      a[j] = vfma(-aw, w[j], gz[j]);                         // gh
+      b[j] = vscale(-1.f, a[j]);                             // gt
+      w[j] = vfma(-aw, q, vscale(-sq, gz[j]));               // gw
+    }
+    cx.scatter_add(gE + hr * lde, a);
+    cx.scatter_add(gE + tr * lde, b);
+    cx.scatter_add(gR + rr * ldr, gz);
+    cx.scatter_add(gN + rr * ldn, w);
+  }
+};
+
+// ------------------------------------------------------------------------------ K4 TransR
+// One wave per triple.  q = h - t is staged in LDS; lane j owns output coordinate j of M_r q (+ r_j).
+// (Computes M(h - t) where the reference computes Mh - Mt, transR.py:71-72: same value up to fp32 rounding.)
+// First version: the d x d matrix of the triple's relation is streamed from L2 per triple; bucketing triples
+// by relation so a workgroup keeps M_r in LDS is the planned optimisation (only R distinct matrices exist).
+template <bool BWD>
+__global__ __launch_bounds__(256) void transr_kernel(const float* __restrict__ E, int64_t lde, const float* __restrict__ R,
+                                                     int64_t ldr, const float* __restrict__ M, int64_t ldm, int d,
+                                                     const int64_t* __restrict__ h, const int64_t* __restrict__ t,
+                                                     const int64_t* __restrict__ r, int64_t n, bool l1,
+                                                     float* __restrict__ score, const float* __restrict__ gs,
+                                                     float* gE, float* gR, float* gM) {
+  extern __shared__ float smem[];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  float* q = smem + wv * 2 * d;  // q[d] then gz[d] (backward)
+  float* gzs = q + d;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wv; row < n; row += (int64_t)gridDim.x * 4) {
+    const int64_t hr = h[row], tr = t[row], rr = r[row];
+    for (int k = lane; k < d; k += 64) q[k] = E[hr * lde + k] - E[tr * lde + k];
+    __builtin_amdgcn_wave_barrier();
+    const float* Mr = M + rr * ldm;
+    float part = 0.f;
+    const float g = BWD ? gs[row] : 0.f;
+    for (int j = lane; j < d; j += 64) {
+      const float* mrow = Mr + (int64_t)j * d;
+      float acc = 0.f;
+      for (int k = 0; k < d; ++k) acc = fmaf(mrow[k], q[k], acc);
+      const float z = acc + R[rr * ldr + j];
+      if (BWD) {
+        const float gz = g * ddist1(z, l1);
+        gzs[j] = gz;
+        atomicAdd(gR + rr * ldr + j, gz);
+      } else {
+        part += dist1(z, l1);
+      }
+    }
+    if (!BWD) {
+      part = group_sum<64>(part);
+      if (lane == 0) score[row] = part;
+    } else {
+      __builtin_amdgcn_wave_barrier();
+      // lane k: gq_k = sum_j M[j][k] gz_j (coalesced over k); gM[j][k] += gz_j q_k
+      float* gMr = gM + rr * ldm;
+      for (int k = lane; k < d; k += 64) {
+        float gq = 0.f;
+        const float qk = q[k];
+        for (int j = 0; j < d; ++j) {
+          const float gz = gzs[j];
+          gq = fmaf(Mr[(int64_t)j * d + k], gz, gq);
+          atomicAdd(gMr + (int64_t)j * d + k, gz * qk);
+        }
+        atomicAdd(gE + hr * lde + k, gq);
+        atomicAdd(gE + tr * lde + k, -gq);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+int check_common(const char* name, int d, int64_t n) {
+  if (d <= 0) return set_error(KTUP_ERR_INVALID_ARG, "%s: embedding_size must be positive (got %d)", name, d);
+  if (n < 0) return set_error(KTUP_ERR_INVALID_ARG, "%s: negative row count", name);
+  return KTUP_OK;
+}
+
+}  // namespace
+
+#define KTUP_NONNULL(name, p) KTUP_REQUIRE((p) != nullptr || n == 0, name ": null pointer argument '" #p "'")
+
+extern "C" int ktup_score_bprmf_fwd(const float* U, int64_t ldu, const float* I, int64_t ldi, int d, const int64_t* u_ids,
+                                    const int64_t* i_ids, int64_t n, float* score, void* stream) {
+  if (int e = check_common("ktup_score_bprmf_fwd", d, n)) return e;
+  KTUP_NONNULL("ktup_score_bprmf_fwd", U); KTUP_NONNULL("ktup_score_bprmf_fwd", I);
+  KTUP_NONNULL("ktup_score_bprmf_fwd", u_ids); KTUP_NONNULL("ktup_score_bprmf_fwd", i_ids);
+  KTUP_NONNULL("ktup_score_bprmf_fwd", score);
+  BprmfFwd op{U, I, ldu, ldi, u_ids, i_ids, score};
+  return launch_rows(op, d, can_vec4(d, {U, I}, {ldu, ldi}), n, (hipStream_t)stream, "ktup_score_bprmf_fwd");
+}
+
+extern "C" int ktup_score_bprmf_bwd(const float* U, int64_t ldu, const float* I, int64_t ldi, int d, const int64_t* u_ids,
+                                    const int64_t* i_ids, int64_t n, const float* gscore, float* gU, float* gI,
+                                    void* stream) {
+  if (int e = check_common("ktup_score_bprmf_bwd", d, n)) return e;
+  KTUP_NONNULL("ktup_score_bprmf_bwd", U); KTUP_NONNULL("ktup_score_bprmf_bwd", I);
+  KTUP_NONNULL("ktup_score_bprmf_bwd", gscore); KTUP_NONNULL("ktup_score_bprmf_bwd", gU);
+  KTUP_NONNULL("ktup_score_bprmf_bwd", gI);
+  BprmfBwd op{U, I, ldu, ldi, u_ids, i_ids, gscore, gU, gI};
+  return launch_rows(op, d, can_vec4(d, {U, I, gU, gI}, {ldu, ldi}), n, (hipStream_t)stream, "ktup_score_bprmf_bwd");
+}
+
+extern "C" int ktup_score_transe_fwd(const float* E, int64_t lde, const float* R, int64_t ldr, int d, const int64_t* h,
+                                     const int64_t* t, const int64_t* r, int64_t n, int l1, float* score, void* stream) {
+  if (int e = check_common("ktup_score_transe_fwd", d, n)) return e;
+  KTUP_NONNULL("ktup_score_transe_fwd", E); KTUP_NONNULL("ktup_score_transe_fwd", R);
+  KTUP_NONNULL("ktup_score_transe_fwd", h); KTUP_NONNULL("ktup_score_transe_fwd", t);
+  KTUP_NONNULL("ktup_score_transe_fwd", r); KTUP_NONNULL("ktup_score_transe_fwd", score);
+  TranseFwd op{E, R, lde, ldr, h, t, r, l1 != 0, score};
+  return launch_rows(op, d, can_vec4(d, {E, R}, {lde, ldr}), n, (hipStream_t)stream, "ktup_score_transe_fwd");
+}
+
+extern "C" int ktup_score_transe_bwd(const float* E, int64_t lde, const float* R, int64_t ldr, int d, const int64_t* h,
+                                     const int64_t* t, const int64_t* r, int64_t n, int l1, const float* gscore,
+                                     float* gE, float* gR, void* stream) {
+  if (int e = check_common("ktup_score_transe_bwd", d, n)) return e;
+  KTUP_NONNULL("ktup_score_transe_bwd", E); KTUP_NONNULL("ktup_score_transe_bwd", R);
+  KTUP_NONNULL("ktup_score_transe_bwd", gscore); KTUP_NONNULL("ktup_score_transe_bwd", gE);
+  KTUP_NONNULL("ktup_score_transe_bwd", gR);
+  TranseBwd op{E, R, lde, ldr, h, t, r, l1 != 0, gscore, gE, gR};
+  return launch_rows(op, d, can_vec4(d, {E, R, gE, gR}, {lde, ldr}), n, (hipStream_t)stream, "ktup_score_transe_bwd");
+}
+
+extern "C" int ktup_score_transh_fwd(const float* E, int64_t lde, const float* R, int64_t ldr, const float* Nrm, int64_t ldn,
+                                     int d, const int64_t* h, const int64_t* t, const int64_t* r, int64_t n, int l1,
+                                     float* score, void* stream) {
+  if (int e = check_common("ktup_score_transh_fwd", d, n)) return e;
+  KTUP_NONNULL("ktup_score_transh_fwd", E); KTUP_NONNULL("ktup_score_transh_fwd", R);
+  KTUP_NONNULL("ktup_score_transh_fwd", Nrm); KTUP_NONNULL("ktup_score_transh_fwd", h);
+  KTUP_NONNULL("ktup_score_transh_fwd", t); KTUP_NONNULL("ktup_score_transh_fwd", r);
+  KTUP_NONNULL("ktup_score_transh_fwd", score);
+  TranshFwd op{E, R, Nrm, lde, ldr, ldn, h, t, r, l1 != 0, score};
+  return launch_rows(op, d, can_vec4(d, {E, R, Nrm}, {lde, ldr, ldn}), n, (hipStream_t)stream, "ktup_score_transh_fwd");
+}
+
+extern "C" int ktup_score_transh_bwd(const float* E, int64_t lde, const float* R, int64_t ldr, const float* Nrm, int64_t ldn,
+                                     int d, const int64_t* h, const int64_t* t, const int64_t* r, int64_t n, int l1,
+                                     const float* gscore, float* gE, float* gR, float* gN, void* stream) {
+  if (int e = check_common("ktup_score_transh_bwd", d, n)) return e;
+  KTUP_NONNULL("ktup_score_transh_bwd", E); KTUP_NONNULL("ktup_score_transh_bwd", R);
+  KTUP_NONNULL("ktup_score_transh_bwd", Nrm); KTUP_NONNULL("ktup_score_transh_bwd", gscore);
+  KTUP_NONNULL("ktup_score_transh_bwd", gE); KTUP_NONNULL("ktup_score_transh_bwd", gR);
+  KTUP_NONNULL("ktup_score_transh_bwd", gN);
+  TranshBwd op{E, R, Nrm, lde, ldr, ldn, h, t, r, l1 != 0, gscore, gE, gR, gN};
+  return launch_rows(op, d, can_vec4(d, {E, R, Nrm, gE, gR, gN}, {lde, ldr, ldn}), n, (hipStream_t)stream,
+                     "ktup_score_transh_bwd");
+}
+
+static int transr_launch(bool bwd, const float* E, int64_t lde, const float* R, int64_t ldr, const float* M, int64_t ldm,
+                         int d, const int64_t* h, const int64_t* t, const int64_t* r, int64_t n, int l1, float* score,
+                         const float* gs, float* gE, float* gR, float* gM, void* stream, const char* name) {
+  if (int e = check_common(name, d, n)) return e;
+  KTUP_REQUIRE(n == 0 || (E && R && M && h && t && r), "%s: null pointer argument", name);
+  KTUP_REQUIRE(ldm >= (int64_t)d * d, "%s: projection pitch %lld < d*d", name, (long long)ldm);
+  if (n == 0) return KTUP_OK;
+  const size_t lds = (size_t)4 * 2 * d * sizeof(float);
+  KTUP_REQUIRE(lds <= 64 * 1024, "%s: embedding_size %d too large", name, d);
+  const int grid = grid_for((n + 3) / 4);
+  if (bwd) {
+    KTUP_REQUIRE(gs && gE && gR && gM, "%s: null gradient pointer", name);
+    hipLaunchKernelGGL(transr_kernel<true>, dim3(grid), dim3(256), lds, (hipStream_t)stream, E, lde, R, ldr, M, ldm, d,
+                       h, t, r, n, l1 != 0, nullptr, gs, gE, gR, gM);
+  } else {
+    KTUP_REQUIRE(score, "%s: null score pointer", name);
+    hipLaunchKernelGGL(transr_kernel<false>, dim3(grid), dim3(256), lds, (hipStream_t)stream, E, lde, R, ldr, M, ldm, d,
+                       h, t, r, n, l1 != 0, score, nullptr, nullptr, nullptr, nullptr);
+  }
+  return check_launch(name);
+}
+
+extern "C" int ktup_score_transr_fwd(const float* E, int64_t lde, const float* R, int64_t ldr, const float* M, int64_t ldm,
+                                     int d, const int64_t* h, const int64_t* t, const int64_t* r, int64_t n, int l1,
+                                     float* score, void* stream) {
+  return transr_launch(false, E, lde, R, ldr, M, ldm, d, h, t, r, n, l1, score, nullptr, nullptr, nullptr, nullptr,
+                       stream, "ktup_score_transr_fwd");
+}
+
+extern "C" int ktup_score_transr_bwd(const float* E, int64_t lde, const float* R, int64_t ldr, const float* M, int64_t ldm,
+                                     int d, const int64_t* h, const int64_t* t, const int64_t* r, int64_t n, int l1,
+                                     const float* gscore, float* gE, float* gR, float* gM, void* stream) {
+  return transr_launch(true, E, lde, R, ldr, M, ldm, d, h, t, r, n, l1, nullptr, gscore, gE, gR, gM, stream,
+                       "ktup_score_transr_bwd");
+}

@@ -1,0 +1,73 @@
+"""ctypes binding of libktup_hip.so (declared in include/ktup_hip.h).
+
+The library is the product: there is NO CPU or eager-torch fallback.  If it is missing or a call fails
+the error is raised, never swallowed.  torch is imported first on purpose: the library's NEEDED
+libamdhip64.so.7 then resolves to the HIP runtime torch already loaded, so torch's streams and
+device pointers are valid inside the library.
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (must precede the CDLL below, see module docstring)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get('KTUP_HIP_LIB', os.path.normpath(os.path.join(_HERE, '..', '..', 'libktup_hip.so')))
+
+c_p = ctypes.c_void_p
+c_i = ctypes.c_int
+c_l = ctypes.c_int64
+c_u = ctypes.c_uint64
+c_f = ctypes.c_float
+
+# name -> argtypes (restype is int unless listed in _RESTYPE)
+SIGNATURES = {
+    'ktup_version': [],
+    'ktup_last_error': [],
+    'ktup_score_bprmf_fwd': [c_p, c_l, c_p, c_l, c_i, c_p, c_p, c_l, c_p, c_p],
+    'ktup_score_bprmf_bwd': [c_p, c_l, c_p, c_l, c_i, c_p, c_p, c_l, c_p, c_p, c_p, c_p],
+    'ktup_score_transe_fwd': [c_p, c_l, c_p, c_l, c_i, c_p, c_p, c_p, c_l, c_i, c_p, c_p],
+    'ktup_score_transe_bwd': [c_p, c_l, c_p, c_l, c_i, c_p, c_p, c_p, c_l, c_i, c_p, c_p, c_p, c_p],
+    'ktup_score_transh_fwd': [c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_p, c_p, c_p, c_l, c_i, c_p, c_p],
+    'ktup_score_transh_bwd': [c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_p, c_p, c_p, c_l, c_i, c_p, c_p, c_p, c_p, c_p],
+    'ktup_score_transr_fwd': [c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_p, c_p, c_p, c_l, c_i, c_p, c_p],
+    'ktup_score_transr_bwd': [c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_p, c_p, c_p, c_l, c_i, c_p, c_p, c_p, c_p, c_p],
+    'ktup_pref_workspace_bytes': [c_i, c_i],
+    'ktup_pref_prepare': [c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_p, c_p],
+    'ktup_score_tup_fwd': [c_p, c_l, c_p, c_l, c_p, c_i, c_i, c_p, c_p, c_l, c_i, c_i, c_p, c_u, c_u, c_p, c_p],
+    'ktup_score_ktup_fwd': [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_p, c_i, c_i, c_p, c_p, c_l, c_i, c_i, c_p, c_u, c_u, c_p, c_p],
+    'ktup_score_tup_bwd': [c_p, c_l, c_p, c_l, c_p, c_i, c_i, c_p, c_p, c_l, c_i, c_i, c_p, c_u, c_u, c_p, c_p, c_p, c_p, c_p, c_p],
+    'ktup_score_ktup_bwd': [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_i, c_i, c_p, c_p, c_l, c_i, c_i, c_p, c_u, c_u,
+                            c_p, c_p, c_p, c_p, c_p, c_p, c_p],
+}
+_RESTYPE = {'ktup_last_error': ctypes.c_char_p, 'ktup_pref_workspace_bytes': ctypes.c_size_t}
+
+_lib = None
+
+
+class KtupError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library once; raise (loudly) if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise KtupError('libktup_hip.so not found at %s -- build it with '
+                        '`python joint-kg-recommender_amd/build_hip.py` (there is no CPU fallback)' % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPE.get(name, ctypes.c_int)
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    """Call an int-returning entry point; a non-zero status raises with the library's message."""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise KtupError('%s failed (%d): %s' % (name, rc, lib.ktup_last_error().decode('utf-8', 'replace')))

@@ -1,0 +1,253 @@
+"""torch-facing wrappers of the HIP scoring kernels: argument checking, output allocation, autograd.
+
+PyTorch is plumbing here (device memory, streams, autograd graph); all arithmetic on the hot path is
+done by libktup_hip.so through its C ABI.  CPU tensors are rejected: there is no fallback path.
+"""
+import torch
+from torch.autograd import Function
+
+from . import lib as L
+
+GUMBEL_OFF, GUMBEL_INPUT, GUMBEL_PHILOX = 0, 1, 2
+
+
+def _dev(t):
+    if not t.is_cuda:
+        raise L.KtupError('ktup HIP ops need tensors on an MI355X device (got a CPU tensor); '
+                          'there is no CPU fallback by design')
+    return t.device
+
+
+def _table(name, t):
+    _dev(t)
+    if t.dtype != torch.float32 or t.dim() != 2 or t.stride(1) != 1:
+        raise L.KtupError('%s must be a 2-D fp32 table with unit inner stride (got %s %s strides %s)'
+                          % (name, t.dtype, tuple(t.shape), t.stride()))
+    return t
+
+
+def _ids(name, t, dev, n=None):
+    if t.device != dev:
+        raise L.KtupError('%s must live on %s (got %s)' % (name, dev, t.device))
+    if t.dtype != torch.int64 or t.dim() != 1:
+        raise L.KtupError('%s must be a 1-D int64 index tensor (got %s %s)' % (name, t.dtype, tuple(t.shape)))
+    if n is not None and t.numel() != n:
+        raise L.KtupError('%s has %d entries, expected %d' % (name, t.numel(), n))
+    return t.contiguous()
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream(dev):
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+def _vec(t, n):
+    t = t.contiguous()
+    if t.dtype != torch.float32 or t.numel() != n:
+        raise L.KtupError('expected %d fp32 values, got %s %s' % (n, t.dtype, tuple(t.shape)))
+    return t
+
+
+# ------------------------------------------------------------------------------------------ K1 BPRMF
+class _ScoreBprmf(Function):
+    @staticmethod
+    def forward(ctx, U, I, u, i):
+        dev = _dev(_table('user table', U)); _table('item table', I)
+        n = u.numel(); u = _ids('u_ids', u, dev); i = _ids('i_ids', i, dev, n)
+        score = torch.empty(n, dtype=torch.float32, device=dev)
+        L.call('ktup_score_bprmf_fwd', _p(U), U.stride(0), _p(I), I.stride(0), U.shape[1], _p(u), _p(i), n, _p(score), _stream(dev))
+        ctx.save_for_backward(U, I, u, i)
+        return score
+
+    @staticmethod
+    def backward(ctx, gs):
+        U, I, u, i = ctx.saved_tensors
+        gs = _vec(gs, u.numel())
+        gU, gI = torch.zeros_like(U), torch.zeros_like(I)
+        L.call('ktup_score_bprmf_bwd', _p(U), U.stride(0), _p(I), I.stride(0), U.shape[1], _p(u), _p(i), u.numel(), _p(gs),
+               _p(gU), _p(gI), _stream(U.device))
+        return gU, gI, None, None
+
+
+def score_bprmf(U, I, u, i):
+    """bprmf.py:46-49."""
+    return _ScoreBprmf.apply(U, I, u, i)
+
+
+# ------------------------------------------------------------------------------------------ K2-K4 TransE/H/R
+class _ScoreTransE(Function):
+    @staticmethod
+    def forward(ctx, E, R, h, t, r, l1):
+        dev = _dev(_table('entity table', E)); _table('relation table', R)
+        n = h.numel(); h = _ids('h', h, dev); t = _ids('t', t, dev, n); r = _ids('r', r, dev, n)
+        score = torch.empty(n, dtype=torch.float32, device=dev)
+        L.call('ktup_score_transe_fwd', _p(E), E.stride(0), _p(R), R.stride(0), E.shape[1], _p(h), _p(t), _p(r), n, int(l1),
+               _p(score), _stream(dev))
+        ctx.save_for_backward(E, R, h, t, r); ctx.l1 = int(l1)
+        return score
+
+    @staticmethod
+    def backward(ctx, gs):
+        E, R, h, t, r = ctx.saved_tensors
+        gs = _vec(gs, h.numel())
+        gE, gR = torch.zeros_like(E), torch.zeros_like(R)
+        L.call('ktup_score_transe_bwd', _p(E), E.stride(0), _p(R), R.stride(0), E.shape[1], _p(h), _p(t), _p(r), h.numel(),
+               ctx.l1, _p(gs), _p(gE), _p(gR), _stream(E.device))
+        return gE, gR, None, None, None, None
+
+
+class _ScoreTransH(Function):
+    @staticmethod
+    def forward(ctx, E, R, N, h, t, r, l1):
+        dev = _dev(_table('entity table', E)); _table('relation table', R); _table('norm table', N)
+        n = h.numel(); h = _ids('h', h, dev); t = _ids('t', t, dev, n); r = _ids('r', r, dev, n)
+        score = torch.empty(n, dtype=torch.float32, device=dev)
+        L.call('ktup_score_transh_fwd', _p(E), E.stride(0), _p(R), R.stride(0), _p(N), N.stride(0), E.shape[1], _p(h), _p(t),
+               _p(r), n, int(l1), _p(score), _stream(dev))
+        ctx.save_for_backward(E, R, N, h, t, r); ctx.l1 = int(l1)
+        return score
+
+    @staticmethod
+    def backward(ctx, gs):
+        E, R, N, h, t, r = ctx.saved_tensors
+        gs = _vec(gs, h.numel())
+        gE, gR, gN = torch.zeros_like(E), torch.zeros_like(R), torch.zeros_like(N)
+        L.call('ktup_score_transh_bwd', _p(E), E.stride(0), _p(R), R.stride(0), _p(N), N.stride(0), E.shape[1], _p(h), _p(t),
+               _p(r), h.numel(), ctx.l1, _p(gs), _p(gE), _p(gR), _p(gN), _stream(E.device))
+        return gE, gR, gN, None, None, None, None
+
+
+class _ScoreTransR(Function):
+    @staticmethod
+    def forward(ctx, E, R, M, h, t, r, l1):
+        dev = _dev(_table('entity table', E)); _table('relation table', R); _table('projection table', M)
+        n = h.numel(); h = _ids('h', h, dev); t = _ids('t', t, dev, n); r = _ids('r', r, dev, n)
+        score = torch.empty(n, dtype=torch.float32, device=dev)
+        L.call('ktup_score_transr_fwd', _p(E), E.stride(0), _p(R), R.stride(0), _p(M), M.stride(0), E.shape[1], _p(h), _p(t),
+               _p(r), n, int(l1), _p(score), _stream(dev))
+        ctx.save_for_backward(E, R, M, h, t, r); ctx.l1 = int(l1)
+        return score
+
+    @staticmethod
+    def backward(ctx, gs):
+        E, R, M, h, t, r = ctx.saved_tensors
+        gs = _vec(gs, h.numel())
+        gE, gR, gM = torch.zeros_like(E), torch.zeros_like(R), torch.zeros_like(M)
+        L.call('ktup_score_transr_bwd', _p(E), E.stride(0), _p(R), R.stride(0), _p(M), M.stride(0), E.shape[1], _p(h), _p(t),
+               _p(r), h.numel(), ctx.l1, _p(gs), _p(gE), _p(gR), _p(gM), _stream(E.device))
+        return gE, gR, gM, None, None, None, None
+
+
+def score_transe(E, R, h, t, r, l1):
+    """transE.py:51-63."""
+    return _ScoreTransE.apply(E, R, h, t, r, l1)
+
+
+def score_transh(E, R, N, h, t, r, l1):
+    """transH.py:58-71 (also KTUP's KG branch, jTransUP.py:144-157)."""
+    return _ScoreTransH.apply(E, R, N, h, t, r, l1)
+
+
+def score_transr(E, R, M, h, t, r, l1):
+    """transR.py:65-78."""
+    return _ScoreTransR.apply(E, R, M, h, t, r, l1)
+
+
+# ------------------------------------------------------------------------------------------ K5-K7 TUP / KTUP
+_ws_cache = {}
+
+
+def pref_workspace(pref, pref_norm, rel=None, norm=None):
+    """Mixed, pre-scaled preference tables (ktup_pref_prepare), cached per table version."""
+    dev = _dev(_table('pref table', pref)); _table('pref_norm table', pref_norm)
+    tabs = [pref, pref_norm] + ([rel, norm] if rel is not None else [])
+    for t in tabs:
+        _table('preference-side table', t)
+        if t.shape != pref.shape or t.stride(0) != pref.stride(0):
+            raise L.KtupError('preference / relation tables must share shape and pitch')
+    key = tuple((t.data_ptr(), t._version) for t in tabs) + (torch.cuda.current_stream(dev).cuda_stream,)
+    ws = _ws_cache.get(key)
+    if ws is None:
+        P, d = pref.shape
+        nbytes = L.load().ktup_pref_workspace_bytes(d, P)
+        if nbytes == 0:
+            raise L.KtupError('TUP/KTUP kernels need embedding_size %% 4 == 0 and <= 256 (got %d)' % d)
+        ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
+        L.call('ktup_pref_prepare', _p(pref), _p(pref_norm), _p(rel), _p(norm), pref.stride(0), P, d, _p(ws), _stream(dev))
+        if len(_ws_cache) > 16:
+            _ws_cache.clear()
+        _ws_cache[key] = ws
+    return ws
+
+
+_philox_offset = [0]
+
+
+def next_philox_offset(count):
+    off = _philox_offset[0]
+    _philox_offset[0] += int(count)
+    return off
+
+
+class _ScorePref(Function):
+    """TUP when E is None, KTUP otherwise."""
+
+    @staticmethod
+    def forward(ctx, U, I, E, pref, pref_norm, rel, norm, item2ent, u, i, l1, gumbel_mode, uniform, seed, offset, ent_pad):
+        dev = _dev(_table('user table', U)); _table('item table', I)
+        n = u.numel(); u = _ids('u_ids', u, dev); i = _ids('i_ids', i, dev, n)
+        P, d = pref.shape
+        ws = pref_workspace(pref, pref_norm, rel, norm)
+        if gumbel_mode == GUMBEL_INPUT:
+            if uniform is None or tuple(uniform.shape) != (n, P) or uniform.dtype != torch.float32 or uniform.device != dev:
+                raise L.KtupError('uniform must be an (n, n_pref) fp32 device tensor')
+            uniform = uniform.contiguous()
+        else:
+            uniform = None
+        score = torch.empty(n, dtype=torch.float32, device=dev)
+        if E is None:
+            L.call('ktup_score_tup_fwd', _p(U), U.stride(0), _p(I), I.stride(0), _p(ws), P, d, _p(u), _p(i), n, int(l1),
+                   int(gumbel_mode), _p(uniform), int(seed), int(offset), _p(score), _stream(dev))
+        else:
+            _table('entity table', E)
+            if item2ent.dtype != torch.int32 or item2ent.device != dev or item2ent.numel() < I.shape[0]:
+                raise L.KtupError('item2ent must be an int32 device table with one entry per item')
+            L.call('ktup_score_ktup_fwd', _p(U), U.stride(0), _p(I), I.stride(0), _p(E), E.stride(0), _p(item2ent), _p(ws), P, d,
+                   _p(u), _p(i), n, int(l1), int(gumbel_mode), _p(uniform), int(seed), int(offset), _p(score), _stream(dev))
+        ctx.save_for_backward(U, I, E, pref, pref_norm, rel, norm, item2ent, u, i, uniform, ws)
+        ctx.cfg = (int(l1), int(gumbel_mode), int(seed), int(offset), int(ent_pad))
+        return score
+
+    @staticmethod
+    def backward(ctx, gs):
+        U, I, E, pref, pref_norm, rel, norm, item2ent, u, i, uniform, ws = ctx.saved_tensors
+        l1, gumbel_mode, seed, offset, ent_pad = ctx.cfg
+        n = u.numel(); P, d = pref.shape; dev = U.device
+        gs = _vec(gs, n)
+        gU, gI = torch.zeros_like(U), torch.zeros_like(I)
+        gA = torch.zeros(P, d, dtype=torch.float32, device=dev)
+        gC = torch.zeros(P, d, dtype=torch.float32, device=dev)
+        if E is None:
+            L.call('ktup_score_tup_bwd', _p(U), U.stride(0), _p(I), I.stride(0), _p(ws), P, d, _p(u), _p(i), n, l1, gumbel_mode,
+                   _p(uniform), seed, offset, _p(gs), _p(gU), _p(gI), _p(gA), _p(gC), _stream(dev))
+            return gU, gI, None, gA, gC, None, None, None, None, None, None, None, None, None, None, None
+        gE = torch.zeros_like(E)
+        L.call('ktup_score_ktup_bwd', _p(U), U.stride(0), _p(I), I.stride(0), _p(E), E.stride(0), _p(item2ent), ent_pad, _p(ws), P,
+               d, _p(u), _p(i), n, l1, gumbel_mode, _p(uniform), seed, offset, _p(gs), _p(gU), _p(gI), _p(gE), _p(gA), _p(gC),
+               _stream(dev))
+        # A = pref + rel and C = pref_norm + norm: the mixed-table gradient goes to both summands
+        return gU, gI, gE, gA, gC, gA.clone(), gC.clone(), None, None, None, None, None, None, None, None, None
+
+
+def score_tup(U, I, pref, pref_norm, u, i, l1, gumbel_mode=GUMBEL_OFF, uniform=None, seed=0, offset=0):
+    """transUP.py:69-82 (forward) with getPreferences / st_gumbel_softmax fused (transUP.py:105-170)."""
+    return _ScorePref.apply(U, I, None, pref, pref_norm, None, None, None, u, i, l1, gumbel_mode, uniform, seed, offset, -1)
+
+
+def score_ktup(U, I, E, pref, pref_norm, rel, norm, item2ent, u, i, l1, gumbel_mode=GUMBEL_OFF, uniform=None, seed=0,
+               offset=0, ent_pad=-1):
+    """jTransUP.py:122-143 (is_rec branch) with paddingItems replaced by the int32 `item2ent` device table."""
+    return _ScorePref.apply(U, I, E, pref, pref_norm, rel, norm, item2ent, u, i, l1, gumbel_mode, uniform, seed, offset, ent_pad)

@@ -1,0 +1,64 @@
+"""CPU-side checks of the C-ABI boundary: the library loads, exports every symbol include/ktup_hip.h
+declares, and the Python binding table covers exactly that set.  No compute call is made (no GPU here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, 'include', 'ktup_hip.h')
+
+
+def declared_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(ktup_[a-z0-9_]+)\s*\(', text)))
+
+
+@pytest.fixture(scope='module')
+def lib():
+    from jTransUP.hip import lib as L
+    if not os.path.exists(L.LIB_PATH):
+        import importlib.util
+        spec = importlib.util.spec_from_file_location('build_hip', os.path.join(ROOT, 'joint-kg-recommender_amd', 'build_hip.py'))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        mod.build(verbose=False)
+    return L
+
+
+def test_header_declares_something():
+    syms = declared_symbols()
+    assert 'ktup_score_ktup_fwd' in syms and 'ktup_last_error' in syms and len(syms) >= 15
+
+
+def test_library_exports_every_declared_symbol(lib):
+    handle = ctypes.CDLL(lib.LIB_PATH)
+    missing = [s for s in declared_symbols() if not hasattr(handle, s)]
+    assert not missing, 'declared in include/ktup_hip.h but not exported: %s' % missing
+
+
+def test_binding_table_matches_header(lib):
+    assert sorted(lib.SIGNATURES) == declared_symbols()
+    lib.load()                       # sets argtypes / restype on every entry point
+    assert lib.load().ktup_version() >= 1
+
+
+def test_invalid_argument_is_reported_not_swallowed(lib):
+    # argument validation happens on the host before any launch, so this is safe without a GPU
+    with pytest.raises(lib.KtupError) as e:
+        lib.call('ktup_score_transe_fwd', None, 100, None, 100, -3, None, None, None, 5, 0, None, None)
+    assert 'embedding_size' in str(e.value)
+    assert lib.load().ktup_pref_workspace_bytes(100, 20) > 0
+    assert lib.load().ktup_pref_workspace_bytes(50, 20) == 0       # d % 4 != 0 is unsupported by the tile kernels
+
+
+def test_cpu_tensors_fail_loudly(lib):
+    import torch
+    from jTransUP.models import transE
+    m = transE.TransEModel(False, 8, 5, 3)
+    if torch.cuda.is_available():
+        pytest.skip('GPU present: covered by the gpu tests')
+    with pytest.raises(lib.KtupError):
+        m(torch.tensor([0]), torch.tensor([1]), torch.tensor([2]))

@@ -58,25 +58,34 @@ def build_world(seed, device):
     return W, i2e, idx
 
 
-def cpu_baseline(W, i2e, idx, budget_s=12.0):
+def cpu_baseline(W, i2e, idx, budget_s=14.0):
     """The oracle (a torch-CPU port of the reference's forward; note it replaces the reference's per-item python
-    dict walk by a tensor lookup, so it is FASTER than the reference itself) on all host cores, B=512, 7:3 mix."""
+    dict walk by a tensor lookup, so it is FASTER than the reference itself), B=512, 7 rec : 3 kg.
+    torch's default of one intra-op thread per host core is pathological for these small ops on a many-core host,
+    so a few thread counts are tried and the BEST is reported (with the thread count it used)."""
     from oracle import cpu_ref as O
-    threads = os.cpu_count() or 1
-    torch.set_num_threads(threads)
-    B, rows, t0, it = 512, 0, time.perf_counter(), 0
+    ncpu = os.cpu_count() or 1
+    B = 512
+    cands = sorted(set(t for t in (1, 4, 8, 16, 32, 64) if t <= ncpu))
+    best = None
     with torch.no_grad():
-        while time.perf_counter() - t0 < budget_s:
-            lo = (it * B) % (KG_ROWS - B)
-            if it % 10 < 7:
-                O.score_ktup_rec(W['U'], W['I'], W['E'], W['P'], W['Pn'], W['R'], W['Rn'], i2e, idx['u'][lo:lo + B], idx['i'][lo:lo + B], False)
-            else:
-                O.score_ktup_kg(W['E'], W['R'], W['Rn'], idx['h'][lo:lo + B], idx['t'][lo:lo + B], idx['r'][lo:lo + B], False)
-            rows += B
-            it += 1
-    dt = time.perf_counter() - t0
-    return {'value': rows / dt, 'unit': 'scored rows/s', 'cores': threads, 'kind': 'port',
-            'sample': '%d batches of 512 (7 rec : 3 kg), %.1f s, oracle/cpu_ref.py, torch %s CPU' % (it, dt, torch.__version__)}
+        for threads in cands:
+            torch.set_num_threads(threads)
+            rows, it, t0 = 0, 0, time.perf_counter()
+            while time.perf_counter() - t0 < budget_s / len(cands):
+                lo = (it * B) % (KG_ROWS - B)
+                if it % 10 < 7:
+                    O.score_ktup_rec(W['U'], W['I'], W['E'], W['P'], W['Pn'], W['R'], W['Rn'], i2e, idx['u'][lo:lo + B], idx['i'][lo:lo + B], False)
+                else:
+                    O.score_ktup_kg(W['E'], W['R'], W['Rn'], idx['h'][lo:lo + B], idx['t'][lo:lo + B], idx['r'][lo:lo + B], False)
+                rows += B
+                it += 1
+            dt = time.perf_counter() - t0
+            if best is None or rows / dt > best[0]:
+                best = (rows / dt, threads, it, dt)
+    return {'value': best[0], 'unit': 'scored rows/s', 'cores': best[1], 'kind': 'port', 'host_cores': ncpu,
+            'sample': '%d batches of 512 (7 rec : 3 kg) in %.1f s at the best of %s torch threads; oracle/cpu_ref.py, torch %s CPU'
+                      % (best[2], best[3], cands, torch.__version__)}
 
 
 def train_step_bench(device, steps=200, warmup=20):

@@ -106,6 +106,76 @@ int ktup_score_ktup_bwd(const float* U, int64_t ldu, const float* I, int64_t ldi
                         const float* uniform, uint64_t seed, uint64_t offset, const float* gscore, float* gU,
                         float* gI, float* gE, float* gA, float* gC, void* stream);
 
+/* ------------------------------------------- K8/K9  pairwise losses  utils/loss.py:8-16,29-31
+ * bpr   : loss = mean(-logsigmoid(target * (pos - neg)))   target = +1 (bprmf) / -1 (translation models,
+ *         utils/trainer.py:15-17);   margin: loss = SUM max(pos - neg + margin, 0).
+ * `loss` is one device float (overwritten); `gloss` is the upstream gradient as a DEVICE scalar.        */
+int ktup_loss_bpr_fwd(const float* pos, const float* neg, int64_t n, float target, float* loss, void* stream);
+int ktup_loss_bpr_bwd(const float* pos, const float* neg, int64_t n, float target, const float* gloss,
+                      float* gpos, float* gneg, void* stream);
+int ktup_loss_margin_fwd(const float* pos, const float* neg, int64_t n, float margin, float* loss, void* stream);
+int ktup_loss_margin_bwd(const float* pos, const float* neg, int64_t n, float margin, const float* gloss,
+                         float* gpos, float* gneg, void* stream);
+
+/* ------------------------------------------- K10  regularisers  utils/loss.py:18-23
+ * norm : sum over rows T[ids[i]] of max(|x|^2 - 1, 0);  orth: sum over rows of (Nrm[r].Rel[r])^2 / |Rel[r]|^2.
+ * ids == NULL means rows 0..n-1 (whole table); otherwise the gather the reference does with a second
+ * nn.Embedding lookup (item_recommendation.py:177-180, knowledge_representation.py:197-204) is fused.
+ * Backward accumulates into table-shaped gradients (same pitch as the table).                            */
+int ktup_reg_norm_fwd(const float* T, int64_t ld, int d, const int64_t* ids, int64_t n, float* loss, void* stream);
+int ktup_reg_norm_bwd(const float* T, int64_t ld, int d, const int64_t* ids, int64_t n, const float* gloss,
+                      float* gT, void* stream);
+int ktup_reg_orth_fwd(const float* Rel, int64_t ldr, const float* Nrm, int64_t ldn, int d, const int64_t* ids,
+                      int64_t n, float* loss, void* stream);
+int ktup_reg_orth_bwd(const float* Rel, int64_t ldr, const float* Nrm, int64_t ldn, int d, const int64_t* ids,
+                      int64_t n, const float* gloss, float* gRel, float* gNrm, void* stream);
+
+/* ------------------------------------------- K11-K16  all-candidate scores for evaluation
+ * Every function writes the full (nq x n_cand) fp32 score matrix `out` (pitch ldo), which keeps the
+ * reference's evaluate / evaluateRec / evaluateHead / evaluateTail drop-in; `ws` is caller scratch of the
+ * size the matching *_workspace_bytes reports.  head != 0: query is (t, r), candidates are heads
+ * (c = proj(t) - r); head == 0: query is (h, r), candidates are tails (c = proj(h) + r).                  */
+
+/* K11  bprmf.py:51-54 : out = U[u] . I^T  (fp32-input MFMA). */
+int ktup_eval_bprmf_scores(const float* U, int64_t ldu, const float* I, int64_t ldi, int d, const int64_t* u_ids,
+                           int64_t nq, int64_t n_items, float* out, int64_t ldo, void* stream);
+
+size_t ktup_eval_kg_workspace_bytes(int d, int64_t nq);
+/* K12  transE.py:65-105.  C (n_cand x d) is the candidate table (normally E itself). */
+int ktup_eval_transe_scores(const float* E, int64_t lde, const float* R, int64_t ldr, int d, const float* C,
+                            int64_t ldc, int64_t n_cand, const int64_t* q, const int64_t* r, int64_t nq, int l1,
+                            int head, float* out, int64_t ldo, float* ws, void* stream);
+/* K13  transH.py:73-121, jTransUP.py:193-247 (there C includes the zero pad row, which is ranked). */
+int ktup_eval_transh_scores(const float* E, int64_t lde, const float* R, int64_t ldr, const float* Nrm, int64_t ldn,
+                            int d, const float* C, int64_t ldc, int64_t n_cand, const int64_t* q, const int64_t* r,
+                            int64_t nq, int l1, int head, float* out, int64_t ldo, float* ws, void* stream);
+/* K14  transR.py:80-128 + utils/misc.py:29-33 : candidates projected by the query's relation matrix. */
+size_t ktup_eval_transr_workspace_bytes(int d, int64_t nq, int64_t n_ent, int n_rel);
+int ktup_eval_transr_scores(const float* E, int64_t lde, const float* R, int64_t ldr, const float* M, int64_t ldm,
+                            int d, int64_t n_ent, int n_rel, const int64_t* q, const int64_t* r, int64_t nq, int l1,
+                            int head, float* out, int64_t ldo, float* ws, void* stream);
+/* K15/K16  transUP.py:84-102 (E == NULL) and jTransUP.py:163-191.  item2ent has one int32 per ROW of I;
+ * uniform is (nq x n_items x n_pref) for KTUP_GUMBEL_INPUT (the reference draws noise in evaluate too).   */
+size_t ktup_eval_pref_workspace_bytes(int d, int n_pref, int64_t nq, int64_t n_items);
+int ktup_eval_pref_scores(const float* U, int64_t ldu, const float* I, int64_t ldi, const float* E, int64_t lde,
+                          const int32_t* item2ent, const float* pref_ws, int n_pref, int d, const int64_t* u_ids,
+                          int64_t nq, int64_t n_items, int l1, int gumbel_mode, const float* uniform, uint64_t seed,
+                          uint64_t offset, float* out, int64_t ldo, float* ws, void* stream);
+
+/* ------------------------------------------- K17/K18  ranking walk  utils/misc.py:125-146,213-248
+ * Order: ascending score (descending != 0 negates first, misc.py:93,180), ties -> lower id (declared rule).
+ * Filter sets are CSR: filt_off[nq + 1] (int64) into filt_ids (int32); filt_off == NULL means no filter.
+ * topk : the first `topn` unfiltered candidate ids per query (-1 padded), optionally their scores.
+ * ranks: for every gold entry (CSR gold_off / gold_ids) its 0-based rank among unfiltered NON-gold
+ *        candidates (other golds do not advance the rank); -1 if the gold id is itself filtered.
+ * Single-workgroup path: n_cand <= 19000 (ml1m: 3240 items / 14709 entities).                             */
+int ktup_eval_topk_filtered(const float* scores, int64_t lds, int64_t nq, int64_t n_cand, int descending,
+                            const int64_t* filt_off, const int32_t* filt_ids, int topn, int32_t* top_ids,
+                            float* top_scores, void* stream);
+int ktup_eval_gold_ranks(const float* scores, int64_t lds, int64_t nq, int64_t n_cand, int descending,
+                         const int64_t* filt_off, const int32_t* filt_ids, const int64_t* gold_off,
+                         const int32_t* gold_ids, int32_t* ranks, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,565 @@
+// K11-K16: all-candidate scoring for evaluation (every item for a batch of users / every entity for a batch of
+// (h,r) or (t,r) queries).  reference: bprmf.py:51-54, transE.py:65-105, transH.py:73-121, transR.py:80-128,
+// transUP.py:84-102, jTransUP.py:163-247.
+//
+// The reference materialises several (B x N x d) tensors per call (663 MB each at B=512, N=3240, d=100) and runs
+// the per-pair P x d contractions B*N times.  Here:
+//   * the preference gate is decomposed: logits(b,j) = LU_b + LV_j, and in the soft gate r and n are linear in the
+//     logits, so r(b,j) = RU_b + RV_j and n(b,j) = NU_b + NV_j.  The P x d contractions run once per user and once
+//     per item (pref_project_kernel); the pair kernel is purely elementwise:
+//         s = (u_b - v_j).(NU_b + NV_j),   z = (u_b + RU_b) - (v_j - RV_j) - s (NU_b + NV_j)
+//   * TransH: z = c_b - e_j + (e_j.w_b) w_b   and TransE: z = c_b - e_j   use the same pair kernel;
+//   * BPRMF's U[u].I^T is the one real GEMM: fp32-input MFMA (v_mfma_f32_32x32x2_f32), exact fp32 fma chains.
+// Pair-kernel mapping: lane <-> candidate (64-candidate tile staged once in LDS as [k/4][lane] float4, conflict-free
+// ds_read_b128); the 4 waves of a workgroup take different queries, QB = 4 queries at a time, whose vectors are
+// wave-uniform and therefore come through scalar loads into SGPRs.  The (B x N) score row is written coalesced.
+#include "ktup_pref_geom.h"
+
+using namespace ktup;
+
+namespace {
+
+constexpr int CT = 64;  // candidates per workgroup tile
+constexpr int QB = 4;   // queries a wave scores together (amortises each LDS read over QB queries)
+
+KTUP_DEV float wave_sum(float v) { return group_sum<64>(v); }
+
+// ---------------------------------------------------------------------------------------------------------
+// Query-side vectors for the KG models.  QW[b][3][dq]: slot 0 = c_b (translated query), slot 2 = w_b (TransH).
+// model: 0 TransE, 1 TransH, 2 TransR.   One wave per query.
+__global__ __launch_bounds__(256) void kg_query_prep_kernel(int model, const float* __restrict__ E, int64_t lde,
+                                                            const float* __restrict__ R, int64_t ldr,
+                                                            const float* __restrict__ X, int64_t ldx, int d, int dq,
+                                                            const int64_t* __restrict__ q, const int64_t* __restrict__ r,
+                                                            int64_t nq, int head, float* __restrict__ QW) {
+  const int lane = threadIdx.x & 63;
+  const float sgn = head ? -1.f : 1.f;  // head: c = proj(t) - r ; tail: c = proj(h) + r
+  for (int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); b < nq; b += (int64_t)gridDim.x * 4) {
+    const float* e = E + q[b] * lde;
+    const float* rel = R + r[b] * ldr;
+    float* out = QW + b * 3 * dq;
+    if (model == 0) {
+      for (int k = lane; k < dq; k += 64) out[k] = k < d ? e[k] + sgn * rel[k] : 0.f;
+    } else if (model == 1) {
+      const float* w = X + r[b] * ldx;
+      float dot = 0.f;
+      for (int k = lane; k < d; k += 64) dot = fmaf(e[k], w[k], dot);
+      dot = wave_sum(dot);
+      for (int k = lane; k < dq; k += 64) {
+        out[k] = k < d ? (e[k] - dot * w[k]) + sgn * rel[k] : 0.f;
+        out[2 * dq + k] = k < d ? w[k] : 0.f;
+      }
+    } else {
+      const float* M = X + r[b] * ldx;  // (d x d) row-major: out_i = sum_k M[i][k] e[k]   (misc.py:21-26)
+      for (int i = lane; i < dq; i += 64) {
+        float acc = 0.f;
+        if (i < d) {
+          for (int k = 0; k < d; ++k) acc = fmaf(M[(int64_t)i * d + k], e[k], acc);
+          acc += sgn * rel[i];
+        }
+        out[i] = acc;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Preference projections of one table (users or items): logits L = (A x)/2, R = beta A^T L, N = beta C^T L.
+// Outputs (pitch d): O0 = x + sign*R, O1 = x, O2 = N, OL = L (n_pref per row).  One wave per row, lane = 16-B chunk.
+__global__ __launch_bounds__(256) void pref_project_kernel(const float* __restrict__ X, int64_t ldx, const float* __restrict__ E,
+                                                           int64_t lde, const int32_t* __restrict__ item2ent,
+                                                           const int64_t* __restrict__ ids, int64_t nrows, int d, int P,
+                                                           const float* __restrict__ ws, int ppad, int dp, float sign,
+                                                           int64_t opitch, float* __restrict__ O0, float* __restrict__ O1,
+                                                           float* __restrict__ O2, float* __restrict__ OL) {
+  const int lane = threadIdx.x & 63;
+  const int nch = d / 4;
+  const float4* Alog = reinterpret_cast<const float4*>(ws);
+  const float4* Ar = reinterpret_cast<const float4*>(ws + (size_t)ppad * dp);
+  const float4* Cn = reinterpret_cast<const float4*>(ws + (size_t)(ppad + P) * dp);
+  const int dp4 = dp / 4;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < nrows; row += (int64_t)gridDim.x * 4) {
+    const int64_t src = ids ? ids[row] : row;
+    float4 x = f4zero();
+    if (lane < nch) {
+      x = reinterpret_cast<const float4*>(X + src * ldx)[lane];
+      if (E) x = x + reinterpret_cast<const float4*>(E + (int64_t)item2ent[src] * lde)[lane];
+    }
+    float4 racc = f4zero(), nacc = f4zero();
+    float mylog = 0.f;
+    for (int p = 0; p < P; ++p) {
+      float part = lane < nch ? dot4(x, Alog[p * dp4 + lane]) : 0.f;
+      part = wave_sum(part);
+      if (lane == (p & 63)) mylog = part;
+      if (lane < nch) {
+        racc = fma4(part, Ar[p * dp4 + lane], racc);
+        nacc = fma4(part, Cn[p * dp4 + lane], nacc);
+      }
+      if ((p & 63) == 63 || p == P - 1) {  // flush up to 64 logits per pass
+        const int pw = (p & ~63) + lane;
+        if (pw <= p) OL[row * P + pw] = mylog;
+      }
+    }
+    if (lane < nch) {
+      reinterpret_cast<float4*>(O0 + row * opitch)[lane] = fma4(sign, racc, x);
+      reinterpret_cast<float4*>(O1 + row * opitch)[lane] = x;
+      reinterpret_cast<float4*>(O2 + row * opitch)[lane] = nacc;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+struct PairsArgs {
+  const float *C0, *C1, *C2;  // candidate-side vectors: C0 enters z, C1 enters s, C2 = candidate part of the normal
+  int64_t ldc0, ldc1, ldc2;
+  const float* QW;            // [nq][3][dq] : A, Q1, NQ
+  int64_t n_cand, nq;
+  int d, dq, l1;
+  float* out;
+  int64_t ldo;
+  int cvec;                   // candidate rows readable as aligned float4
+  // TransR only: candidates depend on the query's relation -> grid.z = relation, queries bucketed by relation
+  const int32_t* qperm;       // query order sorted by relation (NULL otherwise)
+  const int32_t* rel_off;     // [n_rel + 1] bucket offsets into qperm
+  int64_t rel_stride;         // elements between the projected-candidate tables of consecutive relations
+};
+
+KTUP_DEV float4 load_cand4(const float* base, int64_t ld, int64_t row, int c, int d, bool vec) {
+  const float* p = base + row * ld + 4 * c;
+  if (vec) return *reinterpret_cast<const float4*>(p);
+  float4 v;
+  v.x = 4 * c + 0 < d ? p[0] : 0.f;
+  v.y = 4 * c + 1 < d ? p[1] : 0.f;
+  v.z = 4 * c + 2 < d ? p[2] : 0.f;
+  v.w = 4 * c + 3 < d ? p[3] : 0.f;
+  return v;
+}
+
+// MODE 0: z = A - C0 (TransE / TransR-projected)   MODE 1: TransH   MODE 2: TUP / KTUP soft gate
+template <int MODE>
+__global__ __launch_bounds__(256) void pairs_kernel(PairsArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float4* cand = reinterpret_cast<float4*>(smem);  // [NCV][nch4][CT]
+  constexpr int NCV = MODE == 2 ? 3 : 1;
+  const int t = threadIdx.x, lane = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int nch4 = a.dq / 4;
+  const int64_t j0 = (int64_t)blockIdx.x * CT;
+  int64_t range_lo = 0, range_hi = a.nq;
+  const float* C0 = a.C0;
+  if (a.qperm) {  // (uniform per workgroup)
+    range_lo = a.rel_off[blockIdx.z];
+    range_hi = a.rel_off[blockIdx.z + 1];
+    if (range_lo >= range_hi) return;
+    C0 += (int64_t)blockIdx.z * a.rel_stride;
+  }
+  for (int idx = t; idx < nch4 * CT; idx += 256) {
+    const int j = idx & (CT - 1), c = idx >> 6;
+    const int64_t gj = min(j0 + j, a.n_cand - 1);
+    cand[(0 * nch4 + c) * CT + j] = load_cand4(C0, a.ldc0, gj, c, a.d, a.cvec);
+    if (NCV == 3) {
+      cand[(1 * nch4 + c) * CT + j] = load_cand4(a.C1, a.ldc1, gj, c, a.d, a.cvec);
+      cand[(2 * nch4 + c) * CT + j] = load_cand4(a.C2, a.ldc2, gj, c, a.d, a.cvec);
+    }
+  }
+  __syncthreads();
+  const sptr4 QW = as_scalar(a.QW);
+  const int dq4 = nch4;
+  const bool l1 = a.l1 != 0;
+  // this workgroup's slice of the queries (grid.y splits them), QB at a time per wave
+  const int64_t nrange = range_hi - range_lo;
+  const int64_t per = ((nrange + gridDim.y - 1) / gridDim.y + 4 * QB - 1) / (4 * QB) * (4 * QB);
+  const int64_t qlo = range_lo + (int64_t)blockIdx.y * per, qhi = min(range_hi, qlo + per);
+  for (int64_t b0 = qlo + w * QB; b0 < qhi; b0 += 4 * QB) {
+    int qrow[QB];
+    int64_t qid[QB];
+#pragma unroll
+    for (int qi = 0; qi < QB; ++qi) {
+      const int64_t pos = min(b0 + qi, range_hi - 1);
+      qid[qi] = a.qperm ? (int64_t)a.qperm[pos] : pos;
+      qrow[qi] = (int)qid[qi] * 3 * dq4;
+    }
+    float s[QB], acc[QB];
+#pragma unroll
+    for (int qi = 0; qi < QB; ++qi) { s[qi] = 0.f; acc[qi] = 0.f; }
+    if (MODE >= 1) {
+      for (int c = 0; c < nch4; ++c) {
+        const float4 c1 = cand[((MODE == 2 ? 1 : 0) * nch4 + c) * CT + lane];
+        const float4 nc = MODE == 2 ? cand[(2 * nch4 + c) * CT + lane] : f4zero();
+#pragma unroll
+        for (int qi = 0; qi < QB; ++qi) {
+          const float4 nqv = sld(QW, qrow[qi] + 2 * dq4 + c);
+          const float4 q1 = MODE == 2 ? sld(QW, qrow[qi] + dq4 + c) : f4zero();
+          s[qi] += dot4(q1 - c1, nqv + nc);
+        }
+      }
+    }
+    for (int c = 0; c < nch4; ++c) {
+      const float4 c0 = cand[c * CT + lane];
+      const float4 nc = MODE == 2 ? cand[(2 * nch4 + c) * CT + lane] : f4zero();
+#pragma unroll
+      for (int qi = 0; qi < QB; ++qi) {
+        const float4 av = sld(QW, qrow[qi] + c);
+        float4 z = av - c0;
+        if (MODE >= 1) z = fma4(-s[qi], sld(QW, qrow[qi] + 2 * dq4 + c) + nc, z);
+        acc[qi] += dist4(z, l1);
+      }
+    }
+    if (j0 + lane < a.n_cand) {
+#pragma unroll
+      for (int qi = 0; qi < QB; ++qi)
+        if (b0 + qi < qhi) a.out[qid[qi] * a.ldo + j0 + lane] = acc[qi];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Hard (ST-Gumbel) gate, K15/K16 with use_st_gumbel: w(b,j) = onehot(argmax_p LU_b[p] + LV_j[p] + g(b,j,p)),
+// r = beta A[p*], n = beta C[p*]; z = q + r - (q.n) n with q = u_b - v_j.  Noise is per (user, item, preference)
+// exactly like the reference, which draws a (B x N x P) uniform tensor inside evaluate (transUP.py:92).
+struct HardArgs {
+  const float *V, *LV;  // candidate vectors v_j [N][d], logits [N][P]
+  const float *QW, *QL; // query vectors (slot 1 = u_b), logits [nq][P]
+  const float* ws;      // prepared tables
+  int ppad, dp, P, d;
+  int64_t n_cand, nq;
+  int l1, gumbel;
+  const float* uniform;
+  uint64_t seed, offset;
+  float* out;
+  int64_t ldo;
+};
+
+__global__ __launch_bounds__(256) void pairs_hard_kernel(HardArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int nch4 = a.d / 4, dp4 = a.dp / 4;
+  float4* cand = reinterpret_cast<float4*>(smem);              // [nch4][CT]
+  float4* tabA = cand + nch4 * CT;                              // [P][dp4]
+  float4* tabC = tabA + a.P * dp4;                              // [P][dp4]
+  float* lv = reinterpret_cast<float*>(tabC + a.P * dp4);      // [P][CT]
+  const int t = threadIdx.x, lane = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int64_t j0 = (int64_t)blockIdx.x * CT;
+  const int64_t gj = min(j0 + lane, a.n_cand - 1);
+  for (int idx = t; idx < nch4 * CT; idx += 256) {
+    const int j = idx & (CT - 1), c = idx >> 6;
+    cand[c * CT + j] = reinterpret_cast<const float4*>(a.V + min(j0 + j, a.n_cand - 1) * a.d)[c];
+  }
+  {
+    const float4* Ar = reinterpret_cast<const float4*>(a.ws + (size_t)a.ppad * a.dp);
+    for (int idx = t; idx < 2 * a.P * dp4; idx += 256) tabA[idx] = Ar[idx];  // Ar then Cn are adjacent in ws
+    for (int idx = t; idx < a.P * CT; idx += 256) {
+      const int j = idx & (CT - 1), p = idx >> 6;
+      lv[p * CT + j] = a.LV[min(j0 + j, a.n_cand - 1) * a.P + p];
+    }
+  }
+  __syncthreads();
+  const sptr4 QW = as_scalar(a.QW);
+  const bool l1 = a.l1 != 0;
+  const int64_t per = (a.nq + gridDim.y - 1) / gridDim.y;
+  const int64_t qlo = (int64_t)blockIdx.y * per, qhi = min(a.nq, qlo + per);
+  for (int64_t b = qlo + w; b < qhi; b += 4) {
+    const float* ql = a.QL + b * a.P;  // wave-uniform -> scalar loads
+    int ps = 0;
+    float best = -INFINITY;
+    const uint64_t base = ((uint64_t)b * (uint64_t)a.n_cand + (uint64_t)gj) * (uint64_t)a.P;
+    for (int p = 0; p < a.P; ++p) {
+      float u;
+      if (a.gumbel == KTUP_GUMBEL_INPUT) {
+        u = a.uniform[base + p];
+      } else {
+        const uint64_t idx = base + p + a.offset;
+        const uint4 r = Philox(a.seed)(idx >> 2, 0x4b545550ull);
+        u = u01((idx & 3) == 0 ? r.x : (idx & 3) == 1 ? r.y : (idx & 3) == 2 ? r.z : r.w);
+      }
+      const float v = (ql[p] + lv[p * CT + lane]) + gumbel_from_uniform(u);
+      if (v > best) { best = v; ps = p; }
+    }
+    const int urow = (int)b * 3 * nch4 + nch4;  // slot 1 = u_b
+    const float4* cn = tabC + ps * dp4;
+    const float4* ar = tabA + ps * dp4;
+    float s = 0.f;
+    for (int c = 0; c < nch4; ++c) s += dot4(sld(QW, urow + c) - cand[c * CT + lane], cn[c]);
+    float acc = 0.f;
+    for (int c = 0; c < nch4; ++c) {
+      const float4 q = sld(QW, urow + c) - cand[c * CT + lane];
+      acc += dist4(fma4(-s, cn[c], q + ar[c]), l1);
+    }
+    if (j0 + lane < a.n_cand) a.out[b * a.ldo + j0 + lane] = acc;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// K11: out[b][j] = U[u_b] . I[j]  with v_mfma_f32_32x32x2_f32 (fp32 in / fp32 accumulate: bit-for-bit an fmaf chain).
+// One wave per 32 x 32 output tile; A operand lane l = U[u_(m0 + l&31)][k + (l>>5)], B operand = I[n0 + l&31][k + (l>>5)].
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(256) void bprmf_eval_kernel(const float* __restrict__ U, int64_t ldu, const float* __restrict__ I,
+                                                         int64_t ldi, int d, const int64_t* __restrict__ u_ids, int64_t nq,
+                                                         int64_t n_items, float* __restrict__ out, int64_t ldo, int vec) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t m0 = (int64_t)blockIdx.y * 64 + (wv & 1) * 32;
+  const int64_t n0 = (int64_t)blockIdx.x * 64 + (wv >> 1) * 32;
+  if (m0 >= nq || n0 >= n_items) return;
+  const int hi = lane >> 5;
+  const float* arow = U + u_ids[min(m0 + (lane & 31), nq - 1)] * ldu;
+  const float* brow = I + min(n0 + (lane & 31), n_items - 1) * ldi;
+  v16f acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  if (vec) {
+    const int nch = d / 4;
+    for (int c = 0; c < nch; ++c) {
+      const float4 a4 = reinterpret_cast<const float4*>(arow)[c];
+      const float4 b4 = reinterpret_cast<const float4*>(brow)[c];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(hi ? a4.y : a4.x, hi ? b4.y : b4.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(hi ? a4.w : a4.z, hi ? b4.w : b4.z, acc, 0, 0, 0);
+    }
+  } else {
+    for (int k = 0; k < d; k += 2) {
+      const int kk = k + hi;
+      const float av = kk < d ? arow[kk] : 0.f, bv = kk < d ? brow[kk] : 0.f;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+    }
+  }
+  const int64_t col = n0 + (lane & 31);
+  if (col < n_items) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int64_t row = m0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      if (row < nq) out[row * ldo + col] = acc[r];
+    }
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------
+// K14 (TransR): every entity projected by every relation's matrix, PE[rho][j] = M_rho e_j (misc.py:29-33); the
+// reference recomputes (B x d x d).(d x E) per query although only n_rel distinct products exist.
+// Workgroup = (64-entity tile, relation); lane <-> entity, waves split the output coordinates; M rows are
+// wave-uniform -> scalar loads.
+__global__ __launch_bounds__(256) void transr_project_kernel(const float* __restrict__ E, int64_t lde, const float* __restrict__ M,
+                                                             int64_t ldm, int d, int dq, int64_t n_ent, int evec, int mvec,
+                                                             float* __restrict__ PE) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float4* cand = reinterpret_cast<float4*>(smem);  // [nch4][CT]
+  const int t = threadIdx.x, lane = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int nch4 = dq / 4;
+  const int64_t j0 = (int64_t)blockIdx.x * CT;
+  const int rho = blockIdx.y;
+  for (int idx = t; idx < nch4 * CT; idx += 256) {
+    const int j = idx & (CT - 1), c = idx >> 6;
+    cand[c * CT + j] = load_cand4(E, lde, min(j0 + j, n_ent - 1), c, d, evec);
+  }
+  __syncthreads();
+  const float* Mr = M + (int64_t)rho * ldm;
+  float* outrow = PE + ((int64_t)rho * n_ent + min(j0 + lane, n_ent - 1)) * dq;
+  const bool live = j0 + lane < n_ent;
+  for (int i = w; i < dq; i += 4) {
+    float acc = 0.f;
+    if (i < d) {
+      if (mvec) {
+        const sptr4 mrow = as_scalar(Mr + (int64_t)i * d);
+        for (int c = 0; c < nch4; ++c) acc += dot4(sld(mrow, c), cand[c * CT + lane]);
+      } else {
+        const float* mrow = Mr + (int64_t)i * d;
+        for (int k = 0; k < d; ++k) {
+          const float4 e4 = cand[(k >> 2) * CT + lane];
+          const float ev = (k & 3) == 0 ? e4.x : (k & 3) == 1 ? e4.y : (k & 3) == 2 ? e4.z : e4.w;
+          acc = fmaf(mrow[k], ev, acc);
+        }
+      }
+    }
+    if (live) outrow[i] = acc;
+  }
+}
+
+// Counting sort of the queries by relation (single workgroup; nq is an evaluation batch, n_rel is small).
+__global__ __launch_bounds__(256) void rel_bucket_kernel(const int64_t* __restrict__ r, int64_t nq, int n_rel,
+                                                         int32_t* __restrict__ rel_off, int32_t* __restrict__ qperm) {
+  extern __shared__ int cnt[];  // [n_rel] counts, then running cursors
+  for (int i = threadIdx.x; i < n_rel; i += 256) cnt[i] = 0;
+  __syncthreads();
+  for (int64_t b = threadIdx.x; b < nq; b += 256) atomicAdd(&cnt[(int)r[b]], 1);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int i = 0; i < n_rel; ++i) { const int c = cnt[i]; rel_off[i] = run; cnt[i] = run; run += c; }
+    rel_off[n_rel] = run;
+  }
+  __syncthreads();
+  for (int64_t b = threadIdx.x; b < nq; b += 256) qperm[atomicAdd(&cnt[(int)r[b]], 1)] = (int32_t)b;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+dim3 pairs_grid(int64_t n_cand, int64_t nq) {
+  const int64_t tiles = (n_cand + CT - 1) / CT;
+  int64_t ysplit = (2048 + tiles - 1) / tiles;
+  const int64_t ymax = (nq + 4 * QB - 1) / (4 * QB);
+  if (ysplit > ymax) ysplit = ymax;
+  if (ysplit < 1) ysplit = 1;
+  return dim3((unsigned)tiles, (unsigned)ysplit);
+}
+
+template <int MODE>
+int launch_pairs(const PairsArgs& a, hipStream_t st, const char* name, int nrel = 1) {
+  const int ncv = MODE == 2 ? 3 : 1;
+  const size_t lds = (size_t)ncv * (a.dq / 4) * CT * 16;
+  if (lds > 160 * 1024) return set_error(KTUP_ERR_UNSUPPORTED, "%s: embedding_size %d needs %zu B of LDS", name, a.d, lds);
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute((const void*)pairs_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  dim3 grid = pairs_grid(a.n_cand, a.nq);
+  if (a.qperm) grid.z = (unsigned)nrel;
+  hipLaunchKernelGGL(pairs_kernel<MODE>, grid, dim3(256), lds, st, a);
+  return check_launch(name);
+}
+
+inline int round4(int d) { return (d + 3) / 4 * 4; }
+inline size_t pad4(size_t x) { return (x + 3) & ~(size_t)3; }
+
+int kg_eval(int model, const char* name, const float* E, int64_t lde, const float* R, int64_t ldr, const float* X, int64_t ldx,
+            int d, const float* C, int64_t ldc, int64_t n_cand, const int64_t* q, const int64_t* r, int64_t nq, int l1, int head,
+            float* out, int64_t ldo, float* ws, void* stream) {
+  KTUP_REQUIRE(d > 0 && nq >= 0 && n_cand >= 0, "%s: bad sizes", name);
+  if (nq == 0 || n_cand == 0) return KTUP_OK;
+  KTUP_REQUIRE(E && R && C && q && r && out && ws && (model == 0 || X), "%s: null pointer argument", name);
+  KTUP_REQUIRE(ldo >= n_cand, "%s: output pitch %lld < n_cand", name, (long long)ldo);
+  KTUP_REQUIRE(model != 2 || ldx >= (int64_t)d * d, "%s: projection pitch < d*d", name);
+  hipStream_t st = (hipStream_t)stream;
+  const int dq = round4(d);
+  hipLaunchKernelGGL(kg_query_prep_kernel, dim3(grid_for((nq + 3) / 4)), dim3(256), 0, st, model, E, lde, R, ldr, X, ldx, d, dq,
+                     q, r, nq, head, ws);
+  if (int e = check_launch(name)) return e;
+  PairsArgs a{};
+  a.C0 = C; a.ldc0 = ldc; a.QW = ws; a.n_cand = n_cand; a.nq = nq; a.d = d; a.dq = dq; a.l1 = l1; a.out = out; a.ldo = ldo;
+  a.cvec = (d % 4 == 0) && aligned16(C) && (ldc % 4 == 0);
+  return model == 1 ? launch_pairs<1>(a, st, name) : launch_pairs<0>(a, st, name);
+}
+
+}  // namespace
+
+extern "C" size_t ktup_eval_kg_workspace_bytes(int d, int64_t nq) { return (size_t)nq * 3 * round4(d) * sizeof(float); }
+
+extern "C" size_t ktup_eval_pref_workspace_bytes(int d, int n_pref, int64_t nq, int64_t n_items) {
+  // QW[nq][3][d] | QL[nq][P] (padded to 16 B) | CW0, CW1, CW2 [N][d] | CL[N][P]
+  return ((size_t)nq * 3 * d + pad4((size_t)nq * n_pref) + (size_t)n_items * 3 * d + pad4((size_t)n_items * n_pref)) * sizeof(float);
+}
+
+extern "C" int ktup_eval_bprmf_scores(const float* U, int64_t ldu, const float* I, int64_t ldi, int d, const int64_t* u_ids,
+                                      int64_t nq, int64_t n_items, float* out, int64_t ldo, void* stream) {
+  KTUP_REQUIRE(d > 0 && nq >= 0 && n_items >= 0, "ktup_eval_bprmf_scores: bad sizes");
+  if (nq == 0 || n_items == 0) return KTUP_OK;
+  KTUP_REQUIRE(U && I && u_ids && out && ldo >= n_items, "ktup_eval_bprmf_scores: bad argument");
+  const int vec = (d % 4 == 0) && aligned16(U) && aligned16(I) && ldu % 4 == 0 && ldi % 4 == 0;
+  dim3 grid((unsigned)((n_items + 63) / 64), (unsigned)((nq + 63) / 64));
+  hipLaunchKernelGGL(bprmf_eval_kernel, grid, dim3(256), 0, (hipStream_t)stream, U, ldu, I, ldi, d, u_ids, nq, n_items, out, ldo,
+                     vec);
+  return check_launch("ktup_eval_bprmf_scores");
+}
+
+extern "C" int ktup_eval_transe_scores(const float* E, int64_t lde, const float* R, int64_t ldr, int d, const float* C,
+                                       int64_t ldc, int64_t n_cand, const int64_t* q, const int64_t* r, int64_t nq, int l1,
+                                       int head, float* out, int64_t ldo, float* ws, void* stream) {
+  return kg_eval(0, "ktup_eval_transe_scores", E, lde, R, ldr, nullptr, 0, d, C, ldc, n_cand, q, r, nq, l1, head, out, ldo, ws,
+                 stream);
+}
+
+extern "C" int ktup_eval_transh_scores(const float* E, int64_t lde, const float* R, int64_t ldr, const float* Nrm, int64_t ldn,
+                                       int d, const float* C, int64_t ldc, int64_t n_cand, const int64_t* q, const int64_t* r,
+                                       int64_t nq, int l1, int head, float* out, int64_t ldo, float* ws, void* stream) {
+  return kg_eval(1, "ktup_eval_transh_scores", E, lde, R, ldr, Nrm, ldn, d, C, ldc, n_cand, q, r, nq, l1, head, out, ldo, ws,
+                 stream);
+}
+
+
+extern "C" size_t ktup_eval_transr_workspace_bytes(int d, int64_t nq, int64_t n_ent, int n_rel) {
+  // QW[nq][3][dq] | PE[n_rel][n_ent][dq] | rel_off[n_rel + 1] | qperm[nq]
+  return ((size_t)nq * 3 * round4(d) + (size_t)n_rel * n_ent * round4(d)) * sizeof(float) +
+         pad4((size_t)n_rel + 1 + (size_t)nq) * sizeof(int32_t);
+}
+
+extern "C" int ktup_eval_transr_scores(const float* E, int64_t lde, const float* R, int64_t ldr, const float* M, int64_t ldm,
+                                       int d, int64_t n_ent, int n_rel, const int64_t* q, const int64_t* r, int64_t nq, int l1,
+                                       int head, float* out, int64_t ldo, float* ws, void* stream) {
+  const char* name = "ktup_eval_transr_scores";
+  KTUP_REQUIRE(d > 0 && nq >= 0 && n_ent >= 0 && n_rel > 0, "%s: bad sizes", name);
+  if (nq == 0 || n_ent == 0) return KTUP_OK;
+  KTUP_REQUIRE(E && R && M && q && r && out && ws && ldo >= n_ent && ldm >= (int64_t)d * d, "%s: bad argument", name);
+  hipStream_t st = (hipStream_t)stream;
+  const int dq = round4(d);
+  float* QW = ws;
+  float* PE = QW + (size_t)nq * 3 * dq;
+  int32_t* rel_off = reinterpret_cast<int32_t*>(PE + (size_t)n_rel * n_ent * dq);
+  int32_t* qperm = rel_off + n_rel + 1;
+  hipLaunchKernelGGL(kg_query_prep_kernel, dim3(grid_for((nq + 3) / 4)), dim3(256), 0, st, 2, E, lde, R, ldr, M, ldm, d, dq, q, r,
+                     nq, head, QW);
+  if (int e = check_launch(name)) return e;
+  const size_t lds = (size_t)(dq / 4) * CT * 16;
+  KTUP_REQUIRE(lds <= 64 * 1024 && (size_t)n_rel * 4 <= 64 * 1024, "%s: embedding_size / n_rel too large", name);
+  const int evec = (d % 4 == 0) && aligned16(E) && lde % 4 == 0;
+  const int mvec = (d % 4 == 0) && aligned16(M) && ldm % 4 == 0;
+  hipLaunchKernelGGL(transr_project_kernel, dim3((unsigned)((n_ent + CT - 1) / CT), (unsigned)n_rel), dim3(256), lds, st, E, lde,
+                     M, ldm, d, dq, n_ent, evec, mvec, PE);
+  if (int e = check_launch(name)) return e;
+  hipLaunchKernelGGL(rel_bucket_kernel, dim3(1), dim3(256), (size_t)n_rel * 4, st, r, nq, n_rel, rel_off, qperm);
+  if (int e = check_launch(name)) return e;
+  PairsArgs a{};
+  a.C0 = PE; a.ldc0 = dq; a.QW = QW; a.n_cand = n_ent; a.nq = nq; a.d = d; a.dq = dq; a.l1 = l1; a.out = out; a.ldo = ldo;
+  a.cvec = 1; a.qperm = qperm; a.rel_off = rel_off; a.rel_stride = (int64_t)n_ent * dq;
+  return launch_pairs<0>(a, st, name, n_rel);
+}
+
+// TUP (E == NULL) / KTUP all-item scores.  `pref_ws` is the ktup_pref_prepare workspace; `item2ent` has one entry per
+// ROW of I (the caller passes the evaluateRec pairing, jTransUP.py:174); `uniform` is (nq x n_items x n_pref).
+extern "C" int ktup_eval_pref_scores(const float* U, int64_t ldu, const float* I, int64_t ldi, const float* E, int64_t lde,
+                                     const int32_t* item2ent, const float* pref_ws, int n_pref, int d, const int64_t* u_ids,
+                                     int64_t nq, int64_t n_items, int l1, int gumbel_mode, const float* uniform, uint64_t seed,
+                                     uint64_t offset, float* out, int64_t ldo, float* ws, void* stream) {
+  const char* name = "ktup_eval_pref_scores";
+  KTUP_REQUIRE(nq >= 0 && n_items >= 0, "%s: bad sizes", name);
+  if (nq == 0 || n_items == 0) return KTUP_OK;
+  const PrefGeom g = pref_geom(d, n_pref);
+  if (!g.ok) return set_error(KTUP_ERR_UNSUPPORTED, "%s: embedding_size must be a multiple of 4 in [4, 256] (got %d)", name, d);
+  KTUP_REQUIRE(U && I && pref_ws && u_ids && out && ws && ldo >= n_items, "%s: bad argument", name);
+  KTUP_REQUIRE((E == nullptr) == (item2ent == nullptr), "%s: E and item2ent must be given together", name);
+  KTUP_REQUIRE(aligned16(U) && aligned16(I) && aligned16(E) && aligned16(pref_ws) && aligned16(ws) && ldu % 4 == 0 &&
+                   ldi % 4 == 0 && (!E || lde % 4 == 0), "%s: tables must be 16-byte aligned with pitches %% 4 == 0", name);
+  KTUP_REQUIRE(gumbel_mode >= KTUP_GUMBEL_OFF && gumbel_mode <= KTUP_GUMBEL_PHILOX, "%s: bad gumbel_mode", name);
+  KTUP_REQUIRE(gumbel_mode != KTUP_GUMBEL_INPUT || uniform, "%s: KTUP_GUMBEL_INPUT needs the uniform tensor", name);
+  hipStream_t st = (hipStream_t)stream;
+  float* QW = ws;
+  float* QL = QW + (size_t)nq * 3 * d;
+  float* CW0 = QL + pad4((size_t)nq * n_pref);
+  float* CW1 = CW0 + (size_t)n_items * d;
+  float* CW2 = CW1 + (size_t)n_items * d;
+  float* CL = CW2 + (size_t)n_items * d;
+  // users: slot 0 = u + RU, slot 1 = u, slot 2 = NU, rows of pitch 3d;   items: v - RV, v, NV, rows of pitch d
+  hipLaunchKernelGGL(pref_project_kernel, dim3(grid_for((nq + 3) / 4)), dim3(256), 0, st, U, ldu, (const float*)nullptr,
+                     (int64_t)0, (const int32_t*)nullptr, u_ids, nq, d, n_pref, pref_ws, g.ppad, g.dp, 1.0f, (int64_t)3 * d, QW,
+                     QW + d, QW + 2 * d, QL);
+  if (int e = check_launch(name)) return e;
+  hipLaunchKernelGGL(pref_project_kernel, dim3(grid_for((n_items + 3) / 4)), dim3(256), 0, st, I, ldi, E, lde, item2ent,
+                     (const int64_t*)nullptr, n_items, d, n_pref, pref_ws, g.ppad, g.dp, -1.0f, (int64_t)d, CW0, CW1, CW2, CL);
+  if (int e = check_launch(name)) return e;
+  if (gumbel_mode == KTUP_GUMBEL_OFF) {
+    PairsArgs a{};
+    a.C0 = CW0; a.C1 = CW1; a.C2 = CW2; a.ldc0 = a.ldc1 = a.ldc2 = d;
+    a.QW = QW; a.n_cand = n_items; a.nq = nq; a.d = d; a.dq = d; a.l1 = l1; a.out = out; a.ldo = ldo; a.cvec = 1;
+    return launch_pairs<2>(a, st, name);
+  }
+  HardArgs h{};
+  h.V = CW1; h.LV = CL; h.QW = QW; h.QL = QL; h.ws = pref_ws; h.ppad = g.ppad; h.dp = g.dp; h.P = n_pref; h.d = d;
+  h.n_cand = n_items; h.nq = nq; h.l1 = l1; h.gumbel = gumbel_mode; h.uniform = uniform; h.seed = seed; h.offset = offset;
+  h.out = out; h.ldo = ldo;
+  const size_t lds = (size_t)(d / 4) * CT * 16 + (size_t)2 * n_pref * g.dp * 4 + (size_t)n_pref * CT * 4;
+  if (lds > 160 * 1024) return set_error(KTUP_ERR_UNSUPPORTED, "%s: hard-gate tile needs %zu B of LDS", name, lds);
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute((const void*)pairs_hard_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const int64_t tiles = (n_items + CT - 1) / CT;
+  int64_t ysplit = (2048 + tiles - 1) / tiles;
+  if (ysplit > (nq + 3) / 4) ysplit = (nq + 3) / 4;
+  if (ysplit < 1) ysplit = 1;
+  hipLaunchKernelGGL(pairs_hard_kernel, dim3((unsigned)tiles, (unsigned)ysplit), dim3(256), lds, st, h);
+  return check_launch(name);
+}

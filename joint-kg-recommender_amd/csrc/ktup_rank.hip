@@ -1,0 +1,169 @@
+// K17 / K18: the ranking walk of evaluation on the device.
+//   reference: jTransUP/utils/misc.py:213-248 (getRecPerformance) and :125-146 (getKGPerformance), which
+//   np.argsort the full score row on the host (after a 6.6 MB D2H copy per batch, pickled to worker processes)
+//   and then walk it in python skipping filtered ids.
+// Integer work, bit-exact by construction: every candidate gets the 64-bit key
+//        key = (order-preserving image of the fp32 score) << 32 | candidate id
+// so the order is total: ascending score, ties -> lower id first (the declared tie rule; np.argsort's default sort
+// is not stable, so the reference leaves ties unspecified).  `descending` negates the score first, exactly like
+// `per_scores = -pred` (misc.py:93,180).  Filtered candidates get key = 2^64-1 and never rank.
+// One workgroup per query row; the row's keys live in LDS (8 B per candidate: 26 KB for ml1m's 3240 items,
+// 118 KB for its 14709 entities), so the score row is read from HBM exactly once.
+#include "ktup_common.h"
+
+using namespace ktup;
+
+namespace {
+
+constexpr uint64_t KEY_MAX = ~0ull;
+constexpr int64_t MAX_LDS_CAND = 19000;  // 152 KB of keys + reduction scratch within the 160 KB LDS
+
+KTUP_DEV uint64_t make_key(float s, bool descending, uint32_t id) {
+  if (descending) s = -s;
+  if (s == 0.f) s = 0.f;  // -0.0 and +0.0 compare equal in the reference's sort: one key for both
+  uint32_t u = __float_as_uint(s);
+  u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+  return ((uint64_t)u << 32) | id;
+}
+
+KTUP_DEV uint64_t wave_min64(uint64_t v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    const uint64_t o = __shfl_xor(v, m, 64);
+    v = o < v ? o : v;
+  }
+  return v;
+}
+
+KTUP_DEV int wave_sum_int(int v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+
+KTUP_DEV void load_keys(uint64_t* keys, const float* row, int64_t n_cand, bool descending, const int32_t* fids, int64_t nf) {
+  for (int64_t j = threadIdx.x; j < n_cand; j += 256) keys[j] = make_key(row[j], descending, (uint32_t)j);
+  __syncthreads();
+  for (int64_t f = threadIdx.x; f < nf; f += 256) {
+    const int32_t id = fids[f];
+    if (id >= 0 && id < n_cand) keys[id] = KEY_MAX;
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void topk_filtered_kernel(const float* __restrict__ scores, int64_t lds, int64_t n_cand,
+                                                            int descending, const int64_t* __restrict__ filt_off,
+                                                            const int32_t* __restrict__ filt_ids, int topn,
+                                                            int32_t* __restrict__ top_ids, float* __restrict__ top_scores) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint64_t* keys = reinterpret_cast<uint64_t*>(smem);
+  __shared__ uint64_t red[4];
+  const int64_t b = blockIdx.x;
+  const float* row = scores + b * lds;
+  const int64_t f0 = filt_off ? filt_off[b] : 0, f1 = filt_off ? filt_off[b + 1] : 0;
+  load_keys(keys, row, n_cand, descending != 0, filt_ids + f0, f1 - f0);
+  uint64_t prev = 0;
+  bool first = true;
+  for (int r = 0; r < topn; ++r) {
+    uint64_t best = KEY_MAX;
+    for (int64_t j = threadIdx.x; j < n_cand; j += 256) {
+      const uint64_t k = keys[j];
+      if ((first || k > prev) && k < best) best = k;
+    }
+    best = wave_min64(best);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = best;
+    __syncthreads();
+    best = min(min(red[0], red[1]), min(red[2], red[3]));
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const bool ok = best != KEY_MAX;
+      const int32_t id = ok ? (int32_t)(uint32_t)best : -1;
+      top_ids[b * topn + r] = id;
+      if (top_scores) top_scores[b * topn + r] = ok ? row[id] : 0.f;
+    }
+    prev = best;
+    first = false;
+    if (best == KEY_MAX) {  // fewer than topn unfiltered candidates: pad the rest (uniform branch)
+      for (int rr = r + 1 + threadIdx.x; rr < topn; rr += 256) {
+        top_ids[b * topn + rr] = -1;
+        if (top_scores) top_scores[b * topn + rr] = 0.f;
+      }
+      break;
+    }
+  }
+}
+
+// rank of gold g = #{unfiltered, non-gold candidates ordered before g}  (0-based; other golds do not advance the rank,
+// misc.py:134-144).  A gold id that is itself filtered is never reached by the reference's walk: rank -1.
+__global__ __launch_bounds__(256) void gold_ranks_kernel(const float* __restrict__ scores, int64_t lds, int64_t n_cand,
+                                                         int descending, const int64_t* __restrict__ filt_off,
+                                                         const int32_t* __restrict__ filt_ids,
+                                                         const int64_t* __restrict__ gold_off,
+                                                         const int32_t* __restrict__ gold_ids, int32_t* __restrict__ ranks) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint64_t* keys = reinterpret_cast<uint64_t*>(smem);
+  __shared__ int red[4];
+  const int64_t b = blockIdx.x;
+  const float* row = scores + b * lds;
+  const int64_t f0 = filt_off ? filt_off[b] : 0, f1 = filt_off ? filt_off[b + 1] : 0;
+  load_keys(keys, row, n_cand, descending != 0, filt_ids + f0, f1 - f0);
+  const int64_t g0 = gold_off[b], g1 = gold_off[b + 1];
+  for (int64_t gi = g0; gi < g1; ++gi) {
+    const int32_t g = gold_ids[gi];
+    const uint64_t gk = (g >= 0 && g < n_cand) ? keys[g] : KEY_MAX;
+    if (gk == KEY_MAX) {  // uniform: every thread read the same LDS word
+      if (threadIdx.x == 0) ranks[gi] = -1;
+      continue;
+    }
+    int cnt = 0;
+    for (int64_t j = threadIdx.x; j < n_cand; j += 256) cnt += keys[j] < gk ? 1 : 0;
+    for (int64_t o = g0 + threadIdx.x; o < g1; o += 256) {
+      const int32_t og = gold_ids[o];
+      if (og >= 0 && og < n_cand && keys[og] < gk) cnt -= 1;
+    }
+    cnt = wave_sum_int(cnt);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) ranks[gi] = red[0] + red[1] + red[2] + red[3];
+    __syncthreads();
+  }
+}
+
+int prep_lds(const void* fn, int64_t n_cand, size_t* lds, const char* name) {
+  if (n_cand > MAX_LDS_CAND)
+    return set_error(KTUP_ERR_UNSUPPORTED, "%s: %lld candidates exceed the single-workgroup LDS ranking path (max %lld)", name,
+                     (long long)n_cand, (long long)MAX_LDS_CAND);
+  *lds = (size_t)n_cand * 8;
+  if (*lds > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)*lds);
+  return KTUP_OK;
+}
+
+}  // namespace
+
+extern "C" int ktup_eval_topk_filtered(const float* scores, int64_t lds, int64_t nq, int64_t n_cand, int descending,
+                                       const int64_t* filt_off, const int32_t* filt_ids, int topn, int32_t* top_ids,
+                                       float* top_scores, void* stream) {
+  const char* name = "ktup_eval_topk_filtered";
+  KTUP_REQUIRE(nq >= 0 && n_cand > 0 && topn > 0 && lds >= n_cand, "%s: bad sizes", name);
+  if (nq == 0) return KTUP_OK;
+  KTUP_REQUIRE(scores && top_ids && ((filt_off == nullptr) || filt_ids), "%s: null pointer argument", name);
+  size_t bytes = 0;
+  if (int e = prep_lds((const void*)topk_filtered_kernel, n_cand, &bytes, name)) return e;
+  hipLaunchKernelGGL(topk_filtered_kernel, dim3((unsigned)nq), dim3(256), bytes, (hipStream_t)stream, scores, lds, n_cand,
+                     descending, filt_off, filt_ids, topn, top_ids, top_scores);
+  return check_launch(name);
+}
+
+extern "C" int ktup_eval_gold_ranks(const float* scores, int64_t lds, int64_t nq, int64_t n_cand, int descending,
+                                    const int64_t* filt_off, const int32_t* filt_ids, const int64_t* gold_off,
+                                    const int32_t* gold_ids, int32_t* ranks, void* stream) {
+  const char* name = "ktup_eval_gold_ranks";
+  KTUP_REQUIRE(nq >= 0 && n_cand > 0 && lds >= n_cand, "%s: bad sizes", name);
+  if (nq == 0) return KTUP_OK;
+  KTUP_REQUIRE(scores && gold_off && gold_ids && ranks && ((filt_off == nullptr) || filt_ids), "%s: null pointer argument", name);
+  size_t bytes = 0;
+  if (int e = prep_lds((const void*)gold_ranks_kernel, n_cand, &bytes, name)) return e;
+  hipLaunchKernelGGL(gold_ranks_kernel, dim3((unsigned)nq), dim3(256), bytes, (hipStream_t)stream, scores, lds, n_cand,
+                     descending, filt_off, filt_ids, gold_off, gold_ids, ranks);
+  return check_launch(name);
+}

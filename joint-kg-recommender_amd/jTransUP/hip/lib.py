@@ -38,8 +38,29 @@ SIGNATURES = {
     'ktup_score_tup_bwd': [c_p, c_l, c_p, c_l, c_p, c_i, c_i, c_p, c_p, c_l, c_i, c_i, c_p, c_u, c_u, c_p, c_p, c_p, c_p, c_p, c_p],
     'ktup_score_ktup_bwd': [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_i, c_i, c_p, c_p, c_l, c_i, c_i, c_p, c_u, c_u,
                             c_p, c_p, c_p, c_p, c_p, c_p, c_p],
+    'ktup_loss_bpr_fwd': [c_p, c_p, c_l, c_f, c_p, c_p],
+    'ktup_loss_bpr_bwd': [c_p, c_p, c_l, c_f, c_p, c_p, c_p, c_p],
+    'ktup_loss_margin_fwd': [c_p, c_p, c_l, c_f, c_p, c_p],
+    'ktup_loss_margin_bwd': [c_p, c_p, c_l, c_f, c_p, c_p, c_p, c_p],
+    'ktup_reg_norm_fwd': [c_p, c_l, c_i, c_p, c_l, c_p, c_p],
+    'ktup_reg_norm_bwd': [c_p, c_l, c_i, c_p, c_l, c_p, c_p, c_p],
+    'ktup_reg_orth_fwd': [c_p, c_l, c_p, c_l, c_i, c_p, c_l, c_p, c_p],
+    'ktup_reg_orth_bwd': [c_p, c_l, c_p, c_l, c_i, c_p, c_l, c_p, c_p, c_p, c_p],
+    'ktup_eval_bprmf_scores': [c_p, c_l, c_p, c_l, c_i, c_p, c_l, c_l, c_p, c_l, c_p],
+    'ktup_eval_kg_workspace_bytes': [c_i, c_l],
+    'ktup_eval_transe_scores': [c_p, c_l, c_p, c_l, c_i, c_p, c_l, c_l, c_p, c_p, c_l, c_i, c_i, c_p, c_l, c_p, c_p],
+    'ktup_eval_transh_scores': [c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_p, c_l, c_l, c_p, c_p, c_l, c_i, c_i, c_p, c_l, c_p, c_p],
+    'ktup_eval_transr_workspace_bytes': [c_i, c_l, c_l, c_i],
+    'ktup_eval_transr_scores': [c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_l, c_i, c_p, c_p, c_l, c_i, c_i, c_p, c_l, c_p, c_p],
+    'ktup_eval_pref_workspace_bytes': [c_i, c_i, c_l, c_l],
+    'ktup_eval_pref_scores': [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_p, c_i, c_i, c_p, c_l, c_l, c_i, c_i, c_p, c_u, c_u, c_p, c_l,
+                              c_p, c_p],
+    'ktup_eval_topk_filtered': [c_p, c_l, c_l, c_l, c_i, c_p, c_p, c_i, c_p, c_p, c_p],
+    'ktup_eval_gold_ranks': [c_p, c_l, c_l, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_p],
 }
-_RESTYPE = {'ktup_last_error': ctypes.c_char_p, 'ktup_pref_workspace_bytes': ctypes.c_size_t}
+_RESTYPE = {'ktup_last_error': ctypes.c_char_p, 'ktup_pref_workspace_bytes': ctypes.c_size_t,
+            'ktup_eval_kg_workspace_bytes': ctypes.c_size_t, 'ktup_eval_transr_workspace_bytes': ctypes.c_size_t,
+            'ktup_eval_pref_workspace_bytes': ctypes.c_size_t}
 
 _lib = None
 

@@ -251,3 +251,206 @@ def score_ktup(U, I, E, pref, pref_norm, rel, norm, item2ent, u, i, l1, gumbel_m
                offset=0, ent_pad=-1):
     """jTransUP.py:122-143 (is_rec branch) with paddingItems replaced by the int32 `item2ent` device table."""
     return _ScorePref.apply(U, I, E, pref, pref_norm, rel, norm, item2ent, u, i, l1, gumbel_mode, uniform, seed, offset, ent_pad)
+
+
+# ------------------------------------------------------------------------------------------ K8-K10 losses
+class _PairLoss(Function):
+    @staticmethod
+    def forward(ctx, pos, neg, param, margin):
+        dev = _dev(pos)
+        n = pos.numel()
+        pos = _vec(pos, n); neg = _vec(neg, n)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        L.call('ktup_loss_margin_fwd' if margin else 'ktup_loss_bpr_fwd', _p(pos), _p(neg), n, float(param), _p(loss), _stream(dev))
+        ctx.save_for_backward(pos, neg); ctx.cfg = (float(param), bool(margin))
+        return loss
+
+    @staticmethod
+    def backward(ctx, gloss):
+        pos, neg = ctx.saved_tensors
+        param, margin = ctx.cfg
+        gloss = gloss.contiguous().float()
+        gpos, gneg = torch.empty_like(pos), torch.empty_like(neg)
+        L.call('ktup_loss_margin_bwd' if margin else 'ktup_loss_bpr_bwd', _p(pos), _p(neg), pos.numel(), param, _p(gloss),
+               _p(gpos), _p(gneg), _stream(pos.device))
+        return gpos, gneg, None, None
+
+
+def bpr_loss(pos, neg, target=1.0):
+    """utils/loss.py:29-31 -- a MEAN over the batch."""
+    return _PairLoss.apply(pos, neg, target, False)
+
+
+def margin_loss(pos, neg, margin):
+    """utils/loss.py:8-16 -- a SUM over the batch."""
+    return _PairLoss.apply(pos, neg, margin, True)
+
+
+class _NormLoss(Function):
+    @staticmethod
+    def forward(ctx, T, ids):
+        dev = _dev(_table('embedding table', T))
+        n = T.shape[0] if ids is None else ids.numel()
+        ids = None if ids is None else _ids('ids', ids, dev)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        L.call('ktup_reg_norm_fwd', _p(T), T.stride(0), T.shape[1], _p(ids), n, _p(loss), _stream(dev))
+        ctx.save_for_backward(T, ids); ctx.n = n
+        return loss
+
+    @staticmethod
+    def backward(ctx, gloss):
+        T, ids = ctx.saved_tensors
+        gT = torch.zeros_like(T)
+        gloss = gloss.contiguous().float()
+        L.call('ktup_reg_norm_bwd', _p(T), T.stride(0), T.shape[1], _p(ids), ctx.n, _p(gloss), _p(gT), _stream(T.device))
+        return gT, None
+
+
+class _OrthLoss(Function):
+    @staticmethod
+    def forward(ctx, R, N, ids):
+        dev = _dev(_table('rel table', R)); _table('norm table', N)
+        if R.shape != N.shape:
+            raise L.KtupError('orthogonalLoss: rel and norm tables must have the same shape')
+        n = R.shape[0] if ids is None else ids.numel()
+        ids = None if ids is None else _ids('ids', ids, dev)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        L.call('ktup_reg_orth_fwd', _p(R), R.stride(0), _p(N), N.stride(0), R.shape[1], _p(ids), n, _p(loss), _stream(dev))
+        ctx.save_for_backward(R, N, ids); ctx.n = n
+        return loss
+
+    @staticmethod
+    def backward(ctx, gloss):
+        R, N, ids = ctx.saved_tensors
+        gR, gN = torch.zeros_like(R), torch.zeros_like(N)
+        gloss = gloss.contiguous().float()
+        L.call('ktup_reg_orth_bwd', _p(R), R.stride(0), _p(N), N.stride(0), R.shape[1], _p(ids), ctx.n, _p(gloss), _p(gR), _p(gN),
+               _stream(R.device))
+        return gR, gN, None
+
+
+def norm_loss(table, ids=None):
+    """utils/loss.py:21-23 over rows table[ids] (ids None = every row); the gather is fused."""
+    return _NormLoss.apply(table, ids)
+
+
+def orthogonal_loss(rel, norm, ids=None):
+    """utils/loss.py:18-19 over row pairs (rel[ids], norm[ids])."""
+    return _OrthLoss.apply(rel, norm, ids)
+
+
+# ------------------------------------------------------------------------------------------ K11-K16 evaluation scores
+def _scratch(nbytes, dev):
+    return torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=dev)
+
+
+@torch.no_grad()
+def eval_bprmf(U, I, u):
+    """bprmf.py:51-54 -> (len(u), n_items)."""
+    dev = _dev(_table('user table', U)); _table('item table', I)
+    u = _ids('u_ids', u, dev)
+    out = torch.empty(u.numel(), I.shape[0], dtype=torch.float32, device=dev)
+    L.call('ktup_eval_bprmf_scores', _p(U), U.stride(0), _p(I), I.stride(0), U.shape[1], _p(u), u.numel(), I.shape[0], _p(out),
+           out.stride(0), _stream(dev))
+    return out
+
+
+@torch.no_grad()
+def eval_transe(E, R, q, r, l1, head, candidates=None):
+    """transE.py:65-105 -> (len(q), n_candidates)."""
+    dev = _dev(_table('entity table', E)); _table('relation table', R)
+    C = E if candidates is None else _table('candidate table', candidates)
+    nq = q.numel(); q = _ids('q', q, dev); r = _ids('r', r, dev, nq)
+    out = torch.empty(nq, C.shape[0], dtype=torch.float32, device=dev)
+    ws = _scratch(L.load().ktup_eval_kg_workspace_bytes(E.shape[1], nq), dev)
+    L.call('ktup_eval_transe_scores', _p(E), E.stride(0), _p(R), R.stride(0), E.shape[1], _p(C), C.stride(0), C.shape[0], _p(q),
+           _p(r), nq, int(l1), int(head), _p(out), out.stride(0), _p(ws), _stream(dev))
+    return out
+
+
+@torch.no_grad()
+def eval_transh(E, R, N, q, r, l1, head, candidates=None):
+    """transH.py:73-121 / jTransUP.py:193-247 -> (len(q), n_candidates)."""
+    dev = _dev(_table('entity table', E)); _table('relation table', R); _table('norm table', N)
+    C = E if candidates is None else _table('candidate table', candidates)
+    nq = q.numel(); q = _ids('q', q, dev); r = _ids('r', r, dev, nq)
+    out = torch.empty(nq, C.shape[0], dtype=torch.float32, device=dev)
+    ws = _scratch(L.load().ktup_eval_kg_workspace_bytes(E.shape[1], nq), dev)
+    L.call('ktup_eval_transh_scores', _p(E), E.stride(0), _p(R), R.stride(0), _p(N), N.stride(0), E.shape[1], _p(C), C.stride(0),
+           C.shape[0], _p(q), _p(r), nq, int(l1), int(head), _p(out), out.stride(0), _p(ws), _stream(dev))
+    return out
+
+
+@torch.no_grad()
+def eval_transr(E, R, M, q, r, l1, head):
+    """transR.py:80-128 -> (len(q), n_entities)."""
+    dev = _dev(_table('entity table', E)); _table('relation table', R); _table('projection table', M)
+    nq = q.numel(); q = _ids('q', q, dev); r = _ids('r', r, dev, nq)
+    out = torch.empty(nq, E.shape[0], dtype=torch.float32, device=dev)
+    ws = _scratch(L.load().ktup_eval_transr_workspace_bytes(E.shape[1], nq, E.shape[0], R.shape[0]), dev)
+    L.call('ktup_eval_transr_scores', _p(E), E.stride(0), _p(R), R.stride(0), _p(M), M.stride(0), E.shape[1], E.shape[0], R.shape[0],
+           _p(q), _p(r), nq, int(l1), int(head), _p(out), out.stride(0), _p(ws), _stream(dev))
+    return out
+
+
+@torch.no_grad()
+def _eval_pref(U, I, E, pref, pref_norm, rel, norm, item2ent, u, l1, gumbel_mode, uniform, seed, offset):
+    dev = _dev(_table('user table', U)); _table('item table', I)
+    u = _ids('u_ids', u, dev)
+    nq, ni = u.numel(), I.shape[0]
+    P, d = pref.shape
+    pws = pref_workspace(pref, pref_norm, rel, norm)
+    if gumbel_mode == GUMBEL_INPUT:
+        if uniform is None or tuple(uniform.shape) != (nq, ni, P) or uniform.dtype != torch.float32 or uniform.device != dev:
+            raise L.KtupError('uniform must be an (n_users, n_items, n_pref) fp32 device tensor')
+        uniform = uniform.contiguous()
+    else:
+        uniform = None
+    if E is not None:
+        _table('entity table', E)
+        if item2ent.dtype != torch.int32 or item2ent.device != dev or item2ent.numel() != ni:
+            raise L.KtupError('item2ent must be an int32 device table with one entry per item row')
+    out = torch.empty(nq, ni, dtype=torch.float32, device=dev)
+    ws = _scratch(L.load().ktup_eval_pref_workspace_bytes(d, P, nq, ni), dev)
+    L.call('ktup_eval_pref_scores', _p(U), U.stride(0), _p(I), I.stride(0), _p(E), 0 if E is None else E.stride(0), _p(item2ent),
+           _p(pws), P, d, _p(u), nq, ni, int(l1), int(gumbel_mode), _p(uniform), int(seed), int(offset), _p(out), out.stride(0),
+           _p(ws), _stream(dev))
+    return out
+
+
+def eval_tup(U, I, pref, pref_norm, u, l1, gumbel_mode=GUMBEL_OFF, uniform=None, seed=0, offset=0):
+    """transUP.py:84-102 -> (len(u), n_items)."""
+    return _eval_pref(U, I, None, pref, pref_norm, None, None, None, u, l1, gumbel_mode, uniform, seed, offset)
+
+
+def eval_ktup(U, I, E, pref, pref_norm, rel, norm, item2ent, u, l1, gumbel_mode=GUMBEL_OFF, uniform=None, seed=0, offset=0):
+    """jTransUP.py:163-191 -> (len(u), n_items)."""
+    return _eval_pref(U, I, E, pref, pref_norm, rel, norm, item2ent, u, l1, gumbel_mode, uniform, seed, offset)
+
+
+# ------------------------------------------------------------------------------------------ K17-K18 ranking
+@torch.no_grad()
+def topk_filtered(scores, descending, topn, filt_off=None, filt_ids=None, with_scores=False):
+    """First `topn` unfiltered candidate ids per row (ascending score, ties -> lower id); int32 (nq, topn), -1 padded."""
+    dev = _dev(scores)
+    if scores.dtype != torch.float32 or scores.dim() != 2 or scores.stride(1) != 1:
+        raise L.KtupError('scores must be a 2-D fp32 device matrix with unit inner stride')
+    nq, nc = scores.shape
+    top = torch.empty(nq, topn, dtype=torch.int32, device=dev)
+    ts = torch.empty(nq, topn, dtype=torch.float32, device=dev) if with_scores else None
+    L.call('ktup_eval_topk_filtered', _p(scores), scores.stride(0), nq, nc, int(bool(descending)), _p(filt_off), _p(filt_ids),
+           int(topn), _p(top), _p(ts), _stream(dev))
+    return (top, ts) if with_scores else top
+
+
+@torch.no_grad()
+def gold_ranks(scores, descending, gold_off, gold_ids, filt_off=None, filt_ids=None):
+    """0-based filtered rank of every gold entry (CSR); -1 where the gold id is itself filtered."""
+    dev = _dev(scores)
+    if scores.dtype != torch.float32 or scores.dim() != 2 or scores.stride(1) != 1:
+        raise L.KtupError('scores must be a 2-D fp32 device matrix with unit inner stride')
+    nq, nc = scores.shape
+    ranks = torch.empty(gold_ids.numel(), dtype=torch.int32, device=dev)
+    L.call('ktup_eval_gold_ranks', _p(scores), scores.stride(0), nq, nc, int(bool(descending)), _p(filt_off), _p(filt_ids),
+           _p(gold_off), _p(gold_ids), _p(ranks), _stream(dev))
+    return ranks

@@ -31,3 +31,29 @@ class Accumulator(object):
     def get_avg(self, key, clear=True):
         import numpy as np
         return np.array(self.get(key, clear)).mean()
+
+
+# ---- ranking entry points (utils/misc.py:61-248 of the reference), device-backed: see jTransUP/utils/ranking.py
+def evalRecProcess(*args, **kwargs):
+    from jTransUP.utils.ranking import evalRecProcess as f
+    return f(*args, **kwargs)
+
+
+def evalKGProcess(*args, **kwargs):
+    from jTransUP.utils.ranking import evalKGProcess as f
+    return f(*args, **kwargs)
+
+
+def getRecPerformance(pred, gold, fliter_samples=None, topn=10):
+    """utils/misc.py:213-248 for one (already sign-adjusted, lower = better) score row."""
+    rows = evalRecProcess([(0, pred)], {0: gold}, all_dicts=None if fliter_samples is None else [{0: fliter_samples}],
+                          descending=False, topn=topn)
+    f1, p, r, hit, ndcg, (_, top_ids, _) = rows[0]
+    return f1, p, r, hit, ndcg, top_ids
+
+
+def getKGPerformance(pred, gold, fliter_samples=None, topn=10):
+    """utils/misc.py:125-146 for one (already sign-adjusted) score row."""
+    rows = evalKGProcess([(0, pred)], {0: gold}, all_dicts=None if fliter_samples is None else [{0: fliter_samples}],
+                         descending=False, topn=topn)
+    return [h for h, _, _, _ in rows], [rk for _, rk, _, _ in rows], [g for _, _, _, g in rows]

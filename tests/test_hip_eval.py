@@ -1,0 +1,201 @@
+"""GPU parity of the all-candidate evaluation kernels (K11-K16) and the ranking kernels (K17/K18).
+
+Scores: golden matrices the reference produced + the CPU oracle at sizes it finishes in seconds (incl. ml1m-sized
+catalogues).  Ranked id lists / ranks are integer results and must be bit-exact.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cpu_ref as O
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def dv(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    return t.to(DEV) if dtype is None else t.to(DEV, dtype)
+
+
+def close(got, want, rtol=1e-4, atol=1e-5):
+    got = got.detach().cpu().numpy() if isinstance(got, torch.Tensor) else got
+    want = want.detach().cpu().numpy() if isinstance(want, torch.Tensor) else want
+    np.testing.assert_allclose(got, want, rtol=rtol, atol=atol)
+
+
+def ops():
+    from jTransUP.hip import ops as _ops
+    return _ops
+
+
+def test_eval_matrices_golden(golden):
+    g = golden('eval_small')
+    uq, eq, rq = dv(g['uq']), dv(g['eq']), dv(g['rq'])
+    close(ops().eval_bprmf(dv(g['bprmf.user_embeddings.weight']), dv(g['bprmf.item_embeddings.weight']), uq), g['bprmf.eval'])
+    for l1 in (False, True):
+        L = 'L1' if l1 else 'L2'
+        E, R = dv(g['transe.ent_embeddings.weight']), dv(g['transe.rel_embeddings.weight'])
+        close(ops().eval_transe(E, R, eq, rq, l1, True), g['transe.%s.head' % L])
+        close(ops().eval_transe(E, R, eq, rq, l1, False), g['transe.%s.tail' % L])
+        E, R, N = (dv(g['transh.%s.weight' % k]) for k in ('ent_embeddings', 'rel_embeddings', 'norm_embeddings'))
+        close(ops().eval_transh(E, R, N, eq, rq, l1, True), g['transh.%s.head' % L])
+        close(ops().eval_transh(E, R, N, eq, rq, l1, False), g['transh.%s.tail' % L])
+        E, R, M = (dv(g['transr.%s.weight' % k]) for k in ('ent_embeddings', 'rel_embeddings', 'proj_embeddings'))
+        close(ops().eval_transr(E, R, M, eq, rq, l1, True), g['transr.%s.head' % L], rtol=2e-4, atol=5e-5)
+        close(ops().eval_transr(E, R, M, eq, rq, l1, False), g['transr.%s.tail' % L], rtol=2e-4, atol=5e-5)
+        for gum in (False, True):
+            H = 'hard' if gum else 'soft'
+            mode = ops().GUMBEL_INPUT if gum else ops().GUMBEL_OFF
+            U, I, P, Pn = (dv(g['tup.%s.weight' % k]) for k in ('user_embeddings', 'item_embeddings', 'pref_embeddings', 'pref_norm_embeddings'))
+            uni = dv(g['tup.%s.%s.uni' % (L, H)]) if gum else None
+            close(ops().eval_tup(U, I, P, Pn, uq, l1, mode, uni), g['tup.%s.%s.eval' % (L, H)])
+            K = {k: dv(g['ktup.%s.weight' % k]) for k in ('user_embeddings', 'item_embeddings', 'ent_embeddings', 'pref_embeddings',
+                                                          'pref_norm_embeddings', 'rel_embeddings', 'norm_embeddings')}
+            uni = dv(g['ktup.%s.%s.uni' % (L, H)]) if gum else None
+            got = ops().eval_ktup(K['user_embeddings'], K['item_embeddings'], K['ent_embeddings'], K['pref_embeddings'],
+                                  K['pref_norm_embeddings'], K['rel_embeddings'], K['norm_embeddings'],
+                                  dv(g['ktup.item2ent'], torch.int32), uq, l1, mode, uni)
+            close(got, g['ktup.%s.%s.evalRec' % (L, H)])
+            if not gum:   # pad entity row is a candidate too: (BQ, NE + 1)
+                close(ops().eval_transh(K['ent_embeddings'], K['rel_embeddings'], K['norm_embeddings'], eq, rq, l1, True), g['ktup.%s.soft.evalHead' % L])
+                close(ops().eval_transh(K['ent_embeddings'], K['rel_embeddings'], K['norm_embeddings'], eq, rq, l1, False), g['ktup.%s.soft.evalTail' % L])
+
+
+def world(seed, nu, ni, ne, nr, d):
+    gen = torch.Generator().manual_seed(seed)
+    mk = lambda r: O.make_table(r, d, gen)
+    W = dict(U=mk(nu), I=mk(ni), E=torch.cat([mk(ne), torch.zeros(1, d)]), P=mk(nr), Pn=mk(nr), R=mk(nr), Rn=mk(nr))
+    i2e = torch.randint(0, ne, (ni,), generator=gen)
+    i2e[torch.rand(ni, generator=gen) < 0.1] = ne
+    return W, i2e, gen
+
+
+@pytest.mark.parametrize('d,ni,nq,npref', [(100, 3240, 70, 20), (64, 130, 33, 4), (128, 1000, 5, 13), (100, 63, 1, 20)])
+def test_pref_eval_vs_oracle(d, ni, nq, npref):
+    """TUP / KTUP all-item scores at the ml1m catalogue size (3240 items) and ragged small shapes, soft and hard gate."""
+    W, i2e, gen = world(d + ni, 300, ni, 500, npref, d)
+    u = torch.randint(0, 300, (nq,), generator=gen)
+    D = {k: v.to(DEV) for k, v in W.items()}
+    for l1 in (False, True):
+        for gum in (False, True):
+            uni = torch.rand(nq, ni, npref, generator=gen) if gum else None
+            mode = ops().GUMBEL_INPUT if gum else ops().GUMBEL_OFF
+            ud = uni.to(DEV) if gum else None
+            close(ops().eval_tup(D['U'], D['I'], D['P'], D['Pn'], u.to(DEV), l1, mode, ud), O.eval_tup(W['U'], W['I'], W['P'], W['Pn'], u, l1, uni))
+            close(ops().eval_ktup(D['U'], D['I'], D['E'], D['P'], D['Pn'], D['R'], D['Rn'], i2e.to(DEV, torch.int32), u.to(DEV), l1, mode, ud),
+                  O.eval_ktup_rec(W['U'], W['I'], W['E'], W['P'], W['Pn'], W['R'], W['Rn'], i2e, u, l1, uni))
+
+
+@pytest.mark.parametrize('d,ne,nq', [(100, 14709, 40), (50, 777, 19), (64, 64, 4), (7, 65, 3)])
+def test_kg_eval_vs_oracle(d, ne, nq):
+    """TransE / TransH / TransR all-entity scores incl. the ml1m entity count and d % 4 != 0."""
+    gen = torch.Generator().manual_seed(d * 7 + ne)
+    E, R, N = O.make_table(ne, d, gen), O.make_table(11, d, gen), O.make_table(11, d, gen)
+    M = torch.randn(11, d * d, generator=gen) * 0.1
+    q = torch.randint(0, ne, (nq,), generator=gen); r = torch.randint(0, 11, (nq,), generator=gen)
+    Ed, Rd, Nd, Md = E.to(DEV), R.to(DEV), N.to(DEV), M.to(DEV)
+    for l1 in (False, True):
+        for head in (True, False):
+            close(ops().eval_transe(Ed, Rd, q.to(DEV), r.to(DEV), l1, head), O.eval_transe(E, R, q, r, l1, head))
+            close(ops().eval_transh(Ed, Rd, Nd, q.to(DEV), r.to(DEV), l1, head), O.eval_transh(E, R, N, q, r, l1, head))
+            if ne <= 1000:
+                close(ops().eval_transr(Ed, Rd, Md, q.to(DEV), r.to(DEV), l1, head), O.eval_transr(E, R, M, q, r, l1, head), rtol=2e-4, atol=5e-5)
+
+
+@pytest.mark.parametrize('d,nu,ni,nq', [(64, 6040, 3240, 512), (100, 50, 70, 33), (30, 40, 129, 65)])
+def test_bprmf_eval_mfma_vs_oracle(d, nu, ni, nq):
+    gen = torch.Generator().manual_seed(nq)
+    U, I = O.make_table(nu, d, gen), O.make_table(ni, d, gen)
+    I[3] = I[3] * 4.0      # asymmetric operands: a transposed C/D mapping cannot pass
+    u = torch.randint(0, nu, (nq,), generator=gen)
+    close(ops().eval_bprmf(U.to(DEV), I.to(DEV), u.to(DEV)), O.eval_bprmf(U, I, u), rtol=1e-5, atol=1e-6)
+
+
+def test_module_evaluate_surface():
+    from jTransUP.models import bprmf, jTransUP as jt, transE, transH, transR, transUP
+    torch.manual_seed(1)
+    u = torch.tensor([0, 5, 7], device=DEV)
+    assert bprmf.BPRMF(64, 20, 33).evaluate(u).shape == (3, 33)
+    assert transUP.TransUPModel(True, 100, 20, 33, 5, False).evaluate(u).shape == (3, 33)
+    assert transUP.TransUPModel(True, 100, 20, 33, 5, True).evaluate(u).shape == (3, 33)      # Philox noise
+    r = torch.tensor([0, 1, 2], device=DEV)
+    for cls in (transE.TransEModel, transH.TransHModel, transR.TransRModel):
+        m = cls(False, 20, 41, 3)
+        assert m.evaluateHead(u, r).shape == (3, 41) and m.evaluateTail(u, r).shape == (3, 41)
+    im = {i: i for i in range(33)}
+    nm = {i: ((i if i % 3 else -1), i) for i in range(33)}
+    k = jt.jTransUPModel(False, 100, 20, 33, 41, 3, im, nm, False, False)
+    assert k.evaluateRec(u).shape == (3, 33)
+    assert k.evaluateHead(u, r).shape == (3, 42)          # pad entity is ranked too (jTransUP.py:195-196)
+    # evaluateRec row == forward on the same (u, i) pairs (soft gate)
+    items = torch.arange(33, device=DEV)
+    fw = k((u[1].expand(33).contiguous(), items), None, is_rec=True)
+    close(k.evaluateRec(u)[1], fw.detach())
+
+
+def test_ranking_golden_exact(golden):
+    from jTransUP.utils import ranking as RK
+    g = golden('ranking')
+    J = json.load(open(os.path.join(GOLDEN, 'ranking.json')))
+    nrec = g['rec.rows'].shape[0]
+    for b, c in enumerate(J['rec']):
+        desc = c.get('descending', False)
+        row = g['rec.bprmf_rows'][b - nrec] if desc else g['rec.rows'][b]
+        all_dicts = None if c['filter'] is None else [{7: set(c['filter'])}]
+        out = RK.evalRecProcess([(7, row)], {7: set(c['gold'])}, all_dicts=all_dicts, descending=desc, topn=10)
+        f1, p, r, hit, ndcg, (key, top_ids, gold) = out[0]
+        assert top_ids == c['top_ids']
+        assert hit == c['hit']
+        np.testing.assert_allclose([f1, p, r, ndcg], [c['f1'], c['p'], c['r'], c['ndcg']], rtol=1e-12, atol=0)
+    for b, c in enumerate(J['kg']):
+        out = RK.evalKGProcess([((1, 2), g['kg.rows'][b])], {(1, 2): set(c['gold'])}, all_dicts=[{(1, 2): set(c['filter'])}],
+                               descending=False, topn=10)
+        want = sorted(zip(c['ranks'], c['ids'], c['hits']))
+        assert sorted((rk, gid, h) for h, rk, _, gid in out) == want
+
+
+def test_ranking_batched_vs_oracle_with_ties_and_filters():
+    """A whole batch through RankIndex slices: quantised scores (many exact ties), per-row filters, gold overlapping filter."""
+    from jTransUP.utils import ranking as RK
+    rng = np.random.RandomState(5)
+    nq, nc = 37, 3240
+    scores = (rng.randint(0, 50, size=(nq, nc)) / 7.0).astype(np.float32)
+    scores[3] = 0.0; scores[4, ::2] = -0.0
+    keys = list(range(100, 100 + nq))
+    eval_dict = {k: set(rng.permutation(nc)[:rng.randint(1, 30)].tolist()) for k in keys if k % 5}
+    train = {k: set(rng.permutation(nc)[:rng.randint(0, 400)].tolist()) for k in keys}
+    other = {k: set(rng.permutation(nc)[:5].tolist()) for k in keys[::2]}
+    mat = torch.from_numpy(scores).to(DEV)
+    for desc in (False, True):
+        idx = RK.RankIndex(keys, eval_dict, [train, other], mat.device)
+        got = RK.evalRecProcess((keys[8:30], mat[8:30].contiguous()), eval_dict, [train, other], descending=desc, topn=10, index=idx)
+        want = O.eval_rec_rows(list(zip(keys[8:30], scores[8:30])), eval_dict, [train, other], descending=desc, topn=10)
+        assert len(got) == len(want)
+        for a, b in zip(got, want):
+            assert a[5][1] == b[5][1] and a[5][0] == b[5][0]
+            np.testing.assert_allclose(a[:5], b[:5], rtol=1e-12)
+        gotk = RK.evalKGProcess((keys, mat), eval_dict, [train, other], descending=desc, topn=10, index=idx)
+        wantk = O.eval_kg_rows(list(zip(keys, scores)), eval_dict, [train, other], descending=desc, topn=10)
+        assert sorted(gotk) == sorted((int(h), int(r), k, int(g)) for h, r, k, g in wantk)
+
+
+def test_topk_properties_full_catalogue():
+    """ml1m entity count: output is sorted by (score, id), unfiltered, and is exactly the head of the stable argsort."""
+    rng = np.random.RandomState(1)
+    nq, nc = 64, 14709
+    scores = rng.rand(nq, nc).astype(np.float32)
+    scores[:, 100:200] = scores[:, :100]                       # duplicated scores -> ties across ids
+    f_off = np.arange(0, (nq + 1) * 300, 300, dtype=np.int64)
+    f_ids = np.concatenate([np.sort(rng.permutation(nc)[:300]) for _ in range(nq)]).astype(np.int32)
+    top, ts = ops().topk_filtered(dv(scores), False, 10, dv(f_off), dv(f_ids), with_scores=True)
+    top, ts = top.cpu().numpy(), ts.cpu().numpy()
+    for b in range(nq):
+        filt = set(f_ids[f_off[b]:f_off[b + 1]].tolist())
+        order = [j for j in np.argsort(scores[b], kind='stable') if j not in filt][:10]
+        assert top[b].tolist() == order
+        np.testing.assert_array_equal(ts[b], scores[b][order])

@@ -157,29 +157,24 @@ def score_transr(E, R, M, h, t, r, l1):
 
 
 # ------------------------------------------------------------------------------------------ K5-K7 TUP / KTUP
-_ws_cache = {}
-
-
 def pref_workspace(pref, pref_norm, rel=None, norm=None):
-    """Mixed, pre-scaled preference tables (ktup_pref_prepare), cached per table version."""
+    """Mixed, pre-scaled preference tables (ktup_pref_prepare) for the CURRENT table contents.
+
+    Deliberately not cached across calls: tensor identity / version counters do not see `.data` writes
+    (trainer.loadEmbedding does exactly that) and allocator address reuse makes pointer keys unsafe.  The prepare
+    kernel touches ~24 KB; forward saves the workspace so backward never re-runs it."""
     dev = _dev(_table('pref table', pref)); _table('pref_norm table', pref_norm)
     tabs = [pref, pref_norm] + ([rel, norm] if rel is not None else [])
     for t in tabs:
         _table('preference-side table', t)
         if t.shape != pref.shape or t.stride(0) != pref.stride(0):
             raise L.KtupError('preference / relation tables must share shape and pitch')
-    key = tuple((t.data_ptr(), t._version) for t in tabs) + (torch.cuda.current_stream(dev).cuda_stream,)
-    ws = _ws_cache.get(key)
-    if ws is None:
-        P, d = pref.shape
-        nbytes = L.load().ktup_pref_workspace_bytes(d, P)
-        if nbytes == 0:
-            raise L.KtupError('TUP/KTUP kernels need embedding_size %% 4 == 0 and <= 256 (got %d)' % d)
-        ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
-        L.call('ktup_pref_prepare', _p(pref), _p(pref_norm), _p(rel), _p(norm), pref.stride(0), P, d, _p(ws), _stream(dev))
-        if len(_ws_cache) > 16:
-            _ws_cache.clear()
-        _ws_cache[key] = ws
+    P, d = pref.shape
+    nbytes = L.load().ktup_pref_workspace_bytes(d, P)
+    if nbytes == 0:
+        raise L.KtupError('TUP/KTUP kernels need embedding_size %% 4 == 0 and <= 256 (got %d)' % d)
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
+    L.call('ktup_pref_prepare', _p(pref), _p(pref_norm), _p(rel), _p(norm), pref.stride(0), P, d, _p(ws), _stream(dev))
     return ws
 
 

@@ -17,6 +17,9 @@ OBJ = os.path.join(HERE, 'build')
 LIB = os.path.join(HERE, 'libktup_hip.so')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-munsafe-fp-atomics', '-Wall', '-Wno-unused-function']
+# SLP packs scalar-operand FMAs into v_pk_fma_f32, which needs SGPR operands in aligned pairs (one s_mov per FMA): off
+# for the kernels that feed FMAs from SGPRs.
+PER_FILE_FLAGS = {'ktup_score_pref.hip': ['-fno-slp-vectorize'], 'ktup_eval.hip': ['-fno-slp-vectorize']}
 
 
 def _sources():
@@ -37,7 +40,7 @@ def _stale(target, deps):
 
 def _compile(src, extra):
     obj = os.path.join(OBJ, os.path.basename(src)[:-4] + '.o')
-    cmd = [HIPCC] + FLAGS + extra + ['-c', src, '-o', obj]
+    cmd = [HIPCC] + FLAGS + PER_FILE_FLAGS.get(os.path.basename(src), []) + extra + ['-c', src, '-o', obj]
     r = subprocess.run(cmd, capture_output=True, text=True, cwd=OBJ)
     return src, obj, r.returncode, r.stdout + r.stderr
 

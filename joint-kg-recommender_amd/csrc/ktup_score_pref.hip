@@ -19,31 +19,53 @@
 //            pair's logits against SGPR table values; q re-written to the same LDS tile;
 //   s and the final sum are combined across the NW waves through two tiny LDS arrays.
 // No cross-lane shuffles at all in the P x d contractions; LDS holds one 64 x d tile (25.6 KB at d=100).
+#include <cstdlib>
+
 #include "ktup_pref_geom.h"
 
 using namespace ktup;
 
 namespace {
 
+KTUP_DEV float mixed(const float* __restrict__ a, const float* __restrict__ b, int64_t ld, int row, int k, float scale) {
+  return scale * (a[row * ld + k] + (b ? b[row * ld + k] : 0.f));
+}
+
 __global__ void pref_prepare_kernel(const float* __restrict__ pref, const float* __restrict__ pnorm,
                                     const float* __restrict__ rel, const float* __restrict__ norm, int64_t ld, int P,
-                                    int d, int dp, int ppad, float* __restrict__ ws) {
-  const int total = (ppad + 2 * P) * dp;
+                                    int d, int dp, int ppad, PrefGeom2 g2, int64_t off2, float* __restrict__ ws) {
   const float beta = rel ? 0.5f : 1.0f;
-  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
-    int row = idx / dp;
-    const int k = idx - row * dp;
+  const int total1 = (ppad + 2 * P) * dp;
+  const int nA2 = g2.ppad2 * g2.dpa, nAC2 = P * g2.NW * g2.ev * 16;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total1 + nA2 + nAC2; idx += gridDim.x * blockDim.x) {
     float v = 0.f;
-    if (row < ppad) {  // logit table: (pref + rel) / 2  (transUP.py:108, jTransUP.py:253); /2 is exact
-      if (row < P && k < d) v = 0.5f * (pref[row * ld + k] + (rel ? rel[row * ld + k] : 0.f));
-    } else if (row < ppad + P) {
-      row -= ppad;
-      if (k < d) v = beta * (pref[row * ld + k] + (rel ? rel[row * ld + k] : 0.f));
+    if (idx < total1) {
+      int row = idx / dp;
+      const int k = idx - row * dp;
+      if (row < ppad) {  // logit table: (pref + rel) / 2  (transUP.py:108, jTransUP.py:253); the /2 is exact
+        if (row < P && k < d) v = mixed(pref, rel, ld, row, k, 0.5f);
+      } else if (row < ppad + P) {
+        if (k < d) v = mixed(pref, rel, ld, row - ppad, k, beta);
+      } else {
+        if (k < d) v = mixed(pnorm, norm, ld, row - ppad - P, k, beta);
+      }
+      ws[idx] = v;
+    } else if (idx < total1 + nA2) {
+      const int i2 = idx - total1, row = i2 / g2.dpa, k = i2 - row * g2.dpa;
+      if (row < P && k < d) v = mixed(pref, rel, ld, row, k, 0.5f);
+      ws[off2 + i2] = v;
     } else {
-      row -= ppad + P;
-      if (k < d) v = beta * (pnorm[row * ld + k] + (norm ? norm[row * ld + k] : 0.f));
+      const int i3 = idx - total1 - nA2;
+      const int entry = i3 / (g2.ev * 16), within = i3 - entry * (g2.ev * 16);
+      const int p = entry / g2.NW, w = entry - p * g2.NW;
+      const int q4 = within / 4, e = within & 3;            // float4 index inside the entry, element
+      if (q4 < 2 * g2.CH) {
+        const int j = q4 < g2.CH ? q4 : q4 - g2.CH;
+        const int k = 4 * (w + g2.NW * j) + e;
+        if (k < d) v = q4 < g2.CH ? mixed(pref, rel, ld, p, k, beta) : mixed(pnorm, norm, ld, p, k, beta);
+      }
+      ws[off2 + nA2 + i3] = v;
     }
-    ws[idx] = v;
   }
 }
 
@@ -52,6 +74,8 @@ struct PrefArgs {
   int64_t ldu4, ldi4, lde4;     // pitches in float4
   const int32_t* item2ent;      // null for TUP
   const float4 *Alog, *Ar, *Cn; // prepared tables, pitch dp4
+  const float *Alog2, *AC2;     // 64-byte-vector layouts for pref_fwd2 (ktup_pref_geom.h)
+  int dpa16, ppad2;             // Alog2 row pitch in 64-byte vectors, rows
   int P, ppad, lp, nch, dp4;  // lp = LDS pitch of the per-pair logit rows (odd: conflict-free b32)
   const int64_t *u_ids, *i_ids;
   int64_t n;
@@ -459,6 +483,216 @@ __global__ __launch_bounds__(NW * 64) void pref_bwd_kernel(PrefArgs a) {
   }
 }
 
+
+// =============================================================================================================
+// pref_fwd2: the tuned forward.  Same math and mapping as pref_fwd_kernel; what changes is how the wave-uniform table
+// values reach the SGPRs and how much bookkeeping surrounds each FMA (rocprof on v1: 56 M SALU + 18 M SMEM
+// wave-instructions next to 79 M VALU, waves parked in s_waitcnt 48 % of their cycles):
+//   * tables are pre-laid-out by ktup_pref_prepare so that what a wave needs for one step is contiguous and aligned:
+//     stage 1 uses one s_load_dwordx8 per preference per 2 chunks, stage 2 three s_load_dwordx16 per preference
+//     (v1: one s_load_dwordx4 plus 4 SALU address ops per 4 FMAs);
+//   * geometry fits d exactly (d=100: 5 waves x 5 chunks = 25 chunks, 20 preferences = 5 waves x 4): no padded FMAs;
+//   * the gate mode is a template parameter (the soft kernel carries no Gumbel / Philox code or registers);
+//   * the next tile's ids (and the dependent item->entity lookup) are prefetched under the current tile's compute;
+//   * this file is built with -fno-slp-vectorize: SLP turns the scalar-operand FMAs into v_pk_fma_f32, which needs its
+//     SGPR operands in aligned pairs and costs one s_mov per FMA to build them (v_pk_fma is not faster than 2 v_fmac).
+typedef float v8f __attribute__((ext_vector_type(8)));
+typedef const __attribute__((address_space(4))) v8f* sptr8;
+
+template <int NW, int CH, bool HARD>
+__global__ __launch_bounds__(NW * 64) void pref_fwd2_kernel(PrefArgs a) {
+  constexpr int NT = NW * 64, EV = (2 * CH + 3) / 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int nch = a.nch, lp = a.ppad2 | 1;
+  float4* tile = reinterpret_cast<float4*>(smem);                       // [TR * nch] + 4 zero chunks of slack
+  float* logit = reinterpret_cast<float*>(tile + TR * nch + 4);         // [TR * lp]
+  float* red_s = logit + TR * lp;                                       // [NW * TR]
+  float* red_z = red_s + NW * TR;                                       // [NW * TR]
+  int32_t* sid = reinterpret_cast<int32_t*>(red_z + NW * TR);           // [2][3][TR] double-buffered row ids
+  const int t = threadIdx.x, lane = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const bool l1 = a.l1 != 0;
+  const int64_t ntiles = (a.n + TR - 1) / TR;
+  const int total = TR * nch;
+  const int qstep = NT / nch, rstep = NT - qstep * nch;
+  const int nv2 = (nch + 1) / 2;  // stage-1 steps of 2 chunks (the table is zero padded past nch)
+
+  if (t < 4) tile[total + t] = f4zero();
+  if (t < TR) {  // ids of the first tile
+    const int64_t gr = (int64_t)blockIdx.x * TR + t;
+    const bool ok = gr < a.n;
+    const int64_t uid = ok ? a.u_ids[gr] : 0, iid = ok ? a.i_ids[gr] : 0;
+    sid[t] = (int32_t)uid;
+    sid[TR + t] = (int32_t)iid;
+    sid[2 * TR + t] = a.E ? a.item2ent[iid] : 0;
+  }
+  __syncthreads();
+
+  int it = 0;
+  for (int64_t tile_id = blockIdx.x; tile_id < ntiles; tile_id += gridDim.x, ++it) {
+    const int64_t row0 = tile_id * TR;
+    const int32_t* cur = sid + (it & 1) * 3 * TR;
+    int32_t* nxt = sid + ((it & 1) ^ 1) * 3 * TR;
+    // ---- gather (linear mapping) -- row loads first, the id prefetch queues behind them
+    float4 uu[CH], vv[CH];
+    int32_t pre_u = 0, pre_i = 0, pre_e = 0;
+    const bool pre = t < TR && tile_id + gridDim.x < ntiles;
+    {
+      float4 ee[CH];
+      int v = t, row = t / nch, c = t - (t / nch) * nch;
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        if (v < total) {
+          uu[j] = a.U[(int64_t)cur[row] * a.ldu4 + c];
+          vv[j] = a.I[(int64_t)cur[TR + row] * a.ldi4 + c];
+          ee[j] = a.E ? a.E[(int64_t)cur[2 * TR + row] * a.lde4 + c] : f4zero();
+        } else {
+          uu[j] = f4zero(); vv[j] = f4zero(); ee[j] = f4zero();
+        }
+        v += NT; row += qstep; c += rstep;
+        if (c >= nch) { c -= nch; ++row; }
+      }
+      const int64_t ngr = (tile_id + gridDim.x) * TR + t;
+      int64_t nuid = 0, niid = 0;
+      if (pre && ngr < a.n) { nuid = a.u_ids[ngr]; niid = a.i_ids[ngr]; }
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        vv[j] = vv[j] + ee[j];
+        const int vj = t + NT * j;
+        if (vj < total) tile[vj] = uu[j] + vv[j];
+      }
+      pre_u = (int32_t)nuid; pre_i = (int32_t)niid;
+      if (pre && a.E) pre_e = a.item2ent[niid];   // dependent lookup: consumed only after stage 1
+    }
+    __syncthreads();
+    // ---- stage 1: lane = pair, wave = 4 preferences; per step 2 chunks of x against one 32-byte scalar load per preference
+    {
+      const float4* xrow = tile + lane * nch;
+      for (int pbase = w * PB2; pbase < a.ppad2; pbase += NW * PB2) {
+        const sptr8 A0 = (sptr8)(uintptr_t)(a.Alog2 + (size_t)pbase * a.dpa16 * 16);
+        const int pitch8 = a.dpa16 * 2;
+        float acc[PB2];
+#pragma unroll
+        for (int pp = 0; pp < PB2; ++pp) acc[pp] = 0.f;
+        for (int v = 0; v < nv2; ++v) {
+          v8f A[PB2];
+#pragma unroll
+          for (int pp = 0; pp < PB2; ++pp) A[pp] = A0[pp * pitch8 + v];
+          const float4 x0 = xrow[2 * v], x1 = xrow[2 * v + 1];  // a chunk past the row end meets zero table entries
+#pragma unroll
+          for (int pp = 0; pp < PB2; ++pp) {
+            acc[pp] = fmaf(x0.x, A[pp][0], acc[pp]); acc[pp] = fmaf(x0.y, A[pp][1], acc[pp]);
+            acc[pp] = fmaf(x0.z, A[pp][2], acc[pp]); acc[pp] = fmaf(x0.w, A[pp][3], acc[pp]);
+            acc[pp] = fmaf(x1.x, A[pp][4], acc[pp]); acc[pp] = fmaf(x1.y, A[pp][5], acc[pp]);
+            acc[pp] = fmaf(x1.z, A[pp][6], acc[pp]); acc[pp] = fmaf(x1.w, A[pp][7], acc[pp]);
+          }
+        }
+#pragma unroll
+        for (int pp = 0; pp < PB2; ++pp) logit[lane * lp + pbase + pp] = acc[pp];
+        if (HARD) {
+          const int64_t grow = min(row0 + lane, a.n - 1);
+#pragma unroll 1
+          for (int pp = 0; pp < PB2; ++pp) {
+            const int p = pbase + pp;
+            float* slot = logit + lane * lp + p;
+            *slot = p < a.P ? *slot + gumbel_from_uniform(draw_uniform(a, grow, p)) : -INFINITY;
+          }
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      const int vj = t + NT * j;
+      if (vj < total) tile[vj] = uu[j] - vv[j];  // q = u - ie
+    }
+    if (pre) { nxt[t] = pre_u; nxt[TR + t] = pre_i; nxt[2 * TR + t] = pre_e; }
+    __syncthreads();
+    // ---- stage 2: lane = pair, wave = chunks w, w + NW, ...
+    float4 r[CH], nn[CH];
+    if (!HARD) {
+#pragma unroll
+      for (int j = 0; j < CH; ++j) { r[j] = f4zero(); nn[j] = f4zero(); }
+      sptr16 ac = as_scalar16(a.AC2) + w * EV;
+      const float* lrow = logit + lane * lp;
+      for (int p = 0; p < a.P; ++p, ac += NW * EV) {
+        v16f V[EV];
+#pragma unroll
+        for (int e = 0; e < EV; ++e) V[e] = ac[e];
+        const float wg = lrow[p];
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+          constexpr int dummy = 0; (void)dummy;
+          const int qa = j, qc = CH + j;
+          r[j].x = fmaf(wg, V[qa / 4][(qa % 4) * 4 + 0], r[j].x); r[j].y = fmaf(wg, V[qa / 4][(qa % 4) * 4 + 1], r[j].y);
+          r[j].z = fmaf(wg, V[qa / 4][(qa % 4) * 4 + 2], r[j].z); r[j].w = fmaf(wg, V[qa / 4][(qa % 4) * 4 + 3], r[j].w);
+          nn[j].x = fmaf(wg, V[qc / 4][(qc % 4) * 4 + 0], nn[j].x); nn[j].y = fmaf(wg, V[qc / 4][(qc % 4) * 4 + 1], nn[j].y);
+          nn[j].z = fmaf(wg, V[qc / 4][(qc % 4) * 4 + 2], nn[j].z); nn[j].w = fmaf(wg, V[qc / 4][(qc % 4) * 4 + 3], nn[j].w);
+        }
+      }
+    } else {
+      const int ps = row_argmax(logit + lane * lp, a.P);
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        const int c = w + NW * j;
+        r[j] = c < nch ? a.Ar[ps * a.dp4 + c] : f4zero();
+        nn[j] = c < nch ? a.Cn[ps * a.dp4 + c] : f4zero();
+      }
+    }
+    float4 q[CH];
+    float sp = 0.f;
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      const int c = w + NW * j;
+      q[j] = c < nch ? tile[lane * nch + c] : f4zero();
+      sp += dot4(q[j], nn[j]);
+    }
+    red_s[w * TR + lane] = sp;
+    __syncthreads();
+    float sfull = 0.f;
+#pragma unroll
+    for (int k = 0; k < NW; ++k) sfull += red_s[k * TR + lane];
+    float zp = 0.f;
+#pragma unroll
+    for (int j = 0; j < CH; ++j) zp += dist4(fma4(-sfull, nn[j], q[j] + r[j]), l1);
+    red_z[w * TR + lane] = zp;
+    __syncthreads();
+    if (w == 0 && row0 + lane < a.n) {
+      float tot = 0.f;
+#pragma unroll
+      for (int k = 0; k < NW; ++k) tot += red_z[k * TR + lane];
+      a.score[row0 + lane] = tot;
+    }
+  }
+}
+
+template <int NW, int CH>
+int launch_pref2(const PrefArgs& a, hipStream_t st, const char* name) {
+  const int lp = a.ppad2 | 1;
+  const size_t lds = ((size_t)TR * a.nch + 4) * 16 + (size_t)TR * lp * 4 + 2 * (size_t)NW * TR * 4 + 2 * 3 * (size_t)TR * 4;
+  if (lds > 160 * 1024) return set_error(KTUP_ERR_UNSUPPORTED, "%s: tile needs %zu B of LDS", name, lds);
+  const bool hard = a.gumbel != KTUP_GUMBEL_OFF;
+  const void* fn = hard ? (const void*)pref_fwd2_kernel<NW, CH, true> : (const void*)pref_fwd2_kernel<NW, CH, false>;
+  if (lds > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const int64_t ntiles = (a.n + TR - 1) / TR;
+  // persistent grid = what is actually resident (a queued extra workgroup per CU would run its whole tile loop late)
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, NW * 64, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+  if (const char* env = getenv("KTUP_PREF_WGS_PER_CU")) per_cu = atoi(env) > 0 ? atoi(env) : per_cu;
+  const int grid = grid_for(ntiles, 256 * per_cu);
+  if (hard) hipLaunchKernelGGL((pref_fwd2_kernel<NW, CH, true>), dim3(grid), dim3(NW * 64), lds, st, a);
+  else hipLaunchKernelGGL((pref_fwd2_kernel<NW, CH, false>), dim3(grid), dim3(NW * 64), lds, st, a);
+  return check_launch(name);
+}
+
+int dispatch_fwd2(const PrefArgs& a, int d, int n_pref, hipStream_t st, const char* name) {
+  const PrefGeom2 g = pref_geom2(d, n_pref);
+#define KTUP_F2(NW_, CH_) if (g.NW == NW_ && g.CH == CH_) return launch_pref2<NW_, CH_>(a, st, name);
+  KTUP_F2(4, 4) KTUP_F2(5, 4) KTUP_F2(5, 5) KTUP_F2(8, 4) KTUP_F2(8, 5)
+#undef KTUP_F2
+  return launch_pref2<8, 8>(a, st, name);
+}
+
 template <int CH, int NW>
 int launch_pref(bool bwd, const PrefArgs& a, hipStream_t st, const char* name) {
   const int64_t ntiles = (a.n + TR - 1) / TR;
@@ -503,6 +737,10 @@ int run_pref(bool bwd, const char* name, const float* U, int64_t ldu, const floa
   a.Ar = reinterpret_cast<const float4*>(base + (size_t)g.ppad * g.dp);
   a.Cn = reinterpret_cast<const float4*>(base + (size_t)(g.ppad + n_pref) * g.dp);
   a.P = n_pref; a.ppad = g.ppad; a.lp = g.ppad | 1; a.nch = d / 4; a.dp4 = g.dp / 4;
+  const PrefGeom2 g2 = pref_geom2(d, n_pref);
+  a.Alog2 = base + ws1_floats(g, n_pref);
+  a.AC2 = a.Alog2 + (size_t)g2.ppad2 * g2.dpa;
+  a.dpa16 = g2.dpa / 16; a.ppad2 = g2.ppad2;
   a.u_ids = u_ids; a.i_ids = i_ids; a.n = n; a.l1 = l1; a.gumbel = gumbel_mode; a.uniform = uniform;
   a.seed = seed; a.offset = offset; a.score = score;
   a.gscore = gscore; a.gU = gU; a.gI = gI; a.gE = gE; a.gA = gA; a.gC = gC; a.ent_pad = ent_pad;
@@ -517,6 +755,11 @@ int run_pref(bool bwd, const char* name, const float* U, int64_t ldu, const floa
     KTUP_REQUIRE(score, "%s: null score pointer", name);
   }
   hipStream_t st = (hipStream_t)stream;
+  if (!bwd) {  // KTUP_PREF_FWD selects the forward variant (A/B measurements); default = tuned kernel, one pair per lane
+    const char* env = getenv("KTUP_PREF_FWD");
+    const int variant = env ? atoi(env) : 1;
+    if (variant != 0) return dispatch_fwd2(a, d, n_pref, st, name);
+  }
   if (g.CH == 4 && g.NW == 4) return launch_pref<4, 4>(bwd, a, st, name);
   if (g.CH == 7 && g.NW == 4) return launch_pref<7, 4>(bwd, a, st, name);
   if (g.CH == 8 && g.NW == 4) return launch_pref<8, 4>(bwd, a, st, name);
@@ -527,7 +770,7 @@ int run_pref(bool bwd, const char* name, const float* U, int64_t ldu, const floa
 
 extern "C" size_t ktup_pref_workspace_bytes(int d, int n_pref) {
   const PrefGeom g = pref_geom(d, n_pref);
-  return g.ok ? ws_floats(g, n_pref) * sizeof(float) : 0;
+  return g.ok ? ws_floats(g, d, n_pref) * sizeof(float) : 0;
 }
 
 extern "C" int ktup_pref_prepare(const float* pref, const float* pref_norm, const float* rel, const float* norm, int64_t ld,
@@ -538,9 +781,10 @@ extern "C" int ktup_pref_prepare(const float* pref, const float* pref_norm, cons
   KTUP_REQUIRE(pref && pref_norm && ws, "ktup_pref_prepare: null pointer argument");
   KTUP_REQUIRE((rel == nullptr) == (norm == nullptr), "ktup_pref_prepare: rel and norm must be given together");
   KTUP_REQUIRE(ld >= d, "ktup_pref_prepare: pitch %lld < d", (long long)ld);
-  const int total = (int)ws_floats(g, n_pref);
+  KTUP_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 63u) == 0, "ktup_pref_prepare: workspace must be 64-byte aligned");
+  const int total = (int)ws_floats(g, d, n_pref);
   hipLaunchKernelGGL(pref_prepare_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, pref, pref_norm, rel,
-                     norm, ld, n_pref, d, g.dp, g.ppad, ws);
+                     norm, ld, n_pref, d, g.dp, g.ppad, pref_geom2(d, n_pref), (int64_t)ws1_floats(g, n_pref), ws);
   return check_launch("ktup_pref_prepare");
 }
 

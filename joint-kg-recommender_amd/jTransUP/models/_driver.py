@@ -1,0 +1,155 @@
+"""Shared plumbing of the three task drivers: logging, the periodic-evaluation training loop, and the
+evaluation passes (device scores -> device ranking -> host metric means).
+
+What differs from the reference's loops (jTransUP/models/{item_recommendation,knowledge_representation,
+knowledgable_recommendation}.py) is mechanical only: losses stay on the device and are read back once per
+evaluation interval (the reference syncs with `losses.data[0]` every step), index tensors are created directly on the
+device, ranking runs on the device, and 0.3-era APIs (`Variable`, `clip_grad_norm`) are the modern equivalents."""
+import json
+import logging
+import os
+
+import numpy as np
+import torch
+import torch.nn as nn
+from tqdm import tqdm
+
+from jTransUP.utils.misc import USE_CUDA
+from jTransUP.utils.ranking import RankIndex, evalKGProcess, evalRecProcess
+
+DEV = torch.device('cuda') if USE_CUDA else torch.device('cpu')
+
+
+def ids(values):
+    return torch.tensor(values, dtype=torch.long, device=DEV)
+
+
+def setup_logger(FLAGS):
+    os.makedirs(FLAGS.log_path, exist_ok=True)
+    logger = logging.getLogger()
+    logger.setLevel(logging.DEBUG if FLAGS.log_level == 'debug' else logging.INFO)
+    fmt = logging.Formatter('%(asctime)s - %(name)s - %(levelname)s - %(message)s')
+    for h in (logging.FileHandler(os.path.join(FLAGS.log_path, FLAGS.experiment_name + '.log')), logging.StreamHandler()):
+        h.setFormatter(fmt)
+        logger.addHandler(h)
+    logger.info('Flag Values:\n' + json.dumps(FLAGS.FlagValuesDict(), indent=4, sort_keys=True))
+    return logger
+
+
+def make_visualizer(FLAGS):
+    if not FLAGS.has_visualization:
+        return None
+    from jTransUP.utils.visuliazer import Visualizer
+    vis = Visualizer(env=FLAGS.experiment_name, port=FLAGS.visualization_port)
+    vis.log(json.dumps(FLAGS.FlagValuesDict(), indent=4, sort_keys=True), win_name='Parameter')
+    return vis
+
+
+def flat_keys(eval_iter):
+    return [k if not isinstance(k, list) else tuple(k) for batch in eval_iter for k in batch]
+
+
+def rec_eval_pass(FLAGS, score_fn, eval_iter, eval_dict, all_dicts, descending):
+    """One pass over the evaluation users: all-item scores, filtered top-n, metric rows (misc.py:148-248 semantics)."""
+    index = RankIndex(flat_keys(eval_iter), eval_dict, all_dicts, DEV)
+    results = []
+    pbar = tqdm(total=len(eval_iter), desc='Run Eval')
+    for u_ids in eval_iter:
+        scores = score_fn(ids(u_ids))
+        results.extend(evalRecProcess((u_ids, scores), eval_dict, all_dicts=all_dicts, descending=descending, topn=FLAGS.topn,
+                                      index=index))
+        pbar.update(1)
+    pbar.close()
+    return results
+
+
+def kg_eval_pass(FLAGS, score_fn, eval_iter, eval_dict, all_dicts, descending, remap=None):
+    """One pass over (t, r) or (h, r) keys: all-entity scores, filtered gold ranks (misc.py:61-146 semantics)."""
+    index = RankIndex(flat_keys(eval_iter), eval_dict, all_dicts, DEV)
+    results = []
+    pbar = tqdm(total=len(eval_iter), desc='Run Eval')
+    for batch in eval_iter:
+        q = [k[0] if remap is None else remap[k[0]] for k in batch]
+        r = [k[1] for k in batch]
+        scores = score_fn(ids(q), ids(r))
+        keys = [tuple(k) for k in batch]
+        results.extend(evalKGProcess((keys, scores), eval_dict, all_dicts=all_dicts, descending=descending, topn=FLAGS.topn,
+                                     index=index))
+        pbar.update(1)
+    pbar.close()
+    return results
+
+
+def summarize_rec(FLAGS, results, logger):
+    f1, p, r, hit, ndcg = np.array([row[:5] for row in results]).mean(axis=0)
+    logger.info('f1:{:.4f}, p:{:.4f}, r:{:.4f}, hit:{:.4f}, ndcg:{:.4f}, topn:{}.'.format(f1, p, r, hit, ndcg, FLAGS.topn))
+    return f1, p, r, hit, ndcg
+
+
+def summarize_kg(FLAGS, head_results, tail_results, logger):
+    head_hit, head_rank = np.array([row[:2] for row in head_results]).mean(axis=0)
+    tail_hit, tail_rank = np.array([row[:2] for row in tail_results]).mean(axis=0)
+    logger.info('head hit:{:.4f}, head mean rank:{:.4f}, topn:{}.'.format(head_hit, head_rank, FLAGS.topn))
+    logger.info('tail hit:{:.4f}, tail mean rank:{:.4f}, topn:{}.'.format(tail_hit, tail_rank, FLAGS.topn))
+    hn, tn = len(head_results), len(tail_results)
+    avg_hit = float(head_hit * hn + tail_hit * tn) / (hn + tn)
+    avg_rank = float(head_rank * hn + tail_rank * tn) / (hn + tn)
+    logger.info('avg hit:{:.4f}, avg mean rank:{:.4f}, topn:{}.'.format(avg_hit, avg_rank, FLAGS.topn))
+    return avg_hit, avg_rank
+
+
+def report_kg(head_results, tail_results, logger):
+    for hit, _, (t, r), gold_h in head_results:
+        logger.info('H\t{}\t{}\t{}\t{}'.format(gold_h, t, r, hit))
+    for hit, _, (h, r), gold_t in tail_results:
+        logger.info('T\t{}\t{}\t{}\t{}'.format(h, gold_t, r, hit))
+
+
+def report_rec(FLAGS, model, results, all_dicts, eval_dict, logger, with_preferences):
+    """item_recommendation.py:55-73: per-user gold / top lists, with the induced preference of every gold item."""
+    for row in results:
+        u_id, top_ids, gold = row[-1]
+        gold_ids = list(gold)
+        if with_preferences:
+            for d in all_dicts or []:
+                gold_ids += list(d.get(u_id, set()))
+            gold_ids += list(eval_dict.get(u_id, set()))
+            probs, _, _ = model.reportPreference(ids([u_id]), ids(gold_ids))
+            best = torch.max(probs, 1)[1].tolist()
+            gold_strs = ','.join('{}({})'.format(i, p) for i, p in zip(gold_ids, best))
+        else:
+            gold_strs = ','.join(str(i) for i in gold_ids)
+        logger.info('user:{}\tgold:{}\ttop:{}'.format(u_id, gold_strs, ','.join(str(i) for i in top_ids)))
+
+
+def clip_and_step(FLAGS, model, trainer):
+    """Global-norm clip over ALL tables, then the dense optimizer step (e.g. item_recommendation.py:189-192)."""
+    nn.utils.clip_grad_norm_([p for _, p in model.named_parameters()], FLAGS.clipping_max_value)
+    trainer.optimizer_step()
+
+
+def training_loop(FLAGS, model, trainer, logger, do_step, do_eval, loss_names, on_train_mode=None):
+    """The reference's loop skeleton: early stopping, evaluation every eval_interval_steps (including step 0, where
+    only the metrics are logged), otherwise one optimisation step.  `do_step(step)` returns (name, loss_tensor);
+    `do_eval(mean_losses)` returns the performance list whose first entry drives checkpointing / LR decay."""
+    pbar = None
+    sums = {k: torch.zeros((), device=DEV) for k in loss_names}
+    model.train(); model.enable_grad()
+    for _ in range(trainer.step, FLAGS.training_steps):
+        if FLAGS.early_stopping_steps_to_wait > 0 and (trainer.step - trainer.best_step) > FLAGS.early_stopping_steps_to_wait:
+            logger.info('No improvement after ' + str(FLAGS.early_stopping_steps_to_wait) + ' steps. Stopping training.')
+            break
+        if trainer.step % FLAGS.eval_interval_steps == 0:
+            if pbar is not None:
+                pbar.close()
+            totals = {k: float(v.item()) for k, v in sums.items()}      # the only loss read-back
+            do_eval(totals)
+            pbar = tqdm(total=FLAGS.eval_interval_steps, desc='Training')
+            for v in sums.values():
+                v.zero_()
+            model.train(); model.enable_grad()
+        name, loss = do_step(trainer.step)
+        sums[name] += loss.detach()
+        pbar.update(1)
+    if pbar is not None:
+        pbar.close()

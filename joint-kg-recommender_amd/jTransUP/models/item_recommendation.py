@@ -1,0 +1,102 @@
+"""Item-recommendation task driver (BPRMF / TUP) with the reference's entry points
+(jTransUP/models/item_recommendation.py: evaluate :27-75, train_loop :77-194, run :196-273)."""
+import math
+import os
+import random
+
+import torch
+
+from jTransUP.data.load_rating_data import load_data
+from jTransUP.models import _driver as D
+from jTransUP.models.base import flag_defaults, get_flags, init_model
+from jTransUP.utils import flags as gflags
+from jTransUP.utils.data import getNegRatings
+from jTransUP.utils.loss import bprLoss, normLoss, orthogonalLoss
+from jTransUP.utils.trainer import ModelTrainer
+
+FLAGS = gflags.FLAGS
+
+
+def evaluate(FLAGS, model, eval_iter, eval_dict, all_dicts, logger, eval_descending=True, is_report=False):
+    model.eval(); model.disable_grad()
+    results = D.rec_eval_pass(FLAGS, model.evaluate, eval_iter, eval_dict, all_dicts, eval_descending)
+    perf = D.summarize_rec(FLAGS, results, logger)
+    if is_report:
+        D.report_rec(FLAGS, model, results, all_dicts, eval_dict, logger, FLAGS.model_type in ('transup', 'jtransup', 'cjtransup'))
+    model.enable_grad()
+    return perf
+
+
+def train_loop(FLAGS, model, trainer, train_dataset, eval_datasets, user_total, item_total, logger, vis=None, is_report=False):
+    train_iter, train_total, train_list, train_dict = train_dataset
+    all_dicts = [train_dict] + [d[3] for d in eval_datasets] if FLAGS.filter_wrong_corrupted else None
+    logger.info('Training.')
+
+    def do_eval(totals):
+        logger.info('train loss:{:.4f}!'.format(totals['rec'] / FLAGS.eval_interval_steps))
+        perfs = []
+        for i, ed in enumerate(eval_datasets):
+            others = [train_dict] + [d[3] for j, d in enumerate(eval_datasets) if j != i] if FLAGS.filter_wrong_corrupted else None
+            perfs.append(evaluate(FLAGS, model, ed[0], ed[3], others, logger, eval_descending=trainer.model_target == 1,
+                                  is_report=is_report))
+        if trainer.step > 0 and perfs:
+            trainer.new_performance(perfs[0], perfs)
+            if vis is not None:
+                vis.plot_many_stack({'Rec Train Loss': totals['rec'] / FLAGS.eval_interval_steps}, win_name='Loss Curve')
+                for name, col in (('F1', 0), ('Precision', 1), ('Recall', 2), ('Hit Ratio', 3), ('NDCG', 4)):
+                    vis.plot_many_stack({'Rec Eval {} {}'.format(i, name): p[col] for i, p in enumerate(perfs)},
+                                        win_name='Rec {}@{}'.format(name, FLAGS.topn))
+        return perfs
+
+    def do_step(step):
+        u, pi, ni = getNegRatings(next(train_iter), item_total, all_dicts=all_dicts)
+        u_var, pi_var, ni_var = D.ids(u), D.ids(pi), D.ids(ni)
+        trainer.optimizer_zero_grad()
+        pos_score, neg_score = model(u_var, pi_var), model(u_var, ni_var)
+        losses = bprLoss(pos_score, neg_score, target=trainer.model_target)
+        if FLAGS.model_type in ('transup', 'transupb'):       # item_recommendation.py:177-180, gathers fused
+            losses = losses + orthogonalLoss(model.pref_embeddings.weight, model.pref_norm_embeddings.weight) \
+                + normLoss(model.user_embeddings.weight, ids=u_var) \
+                + normLoss(model.item_embeddings.weight, ids=torch.cat([pi_var, ni_var])) \
+                + normLoss(model.pref_embeddings.weight)
+        losses.backward()
+        D.clip_and_step(FLAGS, model, trainer)
+        return 'rec', losses
+
+    D.training_loop(FLAGS, model, trainer, logger, do_step, do_eval, ['rec'])
+
+
+def run(only_forward=False):
+    if FLAGS.seed != 0:
+        random.seed(FLAGS.seed)
+        torch.manual_seed(FLAGS.seed)
+    vis = D.make_visualizer(FLAGS)
+    logger = D.setup_logger(FLAGS)
+    dataset_path = os.path.join(FLAGS.data_path, FLAGS.dataset)
+    train_dataset, eval_datasets, u_map, i_map = load_data(dataset_path, FLAGS.rec_test_files.split(':'), FLAGS.batch_size,
+                                                           logger=logger, negtive_samples=FLAGS.negtive_samples)
+    train_iter, train_total, train_list, train_dict = train_dataset
+    user_total = max(len(u_map), max(u_map.values()))
+    item_total = max(len(i_map), max(i_map.values()))
+    model = init_model(FLAGS, user_total, item_total, 0, 0, logger)
+    trainer = ModelTrainer(model, logger, math.ceil(train_total / FLAGS.batch_size), FLAGS)
+    if FLAGS.load_ckpt_file is not None:
+        trainer.loadEmbedding(os.path.join(FLAGS.log_path, FLAGS.load_ckpt_file), model.state_dict(), cpu=not D.USE_CUDA)
+        model.is_pretrained = True
+    if only_forward:
+        for i, ed in enumerate(eval_datasets):
+            others = [train_dict] + [d[3] for j, d in enumerate(eval_datasets) if j != i] if FLAGS.filter_wrong_corrupted else None
+            evaluate(FLAGS, model, ed[0], ed[3], others, logger, eval_descending=trainer.model_target == 1,
+                     is_report=FLAGS.is_report)
+    else:
+        train_loop(FLAGS, model, trainer, train_dataset, eval_datasets, user_total, item_total, logger, vis=vis, is_report=False)
+    if vis is not None:
+        vis.log('Finish!', win_name='Best Performances')
+
+
+if __name__ == '__main__':
+    import sys
+    get_flags()
+    FLAGS(sys.argv)
+    flag_defaults(FLAGS)
+    run(only_forward=FLAGS.eval_only_mode)

@@ -1,0 +1,70 @@
+"""End-to-end on the GPU: the three drop-in command lines train a few steps on a synthetic dataset in the reference's
+file formats, evaluate with the device ranking kernels, checkpoint, and reload in -eval_only_mode."""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+from tests.synth import make_dataset
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, 'joint-kg-recommender_amd')
+
+
+def run_cli(script, tmp, name, extra):
+    data = str(tmp)
+    logs = os.path.join(data, 'log')
+    os.makedirs(logs, exist_ok=True)
+    cmd = [sys.executable, os.path.join(PKG, script), '-data_path', data, '-log_path', logs, '-dataset', 'ml1m',
+           '-experiment_name', name, '-nohas_visualization', '-batch_size', '32', '-embedding_size', '20', '-seed', '3',
+           '-eval_interval_steps', '10', '-training_steps', '25', '-early_stopping_steps_to_wait', '0', '-learning_rate', '0.05',
+           '-topn', '10'] + extra
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    return open(os.path.join(logs, name + '.log')).read(), logs
+
+
+@pytest.fixture(scope='module')
+def dataset(tmp_path_factory):
+    tmp = tmp_path_factory.mktemp('ds')
+    make_dataset(str(tmp))
+    return tmp
+
+
+@pytest.mark.parametrize('model,extra', [('bprmf', []), ('transup', ['-num_preferences', '6', '-L1_flag']),
+                                         ('transup', ['-num_preferences', '6', '-use_st_gumbel'])])
+def test_item_recommendation_cli(dataset, model, extra):
+    name = 'rec-' + model + ('-g' if '-use_st_gumbel' in extra else '')
+    log, logs = run_cli('run_item_recommendation.py', dataset, name, ['-model_type', model, '-rec_test_files', 'valid.dat:test.dat'] + extra)
+    assert len(re.findall(r'f1:\d\.\d+, p:\d\.\d+, r:\d\.\d+, hit:\d\.\d+, ndcg:\d\.\d+, topn:10', log)) >= 6   # 3 evals x 2 files
+    assert 'train loss:' in log and 'Checkpointing' in log
+    assert os.path.isfile(os.path.join(logs, name + '.ckpt'))
+    log2, _ = run_cli('run_item_recommendation.py', dataset, name + '-eval',
+                      ['-model_type', model, '-rec_test_files', 'test.dat', '-eval_only_mode', '-load_experiment_name',
+                       os.path.join(logs, name + '.ckpt'), '-is_report'] + extra)
+    assert 'Found checkpoint, restoring.' in log2 and 'user:' in log2
+
+
+@pytest.mark.parametrize('model,extra', [('transe', ['-L1_flag']), ('transh', []), ('transr', [])])
+def test_knowledge_representation_cli(dataset, model, extra):
+    name = 'kg-' + model
+    log, logs = run_cli('run_knowledge_representation.py', dataset, name, ['-model_type', model, '-kg_test_files', 'valid.dat:test.dat'] + extra)
+    assert len(re.findall(r'avg hit:\d\.\d+, avg mean rank:\d+\.\d+, topn:10', log)) >= 6
+    assert os.path.isfile(os.path.join(logs, name + '.ckpt_final'))
+
+
+def test_joint_cli_ktup_with_pretrained_tables(dataset):
+    """The published KTUP recipe loads TUP + TransH checkpoints first (ktup.sh:1)."""
+    _, logs = run_cli('run_item_recommendation.py', dataset, 'pre-tup', ['-model_type', 'transup', '-rec_test_files', 'valid.dat',
+                                                                      '-num_preferences', '5'])
+    _, _ = run_cli('run_knowledge_representation.py', dataset, 'pre-transh', ['-model_type', 'transh', '-kg_test_files', 'valid.dat'])
+    log, logs = run_cli('run_knowledgable_recommendation.py', dataset, 'ktup',
+                        ['-model_type', 'jtransup', '-rec_test_files', 'valid.dat:test.dat', '-kg_test_files', 'valid.dat:test.dat',
+                         '-joint_ratio', '0.7', '-noshare_embeddings', '-load_ckpt_file', 'pre-tup.ckpt:pre-transh.ckpt_final'])
+    assert 'Restored 60 entities from checkpoint.' in log
+    assert 'rec train loss:' in log and 'kg train loss:' in log
+    assert len(re.findall(r'f1:\d\.\d+', log)) >= 6 and len(re.findall(r'avg hit:', log)) >= 6
+    assert os.path.isfile(os.path.join(logs, 'ktup.ckpt'))

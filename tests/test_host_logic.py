@@ -1,0 +1,155 @@
+"""CPU tests of the host side of the boundary: flags, file formats, samplers, iterators, joint schedule, metrics,
+trainer checkpoints.  (G7-G9 of SURVEY.md section 8c: constraint / structure checks, no RNG parity with the reference.)"""
+import collections
+import logging
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from tests.synth import make_dataset
+
+
+def test_flags_gflags_compatible_surface():
+    from jTransUP.models.base import flag_defaults, get_flags
+    from jTransUP.utils.flags import FLAGS, FlagError
+    get_flags(); FLAGS.reset()
+    rest = FLAGS(['prog', '-model_type', 'jtransup', '-noshare_embeddings', '-L1_flag', '-embedding_size', '100', '-joint_ratio=0.7',
+                  '--seed', '3', '-nohas_visualization', '-rec_test_files', 'valid.dat:test.dat', 'positional'])
+    assert rest == ['prog', 'positional']
+    assert (FLAGS.model_type, FLAGS.L1_flag, FLAGS.embedding_size, FLAGS.joint_ratio, FLAGS.seed, FLAGS.has_visualization) == \
+        ('jtransup', True, 100, 0.7, 3, False)
+    # reference defaults (base.py:22-98)
+    assert (FLAGS.batch_size, FLAGS.num_preferences, FLAGS.topn, FLAGS.margin, FLAGS.optimizer_type, FLAGS.l2_lambda,
+            FLAGS.clipping_max_value, FLAGS.eval_interval_steps, FLAGS.negtive_samples) == (512, 4, 10, 1.0, 'Adagrad', 1e-5, 5.0, 14000, 1)
+    FLAGS.share_embeddings = True
+    flag_defaults(FLAGS)
+    assert FLAGS.share_embeddings is False                 # forced off for jtransup (base.py:120-123)
+    assert FLAGS.data_path == '../datasets/' and FLAGS.ckpt_path == FLAGS.log_path
+    with pytest.raises(FlagError):
+        FLAGS(['prog', '-model_type', 'bpr'])               # the enum spells it `bprmf`
+    with pytest.raises(FlagError):
+        FLAGS(['prog', '-no_such_flag', '1'])
+    assert 'model_type' in FLAGS.FlagValuesDict()
+    FLAGS.reset()
+
+
+def test_file_formats_and_totals(tmp_path):
+    from jTransUP.data import load_kg_rating_data, load_rating_data, load_triple_data
+    d = make_dataset(str(tmp_path))
+    train, evals, u_map, i_map = load_rating_data.load_data(d, ['valid.dat', 'test.dat'], 16)
+    assert train[1] == len(train[2]) == 720 and len(evals) == 2 and evals[0][1] == 90
+    assert all(i in train[3][u] for u, i in train[2])
+    assert max(len(u_map), max(u_map.values())) == 40 and max(len(i_map), max(i_map.values())) == 50
+    assert sum(len(b) for b in evals[0][0]) == len(evals[0][3])            # eval iterator keeps the tail batch
+    ttrain, tevals, e_map, r_map = load_triple_data.load_data(os.path.join(d, 'kg'), ['valid.dat'], 16)
+    h, t, r = ttrain[2][0]
+    first = open(os.path.join(d, 'kg', 'train.dat')).readline().split('\t')
+    assert (h, t, r) == (int(first[0]), int(first[1]), int(first[2]))       # head, TAIL, relation order
+    assert h in ttrain[3][(t, r)] and t in ttrain[4][(h, r)]
+    out = load_kg_rating_data.load_data(d, ['valid.dat'], ['valid.dat'], 16)
+    i_remap, e_remap, ikg_map = out[3], out[6], out[8]
+    assert len(i_remap) == 50 and len(e_remap) == 60 and len(ikg_map) == 50 + 60 - 35
+    for i_id, idx in i_remap.items():
+        assert ikg_map[idx][1] == i_id
+    assert sum(1 for v in ikg_map.values() if v[0] != -1 and v[1] != -1) == 35
+
+
+def test_negative_samplers_constraints(tmp_path):
+    from jTransUP.data import load_rating_data, load_triple_data
+    from jTransUP.utils.data import getNegRatings, getTrainTripleBatch
+    d = make_dataset(str(tmp_path))
+    train, evals, _, _ = load_rating_data.load_data(d, ['valid.dat', 'test.dat'], 32)
+    all_dicts = [train[3]] + [e[3] for e in evals]
+    random.seed(1)
+    for _ in range(20):
+        batch = next(train[0])
+        u, pi, ni = getNegRatings(batch, 50, all_dicts=all_dicts)
+        assert len(ni) == len(set(ni)) == len(batch)                         # unique inside the batch (data.py:77-82)
+        for uu, p, n in zip(u, pi, ni):
+            assert n != p and all(n not in dic.get(uu, ()) for dic in all_dicts)
+    with pytest.raises(TypeError):
+        getNegRatings(next(train[0]), 50, all_dicts=None)                    # the reference crashes here too (data.py:79)
+    ttrain, tevals, _, _ = load_triple_data.load_data(os.path.join(d, 'kg'), ['valid.dat'], 64)
+    hd, td = [ttrain[3], tevals[0][4]], [ttrain[4], tevals[0][5]]
+    heads = tails = 0
+    for _ in range(30):
+        batch = [tuple(x) for x in next(ttrain[0])]
+        ph, pt, pr, nh, nt, nr = getTrainTripleBatch(batch, 60, all_head_dicts=hd, all_tail_dicts=td)
+        assert pr == nr
+        for a, b, c, e, f in zip(ph, pt, pr, nh, nt):
+            assert (a != e) != (b != f)                                      # exactly one side is corrupted
+            if a != e:
+                heads += 1
+                assert all(e not in dic.get((b, c), ()) for dic in hd)
+            else:
+                tails += 1
+                assert all(f not in dic.get((a, c), ()) for dic in td)
+    assert 0.4 < heads / float(heads + tails) < 0.6                          # fair coin (data.py:13-14)
+
+
+def test_train_iterator_drops_tail_and_reshuffles():
+    from jTransUP.utils.data import MakeEvalIterator, MakeTrainIterator
+    random.seed(0)
+    data = [(i, i) for i in range(10)]
+    it = MakeTrainIterator(data, 4)
+    epoch1 = [tuple(x) for _ in range(2) for x in next(it)]
+    epoch2 = [tuple(x) for _ in range(2) for x in next(it)]
+    assert len(set(epoch1)) == 8 and len(set(epoch2)) == 8                   # 2 full batches per epoch, tail of 2 dropped
+    ev = MakeEvalIterator(list(range(10)), np.dtype('int'), 4)
+    assert [len(b) for b in ev] == [4, 4, 2]
+
+
+def test_joint_schedule_matches_reference_rule():
+    for ratio, nrec in ((0.5, 5), (0.7, 7), (0.9, 9)):
+        assert [s % 10 < 10 * ratio for s in range(10)] == [s < nrec for s in range(10)]
+
+
+def test_ndcg_known_answers_and_metrics():
+    from jTransUP.utils.evaluation import dcg_at_k, ndcg_at_k
+    from jTransUP.utils.ranking import rec_metrics
+    assert ndcg_at_k([2, 1, 2, 0], 4) == pytest.approx(0.9203032077642922, rel=1e-15)
+    assert ndcg_at_k([2, 1, 2, 0], 4, method=1) == pytest.approx(0.96519546960144276, rel=1e-15)
+    assert ndcg_at_k([0], 1) == 0.0 and ndcg_at_k([1], 2) == 1.0
+    assert dcg_at_k([3, 2, 3, 0, 0, 1, 2, 2, 3, 0], 10, method=0) == pytest.approx(9.6051177391888114)
+    f1, p, r, hit, ndcg = rec_metrics([5, 9, 1, 7], {9, 7, 33})
+    assert (p, r, hit) == (0.5, 2 / 3.0, 1) and f1 == pytest.approx(2 * 0.5 * (2 / 3.0) / (0.5 + 2 / 3.0))
+    assert rec_metrics([1, 2], {3}) == (0.0, 0.0, 0.0, 0, 0.0)
+
+
+def test_trainer_checkpoint_layout_and_pretrain_load(tmp_path):
+    """State-dict keys, save/load round trip, and loadEmbedding's E -> E+1 padded-entity case (trainer.py:164-169)."""
+    from jTransUP.models import jTransUP as jt, transH
+    from jTransUP.models.base import get_flags
+    from jTransUP.utils.flags import FLAGS
+    from jTransUP.utils.trainer import ModelTrainer, get_model_target
+    get_flags(); FLAGS.reset()
+    FLAGS(['prog', '-model_type', 'transh', '-log_path', str(tmp_path), '-experiment_name', 'th', '-optimizer_type', 'Adam'])
+    FLAGS.ckpt_path = str(tmp_path)
+    logger = logging.getLogger('t')
+    torch.manual_seed(0)
+    th = transH.TransHModel(False, 8, 11, 3)
+    tr = ModelTrainer(th, logger, 10, FLAGS)
+    tr.step, tr.best_step, tr.best_dev_performance = 7, 5, 0.25
+    tr.save(tr.checkpoint_path)
+    ck = torch.load(tr.checkpoint_path, weights_only=False)
+    assert sorted(ck) == ['best_dev_performance', 'best_step', 'model_state_dict', 'optimizer_state_dict', 'step']
+    assert sorted(ck['model_state_dict']) == ['ent_embeddings.weight', 'norm_embeddings.weight', 'rel_embeddings.weight']
+    th2 = transH.TransHModel(False, 8, 11, 3)
+    tr2 = ModelTrainer(th2, logger, 10, FLAGS)
+    tr2.load(tr.checkpoint_path, cpu=True)
+    assert (tr2.step, tr2.best_step, tr2.best_dev_performance) == (7, 5, 0.25)
+    assert torch.equal(th2.ent_embeddings.weight.cpu(), th.ent_embeddings.weight.cpu())
+    im = {i: i for i in range(6)}
+    nm = {i: (i, i) for i in range(6)}
+    k = jt.jTransUPModel(False, 8, 4, 6, 11, 3, im, nm, False, False)
+    FLAGS.model_type = 'jtransup'
+    trk = ModelTrainer(k, logger, 10, FLAGS)
+    trk.loadEmbedding(tr.checkpoint_path, k.state_dict())
+    assert torch.equal(k.ent_embeddings.weight[:11].cpu(), th.ent_embeddings.weight.cpu())
+    assert float(k.ent_embeddings.weight[11].abs().sum()) == 0.0            # pad row untouched
+    assert torch.equal(k.rel_embeddings.weight.cpu(), th.rel_embeddings.weight.cpu())
+    assert get_model_target('bprmf') == 1 and get_model_target('jtransup') == -1
+    FLAGS.reset()

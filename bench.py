@@ -126,6 +126,66 @@ def train_step_bench(device, steps=200, warmup=20):
             'note': 'fwd pos+neg, loss, bwd, clip_grad_norm, dense Adagrad (torch.optim); eager launches, no graph'}
 
 
+def eval_bench(device, batch=512, seed=11):
+    """Second half of the metric: all-item Hit@10 evaluation latency at ml1m shape -- every one of the 6040 users scored
+    against all 3240 items by KTUP's evaluateRec (K16), filtered top-10 on the device (K17: ~165 filtered items per user,
+    1-30 gold items), metric arithmetic on the host -- i.e. one complete pass of knowledgable_recommendation.evaluateRec."""
+    import numpy as np
+    from jTransUP.models import jTransUP as jt
+    from jTransUP.utils import ranking as RK
+    torch.manual_seed(3)
+    rng = np.random.RandomState(seed)
+    i_map = {i: i for i in range(NI)}
+    new_map = {i: ((i * 4) % NE if i < ALIGNED else -1, i) for i in range(NI)}
+    m = jt.jTransUPModel(False, D, NU, NI, NE, NR, i_map, new_map, False, False)
+    m.eval(); m.disable_grad()
+    users = list(range(NU))
+    train = {u: set(rng.randint(0, NI, size=165).tolist()) for u in users}
+    gold = {u: set(rng.randint(0, NI, size=rng.randint(1, 31)).tolist()) - train[u] or {int(rng.randint(NI))} for u in users}
+    t0 = time.perf_counter()
+    index = RK.RankIndex(users, gold, [train], device)
+    t_index = time.perf_counter() - t0
+    batches = [users[s:s + batch] for s in range(0, NU, batch)]
+    ub = [torch.tensor(b, dtype=torch.long, device=device) for b in batches]
+
+    def one_pass(host_metrics):
+        out = []
+        for b, u in zip(batches, ub):
+            scores = m.evaluateRec(u)
+            if host_metrics:
+                out.extend(RK.evalRecProcess((b, scores), gold, [train], descending=False, topn=10, index=index))
+            else:
+                s, e = index.rows_of(b)
+                f_off, f_ids = index.filter_slice(s, e)
+                out.append(RK.ops.topk_filtered(scores, False, 10, f_off, f_ids))
+        torch.cuda.synchronize(device)
+        return out
+    one_pass(False)
+    reps = 5
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        one_pass(False)
+    dev_ms = 1e3 * (time.perf_counter() - t0) / reps
+    t0 = time.perf_counter()
+    rows = one_pass(True)
+    full_ms = 1e3 * (time.perf_counter() - t0)
+    hit = float(np.mean([r[3] for r in rows]))
+    return {'users': NU, 'items': NI, 'batch': batch, 'batches': len(batches), 'topn': 10,
+            'device_ms_full_pass': dev_ms, 'device_ms_per_batch': dev_ms / len(batches),
+            'full_pass_ms_incl_host_metrics': full_ms, 'filter_index_build_ms': 1e3 * t_index, 'hit_at_10_random_init': hit,
+            'note': 'scores (K16) + filtered top-10 (K17) on the device; ids copied back; f1/p/r/hit/ndcg on the host'}
+
+
+def hbm_traffic(kind):
+    """HBM bytes per launch from the committed PMC passes (profiles/r01_hbm_traffic.json: separate FETCH_SIZE / WRITE_SIZE
+    runs of this same command, read side doubled per MI355X_MICROARCH.md); None when the file is absent."""
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'r01_hbm_traffic.json')) as f:
+            return json.load(f)[kind]['hbm_bytes_per_launch']
+    except Exception:      # noqa: BLE001
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -189,9 +249,9 @@ def main():
                                '716800 (u,i) pairs + 307200 (h,t,r) triples (= 2000 batches of 512 at joint_ratio 0.7), '
                                'tables replicated per GPU', 'rows_per_step_per_gpu': REC_ROWS + KG_ROWS,
                    'users': NU, 'items': NI, 'entities': NE, 'relations': NR, 'd': D},
-        'roofline': {'bound': 'hbm', 'kernel': 'pref_fwd_kernel<7,4> (KTUP rec forward, K6)',
+        'roofline': {'bound': 'hbm', 'kernel': 'pref_fwd2_kernel<5,5,false> (KTUP rec forward, K6)',
                      'achieved': REC_ROWS * BYTES_REC / (rec_ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                     'frac': REC_ROWS * BYTES_REC / (rec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 'traffic': None,
+                     'frac': REC_ROWS * BYTES_REC / (rec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 'traffic': hbm_traffic('ktup_rec_forward'),
                      'bytes_per_row': BYTES_REC, 'rows_per_launch': REC_ROWS, 'ms_per_launch': rec_ms,
                      'note': 'ml1m tables (9.7 MB) are L2/Infinity-Cache resident; algorithmic bytes, not HBM traffic',
                      'kg_kernel': {'kernel': 'row_kernel<float4,32,1,TranshFwd> (K3)', 'ms_per_launch': kg_ms,
@@ -201,6 +261,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_extras:
         out['cpu_baseline'] = cpu_baseline(W, i2e, idx)
         out['train_step_b512'] = train_step_bench(device)
+        out['eval_all_item_hit10'] = eval_bench(device)
     elif rank == 0:
         out['cpu_baseline'] = None
     if rank == 0:

@@ -176,6 +176,15 @@ int ktup_eval_gold_ranks(const float* scores, int64_t lds, int64_t nq, int64_t n
                          const int64_t* filt_off, const int32_t* filt_ids, const int64_t* gold_off,
                          const int32_t* gold_ids, int32_t* ranks, void* stream);
 
+/* ------------------------------------------- row-sharded tables (new: the reference is single-device)
+ * Device halves of the all-to-all lookup exchange for tables partitioned by `row % world_size`:
+ * pack  : out[k,:] = table[ids[k],:]         owner side, rows a peer asked for -> contiguous send buffer
+ * unpack: gtable[ids[k],:] += rows[k,:]      owner side, returned row gradients -> shard gradient (atomics) */
+int ktup_shard_pack_rows(const float* table, int64_t ldt, int d, const int64_t* ids, int64_t n, float* out,
+                         int64_t ldo, void* stream);
+int ktup_shard_unpack_rows_add(const float* rows, int64_t ldr, int d, const int64_t* ids, int64_t n, float* gtable,
+                               int64_t ldg, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

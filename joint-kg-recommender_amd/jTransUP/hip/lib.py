@@ -57,6 +57,8 @@ SIGNATURES = {
                               c_p, c_p],
     'ktup_eval_topk_filtered': [c_p, c_l, c_l, c_l, c_i, c_p, c_p, c_i, c_p, c_p, c_p],
     'ktup_eval_gold_ranks': [c_p, c_l, c_l, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_p],
+    'ktup_shard_pack_rows': [c_p, c_l, c_i, c_p, c_l, c_p, c_l, c_p],
+    'ktup_shard_unpack_rows_add': [c_p, c_l, c_i, c_p, c_l, c_p, c_l, c_p],
 }
 _RESTYPE = {'ktup_last_error': ctypes.c_char_p, 'ktup_pref_workspace_bytes': ctypes.c_size_t,
             'ktup_eval_kg_workspace_bytes': ctypes.c_size_t, 'ktup_eval_transr_workspace_bytes': ctypes.c_size_t,

@@ -449,3 +449,24 @@ def gold_ranks(scores, descending, gold_off, gold_ids, filt_off=None, filt_ids=N
     L.call('ktup_eval_gold_ranks', _p(scores), scores.stride(0), nq, nc, int(bool(descending)), _p(filt_off), _p(filt_ids),
            _p(gold_off), _p(gold_ids), _p(ranks), _stream(dev))
     return ranks
+
+
+# ------------------------------------------------------------------------------------------ sharded-table exchange halves
+@torch.no_grad()
+def pack_rows(table, ids):
+    """out[k] = table[ids[k]] (owner side of the all-to-all lookup)."""
+    dev = _dev(_table('table shard', table))
+    ids = _ids('ids', ids, dev)
+    out = torch.empty(ids.numel(), table.shape[1], dtype=torch.float32, device=dev)
+    L.call('ktup_shard_pack_rows', _p(table), table.stride(0), table.shape[1], _p(ids), ids.numel(), _p(out), out.stride(0), _stream(dev))
+    return out
+
+
+@torch.no_grad()
+def unpack_rows_add(rows, ids, gtable):
+    """gtable[ids[k]] += rows[k] (owner side of the gradient return)."""
+    dev = _dev(_table('row gradients', rows)); _table('shard gradient', gtable)
+    ids = _ids('ids', ids, dev, rows.shape[0])
+    L.call('ktup_shard_unpack_rows_add', _p(rows), rows.stride(0), rows.shape[1], _p(ids), ids.numel(), _p(gtable), gtable.stride(0),
+           _stream(dev))
+    return gtable

@@ -693,6 +693,248 @@ int dispatch_fwd2(const PrefArgs& a, int d, int n_pref, hipStream_t st, const ch
   return launch_pref2<8, 8>(a, st, name);
 }
 
+
+// =============================================================================================================
+// pref_fwd3: soft-gate forward with the two P x d contractions on the fp32-input matrix cores.
+// tools/ubench (profiles/r01_ubench.txt): FMAs fed from SGPRs issue at <= 71 TF (37 TF at one wave per SIMD), the
+// v_mfma_f32_32x32x2_f32 pipe sustains 150-158 TF at ANY occupancy; the KTUP gate needs 12 kflop per pair.
+// Each wave owns 32 pairs from gather to score -- no workgroup barrier after the tables are staged in LDS -- and
+// LANE = PAIR in every phase, because the products are computed TRANSPOSED (D = A.B with the table as A, the pairs as B):
+//   gather : the wave's 32 rows of U / I / E as one linear run of 16-B chunks; x = u + v -> its LDS tile, q = u - v stays
+//            in registers until stage 1 is done, then overwrites x in place;
+//   stage 1: logits^T (P x 32 pairs) = Alog (P x d) . X^T.  k-pairing: for k-group g the lanes of half h read the float4
+//            [8g + 4h .. +3] of their table row (A) / their pair's x row (B); component c of the float4 pair feeds MFMA c,
+//            whose two k's are (8g + c, 8g + 4 + c): one ds_read_b128 per operand feeds 4 MFMAs, no lane selects.
+//            Result layout: lane (h, pair) holds the logits of ITS pair for preferences p = (r&3) + 8(r>>2) + 4h;
+//   stage 2: n^T (d x 32 pairs) = Cn^T . logits^T and r^T likewise, in 32-coordinate tiles.  Result register r of stage 1
+//            IS the B operand of stage-2 MFMA r (k pair = preferences (r&3)+8(r>>2) and +4): no LDS round trip, no shuffle;
+//   tail   : lane (h, pair) holds coordinates 32t + (r&3) + 8(r>>2) + 4h of its own pair, so s = q.n and sum f(q + r - s n)
+//            are in-lane sums over registers (q read back as conflict-free ds_read_b128) plus ONE cross-half add each.
+struct Fwd3Geom {
+  int kg, pitchA4, prow, nr, nt, nw;
+  size_t table_bytes, wave_bytes;
+};
+inline Fwd3Geom fwd3_geom(int d, int P) {
+  Fwd3Geom g{};
+  g.kg = (d + 7) / 8;
+  g.pitchA4 = 2 * g.kg + 1;                 // odd number of float4 per logit-table row: conflict-free b128 reads
+  g.prow = 8 * ((P + 7) / 8);               // stage-2 table rows (preferences padded to the MFMA k pairing), zero filled
+  g.nr = g.prow / 2;                        // stage-2 MFMAs per 32-coordinate tile and table (= stage-1 registers used)
+  g.nt = (d + 31) / 32;
+  g.table_bytes = (size_t)(P + 1) * g.pitchA4 * 16 + (size_t)2 * g.prow * 128 * 4;
+  g.wave_bytes = ((size_t)32 * (d / 4) + 1) * 16 + 3 * 32 * 4 + 16;
+  g.wave_bytes = (g.wave_bytes + 15) & ~(size_t)15;
+  const size_t budget = 160 * 1024 - g.table_bytes;
+  g.nw = (int)(budget / g.wave_bytes);
+  if (g.nw > 8) g.nw = 8;
+  return g;
+}
+
+template <int J, int NT2>
+__global__ __launch_bounds__(512) void pref_fwd3_kernel(PrefArgs a, Fwd3Geom g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int nch = a.nch, d = nch * 4, P = a.P;
+  float4* AlogL = reinterpret_cast<float4*>(smem);                                    // [(P + 1)][pitchA4], row P = 0
+  float* CnL = reinterpret_cast<float*>(AlogL + (P + 1) * g.pitchA4);                  // [prow][128]
+  float* ArL = CnL + g.prow * 128;                                                     // [prow][128]
+  const int t = threadIdx.x, lane = t & 63, h = lane >> 5, j = lane & 31;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  char* wbase = reinterpret_cast<char*>(ArL + g.prow * 128) + (size_t)w * g.wave_bytes;
+  float4* xt = reinterpret_cast<float4*>(wbase);                                       // [32 * nch] + 1 zero chunk
+  int32_t* sid = reinterpret_cast<int32_t*>(xt + 32 * nch + 1);                        // [3][32]
+  // ---- stage the preference tables once per workgroup (zero padded)
+  {
+    const float* Alog = reinterpret_cast<const float*>(a.Alog);
+    const float* Ar = reinterpret_cast<const float*>(a.Ar);
+    const float* Cn = reinterpret_cast<const float*>(a.Cn);
+    const int dp = a.dp4 * 4, nA = (P + 1) * g.pitchA4 * 4, nT = g.prow * 128;
+    float* AlogLf = reinterpret_cast<float*>(AlogL);
+    for (int idx = t; idx < nA; idx += blockDim.x) {
+      const int p = idx / (g.pitchA4 * 4), k = idx - p * (g.pitchA4 * 4);
+      AlogLf[idx] = (p < P && k < d) ? Alog[p * dp + k] : 0.f;
+    }
+    for (int idx = t; idx < nT; idx += blockDim.x) {
+      const int p = idx >> 7, c = idx & 127;
+      const bool ok = p < P && c < d;
+      CnL[idx] = ok ? Cn[p * dp + c] : 0.f;
+      ArL[idx] = ok ? Ar[p * dp + c] : 0.f;
+    }
+    if (lane == 0) xt[32 * nch] = f4zero();
+  }
+  __syncthreads();
+  const bool l1 = a.l1 != 0;
+  const int64_t ntiles = (a.n + 31) / 32;
+  const int total = 32 * nch;
+  const int qstep = 64 / nch, rstep = 64 - qstep * nch;
+  const int peff = j < P ? j : P;
+  const int64_t wstride = (int64_t)gridDim.x * g.nw;
+  bool first = true;
+  for (int64_t tile_id = (int64_t)blockIdx.x * g.nw + w; tile_id < ntiles; tile_id += wstride) {
+    const int64_t row0 = tile_id * 32;
+    // ---- ids of the wave's 32 pairs: loaded for the first tile here, afterwards prefetched one tile ahead (below)
+    if (first && lane < 32) {
+      const int64_t gr = row0 + lane;
+      const bool ok = gr < a.n;
+      const int64_t uid = ok ? a.u_ids[gr] : 0, iid = ok ? a.i_ids[gr] : 0;
+      sid[lane] = (int32_t)uid;
+      sid[32 + lane] = (int32_t)iid;
+      sid[64 + lane] = a.E ? a.item2ent[iid] : 0;
+    }
+    first = false;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // ---- gather: x -> LDS tile, q kept in registers; all row loads of the tile in flight at once
+    float4 q[J];
+    {
+      int v = lane, row = lane / nch, c = lane - (lane / nch) * nch;
+      asm volatile("" : "+v"(v), "+v"(row), "+v"(c));  // opaque per tile: stops LICM from hoisting J x (row, chunk)
+                                                       // address sets out of the persistent loop (they get spilled)
+      float4 uu[J], vv[J], ee[J];
+      int vs[J];
+#pragma unroll
+      for (int jj = 0; jj < J; ++jj) {
+        vs[jj] = v;
+        if (v < total) {
+          uu[jj] = a.U[(int64_t)sid[row] * a.ldu4 + c];
+          vv[jj] = a.I[(int64_t)sid[32 + row] * a.ldi4 + c];
+          ee[jj] = a.E ? a.E[(int64_t)sid[64 + row] * a.lde4 + c] : f4zero();
+        } else {
+          uu[jj] = f4zero(); vv[jj] = f4zero(); ee[jj] = f4zero();
+        }
+        v += 64; row += qstep; c += rstep;
+        if (c >= nch) { c -= nch; ++row; }
+      }
+#pragma unroll
+      for (int jj = 0; jj < J; ++jj) {
+        const float4 ve = vv[jj] + ee[jj];
+        if (vs[jj] < total) xt[vs[jj]] = uu[jj] + ve;
+        q[jj] = uu[jj] - ve;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // ---- next tile's ids (and the dependent item -> entity lookup) travel under the matrix phases of this tile
+    int32_t nx_u = 0, nx_i = 0, nx_e = 0;
+    const bool pre = lane < 32 && tile_id + wstride < ntiles;
+    if (pre) {
+      const int64_t gr = (tile_id + wstride) * 32 + lane;
+      const bool ok = gr < a.n;
+      const int64_t uid = ok ? a.u_ids[gr] : 0, iid = ok ? a.i_ids[gr] : 0;
+      nx_u = (int32_t)uid; nx_i = (int32_t)iid;
+      nx_e = a.E ? a.item2ent[iid] : 0;
+    }
+    // ---- stage 1: logits^T = Alog . X^T   (A = table row p = lane & 31, B = x of pair lane & 31)
+    v16f lg;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) lg[r] = 0.f;
+    {
+      const float4* xb = xt + j * nch + h;
+      const float4* ta = AlogL + peff * g.pitchA4 + h;
+      for (int gk = 0; gk < g.kg; ++gk) {
+        const float4 av = ta[2 * gk], bv = xb[2 * gk];
+        lg = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, lg, 0, 0, 0);
+        lg = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, lg, 0, 0, 0);
+        lg = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, lg, 0, 0, 0);
+        lg = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, lg, 0, 0, 0);
+      }
+    }
+    // ---- q overwrites x (every x read above was issued earlier by this same wave)
+    {
+      int v = lane;
+#pragma unroll
+      for (int jj = 0; jj < J; ++jj) {
+        if (v < total) xt[v] = q[jj];
+        v += 64;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // ---- stage 2a: n^T tiles.  MFMA r: A = Cn[p][coordinate 32t + lane&31] with p = (r&3) + 8(r>>2) + 4h, B = lg[r]
+    v16f accN[NT2];
+#pragma unroll
+    for (int nt = 0; nt < NT2; ++nt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accN[nt][r] = 0.f;
+      if (nt < g.nt) {
+        const float* trow = CnL + (4 * h) * 128 + 32 * nt + j;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (r < g.nr) accN[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(trow[((r & 3) + 8 * (r >> 2)) * 128], lg[r], accN[nt], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);  // keep later tiles' operand reads from being hoisted (VGPR pressure)
+    }
+    // ---- s = q . n : lane (h, pair) owns coordinates 32t + 8(r>>2) + 4h + (r&3): four float4 of q per tile
+    const float4* qrow = xt + j * nch + h;
+    float sp = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < NT2; ++nt) {
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        const int ci = 8 * nt + 2 * rq + h;
+        if (ci < nch) {
+          const float4 qv = qrow[8 * nt + 2 * rq];
+          sp = fmaf(qv.x, accN[nt][4 * rq], fmaf(qv.y, accN[nt][4 * rq + 1], fmaf(qv.z, accN[nt][4 * rq + 2], fmaf(qv.w, accN[nt][4 * rq + 3], sp))));
+        }
+      }
+    }
+    const float sfull = sp + __shfl_xor(sp, 32, 64);
+    // ---- stage 2b: r^T tiles and the distance
+    float dsum = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < NT2; ++nt) {
+      if (nt < g.nt) {
+        v16f accR;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accR[r] = 0.f;
+        const float* trow = ArL + (4 * h) * 128 + 32 * nt + j;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (r < g.nr) accR = __builtin_amdgcn_mfma_f32_32x32x2f32(trow[((r & 3) + 8 * (r >> 2)) * 128], lg[r], accR, 0, 0, 0);
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+          const int ci = 8 * nt + 2 * rq + h;
+          if (ci < nch) {
+            const float4 qv = qrow[8 * nt + 2 * rq];
+            dsum += dist1(fmaf(-sfull, accN[nt][4 * rq], qv.x + accR[4 * rq]), l1) +
+                    dist1(fmaf(-sfull, accN[nt][4 * rq + 1], qv.y + accR[4 * rq + 1]), l1) +
+                    dist1(fmaf(-sfull, accN[nt][4 * rq + 2], qv.z + accR[4 * rq + 2]), l1) +
+                    dist1(fmaf(-sfull, accN[nt][4 * rq + 3], qv.w + accR[4 * rq + 3]), l1);
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    const float score = dsum + __shfl_xor(dsum, 32, 64);
+    if (h == 0 && row0 + j < a.n) a.score[row0 + j] = score;
+    if (pre) { sid[lane] = nx_u; sid[32 + lane] = nx_i; sid[64 + lane] = nx_e; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+template <int J, int NT2>
+int launch_pref3(const PrefArgs& a, const Fwd3Geom& g, hipStream_t st, const char* name) {
+  const size_t lds = g.table_bytes + (size_t)g.nw * g.wave_bytes;
+  (void)hipFuncSetAttribute((const void*)pref_fwd3_kernel<J, NT2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const int64_t ntiles = (a.n + 31) / 32;
+  const int grid = grid_for((ntiles + g.nw - 1) / g.nw, 256);
+  hipLaunchKernelGGL((pref_fwd3_kernel<J, NT2>), dim3(grid), dim3(g.nw * 64), lds, st, a, g);
+  return check_launch(name);
+}
+
+// soft gate, d <= 128, P <= 32 and enough LDS for >= 2 waves; otherwise the caller falls back to pref_fwd2
+bool fwd3_supported(const PrefArgs& a, int d, int P, Fwd3Geom* out) {
+  if (a.gumbel != KTUP_GUMBEL_OFF || d > 128 || P > 32) return false;
+  *out = fwd3_geom(d, P);
+  return out->nw >= 2;
+}
+
+int dispatch_fwd3(const PrefArgs& a, int d, const Fwd3Geom& g, hipStream_t st, const char* name) {
+  if (d <= 64) return launch_pref3<8, 2>(a, g, st, name);
+  if (d <= 104) return launch_pref3<13, 4>(a, g, st, name);
+  return launch_pref3<16, 4>(a, g, st, name);
+}
+
 template <int CH, int NW>
 int launch_pref(bool bwd, const PrefArgs& a, hipStream_t st, const char* name) {
   const int64_t ntiles = (a.n + TR - 1) / TR;
@@ -757,7 +999,9 @@ int run_pref(bool bwd, const char* name, const float* U, int64_t ldu, const floa
   hipStream_t st = (hipStream_t)stream;
   if (!bwd) {  // KTUP_PREF_FWD selects the forward variant (A/B measurements); default = tuned kernel, one pair per lane
     const char* env = getenv("KTUP_PREF_FWD");
-    const int variant = env ? atoi(env) : 1;
+    const int variant = env ? atoi(env) : 3;   // 0 = first kernel, 2 = SGPR-FMA kernel, 3 (default) = matrix-core kernel
+    Fwd3Geom g3;
+    if (variant == 3 && fwd3_supported(a, d, n_pref, &g3)) return dispatch_fwd3(a, d, g3, st, name);
     if (variant != 0) return dispatch_fwd2(a, d, n_pref, st, name);
   }
   if (g.CH == 4 && g.NW == 4) return launch_pref<4, 4>(bwd, a, st, name);

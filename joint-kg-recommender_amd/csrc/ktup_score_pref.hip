@@ -19,7 +19,9 @@
 //            pair's logits against SGPR table values; q re-written to the same LDS tile;
 //   s and the final sum are combined across the NW waves through two tiny LDS arrays.
 // No cross-lane shuffles at all in the P x d contractions; LDS holds one 64 x d tile (25.6 KB at d=100).
+#include <cstdio>
 #include <cstdlib>
+#include <vector>
 
 #include "ktup_pref_geom.h"
 
@@ -711,7 +713,8 @@ int dispatch_fwd2(const PrefArgs& a, int d, int n_pref, hipStream_t st, const ch
 //   tail   : lane (h, pair) holds coordinates 32t + (r&3) + 8(r>>2) + 4h of its own pair, so s = q.n and sum f(q + r - s n)
 //            are in-lane sums over registers (q read back as conflict-free ds_read_b128) plus ONE cross-half add each.
 struct Fwd3Geom {
-  int kg, pitchA4, prow, nr, nt, nw;
+  int kg, pitchA4, prow, nr, nt, nw, pair, exp;
+  unsigned long long* trace;   // debug (KTUP_PREF_TRACE=<file>): s_memtime stamps of workgroup 0, [wave][tile < 8][8 marks]
   size_t table_bytes, wave_bytes;
 };
 inline Fwd3Geom fwd3_geom(int d, int P) {
@@ -724,13 +727,13 @@ inline Fwd3Geom fwd3_geom(int d, int P) {
   g.table_bytes = (size_t)(P + 1) * g.pitchA4 * 16 + (size_t)2 * g.prow * 128 * 4;
   g.wave_bytes = ((size_t)32 * (d / 4) + 1) * 16 + 3 * 32 * 4 + 16;
   g.wave_bytes = (g.wave_bytes + 15) & ~(size_t)15;
-  const size_t budget = 160 * 1024 - g.table_bytes;
+  const size_t budget = 160 * 1024 - g.table_bytes - 64;   // 64 B of pair flags
   g.nw = (int)(budget / g.wave_bytes);
   if (g.nw > 8) g.nw = 8;
   return g;
 }
 
-template <int J, int NT2>
+template <int J, int NT2, int NR>
 __global__ __launch_bounds__(512) void pref_fwd3_kernel(PrefArgs a, Fwd3Geom g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int nch = a.nch, d = nch * 4, P = a.P;
@@ -742,6 +745,12 @@ __global__ __launch_bounds__(512) void pref_fwd3_kernel(PrefArgs a, Fwd3Geom g) 
   char* wbase = reinterpret_cast<char*>(ArL + g.prow * 128) + (size_t)w * g.wave_bytes;
   float4* xt = reinterpret_cast<float4*>(wbase);                                       // [32 * nch] + 1 zero chunk
   int32_t* sid = reinterpret_cast<int32_t*>(xt + 32 * nch + 1);                        // [3][32]
+  // matrix-phase token of each wave pair (w, w + nw/2): turn[pair] = side allowed in, done[w] = wave w has left its loop
+  volatile int* turn = reinterpret_cast<volatile int*>(reinterpret_cast<char*>(ArL + g.prow * 128) + (size_t)g.nw * g.wave_bytes);
+  volatile int* done = turn + 8;
+  const int half_nw = g.nw / 2;
+  const bool paired = g.pair != 0 && (g.nw & 1) == 0;
+  const int pairi = paired ? w % half_nw : 0, side = paired ? w / half_nw : 0, partner = paired ? (w + half_nw) % g.nw : 0;
   // ---- stage the preference tables once per workgroup (zero padded)
   {
     const float* Alog = reinterpret_cast<const float*>(a.Alog);
@@ -760,8 +769,13 @@ __global__ __launch_bounds__(512) void pref_fwd3_kernel(PrefArgs a, Fwd3Geom g) 
       ArL[idx] = ok ? Ar[p * dp + c] : 0.f;
     }
     if (lane == 0) xt[32 * nch] = f4zero();
+    if (t < 16) turn[t] = 0;   // turn[0..7] = side 0 first, done[0..7] = 0
   }
   __syncthreads();
+  // Waves w and w + nw/2 share a SIMD (a workgroup's waves are dealt to the 4 SIMDs cyclically) and run the same loop.
+  // Left alone they march in lockstep -- every wave gathers at once (a ~12 TB/s burst on L2), then every wave wants the
+  // matrix pipe at once -- so nothing overlaps (s_memtime trace).  A token per pair makes the two
+  // waves alternate: one is in its matrix phases while the other gathers / finishes its tail.
   const bool l1 = a.l1 != 0;
   const int64_t ntiles = (a.n + 31) / 32;
   const int total = 32 * nch;
@@ -769,7 +783,10 @@ __global__ __launch_bounds__(512) void pref_fwd3_kernel(PrefArgs a, Fwd3Geom g) 
   const int peff = j < P ? j : P;
   const int64_t wstride = (int64_t)gridDim.x * g.nw;
   bool first = true;
+  int it = -1;
   for (int64_t tile_id = (int64_t)blockIdx.x * g.nw + w; tile_id < ntiles; tile_id += wstride) {
+    ++it;
+    if (g.trace && blockIdx.x == 0 && lane == 0 && it < 8) g.trace[((size_t)w * 8 + it) * 8 + 0] = __builtin_amdgcn_s_memtime();
     const int64_t row0 = tile_id * 32;
     // ---- ids of the wave's 32 pairs: loaded for the first tile here, afterwards prefetched one tile ahead (below)
     if (first && lane < 32) {
@@ -813,6 +830,7 @@ __global__ __launch_bounds__(512) void pref_fwd3_kernel(PrefArgs a, Fwd3Geom g) 
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    if (g.trace && blockIdx.x == 0 && lane == 0 && it < 8) g.trace[((size_t)w * 8 + it) * 8 + 1] = __builtin_amdgcn_s_memtime();
     // ---- next tile's ids (and the dependent item -> entity lookup) travel under the matrix phases of this tile
     int32_t nx_u = 0, nx_i = 0, nx_e = 0;
     const bool pre = lane < 32 && tile_id + wstride < ntiles;
@@ -823,6 +841,9 @@ __global__ __launch_bounds__(512) void pref_fwd3_kernel(PrefArgs a, Fwd3Geom g) 
       nx_u = (int32_t)uid; nx_i = (int32_t)iid;
       nx_e = a.E ? a.item2ent[iid] : 0;
     }
+    if (paired) {  // acquire the pair's matrix-phase token (the partner may already have left its loop)
+      while (turn[pairi] != side && done[partner] == 0) __builtin_amdgcn_s_sleep(2);
+    }
     // ---- stage 1: logits^T = Alog . X^T   (A = table row p = lane & 31, B = x of pair lane & 31)
     v16f lg;
 #pragma unroll
@@ -830,14 +851,19 @@ __global__ __launch_bounds__(512) void pref_fwd3_kernel(PrefArgs a, Fwd3Geom g) 
     {
       const float4* xb = xt + j * nch + h;
       const float4* ta = AlogL + peff * g.pitchA4 + h;
-      for (int gk = 0; gk < g.kg; ++gk) {
-        const float4 av = ta[2 * gk], bv = xb[2 * gk];
+      float4 av = ta[0], bv = xb[0];
+      for (int gk = 0; gk < g.kg; ++gk) {   // operands of group gk + 1 are fetched under the 4 MFMAs of group gk
+        const int nx = gk + 1 < g.kg ? 2 * (gk + 1) : 0;
+        const float4 an = ta[nx], bn = xb[nx];
         lg = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, lg, 0, 0, 0);
         lg = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, lg, 0, 0, 0);
         lg = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, lg, 0, 0, 0);
         lg = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, lg, 0, 0, 0);
+        av = an; bv = bn;
       }
     }
+    asm volatile("" :: "v"(lg[0]));
+    if (g.trace && blockIdx.x == 0 && lane == 0 && it < 8) g.trace[((size_t)w * 8 + it) * 8 + 2] = __builtin_amdgcn_s_memtime();
     // ---- q overwrites x (every x read above was issued earlier by this same wave)
     {
       int v = lane;
@@ -851,18 +877,28 @@ __global__ __launch_bounds__(512) void pref_fwd3_kernel(PrefArgs a, Fwd3Geom g) 
     __builtin_amdgcn_wave_barrier();
     // ---- stage 2a: n^T tiles.  MFMA r: A = Cn[p][coordinate 32t + lane&31] with p = (r&3) + 8(r>>2) + 4h, B = lg[r]
     v16f accN[NT2];
+    {
+      const float* tbase = CnL + (4 * h) * 128 + j;
+      float ta[NR], tn[NR];
 #pragma unroll
-    for (int nt = 0; nt < NT2; ++nt) {
+      for (int r = 0; r < NR; ++r) ta[r] = tbase[((r & 3) + 8 * (r >> 2)) * 128];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) accN[nt][r] = 0.f;
-      if (nt < g.nt) {
-        const float* trow = CnL + (4 * h) * 128 + 32 * nt + j;
+      for (int nt = 0; nt < NT2; ++nt) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          if (r < g.nr) accN[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(trow[((r & 3) + 8 * (r >> 2)) * 128], lg[r], accN[nt], 0, 0, 0);
+        for (int r = 0; r < 16; ++r) accN[nt][r] = 0.f;
+        if (nt < g.nt) {
+          const int nn = nt + 1 < g.nt ? 32 * (nt + 1) : 0;   // next tile's operands travel under this tile's MFMAs
+#pragma unroll
+          for (int r = 0; r < NR; ++r) tn[r] = tbase[((r & 3) + 8 * (r >> 2)) * 128 + nn];
+#pragma unroll
+          for (int r = 0; r < NR; ++r) accN[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ta[r], lg[r], accN[nt], 0, 0, 0);
+#pragma unroll
+          for (int r = 0; r < NR; ++r) ta[r] = tn[r];
+        }
       }
-      __builtin_amdgcn_sched_barrier(0);  // keep later tiles' operand reads from being hoisted (VGPR pressure)
     }
+    asm volatile("" :: "v"(accN[0][0]));
+    if (g.trace && blockIdx.x == 0 && lane == 0 && it < 8) g.trace[((size_t)w * 8 + it) * 8 + 3] = __builtin_amdgcn_s_memtime();
     // ---- s = q . n : lane (h, pair) owns coordinates 32t + 8(r>>2) + 4h + (r&3): four float4 of q per tile
     const float4* qrow = xt + j * nch + h;
     float sp = 0.f;
@@ -878,47 +914,79 @@ __global__ __launch_bounds__(512) void pref_fwd3_kernel(PrefArgs a, Fwd3Geom g) 
       }
     }
     const float sfull = sp + __shfl_xor(sp, 32, 64);
+    if (g.trace && blockIdx.x == 0 && lane == 0 && it < 8) g.trace[((size_t)w * 8 + it) * 8 + 4] = __builtin_amdgcn_s_memtime();
     // ---- stage 2b: r^T tiles and the distance
     float dsum = 0.f;
+    {
+      const float* tbase = ArL + (4 * h) * 128 + j;
+      float ta[NR], tn[NR];
 #pragma unroll
-    for (int nt = 0; nt < NT2; ++nt) {
-      if (nt < g.nt) {
-        v16f accR;
+      for (int r = 0; r < NR; ++r) ta[r] = tbase[((r & 3) + 8 * (r >> 2)) * 128];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) accR[r] = 0.f;
-        const float* trow = ArL + (4 * h) * 128 + 32 * nt + j;
+      for (int nt = 0; nt < NT2; ++nt) {
+        if (nt < g.nt) {
+          v16f accR;
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          if (r < g.nr) accR = __builtin_amdgcn_mfma_f32_32x32x2f32(trow[((r & 3) + 8 * (r >> 2)) * 128], lg[r], accR, 0, 0, 0);
+          for (int r = 0; r < 16; ++r) accR[r] = 0.f;
+          const int nn = nt + 1 < g.nt ? 32 * (nt + 1) : 0;
 #pragma unroll
-        for (int rq = 0; rq < 4; ++rq) {
-          const int ci = 8 * nt + 2 * rq + h;
-          if (ci < nch) {
-            const float4 qv = qrow[8 * nt + 2 * rq];
-            dsum += dist1(fmaf(-sfull, accN[nt][4 * rq], qv.x + accR[4 * rq]), l1) +
-                    dist1(fmaf(-sfull, accN[nt][4 * rq + 1], qv.y + accR[4 * rq + 1]), l1) +
-                    dist1(fmaf(-sfull, accN[nt][4 * rq + 2], qv.z + accR[4 * rq + 2]), l1) +
-                    dist1(fmaf(-sfull, accN[nt][4 * rq + 3], qv.w + accR[4 * rq + 3]), l1);
+          for (int r = 0; r < NR; ++r) tn[r] = tbase[((r & 3) + 8 * (r >> 2)) * 128 + nn];
+          float4 qv[4];
+#pragma unroll
+          for (int rq = 0; rq < 4; ++rq) qv[rq] = (8 * nt + 2 * rq + h < nch) ? qrow[8 * nt + 2 * rq] : f4zero();
+#pragma unroll
+          for (int r = 0; r < NR; ++r) accR = __builtin_amdgcn_mfma_f32_32x32x2f32(ta[r], lg[r], accR, 0, 0, 0);
+#pragma unroll
+          for (int r = 0; r < NR; ++r) ta[r] = tn[r];
+#pragma unroll
+          for (int rq = 0; rq < 4; ++rq) {   // chunks past the row end have q = r = n = 0: they add f(0) = 0
+            dsum += dist1(fmaf(-sfull, accN[nt][4 * rq], qv[rq].x + accR[4 * rq]), l1) +
+                    dist1(fmaf(-sfull, accN[nt][4 * rq + 1], qv[rq].y + accR[4 * rq + 1]), l1) +
+                    dist1(fmaf(-sfull, accN[nt][4 * rq + 2], qv[rq].z + accR[4 * rq + 2]), l1) +
+                    dist1(fmaf(-sfull, accN[nt][4 * rq + 3], qv[rq].w + accR[4 * rq + 3]), l1);
           }
         }
       }
-      __builtin_amdgcn_sched_barrier(0);
     }
+    if (paired && lane == 0) turn[pairi] = 1 - side;  // release: the partner's matrix phases may start
     const float score = dsum + __shfl_xor(dsum, 32, 64);
+    if (g.trace && blockIdx.x == 0 && lane == 0 && it < 8) g.trace[((size_t)w * 8 + it) * 8 + 5] = __builtin_amdgcn_s_memtime();
+
     if (h == 0 && row0 + j < a.n) a.score[row0 + j] = score;
     if (pre) { sid[lane] = nx_u; sid[32 + lane] = nx_i; sid[64 + lane] = nx_e; }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    if (g.trace && blockIdx.x == 0 && lane == 0 && it < 8) g.trace[((size_t)w * 8 + it) * 8 + 6] = __builtin_amdgcn_s_memtime();
   }
+  if (paired && lane == 0) { done[w] = 1; turn[pairi] = 1 - side; }
 }
 
-template <int J, int NT2>
+template <int J, int NT2, int NR>
 int launch_pref3(const PrefArgs& a, const Fwd3Geom& g, hipStream_t st, const char* name) {
-  const size_t lds = g.table_bytes + (size_t)g.nw * g.wave_bytes;
-  (void)hipFuncSetAttribute((const void*)pref_fwd3_kernel<J, NT2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const size_t lds = g.table_bytes + (size_t)g.nw * g.wave_bytes + 64;
+  (void)hipFuncSetAttribute((const void*)pref_fwd3_kernel<J, NT2, NR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   const int64_t ntiles = (a.n + 31) / 32;
   const int grid = grid_for((ntiles + g.nw - 1) / g.nw, 256);
-  hipLaunchKernelGGL((pref_fwd3_kernel<J, NT2>), dim3(grid), dim3(g.nw * 64), lds, st, a, g);
+  Fwd3Geom gg = g;
+  const char* tpath = getenv("KTUP_PREF_TRACE");     // debug only: dump s_memtime marks of workgroup 0
+  const size_t tbytes = (size_t)8 * 8 * 8 * sizeof(unsigned long long);
+  if (tpath && hipMalloc((void**)&gg.trace, tbytes) == hipSuccess) (void)hipMemsetAsync(gg.trace, 0, tbytes, st); else gg.trace = nullptr;
+  hipLaunchKernelGGL((pref_fwd3_kernel<J, NT2, NR>), dim3(grid), dim3(g.nw * 64), lds, st, a, gg);
+  if (gg.trace) {
+    std::vector<unsigned long long> hbuf(8 * 8 * 8);
+    (void)hipStreamSynchronize(st);
+    (void)hipMemcpy(hbuf.data(), gg.trace, tbytes, hipMemcpyDeviceToHost);
+    if (FILE* f = fopen(tpath, "w")) {
+      for (int w = 0; w < 8; ++w)
+        for (int it = 0; it < 8; ++it) {
+          fprintf(f, "w%d it%d", w, it);
+          for (int k = 0; k < 8; ++k) fprintf(f, " %llu", hbuf[((size_t)w * 8 + it) * 8 + k]);
+          fprintf(f, "\n");
+        }
+      fclose(f);
+    }
+    (void)hipFree(gg.trace);
+  }
   return check_launch(name);
 }
 
@@ -926,13 +994,26 @@ int launch_pref3(const PrefArgs& a, const Fwd3Geom& g, hipStream_t st, const cha
 bool fwd3_supported(const PrefArgs& a, int d, int P, Fwd3Geom* out) {
   if (a.gumbel != KTUP_GUMBEL_OFF || d > 128 || P > 32) return false;
   *out = fwd3_geom(d, P);
+  { const char* e = getenv("KTUP_PREF_PAIR"); out->pair = e ? atoi(e) : 0; }
+  { const char* e = getenv("KTUP_PREF_EXP"); out->exp = e ? atoi(e) : 0; }
+  out->trace = nullptr;
   return out->nw >= 2;
 }
 
+template <int J, int NT2>
+int dispatch_fwd3_nr(const PrefArgs& a, const Fwd3Geom& g, hipStream_t st, const char* name) {
+  switch (g.nr) {   // stage-2 MFMAs per tile and table = 4 * ceil(P / 8)
+    case 4: return launch_pref3<J, NT2, 4>(a, g, st, name);
+    case 8: return launch_pref3<J, NT2, 8>(a, g, st, name);
+    case 12: return launch_pref3<J, NT2, 12>(a, g, st, name);
+    default: return launch_pref3<J, NT2, 16>(a, g, st, name);
+  }
+}
+
 int dispatch_fwd3(const PrefArgs& a, int d, const Fwd3Geom& g, hipStream_t st, const char* name) {
-  if (d <= 64) return launch_pref3<8, 2>(a, g, st, name);
-  if (d <= 104) return launch_pref3<13, 4>(a, g, st, name);
-  return launch_pref3<16, 4>(a, g, st, name);
+  if (d <= 64) return dispatch_fwd3_nr<8, 2>(a, g, st, name);
+  if (d <= 104) return dispatch_fwd3_nr<13, 4>(a, g, st, name);
+  return dispatch_fwd3_nr<16, 4>(a, g, st, name);
 }
 
 template <int CH, int NW>

@@ -1016,6 +1016,255 @@ int dispatch_fwd3(const PrefArgs& a, int d, const Fwd3Geom& g, hipStream_t st, c
   return dispatch_fwd3_nr<16, 4>(a, g, st, name);
 }
 
+
+// =============================================================================================================
+// pref_fwd4: the same transposed matrix-core formulation as pref_fwd3 on v_mfma_f32_16x16x4_f32, 16 pairs per wave.
+// Why: pref_fwd3's s_memtime trace (profiles/r01_fwd3_smemtime_trace.txt) shows a wave's gather (~14 k cycles, running at
+// the ~10 B/clk/CU vector-memory rate) and its matrix phases (~20 k) strictly in series, with only 2 waves per SIMD to
+// overlap them (12.8 KB LDS tile + 185 VGPRs per wave).  Halving the tile to 16 pairs halves the LDS tile and the
+// accumulators (n^T: 7 x 4 registers instead of 4 x 16), so 16 waves (4 per SIMD) are resident per CU, and the finer
+// tiles waste less: d=100 is 7 x 16 coordinates (not 4 x 32), and the preferences pack 4 per MFMA exactly (P=20 -> 5).
+//   lane l: kq = l >> 4 (k slot 0..3), j = l & 15 (pair for B / D columns, table row for A).
+//   stage 1: D1[t][slot i][pair], slot i = 4 kq' + reg  <->  preference p = 16 t + 4 reg + kq' (block-transposed so that a
+//            partial last tile spreads its preferences over the 4 k slots); k-group g: lane reads float4 [16g + 4kq .. +3]
+//            of its table row (A) / its pair's x row (B) and component c feeds MFMA c;
+//   stage 2: MFMA m = 4 t + reg uses B = lg[t][reg] (register, no data movement) and A = T[16t + 4 reg + kq][16 ct + j];
+//   tail   : lane (kq, pair) owns coordinates 16 ct + 4 kq + reg = ONE float4 of q per tile; sums over kq by 2 xor-adds.
+typedef float v4 __attribute__((ext_vector_type(4)));
+
+struct Fwd4Geom {
+  int kg, pitchA4, pt, np, trow, tpitch, ct, nw;
+  size_t table_bytes, wave_bytes;
+};
+inline Fwd4Geom fwd4_geom(int d, int P) {
+  Fwd4Geom g{};
+  g.kg = (d + 15) / 16;                       // stage-1 k groups of 16 coordinates
+  g.pitchA4 = 4 * g.kg + 1;                   // odd float4 pitch of the slot-ordered logit table
+  g.pt = (P + 15) / 16;                       // preference tiles of 16 slots
+  g.np = (P + 3) / 4;                         // stage-2 MFMAs per coordinate tile and table,
+  g.np = g.np <= 2 ? g.np : g.np <= 4 ? 4 : g.np <= 5 ? 5 : 8;   // rounded up to an instantiated count (1, 2, 4, 5, 8)
+  g.trow = 4 * g.np;                          // rows of the stage-2 tables (zero padded)
+  g.ct = (d + 15) / 16;                       // coordinate tiles
+  g.tpitch = 16 * g.ct + ((16 * g.ct) % 32 == 0 ? 16 : 0);   // pitch == 16 (mod 32): the two rows a 32-lane group reads never collide
+  g.table_bytes = (size_t)g.pt * 16 * g.pitchA4 * 16 + (size_t)2 * g.trow * g.tpitch * 4;
+  g.wave_bytes = (((size_t)16 * (d / 4) + 3) * 16 + 3 * 16 * 4 + 15) & ~(size_t)15;
+  const size_t budget = 160 * 1024 - g.table_bytes;
+  g.nw = (int)(budget / g.wave_bytes);
+  if (g.nw > 16) g.nw = 16;
+  g.nw &= ~3;                                 // whole waves per SIMD
+  return g;
+}
+
+template <int J, int CT, int NP>
+__global__ __launch_bounds__(1024) void pref_fwd4_kernel(PrefArgs a, Fwd4Geom g) {
+  constexpr int PT = (NP + 3) / 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int nch = a.nch, d = nch * 4, P = a.P;
+  float4* AlogS = reinterpret_cast<float4*>(smem);                                     // [pt * 16 slots][pitchA4]
+  float* CnS = reinterpret_cast<float*>(AlogS + g.pt * 16 * g.pitchA4);                 // [trow][tpitch]
+  float* ArS = CnS + g.trow * g.tpitch;                                                 // [trow][tpitch]
+  const int t = threadIdx.x, lane = t & 63, kq = lane >> 4, j = lane & 15;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  char* wbase = reinterpret_cast<char*>(ArS + g.trow * g.tpitch) + (size_t)w * g.wave_bytes;
+  float4* xt = reinterpret_cast<float4*>(wbase);                                        // [16 * nch] + 3 zero chunks
+  int32_t* sid = reinterpret_cast<int32_t*>(xt + 16 * nch + 3);                         // [3][16]
+  // ---- stage the tables once per workgroup
+  {
+    const float* Alog = reinterpret_cast<const float*>(a.Alog);
+    const float* Ar = reinterpret_cast<const float*>(a.Ar);
+    const float* Cn = reinterpret_cast<const float*>(a.Cn);
+    const int dp = a.dp4 * 4, rowf = g.pitchA4 * 4, nA = g.pt * 16 * rowf, nT = g.trow * g.tpitch;
+    float* AlogSf = reinterpret_cast<float*>(AlogS);
+    for (int idx = t; idx < nA; idx += blockDim.x) {
+      const int srow = idx / rowf, k = idx - srow * rowf;
+      const int tt = srow >> 4, i = srow & 15;
+      const int p = 16 * tt + 4 * (i & 3) + (i >> 2);          // slot -> preference (block transposed)
+      AlogSf[idx] = (p < P && k < d) ? Alog[p * dp + k] : 0.f;
+    }
+    for (int idx = t; idx < nT; idx += blockDim.x) {
+      const int p = idx / g.tpitch, c = idx - p * g.tpitch;
+      const bool ok = p < P && c < d;
+      CnS[idx] = ok ? Cn[p * dp + c] : 0.f;
+      ArS[idx] = ok ? Ar[p * dp + c] : 0.f;
+    }
+    if (lane < 3) xt[16 * nch + lane] = f4zero();
+  }
+  __syncthreads();
+  const bool l1 = a.l1 != 0;
+  const int64_t ntiles = (a.n + 15) / 16;
+  const int total = 16 * nch;
+  const int qstep = 64 / nch, rstep = 64 - qstep * nch;
+  const int64_t wstride = (int64_t)gridDim.x * g.nw;
+  bool first = true;
+  for (int64_t tile_id = (int64_t)blockIdx.x * g.nw + w; tile_id < ntiles; tile_id += wstride) {
+    const int64_t row0 = tile_id * 16;
+    if (first && lane < 16) {
+      const int64_t gr = row0 + lane;
+      const bool ok = gr < a.n;
+      const int64_t uid = ok ? a.u_ids[gr] : 0, iid = ok ? a.i_ids[gr] : 0;
+      sid[lane] = (int32_t)uid;
+      sid[16 + lane] = (int32_t)iid;
+      sid[32 + lane] = a.E ? a.item2ent[iid] : 0;
+    }
+    first = false;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // ---- gather: x -> LDS tile, q in registers
+    float4 q[J];
+    {
+      int v = lane, row = lane / nch, c = lane - (lane / nch) * nch;
+      asm volatile("" : "+v"(v), "+v"(row), "+v"(c));   // opaque per tile (LICM would hoist and spill the address sets)
+      float4 uu[J], vv[J], ee[J];
+      int vs[J];
+#pragma unroll
+      for (int jj = 0; jj < J; ++jj) {
+        vs[jj] = v;
+        if (v < total) {
+          uu[jj] = a.U[(int64_t)sid[row] * a.ldu4 + c];
+          vv[jj] = a.I[(int64_t)sid[16 + row] * a.ldi4 + c];
+          ee[jj] = a.E ? a.E[(int64_t)sid[32 + row] * a.lde4 + c] : f4zero();
+        } else {
+          uu[jj] = f4zero(); vv[jj] = f4zero(); ee[jj] = f4zero();
+        }
+        v += 64; row += qstep; c += rstep;
+        if (c >= nch) { c -= nch; ++row; }
+      }
+#pragma unroll
+      for (int jj = 0; jj < J; ++jj) {
+        const float4 ve = vv[jj] + ee[jj];
+        if (vs[jj] < total) xt[vs[jj]] = uu[jj] + ve;
+        q[jj] = uu[jj] - ve;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // ---- next tile's ids travel under the matrix phases
+    int32_t nx_u = 0, nx_i = 0, nx_e = 0;
+    const bool pre = lane < 16 && tile_id + wstride < ntiles;
+    if (pre) {
+      const int64_t gr = (tile_id + wstride) * 16 + lane;
+      const bool ok = gr < a.n;
+      const int64_t uid = ok ? a.u_ids[gr] : 0, iid = ok ? a.i_ids[gr] : 0;
+      nx_u = (int32_t)uid; nx_i = (int32_t)iid;
+      nx_e = a.E ? a.item2ent[iid] : 0;
+    }
+    // ---- stage 1: logits^T, PT independent accumulator chains
+    v4 lg[PT];
+#pragma unroll
+    for (int tt = 0; tt < PT; ++tt) lg[tt] = (v4){0.f, 0.f, 0.f, 0.f};
+    {
+      const float4* xb = xt + j * nch + kq;
+      const float4* ta = AlogS + j * g.pitchA4 + kq;
+      for (int gk = 0; gk < g.kg; ++gk) {
+        const float4 bv = xb[4 * gk];
+        float4 av[PT];
+#pragma unroll
+        for (int tt = 0; tt < PT; ++tt) av[tt] = ta[tt * 16 * g.pitchA4 + 4 * gk];
+#pragma unroll
+        for (int tt = 0; tt < PT; ++tt) lg[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[tt].x, bv.x, lg[tt], 0, 0, 0);
+#pragma unroll
+        for (int tt = 0; tt < PT; ++tt) lg[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[tt].y, bv.y, lg[tt], 0, 0, 0);
+#pragma unroll
+        for (int tt = 0; tt < PT; ++tt) lg[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[tt].z, bv.z, lg[tt], 0, 0, 0);
+#pragma unroll
+        for (int tt = 0; tt < PT; ++tt) lg[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[tt].w, bv.w, lg[tt], 0, 0, 0);
+      }
+    }
+    // ---- q overwrites x
+    {
+      int v = lane;
+#pragma unroll
+      for (int jj = 0; jj < J; ++jj) {
+        if (v < total) xt[v] = q[jj];
+        v += 64;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // ---- stage 2a: n^T coordinate tiles (two tiles in flight: independent accumulator chains)
+    v4 accN[CT];
+    const float* tn0 = CnS + kq * g.tpitch + j;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      accN[ct] = (v4){0.f, 0.f, 0.f, 0.f};
+      if (ct < g.ct) {
+        float ta[NP];
+#pragma unroll
+        for (int m = 0; m < NP; ++m) ta[m] = tn0[(16 * (m >> 2) + 4 * (m & 3)) * g.tpitch + 16 * ct];
+#pragma unroll
+        for (int m = 0; m < NP; ++m) accN[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(ta[m], lg[m >> 2][m & 3], accN[ct], 0, 0, 0);
+      }
+    }
+    // ---- s = q . n
+    const float4* qrow = xt + j * nch + kq;
+    float sp = 0.f;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      if (4 * ct + kq < nch) {
+        const float4 qv = qrow[4 * ct];
+        sp = fmaf(qv.x, accN[ct][0], fmaf(qv.y, accN[ct][1], fmaf(qv.z, accN[ct][2], fmaf(qv.w, accN[ct][3], sp))));
+      }
+    }
+    sp += __shfl_xor(sp, 16, 64);
+    const float sfull = sp + __shfl_xor(sp, 32, 64);
+    // ---- stage 2b: r^T tiles and the distance
+    float dsum = 0.f;
+    const float* tr0 = ArS + kq * g.tpitch + j;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      if (ct < g.ct) {
+        float ta[NP];
+#pragma unroll
+        for (int m = 0; m < NP; ++m) ta[m] = tr0[(16 * (m >> 2) + 4 * (m & 3)) * g.tpitch + 16 * ct];
+        const float4 qv = (4 * ct + kq < nch) ? qrow[4 * ct] : f4zero();
+        v4 accR = (v4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int m = 0; m < NP; ++m) accR = __builtin_amdgcn_mfma_f32_16x16x4f32(ta[m], lg[m >> 2][m & 3], accR, 0, 0, 0);
+        dsum += dist1(fmaf(-sfull, accN[ct][0], qv.x + accR[0]), l1) + dist1(fmaf(-sfull, accN[ct][1], qv.y + accR[1]), l1) +
+                dist1(fmaf(-sfull, accN[ct][2], qv.z + accR[2]), l1) + dist1(fmaf(-sfull, accN[ct][3], qv.w + accR[3]), l1);
+      }
+    }
+    dsum += __shfl_xor(dsum, 16, 64);
+    const float score = dsum + __shfl_xor(dsum, 32, 64);
+    if (kq == 0 && row0 + j < a.n) a.score[row0 + j] = score;
+    if (pre) { sid[lane] = nx_u; sid[16 + lane] = nx_i; sid[32 + lane] = nx_e; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+template <int J, int CT, int NP>
+int launch_pref4(const PrefArgs& a, const Fwd4Geom& g, hipStream_t st, const char* name) {
+  const size_t lds = g.table_bytes + (size_t)g.nw * g.wave_bytes;
+  (void)hipFuncSetAttribute((const void*)pref_fwd4_kernel<J, CT, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const int64_t ntiles = (a.n + 15) / 16;
+  const int grid = grid_for((ntiles + g.nw - 1) / g.nw, 256);
+  hipLaunchKernelGGL((pref_fwd4_kernel<J, CT, NP>), dim3(grid), dim3(g.nw * 64), lds, st, a, g);
+  return check_launch(name);
+}
+
+template <int J, int CT>
+int dispatch_fwd4_np(const PrefArgs& a, const Fwd4Geom& g, hipStream_t st, const char* name) {
+  if (g.np <= 1) return launch_pref4<J, CT, 1>(a, g, st, name);
+  if (g.np <= 2) return launch_pref4<J, CT, 2>(a, g, st, name);
+  if (g.np <= 4) return launch_pref4<J, CT, 4>(a, g, st, name);
+  if (g.np <= 5) return launch_pref4<J, CT, 5>(a, g, st, name);
+  return launch_pref4<J, CT, 8>(a, g, st, name);
+}
+
+// soft gate, d <= 128, P <= 32
+bool fwd4_supported(const PrefArgs& a, int d, int P, Fwd4Geom* out) {
+  if (a.gumbel != KTUP_GUMBEL_OFF || d > 128 || P > 32) return false;
+  *out = fwd4_geom(d, P);
+  return out->nw >= 4;
+}
+
+int dispatch_fwd4(const PrefArgs& a, int d, const Fwd4Geom& g, hipStream_t st, const char* name) {
+  if (d <= 64) return dispatch_fwd4_np<4, 4>(a, g, st, name);
+  if (d <= 112) return dispatch_fwd4_np<7, 7>(a, g, st, name);
+  return dispatch_fwd4_np<8, 8>(a, g, st, name);
+}
+
 template <int CH, int NW>
 int launch_pref(bool bwd, const PrefArgs& a, hipStream_t st, const char* name) {
   const int64_t ntiles = (a.n + TR - 1) / TR;
@@ -1080,9 +1329,11 @@ int run_pref(bool bwd, const char* name, const float* U, int64_t ldu, const floa
   hipStream_t st = (hipStream_t)stream;
   if (!bwd) {  // KTUP_PREF_FWD selects the forward variant (A/B measurements); default = tuned kernel, one pair per lane
     const char* env = getenv("KTUP_PREF_FWD");
-    const int variant = env ? atoi(env) : 3;   // 0 = first kernel, 2 = SGPR-FMA kernel, 3 (default) = matrix-core kernel
+    const int variant = env ? atoi(env) : 4;   // 0 = first kernel, 2 = SGPR-FMA kernel, 3 = 32x32x2 MFMA, 4 (default) = 16x16x4 MFMA
+    Fwd4Geom g4;
+    if (variant == 4 && fwd4_supported(a, d, n_pref, &g4)) return dispatch_fwd4(a, d, g4, st, name);
     Fwd3Geom g3;
-    if (variant == 3 && fwd3_supported(a, d, n_pref, &g3)) return dispatch_fwd3(a, d, g3, st, name);
+    if ((variant == 3 || variant == 4) && fwd3_supported(a, d, n_pref, &g3)) return dispatch_fwd3(a, d, g3, st, name);
     if (variant != 0) return dispatch_fwd2(a, d, n_pref, st, name);
   }
   if (g.CH == 4 && g.NW == 4) return launch_pref<4, 4>(bwd, a, st, name);

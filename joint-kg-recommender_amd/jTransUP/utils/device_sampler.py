@@ -1,0 +1,69 @@
+"""On-device negative samplers (K19) with the constraints of the reference's host samplers (jTransUP/utils/data.py:12-85).
+
+The filter structures live on the device for the whole run: one bit per (user, item) for "rated in any split", and the
+sorted 64-bit keys of every known (h, r, t).  Draws are counter-based (Philox), so a (seed, offset) pair reproduces a batch."""
+import numpy as np
+import torch
+
+from jTransUP.hip import lib as L
+from jTransUP.hip.ops import _p, _stream
+
+TRIES = 4096   # counter stride per row inside the kernels
+
+
+class DeviceSampler(object):
+    def __init__(self, device, seed=0):
+        self.device = torch.device(device)
+        self.seed = int(seed) & (2 ** 63 - 1)
+        self.offset = 0
+        self.bitmap = self.keys = None
+        self.n_items = self.n_ent = self.n_rel = 0
+
+    # ---- filter structures
+    def set_rating_dicts(self, user_total, item_total, all_dicts):
+        """all_dicts: [{user: set(items)}, ...] (train + every eval split), as the drivers build them."""
+        words = (item_total + 31) // 32
+        bits = np.zeros((user_total, words), dtype=np.uint32)
+        for dic in all_dicts or []:
+            for u, items in dic.items():
+                it = np.fromiter(items, dtype=np.int64)
+                np.bitwise_or.at(bits[u], it >> 5, (np.uint32(1) << (it & 31).astype(np.uint32)))
+        self.bitmap = torch.from_numpy(bits.view(np.int32)).to(self.device) if all_dicts is not None else None
+        self.n_items, self.words = item_total, words
+
+    def set_triples(self, entity_total, relation_total, triple_lists):
+        """triple_lists: iterable of [(h, t, r), ...] lists (train + every eval split; tail before relation, like the files)."""
+        self.n_ent, self.n_rel = entity_total, relation_total
+        if triple_lists is None:
+            self.keys = None
+            return
+        arr = np.concatenate([np.asarray(tl, dtype=np.uint64).reshape(-1, 3) for tl in triple_lists if len(tl)])
+        keys = (arr[:, 0] * np.uint64(relation_total) + arr[:, 2]) * np.uint64(entity_total) + arr[:, 1]
+        self.keys = torch.from_numpy(np.unique(keys).view(np.int64)).to(self.device)
+
+    # ---- draws
+    def _advance(self, n):
+        off = self.offset
+        self.offset += int(n) * TRIES
+        return off
+
+    @torch.no_grad()
+    def sample_rec(self, u, pos_i, unique_in_batch=True):
+        """-> negative item per (u, pos_i) row; raises if the constraints cannot be met."""
+        n = u.numel()
+        neg = torch.empty(n, dtype=torch.int64, device=self.device)
+        ws = torch.empty((L.load().ktup_negsample_rec_workspace_bytes(self.n_items) + 3) // 4, dtype=torch.int32, device=self.device)
+        L.call('ktup_negsample_rec', _p(u.contiguous()), _p(pos_i.contiguous()), n, self.n_items, _p(self.bitmap),
+               self.words if self.bitmap is not None else 0, self.seed, self._advance(n), int(unique_in_batch), _p(neg), _p(ws),
+               _stream(self.device))
+        return neg
+
+    @torch.no_grad()
+    def sample_kg(self, h, t, r):
+        """-> (neg_h, neg_t): exactly one side corrupted per triple."""
+        n = h.numel()
+        nh = torch.empty(n, dtype=torch.int64, device=self.device)
+        nt = torch.empty(n, dtype=torch.int64, device=self.device)
+        L.call('ktup_negsample_kg', _p(h.contiguous()), _p(t.contiguous()), _p(r.contiguous()), n, self.n_ent, self.n_rel, _p(self.keys),
+               0 if self.keys is None else self.keys.numel(), self.seed, self._advance(n), _p(nh), _p(nt), _stream(self.device))
+        return nh, nt

@@ -1,0 +1,62 @@
+"""GPU checks of the on-device negative samplers (K19): the constraints of utils/data.py:12-85 hold for every draw,
+draws are reproducible from (seed, offset), and the distributions are uniform / fair (no RNG parity with python's MT)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def test_rec_sampler_constraints_and_uniformity():
+    from jTransUP.utils.device_sampler import DeviceSampler
+    rng = np.random.RandomState(0)
+    nu, ni, n = 200, 3240, 512
+    train = {u: set(rng.randint(0, ni, size=165).tolist()) for u in range(nu)}
+    valid = {u: set(rng.randint(0, ni, size=10).tolist()) for u in range(0, nu, 2)}
+    s = DeviceSampler(DEV, seed=3)
+    s.set_rating_dicts(nu, ni, [train, valid])
+    counts = np.zeros(ni)
+    for rep in range(40):
+        u = torch.from_numpy(rng.randint(0, nu, size=n)).to(DEV)
+        pos = torch.from_numpy(np.array([rng.choice(sorted(train[int(x)])) for x in u.cpu()])).to(DEV)
+        neg = s.sample_rec(u, pos).cpu().numpy()
+        assert (neg >= 0).all() and (neg < ni).all()
+        assert len(set(neg.tolist())) == n                                  # unique inside the batch
+        for uu, p, g in zip(u.cpu().tolist(), pos.cpu().tolist(), neg.tolist()):
+            assert g != p and g not in train[uu] and g not in valid.get(uu, ())
+        counts[neg] += 1
+    assert counts.std() / counts.mean() < 0.6                               # ~Poisson(6.3): relative spread ~0.4
+    s2 = DeviceSampler(DEV, seed=3)
+    s2.set_rating_dicts(nu, ni, [train, valid])
+    u = torch.arange(n, device=DEV) % nu; pos = torch.zeros(n, dtype=torch.long, device=DEV)
+    s.offset = s2.offset = 777
+    a, b = s.sample_rec(u, pos, unique_in_batch=False), s2.sample_rec(u, pos, unique_in_batch=False)
+    assert torch.equal(a, b)                                                # (seed, offset) reproduces the batch
+    # impossible request: more rows than admissible items -> -1 markers, no hang
+    tiny = DeviceSampler(DEV, seed=1); tiny.set_rating_dicts(2, 40, [{0: set(range(30))}])
+    out = tiny.sample_rec(torch.zeros(64, dtype=torch.long, device=DEV), torch.zeros(64, dtype=torch.long, device=DEV)).cpu()
+    assert int((out >= 0).sum()) <= 10 and int((out < 0).sum()) >= 54
+
+
+def test_kg_sampler_constraints_and_fair_coin():
+    from jTransUP.utils.device_sampler import DeviceSampler
+    rng = np.random.RandomState(1)
+    ne, nr, n = 500, 7, 4096
+    train = [(int(rng.randint(ne)), int(rng.randint(ne)), int(rng.randint(nr))) for _ in range(20000)]
+    test = [(int(rng.randint(ne)), int(rng.randint(ne)), int(rng.randint(nr))) for _ in range(2000)]
+    known = set(train) | set(test)
+    s = DeviceSampler(DEV, seed=9)
+    s.set_triples(ne, nr, [train, test])
+    batch = [train[i] for i in rng.randint(0, len(train), size=n)]
+    h = torch.tensor([x[0] for x in batch], device=DEV); t = torch.tensor([x[1] for x in batch], device=DEV)
+    r = torch.tensor([x[2] for x in batch], device=DEV)
+    nh, nt = s.sample_kg(h, t, r)
+    heads = 0
+    for (a, b, c), x, y in zip(batch, nh.cpu().tolist(), nt.cpu().tolist()):
+        assert (x != a) != (y != b)                                         # exactly one side corrupted
+        assert (x, y, c) not in known                                        # never a known-true triple
+        heads += x != a
+    assert 0.45 < heads / float(n) < 0.55                                    # fair coin (data.py:13-14)
+    nh2, nt2 = s.sample_kg(h, t, r)
+    assert not (torch.equal(nh, nh2) and torch.equal(nt, nt2))              # the offset advanced

@@ -249,7 +249,7 @@ def main():
                                '716800 (u,i) pairs + 307200 (h,t,r) triples (= 2000 batches of 512 at joint_ratio 0.7), '
                                'tables replicated per GPU', 'rows_per_step_per_gpu': REC_ROWS + KG_ROWS,
                    'users': NU, 'items': NI, 'entities': NE, 'relations': NR, 'd': D},
-        'roofline': {'bound': 'hbm', 'kernel': 'pref_fwd2_kernel<5,5,false> (KTUP rec forward, K6)',
+        'roofline': {'bound': 'hbm', 'kernel': 'pref_fwd4_kernel<7,7,5> (KTUP rec forward, K6; the launch also runs the 20-row pref_prepare_kernel)',
                      'achieved': REC_ROWS * BYTES_REC / (rec_ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': REC_ROWS * BYTES_REC / (rec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 'traffic': hbm_traffic('ktup_rec_forward'),
                      'bytes_per_row': BYTES_REC, 'rows_per_launch': REC_ROWS, 'ms_per_launch': rec_ms,

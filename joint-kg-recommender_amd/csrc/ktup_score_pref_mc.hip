@@ -1,0 +1,344 @@
+// K5-K7 forward, soft gate, compile-time geometry: the matrix-core kernel for the common embedding sizes.
+//
+// Reference path: jTransUP/models/transUP.py:69-82,105-115 (TUP) and jTransUP/models/jTransUP.py:122-143,250-262 (KTUP):
+//   x = u + i (+ e),  logits = x . A^T,  r = logits . Ar,  n = logits . Cn,  q = u - i (- e),
+//   score = sum_k dist( q + r - (q . n) n )_k         (A, Ar, Cn: the mixed / pre-scaled tables of ktup_pref_prepare)
+//
+// Formulation (same as pref_fwd4 in ktup_score_pref.hip): a wave owns 16 pairs; logits^T = A . x^T and then
+// r^T = Ar^T . logits^T, n^T = Cn^T . logits^T on v_mfma_f32_16x16x4_f32, pairs along the MFMA columns, so that the
+// stage-1 accumulators ARE the stage-2 B operands.
+//
+// Why a second kernel: measurements on MI355X (tools/coissue_bench.hip, tools/valu_rate_bench.hip, profiles/) show that
+// fp32 MFMA and VALU instructions do NOT overlap on a gfx950 SIMD -- not inside a wave, not across waves -- so this
+// kernel's time is (MFMA passes + VALU instructions + exposed memory).  pref_fwd4 spends ~4000 clk per tile in MFMA
+// and ~3500 clk in address arithmetic, bounds checks and scalar float4 math, because its geometry is run-time data.
+// Here everything about the geometry is a template constant:
+//   * gather: (row, chunk) of each of a lane's J loads is loop invariant; one v_mad_u64_u32 + one v_lshl_add_u64 per
+//     row load (ids read from LDS with immediate offsets);
+//   * all LDS operand addresses are one base register + immediates; no bounds checks in the matrix phases;
+//   * x / q / distance math on <4 x float> values -> v_pk_add_f32 / v_pk_fma_f32;
+//   * when the last 16-slot preference tile holds <= 4 preferences (P = 20), its logits come from
+//     v_mfma_f32_4x4x1_16B_f32 (16 blocks = 4 pair groups x 4 k-quarters, 8 clk each) instead of a 3/4-empty 16x16x4.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdlib>
+
+#include "ktup_common.h"
+#include "ktup_pref_geom.h"
+
+namespace ktup {
+namespace {
+
+typedef float v4 __attribute__((ext_vector_type(4)));
+
+template <int NCH_, int NP_, bool HASE_>
+struct McGeom {
+  static constexpr int NCH = NCH_, NP = NP_;
+  static constexpr bool HASE = HASE_;
+  static constexpr int D = 4 * NCH;
+  static constexpr int KG = (D + 15) / 16;               // stage-1 k groups of 16 coordinates
+  static constexpr int CT = KG;                          // stage-2 coordinate tiles of 16
+  static constexpr int REM = NP * 4 - ((NP * 4 - 1) / 16) * 16;   // slots used in the last 16-slot tile (multiple of 4)
+  static constexpr bool REM4 = (NP > 4) && REM == 4;     // last tile = one group of <= 4 preferences -> 4x4x1 path
+  static constexpr int PT = (NP + 3) / 4;                // 16-slot preference tiles (including a REM4 tile)
+  static constexpr int PTF = REM4 ? PT - 1 : PT;         // tiles computed with 16x16x4
+  static constexpr int J = (16 * NCH + 63) / 64;         // float4 loads per lane, table and tile
+  static constexpr int TOTAL = 16 * NCH;
+  static constexpr int PITCHA4 = 4 * KG + 1;             // odd float4 pitch of the slot-ordered logit table
+  static constexpr int KQ = (NCH + 3) / 4;               // REM4: float4 chunks per k-quarter
+  static constexpr int TROW = 4 * NP;
+  static constexpr int TPITCH = 16 * CT + ((16 * CT) % 32 == 0 ? 16 : 0);   // == 16 (mod 32)
+  static constexpr int A_F4 = PTF * 16 * PITCHA4;        // float4s of the 16x16x4 logit table
+  static constexpr int A4_F4 = REM4 ? 4 * 4 * KQ : 0;    // REM4 table: [4 prefs][4 quarters][KQ] float4
+  static constexpr int T_F = TROW * TPITCH;              // floats per stage-2 table
+  static constexpr size_t TABLE_BYTES = (size_t)(A_F4 + A4_F4) * 16 + (size_t)2 * T_F * 4;
+  static constexpr int XT_F4 = 16 * NCH + 3;             // x / q tile + 3 zero chunks (stage-1 reads run past the last row)
+  static constexpr size_t WAVE_BYTES = ((size_t)XT_F4 * 16 + 3 * 16 * 4 + 15) & ~(size_t)15;
+  static constexpr int NW_MAX = (int)((160 * 1024 - TABLE_BYTES) / WAVE_BYTES);
+  static constexpr int NW = NW_MAX >= 16 ? 16 : (NW_MAX & ~3);
+};
+
+struct McArgs {
+  const v4 *U, *I, *E;
+  uint32_t ldu4, ldi4, lde4;
+  const int32_t* item2ent;
+  const float *Alog, *Ar, *Cn;   // prepared tables, row pitch dp floats
+  int dp, P, l1;
+  const int64_t *u_ids, *i_ids;
+  int64_t n;
+  float* score;
+};
+
+template <typename G>
+__global__ __launch_bounds__(G::NW * 64) void pref_fwd_mc_kernel(McArgs a) {
+  constexpr int NCH = G::NCH, NP = G::NP, KG = G::KG, CT = G::CT, PTF = G::PTF, J = G::J, TOTAL = G::TOTAL;
+  constexpr int PITCHA4 = G::PITCHA4, TPITCH = G::TPITCH, KQ = G::KQ;
+  constexpr bool HASE = G::HASE, REM4 = G::REM4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  v4* AlogS = reinterpret_cast<v4*>(smem);                       // [PTF * 16 slots][PITCHA4]
+  v4* A4S = AlogS + G::A_F4;                                     // REM4: [4 prefs][4 quarters][KQ]
+  float* CnS = reinterpret_cast<float*>(A4S + G::A4_F4);         // [TROW][TPITCH]
+  float* ArS = CnS + G::T_F;
+  const int t = threadIdx.x, lane = t & 63, kq = lane >> 4, j = lane & 15;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  char* wbase = reinterpret_cast<char*>(ArS + G::T_F) + (size_t)w * G::WAVE_BYTES;
+  v4* xt = reinterpret_cast<v4*>(wbase);                         // [16 * NCH] + 3 zero chunks
+  int32_t* sid = reinterpret_cast<int32_t*>(xt + G::XT_F4);      // [3][16]
+  // ---- stage the tables once per workgroup
+  {
+    const int P = a.P, dp = a.dp;
+    float* AlogSf = reinterpret_cast<float*>(AlogS);
+    constexpr int rowf = PITCHA4 * 4;
+    for (int idx = t; idx < G::A_F4 * 4; idx += G::NW * 64) {
+      const int srow = idx / rowf, k = idx - srow * rowf;
+      const int tt = srow >> 4, i = srow & 15;
+      const int p = 16 * tt + 4 * (i & 3) + (i >> 2);            // slot -> preference (block transposed)
+      AlogSf[idx] = (p < P && k < G::D) ? a.Alog[p * dp + k] : 0.f;
+    }
+    if (REM4) {
+      float* A4Sf = reinterpret_cast<float*>(A4S);
+      for (int idx = t; idx < G::A4_F4 * 4; idx += G::NW * 64) {
+        const int i = idx / (16 * KQ), rem = idx - i * (16 * KQ);
+        const int kp = rem / (4 * KQ), kk = rem - kp * (4 * KQ);
+        const int p = 16 * PTF + i, k = 4 * KQ * kp + kk;
+        A4Sf[idx] = (p < P && k < G::D) ? a.Alog[p * dp + k] : 0.f;
+      }
+    }
+    for (int idx = t; idx < G::T_F; idx += G::NW * 64) {
+      const int p = idx / TPITCH, c = idx - p * TPITCH;
+      const bool ok = p < P && c < G::D;
+      CnS[idx] = ok ? a.Cn[p * dp + c] : 0.f;
+      ArS[idx] = ok ? a.Ar[p * dp + c] : 0.f;
+    }
+    if (lane < 3) xt[16 * NCH + lane] = (v4){0.f, 0.f, 0.f, 0.f};
+  }
+  __syncthreads();
+  // ---- loop-invariant lane geometry
+  int grow[J], gc[J];                                            // (row, chunk) of this lane's jj-th load
+#pragma unroll
+  for (int jj = 0; jj < J; ++jj) {
+    const int e = lane + 64 * jj;
+    const bool past = e >= TOTAL;                                // lanes past the tile re-read chunk 0 of row 0 (never stored)
+    grow[jj] = past ? 0 : e / NCH;
+    gc[jj] = past ? 0 : e % NCH;
+  }
+  const bool last_ok = lane + 64 * (J - 1) < TOTAL;
+  const v4* xb = xt + j * NCH + kq;                              // stage-1 B operand / q rows of this lane
+  const v4* tab = AlogS + j * PITCHA4 + kq;                      // stage-1 A operand
+  const float* tn0 = CnS + kq * TPITCH + j;
+  const float* tr0 = ArS + kq * TPITCH + j;
+  const bool l1 = a.l1 != 0;
+  const int64_t ntiles = (a.n + 15) / 16;
+  const int64_t wstride = (int64_t)gridDim.x * G::NW;
+  bool first = true;
+  for (int64_t tile_id = (int64_t)blockIdx.x * G::NW + w; tile_id < ntiles; tile_id += wstride) {
+    const int64_t row0 = tile_id * 16;
+    if (first && lane < 16) {
+      const int64_t gr = row0 + lane;
+      const bool ok = gr < a.n;
+      const int64_t uid = ok ? a.u_ids[gr] : 0, iid = ok ? a.i_ids[gr] : 0;
+      sid[lane] = (int32_t)uid;
+      sid[16 + lane] = (int32_t)iid;
+      sid[32 + lane] = HASE ? a.item2ent[iid] : 0;
+    }
+    first = false;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // ---- gather: x -> LDS tile, q in registers
+    v4 q[J];
+    {
+      v4 uu[J], vv[J], ee[J];
+#pragma unroll
+      for (int jj = 0; jj < J; ++jj) {
+        asm volatile("" : "+v"(gc[jj]));     // opaque per tile: LICM would hoist 3 x J 64-bit (table + chunk) bases and spill them
+        const uint32_t idu = (uint32_t)sid[grow[jj]], idi = (uint32_t)sid[16 + grow[jj]];
+        uu[jj] = a.U[(uint64_t)idu * a.ldu4 + (uint32_t)gc[jj]];
+        vv[jj] = a.I[(uint64_t)idi * a.ldi4 + (uint32_t)gc[jj]];
+        if (HASE) {
+          const uint32_t ide = (uint32_t)sid[32 + grow[jj]];
+          ee[jj] = a.E[(uint64_t)ide * a.lde4 + (uint32_t)gc[jj]];
+        }
+      }
+#pragma unroll
+      for (int jj = 0; jj < J; ++jj) {
+        const v4 ve = HASE ? vv[jj] + ee[jj] : vv[jj];
+        if (jj < J - 1 || last_ok) xt[lane + 64 * jj] = uu[jj] + ve;
+        q[jj] = uu[jj] - ve;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // ---- next tile's ids travel under the matrix phases
+    int32_t nx_u = 0, nx_i = 0, nx_e = 0;
+    const bool pre = lane < 16 && tile_id + wstride < ntiles;
+    if (pre) {
+      const int64_t gr = (tile_id + wstride) * 16 + lane;
+      const bool ok = gr < a.n;
+      const int64_t uid = ok ? a.u_ids[gr] : 0, iid = ok ? a.i_ids[gr] : 0;
+      nx_u = (int32_t)uid; nx_i = (int32_t)iid;
+      nx_e = HASE ? a.item2ent[iid] : 0;
+    }
+    // ---- stage 1: logits^T.  lg[tt][reg] of lane (kq, pair j) = logit of preference 16 tt + 4 reg + kq
+    v4 lg[G::PT];
+#pragma unroll
+    for (int tt = 0; tt < G::PT; ++tt) lg[tt] = (v4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int gk = 0; gk < KG; ++gk) {
+      v4 bv = xb[4 * gk];
+      if (4 * gk + 3 >= NCH) {                                   // chunks past the row (table is zero there): see REM4 note
+        if (4 * gk + kq >= NCH) bv = (v4){0.f, 0.f, 0.f, 0.f};
+      }
+      v4 av[PTF];
+#pragma unroll
+      for (int tt = 0; tt < PTF; ++tt) av[tt] = tab[tt * 16 * PITCHA4 + 4 * gk];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+#pragma unroll
+        for (int tt = 0; tt < PTF; ++tt) lg[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[tt][c], bv[c], lg[tt], 0, 0, 0);
+      }
+    }
+    if (REM4) {
+      // 16 blocks of 4x4x1: block b = lane >> 2 = (k-quarter kp = b >> 2 == kq, pair group pg = b & 3), A row i = lane & 3
+      // = preference 16 PTF + i, B column jb = lane & 3 = pair 4 pg + jb.  D[reg i] of lane (b, jb) sums over the quarter.
+      const int pg = (lane >> 2) & 3, jb = lane & 3;
+      const v4* a4 = A4S + (jb * 4 + kq) * KQ;                   // row (pref jb, quarter kq)
+      const v4* b4 = xt + (4 * pg + jb) * NCH + kq * KQ;         // pair 4 pg + jb, quarter kq
+      v4 acc = (v4){0.f, 0.f, 0.f, 0.f}, acc1 = acc;              // two chains: a 4x4x1 result is not ready for the next issue slot
+#pragma unroll
+      for (int kk = 0; kk < KQ; ++kk) {
+        const v4 av = a4[kk];
+        v4 bv = b4[kk];
+        if (3 * KQ + kk >= NCH) {                                // the last quarter runs past the row: A is zero there,
+          if (kq * KQ + kk >= NCH) bv = (v4){0.f, 0.f, 0.f, 0.f};   // but keep a neighbour's inf / nan out of 0 * x
+        }
+#pragma unroll
+        for (int c = 0; c < 4; c += 2) {
+          acc = __builtin_amdgcn_mfma_f32_4x4x1f32(av[c], bv[c], acc, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(av[c + 1], bv[c + 1], acc1, 0, 0, 0);
+        }
+      }
+      acc += acc1;
+      // sum the 4 k-quarters (lanes l, l^16, l^32, l^48 hold the same (pair, pref) block position)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float v = acc[c];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        acc[c] = v;
+      }
+      // lane (kq, pair j16 = lane & 15) needs preference 16 PTF + kq of pair j16 = 4 pg + jb: that is acc[kq] of this very lane
+      const float mine = kq == 0 ? acc[0] : kq == 1 ? acc[1] : kq == 2 ? acc[2] : acc[3];
+      lg[PTF] = (v4){mine, 0.f, 0.f, 0.f};
+    }
+    // ---- q overwrites x
+#pragma unroll
+    for (int jj = 0; jj < J; ++jj) {
+      if (jj < J - 1 || last_ok) xt[lane + 64 * jj] = q[jj];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // ---- stage 2a: n^T coordinate tiles
+    v4 accN[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      accN[ct] = (v4){0.f, 0.f, 0.f, 0.f};
+      float ta[NP];
+#pragma unroll
+      for (int m = 0; m < NP; ++m) ta[m] = tn0[(16 * (m >> 2) + 4 * (m & 3)) * TPITCH + 16 * ct];
+#pragma unroll
+      for (int m = 0; m < NP; ++m) accN[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(ta[m], lg[m >> 2][m & 3], accN[ct], 0, 0, 0);
+    }
+    // ---- s = q . n   (lane (kq, j) owns coordinates 16 ct + 4 kq .. + 3 = q chunk 4 ct + kq of pair j)
+    v4 sacc = (v4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      if (4 * ct + 3 < NCH) {
+        sacc += xb[4 * ct] * accN[ct];
+      } else if (4 * ct < NCH) {
+        if (4 * ct + kq < NCH) sacc += xb[4 * ct] * accN[ct];
+      }
+    }
+    float sp = (sacc[0] + sacc[1]) + (sacc[2] + sacc[3]);
+    sp += __shfl_xor(sp, 16, 64);
+    const float sfull = sp + __shfl_xor(sp, 32, 64);
+    const v4 ms = (v4){-sfull, -sfull, -sfull, -sfull};
+    // ---- stage 2b: r^T tiles and the distance
+    v4 dacc = (v4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      float ta[NP];
+#pragma unroll
+      for (int m = 0; m < NP; ++m) ta[m] = tr0[(16 * (m >> 2) + 4 * (m & 3)) * TPITCH + 16 * ct];
+      v4 qv = (v4){0.f, 0.f, 0.f, 0.f};
+      if (4 * ct + 3 < NCH) {
+        qv = xb[4 * ct];
+      } else if (4 * ct < NCH) {
+        if (4 * ct + kq < NCH) qv = xb[4 * ct];
+      }
+      v4 accR = qv;                                              // q + r: start the accumulator at q
+#pragma unroll
+      for (int m = 0; m < NP; ++m) accR = __builtin_amdgcn_mfma_f32_16x16x4f32(ta[m], lg[m >> 2][m & 3], accR, 0, 0, 0);
+      const v4 tv = __builtin_elementwise_fma(ms, accN[ct], accR);
+      if (l1) dacc += __builtin_elementwise_abs(tv);
+      else dacc = __builtin_elementwise_fma(tv, tv, dacc);
+    }
+    float dsum = (dacc[0] + dacc[1]) + (dacc[2] + dacc[3]);
+    dsum += __shfl_xor(dsum, 16, 64);
+    const float score = dsum + __shfl_xor(dsum, 32, 64);
+    if (kq == 0 && row0 + j < a.n) a.score[row0 + j] = score;
+    if (pre) { sid[lane] = nx_u; sid[16 + lane] = nx_i; sid[32 + lane] = nx_e; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+template <typename G>
+int launch_mc(const McArgs& a, hipStream_t st, const char* name) {
+  static_assert(G::NW >= 4, "LDS budget");
+  constexpr size_t lds = G::TABLE_BYTES + (size_t)G::NW * G::WAVE_BYTES;
+  (void)hipFuncSetAttribute((const void*)pref_fwd_mc_kernel<G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const int64_t ntiles = (a.n + 15) / 16;
+  const int grid = grid_for((ntiles + G::NW - 1) / G::NW, 256);
+  hipLaunchKernelGGL((pref_fwd_mc_kernel<G>), dim3(grid), dim3(G::NW * 64), lds, st, a);
+  return check_launch(name);
+}
+
+template <int NCH, int NP>
+int launch_mc_e(const McArgs& a, hipStream_t st, const char* name) {
+  if (a.E) return launch_mc<McGeom<NCH, NP, true>>(a, st, name);
+  return launch_mc<McGeom<NCH, NP, false>>(a, st, name);
+}
+
+template <int NCH>
+int launch_mc_np(const McArgs& a, int np, hipStream_t st, const char* name) {
+  if (np <= 2) return launch_mc_e<NCH, 2>(a, st, name);
+  if (np <= 4) return launch_mc_e<NCH, 4>(a, st, name);
+  if (np <= 5) return launch_mc_e<NCH, 5>(a, st, name);
+  return launch_mc_e<NCH, 8>(a, st, name);
+}
+
+}  // namespace
+
+// Soft gate only.  Returns KTUP_OK / an error, or 1 when (d, P) is not one of the instantiated geometries (the caller
+// then runs the run-time-geometry kernel).
+int pref_fwd_mc(const float* U, int64_t ldu, const float* I, int64_t ldi, const float* E, int64_t lde, const int32_t* item2ent,
+                const float* Alog, const float* Ar, const float* Cn, int dp, int n_pref, int d, const int64_t* u_ids,
+                const int64_t* i_ids, int64_t n, int l1, float* score, hipStream_t st, const char* name) {
+  if (n_pref > 32 || (d != 64 && d != 100 && d != 128)) return 1;
+  if ((ldu | ldi | lde) & 3) return 1;
+  if ((ldu >> 2) > 0xffffffffll || (ldi >> 2) > 0xffffffffll || (lde >> 2) > 0xffffffffll) return 1;
+  McArgs a;
+  a.U = reinterpret_cast<const v4*>(U); a.I = reinterpret_cast<const v4*>(I); a.E = reinterpret_cast<const v4*>(E);
+  a.ldu4 = (uint32_t)(ldu >> 2); a.ldi4 = (uint32_t)(ldi >> 2); a.lde4 = (uint32_t)(lde >> 2);
+  a.item2ent = item2ent;
+  a.Alog = Alog; a.Ar = Ar; a.Cn = Cn;
+  a.dp = dp; a.P = n_pref; a.l1 = l1;
+  a.u_ids = u_ids; a.i_ids = i_ids; a.n = n; a.score = score;
+  const int np = (n_pref + 3) / 4;
+  if (d == 64) return launch_mc_np<16>(a, np, st, name);
+  if (d == 100) return launch_mc_np<25>(a, np, st, name);
+  return launch_mc_np<32>(a, np, st, name);
+}
+
+}  // namespace ktup

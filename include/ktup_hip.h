@@ -55,9 +55,11 @@ int ktup_score_transe_bwd(const float* E, int64_t lde, const float* R, int64_t l
 
 /* ------------------------------------------- K3  TransH  transH.py:58-71 + utils/misc.py:18-19
  * (also the KG branch of KTUP, jTransUP.py:144-157, on its ent/rel/norm tables)                  */
+/* n_rel = rows of R and Nrm (relation_total); when both tables fit 16 KB they are staged in LDS and only
+ * the entity rows are gathered.  Pass 0 if unknown: the relation rows are then gathered per triple.      */
 int ktup_score_transh_fwd(const float* E, int64_t lde, const float* R, int64_t ldr, const float* Nrm, int64_t ldn,
-                          int d, const int64_t* h, const int64_t* t, const int64_t* r, int64_t n, int l1,
-                          float* score, void* stream);
+                          int64_t n_rel, int d, const int64_t* h, const int64_t* t, const int64_t* r, int64_t n,
+                          int l1, float* score, void* stream);
 int ktup_score_transh_bwd(const float* E, int64_t lde, const float* R, int64_t ldr, const float* Nrm, int64_t ldn,
                           int d, const int64_t* h, const int64_t* t, const int64_t* r, int64_t n, int l1,
                           const float* gscore, float* gE, float* gR, float* gN, void* stream);

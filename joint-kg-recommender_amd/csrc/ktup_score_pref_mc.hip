@@ -31,6 +31,28 @@ namespace ktup {
 namespace {
 
 typedef float v4 __attribute__((ext_vector_type(4)));
+typedef unsigned u2 __attribute__((ext_vector_type(2)));
+
+// gfx950 lane swaps (VALU, no LDS): permlane32_swap exchanges lanes 32-63 of its first operand with lanes 0-31 of its
+// second; permlane16_swap exchanges the odd 16-lane rows of the first with the even rows of the second.
+KTUP_DEV float swap32_sum(float a, float b) {   // lanes 0-31: a[l] + a[l+32]; lanes 32-63: b[l-32] + b[l]
+  const u2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+KTUP_DEV float swap16_sum(float a, float b) {   // even rows: a[row] + a[row+1]; odd rows: b[row-1] + b[row]
+  const u2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+KTUP_DEV float allsum_kq(float v) {             // sum over the 4 lanes l, l^16, l^32, l^48, in all of them
+  v = swap32_sum(v, v);
+  return swap16_sum(v, v);
+}
+// reduce-scatter over the same 4 lanes: lane with kq = l >> 4 ends up with the 4-lane sum of component kq
+KTUP_DEV float scatter_kq(const v4& a) {
+  const float v0 = swap32_sum(a[0], a[2]);      // kq 0,1: component 0; kq 2,3: component 2   (summed over l, l^32)
+  const float v1 = swap32_sum(a[1], a[3]);      // kq 0,1: component 1; kq 2,3: component 3
+  return swap16_sum(v0, v1);                    // row kq: component kq
+}
 
 template <int NCH_, int NP_, bool HASE_>
 struct McGeom {
@@ -43,6 +65,9 @@ struct McGeom {
   static constexpr bool REM4 = (NP > 4) && REM == 4;     // last tile = one group of <= 4 preferences -> 4x4x1 path
   static constexpr int PT = (NP + 3) / 4;                // 16-slot preference tiles (including a REM4 tile)
   static constexpr int PTF = REM4 ? PT - 1 : PT;         // tiles computed with 16x16x4
+  static constexpr bool TAIL1 = NCH - 4 * (KG - 1) == 1;  // the last k group / coordinate tile holds ONE float4 chunk (d = 100):
+  static constexpr int KGF = TAIL1 ? KG - 1 : KG;        //   stage 1 finishes with one b32-operand MFMA instead of four,
+  static constexpr int CTF = TAIL1 ? CT - 1 : CT;        //   stage 2 does those 4 coordinates with 4x4x1 MFMAs
   static constexpr int J = (16 * NCH + 63) / 64;         // float4 loads per lane, table and tile
   static constexpr int TOTAL = 16 * NCH;
   static constexpr int PITCHA4 = 4 * KG + 1;             // odd float4 pitch of the slot-ordered logit table
@@ -74,7 +99,8 @@ template <typename G>
 __global__ __launch_bounds__(G::NW * 64) void pref_fwd_mc_kernel(McArgs a) {
   constexpr int NCH = G::NCH, NP = G::NP, KG = G::KG, CT = G::CT, PTF = G::PTF, J = G::J, TOTAL = G::TOTAL;
   constexpr int PITCHA4 = G::PITCHA4, TPITCH = G::TPITCH, KQ = G::KQ;
-  constexpr bool HASE = G::HASE, REM4 = G::REM4;
+  constexpr bool HASE = G::HASE, REM4 = G::REM4, TAIL1 = G::TAIL1;
+  constexpr int KGF = G::KGF, CTF = G::CTF;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   v4* AlogS = reinterpret_cast<v4*>(smem);                       // [PTF * 16 slots][PITCHA4]
   v4* A4S = AlogS + G::A_F4;                                     // REM4: [4 prefs][4 quarters][KQ]
@@ -164,7 +190,7 @@ __global__ __launch_bounds__(G::NW * 64) void pref_fwd_mc_kernel(McArgs a) {
       for (int jj = 0; jj < J; ++jj) {
         const v4 ve = HASE ? vv[jj] + ee[jj] : vv[jj];
         if (jj < J - 1 || last_ok) xt[lane + 64 * jj] = uu[jj] + ve;
-        q[jj] = uu[jj] - ve;
+        q[jj] = uu[jj] + (-ve);
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -184,7 +210,7 @@ __global__ __launch_bounds__(G::NW * 64) void pref_fwd_mc_kernel(McArgs a) {
 #pragma unroll
     for (int tt = 0; tt < G::PT; ++tt) lg[tt] = (v4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int gk = 0; gk < KG; ++gk) {
+    for (int gk = 0; gk < KGF; ++gk) {
       v4 bv = xb[4 * gk];
       if (4 * gk + 3 >= NCH) {                                   // chunks past the row (table is zero there): see REM4 note
         if (4 * gk + kq >= NCH) bv = (v4){0.f, 0.f, 0.f, 0.f};
@@ -196,6 +222,14 @@ __global__ __launch_bounds__(G::NW * 64) void pref_fwd_mc_kernel(McArgs a) {
       for (int c = 0; c < 4; ++c) {
 #pragma unroll
         for (int tt = 0; tt < PTF; ++tt) lg[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[tt][c], bv[c], lg[tt], 0, 0, 0);
+      }
+    }
+    if (TAIL1) {                                                 // coordinates 16 KGF + kq: one MFMA, scalar operands
+      const float bs = reinterpret_cast<const float*>(xt + j * NCH + 4 * KGF)[kq];
+#pragma unroll
+      for (int tt = 0; tt < PTF; ++tt) {
+        const float as = reinterpret_cast<const float*>(AlogS + (tt * 16 + j) * PITCHA4 + 4 * KGF)[kq];
+        lg[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(as, bs, lg[tt], 0, 0, 0);
       }
     }
     if (REM4) {
@@ -219,16 +253,9 @@ __global__ __launch_bounds__(G::NW * 64) void pref_fwd_mc_kernel(McArgs a) {
         }
       }
       acc += acc1;
-      // sum the 4 k-quarters (lanes l, l^16, l^32, l^48 hold the same (pair, pref) block position)
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        float v = acc[c];
-        v += __shfl_xor(v, 16, 64);
-        v += __shfl_xor(v, 32, 64);
-        acc[c] = v;
-      }
-      // lane (kq, pair j16 = lane & 15) needs preference 16 PTF + kq of pair j16 = 4 pg + jb: that is acc[kq] of this very lane
-      const float mine = kq == 0 ? acc[0] : kq == 1 ? acc[1] : kq == 2 ? acc[2] : acc[3];
+      // lane (kq, pair j16 = lane & 15) needs preference 16 PTF + kq of pair j16 = 4 pg + jb, summed over the 4 k-quarters
+      // held by lanes l, l^16, l^32, l^48 (same block position): a reduce-scatter over kq
+      const float mine = scatter_kq(acc);
       lg[PTF] = (v4){mine, 0.f, 0.f, 0.f};
     }
     // ---- q overwrites x
@@ -239,9 +266,9 @@ __global__ __launch_bounds__(G::NW * 64) void pref_fwd_mc_kernel(McArgs a) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     // ---- stage 2a: n^T coordinate tiles
-    v4 accN[CT];
+    v4 accN[CTF];
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct) {
+    for (int ct = 0; ct < CTF; ++ct) {
       accN[ct] = (v4){0.f, 0.f, 0.f, 0.f};
       float ta[NP];
 #pragma unroll
@@ -249,24 +276,39 @@ __global__ __launch_bounds__(G::NW * 64) void pref_fwd_mc_kernel(McArgs a) {
 #pragma unroll
       for (int m = 0; m < NP; ++m) accN[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(ta[m], lg[m >> 2][m & 3], accN[ct], 0, 0, 0);
     }
-    // ---- s = q . n   (lane (kq, j) owns coordinates 16 ct + 4 kq .. + 3 = q chunk 4 ct + kq of pair j)
-    v4 sacc = (v4){0.f, 0.f, 0.f, 0.f};
+    // TAIL1: the last 4 coordinates c0 + i (c0 = 16 CTF) on 4x4x1 blocks.  Block (kq, pair group): A row i = T[kq + 4 s][c0 + i],
+    // B column = logit(kq + 4 s, pair) = lg[s >> 2][s & 3] of THIS lane, k step s.  n4 / r4 of lane (kq, pair) are partial
+    // over the NP preferences {kq + 4 s}; the sum over kq comes with the s reduction (linear) or a reduce-scatter (distance).
+    v4 n4 = (v4){0.f, 0.f, 0.f, 0.f}, r4 = n4, q4 = n4;
+    if (TAIL1) {
+      const float* tn4 = CnS + kq * TPITCH + 16 * CTF + (lane & 3);
+      const float* tr4 = ArS + kq * TPITCH + 16 * CTF + (lane & 3);
+      float tan[NP], tar[NP];
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct) {
+      for (int sidx = 0; sidx < NP; ++sidx) { tan[sidx] = tn4[4 * sidx * TPITCH]; tar[sidx] = tr4[4 * sidx * TPITCH]; }
+#pragma unroll
+      for (int sidx = 0; sidx < NP; ++sidx) {
+        n4 = __builtin_amdgcn_mfma_f32_4x4x1f32(tan[sidx], lg[sidx >> 2][sidx & 3], n4, 0, 0, 0);
+        r4 = __builtin_amdgcn_mfma_f32_4x4x1f32(tar[sidx], lg[sidx >> 2][sidx & 3], r4, 0, 0, 0);
+      }
+      q4 = xt[j * NCH + 4 * CTF];                                // q chunk of coordinates c0 .. c0 + 3 (same for the 4 kq lanes)
+    }
+    // ---- s = q . n   (lane (kq, j) owns coordinates 16 ct + 4 kq .. + 3 = q chunk 4 ct + kq of pair j)
+    v4 sacc = TAIL1 ? q4 * n4 : (v4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ct = 0; ct < CTF; ++ct) {
       if (4 * ct + 3 < NCH) {
         sacc += xb[4 * ct] * accN[ct];
       } else if (4 * ct < NCH) {
         if (4 * ct + kq < NCH) sacc += xb[4 * ct] * accN[ct];
       }
     }
-    float sp = (sacc[0] + sacc[1]) + (sacc[2] + sacc[3]);
-    sp += __shfl_xor(sp, 16, 64);
-    const float sfull = sp + __shfl_xor(sp, 32, 64);
+    const float sfull = allsum_kq((sacc[0] + sacc[1]) + (sacc[2] + sacc[3]));
     const v4 ms = (v4){-sfull, -sfull, -sfull, -sfull};
     // ---- stage 2b: r^T tiles and the distance
     v4 dacc = (v4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct) {
+    for (int ct = 0; ct < CTF; ++ct) {
       float ta[NP];
 #pragma unroll
       for (int m = 0; m < NP; ++m) ta[m] = tr0[(16 * (m >> 2) + 4 * (m & 3)) * TPITCH + 16 * ct];
@@ -283,9 +325,13 @@ __global__ __launch_bounds__(G::NW * 64) void pref_fwd_mc_kernel(McArgs a) {
       if (l1) dacc += __builtin_elementwise_abs(tv);
       else dacc = __builtin_elementwise_fma(tv, tv, dacc);
     }
-    float dsum = (dacc[0] + dacc[1]) + (dacc[2] + dacc[3]);
-    dsum += __shfl_xor(dsum, 16, 64);
-    const float score = dsum + __shfl_xor(dsum, 32, 64);
+    if (TAIL1) {                                                 // lane kq takes coordinate c0 + kq
+      const float nf = scatter_kq(n4), rf = scatter_kq(r4);
+      const float qe = kq == 0 ? q4[0] : kq == 1 ? q4[1] : kq == 2 ? q4[2] : q4[3];
+      const float tv = fmaf(-sfull, nf, qe + rf);
+      dacc[0] += l1 ? fabsf(tv) : tv * tv;
+    }
+    const float score = allsum_kq((dacc[0] + dacc[1]) + (dacc[2] + dacc[3]));
     if (kq == 0 && row0 + j < a.n) a.score[row0 + j] = score;
     if (pre) { sid[lane] = nx_u; sid[16 + lane] = nx_i; sid[32 + lane] = nx_e; }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

@@ -107,6 +107,39 @@ struct TranshFwd {
     if (cx.lane == 0) score[row] = s;
   }
 };
+// K3 forward with both relation tables staged in LDS (n_rel * d small: 16 KB at ml1m).  The generic row kernel gathers
+// 4 rows per triple through the vector-memory path, which is what bounds it (tools/gather_bench.hip: ~16-20 B/clk/CU of
+// scattered 400-byte rows); r and w come from LDS here, so only h and t (the algorithmic bytes) are gathered.
+template <int G>
+__global__ __launch_bounds__(256) void transh_fwd_lds_kernel(TranshFwd op, int nch, int n_rel, int64_t n) {
+  extern __shared__ float4 ktup_transh_tabs[];
+  float4* Rs = ktup_transh_tabs;                 // [n_rel][nch]
+  float4* Ws = ktup_transh_tabs + n_rel * nch;
+  for (int idx = threadIdx.x; idx < n_rel * nch; idx += 256) {
+    const int row = idx / nch, c = idx - row * nch;
+    Rs[idx] = reinterpret_cast<const float4*>(op.R + (int64_t)row * op.ldr)[c];
+    Ws[idx] = reinterpret_cast<const float4*>(op.Nm + (int64_t)row * op.ldn)[c];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x % G;
+  constexpr int GPB = 256 / G;
+  const bool on = lane < nch;
+  for (int64_t row = (int64_t)blockIdx.x * GPB + threadIdx.x / G; row < n; row += (int64_t)gridDim.x * GPB) {
+    const int rr = (int)op.r[row];
+    float4 a = f4zero(), b = f4zero(), c = f4zero(), w = f4zero();
+    if (on) {
+      a = reinterpret_cast<const float4*>(op.E + op.h[row] * op.lde)[lane];
+      b = reinterpret_cast<const float4*>(op.E + op.t[row] * op.lde)[lane];
+      c = Rs[rr * nch + lane];
+      w = Ws[rr * nch + lane];
+    }
+    const float dh = group_sum<G>(dot4(a, w)), dt = group_sum<G>(dot4(b, w));
+    const float4 ph = fma4(-dh, w, a), pt = fma4(-dt, w, b);
+    const float s = group_sum<G>(dist4((ph + c) - pt, op.l1));
+    if (lane == 0) op.score[row] = s;
+  }
+}
+
 // With q = h - t, s = q.w, a = gz.w :  gh = gz - a w, gt = -gh, gr = gz, gw = -s gz - a q.
 struct TranshBwd {
   const float *E, *R, *Nm; int64_t lde, ldr, ldn; const int64_t *h, *t, *r; bool l1; const float* gs;
@@ -261,15 +294,27 @@ extern "C" int ktup_score_transe_bwd(const float* E, int64_t lde, const float* R
 }
 
 extern "C" int ktup_score_transh_fwd(const float* E, int64_t lde, const float* R, int64_t ldr, const float* Nrm, int64_t ldn,
-                                     int d, const int64_t* h, const int64_t* t, const int64_t* r, int64_t n, int l1,
-                                     float* score, void* stream) {
+                                     int64_t n_rel, int d, const int64_t* h, const int64_t* t, const int64_t* r, int64_t n,
+                                     int l1, float* score, void* stream) {
   if (int e = check_common("ktup_score_transh_fwd", d, n)) return e;
   KTUP_NONNULL("ktup_score_transh_fwd", E); KTUP_NONNULL("ktup_score_transh_fwd", R);
   KTUP_NONNULL("ktup_score_transh_fwd", Nrm); KTUP_NONNULL("ktup_score_transh_fwd", h);
   KTUP_NONNULL("ktup_score_transh_fwd", t); KTUP_NONNULL("ktup_score_transh_fwd", r);
   KTUP_NONNULL("ktup_score_transh_fwd", score);
   TranshFwd op{E, R, Nrm, lde, ldr, ldn, h, t, r, l1 != 0, score};
-  return launch_rows(op, d, can_vec4(d, {E, R, Nrm}, {lde, ldr, ldn}), n, (hipStream_t)stream, "ktup_score_transh_fwd");
+  const bool v4ok = can_vec4(d, {E, R, Nrm}, {lde, ldr, ldn});
+  const int64_t tab_bytes = 2 * n_rel * (int64_t)d * 4;
+  if (n > 0 && v4ok && d <= 256 && n_rel > 0 && tab_bytes <= 16 * 1024 && n >= 4 * n_rel) {   // 8 workgroups per CU keep their tables
+    const int nch = d / 4;
+    const int G = nch <= 16 ? 16 : nch <= 32 ? 32 : 64;
+    const int grid = grid_for((n + (256 / G) - 1) / (256 / G));
+    hipStream_t st = (hipStream_t)stream;
+    if (G == 16) hipLaunchKernelGGL(transh_fwd_lds_kernel<16>, dim3(grid), dim3(256), tab_bytes, st, op, nch, (int)n_rel, n);
+    else if (G == 32) hipLaunchKernelGGL(transh_fwd_lds_kernel<32>, dim3(grid), dim3(256), tab_bytes, st, op, nch, (int)n_rel, n);
+    else hipLaunchKernelGGL(transh_fwd_lds_kernel<64>, dim3(grid), dim3(256), tab_bytes, st, op, nch, (int)n_rel, n);
+    return check_launch("ktup_score_transh_fwd");
+  }
+  return launch_rows(op, d, v4ok, n, (hipStream_t)stream, "ktup_score_transh_fwd");
 }
 
 extern "C" int ktup_score_transh_bwd(const float* E, int64_t lde, const float* R, int64_t ldr, const float* Nrm, int64_t ldn,

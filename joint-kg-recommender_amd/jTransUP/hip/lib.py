@@ -27,7 +27,7 @@ SIGNATURES = {
     'ktup_score_bprmf_bwd': [c_p, c_l, c_p, c_l, c_i, c_p, c_p, c_l, c_p, c_p, c_p, c_p],
     'ktup_score_transe_fwd': [c_p, c_l, c_p, c_l, c_i, c_p, c_p, c_p, c_l, c_i, c_p, c_p],
     'ktup_score_transe_bwd': [c_p, c_l, c_p, c_l, c_i, c_p, c_p, c_p, c_l, c_i, c_p, c_p, c_p, c_p],
-    'ktup_score_transh_fwd': [c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_p, c_p, c_p, c_l, c_i, c_p, c_p],
+    'ktup_score_transh_fwd': [c_p, c_l, c_p, c_l, c_p, c_l, c_l, c_i, c_p, c_p, c_p, c_l, c_i, c_p, c_p],
     'ktup_score_transh_bwd': [c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_p, c_p, c_p, c_l, c_i, c_p, c_p, c_p, c_p, c_p],
     'ktup_score_transr_fwd': [c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_p, c_p, c_p, c_l, c_i, c_p, c_p],
     'ktup_score_transr_bwd': [c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_p, c_p, c_p, c_l, c_i, c_p, c_p, c_p, c_p, c_p],
@@ -97,3 +97,19 @@ def call(name, *args):
     rc = getattr(lib, name)(*args)
     if rc != 0:
         raise KtupError('%s failed (%d): %s' % (name, rc, lib.ktup_last_error().decode('utf-8', 'replace')))
+
+
+def bind(name, *args):
+    """Pre-convert the arguments of an int-returning entry point once and return a zero-argument launcher: for loops that
+    issue the SAME launch many times (fixed buffers), where Python-side argument marshalling would otherwise starve the GPU."""
+    lib = load()
+    fn = getattr(lib, name)
+    conv = [a if a is None else t(a) for t, a in zip(fn.argtypes, args)]
+    if len(conv) != len(args):
+        raise KtupError('%s takes %d arguments, got %d' % (name, len(fn.argtypes), len(args)))
+
+    def run():
+        rc = fn(*conv)
+        if rc != 0:
+            raise KtupError('%s failed (%d): %s' % (name, rc, lib.ktup_last_error().decode('utf-8', 'replace')))
+    return run

@@ -105,8 +105,8 @@ class _ScoreTransH(Function):
         dev = _dev(_table('entity table', E)); _table('relation table', R); _table('norm table', N)
         n = h.numel(); h = _ids('h', h, dev); t = _ids('t', t, dev, n); r = _ids('r', r, dev, n)
         score = torch.empty(n, dtype=torch.float32, device=dev)
-        L.call('ktup_score_transh_fwd', _p(E), E.stride(0), _p(R), R.stride(0), _p(N), N.stride(0), E.shape[1], _p(h), _p(t),
-               _p(r), n, int(l1), _p(score), _stream(dev))
+        L.call('ktup_score_transh_fwd', _p(E), E.stride(0), _p(R), R.stride(0), _p(N), N.stride(0), min(R.shape[0], N.shape[0]),
+               E.shape[1], _p(h), _p(t), _p(r), n, int(l1), _p(score), _stream(dev))
         ctx.save_for_backward(E, R, N, h, t, r); ctx.l1 = int(l1)
         return score
 
@@ -191,11 +191,12 @@ class _ScorePref(Function):
     """TUP when E is None, KTUP otherwise."""
 
     @staticmethod
-    def forward(ctx, U, I, E, pref, pref_norm, rel, norm, item2ent, u, i, l1, gumbel_mode, uniform, seed, offset, ent_pad):
+    def forward(ctx, U, I, E, pref, pref_norm, rel, norm, item2ent, u, i, l1, gumbel_mode, uniform, seed, offset, ent_pad, ws):
         dev = _dev(_table('user table', U)); _table('item table', I)
         n = u.numel(); u = _ids('u_ids', u, dev); i = _ids('i_ids', i, dev, n)
         P, d = pref.shape
-        ws = pref_workspace(pref, pref_norm, rel, norm)
+        if ws is None:
+            ws = pref_workspace(pref, pref_norm, rel, norm)
         if gumbel_mode == GUMBEL_INPUT:
             if uniform is None or tuple(uniform.shape) != (n, P) or uniform.dtype != torch.float32 or uniform.device != dev:
                 raise L.KtupError('uniform must be an (n, n_pref) fp32 device tensor')
@@ -228,24 +229,28 @@ class _ScorePref(Function):
         if E is None:
             L.call('ktup_score_tup_bwd', _p(U), U.stride(0), _p(I), I.stride(0), _p(ws), P, d, _p(u), _p(i), n, l1, gumbel_mode,
                    _p(uniform), seed, offset, _p(gs), _p(gU), _p(gI), _p(gA), _p(gC), _stream(dev))
-            return gU, gI, None, gA, gC, None, None, None, None, None, None, None, None, None, None, None
+            return gU, gI, None, gA, gC, None, None, None, None, None, None, None, None, None, None, None, None
         gE = torch.zeros_like(E)
         L.call('ktup_score_ktup_bwd', _p(U), U.stride(0), _p(I), I.stride(0), _p(E), E.stride(0), _p(item2ent), ent_pad, _p(ws), P,
                d, _p(u), _p(i), n, l1, gumbel_mode, _p(uniform), seed, offset, _p(gs), _p(gU), _p(gI), _p(gE), _p(gA), _p(gC),
                _stream(dev))
         # A = pref + rel and C = pref_norm + norm: the mixed-table gradient goes to both summands
-        return gU, gI, gE, gA, gC, gA.clone(), gC.clone(), None, None, None, None, None, None, None, None, None
+        return gU, gI, gE, gA, gC, gA.clone(), gC.clone(), None, None, None, None, None, None, None, None, None, None
 
 
-def score_tup(U, I, pref, pref_norm, u, i, l1, gumbel_mode=GUMBEL_OFF, uniform=None, seed=0, offset=0):
-    """transUP.py:69-82 (forward) with getPreferences / st_gumbel_softmax fused (transUP.py:105-170)."""
-    return _ScorePref.apply(U, I, None, pref, pref_norm, None, None, None, u, i, l1, gumbel_mode, uniform, seed, offset, -1)
+def score_tup(U, I, pref, pref_norm, u, i, l1, gumbel_mode=GUMBEL_OFF, uniform=None, seed=0, offset=0, ws=None):
+    """transUP.py:69-82 (forward) with getPreferences / st_gumbel_softmax fused (transUP.py:105-170).
+    `ws`: a pref_workspace(...) of the CURRENT table contents, to share one ktup_pref_prepare between several calls
+    (pos / neg batches of a step); None prepares one here."""
+    return _ScorePref.apply(U, I, None, pref, pref_norm, None, None, None, u, i, l1, gumbel_mode, uniform, seed, offset, -1, ws)
 
 
 def score_ktup(U, I, E, pref, pref_norm, rel, norm, item2ent, u, i, l1, gumbel_mode=GUMBEL_OFF, uniform=None, seed=0,
-               offset=0, ent_pad=-1):
-    """jTransUP.py:122-143 (is_rec branch) with paddingItems replaced by the int32 `item2ent` device table."""
-    return _ScorePref.apply(U, I, E, pref, pref_norm, rel, norm, item2ent, u, i, l1, gumbel_mode, uniform, seed, offset, ent_pad)
+               offset=0, ent_pad=-1, ws=None):
+    """jTransUP.py:122-143 (is_rec branch) with paddingItems replaced by the int32 `item2ent` device table.  `ws` as in
+    score_tup."""
+    return _ScorePref.apply(U, I, E, pref, pref_norm, rel, norm, item2ent, u, i, l1, gumbel_mode, uniform, seed, offset, ent_pad,
+                            ws)
 
 
 # ------------------------------------------------------------------------------------------ K8-K10 losses

@@ -171,26 +171,35 @@ __global__ __launch_bounds__(G::NW * 64) void pref_fwd_mc_kernel(McArgs a) {
     first = false;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    // ---- gather: x -> LDS tile, q in registers
+    // ---- gather: x -> LDS tile, q in registers.  Two batches of row loads: 16 waves x 3 x JA KB in flight per CU is
+    // already several times the latency-bandwidth product, and 3 x J live float4 would push the kernel past 128 VGPRs.
     v4 q[J];
-    {
-      v4 uu[J], vv[J], ee[J];
+    constexpr int JA = G::NW >= 16 ? (J + 1) / 2 : J;
 #pragma unroll
-      for (int jj = 0; jj < J; ++jj) {
-        asm volatile("" : "+v"(gc[jj]));     // opaque per tile: LICM would hoist 3 x J 64-bit (table + chunk) bases and spill them
-        const uint32_t idu = (uint32_t)sid[grow[jj]], idi = (uint32_t)sid[16 + grow[jj]];
-        uu[jj] = a.U[(uint64_t)idu * a.ldu4 + (uint32_t)gc[jj]];
-        vv[jj] = a.I[(uint64_t)idi * a.ldi4 + (uint32_t)gc[jj]];
-        if (HASE) {
-          const uint32_t ide = (uint32_t)sid[32 + grow[jj]];
-          ee[jj] = a.E[(uint64_t)ide * a.lde4 + (uint32_t)gc[jj]];
+    for (int j0 = 0; j0 < J; j0 += JA) {
+      v4 uu[JA], vv[JA], ee[JA];
+#pragma unroll
+      for (int jb = 0; jb < JA; ++jb) {
+        const int jj = j0 + jb;
+        if (jj < J) {
+          asm volatile("" : "+v"(gc[jj]));   // opaque per tile: LICM would hoist 3 x J 64-bit (table + chunk) bases and spill them
+          const uint32_t idu = (uint32_t)sid[grow[jj]], idi = (uint32_t)sid[16 + grow[jj]];
+          uu[jb] = a.U[(uint64_t)idu * a.ldu4 + (uint32_t)gc[jj]];
+          vv[jb] = a.I[(uint64_t)idi * a.ldi4 + (uint32_t)gc[jj]];
+          if (HASE) {
+            const uint32_t ide = (uint32_t)sid[32 + grow[jj]];
+            ee[jb] = a.E[(uint64_t)ide * a.lde4 + (uint32_t)gc[jj]];
+          }
         }
       }
 #pragma unroll
-      for (int jj = 0; jj < J; ++jj) {
-        const v4 ve = HASE ? vv[jj] + ee[jj] : vv[jj];
-        if (jj < J - 1 || last_ok) xt[lane + 64 * jj] = uu[jj] + ve;
-        q[jj] = uu[jj] + (-ve);
+      for (int jb = 0; jb < JA; ++jb) {
+        const int jj = j0 + jb;
+        if (jj < J) {
+          const v4 ve = HASE ? vv[jb] + ee[jb] : vv[jb];
+          if (jj < J - 1 || last_ok) xt[lane + 64 * jj] = uu[jb] + ve;
+          q[jj] = uu[jb] + (-ve);
+        }
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

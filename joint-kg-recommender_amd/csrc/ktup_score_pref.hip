@@ -289,7 +289,9 @@ __global__ __launch_bounds__(NW * 64) void pref_fwd_kernel(PrefArgs a) {
 // Extra LDS vs forward: gw[TR][ppad], and two more 64 x d tiles (gr and gn) for the table-gradient pass,
 // which maps lane -> coordinate k and loops the tile's 64 pairs; its accumulators live in registers across
 // all tiles of the workgroup and are flushed with one atomic per (p, k) at the end.
-template <int CH, int NW>
+// KS = column slices of the table-gradient pass: its x / gr / gn tiles hold nch / KS chunks per pair (d > 128 does not
+// fit three whole extra tiles in 160 KB of LDS); slice sl = chunks [sl * SW, (sl + 1) * SW) = this wave's j in [sl * CH / KS, ...).
+template <int CH, int NW, int KS>
 __global__ __launch_bounds__(NW * 64) void pref_bwd_kernel(PrefArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NT = NW * 64;
@@ -299,9 +301,11 @@ __global__ __launch_bounds__(NW * 64) void pref_bwd_kernel(PrefArgs a) {
   char* extra = smem + Tile<CH, NW>::bytes(nch, a.lp);
   float* gw = reinterpret_cast<float*>(extra);                 // [TR * lp]  gw then gl
   float* wt = gw + TR * a.lp;                                  // [TR * lp]  mixture weights w
-  float4* tgr = reinterpret_cast<float4*>(wt + TR * a.lp + (TR * a.lp & 3 ? 4 - (TR * a.lp & 3) : 0));  // 16-B aligned
-  float4* tgn = tgr + TR * nch;                                // [TR * nch]   gn
-  float4* tx = tgn + TR * nch;                                 // [TR * nch]   x (again)
+  float4* tgr = reinterpret_cast<float4*>(wt + TR * a.lp + (TR * a.lp & 3 ? 4 - (TR * a.lp & 3) : 0));  // 16-B aligned, [TR * SW] gr
+  static_assert(CH % KS == 0, "slices are whole j ranges");
+  const int SW = KS == 1 ? nch : NW * (CH / KS);               // chunks per slice: c = w + NW j, j in a slice's range
+  float4* tgn = tgr + TR * SW;                                 // [TR * SW]   gn
+  float4* tx = tgn + TR * SW;                                  // [TR * SW]   x (again)
   const int t = threadIdx.x, lane = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
   const bool l1 = a.l1 != 0;
@@ -326,11 +330,13 @@ __global__ __launch_bounds__(NW * 64) void pref_bwd_kernel(PrefArgs a) {
     tile_front<CH, NW>(a, T, row0, t, lane, w, uu, vv);
     // x again (tile_front overwrote the X tile with q), and zero gw
     {
-      const int total = TR * nch;
+      if (KS == 1) {
+        const int total = TR * nch;
 #pragma unroll
-      for (int j = 0; j < CH; ++j) {
-        const int vj = t + NT * j;
-        if (vj < total) tx[vj] = uu[j] + vv[j];
+        for (int j = 0; j < CH; ++j) {
+          const int vj = t + NT * j;
+          if (vj < total) tx[vj] = uu[j] + vv[j];
+        }
       }
       for (int i = t; i < TR * a.lp; i += NT) gw[i] = 0.f;
     }
@@ -399,7 +405,7 @@ __global__ __launch_bounds__(NW * 64) void pref_bwd_kernel(PrefArgs a) {
       gq[j] = fma4(-av, nn[j], gz[j]);
       gn[j] = fma4(-av, q[j], (-s) * gz[j]);
       const int c = w + NW * j;
-      if (c < nch) { tgr[lane * nch + c] = gz[j]; tgn[lane * nch + c] = gn[j]; }
+      if (KS == 1 && c < nch) { tgr[lane * nch + c] = gz[j]; tgn[lane * nch + c] = gn[j]; }
     }
     // ---- gw_p = Ar_p . gr + Cn_p . gn  (Ar, Cn already carry beta), partial over this wave's chunks
     for (int p = 0; p < a.P; ++p) {
@@ -450,23 +456,43 @@ __global__ __launch_bounds__(NW * 64) void pref_bwd_kernel(PrefArgs a) {
         }
       }
     }
-    // ---- table gradients: lane -> coordinate, loop the tile's pairs (gl in gw, w in wt, x / gr / gn tiles)
-    if (tg_active) {
-      const float* fx = reinterpret_cast<const float*>(tx);
-      const float* fgr = reinterpret_cast<const float*>(tgr);
-      const float* fgn = reinterpret_cast<const float*>(tgn);
-      const int p0 = grp * pg;
-      const int64_t rows_here = min((int64_t)TR, a.n - row0);
-      for (int rr = 0; rr < rows_here; ++rr) {
-        const float xk = fx[rr * d + kcol], grk = fgr[rr * d + kcol], gnk = fgn[rr * d + kcol];
-        const float* glr = gw + rr * a.lp + p0;
-        const float* wr = wt + rr * a.lp + p0;
+    // ---- table gradients: lane -> coordinate, loop the tile's pairs (gl in gw, w in wt, x / gr / gn tiles), slice by slice
 #pragma unroll
-        for (int i = 0; i < PGMAX; ++i) {
-          if (i < pg && p0 + i < a.P) {
-            const float wv = wr[i];
-            accA[i] = fmaf(0.5f * glr[i], xk, fmaf(beta * wv, grk, accA[i]));
-            accC[i] = fmaf(beta * wv, gnk, accC[i]);
+    for (int sl = 0; sl < KS; ++sl) {
+      if (KS > 1) {
+        if (sl > 0) __syncthreads();                     // the previous slice has been consumed
+        const int total = TR * nch;
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {                   // x: linear gather mapping
+          const int vj = t + NT * j;
+          const int row = vj / nch, c = vj - row * nch;
+          if (vj < total && c / SW == sl) tx[row * SW + c - sl * SW] = uu[j] + vv[j];
+        }
+#pragma unroll
+        for (int j = sl * (CH / KS); j < (sl + 1) * (CH / KS); ++j) {   // gr / gn: this wave's chunks of the slice
+          const int c = w + NW * j;
+          if (c < nch) { tgr[lane * SW + c - sl * SW] = gz[j]; tgn[lane * SW + c - sl * SW] = gn[j]; }
+        }
+        __syncthreads();
+      }
+      const int k0 = sl * SW * 4;                        // first coordinate of the slice
+      if (tg_active && kcol >= k0 && kcol < k0 + SW * 4) {
+        const float* fx = reinterpret_cast<const float*>(tx);
+        const float* fgr = reinterpret_cast<const float*>(tgr);
+        const float* fgn = reinterpret_cast<const float*>(tgn);
+        const int p0 = grp * pg, ds = SW * 4, kk = kcol - k0;
+        const int64_t rows_here = min((int64_t)TR, a.n - row0);
+        for (int rr = 0; rr < rows_here; ++rr) {
+          const float xk = fx[rr * ds + kk], grk = fgr[rr * ds + kk], gnk = fgn[rr * ds + kk];
+          const float* glr = gw + rr * a.lp + p0;
+          const float* wr = wt + rr * a.lp + p0;
+#pragma unroll
+          for (int i = 0; i < PGMAX; ++i) {
+            if (i < pg && p0 + i < a.P) {
+              const float wv = wr[i];
+              accA[i] = fmaf(0.5f * glr[i], xk, fmaf(beta * wv, grk, accA[i]));
+              accC[i] = fmaf(beta * wv, gnk, accC[i]);
+            }
           }
         }
       }
@@ -1540,13 +1566,23 @@ template <int CH, int NW>
 int launch_pref(bool bwd, const PrefArgs& a, hipStream_t st, const char* name) {
   const int64_t ntiles = (a.n + TR - 1) / TR;
   size_t lds = Tile<CH, NW>::bytes(a.nch, a.lp);
-  if (bwd) lds += (size_t)2 * TR * a.lp * 4 + 16 + (size_t)3 * TR * a.nch * 16;
+  const size_t bwd_fixed = (size_t)2 * TR * a.lp * 4 + 16;
+  constexpr int KSL = (CH % 4 == 0) ? 4 : 1;            // sliced variant instantiated for the wide geometries only
+  bool sliced = false;
+  if (bwd) {
+    const size_t whole = lds + bwd_fixed + (size_t)3 * TR * a.nch * 16;
+    sliced = whole > 160 * 1024 && KSL > 1;
+    lds += bwd_fixed + (size_t)3 * TR * (sliced ? NW * (CH / KSL) : a.nch) * 16;
+  }
   if (lds > 160 * 1024) return set_error(KTUP_ERR_UNSUPPORTED, "%s: tile needs %zu B of LDS", name, lds);
   const int grid = grid_for(ntiles, 256 * 4);
-  if (bwd) {
+  if (bwd && sliced) {
+    (void)hipFuncSetAttribute((const void*)pref_bwd_kernel<CH, NW, KSL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((pref_bwd_kernel<CH, NW, KSL>), dim3(grid), dim3(NW * 64), lds, st, a);
+  } else if (bwd) {
     if (lds > 64 * 1024)
-      (void)hipFuncSetAttribute((const void*)pref_bwd_kernel<CH, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((pref_bwd_kernel<CH, NW>), dim3(grid), dim3(NW * 64), lds, st, a);
+      (void)hipFuncSetAttribute((const void*)pref_bwd_kernel<CH, NW, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((pref_bwd_kernel<CH, NW, 1>), dim3(grid), dim3(NW * 64), lds, st, a);
   } else {
     if (lds > 64 * 1024)
       (void)hipFuncSetAttribute((const void*)pref_fwd_kernel<CH, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

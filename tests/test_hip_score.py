@@ -201,7 +201,7 @@ def test_odd_and_unaligned_tables_vs_oracle(d):
         close(ops().score_bprmf(Ed, Ed, h.to(DEV), t.to(DEV)), O.score_bprmf(E, E, h, t))
 
 
-@pytest.mark.parametrize('d,npref', [(100, 20), (64, 4), (128, 13), (256, 20), (8, 33)])
+@pytest.mark.parametrize('d,npref', [(100, 20), (64, 4), (128, 13), (256, 20), (200, 20), (8, 33)])
 def test_ml1m_shape_vs_oracle_fwd_bwd(d, npref):
     """ml1m-shape tables (scaled down in rows for d=256), B=512*3 pairs, forward and full backward."""
     nu, ni, ne = (6040, 3240, 14708) if d <= 128 else (600, 300, 1500)

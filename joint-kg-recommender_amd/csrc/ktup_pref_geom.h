@@ -76,10 +76,11 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 typedef const __attribute__((address_space(4))) v16f* sptr16;  // 64-byte scalar loads (s_load_dwordx16)
 KTUP_DEV sptr16 as_scalar16(const float* p) { return (sptr16)(uintptr_t)p; }
 
-// ktup_score_pref_mc.hip: compile-time-geometry matrix-core forward (soft gate).  Returns 1 when (d, n_pref) is not an
+// ktup_score_pref_mc.hip: compile-time-geometry matrix-core forward (soft gate and ST-Gumbel gate).  Returns 1 when (d, n_pref) is not an
 // instantiated geometry.
 int pref_fwd_mc(const float* U, int64_t ldu, const float* I, int64_t ldi, const float* E, int64_t lde, const int32_t* item2ent,
                 const float* Alog, const float* Ar, const float* Cn, int dp, int n_pref, int d, const int64_t* u_ids,
-                const int64_t* i_ids, int64_t n, int l1, float* score, hipStream_t st, const char* name);
+                const int64_t* i_ids, int64_t n, int l1, int gumbel_mode, const float* uniform, uint64_t seed, uint64_t offset,
+                float* score, hipStream_t st, const char* name);
 
 }  // namespace ktup

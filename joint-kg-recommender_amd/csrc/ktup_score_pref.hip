@@ -1637,11 +1637,11 @@ int run_pref(bool bwd, const char* name, const float* U, int64_t ldu, const floa
   if (!bwd) {  // KTUP_PREF_FWD selects the forward variant (A/B measurements); default = tuned kernel, one pair per lane
     const char* env = getenv("KTUP_PREF_FWD");
     const int variant = env ? atoi(env) : 7;   // 0 = first kernel, 2 = SGPR-FMA kernel, 3 = 32x32x2 MFMA, 4 (default) = 16x16x4 MFMA
-    if (variant == 7 && a.gumbel == KTUP_GUMBEL_OFF) {
+    if (variant == 7) {
       const int rc = pref_fwd_mc(reinterpret_cast<const float*>(a.U), a.ldu4 * 4, reinterpret_cast<const float*>(a.I), a.ldi4 * 4,
                                  reinterpret_cast<const float*>(a.E), a.lde4 * 4, a.item2ent, reinterpret_cast<const float*>(a.Alog),
                                  reinterpret_cast<const float*>(a.Ar), reinterpret_cast<const float*>(a.Cn), a.dp4 * 4, n_pref, d,
-                                 a.u_ids, a.i_ids, a.n, a.l1, a.score, st, name);
+                                 a.u_ids, a.i_ids, a.n, a.l1, a.gumbel, a.uniform, a.seed, a.offset, a.score, st, name);
       if (rc != 1) return rc;
     }
     Fwd4Geom g4;

@@ -54,10 +54,10 @@ KTUP_DEV float scatter_kq(const v4& a) {
   return swap16_sum(v0, v1);                    // row kq: component kq
 }
 
-template <int NCH_, int NP_, bool HASE_>
+template <int NCH_, int NP_, bool HASE_, bool HARD_>
 struct McGeom {
   static constexpr int NCH = NCH_, NP = NP_;
-  static constexpr bool HASE = HASE_;
+  static constexpr bool HASE = HASE_, HARD = HARD_;   // HARD: straight-through Gumbel gate (forward value = one-hot)
   static constexpr int D = 4 * NCH;
   static constexpr int KG = (D + 15) / 16;               // stage-1 k groups of 16 coordinates
   static constexpr int CT = KG;                          // stage-2 coordinate tiles of 16
@@ -76,10 +76,12 @@ struct McGeom {
   static constexpr int TPITCH = 16 * CT + ((16 * CT) % 32 == 0 ? 16 : 0);   // == 16 (mod 32)
   static constexpr int A_F4 = PTF * 16 * PITCHA4;        // float4s of the 16x16x4 logit table
   static constexpr int A4_F4 = REM4 ? 4 * 4 * KQ : 0;    // REM4 table: [4 prefs][4 quarters][KQ] float4
-  static constexpr int T_F = TROW * TPITCH;              // floats per stage-2 table
+  static constexpr int HP = NCH | 1;                     // HARD: odd float4 pitch of the row-major tables (one row is looked up per pair)
+  static constexpr int T_F = HARD ? TROW * HP * 4 : TROW * TPITCH;   // floats per stage-2 table
   static constexpr size_t TABLE_BYTES = (size_t)(A_F4 + A4_F4) * 16 + (size_t)2 * T_F * 4;
   static constexpr int XT_F4 = 16 * NCH + 3;             // x / q tile + 3 zero chunks (stage-1 reads run past the last row)
-  static constexpr size_t WAVE_BYTES = ((size_t)XT_F4 * 16 + 3 * 16 * 4 + 15) & ~(size_t)15;
+  static constexpr int NOISE_F = HARD ? 16 * TROW : 0;   // HARD: Gumbel noise of the tile, [pair][preference]
+  static constexpr size_t WAVE_BYTES = ((size_t)XT_F4 * 16 + 3 * 16 * 4 + (size_t)NOISE_F * 4 + 15) & ~(size_t)15;
   static constexpr int NW_MAX = (int)((160 * 1024 - TABLE_BYTES) / WAVE_BYTES);
   static constexpr int NW = NW_MAX >= 16 ? 16 : (NW_MAX & ~3);
 };
@@ -90,6 +92,9 @@ struct McArgs {
   const int32_t* item2ent;
   const float *Alog, *Ar, *Cn;   // prepared tables, row pitch dp floats
   int dp, P, l1;
+  int gumbel;                    // KTUP_GUMBEL_* (HARD kernels): INPUT reads `uniform` (n x P), PHILOX draws (seed, offset)
+  const float* uniform;
+  uint64_t seed, offset;
   const int64_t *u_ids, *i_ids;
   int64_t n;
   float* score;
@@ -99,7 +104,8 @@ template <typename G>
 __global__ __launch_bounds__(G::NW * 64) void pref_fwd_mc_kernel(McArgs a) {
   constexpr int NCH = G::NCH, NP = G::NP, KG = G::KG, CT = G::CT, PTF = G::PTF, J = G::J, TOTAL = G::TOTAL;
   constexpr int PITCHA4 = G::PITCHA4, TPITCH = G::TPITCH, KQ = G::KQ;
-  constexpr bool HASE = G::HASE, REM4 = G::REM4, TAIL1 = G::TAIL1;
+  constexpr bool HASE = G::HASE, REM4 = G::REM4, TAIL1 = G::TAIL1, HARD = G::HARD;
+  constexpr int HP = G::HP;
   constexpr int KGF = G::KGF, CTF = G::CTF;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   v4* AlogS = reinterpret_cast<v4*>(smem);                       // [PTF * 16 slots][PITCHA4]
@@ -111,6 +117,7 @@ __global__ __launch_bounds__(G::NW * 64) void pref_fwd_mc_kernel(McArgs a) {
   char* wbase = reinterpret_cast<char*>(ArS + G::T_F) + (size_t)w * G::WAVE_BYTES;
   v4* xt = reinterpret_cast<v4*>(wbase);                         // [16 * NCH] + 3 zero chunks
   int32_t* sid = reinterpret_cast<int32_t*>(xt + G::XT_F4);      // [3][16]
+  float* noise = reinterpret_cast<float*>(sid + 48);             // HARD: [16][TROW]
   // ---- stage the tables once per workgroup
   {
     const int P = a.P, dp = a.dp;
@@ -132,7 +139,8 @@ __global__ __launch_bounds__(G::NW * 64) void pref_fwd_mc_kernel(McArgs a) {
       }
     }
     for (int idx = t; idx < G::T_F; idx += G::NW * 64) {
-      const int p = idx / TPITCH, c = idx - p * TPITCH;
+      const int pitch = HARD ? HP * 4 : TPITCH;
+      const int p = idx / pitch, c = idx - p * pitch;
       const bool ok = p < P && c < G::D;
       CnS[idx] = ok ? a.Cn[p * dp + c] : 0.f;
       ArS[idx] = ok ? a.Ar[p * dp + c] : 0.f;
@@ -272,6 +280,85 @@ __global__ __launch_bounds__(G::NW * 64) void pref_fwd_mc_kernel(McArgs a) {
     for (int jj = 0; jj < J; ++jj) {
       if (jj < J - 1 || last_ok) xt[lane + 64 * jj] = q[jj];
     }
+    v4 dacc = (v4){0.f, 0.f, 0.f, 0.f};
+    if constexpr (HARD) {
+      // ---- ST-Gumbel gate (transUP.py:118-170): y = one_hot(argmax_p(logit_p + g_p)), g = -log(-log(u + eps) + eps); the
+      // forward value of the straight-through estimator is exactly the one-hot, so r = Ar[p*], n = Cn[p*].
+      const int64_t grow = min(row0 + j, a.n - 1);
+      const uint64_t base = (uint64_t)grow * (uint64_t)a.P;
+      float best = -INFINITY;
+      int bp = 0x7fffffff;
+      if (a.gumbel == KTUP_GUMBEL_PHILOX) {
+        // same stream as the other kernels (ktup_score_pref.hip draw_uniform): word (idx & 3) of Philox block idx >> 2,
+        // idx = grow * P + p + offset.  The 4 kq lanes of a pair share its <= P/4 + 1 blocks and trade through LDS.
+        const uint64_t i0 = base + a.offset, fb = i0 >> 2, lb = (i0 + (uint64_t)a.P - 1) >> 2;
+        const Philox ph(a.seed);
+        for (uint64_t b = fb + kq; b <= lb; b += 4) {
+          const uint4 r = ph(b, 0x4b545550ull /* "KTUP" stream tag */);
+          const uint32_t wds[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+          for (int wd = 0; wd < 4; ++wd) {
+            const int64_t pp = (int64_t)((b << 2) + wd) - (int64_t)i0;
+            if (pp >= 0 && pp < a.P) noise[j * G::TROW + (int)pp] = gumbel_from_uniform(u01(wds[wd]));
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
+#pragma unroll
+      for (int sidx = 0; sidx < NP; ++sidx) {                    // ascending p: strict > keeps the first maximum (torch.max)
+        const int pp = 4 * sidx + kq;
+        if (pp < a.P) {
+          const float g = a.gumbel == KTUP_GUMBEL_PHILOX ? noise[j * G::TROW + pp] : gumbel_from_uniform(a.uniform[base + pp]);
+          const float v = lg[sidx >> 2][sidx & 3] + g;
+          if (v > best || bp == 0x7fffffff) { best = v; bp = pp; }
+        }
+      }
+      // first-max over the 4 kq lanes: (value, preference) pairs, lower preference wins ties
+      {
+        const u2 rv = __builtin_amdgcn_permlane32_swap(__float_as_uint(best), __float_as_uint(best), false, false);
+        const u2 rp = __builtin_amdgcn_permlane32_swap((unsigned)bp, (unsigned)bp, false, false);
+        const float v0 = __uint_as_float(rv[0]), v1 = __uint_as_float(rv[1]);
+        const int p0 = (int)rp[0], p1 = (int)rp[1];
+        const bool take1 = p0 == 0x7fffffff || (p1 != 0x7fffffff && (v1 > v0 || (v1 == v0 && p1 < p0)));
+        best = take1 ? v1 : v0; bp = take1 ? p1 : p0;
+      }
+      {
+        const u2 rv = __builtin_amdgcn_permlane16_swap(__float_as_uint(best), __float_as_uint(best), false, false);
+        const u2 rp = __builtin_amdgcn_permlane16_swap((unsigned)bp, (unsigned)bp, false, false);
+        const float v0 = __uint_as_float(rv[0]), v1 = __uint_as_float(rv[1]);
+        const int p0 = (int)rp[0], p1 = (int)rp[1];
+        const bool take1 = p0 == 0x7fffffff || (p1 != 0x7fffffff && (v1 > v0 || (v1 == v0 && p1 < p0)));
+        bp = take1 ? p1 : p0;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // q tile written above
+      __builtin_amdgcn_wave_barrier();
+      const v4* nrow = reinterpret_cast<const v4*>(CnS) + bp * HP + kq;
+      const v4* rrow = reinterpret_cast<const v4*>(ArS) + bp * HP + kq;
+      v4 sacc = (v4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {                          // lane (kq, j) owns q chunks 4 ct + kq
+        if (4 * ct + 3 < NCH) {
+          sacc += xb[4 * ct] * nrow[4 * ct];
+        } else if (4 * ct < NCH) {
+          if (4 * ct + kq < NCH) sacc += xb[4 * ct] * nrow[4 * ct];
+        }
+      }
+      const float sfull = allsum_kq((sacc[0] + sacc[1]) + (sacc[2] + sacc[3]));
+      const v4 ms = (v4){-sfull, -sfull, -sfull, -sfull};
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        bool on = 4 * ct + 3 < NCH;
+        if (!on && 4 * ct < NCH) on = 4 * ct + kq < NCH;
+        if (4 * ct < NCH) {
+          if (on) {
+            const v4 tv = __builtin_elementwise_fma(ms, nrow[4 * ct], xb[4 * ct] + rrow[4 * ct]);
+            if (l1) dacc += __builtin_elementwise_abs(tv);
+            else dacc = __builtin_elementwise_fma(tv, tv, dacc);
+          }
+        }
+      }
+    } else {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     // ---- stage 2a: n^T coordinate tiles
@@ -315,7 +402,6 @@ __global__ __launch_bounds__(G::NW * 64) void pref_fwd_mc_kernel(McArgs a) {
     const float sfull = allsum_kq((sacc[0] + sacc[1]) + (sacc[2] + sacc[3]));
     const v4 ms = (v4){-sfull, -sfull, -sfull, -sfull};
     // ---- stage 2b: r^T tiles and the distance
-    v4 dacc = (v4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ct = 0; ct < CTF; ++ct) {
       float ta[NP];
@@ -340,6 +426,7 @@ __global__ __launch_bounds__(G::NW * 64) void pref_fwd_mc_kernel(McArgs a) {
       const float tv = fmaf(-sfull, nf, qe + rf);
       dacc[0] += l1 ? fabsf(tv) : tv * tv;
     }
+    }
     const float score = allsum_kq((dacc[0] + dacc[1]) + (dacc[2] + dacc[3]));
     if (kq == 0 && row0 + j < a.n) a.score[row0 + j] = score;
     if (pre) { sid[lane] = nx_u; sid[16 + lane] = nx_i; sid[32 + lane] = nx_e; }
@@ -361,8 +448,12 @@ int launch_mc(const McArgs& a, hipStream_t st, const char* name) {
 
 template <int NCH, int NP>
 int launch_mc_e(const McArgs& a, hipStream_t st, const char* name) {
-  if (a.E) return launch_mc<McGeom<NCH, NP, true>>(a, st, name);
-  return launch_mc<McGeom<NCH, NP, false>>(a, st, name);
+  if (a.gumbel != KTUP_GUMBEL_OFF) {
+    if (a.E) return launch_mc<McGeom<NCH, NP, true, true>>(a, st, name);
+    return launch_mc<McGeom<NCH, NP, false, true>>(a, st, name);
+  }
+  if (a.E) return launch_mc<McGeom<NCH, NP, true, false>>(a, st, name);
+  return launch_mc<McGeom<NCH, NP, false, false>>(a, st, name);
 }
 
 template <int NCH>
@@ -375,11 +466,12 @@ int launch_mc_np(const McArgs& a, int np, hipStream_t st, const char* name) {
 
 }  // namespace
 
-// Soft gate only.  Returns KTUP_OK / an error, or 1 when (d, P) is not one of the instantiated geometries (the caller
-// then runs the run-time-geometry kernel).
+// Returns KTUP_OK / an error, or 1 when (d, P) is not one of the instantiated geometries (the caller then runs the
+// run-time-geometry kernel).
 int pref_fwd_mc(const float* U, int64_t ldu, const float* I, int64_t ldi, const float* E, int64_t lde, const int32_t* item2ent,
                 const float* Alog, const float* Ar, const float* Cn, int dp, int n_pref, int d, const int64_t* u_ids,
-                const int64_t* i_ids, int64_t n, int l1, float* score, hipStream_t st, const char* name) {
+                const int64_t* i_ids, int64_t n, int l1, int gumbel_mode, const float* uniform, uint64_t seed, uint64_t offset,
+                float* score, hipStream_t st, const char* name) {
   if (n_pref > 32 || (d != 64 && d != 100 && d != 128)) return 1;
   if ((ldu | ldi | lde) & 3) return 1;
   if ((ldu >> 2) > 0xffffffffll || (ldi >> 2) > 0xffffffffll || (lde >> 2) > 0xffffffffll) return 1;
@@ -389,6 +481,7 @@ int pref_fwd_mc(const float* U, int64_t ldu, const float* I, int64_t ldi, const 
   a.item2ent = item2ent;
   a.Alog = Alog; a.Ar = Ar; a.Cn = Cn;
   a.dp = dp; a.P = n_pref; a.l1 = l1;
+  a.gumbel = gumbel_mode; a.uniform = uniform; a.seed = seed; a.offset = offset;
   a.u_ids = u_ids; a.i_ids = i_ids; a.n = n; a.score = score;
   const int np = (n_pref + 3) / 4;
   if (d == 64) return launch_mc_np<16>(a, np, st, name);

@@ -90,40 +90,52 @@ def cpu_baseline(W, i2e, idx, budget_s=14.0):
 
 def train_step_bench(device, steps=200, warmup=20):
     """Secondary figure: the reference's B=512 joint training step (forward pos+neg, loss, backward, global-norm clip,
-    dense Adagrad step) through the drop-in module, 7 rec : 3 kg."""
+    dense Adagrad step with weight decay) through the drop-in module, 7 rec : 3 kg; clip + step either by torch
+    (clip_grad_norm_ + torch.optim) or by the two K20 launches (utils/fused_optim.py)."""
     from jTransUP.models import jTransUP as jt
-    torch.manual_seed(3)
-    i_map = {i: i for i in range(NI)}
-    new_map = {i: ((i * 4) % NE if i < ALIGNED else -1, i) for i in range(NI)}
-    m = jt.jTransUPModel(False, D, NU, NI, NE, NR, i_map, new_map, False, False)
-    opt = torch.optim.Adagrad(m.parameters(), lr=0.005, weight_decay=1e-5)
+    from jTransUP.utils.fused_optim import FusedOptimizer
     B = 512
     gen = torch.Generator().manual_seed(5)
     mk = lambda hi: torch.randint(0, hi, (steps + warmup, B), generator=gen).to(device)
     u, pi, ni_, h, t, nh, nt, r = mk(NU), mk(NI), mk(NI), mk(NE), mk(NE), mk(NE), mk(NE), mk(NR)
+    out = {'batch': B, 'steps': steps}
+    for mode in ('torch', 'fused'):
+        torch.manual_seed(3)
+        i_map = {i: i for i in range(NI)}
+        new_map = {i: ((i * 4) % NE if i < ALIGNED else -1, i) for i in range(NI)}
+        m = jt.jTransUPModel(False, D, NU, NI, NE, NR, i_map, new_map, False, False)
+        opt = torch.optim.Adagrad(m.parameters(), lr=0.005, weight_decay=1e-5)
+        fused = FusedOptimizer(opt) if mode == 'fused' else None
+        params = list(m.parameters())
 
-    def step(s):
-        opt.zero_grad(set_to_none=True)
-        if s % 10 < 7:
-            pos = m((u[s], pi[s]), None, is_rec=True); neg = m((u[s], ni_[s]), None, is_rec=True)
-            loss = (-F.logsigmoid(-(pos - neg))).mean()
-        else:
-            pos = m(None, (h[s], t[s], r[s]), is_rec=False); neg = m(None, (nh[s], nt[s], r[s]), is_rec=False)
-            loss = torch.sum(torch.clamp(pos - neg + 1.0, min=0.0))
-        loss.backward()
-        torch.nn.utils.clip_grad_norm_(m.parameters(), 5.0)
-        opt.step()
+        def step(s):
+            opt.zero_grad(set_to_none=False)
+            if s % 10 < 7:
+                pos = m((u[s], pi[s]), None, is_rec=True); neg = m((u[s], ni_[s]), None, is_rec=True)
+                loss = (-F.logsigmoid(-(pos - neg))).mean()
+            else:
+                pos = m(None, (h[s], t[s], r[s]), is_rec=False); neg = m(None, (nh[s], nt[s], r[s]), is_rec=False)
+                loss = torch.sum(torch.clamp(pos - neg + 1.0, min=0.0))
+            loss.backward()
+            if fused is not None:
+                fused.clip_and_step(5.0)
+            else:
+                torch.nn.utils.clip_grad_norm_(params, 5.0)
+                opt.step()
 
-    for s in range(warmup):
-        step(s)
-    torch.cuda.synchronize(device)
-    t0 = time.perf_counter()
-    for s in range(warmup, warmup + steps):
-        step(s)
-    torch.cuda.synchronize(device)
-    dt = time.perf_counter() - t0
-    return {'batch': B, 'steps': steps, 'ms_per_step': 1e3 * dt / steps, 'scored_rows_per_s': 2 * B * steps / dt,
-            'note': 'fwd pos+neg, loss, bwd, clip_grad_norm, dense Adagrad (torch.optim); eager launches, no graph'}
+        for s in range(warmup):
+            step(s)
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for s in range(warmup, warmup + steps):
+            step(s)
+        torch.cuda.synchronize(device)
+        dt = time.perf_counter() - t0
+        out['ms_per_step_' + mode] = 1e3 * dt / steps
+    out['ms_per_step'] = out['ms_per_step_fused']
+    out['scored_rows_per_s'] = 2 * B / (out['ms_per_step'] * 1e-3)
+    out['note'] = 'fwd pos+neg, loss, bwd, clip, dense Adagrad; eager launches, no graph; fused = K20 clip+step in two launches'
+    return out
 
 
 def eval_bench(device, batch=512, seed=11):

@@ -202,6 +202,26 @@ int ktup_negsample_kg(const int64_t* h, const int64_t* t, const int64_t* r, int6
                       const uint64_t* sorted_keys, int64_t n_keys, uint64_t seed, uint64_t offset, int64_t* neg_h,
                       int64_t* neg_t, void* stream);
 
+/* ------------------------------------------- K20  global-norm clip + dense optimizer step
+ * Replaces   torch.nn.utils.clip_grad_norm(params, max_norm); optimizer.step()
+ * (item_recommendation.py:189-192, knowledge_representation.py:209-211, knowledgable_recommendation.py:399-401) for the
+ * optimizers of utils/trainer.py:63-77 with weight_decay = l2_lambda, in two launches over a list of tables.
+ * `params/grads/state1/state2/sizes/steps/first` are HOST arrays of n_tensors entries (device pointers, element counts,
+ * each tensor's own 1-based step count for Adam, 1 where a momentum buffer is still uninitialised).
+ * state1 / state2:  SGD momentum_buffer / -;  Adagrad sum / -;  Adam exp_avg / exp_avg_sq;  RMSprop square_avg /
+ * momentum_buffer.  The clip factor min(1, max_norm / (||g|| + 1e-6)) is applied to the gradients in place, like
+ * clip_grad_norm_; max_norm <= 0 disables clipping (sumsq, one device double, may then be NULL).                    */
+#define KTUP_OPTIM_MAX_TENSORS 12
+#define KTUP_OPT_SGD 0
+#define KTUP_OPT_ADAGRAD 1
+#define KTUP_OPT_ADAM 2
+#define KTUP_OPT_RMSPROP 3
+int ktup_optim_gradnorm(int n_tensors, float* const* grads, const int64_t* sizes, double* sumsq, void* stream);
+int ktup_optim_step(int kind, int n_tensors, float* const* params, float* const* grads, float* const* state1,
+                    float* const* state2, const int64_t* sizes, const int64_t* steps, const int32_t* first, float lr,
+                    float weight_decay, float momentum, float beta1, float beta2, float eps, float alpha,
+                    const double* sumsq, float max_norm, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

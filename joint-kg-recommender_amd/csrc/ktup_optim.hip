@@ -1,0 +1,226 @@
+// K20: global-norm gradient clip + dense optimizer step over a LIST of tables, two launches.
+//
+// Reference: every driver ends its step with  clip_grad_norm([all params], clipping_max_value); optimizer.step()
+// (item_recommendation.py:189-192, knowledge_representation.py:209-211, knowledgable_recommendation.py:399-401) on one of
+// torch.optim.{Adagrad, Adam, SGD(momentum), RMSprop(momentum)} with weight_decay = l2_lambda (utils/trainer.py:63-77).
+// torch runs that as ~5 multi-tensor passes per optimizer plus 3 for the clip, each re-reading every table.  Here:
+//   launch 1  ktup_optim_gradnorm : sum of squares of all gradients -> one device double
+//   launch 2  ktup_optim_step     : g <- g * min(1, max_norm / (||g|| + 1e-6))  [written back, like clip_grad_norm_],
+//                                   weight decay, state update, parameter update; one read and one write per array.
+// Arithmetic follows torch.optim's single-tensor formulas operation by operation (fp32), so results agree to rounding.
+// All tables are flattened into one index space; a workgroup-sized chunk never straddles two tables.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "ktup_common.h"
+
+namespace {
+
+using namespace ktup;
+
+constexpr int MAXT = KTUP_OPTIM_MAX_TENSORS;
+constexpr int CHUNK = 256 * 4 * 4;   // floats per workgroup iteration: 256 threads x 4 float4
+
+struct OptTensors {
+  float* p[MAXT];
+  float* g[MAXT];
+  float* s1[MAXT];
+  float* s2[MAXT];
+  int64_t chunk0[MAXT + 1];   // first chunk of each tensor in the flattened chunk space
+  int64_t n[MAXT];
+  float bc1[MAXT], bc2s[MAXT];   // Adam: 1 - beta1^t, sqrt(1 - beta2^t) of each tensor's own step count
+  int first[MAXT];               // SGD / RMSprop momentum: buffer not initialised yet (torch clones the gradient)
+  int count;
+};
+
+KTUP_DEV int find_tensor(const OptTensors& T, int64_t chunk) {
+  int k = 0;
+#pragma unroll
+  for (int i = 1; i < MAXT; ++i) k += (i < T.count && chunk >= T.chunk0[i]) ? 1 : 0;
+  return k;
+}
+
+__global__ __launch_bounds__(256) void gradnorm_kernel(OptTensors T, double* __restrict__ sumsq) {
+  const int64_t nchunks = T.chunk0[T.count];
+  float acc = 0.f;
+  for (int64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+    const int k = find_tensor(T, chunk);
+    const int64_t base = (chunk - T.chunk0[k]) * CHUNK;
+    const float* g = T.g[k];
+    const int64_t n = T.n[k];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int64_t i = base + ((int64_t)r * 256 + threadIdx.x) * 4;
+      if (i + 3 < n) {
+        const float4 v = *reinterpret_cast<const float4*>(g + i);
+        acc += dot4(v, v);
+      } else {
+        for (int64_t e = i; e < n; ++e) acc = fmaf(g[e], g[e], acc);
+      }
+    }
+  }
+  acc = group_sum<64>(acc);                    // <= 64 x (a few chunks x 16) fp32 terms per wave; the cross-workgroup sum is fp64
+  __shared__ float red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(sumsq, ((double)red[0] + (double)red[1]) + ((double)red[2] + (double)red[3]));
+}
+
+struct Hyper {
+  float lr, wd, momentum, beta1, beta2, eps, alpha;
+  float max_norm;   // <= 0: no clipping
+};
+
+template <int KIND>
+KTUP_DEV void update1(float& p, float& g, float& s1, float& s2, const Hyper& h, float coef, float bc1, float bc2s, bool first) {
+  g *= coef;                                   // clip_grad_norm_ scales .grad in place (also by 1.0)
+  float d = fmaf(h.wd, p, g);                  // grad.add(param, alpha=weight_decay)
+  if (h.wd == 0.f) d = g;
+  if (KIND == KTUP_OPT_SGD) {                  // torch/optim/sgd.py _single_tensor_sgd (dampening 0, no nesterov)
+    if (h.momentum != 0.f) {
+      s1 = first ? d : fmaf(h.momentum, s1, d);
+      d = s1;
+    }
+    p = fmaf(-h.lr, d, p);
+  } else if (KIND == KTUP_OPT_ADAGRAD) {       // adagrad.py: lr_decay 0 -> clr = lr; eps 1e-10
+    s1 = fmaf(d, d, s1);
+    p = p - h.lr * (d / (sqrtf(s1) + h.eps));
+  } else if (KIND == KTUP_OPT_ADAM) {          // adam.py _single_tensor_adam (amsgrad off)
+    s1 = s1 + (d - s1) * (1.f - h.beta1);      // exp_avg.lerp_(grad, 1 - beta1)
+    s2 = fmaf(1.f - h.beta2, d * d, h.beta2 * s2);
+    const float denom = sqrtf(s2) / bc2s + h.eps;
+    p = p - (h.lr / bc1) * (s1 / denom);
+  } else {                                     // rmsprop.py (centered off)
+    s1 = fmaf(1.f - h.alpha, d * d, h.alpha * s1);
+    const float avg = sqrtf(s1) + h.eps;
+    if (h.momentum > 0.f) {
+      s2 = first ? d / avg : fmaf(h.momentum, s2, d / avg);   // buf.mul_(momentum).addcdiv_(grad, avg); buf starts at 0
+      p = fmaf(-h.lr, s2, p);
+    } else {
+      p = p - h.lr * (d / avg);
+    }
+  }
+}
+
+template <int KIND>
+__global__ __launch_bounds__(256) void step_kernel(OptTensors T, Hyper h, const double* __restrict__ sumsq) {
+  float coef = 1.f;
+  if (h.max_norm > 0.f) {
+    const float c = h.max_norm / ((float)sqrt(*sumsq) + 1e-6f);
+    coef = c < 1.f ? c : 1.f;
+  }
+  const int64_t nchunks = T.chunk0[T.count];
+  for (int64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+    const int k = find_tensor(T, chunk);
+    const int64_t base = (chunk - T.chunk0[k]) * CHUNK;
+    float* p = T.p[k];
+    float* g = T.g[k];
+    float* s1 = T.s1[k];
+    float* s2 = T.s2[k];
+    const int64_t n = T.n[k];
+    const float bc1 = T.bc1[k], bc2s = T.bc2s[k];
+    const bool first = T.first[k] != 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int64_t i = base + ((int64_t)r * 256 + threadIdx.x) * 4;
+      const int m = i + 3 < n ? 4 : (i < n ? (int)(n - i) : 0);
+      if (m == 4) {
+        float4 pv = *reinterpret_cast<float4*>(p + i), gv = *reinterpret_cast<float4*>(g + i);
+        float4 a = s1 ? *reinterpret_cast<float4*>(s1 + i) : f4zero(), b = s2 ? *reinterpret_cast<float4*>(s2 + i) : f4zero();
+        update1<KIND>(pv.x, gv.x, a.x, b.x, h, coef, bc1, bc2s, first);
+        update1<KIND>(pv.y, gv.y, a.y, b.y, h, coef, bc1, bc2s, first);
+        update1<KIND>(pv.z, gv.z, a.z, b.z, h, coef, bc1, bc2s, first);
+        update1<KIND>(pv.w, gv.w, a.w, b.w, h, coef, bc1, bc2s, first);
+        *reinterpret_cast<float4*>(p + i) = pv;
+        if (h.max_norm > 0.f) *reinterpret_cast<float4*>(g + i) = gv;
+        if (s1) *reinterpret_cast<float4*>(s1 + i) = a;
+        if (s2) *reinterpret_cast<float4*>(s2 + i) = b;
+      } else {
+        for (int e = 0; e < m; ++e) {
+          float pv = p[i + e], gv = g[i + e], a = s1 ? s1[i + e] : 0.f, b = s2 ? s2[i + e] : 0.f;
+          update1<KIND>(pv, gv, a, b, h, coef, bc1, bc2s, first);
+          p[i + e] = pv;
+          if (h.max_norm > 0.f) g[i + e] = gv;
+          if (s1) s1[i + e] = a;
+          if (s2) s2[i + e] = b;
+        }
+      }
+    }
+  }
+}
+
+int fill(const char* name, OptTensors& T, int n_tensors, float* const* params, float* const* grads, float* const* state1,
+         float* const* state2, const int64_t* sizes) {
+  KTUP_REQUIRE(n_tensors >= 0 && n_tensors <= MAXT, "%s: %d tensors (max %d per call)", name, n_tensors, MAXT);
+  T.count = n_tensors;
+  int64_t c = 0;
+  for (int i = 0; i < n_tensors; ++i) {
+    KTUP_REQUIRE(grads[i] && sizes[i] >= 0, "%s: tensor %d: null gradient or negative size", name, i);
+    KTUP_REQUIRE(aligned16(grads[i]) && (!params || aligned16(params[i])) && (!state1 || !state1[i] || aligned16(state1[i])) &&
+                     (!state2 || !state2[i] || aligned16(state2[i])),
+                 "%s: tensor %d: arrays must be 16-byte aligned", name, i);
+    T.p[i] = params ? params[i] : nullptr;
+    T.g[i] = grads[i];
+    T.s1[i] = state1 ? state1[i] : nullptr;
+    T.s2[i] = state2 ? state2[i] : nullptr;
+    T.n[i] = sizes[i];
+    T.chunk0[i] = c;
+    c += (sizes[i] + CHUNK - 1) / CHUNK;
+    T.bc1[i] = 1.f; T.bc2s[i] = 1.f; T.first[i] = 0;
+  }
+  for (int i = n_tensors; i <= MAXT; ++i) T.chunk0[i] = c;
+  T.chunk0[n_tensors] = c;
+  return KTUP_OK;
+}
+
+}  // namespace
+
+extern "C" int ktup_optim_gradnorm(int n_tensors, float* const* grads, const int64_t* sizes, double* sumsq, void* stream) {
+  OptTensors T{};
+  KTUP_REQUIRE(grads && sizes && sumsq, "ktup_optim_gradnorm: null pointer argument");
+  if (int e = fill("ktup_optim_gradnorm", T, n_tensors, nullptr, grads, nullptr, nullptr, sizes)) return e;
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(sumsq, 0, sizeof(double), st) != hipSuccess) return check_launch("ktup_optim_gradnorm");
+  const int64_t nchunks = T.chunk0[T.count];
+  if (nchunks == 0) return KTUP_OK;
+  hipLaunchKernelGGL(gradnorm_kernel, dim3(grid_for(nchunks, 256 * 4)), dim3(256), 0, st, T, sumsq);
+  return check_launch("ktup_optim_gradnorm");
+}
+
+extern "C" int ktup_optim_step(int kind, int n_tensors, float* const* params, float* const* grads, float* const* state1,
+                               float* const* state2, const int64_t* sizes, const int64_t* steps, const int32_t* first, float lr,
+                               float weight_decay, float momentum, float beta1, float beta2, float eps, float alpha,
+                               const double* sumsq, float max_norm, void* stream) {
+  KTUP_REQUIRE(kind >= KTUP_OPT_SGD && kind <= KTUP_OPT_RMSPROP, "ktup_optim_step: unknown optimizer kind %d", kind);
+  KTUP_REQUIRE(params && grads && sizes, "ktup_optim_step: null pointer argument");
+  KTUP_REQUIRE(max_norm <= 0.f || sumsq, "ktup_optim_step: clipping needs the gradnorm result");
+  OptTensors T{};
+  if (int e = fill("ktup_optim_step", T, n_tensors, params, grads, state1, state2, sizes)) return e;
+  for (int i = 0; i < n_tensors; ++i) {
+    KTUP_REQUIRE(params[i], "ktup_optim_step: tensor %d: null parameter", i);
+    const bool need1 = kind == KTUP_OPT_ADAGRAD || kind == KTUP_OPT_ADAM || kind == KTUP_OPT_RMSPROP ||
+                       (kind == KTUP_OPT_SGD && momentum != 0.f);
+    const bool need2 = kind == KTUP_OPT_ADAM || (kind == KTUP_OPT_RMSPROP && momentum > 0.f);
+    KTUP_REQUIRE((!need1 || T.s1[i]) && (!need2 || T.s2[i]), "ktup_optim_step: tensor %d: optimizer state missing", i);
+    if (kind == KTUP_OPT_ADAM) {
+      KTUP_REQUIRE(steps && steps[i] >= 1, "ktup_optim_step: Adam needs the (already incremented) step count of tensor %d", i);
+      const double t = (double)steps[i];
+      T.bc1[i] = (float)(1.0 - pow((double)beta1, t));
+      T.bc2s[i] = (float)sqrt(1.0 - pow((double)beta2, t));
+    }
+    T.first[i] = first ? first[i] : 0;
+  }
+  const int64_t nchunks = T.chunk0[T.count];
+  if (nchunks == 0) return KTUP_OK;
+  const Hyper h{lr, weight_decay, momentum, beta1, beta2, eps, alpha, max_norm};
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid(grid_for(nchunks, 256 * 8)), block(256);
+  switch (kind) {
+    case KTUP_OPT_SGD: hipLaunchKernelGGL(step_kernel<KTUP_OPT_SGD>, grid, block, 0, st, T, h, sumsq); break;
+    case KTUP_OPT_ADAGRAD: hipLaunchKernelGGL(step_kernel<KTUP_OPT_ADAGRAD>, grid, block, 0, st, T, h, sumsq); break;
+    case KTUP_OPT_ADAM: hipLaunchKernelGGL(step_kernel<KTUP_OPT_ADAM>, grid, block, 0, st, T, h, sumsq); break;
+    default: hipLaunchKernelGGL(step_kernel<KTUP_OPT_RMSPROP>, grid, block, 0, st, T, h, sumsq); break;
+  }
+  return check_launch("ktup_optim_step");
+}

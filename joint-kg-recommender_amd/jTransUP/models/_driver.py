@@ -124,8 +124,7 @@ def report_rec(FLAGS, model, results, all_dicts, eval_dict, logger, with_prefere
 
 def clip_and_step(FLAGS, model, trainer):
     """Global-norm clip over ALL tables, then the dense optimizer step (e.g. item_recommendation.py:189-192)."""
-    nn.utils.clip_grad_norm_([p for _, p in model.named_parameters()], FLAGS.clipping_max_value)
-    trainer.optimizer_step()
+    trainer.clip_and_step(FLAGS.clipping_max_value)
 
 
 def training_loop(FLAGS, model, trainer, logger, do_step, do_eval, loss_names, on_train_mode=None):

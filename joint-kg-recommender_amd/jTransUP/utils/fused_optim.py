@@ -1,0 +1,123 @@
+"""Global-norm clip + dense optimizer step as two HIP launches (ktup_optim_gradnorm / ktup_optim_step, K20).
+
+The reference ends every training step with `clip_grad_norm(all params, clipping_max_value); optimizer.step()`
+(item_recommendation.py:189-192, knowledge_representation.py:209-211, knowledgable_recommendation.py:399-401) on
+torch.optim.{Adagrad, Adam, SGD, RMSprop} with weight_decay = l2_lambda (utils/trainer.py:63-77).  FusedOptimizer wraps the
+very torch.optim object the trainer creates: hyper-parameters and state tensors stay in torch's own layout (so
+`state_dict()` / `load_state_dict()` and checkpoints are interchangeable with an unfused run); only the arithmetic of
+clip + step moves into the library."""
+import ctypes
+
+import torch
+import torch.optim as optim
+
+from jTransUP.hip import lib as L
+
+MAX_TENSORS = 12
+KINDS = {optim.SGD: 0, optim.Adagrad: 1, optim.Adam: 2, optim.RMSprop: 3}
+
+
+def _arr(ctype, values):
+    return (ctype * len(values))(*values)
+
+
+class FusedOptimizer(object):
+    def __init__(self, optimizer):
+        if type(optimizer) not in KINDS:
+            raise L.KtupError('FusedOptimizer supports SGD, Adagrad, Adam and RMSprop (got %s)' % type(optimizer).__name__)
+        if len(optimizer.param_groups) != 1:
+            raise L.KtupError('FusedOptimizer expects the single parameter group utils/trainer.py builds')
+        self.optimizer = optimizer
+        self.kind = KINDS[type(optimizer)]
+        g = optimizer.param_groups[0]
+        if g.get('maximize') or g.get('amsgrad') or g.get('nesterov') or g.get('centered') or g.get('dampening', 0) != 0 \
+                or g.get('lr_decay', 0) != 0:
+            raise L.KtupError('FusedOptimizer implements the reference configuration only (no maximize / amsgrad / nesterov / '
+                              'centered / dampening / lr_decay)')
+        self._sumsq = None
+
+    # ---- torch.optim surface the trainer uses
+    def zero_grad(self):
+        """Zero-FILL, like torch 0.3's zero_grad: a table that has received a gradient once keeps being updated (weight
+        decay, moment decay) on steps that do not touch it, e.g. user/item tables on KTUP's KG steps."""
+        self.optimizer.zero_grad(set_to_none=False)
+
+    def state_dict(self):
+        return self.optimizer.state_dict()
+
+    def load_state_dict(self, sd):
+        self.optimizer.load_state_dict(sd)
+
+    @property
+    def param_groups(self):
+        return self.optimizer.param_groups
+
+    # ---- state in torch's layout (created the way each torch optimizer creates it)
+    def _state(self, p, group):
+        if self.kind == 0 and group['momentum'] == 0:
+            return None, None, 0, 0              # plain SGD keeps no state (torch leaves optimizer.state empty)
+        st = self.optimizer.state[p]
+        first = 0
+        if self.kind == 0:                       # SGD: momentum_buffer (None until the first step)
+            if st.get('momentum_buffer') is None:
+                st['momentum_buffer'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                first = 1
+            return st.get('momentum_buffer'), None, 0, first
+        if 'step' not in st:
+            st['step'] = torch.tensor(0.0, dtype=torch.float32)
+        if self.kind == 1:                       # Adagrad: 'sum' exists from construction
+            if 'sum' not in st:
+                st['sum'] = torch.full_like(p, group.get('initial_accumulator_value', 0.0), memory_format=torch.preserve_format)
+            s1, s2 = st['sum'], None
+        elif self.kind == 2:
+            if 'exp_avg' not in st:
+                st['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            s1, s2 = st['exp_avg'], st['exp_avg_sq']
+        else:
+            if 'square_avg' not in st:
+                st['square_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                if group['momentum'] > 0:
+                    st['momentum_buffer'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            s1, s2 = st['square_avg'], st.get('momentum_buffer')
+        st['step'] += 1
+        return s1, s2, int(st['step'].item()), first
+
+    @torch.no_grad()
+    def clip_and_step(self, max_norm):
+        group = self.optimizer.param_groups[0]
+        ps = [p for p in group['params'] if p.grad is not None]
+        if not ps:
+            return
+        if len(ps) > MAX_TENSORS:
+            raise L.KtupError('FusedOptimizer handles up to %d tables per step (got %d)' % (MAX_TENSORS, len(ps)))
+        dev = ps[0].device
+        for p in ps:
+            if not p.is_cuda or p.device != dev or p.dtype != torch.float32 or not p.is_contiguous() or not p.grad.is_contiguous() \
+                    or p.grad.dtype != torch.float32 or p.grad.is_sparse:
+                raise L.KtupError('FusedOptimizer needs dense contiguous fp32 parameters and gradients on one MI355X device')
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        n = len(ps)
+        sizes = _arr(ctypes.c_int64, [p.numel() for p in ps])
+        grads = _arr(ctypes.c_void_p, [p.grad.data_ptr() for p in ps])
+        params = _arr(ctypes.c_void_p, [p.data_ptr() for p in ps])
+        s1l, s2l, steps, firsts = [], [], [], []
+        for p in ps:
+            s1, s2, step, first = self._state(p, group)
+            s1l.append(None if s1 is None else s1.data_ptr()); s2l.append(None if s2 is None else s2.data_ptr())
+            steps.append(max(step, 1)); firsts.append(first)
+        sumsq = None
+        if max_norm is not None and max_norm > 0:
+            if self._sumsq is None or self._sumsq.device != dev:
+                self._sumsq = torch.zeros(1, dtype=torch.float64, device=dev)
+            sumsq = self._sumsq.data_ptr()
+            L.call('ktup_optim_gradnorm', n, grads, sizes, sumsq, stream)
+        betas = group.get('betas', (0.9, 0.999))
+        L.call('ktup_optim_step', self.kind, n, params, grads, _arr(ctypes.c_void_p, s1l), _arr(ctypes.c_void_p, s2l), sizes,
+               _arr(ctypes.c_int64, steps), _arr(ctypes.c_int32, firsts), float(group['lr']), float(group['weight_decay']),
+               float(group.get('momentum', 0.0)), float(betas[0]), float(betas[1]), float(group.get('eps', 0.0)),
+               float(group.get('alpha', 0.0)), sumsq, float(max_norm) if sumsq is not None else 0.0, stream)
+
+    def total_norm(self):
+        """Gradient norm of the last clipped step (device -> host sync; diagnostics only)."""
+        return None if self._sumsq is None else float(self._sumsq.sqrt().item())

@@ -1,8 +1,9 @@
 """ModelTrainer with the reference's interface and checkpoint layout (jTransUP/utils/trainer.py:20-217).
 
-The optimizer is torch.optim on the device (dense update of every table each step, weight_decay = l2_lambda,
-re-created on LR decay -- exactly the reference's semantics; a fused row-sparse HIP optimizer is listed as the next
-step in SURVEY.md section 8f)."""
+The optimizer is a torch.optim object (dense update of every table each step, weight_decay = l2_lambda, re-created on
+LR decay -- exactly the reference's semantics).  On the GPU its clip_grad_norm + step() arithmetic runs as two HIP
+launches (utils/fused_optim.py, K20) on the same state tensors, so checkpoints do not change; KTUP_FUSED_OPTIM=0 keeps
+torch's own multi-tensor kernels."""
 import os
 
 import torch
@@ -64,13 +65,28 @@ class ModelTrainer(object):
             self.optimizer = optim.Adagrad(self.parameters, **kw)
         elif self.optimizer_type == 'Rmsprop':
             self.optimizer = optim.RMSprop(self.parameters, momentum=self.momentum, **kw)
+        self.fused = None
+        if USE_CUDA and os.environ.get('KTUP_FUSED_OPTIM', '1') != '0':
+            from jTransUP.utils.fused_optim import FusedOptimizer
+            self.fused = FusedOptimizer(self.optimizer)
 
     def optimizer_step(self):
         self.optimizer.step()
         self.step += 1
 
+    def clip_and_step(self, max_norm):
+        """clip_grad_norm over ALL tables, then the optimizer step (e.g. item_recommendation.py:189-192)."""
+        if self.fused is not None:
+            self.fused.clip_and_step(max_norm)
+            self.step += 1
+        else:
+            torch.nn.utils.clip_grad_norm_(self.parameters, max_norm)
+            self.optimizer_step()
+
     def optimizer_zero_grad(self):
-        self.optimizer.zero_grad()
+        """Zero-fill (torch 0.3 semantics): tables that have had a gradient keep receiving weight decay / moment decay
+        on steps that do not touch them (KTUP alternates rec and KG steps)."""
+        self.optimizer.zero_grad(set_to_none=False)
 
     def new_performance(self, dev_performance, performances):
         """trainer.py:86-103: checkpoint on a new best of metric[0]; halve the LR after an epoch without one."""

@@ -58,7 +58,7 @@ def build_world(seed, device):
     return W, i2e, idx
 
 
-def cpu_baseline(W, i2e, idx, budget_s=14.0):
+def cpu_baseline(W, i2e, idx, budget_s=18.0):
     """The oracle (a torch-CPU port of the reference's forward; note it replaces the reference's per-item python
     dict walk by a tensor lookup, so it is FASTER than the reference itself), B=512, 7 rec : 3 kg.
     torch's default of one intra-op thread per host core is pathological for these small ops on a many-core host,
@@ -68,6 +68,7 @@ def cpu_baseline(W, i2e, idx, budget_s=14.0):
     B = 512
     cands = sorted(set(t for t in (1, 4, 8, 16, 32, 64) if t <= ncpu))
     best = None
+    threads_before = torch.get_num_threads()
     with torch.no_grad():
         for threads in cands:
             torch.set_num_threads(threads)
@@ -83,9 +84,10 @@ def cpu_baseline(W, i2e, idx, budget_s=14.0):
             dt = time.perf_counter() - t0
             if best is None or rows / dt > best[0]:
                 best = (rows / dt, threads, it, dt)
+    torch.set_num_threads(threads_before)
     return {'value': best[0], 'unit': 'scored rows/s', 'cores': best[1], 'kind': 'port', 'host_cores': ncpu,
-            'sample': '%d batches of 512 (7 rec : 3 kg) in %.1f s at the best of %s torch threads; oracle/cpu_ref.py, torch %s CPU'
-                      % (best[2], best[3], cands, torch.__version__)}
+            'sample': '%d batches of 512 (7 rec : 3 kg) in %.1f s at the best of %s torch threads (%.0f s of CPU work over all '
+                      'thread counts); oracle/cpu_ref.py, torch %s CPU' % (best[2], best[3], cands, budget_s, torch.__version__)}
 
 
 def train_step_bench(device, steps=200, warmup=20):

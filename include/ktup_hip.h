@@ -210,7 +210,8 @@ int ktup_negsample_kg(const int64_t* h, const int64_t* t, const int64_t* r, int6
  * each tensor's own 1-based step count for Adam, 1 where a momentum buffer is still uninitialised).
  * state1 / state2:  SGD momentum_buffer / -;  Adagrad sum / -;  Adam exp_avg / exp_avg_sq;  RMSprop square_avg /
  * momentum_buffer.  The clip factor min(1, max_norm / (||g|| + 1e-6)) is applied to the gradients in place, like
- * clip_grad_norm_; max_norm <= 0 disables clipping (sumsq, one device double, may then be NULL).                    */
+ * clip_grad_norm_; max_norm <= 0 disables clipping (sumsq, one device double, may then be NULL).  zero_grads != 0
+ * stores zeros instead (optimizer.zero_grad() of the NEXT step folded into this pass).                              */
 #define KTUP_OPTIM_MAX_TENSORS 12
 #define KTUP_OPT_SGD 0
 #define KTUP_OPT_ADAGRAD 1
@@ -220,7 +221,7 @@ int ktup_optim_gradnorm(int n_tensors, float* const* grads, const int64_t* sizes
 int ktup_optim_step(int kind, int n_tensors, float* const* params, float* const* grads, float* const* state1,
                     float* const* state2, const int64_t* sizes, const int64_t* steps, const int32_t* first, float lr,
                     float weight_decay, float momentum, float beta1, float beta2, float eps, float alpha,
-                    const double* sumsq, float max_norm, void* stream);
+                    const double* sumsq, float max_norm, int zero_grads, void* stream);
 
 #ifdef __cplusplus
 }

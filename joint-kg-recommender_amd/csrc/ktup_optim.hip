@@ -70,6 +70,7 @@ __global__ __launch_bounds__(256) void gradnorm_kernel(OptTensors T, double* __r
 struct Hyper {
   float lr, wd, momentum, beta1, beta2, eps, alpha;
   float max_norm;   // <= 0: no clipping
+  int zero_grads;   // write 0 to the gradients instead of their clipped values (the next step starts from zero-filled grads)
 };
 
 template <int KIND>
@@ -133,7 +134,8 @@ __global__ __launch_bounds__(256) void step_kernel(OptTensors T, Hyper h, const 
         update1<KIND>(pv.z, gv.z, a.z, b.z, h, coef, bc1, bc2s, first);
         update1<KIND>(pv.w, gv.w, a.w, b.w, h, coef, bc1, bc2s, first);
         *reinterpret_cast<float4*>(p + i) = pv;
-        if (h.max_norm > 0.f) *reinterpret_cast<float4*>(g + i) = gv;
+        if (h.zero_grads) *reinterpret_cast<float4*>(g + i) = f4zero();
+        else if (h.max_norm > 0.f) *reinterpret_cast<float4*>(g + i) = gv;
         if (s1) *reinterpret_cast<float4*>(s1 + i) = a;
         if (s2) *reinterpret_cast<float4*>(s2 + i) = b;
       } else {
@@ -141,7 +143,8 @@ __global__ __launch_bounds__(256) void step_kernel(OptTensors T, Hyper h, const 
           float pv = p[i + e], gv = g[i + e], a = s1 ? s1[i + e] : 0.f, b = s2 ? s2[i + e] : 0.f;
           update1<KIND>(pv, gv, a, b, h, coef, bc1, bc2s, first);
           p[i + e] = pv;
-          if (h.max_norm > 0.f) g[i + e] = gv;
+          if (h.zero_grads) g[i + e] = 0.f;
+          else if (h.max_norm > 0.f) g[i + e] = gv;
           if (s1) s1[i + e] = a;
           if (s2) s2[i + e] = b;
         }
@@ -191,7 +194,7 @@ extern "C" int ktup_optim_gradnorm(int n_tensors, float* const* grads, const int
 extern "C" int ktup_optim_step(int kind, int n_tensors, float* const* params, float* const* grads, float* const* state1,
                                float* const* state2, const int64_t* sizes, const int64_t* steps, const int32_t* first, float lr,
                                float weight_decay, float momentum, float beta1, float beta2, float eps, float alpha,
-                               const double* sumsq, float max_norm, void* stream) {
+                               const double* sumsq, float max_norm, int zero_grads, void* stream) {
   KTUP_REQUIRE(kind >= KTUP_OPT_SGD && kind <= KTUP_OPT_RMSPROP, "ktup_optim_step: unknown optimizer kind %d", kind);
   KTUP_REQUIRE(params && grads && sizes, "ktup_optim_step: null pointer argument");
   KTUP_REQUIRE(max_norm <= 0.f || sumsq, "ktup_optim_step: clipping needs the gradnorm result");
@@ -213,7 +216,7 @@ extern "C" int ktup_optim_step(int kind, int n_tensors, float* const* params, fl
   }
   const int64_t nchunks = T.chunk0[T.count];
   if (nchunks == 0) return KTUP_OK;
-  const Hyper h{lr, weight_decay, momentum, beta1, beta2, eps, alpha, max_norm};
+  const Hyper h{lr, weight_decay, momentum, beta1, beta2, eps, alpha, max_norm, zero_grads};
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid(grid_for(nchunks, 256 * 8)), block(256);
   switch (kind) {

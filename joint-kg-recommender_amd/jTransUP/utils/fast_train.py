@@ -1,0 +1,111 @@
+"""GPU-resident training step of the joint driver (KTUP, -noshare_embeddings): the arithmetic of
+knowledgable_recommendation.py:330-401 (`train_loop`'s step body) issued as ~a dozen launches through the C ABI.
+
+The autograd route (`model(...)`, `bprLoss`, `.backward()`, `clip_and_step`) costs ~50 launches and ~0.5 ms of Python per
+B=512 step: every Function allocates and zero-fills table-shaped gradients which autograd then adds into `.grad`, and
+positives and negatives are scored by separate launches.  Here positives and negatives share one forward and one
+backward launch (ids concatenated in fixed buffers), the backward kernels accumulate straight into the persistent,
+zero-filled `.grad` tensors, and the optimizer pass leaves them zeroed for the next step.  Same kernels, same
+arithmetic: tests/test_fast_train.py checks the tables against the autograd route after a mixed rec/kg schedule.
+
+rec step (knowledgable_recommendation.py:335-344):  bprLoss(pos, neg, target=-1) + orthogonalLoss(pref, pref_norm)
+kg step  (:345-382):  kg_lambda * ( marginLoss(pos, neg, margin) + orthogonalLoss(rel, norm)[rel ids]
+                                    + normLoss(ent)[h, t ids of pos and neg] + normLoss(rel)[rel ids] )
+"""
+import torch
+
+from jTransUP.hip import lib as L
+from jTransUP.hip import ops
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+class JointStepper(object):
+    def __init__(self, model, trainer, FLAGS, batch_size):
+        if trainer.fused is None:
+            raise L.KtupError('JointStepper needs the fused optimizer (KTUP_FUSED_OPTIM=0 disables it)')
+        self.m, self.trainer = model, trainer
+        self.B = int(batch_size)
+        self.margin, self.kg_lambda, self.max_norm = float(FLAGS.margin), float(FLAGS.kg_lambda), float(FLAGS.clipping_max_value)
+        self.target = float(trainer.model_target)
+        self.l1 = int(bool(model.L1_flag))
+        U, I, E, P, Pn, R, Rn = model._rec_tables()
+        self.tabs = (U, I, E, P, Pn, R, Rn)
+        dev = U.device
+        self.dev = dev
+        for p in trainer.parameters:                     # persistent zero-filled gradients (torch 0.3 zero_grad semantics)
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+            else:
+                p.grad.zero_()
+        B = self.B
+        i64 = dict(dtype=torch.int64, device=dev)
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.u2, self.i2 = torch.zeros(2 * B, **i64), torch.zeros(2 * B, **i64)          # [pos ; neg]
+        self.h2, self.t2, self.r2 = torch.zeros(2 * B, **i64), torch.zeros(2 * B, **i64), torch.zeros(2 * B, **i64)
+        self.ht4 = torch.zeros(4 * B, **i64)                                             # ph, pt, nh, nt (normLoss rows)
+        self.score, self.gscore = torch.zeros(2 * B, **f32), torch.zeros(2 * B, **f32)
+        self.gAC = torch.zeros(2, P.shape[0], P.shape[1], **f32)                         # mixed-table gradients gA, gC
+        self.loss = torch.zeros(4, **f32)
+        self.one = torch.ones((), **f32)
+        self.lam = torch.full((), self.kg_lambda, **f32)
+        self.ws = ops.pref_workspace(P, Pn, R, Rn)
+        self.ent_pad = model.ent_total - 1
+        self.i2e = model._item2ent
+
+    # ------------------------------------------------------------------------------------------------ rec
+    def rec_step(self, u, pi, ni):
+        """u, pi, ni: int64 device tensors of B ids.  Returns the step's loss (0-dim device tensor)."""
+        m, B = self.m, self.B
+        U, I, E, P, Pn, R, Rn = self.tabs
+        st = torch.cuda.current_stream(self.dev).cuda_stream
+        self.u2[:B].copy_(u); self.u2[B:].copy_(u); self.i2[:B].copy_(pi); self.i2[B:].copy_(ni)
+        n_pref, d = P.shape
+        mode, uni, seed, off = m._gumbel.mode_and_stream(m.use_st_gumbel, None, 2 * B * n_pref)
+        L.call('ktup_pref_prepare', _p(P), _p(Pn), _p(R), _p(Rn), P.stride(0), n_pref, d, _p(self.ws), st)
+        L.call('ktup_score_ktup_fwd', _p(U), U.stride(0), _p(I), I.stride(0), _p(E), E.stride(0), _p(self.i2e), _p(self.ws), n_pref, d,
+               _p(self.u2), _p(self.i2), 2 * B, self.l1, int(mode), _p(uni), int(seed), int(off), _p(self.score), st)
+        pos, neg, gpos, gneg = self.score[:B], self.score[B:], self.gscore[:B], self.gscore[B:]
+        L.call('ktup_loss_bpr_fwd', _p(pos), _p(neg), B, self.target, _p(self.loss[0:]), st)
+        L.call('ktup_loss_bpr_bwd', _p(pos), _p(neg), B, self.target, _p(self.one), _p(gpos), _p(gneg), st)
+        self.gAC.zero_()
+        L.call('ktup_score_ktup_bwd', _p(U), U.stride(0), _p(I), I.stride(0), _p(E), E.stride(0), _p(self.i2e), self.ent_pad,
+               _p(self.ws), n_pref, d, _p(self.u2), _p(self.i2), 2 * B, self.l1, int(mode), _p(uni), int(seed), int(off),
+               _p(self.gscore), _p(U.grad), _p(I.grad), _p(E.grad), _p(self.gAC[0]), _p(self.gAC[1]), st)
+        # A = pref + rel and C = pref_norm + norm: the mixed-table gradient goes to both summands
+        torch._foreach_add_([P.grad, R.grad, Pn.grad, Rn.grad], [self.gAC[0], self.gAC[0], self.gAC[1], self.gAC[1]])
+        L.call('ktup_reg_orth_fwd', _p(P), P.stride(0), _p(Pn), Pn.stride(0), d, None, n_pref, _p(self.loss[1:]), st)
+        L.call('ktup_reg_orth_bwd', _p(P), P.stride(0), _p(Pn), Pn.stride(0), d, None, n_pref, _p(self.one), _p(P.grad), _p(Pn.grad), st)
+        self._optimizer_step()
+        return self.loss[0] + self.loss[1]
+
+    # ------------------------------------------------------------------------------------------------ kg
+    def kg_step(self, ph, pt, pr, nh, nt, nr):
+        B = self.B
+        _, _, E, _, _, R, Rn = self.tabs
+        st = torch.cuda.current_stream(self.dev).cuda_stream
+        self.h2[:B].copy_(ph); self.h2[B:].copy_(nh); self.t2[:B].copy_(pt); self.t2[B:].copy_(nt)
+        self.r2[:B].copy_(pr); self.r2[B:].copy_(nr)
+        self.ht4[:B].copy_(ph); self.ht4[B:2 * B].copy_(pt); self.ht4[2 * B:3 * B].copy_(nh); self.ht4[3 * B:].copy_(nt)
+        d, n_rel = E.shape[1], min(R.shape[0], Rn.shape[0])
+        L.call('ktup_score_transh_fwd', _p(E), E.stride(0), _p(R), R.stride(0), _p(Rn), Rn.stride(0), n_rel, d, _p(self.h2),
+               _p(self.t2), _p(self.r2), 2 * B, self.l1, _p(self.score), st)
+        pos, neg, gpos, gneg = self.score[:B], self.score[B:], self.gscore[:B], self.gscore[B:]
+        L.call('ktup_loss_margin_fwd', _p(pos), _p(neg), B, self.margin, _p(self.loss[0:]), st)
+        L.call('ktup_loss_margin_bwd', _p(pos), _p(neg), B, self.margin, _p(self.lam), _p(gpos), _p(gneg), st)
+        L.call('ktup_score_transh_bwd', _p(E), E.stride(0), _p(R), R.stride(0), _p(Rn), Rn.stride(0), d, _p(self.h2), _p(self.t2),
+               _p(self.r2), 2 * B, self.l1, _p(self.gscore), _p(E.grad), _p(R.grad), _p(Rn.grad), st)
+        L.call('ktup_reg_orth_fwd', _p(R), R.stride(0), _p(Rn), Rn.stride(0), d, _p(self.r2), 2 * B, _p(self.loss[1:]), st)
+        L.call('ktup_reg_orth_bwd', _p(R), R.stride(0), _p(Rn), Rn.stride(0), d, _p(self.r2), 2 * B, _p(self.lam), _p(R.grad), _p(Rn.grad), st)
+        L.call('ktup_reg_norm_fwd', _p(E), E.stride(0), d, _p(self.ht4), 4 * B, _p(self.loss[2:]), st)
+        L.call('ktup_reg_norm_bwd', _p(E), E.stride(0), d, _p(self.ht4), 4 * B, _p(self.lam), _p(E.grad), st)
+        L.call('ktup_reg_norm_fwd', _p(R), R.stride(0), d, _p(self.r2), 2 * B, _p(self.loss[3:]), st)
+        L.call('ktup_reg_norm_bwd', _p(R), R.stride(0), d, _p(self.r2), 2 * B, _p(self.lam), _p(R.grad), st)
+        self._optimizer_step()
+        return self.kg_lambda * self.loss.sum()
+
+    def _optimizer_step(self):
+        self.trainer.fused.clip_and_step(self.max_norm, zero_grads=True)
+        self.trainer.step += 1

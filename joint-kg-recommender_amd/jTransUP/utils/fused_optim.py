@@ -84,7 +84,9 @@ class FusedOptimizer(object):
         return s1, s2, int(st['step'].item()), first
 
     @torch.no_grad()
-    def clip_and_step(self, max_norm):
+    def clip_and_step(self, max_norm, zero_grads=False):
+        """`zero_grads`: leave the gradients zero-filled (the next step's zero_grad folded into this pass) instead of
+        clipped in place."""
         group = self.optimizer.param_groups[0]
         ps = [p for p in group['params'] if p.grad is not None]
         if not ps:
@@ -116,7 +118,7 @@ class FusedOptimizer(object):
         L.call('ktup_optim_step', self.kind, n, params, grads, _arr(ctypes.c_void_p, s1l), _arr(ctypes.c_void_p, s2l), sizes,
                _arr(ctypes.c_int64, steps), _arr(ctypes.c_int32, firsts), float(group['lr']), float(group['weight_decay']),
                float(group.get('momentum', 0.0)), float(betas[0]), float(betas[1]), float(group.get('eps', 0.0)),
-               float(group.get('alpha', 0.0)), sumsq, float(max_norm) if sumsq is not None else 0.0, stream)
+               float(group.get('alpha', 0.0)), sumsq, float(max_norm) if sumsq is not None else 0.0, int(bool(zero_grads)), stream)
 
     def total_norm(self):
         """Gradient norm of the last clipped step (device -> host sync; diagnostics only)."""

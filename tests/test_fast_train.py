@@ -1,0 +1,76 @@
+"""The GPU-resident joint training step (utils/fast_train.py) against the autograd route that mirrors the reference's step
+body (knowledgable_recommendation.py:330-401): same tables after a mixed rec / kg schedule."""
+import copy
+import logging
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device('cuda', 0)
+
+
+def build(tmp_path, optimizer, gumbel):
+    from jTransUP.models import jTransUP as jt
+    from jTransUP.models.base import get_flags
+    from jTransUP.utils.flags import FLAGS
+    from jTransUP.utils.trainer import ModelTrainer
+    get_flags(); FLAGS.reset()
+    FLAGS(['prog', '-model_type', 'jtransup', '-noshare_embeddings', '-log_path', str(tmp_path), '-experiment_name', 'ft',
+           '-optimizer_type', optimizer, '-learning_rate', '0.05', '-kg_lambda', '0.5'])
+    FLAGS.ckpt_path = str(tmp_path)
+    NU, NI, NE, NR, D = 50, 40, 70, 6, 36
+    i_map = {i: i for i in range(NI)}
+    new_map = {i: ((i * 3) % NE if i % 5 else -1, i) for i in range(NI)}
+    torch.manual_seed(4)
+    m = jt.jTransUPModel(False, D, NU, NI, NE, NR, i_map, new_map, False, gumbel)
+    return FLAGS, m, ModelTrainer(m, logging.getLogger('ft'), 10, FLAGS), (NU, NI, NE, NR)
+
+
+@pytest.mark.parametrize('optimizer', ['Adagrad', 'SGD'])
+def test_fast_steps_match_the_autograd_route(tmp_path, optimizer):
+    from jTransUP.utils import loss
+    from jTransUP.utils.fast_train import JointStepper
+    FLAGS, m1, tr1, (NU, NI, NE, NR) = build(tmp_path, optimizer, False)
+    _, m2, tr2, _ = build(tmp_path, optimizer, False)
+    m2.load_state_dict(copy.deepcopy(m1.state_dict()))
+    B = 64
+    fast = JointStepper(m2, tr2, FLAGS, B)
+    gen = torch.Generator().manual_seed(9)
+    rnd = lambda hi: torch.randint(0, hi, (B,), generator=gen).to(DEV)
+    for step, is_rec in enumerate([True, True, False, True, False, False, True]):
+        if is_rec:
+            u, pi, ni = rnd(NU), rnd(NI), rnd(NI)
+            tr1.optimizer_zero_grad()
+            pos, neg = m1((u, pi), None, is_rec=True), m1((u, ni), None, is_rec=True)
+            losses = loss.bprLoss(pos, neg, target=tr1.model_target) + \
+                loss.orthogonalLoss(m1.pref_embeddings.weight, m1.pref_norm_embeddings.weight)
+            losses.backward()
+            tr1.clip_and_step(FLAGS.clipping_max_value)
+            fast_loss = fast.rec_step(u, pi, ni)
+        else:
+            ph, pt, pr, nh, nt = rnd(NE), rnd(NE), rnd(NR), rnd(NE), rnd(NE)
+            nr = pr
+            tr1.optimizer_zero_grad()
+            pos, neg = m1(None, (ph, pt, pr), is_rec=False), m1(None, (nh, nt, nr), is_rec=False)
+            rel_ids = torch.cat([pr, nr])
+            losses = loss.marginLoss()(pos, neg, FLAGS.margin)
+            losses = losses + loss.orthogonalLoss(m1.rel_embeddings.weight, m1.norm_embeddings.weight, ids=rel_ids)
+            losses = losses + loss.normLoss(m1.ent_embeddings.weight, ids=torch.cat([ph, pt, nh, nt])) \
+                + loss.normLoss(m1.rel_embeddings.weight, ids=rel_ids)
+            losses = FLAGS.kg_lambda * losses
+            losses.backward()
+            tr1.clip_and_step(FLAGS.clipping_max_value)
+            fast_loss = fast.kg_step(ph, pt, pr, nh, nt, nr)
+        torch.testing.assert_close(fast_loss, losses.detach(), rtol=1e-5, atol=1e-6)
+        assert tr1.step == tr2.step == step + 1
+        for (k, a), (_, b) in zip(m1.state_dict().items(), m2.state_dict().items()):
+            # gradient atomics land in a different order on the two routes; Adagrad's lr * d / (sqrt(sum) + eps) turns a
+            # last-bit difference of d into a visible one where sum is ~eps^2 (rows only touched by weight decay), so a
+            # stray element per table is tolerated, bounded by a fraction of one learning-rate-sized update
+            err = (b - a).abs()
+            bad = err > 2e-6 + 2e-5 * a.abs()
+            assert float(bad.float().mean()) <= 2e-3 and float(err.max()) <= 1e-3 * 0.05, \
+                '%s after step %d: %d elements off, max %.3g' % (k, step, int(bad.sum()), float(err.max()))
+    # the pad entity row never moves
+    assert float(m2.ent_embeddings.weight[m2.ent_total - 1].abs().sum()) == 0.0

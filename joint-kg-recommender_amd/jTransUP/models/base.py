@@ -40,6 +40,8 @@ def get_flags():
     g.DEFINE_float('clipping_max_value', 5.0, '')
     g.DEFINE_float('margin', 1.0, 'Used in margin loss.')
     g.DEFINE_float('momentum', 0.9, 'The momentum of the optimizer.')
+    g.DEFINE_bool('device_sampling', False, '(this build) keep the training data on the GPU and draw negatives with the '
+                  'on-device samplers (K19) instead of the host samplers of utils/data.py')
     g.DEFINE_integer('seed', 0, 'Fix the random seed. 0 means no seeding.')
     g.DEFINE_integer('topn', 10, '')
     g.DEFINE_integer('num_preferences', 4, '')

@@ -82,6 +82,25 @@ def train_loop(FLAGS, model, trainer, rating_train_dataset, triple_train_dataset
         all_tail_dicts = [tail_train_dict] + [d[5] for d in triple_eval_datasets]
     item_total, entity_total = len(i_map), len(e_map)
     step_to_switch = 10 * FLAGS.joint_ratio          # :209 -- rec step iff step % 10 < 10 * joint_ratio
+    # KTUP with its own tables: the step body below runs as ~a dozen C-ABI launches (utils/fast_train.py) instead of through
+    # autograd; with -device_sampling the batches and their negatives never leave the GPU either.
+    stepper = rec_feed = kg_feed = sampler = None
+    if D.USE_CUDA and FLAGS.model_type == 'jtransup' and not FLAGS.share_embeddings and trainer.fused is not None \
+            and os.environ.get('KTUP_FAST_TRAIN', '1') != '0':
+        from jTransUP.utils.fast_train import DeviceFeeder, JointStepper
+        stepper = JointStepper(model, trainer, FLAGS, FLAGS.batch_size)
+        logger.info('GPU-resident training step enabled (KTUP_FAST_TRAIN=0 selects the autograd route).')
+        if FLAGS.device_sampling:
+            from jTransUP.utils.device_sampler import DeviceSampler
+            sampler = DeviceSampler(D.DEV, seed=FLAGS.seed)
+            sampler.set_rating_dicts(model.user_total, item_total, all_rating_dicts)
+            known = None
+            if FLAGS.filter_wrong_corrupted:
+                known = [triple_train_list] + [[(h, t, r) for (t, r), hs in d[4].items() for h in hs] for d in triple_eval_datasets]
+            sampler.set_triples(entity_total, model.rel_total, known)
+            rec_feed = DeviceFeeder(rating_train_list, FLAGS.batch_size, D.DEV, FLAGS.negtive_samples, seed=FLAGS.seed)
+            kg_feed = DeviceFeeder(triple_train_list, FLAGS.batch_size, D.DEV, FLAGS.negtive_samples, seed=FLAGS.seed + 1)
+            logger.info('Training data and negative sampling are device-resident (-device_sampling).')
     logger.info('Training.')
 
     def do_eval(totals):
@@ -117,6 +136,26 @@ def train_loop(FLAGS, model, trainer, rating_train_dataset, triple_train_dataset
     def do_step(step):
         is_rec = step % 10 < step_to_switch
         e_ids = i_ids = None
+        if stepper is not None and rec_feed is not None:
+            if is_rec:
+                rows = rec_feed.next()
+                u, pi = rows[:, 0].contiguous(), rows[:, 1].contiguous()
+                return 'rec', stepper.rec_step(u, pi, sampler.sample_rec(u, pi))
+            rows = kg_feed.next()                          # (h, t, r): tail before relation, like the files
+            ph, pt, pr = rows[:, 0].contiguous(), rows[:, 1].contiguous(), rows[:, 2].contiguous()
+            nh, nt = sampler.sample_kg(ph, pt, pr)
+            return 'kg', stepper.kg_step(ph, pt, pr, nh, nt, pr)
+        if stepper is not None:
+            if is_rec:
+                u, pi, ni = getNegRatings(next(rating_train_iter), item_total, all_dicts=all_rating_dicts)
+                if len(u) == stepper.B:
+                    return 'rec', stepper.rec_step(D.ids(u), D.ids(pi), D.ids(ni))
+            else:
+                ph, pt, pr, nh, nt, nr = getTrainTripleBatch(next(triple_train_iter), entity_total, all_head_dicts=all_head_dicts,
+                                                             all_tail_dicts=all_tail_dicts)
+                if len(ph) == stepper.B:
+                    return 'kg', stepper.kg_step(*(D.ids(x) for x in (ph, pt, pr, nh, nt, nr)))
+            raise RuntimeError('training batch of unexpected size (MakeTrainIterator yields full batches)')
         if is_rec:
             u, pi, ni = getNegRatings(next(rating_train_iter), item_total, all_dicts=all_rating_dicts)
             e_ids, i_ids = getMappedEntities(pi + ni, i_map, ikg_map)

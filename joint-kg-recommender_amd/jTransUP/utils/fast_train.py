@@ -109,3 +109,31 @@ class JointStepper(object):
     def _optimizer_step(self):
         self.trainer.fused.clip_and_step(self.max_norm, zero_grads=True)
         self.trainer.step += 1
+
+
+class DeviceFeeder(object):
+    """Device-resident training data for the GPU-resident loop: the rating / triple lists as device tensors, an epoch
+    permutation drawn on the device, batches as slices, negatives from the K19 samplers (utils/device_sampler.py).
+    Iterator contract of utils/data.py MakeTrainIterator (data.py:87-110): endless, reshuffled every epoch, the tail
+    partial batch dropped, `negtive_samples` copies of every example per epoch."""
+
+    def __init__(self, rows, batch_size, device, negtive_samples=1, seed=0):
+        self.rows = torch.as_tensor(rows, dtype=torch.int64).reshape(len(rows), -1)[:, :3].contiguous().to(device)
+        self.B, self.dev, self.rep = int(batch_size), device, int(negtive_samples)
+        self.gen = torch.Generator(device=device)
+        self.gen.manual_seed(int(seed))
+        self.n = self.rows.shape[0]
+        if self.n * self.rep < self.B:
+            raise ValueError('fewer training examples (%d) than one batch (%d)' % (self.n * self.rep, self.B))
+        self._shuffle()
+
+    def _shuffle(self):
+        self.order = torch.randperm(self.n * self.rep, generator=self.gen, device=self.dev) % self.n
+        self.start = 0
+
+    def next(self):
+        if self.start > self.order.numel() - self.B:
+            self._shuffle()
+        idx = self.order[self.start:self.start + self.B]
+        self.start += self.B
+        return self.rows.index_select(0, idx)

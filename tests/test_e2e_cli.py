@@ -68,3 +68,23 @@ def test_joint_cli_ktup_with_pretrained_tables(dataset):
     assert 'rec train loss:' in log and 'kg train loss:' in log
     assert len(re.findall(r'f1:\d\.\d+', log)) >= 6 and len(re.findall(r'avg hit:', log)) >= 6
     assert os.path.isfile(os.path.join(logs, 'ktup.ckpt'))
+
+
+@pytest.mark.parametrize('mode', ['device_sampling', 'autograd_route', 'gumbel'])
+def test_joint_cli_training_routes(dataset, mode, monkeypatch):
+    """KTUP through the GPU-resident step with on-device data + sampling (-device_sampling), through the autograd route
+    (KTUP_FAST_TRAIN=0), and with the ST-Gumbel gate on the GPU-resident step."""
+    extra = ['-model_type', 'jtransup', '-rec_test_files', 'valid.dat', '-kg_test_files', 'valid.dat', '-joint_ratio', '0.7',
+             '-noshare_embeddings']
+    if mode == 'device_sampling':
+        extra.append('-device_sampling')
+    if mode == 'gumbel':
+        extra.append('-use_st_gumbel')
+    if mode == 'autograd_route':
+        monkeypatch.setenv('KTUP_FAST_TRAIN', '0')
+    log, _ = run_cli('run_knowledgable_recommendation.py', dataset, 'ktup-' + mode, extra)
+    assert ('GPU-resident training step enabled' in log) == (mode != 'autograd_route')
+    assert ('device-resident' in log) == (mode == 'device_sampling')
+    losses = [float(x) for x in re.findall(r'rec train loss:(\d+\.\d+)', log)]
+    assert len(losses) >= 2 and all(l == l and l < 1e3 for l in losses)
+    assert len(re.findall(r'f1:\d\.\d+', log)) >= 3 and len(re.findall(r'avg hit:', log)) >= 3

@@ -237,11 +237,14 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (no CPU fallback: the HIP library is the product)')
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        # "nccl" is RCCL on ROCm.  KTUP_BENCH_BACKEND=gloo is a test hook: it lets the world > 1 code path run with several
+        # ranks sharing the one GPU of a single-GPU box (RCCL refuses duplicate devices).
+        dist.init_process_group(os.environ.get('KTUP_BENCH_BACKEND', 'nccl'), rank=rank, world_size=world)
+    local = local % torch.cuda.device_count()
     device = torch.device('cuda', local)
     torch.cuda.set_device(device)
 

@@ -66,9 +66,13 @@ int ktup_score_transh_bwd(const float* E, int64_t lde, const float* R, int64_t l
 
 /* ------------------------------------------- K4  TransR  transR.py:65-78 + utils/misc.py:21-26
  * M is the (n_rel x d*d) projection table, row r reshaped (d_rel=d) x (d_ent=d), row-major.       */
+/* Forward with scratch `ws` of ktup_score_transr_workspace_bytes(n, n_rel) bytes (4-byte aligned): the batch is bucketed
+ * by relation and each M_r is staged once per workgroup for a matrix-core projection (d in {64,100,128}, n_rel <= 4096);
+ * ws == NULL (or another shape) gathers M_r per triple like the reference does.                                      */
+size_t ktup_score_transr_workspace_bytes(int64_t n, int64_t n_rel);
 int ktup_score_transr_fwd(const float* E, int64_t lde, const float* R, int64_t ldr, const float* M, int64_t ldm,
-                          int d, const int64_t* h, const int64_t* t, const int64_t* r, int64_t n, int l1,
-                          float* score, void* stream);
+                          int64_t n_rel, int d, const int64_t* h, const int64_t* t, const int64_t* r, int64_t n,
+                          int l1, float* score, void* ws, void* stream);
 int ktup_score_transr_bwd(const float* E, int64_t lde, const float* R, int64_t ldr, const float* M, int64_t ldm,
                           int d, const int64_t* h, const int64_t* t, const int64_t* r, int64_t n, int l1,
                           const float* gscore, float* gE, float* gR, float* gM, void* stream);

@@ -83,4 +83,10 @@ int pref_fwd_mc(const float* U, int64_t ldu, const float* I, int64_t ldi, const 
                 const int64_t* i_ids, int64_t n, int l1, int gumbel_mode, const float* uniform, uint64_t seed, uint64_t offset,
                 float* score, hipStream_t st, const char* name);
 
+// ktup_score_transr_mc.hip: relation-bucketed matrix-core TransR forward.  Returns 1 when the shape is not covered.
+size_t transr_mc_workspace_bytes(int64_t n, int64_t n_rel);
+int transr_fwd_mc(const float* E, int64_t lde, const float* R, int64_t ldr, const float* M, int64_t ldm, int64_t n_rel, int d,
+                  const int64_t* h, const int64_t* t, const int64_t* r, int64_t n, int l1, float* score, void* ws, hipStream_t st,
+                  const char* name);
+
 }  // namespace ktup

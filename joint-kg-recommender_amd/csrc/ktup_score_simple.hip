@@ -7,6 +7,7 @@
 // index_select x3 + ~4-10 elementwise kernels, each materialising a (B x d) temporary.
 // When a pointer or pitch is not 16-B aligned (or d % 4 != 0) the same code runs with 4-byte lanes.
 #include "ktup_rows.h"
+#include "ktup_pref_geom.h"
 
 using namespace ktup;
 
@@ -352,9 +353,18 @@ static int transr_launch(bool bwd, const float* E, int64_t lde, const float* R, 
   return check_launch(name);
 }
 
+extern "C" size_t ktup_score_transr_workspace_bytes(int64_t n, int64_t n_rel) {
+  return n > 0 && n_rel > 0 ? ktup::transr_mc_workspace_bytes(n, n_rel) : 0;
+}
+
 extern "C" int ktup_score_transr_fwd(const float* E, int64_t lde, const float* R, int64_t ldr, const float* M, int64_t ldm,
-                                     int d, const int64_t* h, const int64_t* t, const int64_t* r, int64_t n, int l1,
-                                     float* score, void* stream) {
+                                     int64_t n_rel, int d, const int64_t* h, const int64_t* t, const int64_t* r, int64_t n,
+                                     int l1, float* score, void* ws, void* stream) {
+  if (ws && n > 0 && E && R && M && h && t && r && score && ldm >= (int64_t)d * d) {
+    const int rc = ktup::transr_fwd_mc(E, lde, R, ldr, M, ldm, n_rel, d, h, t, r, n, l1, score, ws, (hipStream_t)stream,
+                                       "ktup_score_transr_fwd");
+    if (rc != 1) return rc;
+  }
   return transr_launch(false, E, lde, R, ldr, M, ldm, d, h, t, r, n, l1, score, nullptr, nullptr, nullptr, nullptr,
                        stream, "ktup_score_transr_fwd");
 }

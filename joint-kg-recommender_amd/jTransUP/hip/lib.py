@@ -29,7 +29,8 @@ SIGNATURES = {
     'ktup_score_transe_bwd': [c_p, c_l, c_p, c_l, c_i, c_p, c_p, c_p, c_l, c_i, c_p, c_p, c_p, c_p],
     'ktup_score_transh_fwd': [c_p, c_l, c_p, c_l, c_p, c_l, c_l, c_i, c_p, c_p, c_p, c_l, c_i, c_p, c_p],
     'ktup_score_transh_bwd': [c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_p, c_p, c_p, c_l, c_i, c_p, c_p, c_p, c_p, c_p],
-    'ktup_score_transr_fwd': [c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_p, c_p, c_p, c_l, c_i, c_p, c_p],
+    'ktup_score_transr_workspace_bytes': [c_l, c_l],
+    'ktup_score_transr_fwd': [c_p, c_l, c_p, c_l, c_p, c_l, c_l, c_i, c_p, c_p, c_p, c_l, c_i, c_p, c_p, c_p],
     'ktup_score_transr_bwd': [c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_p, c_p, c_p, c_l, c_i, c_p, c_p, c_p, c_p, c_p],
     'ktup_pref_workspace_bytes': [c_i, c_i],
     'ktup_pref_prepare': [c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_p, c_p],
@@ -66,7 +67,7 @@ SIGNATURES = {
     'ktup_negsample_kg': [c_p, c_p, c_p, c_l, c_l, c_l, c_p, c_l, c_u, c_u, c_p, c_p, c_p],
 }
 _RESTYPE = {'ktup_last_error': ctypes.c_char_p, 'ktup_pref_workspace_bytes': ctypes.c_size_t,
-            'ktup_eval_kg_workspace_bytes': ctypes.c_size_t, 'ktup_eval_transr_workspace_bytes': ctypes.c_size_t,
+            'ktup_eval_kg_workspace_bytes': ctypes.c_size_t, 'ktup_eval_transr_workspace_bytes': ctypes.c_size_t, 'ktup_score_transr_workspace_bytes': ctypes.c_size_t,
             'ktup_eval_pref_workspace_bytes': ctypes.c_size_t, 'ktup_negsample_rec_workspace_bytes': ctypes.c_size_t}
 
 _lib = None

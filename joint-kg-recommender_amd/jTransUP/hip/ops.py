@@ -126,8 +126,11 @@ class _ScoreTransR(Function):
         dev = _dev(_table('entity table', E)); _table('relation table', R); _table('projection table', M)
         n = h.numel(); h = _ids('h', h, dev); t = _ids('t', t, dev, n); r = _ids('r', r, dev, n)
         score = torch.empty(n, dtype=torch.float32, device=dev)
-        L.call('ktup_score_transr_fwd', _p(E), E.stride(0), _p(R), R.stride(0), _p(M), M.stride(0), E.shape[1], _p(h), _p(t),
-               _p(r), n, int(l1), _p(score), _stream(dev))
+        n_rel = min(R.shape[0], M.shape[0])
+        nbytes = L.load().ktup_score_transr_workspace_bytes(n, n_rel)
+        ws = torch.empty((nbytes + 3) // 4, dtype=torch.int32, device=dev) if nbytes else None
+        L.call('ktup_score_transr_fwd', _p(E), E.stride(0), _p(R), R.stride(0), _p(M), M.stride(0), n_rel, E.shape[1], _p(h), _p(t),
+               _p(r), n, int(l1), _p(score), _p(ws), _stream(dev))
         ctx.save_for_backward(E, R, M, h, t, r); ctx.l1 = int(l1)
         return score
 

@@ -25,9 +25,10 @@ def init_distributed(backend=None):
     if world == 1 or dist.is_initialized():
         return dist.get_rank() if dist.is_initialized() else 0, world
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-    backend = backend or ('nccl' if torch.cuda.is_available() else 'gloo')
-    if backend == 'nccl':
-        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
+    # KTUP_DIST_BACKEND=gloo is a test hook: several ranks can then share the one GPU of a single-GPU box
+    backend = backend or os.environ.get('KTUP_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
+    if torch.cuda.is_available():
+        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')) % torch.cuda.device_count())
     dist.init_process_group(backend, rank=int(os.environ['RANK']), world_size=world)
     return dist.get_rank(), world
 

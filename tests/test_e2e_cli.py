@@ -88,3 +88,24 @@ def test_joint_cli_training_routes(dataset, mode, monkeypatch):
     losses = [float(x) for x in re.findall(r'rec train loss:(\d+\.\d+)', log)]
     assert len(losses) >= 2 and all(l == l and l < 1e3 for l in losses)
     assert len(re.findall(r'f1:\d\.\d+', log)) >= 3 and len(re.findall(r'avg hit:', log)) >= 3
+
+
+def test_joint_cli_data_parallel_torchrun(dataset):
+    """torchrun with two ranks (gloo test hook: they share this box's GPU): both replicas log the same metrics."""
+    data = str(dataset)
+    logs = os.path.join(data, 'log')
+    env = dict(os.environ, KTUP_DIST_BACKEND='gloo')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', '29533', os.path.join(PKG, 'run_knowledgable_recommendation.py'), '-data_path', data, '-log_path', logs,
+           '-dataset', 'ml1m', '-experiment_name', 'ktup-dp', '-nohas_visualization', '-batch_size', '32', '-embedding_size', '20',
+           '-seed', '3', '-eval_interval_steps', '10', '-training_steps', '25', '-early_stopping_steps_to_wait', '0',
+           '-learning_rate', '0.05', '-topn', '10', '-model_type', 'jtransup', '-rec_test_files', 'valid.dat', '-kg_test_files',
+           'valid.dat', '-joint_ratio', '0.7', '-noshare_embeddings']
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    log0 = open(os.path.join(logs, 'ktup-dp.log')).read()
+    log1 = open(os.path.join(logs, 'ktup-dp.rank1.log')).read()
+    m0 = re.findall(r'f1:\d\.\d+, p:\d\.\d+, r:\d\.\d+, hit:\d\.\d+, ndcg:\d\.\d+', log0)
+    m1 = re.findall(r'f1:\d\.\d+, p:\d\.\d+, r:\d\.\d+, hit:\d\.\d+, ndcg:\d\.\d+', log1)
+    assert len(m0) >= 3 and m0 == m1
+    assert re.findall(r'rec train loss:\d+\.\d+, kg train loss:\d+\.\d+', log0) == re.findall(r'rec train loss:\d+\.\d+, kg train loss:\d+\.\d+', log1)

@@ -74,3 +74,60 @@ def test_fast_steps_match_the_autograd_route(tmp_path, optimizer):
                 '%s after step %d: %d elements off, max %.3g' % (k, step, int(bad.sum()), float(err.max()))
     # the pad entity row never moves
     assert float(m2.ent_embeddings.weight[m2.ent_total - 1].abs().sum()) == 0.0
+
+
+def _dp_worker(rank, world, port, tmp, out):
+    import os
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)     # both ranks share the one GPU: RCCL refuses that, gloo does not
+    try:
+        from jTransUP.utils.fast_train import JointStepper
+        FLAGS, m, tr, (NU, NI, NE, NR) = build(os.path.join(tmp, 'r%d' % rank), 'Adagrad', False)
+        B = 64
+        fast = JointStepper(m, tr, FLAGS, B)
+        assert fast.world == world and fast.B == B // world
+        gen = torch.Generator().manual_seed(9)
+        rnd = lambda hi: torch.randint(0, hi, (B,), generator=gen).to(DEV)
+        losses = []
+        for is_rec in [True, False, True, False]:
+            if is_rec:
+                losses.append(float(fast.rec_step(rnd(NU), rnd(NI), rnd(NI))))
+            else:
+                ph, pt, pr, nh, nt = rnd(NE), rnd(NE), rnd(NR), rnd(NE), rnd(NE)
+                losses.append(float(fast.kg_step(ph, pt, pr, nh, nt, pr)))
+        torch.save({'state': {k: v.cpu() for k, v in m.state_dict().items()}, 'losses': losses}, os.path.join(out, 'rank%d.pt' % rank))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_steps_match_one_process(tmp_path):
+    """Two replicas (gloo, sharing this box's GPU) on halves of each global batch == one process on the whole batch."""
+    import os
+    import socket
+    import torch.multiprocessing as mp
+    from jTransUP.utils.fast_train import JointStepper
+    for r in range(2):
+        os.makedirs(os.path.join(str(tmp_path), 'r%d' % r))
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_dp_worker, args=(2, port, str(tmp_path), str(tmp_path)), nprocs=2, join=True)
+    FLAGS, m, tr, (NU, NI, NE, NR) = build(tmp_path, 'Adagrad', False)
+    B = 64
+    fast = JointStepper(m, tr, FLAGS, B)
+    gen = torch.Generator().manual_seed(9)
+    rnd = lambda hi: torch.randint(0, hi, (B,), generator=gen).to(DEV)
+    losses = []
+    for is_rec in [True, False, True, False]:
+        if is_rec:
+            losses.append(float(fast.rec_step(rnd(NU), rnd(NI), rnd(NI))))
+        else:
+            ph, pt, pr, nh, nt = rnd(NE), rnd(NE), rnd(NR), rnd(NE), rnd(NE)
+            losses.append(float(fast.kg_step(ph, pt, pr, nh, nt, pr)))
+    r0 = torch.load(os.path.join(str(tmp_path), 'rank0.pt'))
+    r1 = torch.load(os.path.join(str(tmp_path), 'rank1.pt'))
+    for k, v in m.state_dict().items():
+        assert torch.equal(r0['state'][k], r1['state'][k]), k                 # replicas stay identical
+        err = (r0['state'][k] - v.cpu()).abs()
+        bad = err > 2e-6 + 2e-5 * v.cpu().abs()
+        assert float(bad.float().mean()) <= 2e-3 and float(err.max()) <= 1e-3 * 0.05, (k, int(bad.sum()), float(err.max()))
+    torch.testing.assert_close(torch.tensor(r0['losses']), torch.tensor(losses), rtol=1e-5, atol=1e-6)

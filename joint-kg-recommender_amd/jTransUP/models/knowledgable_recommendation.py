@@ -47,7 +47,7 @@ def evaluateRec(FLAGS, model, eval_iter, eval_dict, all_dicts, i_map, logger, ev
     all_i_var = D.ids([i_map[i] for i in range(len(i_map))]) if FLAGS.share_embeddings else None
     model.eval(); model.disable_grad()
     results = D.rec_eval_pass(FLAGS, lambda u: model.evaluateRec(u, all_i_ids=all_i_var), eval_iter, eval_dict, all_dicts,
-                              eval_descending)
+                              eval_descending, want_rows=is_report)
     perf = D.summarize_rec(FLAGS, results, logger)
     if is_report:
         D.report_rec(FLAGS, model, results, all_dicts, eval_dict, logger, FLAGS.model_type in ('transup', 'jtransup'))

@@ -55,6 +55,10 @@ class RankIndex(object):
         self.g_off = torch.from_numpy(self.g_off_h).to(device)
         self.f_ids = torch.from_numpy(np.asarray(f_ids if f_ids else [0], dtype=np.int32)).to(device)
         self.g_ids = torch.from_numpy(self.g_ids_h if len(g_ids) else np.zeros(1, np.int32)).to(device)
+        # sorted (row << 32 | id) keys of the gold pairs: membership of a whole batch of top-n lists is one searchsorted
+        rows = np.repeat(np.arange(len(self.keys), dtype=np.int64), np.diff(self.g_off_h))
+        self.g_keys_h = (rows << 32) | self.g_ids_h.astype(np.int64)
+        self.present_h = np.asarray(self.present, dtype=bool)
 
     def rows_of(self, batch_keys):
         rows = [self.pos[k if not isinstance(k, list) else tuple(k)] for k in batch_keys]
@@ -103,10 +107,11 @@ def _device():
 
 
 def evalRecProcess(pred_scores, eval_dict, all_dicts=None, descending=True, num_processes=None, topn=10, queue_limit=10,
-                   index=None):
+                   index=None, as_array=False):
     """utils/misc.py:186-210.  Returns [[f1, p, r, hit, ndcg, (key, top_ids, gold)], ...] for the keys found in
     eval_dict.  `num_processes` / `queue_limit` are accepted and ignored (there is no process fan-out);
-    `index` (a RankIndex over the pass's keys) avoids rebuilding the CSR sets per batch."""
+    `index` (a RankIndex over the pass's keys) avoids rebuilding the CSR sets per batch.  `as_array=True` (this build) returns
+    only the (n x 5) float64 metric columns -- what the training-time evaluation needs -- without building per-user rows."""
     keys, mat = _as_device_rows(pred_scores, _device())
     if len(keys) == 0:
         return []
@@ -114,16 +119,44 @@ def evalRecProcess(pred_scores, eval_dict, all_dicts=None, descending=True, num_
         index = RankIndex(keys, eval_dict, all_dicts, mat.device)
     s, e = index.rows_of(keys)
     f_off, f_ids = index.filter_slice(s, e)
-    top = ops.topk_filtered(mat, descending, topn, f_off, f_ids).cpu().numpy()
+    top = ops.topk_filtered(mat, descending, topn, f_off, f_ids).cpu().numpy().astype(np.int64)
+    f1, p, r, hit, ndcg = rec_metrics_batch(top, index, s)
+    if as_array:
+        return np.stack([f1, p, r, hit.astype(np.float64), ndcg], axis=1)[index.present_h[s:e]]
     out = []
-    for b, key in enumerate(keys):
-        if not index.present[s + b]:
-            continue
-        gold = index.gold_sets[s + b]
-        ids = [int(i) for i in top[b] if i >= 0]
-        f1, p, r, hit, ndcg = rec_metrics(ids, gold)
-        out.append([f1, p, r, hit, ndcg, (key, ids, gold)])
+    cols = zip(f1.tolist(), p.tolist(), r.tolist(), hit.tolist(), ndcg.tolist(), top.tolist(), keys, index.gold_sets[s:e],
+               index.present_h[s:e].tolist())
+    for a, b, c, d, g, ids, key, gold, here in cols:
+        if here:
+            out.append([a, b, c, d, g, (key, [i for i in ids if i >= 0], gold)])
     return out
+
+
+def rec_metrics_batch(top, index, s):
+    """utils/misc.py:232-248 + evaluation.py:41-110 (NDCG method 0, ideal from the OBSERVED hits) for a whole batch of ranked
+    lists at once: float64 arrays (f1, p, r, hit, ndcg).  `top` is (B x topn) int64, -1 padded; rows are index rows s..s+B-1."""
+    B, topn = top.shape
+    valid = top >= 0
+    tk = ((np.arange(s, s + B, dtype=np.int64)[:, None]) << 32) | np.where(valid, top, 0)
+    pos = np.searchsorted(index.g_keys_h, tk)
+    found = index.g_keys_h[np.minimum(pos, max(len(index.g_keys_h) - 1, 0))] == tk if len(index.g_keys_h) else np.zeros_like(valid)
+    hits = (found & valid).astype(np.float64)
+    k = valid.sum(1).astype(np.float64)
+    hc = hits.sum(1)
+    k_gold = (index.g_off_h[s + 1:s + B + 1] - index.g_off_h[s:s + B]).astype(np.float64)
+    some = hc > 0
+    with np.errstate(divide='ignore', invalid='ignore'):
+        p = np.where(some, hc / k, 0.0)
+        r = np.where(some, hc / k_gold, 0.0)
+        f1 = np.where(some, 2 * p * r / (p + r), 0.0)
+        w = np.ones(topn, dtype=np.float64)
+        if topn > 1:
+            w[1:] = 1.0 / np.log2(np.arange(2, topn + 1))
+        dcg = hits[:, 0] + (hits[:, 1:] * w[1:]).sum(1)
+        ideal_by_count = np.concatenate([[0.0], w[0] + np.concatenate([[0.0], np.cumsum(w[1:])])])   # ideal DCG of c hits, c = 0..topn
+        ideal = ideal_by_count[hc.astype(np.int64)]
+        ndcg = np.where(some, dcg / ideal, 0.0)
+    return f1, p, r, some.astype(np.int64), ndcg
 
 
 def evalKGProcess(pred_scores, eval_dict, all_dicts=None, descending=True, num_processes=None, topn=10, queue_limit=10,

@@ -13,6 +13,8 @@
 // Pair-kernel mapping: lane <-> candidate (64-candidate tile staged once in LDS as [k/4][lane] float4, conflict-free
 // ds_read_b128); the 4 waves of a workgroup take different queries, QB = 4 queries at a time, whose vectors are
 // wave-uniform and therefore come through scalar loads into SGPRs.  The (B x N) score row is written coalesced.
+#include <cstdlib>
+
 #include "ktup_pref_geom.h"
 
 using namespace ktup;
@@ -543,6 +545,13 @@ extern "C" int ktup_eval_pref_scores(const float* U, int64_t ldu, const float* I
                      (const int64_t*)nullptr, n_items, d, n_pref, pref_ws, g.ppad, g.dp, -1.0f, (int64_t)d, CW0, CW1, CW2, CL);
   if (int e = check_launch(name)) return e;
   if (gumbel_mode == KTUP_GUMBEL_OFF) {
+    if (!l1) {     // squared L2: six (users x items) GEMMs on the matrix cores (ktup_eval_mc.hip); KTUP_EVAL_MC=0 for A/B runs
+      const char* env = getenv("KTUP_EVAL_MC");
+      if (!env || atoi(env) != 0) {
+        const int rc = ktup::pairs_l2_mc(QW, CW0, CW1, CW2, d, nq, n_items, out, ldo, st, name);
+        if (rc != 1) return rc;
+      }
+    }
     PairsArgs a{};
     a.C0 = CW0; a.C1 = CW1; a.C2 = CW2; a.ldc0 = a.ldc1 = a.ldc2 = d;
     a.QW = QW; a.n_cand = n_items; a.nq = nq; a.d = d; a.dq = d; a.l1 = l1; a.out = out; a.ldo = ldo; a.cvec = 1;

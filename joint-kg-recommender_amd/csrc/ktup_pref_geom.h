@@ -89,4 +89,8 @@ int transr_fwd_mc(const float* E, int64_t lde, const float* R, int64_t ldr, cons
                   const int64_t* h, const int64_t* t, const int64_t* r, int64_t n, int l1, float* score, void* ws, hipStream_t st,
                   const char* name);
 
+// ktup_eval_mc.hip: squared-L2 soft-gate all-item scores as six matrix-core GEMMs.  Returns 1 for sizes it does not cover.
+int pairs_l2_mc(const float* QW, const float* C0, const float* C1, const float* C2, int d, int64_t nq, int64_t n_items, float* out,
+                int64_t ldo, hipStream_t st, const char* name);
+
 }  // namespace ktup

@@ -433,6 +433,13 @@ int kg_eval(int model, const char* name, const float* E, int64_t lde, const floa
   hipLaunchKernelGGL(kg_query_prep_kernel, dim3(grid_for((nq + 3) / 4)), dim3(256), 0, st, model, E, lde, R, ldr, X, ldx, d, dq,
                      q, r, nq, head, ws);
   if (int e = check_launch(name)) return e;
+  if (!l1 && model <= 1) {   // squared L2: one (TransE) or two (TransH) GEMMs on the matrix cores; KTUP_EVAL_MC=0 for A/B runs
+    const char* env = getenv("KTUP_EVAL_MC");
+    if (!env || atoi(env) != 0) {
+      const int rc = ktup::pairs_kg_l2_mc(model, ws, dq, C, ldc, d, nq, n_cand, out, ldo, st, name);
+      if (rc != 1) return rc;
+    }
+  }
   PairsArgs a{};
   a.C0 = C; a.ldc0 = ldc; a.QW = ws; a.n_cand = n_cand; a.nq = nq; a.d = d; a.dq = dq; a.l1 = l1; a.out = out; a.ldo = ldo;
   a.cvec = (d % 4 == 0) && aligned16(C) && (ldc % 4 == 0);

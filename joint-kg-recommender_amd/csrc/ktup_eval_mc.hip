@@ -144,6 +144,137 @@ int launch(const EArgs& a, hipStream_t st, const char* name) {
   return check_launch(name);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// K12 / K13, squared L2: all-entity TransE / TransH scores.  Per query b (kg_query_prep_kernel): c_b (translated, projected
+// query) and, for TransH, the hyperplane normal w_b; per candidate: the entity row e_j.
+//   TransE (transE.py:65-105):   score = |c - e|^2                   = |c|^2 - 2 [c.e] + |e|^2
+//   TransH (transH.py:73-121):   score = |c - e + (e.w) w|^2         = |c|^2 + |e|^2 - 2 [c.e] + [e.w] (2 c.w + [e.w] (|w|^2 - 2))
+// (the reference projects every candidate on every query's hyperplane: three B x E x d tensors).  One or two GEMMs [.] on the
+// matrix cores, the rest per-row scalars.  L1 stays on pairs_kernel<0/1>.
+template <int NCH_, bool TRANSH_>
+struct KGeom {
+  static constexpr int NCH = NCH_, D = 4 * NCH;
+  static constexpr bool TRANSH = TRANSH_;
+  static constexpr int KG = (D + 15) / 16;
+  static constexpr bool TAIL1 = NCH - 4 * (KG - 1) == 1;
+  static constexpr int KGF = TAIL1 ? KG - 1 : KG;
+  static_assert(TAIL1 || NCH % 4 == 0, "k groups must be whole (d % 16 in {0, 4})");
+  static constexpr int P4 = NCH | 1;
+  static constexpr int QV = TRANSH ? 2 : 1;                    // vectors per query
+  static constexpr int UB = 64, NW = 16;
+  static constexpr size_t LDS = (size_t)(UB * QV + IB) * P4 * 16 + (size_t)(UB * 4 + IB) * 4;
+};
+
+struct KArgs {
+  const float* QW; int dq;          // queries: rows of 3 dq floats, slot 0 = c, slot 2 = w
+  const float* C; int64_t ldc;      // candidates
+  int64_t nq, n_cand;
+  float* out; int64_t ldo;
+};
+
+template <typename G>
+__global__ __launch_bounds__(G::NW * 64) void pairs_kg_l2_mc_kernel(KArgs a) {
+  constexpr int NCH = G::NCH, UB = G::UB, KGF = G::KGF, P4 = G::P4, NW = G::NW, QV = G::QV;
+  constexpr bool TAIL1 = G::TAIL1, TRANSH = G::TRANSH;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  v4* Q = reinterpret_cast<v4*>(smem);                         // [UB][QV][P4]
+  v4* Cd = Q + UB * QV * P4;                                   // [IB][P4]
+  float* qs = reinterpret_cast<float*>(Cd + IB * P4);          // [UB][4]: |c|^2, c.w, |w|^2
+  float* cs = qs + UB * 4;                                     // [IB]:    |e|^2
+  const int tid = threadIdx.x, lane = tid & 63, kq = lane >> 4, j = lane & 15;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t u0 = (int64_t)blockIdx.y * UB, i0 = (int64_t)blockIdx.x * IB;
+  for (int idx = tid; idx < UB * QV * NCH; idx += NW * 64) {
+    const int row = idx / (QV * NCH), rem = idx - row * (QV * NCH), vec = rem / NCH, c = rem - vec * NCH;
+    v4 val = (v4){0.f, 0.f, 0.f, 0.f};
+    if (u0 + row < a.nq) val = *reinterpret_cast<const v4*>(a.QW + ((u0 + row) * 3 + 2 * vec) * a.dq + 4 * c);
+    Q[(row * QV + vec) * P4 + c] = val;
+  }
+  for (int idx = tid; idx < IB * NCH; idx += NW * 64) {
+    const int row = idx / NCH, c = idx - row * NCH;
+    v4 val = (v4){0.f, 0.f, 0.f, 0.f};
+    if (i0 + row < a.n_cand) val = *reinterpret_cast<const v4*>(a.C + (i0 + row) * a.ldc + 4 * c);
+    Cd[row * P4 + c] = val;
+  }
+  __syncthreads();
+  for (int row = tid >> 3; row < UB + IB; row += (NW * 64) >> 3) {   // 8 lanes per row
+    v4 s0 = (v4){0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0;
+    if (row < UB) {
+      const v4* r0 = Q + row * QV * P4;
+      for (int c = tid & 7; c < NCH; c += 8) {
+        const v4 x0 = r0[c];
+        s0 += x0 * x0;
+        if (TRANSH) { const v4 x1 = r0[P4 + c]; s1 += x0 * x1; s2 += x1 * x1; }
+      }
+    } else {
+      const v4* r0 = Cd + (row - UB) * P4;
+      for (int c = tid & 7; c < NCH; c += 8) { const v4 x0 = r0[c]; s0 += x0 * x0; }
+    }
+    float f0 = (s0[0] + s0[1]) + (s0[2] + s0[3]), f1 = (s1[0] + s1[1]) + (s1[2] + s1[3]), f2 = (s2[0] + s2[1]) + (s2[2] + s2[3]);
+#pragma unroll
+    for (int m = 1; m < 8; m <<= 1) { f0 += __shfl_xor(f0, m, 64); f1 += __shfl_xor(f1, m, 64); f2 += __shfl_xor(f2, m, 64); }
+    if ((tid & 7) == 0) {
+      if (row < UB) { qs[row * 4 + 0] = f0; qs[row * 4 + 1] = f1; qs[row * 4 + 2] = f2; }
+      else cs[row - UB] = f0;
+    }
+  }
+  __syncthreads();
+  const int ut = w >> 2, it = w & 3;
+  const v4* qa = Q + ((16 * ut + j) * QV) * P4 + kq;
+  const v4* cb = Cd + (16 * it + j) * P4 + kq;
+  v4 ce = (v4){0.f, 0.f, 0.f, 0.f}, we = ce;
+#pragma unroll
+  for (int g = 0; g < KGF; ++g) {
+    const v4 ac = qa[4 * g], be = cb[4 * g];
+    v4 aw = ac;
+    if (TRANSH) aw = qa[P4 + 4 * g];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      ce = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[c], be[c], ce, 0, 0, 0);
+      if (TRANSH) we = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[c], be[c], we, 0, 0, 0);
+    }
+  }
+  if (TAIL1) {
+    const float* qf = reinterpret_cast<const float*>(Q + ((16 * ut + j) * QV) * P4 + 4 * KGF) + kq;
+    const float be = (reinterpret_cast<const float*>(Cd + (16 * it + j) * P4 + 4 * KGF) + kq)[0];
+    ce = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[0], be, ce, 0, 0, 0);
+    if (TRANSH) we = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[4 * P4], be, we, 0, 0, 0);
+  }
+  const float ee = cs[16 * it + j];
+  const int64_t cand = i0 + 16 * it + j;
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) {
+    const int ur = 16 * ut + 4 * kq + reg;
+    const float cc = qs[ur * 4 + 0];
+    float score = fmaf(-2.f, ce[reg], cc + ee);
+    if (TRANSH) {
+      const float cw = qs[ur * 4 + 1], ww = qs[ur * 4 + 2], ew = we[reg];
+      score = fmaf(ew, fmaf(ew, ww - 2.f, 2.f * cw), score);
+    }
+    if (u0 + ur < a.nq && cand < a.n_cand) a.out[(u0 + ur) * a.ldo + cand] = score;
+  }
+}
+
+template <typename G>
+int launch_kg(const KArgs& a, hipStream_t st, const char* name) {
+  (void)hipFuncSetAttribute((const void*)pairs_kg_l2_mc_kernel<G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS);
+  const dim3 grid((unsigned)((a.n_cand + IB - 1) / IB), (unsigned)((a.nq + G::UB - 1) / G::UB));
+  hipLaunchKernelGGL((pairs_kg_l2_mc_kernel<G>), grid, dim3(G::NW * 64), G::LDS, st, a);
+  return check_launch(name);
+}
+
+template <bool TRANSH>
+int dispatch_kg(const KArgs& a, int d, hipStream_t st, const char* name) {
+  switch (d) {
+    case 20: return launch_kg<KGeom<5, TRANSH>>(a, st, name);
+    case 36: return launch_kg<KGeom<9, TRANSH>>(a, st, name);
+    case 64: return launch_kg<KGeom<16, TRANSH>>(a, st, name);
+    case 100: return launch_kg<KGeom<25, TRANSH>>(a, st, name);
+    case 128: return launch_kg<KGeom<32, TRANSH>>(a, st, name);
+    default: return 1;
+  }
+}
+
 }  // namespace
 
 // Returns KTUP_OK / an error, or 1 when d is not an instantiated size (the caller runs the VALU kernel).
@@ -160,6 +291,15 @@ int pairs_l2_mc(const float* QW, const float* C0, const float* C1, const float* 
     case 128: return launch<EGeom<32, 32>>(a, st, name);
     default: return 1;
   }
+}
+
+// model: 0 TransE, 1 TransH.  Same contract as pairs_l2_mc.
+int pairs_kg_l2_mc(int model, const float* QW, int dq, const float* C, int64_t ldc, int d, int64_t nq, int64_t n_cand, float* out,
+                   int64_t ldo, hipStream_t st, const char* name) {
+  if (!aligned16(QW) || !aligned16(C) || (ldc & 3) || dq != d) return 1;
+  if ((nq + 63) / 64 > 65535) return 1;
+  const KArgs a{QW, dq, C, ldc, nq, n_cand, out, ldo};
+  return model == 1 ? dispatch_kg<true>(a, d, st, name) : dispatch_kg<false>(a, d, st, name);
 }
 
 }  // namespace ktup

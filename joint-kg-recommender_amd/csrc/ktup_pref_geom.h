@@ -93,4 +93,7 @@ int transr_fwd_mc(const float* E, int64_t lde, const float* R, int64_t ldr, cons
 int pairs_l2_mc(const float* QW, const float* C0, const float* C1, const float* C2, int d, int64_t nq, int64_t n_items, float* out,
                 int64_t ldo, hipStream_t st, const char* name);
 
+int pairs_kg_l2_mc(int model, const float* QW, int dq, const float* C, int64_t ldc, int d, int64_t nq, int64_t n_cand, float* out,
+                   int64_t ldo, hipStream_t st, const char* name);
+
 }  // namespace ktup

@@ -1,0 +1,364 @@
+// K5 / K6 backward, soft gate, on the matrix cores (transUP.py:69-115 / jTransUP.py:122-143,250-262 differentiated).
+//
+// Forward (per pair):  x = u + i (+ e),  q = u - i (- e),  L = x . Alog^T,  r = L . Ar,  n = L . Cn,  s = q . n,
+//                      z = q + r - s n,  score = sum_k dist(z_k)      (Alog = A/2, Ar = beta A, Cn = beta C, ktup_pref_prepare)
+// Backward for upstream g:   gz = g dist'(z),  av = gz . n,  gq = gz - av n,  gr = gz,  gn = -av q - s gz,
+//                            gL_p = Ar_p . gr + Cn_p . gn,   gx = sum_p gL_p Alog_p,   gu = gq + gx,   gi = ge = gx - gq,
+//                            gA_p += 1/2 gL_p x + beta L_p gr,   gC_p += beta L_p gn        (mixed tables A, C)
+// A wave owns 16 pairs through all phases; every contraction runs on v_mfma_f32_16x16x4_f32 with the operand layouts of
+// pref_fwd_mc (lane = (kq, pair); D registers of one phase are the B operands of the next):
+//   A  forward recompute  L^T = Alog . x^T   then  n^T, r^T = Cn^T L^T, Ar^T L^T                (as pref_fwd_mc)
+//   B  gL^T = ArSlot . gr^T + CnSlot . gn^T        B operands = the gz / gn registers of phase A's coordinate layout
+//   C  gx^T = Alog2^T . gL^T                       B operands = the gL registers
+//   D  gA += (gL/2)^T-by-pairs . X + (beta L) . GR,  gC += (beta L) . GN     K = the tile's 16 pairs; operands via small LDS
+//      transposes; accumulators stay in registers across the wave's tiles and reach memory with one atomic per element.
+// The first backward kernel (pref_bwd_kernel, lane = pair, 64-pair workgroup tiles, VALU) needs 118 us for the 1024 pairs
+// of a B=512 step because only 16 workgroups exist and each walks its tile serially; here a tile is ~450 MFMAs.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "ktup_common.h"
+#include "ktup_lane_swap.h"
+#include "ktup_pref_geom.h"
+
+namespace ktup {
+namespace {
+
+template <int NCH_, int NP_, bool HASE_>
+struct BGeom {
+  static constexpr int NCH = NCH_, NP = NP_, D = 4 * NCH;
+  static constexpr bool HASE = HASE_;
+  static constexpr int KG = (D + 15) / 16, CT = KG;
+  static constexpr int PT = (NP + 3) / 4;                  // 16-slot preference tiles
+  static constexpr int J = (16 * NCH + 63) / 64;
+  static constexpr int TOTAL = 16 * NCH;
+  static constexpr int PITCHA4 = 4 * KG + 1;               // slot-ordered tables (A operand of K = coordinate GEMMs)
+  static constexpr int SLOT_F4 = PT * 16 * PITCHA4;
+  static constexpr int TROW = 16 * PT;                     // [preference][coordinate] tables (A operand of K = preference GEMMs)
+  static constexpr int TPITCH = 16 * CT + ((16 * CT) % 32 == 0 ? 16 : 0);
+  static constexpr int T_F = TROW * TPITCH;
+  static constexpr size_t TABLE_BYTES = (size_t)3 * SLOT_F4 * 16 + (size_t)3 * T_F * 4;
+  static constexpr int TILE_F4 = 16 * NCH + 3;             // one (16 pairs x d) tile + 3 zero chunks
+  static constexpr int LT_F = TROW * 17;                   // transposed [preference][pair] arrays, pitch 17
+  static constexpr size_t WAVE_BYTES = ((size_t)4 * TILE_F4 * 16 + (size_t)2 * LT_F * 4 + 3 * 16 * 4 + 15) & ~(size_t)15;
+  static constexpr int NW = TABLE_BYTES + 2 * WAVE_BYTES <= 160 * 1024 ? 2 : 1;
+  static constexpr size_t LDS = TABLE_BYTES + NW * WAVE_BYTES;
+};
+
+struct BArgs {
+  const v4 *U, *I, *E;
+  uint32_t ldu4, ldi4, lde4;
+  const int32_t* item2ent;
+  const float *Alog, *Ar, *Cn;   // prepared tables, row pitch dp floats
+  int dp, P, l1;
+  float beta;
+  const int64_t *u_ids, *i_ids;
+  int64_t n, ent_pad;
+  const float* gscore;
+  float *gU, *gI, *gE, *gA, *gC;
+};
+
+template <typename G>
+__global__ __launch_bounds__(G::NW * 64) void pref_bwd_mc_kernel(BArgs a) {
+  constexpr int NCH = G::NCH, NP = G::NP, D = G::D, KG = G::KG, CT = G::CT, PT = G::PT, J = G::J, TOTAL = G::TOTAL;
+  constexpr int PITCHA4 = G::PITCHA4, TPITCH = G::TPITCH, TROW = G::TROW, NW = G::NW;
+  constexpr bool HASE = G::HASE;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  v4* AlogSlot = reinterpret_cast<v4*>(smem);                 // [PT*16 slots][PITCHA4]
+  v4* ArSlot = AlogSlot + G::SLOT_F4;
+  v4* CnSlot = ArSlot + G::SLOT_F4;
+  float* Alog2 = reinterpret_cast<float*>(CnSlot + G::SLOT_F4);   // [TROW][TPITCH]
+  float* Ar2 = Alog2 + G::T_F;
+  float* Cn2 = Ar2 + G::T_F;
+  const int tid = threadIdx.x, lane = tid & 63, kq = lane >> 4, j = lane & 15;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  char* wbase = reinterpret_cast<char*>(Cn2 + G::T_F) + (size_t)w * G::WAVE_BYTES;
+  v4* XT = reinterpret_cast<v4*>(wbase);                      // x   [16][NCH]
+  v4* QT = XT + G::TILE_F4;                                   // q
+  v4* GRT = QT + G::TILE_F4;                                  // gr = gz
+  v4* GNT = GRT + G::TILE_F4;                                 // gn
+  float* LT = reinterpret_cast<float*>(GNT + G::TILE_F4);     // [TROW][17]  beta * L   (transposed: preference major)
+  float* GLT = LT + G::LT_F;                                  // [TROW][17]  gL / 2
+  int32_t* sid = reinterpret_cast<int32_t*>(GLT + G::LT_F);   // [3][16]
+  // ---- stage the three tables in both layouts
+  {
+    const int P = a.P, dp = a.dp;
+    constexpr int rowf = PITCHA4 * 4;
+    float* s0 = reinterpret_cast<float*>(AlogSlot);
+    float* s1 = reinterpret_cast<float*>(ArSlot);
+    float* s2 = reinterpret_cast<float*>(CnSlot);
+    for (int idx = tid; idx < G::SLOT_F4 * 4; idx += NW * 64) {
+      const int srow = idx / rowf, k = idx - srow * rowf;
+      const int tt = srow >> 4, i = srow & 15;
+      const int p = 16 * tt + 4 * (i & 3) + (i >> 2);          // slot -> preference (block transposed, as in pref_fwd_mc)
+      const bool ok = p < P && k < D;
+      s0[idx] = ok ? a.Alog[p * dp + k] : 0.f;
+      s1[idx] = ok ? a.Ar[p * dp + k] : 0.f;
+      s2[idx] = ok ? a.Cn[p * dp + k] : 0.f;
+    }
+    for (int idx = tid; idx < G::T_F; idx += NW * 64) {
+      const int p = idx / TPITCH, c = idx - p * TPITCH;
+      const bool ok = p < P && c < D;
+      Alog2[idx] = ok ? a.Alog[p * dp + c] : 0.f;
+      Ar2[idx] = ok ? a.Ar[p * dp + c] : 0.f;
+      Cn2[idx] = ok ? a.Cn[p * dp + c] : 0.f;
+    }
+    if (lane < 3) {
+      XT[16 * NCH + lane] = (v4){0.f, 0.f, 0.f, 0.f}; QT[16 * NCH + lane] = XT[16 * NCH + lane];
+      GRT[16 * NCH + lane] = XT[16 * NCH + lane]; GNT[16 * NCH + lane] = XT[16 * NCH + lane];
+    }
+  }
+  __syncthreads();
+  int grow[J], gc[J];
+#pragma unroll
+  for (int jj = 0; jj < J; ++jj) {
+    const int e = lane + 64 * jj;
+    const bool past = e >= TOTAL;
+    grow[jj] = past ? 0 : e / NCH;
+    gc[jj] = past ? 0 : e % NCH;
+  }
+  const bool last_ok = lane + 64 * (J - 1) < TOTAL;
+  const bool l1 = a.l1 != 0;
+  const float beta = a.beta;
+  // table-gradient accumulators: phase D's D layout, lane (kq, n) <-> preference 16 pt + 4 kq + reg, coordinate 16 ct + n
+  v4 accA[PT][CT], accC[PT][CT];
+#pragma unroll
+  for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) { accA[pt][ct] = (v4){0.f, 0.f, 0.f, 0.f}; accC[pt][ct] = accA[pt][ct]; }
+  const int64_t ntiles = (a.n + 15) / 16;
+  for (int64_t tile_id = (int64_t)blockIdx.x * NW + w; tile_id < ntiles; tile_id += (int64_t)gridDim.x * NW) {
+    const int64_t row0 = tile_id * 16;
+    if (lane < 16) {
+      const int64_t gr = row0 + lane;
+      const bool ok = gr < a.n;
+      const int64_t uid = ok ? a.u_ids[gr] : 0, iid = ok ? a.i_ids[gr] : 0;
+      sid[lane] = (int32_t)uid;
+      sid[16 + lane] = (int32_t)iid;
+      sid[32 + lane] = HASE ? a.item2ent[iid] : 0;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // ---- gather: x and q tiles
+    {
+      v4 uu[J], vv[J], ee[J];
+#pragma unroll
+      for (int jj = 0; jj < J; ++jj) {
+        asm volatile("" : "+v"(gc[jj]));
+        const uint32_t idu = (uint32_t)sid[grow[jj]], idi = (uint32_t)sid[16 + grow[jj]];
+        uu[jj] = a.U[(uint64_t)idu * a.ldu4 + (uint32_t)gc[jj]];
+        vv[jj] = a.I[(uint64_t)idi * a.ldi4 + (uint32_t)gc[jj]];
+        if (HASE) {
+          const uint32_t ide = (uint32_t)sid[32 + grow[jj]];
+          ee[jj] = a.E[(uint64_t)ide * a.lde4 + (uint32_t)gc[jj]];
+        }
+      }
+#pragma unroll
+      for (int jj = 0; jj < J; ++jj) {
+        const v4 ve = HASE ? vv[jj] + ee[jj] : vv[jj];
+        if (jj < J - 1 || last_ok) { XT[lane + 64 * jj] = uu[jj] + ve; QT[lane + 64 * jj] = uu[jj] + (-ve); }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // ---- A1: L^T.  lg[tt][reg] of lane (kq, pair j) = logit of preference 16 tt + 4 reg + kq
+    v4 lg[PT];
+#pragma unroll
+    for (int tt = 0; tt < PT; ++tt) lg[tt] = (v4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int g = 0; g < KG; ++g) {
+      v4 bv = XT[j * NCH + 4 * g + kq];
+      if (4 * g + 3 >= NCH) {
+        if (4 * g + kq >= NCH) bv = (v4){0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int tt = 0; tt < PT; ++tt) {
+        const v4 av = AlogSlot[(tt * 16 + j) * PITCHA4 + 4 * g + kq];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) lg[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c], bv[c], lg[tt], 0, 0, 0);
+      }
+    }
+    // ---- A2: n^T, r^T per coordinate tile; lane (kq, j) owns coordinates 16 ct + 4 kq + reg of pair j
+    v4 nn[CT], zz[CT], qv[CT];
+    v4 sacc = (v4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      qv[ct] = (4 * ct + kq < NCH) ? QT[j * NCH + 4 * ct + kq] : (v4){0.f, 0.f, 0.f, 0.f};
+      nn[ct] = (v4){0.f, 0.f, 0.f, 0.f};
+      zz[ct] = qv[ct];                                          // q + r accumulates on top of q
+#pragma unroll
+      for (int m = 0; m < NP; ++m) {
+        const int prow = (16 * (m >> 2) + 4 * (m & 3) + kq) * TPITCH + 16 * ct + j;
+        nn[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(Cn2[prow], lg[m >> 2][m & 3], nn[ct], 0, 0, 0);
+        zz[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(Ar2[prow], lg[m >> 2][m & 3], zz[ct], 0, 0, 0);
+      }
+      sacc += qv[ct] * nn[ct];
+    }
+    const float s = allsum_kq((sacc[0] + sacc[1]) + (sacc[2] + sacc[3]));
+    const float g = row0 + j < a.n ? a.gscore[row0 + j] : 0.f;    // tail pairs contribute nothing
+    // gz (kept in zz), av
+    v4 aacc = (v4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      const v4 z = zz[ct] - s * nn[ct];
+      v4 gz;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) gz[c] = g * ddist1(z[c], l1);
+      zz[ct] = gz;
+      aacc += gz * nn[ct];
+    }
+    const float av = allsum_kq((aacc[0] + aacc[1]) + (aacc[2] + aacc[3]));
+    // gq (into qv), gn (into nn); gr = gz.  Tiles GRT / GNT for phase D.
+    v4 gq[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      gq[ct] = zz[ct] - av * nn[ct];
+      nn[ct] = -av * qv[ct] - s * zz[ct];
+      if (4 * ct + kq < NCH) { GRT[j * NCH + 4 * ct + kq] = zz[ct]; GNT[j * NCH + 4 * ct + kq] = nn[ct]; }
+    }
+    // ---- B: gL^T = ArSlot . gr^T + CnSlot . gn^T   (K = coordinates; B operands are zz / nn in registers)
+    v4 gl[PT];
+#pragma unroll
+    for (int tt = 0; tt < PT; ++tt) gl[tt] = (v4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int g4 = 0; g4 < KG; ++g4) {
+#pragma unroll
+      for (int tt = 0; tt < PT; ++tt) {
+        const v4 ar = ArSlot[(tt * 16 + j) * PITCHA4 + 4 * g4 + kq];
+        const v4 cn = CnSlot[(tt * 16 + j) * PITCHA4 + 4 * g4 + kq];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          gl[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[c], zz[g4][c], gl[tt], 0, 0, 0);
+          gl[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(cn[c], nn[g4][c], gl[tt], 0, 0, 0);
+        }
+      }
+    }
+    // transposed copies for phase D: LT[p][pair] = beta L, GLT[p][pair] = gL / 2
+#pragma unroll
+    for (int tt = 0; tt < PT; ++tt)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int p = 16 * tt + 4 * reg + kq;
+        LT[p * 17 + j] = beta * lg[tt][reg];
+        GLT[p * 17 + j] = 0.5f * gl[tt][reg];
+      }
+    // ---- C: gx^T = Alog2^T . gL^T, then the row gradients
+    {
+      const int64_t gr = row0 + j;
+      const bool live = gr < a.n;
+      const int32_t ur = sid[j], ir = sid[16 + j], er = sid[32 + j];
+      float* pu = a.gU + (int64_t)ur * a.ldu4 * 4;
+      float* pi = a.gI + (int64_t)ir * a.ldi4 * 4;
+      float* pe = (HASE && er != a.ent_pad) ? a.gE + (int64_t)er * a.lde4 * 4 : nullptr;
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        v4 gx = (v4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int m = 0; m < NP; ++m) {
+          const int prow = (16 * (m >> 2) + 4 * (m & 3) + kq) * TPITCH + 16 * ct + j;
+          gx = __builtin_amdgcn_mfma_f32_16x16x4f32(Alog2[prow], gl[m >> 2][m & 3], gx, 0, 0, 0);
+        }
+        const int c0 = 16 * ct + 4 * kq;
+        if (live && 4 * ct + kq < NCH) {
+          const v4 gu = gq[ct] + gx, gv = gx - gq[ct];
+          atomic_add4(pu + c0, make_float4(gu[0], gu[1], gu[2], gu[3]));
+          atomic_add4(pi + c0, make_float4(gv[0], gv[1], gv[2], gv[3]));
+          if (pe) atomic_add4(pe + c0, make_float4(gv[0], gv[1], gv[2], gv[3]));
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // ---- D: table gradients, K = the tile's 16 pairs (4 k-steps).  A[i = preference][k = pair] from LT / GLT,
+    //         B[k = pair][n = coordinate] from the XT / GRT / GNT tiles (b32 reads, 16 consecutive coordinates per kq group)
+    {
+      const float* xf = reinterpret_cast<const float*>(XT);
+      const float* grf = reinterpret_cast<const float*>(GRT);
+      const float* gnf = reinterpret_cast<const float*>(GNT);
+#pragma unroll
+      for (int st = 0; st < 4; ++st) {
+        float al[PT], agl[PT];
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) { al[pt] = LT[(16 * pt + j) * 17 + 4 * st + kq]; agl[pt] = GLT[(16 * pt + j) * 17 + 4 * st + kq]; }
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+          const int col = 16 * ct + j;
+          const int off = (4 * st + kq) * (NCH * 4) + col;
+          const bool in = col < D;
+          const float bx = in ? xf[off] : 0.f, bgr = in ? grf[off] : 0.f, bgn = in ? gnf[off] : 0.f;
+#pragma unroll
+          for (int pt = 0; pt < PT; ++pt) {
+            accA[pt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(agl[pt], bx, accA[pt][ct], 0, 0, 0);
+            accA[pt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(al[pt], bgr, accA[pt][ct], 0, 0, 0);
+            accC[pt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(al[pt], bgn, accC[pt][ct], 0, 0, 0);
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  // ---- flush the table gradients: lane (kq, n) holds preference 16 pt + 4 kq + reg, coordinate 16 ct + n
+#pragma unroll
+  for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int p = 16 * pt + 4 * kq + reg, c = 16 * ct + j;
+        if (p < a.P && c < D) {
+          const float va = accA[pt][ct][reg], vc = accC[pt][ct][reg];
+          if (va != 0.f) atomicAdd(a.gA + (int64_t)p * D + c, va);
+          if (vc != 0.f) atomicAdd(a.gC + (int64_t)p * D + c, vc);
+        }
+      }
+}
+
+template <typename G>
+int launch(const BArgs& a, hipStream_t st, const char* name) {
+  static_assert(G::LDS <= 160 * 1024, "LDS budget");
+  (void)hipFuncSetAttribute((const void*)pref_bwd_mc_kernel<G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS);
+  const int64_t ntiles = (a.n + 15) / 16;
+  const int grid = grid_for((ntiles + G::NW - 1) / G::NW, 256);
+  hipLaunchKernelGGL((pref_bwd_mc_kernel<G>), dim3(grid), dim3(G::NW * 64), G::LDS, st, a);
+  return check_launch(name);
+}
+
+template <int NCH, int NP>
+int launch_e(const BArgs& a, hipStream_t st, const char* name) {
+  if (a.E) return launch<BGeom<NCH, NP, true>>(a, st, name);
+  return launch<BGeom<NCH, NP, false>>(a, st, name);
+}
+
+template <int NCH>
+int launch_np(const BArgs& a, int np, hipStream_t st, const char* name) {
+  if (np <= 4) return launch_e<NCH, 4>(a, st, name);
+  if (np <= 5) return launch_e<NCH, 5>(a, st, name);
+  return launch_e<NCH, 8>(a, st, name);
+}
+
+}  // namespace
+
+// Soft gate only.  Returns KTUP_OK / an error, or 1 when (d, P) is not covered (the caller runs pref_bwd_kernel).
+int pref_bwd_mc(const float* U, int64_t ldu, const float* I, int64_t ldi, const float* E, int64_t lde, const int32_t* item2ent,
+                int64_t ent_pad, const float* Alog, const float* Ar, const float* Cn, int dp, float beta, int n_pref, int d,
+                const int64_t* u_ids, const int64_t* i_ids, int64_t n, int l1, const float* gscore, float* gU, float* gI, float* gE,
+                float* gA, float* gC, hipStream_t st, const char* name) {
+  if (n_pref > 32 || (d != 64 && d != 100 && d != 128)) return 1;
+  if ((ldu | ldi | lde) & 3) return 1;
+  if ((ldu >> 2) > 0xffffffffll || (ldi >> 2) > 0xffffffffll || (lde >> 2) > 0xffffffffll) return 1;
+  BArgs a;
+  a.U = reinterpret_cast<const v4*>(U); a.I = reinterpret_cast<const v4*>(I); a.E = reinterpret_cast<const v4*>(E);
+  a.ldu4 = (uint32_t)(ldu >> 2); a.ldi4 = (uint32_t)(ldi >> 2); a.lde4 = (uint32_t)(lde >> 2);
+  a.item2ent = item2ent;
+  a.Alog = Alog; a.Ar = Ar; a.Cn = Cn; a.dp = dp; a.P = n_pref; a.l1 = l1; a.beta = beta;
+  a.u_ids = u_ids; a.i_ids = i_ids; a.n = n; a.ent_pad = ent_pad;
+  a.gscore = gscore; a.gU = gU; a.gI = gI; a.gE = gE; a.gA = gA; a.gC = gC;
+  const int np = (n_pref + 3) / 4;
+  if (d == 64) return launch_np<16>(a, np, st, name);
+  if (d == 100) return launch_np<25>(a, np, st, name);
+  return launch_np<32>(a, np, st, name);
+}
+
+}  // namespace ktup

@@ -29,7 +29,7 @@ def _p(t):
 
 
 class JointStepper(object):
-    def __init__(self, model, trainer, FLAGS, batch_size, group=None):
+    def __init__(self, model, trainer, FLAGS, batch_size, group=None, use_graphs=None):
         if trainer.fused is None:
             raise L.KtupError('JointStepper needs the fused optimizer (KTUP_FUSED_OPTIM=0 disables it)')
         self.m, self.trainer = model, trainer
@@ -72,71 +72,158 @@ class JointStepper(object):
         self.ws = ops.pref_workspace(P, Pn, R, Rn)
         self.ent_pad = model.ent_total - 1
         self.i2e = model._item2ent
+        self._keys = None
+        self._stream = None
+        # HIP graphs: with the soft gate and a step-independent optimizer every launch argument of a step is static, so the
+        # ~15 launches replay as ONE graph launch (KTUP_TRAIN_GRAPHS=0 disables).  Inputs are copied into fixed buffers first.
+        if use_graphs is None:
+            import os
+            use_graphs = os.environ.get('KTUP_TRAIN_GRAPHS', '1') != '0'
+        self.use_graphs = bool(use_graphs) and self.world == 1 and not model.use_st_gumbel
+        self._graphs = {}
+        self._eager_steps = {'rec': 0, 'kg': 0}
+        GB = self.GB
+        self._in = {'rec': [torch.zeros(GB, **i64) for _ in range(3)], 'kg': [torch.zeros(GB, **i64) for _ in range(6)]}
 
     def _mine(self, t):
         """This rank's rows of a global-batch id tensor."""
         return t if self.world == 1 else t[self.rank * self.B:(self.rank + 1) * self.B]
 
+    # ------------------------------------------------------------------------------------------------ launch plans
+    def _bind(self):
+        """Every launch of a step has fixed arguments (persistent buffers): marshal them once (lib.bind).  Re-done when a
+        table's storage moves (load_state_dict keeps storages, so in practice never)."""
+        U, I, E, P, Pn, R, Rn = self.tabs
+        B, st = self.B, torch.cuda.current_stream(self.dev).cuda_stream
+        n_pref, d = P.shape
+        n_rel = min(R.shape[0], Rn.shape[0])
+        pos, neg, gpos, gneg = self.score[:B], self.score[B:], self.gscore[:B], self.gscore[B:]
+        off = ops.GUMBEL_OFF
+        b = L.bind
+        self._keys = tuple(t.data_ptr() for t in self.tabs) + tuple(t.grad.data_ptr() for t in self.tabs)
+        self._stream = st
+        self._rec_head = [
+            b('ktup_pref_prepare', _p(P), _p(Pn), _p(R), _p(Rn), P.stride(0), n_pref, d, _p(self.ws), st)]
+        self._rec_soft = [            # soft gate only: the Gumbel stream advances per step and is marshalled per call
+            b('ktup_score_ktup_fwd', _p(U), U.stride(0), _p(I), I.stride(0), _p(E), E.stride(0), _p(self.i2e), _p(self.ws), n_pref, d,
+              _p(self.u2), _p(self.i2), 2 * B, self.l1, off, None, 0, 0, _p(self.score), st)]
+        self._rec_loss = [
+            b('ktup_loss_bpr_fwd', _p(pos), _p(neg), B, self.target, _p(self.loss[0:]), st),
+            b('ktup_loss_bpr_bwd', _p(pos), _p(neg), B, self.target, _p(self.inv_world), _p(gpos), _p(gneg), st)]
+        self._rec_soft_bwd = [
+            b('ktup_score_ktup_bwd', _p(U), U.stride(0), _p(I), I.stride(0), _p(E), E.stride(0), _p(self.i2e), self.ent_pad,
+              _p(self.ws), n_pref, d, _p(self.u2), _p(self.i2), 2 * B, self.l1, off, None, 0, 0,
+              _p(self.gscore), _p(U.grad), _p(I.grad), _p(E.grad), _p(self.gAC[0]), _p(self.gAC[1]), st)]
+        self._rec_tail = [
+            b('ktup_reg_orth_fwd', _p(P), P.stride(0), _p(Pn), Pn.stride(0), d, None, n_pref, _p(self.loss[1:]), st),
+            b('ktup_reg_orth_bwd', _p(P), P.stride(0), _p(Pn), Pn.stride(0), d, None, n_pref, _p(self.inv_world), _p(P.grad), _p(Pn.grad), st)]
+        self._kg = [
+            b('ktup_score_transh_fwd', _p(E), E.stride(0), _p(R), R.stride(0), _p(Rn), Rn.stride(0), n_rel, d, _p(self.h2),
+              _p(self.t2), _p(self.r2), 2 * B, self.l1, _p(self.score), st),
+            b('ktup_loss_margin_fwd', _p(pos), _p(neg), B, self.margin, _p(self.loss[0:]), st),
+            b('ktup_loss_margin_bwd', _p(pos), _p(neg), B, self.margin, _p(self.lam), _p(gpos), _p(gneg), st),
+            b('ktup_score_transh_bwd', _p(E), E.stride(0), _p(R), R.stride(0), _p(Rn), Rn.stride(0), d, _p(self.h2), _p(self.t2),
+              _p(self.r2), 2 * B, self.l1, _p(self.gscore), _p(E.grad), _p(R.grad), _p(Rn.grad), st),
+            b('ktup_reg_orth_fwd', _p(R), R.stride(0), _p(Rn), Rn.stride(0), d, _p(self.r2), 2 * B, _p(self.loss[1:]), st),
+            b('ktup_reg_orth_bwd', _p(R), R.stride(0), _p(Rn), Rn.stride(0), d, _p(self.r2), 2 * B, _p(self.lam), _p(R.grad), _p(Rn.grad), st),
+            b('ktup_reg_norm_fwd', _p(E), E.stride(0), d, _p(self.ht4), 4 * B, _p(self.loss[2:]), st),
+            b('ktup_reg_norm_bwd', _p(E), E.stride(0), d, _p(self.ht4), 4 * B, _p(self.lam), _p(E.grad), st),
+            b('ktup_reg_norm_fwd', _p(R), R.stride(0), d, _p(self.r2), 2 * B, _p(self.loss[3:]), st),
+            b('ktup_reg_norm_bwd', _p(R), R.stride(0), d, _p(self.r2), 2 * B, _p(self.lam), _p(R.grad), st)]
+
+    def _plans(self):
+        st = torch.cuda.current_stream(self.dev).cuda_stream
+        if self._keys is None or st != self._stream or self._keys[0] != self.tabs[0].data_ptr() or \
+                self._keys != tuple(t.data_ptr() for t in self.tabs) + tuple(t.grad.data_ptr() for t in self.tabs):
+            self._bind()
+
     # ------------------------------------------------------------------------------------------------ rec
-    def rec_step(self, u, pi, ni):
-        """u, pi, ni: int64 device tensors of B ids.  Returns the step's loss (0-dim device tensor)."""
+    def _rec_eager(self, u, pi, ni):
         m, B = self.m, self.B
         U, I, E, P, Pn, R, Rn = self.tabs
-        st = torch.cuda.current_stream(self.dev).cuda_stream
+        self._plans()
         u, pi, ni = self._mine(u), self._mine(pi), self._mine(ni)
-        self.u2[:B].copy_(u); self.u2[B:].copy_(u); self.i2[:B].copy_(pi); self.i2[B:].copy_(ni)
-        n_pref, d = P.shape
-        mode, uni, seed, off = m._gumbel.mode_and_stream(m.use_st_gumbel, None, 2 * B * n_pref)
-        L.call('ktup_pref_prepare', _p(P), _p(Pn), _p(R), _p(Rn), P.stride(0), n_pref, d, _p(self.ws), st)
-        L.call('ktup_score_ktup_fwd', _p(U), U.stride(0), _p(I), I.stride(0), _p(E), E.stride(0), _p(self.i2e), _p(self.ws), n_pref, d,
-               _p(self.u2), _p(self.i2), 2 * B, self.l1, int(mode), _p(uni), int(seed), int(off), _p(self.score), st)
-        pos, neg, gpos, gneg = self.score[:B], self.score[B:], self.gscore[:B], self.gscore[B:]
-        L.call('ktup_loss_bpr_fwd', _p(pos), _p(neg), B, self.target, _p(self.loss[0:]), st)
-        L.call('ktup_loss_bpr_bwd', _p(pos), _p(neg), B, self.target, _p(self.inv_world), _p(gpos), _p(gneg), st)
+        torch.cat((u, u), out=self.u2); torch.cat((pi, ni), out=self.i2)
+        self._rec_head[0]()
         self.gAC.zero_()
-        L.call('ktup_score_ktup_bwd', _p(U), U.stride(0), _p(I), I.stride(0), _p(E), E.stride(0), _p(self.i2e), self.ent_pad,
-               _p(self.ws), n_pref, d, _p(self.u2), _p(self.i2), 2 * B, self.l1, int(mode), _p(uni), int(seed), int(off),
-               _p(self.gscore), _p(U.grad), _p(I.grad), _p(E.grad), _p(self.gAC[0]), _p(self.gAC[1]), st)
+        if not m.use_st_gumbel:
+            self._rec_soft[0](); self._rec_loss[0](); self._rec_loss[1](); self._rec_soft_bwd[0]()
+        else:
+            n_pref, d = P.shape
+            st = self._stream
+            mode, uni, seed, off = m._gumbel.mode_and_stream(True, None, 2 * B * n_pref)
+            L.call('ktup_score_ktup_fwd', _p(U), U.stride(0), _p(I), I.stride(0), _p(E), E.stride(0), _p(self.i2e), _p(self.ws), n_pref,
+                   d, _p(self.u2), _p(self.i2), 2 * B, self.l1, int(mode), _p(uni), int(seed), int(off), _p(self.score), st)
+            self._rec_loss[0](); self._rec_loss[1]()
+            L.call('ktup_score_ktup_bwd', _p(U), U.stride(0), _p(I), I.stride(0), _p(E), E.stride(0), _p(self.i2e), self.ent_pad,
+                   _p(self.ws), n_pref, d, _p(self.u2), _p(self.i2), 2 * B, self.l1, int(mode), _p(uni), int(seed), int(off),
+                   _p(self.gscore), _p(U.grad), _p(I.grad), _p(E.grad), _p(self.gAC[0]), _p(self.gAC[1]), st)
         # A = pref + rel and C = pref_norm + norm: the mixed-table gradient goes to both summands
         torch._foreach_add_([P.grad, R.grad, Pn.grad, Rn.grad], [self.gAC[0], self.gAC[0], self.gAC[1], self.gAC[1]])
-        L.call('ktup_reg_orth_fwd', _p(P), P.stride(0), _p(Pn), Pn.stride(0), d, None, n_pref, _p(self.loss[1:]), st)
-        L.call('ktup_reg_orth_bwd', _p(P), P.stride(0), _p(Pn), Pn.stride(0), d, None, n_pref, _p(self.inv_world), _p(P.grad), _p(Pn.grad), st)
+        self._rec_tail[0](); self._rec_tail[1]()
         if self.world > 1:
             self.loss[:2].mul_(self.inv_world); self.loss[2:].zero_()
-        self._optimizer_step()
+        self._optimizer_launches()
         return self.loss[0] + self.loss[1]
 
     # ------------------------------------------------------------------------------------------------ kg
-    def kg_step(self, ph, pt, pr, nh, nt, nr):
-        B = self.B
-        _, _, E, _, _, R, Rn = self.tabs
-        st = torch.cuda.current_stream(self.dev).cuda_stream
+    def _kg_eager(self, ph, pt, pr, nh, nt, nr):
+        self._plans()
         ph, pt, pr, nh, nt, nr = (self._mine(x) for x in (ph, pt, pr, nh, nt, nr))
-        self.h2[:B].copy_(ph); self.h2[B:].copy_(nh); self.t2[:B].copy_(pt); self.t2[B:].copy_(nt)
-        self.r2[:B].copy_(pr); self.r2[B:].copy_(nr)
-        self.ht4[:B].copy_(ph); self.ht4[B:2 * B].copy_(pt); self.ht4[2 * B:3 * B].copy_(nh); self.ht4[3 * B:].copy_(nt)
-        d, n_rel = E.shape[1], min(R.shape[0], Rn.shape[0])
-        L.call('ktup_score_transh_fwd', _p(E), E.stride(0), _p(R), R.stride(0), _p(Rn), Rn.stride(0), n_rel, d, _p(self.h2),
-               _p(self.t2), _p(self.r2), 2 * B, self.l1, _p(self.score), st)
-        pos, neg, gpos, gneg = self.score[:B], self.score[B:], self.gscore[:B], self.gscore[B:]
-        L.call('ktup_loss_margin_fwd', _p(pos), _p(neg), B, self.margin, _p(self.loss[0:]), st)
-        L.call('ktup_loss_margin_bwd', _p(pos), _p(neg), B, self.margin, _p(self.lam), _p(gpos), _p(gneg), st)
-        L.call('ktup_score_transh_bwd', _p(E), E.stride(0), _p(R), R.stride(0), _p(Rn), Rn.stride(0), d, _p(self.h2), _p(self.t2),
-               _p(self.r2), 2 * B, self.l1, _p(self.gscore), _p(E.grad), _p(R.grad), _p(Rn.grad), st)
-        L.call('ktup_reg_orth_fwd', _p(R), R.stride(0), _p(Rn), Rn.stride(0), d, _p(self.r2), 2 * B, _p(self.loss[1:]), st)
-        L.call('ktup_reg_orth_bwd', _p(R), R.stride(0), _p(Rn), Rn.stride(0), d, _p(self.r2), 2 * B, _p(self.lam), _p(R.grad), _p(Rn.grad), st)
-        L.call('ktup_reg_norm_fwd', _p(E), E.stride(0), d, _p(self.ht4), 4 * B, _p(self.loss[2:]), st)
-        L.call('ktup_reg_norm_bwd', _p(E), E.stride(0), d, _p(self.ht4), 4 * B, _p(self.lam), _p(E.grad), st)
-        L.call('ktup_reg_norm_fwd', _p(R), R.stride(0), d, _p(self.r2), 2 * B, _p(self.loss[3:]), st)
-        L.call('ktup_reg_norm_bwd', _p(R), R.stride(0), d, _p(self.r2), 2 * B, _p(self.lam), _p(R.grad), st)
-        self._optimizer_step()
+        torch.cat((ph, nh), out=self.h2); torch.cat((pt, nt), out=self.t2); torch.cat((pr, nr), out=self.r2)
+        torch.cat((ph, pt, nh, nt), out=self.ht4)
+        for launch in self._kg:
+            launch()
+        self._optimizer_launches()
         return self.kg_lambda * self.loss.sum()
 
-    def _optimizer_step(self):
+    def _optimizer_launches(self):
         if self.world > 1:       # gradients of all tables + the loss scalars, one bucket
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
         self.trainer.fused.clip_and_step(self.max_norm, zero_grads=True)
+
+    # ------------------------------------------------------------------------------------------------ public steps
+    def rec_step(self, u, pi, ni):
+        """u, pi, ni: int64 device tensors of the GLOBAL batch.  Returns the step's loss (0-dim device tensor)."""
+        return self._step('rec', self._rec_eager, (u, pi, ni))
+
+    def kg_step(self, ph, pt, pr, nh, nt, nr):
+        return self._step('kg', self._kg_eager, (ph, pt, pr, nh, nt, nr))
+
+    def _step(self, kind, eager, args):
+        fused = self.trainer.fused
+        if not (self.use_graphs and fused.graph_safe()):
+            out = eager(*args)
+            self.trainer.step += 1
+            return out
+        entry = self._graphs.get(kind)
+        if entry is not None and entry[2] is not fused:       # the trainer re-created its optimizer (LR decay): capture again
+            entry = None
+            self._eager_steps[kind] = 0
+        if entry is None and self._eager_steps[kind] < 2:       # the first steps run eagerly (allocations, lazy optimizer state)
+            self._eager_steps[kind] += 1
+            out = eager(*args)
+            self.trainer.step += 1
+            return out
+        ins = self._in[kind]
+        for dst, src in zip(ins, args):
+            dst.copy_(src)
+        if entry is None:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = eager(*ins)
+            self._keys = None                                    # plans were bound to the capture stream: rebind for eager use
+            fused._plan = None
+            entry = (graph, out, fused)
+            self._graphs[kind] = entry
+            captured = True                                      # the capture pass already ran the host side of clip_and_step
+        else:
+            captured = False
+        entry[0].replay()
+        if not captured:
+            fused.bump_steps()
         self.trainer.step += 1
+        return entry[1]
 
 
 class DeviceFeeder(object):

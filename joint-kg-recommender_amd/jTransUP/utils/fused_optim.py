@@ -35,6 +35,8 @@ class FusedOptimizer(object):
             raise L.KtupError('FusedOptimizer implements the reference configuration only (no maximize / amsgrad / nesterov / '
                               'centered / dampening / lr_decay)')
         self._sumsq = None
+        self._plan = None
+        self._fresh = []
 
     # ---- torch.optim surface the trainer uses
     def zero_grad(self):
@@ -47,6 +49,7 @@ class FusedOptimizer(object):
 
     def load_state_dict(self, sd):
         self.optimizer.load_state_dict(sd)
+        self._plan = None                        # the state tensors were replaced
 
     @property
     def param_groups(self):
@@ -54,15 +57,16 @@ class FusedOptimizer(object):
 
     # ---- state in torch's layout (created the way each torch optimizer creates it)
     def _state(self, p, group):
+        """Create the state tensors the way each torch optimizer does; returns (state1, state2, momentum buffer is fresh)."""
         if self.kind == 0 and group['momentum'] == 0:
-            return None, None, 0, 0              # plain SGD keeps no state (torch leaves optimizer.state empty)
+            return None, None, 0                 # plain SGD keeps no state (torch leaves optimizer.state empty)
         st = self.optimizer.state[p]
         first = 0
         if self.kind == 0:                       # SGD: momentum_buffer (None until the first step)
             if st.get('momentum_buffer') is None:
                 st['momentum_buffer'] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 first = 1
-            return st.get('momentum_buffer'), None, 0, first
+            return st.get('momentum_buffer'), None, first
         if 'step' not in st:
             st['step'] = torch.tensor(0.0, dtype=torch.float32)
         if self.kind == 1:                       # Adagrad: 'sum' exists from construction
@@ -80,8 +84,7 @@ class FusedOptimizer(object):
                 if group['momentum'] > 0:
                     st['momentum_buffer'] = torch.zeros_like(p, memory_format=torch.preserve_format)
             s1, s2 = st['square_avg'], st.get('momentum_buffer')
-        st['step'] += 1
-        return s1, s2, int(st['step'].item()), first
+        return s1, s2, first
 
     @torch.no_grad()
     def clip_and_step(self, max_norm, zero_grads=False):
@@ -91,23 +94,21 @@ class FusedOptimizer(object):
         ps = [p for p in group['params'] if p.grad is not None]
         if not ps:
             return
-        if len(ps) > MAX_TENSORS:
-            raise L.KtupError('FusedOptimizer handles up to %d tables per step (got %d)' % (MAX_TENSORS, len(ps)))
-        dev = ps[0].device
-        for p in ps:
-            if not p.is_cuda or p.device != dev or p.dtype != torch.float32 or not p.is_contiguous() or not p.grad.is_contiguous() \
-                    or p.grad.dtype != torch.float32 or p.grad.is_sparse:
-                raise L.KtupError('FusedOptimizer needs dense contiguous fp32 parameters and gradients on one MI355X device')
-        stream = torch.cuda.current_stream(dev).cuda_stream
-        n = len(ps)
-        sizes = _arr(ctypes.c_int64, [p.numel() for p in ps])
-        grads = _arr(ctypes.c_void_p, [p.grad.data_ptr() for p in ps])
-        params = _arr(ctypes.c_void_p, [p.data_ptr() for p in ps])
-        s1l, s2l, steps, firsts = [], [], [], []
-        for p in ps:
-            s1, s2, step, first = self._state(p, group)
-            s1l.append(None if s1 is None else s1.data_ptr()); s2l.append(None if s2 is None else s2.data_ptr())
-            steps.append(max(step, 1)); firsts.append(first)
+        key = tuple((p.data_ptr(), p.grad.data_ptr()) for p in ps) + (torch.cuda.current_stream(ps[0].device).cuda_stream,)
+        plan = self._plan if self._plan is not None and self._plan[0] == key else self._make_plan(ps, key, group)
+        _, n, params, grads, s1, s2, sizes, stream, dev = plan
+        steps, firsts = [], []
+        for p in ps:                                            # per-tensor step counts (Adam bias correction), first-use flags
+            st = self.optimizer.state.get(p)
+            if st is not None and 'step' in st:
+                st['step'] += 1
+                steps.append(int(st['step'].item()))
+            else:
+                steps.append(1)
+            firsts.append(0)
+        if self.kind == 0 and group['momentum'] != 0:
+            firsts = [1 if f else 0 for f in self._fresh]
+            self._fresh = [False] * n
         sumsq = None
         if max_norm is not None and max_norm > 0:
             if self._sumsq is None or self._sumsq.device != dev:
@@ -115,10 +116,43 @@ class FusedOptimizer(object):
             sumsq = self._sumsq.data_ptr()
             L.call('ktup_optim_gradnorm', n, grads, sizes, sumsq, stream)
         betas = group.get('betas', (0.9, 0.999))
-        L.call('ktup_optim_step', self.kind, n, params, grads, _arr(ctypes.c_void_p, s1l), _arr(ctypes.c_void_p, s2l), sizes,
-               _arr(ctypes.c_int64, steps), _arr(ctypes.c_int32, firsts), float(group['lr']), float(group['weight_decay']),
-               float(group.get('momentum', 0.0)), float(betas[0]), float(betas[1]), float(group.get('eps', 0.0)),
-               float(group.get('alpha', 0.0)), sumsq, float(max_norm) if sumsq is not None else 0.0, int(bool(zero_grads)), stream)
+        L.call('ktup_optim_step', self.kind, n, params, grads, s1, s2, sizes, _arr(ctypes.c_int64, steps), _arr(ctypes.c_int32, firsts),
+               float(group['lr']), float(group['weight_decay']), float(group.get('momentum', 0.0)), float(betas[0]), float(betas[1]),
+               float(group.get('eps', 0.0)), float(group.get('alpha', 0.0)), sumsq, float(max_norm) if sumsq is not None else 0.0,
+               int(bool(zero_grads)), stream)
+
+    def _make_plan(self, ps, key, group):
+        """Validate once per set of (parameter, gradient) buffers and keep the pointer arrays: rebuilding them every step
+        costs more host time than the two launches take on the device."""
+        if len(ps) > MAX_TENSORS:
+            raise L.KtupError('FusedOptimizer handles up to %d tables per step (got %d)' % (MAX_TENSORS, len(ps)))
+        dev = ps[0].device
+        for p in ps:
+            if not p.is_cuda or p.device != dev or p.dtype != torch.float32 or not p.is_contiguous() or not p.grad.is_contiguous() \
+                    or p.grad.dtype != torch.float32 or p.grad.is_sparse:
+                raise L.KtupError('FusedOptimizer needs dense contiguous fp32 parameters and gradients on one MI355X device')
+        s1l, s2l, fresh = [], [], []
+        for p in ps:
+            s1, s2, first = self._state(p, group)
+            s1l.append(None if s1 is None else s1.data_ptr()); s2l.append(None if s2 is None else s2.data_ptr()); fresh.append(bool(first))
+        self._fresh = fresh
+        self._plan = (key, len(ps), _arr(ctypes.c_void_p, [p.data_ptr() for p in ps]), _arr(ctypes.c_void_p, [p.grad.data_ptr() for p in ps]),
+                      _arr(ctypes.c_void_p, s1l), _arr(ctypes.c_void_p, s2l), _arr(ctypes.c_int64, [p.numel() for p in ps]),
+                      torch.cuda.current_stream(dev).cuda_stream, dev)
+        return self._plan
+
+    def graph_safe(self):
+        """True when a step has no host-computed, step-dependent launch arguments (Adam's bias corrections are) and can
+        therefore be replayed from a captured HIP graph."""
+        return self.kind != 2
+
+    def bump_steps(self):
+        """Advance the per-parameter step counters like one clip_and_step would (used when the launches are replayed from
+        a graph and this object's Python code does not run)."""
+        for p in self.optimizer.param_groups[0]['params']:
+            st = self.optimizer.state.get(p)
+            if p.grad is not None and st is not None and 'step' in st:
+                st['step'] += 1
 
     def total_norm(self):
         """Gradient norm of the last clipped step (device -> host sync; diagnostics only)."""

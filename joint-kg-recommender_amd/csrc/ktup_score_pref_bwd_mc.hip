@@ -5,6 +5,7 @@
 // Backward for upstream g:   gz = g dist'(z),  av = gz . n,  gq = gz - av n,  gr = gz,  gn = -av q - s gz,
 //                            gL_p = Ar_p . gr + Cn_p . gn,   gx = sum_p gL_p Alog_p,   gu = gq + gx,   gi = ge = gx - gq,
 //                            gA_p += 1/2 gL_p x + beta L_p gr,   gC_p += beta L_p gn        (mixed tables A, C)
+// The three tables are staged once, slot-ordered with an odd float4 pitch; both operand patterns read the same rows.
 // A wave owns 16 pairs through all phases; every contraction runs on v_mfma_f32_16x16x4_f32 with the operand layouts of
 // pref_fwd_mc (lane = (kq, pair); D registers of one phase are the B operands of the next):
 //   A  forward recompute  L^T = Alog . x^T   then  n^T, r^T = Cn^T L^T, Ar^T L^T                (as pref_fwd_mc)
@@ -35,14 +36,13 @@ struct BGeom {
   static constexpr int TOTAL = 16 * NCH;
   static constexpr int PITCHA4 = 4 * KG + 1;               // slot-ordered tables (A operand of K = coordinate GEMMs)
   static constexpr int SLOT_F4 = PT * 16 * PITCHA4;
-  static constexpr int TROW = 16 * PT;                     // [preference][coordinate] tables (A operand of K = preference GEMMs)
-  static constexpr int TPITCH = 16 * CT + ((16 * CT) % 32 == 0 ? 16 : 0);
-  static constexpr int T_F = TROW * TPITCH;
-  static constexpr size_t TABLE_BYTES = (size_t)3 * SLOT_F4 * 16 + (size_t)3 * T_F * 4;
+  static constexpr int TROW = 16 * PT;
+  static constexpr int RP = PITCHA4 * 4;                   // the same rows serve the K = preference GEMMs: float pitch of a slot row
+  static constexpr size_t TABLE_BYTES = (size_t)3 * SLOT_F4 * 16;
   static constexpr int TILE_F4 = 16 * NCH + 3;             // one (16 pairs x d) tile + 3 zero chunks
   static constexpr int LT_F = TROW * 17;                   // transposed [preference][pair] arrays, pitch 17
   static constexpr size_t WAVE_BYTES = ((size_t)4 * TILE_F4 * 16 + (size_t)2 * LT_F * 4 + 3 * 16 * 4 + 15) & ~(size_t)15;
-  static constexpr int NW = TABLE_BYTES + 2 * WAVE_BYTES <= 160 * 1024 ? 2 : 1;
+  static constexpr int NW = TABLE_BYTES + 3 * WAVE_BYTES <= 160 * 1024 ? 3 : TABLE_BYTES + 2 * WAVE_BYTES <= 160 * 1024 ? 2 : 1;
   static constexpr size_t LDS = TABLE_BYTES + NW * WAVE_BYTES;
 };
 
@@ -62,18 +62,19 @@ struct BArgs {
 template <typename G>
 __global__ __launch_bounds__(G::NW * 64) void pref_bwd_mc_kernel(BArgs a) {
   constexpr int NCH = G::NCH, NP = G::NP, D = G::D, KG = G::KG, CT = G::CT, PT = G::PT, J = G::J, TOTAL = G::TOTAL;
-  constexpr int PITCHA4 = G::PITCHA4, TPITCH = G::TPITCH, TROW = G::TROW, NW = G::NW;
+  constexpr int PITCHA4 = G::PITCHA4, RP = G::RP, NW = G::NW;
   constexpr bool HASE = G::HASE;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   v4* AlogSlot = reinterpret_cast<v4*>(smem);                 // [PT*16 slots][PITCHA4]
   v4* ArSlot = AlogSlot + G::SLOT_F4;
   v4* CnSlot = ArSlot + G::SLOT_F4;
-  float* Alog2 = reinterpret_cast<float*>(CnSlot + G::SLOT_F4);   // [TROW][TPITCH]
-  float* Ar2 = Alog2 + G::T_F;
-  float* Cn2 = Ar2 + G::T_F;
+  // the K = preference GEMMs read the same rows by b32: preference 16 t + 4 reg + kq lives in slot row 16 t + 4 kq + reg
+  const float* Alog2 = reinterpret_cast<const float*>(AlogSlot);
+  const float* Ar2 = reinterpret_cast<const float*>(ArSlot);
+  const float* Cn2 = reinterpret_cast<const float*>(CnSlot);
   const int tid = threadIdx.x, lane = tid & 63, kq = lane >> 4, j = lane & 15;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  char* wbase = reinterpret_cast<char*>(Cn2 + G::T_F) + (size_t)w * G::WAVE_BYTES;
+  char* wbase = reinterpret_cast<char*>(CnSlot + G::SLOT_F4) + (size_t)w * G::WAVE_BYTES;
   v4* XT = reinterpret_cast<v4*>(wbase);                      // x   [16][NCH]
   v4* QT = XT + G::TILE_F4;                                   // q
   v4* GRT = QT + G::TILE_F4;                                  // gr = gz
@@ -96,13 +97,6 @@ __global__ __launch_bounds__(G::NW * 64) void pref_bwd_mc_kernel(BArgs a) {
       s0[idx] = ok ? a.Alog[p * dp + k] : 0.f;
       s1[idx] = ok ? a.Ar[p * dp + k] : 0.f;
       s2[idx] = ok ? a.Cn[p * dp + k] : 0.f;
-    }
-    for (int idx = tid; idx < G::T_F; idx += NW * 64) {
-      const int p = idx / TPITCH, c = idx - p * TPITCH;
-      const bool ok = p < P && c < D;
-      Alog2[idx] = ok ? a.Alog[p * dp + c] : 0.f;
-      Ar2[idx] = ok ? a.Ar[p * dp + c] : 0.f;
-      Cn2[idx] = ok ? a.Cn[p * dp + c] : 0.f;
     }
     if (lane < 3) {
       XT[16 * NCH + lane] = (v4){0.f, 0.f, 0.f, 0.f}; QT[16 * NCH + lane] = XT[16 * NCH + lane];
@@ -189,7 +183,7 @@ __global__ __launch_bounds__(G::NW * 64) void pref_bwd_mc_kernel(BArgs a) {
       zz[ct] = qv[ct];                                          // q + r accumulates on top of q
 #pragma unroll
       for (int m = 0; m < NP; ++m) {
-        const int prow = (16 * (m >> 2) + 4 * (m & 3) + kq) * TPITCH + 16 * ct + j;
+        const int prow = (16 * (m >> 2) + 4 * kq + (m & 3)) * RP + 16 * ct + j;
         nn[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(Cn2[prow], lg[m >> 2][m & 3], nn[ct], 0, 0, 0);
         zz[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(Ar2[prow], lg[m >> 2][m & 3], zz[ct], 0, 0, 0);
       }
@@ -256,7 +250,7 @@ __global__ __launch_bounds__(G::NW * 64) void pref_bwd_mc_kernel(BArgs a) {
         v4 gx = (v4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int m = 0; m < NP; ++m) {
-          const int prow = (16 * (m >> 2) + 4 * (m & 3) + kq) * TPITCH + 16 * ct + j;
+          const int prow = (16 * (m >> 2) + 4 * kq + (m & 3)) * RP + 16 * ct + j;
           gx = __builtin_amdgcn_mfma_f32_16x16x4f32(Alog2[prow], gl[m >> 2][m & 3], gx, 0, 0, 0);
         }
         const int c0 = 16 * ct + 4 * kq;

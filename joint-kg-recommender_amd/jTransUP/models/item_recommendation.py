@@ -30,6 +30,20 @@ def evaluate(FLAGS, model, eval_iter, eval_dict, all_dicts, logger, eval_descend
 def train_loop(FLAGS, model, trainer, train_dataset, eval_datasets, user_total, item_total, logger, vis=None, is_report=False):
     train_iter, train_total, train_list, train_dict = train_dataset
     all_dicts = [train_dict] + [d[3] for d in eval_datasets] if FLAGS.filter_wrong_corrupted else None
+    # TUP / BPRMF: the step body below as a handful of C-ABI launches (utils/fast_train.py RecStepper), optionally with the
+    # training data and the negative sampling on the device (-device_sampling)
+    stepper = feed = sampler = None
+    if D.USE_CUDA and FLAGS.model_type in ('transup', 'bprmf') and trainer.fused is not None \
+            and os.environ.get('KTUP_FAST_TRAIN', '1') != '0':
+        from jTransUP.utils.fast_train import DeviceFeeder, RecStepper
+        stepper = RecStepper(model, trainer, FLAGS, FLAGS.batch_size)
+        logger.info('GPU-resident training step enabled (KTUP_FAST_TRAIN=0 selects the autograd route).')
+        if FLAGS.device_sampling:
+            from jTransUP.utils.device_sampler import DeviceSampler
+            sampler = DeviceSampler(D.DEV, seed=FLAGS.seed)
+            sampler.set_rating_dicts(user_total, item_total, all_dicts)
+            feed = DeviceFeeder(train_list, FLAGS.batch_size, D.DEV, FLAGS.negtive_samples, seed=FLAGS.seed)
+            logger.info('Training data and negative sampling are device-resident (-device_sampling).')
     logger.info('Training.')
 
     def do_eval(totals):
@@ -49,8 +63,14 @@ def train_loop(FLAGS, model, trainer, train_dataset, eval_datasets, user_total, 
         return perfs
 
     def do_step(step):
+        if feed is not None:
+            rows = feed.next()
+            u_d, pi_d = rows[:, 0].contiguous(), rows[:, 1].contiguous()
+            return 'rec', stepper.rec_step(u_d, pi_d, sampler.sample_rec(u_d, pi_d))
         u, pi, ni = getNegRatings(next(train_iter), item_total, all_dicts=all_dicts)
         u_var, pi_var, ni_var = D.ids(u), D.ids(pi), D.ids(ni)
+        if stepper is not None and len(u) == stepper.GB:
+            return 'rec', stepper.rec_step(u_var, pi_var, ni_var)
         trainer.optimizer_zero_grad()
         pos_score, neg_score = model(u_var, pi_var), model(u_var, ni_var)
         losses = bprLoss(pos_score, neg_score, target=trainer.model_target)

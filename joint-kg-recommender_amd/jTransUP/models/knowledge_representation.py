@@ -45,6 +45,23 @@ def train_loop(FLAGS, model, trainer, train_dataset, eval_datasets, entity_total
     if FLAGS.filter_wrong_corrupted:
         all_head_dicts = [train_head_dict] + [d[4] for d in eval_datasets]
         all_tail_dicts = [train_tail_dict] + [d[5] for d in eval_datasets]
+    # TransE / TransH: the step body below as a handful of C-ABI launches (utils/fast_train.py KGStepper), optionally with the
+    # triples and the corruption sampling on the device (-device_sampling)
+    stepper = feed = sampler = None
+    if D.USE_CUDA and FLAGS.model_type in ('transe', 'transh') and trainer.fused is not None \
+            and os.environ.get('KTUP_FAST_TRAIN', '1') != '0':
+        from jTransUP.utils.fast_train import DeviceFeeder, KGStepper
+        stepper = KGStepper(model, trainer, FLAGS, FLAGS.batch_size)
+        logger.info('GPU-resident training step enabled (KTUP_FAST_TRAIN=0 selects the autograd route).')
+        if FLAGS.device_sampling:
+            from jTransUP.utils.device_sampler import DeviceSampler
+            sampler = DeviceSampler(D.DEV, seed=FLAGS.seed)
+            known = None
+            if FLAGS.filter_wrong_corrupted:
+                known = [train_list] + [[(h, t, r) for (t, r), hs in d[4].items() for h in hs] for d in eval_datasets]
+            sampler.set_triples(entity_total, relation_total, known)
+            feed = DeviceFeeder(train_list, FLAGS.batch_size, D.DEV, FLAGS.negtive_samples, seed=FLAGS.seed)
+            logger.info('Training data and negative sampling are device-resident (-device_sampling).')
     logger.info('Training.')
 
     def do_eval(totals):
@@ -67,6 +84,17 @@ def train_loop(FLAGS, model, trainer, train_dataset, eval_datasets, entity_total
         return perfs
 
     def do_step(step):
+        if feed is not None:
+            rows = feed.next()                             # (h, t, r): tail before relation, like the files
+            ph, pt, pr = rows[:, 0].contiguous(), rows[:, 1].contiguous(), rows[:, 2].contiguous()
+            nh, nt = sampler.sample_kg(ph, pt, pr)
+            return 'kg', stepper.kg_step(ph, pt, pr, nh, nt, pr)
+        if stepper is not None:
+            ph, pt, pr, nh, nt, nr = getTrainTripleBatch(next(train_iter), entity_total, all_head_dicts=all_head_dicts,
+                                                         all_tail_dicts=all_tail_dicts)
+            if len(ph) != stepper.GB:
+                raise RuntimeError('training batch of unexpected size (MakeTrainIterator yields full batches)')
+            return 'kg', stepper.kg_step(*(D.ids(x) for x in (ph, pt, pr, nh, nt, nr)))
         pos, neg, ent_ids, rel_ids = kg_step_loss(FLAGS, model, next(train_iter), entity_total, all_head_dicts, all_tail_dicts,
                                                   FLAGS.model_type == 'transh')
         trainer.optimizer_zero_grad()

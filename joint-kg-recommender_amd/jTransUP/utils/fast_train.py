@@ -28,10 +28,16 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
-class JointStepper(object):
+class _StepperBase(object):
+    """Shared machinery: flat gradient bucket (grads are views, 8 loss scalars at its end), data-parallel slice + all-reduce,
+    pre-bound launches, HIP-graph replay, the K20 clip + step."""
+
+    KINDS = ()        # step kinds of the subclass, e.g. ('rec', 'kg'), with the number of id tensors each takes
+    N_IDS = {}
+
     def __init__(self, model, trainer, FLAGS, batch_size, group=None, use_graphs=None):
         if trainer.fused is None:
-            raise L.KtupError('JointStepper needs the fused optimizer (KTUP_FUSED_OPTIM=0 disables it)')
+            raise L.KtupError('the GPU-resident step needs the fused optimizer (KTUP_FUSED_OPTIM=0 disables it)')
         self.m, self.trainer = model, trainer
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -40,38 +46,30 @@ class JointStepper(object):
             raise L.KtupError('batch_size %d is not divisible by the %d data-parallel ranks' % (batch_size, self.world))
         self.GB = int(batch_size)                    # global batch (what the driver samples)
         self.B = self.GB // self.world               # rows this rank scores
-        self.margin, self.kg_lambda, self.max_norm = float(FLAGS.margin), float(FLAGS.kg_lambda), float(FLAGS.clipping_max_value)
+        self.margin, self.max_norm = float(FLAGS.margin), float(FLAGS.clipping_max_value)
         self.target = float(trainer.model_target)
-        self.l1 = int(bool(model.L1_flag))
-        U, I, E, P, Pn, R, Rn = model._rec_tables()
-        self.tabs = (U, I, E, P, Pn, R, Rn)
-        dev = U.device
+        self.l1 = int(bool(getattr(model, 'L1_flag', False)))
+        self.tabs = tuple(trainer.parameters)
+        dev = self.tabs[0].device
         self.dev = dev
         f32 = dict(dtype=torch.float32, device=dev)
-        # persistent zero-filled gradients (torch 0.3 zero_grad semantics) as views into one flat bucket; 4 loss scalars at its end
+        i64 = dict(dtype=torch.int64, device=dev)
+        # persistent zero-filled gradients (torch 0.3 zero_grad semantics) as views into one flat bucket; 8 loss scalars at its end
         sizes = [p.numel() for p in trainer.parameters]
         pad = [(-n) % 4 for n in sizes]              # keep every view 16-byte aligned for the float4 kernels
-        self.flat = torch.zeros(sum(sizes) + sum(pad) + 4, **f32)
+        self.flat = torch.zeros(sum(sizes) + sum(pad) + 8, **f32)
         off = 0
         for p, n, q in zip(trainer.parameters, sizes, pad):
             p.grad = self.flat[off:off + n].view_as(p)
             off += n + q
-        self.loss = self.flat[off:off + 4]
+        self.loss = self.flat[off:off + 8]
         if self.world > 1:                           # identical replicas to start from
             for p in trainer.parameters:
                 dist.broadcast(p.data, src=0, group=group)
         B = self.B
-        i64 = dict(dtype=torch.int64, device=dev)
-        self.u2, self.i2 = torch.zeros(2 * B, **i64), torch.zeros(2 * B, **i64)          # [pos ; neg]
-        self.h2, self.t2, self.r2 = torch.zeros(2 * B, **i64), torch.zeros(2 * B, **i64), torch.zeros(2 * B, **i64)
-        self.ht4 = torch.zeros(4 * B, **i64)                                             # ph, pt, nh, nt (normLoss rows)
         self.score, self.gscore = torch.zeros(2 * B, **f32), torch.zeros(2 * B, **f32)
-        self.gAC = torch.zeros(2, P.shape[0], P.shape[1], **f32)                         # mixed-table gradients gA, gC
         self.inv_world = torch.full((), 1.0 / self.world, **f32)                         # upstream gradient of 'mean' / 'replicated' terms
-        self.lam = torch.full((), self.kg_lambda, **f32)                                 # ... of the KG 'sum' terms
-        self.ws = ops.pref_workspace(P, Pn, R, Rn)
-        self.ent_pad = model.ent_total - 1
-        self.i2e = model._item2ent
+        self.one = torch.ones((), **f32)
         self._keys = None
         self._stream = None
         # HIP graphs: with the soft gate and a step-independent optimizer every launch argument of a step is static, so the
@@ -79,29 +77,94 @@ class JointStepper(object):
         if use_graphs is None:
             import os
             use_graphs = os.environ.get('KTUP_TRAIN_GRAPHS', '1') != '0'
-        self.use_graphs = bool(use_graphs) and self.world == 1 and not model.use_st_gumbel
+        self.use_graphs = bool(use_graphs) and self.world == 1 and not getattr(model, 'use_st_gumbel', False)
         self._graphs = {}
-        self._eager_steps = {'rec': 0, 'kg': 0}
-        GB = self.GB
-        self._in = {'rec': [torch.zeros(GB, **i64) for _ in range(3)], 'kg': [torch.zeros(GB, **i64) for _ in range(6)]}
+        self._eager_steps = {k: 0 for k in self.KINDS}
+        self._in = {k: [torch.zeros(self.GB, **i64) for _ in range(self.N_IDS[k])] for k in self.KINDS}
+        self._setup(FLAGS, f32, i64)
 
     def _mine(self, t):
         """This rank's rows of a global-batch id tensor."""
         return t if self.world == 1 else t[self.rank * self.B:(self.rank + 1) * self.B]
 
+    def _plans(self):
+        st = torch.cuda.current_stream(self.dev).cuda_stream
+        if self._keys is None or st != self._stream or \
+                self._keys != tuple(t.data_ptr() for t in self.tabs) + tuple(t.grad.data_ptr() for t in self.tabs):
+            self._keys = tuple(t.data_ptr() for t in self.tabs) + tuple(t.grad.data_ptr() for t in self.tabs)
+            self._stream = st
+            self._bind(st)
+
+    def _optimizer_launches(self):
+        if self.world > 1:       # gradients of all tables + the loss scalars, one bucket
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+        self.trainer.fused.clip_and_step(self.max_norm, zero_grads=True)
+
+    def _step(self, kind, eager, args):
+        fused = self.trainer.fused
+        if not (self.use_graphs and fused.graph_safe()):
+            out = eager(*args)
+            self.trainer.step += 1
+            return out
+        entry = self._graphs.get(kind)
+        if entry is not None and entry[2] is not fused:       # the trainer re-created its optimizer (LR decay): capture again
+            entry = None
+            self._eager_steps[kind] = 0
+        if entry is None and self._eager_steps[kind] < 2:       # the first steps run eagerly (allocations, lazy optimizer state)
+            self._eager_steps[kind] += 1
+            out = eager(*args)
+            self.trainer.step += 1
+            return out
+        ins = self._in[kind]
+        for dst, src in zip(ins, args):
+            dst.copy_(src)
+        if entry is None:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = eager(*ins)
+            self._keys = None                                    # plans were bound to the capture stream: rebind for eager use
+            fused._plan = None
+            entry = (graph, out, fused)
+            self._graphs[kind] = entry
+            captured = True                                      # the capture pass already ran the host side of clip_and_step
+        else:
+            captured = False
+        entry[0].replay()
+        if not captured:
+            fused.bump_steps()
+        self.trainer.step += 1
+        return entry[1]
+
+class JointStepper(_StepperBase):
+    """KTUP (jtransup, own tables): knowledgable_recommendation.py:330-401."""
+    KINDS = ('rec', 'kg')
+    N_IDS = {'rec': 3, 'kg': 6}
+
+    def _setup(self, FLAGS, f32, i64):
+        model, B = self.m, self.B
+        self.kg_lambda = float(FLAGS.kg_lambda)
+        U, I, E, P, Pn, R, Rn = model._rec_tables()
+        self.tabs = (U, I, E, P, Pn, R, Rn)
+        self.u2, self.i2 = torch.zeros(2 * B, **i64), torch.zeros(2 * B, **i64)          # [pos ; neg]
+        self.h2, self.t2, self.r2 = torch.zeros(2 * B, **i64), torch.zeros(2 * B, **i64), torch.zeros(2 * B, **i64)
+        self.ht4 = torch.zeros(4 * B, **i64)                                             # ph, pt, nh, nt (normLoss rows)
+        self.gAC = torch.zeros(2, P.shape[0], P.shape[1], **f32)                         # mixed-table gradients gA, gC
+        self.lam = torch.full((), self.kg_lambda, **f32)                                 # upstream gradient of the KG 'sum' terms
+        self.ws = ops.pref_workspace(P, Pn, R, Rn)
+        self.ent_pad = model.ent_total - 1
+        self.i2e = model._item2ent
+
     # ------------------------------------------------------------------------------------------------ launch plans
-    def _bind(self):
+    def _bind(self, st):
         """Every launch of a step has fixed arguments (persistent buffers): marshal them once (lib.bind).  Re-done when a
-        table's storage moves (load_state_dict keeps storages, so in practice never)."""
+        table's storage moves (load_state_dict keeps storages, so in practice never) or the stream changes (graph capture)."""
         U, I, E, P, Pn, R, Rn = self.tabs
-        B, st = self.B, torch.cuda.current_stream(self.dev).cuda_stream
+        B = self.B
         n_pref, d = P.shape
         n_rel = min(R.shape[0], Rn.shape[0])
         pos, neg, gpos, gneg = self.score[:B], self.score[B:], self.gscore[:B], self.gscore[B:]
         off = ops.GUMBEL_OFF
         b = L.bind
-        self._keys = tuple(t.data_ptr() for t in self.tabs) + tuple(t.grad.data_ptr() for t in self.tabs)
-        self._stream = st
         self._rec_head = [
             b('ktup_pref_prepare', _p(P), _p(Pn), _p(R), _p(Rn), P.stride(0), n_pref, d, _p(self.ws), st)]
         self._rec_soft = [            # soft gate only: the Gumbel stream advances per step and is marshalled per call
@@ -130,12 +193,6 @@ class JointStepper(object):
             b('ktup_reg_norm_bwd', _p(E), E.stride(0), d, _p(self.ht4), 4 * B, _p(self.lam), _p(E.grad), st),
             b('ktup_reg_norm_fwd', _p(R), R.stride(0), d, _p(self.r2), 2 * B, _p(self.loss[3:]), st),
             b('ktup_reg_norm_bwd', _p(R), R.stride(0), d, _p(self.r2), 2 * B, _p(self.lam), _p(R.grad), st)]
-
-    def _plans(self):
-        st = torch.cuda.current_stream(self.dev).cuda_stream
-        if self._keys is None or st != self._stream or self._keys[0] != self.tabs[0].data_ptr() or \
-                self._keys != tuple(t.data_ptr() for t in self.tabs) + tuple(t.grad.data_ptr() for t in self.tabs):
-            self._bind()
 
     # ------------------------------------------------------------------------------------------------ rec
     def _rec_eager(self, u, pi, ni):
@@ -175,12 +232,7 @@ class JointStepper(object):
         for launch in self._kg:
             launch()
         self._optimizer_launches()
-        return self.kg_lambda * self.loss.sum()
-
-    def _optimizer_launches(self):
-        if self.world > 1:       # gradients of all tables + the loss scalars, one bucket
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
-        self.trainer.fused.clip_and_step(self.max_norm, zero_grads=True)
+        return self.kg_lambda * self.loss[:4].sum()
 
     # ------------------------------------------------------------------------------------------------ public steps
     def rec_step(self, u, pi, ni):
@@ -190,40 +242,149 @@ class JointStepper(object):
     def kg_step(self, ph, pt, pr, nh, nt, nr):
         return self._step('kg', self._kg_eager, (ph, pt, pr, nh, nt, nr))
 
-    def _step(self, kind, eager, args):
-        fused = self.trainer.fused
-        if not (self.use_graphs and fused.graph_safe()):
-            out = eager(*args)
-            self.trainer.step += 1
-            return out
-        entry = self._graphs.get(kind)
-        if entry is not None and entry[2] is not fused:       # the trainer re-created its optimizer (LR decay): capture again
-            entry = None
-            self._eager_steps[kind] = 0
-        if entry is None and self._eager_steps[kind] < 2:       # the first steps run eagerly (allocations, lazy optimizer state)
-            self._eager_steps[kind] += 1
-            out = eager(*args)
-            self.trainer.step += 1
-            return out
-        ins = self._in[kind]
-        for dst, src in zip(ins, args):
-            dst.copy_(src)
-        if entry is None:
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                out = eager(*ins)
-            self._keys = None                                    # plans were bound to the capture stream: rebind for eager use
-            fused._plan = None
-            entry = (graph, out, fused)
-            self._graphs[kind] = entry
-            captured = True                                      # the capture pass already ran the host side of clip_and_step
+
+class RecStepper(_StepperBase):
+    """Rec-only driver (item_recommendation.py:160-195): TUP (transup) with its regularisers (:177-180), or BPRMF (bpr only).
+    loss slots: 0 bpr, 1 orthogonalLoss(pref, pref_norm), 2 normLoss(user rows), 3 normLoss(item rows), 4 normLoss(pref)."""
+    KINDS = ('rec',)
+    N_IDS = {'rec': 3}
+
+    def _setup(self, FLAGS, f32, i64):
+        model, B = self.m, self.B
+        self.tup = hasattr(model, 'pref_embeddings')
+        if self.tup:
+            U, I, P, Pn = model._tables()
+            self.tabs = (U, I, P, Pn)
+            self.gAC = torch.zeros(2, P.shape[0], P.shape[1], **f32)
+            self.ws = ops.pref_workspace(P, Pn)
         else:
-            captured = False
-        entry[0].replay()
-        if not captured:
-            fused.bump_steps()
-        self.trainer.step += 1
-        return entry[1]
+            self.tabs = (model.user_embeddings.weight, model.item_embeddings.weight)
+        self.u2, self.i2 = torch.zeros(2 * B, **i64), torch.zeros(2 * B, **i64)
+
+    def _bind(self, st):
+        B, b = self.B, L.bind
+        U, I = self.tabs[0], self.tabs[1]
+        d = U.shape[1]
+        pos, neg, gpos, gneg = self.score[:B], self.score[B:], self.gscore[:B], self.gscore[B:]
+        self._loss = [b('ktup_loss_bpr_fwd', _p(pos), _p(neg), B, self.target, _p(self.loss[0:]), st),
+                      b('ktup_loss_bpr_bwd', _p(pos), _p(neg), B, self.target, _p(self.inv_world), _p(gpos), _p(gneg), st)]
+        if not self.tup:
+            self._fwd = b('ktup_score_bprmf_fwd', _p(U), U.stride(0), _p(I), I.stride(0), d, _p(self.u2), _p(self.i2), 2 * B,
+                          _p(self.score), st)
+            self._bwd = b('ktup_score_bprmf_bwd', _p(U), U.stride(0), _p(I), I.stride(0), d, _p(self.u2), _p(self.i2), 2 * B,
+                          _p(self.gscore), _p(U.grad), _p(I.grad), st)
+            return
+        P, Pn = self.tabs[2], self.tabs[3]
+        n_pref, off = P.shape[0], ops.GUMBEL_OFF
+        self._prep = b('ktup_pref_prepare', _p(P), _p(Pn), None, None, P.stride(0), n_pref, d, _p(self.ws), st)
+        self._fwd = b('ktup_score_tup_fwd', _p(U), U.stride(0), _p(I), I.stride(0), _p(self.ws), n_pref, d, _p(self.u2), _p(self.i2),
+                      2 * B, self.l1, off, None, 0, 0, _p(self.score), st)
+        self._bwd = b('ktup_score_tup_bwd', _p(U), U.stride(0), _p(I), I.stride(0), _p(self.ws), n_pref, d, _p(self.u2), _p(self.i2),
+                      2 * B, self.l1, off, None, 0, 0, _p(self.gscore), _p(U.grad), _p(I.grad), _p(self.gAC[0]), _p(self.gAC[1]), st)
+        self._regs = [
+            b('ktup_reg_orth_fwd', _p(P), P.stride(0), _p(Pn), Pn.stride(0), d, None, n_pref, _p(self.loss[1:]), st),
+            b('ktup_reg_orth_bwd', _p(P), P.stride(0), _p(Pn), Pn.stride(0), d, None, n_pref, _p(self.inv_world), _p(P.grad), _p(Pn.grad), st),
+            b('ktup_reg_norm_fwd', _p(U), U.stride(0), d, _p(self.u2), B, _p(self.loss[2:]), st),          # the step's users once
+            b('ktup_reg_norm_bwd', _p(U), U.stride(0), d, _p(self.u2), B, _p(self.one), _p(U.grad), st),
+            b('ktup_reg_norm_fwd', _p(I), I.stride(0), d, _p(self.i2), 2 * B, _p(self.loss[3:]), st),      # positive and negative items
+            b('ktup_reg_norm_bwd', _p(I), I.stride(0), d, _p(self.i2), 2 * B, _p(self.one), _p(I.grad), st),
+            b('ktup_reg_norm_fwd', _p(P), P.stride(0), d, None, n_pref, _p(self.loss[4:]), st),
+            b('ktup_reg_norm_bwd', _p(P), P.stride(0), d, None, n_pref, _p(self.inv_world), _p(P.grad), st)]
+
+    def _rec_eager(self, u, pi, ni):
+        m, B = self.m, self.B
+        self._plans()
+        u, pi, ni = self._mine(u), self._mine(pi), self._mine(ni)
+        torch.cat((u, u), out=self.u2); torch.cat((pi, ni), out=self.i2)
+        if not self.tup:
+            self._fwd(); self._loss[0](); self._loss[1](); self._bwd()
+            if self.world > 1:
+                self.loss[:1].mul_(self.inv_world); self.loss[1:].zero_()
+            self._optimizer_launches()
+            return self.loss[0] + 0.0
+        U, I, P, Pn = self.tabs
+        self._prep()
+        self.gAC.zero_()
+        if not m.use_st_gumbel:
+            self._fwd(); self._loss[0](); self._loss[1](); self._bwd()
+        else:
+            n_pref, d, st = P.shape[0], P.shape[1], self._stream
+            mode, uni, seed, off = m._gumbel.mode_and_stream(True, None, 2 * B * n_pref)
+            L.call('ktup_score_tup_fwd', _p(U), U.stride(0), _p(I), I.stride(0), _p(self.ws), n_pref, d, _p(self.u2), _p(self.i2), 2 * B,
+                   self.l1, int(mode), _p(uni), int(seed), int(off), _p(self.score), st)
+            self._loss[0](); self._loss[1]()
+            L.call('ktup_score_tup_bwd', _p(U), U.stride(0), _p(I), I.stride(0), _p(self.ws), n_pref, d, _p(self.u2), _p(self.i2), 2 * B,
+                   self.l1, int(mode), _p(uni), int(seed), int(off), _p(self.gscore), _p(U.grad), _p(I.grad), _p(self.gAC[0]),
+                   _p(self.gAC[1]), st)
+        torch._foreach_add_([P.grad, Pn.grad], [self.gAC[0], self.gAC[1]])
+        for launch in self._regs:
+            launch()
+        if self.world > 1:       # batch mean and whole-table terms by 1/G, batch sums as they are
+            self.loss[:2].mul_(self.inv_world); self.loss[4:5].mul_(self.inv_world); self.loss[5:].zero_()
+        self._optimizer_launches()
+        return self.loss[:5].sum()
+
+    def rec_step(self, u, pi, ni):
+        return self._step('rec', self._rec_eager, (u, pi, ni))
+
+
+class KGStepper(_StepperBase):
+    """KG-only driver (knowledge_representation.py:176-211) for TransE / TransH: marginLoss + normLoss(entity rows of the
+    positive and negative triples) + normLoss(relation rows) (+ orthogonalLoss(rel, norm) rows for TransH)."""
+    KINDS = ('kg',)
+    N_IDS = {'kg': 6}
+
+    def _setup(self, FLAGS, f32, i64):
+        model, B = self.m, self.B
+        self.transh = hasattr(model, 'norm_embeddings')
+        E, R = model.ent_embeddings.weight, model.rel_embeddings.weight
+        self.tabs = (E, R, model.norm_embeddings.weight) if self.transh else (E, R)
+        self.h2, self.t2, self.r2 = torch.zeros(2 * B, **i64), torch.zeros(2 * B, **i64), torch.zeros(2 * B, **i64)
+        self.ht4 = torch.zeros(4 * B, **i64)
+
+    def _bind(self, st):
+        B, b = self.B, L.bind
+        E, R = self.tabs[0], self.tabs[1]
+        d = E.shape[1]
+        pos, neg, gpos, gneg = self.score[:B], self.score[B:], self.gscore[:B], self.gscore[B:]
+        calls = []
+        if self.transh:
+            Rn = self.tabs[2]
+            n_rel = min(R.shape[0], Rn.shape[0])
+            calls.append(b('ktup_score_transh_fwd', _p(E), E.stride(0), _p(R), R.stride(0), _p(Rn), Rn.stride(0), n_rel, d, _p(self.h2),
+                           _p(self.t2), _p(self.r2), 2 * B, self.l1, _p(self.score), st))
+        else:
+            calls.append(b('ktup_score_transe_fwd', _p(E), E.stride(0), _p(R), R.stride(0), d, _p(self.h2), _p(self.t2), _p(self.r2),
+                           2 * B, self.l1, _p(self.score), st))
+        calls += [b('ktup_loss_margin_fwd', _p(pos), _p(neg), B, self.margin, _p(self.loss[0:]), st),
+                  b('ktup_loss_margin_bwd', _p(pos), _p(neg), B, self.margin, _p(self.one), _p(gpos), _p(gneg), st)]
+        if self.transh:
+            calls += [b('ktup_score_transh_bwd', _p(E), E.stride(0), _p(R), R.stride(0), _p(Rn), Rn.stride(0), d, _p(self.h2), _p(self.t2),
+                        _p(self.r2), 2 * B, self.l1, _p(self.gscore), _p(E.grad), _p(R.grad), _p(Rn.grad), st),
+                      b('ktup_reg_orth_fwd', _p(R), R.stride(0), _p(Rn), Rn.stride(0), d, _p(self.r2), 2 * B, _p(self.loss[1:]), st),
+                      b('ktup_reg_orth_bwd', _p(R), R.stride(0), _p(Rn), Rn.stride(0), d, _p(self.r2), 2 * B, _p(self.one), _p(R.grad),
+                        _p(Rn.grad), st)]
+        else:
+            calls.append(b('ktup_score_transe_bwd', _p(E), E.stride(0), _p(R), R.stride(0), d, _p(self.h2), _p(self.t2), _p(self.r2),
+                           2 * B, self.l1, _p(self.gscore), _p(E.grad), _p(R.grad), st))
+        calls += [b('ktup_reg_norm_fwd', _p(E), E.stride(0), d, _p(self.ht4), 4 * B, _p(self.loss[2:]), st),
+                  b('ktup_reg_norm_bwd', _p(E), E.stride(0), d, _p(self.ht4), 4 * B, _p(self.one), _p(E.grad), st),
+                  b('ktup_reg_norm_fwd', _p(R), R.stride(0), d, _p(self.r2), 2 * B, _p(self.loss[3:]), st),
+                  b('ktup_reg_norm_bwd', _p(R), R.stride(0), d, _p(self.r2), 2 * B, _p(self.one), _p(R.grad), st)]
+        self._calls = calls
+
+    def _kg_eager(self, ph, pt, pr, nh, nt, nr):
+        self._plans()
+        ph, pt, pr, nh, nt, nr = (self._mine(x) for x in (ph, pt, pr, nh, nt, nr))
+        torch.cat((ph, nh), out=self.h2); torch.cat((pt, nt), out=self.t2); torch.cat((pr, nr), out=self.r2)
+        torch.cat((ph, pt, nh, nt), out=self.ht4)
+        for launch in self._calls:
+            launch()
+        self._optimizer_launches()
+        return self.loss[:4].sum()
+
+    def kg_step(self, ph, pt, pr, nh, nt, nr):
+        return self._step('kg', self._kg_eager, (ph, pt, pr, nh, nt, nr))
 
 
 class DeviceFeeder(object):

@@ -109,3 +109,16 @@ def test_joint_cli_data_parallel_torchrun(dataset):
     m1 = re.findall(r'f1:\d\.\d+, p:\d\.\d+, r:\d\.\d+, hit:\d\.\d+, ndcg:\d\.\d+', log1)
     assert len(m0) >= 3 and m0 == m1
     assert re.findall(r'rec train loss:\d+\.\d+, kg train loss:\d+\.\d+', log0) == re.findall(r'rec train loss:\d+\.\d+, kg train loss:\d+\.\d+', log1)
+
+
+@pytest.mark.parametrize('script,extra,metric', [
+    ('run_item_recommendation.py', ['-model_type', 'transup', '-num_preferences', '6', '-rec_test_files', 'valid.dat'], r'f1:\d\.\d+'),
+    ('run_knowledge_representation.py', ['-model_type', 'transh', '-kg_test_files', 'valid.dat'], r'avg hit:'),
+])
+def test_single_task_cli_device_sampling(dataset, script, extra, metric):
+    """The rec-only and KG-only drivers with device-resident batches and negative sampling (-device_sampling)."""
+    log, _ = run_cli(script, dataset, 'ds-' + extra[1], extra + ['-device_sampling'])
+    assert 'GPU-resident training step enabled' in log and 'device-resident' in log
+    losses = [float(x) for x in re.findall(r'train loss:(\d+\.\d+)', log)]
+    assert len(losses) >= 2 and all(l == l and l < 1e4 for l in losses)
+    assert len(re.findall(metric, log)) >= 3

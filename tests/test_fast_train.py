@@ -131,3 +131,86 @@ def test_data_parallel_steps_match_one_process(tmp_path):
         bad = err > 2e-6 + 2e-5 * v.cpu().abs()
         assert float(bad.float().mean()) <= 2e-3 and float(err.max()) <= 1e-3 * 0.05, (k, int(bad.sum()), float(err.max()))
     torch.testing.assert_close(torch.tensor(r0['losses']), torch.tensor(losses), rtol=1e-5, atol=1e-6)
+
+
+def _trainer_for(tmp_path, model_type, model, optimizer='Adagrad'):
+    from jTransUP.models.base import get_flags
+    from jTransUP.utils.flags import FLAGS
+    from jTransUP.utils.trainer import ModelTrainer
+    get_flags(); FLAGS.reset()
+    FLAGS(['prog', '-model_type', model_type, '-log_path', str(tmp_path), '-experiment_name', 'st', '-optimizer_type', optimizer,
+           '-learning_rate', '0.05'])
+    FLAGS.ckpt_path = str(tmp_path)
+    return FLAGS, ModelTrainer(model, logging.getLogger('st'), 10, FLAGS)
+
+
+def _assert_tables_close(m1, m2, step):
+    for (k, a), (_, b) in zip(m1.state_dict().items(), m2.state_dict().items()):
+        err = (b - a).abs()
+        bad = err > 2e-6 + 2e-5 * a.abs()
+        assert float(bad.float().mean()) <= 2e-3 and float(err.max()) <= 1e-3 * 0.05, \
+            '%s after step %d: %d elements off, max %.3g' % (k, step, int(bad.sum()), float(err.max()))
+
+
+@pytest.mark.parametrize('model_type', ['transup', 'bprmf'])
+def test_rec_stepper_matches_the_autograd_route(tmp_path, model_type):
+    """item_recommendation.py:160-195 step body vs RecStepper (graph replay kicks in from the third step)."""
+    from jTransUP.models import bprmf, transUP
+    from jTransUP.utils import loss
+    from jTransUP.utils.fast_train import RecStepper
+    NU, NI, D, B = 50, 40, 36, 64
+    torch.manual_seed(4)
+    mk = (lambda: transUP.TransUPModel(False, D, NU, NI, 5, False)) if model_type == 'transup' else (lambda: bprmf.BPRMF(D, NU, NI))
+    m1, m2 = mk(), mk()
+    m2.load_state_dict(copy.deepcopy(m1.state_dict()))
+    FLAGS, tr1 = _trainer_for(tmp_path, model_type, m1)
+    _, tr2 = _trainer_for(tmp_path, model_type, m2)
+    fast = RecStepper(m2, tr2, FLAGS, B)
+    gen = torch.Generator().manual_seed(9)
+    rnd = lambda hi: torch.randint(0, hi, (B,), generator=gen).to(DEV)
+    for step in range(5):
+        u, pi, ni = rnd(NU), rnd(NI), rnd(NI)
+        tr1.optimizer_zero_grad()
+        losses = loss.bprLoss(m1(u, pi), m1(u, ni), target=tr1.model_target)
+        if model_type == 'transup':
+            losses = losses + loss.orthogonalLoss(m1.pref_embeddings.weight, m1.pref_norm_embeddings.weight) \
+                + loss.normLoss(m1.user_embeddings.weight, ids=u) + loss.normLoss(m1.item_embeddings.weight, ids=torch.cat([pi, ni])) \
+                + loss.normLoss(m1.pref_embeddings.weight)
+        losses.backward()
+        tr1.clip_and_step(FLAGS.clipping_max_value)
+        fast_loss = fast.rec_step(u, pi, ni)
+        torch.testing.assert_close(fast_loss, losses.detach(), rtol=1e-5, atol=1e-6)
+        _assert_tables_close(m1, m2, step)
+    assert 'rec' in fast._graphs or not fast.use_graphs
+
+
+@pytest.mark.parametrize('model_type', ['transe', 'transh'])
+def test_kg_stepper_matches_the_autograd_route(tmp_path, model_type):
+    """knowledge_representation.py:176-211 step body vs KGStepper."""
+    from jTransUP.models import transE, transH
+    from jTransUP.utils import loss
+    from jTransUP.utils.fast_train import KGStepper
+    NE, NR, D, B = 70, 6, 36, 64
+    torch.manual_seed(4)
+    mk = (lambda: transH.TransHModel(True, D, NE, NR)) if model_type == 'transh' else (lambda: transE.TransEModel(False, D, NE, NR))
+    m1, m2 = mk(), mk()
+    m2.load_state_dict(copy.deepcopy(m1.state_dict()))
+    FLAGS, tr1 = _trainer_for(tmp_path, model_type, m1, 'SGD')
+    _, tr2 = _trainer_for(tmp_path, model_type, m2, 'SGD')
+    fast = KGStepper(m2, tr2, FLAGS, B)
+    gen = torch.Generator().manual_seed(9)
+    rnd = lambda hi: torch.randint(0, hi, (B,), generator=gen).to(DEV)
+    for step in range(5):
+        ph, pt, pr, nh, nt = rnd(NE), rnd(NE), rnd(NR), rnd(NE), rnd(NE)
+        tr1.optimizer_zero_grad()
+        losses = loss.marginLoss()(m1(ph, pt, pr), m1(nh, nt, pr), FLAGS.margin)
+        rel_ids = torch.cat([pr, pr])
+        if model_type == 'transh':
+            losses = losses + loss.orthogonalLoss(m1.rel_embeddings.weight, m1.norm_embeddings.weight, ids=rel_ids)
+        losses = losses + loss.normLoss(m1.ent_embeddings.weight, ids=torch.cat([ph, pt, nh, nt])) \
+            + loss.normLoss(m1.rel_embeddings.weight, ids=rel_ids)
+        losses.backward()
+        tr1.clip_and_step(FLAGS.clipping_max_value)
+        fast_loss = fast.kg_step(ph, pt, pr, nh, nt, pr)
+        torch.testing.assert_close(fast_loss, losses.detach(), rtol=1e-5, atol=1e-6)
+        _assert_tables_close(m1, m2, step)

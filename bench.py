@@ -217,6 +217,46 @@ def eval_bench(device, batch=512, seed=11):
                     '(the training-time evaluation path; the filter index is built once per run)'}
 
 
+def gather_stress_bench(device, scale=1000, reps=20):
+    """SURVEY.md 8(d) gather-stress variant: the same KTUP forward with every big table scaled x1000 in rows (9.7 GB, far
+    beyond L2 and Infinity Cache) and uniform ids, so every row really comes from HBM.  A 400-byte row at its natural pitch
+    costs four 128-byte lines, which caps useful row bytes at ~72 % of the HBM peak (tools/gather_bench.hip)."""
+    from jTransUP.hip import ops
+    gen = torch.Generator(device=device); gen.manual_seed(3)
+    nu, ni, ne = NU * scale, NI * scale, NE * scale
+    free, _ = torch.cuda.mem_get_info(device)
+    need = (nu + ni + ne) * D * 4
+    if free < 1.5 * need:
+        return {'skipped': 'needs %.1f GB of device memory' % (need / 1e9)}
+    mk = lambda rows: torch.nn.functional.normalize(torch.randn(rows, D, generator=gen, device=device), dim=1)
+    U, I, E = mk(nu), mk(ni), mk(ne + 1)
+    P, Pn, R, Rn = mk(NR), mk(NR), mk(NR), mk(NR)
+    i2e = torch.randint(0, ne, (ni,), generator=gen, device=device).to(torch.int32)
+    u = torch.randint(0, nu, (REC_ROWS,), generator=gen, device=device)
+    i = torch.randint(0, ni, (REC_ROWS,), generator=gen, device=device)
+    h = torch.randint(0, ne, (KG_ROWS,), generator=gen, device=device)
+    t = torch.randint(0, ne, (KG_ROWS,), generator=gen, device=device)
+    r = torch.randint(0, NR, (KG_ROWS,), generator=gen, device=device)
+    out = {'tables_GB': need / 1e9, 'rows_scale': scale}
+    with torch.no_grad():
+        ws = ops.pref_workspace(P, Pn, R, Rn)
+        for name, f, rows, bpr in (('ktup_rec_forward', lambda: ops.score_ktup(U, I, E, P, Pn, R, Rn, i2e, u, i, False, ws=ws), REC_ROWS, BYTES_REC),
+                                   ('ktup_kg_forward', lambda: ops.score_transh(E, R, Rn, h, t, r, False), KG_ROWS, BYTES_KG)):
+            for _ in range(3):
+                f()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize(device)
+            a.record()
+            for _ in range(reps):
+                f()
+            b.record(); torch.cuda.synchronize(device)
+            ms = a.elapsed_time(b) / reps
+            out[name] = {'ms_per_launch': ms, 'achieved_GBs': rows * bpr / (ms * 1e-3) / 1e9,
+                         'frac_of_hbm_peak': rows * bpr / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    out['note'] = 'algorithmic row bytes / time incl. the wrapper launch; tables HBM-resident, so traffic ~ algorithmic x 512/400'
+    return out
+
+
 def hbm_traffic(kind):
     """HBM bytes per launch from the committed PMC passes (profiles/r01_hbm_traffic.json: separate FETCH_SIZE / WRITE_SIZE
     runs of this same command, read side doubled per MI355X_MICROARCH.md); None when the file is absent."""
@@ -326,6 +366,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_extras:
         out['eval_all_item_hit10'] = eval_bench(device)       # before the CPU baseline: its OpenMP pools disturb host-side timing
         out['train_step_b512'] = train_step_bench(device)
+        out['gather_stress_x1000'] = gather_stress_bench(device)
         out['cpu_baseline'] = cpu_baseline(W, i2e, idx)
     elif rank == 0:
         out['cpu_baseline'] = None

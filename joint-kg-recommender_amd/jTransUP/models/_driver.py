@@ -63,40 +63,66 @@ def rank_index(eval_iter, eval_dict, all_dicts):
     return hit[3]
 
 
+def _my_batches(n_batches):
+    """Evaluation batches of this rank under torchrun (batch b goes to rank b % world); every batch in a single process."""
+    import torch.distributed as dist
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        return range(dist.get_rank(), n_batches, dist.get_world_size()), dist.get_world_size()
+    return range(n_batches), 1
+
+
+def _gather_batches(per_batch, n_batches, world):
+    """{batch index: result} of every rank -> list in batch order on every rank."""
+    if world == 1:
+        return [per_batch[b] for b in range(n_batches)]
+    import torch.distributed as dist
+    parts = [None] * world
+    dist.all_gather_object(parts, per_batch)
+    merged = {}
+    for part in parts:
+        merged.update(part)
+    return [merged[b] for b in range(n_batches)]
+
+
 def rec_eval_pass(FLAGS, score_fn, eval_iter, eval_dict, all_dicts, descending, want_rows=True):
     """One pass over the evaluation users: all-item scores, filtered top-n, metric rows (misc.py:148-248 semantics).
-    want_rows=False returns the (n x 5) metric array only (no per-user report rows)."""
+    want_rows=False returns the (n x 5) metric array only (no per-user report rows).  Under torchrun the batches are
+    dealt round-robin to the ranks and the results gathered, so every rank reports the same numbers."""
     index = rank_index(eval_iter, eval_dict, all_dicts)
-    results = []
-    pbar = tqdm(total=len(eval_iter), desc='Run Eval')
-    for u_ids in eval_iter:
+    mine, world = _my_batches(len(eval_iter))
+    per_batch = {}
+    pbar = tqdm(total=len(mine), desc='Run Eval')
+    for b in mine:
+        u_ids = eval_iter[b]
         scores = score_fn(ids(u_ids))
-        res = evalRecProcess((u_ids, scores), eval_dict, all_dicts=all_dicts, descending=descending, topn=FLAGS.topn, index=index,
-                             as_array=not want_rows)
-        if want_rows:
-            results.extend(res)
-        else:
-            results.append(res)
+        per_batch[b] = evalRecProcess((u_ids, scores), eval_dict, all_dicts=all_dicts, descending=descending, topn=FLAGS.topn,
+                                      index=index, as_array=not want_rows)
         pbar.update(1)
     pbar.close()
-    return results if want_rows else np.concatenate(results, axis=0)
+    parts = _gather_batches(per_batch, len(eval_iter), world)
+    if want_rows:
+        return [row for part in parts for row in part]
+    return np.concatenate(parts, axis=0) if parts else np.zeros((0, 5))
 
 
 def kg_eval_pass(FLAGS, score_fn, eval_iter, eval_dict, all_dicts, descending, remap=None):
-    """One pass over (t, r) or (h, r) keys: all-entity scores, filtered gold ranks (misc.py:61-146 semantics)."""
+    """One pass over (t, r) or (h, r) keys: all-entity scores, filtered gold ranks (misc.py:61-146 semantics); batches are
+    dealt to the ranks like in rec_eval_pass."""
     index = rank_index(eval_iter, eval_dict, all_dicts)
-    results = []
-    pbar = tqdm(total=len(eval_iter), desc='Run Eval')
-    for batch in eval_iter:
+    mine, world = _my_batches(len(eval_iter))
+    per_batch = {}
+    pbar = tqdm(total=len(mine), desc='Run Eval')
+    for b in mine:
+        batch = eval_iter[b]
         q = [k[0] if remap is None else remap[k[0]] for k in batch]
         r = [k[1] for k in batch]
         scores = score_fn(ids(q), ids(r))
         keys = [tuple(k) for k in batch]
-        results.extend(evalKGProcess((keys, scores), eval_dict, all_dicts=all_dicts, descending=descending, topn=FLAGS.topn,
-                                     index=index))
+        per_batch[b] = evalKGProcess((keys, scores), eval_dict, all_dicts=all_dicts, descending=descending, topn=FLAGS.topn,
+                                     index=index)
         pbar.update(1)
     pbar.close()
-    return results
+    return [row for part in _gather_batches(per_batch, len(eval_iter), world) for row in part]
 
 
 def summarize_rec(FLAGS, results, logger):

@@ -80,12 +80,20 @@ class _StepperBase(object):
         self.use_graphs = bool(use_graphs) and self.world == 1 and not getattr(model, 'use_st_gumbel', False)
         self._graphs = {}
         self._eager_steps = {k: 0 for k in self.KINDS}
-        self._in = {k: [torch.zeros(self.GB, **i64) for _ in range(self.N_IDS[k])] for k in self.KINDS}
         self._setup(FLAGS, f32, i64)
 
     def _mine(self, t):
         """This rank's rows of a global-batch id tensor."""
         return t if self.world == 1 else t[self.rank * self.B:(self.rank + 1) * self.B]
+
+    def _pack(self, kind, args):
+        if kind == 'rec':
+            u, pi, ni = (self._mine(x) for x in args)
+            torch.cat((u, u), out=self.u2); torch.cat((pi, ni), out=self.i2)
+        else:
+            ph, pt, pr, nh, nt, nr = (self._mine(x) for x in args)
+            torch.cat((ph, nh), out=self.h2); torch.cat((pt, nt), out=self.t2); torch.cat((pr, nr), out=self.r2)
+            torch.cat((ph, pt, nh, nt), out=self.ht4)
 
     def _plans(self):
         st = torch.cuda.current_stream(self.dev).cuda_stream
@@ -115,13 +123,11 @@ class _StepperBase(object):
             out = eager(*args)
             self.trainer.step += 1
             return out
-        ins = self._in[kind]
-        for dst, src in zip(ins, args):
-            dst.copy_(src)
+        self._pack(kind, args)                                   # ids -> the persistent [pos ; neg] buffers (outside the graph)
         if entry is None:
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                out = eager(*ins)
+                out = eager(*([None] * len(args)))               # None: ids are already packed
             self._keys = None                                    # plans were bound to the capture stream: rebind for eager use
             fused._plan = None
             entry = (graph, out, fused)
@@ -199,8 +205,8 @@ class JointStepper(_StepperBase):
         m, B = self.m, self.B
         U, I, E, P, Pn, R, Rn = self.tabs
         self._plans()
-        u, pi, ni = self._mine(u), self._mine(pi), self._mine(ni)
-        torch.cat((u, u), out=self.u2); torch.cat((pi, ni), out=self.i2)
+        if u is not None:
+            self._pack('rec', (u, pi, ni))
         self._rec_head[0]()
         self.gAC.zero_()
         if not m.use_st_gumbel:
@@ -226,9 +232,8 @@ class JointStepper(_StepperBase):
     # ------------------------------------------------------------------------------------------------ kg
     def _kg_eager(self, ph, pt, pr, nh, nt, nr):
         self._plans()
-        ph, pt, pr, nh, nt, nr = (self._mine(x) for x in (ph, pt, pr, nh, nt, nr))
-        torch.cat((ph, nh), out=self.h2); torch.cat((pt, nt), out=self.t2); torch.cat((pr, nr), out=self.r2)
-        torch.cat((ph, pt, nh, nt), out=self.ht4)
+        if ph is not None:
+            self._pack('kg', (ph, pt, pr, nh, nt, nr))
         for launch in self._kg:
             launch()
         self._optimizer_launches()
@@ -294,8 +299,8 @@ class RecStepper(_StepperBase):
     def _rec_eager(self, u, pi, ni):
         m, B = self.m, self.B
         self._plans()
-        u, pi, ni = self._mine(u), self._mine(pi), self._mine(ni)
-        torch.cat((u, u), out=self.u2); torch.cat((pi, ni), out=self.i2)
+        if u is not None:
+            self._pack('rec', (u, pi, ni))
         if not self.tup:
             self._fwd(); self._loss[0](); self._loss[1](); self._bwd()
             if self.world > 1:
@@ -375,9 +380,8 @@ class KGStepper(_StepperBase):
 
     def _kg_eager(self, ph, pt, pr, nh, nt, nr):
         self._plans()
-        ph, pt, pr, nh, nt, nr = (self._mine(x) for x in (ph, pt, pr, nh, nt, nr))
-        torch.cat((ph, nh), out=self.h2); torch.cat((pt, nt), out=self.t2); torch.cat((pr, nr), out=self.r2)
-        torch.cat((ph, pt, nh, nt), out=self.ht4)
+        if ph is not None:
+            self._pack('kg', (ph, pt, pr, nh, nt, nr))
         for launch in self._calls:
             launch()
         self._optimizer_launches()

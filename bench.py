@@ -270,8 +270,8 @@ def hbm_traffic(kind):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=30)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=200)       # a step is ~0.17 ms: 200 steps = 35 ms of timed work
+    ap.add_argument('--warmup', type=int, default=50)       # long enough for the clocks to settle
     ap.add_argument('--no-extras', action='store_true', help='skip cpu_baseline / train-step / eval side measurements')
     args = ap.parse_args()
 
@@ -323,6 +323,10 @@ def main():
         if world > 1:
             dist.barrier()
 
+    t_ramp = time.perf_counter()                        # clock ramp: a fresh device needs ~50 ms of load to reach its clocks,
+    while time.perf_counter() - t_ramp < 0.08:          # whatever --warmup says (untimed, like the warm-up steps)
+        prep(); rec(); kg()
+        torch.cuda.synchronize(device)
     for _ in range(args.warmup):
         prep(); rec(); kg()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]

@@ -1,15 +1,9 @@
-"""Command line entry, same flags as the reference's run_item_recommendation.py (single-dash gflags style)."""
+"""python run_item_recommendation.py -model_type ... : the reference's command line on the MI355X package."""
 import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
-from jTransUP.models import item_recommendation
-from jTransUP.models.base import flag_defaults, get_flags
-from jTransUP.utils.flags import FLAGS
-
 if __name__ == '__main__':
-    get_flags()
-    FLAGS(sys.argv)
-    flag_defaults(FLAGS)
-    item_recommendation.run(only_forward=FLAGS.eval_only_mode)
+    from jTransUP.cli import main
+    main('item_recommendation')

@@ -280,3 +280,35 @@ def test_module_surface_matches_reference_names():
     assert float(k.ent_embeddings.weight.grad[-1].abs().sum()) == 0.0
     k.disable_grad(); assert not k.user_embeddings.weight.requires_grad
     k.enable_grad(); assert k.user_embeddings.weight.requires_grad
+
+
+@pytest.mark.parametrize('n', [1, 15, 16, 17, 49, 300])
+def test_matrix_core_kernels_ragged_fwd_bwd(n):
+    """Wave tiles of the matrix-core kernels hold 16 rows: sizes around the tile edge, forward AND backward, soft and hard gate
+    (uniforms supplied, so the oracle sees the same Gumbel draw), plus the relation-bucketed TransR forward when most relations
+    have no triple at all."""
+    W, i2e, gen = rand_world(2, 50, 60, 70, 20, 100)
+    u = torch.randint(0, 50, (n,), generator=gen); i = torch.randint(0, 60, (n,), generator=gen)
+    uni = torch.rand(n, 20, generator=gen)
+    wgt = torch.randn(n, generator=gen)
+    names = ('U', 'I', 'E', 'P', 'Pn', 'R', 'Rn')
+    for l1 in (False, True):
+        for hard in (False, True):
+            Wc = {k: W[k].clone().requires_grad_(True) for k in names}
+            Wd = {k: W[k].to(DEV).requires_grad_(True) for k in names}
+            ref = O.score_ktup_rec(*(Wc[k] for k in names), i2e, u, i, l1, uniform=uni if hard else None)
+            got = ops().score_ktup(*(Wd[k] for k in names), i2e.to(DEV, torch.int32), u.to(DEV), i.to(DEV), l1,
+                                   ops().GUMBEL_INPUT if hard else ops().GUMBEL_OFF, uni.to(DEV) if hard else None, ent_pad=70)
+            close(got, ref)
+            (ref * wgt).sum().backward(); (got * wgt.to(DEV)).sum().backward()
+            Wc['E'].grad[70] = 0.0                                        # nn.Embedding(padding_idx=...) of the reference: no gradient
+            for k in names:
+                close(Wd[k].grad, Wc[k].grad, atol=GAT)
+            assert float(Wd['E'].grad[70].abs().sum()) == 0.0            # the pad entity row never receives a gradient
+    # TransR: d = 100 takes the bucketed matrix-core forward; only relations 3 and 17 occur
+    M = torch.nn.functional.normalize(torch.randn(20, 100 * 100, generator=gen), dim=1)
+    h = torch.randint(0, 70, (n,), generator=gen); t = torch.randint(0, 70, (n,), generator=gen)
+    r = torch.where(torch.rand(n, generator=gen) < 0.5, torch.tensor(3), torch.tensor(17))
+    for l1 in (False, True):
+        close(ops().score_transr(W['E'].to(DEV), W['R'].to(DEV), M.to(DEV), h.to(DEV), t.to(DEV), r.to(DEV), l1),
+              O.score_transr(W['E'], W['R'], M, h, t, r, l1))

@@ -96,10 +96,11 @@ int pairs_l2_mc(const float* QW, const float* C0, const float* C1, const float* 
 int pairs_kg_l2_mc(int model, const float* QW, int dq, const float* C, int64_t ldc, int d, int64_t nq, int64_t n_cand, float* out,
                    int64_t ldo, hipStream_t st, const char* name);
 
-// ktup_score_pref_bwd_mc.hip: matrix-core backward of the soft-gate TUP / KTUP score.  Returns 1 for shapes it does not cover.
+// ktup_score_pref_bwd_mc.hip: matrix-core backward of the TUP / KTUP score (soft and ST-Gumbel gate).  Returns 1 for shapes it does not cover.
 int pref_bwd_mc(const float* U, int64_t ldu, const float* I, int64_t ldi, const float* E, int64_t lde, const int32_t* item2ent,
                 int64_t ent_pad, const float* Alog, const float* Ar, const float* Cn, int dp, float beta, int n_pref, int d,
-                const int64_t* u_ids, const int64_t* i_ids, int64_t n, int l1, const float* gscore, float* gU, float* gI, float* gE,
-                float* gA, float* gC, hipStream_t st, const char* name);
+                const int64_t* u_ids, const int64_t* i_ids, int64_t n, int l1, int gumbel_mode, const float* uniform, uint64_t seed,
+                uint64_t offset, const float* gscore, float* gU, float* gI, float* gE, float* gA, float* gC, hipStream_t st,
+                const char* name);
 
 }  // namespace ktup

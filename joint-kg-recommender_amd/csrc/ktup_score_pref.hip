@@ -1652,14 +1652,14 @@ int run_pref(bool bwd, const char* name, const float* U, int64_t ldu, const floa
     if (variant >= 3 && fwd3_supported(a, d, n_pref, &g3)) return dispatch_fwd3(a, d, g3, st, name);
     if (variant != 0) return dispatch_fwd2(a, d, n_pref, st, name);
   }
-  if (bwd && a.gumbel == KTUP_GUMBEL_OFF) {   // soft gate: matrix-core backward (KTUP_PREF_BWD=0 keeps the first kernel for A/B runs)
+  if (bwd) {   // matrix-core backward (KTUP_PREF_BWD=0 keeps the first kernel for A/B runs)
     const char* env = getenv("KTUP_PREF_BWD");
     if (!env || atoi(env) != 0) {
       const int rc = pref_bwd_mc(reinterpret_cast<const float*>(a.U), a.ldu4 * 4, reinterpret_cast<const float*>(a.I), a.ldi4 * 4,
                                  reinterpret_cast<const float*>(a.E), a.lde4 * 4, a.item2ent, a.ent_pad,
                                  reinterpret_cast<const float*>(a.Alog), reinterpret_cast<const float*>(a.Ar),
                                  reinterpret_cast<const float*>(a.Cn), a.dp4 * 4, a.alpha_beta, n_pref, d, a.u_ids, a.i_ids, a.n, a.l1,
-                                 a.gscore, a.gU, a.gI, a.gE, a.gA, a.gC, st, name);
+                                 a.gumbel, a.uniform, a.seed, a.offset, a.gscore, a.gU, a.gI, a.gE, a.gA, a.gC, st, name);
       if (rc != 1) return rc;
     }
   }

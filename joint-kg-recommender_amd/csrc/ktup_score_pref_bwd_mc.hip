@@ -1,4 +1,4 @@
-// K5 / K6 backward, soft gate, on the matrix cores (transUP.py:69-115 / jTransUP.py:122-143,250-262 differentiated).
+// K5 / K6 / K7 backward on the matrix cores, soft and straight-through Gumbel gate (transUP.py:69-115 / jTransUP.py:122-143,250-262 differentiated).
 //
 // Forward (per pair):  x = u + i (+ e),  q = u - i (- e),  L = x . Alog^T,  r = L . Ar,  n = L . Cn,  s = q . n,
 //                      z = q + r - s n,  score = sum_k dist(z_k)      (Alog = A/2, Ar = beta A, Cn = beta C, ktup_pref_prepare)
@@ -26,10 +26,10 @@
 namespace ktup {
 namespace {
 
-template <int NCH_, int NP_, bool HASE_>
+template <int NCH_, int NP_, bool HASE_, bool HARD_>
 struct BGeom {
   static constexpr int NCH = NCH_, NP = NP_, D = 4 * NCH;
-  static constexpr bool HASE = HASE_;
+  static constexpr bool HASE = HASE_, HARD = HARD_;   // HARD: straight-through Gumbel gate
   static constexpr int KG = (D + 15) / 16, CT = KG;
   static constexpr int PT = (NP + 3) / 4;                  // 16-slot preference tiles
   static constexpr int J = (16 * NCH + 63) / 64;
@@ -41,7 +41,8 @@ struct BGeom {
   static constexpr size_t TABLE_BYTES = (size_t)3 * SLOT_F4 * 16;
   static constexpr int TILE_F4 = 16 * NCH + 3;             // one (16 pairs x d) tile + 3 zero chunks
   static constexpr int LT_F = TROW * 17;                   // transposed [preference][pair] arrays, pitch 17
-  static constexpr size_t WAVE_BYTES = ((size_t)4 * TILE_F4 * 16 + (size_t)2 * LT_F * 4 + 3 * 16 * 4 + 15) & ~(size_t)15;
+  static constexpr int NOISE_F = HARD ? 16 * TROW : 0;     // HARD: Gumbel noise of the tile, [pair][preference]
+  static constexpr size_t WAVE_BYTES = ((size_t)4 * TILE_F4 * 16 + (size_t)2 * LT_F * 4 + 3 * 16 * 4 + (size_t)NOISE_F * 4 + 15) & ~(size_t)15;
   static constexpr int NW = TABLE_BYTES + 3 * WAVE_BYTES <= 160 * 1024 ? 3 : TABLE_BYTES + 2 * WAVE_BYTES <= 160 * 1024 ? 2 : 1;
   static constexpr size_t LDS = TABLE_BYTES + NW * WAVE_BYTES;
 };
@@ -57,13 +58,17 @@ struct BArgs {
   int64_t n, ent_pad;
   const float* gscore;
   float *gU, *gI, *gE, *gA, *gC;
+  int gumbel;                    // KTUP_GUMBEL_* (HARD kernels)
+  const float* uniform;
+  uint64_t seed, offset;
 };
 
 template <typename G>
 __global__ __launch_bounds__(G::NW * 64) void pref_bwd_mc_kernel(BArgs a) {
   constexpr int NCH = G::NCH, NP = G::NP, D = G::D, KG = G::KG, CT = G::CT, PT = G::PT, J = G::J, TOTAL = G::TOTAL;
   constexpr int PITCHA4 = G::PITCHA4, RP = G::RP, NW = G::NW;
-  constexpr bool HASE = G::HASE;
+  constexpr bool HASE = G::HASE, HARD = G::HARD;
+  constexpr int TROW = G::TROW;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   v4* AlogSlot = reinterpret_cast<v4*>(smem);                 // [PT*16 slots][PITCHA4]
   v4* ArSlot = AlogSlot + G::SLOT_F4;
@@ -82,6 +87,7 @@ __global__ __launch_bounds__(G::NW * 64) void pref_bwd_mc_kernel(BArgs a) {
   float* LT = reinterpret_cast<float*>(GNT + G::TILE_F4);     // [TROW][17]  beta * L   (transposed: preference major)
   float* GLT = LT + G::LT_F;                                  // [TROW][17]  gL / 2
   int32_t* sid = reinterpret_cast<int32_t*>(GLT + G::LT_F);   // [3][16]
+  float* noise = reinterpret_cast<float*>(sid + 48);         // HARD: [16][TROW]
   // ---- stage the three tables in both layouts
   {
     const int P = a.P, dp = a.dp;
@@ -173,6 +179,72 @@ __global__ __launch_bounds__(G::NW * 64) void pref_bwd_mc_kernel(BArgs a) {
         for (int c = 0; c < 4; ++c) lg[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c], bv[c], lg[tt], 0, 0, 0);
       }
     }
+    // ---- ST-Gumbel gate (transUP.py:118-170): forward weights w = one_hot(argmax(l + g)), backward through y = softmax(l + g).
+    //      From here on `lg` holds the FORWARD weights (the raw logits for the soft gate); ysoft keeps y for the Jacobian.
+    v4 ysoft[PT];
+    if constexpr (HARD) {
+      const int64_t grow = min(row0 + j, a.n - 1);
+      const uint64_t base = (uint64_t)grow * (uint64_t)a.P;
+      if (a.gumbel == KTUP_GUMBEL_PHILOX) {     // same stream and block sharing as pref_fwd_mc
+        const uint64_t i0 = base + a.offset, fb = i0 >> 2, lb = (i0 + (uint64_t)a.P - 1) >> 2;
+        const Philox ph(a.seed);
+        for (uint64_t b = fb + kq; b <= lb; b += 4) {
+          const uint4 r = ph(b, 0x4b545550ull /* "KTUP" stream tag */);
+          const uint32_t wds[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+          for (int wd = 0; wd < 4; ++wd) {
+            const int64_t pp = (int64_t)((b << 2) + wd) - (int64_t)i0;
+            if (pp >= 0 && pp < a.P) noise[j * TROW + (int)pp] = gumbel_from_uniform(u01(wds[wd]));
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
+      float best = -INFINITY;
+      int bp = 0x7fffffff;
+#pragma unroll
+      for (int tt = 0; tt < PT; ++tt)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {               // ascending p within the lane: strict > keeps the first maximum
+          const int pp = 16 * tt + 4 * reg + kq;
+          float v = -INFINITY;
+          if (pp < a.P) {
+            const float g = a.gumbel == KTUP_GUMBEL_PHILOX ? noise[j * TROW + pp] : gumbel_from_uniform(a.uniform[base + pp]);
+            v = lg[tt][reg] + g;
+            if (v > best || bp == 0x7fffffff) { best = v; bp = pp; }
+          }
+          lg[tt][reg] = v;                                // noisy logit (-inf for padding preferences)
+        }
+      {
+        const u2 rv = __builtin_amdgcn_permlane32_swap(__float_as_uint(best), __float_as_uint(best), false, false);
+        const u2 rp = __builtin_amdgcn_permlane32_swap((unsigned)bp, (unsigned)bp, false, false);
+        const float v0 = __uint_as_float(rv[0]), v1 = __uint_as_float(rv[1]);
+        const int p0 = (int)rp[0], p1 = (int)rp[1];
+        const bool take1 = p0 == 0x7fffffff || (p1 != 0x7fffffff && (v1 > v0 || (v1 == v0 && p1 < p0)));
+        best = take1 ? v1 : v0; bp = take1 ? p1 : p0;
+      }
+      {
+        const u2 rv = __builtin_amdgcn_permlane16_swap(__float_as_uint(best), __float_as_uint(best), false, false);
+        const u2 rp = __builtin_amdgcn_permlane16_swap((unsigned)bp, (unsigned)bp, false, false);
+        const float v0 = __uint_as_float(rv[0]), v1 = __uint_as_float(rv[1]);
+        const int p0 = (int)rp[0], p1 = (int)rp[1];
+        const bool take1 = p0 == 0x7fffffff || (p1 != 0x7fffffff && (v1 > v0 || (v1 == v0 && p1 < p0)));
+        best = take1 ? v1 : v0; bp = take1 ? p1 : p0;
+      }
+      float den = 0.f;
+#pragma unroll
+      for (int tt = 0; tt < PT; ++tt)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const float e = expf(lg[tt][reg] - best);        // exp(-inf) = 0 for padding preferences
+          ysoft[tt][reg] = e;
+          den += e;
+          lg[tt][reg] = (16 * tt + 4 * reg + kq == bp) ? 1.f : 0.f;
+        }
+      const float inv = 1.f / allsum_kq(den);
+#pragma unroll
+      for (int tt = 0; tt < PT; ++tt) ysoft[tt] = ysoft[tt] * inv;
+    }
     // ---- A2: n^T, r^T per coordinate tile; lane (kq, j) owns coordinates 16 ct + 4 kq + reg of pair j
     v4 nn[CT], zz[CT], qv[CT];
     v4 sacc = (v4){0.f, 0.f, 0.f, 0.f};
@@ -228,7 +300,15 @@ __global__ __launch_bounds__(G::NW * 64) void pref_bwd_mc_kernel(BArgs a) {
         }
       }
     }
-    // transposed copies for phase D: LT[p][pair] = beta L, GLT[p][pair] = gL / 2
+    if constexpr (HARD) {        // gl <- y * (gw - y . gw): the softmax Jacobian of y = softmax(l + g) applied to gw
+      float dot = 0.f;
+#pragma unroll
+      for (int tt = 0; tt < PT; ++tt) dot += (ysoft[tt][0] * gl[tt][0] + ysoft[tt][1] * gl[tt][1]) + (ysoft[tt][2] * gl[tt][2] + ysoft[tt][3] * gl[tt][3]);
+      dot = allsum_kq(dot);
+#pragma unroll
+      for (int tt = 0; tt < PT; ++tt) gl[tt] = ysoft[tt] * (gl[tt] - dot);
+    }
+    // transposed copies for phase D: LT[p][pair] = beta w (w = L for the soft gate), GLT[p][pair] = gl / 2
 #pragma unroll
     for (int tt = 0; tt < PT; ++tt)
 #pragma unroll
@@ -321,8 +401,12 @@ int launch(const BArgs& a, hipStream_t st, const char* name) {
 
 template <int NCH, int NP>
 int launch_e(const BArgs& a, hipStream_t st, const char* name) {
-  if (a.E) return launch<BGeom<NCH, NP, true>>(a, st, name);
-  return launch<BGeom<NCH, NP, false>>(a, st, name);
+  if (a.gumbel != KTUP_GUMBEL_OFF) {
+    if (a.E) return launch<BGeom<NCH, NP, true, true>>(a, st, name);
+    return launch<BGeom<NCH, NP, false, true>>(a, st, name);
+  }
+  if (a.E) return launch<BGeom<NCH, NP, true, false>>(a, st, name);
+  return launch<BGeom<NCH, NP, false, false>>(a, st, name);
 }
 
 template <int NCH>
@@ -334,11 +418,12 @@ int launch_np(const BArgs& a, int np, hipStream_t st, const char* name) {
 
 }  // namespace
 
-// Soft gate only.  Returns KTUP_OK / an error, or 1 when (d, P) is not covered (the caller runs pref_bwd_kernel).
+// Returns KTUP_OK / an error, or 1 when (d, P) is not covered (the caller runs pref_bwd_kernel).
 int pref_bwd_mc(const float* U, int64_t ldu, const float* I, int64_t ldi, const float* E, int64_t lde, const int32_t* item2ent,
                 int64_t ent_pad, const float* Alog, const float* Ar, const float* Cn, int dp, float beta, int n_pref, int d,
-                const int64_t* u_ids, const int64_t* i_ids, int64_t n, int l1, const float* gscore, float* gU, float* gI, float* gE,
-                float* gA, float* gC, hipStream_t st, const char* name) {
+                const int64_t* u_ids, const int64_t* i_ids, int64_t n, int l1, int gumbel_mode, const float* uniform, uint64_t seed,
+                uint64_t offset, const float* gscore, float* gU, float* gI, float* gE, float* gA, float* gC, hipStream_t st,
+                const char* name) {
   if (n_pref > 32 || (d != 64 && d != 100 && d != 128)) return 1;
   if ((ldu | ldi | lde) & 3) return 1;
   if ((ldu >> 2) > 0xffffffffll || (ldi >> 2) > 0xffffffffll || (lde >> 2) > 0xffffffffll) return 1;
@@ -349,6 +434,7 @@ int pref_bwd_mc(const float* U, int64_t ldu, const float* I, int64_t ldi, const 
   a.Alog = Alog; a.Ar = Ar; a.Cn = Cn; a.dp = dp; a.P = n_pref; a.l1 = l1; a.beta = beta;
   a.u_ids = u_ids; a.i_ids = i_ids; a.n = n; a.ent_pad = ent_pad;
   a.gscore = gscore; a.gU = gU; a.gI = gI; a.gE = gE; a.gA = gA; a.gC = gC;
+  a.gumbel = gumbel_mode; a.uniform = uniform; a.seed = seed; a.offset = offset;
   const int np = (n_pref + 3) / 4;
   if (d == 64) return launch_np<16>(a, np, st, name);
   if (d == 100) return launch_np<25>(a, np, st, name);

@@ -90,19 +90,16 @@ __global__ __launch_bounds__(G::NW * 64) void pref_bwd_mc_kernel(BArgs a) {
   float* noise = reinterpret_cast<float*>(sid + 48);         // HARD: [16][TROW]
   // ---- stage the three tables in both layouts
   {
-    const int P = a.P, dp = a.dp;
-    constexpr int rowf = PITCHA4 * 4;
-    float* s0 = reinterpret_cast<float*>(AlogSlot);
-    float* s1 = reinterpret_cast<float*>(ArSlot);
-    float* s2 = reinterpret_cast<float*>(CnSlot);
-    for (int idx = tid; idx < G::SLOT_F4 * 4; idx += NW * 64) {
-      const int srow = idx / rowf, k = idx - srow * rowf;
+    const int P = a.P, dp = a.dp;                              // float4 granularity: rows are 16-byte aligned, pitch % 4 == 0
+    const v4 zero = (v4){0.f, 0.f, 0.f, 0.f};
+    for (int idx = tid; idx < G::SLOT_F4; idx += NW * 64) {
+      const int srow = idx / PITCHA4, c = idx - srow * PITCHA4;
       const int tt = srow >> 4, i = srow & 15;
       const int p = 16 * tt + 4 * (i & 3) + (i >> 2);          // slot -> preference (block transposed, as in pref_fwd_mc)
-      const bool ok = p < P && k < D;
-      s0[idx] = ok ? a.Alog[p * dp + k] : 0.f;
-      s1[idx] = ok ? a.Ar[p * dp + k] : 0.f;
-      s2[idx] = ok ? a.Cn[p * dp + k] : 0.f;
+      const bool ok = p < P && c < NCH;
+      AlogSlot[idx] = ok ? *reinterpret_cast<const v4*>(a.Alog + p * dp + 4 * c) : zero;
+      ArSlot[idx] = ok ? *reinterpret_cast<const v4*>(a.Ar + p * dp + 4 * c) : zero;
+      CnSlot[idx] = ok ? *reinterpret_cast<const v4*>(a.Cn + p * dp + 4 * c) : zero;
     }
     if (lane < 3) {
       XT[16 * NCH + lane] = (v4){0.f, 0.f, 0.f, 0.f}; QT[16 * NCH + lane] = XT[16 * NCH + lane];

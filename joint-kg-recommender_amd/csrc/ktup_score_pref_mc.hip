@@ -97,30 +97,34 @@ __global__ __launch_bounds__(G::NW * 64) void pref_fwd_mc_kernel(McArgs a) {
   float* noise = reinterpret_cast<float*>(sid + 48);             // HARD: [16][TROW]
   // ---- stage the tables once per workgroup
   {
+    // float4 granularity (table rows are 16-byte aligned with a pitch that is a multiple of 4 floats): for a B=512 step this
+    // staging is a visible part of the launch
     const int P = a.P, dp = a.dp;
-    float* AlogSf = reinterpret_cast<float*>(AlogS);
-    constexpr int rowf = PITCHA4 * 4;
-    for (int idx = t; idx < G::A_F4 * 4; idx += G::NW * 64) {
-      const int srow = idx / rowf, k = idx - srow * rowf;
+    const v4 zero = (v4){0.f, 0.f, 0.f, 0.f};
+    for (int idx = t; idx < G::A_F4; idx += G::NW * 64) {
+      const int srow = idx / PITCHA4, c = idx - srow * PITCHA4;
       const int tt = srow >> 4, i = srow & 15;
       const int p = 16 * tt + 4 * (i & 3) + (i >> 2);            // slot -> preference (block transposed)
-      AlogSf[idx] = (p < P && k < G::D) ? a.Alog[p * dp + k] : 0.f;
+      AlogS[idx] = (p < P && c < NCH) ? *reinterpret_cast<const v4*>(a.Alog + p * dp + 4 * c) : zero;
     }
     if (REM4) {
-      float* A4Sf = reinterpret_cast<float*>(A4S);
-      for (int idx = t; idx < G::A4_F4 * 4; idx += G::NW * 64) {
-        const int i = idx / (16 * KQ), rem = idx - i * (16 * KQ);
-        const int kp = rem / (4 * KQ), kk = rem - kp * (4 * KQ);
-        const int p = 16 * PTF + i, k = 4 * KQ * kp + kk;
-        A4Sf[idx] = (p < P && k < G::D) ? a.Alog[p * dp + k] : 0.f;
+      for (int idx = t; idx < G::A4_F4; idx += G::NW * 64) {     // [pref i][quarter kp][KQ chunks]
+        const int i = idx / (4 * KQ), rem = idx - i * (4 * KQ);
+        const int kp = rem / KQ, kk = rem - kp * KQ;
+        const int p = 16 * PTF + i, c = KQ * kp + kk;
+        A4S[idx] = (p < P && c < NCH) ? *reinterpret_cast<const v4*>(a.Alog + p * dp + 4 * c) : zero;
       }
     }
-    for (int idx = t; idx < G::T_F; idx += G::NW * 64) {
-      const int pitch = HARD ? HP * 4 : TPITCH;
-      const int p = idx / pitch, c = idx - p * pitch;
-      const bool ok = p < P && c < G::D;
-      CnS[idx] = ok ? a.Cn[p * dp + c] : 0.f;
-      ArS[idx] = ok ? a.Ar[p * dp + c] : 0.f;
+    {
+      constexpr int pitch4 = HARD ? HP : TPITCH / 4;
+      v4* Cn4 = reinterpret_cast<v4*>(CnS);
+      v4* Ar4 = reinterpret_cast<v4*>(ArS);
+      for (int idx = t; idx < G::T_F / 4; idx += G::NW * 64) {
+        const int p = idx / pitch4, c = idx - p * pitch4;
+        const bool ok = p < P && c < NCH;
+        Cn4[idx] = ok ? *reinterpret_cast<const v4*>(a.Cn + p * dp + 4 * c) : zero;
+        Ar4[idx] = ok ? *reinterpret_cast<const v4*>(a.Ar + p * dp + 4 * c) : zero;
+      }
     }
     if (lane < 3) xt[16 * NCH + lane] = (v4){0.f, 0.f, 0.f, 0.f};
   }

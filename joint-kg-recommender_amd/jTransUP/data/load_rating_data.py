@@ -4,6 +4,7 @@ import os
 
 import numpy as np
 
+from jTransUP.data.cache import cached
 from jTransUP.utils.data import MakeEvalIterator, MakeTrainIterator
 
 
@@ -33,14 +34,14 @@ def loadRatings(filename):
 
 
 def load_data(data_path, eval_filenames, batch_size, negtive_samples=1, logger=None):
-    train_total, train_list, train_dict = loadRatings(os.path.join(data_path, 'train.dat'))
+    train_total, train_list, train_dict = cached(os.path.join(data_path, 'train.dat'), loadRatings)
     eval_files = [os.path.join(data_path, f) for f in eval_filenames]
-    evals = [loadRatings(f) for f in eval_files]
+    evals = [cached(f, loadRatings) for f in eval_files]
     if logger is not None:
         logger.info('Totally {} train ratings, {} eval ratings in files: {}!'.format(
             train_total, ','.join(str(e[0]) for e in evals), ';'.join(eval_files)))
-    u_map = loadVocab(os.path.join(data_path, 'u_map.dat'))
-    i_map = loadVocab(os.path.join(data_path, 'i_map.dat'))
+    u_map = cached(os.path.join(data_path, 'u_map.dat'), loadVocab)
+    i_map = cached(os.path.join(data_path, 'i_map.dat'), loadVocab)
     if logger is not None:
         logger.info('successfully load {} users and {} items!'.format(len(u_map), len(i_map)))
     train_iter = MakeTrainIterator(train_list, batch_size, negtive_samples=negtive_samples)

@@ -4,6 +4,7 @@ import os
 
 import numpy as np
 
+from jTransUP.data.cache import cached
 from jTransUP.utils.data import MakeEvalIterator, MakeTrainIterator
 
 
@@ -33,14 +34,14 @@ def loadVocab(filename):
 
 
 def load_data(kg_path, eval_filenames, batch_size, negtive_samples=1, logger=None):
-    train_total, train_list, train_head_dict, train_tail_dict = loadTriples(os.path.join(kg_path, 'train.dat'))
+    train_total, train_list, train_head_dict, train_tail_dict = cached(os.path.join(kg_path, 'train.dat'), loadTriples)
     eval_files = [os.path.join(kg_path, f) for f in eval_filenames]
-    evals = [loadTriples(f) for f in eval_files]
+    evals = [cached(f, loadTriples) for f in eval_files]
     if logger is not None:
         logger.info('Totally {} train triples, {} eval triples in files: {}!'.format(
             train_total, ','.join(str(e[0]) for e in evals), ';'.join(eval_files)))
-    e_map = loadVocab(os.path.join(kg_path, 'e_map.dat'))
-    r_map = loadVocab(os.path.join(kg_path, 'r_map.dat'))
+    e_map = cached(os.path.join(kg_path, 'e_map.dat'), loadVocab)
+    r_map = cached(os.path.join(kg_path, 'r_map.dat'), loadVocab)
     if logger is not None:
         logger.info('successfully load {} entities and {} relations!'.format(len(e_map), len(r_map)))
     train_iter = MakeTrainIterator(train_list, batch_size, negtive_samples=negtive_samples)

@@ -153,3 +153,35 @@ def test_trainer_checkpoint_layout_and_pretrain_load(tmp_path):
     assert torch.equal(k.rel_embeddings.weight.cpu(), th.rel_embeddings.weight.cpu())
     assert get_model_target('bprmf') == 1 and get_model_target('jtransup') == -1
     FLAGS.reset()
+
+
+def test_binary_dataset_cache_round_trip_and_staleness(tmp_path, monkeypatch):
+    """data/cache.py: the second load comes from the pickle (same structures, same dict order), an edited source file is
+    re-parsed, KTUP_DATA_CACHE=0 bypasses the cache."""
+    import os
+    import time
+    from jTransUP.data import cache, load_kg_rating_data
+    make_dataset(str(tmp_path))
+    root = os.path.join(str(tmp_path), 'ml1m')
+    monkeypatch.delenv('KTUP_DATA_CACHE', raising=False)
+    calls = []
+    real = cache.pickle.load
+    monkeypatch.setattr(cache.pickle, 'load', lambda f: (calls.append(1), real(f))[1])
+    first = load_kg_rating_data.load_data(root, ['valid.dat'], ['valid.dat'], 16)
+    assert not calls and os.path.isdir(os.path.join(root, '.ktup_cache'))
+    second = load_kg_rating_data.load_data(root, ['valid.dat'], ['valid.dat'], 16)
+    assert len(calls) >= 8                                          # every parsed file came from its pickle
+    for a, b in ((first[0], second[0]), (first[4], second[4])):     # train datasets: totals, lists, dicts
+        assert a[1:] == b[1:]
+    assert list(first[3].items()) == list(second[3].items()) and first[8] == second[8]     # i_remap order, joint map
+    # stale: append a rating -> the train file is parsed again and the new pair shows up
+    train = os.path.join(root, 'train.dat')
+    with open(train, 'a') as f:
+        f.write('0\t1\t5\n')
+    os.utime(train, ns=(time.time_ns(), time.time_ns()))
+    third = load_kg_rating_data.load_data(root, ['valid.dat'], ['valid.dat'], 16)
+    assert third[0][1] == first[0][1] + 1
+    monkeypatch.setenv('KTUP_DATA_CACHE', '0')
+    calls.clear()
+    load_kg_rating_data.load_data(root, ['valid.dat'], ['valid.dat'], 16)
+    assert not calls

@@ -46,7 +46,8 @@ int ktup_score_bprmf_bwd(const float* U, int64_t ldu, const float* I, int64_t ld
                          float* gU, float* gI, void* stream);
 
 /* ------------------------------------------------------------------ K2  TransE  transE.py:51-63 */
-int ktup_score_transe_fwd(const float* E, int64_t lde, const float* R, int64_t ldr, int d,
+/* n_rel = rows of R (0 if unknown): large batches with a small relation table take the wave-tile forward.     */
+int ktup_score_transe_fwd(const float* E, int64_t lde, const float* R, int64_t ldr, int64_t n_rel, int d,
                           const int64_t* h, const int64_t* t, const int64_t* r, int64_t n, int l1,
                           float* score, void* stream);
 int ktup_score_transe_bwd(const float* E, int64_t lde, const float* R, int64_t ldr, int d,
@@ -55,8 +56,8 @@ int ktup_score_transe_bwd(const float* E, int64_t lde, const float* R, int64_t l
 
 /* ------------------------------------------- K3  TransH  transH.py:58-71 + utils/misc.py:18-19
  * (also the KG branch of KTUP, jTransUP.py:144-157, on its ent/rel/norm tables)                  */
-/* n_rel = rows of R and Nrm (relation_total); when both tables fit 16 KB they are staged in LDS and only
- * the entity rows are gathered.  Pass 0 if unknown: the relation rows are then gathered per triple.      */
+/* n_rel = rows of R and Nrm (relation_total); small relation tables are staged in LDS and only the entity rows
+ * are gathered (wave-tile kernel for large batches).  Pass 0 if unknown: relation rows are gathered per triple. */
 int ktup_score_transh_fwd(const float* E, int64_t lde, const float* R, int64_t ldr, const float* Nrm, int64_t ldn,
                           int64_t n_rel, int d, const int64_t* h, const int64_t* t, const int64_t* r, int64_t n,
                           int l1, float* score, void* stream);

@@ -7,6 +7,7 @@
 // index_select x3 + ~4-10 elementwise kernels, each materialising a (B x d) temporary.
 // When a pointer or pitch is not 16-B aligned (or d % 4 != 0) the same code runs with 4-byte lanes.
 #include "ktup_rows.h"
+#include "ktup_lane_swap.h"
 #include "ktup_pref_geom.h"
 
 using namespace ktup;
@@ -141,6 +142,116 @@ __global__ __launch_bounds__(256) void transh_fwd_lds_kernel(TranshFwd op, int n
   }
 }
 
+// K3 forward, wave-tile form for large batches: a wave gathers the h and t rows of 16 triples with the linear (row, chunk)
+// lane mapping of pref_fwd_mc (every lane busy, 2 x J float4 loads in flight per lane; the lane-group kernels above keep
+// 25 of 32 lanes busy at d = 100 and 2 loads in flight), puts q = h - t into an LDS tile, and lane (kq, triple) then walks
+// chunks kq, kq + 4, ... of its triple against the LDS-resident relation rows.
+template <int NCH, bool TRANSH>
+__global__ __launch_bounds__(1024) void transh_fwd_tile_kernel(TranshFwd op, int n_rel, int64_t n) {   // TRANSH false: TransE (op.Nm unused)
+  typedef float v4 __attribute__((ext_vector_type(4)));
+  constexpr int J = (16 * NCH + 63) / 64, TOTAL = 16 * NCH, P4 = NCH | 1, NW = 16;
+  constexpr int CPL = (NCH + 3) / 4;                                  // chunks per lane in the compute mapping
+  extern __shared__ __attribute__((aligned(16))) char ktup_transh_tile_smem[];
+  v4* Rs = reinterpret_cast<v4*>(ktup_transh_tile_smem);              // [n_rel][P4]
+  v4* Ws = Rs + n_rel * P4;
+  const int tid = threadIdx.x, lane = tid & 63, kq = lane >> 4, j = lane & 15;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  v4* QT = Ws + n_rel * P4 + w * (16 * P4 + 12);                      // per wave: q = h - t tile [16][P4], ids [3][16]
+  int32_t* sid = reinterpret_cast<int32_t*>(QT + 16 * P4);
+  for (int idx = tid; idx < n_rel * NCH; idx += NW * 64) {
+    const int row = idx / NCH, c = idx - row * NCH;
+    Rs[row * P4 + c] = *reinterpret_cast<const v4*>(op.R + (int64_t)row * op.ldr + 4 * c);
+    if (TRANSH) Ws[row * P4 + c] = *reinterpret_cast<const v4*>(op.Nm + (int64_t)row * op.ldn + 4 * c);
+  }
+  __syncthreads();
+  int grow[J], gc[J];
+#pragma unroll
+  for (int jj = 0; jj < J; ++jj) {
+    const int e = lane + 64 * jj;
+    const bool past = e >= TOTAL;
+    grow[jj] = past ? 0 : e / NCH;
+    gc[jj] = past ? 0 : e % NCH;
+  }
+  const bool last_ok = lane + 64 * (J - 1) < TOTAL;
+  const v4* E4 = reinterpret_cast<const v4*>(op.E);
+  const uint32_t lde4 = (uint32_t)(op.lde >> 2);
+  const int64_t ntiles = (n + 15) / 16;
+  for (int64_t tile = (int64_t)blockIdx.x * NW + w; tile < ntiles; tile += (int64_t)gridDim.x * NW) {
+    const int64_t row0 = tile * 16;
+    if (lane < 16) {
+      const int64_t gr = min(row0 + lane, n - 1);
+      sid[lane] = (int32_t)op.h[gr]; sid[16 + lane] = (int32_t)op.t[gr]; sid[32 + lane] = (int32_t)op.r[gr];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    {
+      v4 hh[J], tt[J];
+#pragma unroll
+      for (int jj = 0; jj < J; ++jj) {
+        asm volatile("" : "+v"(gc[jj]));
+        hh[jj] = E4[(uint64_t)(uint32_t)sid[grow[jj]] * lde4 + (uint32_t)gc[jj]];
+        tt[jj] = E4[(uint64_t)(uint32_t)sid[16 + grow[jj]] * lde4 + (uint32_t)gc[jj]];
+      }
+#pragma unroll
+      for (int jj = 0; jj < J; ++jj) {
+        if (jj < J - 1 || last_ok) QT[grow[jj] * P4 + gc[jj]] = hh[jj] + (-tt[jj]);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // z = (h - (h.w) w) + r - (t - (t.w) w) = q + r - (q.w) w with q = h - t (the projection is linear)
+    const int rr = sid[32 + j];
+    const v4* qrow = QT + j * P4;
+    const v4* wrow = Ws + rr * P4;
+    const v4* rrow = Rs + rr * P4;
+    v4 qv[CPL], wv[CPL];
+    v4 da = (v4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+      const int c = kq + 4 * k;
+      qv[k] = da * 0.f; wv[k] = qv[k];
+      if (c < NCH) { qv[k] = qrow[c]; if (TRANSH) { wv[k] = wrow[c]; da += qv[k] * wv[k]; } }
+    }
+    const float sq = TRANSH ? ktup::allsum_kq((da[0] + da[1]) + (da[2] + da[3])) : 0.f;
+    v4 acc = (v4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+      const int c = kq + 4 * k;
+      if (c < NCH) {
+        const v4 z = TRANSH ? (qv[k] + rrow[c]) - sq * wv[k] : qv[k] + rrow[c];
+        if (op.l1) acc += __builtin_elementwise_abs(z);
+        else acc += z * z;
+      }
+    }
+    const float s = ktup::allsum_kq((acc[0] + acc[1]) + (acc[2] + acc[3]));
+    if (lane < 16 && row0 + lane < n) op.score[row0 + lane] = s;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+
+inline bool tile_forward_applies(int64_t n, int64_t n_rel, int d, int64_t lde) {      // large batches, instantiated sizes
+  return n >= 65536 && n_rel > 0 && (d == 64 || d == 100 || d == 128) && (lde >> 2) <= 0xffffffffll;
+}
+
+// Returns 1 when the relation tables do not fit LDS next to the 16 wave tiles.
+template <bool TRANSH>
+int launch_tile_forward(const TranshFwd& op, int d, int64_t n_rel, int64_t n, hipStream_t st, const char* name) {
+  const int nch = d / 4, p4 = nch | 1;
+  const size_t lds = ((size_t)2 * n_rel * p4 + (size_t)16 * (16 * p4 + 12)) * 16;
+  if (lds > 160 * 1024) return 1;
+  const int grid = grid_for(((n + 15) / 16 + 15) / 16, 256);
+#define KTUP_TILE(NCH)                                                                                                              \
+  {                                                                                                                                 \
+    (void)hipFuncSetAttribute((const void*)transh_fwd_tile_kernel<NCH, TRANSH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL((transh_fwd_tile_kernel<NCH, TRANSH>), dim3(grid), dim3(1024), lds, st, op, (int)n_rel, n);                    \
+  }
+  if (d == 64) KTUP_TILE(16) else if (d == 100) KTUP_TILE(25) else KTUP_TILE(32)
+#undef KTUP_TILE
+  return check_launch(name);
+}
+
 // With q = h - t, s = q.w, a = gz.w :  gh = gz - a w, gt = -gh, gr = gz, gw = -s gz - a q.
 struct TranshBwd {
   const float *E, *R, *Nm; int64_t lde, ldr, ldn; const int64_t *h, *t, *r; bool l1; const float* gs;
@@ -273,14 +384,21 @@ extern "C" int ktup_score_bprmf_bwd(const float* U, int64_t ldu, const float* I,
   return launch_rows(op, d, can_vec4(d, {U, I, gU, gI}, {ldu, ldi}), n, (hipStream_t)stream, "ktup_score_bprmf_bwd");
 }
 
-extern "C" int ktup_score_transe_fwd(const float* E, int64_t lde, const float* R, int64_t ldr, int d, const int64_t* h,
-                                     const int64_t* t, const int64_t* r, int64_t n, int l1, float* score, void* stream) {
+extern "C" int ktup_score_transe_fwd(const float* E, int64_t lde, const float* R, int64_t ldr, int64_t n_rel, int d,
+                                     const int64_t* h, const int64_t* t, const int64_t* r, int64_t n, int l1, float* score,
+                                     void* stream) {
   if (int e = check_common("ktup_score_transe_fwd", d, n)) return e;
   KTUP_NONNULL("ktup_score_transe_fwd", E); KTUP_NONNULL("ktup_score_transe_fwd", R);
   KTUP_NONNULL("ktup_score_transe_fwd", h); KTUP_NONNULL("ktup_score_transe_fwd", t);
   KTUP_NONNULL("ktup_score_transe_fwd", r); KTUP_NONNULL("ktup_score_transe_fwd", score);
   TranseFwd op{E, R, lde, ldr, h, t, r, l1 != 0, score};
-  return launch_rows(op, d, can_vec4(d, {E, R}, {lde, ldr}), n, (hipStream_t)stream, "ktup_score_transe_fwd");
+  const bool v4ok = can_vec4(d, {E, R}, {lde, ldr});
+  if (v4ok && tile_forward_applies(n, n_rel, d, lde)) {
+    const TranshFwd top{E, R, nullptr, lde, ldr, 0, h, t, r, l1 != 0, score};
+    const int rc = launch_tile_forward<false>(top, d, n_rel, n, (hipStream_t)stream, "ktup_score_transe_fwd");
+    if (rc != 1) return rc;
+  }
+  return launch_rows(op, d, v4ok, n, (hipStream_t)stream, "ktup_score_transe_fwd");
 }
 
 extern "C" int ktup_score_transe_bwd(const float* E, int64_t lde, const float* R, int64_t ldr, int d, const int64_t* h,
@@ -305,6 +423,10 @@ extern "C" int ktup_score_transh_fwd(const float* E, int64_t lde, const float* R
   TranshFwd op{E, R, Nrm, lde, ldr, ldn, h, t, r, l1 != 0, score};
   const bool v4ok = can_vec4(d, {E, R, Nrm}, {lde, ldr, ldn});
   const int64_t tab_bytes = 2 * n_rel * (int64_t)d * 4;
+  if (v4ok && tile_forward_applies(n, n_rel, d, lde)) {
+    const int rc = launch_tile_forward<true>(op, d, n_rel, n, (hipStream_t)stream, "ktup_score_transh_fwd");
+    if (rc != 1) return rc;
+  }
   if (n > 0 && v4ok && d <= 256 && n_rel > 0 && tab_bytes <= 16 * 1024 && n >= 4 * n_rel) {   // 8 workgroups per CU keep their tables
     const int nch = d / 4;
     const int G = nch <= 16 ? 16 : nch <= 32 ? 32 : 64;

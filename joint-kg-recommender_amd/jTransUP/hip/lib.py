@@ -25,7 +25,7 @@ SIGNATURES = {
     'ktup_last_error': [],
     'ktup_score_bprmf_fwd': [c_p, c_l, c_p, c_l, c_i, c_p, c_p, c_l, c_p, c_p],
     'ktup_score_bprmf_bwd': [c_p, c_l, c_p, c_l, c_i, c_p, c_p, c_l, c_p, c_p, c_p, c_p],
-    'ktup_score_transe_fwd': [c_p, c_l, c_p, c_l, c_i, c_p, c_p, c_p, c_l, c_i, c_p, c_p],
+    'ktup_score_transe_fwd': [c_p, c_l, c_p, c_l, c_l, c_i, c_p, c_p, c_p, c_l, c_i, c_p, c_p],
     'ktup_score_transe_bwd': [c_p, c_l, c_p, c_l, c_i, c_p, c_p, c_p, c_l, c_i, c_p, c_p, c_p, c_p],
     'ktup_score_transh_fwd': [c_p, c_l, c_p, c_l, c_p, c_l, c_l, c_i, c_p, c_p, c_p, c_l, c_i, c_p, c_p],
     'ktup_score_transh_bwd': [c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_p, c_p, c_p, c_l, c_i, c_p, c_p, c_p, c_p, c_p],

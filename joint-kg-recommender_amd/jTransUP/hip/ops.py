@@ -84,7 +84,7 @@ class _ScoreTransE(Function):
         dev = _dev(_table('entity table', E)); _table('relation table', R)
         n = h.numel(); h = _ids('h', h, dev); t = _ids('t', t, dev, n); r = _ids('r', r, dev, n)
         score = torch.empty(n, dtype=torch.float32, device=dev)
-        L.call('ktup_score_transe_fwd', _p(E), E.stride(0), _p(R), R.stride(0), E.shape[1], _p(h), _p(t), _p(r), n, int(l1),
+        L.call('ktup_score_transe_fwd', _p(E), E.stride(0), _p(R), R.stride(0), R.shape[0], E.shape[1], _p(h), _p(t), _p(r), n, int(l1),
                _p(score), _stream(dev))
         ctx.save_for_backward(E, R, h, t, r); ctx.l1 = int(l1)
         return score

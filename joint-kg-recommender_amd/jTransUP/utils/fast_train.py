@@ -359,7 +359,7 @@ class KGStepper(_StepperBase):
             calls.append(b('ktup_score_transh_fwd', _p(E), E.stride(0), _p(R), R.stride(0), _p(Rn), Rn.stride(0), n_rel, d, _p(self.h2),
                            _p(self.t2), _p(self.r2), 2 * B, self.l1, _p(self.score), st))
         else:
-            calls.append(b('ktup_score_transe_fwd', _p(E), E.stride(0), _p(R), R.stride(0), d, _p(self.h2), _p(self.t2), _p(self.r2),
+            calls.append(b('ktup_score_transe_fwd', _p(E), E.stride(0), _p(R), R.stride(0), R.shape[0], d, _p(self.h2), _p(self.t2), _p(self.r2),
                            2 * B, self.l1, _p(self.score), st))
         calls += [b('ktup_loss_margin_fwd', _p(pos), _p(neg), B, self.margin, _p(self.loss[0:]), st),
                   b('ktup_loss_margin_bwd', _p(pos), _p(neg), B, self.margin, _p(self.one), _p(gpos), _p(gneg), st)]

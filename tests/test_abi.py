@@ -48,7 +48,7 @@ def test_binding_table_matches_header(lib):
 def test_invalid_argument_is_reported_not_swallowed(lib):
     # argument validation happens on the host before any launch, so this is safe without a GPU
     with pytest.raises(lib.KtupError) as e:
-        lib.call('ktup_score_transe_fwd', None, 100, None, 100, -3, None, None, None, 5, 0, None, None)
+        lib.call('ktup_score_transe_fwd', None, 100, None, 100, 20, -3, None, None, None, 5, 0, None, None)
     assert 'embedding_size' in str(e.value)
     assert lib.load().ktup_pref_workspace_bytes(100, 20) > 0
     assert lib.load().ktup_pref_workspace_bytes(50, 20) == 0       # d % 4 != 0 is unsupported by the tile kernels

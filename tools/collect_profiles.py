@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TAG = sys.argv[1] if len(sys.argv) > 1 else 'r01'
 OUT = os.path.join(ROOT, 'gpurun_out', 'profiles')
 BENCH = ['python', os.path.join(ROOT, 'bench.py'), '--no-extras']
-KERNELS = {'ktup_rec_forward': 'pref_fwd_mc_kernel', 'ktup_kg_forward': 'transh_fwd_lds_kernel'}
+KERNELS = {'ktup_rec_forward': 'pref_fwd_mc_kernel', 'ktup_kg_forward': 'transh_fwd_tile_kernel'}
 
 
 def rocprof(name, flags, bench_args):

@@ -231,6 +231,75 @@ __global__ __launch_bounds__(1024) void transh_fwd_tile_kernel(TranshFwd op, int
 }
 
 
+// K1 forward, wave-tile form for large batches (same reasoning as transh_fwd_tile_kernel): the u (.) i products of 16 pairs go
+// through an LDS tile and are row-summed by lane (kq, pair).
+template <int NCH>
+__global__ __launch_bounds__(1024) void bprmf_fwd_tile_kernel(BprmfFwd op, int64_t n) {
+  typedef float v4 __attribute__((ext_vector_type(4)));
+  constexpr int J = (16 * NCH + 63) / 64, TOTAL = 16 * NCH, P4 = NCH | 1, NW = 16, CPL = (NCH + 3) / 4;
+  extern __shared__ __attribute__((aligned(16))) char ktup_bprmf_tile_smem[];
+  const int tid = threadIdx.x, lane = tid & 63, kq = lane >> 4, j = lane & 15;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  v4* PT = reinterpret_cast<v4*>(ktup_bprmf_tile_smem) + w * (16 * P4 + 8);
+  int32_t* sid = reinterpret_cast<int32_t*>(PT + 16 * P4);            // [2][16]
+  int grow[J], gc[J];
+#pragma unroll
+  for (int jj = 0; jj < J; ++jj) {
+    const int e = lane + 64 * jj;
+    const bool past = e >= TOTAL;
+    grow[jj] = past ? 0 : e / NCH;
+    gc[jj] = past ? 0 : e % NCH;
+  }
+  const bool last_ok = lane + 64 * (J - 1) < TOTAL;
+  const v4* U4 = reinterpret_cast<const v4*>(op.U);
+  const v4* I4 = reinterpret_cast<const v4*>(op.I);
+  const uint32_t ldu4 = (uint32_t)(op.ldu >> 2), ldi4 = (uint32_t)(op.ldi >> 2);
+  const int64_t ntiles = (n + 15) / 16;
+  for (int64_t tile = (int64_t)blockIdx.x * NW + w; tile < ntiles; tile += (int64_t)gridDim.x * NW) {
+    const int64_t row0 = tile * 16;
+    if (lane < 16) {
+      const int64_t gr = min(row0 + lane, n - 1);
+      sid[lane] = (int32_t)op.u[gr]; sid[16 + lane] = (int32_t)op.i[gr];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    {
+      v4 uu[J], ii[J];
+#pragma unroll
+      for (int jj = 0; jj < J; ++jj) {
+        asm volatile("" : "+v"(gc[jj]));
+        uu[jj] = U4[(uint64_t)(uint32_t)sid[grow[jj]] * ldu4 + (uint32_t)gc[jj]];
+        ii[jj] = I4[(uint64_t)(uint32_t)sid[16 + grow[jj]] * ldi4 + (uint32_t)gc[jj]];
+      }
+#pragma unroll
+      for (int jj = 0; jj < J; ++jj) {
+        if (jj < J - 1 || last_ok) PT[grow[jj] * P4 + gc[jj]] = uu[jj] * ii[jj];
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    v4 acc = (v4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+      const int c = kq + 4 * k;
+      if (c < NCH) acc += PT[j * P4 + c];
+    }
+    const float s = ktup::allsum_kq((acc[0] + acc[1]) + (acc[2] + acc[3]));
+    if (lane < 16 && row0 + lane < n) op.score[row0 + lane] = s;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+template <int NCH>
+int launch_bprmf_tile(const BprmfFwd& op, int64_t n, hipStream_t st) {
+  const size_t lds = (size_t)16 * (16 * (NCH | 1) + 8) * 16;
+  (void)hipFuncSetAttribute((const void*)bprmf_fwd_tile_kernel<NCH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(bprmf_fwd_tile_kernel<NCH>, dim3(grid_for(((n + 15) / 16 + 15) / 16, 256)), dim3(1024), lds, st, op, n);
+  return check_launch("ktup_score_bprmf_fwd");
+}
+
+
 inline bool tile_forward_applies(int64_t n, int64_t n_rel, int d, int64_t lde) {      // large batches, instantiated sizes
   return n >= 65536 && n_rel > 0 && (d == 64 || d == 100 || d == 128) && (lde >> 2) <= 0xffffffffll;
 }
@@ -370,7 +439,13 @@ extern "C" int ktup_score_bprmf_fwd(const float* U, int64_t ldu, const float* I,
   KTUP_NONNULL("ktup_score_bprmf_fwd", u_ids); KTUP_NONNULL("ktup_score_bprmf_fwd", i_ids);
   KTUP_NONNULL("ktup_score_bprmf_fwd", score);
   BprmfFwd op{U, I, ldu, ldi, u_ids, i_ids, score};
-  return launch_rows(op, d, can_vec4(d, {U, I}, {ldu, ldi}), n, (hipStream_t)stream, "ktup_score_bprmf_fwd");
+  const bool v4ok = can_vec4(d, {U, I}, {ldu, ldi});
+  if (v4ok && n >= 65536 && (ldu >> 2) <= 0xffffffffll && (ldi >> 2) <= 0xffffffffll) {      // large batches: wave tiles
+    if (d == 64) return launch_bprmf_tile<16>(op, n, (hipStream_t)stream);
+    if (d == 100) return launch_bprmf_tile<25>(op, n, (hipStream_t)stream);
+    if (d == 128) return launch_bprmf_tile<32>(op, n, (hipStream_t)stream);
+  }
+  return launch_rows(op, d, v4ok, n, (hipStream_t)stream, "ktup_score_bprmf_fwd");
 }
 
 extern "C" int ktup_score_bprmf_bwd(const float* U, int64_t ldu, const float* I, int64_t ldi, int d, const int64_t* u_ids,

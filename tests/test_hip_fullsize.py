@@ -77,3 +77,23 @@ def test_filtered_topk_properties_at_full_catalogue(world):
     # reference order: ascending score, ties to the lower id
     order = torch.argsort(masked, dim=1, stable=True)[:, :10]
     assert torch.equal(top.long(), order)
+
+
+@pytest.mark.parametrize('d', [64, 100, 128])
+def test_large_batch_tile_kernels_vs_oracle(d):
+    """Batches >= 65,536 rows take the wave-tile forward kernels of K1-K3; 70,001 rows (ragged last tile) vs the oracle."""
+    from oracle import cpu_ref as O
+    gen = torch.Generator().manual_seed(d)
+    n, NU, NI, NE, NR = 70001, 3000, 2000, 5000, 20
+    U, I, E = O.make_table(NU, d, gen), O.make_table(NI, d, gen), O.make_table(NE, d, gen)
+    R, Rn = O.make_table(NR, d, gen), O.make_table(NR, d, gen)
+    u, i = torch.randint(0, NU, (n,), generator=gen), torch.randint(0, NI, (n,), generator=gen)
+    h, t, r = torch.randint(0, NE, (n,), generator=gen), torch.randint(0, NE, (n,), generator=gen), torch.randint(0, NR, (n,), generator=gen)
+    dv = lambda x: x.to(DEV)
+    with torch.no_grad():
+        torch.testing.assert_close(ops().score_bprmf(dv(U), dv(I), dv(u), dv(i)).cpu(), O.score_bprmf(U, I, u, i), rtol=1e-4, atol=1e-5)
+        for l1 in (False, True):
+            torch.testing.assert_close(ops().score_transe(dv(E), dv(R), dv(h), dv(t), dv(r), l1).cpu(), O.score_transe(E, R, h, t, r, l1),
+                                       rtol=1e-4, atol=1e-5)
+            torch.testing.assert_close(ops().score_transh(dv(E), dv(R), dv(Rn), dv(h), dv(t), dv(r), l1).cpu(),
+                                       O.score_transh(E, R, Rn, h, t, r, l1), rtol=1e-4, atol=1e-5)

@@ -137,6 +137,18 @@ int ktup_reg_orth_fwd(const float* Rel, int64_t ldr, const float* Nrm, int64_t l
 int ktup_reg_orth_bwd(const float* Rel, int64_t ldr, const float* Nrm, int64_t ldn, int d, const int64_t* ids,
                       int64_t n, const float* gloss, float* gRel, float* gNrm, void* stream);
 
+/* Value + gradient in one launch (the GPU-resident training step issues these): same arithmetic as the _fwd / _bwd pairs
+ * above, but the loss VALUE is added to *loss_acc instead of overwriting it -- the caller zeroes its loss slots once per
+ * step -- and the gradients are produced in the same pass.                                                        */
+int ktup_loss_bpr_fused(const float* pos, const float* neg, int64_t n, float target, const float* gloss, float* loss_acc,
+                        float* gpos, float* gneg, void* stream);
+int ktup_loss_margin_fused(const float* pos, const float* neg, int64_t n, float margin, const float* gloss, float* loss_acc,
+                           float* gpos, float* gneg, void* stream);
+int ktup_reg_norm_fused(const float* T, int64_t ld, int d, const int64_t* ids, int64_t n, const float* gloss, float* loss_acc,
+                        float* gT, void* stream);
+int ktup_reg_orth_fused(const float* Rel, int64_t ldr, const float* Nrm, int64_t ldn, int d, const int64_t* ids, int64_t n,
+                        const float* gloss, float* loss_acc, float* gRel, float* gNrm, void* stream);
+
 /* ------------------------------------------- K11-K16  all-candidate scores for evaluation
  * Every function writes the full (nq x n_cand) fp32 score matrix `out` (pitch ldo), which keeps the
  * reference's evaluate / evaluateRec / evaluateHead / evaluateTail drop-in; `ws` is caller scratch of the

@@ -40,6 +40,26 @@ __global__ __launch_bounds__(256) void pair_loss_bwd_kernel(const float* __restr
   }
 }
 
+// value + gradient in one pass (the GPU-resident training step): the loss is ADDED to *loss_acc, which the caller zeroes once
+// per step for all its loss terms
+template <bool MARGIN>
+__global__ __launch_bounds__(256) void pair_loss_fused_kernel(const float* __restrict__ pos, const float* __restrict__ neg,
+                                                              int64_t n, float param, float scale, const float* __restrict__ gloss,
+                                                              float* __restrict__ loss_acc, float* __restrict__ gpos,
+                                                              float* __restrict__ gneg) {
+  const float g = gloss[0] * scale;
+  float part = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float diff = pos[i] - neg[i];
+    part += MARGIN ? fmaxf(diff + param, 0.f) : neg_logsigmoid(param * diff);
+    const float gd = MARGIN ? (diff + param > 0.f ? g : 0.f) : -g * param * sigmoidf(-param * diff);
+    gpos[i] = gd;
+    gneg[i] = -gd;
+  }
+  part = block_sum_256(part);
+  if (threadIdx.x == 0) atomicAdd(loss_acc, part * scale);
+}
+
 struct NormFwd {  // loss.py:21-23  sum_rows max(|x|^2 - 1, 0)
   const float* T; int64_t ld; const int64_t* ids;
   template <typename V, int G, int CPL>
@@ -113,6 +133,53 @@ struct OrthBwd {  // d/dw = (2a/b) r ;  d/dr = (2a/b) w - (2a^2/b^2) r   with a 
   }
 };
 
+struct NormFused {   // NormFwd value + NormBwd scatter
+  const float* T; int64_t ld; const int64_t* ids; const float* gloss; float* gT;
+  template <typename V, int G, int CPL>
+  KTUP_DEV float run(const RowCtx<V, G, CPL>& cx, int64_t row) const {
+    const int64_t r = ids ? ids[row] : row;
+    V x[CPL];
+    cx.load(x, T + r * ld);
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) s += vdot(x[j], x[j]);
+    s = group_sum<G>(s);
+    if (s - 1.f > 0.f) {
+      const float g = 2.f * gloss[0];
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) x[j] = vscale(g, x[j]);
+      cx.scatter_add(gT + r * ld, x);
+    }
+    return fmaxf(s - 1.f, 0.f);
+  }
+};
+
+struct OrthFused {   // OrthFwd value + OrthBwd scatter
+  const float *R, *W; int64_t ldr, ldw; const int64_t* ids; const float* gloss; float *gR, *gW;
+  template <typename V, int G, int CPL>
+  KTUP_DEV float run(const RowCtx<V, G, CPL>& cx, int64_t row) const {
+    const int64_t r = ids ? ids[row] : row;
+    V a[CPL], w[CPL];
+    cx.load(a, R + r * ldr);
+    cx.load(w, W + r * ldw);
+    float dot = 0.f, nr = 0.f;
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) { dot += vdot(a[j], w[j]); nr += vdot(a[j], a[j]); }
+    dot = group_sum<G>(dot);
+    nr = group_sum<G>(nr);
+    const float g = gloss[0], c1 = g * 2.f * dot / nr, c2 = g * 2.f * dot * dot / (nr * nr);
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+      const V gw = vscale(c1, a[j]);
+      a[j] = vfma(-c2, a[j], vscale(c1, w[j]));
+      w[j] = gw;
+    }
+    cx.scatter_add(gR + r * ldr, a);
+    cx.scatter_add(gW + r * ldw, w);
+    return dot * dot / nr;
+  }
+};
+
 template <bool MARGIN>
 int pair_loss(bool bwd, const char* name, const float* pos, const float* neg, int64_t n, float param, bool mean,
               float* loss, const float* gloss, float* gpos, float* gneg, void* stream) {
@@ -174,4 +241,38 @@ extern "C" int ktup_reg_orth_bwd(const float* Rel, int64_t ldr, const float* Nrm
   KTUP_REQUIRE(d > 0 && n >= 0 && ((Rel && Nrm && gloss && gRel && gNrm) || n == 0), "ktup_reg_orth_bwd: bad argument");
   OrthBwd op{Rel, Nrm, ldr, ldn, ids, gloss, gRel, gNrm};
   return launch_rows(op, d, can_vec4(d, {Rel, Nrm, gRel, gNrm}, {ldr, ldn}), n, (hipStream_t)stream, "ktup_reg_orth_bwd");
+}
+
+// ---- value + gradient in one launch each; `loss_acc` is accumulated into (zero it once per step)
+template <bool MARGIN>
+static int pair_loss_fused(const char* name, const float* pos, const float* neg, int64_t n, float param, bool mean,
+                           const float* gloss, float* loss_acc, float* gpos, float* gneg, void* stream) {
+  KTUP_REQUIRE(n >= 0, "%s: negative length", name);
+  if (n == 0) return KTUP_OK;
+  KTUP_REQUIRE(pos && neg && gloss && loss_acc && gpos && gneg, "%s: null pointer argument", name);
+  const float scale = mean ? 1.f / (float)n : 1.f;
+  hipLaunchKernelGGL(pair_loss_fused_kernel<MARGIN>, dim3(grid_for((n + 1023) / 1024, 64)), dim3(256), 0, (hipStream_t)stream, pos,
+                     neg, n, param, scale, gloss, loss_acc, gpos, gneg);
+  return check_launch(name);
+}
+extern "C" int ktup_loss_bpr_fused(const float* pos, const float* neg, int64_t n, float target, const float* gloss, float* loss_acc,
+                                   float* gpos, float* gneg, void* stream) {
+  return pair_loss_fused<false>("ktup_loss_bpr_fused", pos, neg, n, target, true, gloss, loss_acc, gpos, gneg, stream);
+}
+extern "C" int ktup_loss_margin_fused(const float* pos, const float* neg, int64_t n, float margin, const float* gloss,
+                                      float* loss_acc, float* gpos, float* gneg, void* stream) {
+  return pair_loss_fused<true>("ktup_loss_margin_fused", pos, neg, n, margin, false, gloss, loss_acc, gpos, gneg, stream);
+}
+extern "C" int ktup_reg_norm_fused(const float* T, int64_t ld, int d, const int64_t* ids, int64_t n, const float* gloss,
+                                   float* loss_acc, float* gT, void* stream) {
+  KTUP_REQUIRE(d > 0 && n >= 0 && ((T && gloss && loss_acc && gT) || n == 0), "ktup_reg_norm_fused: bad argument");
+  NormFused op{T, ld, ids, gloss, gT};
+  return launch_rows_reduce(op, d, can_vec4(d, {T, gT}, {ld}), n, loss_acc, (hipStream_t)stream, "ktup_reg_norm_fused", false);
+}
+extern "C" int ktup_reg_orth_fused(const float* Rel, int64_t ldr, const float* Nrm, int64_t ldn, int d, const int64_t* ids,
+                                   int64_t n, const float* gloss, float* loss_acc, float* gRel, float* gNrm, void* stream) {
+  KTUP_REQUIRE(d > 0 && n >= 0 && ((Rel && Nrm && gloss && loss_acc && gRel && gNrm) || n == 0), "ktup_reg_orth_fused: bad argument");
+  OrthFused op{Rel, Nrm, ldr, ldn, ids, gloss, gRel, gNrm};
+  return launch_rows_reduce(op, d, can_vec4(d, {Rel, Nrm, gRel, gNrm}, {ldr, ldn}), n, loss_acc, (hipStream_t)stream,
+                            "ktup_reg_orth_fused", false);
 }

@@ -120,8 +120,8 @@ __global__ __launch_bounds__(256) void row_reduce_kernel(Op op, int nch, int64_t
 }
 
 template <typename Op>
-int launch_rows_reduce(const Op& op, int d, bool vec4, int64_t n, float* out, hipStream_t st, const char* name) {
-  if (hipMemsetAsync(out, 0, sizeof(float), st) != hipSuccess) return check_launch(name);
+int launch_rows_reduce(const Op& op, int d, bool vec4, int64_t n, float* out, hipStream_t st, const char* name, bool zero_first = true) {
+  if (zero_first && hipMemsetAsync(out, 0, sizeof(float), st) != hipSuccess) return check_launch(name);
   if (n == 0) return KTUP_OK;
   const int nch = vec4 ? d / 4 : d;
 #define KTUP_L(V, G, CPL)                                                                                   \

@@ -43,6 +43,10 @@ SIGNATURES = {
     'ktup_loss_bpr_bwd': [c_p, c_p, c_l, c_f, c_p, c_p, c_p, c_p],
     'ktup_loss_margin_fwd': [c_p, c_p, c_l, c_f, c_p, c_p],
     'ktup_loss_margin_bwd': [c_p, c_p, c_l, c_f, c_p, c_p, c_p, c_p],
+    'ktup_loss_bpr_fused': [c_p, c_p, c_l, c_f, c_p, c_p, c_p, c_p, c_p],
+    'ktup_loss_margin_fused': [c_p, c_p, c_l, c_f, c_p, c_p, c_p, c_p, c_p],
+    'ktup_reg_norm_fused': [c_p, c_l, c_i, c_p, c_l, c_p, c_p, c_p, c_p],
+    'ktup_reg_orth_fused': [c_p, c_l, c_p, c_l, c_i, c_p, c_l, c_p, c_p, c_p, c_p, c_p],
     'ktup_reg_norm_fwd': [c_p, c_l, c_i, c_p, c_l, c_p, c_p],
     'ktup_reg_norm_bwd': [c_p, c_l, c_i, c_p, c_l, c_p, c_p, c_p],
     'ktup_reg_orth_fwd': [c_p, c_l, c_p, c_l, c_i, c_p, c_l, c_p, c_p],

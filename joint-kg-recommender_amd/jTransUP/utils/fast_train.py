@@ -176,29 +176,26 @@ class JointStepper(_StepperBase):
         self._rec_soft = [            # soft gate only: the Gumbel stream advances per step and is marshalled per call
             b('ktup_score_ktup_fwd', _p(U), U.stride(0), _p(I), I.stride(0), _p(E), E.stride(0), _p(self.i2e), _p(self.ws), n_pref, d,
               _p(self.u2), _p(self.i2), 2 * B, self.l1, off, None, 0, 0, _p(self.score), st)]
+        # value + gradient in one launch; the loss slots are zeroed once at the top of a step and accumulated into
         self._rec_loss = [
-            b('ktup_loss_bpr_fwd', _p(pos), _p(neg), B, self.target, _p(self.loss[0:]), st),
-            b('ktup_loss_bpr_bwd', _p(pos), _p(neg), B, self.target, _p(self.inv_world), _p(gpos), _p(gneg), st)]
+            b('ktup_loss_bpr_fused', _p(pos), _p(neg), B, self.target, _p(self.inv_world), _p(self.loss[0:]), _p(gpos), _p(gneg), st)]
         self._rec_soft_bwd = [
             b('ktup_score_ktup_bwd', _p(U), U.stride(0), _p(I), I.stride(0), _p(E), E.stride(0), _p(self.i2e), self.ent_pad,
               _p(self.ws), n_pref, d, _p(self.u2), _p(self.i2), 2 * B, self.l1, off, None, 0, 0,
               _p(self.gscore), _p(U.grad), _p(I.grad), _p(E.grad), _p(self.gAC[0]), _p(self.gAC[1]), st)]
         self._rec_tail = [
-            b('ktup_reg_orth_fwd', _p(P), P.stride(0), _p(Pn), Pn.stride(0), d, None, n_pref, _p(self.loss[1:]), st),
-            b('ktup_reg_orth_bwd', _p(P), P.stride(0), _p(Pn), Pn.stride(0), d, None, n_pref, _p(self.inv_world), _p(P.grad), _p(Pn.grad), st)]
+            b('ktup_reg_orth_fused', _p(P), P.stride(0), _p(Pn), Pn.stride(0), d, None, n_pref, _p(self.inv_world), _p(self.loss[1:]),
+              _p(P.grad), _p(Pn.grad), st)]
         self._kg = [
             b('ktup_score_transh_fwd', _p(E), E.stride(0), _p(R), R.stride(0), _p(Rn), Rn.stride(0), n_rel, d, _p(self.h2),
               _p(self.t2), _p(self.r2), 2 * B, self.l1, _p(self.score), st),
-            b('ktup_loss_margin_fwd', _p(pos), _p(neg), B, self.margin, _p(self.loss[0:]), st),
-            b('ktup_loss_margin_bwd', _p(pos), _p(neg), B, self.margin, _p(self.lam), _p(gpos), _p(gneg), st),
+            b('ktup_loss_margin_fused', _p(pos), _p(neg), B, self.margin, _p(self.lam), _p(self.loss[0:]), _p(gpos), _p(gneg), st),
             b('ktup_score_transh_bwd', _p(E), E.stride(0), _p(R), R.stride(0), _p(Rn), Rn.stride(0), d, _p(self.h2), _p(self.t2),
               _p(self.r2), 2 * B, self.l1, _p(self.gscore), _p(E.grad), _p(R.grad), _p(Rn.grad), st),
-            b('ktup_reg_orth_fwd', _p(R), R.stride(0), _p(Rn), Rn.stride(0), d, _p(self.r2), 2 * B, _p(self.loss[1:]), st),
-            b('ktup_reg_orth_bwd', _p(R), R.stride(0), _p(Rn), Rn.stride(0), d, _p(self.r2), 2 * B, _p(self.lam), _p(R.grad), _p(Rn.grad), st),
-            b('ktup_reg_norm_fwd', _p(E), E.stride(0), d, _p(self.ht4), 4 * B, _p(self.loss[2:]), st),
-            b('ktup_reg_norm_bwd', _p(E), E.stride(0), d, _p(self.ht4), 4 * B, _p(self.lam), _p(E.grad), st),
-            b('ktup_reg_norm_fwd', _p(R), R.stride(0), d, _p(self.r2), 2 * B, _p(self.loss[3:]), st),
-            b('ktup_reg_norm_bwd', _p(R), R.stride(0), d, _p(self.r2), 2 * B, _p(self.lam), _p(R.grad), st)]
+            b('ktup_reg_orth_fused', _p(R), R.stride(0), _p(Rn), Rn.stride(0), d, _p(self.r2), 2 * B, _p(self.lam), _p(self.loss[1:]),
+              _p(R.grad), _p(Rn.grad), st),
+            b('ktup_reg_norm_fused', _p(E), E.stride(0), d, _p(self.ht4), 4 * B, _p(self.lam), _p(self.loss[2:]), _p(E.grad), st),
+            b('ktup_reg_norm_fused', _p(R), R.stride(0), d, _p(self.r2), 2 * B, _p(self.lam), _p(self.loss[3:]), _p(R.grad), st)]
 
     # ------------------------------------------------------------------------------------------------ rec
     def _rec_eager(self, u, pi, ni):
@@ -208,24 +205,24 @@ class JointStepper(_StepperBase):
         if u is not None:
             self._pack('rec', (u, pi, ni))
         self._rec_head[0]()
-        self.gAC.zero_()
+        self.gAC.zero_(); self.loss.zero_()
         if not m.use_st_gumbel:
-            self._rec_soft[0](); self._rec_loss[0](); self._rec_loss[1](); self._rec_soft_bwd[0]()
+            self._rec_soft[0](); self._rec_loss[0](); self._rec_soft_bwd[0]()
         else:
             n_pref, d = P.shape
             st = self._stream
             mode, uni, seed, off = m._gumbel.mode_and_stream(True, None, 2 * B * n_pref)
             L.call('ktup_score_ktup_fwd', _p(U), U.stride(0), _p(I), I.stride(0), _p(E), E.stride(0), _p(self.i2e), _p(self.ws), n_pref,
                    d, _p(self.u2), _p(self.i2), 2 * B, self.l1, int(mode), _p(uni), int(seed), int(off), _p(self.score), st)
-            self._rec_loss[0](); self._rec_loss[1]()
+            self._rec_loss[0]()
             L.call('ktup_score_ktup_bwd', _p(U), U.stride(0), _p(I), I.stride(0), _p(E), E.stride(0), _p(self.i2e), self.ent_pad,
                    _p(self.ws), n_pref, d, _p(self.u2), _p(self.i2), 2 * B, self.l1, int(mode), _p(uni), int(seed), int(off),
                    _p(self.gscore), _p(U.grad), _p(I.grad), _p(E.grad), _p(self.gAC[0]), _p(self.gAC[1]), st)
         # A = pref + rel and C = pref_norm + norm: the mixed-table gradient goes to both summands
         torch._foreach_add_([P.grad, R.grad, Pn.grad, Rn.grad], [self.gAC[0], self.gAC[0], self.gAC[1], self.gAC[1]])
-        self._rec_tail[0](); self._rec_tail[1]()
+        self._rec_tail[0]()
         if self.world > 1:
-            self.loss[:2].mul_(self.inv_world); self.loss[2:].zero_()
+            self.loss[:2].mul_(self.inv_world)
         self._optimizer_launches()
         return self.loss[0] + self.loss[1]
 
@@ -234,6 +231,7 @@ class JointStepper(_StepperBase):
         self._plans()
         if ph is not None:
             self._pack('kg', (ph, pt, pr, nh, nt, nr))
+        self.loss.zero_()
         for launch in self._kg:
             launch()
         self._optimizer_launches()
@@ -271,8 +269,8 @@ class RecStepper(_StepperBase):
         U, I = self.tabs[0], self.tabs[1]
         d = U.shape[1]
         pos, neg, gpos, gneg = self.score[:B], self.score[B:], self.gscore[:B], self.gscore[B:]
-        self._loss = [b('ktup_loss_bpr_fwd', _p(pos), _p(neg), B, self.target, _p(self.loss[0:]), st),
-                      b('ktup_loss_bpr_bwd', _p(pos), _p(neg), B, self.target, _p(self.inv_world), _p(gpos), _p(gneg), st)]
+        self._loss = [b('ktup_loss_bpr_fused', _p(pos), _p(neg), B, self.target, _p(self.inv_world), _p(self.loss[0:]), _p(gpos),
+                        _p(gneg), st)]
         if not self.tup:
             self._fwd = b('ktup_score_bprmf_fwd', _p(U), U.stride(0), _p(I), I.stride(0), d, _p(self.u2), _p(self.i2), 2 * B,
                           _p(self.score), st)
@@ -287,37 +285,35 @@ class RecStepper(_StepperBase):
         self._bwd = b('ktup_score_tup_bwd', _p(U), U.stride(0), _p(I), I.stride(0), _p(self.ws), n_pref, d, _p(self.u2), _p(self.i2),
                       2 * B, self.l1, off, None, 0, 0, _p(self.gscore), _p(U.grad), _p(I.grad), _p(self.gAC[0]), _p(self.gAC[1]), st)
         self._regs = [
-            b('ktup_reg_orth_fwd', _p(P), P.stride(0), _p(Pn), Pn.stride(0), d, None, n_pref, _p(self.loss[1:]), st),
-            b('ktup_reg_orth_bwd', _p(P), P.stride(0), _p(Pn), Pn.stride(0), d, None, n_pref, _p(self.inv_world), _p(P.grad), _p(Pn.grad), st),
-            b('ktup_reg_norm_fwd', _p(U), U.stride(0), d, _p(self.u2), B, _p(self.loss[2:]), st),          # the step's users once
-            b('ktup_reg_norm_bwd', _p(U), U.stride(0), d, _p(self.u2), B, _p(self.one), _p(U.grad), st),
-            b('ktup_reg_norm_fwd', _p(I), I.stride(0), d, _p(self.i2), 2 * B, _p(self.loss[3:]), st),      # positive and negative items
-            b('ktup_reg_norm_bwd', _p(I), I.stride(0), d, _p(self.i2), 2 * B, _p(self.one), _p(I.grad), st),
-            b('ktup_reg_norm_fwd', _p(P), P.stride(0), d, None, n_pref, _p(self.loss[4:]), st),
-            b('ktup_reg_norm_bwd', _p(P), P.stride(0), d, None, n_pref, _p(self.inv_world), _p(P.grad), st)]
+            b('ktup_reg_orth_fused', _p(P), P.stride(0), _p(Pn), Pn.stride(0), d, None, n_pref, _p(self.inv_world), _p(self.loss[1:]),
+              _p(P.grad), _p(Pn.grad), st),
+            b('ktup_reg_norm_fused', _p(U), U.stride(0), d, _p(self.u2), B, _p(self.one), _p(self.loss[2:]), _p(U.grad), st),      # the step's users once
+            b('ktup_reg_norm_fused', _p(I), I.stride(0), d, _p(self.i2), 2 * B, _p(self.one), _p(self.loss[3:]), _p(I.grad), st),  # pos and neg items
+            b('ktup_reg_norm_fused', _p(P), P.stride(0), d, None, n_pref, _p(self.inv_world), _p(self.loss[4:]), _p(P.grad), st)]
 
     def _rec_eager(self, u, pi, ni):
         m, B = self.m, self.B
         self._plans()
         if u is not None:
             self._pack('rec', (u, pi, ni))
+        self.loss.zero_()
         if not self.tup:
-            self._fwd(); self._loss[0](); self._loss[1](); self._bwd()
+            self._fwd(); self._loss[0](); self._bwd()
             if self.world > 1:
-                self.loss[:1].mul_(self.inv_world); self.loss[1:].zero_()
+                self.loss[:1].mul_(self.inv_world)
             self._optimizer_launches()
             return self.loss[0] + 0.0
         U, I, P, Pn = self.tabs
         self._prep()
         self.gAC.zero_()
         if not m.use_st_gumbel:
-            self._fwd(); self._loss[0](); self._loss[1](); self._bwd()
+            self._fwd(); self._loss[0](); self._bwd()
         else:
             n_pref, d, st = P.shape[0], P.shape[1], self._stream
             mode, uni, seed, off = m._gumbel.mode_and_stream(True, None, 2 * B * n_pref)
             L.call('ktup_score_tup_fwd', _p(U), U.stride(0), _p(I), I.stride(0), _p(self.ws), n_pref, d, _p(self.u2), _p(self.i2), 2 * B,
                    self.l1, int(mode), _p(uni), int(seed), int(off), _p(self.score), st)
-            self._loss[0](); self._loss[1]()
+            self._loss[0]()
             L.call('ktup_score_tup_bwd', _p(U), U.stride(0), _p(I), I.stride(0), _p(self.ws), n_pref, d, _p(self.u2), _p(self.i2), 2 * B,
                    self.l1, int(mode), _p(uni), int(seed), int(off), _p(self.gscore), _p(U.grad), _p(I.grad), _p(self.gAC[0]),
                    _p(self.gAC[1]), st)
@@ -325,7 +321,7 @@ class RecStepper(_StepperBase):
         for launch in self._regs:
             launch()
         if self.world > 1:       # batch mean and whole-table terms by 1/G, batch sums as they are
-            self.loss[:2].mul_(self.inv_world); self.loss[4:5].mul_(self.inv_world); self.loss[5:].zero_()
+            self.loss[:2].mul_(self.inv_world); self.loss[4:5].mul_(self.inv_world)
         self._optimizer_launches()
         return self.loss[:5].sum()
 
@@ -361,27 +357,24 @@ class KGStepper(_StepperBase):
         else:
             calls.append(b('ktup_score_transe_fwd', _p(E), E.stride(0), _p(R), R.stride(0), R.shape[0], d, _p(self.h2), _p(self.t2), _p(self.r2),
                            2 * B, self.l1, _p(self.score), st))
-        calls += [b('ktup_loss_margin_fwd', _p(pos), _p(neg), B, self.margin, _p(self.loss[0:]), st),
-                  b('ktup_loss_margin_bwd', _p(pos), _p(neg), B, self.margin, _p(self.one), _p(gpos), _p(gneg), st)]
+        calls.append(b('ktup_loss_margin_fused', _p(pos), _p(neg), B, self.margin, _p(self.one), _p(self.loss[0:]), _p(gpos), _p(gneg), st))
         if self.transh:
             calls += [b('ktup_score_transh_bwd', _p(E), E.stride(0), _p(R), R.stride(0), _p(Rn), Rn.stride(0), d, _p(self.h2), _p(self.t2),
                         _p(self.r2), 2 * B, self.l1, _p(self.gscore), _p(E.grad), _p(R.grad), _p(Rn.grad), st),
-                      b('ktup_reg_orth_fwd', _p(R), R.stride(0), _p(Rn), Rn.stride(0), d, _p(self.r2), 2 * B, _p(self.loss[1:]), st),
-                      b('ktup_reg_orth_bwd', _p(R), R.stride(0), _p(Rn), Rn.stride(0), d, _p(self.r2), 2 * B, _p(self.one), _p(R.grad),
-                        _p(Rn.grad), st)]
+                      b('ktup_reg_orth_fused', _p(R), R.stride(0), _p(Rn), Rn.stride(0), d, _p(self.r2), 2 * B, _p(self.one),
+                        _p(self.loss[1:]), _p(R.grad), _p(Rn.grad), st)]
         else:
             calls.append(b('ktup_score_transe_bwd', _p(E), E.stride(0), _p(R), R.stride(0), d, _p(self.h2), _p(self.t2), _p(self.r2),
                            2 * B, self.l1, _p(self.gscore), _p(E.grad), _p(R.grad), st))
-        calls += [b('ktup_reg_norm_fwd', _p(E), E.stride(0), d, _p(self.ht4), 4 * B, _p(self.loss[2:]), st),
-                  b('ktup_reg_norm_bwd', _p(E), E.stride(0), d, _p(self.ht4), 4 * B, _p(self.one), _p(E.grad), st),
-                  b('ktup_reg_norm_fwd', _p(R), R.stride(0), d, _p(self.r2), 2 * B, _p(self.loss[3:]), st),
-                  b('ktup_reg_norm_bwd', _p(R), R.stride(0), d, _p(self.r2), 2 * B, _p(self.one), _p(R.grad), st)]
+        calls += [b('ktup_reg_norm_fused', _p(E), E.stride(0), d, _p(self.ht4), 4 * B, _p(self.one), _p(self.loss[2:]), _p(E.grad), st),
+                  b('ktup_reg_norm_fused', _p(R), R.stride(0), d, _p(self.r2), 2 * B, _p(self.one), _p(self.loss[3:]), _p(R.grad), st)]
         self._calls = calls
 
     def _kg_eager(self, ph, pt, pr, nh, nt, nr):
         self._plans()
         if ph is not None:
             self._pack('kg', (ph, pt, pr, nh, nt, nr))
+        self.loss.zero_()
         for launch in self._calls:
             launch()
         self._optimizer_launches()

@@ -104,3 +104,44 @@ def test_gathered_call_shape_still_works():
     close(got, want)
     want.backward(); got.backward()
     close(Td.grad, Tc.grad, atol=1e-5)
+
+
+@pytest.mark.parametrize('n,d', [(1, 64), (333, 100), (2048, 36)])
+def test_fused_value_and_gradient_entries_vs_oracle(n, d):
+    """The one-launch value+gradient entry points used by the GPU-resident steppers: the loss is ADDED to the accumulator,
+    the gradient (scaled by the device scalar `gloss`) is ADDED to the table gradient / written to gpos, gneg."""
+    from jTransUP.hip import lib as L
+    gen = torch.Generator().manual_seed(n + d)
+    p = lambda t: t.data_ptr()
+    st = torch.cuda.current_stream().cuda_stream
+    gl = torch.full((), 0.75, device=DEV)
+    # pair losses
+    pos, neg = torch.randn(n, generator=gen) * 2, torch.randn(n, generator=gen) * 2
+    for name, param, ref in (('ktup_loss_bpr_fused', -1.0, lambda a, b: O.bpr_loss(a, b, -1.0)),
+                             ('ktup_loss_margin_fused', 1.0, lambda a, b: O.margin_loss(a, b, 1.0))):
+        pc, nc = pos.clone().requires_grad_(True), neg.clone().requires_grad_(True)
+        want = ref(pc, nc); (want * 0.75).backward()
+        pd, nd = pos.to(DEV), neg.to(DEV)
+        acc = torch.full((1,), 2.0, device=DEV); gp, gn = torch.empty_like(pd), torch.empty_like(nd)
+        L.call(name, p(pd), p(nd), n, param, p(gl), p(acc), p(gp), p(gn), st)
+        close(acc[0] - 2.0, want, rtol=1e-4, atol=1e-4)
+        close(gp, pc.grad, atol=1e-7); close(gn, nc.grad, atol=1e-7)
+    # regularisers over gathered rows (duplicates on purpose) and over whole tables (ids = NULL)
+    rows = 57
+    T, N = torch.randn(rows, d, generator=gen) * 0.3, torch.randn(rows, d, generator=gen) * 0.3
+    ids = torch.randint(0, rows, (n,), generator=gen)
+    for use_ids in (True, False):
+        Tc, Nc = T.clone().requires_grad_(True), N.clone().requires_grad_(True)
+        sel = (lambda w: w[ids]) if use_ids else (lambda w: w)
+        want_n = O.norm_loss(sel(Tc)); want_o = O.orthogonal_loss(sel(Tc), sel(Nc))
+        ((want_n + want_o) * 0.75).backward()
+        Td, Nd = T.to(DEV), N.to(DEV)
+        gT, gN = torch.ones_like(Td), torch.ones_like(Nd)          # accumulate on top of existing gradients
+        acc = torch.zeros(2, device=DEV)
+        idp, cnt = (p(ids.to(DEV)), n) if use_ids else (None, rows)
+        idd = ids.to(DEV)
+        idp = p(idd) if use_ids else None
+        L.call('ktup_reg_norm_fused', p(Td), Td.stride(0), d, idp, cnt, p(gl), p(acc[0:]), p(gT), st)
+        L.call('ktup_reg_orth_fused', p(Td), Td.stride(0), p(Nd), Nd.stride(0), d, idp, cnt, p(gl), p(acc[1:]), p(gT), p(gN), st)
+        close(acc[0], want_n, rtol=1e-4, atol=1e-5); close(acc[1], want_o, rtol=1e-4, atol=1e-5)
+        close(gT - 1.0, Tc.grad, rtol=1e-4, atol=2e-5); close(gN - 1.0, Nc.grad, rtol=1e-4, atol=2e-5)

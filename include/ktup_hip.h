@@ -187,7 +187,8 @@ int ktup_eval_pref_scores(const float* U, int64_t ldu, const float* I, int64_t l
  * topk : the first `topn` unfiltered candidate ids per query (-1 padded), optionally their scores.
  * ranks: for every gold entry (CSR gold_off / gold_ids) its 0-based rank among unfiltered NON-gold
  *        candidates (other golds do not advance the rank); -1 if the gold id is itself filtered.
- * Single-workgroup path: n_cand <= 19000 (ml1m: 3240 items / 14709 entities).                             */
+ * n_cand <= 19000 (ml1m: 3240 items / 14709 entities): the row's keys sit in LDS, one read of the score row.
+ * Larger catalogues stream through LDS in 16 K-key chunks (same results; topn <= 1024 there); ids are 32-bit. */
 int ktup_eval_topk_filtered(const float* scores, int64_t lds, int64_t nq, int64_t n_cand, int descending,
                             const int64_t* filt_off, const int32_t* filt_ids, int topn, int32_t* top_ids,
                             float* top_scores, void* stream);

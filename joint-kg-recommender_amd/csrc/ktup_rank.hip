@@ -9,6 +9,11 @@
 // `per_scores = -pred` (misc.py:93,180).  Filtered candidates get key = 2^64-1 and never rank.
 // One workgroup per query row; the row's keys live in LDS (8 B per candidate: 26 KB for ml1m's 3240 items,
 // 118 KB for its 14709 entities), so the score row is read from HBM exactly once.
+// Catalogues beyond 19,000 candidates (amazon-book / last-fm / yelp2018 entities, config 5's 1 M items) take the
+// chunked kernels below: the row streams through LDS in chunks of 16 K keys, still one read of the score row for
+// top-n and one per batch of 1024 golds for the ranks, no workspace.
+#include <cstdlib>
+
 #include "ktup_common.h"
 
 using namespace ktup;
@@ -129,6 +134,157 @@ __global__ __launch_bounds__(256) void gold_ranks_kernel(const float* __restrict
   }
 }
 
+// ---------------------------------------------------------------------------------------------- chunked (any n_cand)
+KTUP_DEV uint64_t block_min64(uint64_t v, uint64_t* red) {
+  v = wave_min64(v);
+  __syncthreads();  // red[] may still be read from the previous round
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return min(min(red[0], red[1]), min(red[2], red[3]));
+}
+
+// keys[0, len) <- keys of candidates [c0, c0 + len), anything >= `limit` or filtered becomes KEY_MAX.
+// Returns (block-uniform) whether any candidate was below `limit` before the filter was applied.
+KTUP_DEV bool load_chunk(uint64_t* keys, const float* row, int64_t c0, int len, bool descending, uint64_t limit,
+                         const int32_t* fids, int64_t nf) {
+  int any = 0;
+  for (int j = threadIdx.x; j < len; j += 256) {
+    uint64_t k = make_key(row[c0 + j], descending, (uint32_t)(c0 + j));
+    if (k >= limit) k = KEY_MAX;
+    any |= k != KEY_MAX;
+    keys[j] = k;
+  }
+  if (!__syncthreads_or(any)) return false;
+  for (int64_t f = threadIdx.x; f < nf; f += 256) {
+    const int64_t id = (int64_t)fids[f] - c0;
+    if (id >= 0 && id < len) keys[id] = KEY_MAX;
+  }
+  __syncthreads();
+  return true;
+}
+
+// top-n over a streamed row: slots [CH, CH + topn) of the key array hold the running list; a chunk that has a
+// candidate below the list's current worst key is merged by extracting the topn smallest of chunk + list.
+__global__ __launch_bounds__(256) void topk_chunked_kernel(const float* __restrict__ scores, int64_t lds, int64_t n_cand,
+                                                           int descending, const int64_t* __restrict__ filt_off,
+                                                           const int32_t* __restrict__ filt_ids, int topn, int CH,
+                                                           int32_t* __restrict__ top_ids, float* __restrict__ top_scores) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint64_t* keys = reinterpret_cast<uint64_t*>(smem);
+  uint64_t* run = keys + CH;          // [topn] sorted ascending, KEY_MAX padded
+  uint64_t* merged = run + topn;      // [topn]
+  __shared__ uint64_t red[4];
+  const int64_t b = blockIdx.x;
+  const float* row = scores + b * lds;
+  const int64_t f0 = filt_off ? filt_off[b] : 0, f1 = filt_off ? filt_off[b + 1] : 0;
+  for (int r = threadIdx.x; r < topn; r += 256) run[r] = KEY_MAX;
+  __syncthreads();
+  for (int64_t c0 = 0; c0 < n_cand; c0 += CH) {
+    const int len = (int)min((int64_t)CH, n_cand - c0);
+    const uint64_t limit = run[topn - 1];
+    __syncthreads();                  // everyone has read `limit` before the list is rewritten below
+    if (!load_chunk(keys, row, c0, len, descending != 0, limit, filt_ids + f0, f1 - f0)) continue;
+    for (int j = len + threadIdx.x; j < CH; j += 256) keys[j] = KEY_MAX;   // the tail chunk: neutral keys up to the list
+    __syncthreads();
+    uint64_t prev = 0;
+    for (int r = 0; r < topn; ++r) {
+      uint64_t best = KEY_MAX;
+      for (int j = threadIdx.x; j < CH + topn; j += 256) {
+        const uint64_t k = keys[j];
+        if ((r == 0 || k > prev) && k < best) best = k;
+      }
+      best = block_min64(best, red);
+      if (threadIdx.x == 0) merged[r] = best;
+      prev = best;
+      if (best == KEY_MAX) {          // uniform: fewer than topn unfiltered candidates so far
+        for (int rr = r + 1 + threadIdx.x; rr < topn; rr += 256) merged[rr] = KEY_MAX;
+        break;
+      }
+    }
+    __syncthreads();
+    for (int r = threadIdx.x; r < topn; r += 256) run[r] = merged[r];
+    __syncthreads();
+  }
+  for (int r = threadIdx.x; r < topn; r += 256) {
+    const uint64_t k = run[r];
+    const int32_t id = k != KEY_MAX ? (int32_t)(uint32_t)k : -1;
+    top_ids[b * topn + r] = id;
+    if (top_scores) top_scores[b * topn + r] = id >= 0 ? row[id] : 0.f;
+  }
+}
+
+constexpr int GOLD_BATCH = 1024;
+
+__global__ __launch_bounds__(256) void gold_ranks_chunked_kernel(const float* __restrict__ scores, int64_t lds, int64_t n_cand,
+                                                                 int descending, const int64_t* __restrict__ filt_off,
+                                                                 const int32_t* __restrict__ filt_ids,
+                                                                 const int64_t* __restrict__ gold_off,
+                                                                 const int32_t* __restrict__ gold_ids, int CH,
+                                                                 int32_t* __restrict__ ranks) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint64_t* keys = reinterpret_cast<uint64_t*>(smem);
+  __shared__ uint64_t gkey[GOLD_BATCH];
+  __shared__ int gid[GOLD_BATCH];
+  __shared__ int acc[GOLD_BATCH];
+  const int64_t b = blockIdx.x;
+  const float* row = scores + b * lds;
+  const int32_t* fids = filt_ids + (filt_off ? filt_off[b] : 0);
+  const int64_t nf = filt_off ? filt_off[b + 1] - filt_off[b] : 0;
+  const int64_t g0 = gold_off[b], g1 = gold_off[b + 1];
+  for (int64_t gb = g0; gb < g1; gb += GOLD_BATCH) {
+    const int ng = (int)min((int64_t)GOLD_BATCH, g1 - gb);
+    __syncthreads();
+    for (int i = threadIdx.x; i < ng; i += 256) {
+      const int32_t g = gold_ids[gb + i];
+      const bool ok = g >= 0 && g < n_cand;
+      gid[i] = ok ? g : -1;
+      gkey[i] = ok ? make_key(row[g], descending != 0, (uint32_t)g) : KEY_MAX;
+      acc[i] = 0;
+    }
+    __syncthreads();
+    for (int64_t f = threadIdx.x; f < nf; f += 256) {   // a gold that is itself filtered is never reached: rank -1
+      const int32_t id = fids[f];
+      for (int i = 0; i < ng; ++i)
+        if (gid[i] == id) gkey[i] = KEY_MAX;
+    }
+    __syncthreads();
+    for (int64_t c0 = 0; c0 < n_cand; c0 += CH) {
+      const int len = (int)min((int64_t)CH, n_cand - c0);
+      __syncthreads();
+      (void)load_chunk(keys, row, c0, len, descending != 0, KEY_MAX, fids, nf);
+      for (int i = 0; i < ng; ++i) {
+        const uint64_t gk = gkey[i];
+        if (gk == KEY_MAX) continue;  // uniform (LDS broadcast)
+        int cnt = 0;
+        for (int j = threadIdx.x; j < len; j += 256) cnt += keys[j] < gk ? 1 : 0;
+        for (int64_t o = g0 + threadIdx.x; o < g1; o += 256) {   // other golds do not advance the rank
+          const int64_t og = (int64_t)gold_ids[o] - c0;
+          if (og >= 0 && og < len && keys[og] < gk) cnt -= 1;
+        }
+        cnt = wave_sum_int(cnt);
+        if ((threadIdx.x & 63) == 0 && cnt != 0) atomicAdd(&acc[i], cnt);
+      }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < ng; i += 256) ranks[gb + i] = gkey[i] == KEY_MAX ? -1 : acc[i];
+  }
+}
+
+constexpr int CHUNK_KEYS = 16384;  // 128 KB of keys per chunk
+
+// 0 = take the single-workgroup path; otherwise the chunk size.  KTUP_RANK_CHUNK=<keys> forces the chunked path (tests).
+int chunk_for(int64_t n_cand) {
+  if (const char* e = getenv("KTUP_RANK_CHUNK")) {
+    const int v = atoi(e);
+    if (v > 0) return min(max(v, 64), CHUNK_KEYS);
+  }
+  return n_cand > MAX_LDS_CAND ? CHUNK_KEYS : 0;
+}
+
+void allow_lds(const void* fn, size_t bytes) {
+  if (bytes > 48 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
 int prep_lds(const void* fn, int64_t n_cand, size_t* lds, const char* name) {
   if (n_cand > MAX_LDS_CAND)
     return set_error(KTUP_ERR_UNSUPPORTED, "%s: %lld candidates exceed the single-workgroup LDS ranking path (max %lld)", name,
@@ -147,6 +303,15 @@ extern "C" int ktup_eval_topk_filtered(const float* scores, int64_t lds, int64_t
   KTUP_REQUIRE(nq >= 0 && n_cand > 0 && topn > 0 && lds >= n_cand, "%s: bad sizes", name);
   if (nq == 0) return KTUP_OK;
   KTUP_REQUIRE(scores && top_ids && ((filt_off == nullptr) || filt_ids), "%s: null pointer argument", name);
+  KTUP_REQUIRE(n_cand <= 0x7fffffffll, "%s: candidate ids are 32-bit", name);
+  if (const int ch = chunk_for(n_cand)) {
+    KTUP_REQUIRE(topn <= 1024, "%s: topn %d > 1024 on the chunked path", name, topn);
+    const size_t lbytes = ((size_t)ch + 2 * (size_t)topn) * 8;
+    allow_lds((const void*)topk_chunked_kernel, lbytes);
+    hipLaunchKernelGGL(topk_chunked_kernel, dim3((unsigned)nq), dim3(256), lbytes, (hipStream_t)stream, scores, lds, n_cand,
+                       descending, filt_off, filt_ids, topn, ch, top_ids, top_scores);
+    return check_launch(name);
+  }
   size_t bytes = 0;
   if (int e = prep_lds((const void*)topk_filtered_kernel, n_cand, &bytes, name)) return e;
   hipLaunchKernelGGL(topk_filtered_kernel, dim3((unsigned)nq), dim3(256), bytes, (hipStream_t)stream, scores, lds, n_cand,
@@ -161,6 +326,14 @@ extern "C" int ktup_eval_gold_ranks(const float* scores, int64_t lds, int64_t nq
   KTUP_REQUIRE(nq >= 0 && n_cand > 0 && lds >= n_cand, "%s: bad sizes", name);
   if (nq == 0) return KTUP_OK;
   KTUP_REQUIRE(scores && gold_off && gold_ids && ranks && ((filt_off == nullptr) || filt_ids), "%s: null pointer argument", name);
+  KTUP_REQUIRE(n_cand <= 0x7fffffffll, "%s: candidate ids are 32-bit", name);
+  if (const int ch = chunk_for(n_cand)) {
+    const size_t lbytes = (size_t)ch * 8;
+    allow_lds((const void*)gold_ranks_chunked_kernel, lbytes);
+    hipLaunchKernelGGL(gold_ranks_chunked_kernel, dim3((unsigned)nq), dim3(256), lbytes, (hipStream_t)stream, scores, lds, n_cand,
+                       descending, filt_off, filt_ids, gold_off, gold_ids, ch, ranks);
+    return check_launch(name);
+  }
   size_t bytes = 0;
   if (int e = prep_lds((const void*)gold_ranks_kernel, n_cand, &bytes, name)) return e;
   hipLaunchKernelGGL(gold_ranks_kernel, dim3((unsigned)nq), dim3(256), bytes, (hipStream_t)stream, scores, lds, n_cand,

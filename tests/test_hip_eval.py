@@ -199,3 +199,84 @@ def test_topk_properties_full_catalogue():
         order = [j for j in np.argsort(scores[b], kind='stable') if j not in filt][:10]
         assert top[b].tolist() == order
         np.testing.assert_array_equal(ts[b], scores[b][order])
+
+
+def _rank_case(rng, nq, nc, nf, max_gold, quant):
+    scores = (rng.randint(0, quant, size=(nq, nc)) / 7.0).astype(np.float32) if quant else rng.randn(nq, nc).astype(np.float32)
+    scores[0, ::3] = -0.0
+    filt = [np.sort(rng.choice(nc, size=rng.randint(0, nf + 1), replace=False)).astype(np.int32) for _ in range(nq)]
+    gold = [rng.choice(nc, size=rng.randint(0, max_gold + 1), replace=False).astype(np.int32) for _ in range(nq)]
+    gold[1] = np.concatenate([gold[1], filt[1][:3]]).astype(np.int32)          # golds that are themselves filtered
+    off = lambda parts: np.concatenate([[0], np.cumsum([len(p) for p in parts])]).astype(np.int64)
+    cat = lambda parts: np.concatenate(parts).astype(np.int32) if sum(len(p) for p in parts) else np.zeros(0, np.int32)
+    return scores, filt, gold, off(filt), cat(filt), off(gold), cat(gold)
+
+
+def _rank_oracle(scores, filt, gold, desc, topn):
+    """Plain walk of the stable (score, id) order: misc.py:125-146 / :213-248 with the declared tie rule."""
+    tops, ranks = [], []
+    for b in range(scores.shape[0]):
+        s = -scores[b] if desc else scores[b]
+        order = np.argsort(s + 0.0, kind='stable')
+        fs, gs = set(filt[b].tolist()), set(gold[b].tolist())
+        top = [int(j) for j in order if j not in fs][:topn]
+        tops.append(top + [-1] * (topn - len(top)))
+        pos, r = {}, 0
+        for j in order:
+            j = int(j)
+            if j in fs:
+                continue
+            if j in gs:
+                pos[j] = r
+            else:
+                r += 1
+        ranks += [pos.get(int(g), -1) for g in gold[b]]
+    return np.array(tops, np.int32), np.array(ranks, np.int32)
+
+
+@pytest.mark.parametrize('nc,quant', [(19001, 0), (50000, 40), (131072 + 17, 0)])
+@pytest.mark.parametrize('desc', [False, True])
+def test_chunked_ranking_large_catalogue_vs_oracle(nc, quant, desc):
+    """Catalogues beyond the single-workgroup LDS path (amazon-book / last-fm entities): chunked K17/K18, bit-exact."""
+    rng = np.random.RandomState(nc % 1000 + int(desc))
+    nq = 9
+    scores, filt, gold, f_off, f_ids, g_off, g_ids = _rank_case(rng, nq, nc, 2000, 40, quant)
+    want_top, want_ranks = _rank_oracle(scores, filt, gold, desc, 10)
+    mat = dv(scores)
+    top, ts = ops().topk_filtered(mat, desc, 10, dv(f_off), dv(f_ids), with_scores=True)
+    np.testing.assert_array_equal(top.cpu().numpy(), want_top)
+    np.testing.assert_array_equal(ts.cpu().numpy(), np.take_along_axis(scores, np.maximum(want_top, 0), 1) * (want_top >= 0))
+    ranks = ops().gold_ranks(mat, desc, dv(g_off), dv(g_ids), dv(f_off), dv(f_ids))
+    np.testing.assert_array_equal(ranks.cpu().numpy(), want_ranks)
+    top_nf = ops().topk_filtered(mat, desc, 10)                                  # no filter at all
+    want_nf, _ = _rank_oracle(scores, [np.zeros(0, np.int32)] * nq, gold, desc, 10)
+    np.testing.assert_array_equal(top_nf.cpu().numpy(), want_nf)
+
+
+@pytest.mark.parametrize('chunk', [64, 1000, 4096])
+def test_chunked_ranking_equals_lds_path(chunk, monkeypatch):
+    """KTUP_RANK_CHUNK forces the chunked kernels at small N: same integers as the single-workgroup kernels, incl. many
+    golds (more than one gold batch), topn larger than the unfiltered set, and everything filtered."""
+    rng = np.random.RandomState(chunk)
+    nq, nc = 12, 5000
+    scores, filt, gold, f_off, f_ids, g_off, g_ids = _rank_case(rng, nq, nc, 600, 30, 25)
+    gold[2] = rng.choice(nc, size=2500, replace=False).astype(np.int32)          # > GOLD_BATCH golds
+    filt[3] = np.arange(nc, dtype=np.int32)                                      # nothing left to rank
+    filt[4] = np.sort(rng.choice(nc, size=nc - 4, replace=False)).astype(np.int32)   # 4 candidates left, topn = 50
+    off = lambda parts: np.concatenate([[0], np.cumsum([len(p) for p in parts])]).astype(np.int64)
+    f_off, f_ids, g_off, g_ids = off(filt), np.concatenate(filt), off(gold), np.concatenate(gold)
+    mat = dv(scores)
+    args = (dv(f_off), dv(f_ids))
+    for desc in (False, True):
+        for topn in (1, 10, 50):
+            monkeypatch.delenv('KTUP_RANK_CHUNK', raising=False)
+            a = ops().topk_filtered(mat, desc, topn, *args, with_scores=True)
+            ra = ops().gold_ranks(mat, desc, dv(g_off), dv(g_ids), *args)
+            monkeypatch.setenv('KTUP_RANK_CHUNK', str(chunk))
+            b = ops().topk_filtered(mat, desc, topn, *args, with_scores=True)
+            rb = ops().gold_ranks(mat, desc, dv(g_off), dv(g_ids), *args)
+            assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(ra, rb)
+    monkeypatch.delenv('KTUP_RANK_CHUNK', raising=False)
+    want_top, want_ranks = _rank_oracle(scores, filt, gold, False, 10)
+    np.testing.assert_array_equal(ops().topk_filtered(mat, False, 10, *args).cpu().numpy(), want_top)
+    np.testing.assert_array_equal(ops().gold_ranks(mat, False, dv(g_off), dv(g_ids), *args).cpu().numpy(), want_ranks)

@@ -34,6 +34,9 @@ extern "C" {
 #define KTUP_GUMBEL_OFF 0     /* soft: raw logits are the mixture weights (transUP.py:108-113)      */
 #define KTUP_GUMBEL_INPUT 1   /* hard, uniforms supplied by the caller (parity mode)                 */
 #define KTUP_GUMBEL_PHILOX 2  /* hard, uniforms drawn on device from Philox4x32-10(seed, offset)     */
+#define KTUP_GUMBEL_PHILOX_DEV 3 /* as PHILOX, but (seed, offset) are read from device memory when the kernel
+                                  * runs: `uniform` points at a uint64_t[2] = {seed, offset}; the `seed` /
+                                  * `offset` arguments are ignored.  For launches captured in a HIP graph. */
 
 int ktup_version(void);
 const char* ktup_last_error(void);

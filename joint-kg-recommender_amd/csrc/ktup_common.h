@@ -63,6 +63,18 @@ KTUP_DEV void atomic_add4(float* p, float4 v) {
 KTUP_DEV float gumbel_from_uniform(float u) { return -logf(-logf(u + 1e-20f) + 1e-20f); }
 
 // Philox4x32-10 (counter-based; production Gumbel / negative-sampling draws).
+// KTUP_GUMBEL_PHILOX_DEV: the stream position lives in device memory (graph replay); resolve it into the by-value
+// argument block at kernel entry (uniform address -> scalar loads) and continue as KTUP_GUMBEL_PHILOX.
+#define KTUP_RESOLVE_GUMBEL(a)                                              \
+  do {                                                                      \
+    if ((a).gumbel == KTUP_GUMBEL_PHILOX_DEV) {                             \
+      const uint64_t* ktup_gs_ = reinterpret_cast<const uint64_t*>((a).uniform); \
+      (a).seed = ktup_gs_[0];                                               \
+      (a).offset = ktup_gs_[1];                                             \
+      (a).gumbel = KTUP_GUMBEL_PHILOX;                                      \
+    }                                                                       \
+  } while (0)
+
 struct Philox {
   uint32_t k0, k1;
   KTUP_DEV Philox(uint64_t seed) : k0((uint32_t)seed), k1((uint32_t)(seed >> 32)) {}

@@ -233,6 +233,7 @@ struct HardArgs {
 };
 
 __global__ __launch_bounds__(256) void pairs_hard_kernel(HardArgs a) {
+  KTUP_RESOLVE_GUMBEL(a);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int nch4 = a.d / 4, dp4 = a.dp / 4;
   float4* cand = reinterpret_cast<float4*>(smem);              // [nch4][CT]
@@ -534,8 +535,9 @@ extern "C" int ktup_eval_pref_scores(const float* U, int64_t ldu, const float* I
   KTUP_REQUIRE((E == nullptr) == (item2ent == nullptr), "%s: E and item2ent must be given together", name);
   KTUP_REQUIRE(aligned16(U) && aligned16(I) && aligned16(E) && aligned16(pref_ws) && aligned16(ws) && ldu % 4 == 0 &&
                    ldi % 4 == 0 && (!E || lde % 4 == 0), "%s: tables must be 16-byte aligned with pitches %% 4 == 0", name);
-  KTUP_REQUIRE(gumbel_mode >= KTUP_GUMBEL_OFF && gumbel_mode <= KTUP_GUMBEL_PHILOX, "%s: bad gumbel_mode", name);
-  KTUP_REQUIRE(gumbel_mode != KTUP_GUMBEL_INPUT || uniform, "%s: KTUP_GUMBEL_INPUT needs the uniform tensor", name);
+  KTUP_REQUIRE(gumbel_mode >= KTUP_GUMBEL_OFF && gumbel_mode <= KTUP_GUMBEL_PHILOX_DEV, "%s: bad gumbel_mode", name);
+  KTUP_REQUIRE((gumbel_mode != KTUP_GUMBEL_INPUT && gumbel_mode != KTUP_GUMBEL_PHILOX_DEV) || uniform,
+               "%s: KTUP_GUMBEL_INPUT / KTUP_GUMBEL_PHILOX_DEV need the `uniform` pointer", name);
   hipStream_t st = (hipStream_t)stream;
   float* QW = ws;
   float* QL = QW + (size_t)nq * 3 * d;

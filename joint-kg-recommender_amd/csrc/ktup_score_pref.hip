@@ -216,6 +216,7 @@ KTUP_DEV int row_argmax(const float* lrow, int P) {
 
 template <int CH, int NW>
 __global__ __launch_bounds__(NW * 64) void pref_fwd_kernel(PrefArgs a) {
+  KTUP_RESOLVE_GUMBEL(a);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   Tile<CH, NW> T;
   T.carve(smem, a.nch, a.lp);
@@ -293,6 +294,7 @@ __global__ __launch_bounds__(NW * 64) void pref_fwd_kernel(PrefArgs a) {
 // fit three whole extra tiles in 160 KB of LDS); slice sl = chunks [sl * SW, (sl + 1) * SW) = this wave's j in [sl * CH / KS, ...).
 template <int CH, int NW, int KS>
 __global__ __launch_bounds__(NW * 64) void pref_bwd_kernel(PrefArgs a) {
+  KTUP_RESOLVE_GUMBEL(a);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NT = NW * 64;
   Tile<CH, NW> T;
@@ -529,6 +531,7 @@ typedef const __attribute__((address_space(4))) v8f* sptr8;
 
 template <int NW, int CH, bool HARD>
 __global__ __launch_bounds__(NW * 64) void pref_fwd2_kernel(PrefArgs a) {
+  KTUP_RESOLVE_GUMBEL(a);
   constexpr int NT = NW * 64, EV = (2 * CH + 3) / 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int nch = a.nch, lp = a.ppad2 | 1;
@@ -1605,8 +1608,9 @@ int run_pref(bool bwd, const char* name, const float* U, int64_t ldu, const floa
   KTUP_REQUIRE((E == nullptr) == (item2ent == nullptr), "%s: E and item2ent must be given together", name);
   KTUP_REQUIRE(aligned16(U) && aligned16(I) && aligned16(E) && aligned16(pref_ws), "%s: tables must be 16-byte aligned", name);
   KTUP_REQUIRE(ldu % 4 == 0 && ldi % 4 == 0 && (!E || lde % 4 == 0), "%s: row pitches must be multiples of 4 floats", name);
-  KTUP_REQUIRE(gumbel_mode >= KTUP_GUMBEL_OFF && gumbel_mode <= KTUP_GUMBEL_PHILOX, "%s: bad gumbel_mode %d", name, gumbel_mode);
-  KTUP_REQUIRE(gumbel_mode != KTUP_GUMBEL_INPUT || uniform, "%s: KTUP_GUMBEL_INPUT needs the uniform tensor", name);
+  KTUP_REQUIRE(gumbel_mode >= KTUP_GUMBEL_OFF && gumbel_mode <= KTUP_GUMBEL_PHILOX_DEV, "%s: bad gumbel_mode %d", name, gumbel_mode);
+  KTUP_REQUIRE((gumbel_mode != KTUP_GUMBEL_INPUT && gumbel_mode != KTUP_GUMBEL_PHILOX_DEV) || uniform,
+               "%s: KTUP_GUMBEL_INPUT / KTUP_GUMBEL_PHILOX_DEV need the `uniform` pointer", name);
   PrefArgs a{};
   a.U = reinterpret_cast<const float4*>(U); a.I = reinterpret_cast<const float4*>(I); a.E = reinterpret_cast<const float4*>(E);
   a.ldu4 = ldu / 4; a.ldi4 = ldi / 4; a.lde4 = lde / 4;

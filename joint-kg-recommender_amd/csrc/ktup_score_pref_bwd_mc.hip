@@ -65,6 +65,7 @@ struct BArgs {
 
 template <typename G>
 __global__ __launch_bounds__(G::NW * 64) void pref_bwd_mc_kernel(BArgs a) {
+  KTUP_RESOLVE_GUMBEL(a);
   constexpr int NCH = G::NCH, NP = G::NP, D = G::D, KG = G::KG, CT = G::CT, PT = G::PT, J = G::J, TOTAL = G::TOTAL;
   constexpr int PITCHA4 = G::PITCHA4, RP = G::RP, NW = G::NW;
   constexpr bool HASE = G::HASE, HARD = G::HARD;

@@ -79,6 +79,7 @@ struct McArgs {
 
 template <typename G>
 __global__ __launch_bounds__(G::NW * 64) void pref_fwd_mc_kernel(McArgs a) {
+  KTUP_RESOLVE_GUMBEL(a);
   constexpr int NCH = G::NCH, NP = G::NP, KG = G::KG, CT = G::CT, PTF = G::PTF, J = G::J, TOTAL = G::TOTAL;
   constexpr int PITCHA4 = G::PITCHA4, TPITCH = G::TPITCH, KQ = G::KQ;
   constexpr bool HASE = G::HASE, REM4 = G::REM4, TAIL1 = G::TAIL1, HARD = G::HARD;

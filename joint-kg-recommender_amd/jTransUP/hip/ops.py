@@ -8,7 +8,7 @@ from torch.autograd import Function
 
 from . import lib as L
 
-GUMBEL_OFF, GUMBEL_INPUT, GUMBEL_PHILOX = 0, 1, 2
+GUMBEL_OFF, GUMBEL_INPUT, GUMBEL_PHILOX, GUMBEL_PHILOX_DEV = 0, 1, 2, 3
 
 
 def _dev(t):
@@ -204,6 +204,9 @@ class _ScorePref(Function):
             if uniform is None or tuple(uniform.shape) != (n, P) or uniform.dtype != torch.float32 or uniform.device != dev:
                 raise L.KtupError('uniform must be an (n, n_pref) fp32 device tensor')
             uniform = uniform.contiguous()
+        elif gumbel_mode == GUMBEL_PHILOX_DEV:     # `uniform` is the device-side stream position {seed, offset}
+            if uniform is None or uniform.dtype != torch.int64 or uniform.numel() != 2 or uniform.device != dev or not uniform.is_contiguous():
+                raise L.KtupError('GUMBEL_PHILOX_DEV takes a contiguous int64[2] device tensor {seed, offset}')
         else:
             uniform = None
         score = torch.empty(n, dtype=torch.float32, device=dev)

@@ -72,15 +72,33 @@ class _StepperBase(object):
         self.one = torch.ones((), **f32)
         self._keys = None
         self._stream = None
-        # HIP graphs: with the soft gate and a step-independent optimizer every launch argument of a step is static, so the
-        # ~15 launches replay as ONE graph launch (KTUP_TRAIN_GRAPHS=0 disables).  Inputs are copied into fixed buffers first.
+        # HIP graphs: with a step-independent optimizer every launch argument of a step is static (the ST-Gumbel stream
+        # position lives in device memory, KTUP_GUMBEL_PHILOX_DEV), so the launches of a step replay as ONE graph launch
+        # (KTUP_TRAIN_GRAPHS=0 disables).  Inputs are copied into fixed buffers first.
         if use_graphs is None:
             import os
             use_graphs = os.environ.get('KTUP_TRAIN_GRAPHS', '1') != '0'
-        self.use_graphs = bool(use_graphs) and self.world == 1 and not getattr(model, 'use_st_gumbel', False)
+        self.use_graphs = bool(use_graphs) and self.world == 1
         self._graphs = {}
         self._eager_steps = {k: 0 for k in self.KINDS}
         self._setup(FLAGS, f32, i64)
+
+    def _gumbel_stream(self, draws_per_step):
+        """(mode, pointer argument) of the preference gate, and the device-side stream position for the hard gate:
+        uint64[2] = {seed, offset}; `_gumbel_advance()` moves the offset past a step's draws (a captured launch)."""
+        if not getattr(self.m, 'use_st_gumbel', False):
+            self.gstate = None
+            return
+        seed = (int(self.m._gumbel.seed) * 6364136223846793005 + 1442695040888963407) % (1 << 62)   # own stream, apart from eval's
+        self.gstate = torch.tensor([seed, 0], dtype=torch.int64, device=self.dev)
+        self.gadv = torch.tensor([0, int(draws_per_step)], dtype=torch.int64, device=self.dev)
+
+    def _gate_args(self):
+        return (ops.GUMBEL_OFF, None) if self.gstate is None else (ops.GUMBEL_PHILOX_DEV, _p(self.gstate))
+
+    def _gumbel_advance(self):
+        if self.gstate is not None:
+            self.gstate.add_(self.gadv)
 
     def _mine(self, t):
         """This rank's rows of a global-batch id tensor."""
@@ -159,6 +177,7 @@ class JointStepper(_StepperBase):
         self.ws = ops.pref_workspace(P, Pn, R, Rn)
         self.ent_pad = model.ent_total - 1
         self.i2e = model._item2ent
+        self._gumbel_stream(2 * B * P.shape[0])
 
     # ------------------------------------------------------------------------------------------------ launch plans
     def _bind(self, st):
@@ -169,19 +188,19 @@ class JointStepper(_StepperBase):
         n_pref, d = P.shape
         n_rel = min(R.shape[0], Rn.shape[0])
         pos, neg, gpos, gneg = self.score[:B], self.score[B:], self.gscore[:B], self.gscore[B:]
-        off = ops.GUMBEL_OFF
+        gate, gptr = self._gate_args()
         b = L.bind
         self._rec_head = [
             b('ktup_pref_prepare', _p(P), _p(Pn), _p(R), _p(Rn), P.stride(0), n_pref, d, _p(self.ws), st)]
-        self._rec_soft = [            # soft gate only: the Gumbel stream advances per step and is marshalled per call
+        self._rec_soft = [
             b('ktup_score_ktup_fwd', _p(U), U.stride(0), _p(I), I.stride(0), _p(E), E.stride(0), _p(self.i2e), _p(self.ws), n_pref, d,
-              _p(self.u2), _p(self.i2), 2 * B, self.l1, off, None, 0, 0, _p(self.score), st)]
+              _p(self.u2), _p(self.i2), 2 * B, self.l1, gate, gptr, 0, 0, _p(self.score), st)]
         # value + gradient in one launch; the loss slots are zeroed once at the top of a step and accumulated into
         self._rec_loss = [
             b('ktup_loss_bpr_fused', _p(pos), _p(neg), B, self.target, _p(self.inv_world), _p(self.loss[0:]), _p(gpos), _p(gneg), st)]
         self._rec_soft_bwd = [
             b('ktup_score_ktup_bwd', _p(U), U.stride(0), _p(I), I.stride(0), _p(E), E.stride(0), _p(self.i2e), self.ent_pad,
-              _p(self.ws), n_pref, d, _p(self.u2), _p(self.i2), 2 * B, self.l1, off, None, 0, 0,
+              _p(self.ws), n_pref, d, _p(self.u2), _p(self.i2), 2 * B, self.l1, gate, gptr, 0, 0,
               _p(self.gscore), _p(U.grad), _p(I.grad), _p(E.grad), _p(self.gAC[0]), _p(self.gAC[1]), st)]
         self._rec_tail = [
             b('ktup_reg_orth_fused', _p(P), P.stride(0), _p(Pn), Pn.stride(0), d, None, n_pref, _p(self.inv_world), _p(self.loss[1:]),
@@ -206,18 +225,8 @@ class JointStepper(_StepperBase):
             self._pack('rec', (u, pi, ni))
         self._rec_head[0]()
         self.gAC.zero_(); self.loss.zero_()
-        if not m.use_st_gumbel:
-            self._rec_soft[0](); self._rec_loss[0](); self._rec_soft_bwd[0]()
-        else:
-            n_pref, d = P.shape
-            st = self._stream
-            mode, uni, seed, off = m._gumbel.mode_and_stream(True, None, 2 * B * n_pref)
-            L.call('ktup_score_ktup_fwd', _p(U), U.stride(0), _p(I), I.stride(0), _p(E), E.stride(0), _p(self.i2e), _p(self.ws), n_pref,
-                   d, _p(self.u2), _p(self.i2), 2 * B, self.l1, int(mode), _p(uni), int(seed), int(off), _p(self.score), st)
-            self._rec_loss[0]()
-            L.call('ktup_score_ktup_bwd', _p(U), U.stride(0), _p(I), I.stride(0), _p(E), E.stride(0), _p(self.i2e), self.ent_pad,
-                   _p(self.ws), n_pref, d, _p(self.u2), _p(self.i2), 2 * B, self.l1, int(mode), _p(uni), int(seed), int(off),
-                   _p(self.gscore), _p(U.grad), _p(I.grad), _p(E.grad), _p(self.gAC[0]), _p(self.gAC[1]), st)
+        self._rec_soft[0](); self._rec_loss[0](); self._rec_soft_bwd[0]()
+        self._gumbel_advance()
         # A = pref + rel and C = pref_norm + norm: the mixed-table gradient goes to both summands
         torch._foreach_add_([P.grad, R.grad, Pn.grad, Rn.grad], [self.gAC[0], self.gAC[0], self.gAC[1], self.gAC[1]])
         self._rec_tail[0]()
@@ -263,6 +272,7 @@ class RecStepper(_StepperBase):
         else:
             self.tabs = (model.user_embeddings.weight, model.item_embeddings.weight)
         self.u2, self.i2 = torch.zeros(2 * B, **i64), torch.zeros(2 * B, **i64)
+        self._gumbel_stream(2 * B * self.tabs[2].shape[0] if self.tup else 0)
 
     def _bind(self, st):
         B, b = self.B, L.bind
@@ -278,12 +288,13 @@ class RecStepper(_StepperBase):
                           _p(self.gscore), _p(U.grad), _p(I.grad), st)
             return
         P, Pn = self.tabs[2], self.tabs[3]
-        n_pref, off = P.shape[0], ops.GUMBEL_OFF
+        n_pref = P.shape[0]
+        gate, gptr = self._gate_args()
         self._prep = b('ktup_pref_prepare', _p(P), _p(Pn), None, None, P.stride(0), n_pref, d, _p(self.ws), st)
         self._fwd = b('ktup_score_tup_fwd', _p(U), U.stride(0), _p(I), I.stride(0), _p(self.ws), n_pref, d, _p(self.u2), _p(self.i2),
-                      2 * B, self.l1, off, None, 0, 0, _p(self.score), st)
+                      2 * B, self.l1, gate, gptr, 0, 0, _p(self.score), st)
         self._bwd = b('ktup_score_tup_bwd', _p(U), U.stride(0), _p(I), I.stride(0), _p(self.ws), n_pref, d, _p(self.u2), _p(self.i2),
-                      2 * B, self.l1, off, None, 0, 0, _p(self.gscore), _p(U.grad), _p(I.grad), _p(self.gAC[0]), _p(self.gAC[1]), st)
+                      2 * B, self.l1, gate, gptr, 0, 0, _p(self.gscore), _p(U.grad), _p(I.grad), _p(self.gAC[0]), _p(self.gAC[1]), st)
         self._regs = [
             b('ktup_reg_orth_fused', _p(P), P.stride(0), _p(Pn), Pn.stride(0), d, None, n_pref, _p(self.inv_world), _p(self.loss[1:]),
               _p(P.grad), _p(Pn.grad), st),
@@ -306,17 +317,8 @@ class RecStepper(_StepperBase):
         U, I, P, Pn = self.tabs
         self._prep()
         self.gAC.zero_()
-        if not m.use_st_gumbel:
-            self._fwd(); self._loss[0](); self._bwd()
-        else:
-            n_pref, d, st = P.shape[0], P.shape[1], self._stream
-            mode, uni, seed, off = m._gumbel.mode_and_stream(True, None, 2 * B * n_pref)
-            L.call('ktup_score_tup_fwd', _p(U), U.stride(0), _p(I), I.stride(0), _p(self.ws), n_pref, d, _p(self.u2), _p(self.i2), 2 * B,
-                   self.l1, int(mode), _p(uni), int(seed), int(off), _p(self.score), st)
-            self._loss[0]()
-            L.call('ktup_score_tup_bwd', _p(U), U.stride(0), _p(I), I.stride(0), _p(self.ws), n_pref, d, _p(self.u2), _p(self.i2), 2 * B,
-                   self.l1, int(mode), _p(uni), int(seed), int(off), _p(self.gscore), _p(U.grad), _p(I.grad), _p(self.gAC[0]),
-                   _p(self.gAC[1]), st)
+        self._fwd(); self._loss[0](); self._bwd()
+        self._gumbel_advance()
         torch._foreach_add_([P.grad, Pn.grad], [self.gAC[0], self.gAC[1]])
         for launch in self._regs:
             launch()

@@ -214,3 +214,39 @@ def test_kg_stepper_matches_the_autograd_route(tmp_path, model_type):
         fast_loss = fast.kg_step(ph, pt, pr, nh, nt, pr)
         torch.testing.assert_close(fast_loss, losses.detach(), rtol=1e-5, atol=1e-6)
         _assert_tables_close(m1, m2, step)
+
+
+@pytest.mark.parametrize('kind', ['jtransup', 'transup'])
+def test_hard_gate_steps_replay_as_graphs(tmp_path, kind):
+    """-use_st_gumbel: the Philox stream position lives in device memory, so the step replays as a HIP graph; the replayed
+    steps draw the same noise, step for step, as the same launches issued eagerly (use_graphs=False)."""
+    from jTransUP.models import transUP
+    from jTransUP.utils.fast_train import JointStepper, RecStepper
+    B, P = 64, 5
+    if kind == 'jtransup':
+        FLAGS, m1, tr1, (NU, NI, NE, NR) = build(tmp_path, 'Adagrad', True)
+        _, m2, tr2, _ = build(tmp_path, 'Adagrad', True)
+        P = NR
+        Stepper = JointStepper
+    else:
+        NU, NI, D = 50, 40, 36
+        torch.manual_seed(4)
+        m1, m2 = transUP.TransUPModel(False, D, NU, NI, P, True), transUP.TransUPModel(False, D, NU, NI, P, True)
+        FLAGS, tr1 = _trainer_for(tmp_path, 'transup', m1)
+        _, tr2 = _trainer_for(tmp_path, 'transup', m2)
+        Stepper = RecStepper
+    m2.load_state_dict(copy.deepcopy(m1.state_dict()))
+    m2._gumbel.seed = m1._gumbel.seed
+    eager, graphed = Stepper(m1, tr1, FLAGS, B, use_graphs=False), Stepper(m2, tr2, FLAGS, B, use_graphs=True)
+    gen = torch.Generator().manual_seed(9)
+    rnd = lambda hi: torch.randint(0, hi, (B,), generator=gen).to(DEV)
+    losses = []
+    for step in range(6):
+        u, pi, ni = rnd(NU), rnd(NI), rnd(NI)
+        la, lb = eager.rec_step(u, pi, ni), graphed.rec_step(u, pi, ni)
+        torch.testing.assert_close(la, lb, rtol=1e-5, atol=1e-6)
+        losses.append(float(la))
+        _assert_tables_close(m1, m2, step)
+        assert graphed.gstate.tolist() == eager.gstate.tolist() and int(graphed.gstate[1]) == (step + 1) * 2 * B * P
+    assert 'rec' in graphed._graphs and not eager._graphs
+    assert len(set(losses)) == len(losses)

@@ -312,3 +312,34 @@ def test_matrix_core_kernels_ragged_fwd_bwd(n):
     for l1 in (False, True):
         close(ops().score_transr(W['E'].to(DEV), W['R'].to(DEV), M.to(DEV), h.to(DEV), t.to(DEV), r.to(DEV), l1),
               O.score_transr(W['E'], W['R'], M, h, t, r, l1))
+
+
+@pytest.mark.parametrize('d,P', [(100, 20), (64, 4), (36, 7)])
+def test_philox_stream_position_in_device_memory(d, P):
+    """KTUP_GUMBEL_PHILOX_DEV (graph-capturable hard gate): {seed, offset} read from device memory give the same scores and
+    gradients, bit for bit, as the same values passed as launch arguments -- for TUP and KTUP, mc and generic kernels."""
+    W, i2e, gen = rand_world(d + P, 90, 70, 80, P, d)
+    n = 1500
+    u = torch.randint(0, 90, (n,), generator=gen).to(DEV); i = torch.randint(0, 70, (n,), generator=gen).to(DEV)
+    seed, off = 987654321987, 4242
+    state = torch.tensor([seed, off], dtype=torch.int64, device=DEV)
+    o = ops()
+    for ktup in (False, True):
+        outs = []
+        for mode, uni, sd, of in ((o.GUMBEL_PHILOX, None, seed, off), (o.GUMBEL_PHILOX_DEV, state, 0, 0)):
+            D = {k: v.to(DEV).clone().requires_grad_(True) for k, v in W.items()}
+            if ktup:
+                s = o.score_ktup(D['U'], D['I'], D['E'], D['P'], D['Pn'], D["R"], D["Rn"], i2e.to(DEV, torch.int32), u, i, False, mode, uni, sd, of,
+                                 ent_pad=D['E'].shape[0] - 1)
+            else:
+                s = o.score_tup(D['U'], D['I'], D['P'], D['Pn'], u, i, False, mode, uni, sd, of)
+            (s * torch.linspace(0.5, 1.5, n, device=DEV)).sum().backward()
+            outs.append((s.detach(), D))
+        assert torch.equal(outs[0][0], outs[1][0])
+        for k in ('U', 'I', 'P', 'Pn') + (('E', 'R', 'Rn') if ktup else ()):
+            torch.testing.assert_close(outs[0][1][k].grad, outs[1][1][k].grad, rtol=1e-4, atol=1e-5)     # atomics order only
+    state[1] += n * P                                                  # the next step's draws
+    D = {k: v.to(DEV) for k, v in W.items()}
+    a = o.score_tup(D['U'], D['I'], D['P'], D['Pn'], u, i, False, o.GUMBEL_PHILOX_DEV, state)
+    b = o.score_tup(D['U'], D['I'], D['P'], D['Pn'], u, i, False, o.GUMBEL_PHILOX, None, seed, off + n * P)
+    assert torch.equal(a, b) and not torch.equal(a, outs[0][0])

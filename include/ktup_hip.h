@@ -232,7 +232,9 @@ int ktup_negsample_kg(const int64_t* h, const int64_t* t, const int64_t* r, int6
  * state1 / state2:  SGD momentum_buffer / -;  Adagrad sum / -;  Adam exp_avg / exp_avg_sq;  RMSprop square_avg /
  * momentum_buffer.  The clip factor min(1, max_norm / (||g|| + 1e-6)) is applied to the gradients in place, like
  * clip_grad_norm_; max_norm <= 0 disables clipping (sumsq, one device double, may then be NULL).  zero_grads != 0
- * stores zeros instead (optimizer.zero_grad() of the NEXT step folded into this pass).                              */
+ * stores zeros instead (optimizer.zero_grad() of the NEXT step folded into this pass).  `steps_dev` (Adam; may be
+ * NULL): the same step counts as n_tensors int64 in DEVICE memory, read when the kernel runs -- it overrides `steps`
+ * and makes the launch replayable from a HIP graph (the caller increments the counters with a captured launch).      */
 #define KTUP_OPTIM_MAX_TENSORS 12
 #define KTUP_OPT_SGD 0
 #define KTUP_OPT_ADAGRAD 1
@@ -240,8 +242,8 @@ int ktup_negsample_kg(const int64_t* h, const int64_t* t, const int64_t* r, int6
 #define KTUP_OPT_RMSPROP 3
 int ktup_optim_gradnorm(int n_tensors, float* const* grads, const int64_t* sizes, double* sumsq, void* stream);
 int ktup_optim_step(int kind, int n_tensors, float* const* params, float* const* grads, float* const* state1,
-                    float* const* state2, const int64_t* sizes, const int64_t* steps, const int32_t* first, float lr,
-                    float weight_decay, float momentum, float beta1, float beta2, float eps, float alpha,
+                    float* const* state2, const int64_t* sizes, const int64_t* steps, const int64_t* steps_dev,
+                    const int32_t* first, float lr, float weight_decay, float momentum, float beta1, float beta2, float eps, float alpha,
                     const double* sumsq, float max_norm, int zero_grads, void* stream);
 
 #ifdef __cplusplus

@@ -105,7 +105,19 @@ KTUP_DEV void update1(float& p, float& g, float& s1, float& s2, const Hyper& h, 
 }
 
 template <int KIND>
-__global__ __launch_bounds__(256) void step_kernel(OptTensors T, Hyper h, const double* __restrict__ sumsq) {
+__global__ __launch_bounds__(256) void step_kernel(OptTensors T, Hyper h, const double* __restrict__ sumsq,
+                                                   const int64_t* __restrict__ steps_dev) {
+  // Adam with device-resident step counts (graph replay): the bias corrections are evaluated here, the way the host does
+  __shared__ float dev_bc1[MAXT], dev_bc2s[MAXT];
+  const bool dev_bc = KIND == KTUP_OPT_ADAM && steps_dev != nullptr;
+  if (dev_bc) {
+    if ((int)threadIdx.x < T.count) {
+      const double t = (double)steps_dev[threadIdx.x];
+      dev_bc1[threadIdx.x] = (float)(1.0 - pow((double)h.beta1, t));
+      dev_bc2s[threadIdx.x] = (float)sqrt(1.0 - pow((double)h.beta2, t));
+    }
+    __syncthreads();
+  }
   float coef = 1.f;
   if (h.max_norm > 0.f) {
     const float c = h.max_norm / ((float)sqrt(*sumsq) + 1e-6f);
@@ -120,7 +132,7 @@ __global__ __launch_bounds__(256) void step_kernel(OptTensors T, Hyper h, const 
     float* s1 = T.s1[k];
     float* s2 = T.s2[k];
     const int64_t n = T.n[k];
-    const float bc1 = T.bc1[k], bc2s = T.bc2s[k];
+    const float bc1 = dev_bc ? dev_bc1[k] : T.bc1[k], bc2s = dev_bc ? dev_bc2s[k] : T.bc2s[k];
     const bool first = T.first[k] != 0;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -192,7 +204,8 @@ extern "C" int ktup_optim_gradnorm(int n_tensors, float* const* grads, const int
 }
 
 extern "C" int ktup_optim_step(int kind, int n_tensors, float* const* params, float* const* grads, float* const* state1,
-                               float* const* state2, const int64_t* sizes, const int64_t* steps, const int32_t* first, float lr,
+                               float* const* state2, const int64_t* sizes, const int64_t* steps, const int64_t* steps_dev,
+                               const int32_t* first, float lr,
                                float weight_decay, float momentum, float beta1, float beta2, float eps, float alpha,
                                const double* sumsq, float max_norm, int zero_grads, void* stream) {
   KTUP_REQUIRE(kind >= KTUP_OPT_SGD && kind <= KTUP_OPT_RMSPROP, "ktup_optim_step: unknown optimizer kind %d", kind);
@@ -206,7 +219,7 @@ extern "C" int ktup_optim_step(int kind, int n_tensors, float* const* params, fl
                        (kind == KTUP_OPT_SGD && momentum != 0.f);
     const bool need2 = kind == KTUP_OPT_ADAM || (kind == KTUP_OPT_RMSPROP && momentum > 0.f);
     KTUP_REQUIRE((!need1 || T.s1[i]) && (!need2 || T.s2[i]), "ktup_optim_step: tensor %d: optimizer state missing", i);
-    if (kind == KTUP_OPT_ADAM) {
+    if (kind == KTUP_OPT_ADAM && !steps_dev) {
       KTUP_REQUIRE(steps && steps[i] >= 1, "ktup_optim_step: Adam needs the (already incremented) step count of tensor %d", i);
       const double t = (double)steps[i];
       T.bc1[i] = (float)(1.0 - pow((double)beta1, t));
@@ -220,10 +233,10 @@ extern "C" int ktup_optim_step(int kind, int n_tensors, float* const* params, fl
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid(grid_for(nchunks, 256 * 8)), block(256);
   switch (kind) {
-    case KTUP_OPT_SGD: hipLaunchKernelGGL(step_kernel<KTUP_OPT_SGD>, grid, block, 0, st, T, h, sumsq); break;
-    case KTUP_OPT_ADAGRAD: hipLaunchKernelGGL(step_kernel<KTUP_OPT_ADAGRAD>, grid, block, 0, st, T, h, sumsq); break;
-    case KTUP_OPT_ADAM: hipLaunchKernelGGL(step_kernel<KTUP_OPT_ADAM>, grid, block, 0, st, T, h, sumsq); break;
-    default: hipLaunchKernelGGL(step_kernel<KTUP_OPT_RMSPROP>, grid, block, 0, st, T, h, sumsq); break;
+    case KTUP_OPT_SGD: hipLaunchKernelGGL(step_kernel<KTUP_OPT_SGD>, grid, block, 0, st, T, h, sumsq, steps_dev); break;
+    case KTUP_OPT_ADAGRAD: hipLaunchKernelGGL(step_kernel<KTUP_OPT_ADAGRAD>, grid, block, 0, st, T, h, sumsq, steps_dev); break;
+    case KTUP_OPT_ADAM: hipLaunchKernelGGL(step_kernel<KTUP_OPT_ADAM>, grid, block, 0, st, T, h, sumsq, steps_dev); break;
+    default: hipLaunchKernelGGL(step_kernel<KTUP_OPT_RMSPROP>, grid, block, 0, st, T, h, sumsq, steps_dev); break;
   }
   return check_launch("ktup_optim_step");
 }

@@ -37,6 +37,8 @@ class FusedOptimizer(object):
         self._sumsq = None
         self._plan = None
         self._fresh = []
+        self._dev_steps = None                   # Adam: step counts in device memory (the launch is then graph-replayable)
+        self._dev_steps_for = None
 
     # ---- torch.optim surface the trainer uses
     def zero_grad(self):
@@ -50,6 +52,7 @@ class FusedOptimizer(object):
     def load_state_dict(self, sd):
         self.optimizer.load_state_dict(sd)
         self._plan = None                        # the state tensors were replaced
+        self._dev_steps_for = None
 
     @property
     def param_groups(self):
@@ -109,6 +112,13 @@ class FusedOptimizer(object):
         if self.kind == 0 and group['momentum'] != 0:
             firsts = [1 if f else 0 for f in self._fresh]
             self._fresh = [False] * n
+        steps_dev = None
+        if self.kind == 2:                                      # device copy of the counters, advanced by a (capturable) launch
+            if self._dev_steps_for != key[:-1]:
+                self._dev_steps = torch.tensor([s - 1 for s in steps], dtype=torch.int64, device=dev)
+                self._dev_steps_for = key[:-1]
+            self._dev_steps.add_(1)
+            steps_dev = self._dev_steps.data_ptr()
         sumsq = None
         if max_norm is not None and max_norm > 0:
             if self._sumsq is None or self._sumsq.device != dev:
@@ -116,7 +126,8 @@ class FusedOptimizer(object):
             sumsq = self._sumsq.data_ptr()
             L.call('ktup_optim_gradnorm', n, grads, sizes, sumsq, stream)
         betas = group.get('betas', (0.9, 0.999))
-        L.call('ktup_optim_step', self.kind, n, params, grads, s1, s2, sizes, _arr(ctypes.c_int64, steps), _arr(ctypes.c_int32, firsts),
+        L.call('ktup_optim_step', self.kind, n, params, grads, s1, s2, sizes, _arr(ctypes.c_int64, steps), steps_dev,
+               _arr(ctypes.c_int32, firsts),
                float(group['lr']), float(group['weight_decay']), float(group.get('momentum', 0.0)), float(betas[0]), float(betas[1]),
                float(group.get('eps', 0.0)), float(group.get('alpha', 0.0)), sumsq, float(max_norm) if sumsq is not None else 0.0,
                int(bool(zero_grads)), stream)
@@ -142,9 +153,10 @@ class FusedOptimizer(object):
         return self._plan
 
     def graph_safe(self):
-        """True when a step has no host-computed, step-dependent launch arguments (Adam's bias corrections are) and can
-        therefore be replayed from a captured HIP graph."""
-        return self.kind != 2
+        """True when a step has no host-computed, step-dependent launch arguments and can therefore be replayed from a
+        captured HIP graph: always, now that Adam's step counts are also kept in device memory (bias corrections are
+        evaluated by the kernel)."""
+        return True
 
     def bump_steps(self):
         """Advance the per-parameter step counters like one clip_and_step would (used when the launches are replayed from

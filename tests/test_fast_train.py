@@ -27,7 +27,7 @@ def build(tmp_path, optimizer, gumbel):
     return FLAGS, m, ModelTrainer(m, logging.getLogger('ft'), 10, FLAGS), (NU, NI, NE, NR)
 
 
-@pytest.mark.parametrize('optimizer', ['Adagrad', 'SGD'])
+@pytest.mark.parametrize('optimizer', ['Adagrad', 'SGD', 'Adam'])
 def test_fast_steps_match_the_autograd_route(tmp_path, optimizer):
     from jTransUP.utils import loss
     from jTransUP.utils.fast_train import JointStepper
@@ -70,8 +70,10 @@ def test_fast_steps_match_the_autograd_route(tmp_path, optimizer):
             # stray element per table is tolerated, bounded by a fraction of one learning-rate-sized update
             err = (b - a).abs()
             bad = err > 2e-6 + 2e-5 * a.abs()
-            assert float(bad.float().mean()) <= 2e-3 and float(err.max()) <= 1e-3 * 0.05, \
+            # (Adam's m / sqrt(v) does the same wherever a gradient is itself rounding noise: a few more strays, same bound)
+            assert float(bad.float().mean()) <= (2e-2 if optimizer == 'Adam' else 2e-3) and float(err.max()) <= 1e-3 * 0.05, \
                 '%s after step %d: %d elements off, max %.3g' % (k, step, int(bad.sum()), float(err.max()))
+    assert fast._graphs                      # every optimizer kind replays from graphs (Adam: device-resident step counts)
     # the pad entity row never moves
     assert float(m2.ent_embeddings.weight[m2.ent_total - 1].abs().sum()) == 0.0
 

@@ -45,10 +45,10 @@ def train_loop(FLAGS, model, trainer, train_dataset, eval_datasets, entity_total
     if FLAGS.filter_wrong_corrupted:
         all_head_dicts = [train_head_dict] + [d[4] for d in eval_datasets]
         all_tail_dicts = [train_tail_dict] + [d[5] for d in eval_datasets]
-    # TransE / TransH: the step body below as a handful of C-ABI launches (utils/fast_train.py KGStepper), optionally with the
+    # TransE / TransH / TransR: the step body below as a handful of C-ABI launches (utils/fast_train.py KGStepper), optionally with the
     # triples and the corruption sampling on the device (-device_sampling)
     stepper = feed = sampler = None
-    if D.USE_CUDA and FLAGS.model_type in ('transe', 'transh') and trainer.fused is not None \
+    if D.USE_CUDA and FLAGS.model_type in ('transe', 'transh', 'transr') and trainer.fused is not None \
             and os.environ.get('KTUP_FAST_TRAIN', '1') != '0':
         from jTransUP.utils.fast_train import DeviceFeeder, KGStepper
         stepper = KGStepper(model, trainer, FLAGS, FLAGS.batch_size)

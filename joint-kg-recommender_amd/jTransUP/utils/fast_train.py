@@ -332,16 +332,20 @@ class RecStepper(_StepperBase):
 
 
 class KGStepper(_StepperBase):
-    """KG-only driver (knowledge_representation.py:176-211) for TransE / TransH: marginLoss + normLoss(entity rows of the
-    positive and negative triples) + normLoss(relation rows) (+ orthogonalLoss(rel, norm) rows for TransH)."""
+    """KG-only driver (knowledge_representation.py:176-211) for TransE / TransH / TransR: marginLoss + normLoss(entity rows
+    of the positive and negative triples) + normLoss(relation rows) (+ orthogonalLoss(rel, norm) rows for TransH)."""
     KINDS = ('kg',)
     N_IDS = {'kg': 6}
 
     def _setup(self, FLAGS, f32, i64):
         model, B = self.m, self.B
         self.transh = hasattr(model, 'norm_embeddings')
+        self.transr = hasattr(model, 'proj_embeddings')
         E, R = model.ent_embeddings.weight, model.rel_embeddings.weight
-        self.tabs = (E, R, model.norm_embeddings.weight) if self.transh else (E, R)
+        self.tabs = (E, R, model.norm_embeddings.weight) if self.transh else (E, R, model.proj_embeddings.weight) if self.transr else (E, R)
+        if self.transr:             # scratch of the relation-bucketed forward (K4)
+            nbytes = L.load().ktup_score_transr_workspace_bytes(2 * B, R.shape[0])
+            self.rws = torch.empty((nbytes + 3) // 4, dtype=torch.int32, device=self.dev)
         self.h2, self.t2, self.r2 = torch.zeros(2 * B, **i64), torch.zeros(2 * B, **i64), torch.zeros(2 * B, **i64)
         self.ht4 = torch.zeros(4 * B, **i64)
 
@@ -356,6 +360,10 @@ class KGStepper(_StepperBase):
             n_rel = min(R.shape[0], Rn.shape[0])
             calls.append(b('ktup_score_transh_fwd', _p(E), E.stride(0), _p(R), R.stride(0), _p(Rn), Rn.stride(0), n_rel, d, _p(self.h2),
                            _p(self.t2), _p(self.r2), 2 * B, self.l1, _p(self.score), st))
+        elif self.transr:
+            M = self.tabs[2]
+            calls.append(b('ktup_score_transr_fwd', _p(E), E.stride(0), _p(R), R.stride(0), _p(M), M.stride(0), min(R.shape[0], M.shape[0]),
+                           d, _p(self.h2), _p(self.t2), _p(self.r2), 2 * B, self.l1, _p(self.score), _p(self.rws), st))
         else:
             calls.append(b('ktup_score_transe_fwd', _p(E), E.stride(0), _p(R), R.stride(0), R.shape[0], d, _p(self.h2), _p(self.t2), _p(self.r2),
                            2 * B, self.l1, _p(self.score), st))
@@ -365,6 +373,9 @@ class KGStepper(_StepperBase):
                         _p(self.r2), 2 * B, self.l1, _p(self.gscore), _p(E.grad), _p(R.grad), _p(Rn.grad), st),
                       b('ktup_reg_orth_fused', _p(R), R.stride(0), _p(Rn), Rn.stride(0), d, _p(self.r2), 2 * B, _p(self.one),
                         _p(self.loss[1:]), _p(R.grad), _p(Rn.grad), st)]
+        elif self.transr:
+            calls.append(b('ktup_score_transr_bwd', _p(E), E.stride(0), _p(R), R.stride(0), _p(M), M.stride(0), d, _p(self.h2), _p(self.t2),
+                           _p(self.r2), 2 * B, self.l1, _p(self.gscore), _p(E.grad), _p(R.grad), _p(M.grad), st))
         else:
             calls.append(b('ktup_score_transe_bwd', _p(E), E.stride(0), _p(R), R.stride(0), d, _p(self.h2), _p(self.t2), _p(self.r2),
                            2 * B, self.l1, _p(self.gscore), _p(E.grad), _p(R.grad), st))

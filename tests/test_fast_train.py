@@ -186,15 +186,16 @@ def test_rec_stepper_matches_the_autograd_route(tmp_path, model_type):
     assert 'rec' in fast._graphs or not fast.use_graphs
 
 
-@pytest.mark.parametrize('model_type', ['transe', 'transh'])
+@pytest.mark.parametrize('model_type', ['transe', 'transh', 'transr'])
 def test_kg_stepper_matches_the_autograd_route(tmp_path, model_type):
     """knowledge_representation.py:176-211 step body vs KGStepper."""
-    from jTransUP.models import transE, transH
+    from jTransUP.models import transE, transH, transR
     from jTransUP.utils import loss
     from jTransUP.utils.fast_train import KGStepper
     NE, NR, D, B = 70, 6, 36, 64
     torch.manual_seed(4)
-    mk = (lambda: transH.TransHModel(True, D, NE, NR)) if model_type == 'transh' else (lambda: transE.TransEModel(False, D, NE, NR))
+    mk = {'transh': lambda: transH.TransHModel(True, D, NE, NR), 'transe': lambda: transE.TransEModel(False, D, NE, NR),
+          'transr': lambda: transR.TransRModel(False, D, NE, NR)}[model_type]
     m1, m2 = mk(), mk()
     m2.load_state_dict(copy.deepcopy(m1.state_dict()))
     FLAGS, tr1 = _trainer_for(tmp_path, model_type, m1, 'SGD')

@@ -257,6 +257,55 @@ def gather_stress_bench(device, scale=1000, reps=20):
     return out
 
 
+def variants_bench(device, D_, i2e_d, X, reps=10, inner=8):
+    """The other kernels of the path at the headline's sizes (716,800 pairs / 307,200 triples per launch): L1 distance (7 of
+    the reference's recipes pass -L1_flag), the ST-Gumbel gate (transup.sh), TUP, TransE, TransR, BPRMF.  Each variant is
+    captured into a HIP graph of `inner` launches and replayed, so the figure is kernel time, not Python time."""
+    from jTransUP.hip import ops
+    U, I, E, P, Pn, R, Rn = (D_[k] for k in ('U', 'I', 'E', 'P', 'Pn', 'R', 'Rn'))
+    u, i, h, t, r = (X[k] for k in ('u', 'i', 'h', 't', 'r'))
+    gen = torch.Generator(device=device); gen.manual_seed(5)
+    M = torch.randn(NR, D * D, generator=gen, device=device) * 0.1
+    U64 = F.normalize(torch.randn(NU, 64, generator=gen, device=device), dim=1)
+    I64 = F.normalize(torch.randn(NI, 64, generator=gen, device=device), dim=1)
+    ws = ops.pref_workspace(P, Pn, R, Rn)
+    ws_tup = ops.pref_workspace(P, Pn)
+    PH, OFF = ops.GUMBEL_PHILOX, ops.GUMBEL_OFF
+    cases = [
+        ('ktup_rec_soft_L2', lambda: ops.score_ktup(U, I, E, P, Pn, R, Rn, i2e_d, u, i, False, ws=ws), REC_ROWS, BYTES_REC),   # the headline kernel, for calibration
+        ('ktup_rec_soft_L1', lambda: ops.score_ktup(U, I, E, P, Pn, R, Rn, i2e_d, u, i, True, ws=ws), REC_ROWS, BYTES_REC),
+        ('ktup_rec_hard_L2', lambda: ops.score_ktup(U, I, E, P, Pn, R, Rn, i2e_d, u, i, False, PH, None, 7, 0, ws=ws), REC_ROWS, BYTES_REC),
+        ('ktup_rec_hard_L1', lambda: ops.score_ktup(U, I, E, P, Pn, R, Rn, i2e_d, u, i, True, PH, None, 7, 0, ws=ws), REC_ROWS, BYTES_REC),
+        ('tup_soft_L2', lambda: ops.score_tup(U, I, P, Pn, u, i, False, OFF, ws=ws_tup), REC_ROWS, 8 * D + 20),
+        ('tup_hard_L1', lambda: ops.score_tup(U, I, P, Pn, u, i, True, PH, None, 7, 0, ws=ws_tup), REC_ROWS, 8 * D + 20),
+        ('transh_L1', lambda: ops.score_transh(E, R, Rn, h, t, r, True), KG_ROWS, BYTES_KG),
+        ('transe_L2', lambda: ops.score_transe(E, R, h, t, r, False), KG_ROWS, BYTES_KG),
+        ('transe_L1', lambda: ops.score_transe(E, R, h, t, r, True), KG_ROWS, BYTES_KG),
+        ('transr_L2', lambda: ops.score_transr(E, R, M, h, t, r, False), KG_ROWS, BYTES_KG),
+        ('bprmf_d64', lambda: ops.score_bprmf(U64, I64, u, i), REC_ROWS, 8 * 64 + 20),
+    ]
+    out = {}
+    with torch.no_grad():
+        for name, f, rows, bpr in cases:
+            f(); torch.cuda.synchronize(device)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                for _ in range(inner):
+                    f()
+            g.replay(); torch.cuda.synchronize(device)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(reps):
+                g.replay()
+            b.record(); torch.cuda.synchronize(device)
+            ms = a.elapsed_time(b) / (reps * inner)
+            out[name] = {'ms_per_launch': round(ms, 5), 'rows_per_launch': rows, 'Grows_per_s': round(rows / ms / 1e6, 3),
+                         'frac_of_hbm_peak': round(rows * bpr / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 3)}
+    out['note'] = ('forward kernels, tables cache-resident (ml1m shape); frac = algorithmic bytes per row x rows / time / 8 TB/s; '
+                   'time = graph replay of back-to-back launches, i.e. including the inter-kernel gap the HIP-event figure of the headline excludes')
+    return out
+
+
 def hbm_traffic(kind):
     """HBM bytes per launch from the committed PMC passes (profiles/r01_hbm_traffic.json: separate FETCH_SIZE / WRITE_SIZE
     runs of this same command, read side doubled per MI355X_MICROARCH.md); None when the file is absent."""
@@ -358,7 +407,7 @@ def main():
                                '716800 (u,i) pairs + 307200 (h,t,r) triples (= 2000 batches of 512 at joint_ratio 0.7), '
                                'tables replicated per GPU', 'rows_per_step_per_gpu': REC_ROWS + KG_ROWS,
                    'users': NU, 'items': NI, 'entities': NE, 'relations': NR, 'd': D},
-        'roofline': {'bound': 'hbm', 'kernel': 'pref_fwd_mc_kernel<McGeom<25,5,true>> (KTUP rec forward, K6)',
+        'roofline': {'bound': 'hbm', 'kernel': 'pref_fwd_mc_kernel<McGeom<25,5,true,false>,false> (KTUP rec forward, K6)',
                      'achieved': REC_ROWS * BYTES_REC / (rec_ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': REC_ROWS * BYTES_REC / (rec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 'traffic': hbm_traffic('ktup_rec_forward'),
                      'bytes_per_row': BYTES_REC, 'rows_per_launch': REC_ROWS, 'ms_per_launch': rec_ms,
@@ -370,6 +419,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_extras:
         out['eval_all_item_hit10'] = eval_bench(device)       # before the CPU baseline: its OpenMP pools disturb host-side timing
         out['train_step_b512'] = train_step_bench(device)
+        out['variants'] = variants_bench(device, D_, i2e_d, X)
         out['gather_stress_x1000'] = gather_stress_bench(device)
         out['cpu_baseline'] = cpu_baseline(W, i2e, idx)
     elif rank == 0:

@@ -77,7 +77,9 @@ struct McArgs {
   float* score;
 };
 
-template <typename G>
+// L1: the distance is compile-time too -- with a run-time flag the compiler evaluates |z| AND z^2 for every coordinate and
+// selects (v_and + v_cndmask per element: ~70 of a tile's ~330 VALU instructions).
+template <typename G, bool L1>
 __global__ __launch_bounds__(G::NW * 64) void pref_fwd_mc_kernel(McArgs a) {
   KTUP_RESOLVE_GUMBEL(a);
   constexpr int NCH = G::NCH, NP = G::NP, KG = G::KG, CT = G::CT, PTF = G::PTF, J = G::J, TOTAL = G::TOTAL;
@@ -144,7 +146,7 @@ __global__ __launch_bounds__(G::NW * 64) void pref_fwd_mc_kernel(McArgs a) {
   const v4* tab = AlogS + j * PITCHA4 + kq;                      // stage-1 A operand
   const float* tn0 = CnS + kq * TPITCH + j;
   const float* tr0 = ArS + kq * TPITCH + j;
-  const bool l1 = a.l1 != 0;
+  constexpr bool l1 = L1;
   const int64_t ntiles = (a.n + 15) / 16;
   const int64_t wstride = (int64_t)gridDim.x * G::NW;
   bool first = true;
@@ -417,15 +419,20 @@ __global__ __launch_bounds__(G::NW * 64) void pref_fwd_mc_kernel(McArgs a) {
   }
 }
 
-template <typename G>
-int launch_mc(const McArgs& a, hipStream_t st, const char* name) {
+template <typename G, bool L1>
+int launch_mc_l(const McArgs& a, hipStream_t st, const char* name) {
   static_assert(G::NW >= 4, "LDS budget");
   constexpr size_t lds = G::TABLE_BYTES + (size_t)G::NW * G::WAVE_BYTES;
-  (void)hipFuncSetAttribute((const void*)pref_fwd_mc_kernel<G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  (void)hipFuncSetAttribute((const void*)pref_fwd_mc_kernel<G, L1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   const int64_t ntiles = (a.n + 15) / 16;
   const int grid = grid_for((ntiles + G::NW - 1) / G::NW, 256);
-  hipLaunchKernelGGL((pref_fwd_mc_kernel<G>), dim3(grid), dim3(G::NW * 64), lds, st, a);
+  hipLaunchKernelGGL((pref_fwd_mc_kernel<G, L1>), dim3(grid), dim3(G::NW * 64), lds, st, a);
   return check_launch(name);
+}
+
+template <typename G>
+int launch_mc(const McArgs& a, hipStream_t st, const char* name) {
+  return a.l1 ? launch_mc_l<G, true>(a, st, name) : launch_mc_l<G, false>(a, st, name);
 }
 
 template <int NCH, int NP>

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
 #include <cstdint>
 
@@ -81,12 +82,15 @@ float run(const float* table, int64_t pitch, int d, const int32_t* ids, int64_t 
   return ms / reps;
 }
 
-int main() {
+int main(int argc, char** argv) {
+  const bool big = argc > 1 && std::string(argv[1]) == "big";   // working sets beyond L2 + Infinity Cache only
   const int d = 100;
   const int64_t nrows = 2150400;   // 3 x 716800 row reads, like one KTUP launch
   struct Cfg { const char* name; int64_t trows; int64_t pitch; };
-  const Cfg cfgs[] = {{"1.3MB p100", 3240, 100}, {"9.7MB p100", 24248, 100}, {"9.7MB p128", 24248, 128}, {"410MB p100", 1024000, 100}};
+  const Cfg cfgs[] = {{"1.3MB p100", 3240, 100}, {"9.7MB p100", 24248, 100}, {"9.7MB p128", 24248, 128}, {"410MB p100", 1024000, 100},
+                      {"9.7GB p100", 24248000, 100}, {"12.4GB p128", 24248000, 128}};
   for (const Cfg& c : cfgs) {
+    if (big ? c.trows < 1024000 : c.trows > 1024000) continue;
     float* table; int32_t* ids; float* out;
     hipMalloc(&table, c.trows * c.pitch * 4);
     hipMemset(table, 0, c.trows * c.pitch * 4);

@@ -11,6 +11,7 @@ import os
 
 import numpy as np
 import torch
+import torch.distributed as dist
 import torch.nn as nn
 from tqdm import tqdm
 
@@ -52,6 +53,25 @@ def flat_keys(eval_iter):
 _INDEX_CACHE = {}
 
 
+def setup_replicas(FLAGS):
+    """torchrun (WORLD_SIZE > 1): one process per GPU, replicas with ONE gradient all-reduce per step (config 4, see
+    utils/fast_train.py).  Every rank draws the same global batches (same -seed) and scores its slice; evaluation batches
+    are dealt to the ranks; ranks > 0 log and checkpoint under their own experiment name.  -> (rank, world)."""
+    from jTransUP import parallel
+    rank, world = parallel.init_distributed()
+    if world > 1:
+        if rank > 0:
+            FLAGS.experiment_name = '%s.rank%d' % (FLAGS.experiment_name, rank)
+        if FLAGS.seed == 0:
+            raise ValueError('data-parallel runs need a fixed -seed (every rank must draw the same batches)')
+    return rank, world
+
+
+def require_stepper_for_replicas(stepper, which):
+    if dist.is_initialized() and dist.get_world_size() > 1 and stepper is None:
+        raise NotImplementedError('data-parallel training runs through the GPU-resident step (%s)' % which)
+
+
 def rank_index(eval_iter, eval_dict, all_dicts):
     """The CSR filter / gold sets of an evaluation pass are a function of the datasets only: built once per run and reused by
     every periodic evaluation (building them costs ~20x the device pass at ml1m size)."""
@@ -65,7 +85,6 @@ def rank_index(eval_iter, eval_dict, all_dicts):
 
 def _my_batches(n_batches):
     """Evaluation batches of this rank under torchrun (batch b goes to rank b % world); every batch in a single process."""
-    import torch.distributed as dist
     if dist.is_initialized() and dist.get_world_size() > 1:
         return range(dist.get_rank(), n_batches, dist.get_world_size()), dist.get_world_size()
     return range(n_batches), 1
@@ -75,7 +94,6 @@ def _gather_batches(per_batch, n_batches, world):
     """{batch index: result} of every rank -> list in batch order on every rank."""
     if world == 1:
         return [per_batch[b] for b in range(n_batches)]
-    import torch.distributed as dist
     parts = [None] * world
     dist.all_gather_object(parts, per_batch)
     merged = {}

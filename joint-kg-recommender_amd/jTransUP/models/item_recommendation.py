@@ -44,6 +44,7 @@ def train_loop(FLAGS, model, trainer, train_dataset, eval_datasets, user_total, 
             sampler.set_rating_dicts(user_total, item_total, all_dicts)
             feed = DeviceFeeder(train_list, FLAGS.batch_size, D.DEV, FLAGS.negtive_samples, seed=FLAGS.seed)
             logger.info('Training data and negative sampling are device-resident (-device_sampling).')
+    D.require_stepper_for_replicas(stepper, 'transup, bprmf')
     logger.info('Training.')
 
     def do_eval(totals):
@@ -87,6 +88,7 @@ def train_loop(FLAGS, model, trainer, train_dataset, eval_datasets, user_total, 
 
 
 def run(only_forward=False):
+    D.setup_replicas(FLAGS)
     if FLAGS.seed != 0:
         random.seed(FLAGS.seed)
         torch.manual_seed(FLAGS.seed)

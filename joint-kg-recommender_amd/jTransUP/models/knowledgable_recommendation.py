@@ -101,9 +101,7 @@ def train_loop(FLAGS, model, trainer, rating_train_dataset, triple_train_dataset
             rec_feed = DeviceFeeder(rating_train_list, FLAGS.batch_size, D.DEV, FLAGS.negtive_samples, seed=FLAGS.seed)
             kg_feed = DeviceFeeder(triple_train_list, FLAGS.batch_size, D.DEV, FLAGS.negtive_samples, seed=FLAGS.seed + 1)
             logger.info('Training data and negative sampling are device-resident (-device_sampling).')
-    import torch.distributed as dist
-    if dist.is_initialized() and dist.get_world_size() > 1 and stepper is None:
-        raise NotImplementedError('data-parallel training runs through the GPU-resident step (jtransup, -noshare_embeddings)')
+    D.require_stepper_for_replicas(stepper, 'jtransup, -noshare_embeddings')
     logger.info('Training.')
 
     def do_eval(totals):
@@ -199,16 +197,7 @@ def train_loop(FLAGS, model, trainer, rating_train_dataset, triple_train_dataset
 
 
 def run(only_forward=False):
-    # torchrun (WORLD_SIZE > 1): one process per GPU, replicas with one gradient all-reduce per step (config 4, see
-    # utils/fast_train.py).  Every rank draws the same global batches (same seed) and evaluates; ranks > 0 log and
-    # checkpoint under their own experiment name.
-    from jTransUP import parallel
-    rank, world = parallel.init_distributed()
-    if world > 1:
-        if rank > 0:
-            FLAGS.experiment_name = '%s.rank%d' % (FLAGS.experiment_name, rank)
-        if FLAGS.seed == 0:
-            raise ValueError('data-parallel runs need a fixed -seed (every rank must draw the same batches)')
+    D.setup_replicas(FLAGS)
     if FLAGS.seed != 0:
         random.seed(FLAGS.seed)
         torch.manual_seed(FLAGS.seed)

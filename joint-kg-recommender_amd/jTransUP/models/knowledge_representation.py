@@ -62,6 +62,7 @@ def train_loop(FLAGS, model, trainer, train_dataset, eval_datasets, entity_total
             sampler.set_triples(entity_total, relation_total, known)
             feed = DeviceFeeder(train_list, FLAGS.batch_size, D.DEV, FLAGS.negtive_samples, seed=FLAGS.seed)
             logger.info('Training data and negative sampling are device-resident (-device_sampling).')
+    D.require_stepper_for_replicas(stepper, 'transe, transh, transr')
     logger.info('Training.')
 
     def do_eval(totals):
@@ -113,6 +114,7 @@ def train_loop(FLAGS, model, trainer, train_dataset, eval_datasets, entity_total
 
 
 def run(only_forward=False):
+    D.setup_replicas(FLAGS)
     if FLAGS.seed != 0:
         random.seed(FLAGS.seed)
         torch.manual_seed(FLAGS.seed)

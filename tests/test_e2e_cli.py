@@ -122,3 +122,30 @@ def test_single_task_cli_device_sampling(dataset, script, extra, metric):
     losses = [float(x) for x in re.findall(r'train loss:(\d+\.\d+)', log)]
     assert len(losses) >= 2 and all(l == l and l < 1e4 for l in losses)
     assert len(re.findall(metric, log)) >= 3
+
+
+@pytest.mark.parametrize('script,extra,metric,port', [
+    ('run_item_recommendation.py', ['-model_type', 'transup', '-num_preferences', '6', '-use_st_gumbel', '-rec_test_files', 'valid.dat'],
+     r'f1:\d\.\d+, p:\d\.\d+, r:\d\.\d+, hit:\d\.\d+, ndcg:\d\.\d+', '29541'),
+    ('run_knowledge_representation.py', ['-model_type', 'transe', '-L1_flag', '-kg_test_files', 'valid.dat'], r'avg hit:\d\.\d+, avg mean rank:\d+\.\d+',
+     '29542'),
+])
+def test_single_task_cli_data_parallel_torchrun(dataset, script, extra, metric, port):
+    """The rec-only and KG-only drivers as two replicas under torchrun (gloo hook: both ranks share this box's GPU)."""
+    data = str(dataset)
+    logs = os.path.join(data, 'log')
+    name = 'dp-' + extra[1]
+    env = dict(os.environ, KTUP_DIST_BACKEND='gloo')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', port, os.path.join(PKG, script), '-data_path', data, '-log_path', logs, '-dataset', 'ml1m',
+           '-experiment_name', name, '-nohas_visualization', '-batch_size', '32', '-embedding_size', '20', '-seed', '3',
+           '-eval_interval_steps', '10', '-training_steps', '25', '-early_stopping_steps_to_wait', '0', '-learning_rate', '0.05',
+           '-topn', '10'] + extra
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    log0 = open(os.path.join(logs, name + '.log')).read()
+    log1 = open(os.path.join(logs, name + '.rank1.log')).read()
+    assert 'GPU-resident training step enabled' in log0
+    m0, m1 = re.findall(metric, log0), re.findall(metric, log1)
+    assert len(m0) >= 3 and m0 == m1
+    assert re.findall(r'train loss:\d+\.\d+', log0) == re.findall(r'train loss:\d+\.\d+', log1)

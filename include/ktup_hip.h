@@ -199,6 +199,13 @@ int ktup_eval_gold_ranks(const float* scores, int64_t lds, int64_t nq, int64_t n
                          const int64_t* filt_off, const int32_t* filt_ids, const int64_t* gold_off,
                          const int32_t* gold_ids, int32_t* ranks, void* stream);
 
+/* K18b  utils/misc.py:232-248 + utils/evaluation.py:80-110 (ndcg_at_k, method 0): per query (f1, precision, recall,
+ * hit, ndcg) as 5 float64 from its ranked id list (`topn` entries, -1 padded as ktup_eval_topk_filtered writes them)
+ * and its gold ids (CSR, ASCENDING within a query).  precision divides by the number of valid entries, recall by
+ * |gold|, the NDCG ideal is the best ordering of the observed hits -- all as the reference computes them.        */
+int ktup_eval_rec_metrics(const int32_t* top_ids, int64_t nq, int topn, const int64_t* gold_off, const int32_t* gold_ids,
+                          double* out, void* stream);
+
 /* ------------------------------------------- row-sharded tables (new: the reference is single-device)
  * Device halves of the all-to-all lookup exchange for tables partitioned by `row % world_size`:
  * pack  : out[k,:] = table[ids[k],:]         owner side, rows a peer asked for -> contiguous send buffer

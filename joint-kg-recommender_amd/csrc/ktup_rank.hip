@@ -270,6 +270,47 @@ __global__ __launch_bounds__(256) void gold_ranks_chunked_kernel(const float* __
   }
 }
 
+// K18b  per-query recommendation metrics (utils/misc.py:232-248, utils/evaluation.py:80-110): hits of the ranked ids in
+// the gold set, precision = hits / len(list), recall = hits / |gold|, F1, hit flag and NDCG with method-0 weights
+// (1, 1, 1/log2(3), ...) whose ideal is the best ordering of the OBSERVED hits.  One thread per query, float64 like the
+// reference; the gold ids of a query are ascending (binary search).
+__global__ __launch_bounds__(64) void rec_metrics_kernel(const int32_t* __restrict__ top_ids, int64_t nq, int topn,
+                                                         const int64_t* __restrict__ gold_off,
+                                                         const int32_t* __restrict__ gold_ids, double* __restrict__ out) {
+  const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (b >= nq) return;
+  const int64_t g0 = gold_off[b], g1 = gold_off[b + 1];
+  int k = 0, hc = 0;
+  double dcg = 0.0;
+  for (int r = 0; r < topn; ++r) {
+    const int32_t id = top_ids[b * topn + r];
+    if (id < 0) continue;                       // -1 padding: the reference's list is simply shorter
+    // position in the reference's (shorter) list = number of valid entries before it; padding only ever trails
+    int64_t lo = g0, hi = g1;
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (gold_ids[mid] < id) lo = mid + 1; else hi = mid;
+    }
+    const bool hit = lo < g1 && gold_ids[lo] == id;
+    if (hit) {
+      hc += 1;
+      dcg += k == 0 ? 1.0 : 1.0 / log2((double)(k + 1));
+    }
+    k += 1;
+  }
+  double f1 = 0.0, p = 0.0, rc = 0.0, ndcg = 0.0;
+  if (hc > 0) {
+    p = (double)hc / (double)k;
+    rc = (double)hc / (double)(g1 - g0);
+    f1 = 2.0 * p * rc / (p + rc);
+    double ideal = 1.0;                         // hc hits in the first hc positions
+    for (int c = 1; c < hc; ++c) ideal += 1.0 / log2((double)(c + 1));
+    ndcg = dcg / ideal;
+  }
+  double* o = out + b * 5;
+  o[0] = f1; o[1] = p; o[2] = rc; o[3] = hc > 0 ? 1.0 : 0.0; o[4] = ndcg;
+}
+
 constexpr int CHUNK_KEYS = 16384;  // 128 KB of keys per chunk
 
 // 0 = take the single-workgroup path; otherwise the chunk size.  KTUP_RANK_CHUNK=<keys> forces the chunked path (tests).
@@ -338,5 +379,16 @@ extern "C" int ktup_eval_gold_ranks(const float* scores, int64_t lds, int64_t nq
   if (int e = prep_lds((const void*)gold_ranks_kernel, n_cand, &bytes, name)) return e;
   hipLaunchKernelGGL(gold_ranks_kernel, dim3((unsigned)nq), dim3(256), bytes, (hipStream_t)stream, scores, lds, n_cand,
                      descending, filt_off, filt_ids, gold_off, gold_ids, ranks);
+  return check_launch(name);
+}
+
+extern "C" int ktup_eval_rec_metrics(const int32_t* top_ids, int64_t nq, int topn, const int64_t* gold_off,
+                                     const int32_t* gold_ids, double* out, void* stream) {
+  const char* name = "ktup_eval_rec_metrics";
+  KTUP_REQUIRE(nq >= 0 && topn > 0, "%s: bad sizes", name);
+  if (nq == 0) return KTUP_OK;
+  KTUP_REQUIRE(top_ids && gold_off && gold_ids && out, "%s: null pointer argument", name);
+  hipLaunchKernelGGL(rec_metrics_kernel, dim3((unsigned)((nq + 63) / 64)), dim3(64), 0, (hipStream_t)stream, top_ids, nq, topn,
+                     gold_off, gold_ids, out);
   return check_launch(name);
 }

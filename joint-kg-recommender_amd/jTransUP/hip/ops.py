@@ -462,6 +462,18 @@ def gold_ranks(scores, descending, gold_off, gold_ids, filt_off=None, filt_ids=N
     return ranks
 
 
+@torch.no_grad()
+def rec_metrics(top_ids, gold_off, gold_ids):
+    """(nq, 5) float64 device tensor of (f1, p, r, hit, ndcg) per ranked list (K18b); gold ids ascending per query."""
+    dev = _dev(top_ids)
+    if top_ids.dtype != torch.int32 or top_ids.dim() != 2 or not top_ids.is_contiguous():
+        raise L.KtupError('top_ids must be a contiguous (nq, topn) int32 device tensor')
+    nq, topn = top_ids.shape
+    out = torch.empty(nq, 5, dtype=torch.float64, device=dev)
+    L.call('ktup_eval_rec_metrics', _p(top_ids), nq, topn, _p(gold_off), _p(gold_ids), _p(out), _stream(dev))
+    return out
+
+
 # ------------------------------------------------------------------------------------------ sharded-table exchange halves
 @torch.no_grad()
 def pack_rows(table, ids):

@@ -114,9 +114,17 @@ def rec_eval_pass(FLAGS, score_fn, eval_iter, eval_dict, all_dicts, descending, 
         u_ids = eval_iter[b]
         scores = score_fn(ids(u_ids))
         per_batch[b] = evalRecProcess((u_ids, scores), eval_dict, all_dicts=all_dicts, descending=descending, topn=FLAGS.topn,
-                                      index=index, as_array=not want_rows)
+                                      index=index, as_array=False if want_rows else 'device')
         pbar.update(1)
     pbar.close()
+    if not want_rows and per_batch:               # metric columns stayed on the device: ONE copy back for the whole pass
+        order = list(per_batch)
+        host = torch.cat([per_batch[b] for b in order]).cpu().numpy()
+        at = 0
+        for b in order:
+            s, e = index.rows_of(eval_iter[b])
+            per_batch[b] = host[at:at + e - s][index.present_h[s:e]]
+            at += e - s
     parts = _gather_batches(per_batch, len(eval_iter), world)
     if want_rows:
         return [row for part in parts for row in part]

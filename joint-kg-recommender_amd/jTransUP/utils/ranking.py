@@ -111,7 +111,8 @@ def evalRecProcess(pred_scores, eval_dict, all_dicts=None, descending=True, num_
     """utils/misc.py:186-210.  Returns [[f1, p, r, hit, ndcg, (key, top_ids, gold)], ...] for the keys found in
     eval_dict.  `num_processes` / `queue_limit` are accepted and ignored (there is no process fan-out);
     `index` (a RankIndex over the pass's keys) avoids rebuilding the CSR sets per batch.  `as_array=True` (this build) returns
-    only the (n x 5) float64 metric columns -- what the training-time evaluation needs -- without building per-user rows."""
+    only the (n x 5) float64 metric columns -- what the training-time evaluation needs -- without building per-user rows;
+    `as_array='device'` leaves them on the device, one row per key of the batch (no host sync)."""
     keys, mat = _as_device_rows(pred_scores, _device())
     if len(keys) == 0:
         return []
@@ -119,10 +120,15 @@ def evalRecProcess(pred_scores, eval_dict, all_dicts=None, descending=True, num_
         index = RankIndex(keys, eval_dict, all_dicts, mat.device)
     s, e = index.rows_of(keys)
     f_off, f_ids = index.filter_slice(s, e)
-    top = ops.topk_filtered(mat, descending, topn, f_off, f_ids).cpu().numpy().astype(np.int64)
+    top = ops.topk_filtered(mat, descending, topn, f_off, f_ids)
+    if as_array:                                  # metrics on the device too (K18b): nothing but 5 doubles per key leaves it
+        g_off, g_ids = index.gold_slice(s, e)[:2]
+        cols = ops.rec_metrics(top, g_off, g_ids)
+        if as_array == 'device':                  # no host sync; the caller drops keys absent from eval_dict (index.present_h)
+            return cols
+        return cols.cpu().numpy()[index.present_h[s:e]]
+    top = top.cpu().numpy().astype(np.int64)
     f1, p, r, hit, ndcg = rec_metrics_batch(top, index, s)
-    if as_array:
-        return np.stack([f1, p, r, hit.astype(np.float64), ndcg], axis=1)[index.present_h[s:e]]
     out = []
     cols = zip(f1.tolist(), p.tolist(), r.tolist(), hit.tolist(), ndcg.tolist(), top.tolist(), keys, index.gold_sets[s:e],
                index.present_h[s:e].tolist())

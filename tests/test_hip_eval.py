@@ -280,3 +280,32 @@ def test_chunked_ranking_equals_lds_path(chunk, monkeypatch):
     want_top, want_ranks = _rank_oracle(scores, filt, gold, False, 10)
     np.testing.assert_array_equal(ops().topk_filtered(mat, False, 10, *args).cpu().numpy(), want_top)
     np.testing.assert_array_equal(ops().gold_ranks(mat, False, dv(g_off), dv(g_ids), *args).cpu().numpy(), want_ranks)
+
+
+def test_rec_metrics_on_device_match_host_and_golden(golden):
+    """K18b: (f1, p, r, hit, ndcg) per ranked list on the device == the host arithmetic (ranking.rec_metrics, itself pinned by
+    the golden ranking cases), incl. short lists (-1 padded), no hits, all hits, a single gold id."""
+    from jTransUP.utils import ranking as RK
+    rng = np.random.RandomState(2)
+    nq, nc, topn = 300, 500, 10
+    top = np.stack([rng.permutation(nc)[:topn] for _ in range(nq)]).astype(np.int32)
+    gold = [np.sort(rng.choice(nc, size=rng.randint(1, 40), replace=False)).astype(np.int32) for _ in range(nq)]
+    top[0, 4:] = -1; top[1, :] = -1; top[2, 1:] = -1
+    gold[3] = np.sort(top[3].copy()); gold[4] = top[4, :1].copy(); gold[5] = np.array([nc + 5], np.int32)
+    gold[0] = np.unique(np.concatenate([top[0, :2], [0]])).astype(np.int32)
+    g_off = np.concatenate([[0], np.cumsum([len(g) for g in gold])]).astype(np.int64)
+    got = ops().rec_metrics(dv(top), dv(g_off), dv(np.concatenate(gold))).cpu().numpy()
+    want = np.array([RK.rec_metrics([int(i) for i in row if i >= 0], set(g.tolist())) if (row >= 0).any() else (0, 0, 0, 0, 0)
+                     for row, g in zip(top, gold)], dtype=np.float64)
+    np.testing.assert_allclose(got, want, rtol=1e-12, atol=0)
+    assert got[3, 3] == 1 and got[3, 1] == 1.0 and got[3, 4] == 1.0 and got[5].sum() == 0
+    # the golden rec cases through the whole device pipeline
+    g = golden('ranking')
+    J = json.load(open(os.path.join(GOLDEN, 'ranking.json')))
+    nrec = g['rec.rows'].shape[0]
+    for b, c in enumerate(J['rec']):
+        desc = c.get('descending', False)
+        row = g['rec.bprmf_rows'][b - nrec] if desc else g['rec.rows'][b]
+        all_dicts = None if c['filter'] is None else [{7: set(c['filter'])}]
+        cols = RK.evalRecProcess([(7, row)], {7: set(c['gold'])}, all_dicts=all_dicts, descending=desc, topn=10, as_array=True)
+        np.testing.assert_allclose(cols[0], [c['f1'], c['p'], c['r'], c['hit'], c['ndcg']], rtol=1e-12, atol=0)

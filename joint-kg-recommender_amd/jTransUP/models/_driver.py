@@ -131,9 +131,10 @@ def rec_eval_pass(FLAGS, score_fn, eval_iter, eval_dict, all_dicts, descending, 
     return np.concatenate(parts, axis=0) if parts else np.zeros((0, 5))
 
 
-def kg_eval_pass(FLAGS, score_fn, eval_iter, eval_dict, all_dicts, descending, remap=None):
+def kg_eval_pass(FLAGS, score_fn, eval_iter, eval_dict, all_dicts, descending, remap=None, want_rows=True):
     """One pass over (t, r) or (h, r) keys: all-entity scores, filtered gold ranks (misc.py:61-146 semantics); batches are
-    dealt to the ranks like in rec_eval_pass."""
+    dealt to the ranks like in rec_eval_pass.  want_rows=False returns the (n x 2) array of (hit, rank) only: the ranks stay
+    on the device until ONE copy back at the end of the pass."""
     index = rank_index(eval_iter, eval_dict, all_dicts)
     mine, world = _my_batches(len(eval_iter))
     per_batch = {}
@@ -145,9 +146,21 @@ def kg_eval_pass(FLAGS, score_fn, eval_iter, eval_dict, all_dicts, descending, r
         scores = score_fn(ids(q), ids(r))
         keys = [tuple(k) for k in batch]
         per_batch[b] = evalKGProcess((keys, scores), eval_dict, all_dicts=all_dicts, descending=descending, topn=FLAGS.topn,
-                                     index=index)
+                                     index=index, as_array=False if want_rows else 'device')
         pbar.update(1)
     pbar.close()
+    if not want_rows:
+        order = [b for b in per_batch if torch.is_tensor(per_batch[b])]
+        host = torch.cat([per_batch[b] for b in order]).cpu().numpy() if order else np.zeros(0, np.int32)
+        at = 0
+        for b in per_batch:
+            n = per_batch[b].numel() if torch.is_tensor(per_batch[b]) else 0
+            ranks = host[at:at + n]
+            ranks = ranks[ranks >= 0]
+            per_batch[b] = np.stack([(ranks < FLAGS.topn).astype(np.float64), ranks.astype(np.float64)], axis=1)
+            at += n
+        parts = _gather_batches(per_batch, len(eval_iter), world)
+        return np.concatenate(parts, axis=0) if parts else np.zeros((0, 2))
     return [row for part in _gather_batches(per_batch, len(eval_iter), world) for row in part]
 
 
@@ -158,8 +171,9 @@ def summarize_rec(FLAGS, results, logger):
 
 
 def summarize_kg(FLAGS, head_results, tail_results, logger):
-    head_hit, head_rank = np.array([row[:2] for row in head_results]).mean(axis=0)
-    tail_hit, tail_rank = np.array([row[:2] for row in tail_results]).mean(axis=0)
+    as_cols = lambda res: res if isinstance(res, np.ndarray) else np.array([row[:2] for row in res])
+    head_hit, head_rank = as_cols(head_results).mean(axis=0)
+    tail_hit, tail_rank = as_cols(tail_results).mean(axis=0)
     logger.info('head hit:{:.4f}, head mean rank:{:.4f}, topn:{}.'.format(head_hit, head_rank, FLAGS.topn))
     logger.info('tail hit:{:.4f}, tail mean rank:{:.4f}, topn:{}.'.format(tail_hit, tail_rank, FLAGS.topn))
     hn, tn = len(head_results), len(tail_results)

@@ -20,8 +20,10 @@ FLAGS = gflags.FLAGS
 def evaluate(FLAGS, model, entity_total, relation_total, eval_head_iter, eval_tail_iter, eval_head_dict, eval_tail_dict,
              all_head_dicts, all_tail_dicts, logger, eval_descending=True, is_report=False):
     model.eval(); model.disable_grad()
-    head_results = D.kg_eval_pass(FLAGS, model.evaluateHead, eval_head_iter, eval_head_dict, all_head_dicts, eval_descending)
-    tail_results = D.kg_eval_pass(FLAGS, model.evaluateTail, eval_tail_iter, eval_tail_dict, all_tail_dicts, eval_descending)
+    head_results = D.kg_eval_pass(FLAGS, model.evaluateHead, eval_head_iter, eval_head_dict, all_head_dicts, eval_descending,
+                                  want_rows=is_report)
+    tail_results = D.kg_eval_pass(FLAGS, model.evaluateTail, eval_tail_iter, eval_tail_dict, all_tail_dicts, eval_descending,
+                                  want_rows=is_report)
     perf = D.summarize_kg(FLAGS, head_results, tail_results, logger)
     if is_report:
         D.report_kg(head_results, tail_results, logger)

@@ -166,8 +166,10 @@ def rec_metrics_batch(top, index, s):
 
 
 def evalKGProcess(pred_scores, eval_dict, all_dicts=None, descending=True, num_processes=None, topn=10, queue_limit=10,
-                  index=None):
-    """utils/misc.py:98-122.  Returns [(hit, rank, key, gold_id), ...] (0-based filtered ranks)."""
+                  index=None, as_array=False):
+    """utils/misc.py:98-122.  Returns [(hit, rank, key, gold_id), ...] (0-based filtered ranks).  `as_array='device'` (this
+    build) returns the int32 device vector of ranks instead, one per gold entry of the batch and -1 where the walk never
+    reaches the gold id -- what the training-time evaluation needs for its two means, without a host sync per batch."""
     keys, mat = _as_device_rows(pred_scores, _device())
     if len(keys) == 0:
         return []
@@ -178,7 +180,10 @@ def evalKGProcess(pred_scores, eval_dict, all_dicts=None, descending=True, num_p
     g_off, g_ids, g_off_h, g_ids_h = index.gold_slice(s, e)
     if len(g_ids_h) == 0:
         return []
-    ranks = ops.gold_ranks(mat, descending, g_off, g_ids, f_off, f_ids).cpu().numpy()
+    ranks = ops.gold_ranks(mat, descending, g_off, g_ids, f_off, f_ids)
+    if as_array == 'device':
+        return ranks[:int(g_off_h[-1])]          # g_ids is an open-ended view of the index: only this batch's entries were ranked
+    ranks = ranks.cpu().numpy()
     out = []
     for b, key in enumerate(keys):
         lo, hi = int(g_off_h[b]), int(g_off_h[b + 1])

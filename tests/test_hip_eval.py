@@ -309,3 +309,35 @@ def test_rec_metrics_on_device_match_host_and_golden(golden):
         all_dicts = None if c['filter'] is None else [{7: set(c['filter'])}]
         cols = RK.evalRecProcess([(7, row)], {7: set(c['gold'])}, all_dicts=all_dicts, descending=desc, topn=10, as_array=True)
         np.testing.assert_allclose(cols[0], [c['f1'], c['p'], c['r'], c['hit'], c['ndcg']], rtol=1e-12, atol=0)
+
+
+def test_eval_passes_fast_paths_equal_the_row_paths():
+    """_driver.{rec,kg}_eval_pass with want_rows=False (metric columns / ranks stay on the device, one copy back per pass)
+    report the same numbers as the per-row paths the reference's report mode uses."""
+    import types
+    from jTransUP.models import _driver as D
+    rng = np.random.RandomState(4)
+    FL = types.SimpleNamespace(topn=10)
+    nq, nc = 150, 700
+    scores = torch.from_numpy(rng.rand(nq, nc).astype(np.float32)).to(DEV)
+    # rec: integer user keys in batches of 64
+    users = list(range(nq))
+    gold = {u: set(rng.choice(nc, size=rng.randint(1, 20), replace=False).tolist()) for u in users if u % 7}
+    train = {u: set(rng.choice(nc, size=60, replace=False).tolist()) for u in users}
+    batches = [np.array(users[s:s + 64]) for s in range(0, nq, 64)]
+    fn = lambda u: scores[u]
+    rows = D.rec_eval_pass(FL, fn, batches, gold, [train], False, want_rows=True)
+    cols = D.rec_eval_pass(FL, fn, batches, gold, [train], False, want_rows=False)
+    assert cols.shape == (len(rows), 5)
+    np.testing.assert_allclose(cols, np.array([r[:5] for r in rows], dtype=np.float64), rtol=1e-12)
+    # kg: (t, r) keys, several golds per key, filters that contain some golds
+    keys = [(int(t), int(t) % 5) for t in range(nq)]
+    kgold = {k: set(rng.choice(nc, size=rng.randint(1, 6), replace=False).tolist()) for k in keys}
+    kfilt = {k: set(rng.choice(nc, size=40, replace=False).tolist()) | (set(list(kgold[k])[:1]) if k[0] % 3 == 0 else set()) for k in keys}
+    kb = [keys[s:s + 64] for s in range(0, nq, 64)]
+    kfn = lambda q, r: scores[q]
+    krows = D.kg_eval_pass(FL, kfn, kb, kgold, [kfilt], False, want_rows=True)
+    kcols = D.kg_eval_pass(FL, kfn, kb, kgold, [kfilt], False, want_rows=False)
+    assert kcols.shape == (len(krows), 2) and len(krows) > 0
+    want = np.array(sorted((float(h), float(rk)) for h, rk, _, _ in krows))
+    np.testing.assert_array_equal(np.array(sorted(map(tuple, kcols.tolist()))), want)

@@ -266,13 +266,18 @@ __global__ __launch_bounds__(256) void pairs_hard_kernel(HardArgs a) {
     int ps = 0;
     float best = -INFINITY;
     const uint64_t base = ((uint64_t)b * (uint64_t)a.n_cand + (uint64_t)gj) * (uint64_t)a.P;
+    uint64_t blk = ~0ull;              // the Philox block (4 draws) in hand: consecutive preferences share it
+    uint4 r = {0u, 0u, 0u, 0u};
     for (int p = 0; p < a.P; ++p) {
       float u;
       if (a.gumbel == KTUP_GUMBEL_INPUT) {
         u = a.uniform[base + p];
       } else {
         const uint64_t idx = base + p + a.offset;
-        const uint4 r = Philox(a.seed)(idx >> 2, 0x4b545550ull);
+        if ((idx >> 2) != blk) {
+          blk = idx >> 2;
+          r = Philox(a.seed)(blk, 0x4b545550ull);
+        }
         u = u01((idx & 3) == 0 ? r.x : (idx & 3) == 1 ? r.y : (idx & 3) == 2 ? r.z : r.w);
       }
       const float v = (ql[p] + lv[p * CT + lane]) + gumbel_from_uniform(u);

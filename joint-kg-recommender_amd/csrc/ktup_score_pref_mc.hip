@@ -60,7 +60,7 @@ struct McGeom {
   static constexpr int NOISE_F = HARD ? 16 * TROW : 0;   // HARD: Gumbel noise of the tile, [pair][preference]
   static constexpr size_t WAVE_BYTES = ((size_t)XT_F4 * 16 + 3 * 16 * 4 + (size_t)NOISE_F * 4 + 15) & ~(size_t)15;
   static constexpr int NW_MAX = (int)((160 * 1024 - TABLE_BYTES) / WAVE_BYTES);
-  static constexpr int NW = NW_MAX >= 16 ? 16 : (NW_MAX & ~3);
+  static constexpr int NW = NW_MAX >= 16 ? 16 : NW_MAX >= 4 ? (NW_MAX & ~3) : NW_MAX;   // < 2: the geometry does not fit (d = 256 with P > 20)
 };
 
 struct McArgs {
@@ -421,7 +421,7 @@ __global__ __launch_bounds__(G::NW * 64) void pref_fwd_mc_kernel(McArgs a) {
 
 template <typename G, bool L1>
 int launch_mc_l(const McArgs& a, hipStream_t st, const char* name) {
-  static_assert(G::NW >= 4, "LDS budget");
+  static_assert(G::NW >= 2, "LDS budget");
   constexpr size_t lds = G::TABLE_BYTES + (size_t)G::NW * G::WAVE_BYTES;
   (void)hipFuncSetAttribute((const void*)pref_fwd_mc_kernel<G, L1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   const int64_t ntiles = (a.n + 15) / 16;
@@ -432,7 +432,11 @@ int launch_mc_l(const McArgs& a, hipStream_t st, const char* name) {
 
 template <typename G>
 int launch_mc(const McArgs& a, hipStream_t st, const char* name) {
-  return a.l1 ? launch_mc_l<G, true>(a, st, name) : launch_mc_l<G, false>(a, st, name);
+  if constexpr (G::NW < 2) {
+    return 1;                                   // tables + one wave's tiles exceed the LDS: the caller's generic kernel runs
+  } else {
+    return a.l1 ? launch_mc_l<G, true>(a, st, name) : launch_mc_l<G, false>(a, st, name);
+  }
 }
 
 template <int NCH, int NP>
@@ -461,7 +465,7 @@ int pref_fwd_mc(const float* U, int64_t ldu, const float* I, int64_t ldi, const 
                 const float* Alog, const float* Ar, const float* Cn, int dp, int n_pref, int d, const int64_t* u_ids,
                 const int64_t* i_ids, int64_t n, int l1, int gumbel_mode, const float* uniform, uint64_t seed, uint64_t offset,
                 float* score, hipStream_t st, const char* name) {
-  if (n_pref > 32 || (d != 64 && d != 100 && d != 128)) return 1;
+  if (n_pref > 32 || (d != 64 && d != 100 && d != 128 && d != 256)) return 1;
   if ((ldu | ldi | lde) & 3) return 1;
   if ((ldu >> 2) > 0xffffffffll || (ldi >> 2) > 0xffffffffll || (lde >> 2) > 0xffffffffll) return 1;
   McArgs a;
@@ -475,6 +479,7 @@ int pref_fwd_mc(const float* U, int64_t ldu, const float* I, int64_t ldi, const 
   const int np = (n_pref + 3) / 4;
   if (d == 64) return launch_mc_np<16>(a, np, st, name);
   if (d == 100) return launch_mc_np<25>(a, np, st, name);
+  if (d == 256) return launch_mc_np<64>(a, np, st, name);     // config 5: 4 waves per CU (the x tiles fill the LDS)
   return launch_mc_np<32>(a, np, st, name);
 }
 

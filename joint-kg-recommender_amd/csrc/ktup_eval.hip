@@ -138,7 +138,8 @@ KTUP_DEV float4 load_cand4(const float* base, int64_t ld, int64_t row, int c, in
 }
 
 // MODE 0: z = A - C0 (TransE / TransR-projected)   MODE 1: TransH   MODE 2: TUP / KTUP soft gate
-template <int MODE>
+// L1: the distance kind is compile-time -- a run-time flag makes the compiler evaluate |z| AND z^2 per element and select.
+template <int MODE, bool L1>
 __global__ __launch_bounds__(256) void pairs_kernel(PairsArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float4* cand = reinterpret_cast<float4*>(smem);  // [NCV][nch4][CT]
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(256) void pairs_kernel(PairsArgs a) {
   __syncthreads();
   const sptr4 QW = as_scalar(a.QW);
   const int dq4 = nch4;
-  const bool l1 = a.l1 != 0;
+  constexpr bool l1 = L1;
   // this workgroup's slice of the queries (grid.y splits them), QB at a time per wave
   const int64_t nrange = range_hi - range_lo;
   const int64_t per = ((nrange + gridDim.y - 1) / gridDim.y + 4 * QB - 1) / (4 * QB) * (4 * QB);
@@ -191,8 +192,11 @@ __global__ __launch_bounds__(256) void pairs_kernel(PairsArgs a) {
 #pragma unroll
         for (int qi = 0; qi < QB; ++qi) {
           const float4 nqv = sld(QW, qrow[qi] + 2 * dq4 + c);
-          const float4 q1 = MODE == 2 ? sld(QW, qrow[qi] + dq4 + c) : f4zero();
-          s[qi] += dot4(q1 - c1, nqv + nc);
+          if constexpr (MODE == 2) {
+            s[qi] += dot4(sld(QW, qrow[qi] + dq4 + c) - c1, nqv + nc);
+          } else {                      // TransH: s = -(e . w); no zero operands for the compiler to keep (x + 0 is not x for -0)
+            s[qi] -= dot4(c1, nqv);
+          }
         }
       }
     }
@@ -203,7 +207,8 @@ __global__ __launch_bounds__(256) void pairs_kernel(PairsArgs a) {
       for (int qi = 0; qi < QB; ++qi) {
         const float4 av = sld(QW, qrow[qi] + c);
         float4 z = av - c0;
-        if (MODE >= 1) z = fma4(-s[qi], sld(QW, qrow[qi] + 2 * dq4 + c) + nc, z);
+        if constexpr (MODE == 2) z = fma4(-s[qi], sld(QW, qrow[qi] + 2 * dq4 + c) + nc, z);
+        if constexpr (MODE == 1) z = fma4(-s[qi], sld(QW, qrow[qi] + 2 * dq4 + c), z);
         acc[qi] += dist4(z, l1);
       }
     }
@@ -232,6 +237,7 @@ struct HardArgs {
   int64_t ldo;
 };
 
+template <bool L1>
 __global__ __launch_bounds__(256) void pairs_hard_kernel(HardArgs a) {
   KTUP_RESOLVE_GUMBEL(a);
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -258,7 +264,7 @@ __global__ __launch_bounds__(256) void pairs_hard_kernel(HardArgs a) {
   }
   __syncthreads();
   const sptr4 QW = as_scalar(a.QW);
-  const bool l1 = a.l1 != 0;
+  constexpr bool l1 = L1;
   const int64_t per = (a.nq + gridDim.y - 1) / gridDim.y;
   const int64_t qlo = (int64_t)blockIdx.y * per, qhi = min(a.nq, qlo + per);
   for (int64_t b = qlo + w; b < qhi; b += 4) {
@@ -415,11 +421,17 @@ int launch_pairs(const PairsArgs& a, hipStream_t st, const char* name, int nrel 
   const int ncv = MODE == 2 ? 3 : 1;
   const size_t lds = (size_t)ncv * (a.dq / 4) * CT * 16;
   if (lds > 160 * 1024) return set_error(KTUP_ERR_UNSUPPORTED, "%s: embedding_size %d needs %zu B of LDS", name, a.d, lds);
-  if (lds > 64 * 1024)
-    (void)hipFuncSetAttribute((const void*)pairs_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   dim3 grid = pairs_grid(a.n_cand, a.nq);
   if (a.qperm) grid.z = (unsigned)nrel;
-  hipLaunchKernelGGL(pairs_kernel<MODE>, grid, dim3(256), lds, st, a);
+  if (a.l1) {
+    if (lds > 64 * 1024)
+      (void)hipFuncSetAttribute((const void*)pairs_kernel<MODE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((pairs_kernel<MODE, true>), grid, dim3(256), lds, st, a);
+  } else {
+    if (lds > 64 * 1024)
+      (void)hipFuncSetAttribute((const void*)pairs_kernel<MODE, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((pairs_kernel<MODE, false>), grid, dim3(256), lds, st, a);
+  }
   return check_launch(name);
 }
 
@@ -577,12 +589,19 @@ extern "C" int ktup_eval_pref_scores(const float* U, int64_t ldu, const float* I
   h.out = out; h.ldo = ldo;
   const size_t lds = (size_t)(d / 4) * CT * 16 + (size_t)2 * n_pref * g.dp * 4 + (size_t)n_pref * CT * 4;
   if (lds > 160 * 1024) return set_error(KTUP_ERR_UNSUPPORTED, "%s: hard-gate tile needs %zu B of LDS", name, lds);
-  if (lds > 64 * 1024)
-    (void)hipFuncSetAttribute((const void*)pairs_hard_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   const int64_t tiles = (n_items + CT - 1) / CT;
   int64_t ysplit = (2048 + tiles - 1) / tiles;
   if (ysplit > (nq + 3) / 4) ysplit = (nq + 3) / 4;
   if (ysplit < 1) ysplit = 1;
-  hipLaunchKernelGGL(pairs_hard_kernel, dim3((unsigned)tiles, (unsigned)ysplit), dim3(256), lds, st, h);
+  const dim3 hgrid((unsigned)tiles, (unsigned)ysplit);
+  if (l1) {
+    if (lds > 64 * 1024)
+      (void)hipFuncSetAttribute((const void*)pairs_hard_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(pairs_hard_kernel<true>, hgrid, dim3(256), lds, st, h);
+  } else {
+    if (lds > 64 * 1024)
+      (void)hipFuncSetAttribute((const void*)pairs_hard_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(pairs_hard_kernel<false>, hgrid, dim3(256), lds, st, h);
+  }
   return check_launch(name);
 }

@@ -139,8 +139,13 @@ KTUP_DEV float4 load_cand4(const float* base, int64_t ld, int64_t row, int c, in
 
 // MODE 0: z = A - C0 (TransE / TransR-projected)   MODE 1: TransH   MODE 2: TUP / KTUP soft gate
 // L1: the distance kind is compile-time -- a run-time flag makes the compiler evaluate |z| AND z^2 per element and select.
+// MODE 2 keeps three candidate vectors in LDS (77 KB at d = 100: two workgroups per CU), so its workgroups are 8 waves.
+template <int MODE>
+struct PairsWG { static constexpr int NWV = MODE == 2 ? 8 : 4, NT = NWV * 64; };
+
 template <int MODE, bool L1>
-__global__ __launch_bounds__(256) void pairs_kernel(PairsArgs a) {
+__global__ __launch_bounds__(PairsWG<MODE>::NT) void pairs_kernel(PairsArgs a) {
+  constexpr int NWV = PairsWG<MODE>::NWV, NT = PairsWG<MODE>::NT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float4* cand = reinterpret_cast<float4*>(smem);  // [NCV][nch4][CT]
   constexpr int NCV = MODE == 2 ? 3 : 1;
@@ -156,7 +161,7 @@ __global__ __launch_bounds__(256) void pairs_kernel(PairsArgs a) {
     if (range_lo >= range_hi) return;
     C0 += (int64_t)blockIdx.z * a.rel_stride;
   }
-  for (int idx = t; idx < nch4 * CT; idx += 256) {
+  for (int idx = t; idx < nch4 * CT; idx += NT) {
     const int j = idx & (CT - 1), c = idx >> 6;
     const int64_t gj = min(j0 + j, a.n_cand - 1);
     cand[(0 * nch4 + c) * CT + j] = load_cand4(C0, a.ldc0, gj, c, a.d, a.cvec);
@@ -171,44 +176,49 @@ __global__ __launch_bounds__(256) void pairs_kernel(PairsArgs a) {
   constexpr bool l1 = L1;
   // this workgroup's slice of the queries (grid.y splits them), QB at a time per wave
   const int64_t nrange = range_hi - range_lo;
-  const int64_t per = ((nrange + gridDim.y - 1) / gridDim.y + 4 * QB - 1) / (4 * QB) * (4 * QB);
+  const int64_t per = ((nrange + gridDim.y - 1) / gridDim.y + NWV * QB - 1) / (NWV * QB) * (NWV * QB);
   const int64_t qlo = range_lo + (int64_t)blockIdx.y * per, qhi = min(range_hi, qlo + per);
-  for (int64_t b0 = qlo + w * QB; b0 < qhi; b0 += 4 * QB) {
-    int qrow[QB];
+  for (int64_t b0 = qlo + w * QB; b0 < qhi; b0 += NWV * QB) {
+    // per-query scalar base pointers (A, Q1, NQ vectors), hoisted: inside the chunk loops every scalar load is then
+    // base + one shared 32-bit offset -- with an index recomputed per load, 64-bit scalar address arithmetic (5 SALU per
+    // s_load) costs as many issue slots as the VALU work it feeds
+    sptr4 qa[QB], qn[QB], q1p[QB];
     int64_t qid[QB];
 #pragma unroll
     for (int qi = 0; qi < QB; ++qi) {
       const int64_t pos = min(b0 + qi, range_hi - 1);
       qid[qi] = a.qperm ? (int64_t)a.qperm[pos] : pos;
-      qrow[qi] = (int)qid[qi] * 3 * dq4;
+      qa[qi] = QW + qid[qi] * 3 * dq4;
+      q1p[qi] = qa[qi] + dq4;
+      qn[qi] = qa[qi] + 2 * dq4;
     }
     float s[QB], acc[QB];
 #pragma unroll
     for (int qi = 0; qi < QB; ++qi) { s[qi] = 0.f; acc[qi] = 0.f; }
     if (MODE >= 1) {
-      for (int c = 0; c < nch4; ++c) {
+      for (uint32_t c = 0; c < (uint32_t)nch4; ++c) {
         const float4 c1 = cand[((MODE == 2 ? 1 : 0) * nch4 + c) * CT + lane];
         const float4 nc = MODE == 2 ? cand[(2 * nch4 + c) * CT + lane] : f4zero();
 #pragma unroll
         for (int qi = 0; qi < QB; ++qi) {
-          const float4 nqv = sld(QW, qrow[qi] + 2 * dq4 + c);
+          const float4 nqv = sldp(qn[qi] + c);
           if constexpr (MODE == 2) {
-            s[qi] += dot4(sld(QW, qrow[qi] + dq4 + c) - c1, nqv + nc);
+            s[qi] += dot4(sldp(q1p[qi] + c) - c1, nqv + nc);
           } else {                      // TransH: s = -(e . w); no zero operands for the compiler to keep (x + 0 is not x for -0)
             s[qi] -= dot4(c1, nqv);
           }
         }
       }
     }
-    for (int c = 0; c < nch4; ++c) {
+    for (uint32_t c = 0; c < (uint32_t)nch4; ++c) {
       const float4 c0 = cand[c * CT + lane];
       const float4 nc = MODE == 2 ? cand[(2 * nch4 + c) * CT + lane] : f4zero();
 #pragma unroll
       for (int qi = 0; qi < QB; ++qi) {
-        const float4 av = sld(QW, qrow[qi] + c);
+        const float4 av = sldp(qa[qi] + c);
         float4 z = av - c0;
-        if constexpr (MODE == 2) z = fma4(-s[qi], sld(QW, qrow[qi] + 2 * dq4 + c) + nc, z);
-        if constexpr (MODE == 1) z = fma4(-s[qi], sld(QW, qrow[qi] + 2 * dq4 + c), z);
+        if constexpr (MODE == 2) z = fma4(-s[qi], sldp(qn[qi] + c) + nc, z);
+        if constexpr (MODE == 1) z = fma4(-s[qi], sldp(qn[qi] + c), z);
         acc[qi] += dist4(z, l1);
       }
     }
@@ -237,8 +247,10 @@ struct HardArgs {
   int64_t ldo;
 };
 
+constexpr int HARD_NT = 512;   // 8 waves share a candidate tile + tables (47 KB at d = 100, P = 20): 3 workgroups per CU
+
 template <bool L1>
-__global__ __launch_bounds__(256) void pairs_hard_kernel(HardArgs a) {
+__global__ __launch_bounds__(HARD_NT) void pairs_hard_kernel(HardArgs a) {
   KTUP_RESOLVE_GUMBEL(a);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int nch4 = a.d / 4, dp4 = a.dp / 4;
@@ -250,14 +262,14 @@ __global__ __launch_bounds__(256) void pairs_hard_kernel(HardArgs a) {
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
   const int64_t j0 = (int64_t)blockIdx.x * CT;
   const int64_t gj = min(j0 + lane, a.n_cand - 1);
-  for (int idx = t; idx < nch4 * CT; idx += 256) {
+  for (int idx = t; idx < nch4 * CT; idx += HARD_NT) {
     const int j = idx & (CT - 1), c = idx >> 6;
     cand[c * CT + j] = reinterpret_cast<const float4*>(a.V + min(j0 + j, a.n_cand - 1) * a.d)[c];
   }
   {
     const float4* Ar = reinterpret_cast<const float4*>(a.ws + (size_t)a.ppad * a.dp);
-    for (int idx = t; idx < 2 * a.P * dp4; idx += 256) tabA[idx] = Ar[idx];  // Ar then Cn are adjacent in ws
-    for (int idx = t; idx < a.P * CT; idx += 256) {
+    for (int idx = t; idx < 2 * a.P * dp4; idx += HARD_NT) tabA[idx] = Ar[idx];  // Ar then Cn are adjacent in ws
+    for (int idx = t; idx < a.P * CT; idx += HARD_NT) {
       const int j = idx & (CT - 1), p = idx >> 6;
       lv[p * CT + j] = a.LV[min(j0 + j, a.n_cand - 1) * a.P + p];
     }
@@ -267,7 +279,7 @@ __global__ __launch_bounds__(256) void pairs_hard_kernel(HardArgs a) {
   constexpr bool l1 = L1;
   const int64_t per = (a.nq + gridDim.y - 1) / gridDim.y;
   const int64_t qlo = (int64_t)blockIdx.y * per, qhi = min(a.nq, qlo + per);
-  for (int64_t b = qlo + w; b < qhi; b += 4) {
+  for (int64_t b = qlo + w; b < qhi; b += HARD_NT / 64) {
     const float* ql = a.QL + b * a.P;  // wave-uniform -> scalar loads
     int ps = 0;
     float best = -INFINITY;
@@ -289,14 +301,14 @@ __global__ __launch_bounds__(256) void pairs_hard_kernel(HardArgs a) {
       const float v = (ql[p] + lv[p * CT + lane]) + gumbel_from_uniform(u);
       if (v > best) { best = v; ps = p; }
     }
-    const int urow = (int)b * 3 * nch4 + nch4;  // slot 1 = u_b
+    const sptr4 ub = QW + (b * 3 + 1) * nch4;   // slot 1 = u_b; one scalar base, the chunk index is the only offset
     const float4* cn = tabC + ps * dp4;
     const float4* ar = tabA + ps * dp4;
     float s = 0.f;
-    for (int c = 0; c < nch4; ++c) s += dot4(sld(QW, urow + c) - cand[c * CT + lane], cn[c]);
+    for (uint32_t c = 0; c < (uint32_t)nch4; ++c) s += dot4(sldp(ub + c) - cand[c * CT + lane], cn[c]);
     float acc = 0.f;
-    for (int c = 0; c < nch4; ++c) {
-      const float4 q = sld(QW, urow + c) - cand[c * CT + lane];
+    for (uint32_t c = 0; c < (uint32_t)nch4; ++c) {
+      const float4 q = sldp(ub + c) - cand[c * CT + lane];
       acc += dist4(fma4(-s, cn[c], q + ar[c]), l1);
     }
     if (j0 + lane < a.n_cand) a.out[b * a.ldo + j0 + lane] = acc;
@@ -407,13 +419,18 @@ __global__ __launch_bounds__(256) void rel_bucket_kernel(const int64_t* __restri
 }
 
 // ---------------------------------------------------------------------------------------------------------
-dim3 pairs_grid(int64_t n_cand, int64_t nq) {
+// grid.y splits the queries: enough workgroups to fill the chip (`target`: ~2 rounds of the resident workgroups), but
+// every split a whole number of NWV x QB query groups and none of them empty.
+dim3 pairs_grid(int64_t n_cand, int64_t nq, int nwv, int64_t target) {
   const int64_t tiles = (n_cand + CT - 1) / CT;
-  int64_t ysplit = (2048 + tiles - 1) / tiles;
-  const int64_t ymax = (nq + 4 * QB - 1) / (4 * QB);
+  const int64_t group = (int64_t)nwv * QB;
+  int64_t ysplit = (target + tiles - 1) / tiles;
+  const int64_t ymax = (nq + group - 1) / group;
   if (ysplit > ymax) ysplit = ymax;
   if (ysplit < 1) ysplit = 1;
-  return dim3((unsigned)tiles, (unsigned)ysplit);
+  const int64_t per = ((nq + ysplit - 1) / ysplit + group - 1) / group * group;   // what the kernel computes from gridDim.y
+  ysplit = (nq + per - 1) / per;
+  return dim3((unsigned)tiles, (unsigned)(ysplit < 1 ? 1 : ysplit));
 }
 
 template <int MODE>
@@ -421,16 +438,16 @@ int launch_pairs(const PairsArgs& a, hipStream_t st, const char* name, int nrel 
   const int ncv = MODE == 2 ? 3 : 1;
   const size_t lds = (size_t)ncv * (a.dq / 4) * CT * 16;
   if (lds > 160 * 1024) return set_error(KTUP_ERR_UNSUPPORTED, "%s: embedding_size %d needs %zu B of LDS", name, a.d, lds);
-  dim3 grid = pairs_grid(a.n_cand, a.nq);
+  dim3 grid = pairs_grid(a.n_cand, a.nq, PairsWG<MODE>::NWV, MODE == 2 ? 512 : 2048);
   if (a.qperm) grid.z = (unsigned)nrel;
   if (a.l1) {
     if (lds > 64 * 1024)
       (void)hipFuncSetAttribute((const void*)pairs_kernel<MODE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((pairs_kernel<MODE, true>), grid, dim3(256), lds, st, a);
+    hipLaunchKernelGGL((pairs_kernel<MODE, true>), grid, dim3(PairsWG<MODE>::NT), lds, st, a);
   } else {
     if (lds > 64 * 1024)
       (void)hipFuncSetAttribute((const void*)pairs_kernel<MODE, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((pairs_kernel<MODE, false>), grid, dim3(256), lds, st, a);
+    hipLaunchKernelGGL((pairs_kernel<MODE, false>), grid, dim3(PairsWG<MODE>::NT), lds, st, a);
   }
   return check_launch(name);
 }
@@ -590,18 +607,18 @@ extern "C" int ktup_eval_pref_scores(const float* U, int64_t ldu, const float* I
   const size_t lds = (size_t)(d / 4) * CT * 16 + (size_t)2 * n_pref * g.dp * 4 + (size_t)n_pref * CT * 4;
   if (lds > 160 * 1024) return set_error(KTUP_ERR_UNSUPPORTED, "%s: hard-gate tile needs %zu B of LDS", name, lds);
   const int64_t tiles = (n_items + CT - 1) / CT;
-  int64_t ysplit = (2048 + tiles - 1) / tiles;
-  if (ysplit > (nq + 3) / 4) ysplit = (nq + 3) / 4;
+  int64_t ysplit = (768 + tiles - 1) / tiles;    // ~ the resident workgroups (3 per CU): each stages 47 KB, so not many more
+  if (ysplit > (nq + HARD_NT / 64 - 1) / (HARD_NT / 64)) ysplit = (nq + HARD_NT / 64 - 1) / (HARD_NT / 64);
   if (ysplit < 1) ysplit = 1;
   const dim3 hgrid((unsigned)tiles, (unsigned)ysplit);
   if (l1) {
     if (lds > 64 * 1024)
       (void)hipFuncSetAttribute((const void*)pairs_hard_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(pairs_hard_kernel<true>, hgrid, dim3(256), lds, st, h);
+    hipLaunchKernelGGL(pairs_hard_kernel<true>, hgrid, dim3(HARD_NT), lds, st, h);
   } else {
     if (lds > 64 * 1024)
       (void)hipFuncSetAttribute((const void*)pairs_hard_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(pairs_hard_kernel<false>, hgrid, dim3(256), lds, st, h);
+    hipLaunchKernelGGL(pairs_hard_kernel<false>, hgrid, dim3(HARD_NT), lds, st, h);
   }
   return check_launch(name);
 }

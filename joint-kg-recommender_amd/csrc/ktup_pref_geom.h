@@ -72,6 +72,7 @@ typedef const __attribute__((address_space(4))) v4f* sptr4;
 KTUP_DEV sptr4 as_scalar(const float4* p) { return (sptr4)(uintptr_t)p; }
 KTUP_DEV sptr4 as_scalar(const float* p) { return (sptr4)(uintptr_t)p; }
 KTUP_DEV float4 sld(sptr4 p, int idx) { const v4f v = p[idx]; return make_float4(v.x, v.y, v.z, v.w); }
+KTUP_DEV float4 sldp(sptr4 p) { const v4f v = *p; return make_float4(v.x, v.y, v.z, v.w); }
 typedef float v16f __attribute__((ext_vector_type(16)));
 typedef const __attribute__((address_space(4))) v16f* sptr16;  // 64-byte scalar loads (s_load_dwordx16)
 KTUP_DEV sptr16 as_scalar16(const float* p) { return (sptr16)(uintptr_t)p; }

@@ -1307,264 +1307,6 @@ int dispatch_fwd4(const PrefArgs& a, int d, const Fwd4Geom& g, hipStream_t st, c
   return dispatch_fwd4_np<8, 8>(a, g, st, name);
 }
 
-template <int J, int CT, int NP, int NWMAX, bool HASE>
-__global__ __launch_bounds__(NWMAX * 64) void pref_fwd5_kernel(PrefArgs a, Fwd4Geom g) {
-  constexpr int PT = (NP + 3) / 4;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int nch = a.nch, d = nch * 4, P = a.P;
-  float4* AlogS = reinterpret_cast<float4*>(smem);                                     // [pt * 16 slots][pitchA4]
-  float* CnS = reinterpret_cast<float*>(AlogS + g.pt * 16 * g.pitchA4);                 // [trow][tpitch]
-  float* ArS = CnS + g.trow * g.tpitch;                                                 // [trow][tpitch]
-  const int t = threadIdx.x, lane = t & 63, kq = lane >> 4, j = lane & 15;
-  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-  char* wbase = reinterpret_cast<char*>(ArS + g.trow * g.tpitch) + (size_t)w * g.wave_bytes;
-  float4* xt = reinterpret_cast<float4*>(wbase);                                        // [16 * nch] + 3 zero chunks
-  int32_t* sid = reinterpret_cast<int32_t*>(xt + 16 * nch + 3);                         // [3][16]
-  // ---- stage the tables once per workgroup
-  {
-    const float* Alog = reinterpret_cast<const float*>(a.Alog);
-    const float* Ar = reinterpret_cast<const float*>(a.Ar);
-    const float* Cn = reinterpret_cast<const float*>(a.Cn);
-    const int dp = a.dp4 * 4, rowf = g.pitchA4 * 4, nA = g.pt * 16 * rowf, nT = g.trow * g.tpitch;
-    float* AlogSf = reinterpret_cast<float*>(AlogS);
-    for (int idx = t; idx < nA; idx += blockDim.x) {
-      const int srow = idx / rowf, k = idx - srow * rowf;
-      const int tt = srow >> 4, i = srow & 15;
-      const int p = 16 * tt + 4 * (i & 3) + (i >> 2);          // slot -> preference (block transposed)
-      AlogSf[idx] = (p < P && k < d) ? Alog[p * dp + k] : 0.f;
-    }
-    for (int idx = t; idx < nT; idx += blockDim.x) {
-      const int p = idx / g.tpitch, c = idx - p * g.tpitch;
-      const bool ok = p < P && c < d;
-      CnS[idx] = ok ? Cn[p * dp + c] : 0.f;
-      ArS[idx] = ok ? Ar[p * dp + c] : 0.f;
-    }
-    if (lane < 3) xt[16 * nch + lane] = f4zero();
-  }
-  __syncthreads();
-  const bool l1 = a.l1 != 0;
-  const int64_t ntiles = (a.n + 15) / 16;
-  const int total = 16 * nch;
-  const int qstep = 64 / nch, rstep = 64 - qstep * nch;
-  const int64_t wstride = (int64_t)gridDim.x * g.nw;
-  // Software pipeline: the next tile's 3 x J row loads are issued BEFORE the current tile's matrix phases and land in
-  // registers while they run (a wave's gather and its MFMAs were strictly serial in pref_fwd4, and waves of a SIMD fall
-  // into lock step); 3 waves per SIMD leave room for the 84 extra registers.
-  // Row loads are inline asm: the compiler's waitcnt pass then inserts no vmcnt waits for them (it parked vmcnt(0) waits
-  // in the middle of the matrix phases otherwise), and ONE explicit s_waitcnt at the bottom of the loop body, which takes
-  // every loaded register as an in/out operand, is the only point where their values become visible to the compiler.
-  v4 uu[J], vv[J], ee[J];
-#pragma unroll
-  for (int jj = 0; jj < J; ++jj) { uu[jj] = (v4){0.f, 0.f, 0.f, 0.f}; vv[jj] = uu[jj]; ee[jj] = uu[jj]; }
-  // ids: (a_*) = the next tile, complete; (b_*) = the tile after it, entity id still to be looked up.
-  int32_t a_u = 0, a_i = 0, a_e = 0, b_u = 0, b_i = 0;
-  auto raw_ids = [&](int64_t tile, int32_t& ou, int32_t& oi) {
-    ou = 0; oi = 0;
-    if (lane < 16 && tile < ntiles) {
-      const int64_t gr = tile * 16 + lane;
-      if (gr < a.n) { ou = (int32_t)a.u_ids[gr]; oi = (int32_t)a.i_ids[gr]; }
-    }
-  };
-  auto ent_id = [&](int32_t iid) -> int32_t { return (HASE && lane < 16) ? a.item2ent[iid] : 0; };
-  auto issue_rows = [&]() {      // ids of the tile are in sid[]
-    int v = lane, row = lane / nch, c = lane - (lane / nch) * nch;
-    asm volatile("" : "+v"(v), "+v"(row), "+v"(c));   // opaque per tile (LICM would hoist and spill the address sets)
-    int idu[J], idi[J], ide[J], cc[J];
-#pragma unroll
-    for (int jj = 0; jj < J; ++jj) {                  // all id reads first: one LDS round trip, not one per row load
-      const bool past = v >= total;                   // lanes past the tile re-read chunk 0 of row 0 (never stored)
-      const int rr = past ? 0 : row;
-      cc[jj] = past ? 0 : c;
-      idu[jj] = sid[rr]; idi[jj] = sid[16 + rr];
-      ide[jj] = HASE ? sid[32 + rr] : 0;
-      v += 64; row += qstep; c += rstep;
-      if (c >= nch) { c -= nch; ++row; }
-    }
-#pragma unroll
-    for (int jj = 0; jj < J; ++jj) {
-      const float4* pu = a.U + ((int64_t)idu[jj] * a.ldu4 + cc[jj]);
-      const float4* pi = a.I + ((int64_t)idi[jj] * a.ldi4 + cc[jj]);
-      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(uu[jj]) : "v"(pu));
-      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(vv[jj]) : "v"(pi));
-      if (HASE) {
-        const float4* pe = a.E + ((int64_t)ide[jj] * a.lde4 + cc[jj]);
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ee[jj]) : "v"(pe));
-      }
-    }
-  };
-  auto rows_landed = [&]() {
-    static_assert(J == 4 || J == 7 || J == 8, "operand lists below");
-    if constexpr (J == 4) {
-      asm volatile("s_waitcnt vmcnt(0)" : "+v"(uu[0]), "+v"(uu[1]), "+v"(uu[2]), "+v"(uu[3]), "+v"(vv[0]), "+v"(vv[1]), "+v"(vv[2]),
-                   "+v"(vv[3]), "+v"(ee[0]), "+v"(ee[1]), "+v"(ee[2]), "+v"(ee[3]));
-    } else if constexpr (J == 7) {
-      asm volatile("s_waitcnt vmcnt(0)" : "+v"(uu[0]), "+v"(uu[1]), "+v"(uu[2]), "+v"(uu[3]), "+v"(uu[4]), "+v"(uu[5]), "+v"(uu[6]),
-                   "+v"(vv[0]), "+v"(vv[1]), "+v"(vv[2]), "+v"(vv[3]), "+v"(vv[4]), "+v"(vv[5]), "+v"(vv[6]));
-      asm volatile("" : "+v"(ee[0]), "+v"(ee[1]), "+v"(ee[2]), "+v"(ee[3]), "+v"(ee[4]), "+v"(ee[5]), "+v"(ee[6]));
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" : "+v"(uu[0]), "+v"(uu[1]), "+v"(uu[2]), "+v"(uu[3]), "+v"(uu[4]), "+v"(uu[5]), "+v"(uu[6]),
-                   "+v"(uu[7]), "+v"(vv[0]), "+v"(vv[1]), "+v"(vv[2]), "+v"(vv[3]), "+v"(vv[4]), "+v"(vv[5]), "+v"(vv[6]));
-      asm volatile("" : "+v"(vv[7]), "+v"(ee[0]), "+v"(ee[1]), "+v"(ee[2]), "+v"(ee[3]), "+v"(ee[4]), "+v"(ee[5]), "+v"(ee[6]),
-                   "+v"(ee[7]));
-    }
-  };
-  const int64_t tile0 = (int64_t)blockIdx.x * g.nw + w;
-  raw_ids(tile0, a_u, a_i);
-  a_e = ent_id(a_i);
-  if (lane < 16) { sid[lane] = a_u; sid[16 + lane] = a_i; sid[32 + lane] = a_e; }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  raw_ids(tile0 + wstride, a_u, a_i);
-  a_e = ent_id(a_i);
-  raw_ids(tile0 + 2 * wstride, b_u, b_i);
-  if (tile0 < ntiles) issue_rows();
-  rows_landed();
-  for (int64_t tile_id = tile0; tile_id < ntiles; tile_id += wstride) {
-    const int64_t row0 = tile_id * 16;
-    // ---- the rows of this tile have landed: x -> LDS tile, q in registers
-    float4 q[J];
-    {
-      int v = lane;
-#pragma unroll
-      for (int jj = 0; jj < J; ++jj) {
-        const float4 u4 = make_float4(uu[jj][0], uu[jj][1], uu[jj][2], uu[jj][3]);
-        float4 ve = make_float4(vv[jj][0], vv[jj][1], vv[jj][2], vv[jj][3]);
-        if (HASE) ve = ve + make_float4(ee[jj][0], ee[jj][1], ee[jj][2], ee[jj][3]);
-        if (v < total) xt[v] = u4 + ve;
-        q[jj] = u4 - ve;
-        v += 64;
-      }
-    }
-    // ---- next tile: ids -> LDS; its row loads, in flight under the matrix phases; id loads for the tiles after it
-    if (lane < 16) { sid[lane] = a_u; sid[16 + lane] = a_i; sid[32 + lane] = a_e; }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    if (tile_id + wstride < ntiles) issue_rows();
-    __builtin_amdgcn_sched_barrier(0);
-    const int32_t e2 = ent_id(b_i);           // b_i arrived an iteration ago; first use of e2 / c_* is the rotation below
-    int32_t c_u, c_i;
-    raw_ids(tile_id + 3 * wstride, c_u, c_i);
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- stage 1: logits^T, PT independent accumulator chains
-    v4 lg[PT];
-#pragma unroll
-    for (int tt = 0; tt < PT; ++tt) lg[tt] = (v4){0.f, 0.f, 0.f, 0.f};
-    {
-      const float4* xb = xt + j * nch + kq;
-      const float4* ta = AlogS + j * g.pitchA4 + kq;
-      for (int gk = 0; gk < g.kg; ++gk) {
-        const float4 bv = xb[4 * gk];
-        float4 av[PT];
-#pragma unroll
-        for (int tt = 0; tt < PT; ++tt) av[tt] = ta[tt * 16 * g.pitchA4 + 4 * gk];
-#pragma unroll
-        for (int tt = 0; tt < PT; ++tt) lg[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[tt].x, bv.x, lg[tt], 0, 0, 0);
-#pragma unroll
-        for (int tt = 0; tt < PT; ++tt) lg[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[tt].y, bv.y, lg[tt], 0, 0, 0);
-#pragma unroll
-        for (int tt = 0; tt < PT; ++tt) lg[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[tt].z, bv.z, lg[tt], 0, 0, 0);
-#pragma unroll
-        for (int tt = 0; tt < PT; ++tt) lg[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[tt].w, bv.w, lg[tt], 0, 0, 0);
-      }
-    }
-    // ---- q overwrites x
-    {
-      int v = lane;
-#pragma unroll
-      for (int jj = 0; jj < J; ++jj) {
-        if (v < total) xt[v] = q[jj];
-        v += 64;
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    // ---- stage 2a: n^T coordinate tiles (two tiles in flight: independent accumulator chains)
-    v4 accN[CT];
-    const float* tn0 = CnS + kq * g.tpitch + j;
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct) {
-      accN[ct] = (v4){0.f, 0.f, 0.f, 0.f};
-      if (ct < g.ct) {
-        float ta[NP];
-#pragma unroll
-        for (int m = 0; m < NP; ++m) ta[m] = tn0[(16 * (m >> 2) + 4 * (m & 3)) * g.tpitch + 16 * ct];
-#pragma unroll
-        for (int m = 0; m < NP; ++m) accN[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(ta[m], lg[m >> 2][m & 3], accN[ct], 0, 0, 0);
-      }
-    }
-    // ---- s = q . n
-    const float4* qrow = xt + j * nch + kq;
-    float sp = 0.f;
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct) {
-      if (4 * ct + kq < nch) {
-        const float4 qv = qrow[4 * ct];
-        sp = fmaf(qv.x, accN[ct][0], fmaf(qv.y, accN[ct][1], fmaf(qv.z, accN[ct][2], fmaf(qv.w, accN[ct][3], sp))));
-      }
-    }
-    sp += __shfl_xor(sp, 16, 64);
-    const float sfull = sp + __shfl_xor(sp, 32, 64);
-    // ---- stage 2b: r^T tiles and the distance
-    float dsum = 0.f;
-    const float* tr0 = ArS + kq * g.tpitch + j;
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct) {
-      if (ct < g.ct) {
-        float ta[NP];
-#pragma unroll
-        for (int m = 0; m < NP; ++m) ta[m] = tr0[(16 * (m >> 2) + 4 * (m & 3)) * g.tpitch + 16 * ct];
-        const float4 qv = (4 * ct + kq < nch) ? qrow[4 * ct] : f4zero();
-        v4 accR = (v4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int m = 0; m < NP; ++m) accR = __builtin_amdgcn_mfma_f32_16x16x4f32(ta[m], lg[m >> 2][m & 3], accR, 0, 0, 0);
-        dsum += dist1(fmaf(-sfull, accN[ct][0], qv.x + accR[0]), l1) + dist1(fmaf(-sfull, accN[ct][1], qv.y + accR[1]), l1) +
-                dist1(fmaf(-sfull, accN[ct][2], qv.z + accR[2]), l1) + dist1(fmaf(-sfull, accN[ct][3], qv.w + accR[3]), l1);
-      }
-    }
-    dsum += __shfl_xor(dsum, 16, 64);
-    const float score = dsum + __shfl_xor(dsum, 32, 64);
-    if (kq == 0 && row0 + j < a.n) a.score[row0 + j] = score;
-    __builtin_amdgcn_sched_barrier(0);
-    rows_landed();
-    a_u = b_u; a_i = b_i; a_e = e2;
-    b_u = c_u; b_i = c_i;
-  }
-}
-
-
-template <int J, int CT, int NP, int NWMAX, bool HASE>
-int launch_pref5e(const PrefArgs& a, const Fwd4Geom& g, hipStream_t st, const char* name) {
-  const size_t lds = g.table_bytes + (size_t)g.nw * g.wave_bytes;
-  (void)hipFuncSetAttribute((const void*)pref_fwd5_kernel<J, CT, NP, NWMAX, HASE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  const int64_t ntiles = (a.n + 15) / 16;
-  const int grid = grid_for((ntiles + g.nw - 1) / g.nw, 256);
-  hipLaunchKernelGGL((pref_fwd5_kernel<J, CT, NP, NWMAX, HASE>), dim3(grid), dim3(g.nw * 64), lds, st, a, g);
-  return check_launch(name);
-}
-
-template <int J, int CT, int NP, int NWMAX>
-int launch_pref5(const PrefArgs& a, Fwd4Geom g, hipStream_t st, const char* name) {
-  if (g.nw > NWMAX) g.nw = NWMAX;
-  if (a.E) return launch_pref5e<J, CT, NP, NWMAX, true>(a, g, st, name);
-  return launch_pref5e<J, CT, NP, NWMAX, false>(a, g, st, name);
-}
-
-template <int J, int CT, int NWMAX>
-int dispatch_fwd5_np(const PrefArgs& a, const Fwd4Geom& g, hipStream_t st, const char* name) {
-  if (g.np <= 1) return launch_pref5<J, CT, 1, NWMAX>(a, g, st, name);
-  if (g.np <= 2) return launch_pref5<J, CT, 2, NWMAX>(a, g, st, name);
-  if (g.np <= 4) return launch_pref5<J, CT, 4, NWMAX>(a, g, st, name);
-  if (g.np <= 5) return launch_pref5<J, CT, 5, NWMAX>(a, g, st, name);
-  return launch_pref5<J, CT, 8, NWMAX>(a, g, st, name);
-}
-
-template <int NWMAX>
-int dispatch_fwd5(const PrefArgs& a, int d, const Fwd4Geom& g, hipStream_t st, const char* name) {
-  if (d <= 64) return dispatch_fwd5_np<4, 4, NWMAX>(a, g, st, name);
-  if (d <= 112) return dispatch_fwd5_np<7, 7, NWMAX>(a, g, st, name);
-  return dispatch_fwd5_np<8, 8, NWMAX>(a, g, st, name);
-}
-
 template <int CH, int NW>
 int launch_pref(bool bwd, const PrefArgs& a, hipStream_t st, const char* name) {
   const int64_t ntiles = (a.n + TR - 1) / TR;
@@ -1640,7 +1382,7 @@ int run_pref(bool bwd, const char* name, const float* U, int64_t ldu, const floa
   hipStream_t st = (hipStream_t)stream;
   if (!bwd) {  // KTUP_PREF_FWD selects the forward variant (A/B measurements); default = tuned kernel, one pair per lane
     const char* env = getenv("KTUP_PREF_FWD");
-    const int variant = env ? atoi(env) : 7;   // 0 = first kernel, 2 = SGPR-FMA kernel, 3 = 32x32x2 MFMA, 4 (default) = 16x16x4 MFMA
+    const int variant = env ? atoi(env) : 7;   // 0 = first kernel, 2 = SGPR-FMA kernel, 3 = 32x32x2 MFMA, 4 = 16x16x4 MFMA (run-time geometry), 7 (default) = compile-time-geometry kernel first
     if (variant == 7) {
       const int rc = pref_fwd_mc(reinterpret_cast<const float*>(a.U), a.ldu4 * 4, reinterpret_cast<const float*>(a.I), a.ldi4 * 4,
                                  reinterpret_cast<const float*>(a.E), a.lde4 * 4, a.item2ent, reinterpret_cast<const float*>(a.Alog),
@@ -1649,8 +1391,6 @@ int run_pref(bool bwd, const char* name, const float* U, int64_t ldu, const floa
       if (rc != 1) return rc;
     }
     Fwd4Geom g4;
-    if (variant == 5 && fwd4_supported(a, d, n_pref, &g4)) return dispatch_fwd5<8>(a, d, g4, st, name);
-    if (variant == 6 && fwd4_supported(a, d, n_pref, &g4)) return dispatch_fwd5<12>(a, d, g4, st, name);
     if ((variant == 4 || variant == 7) && fwd4_supported(a, d, n_pref, &g4)) return dispatch_fwd4(a, d, g4, st, name);
     Fwd3Geom g3;
     if (variant >= 3 && fwd3_supported(a, d, n_pref, &g3)) return dispatch_fwd3(a, d, g3, st, name);

@@ -215,6 +215,14 @@ int ktup_shard_pack_rows(const float* table, int64_t ldt, int d, const int64_t* 
 int ktup_shard_unpack_rows_add(const float* rows, int64_t ldr, int d, const int64_t* ids, int64_t n, float* gtable,
                                int64_t ldg, void* stream);
 
+/* owner-side sparse optimizer: update only the `n` UNIQUE rows `ids` of a shard with the
+ * combined row gradients `grows` (n x d).  g' = g * min(1, max_norm / (sqrt(*sumsq) + 1e-6)) (sumsq: one device double, the
+ * job-wide sum of squared gradients; max_norm <= 0: no clip).  KTUP_OPT_SGD: p -= lr g';  KTUP_OPT_ADAGRAD: state += g'^2,
+ * p -= lr g' / (sqrt(state) + eps).  Equal to the reference's dense step (utils/trainer.py:63-77) when l2_lambda = 0.   */
+int ktup_shard_sparse_step(int kind, float* table, int64_t ldt, float* state, int64_t lds, int d, const int64_t* ids,
+                           int64_t n, const float* grows, int64_t ldg, float lr, float eps, const double* sumsq,
+                           float max_norm, void* stream);
+
 /* ------------------------------------------- K19  negative sampling on the device  utils/data.py:12-85
  * rec: one uniform negative item per (u, positive): != positive, bit not set in the user's row of
  *      `user_item_bitmap` (n_users x words_per_user uint32, train + eval items; NULL = no filter), and -- when

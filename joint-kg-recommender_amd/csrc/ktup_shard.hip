@@ -35,7 +35,70 @@ struct UnpackAdd {
   }
 };
 
+// Owner-side sparse optimizer: update only the rows a step touched.
+//   g' = coef * g,  coef = min(1, max_norm / (sqrt(*sumsq) + 1e-6))   (the global-norm clip; sumsq is the all-reduced sum)
+//   SGD     : p -= lr * g'
+//   Adagrad : sum += g'^2;  p -= lr * g' / (sqrt(sum) + eps)
+// With weight_decay = 0 (and no momentum) this IS the reference's dense step: rows with a zero gradient do not move under
+// either rule (utils/trainer.py:63-77 with l2_lambda = 0).  `ids` must be unique (one update per row).
+KTUP_DEV float up1(float& p, float& st, float g, float lr, float eps, bool adagrad) {
+  if (adagrad) {
+    st = fmaf(g, g, st);
+    p = p - lr * (g / (sqrtf(st) + eps));
+  } else {
+    p = fmaf(-lr, g, p);
+  }
+  return p;
+}
+KTUP_DEV void upv(float& p, float& st, float g, float lr, float eps, bool adagrad) { up1(p, st, g, lr, eps, adagrad); }
+KTUP_DEV void upv(float4& p, float4& st, float4 g, float lr, float eps, bool adagrad) {
+  up1(p.x, st.x, g.x, lr, eps, adagrad); up1(p.y, st.y, g.y, lr, eps, adagrad);
+  up1(p.z, st.z, g.z, lr, eps, adagrad); up1(p.w, st.w, g.w, lr, eps, adagrad);
+}
+
+struct SparseRowStep {
+  float* T; int64_t ldt; float* S; int64_t lds; const int64_t* ids; const float* g; int64_t ldg;
+  float lr, eps, max_norm; const double* sumsq; bool adagrad;
+  template <typename V, int G, int CPL>
+  KTUP_DEV void run(const RowCtx<V, G, CPL>& cx, int64_t row) const {
+    float coef = 1.f;
+    if (max_norm > 0.f) {
+      const float c = max_norm / ((float)sqrt(*sumsq) + 1e-6f);
+      coef = c < 1.f ? c : 1.f;
+    }
+    const int64_t r = ids[row];
+    V p[CPL], st[CPL], gr[CPL];
+    cx.load(p, T + r * ldt);
+    cx.load(gr, g + row * ldg);
+    if (adagrad) cx.load(st, S + r * lds);
+    V* po = reinterpret_cast<V*>(T + r * ldt);
+    V* so = reinterpret_cast<V*>(S + r * lds);
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+      const int c = cx.lane + j * G;
+      if (c < cx.nch) {
+        upv(p[j], st[j], vscale(coef, gr[j]), lr, eps, adagrad);
+        po[c] = p[j];
+        if (adagrad) so[c] = st[j];
+      }
+    }
+  }
+};
+
 }  // namespace
+
+extern "C" int ktup_shard_sparse_step(int kind, float* table, int64_t ldt, float* state, int64_t lds, int d, const int64_t* ids,
+                                      int64_t n, const float* grows, int64_t ldg, float lr, float eps, const double* sumsq,
+                                      float max_norm, void* stream) {
+  const char* name = "ktup_shard_sparse_step";
+  KTUP_REQUIRE(kind == KTUP_OPT_SGD || kind == KTUP_OPT_ADAGRAD, "%s: only plain SGD and Adagrad have an exact row-sparse form", name);
+  KTUP_REQUIRE(d > 0 && n >= 0 && ldg >= d, "%s: bad sizes", name);
+  if (n == 0) return KTUP_OK;
+  KTUP_REQUIRE(table && ids && grows && (kind == KTUP_OPT_SGD || state), "%s: null pointer argument", name);
+  KTUP_REQUIRE(max_norm <= 0.f || sumsq, "%s: clipping needs the (all-reduced) sum of squared gradients", name);
+  SparseRowStep op{table, ldt, state ? state : table, state ? lds : ldt, ids, grows, ldg, lr, eps, max_norm, sumsq, kind == KTUP_OPT_ADAGRAD};
+  return launch_rows(op, d, can_vec4(d, {table, state, grows}, {ldt, state ? lds : 4, ldg}), n, (hipStream_t)stream, name);
+}
 
 extern "C" int ktup_shard_pack_rows(const float* table, int64_t ldt, int d, const int64_t* ids, int64_t n, float* out,
                                     int64_t ldo, void* stream) {

@@ -69,6 +69,7 @@ SIGNATURES = {
     'ktup_optim_gradnorm': [c_i, c_p, c_p, c_p, c_p],
     'ktup_optim_step': [c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_p, c_f, c_i, c_p],
     'ktup_eval_rec_metrics': [c_p, c_l, c_i, c_p, c_p, c_p, c_p],
+    'ktup_shard_sparse_step': [c_i, c_p, c_l, c_p, c_l, c_i, c_p, c_l, c_p, c_l, c_f, c_f, c_p, c_f, c_p],
     'ktup_negsample_kg': [c_p, c_p, c_p, c_l, c_l, c_l, c_p, c_l, c_u, c_u, c_p, c_p, c_p],
 }
 _RESTYPE = {'ktup_last_error': ctypes.c_char_p, 'ktup_pref_workspace_bytes': ctypes.c_size_t,

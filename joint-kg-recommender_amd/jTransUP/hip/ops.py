@@ -493,3 +493,44 @@ def unpack_rows_add(rows, ids, gtable):
     L.call('ktup_shard_unpack_rows_add', _p(rows), rows.stride(0), rows.shape[1], _p(ids), ids.numel(), _p(gtable), gtable.stride(0),
            _stream(dev))
     return gtable
+
+
+@torch.no_grad()
+def grad_sumsq(tensors, out=None):
+    """Sum of squares of a list of dense fp32 device tensors -> one device double (K20's first launch, ktup_optim_gradnorm);
+    no host sync.  Tensors must be contiguous and 16-byte aligned."""
+    import ctypes
+    tensors = [t for t in tensors if t is not None and t.numel()]
+    dev = _dev(tensors[0]) if tensors else (out.device if out is not None else torch.device('cuda', torch.cuda.current_device()))
+    if out is None:
+        out = torch.zeros(1, dtype=torch.float64, device=dev)
+    if not tensors:
+        return out.zero_()
+    for t in tensors:
+        if t.dtype != torch.float32 or not t.is_contiguous() or t.device != dev:
+            raise L.KtupError('grad_sumsq needs contiguous fp32 tensors on one device')
+    n = len(tensors)
+    grads = (ctypes.c_void_p * n)(*[t.data_ptr() for t in tensors])
+    sizes = (ctypes.c_int64 * n)(*[t.numel() for t in tensors])
+    L.call('ktup_optim_gradnorm', n, grads, sizes, _p(out), _stream(dev))
+    return out
+
+
+SPARSE_KINDS = {'sgd': 0, 'adagrad': 1}
+
+
+@torch.no_grad()
+def sparse_step(kind, table, state, ids, grows, lr, eps=1e-10, sumsq=None, max_norm=0.0):
+    """Owner-side row-sparse optimizer step (ktup_shard_sparse_step): rows `ids` (unique) of `table` (and of the Adagrad
+    `state`) are updated in place with the combined row gradients `grows`; clip coefficient from the device double `sumsq`."""
+    dev = _dev(_table('table shard', table)); _table('row gradients', grows)
+    ids = _ids('ids', ids, dev, grows.shape[0])
+    k = SPARSE_KINDS[kind]
+    if k == 1:
+        _table('optimizer state', state)
+        if state.shape != table.shape:
+            raise L.KtupError('Adagrad state must have the shape of the table shard')
+    L.call('ktup_shard_sparse_step', k, _p(table), table.stride(0), _p(state) if k == 1 else None, state.stride(0) if k == 1 else 0,
+           table.shape[1], _p(ids), ids.numel(), _p(grows), grows.stride(0), float(lr), float(eps), _p(sumsq),
+           float(max_norm) if sumsq is not None else 0.0, _stream(dev))
+    return table

@@ -86,18 +86,40 @@ class ReplicaGradSync(object):
 
 
 # ------------------------------------------------------------------------------------------ config 5: row-sharded tables
-def _default_pack(table, local_ids):
-    if table.is_cuda:
+class RowOps(object):
+    """The device halves of the exchange.  The defaults are the HIP kernels and nothing else (CPU tensors raise): the
+    world-size-2 gloo tests that run without a GPU pass their own torch stand-ins."""
+
+    @staticmethod
+    def pack(table, local_ids):                                   # out[k] = table[ids[k]]
         from jTransUP.hip import ops
         return ops.pack_rows(table, local_ids)
-    return table.index_select(0, local_ids)          # CPU tensors only occur in the gloo tests
 
-
-def _default_unpack_add(rows, local_ids, gtable):
-    if gtable.is_cuda:
+    @staticmethod
+    def unpack_add(rows, local_ids, gtable):                      # gtable[ids[k]] += rows[k]
         from jTransUP.hip import ops
         return ops.unpack_rows_add(rows.contiguous(), local_ids, gtable)
-    return gtable.index_add_(0, local_ids, rows)
+
+    @staticmethod
+    def sumsq(tensors):                                           # -> one device double
+        from jTransUP.hip import ops
+        return ops.grad_sumsq([t.contiguous() for t in tensors])
+
+    @staticmethod
+    def sparse_step(kind, table, state, ids, grows, lr, eps, sumsq, max_norm):
+        from jTransUP.hip import ops
+        return ops.sparse_step(kind, table, state, ids, grows.contiguous(), lr, eps, sumsq, max_norm)
+
+
+def _a2a(out, inp, out_splits, in_splits, group):
+    """all_to_all_single.  Under the gloo test hook (several ranks sharing one GPU: RCCL refuses that) device tensors are
+    staged through the host, gloo having no device all-to-all."""
+    if inp.is_cuda and dist.get_backend(group) == 'gloo':
+        host = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_to_all_single(host, inp.cpu(), output_split_sizes=out_splits, input_split_sizes=in_splits, group=group)
+        out.copy_(host)
+    else:
+        dist.all_to_all_single(out, inp, output_split_sizes=out_splits, input_split_sizes=in_splits, group=group)
 
 
 class _Plan(object):
@@ -110,12 +132,11 @@ class _Plan(object):
         self.send_local = (uniq // world)[order].contiguous()                 # owner-local row numbers, grouped by owner
         self.send_counts = torch.bincount(owner, minlength=world)
         recv_counts = torch.empty_like(self.send_counts)
-        dist.all_to_all_single(recv_counts, self.send_counts, group=group)
+        _a2a(recv_counts, self.send_counts, None, None, group)
         self.send_counts_l = self.send_counts.tolist()
         self.recv_counts_l = recv_counts.tolist()
         self.recv_local = torch.empty(int(sum(self.recv_counts_l)), dtype=uniq.dtype, device=uniq.device)
-        dist.all_to_all_single(self.recv_local, self.send_local, output_split_sizes=self.recv_counts_l,
-                               input_split_sizes=self.send_counts_l, group=group)
+        _a2a(self.recv_local, self.send_local, self.recv_counts_l, self.send_counts_l, group)
 
 
 class _ShardedLookup(torch.autograd.Function):
@@ -125,8 +146,7 @@ class _ShardedLookup(torch.autograd.Function):
         plan = _Plan(uniq, world, group)
         packed = table.pack(shard, plan.recv_local)                              # rows my peers asked me for
         rows_sorted = torch.empty(uniq.numel(), shard.shape[1], dtype=shard.dtype, device=shard.device)
-        dist.all_to_all_single(rows_sorted, packed, output_split_sizes=plan.send_counts_l,
-                               input_split_sizes=plan.recv_counts_l, group=group)
+        _a2a(rows_sorted, packed, plan.send_counts_l, plan.recv_counts_l, group)
         rows = torch.empty_like(rows_sorted)
         rows[plan.order] = rows_sorted                                           # back to the order of `uniq`
         ctx.plan, ctx.table, ctx.shape = plan, table, shard.shape
@@ -137,8 +157,7 @@ class _ShardedLookup(torch.autograd.Function):
         plan, table = ctx.plan, ctx.table
         send = grows[plan.order].contiguous()
         recv = torch.empty(plan.recv_local.numel(), grows.shape[1], dtype=grows.dtype, device=grows.device)
-        dist.all_to_all_single(recv, send, output_split_sizes=plan.recv_counts_l, input_split_sizes=plan.send_counts_l,
-                               group=table.group)
+        _a2a(recv, send, plan.recv_counts_l, plan.send_counts_l, table.group)
         gshard = torch.zeros(ctx.shape, dtype=grows.dtype, device=grows.device)
         table.unpack_add(recv, plan.recv_local, gshard)
         return gshard, None, None
@@ -159,18 +178,19 @@ class ShardedTable(torch.nn.Module):
         if init is not None:                        # init(global_row_ids) -> (n x d) values, for reproducible tests / loading
             w.copy_(init(torch.arange(self.rank, total_rows, self.world)))
         self.weight = torch.nn.Parameter(w)
-        self.pack = pack or _default_pack
-        self.unpack_add = unpack_add or _default_unpack_add
+        self.pack = pack or RowOps.pack
+        self.unpack_add = unpack_add or RowOps.unpack_add
+        self.state = None                           # Adagrad accumulator of the shard (ShardedStep creates it)
 
     def lookup(self, ids):
         uniq, inverse = torch.unique(ids, return_inverse=True)
         if self.world == 1:
-            return self.weight.index_select(0, uniq) if not self.weight.is_cuda else _LocalGather.apply(self.weight, uniq, self), inverse
+            return _LocalGather.apply(self.weight, uniq, self), inverse
         return _ShardedLookup.apply(self.weight, uniq, self), inverse
 
 
 class _LocalGather(torch.autograd.Function):
-    """world == 1 on a GPU: the same pack / unpack kernels without the exchange."""
+    """world == 1: the same pack / unpack kernels without the exchange."""
 
     @staticmethod
     def forward(ctx, shard, uniq, table):
@@ -183,6 +203,97 @@ class _LocalGather(torch.autograd.Function):
         g = torch.zeros(ctx.shape, dtype=grows.dtype, device=grows.device)
         ctx.table.unpack_add(grows, uniq, g)
         return g, None, None
+
+
+class ShardedStep(object):
+    """One training step over row-sharded tables that never materialises a shard-sized gradient:
+
+        step = ShardedStep('adagrad', lr, max_norm=5.0)
+        u_rows, u_at = step.lookup(user_table, u_ids)          # compact rows of the batch's distinct ids + positions
+        ...score on (compact rows, positions), loss scaled for the global batch..., loss.backward()
+        step.apply(replicated=[pref, pref_norm, rel, norm])
+
+    lookup : ids -> all-to-all -> owner-side pack -> all-to-all of rows; `rows` is a leaf collecting the dense (compact)
+             row gradients of this rank.
+    apply  : row gradients -> all-to-all back to the owners, duplicates from different ranks combined (atomics into a
+             compact buffer); gradients of the small replicated tables all-reduced; ONE scalar all-reduce gives the job-wide
+             gradient norm for the clip; then the owner updates exactly the touched rows (K: ktup_shard_sparse_step) and
+             every rank applies the same rule to its copy of the replicated tables.
+    Exact w.r.t. the reference's dense step for plain SGD / Adagrad with l2_lambda = 0 (rows with zero gradient do not
+    move); weight decay or momentum would touch every row of every shard each step and are refused."""
+
+    def __init__(self, kind, lr, eps=1e-10, max_norm=0.0, group=None, ops=RowOps):
+        if kind not in ('sgd', 'adagrad'):
+            raise ValueError('row-sparse steps exist for plain SGD and Adagrad only')
+        self.kind, self.lr, self.eps, self.max_norm = kind, float(lr), float(eps), float(max_norm)
+        self.group, self.world, self.ops = group, _world(group), ops
+        self._pending = []
+        self._rep_state = {}
+
+    def lookup(self, table, ids):
+        if any(t is table for t, _, _, _ in self._pending):
+            raise ValueError('one lookup per table and step: concatenate the ids (duplicates are sent once anyway)')
+        uniq, inverse = torch.unique(ids, return_inverse=True)
+        with torch.no_grad():
+            if self.world == 1:
+                plan, rows = None, table.pack(table.weight.data, uniq)
+            else:
+                plan = _Plan(uniq, self.world, self.group)
+                packed = table.pack(table.weight.data, plan.recv_local)
+                rows_sorted = torch.empty(uniq.numel(), table.d, dtype=packed.dtype, device=packed.device)
+                _a2a(rows_sorted, packed, plan.send_counts_l, plan.recv_counts_l, self.group)
+                rows = torch.empty_like(rows_sorted)
+                rows[plan.order] = rows_sorted
+        rows.requires_grad_(True)
+        self._pending.append((table, uniq, plan, rows))
+        return rows, inverse
+
+    def _state_of(self, key, like):
+        if self.kind != 'adagrad':
+            return None
+        st = self._rep_state.get(key)
+        if st is None:
+            st = self._rep_state[key] = torch.zeros_like(like)
+        return st
+
+    @torch.no_grad()
+    def apply(self, replicated=()):
+        ops = self.ops
+        work = []
+        for table, uniq, plan, rows in self._pending:
+            g = rows.grad if rows.grad is not None else torch.zeros_like(rows)
+            if plan is None:
+                ids_local, gsum = uniq, g
+            else:
+                recv = torch.empty(plan.recv_local.numel(), table.d, dtype=g.dtype, device=g.device)
+                _a2a(recv, g[plan.order].contiguous(), plan.recv_counts_l, plan.send_counts_l, self.group)
+                ids_local, at = torch.unique(plan.recv_local, return_inverse=True)     # the same row asked for by several ranks
+                gsum = torch.zeros(ids_local.numel(), table.d, dtype=g.dtype, device=g.device)
+                if recv.shape[0]:
+                    table.unpack_add(recv, at, gsum)
+            work.append((table, ids_local, gsum))
+        self._pending = []
+        reps = [p for p in replicated if p.grad is not None]
+        if self.world > 1:
+            for p in reps:                                                              # small tables: plain all-reduce
+                dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, group=self.group)
+        sumsq = None
+        if self.max_norm > 0:
+            sumsq = ops.sumsq([g for _, _, g in work if g.numel()])                     # every touched row once, at its owner
+            if self.world > 1:
+                dist.all_reduce(sumsq, op=dist.ReduceOp.SUM, group=self.group)
+            if reps:
+                sumsq += ops.sumsq([p.grad for p in reps])                              # identical on every rank: counted once
+        for table, ids_local, gsum in work:
+            if self.kind == 'adagrad' and table.state is None:
+                table.state = torch.zeros_like(table.weight.data)
+            if ids_local.numel():
+                ops.sparse_step(self.kind, table.weight.data, table.state, ids_local, gsum, self.lr, self.eps, sumsq, self.max_norm)
+        for p in reps:
+            every = torch.arange(p.shape[0], device=p.device)
+            ops.sparse_step(self.kind, p.data, self._state_of(id(p), p.data), every, p.grad, self.lr, self.eps, sumsq, self.max_norm)
+            p.grad = None
+        return sumsq
 
 
 # ------------------------------------------------------------------------------------------ sharded-candidate evaluation

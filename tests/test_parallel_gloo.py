@@ -3,12 +3,15 @@
 so plain torch embedding arithmetic stands in for them here: what is under test is the distributed logic."""
 import os
 import socket
+import sys
 
 import numpy as np
 import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))     # _sharded_case, also in the spawned ranks
 
 
 def _free_port():
@@ -75,7 +78,8 @@ def _init_rows(g):
 
 def _sharded_worker(rank, world):
     from jTransUP.parallel import ShardedTable
-    table = ShardedTable(37, 8, init=_init_rows)
+    from _sharded_case import TorchRowOps            # no GPU here: torch stand-ins for the HIP row kernels
+    table = ShardedTable(37, 8, init=_init_rows, pack=TorchRowOps.pack, unpack_add=TorchRowOps.unpack_add)
     assert table.weight.shape[0] == (19 if rank == 0 else 18)
     gens = [torch.Generator().manual_seed(100 + r) for r in range(world)]
     all_ids = [torch.randint(0, 37, (50,), generator=g) for g in gens]      # duplicates on purpose
@@ -94,6 +98,13 @@ def _sharded_worker(rank, world):
     # an empty request from one rank must not deadlock or corrupt the other
     compact, cids = table.lookup(ids[:0] if rank == 0 else ids[:5])
     assert compact.shape[0] == (0 if rank == 0 else len(torch.unique(ids[:5])))
+
+
+def _sharded_step_worker(rank, world):
+    """Config 5's whole step (lookups, row-gradient return, duplicate combine, global clip, row-sparse update) == dense."""
+    from _sharded_case import TorchRowOps, check_against_dense
+    for kind, lr, max_norm in (('adagrad', 0.1, 0.05), ('sgd', 0.05, 0.0), ('sgd', 0.05, 0.02)):
+        check_against_dense(kind, lr, max_norm, 3, torch.device('cpu'), TorchRowOps, rank, world)
 
 
 def _merge_worker(rank, world):
@@ -126,7 +137,7 @@ def _merge_worker(rank, world):
     assert got_ids[0].tolist() == pool
 
 
-@pytest.mark.parametrize('worker', [_replica_worker, _sharded_worker, _merge_worker])
+@pytest.mark.parametrize('worker', [_replica_worker, _sharded_worker, _sharded_step_worker, _merge_worker])
 def test_world_size_2_gloo(worker):
     _spawn(worker)
 
@@ -134,7 +145,8 @@ def test_world_size_2_gloo(worker):
 def test_single_process_paths():
     """world == 1 without a process group: ShardedTable degenerates to a local gather, merge_topk to a sort."""
     from jTransUP.parallel import ReplicaGradSync, ShardedTable, merge_topk
-    t = ShardedTable(10, 8, rank=0, world=1, init=_init_rows)
+    from _sharded_case import TorchRowOps, check_against_dense
+    t = ShardedTable(10, 8, rank=0, world=1, init=_init_rows, pack=TorchRowOps.pack, unpack_add=TorchRowOps.unpack_add)
     ids = torch.tensor([3, 3, 9, 0])
     compact, cids = t.lookup(ids)
     assert torch.equal(compact[cids], _init_rows(ids))
@@ -144,3 +156,6 @@ def test_single_process_paths():
     assert ids_.tolist() == [[2, 5]]
     s = ReplicaGradSync([torch.nn.Parameter(torch.ones(2))])
     assert float(s.scale(torch.tensor(4.0), 'mean')) == 4.0
+    check_against_dense('adagrad', 0.1, 0.05, 3, torch.device('cpu'), TorchRowOps, 0, 1)
+    with pytest.raises(Exception):                   # the product's default row ops are the HIP kernels: CPU tensors are refused
+        ShardedTable(10, 8, rank=0, world=1, init=_init_rows).lookup(ids)

@@ -1,0 +1,87 @@
+"""BASELINE config 5 (KTUP, d = 256, row-sharded user / item / entity tables): the per-GPU training step, timed.
+
+    python tools/config5_step.py                       # one GPU: this rank owns every row (no exchange)
+    torchrun --nproc-per-node 8 tools/config5_step.py  # rows partitioned by row % 8, RCCL all-to-all over xGMI
+
+Per rank and step: B (u, pos, neg) triples.  lookup (unique ids -> [all-to-all -> pack -> all-to-all] -> compact rows),
+KTUP scores of [pos ; neg] on the compact tables (K6, d = 256 matrix-core kernel), BPR loss, backward (dense gradients of
+the compact rows only), ShardedStep.apply (row gradients back to their owners, global-norm clip, row-sparse Adagrad).
+Table sizes are 1/8 of config 5 per rank (10 M users, 1 M items, 5 M entities over 8 GPUs) unless --full is given."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'joint-kg-recommender_amd'))
+
+import torch
+import torch.distributed as dist
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--batch', type=int, default=8192)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--d', type=int, default=256)
+    ap.add_argument('--full', action='store_true', help='the whole 10M / 1M / 5M tables on this rank set (needs ~17 GB per rank at world 1)')
+    args = ap.parse_args()
+    from jTransUP import parallel
+    from jTransUP.hip import ops
+    from jTransUP.utils import loss as Lf
+    rank, world = parallel.init_distributed()
+    dev = torch.device('cuda', torch.cuda.current_device())
+    scale = 1 if args.full else 8
+    NU, NI, NE, P, d, B = 10_000_000 // scale * world, 1_000_000 // scale * world, 5_000_000 // scale * world, 20, args.d, args.batch
+    gen = torch.Generator(device=dev); gen.manual_seed(3 + rank)
+    def table(n):
+        t = parallel.ShardedTable(n, d, rank=rank, world=world, device=dev)
+        t.weight.data.copy_(torch.nn.functional.normalize(torch.randn(t.weight.shape, generator=gen, device=dev), dim=1))
+        return t
+    Ut, It, Et = table(NU), table(NI), table(NE)
+    small = [torch.nn.Parameter(torch.nn.functional.normalize(torch.randn(P, d, generator=gen, device=dev), dim=1)) for _ in range(4)]
+    Pm, Pn, R, Rn = small
+    item2ent = torch.randint(0, NE, (NI,), generator=gen, device=dev)          # alignment map (replicated, int64 here)
+    step = parallel.ShardedStep('adagrad', lr=0.005, max_norm=5.0)
+    times = {'lookup': 0.0, 'score_fwd_bwd': 0.0, 'apply': 0.0}
+    def tick():
+        torch.cuda.synchronize(dev)
+        return time.perf_counter()
+    losses = []
+    for s in range(args.steps + 3):
+        u = torch.randint(0, NU, (B,), generator=gen, device=dev)
+        pi = torch.randint(0, NI, (B,), generator=gen, device=dev); ni = torch.randint(0, NI, (B,), generator=gen, device=dev)
+        t0 = tick()
+        items = torch.cat([pi, ni])
+        u_rows, u_at = step.lookup(Ut, u)
+        i_rows, i_at = step.lookup(It, items)
+        e_rows, e_at = step.lookup(Et, item2ent[items])                         # every item's entity row (no pad rows here)
+        t1 = tick()
+        # the scorer addresses the compact tables: item k of the batch -> compact item row i_at[k], compact entity row e_at[k];
+        # item2ent for the compact item table = the entity position of (one of) the batch entries that produced that row
+        i2e_compact = torch.empty(i_rows.shape[0], dtype=torch.int32, device=dev)
+        i2e_compact[i_at] = e_at.to(torch.int32)
+        uu = torch.cat([u_at, u_at])
+        score = ops.score_ktup(u_rows, i_rows, e_rows, Pm, Pn, R, Rn, i2e_compact, uu, i_at, False, ent_pad=-1)
+        loss = Lf.bprLoss(score[:B], score[B:], target=-1) / world              # global mean over world * B
+        loss.backward()
+        t2 = tick()
+        step.apply(replicated=small)
+        t3 = tick()
+        if s >= 3:
+            times['lookup'] += t1 - t0; times['score_fwd_bwd'] += t2 - t1; times['apply'] += t3 - t2
+            losses.append(float(loss.detach()) * world)
+    total = sum(times.values())
+    if world > 1:
+        tt = torch.tensor([total], device=dev); dist.all_reduce(tt, op=dist.ReduceOp.MAX); total = float(tt)
+    if rank == 0:
+        print(json.dumps({'config': 'KTUP d=%d, %d/%d/%d rows (users/items/entities) over %d rank(s), B=%d per rank' % (d, NU, NI, NE, world, B),
+                          'ms_per_step': 1e3 * total / args.steps, 'ms': {k: 1e3 * v / args.steps for k, v in times.items()},
+                          'scored_rows_per_s': 2 * B * world * args.steps / total, 'loss_first_last': [losses[0], losses[-1]]}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -7,6 +7,8 @@ ROCm; "gloo" on CPU tensors for the world-size-2 tests).  The reference is singl
   * ShardedTable     -- config 5: a table too big to replicate is partitioned by `row % world`; a batch lookup is
                         ids -> all-to-all -> owner-side row pack -> all-to-all of rows, and the row gradients travel the
                         reverse route into the owner's shard gradient.  Duplicate ids are sent once.
+  * ShardedStep      -- config 5's whole step without a shard-sized gradient: compact row gradients back to the owners, ONE
+                        scalar all-reduce for the global-norm clip, row-sparse SGD / Adagrad on the touched rows.
   * merge_topk       -- evaluation with the candidate catalogue sharded across GPUs: local filtered top-n per shard, then
                         an all-gather of (score, id) pairs and a merge under the same (score, id) order.
 

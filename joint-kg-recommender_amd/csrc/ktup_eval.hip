@@ -88,18 +88,29 @@ __global__ __launch_bounds__(256) void pref_project_kernel(const float* __restri
       if (E) x = x + reinterpret_cast<const float4*>(E + (int64_t)item2ent[src] * lde)[lane];
     }
     float4 racc = f4zero(), nacc = f4zero();
-    float mylog = 0.f;
-    for (int p = 0; p < P; ++p) {
-      float part = lane < nch ? dot4(x, Alog[p * dp4 + lane]) : 0.f;
-      part = wave_sum(part);
-      if (lane == (p & 63)) mylog = part;
-      if (lane < nch) {
-        racc = fma4(part, Ar[p * dp4 + lane], racc);
-        nacc = fma4(part, Cn[p * dp4 + lane], nacc);
+    for (int pb = 0; pb < P; pb += 64) {          // up to 64 logits per pass: lane l keeps logit pb + l
+      const int pe = min(P, pb + 64);
+      float mylog = 0.f;
+      // phase 1: the logits.  Four preferences per trip = four INDEPENDENT cross-lane reductions in flight (one dependent
+      // reduction per preference, as a single loop had it, is a chain of ~20 x 6 shuffle latencies per row)
+      for (int p = pb; p < pe; p += 4) {
+        float part[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) part[k] = (lane < nch && p + k < pe) ? dot4(x, Alog[min(p + k, pe - 1) * dp4 + lane]) : 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) part[k] = wave_sum(part[k]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (lane == p + k - pb) mylog = part[k];
       }
-      if ((p & 63) == 63 || p == P - 1) {  // flush up to 64 logits per pass
-        const int pw = (p & ~63) + lane;
-        if (pw <= p) OL[row * P + pw] = mylog;
+      if (pb + lane < pe) OL[row * P + pb + lane] = mylog;
+      // phase 2: R and N accumulate over the preferences; logit p comes from lane p - pb (uniform index -> v_readlane)
+      for (int p = pb; p < pe; ++p) {
+        const float lp = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mylog), p - pb));
+        if (lane < nch) {
+          racc = fma4(lp, Ar[p * dp4 + lane], racc);
+          nacc = fma4(lp, Cn[p * dp4 + lane], nacc);
+        }
       }
     }
     if (lane < nch) {

@@ -180,7 +180,19 @@ def summarize_kg(FLAGS, head_results, tail_results, logger):
     avg_hit = float(head_hit * hn + tail_hit * tn) / (hn + tn)
     avg_rank = float(head_rank * hn + tail_rank * tn) / (hn + tn)
     logger.info('avg hit:{:.4f}, avg mean rank:{:.4f}, topn:{}.'.format(avg_hit, avg_rank, FLAGS.topn))
+    # MRR is not a metric of the reference (it reports hit@n and mean rank only): mean 1 / (rank + 1) over the same 0-based
+    # filtered ranks, logged on its own line so that the reference's log lines and return value stay as they are
+    logger.info('avg mrr:{:.4f} (head {:.4f}, tail {:.4f}).'.format(*kg_mrr(head_results, tail_results)))
     return avg_hit, avg_rank
+
+
+def kg_mrr(head_results, tail_results):
+    """(avg, head, tail) mean reciprocal rank from kg_eval_pass results (rows or (n x 2) arrays of (hit, 0-based rank))."""
+    ranks = lambda res: (res[:, 1] if isinstance(res, np.ndarray) else np.array([row[1] for row in res], dtype=np.float64)).astype(np.float64)
+    h, t = ranks(head_results), ranks(tail_results)
+    rr = lambda r: float((1.0 / (r + 1.0)).mean()) if r.size else 0.0
+    both = np.concatenate([h, t])
+    return rr(both), rr(h), rr(t)
 
 
 def report_kg(head_results, tail_results, logger):

@@ -272,6 +272,14 @@ def kg_performance(pred, gold, filter_samples=None, topn=10):
     return hits, gold_ranks, gold_ids
 
 
+def mrr_from_ranks(gold_ranks):
+    """Mean reciprocal rank over the 0-based filtered ranks of utils/misc.py:134-144: mean of 1 / (rank + 1).  The reference
+    never computes MRR (its KG summary is hit@n and mean rank, knowledge_representation.py:49-63); BASELINE.json's north_star
+    asks for it, so it is DEFINED here on the reference's own rank lists."""
+    ranks = np.asarray(list(gold_ranks), dtype=np.float64)
+    return float((1.0 / (ranks + 1.0)).mean()) if ranks.size else 0.0
+
+
 def _filter_union(key, all_dicts):
     """utils/misc.py:83-89,168-174."""
     if all_dicts is None:

@@ -185,3 +185,34 @@ def test_binary_dataset_cache_round_trip_and_staleness(tmp_path, monkeypatch):
     calls.clear()
     load_kg_rating_data.load_data(root, ['valid.dat'], ['valid.dat'], 16)
     assert not calls
+
+
+def test_kg_summary_and_mrr_from_the_reference_rank_lists():
+    """summarize_kg keeps the reference's numbers (hit@n, mean 0-based rank) and adds MRR = mean 1 / (rank + 1) over the same
+    filtered ranks -- rows (report mode) and (n x 2) arrays (fast path) agree with the oracle's walk."""
+    import logging
+    import types
+    import numpy as np
+    from jTransUP.models import _driver as D
+    from oracle import cpu_ref as O
+    rng = np.random.RandomState(0)
+    FL = types.SimpleNamespace(topn=10)
+    head, tail, all_ranks = [], [], {'h': [], 't': []}
+    for side, out in (('h', head), ('t', tail)):
+        for q in range(40):
+            pred = rng.rand(300).astype(np.float32)
+            gold = set(rng.choice(300, size=rng.randint(1, 5), replace=False).tolist())
+            filt = set(rng.choice(300, size=30, replace=False).tolist()) - gold
+            hits, ranks, ids = O.kg_performance(pred, gold, filt, topn=10)
+            out.extend((h, r, (q, 0), g) for h, r, g in zip(hits, ranks, ids))
+            all_ranks[side].extend(ranks)
+    log = logging.getLogger('mrr-test')
+    avg_hit, avg_rank = D.summarize_kg(FL, head, tail, log)
+    n = len(head) + len(tail)
+    assert abs(avg_rank - (sum(all_ranks['h']) + sum(all_ranks['t'])) / n) < 1e-9
+    assert abs(avg_hit - (sum(r[0] for r in head) + sum(r[0] for r in tail)) / n) < 1e-12
+    want = (O.mrr_from_ranks(all_ranks['h'] + all_ranks['t']), O.mrr_from_ranks(all_ranks['h']), O.mrr_from_ranks(all_ranks['t']))
+    np.testing.assert_allclose(D.kg_mrr(head, tail), want, rtol=1e-12)
+    cols = lambda rows: np.array([[r[0], r[1]] for r in rows], dtype=np.float64)
+    np.testing.assert_allclose(D.kg_mrr(cols(head), cols(tail)), want, rtol=1e-12)
+    assert O.mrr_from_ranks([0, 1, 3]) == (1 + 0.5 + 0.25) / 3

@@ -412,6 +412,47 @@ __global__ __launch_bounds__(256) void transr_project_kernel(const float* __rest
   }
 }
 
+// TransR, squared L2, on the matrix cores:  |c - M_r e|^2 = |c|^2 - 2 (M_r^T c) . e + |M_r e|^2.
+//   fold : per query, c' = M_r^T c replaces c in slot 0 (so the pair term is ONE (queries x d) . (d x entities) GEMM against the
+//          UNPROJECTED entity table), |c|^2 and the relation id go to side arrays.  One wave per query.
+//   norms: |M_r e|^2 for every (relation, entity) = the K4 matrix-core forward with h = e, no tail, no translation.
+__global__ __launch_bounds__(256) void transr_query_fold_kernel(float* __restrict__ QW, int dq, const float* __restrict__ M,
+                                                                int64_t ldm, int d, const int64_t* __restrict__ r, int64_t nq,
+                                                                float* __restrict__ qcc, int32_t* __restrict__ qrel) {
+  __shared__ float cs[4][256];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t b = (int64_t)blockIdx.x * 4 + w;
+  if (b >= nq) return;
+  float* c = QW + b * 3 * dq;
+  const int rel = (int)r[b];
+  float part = 0.f;
+  for (int k = lane; k < d; k += 64) { const float v = c[k]; cs[w][k] = v; part = fmaf(v, v, part); }
+  part = wave_sum(part);
+  const float* Mr = M + (int64_t)rel * ldm;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};                          // c'[k] for k = lane + 64 m  (d <= 256)
+  for (int i = 0; i < d; ++i) {
+    const float ci = cs[w][i];                                  // LDS broadcast
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int k = lane + 64 * m;
+      if (k < d) acc[m] = fmaf(Mr[(int64_t)i * d + k], ci, acc[m]);
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const int k = lane + 64 * m;
+    if (k < d) c[k] = acc[m];
+  }
+  if (lane == 0) { qcc[b] = part; qrel[b] = rel; }
+}
+
+__global__ __launch_bounds__(256) void transr_all_pairs_ids_kernel(int64_t n_ent, int64_t n, int64_t* __restrict__ h, int64_t* __restrict__ r) {
+  for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (int64_t)gridDim.x * 256) {
+    h[k] = k % n_ent;
+    r[k] = k / n_ent;
+  }
+}
+
 // Counting sort of the queries by relation (single workgroup; nq is an evaluation batch, n_rel is small).
 __global__ __launch_bounds__(256) void rel_bucket_kernel(const int64_t* __restrict__ r, int64_t nq, int n_rel,
                                                          int32_t* __restrict__ rel_off, int32_t* __restrict__ qperm) {
@@ -550,6 +591,30 @@ extern "C" int ktup_eval_transr_scores(const float* E, int64_t lde, const float*
   hipLaunchKernelGGL(kg_query_prep_kernel, dim3(grid_for((nq + 3) / 4)), dim3(256), 0, st, 2, E, lde, R, ldr, M, ldm, d, dq, q, r,
                      nq, head, QW);
   if (int e = check_launch(name)) return e;
+  if (!l1 && (d == 64 || d == 100 || d == 128) && aligned16(E) && lde % 4 == 0 && getenv("KTUP_EVAL_MC") == nullptr) {
+    // squared L2 on the matrix cores; the scratch of this route lives in the PE region (it is far smaller than the
+    // projected tables the VALU route stores there)
+    const int64_t n = (int64_t)n_rel * n_ent;
+    float* qcc = PE;                                            // [nq]
+    float* norms = qcc + pad4((size_t)nq);                      // [n_rel][n_ent]
+    int32_t* qrel = reinterpret_cast<int32_t*>(norms + pad4((size_t)n));
+    int64_t* hid = reinterpret_cast<int64_t*>(qrel + pad4((size_t)nq) + 2);
+    hid = reinterpret_cast<int64_t*>(((uintptr_t)hid + 15) & ~(uintptr_t)15);
+    int64_t* rid = hid + n;
+    void* bws = rid + n;
+    const size_t need = (size_t)((char*)bws - (char*)PE) + ktup::transr_mc_workspace_bytes(n, n_rel);
+    if (need <= (size_t)n_rel * n_ent * dq * sizeof(float)) {
+      hipLaunchKernelGGL(transr_query_fold_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, st, QW, dq, M, ldm, d, r, nq, qcc, qrel);
+      hipLaunchKernelGGL(transr_all_pairs_ids_kernel, dim3(grid_for((n + 255) / 256)), dim3(256), 0, st, n_ent, n, hid, rid);
+      if (int e = check_launch(name)) return e;
+      int rc = ktup::transr_fwd_mc(E, lde, nullptr, 0, M, ldm, n_rel, d, hid, nullptr, rid, n, 0, norms, bws, st, name);
+      if (rc == KTUP_OK) rc = ktup::pairs_kg_l2_mc(0, QW, dq, E, lde, d, nq, n_ent, out, ldo, st, name, qcc, norms, qrel);
+      if (rc != 1) return rc;
+      // (not an instantiated shape after all: c' has overwritten c, so rebuild the queries for the VALU route)
+      hipLaunchKernelGGL(kg_query_prep_kernel, dim3(grid_for((nq + 3) / 4)), dim3(256), 0, st, 2, E, lde, R, ldr, M, ldm, d, dq, q, r,
+                         nq, head, QW);
+    }
+  }
   const size_t lds = (size_t)(dq / 4) * CT * 16;
   KTUP_REQUIRE(lds <= 64 * 1024 && (size_t)n_rel * 4 <= 64 * 1024, "%s: embedding_size / n_rel too large", name);
   const int evec = (d % 4 == 0) && aligned16(E) && lde % 4 == 0;

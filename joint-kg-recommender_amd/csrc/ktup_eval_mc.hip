@@ -170,6 +170,9 @@ struct KArgs {
   const float* C; int64_t ldc;      // candidates
   int64_t nq, n_cand;
   float* out; int64_t ldo;
+  // TransR (all three non-NULL): slot 0 holds c' = M_r^T c, the query's |c|^2 comes from qcc and the candidate term is
+  // |M_r e|^2 = cnorm[qrel[query] * n_cand + candidate]  (|c - M_r e|^2 = |c|^2 - 2 c'.e + |M_r e|^2)
+  const float* qcc; const float* cnorm; const int32_t* qrel;
 };
 
 template <typename G>
@@ -245,8 +248,12 @@ __global__ __launch_bounds__(G::NW * 64) void pairs_kg_l2_mc_kernel(KArgs a) {
 #pragma unroll
   for (int reg = 0; reg < 4; ++reg) {
     const int ur = 16 * ut + 4 * kq + reg;
-    const float cc = qs[ur * 4 + 0];
-    float score = fmaf(-2.f, ce[reg], cc + ee);
+    float cc = qs[ur * 4 + 0], en = ee;
+    if (a.cnorm && u0 + ur < a.nq && cand < a.n_cand) {
+      cc = a.qcc[u0 + ur];
+      en = a.cnorm[(int64_t)a.qrel[u0 + ur] * a.n_cand + cand];
+    }
+    float score = fmaf(-2.f, ce[reg], cc + en);
     if (TRANSH) {
       const float cw = qs[ur * 4 + 1], ww = qs[ur * 4 + 2], ew = we[reg];
       score = fmaf(ew, fmaf(ew, ww - 2.f, 2.f * cw), score);
@@ -295,10 +302,10 @@ int pairs_l2_mc(const float* QW, const float* C0, const float* C1, const float* 
 
 // model: 0 TransE, 1 TransH.  Same contract as pairs_l2_mc.
 int pairs_kg_l2_mc(int model, const float* QW, int dq, const float* C, int64_t ldc, int d, int64_t nq, int64_t n_cand, float* out,
-                   int64_t ldo, hipStream_t st, const char* name) {
+                   int64_t ldo, hipStream_t st, const char* name, const float* qcc, const float* cnorm, const int32_t* qrel) {
   if (!aligned16(QW) || !aligned16(C) || (ldc & 3) || dq != d) return 1;
   if ((nq + 63) / 64 > 65535) return 1;
-  const KArgs a{QW, dq, C, ldc, nq, n_cand, out, ldo};
+  const KArgs a{QW, dq, C, ldc, nq, n_cand, out, ldo, qcc, cnorm, qrel};
   return model == 1 ? dispatch_kg<true>(a, d, st, name) : dispatch_kg<false>(a, d, st, name);
 }
 

@@ -95,7 +95,8 @@ int pairs_l2_mc(const float* QW, const float* C0, const float* C1, const float* 
                 int64_t ldo, hipStream_t st, const char* name);
 
 int pairs_kg_l2_mc(int model, const float* QW, int dq, const float* C, int64_t ldc, int d, int64_t nq, int64_t n_cand, float* out,
-                   int64_t ldo, hipStream_t st, const char* name);
+                   int64_t ldo, hipStream_t st, const char* name, const float* qcc = nullptr,
+                   const float* cnorm = nullptr, const int32_t* qrel = nullptr);
 
 // ktup_score_pref_bwd_mc.hip: matrix-core backward of the TUP / KTUP score (soft and ST-Gumbel gate).  Returns 1 for shapes it does not cover.
 int pref_bwd_mc(const float* U, int64_t ldu, const float* I, int64_t ldi, const float* E, int64_t lde, const int32_t* item2ent,

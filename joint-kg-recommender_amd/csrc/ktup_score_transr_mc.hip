@@ -158,7 +158,7 @@ __global__ __launch_bounds__(G::NW * 64) void transr_fwd_mc_kernel(RArgs a) {
         Msf[idx] = (row < D && k < D) ? Mg[row * D + k] : 0.f;
       }
       float* rSf = reinterpret_cast<float*>(rS);
-      for (int idx = tid; idx < 16 * CT; idx += NW * 64) rSf[idx] = idx < D ? a.R[(int64_t)rr * a.ldr + idx] : 0.f;
+      for (int idx = tid; idx < 16 * CT; idx += NW * 64) rSf[idx] = (a.R && idx < D) ? a.R[(int64_t)rr * a.ldr + idx] : 0.f;   // R == NULL: no translation
       __syncthreads();
       staged = rr;
     }
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(G::NW * 64) void transr_fwd_mc_kernel(RArgs a) {
         if (sub * 16 + lane < count) my = b.perm[base + lane];
         const int src = my >= 0 ? my : b.perm[base];                       // tail lanes re-read the tile's first triple
         sid[lane] = (int32_t)a.h[src];
-        sid[16 + lane] = (int32_t)a.t[src];
+        sid[16 + lane] = a.t ? (int32_t)a.t[src] : 0;
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(G::NW * 64) void transr_fwd_mc_kernel(RArgs a) {
           asm volatile("" : "+v"(gc[jj]));
           const uint32_t ih = (uint32_t)sid[grow[jj]], it = (uint32_t)sid[16 + grow[jj]];
           hh[jj] = a.E[(uint64_t)ih * a.lde4 + (uint32_t)gc[jj]];
-          tt[jj] = a.E[(uint64_t)it * a.lde4 + (uint32_t)gc[jj]];
+          tt[jj] = a.t ? a.E[(uint64_t)it * a.lde4 + (uint32_t)gc[jj]] : (v4){0.f, 0.f, 0.f, 0.f};   // t == NULL: project h alone
         }
 #pragma unroll
         for (int jj = 0; jj < J; ++jj) {

@@ -42,22 +42,32 @@ KTUP_DEV int find_tensor(const OptTensors& T, int64_t chunk) {
 }
 
 __global__ __launch_bounds__(256) void gradnorm_kernel(OptTensors T, double* __restrict__ sumsq) {
-  const int64_t nchunks = T.chunk0[T.count];
+  // work unit = a quarter chunk (256 float4).  At ml1m size (2.4 M gradient floats) this pass is latency-bound, and its
+  // cost is the serialised double atomics on ONE address (one per workgroup): few workgroups, four loads in flight each
+  const int64_t nunits = T.chunk0[T.count] * 4;
   float acc = 0.f;
-  for (int64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-    const int k = find_tensor(T, chunk);
-    const int64_t base = (chunk - T.chunk0[k]) * CHUNK;
-    const float* g = T.g[k];
-    const int64_t n = T.n[k];
+  for (int64_t u0 = blockIdx.x; u0 < nunits; u0 += (int64_t)gridDim.x * 4) {
+    float4 v[4];
+    int64_t rest_i[4], rest_n[4];
+    const float* rest_g[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int64_t i = base + ((int64_t)r * 256 + threadIdx.x) * 4;
-      if (i + 3 < n) {
-        const float4 v = *reinterpret_cast<const float4*>(g + i);
-        acc += dot4(v, v);
-      } else {
-        for (int64_t e = i; e < n; ++e) acc = fmaf(g[e], g[e], acc);
+    for (int q = 0; q < 4; ++q) {
+      const int64_t unit = u0 + (int64_t)q * gridDim.x;
+      v[q] = f4zero(); rest_g[q] = nullptr; rest_i[q] = 0; rest_n[q] = 0;
+      if (unit < nunits) {
+        const int64_t chunk = unit >> 2;
+        const int k = find_tensor(T, chunk);
+        const float* g = T.g[k];
+        const int64_t n = T.n[k];
+        const int64_t i = (chunk - T.chunk0[k]) * CHUNK + ((unit & 3) * 256 + threadIdx.x) * 4;
+        if (i + 3 < n) v[q] = *reinterpret_cast<const float4*>(g + i);
+        else { rest_g[q] = g; rest_i[q] = i; rest_n[q] = n; }
       }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      acc += dot4(v[q], v[q]);
+      for (int64_t e = rest_i[q]; e < rest_n[q]; ++e) acc = fmaf(rest_g[q][e], rest_g[q][e], acc);
     }
   }
   acc = group_sum<64>(acc);                    // <= 64 x (a few chunks x 16) fp32 terms per wave; the cross-workgroup sum is fp64
@@ -199,7 +209,7 @@ extern "C" int ktup_optim_gradnorm(int n_tensors, float* const* grads, const int
   if (hipMemsetAsync(sumsq, 0, sizeof(double), st) != hipSuccess) return check_launch("ktup_optim_gradnorm");
   const int64_t nchunks = T.chunk0[T.count];
   if (nchunks == 0) return KTUP_OK;
-  hipLaunchKernelGGL(gradnorm_kernel, dim3(grid_for(nchunks, 256 * 4)), dim3(256), 0, st, T, sumsq);
+  hipLaunchKernelGGL(gradnorm_kernel, dim3(grid_for((nchunks * 4 + 3) / 4, 256)), dim3(256), 0, st, T, sumsq);
   return check_launch("ktup_optim_gradnorm");
 }
 

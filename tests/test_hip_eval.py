@@ -341,3 +341,26 @@ def test_eval_passes_fast_paths_equal_the_row_paths():
     assert kcols.shape == (len(krows), 2) and len(krows) > 0
     want = np.array(sorted((float(h), float(rk)) for h, rk, _, _ in krows))
     np.testing.assert_array_equal(np.array(sorted(map(tuple, kcols.tolist()))), want)
+
+
+@pytest.mark.parametrize('d,ne,nq,nrel', [(100, 3000, 70, 20), (128, 1500, 33, 7), (64, 2049, 65, 20)])
+def test_transr_l2_matrix_core_route_vs_oracle(d, ne, nq, nrel, monkeypatch):
+    """TransR squared-L2 evaluation on the matrix cores (queries folded through M_r^T, |M_r e|^2 from the K4 forward) against
+    the oracle, and against the VALU route (KTUP_EVAL_MC=0) at the ml1m entity count."""
+    gen = torch.Generator().manual_seed(d + ne)
+    E, R = O.make_table(ne, d, gen), O.make_table(nrel, d, gen)
+    M = torch.eye(d).reshape(1, d * d).repeat(nrel, 1) + torch.randn(nrel, d * d, generator=gen) * 0.05   # ~ the ctor's identity init
+    q = torch.randint(0, ne, (nq,), generator=gen); r = torch.randint(0, nrel, (nq,), generator=gen)
+    r[:3] = r[0]                                                   # several queries of one relation
+    Ed, Rd, Md = E.to(DEV), R.to(DEV), M.to(DEV)
+    for head in (True, False):
+        got = ops().eval_transr(Ed, Rd, Md, q.to(DEV), r.to(DEV), False, head)
+        close(got, O.eval_transr(E, R, M, q, r, False, head), rtol=2e-4, atol=5e-5)
+    big = O.make_table(14709, d, gen).to(DEV)
+    qb = torch.randint(0, 14709, (200,), generator=gen).to(DEV); rb = torch.randint(0, nrel, (200,), generator=gen).to(DEV)
+    a = ops().eval_transr(big, Rd, Md, qb, rb, False, True)
+    monkeypatch.setenv('KTUP_EVAL_MC', '0')
+    b = ops().eval_transr(big, Rd, Md, qb, rb, False, True)
+    monkeypatch.delenv('KTUP_EVAL_MC')
+    close(a, b, rtol=2e-4, atol=5e-5)
+    assert torch.equal(a.argsort(1)[:, :5], b.argsort(1)[:, :5])   # same best candidates either way

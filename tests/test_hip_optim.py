@@ -87,3 +87,31 @@ def test_trainer_uses_the_fused_step(tmp_path):
     m(u, i).sum().backward()
     tr.clip_and_step(FLAGS.clipping_max_value)
     assert tr.step == 1 and not torch.equal(before, m.user_embeddings.weight.detach())
+
+
+def test_adam_step_counts_host_array_and_device_array_agree():
+    """ktup_optim_step takes Adam's step counts as a host array (`steps`) or from device memory (`steps_dev`, for graph
+    replay): same update, and both equal torch.optim.Adam at that step."""
+    import ctypes
+    from jTransUP.hip import lib as L
+    gen = torch.Generator().manual_seed(0)
+    n, t = 5000, 7
+    p0, g0 = torch.randn(n, generator=gen), torch.randn(n, generator=gen) * 0.1
+    m0, v0 = torch.randn(n, generator=gen) * 0.01, torch.rand(n, generator=gen) * 0.01
+    outs = []
+    for use_dev in (False, True):
+        p, g, m, v = (x.clone().to(DEV) for x in (p0, g0, m0, v0))
+        arr = lambda vals: (ctypes.c_void_p * 1)(*vals)
+        steps = (ctypes.c_int64 * 1)(t if not use_dev else 12345)            # ignored when steps_dev is given
+        dsteps = torch.tensor([t], dtype=torch.int64, device=DEV)
+        L.call('ktup_optim_step', 2, 1, arr([p.data_ptr()]), arr([g.data_ptr()]), arr([m.data_ptr()]), arr([v.data_ptr()]),
+               (ctypes.c_int64 * 1)(n), steps, dsteps.data_ptr() if use_dev else None, (ctypes.c_int32 * 1)(0), 0.01, 0.0, 0.0, 0.9, 0.999,
+               1e-8, 0.0, None, 0.0, 0, torch.cuda.current_stream().cuda_stream)
+        outs.append((p.cpu(), m.cpu(), v.cpu()))
+    for a, b in zip(*outs):
+        torch.testing.assert_close(a, b, rtol=1e-6, atol=1e-7)
+    pt = torch.nn.Parameter(p0.clone()); pt.grad = g0.clone()
+    opt = torch.optim.Adam([pt], lr=0.01)
+    opt.state[pt] = {'step': torch.tensor(float(t - 1)), 'exp_avg': m0.clone(), 'exp_avg_sq': v0.clone()}
+    opt.step()
+    torch.testing.assert_close(outs[0][0], pt.data, rtol=1e-5, atol=1e-6)

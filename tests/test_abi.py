@@ -62,3 +62,23 @@ def test_cpu_tensors_fail_loudly(lib):
         pytest.skip('GPU present: covered by the gpu tests')
     with pytest.raises(lib.KtupError):
         m(torch.tensor([0]), torch.tensor([1]), torch.tensor([2]))
+
+
+def test_host_side_validation_of_the_newer_entry_points(lib):
+    """Every rejection below happens before any launch (no GPU needed): status < 0 -> KtupError carrying ktup_last_error()."""
+    d = 16                                                # a non-null dummy: validated, never dereferenced on the host
+    with pytest.raises(lib.KtupError) as e:               # chunked ranking path: topn is bounded by its LDS list
+        lib.call('ktup_eval_topk_filtered', d, 20000, 4, 20000, 0, None, None, 2000, d, None, None)
+    assert 'topn' in str(e.value)
+    with pytest.raises(lib.KtupError) as e:               # row-sparse step exists for plain SGD / Adagrad only
+        lib.call('ktup_shard_sparse_step', 2, d, 100, d, 100, 100, d, 5, d, 100, 0.1, 1e-10, None, 0.0, None)
+    assert 'SGD' in str(e.value)
+    with pytest.raises(lib.KtupError):                    # clipping without the sum of squares
+        lib.call('ktup_shard_sparse_step', 0, d, 100, None, 0, 100, d, 5, d, 100, 0.1, 1e-10, None, 1.0, None)
+    with pytest.raises(lib.KtupError):
+        lib.call('ktup_eval_rec_metrics', None, 4, 10, d, d, d, None)
+    with pytest.raises(lib.KtupError) as e:               # device-resident Philox state needs its pointer
+        lib.call('ktup_score_tup_fwd', d, 100, d, 100, d, 20, 100, d, d, 5, 0, 3, None, 0, 0, d, None)
+    assert 'PHILOX_DEV' in str(e.value)
+    with pytest.raises(lib.KtupError):                    # fused loss: null accumulator
+        lib.call('ktup_loss_bpr_fused', d, d, 5, -1.0, d, None, d, d, None)

@@ -25,6 +25,7 @@ def main():
     ap.add_argument('--batch', type=int, default=8192)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--d', type=int, default=256)
+    ap.add_argument('--zipf', type=float, default=0.0, help='draw ids from Zipf(a) (hot rows: contention in the row-gradient atomics) instead of uniformly, e.g. 1.05')
     ap.add_argument('--full', action='store_true', help='the whole 10M / 1M / 5M tables on this rank set (needs ~17 GB per rank at world 1)')
     args = ap.parse_args()
     from jTransUP import parallel
@@ -49,9 +50,18 @@ def main():
         torch.cuda.synchronize(dev)
         return time.perf_counter()
     losses = []
+    def draw(n_rows):
+        if args.zipf <= 0:
+            return torch.randint(0, n_rows, (B,), generator=gen, device=dev)
+        # Zipf(a) by inverse transform of the continuous power law on [1, n_rows]: rank ~ u^(-1/(a-1)) truncated (a > 1)
+        uu = torch.rand(B, generator=gen, device=dev, dtype=torch.float64)
+        a1 = args.zipf - 1.0
+        top = float(n_rows) ** (-a1)
+        rank = (1.0 - uu * (1.0 - top)) ** (-1.0 / a1)
+        return (rank.clamp(1, n_rows) - 1).to(torch.int64)
     for s in range(args.steps + 3):
-        u = torch.randint(0, NU, (B,), generator=gen, device=dev)
-        pi = torch.randint(0, NI, (B,), generator=gen, device=dev); ni = torch.randint(0, NI, (B,), generator=gen, device=dev)
+        u = draw(NU)
+        pi = draw(NI); ni = draw(NI)
         t0 = tick()
         items = torch.cat([pi, ni])
         u_rows, u_at = step.lookup(Ut, u)
@@ -76,7 +86,7 @@ def main():
     if world > 1:
         tt = torch.tensor([total], device=dev); dist.all_reduce(tt, op=dist.ReduceOp.MAX); total = float(tt)
     if rank == 0:
-        print(json.dumps({'config': 'KTUP d=%d, %d/%d/%d rows (users/items/entities) over %d rank(s), B=%d per rank' % (d, NU, NI, NE, world, B),
+        print(json.dumps({'config': 'KTUP d=%d, %d/%d/%d rows (users/items/entities) over %d rank(s), B=%d per rank, ids %s' % (d, NU, NI, NE, world, B, 'Zipf(%.2f)' % args.zipf if args.zipf > 0 else 'uniform'),
                           'ms_per_step': 1e3 * total / args.steps, 'ms': {k: 1e3 * v / args.steps for k, v in times.items()},
                           'scored_rows_per_s': 2 * B * world * args.steps / total, 'loss_first_last': [losses[0], losses[-1]]}))
     if world > 1:

@@ -186,7 +186,15 @@ __global__ __launch_bounds__(G::NW * 64) void pairs_kg_l2_mc_kernel(KArgs a) {
   float* cs = qs + UB * 4;                                     // [IB]:    |e|^2
   const int tid = threadIdx.x, lane = tid & 63, kq = lane >> 4, j = lane & 15;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int64_t u0 = (int64_t)blockIdx.y * UB, i0 = (int64_t)blockIdx.x * IB;
+  // XCD-aware tile order: the hardware deals consecutive workgroups round-robin to the 8 XCDs (each with its own 4 MB L2).
+  // The entity table (5.9 MB at ml1m) does not fit one L2, so every XCD gets a contiguous BAND of candidate tiles (all of
+  // its workgroups then re-read the same ~0.75 MB of candidates and the whole, small, query block) instead of all of them.
+  // The launch pads grid.x to 8 bands of nxp tiles; tiles past the last real one exit here.
+  const int nxp = gridDim.x >> 3;
+  const int bid = blockIdx.y * gridDim.x + blockIdx.x, xcd = bid & 7, local = bid >> 3;
+  const int tx = xcd * nxp + local % nxp, ty = local / nxp;
+  if ((int64_t)tx * IB >= a.n_cand) return;
+  const int64_t u0 = (int64_t)ty * UB, i0 = (int64_t)tx * IB;
   for (int idx = tid; idx < UB * QV * NCH; idx += NW * 64) {
     const int row = idx / (QV * NCH), rem = idx - row * (QV * NCH), vec = rem / NCH, c = rem - vec * NCH;
     v4 val = (v4){0.f, 0.f, 0.f, 0.f};
@@ -265,7 +273,8 @@ __global__ __launch_bounds__(G::NW * 64) void pairs_kg_l2_mc_kernel(KArgs a) {
 template <typename G>
 int launch_kg(const KArgs& a, hipStream_t st, const char* name) {
   (void)hipFuncSetAttribute((const void*)pairs_kg_l2_mc_kernel<G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS);
-  const dim3 grid((unsigned)((a.n_cand + IB - 1) / IB), (unsigned)((a.nq + G::UB - 1) / G::UB));
+  const unsigned nx = (unsigned)((a.n_cand + IB - 1) / IB), nxp = (nx + 7) / 8;       // 8 XCD bands of nxp candidate tiles
+  const dim3 grid(8 * nxp, (unsigned)((a.nq + G::UB - 1) / G::UB));
   hipLaunchKernelGGL((pairs_kg_l2_mc_kernel<G>), grid, dim3(G::NW * 64), G::LDS, st, a);
   return check_launch(name);
 }

@@ -94,6 +94,7 @@ __global__ __launch_bounds__(G::NW * 64) void pref_fwd_mc_kernel(McArgs a) {
   float* ArS = CnS + G::T_F;
   const int t = threadIdx.x, lane = t & 63, kq = lane >> 4, j = lane & 15;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int nthr = blockDim.x, nwr = nthr >> 6;                  // waves actually launched (<= G::NW; fewer for small batches)
   char* wbase = reinterpret_cast<char*>(ArS + G::T_F) + (size_t)w * G::WAVE_BYTES;
   v4* xt = reinterpret_cast<v4*>(wbase);                         // [16 * NCH] + 3 zero chunks
   int32_t* sid = reinterpret_cast<int32_t*>(xt + G::XT_F4);      // [3][16]
@@ -104,14 +105,14 @@ __global__ __launch_bounds__(G::NW * 64) void pref_fwd_mc_kernel(McArgs a) {
     // staging is a visible part of the launch
     const int P = a.P, dp = a.dp;
     const v4 zero = (v4){0.f, 0.f, 0.f, 0.f};
-    for (int idx = t; idx < G::A_F4; idx += G::NW * 64) {
+    for (int idx = t; idx < G::A_F4; idx += nthr) {
       const int srow = idx / PITCHA4, c = idx - srow * PITCHA4;
       const int tt = srow >> 4, i = srow & 15;
       const int p = 16 * tt + 4 * (i & 3) + (i >> 2);            // slot -> preference (block transposed)
       AlogS[idx] = (p < P && c < NCH) ? *reinterpret_cast<const v4*>(a.Alog + p * dp + 4 * c) : zero;
     }
     if (REM4) {
-      for (int idx = t; idx < G::A4_F4; idx += G::NW * 64) {     // [pref i][quarter kp][KQ chunks]
+      for (int idx = t; idx < G::A4_F4; idx += nthr) {     // [pref i][quarter kp][KQ chunks]
         const int i = idx / (4 * KQ), rem = idx - i * (4 * KQ);
         const int kp = rem / KQ, kk = rem - kp * KQ;
         const int p = 16 * PTF + i, c = KQ * kp + kk;
@@ -122,7 +123,7 @@ __global__ __launch_bounds__(G::NW * 64) void pref_fwd_mc_kernel(McArgs a) {
       constexpr int pitch4 = HARD ? HP : TPITCH / 4;
       v4* Cn4 = reinterpret_cast<v4*>(CnS);
       v4* Ar4 = reinterpret_cast<v4*>(ArS);
-      for (int idx = t; idx < G::T_F / 4; idx += G::NW * 64) {
+      for (int idx = t; idx < G::T_F / 4; idx += nthr) {
         const int p = idx / pitch4, c = idx - p * pitch4;
         const bool ok = p < P && c < NCH;
         Cn4[idx] = ok ? *reinterpret_cast<const v4*>(a.Cn + p * dp + 4 * c) : zero;
@@ -148,9 +149,9 @@ __global__ __launch_bounds__(G::NW * 64) void pref_fwd_mc_kernel(McArgs a) {
   const float* tr0 = ArS + kq * TPITCH + j;
   constexpr bool l1 = L1;
   const int64_t ntiles = (a.n + 15) / 16;
-  const int64_t wstride = (int64_t)gridDim.x * G::NW;
+  const int64_t wstride = (int64_t)gridDim.x * nwr;
   bool first = true;
-  for (int64_t tile_id = (int64_t)blockIdx.x * G::NW + w; tile_id < ntiles; tile_id += wstride) {
+  for (int64_t tile_id = (int64_t)blockIdx.x * nwr + w; tile_id < ntiles; tile_id += wstride) {
     const int64_t row0 = tile_id * 16;
     if (first && lane < 16) {
       const int64_t gr = row0 + lane;
@@ -425,8 +426,12 @@ int launch_mc_l(const McArgs& a, hipStream_t st, const char* name) {
   constexpr size_t lds = G::TABLE_BYTES + (size_t)G::NW * G::WAVE_BYTES;
   (void)hipFuncSetAttribute((const void*)pref_fwd_mc_kernel<G, L1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   const int64_t ntiles = (a.n + 15) / 16;
-  const int grid = grid_for((ntiles + G::NW - 1) / G::NW, 256);
-  hipLaunchKernelGGL((pref_fwd_mc_kernel<G, L1>), dim3(grid), dim3(G::NW * 64), lds, st, a);
+  // small batches (a B = 512 training step is 64 tiles): fewer waves per workgroup, so that the tiles spread over many CUs
+  // (one tile per SIMD) instead of queueing four deep on the matrix pipe of four CUs
+  int nw = (int)((ntiles + 255) / 256);
+  nw = nw < 4 ? (G::NW < 4 ? G::NW : 4) : (nw > G::NW ? G::NW : nw);
+  const int grid = grid_for((ntiles + nw - 1) / nw, 256);
+  hipLaunchKernelGGL((pref_fwd_mc_kernel<G, L1>), dim3(grid), dim3(nw * 64), lds, st, a);
   return check_launch(name);
 }
 

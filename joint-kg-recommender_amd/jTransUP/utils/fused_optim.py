@@ -39,6 +39,7 @@ class FusedOptimizer(object):
         self._fresh = []
         self._dev_steps = None                   # Adam: step counts in device memory (the launch is then graph-replayable)
         self._dev_steps_for = None
+        self._replayed = 0                       # steps replayed from a graph whose host-side counters are not written back yet
 
     # ---- torch.optim surface the trainer uses
     def zero_grad(self):
@@ -47,9 +48,11 @@ class FusedOptimizer(object):
         self.optimizer.zero_grad(set_to_none=False)
 
     def state_dict(self):
+        self._flush_steps()
         return self.optimizer.state_dict()
 
     def load_state_dict(self, sd):
+        self._replayed = 0
         self.optimizer.load_state_dict(sd)
         self._plan = None                        # the state tensors were replaced
         self._dev_steps_for = None
@@ -93,6 +96,7 @@ class FusedOptimizer(object):
     def clip_and_step(self, max_norm, zero_grads=False):
         """`zero_grads`: leave the gradients zero-filled (the next step's zero_grad folded into this pass) instead of
         clipped in place."""
+        self._flush_steps()
         group = self.optimizer.param_groups[0]
         ps = [p for p in group['params'] if p.grad is not None]
         if not ps:
@@ -159,12 +163,19 @@ class FusedOptimizer(object):
         return True
 
     def bump_steps(self):
-        """Advance the per-parameter step counters like one clip_and_step would (used when the launches are replayed from
-        a graph and this object's Python code does not run)."""
+        """Account for one step whose launches were replayed from a graph (this object's Python code did not run).  The
+        torch-side `state[p]['step']` tensors are brought up to date lazily -- before the next eager step and before
+        state_dict() -- because touching seven CPU tensors per replay costs more host time than the replay itself."""
+        self._replayed += 1
+
+    def _flush_steps(self):
+        if not self._replayed:
+            return
+        n, self._replayed = self._replayed, 0
         for p in self.optimizer.param_groups[0]['params']:
             st = self.optimizer.state.get(p)
             if p.grad is not None and st is not None and 'step' in st:
-                st['step'] += 1
+                st['step'] += n
 
     def total_norm(self):
         """Gradient norm of the last clipped step (device -> host sync; diagnostics only)."""

@@ -114,7 +114,7 @@ class ModelTrainer(object):
     def save(self, filename):
         tables = {name: tensor.detach().cpu() for name, tensor in self.model.state_dict().items()}
         torch.save({'step': self.step, 'best_step': self.best_step, 'best_dev_performance': self.best_dev_performance,
-                    'model_state_dict': tables, 'optimizer_state_dict': self.optimizer.state_dict()}, filename)
+                    'model_state_dict': tables, 'optimizer_state_dict': (self.fused or self.optimizer).state_dict()}, filename)
 
     def load(self, filename, cpu=False):
         ck = torch.load(filename, map_location='cpu' if cpu else None, weights_only=False)

@@ -253,3 +253,21 @@ def test_hard_gate_steps_replay_as_graphs(tmp_path, kind):
         assert graphed.gstate.tolist() == eager.gstate.tolist() and int(graphed.gstate[1]) == (step + 1) * 2 * B * P
     assert 'rec' in graphed._graphs and not eager._graphs
     assert len(set(losses)) == len(losses)
+
+
+def test_replayed_steps_reach_the_optimizer_state(tmp_path):
+    """Graph replays do not run the optimizer's Python: its per-parameter `step` counters are written back lazily, and a
+    checkpoint taken afterwards carries the true count (Adagrad / Adam keep `step` in their state_dict)."""
+    from jTransUP.utils.fast_train import JointStepper
+    FLAGS, m, tr, (NU, NI, NE, NR) = build(tmp_path, 'Adam', False)
+    fast = JointStepper(m, tr, FLAGS, 64)
+    gen = torch.Generator().manual_seed(1)
+    rnd = lambda hi: torch.randint(0, hi, (64,), generator=gen).to(DEV)
+    for _ in range(9):
+        fast.rec_step(rnd(NU), rnd(NI), rnd(NI))
+    assert 'rec' in fast._graphs and tr.step == 9
+    sd = tr.fused.state_dict()
+    assert {int(v['step']) for v in sd['state'].values()} == {9}
+    fast.rec_step(rnd(NU), rnd(NI), rnd(NI))
+    assert {int(v['step']) for v in tr.fused.state_dict()['state'].values()} == {10}
+    assert tr.fused._dev_steps.tolist() == [10] * len(sd['state'])

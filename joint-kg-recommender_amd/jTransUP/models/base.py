@@ -53,7 +53,7 @@ FLAG_TABLE = [
     ('num_processes', 'int', 4, 'accepted for compatibility: ranking runs on the device'),
     ('max_queue', 'int', 10, 'accepted for compatibility: no worker processes here'),
     # this build
-    ('device_sampling', 'bool', False, 'keep training data and negative sampling on the GPU (K19)'),
+    ('device_sampling', 'bool', True, 'keep training data and negative sampling on the GPU (K19); -nodevice_sampling runs the python samplers'),
     # files
     ('data_path', 'str', None, 'root of the datasets'),
     ('log_path', 'str', None, 'logs (and, by default, checkpoints)'),

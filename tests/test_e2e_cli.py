@@ -70,21 +70,21 @@ def test_joint_cli_ktup_with_pretrained_tables(dataset):
     assert os.path.isfile(os.path.join(logs, 'ktup.ckpt'))
 
 
-@pytest.mark.parametrize('mode', ['device_sampling', 'autograd_route', 'gumbel'])
+@pytest.mark.parametrize('mode', ['device_sampling', 'host_sampling', 'autograd_route', 'gumbel'])
 def test_joint_cli_training_routes(dataset, mode, monkeypatch):
-    """KTUP through the GPU-resident step with on-device data + sampling (-device_sampling), through the autograd route
-    (KTUP_FAST_TRAIN=0), and with the ST-Gumbel gate on the GPU-resident step."""
+    """KTUP through the GPU-resident step with on-device data + sampling (the default), with the reference's python samplers
+    (-nodevice_sampling), through the autograd route (KTUP_FAST_TRAIN=0), and with the ST-Gumbel gate."""
     extra = ['-model_type', 'jtransup', '-rec_test_files', 'valid.dat', '-kg_test_files', 'valid.dat', '-joint_ratio', '0.7',
              '-noshare_embeddings']
-    if mode == 'device_sampling':
-        extra.append('-device_sampling')
+    if mode == 'host_sampling':
+        extra.append('-nodevice_sampling')
     if mode == 'gumbel':
         extra.append('-use_st_gumbel')
     if mode == 'autograd_route':
         monkeypatch.setenv('KTUP_FAST_TRAIN', '0')
     log, _ = run_cli('run_knowledgable_recommendation.py', dataset, 'ktup-' + mode, extra)
     assert ('GPU-resident training step enabled' in log) == (mode != 'autograd_route')
-    assert ('device-resident' in log) == (mode == 'device_sampling')
+    assert ('device-resident' in log) == (mode in ('device_sampling', 'gumbel'))
     losses = [float(x) for x in re.findall(r'rec train loss:(\d+\.\d+)', log)]
     assert len(losses) >= 2 and all(l == l and l < 1e3 for l in losses)
     assert len(re.findall(r'f1:\d\.\d+', log)) >= 3 and len(re.findall(r'avg hit:', log)) >= 3
@@ -117,7 +117,7 @@ def test_joint_cli_data_parallel_torchrun(dataset):
 ])
 def test_single_task_cli_device_sampling(dataset, script, extra, metric):
     """The rec-only and KG-only drivers with device-resident batches and negative sampling (-device_sampling)."""
-    log, _ = run_cli(script, dataset, 'ds-' + extra[1], extra + ['-device_sampling'])
+    log, _ = run_cli(script, dataset, 'ds-' + extra[1], extra)             # -device_sampling is the default
     assert 'GPU-resident training step enabled' in log and 'device-resident' in log
     losses = [float(x) for x in re.findall(r'train loss:(\d+\.\d+)', log)]
     assert len(losses) >= 2 and all(l == l and l < 1e4 for l in losses)

@@ -190,8 +190,9 @@ def eval_bench(device, batch=512, seed=11):
 
     def one_pass(with_metrics):
         out = []
+        items = m.prepare_items()                     # item side of the gate once per pass, like the drivers (weights are frozen)
         for b, u in zip(batches, ub):
-            scores = m.evaluateRec(u)
+            scores = m.evaluateRec(u, items=items)
             if with_metrics:                          # what _driver.rec_eval_pass does: metric columns stay on the device
                 out.append(RK.evalRecProcess((b, scores), gold, [train], descending=False, topn=10, index=index, as_array='device'))
             else:

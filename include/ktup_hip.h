@@ -183,6 +183,15 @@ int ktup_eval_pref_scores(const float* U, int64_t ldu, const float* I, int64_t l
                           const int32_t* item2ent, const float* pref_ws, int n_pref, int d, const int64_t* u_ids,
                           int64_t nq, int64_t n_items, int l1, int gumbel_mode, const float* uniform, uint64_t seed,
                           uint64_t offset, float* out, int64_t ldo, float* ws, void* stream);
+/* The same in two halves, for an evaluation PASS (the weights are frozen while transUP.py:84-102 / jTransUP.py:163-191 are
+ * called batch after batch): the item-side projections once, then every batch of users against them.  `ws` of the second
+ * call needs ktup_eval_pref_workspace_bytes(d, n_pref, nq, 0) bytes (the user side only).                          */
+size_t ktup_eval_pref_items_workspace_bytes(int d, int n_pref, int64_t n_items);
+int ktup_eval_pref_items_prepare(const float* I, int64_t ldi, const float* E, int64_t lde, const int32_t* item2ent,
+                                 const float* pref_ws, int n_pref, int d, int64_t n_items, float* items_ws, void* stream);
+int ktup_eval_pref_scores_prepared(const float* U, int64_t ldu, const float* pref_ws, int n_pref, int d, const int64_t* u_ids,
+                                   int64_t nq, int64_t n_items, int l1, int gumbel_mode, const float* uniform, uint64_t seed,
+                                   uint64_t offset, float* out, int64_t ldo, const float* items_ws, float* ws, void* stream);
 
 /* ------------------------------------------- K17/K18  ranking walk  utils/misc.py:125-146,213-248
  * Order: ascending score (descending != 0 negates first, misc.py:93,180), ties -> lower id (declared rule).

@@ -632,36 +632,48 @@ extern "C" int ktup_eval_transr_scores(const float* E, int64_t lde, const float*
 
 // TUP (E == NULL) / KTUP all-item scores.  `pref_ws` is the ktup_pref_prepare workspace; `item2ent` has one entry per
 // ROW of I (the caller passes the evaluateRec pairing, jTransUP.py:174); `uniform` is (nq x n_items x n_pref).
-extern "C" int ktup_eval_pref_scores(const float* U, int64_t ldu, const float* I, int64_t ldi, const float* E, int64_t lde,
-                                     const int32_t* item2ent, const float* pref_ws, int n_pref, int d, const int64_t* u_ids,
-                                     int64_t nq, int64_t n_items, int l1, int gumbel_mode, const float* uniform, uint64_t seed,
-                                     uint64_t offset, float* out, int64_t ldo, float* ws, void* stream) {
-  const char* name = "ktup_eval_pref_scores";
-  KTUP_REQUIRE(nq >= 0 && n_items >= 0, "%s: bad sizes", name);
-  if (nq == 0 || n_items == 0) return KTUP_OK;
+namespace {
+
+struct ItemSide { float *CW0, *CW1, *CW2, *CL; };
+
+// items_ws layout: CW0 | CW1 | CW2 [N][d] | CL [N][P]  (v - RV, v, NV, item logits)
+ItemSide item_side(float* base, int64_t n_items, int d) {
+  ItemSide s;
+  s.CW0 = base; s.CW1 = s.CW0 + (size_t)n_items * d; s.CW2 = s.CW1 + (size_t)n_items * d; s.CL = s.CW2 + (size_t)n_items * d;
+  return s;
+}
+
+int pref_items_project(const char* name, const float* I, int64_t ldi, const float* E, int64_t lde, const int32_t* item2ent,
+                       const float* pref_ws, int n_pref, int d, int64_t n_items, const ItemSide& it, hipStream_t st) {
   const PrefGeom g = pref_geom(d, n_pref);
   if (!g.ok) return set_error(KTUP_ERR_UNSUPPORTED, "%s: embedding_size must be a multiple of 4 in [4, 256] (got %d)", name, d);
-  KTUP_REQUIRE(U && I && pref_ws && u_ids && out && ws && ldo >= n_items, "%s: bad argument", name);
+  KTUP_REQUIRE(I && pref_ws && it.CW0, "%s: bad argument", name);
   KTUP_REQUIRE((E == nullptr) == (item2ent == nullptr), "%s: E and item2ent must be given together", name);
-  KTUP_REQUIRE(aligned16(U) && aligned16(I) && aligned16(E) && aligned16(pref_ws) && aligned16(ws) && ldu % 4 == 0 &&
-                   ldi % 4 == 0 && (!E || lde % 4 == 0), "%s: tables must be 16-byte aligned with pitches %% 4 == 0", name);
+  KTUP_REQUIRE(aligned16(I) && aligned16(E) && aligned16(pref_ws) && aligned16(it.CW0) && ldi % 4 == 0 && (!E || lde % 4 == 0),
+               "%s: tables must be 16-byte aligned with pitches %% 4 == 0", name);
+  hipLaunchKernelGGL(pref_project_kernel, dim3(grid_for((n_items + 3) / 4)), dim3(256), 0, st, I, ldi, E, lde, item2ent,
+                     (const int64_t*)nullptr, n_items, d, n_pref, pref_ws, g.ppad, g.dp, -1.0f, (int64_t)d, it.CW0, it.CW1, it.CW2, it.CL);
+  return check_launch(name);
+}
+
+// users' projections + the pair kernels, the item side already in `it`
+int pref_scores_tail(const char* name, const float* U, int64_t ldu, const float* pref_ws, int n_pref, int d, const int64_t* u_ids,
+                     int64_t nq, int64_t n_items, int l1, int gumbel_mode, const float* uniform, uint64_t seed, uint64_t offset,
+                     float* out, int64_t ldo, const ItemSide& it, float* ws, hipStream_t st) {
+  const PrefGeom g = pref_geom(d, n_pref);
+  if (!g.ok) return set_error(KTUP_ERR_UNSUPPORTED, "%s: embedding_size must be a multiple of 4 in [4, 256] (got %d)", name, d);
+  KTUP_REQUIRE(U && pref_ws && u_ids && out && ws && ldo >= n_items, "%s: bad argument", name);
+  KTUP_REQUIRE(aligned16(U) && aligned16(pref_ws) && aligned16(ws) && ldu % 4 == 0, "%s: tables must be 16-byte aligned with pitches %% 4 == 0", name);
   KTUP_REQUIRE(gumbel_mode >= KTUP_GUMBEL_OFF && gumbel_mode <= KTUP_GUMBEL_PHILOX_DEV, "%s: bad gumbel_mode", name);
   KTUP_REQUIRE((gumbel_mode != KTUP_GUMBEL_INPUT && gumbel_mode != KTUP_GUMBEL_PHILOX_DEV) || uniform,
                "%s: KTUP_GUMBEL_INPUT / KTUP_GUMBEL_PHILOX_DEV need the `uniform` pointer", name);
-  hipStream_t st = (hipStream_t)stream;
   float* QW = ws;
   float* QL = QW + (size_t)nq * 3 * d;
-  float* CW0 = QL + pad4((size_t)nq * n_pref);
-  float* CW1 = CW0 + (size_t)n_items * d;
-  float* CW2 = CW1 + (size_t)n_items * d;
-  float* CL = CW2 + (size_t)n_items * d;
+  float *CW0 = it.CW0, *CW1 = it.CW1, *CW2 = it.CW2, *CL = it.CL;
   // users: slot 0 = u + RU, slot 1 = u, slot 2 = NU, rows of pitch 3d;   items: v - RV, v, NV, rows of pitch d
   hipLaunchKernelGGL(pref_project_kernel, dim3(grid_for((nq + 3) / 4)), dim3(256), 0, st, U, ldu, (const float*)nullptr,
                      (int64_t)0, (const int32_t*)nullptr, u_ids, nq, d, n_pref, pref_ws, g.ppad, g.dp, 1.0f, (int64_t)3 * d, QW,
                      QW + d, QW + 2 * d, QL);
-  if (int e = check_launch(name)) return e;
-  hipLaunchKernelGGL(pref_project_kernel, dim3(grid_for((n_items + 3) / 4)), dim3(256), 0, st, I, ldi, E, lde, item2ent,
-                     (const int64_t*)nullptr, n_items, d, n_pref, pref_ws, g.ppad, g.dp, -1.0f, (int64_t)d, CW0, CW1, CW2, CL);
   if (int e = check_launch(name)) return e;
   if (gumbel_mode == KTUP_GUMBEL_OFF) {
     if (!l1) {     // squared L2: six (users x items) GEMMs on the matrix cores (ktup_eval_mc.hip); KTUP_EVAL_MC=0 for A/B runs
@@ -697,4 +709,45 @@ extern "C" int ktup_eval_pref_scores(const float* U, int64_t ldu, const float* I
     hipLaunchKernelGGL(pairs_hard_kernel<false>, hgrid, dim3(HARD_NT), lds, st, h);
   }
   return check_launch(name);
+}
+
+}  // namespace
+
+extern "C" size_t ktup_eval_pref_items_workspace_bytes(int d, int n_pref, int64_t n_items) {
+  return ((size_t)n_items * 3 * d + pad4((size_t)n_items * n_pref)) * sizeof(float);
+}
+
+extern "C" int ktup_eval_pref_items_prepare(const float* I, int64_t ldi, const float* E, int64_t lde, const int32_t* item2ent,
+                                            const float* pref_ws, int n_pref, int d, int64_t n_items, float* items_ws, void* stream) {
+  const char* name = "ktup_eval_pref_items_prepare";
+  KTUP_REQUIRE(n_items >= 0, "%s: bad sizes", name);
+  if (n_items == 0) return KTUP_OK;
+  return pref_items_project(name, I, ldi, E, lde, item2ent, pref_ws, n_pref, d, n_items, item_side(items_ws, n_items, d), (hipStream_t)stream);
+}
+
+extern "C" int ktup_eval_pref_scores_prepared(const float* U, int64_t ldu, const float* pref_ws, int n_pref, int d,
+                                              const int64_t* u_ids, int64_t nq, int64_t n_items, int l1, int gumbel_mode,
+                                              const float* uniform, uint64_t seed, uint64_t offset, float* out, int64_t ldo,
+                                              const float* items_ws, float* ws, void* stream) {
+  const char* name = "ktup_eval_pref_scores_prepared";
+  KTUP_REQUIRE(nq >= 0 && n_items >= 0, "%s: bad sizes", name);
+  if (nq == 0 || n_items == 0) return KTUP_OK;
+  KTUP_REQUIRE(items_ws && aligned16(items_ws), "%s: item-side workspace missing or unaligned", name);
+  return pref_scores_tail(name, U, ldu, pref_ws, n_pref, d, u_ids, nq, n_items, l1, gumbel_mode, uniform, seed, offset, out, ldo,
+                          item_side(const_cast<float*>(items_ws), n_items, d), ws, (hipStream_t)stream);
+}
+
+extern "C" int ktup_eval_pref_scores(const float* U, int64_t ldu, const float* I, int64_t ldi, const float* E, int64_t lde,
+                                     const int32_t* item2ent, const float* pref_ws, int n_pref, int d, const int64_t* u_ids,
+                                     int64_t nq, int64_t n_items, int l1, int gumbel_mode, const float* uniform, uint64_t seed,
+                                     uint64_t offset, float* out, int64_t ldo, float* ws, void* stream) {
+  const char* name = "ktup_eval_pref_scores";
+  KTUP_REQUIRE(nq >= 0 && n_items >= 0, "%s: bad sizes", name);
+  if (nq == 0 || n_items == 0) return KTUP_OK;
+  KTUP_REQUIRE(ws && aligned16(ws), "%s: bad argument", name);
+  // QW[nq][3][d] | QL[nq][P] (padded to 16 B) | the item side
+  const ItemSide it = item_side(ws + (size_t)nq * 3 * d + pad4((size_t)nq * n_pref), n_items, d);
+  if (int e = pref_items_project(name, I, ldi, E, lde, item2ent, pref_ws, n_pref, d, n_items, it, (hipStream_t)stream)) return e;
+  return pref_scores_tail(name, U, ldu, pref_ws, n_pref, d, u_ids, nq, n_items, l1, gumbel_mode, uniform, seed, offset, out, ldo, it,
+                          ws, (hipStream_t)stream);
 }

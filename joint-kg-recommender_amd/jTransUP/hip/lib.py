@@ -60,6 +60,9 @@ SIGNATURES = {
     'ktup_eval_pref_workspace_bytes': [c_i, c_i, c_l, c_l],
     'ktup_eval_pref_scores': [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_p, c_i, c_i, c_p, c_l, c_l, c_i, c_i, c_p, c_u, c_u, c_p, c_l,
                               c_p, c_p],
+    'ktup_eval_pref_items_workspace_bytes': [c_i, c_i, c_l],
+    'ktup_eval_pref_items_prepare': [c_p, c_l, c_p, c_l, c_p, c_p, c_i, c_i, c_l, c_p, c_p],
+    'ktup_eval_pref_scores_prepared': [c_p, c_l, c_p, c_i, c_i, c_p, c_l, c_l, c_i, c_i, c_p, c_u, c_u, c_p, c_l, c_p, c_p, c_p],
     'ktup_eval_topk_filtered': [c_p, c_l, c_l, c_l, c_i, c_p, c_p, c_i, c_p, c_p, c_p],
     'ktup_eval_gold_ranks': [c_p, c_l, c_l, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_p],
     'ktup_shard_pack_rows': [c_p, c_l, c_i, c_p, c_l, c_p, c_l, c_p],
@@ -74,7 +77,7 @@ SIGNATURES = {
 }
 _RESTYPE = {'ktup_last_error': ctypes.c_char_p, 'ktup_pref_workspace_bytes': ctypes.c_size_t,
             'ktup_eval_kg_workspace_bytes': ctypes.c_size_t, 'ktup_eval_transr_workspace_bytes': ctypes.c_size_t, 'ktup_score_transr_workspace_bytes': ctypes.c_size_t,
-            'ktup_eval_pref_workspace_bytes': ctypes.c_size_t, 'ktup_negsample_rec_workspace_bytes': ctypes.c_size_t}
+            'ktup_eval_pref_workspace_bytes': ctypes.c_size_t, 'ktup_eval_pref_items_workspace_bytes': ctypes.c_size_t, 'ktup_negsample_rec_workspace_bytes': ctypes.c_size_t}
 
 _lib = None
 

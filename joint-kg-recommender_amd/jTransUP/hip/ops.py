@@ -399,12 +399,50 @@ def eval_transr(E, R, M, q, r, l1, head):
     return out
 
 
+class PreparedItems(object):
+    """Item side of K15 / K16 for one evaluation pass: the prepared preference tables and the per-item projections
+    (ktup_eval_pref_items_prepare).  Valid as long as the tables it was built from do not change."""
+
+    def __init__(self, pws, items_ws, n_items, P, d):
+        self.pws, self.items_ws, self.n_items, self.P, self.d = pws, items_ws, n_items, P, d
+
+
 @torch.no_grad()
-def _eval_pref(U, I, E, pref, pref_norm, rel, norm, item2ent, u, l1, gumbel_mode, uniform, seed, offset):
+def eval_pref_items(I, E, pref, pref_norm, rel, norm, item2ent):
+    dev = _dev(_table('item table', I))
+    ni = I.shape[0]
+    P, d = pref.shape
+    pws = pref_workspace(pref, pref_norm, rel, norm)
+    if E is not None:
+        _table('entity table', E)
+        if item2ent.dtype != torch.int32 or item2ent.device != dev or item2ent.numel() != ni:
+            raise L.KtupError('item2ent must be an int32 device table with one entry per item row')
+    items_ws = _scratch(L.load().ktup_eval_pref_items_workspace_bytes(d, P, ni), dev)
+    L.call('ktup_eval_pref_items_prepare', _p(I), I.stride(0), _p(E), 0 if E is None else E.stride(0), _p(item2ent), _p(pws), P, d, ni,
+           _p(items_ws), _stream(dev))
+    return PreparedItems(pws, items_ws, ni, P, d)
+
+
+@torch.no_grad()
+def _eval_pref(U, I, E, pref, pref_norm, rel, norm, item2ent, u, l1, gumbel_mode, uniform, seed, offset, items=None):
     dev = _dev(_table('user table', U)); _table('item table', I)
     u = _ids('u_ids', u, dev)
     nq, ni = u.numel(), I.shape[0]
     P, d = pref.shape
+    if items is not None:                        # the pass prepared the item side once: users only here
+        if (items.n_items, items.P, items.d) != (ni, P, d):
+            raise L.KtupError('prepared item side does not match the tables')
+        if gumbel_mode == GUMBEL_INPUT:
+            if uniform is None or tuple(uniform.shape) != (nq, ni, P) or uniform.dtype != torch.float32 or uniform.device != dev:
+                raise L.KtupError('uniform must be an (n_users, n_items, n_pref) fp32 device tensor')
+            uniform = uniform.contiguous()
+        else:
+            uniform = None
+        out = torch.empty(nq, ni, dtype=torch.float32, device=dev)
+        ws = _scratch(L.load().ktup_eval_pref_workspace_bytes(d, P, nq, 0), dev)
+        L.call('ktup_eval_pref_scores_prepared', _p(U), U.stride(0), _p(items.pws), P, d, _p(u), nq, ni, int(l1), int(gumbel_mode),
+               _p(uniform), int(seed), int(offset), _p(out), out.stride(0), _p(items.items_ws), _p(ws), _stream(dev))
+        return out
     pws = pref_workspace(pref, pref_norm, rel, norm)
     if gumbel_mode == GUMBEL_INPUT:
         if uniform is None or tuple(uniform.shape) != (nq, ni, P) or uniform.dtype != torch.float32 or uniform.device != dev:
@@ -424,14 +462,15 @@ def _eval_pref(U, I, E, pref, pref_norm, rel, norm, item2ent, u, l1, gumbel_mode
     return out
 
 
-def eval_tup(U, I, pref, pref_norm, u, l1, gumbel_mode=GUMBEL_OFF, uniform=None, seed=0, offset=0):
-    """transUP.py:84-102 -> (len(u), n_items)."""
-    return _eval_pref(U, I, None, pref, pref_norm, None, None, None, u, l1, gumbel_mode, uniform, seed, offset)
+def eval_tup(U, I, pref, pref_norm, u, l1, gumbel_mode=GUMBEL_OFF, uniform=None, seed=0, offset=0, items=None):
+    """transUP.py:84-102 -> (len(u), n_items).  `items`: eval_pref_items(...) of the same tables (one per evaluation pass)."""
+    return _eval_pref(U, I, None, pref, pref_norm, None, None, None, u, l1, gumbel_mode, uniform, seed, offset, items)
 
 
-def eval_ktup(U, I, E, pref, pref_norm, rel, norm, item2ent, u, l1, gumbel_mode=GUMBEL_OFF, uniform=None, seed=0, offset=0):
+def eval_ktup(U, I, E, pref, pref_norm, rel, norm, item2ent, u, l1, gumbel_mode=GUMBEL_OFF, uniform=None, seed=0, offset=0,
+              items=None):
     """jTransUP.py:163-191 -> (len(u), n_items)."""
-    return _eval_pref(U, I, E, pref, pref_norm, rel, norm, item2ent, u, l1, gumbel_mode, uniform, seed, offset)
+    return _eval_pref(U, I, E, pref, pref_norm, rel, norm, item2ent, u, l1, gumbel_mode, uniform, seed, offset, items)
 
 
 # ------------------------------------------------------------------------------------------ K17-K18 ranking

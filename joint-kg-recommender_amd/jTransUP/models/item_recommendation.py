@@ -19,7 +19,11 @@ FLAGS = gflags.FLAGS
 
 def evaluate(FLAGS, model, eval_iter, eval_dict, all_dicts, logger, eval_descending=True, is_report=False):
     model.eval(); model.disable_grad()
-    results = D.rec_eval_pass(FLAGS, model.evaluate, eval_iter, eval_dict, all_dicts, eval_descending, want_rows=is_report)
+    score_fn = model.evaluate
+    if hasattr(model, 'prepare_items'):            # TUP: the item side of the gate once per pass (weights are frozen here)
+        items = model.prepare_items()
+        score_fn = lambda u: model.evaluate(u, items=items)
+    results = D.rec_eval_pass(FLAGS, score_fn, eval_iter, eval_dict, all_dicts, eval_descending, want_rows=is_report)
     perf = D.summarize_rec(FLAGS, results, logger)
     if is_report:
         D.report_rec(FLAGS, model, results, all_dicts, eval_dict, logger, FLAGS.model_type in ('transup', 'jtransup', 'cjtransup'))

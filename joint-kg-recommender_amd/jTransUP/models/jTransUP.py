@@ -95,19 +95,29 @@ class jTransUPModel(nn.Module, GradToggle):
         else:
             raise NotImplementedError
 
-    def evaluateRec(self, u_ids, all_i_ids=None, uniform=None):
-        """K16: jTransUP.py:163-191."""
-        U, I, E, P, Pn, R, Rn = self._rec_tables()
+    def _eval_items(self, all_i_ids):
+        I = self.item_embeddings.weight
         if all_i_ids is not None and self.is_share:
             I = self.item_embeddings(all_i_ids)
-            item2ent = to_gpu(torch.tensor(self.paddingItems(all_i_ids.tolist(), self.ent_total - 1), dtype=torch.int32))
-        else:
-            item2ent = self._eval_item2ent
-            if item2ent.numel() != I.shape[0]:
-                raise ValueError('evaluateRec: i_map has %d items but the item table has %d rows' % (item2ent.numel(), I.shape[0]))
+            return I, to_gpu(torch.tensor(self.paddingItems(all_i_ids.tolist(), self.ent_total - 1), dtype=torch.int32))
+        item2ent = self._eval_item2ent
+        if item2ent.numel() != I.shape[0]:
+            raise ValueError('evaluateRec: i_map has %d items but the item table has %d rows' % (item2ent.numel(), I.shape[0]))
+        return I, item2ent
+
+    def evaluateRec(self, u_ids, all_i_ids=None, uniform=None, items=None):
+        """K16: jTransUP.py:163-191.  `items` (this build): `prepare_items(all_i_ids)` taken once per evaluation pass."""
+        U, _, E, P, Pn, R, Rn = self._rec_tables()
+        I, item2ent = self._eval_items(all_i_ids)
         mode, uni, seed, off = self._gumbel.mode_and_stream(self.use_st_gumbel, uniform,
                                                             u_ids.numel() * I.shape[0] * P.shape[0])
-        return ops.eval_ktup(U, I, E, P, Pn, R, Rn, item2ent, u_ids, self.L1_flag, mode, uni, seed, off)
+        return ops.eval_ktup(U, I, E, P, Pn, R, Rn, item2ent, u_ids, self.L1_flag, mode, uni, seed, off, items=items)
+
+    def prepare_items(self, all_i_ids=None):
+        """Item side of `evaluateRec` (item + entity rows through the preference gate), to share between the batches of a pass."""
+        _, _, E, P, Pn, R, Rn = self._rec_tables()
+        I, item2ent = self._eval_items(all_i_ids)
+        return ops.eval_pref_items(I, E, P, Pn, R, Rn, item2ent)
 
     def _all_entities(self, all_e_ids):
         return self.ent_embeddings(all_e_ids) if all_e_ids is not None and self.is_share else self.ent_embeddings.weight

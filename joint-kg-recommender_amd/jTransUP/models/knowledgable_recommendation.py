@@ -46,8 +46,10 @@ def getMappedItems(e_ids, e_remap, new_map):
 def evaluateRec(FLAGS, model, eval_iter, eval_dict, all_dicts, i_map, logger, eval_descending=True, is_report=False):
     all_i_var = D.ids([i_map[i] for i in range(len(i_map))]) if FLAGS.share_embeddings else None
     model.eval(); model.disable_grad()
-    results = D.rec_eval_pass(FLAGS, lambda u: model.evaluateRec(u, all_i_ids=all_i_var), eval_iter, eval_dict, all_dicts,
-                              eval_descending, want_rows=is_report)
+    items = model.prepare_items(all_i_var) if hasattr(model, 'prepare_items') else None     # item side once per pass
+    score_fn = (lambda u: model.evaluateRec(u, all_i_ids=all_i_var, items=items)) if items is not None \
+        else (lambda u: model.evaluateRec(u, all_i_ids=all_i_var))
+    results = D.rec_eval_pass(FLAGS, score_fn, eval_iter, eval_dict, all_dicts, eval_descending, want_rows=is_report)
     perf = D.summarize_rec(FLAGS, results, logger)
     if is_report:
         D.report_rec(FLAGS, model, results, all_dicts, eval_dict, logger, FLAGS.model_type in ('transup', 'jtransup'))

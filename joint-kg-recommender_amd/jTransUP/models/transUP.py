@@ -43,12 +43,18 @@ class TransUPModel(nn.Module, GradToggle):
         mode, uni, seed, off = self._gumbel.mode_and_stream(self.use_st_gumbel, uniform, u_ids.numel() * P.shape[0])
         return ops.score_tup(U, I, P, Pn, u_ids, i_ids, self.L1_flag, mode, uni, seed, off)
 
-    def evaluate(self, u_ids, uniform=None):
-        """K15: TUP score of every (user, item) pair (transUP.py:84-102); stochastic under ST-Gumbel like the reference."""
+    def evaluate(self, u_ids, uniform=None, items=None):
+        """K15: TUP score of every (user, item) pair (transUP.py:84-102); stochastic under ST-Gumbel like the reference.
+        `items` (this build): `prepare_items()` taken once per evaluation pass, while the weights are frozen."""
         U, I, P, Pn = self._tables()
         mode, uni, seed, off = self._gumbel.mode_and_stream(self.use_st_gumbel, uniform,
                                                             u_ids.numel() * I.shape[0] * P.shape[0])
-        return ops.eval_tup(U, I, P, Pn, u_ids, self.L1_flag, mode, uni, seed, off)
+        return ops.eval_tup(U, I, P, Pn, u_ids, self.L1_flag, mode, uni, seed, off, items=items)
+
+    def prepare_items(self):
+        """Item side of `evaluate` (the item projections of the preference gate), to share between the batches of a pass."""
+        U, I, P, Pn = self._tables()
+        return ops.eval_pref_items(I, None, P, Pn, None, None, None)
 
     def getPreferences(self, u_e, i_e, use_st_gumbel=False):
         """transUP.py:105-115 on already-gathered embeddings (reporting path only)."""

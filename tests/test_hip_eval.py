@@ -364,3 +364,26 @@ def test_transr_l2_matrix_core_route_vs_oracle(d, ne, nq, nrel, monkeypatch):
     monkeypatch.delenv('KTUP_EVAL_MC')
     close(a, b, rtol=2e-4, atol=5e-5)
     assert torch.equal(a.argsort(1)[:, :5], b.argsort(1)[:, :5])   # same best candidates either way
+
+
+@pytest.mark.parametrize('gum', [False, True])
+@pytest.mark.parametrize('l1', [False, True])
+def test_prepared_item_side_gives_the_same_scores(l1, gum):
+    """K15 / K16 with the item-side projections prepared once per pass (ktup_eval_pref_items_prepare +
+    ktup_eval_pref_scores_prepared) == the one-call form, bit for bit, for batches of different sizes."""
+    from jTransUP.models import jTransUP as jt, transUP
+    torch.manual_seed(3)
+    NU, NI, NE, NR, D = 90, 130, 150, 7, 100
+    i_map = {i: i for i in range(NI)}
+    new_map = {i: ((i * 3) % NE if i % 5 else -1, i) for i in range(NI)}
+    mk = jt.jTransUPModel(l1, D, NU, NI, NE, NR, i_map, new_map, False, gum)
+    mt = transUP.TransUPModel(l1, D, NU, NI, NR, gum)
+    for m, fn in ((mk, lambda m, u, **kw: m.evaluateRec(u, **kw)), (mt, lambda m, u, **kw: m.evaluate(u, **kw))):
+        m.eval(); m.disable_grad()
+        items = m.prepare_items()
+        for nq in (64, 17, 1):
+            u = torch.randint(0, NU, (nq,), device=DEV)
+            uni = torch.rand(nq, NI, NR, device=DEV) if gum else None
+            a = fn(m, u, uniform=uni)
+            b = fn(m, u, uniform=uni, items=items)
+            assert torch.equal(a, b)

@@ -119,7 +119,7 @@ def score_cases():
     i_map = IntKeyDict(i_remap)
     pad = NE
 
-    for d in (64, 100, 36):
+    for d in (64, 100, 36, 256):          # 256 (config 5's size) last: the earlier files keep their random draws
         out = {}
         u = torch.from_numpy(rng.randint(0, NU, B)).long()
         pi = torch.from_numpy(rng.randint(0, NI, B)).long()
@@ -144,8 +144,8 @@ def score_cases():
         # ---- TransE / TransH / TransR : marginLoss + normLoss (+ orthogonalLoss for transh)
         #      exactly as knowledge_representation.py:189-204 assembles the loss
         for name, mod, cls in (('transe', transE, 'TransEModel'), ('transh', transH, 'TransHModel'), ('transr', transR, 'TransRModel')):
-            if name == 'transr' and d == 100:
-                pass
+            if name == 'transr' and d == 256:
+                continue                   # a 7 x 65536 projection table plus its gradients would make the fixture 6 MB
             for l1 in (False, True):
                 tag = '%s.%s.' % (name, 'L1' if l1 else 'L2')
                 m = getattr(mod, cls)(l1, d, NE, NR)

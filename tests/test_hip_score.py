@@ -46,7 +46,7 @@ def t_orth_loss(rel, nrm):
     return torch.sum(torch.sum(nrm * rel, dim=1, keepdim=True) ** 2 / torch.sum(rel ** 2, dim=1, keepdim=True))
 
 
-@pytest.mark.parametrize('d', [36, 64, 100])
+@pytest.mark.parametrize('d', [36, 64, 100, 256])
 def test_bprmf_golden(golden, d):
     g = golden('score_d%d' % d)
     U, I = leaf(g['bprmf.user_embeddings.weight']), leaf(g['bprmf.item_embeddings.weight'])
@@ -58,10 +58,12 @@ def test_bprmf_golden(golden, d):
     close(I.grad, g['bprmf.grad.item_embeddings.weight'], atol=GAT)
 
 
-@pytest.mark.parametrize('d', [36, 64, 100])
+@pytest.mark.parametrize('d', [36, 64, 100, 256])
 @pytest.mark.parametrize('l1', [False, True])
 @pytest.mark.parametrize('name', ['transe', 'transh', 'transr'])
 def test_kg_golden(golden, d, l1, name):
+    if name == 'transr' and d == 256:
+        pytest.skip('no TransR golden at d=256 (the projection table would make the fixture 6 MB)')
     g = golden('score_d%d' % d)
     tag = '%s.%s.' % (name, 'L1' if l1 else 'L2')
     E, R = leaf(g[name + '.ent_embeddings.weight']), leaf(g[name + '.rel_embeddings.weight'])
@@ -94,7 +96,7 @@ def test_kg_golden(golden, d, l1, name):
         close(X.grad, g[tag + 'grad.proj_embeddings.weight'], atol=gat)
 
 
-@pytest.mark.parametrize('d', [36, 64, 100])
+@pytest.mark.parametrize('d', [36, 64, 100, 256])
 @pytest.mark.parametrize('l1', [False, True])
 @pytest.mark.parametrize('gum', [False, True])
 def test_tup_golden(golden, d, l1, gum):
@@ -114,14 +116,15 @@ def test_tup_golden(golden, d, l1, gum):
     close(loss, g[tag + 'loss'])
     loss.backward()
     for w, k in ((U, 'user_embeddings'), (I, 'item_embeddings'), (P, 'pref_embeddings'), (Pn, 'pref_norm_embeddings')):
-        close(w.grad, g[tag + 'grad.%s.weight' % k], atol=GAT)
+        want = g[tag + 'grad.%s.weight' % k]
+        close(w.grad, want, atol=max(GAT, 2e-6 * float(np.abs(want).max())))   # fp32 sums of a batch: the floor scales with the gradient
 
 
 KT = ['user_embeddings', 'item_embeddings', 'ent_embeddings', 'pref_embeddings', 'pref_norm_embeddings', 'rel_embeddings',
       'norm_embeddings']
 
 
-@pytest.mark.parametrize('d', [36, 64, 100])
+@pytest.mark.parametrize('d', [36, 64, 100, 256])
 @pytest.mark.parametrize('l1', [False, True])
 @pytest.mark.parametrize('gum', [False, True])
 def test_ktup_golden(golden, d, l1, gum):
@@ -145,7 +148,7 @@ def test_ktup_golden(golden, d, l1, gum):
     for k in KT:
         key = tag + 'rec.grad.%s.weight' % k
         if key in g:
-            close(W[k].grad, g[key], atol=GAT)      # incl. the pad row staying exactly zero
+            close(W[k].grad, g[key], atol=max(GAT, 2e-6 * float(np.abs(g[key]).max())))      # incl. the pad row staying exactly zero
     if not gum:
         for w in W.values():
             w.grad = None

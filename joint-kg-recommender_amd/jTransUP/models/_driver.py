@@ -25,6 +25,18 @@ def ids(values):
     return torch.tensor(values, dtype=torch.long, device=DEV)
 
 
+_BATCH_IDS = {}
+_KG_BATCH = {}
+
+
+def batch_ids(batch, values=None):
+    """Device ids of an evaluation batch, uploaded once: the iterator hands out the same batch objects in every pass."""
+    hit = _BATCH_IDS.get(id(batch))
+    if hit is None or hit[0] is not batch:
+        hit = _BATCH_IDS[id(batch)] = (batch, ids(batch if values is None else values))
+    return hit[1]
+
+
 def setup_logger(FLAGS):
     os.makedirs(FLAGS.log_path, exist_ok=True)
     logger = logging.getLogger()
@@ -112,7 +124,7 @@ def rec_eval_pass(FLAGS, score_fn, eval_iter, eval_dict, all_dicts, descending, 
     pbar = tqdm(total=len(mine), desc='Run Eval')
     for b in mine:
         u_ids = eval_iter[b]
-        scores = score_fn(ids(u_ids))
+        scores = score_fn(batch_ids(u_ids))
         per_batch[b] = evalRecProcess((u_ids, scores), eval_dict, all_dicts=all_dicts, descending=descending, topn=FLAGS.topn,
                                       index=index, as_array=False if want_rows else 'device')
         pbar.update(1)
@@ -141,10 +153,12 @@ def kg_eval_pass(FLAGS, score_fn, eval_iter, eval_dict, all_dicts, descending, r
     pbar = tqdm(total=len(mine), desc='Run Eval')
     for b in mine:
         batch = eval_iter[b]
-        q = [k[0] if remap is None else remap[k[0]] for k in batch]
-        r = [k[1] for k in batch]
-        scores = score_fn(ids(q), ids(r))
-        keys = [tuple(k) for k in batch]
+        hit = _KG_BATCH.get(id(batch))
+        if hit is None or hit[0] is not batch or hit[1] is not remap:      # per batch object: device ids and key tuples, once
+            q = [k[0] if remap is None else remap[k[0]] for k in batch]
+            hit = _KG_BATCH[id(batch)] = (batch, remap, ids(q), ids([k[1] for k in batch]), [tuple(k) for k in batch])
+        _, _, q_dev, r_dev, keys = hit
+        scores = score_fn(q_dev, r_dev)
         per_batch[b] = evalKGProcess((keys, scores), eval_dict, all_dicts=all_dicts, descending=descending, topn=FLAGS.topn,
                                      index=index, as_array=False if want_rows else 'device')
         pbar.update(1)

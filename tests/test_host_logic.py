@@ -216,3 +216,49 @@ def test_kg_summary_and_mrr_from_the_reference_rank_lists():
     cols = lambda rows: np.array([[r[0], r[1]] for r in rows], dtype=np.float64)
     np.testing.assert_allclose(D.kg_mrr(cols(head), cols(tail)), want, rtol=1e-12)
     assert O.mrr_from_ranks([0, 1, 3]) == (1 + 0.5 + 0.25) / 3
+
+
+def test_device_feeder_iterator_contract_on_cpu():
+    """DeviceFeeder mirrors MakeTrainIterator (utils/data.py:87-110): endless, every example `negtive_samples` times per
+    epoch, tail partial batch dropped, reshuffled per epoch.  (The class only needs a torch device, so it runs on CPU here.)"""
+    import torch
+    from jTransUP.utils.fast_train import DeviceFeeder
+    rows = [(i, i * 2 % 17, 1) for i in range(50)]
+    f = DeviceFeeder(rows, 16, torch.device('cpu'), negtive_samples=2, seed=5)
+    per_epoch = (50 * 2) // 16                                   # 6 full batches, the 4 left-over examples are dropped
+    epochs = []
+    for _ in range(3):
+        got = torch.cat([f.next() for _ in range(per_epoch)])
+        assert got.shape == (per_epoch * 16, 3)
+        assert all(tuple(r) in set(rows) for r in got.tolist())
+        counts = torch.bincount(got[:, 0], minlength=50)
+        assert int(counts.max()) <= 2 and int(counts.sum()) == per_epoch * 16      # each example at most `negtive_samples` times
+        epochs.append(got)
+    assert not torch.equal(epochs[0], epochs[1])                 # a new permutation every epoch
+    with pytest.raises(ValueError):
+        DeviceFeeder(rows[:5], 16, torch.device('cpu'))
+
+
+def test_rank_index_csr_layout_on_cpu():
+    """RankIndex: CSR filter / gold sets of an evaluation pass (filters = union over all_dicts, golds ascending, keys absent
+    from eval_dict flagged), contiguous-slice look-ups and their memoisation."""
+    import torch
+    from jTransUP.utils.ranking import RankIndex
+    keys = [3, 7, 9, 11]
+    eval_dict = {3: {5, 1}, 9: {2}, 11: {8, 0, 4}}
+    a, b = {3: {1, 9}, 7: {4}}, {3: {2}, 11: {6}}
+    idx = RankIndex(keys, eval_dict, [a, b], torch.device('cpu'))
+    assert idx.f_off.tolist() == [0, 3, 4, 4, 5] and idx.f_ids.tolist() == [1, 2, 9, 4, 6]
+    assert idx.g_off.tolist() == [0, 2, 2, 3, 6] and idx.g_ids.tolist()[:6] == [1, 5, 2, 0, 4, 8]
+    assert idx.present_h.tolist() == [True, False, True, True]
+    batch = [7, 9]
+    assert idx.rows_of(batch) == (1, 3) and idx.rows_of(batch) == (1, 3)
+    f_off, f_ids = idx.filter_slice(1, 3)
+    assert f_off.tolist() == [0, 1, 1] and f_ids.tolist()[:1] == [4]
+    assert idx.filter_slice(1, 3)[0] is f_off                      # memoised
+    g_off, g_ids, g_off_h, g_ids_h = idx.gold_slice(1, 3)
+    assert g_off.tolist() == [0, 0, 1] and g_ids_h.tolist() == [2]
+    with pytest.raises(KeyError):
+        idx.rows_of([9, 7])
+    none = RankIndex(keys, eval_dict, None, torch.device('cpu'))
+    assert none.filter_slice(0, 2) == (None, None)

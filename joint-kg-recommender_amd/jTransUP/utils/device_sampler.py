@@ -18,6 +18,7 @@ class DeviceSampler(object):
         self.offset = 0
         self.bitmap = self.keys = None
         self.n_items = self.n_ent = self.n_rel = 0
+        self._ws, self._ws_items = None, -1
 
     # ---- filter structures
     def set_rating_dicts(self, user_total, item_total, all_dicts):
@@ -52,7 +53,10 @@ class DeviceSampler(object):
         """-> negative item per (u, pos_i) row; raises if the constraints cannot be met."""
         n = u.numel()
         neg = torch.empty(n, dtype=torch.int64, device=self.device)
-        ws = torch.empty((L.load().ktup_negsample_rec_workspace_bytes(self.n_items) + 3) // 4, dtype=torch.int32, device=self.device)
+        if self._ws is None or self._ws_items != self.n_items:     # batch-uniqueness bitmap: zeroed by the entry point itself
+            nbytes = L.load().ktup_negsample_rec_workspace_bytes(self.n_items)
+            self._ws, self._ws_items = torch.empty((nbytes + 3) // 4, dtype=torch.int32, device=self.device), self.n_items
+        ws = self._ws
         L.call('ktup_negsample_rec', _p(u.contiguous()), _p(pos_i.contiguous()), n, self.n_items, _p(self.bitmap),
                self.words if self.bitmap is not None else 0, self.seed, self._advance(n), int(unique_in_batch), _p(neg), _p(ws),
                _stream(self.device))

@@ -1,5 +1,7 @@
-"""GPU-resident training step of the joint driver (KTUP, -noshare_embeddings): the arithmetic of
-knowledgable_recommendation.py:330-401 (`train_loop`'s step body) issued as ~a dozen launches through the C ABI.
+"""GPU-resident training steps of the three drivers: the arithmetic of their `train_loop` step bodies
+(knowledgable_recommendation.py:330-401 -> JointStepper; item_recommendation.py:160-195 -> RecStepper;
+knowledge_representation.py:176-211 -> KGStepper) issued as about a dozen launches through the C ABI and, in a single
+process, replayed from one HIP graph per step kind.
 
 The autograd route (`model(...)`, `bprLoss`, `.backward()`, `clip_and_step`) costs ~50 launches and ~0.5 ms of Python per
 B=512 step: every Function allocates and zero-fills table-shaped gradients which autograd then adds into `.grad`, and

@@ -235,17 +235,22 @@ int ktup_shard_sparse_step(int kind, float* table, int64_t ldt, float* state, in
 /* ------------------------------------------- K19  negative sampling on the device  utils/data.py:12-85
  * rec: one uniform negative item per (u, positive): != positive, bit not set in the user's row of
  *      `user_item_bitmap` (n_users x words_per_user uint32, train + eval items; NULL = no filter), and -- when
- *      unique_in_batch -- not drawn by another row of this batch (data.py:77-82).  neg = -1 if impossible.
+ *      unique_in_batch -- not drawn by another row of this batch (data.py:77-82).  Batch uniqueness is deterministic:
+ *      (seed, offset, inputs) fix the batch (earlier try rounds win, then lower rows), so replicas that draw the same
+ *      global batch agree.  `ws`: ktup_negsample_rec_workspace_bytes(n_items) bytes, 8-byte aligned (unique_in_batch only).
  * kg : per triple a fair coin corrupts head or tail with a uniform entity != original whose triple is not in
  *      `sorted_keys` (ascending uint64 ((h * n_rel + r) * n_ent + t) of every known triple; NULL = no filter).
- * Draws are Philox4x32-10(seed, offset + row * 4096 + attempt): advance `offset` by n * 4096 per call.          */
+ * Draws are Philox4x32-10(seed, offset + row * 4096 + attempt): advance `offset` by n * 4096 per call.
+ * Outputs are ALWAYS valid row indices: after 4096 failed tries a deterministic scan finds an admissible candidate; if
+ * none exists the row gets an in-range stand-in and the device counter *fail_count (int32, caller-zeroed, may be NULL)
+ * is incremented -- check it before trusting a run (jTransUP/utils/device_sampler.py DeviceSampler.check).            */
 size_t ktup_negsample_rec_workspace_bytes(int64_t n_items);
 int ktup_negsample_rec(const int64_t* u_ids, const int64_t* pos_items, int64_t n, int64_t n_items,
                        const uint32_t* user_item_bitmap, int64_t words_per_user, uint64_t seed, uint64_t offset,
-                       int unique_in_batch, int64_t* neg_items, void* ws, void* stream);
+                       int unique_in_batch, int64_t* neg_items, void* ws, int32_t* fail_count, void* stream);
 int ktup_negsample_kg(const int64_t* h, const int64_t* t, const int64_t* r, int64_t n, int64_t n_ent, int64_t n_rel,
                       const uint64_t* sorted_keys, int64_t n_keys, uint64_t seed, uint64_t offset, int64_t* neg_h,
-                      int64_t* neg_t, void* stream);
+                      int64_t* neg_t, int32_t* fail_count, void* stream);
 
 /* ------------------------------------------- K20  global-norm clip + dense optimizer step
  * Replaces   torch.nn.utils.clip_grad_norm(params, max_norm); optimizer.step()

@@ -68,12 +68,12 @@ SIGNATURES = {
     'ktup_shard_pack_rows': [c_p, c_l, c_i, c_p, c_l, c_p, c_l, c_p],
     'ktup_shard_unpack_rows_add': [c_p, c_l, c_i, c_p, c_l, c_p, c_l, c_p],
     'ktup_negsample_rec_workspace_bytes': [c_l],
-    'ktup_negsample_rec': [c_p, c_p, c_l, c_l, c_p, c_l, c_u, c_u, c_i, c_p, c_p, c_p],
+    'ktup_negsample_rec': [c_p, c_p, c_l, c_l, c_p, c_l, c_u, c_u, c_i, c_p, c_p, c_p, c_p],
     'ktup_optim_gradnorm': [c_i, c_p, c_p, c_p, c_p],
     'ktup_optim_step': [c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_p, c_f, c_i, c_p],
     'ktup_eval_rec_metrics': [c_p, c_l, c_i, c_p, c_p, c_p, c_p],
     'ktup_shard_sparse_step': [c_i, c_p, c_l, c_p, c_l, c_i, c_p, c_l, c_p, c_l, c_f, c_f, c_p, c_f, c_p],
-    'ktup_negsample_kg': [c_p, c_p, c_p, c_l, c_l, c_l, c_p, c_l, c_u, c_u, c_p, c_p, c_p],
+    'ktup_negsample_kg': [c_p, c_p, c_p, c_l, c_l, c_l, c_p, c_l, c_u, c_u, c_p, c_p, c_p, c_p],
 }
 _RESTYPE = {'ktup_last_error': ctypes.c_char_p, 'ktup_pref_workspace_bytes': ctypes.c_size_t,
             'ktup_eval_kg_workspace_bytes': ctypes.c_size_t, 'ktup_eval_transr_workspace_bytes': ctypes.c_size_t, 'ktup_score_transr_workspace_bytes': ctypes.c_size_t,

@@ -238,10 +238,12 @@ def clip_and_step(FLAGS, model, trainer):
     trainer.clip_and_step(FLAGS.clipping_max_value)
 
 
-def training_loop(FLAGS, model, trainer, logger, do_step, do_eval, loss_names, on_train_mode=None):
+def training_loop(FLAGS, model, trainer, logger, do_step, do_eval, loss_names, on_train_mode=None, sampler=None):
     """The reference's loop skeleton: early stopping, evaluation every eval_interval_steps (including step 0, where
     only the metrics are logged), otherwise one optimisation step.  `do_step(step)` returns (name, loss_tensor);
-    `do_eval(mean_losses)` returns the performance list whose first entry drives checkpointing / LR decay."""
+    `do_eval(mean_losses)` returns the performance list whose first entry drives checkpointing / LR decay.  `sampler`: the
+    on-device negative sampler, whose failure counter is checked where the loop syncs anyway (before every evaluation and
+    at the end): a draw without an admissible candidate raises instead of training on a stand-in."""
     pbar = None
     sums = {k: torch.zeros((), device=DEV) for k in loss_names}
     model.train(); model.enable_grad()
@@ -253,6 +255,8 @@ def training_loop(FLAGS, model, trainer, logger, do_step, do_eval, loss_names, o
             if pbar is not None:
                 pbar.close()
             totals = {k: float(v.item()) for k, v in sums.items()}      # the only loss read-back
+            if sampler is not None:
+                sampler.check()
             do_eval(totals)
             pbar = tqdm(total=FLAGS.eval_interval_steps, desc='Training')
             for v in sums.values():
@@ -263,3 +267,5 @@ def training_loop(FLAGS, model, trainer, logger, do_step, do_eval, loss_names, o
         pbar.update(1)
     if pbar is not None:
         pbar.close()
+    if sampler is not None:
+        sampler.check()

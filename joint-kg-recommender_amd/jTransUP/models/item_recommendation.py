@@ -88,7 +88,7 @@ def train_loop(FLAGS, model, trainer, train_dataset, eval_datasets, user_total, 
         D.clip_and_step(FLAGS, model, trainer)
         return 'rec', losses
 
-    D.training_loop(FLAGS, model, trainer, logger, do_step, do_eval, ['rec'])
+    D.training_loop(FLAGS, model, trainer, logger, do_step, do_eval, ['rec'], sampler=sampler)
 
 
 def run(only_forward=False):

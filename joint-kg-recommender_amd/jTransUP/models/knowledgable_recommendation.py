@@ -195,7 +195,7 @@ def train_loop(FLAGS, model, trainer, rating_train_dataset, triple_train_dataset
         D.clip_and_step(FLAGS, model, trainer)
         return ('rec' if is_rec else 'kg'), losses
 
-    D.training_loop(FLAGS, model, trainer, logger, do_step, do_eval, ['rec', 'kg'])
+    D.training_loop(FLAGS, model, trainer, logger, do_step, do_eval, ['rec', 'kg'], sampler=sampler)
 
 
 def run(only_forward=False):

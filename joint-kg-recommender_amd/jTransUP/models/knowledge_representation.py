@@ -111,7 +111,7 @@ def train_loop(FLAGS, model, trainer, train_dataset, eval_datasets, entity_total
         D.clip_and_step(FLAGS, model, trainer)
         return 'kg', losses
 
-    D.training_loop(FLAGS, model, trainer, logger, do_step, do_eval, ['kg'])
+    D.training_loop(FLAGS, model, trainer, logger, do_step, do_eval, ['kg'], sampler=sampler)
     trainer.save(trainer.checkpoint_path + '_final')      # knowledge_representation.py:219
 
 

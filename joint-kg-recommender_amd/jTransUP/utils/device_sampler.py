@@ -1,7 +1,12 @@
 """On-device negative samplers (K19) with the constraints of the reference's host samplers (jTransUP/utils/data.py:12-85).
 
 The filter structures live on the device for the whole run: one bit per (user, item) for "rated in any split", and the
-sorted 64-bit keys of every known (h, r, t).  Draws are counter-based (Philox), so a (seed, offset) pair reproduces a batch."""
+sorted 64-bit keys of every known (h, r, t).  Draws are counter-based (Philox) and batch uniqueness is resolved by
+deterministic rounds (csrc/ktup_sample.hip), so a (seed, offset) pair reproduces a batch on every rank, whatever the timing.
+
+The kernels never emit an out-of-range id: when no admissible candidate exists (e.g. more rows than admissible items under
+unique_in_batch) the row gets an in-range stand-in and a device-side counter is bumped; `check()` (one small sync; the drivers
+call it before every evaluation and at the end of training) raises on a non-zero counter."""
 import numpy as np
 import torch
 
@@ -19,6 +24,15 @@ class DeviceSampler(object):
         self.bitmap = self.keys = None
         self.n_items = self.n_ent = self.n_rel = 0
         self._ws, self._ws_items = None, -1
+        self.fail = torch.zeros(1, dtype=torch.int32, device=self.device)     # rows whose constraints could not be met
+
+    def check(self):
+        """Raise if any draw since the last check had no admissible candidate (syncs the device once)."""
+        bad = int(self.fail.item())
+        if bad:
+            self.fail.zero_()
+            raise L.KtupError('%d negative draws had no admissible candidate (batch larger than the admissible items under '
+                              'unique_in_batch, or a user / (h, r) that is connected to everything)' % bad)
 
     # ---- filter structures
     def set_rating_dicts(self, user_total, item_total, all_dicts):
@@ -50,16 +64,16 @@ class DeviceSampler(object):
 
     @torch.no_grad()
     def sample_rec(self, u, pos_i, unique_in_batch=True):
-        """-> negative item per (u, pos_i) row; raises if the constraints cannot be met."""
+        """-> negative item per (u, pos_i) row, always a valid item id; `check()` reports rows whose constraints had no solution."""
         n = u.numel()
         neg = torch.empty(n, dtype=torch.int64, device=self.device)
         if self._ws is None or self._ws_items != self.n_items:     # batch-uniqueness bitmap: zeroed by the entry point itself
             nbytes = L.load().ktup_negsample_rec_workspace_bytes(self.n_items)
-            self._ws, self._ws_items = torch.empty((nbytes + 3) // 4, dtype=torch.int32, device=self.device), self.n_items
+            self._ws, self._ws_items = torch.empty((nbytes + 7) // 8, dtype=torch.int64, device=self.device), self.n_items
         ws = self._ws
         L.call('ktup_negsample_rec', _p(u.contiguous()), _p(pos_i.contiguous()), n, self.n_items, _p(self.bitmap),
                self.words if self.bitmap is not None else 0, self.seed, self._advance(n), int(unique_in_batch), _p(neg), _p(ws),
-               _stream(self.device))
+               _p(self.fail), _stream(self.device))
         return neg
 
     @torch.no_grad()
@@ -69,5 +83,6 @@ class DeviceSampler(object):
         nh = torch.empty(n, dtype=torch.int64, device=self.device)
         nt = torch.empty(n, dtype=torch.int64, device=self.device)
         L.call('ktup_negsample_kg', _p(h.contiguous()), _p(t.contiguous()), _p(r.contiguous()), n, self.n_ent, self.n_rel, _p(self.keys),
-               0 if self.keys is None else self.keys.numel(), self.seed, self._advance(n), _p(nh), _p(nt), _stream(self.device))
+               0 if self.keys is None else self.keys.numel(), self.seed, self._advance(n), _p(nh), _p(nt), _p(self.fail),
+               _stream(self.device))
         return nh, nt

@@ -402,8 +402,10 @@ class KGStepper(_StepperBase):
 class DeviceFeeder(object):
     """Device-resident training data for the GPU-resident loop: the rating / triple lists as device tensors, an epoch
     permutation drawn on the device, batches as slices, negatives from the K19 samplers (utils/device_sampler.py).
-    Iterator contract of utils/data.py MakeTrainIterator (data.py:87-110): endless, reshuffled every epoch, the tail
-    partial batch dropped, `negtive_samples` copies of every example per epoch."""
+    Iterator contract of utils/data.py MakeTrainIterator (data.py:87-110): endless, the order list holds `negtive_samples`
+    copies of every example, and -- exactly like the reference -- it wraps (reshuffles) once `start > n - batch_size` with
+    n = the number of DISTINCT examples, so only the first n entries of each shuffled order are consumed, and the tail
+    partial batch is dropped.  -device_sampling and -nodevice_sampling therefore share one epoch / shuffle cadence."""
 
     def __init__(self, rows, batch_size, device, negtive_samples=1, seed=0):
         self.rows = torch.as_tensor(rows, dtype=torch.int64).reshape(len(rows), -1)[:, :3].contiguous().to(device)
@@ -420,7 +422,7 @@ class DeviceFeeder(object):
         self.start = 0
 
     def next(self):
-        if self.start > self.order.numel() - self.B:
+        if self.start > self.n - self.B:              # data.py:101-103: dataset_size, not len(order)
             self._shuffle()
         idx = self.order[self.start:self.start + self.B]
         self.start += self.B

@@ -72,6 +72,8 @@ class RankIndex(object):
         if rows != list(range(rows[0], rows[0] + len(rows))):
             raise KeyError('batch is not a contiguous slice of the indexed keys')
         span = (rows[0], rows[0] + len(rows))
+        if len(self._memo) >= 4096:     # the batches of a pass are a handful of objects; never grow without bound
+            self._memo.clear()
         self._memo[id(batch_keys)] = (batch_keys, span)
         return span
 
@@ -112,7 +114,7 @@ def _as_device_rows(pred_scores, device):
     """Accept the reference's list of (key, numpy row) as well as (keys, device matrix)."""
     if isinstance(pred_scores, tuple) and len(pred_scores) == 2 and torch.is_tensor(pred_scores[1]):
         keys, mat = pred_scores
-        return list(keys), mat
+        return (keys if isinstance(keys, list) else list(keys)), mat    # the SAME list object: RankIndex.rows_of memoises on it
     keys = [k for k, _ in pred_scores]
     rows = [r if torch.is_tensor(r) else torch.from_numpy(np.ascontiguousarray(r, dtype=np.float32)) for _, r in pred_scores]
     return keys, torch.stack([r.to(device) for r in rows]).contiguous()

@@ -33,10 +33,31 @@ def test_rec_sampler_constraints_and_uniformity():
     s.offset = s2.offset = 777
     a, b = s.sample_rec(u, pos, unique_in_batch=False), s2.sample_rec(u, pos, unique_in_batch=False)
     assert torch.equal(a, b)                                                # (seed, offset) reproduces the batch
-    # impossible request: more rows than admissible items -> -1 markers, no hang
+    # ... and so does the batch-unique mode: collisions are resolved by deterministic rounds, not by an atomic race
+    u = torch.from_numpy(rng.randint(0, nu, size=n)).to(DEV); pos = torch.from_numpy(rng.randint(0, ni, size=n)).to(DEV)
+    ref = None
+    for _ in range(5):
+        s.offset = s2.offset = 4242
+        a, b = s.sample_rec(u, pos), s2.sample_rec(u, pos)
+        assert torch.equal(a, b) and (ref is None or torch.equal(a, ref))
+        ref = a
+    s.check(); s2.check()                                                   # nothing failed so far
+    # impossible request: more rows than admissible items -> still valid ids everywhere (never a -1 into the scoring kernels),
+    # the admissible ones each used once, and check() raises
+    from jTransUP.hip.lib import KtupError
     tiny = DeviceSampler(DEV, seed=1); tiny.set_rating_dicts(2, 40, [{0: set(range(30))}])
     out = tiny.sample_rec(torch.zeros(64, dtype=torch.long, device=DEV), torch.zeros(64, dtype=torch.long, device=DEV)).cpu()
-    assert int((out >= 0).sum()) <= 10 and int((out < 0).sum()) >= 54
+    assert int(out.min()) >= 0 and int(out.max()) < 40
+    ok = out[out >= 30]
+    assert sorted(ok.tolist()) == list(range(30, 40))                       # the 10 admissible items, each exactly once
+    with pytest.raises(KtupError):
+        tiny.check()
+    tiny.check()                                                            # the counter was reset
+    # a user who rated everything but one item: the scan fallback finds it (no failure)
+    full = DeviceSampler(DEV, seed=2); full.set_rating_dicts(1, 5000, [{0: set(range(5000)) - {4321}}])
+    z = torch.zeros(3, dtype=torch.long, device=DEV)
+    assert full.sample_rec(z, z, unique_in_batch=False).cpu().tolist() == [4321] * 3
+    full.check()
 
 
 def test_kg_sampler_constraints_and_fair_coin():

@@ -156,8 +156,9 @@ def test_trainer_checkpoint_layout_and_pretrain_load(tmp_path):
 
 
 def test_binary_dataset_cache_round_trip_and_staleness(tmp_path, monkeypatch):
-    """data/cache.py: the second load comes from the pickle (same structures, same dict order), an edited source file is
-    re-parsed, KTUP_DATA_CACHE=0 bypasses the cache."""
+    """data/cache.py: the second load comes from the .npz cache (same structures, same dict order), an edited source file
+    is re-parsed, KTUP_DATA_CACHE=0 bypasses the cache; cache files are numpy-only data (no pickle: a planted file cannot run
+    code and is simply ignored)."""
     import os
     import time
     from jTransUP.data import cache, load_kg_rating_data
@@ -165,12 +166,13 @@ def test_binary_dataset_cache_round_trip_and_staleness(tmp_path, monkeypatch):
     root = os.path.join(str(tmp_path), 'ml1m')
     monkeypatch.delenv('KTUP_DATA_CACHE', raising=False)
     calls = []
-    real = cache.pickle.load
-    monkeypatch.setattr(cache.pickle, 'load', lambda f: (calls.append(1), real(f))[1])
+    real = cache._read
+    monkeypatch.setattr(cache, '_read', lambda f: (real(f), calls.append(1))[0])     # counts successful reads
+    assert not hasattr(cache, 'pickle')
     first = load_kg_rating_data.load_data(root, ['valid.dat'], ['valid.dat'], 16)
     assert not calls and os.path.isdir(os.path.join(root, '.ktup_cache'))
     second = load_kg_rating_data.load_data(root, ['valid.dat'], ['valid.dat'], 16)
-    assert len(calls) >= 8                                          # every parsed file came from its pickle
+    assert len(calls) >= 8                                          # every parsed file came from its cache file
     for a, b in ((first[0], second[0]), (first[4], second[4])):     # train datasets: totals, lists, dicts
         assert a[1:] == b[1:]
     assert list(first[3].items()) == list(second[3].items()) and first[8] == second[8]     # i_remap order, joint map
@@ -181,6 +183,13 @@ def test_binary_dataset_cache_round_trip_and_staleness(tmp_path, monkeypatch):
     os.utime(train, ns=(time.time_ns(), time.time_ns()))
     third = load_kg_rating_data.load_data(root, ['valid.dat'], ['valid.dat'], 16)
     assert third[0][1] == first[0][1] + 1
+    # a planted / corrupt cache file is data, not code: it fails to load as an .npz and the source is parsed instead
+    import pickle
+    planted = cache._cache_file(train)
+    with open(planted, 'wb') as f:
+        pickle.dump(('boom',), f)
+    fourth = load_kg_rating_data.load_data(root, ['valid.dat'], ['valid.dat'], 16)
+    assert fourth[0][1:] == third[0][1:]
     monkeypatch.setenv('KTUP_DATA_CACHE', '0')
     calls.clear()
     load_kg_rating_data.load_data(root, ['valid.dat'], ['valid.dat'], 16)
@@ -219,13 +228,15 @@ def test_kg_summary_and_mrr_from_the_reference_rank_lists():
 
 
 def test_device_feeder_iterator_contract_on_cpu():
-    """DeviceFeeder mirrors MakeTrainIterator (utils/data.py:87-110): endless, every example `negtive_samples` times per
-    epoch, tail partial batch dropped, reshuffled per epoch.  (The class only needs a torch device, so it runs on CPU here.)"""
+    """DeviceFeeder mirrors MakeTrainIterator (utils/data.py:87-110): endless, the order holds every example
+    `negtive_samples` times, and -- the reference's cadence -- it reshuffles once start > n - batch_size with n the number
+    of DISTINCT examples (so with negtive_samples > 1 only the first n order entries are consumed per shuffle), tail partial
+    batch dropped.  (The class only needs a torch device, so it runs on CPU here.)"""
     import torch
     from jTransUP.utils.fast_train import DeviceFeeder
     rows = [(i, i * 2 % 17, 1) for i in range(50)]
     f = DeviceFeeder(rows, 16, torch.device('cpu'), negtive_samples=2, seed=5)
-    per_epoch = (50 * 2) // 16                                   # 6 full batches, the 4 left-over examples are dropped
+    per_epoch = 50 // 16                                         # starts 0, 16, 32; 48 > 50 - 16 wraps (data.py:101-103)
     epochs = []
     for _ in range(3):
         got = torch.cat([f.next() for _ in range(per_epoch)])
@@ -233,8 +244,21 @@ def test_device_feeder_iterator_contract_on_cpu():
         assert all(tuple(r) in set(rows) for r in got.tolist())
         counts = torch.bincount(got[:, 0], minlength=50)
         assert int(counts.max()) <= 2 and int(counts.sum()) == per_epoch * 16      # each example at most `negtive_samples` times
-        epochs.append(got)
-    assert not torch.equal(epochs[0], epochs[1])                 # a new permutation every epoch
+        epochs.append((got, f.order))
+    assert epochs[0][1] is not epochs[1][1] and not torch.equal(epochs[0][1], epochs[1][1])   # a new permutation every epoch
+    # same cadence as the host iterator the reference uses: count its reshuffles over the same number of batches
+    import random
+    from jTransUP.utils import data as host_data
+    shuffles = []
+    real = random.shuffle
+    try:
+        random.shuffle = lambda x: (shuffles.append(1), real(x))[1]
+        it = host_data.MakeTrainIterator(rows, 16, negtive_samples=2)
+        for _ in range(3 * per_epoch):
+            next(it)
+    finally:
+        random.shuffle = real
+    assert len(shuffles) == 3                                    # initial shuffle + one per wrap, like the feeder's 3 orders
     with pytest.raises(ValueError):
         DeviceFeeder(rows[:5], 16, torch.device('cpu'))
 

@@ -13,7 +13,8 @@
  *   - nothing is allocated or freed: outputs and scratch are caller-owned (see *_workspace_bytes);
  *   - gradient outputs are ACCUMULATED with atomics (caller zero-fills, like a dense .grad);
  *   - return 0 on success, <0 on error; ktup_last_error() gives the thread-local message;
- *   - no global mutable state: callable from any host thread.
+ *   - callable from any host thread: the only shared state is the set of integer options below (ktup_set_option), which
+ *     choose between kernels computing the same results and are never read from the environment on the launch path.
  */
 #ifndef KTUP_HIP_H
 #define KTUP_HIP_H
@@ -40,6 +41,16 @@ extern "C" {
 
 int ktup_version(void);
 const char* ktup_last_error(void);
+
+/* Process-wide integer options for tests and A/B measurements; each is seeded once, at library load, from the environment
+ * variable in brackets.  They select between kernels that return the same results.
+ *   "pref_mc"     [KTUP_PREF_MC, 1]      0: the generic K5-K7 kernels even for shapes the matrix-core kernels cover
+ *   "eval_mc"     [KTUP_EVAL_MC, 1]      0: VALU all-candidate kernels instead of the matrix-core ones
+ *   "rank_chunk"  [KTUP_RANK_CHUNK, 0]   > 0: force the chunked ranking kernels with this chunk size
+ *   "seg_bwd_min" [KTUP_SEG_BWD_MIN, 8192]  batch size from which the *_bwd entry points given a workspace reduce row
+ *                                        gradients by sorted segments instead of atomics (0: never)                       */
+int ktup_set_option(const char* name, int value);
+int ktup_get_option(const char* name, int* value);
 
 /* ------------------------------------------------------------------ K1  BPRMF  bprmf.py:46-49 */
 int ktup_score_bprmf_fwd(const float* U, int64_t ldu, const float* I, int64_t ldi, int d,

@@ -11,6 +11,11 @@ namespace ktup {
 // ---- host side -------------------------------------------------------------------------------
 int set_error(int code, const char* fmt, ...);  // records a thread-local message, returns `code`
 int check_launch(const char* what);             // hipGetLastError() -> KTUP_OK / KTUP_ERR_LAUNCH
+// process-wide options (ktup_runtime.hip): read from the environment once at load, changed by ktup_set_option
+int opt_pref_mc();
+int opt_eval_mc();
+int opt_rank_chunk();
+int opt_seg_bwd_min();
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 

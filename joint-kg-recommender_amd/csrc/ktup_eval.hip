@@ -520,9 +520,8 @@ int kg_eval(int model, const char* name, const float* E, int64_t lde, const floa
   hipLaunchKernelGGL(kg_query_prep_kernel, dim3(grid_for((nq + 3) / 4)), dim3(256), 0, st, model, E, lde, R, ldr, X, ldx, d, dq,
                      q, r, nq, head, ws);
   if (int e = check_launch(name)) return e;
-  if (!l1 && model <= 1) {   // squared L2: one (TransE) or two (TransH) GEMMs on the matrix cores; KTUP_EVAL_MC=0 for A/B runs
-    const char* env = getenv("KTUP_EVAL_MC");
-    if (!env || atoi(env) != 0) {
+  if (!l1 && model <= 1) {   // squared L2: one (TransE) or two (TransH) GEMMs on the matrix cores; option eval_mc = 0 for A/B runs
+    if (ktup::opt_eval_mc()) {
       const int rc = ktup::pairs_kg_l2_mc(model, ws, dq, C, ldc, d, nq, n_cand, out, ldo, st, name);
       if (rc != 1) return rc;
     }
@@ -591,7 +590,7 @@ extern "C" int ktup_eval_transr_scores(const float* E, int64_t lde, const float*
   hipLaunchKernelGGL(kg_query_prep_kernel, dim3(grid_for((nq + 3) / 4)), dim3(256), 0, st, 2, E, lde, R, ldr, M, ldm, d, dq, q, r,
                      nq, head, QW);
   if (int e = check_launch(name)) return e;
-  if (!l1 && (d == 64 || d == 100 || d == 128) && aligned16(E) && lde % 4 == 0 && getenv("KTUP_EVAL_MC") == nullptr) {
+  if (!l1 && (d == 64 || d == 100 || d == 128) && aligned16(E) && lde % 4 == 0 && ktup::opt_eval_mc()) {
     // squared L2 on the matrix cores; the scratch of this route lives in the PE region (it is far smaller than the
     // projected tables the VALU route stores there)
     const int64_t n = (int64_t)n_rel * n_ent;
@@ -676,9 +675,8 @@ int pref_scores_tail(const char* name, const float* U, int64_t ldu, const float*
                      QW + d, QW + 2 * d, QL);
   if (int e = check_launch(name)) return e;
   if (gumbel_mode == KTUP_GUMBEL_OFF) {
-    if (!l1) {     // squared L2: six (users x items) GEMMs on the matrix cores (ktup_eval_mc.hip); KTUP_EVAL_MC=0 for A/B runs
-      const char* env = getenv("KTUP_EVAL_MC");
-      if (!env || atoi(env) != 0) {
+    if (!l1) {     // squared L2: six (users x items) GEMMs on the matrix cores (ktup_eval_mc.hip); option eval_mc = 0 for A/B runs
+      if (ktup::opt_eval_mc()) {
         const int rc = ktup::pairs_l2_mc(QW, CW0, CW1, CW2, d, nq, n_items, out, ldo, st, name);
         if (rc != 1) return rc;
       }

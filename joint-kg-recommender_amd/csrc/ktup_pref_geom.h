@@ -30,39 +30,8 @@ inline PrefGeom pref_geom(int d, int n_pref) {
   g.ok = true;
   return g;
 }
-// workspace layout part 1 (floats): Alog[ppad][dp] | Ar[P][dp] | Cn[P][dp]   (row-major; backward, eval, hard gate)
-inline size_t ws1_floats(const PrefGeom& g, int n_pref) { return ((size_t)(g.ppad + 2 * n_pref) * g.dp + 15) & ~(size_t)15; }
-
-// Part 2 serves the tuned forward kernel (pref_fwd2): tables laid out for 64-byte scalar loads (s_load_dwordx16).
-//   Alog2[ppad2][dpa]            logit table, row pitch dpa floats (multiple of 16), zero padded
-//   AC2[P][NW2][EV][16]          for preference p and wave w: the wave's CH2 chunks (c = w + NW2*j) of beta*A,
-//                                then of beta*C, contiguous, padded to EV 64-byte vectors
-constexpr int PB2 = 4;  // preferences per stage-1 pass of one wave in pref_fwd2
-struct PrefGeom2 {
-  int NW, CH;   // waves per workgroup, 16-B chunks per lane in stage 2 (NW * CH >= d / 4, minimal waste)
-  int dpa;      // Alog2 row pitch in floats
-  int ppad2;    // Alog2 rows: multiple of NW * PB2
-  int ev;       // 64-byte vectors per AC2 entry
-};
-inline PrefGeom2 pref_geom2(int d, int n_pref) {
-  PrefGeom2 g{0, 0, 0, 0, 0};
-  const int nch = d / 4;
-  if (nch <= 16) { g.NW = 4; g.CH = 4; }
-  else if (nch <= 20) { g.NW = 5; g.CH = 4; }
-  else if (nch <= 25) { g.NW = 5; g.CH = 5; }
-  else if (nch <= 32) { g.NW = 8; g.CH = 4; }
-  else if (nch <= 40) { g.NW = 8; g.CH = 5; }
-  else { g.NW = 8; g.CH = 8; }
-  g.dpa = ((nch + 3) / 4) * 16;
-  const int step = g.NW * PB2;
-  g.ppad2 = ((n_pref + step - 1) / step) * step;
-  g.ev = (2 * g.CH + 3) / 4;
-  return g;
-}
-inline size_t ws2_floats(const PrefGeom2& g, int n_pref) {
-  return (size_t)g.ppad2 * g.dpa + (size_t)n_pref * g.NW * g.ev * 16;
-}
-inline size_t ws_floats(const PrefGeom& g, int d, int n_pref) { return ws1_floats(g, n_pref) + ws2_floats(pref_geom2(d, n_pref), n_pref); }
+// workspace layout (floats): Alog[ppad][dp] | Ar[P][dp] | Cn[P][dp]   (row-major, zero padded)
+inline size_t ws_floats(const PrefGeom& g, int n_pref) { return ((size_t)(g.ppad + 2 * n_pref) * g.dp + 15) & ~(size_t)15; }
 
 
 // Constant-address-space view of a read-only table: a wave-uniform index selects s_load_dwordx4 and the

@@ -313,10 +313,10 @@ __global__ __launch_bounds__(64) void rec_metrics_kernel(const int32_t* __restri
 
 constexpr int CHUNK_KEYS = 16384;  // 128 KB of keys per chunk
 
-// 0 = take the single-workgroup path; otherwise the chunk size.  KTUP_RANK_CHUNK=<keys> forces the chunked path (tests).
+// 0 = take the single-workgroup path; otherwise the chunk size.  Option rank_chunk = <keys> forces the chunked path (tests).
 int chunk_for(int64_t n_cand) {
-  if (const char* e = getenv("KTUP_RANK_CHUNK")) {
-    const int v = atoi(e);
+  {
+    const int v = ktup::opt_rank_chunk();
     if (v > 0) return min(max(v, 64), CHUNK_KEYS);
   }
   return n_cand > MAX_LDS_CAND ? CHUNK_KEYS : 0;

@@ -1,6 +1,13 @@
-// Error reporting for libktup_hip.so: thread-local message, no global mutable state.
+// Error reporting and process-wide options of libktup_hip.so.
+//
+// Errors: thread-local message, nothing shared.  Options: three integer knobs for tests and A/B runs, seeded ONCE from the
+// environment when the library is loaded (never re-read on the launch path) and changeable through ktup_set_option; they
+// select between kernels that compute the same results, so no caller depends on them for correctness.
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
+#include <cstring>
 
 #include "ktup_common.h"
 
@@ -22,7 +29,45 @@ int check_launch(const char* what) {
   return KTUP_OK;
 }
 
+namespace {
+int env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e && *e ? atoi(e) : dflt;
+}
+struct Option { const char* name; const char* env; std::atomic<int> value; };
+Option g_opts[] = {
+    {"pref_mc", "KTUP_PREF_MC", {env_int("KTUP_PREF_MC", 1)}},          // 0: generic K5-K7 kernels even where the matrix-core ones apply
+    {"eval_mc", "KTUP_EVAL_MC", {env_int("KTUP_EVAL_MC", 1)}},          // 0: VALU evaluation kernels instead of the matrix-core ones
+    {"rank_chunk", "KTUP_RANK_CHUNK", {env_int("KTUP_RANK_CHUNK", 0)}}, // > 0: force the chunked ranking kernels with this chunk size
+    {"seg_bwd_min", "KTUP_SEG_BWD_MIN", {env_int("KTUP_SEG_BWD_MIN", 8192)}},   // rows from which the backward kernels reduce row gradients by segments (0: never)
+};
+Option* find(const char* name) {
+  for (auto& o : g_opts)
+    if (name && strcmp(name, o.name) == 0) return &o;
+  return nullptr;
+}
+}  // namespace
+
+int opt_pref_mc() { return g_opts[0].value.load(std::memory_order_relaxed); }
+int opt_eval_mc() { return g_opts[1].value.load(std::memory_order_relaxed); }
+int opt_rank_chunk() { return g_opts[2].value.load(std::memory_order_relaxed); }
+int opt_seg_bwd_min() { return g_opts[3].value.load(std::memory_order_relaxed); }
+
 }  // namespace ktup
 
-extern "C" int ktup_version(void) { return 1; }
+extern "C" int ktup_version(void) { return 2; }
 extern "C" const char* ktup_last_error(void) { return ktup::g_err; }
+
+extern "C" int ktup_set_option(const char* name, int value) {
+  ktup::Option* o = ktup::find(name);
+  if (!o) return ktup::set_error(KTUP_ERR_INVALID_ARG, "ktup_set_option: unknown option '%s'", name ? name : "(null)");
+  o->value.store(value, std::memory_order_relaxed);
+  return KTUP_OK;
+}
+
+extern "C" int ktup_get_option(const char* name, int* value) {
+  ktup::Option* o = ktup::find(name);
+  if (!o || !value) return ktup::set_error(KTUP_ERR_INVALID_ARG, "ktup_get_option: unknown option '%s'", name ? name : "(null)");
+  *value = o->value.load(std::memory_order_relaxed);
+  return KTUP_OK;
+}

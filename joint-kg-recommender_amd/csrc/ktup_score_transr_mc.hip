@@ -249,7 +249,7 @@ int transr_fwd_mc(const float* E, int64_t lde, const float* R, int64_t ldr, cons
                   const char* name) {
   if (!ws || n_rel <= 0 || n_rel > 4096 || n >= (1ll << 31) || (d != 64 && d != 100 && d != 128)) return 1;
   if ((lde & 3) || !aligned16(E) || (lde >> 2) > 0xffffffffll) return 1;
-  hipMemsetAsync(ws, 0, (size_t)2 * n_rel * sizeof(int32_t), st);           // cnt, cursor
+  if (hipMemsetAsync(ws, 0, (size_t)2 * n_rel * sizeof(int32_t), st) != hipSuccess) return check_launch(name);   // cnt, cursor
   const int g1 = grid_for((n + 2047) / 2048, 512);
   hipLaunchKernelGGL(bucket_hist_kernel, dim3(g1), dim3(256), (size_t)n_rel * 4, st, r, n, (int)n_rel, ws);
   hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(1), 0, st, n, (int)n_rel, ws);

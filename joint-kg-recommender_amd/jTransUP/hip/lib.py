@@ -23,6 +23,8 @@ c_f = ctypes.c_float
 SIGNATURES = {
     'ktup_version': [],
     'ktup_last_error': [],
+    'ktup_set_option': [ctypes.c_char_p, c_i],
+    'ktup_get_option': [ctypes.c_char_p, c_p],
     'ktup_score_bprmf_fwd': [c_p, c_l, c_p, c_l, c_i, c_p, c_p, c_l, c_p, c_p],
     'ktup_score_bprmf_bwd': [c_p, c_l, c_p, c_l, c_i, c_p, c_p, c_l, c_p, c_p, c_p, c_p],
     'ktup_score_transe_fwd': [c_p, c_l, c_p, c_l, c_l, c_i, c_p, c_p, c_p, c_l, c_i, c_p, c_p],
@@ -109,6 +111,15 @@ def call(name, *args):
     rc = getattr(lib, name)(*args)
     if rc != 0:
         raise KtupError('%s failed (%d): %s' % (name, rc, lib.ktup_last_error().decode('utf-8', 'replace')))
+
+
+def set_option(name, value):
+    """Process-wide kernel-selection knob (include/ktup_hip.h ktup_set_option); returns the previous value."""
+    lib = load()
+    old = ctypes.c_int(0)
+    if lib.ktup_get_option(name.encode(), ctypes.byref(old)) != 0 or lib.ktup_set_option(name.encode(), int(value)) != 0:
+        raise KtupError(lib.ktup_last_error().decode('utf-8', 'replace'))
+    return old.value
 
 
 def bind(name, *args):

@@ -11,6 +11,7 @@ import pytest
 import torch
 
 from oracle import cpu_ref as O
+from jTransUP.hip import lib as L
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda'
@@ -254,8 +255,8 @@ def test_chunked_ranking_large_catalogue_vs_oracle(nc, quant, desc):
 
 
 @pytest.mark.parametrize('chunk', [64, 1000, 4096])
-def test_chunked_ranking_equals_lds_path(chunk, monkeypatch):
-    """KTUP_RANK_CHUNK forces the chunked kernels at small N: same integers as the single-workgroup kernels, incl. many
+def test_chunked_ranking_equals_lds_path(chunk):
+    """Option rank_chunk (ktup_set_option) forces the chunked kernels at small N: same integers as the single-workgroup kernels, incl. many
     golds (more than one gold batch), topn larger than the unfiltered set, and everything filtered."""
     rng = np.random.RandomState(chunk)
     nq, nc = 12, 5000
@@ -269,14 +270,15 @@ def test_chunked_ranking_equals_lds_path(chunk, monkeypatch):
     args = (dv(f_off), dv(f_ids))
     for desc in (False, True):
         for topn in (1, 10, 50):
-            monkeypatch.delenv('KTUP_RANK_CHUNK', raising=False)
             a = ops().topk_filtered(mat, desc, topn, *args, with_scores=True)
             ra = ops().gold_ranks(mat, desc, dv(g_off), dv(g_ids), *args)
-            monkeypatch.setenv('KTUP_RANK_CHUNK', str(chunk))
-            b = ops().topk_filtered(mat, desc, topn, *args, with_scores=True)
-            rb = ops().gold_ranks(mat, desc, dv(g_off), dv(g_ids), *args)
+            old = L.set_option('rank_chunk', chunk)
+            try:
+                b = ops().topk_filtered(mat, desc, topn, *args, with_scores=True)
+                rb = ops().gold_ranks(mat, desc, dv(g_off), dv(g_ids), *args)
+            finally:
+                L.set_option('rank_chunk', old)
             assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(ra, rb)
-    monkeypatch.delenv('KTUP_RANK_CHUNK', raising=False)
     want_top, want_ranks = _rank_oracle(scores, filt, gold, False, 10)
     np.testing.assert_array_equal(ops().topk_filtered(mat, False, 10, *args).cpu().numpy(), want_top)
     np.testing.assert_array_equal(ops().gold_ranks(mat, False, dv(g_off), dv(g_ids), *args).cpu().numpy(), want_ranks)
@@ -344,9 +346,9 @@ def test_eval_passes_fast_paths_equal_the_row_paths():
 
 
 @pytest.mark.parametrize('d,ne,nq,nrel', [(100, 3000, 70, 20), (128, 1500, 33, 7), (64, 2049, 65, 20)])
-def test_transr_l2_matrix_core_route_vs_oracle(d, ne, nq, nrel, monkeypatch):
+def test_transr_l2_matrix_core_route_vs_oracle(d, ne, nq, nrel):
     """TransR squared-L2 evaluation on the matrix cores (queries folded through M_r^T, |M_r e|^2 from the K4 forward) against
-    the oracle, and against the VALU route (KTUP_EVAL_MC=0) at the ml1m entity count."""
+    the oracle, and against the VALU route (option eval_mc = 0) at the ml1m entity count."""
     gen = torch.Generator().manual_seed(d + ne)
     E, R = O.make_table(ne, d, gen), O.make_table(nrel, d, gen)
     M = torch.eye(d).reshape(1, d * d).repeat(nrel, 1) + torch.randn(nrel, d * d, generator=gen) * 0.05   # ~ the ctor's identity init
@@ -359,9 +361,11 @@ def test_transr_l2_matrix_core_route_vs_oracle(d, ne, nq, nrel, monkeypatch):
     big = O.make_table(14709, d, gen).to(DEV)
     qb = torch.randint(0, 14709, (200,), generator=gen).to(DEV); rb = torch.randint(0, nrel, (200,), generator=gen).to(DEV)
     a = ops().eval_transr(big, Rd, Md, qb, rb, False, True)
-    monkeypatch.setenv('KTUP_EVAL_MC', '0')
-    b = ops().eval_transr(big, Rd, Md, qb, rb, False, True)
-    monkeypatch.delenv('KTUP_EVAL_MC')
+    old = L.set_option('eval_mc', 0)
+    try:
+        b = ops().eval_transr(big, Rd, Md, qb, rb, False, True)
+    finally:
+        L.set_option('eval_mc', old)
     close(a, b, rtol=2e-4, atol=5e-5)
     assert torch.equal(a.argsort(1)[:, :5], b.argsort(1)[:, :5])   # same best candidates either way
 

@@ -34,8 +34,22 @@ import torch.nn.functional as F
 NU, NI, NE, NR, ALIGNED, D = 6040, 3240, 14708, 20, 2934, 100
 REC_ROWS, KG_ROWS = 716800, 307200
 HBM_PEAK_GBS = 8000.0                      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+FP32_PEAK_TFLOPS = 157.3                   # dense fp32 MFMA = VALU fp32 peak (same pipe on gfx950, MI355X_MICROARCH.md)
 BYTES_REC = 12 * D + 16 + 4 + 4            # 3 gathered fp32 rows + two int64 ids + int32 map entry + fp32 score
 BYTES_KG = 8 * D + 24 + 4                  # h, t rows (rel/norm rows: 20-row tables, counted once) + 3 ids + score
+FLOP_REC = 6 * D * NR + 10 * D             # three (d x P) contractions + the elementwise tail, soft gate
+FLOP_KG = 12 * D
+K6_SOURCES = ('ktup_score_pref_mc.hip', 'ktup_pref_geom.h', 'ktup_lane_swap.h', 'ktup_common.h')   # define the dominant kernel
+
+
+def kernel_src_sha16(files=K6_SOURCES):
+    """Hash of the sources that define the dominant kernel: PMC traffic measured on another version of them is stale."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in files:
+        with open(os.path.join(ROOT, 'joint-kg-recommender_amd', 'csrc', f), 'rb') as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def make_table(rows, d, gen):
@@ -66,8 +80,8 @@ def cpu_baseline(W, i2e, idx, budget_s=18.0):
     from oracle import cpu_ref as O
     ncpu = os.cpu_count() or 1
     B = 512
-    cands = sorted(set(t for t in (1, 4, 8, 16, 32, 64) if t <= ncpu))
-    best = None
+    cands = sorted(set([t for t in (1, 4, 8, 16, 32, 64) if t <= ncpu] + [ncpu]))     # incl. "all cores" 
+    best, by_threads = None, {}
     threads_before = torch.get_num_threads()
     with torch.no_grad():
         for threads in cands:
@@ -82,10 +96,12 @@ def cpu_baseline(W, i2e, idx, budget_s=18.0):
                 rows += B
                 it += 1
             dt = time.perf_counter() - t0
+            by_threads[str(threads)] = rows / dt
             if best is None or rows / dt > best[0]:
                 best = (rows / dt, threads, it, dt)
     torch.set_num_threads(threads_before)
     return {'value': best[0], 'unit': 'scored rows/s', 'cores': best[1], 'kind': 'port', 'host_cores': ncpu,
+            'rows_per_s_by_threads': by_threads, 'rows_per_s_all_cores': by_threads[str(ncpu)],
             'sample': '%d batches of 512 (7 rec : 3 kg) in %.1f s at the best of %s torch threads (%.0f s of CPU work over all '
                       'thread counts); oracle/cpu_ref.py, torch %s CPU' % (best[2], best[3], cands, budget_s, torch.__version__)}
 
@@ -166,7 +182,7 @@ def train_step_bench(device, steps=200, warmup=20):
     return out
 
 
-def eval_bench(device, batch=512, seed=11):
+def eval_bench(device, batch=512, seed=11, keep=None):
     """Second half of the metric: all-item Hit@10 evaluation latency at ml1m shape -- every one of the 6040 users scored
     against all 3240 items by KTUP's evaluateRec (K16), filtered top-10 on the device (K17: ~165 filtered items per user,
     1-30 gold items), metric arithmetic on the host -- i.e. one complete pass of knowledgable_recommendation.evaluateRec."""
@@ -214,6 +230,8 @@ def eval_bench(device, batch=512, seed=11):
         rows = one_pass(True)
     full_ms = 1e3 * (time.perf_counter() - t0) / reps
     hit = float(rows[:, 3].mean())
+    if keep is not None:                              # for the CPU side-by-side, run after every GPU timing (main)
+        keep.update(m=m, users=users, gold=gold, train=train, rows=rows)
     return {'users': NU, 'items': NI, 'batch': batch, 'batches': len(batches), 'topn': 10,
             'device_ms_full_pass': dev_ms, 'device_ms_per_batch': dev_ms / len(batches),
             'full_pass_ms_incl_metrics': full_ms, 'filter_index_build_ms': 1e3 * t_index, 'hit_at_10_random_init': hit,
@@ -221,10 +239,51 @@ def eval_bench(device, batch=512, seed=11):
                     'copy back per pass (the training-time evaluation path; the filter index is built once per run)'}
 
 
+def cpu_eval_baseline(m, users, gold, train, gpu_rows, budget_s=8.0, cb=32):
+    """CPU side-by-side for the evaluation half of the metric: the oracle's reference-shaped evaluateRec
+    (jTransUP.py:163-191: B x N x d materialisations, so B is reduced to 32 users to fit RAM like SURVEY prescribes) plus the
+    evalRecProcess-equivalent ranking walk (utils/misc.py:186-248), on this box's host cores, on a bounded sample of the same
+    users; the per-user rate is extrapolated to the 6040-user pass.  Also a parity spot check: the sample's metric rows must
+    equal the device pass's rows."""
+    import numpy as np
+    from oracle import cpu_ref as O
+    W = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    i2e = m._eval_item2ent.cpu().long()
+    threads_before = torch.get_num_threads()
+    ncpu = os.cpu_count() or 1
+    torch.set_num_threads(min(ncpu, 32))
+    done, t_score, t_rank, worst = 0, 0.0, 0.0, 0.0
+    t_start = time.perf_counter()
+    with torch.no_grad():
+        while time.perf_counter() - t_start < budget_s and done + cb <= len(users):
+            ub = users[done:done + cb]
+            t0 = time.perf_counter()
+            sc = O.eval_ktup_rec(W['user_embeddings.weight'], W['item_embeddings.weight'], W['ent_embeddings.weight'],
+                                 W['pref_embeddings.weight'], W['pref_norm_embeddings.weight'], W['rel_embeddings.weight'],
+                                 W['norm_embeddings.weight'], i2e, torch.tensor(ub), False).numpy()
+            t1 = time.perf_counter()
+            out = O.eval_rec_rows(list(zip(ub, sc)), gold, [train], descending=False, topn=10)
+            t2 = time.perf_counter()
+            t_score += t1 - t0; t_rank += t2 - t1
+            want = np.array([r[:5] for r in out], dtype=np.float64)
+            worst = max(worst, float(np.abs(want - gpu_rows[done:done + cb]).max()))
+            done += cb
+    torch.set_num_threads(threads_before)
+    per_user_ms = 1e3 * (t_score + t_rank) / max(done, 1)
+    return {'kind': 'port', 'cores': min(ncpu, 32), 'host_cores': ncpu, 'users_sampled': done, 'batch': cb,
+            'ms_per_user': per_user_ms, 'ms_per_user_scoring': 1e3 * t_score / max(done, 1), 'ms_per_user_ranking': 1e3 * t_rank / max(done, 1),
+            'full_pass_ms_extrapolated': per_user_ms * len(users), 'max_abs_metric_diff_vs_device': worst,
+            'sample': 'first %d users in batches of %d: oracle eval_ktup_rec (reference-shaped, B x N x d) + eval_rec_rows '
+                      '(serial evalRecProcess equivalent), %.1f s of CPU work' % (done, cb, t_score + t_rank)}
+
+
 def gather_stress_bench(device, scale=1000, reps=20):
-    """SURVEY.md 8(d) gather-stress variant: the same KTUP forward with every big table scaled x1000 in rows (9.7 GB, far
-    beyond L2 and Infinity Cache) and uniform ids, so every row really comes from HBM.  A 400-byte row at its natural pitch
-    costs four 128-byte lines, which caps useful row bytes at ~72 % of the HBM peak (tools/gather_bench.hip)."""
+    """SURVEY.md 8(d) gather-stress variant = the HBM-bound companion of the headline: the same KTUP forward with every big
+    table scaled x1000 in rows (9.7 GB, far beyond L2 and Infinity Cache) and uniform ids, so every row really comes from
+    HBM.  A 400-byte row at its natural pitch costs four 128-byte lines (traffic ~ 512/400 x algorithmic), which caps useful
+    row bytes at ~72 % of the HBM peak; tools/gather_bench.hip measured 4.7-4.9 TB/s for scattered 400-B rows at this
+    working set (profiles/r01_gather_ceiling.txt).  Launches are pre-bound (no wrapper time inside the HIP events)."""
+    from jTransUP.hip import lib as L
     from jTransUP.hip import ops
     gen = torch.Generator(device=device); gen.manual_seed(3)
     nu, ni, ne = NU * scale, NI * scale, NE * scale
@@ -242,23 +301,49 @@ def gather_stress_bench(device, scale=1000, reps=20):
     t = torch.randint(0, ne, (KG_ROWS,), generator=gen, device=device)
     r = torch.randint(0, NR, (KG_ROWS,), generator=gen, device=device)
     out = {'tables_GB': need / 1e9, 'rows_scale': scale}
-    with torch.no_grad():
-        ws = ops.pref_workspace(P, Pn, R, Rn)
-        for name, f, rows, bpr in (('ktup_rec_forward', lambda: ops.score_ktup(U, I, E, P, Pn, R, Rn, i2e, u, i, False, ws=ws), REC_ROWS, BYTES_REC),
-                                   ('ktup_kg_forward', lambda: ops.score_transh(E, R, Rn, h, t, r, False), KG_ROWS, BYTES_KG)):
-            for _ in range(3):
-                f()
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            torch.cuda.synchronize(device)
-            a.record()
-            for _ in range(reps):
-                f()
-            b.record(); torch.cuda.synchronize(device)
-            ms = a.elapsed_time(b) / reps
-            out[name] = {'ms_per_launch': ms, 'achieved_GBs': rows * bpr / (ms * 1e-3) / 1e9,
-                         'frac_of_hbm_peak': rows * bpr / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
-    out['note'] = 'algorithmic row bytes / time incl. the wrapper launch; tables HBM-resident, so traffic ~ algorithmic x 512/400'
+    st = torch.cuda.current_stream(device).cuda_stream
+    ws = ops.pref_workspace(P, Pn, R, Rn)
+    s_rec = torch.empty(REC_ROWS, dtype=torch.float32, device=device)
+    s_kg = torch.empty(KG_ROWS, dtype=torch.float32, device=device)
+    rec = L.bind('ktup_score_ktup_fwd', U.data_ptr(), U.stride(0), I.data_ptr(), I.stride(0), E.data_ptr(), E.stride(0), i2e.data_ptr(),
+                 ws.data_ptr(), NR, D, u.data_ptr(), i.data_ptr(), REC_ROWS, 0, ops.GUMBEL_OFF, None, 0, 0, s_rec.data_ptr(), st)
+    kg = L.bind('ktup_score_transh_fwd', E.data_ptr(), E.stride(0), R.data_ptr(), R.stride(0), Rn.data_ptr(), Rn.stride(0), NR, D,
+                h.data_ptr(), t.data_ptr(), r.data_ptr(), KG_ROWS, 0, s_kg.data_ptr(), st)
+    for name, f, rows, bpr in (('ktup_rec_forward', rec, REC_ROWS, BYTES_REC), ('ktup_kg_forward', kg, KG_ROWS, BYTES_KG)):
+        for _ in range(3):
+            f()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        torch.cuda.synchronize(device)
+        for a, b in ev:
+            a.record(); f(); b.record()
+        torch.cuda.synchronize(device)
+        ms = sorted(a.elapsed_time(b) for a, b in ev)[reps // 2]
+        out[name] = {'ms_per_launch': ms, 'achieved_GBs': rows * bpr / (ms * 1e-3) / 1e9,
+                     'frac_of_hbm_peak': rows * bpr / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    out['note'] = 'algorithmic row bytes / median HIP-event time of the bound launch; tables HBM-resident, so traffic ~ algorithmic x 512/400'
     return out
+
+
+def roofline_hbm_resident(gs):
+    """First-class companion of `roofline` for the case the north star means by "gather-bound": tables far larger than the
+    caches.  Same schema; traffic from the gather-stress PMC pass of tools/collect_profiles.py when its stamp matches."""
+    if 'ktup_rec_forward' not in gs:
+        return {'skipped': gs.get('skipped', 'not run')}
+    e = gs['ktup_rec_forward']
+    traffic, tnote = hbm_traffic('gather_stress_ktup_rec_forward')
+    t = e['ms_per_launch'] * 1e-3
+    return {'bound': 'hbm', 'kernel': 'pref_fwd_mc_kernel<McGeom<25,5,true,false>,false> on tables x%d rows (%.1f GB, uniform ids)'
+                                      % (gs['rows_scale'], gs['tables_GB']),
+            'achieved': e['achieved_GBs'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': e['frac_of_hbm_peak'],
+            'traffic': traffic, 'traffic_source': tnote,
+            'traffic_frac_of_hbm_peak': None if traffic is None else traffic / t / 1e9 / HBM_PEAK_GBS,
+            'traffic_over_algorithmic': None if traffic is None else traffic / (REC_ROWS * BYTES_REC),
+            'expected_traffic_over_algorithmic': 512.0 / 400.0,
+            'scattered_row_ceiling_GBs': 4800.0, 'frac_of_scattered_row_ceiling': e['achieved_GBs'] / 4800.0,
+            'ms_per_launch': e['ms_per_launch'], 'rows_per_launch': REC_ROWS, 'bytes_per_row': BYTES_REC,
+            'kg_kernel': gs.get('ktup_kg_forward'),
+            'note': '400-byte rows at their natural pitch cost four 128-byte lines; the ceiling is the pure gather microbenchmark '
+                    '(tools/gather_bench.hip, profiles/r01_gather_ceiling.txt) at the same working set'}
 
 
 def variants_bench(device, D_, i2e_d, X, reps=10, inner=8):
@@ -327,14 +412,57 @@ def variants_bench(device, D_, i2e_d, X, reps=10, inner=8):
     return out
 
 
-def hbm_traffic(kind):
-    """HBM bytes per launch from the committed PMC passes (profiles/r01_hbm_traffic.json: separate FETCH_SIZE / WRITE_SIZE
-    runs of this same command, read side doubled per MI355X_MICROARCH.md); None when the file is absent."""
-    try:
-        with open(os.path.join(ROOT, 'profiles', 'r01_hbm_traffic.json')) as f:
-            return json.load(f)[kind]['hbm_bytes_per_launch']
-    except Exception:      # noqa: BLE001
-        return None
+def hbm_traffic(kind, tag=None):
+    """HBM bytes per launch from the committed PMC passes (profiles/<tag>_hbm_traffic.json written by tools/collect_profiles.py:
+    separate FETCH_SIZE / WRITE_SIZE runs of this same command, read side doubled per MI355X_MICROARCH.md).  The file is
+    stamped with the kernel name and a hash of the kernel's sources; a stamp that does not match the tree means the counters
+    were taken on another version of the kernel -> (None, reason) instead of a stale number."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_hbm_traffic.json')))
+    if tag:
+        files = [f for f in files if os.path.basename(f).startswith(tag)]
+    for path in reversed(files):
+        try:
+            with open(path) as f:
+                rec = json.load(f)
+            e = rec[kind]
+        except Exception:      # noqa: BLE001
+            continue
+        stamp = rec.get('kernel_src_sha16')
+        if stamp != kernel_src_sha16():
+            return None, 'stale: %s was measured on kernel sources %s, the tree has %s' % (os.path.basename(path), stamp, kernel_src_sha16())
+        return e['hbm_bytes_per_launch'], '%s (%s)' % (os.path.basename(path), e.get('kernel', '?'))
+    return None, 'no profiles/*_hbm_traffic.json'
+
+
+def roofline(rec_ms, kg_ms):
+    """The dominant kernel (K6, KTUP rec forward) against BOTH ceilings it could touch.  `achieved / frac` keep SURVEY 8(d)'s
+    definition (ALGORITHMIC bytes per launch / HIP-event time / 8 TB/s); at ml1m shape the 9.7 MB of tables are L2 /
+    Infinity-Cache resident, so that figure is not an HBM measurement (it can exceed 1 for the lighter kernels): `traffic`
+    is what the fabric counters saw, `fp32_frac` prices the useful flops against the fp32 pipe the kernel actually sits on,
+    and `bound` is whichever of the two minimum times (algorithmic bytes at 8 TB/s, useful flops at 157.3 TF) is larger.
+    The honest HBM-bound companion is `roofline_hbm_resident` (tables x1000 rows)."""
+    t = rec_ms * 1e-3
+    ach = REC_ROWS * BYTES_REC / t / 1e9
+    tf = REC_ROWS * FLOP_REC / t / 1e12
+    t_hbm, t_fp32 = REC_ROWS * BYTES_REC / (HBM_PEAK_GBS * 1e9), REC_ROWS * FLOP_REC / (FP32_PEAK_TFLOPS * 1e12)
+    traffic, tnote = hbm_traffic('ktup_rec_forward')
+    out = {'bound': 'hbm' if t_hbm >= t_fp32 else 'fp32',
+           'kernel': 'pref_fwd_mc_kernel<McGeom<25,5,true,false>,false> (KTUP rec forward, K6)',
+           'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS,
+           'achieved_is': 'algorithmic bytes / time (SURVEY 8d); tables are cache-resident at ml1m shape, see traffic / fp32_frac',
+           'traffic': traffic, 'traffic_source': tnote,
+           'traffic_frac_of_hbm_peak': None if traffic is None else traffic / t / 1e9 / HBM_PEAK_GBS,
+           'traffic_over_algorithmic': None if traffic is None else traffic / (REC_ROWS * BYTES_REC),
+           'fp32_achieved_tflops': tf, 'fp32_peak_tflops': FP32_PEAK_TFLOPS, 'fp32_frac': tf / FP32_PEAK_TFLOPS,
+           'flop_per_row': FLOP_REC, 'min_time_us': {'hbm_algorithmic': 1e6 * t_hbm, 'fp32': 1e6 * t_fp32},
+           'bytes_per_row': BYTES_REC, 'rows_per_launch': REC_ROWS, 'ms_per_launch': rec_ms,
+           'kg_kernel': {'kernel': 'transh_fwd_tile_kernel<25,true> (K3)', 'ms_per_launch': kg_ms,
+                         'achieved': KG_ROWS * BYTES_KG / (kg_ms * 1e-3) / 1e9,
+                         'frac': KG_ROWS * BYTES_KG / (kg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         'fp32_frac': KG_ROWS * FLOP_KG / (kg_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
+                         'note': 'algorithmic bytes; > 1 is possible because the entity table is cache-resident'}}
+    return out
 
 
 def main():
@@ -343,6 +471,8 @@ def main():
     ap.add_argument('--steps', type=int, default=200)       # a step is ~0.17 ms: 200 steps = 35 ms of timed work
     ap.add_argument('--warmup', type=int, default=50)       # long enough for the clocks to settle
     ap.add_argument('--no-extras', action='store_true', help='skip cpu_baseline / train-step / eval side measurements')
+    ap.add_argument('--only', default=None, choices=['gather_stress'],
+                    help='profiling hook: run only this side measurement (for a rocprofv3 pass) and print its JSON')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -360,6 +490,9 @@ def main():
     torch.cuda.set_device(device)
 
     from jTransUP.hip import ops
+    if args.only == 'gather_stress':
+        print(json.dumps({'gather_stress_x1000': gather_stress_bench(device, reps=10)}))
+        return
     W, i2e, idx = build_world(3 + rank, device)          # seed 3 like every recipe (swipe.sh); per-rank row shard
     D_ = {k: v.to(device) for k, v in W.items()}
     i2e_d = i2e.to(device, torch.int32)
@@ -428,21 +561,17 @@ def main():
                                '716800 (u,i) pairs + 307200 (h,t,r) triples (= 2000 batches of 512 at joint_ratio 0.7), '
                                'tables replicated per GPU', 'rows_per_step_per_gpu': REC_ROWS + KG_ROWS,
                    'users': NU, 'items': NI, 'entities': NE, 'relations': NR, 'd': D},
-        'roofline': {'bound': 'hbm', 'kernel': 'pref_fwd_mc_kernel<McGeom<25,5,true,false>,false> (KTUP rec forward, K6)',
-                     'achieved': REC_ROWS * BYTES_REC / (rec_ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                     'frac': REC_ROWS * BYTES_REC / (rec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 'traffic': hbm_traffic('ktup_rec_forward'),
-                     'bytes_per_row': BYTES_REC, 'rows_per_launch': REC_ROWS, 'ms_per_launch': rec_ms,
-                     'note': 'ml1m tables (9.7 MB) are L2/Infinity-Cache resident; algorithmic bytes, not HBM traffic',
-                     'kg_kernel': {'kernel': 'transh_fwd_tile_kernel<25,true> (K3)', 'ms_per_launch': kg_ms,
-                                   'achieved': KG_ROWS * BYTES_KG / (kg_ms * 1e-3) / 1e9,
-                                   'frac': KG_ROWS * BYTES_KG / (kg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}},
+        'roofline': roofline(rec_ms, kg_ms),
     }
     if rank == 0 and world == 1 and not args.no_extras:
-        out['eval_all_item_hit10'] = eval_bench(device)       # before the CPU baseline: its OpenMP pools disturb host-side timing
+        keep = {}
+        out['eval_all_item_hit10'] = eval_bench(device, keep=keep)   # before the CPU baselines: their OpenMP pools disturb host-side timing
         out['train_step_b512'] = train_step_bench(device)
         out['variants'] = variants_bench(device, D_, i2e_d, X)
         out['gather_stress_x1000'] = gather_stress_bench(device)
+        out['roofline_hbm_resident'] = roofline_hbm_resident(out['gather_stress_x1000'])
         out['cpu_baseline'] = cpu_baseline(W, i2e, idx)
+        out['eval_all_item_hit10']['cpu_baseline'] = cpu_eval_baseline(keep['m'], keep['users'], keep['gold'], keep['train'], keep['rows'])
     elif rank == 0:
         out['cpu_baseline'] = None
     if rank == 0:

@@ -18,14 +18,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TAG = sys.argv[1] if len(sys.argv) > 1 else 'r01'
 OUT = os.path.join(ROOT, 'gpurun_out', 'profiles')
 BENCH = ['python', os.path.join(ROOT, 'bench.py'), '--no-extras']
+BENCH_GS = ['python', os.path.join(ROOT, 'bench.py'), '--only', 'gather_stress']
+sys.path.insert(0, ROOT)
 KERNELS = {'ktup_rec_forward': 'pref_fwd_mc_kernel', 'ktup_kg_forward': 'transh_fwd_tile_kernel'}
 
 
-def rocprof(name, flags, bench_args):
+def rocprof(name, flags, bench_args, bench=None):
     d = os.path.join('/tmp', 'ktup_prof_' + name)
     shutil.rmtree(d, ignore_errors=True)
     env = dict(os.environ, TMPDIR='/tmp')
-    cmd = ['rocprofv3'] + flags + ['--output-format', 'csv', '-d', d, '--'] + BENCH + bench_args
+    cmd = ['rocprofv3'] + flags + ['--output-format', 'csv', '-d', d, '--'] + (bench or BENCH) + bench_args
     r = subprocess.run(cmd, cwd='/tmp', env=env, capture_output=True, text=True)
     if r.returncode != 0:
         print(r.stdout[-2000:], r.stderr[-2000:])
@@ -84,6 +86,19 @@ def main():
         read, write = 2.0 * rd_kb * 1024.0, wr_kb * 1024.0
         traffic[tag] = {'kernel': name, 'launches': n, 'hbm_bytes_per_launch': int(read + write), 'read': int(read),
                         'write': int(write)}
+    # gather-stress companion (tables x1000 rows, HBM-resident): the same two counters over `bench.py --only gather_stress`
+    gs = {}
+    for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+        d = rocprof('gs_' + counter.lower(), ['--kernel-trace', '--pmc', counter], [], bench=BENCH_GS)
+        gs[counter] = counter_per_launch(find(d, 'counter_collection.csv'), counter)
+    for tag in KERNELS:
+        rd_kb, n, name = gs['FETCH_SIZE'][tag]
+        wr_kb, _, _ = gs['WRITE_SIZE'][tag]
+        read, write = 2.0 * rd_kb * 1024.0, wr_kb * 1024.0
+        traffic['gather_stress_' + tag] = {'kernel': name, 'launches': n, 'hbm_bytes_per_launch': int(read + write), 'read': int(read),
+                                           'write': int(write)}
+    import bench as B
+    traffic['kernel_src_sha16'] = B.kernel_src_sha16()          # bench.py drops `traffic` when the kernel sources have changed since
     traffic['_method'] = ('rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (KB units); read side doubled per '
                           'MI355X_MICROARCH.md (gfx950 FETCH_SIZE reports half of wide coalesced reads); average over all '
                           'launches of `bench.py --steps 5 --warmup 2 --no-extras`')

@@ -127,6 +127,35 @@ int ktup_score_ktup_bwd(const float* U, int64_t ldu, const float* I, int64_t ldi
                         const float* uniform, uint64_t seed, uint64_t offset, const float* gscore, float* gU,
                         float* gI, float* gE, float* gA, float* gC, void* stream);
 
+/* Backward with caller scratch, for large batches and hot rows: from n >= option seg_bwd_min (default 8192) and
+ * d in {64, 100, 128, 256} the kernel writes each pair's row gradients with plain stores (2 x n x d floats of `ws`) and they are
+ * summed per table row by sorted segments (ktup_segment_reduce_rows below) -- (segments + chunks) x d atomics instead of
+ * 3 n d, and no serialisation on rows that many pairs share.  Otherwise identical to ktup_score_{tup,ktup}_bwd (ws unused).
+ * n_user_rows / n_item_rows = rows of U / I.  ktup_score_pref_bwd_workspace_bytes returns 0 when the atomics path applies. */
+size_t ktup_score_pref_bwd_workspace_bytes(int64_t n, int d, int64_t n_user_rows, int64_t n_item_rows);
+int ktup_score_tup_bwd_ws(const float* U, int64_t ldu, const float* I, int64_t ldi, const float* pref_ws, int n_pref,
+                          int d, const int64_t* u_ids, const int64_t* i_ids, int64_t n, int l1, int gumbel_mode,
+                          const float* uniform, uint64_t seed, uint64_t offset, const float* gscore, float* gU,
+                          float* gI, float* gA, float* gC, int64_t n_user_rows, int64_t n_item_rows, void* ws, void* stream);
+int ktup_score_ktup_bwd_ws(const float* U, int64_t ldu, const float* I, int64_t ldi, const float* E, int64_t lde,
+                           const int32_t* item2ent, int64_t ent_pad, const float* pref_ws, int n_pref, int d,
+                           const int64_t* u_ids, const int64_t* i_ids, int64_t n, int l1, int gumbel_mode,
+                           const float* uniform, uint64_t seed, uint64_t offset, const float* gscore, float* gU,
+                           float* gI, float* gE, float* gA, float* gC, int64_t n_user_rows, int64_t n_item_rows, void* ws,
+                           void* stream);
+
+/* ------------------------------------------- row-gradient reduction by sorted segments (new; replaces n x d float atomics)
+ * gT[ids[e], :] += sign(e) * G[e mod n_src, :]   for e in [0, m), sign = +1 for e < sign_split, -1 otherwise; m = n_src
+ * (one id per source row) or 2 n_src (two roles per source row, e.g. TransE: ids = h ++ t, sign_split = n_src:
+ * gE[h] += gz, gE[t] -= gz, transE.py:51-63 differentiated).  The ids are counting-sorted over the key range [0, n_rows)
+ * and consecutive entries of a row are summed in registers; if map2 != NULL every flushed row sum is also added to
+ * gT2[map2[row], :] unless map2[row] == pad2 (KTUP: gE[item2ent[i]] gets what gI[i] gets, jTransUP.py:122-130).
+ * d % 4 == 0, 16-byte aligned rows, m and n_rows < 2^31; `ws`: ktup_segment_workspace_bytes(m, n_rows) bytes, 16-byte aligned. */
+size_t ktup_segment_workspace_bytes(int64_t m, int64_t n_rows);
+int ktup_segment_reduce_rows(const float* G, int64_t ldg, int d, int64_t n_src, const int64_t* ids, int64_t m,
+                             int64_t sign_split, int64_t n_rows, float* gT, int64_t ldt, const int32_t* map2, int64_t pad2,
+                             float* gT2, int64_t ldt2, void* ws, void* stream);
+
 /* ------------------------------------------- K8/K9  pairwise losses  utils/loss.py:8-16,29-31
  * bpr   : loss = mean(-logsigmoid(target * (pos - neg)))   target = +1 (bprmf) / -1 (translation models,
  *         utils/trainer.py:15-17);   margin: loss = SUM max(pos - neg + margin, 0).
@@ -230,6 +259,12 @@ int ktup_eval_rec_metrics(const int32_t* top_ids, int64_t nq, int topn, const in
  * Device halves of the all-to-all lookup exchange for tables partitioned by `row % world_size`:
  * pack  : out[k,:] = table[ids[k],:]         owner side, rows a peer asked for -> contiguous send buffer
  * unpack: gtable[ids[k],:] += rows[k,:]      owner side, returned row gradients -> shard gradient (atomics) */
+/* Negative ids are padding (fixed-capacity id lists): pack writes a zero row, unpack and the sparse step skip them.
+ * dedupe: uniq[0 .. *n_unique) = the distinct ids of the batch (no particular order), the rest of uniq[0 .. n) = -1,
+ *         inverse[e] = position of ids[e] in uniq; *n_unique is one DEVICE int32 -- the host never needs the count.
+ *         `ws`: ktup_shard_dedupe_workspace_bytes(n) bytes, 8-byte aligned (an open-addressing hash table).              */
+size_t ktup_shard_dedupe_workspace_bytes(int64_t n);
+int ktup_shard_dedupe(const int64_t* ids, int64_t n, int64_t* uniq, int64_t* inverse, int32_t* n_unique, void* ws, void* stream);
 int ktup_shard_pack_rows(const float* table, int64_t ldt, int d, const int64_t* ids, int64_t n, float* out,
                          int64_t ldo, void* stream);
 int ktup_shard_unpack_rows_add(const float* rows, int64_t ldr, int d, const int64_t* ids, int64_t n, float* gtable,

@@ -72,6 +72,18 @@ int pref_bwd_mc(const float* U, int64_t ldu, const float* I, int64_t ldi, const 
                 int64_t ent_pad, const float* Alog, const float* Ar, const float* Cn, int dp, float beta, int n_pref, int d,
                 const int64_t* u_ids, const int64_t* i_ids, int64_t n, int l1, int gumbel_mode, const float* uniform, uint64_t seed,
                 uint64_t offset, const float* gscore, float* gU, float* gI, float* gE, float* gA, float* gC, hipStream_t st,
-                const char* name);
+                const char* name, float* GU = nullptr, float* GV = nullptr);
+// ktup_score_pref_bwd_wide.hip: the same backward for d = 256 (config 5): four waves share a 16-pair tile, 64 coordinates each.
+int pref_bwd_mc_wide(const float* U, int64_t ldu, const float* I, int64_t ldi, const float* E, int64_t lde, const int32_t* item2ent,
+                     int64_t ent_pad, const float* Alog, const float* Ar, const float* Cn, int dp, float beta, int n_pref, int d,
+                     const int64_t* u_ids, const int64_t* i_ids, int64_t n, int l1, int gumbel_mode, const float* uniform, uint64_t seed,
+                     uint64_t offset, const float* gscore, float* gU, float* gI, float* gE, float* gA, float* gC, hipStream_t st,
+                     const char* name, float* GU, float* GV);
+
+// ktup_segreduce.hip: gT[ids[e]] += (+/-) G[e mod n_src] by sorted segments (1 = shape not covered, caller keeps atomics)
+size_t seg_ws_bytes(int64_t m, int64_t n_rows);
+int seg_reduce(const float* G, int64_t ldg, int d, int64_t n_src, const int64_t* ids, int64_t m, int64_t sign_split, int64_t n_rows,
+               float* gT, int64_t ldt, const int32_t* map2, int64_t pad2, float* gT2, int64_t ldt2, void* ws, hipStream_t st,
+               const char* name);
 
 }  // namespace ktup

@@ -527,7 +527,7 @@ int run_pref(bool bwd, const char* name, const float* U, int64_t ldu, const floa
              int64_t lde, const int32_t* item2ent, int64_t ent_pad, const float* pref_ws, int n_pref, int d,
              const int64_t* u_ids, const int64_t* i_ids, int64_t n, int l1, int gumbel_mode, const float* uniform,
              uint64_t seed, uint64_t offset, float* score, const float* gscore, float* gU, float* gI, float* gE,
-             float* gA, float* gC, void* stream) {
+             float* gA, float* gC, void* stream, int64_t n_user_rows = 0, int64_t n_item_rows = 0, void* bws = nullptr) {
   KTUP_REQUIRE(n >= 0, "%s: negative row count", name);
   if (n == 0) return KTUP_OK;
   const PrefGeom g = pref_geom(d, n_pref);
@@ -564,16 +564,39 @@ int run_pref(bool bwd, const char* name, const float* U, int64_t ldu, const floa
   }
   hipStream_t st = (hipStream_t)stream;
   if (opt_pref_mc()) {   // matrix-core kernels (compile-time geometry) for the shapes they cover; 1 = not covered
-    const int rc = bwd
-        ? pref_bwd_mc(reinterpret_cast<const float*>(a.U), a.ldu4 * 4, reinterpret_cast<const float*>(a.I), a.ldi4 * 4,
-                      reinterpret_cast<const float*>(a.E), a.lde4 * 4, a.item2ent, a.ent_pad, reinterpret_cast<const float*>(a.Alog),
-                      reinterpret_cast<const float*>(a.Ar), reinterpret_cast<const float*>(a.Cn), a.dp4 * 4, a.alpha_beta, n_pref, d,
-                      a.u_ids, a.i_ids, a.n, a.l1, a.gumbel, a.uniform, a.seed, a.offset, a.gscore, a.gU, a.gI, a.gE, a.gA, a.gC, st, name)
-        : pref_fwd_mc(reinterpret_cast<const float*>(a.U), a.ldu4 * 4, reinterpret_cast<const float*>(a.I), a.ldi4 * 4,
-                      reinterpret_cast<const float*>(a.E), a.lde4 * 4, a.item2ent, reinterpret_cast<const float*>(a.Alog),
-                      reinterpret_cast<const float*>(a.Ar), reinterpret_cast<const float*>(a.Cn), a.dp4 * 4, n_pref, d, a.u_ids, a.i_ids,
-                      a.n, a.l1, a.gumbel, a.uniform, a.seed, a.offset, a.score, st, name);
-    if (rc != 1) return rc;
+    if (bwd) {
+      // large batches with a workspace: per-pair row gradients by plain stores + a reduction by sorted segments instead of
+      // d float atomics per gathered row (ktup_segreduce.hip)
+      const size_t gbytes = (((size_t)n * d * sizeof(float)) + 255) & ~(size_t)255;
+      float* GU = nullptr; float* GV = nullptr; char* sws = nullptr;
+      if (bws && n_user_rows > 0 && n_item_rows > 0 && opt_seg_bwd_min() > 0 && n >= opt_seg_bwd_min() && (d == 64 || d == 100 || d == 128 || d == 256)) {
+        GU = reinterpret_cast<float*>(bws);
+        GV = reinterpret_cast<float*>(reinterpret_cast<char*>(bws) + gbytes);
+        sws = reinterpret_cast<char*>(bws) + 2 * gbytes;
+      }
+      const int rc = pref_bwd_mc(reinterpret_cast<const float*>(a.U), a.ldu4 * 4, reinterpret_cast<const float*>(a.I), a.ldi4 * 4,
+                                 reinterpret_cast<const float*>(a.E), a.lde4 * 4, a.item2ent, a.ent_pad, reinterpret_cast<const float*>(a.Alog),
+                                 reinterpret_cast<const float*>(a.Ar), reinterpret_cast<const float*>(a.Cn), a.dp4 * 4, a.alpha_beta, n_pref, d,
+                                 a.u_ids, a.i_ids, a.n, a.l1, a.gumbel, a.uniform, a.seed, a.offset, a.gscore, a.gU, a.gI, a.gE, a.gA, a.gC, st,
+                                 name, GU, GV);
+      if (rc == KTUP_OK && GU) {
+        int r2 = seg_reduce(GU, d, d, n, u_ids, n, n, n_user_rows, gU, ldu, nullptr, -1, nullptr, 0, sws, st, name);
+        if (r2 == KTUP_OK)
+          r2 = seg_reduce(GV, d, d, n, i_ids, n, n, n_item_rows, gI, ldi, E ? item2ent : nullptr, ent_pad, gE, lde, sws, st, name);
+        if (r2 == 1) return set_error(KTUP_ERR_UNSUPPORTED, "%s: segment reduction does not cover this shape", name);
+        return r2;
+      }
+      if (rc != 1) return rc;
+      if (GU) {    // the matrix-core kernel does not cover this shape after all: fall through to the atomics kernels
+        GU = GV = nullptr;
+      }
+    } else {
+      const int rc = pref_fwd_mc(reinterpret_cast<const float*>(a.U), a.ldu4 * 4, reinterpret_cast<const float*>(a.I), a.ldi4 * 4,
+                                 reinterpret_cast<const float*>(a.E), a.lde4 * 4, a.item2ent, reinterpret_cast<const float*>(a.Alog),
+                                 reinterpret_cast<const float*>(a.Ar), reinterpret_cast<const float*>(a.Cn), a.dp4 * 4, n_pref, d, a.u_ids,
+                                 a.i_ids, a.n, a.l1, a.gumbel, a.uniform, a.seed, a.offset, a.score, st, name);
+      if (rc != 1) return rc;
+    }
   }
   // generic kernels: any d % 4 == 0 up to 256, both gates
   if (g.CH == 4 && g.NW == 4) return launch_pref<4, 4>(bwd, a, st, name);
@@ -636,4 +659,33 @@ extern "C" int ktup_score_ktup_bwd(const float* U, int64_t ldu, const float* I, 
   KTUP_REQUIRE(E && item2ent, "ktup_score_ktup_bwd: E and item2ent are required (use ktup_score_tup_bwd for TUP)");
   return run_pref(true, "ktup_score_ktup_bwd", U, ldu, I, ldi, E, lde, item2ent, ent_pad, pref_ws, n_pref, d, u_ids, i_ids, n,
                   l1, gumbel_mode, uniform, seed, offset, nullptr, gscore, gU, gI, gE, gA, gC, stream);
+}
+
+// Backward with a workspace: for n >= option seg_bwd_min (default 8192) and the matrix-core shapes, the row gradients are
+// written per pair and reduced per table row by sorted segments (ktup_segreduce.hip) instead of float atomics; otherwise exactly
+// ktup_score_{tup,ktup}_bwd.  n_user_rows / n_item_rows: rows of U / I (the key range of the counting sort).
+extern "C" size_t ktup_score_pref_bwd_workspace_bytes(int64_t n, int d, int64_t n_user_rows, int64_t n_item_rows) {
+  if (n <= 0 || d <= 0 || n_user_rows <= 0 || n_item_rows <= 0) return 0;
+  if (opt_seg_bwd_min() <= 0 || n < opt_seg_bwd_min() || !(d == 64 || d == 100 || d == 128 || d == 256)) return 0;
+  const size_t gbytes = (((size_t)n * d * sizeof(float)) + 255) & ~(size_t)255;
+  return 2 * gbytes + seg_ws_bytes(n, n_user_rows > n_item_rows ? n_user_rows : n_item_rows);
+}
+
+extern "C" int ktup_score_tup_bwd_ws(const float* U, int64_t ldu, const float* I, int64_t ldi, const float* pref_ws, int n_pref,
+                                     int d, const int64_t* u_ids, const int64_t* i_ids, int64_t n, int l1, int gumbel_mode,
+                                     const float* uniform, uint64_t seed, uint64_t offset, const float* gscore, float* gU,
+                                     float* gI, float* gA, float* gC, int64_t n_user_rows, int64_t n_item_rows, void* ws, void* stream) {
+  return run_pref(true, "ktup_score_tup_bwd_ws", U, ldu, I, ldi, nullptr, 0, nullptr, -1, pref_ws, n_pref, d, u_ids, i_ids, n, l1,
+                  gumbel_mode, uniform, seed, offset, nullptr, gscore, gU, gI, nullptr, gA, gC, stream, n_user_rows, n_item_rows, ws);
+}
+
+extern "C" int ktup_score_ktup_bwd_ws(const float* U, int64_t ldu, const float* I, int64_t ldi, const float* E, int64_t lde,
+                                      const int32_t* item2ent, int64_t ent_pad, const float* pref_ws, int n_pref, int d,
+                                      const int64_t* u_ids, const int64_t* i_ids, int64_t n, int l1, int gumbel_mode,
+                                      const float* uniform, uint64_t seed, uint64_t offset, const float* gscore, float* gU,
+                                      float* gI, float* gE, float* gA, float* gC, int64_t n_user_rows, int64_t n_item_rows, void* ws,
+                                      void* stream) {
+  KTUP_REQUIRE(E && item2ent, "ktup_score_ktup_bwd_ws: E and item2ent are required (use ktup_score_tup_bwd_ws for TUP)");
+  return run_pref(true, "ktup_score_ktup_bwd_ws", U, ldu, I, ldi, E, lde, item2ent, ent_pad, pref_ws, n_pref, d, u_ids, i_ids, n,
+                  l1, gumbel_mode, uniform, seed, offset, nullptr, gscore, gU, gI, gE, gA, gC, stream, n_user_rows, n_item_rows, ws);
 }

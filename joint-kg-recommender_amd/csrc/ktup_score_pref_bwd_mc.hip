@@ -58,12 +58,16 @@ struct BArgs {
   int64_t n, ent_pad;
   const float* gscore;
   float *gU, *gI, *gE, *gA, *gC;
+  float *GU, *GV;                // ROWOUT kernels: per-pair row gradients (n x D, pitch D) instead of atomics into gU / gI / gE
   int gumbel;                    // KTUP_GUMBEL_* (HARD kernels)
   const float* uniform;
   uint64_t seed, offset;
 };
 
-template <typename G>
+// ROWOUT: the row gradients gu = gq + gx and gv = gx - gq leave as plain stores into GU / GV (one row per pair); the launcher
+// then sums them per table row by sorted segments (ktup_segreduce.hip) -- for large batches / hot rows, where d float atomics
+// per gathered row serialise on shared L2 lines.
+template <typename G, bool ROWOUT>
 __global__ __launch_bounds__(G::NW * 64) void pref_bwd_mc_kernel(BArgs a) {
   KTUP_RESOLVE_GUMBEL(a);
   constexpr int NCH = G::NCH, NP = G::NP, D = G::D, KG = G::KG, CT = G::CT, PT = G::PT, J = G::J, TOTAL = G::TOTAL;
@@ -334,9 +338,14 @@ __global__ __launch_bounds__(G::NW * 64) void pref_bwd_mc_kernel(BArgs a) {
         const int c0 = 16 * ct + 4 * kq;
         if (live && 4 * ct + kq < NCH) {
           const v4 gu = gq[ct] + gx, gv = gx - gq[ct];
-          atomic_add4(pu + c0, make_float4(gu[0], gu[1], gu[2], gu[3]));
-          atomic_add4(pi + c0, make_float4(gv[0], gv[1], gv[2], gv[3]));
-          if (pe) atomic_add4(pe + c0, make_float4(gv[0], gv[1], gv[2], gv[3]));
+          if constexpr (ROWOUT) {
+            *reinterpret_cast<v4*>(a.GU + gr * D + c0) = gu;
+            *reinterpret_cast<v4*>(a.GV + gr * D + c0) = gv;
+          } else {
+            atomic_add4(pu + c0, make_float4(gu[0], gu[1], gu[2], gu[3]));
+            atomic_add4(pi + c0, make_float4(gv[0], gv[1], gv[2], gv[3]));
+            if (pe) atomic_add4(pe + c0, make_float4(gv[0], gv[1], gv[2], gv[3]));
+          }
         }
       }
     }
@@ -387,14 +396,19 @@ __global__ __launch_bounds__(G::NW * 64) void pref_bwd_mc_kernel(BArgs a) {
       }
 }
 
-template <typename G>
-int launch(const BArgs& a, hipStream_t st, const char* name) {
+template <typename G, bool ROWOUT>
+int launch_r(const BArgs& a, hipStream_t st, const char* name) {
   static_assert(G::LDS <= 160 * 1024, "LDS budget");
-  (void)hipFuncSetAttribute((const void*)pref_bwd_mc_kernel<G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS);
+  (void)hipFuncSetAttribute((const void*)pref_bwd_mc_kernel<G, ROWOUT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS);
   const int64_t ntiles = (a.n + 15) / 16;
   const int grid = grid_for((ntiles + G::NW - 1) / G::NW, 256);
-  hipLaunchKernelGGL((pref_bwd_mc_kernel<G>), dim3(grid), dim3(G::NW * 64), G::LDS, st, a);
+  hipLaunchKernelGGL((pref_bwd_mc_kernel<G, ROWOUT>), dim3(grid), dim3(G::NW * 64), G::LDS, st, a);
   return check_launch(name);
+}
+
+template <typename G>
+int launch(const BArgs& a, hipStream_t st, const char* name) {
+  return a.GU ? launch_r<G, true>(a, st, name) : launch_r<G, false>(a, st, name);
 }
 
 template <int NCH, int NP>
@@ -421,8 +435,12 @@ int pref_bwd_mc(const float* U, int64_t ldu, const float* I, int64_t ldi, const 
                 int64_t ent_pad, const float* Alog, const float* Ar, const float* Cn, int dp, float beta, int n_pref, int d,
                 const int64_t* u_ids, const int64_t* i_ids, int64_t n, int l1, int gumbel_mode, const float* uniform, uint64_t seed,
                 uint64_t offset, const float* gscore, float* gU, float* gI, float* gE, float* gA, float* gC, hipStream_t st,
-                const char* name) {
-  if (n_pref > 32 || (d != 64 && d != 100 && d != 128)) return 1;
+                const char* name, float* GU, float* GV) {
+  if (n_pref > 32) return 1;
+  if (d == 256)
+    return pref_bwd_mc_wide(U, ldu, I, ldi, E, lde, item2ent, ent_pad, Alog, Ar, Cn, dp, beta, n_pref, d, u_ids, i_ids, n, l1, gumbel_mode,
+                            uniform, seed, offset, gscore, gU, gI, gE, gA, gC, st, name, GU, GV);
+  if (d != 64 && d != 100 && d != 128) return 1;
   if ((ldu | ldi | lde) & 3) return 1;
   if ((ldu >> 2) > 0xffffffffll || (ldi >> 2) > 0xffffffffll || (lde >> 2) > 0xffffffffll) return 1;
   BArgs a;
@@ -432,6 +450,7 @@ int pref_bwd_mc(const float* U, int64_t ldu, const float* I, int64_t ldi, const 
   a.Alog = Alog; a.Ar = Ar; a.Cn = Cn; a.dp = dp; a.P = n_pref; a.l1 = l1; a.beta = beta;
   a.u_ids = u_ids; a.i_ids = i_ids; a.n = n; a.ent_pad = ent_pad;
   a.gscore = gscore; a.gU = gU; a.gI = gI; a.gE = gE; a.gA = gA; a.gC = gC;
+  a.GU = GU; a.GV = GV;
   a.gumbel = gumbel_mode; a.uniform = uniform; a.seed = seed; a.offset = offset;
   const int np = (n_pref + 3) / 4;
   if (d == 64) return launch_np<16>(a, np, st, name);

@@ -4,6 +4,10 @@
 //   pack  : out[k, :]  = table[ids[k], :]        (owner side: rows requested by a peer -> contiguous send buffer)
 //   unpack: gtable[ids[k], :] += rows[k, :]      (owner side: row gradients coming back -> shard gradient, atomics)
 // Same lane-group-per-row mapping as the scorers (contiguous 16-B pieces per row).
+// Negative ids are padding (fixed-capacity id lists keep the host out of the loop: the number of distinct ids of a batch
+// stays on the device): pack writes a zero row for them, unpack and the sparse step skip them.
+//   dedupe: distinct ids of a batch + each entry's position among them, by an open-addressing hash table in caller scratch
+//           (two launches; replaces sort + unique + a host sync for the size).
 #include "ktup_rows.h"
 
 using namespace ktup;
@@ -15,7 +19,13 @@ struct PackRows {
   template <typename V, int G, int CPL>
   KTUP_DEV void run(const RowCtx<V, G, CPL>& cx, int64_t row) const {
     V x[CPL];
-    cx.load(x, T + ids[row] * ldt);
+    const int64_t id = ids[row];
+    if (id >= 0) {
+      cx.load(x, T + id * ldt);
+    } else {
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) vzero(x[j]);
+    }
     V* o = reinterpret_cast<V*>(out + row * ldo);
 #pragma unroll
     for (int j = 0; j < CPL; ++j) {
@@ -30,8 +40,10 @@ struct UnpackAdd {
   template <typename V, int G, int CPL>
   KTUP_DEV void run(const RowCtx<V, G, CPL>& cx, int64_t row) const {
     V x[CPL];
+    const int64_t id = ids[row];
+    if (id < 0) return;
     cx.load(x, rows + row * ldr);
-    cx.scatter_add(gT + ids[row] * ldg, x);
+    cx.scatter_add(gT + id * ldg, x);
   }
 };
 
@@ -67,6 +79,7 @@ struct SparseRowStep {
       coef = c < 1.f ? c : 1.f;
     }
     const int64_t r = ids[row];
+    if (r < 0) return;
     V p[CPL], st[CPL], gr[CPL];
     cx.load(p, T + r * ldt);
     cx.load(gr, g + row * ldg);
@@ -85,7 +98,80 @@ struct SparseRowStep {
   }
 };
 
+// ---- dedupe: open addressing, linear probing, keys = ids (>= 0), empty = -1
+KTUP_DEV uint64_t mix64(uint64_t x) {
+  x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ull;
+  x ^= x >> 27; x *= 0x94d049bb133111ebull;
+  return x ^ (x >> 31);
+}
+
+__global__ __launch_bounds__(256) void dedupe_insert_kernel(const int64_t* __restrict__ ids, int64_t n, unsigned long long* keys,
+                                                            int32_t* __restrict__ slot_idx, uint64_t mask, int32_t* count,
+                                                            int64_t* __restrict__ uniq) {
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+    const unsigned long long id = (unsigned long long)ids[e];
+    uint64_t h = mix64(id) & mask;
+    for (;;) {
+      const unsigned long long prev = atomicCAS(keys + h, ~0ull, id);
+      if (prev == ~0ull) {                       // this thread created the entry: it names the compact row
+        const int32_t idx = atomicAdd(count, 1);
+        slot_idx[h] = idx;
+        uniq[idx] = (int64_t)id;
+        break;
+      }
+      if (prev == id) break;
+      h = (h + 1) & mask;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void dedupe_lookup_kernel(const int64_t* __restrict__ ids, int64_t n,
+                                                            const unsigned long long* __restrict__ keys,
+                                                            const int32_t* __restrict__ slot_idx, uint64_t mask,
+                                                            int64_t* __restrict__ inverse) {
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+    const unsigned long long id = (unsigned long long)ids[e];
+    uint64_t h = mix64(id) & mask;
+    while (keys[h] != id) h = (h + 1) & mask;
+    inverse[e] = slot_idx[h];
+  }
+}
+
+uint64_t dedupe_slots(int64_t n) {
+  uint64_t s = 64;
+  while (s < (uint64_t)(2 * n)) s <<= 1;
+  return s;
+}
+
 }  // namespace
+
+// Distinct ids of a batch without leaving the device: uniq[0 .. *n_unique) = the distinct ids (in no particular order),
+// uniq[*n_unique .. n) = -1, inverse[e] = position of ids[e] in uniq.  ids must be >= 0.
+extern "C" size_t ktup_shard_dedupe_workspace_bytes(int64_t n) {
+  if (n <= 0) return 0;
+  return (size_t)dedupe_slots(n) * (sizeof(unsigned long long) + sizeof(int32_t));
+}
+
+extern "C" int ktup_shard_dedupe(const int64_t* ids, int64_t n, int64_t* uniq, int64_t* inverse, int32_t* n_unique, void* ws,
+                                 void* stream) {
+  const char* name = "ktup_shard_dedupe";
+  KTUP_REQUIRE(n >= 0 && n < (1ll << 30), "%s: bad size", name);
+  KTUP_REQUIRE(n_unique, "%s: null pointer argument", name);
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(n_unique, 0, sizeof(int32_t), st) != hipSuccess) return check_launch(name);
+  if (n == 0) return KTUP_OK;
+  KTUP_REQUIRE(ids && uniq && inverse && ws, "%s: null pointer argument", name);
+  KTUP_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 7u) == 0, "%s: workspace must be 8-byte aligned", name);
+  const uint64_t slots = dedupe_slots(n);
+  unsigned long long* keys = reinterpret_cast<unsigned long long*>(ws);
+  int32_t* slot_idx = reinterpret_cast<int32_t*>(keys + slots);
+  if (hipMemsetAsync(keys, 0xff, slots * sizeof(unsigned long long), st) != hipSuccess) return check_launch(name);
+  if (hipMemsetAsync(uniq, 0xff, (size_t)n * sizeof(int64_t), st) != hipSuccess) return check_launch(name);
+  const int grid = grid_for((n + 255) / 256, 1024);
+  hipLaunchKernelGGL(dedupe_insert_kernel, dim3(grid), dim3(256), 0, st, ids, n, keys, slot_idx, slots - 1, n_unique, uniq);
+  hipLaunchKernelGGL(dedupe_lookup_kernel, dim3(grid), dim3(256), 0, st, ids, n, keys, slot_idx, slots - 1, inverse);
+  return check_launch(name);
+}
 
 extern "C" int ktup_shard_sparse_step(int kind, float* table, int64_t ldt, float* state, int64_t lds, int d, const int64_t* ids,
                                       int64_t n, const float* grows, int64_t ldg, float lr, float eps, const double* sumsq,

@@ -41,6 +41,13 @@ SIGNATURES = {
     'ktup_score_tup_bwd': [c_p, c_l, c_p, c_l, c_p, c_i, c_i, c_p, c_p, c_l, c_i, c_i, c_p, c_u, c_u, c_p, c_p, c_p, c_p, c_p, c_p],
     'ktup_score_ktup_bwd': [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_i, c_i, c_p, c_p, c_l, c_i, c_i, c_p, c_u, c_u,
                             c_p, c_p, c_p, c_p, c_p, c_p, c_p],
+    'ktup_score_pref_bwd_workspace_bytes': [c_l, c_i, c_l, c_l],
+    'ktup_score_tup_bwd_ws': [c_p, c_l, c_p, c_l, c_p, c_i, c_i, c_p, c_p, c_l, c_i, c_i, c_p, c_u, c_u, c_p, c_p, c_p, c_p, c_p, c_l, c_l,
+                              c_p, c_p],
+    'ktup_score_ktup_bwd_ws': [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_i, c_i, c_p, c_p, c_l, c_i, c_i, c_p, c_u, c_u,
+                               c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_l, c_p, c_p],
+    'ktup_segment_workspace_bytes': [c_l, c_l],
+    'ktup_segment_reduce_rows': [c_p, c_l, c_i, c_l, c_p, c_l, c_l, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_p],
     'ktup_loss_bpr_fwd': [c_p, c_p, c_l, c_f, c_p, c_p],
     'ktup_loss_bpr_bwd': [c_p, c_p, c_l, c_f, c_p, c_p, c_p, c_p],
     'ktup_loss_margin_fwd': [c_p, c_p, c_l, c_f, c_p, c_p],
@@ -67,6 +74,8 @@ SIGNATURES = {
     'ktup_eval_pref_scores_prepared': [c_p, c_l, c_p, c_i, c_i, c_p, c_l, c_l, c_i, c_i, c_p, c_u, c_u, c_p, c_l, c_p, c_p, c_p],
     'ktup_eval_topk_filtered': [c_p, c_l, c_l, c_l, c_i, c_p, c_p, c_i, c_p, c_p, c_p],
     'ktup_eval_gold_ranks': [c_p, c_l, c_l, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_p],
+    'ktup_shard_dedupe_workspace_bytes': [c_l],
+    'ktup_shard_dedupe': [c_p, c_l, c_p, c_p, c_p, c_p, c_p],
     'ktup_shard_pack_rows': [c_p, c_l, c_i, c_p, c_l, c_p, c_l, c_p],
     'ktup_shard_unpack_rows_add': [c_p, c_l, c_i, c_p, c_l, c_p, c_l, c_p],
     'ktup_negsample_rec_workspace_bytes': [c_l],
@@ -79,7 +88,8 @@ SIGNATURES = {
 }
 _RESTYPE = {'ktup_last_error': ctypes.c_char_p, 'ktup_pref_workspace_bytes': ctypes.c_size_t,
             'ktup_eval_kg_workspace_bytes': ctypes.c_size_t, 'ktup_eval_transr_workspace_bytes': ctypes.c_size_t, 'ktup_score_transr_workspace_bytes': ctypes.c_size_t,
-            'ktup_eval_pref_workspace_bytes': ctypes.c_size_t, 'ktup_eval_pref_items_workspace_bytes': ctypes.c_size_t, 'ktup_negsample_rec_workspace_bytes': ctypes.c_size_t}
+            'ktup_eval_pref_workspace_bytes': ctypes.c_size_t, 'ktup_eval_pref_items_workspace_bytes': ctypes.c_size_t, 'ktup_negsample_rec_workspace_bytes': ctypes.c_size_t,
+            'ktup_score_pref_bwd_workspace_bytes': ctypes.c_size_t, 'ktup_segment_workspace_bytes': ctypes.c_size_t, 'ktup_shard_dedupe_workspace_bytes': ctypes.c_size_t}
 
 _lib = None
 

@@ -232,14 +232,18 @@ class _ScorePref(Function):
         gU, gI = torch.zeros_like(U), torch.zeros_like(I)
         gA = torch.zeros(P, d, dtype=torch.float32, device=dev)
         gC = torch.zeros(P, d, dtype=torch.float32, device=dev)
+        # large batches: per-pair row gradients + reduction by sorted segments instead of float atomics (the library decides:
+        # 0 bytes = the atomics path)
+        nbytes = L.load().ktup_score_pref_bwd_workspace_bytes(n, d, U.shape[0], I.shape[0])
+        bws = torch.empty((nbytes + 3) // 4, dtype=torch.int32, device=dev) if nbytes else None
         if E is None:
-            L.call('ktup_score_tup_bwd', _p(U), U.stride(0), _p(I), I.stride(0), _p(ws), P, d, _p(u), _p(i), n, l1, gumbel_mode,
-                   _p(uniform), seed, offset, _p(gs), _p(gU), _p(gI), _p(gA), _p(gC), _stream(dev))
+            L.call('ktup_score_tup_bwd_ws', _p(U), U.stride(0), _p(I), I.stride(0), _p(ws), P, d, _p(u), _p(i), n, l1, gumbel_mode,
+                   _p(uniform), seed, offset, _p(gs), _p(gU), _p(gI), _p(gA), _p(gC), U.shape[0], I.shape[0], _p(bws), _stream(dev))
             return gU, gI, None, gA, gC, None, None, None, None, None, None, None, None, None, None, None, None
         gE = torch.zeros_like(E)
-        L.call('ktup_score_ktup_bwd', _p(U), U.stride(0), _p(I), I.stride(0), _p(E), E.stride(0), _p(item2ent), ent_pad, _p(ws), P,
+        L.call('ktup_score_ktup_bwd_ws', _p(U), U.stride(0), _p(I), I.stride(0), _p(E), E.stride(0), _p(item2ent), ent_pad, _p(ws), P,
                d, _p(u), _p(i), n, l1, gumbel_mode, _p(uniform), seed, offset, _p(gs), _p(gU), _p(gI), _p(gE), _p(gA), _p(gC),
-               _stream(dev))
+               U.shape[0], I.shape[0], _p(bws), _stream(dev))
         # A = pref + rel and C = pref_norm + norm: the mixed-table gradient goes to both summands
         return gU, gI, gE, gA, gC, gA.clone(), gC.clone(), None, None, None, None, None, None, None, None, None, None
 
@@ -515,6 +519,22 @@ def rec_metrics(top_ids, gold_off, gold_ids):
 
 # ------------------------------------------------------------------------------------------ sharded-table exchange halves
 @torch.no_grad()
+def dedupe(ids):
+    """Distinct ids of a batch without a host sync (ktup_shard_dedupe): -> (uniq, inverse) with uniq padded to len(ids) with -1
+    (no particular order among the distinct ids) and inverse[e] = position of ids[e] in uniq."""
+    dev = _dev(ids)
+    ids = _ids('ids', ids, dev)
+    n = ids.numel()
+    uniq = torch.empty(n, dtype=torch.int64, device=dev)
+    inverse = torch.empty(n, dtype=torch.int64, device=dev)
+    count = torch.empty(1, dtype=torch.int32, device=dev)
+    nbytes = L.load().ktup_shard_dedupe_workspace_bytes(n)
+    ws = torch.empty((nbytes + 7) // 8, dtype=torch.int64, device=dev) if nbytes else None
+    L.call('ktup_shard_dedupe', _p(ids), n, _p(uniq), _p(inverse), _p(count), _p(ws), _stream(dev))
+    return uniq, inverse
+
+
+@torch.no_grad()
 def pack_rows(table, ids):
     """out[k] = table[ids[k]] (owner side of the all-to-all lookup)."""
     dev = _dev(_table('table shard', table))
@@ -531,6 +551,28 @@ def unpack_rows_add(rows, ids, gtable):
     ids = _ids('ids', ids, dev, rows.shape[0])
     L.call('ktup_shard_unpack_rows_add', _p(rows), rows.stride(0), rows.shape[1], _p(ids), ids.numel(), _p(gtable), gtable.stride(0),
            _stream(dev))
+    return gtable
+
+
+@torch.no_grad()
+def segment_reduce_rows(G, ids, gtable, sign_split=None, map2=None, pad2=-1, gtable2=None):
+    """gtable[ids[e]] += (+/-) G[e mod len(G)] by sorted segments (ktup_segment_reduce_rows): the large-batch / hot-row
+    alternative to float atomics.  len(ids) is len(G) or 2 len(G); entries from `sign_split` on are subtracted."""
+    dev = _dev(_table('row gradients', G)); _table('table gradient', gtable)
+    n_src, d = G.shape
+    ids = _ids('ids', ids, dev)
+    m = ids.numel()
+    if m not in (n_src, 2 * n_src):
+        raise L.KtupError('segment_reduce_rows: len(ids) must be len(G) or 2 len(G)')
+    if map2 is not None:
+        _table('second table gradient', gtable2)
+        if map2.dtype != torch.int32 or map2.device != dev or map2.numel() < gtable.shape[0]:
+            raise L.KtupError('map2 must be an int32 device table with one entry per row of gtable')
+    nbytes = L.load().ktup_segment_workspace_bytes(m, gtable.shape[0])
+    ws = torch.empty((nbytes + 3) // 4, dtype=torch.int32, device=dev)
+    L.call('ktup_segment_reduce_rows', _p(G), G.stride(0), d, n_src, _p(ids), m, m if sign_split is None else int(sign_split),
+           gtable.shape[0], _p(gtable), gtable.stride(0), _p(map2), int(pad2), _p(gtable2), 0 if gtable2 is None else gtable2.stride(0),
+           _p(ws), _stream(dev))
     return gtable
 
 

@@ -7,8 +7,10 @@ ROCm; "gloo" on CPU tensors for the world-size-2 tests).  The reference is singl
   * ShardedTable     -- config 5: a table too big to replicate is partitioned by `row % world`; a batch lookup is
                         ids -> all-to-all -> owner-side row pack -> all-to-all of rows, and the row gradients travel the
                         reverse route into the owner's shard gradient.  Duplicate ids are sent once.
-  * ShardedStep      -- config 5's whole step without a shard-sized gradient: compact row gradients back to the owners, ONE
-                        scalar all-reduce for the global-norm clip, row-sparse SGD / Adagrad on the touched rows.
+  * ShardedStep      -- config 5's whole step without a shard-sized gradient: device-side dedupe (no host sync on one rank,
+                        one per step on several), all tables' lookups in ONE id and ONE row all-to-all, compact row gradients
+                        back to the owners in ONE all-to-all, small tables' gradients + the global norm in ONE all-reduce,
+                        row-sparse SGD / Adagrad on the touched rows.
   * merge_topk       -- evaluation with the candidate catalogue sharded across GPUs: local filtered top-n per shard, then
                         an all-gather of (score, id) pairs and a merge under the same (score, id) order.
 
@@ -90,7 +92,14 @@ class ReplicaGradSync(object):
 # ------------------------------------------------------------------------------------------ config 5: row-sharded tables
 class RowOps(object):
     """The device halves of the exchange.  The defaults are the HIP kernels and nothing else (CPU tensors raise): the
-    world-size-2 gloo tests that run without a GPU pass their own torch stand-ins."""
+    world-size-2 gloo tests that run without a GPU pass their own torch stand-ins.  Negative ids are padding everywhere
+    (pack -> zero row, unpack / sparse step -> skipped): id lists keep a fixed capacity so that the number of distinct ids
+    of a batch never has to reach the host."""
+
+    @staticmethod
+    def dedupe(ids):                                              # -> (uniq padded with -1 to len(ids), inverse)
+        from jTransUP.hip import ops
+        return ops.dedupe(ids)
 
     @staticmethod
     def pack(table, local_ids):                                   # out[k] = table[ids[k]]
@@ -124,45 +133,95 @@ def _a2a(out, inp, out_splits, in_splits, group):
         dist.all_to_all_single(out, inp, output_split_sizes=out_splits, input_split_sizes=in_splits, group=group)
 
 
-class _Plan(object):
-    """Routing of one batch of (unique) global row ids: who owns what, in which order it is sent and received."""
+class _Route(object):
+    """Routing of one step's lookups for ALL its tables at once: who owns which distinct id, in which order ids and rows travel.
 
-    def __init__(self, uniq, world, group):
-        owner = uniq % world
-        order = torch.argsort(owner, stable=True)
-        self.order = order
-        self.send_local = (uniq // world)[order].contiguous()                 # owner-local row numbers, grouped by owner
-        self.send_counts = torch.bincount(owner, minlength=world)
-        recv_counts = torch.empty_like(self.send_counts)
-        _a2a(recv_counts, self.send_counts, None, None, group)
-        self.send_counts_l = self.send_counts.tolist()
-        self.recv_counts_l = recv_counts.tolist()
-        self.recv_local = torch.empty(int(sum(self.recv_counts_l)), dtype=uniq.dtype, device=uniq.device)
-        _a2a(self.recv_local, self.send_local, self.recv_counts_l, self.send_counts_l, group)
+    Per table t: uniq_t (distinct global ids, -1 padded), order_t = stable argsort by owner (padding last).  The buffers of the
+    three exchanges are laid out peer-major, table-minor, so each is ONE all-to-all:
+        counts  (world x T int64)  ->  ids (owner-local row numbers)  ->  rows (d floats each; the gradients travel back the same way)
+    and the host reads the two count matrices ONCE per step (the only sync of the step: all_to_all_single wants host split
+    sizes; round 1 did two .tolist() per table and direction)."""
 
+    def __init__(self, uniqs, world, group):
+        self.world, self.group, self.T = world, group, len(uniqs)
+        dev = uniqs[0].device
+        self.order, send_local, cnt = [], [], []
+        for uniq in uniqs:
+            key = torch.where(uniq < 0, torch.full_like(uniq, world), uniq % world)
+            order = torch.argsort(key, stable=True)
+            self.order.append(order)
+            send_local.append(torch.div(uniq, world, rounding_mode='floor')[order])
+            cnt.append(torch.bincount(key, minlength=world + 1)[:world])
+        send_cnt = torch.stack(cnt, 1).contiguous()                               # (world, T): what I ask each peer for, per table
+        recv_cnt = torch.empty_like(send_cnt)
+        _a2a(recv_cnt, send_cnt, None, None, group)
+        both = torch.stack([send_cnt, recv_cnt]).tolist()                         # the step's one host sync
+        self.send_cnt, self.recv_cnt = both[0], both[1]                           # [peer][table]
+        self.send_tot = [sum(r) for r in self.send_cnt]
+        self.recv_tot = [sum(r) for r in self.recv_cnt]
+        self.n_valid = [sum(self.send_cnt[p][t] for p in range(world)) for t in range(self.T)]
+        # ids: peer-major, table-minor
+        parts, offs = [], [[0] * self.T for _ in range(world)]
+        run = [0] * self.T
+        for p in range(world):
+            for t in range(self.T):
+                offs[p][t] = run[t]
+                parts.append(send_local[t][run[t]:run[t] + self.send_cnt[p][t]])
+                run[t] += self.send_cnt[p][t]
+        self.send_off = offs
+        send_ids = torch.cat(parts) if parts else torch.empty(0, dtype=torch.int64, device=dev)
+        self.recv_ids = torch.empty(sum(self.recv_tot), dtype=torch.int64, device=dev)
+        _a2a(self.recv_ids, send_ids, self.recv_tot, self.send_tot, group)
+        # the (peer, table) blocks of what I received, regrouped per table for the owner-side kernels
+        self.recv_blocks = [[None] * self.T for _ in range(world)]
+        at = 0
+        for p in range(world):
+            for t in range(self.T):
+                self.recv_blocks[p][t] = (at, at + self.recv_cnt[p][t])
+                at += self.recv_cnt[p][t]
 
-class _ShardedLookup(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, shard, uniq, table):
-        world, group = table.world, table.group
-        plan = _Plan(uniq, world, group)
-        packed = table.pack(shard, plan.recv_local)                              # rows my peers asked me for
-        rows_sorted = torch.empty(uniq.numel(), shard.shape[1], dtype=shard.dtype, device=shard.device)
-        _a2a(rows_sorted, packed, plan.send_counts_l, plan.recv_counts_l, group)
-        rows = torch.empty_like(rows_sorted)
-        rows[plan.order] = rows_sorted                                           # back to the order of `uniq`
-        ctx.plan, ctx.table, ctx.shape = plan, table, shard.shape
-        return rows
+    def owner_ids(self, t):
+        """Owner-local row numbers my peers asked me for in table t, peer-major."""
+        return torch.cat([self.recv_ids[a:b] for a, b in (self.recv_blocks[p][t] for p in range(self.world))])
 
-    @staticmethod
-    def backward(ctx, grows):
-        plan, table = ctx.plan, ctx.table
-        send = grows[plan.order].contiguous()
-        recv = torch.empty(plan.recv_local.numel(), grows.shape[1], dtype=grows.dtype, device=grows.device)
-        _a2a(recv, send, plan.recv_counts_l, plan.send_counts_l, table.group)
-        gshard = torch.zeros(ctx.shape, dtype=grows.dtype, device=grows.device)
-        table.unpack_add(recv, plan.recv_local, gshard)
-        return gshard, None, None
+    def owner_to_wire(self, per_table):
+        """[rows of table t in owner_ids(t) order] -> one peer-major, table-minor buffer."""
+        cur = [0] * self.T
+        parts = []
+        for p in range(self.world):
+            for t in range(self.T):
+                n = self.recv_cnt[p][t]
+                parts.append(per_table[t][cur[t]:cur[t] + n])
+                cur[t] += n
+        return torch.cat(parts)
+
+    def wire_to_owner(self, buf):
+        """Inverse of owner_to_wire for a buffer that arrived over the reverse route."""
+        out = [[] for _ in range(self.T)]
+        for p in range(self.world):
+            for t in range(self.T):
+                a, b = self.recv_blocks[p][t]
+                out[t].append(buf[a:b])
+        return [torch.cat(o) for o in out]
+
+    def requester_to_wire(self, per_table):
+        """[tensor ordered like order_t (owner-sorted, valid entries first)] -> one peer-major, table-minor buffer."""
+        parts = []
+        for p in range(self.world):
+            for t in range(self.T):
+                a = self.send_off[p][t]
+                parts.append(per_table[t][a:a + self.send_cnt[p][t]])
+        return torch.cat(parts)
+
+    def wire_to_requester(self, buf):
+        out = [[] for _ in range(self.T)]
+        at = 0
+        for p in range(self.world):
+            for t in range(self.T):
+                n = self.send_cnt[p][t]
+                out[t].append(buf[at:at + n])
+                at += n
+        return [torch.cat(o) for o in out]
 
 
 class ShardedTable(torch.nn.Module):
@@ -185,10 +244,35 @@ class ShardedTable(torch.nn.Module):
         self.state = None                           # Adagrad accumulator of the shard (ShardedStep creates it)
 
     def lookup(self, ids):
+        """Autograd form (dense shard gradient): for code that wants `.grad` on the shard.  The training step uses
+        ShardedStep.lookup, which never materialises a shard-sized gradient."""
         uniq, inverse = torch.unique(ids, return_inverse=True)
         if self.world == 1:
             return _LocalGather.apply(self.weight, uniq, self), inverse
         return _ShardedLookup.apply(self.weight, uniq, self), inverse
+
+
+class _ShardedLookup(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, shard, uniq, table):
+        route = _Route([uniq], table.world, table.group)
+        packed = table.pack(shard, route.owner_ids(0))                           # rows my peers asked me for
+        rows_sorted = torch.empty(uniq.numel(), shard.shape[1], dtype=shard.dtype, device=shard.device)
+        _a2a(rows_sorted, route.owner_to_wire([packed]), route.send_tot, route.recv_tot, table.group)
+        rows = torch.empty_like(rows_sorted)
+        rows[route.order[0]] = rows_sorted                                       # back to the order of `uniq`
+        ctx.route, ctx.table, ctx.shape = route, table, shard.shape
+        return rows
+
+    @staticmethod
+    def backward(ctx, grows):
+        route, table = ctx.route, ctx.table
+        send = grows[route.order[0]].contiguous()
+        recv = torch.empty(sum(route.recv_tot), grows.shape[1], dtype=grows.dtype, device=grows.device)
+        _a2a(recv, send, route.recv_tot, route.send_tot, table.group)
+        gshard = torch.zeros(ctx.shape, dtype=grows.dtype, device=grows.device)
+        table.unpack_add(route.wire_to_owner(recv)[0], route.owner_ids(0), gshard)
+        return gshard, None, None
 
 
 class _LocalGather(torch.autograd.Function):
@@ -211,44 +295,62 @@ class ShardedStep(object):
     """One training step over row-sharded tables that never materialises a shard-sized gradient:
 
         step = ShardedStep('adagrad', lr, max_norm=5.0)
-        u_rows, u_at = step.lookup(user_table, u_ids)          # compact rows of the batch's distinct ids + positions
+        (u_rows, u_at), (i_rows, i_at), (e_rows, e_at) = step.lookup_many([(U, u_ids), (I, i_ids), (E, e_ids)])
         ...score on (compact rows, positions), loss scaled for the global batch..., loss.backward()
         step.apply(replicated=[pref, pref_norm, rel, norm])
 
-    lookup : ids -> all-to-all -> owner-side pack -> all-to-all of rows; `rows` is a leaf collecting the dense (compact)
-             row gradients of this rank.
-    apply  : row gradients -> all-to-all back to the owners, duplicates from different ranks combined (atomics into a
-             compact buffer); gradients of the small replicated tables all-reduced; ONE scalar all-reduce gives the job-wide
-             gradient norm for the clip; then the owner updates exactly the touched rows (K: ktup_shard_sparse_step) and
-             every rank applies the same rule to its copy of the replicated tables.
-    Exact w.r.t. the reference's dense step for plain SGD / Adagrad with l2_lambda = 0 (rows with zero gradient do not
-    move); weight decay or momentum would touch every row of every shard each step and are refused."""
+    lookup_many : per table the batch's distinct ids (device-side hash dedupe, fixed capacity, -1 padded: no host sync);
+             one rank: owner-side pack and done.  Several ranks: ONE count exchange for all tables + the step's single host
+             read, ONE all-to-all of ids, owner-side pack, ONE all-to-all of rows.  `rows` is a leaf collecting the dense
+             (compact) row gradients of this rank; padding rows are zero and receive zero gradients.
+    apply  : row gradients -> ONE all-to-all back to the owners, duplicates from different ranks combined into a compact
+             buffer; the gradients of the small replicated tables and the owners' sum of squared row gradients ride in ONE
+             all-reduce (fp64 bucket); then the owner updates exactly the touched rows (ktup_shard_sparse_step) and every
+             rank applies the same rule to its copy of the replicated tables.
+    Collectives per step: 3 + 2 (round 1: >= 9 + 5, with >= 6 host syncs).  Exact w.r.t. the reference's dense step for plain
+    SGD / Adagrad with l2_lambda = 0 (rows with zero gradient do not move); weight decay or momentum would touch every row of
+    every shard each step and are refused."""
 
     def __init__(self, kind, lr, eps=1e-10, max_norm=0.0, group=None, ops=RowOps):
         if kind not in ('sgd', 'adagrad'):
             raise ValueError('row-sparse steps exist for plain SGD and Adagrad only')
         self.kind, self.lr, self.eps, self.max_norm = kind, float(lr), float(eps), float(max_norm)
         self.group, self.world, self.ops = group, _world(group), ops
-        self._pending = []
+        self._pending = []          # (tables, uniqs, route, rows) per lookup_many call
         self._rep_state = {}
+        self._every = {}
 
     def lookup(self, table, ids):
-        if any(t is table for t, _, _, _ in self._pending):
-            raise ValueError('one lookup per table and step: concatenate the ids (duplicates are sent once anyway)')
-        uniq, inverse = torch.unique(ids, return_inverse=True)
+        return self.lookup_many([(table, ids)])[0]
+
+    def lookup_many(self, pairs):
+        tables = [t for t, _ in pairs]
+        for t in tables:
+            if any(t is u for entry in self._pending for u in entry[0]) or sum(1 for u in tables if u is t) > 1:
+                raise ValueError('one lookup per table and step: concatenate the ids (duplicates are sent once anyway)')
         with torch.no_grad():
+            ded = [self.ops.dedupe(ids) for _, ids in pairs]                     # (uniq padded with -1, inverse)
+            uniqs = [u for u, _ in ded]
             if self.world == 1:
-                plan, rows = None, table.pack(table.weight.data, uniq)
+                route = None
+                rows = [t.pack(t.weight.data, u) for t, u in zip(tables, uniqs)]
             else:
-                plan = _Plan(uniq, self.world, self.group)
-                packed = table.pack(table.weight.data, plan.recv_local)
-                rows_sorted = torch.empty(uniq.numel(), table.d, dtype=packed.dtype, device=packed.device)
-                _a2a(rows_sorted, packed, plan.send_counts_l, plan.recv_counts_l, self.group)
-                rows = torch.empty_like(rows_sorted)
-                rows[plan.order] = rows_sorted
-        rows.requires_grad_(True)
-        self._pending.append((table, uniq, plan, rows))
-        return rows, inverse
+                d = tables[0].d
+                if any(t.d != d for t in tables):
+                    raise ValueError('tables of one lookup_many share the row width (one row buffer on the wire)')
+                route = _Route(uniqs, self.world, self.group)
+                packed = [t.pack(t.weight.data, route.owner_ids(k)) for k, t in enumerate(tables)]
+                wire = torch.empty(sum(route.send_tot), d, dtype=torch.float32, device=uniqs[0].device)
+                _a2a(wire, route.owner_to_wire(packed), route.send_tot, route.recv_tot, self.group)
+                rows = []
+                for k, got in enumerate(route.wire_to_requester(wire)):
+                    full = torch.zeros(uniqs[k].numel(), d, dtype=torch.float32, device=got.device)
+                    full[route.order[k][:route.n_valid[k]]] = got                # back to the order of uniq; padding rows stay zero
+                    rows.append(full)
+        for r in rows:
+            r.requires_grad_(True)
+        self._pending.append((tables, uniqs, route, rows))
+        return [(r, inv) for r, (_, inv) in zip(rows, ded)]
 
     def _state_of(self, key, like):
         if self.kind != 'adagrad':
@@ -262,37 +364,47 @@ class ShardedStep(object):
     def apply(self, replicated=()):
         ops = self.ops
         work = []
-        for table, uniq, plan, rows in self._pending:
-            g = rows.grad if rows.grad is not None else torch.zeros_like(rows)
-            if plan is None:
-                ids_local, gsum = uniq, g
-            else:
-                recv = torch.empty(plan.recv_local.numel(), table.d, dtype=g.dtype, device=g.device)
-                _a2a(recv, g[plan.order].contiguous(), plan.recv_counts_l, plan.send_counts_l, self.group)
-                ids_local, at = torch.unique(plan.recv_local, return_inverse=True)     # the same row asked for by several ranks
-                gsum = torch.zeros(ids_local.numel(), table.d, dtype=g.dtype, device=g.device)
-                if recv.shape[0]:
-                    table.unpack_add(recv, at, gsum)
-            work.append((table, ids_local, gsum))
+        for tables, uniqs, route, rows in self._pending:
+            grads = [r.grad if r.grad is not None else torch.zeros_like(r) for r in rows]
+            if route is None:
+                work += [(t, u, g) for t, u, g in zip(tables, uniqs, grads)]
+                continue
+            d = tables[0].d
+            send = route.requester_to_wire([g[route.order[k]] for k, g in enumerate(grads)])
+            recv = torch.empty(sum(route.recv_tot), d, dtype=torch.float32, device=send.device)
+            _a2a(recv, send.contiguous(), route.recv_tot, route.send_tot, self.group)
+            for k, got in enumerate(route.wire_to_owner(recv)):
+                ids_local, at = ops.dedupe(route.owner_ids(k))                   # the same row asked for by several ranks
+                gsum = torch.zeros(ids_local.numel(), d, dtype=torch.float32, device=got.device)
+                if got.shape[0]:
+                    tables[k].unpack_add(got, at, gsum)
+                work.append((tables[k], ids_local, gsum))
         self._pending = []
         reps = [p for p in replicated if p.grad is not None]
-        if self.world > 1:
-            for p in reps:                                                              # small tables: plain all-reduce
-                dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, group=self.group)
         sumsq = None
+        local = ops.sumsq([g for _, _, g in work if g.numel()]) if self.max_norm > 0 else None   # every touched row once, at its owner
+        if self.world > 1 and (reps or local is not None):
+            flat = torch.cat([p.grad.reshape(-1).double() for p in reps] + ([local.reshape(1)] if local is not None else []))
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)        # small tables' gradients + the norm, one bucket
+            off = 0
+            for p in reps:
+                p.grad.copy_(flat[off:off + p.numel()].view_as(p))
+                off += p.numel()
+            if local is not None:
+                local = flat[off:off + 1].clone()
         if self.max_norm > 0:
-            sumsq = ops.sumsq([g for _, _, g in work if g.numel()])                     # every touched row once, at its owner
-            if self.world > 1:
-                dist.all_reduce(sumsq, op=dist.ReduceOp.SUM, group=self.group)
+            sumsq = local
             if reps:
-                sumsq += ops.sumsq([p.grad for p in reps])                              # identical on every rank: counted once
+                sumsq = sumsq + ops.sumsq([p.grad for p in reps])                # identical on every rank: counted once
         for table, ids_local, gsum in work:
             if self.kind == 'adagrad' and table.state is None:
                 table.state = torch.zeros_like(table.weight.data)
             if ids_local.numel():
                 ops.sparse_step(self.kind, table.weight.data, table.state, ids_local, gsum, self.lr, self.eps, sumsq, self.max_norm)
         for p in reps:
-            every = torch.arange(p.shape[0], device=p.device)
+            every = self._every.get(p.shape[0])
+            if every is None or every.device != p.device:
+                every = self._every[p.shape[0]] = torch.arange(p.shape[0], device=p.device)
             ops.sparse_step(self.kind, p.data, self._state_of(id(p), p.data), every, p.grad, self.lr, self.eps, sumsq, self.max_norm)
             p.grad = None
         return sumsq

@@ -11,12 +11,22 @@ class TorchRowOps(object):
     """Test doubles of parallel.RowOps for runs without a GPU (the product's defaults are the HIP kernels only)."""
 
     @staticmethod
+    def dedupe(ids):                                   # (uniq padded with -1 to len(ids), inverse); negative ids = padding everywhere
+        uniq, inverse = torch.unique(ids, return_inverse=True)
+        pad = torch.full((ids.numel() - uniq.numel(),), -1, dtype=ids.dtype, device=ids.device)
+        return torch.cat([uniq, pad]), inverse
+
+    @staticmethod
     def pack(table, local_ids):
-        return table.index_select(0, local_ids)
+        ok = local_ids >= 0
+        out = table.index_select(0, local_ids.clamp(min=0))
+        out[~ok] = 0
+        return out
 
     @staticmethod
     def unpack_add(rows, local_ids, gtable):
-        return gtable.index_add_(0, local_ids, rows)
+        ok = local_ids >= 0
+        return gtable.index_add_(0, local_ids[ok], rows[ok])
 
     @staticmethod
     def sumsq(tensors):
@@ -30,7 +40,8 @@ class TorchRowOps(object):
         coef = 1.0
         if sumsq is not None and max_norm > 0:
             coef = min(1.0, max_norm / (float(sumsq.sqrt()) + 1e-6))
-        g = grows * coef
+        ok = ids >= 0
+        ids, g = ids[ok], (grows * coef)[ok]
         if kind == 'adagrad':
             state[ids] += g * g
             table[ids] -= lr * g / (state[ids].sqrt() + eps)
@@ -75,7 +86,7 @@ def dense_reference(kind, lr, max_norm, world, steps, device):
     return U.data, I.data, P.data
 
 
-def sharded_run(kind, lr, max_norm, steps, device, ops, rank, world, group=None):
+def sharded_run(kind, lr, max_norm, steps, device, ops, rank, world, group=None, many=False):
     """-> this rank's (U shard, I shard, P copy) after `steps` ShardedStep steps on its own batches."""
     from jTransUP.parallel import ShardedStep, ShardedTable
     mk = lambda n, salt: ShardedTable(n, D, rank=rank, world=world, group=group, device=device,
@@ -85,16 +96,19 @@ def sharded_run(kind, lr, max_norm, steps, device, ops, rank, world, group=None)
     st = ShardedStep(kind, lr, max_norm=max_norm, group=group, ops=ops)
     for step in batches(world, steps):
         u, pi, ni = (x.to(device) for x in step[rank])
-        u_rows, u_at = st.lookup(Ut, u)
-        i_rows, i_at = st.lookup(It, torch.cat([pi, ni]))                     # one lookup per table and step
+        if many:                                                              # both tables through ONE id and ONE row exchange
+            (u_rows, u_at), (i_rows, i_at) = st.lookup_many([(Ut, u), (It, torch.cat([pi, ni]))])
+        else:
+            u_rows, u_at = st.lookup(Ut, u)
+            i_rows, i_at = st.lookup(It, torch.cat([pi, ni]))                 # one lookup per table and step
         loss = toy_loss(u_rows[u_at], i_rows[i_at[:B]], i_rows[i_at[B:]], P, u) / (world * B)
         loss.backward()
         st.apply(replicated=[P])
     return Ut.weight.data, It.weight.data, P.data
 
 
-def check_against_dense(kind, lr, max_norm, steps, device, ops, rank, world, group=None, rtol=2e-5, atol=2e-6):
-    Us, Is, Ps = sharded_run(kind, lr, max_norm, steps, device, ops, rank, world, group)
+def check_against_dense(kind, lr, max_norm, steps, device, ops, rank, world, group=None, rtol=2e-5, atol=2e-6, many=False):
+    Us, Is, Ps = sharded_run(kind, lr, max_norm, steps, device, ops, rank, world, group, many=many)
     Ud, Id, Pd = dense_reference(kind, lr, max_norm, world, steps, device)
     torch.testing.assert_close(Us, Ud[torch.arange(rank, NU, world, device=Ud.device)], rtol=rtol, atol=atol)
     torch.testing.assert_close(Is, Id[torch.arange(rank, NI, world, device=Id.device)], rtol=rtol, atol=atol)

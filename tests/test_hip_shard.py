@@ -84,6 +84,7 @@ def test_sharded_step_on_one_gpu_equals_dense():
     from jTransUP.parallel import RowOps
     for kind, lr, max_norm in (('adagrad', 0.1, 0.05), ('sgd', 0.05, 0.02)):
         check_against_dense(kind, lr, max_norm, 3, torch.device(DEV), RowOps, 0, 1)
+        check_against_dense(kind, lr, max_norm, 3, torch.device(DEV), RowOps, 0, 1, many=True)
 
 
 def _two_rank_worker(rank, world, port):
@@ -97,6 +98,7 @@ def _two_rank_worker(rank, world, port):
         from _sharded_case import check_against_dense
         from jTransUP.parallel import RowOps
         check_against_dense('adagrad', 0.1, 0.05, 3, torch.device(DEV), RowOps, rank, world)
+        check_against_dense('adagrad', 0.1, 0.05, 3, torch.device(DEV), RowOps, rank, world, many=True)
     finally:
         dist.destroy_process_group()
 

@@ -105,6 +105,7 @@ def _sharded_step_worker(rank, world):
     from _sharded_case import TorchRowOps, check_against_dense
     for kind, lr, max_norm in (('adagrad', 0.1, 0.05), ('sgd', 0.05, 0.0), ('sgd', 0.05, 0.02)):
         check_against_dense(kind, lr, max_norm, 3, torch.device('cpu'), TorchRowOps, rank, world)
+        check_against_dense(kind, lr, max_norm, 3, torch.device('cpu'), TorchRowOps, rank, world, many=True)   # combined route
 
 
 def _merge_worker(rank, world):

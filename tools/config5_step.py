@@ -64,13 +64,13 @@ def main():
         pi = draw(NI); ni = draw(NI)
         t0 = tick()
         items = torch.cat([pi, ni])
-        u_rows, u_at = step.lookup(Ut, u)
-        i_rows, i_at = step.lookup(It, items)
-        e_rows, e_at = step.lookup(Et, item2ent[items])                         # every item's entity row (no pad rows here)
+        # all three tables through one id exchange and one row exchange (no exchange and no host sync at all on one rank);
+        # every item's entity row travels too (no pad rows here)
+        (u_rows, u_at), (i_rows, i_at), (e_rows, e_at) = step.lookup_many([(Ut, u), (It, items), (Et, item2ent[items])])
         t1 = tick()
         # the scorer addresses the compact tables: item k of the batch -> compact item row i_at[k], compact entity row e_at[k];
         # item2ent for the compact item table = the entity position of (one of) the batch entries that produced that row
-        i2e_compact = torch.empty(i_rows.shape[0], dtype=torch.int32, device=dev)
+        i2e_compact = torch.zeros(i_rows.shape[0], dtype=torch.int32, device=dev)
         i2e_compact[i_at] = e_at.to(torch.int32)
         uu = torch.cat([u_at, u_at])
         score = ops.score_ktup(u_rows, i_rows, e_rows, Pm, Pn, R, Rn, i2e_compact, uu, i_at, False, ent_pad=-1)

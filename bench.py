@@ -150,35 +150,54 @@ def train_step_bench(device, steps=200, warmup=20):
         torch.cuda.synchronize(device)
         dt = time.perf_counter() - t0
         out['ms_per_step_' + mode] = 1e3 * dt / steps
-    # GPU-resident step (utils/fast_train.py JointStepper): what the joint driver runs by default
+    # GPU-resident step (utils/fast_train.py JointStepper): what the joint driver runs by default -- three launches per step
+    # (fused rec / kg kernel, norm + loss, optimizer) replayed from a HIP graph; KTUP_FUSED_STEP=0 = round 1's ~12 launches
     import types
     from jTransUP.utils.fast_train import JointStepper
-    torch.manual_seed(3)
-    m = jt.jTransUPModel(False, D, NU, NI, NE, NR, i_map, new_map, False, False)
-    opt = torch.optim.Adagrad(m.parameters(), lr=0.005, weight_decay=1e-5)
-    tr = types.SimpleNamespace(fused=FusedOptimizer(opt), parameters=list(m.parameters()), model_target=-1, step=0)
-    fl = types.SimpleNamespace(margin=1.0, kg_lambda=1.0, clipping_max_value=5.0)
-    js = JointStepper(m, tr, fl, B)
+    for tag, env in (('gpu_resident_multilaunch', '0'), ('gpu_resident', '1')):
+        os.environ['KTUP_FUSED_STEP'] = env
+        torch.manual_seed(3)
+        m = jt.jTransUPModel(False, D, NU, NI, NE, NR, i_map, new_map, False, False)
+        opt = torch.optim.Adagrad(m.parameters(), lr=0.005, weight_decay=1e-5)
+        tr = types.SimpleNamespace(fused=FusedOptimizer(opt), parameters=list(m.parameters()), model_target=-1, step=0)
+        fl = types.SimpleNamespace(margin=1.0, kg_lambda=1.0, clipping_max_value=5.0)
+        js = JointStepper(m, tr, fl, B)
 
-    def fstep(s):
-        if s % 10 < 7:
-            js.rec_step(u[s], pi[s], ni_[s])
-        else:
-            js.kg_step(h[s], t[s], r[s], nh[s], nt[s], r[s])
+        def fstep(s):
+            if s % 10 < 7:
+                js.rec_step(u[s], pi[s], ni_[s])
+            else:
+                js.kg_step(h[s], t[s], r[s], nh[s], nt[s], r[s])
 
-    for s in range(warmup):
-        fstep(s)
-    torch.cuda.synchronize(device)
-    t0 = time.perf_counter()
-    for s in range(warmup, warmup + steps):
-        fstep(s)
-    torch.cuda.synchronize(device)
-    out['ms_per_step_gpu_resident'] = 1e3 * (time.perf_counter() - t0) / steps
+        for s in range(warmup):
+            fstep(s)
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for s in range(warmup, warmup + steps):
+            fstep(s)
+        torch.cuda.synchronize(device)
+        out['ms_per_step_' + tag] = 1e3 * (time.perf_counter() - t0) / steps
+        if env == '1':
+            out['fused_step'] = bool(js.fused_step)
+            # device time of the replayed graphs alone (HIP events around back-to-back replays of each step kind)
+            for kind in ('rec', 'kg'):
+                g = js._graphs.get(kind)
+                if g is None:
+                    continue
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda.synchronize(device)
+                a.record()
+                for _ in range(50):
+                    g[0].replay()
+                b.record(); torch.cuda.synchronize(device)
+                out['device_ms_per_%s_step' % kind] = a.elapsed_time(b) / 50
+    os.environ.pop('KTUP_FUSED_STEP', None)
     out['ms_per_step'] = out['ms_per_step_gpu_resident']
     out['scored_rows_per_s'] = 2 * B / (out['ms_per_step'] * 1e-3)
     out['note'] = ('fwd pos+neg, loss (+ regularisers on the gpu_resident route), bwd, global-norm clip, dense Adagrad with weight '
-                   'decay. torch = autograd + clip_grad_norm_ + torch.optim; fused = autograd + K20; gpu_resident = JointStepper '
-                   '(~a dozen C-ABI launches, the joint driver\'s default)')
+                   'decay. torch = autograd + clip_grad_norm_ + torch.optim; fused = autograd + K20; gpu_resident = JointStepper, the '
+                   'joint driver\'s default: 3 launches per step (ktup_train_rec_step / ktup_train_kg_step, ktup_optim_gradnorm_loss, '
+                   'ktup_optim_step) replayed from a HIP graph; gpu_resident_multilaunch = the same arithmetic as ~12 launches (round 1)')
     return out
 
 

@@ -321,6 +321,37 @@ int ktup_optim_step(int kind, int n_tensors, float* const* params, float* const*
                     const int32_t* first, float lr, float weight_decay, float momentum, float beta1, float beta2, float eps, float alpha,
                     const double* sumsq, float max_norm, int zero_grads, void* stream);
 
+/* ------------------------------------------- the B = 512 training step in three launches (new; ktup_train_step.hip)
+ * One fused launch per step kind does everything between the sampled ids and the dense gradients; K20 follows.
+ *
+ * ktup_train_rec_step  (knowledgable_recommendation.py:335-344 / item_recommendation.py:160-182):
+ *   rows k and k + B of (u_ids, i_ids) are the positive and the negative pair of example k.  Mixes the RAW preference-side
+ *   tables (what ktup_pref_prepare does), scores both pairs (jTransUP.py:122-143 / transUP.py:69-82), adds
+ *   mean_k -logsigmoid(target (pos_k - neg_k)) to loss[0] and, if orth != 0, orthogonalLoss(pref, pref_norm) to loss[1], and
+ *   ACCUMULATES the gradients of (batch-mean + orth) x gscale into gU / gI / gE (pad entity row skipped) and gP, gPn (+ gR, gRn:
+ *   the mixed-table gradient goes to both summands).  TUP: E == item2ent == rel == norm == gE == gR == gRn == NULL.
+ *   d in {64, 100, 128}, n_pref <= 32; the preference-side tables and every gradient are contiguous (pitch d).
+ * ktup_train_kg_step   (knowledgable_recommendation.py:345-382 / knowledge_representation.py:176-204), TransH (transh != 0) or
+ *   TransE: rows k and k + B of (h, t, r) are the positive triple and its corrupted twin.  loss[0] += sum_k max(pos - neg +
+ *   margin, 0); regs bit 0: loss[1] += orthogonalLoss(R[r], Nrm[r]) over the 2B relation ids, bit 1: loss[2] += normLoss over
+ *   the 4B entity rows, bit 2: loss[3] += normLoss over the 2B relation rows; gradients x gscale accumulated into gE / gR / gN.
+ * Both: if sumsq_zero != NULL it is set to 0.0 (the accumulator of the ktup_optim_gradnorm_loss launch that follows).
+ * ktup_optim_gradnorm_loss: ktup_optim_gradnorm without its memset, plus *loss_out = loss_scale * sum(loss_slots[0..n_slots))
+ *   and loss_slots := 0 for the next step.
+ * ktup_train_step_supported(kind, d, n_pref): 1 if the fused kernel exists (kind 0 rec, 1 kg TransH, 2 kg TransE).        */
+int ktup_train_step_supported(int kind, int d, int n_pref);
+int ktup_train_rec_step(const float* U, int64_t ldu, const float* I, int64_t ldi, const float* E, int64_t lde,
+                        const int32_t* item2ent, int64_t ent_pad, const float* pref, const float* pref_norm,
+                        const float* rel, const float* norm, int64_t ldp, int n_pref, int d, const int64_t* u_ids,
+                        const int64_t* i_ids, int64_t B, int l1, int gumbel_mode, const float* uniform, uint64_t seed,
+                        uint64_t offset, float target, float gscale, int orth, float* loss, float* gU, float* gI, float* gE,
+                        float* gP, float* gPn, float* gR, float* gRn, double* sumsq_zero, void* stream);
+int ktup_train_kg_step(int transh, const float* E, int64_t lde, const float* R, int64_t ldr, const float* Nrm, int64_t ldn,
+                       int d, const int64_t* h, const int64_t* t, const int64_t* r, int64_t B, int l1, float margin,
+                       float gscale, int regs, float* loss, float* gE, float* gR, float* gN, double* sumsq_zero, void* stream);
+int ktup_optim_gradnorm_loss(int n_tensors, float* const* grads, const int64_t* sizes, double* sumsq, float* loss_slots,
+                             int n_slots, float loss_scale, float* loss_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

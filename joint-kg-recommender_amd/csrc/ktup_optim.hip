@@ -41,7 +41,16 @@ KTUP_DEV int find_tensor(const OptTensors& T, int64_t chunk) {
   return k;
 }
 
-__global__ __launch_bounds__(256) void gradnorm_kernel(OptTensors T, double* __restrict__ sumsq) {
+// `slots` (optional): the step's loss terms, accumulated by the fused step kernel that ran before this launch.  Thread 0 of
+// workgroup 0 publishes  *loss_out = loss_scale * sum(slots)  and zeroes the slots for the next step -- the step then needs no
+// separate zero-fill or add launches.
+__global__ __launch_bounds__(256) void gradnorm_kernel(OptTensors T, double* __restrict__ sumsq, float* __restrict__ slots, int n_slots,
+                                                       float loss_scale, float* __restrict__ loss_out) {
+  if (slots && blockIdx.x == 0 && threadIdx.x == 0) {
+    float s = 0.f;
+    for (int i = 0; i < n_slots; ++i) { s += slots[i]; slots[i] = 0.f; }
+    *loss_out = loss_scale * s;
+  }
   // work unit = a quarter chunk (256 float4).  At ml1m size (2.4 M gradient floats) this pass is latency-bound, and its
   // cost is the serialised double atomics on ONE address (one per workgroup): few workgroups, four loads in flight each
   const int64_t nunits = T.chunk0[T.count] * 4;
@@ -209,8 +218,23 @@ extern "C" int ktup_optim_gradnorm(int n_tensors, float* const* grads, const int
   if (hipMemsetAsync(sumsq, 0, sizeof(double), st) != hipSuccess) return check_launch("ktup_optim_gradnorm");
   const int64_t nchunks = T.chunk0[T.count];
   if (nchunks == 0) return KTUP_OK;
-  hipLaunchKernelGGL(gradnorm_kernel, dim3(grid_for((nchunks * 4 + 3) / 4, 256)), dim3(256), 0, st, T, sumsq);
+  hipLaunchKernelGGL(gradnorm_kernel, dim3(grid_for((nchunks * 4 + 3) / 4, 256)), dim3(256), 0, st, T, sumsq, (float*)nullptr, 0, 0.f,
+                     (float*)nullptr);
   return check_launch("ktup_optim_gradnorm");
+}
+
+// ktup_optim_gradnorm for the fused training step (ktup_train_step.hip): *sumsq was zeroed by the step kernel that precedes
+// this launch on the stream (no memset node), and the step's loss slots are folded into *loss_out and cleared (see the kernel).
+extern "C" int ktup_optim_gradnorm_loss(int n_tensors, float* const* grads, const int64_t* sizes, double* sumsq, float* loss_slots,
+                                        int n_slots, float loss_scale, float* loss_out, void* stream) {
+  OptTensors T{};
+  KTUP_REQUIRE(grads && sizes && sumsq && loss_slots && loss_out && n_slots > 0, "ktup_optim_gradnorm_loss: null pointer argument");
+  if (int e = fill("ktup_optim_gradnorm_loss", T, n_tensors, nullptr, grads, nullptr, nullptr, sizes)) return e;
+  const int64_t nchunks = T.chunk0[T.count];
+  const int64_t units = nchunks > 0 ? (nchunks * 4 + 3) / 4 : 1;
+  hipLaunchKernelGGL(gradnorm_kernel, dim3(grid_for(units, 256)), dim3(256), 0, (hipStream_t)stream, T, sumsq, loss_slots, n_slots,
+                     loss_scale, loss_out);
+  return check_launch("ktup_optim_gradnorm_loss");
 }
 
 extern "C" int ktup_optim_step(int kind, int n_tensors, float* const* params, float* const* grads, float* const* state1,

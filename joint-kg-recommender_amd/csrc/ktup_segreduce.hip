@@ -92,8 +92,12 @@ __global__ __launch_bounds__(256) void seg_reduce_kernel(SegArgs a) {
 #pragma unroll
     for (int j = 0; j < CPL; ++j) acc[j] = f4zero();
     int32_t cur = a.skey[k0];
+    // a row whose entries all lie inside this chunk belongs to this lane group alone: plain read-modify-write; only the rows
+    // cut by the chunk's edges (and every row of the mapped second table, which several rows may share) need atomics
+    const int32_t before = k0 > 0 ? a.skey[k0 - 1] : -1, after = k1 < a.m ? a.skey[k1] : -1;
     auto flush = [&](int32_t key) {
       float* row = a.gT + (int64_t)key * a.ldt;
+      const bool mine = key != before && key != after;
       float* row2 = nullptr;
       if (a.map2) {
         const int64_t t2 = a.map2[key];
@@ -103,7 +107,12 @@ __global__ __launch_bounds__(256) void seg_reduce_kernel(SegArgs a) {
       for (int j = 0; j < CPL; ++j) {
         const int ch = lane + j * GL;
         if (ch < a.nch) {
-          atomic_add4(row + 4 * ch, acc[j]);
+          if (mine) {
+            float4* dst = reinterpret_cast<float4*>(row + 4 * ch);
+            *dst = *dst + acc[j];
+          } else {
+            atomic_add4(row + 4 * ch, acc[j]);
+          }
           if (row2) atomic_add4(row2 + 4 * ch, acc[j]);
         }
         acc[j] = f4zero();

@@ -105,22 +105,39 @@ KTUP_DEV uint64_t mix64(uint64_t x) {
   return x ^ (x >> 31);
 }
 
+__global__ __launch_bounds__(256) void dedupe_init_kernel(unsigned long long* __restrict__ keys, uint64_t slots, int64_t* __restrict__ uniq,
+                                                          int64_t n, int32_t* __restrict__ count) {
+  const int64_t total = (int64_t)slots + n;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    if (i < (int64_t)slots) keys[i] = ~0ull; else uniq[i - (int64_t)slots] = -1;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) *count = 0;
+}
+
 __global__ __launch_bounds__(256) void dedupe_insert_kernel(const int64_t* __restrict__ ids, int64_t n, unsigned long long* keys,
                                                             int32_t* __restrict__ slot_idx, uint64_t mask, int32_t* count,
                                                             int64_t* __restrict__ uniq) {
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
     const unsigned long long id = (unsigned long long)ids[e];
     uint64_t h = mix64(id) & mask;
+    bool created = false;
     for (;;) {
       const unsigned long long prev = atomicCAS(keys + h, ~0ull, id);
-      if (prev == ~0ull) {                       // this thread created the entry: it names the compact row
-        const int32_t idx = atomicAdd(count, 1);
-        slot_idx[h] = idx;
-        uniq[idx] = (int64_t)id;
-        break;
-      }
+      if (prev == ~0ull) { created = true; break; }   // this thread created the entry: it names the compact row
       if (prev == id) break;
       h = (h + 1) & mask;
+    }
+    // compact row numbers: ONE counter atomic per wave (a per-thread atomicAdd on one address serialises the whole batch)
+    const unsigned long long made = __ballot(created);
+    if (created) {
+      const int lane = threadIdx.x & 63;
+      const int leader = __ffsll((long long)made) - 1;
+      int32_t base = 0;
+      if (lane == leader) base = atomicAdd(count, __popcll(made));
+      base = __shfl(base, leader, 64);
+      const int32_t idx = base + __popcll(made & ((1ull << lane) - 1ull));
+      slot_idx[h] = idx;
+      uniq[idx] = (int64_t)id;
     }
   }
 }
@@ -158,15 +175,17 @@ extern "C" int ktup_shard_dedupe(const int64_t* ids, int64_t n, int64_t* uniq, i
   KTUP_REQUIRE(n >= 0 && n < (1ll << 30), "%s: bad size", name);
   KTUP_REQUIRE(n_unique, "%s: null pointer argument", name);
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(n_unique, 0, sizeof(int32_t), st) != hipSuccess) return check_launch(name);
-  if (n == 0) return KTUP_OK;
+  if (n == 0) {
+    if (hipMemsetAsync(n_unique, 0, sizeof(int32_t), st) != hipSuccess) return check_launch(name);
+    return KTUP_OK;
+  }
   KTUP_REQUIRE(ids && uniq && inverse && ws, "%s: null pointer argument", name);
   KTUP_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 7u) == 0, "%s: workspace must be 8-byte aligned", name);
   const uint64_t slots = dedupe_slots(n);
   unsigned long long* keys = reinterpret_cast<unsigned long long*>(ws);
   int32_t* slot_idx = reinterpret_cast<int32_t*>(keys + slots);
-  if (hipMemsetAsync(keys, 0xff, slots * sizeof(unsigned long long), st) != hipSuccess) return check_launch(name);
-  if (hipMemsetAsync(uniq, 0xff, (size_t)n * sizeof(int64_t), st) != hipSuccess) return check_launch(name);
+  hipLaunchKernelGGL(dedupe_init_kernel, dim3(grid_for(((int64_t)slots + n + 255) / 256, 1024)), dim3(256), 0, st, keys, slots, uniq, n,
+                     n_unique);
   const int grid = grid_for((n + 255) / 256, 1024);
   hipLaunchKernelGGL(dedupe_insert_kernel, dim3(grid), dim3(256), 0, st, ids, n, keys, slot_idx, slots - 1, n_unique, uniq);
   hipLaunchKernelGGL(dedupe_lookup_kernel, dim3(grid), dim3(256), 0, st, ids, n, keys, slot_idx, slots - 1, inverse);

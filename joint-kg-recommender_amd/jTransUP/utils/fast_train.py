@@ -1,7 +1,10 @@
 """GPU-resident training steps of the three drivers: the arithmetic of their `train_loop` step bodies
 (knowledgable_recommendation.py:330-401 -> JointStepper; item_recommendation.py:160-195 -> RecStepper;
-knowledge_representation.py:176-211 -> KGStepper) issued as about a dozen launches through the C ABI and, in a single
-process, replayed from one HIP graph per step kind.
+knowledge_representation.py:176-211 -> KGStepper) through the C ABI and, in a single process, replayed from one HIP graph per
+step kind.  Where a fused kernel exists (ktup_train_step_supported: TUP / KTUP at d in {64, 100, 128}, TransH / TransE at any
+d % 4 == 0) a step is THREE launches: ktup_train_rec_step or ktup_train_kg_step (scores, loss, regularisers, every gradient),
+ktup_optim_gradnorm_loss, ktup_optim_step.  Otherwise (and with KTUP_FUSED_STEP=0) the round-1 sequence of about a dozen
+launches runs: same arithmetic, separate kernels.
 
 The autograd route (`model(...)`, `bprLoss`, `.backward()`, `clip_and_step`) costs ~50 launches and ~0.5 ms of Python per
 B=512 step: every Function allocates and zero-fills table-shaped gradients which autograd then adds into `.grad`, and
@@ -81,6 +84,9 @@ class _StepperBase(object):
             import os
             use_graphs = os.environ.get('KTUP_TRAIN_GRAPHS', '1') != '0'
         self.use_graphs = bool(use_graphs) and self.world == 1
+        import os as _os
+        self.want_fused = _os.environ.get('KTUP_FUSED_STEP', '1') != '0'
+        self.out = {k: torch.zeros((), **f32) for k in self.KINDS}                       # fused steps: where the step's loss is published
         self._graphs = {}
         self._eager_steps = {k: 0 for k in self.KINDS}
         self._setup(FLAGS, f32, i64)
@@ -123,10 +129,13 @@ class _StepperBase(object):
             self._stream = st
             self._bind(st)
 
-    def _optimizer_launches(self):
+    def _optimizer_launches(self, loss=None):
         if self.world > 1:       # gradients of all tables + the loss scalars, one bucket
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
-        self.trainer.fused.clip_and_step(self.max_norm, zero_grads=True)
+        self.trainer.fused.clip_and_step(self.max_norm, zero_grads=True, loss=loss)
+
+    def _fused_ok(self, kind, d, n_pref=0):
+        return bool(self.want_fused and L.load().ktup_train_step_supported(kind, d, n_pref))
 
     def _step(self, kind, eager, args):
         fused = self.trainer.fused
@@ -192,6 +201,17 @@ class JointStepper(_StepperBase):
         pos, neg, gpos, gneg = self.score[:B], self.score[B:], self.gscore[:B], self.gscore[B:]
         gate, gptr = self._gate_args()
         b = L.bind
+        self.fused_step = self._fused_ok(0, d, n_pref) and self._fused_ok(1, d)
+        if self.fused_step:
+            sq = self.trainer.fused.sumsq_ptr(self.dev)
+            inv = 1.0 / self.world
+            self._rec_fused = b('ktup_train_rec_step', _p(U), U.stride(0), _p(I), I.stride(0), _p(E), E.stride(0), _p(self.i2e), self.ent_pad,
+                                _p(P), _p(Pn), _p(R), _p(Rn), P.stride(0), n_pref, d, _p(self.u2), _p(self.i2), B, self.l1, gate, gptr, 0, 0,
+                                self.target, inv, 1, _p(self.loss), _p(U.grad), _p(I.grad), _p(E.grad), _p(P.grad), _p(Pn.grad),
+                                _p(R.grad), _p(Rn.grad), sq, st)
+            self._kg_fused = b('ktup_train_kg_step', 1, _p(E), E.stride(0), _p(R), R.stride(0), _p(Rn), Rn.stride(0), d, _p(self.h2),
+                               _p(self.t2), _p(self.r2), B, self.l1, self.margin, self.kg_lambda, 7, _p(self.loss), _p(E.grad),
+                               _p(R.grad), _p(Rn.grad), sq, st)
         self._rec_head = [
             b('ktup_pref_prepare', _p(P), _p(Pn), _p(R), _p(Rn), P.stride(0), n_pref, d, _p(self.ws), st)]
         self._rec_soft = [
@@ -225,6 +245,13 @@ class JointStepper(_StepperBase):
         self._plans()
         if u is not None:
             self._pack('rec', (u, pi, ni))
+        if self.fused_step:              # one launch: table mixing, both scores, bprLoss, backward, gradient fan-out, orthogonalLoss
+            self._rec_fused()
+            self._gumbel_advance()
+            if self.world > 1:
+                self.loss[:2].mul_(self.inv_world)
+            self._optimizer_launches(loss=(_p(self.loss), 2, 1.0, _p(self.out['rec'])))
+            return self.out['rec']
         self._rec_head[0]()
         self.gAC.zero_(); self.loss.zero_()
         self._rec_soft[0](); self._rec_loss[0](); self._rec_soft_bwd[0]()
@@ -242,6 +269,10 @@ class JointStepper(_StepperBase):
         self._plans()
         if ph is not None:
             self._pack('kg', (ph, pt, pr, nh, nt, nr))
+        if self.fused_step:              # one launch: both TransH scores, marginLoss, the three regularisers, every gradient
+            self._kg_fused()
+            self._optimizer_launches(loss=(_p(self.loss), 4, self.kg_lambda, _p(self.out['kg'])))
+            return self.out['kg']
         self.loss.zero_()
         for launch in self._kg:
             launch()
@@ -283,6 +314,7 @@ class RecStepper(_StepperBase):
         pos, neg, gpos, gneg = self.score[:B], self.score[B:], self.gscore[:B], self.gscore[B:]
         self._loss = [b('ktup_loss_bpr_fused', _p(pos), _p(neg), B, self.target, _p(self.inv_world), _p(self.loss[0:]), _p(gpos),
                         _p(gneg), st)]
+        self.fused_step = False
         if not self.tup:
             self._fwd = b('ktup_score_bprmf_fwd', _p(U), U.stride(0), _p(I), I.stride(0), d, _p(self.u2), _p(self.i2), 2 * B,
                           _p(self.score), st)
@@ -292,6 +324,12 @@ class RecStepper(_StepperBase):
         P, Pn = self.tabs[2], self.tabs[3]
         n_pref = P.shape[0]
         gate, gptr = self._gate_args()
+        self.fused_step = self._fused_ok(0, d, n_pref)
+        if self.fused_step:
+            self._rec_fused = b('ktup_train_rec_step', _p(U), U.stride(0), _p(I), I.stride(0), None, 0, None, -1, _p(P), _p(Pn), None, None,
+                                P.stride(0), n_pref, d, _p(self.u2), _p(self.i2), B, self.l1, gate, gptr, 0, 0, self.target, 1.0 / self.world,
+                                1, _p(self.loss), _p(U.grad), _p(I.grad), None, _p(P.grad), _p(Pn.grad), None, None,
+                                self.trainer.fused.sumsq_ptr(self.dev), st)
         self._prep = b('ktup_pref_prepare', _p(P), _p(Pn), None, None, P.stride(0), n_pref, d, _p(self.ws), st)
         self._fwd = b('ktup_score_tup_fwd', _p(U), U.stride(0), _p(I), I.stride(0), _p(self.ws), n_pref, d, _p(self.u2), _p(self.i2),
                       2 * B, self.l1, gate, gptr, 0, 0, _p(self.score), st)
@@ -317,6 +355,15 @@ class RecStepper(_StepperBase):
             self._optimizer_launches()
             return self.loss[0] + 0.0
         U, I, P, Pn = self.tabs
+        if self.fused_step:              # scores, bprLoss, backward and orthogonalLoss in one launch; the row regularisers follow
+            self._rec_fused()
+            self._gumbel_advance()
+            for launch in self._regs[1:]:
+                launch()
+            if self.world > 1:
+                self.loss[:2].mul_(self.inv_world); self.loss[4:5].mul_(self.inv_world)
+            self._optimizer_launches(loss=(_p(self.loss), 5, 1.0, _p(self.out['rec'])))
+            return self.out['rec']
         self._prep()
         self.gAC.zero_()
         self._fwd(); self._loss[0](); self._bwd()
@@ -357,6 +404,13 @@ class KGStepper(_StepperBase):
         d = E.shape[1]
         pos, neg, gpos, gneg = self.score[:B], self.score[B:], self.gscore[:B], self.gscore[B:]
         calls = []
+        self.fused_step = (not self.transr) and self._fused_ok(1 if self.transh else 2, d)
+        if self.fused_step:
+            Rn_ = self.tabs[2] if self.transh else None
+            self._kg_fused = b('ktup_train_kg_step', int(self.transh), _p(E), E.stride(0), _p(R), R.stride(0), _p(Rn_),
+                               Rn_.stride(0) if self.transh else 0, d, _p(self.h2), _p(self.t2), _p(self.r2), B, self.l1, self.margin, 1.0,
+                               7 if self.transh else 6, _p(self.loss), _p(E.grad), _p(R.grad), _p(Rn_.grad) if self.transh else None,
+                               self.trainer.fused.sumsq_ptr(self.dev), st)
         if self.transh:
             Rn = self.tabs[2]
             n_rel = min(R.shape[0], Rn.shape[0])
@@ -389,6 +443,10 @@ class KGStepper(_StepperBase):
         self._plans()
         if ph is not None:
             self._pack('kg', (ph, pt, pr, nh, nt, nr))
+        if self.fused_step:
+            self._kg_fused()
+            self._optimizer_launches(loss=(_p(self.loss), 4, 1.0, _p(self.out['kg'])))
+            return self.out['kg']
         self.loss.zero_()
         for launch in self._calls:
             launch()

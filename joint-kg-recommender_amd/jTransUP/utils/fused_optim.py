@@ -92,10 +92,17 @@ class FusedOptimizer(object):
             s1, s2 = st['square_avg'], st.get('momentum_buffer')
         return s1, s2, first
 
+    def sumsq_ptr(self, dev):
+        """Device double the gradient norm accumulates into; the fused step kernels zero it for the launch that follows."""
+        if self._sumsq is None or self._sumsq.device != dev:
+            self._sumsq = torch.zeros(1, dtype=torch.float64, device=dev)
+        return self._sumsq.data_ptr()
+
     @torch.no_grad()
-    def clip_and_step(self, max_norm, zero_grads=False):
+    def clip_and_step(self, max_norm, zero_grads=False, loss=None):
         """`zero_grads`: leave the gradients zero-filled (the next step's zero_grad folded into this pass) instead of
-        clipped in place."""
+        clipped in place.  `loss` = (slots_ptr, n_slots, scale, out_ptr): the fused training step's loss slots are folded into
+        *out and cleared by the norm launch, whose accumulator the step kernel already zeroed (ktup_optim_gradnorm_loss)."""
         self._flush_steps()
         group = self.optimizer.param_groups[0]
         ps = [p for p in group['params'] if p.grad is not None]
@@ -124,10 +131,14 @@ class FusedOptimizer(object):
             self._dev_steps.add_(1)
             steps_dev = self._dev_steps.data_ptr()
         sumsq = None
-        if max_norm is not None and max_norm > 0:
-            if self._sumsq is None or self._sumsq.device != dev:
-                self._sumsq = torch.zeros(1, dtype=torch.float64, device=dev)
-            sumsq = self._sumsq.data_ptr()
+        clip = max_norm is not None and max_norm > 0
+        if loss is not None:
+            sumsq = self.sumsq_ptr(dev)
+            L.call('ktup_optim_gradnorm_loss', n, grads, sizes, sumsq, loss[0], int(loss[1]), float(loss[2]), loss[3], stream)
+            if not clip:
+                sumsq = None
+        elif clip:
+            sumsq = self.sumsq_ptr(dev)
             L.call('ktup_optim_gradnorm', n, grads, sizes, sumsq, stream)
         betas = group.get('betas', (0.9, 0.999))
         L.call('ktup_optim_step', self.kind, n, params, grads, s1, s2, sizes, _arr(ctypes.c_int64, steps), steps_dev,

@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 DEV = torch.device('cuda', 0)
 
 
-def build(tmp_path, optimizer, gumbel):
+def build(tmp_path, optimizer, gumbel, D=36):
     from jTransUP.models import jTransUP as jt
     from jTransUP.models.base import get_flags
     from jTransUP.utils.flags import FLAGS
@@ -19,7 +19,7 @@ def build(tmp_path, optimizer, gumbel):
     FLAGS(['prog', '-model_type', 'jtransup', '-noshare_embeddings', '-log_path', str(tmp_path), '-experiment_name', 'ft',
            '-optimizer_type', optimizer, '-learning_rate', '0.05', '-kg_lambda', '0.5'])
     FLAGS.ckpt_path = str(tmp_path)
-    NU, NI, NE, NR, D = 50, 40, 70, 6, 36
+    NU, NI, NE, NR = 50, 40, 70, 6
     i_map = {i: i for i in range(NI)}
     new_map = {i: ((i * 3) % NE if i % 5 else -1, i) for i in range(NI)}
     torch.manual_seed(4)
@@ -27,12 +27,14 @@ def build(tmp_path, optimizer, gumbel):
     return FLAGS, m, ModelTrainer(m, logging.getLogger('ft'), 10, FLAGS), (NU, NI, NE, NR)
 
 
+@pytest.mark.parametrize('D', [36, 100, 64])
 @pytest.mark.parametrize('optimizer', ['Adagrad', 'SGD', 'Adam'])
-def test_fast_steps_match_the_autograd_route(tmp_path, optimizer):
+def test_fast_steps_match_the_autograd_route(tmp_path, optimizer, D):
+    """D = 36 runs the multi-launch step (no fused rec kernel for that width), D = 100 / 64 the three-launch fused step."""
     from jTransUP.utils import loss
     from jTransUP.utils.fast_train import JointStepper
-    FLAGS, m1, tr1, (NU, NI, NE, NR) = build(tmp_path, optimizer, False)
-    _, m2, tr2, _ = build(tmp_path, optimizer, False)
+    FLAGS, m1, tr1, (NU, NI, NE, NR) = build(tmp_path, optimizer, False, D)
+    _, m2, tr2, _ = build(tmp_path, optimizer, False, D)
     m2.load_state_dict(copy.deepcopy(m1.state_dict()))
     B = 64
     fast = JointStepper(m2, tr2, FLAGS, B)
@@ -74,18 +76,19 @@ def test_fast_steps_match_the_autograd_route(tmp_path, optimizer):
             assert float(bad.float().mean()) <= (2e-2 if optimizer == 'Adam' else 2e-3) and float(err.max()) <= 1e-3 * 0.05, \
                 '%s after step %d: %d elements off, max %.3g' % (k, step, int(bad.sum()), float(err.max()))
     assert fast._graphs                      # every optimizer kind replays from graphs (Adam: device-resident step counts)
+    assert fast.fused_step == (D != 36)
     # the pad entity row never moves
     assert float(m2.ent_embeddings.weight[m2.ent_total - 1].abs().sum()) == 0.0
 
 
-def _dp_worker(rank, world, port, tmp, out):
+def _dp_worker(rank, world, port, tmp, out, D):
     import os
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group('gloo', rank=rank, world_size=world)     # both ranks share the one GPU: RCCL refuses that, gloo does not
     try:
         from jTransUP.utils.fast_train import JointStepper
-        FLAGS, m, tr, (NU, NI, NE, NR) = build(os.path.join(tmp, 'r%d' % rank), 'Adagrad', False)
+        FLAGS, m, tr, (NU, NI, NE, NR) = build(os.path.join(tmp, 'r%d' % rank), 'Adagrad', False, D)
         B = 64
         fast = JointStepper(m, tr, FLAGS, B)
         assert fast.world == world and fast.B == B // world
@@ -103,8 +106,10 @@ def _dp_worker(rank, world, port, tmp, out):
         dist.destroy_process_group()
 
 
-def test_data_parallel_steps_match_one_process(tmp_path):
-    """Two replicas (gloo, sharing this box's GPU) on halves of each global batch == one process on the whole batch."""
+@pytest.mark.parametrize('D', [36, 64])
+def test_data_parallel_steps_match_one_process(tmp_path, D):
+    """Two replicas (gloo, sharing this box's GPU) on halves of each global batch == one process on the whole batch
+    (D = 64: the fused three-launch step on both sides)."""
     import os
     import socket
     import torch.multiprocessing as mp
@@ -112,8 +117,8 @@ def test_data_parallel_steps_match_one_process(tmp_path):
     for r in range(2):
         os.makedirs(os.path.join(str(tmp_path), 'r%d' % r))
     s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
-    mp.spawn(_dp_worker, args=(2, port, str(tmp_path), str(tmp_path)), nprocs=2, join=True)
-    FLAGS, m, tr, (NU, NI, NE, NR) = build(tmp_path, 'Adagrad', False)
+    mp.spawn(_dp_worker, args=(2, port, str(tmp_path), str(tmp_path), D), nprocs=2, join=True)
+    FLAGS, m, tr, (NU, NI, NE, NR) = build(tmp_path, 'Adagrad', False, D)
     B = 64
     fast = JointStepper(m, tr, FLAGS, B)
     gen = torch.Generator().manual_seed(9)
@@ -154,13 +159,15 @@ def _assert_tables_close(m1, m2, step):
             '%s after step %d: %d elements off, max %.3g' % (k, step, int(bad.sum()), float(err.max()))
 
 
+@pytest.mark.parametrize('D', [36, 64])
 @pytest.mark.parametrize('model_type', ['transup', 'bprmf'])
-def test_rec_stepper_matches_the_autograd_route(tmp_path, model_type):
-    """item_recommendation.py:160-195 step body vs RecStepper (graph replay kicks in from the third step)."""
+def test_rec_stepper_matches_the_autograd_route(tmp_path, model_type, D):
+    """item_recommendation.py:160-195 step body vs RecStepper (graph replay kicks in from the third step); D = 64: TUP takes the
+    fused rec kernel + its three row regularisers."""
     from jTransUP.models import bprmf, transUP
     from jTransUP.utils import loss
     from jTransUP.utils.fast_train import RecStepper
-    NU, NI, D, B = 50, 40, 36, 64
+    NU, NI, B = 50, 40, 64
     torch.manual_seed(4)
     mk = (lambda: transUP.TransUPModel(False, D, NU, NI, 5, False)) if model_type == 'transup' else (lambda: bprmf.BPRMF(D, NU, NI))
     m1, m2 = mk(), mk()
@@ -184,15 +191,17 @@ def test_rec_stepper_matches_the_autograd_route(tmp_path, model_type):
         torch.testing.assert_close(fast_loss, losses.detach(), rtol=1e-5, atol=1e-6)
         _assert_tables_close(m1, m2, step)
     assert 'rec' in fast._graphs or not fast.use_graphs
+    assert fast.fused_step == (model_type == 'transup' and D == 64)
 
 
+@pytest.mark.parametrize('D', [36, 100])
 @pytest.mark.parametrize('model_type', ['transe', 'transh', 'transr'])
-def test_kg_stepper_matches_the_autograd_route(tmp_path, model_type):
-    """knowledge_representation.py:176-211 step body vs KGStepper."""
+def test_kg_stepper_matches_the_autograd_route(tmp_path, model_type, D):
+    """knowledge_representation.py:176-211 step body vs KGStepper (TransE / TransH: the fused kg kernel at any d % 4 == 0)."""
     from jTransUP.models import transE, transH, transR
     from jTransUP.utils import loss
     from jTransUP.utils.fast_train import KGStepper
-    NE, NR, D, B = 70, 6, 36, 64
+    NE, NR, B = 70, 6, 64
     torch.manual_seed(4)
     mk = {'transh': lambda: transH.TransHModel(True, D, NE, NR), 'transe': lambda: transE.TransEModel(False, D, NE, NR),
           'transr': lambda: transR.TransRModel(False, D, NE, NR)}[model_type]
@@ -217,22 +226,24 @@ def test_kg_stepper_matches_the_autograd_route(tmp_path, model_type):
         fast_loss = fast.kg_step(ph, pt, pr, nh, nt, pr)
         torch.testing.assert_close(fast_loss, losses.detach(), rtol=1e-5, atol=1e-6)
         _assert_tables_close(m1, m2, step)
+    assert fast.fused_step == (model_type != 'transr')
 
 
+@pytest.mark.parametrize('D', [36, 100])
 @pytest.mark.parametrize('kind', ['jtransup', 'transup'])
-def test_hard_gate_steps_replay_as_graphs(tmp_path, kind):
+def test_hard_gate_steps_replay_as_graphs(tmp_path, kind, D):
     """-use_st_gumbel: the Philox stream position lives in device memory, so the step replays as a HIP graph; the replayed
     steps draw the same noise, step for step, as the same launches issued eagerly (use_graphs=False)."""
     from jTransUP.models import transUP
     from jTransUP.utils.fast_train import JointStepper, RecStepper
     B, P = 64, 5
     if kind == 'jtransup':
-        FLAGS, m1, tr1, (NU, NI, NE, NR) = build(tmp_path, 'Adagrad', True)
-        _, m2, tr2, _ = build(tmp_path, 'Adagrad', True)
+        FLAGS, m1, tr1, (NU, NI, NE, NR) = build(tmp_path, 'Adagrad', True, D)
+        _, m2, tr2, _ = build(tmp_path, 'Adagrad', True, D)
         P = NR
         Stepper = JointStepper
     else:
-        NU, NI, D = 50, 40, 36
+        NU, NI = 50, 40
         torch.manual_seed(4)
         m1, m2 = transUP.TransUPModel(False, D, NU, NI, P, True), transUP.TransUPModel(False, D, NU, NI, P, True)
         FLAGS, tr1 = _trainer_for(tmp_path, 'transup', m1)

@@ -99,7 +99,7 @@ def test_config5_step_at_size(tables, zipf):
         torch.testing.assert_close(p.data, p0 - lr * gg / (gg.abs() + eps), rtol=2e-5, atol=2e-6)
 
 
-def _two_rank_worker(rank, world, port):
+def _two_rank_worker(rank, world, port, kind):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group('gloo', rank=rank, world_size=world)      # both ranks share this box's GPU (RCCL refuses that)
@@ -114,12 +114,16 @@ def _two_rank_worker(rank, world, port):
         i2e = torch.randint(0, ne, (ni,), generator=gen)
         batches = [[(torch.randint(0, nu, (b,), generator=gen), torch.randint(0, ni, (b,), generator=gen),
                      torch.randint(0, ni, (b,), generator=gen)) for _ in range(world)] for _ in range(2)]
-        lr, max_norm = 0.05, 0.5
+        # Adagrad's first steps divide by |g| + eps: with the default eps = 1e-10 an element whose gradient is ~1e-10 turns fp32
+        # rounding noise into an O(lr) difference, so the comparison uses eps = 1e-4 (well-conditioned, same code path); plain
+        # SGD (linear in g) is checked with the default settings
+        lr, max_norm = (0.05, 0.5) if kind == 'adagrad' else (40.0, 0.5)
+        eps = 1e-4
         # sharded run
         mk = lambda key, n: parallel.ShardedTable(n, d, rank=rank, world=world, device=dev, init=lambda g: full[key][g].to(dev))
         Ut, It, Et = mk('U', nu), mk('I', ni), mk('E', ne)
         small = [torch.nn.Parameter(t.clone().to(dev)) for t in small0]
-        st = parallel.ShardedStep('adagrad', lr=lr, max_norm=max_norm)
+        st = parallel.ShardedStep(kind, lr=lr, max_norm=max_norm, eps=eps)
         i2e_d = i2e.to(dev)
         for step in batches:
             u, pi, ni_ = (x.to(dev) for x in step[rank])
@@ -132,7 +136,7 @@ def _two_rank_worker(rank, world, port):
             st.apply(replicated=small)
         # dense single-process reference on the concatenated batches: oracle scorer + clip_grad_norm_ + torch.optim.Adagrad (wd 0)
         Wd = [torch.nn.Parameter(full[k].clone()) for k in ('U', 'I', 'E')] + [torch.nn.Parameter(t.clone()) for t in small0]
-        opt = torch.optim.Adagrad(Wd, lr=lr)
+        opt = torch.optim.Adagrad(Wd, lr=lr, eps=eps) if kind == 'adagrad' else torch.optim.SGD(Wd, lr=lr)
         for step in batches:
             opt.zero_grad()
             u = torch.cat([x[0] for x in step]); pi = torch.cat([x[1] for x in step]); ni_ = torch.cat([x[2] for x in step])
@@ -148,11 +152,12 @@ def _two_rank_worker(rank, world, port):
         dist.destroy_process_group()
 
 
-def test_config5_two_ranks_share_the_gpu_with_the_ktup_scorer():
+@pytest.mark.parametrize('kind', ['sgd', 'adagrad'])
+def test_config5_two_ranks_share_the_gpu_with_the_ktup_scorer(kind):
     """Row-sharded tables (row % 2), the d = 256 KTUP scorer on the compact tables, combined id / row / gradient exchanges,
     global clip and row-sparse Adagrad on two ranks == one dense process on the concatenated batch."""
     import socket
     import torch.multiprocessing as mp
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
-    mp.spawn(_two_rank_worker, args=(2, port), nprocs=2, join=True)
+    mp.spawn(_two_rank_worker, args=(2, port, kind), nprocs=2, join=True)

@@ -248,6 +248,16 @@ int ktup_eval_gold_ranks(const float* scores, int64_t lds, int64_t nq, int64_t n
                          const int64_t* filt_off, const int32_t* filt_ids, const int64_t* gold_off,
                          const int32_t* gold_ids, int32_t* ranks, void* stream);
 
+/* ranks over a candidate SHARD (sharded-catalogue evaluation, one shard per GPU): the rank of ktup_eval_gold_ranks is a count, so
+ * it is additive over disjoint shards.  `scores` (nq x n_local) covers candidates [cand_lo, cand_lo + n_local) with GLOBAL ids in
+ * the filter / gold CSR lists; gold_scores[e] = the score of gold entry e (from the shard that owns it).  counts[e] = this shard's
+ * unfiltered non-gold candidates ordered before gold e (same (score, global id) order), or a large negative value when the gold
+ * is itself filtered: rank = all-reduce(sum) of counts, negative -> -1.                                                   */
+int ktup_eval_gold_rank_counts(const float* scores, int64_t lds, int64_t nq, int64_t n_local, int64_t cand_lo,
+                               int descending, const int64_t* filt_off, const int32_t* filt_ids,
+                               const int64_t* gold_off, const int32_t* gold_ids, const float* gold_scores,
+                               int32_t* counts, void* stream);
+
 /* K18b  utils/misc.py:232-248 + utils/evaluation.py:80-110 (ndcg_at_k, method 0): per query (f1, precision, recall,
  * hit, ndcg) as 5 float64 from its ranked id list (`topn` entries, -1 padded as ktup_eval_topk_filtered writes them)
  * and its gold ids (CSR, ASCENDING within a query).  precision divides by the number of valid entries, recall by

@@ -382,6 +382,84 @@ extern "C" int ktup_eval_gold_ranks(const float* scores, int64_t lds, int64_t nq
   return check_launch(name);
 }
 
+// ---------------------------------------------------------------------------------------------- candidate shards
+// The 0-based filtered rank of a gold id is a COUNT (misc.py:134-144: candidates walked before it, skipping filtered ids and
+// other golds), so it is additive over disjoint candidate shards: this kernel counts, for one shard [c_lo, c_lo + n_local) of
+// the catalogue, the unfiltered non-gold candidates ordered before each gold; the all-reduce(sum) of the shards' counts is the
+// rank.  The gold's own score comes from the shard that owns it (gold_scores, exchanged by the caller).  Keys use GLOBAL ids, so
+// ties break exactly as in the single-device kernels.  A gold that is itself filtered gets FILTERED_GOLD (negative on every
+// shard, so the sum stays negative -> rank -1).
+constexpr int32_t FILTERED_GOLD = -(1 << 20);
+
+__global__ __launch_bounds__(256) void gold_rank_counts_kernel(const float* __restrict__ scores, int64_t lds, int64_t n_local, int64_t c_lo,
+                                                               int descending, const int64_t* __restrict__ filt_off,
+                                                               const int32_t* __restrict__ filt_ids,
+                                                               const int64_t* __restrict__ gold_off,
+                                                               const int32_t* __restrict__ gold_ids,
+                                                               const float* __restrict__ gold_scores, int CH,
+                                                               int32_t* __restrict__ counts) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint64_t* keys = reinterpret_cast<uint64_t*>(smem);
+  __shared__ int red[4];
+  const int64_t b = blockIdx.x;
+  const float* row = scores + b * lds;
+  const int32_t* fids = filt_ids + (filt_off ? filt_off[b] : 0);
+  const int64_t nf = filt_off ? filt_off[b + 1] - filt_off[b] : 0;
+  const int64_t g0 = gold_off[b], g1 = gold_off[b + 1];
+  for (int64_t gi = g0 + threadIdx.x; gi < g1; gi += 256) {            // filtered golds (every shard sees the whole filter list)
+    const int32_t g = gold_ids[gi];
+    int32_t v = 0;
+    for (int64_t f = 0; f < nf; ++f) if (fids[f] == g) { v = FILTERED_GOLD; break; }
+    counts[gi] = v;
+  }
+  for (int64_t c0 = 0; c0 < n_local; c0 += CH) {
+    const int len = (int)min((int64_t)CH, n_local - c0);
+    __syncthreads();
+    for (int j = threadIdx.x; j < len; j += 256) keys[j] = make_key(row[c0 + j], descending != 0, (uint32_t)(c_lo + c0 + j));
+    __syncthreads();
+    for (int64_t f = threadIdx.x; f < nf; f += 256) {                  // filtered candidates and the golds themselves do not count
+      const int64_t id = (int64_t)fids[f] - c_lo - c0;
+      if (id >= 0 && id < len) keys[id] = KEY_MAX;
+    }
+    for (int64_t o = g0 + threadIdx.x; o < g1; o += 256) {
+      const int64_t id = (int64_t)gold_ids[o] - c_lo - c0;
+      if (id >= 0 && id < len) keys[id] = KEY_MAX;
+    }
+    __syncthreads();
+    for (int64_t gi = g0; gi < g1; ++gi) {
+      const uint64_t gk = make_key(gold_scores[gi], descending != 0, (uint32_t)gold_ids[gi]);
+      int cnt = 0;
+      for (int j = threadIdx.x; j < len; j += 256) cnt += keys[j] < gk ? 1 : 0;
+      cnt = wave_sum_int(cnt);
+      if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = cnt;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        const int32_t have = counts[gi];
+        if (have >= 0) counts[gi] = have + red[0] + red[1] + red[2] + red[3];
+      }
+      __syncthreads();
+    }
+  }
+}
+
+extern "C" int ktup_eval_gold_rank_counts(const float* scores, int64_t lds, int64_t nq, int64_t n_local, int64_t cand_lo,
+                                          int descending, const int64_t* filt_off, const int32_t* filt_ids,
+                                          const int64_t* gold_off, const int32_t* gold_ids, const float* gold_scores,
+                                          int32_t* counts, void* stream) {
+  const char* name = "ktup_eval_gold_rank_counts";
+  KTUP_REQUIRE(nq >= 0 && n_local >= 0 && cand_lo >= 0 && (n_local == 0 || lds >= n_local), "%s: bad sizes", name);
+  if (nq == 0) return KTUP_OK;
+  KTUP_REQUIRE((scores || n_local == 0) && gold_off && gold_ids && gold_scores && counts && ((filt_off == nullptr) || filt_ids),
+               "%s: null pointer argument", name);
+  KTUP_REQUIRE(cand_lo + n_local <= 0x7fffffffll, "%s: candidate ids are 32-bit", name);
+  const int ch = (int)(n_local < 1 ? 64 : (n_local < CHUNK_KEYS ? ((n_local + 63) & ~63ll) : CHUNK_KEYS));
+  const size_t lbytes = (size_t)ch * 8;
+  allow_lds((const void*)gold_rank_counts_kernel, lbytes);
+  hipLaunchKernelGGL(gold_rank_counts_kernel, dim3((unsigned)nq), dim3(256), lbytes, (hipStream_t)stream, scores, lds, n_local, cand_lo,
+                     descending, filt_off, filt_ids, gold_off, gold_ids, gold_scores, ch, counts);
+  return check_launch(name);
+}
+
 extern "C" int ktup_eval_rec_metrics(const int32_t* top_ids, int64_t nq, int topn, const int64_t* gold_off,
                                      const int32_t* gold_ids, double* out, void* stream) {
   const char* name = "ktup_eval_rec_metrics";

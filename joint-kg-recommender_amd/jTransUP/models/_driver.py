@@ -114,11 +114,62 @@ def _gather_batches(per_batch, n_batches, world):
     return [merged[b] for b in range(n_batches)]
 
 
-def rec_eval_pass(FLAGS, score_fn, eval_iter, eval_dict, all_dicts, descending, want_rows=True):
+def _shard_mode(FLAGS, shard, want_rows):
+    """Candidate-sharded evaluation applies under torchrun with -shard_eval_candidates, for models with a sliceable candidate
+    table, on the training-time path (metric columns only; the per-user report rows keep the whole-batch route)."""
+    return shard is not None and not want_rows and getattr(FLAGS, 'shard_eval_candidates', False) \
+        and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def _rec_eval_sharded(FLAGS, shard, eval_iter, index, descending):
+    """rec_eval_pass with the catalogue split over the ranks: every rank walks ALL batches, scores its candidate slice, and the
+    filtered top-n lists are merged (parallel.sharded_topk); the metric columns are then identical on every rank."""
+    from jTransUP import parallel
+    from jTransUP.hip import ops
+    n_cand, fn = shard
+    lo, hi = parallel.shard_bounds(n_cand, dist.get_rank(), dist.get_world_size())
+    cols = []
+    for u_ids in eval_iter:
+        s, e = index.rows_of(u_ids)
+        f_off, f_ids = index.filter_slice(s, e)
+        top, _ = parallel.sharded_topk(fn(batch_ids(u_ids), lo, hi), lo, FLAGS.topn, descending, f_off, f_ids)
+        g_off, g_ids = index.gold_slice(s, e)[:2]
+        cols.append(ops.rec_metrics(top.to(torch.int32).contiguous(), g_off, g_ids))
+    host = torch.cat(cols).cpu().numpy() if cols else np.zeros((0, 5))
+    keep = np.concatenate([index.present_h[slice(*index.rows_of(b))] for b in eval_iter]) if cols else np.zeros(0, bool)
+    return host[keep]
+
+
+def _kg_eval_sharded(FLAGS, shard, eval_iter, index, descending, remap):
+    """kg_eval_pass with the entity catalogue split over the ranks: per-shard rank counts, all-reduced (parallel.sharded_gold_ranks)."""
+    from jTransUP import parallel
+    n_cand, fn = shard
+    lo, hi = parallel.shard_bounds(n_cand, dist.get_rank(), dist.get_world_size())
+    out = []
+    for batch in eval_iter:
+        q = ids([k[0] if remap is None else remap[k[0]] for k in batch])
+        r = ids([k[1] for k in batch])
+        keys = [tuple(k) for k in batch]
+        s, e = index.rows_of(keys)
+        f_off, f_ids = index.filter_slice(s, e)
+        g_off, g_ids, g_off_h, _ = index.gold_slice(s, e)
+        n = int(g_off_h[-1])
+        if n == 0:
+            continue
+        g_rows = torch.repeat_interleave(torch.arange(len(keys), device=DEV), (g_off[1:] - g_off[:-1]))
+        out.append(parallel.sharded_gold_ranks(fn(q, r, lo, hi), lo, descending, g_off, g_ids, g_rows, f_off, f_ids))
+    ranks = torch.cat(out).cpu().numpy() if out else np.zeros(0, np.int32)
+    ranks = ranks[ranks >= 0]
+    return np.stack([(ranks < FLAGS.topn).astype(np.float64), ranks.astype(np.float64)], axis=1)
+
+
+def rec_eval_pass(FLAGS, score_fn, eval_iter, eval_dict, all_dicts, descending, want_rows=True, shard=None):
     """One pass over the evaluation users: all-item scores, filtered top-n, metric rows (misc.py:148-248 semantics).
     want_rows=False returns the (n x 5) metric array only (no per-user report rows).  Under torchrun the batches are
     dealt round-robin to the ranks and the results gathered, so every rank reports the same numbers."""
     index = rank_index(eval_iter, eval_dict, all_dicts)
+    if _shard_mode(FLAGS, shard, want_rows):
+        return _rec_eval_sharded(FLAGS, shard, eval_iter, index, descending)
     mine, world = _my_batches(len(eval_iter))
     per_batch = {}
     pbar = tqdm(total=len(mine), desc='Run Eval')
@@ -143,11 +194,13 @@ def rec_eval_pass(FLAGS, score_fn, eval_iter, eval_dict, all_dicts, descending, 
     return np.concatenate(parts, axis=0) if parts else np.zeros((0, 5))
 
 
-def kg_eval_pass(FLAGS, score_fn, eval_iter, eval_dict, all_dicts, descending, remap=None, want_rows=True):
+def kg_eval_pass(FLAGS, score_fn, eval_iter, eval_dict, all_dicts, descending, remap=None, want_rows=True, shard=None):
     """One pass over (t, r) or (h, r) keys: all-entity scores, filtered gold ranks (misc.py:61-146 semantics); batches are
     dealt to the ranks like in rec_eval_pass.  want_rows=False returns the (n x 2) array of (hit, rank) only: the ranks stay
     on the device until ONE copy back at the end of the pass."""
     index = rank_index(eval_iter, eval_dict, all_dicts)
+    if _shard_mode(FLAGS, shard, want_rows):
+        return _kg_eval_sharded(FLAGS, shard, eval_iter, index, descending, remap)
     mine, world = _my_batches(len(eval_iter))
     per_batch = {}
     pbar = tqdm(total=len(mine), desc='Run Eval')

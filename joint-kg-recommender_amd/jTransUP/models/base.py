@@ -54,6 +54,8 @@ FLAG_TABLE = [
     ('max_queue', 'int', 10, 'accepted for compatibility: no worker processes here'),
     # this build
     ('device_sampling', 'bool', True, 'keep training data and negative sampling on the GPU (K19); -nodevice_sampling runs the python samplers'),
+    ('shard_eval_candidates', 'bool', False, 'torchrun only: every rank scores its slice of the item / entity catalogue for ALL queries '
+                                             '(top-n lists merged, KG rank counts all-reduced) instead of whole batches being dealt to the ranks'),
     # files
     ('data_path', 'str', None, 'root of the datasets'),
     ('log_path', 'str', None, 'logs (and, by default, checkpoints)'),

@@ -23,7 +23,9 @@ def evaluate(FLAGS, model, eval_iter, eval_dict, all_dicts, logger, eval_descend
     if hasattr(model, 'prepare_items'):            # TUP: the item side of the gate once per pass (weights are frozen here)
         items = model.prepare_items()
         score_fn = lambda u: model.evaluate(u, items=items)
-    results = D.rec_eval_pass(FLAGS, score_fn, eval_iter, eval_dict, all_dicts, eval_descending, want_rows=is_report)
+    from jTransUP.models._shard_eval import rec_shard_fn
+    results = D.rec_eval_pass(FLAGS, score_fn, eval_iter, eval_dict, all_dicts, eval_descending, want_rows=is_report,
+                              shard=rec_shard_fn(model))
     perf = D.summarize_rec(FLAGS, results, logger)
     if is_report:
         D.report_rec(FLAGS, model, results, all_dicts, eval_dict, logger, FLAGS.model_type in ('transup', 'jtransup', 'cjtransup'))

@@ -49,7 +49,9 @@ def evaluateRec(FLAGS, model, eval_iter, eval_dict, all_dicts, i_map, logger, ev
     items = model.prepare_items(all_i_var) if hasattr(model, 'prepare_items') else None     # item side once per pass
     score_fn = (lambda u: model.evaluateRec(u, all_i_ids=all_i_var, items=items)) if items is not None \
         else (lambda u: model.evaluateRec(u, all_i_ids=all_i_var))
-    results = D.rec_eval_pass(FLAGS, score_fn, eval_iter, eval_dict, all_dicts, eval_descending, want_rows=is_report)
+    from jTransUP.models._shard_eval import rec_shard_fn
+    results = D.rec_eval_pass(FLAGS, score_fn, eval_iter, eval_dict, all_dicts, eval_descending, want_rows=is_report,
+                              shard=rec_shard_fn(model))
     perf = D.summarize_rec(FLAGS, results, logger)
     if is_report:
         D.report_rec(FLAGS, model, results, all_dicts, eval_dict, logger, FLAGS.model_type in ('transup', 'jtransup'))
@@ -62,10 +64,11 @@ def evaluateKG(FLAGS, model, eval_head_iter, eval_tail_iter, eval_head_dict, eva
     model.eval(); model.disable_grad()
     all_e_var = D.ids([e_map[e] for e in range(len(e_map))]) if FLAGS.share_embeddings else None
     remap = None if FLAGS.share_embeddings else e_map      # :125,140 (identity for id-ordered map files)
+    from jTransUP.models._shard_eval import kg_shard_fn
     head_results = D.kg_eval_pass(FLAGS, lambda t, r: model.evaluateHead(t, r, all_e_ids=all_e_var), eval_head_iter, eval_head_dict,
-                                  all_head_dicts, eval_descending, remap=remap, want_rows=is_report)
+                                  all_head_dicts, eval_descending, remap=remap, want_rows=is_report, shard=kg_shard_fn(model, True))
     tail_results = D.kg_eval_pass(FLAGS, lambda h, r: model.evaluateTail(h, r, all_e_ids=all_e_var), eval_tail_iter, eval_tail_dict,
-                                  all_tail_dicts, eval_descending, remap=remap, want_rows=is_report)
+                                  all_tail_dicts, eval_descending, remap=remap, want_rows=is_report, shard=kg_shard_fn(model, False))
     perf = D.summarize_kg(FLAGS, head_results, tail_results, logger)
     if is_report:
         D.report_kg(head_results, tail_results, logger)

@@ -20,10 +20,11 @@ FLAGS = gflags.FLAGS
 def evaluate(FLAGS, model, entity_total, relation_total, eval_head_iter, eval_tail_iter, eval_head_dict, eval_tail_dict,
              all_head_dicts, all_tail_dicts, logger, eval_descending=True, is_report=False):
     model.eval(); model.disable_grad()
+    from jTransUP.models._shard_eval import kg_shard_fn
     head_results = D.kg_eval_pass(FLAGS, model.evaluateHead, eval_head_iter, eval_head_dict, all_head_dicts, eval_descending,
-                                  want_rows=is_report)
+                                  want_rows=is_report, shard=kg_shard_fn(model, True))
     tail_results = D.kg_eval_pass(FLAGS, model.evaluateTail, eval_tail_iter, eval_tail_dict, all_tail_dicts, eval_descending,
-                                  want_rows=is_report)
+                                  want_rows=is_report, shard=kg_shard_fn(model, False))
     perf = D.summarize_kg(FLAGS, head_results, tail_results, logger)
     if is_report:
         D.report_kg(head_results, tail_results, logger)

@@ -424,11 +424,13 @@ def merge_topk(local_ids, local_scores, topn, descending=False, group=None):
     Order: ascending score (descending=True negates), ties -> lower id: the same total order the ranking kernel uses."""
     world = _world(group)
     if world > 1:
-        ids_all = [torch.empty_like(local_ids) for _ in range(world)]
-        sc_all = [torch.empty_like(local_scores) for _ in range(world)]
-        dist.all_gather(ids_all, local_ids.contiguous(), group=group)
-        dist.all_gather(sc_all, local_scores.contiguous(), group=group)
-        ids, sc = torch.cat(ids_all, 1), torch.cat(sc_all, 1)
+        stage = local_ids.is_cuda and dist.get_backend(group) == 'gloo'      # gloo test hook: no device all-gather there
+        src_i, src_s = (local_ids.cpu(), local_scores.cpu()) if stage else (local_ids.contiguous(), local_scores.contiguous())
+        ids_all = [torch.empty_like(src_i) for _ in range(world)]
+        sc_all = [torch.empty_like(src_s) for _ in range(world)]
+        dist.all_gather(ids_all, src_i, group=group)
+        dist.all_gather(sc_all, src_s, group=group)
+        ids, sc = torch.cat(ids_all, 1).to(local_ids.device), torch.cat(sc_all, 1).to(local_ids.device)
     else:
         ids, sc = local_ids, local_scores
     key = -sc if descending else sc.clone()
@@ -441,3 +443,63 @@ def merge_topk(local_ids, local_scores, topn, descending=False, group=None):
     o2 = torch.argsort(key1, dim=1, stable=True)
     order = torch.gather(o1, 1, o2)[:, :topn]
     return torch.gather(ids, 1, order), torch.gather(sc, 1, order)
+
+
+def _local_topk_hip(local_scores, descending, topn, f_off, f_ids_local):
+    from jTransUP.hip import ops
+    return ops.topk_filtered(local_scores, descending, topn, f_off, f_ids_local, with_scores=True)
+
+
+def _local_counts_hip(local_scores, lo, descending, g_off, g_ids, gold_scores, f_off, f_ids):
+    from jTransUP.hip import ops
+    return ops.gold_rank_counts(local_scores, lo, descending, g_off, g_ids, gold_scores, f_off, f_ids)
+
+
+@torch.no_grad()
+def sharded_topk(local_scores, lo, topn, descending, f_off=None, f_ids=None, group=None, local_topk=None):
+    """Filtered top-n of a catalogue sharded over the ranks (utils/misc.py:213-248 on the union of the shards).
+    local_scores: (nq, n_local) scores of candidates [lo, lo + n_local); f_off / f_ids: the filter sets as CSR with GLOBAL
+    candidate ids (ids outside the shard are ignored by the ranking kernel).  Every rank returns the same (nq, topn) global ids
+    (-1 padded) and scores: local filtered top-n -> all-gather of (score, id) -> merge under the same (score, id) order."""
+    local_topk = local_topk or _local_topk_hip
+    if local_scores.shape[1] == 0:
+        ids = torch.full((local_scores.shape[0], topn), -1, dtype=torch.int32, device=local_scores.device)
+        sc = torch.zeros(local_scores.shape[0], topn, dtype=torch.float32, device=local_scores.device)
+    else:
+        fl = None if f_ids is None else (f_ids.to(torch.int64) - lo).to(torch.int32)
+        ids, sc = local_topk(local_scores, descending, topn, f_off, fl)
+        ids = torch.where(ids >= 0, ids + int(lo), ids)
+    return merge_topk(ids, sc, topn, descending=descending, group=group)
+
+
+@torch.no_grad()
+def sharded_gold_ranks(local_scores, lo, descending, g_off, g_ids, g_rows, f_off=None, f_ids=None, group=None, local_counts=None):
+    """0-based filtered ranks of the gold ids (utils/misc.py:125-146) when every rank holds the scores of one candidate shard
+    [lo, lo + n_local).  g_off / g_ids: gold CSR (global ids), g_rows: the query row of every gold entry (int64, len(g_ids));
+    -> int32 ranks per gold entry on every rank (-1: the gold is itself filtered).  Two small collectives: the golds' own
+    scores from their owners (all-reduce of a vector that is zero elsewhere), then the additive per-shard counts."""
+    local_counts = local_counts or _local_counts_hip
+    n_local = local_scores.shape[1]
+    n = g_rows.numel()
+    col = g_ids[:n].to(torch.int64) - lo
+    mine = (col >= 0) & (col < n_local)
+    gold_scores = torch.zeros(n, dtype=torch.float32, device=local_scores.device)
+    if n_local and bool(n):
+        picked = local_scores[g_rows[mine], col[mine]]
+        gold_scores[mine] = picked
+    if _world(group) > 1:
+        _all_reduce(gold_scores, group)
+    counts = local_counts(local_scores, lo, descending, g_off, g_ids, gold_scores, f_off, f_ids)[:n].clone()
+    if _world(group) > 1:
+        _all_reduce(counts, group)
+    return torch.where(counts < 0, torch.full_like(counts, -1), counts)
+
+
+def _all_reduce(t, group):
+    """all_reduce(sum); under the gloo test hook device tensors are staged through the host."""
+    if t.is_cuda and dist.get_backend(group) == 'gloo':
+        host = t.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(host)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)

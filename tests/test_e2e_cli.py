@@ -111,6 +111,32 @@ def test_joint_cli_data_parallel_torchrun(dataset):
     assert re.findall(r'rec train loss:\d+\.\d+, kg train loss:\d+\.\d+', log0) == re.findall(r'rec train loss:\d+\.\d+, kg train loss:\d+\.\d+', log1)
 
 
+def test_joint_cli_sharded_candidate_evaluation(dataset):
+    """-shard_eval_candidates under torchrun: every rank scores its slice of the item / entity catalogue for all queries, top-n
+    lists are merged and KG rank counts all-reduced -- the logged metrics equal those of the run that deals whole batches."""
+    data = str(dataset)
+    logs = os.path.join(data, 'log')
+    env = dict(os.environ, KTUP_DIST_BACKEND='gloo')
+    lines = {}
+    for name, flag, port in (('ktup-whole', [], '29535'), ('ktup-shard', ['-shard_eval_candidates'], '29536')):
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+               '--master-port', port, os.path.join(PKG, 'run_knowledgable_recommendation.py'), '-data_path', data, '-log_path', logs,
+               '-dataset', 'ml1m', '-experiment_name', name, '-nohas_visualization', '-batch_size', '32', '-embedding_size', '20',
+               '-seed', '3', '-eval_interval_steps', '10', '-training_steps', '15', '-early_stopping_steps_to_wait', '0',
+               '-learning_rate', '0.05', '-topn', '10', '-model_type', 'jtransup', '-rec_test_files', 'valid.dat', '-kg_test_files',
+               'valid.dat', '-joint_ratio', '0.7', '-noshare_embeddings'] + flag
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+        per_rank = []
+        for suffix in ('', '.rank1'):
+            log = open(os.path.join(logs, name + suffix + '.log')).read()
+            per_rank.append((re.findall(r'f1:\d\.\d+, p:\d\.\d+, r:\d\.\d+, hit:\d\.\d+, ndcg:\d\.\d+', log),
+                             re.findall(r'avg hit:\d\.\d+, avg mean rank:\d+\.\d+', log), re.findall(r'avg mrr:\d\.\d+', log)))
+        assert per_rank[0] == per_rank[1] and len(per_rank[0][0]) >= 2 and len(per_rank[0][1]) >= 2
+        lines[name] = per_rank[0]
+    assert lines['ktup-whole'] == lines['ktup-shard']
+
+
 @pytest.mark.parametrize('script,extra,metric', [
     ('run_item_recommendation.py', ['-model_type', 'transup', '-num_preferences', '6', '-rec_test_files', 'valid.dat'], r'f1:\d\.\d+'),
     ('run_knowledge_representation.py', ['-model_type', 'transh', '-kg_test_files', 'valid.dat'], r'avg hit:'),

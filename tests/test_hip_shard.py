@@ -109,3 +109,31 @@ def test_sharded_step_two_ranks_share_the_gpu():
     import torch.multiprocessing as mp
     s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
     mp.spawn(_two_rank_worker, args=(2, port), nprocs=2, join=True)
+
+
+def _shard_eval_worker(rank, world, port):
+    import os
+    import sys
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import _shard_eval_case as C
+        C.run(rank, world, DEV)                       # the HIP local kernels: ktup_eval_topk_filtered, ktup_eval_gold_rank_counts
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_candidate_evaluation_two_ranks_share_the_gpu():
+    """Catalogue split over two ranks: per-shard filtered top-n (K17) + merge and per-shard rank counts (ktup_eval_gold_rank_counts)
+    + all-reduce reproduce the reference's golden ranked lists / ranks and a seeded tie-heavy case; also as one shard."""
+    import os
+    import socket
+    import sys
+    import torch.multiprocessing as mp
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import _shard_eval_case as C
+    C.run(0, 1, DEV)
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_shard_eval_worker, args=(2, port), nprocs=2, join=True)

@@ -138,7 +138,14 @@ def _merge_worker(rank, world):
     assert got_ids[0].tolist() == pool
 
 
-@pytest.mark.parametrize('worker', [_replica_worker, _sharded_worker, _sharded_step_worker, _merge_worker])
+def _shard_eval_worker(rank, world):
+    """Sharded-candidate evaluation: per-shard filtered top-n + merge, additive KG rank counts + all-reduce, against
+    the reference's golden ranked lists / ranks and a seeded case with ties (numpy stand-ins for the two local HIP kernels)."""
+    import _shard_eval_case as C
+    C.run(rank, world, 'cpu', local_topk=C.np_local_topk, local_counts=C.np_local_counts)
+
+
+@pytest.mark.parametrize('worker', [_replica_worker, _sharded_worker, _sharded_step_worker, _merge_worker, _shard_eval_worker])
 def test_world_size_2_gloo(worker):
     _spawn(worker)
 
@@ -158,5 +165,7 @@ def test_single_process_paths():
     s = ReplicaGradSync([torch.nn.Parameter(torch.ones(2))])
     assert float(s.scale(torch.tensor(4.0), 'mean')) == 4.0
     check_against_dense('adagrad', 0.1, 0.05, 3, torch.device('cpu'), TorchRowOps, 0, 1)
+    import _shard_eval_case as C                     # one shard = the whole catalogue: same results without a process group
+    C.run(0, 1, 'cpu', local_topk=C.np_local_topk, local_counts=C.np_local_counts)
     with pytest.raises(Exception):                   # the product's default row ops are the HIP kernels: CPU tensors are refused
         ShardedTable(10, 8, rank=0, world=1, init=_init_rows).lookup(ids)

@@ -12,8 +12,8 @@ from jTransUP.utils import flags as gflags
 
 # -model_type -> module under jTransUP.models that provides build_model(...)
 ACCELERATED = {'transup': 'transUP', 'bprmf': 'bprmf', 'transe': 'transE', 'transh': 'transH', 'transr': 'transR',
-               'jtransup': 'jTransUP'}
-REFERENCE_ONLY = ('fm', 'transd', 'cfkg', 'cke', 'cofm')      # baselines of the reference outside the accelerated path
+               'jtransup': 'jTransUP', 'cke': 'CKE', 'cfkg': 'CFKG'}
+REFERENCE_ONLY = ('fm', 'transd', 'cofm')      # baselines of the reference outside the accelerated path (FM-family: no kernel here)
 MODEL_TYPES = ['transup', 'bprmf', 'fm', 'transe', 'transh', 'transr', 'transd', 'cfkg', 'cke', 'cofm', 'jtransup']
 DATASETS = ['ml1m', 'dbbook2014', 'amazon-book', 'last-fm', 'yelp2018']
 

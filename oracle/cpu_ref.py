@@ -128,6 +128,28 @@ def score_ktup_rec(U, I, E, P, Pn, R, Rn, item2ent, u, i, l1, uniform=None):
     return _tup_tail(u_e, ie_e, r_e, norm, l1)
 
 
+def score_cke_rec(U, I, E, item2ent, u, i):
+    """CKE.py:122-135 : BPRMF on the user row and (item row + aligned entity row); E has the zero pad row last."""
+    ie = I[i] + E[item2ent[i]]
+    return torch.bmm(U[u].unsqueeze(1), ie.unsqueeze(2)).reshape(-1)
+
+
+def eval_cke_rec(U, I, E, item2ent, u):
+    """CKE.py:142-153 : every item in id order."""
+    return torch.matmul(U[u], (I + E[item2ent]).t())
+
+
+def score_cfkg_rec(U, E, R, u, i, l1):
+    """CFKG.py:66-80 : TransE with the extra last relation ("buy") between a user and the item's entity row."""
+    return _dist(U[u] + R[R.shape[0] - 1].unsqueeze(0) - E[i], l1, 1)
+
+
+def eval_cfkg_rec(U, E, R, u, l1):
+    """CFKG.py:100-118 : (user + buy) against every row of the shared item / entity table."""
+    c = U[u] + R[R.shape[0] - 1].unsqueeze(0)
+    return _dist(c.unsqueeze(1) - E.unsqueeze(0), l1, 2)
+
+
 def score_ktup_kg(E, R, Rn, h, t, r, l1):
     """jTransUP.py:144-157 == TransH on the shared tables."""
     return score_transh(E, R, Rn, h, t, r, l1)

@@ -363,6 +363,111 @@ def eval_cases(i_map, new_map):
         np.argsort = real_argsort
 
 
+def baseline_cases():
+    """CKE (CKE.py: BPRMF on item + aligned entity rows, TransR on the KG) and CFKG (CFKG.py: TransE with an extra "buy"
+    relation between users and item-entities) -- the reference baselines that reuse the accelerated kernels.  Own seeds and an
+    own file, so the earlier fixtures keep their random draws."""
+    from jTransUP.models import CKE as rcke, CFKG as rcfkg
+    rng = np.random.RandomState(23)
+    gen = torch.Generator().manual_seed(29)
+    e_vocab, i_vocab, kg2i, new_map, e_remap, i_remap, n_aligned = make_alignment(rng)
+    i_map = IntKeyDict(i_remap)
+    out = {}
+    BQ = 9
+    for d in (36, 64):
+        u = torch.from_numpy(rng.randint(0, NU, B)).long()
+        pi = torch.from_numpy(rng.randint(0, NI, B)).long(); ni = torch.from_numpy(rng.randint(0, NI, B)).long()
+        ph = torch.from_numpy(rng.randint(0, NE, B)).long(); pt = torch.from_numpy(rng.randint(0, NE, B)).long()
+        pr = torch.from_numpy(rng.randint(0, NR, B)).long()
+        nh = torch.from_numpy(rng.randint(0, NE, B)).long(); nt = torch.from_numpy(rng.randint(0, NE, B)).long()
+        uq = torch.from_numpy(rng.randint(0, NU, BQ)).long(); eq = torch.from_numpy(rng.randint(0, NE, BQ)).long()
+        rq = torch.from_numpy(rng.randint(0, NR, BQ)).long()
+        pre = 'd%d.' % d
+        out.update({pre + k: npy(v) for k, v in dict(u=u, pi=pi, ni=ni, ph=ph, pt=pt, pr=pr, nh=nh, nt=nt, uq=uq, eq=eq, rq=rq).items()})
+        for l1 in (False, True):
+            tag = pre + 'cke.%s.' % ('L1' if l1 else 'L2')
+            m = rcke.CKE(l1, d, NU, NI, NE, NR, i_map, new_map)
+            if not l1:
+                sd = set_weights(m, gen)
+                out.update({pre + 'cke.' + k: v for k, v in sd.items()})
+                keep = {k: p.data.clone() for k, p in m.named_parameters()}
+                out[pre + 'cke.item2ent'] = np.asarray(m.paddingItems(torch.arange(NI), m.ent_total - 1), dtype=np.int64)
+            else:
+                for k, p in m.named_parameters():
+                    p.data.copy_(keep[k])
+            # rec step (knowledgable_recommendation.py:335-342; target -1 for every model but bprmf / fm / cofm, trainer.py:15-17)
+            pos, neg = m((V(u), V(pi)), None, is_rec=True), m((V(u), V(ni)), None, is_rec=True)
+            loss = rloss.bprLoss(pos, neg, target=-1)
+            zero_grads(m); loss.backward()
+            out.update({tag + 'rec.pos': npy(pos), tag + 'rec.neg': npy(neg), tag + 'rec.loss': npy(loss)})
+            out.update({tag + 'rec.' + k: v for k, v in grads_of(m).items() if 'proj' not in k})
+            # kg step (:345-382): margin + normLoss(ent rows) + normLoss(rel rows)
+            pos, neg = m(None, (V(ph), V(pt), V(pr)), is_rec=False), m(None, (V(nh), V(nt), V(pr)), is_rec=False)
+            loss = rloss.marginLoss()(pos, neg, 1.0)
+            loss = loss + rloss.normLoss(m.ent_embeddings(V(torch.cat([ph, pt, nh, nt])))) + rloss.normLoss(m.rel_embeddings(V(torch.cat([pr, pr]))))
+            zero_grads(m); loss.backward()
+            out.update({tag + 'kg.pos': npy(pos), tag + 'kg.neg': npy(neg), tag + 'kg.loss': npy(loss)})
+            out.update({tag + 'kg.' + k: v for k, v in grads_of(m).items()})
+            out[tag + 'evalRec'] = npy(m.evaluateRec(V(uq)))
+            out[tag + 'evalHead'] = npy(m.evaluateHead(V(eq), V(rq)))
+            out[tag + 'evalTail'] = npy(m.evaluateTail(V(eq), V(rq)))
+        for l1 in (False, True):
+            tag = pre + 'cfkg.%s.' % ('L1' if l1 else 'L2')
+            m = rcfkg.CFKG(l1, d, NU, NI, NE, NR)
+            if not l1:
+                sd = set_weights(m, gen)
+                out.update({pre + 'cfkg.' + k: v for k, v in sd.items()})
+                keep = {k: p.data.clone() for k, p in m.named_parameters()}
+            else:
+                for k, p in m.named_parameters():
+                    p.data.copy_(keep[k])
+            pos, neg = m((V(u), V(pi)), None, is_rec=True), m((V(u), V(ni)), None, is_rec=True)   # item ids index the entity table
+            loss = rloss.bprLoss(pos, neg, target=-1)
+            zero_grads(m); loss.backward()
+            out.update({tag + 'rec.pos': npy(pos), tag + 'rec.neg': npy(neg), tag + 'rec.loss': npy(loss)})
+            out.update({tag + 'rec.' + k: v for k, v in grads_of(m).items()})
+            pos, neg = m(None, (V(ph), V(pt), V(pr)), is_rec=False), m(None, (V(nh), V(nt), V(pr)), is_rec=False)
+            loss = rloss.marginLoss()(pos, neg, 1.0)
+            loss = loss + rloss.normLoss(m.ent_embeddings(V(torch.cat([ph, pt, nh, nt])))) + rloss.normLoss(m.rel_embeddings(V(torch.cat([pr, pr]))))
+            zero_grads(m); loss.backward()
+            out.update({tag + 'kg.pos': npy(pos), tag + 'kg.neg': npy(neg), tag + 'kg.loss': npy(loss)})
+            out.update({tag + 'kg.' + k: v for k, v in grads_of(m).items()})
+            out[tag + 'evalRec'] = npy(m.evaluateRec(V(uq)))
+            out[tag + 'evalHead'] = npy(m.evaluateHead(V(eq), V(rq)))
+            out[tag + 'evalTail'] = npy(m.evaluateTail(V(eq), V(rq)))
+    save('baselines', **out)
+
+
+def transr_d256_case():
+    """TransR at config 5's width.  The (relations x d*d) projection table would make the fixture 2 MB per copy, so it is NOT
+    stored: the test re-creates it from the seed below with the same torch CPU generator calls; stored are the small tables, the
+    ids, the scores and the entity / relation gradients, plus per-relation sums and a strided sample of the projection gradient."""
+    d, seed = 256, 4242
+    rng = np.random.RandomState(31)
+    out = {'seed': np.asarray([seed], dtype=np.int64)}
+    ph = torch.from_numpy(rng.randint(0, NE, B)).long(); pt = torch.from_numpy(rng.randint(0, NE, B)).long()
+    pr = torch.from_numpy(rng.randint(0, NR, B)).long()
+    nh = torch.from_numpy(rng.randint(0, NE, B)).long(); nt = torch.from_numpy(rng.randint(0, NE, B)).long()
+    out.update(ph=npy(ph), pt=npy(pt), pr=npy(pr), nh=npy(nh), nt=npy(nt))
+    for l1 in (False, True):
+        tag = 'L1.' if l1 else 'L2.'
+        m = transR.TransRModel(l1, d, NE, NR)
+        g = torch.Generator().manual_seed(seed)                  # the test repeats exactly these three draws
+        m.ent_embeddings.weight.data.copy_(torch.randn(NE, d, generator=g) * 0.3)
+        m.rel_embeddings.weight.data.copy_(torch.randn(NR, d, generator=g) * 0.3)
+        m.proj_embeddings.weight.data.copy_(torch.randn(NR, d * d, generator=g) * 0.06)
+        pos, neg = m(V(ph), V(pt), V(pr)), m(V(nh), V(nt), V(pr))
+        loss = rloss.marginLoss()(pos, neg, 1.0)
+        zero_grads(m); loss.backward()
+        gp = m.proj_embeddings.weight.grad
+        out.update({tag + 'pos': npy(pos), tag + 'neg': npy(neg), tag + 'loss': npy(loss),
+                    tag + 'grad.ent': npy(m.ent_embeddings.weight.grad), tag + 'grad.rel': npy(m.rel_embeddings.weight.grad),
+                    tag + 'grad.proj.rowsum': npy(gp.sum(1)), tag + 'grad.proj.sample': npy(gp[:, ::997])})
+    save('transr_d256', **out)
+
+
 if __name__ == '__main__':
     i_map, new_map = score_cases()
     eval_cases(i_map, new_map)
+    baseline_cases()
+    transr_d256_case()

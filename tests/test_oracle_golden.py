@@ -208,3 +208,50 @@ def test_alignment_and_schedule():
     for ratio, nrec in ((0.5, 5), (0.7, 7), (0.9, 9)):
         assert sum(O.is_rec_step(s, ratio) for s in range(10)) == nrec
         assert [O.is_rec_step(s, ratio) for s in range(10)] == [s < nrec for s in range(10)]
+
+
+@pytest.mark.parametrize('d', [36, 64])
+def test_baselines_cke_cfkg_golden(golden, d):
+    """The oracle's CKE / CFKG restatements (CKE.py:122-203, CFKG.py:66-158) against what the imported reference produced:
+    scores, losses and the all-candidate evaluation matrices."""
+    g = golden('baselines')
+    p = 'd%d.' % d
+    t = lambda k: torch.from_numpy(g[p + k])
+    u, pi, ni, ph, pt, pr, nh, nt, uq, eq, rq = (t(k).long() for k in ('u', 'pi', 'ni', 'ph', 'pt', 'pr', 'nh', 'nt', 'uq', 'eq', 'rq'))
+    for l1 in (False, True):
+        tag = p + 'cke.%s.' % ('L1' if l1 else 'L2')
+        U, I, E, R, M = (t('cke.' + k) for k in ('user_embeddings.weight', 'item_embeddings.weight', 'ent_embeddings.weight',
+                                                 'rel_embeddings.weight', 'proj_embeddings.weight'))
+        i2e = t('cke.item2ent').long()
+        pos, neg = O.score_cke_rec(U, I, E, i2e, u, pi), O.score_cke_rec(U, I, E, i2e, u, ni)
+        close(pos, g[tag + 'rec.pos']); close(neg, g[tag + 'rec.neg'])
+        close(O.bpr_loss(pos, neg, -1.0), g[tag + 'rec.loss'])
+        kp, kn = O.score_transr(E, R, M, ph, pt, pr, l1), O.score_transr(E, R, M, nh, nt, pr, l1)
+        close(kp, g[tag + 'kg.pos'], rtol=2e-5, atol=1e-5); close(kn, g[tag + 'kg.neg'], rtol=2e-5, atol=1e-5)
+        close(O.eval_cke_rec(U, I, E, i2e, uq), g[tag + 'evalRec'])
+        close(O.eval_transr(E, R, M, eq, rq, l1, True), g[tag + 'evalHead'], rtol=2e-5, atol=1e-5)
+        close(O.eval_transr(E, R, M, eq, rq, l1, False), g[tag + 'evalTail'], rtol=2e-5, atol=1e-5)
+        tag = p + 'cfkg.%s.' % ('L1' if l1 else 'L2')
+        U, E, R = (t('cfkg.' + k) for k in ('user_embeddings.weight', 'ent_embeddings.weight', 'rel_embeddings.weight'))
+        pos, neg = O.score_cfkg_rec(U, E, R, u, pi, l1), O.score_cfkg_rec(U, E, R, u, ni, l1)
+        close(pos, g[tag + 'rec.pos']); close(neg, g[tag + 'rec.neg'])
+        close(O.bpr_loss(pos, neg, -1.0), g[tag + 'rec.loss'])
+        close(O.score_transe(E, R, ph, pt, pr, l1), g[tag + 'kg.pos']); close(O.score_transe(E, R, nh, nt, pr, l1), g[tag + 'kg.neg'])
+        close(O.eval_cfkg_rec(U, E, R, uq, l1), g[tag + 'evalRec'])
+        close(O.eval_transe(E, R, eq, rq, l1, True), g[tag + 'evalHead']); close(O.eval_transe(E, R, eq, rq, l1, False), g[tag + 'evalTail'])
+
+
+def test_transr_d256_seeded_golden(golden):
+    """TransR at d = 256: the projection table is re-created from the fixture's seed (same torch CPU generator calls as the
+    generator script), everything else is stored; the oracle must reproduce the reference's scores."""
+    g = golden('transr_d256')
+    NE, NR, d = 53, 7, 256
+    gen = torch.Generator().manual_seed(int(g['seed'][0]))
+    E = torch.randn(NE, d, generator=gen) * 0.3
+    R = torch.randn(NR, d, generator=gen) * 0.3
+    M = torch.randn(NR, d * d, generator=gen) * 0.06
+    ph, pt, pr, nh, nt = (torch.from_numpy(g[k]).long() for k in ('ph', 'pt', 'pr', 'nh', 'nt'))
+    for l1 in (False, True):
+        tag = 'L1.' if l1 else 'L2.'
+        close(O.score_transr(E, R, M, ph, pt, pr, l1), g[tag + 'pos'], rtol=2e-5, atol=2e-5)
+        close(O.score_transr(E, R, M, nh, nt, pr, l1), g[tag + 'neg'], rtol=2e-5, atol=2e-5)

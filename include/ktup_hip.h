@@ -340,14 +340,16 @@ int ktup_optim_step(int kind, int n_tensors, float* const* params, float* const*
  *   mean_k -logsigmoid(target (pos_k - neg_k)) to loss[0] and, if orth != 0, orthogonalLoss(pref, pref_norm) to loss[1], and
  *   ACCUMULATES the gradients of (batch-mean + orth) x gscale into gU / gI / gE (pad entity row skipped) and gP, gPn (+ gR, gRn:
  *   the mixed-table gradient goes to both summands).  TUP: E == item2ent == rel == norm == gE == gR == gRn == NULL.
- *   d in {64, 100, 128}, n_pref <= 32; the preference-side tables and every gradient are contiguous (pitch d).
+ *   d in {64, 100, 128} with n_pref <= 32, or d = 256 with n_pref <= 20; the preference-side tables and every gradient are
+ *   contiguous (pitch d).
  * ktup_train_kg_step   (knowledgable_recommendation.py:345-382 / knowledge_representation.py:176-204), TransH (transh != 0) or
  *   TransE: rows k and k + B of (h, t, r) are the positive triple and its corrupted twin.  loss[0] += sum_k max(pos - neg +
  *   margin, 0); regs bit 0: loss[1] += orthogonalLoss(R[r], Nrm[r]) over the 2B relation ids, bit 1: loss[2] += normLoss over
  *   the 4B entity rows, bit 2: loss[3] += normLoss over the 2B relation rows; gradients x gscale accumulated into gE / gR / gN.
  * Both: if sumsq_zero != NULL it is set to 0.0 (the accumulator of the ktup_optim_gradnorm_loss launch that follows).
- * ktup_optim_gradnorm_loss: ktup_optim_gradnorm without its memset, plus *loss_out = loss_scale * sum(loss_slots[0..n_slots))
- *   and loss_slots := 0 for the next step.
+ * ktup_optim_gradnorm_loss: ktup_optim_gradnorm without its memset and with a hierarchical cross-workgroup sum (`sumsq` points at
+ *   KTUP_GRADNORM_WS_DOUBLES doubles, zero-filled once by the caller: [0] receives the result, the rest is scratch the kernel
+ *   leaves zeroed), plus *loss_out = loss_scale * sum(loss_slots[0..n_slots)) and loss_slots := 0 for the next step.
  * ktup_train_step_supported(kind, d, n_pref): 1 if the fused kernel exists (kind 0 rec, 1 kg TransH, 2 kg TransE).        */
 int ktup_train_step_supported(int kind, int d, int n_pref);
 int ktup_train_rec_step(const float* U, int64_t ldu, const float* I, int64_t ldi, const float* E, int64_t lde,
@@ -359,6 +361,7 @@ int ktup_train_rec_step(const float* U, int64_t ldu, const float* I, int64_t ldi
 int ktup_train_kg_step(int transh, const float* E, int64_t lde, const float* R, int64_t ldr, const float* Nrm, int64_t ldn,
                        int d, const int64_t* h, const int64_t* t, const int64_t* r, int64_t B, int l1, float margin,
                        float gscale, int regs, float* loss, float* gE, float* gR, float* gN, double* sumsq_zero, void* stream);
+#define KTUP_GRADNORM_WS_DOUBLES 136   /* ktup_optim_gradnorm_loss: doubles behind `sumsq` ([0] = result, rest = zeroed scratch) */
 int ktup_optim_gradnorm_loss(int n_tensors, float* const* grads, const int64_t* sizes, double* sumsq, float* loss_slots,
                              int n_slots, float loss_scale, float* loss_out, void* stream);
 

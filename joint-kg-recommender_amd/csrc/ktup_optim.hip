@@ -44,6 +44,14 @@ KTUP_DEV int find_tensor(const OptTensors& T, int64_t chunk) {
 // `slots` (optional): the step's loss terms, accumulated by the fused step kernel that ran before this launch.  Thread 0 of
 // workgroup 0 publishes  *loss_out = loss_scale * sum(slots)  and zeroes the slots for the next step -- the step then needs no
 // separate zero-fill or add launches.
+// HIER (ktup_optim_gradnorm_loss): the cross-workgroup sum is hierarchical.  One fp64 atomic per workgroup on ONE address
+// serialises at ~30 ns each, which is what bounded this pass at 256 workgroups (8 us for 9.7 MB of gradients); here a workgroup
+// adds to one of GN_SLOTS accumulators on separate 64-byte lines, takes a ticket, and the LAST workgroup folds the slots into
+// sumsq[0] (overwriting it -- no zero-fill launch before the pass) and clears slots and ticket for the next step.  All accesses
+// to the slots / ticket are device-scope atomic read-modify-writes, so they meet at the coherence point whatever the XCD.
+constexpr int GN_SLOTS = 16, GN_STRIDE = 8, GN_TICKET = 1 + GN_SLOTS * GN_STRIDE;     // sumsq[0] | 16 slots, one per 64 B | ticket
+
+template <bool HIER>
 __global__ __launch_bounds__(256) void gradnorm_kernel(OptTensors T, double* __restrict__ sumsq, float* __restrict__ slots, int n_slots,
                                                        float loss_scale, float* __restrict__ loss_out) {
   if (slots && blockIdx.x == 0 && threadIdx.x == 0) {
@@ -83,7 +91,24 @@ __global__ __launch_bounds__(256) void gradnorm_kernel(OptTensors T, double* __r
   __shared__ float red[4];
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(sumsq, ((double)red[0] + (double)red[1]) + ((double)red[2] + (double)red[3]));
+  if (threadIdx.x == 0) {
+    const double blk = ((double)red[0] + (double)red[1]) + ((double)red[2] + (double)red[3]);
+    if (!HIER) {
+      atomicAdd(sumsq, blk);
+    } else {
+      atomicAdd(sumsq + 1 + (blockIdx.x % GN_SLOTS) * GN_STRIDE, blk);
+      __threadfence();
+      unsigned long long* ticket = reinterpret_cast<unsigned long long*>(sumsq + GN_TICKET);
+      if (atomicAdd(ticket, 1ull) == (unsigned long long)gridDim.x - 1) {      // every other workgroup's slot add is done
+        __threadfence();
+        double total = 0.0;
+        for (int k = 0; k < GN_SLOTS; ++k)
+          total += __longlong_as_double((long long)atomicExch(reinterpret_cast<unsigned long long*>(sumsq + 1 + k * GN_STRIDE), 0ull));
+        sumsq[0] = total;
+        atomicExch(ticket, 0ull);
+      }
+    }
+  }
 }
 
 struct Hyper {
@@ -218,21 +243,23 @@ extern "C" int ktup_optim_gradnorm(int n_tensors, float* const* grads, const int
   if (hipMemsetAsync(sumsq, 0, sizeof(double), st) != hipSuccess) return check_launch("ktup_optim_gradnorm");
   const int64_t nchunks = T.chunk0[T.count];
   if (nchunks == 0) return KTUP_OK;
-  hipLaunchKernelGGL(gradnorm_kernel, dim3(grid_for((nchunks * 4 + 3) / 4, 256)), dim3(256), 0, st, T, sumsq, (float*)nullptr, 0, 0.f,
+  hipLaunchKernelGGL(gradnorm_kernel<false>, dim3(grid_for((nchunks * 4 + 3) / 4, 256)), dim3(256), 0, st, T, sumsq, (float*)nullptr, 0, 0.f,
                      (float*)nullptr);
   return check_launch("ktup_optim_gradnorm");
 }
 
-// ktup_optim_gradnorm for the fused training step (ktup_train_step.hip): *sumsq was zeroed by the step kernel that precedes
-// this launch on the stream (no memset node), and the step's loss slots are folded into *loss_out and cleared (see the kernel).
+// ktup_optim_gradnorm for the fused training step (ktup_train_step.hip): no memset node -- `sumsq` points at
+// KTUP_GRADNORM_WS_DOUBLES doubles (zero-filled ONCE by the caller; [0] receives the result, the rest is the kernel's slot /
+// ticket scratch, left zeroed) -- and the step's loss slots are folded into *loss_out and cleared (see the kernel).
 extern "C" int ktup_optim_gradnorm_loss(int n_tensors, float* const* grads, const int64_t* sizes, double* sumsq, float* loss_slots,
                                         int n_slots, float loss_scale, float* loss_out, void* stream) {
   OptTensors T{};
   KTUP_REQUIRE(grads && sizes && sumsq && loss_slots && loss_out && n_slots > 0, "ktup_optim_gradnorm_loss: null pointer argument");
   if (int e = fill("ktup_optim_gradnorm_loss", T, n_tensors, nullptr, grads, nullptr, nullptr, sizes)) return e;
   const int64_t nchunks = T.chunk0[T.count];
+  static_assert(GN_TICKET + 1 <= KTUP_GRADNORM_WS_DOUBLES, "workspace");
   const int64_t units = nchunks > 0 ? (nchunks * 4 + 3) / 4 : 1;
-  hipLaunchKernelGGL(gradnorm_kernel, dim3(grid_for(units, 256)), dim3(256), 0, (hipStream_t)stream, T, sumsq, loss_slots, n_slots,
+  hipLaunchKernelGGL(gradnorm_kernel<true>, dim3(grid_for(units, 1024)), dim3(256), 0, (hipStream_t)stream, T, sumsq, loss_slots, n_slots,
                      loss_scale, loss_out);
   return check_launch("ktup_optim_gradnorm_loss");
 }

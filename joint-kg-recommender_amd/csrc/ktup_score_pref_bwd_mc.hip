@@ -59,14 +59,6 @@ struct BArgs {
   const float* gscore;
   float *gU, *gI, *gE, *gA, *gC;
   float *GU, *GV;                // ROWOUT kernels: per-pair row gradients (n x D, pitch D) instead of atomics into gU / gI / gE
-  // STEP kernels (the fused B = 512 training step, knowledgable_recommendation.py:335-344 / item_recommendation.py:160-182):
-  const float *pref, *pnorm, *rel, *norm;   // RAW preference-side tables (rel / norm null for TUP), row pitch ldp: mixed in-kernel
-  int64_t ldp, B;                // pair k of the step: pos = (u_ids[k], i_ids[k]), neg = (u_ids[k + B], i_ids[k + B])
-  float target, gscale;          // bprLoss target (+1 / -1), upstream gradient of the batch-mean and whole-table terms (1 / world)
-  float* loss;                   // loss[0] += sum_k -logsigmoid(target (pos_k - neg_k)) / B ;  loss[1] += orthogonalLoss(pref, pnorm)
-  float *gP, *gPn, *gR, *gRn;    // gradients of the raw tables (gA goes to gP and gR, gC to gPn and gRn); pitch D
-  int orth;                      // add orthogonalLoss(pref, pnorm) (knowledgable_recommendation.py:343-344)
-  double* sumsq_zero;            // K20's norm accumulator, zeroed here for the launch that follows (may be null)
   int gumbel;                    // KTUP_GUMBEL_* (HARD kernels)
   const float* uniform;
   uint64_t seed, offset;
@@ -75,15 +67,7 @@ struct BArgs {
 // ROWOUT: the row gradients gu = gq + gx and gv = gx - gq leave as plain stores into GU / GV (one row per pair); the launcher
 // then sums them per table row by sorted segments (ktup_segreduce.hip) -- for large batches / hot rows, where d float atomics
 // per gathered row serialise on shared L2 lines.
-// STEP: the whole rec half of a training step in this one launch.  A tile holds 8 (u, pos) pairs in slots 0-7 and the 8
-// (u, neg) pairs of the same k in slots 8-15, so the BPR term of pair k = f(score[j] - score[j ^ 8]) is formed inside the wave
-// right after the forward recompute (phase A) and its gradient feeds phases B-D without the scores ever leaving registers:
-// pref-table mixing (ktup_pref_prepare), forward, bprLoss value + gradient, backward, the gA / gC fan-out to the four raw tables
-// and orthogonalLoss(pref, pref_norm) replace eleven launches of the round-1 step.
-KTUP_DEV float step_neg_logsigmoid(float x) { return fmaxf(-x, 0.f) + log1pf(expf(-fabsf(x))); }   // as ktup_loss.hip / torch
-KTUP_DEV float step_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
-
-template <typename G, bool ROWOUT, bool STEP>
+template <typename G, bool ROWOUT>
 __global__ __launch_bounds__(G::NW * 64) void pref_bwd_mc_kernel(BArgs a) {
   KTUP_RESOLVE_GUMBEL(a);
   constexpr int NCH = G::NCH, NP = G::NP, D = G::D, KG = G::KG, CT = G::CT, PT = G::PT, J = G::J, TOTAL = G::TOTAL;
@@ -118,24 +102,9 @@ __global__ __launch_bounds__(G::NW * 64) void pref_bwd_mc_kernel(BArgs a) {
       const int tt = srow >> 4, i = srow & 15;
       const int p = 16 * tt + 4 * (i & 3) + (i >> 2);          // slot -> preference (block transposed, as in pref_fwd_mc)
       const bool ok = p < P && c < NCH;
-      if constexpr (STEP) {      // mix the raw tables here (ktup_pref_prepare: Alog = (pref + rel) / 2, Ar = beta A, Cn = beta C)
-        v4 A = zero, C = zero;
-        if (ok) {
-          A = *reinterpret_cast<const v4*>(a.pref + (int64_t)p * a.ldp + 4 * c);
-          C = *reinterpret_cast<const v4*>(a.pnorm + (int64_t)p * a.ldp + 4 * c);
-          if (a.rel) {
-            A += *reinterpret_cast<const v4*>(a.rel + (int64_t)p * a.ldp + 4 * c);
-            C += *reinterpret_cast<const v4*>(a.norm + (int64_t)p * a.ldp + 4 * c);
-          }
-        }
-        AlogSlot[idx] = 0.5f * A;
-        ArSlot[idx] = a.beta * A;
-        CnSlot[idx] = a.beta * C;
-      } else {
-        AlogSlot[idx] = ok ? *reinterpret_cast<const v4*>(a.Alog + p * dp + 4 * c) : zero;
-        ArSlot[idx] = ok ? *reinterpret_cast<const v4*>(a.Ar + p * dp + 4 * c) : zero;
-        CnSlot[idx] = ok ? *reinterpret_cast<const v4*>(a.Cn + p * dp + 4 * c) : zero;
-      }
+      AlogSlot[idx] = ok ? *reinterpret_cast<const v4*>(a.Alog + p * dp + 4 * c) : zero;
+      ArSlot[idx] = ok ? *reinterpret_cast<const v4*>(a.Ar + p * dp + 4 * c) : zero;
+      CnSlot[idx] = ok ? *reinterpret_cast<const v4*>(a.Cn + p * dp + 4 * c) : zero;
     }
     if (lane < 3) {
       XT[16 * NCH + lane] = (v4){0.f, 0.f, 0.f, 0.f}; QT[16 * NCH + lane] = XT[16 * NCH + lane];
@@ -160,40 +129,12 @@ __global__ __launch_bounds__(G::NW * 64) void pref_bwd_mc_kernel(BArgs a) {
   for (int pt = 0; pt < PT; ++pt)
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) { accA[pt][ct] = (v4){0.f, 0.f, 0.f, 0.f}; accC[pt][ct] = accA[pt][ct]; }
-  float lpart = 0.f;                                            // STEP: this lane's share of the BPR loss value
-  if constexpr (STEP) {
-    if (blockIdx.x == 0 && tid == 0 && a.sumsq_zero) *a.sumsq_zero = 0.0;
-    // orthogonalLoss(pref, pref_norm) = sum_p (pn_p . p_p)^2 / |p_p|^2 (utils/loss.py:18-19): value + gradient, by the LAST
-    // workgroup's first wave (the others are busy with tiles); the raw rows come straight from memory (P x d floats)
-    if (a.orth && blockIdx.x == gridDim.x - 1 && w == 0) {
-      float lo = 0.f;
-      for (int p = 0; p < a.P; ++p) {
-        const bool on = lane < NCH;
-        const v4 r4 = on ? *reinterpret_cast<const v4*>(a.pref + (int64_t)p * a.ldp + 4 * lane) : (v4){0.f, 0.f, 0.f, 0.f};
-        const v4 w4 = on ? *reinterpret_cast<const v4*>(a.pnorm + (int64_t)p * a.ldp + 4 * lane) : (v4){0.f, 0.f, 0.f, 0.f};
-        const v4 dv = r4 * w4, nv = r4 * r4;
-        const float dot = group_sum<64>((dv[0] + dv[1]) + (dv[2] + dv[3])), nr = group_sum<64>((nv[0] + nv[1]) + (nv[2] + nv[3]));
-        const float c1 = a.gscale * 2.f * dot / nr, c2 = a.gscale * 2.f * dot * dot / (nr * nr);
-        if (on) {
-          const v4 gr4 = c1 * w4 - c2 * r4, gw4 = c1 * r4;
-          atomic_add4(a.gP + (int64_t)p * D + 4 * lane, make_float4(gr4[0], gr4[1], gr4[2], gr4[3]));
-          atomic_add4(a.gPn + (int64_t)p * D + 4 * lane, make_float4(gw4[0], gw4[1], gw4[2], gw4[3]));
-        }
-        lo += dot * dot / nr;
-      }
-      if (lane == 0) atomicAdd(a.loss + 1, lo);
-    }
-  }
-  const int64_t ntiles = STEP ? (a.B + 7) / 8 : (a.n + 15) / 16;
+  const int64_t ntiles = (a.n + 15) / 16;
   for (int64_t tile_id = (int64_t)blockIdx.x * NW + w; tile_id < ntiles; tile_id += (int64_t)gridDim.x * NW) {
     const int64_t row0 = tile_id * 16;
-    // STEP: slot j holds pair k = 8 tile + (j & 7); slots 8-15 are the negatives (rows k + B of the id arrays)
-    const int64_t kpair = STEP ? tile_id * 8 + (j & 7) : row0 + j;
-    const bool live_j = STEP ? kpair < a.B : kpair < a.n;
-    const int64_t row_j = STEP ? kpair + (j >> 3) * a.B : kpair;          // row of the [pos ; neg] id / draw order
     if (lane < 16) {
-      const int64_t gr = STEP ? tile_id * 8 + (lane & 7) + (lane >> 3) * a.B : row0 + lane;
-      const bool ok = STEP ? tile_id * 8 + (lane & 7) < a.B : gr < a.n;
+      const int64_t gr = row0 + lane;
+      const bool ok = gr < a.n;
       const int64_t uid = ok ? a.u_ids[gr] : 0, iid = ok ? a.i_ids[gr] : 0;
       sid[lane] = (int32_t)uid;
       sid[16 + lane] = (int32_t)iid;
@@ -244,7 +185,7 @@ __global__ __launch_bounds__(G::NW * 64) void pref_bwd_mc_kernel(BArgs a) {
     //      From here on `lg` holds the FORWARD weights (the raw logits for the soft gate); ysoft keeps y for the Jacobian.
     v4 ysoft[PT];
     if constexpr (HARD) {
-      const int64_t grow = STEP ? (live_j ? row_j : 0) : min(row0 + j, a.n - 1);
+      const int64_t grow = min(row0 + j, a.n - 1);
       const uint64_t base = (uint64_t)grow * (uint64_t)a.P;
       if (a.gumbel == KTUP_GUMBEL_PHILOX) {     // same stream and block sharing as pref_fwd_mc
         const uint64_t i0 = base + a.offset, fb = i0 >> 2, lb = (i0 + (uint64_t)a.P - 1) >> 2;
@@ -323,37 +264,12 @@ __global__ __launch_bounds__(G::NW * 64) void pref_bwd_mc_kernel(BArgs a) {
       sacc += qv[ct] * nn[ct];
     }
     const float s = allsum_kq((sacc[0] + sacc[1]) + (sacc[2] + sacc[3]));
-    float g;                                                      // upstream gradient of this slot's score; 0 for tail slots
-    if constexpr (STEP) {
-      // z -> score (this IS the forward), then the BPR term of pair k from the two halves of the tile
-      v4 dacc = (v4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int ct = 0; ct < CT; ++ct) {
-        const v4 z = zz[ct] - s * nn[ct];
-        zz[ct] = z;
-        if (4 * ct + kq < NCH) {
-          if (l1) dacc += __builtin_elementwise_abs(z);
-          else dacc = __builtin_elementwise_fma(z, z, dacc);
-        }
-      }
-      const float score = allsum_kq((dacc[0] + dacc[1]) + (dacc[2] + dacc[3]));
-      const float other = __shfl_xor(score, 8, 64);               // same k, other half (lane ^ 8 keeps kq)
-      const bool negh = (j >> 3) != 0;
-      const float diff = negh ? other - score : score - other;   // pos - neg
-      const float g0 = a.gscale * (1.f / (float)a.B);
-      const float gd = -g0 * a.target * step_sigmoid(-a.target * diff);     // d/dpos of mean_k -logsigmoid(target diff_k)
-      g = live_j ? (negh ? -gd : gd) : 0.f;
-      if (live_j && !negh && kq == 0) lpart += step_neg_logsigmoid(a.target * diff);
-    } else {
-      g = live_j ? a.gscore[row0 + j] : 0.f;
-#pragma unroll
-      for (int ct = 0; ct < CT; ++ct) zz[ct] = zz[ct] - s * nn[ct];
-    }
+    const float g = row0 + j < a.n ? a.gscore[row0 + j] : 0.f;    // tail pairs contribute nothing
     // gz (kept in zz), av
     v4 aacc = (v4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
-      const v4 z = zz[ct];
+      const v4 z = zz[ct] - s * nn[ct];
       v4 gz;
 #pragma unroll
       for (int c = 0; c < 4; ++c) gz[c] = g * ddist1(z[c], l1);
@@ -406,7 +322,7 @@ __global__ __launch_bounds__(G::NW * 64) void pref_bwd_mc_kernel(BArgs a) {
     // ---- C: gx^T = Alog2^T . gL^T, then the row gradients
     {
       const int64_t gr = row0 + j;
-      const bool live = live_j;
+      const bool live = gr < a.n;
       const int32_t ur = sid[j], ir = sid[16 + j], er = sid[32 + j];
       float* pu = a.gU + (int64_t)ur * a.ldu4 * 4;
       float* pi = a.gI + (int64_t)ir * a.ldi4 * 4;
@@ -474,36 +390,25 @@ __global__ __launch_bounds__(G::NW * 64) void pref_bwd_mc_kernel(BArgs a) {
         const int p = 16 * pt + 4 * kq + reg, c = 16 * ct + j;
         if (p < a.P && c < D) {
           const float va = accA[pt][ct][reg], vc = accC[pt][ct][reg];
-          if constexpr (STEP) {       // A = pref + rel and C = pref_norm + norm: the mixed-table gradient goes to both summands
-            if (va != 0.f) { atomicAdd(a.gP + (int64_t)p * D + c, va); if (a.gR) atomicAdd(a.gR + (int64_t)p * D + c, va); }
-            if (vc != 0.f) { atomicAdd(a.gPn + (int64_t)p * D + c, vc); if (a.gRn) atomicAdd(a.gRn + (int64_t)p * D + c, vc); }
-          } else {
-            if (va != 0.f) atomicAdd(a.gA + (int64_t)p * D + c, va);
-            if (vc != 0.f) atomicAdd(a.gC + (int64_t)p * D + c, vc);
-          }
+          if (va != 0.f) atomicAdd(a.gA + (int64_t)p * D + c, va);
+          if (vc != 0.f) atomicAdd(a.gC + (int64_t)p * D + c, vc);
         }
       }
-  if constexpr (STEP) {
-    lpart = group_sum<64>(lpart);
-    if (lane == 0 && lpart != 0.f) atomicAdd(a.loss, lpart * (1.f / (float)a.B));
-  }
 }
 
-template <typename G, bool ROWOUT, bool STEP>
+template <typename G, bool ROWOUT>
 int launch_r(const BArgs& a, hipStream_t st, const char* name) {
   static_assert(G::LDS <= 160 * 1024, "LDS budget");
-  (void)hipFuncSetAttribute((const void*)pref_bwd_mc_kernel<G, ROWOUT, STEP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS);
-  const int64_t ntiles = STEP ? (a.B + 7) / 8 : (a.n + 15) / 16;
-  // STEP (a B = 512 step is 64 tiles): one tile per workgroup slot keeps the step's critical path at ONE tile
+  (void)hipFuncSetAttribute((const void*)pref_bwd_mc_kernel<G, ROWOUT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS);
+  const int64_t ntiles = (a.n + 15) / 16;
   const int grid = grid_for((ntiles + G::NW - 1) / G::NW, 256);
-  hipLaunchKernelGGL((pref_bwd_mc_kernel<G, ROWOUT, STEP>), dim3(grid), dim3(G::NW * 64), G::LDS, st, a);
+  hipLaunchKernelGGL((pref_bwd_mc_kernel<G, ROWOUT>), dim3(grid), dim3(G::NW * 64), G::LDS, st, a);
   return check_launch(name);
 }
 
 template <typename G>
 int launch(const BArgs& a, hipStream_t st, const char* name) {
-  if (a.loss) return launch_r<G, false, true>(a, st, name);
-  return a.GU ? launch_r<G, true, false>(a, st, name) : launch_r<G, false, false>(a, st, name);
+  return a.GU ? launch_r<G, true>(a, st, name) : launch_r<G, false>(a, st, name);
 }
 
 template <int NCH, int NP>
@@ -532,7 +437,8 @@ int pref_bwd_mc(const float* U, int64_t ldu, const float* I, int64_t ldi, const 
                 uint64_t offset, const float* gscore, float* gU, float* gI, float* gE, float* gA, float* gC, hipStream_t st,
                 const char* name, float* GU, float* GV) {
   if (n_pref > 32) return 1;
-  if (d == 256)
+  // d = 256 always, and small batches (<= 256 tiles: at most one tile per CU) at the other widths: four waves per tile
+  if (d == 256 || ((d == 64 || d == 100 || d == 128) && n <= 4096 && !GU))
     return pref_bwd_mc_wide(U, ldu, I, ldi, E, lde, item2ent, ent_pad, Alog, Ar, Cn, dp, beta, n_pref, d, u_ids, i_ids, n, l1, gumbel_mode,
                             uniform, seed, offset, gscore, gU, gI, gE, gA, gC, st, name, GU, GV);
   if (d != 64 && d != 100 && d != 128) return 1;
@@ -547,33 +453,6 @@ int pref_bwd_mc(const float* U, int64_t ldu, const float* I, int64_t ldi, const 
   a.gscore = gscore; a.gU = gU; a.gI = gI; a.gE = gE; a.gA = gA; a.gC = gC;
   a.GU = GU; a.GV = GV;
   a.gumbel = gumbel_mode; a.uniform = uniform; a.seed = seed; a.offset = offset;
-  const int np = (n_pref + 3) / 4;
-  if (d == 64) return launch_np<16>(a, np, st, name);
-  if (d == 100) return launch_np<25>(a, np, st, name);
-  return launch_np<32>(a, np, st, name);
-}
-
-// The rec half of a B = 512 training step in one launch (STEP kernels above).  Returns 1 for shapes the matrix-core kernels do
-// not cover (the caller keeps its multi-launch route).
-int pref_step_mc(const float* U, int64_t ldu, const float* I, int64_t ldi, const float* E, int64_t lde, const int32_t* item2ent,
-                 int64_t ent_pad, const float* pref, const float* pnorm, const float* rel, const float* norm, int64_t ldp, int n_pref,
-                 int d, const int64_t* u_ids, const int64_t* i_ids, int64_t B, int l1, int gumbel_mode, const float* uniform,
-                 uint64_t seed, uint64_t offset, float target, float gscale, int orth, float* loss, float* gU, float* gI, float* gE,
-                 float* gP, float* gPn, float* gR, float* gRn, double* sumsq_zero, hipStream_t st, const char* name) {
-  if (n_pref > 32 || (d != 64 && d != 100 && d != 128)) return 1;
-  if ((ldu | ldi | lde | ldp) & 3) return 1;
-  if ((ldu >> 2) > 0xffffffffll || (ldi >> 2) > 0xffffffffll || (lde >> 2) > 0xffffffffll) return 1;
-  BArgs a{};
-  a.U = reinterpret_cast<const v4*>(U); a.I = reinterpret_cast<const v4*>(I); a.E = reinterpret_cast<const v4*>(E);
-  a.ldu4 = (uint32_t)(ldu >> 2); a.ldi4 = (uint32_t)(ldi >> 2); a.lde4 = (uint32_t)(lde >> 2);
-  a.item2ent = item2ent;
-  a.P = n_pref; a.l1 = l1; a.beta = rel ? 0.5f : 1.0f;
-  a.u_ids = u_ids; a.i_ids = i_ids; a.n = 2 * B; a.ent_pad = ent_pad;
-  a.gU = gU; a.gI = gI; a.gE = gE;
-  a.gumbel = gumbel_mode; a.uniform = uniform; a.seed = seed; a.offset = offset;
-  a.pref = pref; a.pnorm = pnorm; a.rel = rel; a.norm = norm; a.ldp = ldp; a.B = B;
-  a.target = target; a.gscale = gscale; a.loss = loss; a.gP = gP; a.gPn = gPn; a.gR = gR; a.gRn = gRn; a.orth = orth;
-  a.sumsq_zero = sumsq_zero;
   const int np = (n_pref + 3) / 4;
   if (d == 64) return launch_np<16>(a, np, st, name);
   if (d == 100) return launch_np<25>(a, np, st, name);

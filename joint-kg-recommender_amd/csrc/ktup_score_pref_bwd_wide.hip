@@ -1,4 +1,7 @@
-// K5 / K6 / K7 backward on the matrix cores for d = 256 (BASELINE config 5): the coordinate-sliced variant of pref_bwd_mc_kernel.
+// K5 / K6 / K7 backward on the matrix cores, coordinate-sliced: four waves share a 16-pair tile.  Used for d = 256 (BASELINE
+// config 5, where one wave cannot hold a tile), for SMALL batches at d = 64 / 100 / 128 (a B = 512 step is 64 tiles: with one
+// wave per tile its whole dependent chain -- 450 MFMAs, five LDS round trips, 300 atomic instructions -- runs on one SIMD while
+// 97 % of the chip idles; sliced four ways the chain is ~4x shorter), and as the fused training-step kernel (STEP, below).
 //
 // Same math, same MFMA operand layouts and the same phases A-D as ktup_score_pref_bwd_mc.hip (read its header first;
 // transUP.py:69-115 / jTransUP.py:122-143,250-262 differentiated).  What changes is who owns what: at d = 256 one wave cannot
@@ -11,8 +14,16 @@
 //     lives only in the owning wave: 4 coordinate tiles per lane instead of 16 ;
 //   * the three tables sit in LDS ONCE per workgroup, one row per preference plus a shared zero row that stands in for the
 //     empty slots of the last 16-slot tile (P = 20 fills 4 of its 16 slots), row pitch 65 float4 (odd: conflict-free b128 reads).
-// LDS at P = 20: 65.5 KB tables + 8 KB reduction scratch + 4 x 19 KB wave-private tiles = 152 KB, one workgroup per CU.
-// MFMA work per tile is unchanged (~1000 16x16x4 instructions) but split four ways: ~250 per wave.
+// LDS at d = 256, P = 20: 65.5 KB tables + 8 KB reduction scratch + 4 x 19 KB wave-private tiles = 152 KB, one workgroup per CU
+// (d = 100: 87 KB).  MFMA work per tile is unchanged but split four ways.  A wave owns CTW coordinate tiles of 16 = NCW = 4 CTW
+// chunks; for d = 100 (25 chunks, CTW = 2) the last wave holds one real chunk: tables and tiles are zero beyond d, so the padded
+// coordinates contribute exact zeros and are simply never written back.
+//
+// STEP (ktup_train_rec_step): the rec half of a training step in this one launch -- see ktup_train_step.hip.  A tile holds 8
+// (u, pos) pairs in slots 0-7 and the 8 (u, neg) pairs of the same examples in slots 8-15; the score is the forward value the
+// backward recomputes anyway, the BPR term of example k = f(score[j] - score[j ^ 8]) is formed in registers, and its gradient
+// feeds phases B-D.  Raw preference tables are mixed while staging (ktup_pref_prepare), gA / gC go straight to the four raw
+// tables' gradients, one extra workgroup computes orthogonalLoss(pref, pref_norm).
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -24,21 +35,24 @@
 namespace ktup {
 namespace {
 
-template <int NP_, bool HASE_, bool HARD_>
+template <int NCH_, int CTW_, int NP_, bool HASE_, bool HARD_>
 struct WGeom {
   static constexpr int NP = NP_;
   static constexpr bool HASE = HASE_, HARD = HARD_;
-  static constexpr int D = 256, NCH = 64, NWC = 4, NCW = 16, CTW = 4;   // 4 waves x 16 chunks = 4 coordinate tiles of 16 each
+  static constexpr int NCH = NCH_, D = 4 * NCH, NWC = 4, CTW = CTW_, NCW = 4 * CTW;   // 4 waves x CTW coordinate tiles of 16 = NCW chunks each
+  static constexpr int NCHP = NWC * NCW;                  // padded chunk count (>= NCH; tables / tiles are zero beyond NCH)
+  static_assert(NCHP >= NCH && NCHP - NCH < NCW, "the last wave must own at least one real chunk");
   static constexpr int PT = (NP + 3) / 4, TROW = 16 * PT;
   static constexpr int ROWS = 4 * NP + 1;                 // preferences 0 .. 4 NP - 1 (rows >= P zero) + the zero row
-  static constexpr int RP4 = NCH + 1, RPF = 4 * RP4;      // table row pitch: 65 float4 = 260 floats
+  static constexpr int RP4 = NCHP + 1, RPF = 4 * RP4;     // table row pitch (odd float4 count: conflict-free b128 reads)
   static constexpr int TAB_F4 = ROWS * RP4;
-  static constexpr int TP4 = NCW + 1, TPF = 4 * TP4;      // wave tile row pitch: 17 float4 = 68 floats
+  static constexpr int TP4 = NCW + 1, TPF = 4 * TP4;      // wave tile row pitch
   static constexpr int TILE_F4 = 16 * TP4;
+  static constexpr int GJ = CTW, GR = 64 / NCW;           // gather: GJ passes of GR rows x NCW chunks
   static constexpr int LT_F = TROW * 17;
   static constexpr int NOISE_F = HARD ? 16 * TROW : 0;
   static constexpr int RED_F = NWC * 64 * PT * 4;         // cross-wave partials of lg / gl
-  static constexpr size_t SHARED_BYTES = (size_t)3 * TAB_F4 * 16 + (size_t)RED_F * 4 + 2 * NWC * 16 * 4;
+  static constexpr size_t SHARED_BYTES = (size_t)3 * TAB_F4 * 16 + (size_t)RED_F * 4 + 3 * NWC * 16 * 4;
   static constexpr size_t WAVE_BYTES = ((size_t)3 * TILE_F4 * 16 + (size_t)2 * LT_F * 4 + 3 * 16 * 4 + (size_t)NOISE_F * 4 + 15) & ~(size_t)15;
   static constexpr size_t LDS = SHARED_BYTES + NWC * WAVE_BYTES;
 };
@@ -54,18 +68,30 @@ struct WArgs {
   int64_t n, ent_pad;
   const float* gscore;
   float *gU, *gI, *gE, *gA, *gC;
-  float *GU, *GV;                // ROWOUT: per-pair row gradients (n x 256)
+  float *GU, *GV;                // ROWOUT: per-pair row gradients (n x D)
+  // STEP (fused training step; ktup_train_rec_step): see BArgs in ktup_score_pref_bwd_mc.hip for the same fields
+  const float *pref, *pnorm, *rel, *norm;   // RAW preference-side tables (rel / norm null for TUP), pitch ldp
+  int64_t ldp, B;                // example k: pos = (u_ids[k], i_ids[k]), neg = (u_ids[k + B], i_ids[k + B])
+  float target, gscale;
+  float* loss;                   // loss[0] += mean_k -logsigmoid(target (pos_k - neg_k)); loss[1] += orthogonalLoss(pref, pnorm)
+  float *gP, *gPn, *gR, *gRn;    // gradients of the raw tables, pitch D
+  int orth;
+  double* sumsq_zero;
   int gumbel;
   const float* uniform;
   uint64_t seed, offset;
 };
 
-template <typename G, bool ROWOUT>
+KTUP_DEV float wstep_neg_logsigmoid(float x) { return fmaxf(-x, 0.f) + log1pf(expf(-fabsf(x))); }   // as ktup_loss.hip / torch
+KTUP_DEV float wstep_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
+
+template <typename G, bool ROWOUT, bool STEP>
 __global__ __launch_bounds__(256) void pref_bwd_wide_kernel(WArgs a) {
   KTUP_RESOLVE_GUMBEL(a);
   constexpr int NP = G::NP, D = G::D, NCH = G::NCH, NCW = G::NCW, CTW = G::CTW, PT = G::PT, TROW = G::TROW;
   constexpr int RP4 = G::RP4, RPF = G::RPF, TP4 = G::TP4, TPF = G::TPF;
   constexpr bool HASE = G::HASE, HARD = G::HARD;
+  constexpr bool RAGGED = G::NCHP != NCH;                     // d = 100: the last wave's slice runs past the row
   extern __shared__ __attribute__((aligned(16))) char smem[];
   v4* AlogT = reinterpret_cast<v4*>(smem);                    // [ROWS][RP4]
   v4* ArT = AlogT + G::TAB_F4;
@@ -73,12 +99,13 @@ __global__ __launch_bounds__(256) void pref_bwd_wide_kernel(WArgs a) {
   float* red = reinterpret_cast<float*>(CnT + G::TAB_F4);     // [4 waves][64 lanes][PT * 4]
   float* reds = red + G::RED_F;                               // [4][16]
   float* redav = reds + G::NWC * 16;                          // [4][16]
+  float* redsc = redav + G::NWC * 16;                         // [4][16]  STEP: partial scores
   const float* Alog2 = reinterpret_cast<const float*>(AlogT);
   const float* Ar2 = reinterpret_cast<const float*>(ArT);
   const float* Cn2 = reinterpret_cast<const float*>(CnT);
   const int tid = threadIdx.x, lane = tid & 63, kq = lane >> 4, j = lane & 15;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);     // this wave's coordinate slice: [64 w, 64 w + 64)
-  char* wbase = reinterpret_cast<char*>(redav + G::NWC * 16) + (size_t)w * G::WAVE_BYTES;
+  char* wbase = reinterpret_cast<char*>(redsc + G::NWC * 16) + (size_t)w * G::WAVE_BYTES;
   v4* XT = reinterpret_cast<v4*>(wbase);                      // x    [16 pairs][TP4]   (this wave's 16 chunks)
   v4* QT = XT + G::TILE_F4;                                   // q, later gn (a lane overwrites exactly what it read)
   v4* GRT = QT + G::TILE_F4;                                  // gr = gz
@@ -87,16 +114,64 @@ __global__ __launch_bounds__(256) void pref_bwd_wide_kernel(WArgs a) {
   int32_t* sid = reinterpret_cast<int32_t*>(GLT + G::LT_F);   // [3][16]
   float* noise = reinterpret_cast<float*>(sid + 48);          // HARD: [16][TROW]
   const int P = a.P;
-  // ---- stage the three tables: row p = preference p (zero beyond P), row pitch 65 float4
+  int nblk = gridDim.x;                                       // workgroups that walk tiles
+  if constexpr (STEP) {
+    if (blockIdx.x == 0 && tid == 0 && a.sumsq_zero) *a.sumsq_zero = 0.0;
+    if (a.orth) {
+      nblk = gridDim.x - 1;
+      if ((int)blockIdx.x == nblk) {
+        // the extra workgroup: orthogonalLoss(pref, pref_norm) = sum_p (pn_p . p_p)^2 / |p_p|^2 (utils/loss.py:18-19), value and
+        // gradient, rows dealt to the four waves; it touches no tile and leaves before any barrier
+        float lo = 0.f;
+        for (int p = w; p < P; p += G::NWC) {
+          float dot = 0.f, nr = 0.f;
+          for (int c = lane; c < NCH; c += 64) {
+            const v4 r4 = *reinterpret_cast<const v4*>(a.pref + (int64_t)p * a.ldp + 4 * c);
+            const v4 w4 = *reinterpret_cast<const v4*>(a.pnorm + (int64_t)p * a.ldp + 4 * c);
+            const v4 dv = r4 * w4, nv = r4 * r4;
+            dot += (dv[0] + dv[1]) + (dv[2] + dv[3]); nr += (nv[0] + nv[1]) + (nv[2] + nv[3]);
+          }
+          dot = group_sum<64>(dot); nr = group_sum<64>(nr);
+          const float c1 = a.gscale * 2.f * dot / nr, c2 = a.gscale * 2.f * dot * dot / (nr * nr);
+          for (int c = lane; c < NCH; c += 64) {
+            const v4 r4 = *reinterpret_cast<const v4*>(a.pref + (int64_t)p * a.ldp + 4 * c);
+            const v4 w4 = *reinterpret_cast<const v4*>(a.pnorm + (int64_t)p * a.ldp + 4 * c);
+            const v4 gr4 = c1 * w4 - c2 * r4, gw4 = c1 * r4;
+            atomic_add4(a.gP + (int64_t)p * D + 4 * c, make_float4(gr4[0], gr4[1], gr4[2], gr4[3]));
+            atomic_add4(a.gPn + (int64_t)p * D + 4 * c, make_float4(gw4[0], gw4[1], gw4[2], gw4[3]));
+          }
+          lo += dot * dot / nr;
+        }
+        if (lane == 0 && lo != 0.f) atomicAdd(a.loss + 1, lo);
+        return;
+      }
+    }
+  }
+  // ---- stage the three tables: row p = preference p (zero beyond P), odd float4 row pitch
   {
     const int dp = a.dp;
     const v4 zero = (v4){0.f, 0.f, 0.f, 0.f};
     for (int idx = tid; idx < G::TAB_F4; idx += 256) {
       const int row = idx / RP4, c = idx - row * RP4;
       const bool ok = row < P && c < NCH;
-      AlogT[idx] = ok ? *reinterpret_cast<const v4*>(a.Alog + row * dp + 4 * c) : zero;
-      ArT[idx] = ok ? *reinterpret_cast<const v4*>(a.Ar + row * dp + 4 * c) : zero;
-      CnT[idx] = ok ? *reinterpret_cast<const v4*>(a.Cn + row * dp + 4 * c) : zero;
+      if constexpr (STEP) {      // mix the raw tables here (ktup_pref_prepare: Alog = (pref + rel) / 2, Ar = beta A, Cn = beta C)
+        v4 A = zero, C = zero;
+        if (ok) {
+          A = *reinterpret_cast<const v4*>(a.pref + (int64_t)row * a.ldp + 4 * c);
+          C = *reinterpret_cast<const v4*>(a.pnorm + (int64_t)row * a.ldp + 4 * c);
+          if (a.rel) {
+            A += *reinterpret_cast<const v4*>(a.rel + (int64_t)row * a.ldp + 4 * c);
+            C += *reinterpret_cast<const v4*>(a.norm + (int64_t)row * a.ldp + 4 * c);
+          }
+        }
+        AlogT[idx] = 0.5f * A;
+        ArT[idx] = a.beta * A;
+        CnT[idx] = a.beta * C;
+      } else {
+        AlogT[idx] = ok ? *reinterpret_cast<const v4*>(a.Alog + row * dp + 4 * c) : zero;
+        ArT[idx] = ok ? *reinterpret_cast<const v4*>(a.Ar + row * dp + 4 * c) : zero;
+        CnT[idx] = ok ? *reinterpret_cast<const v4*>(a.Cn + row * dp + 4 * c) : zero;
+      }
     }
   }
   __syncthreads();
@@ -115,7 +190,9 @@ __global__ __launch_bounds__(256) void pref_bwd_wide_kernel(WArgs a) {
     const int p = 4 * m + kq;
     rb[m] = (p < P ? p : P) * RPF + 4 * NCW * w + j;          // float index; + 16 ct per coordinate tile
   }
-  const int grow_l = lane >> 4, gch = lane & 15;              // gather: row grow_l + 4 jj, chunk gch of the wave's slice
+  const int grow_l = lane / NCW, gch = lane % NCW;            // gather: row grow_l + GR jj, chunk gch of the wave's slice
+  const bool gok = !RAGGED || NCW * w + gch < NCH;            // chunks past the row stay zero in the tiles
+  float lpart = 0.f;                                          // STEP: this lane's share of the BPR loss value
   const bool l1 = a.l1 != 0;
   const float beta = a.beta;
   v4 accA[PT][CTW], accC[PT][CTW];
@@ -123,12 +200,16 @@ __global__ __launch_bounds__(256) void pref_bwd_wide_kernel(WArgs a) {
   for (int pt = 0; pt < PT; ++pt)
 #pragma unroll
     for (int ct = 0; ct < CTW; ++ct) { accA[pt][ct] = (v4){0.f, 0.f, 0.f, 0.f}; accC[pt][ct] = accA[pt][ct]; }
-  const int64_t ntiles = (a.n + 15) / 16;
-  for (int64_t tile_id = blockIdx.x; tile_id < ntiles; tile_id += gridDim.x) {
+  const int64_t ntiles = STEP ? (a.B + 7) / 8 : (a.n + 15) / 16;
+  for (int64_t tile_id = blockIdx.x; tile_id < ntiles; tile_id += nblk) {
     const int64_t row0 = tile_id * 16;
+    // STEP: slot j holds example k = 8 tile + (j & 7); slots 8-15 are the negatives (rows k + B of the id arrays)
+    const int64_t kpair = STEP ? tile_id * 8 + (j & 7) : row0 + j;
+    const bool live_j = STEP ? kpair < a.B : kpair < a.n;
+    const int64_t row_j = STEP ? kpair + (j >> 3) * a.B : kpair;          // row in the [pos ; neg] id / draw order
     if (lane < 16) {
-      const int64_t gr = row0 + lane;
-      const bool ok = gr < a.n;
+      const int64_t gr = STEP ? tile_id * 8 + (lane & 7) + (lane >> 3) * a.B : row0 + lane;
+      const bool ok = STEP ? tile_id * 8 + (lane & 7) < a.B : gr < a.n;
       const int64_t uid = ok ? a.u_ids[gr] : 0, iid = ok ? a.i_ids[gr] : 0;
       sid[lane] = (int32_t)uid;
       sid[16 + lane] = (int32_t)iid;
@@ -136,23 +217,25 @@ __global__ __launch_bounds__(256) void pref_bwd_wide_kernel(WArgs a) {
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    // ---- gather this wave's 64 coordinates of the 16 pairs: x and q tiles
+    // ---- gather this wave's coordinate slice of the 16 pairs: x and q tiles
     {
-      v4 uu[4], vv[4], ee[4];
+      constexpr int GJ = G::GJ, GR = G::GR;
+      v4 uu[GJ], vv[GJ], ee[GJ];
 #pragma unroll
-      for (int jj = 0; jj < 4; ++jj) {
-        const int r = grow_l + 4 * jj;
+      for (int jj = 0; jj < GJ; ++jj) {
+        const int r = grow_l + GR * jj;
         const uint32_t idu = (uint32_t)sid[r], idi = (uint32_t)sid[16 + r];
-        uu[jj] = a.U[(uint64_t)idu * a.ldu4 + (uint32_t)(NCW * w + gch)];
-        vv[jj] = a.I[(uint64_t)idi * a.ldi4 + (uint32_t)(NCW * w + gch)];
+        const v4 zero = (v4){0.f, 0.f, 0.f, 0.f};
+        uu[jj] = gok ? a.U[(uint64_t)idu * a.ldu4 + (uint32_t)(NCW * w + gch)] : zero;
+        vv[jj] = gok ? a.I[(uint64_t)idi * a.ldi4 + (uint32_t)(NCW * w + gch)] : zero;
         if (HASE) {
           const uint32_t ide = (uint32_t)sid[32 + r];
-          ee[jj] = a.E[(uint64_t)ide * a.lde4 + (uint32_t)(NCW * w + gch)];
+          ee[jj] = gok ? a.E[(uint64_t)ide * a.lde4 + (uint32_t)(NCW * w + gch)] : zero;
         }
       }
 #pragma unroll
-      for (int jj = 0; jj < 4; ++jj) {
-        const int r = grow_l + 4 * jj;
+      for (int jj = 0; jj < GJ; ++jj) {
+        const int r = grow_l + GR * jj;
         const v4 ve = HASE ? vv[jj] + ee[jj] : vv[jj];
         XT[r * TP4 + gch] = uu[jj] + ve;
         QT[r * TP4 + gch] = uu[jj] + (-ve);
@@ -190,7 +273,7 @@ __global__ __launch_bounds__(256) void pref_bwd_wide_kernel(WArgs a) {
     // ---- ST-Gumbel gate (as pref_bwd_mc_kernel; every wave does it on the same full logits and the same draws)
     v4 ysoft[PT];
     if constexpr (HARD) {
-      const int64_t grow = min(row0 + j, a.n - 1);
+      const int64_t grow = STEP ? (live_j ? row_j : 0) : min(row0 + j, a.n - 1);
       const uint64_t base = (uint64_t)grow * (uint64_t)P;
       if (a.gumbel == KTUP_GUMBEL_PHILOX) {
         const uint64_t i0 = base + a.offset, fb = i0 >> 2, lb = (i0 + (uint64_t)P - 1) >> 2;
@@ -271,11 +354,36 @@ __global__ __launch_bounds__(256) void pref_bwd_wide_kernel(WArgs a) {
     if (kq == 0) reds[w * 16 + j] = s;
     __syncthreads();
     s = (reds[j] + reds[16 + j]) + (reds[32 + j] + reds[48 + j]);
-    const float g = row0 + j < a.n ? a.gscore[row0 + j] : 0.f;
+    float g;                                                      // upstream gradient of this slot's score; 0 for tail slots
+#pragma unroll
+    for (int ct = 0; ct < CTW; ++ct) zz[ct] = zz[ct] - s * nn[ct];    // z
+    if constexpr (STEP) {
+      // z -> score (this IS the forward): partial over this wave's coordinates, summed across the waves, then the BPR term of
+      // example k from the two halves of the tile (padded coordinates hold exact zeros)
+      v4 dacc = (v4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ct = 0; ct < CTW; ++ct) {
+        if (l1) dacc += __builtin_elementwise_abs(zz[ct]);
+        else dacc = __builtin_elementwise_fma(zz[ct], zz[ct], dacc);
+      }
+      float score = allsum_kq((dacc[0] + dacc[1]) + (dacc[2] + dacc[3]));
+      if (kq == 0) redsc[w * 16 + j] = score;
+      __syncthreads();
+      score = (redsc[j] + redsc[16 + j]) + (redsc[32 + j] + redsc[48 + j]);
+      const float other = (redsc[j ^ 8] + redsc[16 + (j ^ 8)]) + (redsc[32 + (j ^ 8)] + redsc[48 + (j ^ 8)]);
+      const bool negh = (j >> 3) != 0;
+      const float diff = negh ? other - score : score - other;   // pos - neg
+      const float g0 = a.gscale * (1.f / (float)a.B);
+      const float gd = -g0 * a.target * wstep_sigmoid(-a.target * diff);    // d/dpos of mean_k -logsigmoid(target diff_k)
+      g = live_j ? (negh ? -gd : gd) : 0.f;
+      if (w == 0 && live_j && !negh && kq == 0) lpart += wstep_neg_logsigmoid(a.target * diff);
+    } else {
+      g = live_j ? a.gscore[row0 + j] : 0.f;
+    }
     v4 aacc = (v4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ct = 0; ct < CTW; ++ct) {
-      const v4 z = zz[ct] - s * nn[ct];
+      const v4 z = zz[ct];
       v4 gz;
 #pragma unroll
       for (int c = 0; c < 4; ++c) gz[c] = g * ddist1(z[c], l1);
@@ -343,7 +451,7 @@ __global__ __launch_bounds__(256) void pref_bwd_wide_kernel(WArgs a) {
     // ---- C: gx^T = Alog2^T . gL^T of this wave's coordinates, then the row gradients
     {
       const int64_t gr = row0 + j;
-      const bool live = gr < a.n;
+      const bool live = live_j;
       const int32_t ur = sid[j], ir = sid[16 + j], er = sid[32 + j];
       float* pu = a.gU + (int64_t)ur * a.ldu4 * 4;
       float* pi = a.gI + (int64_t)ir * a.ldi4 * 4;
@@ -355,7 +463,7 @@ __global__ __launch_bounds__(256) void pref_bwd_wide_kernel(WArgs a) {
         for (int m = 0; m < NP; ++m)
           gx = __builtin_amdgcn_mfma_f32_16x16x4f32(Alog2[rb[m] + 16 * ct], gl[m >> 2][m & 3], gx, 0, 0, 0);
         const int c0 = 4 * NCW * w + 16 * ct + 4 * kq;
-        if (live) {
+        if (live && (!RAGGED || c0 < D)) {
           const v4 gu = gq[ct] + gx, gv = gx - gq[ct];
           if constexpr (ROWOUT) {
             *reinterpret_cast<v4*>(a.GU + gr * D + c0) = gu;
@@ -403,51 +511,88 @@ __global__ __launch_bounds__(256) void pref_bwd_wide_kernel(WArgs a) {
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
         const int p = 16 * pt + 4 * kq + reg, c = 4 * NCW * w + 16 * ct + j;
-        if (p < P) {
+        if (p < P && (!RAGGED || c < D)) {
           const float va = accA[pt][ct][reg], vc = accC[pt][ct][reg];
-          if (va != 0.f) atomicAdd(a.gA + (int64_t)p * D + c, va);
-          if (vc != 0.f) atomicAdd(a.gC + (int64_t)p * D + c, vc);
+          if constexpr (STEP) {       // A = pref + rel and C = pref_norm + norm: the mixed-table gradient goes to both summands
+            if (va != 0.f) { atomicAdd(a.gP + (int64_t)p * D + c, va); if (a.gR) atomicAdd(a.gR + (int64_t)p * D + c, va); }
+            if (vc != 0.f) { atomicAdd(a.gPn + (int64_t)p * D + c, vc); if (a.gRn) atomicAdd(a.gRn + (int64_t)p * D + c, vc); }
+          } else {
+            if (va != 0.f) atomicAdd(a.gA + (int64_t)p * D + c, va);
+            if (vc != 0.f) atomicAdd(a.gC + (int64_t)p * D + c, vc);
+          }
         }
       }
+  if constexpr (STEP) {
+    lpart = group_sum<64>(lpart);
+    if (lane == 0 && lpart != 0.f) atomicAdd(a.loss, lpart * (1.f / (float)a.B));
+  }
 }
 
-template <typename G, bool ROWOUT>
+template <typename G, bool ROWOUT, bool STEP>
 int launch_r(const WArgs& a, hipStream_t st, const char* name) {
   static_assert(G::LDS <= 160 * 1024, "LDS budget");
-  (void)hipFuncSetAttribute((const void*)pref_bwd_wide_kernel<G, ROWOUT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS);
-  const int64_t ntiles = (a.n + 15) / 16;
-  const int grid = grid_for(ntiles, 256);                  // one workgroup (4 waves) per CU: the LDS footprint allows no more
-  hipLaunchKernelGGL((pref_bwd_wide_kernel<G, ROWOUT>), dim3(grid), dim3(256), G::LDS, st, a);
+  (void)hipFuncSetAttribute((const void*)pref_bwd_wide_kernel<G, ROWOUT, STEP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS);
+  const int64_t ntiles = STEP ? (a.B + 7) / 8 : (a.n + 15) / 16;
+  // d = 256: one workgroup (4 waves) per CU is all the LDS allows; narrower tables: two or three fit
+  const int per_cu = (int)((160 * 1024) / G::LDS) < 1 ? 1 : (int)((160 * 1024) / G::LDS);
+  const int grid = grid_for(ntiles, 256 * per_cu) + ((STEP && a.orth) ? 1 : 0);
+  hipLaunchKernelGGL((pref_bwd_wide_kernel<G, ROWOUT, STEP>), dim3(grid), dim3(256), G::LDS, st, a);
   return check_launch(name);
 }
 
 template <typename G>
 int launch(const WArgs& a, hipStream_t st, const char* name) {
-  return a.GU ? launch_r<G, true>(a, st, name) : launch_r<G, false>(a, st, name);
+  if (a.loss) return launch_r<G, false, true>(a, st, name);
+  return a.GU ? launch_r<G, true, false>(a, st, name) : launch_r<G, false, false>(a, st, name);
 }
 
-template <int NP>
+template <int NCH, int CTW, int NP>
 int launch_e(const WArgs& a, hipStream_t st, const char* name) {
   if (a.gumbel != KTUP_GUMBEL_OFF) {
-    if (a.E) return launch<WGeom<NP, true, true>>(a, st, name);
-    return launch<WGeom<NP, false, true>>(a, st, name);
+    if (a.E) return launch<WGeom<NCH, CTW, NP, true, true>>(a, st, name);
+    return launch<WGeom<NCH, CTW, NP, false, true>>(a, st, name);
   }
-  if (a.E) return launch<WGeom<NP, true, false>>(a, st, name);
-  return launch<WGeom<NP, false, false>>(a, st, name);
+  if (a.E) return launch<WGeom<NCH, CTW, NP, true, false>>(a, st, name);
+  return launch<WGeom<NCH, CTW, NP, false, false>>(a, st, name);
+}
+
+// P <= 20 everywhere (NP in {4, 5}); the narrower widths also take P <= 32 (NP = 8), which d = 256 has no LDS for
+int launch_d(const WArgs& a, int d, int np, hipStream_t st, const char* name) {
+  if (d == 256) {
+    if (np <= 4) return launch_e<64, 4, 4>(a, st, name);
+    if (np <= 5) return launch_e<64, 4, 5>(a, st, name);
+    return 1;
+  }
+  if (d == 64) {
+    if (np <= 4) return launch_e<16, 1, 4>(a, st, name);
+    if (np <= 5) return launch_e<16, 1, 5>(a, st, name);
+    return launch_e<16, 1, 8>(a, st, name);
+  }
+  if (d == 100) {
+    if (np <= 4) return launch_e<25, 2, 4>(a, st, name);
+    if (np <= 5) return launch_e<25, 2, 5>(a, st, name);
+    return launch_e<25, 2, 8>(a, st, name);
+  }
+  if (d == 128) {
+    if (np <= 4) return launch_e<32, 2, 4>(a, st, name);
+    if (np <= 5) return launch_e<32, 2, 5>(a, st, name);
+    return launch_e<32, 2, 8>(a, st, name);
+  }
+  return 1;
 }
 
 }  // namespace
 
-// Returns KTUP_OK / an error, or 1 when the shape is not covered (the caller runs pref_bwd_kernel).
+// Returns KTUP_OK / an error, or 1 when the shape is not covered (the caller runs another kernel).
 int pref_bwd_mc_wide(const float* U, int64_t ldu, const float* I, int64_t ldi, const float* E, int64_t lde, const int32_t* item2ent,
                      int64_t ent_pad, const float* Alog, const float* Ar, const float* Cn, int dp, float beta, int n_pref, int d,
                      const int64_t* u_ids, const int64_t* i_ids, int64_t n, int l1, int gumbel_mode, const float* uniform, uint64_t seed,
                      uint64_t offset, const float* gscore, float* gU, float* gI, float* gE, float* gA, float* gC, hipStream_t st,
                      const char* name, float* GU, float* GV) {
-  if (d != 256 || n_pref > 20) return 1;                   // LDS: (P + 1) table rows x 3 next to the four waves' tiles
+  if (n_pref > 32) return 1;
   if ((ldu | ldi | lde) & 3) return 1;
   if ((ldu >> 2) > 0xffffffffll || (ldi >> 2) > 0xffffffffll || (lde >> 2) > 0xffffffffll) return 1;
-  WArgs a;
+  WArgs a{};
   a.U = reinterpret_cast<const v4*>(U); a.I = reinterpret_cast<const v4*>(I); a.E = reinterpret_cast<const v4*>(E);
   a.ldu4 = (uint32_t)(ldu >> 2); a.ldi4 = (uint32_t)(ldi >> 2); a.lde4 = (uint32_t)(lde >> 2);
   a.item2ent = item2ent;
@@ -456,9 +601,31 @@ int pref_bwd_mc_wide(const float* U, int64_t ldu, const float* I, int64_t ldi, c
   a.gscore = gscore; a.gU = gU; a.gI = gI; a.gE = gE; a.gA = gA; a.gC = gC;
   a.GU = GU; a.GV = GV;
   a.gumbel = gumbel_mode; a.uniform = uniform; a.seed = seed; a.offset = offset;
-  const int np = (n_pref + 3) / 4;
-  if (np <= 4) return launch_e<4>(a, st, name);
-  return launch_e<5>(a, st, name);
+  return launch_d(a, d, (n_pref + 3) / 4, st, name);
+}
+
+// The rec half of a B = 512 training step in one launch (STEP kernels above; see ktup_train_step.hip).  Returns 1 for shapes
+// without a fused kernel (the caller keeps its multi-launch route).
+int pref_step_mc(const float* U, int64_t ldu, const float* I, int64_t ldi, const float* E, int64_t lde, const int32_t* item2ent,
+                 int64_t ent_pad, const float* pref, const float* pnorm, const float* rel, const float* norm, int64_t ldp, int n_pref,
+                 int d, const int64_t* u_ids, const int64_t* i_ids, int64_t B, int l1, int gumbel_mode, const float* uniform,
+                 uint64_t seed, uint64_t offset, float target, float gscale, int orth, float* loss, float* gU, float* gI, float* gE,
+                 float* gP, float* gPn, float* gR, float* gRn, double* sumsq_zero, hipStream_t st, const char* name) {
+  if (n_pref > 32 || (d == 256 && n_pref > 20)) return 1;
+  if ((ldu | ldi | lde | ldp) & 3) return 1;
+  if ((ldu >> 2) > 0xffffffffll || (ldi >> 2) > 0xffffffffll || (lde >> 2) > 0xffffffffll) return 1;
+  WArgs a{};
+  a.U = reinterpret_cast<const v4*>(U); a.I = reinterpret_cast<const v4*>(I); a.E = reinterpret_cast<const v4*>(E);
+  a.ldu4 = (uint32_t)(ldu >> 2); a.ldi4 = (uint32_t)(ldi >> 2); a.lde4 = (uint32_t)(lde >> 2);
+  a.item2ent = item2ent;
+  a.P = n_pref; a.l1 = l1; a.beta = rel ? 0.5f : 1.0f;
+  a.u_ids = u_ids; a.i_ids = i_ids; a.n = 2 * B; a.ent_pad = ent_pad;
+  a.gU = gU; a.gI = gI; a.gE = gE;
+  a.gumbel = gumbel_mode; a.uniform = uniform; a.seed = seed; a.offset = offset;
+  a.pref = pref; a.pnorm = pnorm; a.rel = rel; a.norm = norm; a.ldp = ldp; a.B = B;
+  a.target = target; a.gscale = gscale; a.loss = loss; a.gP = gP; a.gPn = gPn; a.gR = gR; a.gRn = gRn; a.orth = orth;
+  a.sumsq_zero = sumsq_zero;
+  return launch_d(a, d, (n_pref + 3) / 4, st, name);
 }
 
 }  // namespace ktup

@@ -4,7 +4,7 @@
 // loss, backward, regularisers, gradient fan-out, zero-fills): 0.085 ms per step with the device idle most of the time.
 //
 //   rec step (knowledgable_recommendation.py:335-344, item_recommendation.py:160-182):
-//       bprLoss(pos, neg, target) + orthogonalLoss(pref, pref_norm)            -> STEP kernels of ktup_score_pref_bwd_mc.hip
+//       bprLoss(pos, neg, target) + orthogonalLoss(pref, pref_norm)            -> STEP kernels of ktup_score_pref_bwd_wide.hip
 //   kg step  (knowledgable_recommendation.py:345-382, knowledge_representation.py:176-204), TransH / TransE:
 //       marginLoss(pos, neg, margin) + orthogonalLoss(rel, norm)[rel ids] + normLoss(ent)[h, t of pos and neg] + normLoss(rel)[rel ids]
 //                                                                              -> kg_step_kernel below
@@ -153,7 +153,7 @@ int launch_kg(const KgStepArgs& a, hipStream_t st, const char* name) {
 
 // 1 = this (step kind, d, n_pref) has a fused kernel; 0 = keep the multi-launch step.  kind: 0 rec (TUP / KTUP), 1 kg TransH, 2 kg TransE
 extern "C" int ktup_train_step_supported(int kind, int d, int n_pref) {
-  if (kind == 0) return (d == 64 || d == 100 || d == 128) && n_pref > 0 && n_pref <= 32 && opt_pref_mc();
+  if (kind == 0) return n_pref > 0 && ((d == 256 && n_pref <= 20) || ((d == 64 || d == 100 || d == 128) && n_pref <= 32)) && opt_pref_mc();
   if (kind == 1 || kind == 2) return d > 0 && d % 4 == 0 && d <= 256;
   return 0;
 }

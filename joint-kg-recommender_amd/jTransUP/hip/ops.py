@@ -485,6 +485,8 @@ def topk_filtered(scores, descending, topn, filt_off=None, filt_ids=None, with_s
     if scores.dtype != torch.float32 or scores.dim() != 2 or scores.stride(1) != 1:
         raise L.KtupError('scores must be a 2-D fp32 device matrix with unit inner stride')
     nq, nc = scores.shape
+    if filt_ids is not None and filt_ids.numel() == 0:       # an empty id list has no storage to point at: same as no filter
+        filt_off = filt_ids = None
     top = torch.empty(nq, topn, dtype=torch.int32, device=dev)
     ts = torch.empty(nq, topn, dtype=torch.float32, device=dev) if with_scores else None
     L.call('ktup_eval_topk_filtered', _p(scores), scores.stride(0), nq, nc, int(bool(descending)), _p(filt_off), _p(filt_ids),
@@ -499,6 +501,8 @@ def gold_ranks(scores, descending, gold_off, gold_ids, filt_off=None, filt_ids=N
     if scores.dtype != torch.float32 or scores.dim() != 2 or scores.stride(1) != 1:
         raise L.KtupError('scores must be a 2-D fp32 device matrix with unit inner stride')
     nq, nc = scores.shape
+    if filt_ids is not None and filt_ids.numel() == 0:
+        filt_off = filt_ids = None
     ranks = torch.empty(gold_ids.numel(), dtype=torch.int32, device=dev)
     L.call('ktup_eval_gold_ranks', _p(scores), scores.stride(0), nq, nc, int(bool(descending)), _p(filt_off), _p(filt_ids),
            _p(gold_off), _p(gold_ids), _p(ranks), _stream(dev))
@@ -513,6 +517,8 @@ def gold_rank_counts(local_scores, cand_lo, descending, gold_off, gold_ids, gold
     if local_scores.dtype != torch.float32 or local_scores.dim() != 2 or (local_scores.shape[1] and local_scores.stride(1) != 1):
         raise L.KtupError('scores must be a 2-D fp32 device matrix with unit inner stride')
     nq, nl = local_scores.shape
+    if filt_ids is not None and filt_ids.numel() == 0:
+        filt_off = filt_ids = None
     counts = torch.empty(gold_ids.numel(), dtype=torch.int32, device=dev)
     L.call('ktup_eval_gold_rank_counts', _p(local_scores) if nl else None, local_scores.stride(0) if nl else 0, nq, nl, int(cand_lo),
            int(bool(descending)), _p(filt_off), _p(filt_ids), _p(gold_off), _p(gold_ids), _p(gold_scores.contiguous()), _p(counts),

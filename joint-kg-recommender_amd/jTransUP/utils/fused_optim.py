@@ -14,6 +14,7 @@ import torch.optim as optim
 from jTransUP.hip import lib as L
 
 MAX_TENSORS = 12
+GRADNORM_WS_DOUBLES = 136                       # KTUP_GRADNORM_WS_DOUBLES of include/ktup_hip.h
 KINDS = {optim.SGD: 0, optim.Adagrad: 1, optim.Adam: 2, optim.RMSprop: 3}
 
 
@@ -95,7 +96,7 @@ class FusedOptimizer(object):
     def sumsq_ptr(self, dev):
         """Device double the gradient norm accumulates into; the fused step kernels zero it for the launch that follows."""
         if self._sumsq is None or self._sumsq.device != dev:
-            self._sumsq = torch.zeros(1, dtype=torch.float64, device=dev)
+            self._sumsq = torch.zeros(GRADNORM_WS_DOUBLES, dtype=torch.float64, device=dev)   # [0] = the norm; the rest: slot / ticket scratch
         return self._sumsq.data_ptr()
 
     @torch.no_grad()
@@ -190,4 +191,4 @@ class FusedOptimizer(object):
 
     def total_norm(self):
         """Gradient norm of the last clipped step (device -> host sync; diagnostics only)."""
-        return None if self._sumsq is None else float(self._sumsq.sqrt().item())
+        return None if self._sumsq is None else float(self._sumsq[0].sqrt().item())

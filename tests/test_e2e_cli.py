@@ -90,6 +90,19 @@ def test_joint_cli_training_routes(dataset, mode, monkeypatch):
     assert len(re.findall(r'f1:\d\.\d+', log)) >= 3 and len(re.findall(r'avg hit:', log)) >= 3
 
 
+@pytest.mark.parametrize('model', ['cke', 'cfkg'])
+def test_joint_cli_baselines(dataset, model):
+    """The reference baselines that reuse the accelerated kernels run through the joint driver: CKE (own item / entity tables,
+    BPRMF + TransR) and CFKG (shared item-entity table, TransE + "buy" relation; -share_embeddings is forced like the reference)."""
+    log, logs = run_cli('run_knowledgable_recommendation.py', dataset, 'joint-' + model,
+                        ['-model_type', model, '-rec_test_files', 'valid.dat', '-kg_test_files', 'valid.dat', '-joint_ratio', '0.5',
+                         '-embedding_size', '36'])
+    losses = [float(x) for x in re.findall(r'rec train loss:(\d+\.\d+)', log)]
+    assert len(losses) >= 2 and all(l == l and l < 1e4 for l in losses)
+    assert len(re.findall(r'f1:\d\.\d+', log)) >= 3 and len(re.findall(r'avg hit:', log)) >= 3
+    assert os.path.isfile(os.path.join(logs, 'joint-' + model + '.ckpt'))
+
+
 def test_joint_cli_data_parallel_torchrun(dataset):
     """torchrun with two ranks (gloo test hook: they share this box's GPU): both replicas log the same metrics."""
     data = str(dataset)

@@ -249,13 +249,42 @@ def eval_bench(device, batch=512, seed=11, keep=None):
         rows = one_pass(True)
     full_ms = 1e3 * (time.perf_counter() - t0) / reps
     hit = float(rows[:, 3].mean())
+    # the whole pass in one sweep (what the drivers run): item side, users' projections + fused scores / filtered top-10 (no
+    # score matrix), merge, per-user metrics, one copy back
+    all_u = torch.arange(NU, dtype=torch.long, device=device)
+
+    def fused_pass():
+        items = m.prepare_items()
+        top = m.evaluate_topk(all_u, items, 10, index.f_off, index.f_ids)
+        return RK.ops.rec_metrics(top, index.g_off, index.g_ids).cpu().numpy()
+    fused = None
+    if m.evaluate_topk(all_u[:64], m.prepare_items(), 10) is not None:
+        rows_f = fused_pass()
+        t0 = time.perf_counter()
+        for _ in range(reps * 4):
+            rows_f = fused_pass()
+        fused_ms = 1e3 * (time.perf_counter() - t0) / (reps * 4)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        items = m.prepare_items()
+        a.record()
+        for _ in range(20):
+            m.evaluate_topk(all_u, items, 10, index.f_off, index.f_ids)
+        b.record(); torch.cuda.synchronize(device)
+        sweep_ms = a.elapsed_time(b) / 20
+        flop = 6 * 2.0 * NU * NI * D
+        fused = {'full_pass_ms_incl_metrics': fused_ms, 'device_ms_scores_and_topk': sweep_ms,
+                 'gemm_tflops_over_sweep': flop / (sweep_ms * 1e-3) / 1e12, 'gemm_frac_of_fp32_peak': flop / (sweep_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
+                 'rows_equal_batched_route': bool(np.array_equal(rows_f, rows))}
+        rows = rows_f
     if keep is not None:                              # for the CPU side-by-side, run after every GPU timing (main)
         keep.update(m=m, users=users, gold=gold, train=train, rows=rows)
     return {'users': NU, 'items': NI, 'batch': batch, 'batches': len(batches), 'topn': 10,
-            'device_ms_full_pass': dev_ms, 'device_ms_per_batch': dev_ms / len(batches),
-            'full_pass_ms_incl_metrics': full_ms, 'filter_index_build_ms': 1e3 * t_index, 'hit_at_10_random_init': hit,
-            'note': 'scores (K16) + filtered top-10 (K17) + f1/p/r/hit/ndcg per user (K18b) on the device, one (users x 5) float64 '
-                    'copy back per pass (the training-time evaluation path; the filter index is built once per run)'}
+            'full_pass_ms': fused['full_pass_ms_incl_metrics'] if fused else full_ms, 'fused_pass': fused,
+            'batched_route': {'device_ms_full_pass': dev_ms, 'device_ms_per_batch': dev_ms / len(batches), 'full_pass_ms_incl_metrics': full_ms},
+            'filter_index_build_ms': 1e3 * t_index, 'hit_at_10_random_init': hit,
+            'note': 'fused_pass: item side (1 launch), users projections + scores + filtered top-10 in one sweep without the score '
+                    'matrix (ktup_eval_pref_topk_prepared), per-user f1/p/r/hit/ndcg on the device (K18b), one (users x 5) float64 copy '
+                    'back; batched_route: round 1 shape -- 12 batches of 512 users x (K16 matrix + K17 + K18b). The filter index is built once per run'}
 
 
 def cpu_eval_baseline(m, users, gold, train, gpu_rows, budget_s=8.0, cb=32):

@@ -72,6 +72,8 @@ SIGNATURES = {
     'ktup_eval_pref_items_workspace_bytes': [c_i, c_i, c_l],
     'ktup_eval_pref_items_prepare': [c_p, c_l, c_p, c_l, c_p, c_p, c_i, c_i, c_l, c_p, c_p],
     'ktup_eval_pref_scores_prepared': [c_p, c_l, c_p, c_i, c_i, c_p, c_l, c_l, c_i, c_i, c_p, c_u, c_u, c_p, c_l, c_p, c_p, c_p],
+    'ktup_eval_pref_topk_workspace_bytes': [c_i, c_i, c_l, c_i],
+    'ktup_eval_pref_topk_prepared': [c_p, c_l, c_p, c_i, c_i, c_p, c_l, c_l, c_i, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p],
     'ktup_eval_topk_filtered': [c_p, c_l, c_l, c_l, c_i, c_p, c_p, c_i, c_p, c_p, c_p],
     'ktup_eval_gold_rank_counts': [c_p, c_l, c_l, c_l, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
     'ktup_eval_gold_ranks': [c_p, c_l, c_l, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_p],
@@ -95,7 +97,8 @@ SIGNATURES = {
 _RESTYPE = {'ktup_last_error': ctypes.c_char_p, 'ktup_pref_workspace_bytes': ctypes.c_size_t,
             'ktup_eval_kg_workspace_bytes': ctypes.c_size_t, 'ktup_eval_transr_workspace_bytes': ctypes.c_size_t, 'ktup_score_transr_workspace_bytes': ctypes.c_size_t,
             'ktup_eval_pref_workspace_bytes': ctypes.c_size_t, 'ktup_eval_pref_items_workspace_bytes': ctypes.c_size_t, 'ktup_negsample_rec_workspace_bytes': ctypes.c_size_t,
-            'ktup_score_pref_bwd_workspace_bytes': ctypes.c_size_t, 'ktup_segment_workspace_bytes': ctypes.c_size_t, 'ktup_shard_dedupe_workspace_bytes': ctypes.c_size_t}
+            'ktup_score_pref_bwd_workspace_bytes': ctypes.c_size_t, 'ktup_segment_workspace_bytes': ctypes.c_size_t, 'ktup_shard_dedupe_workspace_bytes': ctypes.c_size_t,
+            'ktup_eval_pref_topk_workspace_bytes': ctypes.c_size_t}
 
 _lib = None
 
@@ -127,6 +130,14 @@ def call(name, *args):
     rc = getattr(lib, name)(*args)
     if rc != 0:
         raise KtupError('%s failed (%d): %s' % (name, rc, lib.ktup_last_error().decode('utf-8', 'replace')))
+
+
+def get_option(name):
+    lib = load()
+    val = ctypes.c_int(0)
+    if lib.ktup_get_option(name.encode(), ctypes.byref(val)) != 0:
+        raise KtupError(lib.ktup_last_error().decode('utf-8', 'replace'))
+    return val.value
 
 
 def set_option(name, value):

@@ -24,8 +24,9 @@ def evaluate(FLAGS, model, eval_iter, eval_dict, all_dicts, logger, eval_descend
         items = model.prepare_items()
         score_fn = lambda u: model.evaluate(u, items=items)
     from jTransUP.models._shard_eval import rec_shard_fn
+    pass_fn = (lambda u, fo, fi, n: model.evaluate_topk(u, items, n, fo, fi)) if hasattr(model, 'evaluate_topk') else None
     results = D.rec_eval_pass(FLAGS, score_fn, eval_iter, eval_dict, all_dicts, eval_descending, want_rows=is_report,
-                              shard=rec_shard_fn(model))
+                              shard=rec_shard_fn(model), pass_fn=pass_fn)
     perf = D.summarize_rec(FLAGS, results, logger)
     if is_report:
         D.report_rec(FLAGS, model, results, all_dicts, eval_dict, logger, FLAGS.model_type in ('transup', 'jtransup', 'cjtransup'))

@@ -113,6 +113,13 @@ class jTransUPModel(nn.Module, GradToggle):
                                                             u_ids.numel() * I.shape[0] * P.shape[0])
         return ops.eval_ktup(U, I, E, P, Pn, R, Rn, item2ent, u_ids, self.L1_flag, mode, uni, seed, off, items=items)
 
+    def evaluate_topk(self, u_ids, items, topn, filt_off=None, filt_ids=None):
+        """K16 + K17 for a whole evaluation pass in one sweep (this build): filtered top-n item ids of every user of `u_ids`
+        without the (users x items) matrix.  None when the fused pass does not apply (ST-Gumbel gate, L1, unsupported width)."""
+        if self.use_st_gumbel:
+            return None
+        return ops.eval_pref_topk(self.user_embeddings.weight, u_ids, items, self.L1_flag, topn, filt_off, filt_ids)
+
     def prepare_items(self, all_i_ids=None):
         """Item side of `evaluateRec` (item + entity rows through the preference gate), to share between the batches of a pass."""
         _, _, E, P, Pn, R, Rn = self._rec_tables()

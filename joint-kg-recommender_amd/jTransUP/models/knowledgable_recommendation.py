@@ -50,8 +50,10 @@ def evaluateRec(FLAGS, model, eval_iter, eval_dict, all_dicts, i_map, logger, ev
     score_fn = (lambda u: model.evaluateRec(u, all_i_ids=all_i_var, items=items)) if items is not None \
         else (lambda u: model.evaluateRec(u, all_i_ids=all_i_var))
     from jTransUP.models._shard_eval import rec_shard_fn
+    pass_fn = (lambda u, fo, fi, n: model.evaluate_topk(u, items, n, fo, fi)) \
+        if items is not None and hasattr(model, 'evaluate_topk') and not FLAGS.share_embeddings else None
     results = D.rec_eval_pass(FLAGS, score_fn, eval_iter, eval_dict, all_dicts, eval_descending, want_rows=is_report,
-                              shard=rec_shard_fn(model))
+                              shard=rec_shard_fn(model), pass_fn=pass_fn)
     perf = D.summarize_rec(FLAGS, results, logger)
     if is_report:
         D.report_rec(FLAGS, model, results, all_dicts, eval_dict, logger, FLAGS.model_type in ('transup', 'jtransup'))

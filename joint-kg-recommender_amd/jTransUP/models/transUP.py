@@ -51,6 +51,13 @@ class TransUPModel(nn.Module, GradToggle):
                                                             u_ids.numel() * I.shape[0] * P.shape[0])
         return ops.eval_tup(U, I, P, Pn, u_ids, self.L1_flag, mode, uni, seed, off, items=items)
 
+    def evaluate_topk(self, u_ids, items, topn, filt_off=None, filt_ids=None):
+        """K15 + K17 for a whole evaluation pass in one sweep (this build): filtered top-n item ids of every user of `u_ids`
+        without the (users x items) matrix.  None when the fused pass does not apply (ST-Gumbel gate, L1, unsupported width)."""
+        if self.use_st_gumbel:
+            return None
+        return ops.eval_pref_topk(self.user_embeddings.weight, u_ids, items, self.L1_flag, topn, filt_off, filt_ids)
+
     def prepare_items(self):
         """Item side of `evaluate` (the item projections of the preference gate), to share between the batches of a pass."""
         U, I, P, Pn = self._tables()

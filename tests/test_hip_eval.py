@@ -391,3 +391,48 @@ def test_prepared_item_side_gives_the_same_scores(l1, gum):
             a = fn(m, u, uniform=uni)
             b = fn(m, u, uniform=uni, items=items)
             assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('d,nu,ni,nq,topn', [(100, 6040, 3240, 6040, 10), (64, 300, 177, 65, 32), (128, 90, 16, 1, 3), (100, 70, 5, 63, 10),
+                                             (100, 500, 1000, 129, 1)])
+def test_fused_pass_topk_equals_matrix_route(d, nu, ni, nq, topn):
+    """ktup_eval_pref_topk_prepared (scores + filtered top-n of a whole pass in one sweep, no score matrix) against the matrix
+    route (ktup_eval_pref_scores_prepared + ktup_eval_topk_filtered): the ranked ids are integer results and must be identical,
+    and so must the scores (same MFMA k order and epilogue).  KTUP and TUP; per-user filters incl. empty and everything."""
+    gen = torch.Generator().manual_seed(d + ni)
+    P, ne = 20, 200
+    mk = lambda r: O.make_table(r, d, gen).to(DEV)
+    U, I, E, Pm, Pn, R, Rn = mk(nu), mk(ni), torch.cat([O.make_table(ne, d, gen), torch.zeros(1, d)]).to(DEV), mk(P), mk(P), mk(P), mk(P)
+    i2e = torch.randint(0, ne + 1, (ni,), generator=gen).to(DEV, torch.int32)
+    u = torch.randperm(nu, generator=gen)[:nq].to(DEV) if nq <= nu else torch.arange(nu).to(DEV)
+    rng = np.random.RandomState(ni)
+    filt = [np.sort(rng.choice(ni, size=min(ni, int(rng.randint(0, 170))), replace=False)).astype(np.int32) for _ in range(len(u))]
+    if len(filt) > 2:
+        filt[1] = np.arange(ni, dtype=np.int32)                              # everything filtered -> all -1
+        filt[2] = np.zeros(0, np.int32)
+    f_off = dv(np.concatenate([[0], np.cumsum([len(f) for f in filt])]).astype(np.int64))
+    f_ids = dv(np.concatenate(filt).astype(np.int32)) if sum(len(f) for f in filt) else torch.zeros(0, dtype=torch.int32, device=DEV)
+    for ktup in (True, False):
+        items = ops().eval_pref_items(I, E if ktup else None, Pm, Pn, R if ktup else None, Rn if ktup else None, i2e if ktup else None)
+        got = ops().eval_pref_topk(U, u, items, False, topn, f_off, f_ids, with_scores=True)
+        assert got is not None
+        want_ids, want_sc = [], []
+        for s in range(0, len(u), 512):
+            ub = u[s:s + 512]
+            if ktup:
+                mat = ops().eval_ktup(U, I, E, Pm, Pn, R, Rn, i2e, ub, False, items=items)
+            else:
+                mat = ops().eval_tup(U, I, Pm, Pn, ub, False, items=items)
+            lo = int(f_off[s])
+            fo = f_off[s:s + len(ub) + 1] - lo
+            a, b = ops().topk_filtered(mat, False, topn, fo, f_ids[lo:], with_scores=True)
+            want_ids.append(a); want_sc.append(b)
+        want_ids, want_sc = torch.cat(want_ids), torch.cat(want_sc)
+        assert torch.equal(got[0], want_ids)
+        assert torch.equal(got[1], want_sc)
+        if len(filt) > 2:
+            assert got[0][1].tolist() == [-1] * topn
+        nf = ops().eval_pref_topk(U, u, items, False, topn)                   # no filter at all
+        mat = ops().eval_ktup(U, I, E, Pm, Pn, R, Rn, i2e, u[:64], False, items=items) if ktup else ops().eval_tup(U, I, Pm, Pn, u[:64], False, items=items)
+        assert torch.equal(nf[:64], ops().topk_filtered(mat, False, topn))
+    assert ops().eval_pref_topk(U, u, items, True, topn) is None              # L1 does not decompose: the caller keeps the matrix route

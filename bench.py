@@ -483,6 +483,143 @@ def hbm_traffic(kind, tag=None):
     return None, 'no profiles/*_hbm_traffic.json'
 
 
+def _max_over_ranks(x, device, world):
+    t = torch.tensor([x], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def dp_train_leg(device, world, rank, steps=100, warmup=20):
+    """BASELINE config 4 on N GPUs: the KTUP joint training step (ml1m shape, d=100, 7 rec : 3 kg, Adagrad + weight decay + clip)
+    as data-parallel replicas -- every rank holds all tables, scores its slice of the global batch, ONE all-reduce of the flat
+    gradient bucket (9.7 MB), then the identical clip + step (utils/fast_train.py JointStepper).  Weak scaling = global batch
+    512 x N, strong = 512.  The comm / compute split: the same per-rank work without the exchange (a one-rank group: HIP-graph
+    replay) and the bucket all-reduce alone."""
+    import types
+    from jTransUP.models import jTransUP as jt
+    from jTransUP.utils.fast_train import JointStepper
+    from jTransUP.utils.fused_optim import FusedOptimizer
+    solo = None
+    if world > 1:
+        groups = [dist.new_group([r]) for r in range(world)]          # every rank creates every group (collective call)
+        solo = groups[rank]
+    i_map = {i: i for i in range(NI)}
+    new_map = {i: ((i * 4) % NE if i < ALIGNED else -1, i) for i in range(NI)}
+    fl = types.SimpleNamespace(margin=1.0, kg_lambda=1.0, clipping_max_value=5.0)
+    out = {'backend': dist.get_backend() if world > 1 else 'single process', 'world': world}
+
+    def run(GB, group):
+        torch.manual_seed(3)
+        m = jt.jTransUPModel(False, D, NU, NI, NE, NR, i_map, new_map, False, False)
+        opt = torch.optim.Adagrad(m.parameters(), lr=0.005, weight_decay=1e-5)
+        tr = types.SimpleNamespace(fused=FusedOptimizer(opt), parameters=list(m.parameters()), model_target=-1, step=0)
+        js = JointStepper(m, tr, fl, GB, group=group)
+        gen = torch.Generator().manual_seed(5)                        # every rank draws the same global batches
+        mk = lambda hi: torch.randint(0, hi, (steps + warmup, GB), generator=gen).to(device)
+        u, pi, ni_, h, t, nh, nt, r = mk(NU), mk(NI), mk(NI), mk(NE), mk(NE), mk(NE), mk(NE), mk(NR)
+
+        def fstep(s):
+            if s % 10 < 7:
+                js.rec_step(u[s], pi[s], ni_[s])
+            else:
+                js.kg_step(h[s], t[s], r[s], nh[s], nt[s], r[s])
+        for s in range(warmup):
+            fstep(s)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for s in range(warmup, warmup + steps):
+            fstep(s)
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+        return _max_over_ranks(1e3 * (time.perf_counter() - t0) / steps, device, world), js
+
+    for name, GB in (('weak', 512 * world), ('strong', 512)):
+        if GB % world:
+            continue
+        ms, js = run(GB, None)
+        leg = {'global_batch': GB, 'per_rank_batch': GB // world, 'ms_per_step': ms, 'scored_rows_per_s': 2 * GB / (ms * 1e-3),
+               'bucket_MB': js.flat.numel() * 4 / 1e6}
+        if world > 1:
+            leg['ms_per_step_compute_only'], _ = run(GB // world, solo)      # same per-rank work, no exchange (graph replay)
+            flat = js.flat
+            for _ in range(5):
+                dist.all_reduce(flat)
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            for _ in range(50):
+                dist.all_reduce(flat)
+            torch.cuda.synchronize(device)
+            leg['ms_allreduce_only'] = _max_over_ranks(1e3 * (time.perf_counter() - t0) / 50, device, world)
+        out[name] = leg
+    out['note'] = ('replicas + ONE all-reduce of the flat gradient bucket per step; at ml1m scale every step touches ~20 % of the '
+                   'rows, so an all-gather of (ids, row gradients) would move as many bytes as the dense bucket under weak scaling')
+    return out
+
+
+def config5_leg(device, world, rank, steps=10, warmup=3, batch=8192, full=True):
+    """BASELINE config 5: KTUP at d=256 on 10 M users x 1 M items x 5 M entities, tables row-sharded over the N ranks
+    (row % N), B = 8192 (u, pos, neg) per rank and step: device-side dedupe, ONE id and ONE row all-to-all for the three
+    tables, the matrix-core scorer on the compact tables, row gradients back in ONE all-to-all, global clip, row-sparse Adagrad
+    (parallel.ShardedStep).  With fewer than 8 ranks the same tables simply give bigger shards (16.4 GB of tables + as much
+    optimizer state in total)."""
+    from jTransUP import parallel
+    from jTransUP.hip import ops
+    d, P, B = 256, 20, batch
+    NUs, NIs, NEs = (10_000_000, 1_000_000, 5_000_000) if full else (1_250_000 * world, 125_000 * world, 625_000 * world)
+    free, _ = torch.cuda.mem_get_info(device)
+    need = 2.2 * (NUs + NIs + NEs) * d * 4 / world
+    if free < need:
+        return {'skipped': 'needs %.1f GB of device memory per rank' % (need / 1e9)}
+    gen = torch.Generator(device=device); gen.manual_seed(3 + rank)
+
+    def table(n):
+        t = parallel.ShardedTable(n, d, rank=rank, world=world, device=device)
+        t.weight.data.normal_(generator=gen)
+        t.weight.data.mul_(1.0 / 16.0)                                 # rows of norm ~1 at d = 256
+        return t
+    Ut, It, Et = table(NUs), table(NIs), table(NEs)
+    small = [torch.nn.Parameter(torch.nn.functional.normalize(torch.randn(P, d, generator=gen, device=device), dim=1)) for _ in range(4)]
+    if world > 1:
+        for p in small:
+            dist.broadcast(p.data, src=0)
+    item2ent = torch.randint(0, NEs, (NIs,), generator=torch.Generator(device=device).manual_seed(7), device=device)
+    step = parallel.ShardedStep('adagrad', lr=0.005, max_norm=5.0)
+    times = {'lookup': 0.0, 'score_fwd_bwd': 0.0, 'apply': 0.0}
+
+    def tick():
+        torch.cuda.synchronize(device)
+        return time.perf_counter()
+    for s in range(steps + warmup):
+        u = torch.randint(0, NUs, (B,), generator=gen, device=device)
+        pi = torch.randint(0, NIs, (B,), generator=gen, device=device); ni = torch.randint(0, NIs, (B,), generator=gen, device=device)
+        if world > 1:
+            dist.barrier()
+        t0 = tick()
+        items = torch.cat([pi, ni])
+        (u_rows, u_at), (i_rows, i_at), (e_rows, e_at) = step.lookup_many([(Ut, u), (It, items), (Et, item2ent[items])])
+        t1 = tick()
+        i2e_c = torch.zeros(i_rows.shape[0], dtype=torch.int32, device=device)
+        i2e_c[i_at] = e_at.to(torch.int32)
+        score = ops.score_ktup(u_rows, i_rows, e_rows, *small, i2e_c, torch.cat([u_at, u_at]), i_at, False, ent_pad=-1)
+        (torch.nn.functional.softplus(score[:B] - score[B:]).mean() / world).backward()
+        t2 = tick()
+        step.apply(replicated=small)
+        t3 = tick()
+        if s >= warmup:
+            times['lookup'] += t1 - t0; times['score_fwd_bwd'] += t2 - t1; times['apply'] += t3 - t2
+    total = _max_over_ranks(sum(times.values()), device, world)
+    return {'backend': dist.get_backend() if world > 1 else 'single process', 'world': world, 'batch_per_rank': B,
+            'rows': {'users': NUs, 'items': NIs, 'entities': NEs}, 'd': d, 'tables_GB_per_rank': (NUs + NIs + NEs) * d * 4 / world / 1e9,
+            'ms_per_step': 1e3 * total / steps, 'ms_rank0': {k: 1e3 * v / steps for k, v in times.items()},
+            'scored_rows_per_s': 2 * B * world * steps / total,
+            'note': 'lookup = dedupe + (N > 1: one count, one id, one row all-to-all) + owner-side pack; apply = gradient rows back '
+                    '(one all-to-all), duplicate combine, one all-reduce (small tables + norm), row-sparse Adagrad on the touched rows'}
+
+
 def roofline(rec_ms, kg_ms):
     """The dominant kernel (K6, KTUP rec forward) against BOTH ceilings it could touch.  `achieved / frac` keep SURVEY 8(d)'s
     definition (ALGORITHMIC bytes per launch / HIP-event time / 8 TB/s); at ml1m shape the 9.7 MB of tables are L2 /
@@ -622,6 +759,17 @@ def main():
         out['eval_all_item_hit10']['cpu_baseline'] = cpu_eval_baseline(keep['m'], keep['users'], keep['gold'], keep['train'], keep['rows'])
     elif rank == 0:
         out['cpu_baseline'] = None
+    if not args.no_extras:
+        # the N-GPU legs the scoring headline cannot show (it has no exchange step): config 4's data-parallel training step and
+        # config 5's row-sharded step, each with its comm / compute split (every rank takes part; rank 0 reports)
+        legs = {}
+        for name, fn in (('dp_train_step', dp_train_leg), ('config5_step', config5_leg)):
+            try:
+                legs[name] = fn(device, world, rank)
+            except Exception as e:      # noqa: BLE001 -- a leg must not take the headline line down with it
+                legs[name] = {'error': '%s: %s' % (type(e).__name__, e)}
+        if rank == 0:
+            out.update(legs)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -236,10 +236,10 @@ int ktup_eval_pref_scores_prepared(const float* U, int64_t ldu, const float* pre
 /* K16 + K17 of a whole evaluation PASS fused (new): every user of `u_ids` against all items, filtered top-n, in one sweep that
  * never materialises the (users x items) matrix -- what jTransUP.py:163-191 + utils/misc.py:186-248 compute batch by batch.
  * Same scores (bit for bit) and the same (score, id) order as ktup_eval_pref_scores_prepared + ktup_eval_topk_filtered.
- * Soft gate, squared L2 (l1 == 0), d in {64, 100, 128}, topn <= 32; otherwise KTUP_ERR_UNSUPPORTED and the caller keeps the
+ * Soft gate, squared L2 (l1 == 0), d in {64, 100, 128}, topn <= 16; otherwise KTUP_ERR_UNSUPPORTED and the caller keeps the
  * per-batch pair of calls.  filt_off / filt_ids: CSR filter sets per user of u_ids (NULL = none); top_scores may be NULL.
  * `ws`: ktup_eval_pref_topk_workspace_bytes bytes, 16-byte aligned; `items_ws` from ktup_eval_pref_items_prepare.          */
-size_t ktup_eval_pref_topk_workspace_bytes(int d, int n_pref, int64_t nq, int topn);
+size_t ktup_eval_pref_topk_workspace_bytes(int d, int n_pref, int64_t nq, int64_t n_items, int topn);
 int ktup_eval_pref_topk_prepared(const float* U, int64_t ldu, const float* pref_ws, int n_pref, int d, const int64_t* u_ids,
                                  int64_t nq, int64_t n_items, int l1, const float* items_ws, const int64_t* filt_off,
                                  const int32_t* filt_ids, int topn, int32_t* top_ids, float* top_scores, float* ws, void* stream);

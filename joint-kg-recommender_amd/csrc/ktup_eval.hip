@@ -738,9 +738,9 @@ extern "C" int ktup_eval_pref_scores_prepared(const float* U, int64_t ldu, const
 // K16 + K17 for a whole evaluation pass in one sweep (ktup_eval_pass.hip): users' projections, then the fused score + filtered
 // top-n kernel -- no (users x items) matrix.  Soft gate + squared L2 at d in {64, 100, 128} only (KTUP_ERR_UNSUPPORTED otherwise:
 // the caller keeps ktup_eval_pref_scores_prepared + ktup_eval_topk_filtered per batch).
-extern "C" size_t ktup_eval_pref_topk_workspace_bytes(int d, int n_pref, int64_t nq, int topn) {
-  if (nq <= 0 || topn <= 0) return 0;
-  return ((size_t)nq * 3 * d + pad4((size_t)nq * n_pref)) * sizeof(float) + ktup::eval_pass_part_bytes(nq, topn);
+extern "C" size_t ktup_eval_pref_topk_workspace_bytes(int d, int n_pref, int64_t nq, int64_t n_items, int topn) {
+  if (nq <= 0 || topn <= 0 || n_items < 0) return 0;
+  return ((size_t)nq * 3 * d + pad4((size_t)nq * n_pref)) * sizeof(float) + ktup::eval_pass_part_bytes(nq, topn, n_items);
 }
 
 extern "C" int ktup_eval_pref_topk_prepared(const float* U, int64_t ldu, const float* pref_ws, int n_pref, int d,

@@ -12,11 +12,15 @@
 //     operand vectors in REGISTERS for the whole pass (the A operands: 18 float4 per lane at d = 100); items stream through a
 //     double-buffered 16-item LDS tile (the B operands, 19 KB per buffer) that the next tile's global loads refill under the
 //     MFMAs -- LDS stays at ~60 KB, two workgroups per CU;
-//   * ranking: every wave keeps a sorted top-n list (64-bit keys = order-preserving score image << 32 | item id, the order of
-//     ktup_rank.hip: ascending score, ties -> lower id) per user in LDS.  A score is a candidate only if its key beats the
-//     user's current n-th key and its bit in the wave's filter bitmap (built once from the CSR filter lists, for this
-//     workgroup's item split only: 16 users x (split / 32) words) is clear; candidates are rare after the first tiles
-//     (~n ln(N / n) per user) and are inserted one at a time by the whole wave;
+//   * ranking: a user's sorted top-n list (64-bit keys = order-preserving score image << 32 | item id, the order of
+//     ktup_rank.hip: ascending score, ties -> lower id) lives in REGISTERS, one element per lane of the 16-lane row that owns
+//     the user in the MFMA output layout (lane (kq, j) holds element j of users 4 kq + reg).  A score is a candidate only if its
+//     key beats the user's current n-th key and its bit in the wave's filter bitmap (built once from the CSR filter lists, for
+//     this workgroup's item split only: 16 users x (split / 32) words of LDS) is clear; candidates are rare after the first
+//     tiles (~n ln(N / n) per user).  The four rows insert their candidates in parallel: the shift of the sorted list is one DPP
+//     row_shr per half key, the position a popcount of a ballot -- no LDS round trip (the first version kept the lists in LDS
+//     and inserted one candidate per wave at a time: 830 us per ml1m pass, 3 LDS latencies per candidate);
+//   * item scalars (v.NV, |C0|^2, C0.NV, |NV|^2) are computed once per pass by a small kernel and travel with the tile;
 //   * the splits' partial lists are merged by a second, tiny launch (topk_merge_kernel).
 // L1 distance and the ST-Gumbel gate do not decompose into GEMMs: they keep the per-batch kernels of ktup_eval.hip.
 #include <hip/hip_runtime.h>
@@ -32,7 +36,7 @@ namespace {
 
 constexpr uint64_t PKEY_MAX = ~0ull;
 constexpr int IBT = 16;        // items per LDS tile
-constexpr int TOPN_MAX = 32;   // top-n list capacity per user
+constexpr int TOPN_MAX = 16;   // top-n list capacity per user: one element per lane of a 16-lane row
 
 KTUP_DEV uint64_t pass_key(float s, uint32_t id) {   // ktup_rank.hip make_key, ascending (lower score = better)
   if (s == 0.f) s = 0.f;
@@ -50,11 +54,12 @@ struct PGeom {
   static_assert(TAIL1 || NCH % 4 == 0, "k groups must be whole (d % 16 in {0, 4})");
   static constexpr int P4 = NCH | 1;                           // odd float4 row pitch of the item tile
   static constexpr int TILE_F4 = IBT * 3 * P4;
-  static constexpr int LPT = (IBT * 3 * NCH + 255) / 256;      // float4 loads per thread and tile
+  static constexpr int LPT = (IBT * 3 * NCH + IBT + 255) / 256;   // float4 loads per thread and tile (+ one scalar quad per item)
 };
 
 struct PassArgs {
   const float *QW, *C0, *C1, *C2;   // users: rows of 3 d floats [AU | u | NU]; items: three (n_items x d) arrays
+  const float* ISC;                 // [n_items][4] item scalars (item_scalars_kernel)
   int64_t nq, n_items;
   const int64_t* filt_off;          // CSR filter sets per user (global item ids); null = no filter
   const int32_t* filt_ids;
@@ -73,16 +78,15 @@ __global__ __launch_bounds__(256) void eval_pass_kernel(PassArgs a) {
   float* isc = reinterpret_cast<float*>(Xb + 2 * G::TILE_F4);             // [2][IBT][4] item scalars
   const int tid = threadIdx.x, lane = tid & 63, kq = lane >> 4, j = lane & 15;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  char* wbase = reinterpret_cast<char*>(isc + 2 * IBT * 4) + (size_t)w * ((size_t)16 * 4 * 4 + (size_t)16 * TOPN_MAX * 8 + (size_t)16 * a.bm_words * 4);
+  char* wbase = reinterpret_cast<char*>(isc + 2 * IBT * 4) + (size_t)w * ((size_t)16 * 4 * 4 + (size_t)16 * a.bm_words * 4);
   float* usc = reinterpret_cast<float*>(wbase);                           // [16][4] user scalars
-  uint64_t* tk = reinterpret_cast<uint64_t*>(usc + 64);                   // [16][TOPN_MAX] sorted keys
-  uint32_t* bm = reinterpret_cast<uint32_t*>(tk + 16 * TOPN_MAX);         // [16][bm_words] filter bits of this split
+  uint32_t* bm = reinterpret_cast<uint32_t*>(usc + 64);                   // [16][bm_words] filter bits of this split
+  uint64_t tkr[4] = {PKEY_MAX, PKEY_MAX, PKEY_MAX, PKEY_MAX};             // element j of the sorted top-n lists of users 4 kq + reg
   const int64_t u0 = (int64_t)blockIdx.x * 64 + 16 * w;                   // this wave's first user
   const int64_t i_lo = (int64_t)blockIdx.y * a.split_items;
   const int64_t i_hi = min(a.n_items, i_lo + a.split_items);
   const int topn = a.topn;
   // ---- per-wave setup: top-n lists, filter bitmap of the split, user scalars, A operands
-  for (int idx = lane; idx < 16 * TOPN_MAX; idx += 64) tk[idx] = PKEY_MAX;
   for (int idx = lane; idx < 16 * a.bm_words; idx += 64) bm[idx] = 0u;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -154,11 +158,14 @@ __global__ __launch_bounds__(256) void eval_pass_kernel(PassArgs a) {
           const float* src = vec == 0 ? a.C0 : vec == 1 ? a.C1 : a.C2;
           val = *reinterpret_cast<const v4*>(src + item * D + 4 * c);
         }
+      } else if (idx < IBT * 3 * NCH + IBT) {
+        const int64_t item = i_lo + t * IBT + (idx - IBT * 3 * NCH);
+        if (item < i_hi) val = *reinterpret_cast<const v4*>(a.ISC + item * 4);
       }
       pre[l] = val;
     }
   };
-  auto stash = [&](int buf) {                                             // registers -> LDS tile + its item scalars
+  auto stash = [&](int buf) {                                             // registers -> LDS tile (+ its item scalars)
     v4* X = Xb + buf * G::TILE_F4;
 #pragma unroll
     for (int l = 0; l < LPT; ++l) {
@@ -166,30 +173,8 @@ __global__ __launch_bounds__(256) void eval_pass_kernel(PassArgs a) {
       if (idx < IBT * 3 * NCH) {
         const int row = idx / (3 * NCH), rem = idx - row * (3 * NCH), vec = rem / NCH, c = rem - vec * NCH;
         X[(row * 3 + vec) * P4 + c] = pre[l];
-      }
-    }
-  };
-  auto item_scalars = [&](int buf) {                                      // v.NV, |C0|^2, C0.NV, |NV|^2 (after the tile is visible)
-    const v4* X = Xb + buf * G::TILE_F4;
-    const int row = tid >> 3;
-    if (row < IBT) {
-      const v4* r0 = X + (row * 3 + 0) * P4;
-      const v4* r1 = r0 + P4;
-      const v4* r2 = r1 + P4;
-      v4 s0 = (v4){0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
-      for (int c = tid & 7; c < NCH; c += 8) {
-        const v4 x0 = r0[c], x1 = r1[c], x2 = r2[c];
-        s0 += x1 * x2; s1 += x0 * x0; s2 += x0 * x2; s3 += x2 * x2;
-      }
-      float f0 = (s0[0] + s0[1]) + (s0[2] + s0[3]), f1 = (s1[0] + s1[1]) + (s1[2] + s1[3]);
-      float f2 = (s2[0] + s2[1]) + (s2[2] + s2[3]), f3 = (s3[0] + s3[1]) + (s3[2] + s3[3]);
-#pragma unroll
-      for (int m = 1; m < 8; m <<= 1) {
-        f0 += __shfl_xor(f0, m, 64); f1 += __shfl_xor(f1, m, 64); f2 += __shfl_xor(f2, m, 64); f3 += __shfl_xor(f3, m, 64);
-      }
-      if ((tid & 7) == 0) {
-        float* o = isc + (buf * IBT + row) * 4;
-        o[0] = f0; o[1] = f1; o[2] = f2; o[3] = f3;
+      } else if (idx < IBT * 3 * NCH + IBT) {
+        *reinterpret_cast<v4*>(isc + (buf * IBT + (idx - IBT * 3 * NCH)) * 4) = pre[l];
       }
     }
   };
@@ -197,9 +182,8 @@ __global__ __launch_bounds__(256) void eval_pass_kernel(PassArgs a) {
     fetch(0);
     stash(0);
     __syncthreads();
-    item_scalars(0);
-    __syncthreads();
   }
+  const int rowbase = 16 * kq;
   for (int64_t t = 0; t < ntile; ++t) {
     const int buf = (int)(t & 1);
     if (t + 1 < ntile) fetch(t + 1);                                      // in flight under the MFMAs below
@@ -244,44 +228,68 @@ __global__ __launch_bounds__(256) void eval_pass_kernel(PassArgs a) {
       const float nn = fmaf(2.f, NUNV[reg], us4[3] + is4[3]);
       const float score = fmaf(s * s, nn, fmaf(-2.f * s, an, aa));
       ck[reg] = pass_key(score, (uint32_t)item);
-      bool c = item < i_hi && u0 + ur < a.nq && ck[reg] < tk[ur * TOPN_MAX + topn - 1];
+      // the user's current n-th key sits in lane topn - 1 of this row
+      const uint64_t thr = ((uint64_t)(uint32_t)__shfl((int)(tkr[reg] >> 32), rowbase + topn - 1, 64) << 32) |
+                           (uint32_t)__shfl((int)(uint32_t)tkr[reg], rowbase + topn - 1, 64);
+      bool c = item < i_hi && u0 + ur < a.nq && ck[reg] < thr;
       if (c) c = ((bm[ur * a.bm_words + (lid >> 5)] >> (lid & 31)) & 1u) == 0u;
       cand[reg] = c;
     }
-    // ---- insertions, one candidate at a time (rare after the first tiles): lanes 0 .. topn - 1 shift the user's sorted list
+    // ---- insertions: every 16-lane row serves its own users, one candidate per row and round, all four rows in parallel
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
-      unsigned long long todo = __ballot(cand[reg]);
-      while (todo) {
-        const int src = __ffsll((long long)todo) - 1;
-        todo &= todo - 1;
-        const uint32_t klo = __builtin_amdgcn_readlane((uint32_t)ck[reg], src);
-        const uint32_t khi = __builtin_amdgcn_readlane((uint32_t)(ck[reg] >> 32), src);
-        const uint64_t key = ((uint64_t)khi << 32) | klo;
-        uint64_t* list = tk + (4 * (src >> 4) + reg) * TOPN_MAX;
-        if (key >= list[topn - 1]) continue;                              // an earlier insertion of this round raised the bar
-        uint64_t mine = PKEY_MAX, left = PKEY_MAX;
-        if (lane < topn) { mine = list[lane]; left = lane > 0 ? list[lane - 1] : 0ull; }
-        const int pos = __popcll(__ballot(lane < topn && mine < key));
-        __builtin_amdgcn_wave_barrier();
-        if (lane < topn) list[lane] = lane < pos ? mine : (lane == pos ? key : left);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+      uint32_t rowmask = (uint32_t)((__ballot(cand[reg]) >> rowbase) & 0xffffull);          // this row's candidate lanes
+      while (__ballot(rowmask != 0u)) {                                                      // (wave-uniform trip count)
+        const bool act = rowmask != 0u;
+        const int src = rowbase + (act ? __ffs((int)rowmask) - 1 : 0);
+        rowmask &= rowmask - 1u;
+        const uint64_t key = ((uint64_t)(uint32_t)__shfl((int)(ck[reg] >> 32), src, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)ck[reg], src, 64);
+        const uint64_t mine = tkr[reg];
+        // sorted row: element j - 1 moves to j behind the insertion point (DPP row_shr:1; lane 0 of a row keeps its own value)
+        const uint32_t llo = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)mine, (int)(uint32_t)mine, 0x111, 0xf, 0xf, false);
+        const uint32_t lhi = (uint32_t)__builtin_amdgcn_update_dpp((int)(mine >> 32), (int)(mine >> 32), 0x111, 0xf, 0xf, false);
+        const uint64_t left = ((uint64_t)lhi << 32) | llo;
+        const int pos = __popc((uint32_t)((__ballot(j < topn && mine < key) >> rowbase) & 0xffffull));
+        if (act && pos < topn) tkr[reg] = j < pos ? mine : (j == pos ? key : left);           // pos == topn: an earlier insertion raised the bar
       }
     }
     // ---- next tile: registers -> the other buffer (its last readers passed the barrier of the previous iteration)
-    if (t + 1 < ntile) {
-      stash(buf ^ 1);
-      __syncthreads();
-      item_scalars(buf ^ 1);
-    }
+    if (t + 1 < ntile) stash(buf ^ 1);
     __syncthreads();
   }
-  // ---- this split's lists
-  for (int idx = lane; idx < 16 * topn; idx += 64) {
-    const int r = idx / topn, k = idx - r * topn;
-    if (u0 + r < a.nq) a.part[((u0 + r) * a.nsplit + blockIdx.y) * topn + k] = tk[r * TOPN_MAX + k];
+  // ---- this split's lists: lane (kq, j) holds element j of users 4 kq + reg
+  if (j < topn) {
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int64_t ur = u0 + 4 * kq + reg;
+      if (ur < a.nq) a.part[(ur * a.nsplit + blockIdx.y) * topn + j] = tkr[reg];
+    }
   }
+}
+
+// v.NV, |C0|^2, C0.NV, |NV|^2 per item with the arithmetic of pairs_l2_mc_kernel (8 lanes per row, chunks l, l + 8, ..., then
+// xor-shuffles), once per pass
+template <int NCH>
+__global__ __launch_bounds__(256) void item_scalars_kernel(const float* __restrict__ C0, const float* __restrict__ C1,
+                                                           const float* __restrict__ C2, int64_t n_items, float* __restrict__ ISC) {
+  constexpr int D = 4 * NCH;
+  const int64_t row = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3);
+  const bool ok = row < n_items;
+  const v4* r0 = reinterpret_cast<const v4*>(C0 + (ok ? row : 0) * D);
+  const v4* r1 = reinterpret_cast<const v4*>(C1 + (ok ? row : 0) * D);
+  const v4* r2 = reinterpret_cast<const v4*>(C2 + (ok ? row : 0) * D);
+  v4 s0 = (v4){0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+  for (int c = threadIdx.x & 7; c < NCH; c += 8) {
+    const v4 x0 = r0[c], x1 = r1[c], x2 = r2[c];
+    s0 += x1 * x2; s1 += x0 * x0; s2 += x0 * x2; s3 += x2 * x2;
+  }
+  float f0 = (s0[0] + s0[1]) + (s0[2] + s0[3]), f1 = (s1[0] + s1[1]) + (s1[2] + s1[3]);
+  float f2 = (s2[0] + s2[1]) + (s2[2] + s2[3]), f3 = (s3[0] + s3[1]) + (s3[2] + s3[3]);
+#pragma unroll
+  for (int m = 1; m < 8; m <<= 1) {
+    f0 += __shfl_xor(f0, m, 64); f1 += __shfl_xor(f1, m, 64); f2 += __shfl_xor(f2, m, 64); f3 += __shfl_xor(f3, m, 64);
+  }
+  if (ok && (threadIdx.x & 7) == 0) *reinterpret_cast<v4*>(ISC + row * 4) = (v4){f0, f1, f2, f3};
 }
 
 // partial lists of the splits -> the topn smallest keys per user; one thread per user (nsplit * topn <= a few hundred keys)
@@ -326,9 +334,11 @@ int launch_pass(PassArgs a, int32_t* top_ids, float* top_scores, hipStream_t st,
   nsplit = (int)((a.n_items + a.split_items - 1) / a.split_items);
   a.nsplit = nsplit;
   a.bm_words = (int)((a.split_items + 31) / 32);
-  const size_t wave_bytes = (size_t)16 * 4 * 4 + (size_t)16 * TOPN_MAX * 8 + (size_t)16 * a.bm_words * 4;
+  const size_t wave_bytes = (size_t)16 * 4 * 4 + (size_t)16 * a.bm_words * 4;
   const size_t lds = (size_t)2 * G::TILE_F4 * 16 + (size_t)2 * IBT * 4 * 4 + 4 * wave_bytes;
   if (lds > 160 * 1024) return 1;
+  hipLaunchKernelGGL((item_scalars_kernel<G::NCH>), dim3((unsigned)((a.n_items + 31) / 32)), dim3(256), 0, st, a.C0, a.C1, a.C2, a.n_items,
+                     const_cast<float*>(a.ISC));
   (void)hipFuncSetAttribute((const void*)eval_pass_kernel<G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL((eval_pass_kernel<G>), dim3((unsigned)ublocks, (unsigned)nsplit), dim3(256), lds, st, a);
   if (int e = check_launch(name)) return e;
@@ -339,7 +349,10 @@ int launch_pass(PassArgs a, int32_t* top_ids, float* top_scores, hipStream_t st,
 
 }  // namespace
 
-size_t eval_pass_part_bytes(int64_t nq, int topn) { return (size_t)nq * 8 * topn * sizeof(uint64_t); }
+// scratch behind `part`: the splits' partial lists, then the per-item scalars
+size_t eval_pass_part_bytes(int64_t nq, int topn, int64_t n_items) {
+  return (size_t)nq * 8 * topn * sizeof(uint64_t) + (size_t)n_items * 4 * sizeof(float);
+}
 
 // Returns KTUP_OK / an error, or 1 for shapes the fused pass does not cover (d, topn): the caller keeps the per-batch route.
 int eval_pass_l2_mc(const float* QW, const float* C0, const float* C1, const float* C2, int d, int64_t nq, int64_t n_items,
@@ -349,6 +362,7 @@ int eval_pass_l2_mc(const float* QW, const float* C0, const float* C1, const flo
   PassArgs a{};
   a.QW = QW; a.C0 = C0; a.C1 = C1; a.C2 = C2; a.nq = nq; a.n_items = n_items;
   a.filt_off = filt_off; a.filt_ids = filt_ids; a.topn = topn; a.part = part;
+  a.ISC = reinterpret_cast<const float*>(part + (size_t)nq * 8 * topn);
   if (d == 64) return launch_pass<PGeom<16>>(a, top_ids, top_scores, st, name);
   if (d == 100) return launch_pass<PGeom<25>>(a, top_ids, top_scores, st, name);
   return launch_pass<PGeom<32>>(a, top_ids, top_scores, st, name);

@@ -64,7 +64,7 @@ int pairs_l2_mc(const float* QW, const float* C0, const float* C1, const float* 
                 int64_t ldo, hipStream_t st, const char* name);
 
 // ktup_eval_pass.hip: scores + filtered top-n of a whole evaluation pass in one launch (+ a merge launch).  1 = not covered.
-size_t eval_pass_part_bytes(int64_t nq, int topn);
+size_t eval_pass_part_bytes(int64_t nq, int topn, int64_t n_items);
 int eval_pass_l2_mc(const float* QW, const float* C0, const float* C1, const float* C2, int d, int64_t nq, int64_t n_items,
                     const int64_t* filt_off, const int32_t* filt_ids, int topn, uint64_t* part, int32_t* top_ids, float* top_scores,
                     hipStream_t st, const char* name);

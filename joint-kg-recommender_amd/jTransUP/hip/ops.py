@@ -470,17 +470,17 @@ def _eval_pref(U, I, E, pref, pref_norm, rel, norm, item2ent, u, l1, gumbel_mode
 def eval_pref_topk(U, u, items, l1, topn, filt_off=None, filt_ids=None, with_scores=False):
     """Scores + filtered top-n of a whole evaluation pass in one sweep (ktup_eval_pref_topk_prepared): every user of `u` against
     the prepared item side, no (users x items) matrix.  -> int32 (len(u), topn) ids (-1 padded) [, scores], or None when the
-    fused pass does not cover the shape (L1, d outside {64, 100, 128}, topn > 32): keep eval_tup / eval_ktup + topk_filtered."""
+    fused pass does not cover the shape (L1, d outside {64, 100, 128}, topn > 16): keep eval_tup / eval_ktup + topk_filtered."""
     dev = _dev(_table('user table', U))
     u = _ids('u_ids', u, dev)
     nq, d, P = u.numel(), items.d, items.P
-    if l1 or d not in (64, 100, 128) or not (0 < topn <= 32) or nq == 0 or not L.get_option('eval_mc'):
+    if l1 or d not in (64, 100, 128) or not (0 < topn <= 16) or nq == 0 or not L.get_option('eval_mc'):
         return None
     if filt_ids is not None and filt_ids.numel() == 0:
         filt_off = filt_ids = None
     top = torch.empty(nq, topn, dtype=torch.int32, device=dev)
     ts = torch.empty(nq, topn, dtype=torch.float32, device=dev) if with_scores else None
-    ws = _scratch(L.load().ktup_eval_pref_topk_workspace_bytes(d, P, nq, topn), dev)
+    ws = _scratch(L.load().ktup_eval_pref_topk_workspace_bytes(d, P, nq, items.n_items, topn), dev)
     L.call('ktup_eval_pref_topk_prepared', _p(U), U.stride(0), _p(items.pws), P, d, _p(u), nq, items.n_items, 0, _p(items.items_ws),
            _p(filt_off), _p(filt_ids), int(topn), _p(top), _p(ts), _p(ws), _stream(dev))
     return (top, ts) if with_scores else top

@@ -53,10 +53,22 @@ class ReplicaGradSync(object):
                                                                -> local term / G, gradients summed
     so that the reduced gradient equals the single-process gradient of the loss on the concatenated batch."""
 
-    def __init__(self, params, group=None):
+    def __init__(self, params, group=None, extra=0):
+        """All gradients become views into ONE persistent flat bucket (every view 16-byte aligned for the float4 kernels),
+        followed by `extra` fp32 scalars that ride along in the same all-reduce (loss terms).  Gradients are zero-filled,
+        like the reference's torch-0.3 zero_grad."""
         self.params = [p for p in params]
         self.group = group
         self.world = _world(group)
+        sizes = [p.numel() for p in self.params]
+        pad = [(-n) % 4 for n in sizes]
+        dev = self.params[0].device if self.params else None
+        self.flat = torch.zeros(sum(sizes) + sum(pad) + int(extra), dtype=torch.float32, device=dev)
+        off = 0
+        for p, n, q in zip(self.params, sizes, pad):
+            p.grad = self.flat[off:off + n].view_as(p)
+            off += n + q
+        self.extra = self.flat[off:off + int(extra)]
 
     def scale(self, term, kind):
         if kind in ('mean', 'replicated'):
@@ -67,21 +79,28 @@ class ReplicaGradSync(object):
 
     @torch.no_grad()
     def all_reduce_grads(self):
-        """One bucket: flatten every table's dense gradient, all-reduce(sum), scatter back."""
+        """ONE all-reduce(sum) of the flat bucket: no gather / scatter copies, the gradients are views into it."""
         if self.world == 1:
             return
-        grads = []
-        for p in self.params:
-            if p.grad is None:
-                p.grad = torch.zeros_like(p)
-            grads.append(p.grad.reshape(-1))
-        flat = torch.cat(grads)
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        for p in self.params:                 # autograd may have replaced a view by its own tensor (set_to_none, first backward)
+            if p.grad is None or p.grad.data_ptr() < self.flat.data_ptr() or \
+                    p.grad.data_ptr() >= self.flat.data_ptr() + self.flat.numel() * 4:
+                self._readopt()
+                break
+        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+
+    @torch.no_grad()
+    def _readopt(self):
         off = 0
         for p in self.params:
             n = p.numel()
-            p.grad.copy_(flat[off:off + n].view_as(p))
-            off += n
+            view = self.flat[off:off + n].view_as(p)
+            if p.grad is None:
+                view.zero_()
+            elif p.grad.data_ptr() != view.data_ptr():
+                view.copy_(p.grad)
+            p.grad = view
+            off += n + ((-n) % 4)
 
     def broadcast_params(self, src=0):
         if self.world > 1:

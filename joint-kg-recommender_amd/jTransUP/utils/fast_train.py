@@ -59,15 +59,11 @@ class _StepperBase(object):
         self.dev = dev
         f32 = dict(dtype=torch.float32, device=dev)
         i64 = dict(dtype=torch.int64, device=dev)
-        # persistent zero-filled gradients (torch 0.3 zero_grad semantics) as views into one flat bucket; 8 loss scalars at its end
-        sizes = [p.numel() for p in trainer.parameters]
-        pad = [(-n) % 4 for n in sizes]              # keep every view 16-byte aligned for the float4 kernels
-        self.flat = torch.zeros(sum(sizes) + sum(pad) + 8, **f32)
-        off = 0
-        for p, n, q in zip(trainer.parameters, sizes, pad):
-            p.grad = self.flat[off:off + n].view_as(p)
-            off += n + q
-        self.loss = self.flat[off:off + 8]
+        # persistent zero-filled gradients (torch 0.3 zero_grad semantics) as views into one flat bucket with 8 loss scalars at
+        # its end: parallel.ReplicaGradSync owns the bucket and its ONE all-reduce per step
+        from jTransUP.parallel import ReplicaGradSync
+        self.sync = ReplicaGradSync(trainer.parameters, group=group, extra=8)
+        self.flat, self.loss = self.sync.flat, self.sync.extra
         if self.world > 1:                           # identical replicas to start from
             for p in trainer.parameters:
                 dist.broadcast(p.data, src=0, group=group)
@@ -130,8 +126,7 @@ class _StepperBase(object):
             self._bind(st)
 
     def _optimizer_launches(self, loss=None):
-        if self.world > 1:       # gradients of all tables + the loss scalars, one bucket
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+        self.sync.all_reduce_grads()       # world > 1: gradients of all tables + the loss scalars, one bucket, one collective
         self.trainer.fused.clip_and_step(self.max_norm, zero_grads=True, loss=loss)
 
     def _fused_ok(self, kind, d, n_pref=0):

@@ -46,3 +46,12 @@ def test_two_ranks_as_the_driver_launches_them():
     assert KEYS <= set(out) and out['n_gpus'] == 2 and out['scaling'] == 'weak' and out['cpu_baseline'] is None
     rows = out['config']['rows_per_step_per_gpu']
     assert abs(out['value'] - 2 * rows * 1e3 / out['ms_per_step']) <= 1e-6 * out['value']     # whole-job rows / max-over-ranks time
+    # the N-GPU legs: config 4's data-parallel training step (weak + strong, with its comm / compute split) and config 5's
+    # row-sharded step
+    dp = out['dp_train_step']
+    assert 'error' not in dp and dp['world'] == 2 and dp['backend'] == 'gloo'
+    for leg, gb in (('weak', 1024), ('strong', 512)):
+        assert dp[leg]['global_batch'] == gb and dp[leg]['ms_per_step'] > 0 and dp[leg]['ms_allreduce_only'] > 0
+        assert 0 < dp[leg]['ms_per_step_compute_only'] < dp[leg]['ms_per_step']
+    c5 = out['config5_step']
+    assert 'error' not in c5 and (c5.get('skipped') or (c5['world'] == 2 and c5['ms_per_step'] > 0 and c5['batch_per_rank'] == 8192))

@@ -393,7 +393,7 @@ def test_prepared_item_side_gives_the_same_scores(l1, gum):
             assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize('d,nu,ni,nq,topn', [(100, 6040, 3240, 6040, 10), (64, 300, 177, 65, 32), (128, 90, 16, 1, 3), (100, 70, 5, 63, 10),
+@pytest.mark.parametrize('d,nu,ni,nq,topn', [(100, 6040, 3240, 6040, 10), (64, 300, 177, 65, 16), (128, 90, 16, 1, 3), (100, 70, 5, 63, 10),
                                              (100, 500, 1000, 129, 1)])
 def test_fused_pass_topk_equals_matrix_route(d, nu, ni, nq, topn):
     """ktup_eval_pref_topk_prepared (scores + filtered top-n of a whole pass in one sweep, no score matrix) against the matrix

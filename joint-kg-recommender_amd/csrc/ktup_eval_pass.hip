@@ -146,22 +146,32 @@ __global__ __launch_bounds__(256) void eval_pass_kernel(PassArgs a) {
   // ---- the item stream: tile t of this split, double buffered
   const int64_t ntile = (i_hi - i_lo + IBT - 1) / IBT;
   v4 pre[LPT];
+  // loop-invariant geometry of this thread's LPT float4 of a tile: source element, row inside the tile, LDS destination
+  const float* fsrc[LPT];
+  int frow[LPT], fdst[LPT];
+#pragma unroll
+  for (int l = 0; l < LPT; ++l) {
+    const int idx = tid + 256 * l;
+    if (idx < IBT * 3 * NCH) {
+      const int row = idx / (3 * NCH), rem = idx - row * (3 * NCH), vec = rem / NCH, c = rem - vec * NCH;
+      fsrc[l] = (vec == 0 ? a.C0 : vec == 1 ? a.C1 : a.C2) + (i_lo + row) * D + 4 * c;
+      frow[l] = row;
+      fdst[l] = (row * 3 + vec) * P4 + c;
+    } else if (idx < IBT * 3 * NCH + IBT) {
+      const int row = idx - IBT * 3 * NCH;
+      fsrc[l] = a.ISC + (i_lo + row) * 4;
+      frow[l] = row;
+      fdst[l] = -1 - row;                                                 // scalar quad of item `row`
+    } else {
+      fsrc[l] = nullptr; frow[l] = IBT; fdst[l] = 0;
+    }
+  }
   auto fetch = [&](int64_t t) {                                           // global loads of tile t into registers
 #pragma unroll
     for (int l = 0; l < LPT; ++l) {
-      const int idx = tid + 256 * l;
       v4 val = (v4){0.f, 0.f, 0.f, 0.f};
-      if (idx < IBT * 3 * NCH) {
-        const int row = idx / (3 * NCH), rem = idx - row * (3 * NCH), vec = rem / NCH, c = rem - vec * NCH;
-        const int64_t item = i_lo + t * IBT + row;
-        if (item < i_hi) {
-          const float* src = vec == 0 ? a.C0 : vec == 1 ? a.C1 : a.C2;
-          val = *reinterpret_cast<const v4*>(src + item * D + 4 * c);
-        }
-      } else if (idx < IBT * 3 * NCH + IBT) {
-        const int64_t item = i_lo + t * IBT + (idx - IBT * 3 * NCH);
-        if (item < i_hi) val = *reinterpret_cast<const v4*>(a.ISC + item * 4);
-      }
+      if (fsrc[l] && i_lo + t * IBT + frow[l] < i_hi)
+        val = *reinterpret_cast<const v4*>(fsrc[l] + t * IBT * (fdst[l] >= 0 ? D : 4));
       pre[l] = val;
     }
   };
@@ -169,12 +179,9 @@ __global__ __launch_bounds__(256) void eval_pass_kernel(PassArgs a) {
     v4* X = Xb + buf * G::TILE_F4;
 #pragma unroll
     for (int l = 0; l < LPT; ++l) {
-      const int idx = tid + 256 * l;
-      if (idx < IBT * 3 * NCH) {
-        const int row = idx / (3 * NCH), rem = idx - row * (3 * NCH), vec = rem / NCH, c = rem - vec * NCH;
-        X[(row * 3 + vec) * P4 + c] = pre[l];
-      } else if (idx < IBT * 3 * NCH + IBT) {
-        *reinterpret_cast<v4*>(isc + (buf * IBT + (idx - IBT * 3 * NCH)) * 4) = pre[l];
+      if (fsrc[l]) {
+        if (fdst[l] >= 0) X[fdst[l]] = pre[l];
+        else *reinterpret_cast<v4*>(isc + (buf * IBT + (-1 - fdst[l])) * 4) = pre[l];
       }
     }
   };
@@ -184,6 +191,7 @@ __global__ __launch_bounds__(256) void eval_pass_kernel(PassArgs a) {
     __syncthreads();
   }
   const int rowbase = 16 * kq;
+  uint64_t thr[4] = {PKEY_MAX, PKEY_MAX, PKEY_MAX, PKEY_MAX};             // the users' current n-th keys (lane topn - 1 of the row)
   for (int64_t t = 0; t < ntile; ++t) {
     const int buf = (int)(t & 1);
     if (t + 1 < ntile) fetch(t + 1);                                      // in flight under the MFMAs below
@@ -228,17 +236,16 @@ __global__ __launch_bounds__(256) void eval_pass_kernel(PassArgs a) {
       const float nn = fmaf(2.f, NUNV[reg], us4[3] + is4[3]);
       const float score = fmaf(s * s, nn, fmaf(-2.f * s, an, aa));
       ck[reg] = pass_key(score, (uint32_t)item);
-      // the user's current n-th key sits in lane topn - 1 of this row
-      const uint64_t thr = ((uint64_t)(uint32_t)__shfl((int)(tkr[reg] >> 32), rowbase + topn - 1, 64) << 32) |
-                           (uint32_t)__shfl((int)(uint32_t)tkr[reg], rowbase + topn - 1, 64);
-      bool c = item < i_hi && u0 + ur < a.nq && ck[reg] < thr;
+      bool c = item < i_hi && u0 + ur < a.nq && ck[reg] < thr[reg];
       if (c) c = ((bm[ur * a.bm_words + (lid >> 5)] >> (lid & 31)) & 1u) == 0u;
       cand[reg] = c;
     }
     // ---- insertions: every 16-lane row serves its own users, one candidate per row and round, all four rows in parallel
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
-      uint32_t rowmask = (uint32_t)((__ballot(cand[reg]) >> rowbase) & 0xffffull);          // this row's candidate lanes
+      const unsigned long long any = __ballot(cand[reg]);
+      if (!any) continue;                                                                    // the common case after the first tiles
+      uint32_t rowmask = (uint32_t)((any >> rowbase) & 0xffffull);                           // this row's candidate lanes
       while (__ballot(rowmask != 0u)) {                                                      // (wave-uniform trip count)
         const bool act = rowmask != 0u;
         const int src = rowbase + (act ? __ffs((int)rowmask) - 1 : 0);
@@ -252,6 +259,8 @@ __global__ __launch_bounds__(256) void eval_pass_kernel(PassArgs a) {
         const int pos = __popc((uint32_t)((__ballot(j < topn && mine < key) >> rowbase) & 0xffffull));
         if (act && pos < topn) tkr[reg] = j < pos ? mine : (j == pos ? key : left);           // pos == topn: an earlier insertion raised the bar
       }
+      thr[reg] = ((uint64_t)(uint32_t)__shfl((int)(tkr[reg] >> 32), rowbase + topn - 1, 64) << 32) |
+                 (uint32_t)__shfl((int)(uint32_t)tkr[reg], rowbase + topn - 1, 64);
     }
     // ---- next tile: registers -> the other buffer (its last readers passed the barrier of the previous iteration)
     if (t + 1 < ntile) stash(buf ^ 1);
@@ -325,7 +334,7 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(const uint64_t* __restr
 template <typename G>
 int launch_pass(PassArgs a, int32_t* top_ids, float* top_scores, hipStream_t st, const char* name) {
   const int64_t ublocks = (a.nq + 63) / 64;
-  int nsplit = (int)((512 + ublocks - 1) / ublocks);                      // ~2 workgroups per CU in flight
+  int nsplit = (int)(512 / ublocks);                                      // 2 workgroups per CU are resident: ONE round of <= 512
   if (nsplit > 8) nsplit = 8;
   const int64_t tiles = (a.n_items + IBT - 1) / IBT;
   if (nsplit > tiles) nsplit = (int)tiles;

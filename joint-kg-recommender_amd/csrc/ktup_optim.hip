@@ -45,24 +45,57 @@ KTUP_DEV int find_tensor(const OptTensors& T, int64_t chunk) {
 // workgroup 0 publishes  *loss_out = loss_scale * sum(slots)  and zeroes the slots for the next step -- the step then needs no
 // separate zero-fill or add launches.
 // HIER (ktup_optim_gradnorm_loss): the cross-workgroup sum is hierarchical.  One fp64 atomic per workgroup on ONE address
-// serialises at ~30 ns each, which is what bounded this pass at 256 workgroups (8 us for 9.7 MB of gradients); here a workgroup
-// adds to one of GN_SLOTS accumulators on separate 64-byte lines, takes a ticket, and the LAST workgroup folds the slots into
-// sumsq[0] (overwriting it -- no zero-fill launch before the pass) and clears slots and ticket for the next step.  All accesses
-// to the slots / ticket are device-scope atomic read-modify-writes, so they meet at the coherence point whatever the XCD.
-constexpr int GN_SLOTS = 16, GN_STRIDE = 8, GN_TICKET = 1 + GN_SLOTS * GN_STRIDE;     // sumsq[0] | 16 slots, one per 64 B | ticket
+// serialises at ~30 ns each, which is what bounded this pass at 256 workgroups (8 us for 9.7 MB of gradients) -- and a single
+// "last workgroup" ticket has the same problem.  Here workgroup b belongs to slot b % GN_SLOTS: it adds to the slot's accumulator
+// and takes a ticket of the SLOT (32 short chains on separate 64-byte lines); the workgroup that completes a slot takes a global
+// ticket, and the one that completes the last slot folds the slot sums into sumsq[0] (overwriting it -- no zero-fill launch
+// before the pass) and clears the scratch for the next step.  All accesses to the scratch are device-scope atomic
+// read-modify-writes, so they meet at the coherence point whatever the XCD.
+constexpr int GN_SLOTS = 32, GN_STRIDE = 8;
+constexpr int GN_SUM = 1, GN_TICK = GN_SUM + GN_SLOTS * GN_STRIDE, GN_GLOBAL = GN_TICK + GN_SLOTS * GN_STRIDE;   // doubles / u64 words
+
+// Fold (ktup_optim_gradnorm_loss, optional): the fused step kernels leave the gradients of the SMALL tables (preference /
+// relation side: a few dozen rows that every pair of the batch touches) as per-workgroup partial sums -- plain stores instead of
+// 64 x 8000 contended float atomics.  Element e of `part[w][2][elems]` summed over the n_part workgroups (fixed order) is added
+// to dA0 (and dA1) for e < elems, to dC0 (and dC1) beyond; the same thread adds the squares of the finished gradients to the
+// norm, so these tables are NOT in T and no second pass over them is needed.
+struct FoldArgs {
+  const float* part; int n_part; int elems;
+  float *dA0, *dA1, *dC0, *dC1;
+};
 
 template <bool HIER>
 __global__ __launch_bounds__(256) void gradnorm_kernel(OptTensors T, double* __restrict__ sumsq, float* __restrict__ slots, int n_slots,
-                                                       float loss_scale, float* __restrict__ loss_out) {
+                                                       float loss_scale, float* __restrict__ loss_out, FoldArgs fold) {
   if (slots && blockIdx.x == 0 && threadIdx.x == 0) {
     float s = 0.f;
     for (int i = 0; i < n_slots; ++i) { s += slots[i]; slots[i] = 0.f; }
     *loss_out = loss_scale * s;
   }
+  float facc = 0.f;
+  if (HIER && fold.part) {
+    const int total = 2 * fold.elems;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+      float v = 0.f;
+      for (int w = 0; w < fold.n_part; ++w) v += fold.part[(int64_t)w * total + e];
+      const bool isC = e >= fold.elems;
+      const int i = isC ? e - fold.elems : e;
+      float* d0 = isC ? fold.dC0 : fold.dA0;
+      float* d1 = isC ? fold.dC1 : fold.dA1;
+      const float g0 = d0[i] + v;
+      d0[i] = g0;
+      facc = fmaf(g0, g0, facc);
+      if (d1) {
+        const float g1 = d1[i] + v;
+        d1[i] = g1;
+        facc = fmaf(g1, g1, facc);
+      }
+    }
+  }
   // work unit = a quarter chunk (256 float4).  At ml1m size (2.4 M gradient floats) this pass is latency-bound, and its
   // cost is the serialised double atomics on ONE address (one per workgroup): few workgroups, four loads in flight each
   const int64_t nunits = T.chunk0[T.count] * 4;
-  float acc = 0.f;
+  float acc = facc;
   for (int64_t u0 = blockIdx.x; u0 < nunits; u0 += (int64_t)gridDim.x * 4) {
     float4 v[4];
     int64_t rest_i[4], rest_n[4];
@@ -91,21 +124,40 @@ __global__ __launch_bounds__(256) void gradnorm_kernel(OptTensors T, double* __r
   __shared__ float red[4];
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
+  __shared__ int last_wg;
   if (threadIdx.x == 0) {
     const double blk = ((double)red[0] + (double)red[1]) + ((double)red[2] + (double)red[3]);
+    last_wg = 0;
     if (!HIER) {
       atomicAdd(sumsq, blk);
     } else {
-      atomicAdd(sumsq + 1 + (blockIdx.x % GN_SLOTS) * GN_STRIDE, blk);
+      const int slot = blockIdx.x % GN_SLOTS;
+      const unsigned in_slot = (gridDim.x - slot + GN_SLOTS - 1) / GN_SLOTS;          // workgroups b with b % GN_SLOTS == slot
+      const unsigned used = gridDim.x < GN_SLOTS ? gridDim.x : GN_SLOTS;             // slots that have a workgroup at all
+      unsigned long long* words = reinterpret_cast<unsigned long long*>(sumsq);
+      atomicAdd(sumsq + GN_SUM + slot * GN_STRIDE, blk);
       __threadfence();
-      unsigned long long* ticket = reinterpret_cast<unsigned long long*>(sumsq + GN_TICKET);
-      if (atomicAdd(ticket, 1ull) == (unsigned long long)gridDim.x - 1) {      // every other workgroup's slot add is done
+      if (atomicAdd(words + GN_TICK + slot * GN_STRIDE, 1ull) == in_slot - 1) {      // this slot is complete
         __threadfence();
-        double total = 0.0;
-        for (int k = 0; k < GN_SLOTS; ++k)
-          total += __longlong_as_double((long long)atomicExch(reinterpret_cast<unsigned long long*>(sumsq + 1 + k * GN_STRIDE), 0ull));
-        sumsq[0] = total;
-        atomicExch(ticket, 0ull);
+        if (atomicAdd(words + GN_GLOBAL, 1ull) == used - 1) last_wg = 1;             // ... and so is every other slot
+      }
+    }
+  }
+  if (HIER) {
+    __syncthreads();
+    if (last_wg && threadIdx.x < 64) {       // the last workgroup folds the slots: one lane per slot, all exchanges in flight at once
+      unsigned long long* words = reinterpret_cast<unsigned long long*>(sumsq);
+      double v = 0.0;
+      if (threadIdx.x < GN_SLOTS) {
+        __threadfence();
+        v = __longlong_as_double((long long)atomicExch(words + GN_SUM + threadIdx.x * GN_STRIDE, 0ull));
+        atomicExch(words + GN_TICK + threadIdx.x * GN_STRIDE, 0ull);
+      }
+#pragma unroll
+      for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+      if (threadIdx.x == 0) {
+        sumsq[0] = v;
+        atomicExch(words + GN_GLOBAL, 0ull);
       }
     }
   }
@@ -244,7 +296,7 @@ extern "C" int ktup_optim_gradnorm(int n_tensors, float* const* grads, const int
   const int64_t nchunks = T.chunk0[T.count];
   if (nchunks == 0) return KTUP_OK;
   hipLaunchKernelGGL(gradnorm_kernel<false>, dim3(grid_for((nchunks * 4 + 3) / 4, 256)), dim3(256), 0, st, T, sumsq, (float*)nullptr, 0, 0.f,
-                     (float*)nullptr);
+                     (float*)nullptr, FoldArgs{});
   return check_launch("ktup_optim_gradnorm");
 }
 
@@ -252,15 +304,18 @@ extern "C" int ktup_optim_gradnorm(int n_tensors, float* const* grads, const int
 // KTUP_GRADNORM_WS_DOUBLES doubles (zero-filled ONCE by the caller; [0] receives the result, the rest is the kernel's slot /
 // ticket scratch, left zeroed) -- and the step's loss slots are folded into *loss_out and cleared (see the kernel).
 extern "C" int ktup_optim_gradnorm_loss(int n_tensors, float* const* grads, const int64_t* sizes, double* sumsq, float* loss_slots,
-                                        int n_slots, float loss_scale, float* loss_out, void* stream) {
+                                        int n_slots, float loss_scale, float* loss_out, const float* part, int n_part, int part_elems,
+                                        float* dA0, float* dA1, float* dC0, float* dC1, void* stream) {
   OptTensors T{};
   KTUP_REQUIRE(grads && sizes && sumsq && loss_slots && loss_out && n_slots > 0, "ktup_optim_gradnorm_loss: null pointer argument");
+  KTUP_REQUIRE(!part || (n_part > 0 && part_elems > 0 && dA0 && dC0), "ktup_optim_gradnorm_loss: bad partial-sum arguments");
   if (int e = fill("ktup_optim_gradnorm_loss", T, n_tensors, nullptr, grads, nullptr, nullptr, sizes)) return e;
   const int64_t nchunks = T.chunk0[T.count];
-  static_assert(GN_TICKET + 1 <= KTUP_GRADNORM_WS_DOUBLES, "workspace");
+  static_assert(GN_GLOBAL + 1 <= KTUP_GRADNORM_WS_DOUBLES, "workspace");
   const int64_t units = nchunks > 0 ? (nchunks * 4 + 3) / 4 : 1;
+  const FoldArgs fold{part, n_part, part_elems, dA0, dA1, dC0, dC1};
   hipLaunchKernelGGL(gradnorm_kernel<true>, dim3(grid_for(units, 1024)), dim3(256), 0, (hipStream_t)stream, T, sumsq, loss_slots, n_slots,
-                     loss_scale, loss_out);
+                     loss_scale, loss_out, fold);
   return check_launch("ktup_optim_gradnorm_loss");
 }
 

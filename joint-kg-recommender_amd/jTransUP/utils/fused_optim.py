@@ -14,7 +14,7 @@ import torch.optim as optim
 from jTransUP.hip import lib as L
 
 MAX_TENSORS = 12
-GRADNORM_WS_DOUBLES = 136                       # KTUP_GRADNORM_WS_DOUBLES of include/ktup_hip.h
+GRADNORM_WS_DOUBLES = 520                       # KTUP_GRADNORM_WS_DOUBLES of include/ktup_hip.h
 KINDS = {optim.SGD: 0, optim.Adagrad: 1, optim.Adam: 2, optim.RMSprop: 3}
 
 
@@ -100,10 +100,12 @@ class FusedOptimizer(object):
         return self._sumsq.data_ptr()
 
     @torch.no_grad()
-    def clip_and_step(self, max_norm, zero_grads=False, loss=None):
+    def clip_and_step(self, max_norm, zero_grads=False, loss=None, fold=None):
         """`zero_grads`: leave the gradients zero-filled (the next step's zero_grad folded into this pass) instead of
         clipped in place.  `loss` = (slots_ptr, n_slots, scale, out_ptr): the fused training step's loss slots are folded into
-        *out and cleared by the norm launch, whose accumulator the step kernel already zeroed (ktup_optim_gradnorm_loss)."""
+        *out and cleared by the norm launch (ktup_optim_gradnorm_loss).  `fold` = (part_ptr, n_part, elems, dA0, dA1, dC0, dC1):
+        the step kernel left the small tables' gradients as per-workgroup partial sums; the norm launch folds them into the
+        gradient tensors dA0 (dA1) / dC0 (dC1) -- torch tensors, excluded from its own tensor list (include/ktup_hip.h)."""
         self._flush_steps()
         group = self.optimizer.param_groups[0]
         ps = [p for p in group['params'] if p.grad is not None]
@@ -135,7 +137,20 @@ class FusedOptimizer(object):
         clip = max_norm is not None and max_norm > 0
         if loss is not None:
             sumsq = self.sumsq_ptr(dev)
-            L.call('ktup_optim_gradnorm_loss', n, grads, sizes, sumsq, loss[0], int(loss[1]), float(loss[2]), loss[3], stream)
+            if fold is not None:
+                skip = {t.data_ptr() for t in fold[3:] if t is not None}
+                fkey = tuple(sorted(skip))
+                if getattr(self, '_fold_plan', None) is None or self._fold_plan[0] != (key, fkey):
+                    keep = [p for p in ps if p.grad.data_ptr() not in skip]
+                    self._fold_plan = ((key, fkey), len(keep), _arr(ctypes.c_void_p, [p.grad.data_ptr() for p in keep]),
+                                       _arr(ctypes.c_int64, [p.numel() for p in keep]))
+                _, fn, fgrads, fsizes = self._fold_plan
+                dp = [None if t is None else t.data_ptr() for t in fold[3:]]
+                L.call('ktup_optim_gradnorm_loss', fn, fgrads, fsizes, sumsq, loss[0], int(loss[1]), float(loss[2]), loss[3],
+                       fold[0], int(fold[1]), int(fold[2]), dp[0], dp[1], dp[2], dp[3], stream)
+            else:
+                L.call('ktup_optim_gradnorm_loss', n, grads, sizes, sumsq, loss[0], int(loss[1]), float(loss[2]), loss[3],
+                       None, 0, 0, None, None, None, None, stream)
             if not clip:
                 sumsq = None
         elif clip:

@@ -1,0 +1,37 @@
+"""Small fixed workloads for rocprofv3 counter passes (run under `rocprofv3 --kernel-trace --pmc ... -- python tools/pmc_workloads.py <name>`):
+    eval_pass   the fused all-item evaluation sweep at ml1m shape (ktup_eval_pref_topk_prepared), 5 sweeps
+    train_step  the three-launch B=512 joint training step, 20 rec + 20 kg steps
+tools/pmc_summary.py turns the counter_collection.csv into per-kernel averages."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'joint-kg-recommender_amd'))
+import torch
+
+import bench as B
+
+
+def eval_pass(dev):
+    from jTransUP.models import jTransUP as jt
+    torch.manual_seed(3)
+    i_map = {i: i for i in range(B.NI)}
+    new_map = {i: ((i * 4) % B.NE if i < B.ALIGNED else -1, i) for i in range(B.NI)}
+    m = jt.jTransUPModel(False, B.D, B.NU, B.NI, B.NE, B.NR, i_map, new_map, False, False)
+    m.eval(); m.disable_grad()
+    u = torch.arange(B.NU, device=dev)
+    gen = torch.Generator().manual_seed(1)
+    f_off = (torch.arange(B.NU + 1) * 165).to(dev)
+    f_ids = torch.randint(0, B.NI, (B.NU * 165,), generator=gen).to(dev, torch.int32)
+    items = m.prepare_items()
+    for _ in range(5):
+        m.evaluate_topk(u, items, 10, f_off, f_ids)
+    torch.cuda.synchronize()
+
+
+def train_step(dev):
+    B.train_step_bench(dev, steps=40, warmup=10)
+
+
+if __name__ == '__main__':
+    {'eval_pass': eval_pass, 'train_step': train_step}[sys.argv[1]](torch.device('cuda'))

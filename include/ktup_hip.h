@@ -92,6 +92,24 @@ int ktup_score_transr_bwd(const float* E, int64_t lde, const float* R, int64_t l
                           int d, const int64_t* h, const int64_t* t, const int64_t* r, int64_t n, int l1,
                           const float* gscore, float* gE, float* gR, float* gM, void* stream);
 
+/* K1-K3 backward with caller scratch, for large batches: from n >= option seg_bwd_min (default 8192) every row's gradient vector
+ * is written with plain stores and summed per table row by sorted segments (ktup_segment_reduce_rows, below) -- float atomics
+ * serialise when hundreds of rows of a batch share a table row -- and the relation-side tables accumulate in LDS.  Otherwise
+ * identical to the *_bwd entry points above (`ws` unused; *_workspace_bytes returns 0).  n_ent / n_users / n_items / n_rel = rows of
+ * the tables (key ranges of the counting sorts, size of the LDS accumulators).                                              */
+size_t ktup_score_kg_bwd_workspace_bytes(int64_t n, int d, int64_t n_ent);
+int ktup_score_transe_bwd_ws(const float* E, int64_t lde, const float* R, int64_t ldr, int d, const int64_t* h,
+                             const int64_t* t, const int64_t* r, int64_t n, int l1, const float* gscore, float* gE,
+                             float* gR, int64_t n_ent, int64_t n_rel, void* ws, void* stream);
+int ktup_score_transh_bwd_ws(const float* E, int64_t lde, const float* R, int64_t ldr, const float* Nrm, int64_t ldn,
+                             int d, const int64_t* h, const int64_t* t, const int64_t* r, int64_t n, int l1,
+                             const float* gscore, float* gE, float* gR, float* gN, int64_t n_ent, int64_t n_rel, void* ws,
+                             void* stream);
+size_t ktup_score_bprmf_bwd_workspace_bytes(int64_t n, int d, int64_t n_users, int64_t n_items);
+int ktup_score_bprmf_bwd_ws(const float* U, int64_t ldu, const float* I, int64_t ldi, int d, const int64_t* u_ids,
+                            const int64_t* i_ids, int64_t n, const float* gscore, float* gU, float* gI, int64_t n_users,
+                            int64_t n_items, void* ws, void* stream);
+
 /* ------------------------------------------- K5/K6/K7  TUP and KTUP preference-gated translation
  * transUP.py:69-82,105-170 ; jTransUP.py:122-143,250-315.
  *

@@ -74,26 +74,32 @@ __global__ __launch_bounds__(256) void gradnorm_kernel(OptTensors T, double* __r
   }
   float facc = 0.f;
   if (HIER && fold.part) {
+    // 8 lanes per element: lane q sums workgroups q, q + 8, ... (independent loads, all in flight), then three xor-shuffles;
+    // a one-thread-per-element loop waits for 64 dependent L2 round trips
     const int total = 2 * fold.elems;
-    for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+    const int q = threadIdx.x & 7;
+    for (int e = (blockIdx.x * 256 + threadIdx.x) >> 3; e < total; e += (gridDim.x * 256) >> 3) {
       float v = 0.f;
-      for (int w = 0; w < fold.n_part; ++w) v += fold.part[(int64_t)w * total + e];
-      const bool isC = e >= fold.elems;
-      const int i = isC ? e - fold.elems : e;
-      float* d0 = isC ? fold.dC0 : fold.dA0;
-      float* d1 = isC ? fold.dC1 : fold.dA1;
-      const float g0 = d0[i] + v;
-      d0[i] = g0;
-      facc = fmaf(g0, g0, facc);
-      if (d1) {
-        const float g1 = d1[i] + v;
-        d1[i] = g1;
-        facc = fmaf(g1, g1, facc);
+#pragma unroll 8
+      for (int w = q; w < fold.n_part; w += 8) v += fold.part[(int64_t)w * total + e];
+      v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
+      if (q == 0) {
+        const bool isC = e >= fold.elems;
+        const int i = isC ? e - fold.elems : e;
+        float* d0 = isC ? fold.dC0 : fold.dA0;
+        float* d1 = isC ? fold.dC1 : fold.dA1;
+        const float g0 = d0[i] + v;
+        d0[i] = g0;
+        facc = fmaf(g0, g0, facc);
+        if (d1) {
+          const float g1 = d1[i] + v;
+          d1[i] = g1;
+          facc = fmaf(g1, g1, facc);
+        }
       }
     }
   }
-  // work unit = a quarter chunk (256 float4).  At ml1m size (2.4 M gradient floats) this pass is latency-bound, and its
-  // cost is the serialised double atomics on ONE address (one per workgroup): few workgroups, four loads in flight each
+  // work unit = a quarter chunk (256 float4): four loads in flight per thread
   const int64_t nunits = T.chunk0[T.count] * 4;
   float acc = facc;
   for (int64_t u0 = blockIdx.x; u0 < nunits; u0 += (int64_t)gridDim.x * 4) {

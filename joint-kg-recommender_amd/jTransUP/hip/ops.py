@@ -40,6 +40,11 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
+def _seg_ws(nbytes, dev):
+    """Scratch of the large-batch backward route (per-row gradients + the segment sort); None = the atomics route applies."""
+    return torch.empty((nbytes + 3) // 4, dtype=torch.int32, device=dev) if nbytes else None
+
+
 def _stream(dev):
     return torch.cuda.current_stream(dev).cuda_stream
 
@@ -67,8 +72,9 @@ class _ScoreBprmf(Function):
         U, I, u, i = ctx.saved_tensors
         gs = _vec(gs, u.numel())
         gU, gI = torch.zeros_like(U), torch.zeros_like(I)
-        L.call('ktup_score_bprmf_bwd', _p(U), U.stride(0), _p(I), I.stride(0), U.shape[1], _p(u), _p(i), u.numel(), _p(gs),
-               _p(gU), _p(gI), _stream(U.device))
+        bws = _seg_ws(L.load().ktup_score_bprmf_bwd_workspace_bytes(u.numel(), U.shape[1], U.shape[0], I.shape[0]), U.device)
+        L.call('ktup_score_bprmf_bwd_ws', _p(U), U.stride(0), _p(I), I.stride(0), U.shape[1], _p(u), _p(i), u.numel(), _p(gs),
+               _p(gU), _p(gI), U.shape[0], I.shape[0], _p(bws), _stream(U.device))
         return gU, gI, None, None
 
 
@@ -94,8 +100,9 @@ class _ScoreTransE(Function):
         E, R, h, t, r = ctx.saved_tensors
         gs = _vec(gs, h.numel())
         gE, gR = torch.zeros_like(E), torch.zeros_like(R)
-        L.call('ktup_score_transe_bwd', _p(E), E.stride(0), _p(R), R.stride(0), E.shape[1], _p(h), _p(t), _p(r), h.numel(),
-               ctx.l1, _p(gs), _p(gE), _p(gR), _stream(E.device))
+        bws = _seg_ws(L.load().ktup_score_kg_bwd_workspace_bytes(h.numel(), E.shape[1], E.shape[0]), E.device)
+        L.call('ktup_score_transe_bwd_ws', _p(E), E.stride(0), _p(R), R.stride(0), E.shape[1], _p(h), _p(t), _p(r), h.numel(),
+               ctx.l1, _p(gs), _p(gE), _p(gR), E.shape[0], R.shape[0], _p(bws), _stream(E.device))
         return gE, gR, None, None, None, None
 
 
@@ -115,8 +122,10 @@ class _ScoreTransH(Function):
         E, R, N, h, t, r = ctx.saved_tensors
         gs = _vec(gs, h.numel())
         gE, gR, gN = torch.zeros_like(E), torch.zeros_like(R), torch.zeros_like(N)
-        L.call('ktup_score_transh_bwd', _p(E), E.stride(0), _p(R), R.stride(0), _p(N), N.stride(0), E.shape[1], _p(h), _p(t),
-               _p(r), h.numel(), ctx.l1, _p(gs), _p(gE), _p(gR), _p(gN), _stream(E.device))
+        bws = _seg_ws(L.load().ktup_score_kg_bwd_workspace_bytes(h.numel(), E.shape[1], E.shape[0]), E.device)
+        L.call('ktup_score_transh_bwd_ws', _p(E), E.stride(0), _p(R), R.stride(0), _p(N), N.stride(0), E.shape[1], _p(h), _p(t),
+               _p(r), h.numel(), ctx.l1, _p(gs), _p(gE), _p(gR), _p(gN), E.shape[0], min(R.shape[0], N.shape[0]), _p(bws),
+               _stream(E.device))
         return gE, gR, gN, None, None, None, None
 
 

@@ -187,3 +187,41 @@ def test_generic_kernels_on_a_matrix_core_shape():
         close(out[0][1][k], out[1][1][k], rtol=2e-4, atol=GAT * max(1.0, float(out[1][1][k].abs().max())))
     with pytest.raises(L.KtupError):
         L.set_option('no_such_option', 1)
+
+
+@pytest.mark.parametrize('d', [100, 64, 256])
+def test_kg_and_bprmf_backward_by_segments(d):
+    """K1-K3 at n above the seg_bwd_min threshold: per-row gradient vectors + reduction by sorted segments (heads and tails with
+    opposite signs), relation-side tables through LDS accumulators -- against the oracle's autograd and against the atomics route
+    (option seg_bwd_min = 0).  Small tables: hundreds of rows of the batch per table row."""
+    ne, nr, nu, ni, n = 130, 7, 90, 70, 9000
+    gen = torch.Generator().manual_seed(d)
+    E, R, N = O.make_table(ne, d, gen), O.make_table(nr, d, gen), O.make_table(nr, d, gen)
+    U, I = O.make_table(nu, d, gen), O.make_table(ni, d, gen)
+    h = torch.randint(0, ne, (n,), generator=gen); t = torch.randint(0, ne, (n,), generator=gen); r = torch.randint(0, nr, (n,), generator=gen)
+    h[:1500] = 3
+    u = torch.randint(0, nu, (n,), generator=gen); i = torch.randint(0, ni, (n,), generator=gen)
+    wgt = torch.randn(n, generator=gen)
+    assert L.load().ktup_score_kg_bwd_workspace_bytes(n, d, ne) > 0 and L.load().ktup_score_bprmf_bwd_workspace_bytes(n, d, nu, ni) > 0
+    cases = [('transe', [E, R], lambda W, l1: O.score_transe(W[0], W[1], h, t, r, l1),
+              lambda W, l1: ops().score_transe(W[0], W[1], h.to(DEV), t.to(DEV), r.to(DEV), l1)),
+             ('transh', [E, R, N], lambda W, l1: O.score_transh(W[0], W[1], W[2], h, t, r, l1),
+              lambda W, l1: ops().score_transh(W[0], W[1], W[2], h.to(DEV), t.to(DEV), r.to(DEV), l1)),
+             ('bprmf', [U, I], lambda W, l1: O.score_bprmf(W[0], W[1], u, i),
+              lambda W, l1: ops().score_bprmf(W[0], W[1], u.to(DEV), i.to(DEV)))]
+    for name, tabs, ref_fn, hip_fn in cases:
+        for l1 in ((False, True) if name != 'bprmf' else (False,)):
+            Wc = [x.clone().requires_grad_(True) for x in tabs]
+            (ref_fn(Wc, l1) * wgt).sum().backward()
+            for thresh in (8192, 0):
+                old = L.set_option('seg_bwd_min', thresh)
+                try:
+                    Wd = [x.to(DEV).requires_grad_(True) for x in tabs]
+                    got = hip_fn(Wd, l1)
+                    (got * wgt.to(DEV)).sum().backward()
+                finally:
+                    L.set_option('seg_bwd_min', old)
+                close(got, ref_fn([x.detach() for x in Wc], l1))
+                for a, b in zip(Wd, Wc):
+                    scale = float(b.grad.abs().max())
+                    close(a.grad, b.grad, rtol=2e-4, atol=2e-5 * max(scale, 1.0))

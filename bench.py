@@ -150,7 +150,7 @@ def train_step_bench(device, steps=200, warmup=20):
         torch.cuda.synchronize(device)
         dt = time.perf_counter() - t0
         out['ms_per_step_' + mode] = 1e3 * dt / steps
-    # GPU-resident step (utils/fast_train.py JointStepper): what the joint driver runs by default -- three launches per step
+    # GPU-resident step (utils/fast_train.py JointStepper): what the joint driver runs by default -- two launches per step
     # (fused rec / kg kernel, norm + loss, optimizer) replayed from a HIP graph; KTUP_FUSED_STEP=0 = round 1's ~12 launches
     import types
     from jTransUP.utils.fast_train import JointStepper
@@ -196,8 +196,8 @@ def train_step_bench(device, steps=200, warmup=20):
     out['scored_rows_per_s'] = 2 * B / (out['ms_per_step'] * 1e-3)
     out['note'] = ('fwd pos+neg, loss (+ regularisers on the gpu_resident route), bwd, global-norm clip, dense Adagrad with weight '
                    'decay. torch = autograd + clip_grad_norm_ + torch.optim; fused = autograd + K20; gpu_resident = JointStepper, the '
-                   'joint driver\'s default: 3 launches per step (ktup_train_rec_step / ktup_train_kg_step, ktup_optim_gradnorm_loss, '
-                   'ktup_optim_step) replayed from a HIP graph; gpu_resident_multilaunch = the same arithmetic as ~12 launches (round 1)')
+                   'joint driver\'s default: 2 launches per step (ktup_train_rec_step / ktup_train_kg_step, then ktup_optim_clip_step: '
+                   'norm, clip and optimizer around a grid barrier) replayed from a HIP graph; gpu_resident_multilaunch = the same arithmetic as ~12 launches (round 1)')
     return out
 
 

@@ -360,8 +360,8 @@ int ktup_optim_step(int kind, int n_tensors, float* const* params, float* const*
                     const int32_t* first, float lr, float weight_decay, float momentum, float beta1, float beta2, float eps, float alpha,
                     const double* sumsq, float max_norm, int zero_grads, void* stream);
 
-/* ------------------------------------------- the B = 512 training step in three launches (new; ktup_train_step.hip)
- * One fused launch per step kind does everything between the sampled ids and the dense gradients; K20 follows.
+/* ------------------------------------------- the B = 512 training step in two launches (new; ktup_train_step.hip)
+ * One fused launch per step kind does everything between the sampled ids and the dense gradients; ktup_optim_clip_step follows.
  *
  * ktup_train_rec_step  (knowledgable_recommendation.py:335-344 / item_recommendation.py:160-182):
  *   rows k and k + B of (u_ids, i_ids) are the positive and the negative pair of example k.  Mixes the RAW preference-side
@@ -375,34 +375,31 @@ int ktup_optim_step(int kind, int n_tensors, float* const* params, float* const*
  *   TransE: rows k and k + B of (h, t, r) are the positive triple and its corrupted twin.  loss[0] += sum_k max(pos - neg +
  *   margin, 0); regs bit 0: loss[1] += orthogonalLoss(R[r], Nrm[r]) over the 2B relation ids, bit 1: loss[2] += normLoss over
  *   the 4B entity rows, bit 2: loss[3] += normLoss over the 2B relation rows; gradients x gscale accumulated into gE / gR / gN.
- * Both: if sumsq_zero != NULL it is set to 0.0 (the accumulator of the ktup_optim_gradnorm_loss launch that follows).
- * Small-table partials (`part` != NULL; single-process steps): the gradients of the few-row tables every example of the batch
- *   touches -- rec: gA / gC of the mixed preference tables, kg: gR / gN -- are NOT added to their tables with atomics (64
- *   workgroups x 8000 contended float atomics, ~40 G atomics/s on this chip); each workgroup stores its partial sum to
- *   part[w][2][rows][d] (KTUP_TRAIN_PART_MAX_WG workgroups at most; *n_part, a HOST int, receives the count) and the
- *   ktup_optim_gradnorm_loss launch that follows folds them: dA0 (and dA1) += sum_w part[w][0], dC0 (and dC1) += sum_w
- *   part[w][1], adding the finished gradients' squares to the norm -- so those tables must NOT be in its `grads` list.
- *   rec: (dA0, dA1, dC0, dC1) = (gP, gR, gPn, gRn); kg: (gR, NULL, gN, NULL), part_elems = rows x d.
- * ktup_optim_gradnorm_loss: ktup_optim_gradnorm without its memset and with a hierarchical cross-workgroup sum (`sumsq` points at
- *   KTUP_GRADNORM_WS_DOUBLES doubles, zero-filled once by the caller: [0] receives the result, the rest is scratch the kernel
- *   leaves zeroed), plus *loss_out = loss_scale * sum(loss_slots[0..n_slots)) and loss_slots := 0 for the next step.
- * ktup_train_step_supported(kind, d, n_pref): 1 if the fused kernel exists (kind 0 rec, 1 kg TransH, 2 kg TransE).        */
+ * ktup_train_step_supported(kind, d, n_pref): 1 if the fused kernel exists (kind 0 rec, 1 kg TransH, 2 kg TransE).
+ *
+ * ktup_optim_clip_step = ktup_optim_gradnorm + ktup_optim_step (same arguments, same arithmetic) as ONE launch: the gradients
+ *   stay in registers across a grid-wide barrier between the norm and the update (at most 512 workgroups, all resident).  `ws`:
+ *   KTUP_OPTIM_WS_DOUBLES doubles, zero-filled ONCE by the caller; every launch leaves them consistent for the next, ws[0] =
+ *   the squared gradient norm of the last clipped step.  max_norm <= 0: no clipping, no barrier.  loss_slots (may be NULL):
+ *   *loss_out = loss_scale * sum(loss_slots[0..n_slots)) and loss_slots := 0 for the next step -- the step kernels above
+ *   accumulate into them.  The barrier's poll is bounded; after a timeout (never observed; a lost workgroup would otherwise
+ *   hang the GPU) ws[KTUP_OPTIM_WS_DOUBLES - 1] reads non-zero (as a uint64) and that step was applied unclipped.          */
 int ktup_train_step_supported(int kind, int d, int n_pref);
 int ktup_train_rec_step(const float* U, int64_t ldu, const float* I, int64_t ldi, const float* E, int64_t lde,
                         const int32_t* item2ent, int64_t ent_pad, const float* pref, const float* pref_norm,
                         const float* rel, const float* norm, int64_t ldp, int n_pref, int d, const int64_t* u_ids,
                         const int64_t* i_ids, int64_t B, int l1, int gumbel_mode, const float* uniform, uint64_t seed,
                         uint64_t offset, float target, float gscale, int orth, float* loss, float* gU, float* gI, float* gE,
-                        float* gP, float* gPn, float* gR, float* gRn, double* sumsq_zero, float* part, int* n_part, void* stream);
+                        float* gP, float* gPn, float* gR, float* gRn, void* stream);
 int ktup_train_kg_step(int transh, const float* E, int64_t lde, const float* R, int64_t ldr, const float* Nrm, int64_t ldn,
                        int d, const int64_t* h, const int64_t* t, const int64_t* r, int64_t B, int l1, float margin,
-                       float gscale, int regs, float* loss, float* gE, float* gR, float* gN, double* sumsq_zero, int n_rel,
-                       float* part, int* n_part, void* stream);
-#define KTUP_TRAIN_PART_MAX_WG 1024
-#define KTUP_GRADNORM_WS_DOUBLES 520   /* ktup_optim_gradnorm_loss: doubles behind `sumsq` ([0] = result, rest = zeroed scratch) */
-int ktup_optim_gradnorm_loss(int n_tensors, float* const* grads, const int64_t* sizes, double* sumsq, float* loss_slots,
-                             int n_slots, float loss_scale, float* loss_out, const float* part, int n_part, int part_elems,
-                             float* dA0, float* dA1, float* dC0, float* dC1, void* stream);
+                       float gscale, int regs, float* loss, float* gE, float* gR, float* gN, void* stream);
+#define KTUP_OPTIM_WS_DOUBLES 784
+int ktup_optim_clip_step(int kind, int n_tensors, float* const* params, float* const* grads, float* const* state1,
+                         float* const* state2, const int64_t* sizes, const int64_t* steps, const int64_t* steps_dev,
+                         const int32_t* first, float lr, float weight_decay, float momentum, float beta1, float beta2, float eps,
+                         float alpha, double* ws, float max_norm, int zero_grads, float* loss_slots, int n_slots, float loss_scale,
+                         float* loss_out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -16,6 +16,7 @@ int opt_pref_mc();
 int opt_eval_mc();
 int opt_rank_chunk();
 int opt_seg_bwd_min();
+int opt_bwd_wide_max();
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 

@@ -1,4 +1,5 @@
-// K20: global-norm gradient clip + dense optimizer step over a LIST of tables, two launches.
+// K20: global-norm gradient clip + dense optimizer step over a LIST of tables: two launches
+// (ktup_optim_gradnorm, ktup_optim_step), or ONE with a grid-wide barrier between the norm and the update (ktup_optim_clip_step).
 //
 // Reference: every driver ends its step with  clip_grad_norm([all params], clipping_max_value); optimizer.step()
 // (item_recommendation.py:189-192, knowledge_representation.py:209-211, knowledgable_recommendation.py:399-401) on one of
@@ -41,67 +42,10 @@ KTUP_DEV int find_tensor(const OptTensors& T, int64_t chunk) {
   return k;
 }
 
-// `slots` (optional): the step's loss terms, accumulated by the fused step kernel that ran before this launch.  Thread 0 of
-// workgroup 0 publishes  *loss_out = loss_scale * sum(slots)  and zeroes the slots for the next step -- the step then needs no
-// separate zero-fill or add launches.
-// HIER (ktup_optim_gradnorm_loss): the cross-workgroup sum is hierarchical.  One fp64 atomic per workgroup on ONE address
-// serialises at ~30 ns each, which is what bounded this pass at 256 workgroups (8 us for 9.7 MB of gradients) -- and a single
-// "last workgroup" ticket has the same problem.  Here workgroup b belongs to slot b % GN_SLOTS: it adds to the slot's accumulator
-// and takes a ticket of the SLOT (32 short chains on separate 64-byte lines); the workgroup that completes a slot takes a global
-// ticket, and the one that completes the last slot folds the slot sums into sumsq[0] (overwriting it -- no zero-fill launch
-// before the pass) and clears the scratch for the next step.  All accesses to the scratch are device-scope atomic
-// read-modify-writes, so they meet at the coherence point whatever the XCD.
-constexpr int GN_SLOTS = 32, GN_STRIDE = 8;
-constexpr int GN_SUM = 1, GN_TICK = GN_SUM + GN_SLOTS * GN_STRIDE, GN_GLOBAL = GN_TICK + GN_SLOTS * GN_STRIDE;   // doubles / u64 words
-
-// Fold (ktup_optim_gradnorm_loss, optional): the fused step kernels leave the gradients of the SMALL tables (preference /
-// relation side: a few dozen rows that every pair of the batch touches) as per-workgroup partial sums -- plain stores instead of
-// 64 x 8000 contended float atomics.  Element e of `part[w][2][elems]` summed over the n_part workgroups (fixed order) is added
-// to dA0 (and dA1) for e < elems, to dC0 (and dC1) beyond; the same thread adds the squares of the finished gradients to the
-// norm, so these tables are NOT in T and no second pass over them is needed.
-struct FoldArgs {
-  const float* part; int n_part; int elems;
-  float *dA0, *dA1, *dC0, *dC1;
-};
-
-template <bool HIER>
-__global__ __launch_bounds__(256) void gradnorm_kernel(OptTensors T, double* __restrict__ sumsq, float* __restrict__ slots, int n_slots,
-                                                       float loss_scale, float* __restrict__ loss_out, FoldArgs fold) {
-  if (slots && blockIdx.x == 0 && threadIdx.x == 0) {
-    float s = 0.f;
-    for (int i = 0; i < n_slots; ++i) { s += slots[i]; slots[i] = 0.f; }
-    *loss_out = loss_scale * s;
-  }
-  float facc = 0.f;
-  if (HIER && fold.part) {
-    // 8 lanes per element: lane q sums workgroups q, q + 8, ... (independent loads, all in flight), then three xor-shuffles;
-    // a one-thread-per-element loop waits for 64 dependent L2 round trips
-    const int total = 2 * fold.elems;
-    const int q = threadIdx.x & 7;
-    for (int e = (blockIdx.x * 256 + threadIdx.x) >> 3; e < total; e += (gridDim.x * 256) >> 3) {
-      float v = 0.f;
-#pragma unroll 8
-      for (int w = q; w < fold.n_part; w += 8) v += fold.part[(int64_t)w * total + e];
-      v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
-      if (q == 0) {
-        const bool isC = e >= fold.elems;
-        const int i = isC ? e - fold.elems : e;
-        float* d0 = isC ? fold.dC0 : fold.dA0;
-        float* d1 = isC ? fold.dC1 : fold.dA1;
-        const float g0 = d0[i] + v;
-        d0[i] = g0;
-        facc = fmaf(g0, g0, facc);
-        if (d1) {
-          const float g1 = d1[i] + v;
-          d1[i] = g1;
-          facc = fmaf(g1, g1, facc);
-        }
-      }
-    }
-  }
+__global__ __launch_bounds__(256) void gradnorm_kernel(OptTensors T, double* __restrict__ sumsq) {
   // work unit = a quarter chunk (256 float4): four loads in flight per thread
   const int64_t nunits = T.chunk0[T.count] * 4;
-  float acc = facc;
+  float acc = 0.f;
   for (int64_t u0 = blockIdx.x; u0 < nunits; u0 += (int64_t)gridDim.x * 4) {
     float4 v[4];
     int64_t rest_i[4], rest_n[4];
@@ -130,43 +74,7 @@ __global__ __launch_bounds__(256) void gradnorm_kernel(OptTensors T, double* __r
   __shared__ float red[4];
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
-  __shared__ int last_wg;
-  if (threadIdx.x == 0) {
-    const double blk = ((double)red[0] + (double)red[1]) + ((double)red[2] + (double)red[3]);
-    last_wg = 0;
-    if (!HIER) {
-      atomicAdd(sumsq, blk);
-    } else {
-      const int slot = blockIdx.x % GN_SLOTS;
-      const unsigned in_slot = (gridDim.x - slot + GN_SLOTS - 1) / GN_SLOTS;          // workgroups b with b % GN_SLOTS == slot
-      const unsigned used = gridDim.x < GN_SLOTS ? gridDim.x : GN_SLOTS;             // slots that have a workgroup at all
-      unsigned long long* words = reinterpret_cast<unsigned long long*>(sumsq);
-      atomicAdd(sumsq + GN_SUM + slot * GN_STRIDE, blk);
-      __threadfence();
-      if (atomicAdd(words + GN_TICK + slot * GN_STRIDE, 1ull) == in_slot - 1) {      // this slot is complete
-        __threadfence();
-        if (atomicAdd(words + GN_GLOBAL, 1ull) == used - 1) last_wg = 1;             // ... and so is every other slot
-      }
-    }
-  }
-  if (HIER) {
-    __syncthreads();
-    if (last_wg && threadIdx.x < 64) {       // the last workgroup folds the slots: one lane per slot, all exchanges in flight at once
-      unsigned long long* words = reinterpret_cast<unsigned long long*>(sumsq);
-      double v = 0.0;
-      if (threadIdx.x < GN_SLOTS) {
-        __threadfence();
-        v = __longlong_as_double((long long)atomicExch(words + GN_SUM + threadIdx.x * GN_STRIDE, 0ull));
-        atomicExch(words + GN_TICK + threadIdx.x * GN_STRIDE, 0ull);
-      }
-#pragma unroll
-      for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-      if (threadIdx.x == 0) {
-        sumsq[0] = v;
-        atomicExch(words + GN_GLOBAL, 0ull);
-      }
-    }
-  }
+  if (threadIdx.x == 0) atomicAdd(sumsq, ((double)red[0] + (double)red[1]) + ((double)red[2] + (double)red[3]));
 }
 
 struct Hyper {
@@ -267,6 +175,205 @@ __global__ __launch_bounds__(256) void step_kernel(OptTensors T, Hyper h, const 
   }
 }
 
+// ktup_optim_clip_step: norm + clip + update in ONE launch.  Two launches cost a second pass over the gradients plus the gap
+// between two dependent kernels -- at B = 512 that pair was 25 us of a 49 us step whose tables (9.7 MB) fit in registers chip-wide.
+//   phase 1  a thread loads its CS_UPT float4 of gradient (and, while those are in flight, of parameter and state) and the
+//            workgroup's sum of squares joins a hierarchical fp64 sum: workgroup b belongs to slot b % GN_SLOTS, adds to the
+//            slot's accumulator and takes a ticket of the SLOT (one atomic per workgroup on ONE address serialises at ~30 ns each;
+//            32 short chains on separate 64-byte lines do not); the workgroup completing a slot takes a global ticket, and
+//            the one completing the last slot folds the slot sums, clears the scratch for the next launch and publishes the
+//            total next to each slot's epoch word, which it then increments;
+//   barrier  thread 0 of every workgroup read its slot's epoch BEFORE arriving (the epoch cannot move until every workgroup of
+//            this launch has arrived) and polls it with agent-scope loads until it changes;
+//   phase 2  the update runs on the registers of phase 1: no second read of anything.
+// All workgroups must be resident at once: the grid is capped at CS_MAX_WG = 512 workgroups of 256 threads (two per CU -- a
+// second process sharing the GPU, as in the 2-rank tests, still fits).  Tables too large for CS_UPT registers per thread take
+// the same kernel with phase 2 re-reading (resident == false).  The poll is bounded: on a timeout ws[GN_ERR] is set and the
+// update proceeds unclipped -- wrong, but never a hung GPU.
+// `slots` (optional): the step's loss terms, accumulated by the fused step kernel that ran before this launch.  Thread 0 of
+// workgroup 0 publishes  *loss_out = loss_scale * sum(slots)  and zeroes the slots for the next step.
+constexpr int GN_SLOTS = 32, GN_STRIDE = 8;                       // doubles / u64 words; one 64-byte line per slot
+constexpr int GN_SUM = 1, GN_TICK = GN_SUM + GN_SLOTS * GN_STRIDE, GN_GLOBAL = GN_TICK + GN_SLOTS * GN_STRIDE;
+constexpr int GN_EPOCH = GN_GLOBAL + GN_STRIDE;                   // [slot]: {epoch, total} on one line
+constexpr int GN_ERR = KTUP_OPTIM_WS_DOUBLES - 1;
+static_assert(GN_EPOCH + GN_SLOTS * GN_STRIDE <= GN_ERR, "workspace");
+constexpr int CS_UPT = 5, CS_MAX_WG = 512, CS_SPIN_LIMIT = 1 << 21;
+
+template <int KIND>
+__global__ __launch_bounds__(256, 4) void clip_step_kernel(OptTensors T, Hyper h, double* __restrict__ ws, float* __restrict__ slots,
+                                                        int n_slots, float loss_scale, float* __restrict__ loss_out,
+                                                        const int64_t* __restrict__ steps_dev) {
+  __shared__ float dev_bc1[MAXT], dev_bc2s[MAXT];
+  __shared__ float red[4];
+  __shared__ float coef_s;
+  __shared__ int last_wg;
+  unsigned long long* words = reinterpret_cast<unsigned long long*>(ws);
+  const int slot = blockIdx.x % GN_SLOTS;
+  const bool clip = h.max_norm > 0.f;
+  unsigned long long e0 = 0;
+  if (threadIdx.x == 0) {
+    if (clip) e0 = __hip_atomic_load(words + GN_EPOCH + slot * GN_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (slots && blockIdx.x == 0) {
+      float s = 0.f;
+      for (int i = 0; i < n_slots; ++i) { s += slots[i]; slots[i] = 0.f; }
+      *loss_out = loss_scale * s;
+    }
+  }
+  const bool dev_bc = KIND == KTUP_OPT_ADAM && steps_dev != nullptr;
+  if (dev_bc && (int)threadIdx.x < T.count) {
+    const double t = (double)steps_dev[threadIdx.x];
+    dev_bc1[threadIdx.x] = (float)(1.0 - pow((double)h.beta1, t));
+    dev_bc2s[threadIdx.x] = (float)sqrt(1.0 - pow((double)h.beta2, t));
+  }
+  const int64_t nunits = T.chunk0[T.count] * 4;                   // unit = a quarter chunk: 256 float4
+  const int64_t stride = (int64_t)gridDim.x * CS_UPT;
+  const bool resident = nunits <= stride;                         // everything this thread touches stays in its registers
+  int kk[CS_UPT], mm[CS_UPT];
+  uint32_t ii[CS_UPT];                                            // element offsets (tensors of 2^32 floats and more: see the host side)
+  float4 gv[CS_UPT], pv[CS_UPT], av[CS_UPT];
+  auto locate = [&](int64_t unit, int q) {
+    kk[q] = 0; ii[q] = 0; mm[q] = 0;
+    if (unit < nunits) {
+      const int64_t chunk = unit >> 2;
+      const int k = find_tensor(T, chunk);
+      const int64_t i = (chunk - T.chunk0[k]) * CHUNK + ((unit & 3) * 256 + threadIdx.x) * 4, n = T.n[k];
+      kk[q] = k; ii[q] = (uint32_t)i;
+      mm[q] = i + 3 < n ? 4 : (i < n ? (int)(n - i) : 0);
+    }
+  };
+  float coef = 1.f;
+  if (clip) {
+    float acc = 0.f;
+    for (int64_t base = blockIdx.x; base < nunits; base += stride) {
+#pragma unroll
+      for (int q = 0; q < CS_UPT; ++q) {
+        locate(base + (int64_t)q * gridDim.x, q);
+        gv[q] = mm[q] == 4 ? *reinterpret_cast<const float4*>(T.g[kk[q]] + ii[q]) : f4zero();
+      }
+      if (resident) {
+#pragma unroll
+        for (int q = 0; q < CS_UPT; ++q) {
+          pv[q] = mm[q] == 4 ? *reinterpret_cast<const float4*>(T.p[kk[q]] + ii[q]) : f4zero();
+          av[q] = (mm[q] == 4 && T.s1[kk[q]]) ? *reinterpret_cast<const float4*>(T.s1[kk[q]] + ii[q]) : f4zero();
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < CS_UPT; ++q) {
+        acc += dot4(gv[q], gv[q]);
+        if (mm[q] > 0 && mm[q] < 4)
+          for (int e = 0; e < mm[q]; ++e) acc = fmaf(T.g[kk[q]][ii[q] + e], T.g[kk[q]][ii[q] + e], acc);
+      }
+    }
+    acc = group_sum<64>(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const double blk = ((double)red[0] + (double)red[1]) + ((double)red[2] + (double)red[3]);
+      const unsigned in_slot = (gridDim.x - slot + GN_SLOTS - 1) / GN_SLOTS;          // workgroups b with b % GN_SLOTS == slot
+      const unsigned used = gridDim.x < GN_SLOTS ? gridDim.x : GN_SLOTS;             // slots that have a workgroup at all
+      int last = 0;
+      // no __threadfence() anywhere in this protocol: at agent scope it writes back / invalidates the XCD's whole L2 (the first
+      // version spent 50 us in fences).  Everything the workgroups exchange travels in agent-scope atomics, which are performed
+      // at the memory side whatever the XCD; order between two of them = wait for the first one's RETURN value.
+      const double prev = atomicAdd(ws + GN_SUM + slot * GN_STRIDE, blk);
+      asm volatile("s_waitcnt vmcnt(0)" ::"v"(prev) : "memory");
+      if (atomicAdd(words + GN_TICK + slot * GN_STRIDE, 1ull) == in_slot - 1) {      // this slot is complete
+        if (atomicAdd(words + GN_GLOBAL, 1ull) == used - 1) last = 1;                // ... and so is every other slot
+      }
+      last_wg = last;
+    }
+    __syncthreads();
+    if (last_wg && threadIdx.x < 64) {         // fold the slots: one lane per slot, all exchanges in flight at once
+      double v = 0.0;
+      unsigned long long t0 = 0;
+      if (threadIdx.x < GN_SLOTS) {
+        v = __longlong_as_double((long long)atomicExch(words + GN_SUM + threadIdx.x * GN_STRIDE, 0ull));
+        t0 = atomicExch(words + GN_TICK + threadIdx.x * GN_STRIDE, 0ull);
+      }
+#pragma unroll
+      for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+      unsigned long long g0 = 0;
+      if (threadIdx.x == 0) {
+        ws[0] = v;                             // for the host (total_norm) and later launches
+        g0 = atomicExch(words + GN_GLOBAL, 0ull);
+      }
+      if (threadIdx.x < GN_SLOTS) {            // the total, then (once that exchange has returned) the epoch that releases the waiters
+        const unsigned long long was =
+            atomicExch(words + GN_EPOCH + threadIdx.x * GN_STRIDE + 1, (unsigned long long)__double_as_longlong(v));
+        asm volatile("s_waitcnt vmcnt(0)" ::"v"(was), "v"(t0), "v"(g0) : "memory");
+        atomicAdd(words + GN_EPOCH + threadIdx.x * GN_STRIDE, 1ull);
+      }
+    }
+    if (threadIdx.x == 0) {
+      int spins = 0;
+      bool ok = true;
+      while (__hip_atomic_load(words + GN_EPOCH + slot * GN_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == e0) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > CS_SPIN_LIMIT) { ok = false; break; }
+      }
+      float c = 1.f;
+      if (ok) {
+        const double total = __longlong_as_double((long long)__hip_atomic_load(words + GN_EPOCH + slot * GN_STRIDE + 1, __ATOMIC_RELAXED,
+                                                                               __HIP_MEMORY_SCOPE_AGENT));
+        c = h.max_norm / ((float)sqrt(total) + 1e-6f);
+        c = c < 1.f ? c : 1.f;
+      } else {
+        atomicExch(words + GN_ERR, 1ull);
+      }
+      coef_s = c;
+    }
+    __syncthreads();
+    coef = coef_s;
+  } else {
+    __syncthreads();                                              // dev_bc tables
+  }
+  const bool in_regs = clip && resident;
+  for (int64_t base = blockIdx.x; base < nunits; base += stride) {
+#pragma unroll
+    for (int q = 0; q < CS_UPT; ++q) {
+      if (!in_regs) {
+        locate(base + (int64_t)q * gridDim.x, q);
+        if (mm[q] == 4) {
+          gv[q] = *reinterpret_cast<const float4*>(T.g[kk[q]] + ii[q]);
+          pv[q] = *reinterpret_cast<const float4*>(T.p[kk[q]] + ii[q]);
+          av[q] = T.s1[kk[q]] ? *reinterpret_cast<const float4*>(T.s1[kk[q]] + ii[q]) : f4zero();
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < CS_UPT; ++q) {
+      if (mm[q] == 0) continue;
+      const int k = kk[q];
+      const size_t i = ii[q];
+      float *p = T.p[k], *g = T.g[k], *s1 = T.s1[k], *s2 = T.s2[k];
+      const float bc1 = dev_bc ? dev_bc1[k] : T.bc1[k], bc2s = dev_bc ? dev_bc2s[k] : T.bc2s[k];
+      const bool first = T.first[k] != 0;
+      if (mm[q] == 4) {
+        float4 b = s2 ? *reinterpret_cast<float4*>(s2 + i) : f4zero();
+        update1<KIND>(pv[q].x, gv[q].x, av[q].x, b.x, h, coef, bc1, bc2s, first);
+        update1<KIND>(pv[q].y, gv[q].y, av[q].y, b.y, h, coef, bc1, bc2s, first);
+        update1<KIND>(pv[q].z, gv[q].z, av[q].z, b.z, h, coef, bc1, bc2s, first);
+        update1<KIND>(pv[q].w, gv[q].w, av[q].w, b.w, h, coef, bc1, bc2s, first);
+        *reinterpret_cast<float4*>(p + i) = pv[q];
+        if (h.zero_grads) *reinterpret_cast<float4*>(g + i) = f4zero();
+        else if (clip) *reinterpret_cast<float4*>(g + i) = gv[q];
+        if (s1) *reinterpret_cast<float4*>(s1 + i) = av[q];
+        if (s2) *reinterpret_cast<float4*>(s2 + i) = b;
+      } else {
+        for (int e = 0; e < mm[q]; ++e) {
+          float pe = p[i + e], ge = g[i + e], a = s1 ? s1[i + e] : 0.f, b = s2 ? s2[i + e] : 0.f;
+          update1<KIND>(pe, ge, a, b, h, coef, bc1, bc2s, first);
+          p[i + e] = pe;
+          if (h.zero_grads) g[i + e] = 0.f;
+          else if (clip) g[i + e] = ge;
+          if (s1) s1[i + e] = a;
+          if (s2) s2[i + e] = b;
+        }
+      }
+    }
+  }
+}
+
 int fill(const char* name, OptTensors& T, int n_tensors, float* const* params, float* const* grads, float* const* state1,
          float* const* state2, const int64_t* sizes) {
   KTUP_REQUIRE(n_tensors >= 0 && n_tensors <= MAXT, "%s: %d tensors (max %d per call)", name, n_tensors, MAXT);
@@ -301,54 +408,47 @@ extern "C" int ktup_optim_gradnorm(int n_tensors, float* const* grads, const int
   if (hipMemsetAsync(sumsq, 0, sizeof(double), st) != hipSuccess) return check_launch("ktup_optim_gradnorm");
   const int64_t nchunks = T.chunk0[T.count];
   if (nchunks == 0) return KTUP_OK;
-  hipLaunchKernelGGL(gradnorm_kernel<false>, dim3(grid_for((nchunks * 4 + 3) / 4, 256)), dim3(256), 0, st, T, sumsq, (float*)nullptr, 0, 0.f,
-                     (float*)nullptr, FoldArgs{});
+  hipLaunchKernelGGL(gradnorm_kernel, dim3(grid_for((nchunks * 4 + 3) / 4, 256)), dim3(256), 0, st, T, sumsq);
   return check_launch("ktup_optim_gradnorm");
 }
 
-// ktup_optim_gradnorm for the fused training step (ktup_train_step.hip): no memset node -- `sumsq` points at
-// KTUP_GRADNORM_WS_DOUBLES doubles (zero-filled ONCE by the caller; [0] receives the result, the rest is the kernel's slot /
-// ticket scratch, left zeroed) -- and the step's loss slots are folded into *loss_out and cleared (see the kernel).
-extern "C" int ktup_optim_gradnorm_loss(int n_tensors, float* const* grads, const int64_t* sizes, double* sumsq, float* loss_slots,
-                                        int n_slots, float loss_scale, float* loss_out, const float* part, int n_part, int part_elems,
-                                        float* dA0, float* dA1, float* dC0, float* dC1, void* stream) {
-  OptTensors T{};
-  KTUP_REQUIRE(grads && sizes && sumsq && loss_slots && loss_out && n_slots > 0, "ktup_optim_gradnorm_loss: null pointer argument");
-  KTUP_REQUIRE(!part || (n_part > 0 && part_elems > 0 && dA0 && dC0), "ktup_optim_gradnorm_loss: bad partial-sum arguments");
-  if (int e = fill("ktup_optim_gradnorm_loss", T, n_tensors, nullptr, grads, nullptr, nullptr, sizes)) return e;
-  const int64_t nchunks = T.chunk0[T.count];
-  static_assert(GN_GLOBAL + 1 <= KTUP_GRADNORM_WS_DOUBLES, "workspace");
-  const int64_t units = nchunks > 0 ? (nchunks * 4 + 3) / 4 : 1;
-  const FoldArgs fold{part, n_part, part_elems, dA0, dA1, dC0, dC1};
-  hipLaunchKernelGGL(gradnorm_kernel<true>, dim3(grid_for(units, 1024)), dim3(256), 0, (hipStream_t)stream, T, sumsq, loss_slots, n_slots,
-                     loss_scale, loss_out, fold);
-  return check_launch("ktup_optim_gradnorm_loss");
-}
+namespace {
 
-extern "C" int ktup_optim_step(int kind, int n_tensors, float* const* params, float* const* grads, float* const* state1,
-                               float* const* state2, const int64_t* sizes, const int64_t* steps, const int64_t* steps_dev,
-                               const int32_t* first, float lr,
-                               float weight_decay, float momentum, float beta1, float beta2, float eps, float alpha,
-                               const double* sumsq, float max_norm, int zero_grads, void* stream) {
-  KTUP_REQUIRE(kind >= KTUP_OPT_SGD && kind <= KTUP_OPT_RMSPROP, "ktup_optim_step: unknown optimizer kind %d", kind);
-  KTUP_REQUIRE(params && grads && sizes, "ktup_optim_step: null pointer argument");
-  KTUP_REQUIRE(max_norm <= 0.f || sumsq, "ktup_optim_step: clipping needs the gradnorm result");
-  OptTensors T{};
-  if (int e = fill("ktup_optim_step", T, n_tensors, params, grads, state1, state2, sizes)) return e;
+int prep_step(const char* name, OptTensors& T, int kind, int n_tensors, float* const* params, float* const* grads, float* const* state1,
+              float* const* state2, const int64_t* sizes, const int64_t* steps, const int64_t* steps_dev, const int32_t* first,
+              float momentum, float beta1, float beta2) {
+  KTUP_REQUIRE(kind >= KTUP_OPT_SGD && kind <= KTUP_OPT_RMSPROP, "%s: unknown optimizer kind %d", name, kind);
+  KTUP_REQUIRE(params && grads && sizes, "%s: null pointer argument", name);
+  if (int e = fill(name, T, n_tensors, params, grads, state1, state2, sizes)) return e;
   for (int i = 0; i < n_tensors; ++i) {
-    KTUP_REQUIRE(params[i], "ktup_optim_step: tensor %d: null parameter", i);
+    KTUP_REQUIRE(params[i], "%s: tensor %d: null parameter", name, i);
     const bool need1 = kind == KTUP_OPT_ADAGRAD || kind == KTUP_OPT_ADAM || kind == KTUP_OPT_RMSPROP ||
                        (kind == KTUP_OPT_SGD && momentum != 0.f);
     const bool need2 = kind == KTUP_OPT_ADAM || (kind == KTUP_OPT_RMSPROP && momentum > 0.f);
-    KTUP_REQUIRE((!need1 || T.s1[i]) && (!need2 || T.s2[i]), "ktup_optim_step: tensor %d: optimizer state missing", i);
+    KTUP_REQUIRE((!need1 || T.s1[i]) && (!need2 || T.s2[i]), "%s: tensor %d: optimizer state missing", name, i);
     if (kind == KTUP_OPT_ADAM && !steps_dev) {
-      KTUP_REQUIRE(steps && steps[i] >= 1, "ktup_optim_step: Adam needs the (already incremented) step count of tensor %d", i);
+      KTUP_REQUIRE(steps && steps[i] >= 1, "%s: Adam needs the (already incremented) step count of tensor %d", name, i);
       const double t = (double)steps[i];
       T.bc1[i] = (float)(1.0 - pow((double)beta1, t));
       T.bc2s[i] = (float)sqrt(1.0 - pow((double)beta2, t));
     }
     T.first[i] = first ? first[i] : 0;
   }
+  return KTUP_OK;
+}
+
+}  // namespace
+
+extern "C" int ktup_optim_step(int kind, int n_tensors, float* const* params, float* const* grads, float* const* state1,
+                               float* const* state2, const int64_t* sizes, const int64_t* steps, const int64_t* steps_dev,
+                               const int32_t* first, float lr,
+                               float weight_decay, float momentum, float beta1, float beta2, float eps, float alpha,
+                               const double* sumsq, float max_norm, int zero_grads, void* stream) {
+  KTUP_REQUIRE(max_norm <= 0.f || sumsq, "ktup_optim_step: clipping needs the gradnorm result");
+  OptTensors T{};
+  if (int e = prep_step("ktup_optim_step", T, kind, n_tensors, params, grads, state1, state2, sizes, steps, steps_dev, first, momentum,
+                        beta1, beta2))
+    return e;
   const int64_t nchunks = T.chunk0[T.count];
   if (nchunks == 0) return KTUP_OK;
   const Hyper h{lr, weight_decay, momentum, beta1, beta2, eps, alpha, max_norm, zero_grads};
@@ -361,4 +461,40 @@ extern "C" int ktup_optim_step(int kind, int n_tensors, float* const* params, fl
     default: hipLaunchKernelGGL(step_kernel<KTUP_OPT_RMSPROP>, grid, block, 0, st, T, h, sumsq, steps_dev); break;
   }
   return check_launch("ktup_optim_step");
+}
+
+// ktup_optim_gradnorm + ktup_optim_step as one launch (see clip_step_kernel); `ws`: KTUP_OPTIM_WS_DOUBLES doubles, zero-filled
+// ONCE by the caller and left consistent by every launch ([0] = the squared norm of the last clipped step).
+extern "C" int ktup_optim_clip_step(int kind, int n_tensors, float* const* params, float* const* grads, float* const* state1,
+                                    float* const* state2, const int64_t* sizes, const int64_t* steps, const int64_t* steps_dev,
+                                    const int32_t* first, float lr, float weight_decay, float momentum, float beta1, float beta2,
+                                    float eps, float alpha, double* ws, float max_norm, int zero_grads, float* loss_slots, int n_slots,
+                                    float loss_scale, float* loss_out, void* stream) {
+  const char* name = "ktup_optim_clip_step";
+  KTUP_REQUIRE(ws, "%s: null workspace", name);
+  KTUP_REQUIRE(!loss_slots || (n_slots > 0 && loss_out), "%s: loss slots need a count and an output", name);
+  OptTensors T{};
+  if (int e = prep_step(name, T, kind, n_tensors, params, grads, state1, state2, sizes, steps, steps_dev, first, momentum, beta1, beta2))
+    return e;
+  for (int i = 0; i < n_tensors; ++i) KTUP_REQUIRE(sizes[i] < (1ll << 32), "%s: tensor %d: 2^32 elements or more", name, i);
+  const int64_t nunits = T.chunk0[T.count] * 4;
+  if (nunits == 0 && !loss_slots) return KTUP_OK;
+  const Hyper h{lr, weight_decay, momentum, beta1, beta2, eps, alpha, max_norm, zero_grads};
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid((unsigned)(nunits < 1 ? 1 : nunits < CS_MAX_WG ? nunits : CS_MAX_WG)), block(256);
+  switch (kind) {
+    case KTUP_OPT_SGD:
+      hipLaunchKernelGGL(clip_step_kernel<KTUP_OPT_SGD>, grid, block, 0, st, T, h, ws, loss_slots, n_slots, loss_scale, loss_out, steps_dev);
+      break;
+    case KTUP_OPT_ADAGRAD:
+      hipLaunchKernelGGL(clip_step_kernel<KTUP_OPT_ADAGRAD>, grid, block, 0, st, T, h, ws, loss_slots, n_slots, loss_scale, loss_out, steps_dev);
+      break;
+    case KTUP_OPT_ADAM:
+      hipLaunchKernelGGL(clip_step_kernel<KTUP_OPT_ADAM>, grid, block, 0, st, T, h, ws, loss_slots, n_slots, loss_scale, loss_out, steps_dev);
+      break;
+    default:
+      hipLaunchKernelGGL(clip_step_kernel<KTUP_OPT_RMSPROP>, grid, block, 0, st, T, h, ws, loss_slots, n_slots, loss_scale, loss_out, steps_dev);
+      break;
+  }
+  return check_launch(name);
 }

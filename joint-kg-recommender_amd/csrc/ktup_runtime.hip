@@ -40,6 +40,7 @@ Option g_opts[] = {
     {"eval_mc", "KTUP_EVAL_MC", {env_int("KTUP_EVAL_MC", 1)}},          // 0: VALU evaluation kernels instead of the matrix-core ones
     {"rank_chunk", "KTUP_RANK_CHUNK", {env_int("KTUP_RANK_CHUNK", 0)}}, // > 0: force the chunked ranking kernels with this chunk size
     {"seg_bwd_min", "KTUP_SEG_BWD_MIN", {env_int("KTUP_SEG_BWD_MIN", 8192)}},   // rows from which the backward kernels reduce row gradients by segments (0: never)
+    {"bwd_wide_max", "KTUP_BWD_WIDE_MAX", {env_int("KTUP_BWD_WIDE_MAX", 4096)}},   // K5-K7 backward: pairs up to which four waves share a 16-pair tile (d <= 128)
 };
 Option* find(const char* name) {
   for (auto& o : g_opts)
@@ -52,6 +53,7 @@ int opt_pref_mc() { return g_opts[0].value.load(std::memory_order_relaxed); }
 int opt_eval_mc() { return g_opts[1].value.load(std::memory_order_relaxed); }
 int opt_rank_chunk() { return g_opts[2].value.load(std::memory_order_relaxed); }
 int opt_seg_bwd_min() { return g_opts[3].value.load(std::memory_order_relaxed); }
+int opt_bwd_wide_max() { return g_opts[4].value.load(std::memory_order_relaxed); }
 
 }  // namespace ktup
 

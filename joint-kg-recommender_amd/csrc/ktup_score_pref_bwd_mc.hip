@@ -438,7 +438,7 @@ int pref_bwd_mc(const float* U, int64_t ldu, const float* I, int64_t ldi, const 
                 const char* name, float* GU, float* GV) {
   if (n_pref > 32) return 1;
   // d = 256 always, and small batches (<= 256 tiles: at most one tile per CU) at the other widths: four waves per tile
-  if (d == 256 || ((d == 64 || d == 100 || d == 128) && n <= 4096 && !GU))
+  if (d == 256 || ((d == 64 || d == 100 || d == 128) && n <= opt_bwd_wide_max()))
     return pref_bwd_mc_wide(U, ldu, I, ldi, E, lde, item2ent, ent_pad, Alog, Ar, Cn, dp, beta, n_pref, d, u_ids, i_ids, n, l1, gumbel_mode,
                             uniform, seed, offset, gscore, gU, gI, gE, gA, gC, st, name, GU, GV);
   if (d != 64 && d != 100 && d != 128) return 1;

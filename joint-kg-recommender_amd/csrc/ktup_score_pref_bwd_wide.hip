@@ -76,9 +76,6 @@ struct WArgs {
   float* loss;                   // loss[0] += mean_k -logsigmoid(target (pos_k - neg_k)); loss[1] += orthogonalLoss(pref, pnorm)
   float *gP, *gPn, *gR, *gRn;    // gradients of the raw tables, pitch D
   int orth;
-  double* sumsq_zero;
-  float* part;                   // STEP, optional: [tile workgroups][2][P][D] per-workgroup gA / gC partials, plain stores (the norm
-                                 // launch that follows folds them into the four raw tables' gradients: no flush atomics)
   int gumbel;
   const float* uniform;
   uint64_t seed, offset;
@@ -118,7 +115,6 @@ __global__ __launch_bounds__(256) void pref_bwd_wide_kernel(WArgs a) {
   const int P = a.P;
   int nblk = gridDim.x;                                       // workgroups that walk tiles
   if constexpr (STEP) {
-    if (blockIdx.x == 0 && tid == 0 && a.sumsq_zero) *a.sumsq_zero = 0.0;
     if (a.orth) {
       nblk = gridDim.x - 1;
       if ((int)blockIdx.x == nblk) {
@@ -533,14 +529,8 @@ __global__ __launch_bounds__(256) void pref_bwd_wide_kernel(WArgs a) {
         if (p < P && (!RAGGED || c < D)) {
           const float va = accA[pt][ct][reg], vc = accC[pt][ct][reg];
           if constexpr (STEP) {       // A = pref + rel and C = pref_norm + norm: the mixed-table gradient goes to both summands
-            if (a.part) {               // this workgroup's partial (it covers every (p, c) exactly once, zeros included)
-              float* mine = a.part + (int64_t)blockIdx.x * 2 * P * D;
-              mine[(int64_t)p * D + c] = va;
-              mine[(int64_t)(P + p) * D + c] = vc;
-            } else {
-              if (va != 0.f) { atomicAdd(a.gP + (int64_t)p * D + c, va); if (a.gR) atomicAdd(a.gR + (int64_t)p * D + c, va); }
-              if (vc != 0.f) { atomicAdd(a.gPn + (int64_t)p * D + c, vc); if (a.gRn) atomicAdd(a.gRn + (int64_t)p * D + c, vc); }
-            }
+            if (va != 0.f) { atomicAdd(a.gP + (int64_t)p * D + c, va); if (a.gR) atomicAdd(a.gR + (int64_t)p * D + c, va); }
+            if (vc != 0.f) { atomicAdd(a.gPn + (int64_t)p * D + c, vc); if (a.gRn) atomicAdd(a.gRn + (int64_t)p * D + c, vc); }
           } else {
             if (va != 0.f) atomicAdd(a.gA + (int64_t)p * D + c, va);
             if (vc != 0.f) atomicAdd(a.gC + (int64_t)p * D + c, vc);
@@ -554,55 +544,54 @@ __global__ __launch_bounds__(256) void pref_bwd_wide_kernel(WArgs a) {
 }
 
 template <typename G, bool ROWOUT, bool STEP>
-int launch_r(const WArgs& a, hipStream_t st, const char* name, int* n_part = nullptr) {
+int launch_r(const WArgs& a, hipStream_t st, const char* name) {
   static_assert(G::LDS <= 160 * 1024, "LDS budget");
   (void)hipFuncSetAttribute((const void*)pref_bwd_wide_kernel<G, ROWOUT, STEP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS);
   const int64_t ntiles = STEP ? (a.B + 7) / 8 : (a.n + 15) / 16;
   // d = 256: one workgroup (4 waves) per CU is all the LDS allows; narrower tables: two or three fit
   const int per_cu = (int)((160 * 1024) / G::LDS) < 1 ? 1 : (int)((160 * 1024) / G::LDS);
   const int grid = grid_for(ntiles, 256 * per_cu) + ((STEP && a.orth) ? 1 : 0);
-  if (n_part) *n_part = grid - ((STEP && a.orth) ? 1 : 0);              // workgroups that write a partial
   hipLaunchKernelGGL((pref_bwd_wide_kernel<G, ROWOUT, STEP>), dim3(grid), dim3(256), G::LDS, st, a);
   return check_launch(name);
 }
 
 template <typename G>
-int launch(const WArgs& a, hipStream_t st, const char* name, int* n_part = nullptr) {
-  if (a.loss) return launch_r<G, false, true>(a, st, name, n_part);
+int launch(const WArgs& a, hipStream_t st, const char* name) {
+  if (a.loss) return launch_r<G, false, true>(a, st, name);
   return a.GU ? launch_r<G, true, false>(a, st, name) : launch_r<G, false, false>(a, st, name);
 }
 
 template <int NCH, int CTW, int NP>
-int launch_e(const WArgs& a, hipStream_t st, const char* name, int* n_part) {
+int launch_e(const WArgs& a, hipStream_t st, const char* name) {
   if (a.gumbel != KTUP_GUMBEL_OFF) {
-    if (a.E) return launch<WGeom<NCH, CTW, NP, true, true>>(a, st, name, n_part);
-    return launch<WGeom<NCH, CTW, NP, false, true>>(a, st, name, n_part);
+    if (a.E) return launch<WGeom<NCH, CTW, NP, true, true>>(a, st, name);
+    return launch<WGeom<NCH, CTW, NP, false, true>>(a, st, name);
   }
-  if (a.E) return launch<WGeom<NCH, CTW, NP, true, false>>(a, st, name, n_part);
-  return launch<WGeom<NCH, CTW, NP, false, false>>(a, st, name, n_part);
+  if (a.E) return launch<WGeom<NCH, CTW, NP, true, false>>(a, st, name);
+  return launch<WGeom<NCH, CTW, NP, false, false>>(a, st, name);
 }
 
 // P <= 20 everywhere (NP in {4, 5}); the narrower widths also take P <= 32 (NP = 8), which d = 256 has no LDS for
-int launch_d(const WArgs& a, int d, int np, hipStream_t st, const char* name, int* n_part = nullptr) {
+int launch_d(const WArgs& a, int d, int np, hipStream_t st, const char* name) {
   if (d == 256) {
-    if (np <= 4) return launch_e<64, 4, 4>(a, st, name, n_part);
-    if (np <= 5) return launch_e<64, 4, 5>(a, st, name, n_part);
+    if (np <= 4) return launch_e<64, 4, 4>(a, st, name);
+    if (np <= 5) return launch_e<64, 4, 5>(a, st, name);
     return 1;
   }
   if (d == 64) {
-    if (np <= 4) return launch_e<16, 1, 4>(a, st, name, n_part);
-    if (np <= 5) return launch_e<16, 1, 5>(a, st, name, n_part);
-    return launch_e<16, 1, 8>(a, st, name, n_part);
+    if (np <= 4) return launch_e<16, 1, 4>(a, st, name);
+    if (np <= 5) return launch_e<16, 1, 5>(a, st, name);
+    return launch_e<16, 1, 8>(a, st, name);
   }
   if (d == 100) {
-    if (np <= 4) return launch_e<25, 2, 4>(a, st, name, n_part);
-    if (np <= 5) return launch_e<25, 2, 5>(a, st, name, n_part);
-    return launch_e<25, 2, 8>(a, st, name, n_part);
+    if (np <= 4) return launch_e<25, 2, 4>(a, st, name);
+    if (np <= 5) return launch_e<25, 2, 5>(a, st, name);
+    return launch_e<25, 2, 8>(a, st, name);
   }
   if (d == 128) {
-    if (np <= 4) return launch_e<32, 2, 4>(a, st, name, n_part);
-    if (np <= 5) return launch_e<32, 2, 5>(a, st, name, n_part);
-    return launch_e<32, 2, 8>(a, st, name, n_part);
+    if (np <= 4) return launch_e<32, 2, 4>(a, st, name);
+    if (np <= 5) return launch_e<32, 2, 5>(a, st, name);
+    return launch_e<32, 2, 8>(a, st, name);
   }
   return 1;
 }
@@ -636,10 +625,9 @@ int pref_step_mc(const float* U, int64_t ldu, const float* I, int64_t ldi, const
                  int64_t ent_pad, const float* pref, const float* pnorm, const float* rel, const float* norm, int64_t ldp, int n_pref,
                  int d, const int64_t* u_ids, const int64_t* i_ids, int64_t B, int l1, int gumbel_mode, const float* uniform,
                  uint64_t seed, uint64_t offset, float target, float gscale, int orth, float* loss, float* gU, float* gI, float* gE,
-                 float* gP, float* gPn, float* gR, float* gRn, double* sumsq_zero, float* part, int* n_part, hipStream_t st,
+                 float* gP, float* gPn, float* gR, float* gRn, hipStream_t st,
                  const char* name) {
   if (n_pref > 32 || (d == 256 && n_pref > 20)) return 1;
-  if (n_part) *n_part = (int)((B + 7) / 8 < 256 * 3 ? (B + 7) / 8 : 256 * 3);      // upper bound of the tile workgroups (launch_r)
   if ((ldu | ldi | lde | ldp) & 3) return 1;
   if ((ldu >> 2) > 0xffffffffll || (ldi >> 2) > 0xffffffffll || (lde >> 2) > 0xffffffffll) return 1;
   WArgs a{};
@@ -652,9 +640,7 @@ int pref_step_mc(const float* U, int64_t ldu, const float* I, int64_t ldi, const
   a.gumbel = gumbel_mode; a.uniform = uniform; a.seed = seed; a.offset = offset;
   a.pref = pref; a.pnorm = pnorm; a.rel = rel; a.norm = norm; a.ldp = ldp; a.B = B;
   a.target = target; a.gscale = gscale; a.loss = loss; a.gP = gP; a.gPn = gPn; a.gR = gR; a.gRn = gRn; a.orth = orth;
-  a.sumsq_zero = sumsq_zero;
-  a.part = part;
-  return launch_d(a, d, (n_pref + 3) / 4, st, name, n_part);
+  return launch_d(a, d, (n_pref + 3) / 4, st, name);
 }
 
 }  // namespace ktup

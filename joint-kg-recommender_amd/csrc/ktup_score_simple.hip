@@ -551,35 +551,54 @@ __global__ __launch_bounds__(256) void kg_bwd_rowout_kernel(KgSegArgs a) {
   constexpr int GPB = 256 / GL;
   const int lane = threadIdx.x % GL;
   const bool on = lane < a.nch;
-  for (int64_t k = (int64_t)blockIdx.x * GPB + threadIdx.x / GL; k < a.n; k += (int64_t)gridDim.x * GPB) {
-    const int64_t rr = a.r[k];
-    float4 hh = f4zero(), tt = f4zero(), c = f4zero(), w = f4zero();
-    if (on) {
-      hh = reinterpret_cast<const float4*>(a.E + a.h[k] * a.lde)[lane];
-      tt = reinterpret_cast<const float4*>(a.E + a.t[k] * a.lde)[lane];
-      c = reinterpret_cast<const float4*>(a.R + rr * a.ldr)[lane];
-      if (TRANSH) w = reinterpret_cast<const float4*>(a.Nm + rr * a.ldn)[lane];
+  // two triples per lane group and trip: both id loads, then all eight row loads, are in flight together (one triple per trip
+  // left the kernel waiting on two dependent memory round trips per 1.6 KB moved)
+  const int64_t stride = (int64_t)gridDim.x * GPB;
+  for (int64_t k0 = (int64_t)blockIdx.x * GPB + threadIdx.x / GL; k0 < a.n; k0 += 2 * stride) {
+    int64_t kk[2], rr[2], hi[2], ti[2];
+    bool live[2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+      kk[x] = k0 + x * stride;
+      live[x] = kk[x] < a.n;
+      const int64_t kc = live[x] ? kk[x] : k0;
+      rr[x] = a.r[kc]; hi[x] = a.h[kc]; ti[x] = a.t[kc];
     }
-    const float g = a.gs[k];
-    float4 gz, gh, gw = f4zero();
-    if (TRANSH) {                                                  // the arithmetic of TranshBwd
-      const float dh = group_sum<GL>(dot4(hh, w)), dt = group_sum<GL>(dot4(tt, w));
-      const float4 ph = fma4(-dh, w, hh), pt = fma4(-dt, w, tt);
-      gz = g * ddist4((ph + c) - pt, a.l1);
-      const float aw = group_sum<GL>(dot4(gz, w));
-      gh = fma4(-aw, w, gz);
-      gw = fma4(-aw, hh - tt, (-(dh - dt)) * gz);
-    } else {
-      gz = g * ddist4((hh + c) - tt, a.l1);
-      gh = gz;
+    float4 hh[2], tt[2], c[2], w[2];
+    float g[2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+      hh[x] = tt[x] = c[x] = w[x] = f4zero();
+      if (on) {
+        hh[x] = reinterpret_cast<const float4*>(a.E + hi[x] * a.lde)[lane];
+        tt[x] = reinterpret_cast<const float4*>(a.E + ti[x] * a.lde)[lane];
+        c[x] = reinterpret_cast<const float4*>(a.R + rr[x] * a.ldr)[lane];
+        if (TRANSH) w[x] = reinterpret_cast<const float4*>(a.Nm + rr[x] * a.ldn)[lane];
+      }
+      g[x] = a.gs[live[x] ? kk[x] : k0];
     }
-    if (on) {
-      reinterpret_cast<float4*>(a.G + k * a.d)[lane] = gh;
-      float* r0 = kacc + rr * a.d + 4 * lane;
-      atomicAdd(r0 + 0, gz.x); atomicAdd(r0 + 1, gz.y); atomicAdd(r0 + 2, gz.z); atomicAdd(r0 + 3, gz.w);
-      if (TRANSH) {
-        float* w0 = r0 + relems;
-        atomicAdd(w0 + 0, gw.x); atomicAdd(w0 + 1, gw.y); atomicAdd(w0 + 2, gw.z); atomicAdd(w0 + 3, gw.w);
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+      float4 gz, gh, gw = f4zero();
+      if (TRANSH) {                                                  // the arithmetic of TranshBwd
+        const float dh = group_sum<GL>(dot4(hh[x], w[x])), dt = group_sum<GL>(dot4(tt[x], w[x]));
+        const float4 ph = fma4(-dh, w[x], hh[x]), pt = fma4(-dt, w[x], tt[x]);
+        gz = g[x] * ddist4((ph + c[x]) - pt, a.l1);
+        const float aw = group_sum<GL>(dot4(gz, w[x]));
+        gh = fma4(-aw, w[x], gz);
+        gw = fma4(-aw, hh[x] - tt[x], (-(dh - dt)) * gz);
+      } else {
+        gz = g[x] * ddist4((hh[x] + c[x]) - tt[x], a.l1);
+        gh = gz;
+      }
+      if (on && live[x]) {
+        reinterpret_cast<float4*>(a.G + kk[x] * a.d)[lane] = gh;
+        float* r0 = kacc + rr[x] * a.d + 4 * lane;
+        atomicAdd(r0 + 0, gz.x); atomicAdd(r0 + 1, gz.y); atomicAdd(r0 + 2, gz.z); atomicAdd(r0 + 3, gz.w);
+        if (TRANSH) {
+          float* w0 = r0 + relems;
+          atomicAdd(w0 + 0, gw.x); atomicAdd(w0 + 1, gw.y); atomicAdd(w0 + 2, gw.z); atomicAdd(w0 + 3, gw.w);
+        }
       }
     }
   }
@@ -678,7 +697,7 @@ static int kg_bwd_seg(bool transh, const char* name, const float* E, int64_t lde
   const int nch = d / 4;
 #define KTUP_KGSEG(GL)                                                                                                     \
   {                                                                                                                        \
-    const int grid = grid_for((n + (256 / GL) - 1) / (256 / GL), 256 * 4);                                                 \
+    const int grid = grid_for((n + (256 / GL) - 1) / (256 / GL), 256 * 2);   /* every workgroup ends with n_rel x d atomics */ \
     if (transh) hipLaunchKernelGGL((kg_bwd_rowout_kernel<GL, true>), dim3(grid), dim3(256), lds, st, a);                   \
     else hipLaunchKernelGGL((kg_bwd_rowout_kernel<GL, false>), dim3(grid), dim3(256), lds, st, a);                         \
   }

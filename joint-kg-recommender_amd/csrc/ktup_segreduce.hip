@@ -6,8 +6,8 @@
 // lines: round 1 measured 5.2 ms for the 716,800-pair KTUP backward against a 0.11 ms forward.  Here the batch's ids are
 // counting-sorted (histogram of int atomics -> exclusive scan -> scatter; the key range is the table's row count), the scorer's
 // backward writes its per-sample row gradients G (n x d) with plain coalesced stores, and a lane group walks a chunk of the
-// sorted order summing consecutive entries of one row in registers; a row's sum reaches memory with ONE float4 atomic per chunk it
-// spans (atomics: (segments + chunks) x d instead of n x d).  Optionally every flushed row is also added to a second table
+// sorted order summing consecutive entries of one row in registers; runs cut by a chunk edge are joined inside the workgroup, so a
+// row's sum reaches memory with a plain read-modify-write, or one float4 atomic per WORKGROUP it spans (see the kernel).  Optionally every flushed row is also added to a second table
 // through an int32 map (KTUP: gE[item2ent[i]] += what goes to gI[i], skipping the pad entity, jTransUP.py:96,122-130).
 //
 // ws layout (int32): start[n_rows + 1] | rank[m] | perm[m] | skey[m]
@@ -80,70 +80,116 @@ struct SegArgs {
   int chunk;
 };
 
-// GL lanes own one chunk of `chunk` consecutive sorted entries; lane l holds float4 chunks l, l + GL, ... of the running row sum
+// GL lanes own one chunk of `chunk` consecutive sorted entries; lane l holds float4 chunks l, l + GL, ... of the running row sum.
+// A row whose entries all lie inside the chunk belongs to this lane group alone: plain read-modify-write.  The runs cut by the
+// chunk's edges (a user's 119 pairs span several 64-entry chunks) go to LDS instead of to float atomics: the workgroup's
+// 256 / GL chunks are consecutive in the sorted order, so after a barrier one lane group walks the 2 x 256 / GL edge partials in
+// order, joins equal keys, and only the rows that continue into the NEIGHBOURING workgroups need atomics -- 2 rows per
+// 256 / GL chunks instead of 2 per chunk (2.2 M float atomics -> 0.28 M at 716,800 pairs; ~41 G atomics/s is the chip's rate).
+// Rows of the mapped second table (several rows may share one) always take atomics.
 template <int GL, int CPL>
 __global__ __launch_bounds__(256) void seg_reduce_kernel(SegArgs a) {
-  const int lane = threadIdx.x % GL;
+  const int lane = threadIdx.x % GL, grp = threadIdx.x / GL;
   constexpr int GPB = 256 / GL;
+  constexpr int ROW4 = GL * CPL;                                  // float4 per edge partial
+  __shared__ float4 edge[2 * GPB * ROW4];
+  __shared__ int32_t ekey[2 * GPB];
   const int64_t nchunks = (a.m + a.chunk - 1) / a.chunk;
-  for (int64_t c = (int64_t)blockIdx.x * GPB + threadIdx.x / GL; c < nchunks; c += (int64_t)gridDim.x * GPB) {
-    const int64_t k0 = c * a.chunk, k1 = min(a.m, k0 + a.chunk);
-    float4 acc[CPL];
+  auto to_memory = [&](int32_t key, const float4* acc, bool atomic) {
+    float* row = a.gT + (int64_t)key * a.ldt;
+    float* row2 = nullptr;
+    if (a.map2) {
+      const int64_t t2 = a.map2[key];
+      if (t2 != a.pad2) row2 = a.gT2 + t2 * a.ldt2;
+    }
 #pragma unroll
-    for (int j = 0; j < CPL; ++j) acc[j] = f4zero();
-    int32_t cur = a.skey[k0];
-    // a row whose entries all lie inside this chunk belongs to this lane group alone: plain read-modify-write; only the rows
-    // cut by the chunk's edges (and every row of the mapped second table, which several rows may share) need atomics
-    const int32_t before = k0 > 0 ? a.skey[k0 - 1] : -1, after = k1 < a.m ? a.skey[k1] : -1;
-    auto flush = [&](int32_t key) {
-      float* row = a.gT + (int64_t)key * a.ldt;
-      const bool mine = key != before && key != after;
-      float* row2 = nullptr;
-      if (a.map2) {
-        const int64_t t2 = a.map2[key];
-        if (t2 != a.pad2) row2 = a.gT2 + t2 * a.ldt2;
-      }
-#pragma unroll
-      for (int j = 0; j < CPL; ++j) {
-        const int ch = lane + j * GL;
-        if (ch < a.nch) {
-          if (mine) {
-            float4* dst = reinterpret_cast<float4*>(row + 4 * ch);
-            *dst = *dst + acc[j];
-          } else {
-            atomic_add4(row + 4 * ch, acc[j]);
-          }
-          if (row2) atomic_add4(row2 + 4 * ch, acc[j]);
+    for (int j = 0; j < CPL; ++j) {
+      const int ch = lane + j * GL;
+      if (ch < a.nch) {
+        if (atomic) {
+          atomic_add4(row + 4 * ch, acc[j]);
+        } else {
+          float4* dst = reinterpret_cast<float4*>(row + 4 * ch);
+          *dst = *dst + acc[j];
         }
-        acc[j] = f4zero();
-      }
-    };
-    for (int64_t k = k0; k < k1; k += 4) {
-      int32_t key[4], e[4];
-      float4 v[4][CPL];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {                             // four independent row reads in flight
-        const bool on = k + u < k1;
-        key[u] = on ? a.skey[k + u] : -1;
-        e[u] = on ? a.perm[k + u] : 0;
-        const int64_t src = e[u] >= a.n_src ? e[u] - a.n_src : e[u];
-        const float4* row = a.G + src * a.ldg4;
-#pragma unroll
-        for (int j = 0; j < CPL; ++j) {
-          const int ch = lane + j * GL;
-          v[u][j] = (on && ch < a.nch) ? row[ch] : f4zero();
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        if (key[u] < 0) break;
-        if (key[u] != cur) { flush(cur); cur = key[u]; }
-        const float sg = e[u] < a.sign_split ? 1.f : -1.f;
-#pragma unroll
-        for (int j = 0; j < CPL; ++j) acc[j] = fma4(sg, v[u][j], acc[j]);
+        if (row2) atomic_add4(row2 + 4 * ch, acc[j]);
       }
     }
-    flush(cur);
+  };
+  for (int64_t c0 = (int64_t)blockIdx.x * GPB; c0 < nchunks; c0 += (int64_t)gridDim.x * GPB) {
+    const int64_t c = c0 + grp;
+    const bool active = c < nchunks;
+    if (lane == 0) { ekey[2 * grp] = -1; ekey[2 * grp + 1] = -1; }
+    if (active) {
+      const int64_t k0 = c * a.chunk, k1 = min(a.m, k0 + a.chunk);
+      float4 acc[CPL];
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) acc[j] = f4zero();
+      int32_t cur = a.skey[k0];
+      const int32_t before = k0 > 0 ? a.skey[k0 - 1] : -1, after = k1 < a.m ? a.skey[k1] : -1;
+      bool head_open = true;                                      // no run has been closed yet: `cur` may continue the previous chunk
+      auto flush = [&](int32_t key, bool last) {
+        const bool is_head = head_open && key == before, is_tail = last && key == after;
+        if (is_head || is_tail) {
+          const int slot = is_head ? 2 * grp : 2 * grp + 1;       // a run that is both (the whole chunk is one row) is a head
+          if (lane == 0) ekey[slot] = key;
+#pragma unroll
+          for (int j = 0; j < CPL; ++j) edge[slot * ROW4 + lane + j * GL] = acc[j];
+        } else {
+          to_memory(key, acc, false);
+        }
+        head_open = false;
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) acc[j] = f4zero();
+      };
+      for (int64_t k = k0; k < k1; k += 4) {
+        int32_t key[4], e[4];
+        float4 v[4][CPL];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {                             // four independent row reads in flight
+          const bool on = k + u < k1;
+          key[u] = on ? a.skey[k + u] : -1;
+          e[u] = on ? a.perm[k + u] : 0;
+          const int64_t src = e[u] >= a.n_src ? e[u] - a.n_src : e[u];
+          const float4* row = a.G + src * a.ldg4;
+#pragma unroll
+          for (int j = 0; j < CPL; ++j) {
+            const int ch = lane + j * GL;
+            v[u][j] = (on && ch < a.nch) ? row[ch] : f4zero();
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (key[u] < 0) break;
+          if (key[u] != cur) { flush(cur, false); cur = key[u]; }
+          const float sg = e[u] < a.sign_split ? 1.f : -1.f;
+#pragma unroll
+          for (int j = 0; j < CPL; ++j) acc[j] = fma4(sg, v[u][j], acc[j]);
+        }
+      }
+      flush(cur, true);
+    }
+    __syncthreads();
+    if (grp == 0) {                                               // join the edge partials of this workgroup's consecutive chunks
+      const int64_t w0 = c0 * a.chunk, w1 = min(a.m, (c0 + GPB) * a.chunk);
+      const int32_t wbefore = w0 > 0 ? a.skey[w0 - 1] : -1, wafter = w1 < a.m ? a.skey[w1] : -1;
+      float4 acc[CPL];
+      int32_t cur = -1;
+      for (int sl = 0; sl < 2 * GPB; ++sl) {
+        const int32_t key = ekey[sl];
+        if (key < 0) continue;
+        if (key != cur) {
+          if (cur >= 0) to_memory(cur, acc, cur == wbefore || cur == wafter);
+          cur = key;
+#pragma unroll
+          for (int j = 0; j < CPL; ++j) acc[j] = f4zero();
+        }
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) acc[j] = acc[j] + edge[sl * ROW4 + lane + j * GL];
+      }
+      if (cur >= 0) to_memory(cur, acc, cur == wbefore || cur == wafter);
+    }
+    __syncthreads();                                              // the next trip rewrites the edge slots
   }
 }
 

@@ -1,6 +1,6 @@
-// The B = 512 training step of the drivers as THREE launches: (1) one fused kernel per step kind that scores the positive and
-// negative rows, forms the pairwise loss and every regulariser, and scatters all gradients; (2) + (3) the K20 global-norm clip +
-// dense optimizer step (ktup_optim.hip).  Round 1 issued the same arithmetic as ~12 small launches per step (prepare, forward,
+// The B = 512 training step of the drivers as TWO launches: (1) one fused kernel per step kind that scores the positive and
+// negative rows, forms the pairwise loss and every regulariser, and scatters all gradients; (2) the K20 global-norm clip + dense
+// optimizer step in one launch (ktup_optim_clip_step, ktup_optim.hip).  Round 1 issued the same arithmetic as ~12 small launches per step (prepare, forward,
 // loss, backward, regularisers, gradient fan-out, zero-fills): 0.085 ms per step with the device idle most of the time.
 //
 //   rec step (knowledgable_recommendation.py:335-344, item_recommendation.py:160-182):
@@ -26,9 +26,6 @@ struct KgStepArgs {
   int regs;                      // bit 0 orthogonalLoss(rel, norm) rows, bit 1 normLoss(entity rows), bit 2 normLoss(relation rows)
   float* loss;                   // [4]: margin sum, orth, normE, normR  (accumulated)
   float *gE, *gR, *gN;
-  double* sumsq_zero;
-  float* part;                   // optional: [workgroups][2][n_rel][d] per-workgroup gR / gN partials (folded by the norm launch)
-  int n_rel, d;
 };
 
 template <int GL, bool TRANSH>
@@ -36,15 +33,6 @@ __global__ __launch_bounds__(256) void kg_step_kernel(KgStepArgs a) {
   constexpr int GPB = 256 / GL;
   const int lane = threadIdx.x % GL;
   const bool on = lane < a.nch;
-  if (blockIdx.x == 0 && threadIdx.x == 0 && a.sumsq_zero) *a.sumsq_zero = 0.0;
-  // relation-side gradients (a few rows every triple of the batch hits): LDS accumulators + one plain-stored partial per
-  // workgroup instead of 2 x 2B x d contended float atomics on 2 x n_rel rows
-  extern __shared__ float racc[];                                 // [2][n_rel * d] when a.part
-  const int relems = a.n_rel * a.d;
-  if (a.part) {
-    for (int i = threadIdx.x; i < 2 * relems; i += 256) racc[i] = 0.f;
-    __syncthreads();
-  }
   float part[4] = {0.f, 0.f, 0.f, 0.f};
   const float g1 = a.gscale;
   for (int64_t k = (int64_t)blockIdx.x * GPB + threadIdx.x / GL; k < a.B; k += (int64_t)gridDim.x * GPB) {
@@ -126,24 +114,10 @@ __global__ __launch_bounds__(256) void kg_step_kernel(KgStepArgs a) {
       for (int x = 0; x < 4; ++x) atomic_add4(a.gE + id[x] * a.lde + 4 * lane, ge[x]);
 #pragma unroll
       for (int x = 0; x < 2; ++x) {
-        if (a.part) {
-          float* r0 = racc + rid[x] * a.d + 4 * lane;
-          atomicAdd(r0 + 0, gr[x].x); atomicAdd(r0 + 1, gr[x].y); atomicAdd(r0 + 2, gr[x].z); atomicAdd(r0 + 3, gr[x].w);
-          if (TRANSH) {
-            float* w0 = r0 + relems;
-            atomicAdd(w0 + 0, gw[x].x); atomicAdd(w0 + 1, gw[x].y); atomicAdd(w0 + 2, gw[x].z); atomicAdd(w0 + 3, gw[x].w);
-          }
-        } else {
-          atomic_add4(a.gR + rid[x] * a.ldr + 4 * lane, gr[x]);
-          if (TRANSH) atomic_add4(a.gN + rid[x] * a.ldn + 4 * lane, gw[x]);
-        }
+        atomic_add4(a.gR + rid[x] * a.ldr + 4 * lane, gr[x]);
+        if (TRANSH) atomic_add4(a.gN + rid[x] * a.ldn + 4 * lane, gw[x]);
       }
     }
-  }
-  if (a.part) {
-    __syncthreads();
-    float* mine = a.part + (int64_t)blockIdx.x * 2 * relems;
-    for (int i = threadIdx.x; i < 2 * relems; i += 256) mine[i] = racc[i];
   }
   // ---- the four loss values: wave sums -> one atomic per workgroup and slot
   __shared__ float red[4][4];
@@ -160,13 +134,11 @@ __global__ __launch_bounds__(256) void kg_step_kernel(KgStepArgs a) {
 }
 
 template <bool TRANSH>
-int launch_kg(const KgStepArgs& a, hipStream_t st, const char* name, int* n_part) {
+int launch_kg(const KgStepArgs& a, hipStream_t st, const char* name) {
 #define KTUP_KG(GL)                                                                                            \
   {                                                                                                            \
     const int grid = grid_for((a.B + (256 / GL) - 1) / (256 / GL), 1024);                                      \
-    const size_t lds = a.part ? (size_t)2 * a.n_rel * a.d * sizeof(float) : 0;                                 \
-    if (n_part) *n_part = grid;                                                                                \
-    hipLaunchKernelGGL((kg_step_kernel<GL, TRANSH>), dim3(grid), dim3(256), lds, st, a);                       \
+    hipLaunchKernelGGL((kg_step_kernel<GL, TRANSH>), dim3(grid), dim3(256), 0, st, a);                         \
     return check_launch(name);                                                                                 \
   }
   if (a.nch <= 16) KTUP_KG(16)
@@ -189,8 +161,7 @@ extern "C" int ktup_train_rec_step(const float* U, int64_t ldu, const float* I, 
                                    const float* rel, const float* norm, int64_t ldp, int n_pref, int d, const int64_t* u_ids,
                                    const int64_t* i_ids, int64_t B, int l1, int gumbel_mode, const float* uniform, uint64_t seed,
                                    uint64_t offset, float target, float gscale, int orth, float* loss, float* gU, float* gI, float* gE,
-                                   float* gP, float* gPn, float* gR, float* gRn, double* sumsq_zero, float* part, int* n_part,
-                                   void* stream) {
+                                   float* gP, float* gPn, float* gR, float* gRn, void* stream) {
   const char* name = "ktup_train_rec_step";
   KTUP_REQUIRE(B >= 0, "%s: negative batch", name);
   if (B == 0) return KTUP_OK;
@@ -205,16 +176,15 @@ extern "C" int ktup_train_rec_step(const float* U, int64_t ldu, const float* I, 
   KTUP_REQUIRE((gumbel_mode != KTUP_GUMBEL_INPUT && gumbel_mode != KTUP_GUMBEL_PHILOX_DEV) || uniform,
                "%s: KTUP_GUMBEL_INPUT / KTUP_GUMBEL_PHILOX_DEV need the `uniform` pointer", name);
   const int rc = pref_step_mc(U, ldu, I, ldi, E, lde, item2ent, ent_pad, pref, pref_norm, rel, norm, ldp, n_pref, d, u_ids, i_ids, B, l1,
-                              gumbel_mode, uniform, seed, offset, target, gscale, orth, loss, gU, gI, gE, gP, gPn, gR, gRn, sumsq_zero,
-                              part, n_part, (hipStream_t)stream, name);
+                              gumbel_mode, uniform, seed, offset, target, gscale, orth, loss, gU, gI, gE, gP, gPn, gR, gRn,
+                              (hipStream_t)stream, name);
   if (rc == 1) return set_error(KTUP_ERR_UNSUPPORTED, "%s: no fused kernel for d=%d, n_pref=%d (see ktup_train_step_supported)", name, d, n_pref);
   return rc;
 }
 
 extern "C" int ktup_train_kg_step(int transh, const float* E, int64_t lde, const float* R, int64_t ldr, const float* Nrm, int64_t ldn,
                                   int d, const int64_t* h, const int64_t* t, const int64_t* r, int64_t B, int l1, float margin,
-                                  float gscale, int regs, float* loss, float* gE, float* gR, float* gN, double* sumsq_zero, int n_rel,
-                                  float* part, int* n_part, void* stream) {
+                                  float gscale, int regs, float* loss, float* gE, float* gR, float* gN, void* stream) {
   const char* name = "ktup_train_kg_step";
   KTUP_REQUIRE(B >= 0, "%s: negative batch", name);
   if (B == 0) return KTUP_OK;
@@ -222,8 +192,6 @@ extern "C" int ktup_train_kg_step(int transh, const float* E, int64_t lde, const
   if (d <= 0 || d % 4 || d > 256 || (lde | ldr | (transh ? ldn : 0)) % 4 || !aligned16(E) || !aligned16(R) || !aligned16(gE) || !aligned16(gR) ||
       (transh && (!aligned16(Nrm) || !aligned16(gN))))
     return set_error(KTUP_ERR_UNSUPPORTED, "%s: needs d %% 4 == 0 (<= 256) and 16-byte aligned rows", name);
-  if (part && (n_rel <= 0 || (size_t)2 * n_rel * d * sizeof(float) > 64 * 1024)) part = nullptr;   // relation tables too big for LDS: atomics
-  if (n_part) *n_part = 0;
-  KgStepArgs a{E, R, Nrm, lde, ldr, ldn, h, t, r, B, d / 4, l1 != 0, margin, gscale, regs, loss, gE, gR, gN, sumsq_zero, part, n_rel, d};
-  return transh ? launch_kg<true>(a, (hipStream_t)stream, name, n_part) : launch_kg<false>(a, (hipStream_t)stream, name, n_part);
+  KgStepArgs a{E, R, Nrm, lde, ldr, ldn, h, t, r, B, d / 4, l1 != 0, margin, gscale, regs, loss, gE, gR, gN};
+  return transh ? launch_kg<true>(a, (hipStream_t)stream, name) : launch_kg<false>(a, (hipStream_t)stream, name);
 }

@@ -2,8 +2,8 @@
 (knowledgable_recommendation.py:330-401 -> JointStepper; item_recommendation.py:160-195 -> RecStepper;
 knowledge_representation.py:176-211 -> KGStepper) through the C ABI and, in a single process, replayed from one HIP graph per
 step kind.  Where a fused kernel exists (ktup_train_step_supported: TUP / KTUP at d in {64, 100, 128}, TransH / TransE at any
-d % 4 == 0) a step is THREE launches: ktup_train_rec_step or ktup_train_kg_step (scores, loss, regularisers, every gradient),
-ktup_optim_gradnorm_loss, ktup_optim_step.  Otherwise (and with KTUP_FUSED_STEP=0) the round-1 sequence of about a dozen
+d % 4 == 0) a step is TWO launches: ktup_train_rec_step or ktup_train_kg_step (scores, loss, regularisers, every gradient) and
+ktup_optim_clip_step (norm, clip, optimizer, zero-fill of the gradients).  Otherwise (and with KTUP_FUSED_STEP=0) the round-1 sequence of about a dozen
 launches runs: same arithmetic, separate kernels.
 
 The autograd route (`model(...)`, `bprLoss`, `.backward()`, `clip_and_step`) costs ~50 launches and ~0.5 ms of Python per
@@ -125,19 +125,9 @@ class _StepperBase(object):
             self._stream = st
             self._bind(st)
 
-    def _optimizer_launches(self, loss=None, fold=None):
+    def _optimizer_launches(self, loss=None):
         self.sync.all_reduce_grads()       # world > 1: gradients of all tables + the loss scalars, one bucket, one collective
-        self.trainer.fused.clip_and_step(self.max_norm, zero_grads=True, loss=loss, fold=fold)
-
-    def _partials(self, rows, d):
-        """Scratch for the small tables' per-workgroup partial gradients (single process only: with replicas the gradients
-        must be complete before the all-reduce, so the step kernels keep their atomics) + the host int the launch reports its
-        workgroup count in."""
-        import ctypes
-        if self.world > 1:
-            return None, None
-        buf = torch.zeros(1024 * 2 * rows * d, dtype=torch.float32, device=self.dev)        # KTUP_TRAIN_PART_MAX_WG sets
-        return buf, ctypes.c_int(0)
+        self.trainer.fused.clip_and_step(self.max_norm, zero_grads=True, loss=loss)
 
     def _fused_ok(self, kind, d, n_pref=0):
         return bool(self.want_fused and L.load().ktup_train_step_supported(kind, d, n_pref))
@@ -208,19 +198,14 @@ class JointStepper(_StepperBase):
         b = L.bind
         self.fused_step = self._fused_ok(0, d, n_pref) and self._fused_ok(1, d)
         if self.fused_step:
-            import ctypes
-            sq = self.trainer.fused.sumsq_ptr(self.dev)
             inv = 1.0 / self.world
-            self._rec_part, self._rec_np = self._partials(n_pref, d)
-            self._kg_part, self._kg_np = self._partials(n_rel, d)
-            byref = lambda c: None if c is None else ctypes.cast(ctypes.pointer(c), ctypes.c_void_p).value
             self._rec_fused = b('ktup_train_rec_step', _p(U), U.stride(0), _p(I), I.stride(0), _p(E), E.stride(0), _p(self.i2e), self.ent_pad,
                                 _p(P), _p(Pn), _p(R), _p(Rn), P.stride(0), n_pref, d, _p(self.u2), _p(self.i2), B, self.l1, gate, gptr, 0, 0,
                                 self.target, inv, 1, _p(self.loss), _p(U.grad), _p(I.grad), _p(E.grad), _p(P.grad), _p(Pn.grad),
-                                _p(R.grad), _p(Rn.grad), sq, _p(self._rec_part), byref(self._rec_np), st)
+                                _p(R.grad), _p(Rn.grad), st)
             self._kg_fused = b('ktup_train_kg_step', 1, _p(E), E.stride(0), _p(R), R.stride(0), _p(Rn), Rn.stride(0), d, _p(self.h2),
                                _p(self.t2), _p(self.r2), B, self.l1, self.margin, self.kg_lambda, 7, _p(self.loss), _p(E.grad),
-                               _p(R.grad), _p(Rn.grad), sq, n_rel, _p(self._kg_part), byref(self._kg_np), st)
+                               _p(R.grad), _p(Rn.grad), st)
         self._rec_head = [
             b('ktup_pref_prepare', _p(P), _p(Pn), _p(R), _p(Rn), P.stride(0), n_pref, d, _p(self.ws), st)]
         self._rec_soft = [
@@ -259,10 +244,7 @@ class JointStepper(_StepperBase):
             self._gumbel_advance()
             if self.world > 1:
                 self.loss[:2].mul_(self.inv_world)
-            fold = None
-            if self._rec_part is not None:       # gA -> (P, R), gC -> (Pn, Rn): folded by the norm launch from the workgroups' partials
-                fold = (_p(self._rec_part), self._rec_np.value, P.numel(), P.grad, R.grad, Pn.grad, Rn.grad)
-            self._optimizer_launches(loss=(_p(self.loss), 2, 1.0, _p(self.out['rec'])), fold=fold)
+            self._optimizer_launches(loss=(_p(self.loss), 2, 1.0, _p(self.out['rec'])))
             return self.out['rec']
         self._rec_head[0]()
         self.gAC.zero_(); self.loss.zero_()
@@ -283,11 +265,7 @@ class JointStepper(_StepperBase):
             self._pack('kg', (ph, pt, pr, nh, nt, nr))
         if self.fused_step:              # one launch: both TransH scores, marginLoss, the three regularisers, every gradient
             self._kg_fused()
-            fold = None
-            if self._kg_part is not None and self._kg_np.value > 0:
-                R_, Rn_ = self.tabs[5], self.tabs[6]
-                fold = (_p(self._kg_part), self._kg_np.value, R_.numel(), R_.grad, None, Rn_.grad, None)
-            self._optimizer_launches(loss=(_p(self.loss), 4, self.kg_lambda, _p(self.out['kg'])), fold=fold)
+            self._optimizer_launches(loss=(_p(self.loss), 4, self.kg_lambda, _p(self.out['kg'])))
             return self.out['kg']
         self.loss.zero_()
         for launch in self._kg:
@@ -344,8 +322,7 @@ class RecStepper(_StepperBase):
         if self.fused_step:
             self._rec_fused = b('ktup_train_rec_step', _p(U), U.stride(0), _p(I), I.stride(0), None, 0, None, -1, _p(P), _p(Pn), None, None,
                                 P.stride(0), n_pref, d, _p(self.u2), _p(self.i2), B, self.l1, gate, gptr, 0, 0, self.target, 1.0 / self.world,
-                                1, _p(self.loss), _p(U.grad), _p(I.grad), None, _p(P.grad), _p(Pn.grad), None, None,
-                                self.trainer.fused.sumsq_ptr(self.dev), None, None, st)
+                                1, _p(self.loss), _p(U.grad), _p(I.grad), None, _p(P.grad), _p(Pn.grad), None, None, st)
         self._prep = b('ktup_pref_prepare', _p(P), _p(Pn), None, None, P.stride(0), n_pref, d, _p(self.ws), st)
         self._fwd = b('ktup_score_tup_fwd', _p(U), U.stride(0), _p(I), I.stride(0), _p(self.ws), n_pref, d, _p(self.u2), _p(self.i2),
                       2 * B, self.l1, gate, gptr, 0, 0, _p(self.score), st)
@@ -425,8 +402,7 @@ class KGStepper(_StepperBase):
             Rn_ = self.tabs[2] if self.transh else None
             self._kg_fused = b('ktup_train_kg_step', int(self.transh), _p(E), E.stride(0), _p(R), R.stride(0), _p(Rn_),
                                Rn_.stride(0) if self.transh else 0, d, _p(self.h2), _p(self.t2), _p(self.r2), B, self.l1, self.margin, 1.0,
-                               7 if self.transh else 6, _p(self.loss), _p(E.grad), _p(R.grad), _p(Rn_.grad) if self.transh else None,
-                               self.trainer.fused.sumsq_ptr(self.dev), R.shape[0], None, None, st)
+                               7 if self.transh else 6, _p(self.loss), _p(E.grad), _p(R.grad), _p(Rn_.grad) if self.transh else None, st)
         if self.transh:
             Rn = self.tabs[2]
             n_rel = min(R.shape[0], Rn.shape[0])

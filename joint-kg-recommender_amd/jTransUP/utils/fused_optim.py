@@ -1,4 +1,5 @@
-"""Global-norm clip + dense optimizer step as two HIP launches (ktup_optim_gradnorm / ktup_optim_step, K20).
+"""Global-norm clip + dense optimizer step as one HIP launch (ktup_optim_clip_step, K20; two launches -- ktup_optim_gradnorm /
+ktup_optim_step -- with KTUP_CLIP_STEP=0).
 
 The reference ends every training step with `clip_grad_norm(all params, clipping_max_value); optimizer.step()`
 (item_recommendation.py:189-192, knowledge_representation.py:209-211, knowledgable_recommendation.py:399-401) on
@@ -7,6 +8,7 @@ very torch.optim object the trainer creates: hyper-parameters and state tensors 
 `state_dict()` / `load_state_dict()` and checkpoints are interchangeable with an unfused run); only the arithmetic of
 clip + step moves into the library."""
 import ctypes
+import os
 
 import torch
 import torch.optim as optim
@@ -14,7 +16,7 @@ import torch.optim as optim
 from jTransUP.hip import lib as L
 
 MAX_TENSORS = 12
-GRADNORM_WS_DOUBLES = 520                       # KTUP_GRADNORM_WS_DOUBLES of include/ktup_hip.h
+OPTIM_WS_DOUBLES = 784                          # KTUP_OPTIM_WS_DOUBLES of include/ktup_hip.h
 KINDS = {optim.SGD: 0, optim.Adagrad: 1, optim.Adam: 2, optim.RMSprop: 3}
 
 
@@ -36,6 +38,7 @@ class FusedOptimizer(object):
             raise L.KtupError('FusedOptimizer implements the reference configuration only (no maximize / amsgrad / nesterov / '
                               'centered / dampening / lr_decay)')
         self._sumsq = None
+        self.one_launch = os.environ.get('KTUP_CLIP_STEP', '1') != '0'
         self._plan = None
         self._fresh = []
         self._dev_steps = None                   # Adam: step counts in device memory (the launch is then graph-replayable)
@@ -94,18 +97,21 @@ class FusedOptimizer(object):
         return s1, s2, first
 
     def sumsq_ptr(self, dev):
-        """Device double the gradient norm accumulates into; the fused step kernels zero it for the launch that follows."""
+        """Device workspace of the clip: [0] = the squared gradient norm of the last clipped step, the rest is the one-launch
+        kernel's barrier scratch (zero-filled once, here)."""
         if self._sumsq is None or self._sumsq.device != dev:
-            self._sumsq = torch.zeros(GRADNORM_WS_DOUBLES, dtype=torch.float64, device=dev)   # [0] = the norm; the rest: slot / ticket scratch
+            self._sumsq = torch.zeros(OPTIM_WS_DOUBLES, dtype=torch.float64, device=dev)
         return self._sumsq.data_ptr()
 
+    def barrier_timeouts(self):
+        """Non-zero if a ktup_optim_clip_step launch ever gave up waiting at its grid barrier (device -> host sync; tests)."""
+        return 0 if self._sumsq is None else int(self._sumsq[OPTIM_WS_DOUBLES - 1:].view(torch.int64).item())
+
     @torch.no_grad()
-    def clip_and_step(self, max_norm, zero_grads=False, loss=None, fold=None):
+    def clip_and_step(self, max_norm, zero_grads=False, loss=None):
         """`zero_grads`: leave the gradients zero-filled (the next step's zero_grad folded into this pass) instead of
         clipped in place.  `loss` = (slots_ptr, n_slots, scale, out_ptr): the fused training step's loss slots are folded into
-        *out and cleared by the norm launch (ktup_optim_gradnorm_loss).  `fold` = (part_ptr, n_part, elems, dA0, dA1, dC0, dC1):
-        the step kernel left the small tables' gradients as per-workgroup partial sums; the norm launch folds them into the
-        gradient tensors dA0 (dA1) / dC0 (dC1) -- torch tensors, excluded from its own tensor list (include/ktup_hip.h)."""
+        *out and cleared by the same launch (needs the one-launch route)."""
         self._flush_steps()
         group = self.optimizer.param_groups[0]
         ps = [p for p in group['params'] if p.grad is not None]
@@ -133,35 +139,20 @@ class FusedOptimizer(object):
                 self._dev_steps_for = key[:-1]
             self._dev_steps.add_(1)
             steps_dev = self._dev_steps.data_ptr()
-        sumsq = None
         clip = max_norm is not None and max_norm > 0
-        if loss is not None:
-            sumsq = self.sumsq_ptr(dev)
-            if fold is not None:
-                skip = {t.data_ptr() for t in fold[3:] if t is not None}
-                fkey = tuple(sorted(skip))
-                if getattr(self, '_fold_plan', None) is None or self._fold_plan[0] != (key, fkey):
-                    keep = [p for p in ps if p.grad.data_ptr() not in skip]
-                    self._fold_plan = ((key, fkey), len(keep), _arr(ctypes.c_void_p, [p.grad.data_ptr() for p in keep]),
-                                       _arr(ctypes.c_int64, [p.numel() for p in keep]))
-                _, fn, fgrads, fsizes = self._fold_plan
-                dp = [None if t is None else t.data_ptr() for t in fold[3:]]
-                L.call('ktup_optim_gradnorm_loss', fn, fgrads, fsizes, sumsq, loss[0], int(loss[1]), float(loss[2]), loss[3],
-                       fold[0], int(fold[1]), int(fold[2]), dp[0], dp[1], dp[2], dp[3], stream)
-            else:
-                L.call('ktup_optim_gradnorm_loss', n, grads, sizes, sumsq, loss[0], int(loss[1]), float(loss[2]), loss[3],
-                       None, 0, 0, None, None, None, None, stream)
-            if not clip:
-                sumsq = None
-        elif clip:
+        betas = group.get('betas', (0.9, 0.999))
+        hyper = (float(group['lr']), float(group['weight_decay']), float(group.get('momentum', 0.0)), float(betas[0]), float(betas[1]),
+                 float(group.get('eps', 0.0)), float(group.get('alpha', 0.0)))
+        head = (self.kind, n, params, grads, s1, s2, sizes, _arr(ctypes.c_int64, steps), steps_dev, _arr(ctypes.c_int32, firsts)) + hyper
+        if self.one_launch or loss is not None:
+            lo = (None, 0, 0.0, None) if loss is None else (loss[0], int(loss[1]), float(loss[2]), loss[3])
+            L.call('ktup_optim_clip_step', *head, self.sumsq_ptr(dev), float(max_norm) if clip else 0.0, int(bool(zero_grads)), *lo, stream)
+            return
+        sumsq = None
+        if clip:
             sumsq = self.sumsq_ptr(dev)
             L.call('ktup_optim_gradnorm', n, grads, sizes, sumsq, stream)
-        betas = group.get('betas', (0.9, 0.999))
-        L.call('ktup_optim_step', self.kind, n, params, grads, s1, s2, sizes, _arr(ctypes.c_int64, steps), steps_dev,
-               _arr(ctypes.c_int32, firsts),
-               float(group['lr']), float(group['weight_decay']), float(group.get('momentum', 0.0)), float(betas[0]), float(betas[1]),
-               float(group.get('eps', 0.0)), float(group.get('alpha', 0.0)), sumsq, float(max_norm) if sumsq is not None else 0.0,
-               int(bool(zero_grads)), stream)
+        L.call('ktup_optim_step', *head, sumsq, float(max_norm) if clip else 0.0, int(bool(zero_grads)), stream)
 
     def _make_plan(self, ps, key, group):
         """Validate once per set of (parameter, gradient) buffers and keep the pointer arrays: rebuilding them every step

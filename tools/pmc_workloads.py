@@ -1,6 +1,7 @@
 """Small fixed workloads for rocprofv3 counter passes (run under `rocprofv3 --kernel-trace --pmc ... -- python tools/pmc_workloads.py <name>`):
     eval_pass   the fused all-item evaluation sweep at ml1m shape (ktup_eval_pref_topk_prepared), 5 sweeps
     train_step  the three-launch B=512 joint training step, 20 rec + 20 kg steps
+    seg_bwd     the large-batch backwards by sorted segments: TransE (307,200 triples) and KTUP (716,800 pairs), 5 each
 tools/pmc_summary.py turns the counter_collection.csv into per-kernel averages."""
 import os
 import sys
@@ -33,5 +34,19 @@ def train_step(dev):
     B.train_step_bench(dev, steps=40, warmup=10)
 
 
+def seg_bwd(dev):
+    from jTransUP.hip import ops
+    W, i2e, idx = B.build_world(3, dev)
+    T = {k: v.to(dev) for k, v in W.items()}
+    X = {k: v.to(dev) for k, v in idx.items()}
+    i2e = i2e.to(dev, torch.int32)
+    for _ in range(5):
+        E, R = (T[k].detach().clone().requires_grad_(True) for k in ('E', 'R'))
+        ops.score_transe(E, R, X['h'], X['t'], X['r'], False).sum().backward()
+        tabs = [T[k].detach().clone().requires_grad_(True) for k in ('U', 'I', 'E', 'P', 'Pn', 'R', 'Rn')]
+        ops.score_ktup(*tabs, i2e, X['u'], X['i'], False).sum().backward()
+    torch.cuda.synchronize()
+
+
 if __name__ == '__main__':
-    {'eval_pass': eval_pass, 'train_step': train_step}[sys.argv[1]](torch.device('cuda'))
+    {'eval_pass': eval_pass, 'train_step': train_step, 'seg_bwd': seg_bwd}[sys.argv[1]](torch.device('cuda'))

@@ -91,6 +91,16 @@ int ktup_score_transr_fwd(const float* E, int64_t lde, const float* R, int64_t l
 int ktup_score_transr_bwd(const float* E, int64_t lde, const float* R, int64_t ldr, const float* M, int64_t ldm,
                           int d, const int64_t* h, const int64_t* t, const int64_t* r, int64_t n, int l1,
                           const float* gscore, float* gE, float* gR, float* gM, void* stream);
+/* Backward with scratch `ws` of ktup_score_transr_bwd_workspace_bytes(n, d, n_ent, n_rel) bytes (256-byte aligned; 0 = no
+ * scratch route for this shape): the batch is bucketed by relation like the forward, gq = M_r^T gy and gM_r += gy (x) (h - t)
+ * run on the matrix cores (d in {64,100,128}, n_rel <= 4096, ldm >= d*d) with gM_r / gR accumulated in registers per relation
+ * run, and from n >= option seg_bwd_min the entity-row gradients are summed by sorted segments instead of float atomics.
+ * ws == NULL or another shape: exactly ktup_score_transr_bwd (M_r streamed and d*d atomics per triple).                 */
+size_t ktup_score_transr_bwd_workspace_bytes(int64_t n, int d, int64_t n_ent, int64_t n_rel);
+int ktup_score_transr_bwd_ws(const float* E, int64_t lde, const float* R, int64_t ldr, const float* M, int64_t ldm,
+                             int d, const int64_t* h, const int64_t* t, const int64_t* r, int64_t n, int l1,
+                             const float* gscore, float* gE, float* gR, float* gM, int64_t n_ent, int64_t n_rel, void* ws,
+                             void* stream);
 
 /* K1-K3 backward with caller scratch, for large batches: from n >= option seg_bwd_min (default 8192) every row's gradient vector
  * is written with plain stores and summed per table row by sorted segments (ktup_segment_reduce_rows, below) -- float atomics

@@ -58,6 +58,10 @@ size_t transr_mc_workspace_bytes(int64_t n, int64_t n_rel);
 int transr_fwd_mc(const float* E, int64_t lde, const float* R, int64_t ldr, const float* M, int64_t ldm, int64_t n_rel, int d,
                   const int64_t* h, const int64_t* t, const int64_t* r, int64_t n, int l1, float* score, void* ws, hipStream_t st,
                   const char* name);
+// relation-bucketed matrix-core TransR backward (same scratch as the forward); G != NULL: entity-row gradients stored per triple
+int transr_bwd_mc(const float* E, int64_t lde, const float* R, int64_t ldr, const float* M, int64_t ldm, int64_t n_rel, int d,
+                  const int64_t* h, const int64_t* t, const int64_t* r, int64_t n, int l1, const float* gscore, float* gE, float* gR,
+                  float* gM, float* G, void* ws, hipStream_t st, const char* name);
 
 // ktup_eval_mc.hip: squared-L2 soft-gate all-item scores as six matrix-core GEMMs.  Returns 1 for sizes it does not cover.
 int pairs_l2_mc(const float* QW, const float* C0, const float* C1, const float* C2, int d, int64_t nq, int64_t n_items, float* out,

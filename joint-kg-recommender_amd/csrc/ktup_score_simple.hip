@@ -542,14 +542,20 @@ struct KgSegArgs {
   const float* gs; float* G; float *gR, *gN;
 };
 
-template <int GL, bool TRANSH>
+// PRIV: every lane group accumulates the relation-side gradients in its OWN LDS copy with float4 read-modify-writes (a wave's LDS
+// operations execute in order, and the lanes of a group own distinct addresses).  Shared accumulators with ds_add_f32 ran at
+// 0.3 lane-atomics per clock and CU -- the two lane groups of a wave usually hit the same relation row -- and were 150 of the
+// kernel's 168 us at 307,200 triples; they remain for relation tables too large for 256 / GL copies.
+template <int GL, bool TRANSH, bool PRIV>
 __global__ __launch_bounds__(256) void kg_bwd_rowout_kernel(KgSegArgs a) {
-  extern __shared__ float kacc[];                                 // [(TRANSH ? 2 : 1)][n_rel * d]
+  extern __shared__ __attribute__((aligned(16))) float kacc[];    // [PRIV ? 256 / GL : 1][(TRANSH ? 2 : 1)][n_rel * d]
   const int relems = a.n_rel * a.d;
-  for (int i = threadIdx.x; i < (TRANSH ? 2 : 1) * relems; i += 256) kacc[i] = 0.f;
-  __syncthreads();
   constexpr int GPB = 256 / GL;
+  constexpr int NT = TRANSH ? 2 : 1;
+  for (int i = threadIdx.x; i < (PRIV ? GPB : 1) * NT * relems; i += 256) kacc[i] = 0.f;
+  __syncthreads();
   const int lane = threadIdx.x % GL;
+  float* mine = kacc + (PRIV ? (threadIdx.x / GL) * NT * relems : 0);
   const bool on = lane < a.nch;
   // two triples per lane group and trip: both id loads, then all eight row loads, are in flight together (one triple per trip
   // left the kernel waiting on two dependent memory round trips per 1.6 KB moved)
@@ -593,11 +599,20 @@ __global__ __launch_bounds__(256) void kg_bwd_rowout_kernel(KgSegArgs a) {
       }
       if (on && live[x]) {
         reinterpret_cast<float4*>(a.G + kk[x] * a.d)[lane] = gh;
-        float* r0 = kacc + rr[x] * a.d + 4 * lane;
-        atomicAdd(r0 + 0, gz.x); atomicAdd(r0 + 1, gz.y); atomicAdd(r0 + 2, gz.z); atomicAdd(r0 + 3, gz.w);
-        if (TRANSH) {
-          float* w0 = r0 + relems;
-          atomicAdd(w0 + 0, gw.x); atomicAdd(w0 + 1, gw.y); atomicAdd(w0 + 2, gw.z); atomicAdd(w0 + 3, gw.w);
+        float* r0 = mine + rr[x] * a.d + 4 * lane;
+        if (PRIV) {
+          float4* q0 = reinterpret_cast<float4*>(r0);
+          *q0 = *q0 + gz;
+          if (TRANSH) {
+            float4* q1 = reinterpret_cast<float4*>(r0 + relems);
+            *q1 = *q1 + gw;
+          }
+        } else {
+          atomicAdd(r0 + 0, gz.x); atomicAdd(r0 + 1, gz.y); atomicAdd(r0 + 2, gz.z); atomicAdd(r0 + 3, gz.w);
+          if (TRANSH) {
+            float* w0 = r0 + relems;
+            atomicAdd(w0 + 0, gw.x); atomicAdd(w0 + 1, gw.y); atomicAdd(w0 + 2, gw.z); atomicAdd(w0 + 3, gw.w);
+          }
         }
       }
     }
@@ -605,8 +620,14 @@ __global__ __launch_bounds__(256) void kg_bwd_rowout_kernel(KgSegArgs a) {
   __syncthreads();
   for (int i = threadIdx.x; i < relems; i += 256) {
     const int row = i / a.d, col = i - row * a.d;
-    if (kacc[i] != 0.f) atomicAdd(a.gR + (int64_t)row * a.ldr + col, kacc[i]);
-    if (TRANSH && kacc[relems + i] != 0.f) atomicAdd(a.gN + (int64_t)row * a.ldn + col, kacc[relems + i]);
+    float vr = 0.f, vn = 0.f;
+#pragma unroll
+    for (int g = 0; g < (PRIV ? GPB : 1); ++g) {
+      vr += kacc[g * NT * relems + i];
+      if (TRANSH) vn += kacc[g * NT * relems + relems + i];
+    }
+    if (vr != 0.f) atomicAdd(a.gR + (int64_t)row * a.ldr + col, vr);
+    if (TRANSH && vn != 0.f) atomicAdd(a.gN + (int64_t)row * a.ldn + col, vn);
   }
 }
 
@@ -679,6 +700,39 @@ extern "C" int ktup_score_transr_bwd(const float* E, int64_t lde, const float* R
                        "ktup_score_transr_bwd");
 }
 
+// K4 backward with caller scratch: relation-bucketed on the matrix cores (d in {64, 100, 128}); from option seg_bwd_min rows on,
+// the entity-row gradients go through the segment reduction instead of 2 d float atomics per triple.  Other shapes, or no
+// scratch: exactly ktup_score_transr_bwd.
+static size_t transr_bucket_bytes(int64_t n, int64_t n_rel) { return (ktup::transr_mc_workspace_bytes(n, n_rel) + 255) & ~(size_t)255; }
+static bool transr_seg(int64_t n, int64_t n_ent) { return n_ent > 0 && ktup::opt_seg_bwd_min() > 0 && n >= ktup::opt_seg_bwd_min(); }
+
+extern "C" size_t ktup_score_transr_bwd_workspace_bytes(int64_t n, int d, int64_t n_ent, int64_t n_rel) {
+  if (n <= 0 || n_rel <= 0 || (d != 64 && d != 100 && d != 128)) return 0;
+  return transr_bucket_bytes(n, n_rel) + (transr_seg(n, n_ent) ? g_bytes(n, d) + ktup::seg_ws_bytes(n, n_ent) : 0);
+}
+
+extern "C" int ktup_score_transr_bwd_ws(const float* E, int64_t lde, const float* R, int64_t ldr, const float* M, int64_t ldm,
+                                        int d, const int64_t* h, const int64_t* t, const int64_t* r, int64_t n, int l1,
+                                        const float* gscore, float* gE, float* gR, float* gM, int64_t n_ent, int64_t n_rel, void* ws,
+                                        void* stream) {
+  const char* name = "ktup_score_transr_bwd_ws";
+  if (ws && n > 0 && n_rel > 0 && E && R && M && h && t && r && gscore && gE && gR && gM && ktup::opt_pref_mc()) {
+    hipStream_t st = (hipStream_t)stream;
+    const bool seg = transr_seg(n, n_ent);
+    char* base = reinterpret_cast<char*>(ws) + transr_bucket_bytes(n, n_rel);
+    float* G = seg ? reinterpret_cast<float*>(base) : nullptr;
+    int rc = ktup::transr_bwd_mc(E, lde, R, ldr, M, ldm, n_rel, d, h, t, r, n, l1, gscore, gE, gR, gM, G, ws, st, name);
+    if (rc == KTUP_OK && seg) {
+      void* sws = base + g_bytes(n, d);
+      rc = ktup::seg_reduce(G, d, d, n, h, n, n, n_ent, gE, lde, nullptr, -1, nullptr, 0, sws, st, name);
+      if (rc == KTUP_OK) rc = ktup::seg_reduce(G, d, d, n, t, n, 0, n_ent, gE, lde, nullptr, -1, nullptr, 0, sws, st, name);
+      if (rc == 1) return set_error(KTUP_ERR_UNSUPPORTED, "%s: segment reduction does not cover this shape", name);
+    }
+    if (rc != 1) return rc;
+  }
+  return transr_launch(true, E, lde, R, ldr, M, ldm, d, h, t, r, n, l1, nullptr, gscore, gE, gR, gM, stream, name);
+}
+
 // ---- backward with caller scratch: for n >= option seg_bwd_min (default 8192) the row gradients are written per row and summed
 // per table row by sorted segments (ktup_segment_reduce_rows) instead of float atomics; otherwise exactly the *_bwd entry points.
 extern "C" size_t ktup_score_kg_bwd_workspace_bytes(int64_t n, int d, int64_t n_ent) {
@@ -698,8 +752,20 @@ static int kg_bwd_seg(bool transh, const char* name, const float* E, int64_t lde
 #define KTUP_KGSEG(GL)                                                                                                     \
   {                                                                                                                        \
     const int grid = grid_for((n + (256 / GL) - 1) / (256 / GL), 256 * 2);   /* every workgroup ends with n_rel x d atomics */ \
-    if (transh) hipLaunchKernelGGL((kg_bwd_rowout_kernel<GL, true>), dim3(grid), dim3(256), lds, st, a);                   \
-    else hipLaunchKernelGGL((kg_bwd_rowout_kernel<GL, false>), dim3(grid), dim3(256), lds, st, a);                         \
+    const size_t plds = lds * (256 / GL);                                                                                  \
+    const bool priv = plds <= 144 * 1024;                                                                                  \
+    if (priv) {                                                                                                            \
+      if (transh) {                                                                                                        \
+        (void)hipFuncSetAttribute((const void*)kg_bwd_rowout_kernel<GL, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds); \
+        hipLaunchKernelGGL((kg_bwd_rowout_kernel<GL, true, true>), dim3(grid), dim3(256), plds, st, a);                    \
+      } else {                                                                                                             \
+        (void)hipFuncSetAttribute((const void*)kg_bwd_rowout_kernel<GL, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds); \
+        hipLaunchKernelGGL((kg_bwd_rowout_kernel<GL, false, true>), dim3(grid), dim3(256), plds, st, a);                   \
+      }                                                                                                                    \
+    } else {                                                                                                               \
+      if (transh) hipLaunchKernelGGL((kg_bwd_rowout_kernel<GL, true, false>), dim3(grid), dim3(256), lds, st, a);          \
+      else hipLaunchKernelGGL((kg_bwd_rowout_kernel<GL, false, false>), dim3(grid), dim3(256), lds, st, a);                \
+    }                                                                                                                      \
   }
   if (nch <= 16) KTUP_KGSEG(16) else if (nch <= 32) KTUP_KGSEG(32) else KTUP_KGSEG(64)
 #undef KTUP_KGSEG

@@ -34,6 +34,8 @@ SIGNATURES = {
     'ktup_score_transr_workspace_bytes': [c_l, c_l],
     'ktup_score_transr_fwd': [c_p, c_l, c_p, c_l, c_p, c_l, c_l, c_i, c_p, c_p, c_p, c_l, c_i, c_p, c_p, c_p],
     'ktup_score_transr_bwd': [c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_p, c_p, c_p, c_l, c_i, c_p, c_p, c_p, c_p, c_p],
+    'ktup_score_transr_bwd_workspace_bytes': [c_l, c_i, c_l, c_l],
+    'ktup_score_transr_bwd_ws': [c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_p, c_p, c_p, c_l, c_i, c_p, c_p, c_p, c_p, c_l, c_l, c_p, c_p],
     'ktup_score_kg_bwd_workspace_bytes': [c_l, c_i, c_l],
     'ktup_score_transe_bwd_ws': [c_p, c_l, c_p, c_l, c_i, c_p, c_p, c_p, c_l, c_i, c_p, c_p, c_p, c_l, c_l, c_p, c_p],
     'ktup_score_transh_bwd_ws': [c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_p, c_p, c_p, c_l, c_i, c_p, c_p, c_p, c_p, c_l, c_l, c_p, c_p],
@@ -101,7 +103,7 @@ SIGNATURES = {
     'ktup_negsample_kg': [c_p, c_p, c_p, c_l, c_l, c_l, c_p, c_l, c_u, c_u, c_p, c_p, c_p, c_p],
 }
 _RESTYPE = {'ktup_last_error': ctypes.c_char_p, 'ktup_pref_workspace_bytes': ctypes.c_size_t,
-            'ktup_eval_kg_workspace_bytes': ctypes.c_size_t, 'ktup_eval_transr_workspace_bytes': ctypes.c_size_t, 'ktup_score_transr_workspace_bytes': ctypes.c_size_t,
+            'ktup_eval_kg_workspace_bytes': ctypes.c_size_t, 'ktup_eval_transr_workspace_bytes': ctypes.c_size_t, 'ktup_score_transr_workspace_bytes': ctypes.c_size_t, 'ktup_score_transr_bwd_workspace_bytes': ctypes.c_size_t,
             'ktup_eval_pref_workspace_bytes': ctypes.c_size_t, 'ktup_eval_pref_items_workspace_bytes': ctypes.c_size_t, 'ktup_negsample_rec_workspace_bytes': ctypes.c_size_t,
             'ktup_score_pref_bwd_workspace_bytes': ctypes.c_size_t, 'ktup_segment_workspace_bytes': ctypes.c_size_t, 'ktup_shard_dedupe_workspace_bytes': ctypes.c_size_t,
             'ktup_eval_pref_topk_workspace_bytes': ctypes.c_size_t,

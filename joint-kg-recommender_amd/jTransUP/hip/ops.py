@@ -148,8 +148,10 @@ class _ScoreTransR(Function):
         E, R, M, h, t, r = ctx.saved_tensors
         gs = _vec(gs, h.numel())
         gE, gR, gM = torch.zeros_like(E), torch.zeros_like(R), torch.zeros_like(M)
-        L.call('ktup_score_transr_bwd', _p(E), E.stride(0), _p(R), R.stride(0), _p(M), M.stride(0), E.shape[1], _p(h), _p(t),
-               _p(r), h.numel(), ctx.l1, _p(gs), _p(gE), _p(gR), _p(gM), _stream(E.device))
+        n, n_rel = h.numel(), min(R.shape[0], M.shape[0])
+        ws = _seg_ws(L.load().ktup_score_transr_bwd_workspace_bytes(n, E.shape[1], E.shape[0], n_rel), E.device)
+        L.call('ktup_score_transr_bwd_ws', _p(E), E.stride(0), _p(R), R.stride(0), _p(M), M.stride(0), E.shape[1], _p(h), _p(t),
+               _p(r), n, ctx.l1, _p(gs), _p(gE), _p(gR), _p(gM), E.shape[0], n_rel, _p(ws), _stream(E.device))
         return gE, gR, gM, None, None, None, None
 
 

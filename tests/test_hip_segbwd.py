@@ -225,3 +225,39 @@ def test_kg_and_bprmf_backward_by_segments(d):
                 for a, b in zip(Wd, Wc):
                     scale = float(b.grad.abs().max())
                     close(a.grad, b.grad, rtol=2e-4, atol=2e-5 * max(scale, 1.0))
+
+
+@pytest.mark.parametrize('d', [100, 64, 128])
+@pytest.mark.parametrize('n', [700, 9000])
+def test_transr_backward_on_the_matrix_cores(d, n):
+    """K4 backward (ktup_score_transr_bwd_ws): relation buckets, gq = M^T gy and gM += gy (x) (h - t) on the matrix cores, against
+    the oracle's autograd and against the generic per-triple kernel (option pref_mc = 0).  n = 700: atomics for the entity rows,
+    partial 16-triple tiles and rounds with idle waves; n = 9000: entity rows by sorted segments; one relation takes most of the
+    batch (several 1024-triple passes), two relations never occur."""
+    ne, nr = 150, 9
+    gen = torch.Generator().manual_seed(1000 * d + n)
+    E, R = O.make_table(ne, d, gen), O.make_table(nr, d, gen)
+    M = torch.nn.functional.normalize(torch.randn(nr, d * d, generator=gen), dim=1)
+    h = torch.randint(0, ne, (n,), generator=gen); t = torch.randint(0, ne, (n,), generator=gen)
+    r = torch.randint(0, nr - 2, (n,), generator=gen)
+    r[torch.rand(n, generator=gen) < 0.6] = 4
+    h[: n // 6] = 3
+    wgt = torch.randn(n, generator=gen)
+    assert L.load().ktup_score_transr_bwd_workspace_bytes(n, d, ne, nr) > 0
+    for l1 in (False, True):
+        Wc = [x.clone().requires_grad_(True) for x in (E, R, M)]
+        ref = O.score_transr(Wc[0], Wc[1], Wc[2], h, t, r, l1)
+        (ref * wgt).sum().backward()
+        for mc in (1, 0):
+            old = L.set_option('pref_mc', mc)
+            try:
+                Wd = [x.to(DEV).requires_grad_(True) for x in (E, R, M)]
+                got = ops().score_transr(Wd[0], Wd[1], Wd[2], h.to(DEV), t.to(DEV), r.to(DEV), l1)
+                (got * wgt.to(DEV)).sum().backward()
+            finally:
+                L.set_option('pref_mc', old)
+            close(got, ref, rtol=2e-4, atol=5e-5)
+            for a, b in zip(Wd, Wc):
+                scale = float(b.grad.abs().max())
+                close(a.grad, b.grad, rtol=2e-4, atol=2e-5 * max(scale, 1.0))
+            assert float(Wd[2].grad[7:].abs().sum()) == 0.0                   # relations that never occur receive nothing

@@ -19,6 +19,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -32,6 +33,7 @@ import torch.nn.functional as F
 
 # ml1m shape: users, items, entities, relations, aligned items
 NU, NI, NE, NR, ALIGNED, D = 6040, 3240, 14708, 20, 2934, 100
+LEG_TIMEOUT_S = 240          # the N-GPU legs (dp_train_step, config5_step) may take this long before rank 0 reports without them
 REC_ROWS, KG_ROWS = 716800, 307200
 HBM_PEAK_GBS = 8000.0                      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 FP32_PEAK_TFLOPS = 157.3                   # dense fp32 MFMA = VALU fp32 peak (same pipe on gfx950, MI355X_MICROARCH.md)
@@ -763,11 +765,24 @@ def main():
         # the N-GPU legs the scoring headline cannot show (it has no exchange step): config 4's data-parallel training step and
         # config 5's row-sharded step, each with its comm / compute split (every rank takes part; rank 0 reports)
         legs = {}
+
+        def give_up():          # a rank stuck in a leg's collective must not take the headline line down with it
+            if rank == 0:
+                done = dict(out)
+                for name in ('dp_train_step', 'config5_step'):
+                    done[name] = legs.get(name, {'error': 'timeout after %d s' % LEG_TIMEOUT_S})
+                print(json.dumps(done), flush=True)
+            os._exit(0)
+
+        watchdog = threading.Timer(LEG_TIMEOUT_S, give_up)
+        watchdog.daemon = True
+        watchdog.start()
         for name, fn in (('dp_train_step', dp_train_leg), ('config5_step', config5_leg)):
             try:
                 legs[name] = fn(device, world, rank)
             except Exception as e:      # noqa: BLE001 -- a leg must not take the headline line down with it
                 legs[name] = {'error': '%s: %s' % (type(e).__name__, e)}
+        watchdog.cancel()
         if rank == 0:
             out.update(legs)
     if rank == 0:

@@ -346,6 +346,22 @@ int ktup_negsample_rec(const int64_t* u_ids, const int64_t* pos_items, int64_t n
 int ktup_negsample_kg(const int64_t* h, const int64_t* t, const int64_t* r, int64_t n, int64_t n_ent, int64_t n_rel,
                       const uint64_t* sorted_keys, int64_t n_keys, uint64_t seed, uint64_t offset, int64_t* neg_h,
                       int64_t* neg_t, int32_t* fail_count, void* stream);
+/* Feed (new): one launch builds a whole training batch in the steppers' layout from DEVICE-resident state, so that a step
+ * replays from a HIP graph with no host work in between (the reference assembles each batch in python: utils/data.py:87-110
+ * MakeTrainIterator, then :64-85 / :12-56).  `col_*`: this epoch's shuffled example columns (n_rows each; the host reshuffles
+ * them in place once per epoch and resets *cursor); rows [*cursor, *cursor + B) are the batch.  Negatives exactly as
+ * ktup_negsample_rec / _kg draw them for (seed, *offset_dev).  Outputs, 2B ids each: u2 = [u ; u], i2 = [pos ; neg] resp.
+ * h2 = [h ; neg_h], t2 = [t ; neg_t], r2 = [r ; r] -- the id arrays of ktup_train_rec_step / ktup_train_kg_step.  Afterwards
+ * *cursor += B and *offset_dev += B * 4096.  A cursor outside [0, n_rows - B] counts as a failure and restarts at row 0.
+ * ktup_feed_rec's `ws` (unique_in_batch; ktup_negsample_rec_workspace_bytes) must be all-ones (0xff bytes) before the FIRST call;
+ * every call leaves it all-ones again -- no memset inside the launch (a memset node captured in a HIP graph was observed to stop
+ * taking effect after eager memsets ran between replays).                                                              */
+int ktup_feed_rec(const int64_t* col_u, const int64_t* col_i, int64_t n_rows, int64_t B, int64_t* cursor, uint64_t* offset_dev,
+                  int64_t n_items, const uint32_t* user_item_bitmap, int64_t words_per_user, uint64_t seed, int unique_in_batch,
+                  int64_t* u2, int64_t* i2, void* ws, int32_t* fail_count, void* stream);
+int ktup_feed_kg(const int64_t* col_h, const int64_t* col_t, const int64_t* col_r, int64_t n_rows, int64_t B, int64_t* cursor,
+                 uint64_t* offset_dev, int64_t n_ent, int64_t n_rel, const uint64_t* sorted_keys, int64_t n_keys, uint64_t seed,
+                 int64_t* h2, int64_t* t2, int64_t* r2, int32_t* fail_count, void* stream);
 
 /* ------------------------------------------- K20  global-norm clip + dense optimizer step
  * Replaces   torch.nn.utils.clip_grad_norm(params, max_norm); optimizer.step()

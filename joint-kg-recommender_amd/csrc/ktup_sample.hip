@@ -34,45 +34,48 @@ KTUP_DEV int64_t draw_item(const Philox& ph, uint64_t offset, int64_t row, int t
 }
 KTUP_DEV bool rated(const uint32_t* ubits, int64_t c) { return ubits && ((ubits[c >> 5] >> (c & 31)) & 1u); }
 
+// one row without batch-uniqueness
+KTUP_DEV int64_t rec_pick(const Philox& ph, uint64_t offset, int64_t b, int64_t user, int64_t p, int64_t n_items,
+                          const uint32_t* __restrict__ bitmap, int64_t words, int32_t* __restrict__ fail) {
+  const uint32_t* ubits = bitmap ? bitmap + user * words : nullptr;
+  int64_t pick = -1;
+  for (int tries = 0; tries < MAX_TRIES && pick < 0; ++tries) {
+    const int64_t c = draw_item(ph, offset, b, tries, n_items);
+    if (c != p && !rated(ubits, c)) pick = c;
+  }
+  if (pick < 0) {                                          // a user who rated (nearly) everything: scan from the last draw
+    const int64_t s0 = draw_item(ph, offset, b, MAX_TRIES - 1, n_items);
+    for (int64_t k = 0; k < n_items && pick < 0; ++k) {
+      const int64_t c = s0 + k < n_items ? s0 + k : s0 + k - n_items;
+      if (c != p && !rated(ubits, c)) pick = c;
+    }
+  }
+  if (pick < 0) {                                          // no admissible item exists: in-range stand-in + error count
+    if (fail) atomicAdd(fail, 1);
+    pick = p + 1 < n_items ? p + 1 : 0;
+  }
+  return pick;
+}
+
 // no batch-uniqueness: rows are independent
 __global__ __launch_bounds__(256) void negsample_rec_kernel(const int64_t* __restrict__ u, const int64_t* __restrict__ pos,
                                                             int64_t n, int64_t n_items, const uint32_t* __restrict__ bitmap,
                                                             int64_t words, uint64_t seed, uint64_t offset,
                                                             int64_t* __restrict__ neg, int32_t* __restrict__ fail) {
   const Philox ph(seed);
-  for (int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x; b < n; b += (int64_t)gridDim.x * 256) {
-    const uint32_t* ubits = bitmap ? bitmap + u[b] * words : nullptr;
-    const int64_t p = pos[b];
-    int64_t pick = -1;
-    for (int tries = 0; tries < MAX_TRIES && pick < 0; ++tries) {
-      const int64_t c = draw_item(ph, offset, b, tries, n_items);
-      if (c != p && !rated(ubits, c)) pick = c;
-    }
-    if (pick < 0) {                                        // a user who rated (nearly) everything: scan from the last draw
-      const int64_t s0 = draw_item(ph, offset, b, MAX_TRIES - 1, n_items);
-      for (int64_t k = 0; k < n_items && pick < 0; ++k) {
-        const int64_t c = s0 + k < n_items ? s0 + k : s0 + k - n_items;
-        if (c != p && !rated(ubits, c)) pick = c;
-      }
-    }
-    if (pick < 0) {                                        // no admissible item exists: in-range stand-in + error count
-      if (fail) atomicAdd(fail, 1);
-      pick = p + 1 < n_items ? p + 1 : 0;
-    }
-    neg[b] = pick;
-  }
+  for (int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x; b < n; b += (int64_t)gridDim.x * 256)
+    neg[b] = rec_pick(ph, offset, b, u[b], pos[b], n_items, bitmap, words, fail);
 }
 
-// batch-unique negatives, one workgroup, deterministic rounds (see the file comment).  owner[] is all-ones on entry.
-__global__ __launch_bounds__(UNIQ_THREADS) void negsample_rec_unique_kernel(const int64_t* __restrict__ u, const int64_t* __restrict__ pos,
-                                                                            int64_t n, int64_t n_items,
-                                                                            const uint32_t* __restrict__ bitmap, int64_t words,
-                                                                            uint64_t seed, uint64_t offset, int64_t* neg,
-                                                                            unsigned long long* owner, int32_t* __restrict__ fail) {
-  const Philox ph(seed);
+// batch-unique negatives by ONE workgroup of UNIQ_THREADS threads, deterministic rounds (see the file comment).  owner[] is
+// all-ones on entry; every thread of the workgroup must call this (barriers inside).
+KTUP_DEV void rec_unique_rounds(const Philox& ph, const int64_t* __restrict__ u, const int64_t* __restrict__ pos, int64_t n,
+                                int64_t n_items, const uint32_t* __restrict__ bitmap, int64_t words, uint64_t offset, int64_t* neg,
+                                unsigned long long* owner, int32_t* __restrict__ fail, bool leave_clean) {
   const int tid = threadIdx.x;
   for (int64_t b = tid; b < n; b += UNIQ_THREADS) neg[b] = -1;        // a thread only ever touches its own rows of neg[]
-  for (int t = 0; t < MAX_TRIES; ++t) {
+  bool all_done = false;
+  for (int t = 0; t < MAX_TRIES && !all_done; ++t) {
     for (int64_t b = tid; b < n; b += UNIQ_THREADS) {
       if (neg[b] >= 0) continue;
       const int64_t c = draw_item(ph, offset, b, t, n_items);
@@ -94,30 +97,46 @@ __global__ __launch_bounds__(UNIQ_THREADS) void negsample_rec_unique_kernel(cons
       }
       open = 1;
     }
-    if (!__syncthreads_or(open)) return;
+    all_done = !__syncthreads_or(open);
   }
-  // tries exhausted for some rows (more rows than admissible items, or a nearly full user): thread 0 serves them in row order
-  if (tid == 0) {
-    for (int64_t b = 0; b < n; ++b) {
-      if (neg[b] >= 0) continue;
-      const uint32_t* ubits = bitmap ? bitmap + u[b] * words : nullptr;
-      const int64_t p = pos[b], s0 = draw_item(ph, offset, b, MAX_TRIES - 1, n_items);
-      int64_t pick = -1;
-      for (int64_t k = 0; k < n_items && pick < 0; ++k) {
-        const int64_t c = s0 + k < n_items ? s0 + k : s0 + k - n_items;
-        if (c == p || rated(ubits, c)) continue;
-        if (__hip_atomic_load(owner + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ~0ull) continue;
-        pick = c;
+  if (!all_done) {
+    // tries exhausted for some rows (more rows than admissible items, or a nearly full user): thread 0 serves them in row order
+    if (tid == 0) {
+      for (int64_t b = 0; b < n; ++b) {
+        if (neg[b] >= 0) continue;
+        const uint32_t* ubits = bitmap ? bitmap + u[b] * words : nullptr;
+        const int64_t p = pos[b], s0 = draw_item(ph, offset, b, MAX_TRIES - 1, n_items);
+        int64_t pick = -1;
+        for (int64_t k = 0; k < n_items && pick < 0; ++k) {
+          const int64_t c = s0 + k < n_items ? s0 + k : s0 + k - n_items;
+          if (c == p || rated(ubits, c)) continue;
+          if (__hip_atomic_load(owner + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ~0ull) continue;
+          pick = c;
+        }
+        if (pick >= 0) {
+          __hip_atomic_store(owner + pick, (unsigned long long)b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+          if (fail) atomicAdd(fail, 1);
+          pick = p + 1 < n_items ? p + 1 : 0;
+        }
+        neg[b] = pick;
       }
-      if (pick >= 0) {
-        __hip_atomic_store(owner + pick, (unsigned long long)b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      } else {
-        if (fail) atomicAdd(fail, 1);
-        pick = p + 1 < n_items ? p + 1 : 0;
-      }
-      neg[b] = pick;
     }
+    __syncthreads();
   }
+  // leave owner[] all-ones again: every entry a proposal touched ended up with the key of the row that won it (earlier rounds
+  // and lower rows win, nothing overwrites a smaller key), so clearing the batch's own negatives clears everything
+  if (leave_clean)
+    for (int64_t b = tid; b < n; b += UNIQ_THREADS) __hip_atomic_store(owner + neg[b], ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ __launch_bounds__(UNIQ_THREADS) void negsample_rec_unique_kernel(const int64_t* __restrict__ u, const int64_t* __restrict__ pos,
+                                                                            int64_t n, int64_t n_items,
+                                                                            const uint32_t* __restrict__ bitmap, int64_t words,
+                                                                            uint64_t seed, uint64_t offset, int64_t* neg,
+                                                                            unsigned long long* owner, int32_t* __restrict__ fail) {
+  const Philox ph(seed);
+  rec_unique_rounds(ph, u, pos, n, n_items, bitmap, words, offset, neg, owner, fail, true);
 }
 
 KTUP_DEV bool known(const uint64_t* __restrict__ keys, int64_t nk, uint64_t key) {
@@ -129,39 +148,98 @@ KTUP_DEV bool known(const uint64_t* __restrict__ keys, int64_t nk, uint64_t key)
   return lo < nk && keys[lo] == key;
 }
 
+// one triple: fair coin -> corrupt head or tail
+KTUP_DEV void kg_pick(const Philox& ph, uint64_t offset, int64_t b, int64_t hh, int64_t tt, int64_t rr, int64_t n_ent, int64_t n_rel,
+                      const uint64_t* __restrict__ keys, int64_t nk, int32_t* __restrict__ fail, int64_t& out_h, int64_t& out_t) {
+  const uint64_t base = offset + (uint64_t)b * MAX_TRIES;
+  const bool corrupt_head = (draw(ph, base >> 2, (int)(base & 3)) & 0x80000000u) != 0;   // fair coin (data.py:13)
+  const int64_t orig = corrupt_head ? hh : tt;
+  auto admissible = [&](int64_t c) {
+    if (c == orig) return false;
+    if (!keys) return true;
+    const uint64_t key = corrupt_head ? ((uint64_t)c * n_rel + rr) * n_ent + tt : ((uint64_t)hh * n_rel + rr) * n_ent + c;
+    return !known(keys, nk, key);
+  };
+  int64_t pick = -1, last = 0;
+  for (int tries = 1; tries < MAX_TRIES && pick < 0; ++tries) {
+    last = draw_item(ph, offset, b, tries, n_ent);
+    if (admissible(last)) pick = last;
+  }
+  for (int64_t k = 0; k < n_ent && pick < 0; ++k) {        // tries exhausted: deterministic scan from the last draw
+    const int64_t c = last + k < n_ent ? last + k : last + k - n_ent;
+    if (admissible(c)) pick = c;
+  }
+  if (pick < 0) {
+    if (fail) atomicAdd(fail, 1);
+    pick = orig + 1 < n_ent ? orig + 1 : 0;
+  }
+  out_h = corrupt_head ? pick : hh;
+  out_t = corrupt_head ? tt : pick;
+}
+
 __global__ __launch_bounds__(256) void negsample_kg_kernel(const int64_t* __restrict__ h, const int64_t* __restrict__ t,
                                                            const int64_t* __restrict__ r, int64_t n, int64_t n_ent, int64_t n_rel,
                                                            const uint64_t* __restrict__ keys, int64_t nk, uint64_t seed,
                                                            uint64_t offset, int64_t* __restrict__ nh, int64_t* __restrict__ nt,
                                                            int32_t* __restrict__ fail) {
   const Philox ph(seed);
-  for (int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x; b < n; b += (int64_t)gridDim.x * 256) {
-    const int64_t hh = h[b], tt = t[b], rr = r[b];
-    const uint64_t base = offset + (uint64_t)b * MAX_TRIES;
-    const bool corrupt_head = (draw(ph, base >> 2, (int)(base & 3)) & 0x80000000u) != 0;   // fair coin (data.py:13)
-    const int64_t orig = corrupt_head ? hh : tt;
-    auto admissible = [&](int64_t c) {
-      if (c == orig) return false;
-      if (!keys) return true;
-      const uint64_t key = corrupt_head ? ((uint64_t)c * n_rel + rr) * n_ent + tt : ((uint64_t)hh * n_rel + rr) * n_ent + c;
-      return !known(keys, nk, key);
-    };
-    int64_t pick = -1, last = 0;
-    for (int tries = 1; tries < MAX_TRIES && pick < 0; ++tries) {
-      last = draw_item(ph, offset, b, tries, n_ent);
-      if (admissible(last)) pick = last;
-    }
-    for (int64_t k = 0; k < n_ent && pick < 0; ++k) {        // tries exhausted: deterministic scan from the last draw
-      const int64_t c = last + k < n_ent ? last + k : last + k - n_ent;
-      if (admissible(c)) pick = c;
-    }
-    if (pick < 0) {
-      if (fail) atomicAdd(fail, 1);
-      pick = orig + 1 < n_ent ? orig + 1 : 0;
-    }
-    nh[b] = corrupt_head ? pick : hh;
-    nt[b] = corrupt_head ? tt : pick;
+  for (int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x; b < n; b += (int64_t)gridDim.x * 256)
+    kg_pick(ph, offset, b, h[b], t[b], r[b], n_ent, n_rel, keys, nk, fail, nh[b], nt[b]);
+}
+
+// ---- feed kernels: batch + negatives + the steppers' [pos ; neg] id layout in ONE launch whose every argument is static, so a
+// training step replays from a HIP graph with no host work between steps (the reference builds each batch in python:
+// utils/data.py:87-110 MakeTrainIterator + :64-85 / :12-56).  `cols`: this epoch's shuffled example columns (the host
+// reshuffles them in place once per epoch); *cursor: first row of the next batch; *offset_dev: the Philox counter the
+// host-driven samplers take as an argument -- the same (seed, offset) sequence, hence the same negatives.  One workgroup.
+__global__ __launch_bounds__(UNIQ_THREADS) void feed_rec_kernel(const int64_t* __restrict__ col_u, const int64_t* __restrict__ col_i,
+                                                                int64_t n_rows, int64_t B, int64_t* cursor, uint64_t* offset_dev,
+                                                                int64_t n_items, const uint32_t* __restrict__ bitmap, int64_t words,
+                                                                uint64_t seed, int unique, int64_t* u2, int64_t* i2,
+                                                                unsigned long long* owner, int32_t* __restrict__ fail) {
+  const Philox ph(seed);
+  int64_t start = *cursor;
+  const uint64_t offset = *offset_dev;
+  if (start < 0 || start + B > n_rows) {                   // the host wraps before this can happen; never read out of bounds
+    if (threadIdx.x == 0 && fail) atomicAdd(fail, 1);
+    start = 0;
   }
+  __syncthreads();                                         // everyone holds the cursor before thread 0 moves it
+  const int64_t *u = col_u + start, *pos = col_i + start;
+  int64_t* neg = i2 + B;
+  if (unique) {
+    rec_unique_rounds(ph, u, pos, B, n_items, bitmap, words, offset, neg, owner, fail, true);
+  } else {
+    for (int64_t b = threadIdx.x; b < B; b += UNIQ_THREADS) neg[b] = rec_pick(ph, offset, b, u[b], pos[b], n_items, bitmap, words, fail);
+  }
+  for (int64_t b = threadIdx.x; b < B; b += UNIQ_THREADS) {
+    const int64_t uu = u[b];
+    u2[b] = uu; u2[b + B] = uu; i2[b] = pos[b];
+  }
+  if (threadIdx.x == 0) { *cursor = start + B; *offset_dev = offset + (uint64_t)B * MAX_TRIES; }
+}
+
+__global__ __launch_bounds__(UNIQ_THREADS) void feed_kg_kernel(const int64_t* __restrict__ col_h, const int64_t* __restrict__ col_t,
+                                                               const int64_t* __restrict__ col_r, int64_t n_rows, int64_t B,
+                                                               int64_t* cursor, uint64_t* offset_dev, int64_t n_ent, int64_t n_rel,
+                                                               const uint64_t* __restrict__ keys, int64_t nk, uint64_t seed,
+                                                               int64_t* h2, int64_t* t2, int64_t* r2, int32_t* __restrict__ fail) {
+  const Philox ph(seed);
+  int64_t start = *cursor;
+  const uint64_t offset = *offset_dev;
+  if (start < 0 || start + B > n_rows) {
+    if (threadIdx.x == 0 && fail) atomicAdd(fail, 1);
+    start = 0;
+  }
+  __syncthreads();
+  for (int64_t b = threadIdx.x; b < B; b += UNIQ_THREADS) {
+    const int64_t hh = col_h[start + b], tt = col_t[start + b], rr = col_r[start + b];
+    int64_t nh, nt;
+    kg_pick(ph, offset, b, hh, tt, rr, n_ent, n_rel, keys, nk, fail, nh, nt);
+    h2[b] = hh; t2[b] = tt; r2[b] = rr;
+    h2[b + B] = nh; t2[b + B] = nt; r2[b + B] = rr;
+  }
+  if (threadIdx.x == 0) { *cursor = start + B; *offset_dev = offset + (uint64_t)B * MAX_TRIES; }
 }
 
 }  // namespace
@@ -200,5 +278,32 @@ extern "C" int ktup_negsample_kg(const int64_t* h, const int64_t* t, const int64
   KTUP_REQUIRE(h && t && r && neg_h && neg_t, "%s: null pointer argument", name);
   hipLaunchKernelGGL(negsample_kg_kernel, dim3(grid_for((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, h, t, r, n, n_ent, n_rel,
                      sorted_keys, n_keys, seed, offset, neg_h, neg_t, fail_count);
+  return check_launch(name);
+}
+
+extern "C" int ktup_feed_rec(const int64_t* col_u, const int64_t* col_i, int64_t n_rows, int64_t B, int64_t* cursor,
+                             uint64_t* offset_dev, int64_t n_items, const uint32_t* user_item_bitmap, int64_t words_per_user,
+                             uint64_t seed, int unique_in_batch, int64_t* u2, int64_t* i2, void* ws, int32_t* fail_count,
+                             void* stream) {
+  const char* name = "ktup_feed_rec";
+  KTUP_REQUIRE(B > 0 && n_rows >= B && n_items > 1, "%s: bad sizes", name);
+  KTUP_REQUIRE(col_u && col_i && cursor && offset_dev && u2 && i2, "%s: null pointer argument", name);
+  KTUP_REQUIRE(!user_item_bitmap || words_per_user * 32 >= n_items, "%s: bitmap rows too short", name);
+  KTUP_REQUIRE(!unique_in_batch || (ws && (reinterpret_cast<uintptr_t>(ws) & 7u) == 0), "%s: unique_in_batch needs the 8-byte aligned workspace",
+               name);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(feed_rec_kernel, dim3(1), dim3(UNIQ_THREADS), 0, st, col_u, col_i, n_rows, B, cursor, offset_dev, n_items,
+                     user_item_bitmap, words_per_user, seed, unique_in_batch, u2, i2, (unsigned long long*)ws, fail_count);
+  return check_launch(name);
+}
+
+extern "C" int ktup_feed_kg(const int64_t* col_h, const int64_t* col_t, const int64_t* col_r, int64_t n_rows, int64_t B,
+                            int64_t* cursor, uint64_t* offset_dev, int64_t n_ent, int64_t n_rel, const uint64_t* sorted_keys,
+                            int64_t n_keys, uint64_t seed, int64_t* h2, int64_t* t2, int64_t* r2, int32_t* fail_count, void* stream) {
+  const char* name = "ktup_feed_kg";
+  KTUP_REQUIRE(B > 0 && n_rows >= B && n_ent > 1 && n_rel > 0, "%s: bad sizes", name);
+  KTUP_REQUIRE(col_h && col_t && col_r && cursor && offset_dev && h2 && t2 && r2, "%s: null pointer argument", name);
+  hipLaunchKernelGGL(feed_kg_kernel, dim3(1), dim3(UNIQ_THREADS), 0, (hipStream_t)stream, col_h, col_t, col_r, n_rows, B, cursor,
+                     offset_dev, n_ent, n_rel, sorted_keys, n_keys, seed, h2, t2, r2, fail_count);
   return check_launch(name);
 }

@@ -101,6 +101,8 @@ SIGNATURES = {
     'ktup_eval_rec_metrics': [c_p, c_l, c_i, c_p, c_p, c_p, c_p],
     'ktup_shard_sparse_step': [c_i, c_p, c_l, c_p, c_l, c_i, c_p, c_l, c_p, c_l, c_f, c_f, c_p, c_f, c_p],
     'ktup_negsample_kg': [c_p, c_p, c_p, c_l, c_l, c_l, c_p, c_l, c_u, c_u, c_p, c_p, c_p, c_p],
+    'ktup_feed_rec': [c_p, c_p, c_l, c_l, c_p, c_p, c_l, c_p, c_l, c_u, c_i, c_p, c_p, c_p, c_p, c_p],
+    'ktup_feed_kg': [c_p, c_p, c_p, c_l, c_l, c_p, c_p, c_l, c_l, c_p, c_l, c_u, c_p, c_p, c_p, c_p, c_p],
 }
 _RESTYPE = {'ktup_last_error': ctypes.c_char_p, 'ktup_pref_workspace_bytes': ctypes.c_size_t,
             'ktup_eval_kg_workspace_bytes': ctypes.c_size_t, 'ktup_eval_transr_workspace_bytes': ctypes.c_size_t, 'ktup_score_transr_workspace_bytes': ctypes.c_size_t, 'ktup_score_transr_bwd_workspace_bytes': ctypes.c_size_t,

@@ -50,6 +50,7 @@ def train_loop(FLAGS, model, trainer, train_dataset, eval_datasets, user_total, 
             sampler = DeviceSampler(D.DEV, seed=FLAGS.seed)
             sampler.set_rating_dicts(user_total, item_total, all_dicts)
             feed = DeviceFeeder(train_list, FLAGS.batch_size, D.DEV, FLAGS.negtive_samples, seed=FLAGS.seed)
+            stepper.attach_feeds(sampler, rec=feed)
             logger.info('Training data and negative sampling are device-resident (-device_sampling).')
     D.require_stepper_for_replicas(stepper, 'transup, bprmf')
     logger.info('Training.')
@@ -72,8 +73,9 @@ def train_loop(FLAGS, model, trainer, train_dataset, eval_datasets, user_total, 
 
     def do_step(step):
         if feed is not None:
-            rows = feed.next()
-            u_d, pi_d = rows[:, 0].contiguous(), rows[:, 1].contiguous()
+            if stepper.can_feed('rec'):                    # batch + negatives drawn inside the step's own graph
+                return 'rec', stepper.fed_step('rec')
+            u_d, pi_d = feed.next_cols()
             return 'rec', stepper.rec_step(u_d, pi_d, sampler.sample_rec(u_d, pi_d))
         u, pi, ni = getNegRatings(next(train_iter), item_total, all_dicts=all_dicts)
         u_var, pi_var, ni_var = D.ids(u), D.ids(pi), D.ids(ni)

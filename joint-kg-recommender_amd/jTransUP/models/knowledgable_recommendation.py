@@ -107,6 +107,7 @@ def train_loop(FLAGS, model, trainer, rating_train_dataset, triple_train_dataset
             sampler.set_triples(entity_total, model.rel_total, known)
             rec_feed = DeviceFeeder(rating_train_list, FLAGS.batch_size, D.DEV, FLAGS.negtive_samples, seed=FLAGS.seed)
             kg_feed = DeviceFeeder(triple_train_list, FLAGS.batch_size, D.DEV, FLAGS.negtive_samples, seed=FLAGS.seed + 1)
+            stepper.attach_feeds(sampler, rec=rec_feed, kg=kg_feed)
             logger.info('Training data and negative sampling are device-resident (-device_sampling).')
     D.require_stepper_for_replicas(stepper, 'jtransup, -noshare_embeddings')
     logger.info('Training.')
@@ -145,12 +146,13 @@ def train_loop(FLAGS, model, trainer, rating_train_dataset, triple_train_dataset
         is_rec = step % 10 < step_to_switch
         e_ids = i_ids = None
         if stepper is not None and rec_feed is not None:
+            kind = 'rec' if is_rec else 'kg'
+            if stepper.can_feed(kind):                     # batch + negatives drawn inside the step's own graph
+                return kind, stepper.fed_step(kind)
             if is_rec:
-                rows = rec_feed.next()
-                u, pi = rows[:, 0].contiguous(), rows[:, 1].contiguous()
+                u, pi = rec_feed.next_cols()
                 return 'rec', stepper.rec_step(u, pi, sampler.sample_rec(u, pi))
-            rows = kg_feed.next()                          # (h, t, r): tail before relation, like the files
-            ph, pt, pr = rows[:, 0].contiguous(), rows[:, 1].contiguous(), rows[:, 2].contiguous()
+            ph, pt, pr = kg_feed.next_cols()               # (h, t, r): tail before relation, like the files
             nh, nt = sampler.sample_kg(ph, pt, pr)
             return 'kg', stepper.kg_step(ph, pt, pr, nh, nt, pr)
         if stepper is not None:

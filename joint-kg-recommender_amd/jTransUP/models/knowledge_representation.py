@@ -64,6 +64,7 @@ def train_loop(FLAGS, model, trainer, train_dataset, eval_datasets, entity_total
                 known = [train_list] + [[(h, t, r) for (t, r), hs in d[4].items() for h in hs] for d in eval_datasets]
             sampler.set_triples(entity_total, relation_total, known)
             feed = DeviceFeeder(train_list, FLAGS.batch_size, D.DEV, FLAGS.negtive_samples, seed=FLAGS.seed)
+            stepper.attach_feeds(sampler, kg=feed)
             logger.info('Training data and negative sampling are device-resident (-device_sampling).')
     D.require_stepper_for_replicas(stepper, 'transe, transh, transr')
     logger.info('Training.')
@@ -89,8 +90,9 @@ def train_loop(FLAGS, model, trainer, train_dataset, eval_datasets, entity_total
 
     def do_step(step):
         if feed is not None:
-            rows = feed.next()                             # (h, t, r): tail before relation, like the files
-            ph, pt, pr = rows[:, 0].contiguous(), rows[:, 1].contiguous(), rows[:, 2].contiguous()
+            if stepper.can_feed('kg'):                     # batch + negatives drawn inside the step's own graph
+                return 'kg', stepper.fed_step('kg')
+            ph, pt, pr = feed.next_cols()                  # (h, t, r): tail before relation, like the files
             nh, nt = sampler.sample_kg(ph, pt, pr)
             return 'kg', stepper.kg_step(ph, pt, pr, nh, nt, pr)
         if stepper is not None:

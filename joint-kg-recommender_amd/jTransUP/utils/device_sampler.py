@@ -25,6 +25,10 @@ class DeviceSampler(object):
         self.n_items = self.n_ent = self.n_rel = 0
         self._ws, self._ws_items = None, -1
         self.fail = torch.zeros(1, dtype=torch.int32, device=self.device)     # rows whose constraints could not be met
+        # device copy of the Philox counter for the feed launches (ktup_feed_*: batch + negatives in one graph-replayable
+        # launch, utils/fast_train.py fed_step); `offset` stays authoritative on the host, both advance in lockstep
+        self.offset_dev = torch.zeros(1, dtype=torch.int64, device=self.device)
+        self._dev_ok = True
 
     def check(self):
         """Raise if any draw since the last check had no admissible candidate (syncs the device once)."""
@@ -60,17 +64,29 @@ class DeviceSampler(object):
     def _advance(self, n):
         off = self.offset
         self.offset += int(n) * TRIES
+        self._dev_ok = False
         return off
+
+    def fed(self, n):
+        """Account for the n draws a ktup_feed_* launch is about to make from `offset_dev`."""
+        if not self._dev_ok:
+            self.offset_dev.fill_(self.offset)
+            self._dev_ok = True
+        self.offset += int(n) * TRIES
+
+    def rec_workspace(self):
+        if self._ws is None or self._ws_items != self.n_items:     # batch-uniqueness scratch: reset by the entry points themselves
+            nbytes = L.load().ktup_negsample_rec_workspace_bytes(self.n_items)
+            # all-ones: what ktup_feed_rec expects and leaves behind (ktup_negsample_rec resets it itself on every call)
+            self._ws, self._ws_items = torch.full(((nbytes + 7) // 8,), -1, dtype=torch.int64, device=self.device), self.n_items
+        return self._ws
 
     @torch.no_grad()
     def sample_rec(self, u, pos_i, unique_in_batch=True):
         """-> negative item per (u, pos_i) row, always a valid item id; `check()` reports rows whose constraints had no solution."""
         n = u.numel()
         neg = torch.empty(n, dtype=torch.int64, device=self.device)
-        if self._ws is None or self._ws_items != self.n_items:     # batch-uniqueness bitmap: zeroed by the entry point itself
-            nbytes = L.load().ktup_negsample_rec_workspace_bytes(self.n_items)
-            self._ws, self._ws_items = torch.empty((nbytes + 7) // 8, dtype=torch.int64, device=self.device), self.n_items
-        ws = self._ws
+        ws = self.rec_workspace()
         L.call('ktup_negsample_rec', _p(u.contiguous()), _p(pos_i.contiguous()), n, self.n_items, _p(self.bitmap),
                self.words if self.bitmap is not None else 0, self.seed, self._advance(n), int(unique_in_batch), _p(neg), _p(ws),
                _p(self.fail), _stream(self.device))

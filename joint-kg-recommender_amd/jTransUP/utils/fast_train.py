@@ -85,7 +85,54 @@ class _StepperBase(object):
         self.out = {k: torch.zeros((), **f32) for k in self.KINDS}                       # fused steps: where the step's loss is published
         self._graphs = {}
         self._eager_steps = {k: 0 for k in self.KINDS}
+        self._feeds, self._sampler, self._feed_launch, self._feed_ok = {}, None, {}, {}
         self._setup(FLAGS, f32, i64)
+
+    # ------------------------------------------------------------------------------------------------ device-fed steps
+    def attach_feeds(self, sampler, **feeds):
+        """-device_sampling: `feeds[kind]` (DeviceFeeder) + `sampler` (DeviceSampler) let a step of that kind build its own batch
+        on the device (ktup_feed_rec / ktup_feed_kg, captured in the step's graph): `fed_step(kind)` then needs no id tensors
+        and no host work besides the graph replay.  Single process only (replicas slice one global batch per step)."""
+        self._sampler = sampler
+        self._feeds = dict(feeds)
+        self._feed_ok = {}
+        self._keys = None                       # bind the feed launches with the next plan
+
+    def can_feed(self, kind):
+        ok = self._feed_ok.get(kind)
+        if ok is None:
+            ok = False
+            if kind in self._feeds and self.world == 1:
+                self._plans()                   # decides fused_step for this shape
+                ok = bool(self.fused_step)      # the multi-launch routes take id arrays the feed launches do not fill
+            self._feed_ok[kind] = ok
+        return ok
+
+    def _bind_feeds(self, st):
+        b, sm = L.bind, self._sampler
+        self._feed_launch = {}
+        for kind, feed in self._feeds.items():
+            if kind == 'rec':
+                self._feed_launch[kind] = b('ktup_feed_rec', _p(feed.cols[0]), _p(feed.cols[1]), feed.n, self.B, _p(feed.cursor),
+                                            _p(sm.offset_dev), sm.n_items, _p(sm.bitmap), sm.words if sm.bitmap is not None else 0,
+                                            sm.seed, 1, _p(self.u2), _p(self.i2), _p(sm.rec_workspace()), _p(sm.fail), st)
+            else:
+                self._feed_launch[kind] = b('ktup_feed_kg', _p(feed.cols[0]), _p(feed.cols[1]), _p(feed.cols[2]), feed.n, self.B,
+                                            _p(feed.cursor), _p(sm.offset_dev), sm.n_ent, sm.n_rel, _p(sm.keys),
+                                            0 if sm.keys is None else sm.keys.numel(), sm.seed, _p(self.h2), _p(self.t2), _p(self.r2),
+                                            _p(sm.fail), st)
+
+    def fed_step(self, kind):
+        """One step of `kind` on the feeder's next batch: feed launch + the step's launches, one graph replay."""
+        self._feeds[kind].fed()
+        self._sampler.fed(self.B)
+        eager = self._rec_eager if kind == 'rec' else self._kg_eager
+
+        def prologue():
+            self._plans()
+            self._feed_launch[kind]()
+        out = self._step(kind, eager, (None,) * self.N_IDS[kind], prologue=prologue)
+        return out
 
     def _gumbel_stream(self, draws_per_step):
         """(mode, pointer argument) of the preference gate, and the device-side stream position for the hard gate:
@@ -124,6 +171,8 @@ class _StepperBase(object):
             self._keys = tuple(t.data_ptr() for t in self.tabs) + tuple(t.grad.data_ptr() for t in self.tabs)
             self._stream = st
             self._bind(st)
+            if self._feeds:
+                self._bind_feeds(st)
 
     def _optimizer_launches(self, loss=None):
         self.sync.all_reduce_grads()       # world > 1: gradients of all tables + the loss scalars, one bucket, one collective
@@ -132,13 +181,19 @@ class _StepperBase(object):
     def _fused_ok(self, kind, d, n_pref=0):
         return bool(self.want_fused and L.load().ktup_train_step_supported(kind, d, n_pref))
 
-    def _step(self, kind, eager, args):
+    def _step(self, kind, eager, args, prologue=None):
+        """`prologue` (fed steps): a launch that fills the persistent id buffers itself -- `args` are then all None and the
+        prologue is captured at the head of the step's graph."""
         fused = self.trainer.fused
+        if prologue is not None:
+            run = eager
+            eager = lambda *a: (prologue(), run(*a))[1]
         if not (self.use_graphs and fused.graph_safe()):
             out = eager(*args)
             self.trainer.step += 1
             return out
-        entry = self._graphs.get(kind)
+        gkey = kind if prologue is None else kind + '+fed'
+        entry = self._graphs.get(gkey)
         if entry is not None and entry[2] is not fused:       # the trainer re-created its optimizer (LR decay): capture again
             entry = None
             self._eager_steps[kind] = 0
@@ -147,7 +202,8 @@ class _StepperBase(object):
             out = eager(*args)
             self.trainer.step += 1
             return out
-        self._pack(kind, args)                                   # ids -> the persistent [pos ; neg] buffers (outside the graph)
+        if prologue is None:
+            self._pack(kind, args)                               # ids -> the persistent [pos ; neg] buffers (outside the graph)
         if entry is None:
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
@@ -155,7 +211,7 @@ class _StepperBase(object):
             self._keys = None                                    # plans were bound to the capture stream: rebind for eager use
             fused._plan = None
             entry = (graph, out, fused)
-            self._graphs[kind] = entry
+            self._graphs[gkey] = entry
             captured = True                                      # the capture pass already ran the host side of clip_and_step
         else:
             captured = False
@@ -458,22 +514,47 @@ class DeviceFeeder(object):
     partial batch is dropped.  -device_sampling and -nodevice_sampling therefore share one epoch / shuffle cadence."""
 
     def __init__(self, rows, batch_size, device, negtive_samples=1, seed=0):
-        self.rows = torch.as_tensor(rows, dtype=torch.int64).reshape(len(rows), -1)[:, :3].contiguous().to(device)
+        rows = torch.as_tensor(rows, dtype=torch.int64).reshape(len(rows), -1)[:, :3].to(device)
         self.B, self.dev, self.rep = int(batch_size), device, int(negtive_samples)
         self.gen = torch.Generator(device=device)
         self.gen.manual_seed(int(seed))
-        self.n = self.rows.shape[0]
+        self.n = rows.shape[0]
         if self.n * self.rep < self.B:
             raise ValueError('fewer training examples (%d) than one batch (%d)' % (self.n * self.rep, self.B))
+        # column-major: a batch is then a contiguous SLICE of this epoch's shuffled columns (no per-step gather launches), and
+        # the columns live in fixed storage, reshuffled in place -- what the feed kernels' graph-static arguments point at
+        self.src = [rows[:, c].contiguous() for c in range(rows.shape[1])]
+        self.cols = [torch.empty(self.n, dtype=torch.int64, device=device) for _ in self.src]
+        self.cursor = torch.zeros(1, dtype=torch.int64, device=device)      # device copy of `start` (ktup_feed_* advance it)
         self._shuffle()
 
     def _shuffle(self):
-        self.order = torch.randperm(self.n * self.rep, generator=self.gen, device=self.dev) % self.n
+        self.order = order = (torch.randperm(self.n * self.rep, generator=self.gen, device=self.dev) % self.n)[:self.n]
+        for src, col in zip(self.src, self.cols):
+            torch.index_select(src, 0, order, out=col)
         self.start = 0
+        self.cursor.zero_()
+        self._cursor_ok = True
 
-    def next(self):
+    def _take(self):
         if self.start > self.n - self.B:              # data.py:101-103: dataset_size, not len(order)
             self._shuffle()
-        idx = self.order[self.start:self.start + self.B]
+        s = self.start
         self.start += self.B
-        return self.rows.index_select(0, idx)
+        return s
+
+    def next_cols(self):
+        """The next batch as one contiguous 1-D view per column (no launches)."""
+        s = self._take()
+        self._cursor_ok = False
+        return tuple(col[s:s + self.B] for col in self.cols)
+
+    def next(self):
+        return torch.stack(self.next_cols(), dim=1)
+
+    def fed(self):
+        """Account for one batch a ktup_feed_* launch is about to take (it moves the device cursor the same way)."""
+        s = self._take()
+        if not self._cursor_ok:
+            self.cursor.fill_(s)
+            self._cursor_ok = True

@@ -282,3 +282,63 @@ def test_replayed_steps_reach_the_optimizer_state(tmp_path):
     fast.rec_step(rnd(NU), rnd(NI), rnd(NI))
     assert {int(v['step']) for v in tr.fused.state_dict()['state'].values()} == {10}
     assert tr.fused._dev_steps.tolist() == [10] * len(sd['state'])
+
+
+@pytest.mark.parametrize('D', [100, 36])
+def test_fed_steps_draw_the_same_batches_as_the_host_driven_samplers(tmp_path, D):
+    """-device_sampling, two ways: (a) DeviceFeeder.next_cols + DeviceSampler.sample_* + rec_step / kg_step (ids handed over per
+    step), (b) fed_step (ktup_feed_rec / ktup_feed_kg captured at the head of the step's graph, device-side cursor and Philox
+    counter).  Same seeds -> the SAME id buffers bit for bit at every step, across an epoch wrap of the small rating list, and
+    the same tables up to the order of the gradient atomics.  D = 36 has no fused step: can_feed refuses and (b) = (a)."""
+    from jTransUP.utils.device_sampler import DeviceSampler
+    from jTransUP.utils.fast_train import DeviceFeeder, JointStepper
+    B = 16                                                               # <= the admissible items of every user (40 items, unique negatives)
+    runs = []
+    for fed in (False, True):
+        FLAGS, m, tr, (NU, NI, NE, NR) = build(tmp_path, 'Adagrad', False, D)
+        if runs:
+            m.load_state_dict(copy.deepcopy(runs[0][0]))
+        init = copy.deepcopy(m.state_dict())
+        gen = torch.Generator().manual_seed(21)
+        ratings = [(int(u), int(i)) for u, i in zip(torch.randint(0, NU, (75,), generator=gen), torch.randint(0, NI, (75,), generator=gen))]
+        triples = [(int(h), int(t), int(r)) for h, t, r in zip(torch.randint(0, NE, (500,), generator=gen),
+                                                               torch.randint(0, NE, (500,), generator=gen),
+                                                               torch.randint(0, NR, (500,), generator=gen))]
+        rated = {}
+        for u, i in ratings:
+            rated.setdefault(u, set()).add(i)
+        sampler = DeviceSampler(DEV, seed=5)
+        sampler.set_rating_dicts(NU, NI, [rated])
+        sampler.set_triples(NE, NR, [triples])
+        rec_feed, kg_feed = DeviceFeeder(ratings, B, DEV, seed=3), DeviceFeeder(triples, B, DEV, seed=4)
+        st = JointStepper(m, tr, FLAGS, B)
+        if fed:
+            st.attach_feeds(sampler, rec=rec_feed, kg=kg_feed)
+            assert st.can_feed('rec') == st.can_feed('kg') == (D != 36)
+        ids, losses = [], []
+        for step in range(14):                                            # 75 ratings / 16: the rec feeder wraps after 4 batches
+            kind = 'rec' if step % 10 < 7 else 'kg'
+            if fed and st.can_feed(kind):
+                losses.append(st.fed_step(kind))
+            elif kind == 'rec':
+                u, pi = rec_feed.next_cols()
+                losses.append(st.rec_step(u, pi, sampler.sample_rec(u, pi)))
+            else:
+                ph, pt, pr = kg_feed.next_cols()
+                nh, nt = sampler.sample_kg(ph, pt, pr)
+                losses.append(st.kg_step(ph, pt, pr, nh, nt, pr))
+            bufs = (st.u2, st.i2) if kind == 'rec' else (st.h2, st.t2, st.r2)
+            ids.append([b.clone() for b in bufs])
+            losses[-1] = losses[-1].clone()
+        sampler.check()
+        assert sampler.offset == 14 * B * 4096 and rec_feed.start == (11 % 4) * B          # 11 rec steps, 4 batches per epoch
+        runs.append((init, ids, losses, copy.deepcopy(m.state_dict())))
+    for step, (a, b) in enumerate(zip(runs[0][1], runs[1][1])):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y), 'id buffers differ at step %d' % step
+    for a, b in zip(runs[0][2], runs[1][2]):
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6)
+    for (k, a), (_, b) in zip(runs[0][3].items(), runs[1][3].items()):
+        err = (b - a).abs()
+        bad = err > 2e-6 + 2e-5 * a.abs()
+        assert float(bad.float().mean()) <= 2e-3 and float(err.max()) <= 1e-3 * 0.05, (k, int(bad.sum()), float(err.max()))

@@ -78,8 +78,7 @@ def test_kg_golden(golden, d, l1, name):
         X = leaf(g['transr.proj_embeddings.weight'])
         f = lambda h, t: ops().score_transr(E, R, X, h, t, pr, l1)
     pos, neg = f(ph, pt), f(nh, nt)
-    tol = dict(rtol=2e-4, atol=5e-5) if name == 'transr' else {}
-    close(pos, g[tag + 'pos'], **tol); close(neg, g[tag + 'neg'], **tol)
+    close(pos, g[tag + 'pos']); close(neg, g[tag + 'neg'])              # TransR too: measured 3e-7 relative against the goldens
     loss = torch.sum(torch.clamp(pos - neg + 1.0, min=0.0))
     rel = R[torch.cat([pr, pr])]
     if name == 'transh':

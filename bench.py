@@ -194,12 +194,48 @@ def train_step_bench(device, steps=200, warmup=20):
                 b.record(); torch.cuda.synchronize(device)
                 out['device_ms_per_%s_step' % kind] = a.elapsed_time(b) / 50
     os.environ.pop('KTUP_FUSED_STEP', None)
+    # device-fed steps (what -device_sampling runs): batch slice + negatives drawn by ktup_feed_* at the head of the step's graph;
+    # one graph per step, and ten steps (7 rec + 3 kg) per graph -- what the joint driver replays between evaluations
+    from jTransUP.utils.device_sampler import DeviceSampler
+    from jTransUP.utils.fast_train import DeviceFeeder
+    gen2 = torch.Generator().manual_seed(6)
+    ratings = torch.stack([torch.randint(0, NU, (96000,), generator=gen2), torch.randint(0, NI, (96000,), generator=gen2)], 1)
+    triples = torch.stack([torch.randint(0, NE, (48000,), generator=gen2), torch.randint(0, NE, (48000,), generator=gen2),
+                           torch.randint(0, NR, (48000,), generator=gen2)], 1)
+    cyc = ('rec',) * 7 + ('kg',) * 3
+    torch.manual_seed(3)
+    m = jt.jTransUPModel(False, D, NU, NI, NE, NR, i_map, new_map, False, False)
+    opt = torch.optim.Adagrad(m.parameters(), lr=0.005, weight_decay=1e-5)
+    tr = types.SimpleNamespace(fused=FusedOptimizer(opt), parameters=list(m.parameters()), model_target=-1, step=0)
+    js = JointStepper(m, tr, fl, B)
+    sm = DeviceSampler(device, seed=1)
+    sm.set_rating_dicts(NU, NI, []); sm.set_triples(NE, NR, [triples.tolist()])
+    js.attach_feeds(sm, rec=DeviceFeeder(ratings, B, device, seed=1), kg=DeviceFeeder(triples, B, device, seed=2))
+    for s_ in range(20):
+        js.fed_step(cyc[s_ % 10])
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for s_ in range(steps):
+        js.fed_step(cyc[s_ % 10])
+    torch.cuda.synchronize(device)
+    out['ms_per_step_device_fed'] = 1e3 * (time.perf_counter() - t0) / steps
+    n10 = 0
+    js.fed_cycle(cyc)                                            # capture
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(max(steps // 10, 1)):
+        n10 += js.fed_cycle(cyc) or sum(1 for k in cyc if js.fed_step(k) is not None)
+    torch.cuda.synchronize(device)
+    out['ms_per_step_device_fed_x10'] = 1e3 * (time.perf_counter() - t0) / max(n10, 1)
+    sm.check()
     out['ms_per_step'] = out['ms_per_step_gpu_resident']
     out['scored_rows_per_s'] = 2 * B / (out['ms_per_step'] * 1e-3)
     out['note'] = ('fwd pos+neg, loss (+ regularisers on the gpu_resident route), bwd, global-norm clip, dense Adagrad with weight '
                    'decay. torch = autograd + clip_grad_norm_ + torch.optim; fused = autograd + K20; gpu_resident = JointStepper, the '
                    'joint driver\'s default: 2 launches per step (ktup_train_rec_step / ktup_train_kg_step, then ktup_optim_clip_step: '
-                   'norm, clip and optimizer around a grid barrier) replayed from a HIP graph; gpu_resident_multilaunch = the same arithmetic as ~12 launches (round 1)')
+                   'norm, clip and optimizer around a grid barrier) replayed from a HIP graph; gpu_resident_multilaunch = the same arithmetic as ~12 launches (round 1); '
+                   'device_fed = the same step with its batch and negatives drawn by a third launch at the head of the graph (ktup_feed_*, -device_sampling), '
+                   'device_fed_x10 = ten such steps per graph replay')
     return out
 
 

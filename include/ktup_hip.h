@@ -407,8 +407,8 @@ int ktup_optim_step(int kind, int n_tensors, float* const* params, float* const*
  *   stay in registers across a grid-wide barrier between the norm and the update (at most 512 workgroups, all resident).  `ws`:
  *   KTUP_OPTIM_WS_DOUBLES doubles, zero-filled ONCE by the caller; every launch leaves them consistent for the next, ws[0] =
  *   the squared gradient norm of the last clipped step.  max_norm <= 0: no clipping, no barrier.  loss_slots (may be NULL):
- *   *loss_out = loss_scale * sum(loss_slots[0..n_slots)) and loss_slots := 0 for the next step -- the step kernels above
- *   accumulate into them.  The barrier's poll is bounded; after a timeout (never observed; a lost workgroup would otherwise
+ *   *loss_out = loss_scale * sum(loss_slots[0..n_slots)) (also added to *loss_acc, a running sum, if not NULL) and
+ *   loss_slots := 0 for the next step -- the step kernels above accumulate into them.  The barrier's poll is bounded; after a timeout (never observed; a lost workgroup would otherwise
  *   hang the GPU) ws[KTUP_OPTIM_WS_DOUBLES - 1] reads non-zero (as a uint64) and that step was applied unclipped.          */
 int ktup_train_step_supported(int kind, int d, int n_pref);
 int ktup_train_rec_step(const float* U, int64_t ldu, const float* I, int64_t ldi, const float* E, int64_t lde,
@@ -425,7 +425,7 @@ int ktup_optim_clip_step(int kind, int n_tensors, float* const* params, float* c
                          float* const* state2, const int64_t* sizes, const int64_t* steps, const int64_t* steps_dev,
                          const int32_t* first, float lr, float weight_decay, float momentum, float beta1, float beta2, float eps,
                          float alpha, double* ws, float max_norm, int zero_grads, float* loss_slots, int n_slots, float loss_scale,
-                         float* loss_out, void* stream);
+                         float* loss_out, float* loss_acc, void* stream);
 
 #ifdef __cplusplus
 }

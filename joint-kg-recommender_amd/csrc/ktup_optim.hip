@@ -191,7 +191,8 @@ __global__ __launch_bounds__(256) void step_kernel(OptTensors T, Hyper h, const 
 // the same kernel with phase 2 re-reading (resident == false).  The poll is bounded: on a timeout ws[GN_ERR] is set and the
 // update proceeds unclipped -- wrong, but never a hung GPU.
 // `slots` (optional): the step's loss terms, accumulated by the fused step kernel that ran before this launch.  Thread 0 of
-// workgroup 0 publishes  *loss_out = loss_scale * sum(slots)  and zeroes the slots for the next step.
+// workgroup 0 publishes  *loss_out = loss_scale * sum(slots)  (adding it to *loss_acc, a running sum, if given) and zeroes the
+// slots for the next step.
 constexpr int GN_SLOTS = 32, GN_STRIDE = 8;                       // doubles / u64 words; one 64-byte line per slot
 constexpr int GN_SUM = 1, GN_TICK = GN_SUM + GN_SLOTS * GN_STRIDE, GN_GLOBAL = GN_TICK + GN_SLOTS * GN_STRIDE;
 constexpr int GN_EPOCH = GN_GLOBAL + GN_STRIDE;                   // [slot]: {epoch, total} on one line
@@ -202,7 +203,7 @@ constexpr int CS_UPT = 5, CS_MAX_WG = 512, CS_SPIN_LIMIT = 1 << 21;
 template <int KIND>
 __global__ __launch_bounds__(256, 4) void clip_step_kernel(OptTensors T, Hyper h, double* __restrict__ ws, float* __restrict__ slots,
                                                         int n_slots, float loss_scale, float* __restrict__ loss_out,
-                                                        const int64_t* __restrict__ steps_dev) {
+                                                        float* __restrict__ loss_acc, const int64_t* __restrict__ steps_dev) {
   __shared__ float dev_bc1[MAXT], dev_bc2s[MAXT];
   __shared__ float red[4];
   __shared__ float coef_s;
@@ -217,6 +218,7 @@ __global__ __launch_bounds__(256, 4) void clip_step_kernel(OptTensors T, Hyper h
       float s = 0.f;
       for (int i = 0; i < n_slots; ++i) { s += slots[i]; slots[i] = 0.f; }
       *loss_out = loss_scale * s;
+      if (loss_acc) *loss_acc += loss_scale * s;
     }
   }
   const bool dev_bc = KIND == KTUP_OPT_ADAM && steps_dev != nullptr;
@@ -469,7 +471,7 @@ extern "C" int ktup_optim_clip_step(int kind, int n_tensors, float* const* param
                                     float* const* state2, const int64_t* sizes, const int64_t* steps, const int64_t* steps_dev,
                                     const int32_t* first, float lr, float weight_decay, float momentum, float beta1, float beta2,
                                     float eps, float alpha, double* ws, float max_norm, int zero_grads, float* loss_slots, int n_slots,
-                                    float loss_scale, float* loss_out, void* stream) {
+                                    float loss_scale, float* loss_out, float* loss_acc, void* stream) {
   const char* name = "ktup_optim_clip_step";
   KTUP_REQUIRE(ws, "%s: null workspace", name);
   KTUP_REQUIRE(!loss_slots || (n_slots > 0 && loss_out), "%s: loss slots need a count and an output", name);
@@ -484,16 +486,16 @@ extern "C" int ktup_optim_clip_step(int kind, int n_tensors, float* const* param
   const dim3 grid((unsigned)(nunits < 1 ? 1 : nunits < CS_MAX_WG ? nunits : CS_MAX_WG)), block(256);
   switch (kind) {
     case KTUP_OPT_SGD:
-      hipLaunchKernelGGL(clip_step_kernel<KTUP_OPT_SGD>, grid, block, 0, st, T, h, ws, loss_slots, n_slots, loss_scale, loss_out, steps_dev);
+      hipLaunchKernelGGL(clip_step_kernel<KTUP_OPT_SGD>, grid, block, 0, st, T, h, ws, loss_slots, n_slots, loss_scale, loss_out, loss_acc, steps_dev);
       break;
     case KTUP_OPT_ADAGRAD:
-      hipLaunchKernelGGL(clip_step_kernel<KTUP_OPT_ADAGRAD>, grid, block, 0, st, T, h, ws, loss_slots, n_slots, loss_scale, loss_out, steps_dev);
+      hipLaunchKernelGGL(clip_step_kernel<KTUP_OPT_ADAGRAD>, grid, block, 0, st, T, h, ws, loss_slots, n_slots, loss_scale, loss_out, loss_acc, steps_dev);
       break;
     case KTUP_OPT_ADAM:
-      hipLaunchKernelGGL(clip_step_kernel<KTUP_OPT_ADAM>, grid, block, 0, st, T, h, ws, loss_slots, n_slots, loss_scale, loss_out, steps_dev);
+      hipLaunchKernelGGL(clip_step_kernel<KTUP_OPT_ADAM>, grid, block, 0, st, T, h, ws, loss_slots, n_slots, loss_scale, loss_out, loss_acc, steps_dev);
       break;
     default:
-      hipLaunchKernelGGL(clip_step_kernel<KTUP_OPT_RMSPROP>, grid, block, 0, st, T, h, ws, loss_slots, n_slots, loss_scale, loss_out, steps_dev);
+      hipLaunchKernelGGL(clip_step_kernel<KTUP_OPT_RMSPROP>, grid, block, 0, st, T, h, ws, loss_slots, n_slots, loss_scale, loss_out, loss_acc, steps_dev);
       break;
   }
   return check_launch(name);

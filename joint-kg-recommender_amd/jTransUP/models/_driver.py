@@ -315,16 +315,22 @@ def clip_and_step(FLAGS, model, trainer):
     trainer.clip_and_step(FLAGS.clipping_max_value)
 
 
-def training_loop(FLAGS, model, trainer, logger, do_step, do_eval, loss_names, on_train_mode=None, sampler=None):
+def steps_before_pause(FLAGS, step):
+    """How many consecutive steps may run from `step` before the loop has to look again (next evaluation, end of training)."""
+    return min(FLAGS.eval_interval_steps - step % FLAGS.eval_interval_steps, FLAGS.training_steps - step)
+
+
+def training_loop(FLAGS, model, trainer, logger, do_step, do_eval, loss_names, on_train_mode=None, sampler=None, stepper=None):
     """The reference's loop skeleton: early stopping, evaluation every eval_interval_steps (including step 0, where
     only the metrics are logged), otherwise one optimisation step.  `do_step(step)` returns (name, loss_tensor);
     `do_eval(mean_losses)` returns the performance list whose first entry drives checkpointing / LR decay.  `sampler`: the
     on-device negative sampler, whose failure counter is checked where the loop syncs anyway (before every evaluation and
-    at the end): a draw without an admissible candidate raises instead of training on a stand-in."""
+    at the end): a draw without an admissible candidate raises instead of training on a stand-in.  `stepper`: device-fed steps
+    (fast_train fed_step) return no loss tensor -- they sum their losses on the device, collected here with the other totals."""
     pbar = None
     sums = {k: torch.zeros((), device=DEV) for k in loss_names}
     model.train(); model.enable_grad()
-    for _ in range(trainer.step, FLAGS.training_steps):
+    while trainer.step < FLAGS.training_steps:                 # a device-fed do_step may run several steps per call (fed_cycle)
         if FLAGS.early_stopping_steps_to_wait > 0 and (trainer.step - trainer.best_step) > FLAGS.early_stopping_steps_to_wait:
             logger.info('No improvement after ' + str(FLAGS.early_stopping_steps_to_wait) + ' steps. Stopping training.')
             break
@@ -332,6 +338,9 @@ def training_loop(FLAGS, model, trainer, logger, do_step, do_eval, loss_names, o
             if pbar is not None:
                 pbar.close()
             totals = {k: float(v.item()) for k, v in sums.items()}      # the only loss read-back
+            if stepper is not None:
+                for k, v in stepper.take_sums().items():
+                    totals[k] = totals.get(k, 0.0) + v
             if sampler is not None:
                 sampler.check()
             do_eval(totals)
@@ -339,9 +348,11 @@ def training_loop(FLAGS, model, trainer, logger, do_step, do_eval, loss_names, o
             for v in sums.values():
                 v.zero_()
             model.train(); model.enable_grad()
-        name, loss = do_step(trainer.step)
-        sums[name] += loss.detach()
-        pbar.update(1)
+        before = trainer.step
+        name, loss = do_step(before)
+        if loss is not None:
+            sums[name] += loss.detach()
+        pbar.update(trainer.step - before)
     if pbar is not None:
         pbar.close()
     if sampler is not None:

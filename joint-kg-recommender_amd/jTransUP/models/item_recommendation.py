@@ -74,7 +74,10 @@ def train_loop(FLAGS, model, trainer, train_dataset, eval_datasets, user_total, 
     def do_step(step):
         if feed is not None:
             if stepper.can_feed('rec'):                    # batch + negatives drawn inside the step's own graph
-                return 'rec', stepper.fed_step('rec')
+                if D.steps_before_pause(FLAGS, step) >= 10 and stepper.fed_cycle(('rec',) * 10):
+                    return 'rec', None                     # ten steps in one replay; losses are summed on the device
+                stepper.fed_step('rec')
+                return 'rec', None                         # (stepper.take_sums)
             u_d, pi_d = feed.next_cols()
             return 'rec', stepper.rec_step(u_d, pi_d, sampler.sample_rec(u_d, pi_d))
         u, pi, ni = getNegRatings(next(train_iter), item_total, all_dicts=all_dicts)
@@ -93,7 +96,7 @@ def train_loop(FLAGS, model, trainer, train_dataset, eval_datasets, user_total, 
         D.clip_and_step(FLAGS, model, trainer)
         return 'rec', losses
 
-    D.training_loop(FLAGS, model, trainer, logger, do_step, do_eval, ['rec'], sampler=sampler)
+    D.training_loop(FLAGS, model, trainer, logger, do_step, do_eval, ['rec'], sampler=sampler, stepper=stepper)
 
 
 def run(only_forward=False):

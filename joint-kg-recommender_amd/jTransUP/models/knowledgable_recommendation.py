@@ -142,13 +142,18 @@ def train_loop(FLAGS, model, trainer, rating_train_dataset, triple_train_dataset
                     vis.plot_many_stack({'KG Eval {} MeanRank'.format(i): p[1] for i, p in enumerate(kg_perfs)}, win_name='KG MeanRank')
         return rec_perfs
 
+    cycle10 = tuple('rec' if k < step_to_switch else 'kg' for k in range(10))
+
     def do_step(step):
         is_rec = step % 10 < step_to_switch
         e_ids = i_ids = None
         if stepper is not None and rec_feed is not None:
             kind = 'rec' if is_rec else 'kg'
             if stepper.can_feed(kind):                     # batch + negatives drawn inside the step's own graph
-                return kind, stepper.fed_step(kind)
+                if step % 10 == 0 and D.steps_before_pause(FLAGS, step) >= 10 and stepper.fed_cycle(cycle10):
+                    return kind, None                      # ten steps in one replay; losses are summed on the device
+                stepper.fed_step(kind)
+                return kind, None                          # (stepper.take_sums)
             if is_rec:
                 u, pi = rec_feed.next_cols()
                 return 'rec', stepper.rec_step(u, pi, sampler.sample_rec(u, pi))
@@ -202,7 +207,7 @@ def train_loop(FLAGS, model, trainer, rating_train_dataset, triple_train_dataset
         D.clip_and_step(FLAGS, model, trainer)
         return ('rec' if is_rec else 'kg'), losses
 
-    D.training_loop(FLAGS, model, trainer, logger, do_step, do_eval, ['rec', 'kg'], sampler=sampler)
+    D.training_loop(FLAGS, model, trainer, logger, do_step, do_eval, ['rec', 'kg'], sampler=sampler, stepper=stepper)
 
 
 def run(only_forward=False):

@@ -91,7 +91,10 @@ def train_loop(FLAGS, model, trainer, train_dataset, eval_datasets, entity_total
     def do_step(step):
         if feed is not None:
             if stepper.can_feed('kg'):                     # batch + negatives drawn inside the step's own graph
-                return 'kg', stepper.fed_step('kg')
+                if D.steps_before_pause(FLAGS, step) >= 10 and stepper.fed_cycle(('kg',) * 10):
+                    return 'kg', None                     # ten steps in one replay; losses are summed on the device
+                stepper.fed_step('kg')
+                return 'kg', None                         # (stepper.take_sums)
             ph, pt, pr = feed.next_cols()                  # (h, t, r): tail before relation, like the files
             nh, nt = sampler.sample_kg(ph, pt, pr)
             return 'kg', stepper.kg_step(ph, pt, pr, nh, nt, pr)
@@ -114,7 +117,7 @@ def train_loop(FLAGS, model, trainer, train_dataset, eval_datasets, entity_total
         D.clip_and_step(FLAGS, model, trainer)
         return 'kg', losses
 
-    D.training_loop(FLAGS, model, trainer, logger, do_step, do_eval, ['kg'], sampler=sampler)
+    D.training_loop(FLAGS, model, trainer, logger, do_step, do_eval, ['kg'], sampler=sampler, stepper=stepper)
     trainer.save(trainer.checkpoint_path + '_final')      # knowledge_representation.py:219
 
 

@@ -14,21 +14,24 @@ from jTransUP.hip import lib as L
 from jTransUP.hip.ops import _p, _stream
 
 TRIES = 4096   # counter stride per row inside the kernels
+KG_STREAM = 1 << 62
 
 
 class DeviceSampler(object):
     def __init__(self, device, seed=0):
         self.device = torch.device(device)
         self.seed = int(seed) & (2 ** 63 - 1)
-        self.offset = 0
+        # one Philox counter per sampler kind (the kg stream starts far away from the rec stream), so that the order in which
+        # rec and kg batches are drawn -- which prefetching changes -- does not change the draws
+        self.offsets = {'rec': 0, 'kg': KG_STREAM}
         self.bitmap = self.keys = None
         self.n_items = self.n_ent = self.n_rel = 0
         self._ws, self._ws_items = None, -1
         self.fail = torch.zeros(1, dtype=torch.int32, device=self.device)     # rows whose constraints could not be met
         # device copy of the Philox counter for the feed launches (ktup_feed_*: batch + negatives in one graph-replayable
         # launch, utils/fast_train.py fed_step); `offset` stays authoritative on the host, both advance in lockstep
-        self.offset_dev = torch.zeros(1, dtype=torch.int64, device=self.device)
-        self._dev_ok = True
+        self.offset_dev = torch.tensor([0, KG_STREAM], dtype=torch.int64, device=self.device)      # [rec, kg]
+        self._dev_ok = {'rec': True, 'kg': True}
 
     def check(self):
         """Raise if any draw since the last check had no admissible candidate (syncs the device once)."""
@@ -61,18 +64,23 @@ class DeviceSampler(object):
         self.keys = torch.from_numpy(np.unique(keys).view(np.int64)).to(self.device)
 
     # ---- draws
-    def _advance(self, n):
-        off = self.offset
-        self.offset += int(n) * TRIES
-        self._dev_ok = False
+    @property
+    def offset(self):
+        """Draw counters consumed so far, over both streams."""
+        return self.offsets['rec'] + self.offsets['kg'] - KG_STREAM
+
+    def _advance(self, n, kind):
+        off = self.offsets[kind]
+        self.offsets[kind] += int(n) * TRIES
+        self._dev_ok[kind] = False
         return off
 
-    def fed(self, n):
-        """Account for the n draws a ktup_feed_* launch is about to make from `offset_dev`."""
-        if not self._dev_ok:
-            self.offset_dev.fill_(self.offset)
-            self._dev_ok = True
-        self.offset += int(n) * TRIES
+    def fed(self, n, kind):
+        """Account for the n draws a ktup_feed_* launch of `kind` is about to make from its slot of `offset_dev`."""
+        if not self._dev_ok[kind]:
+            self.offset_dev[0 if kind == 'rec' else 1] = self.offsets[kind]
+            self._dev_ok[kind] = True
+        self.offsets[kind] += int(n) * TRIES
 
     def rec_workspace(self):
         if self._ws is None or self._ws_items != self.n_items:     # batch-uniqueness scratch: reset by the entry points themselves
@@ -88,7 +96,7 @@ class DeviceSampler(object):
         neg = torch.empty(n, dtype=torch.int64, device=self.device)
         ws = self.rec_workspace()
         L.call('ktup_negsample_rec', _p(u.contiguous()), _p(pos_i.contiguous()), n, self.n_items, _p(self.bitmap),
-               self.words if self.bitmap is not None else 0, self.seed, self._advance(n), int(unique_in_batch), _p(neg), _p(ws),
+               self.words if self.bitmap is not None else 0, self.seed, self._advance(n, 'rec'), int(unique_in_batch), _p(neg), _p(ws),
                _p(self.fail), _stream(self.device))
         return neg
 
@@ -99,6 +107,6 @@ class DeviceSampler(object):
         nh = torch.empty(n, dtype=torch.int64, device=self.device)
         nt = torch.empty(n, dtype=torch.int64, device=self.device)
         L.call('ktup_negsample_kg', _p(h.contiguous()), _p(t.contiguous()), _p(r.contiguous()), n, self.n_ent, self.n_rel, _p(self.keys),
-               0 if self.keys is None else self.keys.numel(), self.seed, self._advance(n), _p(nh), _p(nt), _p(self.fail),
+               0 if self.keys is None else self.keys.numel(), self.seed, self._advance(n, 'kg'), _p(nh), _p(nt), _p(self.fail),
                _stream(self.device))
         return nh, nt

@@ -86,6 +86,8 @@ class _StepperBase(object):
         self._graphs = {}
         self._eager_steps = {k: 0 for k in self.KINDS}
         self._feeds, self._sampler, self._feed_launch, self._feed_ok = {}, None, {}, {}
+        self._acc_on = False
+        self.acc = {k: torch.zeros((), **f32) for k in self.KINDS}                       # fed steps: running sum of the steps' losses
         self._setup(FLAGS, f32, i64)
 
     # ------------------------------------------------------------------------------------------------ device-fed steps
@@ -108,31 +110,128 @@ class _StepperBase(object):
             self._feed_ok[kind] = ok
         return ok
 
+    def _acc_ptr(self, kind):
+        """Fed steps: the optimizer launch adds the step's loss to acc[kind] itself."""
+        return _p(self.acc[kind]) if self._acc_on else None
+
+    def _make_feed(self, kind, st):
+        b, sm, feed = L.bind, self._sampler, self._feeds[kind]
+        if kind == 'rec':
+            return b('ktup_feed_rec', _p(feed.cols[0]), _p(feed.cols[1]), feed.n, self.B, _p(feed.cursor), _p(sm.offset_dev[0:]),
+                     sm.n_items, _p(sm.bitmap), sm.words if sm.bitmap is not None else 0, sm.seed, 1, _p(self.u2), _p(self.i2),
+                     _p(sm.rec_workspace()), _p(sm.fail), st)
+        return b('ktup_feed_kg', _p(feed.cols[0]), _p(feed.cols[1]), _p(feed.cols[2]), feed.n, self.B, _p(feed.cursor),
+                 _p(sm.offset_dev[1:]), sm.n_ent, sm.n_rel, _p(sm.keys), 0 if sm.keys is None else sm.keys.numel(), sm.seed,
+                 _p(self.h2), _p(self.t2), _p(self.r2), _p(sm.fail), st)
+
     def _bind_feeds(self, st):
-        b, sm = L.bind, self._sampler
-        self._feed_launch = {}
-        for kind, feed in self._feeds.items():
-            if kind == 'rec':
-                self._feed_launch[kind] = b('ktup_feed_rec', _p(feed.cols[0]), _p(feed.cols[1]), feed.n, self.B, _p(feed.cursor),
-                                            _p(sm.offset_dev), sm.n_items, _p(sm.bitmap), sm.words if sm.bitmap is not None else 0,
-                                            sm.seed, 1, _p(self.u2), _p(self.i2), _p(sm.rec_workspace()), _p(sm.fail), st)
-            else:
-                self._feed_launch[kind] = b('ktup_feed_kg', _p(feed.cols[0]), _p(feed.cols[1]), _p(feed.cols[2]), feed.n, self.B,
-                                            _p(feed.cursor), _p(sm.offset_dev), sm.n_ent, sm.n_rel, _p(sm.keys),
-                                            0 if sm.keys is None else sm.keys.numel(), sm.seed, _p(self.h2), _p(self.t2), _p(self.r2),
-                                            _p(sm.fail), st)
+        self._feed_launch = {kind: self._make_feed(kind, st) for kind in self._feeds}
+
+    def take_sums(self):
+        """{kind: sum of the losses of the fed steps since the last call} (one sync; the fed steps accumulate on the device)."""
+        out = {k: float(v.item()) for k, v in self.acc.items()}
+        for v in self.acc.values():
+            v.zero_()
+        return out
+
+    def fed_cycle(self, kinds):
+        """len(kinds) consecutive fed steps as ONE graph replay (hipGraphLaunch + the Python around it cost ~5 us per replay --
+        a tenth of a step).  Returns len(kinds), or 0 when the cycle cannot run right now: before every kind has its
+        single-step graph (warm-up, lazy optimizer state), after the optimizer was re-created, or when a feeder's epoch ends
+        inside the cycle (the host reshuffles between replays, never inside one)."""
+        fused = self.trainer.fused
+        if not (self.use_graphs and fused.graph_safe()):
+            return 0
+        count = {}
+        for kind in kinds:
+            count[kind] = count.get(kind, 0) + 1
+        for kind, c in count.items():
+            entry = self._graphs.get(kind + '+fed')
+            feed = self._feeds.get(kind)
+            if entry is None or entry[2] is not fused or feed.start + (c - 1) * self.B > feed.n - self.B:
+                return 0
+        for kind, c in count.items():
+            for _ in range(c):
+                self._feeds[kind].fed()
+                self._sampler.fed(self.B, kind)
+        gkey = 'cycle:' + ','.join(kinds)
+        entry = self._graphs.get(gkey)
+        if entry is not None and entry[2] is not fused:
+            entry = None
+        if entry is None:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                self._acc_on = True
+                try:
+                    for kind in kinds:
+                        self._plans()
+                        self._feed_launch[kind]()
+                        (self._rec_eager if kind == 'rec' else self._kg_eager)(*((None,) * self.N_IDS[kind]))
+                finally:
+                    self._acc_on = False
+            self._keys = None
+            fused._plan = None
+            entry = (graph, None, fused)
+            self._graphs[gkey] = entry
+            captured = True
+        else:
+            captured = False
+        entry[0].replay()
+        if not captured:
+            fused.bump_steps(len(kinds))
+        self.trainer.step += len(kinds)
+        return len(kinds)
 
     def fed_step(self, kind):
-        """One step of `kind` on the feeder's next batch: feed launch + the step's launches, one graph replay."""
-        self._feeds[kind].fed()
-        self._sampler.fed(self.B)
+        """One step of `kind` on the feeder's next batch: the step's graph is  feed launch -> step kernel -> clip + optimizer
+        launch, and the host does nothing but replay it.  The optimizer launch adds the step's loss to `acc[kind]` (take_sums).
+        (Drawing the NEXT batch on a side stream beside the optimizer launch was built and measured: the fork / join inside the
+        graph costs more than the 8 us it hides -- 56 vs 50 us per step.)"""
+        feed, sm, fused = self._feeds[kind], self._sampler, self.trainer.fused
         eager = self._rec_eager if kind == 'rec' else self._kg_eager
+        nones = (None,) * self.N_IDS[kind]
 
-        def prologue():
+        def fed_eager():
             self._plans()
             self._feed_launch[kind]()
-        out = self._step(kind, eager, (None,) * self.N_IDS[kind], prologue=prologue)
-        return out
+            self._acc_on = True
+            try:
+                return eager(*nones)
+            finally:
+                self._acc_on = False
+
+        feed.fed()
+        sm.fed(self.B, kind)
+        if not (self.use_graphs and fused.graph_safe()):
+            out = fed_eager()
+            self.trainer.step += 1
+            return out
+        gkey = kind + '+fed'
+        entry = self._graphs.get(gkey)
+        if entry is not None and entry[2] is not fused:       # the trainer re-created its optimizer (LR decay): capture again
+            entry = None
+            self._eager_steps[kind] = 0
+        if entry is None and self._eager_steps[kind] < 2:
+            self._eager_steps[kind] += 1
+            out = fed_eager()
+            self.trainer.step += 1
+            return out
+        if entry is None:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = fed_eager()
+            self._keys = None                                 # plans were bound to the capture stream: rebind for eager use
+            fused._plan = None
+            entry = (graph, out, fused)
+            self._graphs[gkey] = entry
+            captured = True
+        else:
+            captured = False
+        entry[0].replay()
+        if not captured:
+            fused.bump_steps()
+        self.trainer.step += 1
+        return entry[1]
 
     def _gumbel_stream(self, draws_per_step):
         """(mode, pointer argument) of the preference gate, and the device-side stream position for the hard gate:
@@ -181,19 +280,13 @@ class _StepperBase(object):
     def _fused_ok(self, kind, d, n_pref=0):
         return bool(self.want_fused and L.load().ktup_train_step_supported(kind, d, n_pref))
 
-    def _step(self, kind, eager, args, prologue=None):
-        """`prologue` (fed steps): a launch that fills the persistent id buffers itself -- `args` are then all None and the
-        prologue is captured at the head of the step's graph."""
+    def _step(self, kind, eager, args):
         fused = self.trainer.fused
-        if prologue is not None:
-            run = eager
-            eager = lambda *a: (prologue(), run(*a))[1]
         if not (self.use_graphs and fused.graph_safe()):
             out = eager(*args)
             self.trainer.step += 1
             return out
-        gkey = kind if prologue is None else kind + '+fed'
-        entry = self._graphs.get(gkey)
+        entry = self._graphs.get(kind)
         if entry is not None and entry[2] is not fused:       # the trainer re-created its optimizer (LR decay): capture again
             entry = None
             self._eager_steps[kind] = 0
@@ -202,8 +295,7 @@ class _StepperBase(object):
             out = eager(*args)
             self.trainer.step += 1
             return out
-        if prologue is None:
-            self._pack(kind, args)                               # ids -> the persistent [pos ; neg] buffers (outside the graph)
+        self._pack(kind, args)                                   # ids -> the persistent [pos ; neg] buffers (outside the graph)
         if entry is None:
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
@@ -211,7 +303,7 @@ class _StepperBase(object):
             self._keys = None                                    # plans were bound to the capture stream: rebind for eager use
             fused._plan = None
             entry = (graph, out, fused)
-            self._graphs[gkey] = entry
+            self._graphs[kind] = entry
             captured = True                                      # the capture pass already ran the host side of clip_and_step
         else:
             captured = False
@@ -300,7 +392,7 @@ class JointStepper(_StepperBase):
             self._gumbel_advance()
             if self.world > 1:
                 self.loss[:2].mul_(self.inv_world)
-            self._optimizer_launches(loss=(_p(self.loss), 2, 1.0, _p(self.out['rec'])))
+            self._optimizer_launches(loss=(_p(self.loss), 2, 1.0, _p(self.out['rec']), self._acc_ptr('rec')))
             return self.out['rec']
         self._rec_head[0]()
         self.gAC.zero_(); self.loss.zero_()
@@ -321,7 +413,7 @@ class JointStepper(_StepperBase):
             self._pack('kg', (ph, pt, pr, nh, nt, nr))
         if self.fused_step:              # one launch: both TransH scores, marginLoss, the three regularisers, every gradient
             self._kg_fused()
-            self._optimizer_launches(loss=(_p(self.loss), 4, self.kg_lambda, _p(self.out['kg'])))
+            self._optimizer_launches(loss=(_p(self.loss), 4, self.kg_lambda, _p(self.out['kg']), self._acc_ptr('kg')))
             return self.out['kg']
         self.loss.zero_()
         for launch in self._kg:
@@ -411,7 +503,7 @@ class RecStepper(_StepperBase):
                 launch()
             if self.world > 1:
                 self.loss[:2].mul_(self.inv_world); self.loss[4:5].mul_(self.inv_world)
-            self._optimizer_launches(loss=(_p(self.loss), 5, 1.0, _p(self.out['rec'])))
+            self._optimizer_launches(loss=(_p(self.loss), 5, 1.0, _p(self.out['rec']), self._acc_ptr('rec')))
             return self.out['rec']
         self._prep()
         self.gAC.zero_()
@@ -493,7 +585,7 @@ class KGStepper(_StepperBase):
             self._pack('kg', (ph, pt, pr, nh, nt, nr))
         if self.fused_step:
             self._kg_fused()
-            self._optimizer_launches(loss=(_p(self.loss), 4, 1.0, _p(self.out['kg'])))
+            self._optimizer_launches(loss=(_p(self.loss), 4, 1.0, _p(self.out['kg']), self._acc_ptr('kg')))
             return self.out['kg']
         self.loss.zero_()
         for launch in self._calls:

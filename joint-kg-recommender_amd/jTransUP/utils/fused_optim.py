@@ -110,8 +110,8 @@ class FusedOptimizer(object):
     @torch.no_grad()
     def clip_and_step(self, max_norm, zero_grads=False, loss=None):
         """`zero_grads`: leave the gradients zero-filled (the next step's zero_grad folded into this pass) instead of
-        clipped in place.  `loss` = (slots_ptr, n_slots, scale, out_ptr): the fused training step's loss slots are folded into
-        *out and cleared by the same launch (needs the one-launch route)."""
+        clipped in place.  `loss` = (slots_ptr, n_slots, scale, out_ptr[, acc_ptr]): the fused training step's loss slots are folded
+        into *out (and added to the running sum *acc) and cleared by the same launch (needs the one-launch route)."""
         self._flush_steps()
         group = self.optimizer.param_groups[0]
         ps = [p for p in group['params'] if p.grad is not None]
@@ -145,7 +145,7 @@ class FusedOptimizer(object):
                  float(group.get('eps', 0.0)), float(group.get('alpha', 0.0)))
         head = (self.kind, n, params, grads, s1, s2, sizes, _arr(ctypes.c_int64, steps), steps_dev, _arr(ctypes.c_int32, firsts)) + hyper
         if self.one_launch or loss is not None:
-            lo = (None, 0, 0.0, None) if loss is None else (loss[0], int(loss[1]), float(loss[2]), loss[3])
+            lo = (None, 0, 0.0, None, None) if loss is None else (loss[0], int(loss[1]), float(loss[2]), loss[3], loss[4] if len(loss) > 4 else None)
             L.call('ktup_optim_clip_step', *head, self.sumsq_ptr(dev), float(max_norm) if clip else 0.0, int(bool(zero_grads)), *lo, stream)
             return
         sumsq = None
@@ -180,11 +180,11 @@ class FusedOptimizer(object):
         evaluated by the kernel)."""
         return True
 
-    def bump_steps(self):
-        """Account for one step whose launches were replayed from a graph (this object's Python code did not run).  The
+    def bump_steps(self, n=1):
+        """Account for n steps whose launches were replayed from a graph (this object's Python code did not run).  The
         torch-side `state[p]['step']` tensors are brought up to date lazily -- before the next eager step and before
         state_dict() -- because touching seven CPU tensors per replay costs more host time than the replay itself."""
-        self._replayed += 1
+        self._replayed += int(n)
 
     def _flush_steps(self):
         if not self._replayed:

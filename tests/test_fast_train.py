@@ -285,11 +285,12 @@ def test_replayed_steps_reach_the_optimizer_state(tmp_path):
 
 
 @pytest.mark.parametrize('D', [100, 36])
-def test_fed_steps_draw_the_same_batches_as_the_host_driven_samplers(tmp_path, D):
+def test_fed_steps_match_the_host_driven_device_sampling(tmp_path, D):
     """-device_sampling, two ways: (a) DeviceFeeder.next_cols + DeviceSampler.sample_* + rec_step / kg_step (ids handed over per
-    step), (b) fed_step (ktup_feed_rec / ktup_feed_kg captured at the head of the step's graph, device-side cursor and Philox
-    counter).  Same seeds -> the SAME id buffers bit for bit at every step, across an epoch wrap of the small rating list, and
-    the same tables up to the order of the gradient atomics.  D = 36 has no fused step: can_feed refuses and (b) = (a)."""
+    step), (b) fed_step: the batch is drawn by ktup_feed_* at the head of the step's graph, the loss summed by the optimizer
+    launch, losses summed on the device.  Same seeds -> the same batches (tests/test_hip_sample.py checks the ids bit for bit),
+    hence the same loss at every step -- across the switch from eager steps to graph replays and an epoch wrap of the small
+    rating list -- and the same tables up to the order of the gradient atomics.  D = 36 has no fused step: can_feed refuses."""
     from jTransUP.utils.device_sampler import DeviceSampler
     from jTransUP.utils.fast_train import DeviceFeeder, JointStepper
     B = 16                                                               # <= the admissible items of every user (40 items, unique negatives)
@@ -315,30 +316,51 @@ def test_fed_steps_draw_the_same_batches_as_the_host_driven_samplers(tmp_path, D
         if fed:
             st.attach_feeds(sampler, rec=rec_feed, kg=kg_feed)
             assert st.can_feed('rec') == st.can_feed('kg') == (D != 36)
-        ids, losses = [], []
-        for step in range(14):                                            # 75 ratings / 16: the rec feeder wraps after 4 batches
+        losses, total = [], {'rec': 0.0, 'kg': 0.0}
+        for step in range(24):                                            # 75 ratings / 16: the rec feeder wraps after 4 batches
             kind = 'rec' if step % 10 < 7 else 'kg'
             if fed and st.can_feed(kind):
-                losses.append(st.fed_step(kind))
+                out = st.fed_step(kind)
+                assert st.fed_cycle(('rec',) * 7 + ('kg',) * 3) == 0       # 7 rec batches never fit before the 4-batch epoch ends
             elif kind == 'rec':
                 u, pi = rec_feed.next_cols()
-                losses.append(st.rec_step(u, pi, sampler.sample_rec(u, pi)))
+                out = st.rec_step(u, pi, sampler.sample_rec(u, pi))
             else:
                 ph, pt, pr = kg_feed.next_cols()
                 nh, nt = sampler.sample_kg(ph, pt, pr)
-                losses.append(st.kg_step(ph, pt, pr, nh, nt, pr))
-            bufs = (st.u2, st.i2) if kind == 'rec' else (st.h2, st.t2, st.r2)
-            ids.append([b.clone() for b in bufs])
-            losses[-1] = losses[-1].clone()
+                out = st.kg_step(ph, pt, pr, nh, nt, pr)
+            losses.append(float(out))
+            total[kind] += losses[-1]
         sampler.check()
-        assert sampler.offset == 14 * B * 4096 and rec_feed.start == (11 % 4) * B          # 11 rec steps, 4 batches per epoch
-        runs.append((init, ids, losses, copy.deepcopy(m.state_dict())))
+        assert tr.step == 24
+        if fed and D != 36:
+            assert sorted(st._graphs) == ['kg+fed', 'rec+fed']
+            sums = st.take_sums()                                         # accumulated inside the graphs
+            for k in total:
+                assert abs(sums[k] - total[k]) <= 1e-4 * abs(total[k]) + 1e-5
+            assert st.take_sums() == {'rec': 0.0, 'kg': 0.0}
+        # multi-step graphs: 2 x (rec, kg, kg) more steps -- single steps in run (a), ONE replay of a three-step graph each in
+        # run (b) (captured the first time, replayed the second)
+        for rep in range(2):
+            cyc = ('rec', 'kg', 'kg')
+            n = st.fed_cycle(cyc) if fed and D != 36 else 0
+            assert n == (3 if fed and D != 36 else 0)
+            for kind in cyc[n:]:
+                if kind == 'rec':
+                    u, pi = rec_feed.next_cols()
+                    st.rec_step(u, pi, sampler.sample_rec(u, pi))
+                else:
+                    ph, pt, pr = kg_feed.next_cols()
+                    nh, nt = sampler.sample_kg(ph, pt, pr)
+                    st.kg_step(ph, pt, pr, nh, nt, pr)
+        assert tr.step == 30
+        if fed and D != 36:
+            assert 'cycle:rec,kg,kg' in st._graphs
+        sampler.check()
+        runs.append((init, losses, copy.deepcopy(m.state_dict())))
     for step, (a, b) in enumerate(zip(runs[0][1], runs[1][1])):
-        for x, y in zip(a, b):
-            assert torch.equal(x, y), 'id buffers differ at step %d' % step
-    for a, b in zip(runs[0][2], runs[1][2]):
-        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6)
-    for (k, a), (_, b) in zip(runs[0][3].items(), runs[1][3].items()):
+        assert abs(a - b) <= 1e-5 * abs(a) + 1e-6, 'loss differs at step %d: %r vs %r' % (step, a, b)
+    for (k, a), (_, b) in zip(runs[0][2].items(), runs[1][2].items()):
         err = (b - a).abs()
         bad = err > 2e-6 + 2e-5 * a.abs()
         assert float(bad.float().mean()) <= 2e-3 and float(err.max()) <= 1e-3 * 0.05, (k, int(bad.sum()), float(err.max()))

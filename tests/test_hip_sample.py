@@ -30,14 +30,14 @@ def test_rec_sampler_constraints_and_uniformity():
     s2 = DeviceSampler(DEV, seed=3)
     s2.set_rating_dicts(nu, ni, [train, valid])
     u = torch.arange(n, device=DEV) % nu; pos = torch.zeros(n, dtype=torch.long, device=DEV)
-    s.offset = s2.offset = 777
+    s.offsets['rec'] = s2.offsets['rec'] = 777
     a, b = s.sample_rec(u, pos, unique_in_batch=False), s2.sample_rec(u, pos, unique_in_batch=False)
     assert torch.equal(a, b)                                                # (seed, offset) reproduces the batch
     # ... and so does the batch-unique mode: collisions are resolved by deterministic rounds, not by an atomic race
     u = torch.from_numpy(rng.randint(0, nu, size=n)).to(DEV); pos = torch.from_numpy(rng.randint(0, ni, size=n)).to(DEV)
     ref = None
     for _ in range(5):
-        s.offset = s2.offset = 4242
+        s.offsets['rec'] = s2.offsets['rec'] = 4242
         a, b = s.sample_rec(u, pos), s2.sample_rec(u, pos)
         assert torch.equal(a, b) and (ref is None or torch.equal(a, ref))
         ref = a
@@ -81,3 +81,49 @@ def test_kg_sampler_constraints_and_fair_coin():
     assert 0.45 < heads / float(n) < 0.55                                    # fair coin (data.py:13-14)
     nh2, nt2 = s.sample_kg(h, t, r)
     assert not (torch.equal(nh, nh2) and torch.equal(nt, nt2))              # the offset advanced
+
+
+def test_feed_launches_equal_slice_plus_sampler():
+    """ktup_feed_rec / ktup_feed_kg (batch slice + negatives + the steppers' [pos ; neg] layout from a device-side cursor and
+    Philox counter) against the host-driven route: DeviceFeeder.next_cols + DeviceSampler.sample_* with the same seeds -- the
+    same ids bit for bit, launch after launch, across an epoch wrap; cursor and counter end where the host mirrors say."""
+    from jTransUP.hip import lib as L
+    from jTransUP.hip.ops import _p, _stream
+    from jTransUP.utils.device_sampler import DeviceSampler, TRIES
+    from jTransUP.utils.fast_train import DeviceFeeder
+    rng = np.random.RandomState(7)
+    nu, ni, ne, nr, B = 60, 400, 300, 5, 32
+    ratings = [(int(u), int(i)) for u, i in zip(rng.randint(0, nu, 150), rng.randint(0, ni, 150))]
+    triples = [(int(h), int(t), int(r)) for h, t, r in zip(rng.randint(0, ne, 200), rng.randint(0, ne, 200), rng.randint(0, nr, 200))]
+    rated = {}
+    for u, i in ratings:
+        rated.setdefault(u, set()).add(i)
+
+    def make():
+        s = DeviceSampler(DEV, seed=11)
+        s.set_rating_dicts(nu, ni, [rated]); s.set_triples(ne, nr, [triples])
+        return s, DeviceFeeder(ratings, B, DEV, seed=1), DeviceFeeder(triples, B, DEV, seed=2)
+    (sa, ra, ka), (sb, rb, kb) = make(), make()
+    i64 = dict(dtype=torch.int64, device=DEV)
+    u2, i2, h2, t2, r2 = (torch.zeros(2 * B, **i64) for _ in range(5))
+    st = _stream(DEV)
+    for step in range(12):                                                  # 150 / 32: the rating columns wrap after 4 batches
+        if step % 3 < 2:
+            u, pi = ra.next_cols()
+            ni_ = sa.sample_rec(u, pi)
+            rb.fed(); sb.fed(B, 'rec')
+            L.call('ktup_feed_rec', _p(rb.cols[0]), _p(rb.cols[1]), rb.n, B, _p(rb.cursor), _p(sb.offset_dev[0:]), ni, _p(sb.bitmap), sb.words,
+                   sb.seed, 1, _p(u2), _p(i2), _p(sb.rec_workspace()), _p(sb.fail), st)
+            assert torch.equal(u2, torch.cat([u, u])) and torch.equal(i2, torch.cat([pi, ni_])), step
+            assert int(rb.cursor.item()) == rb.start == ra.start
+        else:
+            ph, pt, pr = ka.next_cols()
+            nh, nt = sa.sample_kg(ph, pt, pr)
+            kb.fed(); sb.fed(B, 'kg')
+            L.call('ktup_feed_kg', _p(kb.cols[0]), _p(kb.cols[1]), _p(kb.cols[2]), kb.n, B, _p(kb.cursor), _p(sb.offset_dev[1:]), ne, nr,
+                   _p(sb.keys), sb.keys.numel(), sb.seed, _p(h2), _p(t2), _p(r2), _p(sb.fail), st)
+            assert torch.equal(h2, torch.cat([ph, nh])) and torch.equal(t2, torch.cat([pt, nt])) and torch.equal(r2, torch.cat([pr, pr])), step
+    assert sb.offset_dev.tolist() == [sb.offsets['rec'], sb.offsets['kg']] == [sa.offsets['rec'], sa.offsets['kg']]
+    assert sa.offset == 12 * B * TRIES
+    assert bool((sb.rec_workspace() == -1).all())                          # the uniqueness scratch is left all-ones
+    sa.check(); sb.check()

@@ -1,6 +1,7 @@
 """Small fixed workloads for rocprofv3 counter passes (run under `rocprofv3 --kernel-trace --pmc ... -- python tools/pmc_workloads.py <name>`):
     eval_pass   the fused all-item evaluation sweep at ml1m shape (ktup_eval_pref_topk_prepared), 5 sweeps
     train_step  the three-launch B=512 joint training step, 20 rec + 20 kg steps
+    fed_step    the device-fed B=512 joint step (-device_sampling): feed launch + step + clip/optimizer, ten-step graphs
     seg_bwd     the large-batch backwards by sorted segments: TransE (307,200 triples) and KTUP (716,800 pairs), 5 each
 tools/pmc_summary.py turns the counter_collection.csv into per-kernel averages."""
 import os
@@ -34,6 +35,37 @@ def train_step(dev):
     B.train_step_bench(dev, steps=40, warmup=10)
 
 
+def fed_step(dev):
+    import types
+    from jTransUP.models import jTransUP as jt
+    from jTransUP.utils.device_sampler import DeviceSampler
+    from jTransUP.utils.fast_train import DeviceFeeder, JointStepper
+    from jTransUP.utils.fused_optim import FusedOptimizer
+    torch.manual_seed(3)
+    i_map = {i: i for i in range(B.NI)}
+    new_map = {i: ((i * 4) % B.NE if i < B.ALIGNED else -1, i) for i in range(B.NI)}
+    m = jt.jTransUPModel(False, B.D, B.NU, B.NI, B.NE, B.NR, i_map, new_map, False, False)
+    opt = torch.optim.Adagrad(m.parameters(), lr=0.005, weight_decay=1e-5)
+    tr = types.SimpleNamespace(fused=FusedOptimizer(opt), parameters=list(m.parameters()), model_target=-1, step=0)
+    fl = types.SimpleNamespace(margin=1.0, kg_lambda=1.0, clipping_max_value=5.0)
+    js = JointStepper(m, tr, fl, 512)
+    gen = torch.Generator().manual_seed(6)
+    ratings = torch.stack([torch.randint(0, B.NU, (96000,), generator=gen), torch.randint(0, B.NI, (96000,), generator=gen)], 1)
+    triples = torch.stack([torch.randint(0, B.NE, (48000,), generator=gen), torch.randint(0, B.NE, (48000,), generator=gen),
+                           torch.randint(0, B.NR, (48000,), generator=gen)], 1)
+    sm = DeviceSampler(dev, seed=1)
+    sm.set_rating_dicts(B.NU, B.NI, []); sm.set_triples(B.NE, B.NR, [triples.tolist()])
+    js.attach_feeds(sm, rec=DeviceFeeder(ratings, 512, dev, seed=1), kg=DeviceFeeder(triples, 512, dev, seed=2))
+    cyc = ('rec',) * 7 + ('kg',) * 3
+    for s in range(20):
+        js.fed_step(cyc[s % 10])
+    for _ in range(10):
+        if not js.fed_cycle(cyc):
+            for k in cyc:
+                js.fed_step(k)
+    torch.cuda.synchronize()
+
+
 def seg_bwd(dev):
     from jTransUP.hip import ops
     W, i2e, idx = B.build_world(3, dev)
@@ -49,4 +81,4 @@ def seg_bwd(dev):
 
 
 if __name__ == '__main__':
-    {'eval_pass': eval_pass, 'train_step': train_step, 'seg_bwd': seg_bwd}[sys.argv[1]](torch.device('cuda'))
+    {'eval_pass': eval_pass, 'train_step': train_step, 'fed_step': fed_step, 'seg_bwd': seg_bwd}[sys.argv[1]](torch.device('cuda'))

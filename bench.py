@@ -309,9 +309,15 @@ def eval_bench(device, batch=512, seed=11, keep=None):
             m.evaluate_topk(all_u, items, 10, index.f_off, index.f_ids)
         b.record(); torch.cuda.synchronize(device)
         sweep_ms = a.elapsed_time(b) / 20
-        flop = 6 * 2.0 * NU * NI * D
+        # matrix work of the sweep: every user x item cross term in preference space, K = (d + 2P) + 2P + 2P + P padded to
+        # 16-blocks = 272 multiply-adds per pair at d = 100, P = 20 (the six d-long products of the batched route: 600)
+        p4 = 4 if NR <= 4 else 20 if NR <= 20 else 32           # preferences = relations in KTUP
+        kpad = sum(-(-k // 16) * 16 for k in (D + 2 * p4, 2 * p4, 2 * p4, p4))
+        flop = 2.0 * NU * NI * kpad
         fused = {'full_pass_ms_incl_metrics': fused_ms, 'device_ms_scores_and_topk': sweep_ms,
-                 'gemm_tflops_over_sweep': flop / (sweep_ms * 1e-3) / 1e12, 'gemm_frac_of_fp32_peak': flop / (sweep_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
+                 'mfma_flop_per_pair': 2 * kpad, 'gemm_tflops_over_sweep': flop / (sweep_ms * 1e-3) / 1e12,
+                 'gemm_frac_of_fp32_peak': flop / (sweep_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
+                 'metric_rows_max_abs_diff_vs_batched_route': float(np.abs(rows_f - rows).max()),
                  'rows_equal_batched_route': bool(np.array_equal(rows_f, rows))}
         rows = rows_f
     if keep is not None:                              # for the CPU side-by-side, run after every GPU timing (main)

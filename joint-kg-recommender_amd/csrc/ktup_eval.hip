@@ -735,12 +735,12 @@ extern "C" int ktup_eval_pref_scores_prepared(const float* U, int64_t ldu, const
                           item_side(const_cast<float*>(items_ws), n_items, d), ws, (hipStream_t)stream);
 }
 
-// K16 + K17 for a whole evaluation pass in one sweep (ktup_eval_pass.hip): users' projections, then the fused score + filtered
-// top-n kernel -- no (users x items) matrix.  Soft gate + squared L2 at d in {64, 100, 128} only (KTUP_ERR_UNSUPPORTED otherwise:
+// K16 + K17 for a whole evaluation pass in one sweep (ktup_eval_pass.hip): operand rows in preference space, then the fused score +
+// filtered top-n kernel -- no (users x items) matrix.  Soft gate + squared L2 at d in {64, 100, 128}, n_pref <= 32 only (KTUP_ERR_UNSUPPORTED otherwise:
 // the caller keeps ktup_eval_pref_scores_prepared + ktup_eval_topk_filtered per batch).
 extern "C" size_t ktup_eval_pref_topk_workspace_bytes(int d, int n_pref, int64_t nq, int64_t n_items, int topn) {
   if (nq <= 0 || topn <= 0 || n_items < 0) return 0;
-  return ((size_t)nq * 3 * d + pad4((size_t)nq * n_pref)) * sizeof(float) + ktup::eval_pass_part_bytes(nq, topn, n_items);
+  return ktup::eval_pass_pspace_bytes(d, n_pref, nq, n_items, topn);
 }
 
 extern "C" int ktup_eval_pref_topk_prepared(const float* U, int64_t ldu, const float* pref_ws, int n_pref, int d,
@@ -756,16 +756,10 @@ extern "C" int ktup_eval_pref_topk_prepared(const float* U, int64_t ldu, const f
   KTUP_REQUIRE(aligned16(U) && aligned16(pref_ws) && aligned16(ws) && aligned16(items_ws) && ldu % 4 == 0,
                "%s: tables must be 16-byte aligned with pitches %% 4 == 0", name);
   hipStream_t st = (hipStream_t)stream;
-  float* QW = ws;
-  float* QL = QW + (size_t)nq * 3 * d;
-  uint64_t* part = reinterpret_cast<uint64_t*>(QL + pad4((size_t)nq * n_pref));
   const ItemSide it = item_side(const_cast<float*>(items_ws), n_items, d);
-  hipLaunchKernelGGL(pref_project_kernel, dim3(grid_for((nq + 3) / 4)), dim3(256), 0, st, U, ldu, (const float*)nullptr,
-                     (int64_t)0, (const int32_t*)nullptr, u_ids, nq, d, n_pref, pref_ws, g.ppad, g.dp, 1.0f, (int64_t)3 * d, QW,
-                     QW + d, QW + 2 * d, QL);
-  if (int e = check_launch(name)) return e;
-  const int rc = ktup::eval_pass_l2_mc(QW, it.CW0, it.CW1, it.CW2, d, nq, n_items, filt_off, filt_ids, topn, part, top_ids, top_scores, st, name);
-  if (rc == 1) return set_error(KTUP_ERR_UNSUPPORTED, "%s: no fused pass kernel for d=%d, topn=%d", name, d, topn);
+  const int rc = ktup::eval_pass_pspace(U, ldu, u_ids, nq, it.CW1, n_items, pref_ws, g.ppad, g.dp, n_pref, d, filt_off, filt_ids, topn, ws,
+                                        top_ids, top_scores, st, name);
+  if (rc == 1) return set_error(KTUP_ERR_UNSUPPORTED, "%s: no fused pass kernel for d=%d, n_pref=%d, topn=%d", name, d, n_pref, topn);
   return rc;
 }
 

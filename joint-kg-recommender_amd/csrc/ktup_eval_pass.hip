@@ -1,28 +1,27 @@
 // K16 + K17 fused for a whole evaluation pass (soft gate, squared L2): all-item TUP / KTUP scores AND the filtered top-n of
-// every user in ONE launch that never writes the (users x items) score matrix.
+// every user in ONE sweep that never writes the (users x items) score matrix.
 //
 // Reference: transUP.py:84-102 / jTransUP.py:163-191 (evaluate / evaluateRec) produce a (B x N) matrix per batch of 512 users,
 // which utils/misc.py:186-248 copies to the host, argsorts and walks.  Round 1 kept that shape on the device: per batch a
 // six-GEMM score kernel wrote B x N x 4 bytes (78 MB over an ml1m pass) and a ranking kernel read them back -- 12 batches x
-// ~5 launches, 1.05 ms, the GEMMs at 18 % of the fp32 matrix peak.  Here one persistent kernel walks the pass:
-//   * scores: the same six bilinear terms as pairs_l2_mc_kernel (ktup_eval_mc.hip: |a|^2 - 2 s (a.n) + s^2 |n|^2 with every term a
-//     (users x d).(d x items) product on v_mfma_f32_16x16x4_f32), the same k order and the same epilogue arithmetic, so a score
-//     is bit-identical to the matrix route's;
-//   * a workgroup owns 64 users (4 waves x 16) and a contiguous split of the catalogue.  A wave keeps its 16 users' three
-//     operand vectors in REGISTERS for the whole pass (the A operands: 18 float4 per lane at d = 100); items stream through a
-//     double-buffered 16-item LDS tile (the B operands, 19 KB per buffer) that the next tile's global loads refill under the
-//     MFMAs -- LDS stays at ~60 KB, two workgroups per CU;
+// ~5 launches, 1.05 ms.  Here:
+//   * scores: |a|^2 - 2 s (a.n) + s^2 |n|^2 as in pairs_l2_mc_kernel (ktup_eval_mc.hip), but with every user x item cross term
+//     except u.v contracted in PREFERENCE space (see QGeom below): 68 instead of 156 MFMAs per 16 x 16 tile at d = 100, P = 20.
+//     Scores agree with the matrix route to fp32 rounding (the same sums in another association);
+//   * a workgroup owns 64 users (4 waves x 16) and a contiguous split of the catalogue.  A wave keeps its 16 users' operand
+//     rows in REGISTERS for the whole pass (17 float4 per lane); items stream through a double-buffered LDS buffer of two
+//     16-item tiles (the B operands, 160 floats per item) that the next tiles' global loads refill under the MFMAs -- three
+//     workgroups per CU;
 //   * ranking: a user's sorted top-n list (64-bit keys = order-preserving score image << 32 | item id, the order of
 //     ktup_rank.hip: ascending score, ties -> lower id) lives in REGISTERS, one element per lane of the 16-lane row that owns
 //     the user in the MFMA output layout (lane (kq, j) holds element j of users 4 kq + reg).  A score is a candidate only if its
 //     key beats the user's current n-th key and its bit in the wave's filter bitmap (built once from the CSR filter lists, for
-//     this workgroup's item split only: 16 users x (split / 32) words of LDS) is clear; candidates are rare after the first
-//     tiles (~n ln(N / n) per user).  The four rows insert their candidates in parallel: the shift of the sorted list is one DPP
-//     row_shr per half key, the position a popcount of a ballot -- no LDS round trip (the first version kept the lists in LDS
-//     and inserted one candidate per wave at a time: 830 us per ml1m pass, 3 LDS latencies per candidate);
-//   * item scalars (v.NV, |C0|^2, C0.NV, |NV|^2) are computed once per pass by a small kernel and travel with the tile;
-//   * the splits' partial lists are merged by a second, tiny launch (topk_merge_kernel).
-// L1 distance and the ST-Gumbel gate do not decompose into GEMMs: they keep the per-batch kernels of ktup_eval.hip.
+//     this workgroup's item split only: 16 users x (split / 32) words of LDS) is clear.  The four rows insert their candidates in
+//     parallel: the shift of the sorted list is one DPP row_shr per half key, the position a popcount of a ballot -- no LDS
+//     round trip (the first version kept the lists in LDS and inserted one candidate per wave at a time: 830 us per ml1m pass);
+//   * both operand tables and the per-row scalars are built per pass by one small launch (pspace_rows_kernel) after the three
+//     P x P Gram matrices (pspace_gram_kernel); the splits' partial lists are merged by a last, tiny launch (topk_merge_kernel).
+// L1 distance and the ST-Gumbel gate do not decompose into bilinear terms: they keep the per-batch kernels of ktup_eval.hip.
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -45,48 +44,101 @@ KTUP_DEV uint64_t pass_key(float s, uint32_t id) {   // ktup_rank.hip make_key, 
   return ((uint64_t)u << 32) | id;
 }
 
-template <int NCH_>
-struct PGeom {
-  static constexpr int NCH = NCH_, D = 4 * NCH;
-  static constexpr int KG = (D + 15) / 16;
-  static constexpr bool TAIL1 = NCH - 4 * (KG - 1) == 1;       // d % 16 == 4: the last chunk goes through one b32-operand MFMA
-  static constexpr int KGF = TAIL1 ? KG - 1 : KG;
-  static_assert(TAIL1 || NCH % 4 == 0, "k groups must be whole (d % 16 in {0, 4})");
-  static constexpr int P4 = NCH | 1;                           // odd float4 row pitch of the item tile
-  static constexpr int TILE_F4 = IBT * 3 * P4;
-  static constexpr int LPT = (IBT * 3 * NCH + IBT + 255) / 256;   // float4 loads per thread and tile (+ one scalar quad per item)
+// partial lists of the splits -> the topn smallest keys per user.  One WAVE per user: the <= 128 keys sit two per lane, every lane
+// ranks its keys against all of them (keys are distinct: the item id is their low half) and the lanes whose rank is below topn
+// write their key's slot -- no serial k-way merge, no dependent memory round trips (that version: 22 us for 6040 users).
+constexpr int MERGE_T = 256;
+__global__ __launch_bounds__(MERGE_T) void topk_merge_kernel(const uint64_t* __restrict__ part, int64_t nq, int nsplit, int topn,
+                                                             const float* __restrict__ unused, int32_t* __restrict__ top_ids,
+                                                             float* __restrict__ top_scores) {
+  (void)unused;
+  __shared__ uint64_t wk[MERGE_T / 64][128];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t b = (int64_t)blockIdx.x * (MERGE_T / 64) + w;
+  if (b >= nq) return;                                                    // (whole waves leave: no workgroup barrier below)
+  const int per = nsplit * topn;
+  const uint64_t* p = part + b * per;
+  const uint64_t k0 = lane < per ? p[lane] : PKEY_MAX, k1 = 64 + lane < per ? p[64 + lane] : PKEY_MAX;
+  wk[w][lane] = k0; wk[w][64 + lane] = k1;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  int r0 = 0, r1 = 0;
+  for (int i = 0; i < per; ++i) {
+    const uint64_t k = wk[w][i];
+    r0 += k < k0; r1 += k < k1;
+  }
+  const int valid = __popcll(__ballot(k0 != PKEY_MAX)) + __popcll(__ballot(k1 != PKEY_MAX));
+  auto put = [&](uint64_t key, int r) {
+    if (key == PKEY_MAX || r >= topn) return;
+    top_ids[b * topn + r] = (int32_t)(uint32_t)key;
+    if (top_scores) {
+      uint32_t u = (uint32_t)(key >> 32);
+      u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;                     // inverse of the order-preserving image
+      top_scores[b * topn + r] = __uint_as_float(u);
+    }
+  };
+  put(k0, r0); put(k1, r1);
+  if (lane >= valid && lane < topn) {                                     // fewer candidates than topn: pad
+    top_ids[b * topn + lane] = -1;
+    if (top_scores) top_scores[b * topn + lane] = 0.f;
+  }
+}
+
+// ================================================================================================ preference-space formulation
+// Six d-long products per pair (u.NV, NU.v, AU.C0, AU.NV, NU.C0, NU.NV: round 2's first fused pass, 0.39 ms per ml1m sweep) are
+// more work than the model needs.  With the soft gate every vector of the score lives in
+//   span{x} + span{Ar_p} + span{Cn_p}   (x = u or v;  RU = sum_p L_p Ar_p,  NU = sum_p L_p Cn_p,  L = Alog x, P <= 32 preferences)
+// so every user x item cross term except u.v is a P-long contraction of per-row P-vectors (L, Rx = Ar x, Nx = Cn x) through the
+// three P x P Gram matrices G_RR = Ar Ar^T, G_RN = Ar Cn^T, G_NN = Cn Cn^T:
+//   s  cross = u.NV - v.NU            = [ Nu ; -L ]                          . [ LV ; Nv ]          K = 2 P
+//   an cross = AU.NV - C0.NU          = [ Nu + G_RN^T L + G_RN L ; -L ]      . [ LV ; Nv ]          K = 2 P   (same B)
+//   nn cross = 2 NU.NV                = [ 2 G_NN L ]                         . [ LV ]               K = P     (same B)
+//   aa cross = -2 AU.C0               = [ -2u ; -2L ; 2 (Ru + G_RR L) ]      . [ v ; Rv ; LV ]      K = d + 2 P
+// with the Gram products folded into the USER operand once per pass.  At d = 100, P = 20: 68 MFMAs (K padded to 16-blocks) and
+// 12 ds_read_b128 per 16 x 16 tile instead of 156 and 75; an item row is 160 floats instead of 300.  Scores agree with the
+// d-space kernels to fp32 rounding (a different association of the same sums), not bit for bit.
+template <int NCH_, int NP_>
+struct QGeom {
+  static constexpr int NCH = NCH_, D = 4 * NCH, NP = NP_, P4 = 4 * NP;
+  static constexpr int ROWB = D + 3 * P4;                       // item row: [x ; Rx ; L ; Nx]
+  static constexpr int RB4 = ROWB / 4;
+  static constexpr int ROW4 = RB4 | 1;                          // odd float4 pitch in LDS: 16 rows x 4 k-quads tile the banks
+  static constexpr int SOFF4 = (D + P4) / 4;                    // float4 offset of [L ; Nx] inside a row
+  static constexpr int KA = (D + 2 * P4 + 15) / 16, KS = (2 * P4 + 15) / 16, KN = (P4 + 15) / 16;   // 16-blocks of K
+  static constexpr int NA = KA + 2 * KS + KN;                   // float4 A operands per lane: [AA | S | AN | NN]
+  static constexpr int AROW = 16 * NA;                          // floats per user row
+  static constexpr int SUB = 2;                                 // 16-item sub-tiles per buffer = per workgroup barrier
+  static constexpr int TILE_F4 = SUB * IBT * ROW4 + 4;          // + pad: the padded K blocks read a little past the last row
+  static constexpr int LPT = (IBT * RB4 + IBT + 255) / 256;     // float4 loads per thread and SUB-tile
+  static constexpr int MINW = NA <= 18 ? 3 : 2;                 // waves per SIMD the register budget allows (= workgroups per CU)
 };
 
-struct PassArgs {
-  const float *QW, *C0, *C1, *C2;   // users: rows of 3 d floats [AU | u | NU]; items: three (n_items x d) arrays
-  const float* ISC;                 // [n_items][4] item scalars (item_scalars_kernel)
+struct QArgs {
+  const float *A, *SCU;          // users: AROW floats + 4 scalars each
+  const float *B, *ISC;          // items: ROWB floats + 4 scalars each
   int64_t nq, n_items;
-  const int64_t* filt_off;          // CSR filter sets per user (global item ids); null = no filter
-  const int32_t* filt_ids;
-  int topn, nsplit;
-  int64_t split_items;              // items per split (multiple of IBT)
-  uint64_t* part;                   // [nq][nsplit][topn] partial lists
-  int bm_words;                     // filter bitmap words per user (covers one split)
+  const int64_t* filt_off; const int32_t* filt_ids;
+  int topn, nsplit; int64_t split_items; uint64_t* part; int bm_words;
 };
 
 template <typename G>
-__global__ __launch_bounds__(256) void eval_pass_kernel(PassArgs a) {
-  constexpr int NCH = G::NCH, D = G::D, KGF = G::KGF, P4 = G::P4, LPT = G::LPT;
-  constexpr bool TAIL1 = G::TAIL1;
+__global__ __launch_bounds__(256, G::MINW) void eval_pass_q_kernel(QArgs a) {
+  constexpr int RB4 = G::RB4, ROW4 = G::ROW4, KA = G::KA, KS = G::KS, KN = G::KN, NA = G::NA, LPT = G::LPT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  v4* Xb = reinterpret_cast<v4*>(smem);                                   // [2][IBT][3][P4] item tiles
-  float* isc = reinterpret_cast<float*>(Xb + 2 * G::TILE_F4);             // [2][IBT][4] item scalars
+  v4* Xb = reinterpret_cast<v4*>(smem);                                   // [2][TILE_F4] item tiles
+  constexpr int SUB = G::SUB;
+  float* isc = reinterpret_cast<float*>(Xb + 2 * G::TILE_F4);             // [2][SUB * IBT][4] item scalars
   const int tid = threadIdx.x, lane = tid & 63, kq = lane >> 4, j = lane & 15;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  char* wbase = reinterpret_cast<char*>(isc + 2 * IBT * 4) + (size_t)w * ((size_t)16 * 4 * 4 + (size_t)16 * a.bm_words * 4);
+  char* wbase = reinterpret_cast<char*>(isc + 2 * SUB * IBT * 4) + (size_t)w * ((size_t)16 * 4 * 4 + (size_t)16 * a.bm_words * 4);
   float* usc = reinterpret_cast<float*>(wbase);                           // [16][4] user scalars
   uint32_t* bm = reinterpret_cast<uint32_t*>(usc + 64);                   // [16][bm_words] filter bits of this split
-  uint64_t tkr[4] = {PKEY_MAX, PKEY_MAX, PKEY_MAX, PKEY_MAX};             // element j of the sorted top-n lists of users 4 kq + reg
-  const int64_t u0 = (int64_t)blockIdx.x * 64 + 16 * w;                   // this wave's first user
+  uint64_t tkr[4] = {PKEY_MAX, PKEY_MAX, PKEY_MAX, PKEY_MAX};
+  const int64_t u0 = (int64_t)blockIdx.x * 64 + 16 * w;
   const int64_t i_lo = (int64_t)blockIdx.y * a.split_items;
   const int64_t i_hi = min(a.n_items, i_lo + a.split_items);
   const int topn = a.topn;
-  // ---- per-wave setup: top-n lists, filter bitmap of the split, user scalars, A operands
+  for (int idx = tid; idx < 2 * G::TILE_F4; idx += 256) Xb[idx] = (v4){0.f, 0.f, 0.f, 0.f};   // row pads stay finite (x 0 operands)
   for (int idx = lane; idx < 16 * a.bm_words; idx += 64) bm[idx] = 0u;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -100,173 +152,140 @@ __global__ __launch_bounds__(256) void eval_pass_kernel(PassArgs a) {
       }
     }
   }
-  // user scalars with the arithmetic of pairs_l2_mc_kernel (8 lanes per row, chunks l, l + 8, ..., then xor-shuffles):
-  // u.NU, |AU|^2, AU.NU, |NU|^2
-#pragma unroll
-  for (int pass = 0; pass < 2; ++pass) {
-    const int r = 8 * pass + (lane >> 3);
-    const bool ok = u0 + r < a.nq;
-    const v4* r0 = reinterpret_cast<const v4*>(a.QW + (ok ? u0 + r : 0) * 3 * D);
-    v4 s0 = (v4){0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
-    for (int c = lane & 7; c < NCH; c += 8) {
-      const v4 zero = (v4){0.f, 0.f, 0.f, 0.f};
-      const v4 x0 = ok ? r0[c] : zero, x1 = ok ? r0[NCH + c] : zero, x2 = ok ? r0[2 * NCH + c] : zero;
-      s0 += x1 * x2; s1 += x0 * x0; s2 += x0 * x2; s3 += x2 * x2;
-    }
-    float f0 = (s0[0] + s0[1]) + (s0[2] + s0[3]), f1 = (s1[0] + s1[1]) + (s1[2] + s1[3]);
-    float f2 = (s2[0] + s2[1]) + (s2[2] + s2[3]), f3 = (s3[0] + s3[1]) + (s3[2] + s3[3]);
-#pragma unroll
-    for (int m = 1; m < 8; m <<= 1) {
-      f0 += __shfl_xor(f0, m, 64); f1 += __shfl_xor(f1, m, 64); f2 += __shfl_xor(f2, m, 64); f3 += __shfl_xor(f3, m, 64);
-    }
-    if ((lane & 7) == 0) { usc[r * 4 + 0] = f0; usc[r * 4 + 1] = f1; usc[r * 4 + 2] = f2; usc[r * 4 + 3] = f3; }
-  }
-  // A operands of the whole pass: lane (kq, j) = user row j, chunks 4 g + kq of AU / u / NU (rows past nq are zero)
-  v4 aAU[KGF], au[KGF], aNU[KGF];
-  float tAU = 0.f, tu = 0.f, tNU = 0.f;
+  if (lane < 16) *reinterpret_cast<v4*>(usc + lane * 4) =
+      u0 + lane < a.nq ? *reinterpret_cast<const v4*>(a.SCU + (u0 + lane) * 4) : (v4){0.f, 0.f, 0.f, 0.f};
+  v4 aop[NA];                                                             // A operands of the whole pass: user j, k-quad kq of every block
   {
     const bool ok = u0 + j < a.nq;
-    const v4* r0 = reinterpret_cast<const v4*>(a.QW + (ok ? u0 + j : 0) * 3 * D);
-    const v4 zero = (v4){0.f, 0.f, 0.f, 0.f};
+    const v4* r0 = reinterpret_cast<const v4*>(a.A + (ok ? u0 + j : 0) * G::AROW);
 #pragma unroll
-    for (int g = 0; g < KGF; ++g) {
-      aAU[g] = ok ? r0[4 * g + kq] : zero;
-      au[g] = ok ? r0[NCH + 4 * g + kq] : zero;
-      aNU[g] = ok ? r0[2 * NCH + 4 * g + kq] : zero;
-    }
-    if (TAIL1) {
-      const float* rf = reinterpret_cast<const float*>(r0);
-      tAU = ok ? rf[16 * KGF + kq] : 0.f;
-      tu = ok ? rf[D + 16 * KGF + kq] : 0.f;
-      tNU = ok ? rf[2 * D + 16 * KGF + kq] : 0.f;
-    }
+    for (int g = 0; g < NA; ++g) aop[g] = ok ? r0[4 * g + kq] : (v4){0.f, 0.f, 0.f, 0.f};
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  // ---- the item stream: tile t of this split, double buffered
+  __syncthreads();                                                        // tiles zeroed, bitmaps and scalars in place
   const int64_t ntile = (i_hi - i_lo + IBT - 1) / IBT;
   v4 pre[LPT];
-  // loop-invariant geometry of this thread's LPT float4 of a tile: source element, row inside the tile, LDS destination
   const float* fsrc[LPT];
   int frow[LPT], fdst[LPT];
 #pragma unroll
   for (int l = 0; l < LPT; ++l) {
     const int idx = tid + 256 * l;
-    if (idx < IBT * 3 * NCH) {
-      const int row = idx / (3 * NCH), rem = idx - row * (3 * NCH), vec = rem / NCH, c = rem - vec * NCH;
-      fsrc[l] = (vec == 0 ? a.C0 : vec == 1 ? a.C1 : a.C2) + (i_lo + row) * D + 4 * c;
+    if (idx < IBT * RB4) {
+      const int row = idx / RB4, c = idx - row * RB4;
+      fsrc[l] = a.B + (i_lo + row) * G::ROWB + 4 * c;
       frow[l] = row;
-      fdst[l] = (row * 3 + vec) * P4 + c;
-    } else if (idx < IBT * 3 * NCH + IBT) {
-      const int row = idx - IBT * 3 * NCH;
+      fdst[l] = row * ROW4 + c;
+    } else if (idx < IBT * RB4 + IBT) {
+      const int row = idx - IBT * RB4;
       fsrc[l] = a.ISC + (i_lo + row) * 4;
       frow[l] = row;
-      fdst[l] = -1 - row;                                                 // scalar quad of item `row`
+      fdst[l] = -1 - row;
     } else {
       fsrc[l] = nullptr; frow[l] = IBT; fdst[l] = 0;
     }
   }
-  auto fetch = [&](int64_t t) {                                           // global loads of tile t into registers
+  auto fetch = [&](int64_t t) {
 #pragma unroll
     for (int l = 0; l < LPT; ++l) {
       v4 val = (v4){0.f, 0.f, 0.f, 0.f};
-      if (fsrc[l] && i_lo + t * IBT + frow[l] < i_hi)
-        val = *reinterpret_cast<const v4*>(fsrc[l] + t * IBT * (fdst[l] >= 0 ? D : 4));
+      if (fsrc[l] && i_lo + t * IBT + frow[l] < i_hi) val = *reinterpret_cast<const v4*>(fsrc[l] + t * IBT * (fdst[l] >= 0 ? G::ROWB : 4));
       pre[l] = val;
     }
   };
-  auto stash = [&](int buf) {                                             // registers -> LDS tile (+ its item scalars)
-    v4* X = Xb + buf * G::TILE_F4;
+  auto stash = [&](int buf, int sub) {                                    // registers -> sub-tile `sub` of LDS buffer `buf`
+    v4* X = Xb + buf * G::TILE_F4 + sub * IBT * ROW4;
 #pragma unroll
     for (int l = 0; l < LPT; ++l) {
       if (fsrc[l]) {
         if (fdst[l] >= 0) X[fdst[l]] = pre[l];
-        else *reinterpret_cast<v4*>(isc + (buf * IBT + (-1 - fdst[l])) * 4) = pre[l];
+        else *reinterpret_cast<v4*>(isc + ((buf * SUB + sub) * IBT + (-1 - fdst[l])) * 4) = pre[l];
       }
     }
   };
-  if (ntile > 0) {
-    fetch(0);
-    stash(0);
-    __syncthreads();
-  }
   const int rowbase = 16 * kq;
-  uint64_t thr[4] = {PKEY_MAX, PKEY_MAX, PKEY_MAX, PKEY_MAX};             // the users' current n-th keys (lane topn - 1 of the row)
-  for (int64_t t = 0; t < ntile; ++t) {
-    const int buf = (int)(t & 1);
-    if (t + 1 < ntile) fetch(t + 1);                                      // in flight under the MFMAs below
-    const v4* ib = Xb + buf * G::TILE_F4 + (j * 3) * P4 + kq;             // lane (kq, col j): C0, v, NV of item j of the tile
-    v4 uNV = (v4){0.f, 0.f, 0.f, 0.f}, NUv = uNV, AUC0 = uNV, AUNV = uNV, NUC0 = uNV, NUNV = uNV;
+  uint64_t thr[4] = {PKEY_MAX, PKEY_MAX, PKEY_MAX, PKEY_MAX};
+  // (A split restarts its lists from nothing, so its first tiles insert nearly every item: measured, the insertion rounds are a
+  // third of this kernel's time, more than half of them in a split's first two tiles.  Sharing each user's n-th key between the
+  // concurrent splits -- atomicMin / periodic loads of a global bound -- cut the rounds by 37 % and the time by nothing; a
+  // sorting network for the dense first tiles is the next step.)
+  auto compute = [&](int buf, int sub, int64_t t) {                       // 16 users x the 16 items of tile t
+    const v4* ib = Xb + buf * G::TILE_F4 + (sub * IBT + j) * ROW4 + kq;   // lane (kq, item j): k-quad kq of every 16-block
+    v4 accAA = (v4){0.f, 0.f, 0.f, 0.f}, accS = accAA, accAN = accAA, accNN = accAA;
 #pragma unroll
-    for (int g = 0; g < KGF; ++g) {
-      const v4 bC0 = ib[4 * g], bv = ib[P4 + 4 * g], bNV = ib[2 * P4 + 4 * g];
+    for (int g = 0; g < KA; ++g) {
+      const v4 b = ib[4 * g];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) accAA = __builtin_amdgcn_mfma_f32_16x16x4f32(aop[g][c], b[c], accAA, 0, 0, 0);
+    }
+#pragma unroll
+    for (int g = 0; g < KS; ++g) {
+      const v4 b = ib[G::SOFF4 + 4 * g];
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        uNV = __builtin_amdgcn_mfma_f32_16x16x4f32(au[g][c], bNV[c], uNV, 0, 0, 0);
-        NUv = __builtin_amdgcn_mfma_f32_16x16x4f32(aNU[g][c], bv[c], NUv, 0, 0, 0);
-        AUC0 = __builtin_amdgcn_mfma_f32_16x16x4f32(aAU[g][c], bC0[c], AUC0, 0, 0, 0);
-        AUNV = __builtin_amdgcn_mfma_f32_16x16x4f32(aAU[g][c], bNV[c], AUNV, 0, 0, 0);
-        NUC0 = __builtin_amdgcn_mfma_f32_16x16x4f32(aNU[g][c], bC0[c], NUC0, 0, 0, 0);
-        NUNV = __builtin_amdgcn_mfma_f32_16x16x4f32(aNU[g][c], bNV[c], NUNV, 0, 0, 0);
+        accS = __builtin_amdgcn_mfma_f32_16x16x4f32(aop[KA + g][c], b[c], accS, 0, 0, 0);
+        accAN = __builtin_amdgcn_mfma_f32_16x16x4f32(aop[KA + KS + g][c], b[c], accAN, 0, 0, 0);
+        if (g < KN) accNN = __builtin_amdgcn_mfma_f32_16x16x4f32(aop[KA + 2 * KS + g][c], b[c], accNN, 0, 0, 0);
       }
     }
-    if (TAIL1) {                                                          // coordinates 16 KGF + kq
-      const float* jf = reinterpret_cast<const float*>(Xb + buf * G::TILE_F4 + (j * 3) * P4 + 4 * KGF) + kq;
-      const float bC0 = jf[0], bv = jf[4 * P4], bNV = jf[8 * P4];
-      uNV = __builtin_amdgcn_mfma_f32_16x16x4f32(tu, bNV, uNV, 0, 0, 0);
-      NUv = __builtin_amdgcn_mfma_f32_16x16x4f32(tNU, bv, NUv, 0, 0, 0);
-      AUC0 = __builtin_amdgcn_mfma_f32_16x16x4f32(tAU, bC0, AUC0, 0, 0, 0);
-      AUNV = __builtin_amdgcn_mfma_f32_16x16x4f32(tAU, bNV, AUNV, 0, 0, 0);
-      NUC0 = __builtin_amdgcn_mfma_f32_16x16x4f32(tNU, bC0, NUC0, 0, 0, 0);
-      NUNV = __builtin_amdgcn_mfma_f32_16x16x4f32(tNU, bNV, NUNV, 0, 0, 0);
-    }
-    // ---- epilogue: lane (kq, j) holds users 4 kq + reg (reg = 0..3) x item j of the tile -- pairs_l2_mc_kernel's arithmetic
-    const v4 is4 = *reinterpret_cast<const v4*>(isc + (buf * IBT + j) * 4);
+    const v4 is4 = *reinterpret_cast<const v4*>(isc + ((buf * SUB + sub) * IBT + j) * 4);
     const int64_t item = i_lo + t * IBT + j;
-    const int64_t lid = item - i_lo;                                      // id inside the split (bitmap index)
+    const int64_t lid = item - i_lo;
     uint64_t ck[4];
     bool cand[4];
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
       const int ur = 4 * kq + reg;
       const v4 us4 = *reinterpret_cast<const v4*>(usc + ur * 4);
-      const float s = (us4[0] + uNV[reg]) - (NUv[reg] + is4[0]);
-      const float aa = fmaf(-2.f, AUC0[reg], us4[1] + is4[1]);
-      const float an = (us4[2] + AUNV[reg]) - (NUC0[reg] + is4[2]);
-      const float nn = fmaf(2.f, NUNV[reg], us4[3] + is4[3]);
-      const float score = fmaf(s * s, nn, fmaf(-2.f * s, an, aa));
+      const float sv = (us4[0] + accS[reg]) - is4[0];
+      const float aa = (us4[1] + is4[1]) + accAA[reg];
+      const float an = (us4[2] + accAN[reg]) - is4[2];
+      const float nn = (us4[3] + is4[3]) + accNN[reg];
+      const float score = fmaf(sv * sv, nn, fmaf(-2.f * sv, an, aa));
       ck[reg] = pass_key(score, (uint32_t)item);
       bool c = item < i_hi && u0 + ur < a.nq && ck[reg] < thr[reg];
       if (c) c = ((bm[ur * a.bm_words + (lid >> 5)] >> (lid & 31)) & 1u) == 0u;
       cand[reg] = c;
     }
-    // ---- insertions: every 16-lane row serves its own users, one candidate per row and round, all four rows in parallel
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
       const unsigned long long any = __ballot(cand[reg]);
-      if (!any) continue;                                                                    // the common case after the first tiles
-      uint32_t rowmask = (uint32_t)((any >> rowbase) & 0xffffull);                           // this row's candidate lanes
-      while (__ballot(rowmask != 0u)) {                                                      // (wave-uniform trip count)
+      if (!any) continue;
+      uint32_t rowmask = (uint32_t)((any >> rowbase) & 0xffffull);
+      while (__ballot(rowmask != 0u)) {
         const bool act = rowmask != 0u;
         const int src = rowbase + (act ? __ffs((int)rowmask) - 1 : 0);
         rowmask &= rowmask - 1u;
         const uint64_t key = ((uint64_t)(uint32_t)__shfl((int)(ck[reg] >> 32), src, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)ck[reg], src, 64);
         const uint64_t mine = tkr[reg];
-        // sorted row: element j - 1 moves to j behind the insertion point (DPP row_shr:1; lane 0 of a row keeps its own value)
         const uint32_t llo = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)mine, (int)(uint32_t)mine, 0x111, 0xf, 0xf, false);
         const uint32_t lhi = (uint32_t)__builtin_amdgcn_update_dpp((int)(mine >> 32), (int)(mine >> 32), 0x111, 0xf, 0xf, false);
         const uint64_t left = ((uint64_t)lhi << 32) | llo;
         const int pos = __popc((uint32_t)((__ballot(j < topn && mine < key) >> rowbase) & 0xffffull));
-        if (act && pos < topn) tkr[reg] = j < pos ? mine : (j == pos ? key : left);           // pos == topn: an earlier insertion raised the bar
+        if (act && pos < topn) tkr[reg] = j < pos ? mine : (j == pos ? key : left);
       }
       thr[reg] = ((uint64_t)(uint32_t)__shfl((int)(tkr[reg] >> 32), rowbase + topn - 1, 64) << 32) |
                  (uint32_t)__shfl((int)(uint32_t)tkr[reg], rowbase + topn - 1, 64);
     }
-    // ---- next tile: registers -> the other buffer (its last readers passed the barrier of the previous iteration)
-    if (t + 1 < ntile) stash(buf ^ 1);
+  };
+  if (ntile > 0) {
+#pragma unroll
+    for (int sub = 0; sub < SUB; ++sub) {
+      fetch(sub);                                                          // (tiles past the split's end load zeros)
+      stash(0, sub);
+    }
     __syncthreads();
   }
-  // ---- this split's lists: lane (kq, j) holds element j of users 4 kq + reg
+  // SUB tiles per workgroup barrier; the next group's loads are in flight under each tile's MFMAs
+  for (int64_t t0 = 0; t0 < ntile; t0 += SUB) {
+    const int buf = (int)((t0 / SUB) & 1);
+    const bool more = t0 + SUB < ntile;
+#pragma unroll
+    for (int sub = 0; sub < SUB; ++sub) {
+      if (more) fetch(t0 + SUB + sub);
+      if (t0 + sub < ntile) compute(buf, sub, t0 + sub);
+      if (more) stash(buf ^ 1, sub);
+    }
+    __syncthreads();
+  }
   if (j < topn) {
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
@@ -276,105 +295,223 @@ __global__ __launch_bounds__(256) void eval_pass_kernel(PassArgs a) {
   }
 }
 
-// v.NV, |C0|^2, C0.NV, |NV|^2 per item with the arithmetic of pairs_l2_mc_kernel (8 lanes per row, chunks l, l + 8, ..., then
-// xor-shuffles), once per pass
-template <int NCH>
-__global__ __launch_bounds__(256) void item_scalars_kernel(const float* __restrict__ C0, const float* __restrict__ C1,
-                                                           const float* __restrict__ C2, int64_t n_items, float* __restrict__ ISC) {
-  constexpr int D = 4 * NCH;
-  const int64_t row = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3);
-  const bool ok = row < n_items;
-  const v4* r0 = reinterpret_cast<const v4*>(C0 + (ok ? row : 0) * D);
-  const v4* r1 = reinterpret_cast<const v4*>(C1 + (ok ? row : 0) * D);
-  const v4* r2 = reinterpret_cast<const v4*>(C2 + (ok ? row : 0) * D);
-  v4 s0 = (v4){0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
-  for (int c = threadIdx.x & 7; c < NCH; c += 8) {
-    const v4 x0 = r0[c], x1 = r1[c], x2 = r2[c];
-    s0 += x1 * x2; s1 += x0 * x0; s2 += x0 * x2; s3 += x2 * x2;
+// G_RR | G_RN | G_NN, each [P4][P4] (zero padded), from the prepared tables (row pitch dp): one wave per entry
+__global__ __launch_bounds__(256) void pspace_gram_kernel(const float* __restrict__ Ar, const float* __restrict__ Cn, int dp, int d, int P, int P4,
+                                                          float* __restrict__ grams) {
+  const int lane = threadIdx.x & 63;
+  for (int idx = blockIdx.x * 4 + (threadIdx.x >> 6); idx < 3 * P4 * P4; idx += gridDim.x * 4) {
+    const int t = idx / (P4 * P4), rem = idx - t * P4 * P4, p = rem / P4, q = rem - p * P4;
+    float acc = 0.f;
+    if (p < P && q < P) {
+      const float* x = (t == 2 ? Cn : Ar) + (size_t)p * dp;
+      const float* y = (t == 0 ? Ar : Cn) + (size_t)q * dp;
+      for (int k = lane; k < d; k += 64) acc = fmaf(x[k], y[k], acc);
+    }
+    acc = group_sum<64>(acc);
+    if (lane == 0) grams[idx] = acc;
   }
-  float f0 = (s0[0] + s0[1]) + (s0[2] + s0[3]), f1 = (s1[0] + s1[1]) + (s1[2] + s1[3]);
-  float f2 = (s2[0] + s2[1]) + (s2[2] + s2[3]), f3 = (s3[0] + s3[1]) + (s3[2] + s3[3]);
-#pragma unroll
-  for (int m = 1; m < 8; m <<= 1) {
-    f0 += __shfl_xor(f0, m, 64); f1 += __shfl_xor(f1, m, 64); f2 += __shfl_xor(f2, m, 64); f3 += __shfl_xor(f3, m, 64);
-  }
-  if (ok && (threadIdx.x & 7) == 0) *reinterpret_cast<v4*>(ISC + row * 4) = (v4){f0, f1, f2, f3};
 }
 
-// partial lists of the splits -> the topn smallest keys per user; one thread per user (nsplit * topn <= a few hundred keys)
-__global__ __launch_bounds__(256) void topk_merge_kernel(const uint64_t* __restrict__ part, int64_t nq, int nsplit, int topn,
-                                                         const float* __restrict__ unused, int32_t* __restrict__ top_ids,
-                                                         float* __restrict__ top_scores) {
-  (void)unused;
-  const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (b >= nq) return;
-  const uint64_t* p = part + b * nsplit * topn;
-  int head[8];                                                            // every split's list is sorted: a k-way merge
-  for (int s = 0; s < nsplit; ++s) head[s] = 0;
-  for (int r = 0; r < topn; ++r) {
-    uint64_t best = PKEY_MAX;
-    int bs = -1;
-    for (int s = 0; s < nsplit; ++s) {
-      if (head[s] < topn) {
-        const uint64_t k = p[s * topn + head[s]];
-        if (k < best) { best = k; bs = s; }
+// One wave per row x (user: U[ids[row]]; item: X[row]): L = Alog x, Rx = Ar x, Nx = Cn x (lane = one of the 3 P4 table rows, the
+// tables staged transposed in LDS), then the operand row and the four scalars of the formulation above.
+struct RowsSide { const float* X; int64_t ldx; const int64_t* ids; int64_t nrows; float* out; int orow; float* scal; int blocks; };
+
+template <bool IS_USER, int NCH, int NP>
+KTUP_DEV void pspace_rows(const RowsSide& sd, int block, int P, const float* __restrict__ Alog, const float* __restrict__ Ar,
+                          const float* __restrict__ Cn, int dp, const float* __restrict__ grams, int ka16, int ks16) {
+  const float* __restrict__ X = sd.X;
+  const int64_t ldx = sd.ldx, nrows = sd.nrows;
+  const int64_t* __restrict__ ids = sd.ids;
+  float* __restrict__ out = sd.out;
+  float* __restrict__ scal = sd.scal;
+  const int orow = sd.orow;
+  constexpr int d = 4 * NCH, P4 = 4 * NP;                        // compile-time: the k loops unroll and their LDS reads batch
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  // the tables (3 P x d floats = 24 KB at P = 20, d = 100) and the Gram matrices are read straight from global memory: they stay in
+  // the CU's vector L1, and staging them in LDS per workgroup cost more than the rows' own work
+  float* wv = lds;                                               // per wave: x [d] | res [3 P4] | fold [4 P4]
+  constexpr int wstride = d + 7 * P4;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const float* G = grams;
+  float* xs = wv + w * wstride;
+  float* res = xs + d;
+  float* fold = res + 3 * P4;
+  for (int64_t row = (int64_t)block * 4 + w; row < nrows; row += (int64_t)sd.blocks * 4) {
+    const float* x = X + (ids ? ids[row] : row) * ldx;
+    float sq = 0.f;
+    for (int k = lane; k < d; k += 64) { const float v = x[k]; xs[k] = v; sq = fmaf(v, v, sq); }
+    sq = group_sum<64>(sq);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int col = lane; col < 3 * P4; col += 64) {
+      const int t = col / P4, p = col - t * P4;
+      float4 acc = f4zero();
+      if (p < P) {
+        const float4* tr = reinterpret_cast<const float4*>((t == 0 ? Alog : t == 1 ? Ar : Cn) + (size_t)p * dp);
+        const float4* xr = reinterpret_cast<const float4*>(xs);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) acc = acc + xr[c] * tr[c];
       }
+      res[col] = (acc.x + acc.y) + (acc.z + acc.w);
     }
-    if (bs >= 0) head[bs] += 1;
-    const bool ok = best != PKEY_MAX;
-    top_ids[b * topn + r] = ok ? (int32_t)(uint32_t)best : -1;
-    if (top_scores) {
-      uint32_t u = (uint32_t)(best >> 32);
-      u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;                     // inverse of the order-preserving image
-      top_scores[b * topn + r] = ok ? __uint_as_float(u) : 0.f;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const float* L = res;
+    const float* Rx = res + P4;
+    const float* Nx = res + 2 * P4;
+    // Gram products of L: fold[0] = G_RR L, [1] = G_RN L, [2] = G_RN^T L, [3] = G_NN L; quadratic forms by wave sums
+    float q_rr = 0.f, q_rn = 0.f, q_nn = 0.f, d_nl = 0.f, d_rl = 0.f;
+    if (lane < P4) {
+      float g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f;
+#pragma unroll
+      for (int q = 0; q < P4; ++q) {
+        const float lq = L[q];
+        g0 = fmaf(G[lane * P4 + q], lq, g0);
+        g1 = fmaf(G[P4 * P4 + lane * P4 + q], lq, g1);
+        g2 = fmaf(G[P4 * P4 + q * P4 + lane], lq, g2);
+        g3 = fmaf(G[2 * P4 * P4 + lane * P4 + q], lq, g3);
+      }
+      fold[lane] = g0; fold[P4 + lane] = g1; fold[2 * P4 + lane] = g2; fold[3 * P4 + lane] = g3;
+      const float l = L[lane];
+      q_rr = l * g0; q_rn = l * g1; q_nn = l * g3; d_nl = Nx[lane] * l; d_rl = Rx[lane] * l;
     }
+    q_rr = group_sum<64>(q_rr); q_rn = group_sum<64>(q_rn); q_nn = group_sum<64>(q_nn);
+    d_nl = group_sum<64>(d_nl); d_rl = group_sum<64>(d_rl);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    float* o = out + row * (int64_t)orow;
+    if (IS_USER) {
+      // [AA: -2u ; -2L ; 2 (Ru + G_RR L) ; 0] [S: Nu ; -L ; 0] [AN: Nu + G_RN^T L + G_RN L ; -L ; 0] [NN: 2 G_NN L ; 0]
+      const int oS = 16 * ka16, oAN = oS + 16 * ks16, oNN = oAN + 16 * ks16;
+      for (int k = lane; k < orow; k += 64) {
+        float v = 0.f;
+        if (k < oS) {
+          if (k < d) v = -2.f * xs[k];
+          else if (k < d + P4) v = -2.f * L[k - d];
+          else if (k < d + 2 * P4) v = 2.f * (Rx[k - d - P4] + fold[k - d - P4]);
+        } else if (k < oAN) {
+          const int e = k - oS;
+          if (e < P4) v = Nx[e]; else if (e < 2 * P4) v = -L[e - P4];
+        } else if (k < oNN) {
+          const int e = k - oAN;
+          if (e < P4) v = Nx[e] + fold[2 * P4 + e] + fold[P4 + e]; else if (e < 2 * P4) v = -L[e - P4];
+        } else {
+          const int e = k - oNN;
+          if (e < P4) v = 2.f * fold[3 * P4 + e];
+        }
+        o[k] = v;
+      }
+      // u.NU, |AU|^2, AU.NU, |NU|^2
+      if (lane == 0) *reinterpret_cast<float4*>(scal + row * 4) = make_float4(d_nl, sq + 2.f * d_rl + q_rr, d_nl + q_rn, q_nn);
+    } else {
+      // [x ; Rx ; L ; Nx]
+      for (int k = lane; k < orow; k += 64) o[k] = k < d ? xs[k] : k < d + P4 ? Rx[k - d] : k < d + 2 * P4 ? L[k - d - P4] : Nx[k - d - 2 * P4];
+      // v.NV, |C0|^2, C0.NV, |NV|^2
+      if (lane == 0) *reinterpret_cast<float4*>(scal + row * 4) = make_float4(d_nl, sq - 2.f * d_rl + q_rr, d_nl - q_rn, q_nn);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
   }
+}
+
+// users and items in ONE launch: the first `users.blocks` workgroups take the user rows, the rest the item rows
+template <int NCH, int NP>
+__global__ __launch_bounds__(256) void pspace_rows_kernel(RowsSide users, RowsSide items, int P, const float* __restrict__ Alog,
+                                                          const float* __restrict__ Ar, const float* __restrict__ Cn, int dp,
+                                                          const float* __restrict__ grams, int ka16, int ks16) {
+  if ((int)blockIdx.x < users.blocks) pspace_rows<true, NCH, NP>(users, blockIdx.x, P, Alog, Ar, Cn, dp, grams, ka16, ks16);
+  else pspace_rows<false, NCH, NP>(items, blockIdx.x - users.blocks, P, Alog, Ar, Cn, dp, grams, ka16, ks16);
+}
+
+struct QScratch { float *grams, *A, *SCU, *B, *ISC; uint64_t* part; };
+
+template <typename G>
+QScratch q_carve(void* scratch, int64_t nq, int64_t n_items) {
+  QScratch s;
+  float* p = reinterpret_cast<float*>(scratch);
+  s.grams = p; p += 3 * 32 * 32;
+  s.A = p; p += (size_t)nq * G::AROW;
+  s.SCU = p; p += (size_t)nq * 4;
+  s.B = p; p += (size_t)n_items * G::ROWB + 64;                  // + slack: the last tile fetch never reads past it, the pad keeps 16-B alignment
+  s.ISC = p; p += (size_t)n_items * 4;
+  s.part = reinterpret_cast<uint64_t*>(p);
+  return s;
 }
 
 template <typename G>
-int launch_pass(PassArgs a, int32_t* top_ids, float* top_scores, hipStream_t st, const char* name) {
-  const int64_t ublocks = (a.nq + 63) / 64;
-  int nsplit = (int)(512 / ublocks);                                      // 2 workgroups per CU are resident: ONE round of <= 512
+int launch_q(const float* U, int64_t ldu, const int64_t* u_ids, int64_t nq, const float* item_x, int64_t n_items, const float* pref_ws,
+             int ppad, int dp, int n_pref, const int64_t* filt_off, const int32_t* filt_ids, int topn, void* scratch, int32_t* top_ids,
+             float* top_scores, hipStream_t st, const char* name) {
+  const QScratch q = q_carve<G>(scratch, nq, n_items);
+  const float* Alog = pref_ws;
+  const float* Ar = pref_ws + (size_t)ppad * dp;
+  const float* Cn = pref_ws + (size_t)(ppad + n_pref) * dp;
+  hipLaunchKernelGGL(pspace_gram_kernel, dim3((3 * G::P4 * G::P4 + 3) / 4), dim3(256), 0, st, Ar, Cn, dp, G::D, n_pref, G::P4, q.grams);
+  const size_t lds_rows = (size_t)4 * (G::D + 7 * G::P4) * sizeof(float);
+  // many small workgroups: a row is a chain of dependent round trips (id -> row -> products -> store), hidden only by occupancy
+  RowsSide us{U, ldu, u_ids, nq, q.A, G::AROW, q.SCU, grid_for((nq + 3) / 4, 2048)};
+  RowsSide is{item_x, (int64_t)G::D, nullptr, n_items, q.B, G::ROWB, q.ISC, grid_for((n_items + 3) / 4, 2048)};
+  hipLaunchKernelGGL((pspace_rows_kernel<G::NCH, G::NP>), dim3(us.blocks + is.blocks), dim3(256), lds_rows, st, us, is, n_pref, Alog, Ar, Cn, dp,
+                     q.grams, G::KA, G::KS);
+  if (int e = check_launch(name)) return e;
+  QArgs a{};
+  a.A = q.A; a.SCU = q.SCU; a.B = q.B; a.ISC = q.ISC; a.nq = nq; a.n_items = n_items;
+  a.filt_off = filt_off; a.filt_ids = filt_ids; a.topn = topn; a.part = q.part;
+  const int64_t ublocks = (nq + 63) / 64;
+  int nsplit = (int)(256 * G::MINW / ublocks);                            // MINW workgroups per CU are resident: ONE round
   if (nsplit > 8) nsplit = 8;
-  const int64_t tiles = (a.n_items + IBT - 1) / IBT;
+  const int64_t tiles = (n_items + IBT - 1) / IBT;
   if (nsplit > tiles) nsplit = (int)tiles;
   if (nsplit < 1) nsplit = 1;
   a.split_items = ((tiles + nsplit - 1) / nsplit) * IBT;
-  nsplit = (int)((a.n_items + a.split_items - 1) / a.split_items);
+  nsplit = (int)((n_items + a.split_items - 1) / a.split_items);
   a.nsplit = nsplit;
   a.bm_words = (int)((a.split_items + 31) / 32);
   const size_t wave_bytes = (size_t)16 * 4 * 4 + (size_t)16 * a.bm_words * 4;
-  const size_t lds = (size_t)2 * G::TILE_F4 * 16 + (size_t)2 * IBT * 4 * 4 + 4 * wave_bytes;
+  const size_t lds = (size_t)2 * G::TILE_F4 * 16 + (size_t)2 * G::SUB * IBT * 4 * 4 + 4 * wave_bytes;
   if (lds > 160 * 1024) return 1;
-  hipLaunchKernelGGL((item_scalars_kernel<G::NCH>), dim3((unsigned)((a.n_items + 31) / 32)), dim3(256), 0, st, a.C0, a.C1, a.C2, a.n_items,
-                     const_cast<float*>(a.ISC));
-  (void)hipFuncSetAttribute((const void*)eval_pass_kernel<G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((eval_pass_kernel<G>), dim3((unsigned)ublocks, (unsigned)nsplit), dim3(256), lds, st, a);
+  (void)hipFuncSetAttribute((const void*)eval_pass_q_kernel<G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((eval_pass_q_kernel<G>), dim3((unsigned)ublocks, (unsigned)nsplit), dim3(256), lds, st, a);
   if (int e = check_launch(name)) return e;
-  hipLaunchKernelGGL(topk_merge_kernel, dim3((unsigned)((a.nq + 255) / 256)), dim3(256), 0, st, a.part, a.nq, nsplit, a.topn,
-                     (const float*)nullptr, top_ids, top_scores);
+  hipLaunchKernelGGL(topk_merge_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(MERGE_T), 0, st, q.part, nq, nsplit, topn, (const float*)nullptr, top_ids,
+                     top_scores);
   return check_launch(name);
+}
+
+template <int NCH>
+int launch_q_p(int n_pref, const float* U, int64_t ldu, const int64_t* u_ids, int64_t nq, const float* item_x, int64_t n_items,
+               const float* pref_ws, int ppad, int dp, const int64_t* filt_off, const int32_t* filt_ids, int topn, void* scratch,
+               int32_t* top_ids, float* top_scores, hipStream_t st, const char* name) {
+  if (n_pref <= 4)
+    return launch_q<QGeom<NCH, 1>>(U, ldu, u_ids, nq, item_x, n_items, pref_ws, ppad, dp, n_pref, filt_off, filt_ids, topn, scratch, top_ids, top_scores, st, name);
+  if (n_pref <= 20)
+    return launch_q<QGeom<NCH, 5>>(U, ldu, u_ids, nq, item_x, n_items, pref_ws, ppad, dp, n_pref, filt_off, filt_ids, topn, scratch, top_ids, top_scores, st, name);
+  return launch_q<QGeom<NCH, 8>>(U, ldu, u_ids, nq, item_x, n_items, pref_ws, ppad, dp, n_pref, filt_off, filt_ids, topn, scratch, top_ids, top_scores, st, name);
 }
 
 }  // namespace
 
-// scratch behind `part`: the splits' partial lists, then the per-item scalars
-size_t eval_pass_part_bytes(int64_t nq, int topn, int64_t n_items) {
-  return (size_t)nq * 8 * topn * sizeof(uint64_t) + (size_t)n_items * 4 * sizeof(float);
+}  // namespace ktup
+
+namespace ktup {
+
+// The preference-space pass (see QGeom): scratch for the Gram matrices, both operand tables, the scalars and the partial lists.
+size_t eval_pass_pspace_bytes(int d, int n_pref, int64_t nq, int64_t n_items, int topn) {
+  const size_t p4 = n_pref <= 4 ? 4 : n_pref <= 20 ? 20 : 32;
+  const size_t ka = (d + 2 * p4 + 15) / 16, ks = (2 * p4 + 15) / 16, kn = (p4 + 15) / 16;
+  const size_t arow = 16 * (ka + 2 * ks + kn), rowb = d + 3 * p4;
+  return (3 * 32 * 32 + (size_t)nq * (arow + 4) + (size_t)n_items * (rowb + 4) + 64) * sizeof(float) + (size_t)nq * 8 * topn * sizeof(uint64_t);
 }
 
-// Returns KTUP_OK / an error, or 1 for shapes the fused pass does not cover (d, topn): the caller keeps the per-batch route.
-int eval_pass_l2_mc(const float* QW, const float* C0, const float* C1, const float* C2, int d, int64_t nq, int64_t n_items,
-                    const int64_t* filt_off, const int32_t* filt_ids, int topn, uint64_t* part, int32_t* top_ids, float* top_scores,
-                    hipStream_t st, const char* name) {
-  if ((d != 64 && d != 100 && d != 128) || topn < 1 || topn > TOPN_MAX || n_items >= (1ll << 31)) return 1;
-  PassArgs a{};
-  a.QW = QW; a.C0 = C0; a.C1 = C1; a.C2 = C2; a.nq = nq; a.n_items = n_items;
-  a.filt_off = filt_off; a.filt_ids = filt_ids; a.topn = topn; a.part = part;
-  a.ISC = reinterpret_cast<const float*>(part + (size_t)nq * 8 * topn);
-  if (d == 64) return launch_pass<PGeom<16>>(a, top_ids, top_scores, st, name);
-  if (d == 100) return launch_pass<PGeom<25>>(a, top_ids, top_scores, st, name);
-  return launch_pass<PGeom<32>>(a, top_ids, top_scores, st, name);
+// item_x: the items' vectors (pitch d; i + e for KTUP); pref_ws: the prepared tables (ktup_pref_prepare; ppad / dp its geometry).
+// Returns KTUP_OK / an error, or 1 for shapes the pass does not cover.
+int eval_pass_pspace(const float* U, int64_t ldu, const int64_t* u_ids, int64_t nq, const float* item_x, int64_t n_items, const float* pref_ws,
+                     int ppad, int dp, int n_pref, int d, const int64_t* filt_off, const int32_t* filt_ids, int topn, void* scratch,
+                     int32_t* top_ids, float* top_scores, hipStream_t st, const char* name) {
+  if ((d != 64 && d != 100 && d != 128) || n_pref < 1 || n_pref > 32 || topn < 1 || topn > TOPN_MAX || n_items >= (1ll << 31)) return 1;
+  if (d == 64) return launch_q_p<16>(n_pref, U, ldu, u_ids, nq, item_x, n_items, pref_ws, ppad, dp, filt_off, filt_ids, topn, scratch, top_ids, top_scores, st, name);
+  if (d == 100) return launch_q_p<25>(n_pref, U, ldu, u_ids, nq, item_x, n_items, pref_ws, ppad, dp, filt_off, filt_ids, topn, scratch, top_ids, top_scores, st, name);
+  return launch_q_p<32>(n_pref, U, ldu, u_ids, nq, item_x, n_items, pref_ws, ppad, dp, filt_off, filt_ids, topn, scratch, top_ids, top_scores, st, name);
 }
 
 }  // namespace ktup

@@ -397,8 +397,30 @@ def test_prepared_item_side_gives_the_same_scores(l1, gum):
                                              (100, 500, 1000, 129, 1)])
 def test_fused_pass_topk_equals_matrix_route(d, nu, ni, nq, topn):
     """ktup_eval_pref_topk_prepared (scores + filtered top-n of a whole pass in one sweep, no score matrix) against the matrix
-    route (ktup_eval_pref_scores_prepared + ktup_eval_topk_filtered): the ranked ids are integer results and must be identical,
-    and so must the scores (same MFMA k order and epilogue).  KTUP and TUP; per-user filters incl. empty and everything."""
+    route (ktup_eval_pref_scores_prepared + ktup_eval_topk_filtered).  The sweep contracts every cross term but u.v in preference
+    space -- the same sums in another association -- so scores agree to fp32 rounding and the lists are the matrix route's up to
+    swaps between items whose scores differ by less than that.  KTUP and TUP; per-user filters incl. empty and everything."""
+    _fused_pass_case(d, nu, ni, nq, topn, True)
+
+
+def _same_lists_up_to_rounding(ids, sc, want_ids, want_sc, filt, ni, rtol=2e-5, atol=2e-5):
+    """Ranked lists of two routes whose scores differ by fp32 rounding: same length, valid unfiltered distinct ids, position-wise
+    scores equal within the tolerance (so the lists can only differ by swaps / substitutions among near-ties)."""
+    ids, sc, want_ids, want_sc = ids.cpu().numpy(), sc.cpu().numpy(), want_ids.cpu().numpy(), want_sc.cpu().numpy()
+    assert ids.shape == want_ids.shape
+    assert ((ids >= 0) == (want_ids >= 0)).all()
+    live = want_ids >= 0
+    np.testing.assert_allclose(sc[live], want_sc[live], rtol=rtol, atol=atol)
+    assert (ids[live] < ni).all()
+    for b in range(ids.shape[0]):
+        row = ids[b][ids[b] >= 0]
+        assert len(set(row.tolist())) == len(row)
+        if filt is not None:
+            assert not set(row.tolist()) & set(filt[b].tolist())
+    assert float((ids == want_ids).mean()) > 0.98                          # and almost always they are simply identical
+
+
+def _fused_pass_case(d, nu, ni, nq, topn, pspace):
     gen = torch.Generator().manual_seed(d + ni)
     P, ne = 20, 200
     mk = lambda r: O.make_table(r, d, gen).to(DEV)
@@ -428,11 +450,19 @@ def test_fused_pass_topk_equals_matrix_route(d, nu, ni, nq, topn):
             a, b = ops().topk_filtered(mat, False, topn, fo, f_ids[lo:], with_scores=True)
             want_ids.append(a); want_sc.append(b)
         want_ids, want_sc = torch.cat(want_ids), torch.cat(want_sc)
-        assert torch.equal(got[0], want_ids)
-        assert torch.equal(got[1], want_sc)
+        if not pspace:
+            assert torch.equal(got[0], want_ids)
+            assert torch.equal(got[1], want_sc)
+        else:
+            _same_lists_up_to_rounding(got[0], got[1], want_ids, want_sc, filt, ni)
         if len(filt) > 2:
             assert got[0][1].tolist() == [-1] * topn
         nf = ops().eval_pref_topk(U, u, items, False, topn)                   # no filter at all
         mat = ops().eval_ktup(U, I, E, Pm, Pn, R, Rn, i2e, u[:64], False, items=items) if ktup else ops().eval_tup(U, I, Pm, Pn, u[:64], False, items=items)
-        assert torch.equal(nf[:64], ops().topk_filtered(mat, False, topn))
+        if not pspace:
+            assert torch.equal(nf[:64], ops().topk_filtered(mat, False, topn))
+        else:
+            a, b = ops().topk_filtered(mat, False, topn, with_scores=True)
+            sc = torch.gather(mat, 1, nf[:64].clamp(min=0).long())
+            _same_lists_up_to_rounding(nf[:64], sc, a, b, None, ni)
     assert ops().eval_pref_topk(U, u, items, True, topn) is None              # L1 does not decompose: the caller keeps the matrix route

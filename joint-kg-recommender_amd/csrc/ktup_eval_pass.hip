@@ -44,6 +44,47 @@ KTUP_DEV uint64_t pass_key(float s, uint32_t id) {   // ktup_rank.hip make_key, 
   return ((uint64_t)u << 32) | id;
 }
 
+// ---- 16-lane row networks on 64-bit keys (lane j of a row = element j).  Partner j ^ K through DPP: quad_perm for 1 and 2,
+// row_half_mirror . quad_perm[3,2,1,0] for 4 (7 - i then i ^ 3), row_mirror . row_half_mirror for 8.
+template <int K>
+KTUP_DEV uint32_t row_xor32(uint32_t v) {
+  const int x = (int)v;
+  if constexpr (K == 1) return (uint32_t)__builtin_amdgcn_update_dpp(x, x, 0xB1, 0xf, 0xf, false);
+  else if constexpr (K == 2) return (uint32_t)__builtin_amdgcn_update_dpp(x, x, 0x4E, 0xf, 0xf, false);
+  else if constexpr (K == 4) {
+    const int h = __builtin_amdgcn_update_dpp(x, x, 0x141, 0xf, 0xf, false);
+    return (uint32_t)__builtin_amdgcn_update_dpp(h, h, 0x1B, 0xf, 0xf, false);
+  } else {
+    const int m = __builtin_amdgcn_update_dpp(x, x, 0x140, 0xf, 0xf, false);
+    return (uint32_t)__builtin_amdgcn_update_dpp(m, m, 0x141, 0xf, 0xf, false);
+  }
+}
+// compare-exchange with lane j ^ K: keep the smaller key if keep_min, else the larger
+template <int K>
+KTUP_DEV void row_cmpx(uint64_t& v, bool keep_min) {
+  const uint64_t o = ((uint64_t)row_xor32<K>((uint32_t)(v >> 32)) << 32) | row_xor32<K>((uint32_t)v);
+  if ((o < v) == keep_min) v = o;
+}
+KTUP_DEV uint64_t row_mirror64(uint64_t v) {
+  const int lo = (int)(uint32_t)v, hi = (int)(uint32_t)(v >> 32);
+  return ((uint64_t)(uint32_t)__builtin_amdgcn_update_dpp(hi, hi, 0x140, 0xf, 0xf, false) << 32) |
+         (uint32_t)__builtin_amdgcn_update_dpp(lo, lo, 0x140, 0xf, 0xf, false);
+}
+// list: a row's ascending 16 keys; cand: up to 16 more in any order (PKEY_MAX = none).  Returns the 16 smallest of the 32, ascending:
+// bitonic sort of the candidates (10 exchanges), elementwise min against their mirror (a bitonic row holding the 16 smallest),
+// bitonic merge (4 exchanges) -- a fixed 14 exchanges instead of one dependent ballot / bpermute round per candidate.
+KTUP_DEV uint64_t row_merge16(uint64_t list, uint64_t cand, int j) {
+  const bool b1 = (j & 1) == 0, b2 = (j & 2) == 0, b4 = (j & 4) == 0, b8 = (j & 8) == 0;
+  row_cmpx<1>(cand, b1 == b2);
+  row_cmpx<2>(cand, b2 == b4); row_cmpx<1>(cand, b1 == b4);
+  row_cmpx<4>(cand, b4 == b8); row_cmpx<2>(cand, b2 == b8); row_cmpx<1>(cand, b1 == b8);
+  row_cmpx<8>(cand, b8); row_cmpx<4>(cand, b4); row_cmpx<2>(cand, b2); row_cmpx<1>(cand, b1);
+  const uint64_t r = row_mirror64(cand);
+  uint64_t m = r < list ? r : list;
+  row_cmpx<8>(m, b8); row_cmpx<4>(m, b4); row_cmpx<2>(m, b2); row_cmpx<1>(m, b1);
+  return m;
+}
+
 // partial lists of the splits -> the topn smallest keys per user.  One WAVE per user: the <= 128 keys sit two per lane, every lane
 // ranks its keys against all of them (keys are distinct: the item id is their low half) and the lanes whose rank is below topn
 // write their key's slot -- no serial k-way merge, no dependent memory round trips (that version: 22 us for 6040 users).
@@ -203,10 +244,9 @@ __global__ __launch_bounds__(256, G::MINW) void eval_pass_q_kernel(QArgs a) {
   };
   const int rowbase = 16 * kq;
   uint64_t thr[4] = {PKEY_MAX, PKEY_MAX, PKEY_MAX, PKEY_MAX};
-  // (A split restarts its lists from nothing, so its first tiles insert nearly every item: measured, the insertion rounds are a
-  // third of this kernel's time, more than half of them in a split's first two tiles.  Sharing each user's n-th key between the
-  // concurrent splits -- atomicMin / periodic loads of a global bound -- cut the rounds by 37 % and the time by nothing; a
-  // sorting network for the dense first tiles is the next step.)
+  // (A split restarts its lists from nothing, so its first tiles insert nearly every item.  One ballot / bpermute round per
+  // candidate was a third of this kernel's time, more than half of it in a split's first two tiles; sharing each user's n-th key
+  // between the concurrent splits cut the rounds by 37 % and the time by nothing.  Now a fixed merge network per row.)
   auto compute = [&](int buf, int sub, int64_t t) {                       // 16 users x the 16 items of tile t
     const v4* ib = Xb + buf * G::TILE_F4 + (sub * IBT + j) * ROW4 + kq;   // lane (kq, item j): k-quad kq of every 16-block
     v4 accAA = (v4){0.f, 0.f, 0.f, 0.f}, accS = accAA, accAN = accAA, accNN = accAA;
@@ -249,19 +289,8 @@ __global__ __launch_bounds__(256, G::MINW) void eval_pass_q_kernel(QArgs a) {
     for (int reg = 0; reg < 4; ++reg) {
       const unsigned long long any = __ballot(cand[reg]);
       if (!any) continue;
-      uint32_t rowmask = (uint32_t)((any >> rowbase) & 0xffffull);
-      while (__ballot(rowmask != 0u)) {
-        const bool act = rowmask != 0u;
-        const int src = rowbase + (act ? __ffs((int)rowmask) - 1 : 0);
-        rowmask &= rowmask - 1u;
-        const uint64_t key = ((uint64_t)(uint32_t)__shfl((int)(ck[reg] >> 32), src, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)ck[reg], src, 64);
-        const uint64_t mine = tkr[reg];
-        const uint32_t llo = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)mine, (int)(uint32_t)mine, 0x111, 0xf, 0xf, false);
-        const uint32_t lhi = (uint32_t)__builtin_amdgcn_update_dpp((int)(mine >> 32), (int)(mine >> 32), 0x111, 0xf, 0xf, false);
-        const uint64_t left = ((uint64_t)lhi << 32) | llo;
-        const int pos = __popc((uint32_t)((__ballot(j < topn && mine < key) >> rowbase) & 0xffffull));
-        if (act && pos < topn) tkr[reg] = j < pos ? mine : (j == pos ? key : left);
-      }
+      const uint64_t merged = row_merge16(tkr[reg], cand[reg] ? ck[reg] : PKEY_MAX, j);     // all four rows at once
+      tkr[reg] = j < topn ? merged : PKEY_MAX;
       thr[reg] = ((uint64_t)(uint32_t)__shfl((int)(tkr[reg] >> 32), rowbase + topn - 1, 64) << 32) |
                  (uint32_t)__shfl((int)(uint32_t)tkr[reg], rowbase + topn - 1, 64);
     }

@@ -294,7 +294,8 @@ def eval_bench(device, batch=512, seed=11, keep=None):
     def fused_pass():
         items = m.prepare_items()
         top = m.evaluate_topk(all_u, items, 10, index.f_off, index.f_ids)
-        return RK.ops.rec_metrics(top, index.g_off, index.g_ids).cpu().numpy()
+        return _driver._to_host(RK.ops.rec_metrics(top, index.g_off, index.g_ids))      # as models/_driver.py _rec_eval_fused does
+    from jTransUP.models import _driver
     fused = None
     if m.evaluate_topk(all_u[:64], m.prepare_items(), 10) is not None:
         rows_f = fused_pass()
@@ -327,7 +328,7 @@ def eval_bench(device, batch=512, seed=11, keep=None):
             'batched_route': {'device_ms_full_pass': dev_ms, 'device_ms_per_batch': dev_ms / len(batches), 'full_pass_ms_incl_metrics': full_ms},
             'filter_index_build_ms': 1e3 * t_index, 'hit_at_10_random_init': hit,
             'note': 'fused_pass: item side (1 launch), users projections + scores + filtered top-10 in one sweep without the score '
-                    'matrix (ktup_eval_pref_topk_prepared), per-user f1/p/r/hit/ndcg on the device (K18b), one (users x 5) float64 copy '
+                    'matrix (ktup_eval_pref_topk), per-user f1/p/r/hit/ndcg on the device (K18b), one (users x 5) float64 copy '
                     'back; batched_route: round 1 shape -- 12 batches of 512 users x (K16 matrix + K17 + K18b). The filter index is built once per run'}
 
 

@@ -262,15 +262,18 @@ int ktup_eval_pref_scores_prepared(const float* U, int64_t ldu, const float* pre
                                    uint64_t offset, float* out, int64_t ldo, const float* items_ws, float* ws, void* stream);
 
 /* K16 + K17 of a whole evaluation PASS fused (new): every user of `u_ids` against all items, filtered top-n, in one sweep that
- * never materialises the (users x items) matrix -- what jTransUP.py:163-191 + utils/misc.py:186-248 compute batch by batch.
- * Same scores (bit for bit) and the same (score, id) order as ktup_eval_pref_scores_prepared + ktup_eval_topk_filtered.
- * Soft gate, squared L2 (l1 == 0), d in {64, 100, 128}, topn <= 16; otherwise KTUP_ERR_UNSUPPORTED and the caller keeps the
- * per-batch pair of calls.  filt_off / filt_ids: CSR filter sets per user of u_ids (NULL = none); top_scores may be NULL.
- * `ws`: ktup_eval_pref_topk_workspace_bytes bytes, 16-byte aligned; `items_ws` from ktup_eval_pref_items_prepare.          */
+ * never materialises the (users x items) matrix -- what jTransUP.py:163-191 / transUP.py:84-102 + utils/misc.py:186-248 compute
+ * batch by batch.  Straight from the tables: items are I[row] (+ E[item2ent[row]] for KTUP; E == item2ent == NULL for TUP),
+ * pref_ws the prepared preference tables (ktup_pref_prepare).  Every user x item cross term except u.v is contracted in
+ * preference space (csrc/ktup_eval_pass.hip): scores agree with ktup_eval_pref_scores to fp32 rounding, the order is the
+ * (score, id) order of ktup_eval_topk_filtered.  Soft gate, squared L2 (l1 == 0), d in {64, 100, 128}, n_pref <= 32,
+ * topn <= 16; otherwise KTUP_ERR_UNSUPPORTED and the caller keeps the per-batch pair of calls.  filt_off / filt_ids: CSR filter
+ * sets per user of u_ids (NULL = none); top_scores may be NULL.  `ws`: ktup_eval_pref_topk_workspace_bytes bytes, 16-byte aligned. */
 size_t ktup_eval_pref_topk_workspace_bytes(int d, int n_pref, int64_t nq, int64_t n_items, int topn);
-int ktup_eval_pref_topk_prepared(const float* U, int64_t ldu, const float* pref_ws, int n_pref, int d, const int64_t* u_ids,
-                                 int64_t nq, int64_t n_items, int l1, const float* items_ws, const int64_t* filt_off,
-                                 const int32_t* filt_ids, int topn, int32_t* top_ids, float* top_scores, float* ws, void* stream);
+int ktup_eval_pref_topk(const float* U, int64_t ldu, const float* I, int64_t ldi, const float* E, int64_t lde,
+                        const int32_t* item2ent, const float* pref_ws, int n_pref, int d, const int64_t* u_ids, int64_t nq,
+                        int64_t n_items, int l1, const int64_t* filt_off, const int32_t* filt_ids, int topn, int32_t* top_ids,
+                        float* top_scores, float* ws, void* stream);
 
 /* ------------------------------------------- K17/K18  ranking walk  utils/misc.py:125-146,213-248
  * Order: ascending score (descending != 0 negates first, misc.py:93,180), ties -> lower id (declared rule).

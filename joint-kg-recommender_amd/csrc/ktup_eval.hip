@@ -743,22 +743,20 @@ extern "C" size_t ktup_eval_pref_topk_workspace_bytes(int d, int n_pref, int64_t
   return ktup::eval_pass_pspace_bytes(d, n_pref, nq, n_items, topn);
 }
 
-extern "C" int ktup_eval_pref_topk_prepared(const float* U, int64_t ldu, const float* pref_ws, int n_pref, int d,
-                                            const int64_t* u_ids, int64_t nq, int64_t n_items, int l1, const float* items_ws,
-                                            const int64_t* filt_off, const int32_t* filt_ids, int topn, int32_t* top_ids,
-                                            float* top_scores, float* ws, void* stream) {
-  const char* name = "ktup_eval_pref_topk_prepared";
+extern "C" int ktup_eval_pref_topk(const float* U, int64_t ldu, const float* I, int64_t ldi, const float* E, int64_t lde,
+                                   const int32_t* item2ent, const float* pref_ws, int n_pref, int d, const int64_t* u_ids, int64_t nq,
+                                   int64_t n_items, int l1, const int64_t* filt_off, const int32_t* filt_ids, int topn,
+                                   int32_t* top_ids, float* top_scores, float* ws, void* stream) {
+  const char* name = "ktup_eval_pref_topk";
   KTUP_REQUIRE(nq >= 0 && n_items >= 0 && topn > 0, "%s: bad sizes", name);
   if (nq == 0) return KTUP_OK;
   const PrefGeom g = pref_geom(d, n_pref);
   if (!g.ok || l1 || n_items == 0) return set_error(KTUP_ERR_UNSUPPORTED, "%s: squared-L2 soft gate, d %% 4 == 0 only", name);
-  KTUP_REQUIRE(U && pref_ws && u_ids && items_ws && top_ids && ws && ((filt_off == nullptr) || filt_ids), "%s: null pointer argument", name);
-  KTUP_REQUIRE(aligned16(U) && aligned16(pref_ws) && aligned16(ws) && aligned16(items_ws) && ldu % 4 == 0,
-               "%s: tables must be 16-byte aligned with pitches %% 4 == 0", name);
-  hipStream_t st = (hipStream_t)stream;
-  const ItemSide it = item_side(const_cast<float*>(items_ws), n_items, d);
-  const int rc = ktup::eval_pass_pspace(U, ldu, u_ids, nq, it.CW1, n_items, pref_ws, g.ppad, g.dp, n_pref, d, filt_off, filt_ids, topn, ws,
-                                        top_ids, top_scores, st, name);
+  KTUP_REQUIRE(U && I && pref_ws && u_ids && top_ids && ws && ((filt_off == nullptr) || filt_ids), "%s: null pointer argument", name);
+  KTUP_REQUIRE((E == nullptr) == (item2ent == nullptr), "%s: E and item2ent must be given together", name);
+  KTUP_REQUIRE(aligned16(pref_ws) && aligned16(ws), "%s: workspaces must be 16-byte aligned", name);
+  const int rc = ktup::eval_pass_pspace(U, ldu, u_ids, nq, I, ldi, E, lde, item2ent, n_items, pref_ws, g.ppad, g.dp, n_pref, d, filt_off,
+                                        filt_ids, topn, ws, top_ids, top_scores, (hipStream_t)stream, name);
   if (rc == 1) return set_error(KTUP_ERR_UNSUPPORTED, "%s: no fused pass kernel for d=%d, n_pref=%d, topn=%d", name, d, n_pref, topn);
   return rc;
 }

@@ -343,7 +343,11 @@ __global__ __launch_bounds__(256) void pspace_gram_kernel(const float* __restric
 
 // One wave per row x (user: U[ids[row]]; item: X[row]): L = Alog x, Rx = Ar x, Nx = Cn x (lane = one of the 3 P4 table rows, the
 // tables staged transposed in LDS), then the operand row and the four scalars of the formulation above.
-struct RowsSide { const float* X; int64_t ldx; const int64_t* ids; int64_t nrows; float* out; int orow; float* scal; int blocks; };
+struct RowsSide {
+  const float* X; int64_t ldx; const int64_t* ids;   // rows X[ids[row]] (ids == NULL: X[row])
+  const float* E; int64_t lde; const int32_t* map;    // + E[map[row]] (KTUP items: the aligned entity, the pad row being zero); NULL = none
+  int64_t nrows; float* out; int orow; float* scal; int blocks;
+};
 
 template <bool IS_USER, int NCH, int NP>
 KTUP_DEV void pspace_rows(const RowsSide& sd, int block, int P, const float* __restrict__ Alog, const float* __restrict__ Ar,
@@ -367,8 +371,9 @@ KTUP_DEV void pspace_rows(const RowsSide& sd, int block, int P, const float* __r
   float* fold = res + 3 * P4;
   for (int64_t row = (int64_t)block * 4 + w; row < nrows; row += (int64_t)sd.blocks * 4) {
     const float* x = X + (ids ? ids[row] : row) * ldx;
+    const float* e = sd.E ? sd.E + (int64_t)sd.map[row] * sd.lde : nullptr;
     float sq = 0.f;
-    for (int k = lane; k < d; k += 64) { const float v = x[k]; xs[k] = v; sq = fmaf(v, v, sq); }
+    for (int k = lane; k < d; k += 64) { const float v = e ? x[k] + e[k] : x[k]; xs[k] = v; sq = fmaf(v, v, sq); }
     sq = group_sum<64>(sq);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -468,7 +473,8 @@ QScratch q_carve(void* scratch, int64_t nq, int64_t n_items) {
 }
 
 template <typename G>
-int launch_q(const float* U, int64_t ldu, const int64_t* u_ids, int64_t nq, const float* item_x, int64_t n_items, const float* pref_ws,
+int launch_q(const float* U, int64_t ldu, const int64_t* u_ids, int64_t nq, const float* I, int64_t ldi, const float* E, int64_t lde,
+             const int32_t* item2ent, int64_t n_items, const float* pref_ws,
              int ppad, int dp, int n_pref, const int64_t* filt_off, const int32_t* filt_ids, int topn, void* scratch, int32_t* top_ids,
              float* top_scores, hipStream_t st, const char* name) {
   const QScratch q = q_carve<G>(scratch, nq, n_items);
@@ -478,8 +484,8 @@ int launch_q(const float* U, int64_t ldu, const int64_t* u_ids, int64_t nq, cons
   hipLaunchKernelGGL(pspace_gram_kernel, dim3((3 * G::P4 * G::P4 + 3) / 4), dim3(256), 0, st, Ar, Cn, dp, G::D, n_pref, G::P4, q.grams);
   const size_t lds_rows = (size_t)4 * (G::D + 7 * G::P4) * sizeof(float);
   // many small workgroups: a row is a chain of dependent round trips (id -> row -> products -> store), hidden only by occupancy
-  RowsSide us{U, ldu, u_ids, nq, q.A, G::AROW, q.SCU, grid_for((nq + 3) / 4, 2048)};
-  RowsSide is{item_x, (int64_t)G::D, nullptr, n_items, q.B, G::ROWB, q.ISC, grid_for((n_items + 3) / 4, 2048)};
+  RowsSide us{U, ldu, u_ids, nullptr, 0, nullptr, nq, q.A, G::AROW, q.SCU, grid_for((nq + 3) / 4, 2048)};
+  RowsSide is{I, ldi, nullptr, E, lde, item2ent, n_items, q.B, G::ROWB, q.ISC, grid_for((n_items + 3) / 4, 2048)};
   hipLaunchKernelGGL((pspace_rows_kernel<G::NCH, G::NP>), dim3(us.blocks + is.blocks), dim3(256), lds_rows, st, us, is, n_pref, Alog, Ar, Cn, dp,
                      q.grams, G::KA, G::KS);
   if (int e = check_launch(name)) return e;
@@ -508,14 +514,15 @@ int launch_q(const float* U, int64_t ldu, const int64_t* u_ids, int64_t nq, cons
 }
 
 template <int NCH>
-int launch_q_p(int n_pref, const float* U, int64_t ldu, const int64_t* u_ids, int64_t nq, const float* item_x, int64_t n_items,
+int launch_q_p(int n_pref, const float* U, int64_t ldu, const int64_t* u_ids, int64_t nq, const float* I, int64_t ldi, const float* E,
+               int64_t lde, const int32_t* item2ent, int64_t n_items,
                const float* pref_ws, int ppad, int dp, const int64_t* filt_off, const int32_t* filt_ids, int topn, void* scratch,
                int32_t* top_ids, float* top_scores, hipStream_t st, const char* name) {
   if (n_pref <= 4)
-    return launch_q<QGeom<NCH, 1>>(U, ldu, u_ids, nq, item_x, n_items, pref_ws, ppad, dp, n_pref, filt_off, filt_ids, topn, scratch, top_ids, top_scores, st, name);
+    return launch_q<QGeom<NCH, 1>>(U, ldu, u_ids, nq, I, ldi, E, lde, item2ent, n_items, pref_ws, ppad, dp, n_pref, filt_off, filt_ids, topn, scratch, top_ids, top_scores, st, name);
   if (n_pref <= 20)
-    return launch_q<QGeom<NCH, 5>>(U, ldu, u_ids, nq, item_x, n_items, pref_ws, ppad, dp, n_pref, filt_off, filt_ids, topn, scratch, top_ids, top_scores, st, name);
-  return launch_q<QGeom<NCH, 8>>(U, ldu, u_ids, nq, item_x, n_items, pref_ws, ppad, dp, n_pref, filt_off, filt_ids, topn, scratch, top_ids, top_scores, st, name);
+    return launch_q<QGeom<NCH, 5>>(U, ldu, u_ids, nq, I, ldi, E, lde, item2ent, n_items, pref_ws, ppad, dp, n_pref, filt_off, filt_ids, topn, scratch, top_ids, top_scores, st, name);
+  return launch_q<QGeom<NCH, 8>>(U, ldu, u_ids, nq, I, ldi, E, lde, item2ent, n_items, pref_ws, ppad, dp, n_pref, filt_off, filt_ids, topn, scratch, top_ids, top_scores, st, name);
 }
 
 }  // namespace
@@ -532,15 +539,16 @@ size_t eval_pass_pspace_bytes(int d, int n_pref, int64_t nq, int64_t n_items, in
   return (3 * 32 * 32 + (size_t)nq * (arow + 4) + (size_t)n_items * (rowb + 4) + 64) * sizeof(float) + (size_t)nq * 8 * topn * sizeof(uint64_t);
 }
 
-// item_x: the items' vectors (pitch d; i + e for KTUP); pref_ws: the prepared tables (ktup_pref_prepare; ppad / dp its geometry).
-// Returns KTUP_OK / an error, or 1 for shapes the pass does not cover.
-int eval_pass_pspace(const float* U, int64_t ldu, const int64_t* u_ids, int64_t nq, const float* item_x, int64_t n_items, const float* pref_ws,
+// Items: I[row] (+ E[item2ent[row]] for KTUP; E == NULL for TUP); pref_ws: the prepared tables (ktup_pref_prepare; ppad / dp its
+// geometry).  Returns KTUP_OK / an error, or 1 for shapes the pass does not cover.
+int eval_pass_pspace(const float* U, int64_t ldu, const int64_t* u_ids, int64_t nq, const float* I, int64_t ldi, const float* E, int64_t lde,
+                     const int32_t* item2ent, int64_t n_items, const float* pref_ws,
                      int ppad, int dp, int n_pref, int d, const int64_t* filt_off, const int32_t* filt_ids, int topn, void* scratch,
                      int32_t* top_ids, float* top_scores, hipStream_t st, const char* name) {
   if ((d != 64 && d != 100 && d != 128) || n_pref < 1 || n_pref > 32 || topn < 1 || topn > TOPN_MAX || n_items >= (1ll << 31)) return 1;
-  if (d == 64) return launch_q_p<16>(n_pref, U, ldu, u_ids, nq, item_x, n_items, pref_ws, ppad, dp, filt_off, filt_ids, topn, scratch, top_ids, top_scores, st, name);
-  if (d == 100) return launch_q_p<25>(n_pref, U, ldu, u_ids, nq, item_x, n_items, pref_ws, ppad, dp, filt_off, filt_ids, topn, scratch, top_ids, top_scores, st, name);
-  return launch_q_p<32>(n_pref, U, ldu, u_ids, nq, item_x, n_items, pref_ws, ppad, dp, filt_off, filt_ids, topn, scratch, top_ids, top_scores, st, name);
+  if (d == 64) return launch_q_p<16>(n_pref, U, ldu, u_ids, nq, I, ldi, E, lde, item2ent, n_items, pref_ws, ppad, dp, filt_off, filt_ids, topn, scratch, top_ids, top_scores, st, name);
+  if (d == 100) return launch_q_p<25>(n_pref, U, ldu, u_ids, nq, I, ldi, E, lde, item2ent, n_items, pref_ws, ppad, dp, filt_off, filt_ids, topn, scratch, top_ids, top_scores, st, name);
+  return launch_q_p<32>(n_pref, U, ldu, u_ids, nq, I, ldi, E, lde, item2ent, n_items, pref_ws, ppad, dp, filt_off, filt_ids, topn, scratch, top_ids, top_scores, st, name);
 }
 
 }  // namespace ktup

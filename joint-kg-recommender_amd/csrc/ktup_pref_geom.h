@@ -69,7 +69,8 @@ int pairs_l2_mc(const float* QW, const float* C0, const float* C1, const float* 
 
 // ktup_eval_pass.hip: scores + filtered top-n of a whole evaluation pass in one launch (+ a merge launch).  1 = not covered.
 size_t eval_pass_pspace_bytes(int d, int n_pref, int64_t nq, int64_t n_items, int topn);
-int eval_pass_pspace(const float* U, int64_t ldu, const int64_t* u_ids, int64_t nq, const float* item_x, int64_t n_items, const float* pref_ws,
+int eval_pass_pspace(const float* U, int64_t ldu, const int64_t* u_ids, int64_t nq, const float* I, int64_t ldi, const float* E, int64_t lde,
+                     const int32_t* item2ent, int64_t n_items, const float* pref_ws,
                      int ppad, int dp, int n_pref, int d, const int64_t* filt_off, const int32_t* filt_ids, int topn, void* scratch,
                      int32_t* top_ids, float* top_scores, hipStream_t st, const char* name);
 int pairs_kg_l2_mc(int model, const float* QW, int dq, const float* C, int64_t ldc, int d, int64_t nq, int64_t n_cand, float* out,

@@ -80,7 +80,7 @@ SIGNATURES = {
     'ktup_eval_pref_items_prepare': [c_p, c_l, c_p, c_l, c_p, c_p, c_i, c_i, c_l, c_p, c_p],
     'ktup_eval_pref_scores_prepared': [c_p, c_l, c_p, c_i, c_i, c_p, c_l, c_l, c_i, c_i, c_p, c_u, c_u, c_p, c_l, c_p, c_p, c_p],
     'ktup_eval_pref_topk_workspace_bytes': [c_i, c_i, c_l, c_l, c_i],
-    'ktup_eval_pref_topk_prepared': [c_p, c_l, c_p, c_i, c_i, c_p, c_l, c_l, c_i, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p],
+    'ktup_eval_pref_topk': [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_p, c_i, c_i, c_p, c_l, c_l, c_i, c_p, c_p, c_i, c_p, c_p, c_p, c_p],
     'ktup_eval_topk_filtered': [c_p, c_l, c_l, c_l, c_i, c_p, c_p, c_i, c_p, c_p, c_p],
     'ktup_eval_gold_rank_counts': [c_p, c_l, c_l, c_l, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
     'ktup_eval_gold_ranks': [c_p, c_l, c_l, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_p],

@@ -415,11 +415,22 @@ def eval_transr(E, R, M, q, r, l1, head):
 
 
 class PreparedItems(object):
-    """Item side of K15 / K16 for one evaluation pass: the prepared preference tables and the per-item projections
-    (ktup_eval_pref_items_prepare).  Valid as long as the tables it was built from do not change."""
+    """Item side of K15 / K16 for one evaluation pass: the prepared preference tables, the item tables they go with and -- built on
+    first use, by the per-batch score route only -- the per-item projections (ktup_eval_pref_items_prepare).  Valid as long as
+    the tables it was built from do not change."""
 
-    def __init__(self, pws, items_ws, n_items, P, d):
-        self.pws, self.items_ws, self.n_items, self.P, self.d = pws, items_ws, n_items, P, d
+    def __init__(self, pws, I, E, item2ent, P, d):
+        self.pws, self.I, self.E, self.item2ent, self.n_items, self.P, self.d = pws, I, E, item2ent, I.shape[0], P, d
+        self._items_ws = None
+
+    @property
+    def items_ws(self):
+        if self._items_ws is None:
+            dev, I, E = self.I.device, self.I, self.E
+            self._items_ws = _scratch(L.load().ktup_eval_pref_items_workspace_bytes(self.d, self.P, self.n_items), dev)
+            L.call('ktup_eval_pref_items_prepare', _p(I), I.stride(0), _p(E), 0 if E is None else E.stride(0), _p(self.item2ent),
+                   _p(self.pws), self.P, self.d, self.n_items, _p(self._items_ws), _stream(dev))
+        return self._items_ws
 
 
 @torch.no_grad()
@@ -432,10 +443,7 @@ def eval_pref_items(I, E, pref, pref_norm, rel, norm, item2ent):
         _table('entity table', E)
         if item2ent.dtype != torch.int32 or item2ent.device != dev or item2ent.numel() != ni:
             raise L.KtupError('item2ent must be an int32 device table with one entry per item row')
-    items_ws = _scratch(L.load().ktup_eval_pref_items_workspace_bytes(d, P, ni), dev)
-    L.call('ktup_eval_pref_items_prepare', _p(I), I.stride(0), _p(E), 0 if E is None else E.stride(0), _p(item2ent), _p(pws), P, d, ni,
-           _p(items_ws), _stream(dev))
-    return PreparedItems(pws, items_ws, ni, P, d)
+    return PreparedItems(pws, I, E, item2ent if E is not None else None, P, d)
 
 
 @torch.no_grad()
@@ -479,8 +487,8 @@ def _eval_pref(U, I, E, pref, pref_norm, rel, norm, item2ent, u, l1, gumbel_mode
 
 @torch.no_grad()
 def eval_pref_topk(U, u, items, l1, topn, filt_off=None, filt_ids=None, with_scores=False):
-    """Scores + filtered top-n of a whole evaluation pass in one sweep (ktup_eval_pref_topk_prepared): every user of `u` against
-    the prepared item side, no (users x items) matrix.  -> int32 (len(u), topn) ids (-1 padded) [, scores], or None when the
+    """Scores + filtered top-n of a whole evaluation pass in one sweep (ktup_eval_pref_topk): every user of `u` against the
+    item tables of `items`, no (users x items) matrix, no per-item projections.  -> int32 (len(u), topn) ids (-1 padded) [, scores], or None when the
     fused pass does not cover the shape (L1, d outside {64, 100, 128}, topn > 16): keep eval_tup / eval_ktup + topk_filtered."""
     dev = _dev(_table('user table', U))
     u = _ids('u_ids', u, dev)
@@ -492,8 +500,9 @@ def eval_pref_topk(U, u, items, l1, topn, filt_off=None, filt_ids=None, with_sco
     top = torch.empty(nq, topn, dtype=torch.int32, device=dev)
     ts = torch.empty(nq, topn, dtype=torch.float32, device=dev) if with_scores else None
     ws = _scratch(L.load().ktup_eval_pref_topk_workspace_bytes(d, P, nq, items.n_items, topn), dev)
-    L.call('ktup_eval_pref_topk_prepared', _p(U), U.stride(0), _p(items.pws), P, d, _p(u), nq, items.n_items, 0, _p(items.items_ws),
-           _p(filt_off), _p(filt_ids), int(topn), _p(top), _p(ts), _p(ws), _stream(dev))
+    I, E = items.I, items.E
+    L.call('ktup_eval_pref_topk', _p(U), U.stride(0), _p(I), I.stride(0), _p(E), 0 if E is None else E.stride(0), _p(items.item2ent),
+           _p(items.pws), P, d, _p(u), nq, items.n_items, 0, _p(filt_off), _p(filt_ids), int(topn), _p(top), _p(ts), _p(ws), _stream(dev))
     return (top, ts) if with_scores else top
 
 

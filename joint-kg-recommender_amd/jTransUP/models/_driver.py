@@ -166,6 +166,23 @@ def _kg_eval_sharded(FLAGS, shard, eval_iter, index, descending, remap):
 _PASS_IDS = {}
 
 
+_PINNED = {}
+
+
+def _to_host(t):
+    """Device -> host through a cached pinned buffer (a pageable destination costs a staging copy: 24 vs 14 us for the 240 KB of
+    metric columns of an ml1m pass).  The returned array is a copy."""
+    key = (tuple(t.shape), t.dtype)
+    pin = _PINNED.get(key)
+    if pin is None:
+        if len(_PINNED) > 8:
+            _PINNED.clear()
+        pin = _PINNED[key] = torch.empty(t.shape, dtype=t.dtype).pin_memory()
+    pin.copy_(t, non_blocking=True)
+    torch.cuda.current_stream(t.device).synchronize()
+    return pin.numpy().copy()
+
+
 def _rec_eval_fused(FLAGS, pass_fn, eval_iter, index):
     """The whole pass in one sweep: every evaluation user at once through the fused score + filtered top-n kernel
     (model.evaluate_topk), the per-user metrics on the device (K18b), one (users x 5) copy back.  None if the model declines."""
@@ -180,7 +197,7 @@ def _rec_eval_fused(FLAGS, pass_fn, eval_iter, index):
     if top is None:
         return None
     cols = ops.rec_metrics(top, index.g_off, index.g_ids)
-    return cols.cpu().numpy()[index.present_h]
+    return _to_host(cols)[index.present_h]
 
 
 def rec_eval_pass(FLAGS, score_fn, eval_iter, eval_dict, all_dicts, descending, want_rows=True, shard=None, pass_fn=None):

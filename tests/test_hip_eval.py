@@ -396,7 +396,7 @@ def test_prepared_item_side_gives_the_same_scores(l1, gum):
 @pytest.mark.parametrize('d,nu,ni,nq,topn', [(100, 6040, 3240, 6040, 10), (64, 300, 177, 65, 16), (128, 90, 16, 1, 3), (100, 70, 5, 63, 10),
                                              (100, 500, 1000, 129, 1)])
 def test_fused_pass_topk_equals_matrix_route(d, nu, ni, nq, topn):
-    """ktup_eval_pref_topk_prepared (scores + filtered top-n of a whole pass in one sweep, no score matrix) against the matrix
+    """ktup_eval_pref_topk (scores + filtered top-n of a whole pass in one sweep, no score matrix) against the matrix
     route (ktup_eval_pref_scores_prepared + ktup_eval_topk_filtered).  The sweep contracts every cross term but u.v in preference
     space -- the same sums in another association -- so scores agree to fp32 rounding and the lists are the matrix route's up to
     swaps between items whose scores differ by less than that.  KTUP and TUP; per-user filters incl. empty and everything."""

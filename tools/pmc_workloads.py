@@ -1,5 +1,5 @@
 """Small fixed workloads for rocprofv3 counter passes (run under `rocprofv3 --kernel-trace --pmc ... -- python tools/pmc_workloads.py <name>`):
-    eval_pass   the fused all-item evaluation sweep at ml1m shape (ktup_eval_pref_topk_prepared), 5 sweeps
+    eval_pass   the fused all-item evaluation sweep at ml1m shape (ktup_eval_pref_topk), 5 sweeps
     train_step  the three-launch B=512 joint training step, 20 rec + 20 kg steps
     fed_step    the device-fed B=512 joint step (-device_sampling): feed launch + step + clip/optimizer, ten-step graphs
     seg_bwd     the large-batch backwards by sorted segments: TransE (307,200 triples) and KTUP (716,800 pairs), 5 each

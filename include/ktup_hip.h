@@ -241,9 +241,16 @@ int ktup_eval_transh_scores(const float* E, int64_t lde, const float* R, int64_t
                             int64_t nq, int l1, int head, float* out, int64_t ldo, float* ws, void* stream);
 /* K14  transR.py:80-128 + utils/misc.py:29-33 : candidates projected by the query's relation matrix. */
 size_t ktup_eval_transr_workspace_bytes(int d, int64_t nq, int64_t n_ent, int n_rel);
+/* The entity side of K14 does not depend on the queries: ktup_eval_transr_prepare computes it once per evaluation pass into
+ * `ents_ws` (ktup_eval_transr_entities_workspace_bytes bytes, 16-byte aligned) -- |M_rho e|^2 per (relation, entity) for the
+ * squared-L2 matrix-core route (d in {64,100,128}), the projected table M_rho e otherwise -- and ktup_eval_transr_scores takes
+ * it as `ents_ws` (NULL: recomputed inside every call, as in round 1).  Same tables, l1 and shape on both calls.          */
+size_t ktup_eval_transr_entities_workspace_bytes(int d, int64_t n_ent, int n_rel);
+int ktup_eval_transr_prepare(const float* E, int64_t lde, const float* M, int64_t ldm, int d, int64_t n_ent, int n_rel, int l1,
+                             float* ents_ws, void* stream);
 int ktup_eval_transr_scores(const float* E, int64_t lde, const float* R, int64_t ldr, const float* M, int64_t ldm,
                             int d, int64_t n_ent, int n_rel, const int64_t* q, const int64_t* r, int64_t nq, int l1,
-                            int head, float* out, int64_t ldo, float* ws, void* stream);
+                            int head, float* out, int64_t ldo, float* ws, const float* ents_ws, void* stream);
 /* K15/K16  transUP.py:84-102 (E == NULL) and jTransUP.py:163-191.  item2ent has one int32 per ROW of I;
  * uniform is (nq x n_items x n_pref) for KTUP_GUMBEL_INPUT (the reference draws noise in evaluate too).   */
 size_t ktup_eval_pref_workspace_bytes(int d, int n_pref, int64_t nq, int64_t n_items);

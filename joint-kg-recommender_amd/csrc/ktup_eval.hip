@@ -574,9 +574,69 @@ extern "C" size_t ktup_eval_transr_workspace_bytes(int d, int64_t nq, int64_t n_
          pad4((size_t)n_rel + 1 + (size_t)nq) * sizeof(int32_t);
 }
 
+// The entity side of K14 for one evaluation pass (it does not depend on the queries): `ents_ws` receives either |M_rho e_j|^2 for
+// every (relation, entity) -- the squared-L2 matrix-core route -- or the projected table PE[rho][j] = M_rho e_j (L1 and the other
+// shapes).  ktup_eval_transr_scores recomputes this per call unless it is handed the prepared workspace: per 512 queries that is
+// 140 of 217 us (L2) and 370 of 430 us (L1).
+extern "C" size_t ktup_eval_transr_entities_workspace_bytes(int d, int64_t n_ent, int n_rel) {
+  return (size_t)n_rel * n_ent * round4(d) * sizeof(float);
+}
+
+namespace {
+
+bool transr_mc_route(int d, int l1, const float* E, int64_t lde) {
+  return !l1 && (d == 64 || d == 100 || d == 128) && aligned16(E) && lde % 4 == 0 && ktup::opt_eval_mc();
+}
+
+// norms[n_rel][n_ent] at the head of `region` (`avail` bytes); the rest of the region is this route's scratch.
+// Returns KTUP_OK / an error, or 1 when the region is too small or the shape has no matrix-core kernel.
+int transr_entity_norms(const char* name, const float* E, int64_t lde, const float* M, int64_t ldm, int d, int64_t n_ent, int n_rel,
+                        float* region, size_t avail, hipStream_t st) {
+  const int64_t n = (int64_t)n_rel * n_ent;
+  float* norms = region;
+  int64_t* hid = reinterpret_cast<int64_t*>(((uintptr_t)(norms + pad4((size_t)n)) + 15) & ~(uintptr_t)15);
+  int64_t* rid = hid + n;
+  void* bws = rid + n;
+  const size_t need = (size_t)((char*)bws - (char*)region) + ktup::transr_mc_workspace_bytes(n, n_rel);
+  if (need > avail) return 1;
+  hipLaunchKernelGGL(transr_all_pairs_ids_kernel, dim3(grid_for((n + 255) / 256)), dim3(256), 0, st, n_ent, n, hid, rid);
+  if (int e = check_launch(name)) return e;
+  return ktup::transr_fwd_mc(E, lde, nullptr, 0, M, ldm, n_rel, d, hid, nullptr, rid, n, 0, norms, bws, st, name);
+}
+
+int transr_entity_project(const char* name, const float* E, int64_t lde, const float* M, int64_t ldm, int d, int64_t n_ent, int n_rel,
+                          float* PE, hipStream_t st) {
+  const int dq = round4(d);
+  const size_t lds = (size_t)(dq / 4) * CT * 16;
+  KTUP_REQUIRE(lds <= 64 * 1024 && (size_t)n_rel * 4 <= 64 * 1024, "%s: embedding_size / n_rel too large", name);
+  const int evec = (d % 4 == 0) && aligned16(E) && lde % 4 == 0;
+  const int mvec = (d % 4 == 0) && aligned16(M) && ldm % 4 == 0;
+  hipLaunchKernelGGL(transr_project_kernel, dim3((unsigned)((n_ent + CT - 1) / CT), (unsigned)n_rel), dim3(256), lds, st, E, lde,
+                     M, ldm, d, dq, n_ent, evec, mvec, PE);
+  return check_launch(name);
+}
+
+}  // namespace
+
+extern "C" int ktup_eval_transr_prepare(const float* E, int64_t lde, const float* M, int64_t ldm, int d, int64_t n_ent, int n_rel,
+                                        int l1, float* ents_ws, void* stream) {
+  const char* name = "ktup_eval_transr_prepare";
+  KTUP_REQUIRE(d > 0 && n_ent >= 0 && n_rel > 0, "%s: bad sizes", name);
+  if (n_ent == 0) return KTUP_OK;
+  KTUP_REQUIRE(E && M && ents_ws && aligned16(ents_ws) && ldm >= (int64_t)d * d, "%s: bad argument", name);
+  hipStream_t st = (hipStream_t)stream;
+  if (transr_mc_route(d, l1, E, lde)) {
+    const int rc = transr_entity_norms(name, E, lde, M, ldm, d, n_ent, n_rel, ents_ws, ktup_eval_transr_entities_workspace_bytes(d, n_ent, n_rel), st);
+    if (rc != 1) return rc;
+    return set_error(KTUP_ERR_UNSUPPORTED, "%s: catalogue too small for the matrix-core route's scratch (n_rel x n_ent x d)", name);
+  }
+  return transr_entity_project(name, E, lde, M, ldm, d, n_ent, n_rel, ents_ws, st);
+}
+
+// ents_ws: NULL, or what ktup_eval_transr_prepare left for the SAME tables, l1 and shape.
 extern "C" int ktup_eval_transr_scores(const float* E, int64_t lde, const float* R, int64_t ldr, const float* M, int64_t ldm,
                                        int d, int64_t n_ent, int n_rel, const int64_t* q, const int64_t* r, int64_t nq, int l1,
-                                       int head, float* out, int64_t ldo, float* ws, void* stream) {
+                                       int head, float* out, int64_t ldo, float* ws, const float* ents_ws, void* stream) {
   const char* name = "ktup_eval_transr_scores";
   KTUP_REQUIRE(d > 0 && nq >= 0 && n_ent >= 0 && n_rel > 0, "%s: bad sizes", name);
   if (nq == 0 || n_ent == 0) return KTUP_OK;
@@ -590,41 +650,40 @@ extern "C" int ktup_eval_transr_scores(const float* E, int64_t lde, const float*
   hipLaunchKernelGGL(kg_query_prep_kernel, dim3(grid_for((nq + 3) / 4)), dim3(256), 0, st, 2, E, lde, R, ldr, M, ldm, d, dq, q, r,
                      nq, head, QW);
   if (int e = check_launch(name)) return e;
-  if (!l1 && (d == 64 || d == 100 || d == 128) && aligned16(E) && lde % 4 == 0 && ktup::opt_eval_mc()) {
-    // squared L2 on the matrix cores; the scratch of this route lives in the PE region (it is far smaller than the
-    // projected tables the VALU route stores there)
-    const int64_t n = (int64_t)n_rel * n_ent;
-    float* qcc = PE;                                            // [nq]
-    float* norms = qcc + pad4((size_t)nq);                      // [n_rel][n_ent]
-    int32_t* qrel = reinterpret_cast<int32_t*>(norms + pad4((size_t)n));
-    int64_t* hid = reinterpret_cast<int64_t*>(qrel + pad4((size_t)nq) + 2);
-    hid = reinterpret_cast<int64_t*>(((uintptr_t)hid + 15) & ~(uintptr_t)15);
-    int64_t* rid = hid + n;
-    void* bws = rid + n;
-    const size_t need = (size_t)((char*)bws - (char*)PE) + ktup::transr_mc_workspace_bytes(n, n_rel);
-    if (need <= (size_t)n_rel * n_ent * dq * sizeof(float)) {
-      hipLaunchKernelGGL(transr_query_fold_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, st, QW, dq, M, ldm, d, r, nq, qcc, qrel);
-      hipLaunchKernelGGL(transr_all_pairs_ids_kernel, dim3(grid_for((n + 255) / 256)), dim3(256), 0, st, n_ent, n, hid, rid);
-      if (int e = check_launch(name)) return e;
-      int rc = ktup::transr_fwd_mc(E, lde, nullptr, 0, M, ldm, n_rel, d, hid, nullptr, rid, n, 0, norms, bws, st, name);
-      if (rc == KTUP_OK) rc = ktup::pairs_kg_l2_mc(0, QW, dq, E, lde, d, nq, n_ent, out, ldo, st, name, qcc, norms, qrel);
-      if (rc != 1) return rc;
-      // (not an instantiated shape after all: c' has overwritten c, so rebuild the queries for the VALU route)
-      hipLaunchKernelGGL(kg_query_prep_kernel, dim3(grid_for((nq + 3) / 4)), dim3(256), 0, st, 2, E, lde, R, ldr, M, ldm, d, dq, q, r,
-                         nq, head, QW);
+  if (transr_mc_route(d, l1, E, lde)) {
+    // squared L2 on the matrix cores: queries folded through M_r^T, the pair term one GEMM against the UNPROJECTED entity table,
+    // |M_r e|^2 from the prepared workspace or computed here (side arrays and scratch live in the PE region of `ws`, which this
+    // route does not otherwise use and which is far larger than they need)
+    float* qc = PE;                                                       // [nq] |c|^2 of the folded queries
+    int32_t* qrel = reinterpret_cast<int32_t*>(qc + pad4((size_t)nq));    // [nq] their relation ids
+    const float* norms = ents_ws;
+    int rc = KTUP_OK;
+    if (!norms) {
+      float* region = reinterpret_cast<float*>(qrel + pad4((size_t)nq));
+      const size_t used = (size_t)((char*)region - (char*)PE), total = (size_t)n_rel * n_ent * dq * sizeof(float);
+      rc = used < total ? transr_entity_norms(name, E, lde, M, ldm, d, n_ent, n_rel, region, total - used, st) : 1;
+      norms = region;
     }
+    if (rc == KTUP_OK) {
+      hipLaunchKernelGGL(transr_query_fold_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, st, QW, dq, M, ldm, d, r, nq, qc, qrel);
+      if (int e = check_launch(name)) return e;
+      rc = ktup::pairs_kg_l2_mc(0, QW, dq, E, lde, d, nq, n_ent, out, ldo, st, name, qc, norms, qrel);
+    }
+    if (rc != 1) return rc;
+    KTUP_REQUIRE(!ents_ws, "%s: the prepared workspace holds norms, but this shape needs the projected table", name);
+    // (not an instantiated shape after all: c' may have overwritten c, so rebuild the queries for the VALU route)
+    hipLaunchKernelGGL(kg_query_prep_kernel, dim3(grid_for((nq + 3) / 4)), dim3(256), 0, st, 2, E, lde, R, ldr, M, ldm, d, dq, q, r,
+                       nq, head, QW);
   }
-  const size_t lds = (size_t)(dq / 4) * CT * 16;
-  KTUP_REQUIRE(lds <= 64 * 1024 && (size_t)n_rel * 4 <= 64 * 1024, "%s: embedding_size / n_rel too large", name);
-  const int evec = (d % 4 == 0) && aligned16(E) && lde % 4 == 0;
-  const int mvec = (d % 4 == 0) && aligned16(M) && ldm % 4 == 0;
-  hipLaunchKernelGGL(transr_project_kernel, dim3((unsigned)((n_ent + CT - 1) / CT), (unsigned)n_rel), dim3(256), lds, st, E, lde,
-                     M, ldm, d, dq, n_ent, evec, mvec, PE);
-  if (int e = check_launch(name)) return e;
+  const float* PEc = ents_ws;
+  if (!PEc) {
+    if (int e = transr_entity_project(name, E, lde, M, ldm, d, n_ent, n_rel, PE, st)) return e;
+    PEc = PE;
+  }
   hipLaunchKernelGGL(rel_bucket_kernel, dim3(1), dim3(256), (size_t)n_rel * 4, st, r, nq, n_rel, rel_off, qperm);
   if (int e = check_launch(name)) return e;
   PairsArgs a{};
-  a.C0 = PE; a.ldc0 = dq; a.QW = QW; a.n_cand = n_ent; a.nq = nq; a.d = d; a.dq = dq; a.l1 = l1; a.out = out; a.ldo = ldo;
+  a.C0 = PEc; a.ldc0 = dq; a.QW = QW; a.n_cand = n_ent; a.nq = nq; a.d = d; a.dq = dq; a.l1 = l1; a.out = out; a.ldo = ldo;
   a.cvec = 1; a.qperm = qperm; a.rel_off = rel_off; a.rel_stride = (int64_t)n_ent * dq;
   return launch_pairs<0>(a, st, name, n_rel);
 }

@@ -403,14 +403,34 @@ def eval_transh(E, R, N, q, r, l1, head, candidates=None):
 
 
 @torch.no_grad()
-def eval_transr(E, R, M, q, r, l1, head):
-    """transR.py:80-128 -> (len(q), n_entities)."""
+class PreparedEntities(object):
+    """Entity side of K14 for one evaluation pass (ktup_eval_transr_prepare): valid while the tables it was built from do not
+    change, for the distance kind it was built for."""
+
+    def __init__(self, ws, shape, l1):
+        self.ws, self.shape, self.l1 = ws, shape, bool(l1)
+
+
+@torch.no_grad()
+def eval_transr_entities(E, M, n_rel, l1):
+    """|M_r e|^2 (squared L2 on the matrix cores) or M_r e (L1, other widths) for every relation and entity, once per pass."""
+    dev = _dev(_table('entity table', E)); _table('projection table', M)
+    ws = _scratch(L.load().ktup_eval_transr_entities_workspace_bytes(E.shape[1], E.shape[0], n_rel), dev)
+    L.call('ktup_eval_transr_prepare', _p(E), E.stride(0), _p(M), M.stride(0), E.shape[1], E.shape[0], n_rel, int(l1), _p(ws), _stream(dev))
+    return PreparedEntities(ws, (E.shape[0], E.shape[1], n_rel), l1)
+
+
+@torch.no_grad()
+def eval_transr(E, R, M, q, r, l1, head, ents=None):
+    """transR.py:80-128 -> (len(q), n_entities).  `ents`: eval_transr_entities(...) of the same tables (one per evaluation pass)."""
     dev = _dev(_table('entity table', E)); _table('relation table', R); _table('projection table', M)
     nq = q.numel(); q = _ids('q', q, dev); r = _ids('r', r, dev, nq)
+    if ents is not None and (ents.shape != (E.shape[0], E.shape[1], R.shape[0]) or ents.l1 != bool(l1)):
+        raise L.KtupError('prepared entity side does not match the tables / distance kind')
     out = torch.empty(nq, E.shape[0], dtype=torch.float32, device=dev)
     ws = _scratch(L.load().ktup_eval_transr_workspace_bytes(E.shape[1], nq, E.shape[0], R.shape[0]), dev)
     L.call('ktup_eval_transr_scores', _p(E), E.stride(0), _p(R), R.stride(0), _p(M), M.stride(0), E.shape[1], E.shape[0], R.shape[0],
-           _p(q), _p(r), nq, int(l1), int(head), _p(out), out.stride(0), _p(ws), _stream(dev))
+           _p(q), _p(r), nq, int(l1), int(head), _p(out), out.stride(0), _p(ws), _p(None if ents is None else ents.ws), _stream(dev))
     return out
 
 

@@ -70,12 +70,16 @@ class CKE(nn.Module, GradToggle):
         with torch.no_grad():
             return ops.eval_bprmf(self.user_embeddings.weight, self._item_side().contiguous(), u_ids)
 
-    def evaluateHead(self, t, r, all_e_ids=None):
+    def prepare_entities(self):
+        """Entity side of evaluateHead / evaluateTail, once per evaluation pass (`ents=`)."""
+        return ops.eval_transr_entities(self.ent_embeddings.weight, self.proj_embeddings.weight, self.rel_embeddings.weight.shape[0], self.L1_flag)
+
+    def evaluateHead(self, t, r, all_e_ids=None, ents=None):
         """CKE.py:155-178 over the entity table INCLUDING the pad row."""
         return ops.eval_transr(self.ent_embeddings.weight, self.rel_embeddings.weight, self.proj_embeddings.weight, t, r, self.L1_flag,
-                               head=True)
+                               head=True, ents=ents)
 
-    def evaluateTail(self, h, r, all_e_ids=None):
+    def evaluateTail(self, h, r, all_e_ids=None, ents=None):
         """CKE.py:180-203."""
         return ops.eval_transr(self.ent_embeddings.weight, self.rel_embeddings.weight, self.proj_embeddings.weight, h, r, self.L1_flag,
-                               head=False)
+                               head=False, ents=ents)

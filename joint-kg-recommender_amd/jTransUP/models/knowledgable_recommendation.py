@@ -67,9 +67,10 @@ def evaluateKG(FLAGS, model, eval_head_iter, eval_tail_iter, eval_head_dict, eva
     all_e_var = D.ids([e_map[e] for e in range(len(e_map))]) if FLAGS.share_embeddings else None
     remap = None if FLAGS.share_embeddings else e_map      # :125,140 (identity for id-ordered map files)
     from jTransUP.models._shard_eval import kg_shard_fn
-    head_results = D.kg_eval_pass(FLAGS, lambda t, r: model.evaluateHead(t, r, all_e_ids=all_e_var), eval_head_iter, eval_head_dict,
+    kw = {'ents': model.prepare_entities()} if hasattr(model, 'prepare_entities') else {}       # CKE: TransR's entity side, once
+    head_results = D.kg_eval_pass(FLAGS, lambda t, r: model.evaluateHead(t, r, all_e_ids=all_e_var, **kw), eval_head_iter, eval_head_dict,
                                   all_head_dicts, eval_descending, remap=remap, want_rows=is_report, shard=kg_shard_fn(model, True))
-    tail_results = D.kg_eval_pass(FLAGS, lambda h, r: model.evaluateTail(h, r, all_e_ids=all_e_var), eval_tail_iter, eval_tail_dict,
+    tail_results = D.kg_eval_pass(FLAGS, lambda h, r: model.evaluateTail(h, r, all_e_ids=all_e_var, **kw), eval_tail_iter, eval_tail_dict,
                                   all_tail_dicts, eval_descending, remap=remap, want_rows=is_report, shard=kg_shard_fn(model, False))
     perf = D.summarize_kg(FLAGS, head_results, tail_results, logger)
     if is_report:

@@ -21,9 +21,13 @@ def evaluate(FLAGS, model, entity_total, relation_total, eval_head_iter, eval_ta
              all_head_dicts, all_tail_dicts, logger, eval_descending=True, is_report=False):
     model.eval(); model.disable_grad()
     from jTransUP.models._shard_eval import kg_shard_fn
-    head_results = D.kg_eval_pass(FLAGS, model.evaluateHead, eval_head_iter, eval_head_dict, all_head_dicts, eval_descending,
+    head_fn, tail_fn = model.evaluateHead, model.evaluateTail
+    if hasattr(model, 'prepare_entities'):           # TransR: the entity side of both passes, once (it does not depend on the queries)
+        ents = model.prepare_entities()
+        head_fn, tail_fn = (lambda t, r: model.evaluateHead(t, r, ents=ents)), (lambda h, r: model.evaluateTail(h, r, ents=ents))
+    head_results = D.kg_eval_pass(FLAGS, head_fn, eval_head_iter, eval_head_dict, all_head_dicts, eval_descending,
                                   want_rows=is_report, shard=kg_shard_fn(model, True))
-    tail_results = D.kg_eval_pass(FLAGS, model.evaluateTail, eval_tail_iter, eval_tail_dict, all_tail_dicts, eval_descending,
+    tail_results = D.kg_eval_pass(FLAGS, tail_fn, eval_tail_iter, eval_tail_dict, all_tail_dicts, eval_descending,
                                   want_rows=is_report, shard=kg_shard_fn(model, False))
     perf = D.summarize_kg(FLAGS, head_results, tail_results, logger)
     if is_report:

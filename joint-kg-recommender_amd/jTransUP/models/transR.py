@@ -35,12 +35,18 @@ class TransRModel(nn.Module, GradToggle):
         E, R, M = self._tables()
         return ops.score_transr(E, R, M, h, t, r, self.L1_flag)
 
-    def evaluateHead(self, t, r):
+    def prepare_entities(self):
+        """Entity side of evaluateHead / evaluateTail (every entity under every relation's M_r), to share between the batches of a
+        pass: pass it as `ents=`."""
+        E, R, M = self._tables()
+        return ops.eval_transr_entities(E, M, R.shape[0], self.L1_flag)
+
+    def evaluateHead(self, t, r, ents=None):
         """K14 (transR.py:80-103): every entity projected by the query's M_r."""
         E, R, M = self._tables()
-        return ops.eval_transr(E, R, M, t, r, self.L1_flag, head=True)
+        return ops.eval_transr(E, R, M, t, r, self.L1_flag, head=True, ents=ents)
 
-    def evaluateTail(self, h, r):
+    def evaluateTail(self, h, r, ents=None):
         """K14 (transR.py:105-128)."""
         E, R, M = self._tables()
-        return ops.eval_transr(E, R, M, h, r, self.L1_flag, head=False)
+        return ops.eval_transr(E, R, M, h, r, self.L1_flag, head=False, ents=ents)

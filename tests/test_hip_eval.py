@@ -466,3 +466,23 @@ def _fused_pass_case(d, nu, ni, nq, topn, pspace):
             sc = torch.gather(mat, 1, nf[:64].clamp(min=0).long())
             _same_lists_up_to_rounding(nf[:64], sc, a, b, None, ni)
     assert ops().eval_pref_topk(U, u, items, True, topn) is None              # L1 does not decompose: the caller keeps the matrix route
+
+
+@pytest.mark.parametrize('d,ne,nrel', [(100, 3000, 20), (36, 500, 5), (64, 2049, 7)])
+def test_transr_entity_side_prepared_once_per_pass(d, ne, nrel):
+    """ktup_eval_transr_prepare + ents_ws: the entity side (|M_r e|^2 for the squared-L2 matrix-core route, M_r e otherwise) computed
+    once and shared by the batches of a pass gives bit-identical scores to recomputing it inside every call -- L1 and L2, head
+    and tail, matrix-core widths and d = 36 (VALU route); a workspace prepared for the other distance kind is refused."""
+    gen = torch.Generator().manual_seed(d * 7 + ne)
+    E, R = O.make_table(ne, d, gen).to(DEV), O.make_table(nrel, d, gen).to(DEV)
+    M = (torch.eye(d).reshape(1, d * d).repeat(nrel, 1) + torch.randn(nrel, d * d, generator=gen) * 0.05).to(DEV)
+    for l1 in (False, True):
+        ents = ops().eval_transr_entities(E, M, nrel, l1)
+        for nq in (65, 512):
+            q = torch.randint(0, ne, (nq,), generator=gen).to(DEV); r = torch.randint(0, nrel, (nq,), generator=gen).to(DEV)
+            for head in (True, False):
+                a = ops().eval_transr(E, R, M, q, r, l1, head)
+                b = ops().eval_transr(E, R, M, q, r, l1, head, ents=ents)
+                assert torch.equal(a, b), (d, l1, nq, head)
+        with pytest.raises(L.KtupError):
+            ops().eval_transr(E, R, M, q, r, not l1, True, ents=ents)

@@ -70,7 +70,14 @@ with torch.no_grad():
     rows.append(('K12 TransE eval 512 x E L2', nq, None, timed(lambda: ops.eval_transe(E, R, q, rq, False, False))))
     rows.append(('K12 TransE eval 512 x E L1', nq, None, timed(lambda: ops.eval_transe(E, R, q, rq, True, False))))
     rows.append(('K13 TransH eval 512 x E', nq, None, timed(lambda: ops.eval_transh(E, R, Rn, q, rq, False, False))))
-    rows.append(('K14 TransR eval 512 x E', nq, None, timed(lambda: ops.eval_transr(E, R, M, q, rq, False, False), 5)))
+    rows.append(('K14 TransR eval 512 x E L2', nq, None, timed(lambda: ops.eval_transr(E, R, M, q, rq, False, False), 5)))
+    rows.append(('K14 TransR eval 512 x E L1', nq, None, timed(lambda: ops.eval_transr(E, R, M, q, rq, True, False), 5)))
+    for l1 in (False, True):        # entity side prepared once per pass (ktup_eval_transr_prepare)
+        ents = ops.eval_transr_entities(E, M, R.shape[0], l1)
+        rows.append(('K14 TransR eval %s, prepared' % ('L1' if l1 else 'L2'), nq, None,
+                     timed(lambda: ops.eval_transr(E, R, M, q, rq, l1, False, ents=ents), 5)))
+        rows.append(('K14 TransR entity side %s' % ('L1' if l1 else 'L2'), E.shape[0] * R.shape[0], None,
+                     timed(lambda: ops.eval_transr_entities(E, M, R.shape[0], l1), 5)))
     rows.append(('K15 TUP eval 512 x I', nq, None, timed(lambda: ops.eval_tup(U, I, P, Pn, X['u'][:nq], False))))
     rows.append(('K16 KTUP eval 512 x I', nq, None, timed(lambda: ops.eval_ktup(U, I, E, P, Pn, R, Rn, i2e, X['u'][:nq], False))))
     rows.append(('K11 BPRMF eval 512 x I', nq, None, timed(lambda: ops.eval_bprmf(U, I, X['u'][:nq]))))

@@ -402,7 +402,6 @@ def eval_transh(E, R, N, q, r, l1, head, candidates=None):
     return out
 
 
-@torch.no_grad()
 class PreparedEntities(object):
     """Entity side of K14 for one evaluation pass (ktup_eval_transr_prepare): valid while the tables it was built from do not
     change, for the distance kind it was built for."""

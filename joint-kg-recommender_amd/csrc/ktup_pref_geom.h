@@ -101,5 +101,12 @@ size_t seg_ws_bytes(int64_t m, int64_t n_rows);
 int seg_reduce(const float* G, int64_t ldg, int d, int64_t n_src, const int64_t* ids, int64_t m, int64_t sign_split, int64_t n_rows,
                float* gT, int64_t ldt, const int32_t* map2, int64_t pad2, float* gT2, int64_t ldt2, void* ws, hipStream_t st,
                const char* name);
+// the same in two steps, so that the sort (a function of the ids alone) can run beside the kernel that writes G:
+// seg_sort fills ws from ids (entries [0, n_src)) and ids2 (entries [n_src, m); may be null when m == n_src), seg_apply reduces.
+bool seg_covers(const float* G, int64_t ldg, int d, int64_t n_src, int64_t m, int64_t n_rows, const float* gT, int64_t ldt,
+                const int32_t* map2, const float* gT2, int64_t ldt2, const void* ws);
+int seg_sort(const int64_t* ids, const int64_t* ids2, int64_t n_src, int64_t m, int64_t n_rows, void* ws, hipStream_t st, const char* name);
+int seg_apply(const float* G, int64_t ldg, int d, int64_t n_src, int64_t m, int64_t sign_split, int64_t n_rows, float* gT, int64_t ldt,
+              const int32_t* map2, int64_t pad2, float* gT2, int64_t ldt2, const void* ws, hipStream_t st, const char* name);
 
 }  // namespace ktup

@@ -100,46 +100,12 @@ __global__ __launch_bounds__(256) void topk_filtered_kernel(const float* __restr
 
 // rank of gold g = #{unfiltered, non-gold candidates ordered before g}  (0-based; other golds do not advance the rank,
 // misc.py:134-144).  A gold id that is itself filtered is never reached by the reference's walk: rank -1.
-__global__ __launch_bounds__(256) void gold_ranks_kernel(const float* __restrict__ scores, int64_t lds, int64_t n_cand,
-                                                         int descending, const int64_t* __restrict__ filt_off,
-                                                         const int32_t* __restrict__ filt_ids,
-                                                         const int64_t* __restrict__ gold_off,
-                                                         const int32_t* __restrict__ gold_ids, int32_t* __restrict__ ranks) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  uint64_t* keys = reinterpret_cast<uint64_t*>(smem);
-  __shared__ int red[4];
-  const int64_t b = blockIdx.x;
-  const float* row = scores + b * lds;
-  const int64_t f0 = filt_off ? filt_off[b] : 0, f1 = filt_off ? filt_off[b + 1] : 0;
-  load_keys(keys, row, n_cand, descending != 0, filt_ids + f0, f1 - f0);
-  const int64_t g0 = gold_off[b], g1 = gold_off[b + 1];
-  for (int64_t gi = g0; gi < g1; ++gi) {
-    const int32_t g = gold_ids[gi];
-    const uint64_t gk = (g >= 0 && g < n_cand) ? keys[g] : KEY_MAX;
-    if (gk == KEY_MAX) {  // uniform: every thread read the same LDS word
-      if (threadIdx.x == 0) ranks[gi] = -1;
-      continue;
-    }
-    int cnt = 0;
-    for (int64_t j = threadIdx.x; j < n_cand; j += 256) cnt += keys[j] < gk ? 1 : 0;
-    for (int64_t o = g0 + threadIdx.x; o < g1; o += 256) {
-      const int32_t og = gold_ids[o];
-      if (og >= 0 && og < n_cand && keys[og] < gk) cnt -= 1;
-    }
-    cnt = wave_sum_int(cnt);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = cnt;
-    __syncthreads();
-    if (threadIdx.x == 0) ranks[gi] = red[0] + red[1] + red[2] + red[3];
-    __syncthreads();
-  }
-}
-
-// The same ranks without the key array: a workgroup keeps one BIT per candidate in LDS (filtered or gold: not counted) and
-// streams the score row from global memory, comparing every candidate against up to GOLD_B gold keys held in registers.  1.8 KB
-// of LDS instead of 117 KB at 14,709 entities, so every query of a 512-query batch is resident at once (the key array allowed
-// one workgroup per CU: two rounds of ~20 us).
+// No key array: a workgroup keeps two BITS per candidate in LDS (filtered; filtered or gold: not counted) and streams the score row
+// from global memory, comparing every candidate against up to GOLD_B gold keys held in registers.  3.6 KB of LDS at 14,709 entities,
+// so every query of a 512-query batch is resident at once (a 117 KB key array allowed one workgroup per CU: two rounds).
 constexpr int GOLD_B = 8;
-constexpr int64_t STREAM_MAX_CAND = 64 * 1024 * 8;     // bitmap <= 64 KB
+constexpr int STREAM_U = 8;                            // independent row loads in flight per thread
+constexpr int64_t STREAM_MAX_CAND = 64 * 1024 * 8;     // two bitmaps of <= 64 KB
 
 __global__ __launch_bounds__(256) void gold_ranks_stream_kernel(const float* __restrict__ scores, int64_t lds, int64_t n_cand,
                                                                 int descending, const int64_t* __restrict__ filt_off,
@@ -147,50 +113,60 @@ __global__ __launch_bounds__(256) void gold_ranks_stream_kernel(const float* __r
                                                                 const int64_t* __restrict__ gold_off,
                                                                 const int32_t* __restrict__ gold_ids, int32_t* __restrict__ ranks) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  uint32_t* skip = reinterpret_cast<uint32_t*>(smem);                     // [ceil(n_cand / 32)]
+  const int words = (int)((n_cand + 31) / 32);
+  uint32_t* filt = reinterpret_cast<uint32_t*>(smem);                     // [words]  filtered ids
+  uint32_t* skip = filt + words;                                          // [words]  filtered or gold: never counted
   __shared__ int red[4][GOLD_B];
   __shared__ uint64_t gkeys[GOLD_B];
   const int64_t b = blockIdx.x;
   const float* row = scores + b * lds;
   const bool desc = descending != 0;
-  const int words = (int)((n_cand + 31) / 32);
-  for (int i = threadIdx.x; i < words; i += 256) skip[i] = 0u;
+  for (int i = threadIdx.x; i < words; i += 256) filt[i] = 0u;
   __syncthreads();
   const int64_t f0 = filt_off ? filt_off[b] : 0, f1 = filt_off ? filt_off[b + 1] : 0;
   for (int64_t f = f0 + threadIdx.x; f < f1; f += 256) {
     const int32_t id = filt_ids[f];
-    if (id >= 0 && id < n_cand) atomicOr(skip + (id >> 5), 1u << (id & 31));
+    if (id >= 0 && id < n_cand) atomicOr(filt + (id >> 5), 1u << (id & 31));
   }
   __syncthreads();
+  for (int i = threadIdx.x; i < words; i += 256) skip[i] = filt[i];
+  __syncthreads();
   const int64_t g0 = gold_off[b], g1 = gold_off[b + 1];
-  // a gold that is itself filtered is never reached by the reference's walk (rank -1): decide that before the golds join the skip set
+  for (int64_t o = g0 + threadIdx.x; o < g1; o += 256) {
+    const int32_t og = gold_ids[o];
+    if (og >= 0 && og < n_cand) atomicOr(skip + (og >> 5), 1u << (og & 31));
+  }
+  __syncthreads();
   for (int64_t gb = g0; gb < g1; gb += GOLD_B) {
     if (threadIdx.x < GOLD_B) {
       const int64_t gi = gb + threadIdx.x;
       uint64_t k = KEY_MAX;
       if (gi < g1) {
         const int32_t g = gold_ids[gi];
-        if (g >= 0 && g < n_cand && !((skip[g >> 5] >> (g & 31)) & 1u)) k = make_key(row[g], desc, (uint32_t)g);
+        if (g >= 0 && g < n_cand && !((filt[g >> 5] >> (g & 31)) & 1u)) k = make_key(row[g], desc, (uint32_t)g);
       }
       gkeys[threadIdx.x] = k;
     }
     __syncthreads();
-    if (gb == g0) {                                                       // all golds of the query leave the counted set (once)
-      for (int64_t o = g0 + threadIdx.x; o < g1; o += 256) {
-        const int32_t og = gold_ids[o];
-        if (og >= 0 && og < n_cand) atomicOr(skip + (og >> 5), 1u << (og & 31));
-      }
-      __syncthreads();
-    }
     uint64_t gk[GOLD_B];
     int cnt[GOLD_B];
 #pragma unroll
     for (int i = 0; i < GOLD_B; ++i) { gk[i] = gkeys[i]; cnt[i] = 0; }
-    for (int64_t j = threadIdx.x; j < n_cand; j += 256) {
-      if ((skip[j >> 5] >> (j & 31)) & 1u) continue;
-      const uint64_t k = make_key(row[j], desc, (uint32_t)j);
+    for (int64_t j0 = threadIdx.x; j0 < n_cand; j0 += 256 * STREAM_U) {
+      float v[STREAM_U];
 #pragma unroll
-      for (int i = 0; i < GOLD_B; ++i) cnt[i] += k < gk[i] ? 1 : 0;
+      for (int u = 0; u < STREAM_U; ++u) {
+        const int64_t j = j0 + 256 * u;
+        v[u] = row[j < n_cand ? j : 0];
+      }
+#pragma unroll
+      for (int u = 0; u < STREAM_U; ++u) {
+        const int64_t j = j0 + 256 * u;
+        const bool on = j < n_cand && !((skip[(j < n_cand ? j : 0) >> 5] >> (j & 31)) & 1u);
+        const uint64_t k = on ? make_key(v[u], desc, (uint32_t)j) : KEY_MAX;     // KEY_MAX is below no gold key
+#pragma unroll
+        for (int i = 0; i < GOLD_B; ++i) cnt[i] += k < gk[i] ? 1 : 0;
+      }
     }
 #pragma unroll
     for (int i = 0; i < GOLD_B; ++i) {
@@ -438,24 +414,17 @@ extern "C" int ktup_eval_gold_ranks(const float* scores, int64_t lds, int64_t nq
   if (nq == 0) return KTUP_OK;
   KTUP_REQUIRE(scores && gold_off && gold_ids && ranks && ((filt_off == nullptr) || filt_ids), "%s: null pointer argument", name);
   KTUP_REQUIRE(n_cand <= 0x7fffffffll, "%s: candidate ids are 32-bit", name);
-  if (const int ch = chunk_for(n_cand)) {
+  if (const int ch = (ktup::opt_rank_chunk() > 0 || n_cand > STREAM_MAX_CAND) ? chunk_for(n_cand) : 0) {
     const size_t lbytes = (size_t)ch * 8;
     allow_lds((const void*)gold_ranks_chunked_kernel, lbytes);
     hipLaunchKernelGGL(gold_ranks_chunked_kernel, dim3((unsigned)nq), dim3(256), lbytes, (hipStream_t)stream, scores, lds, n_cand,
                        descending, filt_off, filt_ids, gold_off, gold_ids, ch, ranks);
     return check_launch(name);
   }
-  if (n_cand <= STREAM_MAX_CAND) {
-    const size_t lbytes = (size_t)((n_cand + 31) / 32) * 4;
-    allow_lds((const void*)gold_ranks_stream_kernel, lbytes);
-    hipLaunchKernelGGL(gold_ranks_stream_kernel, dim3((unsigned)nq), dim3(256), lbytes, (hipStream_t)stream, scores, lds, n_cand, descending,
-                       filt_off, filt_ids, gold_off, gold_ids, ranks);
-    return check_launch(name);
-  }
-  size_t bytes = 0;
-  if (int e = prep_lds((const void*)gold_ranks_kernel, n_cand, &bytes, name)) return e;
-  hipLaunchKernelGGL(gold_ranks_kernel, dim3((unsigned)nq), dim3(256), bytes, (hipStream_t)stream, scores, lds, n_cand,
-                     descending, filt_off, filt_ids, gold_off, gold_ids, ranks);
+  const size_t lbytes = (size_t)((n_cand + 31) / 32) * 8;
+  allow_lds((const void*)gold_ranks_stream_kernel, lbytes);
+  hipLaunchKernelGGL(gold_ranks_stream_kernel, dim3((unsigned)nq), dim3(256), lbytes, (hipStream_t)stream, scores, lds, n_cand, descending,
+                     filt_off, filt_ids, gold_off, gold_ids, ranks);
   return check_launch(name);
 }
 

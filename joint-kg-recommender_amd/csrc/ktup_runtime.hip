@@ -41,6 +41,7 @@ Option g_opts[] = {
     {"rank_chunk", "KTUP_RANK_CHUNK", {env_int("KTUP_RANK_CHUNK", 0)}}, // > 0: force the chunked ranking kernels with this chunk size
     {"seg_bwd_min", "KTUP_SEG_BWD_MIN", {env_int("KTUP_SEG_BWD_MIN", 8192)}},   // rows from which the backward kernels reduce row gradients by segments (0: never)
     {"bwd_wide_max", "KTUP_BWD_WIDE_MAX", {env_int("KTUP_BWD_WIDE_MAX", 4096)}},   // K5-K7 backward: pairs up to which four waves share a 16-pair tile (d <= 128)
+    {"side_sort", "KTUP_SIDE_SORT", {env_int("KTUP_SIDE_SORT", 1)}},    // 0: the id sorts of the segment reductions stay on the caller's stream
 };
 Option* find(const char* name) {
   for (auto& o : g_opts)
@@ -54,6 +55,48 @@ int opt_eval_mc() { return g_opts[1].value.load(std::memory_order_relaxed); }
 int opt_rank_chunk() { return g_opts[2].value.load(std::memory_order_relaxed); }
 int opt_seg_bwd_min() { return g_opts[3].value.load(std::memory_order_relaxed); }
 int opt_bwd_wide_max() { return g_opts[4].value.load(std::memory_order_relaxed); }
+
+// A library-owned second stream for work that depends only on a call's INPUTS (the counting sorts of the segment reductions)
+// while the caller's stream runs the kernel that produces the data: fork_side makes it wait for everything enqueued on `st` so far,
+// join_side makes `st` wait for it.  Returns nullptr (the caller stays on `st`) when switched off, while `st` is being captured
+// into a graph, or when the stream / events cannot be made.
+namespace {
+struct Side {
+  hipStream_t stream = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
+  bool tried = false;
+} g_side;
+}  // namespace
+
+hipStream_t fork_side(hipStream_t st) {
+  if (!g_opts[5].value.load(std::memory_order_relaxed)) return nullptr;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  if (!g_side.tried) {
+    g_side.tried = true;
+    if (hipStreamCreateWithFlags(&g_side.stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&g_side.fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&g_side.join, hipEventDisableTiming) != hipSuccess) {
+      (void)hipGetLastError();
+      g_side.stream = nullptr;
+    }
+  }
+  if (!g_side.stream) return nullptr;
+  if (hipEventRecord(g_side.fork, st) != hipSuccess || hipStreamWaitEvent(g_side.stream, g_side.fork, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  return g_side.stream;
+}
+
+void join_side(hipStream_t st, hipStream_t side) {
+  if (!side) return;
+  (void)hipEventRecord(g_side.join, side);
+  (void)hipStreamWaitEvent(st, g_side.join, 0);
+}
 
 }  // namespace ktup
 

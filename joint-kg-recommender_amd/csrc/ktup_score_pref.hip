@@ -568,22 +568,37 @@ int run_pref(bool bwd, const char* name, const float* U, int64_t ldu, const floa
       // large batches with a workspace: per-pair row gradients by plain stores + a reduction by sorted segments instead of
       // d float atomics per gathered row (ktup_segreduce.hip)
       const size_t gbytes = (((size_t)n * d * sizeof(float)) + 255) & ~(size_t)255;
-      float* GU = nullptr; float* GV = nullptr; char* sws = nullptr;
+      float* GU = nullptr; float* GV = nullptr; char* swsU = nullptr; char* swsI = nullptr;
       if (bws && n_user_rows > 0 && n_item_rows > 0 && opt_seg_bwd_min() > 0 && n >= opt_seg_bwd_min() && (d == 64 || d == 100 || d == 128 || d == 256)) {
         GU = reinterpret_cast<float*>(bws);
         GV = reinterpret_cast<float*>(reinterpret_cast<char*>(bws) + gbytes);
-        sws = reinterpret_cast<char*>(bws) + 2 * gbytes;
+        swsU = reinterpret_cast<char*>(bws) + 2 * gbytes;
+        swsI = swsU + seg_ws_bytes(n, n_user_rows);
+        if (!seg_covers(GU, d, d, n, n, n_user_rows, gU, ldu, nullptr, nullptr, 0, swsU) ||
+            !seg_covers(GV, d, d, n, n, n_item_rows, gI, ldi, E ? item2ent : nullptr, gE, lde, swsI))
+          return set_error(KTUP_ERR_UNSUPPORTED, "%s: segment reduction does not cover this shape", name);
+      }
+      // the two counting sorts depend on the ids alone: they run on the library's side stream beside the gradient kernel
+      hipStream_t side = nullptr;
+      if (GU) {
+        side = fork_side(st);
+        hipStream_t ss = side ? side : st;
+        int r1 = seg_sort(u_ids, nullptr, n, n, n_user_rows, swsU, ss, name);
+        if (r1 == KTUP_OK) r1 = seg_sort(i_ids, nullptr, n, n, n_item_rows, swsI, ss, name);
+        if (r1 != KTUP_OK) { join_side(st, side); return r1; }
       }
       const int rc = pref_bwd_mc(reinterpret_cast<const float*>(a.U), a.ldu4 * 4, reinterpret_cast<const float*>(a.I), a.ldi4 * 4,
                                  reinterpret_cast<const float*>(a.E), a.lde4 * 4, a.item2ent, a.ent_pad, reinterpret_cast<const float*>(a.Alog),
                                  reinterpret_cast<const float*>(a.Ar), reinterpret_cast<const float*>(a.Cn), a.dp4 * 4, a.alpha_beta, n_pref, d,
                                  a.u_ids, a.i_ids, a.n, a.l1, a.gumbel, a.uniform, a.seed, a.offset, a.gscore, a.gU, a.gI, a.gE, a.gA, a.gC, st,
                                  name, GU, GV);
+      join_side(st, side);
       if (rc == KTUP_OK && GU) {
-        int r2 = seg_reduce(GU, d, d, n, u_ids, n, n, n_user_rows, gU, ldu, nullptr, -1, nullptr, 0, sws, st, name);
-        if (r2 == KTUP_OK)
-          r2 = seg_reduce(GV, d, d, n, i_ids, n, n, n_item_rows, gI, ldi, E ? item2ent : nullptr, ent_pad, gE, lde, sws, st, name);
-        if (r2 == 1) return set_error(KTUP_ERR_UNSUPPORTED, "%s: segment reduction does not cover this shape", name);
+        // the two reductions touch disjoint tables (gU | gI, gE): side by side, each alone is bound by the latency of its row gathers
+        hipStream_t s2 = fork_side(st);
+        int r2 = seg_apply(GU, d, d, n, n, n, n_user_rows, gU, ldu, nullptr, -1, nullptr, 0, swsU, s2 ? s2 : st, name);
+        if (r2 == KTUP_OK) r2 = seg_apply(GV, d, d, n, n, n, n_item_rows, gI, ldi, E ? item2ent : nullptr, ent_pad, gE, lde, swsI, st, name);
+        join_side(st, s2);
         return r2;
       }
       if (rc != 1) return rc;
@@ -668,7 +683,7 @@ extern "C" size_t ktup_score_pref_bwd_workspace_bytes(int64_t n, int d, int64_t 
   if (n <= 0 || d <= 0 || n_user_rows <= 0 || n_item_rows <= 0) return 0;
   if (opt_seg_bwd_min() <= 0 || n < opt_seg_bwd_min() || !(d == 64 || d == 100 || d == 128 || d == 256)) return 0;
   const size_t gbytes = (((size_t)n * d * sizeof(float)) + 255) & ~(size_t)255;
-  return 2 * gbytes + seg_ws_bytes(n, n_user_rows > n_item_rows ? n_user_rows : n_item_rows);
+  return 2 * gbytes + seg_ws_bytes(n, n_user_rows) + seg_ws_bytes(n, n_item_rows);     // both sorts are alive at once
 }
 
 extern "C" int ktup_score_tup_bwd_ws(const float* U, int64_t ldu, const float* I, int64_t ldi, const float* pref_ws, int n_pref,

@@ -40,10 +40,14 @@ struct BGeom {
   static constexpr int RP = PITCHA4 * 4;                   // the same rows serve the K = preference GEMMs: float pitch of a slot row
   static constexpr size_t TABLE_BYTES = (size_t)3 * SLOT_F4 * 16;
   static constexpr int TILE_F4 = 16 * NCH + 3;             // one (16 pairs x d) tile + 3 zero chunks
-  static constexpr int LT_F = TROW * 17;                   // transposed [preference][pair] arrays, pitch 17
+  static constexpr int LROW = 4 * NP;                      // rows of the transposed arrays that are kept (P <= 4 NP)
+  static constexpr int LT_F = LROW * 17;                   // transposed [preference][pair] arrays, pitch 17
   static constexpr int NOISE_F = HARD ? 16 * TROW : 0;     // HARD: Gumbel noise of the tile, [pair][preference]
-  static constexpr size_t WAVE_BYTES = ((size_t)4 * TILE_F4 * 16 + (size_t)2 * LT_F * 4 + 3 * 16 * 4 + (size_t)NOISE_F * 4 + 15) & ~(size_t)15;
-  static constexpr int NW = TABLE_BYTES + 3 * WAVE_BYTES <= 160 * 1024 ? 3 : TABLE_BYTES + 2 * WAVE_BYTES <= 160 * 1024 ? 2 : 1;
+  static constexpr size_t WAVE_BYTES = ((size_t)4 * TILE_F4 * 16 + (size_t)2 * LT_F * 4 + 2 * 3 * 16 * 4 + (size_t)NOISE_F * 4 + 15) & ~(size_t)15;
+  static constexpr int NW = TABLE_BYTES + 4 * WAVE_BYTES <= 160 * 1024   ? 4      // one wave per SIMD: the accumulators alone are 112 registers
+                            : TABLE_BYTES + 3 * WAVE_BYTES <= 160 * 1024 ? 3
+                            : TABLE_BYTES + 2 * WAVE_BYTES <= 160 * 1024 ? 2
+                                                                         : 1;
   static constexpr size_t LDS = TABLE_BYTES + NW * WAVE_BYTES;
 };
 
@@ -91,8 +95,8 @@ __global__ __launch_bounds__(G::NW * 64) void pref_bwd_mc_kernel(BArgs a) {
   v4* GNT = GRT + G::TILE_F4;                                 // gn
   float* LT = reinterpret_cast<float*>(GNT + G::TILE_F4);     // [TROW][17]  beta * L   (transposed: preference major)
   float* GLT = LT + G::LT_F;                                  // [TROW][17]  gL / 2
-  int32_t* sid = reinterpret_cast<int32_t*>(GLT + G::LT_F);   // [3][16]
-  float* noise = reinterpret_cast<float*>(sid + 48);         // HARD: [16][TROW]
+  int32_t* sid2 = reinterpret_cast<int32_t*>(GLT + G::LT_F);  // [2][3][16]: ids of this tile and of the next one
+  float* noise = reinterpret_cast<float*>(sid2 + 96);        // HARD: [16][TROW]
   // ---- stage the three tables in both layouts
   {
     const int P = a.P, dp = a.dp;                              // float4 granularity: rows are 16-byte aligned, pitch % 4 == 0
@@ -130,40 +134,62 @@ __global__ __launch_bounds__(G::NW * 64) void pref_bwd_mc_kernel(BArgs a) {
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) { accA[pt][ct] = (v4){0.f, 0.f, 0.f, 0.f}; accC[pt][ct] = accA[pt][ct]; }
   const int64_t ntiles = (a.n + 15) / 16;
-  for (int64_t tile_id = (int64_t)blockIdx.x * NW + w; tile_id < ntiles; tile_id += (int64_t)gridDim.x * NW) {
+  const int64_t tstride = (int64_t)gridDim.x * NW;
+  // The gathers run one tile ahead of the arithmetic (a wave is alone on its SIMD: nothing else hides three dependent
+  // trips to memory per tile).  Ids are fetched three tiles ahead, the entity id two tiles ahead, the rows one tile ahead.
+  auto load_ui = [&](int64_t tile, int32_t& u, int32_t& i) {
+    const int64_t gr = tile * 16 + j;
+    const bool ok = lane < 16 && gr < a.n;                    // tiles past the end: id 0 (row 0 is fetched and never used)
+    u = ok ? (int32_t)a.u_ids[gr] : 0;
+    i = ok ? (int32_t)a.i_ids[gr] : 0;
+  };
+  auto load_e = [&](int32_t i) -> int32_t { return (HASE && lane < 16) ? a.item2ent[i] : 0; };
+  v4 uu[J], vv[J], ee[J];
+  auto gather = [&](const int32_t* sid) {
+#pragma unroll
+    for (int jj = 0; jj < J; ++jj) {
+      asm volatile("" : "+v"(gc[jj]));
+      const uint32_t idu = (uint32_t)sid[grow[jj]], idi = (uint32_t)sid[16 + grow[jj]];
+      uu[jj] = a.U[(uint64_t)idu * a.ldu4 + (uint32_t)gc[jj]];
+      vv[jj] = a.I[(uint64_t)idi * a.ldi4 + (uint32_t)gc[jj]];
+      if (HASE) {
+        const uint32_t ide = (uint32_t)sid[32 + grow[jj]];
+        ee[jj] = a.E[(uint64_t)ide * a.lde4 + (uint32_t)gc[jj]];
+      }
+    }
+  };
+  auto put_ids = [&](int32_t* sid, int32_t u, int32_t i, int32_t e) {
+    if (lane < 16) { sid[lane] = u; sid[16 + lane] = i; sid[32 + lane] = e; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  };
+  const int64_t tile0 = (int64_t)blockIdx.x * NW + w;
+  int32_t nu1 = 0, ni1 = 0, ne1 = 0, nu2 = 0, ni2 = 0, ne2 = 0, nu3 = 0, ni3 = 0;
+  int cb = 0;
+  if (tile0 < ntiles) {
+    int32_t nu0, ni0;
+    load_ui(tile0, nu0, ni0);
+    load_ui(tile0 + tstride, nu1, ni1);
+    load_ui(tile0 + 2 * tstride, nu2, ni2);
+    const int32_t ne0 = load_e(ni0);
+    ne1 = load_e(ni1);
+    put_ids(sid2, nu0, ni0, ne0);
+    gather(sid2);
+  }
+  for (int64_t tile_id = tile0; tile_id < ntiles; tile_id += tstride) {
     const int64_t row0 = tile_id * 16;
-    if (lane < 16) {
-      const int64_t gr = row0 + lane;
-      const bool ok = gr < a.n;
-      const int64_t uid = ok ? a.u_ids[gr] : 0, iid = ok ? a.i_ids[gr] : 0;
-      sid[lane] = (int32_t)uid;
-      sid[16 + lane] = (int32_t)iid;
-      sid[32 + lane] = HASE ? a.item2ent[iid] : 0;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    // ---- gather: x and q tiles
-    {
-      v4 uu[J], vv[J], ee[J];
+    const int32_t* sid = sid2 + 48 * cb;
+    // ---- x and q tiles from the rows fetched during the previous tile
 #pragma unroll
-      for (int jj = 0; jj < J; ++jj) {
-        asm volatile("" : "+v"(gc[jj]));
-        const uint32_t idu = (uint32_t)sid[grow[jj]], idi = (uint32_t)sid[16 + grow[jj]];
-        uu[jj] = a.U[(uint64_t)idu * a.ldu4 + (uint32_t)gc[jj]];
-        vv[jj] = a.I[(uint64_t)idi * a.ldi4 + (uint32_t)gc[jj]];
-        if (HASE) {
-          const uint32_t ide = (uint32_t)sid[32 + grow[jj]];
-          ee[jj] = a.E[(uint64_t)ide * a.lde4 + (uint32_t)gc[jj]];
-        }
-      }
-#pragma unroll
-      for (int jj = 0; jj < J; ++jj) {
-        const v4 ve = HASE ? vv[jj] + ee[jj] : vv[jj];
-        if (jj < J - 1 || last_ok) { XT[lane + 64 * jj] = uu[jj] + ve; QT[lane + 64 * jj] = uu[jj] + (-ve); }
-      }
+    for (int jj = 0; jj < J; ++jj) {
+      const v4 ve = HASE ? vv[jj] + ee[jj] : vv[jj];
+      if (jj < J - 1 || last_ok) { XT[lane + 64 * jj] = uu[jj] + ve; QT[lane + 64 * jj] = uu[jj] + (-ve); }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+    // ---- next tile: ids to LDS, rows in flight; the id fetches of the tiles after it
+    put_ids(sid2 + 48 * (cb ^ 1), nu1, ni1, ne1);                 // (its fence also publishes XT / QT)
+    ne2 = load_e(ni2);
+    load_ui(tile_id + 3 * tstride, nu3, ni3);
+    gather(sid2 + 48 * (cb ^ 1));
     // ---- A1: L^T.  lg[tt][reg] of lane (kq, pair j) = logit of preference 16 tt + 4 reg + kq
     v4 lg[PT];
 #pragma unroll
@@ -316,8 +342,10 @@ __global__ __launch_bounds__(G::NW * 64) void pref_bwd_mc_kernel(BArgs a) {
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
         const int p = 16 * tt + 4 * reg + kq;
-        LT[p * 17 + j] = beta * lg[tt][reg];
-        GLT[p * 17 + j] = 0.5f * gl[tt][reg];
+        if (16 * tt + 4 * reg + 3 < G::LROW || p < G::LROW) {
+          LT[p * 17 + j] = beta * lg[tt][reg];
+          GLT[p * 17 + j] = 0.5f * gl[tt][reg];
+        }
       }
     // ---- C: gx^T = Alog2^T . gL^T, then the row gradients
     {
@@ -361,7 +389,11 @@ __global__ __launch_bounds__(G::NW * 64) void pref_bwd_mc_kernel(BArgs a) {
       for (int st = 0; st < 4; ++st) {
         float al[PT], agl[PT];
 #pragma unroll
-        for (int pt = 0; pt < PT; ++pt) { al[pt] = LT[(16 * pt + j) * 17 + 4 * st + kq]; agl[pt] = GLT[(16 * pt + j) * 17 + 4 * st + kq]; }
+        for (int pt = 0; pt < PT; ++pt) {                       // rows past LROW: any finite value (their accumulators are never flushed)
+          const int pr = min(16 * pt + j, G::LROW - 1);
+          al[pt] = LT[pr * 17 + 4 * st + kq];
+          agl[pt] = GLT[pr * 17 + 4 * st + kq];
+        }
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
           const int col = 16 * ct + j;
@@ -379,6 +411,8 @@ __global__ __launch_bounds__(G::NW * 64) void pref_bwd_mc_kernel(BArgs a) {
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    nu1 = nu2; ni1 = ni2; ne1 = ne2; nu2 = nu3; ni2 = ni3;
+    cb ^= 1;
   }
   // ---- flush the table gradients: lane (kq, n) holds preference 16 pt + 4 kq + reg, coordinate 16 ct + n
 #pragma unroll

@@ -708,7 +708,7 @@ static bool transr_seg(int64_t n, int64_t n_ent) { return n_ent > 0 && ktup::opt
 
 extern "C" size_t ktup_score_transr_bwd_workspace_bytes(int64_t n, int d, int64_t n_ent, int64_t n_rel) {
   if (n <= 0 || n_rel <= 0 || (d != 64 && d != 100 && d != 128)) return 0;
-  return transr_bucket_bytes(n, n_rel) + (transr_seg(n, n_ent) ? g_bytes(n, d) + ktup::seg_ws_bytes(n, n_ent) : 0);
+  return transr_bucket_bytes(n, n_rel) + (transr_seg(n, n_ent) ? g_bytes(n, d) + ktup::seg_ws_bytes(2 * n, n_ent) : 0);
 }
 
 extern "C" int ktup_score_transr_bwd_ws(const float* E, int64_t lde, const float* R, int64_t ldr, const float* M, int64_t ldm,
@@ -721,13 +721,17 @@ extern "C" int ktup_score_transr_bwd_ws(const float* E, int64_t lde, const float
     const bool seg = transr_seg(n, n_ent);
     char* base = reinterpret_cast<char*>(ws) + transr_bucket_bytes(n, n_rel);
     float* G = seg ? reinterpret_cast<float*>(base) : nullptr;
-    int rc = ktup::transr_bwd_mc(E, lde, R, ldr, M, ldm, n_rel, d, h, t, r, n, l1, gscore, gE, gR, gM, G, ws, st, name);
-    if (rc == KTUP_OK && seg) {
-      void* sws = base + g_bytes(n, d);
-      rc = ktup::seg_reduce(G, d, d, n, h, n, n, n_ent, gE, lde, nullptr, -1, nullptr, 0, sws, st, name);
-      if (rc == KTUP_OK) rc = ktup::seg_reduce(G, d, d, n, t, n, 0, n_ent, gE, lde, nullptr, -1, nullptr, 0, sws, st, name);
-      if (rc == 1) return set_error(KTUP_ERR_UNSUPPORTED, "%s: segment reduction does not cover this shape", name);
+    void* sws = base + g_bytes(n, d);
+    hipStream_t side = nullptr;
+    if (seg) {     // heads then tails in ONE counting sort (gE[h] += G, gE[t] -= G), on the side stream beside the gradient kernel
+      if (!ktup::seg_covers(G, d, d, n, 2 * n, n_ent, gE, lde, nullptr, nullptr, 0, sws))
+        return set_error(KTUP_ERR_UNSUPPORTED, "%s: segment reduction does not cover this shape", name);
+      side = ktup::fork_side(st);
+      if (int e = ktup::seg_sort(h, t, n, 2 * n, n_ent, sws, side ? side : st, name)) { ktup::join_side(st, side); return e; }
     }
+    int rc = ktup::transr_bwd_mc(E, lde, R, ldr, M, ldm, n_rel, d, h, t, r, n, l1, gscore, gE, gR, gM, G, ws, st, name);
+    ktup::join_side(st, side);
+    if (rc == KTUP_OK && seg) rc = ktup::seg_apply(G, d, d, n, 2 * n, n, n_ent, gE, lde, nullptr, -1, nullptr, 0, sws, st, name);
     if (rc != 1) return rc;
   }
   return transr_launch(true, E, lde, R, ldr, M, ldm, d, h, t, r, n, l1, nullptr, gscore, gE, gR, gM, stream, name);
@@ -743,9 +747,14 @@ extern "C" size_t ktup_score_kg_bwd_workspace_bytes(int64_t n, int d, int64_t n_
 static int kg_bwd_seg(bool transh, const char* name, const float* E, int64_t lde, const float* R, int64_t ldr, const float* Nrm, int64_t ldn,
                       int d, const int64_t* h, const int64_t* t, const int64_t* r, int64_t n, int l1, const float* gscore, float* gE,
                       float* gR, float* gN, int64_t n_ent, int64_t n_rel, void* ws, hipStream_t st) {
-  // ids of the two roles, heads then tails, for ONE sort: they must be contiguous -> copy into the workspace tail
   float* G = reinterpret_cast<float*>(ws);
   char* sws = reinterpret_cast<char*>(ws) + g_bytes(n, d);
+  // ids of the two roles, heads then tails, in ONE counting sort (gE[h] += G, gE[t] -= G); it depends on the ids alone and
+  // runs on the library's side stream beside the gradient kernel
+  if (!ktup::seg_covers(G, d, d, n, 2 * n, n_ent, gE, lde, nullptr, nullptr, 0, sws))
+    return set_error(KTUP_ERR_UNSUPPORTED, "%s: segment reduction does not cover this shape", name);
+  hipStream_t side = ktup::fork_side(st);
+  if (int e = ktup::seg_sort(h, t, n, 2 * n, n_ent, sws, side ? side : st, name)) { ktup::join_side(st, side); return e; }
   KgSegArgs a{E, R, Nrm, lde, ldr, ldn, h, t, r, n, d / 4, d, (int)n_rel, l1 != 0, gscore, G, gR, gN};
   const size_t lds = (size_t)(transh ? 2 : 1) * n_rel * d * sizeof(float);
   const int nch = d / 4;
@@ -769,12 +778,9 @@ static int kg_bwd_seg(bool transh, const char* name, const float* E, int64_t lde
   }
   if (nch <= 16) KTUP_KGSEG(16) else if (nch <= 32) KTUP_KGSEG(32) else KTUP_KGSEG(64)
 #undef KTUP_KGSEG
+  ktup::join_side(st, side);
   if (int e = check_launch(name)) return e;
-  // gE[h] += G, gE[t] -= G: two passes over the same G (ids of one role each) keep the id arrays where the caller has them
-  int rc = ktup::seg_reduce(G, d, d, n, h, n, n, n_ent, gE, lde, nullptr, -1, nullptr, 0, sws, st, name);
-  if (rc == KTUP_OK) rc = ktup::seg_reduce(G, d, d, n, t, n, 0, n_ent, gE, lde, nullptr, -1, nullptr, 0, sws, st, name);
-  if (rc == 1) return set_error(KTUP_ERR_UNSUPPORTED, "%s: segment reduction does not cover this shape", name);
-  return rc;
+  return ktup::seg_apply(G, d, d, n, 2 * n, n, n_ent, gE, lde, nullptr, -1, nullptr, 0, sws, st, name);
 }
 
 extern "C" int ktup_score_transe_bwd_ws(const float* E, int64_t lde, const float* R, int64_t ldr, int d, const int64_t* h,
@@ -804,7 +810,7 @@ extern "C" int ktup_score_transh_bwd_ws(const float* E, int64_t lde, const float
 
 extern "C" size_t ktup_score_bprmf_bwd_workspace_bytes(int64_t n, int d, int64_t n_users, int64_t n_items) {
   if (n <= 0 || d <= 0 || d % 4 || n_users <= 0 || n_items <= 0 || ktup::opt_seg_bwd_min() <= 0 || n < ktup::opt_seg_bwd_min()) return 0;
-  return 2 * g_bytes(n, d) + ktup::seg_ws_bytes(n, n_users > n_items ? n_users : n_items);
+  return 2 * g_bytes(n, d) + ktup::seg_ws_bytes(n, n_users) + ktup::seg_ws_bytes(n, n_items);
 }
 
 extern "C" int ktup_score_bprmf_bwd_ws(const float* U, int64_t ldu, const float* I, int64_t ldi, int d, const int64_t* u_ids,
@@ -819,7 +825,17 @@ extern "C" int ktup_score_bprmf_bwd_ws(const float* U, int64_t ldu, const float*
   hipStream_t st = (hipStream_t)stream;
   float* GU = reinterpret_cast<float*>(ws);
   float* GI = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + g_bytes(n, d));
-  char* sws = reinterpret_cast<char*>(ws) + 2 * g_bytes(n, d);
+  char* swsU = reinterpret_cast<char*>(ws) + 2 * g_bytes(n, d);
+  char* swsI = swsU + ktup::seg_ws_bytes(n, n_users);
+  if (!ktup::seg_covers(GU, d, d, n, n, n_users, gU, ldu, nullptr, nullptr, 0, swsU) || !ktup::seg_covers(GI, d, d, n, n, n_items, gI, ldi, nullptr, nullptr, 0, swsI))
+    return set_error(KTUP_ERR_UNSUPPORTED, "%s: segment reduction does not cover this shape", name);
+  hipStream_t side = ktup::fork_side(st);
+  {
+    hipStream_t ss = side ? side : st;
+    int e = ktup::seg_sort(u_ids, nullptr, n, n, n_users, swsU, ss, name);
+    if (e == KTUP_OK) e = ktup::seg_sort(i_ids, nullptr, n, n, n_items, swsI, ss, name);
+    if (e != KTUP_OK) { ktup::join_side(st, side); return e; }
+  }
   BprmfSegArgs a{U, I, ldu, ldi, u_ids, i_ids, n, d / 4, d, gscore, GU, GI};
   const int nch = d / 4;
 #define KTUP_BSEG(GL)                                                                                         \
@@ -828,9 +844,11 @@ extern "C" int ktup_score_bprmf_bwd_ws(const float* U, int64_t ldu, const float*
   }
   if (nch <= 16) KTUP_BSEG(16) else if (nch <= 32) KTUP_BSEG(32) else KTUP_BSEG(64)
 #undef KTUP_BSEG
+  ktup::join_side(st, side);
   if (int e = check_launch(name)) return e;
-  int rc = ktup::seg_reduce(GU, d, d, n, u_ids, n, n, n_users, gU, ldu, nullptr, -1, nullptr, 0, sws, st, name);
-  if (rc == KTUP_OK) rc = ktup::seg_reduce(GI, d, d, n, i_ids, n, n, n_items, gI, ldi, nullptr, -1, nullptr, 0, sws, st, name);
-  if (rc == 1) return set_error(KTUP_ERR_UNSUPPORTED, "%s: segment reduction does not cover this shape", name);
+  hipStream_t s2 = ktup::fork_side(st);      // disjoint tables: the two reductions run side by side
+  int rc = ktup::seg_apply(GU, d, d, n, n, n, n_users, gU, ldu, nullptr, -1, nullptr, 0, swsU, s2 ? s2 : st, name);
+  if (rc == KTUP_OK) rc = ktup::seg_apply(GI, d, d, n, n, n, n_items, gI, ldi, nullptr, -1, nullptr, 0, swsI, st, name);
+  ktup::join_side(st, s2);
   return rc;
 }

@@ -16,27 +16,30 @@
 namespace ktup {
 namespace {
 
-constexpr int SCAN_T = 1024;
+constexpr int SCAN_T = 256;    // one wave per SIMD and few registers: the scan must fit on a CU beside a gradient kernel that holds
+                               // most of its registers and LDS (it runs on the side stream, ktup_runtime.hip fork_side)
+constexpr int SCAN_V = 8;      // counters per thread per sweep
 
-__global__ __launch_bounds__(256) void seg_hist_kernel(const int64_t* __restrict__ ids, int64_t m, int32_t* __restrict__ start,
-                                                       int32_t* __restrict__ rank) {
+// entries [0, n_src) take their key from ids, entries [n_src, m) from ids2 (the two roles of a triple's entities: one sort)
+__global__ __launch_bounds__(256) void seg_hist_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ ids2, int64_t n_src,
+                                                       int64_t m, int32_t* __restrict__ start, int32_t* __restrict__ rank) {
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < m; e += (int64_t)gridDim.x * 256)
-    rank[e] = atomicAdd(start + ids[e], 1);
+    rank[e] = atomicAdd(start + (e < n_src ? ids[e] : ids2[e - n_src]), 1);
 }
 
-// exclusive scan in place over K + 1 counters (the last one receives the total); one workgroup, SCAN_T x 4 items per sweep
+// exclusive scan in place over K + 1 counters (the last one receives the total); one workgroup, SCAN_T x SCAN_V items per sweep
 __global__ __launch_bounds__(SCAN_T) void seg_scan_kernel(int32_t* __restrict__ start, int64_t K) {
   __shared__ int32_t wsum[SCAN_T / 64];
   __shared__ int32_t carry_s;
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   if (t == 0) carry_s = 0;
   __syncthreads();
-  for (int64_t base = 0; base <= K; base += (int64_t)SCAN_T * 4) {
-    const int64_t i0 = base + (int64_t)t * 4;
-    int32_t v[4];
+  for (int64_t base = 0; base <= K; base += (int64_t)SCAN_T * SCAN_V) {
+    const int64_t i0 = base + (int64_t)t * SCAN_V;
+    int32_t v[SCAN_V];
+    int32_t mine = 0;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) v[c] = (i0 + c < K) ? start[i0 + c] : 0;
-    const int32_t mine = v[0] + v[1] + v[2] + v[3];
+    for (int c = 0; c < SCAN_V; ++c) { v[c] = (i0 + c < K) ? start[i0 + c] : 0; mine += v[c]; }
     int32_t inc = mine;                                         // inclusive scan over the wave
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -51,7 +54,7 @@ __global__ __launch_bounds__(SCAN_T) void seg_scan_kernel(int32_t* __restrict__ 
     for (int k = 0; k < SCAN_T / 64; ++k) total += wsum[k];
     int32_t run = carry_s + woff + inc - mine;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < SCAN_V; ++c) {
       if (i0 + c <= K) start[i0 + c] = run;                     // index K gets the grand total (its own count is 0)
       run += v[c];
     }
@@ -61,11 +64,11 @@ __global__ __launch_bounds__(SCAN_T) void seg_scan_kernel(int32_t* __restrict__ 
   }
 }
 
-__global__ __launch_bounds__(256) void seg_scatter_kernel(const int64_t* __restrict__ ids, int64_t m, const int32_t* __restrict__ start,
-                                                          const int32_t* __restrict__ rank, int32_t* __restrict__ perm,
-                                                          int32_t* __restrict__ skey) {
+__global__ __launch_bounds__(256) void seg_scatter_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ ids2, int64_t n_src,
+                                                          int64_t m, const int32_t* __restrict__ start, const int32_t* __restrict__ rank,
+                                                          int32_t* __restrict__ perm, int32_t* __restrict__ skey) {
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < m; e += (int64_t)gridDim.x * 256) {
-    const int64_t id = ids[e];
+    const int64_t id = e < n_src ? ids[e] : ids2[e - n_src];
     const int32_t pos = start[id] + rank[e];
     perm[pos] = (int32_t)e;
     skey[pos] = (int32_t)id;
@@ -142,11 +145,12 @@ __global__ __launch_bounds__(256) void seg_reduce_kernel(SegArgs a) {
 #pragma unroll
         for (int j = 0; j < CPL; ++j) acc[j] = f4zero();
       };
-      for (int64_t k = k0; k < k1; k += 4) {
-        int32_t key[4], e[4];
-        float4 v[4][CPL];
+      constexpr int UNR = CPL == 1 ? 8 : 4;                       // independent row reads in flight per lane
+      for (int64_t k = k0; k < k1; k += UNR) {
+        int32_t key[UNR], e[UNR];
+        float4 v[UNR][CPL];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {                             // four independent row reads in flight
+        for (int u = 0; u < UNR; ++u) {
           const bool on = k + u < k1;
           key[u] = on ? a.skey[k + u] : -1;
           e[u] = on ? a.perm[k + u] : 0;
@@ -159,7 +163,7 @@ __global__ __launch_bounds__(256) void seg_reduce_kernel(SegArgs a) {
           }
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < UNR; ++u) {
           if (key[u] < 0) break;
           if (key[u] != cur) { flush(cur, false); cur = key[u]; }
           const float sg = e[u] < a.sign_split ? 1.f : -1.f;
@@ -200,24 +204,32 @@ size_t seg_ws_bytes(int64_t m, int64_t n_rows) {
   return (((size_t)(n_rows + 1) + (size_t)3 * m) * sizeof(int32_t) + 15) & ~(size_t)15;
 }
 
-// gT[ids[e]] += sign(e) * G[e mod n_src]  for e in [0, m); sign = + for e < sign_split, - otherwise (m = n_src or 2 n_src).
-// Returns KTUP_OK / an error, or 1 when the shape is not covered (d % 4, alignment, sizes): the caller keeps its atomics.
-int seg_reduce(const float* G, int64_t ldg, int d, int64_t n_src, const int64_t* ids, int64_t m, int64_t sign_split, int64_t n_rows,
-               float* gT, int64_t ldt, const int32_t* map2, int64_t pad2, float* gT2, int64_t ldt2, void* ws, hipStream_t st,
-               const char* name) {
-  if (m == 0) return KTUP_OK;
+bool seg_covers(const float* G, int64_t ldg, int d, int64_t n_src, int64_t m, int64_t n_rows, const float* gT, int64_t ldt,
+                const int32_t* map2, const float* gT2, int64_t ldt2, const void* ws) {
   if (!ws || d % 4 || d > 1024 || ldg % 4 || ldt % 4 || (map2 && ldt2 % 4) || !aligned16(G) || !aligned16(gT) || (map2 && !aligned16(gT2)))
-    return 1;
-  if (m >= (1ll << 31) || n_rows >= (1ll << 31) || (m != n_src && m != 2 * n_src)) return 1;
+    return false;
+  return m < (1ll << 31) && n_rows < (1ll << 31) && (m == n_src || m == 2 * n_src);
+}
+
+int seg_sort(const int64_t* ids, const int64_t* ids2, int64_t n_src, int64_t m, int64_t n_rows, void* ws, hipStream_t st, const char* name) {
+  if (m == 0) return KTUP_OK;
   int32_t* start = reinterpret_cast<int32_t*>(ws);
   int32_t* rank = start + (n_rows + 1);
   int32_t* perm = rank + m;
   int32_t* skey = perm + m;
   if (hipMemsetAsync(start, 0, (size_t)(n_rows + 1) * sizeof(int32_t), st) != hipSuccess) return check_launch(name);
   const int gm = grid_for((m + 255) / 256, 2048);
-  hipLaunchKernelGGL(seg_hist_kernel, dim3(gm), dim3(256), 0, st, ids, m, start, rank);
+  hipLaunchKernelGGL(seg_hist_kernel, dim3(gm), dim3(256), 0, st, ids, ids2, n_src, m, start, rank);
   hipLaunchKernelGGL(seg_scan_kernel, dim3(1), dim3(SCAN_T), 0, st, start, n_rows);
-  hipLaunchKernelGGL(seg_scatter_kernel, dim3(gm), dim3(256), 0, st, ids, m, start, rank, perm, skey);
+  hipLaunchKernelGGL(seg_scatter_kernel, dim3(gm), dim3(256), 0, st, ids, ids2, n_src, m, start, rank, perm, skey);
+  return check_launch(name);
+}
+
+int seg_apply(const float* G, int64_t ldg, int d, int64_t n_src, int64_t m, int64_t sign_split, int64_t n_rows, float* gT, int64_t ldt,
+              const int32_t* map2, int64_t pad2, float* gT2, int64_t ldt2, const void* ws, hipStream_t st, const char* name) {
+  if (m == 0) return KTUP_OK;
+  const int32_t* perm = reinterpret_cast<const int32_t*>(ws) + (n_rows + 1) + m;
+  const int32_t* skey = perm + m;
   SegArgs a;
   a.G = reinterpret_cast<const float4*>(G); a.ldg4 = ldg / 4; a.nch = d / 4; a.n_src = n_src;
   a.perm = perm; a.skey = skey; a.m = m; a.sign_split = sign_split;
@@ -238,6 +250,17 @@ int seg_reduce(const float* G, int64_t ldg, int d, int64_t n_src, const int64_t*
   if (a.nch <= 128) KTUP_SEG(64, 2)
   KTUP_SEG(64, 4)
 #undef KTUP_SEG
+}
+
+// gT[ids[e]] += sign(e) * G[e mod n_src]  for e in [0, m); sign = + for e < sign_split, - otherwise (m = n_src or 2 n_src).
+// Returns KTUP_OK / an error, or 1 when the shape is not covered (d % 4, alignment, sizes): the caller keeps its atomics.
+int seg_reduce(const float* G, int64_t ldg, int d, int64_t n_src, const int64_t* ids, int64_t m, int64_t sign_split, int64_t n_rows,
+               float* gT, int64_t ldt, const int32_t* map2, int64_t pad2, float* gT2, int64_t ldt2, void* ws, hipStream_t st,
+               const char* name) {
+  if (m == 0) return KTUP_OK;
+  if (!seg_covers(G, ldg, d, n_src, m, n_rows, gT, ldt, map2, gT2, ldt2, ws)) return 1;
+  if (int e = seg_sort(ids, ids + n_src, n_src, m, n_rows, ws, st, name)) return e;
+  return seg_apply(G, ldg, d, n_src, m, sign_split, n_rows, gT, ldt, map2, pad2, gT2, ldt2, ws, st, name);
 }
 
 }  // namespace ktup

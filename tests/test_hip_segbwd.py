@@ -86,8 +86,10 @@ def test_backward_by_segments_matches_oracle_and_atomics(d, P):
         (ref * wgt).sum().backward()
         Wc['E'].grad[ne] = 0.0
         grads = {}
-        for route, thresh in (('segments', 8192), ('atomics', 0)):
+        # 'one stream': option side_sort = 0 keeps the two counting sorts on the caller's stream instead of the library's side stream
+        for route, thresh, side in (('segments', 8192, 1), ('segments, one stream', 8192, 0), ('atomics', 0, 1)):
             old = L.set_option('seg_bwd_min', thresh)
+            old_side = L.set_option('side_sort', side)
             try:
                 Wd = {k: W[k].to(DEV).requires_grad_(True) for k in NAMES}
                 got = ops().score_ktup(*(Wd[k] for k in NAMES), i2e.to(DEV, torch.int32), u.to(DEV), i.to(DEV), l1,
@@ -95,6 +97,7 @@ def test_backward_by_segments_matches_oracle_and_atomics(d, P):
                 (got * wgt.to(DEV)).sum().backward()
             finally:
                 L.set_option('seg_bwd_min', old)
+                L.set_option('side_sort', old_side)
             close(got, ref)
             grads[route] = {k: Wd[k].grad.cpu() for k in NAMES}
             for k in NAMES:
@@ -213,14 +216,16 @@ def test_kg_and_bprmf_backward_by_segments(d):
         for l1 in ((False, True) if name != 'bprmf' else (False,)):
             Wc = [x.clone().requires_grad_(True) for x in tabs]
             (ref_fn(Wc, l1) * wgt).sum().backward()
-            for thresh in (8192, 0):
+            for thresh, side in ((8192, 1), (8192, 0), (0, 1)):     # side_sort = 0: the id sort stays on the caller's stream
                 old = L.set_option('seg_bwd_min', thresh)
+                old_side = L.set_option('side_sort', side)
                 try:
                     Wd = [x.to(DEV).requires_grad_(True) for x in tabs]
                     got = hip_fn(Wd, l1)
                     (got * wgt.to(DEV)).sum().backward()
                 finally:
                     L.set_option('seg_bwd_min', old)
+                    L.set_option('side_sort', old_side)
                 close(got, ref_fn([x.detach() for x in Wc], l1))
                 for a, b in zip(Wd, Wc):
                     scale = float(b.grad.abs().max())
@@ -261,3 +266,42 @@ def test_transr_backward_on_the_matrix_cores(d, n):
                 scale = float(b.grad.abs().max())
                 close(a.grad, b.grad, rtol=2e-4, atol=2e-5 * max(scale, 1.0))
             assert float(Wd[2].grad[7:].abs().sum()) == 0.0                   # relations that never occur receive nothing
+
+
+def test_side_stream_sorts_stay_ordered_across_back_to_back_calls():
+    """The id sorts of the segment reductions run on the library's side stream (fork at entry, join before the reduction).  Calls
+    back to back reuse the same scratch memory (torch's caching allocator hands the freed block out again) with DIFFERENT ids:
+    every call must see its own sort.  Also on a non-default caller stream."""
+    d, P, nu, ni, ne, n = 100, 20, 300, 200, 260, 20000
+    W, i2e, gen = world(5, nu, ni, ne, P, d)
+    Wd = {k: W[k].to(DEV) for k in NAMES}
+    cases = []
+    for c in range(4):
+        u = torch.randint(0, nu, (n,), generator=gen); i = torch.randint(0, ni, (n,), generator=gen)
+        cases.append((u.to(DEV), i.to(DEV), torch.randn(n, generator=gen).to(DEV)))
+
+    def run(side):
+        old = L.set_option('side_sort', side)
+        out = []
+        try:
+            for u, i, wgt in cases:
+                T = {k: Wd[k].detach().clone().requires_grad_(True) for k in NAMES}
+                (ops().score_ktup(*(T[k] for k in NAMES), i2e.to(DEV, torch.int32), u, i, False, ent_pad=ne) * wgt).sum().backward()
+                out.append({k: T[k].grad for k in NAMES})
+            torch.cuda.synchronize()
+        finally:
+            L.set_option('side_sort', old)
+        return out
+
+    want = run(0)
+    got = run(1)
+    st = torch.cuda.Stream()
+    st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        got2 = run(1)
+    torch.cuda.current_stream().wait_stream(st)
+    for a, b, c in zip(got, want, got2):
+        for k in NAMES:
+            scale = max(float(b[k].abs().max()), 1.0)
+            close(a[k].cpu(), b[k].cpu(), rtol=2e-4, atol=2e-5 * scale)
+            close(c[k].cpu(), b[k].cpu(), rtol=2e-4, atol=2e-5 * scale)

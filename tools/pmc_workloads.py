@@ -3,6 +3,7 @@
     train_step  the three-launch B=512 joint training step, 20 rec + 20 kg steps
     fed_step    the device-fed B=512 joint step (-device_sampling): feed launch + step + clip/optimizer, ten-step graphs
     seg_bwd     the large-batch backwards by sorted segments: TransE (307,200 triples) and KTUP (716,800 pairs), 5 each
+    kg_rank     the filtered gold ranks of one 512-query KG evaluation batch over 14,709 entities (ktup_eval_gold_ranks), 10 calls
 tools/pmc_summary.py turns the counter_collection.csv into per-kernel averages."""
 import os
 import sys
@@ -80,5 +81,19 @@ def seg_bwd(dev):
     torch.cuda.synchronize()
 
 
+def kg_rank(dev):
+    from jTransUP.hip import ops
+    gen = torch.Generator().manual_seed(5)
+    nq = 512
+    scores = torch.rand(nq, B.NE, generator=gen).to(dev)
+    g_off = (torch.arange(nq + 1) * 3).to(dev)
+    g_ids = torch.randint(0, B.NE, (nq * 3,), generator=gen).to(dev, torch.int32)
+    f_off = (torch.arange(nq + 1) * 40).to(dev)
+    f_ids = torch.randint(0, B.NE, (nq * 40,), generator=gen).to(dev, torch.int32)
+    for _ in range(10):
+        ops.gold_ranks(scores, False, g_off, g_ids, f_off, f_ids)
+    torch.cuda.synchronize()
+
+
 if __name__ == '__main__':
-    {'eval_pass': eval_pass, 'train_step': train_step, 'fed_step': fed_step, 'seg_bwd': seg_bwd}[sys.argv[1]](torch.device('cuda'))
+    {'kg_rank': kg_rank, 'eval_pass': eval_pass, 'train_step': train_step, 'fed_step': fed_step, 'seg_bwd': seg_bwd}[sys.argv[1]](torch.device('cuda'))

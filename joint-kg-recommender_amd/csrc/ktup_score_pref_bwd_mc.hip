@@ -41,6 +41,12 @@ struct BGeom {
   static constexpr size_t TABLE_BYTES = (size_t)3 * SLOT_F4 * 16;
   static constexpr int TILE_F4 = 16 * NCH + 3;             // one (16 pairs x d) tile + 3 zero chunks
   static constexpr int LROW = 4 * NP;                      // rows of the transposed arrays that are kept (P <= 4 NP)
+  // P in 17..20 (NP = 5; the paper's 20 preferences): the second 16-preference tile holds FOUR live rows.  Phase D (168 of a
+  // tile's 441 matrix instructions) handles them with v_mfma_f32_4x4x1 (16 blocks of 4 x 4 outer products, 8 clocks) instead of a
+  // 16 x 16 x 4 tile that is three quarters padding: 96 x 8 clocks instead of 84 x 32, and 16 accumulator registers instead of 56.
+  static constexpr bool THIN = NP == 5;
+  static constexpr int PTD = THIN ? PT - 1 : PT;           // full preference tiles of phase D
+  static constexpr int NG = (D + 63) / 64;                 // THIN: 64-coordinate groups (one per 4x4x1 instruction)
   static constexpr int LT_F = LROW * 17;                   // transposed [preference][pair] arrays, pitch 17
   static constexpr int NOISE_F = HARD ? 16 * TROW : 0;     // HARD: Gumbel noise of the tile, [pair][preference]
   static constexpr size_t WAVE_BYTES = ((size_t)4 * TILE_F4 * 16 + (size_t)2 * LT_F * 4 + 2 * 3 * 16 * 4 + (size_t)NOISE_F * 4 + 15) & ~(size_t)15;
@@ -128,11 +134,17 @@ __global__ __launch_bounds__(G::NW * 64) void pref_bwd_mc_kernel(BArgs a) {
   const bool l1 = a.l1 != 0;
   const float beta = a.beta;
   // table-gradient accumulators: phase D's D layout, lane (kq, n) <-> preference 16 pt + 4 kq + reg, coordinate 16 ct + n
-  v4 accA[PT][CT], accC[PT][CT];
+  constexpr int PTD = G::PTD, NG = G::NG;
+  constexpr bool THIN = G::THIN;
+  v4 accA[PTD][CT], accC[PTD][CT];
 #pragma unroll
-  for (int pt = 0; pt < PT; ++pt)
+  for (int pt = 0; pt < PTD; ++pt)
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) { accA[pt][ct] = (v4){0.f, 0.f, 0.f, 0.f}; accC[pt][ct] = accA[pt][ct]; }
+  // THIN: register r of lane l <-> preference 16 (PT - 1) + r, coordinate 64 g + l   (4x4x1: block = l / 4, D[i = r][j = l % 4])
+  v4 thinA[NG], thinC[NG];
+#pragma unroll
+  for (int g = 0; g < NG; ++g) { thinA[g] = (v4){0.f, 0.f, 0.f, 0.f}; thinC[g] = thinA[g]; }
   const int64_t ntiles = (a.n + 15) / 16;
   const int64_t tstride = (int64_t)gridDim.x * NW;
   // The gathers run one tile ahead of the arithmetic (a wave is alone on its SIMD: nothing else hides three dependent
@@ -194,17 +206,36 @@ __global__ __launch_bounds__(G::NW * 64) void pref_bwd_mc_kernel(BArgs a) {
     v4 lg[PT];
 #pragma unroll
     for (int tt = 0; tt < PT; ++tt) lg[tt] = (v4){0.f, 0.f, 0.f, 0.f};
+    // A wave is alone on its SIMD, so an LDS round trip in front of every group of MFMAs is dead time: in every phase the operands of
+    // step i + 1 are read before the MFMAs of step i are issued (KTUP_PIN keeps the compiler from sinking the reads back down).
+#define KTUP_PIN() __builtin_amdgcn_sched_barrier(0)
+    {
+      auto ld_b = [&](int g) -> v4 {
+        v4 bv = XT[j * NCH + 4 * g + kq];
+        if (4 * g + 3 >= NCH) {
+          if (4 * g + kq >= NCH) bv = (v4){0.f, 0.f, 0.f, 0.f};
+        }
+        return bv;
+      };
+      v4 bn = ld_b(0), an[PT];
 #pragma unroll
-    for (int g = 0; g < KG; ++g) {
-      v4 bv = XT[j * NCH + 4 * g + kq];
-      if (4 * g + 3 >= NCH) {
-        if (4 * g + kq >= NCH) bv = (v4){0.f, 0.f, 0.f, 0.f};
-      }
+      for (int tt = 0; tt < PT; ++tt) an[tt] = AlogSlot[(tt * 16 + j) * PITCHA4 + kq];
 #pragma unroll
-      for (int tt = 0; tt < PT; ++tt) {
-        const v4 av = AlogSlot[(tt * 16 + j) * PITCHA4 + 4 * g + kq];
+      for (int g = 0; g < KG; ++g) {
+        const v4 bv = bn;
+        v4 av[PT];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) lg[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c], bv[c], lg[tt], 0, 0, 0);
+        for (int tt = 0; tt < PT; ++tt) av[tt] = an[tt];
+        if (g + 1 < KG) {
+          bn = ld_b(g + 1);
+#pragma unroll
+          for (int tt = 0; tt < PT; ++tt) an[tt] = AlogSlot[(tt * 16 + j) * PITCHA4 + 4 * (g + 1) + kq];
+        }
+        KTUP_PIN();
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int tt = 0; tt < PT; ++tt) lg[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[tt][c], bv[c], lg[tt], 0, 0, 0);
       }
     }
     // ---- ST-Gumbel gate (transUP.py:118-170): forward weights w = one_hot(argmax(l + g)), backward through y = softmax(l + g).
@@ -276,21 +307,40 @@ __global__ __launch_bounds__(G::NW * 64) void pref_bwd_mc_kernel(BArgs a) {
     // ---- A2: n^T, r^T per coordinate tile; lane (kq, j) owns coordinates 16 ct + 4 kq + reg of pair j
     v4 nn[CT], zz[CT], qv[CT];
     v4 sacc = (v4){0.f, 0.f, 0.f, 0.f};
+    {
+      float cnn[NP], arn[NP];
+      auto ld_t = [&](int ct) {
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct) {
-      qv[ct] = (4 * ct + kq < NCH) ? QT[j * NCH + 4 * ct + kq] : (v4){0.f, 0.f, 0.f, 0.f};
-      nn[ct] = (v4){0.f, 0.f, 0.f, 0.f};
-      zz[ct] = qv[ct];                                          // q + r accumulates on top of q
+        for (int m = 0; m < NP; ++m) {
+          const int prow = (16 * (m >> 2) + 4 * kq + (m & 3)) * RP + 16 * ct + j;
+          cnn[m] = Cn2[prow];
+          arn[m] = Ar2[prow];
+        }
+      };
 #pragma unroll
-      for (int m = 0; m < NP; ++m) {
-        const int prow = (16 * (m >> 2) + 4 * kq + (m & 3)) * RP + 16 * ct + j;
-        nn[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(Cn2[prow], lg[m >> 2][m & 3], nn[ct], 0, 0, 0);
-        zz[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(Ar2[prow], lg[m >> 2][m & 3], zz[ct], 0, 0, 0);
+      for (int ct = 0; ct < CT; ++ct) qv[ct] = (4 * ct + kq < NCH) ? QT[j * NCH + 4 * ct + kq] : (v4){0.f, 0.f, 0.f, 0.f};
+      ld_t(0);
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        float cn[NP], ar[NP];
+#pragma unroll
+        for (int m = 0; m < NP; ++m) { cn[m] = cnn[m]; ar[m] = arn[m]; }
+        if (ct + 1 < CT) ld_t(ct + 1);
+        KTUP_PIN();
+        nn[ct] = (v4){0.f, 0.f, 0.f, 0.f};
+        zz[ct] = qv[ct];                                          // q + r accumulates on top of q
+#pragma unroll
+        for (int m = 0; m < NP; ++m) {
+          nn[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(cn[m], lg[m >> 2][m & 3], nn[ct], 0, 0, 0);
+          zz[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[m], lg[m >> 2][m & 3], zz[ct], 0, 0, 0);
+        }
       }
-      sacc += qv[ct] * nn[ct];
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) sacc += qv[ct] * nn[ct];
     }
     const float s = allsum_kq((sacc[0] + sacc[1]) + (sacc[2] + sacc[3]));
     const float g = row0 + j < a.n ? a.gscore[row0 + j] : 0.f;    // tail pairs contribute nothing
+    const float g1 = l1 ? g : 0.f, g2 = l1 ? 0.f : 2.f * g;       // both norms without a branch per element (2 g z is exact either way)
     // gz (kept in zz), av
     v4 aacc = (v4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -298,7 +348,7 @@ __global__ __launch_bounds__(G::NW * 64) void pref_bwd_mc_kernel(BArgs a) {
       const v4 z = zz[ct] - s * nn[ct];
       v4 gz;
 #pragma unroll
-      for (int c = 0; c < 4; ++c) gz[c] = g * ddist1(z[c], l1);
+      for (int c = 0; c < 4; ++c) gz[c] = fmaf(g2, z[c], g1 * (z[c] > 0.f ? 1.f : (z[c] < 0.f ? -1.f : 0.f)));   // g * ddist1(z, l1)
       zz[ct] = gz;
       aacc += gz * nn[ct];
     }
@@ -315,17 +365,30 @@ __global__ __launch_bounds__(G::NW * 64) void pref_bwd_mc_kernel(BArgs a) {
     v4 gl[PT];
 #pragma unroll
     for (int tt = 0; tt < PT; ++tt) gl[tt] = (v4){0.f, 0.f, 0.f, 0.f};
+    {
+      v4 arn[PT], cnn[PT];
+      auto ld_s = [&](int g4) {
 #pragma unroll
-    for (int g4 = 0; g4 < KG; ++g4) {
-#pragma unroll
-      for (int tt = 0; tt < PT; ++tt) {
-        const v4 ar = ArSlot[(tt * 16 + j) * PITCHA4 + 4 * g4 + kq];
-        const v4 cn = CnSlot[(tt * 16 + j) * PITCHA4 + 4 * g4 + kq];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          gl[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[c], zz[g4][c], gl[tt], 0, 0, 0);
-          gl[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(cn[c], nn[g4][c], gl[tt], 0, 0, 0);
+        for (int tt = 0; tt < PT; ++tt) {
+          arn[tt] = ArSlot[(tt * 16 + j) * PITCHA4 + 4 * g4 + kq];
+          cnn[tt] = CnSlot[(tt * 16 + j) * PITCHA4 + 4 * g4 + kq];
         }
+      };
+      ld_s(0);
+#pragma unroll
+      for (int g4 = 0; g4 < KG; ++g4) {
+        v4 ar[PT], cn[PT];
+#pragma unroll
+        for (int tt = 0; tt < PT; ++tt) { ar[tt] = arn[tt]; cn[tt] = cnn[tt]; }
+        if (g4 + 1 < KG) ld_s(g4 + 1);
+        KTUP_PIN();
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int tt = 0; tt < PT; ++tt) {
+            gl[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[tt][c], zz[g4][c], gl[tt], 0, 0, 0);
+            gl[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(cn[tt][c], nn[g4][c], gl[tt], 0, 0, 0);
+          }
       }
     }
     if constexpr (HARD) {        // gl <- y * (gw - y . gw): the softmax Jacobian of y = softmax(l + g) applied to gw
@@ -355,14 +418,7 @@ __global__ __launch_bounds__(G::NW * 64) void pref_bwd_mc_kernel(BArgs a) {
       float* pu = a.gU + (int64_t)ur * a.ldu4 * 4;
       float* pi = a.gI + (int64_t)ir * a.ldi4 * 4;
       float* pe = (HASE && er != a.ent_pad) ? a.gE + (int64_t)er * a.lde4 * 4 : nullptr;
-#pragma unroll
-      for (int ct = 0; ct < CT; ++ct) {
-        v4 gx = (v4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int m = 0; m < NP; ++m) {
-          const int prow = (16 * (m >> 2) + 4 * kq + (m & 3)) * RP + 16 * ct + j;
-          gx = __builtin_amdgcn_mfma_f32_16x16x4f32(Alog2[prow], gl[m >> 2][m & 3], gx, 0, 0, 0);
-        }
+      auto emit = [&](int ct, const v4& gx) {                    // the row gradients of coordinate tile ct
         const int c0 = 16 * ct + 4 * kq;
         if (live && 4 * ct + kq < NCH) {
           const v4 gu = gq[ct] + gx, gv = gx - gq[ct];
@@ -375,7 +431,28 @@ __global__ __launch_bounds__(G::NW * 64) void pref_bwd_mc_kernel(BArgs a) {
             if (pe) atomic_add4(pe + c0, make_float4(gv[0], gv[1], gv[2], gv[3]));
           }
         }
+      };
+      float aln[NP];
+      auto ld_a = [&](int ct) {
+#pragma unroll
+        for (int m = 0; m < NP; ++m) aln[m] = Alog2[(16 * (m >> 2) + 4 * kq + (m & 3)) * RP + 16 * ct + j];
+      };
+      ld_a(0);
+      v4 gxp = (v4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        float al[NP];
+#pragma unroll
+        for (int m = 0; m < NP; ++m) al[m] = aln[m];
+        if (ct + 1 < CT) ld_a(ct + 1);
+        KTUP_PIN();
+        v4 gx = (v4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int m = 0; m < NP; ++m) gx = __builtin_amdgcn_mfma_f32_16x16x4f32(al[m], gl[m >> 2][m & 3], gx, 0, 0, 0);
+        if (ct > 0) emit(ct - 1, gxp);                          // the previous tile's stores go out under this tile's MFMAs
+        gxp = gx;
       }
+      emit(CT - 1, gxp);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -385,30 +462,75 @@ __global__ __launch_bounds__(G::NW * 64) void pref_bwd_mc_kernel(BArgs a) {
       const float* xf = reinterpret_cast<const float*>(XT);
       const float* grf = reinterpret_cast<const float*>(GRT);
       const float* gnf = reinterpret_cast<const float*>(GNT);
+      float aln[PTD], agln[PTD], bxn, bgrn, bgnn;
+      auto ld_a = [&](int st) {                                 // rows past LROW: any finite value (their accumulators are never flushed)
+#pragma unroll
+        for (int pt = 0; pt < PTD; ++pt) {
+          const int pr = min(16 * pt + j, G::LROW - 1);
+          aln[pt] = LT[pr * 17 + 4 * st + kq];
+          agln[pt] = GLT[pr * 17 + 4 * st + kq];
+        }
+      };
+      auto ld_b = [&](int st, int ct) {
+        const int col = 16 * ct + j;
+        const int off = (4 * st + kq) * (NCH * 4) + col;
+        const bool in = col < D;
+        bxn = in ? xf[off] : 0.f; bgrn = in ? grf[off] : 0.f; bgnn = in ? gnf[off] : 0.f;
+      };
+      ld_a(0);
+      ld_b(0, 0);
 #pragma unroll
       for (int st = 0; st < 4; ++st) {
-        float al[PT], agl[PT];
+        float al[PTD], agl[PTD];
 #pragma unroll
-        for (int pt = 0; pt < PT; ++pt) {                       // rows past LROW: any finite value (their accumulators are never flushed)
-          const int pr = min(16 * pt + j, G::LROW - 1);
-          al[pt] = LT[pr * 17 + 4 * st + kq];
-          agl[pt] = GLT[pr * 17 + 4 * st + kq];
-        }
+        for (int pt = 0; pt < PTD; ++pt) { al[pt] = aln[pt]; agl[pt] = agln[pt]; }
+        if (st + 1 < 4) ld_a(st + 1);
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
-          const int col = 16 * ct + j;
-          const int off = (4 * st + kq) * (NCH * 4) + col;
-          const bool in = col < D;
-          const float bx = in ? xf[off] : 0.f, bgr = in ? grf[off] : 0.f, bgn = in ? gnf[off] : 0.f;
+          const float bx = bxn, bgr = bgrn, bgn = bgnn;
+          if (ct + 1 < CT) ld_b(st, ct + 1);
+          else if (st + 1 < 4) ld_b(st + 1, 0);
+          KTUP_PIN();
 #pragma unroll
-          for (int pt = 0; pt < PT; ++pt) {
+          for (int pt = 0; pt < PTD; ++pt) {
             accA[pt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(agl[pt], bx, accA[pt][ct], 0, 0, 0);
             accA[pt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(al[pt], bgr, accA[pt][ct], 0, 0, 0);
             accC[pt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(al[pt], bgn, accC[pt][ct], 0, 0, 0);
           }
         }
       }
+      if constexpr (THIN) {        // the four live rows of the last preference tile: one pair (K = 1) per instruction
+        const int prow = (16 * PTD + (lane & 3)) * 17;
+        float tal, tagl, tb[NG][3];
+        auto ld_t = [&](int pr) {
+          tal = LT[prow + pr]; tagl = GLT[prow + pr];
+#pragma unroll
+          for (int g = 0; g < NG; ++g) {
+            const int col = 64 * g + lane;
+            const bool in = col < D;
+            const int off = pr * (NCH * 4) + col;
+            tb[g][0] = in ? xf[off] : 0.f; tb[g][1] = in ? grf[off] : 0.f; tb[g][2] = in ? gnf[off] : 0.f;
+          }
+        };
+        ld_t(0);
+#pragma unroll
+        for (int pr = 0; pr < 16; ++pr) {
+          const float al = tal, agl = tagl;
+          float b[NG][3];
+#pragma unroll
+          for (int g = 0; g < NG; ++g) { b[g][0] = tb[g][0]; b[g][1] = tb[g][1]; b[g][2] = tb[g][2]; }
+          if (pr + 1 < 16) ld_t(pr + 1);
+          KTUP_PIN();
+#pragma unroll
+          for (int g = 0; g < NG; ++g) {
+            thinA[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(agl, b[g][0], thinA[g], 0, 0, 0);
+            thinA[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(al, b[g][1], thinA[g], 0, 0, 0);
+            thinC[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(al, b[g][2], thinC[g], 0, 0, 0);
+          }
+        }
+      }
     }
+#undef KTUP_PIN
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     nu1 = nu2; ni1 = ni2; ne1 = ne2; nu2 = nu3; ni2 = ni3;
@@ -416,7 +538,7 @@ __global__ __launch_bounds__(G::NW * 64) void pref_bwd_mc_kernel(BArgs a) {
   }
   // ---- flush the table gradients: lane (kq, n) holds preference 16 pt + 4 kq + reg, coordinate 16 ct + n
 #pragma unroll
-  for (int pt = 0; pt < PT; ++pt)
+  for (int pt = 0; pt < PTD; ++pt)
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
@@ -428,6 +550,19 @@ __global__ __launch_bounds__(G::NW * 64) void pref_bwd_mc_kernel(BArgs a) {
           if (vc != 0.f) atomicAdd(a.gC + (int64_t)p * D + c, vc);
         }
       }
+  if constexpr (THIN) {
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int p = 16 * PTD + reg, c = 64 * g + lane;
+        if (p < a.P && c < D) {
+          const float va = thinA[g][reg], vc = thinC[g][reg];
+          if (va != 0.f) atomicAdd(a.gA + (int64_t)p * D + c, va);
+          if (vc != 0.f) atomicAdd(a.gC + (int64_t)p * D + c, vc);
+        }
+      }
+  }
 }
 
 template <typename G, bool ROWOUT>

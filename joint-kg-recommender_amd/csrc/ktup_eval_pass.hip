@@ -324,9 +324,17 @@ __global__ __launch_bounds__(256, G::MINW) void eval_pass_q_kernel(QArgs a) {
   }
 }
 
-// G_RR | G_RN | G_NN, each [P4][P4] (zero padded), from the prepared tables (row pitch dp): one wave per entry
+// G_RR | G_RN | G_NN, each [P4][P4] (zero padded), from the prepared tables (row pitch dp): one wave per entry.  gs (optional):
+// the same numbers as the A operands of pspace_rows_mc_kernel's fold products, [matrix G_RR, G_RN, G_RN^T, G_NN][pt][k-step m][lane]
+// with lane (k, i) <-> row 16 pt + 4 (i & 3) + (i >> 2), column 16 (m >> 2) + 4 (m & 3) + k; rows >= P4 are zero.
+KTUP_DEV int gs_index(int mtx, int p, int q, int PT, int NP) {
+  const int pt = p >> 4, pr = p & 15, i = (pr >> 2) + 4 * (pr & 3);
+  const int m = (q >> 4) * 4 + ((q & 15) >> 2), k = q & 3;
+  return ((mtx * PT + pt) * NP + m) * 64 + k * 16 + i;
+}
+
 __global__ __launch_bounds__(256) void pspace_gram_kernel(const float* __restrict__ Ar, const float* __restrict__ Cn, int dp, int d, int P, int P4,
-                                                          float* __restrict__ grams) {
+                                                          float* __restrict__ grams, float* __restrict__ gs, int PT, int NP) {
   const int lane = threadIdx.x & 63;
   for (int idx = blockIdx.x * 4 + (threadIdx.x >> 6); idx < 3 * P4 * P4; idx += gridDim.x * 4) {
     const int t = idx / (P4 * P4), rem = idx - t * P4 * P4, p = rem / P4, q = rem - p * P4;
@@ -337,8 +345,19 @@ __global__ __launch_bounds__(256) void pspace_gram_kernel(const float* __restric
       for (int k = lane; k < d; k += 64) acc = fmaf(x[k], y[k], acc);
     }
     acc = group_sum<64>(acc);
-    if (lane == 0) grams[idx] = acc;
+    if (lane == 0) {
+      grams[idx] = acc;
+      if (gs) {
+        if (t == 1) { gs[gs_index(1, p, q, PT, NP)] = acc; gs[gs_index(2, q, p, PT, NP)] = acc; }
+        else gs[gs_index(t == 0 ? 0 : 3, p, q, PT, NP)] = acc;
+      }
+    }
   }
+  if (gs && 16 * PT > P4)                                        // rows P4 .. 16 PT - 1 of the last row tile: zero
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < 4 * (16 * PT - P4) * P4; idx += gridDim.x * 256) {
+      const int mtx = idx / ((16 * PT - P4) * P4), rem = idx - mtx * (16 * PT - P4) * P4;
+      gs[gs_index(mtx, P4 + rem / P4, rem % P4, PT, NP)] = 0.f;
+    }
 }
 
 // One wave per row x (user: U[ids[row]]; item: X[row]): L = Alog x, Rx = Ar x, Nx = Cn x (lane = one of the 3 P4 table rows, the
@@ -457,13 +476,208 @@ __global__ __launch_bounds__(256) void pspace_rows_kernel(RowsSide users, RowsSi
   else pspace_rows<false, NCH, NP>(items, blockIdx.x - users.blocks, P, Alog, Ar, Cn, dp, grams, ka16, ks16);
 }
 
-struct QScratch { float *grams, *A, *SCU, *B, *ISC; uint64_t* part; };
+// The same rows on the matrix cores: a wave owns 16 rows.  L^T, Rx^T, Nx^T = (Alog | Ar | Cn) . x^T with the tables staged
+// slot-ordered in LDS exactly as in pref_fwd_mc (lane (kq, j = row) ends up with preference 16 tt + 4 reg + kq of its row), the
+// four Gram folds G_RR L, G_RN L, G_RN^T L, G_NN L as K = P products whose B operands are those registers (the Gram matrices
+// staged in the matching slot / k order), the row scalars by lane-swap sums over the four kq lanes, and the operand rows written
+// straight from the registers (16 B per (row, preference quad)).  One wave per row (above) is a chain of ~10 dependent round
+// trips per row -- 31 us for the 9,746 rows of an ml1m pass; 16 rows per wave are ~210 MFMAs.
+template <int NCH_, int NP_>
+struct RGeom {
+  static constexpr int NCH = NCH_, NP = NP_, D = 4 * NCH, P4 = 4 * NP;
+  static constexpr int PT = (NP + 3) / 4, KG = (D + 15) / 16;
+  static constexpr int PITCHA4 = 4 * KG + 1;
+  static constexpr int SLOT_F4 = PT * 16 * PITCHA4;              // one table, float4
+  static constexpr int GS_F = 4 * PT * NP * 64;                  // Gram A operands: [matrix][pt][k-step][lane]
+  static constexpr int J = (16 * NCH + 63) / 64;
+  static constexpr int TILE_F4 = 16 * NCH + 3;
+  static constexpr size_t WAVE_BYTES = (size_t)TILE_F4 * 16 + 2 * 16 * 4;
+  static constexpr size_t LDS = (size_t)3 * SLOT_F4 * 16 + (size_t)GS_F * 4 + 4 * WAVE_BYTES;
+};
+
+template <int NCH, int NP>
+__global__ __launch_bounds__(256) void pspace_rows_mc_kernel(RowsSide users, RowsSide items, int P, const float* __restrict__ Alog,
+                                                             const float* __restrict__ Ar, const float* __restrict__ Cn, int dp,
+                                                             const float* __restrict__ gs, int ka16, int ks16) {
+  using R = RGeom<NCH, NP>;
+  constexpr int D = R::D, P4 = R::P4, PT = R::PT, KG = R::KG, PITCHA4 = R::PITCHA4, J = R::J;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  v4* Slot = reinterpret_cast<v4*>(smem);                         // [3][PT * 16 slots][PITCHA4]
+  float* GS = reinterpret_cast<float*>(Slot + 3 * R::SLOT_F4);
+  const int tid = threadIdx.x, lane = tid & 63, kq = lane >> 4, j = lane & 15;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  char* wbase = reinterpret_cast<char*>(GS + R::GS_F) + (size_t)w * R::WAVE_BYTES;
+  v4* XT = reinterpret_cast<v4*>(wbase);                          // x  [16][NCH] (+ 3 chunks never used unmasked)
+  int32_t* sid = reinterpret_cast<int32_t*>(XT + R::TILE_F4);     // [2][16]
+  const bool is_user = (int)blockIdx.x < users.blocks;
+  const RowsSide& sd = is_user ? users : items;
+  const int block = is_user ? (int)blockIdx.x : (int)blockIdx.x - users.blocks;
+  const int64_t row0 = ((int64_t)block * 4 + w) * 16;
+  const bool active = row0 < sd.nrows;
+  const int orow = sd.orow;
+  // the wave's rows are requested first; the tables are staged while they are on their way
+  if (active && lane < 16) {
+    const int64_t gr = row0 + lane;
+    const bool ok = gr < sd.nrows;
+    sid[lane] = ok ? (int32_t)(sd.ids ? sd.ids[gr] : gr) : 0;
+    sid[16 + lane] = (ok && sd.E) ? sd.map[gr] : 0;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  v4 xv[J], ev[J];
+  if (active) {
+    const v4* X4 = reinterpret_cast<const v4*>(sd.X);
+    const v4* E4 = reinterpret_cast<const v4*>(sd.E);
+    const uint32_t ldx4 = (uint32_t)(sd.ldx >> 2), lde4 = (uint32_t)(sd.lde >> 2);
+#pragma unroll
+    for (int jj = 0; jj < J; ++jj) {
+      const int e = lane + 64 * jj;
+      const int r = e < 16 * NCH ? e / NCH : 0, c = e < 16 * NCH ? e % NCH : 0;
+      xv[jj] = X4[(uint64_t)(uint32_t)sid[r] * ldx4 + (uint32_t)c];
+      ev[jj] = E4 ? E4[(uint64_t)(uint32_t)sid[16 + r] * lde4 + (uint32_t)c] : (v4){0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  {   // every load of the staging is issued before the first LDS write (a loop of load -> write round trips cost 6 us here)
+    const v4 zero = (v4){0.f, 0.f, 0.f, 0.f};
+    constexpr int SIT = (R::SLOT_F4 + 255) / 256, GIT = (R::GS_F / 4 + 255) / 256;
+    v4 ta[SIT], tr[SIT], tc[SIT], tg[GIT];
+#pragma unroll
+    for (int it = 0; it < SIT; ++it) {
+      const int idx = tid + 256 * it;
+      const int srow = idx / PITCHA4, c = idx - srow * PITCHA4;
+      const int tt = srow >> 4, i = srow & 15;
+      const int p = 16 * tt + 4 * (i & 3) + (i >> 2);             // slot -> preference (block transposed, as in pref_fwd_mc)
+      const bool ok = idx < R::SLOT_F4 && p < P && c < NCH;
+      ta[it] = ok ? *reinterpret_cast<const v4*>(Alog + (size_t)p * dp + 4 * c) : zero;
+      tr[it] = ok ? *reinterpret_cast<const v4*>(Ar + (size_t)p * dp + 4 * c) : zero;
+      tc[it] = ok ? *reinterpret_cast<const v4*>(Cn + (size_t)p * dp + 4 * c) : zero;
+    }
+    const v4* g4 = reinterpret_cast<const v4*>(gs);               // already in operand order (pspace_gram_kernel)
+#pragma unroll
+    for (int it = 0; it < GIT; ++it) tg[it] = tid + 256 * it < R::GS_F / 4 ? g4[tid + 256 * it] : zero;
+#pragma unroll
+    for (int it = 0; it < SIT; ++it) {
+      const int idx = tid + 256 * it;
+      if (idx < R::SLOT_F4) { Slot[idx] = ta[it]; Slot[R::SLOT_F4 + idx] = tr[it]; Slot[2 * R::SLOT_F4 + idx] = tc[it]; }
+    }
+#pragma unroll
+    for (int it = 0; it < GIT; ++it)
+      if (tid + 256 * it < R::GS_F / 4) reinterpret_cast<v4*>(GS)[tid + 256 * it] = tg[it];
+  }
+  if (active) {
+#pragma unroll
+    for (int jj = 0; jj < J; ++jj) {
+      const int e = lane + 64 * jj;
+      if (e < 16 * NCH) {
+        const int r = e / NCH, c = e % NCH;
+        const v4 v = xv[jj] + ev[jj];
+        XT[e] = v;
+        if (row0 + r < sd.nrows)                                  // the x part of the operand row: [-2u ...] | [x ...]
+          *reinterpret_cast<v4*>(sd.out + (row0 + r) * (int64_t)orow + 4 * c) = is_user ? -2.f * v : v;
+      }
+    }
+  }
+  __syncthreads();
+  if (!active) return;
+  // ---- L^T, Rx^T, Nx^T: acc[t][tt][reg] of lane (kq, row j) = table t's product for preference 16 tt + 4 reg + kq
+  v4 acc[3][PT];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int tt = 0; tt < PT; ++tt) acc[t][tt] = (v4){0.f, 0.f, 0.f, 0.f};
+  float sq = 0.f;
+#pragma unroll
+  for (int g = 0; g < KG; ++g) {
+    v4 bv = XT[j * NCH + 4 * g + kq];
+    if (4 * g + 3 >= NCH) {
+      if (4 * g + kq >= NCH) bv = (v4){0.f, 0.f, 0.f, 0.f};
+    }
+    sq += (bv[0] * bv[0] + bv[1] * bv[1]) + (bv[2] * bv[2] + bv[3] * bv[3]);
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int tt = 0; tt < PT; ++tt) {
+        const v4 av = Slot[t * R::SLOT_F4 + (tt * 16 + j) * PITCHA4 + 4 * g + kq];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[t][tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c], bv[c], acc[t][tt], 0, 0, 0);
+      }
+  }
+  sq = allsum_kq(sq);
+  // ---- Gram folds: fold[0] = G_RR L, [1] = G_RN L, [2] = G_RN^T L, [3] = G_NN L   (same lane layout as L)
+  v4 fold[4][PT];
+#pragma unroll
+  for (int mtx = 0; mtx < 4; ++mtx)
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+      fold[mtx][pt] = (v4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int m = 0; m < NP; ++m)
+        fold[mtx][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(GS[((mtx * PT + pt) * NP + m) * 64 + lane], acc[0][m >> 2][m & 3], fold[mtx][pt], 0, 0, 0);
+    }
+  float q_rr = 0.f, q_rn = 0.f, q_nn = 0.f, d_nl = 0.f, d_rl = 0.f;
+#pragma unroll
+  for (int tt = 0; tt < PT; ++tt)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const float l = acc[0][tt][reg];
+      q_rr = fmaf(l, fold[0][tt][reg], q_rr); q_rn = fmaf(l, fold[1][tt][reg], q_rn); q_nn = fmaf(l, fold[3][tt][reg], q_nn);
+      d_nl = fmaf(acc[2][tt][reg], l, d_nl); d_rl = fmaf(acc[1][tt][reg], l, d_rl);
+    }
+  q_rr = allsum_kq(q_rr); q_rn = allsum_kq(q_rn); q_nn = allsum_kq(q_nn); d_nl = allsum_kq(d_nl); d_rl = allsum_kq(d_rl);
+  const int64_t row = row0 + j;
+  if (row >= sd.nrows) return;
+  float* o = sd.out + row * (int64_t)orow;
+  if (is_user) {
+    // [AA: -2u ; -2L ; 2 (Ru + G_RR L) ; 0] [S: Nu ; -L ; 0] [AN: Nu + G_RN^T L + G_RN L ; -L ; 0] [NN: 2 G_NN L ; 0]
+    const int oS = 16 * ka16, oAN = oS + 16 * ks16, oNN = oAN + 16 * ks16;
+#pragma unroll
+    for (int tt = 0; tt < PT; ++tt)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int p = 16 * tt + 4 * reg + kq;
+        if (p < P4) {
+          const float l = acc[0][tt][reg], rx = acc[1][tt][reg], nx = acc[2][tt][reg];
+          o[D + p] = -2.f * l;
+          o[D + P4 + p] = 2.f * (rx + fold[0][tt][reg]);
+          o[oS + p] = nx;
+          o[oS + P4 + p] = -l;
+          o[oAN + p] = nx + fold[2][tt][reg] + fold[1][tt][reg];
+          o[oAN + P4 + p] = -l;
+          o[oNN + p] = 2.f * fold[3][tt][reg];
+        }
+      }
+    for (int k = D + 2 * P4 + kq; k < oS; k += 4) o[k] = 0.f;
+    for (int k = oS + 2 * P4 + kq; k < oAN; k += 4) o[k] = 0.f;
+    for (int k = oAN + 2 * P4 + kq; k < oNN; k += 4) o[k] = 0.f;
+    for (int k = oNN + P4 + kq; k < orow; k += 4) o[k] = 0.f;
+    // u.NU, |AU|^2, AU.NU, |NU|^2
+    if (kq == 0) *reinterpret_cast<float4*>(sd.scal + row * 4) = make_float4(d_nl, sq + 2.f * d_rl + q_rr, d_nl + q_rn, q_nn);
+  } else {
+    // [x ; Rx ; L ; Nx]
+#pragma unroll
+    for (int tt = 0; tt < PT; ++tt)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int p = 16 * tt + 4 * reg + kq;
+        if (p < P4) {
+          o[D + p] = acc[1][tt][reg];
+          o[D + P4 + p] = acc[0][tt][reg];
+          o[D + 2 * P4 + p] = acc[2][tt][reg];
+        }
+      }
+    // v.NV, |C0|^2, C0.NV, |NV|^2
+    if (kq == 0) *reinterpret_cast<float4*>(sd.scal + row * 4) = make_float4(d_nl, sq - 2.f * d_rl + q_rr, d_nl - q_rn, q_nn);
+  }
+}
+
+struct QScratch { float *grams, *gs, *A, *SCU, *B, *ISC; uint64_t* part; };
 
 template <typename G>
 QScratch q_carve(void* scratch, int64_t nq, int64_t n_items) {
   QScratch s;
   float* p = reinterpret_cast<float*>(scratch);
   s.grams = p; p += 3 * 32 * 32;
+  s.gs = p; p += 4 * 2 * 8 * 64;                                 // RGeom::GS_F at its largest (PT = 2, NP = 8)
   s.A = p; p += (size_t)nq * G::AROW;
   s.SCU = p; p += (size_t)nq * 4;
   s.B = p; p += (size_t)n_items * G::ROWB + 64;                  // + slack: the last tile fetch never reads past it, the pad keeps 16-B alignment
@@ -481,13 +695,24 @@ int launch_q(const float* U, int64_t ldu, const int64_t* u_ids, int64_t nq, cons
   const float* Alog = pref_ws;
   const float* Ar = pref_ws + (size_t)ppad * dp;
   const float* Cn = pref_ws + (size_t)(ppad + n_pref) * dp;
-  hipLaunchKernelGGL(pspace_gram_kernel, dim3((3 * G::P4 * G::P4 + 3) / 4), dim3(256), 0, st, Ar, Cn, dp, G::D, n_pref, G::P4, q.grams);
+  const bool rows_mc = opt_eval_mc() && !((ldu | ldi | lde | dp) & 3) && aligned16(U) && aligned16(I) && (!E || aligned16(E)) && aligned16(pref_ws) &&
+                       nq < (1ll << 31) && n_items < (1ll << 31);
+  using R = RGeom<G::NCH, G::NP>;
+  hipLaunchKernelGGL(pspace_gram_kernel, dim3((3 * G::P4 * G::P4 + 3) / 4), dim3(256), 0, st, Ar, Cn, dp, G::D, n_pref, G::P4, q.grams,
+                     rows_mc ? q.gs : nullptr, R::PT, G::NP);
   const size_t lds_rows = (size_t)4 * (G::D + 7 * G::P4) * sizeof(float);
   // many small workgroups: a row is a chain of dependent round trips (id -> row -> products -> store), hidden only by occupancy
   RowsSide us{U, ldu, u_ids, nullptr, 0, nullptr, nq, q.A, G::AROW, q.SCU, grid_for((nq + 3) / 4, 2048)};
   RowsSide is{I, ldi, nullptr, E, lde, item2ent, n_items, q.B, G::ROWB, q.ISC, grid_for((n_items + 3) / 4, 2048)};
-  hipLaunchKernelGGL((pspace_rows_kernel<G::NCH, G::NP>), dim3(us.blocks + is.blocks), dim3(256), lds_rows, st, us, is, n_pref, Alog, Ar, Cn, dp,
-                     q.grams, G::KA, G::KS);
+  if (rows_mc) {    // 16 rows per wave on the matrix cores
+    us.blocks = (int)((nq + 63) / 64); is.blocks = (int)((n_items + 63) / 64);
+    (void)hipFuncSetAttribute((const void*)pspace_rows_mc_kernel<G::NCH, G::NP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)R::LDS);
+    hipLaunchKernelGGL((pspace_rows_mc_kernel<G::NCH, G::NP>), dim3(us.blocks + is.blocks), dim3(256), R::LDS, st, us, is, n_pref, Alog, Ar, Cn, dp,
+                       q.gs, G::KA, G::KS);
+  } else {
+    hipLaunchKernelGGL((pspace_rows_kernel<G::NCH, G::NP>), dim3(us.blocks + is.blocks), dim3(256), lds_rows, st, us, is, n_pref, Alog, Ar, Cn, dp,
+                       q.grams, G::KA, G::KS);
+  }
   if (int e = check_launch(name)) return e;
   QArgs a{};
   a.A = q.A; a.SCU = q.SCU; a.B = q.B; a.ISC = q.ISC; a.nq = nq; a.n_items = n_items;
@@ -536,7 +761,7 @@ size_t eval_pass_pspace_bytes(int d, int n_pref, int64_t nq, int64_t n_items, in
   const size_t p4 = n_pref <= 4 ? 4 : n_pref <= 20 ? 20 : 32;
   const size_t ka = (d + 2 * p4 + 15) / 16, ks = (2 * p4 + 15) / 16, kn = (p4 + 15) / 16;
   const size_t arow = 16 * (ka + 2 * ks + kn), rowb = d + 3 * p4;
-  return (3 * 32 * 32 + (size_t)nq * (arow + 4) + (size_t)n_items * (rowb + 4) + 64) * sizeof(float) + (size_t)nq * 8 * topn * sizeof(uint64_t);
+  return (3 * 32 * 32 + 4 * 2 * 8 * 64 + (size_t)nq * (arow + 4) + (size_t)n_items * (rowb + 4) + 64) * sizeof(float) + (size_t)nq * 8 * topn * sizeof(uint64_t);
 }
 
 // Items: I[row] (+ E[item2ent[row]] for KTUP; E == NULL for TUP); pref_ws: the prepared tables (ktup_pref_prepare; ppad / dp its

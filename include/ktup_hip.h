@@ -48,7 +48,11 @@ const char* ktup_last_error(void);
  *   "eval_mc"     [KTUP_EVAL_MC, 1]      0: VALU all-candidate kernels instead of the matrix-core ones
  *   "rank_chunk"  [KTUP_RANK_CHUNK, 0]   > 0: force the chunked ranking kernels with this chunk size
  *   "seg_bwd_min" [KTUP_SEG_BWD_MIN, 8192]  batch size from which the *_bwd entry points given a workspace reduce row
- *                                        gradients by sorted segments instead of atomics (0: never)                       */
+ *                                        gradients by sorted segments instead of atomics (0: never)
+ *   "bwd_wide_max" [KTUP_BWD_WIDE_MAX, 4096]  K5-K7 backward, d <= 128: pairs up to which four waves share a 16-pair tile
+ *   "side_sort"   [KTUP_SIDE_SORT, 1]    0: the id sorts of those segment reductions stay on the caller's stream (default: a
+ *                                        library-owned side stream, forked at entry and joined before the reduction; never
+ *                                        while the caller's stream is being captured into a graph)                       */
 int ktup_set_option(const char* name, int value);
 int ktup_get_option(const char* name, int* value);
 

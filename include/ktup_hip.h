@@ -301,6 +301,20 @@ int ktup_eval_gold_ranks(const float* scores, int64_t lds, int64_t nq, int64_t n
                          const int64_t* filt_off, const int32_t* filt_ids, const int64_t* gold_off,
                          const int32_t* gold_ids, int32_t* ranks, void* stream);
 
+/* A whole link-prediction pass in one call (knowledge_representation.py:93-146 evaluate: evaluateHead / evaluateTail per batch
+ * + utils/misc.py:61-146 per batch, here with the loop over batches under the ABI): ranks[g] = the filtered 0-based rank of gold
+ * entry g (as ktup_eval_gold_ranks; -1 for a gold id that is itself filtered) for all nq keys (q[i], r[i]).  filt_off / gold_off
+ * are the pass's CSR offsets (nq + 1 entries, ABSOLUTE offsets into filt_ids / gold_ids); the keys are scored `chunk` at a time
+ * (512 = the reference's batch) into `ws` (ktup_eval_kg_ranks_workspace_bytes) by K12 / K13, so the integers are those of the
+ * per-batch route.  model: KTUP_KG_TRANSE (Nrm ignored) or KTUP_KG_TRANSH; head / l1 / C as in ktup_eval_trans{e,h}_scores. */
+#define KTUP_KG_TRANSE 0
+#define KTUP_KG_TRANSH 1
+size_t ktup_eval_kg_ranks_workspace_bytes(int d, int64_t n_cand, int64_t chunk);
+int ktup_eval_kg_ranks(int model, const float* E, int64_t lde, const float* R, int64_t ldr, const float* Nrm, int64_t ldn, int d,
+                       const float* C, int64_t ldc, int64_t n_cand, const int64_t* q, const int64_t* r, int64_t nq, int l1,
+                       int head, int descending, const int64_t* filt_off, const int32_t* filt_ids, const int64_t* gold_off,
+                       const int32_t* gold_ids, int32_t* ranks, int64_t chunk, void* ws, void* stream);
+
 /* ranks over a candidate SHARD (sharded-catalogue evaluation, one shard per GPU): the rank of ktup_eval_gold_ranks is a count, so
  * it is additive over disjoint shards.  `scores` (nq x n_local) covers candidates [cand_lo, cand_lo + n_local) with GLOBAL ids in
  * the filter / gold CSR lists; gold_scores[e] = the score of gold entry e (from the shard that owns it).  counts[e] = this shard's

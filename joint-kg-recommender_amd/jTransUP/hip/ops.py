@@ -402,6 +402,32 @@ def eval_transh(E, R, N, q, r, l1, head, candidates=None):
     return out
 
 
+KG_TRANSE, KG_TRANSH = 0, 1
+
+
+@torch.no_grad()
+def eval_kg_ranks(E, R, N, q, r, l1, head, descending, gold_off, gold_ids, filt_off=None, filt_ids=None, candidates=None, chunk=512):
+    """A whole link-prediction pass in one call (ktup_eval_kg_ranks): the filtered 0-based rank of every gold entry of every key
+    (q[i], r[i]) among all candidates -- K12 (N is None) or K13 scores `chunk` keys at a time + K18, the loop over the batches
+    under the C ABI.  gold_off / filt_off: the pass's CSR offsets (len(q) + 1, absolute).  -> int32 [gold_off[-1]]; -1 = a gold
+    id that is itself filtered (the reference's walk never reaches it)."""
+    dev = _dev(_table('entity table', E)); _table('relation table', R)
+    if N is not None:
+        _table('norm table', N)
+    C = E if candidates is None else _table('candidate table', candidates)
+    nq = q.numel(); q = _ids('q', q, dev); r = _ids('r', r, dev, nq)
+    if gold_off.numel() != nq + 1 or (filt_off is not None and filt_off.numel() != nq + 1):
+        raise L.KtupError('eval_kg_ranks: CSR offsets need len(q) + 1 entries')
+    n_gold = gold_ids.numel()
+    ranks = torch.empty(max(n_gold, 1), dtype=torch.int32, device=dev)
+    chunk = max(1, min(int(chunk), max(nq, 1)))
+    ws = _scratch(L.load().ktup_eval_kg_ranks_workspace_bytes(E.shape[1], C.shape[0], chunk), dev)
+    L.call('ktup_eval_kg_ranks', KG_TRANSE if N is None else KG_TRANSH, _p(E), E.stride(0), _p(R), R.stride(0), _p(N),
+           0 if N is None else N.stride(0), E.shape[1], _p(C), C.stride(0), C.shape[0], _p(q), _p(r), nq, int(l1), int(head),
+           int(bool(descending)), _p(filt_off), _p(filt_ids), _p(gold_off), _p(gold_ids), _p(ranks), chunk, _p(ws), _stream(dev))
+    return ranks
+
+
 class PreparedEntities(object):
     """Entity side of K14 for one evaluation pass (ktup_eval_transr_prepare): valid while the tables it was built from do not
     change, for the distance kind it was built for."""

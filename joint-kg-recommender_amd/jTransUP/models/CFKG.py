@@ -66,3 +66,9 @@ class CFKG(nn.Module, GradToggle):
         """CFKG.py:140-158."""
         return ops.eval_transe(self.ent_embeddings.weight, self.rel_embeddings.weight, h, r, self.L1_flag, head=False,
                                candidates=self._cand(all_e_ids))
+
+    def rank_entities(self, q, r, head, descending, gold_off, gold_ids, filt_off=None, filt_ids=None, all_e_ids=None):
+        """A whole evaluateHead / evaluateTail pass (CFKG.py:120-158) + the filtered gold ranks of utils/misc.py:125-146 in one call
+        (K12 + K18 per chunk of 512 keys under the C ABI)."""
+        return ops.eval_kg_ranks(self.ent_embeddings.weight, self.rel_embeddings.weight, None, q, r, self.L1_flag, head, descending,
+                                 gold_off, gold_ids, filt_off, filt_ids, candidates=self._cand(all_e_ids))

@@ -164,6 +164,7 @@ def _kg_eval_sharded(FLAGS, shard, eval_iter, index, descending, remap):
 
 
 _PASS_IDS = {}
+_KG_PASS_IDS = {}
 
 
 _PINNED = {}
@@ -235,13 +236,44 @@ def rec_eval_pass(FLAGS, score_fn, eval_iter, eval_dict, all_dicts, descending, 
     return np.concatenate(parts, axis=0) if parts else np.zeros((0, 5))
 
 
-def kg_eval_pass(FLAGS, score_fn, eval_iter, eval_dict, all_dicts, descending, remap=None, want_rows=True, shard=None):
+def _kg_eval_fused(FLAGS, rank_fn, eval_iter, index, descending, remap, want_rows):
+    """The whole pass in one call: every (entity, relation) key of the iterator at once through model.rank_entities (scores +
+    filtered gold ranks per chunk of 512 keys under the C ABI), ONE copy back of the ranks.  Same rows / (hit, rank) array as the
+    per-batch walk below."""
+    hit = _KG_PASS_IDS.get(id(eval_iter))
+    if hit is None or hit[0] is not eval_iter or hit[2] is not remap:
+        keys = [k for batch in eval_iter for k in batch]
+        hit = _KG_PASS_IDS[id(eval_iter)] = (eval_iter, (ids([k[0] if remap is None else remap[k[0]] for k in keys]), ids([k[1] for k in keys])), remap)
+    q_dev, r_dev = hit[1]
+    if q_dev.numel() == 0 or len(index.g_ids_h) == 0:
+        return [] if want_rows else np.zeros((0, 2))
+    ranks = rank_fn(q_dev, r_dev, descending, index.g_off, index.g_ids, index.f_off if index.has_filter else None,
+                    index.f_ids if index.has_filter else None)
+    if ranks is None:
+        return None
+    ranks = _to_host(ranks[:len(index.g_ids_h)])
+    if not want_rows:
+        ranks = ranks[ranks >= 0]
+        return np.stack([(ranks < FLAGS.topn).astype(np.float64), ranks.astype(np.float64)], axis=1)
+    out = []
+    for b, key in enumerate(index.keys):
+        lo, hi = int(index.g_off_h[b]), int(index.g_off_h[b + 1])
+        rows = sorted((int(ranks[i]), int(index.g_ids_h[i])) for i in range(lo, hi) if ranks[i] >= 0)
+        out.extend((1 if rk < FLAGS.topn else 0, rk, key, gid) for rk, gid in rows)
+    return out
+
+
+def kg_eval_pass(FLAGS, score_fn, eval_iter, eval_dict, all_dicts, descending, remap=None, want_rows=True, shard=None, rank_fn=None):
     """One pass over (t, r) or (h, r) keys: all-entity scores, filtered gold ranks (misc.py:61-146 semantics); batches are
     dealt to the ranks like in rec_eval_pass.  want_rows=False returns the (n x 2) array of (hit, rank) only: the ranks stay
     on the device until ONE copy back at the end of the pass."""
     index = rank_index(eval_iter, eval_dict, all_dicts)
     if _shard_mode(FLAGS, shard, want_rows):
         return _kg_eval_sharded(FLAGS, shard, eval_iter, index, descending, remap)
+    if rank_fn is not None and os.environ.get('KTUP_EVAL_PASS', '1') != '0':
+        fused = _kg_eval_fused(FLAGS, rank_fn, eval_iter, index, descending, remap, want_rows)   # every rank runs the whole pass
+        if fused is not None:
+            return fused
     mine, world = _my_batches(len(eval_iter))
     per_batch = {}
     pbar = tqdm(total=len(mine), desc='Run Eval')

@@ -139,6 +139,12 @@ class jTransUPModel(nn.Module, GradToggle):
         return ops.eval_transh(self.ent_embeddings.weight, self.rel_embeddings.weight, self.norm_embeddings.weight, h, r,
                                self.L1_flag, head=False, candidates=self._all_entities(all_e_ids))
 
+    def rank_entities(self, q, r, head, descending, gold_off, gold_ids, filt_off=None, filt_ids=None, all_e_ids=None):
+        """A whole evaluateHead / evaluateTail pass (jTransUP.py:193-247) + the filtered gold ranks of utils/misc.py:125-146 in one
+        call (K13 + K18 per chunk of 512 keys under the C ABI): int32 device vector, one rank per gold entry of the pass's index."""
+        return ops.eval_kg_ranks(self.ent_embeddings.weight, self.rel_embeddings.weight, self.norm_embeddings.weight, q, r, self.L1_flag,
+                                 head, descending, gold_off, gold_ids, filt_off, filt_ids, candidates=self._all_entities(all_e_ids))
+
     def getPreferences(self, u_e, i_e, use_st_gumbel=False):
         """jTransUP.py:250-260 on already-gathered embeddings (reporting path only)."""
         A = self.pref_embeddings.weight + self.rel_embeddings.weight

@@ -68,10 +68,15 @@ def evaluateKG(FLAGS, model, eval_head_iter, eval_tail_iter, eval_head_dict, eva
     remap = None if FLAGS.share_embeddings else e_map      # :125,140 (identity for id-ordered map files)
     from jTransUP.models._shard_eval import kg_shard_fn
     kw = {'ents': model.prepare_entities()} if hasattr(model, 'prepare_entities') else {}       # CKE: TransR's entity side, once
+    # jTransUP / CFKG: the whole pass -- scores and filtered gold ranks -- behind one call per direction (model.rank_entities)
+    rank = (lambda head: (lambda q, r, desc, go, gi, fo, fi: model.rank_entities(q, r, head, desc, go, gi, fo, fi, all_e_ids=all_e_var))) \
+        if hasattr(model, 'rank_entities') else (lambda head: None)
     head_results = D.kg_eval_pass(FLAGS, lambda t, r: model.evaluateHead(t, r, all_e_ids=all_e_var, **kw), eval_head_iter, eval_head_dict,
-                                  all_head_dicts, eval_descending, remap=remap, want_rows=is_report, shard=kg_shard_fn(model, True))
+                                  all_head_dicts, eval_descending, remap=remap, want_rows=is_report, shard=kg_shard_fn(model, True),
+                                  rank_fn=rank(True))
     tail_results = D.kg_eval_pass(FLAGS, lambda h, r: model.evaluateTail(h, r, all_e_ids=all_e_var, **kw), eval_tail_iter, eval_tail_dict,
-                                  all_tail_dicts, eval_descending, remap=remap, want_rows=is_report, shard=kg_shard_fn(model, False))
+                                  all_tail_dicts, eval_descending, remap=remap, want_rows=is_report, shard=kg_shard_fn(model, False),
+                                  rank_fn=rank(False))
     perf = D.summarize_kg(FLAGS, head_results, tail_results, logger)
     if is_report:
         D.report_kg(head_results, tail_results, logger)

@@ -25,10 +25,13 @@ def evaluate(FLAGS, model, entity_total, relation_total, eval_head_iter, eval_ta
     if hasattr(model, 'prepare_entities'):           # TransR: the entity side of both passes, once (it does not depend on the queries)
         ents = model.prepare_entities()
         head_fn, tail_fn = (lambda t, r: model.evaluateHead(t, r, ents=ents)), (lambda h, r: model.evaluateTail(h, r, ents=ents))
+    # models with rank_entities (TransE, TransH): the whole pass -- scores and filtered gold ranks -- behind one call per direction
+    rank = (lambda head: (lambda q, r, desc, go, gi, fo, fi: model.rank_entities(q, r, head, desc, go, gi, fo, fi))) \
+        if hasattr(model, 'rank_entities') else (lambda head: None)
     head_results = D.kg_eval_pass(FLAGS, head_fn, eval_head_iter, eval_head_dict, all_head_dicts, eval_descending,
-                                  want_rows=is_report, shard=kg_shard_fn(model, True))
+                                  want_rows=is_report, shard=kg_shard_fn(model, True), rank_fn=rank(True))
     tail_results = D.kg_eval_pass(FLAGS, tail_fn, eval_tail_iter, eval_tail_dict, all_tail_dicts, eval_descending,
-                                  want_rows=is_report, shard=kg_shard_fn(model, False))
+                                  want_rows=is_report, shard=kg_shard_fn(model, False), rank_fn=rank(False))
     perf = D.summarize_kg(FLAGS, head_results, tail_results, logger)
     if is_report:
         D.report_kg(head_results, tail_results, logger)

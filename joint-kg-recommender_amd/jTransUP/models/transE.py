@@ -35,3 +35,9 @@ class TransEModel(nn.Module, GradToggle):
     def evaluateTail(self, h, r):
         """K12: distance of h + r to every entity (transE.py:86-105)."""
         return ops.eval_transe(self.ent_embeddings.weight, self.rel_embeddings.weight, h, r, self.L1_flag, head=False)
+
+    def rank_entities(self, q, r, head, descending, gold_off, gold_ids, filt_off=None, filt_ids=None):
+        """A whole evaluateHead / evaluateTail pass + the filtered gold ranks of utils/misc.py:125-146 in one call (K12 + K18 per
+        chunk of 512 keys under the C ABI): int32 device vector, one rank per gold entry of the pass's CSR index."""
+        return ops.eval_kg_ranks(self.ent_embeddings.weight, self.rel_embeddings.weight, None, q, r, self.L1_flag, head, descending,
+                                 gold_off, gold_ids, filt_off, filt_ids)

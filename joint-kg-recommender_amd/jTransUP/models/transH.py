@@ -43,3 +43,9 @@ class TransHModel(nn.Module, GradToggle):
         """K13 (transH.py:98-121)."""
         E, R, N = self._tables()
         return ops.eval_transh(E, R, N, h, r, self.L1_flag, head=False)
+
+    def rank_entities(self, q, r, head, descending, gold_off, gold_ids, filt_off=None, filt_ids=None):
+        """A whole evaluateHead / evaluateTail pass + the filtered gold ranks of utils/misc.py:125-146 in one call (K13 + K18 per
+        chunk of 512 keys under the C ABI): int32 device vector, one rank per gold entry of the pass's CSR index."""
+        E, R, N = self._tables()
+        return ops.eval_kg_ranks(E, R, N, q, r, self.L1_flag, head, descending, gold_off, gold_ids, filt_off, filt_ids)

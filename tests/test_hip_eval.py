@@ -486,3 +486,83 @@ def test_transr_entity_side_prepared_once_per_pass(d, ne, nrel):
                 assert torch.equal(a, b), (d, l1, nq, head)
         with pytest.raises(L.KtupError):
             ops().eval_transr(E, R, M, q, r, not l1, True, ents=ents)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('model', ['transe', 'transh'])
+def test_kg_ranks_whole_pass_equals_the_batch_walk(model):
+    """ktup_eval_kg_ranks (the loop over 512-key batches under the C ABI) yields the integers of the per-batch route -- K12 / K13
+    score matrix + K18 on the batch's CSR slice -- and of the oracle's walk over the oracle's scores: 1,100 keys = two full
+    chunks + a ragged one, head and tail, L1 and L2, ascending and descending, with and without filters, golds that are filtered,
+    keys without golds."""
+    rng = np.random.RandomState(17)
+    ne, nr, d, nq = 700, 9, 100, 1100
+    gen = torch.Generator().manual_seed(4)
+    E, R, N = O.make_table(ne, d, gen), O.make_table(nr, d, gen), O.make_table(nr, d, gen)
+    q = torch.from_numpy(rng.randint(0, ne, size=nq)); r = torch.from_numpy(rng.randint(0, nr, size=nq))
+    _, filt, gold, f_off, f_ids, g_off, g_ids = _rank_case(rng, nq, ne, 60, 6, 0)
+    Ed, Rd, Nd = dv(E.numpy()), dv(R.numpy()), dv(N.numpy())
+    qd, rd = q.to(DEV), r.to(DEV)
+    for head in (True, False):
+        for l1 in (False, True):
+            for desc in (False, True):
+                for with_filter in (True, False):
+                    fo, fi = (dv(f_off), dv(f_ids)) if with_filter else (None, None)
+                    got = ops().eval_kg_ranks(Ed, Rd, Nd if model == 'transh' else None, qd, rd, l1, head, desc, dv(g_off), dv(g_ids), fo, fi)
+                    want = []
+                    for s in range(0, nq, 512):
+                        e = min(nq, s + 512)
+                        sc = ops().eval_transe(Ed, Rd, qd[s:e], rd[s:e], l1, head) if model == 'transe' else \
+                            ops().eval_transh(Ed, Rd, Nd, qd[s:e], rd[s:e], l1, head)
+                        lo = int(g_off[s])
+                        args = (dv(f_off[s:e + 1] - f_off[s]), dv(f_ids[int(f_off[s]):])) if with_filter else ()
+                        want.append(ops().gold_ranks(sc, desc, dv(g_off[s:e + 1] - lo), dv(g_ids[lo:]), *args)[:int(g_off[e]) - lo])
+                    assert torch.equal(got[:len(g_ids)], torch.cat(want))
+    # against the oracle end to end (scores of the oracle, stable walk), a few keys of each kind
+    sel = list(range(0, 40)) + list(range(500, 530)) + list(range(1080, 1100))
+    for head in (True, False):
+        sc = (O.eval_transe(E, R, q[sel], r[sel], False, head) if model == 'transe' else O.eval_transh(E, R, N, q[sel], r[sel], False, head)).numpy()
+        _, want_ranks = _rank_oracle(sc, [filt[i] for i in sel], [gold[i] for i in sel], False, 10)
+        got = ops().eval_kg_ranks(Ed, Rd, Nd if model == 'transh' else None, qd, rd, False, head, False, dv(g_off), dv(g_ids), dv(f_off), dv(f_ids)).cpu().numpy()
+        got_sel = np.concatenate([got[int(g_off[i]):int(g_off[i + 1])] for i in sel])
+        # the oracle's scores differ from the device's in the last bits: ranks may move by the number of near-ties only
+        assert np.array_equal(got_sel < 0, want_ranks < 0) and np.abs(got_sel - want_ranks).max() <= 1 and (got_sel == want_ranks).mean() > 0.98
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('want_rows', [False, True])
+def test_kg_eval_pass_whole_pass_route_equals_the_batch_walk(want_rows, monkeypatch):
+    """_driver.kg_eval_pass with a model's rank_entities (scores + filtered gold ranks of the WHOLE pass behind one call) returns
+    exactly what the walk over the batches returns -- the (hit, rank) array of the periodic evaluations and the report rows
+    (hit, rank, key, gold id) -- for TransH through an entity remap, keys without golds, golds that are filtered, and with
+    KTUP_EVAL_PASS=0 it steps aside."""
+    import types
+    from jTransUP.models import _driver as D
+    from jTransUP.models import transH
+    rng = np.random.RandomState(8)
+    torch.manual_seed(2)
+    ne, nr, nq = 600, 6, 700
+    m = transH.TransHModel(False, 64, ne, nr).to(DEV)
+    m.eval(); m.disable_grad()
+    FL = types.SimpleNamespace(topn=10)
+    remap = {e: (e * 7) % ne for e in range(ne)}                  # a permutation of the entity ids (e_map of the joint drivers)
+    keys = [(int(rng.randint(ne)), int(rng.randint(nr))) for _ in range(nq)]
+    keys = list(dict.fromkeys(keys))
+    gold = {k: set(rng.choice(ne, size=rng.randint(1, 5), replace=False).tolist()) for k in keys if k[0] % 11}
+    filt = {k: set(rng.choice(ne, size=30, replace=False).tolist()) | (set(list(gold[k])[:1]) if k in gold and k[0] % 3 == 0 else set()) for k in keys}
+    batches = [keys[s:s + 128] for s in range(0, len(keys), 128)]
+    score_fn = lambda q, r: m.evaluateTail(q, r)
+    rank_fn = lambda q, r, desc, go, gi, fo, fi: m.rank_entities(q, r, False, desc, go, gi, fo, fi)
+    for desc in (False, True):
+        walk = D.kg_eval_pass(FL, score_fn, batches, gold, [filt], desc, remap=remap, want_rows=want_rows)
+        fused = D.kg_eval_pass(FL, score_fn, batches, gold, [filt], desc, remap=remap, want_rows=want_rows, rank_fn=rank_fn)
+        if want_rows:
+            assert fused == walk and len(walk) > 0
+        else:
+            assert fused.shape == walk.shape and walk.shape[0] > 0
+            np.testing.assert_array_equal(fused, walk)
+    calls = []
+    monkeypatch.setenv('KTUP_EVAL_PASS', '0')
+    D.kg_eval_pass(FL, score_fn, batches, gold, [filt], False, remap=remap, want_rows=want_rows,
+                   rank_fn=lambda *a: calls.append(1))
+    assert not calls

@@ -25,5 +25,6 @@ done
 timeout 600 python tools/kernel_times.py > $P/${TAG}_kernel_times.txt 2>/dev/null
 (timeout 300 python tools/config5_step.py; timeout 300 python tools/config5_step.py --zipf 1.05) > $P/${TAG}_config5_step.txt 2>/dev/null
 timeout 900 python tools/cli_throughput.py > $P/${TAG}_cli_throughput.txt 2>/dev/null
+timeout 300 python tools/kg_eval_pass.py > $P/${TAG}_kg_eval_pass.txt 2>/dev/null
 timeout 900 python bench.py > $P/${TAG}_bench.json 2>/dev/null
 ls -la $P

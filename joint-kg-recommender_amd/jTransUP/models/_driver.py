@@ -170,9 +170,10 @@ _KG_PASS_IDS = {}
 _PINNED = {}
 
 
-def _to_host(t):
+def _to_host(t, copy=True):
     """Device -> host through a cached pinned buffer (a pageable destination costs a staging copy: 24 vs 14 us for the 240 KB of
-    metric columns of an ml1m pass).  The returned array is a copy."""
+    metric columns of an ml1m pass).  The returned array is a copy (copy=False: a view of the pinned buffer, valid until the
+    next call with this shape -- for callers that index or copy it right away)."""
     key = (tuple(t.shape), t.dtype)
     pin = _PINNED.get(key)
     if pin is None:
@@ -181,12 +182,29 @@ def _to_host(t):
         pin = _PINNED[key] = torch.empty(t.shape, dtype=t.dtype).pin_memory()
     pin.copy_(t, non_blocking=True)
     torch.cuda.current_stream(t.device).synchronize()
-    return pin.numpy().copy()
+    return pin.numpy().copy() if copy else pin.numpy()
 
 
-def _rec_eval_fused(FLAGS, pass_fn, eval_iter, index):
+_EVAL_GRAPHS = {}
+
+
+def _present_rows(host, index):
+    """The metric rows of the keys that have gold items, as an array of their own (`host` is a view of a reused buffer)."""
+    return host.copy() if index.all_present else host[index.present_h]
+
+
+def model_graph_key(model):
+    """What a captured evaluation pass of `model` depends on besides the pass's own inputs: the addresses of its tables."""
+    return (id(model),) + tuple(p.data_ptr() for p in model.parameters())
+
+
+def _rec_eval_fused(FLAGS, pass_fn, eval_iter, index, graph_key=None):
     """The whole pass in one sweep: every evaluation user at once through the fused score + filtered top-n kernel
-    (model.evaluate_topk), the per-user metrics on the device (K18b), one (users x 5) copy back.  None if the model declines."""
+    (model.evaluate_topk), the per-user metrics on the device (K18b), one (users x 5) copy back.  None if the model declines.
+    With a `graph_key` (model_graph_key: the pass reads the tables in place, so the same launches serve every periodic
+    evaluation of a run) the second pass is captured -- item side, sweep, merge, metrics --
+    and every later one is ONE graph replay + the copy back: the ~6 launches of a 0.22 ms pass otherwise leave ~0.03 ms of gaps between them.
+    KTUP_EVAL_GRAPH=0 switches the replay off."""
     from jTransUP.hip import ops
     hit = _PASS_IDS.get(id(eval_iter))
     if hit is None or hit[0] is not eval_iter:
@@ -194,14 +212,36 @@ def _rec_eval_fused(FLAGS, pass_fn, eval_iter, index):
     users = hit[1]
     if users.numel() == 0:
         return np.zeros((0, 5))
-    top = pass_fn(users, index.f_off if index.has_filter else None, index.f_ids if index.has_filter else None, FLAGS.topn)
-    if top is None:
-        return None
-    cols = ops.rec_metrics(top, index.g_off, index.g_ids)
-    return _to_host(cols)[index.present_h]
+    fo, fi = (index.f_off, index.f_ids) if index.has_filter else (None, None)
+
+    def body():
+        top = pass_fn(users, fo, fi, FLAGS.topn)
+        return None if top is None else ops.rec_metrics(top, index.g_off, index.g_ids)
+
+    use_graph = graph_key is not None and os.environ.get('KTUP_EVAL_GRAPH', '1') != '0'
+    key = (id(eval_iter), id(index), FLAGS.topn, graph_key)
+    entry = _EVAL_GRAPHS.get(key) if use_graph else None
+    if entry is not None and (entry[2] is not eval_iter or entry[3] is not index):
+        entry = None
+    if entry is None:
+        cols = body()                                   # eager: the first pass of a run, or no replay wanted
+        if cols is None:
+            return None
+        if use_graph:
+            if len(_EVAL_GRAPHS) > 16:
+                _EVAL_GRAPHS.clear()
+            _EVAL_GRAPHS[key] = (None, None, eval_iter, index)           # seen once: the next pass captures
+        return _present_rows(_to_host(cols, copy=False), index)
+    if entry[0] is None:                                # second pass: capture (allocations land in the graph's own pool), then replay
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            cols = body()
+        entry = _EVAL_GRAPHS[key] = (graph, cols, eval_iter, index)
+    entry[0].replay()
+    return _present_rows(_to_host(entry[1], copy=False), index)     # the copy back stays outside the graph (a copy node: 0.5 ms)
 
 
-def rec_eval_pass(FLAGS, score_fn, eval_iter, eval_dict, all_dicts, descending, want_rows=True, shard=None, pass_fn=None):
+def rec_eval_pass(FLAGS, score_fn, eval_iter, eval_dict, all_dicts, descending, want_rows=True, shard=None, pass_fn=None, graph_key=None):
     """One pass over the evaluation users: all-item scores, filtered top-n, metric rows (misc.py:148-248 semantics).
     want_rows=False returns the (n x 5) metric array only (no per-user report rows).  Under torchrun the batches are
     dealt round-robin to the ranks and the results gathered, so every rank reports the same numbers."""
@@ -209,7 +249,7 @@ def rec_eval_pass(FLAGS, score_fn, eval_iter, eval_dict, all_dicts, descending, 
     if _shard_mode(FLAGS, shard, want_rows):
         return _rec_eval_sharded(FLAGS, shard, eval_iter, index, descending)
     if pass_fn is not None and not want_rows and not descending and os.environ.get('KTUP_EVAL_PASS', '1') != '0':
-        fused = _rec_eval_fused(FLAGS, pass_fn, eval_iter, index)      # every rank runs the whole pass: ~0.3 ms at ml1m size
+        fused = _rec_eval_fused(FLAGS, pass_fn, eval_iter, index, graph_key)      # every rank runs the whole pass: ~0.3 ms at ml1m size
         if fused is not None:
             return fused
     mine, world = _my_batches(len(eval_iter))

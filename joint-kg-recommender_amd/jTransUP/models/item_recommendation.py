@@ -21,12 +21,17 @@ def evaluate(FLAGS, model, eval_iter, eval_dict, all_dicts, logger, eval_descend
     model.eval(); model.disable_grad()
     score_fn = model.evaluate
     if hasattr(model, 'prepare_items'):            # TUP: the item side of the gate once per pass (weights are frozen here)
-        items = model.prepare_items()
-        score_fn = lambda u: model.evaluate(u, items=items)
+        lazy = []                                  # ... and only if the batch walk runs at all
+
+        def score_fn(u):
+            if not lazy:
+                lazy.append(model.prepare_items())
+            return model.evaluate(u, items=lazy[0])
     from jTransUP.models._shard_eval import rec_shard_fn
-    pass_fn = (lambda u, fo, fi, n: model.evaluate_topk(u, items, n, fo, fi)) if hasattr(model, 'evaluate_topk') else None
+    # the whole-pass route prepares its own item side, so that a captured pass (D._rec_eval_fused) recomputes it from the tables
+    pass_fn = (lambda u, fo, fi, n: model.evaluate_topk(u, model.prepare_items(), n, fo, fi)) if hasattr(model, 'evaluate_topk') else None
     results = D.rec_eval_pass(FLAGS, score_fn, eval_iter, eval_dict, all_dicts, eval_descending, want_rows=is_report,
-                              shard=rec_shard_fn(model), pass_fn=pass_fn)
+                              shard=rec_shard_fn(model), pass_fn=pass_fn, graph_key=D.model_graph_key(model) if pass_fn else None)
     perf = D.summarize_rec(FLAGS, results, logger)
     if is_report:
         D.report_rec(FLAGS, model, results, all_dicts, eval_dict, logger, FLAGS.model_type in ('transup', 'jtransup', 'cjtransup'))

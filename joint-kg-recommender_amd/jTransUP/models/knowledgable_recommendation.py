@@ -46,14 +46,21 @@ def getMappedItems(e_ids, e_remap, new_map):
 def evaluateRec(FLAGS, model, eval_iter, eval_dict, all_dicts, i_map, logger, eval_descending=True, is_report=False):
     all_i_var = D.ids([i_map[i] for i in range(len(i_map))]) if FLAGS.share_embeddings else None
     model.eval(); model.disable_grad()
-    items = model.prepare_items(all_i_var) if hasattr(model, 'prepare_items') else None     # item side once per pass
-    score_fn = (lambda u: model.evaluateRec(u, all_i_ids=all_i_var, items=items)) if items is not None \
-        else (lambda u: model.evaluateRec(u, all_i_ids=all_i_var))
+    has_items = hasattr(model, 'prepare_items')
+    lazy = []                                      # item side once per pass, and only if the batch walk runs at all
+
+    def score_fn(u):
+        if not has_items:
+            return model.evaluateRec(u, all_i_ids=all_i_var)
+        if not lazy:
+            lazy.append(model.prepare_items(all_i_var))
+        return model.evaluateRec(u, all_i_ids=all_i_var, items=lazy[0])
     from jTransUP.models._shard_eval import rec_shard_fn
-    pass_fn = (lambda u, fo, fi, n: model.evaluate_topk(u, items, n, fo, fi)) \
-        if items is not None and hasattr(model, 'evaluate_topk') and not FLAGS.share_embeddings else None
+    # the whole-pass route prepares its own item side, so that a captured pass (D._rec_eval_fused) recomputes it from the tables
+    pass_fn = (lambda u, fo, fi, n: model.evaluate_topk(u, model.prepare_items(), n, fo, fi)) \
+        if has_items and hasattr(model, 'evaluate_topk') and not FLAGS.share_embeddings else None
     results = D.rec_eval_pass(FLAGS, score_fn, eval_iter, eval_dict, all_dicts, eval_descending, want_rows=is_report,
-                              shard=rec_shard_fn(model), pass_fn=pass_fn)
+                              shard=rec_shard_fn(model), pass_fn=pass_fn, graph_key=D.model_graph_key(model) if pass_fn else None)
     perf = D.summarize_rec(FLAGS, results, logger)
     if is_report:
         D.report_rec(FLAGS, model, results, all_dicts, eval_dict, logger, FLAGS.model_type in ('transup', 'jtransup'))

@@ -59,6 +59,7 @@ class RankIndex(object):
         rows = np.repeat(np.arange(len(self.keys), dtype=np.int64), np.diff(self.g_off_h))
         self.g_keys_h = (rows << 32) | self.g_ids_h.astype(np.int64)
         self.present_h = np.asarray(self.present, dtype=bool)
+        self.all_present = bool(self.present_h.all())
         self._memo, self._fslice, self._gslice = {}, {}, {}
 
     # The batches of an evaluation iterator are the same objects in every pass, so what is derived from one (its row range,

@@ -566,3 +566,49 @@ def test_kg_eval_pass_whole_pass_route_equals_the_batch_walk(want_rows, monkeypa
     D.kg_eval_pass(FL, score_fn, batches, gold, [filt], False, remap=remap, want_rows=want_rows,
                    rank_fn=lambda *a: calls.append(1))
     assert not calls
+
+
+@pytest.mark.gpu
+def test_fused_rec_pass_replayed_as_a_graph_follows_the_tables(monkeypatch):
+    """_driver._rec_eval_fused with a graph key: the first pass runs eagerly, the second is captured (item side, sweep, merge,
+    metrics, copy into a pinned buffer) and every later one is a replay -- which must see the tables as they are NOW (the
+    optimizer updates them in place between evaluations).  Every pass equals the eager route on the same tables; a model whose
+    tables moved gets its own graph; KTUP_EVAL_GRAPH=0 keeps everything eager."""
+    import types
+    from jTransUP.models import _driver as D
+    from jTransUP.models import jTransUP as jt
+    torch.manual_seed(5)
+    rng = np.random.RandomState(5)
+    NU, NI, NE, NR, Dm = 300, 177, 150, 7, 100
+    i_map = {i: i for i in range(NI)}
+    new_map = {i: ((i * 3) % NE if i % 5 else -1, i) for i in range(NI)}
+    m = jt.jTransUPModel(False, Dm, NU, NI, NE, NR, i_map, new_map, False, False)
+    m.eval(); m.disable_grad()
+    FL = types.SimpleNamespace(topn=10)
+    users = list(range(NU))
+    gold = {u: set(rng.choice(NI, size=rng.randint(1, 9), replace=False).tolist()) for u in users if u % 9}
+    train = {u: set(rng.choice(NI, size=25, replace=False).tolist()) for u in users}
+    batches = [users[s:s + 64] for s in range(0, NU, 64)]
+    index = D.rank_index(batches, gold, [train])
+    pass_fn = lambda u, fo, fi, n: m.evaluate_topk(u, m.prepare_items(), n, fo, fi)
+    D._EVAL_GRAPHS.clear()
+    for step in range(5):
+        key = D.model_graph_key(m)
+        got = D._rec_eval_fused(FL, pass_fn, batches, index, key)
+        want = D._rec_eval_fused(FL, pass_fn, batches, index, None)
+        assert got.shape == (sum(1 for u in users if u % 9), 5)
+        np.testing.assert_array_equal(got, want)
+        entry = D._EVAL_GRAPHS[(id(batches), id(index), 10, key)]
+        assert (entry[0] is None) == (step == 0)                  # eager once, then a graph
+        with torch.no_grad():                                      # a training step's worth of change, in place
+            for p in m.parameters():
+                p.add_(torch.randn_like(p) * 0.05)
+    moved = m.user_embeddings.weight.data.clone()
+    m.user_embeddings.weight.data = moved                          # the table now lives elsewhere: another key, another graph
+    assert D.model_graph_key(m) != key
+    np.testing.assert_array_equal(D._rec_eval_fused(FL, pass_fn, batches, index, D.model_graph_key(m)),
+                                  D._rec_eval_fused(FL, pass_fn, batches, index, None))
+    monkeypatch.setenv('KTUP_EVAL_GRAPH', '0')
+    n = len(D._EVAL_GRAPHS)
+    D._rec_eval_fused(FL, pass_fn, batches, index, ('other',))
+    assert len(D._EVAL_GRAPHS) == n

@@ -15,6 +15,10 @@
 //      transposes; accumulators stay in registers across the wave's tiles and reach memory with one atomic per element.
 // The first backward kernel (pref_bwd_kernel, lane = pair, 64-pair workgroup tiles, VALU) needs 118 us for the 1024 pairs
 // of a B=512 step because only 16 workgroups exist and each walks its tile serially; here a tile is ~450 MFMAs.
+// Occupancy is one wave per SIMD (four per CU: the per-wave LDS tiles), so the schedule hides its own waits: rows of the next
+// tile gathered a tile ahead, LDS operands of step i + 1 read before the MFMAs of step i, phase C's stores issued under the next
+// coordinate tile's MFMAs (tools/wave_model.py compares such schedules on the ISA).  With 17-20 preferences
+// the four live rows of the second preference tile take v_mfma_f32_4x4x1 in phase D (BGeom::THIN).
 #include <hip/hip_runtime.h>
 
 #include <cstdint>

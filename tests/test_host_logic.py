@@ -286,3 +286,22 @@ def test_rank_index_csr_layout_on_cpu():
         idx.rows_of([9, 7])
     none = RankIndex(keys, eval_dict, None, torch.device('cpu'))
     assert none.filter_slice(0, 2) == (None, None)
+
+
+def test_wave_model_counts_the_waits_a_lone_wave_cannot_hide():
+    """tools/wave_model.py (the one-wave issue model used to compare schedules of the K5-K7 backward tile): an LDS read waited for
+    right away costs its latency; the same read issued ahead of eight independent MFMAs costs nothing; dependent MFMAs serialise on
+    the matrix pipe either way; a VALU read of an MFMA result waits for the pipe."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('wave_model', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools', 'wave_model.py'))
+    W = importlib.util.module_from_spec(spec); spec.loader.exec_module(W)
+    mf = ['v_mfma_f32_16x16x4_f32 a[%d:%d], v1, v2, a[%d:%d]' % (4 * i, 4 * i + 3, 4 * i, 4 * i + 3) for i in range(8)]
+    late = W.model(mf + ['ds_read_b128 v[10:13], v0', 's_waitcnt lgkmcnt(0)', 'v_mfma_f32_16x16x4_f32 a[0:3], v10, v2, a[0:3]'])
+    early = W.model(['ds_read_b128 v[10:13], v0'] + mf + ['s_waitcnt lgkmcnt(0)', 'v_mfma_f32_16x16x4_f32 a[0:3], v10, v2, a[0:3]'])
+    assert late['mfma'] == early['mfma'] == 9
+    assert early['stall_lgkm'] == 0 and late['stall_lgkm'] > 0
+    assert late['clocks'] > early['clocks']
+    chain = W.model(['v_mfma_f32_16x16x4_f32 a[0:3], v1, v2, a[0:3]'] * 4 + ['v_accvgpr_read_b32 v5, a0'])
+    assert chain['clocks'] >= 4 * 32 and chain['stall_mfma_dep'] > 0
+    thin = W.model(['v_mfma_f32_4x4x1_16b_f32 a[0:3], v1, v2, a[0:3]'] * 4)
+    assert thin['clocks'] < W.model(['v_mfma_f32_16x16x4_f32 a[0:3], v1, v2, a[0:3]'] * 4)['clocks']

@@ -7,7 +7,7 @@ R=$(pwd)
 P=$R/gpurun_out/profiles
 mkdir -p $P
 timeout 900 python tools/collect_profiles.py $TAG > $R/gpurun_out/${TAG}_collect.log 2>&1
-for W in train_step fed_step eval_pass seg_bwd kg_rank; do
+for W in train_step fed_step eval_pass seg_bwd kg_rank kg_pass; do
   rm -rf /tmp/kp_$W
   (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kp_$W -- python $R/tools/pmc_workloads.py $W > /dev/null 2>&1)
   F=$(find /tmp/kp_$W -name "*kernel_stats.csv" | head -1)

@@ -4,6 +4,7 @@
     fed_step    the device-fed B=512 joint step (-device_sampling): feed launch + step + clip/optimizer, ten-step graphs
     seg_bwd     the large-batch backwards by sorted segments: TransE (307,200 triples) and KTUP (716,800 pairs), 5 each
     kg_rank     the filtered gold ranks of one 512-query KG evaluation batch over 14,709 entities (ktup_eval_gold_ranks), 10 calls
+    kg_pass     one direction of a link-prediction pass, 20,480 keys x 14,709 entities behind one call (ktup_eval_kg_ranks, TransH), 3 passes
 tools/pmc_summary.py turns the counter_collection.csv into per-kernel averages."""
 import os
 import sys
@@ -95,5 +96,22 @@ def kg_rank(dev):
     torch.cuda.synchronize()
 
 
+def kg_pass(dev):
+    from jTransUP.hip import ops
+    gen = torch.Generator().manual_seed(7)
+    nq = 20480
+    E = torch.nn.functional.normalize(torch.randn(B.NE, B.D, generator=gen), dim=1).to(dev)
+    R = torch.nn.functional.normalize(torch.randn(B.NR, B.D, generator=gen), dim=1).to(dev)
+    N = torch.nn.functional.normalize(torch.randn(B.NR, B.D, generator=gen), dim=1).to(dev)
+    q = torch.randint(0, B.NE, (nq,), generator=gen).to(dev); r = torch.randint(0, B.NR, (nq,), generator=gen).to(dev)
+    g_off = (torch.arange(nq + 1) * 2).to(dev)
+    g_ids = torch.randint(0, B.NE, (nq * 2,), generator=gen).to(dev, torch.int32)
+    f_off = (torch.arange(nq + 1) * 20).to(dev)
+    f_ids = torch.randint(0, B.NE, (nq * 20,), generator=gen).to(dev, torch.int32)
+    for _ in range(3):
+        ops.eval_kg_ranks(E, R, N, q, r, False, False, False, g_off, g_ids, f_off, f_ids)
+    torch.cuda.synchronize()
+
+
 if __name__ == '__main__':
-    {'kg_rank': kg_rank, 'eval_pass': eval_pass, 'train_step': train_step, 'fed_step': fed_step, 'seg_bwd': seg_bwd}[sys.argv[1]](torch.device('cuda'))
+    {'kg_pass': kg_pass, 'kg_rank': kg_rank, 'eval_pass': eval_pass, 'train_step': train_step, 'fed_step': fed_step, 'seg_bwd': seg_bwd}[sys.argv[1]](torch.device('cuda'))

@@ -478,13 +478,31 @@ __global__ __launch_bounds__(256) void pref_bwd_wide_kernel(WArgs a) {
         for (int m = 0; m < NP; ++m)
           gx = __builtin_amdgcn_mfma_f32_16x16x4f32(Alog2[rb[m] + 16 * ct], gl[m >> 2][m & 3], gx, 0, 0, 0);
         const int c0 = 4 * NCW * w + 16 * ct + 4 * kq;
+        v4 gu = gq[ct] + gx;
+        const v4 gv = gx - gq[ct];
+        bool u_mine = true;
+        if constexpr (STEP && !ROWOUT) {
+          // slots j and j ^ 8 hold a positive and its negative -- the same user in a BPR batch: their user-row gradients are summed
+          // through one DPP rotate (row_ror:8, every lane of the wave active here) and slot j < 8 issues ONE atomic for both instead
+          // of two on the same address (a third of the step's row atomics)
+          const int32_t uo = __builtin_amdgcn_update_dpp(ur, ur, 0x128, 0xf, 0xf, false);
+          v4 go;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const int x = __float_as_int(gu[c]);
+            go[c] = __int_as_float(__builtin_amdgcn_update_dpp(x, x, 0x128, 0xf, 0xf, false));
+          }
+          if (uo == ur) {
+            u_mine = j < 8;
+            gu = gu + go;
+          }
+        }
         if (live && (!RAGGED || c0 < D)) {
-          const v4 gu = gq[ct] + gx, gv = gx - gq[ct];
           if constexpr (ROWOUT) {
             *reinterpret_cast<v4*>(a.GU + gr * D + c0) = gu;
             *reinterpret_cast<v4*>(a.GV + gr * D + c0) = gv;
           } else {
-            atomic_add4(pu + c0, make_float4(gu[0], gu[1], gu[2], gu[3]));
+            if (u_mine) atomic_add4(pu + c0, make_float4(gu[0], gu[1], gu[2], gu[3]));
             atomic_add4(pi + c0, make_float4(gv[0], gv[1], gv[2], gv[3]));
             if (pe) atomic_add4(pe + c0, make_float4(gv[0], gv[1], gv[2], gv[3]));
           }

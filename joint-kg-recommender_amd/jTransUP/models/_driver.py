@@ -193,6 +193,13 @@ def _present_rows(host, index):
     return host.copy() if index.all_present else host[index.present_h]
 
 
+def _single_process():
+    """Graph capture of the evaluation pass is kept to single-process runs: under torchrun a collective backend's own threads
+    may touch the device while a capture is open."""
+    import torch.distributed as dist
+    return not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+
+
 def model_graph_key(model):
     """What a captured evaluation pass of `model` depends on besides the pass's own inputs: the addresses of its tables."""
     return (id(model),) + tuple(p.data_ptr() for p in model.parameters())
@@ -204,7 +211,7 @@ def _rec_eval_fused(FLAGS, pass_fn, eval_iter, index, graph_key=None):
     With a `graph_key` (model_graph_key: the pass reads the tables in place, so the same launches serve every periodic
     evaluation of a run) the second pass is captured -- item side, sweep, merge, metrics --
     and every later one is ONE graph replay + the copy back: the ~6 launches of a 0.22 ms pass otherwise leave ~0.03 ms of gaps between them.
-    KTUP_EVAL_GRAPH=0 switches the replay off."""
+    KTUP_EVAL_GRAPH=0 switches the replay off; runs with more than one process never capture."""
     from jTransUP.hip import ops
     hit = _PASS_IDS.get(id(eval_iter))
     if hit is None or hit[0] is not eval_iter:
@@ -218,7 +225,7 @@ def _rec_eval_fused(FLAGS, pass_fn, eval_iter, index, graph_key=None):
         top = pass_fn(users, fo, fi, FLAGS.topn)
         return None if top is None else ops.rec_metrics(top, index.g_off, index.g_ids)
 
-    use_graph = graph_key is not None and os.environ.get('KTUP_EVAL_GRAPH', '1') != '0'
+    use_graph = graph_key is not None and os.environ.get('KTUP_EVAL_GRAPH', '1') != '0' and _single_process()
     key = (id(eval_iter), id(index), FLAGS.topn, graph_key)
     entry = _EVAL_GRAPHS.get(key) if use_graph else None
     if entry is not None and (entry[2] is not eval_iter or entry[3] is not index):

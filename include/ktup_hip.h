@@ -355,6 +355,65 @@ int ktup_shard_sparse_step(int kind, float* table, int64_t ldt, float* state, in
                            int64_t n, const float* grows, int64_t ldg, float lr, float eps, const double* sumsq,
                            float max_norm, void* stream);
 
+/* ---- the same exchange with FIXED shapes: config 5's step without a host synchronisation (csrc/ktup_shard_step.hip) -----------
+ * Replaces, for the KTUP rec step over row-sharded tables, the lines knowledgable_recommendation.py:335-344,394-403 (model(pos),
+ * model(neg), bprLoss, backward, clip_grad_norm, optimizer.step) over jTransUP.py:122-143; the reference is single-device.
+ *
+ * Wire layout.  T <= KTUP_SHARD_MAX_TABLES tables, `world` owners (owner of global row g = g % world, its local row = g / world),
+ * cap[t] slots per (owner, table): wire row  w = owner * capsum + toff[t] + slot  with toff = prefix sums of cap, capsum = sum of
+ * cap, W = world * capsum rows (+ one all-zero row W that stands for "no row").  The id send buffer, the row buffer, the compact
+ * table the scorer reads and the gradient buffer all use this layout, so every exchange is an all-to-all with EQUAL splits
+ * (capsum rows per peer) and nothing is re-ordered between them.
+ *
+ * ktup_shard_route: `ids` = n_entries ids in blocks of `block` entries; inside a block entries [ent_off[t], ent_off[t+1]) belong to
+ *   table t (ent_off: n_tables + 1 HOST values, ent_off[n_tables] = block); negative ids are padding.  Outputs, all on the device:
+ *   inverse[e] = wire row of entry e (W for padding); send_ids[w] = owner-local row of wire row w, -1 where the slot is unused;
+ *   pair_map (may be NULL; needs n_entries == block): for an entry of table pair_a, pair_map[its wire row] = wire row of the entry
+ *   at the same position of table pair_b, or W if that entry is padding (KTUP: item row -> entity row, jTransUP.py:114-130);
+ *   sort_ws (ktup_shard_route_sort_bytes(n_entries, W) bytes, int32): the entries counting-sorted by wire row for
+ *   ktup_shard_reduce_rows; counters: world * n_tables + 1 int32, the last one counts ids that found no free slot (cap too small:
+ *   the caller must then skip the step -- ktup_shard_apply does when handed that word); zero_doubles: n_zero_doubles device doubles
+ *   cleared by the same launch (the step's accumulators).  `ws`: ktup_shard_route_workspace_bytes(n_entries), 8-byte aligned.
+ *   No memset, no host read: five launches, capturable.  On the owner side of a multi-rank step the same call with world = 1 and
+ *   block = capsum groups the rows several peers asked for.
+ * ktup_shard_reduce_rows: gwire[w] += sum of G rows of the entries sorted to wire row w; entry e reads row e of G for e < n_src,
+ *   row e - src_off otherwise (KTUP: G = [GU ; GV] of ktup_train_rec_step_rows, 4B rows; the 2B entity entries re-read GV:
+ *   n_src = 4B, src_off = 2B).  Sorted segments (csrc/ktup_segreduce.hip), no per-element atomics.
+ * ktup_shard_ktup_entries: entries = [u ; u | pos ; neg | item2ent[pos ; neg]] (6B, or 4B when item2ent is NULL), an entity of
+ *   value < 0 or == ent_pad becoming padding.
+ * ktup_shard_pack_wire: out[w] = table_t[ids[w]] for the n_blocks * capsum rows of a wire buffer (t from w's place in its block;
+ *   rows with ids[w] < 0 are left untouched).  tables / ld / cap: HOST arrays of n_tables device pointers / pitches / capacities.
+ * ktup_shard_apply: global-norm clip (coef = min(1, max_norm / (sqrt(*sumsq) + 1e-6))) + row-sparse SGD / Adagrad
+ *   (ktup_shard_sparse_step's rule) for every wire row with ids[w] >= 0, and for `n_small` small replicated gradients of
+ *   small_rows x d each: gradient k updates small_p0[k] (and small_p1[k] if not NULL -- the two summands of a mixed table share
+ *   one gradient); with small_g64 the small gradients are read from that fp64 array (the all-reduced bucket) instead.  Consumed
+ *   gradient rows are zero-filled.  If *skip_count != 0 or *skip_value != 0 (either may be NULL) nothing is updated, gradients are
+ *   still cleared.
+ * ktup_shard_bucket: mode 0: bucket = [small gradients as doubles | *sumsq_local | *overflow]; mode 1 (after the all-reduce):
+ *   *sumsq_total = bucket[n] + small_weight * sum of squares of bucket[0 .. n) (2 when every small gradient feeds two tables).
+ * ktup_zero_async: zero-fill by a kernel (16-byte aligned, multiple of 16 bytes).                                          */
+#define KTUP_SHARD_MAX_TABLES 4
+#define KTUP_SHARD_MAX_SMALL 4
+size_t ktup_shard_route_workspace_bytes(int64_t n_entries);
+size_t ktup_shard_route_sort_bytes(int64_t n_entries, int64_t n_wire_rows);
+int ktup_shard_route(const int64_t* ids, int64_t n_entries, int64_t block, int n_tables, const int64_t* ent_off, int world,
+                     const int64_t* cap, int pair_a, int pair_b, int64_t* inverse, int64_t* send_ids, int32_t* pair_map,
+                     int32_t* sort_ws, int32_t* counters, double* zero_doubles, int n_zero_doubles, void* ws, void* stream);
+int ktup_shard_reduce_rows(const float* G, int64_t ldg, int d, int64_t n_src, int64_t src_off, const int32_t* sort_ws,
+                           int64_t n_entries, int64_t n_wire_rows, float* gwire, int64_t ldw, void* stream);
+int ktup_shard_ktup_entries(const int64_t* u, const int64_t* pos_items, const int64_t* neg_items, int64_t B,
+                            const int32_t* item2ent, int64_t ent_pad, int64_t* entries, void* stream);
+int ktup_shard_pack_wire(int n_tables, float* const* tables, const int64_t* ld, const int64_t* cap, int d, const int64_t* ids,
+                         int64_t n_blocks, float* out, int64_t ldo, void* stream);
+int ktup_shard_apply(int kind, int n_tables, float* const* tables, const int64_t* ld, float* const* states, const int64_t* lds,
+                     const int64_t* cap, int d, const int64_t* ids, int64_t n_blocks, float* grads, int64_t ldg, int n_small,
+                     int small_rows, float* const* small_grads, float* const* small_p0, float* const* small_s0,
+                     float* const* small_p1, float* const* small_s1, const double* small_g64, float lr, float eps,
+                     const double* sumsq, float max_norm, const int32_t* skip_count, const double* skip_value, void* stream);
+int ktup_shard_bucket(int mode, int n_small, float* const* small_grads, int64_t small_elems, double* bucket,
+                      const double* sumsq_local, const int32_t* overflow, double* sumsq_total, double small_weight, void* stream);
+int ktup_zero_async(void* ptr, int64_t nbytes, void* stream);
+
 /* ------------------------------------------- K19  negative sampling on the device  utils/data.py:12-85
  * rec: one uniform negative item per (u, positive): != positive, bit not set in the user's row of
  *      `user_item_bitmap` (n_users x words_per_user uint32, train + eval items; NULL = no filter), and -- when
@@ -409,6 +468,8 @@ int ktup_feed_kg(const int64_t* col_h, const int64_t* col_t, const int64_t* col_
 #define KTUP_OPT_ADAM 2
 #define KTUP_OPT_RMSPROP 3
 int ktup_optim_gradnorm(int n_tensors, float* const* grads, const int64_t* sizes, double* sumsq, void* stream);
+/* the same sum ADDED to *sumsq (no clearing memset inside: for HIP-graph callers that keep their accumulator clean themselves) */
+int ktup_optim_gradnorm_acc(int n_tensors, float* const* grads, const int64_t* sizes, double* sumsq, void* stream);
 int ktup_optim_step(int kind, int n_tensors, float* const* params, float* const* grads, float* const* state1,
                     float* const* state2, const int64_t* sizes, const int64_t* steps, const int64_t* steps_dev,
                     const int32_t* first, float lr, float weight_decay, float momentum, float beta1, float beta2, float eps, float alpha,
@@ -445,6 +506,15 @@ int ktup_train_rec_step(const float* U, int64_t ldu, const float* I, int64_t ldi
                         const int64_t* i_ids, int64_t B, int l1, int gumbel_mode, const float* uniform, uint64_t seed,
                         uint64_t offset, float target, float gscale, int orth, float* loss, float* gU, float* gI, float* gE,
                         float* gP, float* gPn, float* gR, float* gRn, void* stream);
+/* ktup_train_rec_step with the row gradients of pair k (k in [0, 2B): positives then negatives) stored as rows k of GU / GV (GV: the
+ * item row's gradient, which is also its entity row's) instead of accumulated by atomics -- for ktup_shard_reduce_rows / large
+ * batches.  Soft gate only.  gR / gRn may be NULL although rel / norm are given (then orth must be 0): gP / gPn are the gradients
+ * of both summands of the mixed tables.                                                                                   */
+int ktup_train_rec_step_rows(const float* U, int64_t ldu, const float* I, int64_t ldi, const float* E, int64_t lde,
+                             const int32_t* item2ent, int64_t ent_pad, const float* pref, const float* pref_norm,
+                             const float* rel, const float* norm, int64_t ldp, int n_pref, int d, const int64_t* u_ids,
+                             const int64_t* i_ids, int64_t B, int l1, float target, float gscale, int orth, float* loss,
+                             float* GU, float* GV, float* gP, float* gPn, float* gR, float* gRn, void* stream);
 int ktup_train_kg_step(int transh, const float* E, int64_t lde, const float* R, int64_t ldr, const float* Nrm, int64_t ldn,
                        int d, const int64_t* h, const int64_t* t, const int64_t* r, int64_t B, int l1, float margin,
                        float gscale, int regs, float* loss, float* gE, float* gR, float* gN, void* stream);

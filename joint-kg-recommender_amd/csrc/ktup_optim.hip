@@ -414,6 +414,17 @@ extern "C" int ktup_optim_gradnorm(int n_tensors, float* const* grads, const int
   return check_launch("ktup_optim_gradnorm");
 }
 
+// The same sum ADDED to *sumsq (no clearing memset: for callers inside a HIP graph that keep their accumulators clean themselves)
+extern "C" int ktup_optim_gradnorm_acc(int n_tensors, float* const* grads, const int64_t* sizes, double* sumsq, void* stream) {
+  OptTensors T{};
+  KTUP_REQUIRE(grads && sizes && sumsq, "ktup_optim_gradnorm_acc: null pointer argument");
+  if (int e = fill("ktup_optim_gradnorm_acc", T, n_tensors, nullptr, grads, nullptr, nullptr, sizes)) return e;
+  const int64_t nchunks = T.chunk0[T.count];
+  if (nchunks == 0) return KTUP_OK;
+  hipLaunchKernelGGL(gradnorm_kernel, dim3(grid_for((nchunks * 4 + 3) / 4, 256)), dim3(256), 0, (hipStream_t)stream, T, sumsq);
+  return check_launch("ktup_optim_gradnorm_acc");
+}
+
 namespace {
 
 int prep_step(const char* name, OptTensors& T, int kind, int n_tensors, float* const* params, float* const* grads, float* const* state1,

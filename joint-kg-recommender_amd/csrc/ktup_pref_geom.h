@@ -88,7 +88,7 @@ int pref_step_mc(const float* U, int64_t ldu, const float* I, int64_t ldi, const
                  int d, const int64_t* u_ids, const int64_t* i_ids, int64_t B, int l1, int gumbel_mode, const float* uniform,
                  uint64_t seed, uint64_t offset, float target, float gscale, int orth, float* loss, float* gU, float* gI, float* gE,
                  float* gP, float* gPn, float* gR, float* gRn, hipStream_t st,
-                 const char* name);
+                 const char* name, float* GU = nullptr, float* GV = nullptr);
 // ktup_score_pref_bwd_wide.hip: the same backward for d = 256 (config 5): four waves share a 16-pair tile, 64 coordinates each.
 int pref_bwd_mc_wide(const float* U, int64_t ldu, const float* I, int64_t ldi, const float* E, int64_t lde, const int32_t* item2ent,
                      int64_t ent_pad, const float* Alog, const float* Ar, const float* Cn, int dp, float beta, int n_pref, int d,
@@ -108,5 +108,10 @@ bool seg_covers(const float* G, int64_t ldg, int d, int64_t n_src, int64_t m, in
 int seg_sort(const int64_t* ids, const int64_t* ids2, int64_t n_src, int64_t m, int64_t n_rows, void* ws, hipStream_t st, const char* name);
 int seg_apply(const float* G, int64_t ldg, int d, int64_t n_src, int64_t m, int64_t sign_split, int64_t n_rows, float* gT, int64_t ldt,
               const int32_t* map2, int64_t pad2, float* gT2, int64_t ldt2, const void* ws, hipStream_t st, const char* name);
+// for callers that produce the histogram themselves (ktup_shard_step.hip): the scan with a 1024-thread workgroup, and the
+// reduction over a given sorted order whose entry count lives on the device (entry e >= n_src reads row e - src_off of G)
+int seg_scan_wide(int32_t* start, int64_t K, hipStream_t st, const char* name);
+int seg_apply_sorted(const float* G, int64_t ldg, int d, int64_t n_src, int64_t src_off, const int32_t* perm, const int32_t* skey,
+                     int64_t m_max, const int32_t* m_dev, float* gT, int64_t ldt, hipStream_t st, const char* name);
 
 }  // namespace ktup

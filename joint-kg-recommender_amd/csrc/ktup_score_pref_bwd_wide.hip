@@ -465,7 +465,7 @@ __global__ __launch_bounds__(256) void pref_bwd_wide_kernel(WArgs a) {
       }
     // ---- C: gx^T = Alog2^T . gL^T of this wave's coordinates, then the row gradients
     {
-      const int64_t gr = row0 + j;
+      const int64_t gr = STEP ? row_j : row0 + j;                // ROWOUT row: the pair's place in the [pos ; neg] order
       const bool live = live_j;
       const int32_t ur = sid[j], ir = sid[16 + j], er = sid[32 + j];
       float* pu = a.gU + (int64_t)ur * a.ldu4 * 4;
@@ -575,7 +575,7 @@ int launch_r(const WArgs& a, hipStream_t st, const char* name) {
 
 template <typename G>
 int launch(const WArgs& a, hipStream_t st, const char* name) {
-  if (a.loss) return launch_r<G, false, true>(a, st, name);
+  if (a.loss) return a.GU ? launch_r<G, true, true>(a, st, name) : launch_r<G, false, true>(a, st, name);
   return a.GU ? launch_r<G, true, false>(a, st, name) : launch_r<G, false, false>(a, st, name);
 }
 
@@ -644,7 +644,7 @@ int pref_step_mc(const float* U, int64_t ldu, const float* I, int64_t ldi, const
                  int d, const int64_t* u_ids, const int64_t* i_ids, int64_t B, int l1, int gumbel_mode, const float* uniform,
                  uint64_t seed, uint64_t offset, float target, float gscale, int orth, float* loss, float* gU, float* gI, float* gE,
                  float* gP, float* gPn, float* gR, float* gRn, hipStream_t st,
-                 const char* name) {
+                 const char* name, float* GU, float* GV) {
   if (n_pref > 32 || (d == 256 && n_pref > 20)) return 1;
   if ((ldu | ldi | lde | ldp) & 3) return 1;
   if ((ldu >> 2) > 0xffffffffll || (ldi >> 2) > 0xffffffffll || (lde >> 2) > 0xffffffffll) return 1;
@@ -658,6 +658,7 @@ int pref_step_mc(const float* U, int64_t ldu, const float* I, int64_t ldi, const
   a.gumbel = gumbel_mode; a.uniform = uniform; a.seed = seed; a.offset = offset;
   a.pref = pref; a.pnorm = pnorm; a.rel = rel; a.norm = norm; a.ldp = ldp; a.B = B;
   a.target = target; a.gscale = gscale; a.loss = loss; a.gP = gP; a.gPn = gPn; a.gR = gR; a.gRn = gRn; a.orth = orth;
+  a.GU = GU; a.GV = GV;          // both set: the row gradients of pair k leave as rows k of GU / GV (plain stores) instead of atomics
   return launch_d(a, d, (n_pref + 3) / 4, st, name);
 }
 

@@ -16,8 +16,9 @@
 namespace ktup {
 namespace {
 
-constexpr int SCAN_T = 256;    // one wave per SIMD and few registers: the scan must fit on a CU beside a gradient kernel that holds
+constexpr int SCAN_NARROW = 256;    // one wave per SIMD and few registers: the scan must fit on a CU beside a gradient kernel that holds
                                // most of its registers and LDS (it runs on the side stream, ktup_runtime.hip fork_side)
+constexpr int SCAN_WIDE = 1024;    // the sharded step's sort runs alone (ktup_shard_step.hip): 8192 counters per sweep
 constexpr int SCAN_V = 8;      // counters per thread per sweep
 
 // entries [0, n_src) take their key from ids, entries [n_src, m) from ids2 (the two roles of a triple's entities: one sort)
@@ -28,6 +29,7 @@ __global__ __launch_bounds__(256) void seg_hist_kernel(const int64_t* __restrict
 }
 
 // exclusive scan in place over K + 1 counters (the last one receives the total); one workgroup, SCAN_T x SCAN_V items per sweep
+template <int SCAN_T>
 __global__ __launch_bounds__(SCAN_T) void seg_scan_kernel(int32_t* __restrict__ start, int64_t K) {
   __shared__ int32_t wsum[SCAN_T / 64];
   __shared__ int32_t carry_s;
@@ -78,6 +80,8 @@ __global__ __launch_bounds__(256) void seg_scatter_kernel(const int64_t* __restr
 struct SegArgs {
   const float4* G; int64_t ldg4; int nch; int64_t n_src;
   const int32_t *perm, *skey; int64_t m, sign_split;
+  int64_t src_off;                 // entry e >= n_src reads row e - src_off of G (n_src: the second half re-reads the first)
+  const int32_t* m_dev;            // non-null: the number of sorted entries lives on the device (<= m; entries with a negative key were skipped)
   float* gT; int64_t ldt;
   const int32_t* map2; int64_t pad2; float* gT2; int64_t ldt2;
   int chunk;
@@ -97,6 +101,7 @@ __global__ __launch_bounds__(256) void seg_reduce_kernel(SegArgs a) {
   constexpr int ROW4 = GL * CPL;                                  // float4 per edge partial
   __shared__ float4 edge[2 * GPB * ROW4];
   __shared__ int32_t ekey[2 * GPB];
+  if (a.m_dev) a.m = *a.m_dev;
   const int64_t nchunks = (a.m + a.chunk - 1) / a.chunk;
   auto to_memory = [&](int32_t key, const float4* acc, bool atomic) {
     float* row = a.gT + (int64_t)key * a.ldt;
@@ -154,7 +159,7 @@ __global__ __launch_bounds__(256) void seg_reduce_kernel(SegArgs a) {
           const bool on = k + u < k1;
           key[u] = on ? a.skey[k + u] : -1;
           e[u] = on ? a.perm[k + u] : 0;
-          const int64_t src = e[u] >= a.n_src ? e[u] - a.n_src : e[u];
+          const int64_t src = e[u] >= a.n_src ? e[u] - a.src_off : e[u];
           const float4* row = a.G + src * a.ldg4;
 #pragma unroll
           for (int j = 0; j < CPL; ++j) {
@@ -220,7 +225,7 @@ int seg_sort(const int64_t* ids, const int64_t* ids2, int64_t n_src, int64_t m, 
   if (hipMemsetAsync(start, 0, (size_t)(n_rows + 1) * sizeof(int32_t), st) != hipSuccess) return check_launch(name);
   const int gm = grid_for((m + 255) / 256, 2048);
   hipLaunchKernelGGL(seg_hist_kernel, dim3(gm), dim3(256), 0, st, ids, ids2, n_src, m, start, rank);
-  hipLaunchKernelGGL(seg_scan_kernel, dim3(1), dim3(SCAN_T), 0, st, start, n_rows);
+  hipLaunchKernelGGL(seg_scan_kernel<SCAN_NARROW>, dim3(1), dim3(SCAN_NARROW), 0, st, start, n_rows);
   hipLaunchKernelGGL(seg_scatter_kernel, dim3(gm), dim3(256), 0, st, ids, ids2, n_src, m, start, rank, perm, skey);
   return check_launch(name);
 }
@@ -232,12 +237,46 @@ int seg_apply(const float* G, int64_t ldg, int d, int64_t n_src, int64_t m, int6
   const int32_t* skey = perm + m;
   SegArgs a;
   a.G = reinterpret_cast<const float4*>(G); a.ldg4 = ldg / 4; a.nch = d / 4; a.n_src = n_src;
-  a.perm = perm; a.skey = skey; a.m = m; a.sign_split = sign_split;
+  a.perm = perm; a.skey = skey; a.m = m; a.sign_split = sign_split; a.src_off = n_src; a.m_dev = nullptr;
   a.gT = gT; a.ldt = ldt; a.map2 = map2; a.pad2 = pad2; a.gT2 = gT2; a.ldt2 = ldt2;
   int64_t ch = m / 8192;
   a.chunk = (int)(ch < 8 ? 8 : ch > 64 ? 64 : ch);
   a.chunk = (a.chunk + 3) & ~3;
   const int64_t nchunks = (m + a.chunk - 1) / a.chunk;
+#define KTUP_SEG(GL, CPL)                                                                                         \
+  {                                                                                                               \
+    const int grid = grid_for((nchunks + (256 / GL) - 1) / (256 / GL), 4096);                                     \
+    hipLaunchKernelGGL((seg_reduce_kernel<GL, CPL>), dim3(grid), dim3(256), 0, st, a);                            \
+    return check_launch(name);                                                                                    \
+  }
+  if (a.nch <= 16) KTUP_SEG(16, 1)
+  if (a.nch <= 32) KTUP_SEG(32, 1)
+  if (a.nch <= 64) KTUP_SEG(64, 1)
+  if (a.nch <= 128) KTUP_SEG(64, 2)
+  KTUP_SEG(64, 4)
+#undef KTUP_SEG
+}
+
+// ---- pieces for callers that build the sorted order themselves (ktup_shard_step.hip: the histogram is a by-product of its
+// id routing).  seg_scan_wide: exclusive scan of K + 1 counters in place (index K receives the total) with a 1024-thread
+// workgroup; seg_apply_sorted: the reduction over perm / skey with the entry count read from the device (*m_dev <= m_max).
+int seg_scan_wide(int32_t* start, int64_t K, hipStream_t st, const char* name) {
+  hipLaunchKernelGGL(seg_scan_kernel<SCAN_WIDE>, dim3(1), dim3(SCAN_WIDE), 0, st, start, K);
+  return check_launch(name);
+}
+
+int seg_apply_sorted(const float* G, int64_t ldg, int d, int64_t n_src, int64_t src_off, const int32_t* perm, const int32_t* skey,
+                     int64_t m_max, const int32_t* m_dev, float* gT, int64_t ldt, hipStream_t st, const char* name) {
+  if (m_max == 0) return KTUP_OK;
+  if (d % 4 || d > 1024 || ldg % 4 || ldt % 4 || !aligned16(G) || !aligned16(gT) || m_max >= (1ll << 31)) return 1;
+  SegArgs a;
+  a.G = reinterpret_cast<const float4*>(G); a.ldg4 = ldg / 4; a.nch = d / 4; a.n_src = n_src;
+  a.perm = perm; a.skey = skey; a.m = m_max; a.sign_split = m_max; a.src_off = src_off; a.m_dev = m_dev;
+  a.gT = gT; a.ldt = ldt; a.map2 = nullptr; a.pad2 = -1; a.gT2 = nullptr; a.ldt2 = 0;
+  int64_t ch = m_max / 8192;
+  a.chunk = (int)(ch < 8 ? 8 : ch > 64 ? 64 : ch);
+  a.chunk = (a.chunk + 3) & ~3;
+  const int64_t nchunks = (m_max + a.chunk - 1) / a.chunk;
 #define KTUP_SEG(GL, CPL)                                                                                         \
   {                                                                                                               \
     const int grid = grid_for((nchunks + (256 / GL) - 1) / (256 / GL), 4096);                                     \

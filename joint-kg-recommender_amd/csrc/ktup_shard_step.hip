@@ -1,0 +1,519 @@
+// Config 5 (KTUP, d = 256, user / item / entity tables row-sharded by `row % world`): the device side of a training step whose
+// every buffer has a FIXED shape, so that the step has no host synchronisation and replays as a HIP graph (one graph on one
+// rank; three segments around the two all-to-alls on several).  The reference has no distributed code: the step
+// it distributes is knowledgable_recommendation.py:335-344,394-403 (model(pos), model(neg), bprLoss, backward, clip_grad_norm,
+// optimizer.step) over jTransUP.py:122-143.
+//
+//   route   one id list for ALL tables of the step (entries [ent_off[t], ent_off[t+1]) of a block belong to table t; negative
+//           ids are padding).  Distinct ids get a WIRE ROW  w = owner * capsum + toff[t] + slot  (owner = id % world, slot = order
+//           of first appearance among the (owner, table) pair's ids, fewer than cap[t] of them or the step is flagged as
+//           overflowed and skipped by `apply`): the send buffer of the id all-to-all (send_ids[w] = id / world, -1 padded), the
+//           row buffer the rows come back into, the compact table the scorer reads, and the gradient buffer that travels back all
+//           share this one layout, so nothing is ever re-ordered.  inverse[e] = wire row of entry e (what the scorer is
+//           handed as ids); pair_map (KTUP's item -> entity map on the compact tables); and, as a by-product of the same pass
+//           over the entries, the counting sort of the entries by wire row that the row-gradient reduction needs
+//           (ktup_segreduce.hip) -- its histogram is the rank every entry takes among the entries of its row.
+//   pack    owner side: X[w] = table_t[ids[w]] for a whole wire buffer (all tables, one launch).
+//   apply   global-norm clip + row-sparse SGD / Adagrad on the rows a step touched, for all tables and the small replicated
+//           tables in one launch; consumes (zero-fills) the gradient buffers so the next step starts clean without a memset.
+//   bucket  the small tables' gradients + the sum of squares + the overflow flag as ONE fp64 all-reduce bucket.
+// The owner side of several ranks combines the rows different peers asked for with the same route + reduction (world = 1,
+// block = capsum): a row requested by k peers is k entries of one key.
+#include "ktup_pref_geom.h"
+#include "ktup_rows.h"
+
+using namespace ktup;
+
+namespace {
+
+constexpr int MAXT = KTUP_SHARD_MAX_TABLES;
+
+struct RouteArgs {
+  const int64_t* ids; int64_t n, block; int T; int64_t eoff[MAXT + 1];
+  int world; int64_t cap[MAXT], toff[MAXT], capsum, W;
+  int pair_a, pair_b;
+  unsigned long long* keys; int32_t* slot_pos; uint64_t slots;
+  int64_t* inverse; int64_t* send_ids; int32_t* pair_map;
+  int32_t *start, *rank, *perm, *skey, *counters;
+  double* zero_d; int n_zero_d;
+};
+
+KTUP_DEV uint64_t mix64(uint64_t x) {
+  x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ull;
+  x ^= x >> 27; x *= 0x94d049bb133111ebull;
+  return x ^ (x >> 31);
+}
+
+KTUP_DEV int table_of(const RouteArgs& a, int64_t b) {
+  int t = 0;
+#pragma unroll
+  for (int i = 1; i < MAXT; ++i) t += (i < a.T && b >= a.eoff[i]) ? 1 : 0;
+  return t;
+}
+
+// every piece of scratch the step reads before writing: hash keys, the id send buffer, the histogram, the slot counters and the
+// caller's accumulators (sum of squares ...) -- a kernel, not memset nodes (a captured memset stopped taking effect)
+__global__ __launch_bounds__(256) void route_init_kernel(RouteArgs a) {
+  const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x, nth = (int64_t)gridDim.x * 256;
+  for (int64_t i = tid; i < (int64_t)a.slots; i += nth) a.keys[i] = ~0ull;
+  for (int64_t i = tid; i < a.W; i += nth) a.send_ids[i] = -1;
+  for (int64_t i = tid; i <= a.W; i += nth) a.start[i] = 0;
+  for (int64_t i = tid; i <= (int64_t)a.world * a.T; i += nth) a.counters[i] = 0;          // + the overflow word
+  for (int64_t i = tid; i < a.n_zero_d; i += nth) a.zero_d[i] = 0.0;
+}
+
+__global__ __launch_bounds__(256) void route_insert_kernel(RouteArgs a) {
+  const int lane = threadIdx.x & 63;
+  const uint64_t mask = a.slots - 1;
+  for (int64_t base = (int64_t)blockIdx.x * 256; base < a.n; base += (int64_t)gridDim.x * 256) {
+    const int64_t e = base + threadIdx.x;
+    const int64_t id = e < a.n ? a.ids[e] : -1;
+    const bool on = id >= 0;
+    const int t = on ? table_of(a, e % a.block) : 0;
+    uint64_t h = 0;
+    bool created = false;
+    if (on) {
+      const unsigned long long key = ((unsigned long long)t << 56) | (unsigned long long)id;
+      h = mix64(key) & mask;
+      for (;;) {
+        const unsigned long long prev = atomicCAS(a.keys + h, ~0ull, key);
+        if (prev == ~0ull) { created = true; break; }     // this thread names the row
+        if (prev == key) break;
+        h = (h + 1) & mask;
+      }
+    }
+    const int p = (created && a.world > 1) ? (int)(id % a.world) : 0;
+    const int combo = p * a.T + t;
+    // slots: ONE counter atomic per (owner, table) present in the wave, all of them in flight together
+    int leader = 0, rk = 0, cnt = 0;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (int c = 0; c < a.world * a.T; ++c) {
+      const unsigned long long m = __ballot(created && combo == c);
+      if (m != 0ull && created && combo == c) {
+        leader = __ffsll((long long)m) - 1;
+        cnt = __popcll(m);
+        rk = __popcll(m & lt);
+      }
+    }
+    int32_t basev = 0;
+    if (created && lane == leader) basev = atomicAdd(a.counters + combo, cnt);
+    basev = __shfl(basev, leader, 64);
+    if (created) {
+      int64_t slot = basev + rk;
+      const bool fits = slot < a.cap[t];
+      if (!fits) { atomicAdd(a.counters + (int64_t)a.world * a.T, 1); slot = 0; }
+      const int64_t w = (int64_t)p * a.capsum + a.toff[t] + slot;
+      a.slot_pos[h] = (int32_t)w;
+      if (fits) a.send_ids[w] = a.world > 1 ? id / a.world : id;
+    }
+  }
+}
+
+KTUP_DEV int32_t route_find(const RouteArgs& a, int t, int64_t id) {
+  const unsigned long long key = ((unsigned long long)t << 56) | (unsigned long long)id;
+  const uint64_t mask = a.slots - 1;
+  uint64_t h = mix64(key) & mask;
+  while (a.keys[h] != key) h = (h + 1) & mask;
+  return a.slot_pos[h];
+}
+
+__global__ __launch_bounds__(256) void route_finish_kernel(RouteArgs a) {
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < a.n; e += (int64_t)gridDim.x * 256) {
+    const int64_t id = a.ids[e];
+    if (id < 0) {
+      a.inverse[e] = a.W;                                  // the shared zero row
+      a.rank[e] = -1;
+      continue;
+    }
+    const int64_t b = e % a.block;
+    const int t = table_of(a, b);
+    const int32_t w = route_find(a, t, id);
+    a.inverse[e] = w;
+    a.rank[e] = atomicAdd(a.start + w, 1);
+    if (a.pair_map && t == a.pair_a) {                     // KTUP: the compact item row's entity row
+      const int64_t idb = a.ids[e + (a.eoff[a.pair_b] - a.eoff[a.pair_a])];
+      a.pair_map[w] = idb < 0 ? (int32_t)a.W : route_find(a, a.pair_b, idb);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void route_scatter_kernel(RouteArgs a) {
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < a.n; e += (int64_t)gridDim.x * 256) {
+    const int32_t r = a.rank[e];
+    if (r < 0) continue;
+    const int64_t w = a.inverse[e];
+    const int32_t pos = a.start[w] + r;
+    a.perm[pos] = (int32_t)e;
+    a.skey[pos] = (int32_t)w;
+  }
+}
+
+uint64_t route_slots(int64_t n) {
+  uint64_t s = 64;
+  while (s < (uint64_t)(2 * n)) s <<= 1;
+  return s;
+}
+
+// ---- [u ; u], [pos ; neg], item2ent[pos ; neg]: the entry list of a KTUP rec step (jTransUP.py:122-130 paddingItems as a table)
+__global__ __launch_bounds__(256) void ktup_entries_kernel(const int64_t* __restrict__ u, const int64_t* __restrict__ pi,
+                                                           const int64_t* __restrict__ ni, int64_t B, const int32_t* __restrict__ item2ent,
+                                                           int64_t ent_pad, int64_t* __restrict__ out) {
+  for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < 2 * B; k += (int64_t)gridDim.x * 256) {
+    const int64_t item = k < B ? pi[k] : ni[k - B];
+    out[k] = u[k < B ? k : k - B];
+    out[2 * B + k] = item;
+    if (item2ent) {
+      const int64_t ent = item2ent[item];
+      out[4 * B + k] = (ent < 0 || ent == ent_pad) ? -1 : ent;
+    }
+  }
+}
+
+struct WireTables {
+  int T; float* tab[MAXT]; int64_t ldt[MAXT]; float* st[MAXT]; int64_t lds[MAXT]; int64_t toff[MAXT + 1]; int64_t capsum;
+};
+
+KTUP_DEV int wire_table(const WireTables& w, int64_t row) {
+  const int64_t b = row % w.capsum;
+  int t = 0;
+#pragma unroll
+  for (int i = 1; i < MAXT; ++i) t += (i < w.T && b >= w.toff[i]) ? 1 : 0;
+  return t;
+}
+
+struct PackWire {
+  WireTables w; const int64_t* ids; float* out; int64_t ldo;
+  template <typename V, int G, int CPL>
+  KTUP_DEV void run(const RowCtx<V, G, CPL>& cx, int64_t row) const {
+    const int64_t id = ids[row];
+    if (id < 0) return;                                    // padding slots are never addressed by the scorer
+    const int t = wire_table(w, row);
+    V x[CPL];
+    cx.load(x, w.tab[t] + id * w.ldt[t]);
+    V* o = reinterpret_cast<V*>(out + row * ldo);
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+      const int c = cx.lane + j * G;
+      if (c < cx.nch) o[c] = x[j];
+    }
+  }
+};
+
+KTUP_DEV void up1(float& p, float& st, float g, float lr, float eps, bool adagrad) {
+  if (adagrad) {
+    st = fmaf(g, g, st);
+    p = p - lr * (g / (sqrtf(st) + eps));
+  } else {
+    p = fmaf(-lr, g, p);
+  }
+}
+KTUP_DEV void upv(float& p, float& st, float g, float lr, float eps, bool adagrad) { up1(p, st, g, lr, eps, adagrad); }
+KTUP_DEV void upv(float4& p, float4& st, float4 g, float lr, float eps, bool adagrad) {
+  up1(p.x, st.x, g.x, lr, eps, adagrad); up1(p.y, st.y, g.y, lr, eps, adagrad);
+  up1(p.z, st.z, g.z, lr, eps, adagrad); up1(p.w, st.w, g.w, lr, eps, adagrad);
+}
+KTUP_DEV void vfrom(float& o, const double* p) { o = (float)p[0]; }
+KTUP_DEV void vfrom(float4& o, const double* p) { o = make_float4((float)p[0], (float)p[1], (float)p[2], (float)p[3]); }
+
+constexpr int MAXS = KTUP_SHARD_MAX_SMALL;
+
+// Same rule as ktup_shard.hip SparseRowStep (utils/trainer.py:63-77 with l2_lambda = 0 restricted to the touched rows), for
+// every wire row of every table + the rows of the small replicated tables; the gradient rows are zero-filled once consumed.
+struct ApplyRows {
+  WireTables w; const int64_t* ids; int64_t W; float* g; int64_t ldg;
+  int n_small, small_rows; float* sg[MAXS]; float* sp0[MAXS]; float* ss0[MAXS]; float* sp1[MAXS]; float* ss1[MAXS];
+  const double* small_g64;     // non-null: the all-reduced small gradients (fp64 bucket, entries in sg order) replace sg's values
+  int d;
+  float lr, eps, max_norm; const double* sumsq; const int32_t* skip_i; const double* skip_d; bool adagrad;
+
+  template <typename V, int G, int CPL>
+  KTUP_DEV void one(const RowCtx<V, G, CPL>& cx, float* prow, float* srow, const V (&gr)[CPL], float coef) const {
+    V p[CPL], st[CPL];
+    cx.load(p, prow);
+    if (adagrad) cx.load(st, srow);
+    V* po = reinterpret_cast<V*>(prow);
+    V* so = reinterpret_cast<V*>(srow);
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+      const int c = cx.lane + j * G;
+      if (c < cx.nch) {
+        upv(p[j], st[j], vscale(coef, gr[j]), lr, eps, adagrad);
+        po[c] = p[j];
+        if (adagrad) so[c] = st[j];
+      }
+    }
+  }
+
+  template <typename V, int G, int CPL>
+  KTUP_DEV void run(const RowCtx<V, G, CPL>& cx, int64_t row) const {
+    const bool skip = (skip_i && *skip_i != 0) || (skip_d && *skip_d != 0.0);
+    float coef = 1.f;
+    if (max_norm > 0.f) {
+      const float c = max_norm / ((float)sqrt(*sumsq) + 1e-6f);
+      coef = c < 1.f ? c : 1.f;
+    }
+    V gr[CPL], zero[CPL];
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) vzero(zero[j]);
+    if (row < W) {
+      const int64_t id = ids[row];
+      if (id < 0) return;
+      float* grow = g + row * ldg;
+      if (!skip) {
+        const int t = wire_table(w, row);
+        cx.load(gr, grow);
+        one(cx, w.tab[t] + id * w.ldt[t], adagrad ? w.st[t] + id * w.lds[t] : nullptr, gr, coef);
+      }
+      V* go = reinterpret_cast<V*>(grow);
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) {
+        const int c = cx.lane + j * G;
+        if (c < cx.nch) go[c] = zero[j];
+      }
+      return;
+    }
+    const int64_t r = row - W;
+    const int k = (int)(r / small_rows);
+    const int64_t sr = r % small_rows;
+    float* grow = sg[k] + sr * d;
+    if (!skip) {
+      if (small_g64) {
+        const double* src = small_g64 + ((int64_t)k * small_rows + sr) * d;
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) {
+          const int c = cx.lane + j * G;
+          if (c < cx.nch) vfrom(gr[j], src + (int64_t)c * VW<V>::W); else vzero(gr[j]);
+        }
+      } else {
+        cx.load(gr, grow);
+      }
+      one(cx, sp0[k] + sr * d, adagrad ? ss0[k] + sr * d : nullptr, gr, coef);
+      if (sp1[k]) one(cx, sp1[k] + sr * d, adagrad ? ss1[k] + sr * d : nullptr, gr, coef);
+    }
+    V* go = reinterpret_cast<V*>(grow);
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+      const int c = cx.lane + j * G;
+      if (c < cx.nch) go[c] = zero[j];
+    }
+  }
+};
+
+struct BucketArgs {
+  int n_small; const float* sg[MAXS]; int64_t small_elems;     // elements per small gradient (rows x d, contiguous)
+  double* bucket; const double* sumsq_in; const int32_t* overflow; double* sumsq_out; double small_weight;
+};
+
+// mode 0: bucket = [small gradients as doubles | local sum of squares | overflow count]  (what ONE all-reduce carries)
+// mode 1: *sumsq_out = bucket[sum of squares] + sum of the (now global) small gradients' squares -- identical on every rank
+template <int MODE>
+__global__ __launch_bounds__(1024) void bucket_kernel(BucketArgs a) {
+  const int64_t N = (int64_t)a.n_small * a.small_elems;
+  if (MODE == 0) {
+    for (int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x; i < N + 2; i += (int64_t)gridDim.x * 1024) {
+      double v;
+      if (i < N) v = (double)a.sg[i / a.small_elems][i % a.small_elems];
+      else if (i == N) v = *a.sumsq_in;
+      else v = (double)*a.overflow;
+      a.bucket[i] = v;
+    }
+  } else {
+    __shared__ double red[16];
+    double acc = 0.0;
+    for (int64_t i = threadIdx.x; i < N; i += 1024) acc += a.bucket[i] * a.bucket[i];
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double tot = 0.0;
+      for (int k = 0; k < 16; ++k) tot += red[k];
+      *a.sumsq_out = a.bucket[N] + a.small_weight * tot;     // a gradient shared by two tables counts twice in the norm
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void zero_f4_kernel(float4* __restrict__ p, int64_t n4) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) p[i] = f4zero();
+}
+
+int fill_route(const char* name, RouteArgs& a, const int64_t* ids, int64_t n_entries, int64_t block, int n_tables, const int64_t* ent_off,
+               int world, const int64_t* cap) {
+  KTUP_REQUIRE(n_entries > 0 && n_entries < (1ll << 30) && block > 0 && n_entries % block == 0, "%s: bad entry count / block", name);
+  KTUP_REQUIRE(n_tables >= 1 && n_tables <= MAXT && world >= 1 && world <= 64, "%s: 1..%d tables, 1..64 ranks", name, MAXT);
+  KTUP_REQUIRE(ids && ent_off && cap, "%s: null pointer argument", name);
+  KTUP_REQUIRE(ent_off[0] == 0 && ent_off[n_tables] == block, "%s: ent_off must run from 0 to block", name);
+  a.ids = ids; a.n = n_entries; a.block = block; a.T = n_tables; a.world = world;
+  int64_t off = 0;
+  for (int t = 0; t < n_tables; ++t) {
+    KTUP_REQUIRE(ent_off[t + 1] >= ent_off[t] && cap[t] > 0, "%s: table %d: bad entry range or capacity", name, t);
+    a.eoff[t] = ent_off[t]; a.cap[t] = cap[t]; a.toff[t] = off;
+    off += cap[t];
+  }
+  for (int t = n_tables; t <= MAXT; ++t) a.eoff[t] = block;
+  a.capsum = off; a.W = off * world;
+  KTUP_REQUIRE(a.W < (1ll << 31) - 1, "%s: wire buffer too large", name);
+  return KTUP_OK;
+}
+
+int fill_wire(const char* name, WireTables& w, int n_tables, float* const* tables, const int64_t* ld, float* const* states,
+              const int64_t* lds, const int64_t* cap, int d) {
+  KTUP_REQUIRE(n_tables >= 1 && n_tables <= MAXT && tables && ld && cap, "%s: 1..%d tables with pitches and capacities", name, MAXT);
+  w.T = n_tables;
+  int64_t off = 0;
+  for (int t = 0; t < n_tables; ++t) {
+    KTUP_REQUIRE(tables[t] && ld[t] >= d && cap[t] > 0, "%s: table %d: null pointer, pitch < d or no capacity", name, t);
+    w.tab[t] = tables[t]; w.ldt[t] = ld[t];
+    w.st[t] = states ? states[t] : nullptr; w.lds[t] = (states && lds) ? lds[t] : ld[t];
+    w.toff[t] = off;
+    off += cap[t];
+  }
+  for (int t = n_tables; t <= MAXT; ++t) w.toff[t] = off;
+  w.capsum = off;
+  return KTUP_OK;
+}
+
+}  // namespace
+
+extern "C" size_t ktup_shard_route_workspace_bytes(int64_t n_entries) {
+  if (n_entries <= 0) return 0;
+  return (size_t)route_slots(n_entries) * (sizeof(unsigned long long) + sizeof(int32_t));
+}
+
+extern "C" size_t ktup_shard_route_sort_bytes(int64_t n_entries, int64_t n_wire_rows) {
+  if (n_entries <= 0 || n_wire_rows <= 0) return 0;
+  return ((size_t)((n_wire_rows + 2) & ~(int64_t)1) + (size_t)3 * n_entries) * sizeof(int32_t);
+}
+
+extern "C" int ktup_shard_route(const int64_t* ids, int64_t n_entries, int64_t block, int n_tables, const int64_t* ent_off, int world,
+                                const int64_t* cap, int pair_a, int pair_b, int64_t* inverse, int64_t* send_ids, int32_t* pair_map,
+                                int32_t* sort_ws, int32_t* counters, double* zero_doubles, int n_zero_doubles, void* ws, void* stream) {
+  const char* name = "ktup_shard_route";
+  RouteArgs a{};
+  if (int e = fill_route(name, a, ids, n_entries, block, n_tables, ent_off, world, cap)) return e;
+  KTUP_REQUIRE(inverse && send_ids && sort_ws && counters && ws, "%s: null pointer argument", name);
+  KTUP_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 7u) == 0, "%s: workspace must be 8-byte aligned", name);
+  KTUP_REQUIRE(!pair_map || (pair_a >= 0 && pair_a < n_tables && pair_b >= 0 && pair_b < n_tables && pair_a != pair_b &&
+                             ent_off[pair_a + 1] - ent_off[pair_a] == ent_off[pair_b + 1] - ent_off[pair_b] && n_entries == block),
+               "%s: pair_map needs two tables with equally many entries in a single block", name);
+  KTUP_REQUIRE(n_zero_doubles >= 0 && (n_zero_doubles == 0 || zero_doubles), "%s: bad accumulator list", name);
+  a.pair_a = pair_a; a.pair_b = pair_b; a.pair_map = pair_map;
+  a.slots = route_slots(n_entries);
+  a.keys = reinterpret_cast<unsigned long long*>(ws);
+  a.slot_pos = reinterpret_cast<int32_t*>(a.keys + a.slots);
+  a.inverse = inverse; a.send_ids = send_ids;
+  a.start = sort_ws;
+  a.rank = sort_ws + ((a.W + 2) & ~(int64_t)1);
+  a.perm = a.rank + n_entries;
+  a.skey = a.perm + n_entries;
+  a.counters = counters; a.zero_d = zero_doubles; a.n_zero_d = n_zero_doubles;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t init_items = (int64_t)a.slots > a.W + 1 ? (int64_t)a.slots : a.W + 1;
+  hipLaunchKernelGGL(route_init_kernel, dim3(grid_for((init_items + 255) / 256, 1024)), dim3(256), 0, st, a);
+  const int grid = grid_for((n_entries + 255) / 256, 1024);
+  hipLaunchKernelGGL(route_insert_kernel, dim3(grid), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(route_finish_kernel, dim3(grid), dim3(256), 0, st, a);
+  if (int e = check_launch(name)) return e;
+  if (int e = seg_scan_wide(a.start, a.W, st, name)) return e;
+  hipLaunchKernelGGL(route_scatter_kernel, dim3(grid), dim3(256), 0, st, a);
+  return check_launch(name);
+}
+
+extern "C" int ktup_shard_reduce_rows(const float* G, int64_t ldg, int d, int64_t n_src, int64_t src_off, const int32_t* sort_ws,
+                                      int64_t n_entries, int64_t n_wire_rows, float* gwire, int64_t ldw, void* stream) {
+  const char* name = "ktup_shard_reduce_rows";
+  KTUP_REQUIRE(G && sort_ws && gwire && n_entries > 0 && n_wire_rows > 0 && d > 0, "%s: null pointer argument or bad sizes", name);
+  KTUP_REQUIRE(n_src > 0 && n_src <= n_entries && src_off >= 0 && src_off <= n_src, "%s: bad source layout", name);
+  const int32_t* start = sort_ws;
+  const int32_t* perm = sort_ws + ((n_wire_rows + 2) & ~(int64_t)1) + n_entries;
+  const int32_t* skey = perm + n_entries;
+  const int rc = seg_apply_sorted(G, ldg, d, n_src, src_off, perm, skey, n_entries, start + n_wire_rows, gwire, ldw, (hipStream_t)stream, name);
+  if (rc == 1) return set_error(KTUP_ERR_UNSUPPORTED, "%s: needs d %% 4 == 0 and 16-byte aligned rows", name);
+  return rc;
+}
+
+extern "C" int ktup_shard_ktup_entries(const int64_t* u, const int64_t* pos_items, const int64_t* neg_items, int64_t B,
+                                       const int32_t* item2ent, int64_t ent_pad, int64_t* entries, void* stream) {
+  const char* name = "ktup_shard_ktup_entries";
+  KTUP_REQUIRE(B > 0 && u && pos_items && neg_items && entries, "%s: null pointer argument or empty batch", name);
+  hipLaunchKernelGGL(ktup_entries_kernel, dim3(grid_for((2 * B + 255) / 256, 1024)), dim3(256), 0, (hipStream_t)stream, u, pos_items,
+                     neg_items, B, item2ent, ent_pad, entries);
+  return check_launch(name);
+}
+
+extern "C" int ktup_shard_pack_wire(int n_tables, float* const* tables, const int64_t* ld, const int64_t* cap, int d, const int64_t* ids,
+                                    int64_t n_blocks, float* out, int64_t ldo, void* stream) {
+  const char* name = "ktup_shard_pack_wire";
+  WireTables w{};
+  if (int e = fill_wire(name, w, n_tables, tables, ld, nullptr, nullptr, cap, d)) return e;
+  KTUP_REQUIRE(ids && out && n_blocks > 0 && ldo >= d && d > 0, "%s: null pointer argument or bad sizes", name);
+  bool v4 = d % 4 == 0 && aligned16(out) && ldo % 4 == 0;
+  for (int t = 0; t < n_tables; ++t) v4 = v4 && aligned16(tables[t]) && ld[t] % 4 == 0;
+  PackWire op{w, ids, out, ldo};
+  return launch_rows(op, d, v4, n_blocks * w.capsum, (hipStream_t)stream, name);
+}
+
+extern "C" int ktup_shard_apply(int kind, int n_tables, float* const* tables, const int64_t* ld, float* const* states, const int64_t* lds,
+                                const int64_t* cap, int d, const int64_t* ids, int64_t n_blocks, float* grads, int64_t ldg, int n_small,
+                                int small_rows, float* const* small_grads, float* const* small_p0, float* const* small_s0,
+                                float* const* small_p1, float* const* small_s1, const double* small_g64, float lr, float eps,
+                                const double* sumsq, float max_norm, const int32_t* skip_count, const double* skip_value, void* stream) {
+  const char* name = "ktup_shard_apply";
+  KTUP_REQUIRE(kind == KTUP_OPT_SGD || kind == KTUP_OPT_ADAGRAD, "%s: only plain SGD and Adagrad have an exact row-sparse form", name);
+  ApplyRows op{};
+  if (int e = fill_wire(name, op.w, n_tables, tables, ld, states, lds, cap, d)) return e;
+  KTUP_REQUIRE(ids && grads && n_blocks > 0 && ldg >= d && d > 0, "%s: null pointer argument or bad sizes", name);
+  KTUP_REQUIRE(n_small >= 0 && n_small <= MAXS && (n_small == 0 || (small_rows > 0 && small_grads && small_p0)), "%s: bad small-table list", name);
+  KTUP_REQUIRE(max_norm <= 0.f || sumsq, "%s: clipping needs the sum of squared gradients", name);
+  const bool adagrad = kind == KTUP_OPT_ADAGRAD;
+  bool v4 = d % 4 == 0 && aligned16(grads) && ldg % 4 == 0;
+  for (int t = 0; t < n_tables; ++t) {
+    KTUP_REQUIRE(!adagrad || (states && states[t]), "%s: table %d: Adagrad state missing", name, t);
+    v4 = v4 && aligned16(tables[t]) && ld[t] % 4 == 0 && (!adagrad || (aligned16(states[t]) && op.w.lds[t] % 4 == 0));
+  }
+  for (int k = 0; k < n_small; ++k) {
+    KTUP_REQUIRE(small_grads[k] && small_p0[k] && (!adagrad || (small_s0 && small_s0[k])), "%s: small table %d: null pointer", name, k);
+    op.sg[k] = small_grads[k]; op.sp0[k] = small_p0[k]; op.ss0[k] = small_s0 ? small_s0[k] : nullptr;
+    op.sp1[k] = small_p1 ? small_p1[k] : nullptr; op.ss1[k] = small_s1 ? small_s1[k] : nullptr;
+    KTUP_REQUIRE(!op.sp1[k] || !adagrad || op.ss1[k], "%s: small table %d: second table's Adagrad state missing", name, k);
+    v4 = v4 && aligned16(op.sg[k]) && aligned16(op.sp0[k]) && aligned16(op.ss0[k]) && aligned16(op.sp1[k]) && aligned16(op.ss1[k]);
+  }
+  op.ids = ids; op.W = n_blocks * op.w.capsum; op.g = grads; op.ldg = ldg;
+  op.n_small = n_small; op.small_rows = small_rows > 0 ? small_rows : 1; op.small_g64 = small_g64; op.d = d;
+  op.lr = lr; op.eps = eps; op.max_norm = max_norm; op.sumsq = sumsq; op.skip_i = skip_count; op.skip_d = skip_value; op.adagrad = adagrad;
+  return launch_rows(op, d, v4, op.W + (int64_t)n_small * op.small_rows, (hipStream_t)stream, name);
+}
+
+extern "C" int ktup_shard_bucket(int mode, int n_small, float* const* small_grads, int64_t small_elems, double* bucket,
+                                 const double* sumsq_local, const int32_t* overflow, double* sumsq_total, double small_weight,
+                                 void* stream) {
+  const char* name = "ktup_shard_bucket";
+  KTUP_REQUIRE((mode == 0 || mode == 1) && n_small >= 0 && n_small <= MAXS && small_elems >= 0 && bucket, "%s: bad arguments", name);
+  BucketArgs a{};
+  a.n_small = n_small; a.small_elems = small_elems > 0 ? small_elems : 1; a.bucket = bucket;
+  if (n_small == 0) a.small_elems = 1;
+  for (int k = 0; k < n_small; ++k) {
+    KTUP_REQUIRE(mode == 1 || (small_grads && small_grads[k]), "%s: small gradient %d is null", name, k);
+    a.sg[k] = small_grads ? small_grads[k] : nullptr;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (mode == 0) {
+    KTUP_REQUIRE(sumsq_local && overflow, "%s: mode 0 needs the local sum of squares and the overflow word", name);
+    a.sumsq_in = sumsq_local; a.overflow = overflow;
+    const int64_t N = (int64_t)n_small * a.small_elems + 2;
+    hipLaunchKernelGGL(bucket_kernel<0>, dim3(grid_for((N + 1023) / 1024, 64)), dim3(1024), 0, st, a);
+  } else {
+    KTUP_REQUIRE(sumsq_total, "%s: mode 1 needs the output", name);
+    a.sumsq_out = sumsq_total; a.small_weight = small_weight;
+    hipLaunchKernelGGL(bucket_kernel<1>, dim3(1), dim3(1024), 0, st, a);
+  }
+  return check_launch(name);
+}
+
+extern "C" int ktup_zero_async(void* ptr, int64_t nbytes, void* stream) {
+  KTUP_REQUIRE(nbytes >= 0 && nbytes % 16 == 0 && (nbytes == 0 || (ptr && aligned16(ptr))), "ktup_zero_async: needs a 16-byte aligned buffer of 16-byte multiples");
+  if (nbytes == 0) return KTUP_OK;
+  hipLaunchKernelGGL(zero_f4_kernel, dim3(grid_for((nbytes / 16 + 255) / 256, 2048)), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<float4*>(ptr), nbytes / 16);
+  return check_launch("ktup_zero_async");
+}

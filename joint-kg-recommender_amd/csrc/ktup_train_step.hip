@@ -182,6 +182,33 @@ extern "C" int ktup_train_rec_step(const float* U, int64_t ldu, const float* I, 
   return rc;
 }
 
+// The same step with the row gradients of pair k written to rows k of GU / GV (plain stores, 2B x d each; GV is the gradient of
+// the item row AND of its entity row) instead of float atomics into table-shaped buffers: for batches whose rows are then reduced
+// by sorted segments (config 5: ktup_shard_reduce_rows).  gR / gRn may be NULL with rel / norm given: the caller then applies
+// gP / gPn to both summands of the mixed tables itself (they are the same numbers).
+extern "C" int ktup_train_rec_step_rows(const float* U, int64_t ldu, const float* I, int64_t ldi, const float* E, int64_t lde,
+                                        const int32_t* item2ent, int64_t ent_pad, const float* pref, const float* pref_norm,
+                                        const float* rel, const float* norm, int64_t ldp, int n_pref, int d, const int64_t* u_ids,
+                                        const int64_t* i_ids, int64_t B, int l1, float target, float gscale, int orth, float* loss,
+                                        float* GU, float* GV, float* gP, float* gPn, float* gR, float* gRn, void* stream) {
+  const char* name = "ktup_train_rec_step_rows";
+  KTUP_REQUIRE(B >= 0, "%s: negative batch", name);
+  if (B == 0) return KTUP_OK;
+  KTUP_REQUIRE(U && I && pref && pref_norm && u_ids && i_ids && loss && GU && GV && gP && gPn, "%s: null pointer argument", name);
+  KTUP_REQUIRE((E == nullptr) == (item2ent == nullptr), "%s: E and item2ent go together", name);
+  KTUP_REQUIRE((rel == nullptr) == (norm == nullptr) && (gR == nullptr) == (gRn == nullptr) && (rel || !gR), "%s: rel / norm (and gR / gRn) go together", name);
+  KTUP_REQUIRE(!orth || !rel || gR, "%s: orthogonalLoss(pref, pref_norm) needs separate gradients for pref and rel", name);
+  KTUP_REQUIRE(ldp == d, "%s: preference-side tables and their gradients must be contiguous (pitch d)", name);
+  KTUP_REQUIRE(aligned16(U) && aligned16(I) && aligned16(E) && aligned16(pref) && aligned16(pref_norm) && aligned16(rel) && aligned16(norm) &&
+                   aligned16(GU) && aligned16(GV) && aligned16(gP) && aligned16(gPn) && aligned16(gR) && aligned16(gRn),
+               "%s: tables and gradients must be 16-byte aligned", name);
+  const int rc = pref_step_mc(U, ldu, I, ldi, E, lde, item2ent, ent_pad, pref, pref_norm, rel, norm, ldp, n_pref, d, u_ids, i_ids, B, l1,
+                              KTUP_GUMBEL_OFF, nullptr, 0, 0, target, gscale, orth, loss, nullptr, nullptr, nullptr, gP, gPn, gR, gRn,
+                              (hipStream_t)stream, name, GU, GV);
+  if (rc == 1) return set_error(KTUP_ERR_UNSUPPORTED, "%s: no fused kernel for d=%d, n_pref=%d (see ktup_train_step_supported)", name, d, n_pref);
+  return rc;
+}
+
 extern "C" int ktup_train_kg_step(int transh, const float* E, int64_t lde, const float* R, int64_t ldr, const float* Nrm, int64_t ldn,
                                   int d, const int64_t* h, const int64_t* t, const int64_t* r, int64_t B, int l1, float margin,
                                   float gscale, int regs, float* loss, float* gE, float* gR, float* gN, void* stream) {

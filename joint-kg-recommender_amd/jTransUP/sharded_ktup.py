@@ -1,0 +1,294 @@
+"""BASELINE config 5 as ONE replayable step: KTUP's rec step (knowledgable_recommendation.py:335-344,394-403 over
+jTransUP.py:122-143: model(pos), model(neg), bprLoss, backward, clip_grad_norm, optimizer.step) on user / item / entity tables
+that are row-sharded by `row % world` (parallel.ShardedTable), with every buffer of a FIXED shape -- no host synchronisation, no
+torch op, no autograd in the step; the launches go through the C ABI with pre-bound arguments and are replayed as HIP graphs.
+The reference is single-device: everything here is new.
+
+One rank (the whole step is one graph of 12 launches):
+    entries    [u ; u | pos ; neg | item2ent[pos ; neg]]                                     ktup_shard_ktup_entries
+    route      distinct ids -> wire rows (owner-major, fixed capacity), inverse, item -> entity map on the wire rows, and the
+               counting sort of the entries by wire row as a by-product                       ktup_shard_route (5 launches)
+    pack       X[w] = table[ids[w]] for all three tables                                      ktup_shard_pack_wire
+    step       forward of [pos ; neg], BPR term, backward; the row gradient of pair k is row k of GU / GV, the small tables'
+               gradients accumulate in gA / gC                                                ktup_train_rec_step_rows
+    reduce     Gwire[w] += rows of the entries sorted to w (users | items | entities)         ktup_shard_reduce_rows
+    norm       sum of squares of every gradient of the step                                   ktup_optim_gradnorm_acc
+    apply      clip + row-sparse SGD / Adagrad on the touched rows of the three shards and on the four small tables; the
+               gradient buffers are left zero-filled                                          ktup_shard_apply
+Several ranks: the same launches as five graph segments around three all-to-alls with EQUAL splits (ids out, rows back, row
+gradients out) and one fp64 all-reduce (small tables' gradients + the sum of squares + the overflow flag); the owner combines the
+rows several peers asked for with the same route + reduce (a row asked for by k peers is k entries of one key).
+
+Fixed capacity: a rank may ask one owner for at most cap = ceil(capacity_factor * n / world) + 64 distinct rows of a table per
+step (n = batch entries of that table).  Owners are `id % world`, so distinct ids spread like a binomial(n, 1 / world): at
+n = 16384, world = 8 the default factor 1.25 is 10 standard deviations out.  A step that does overflow is SKIPPED on every rank
+(the flag rides in the all-reduce) and counted; `check()` raises.  capacity_factor = world can never overflow.
+"""
+import ctypes
+import math
+
+import torch
+import torch.distributed as dist
+
+from jTransUP.hip import lib as L
+
+KINDS = {'sgd': 0, 'adagrad': 1}
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _ptrs(ts):
+    return (ctypes.c_void_p * len(ts))(*[None if t is None else t.data_ptr() for t in ts])
+
+
+def _i64s(vs):
+    return (ctypes.c_int64 * len(vs))(*[int(v) for v in vs])
+
+
+class ShardedKtupStepper(object):
+    """step = ShardedKtupStepper(Ut, It, Et, pref, pref_norm, rel, norm, item2ent, batch=8192, kind='adagrad', lr=0.005, max_norm=5.0)
+    step(u, pos_items, neg_items)      # int64 device tensors of `batch` ids; returns nothing, syncs nothing
+    step.loss_sum[0]                   # running sum of the steps' batch-mean BPR losses of THIS rank (a device float)
+    step.check()                       # raises if a step overflowed its exchange capacity (and was therefore skipped)
+
+    Ut / It / Et: parallel.ShardedTable (rows {g : g % world == rank}); pref, pref_norm, rel, norm: replicated (P, d) parameters;
+    item2ent: int32 device table, global item -> global entity (negative or `ent_pad`: no aligned entity).  Exact w.r.t. the
+    reference's dense step for plain SGD / Adagrad with l2_lambda = 0 (rows with a zero gradient do not move under either)."""
+
+    def __init__(self, Ut, It, Et, pref, pref_norm, rel, norm, item2ent, batch, kind='adagrad', lr=0.005, eps=1e-10, max_norm=0.0,
+                 l1=False, target=-1.0, orth=False, ent_pad=-1, group=None, capacity_factor=1.25, use_graphs=True, force_exchange=False):
+        if kind not in KINDS:
+            raise ValueError('row-sparse steps exist for plain SGD and Adagrad only')
+        self.tables = [Ut, It, Et]
+        self.small = [pref, pref_norm, rel, norm]
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        for t in self.tables:
+            if t.world != self.world or t.rank != self.rank:
+                raise ValueError('the tables must be sharded over the stepper\'s process group')
+        self.kind, self.lr, self.eps, self.max_norm = kind, float(lr), float(eps), float(max_norm)
+        self.l1, self.target, self.orth = bool(l1), float(target), bool(orth)
+        self.B = B = int(batch)
+        self.d = d = Ut.d
+        self.P = P = pref.shape[0]
+        dev = self.dev = Ut.weight.device
+        if dev.type != 'cuda':
+            raise L.KtupError('ShardedKtupStepper runs the HIP kernels: the tables must live on the GPU (no CPU fallback)')
+        if any(t.d != d for t in self.tables) or any(tuple(s.shape) != (P, d) or not s.is_contiguous() for s in self.small):
+            raise ValueError('one row width for all tables; the small tables are contiguous (P, d)')
+        if not L.load().ktup_train_step_supported(0, d, P):
+            raise L.KtupError('no fused KTUP step kernel for d=%d, n_pref=%d (ktup_train_step_supported)' % (d, P))
+        if item2ent.dtype != torch.int32 or item2ent.device != dev:
+            raise L.KtupError('item2ent must be an int32 device table')
+        self.item2ent, self.ent_pad = item2ent.contiguous(), int(ent_pad)
+        self.use_graphs = bool(use_graphs)
+        # force_exchange: take the several-ranks route (five segments, the three all-to-alls and the all-reduce) on ONE rank too --
+        # what a rank of a bigger job runs, minus the wire; with an initialised process group the collectives are real (RCCL at
+        # world 1), without one they are device copies
+        self.multi = self.world > 1 or bool(force_exchange)
+        self.capacity_factor = float(capacity_factor)
+        W_ = self.world
+        n_ent = [2 * B, 2 * B, 2 * B]                          # entries per table: [u ; u], [pos ; neg], their entities
+        n_dist = [B, 2 * B, 2 * B]                             # at most this many DISTINCT ids per table
+        if W_ == 1:
+            cap = list(n_dist)
+        else:
+            cap = [min(n, int(math.ceil(self.capacity_factor * n / W_)) + 64) for n in n_dist]
+        self.cap, self.capsum = cap, sum(cap)
+        self.W = W = W_ * self.capsum
+        self.E = E = 6 * B
+        i64 = lambda n, fill=None: torch.empty(n, dtype=torch.int64, device=dev) if fill is None else torch.full((n,), fill, dtype=torch.int64, device=dev)
+        i32 = lambda n: torch.zeros(n, dtype=torch.int32, device=dev)
+        f32 = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
+        lib = L.load()
+        self.u, self.pi, self.ni = i64(B, 0), i64(B, 0), i64(B, 0)
+        self.entries, self.inverse = i64(E, -1), i64(E, 0)
+        self.send_ids = i64(W, -1)
+        self.pair_map = i32(W + 1)
+        self.sort_ws = i32((lib.ktup_shard_route_sort_bytes(E, W) + 3) // 4)
+        self.counters = i32(W_ * 3 + 1)
+        self.route_ws = torch.empty((lib.ktup_shard_route_workspace_bytes(E) + 7) // 8, dtype=torch.int64, device=dev)
+        self.X = f32(W + 1, d)                                # row W stays zero: "no entity" (jTransUP.py:96 padding_idx)
+        self.Gcat = f32(4 * B, d)                             # [GU ; GV]
+        self.Gwire = f32(W, d)
+        self.acc = torch.zeros(2, dtype=torch.float64, device=dev)          # [local sum of squares, total]
+        self.loss_sum = f32(2)                                # [sum of batch-mean BPR terms, sum of orthogonalLoss values]
+        n_g = 4 if self.orth else 2
+        self.small_g = [f32(P, d) for _ in range(n_g)]        # orth: gP, gPn, gR, gRn; else gA (pref & rel), gC (pref_norm & norm)
+        self.small_state = [torch.zeros_like(s.data) for s in self.small] if kind == 'adagrad' else [None] * 4
+        for t in self.tables:
+            if kind == 'adagrad' and t.state is None:
+                t.state = torch.zeros_like(t.weight.data)
+        self.steps = 0
+        if self.multi:
+            self.recv_ids = i64(W, -1)
+            self.Xsend = f32(W, d)
+            self.Grecv = f32(W, d)
+            self.cap_own = [max(1, min(W_ * c, t.weight.shape[0])) for c, t in zip(cap, self.tables)]
+            self.W_own = Wo = sum(self.cap_own)
+            self.own_inverse = i64(W, 0)
+            self.own_ids = i64(Wo, -1)
+            self.own_sort = i32((lib.ktup_shard_route_sort_bytes(W, Wo) + 3) // 4)
+            self.own_counters = i32(3 + 1)
+            self.own_ws = torch.empty((lib.ktup_shard_route_workspace_bytes(W) + 7) // 8, dtype=torch.int64, device=dev)
+            self.Gown = f32(Wo, d)
+            self.bucket = torch.zeros(n_g * P * d + 2, dtype=torch.float64, device=dev)
+        self._eager = None
+        self._graphs = None
+        self._graph_steps = 0
+
+    # ------------------------------------------------------------------------------------------------ launch lists
+    def _bind(self, stream):
+        """Pre-bound launches (lib.bind) on `stream`, as the segments between the collectives."""
+        B, d, P, W, E, Wn = self.B, self.d, self.P, self.W, self.E, self.world
+        Ut, It, Et = self.tables
+        pref, pref_norm, rel, norm = [s.data for s in self.small]
+        keep = self._keep = []                                 # ctypes arrays must outlive the bound launches
+
+        def arr(x):
+            keep.append(x)
+            return ctypes.addressof(x)
+        tabs = arr(_ptrs([t.weight.data for t in self.tables]))
+        lds = arr(_i64s([t.weight.data.stride(0) for t in self.tables]))
+        states = arr(_ptrs([t.state for t in self.tables])) if self.kind == 'adagrad' else None
+        cap = arr(_i64s(self.cap))
+        eoff = arr(_i64s([0, 2 * B, 4 * B, 6 * B]))
+        kind = KINDS[self.kind]
+        gscale = 1.0 / Wn
+        g = self.small_g
+        if self.orth:
+            gP, gPn, gR, gRn = g
+            sg_list = [gP, gPn, gR, gRn]
+            sp0, ss0 = [pref, pref_norm, rel, norm], list(self.small_state)
+            sp1, ss1 = [None] * 4, [None] * 4
+            norm_list, small_weight = [gP, gPn, gR, gRn], 1.0
+        else:
+            gP, gPn, gR, gRn = g[0], g[1], None, None
+            sg_list = [g[0], g[1]]
+            sp0, ss0 = [pref, pref_norm], [self.small_state[0], self.small_state[1]]
+            sp1, ss1 = [rel, norm], [self.small_state[2], self.small_state[3]]
+            norm_list, small_weight = [g[0], g[0], g[1], g[1]], 2.0      # the norm runs over all four tables' gradients
+        n_small = len(sg_list)
+        sgp, sp0p, ss0p = arr(_ptrs(sg_list)), arr(_ptrs(sp0)), (arr(_ptrs(ss0)) if self.kind == 'adagrad' else None)
+        sp1p = arr(_ptrs(sp1)) if not self.orth else None
+        ss1p = arr(_ptrs(ss1)) if (not self.orth and self.kind == 'adagrad') else None
+        X, inv = self.X, self.inverse
+        bind = L.bind
+        entries = bind('ktup_shard_ktup_entries', _p(self.u), _p(self.pi), _p(self.ni), B, _p(self.item2ent), self.ent_pad,
+                       _p(self.entries), stream)
+        route = bind('ktup_shard_route', _p(self.entries), E, E, 3, eoff, Wn, cap, 1, 2, _p(inv), _p(self.send_ids), _p(self.pair_map),
+                     _p(self.sort_ws), _p(self.counters), _p(self.acc), 2, _p(self.route_ws), stream)
+        step = bind('ktup_train_rec_step_rows', _p(X), d, _p(X), d, _p(X), d, _p(self.pair_map), W, _p(pref), _p(pref_norm), _p(rel),
+                    _p(norm), d, P, d, _p(inv), inv.data_ptr() + 2 * B * 8, B, int(self.l1), self.target, gscale, int(self.orth),
+                    _p(self.loss_sum), _p(self.Gcat), self.Gcat.data_ptr() + 2 * B * d * 4, _p(gP), _p(gPn), _p(gR), _p(gRn), stream)
+        reduce_ = bind('ktup_shard_reduce_rows', _p(self.Gcat), d, d, 4 * B, 2 * B, _p(self.sort_ws), E, W, _p(self.Gwire), d, stream)
+        if not self.multi:
+            pack = bind('ktup_shard_pack_wire', 3, tabs, lds, cap, d, _p(self.send_ids), 1, _p(X), d, stream)
+            nl = [self.Gwire] + norm_list
+            nptr, nsz = arr(_ptrs(nl)), arr(_i64s([t.numel() for t in nl]))
+            gnorm = bind('ktup_optim_gradnorm_acc', len(nl), nptr, nsz, _p(self.acc), stream)
+            apply_ = bind('ktup_shard_apply', kind, 3, tabs, lds, states, lds, cap, d, _p(self.send_ids), 1, _p(self.Gwire), d, n_small, P,
+                          sgp, sp0p, ss0p, sp1p, ss1p, None, self.lr, self.eps, _p(self.acc), self.max_norm,
+                          self.counters.data_ptr() + 4 * (Wn * 3), None, stream)
+            return [[entries, route, pack, step, reduce_, gnorm, apply_]]
+        capo = arr(_i64s(self.cap_own))
+        eoff_o = arr(_i64s([0, self.cap[0], self.cap[0] + self.cap[1], self.capsum]))
+        pack = bind('ktup_shard_pack_wire', 3, tabs, lds, cap, d, _p(self.recv_ids), Wn, _p(self.Xsend), d, stream)
+        zero = bind('ktup_zero_async', _p(self.Gwire), self.Gwire.numel() * 4, stream)
+        oroute = bind('ktup_shard_route', _p(self.recv_ids), W, self.capsum, 3, eoff_o, 1, capo, 0, 0, _p(self.own_inverse),
+                      _p(self.own_ids), None, _p(self.own_sort), _p(self.own_counters), None, 0, _p(self.own_ws), stream)
+        oreduce = bind('ktup_shard_reduce_rows', _p(self.Grecv), d, d, W, 0, _p(self.own_sort), W, self.W_own, _p(self.Gown), d, stream)
+        nptr, nsz = arr(_ptrs([self.Gown])), arr(_i64s([self.Gown.numel()]))
+        gnorm = bind('ktup_optim_gradnorm_acc', 1, nptr, nsz, _p(self.acc), stream)
+        N = n_small * P * d
+        pack_b = bind('ktup_shard_bucket', 0, n_small, sgp, P * d, _p(self.bucket), _p(self.acc), self.counters.data_ptr() + 4 * (Wn * 3),
+                      None, 1.0, stream)
+        fin_b = bind('ktup_shard_bucket', 1, n_small, None, P * d, _p(self.bucket), None, None, self.acc.data_ptr() + 8, small_weight, stream)
+        apply_ = bind('ktup_shard_apply', kind, 3, tabs, lds, states, lds, capo, d, _p(self.own_ids), 1, _p(self.Gown), d, n_small, P,
+                      sgp, sp0p, ss0p, sp1p, ss1p, _p(self.bucket), self.lr, self.eps, self.acc.data_ptr() + 8, self.max_norm,
+                      None, self.bucket.data_ptr() + 8 * (N + 1), stream)
+        return [[entries, route], [pack], [step, reduce_], [zero, oroute, oreduce, gnorm, pack_b], [fin_b, apply_]]
+
+    def _exchange(self, k):
+        """The collective after segment k (several ranks only)."""
+        from jTransUP.parallel import _a2a, _all_reduce
+        if not dist.is_initialized():                        # force_exchange without a process group: one rank talks to itself
+            if k == 0:
+                self.recv_ids.copy_(self.send_ids)
+            elif k == 1:
+                self.X[:self.W].copy_(self.Xsend)
+            elif k == 2:
+                self.Grecv.copy_(self.Gwire)
+            return
+        if k == 0:
+            _a2a(self.recv_ids, self.send_ids, None, None, self.group)            # ids to their owners
+        elif k == 1:
+            _a2a(self.X[:self.W], self.Xsend, None, None, self.group)             # rows back
+        elif k == 2:
+            _a2a(self.Grecv, self.Gwire, None, None, self.group)                  # row gradients to the owners
+        elif k == 3:
+            _all_reduce(self.bucket, self.group)                                  # small gradients + norm + overflow flag
+
+    # ------------------------------------------------------------------------------------------------ the step
+    def load_batch(self, u, pos_items, neg_items):
+        """Copy a batch into the step's static id buffers (skip it by writing step.u / step.pi / step.ni in place)."""
+        self.u.copy_(u, non_blocking=True); self.pi.copy_(pos_items, non_blocking=True); self.ni.copy_(neg_items, non_blocking=True)
+
+    def __call__(self, u=None, pos_items=None, neg_items=None):
+        if u is not None:
+            self.load_batch(u, pos_items, neg_items)
+        self.run()
+
+    def run(self):
+        """One step on the ids in the static buffers.  The first two steps issue the launches directly (warm-up), then the
+        segments are captured once and replayed."""
+        stream = torch.cuda.current_stream(self.dev).cuda_stream
+        if not self.use_graphs or self.steps < 2:
+            if self._eager is None or self._eager[0] != stream:
+                self._eager = (stream, self._bind(stream), self._keep)
+            for k, seg in enumerate(self._eager[1]):
+                for launch in seg:
+                    launch()
+                if self.multi:
+                    self._exchange(k)
+            self.steps += 1
+            return
+        if self._graphs is None:
+            self._capture()
+        for k, g in enumerate(self._graphs):
+            g.replay()
+            if self.multi:
+                self._exchange(k)
+        self.steps += 1
+
+    def _capture(self):
+        """Each segment becomes one HIP graph (the collectives between them are issued by torch.distributed).  A captured segment
+        also RUNS nothing: the step that triggers the capture replays the fresh graphs."""
+        graphs, keeps = [], []
+        n_seg = 5 if self.multi else 1
+        for k in range(n_seg):
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                cs = torch.cuda.current_stream(self.dev).cuda_stream
+                segs = self._bind(cs)
+                keeps.append(self._keep)
+                for launch in segs[k]:
+                    launch()
+            graphs.append(graph)
+        self._graphs, self._graph_keep = graphs, keeps
+
+    # ------------------------------------------------------------------------------------------------ reporting
+    def overflowed_steps(self):
+        """Cheap only when called rarely: one device read.  The counter of the LAST step's unplaced ids (0 = fine)."""
+        if not self.multi:
+            return int(self.counters[-1].item())
+        return int(self.bucket[-1].item())
+
+    def check(self):
+        n = self.overflowed_steps()
+        if n:
+            raise L.KtupError('the last sharded step asked one owner for more distinct rows than capacity_factor=%.2f allows (%d ids '
+                              'unplaced on the job); the step was skipped -- raise capacity_factor (world = always safe)' % (self.capacity_factor, n))

@@ -1,0 +1,233 @@
+"""The fixed-shape config-5 step (jTransUP/sharded_ktup.py: route -> pack -> fused KTUP step with row-gradient output -> segment
+reduction -> clip + row-sparse optimizer, replayed as HIP graphs) against a single-process DENSE run of the reference's step on
+CPU: the oracle's KTUP scorer (jTransUP.py:122-143 restated in oracle/cpu_ref.py), bprLoss with target -1 (utils/loss.py:29-31 =
+softplus(pos - neg).mean()), clip_grad_norm_ and torch.optim (utils/trainer.py:63-77 with l2_lambda = 0), several consecutive
+steps so that graph replay, the zero-filled gradient buffers and the Adagrad state are all exercised.  One rank, one rank in
+exchange form (the several-ranks route talking to itself, with RCCL at world 1 when a process group exists), two ranks sharing
+the GPU (gloo stages the collectives), at toy sizes and at one rank's share of config 5."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cpu_ref as O
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def _world_tables(nu, ni, ne, P, d, seed, pad_every=0):
+    gen = torch.Generator().manual_seed(seed)
+    full = {k: torch.nn.functional.normalize(torch.randn(n, d, generator=gen), dim=1) for k, n in (('U', nu), ('I', ni), ('E', ne))}
+    small = [torch.nn.functional.normalize(torch.randn(P, d, generator=gen), dim=1) for _ in range(4)]
+    i2e = torch.randint(0, ne, (ni,), generator=gen)
+    if pad_every:
+        i2e[::pad_every] = -1                                   # items without an aligned entity (jTransUP.py:114-120 -> pad row)
+    return full, small, i2e, gen
+
+
+def _dense_reference(full, small0, i2e, batches, kind, lr, eps, max_norm, l1=False, orth=False):
+    """One process, whole tables, the global batch: returns the tables after the steps and the per-step losses."""
+    ne = full['E'].shape[0]
+    E_pad = torch.cat([full['E'], torch.zeros(1, full['E'].shape[1])])           # pad row = ent_total - 1 (jTransUP.py:46,96)
+    W = [torch.nn.Parameter(full['U'].clone()), torch.nn.Parameter(full['I'].clone()), torch.nn.Parameter(E_pad)] + \
+        [torch.nn.Parameter(t.clone()) for t in small0]
+    i2e_pad = torch.where(i2e < 0, torch.full_like(i2e, ne), i2e)
+    opt = torch.optim.Adagrad(W, lr=lr, eps=eps) if kind == 'adagrad' else torch.optim.SGD(W, lr=lr)
+    losses = []
+    for step in batches:
+        opt.zero_grad()
+        u = torch.cat([x[0] for x in step]); pi = torch.cat([x[1] for x in step]); ni_ = torch.cat([x[2] for x in step])
+        pos = O.score_ktup_rec(*W, i2e_pad, u, pi, l1); neg = O.score_ktup_rec(*W, i2e_pad, u, ni_, l1)
+        loss = torch.nn.functional.softplus(pos - neg).mean()
+        if orth:
+            loss = loss + O.orthogonal_loss(W[3], W[4])
+        loss.backward()
+        W[2].grad[-1].zero_()                                                    # padding_idx: the pad row takes no gradient
+        if max_norm > 0:
+            torch.nn.utils.clip_grad_norm_(W, max_norm)
+        opt.step()
+        losses.append(float(loss.detach()))
+    return [w.data for w in W], losses
+
+
+def _run_stepper(full, small0, i2e, batches, kind, lr, eps, max_norm, rank, world, dev, l1=False, orth=False, **kw):
+    from jTransUP import parallel
+    from jTransUP.sharded_ktup import ShardedKtupStepper
+    d = full['U'].shape[1]
+    mk = lambda key: parallel.ShardedTable(full[key].shape[0], d, rank=rank, world=world, device=dev,
+                                           init=lambda g: full[key][g].to(dev))
+    Ut, It, Et = mk('U'), mk('I'), mk('E')
+    small = [torch.nn.Parameter(t.clone().to(dev)) for t in small0]
+    B = batches[0][rank][0].numel()
+    st = ShardedKtupStepper(Ut, It, Et, *small, i2e.to(torch.int32).to(dev), batch=B, kind=kind, lr=lr, eps=eps, max_norm=max_norm,
+                            l1=l1, orth=orth, **kw)
+    for step in batches:
+        st(*(x.to(dev) for x in step[rank]))
+    torch.cuda.synchronize()
+    return (Ut, It, Et), small, st
+
+
+def _check(tables, small, Wd, rank, world, rtol=1e-4, atol=2e-5):
+    for t, w in zip(tables, Wd[:3]):
+        n = t.total_rows
+        torch.testing.assert_close(t.weight.data.cpu(), w[torch.arange(rank, n, world)], rtol=rtol, atol=atol)
+    for p, w in zip(small, Wd[3:]):
+        torch.testing.assert_close(p.data.cpu(), w, rtol=rtol, atol=atol)
+
+
+def _batches(gen, world, steps, nu, ni, b):
+    return [[(torch.randint(0, nu, (b,), generator=gen), torch.randint(0, ni, (b,), generator=gen),
+              torch.randint(0, ni, (b,), generator=gen)) for _ in range(world)] for _ in range(steps)]
+
+
+# Adagrad's first steps divide by |g| + eps: with the default eps = 1e-10 an element whose gradient is ~1e-10 turns fp32 rounding
+# noise into an O(lr) difference, so the comparisons use eps = 1e-4 (well-conditioned, same code path), as tests/test_hip_config5.py
+@pytest.mark.parametrize('d,P', [(256, 20), (100, 20), (64, 4)])
+@pytest.mark.parametrize('kind', ['adagrad', 'sgd'])
+@pytest.mark.parametrize('form', ['one_graph', 'exchange_form', 'eager'])
+def test_stepper_equals_the_dense_reference_step(d, P, kind, form):
+    nu, ni, ne, b, steps = 900, 300, 700, 512, 5                 # duplicates in every batch; every 7th item has no entity
+    full, small0, i2e, gen = _world_tables(nu, ni, ne, P, d, seed=11 + d, pad_every=7)
+    batches = _batches(gen, 1, steps, nu, ni, b)
+    lr, max_norm = (0.05, 0.5) if kind == 'adagrad' else (20.0, 0.5)
+    Wd, losses = _dense_reference(full, small0, i2e, batches, kind, lr, 1e-4, max_norm)
+    kw = {'one_graph': {}, 'exchange_form': {'force_exchange': True}, 'eager': {'use_graphs': False}}[form]
+    tables, small, st = _run_stepper(full, small0, i2e, batches, kind, lr, 1e-4, max_norm, 0, 1, torch.device(DEV), **kw)
+    assert st.steps == steps and (form == 'eager') == (st._graphs is None)
+    _check(tables, small, Wd, 0, 1)
+    np.testing.assert_allclose(float(st.loss_sum[0]), sum(losses), rtol=1e-4)
+    assert st.overflowed_steps() == 0
+    st.check()
+
+
+@pytest.mark.parametrize('l1,orth', [(True, False), (False, True)])
+def test_stepper_l1_distance_and_orthogonal_regulariser(l1, orth):
+    nu, ni, ne, b, steps, d, P = 500, 200, 400, 256, 3, 100, 20
+    full, small0, i2e, gen = _world_tables(nu, ni, ne, P, d, seed=5, pad_every=5)
+    batches = _batches(gen, 1, steps, nu, ni, b)
+    Wd, losses = _dense_reference(full, small0, i2e, batches, 'adagrad', 0.05, 1e-4, 0.5, l1=l1, orth=orth)
+    tables, small, st = _run_stepper(full, small0, i2e, batches, 'adagrad', 0.05, 1e-4, 0.5, 0, 1, torch.device(DEV), l1=l1, orth=orth)
+    _check(tables, small, Wd, 0, 1)
+    np.testing.assert_allclose(float(st.loss_sum[0] + st.loss_sum[1]), sum(losses), rtol=1e-4)
+
+
+def test_stepper_exchange_form_over_rccl_at_world_one():
+    """The several-ranks route with REAL collectives: init_process_group('nccl', world_size=1) -- RCCL's all_to_all_single and
+    all_reduce on the device buffers, between the captured segments."""
+    import torch.distributed as dist
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('nccl', rank=0, world_size=1)
+    try:
+        nu, ni, ne, b, steps, d, P = 900, 300, 700, 512, 4, 256, 20
+        full, small0, i2e, gen = _world_tables(nu, ni, ne, P, d, seed=23, pad_every=9)
+        batches = _batches(gen, 1, steps, nu, ni, b)
+        Wd, _ = _dense_reference(full, small0, i2e, batches, 'adagrad', 0.05, 1e-4, 0.5)
+        tables, small, st = _run_stepper(full, small0, i2e, batches, 'adagrad', 0.05, 1e-4, 0.5, 0, 1, torch.device(DEV), force_exchange=True)
+        assert st.multi and len(st._graphs) == 5
+        _check(tables, small, Wd, 0, 1)
+    finally:
+        dist.destroy_process_group()
+
+
+def _two_rank_worker(rank, world, port, kind, overflow):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)      # both ranks share this box's GPU (RCCL refuses that)
+    try:
+        dev = torch.device(DEV)
+        nu, ni, ne, b, steps, d, P = 901, 301, 703, 512, 4, 256, 20     # odd row counts: the shards differ in size
+        full, small0, i2e, gen = _world_tables(nu, ni, ne, P, d, seed=31, pad_every=6)
+        batches = _batches(gen, world, steps, nu, ni, b)
+        lr, max_norm = (0.05, 0.5) if kind == 'adagrad' else (20.0, 0.5)
+        if overflow:
+            tables, small, st = _run_stepper(full, small0, i2e, batches[:3], kind, lr, 1e-4, max_norm, rank, world, dev, capacity_factor=0.01)
+            assert st.overflowed_steps() > 0                            # cap = 64 + a few rows < the batch's distinct ids per owner
+            with pytest.raises(Exception):
+                st.check()
+            for key, t in zip(('U', 'I', 'E'), tables):                  # every overflowed step was skipped on every rank
+                assert torch.equal(t.weight.data.cpu(), full[key][torch.arange(rank, t.total_rows, world)])
+            for p, w in zip(small, small0):
+                assert torch.equal(p.data.cpu(), w)
+            assert float(st.Gwire.abs().sum()) == 0.0 and float(st.Gown.abs().sum()) == 0.0     # and left no gradient behind
+            return
+        Wd, _ = _dense_reference(full, small0, i2e, batches, kind, lr, 1e-4, max_norm)
+        tables, small, st = _run_stepper(full, small0, i2e, batches, kind, lr, 1e-4, max_norm, rank, world, dev)
+        assert st.multi and len(st._graphs) == 5 and st.overflowed_steps() == 0
+        _check(tables, small, Wd, rank, world)
+        copies = [torch.empty_like(small[0].data.cpu()) for _ in range(world)]
+        dist.all_gather(copies, small[0].data.cpu())
+        assert all(torch.equal(copies[0], c) for c in copies)            # replicated tables stay bit-identical across ranks
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('kind,overflow', [('adagrad', False), ('sgd', False), ('adagrad', True)])
+def test_stepper_two_ranks_share_the_gpu(kind, overflow):
+    import torch.multiprocessing as mp
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_two_rank_worker, args=(2, port, kind, overflow), nprocs=2, join=True)
+
+
+def _zipf(gen, n_rows, n, a):
+    uu = torch.rand(n, generator=gen, dtype=torch.float64)
+    a1 = a - 1.0
+    top = float(n_rows) ** (-a1)
+    rank = (1.0 - uu * (1.0 - top)) ** (-1.0 / a1)
+    return (rank.clamp(1, n_rows) - 1).to(torch.int64)
+
+
+@pytest.mark.parametrize('zipf', [0.0, 1.05])
+def test_stepper_at_one_ranks_share_of_config5(zipf):
+    """1.25 M / 125 K / 625 K rows, d = 256, P = 20, B = 8192, uniform and Zipf(1.05) ids (a hot row takes hundreds of entries of a
+    batch): the touched rows equal the dense reference run on the rows the batches touch, everything else is bit-identical."""
+    from jTransUP import parallel
+    from jTransUP.sharded_ktup import ShardedKtupStepper
+    NU, NI, NE, P, D, B, steps = 1_250_000, 125_000, 625_000, 20, 256, 8192, 3
+    dev = torch.device(DEV)
+    g = torch.Generator(device=DEV); g.manual_seed(3)
+
+    def table(n):
+        t = parallel.ShardedTable(n, D, rank=0, world=1, device=dev)
+        t.weight.data.copy_(torch.nn.functional.normalize(torch.randn(t.weight.shape, generator=g, device=DEV), dim=1))
+        return t
+    Ut, It, Et = table(NU), table(NI), table(NE)
+    small = [torch.nn.Parameter(torch.nn.functional.normalize(torch.randn(P, D, generator=g, device=DEV), dim=1)) for _ in range(4)]
+    item2ent = torch.randint(0, NE, (NI,), generator=g, device=DEV).to(torch.int32)
+    cg = torch.Generator().manual_seed(9)
+    draw = (lambda n_rows: torch.randint(0, n_rows, (B,), generator=cg)) if zipf <= 0 else (lambda n_rows: _zipf(cg, n_rows, B, zipf))
+    batches = [[(draw(NU), draw(NI), draw(NI))] for _ in range(steps)]
+    # the dense reference on the sub-world of touched rows: compact tables (row j = j-th distinct id), remapped batches
+    touched = {}
+    for key, parts in (('U', [b[0][0] for b in batches]), ('I', [x for b in batches for x in b[0][1:]])):
+        touched[key] = torch.unique(torch.cat(parts))
+    i2e_cpu = item2ent.cpu().long()
+    touched['E'] = torch.unique(i2e_cpu[touched['I']])
+    remap = {k: {int(v): j for j, v in enumerate(ids.tolist())} for k, ids in touched.items()}
+    sub = {k: t.weight.data[touched[k].to(DEV)].cpu() for k, t in (('U', Ut), ('I', It), ('E', Et))}
+    sub_i2e = torch.tensor([remap['E'][int(i2e_cpu[i])] for i in touched['I'].tolist()])
+    sub_batches = [[tuple(torch.tensor([remap[k][int(v)] for v in x.tolist()]) for k, x in zip(('U', 'I', 'I'), b[0]))] for b in batches]
+    before = {k: t.weight.data.clone() for k, t in (('U', Ut), ('I', It), ('E', Et))}
+    Wd, losses = _dense_reference(sub, [p.data.cpu() for p in small], sub_i2e, sub_batches, 'adagrad', 0.05, 1e-4, 5.0)
+    st = ShardedKtupStepper(Ut, It, Et, *small, item2ent, batch=B, kind='adagrad', lr=0.05, eps=1e-4, max_norm=5.0)
+    for b in batches:
+        st(*(x.to(DEV) for x in b[0]))
+    torch.cuda.synchronize()
+    assert st._graphs is not None and st.overflowed_steps() == 0
+    if zipf > 0:
+        assert touched['U'].numel() < steps * B // 2                       # hot ids: most entries share rows
+    for k, t, w in (('U', Ut, Wd[0]), ('I', It, Wd[1]), ('E', Et, Wd[2][:-1])):
+        ids = touched[k].to(DEV)
+        torch.testing.assert_close(t.weight.data[ids].cpu(), w, rtol=1e-4, atol=2e-5)
+        mask = torch.ones(t.weight.shape[0], dtype=torch.bool, device=DEV)
+        mask[ids] = False
+        assert torch.equal(t.weight.data[mask], before[k][mask])            # untouched rows bit-identical
+        assert float(t.state[mask].abs().sum()) == 0.0
+    for p, w in zip(small, Wd[3:]):
+        torch.testing.assert_close(p.data.cpu(), w, rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(float(st.loss_sum[0]), sum(losses), rtol=1e-4)

@@ -20,6 +20,69 @@ import torch
 import torch.distributed as dist
 
 
+def fused_main(args):
+    """jTransUP/sharded_ktup.py: the step as HIP-graph replays, no host sync.  Reports wall time per step (host clock around
+    `steps` replays, one synchronize at the end) and the device time between HIP events around the same replays."""
+    from jTransUP import parallel
+    from jTransUP.sharded_ktup import ShardedKtupStepper
+    rank, world = parallel.init_distributed()
+    dev = torch.device('cuda', torch.cuda.current_device())
+    scale = 1 if args.full else 8
+    NU, NI, NE, P, d, B = 10_000_000 // scale * world, 1_000_000 // scale * world, 5_000_000 // scale * world, 20, args.d, args.batch
+    gen = torch.Generator(device=dev); gen.manual_seed(3 + rank)
+
+    def table(n):
+        t = parallel.ShardedTable(n, d, rank=rank, world=world, device=dev)
+        t.weight.data.normal_(generator=gen)
+        t.weight.data.mul_(1.0 / 16.0)
+        return t
+    Ut, It, Et = table(NU), table(NI), table(NE)
+    small = [torch.nn.Parameter(torch.nn.functional.normalize(torch.randn(P, d, generator=gen, device=dev), dim=1)) for _ in range(4)]
+    if world > 1:
+        for p in small:
+            dist.broadcast(p.data, src=0)
+    item2ent = torch.randint(0, NE, (NI,), generator=torch.Generator(device=dev).manual_seed(7), device=dev).to(torch.int32)
+    st = ShardedKtupStepper(Ut, It, Et, *small, item2ent, batch=B, kind='adagrad', lr=0.005, max_norm=5.0, use_graphs=not args.no_graphs,
+                            force_exchange=args.exchange)
+
+    def draw(n_rows):
+        if args.zipf <= 0:
+            return torch.randint(0, n_rows, (B,), generator=gen, device=dev)
+        uu = torch.rand(B, generator=gen, device=dev, dtype=torch.float64)
+        a1 = args.zipf - 1.0
+        top = float(n_rows) ** (-a1)
+        r = (1.0 - uu * (1.0 - top)) ** (-1.0 / a1)
+        return (r.clamp(1, n_rows) - 1).to(torch.int64)
+    n = args.steps + 5
+    batches = [(draw(NU), draw(NI), draw(NI)) for _ in range(n)]
+    for s in range(5):
+        st(*batches[s])
+    torch.cuda.synchronize(dev)
+    l0 = float(st.loss_sum[0])
+    if world > 1:
+        dist.barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for s in range(5, n):
+        st(*batches[s])
+    ev1.record()
+    torch.cuda.synchronize(dev)
+    wall = time.perf_counter() - t0
+    devms = ev0.elapsed_time(ev1) / args.steps
+    if world > 1:
+        tt = torch.tensor([wall], device=dev); dist.all_reduce(tt, op=dist.ReduceOp.MAX); wall = float(tt)
+    st.check()
+    if rank == 0:
+        print(json.dumps({'config': 'KTUP d=%d, %d/%d/%d rows (users/items/entities) over %d rank(s), B=%d per rank, ids %s' % (d, NU, NI, NE, world, B, 'Zipf(%.2f)' % args.zipf if args.zipf > 0 else 'uniform'),
+                          'route': 'sharded_ktup.ShardedKtupStepper (%s%s)' % ('eager launches' if args.no_graphs else 'graph replay', ', exchange form' if args.exchange else ''),
+                          'ms_per_step': 1e3 * wall / args.steps, 'ms_per_step_device': devms,
+                          'scored_rows_per_s': 2 * B * world * args.steps / wall, 'wire_rows': st.W,
+                          'mean_loss': (float(st.loss_sum[0]) - l0) / args.steps}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--batch', type=int, default=8192)
@@ -27,7 +90,12 @@ def main():
     ap.add_argument('--d', type=int, default=256)
     ap.add_argument('--zipf', type=float, default=0.0, help='draw ids from Zipf(a) (hot rows: contention in the row-gradient atomics) instead of uniformly, e.g. 1.05')
     ap.add_argument('--full', action='store_true', help='the whole 10M / 1M / 5M tables on this rank set (needs ~17 GB per rank at world 1)')
+    ap.add_argument('--legacy', action='store_true', help="round 2's route: parallel.ShardedStep through autograd (eager torch ops around the kernels)")
+    ap.add_argument('--exchange', action='store_true', help='one rank in exchange form: the several-ranks route (five segments, all-to-alls) talking to itself')
+    ap.add_argument('--no-graphs', action='store_true')
     args = ap.parse_args()
+    if not args.legacy:
+        return fused_main(args)
     from jTransUP import parallel
     from jTransUP.hip import ops
     from jTransUP.utils import loss as Lf

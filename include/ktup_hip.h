@@ -374,7 +374,7 @@ int ktup_shard_sparse_step(int kind, float* table, int64_t ldt, float* state, in
  *   ktup_shard_reduce_rows; counters: world * n_tables + 1 int32, the last one counts ids that found no free slot (cap too small:
  *   the caller must then skip the step -- ktup_shard_apply does when handed that word); zero_doubles: n_zero_doubles device doubles
  *   cleared by the same launch (the step's accumulators).  `ws`: ktup_shard_route_workspace_bytes(n_entries), 8-byte aligned.
- *   No memset, no host read: five launches, capturable.  On the owner side of a multi-rank step the same call with world = 1 and
+ *   No memset, no host read: five launches, capturable; sort_ws 16-byte aligned.  On the owner side of a multi-rank step the same call with world = 1 and
  *   block = capsum groups the rows several peers asked for.
  * ktup_shard_reduce_rows: gwire[w] += sum of G rows of the entries sorted to wire row w; entry e reads row e of G for e < n_src,
  *   row e - src_off otherwise (KTUP: G = [GU ; GV] of ktup_train_rec_step_rows, 4B rows; the 2B entity entries re-read GV:
@@ -399,6 +399,14 @@ size_t ktup_shard_route_sort_bytes(int64_t n_entries, int64_t n_wire_rows);
 int ktup_shard_route(const int64_t* ids, int64_t n_entries, int64_t block, int n_tables, const int64_t* ent_off, int world,
                      const int64_t* cap, int pair_a, int pair_b, int64_t* inverse, int64_t* send_ids, int32_t* pair_map,
                      int32_t* sort_ws, int32_t* counters, double* zero_doubles, int n_zero_doubles, void* ws, void* stream);
+/* ktup_shard_route for the KTUP rec step with the entry list built by its first launch: batch (*cursor mod n_batches) of the id
+ * columns u / pos_items / neg_items (n_batches x B each; cursor NULL: batch 0) -> entries = [u ; u | pos ; neg | item2ent[pos ; neg]]
+ * (6B int64, written; 4B / two tables when item2ent is NULL), tables 0 / 1 / 2 = users / items / entities, pair_map = item wire row
+ * -> entity wire row.  *cursor (device) is incremented by the call: a replayed graph walks through the columns by itself.   */
+int ktup_shard_route_ktup(const int64_t* u, const int64_t* pos_items, const int64_t* neg_items, int64_t B, int64_t n_batches,
+                          int64_t* cursor, const int32_t* item2ent, int64_t ent_pad, int64_t* entries, int world,
+                          const int64_t* cap, int64_t* inverse, int64_t* send_ids, int32_t* pair_map, int32_t* sort_ws,
+                          int32_t* counters, double* zero_doubles, int n_zero_doubles, void* ws, void* stream);
 int ktup_shard_reduce_rows(const float* G, int64_t ldg, int d, int64_t n_src, int64_t src_off, const int32_t* sort_ws,
                            int64_t n_entries, int64_t n_wire_rows, float* gwire, int64_t ldw, void* stream);
 int ktup_shard_ktup_entries(const int64_t* u, const int64_t* pos_items, const int64_t* neg_items, int64_t B,

@@ -421,7 +421,7 @@ extern "C" int ktup_optim_gradnorm_acc(int n_tensors, float* const* grads, const
   if (int e = fill("ktup_optim_gradnorm_acc", T, n_tensors, nullptr, grads, nullptr, nullptr, sizes)) return e;
   const int64_t nchunks = T.chunk0[T.count];
   if (nchunks == 0) return KTUP_OK;
-  hipLaunchKernelGGL(gradnorm_kernel, dim3(grid_for((nchunks * 4 + 3) / 4, 256)), dim3(256), 0, (hipStream_t)stream, T, sumsq);
+  hipLaunchKernelGGL(gradnorm_kernel, dim3(grid_for((nchunks * 4 + 3) / 4, 1024)), dim3(256), 0, (hipStream_t)stream, T, sumsq);
   return check_launch("ktup_optim_gradnorm_acc");
 }
 

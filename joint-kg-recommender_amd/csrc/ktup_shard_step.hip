@@ -36,7 +36,15 @@ struct RouteArgs {
   int64_t* inverse; int64_t* send_ids; int32_t* pair_map;
   int32_t *start, *rank, *perm, *skey, *counters;
   double* zero_d; int n_zero_d;
+  int32_t* tile_tot; int n_tiles;                      // two-level scan of the histogram (TILE counters per tile); n_tiles = 0: one-workgroup scan
+  // KTUP source (ktup_shard_route_ktup): the init launch also BUILDS ids = [u ; u | pos ; neg | item2ent[pos ; neg]] from batch
+  // (*cursor mod n_batches) of the id columns, and the NEXT launch moves the cursor on
+  const int64_t *src_u, *src_pos, *src_neg; int64_t B, n_batches; const int32_t* item2ent; int64_t ent_pad; int64_t* cursor;
+  int64_t* ids_out;
 };
+
+constexpr int TILE = 1024;                             // histogram counters per scan tile (256 threads x 4)
+constexpr int MAX_TILES = 4096;
 
 KTUP_DEV uint64_t mix64(uint64_t x) {
   x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ull;
@@ -60,10 +68,24 @@ __global__ __launch_bounds__(256) void route_init_kernel(RouteArgs a) {
   for (int64_t i = tid; i <= a.W; i += nth) a.start[i] = 0;
   for (int64_t i = tid; i <= (int64_t)a.world * a.T; i += nth) a.counters[i] = 0;          // + the overflow word
   for (int64_t i = tid; i < a.n_zero_d; i += nth) a.zero_d[i] = 0.0;
+  if (a.src_u) {                                         // jTransUP.py:122-130: paddingItems as a table lookup
+    const int64_t b0 = a.cursor ? ((*a.cursor) % a.n_batches) * a.B : 0;
+    for (int64_t k = tid; k < 2 * a.B; k += nth) {
+      const int64_t kk = k < a.B ? k : k - a.B;
+      const int64_t item = k < a.B ? a.src_pos[b0 + kk] : a.src_neg[b0 + kk];
+      a.ids_out[k] = a.src_u[b0 + kk];
+      a.ids_out[2 * a.B + k] = item;
+      if (a.item2ent) {
+        const int64_t ent = a.item2ent[item];
+        a.ids_out[4 * a.B + k] = (ent < 0 || ent == a.ent_pad) ? -1 : ent;
+      }
+    }
+  }
 }
 
 __global__ __launch_bounds__(256) void route_insert_kernel(RouteArgs a) {
   const int lane = threadIdx.x & 63;
+  if (a.cursor && blockIdx.x == 0 && threadIdx.x == 0) *a.cursor = *a.cursor + 1;     // the init launch has read it
   const uint64_t mask = a.slots - 1;
   for (int64_t base = (int64_t)blockIdx.x * 256; base < a.n; base += (int64_t)gridDim.x * 256) {
     const int64_t e = base + threadIdx.x;
@@ -137,12 +159,67 @@ __global__ __launch_bounds__(256) void route_finish_kernel(RouteArgs a) {
   }
 }
 
+// exclusive scan of the histogram, level 1: every workgroup scans one tile of TILE counters in place and leaves its total
+__global__ __launch_bounds__(256) void route_tile_scan_kernel(RouteArgs a) {
+  __shared__ int32_t wsum[4];
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int64_t i0 = (int64_t)blockIdx.x * TILE + 4 * t;
+  int4 v = make_int4(0, 0, 0, 0);
+  if (i0 + 3 < a.W) v = *reinterpret_cast<const int4*>(a.start + i0);
+  else {
+    if (i0 < a.W) v.x = a.start[i0];
+    if (i0 + 1 < a.W) v.y = a.start[i0 + 1];
+    if (i0 + 2 < a.W) v.z = a.start[i0 + 2];
+  }
+  const int32_t mine = (v.x + v.y) + (v.z + v.w);
+  int32_t inc = mine;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int32_t up = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += up;
+  }
+  if (lane == 63) wsum[wv] = inc;
+  __syncthreads();
+  int32_t run = inc - mine;
+  for (int k = 0; k < wv; ++k) run += wsum[k];
+  const int4 o4 = make_int4(run, run + v.x, run + v.x + v.y, run + v.x + v.y + v.z);
+  if (i0 + 3 < a.W) *reinterpret_cast<int4*>(a.start + i0) = o4;
+  else {
+    if (i0 < a.W) a.start[i0] = o4.x;
+    if (i0 + 1 < a.W) a.start[i0 + 1] = o4.y;
+    if (i0 + 2 < a.W) a.start[i0 + 2] = o4.z;
+  }
+  if (t == 255) a.tile_tot[blockIdx.x] = run + mine;
+}
+
+// level 2 rides in the scatter launch: every workgroup scans the (few) tile totals into LDS
 __global__ __launch_bounds__(256) void route_scatter_kernel(RouteArgs a) {
+  __shared__ int32_t tpre[MAX_TILES];
+  __shared__ int32_t wsum2[4];
+  if (a.n_tiles > 0) {
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int per = (a.n_tiles + 255) / 256;
+    int32_t mine = 0;
+    for (int k = 0; k < per; ++k) { const int i = t * per + k; if (i < a.n_tiles) mine += a.tile_tot[i]; }
+    int32_t inc = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int32_t up = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += up;
+    }
+    if (lane == 63) wsum2[wv] = inc;
+    __syncthreads();
+    int32_t run = inc - mine;
+    for (int k = 0; k < wv; ++k) run += wsum2[k];
+    for (int k = 0; k < per; ++k) { const int i = t * per + k; if (i < a.n_tiles) { tpre[i] = run; run += a.tile_tot[i]; } }
+    if (blockIdx.x == 0 && t == 255) a.start[a.W] = run;          // the number of sorted entries (ktup_shard_reduce_rows reads it)
+    __syncthreads();
+  }
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < a.n; e += (int64_t)gridDim.x * 256) {
     const int32_t r = a.rank[e];
     if (r < 0) continue;
     const int64_t w = a.inverse[e];
-    const int32_t pos = a.start[w] + r;
+    const int32_t pos = a.start[w] + r + (a.n_tiles > 0 ? tpre[w / TILE] : 0);
     a.perm[pos] = (int32_t)e;
     a.skey[pos] = (int32_t)w;
   }
@@ -382,8 +459,49 @@ extern "C" size_t ktup_shard_route_workspace_bytes(int64_t n_entries) {
 
 extern "C" size_t ktup_shard_route_sort_bytes(int64_t n_entries, int64_t n_wire_rows) {
   if (n_entries <= 0 || n_wire_rows <= 0) return 0;
-  return ((size_t)((n_wire_rows + 2) & ~(int64_t)1) + (size_t)3 * n_entries) * sizeof(int32_t);
+  return ((size_t)((n_wire_rows + 2) & ~(int64_t)1) + (size_t)3 * n_entries + (size_t)((n_wire_rows + TILE - 1) / TILE)) * sizeof(int32_t);
 }
+
+namespace {
+
+int route_impl(const char* name, RouteArgs& a, int pair_a, int pair_b, int64_t* inverse, int64_t* send_ids, int32_t* pair_map,
+               int32_t* sort_ws, int32_t* counters, double* zero_doubles, int n_zero_doubles, void* ws, hipStream_t st) {
+  KTUP_REQUIRE(inverse && send_ids && sort_ws && counters && ws, "%s: null pointer argument", name);
+  KTUP_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 7u) == 0 && (reinterpret_cast<uintptr_t>(sort_ws) & 15u) == 0,
+               "%s: workspace must be 8-byte, sort_ws 16-byte aligned", name);
+  KTUP_REQUIRE(!pair_map || (pair_a >= 0 && pair_a < a.T && pair_b >= 0 && pair_b < a.T && pair_a != pair_b &&
+                             a.eoff[pair_a + 1] - a.eoff[pair_a] == a.eoff[pair_b + 1] - a.eoff[pair_b] && a.n == a.block),
+               "%s: pair_map needs two tables with equally many entries in a single block", name);
+  KTUP_REQUIRE(n_zero_doubles >= 0 && (n_zero_doubles == 0 || zero_doubles), "%s: bad accumulator list", name);
+  a.pair_a = pair_a; a.pair_b = pair_b; a.pair_map = pair_map;
+  a.slots = route_slots(a.n);
+  a.keys = reinterpret_cast<unsigned long long*>(ws);
+  a.slot_pos = reinterpret_cast<int32_t*>(a.keys + a.slots);
+  a.inverse = inverse; a.send_ids = send_ids;
+  a.start = sort_ws;
+  a.rank = sort_ws + ((a.W + 2) & ~(int64_t)1);
+  a.perm = a.rank + a.n;
+  a.skey = a.perm + a.n;
+  a.tile_tot = a.skey + a.n;
+  const int64_t n_tiles = (a.W + TILE - 1) / TILE;
+  a.n_tiles = n_tiles <= MAX_TILES ? (int)n_tiles : 0;
+  a.counters = counters; a.zero_d = zero_doubles; a.n_zero_d = n_zero_doubles;
+  const int64_t init_items = (int64_t)a.slots > a.W + 1 ? (int64_t)a.slots : a.W + 1;
+  hipLaunchKernelGGL(route_init_kernel, dim3(grid_for((init_items + 255) / 256, 1024)), dim3(256), 0, st, a);
+  const int grid = grid_for((a.n + 255) / 256, 1024);
+  hipLaunchKernelGGL(route_insert_kernel, dim3(grid), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(route_finish_kernel, dim3(grid), dim3(256), 0, st, a);
+  if (int e = check_launch(name)) return e;
+  if (a.n_tiles > 0) {
+    hipLaunchKernelGGL(route_tile_scan_kernel, dim3(a.n_tiles), dim3(256), 0, st, a);
+  } else if (int e = seg_scan_wide(a.start, a.W, st, name)) {
+    return e;
+  }
+  hipLaunchKernelGGL(route_scatter_kernel, dim3(grid), dim3(256), 0, st, a);
+  return check_launch(name);
+}
+
+}  // namespace
 
 extern "C" int ktup_shard_route(const int64_t* ids, int64_t n_entries, int64_t block, int n_tables, const int64_t* ent_off, int world,
                                 const int64_t* cap, int pair_a, int pair_b, int64_t* inverse, int64_t* send_ids, int32_t* pair_map,
@@ -391,32 +509,27 @@ extern "C" int ktup_shard_route(const int64_t* ids, int64_t n_entries, int64_t b
   const char* name = "ktup_shard_route";
   RouteArgs a{};
   if (int e = fill_route(name, a, ids, n_entries, block, n_tables, ent_off, world, cap)) return e;
-  KTUP_REQUIRE(inverse && send_ids && sort_ws && counters && ws, "%s: null pointer argument", name);
-  KTUP_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 7u) == 0, "%s: workspace must be 8-byte aligned", name);
-  KTUP_REQUIRE(!pair_map || (pair_a >= 0 && pair_a < n_tables && pair_b >= 0 && pair_b < n_tables && pair_a != pair_b &&
-                             ent_off[pair_a + 1] - ent_off[pair_a] == ent_off[pair_b + 1] - ent_off[pair_b] && n_entries == block),
-               "%s: pair_map needs two tables with equally many entries in a single block", name);
-  KTUP_REQUIRE(n_zero_doubles >= 0 && (n_zero_doubles == 0 || zero_doubles), "%s: bad accumulator list", name);
-  a.pair_a = pair_a; a.pair_b = pair_b; a.pair_map = pair_map;
-  a.slots = route_slots(n_entries);
-  a.keys = reinterpret_cast<unsigned long long*>(ws);
-  a.slot_pos = reinterpret_cast<int32_t*>(a.keys + a.slots);
-  a.inverse = inverse; a.send_ids = send_ids;
-  a.start = sort_ws;
-  a.rank = sort_ws + ((a.W + 2) & ~(int64_t)1);
-  a.perm = a.rank + n_entries;
-  a.skey = a.perm + n_entries;
-  a.counters = counters; a.zero_d = zero_doubles; a.n_zero_d = n_zero_doubles;
-  hipStream_t st = (hipStream_t)stream;
-  const int64_t init_items = (int64_t)a.slots > a.W + 1 ? (int64_t)a.slots : a.W + 1;
-  hipLaunchKernelGGL(route_init_kernel, dim3(grid_for((init_items + 255) / 256, 1024)), dim3(256), 0, st, a);
-  const int grid = grid_for((n_entries + 255) / 256, 1024);
-  hipLaunchKernelGGL(route_insert_kernel, dim3(grid), dim3(256), 0, st, a);
-  hipLaunchKernelGGL(route_finish_kernel, dim3(grid), dim3(256), 0, st, a);
-  if (int e = check_launch(name)) return e;
-  if (int e = seg_scan_wide(a.start, a.W, st, name)) return e;
-  hipLaunchKernelGGL(route_scatter_kernel, dim3(grid), dim3(256), 0, st, a);
-  return check_launch(name);
+  return route_impl(name, a, pair_a, pair_b, inverse, send_ids, pair_map, sort_ws, counters, zero_doubles, n_zero_doubles, ws, (hipStream_t)stream);
+}
+
+// The KTUP rec step's route with its entry list built by the first launch (no separate entries launch): batch (*cursor mod
+// n_batches) of the id columns u / pos / neg (n_batches x B each; cursor may be NULL: batch 0), entries = [u ; u | pos ; neg |
+// item2ent[pos ; neg]] written to `entries` (6B; 4B and two tables when item2ent is NULL), tables 0 / 1 / 2 = users / items /
+// entities, pair_map = item wire row -> entity wire row.  *cursor is incremented by the call.
+extern "C" int ktup_shard_route_ktup(const int64_t* u, const int64_t* pos_items, const int64_t* neg_items, int64_t B, int64_t n_batches,
+                                     int64_t* cursor, const int32_t* item2ent, int64_t ent_pad, int64_t* entries, int world,
+                                     const int64_t* cap, int64_t* inverse, int64_t* send_ids, int32_t* pair_map, int32_t* sort_ws,
+                                     int32_t* counters, double* zero_doubles, int n_zero_doubles, void* ws, void* stream) {
+  const char* name = "ktup_shard_route_ktup";
+  KTUP_REQUIRE(B > 0 && n_batches > 0 && u && pos_items && neg_items && entries, "%s: null pointer argument or empty batch", name);
+  const int T = item2ent ? 3 : 2;
+  const int64_t eoff[4] = {0, 2 * B, 4 * B, 6 * B};
+  RouteArgs a{};
+  if (int e = fill_route(name, a, entries, 2 * B * T, 2 * B * T, T, eoff, world, cap)) return e;
+  a.src_u = u; a.src_pos = pos_items; a.src_neg = neg_items; a.B = B; a.n_batches = n_batches; a.cursor = cursor;
+  a.item2ent = item2ent; a.ent_pad = ent_pad; a.ids_out = entries;
+  return route_impl(name, a, 1, 2, inverse, send_ids, item2ent ? pair_map : nullptr, sort_ws, counters, zero_doubles, n_zero_doubles, ws,
+                    (hipStream_t)stream);
 }
 
 extern "C" int ktup_shard_reduce_rows(const float* G, int64_t ldg, int d, int64_t n_src, int64_t src_off, const int32_t* sort_ws,

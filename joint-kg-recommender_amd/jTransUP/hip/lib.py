@@ -96,6 +96,7 @@ SIGNATURES = {
     'ktup_shard_route_workspace_bytes': [c_l],
     'ktup_shard_route_sort_bytes': [c_l, c_l],
     'ktup_shard_route': [c_p, c_l, c_l, c_i, c_p, c_i, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p],
+    'ktup_shard_route_ktup': [c_p, c_p, c_p, c_l, c_l, c_p, c_p, c_l, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p],
     'ktup_shard_reduce_rows': [c_p, c_l, c_i, c_l, c_l, c_p, c_l, c_l, c_p, c_l, c_p],
     'ktup_shard_ktup_entries': [c_p, c_p, c_p, c_l, c_p, c_l, c_p, c_p],
     'ktup_shard_pack_wire': [c_i, c_p, c_p, c_p, c_i, c_p, c_l, c_p, c_l, c_p],

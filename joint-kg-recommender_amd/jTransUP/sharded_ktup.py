@@ -4,11 +4,12 @@ that are row-sharded by `row % world` (parallel.ShardedTable), with every buffer
 torch op, no autograd in the step; the launches go through the C ABI with pre-bound arguments and are replayed as HIP graphs.
 The reference is single-device: everything here is new.
 
-One rank (the whole step is one graph of 12 launches):
-    entries    [u ; u | pos ; neg | item2ent[pos ; neg]]                                     ktup_shard_ktup_entries
-    route      distinct ids -> wire rows (owner-major, fixed capacity), inverse, item -> entity map on the wire rows, and the
-               counting sort of the entries by wire row as a by-product                       ktup_shard_route (5 launches)
-    pack       X[w] = table[ids[w]] for all three tables                                      ktup_shard_pack_wire
+One rank (the whole step is one graph of 9-10 launches):
+    route      entries [u ; u | pos ; neg | item2ent[pos ; neg]] of the cursor's batch; distinct ids -> wire rows (owner-major,
+               fixed capacity), inverse, item -> entity map on the wire rows, and the counting sort of the entries by wire row
+               as a by-product                                                                ktup_shard_route_ktup (5 launches)
+    pack       X[w] = table[ids[w]] for all three tables (skipped on one rank when every item has an entity row: the step
+               kernel then gathers straight from the shards by global id)                     ktup_shard_pack_wire
     step       forward of [pos ; neg], BPR term, backward; the row gradient of pair k is row k of GU / GV, the small tables'
                gradients accumulate in gA / gC                                                ktup_train_rec_step_rows
     reduce     Gwire[w] += rows of the entries sorted to w (users | items | entities)         ktup_shard_reduce_rows
@@ -58,7 +59,8 @@ class ShardedKtupStepper(object):
     reference's dense step for plain SGD / Adagrad with l2_lambda = 0 (rows with a zero gradient do not move under either)."""
 
     def __init__(self, Ut, It, Et, pref, pref_norm, rel, norm, item2ent, batch, kind='adagrad', lr=0.005, eps=1e-10, max_norm=0.0,
-                 l1=False, target=-1.0, orth=False, ent_pad=-1, group=None, capacity_factor=1.25, use_graphs=True, force_exchange=False):
+                 l1=False, target=-1.0, orth=False, ent_pad=-1, group=None, capacity_factor=1.25, use_graphs=True, force_exchange=False,
+                 direct=None):
         if kind not in KINDS:
             raise ValueError('row-sparse steps exist for plain SGD and Adagrad only')
         self.tables = [Ut, It, Et]
@@ -90,6 +92,12 @@ class ShardedKtupStepper(object):
         # world 1), without one they are device copies
         self.multi = self.world > 1 or bool(force_exchange)
         self.capacity_factor = float(capacity_factor)
+        # direct (one rank only): the step kernel gathers straight from the shards by global id -- no pack launch, no compact copy;
+        # it needs every item's entity to be a row of Et (no negative map entries; `ent_pad`, if given, is Et's own zero row)
+        can_direct = not self.multi and not bool((self.item2ent < 0).any())
+        if direct and not can_direct:
+            raise ValueError('direct gathers need a single rank and an item2ent without negative entries')
+        self.direct = can_direct if direct is None else bool(direct)
         W_ = self.world
         n_ent = [2 * B, 2 * B, 2 * B]                          # entries per table: [u ; u], [pos ; neg], their entities
         n_dist = [B, 2 * B, 2 * B]                             # at most this many DISTINCT ids per table
@@ -105,6 +113,8 @@ class ShardedKtupStepper(object):
         f32 = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
         lib = L.load()
         self.u, self.pi, self.ni = i64(B, 0), i64(B, 0), i64(B, 0)
+        self.cursor = torch.zeros(1, dtype=torch.int64, device=dev)       # batch the next step reads (device side, moves by itself)
+        self._feed = (self.u, self.pi, self.ni, 1)
         self.entries, self.inverse = i64(E, -1), i64(E, 0)
         self.send_ids = i64(W, -1)
         self.pair_map = i32(W + 1)
@@ -177,13 +187,20 @@ class ShardedKtupStepper(object):
         ss1p = arr(_ptrs(ss1)) if (not self.orth and self.kind == 'adagrad') else None
         X, inv = self.X, self.inverse
         bind = L.bind
-        entries = bind('ktup_shard_ktup_entries', _p(self.u), _p(self.pi), _p(self.ni), B, _p(self.item2ent), self.ent_pad,
-                       _p(self.entries), stream)
-        route = bind('ktup_shard_route', _p(self.entries), E, E, 3, eoff, Wn, cap, 1, 2, _p(inv), _p(self.send_ids), _p(self.pair_map),
-                     _p(self.sort_ws), _p(self.counters), _p(self.acc), 2, _p(self.route_ws), stream)
-        step = bind('ktup_train_rec_step_rows', _p(X), d, _p(X), d, _p(X), d, _p(self.pair_map), W, _p(pref), _p(pref_norm), _p(rel),
-                    _p(norm), d, P, d, _p(inv), inv.data_ptr() + 2 * B * 8, B, int(self.l1), self.target, gscale, int(self.orth),
-                    _p(self.loss_sum), _p(self.Gcat), self.Gcat.data_ptr() + 2 * B * d * 4, _p(gP), _p(gPn), _p(gR), _p(gRn), stream)
+        fu, fp, fn, nb = self._feed
+        route = bind('ktup_shard_route_ktup', _p(fu), _p(fp), _p(fn), B, nb, _p(self.cursor), _p(self.item2ent), self.ent_pad,
+                     _p(self.entries), Wn, cap, _p(inv), _p(self.send_ids), _p(self.pair_map), _p(self.sort_ws), _p(self.counters),
+                     _p(self.acc), 2, _p(self.route_ws), stream)
+        if self.direct:                                      # global ids straight into the shards (entries = [u ; u | pos ; neg | ...])
+            ent = self.entries
+            step = bind('ktup_train_rec_step_rows', _p(Ut.weight.data), Ut.weight.data.stride(0), _p(It.weight.data), It.weight.data.stride(0),
+                        _p(Et.weight.data), Et.weight.data.stride(0), _p(self.item2ent), self.ent_pad, _p(pref), _p(pref_norm), _p(rel),
+                        _p(norm), d, P, d, _p(ent), ent.data_ptr() + 2 * B * 8, B, int(self.l1), self.target, gscale, int(self.orth),
+                        _p(self.loss_sum), _p(self.Gcat), self.Gcat.data_ptr() + 2 * B * d * 4, _p(gP), _p(gPn), _p(gR), _p(gRn), stream)
+        else:
+            step = bind('ktup_train_rec_step_rows', _p(X), d, _p(X), d, _p(X), d, _p(self.pair_map), W, _p(pref), _p(pref_norm), _p(rel),
+                        _p(norm), d, P, d, _p(inv), inv.data_ptr() + 2 * B * 8, B, int(self.l1), self.target, gscale, int(self.orth),
+                        _p(self.loss_sum), _p(self.Gcat), self.Gcat.data_ptr() + 2 * B * d * 4, _p(gP), _p(gPn), _p(gR), _p(gRn), stream)
         reduce_ = bind('ktup_shard_reduce_rows', _p(self.Gcat), d, d, 4 * B, 2 * B, _p(self.sort_ws), E, W, _p(self.Gwire), d, stream)
         if not self.multi:
             pack = bind('ktup_shard_pack_wire', 3, tabs, lds, cap, d, _p(self.send_ids), 1, _p(X), d, stream)
@@ -193,7 +210,7 @@ class ShardedKtupStepper(object):
             apply_ = bind('ktup_shard_apply', kind, 3, tabs, lds, states, lds, cap, d, _p(self.send_ids), 1, _p(self.Gwire), d, n_small, P,
                           sgp, sp0p, ss0p, sp1p, ss1p, None, self.lr, self.eps, _p(self.acc), self.max_norm,
                           self.counters.data_ptr() + 4 * (Wn * 3), None, stream)
-            return [[entries, route, pack, step, reduce_, gnorm, apply_]]
+            return [[route, step, reduce_, gnorm, apply_] if self.direct else [route, pack, step, reduce_, gnorm, apply_]]
         capo = arr(_i64s(self.cap_own))
         eoff_o = arr(_i64s([0, self.cap[0], self.cap[0] + self.cap[1], self.capsum]))
         pack = bind('ktup_shard_pack_wire', 3, tabs, lds, cap, d, _p(self.recv_ids), Wn, _p(self.Xsend), d, stream)
@@ -210,7 +227,7 @@ class ShardedKtupStepper(object):
         apply_ = bind('ktup_shard_apply', kind, 3, tabs, lds, states, lds, capo, d, _p(self.own_ids), 1, _p(self.Gown), d, n_small, P,
                       sgp, sp0p, ss0p, sp1p, ss1p, _p(self.bucket), self.lr, self.eps, self.acc.data_ptr() + 8, self.max_norm,
                       None, self.bucket.data_ptr() + 8 * (N + 1), stream)
-        return [[entries, route], [pack], [step, reduce_], [zero, oroute, oreduce, gnorm, pack_b], [fin_b, apply_]]
+        return [[route], [pack], [step, reduce_], [zero, oroute, oreduce, gnorm, pack_b], [fin_b, apply_]]
 
     def _exchange(self, k):
         """The collective after segment k (several ranks only)."""
@@ -234,8 +251,27 @@ class ShardedKtupStepper(object):
 
     # ------------------------------------------------------------------------------------------------ the step
     def load_batch(self, u, pos_items, neg_items):
-        """Copy a batch into the step's static id buffers (skip it by writing step.u / step.pi / step.ni in place)."""
+        """Copy a batch into the step's static id buffers (skip it by writing step.u / step.pi / step.ni in place, or by set_feed)."""
+        if self._feed[0] is not self.u:
+            self.set_feed(None)
         self.u.copy_(u, non_blocking=True); self.pi.copy_(pos_items, non_blocking=True); self.ni.copy_(neg_items, non_blocking=True)
+
+    def set_feed(self, columns):
+        """Device-fed batches: columns = (u, pos_items, neg_items), contiguous int64 device tensors of n_batches x B ids each (an epoch
+        of pre-drawn batches, or whatever a device-side sampler refills in place).  Step s reads batch (cursor mod n_batches) and the
+        step's own first launches move the device cursor on: `run()` then needs no per-step copy or argument.  None: back to the
+        static one-batch buffers that load_batch fills."""
+        if columns is None:
+            self._feed = (self.u, self.pi, self.ni, 1)
+        else:
+            u, p, n = columns
+            for c in (u, p, n):
+                if c.dtype != torch.int64 or c.device != self.dev or not c.is_contiguous() or c.numel() % self.B or c.numel() != u.numel():
+                    raise L.KtupError('feed columns are contiguous int64 device tensors of n_batches x B ids each')
+            self._feed = (u, p, n, u.numel() // self.B)
+        self.cursor.zero_()
+        self._eager = None
+        self._graphs = None                                   # the column addresses are baked into the bound launches
 
     def __call__(self, u=None, pos_items=None, neg_items=None):
         if u is not None:

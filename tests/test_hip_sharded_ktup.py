@@ -104,15 +104,43 @@ def test_stepper_equals_the_dense_reference_step(d, P, kind, form):
     st.check()
 
 
-@pytest.mark.parametrize('l1,orth', [(True, False), (False, True)])
-def test_stepper_l1_distance_and_orthogonal_regulariser(l1, orth):
+@pytest.mark.parametrize('l1,orth,pad_every', [(True, False, 0), (False, True, 5), (False, False, 0)])
+def test_stepper_l1_distance_and_orthogonal_regulariser(l1, orth, pad_every):
+    """pad_every = 0: every item has an entity row, so the one-rank step gathers straight from the shards (no pack launch)."""
     nu, ni, ne, b, steps, d, P = 500, 200, 400, 256, 3, 100, 20
-    full, small0, i2e, gen = _world_tables(nu, ni, ne, P, d, seed=5, pad_every=5)
+    full, small0, i2e, gen = _world_tables(nu, ni, ne, P, d, seed=5, pad_every=pad_every)
     batches = _batches(gen, 1, steps, nu, ni, b)
     Wd, losses = _dense_reference(full, small0, i2e, batches, 'adagrad', 0.05, 1e-4, 0.5, l1=l1, orth=orth)
     tables, small, st = _run_stepper(full, small0, i2e, batches, 'adagrad', 0.05, 1e-4, 0.5, 0, 1, torch.device(DEV), l1=l1, orth=orth)
+    assert st.direct == (pad_every == 0)
     _check(tables, small, Wd, 0, 1)
     np.testing.assert_allclose(float(st.loss_sum[0] + st.loss_sum[1]), sum(losses), rtol=1e-4)
+
+
+@pytest.mark.parametrize('direct', [True, False])
+def test_stepper_device_fed_batches_walk_the_columns(direct):
+    """set_feed: an epoch of pre-drawn batches in device columns, the step's own launches move the cursor (no per-step copy or
+    argument); 5 steps over 3 batches wrap around."""
+    from jTransUP import parallel
+    from jTransUP.sharded_ktup import ShardedKtupStepper
+    nu, ni, ne, b, d, P = 700, 250, 500, 256, 128, 20
+    dev = torch.device(DEV)
+    full, small0, i2e, gen = _world_tables(nu, ni, ne, P, d, seed=41)
+    three = _batches(gen, 1, 3, nu, ni, b)
+    order = [0, 1, 2, 0, 1]
+    Wd, losses = _dense_reference(full, small0, i2e, [three[k] for k in order], 'adagrad', 0.05, 1e-4, 0.5)
+    mk = lambda key: parallel.ShardedTable(full[key].shape[0], d, rank=0, world=1, device=dev, init=lambda g: full[key][g].to(dev))
+    Ut, It, Et = mk('U'), mk('I'), mk('E')
+    small = [torch.nn.Parameter(t.clone().to(dev)) for t in small0]
+    st = ShardedKtupStepper(Ut, It, Et, *small, i2e.to(torch.int32).to(dev), batch=b, kind='adagrad', lr=0.05, eps=1e-4, max_norm=0.5, direct=direct)
+    cols = [torch.stack([three[k][0][c] for k in range(3)]).to(dev) for c in range(3)]
+    st.set_feed(cols)
+    for _ in order:
+        st.run()
+    torch.cuda.synchronize()
+    assert int(st.cursor) == len(order) and st._graphs is not None
+    _check((Ut, It, Et), small, Wd, 0, 1)
+    np.testing.assert_allclose(float(st.loss_sum[0]), sum(losses), rtol=1e-4)
 
 
 def test_stepper_exchange_form_over_rccl_at_world_one():

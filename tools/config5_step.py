@@ -43,7 +43,7 @@ def fused_main(args):
             dist.broadcast(p.data, src=0)
     item2ent = torch.randint(0, NE, (NI,), generator=torch.Generator(device=dev).manual_seed(7), device=dev).to(torch.int32)
     st = ShardedKtupStepper(Ut, It, Et, *small, item2ent, batch=B, kind='adagrad', lr=0.005, max_norm=5.0, use_graphs=not args.no_graphs,
-                            force_exchange=args.exchange)
+                            force_exchange=args.exchange, direct=False if (args.no_direct or args.exchange or world > 1) else None)
 
     def draw(n_rows):
         if args.zipf <= 0:
@@ -55,6 +55,9 @@ def fused_main(args):
         return (r.clamp(1, n_rows) - 1).to(torch.int64)
     n = args.steps + 5
     batches = [(draw(NU), draw(NI), draw(NI)) for _ in range(n)]
+    if not args.copy_batches:                                # device-fed: the step's own launches walk the pre-drawn columns
+        st.set_feed([torch.stack([b[c] for b in batches]).contiguous() for c in range(3)])
+        batches = [()] * n
     for s in range(5):
         st(*batches[s])
     torch.cuda.synchronize(dev)
@@ -75,7 +78,8 @@ def fused_main(args):
     st.check()
     if rank == 0:
         print(json.dumps({'config': 'KTUP d=%d, %d/%d/%d rows (users/items/entities) over %d rank(s), B=%d per rank, ids %s' % (d, NU, NI, NE, world, B, 'Zipf(%.2f)' % args.zipf if args.zipf > 0 else 'uniform'),
-                          'route': 'sharded_ktup.ShardedKtupStepper (%s%s)' % ('eager launches' if args.no_graphs else 'graph replay', ', exchange form' if args.exchange else ''),
+                          'route': 'sharded_ktup.ShardedKtupStepper (%s%s%s%s)' % ('eager launches' if args.no_graphs else 'graph replay', ', exchange form' if args.exchange else '',
+                                                                                    ', direct gathers' if st.direct else ', packed rows', ', batches copied in' if args.copy_batches else ', device-fed'),
                           'ms_per_step': 1e3 * wall / args.steps, 'ms_per_step_device': devms,
                           'scored_rows_per_s': 2 * B * world * args.steps / wall, 'wire_rows': st.W,
                           'mean_loss': (float(st.loss_sum[0]) - l0) / args.steps}))
@@ -93,6 +97,8 @@ def main():
     ap.add_argument('--legacy', action='store_true', help="round 2's route: parallel.ShardedStep through autograd (eager torch ops around the kernels)")
     ap.add_argument('--exchange', action='store_true', help='one rank in exchange form: the several-ranks route (five segments, all-to-alls) talking to itself')
     ap.add_argument('--no-graphs', action='store_true')
+    ap.add_argument('--copy-batches', action='store_true', help='hand every batch over as three tensors (three device copies per step) instead of device-fed columns')
+    ap.add_argument('--no-direct', action='store_true', help='one rank: pack the rows into the compact wire table first (what several ranks do)')
     args = ap.parse_args()
     if not args.legacy:
         return fused_main(args)

@@ -383,17 +383,18 @@ int ktup_shard_sparse_step(int kind, float* table, int64_t ldt, float* state, in
  *   value < 0 or == ent_pad becoming padding.
  * ktup_shard_pack_wire: out[w] = table_t[ids[w]] for the n_blocks * capsum rows of a wire buffer (t from w's place in its block;
  *   rows with ids[w] < 0 are left untouched).  tables / ld / cap: HOST arrays of n_tables device pointers / pitches / capacities.
- * ktup_shard_apply: global-norm clip (coef = min(1, max_norm / (sqrt(*sumsq) + 1e-6))) + row-sparse SGD / Adagrad
+ * ktup_shard_apply: global-norm clip (coef = min(1, max_norm / (sqrt(sum of sumsq[0 .. sumsq_slots)) + 1e-6))) + row-sparse SGD / Adagrad
  *   (ktup_shard_sparse_step's rule) for every wire row with ids[w] >= 0, and for `n_small` small replicated gradients of
  *   small_rows x d each: gradient k updates small_p0[k] (and small_p1[k] if not NULL -- the two summands of a mixed table share
  *   one gradient); with small_g64 the small gradients are read from that fp64 array (the all-reduced bucket) instead.  Consumed
  *   gradient rows are zero-filled.  If *skip_count != 0 or *skip_value != 0 (either may be NULL) nothing is updated, gradients are
  *   still cleared.
- * ktup_shard_bucket: mode 0: bucket = [small gradients as doubles | *sumsq_local | *overflow]; mode 1 (after the all-reduce):
+ * ktup_shard_bucket: mode 0: bucket = [small gradients as doubles | sum of sumsq_local[0 .. sumsq_slots) | *overflow]; mode 1 (after the all-reduce):
  *   *sumsq_total = bucket[n] + small_weight * sum of squares of bucket[0 .. n) (2 when every small gradient feeds two tables).
  * ktup_zero_async: zero-fill by a kernel (16-byte aligned, multiple of 16 bytes).                                          */
 #define KTUP_SHARD_MAX_TABLES 4
 #define KTUP_SHARD_MAX_SMALL 4
+#define KTUP_SHARD_SUMSQ_SLOTS 16
 size_t ktup_shard_route_workspace_bytes(int64_t n_entries);
 size_t ktup_shard_route_sort_bytes(int64_t n_entries, int64_t n_wire_rows);
 int ktup_shard_route(const int64_t* ids, int64_t n_entries, int64_t block, int n_tables, const int64_t* ent_off, int world,
@@ -402,11 +403,13 @@ int ktup_shard_route(const int64_t* ids, int64_t n_entries, int64_t block, int n
 /* ktup_shard_route for the KTUP rec step with the entry list built by its first launch: batch (*cursor mod n_batches) of the id
  * columns u / pos_items / neg_items (n_batches x B each; cursor NULL: batch 0) -> entries = [u ; u | pos ; neg | item2ent[pos ; neg]]
  * (6B int64, written; 4B / two tables when item2ent is NULL), tables 0 / 1 / 2 = users / items / entities, pair_map = item wire row
- * -> entity wire row.  *cursor (device) is incremented by the call: a replayed graph walks through the columns by itself.   */
+ * -> entity wire row.  *cursor (device) is incremented by the call: a replayed graph walks through the columns by itself.
+ * phase: 0 = the whole route; 1 = its first launch only (scratch init + the entry list); 2 = the remaining four launches -- a
+ * scorer that needs nothing but the entry list (global ids) can then run beside phase 2 on another stream.                    */
 int ktup_shard_route_ktup(const int64_t* u, const int64_t* pos_items, const int64_t* neg_items, int64_t B, int64_t n_batches,
                           int64_t* cursor, const int32_t* item2ent, int64_t ent_pad, int64_t* entries, int world,
                           const int64_t* cap, int64_t* inverse, int64_t* send_ids, int32_t* pair_map, int32_t* sort_ws,
-                          int32_t* counters, double* zero_doubles, int n_zero_doubles, void* ws, void* stream);
+                          int32_t* counters, double* zero_doubles, int n_zero_doubles, void* ws, int phase, void* stream);
 int ktup_shard_reduce_rows(const float* G, int64_t ldg, int d, int64_t n_src, int64_t src_off, const int32_t* sort_ws,
                            int64_t n_entries, int64_t n_wire_rows, float* gwire, int64_t ldw, void* stream);
 int ktup_shard_ktup_entries(const int64_t* u, const int64_t* pos_items, const int64_t* neg_items, int64_t B,
@@ -417,10 +420,32 @@ int ktup_shard_apply(int kind, int n_tables, float* const* tables, const int64_t
                      const int64_t* cap, int d, const int64_t* ids, int64_t n_blocks, float* grads, int64_t ldg, int n_small,
                      int small_rows, float* const* small_grads, float* const* small_p0, float* const* small_s0,
                      float* const* small_p1, float* const* small_s1, const double* small_g64, float lr, float eps,
-                     const double* sumsq, float max_norm, const int32_t* skip_count, const double* skip_value, void* stream);
+                     const double* sumsq, int sumsq_slots, float max_norm, const int32_t* skip_count, const double* skip_value,
+                     void* stream);
 int ktup_shard_bucket(int mode, int n_small, float* const* small_grads, int64_t small_elems, double* bucket,
-                      const double* sumsq_local, const int32_t* overflow, double* sumsq_total, double small_weight, void* stream);
+                      const double* sumsq_local, int sumsq_slots, const int32_t* overflow, double* sumsq_total, double small_weight,
+                      void* stream);
 int ktup_zero_async(void* ptr, int64_t nbytes, void* stream);
+/* reduce -> norm -> apply WITHOUT a W x d gradient buffer: the segment reduction of ktup_shard_reduce_rows run twice over G.
+ * ktup_shard_reduce_norm: the squared norm of every reduced row (and of the n_small small gradients, weighted by small_weight) is
+ *   ADDED to sumsq[0 .. n_slots) (n_slots = 1 or KTUP_SHARD_SUMSQ_SLOTS); nothing else is written, except that the few rows whose
+ *   entries straddle two workgroups are summed into gwire (all-zero before the call) and listed in xkeys
+ *   (ktup_shard_reduce_list_len(n_entries, d) int32).  Two launches.
+ * ktup_shard_reduce_apply: the same walk again; every reduced row goes straight from registers through the clipped row-sparse
+ *   SGD / Adagrad rule of ktup_shard_apply into table_t[ids[w]]; the listed rows are applied from gwire, which is left all-zero
+ *   again; small tables as in ktup_shard_apply.  Two launches.  Same arguments, same G, same sort_ws as the norm call.        */
+int64_t ktup_shard_reduce_list_len(int64_t n_entries, int d);
+int ktup_shard_reduce_norm(const float* G, int64_t ldg, int d, int64_t n_src, int64_t src_off, const int32_t* sort_ws,
+                           int64_t n_entries, int64_t n_wire_rows, float* gwire, int64_t ldw, int32_t* xkeys, int n_small,
+                           float* const* small_grads, int64_t small_elems, float small_weight, double* sumsq, int n_slots,
+                           void* stream);
+int ktup_shard_reduce_apply(int kind, int n_tables, float* const* tables, const int64_t* ld, float* const* states,
+                            const int64_t* lds, const int64_t* cap, const int64_t* ids, int64_t n_blocks, const float* G,
+                            int64_t ldg, int d, int64_t n_src, int64_t src_off, const int32_t* sort_ws, int64_t n_entries,
+                            float* gwire, int64_t ldw, const int32_t* xkeys, int n_small, int small_rows,
+                            float* const* small_grads, float* const* small_p0, float* const* small_s0, float* const* small_p1,
+                            float* const* small_s1, const double* small_g64, float lr, float eps, const double* sumsq,
+                            int sumsq_slots, float max_norm, const int32_t* skip_count, const double* skip_value, void* stream);
 
 /* ------------------------------------------- K19  negative sampling on the device  utils/data.py:12-85
  * rec: one uniform negative item per (u, positive): != positive, bit not set in the user's row of
@@ -476,8 +501,10 @@ int ktup_feed_kg(const int64_t* col_h, const int64_t* col_t, const int64_t* col_
 #define KTUP_OPT_ADAM 2
 #define KTUP_OPT_RMSPROP 3
 int ktup_optim_gradnorm(int n_tensors, float* const* grads, const int64_t* sizes, double* sumsq, void* stream);
-/* the same sum ADDED to *sumsq (no clearing memset inside: for HIP-graph callers that keep their accumulator clean themselves) */
-int ktup_optim_gradnorm_acc(int n_tensors, float* const* grads, const int64_t* sizes, double* sumsq, void* stream);
+/* the same sum ADDED to sumsq[0 .. n_slots) -- workgroup b adds to slot b mod n_slots, the result is the sum of the slots (one double
+ * atomic per workgroup costs ~20 ns on ONE address) -- with no clearing memset inside: for HIP-graph callers that keep their
+ * accumulators clean themselves */
+int ktup_optim_gradnorm_acc(int n_tensors, float* const* grads, const int64_t* sizes, double* sumsq, int n_slots, void* stream);
 int ktup_optim_step(int kind, int n_tensors, float* const* params, float* const* grads, float* const* state1,
                     float* const* state2, const int64_t* sizes, const int64_t* steps, const int64_t* steps_dev,
                     const int32_t* first, float lr, float weight_decay, float momentum, float beta1, float beta2, float eps, float alpha,

@@ -42,7 +42,7 @@ KTUP_DEV int find_tensor(const OptTensors& T, int64_t chunk) {
   return k;
 }
 
-__global__ __launch_bounds__(256) void gradnorm_kernel(OptTensors T, double* __restrict__ sumsq) {
+__global__ __launch_bounds__(256) void gradnorm_kernel(OptTensors T, double* __restrict__ sumsq, int slots) {
   // work unit = a quarter chunk (256 float4): four loads in flight per thread
   const int64_t nunits = T.chunk0[T.count] * 4;
   float acc = 0.f;
@@ -74,7 +74,8 @@ __global__ __launch_bounds__(256) void gradnorm_kernel(OptTensors T, double* __r
   __shared__ float red[4];
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(sumsq, ((double)red[0] + (double)red[1]) + ((double)red[2] + (double)red[3]));
+  // one double atomic per workgroup; callers with many workgroups spread them over `slots` words (~20 ns each on ONE address)
+  if (threadIdx.x == 0) atomicAdd(sumsq + (slots > 1 ? blockIdx.x % slots : 0), ((double)red[0] + (double)red[1]) + ((double)red[2] + (double)red[3]));
 }
 
 struct Hyper {
@@ -410,18 +411,19 @@ extern "C" int ktup_optim_gradnorm(int n_tensors, float* const* grads, const int
   if (hipMemsetAsync(sumsq, 0, sizeof(double), st) != hipSuccess) return check_launch("ktup_optim_gradnorm");
   const int64_t nchunks = T.chunk0[T.count];
   if (nchunks == 0) return KTUP_OK;
-  hipLaunchKernelGGL(gradnorm_kernel, dim3(grid_for((nchunks * 4 + 3) / 4, 256)), dim3(256), 0, st, T, sumsq);
+  hipLaunchKernelGGL(gradnorm_kernel, dim3(grid_for((nchunks * 4 + 3) / 4, 256)), dim3(256), 0, st, T, sumsq, 1);
   return check_launch("ktup_optim_gradnorm");
 }
 
-// The same sum ADDED to *sumsq (no clearing memset: for callers inside a HIP graph that keep their accumulators clean themselves)
-extern "C" int ktup_optim_gradnorm_acc(int n_tensors, float* const* grads, const int64_t* sizes, double* sumsq, void* stream) {
+// The same sum ADDED to sumsq[0 .. n_slots) (workgroup b adds to slot b mod n_slots; the sum of the slots is the result).  No
+// clearing memset: for callers inside a HIP graph that keep their accumulators clean themselves.
+extern "C" int ktup_optim_gradnorm_acc(int n_tensors, float* const* grads, const int64_t* sizes, double* sumsq, int n_slots, void* stream) {
   OptTensors T{};
-  KTUP_REQUIRE(grads && sizes && sumsq, "ktup_optim_gradnorm_acc: null pointer argument");
+  KTUP_REQUIRE(grads && sizes && sumsq && n_slots >= 1, "ktup_optim_gradnorm_acc: null pointer argument or no slot");
   if (int e = fill("ktup_optim_gradnorm_acc", T, n_tensors, nullptr, grads, nullptr, nullptr, sizes)) return e;
   const int64_t nchunks = T.chunk0[T.count];
   if (nchunks == 0) return KTUP_OK;
-  hipLaunchKernelGGL(gradnorm_kernel, dim3(grid_for((nchunks * 4 + 3) / 4, 1024)), dim3(256), 0, (hipStream_t)stream, T, sumsq);
+  hipLaunchKernelGGL(gradnorm_kernel, dim3(grid_for((nchunks * 4 + 3) / 4, 1024)), dim3(256), 0, (hipStream_t)stream, T, sumsq, n_slots);
   return check_launch("ktup_optim_gradnorm_acc");
 }
 

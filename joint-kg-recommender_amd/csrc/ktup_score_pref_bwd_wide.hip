@@ -76,6 +76,7 @@ struct WArgs {
   float* loss;                   // loss[0] += mean_k -logsigmoid(target (pos_k - neg_k)); loss[1] += orthogonalLoss(pref, pnorm)
   float *gP, *gPn, *gR, *gRn;    // gradients of the raw tables, pitch D
   int orth;
+  int noflush;                   // measurement knob (option dbg_noflush)
   int gumbel;
   const float* uniform;
   uint64_t seed, offset;
@@ -537,6 +538,7 @@ __global__ __launch_bounds__(256) void pref_bwd_wide_kernel(WArgs a) {
     __syncthreads();     // the next tile rewrites `red` and the wave tiles
   }
   // ---- flush the table gradients of this wave's coordinates
+  if (!a.noflush)
 #pragma unroll
   for (int pt = 0; pt < PT; ++pt)
 #pragma unroll
@@ -658,6 +660,7 @@ int pref_step_mc(const float* U, int64_t ldu, const float* I, int64_t ldi, const
   a.gumbel = gumbel_mode; a.uniform = uniform; a.seed = seed; a.offset = offset;
   a.pref = pref; a.pnorm = pnorm; a.rel = rel; a.norm = norm; a.ldp = ldp; a.B = B;
   a.target = target; a.gscale = gscale; a.loss = loss; a.gP = gP; a.gPn = gPn; a.gR = gR; a.gRn = gRn; a.orth = orth;
+  a.noflush = opt_dbg_noflush();
   a.GU = GU; a.GV = GV;          // both set: the row gradients of pair k leave as rows k of GU / GV (plain stores) instead of atomics
   return launch_d(a, d, (n_pref + 3) / 4, st, name);
 }

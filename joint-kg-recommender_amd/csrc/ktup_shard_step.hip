@@ -44,7 +44,7 @@ struct RouteArgs {
 };
 
 constexpr int TILE = 1024;                             // histogram counters per scan tile (256 threads x 4)
-constexpr int MAX_TILES = 4096;
+constexpr int MAX_TILES = 1024;                        // 4 KB of LDS in the scatter launch: it still fits on a CU beside the step kernel's 152 KB
 
 KTUP_DEV uint64_t mix64(uint64_t x) {
   x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ull;
@@ -293,6 +293,22 @@ KTUP_DEV void vfrom(float& o, const double* p) { o = (float)p[0]; }
 KTUP_DEV void vfrom(float4& o, const double* p) { o = make_float4((float)p[0], (float)p[1], (float)p[2], (float)p[3]); }
 
 constexpr int MAXS = KTUP_SHARD_MAX_SMALL;
+constexpr int NSLOT = KTUP_SHARD_SUMSQ_SLOTS;
+
+// min(1, max_norm / (||g|| + 1e-6)) with ||g||^2 spread over 1 or NSLOT accumulator words (independent loads, one latency)
+KTUP_DEV float clip_coef(float max_norm, const double* __restrict__ sumsq, int slots) {
+  if (!(max_norm > 0.f)) return 1.f;
+  double tot = sumsq[0];
+  if (slots == NSLOT) {
+    double v[NSLOT];
+#pragma unroll
+    for (int k = 1; k < NSLOT; ++k) v[k] = sumsq[k];
+#pragma unroll
+    for (int k = 1; k < NSLOT; ++k) tot += v[k];
+  }
+  const float c = max_norm / ((float)sqrt(tot) + 1e-6f);
+  return c < 1.f ? c : 1.f;
+}
 
 // Same rule as ktup_shard.hip SparseRowStep (utils/trainer.py:63-77 with l2_lambda = 0 restricted to the touched rows), for
 // every wire row of every table + the rows of the small replicated tables; the gradient rows are zero-filled once consumed.
@@ -301,7 +317,8 @@ struct ApplyRows {
   int n_small, small_rows; float* sg[MAXS]; float* sp0[MAXS]; float* ss0[MAXS]; float* sp1[MAXS]; float* ss1[MAXS];
   const double* small_g64;     // non-null: the all-reduced small gradients (fp64 bucket, entries in sg order) replace sg's values
   int d;
-  float lr, eps, max_norm; const double* sumsq; const int32_t* skip_i; const double* skip_d; bool adagrad;
+  float lr, eps, max_norm; const double* sumsq; int sumsq_slots; const int32_t* skip_i; const double* skip_d; bool adagrad;
+  const int32_t* xkeys;        // non-null: rows [0, W) are LIST entries -- the wire row is xkeys[row], taken at its first occurrence only
 
   template <typename V, int G, int CPL>
   KTUP_DEV void one(const RowCtx<V, G, CPL>& cx, float* prow, float* srow, const V (&gr)[CPL], float coef) const {
@@ -324,15 +341,16 @@ struct ApplyRows {
   template <typename V, int G, int CPL>
   KTUP_DEV void run(const RowCtx<V, G, CPL>& cx, int64_t row) const {
     const bool skip = (skip_i && *skip_i != 0) || (skip_d && *skip_d != 0.0);
-    float coef = 1.f;
-    if (max_norm > 0.f) {
-      const float c = max_norm / ((float)sqrt(*sumsq) + 1e-6f);
-      coef = c < 1.f ? c : 1.f;
-    }
+    const float coef = clip_coef(max_norm, sumsq, sumsq_slots);
     V gr[CPL], zero[CPL];
 #pragma unroll
     for (int j = 0; j < CPL; ++j) vzero(zero[j]);
     if (row < W) {
+      if (xkeys) {
+        const int32_t key = xkeys[row];
+        if (key < 0 || (row > 0 && xkeys[row - 1] == key)) return;
+        row = key;
+      }
       const int64_t id = ids[row];
       if (id < 0) return;
       float* grow = g + row * ldg;
@@ -376,9 +394,251 @@ struct ApplyRows {
   }
 };
 
+
+// ---- reduction by sorted segments WITHOUT a gradient buffer (one rank's reduce -> norm -> apply, and the owner side of several):
+// the same chunk walk as ktup_segreduce.hip's seg_reduce_kernel over the route's sorted order, run twice.  A row whose entries
+// all lie inside one workgroup ("interior": all but ~2 rows per workgroup) is finished in registers:
+//   MODE 0 (norm)   its squared norm joins the step's sum of squares; nothing is written
+//   MODE 1 (apply)  the clipped row-sparse SGD / Adagrad update is applied to its table row straight from the registers
+// Rows that continue into a neighbouring workgroup ("boundary") are summed by float atomics into gw (zero before, zero after) by
+// MODE 0, which also lists their keys (xkeys[2 wg], [2 wg + 1] = the head / tail boundary row of workgroup wg or -1; equal keys
+// are adjacent); two small launches (xnorm_kernel, ApplyRows with xkeys) then treat each listed row once.  Against reduce + norm
+// + apply through a W x d gradient buffer this moves 2 x |G| + (p, state) instead of |G| + 5 W d + (p, state) bytes.
+struct FusedArgs {
+  const float4* G; int64_t ldg4; int nch; int64_t n_src, src_off;
+  const int32_t *perm, *skey; const int32_t* m_dev; int chunk;
+  float* gw; int64_t ldw; int32_t* xkeys;
+  double* sumsq; int slots;                         // MODE 0: accumulated; MODE 1: read
+  WireTables w; const int64_t* ids; float lr, eps, max_norm; bool adagrad; const int32_t* skip_i; const double* skip_d;
+};
+
+template <int GL, int CPL, int MODE>
+__global__ __launch_bounds__(256) void seg_fused_kernel(FusedArgs a) {
+  const int lane = threadIdx.x % GL, grp = threadIdx.x / GL;
+  constexpr int GPB = 256 / GL;
+  constexpr int ROW4 = GL * CPL;
+  __shared__ float4 edge[2 * GPB * ROW4];
+  __shared__ int32_t ekey[2 * GPB];
+  const int64_t m = *a.m_dev;
+  const int64_t nchunks = (m + a.chunk - 1) / a.chunk;
+  const int64_t c0 = (int64_t)blockIdx.x * GPB;
+  if (MODE == 0 && threadIdx.x < 2) a.xkeys[2 * (int64_t)blockIdx.x + threadIdx.x] = -1;
+  float ss = 0.f;
+  float coef = 1.f;
+  bool skip = false;
+  if (MODE == 1) {
+    coef = clip_coef(a.max_norm, a.sumsq, a.slots);
+    skip = (a.skip_i && *a.skip_i != 0) || (a.skip_d && *a.skip_d != 0.0);
+  }
+  if (c0 >= nchunks) return;
+  auto interior = [&](int32_t key, const float4* acc) {
+    if (MODE == 0) {
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) ss += dot4(acc[j], acc[j]);            // chunks past the row hold zeros
+      return;
+    }
+    if (skip) return;
+    const int64_t id = a.ids[key];
+    if (id < 0) return;
+    const int t = wire_table(a.w, key);
+    float4* prow = reinterpret_cast<float4*>(a.w.tab[t] + id * a.w.ldt[t]);
+    float4* srow = a.adagrad ? reinterpret_cast<float4*>(a.w.st[t] + id * a.w.lds[t]) : nullptr;
+    float4 p[CPL], st[CPL];
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+      const int ch = lane + j * GL;
+      if (ch < a.nch) { p[j] = prow[ch]; if (a.adagrad) st[j] = srow[ch]; }
+    }
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+      const int ch = lane + j * GL;
+      if (ch < a.nch) {
+        upv(p[j], st[j], coef * acc[j], a.lr, a.eps, a.adagrad);
+        prow[ch] = p[j];
+        if (a.adagrad) srow[ch] = st[j];
+      }
+    }
+  };
+  auto boundary = [&](int32_t key, const float4* acc, bool head, bool tail) {
+    if (MODE != 0) return;                                               // MODE 0 put it into gw; the list launch applies it
+    float* row = a.gw + (int64_t)key * a.ldw;
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+      const int ch = lane + j * GL;
+      if (ch < a.nch) atomic_add4(row + 4 * ch, acc[j]);
+    }
+    // a workgroup that lies wholly inside one hot row lists it on BOTH sides: equal keys must stay adjacent in the list
+    if (lane == 0 && head) a.xkeys[2 * (int64_t)blockIdx.x] = key;
+    if (lane == 0 && tail) a.xkeys[2 * (int64_t)blockIdx.x + 1] = key;
+  };
+  {
+    const int64_t c = c0 + grp;
+    const bool active = c < nchunks;
+    if (lane == 0) { ekey[2 * grp] = -1; ekey[2 * grp + 1] = -1; }
+    if (active) {
+      const int64_t k0 = c * a.chunk, k1 = min(m, k0 + a.chunk);
+      float4 acc[CPL];
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) acc[j] = f4zero();
+      int32_t cur = a.skey[k0];
+      const int32_t before = k0 > 0 ? a.skey[k0 - 1] : -1, after = k1 < m ? a.skey[k1] : -1;
+      bool head_open = true;
+      auto flush = [&](int32_t key, bool last) {
+        const bool is_head = head_open && key == before, is_tail = last && key == after;
+        if (is_head || is_tail) {
+          const int slot = is_head ? 2 * grp : 2 * grp + 1;
+          if (lane == 0) ekey[slot] = key;
+#pragma unroll
+          for (int j = 0; j < CPL; ++j) edge[slot * ROW4 + lane + j * GL] = acc[j];
+        } else {
+          interior(key, acc);
+        }
+        head_open = false;
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) acc[j] = f4zero();
+      };
+      constexpr int UNR = CPL == 1 ? 8 : 4;
+      for (int64_t k = k0; k < k1; k += UNR) {
+        int32_t key[UNR], e[UNR];
+        float4 v[UNR][CPL];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+          const bool on = k + u < k1;
+          key[u] = on ? a.skey[k + u] : -1;
+          e[u] = on ? a.perm[k + u] : 0;
+          const int64_t src = e[u] >= a.n_src ? e[u] - a.src_off : e[u];
+          const float4* row = a.G + src * a.ldg4;
+#pragma unroll
+          for (int j = 0; j < CPL; ++j) {
+            const int ch = lane + j * GL;
+            v[u][j] = (on && ch < a.nch) ? row[ch] : f4zero();
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+          if (key[u] < 0) break;
+          if (key[u] != cur) { flush(cur, false); cur = key[u]; }
+#pragma unroll
+          for (int j = 0; j < CPL; ++j) acc[j] = acc[j] + v[u][j];
+        }
+      }
+      flush(cur, true);
+    }
+    __syncthreads();
+    if (grp == 0) {                                               // join the edge partials of this workgroup's consecutive chunks
+      const int64_t w0 = c0 * a.chunk, w1 = min(m, (c0 + GPB) * a.chunk);
+      const int32_t wbefore = w0 > 0 ? a.skey[w0 - 1] : -1, wafter = w1 < m ? a.skey[w1] : -1;
+      float4 acc[CPL];
+      int32_t cur = -1;
+      auto done = [&](int32_t key) {
+        if (key == wbefore || key == wafter) boundary(key, acc, key == wbefore, key == wafter);
+        else interior(key, acc);
+      };
+      for (int sl = 0; sl < 2 * GPB; ++sl) {
+        const int32_t key = ekey[sl];
+        if (key < 0) continue;
+        if (key != cur) {
+          if (cur >= 0) done(cur);
+          cur = key;
+#pragma unroll
+          for (int j = 0; j < CPL; ++j) acc[j] = f4zero();
+        }
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) acc[j] = acc[j] + edge[sl * ROW4 + lane + j * GL];
+      }
+      if (cur >= 0) done(cur);
+    }
+  }
+  if (MODE == 0) {
+    __shared__ float red[4];
+    ss = group_sum<64>(ss);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const double t = ((double)red[0] + (double)red[1]) + ((double)red[2] + (double)red[3]);
+      if (t != 0.0) atomicAdd(a.sumsq + (a.slots > 1 ? blockIdx.x % a.slots : 0), t);
+    }
+  }
+}
+
+// the listed boundary rows (each at its first occurrence) and the small replicated gradients join the sum of squares
+struct XNormArgs {
+  const int32_t* xkeys; int64_t nx; const float* gw; int64_t ldw; int d;
+  int n_small; const float* sg[MAXS]; int64_t small_elems; float small_weight;
+  double* sumsq; int slots;
+};
+
+__global__ __launch_bounds__(256) void xnorm_kernel(XNormArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * 256) >> 6;
+  float ss = 0.f;
+  for (int64_t i = wave; i < a.nx; i += nwaves) {
+    const int32_t key = a.xkeys[i];
+    if (key < 0 || (i > 0 && a.xkeys[i - 1] == key)) continue;
+    const float* row = a.gw + (int64_t)key * a.ldw;
+    for (int c = lane; c < a.d; c += 64) ss = fmaf(row[c], row[c], ss);
+  }
+  const int64_t N = (int64_t)a.n_small * a.small_elems;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < N; i += (int64_t)gridDim.x * 256) {
+    const float v = a.sg[i / a.small_elems][i % a.small_elems];
+    ss = fmaf(a.small_weight * v, v, ss);
+  }
+  __shared__ float red[4];
+  ss = group_sum<64>(ss);
+  if (lane == 0) red[threadIdx.x >> 6] = ss;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double t = ((double)red[0] + (double)red[1]) + ((double)red[2] + (double)red[3]);
+    if (t != 0.0) atomicAdd(a.sumsq + (a.slots > 1 ? blockIdx.x % a.slots : 0), t);
+  }
+}
+
+int fused_chunk(int64_t m_max) {
+  int64_t ch = m_max / 8192;
+  int c = (int)(ch < 8 ? 8 : ch > 64 ? 64 : ch);
+  return (c + 3) & ~3;
+}
+int fused_gl(int d) { const int nch = d / 4; return nch <= 16 ? 16 : nch <= 32 ? 32 : 64; }
+int64_t fused_grid(int64_t m_max, int d) {
+  const int chunk = fused_chunk(m_max);
+  const int64_t nchunks = (m_max + chunk - 1) / chunk;
+  const int gpb = 256 / fused_gl(d);
+  return (nchunks + gpb - 1) / gpb;
+}
+
+template <int MODE>
+int launch_fused(const FusedArgs& a, int64_t grid, hipStream_t st, const char* name) {
+#define KTUP_F(GL, CPL)                                                                                  \
+  {                                                                                                      \
+    hipLaunchKernelGGL((seg_fused_kernel<GL, CPL, MODE>), dim3((unsigned)grid), dim3(256), 0, st, a);    \
+    return check_launch(name);                                                                           \
+  }
+  if (a.nch <= 16) KTUP_F(16, 1)
+  if (a.nch <= 32) KTUP_F(32, 1)
+  if (a.nch <= 64) KTUP_F(64, 1)
+  if (a.nch <= 128) KTUP_F(64, 2)
+  KTUP_F(64, 4)
+#undef KTUP_F
+}
+
+int fill_fused(const char* name, FusedArgs& a, const float* G, int64_t ldg, int d, int64_t n_src, int64_t src_off, const int32_t* sort_ws,
+               int64_t n_entries, int64_t n_wire_rows, float* gwire, int64_t ldw, int32_t* xkeys) {
+  KTUP_REQUIRE(G && sort_ws && gwire && xkeys && n_entries > 0 && n_wire_rows > 0 && d > 0, "%s: null pointer argument or bad sizes", name);
+  KTUP_REQUIRE(n_src > 0 && n_src <= n_entries && src_off >= 0 && src_off <= n_src, "%s: bad source layout", name);
+  if (d % 4 || d > 1024 || ldg % 4 || ldw % 4 || !aligned16(G) || !aligned16(gwire) || n_entries >= (1ll << 31))
+    return set_error(KTUP_ERR_UNSUPPORTED, "%s: needs d %% 4 == 0 (<= 1024) and 16-byte aligned rows", name);
+  a.G = reinterpret_cast<const float4*>(G); a.ldg4 = ldg / 4; a.nch = d / 4; a.n_src = n_src; a.src_off = src_off;
+  a.perm = sort_ws + ((n_wire_rows + 2) & ~(int64_t)1) + n_entries;
+  a.skey = a.perm + n_entries;
+  a.m_dev = sort_ws + n_wire_rows;
+  a.chunk = fused_chunk(n_entries);
+  a.gw = gwire; a.ldw = ldw; a.xkeys = xkeys;
+  return KTUP_OK;
+}
+
 struct BucketArgs {
   int n_small; const float* sg[MAXS]; int64_t small_elems;     // elements per small gradient (rows x d, contiguous)
-  double* bucket; const double* sumsq_in; const int32_t* overflow; double* sumsq_out; double small_weight;
+  double* bucket; const double* sumsq_in; int sumsq_slots; const int32_t* overflow; double* sumsq_out; double small_weight;
 };
 
 // mode 0: bucket = [small gradients as doubles | local sum of squares | overflow count]  (what ONE all-reduce carries)
@@ -390,7 +650,7 @@ __global__ __launch_bounds__(1024) void bucket_kernel(BucketArgs a) {
     for (int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x; i < N + 2; i += (int64_t)gridDim.x * 1024) {
       double v;
       if (i < N) v = (double)a.sg[i / a.small_elems][i % a.small_elems];
-      else if (i == N) v = *a.sumsq_in;
+      else if (i == N) { v = 0.0; for (int k = 0; k < a.sumsq_slots; ++k) v += a.sumsq_in[k]; }
       else v = (double)*a.overflow;
       a.bucket[i] = v;
     }
@@ -464,8 +724,11 @@ extern "C" size_t ktup_shard_route_sort_bytes(int64_t n_entries, int64_t n_wire_
 
 namespace {
 
+// phase 0: all five launches; 1: the first (scratch init + the KTUP entry list) only; 2: the other four -- so that a caller whose
+// scorer needs nothing but the entry list can run the rest of the route on a second stream beside it
 int route_impl(const char* name, RouteArgs& a, int pair_a, int pair_b, int64_t* inverse, int64_t* send_ids, int32_t* pair_map,
-               int32_t* sort_ws, int32_t* counters, double* zero_doubles, int n_zero_doubles, void* ws, hipStream_t st) {
+               int32_t* sort_ws, int32_t* counters, double* zero_doubles, int n_zero_doubles, void* ws, hipStream_t st, int phase = 0) {
+  KTUP_REQUIRE(phase >= 0 && phase <= 2, "%s: phase must be 0 (all), 1 (first launch) or 2 (the rest)", name);
   KTUP_REQUIRE(inverse && send_ids && sort_ws && counters && ws, "%s: null pointer argument", name);
   KTUP_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 7u) == 0 && (reinterpret_cast<uintptr_t>(sort_ws) & 15u) == 0,
                "%s: workspace must be 8-byte, sort_ws 16-byte aligned", name);
@@ -487,7 +750,8 @@ int route_impl(const char* name, RouteArgs& a, int pair_a, int pair_b, int64_t* 
   a.n_tiles = n_tiles <= MAX_TILES ? (int)n_tiles : 0;
   a.counters = counters; a.zero_d = zero_doubles; a.n_zero_d = n_zero_doubles;
   const int64_t init_items = (int64_t)a.slots > a.W + 1 ? (int64_t)a.slots : a.W + 1;
-  hipLaunchKernelGGL(route_init_kernel, dim3(grid_for((init_items + 255) / 256, 1024)), dim3(256), 0, st, a);
+  if (phase != 2) hipLaunchKernelGGL(route_init_kernel, dim3(grid_for((init_items + 255) / 256, 1024)), dim3(256), 0, st, a);
+  if (phase == 1) return check_launch(name);
   const int grid = grid_for((a.n + 255) / 256, 1024);
   hipLaunchKernelGGL(route_insert_kernel, dim3(grid), dim3(256), 0, st, a);
   hipLaunchKernelGGL(route_finish_kernel, dim3(grid), dim3(256), 0, st, a);
@@ -519,7 +783,7 @@ extern "C" int ktup_shard_route(const int64_t* ids, int64_t n_entries, int64_t b
 extern "C" int ktup_shard_route_ktup(const int64_t* u, const int64_t* pos_items, const int64_t* neg_items, int64_t B, int64_t n_batches,
                                      int64_t* cursor, const int32_t* item2ent, int64_t ent_pad, int64_t* entries, int world,
                                      const int64_t* cap, int64_t* inverse, int64_t* send_ids, int32_t* pair_map, int32_t* sort_ws,
-                                     int32_t* counters, double* zero_doubles, int n_zero_doubles, void* ws, void* stream) {
+                                     int32_t* counters, double* zero_doubles, int n_zero_doubles, void* ws, int phase, void* stream) {
   const char* name = "ktup_shard_route_ktup";
   KTUP_REQUIRE(B > 0 && n_batches > 0 && u && pos_items && neg_items && entries, "%s: null pointer argument or empty batch", name);
   const int T = item2ent ? 3 : 2;
@@ -529,7 +793,7 @@ extern "C" int ktup_shard_route_ktup(const int64_t* u, const int64_t* pos_items,
   a.src_u = u; a.src_pos = pos_items; a.src_neg = neg_items; a.B = B; a.n_batches = n_batches; a.cursor = cursor;
   a.item2ent = item2ent; a.ent_pad = ent_pad; a.ids_out = entries;
   return route_impl(name, a, 1, 2, inverse, send_ids, item2ent ? pair_map : nullptr, sort_ws, counters, zero_doubles, n_zero_doubles, ws,
-                    (hipStream_t)stream);
+                    (hipStream_t)stream, phase);
 }
 
 extern "C" int ktup_shard_reduce_rows(const float* G, int64_t ldg, int d, int64_t n_src, int64_t src_off, const int32_t* sort_ws,
@@ -570,14 +834,14 @@ extern "C" int ktup_shard_apply(int kind, int n_tables, float* const* tables, co
                                 const int64_t* cap, int d, const int64_t* ids, int64_t n_blocks, float* grads, int64_t ldg, int n_small,
                                 int small_rows, float* const* small_grads, float* const* small_p0, float* const* small_s0,
                                 float* const* small_p1, float* const* small_s1, const double* small_g64, float lr, float eps,
-                                const double* sumsq, float max_norm, const int32_t* skip_count, const double* skip_value, void* stream) {
+                                const double* sumsq, int sumsq_slots, float max_norm, const int32_t* skip_count, const double* skip_value, void* stream) {
   const char* name = "ktup_shard_apply";
   KTUP_REQUIRE(kind == KTUP_OPT_SGD || kind == KTUP_OPT_ADAGRAD, "%s: only plain SGD and Adagrad have an exact row-sparse form", name);
   ApplyRows op{};
   if (int e = fill_wire(name, op.w, n_tables, tables, ld, states, lds, cap, d)) return e;
   KTUP_REQUIRE(ids && grads && n_blocks > 0 && ldg >= d && d > 0, "%s: null pointer argument or bad sizes", name);
   KTUP_REQUIRE(n_small >= 0 && n_small <= MAXS && (n_small == 0 || (small_rows > 0 && small_grads && small_p0)), "%s: bad small-table list", name);
-  KTUP_REQUIRE(max_norm <= 0.f || sumsq, "%s: clipping needs the sum of squared gradients", name);
+  KTUP_REQUIRE(max_norm <= 0.f || (sumsq && (sumsq_slots == 1 || sumsq_slots == NSLOT)), "%s: clipping needs the sum of squared gradients (1 or %d words)", name, NSLOT);
   const bool adagrad = kind == KTUP_OPT_ADAGRAD;
   bool v4 = d % 4 == 0 && aligned16(grads) && ldg % 4 == 0;
   for (int t = 0; t < n_tables; ++t) {
@@ -593,12 +857,88 @@ extern "C" int ktup_shard_apply(int kind, int n_tables, float* const* tables, co
   }
   op.ids = ids; op.W = n_blocks * op.w.capsum; op.g = grads; op.ldg = ldg;
   op.n_small = n_small; op.small_rows = small_rows > 0 ? small_rows : 1; op.small_g64 = small_g64; op.d = d;
-  op.lr = lr; op.eps = eps; op.max_norm = max_norm; op.sumsq = sumsq; op.skip_i = skip_count; op.skip_d = skip_value; op.adagrad = adagrad;
+  op.lr = lr; op.eps = eps; op.max_norm = max_norm; op.sumsq = sumsq; op.sumsq_slots = sumsq_slots; op.skip_i = skip_count; op.skip_d = skip_value; op.adagrad = adagrad;
   return launch_rows(op, d, v4, op.W + (int64_t)n_small * op.small_rows, (hipStream_t)stream, name);
 }
 
+
+extern "C" int64_t ktup_shard_reduce_list_len(int64_t n_entries, int d) {
+  if (n_entries <= 0 || d <= 0 || d % 4) return 0;
+  return 2 * fused_grid(n_entries, d);
+}
+
+extern "C" int ktup_shard_reduce_norm(const float* G, int64_t ldg, int d, int64_t n_src, int64_t src_off, const int32_t* sort_ws,
+                                      int64_t n_entries, int64_t n_wire_rows, float* gwire, int64_t ldw, int32_t* xkeys, int n_small,
+                                      float* const* small_grads, int64_t small_elems, float small_weight, double* sumsq, int n_slots,
+                                      void* stream) {
+  const char* name = "ktup_shard_reduce_norm";
+  FusedArgs a{};
+  if (int e = fill_fused(name, a, G, ldg, d, n_src, src_off, sort_ws, n_entries, n_wire_rows, gwire, ldw, xkeys)) return e;
+  KTUP_REQUIRE(sumsq && (n_slots == 1 || n_slots == NSLOT), "%s: the sum of squares lives in 1 or %d words", name, NSLOT);
+  KTUP_REQUIRE(n_small >= 0 && n_small <= MAXS && (n_small == 0 || (small_grads && small_elems > 0)), "%s: bad small-gradient list", name);
+  a.sumsq = sumsq; a.slots = n_slots;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t grid = fused_grid(n_entries, d);
+  if (int e = launch_fused<0>(a, grid, st, name)) return e;
+  XNormArgs x{};
+  x.xkeys = xkeys; x.nx = 2 * grid; x.gw = gwire; x.ldw = ldw; x.d = d;
+  x.n_small = n_small; x.small_elems = small_elems > 0 ? small_elems : 1; x.small_weight = small_weight;
+  for (int k = 0; k < n_small; ++k) {
+    KTUP_REQUIRE(small_grads[k], "%s: small gradient %d is null", name, k);
+    x.sg[k] = small_grads[k];
+  }
+  x.sumsq = sumsq; x.slots = n_slots;
+  const int64_t work = (2 * grid + 3) / 4 + ((int64_t)n_small * x.small_elems + 255) / 256;
+  hipLaunchKernelGGL(xnorm_kernel, dim3(grid_for(work, 256)), dim3(256), 0, st, x);
+  return check_launch(name);
+}
+
+extern "C" int ktup_shard_reduce_apply(int kind, int n_tables, float* const* tables, const int64_t* ld, float* const* states,
+                                       const int64_t* lds, const int64_t* cap, const int64_t* ids, int64_t n_blocks, const float* G,
+                                       int64_t ldg, int d, int64_t n_src, int64_t src_off, const int32_t* sort_ws, int64_t n_entries,
+                                       float* gwire, int64_t ldw, const int32_t* xkeys, int n_small, int small_rows,
+                                       float* const* small_grads, float* const* small_p0, float* const* small_s0, float* const* small_p1,
+                                       float* const* small_s1, const double* small_g64, float lr, float eps, const double* sumsq,
+                                       int sumsq_slots, float max_norm, const int32_t* skip_count, const double* skip_value, void* stream) {
+  const char* name = "ktup_shard_reduce_apply";
+  KTUP_REQUIRE(kind == KTUP_OPT_SGD || kind == KTUP_OPT_ADAGRAD, "%s: only plain SGD and Adagrad have an exact row-sparse form", name);
+  ApplyRows op{};
+  if (int e = fill_wire(name, op.w, n_tables, tables, ld, states, lds, cap, d)) return e;
+  KTUP_REQUIRE(ids && n_blocks > 0, "%s: null pointer argument or bad sizes", name);
+  const int64_t W = n_blocks * op.w.capsum;
+  FusedArgs a{};
+  if (int e = fill_fused(name, a, G, ldg, d, n_src, src_off, sort_ws, n_entries, W, gwire, ldw, const_cast<int32_t*>(xkeys))) return e;
+  KTUP_REQUIRE(n_small >= 0 && n_small <= MAXS && (n_small == 0 || (small_rows > 0 && small_grads && small_p0)), "%s: bad small-table list", name);
+  KTUP_REQUIRE(max_norm <= 0.f || (sumsq && (sumsq_slots == 1 || sumsq_slots == NSLOT)), "%s: clipping needs the sum of squared gradients (1 or %d words)", name, NSLOT);
+  const bool adagrad = kind == KTUP_OPT_ADAGRAD;
+  bool v4 = true;
+  for (int t = 0; t < n_tables; ++t) {
+    KTUP_REQUIRE(!adagrad || (states && states[t]), "%s: table %d: Adagrad state missing", name, t);
+    v4 = v4 && aligned16(tables[t]) && ld[t] % 4 == 0 && (!adagrad || (aligned16(states[t]) && op.w.lds[t] % 4 == 0));
+  }
+  for (int k = 0; k < n_small; ++k) {
+    KTUP_REQUIRE(small_grads[k] && small_p0[k] && (!adagrad || (small_s0 && small_s0[k])), "%s: small table %d: null pointer", name, k);
+    op.sg[k] = small_grads[k]; op.sp0[k] = small_p0[k]; op.ss0[k] = small_s0 ? small_s0[k] : nullptr;
+    op.sp1[k] = small_p1 ? small_p1[k] : nullptr; op.ss1[k] = small_s1 ? small_s1[k] : nullptr;
+    KTUP_REQUIRE(!op.sp1[k] || !adagrad || op.ss1[k], "%s: small table %d: second table's Adagrad state missing", name, k);
+    v4 = v4 && aligned16(op.sg[k]) && aligned16(op.sp0[k]) && aligned16(op.ss0[k]) && aligned16(op.sp1[k]) && aligned16(op.ss1[k]);
+  }
+  if (!v4) return set_error(KTUP_ERR_UNSUPPORTED, "%s: tables, states and gradients must be 16-byte aligned with pitches %% 4 == 0", name);
+  a.sumsq = const_cast<double*>(sumsq); a.slots = sumsq_slots; a.w = op.w; a.ids = ids; a.lr = lr; a.eps = eps; a.max_norm = max_norm;
+  a.adagrad = adagrad; a.skip_i = skip_count; a.skip_d = skip_value;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t grid = fused_grid(n_entries, d);
+  if (int e = launch_fused<1>(a, grid, st, name)) return e;
+  // the listed boundary rows from gw (then zero-filled) and the small tables
+  op.ids = ids; op.W = 2 * grid; op.g = gwire; op.ldg = ldw; op.xkeys = xkeys;
+  op.n_small = n_small; op.small_rows = small_rows > 0 ? small_rows : 1; op.small_g64 = small_g64; op.d = d;
+  op.lr = lr; op.eps = eps; op.max_norm = max_norm; op.sumsq = sumsq; op.sumsq_slots = sumsq_slots; op.skip_i = skip_count; op.skip_d = skip_value;
+  op.adagrad = adagrad;
+  return launch_rows(op, d, true, op.W + (int64_t)n_small * op.small_rows, st, name);
+}
+
 extern "C" int ktup_shard_bucket(int mode, int n_small, float* const* small_grads, int64_t small_elems, double* bucket,
-                                 const double* sumsq_local, const int32_t* overflow, double* sumsq_total, double small_weight,
+                                 const double* sumsq_local, int sumsq_slots, const int32_t* overflow, double* sumsq_total, double small_weight,
                                  void* stream) {
   const char* name = "ktup_shard_bucket";
   KTUP_REQUIRE((mode == 0 || mode == 1) && n_small >= 0 && n_small <= MAXS && small_elems >= 0 && bucket, "%s: bad arguments", name);
@@ -611,8 +951,8 @@ extern "C" int ktup_shard_bucket(int mode, int n_small, float* const* small_grad
   }
   hipStream_t st = (hipStream_t)stream;
   if (mode == 0) {
-    KTUP_REQUIRE(sumsq_local && overflow, "%s: mode 0 needs the local sum of squares and the overflow word", name);
-    a.sumsq_in = sumsq_local; a.overflow = overflow;
+    KTUP_REQUIRE(sumsq_local && sumsq_slots >= 1 && overflow, "%s: mode 0 needs the local sum of squares and the overflow word", name);
+    a.sumsq_in = sumsq_local; a.sumsq_slots = sumsq_slots; a.overflow = overflow;
     const int64_t N = (int64_t)n_small * a.small_elems + 2;
     hipLaunchKernelGGL(bucket_kernel<0>, dim3(grid_for((N + 1023) / 1024, 64)), dim3(1024), 0, st, a);
   } else {

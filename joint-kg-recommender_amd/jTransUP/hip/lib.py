@@ -96,15 +96,19 @@ SIGNATURES = {
     'ktup_shard_route_workspace_bytes': [c_l],
     'ktup_shard_route_sort_bytes': [c_l, c_l],
     'ktup_shard_route': [c_p, c_l, c_l, c_i, c_p, c_i, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p],
-    'ktup_shard_route_ktup': [c_p, c_p, c_p, c_l, c_l, c_p, c_p, c_l, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p],
+    'ktup_shard_route_ktup': [c_p, c_p, c_p, c_l, c_l, c_p, c_p, c_l, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_p],
     'ktup_shard_reduce_rows': [c_p, c_l, c_i, c_l, c_l, c_p, c_l, c_l, c_p, c_l, c_p],
     'ktup_shard_ktup_entries': [c_p, c_p, c_p, c_l, c_p, c_l, c_p, c_p],
     'ktup_shard_pack_wire': [c_i, c_p, c_p, c_p, c_i, c_p, c_l, c_p, c_l, c_p],
     'ktup_shard_apply': [c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_l, c_p, c_l, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_f,
-                         c_p, c_f, c_p, c_p, c_p],
-    'ktup_shard_bucket': [c_i, c_i, c_p, c_l, c_p, c_p, c_p, c_p, ctypes.c_double, c_p],
+                         c_p, c_i, c_f, c_p, c_p, c_p],
+    'ktup_shard_bucket': [c_i, c_i, c_p, c_l, c_p, c_p, c_i, c_p, c_p, ctypes.c_double, c_p],
     'ktup_zero_async': [c_p, c_l, c_p],
-    'ktup_optim_gradnorm_acc': [c_i, c_p, c_p, c_p, c_p],
+    'ktup_shard_reduce_list_len': [c_l, c_i],
+    'ktup_shard_reduce_norm': [c_p, c_l, c_i, c_l, c_l, c_p, c_l, c_l, c_p, c_l, c_p, c_i, c_p, c_l, c_f, c_p, c_i, c_p],
+    'ktup_shard_reduce_apply': [c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_p, c_l, c_i, c_l, c_l, c_p, c_l, c_p, c_l, c_p, c_i, c_i,
+                                c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_f, c_p, c_i, c_f, c_p, c_p, c_p],
+    'ktup_optim_gradnorm_acc': [c_i, c_p, c_p, c_p, c_i, c_p],
     'ktup_train_rec_step_rows': [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_p, c_p, c_l, c_i,
                                  c_f, c_f, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
     'ktup_negsample_rec_workspace_bytes': [c_l],
@@ -123,7 +127,7 @@ SIGNATURES = {
     'ktup_feed_rec': [c_p, c_p, c_l, c_l, c_p, c_p, c_l, c_p, c_l, c_u, c_i, c_p, c_p, c_p, c_p, c_p],
     'ktup_feed_kg': [c_p, c_p, c_p, c_l, c_l, c_p, c_p, c_l, c_l, c_p, c_l, c_u, c_p, c_p, c_p, c_p, c_p],
 }
-_RESTYPE = {'ktup_last_error': ctypes.c_char_p, 'ktup_shard_route_workspace_bytes': ctypes.c_size_t,
+_RESTYPE = {'ktup_last_error': ctypes.c_char_p, 'ktup_shard_reduce_list_len': ctypes.c_int64, 'ktup_shard_route_workspace_bytes': ctypes.c_size_t,
             'ktup_shard_route_sort_bytes': ctypes.c_size_t, 'ktup_pref_workspace_bytes': ctypes.c_size_t, 'ktup_eval_kg_ranks_workspace_bytes': ctypes.c_size_t,
             'ktup_eval_kg_workspace_bytes': ctypes.c_size_t, 'ktup_eval_transr_workspace_bytes': ctypes.c_size_t, 'ktup_eval_transr_entities_workspace_bytes': ctypes.c_size_t, 'ktup_score_transr_workspace_bytes': ctypes.c_size_t, 'ktup_score_transr_bwd_workspace_bytes': ctypes.c_size_t,
             'ktup_eval_pref_workspace_bytes': ctypes.c_size_t, 'ktup_eval_pref_items_workspace_bytes': ctypes.c_size_t, 'ktup_negsample_rec_workspace_bytes': ctypes.c_size_t,

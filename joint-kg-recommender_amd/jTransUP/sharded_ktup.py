@@ -34,6 +34,7 @@ import torch.distributed as dist
 from jTransUP.hip import lib as L
 
 KINDS = {'sgd': 0, 'adagrad': 1}
+SLOTS = 16          # the sum of squares is accumulated in this many words (one atomic per workgroup, ~20 ns each on one address)
 
 
 def _p(t):
@@ -60,7 +61,7 @@ class ShardedKtupStepper(object):
 
     def __init__(self, Ut, It, Et, pref, pref_norm, rel, norm, item2ent, batch, kind='adagrad', lr=0.005, eps=1e-10, max_norm=0.0,
                  l1=False, target=-1.0, orth=False, ent_pad=-1, group=None, capacity_factor=1.25, use_graphs=True, force_exchange=False,
-                 direct=None):
+                 direct=None, overlap_route=True, fused_apply=True):
         if kind not in KINDS:
             raise ValueError('row-sparse steps exist for plain SGD and Adagrad only')
         self.tables = [Ut, It, Et]
@@ -87,6 +88,11 @@ class ShardedKtupStepper(object):
             raise L.KtupError('item2ent must be an int32 device table')
         self.item2ent, self.ent_pad = item2ent.contiguous(), int(ent_pad)
         self.use_graphs = bool(use_graphs)
+        self.overlap_route = bool(overlap_route)
+        # fused_apply: reduce -> norm -> apply as two walks over the per-pair gradients (no W x d gradient buffer in between);
+        # False keeps the three-launch form through Gwire (same results to rounding: the tests run both)
+        self.fused_apply = bool(fused_apply)
+        self._side = torch.cuda.Stream(device=Ut.weight.device) if self.overlap_route else None
         # force_exchange: take the several-ranks route (five segments, the three all-to-alls and the all-reduce) on ONE rank too --
         # what a rank of a bigger job runs, minus the wire; with an initialised process group the collectives are real (RCCL at
         # world 1), without one they are device copies
@@ -124,7 +130,8 @@ class ShardedKtupStepper(object):
         self.X = f32(W + 1, d)                                # row W stays zero: "no entity" (jTransUP.py:96 padding_idx)
         self.Gcat = f32(4 * B, d)                             # [GU ; GV]
         self.Gwire = f32(W, d)
-        self.acc = torch.zeros(2, dtype=torch.float64, device=dev)          # [local sum of squares, total]
+        self.xkeys = i32(max(2, lib.ktup_shard_reduce_list_len(E, d)))
+        self.acc = torch.zeros(SLOTS + 1, dtype=torch.float64, device=dev)  # [SLOTS partial sums of squares | the job-wide total]
         self.loss_sum = f32(2)                                # [sum of batch-mean BPR terms, sum of orthogonalLoss values]
         n_g = 4 if self.orth else 2
         self.small_g = [f32(P, d) for _ in range(n_g)]        # orth: gP, gPn, gR, gRn; else gA (pref & rel), gC (pref_norm & norm)
@@ -145,14 +152,18 @@ class ShardedKtupStepper(object):
             self.own_counters = i32(3 + 1)
             self.own_ws = torch.empty((lib.ktup_shard_route_workspace_bytes(W) + 7) // 8, dtype=torch.int64, device=dev)
             self.Gown = f32(Wo, d)
+            self.own_xkeys = i32(max(2, lib.ktup_shard_reduce_list_len(W, d)))
             self.bucket = torch.zeros(n_g * P * d + 2, dtype=torch.float64, device=dev)
         self._eager = None
         self._graphs = None
         self._graph_steps = 0
 
     # ------------------------------------------------------------------------------------------------ launch lists
-    def _bind(self, stream):
-        """Pre-bound launches (lib.bind) on `stream`, as the segments between the collectives."""
+    def _bind(self, stream, side=None):
+        """Pre-bound launches (lib.bind) on `stream`, as the segments between the collectives.  One rank with direct gathers: the
+        step kernel needs only the entry list (the route's first launch), so the rest of the route -- hashing, slots, the
+        counting sort: four small latency-bound launches -- is bound to `side` (a second stream) and runs beside it; the
+        segment then reads [init, ('fork', [...]), step, ('join',), ...]."""
         B, d, P, W, E, Wn = self.B, self.d, self.P, self.W, self.E, self.world
         Ut, It, Et = self.tables
         pref, pref_norm, rel, norm = [s.data for s in self.small]
@@ -188,9 +199,11 @@ class ShardedKtupStepper(object):
         X, inv = self.X, self.inverse
         bind = L.bind
         fu, fp, fn, nb = self._feed
-        route = bind('ktup_shard_route_ktup', _p(fu), _p(fp), _p(fn), B, nb, _p(self.cursor), _p(self.item2ent), self.ent_pad,
-                     _p(self.entries), Wn, cap, _p(inv), _p(self.send_ids), _p(self.pair_map), _p(self.sort_ws), _p(self.counters),
-                     _p(self.acc), 2, _p(self.route_ws), stream)
+        def route_phase(phase, on):
+            return bind('ktup_shard_route_ktup', _p(fu), _p(fp), _p(fn), B, nb, _p(self.cursor), _p(self.item2ent), self.ent_pad,
+                        _p(self.entries), Wn, cap, _p(inv), _p(self.send_ids), _p(self.pair_map), _p(self.sort_ws), _p(self.counters),
+                        _p(self.acc), SLOTS + 1, _p(self.route_ws), phase, on)
+        route = route_phase(0, stream)
         if self.direct:                                      # global ids straight into the shards (entries = [u ; u | pos ; neg | ...])
             ent = self.entries
             step = bind('ktup_train_rec_step_rows', _p(Ut.weight.data), Ut.weight.data.stride(0), _p(It.weight.data), It.weight.data.stride(0),
@@ -206,11 +219,24 @@ class ShardedKtupStepper(object):
             pack = bind('ktup_shard_pack_wire', 3, tabs, lds, cap, d, _p(self.send_ids), 1, _p(X), d, stream)
             nl = [self.Gwire] + norm_list
             nptr, nsz = arr(_ptrs(nl)), arr(_i64s([t.numel() for t in nl]))
-            gnorm = bind('ktup_optim_gradnorm_acc', len(nl), nptr, nsz, _p(self.acc), stream)
+            gnorm = bind('ktup_optim_gradnorm_acc', len(nl), nptr, nsz, _p(self.acc), SLOTS, stream)
             apply_ = bind('ktup_shard_apply', kind, 3, tabs, lds, states, lds, cap, d, _p(self.send_ids), 1, _p(self.Gwire), d, n_small, P,
-                          sgp, sp0p, ss0p, sp1p, ss1p, None, self.lr, self.eps, _p(self.acc), self.max_norm,
+                          sgp, sp0p, ss0p, sp1p, ss1p, None, self.lr, self.eps, _p(self.acc), SLOTS, self.max_norm,
                           self.counters.data_ptr() + 4 * (Wn * 3), None, stream)
-            return [[route, step, reduce_, gnorm, apply_] if self.direct else [route, pack, step, reduce_, gnorm, apply_]]
+            if self.fused_apply:
+                nw = arr(_ptrs(sg_list))
+                rnorm = bind('ktup_shard_reduce_norm', _p(self.Gcat), d, d, 4 * B, 2 * B, _p(self.sort_ws), E, W, _p(self.Gwire), d,
+                             _p(self.xkeys), n_small, nw, P * d, small_weight, _p(self.acc), SLOTS, stream)
+                rapply = bind('ktup_shard_reduce_apply', kind, 3, tabs, lds, states, lds, cap, _p(self.send_ids), 1, _p(self.Gcat), d, d,
+                              4 * B, 2 * B, _p(self.sort_ws), E, _p(self.Gwire), d, _p(self.xkeys), n_small, P, sgp, sp0p, ss0p, sp1p, ss1p,
+                              None, self.lr, self.eps, _p(self.acc), SLOTS, self.max_norm, self.counters.data_ptr() + 4 * (Wn * 3), None,
+                              stream)
+                tail = [rnorm, rapply]
+            else:
+                tail = [reduce_, gnorm, apply_]
+            if self.direct and side is not None:
+                return [[route_phase(1, stream), ('fork', [route_phase(2, side)]), step, ('join',)] + tail]
+            return [([route, step] if self.direct else [route, pack, step]) + tail]
         capo = arr(_i64s(self.cap_own))
         eoff_o = arr(_i64s([0, self.cap[0], self.cap[0] + self.cap[1], self.capsum]))
         pack = bind('ktup_shard_pack_wire', 3, tabs, lds, cap, d, _p(self.recv_ids), Wn, _p(self.Xsend), d, stream)
@@ -219,14 +245,22 @@ class ShardedKtupStepper(object):
                       _p(self.own_ids), None, _p(self.own_sort), _p(self.own_counters), None, 0, _p(self.own_ws), stream)
         oreduce = bind('ktup_shard_reduce_rows', _p(self.Grecv), d, d, W, 0, _p(self.own_sort), W, self.W_own, _p(self.Gown), d, stream)
         nptr, nsz = arr(_ptrs([self.Gown])), arr(_i64s([self.Gown.numel()]))
-        gnorm = bind('ktup_optim_gradnorm_acc', 1, nptr, nsz, _p(self.acc), stream)
+        gnorm = bind('ktup_optim_gradnorm_acc', 1, nptr, nsz, _p(self.acc), SLOTS, stream)
         N = n_small * P * d
-        pack_b = bind('ktup_shard_bucket', 0, n_small, sgp, P * d, _p(self.bucket), _p(self.acc), self.counters.data_ptr() + 4 * (Wn * 3),
+        pack_b = bind('ktup_shard_bucket', 0, n_small, sgp, P * d, _p(self.bucket), _p(self.acc), SLOTS, self.counters.data_ptr() + 4 * (Wn * 3),
                       None, 1.0, stream)
-        fin_b = bind('ktup_shard_bucket', 1, n_small, None, P * d, _p(self.bucket), None, None, self.acc.data_ptr() + 8, small_weight, stream)
+        fin_b = bind('ktup_shard_bucket', 1, n_small, None, P * d, _p(self.bucket), None, 0, None, self.acc.data_ptr() + 8 * SLOTS, small_weight, stream)
         apply_ = bind('ktup_shard_apply', kind, 3, tabs, lds, states, lds, capo, d, _p(self.own_ids), 1, _p(self.Gown), d, n_small, P,
-                      sgp, sp0p, ss0p, sp1p, ss1p, _p(self.bucket), self.lr, self.eps, self.acc.data_ptr() + 8, self.max_norm,
+                      sgp, sp0p, ss0p, sp1p, ss1p, _p(self.bucket), self.lr, self.eps, self.acc.data_ptr() + 8 * SLOTS, 1, self.max_norm,
                       None, self.bucket.data_ptr() + 8 * (N + 1), stream)
+        if self.fused_apply:
+            onorm = bind('ktup_shard_reduce_norm', _p(self.Grecv), d, d, W, 0, _p(self.own_sort), W, self.W_own, _p(self.Gown), d,
+                         _p(self.own_xkeys), 0, None, 0, 1.0, _p(self.acc), SLOTS, stream)
+            oapply = bind('ktup_shard_reduce_apply', kind, 3, tabs, lds, states, lds, capo, _p(self.own_ids), 1, _p(self.Grecv), d, d, W, 0,
+                          _p(self.own_sort), W, _p(self.Gown), d, _p(self.own_xkeys), n_small, P, sgp, sp0p, ss0p, sp1p, ss1p,
+                          _p(self.bucket), self.lr, self.eps, self.acc.data_ptr() + 8 * SLOTS, 1, self.max_norm, None,
+                          self.bucket.data_ptr() + 8 * (N + 1), stream)
+            return [[route], [pack], [step, reduce_], [zero, oroute, onorm, pack_b], [fin_b, oapply]]
         return [[route], [pack], [step, reduce_], [zero, oroute, oreduce, gnorm, pack_b], [fin_b, apply_]]
 
     def _exchange(self, k):
@@ -286,8 +320,7 @@ class ShardedKtupStepper(object):
             if self._eager is None or self._eager[0] != stream:
                 self._eager = (stream, self._bind(stream), self._keep)
             for k, seg in enumerate(self._eager[1]):
-                for launch in seg:
-                    launch()
+                self._issue(seg, None)
                 if self.multi:
                     self._exchange(k)
             self.steps += 1
@@ -300,6 +333,17 @@ class ShardedKtupStepper(object):
                 self._exchange(k)
         self.steps += 1
 
+    def _issue(self, seg, side):
+        for item in seg:
+            if callable(item):
+                item()
+            elif item[0] == 'fork':                           # launches bound to the side stream, ordered after everything so far
+                side.wait_stream(torch.cuda.current_stream(self.dev))
+                for launch in item[1]:
+                    launch()
+            elif item[0] == 'join':
+                torch.cuda.current_stream(self.dev).wait_stream(side)
+
     def _capture(self):
         """Each segment becomes one HIP graph (the collectives between them are issued by torch.distributed).  A captured segment
         also RUNS nothing: the step that triggers the capture replays the fresh graphs."""
@@ -309,10 +353,10 @@ class ShardedKtupStepper(object):
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 cs = torch.cuda.current_stream(self.dev).cuda_stream
-                segs = self._bind(cs)
+                side = self._side if (self.direct and self.overlap_route) else None
+                segs = self._bind(cs, None if side is None else side.cuda_stream)
                 keeps.append(self._keep)
-                for launch in segs[k]:
-                    launch()
+                self._issue(segs[k], side)
             graphs.append(graph)
         self._graphs, self._graph_keep = graphs, keeps
 

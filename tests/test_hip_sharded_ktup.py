@@ -88,20 +88,36 @@ def _batches(gen, world, steps, nu, ni, b):
 # noise into an O(lr) difference, so the comparisons use eps = 1e-4 (well-conditioned, same code path), as tests/test_hip_config5.py
 @pytest.mark.parametrize('d,P', [(256, 20), (100, 20), (64, 4)])
 @pytest.mark.parametrize('kind', ['adagrad', 'sgd'])
-@pytest.mark.parametrize('form', ['one_graph', 'exchange_form', 'eager'])
+@pytest.mark.parametrize('form', ['one_graph', 'exchange_form', 'eager', 'one_graph_gradient_buffer', 'exchange_form_gradient_buffer'])
 def test_stepper_equals_the_dense_reference_step(d, P, kind, form):
     nu, ni, ne, b, steps = 900, 300, 700, 512, 5                 # duplicates in every batch; every 7th item has no entity
     full, small0, i2e, gen = _world_tables(nu, ni, ne, P, d, seed=11 + d, pad_every=7)
     batches = _batches(gen, 1, steps, nu, ni, b)
     lr, max_norm = (0.05, 0.5) if kind == 'adagrad' else (20.0, 0.5)
     Wd, losses = _dense_reference(full, small0, i2e, batches, kind, lr, 1e-4, max_norm)
-    kw = {'one_graph': {}, 'exchange_form': {'force_exchange': True}, 'eager': {'use_graphs': False}}[form]
+    kw = {'one_graph': {}, 'exchange_form': {'force_exchange': True}, 'eager': {'use_graphs': False},
+          'one_graph_gradient_buffer': {'fused_apply': False}, 'exchange_form_gradient_buffer': {'force_exchange': True, 'fused_apply': False}}[form]
     tables, small, st = _run_stepper(full, small0, i2e, batches, kind, lr, 1e-4, max_norm, 0, 1, torch.device(DEV), **kw)
     assert st.steps == steps and (form == 'eager') == (st._graphs is None)
     _check(tables, small, Wd, 0, 1)
     np.testing.assert_allclose(float(st.loss_sum[0]), sum(losses), rtol=1e-4)
     assert st.overflowed_steps() == 0
     st.check()
+
+
+@pytest.mark.parametrize('form', ['one_graph', 'exchange_form', 'one_graph_gradient_buffer'])
+@pytest.mark.parametrize('d', [256, 64])
+def test_stepper_hot_rows_span_many_workgroups(form, d):
+    """12 users / 40 items / 30 entities under 512-pair batches: every row collects dozens of entries, so its sorted segment spans
+    several workgroups of the reduction (32 entries each at d = 256) -- the boundary-row list of the two-walk form."""
+    nu, ni, ne, b, steps, P = 12, 40, 30, 512, 4, 20
+    full, small0, i2e, gen = _world_tables(nu, ni, ne, P, d, seed=3)
+    batches = _batches(gen, 1, steps, nu, ni, b)
+    Wd, losses = _dense_reference(full, small0, i2e, batches, 'adagrad', 0.05, 1e-4, 0.5)
+    kw = {'one_graph': {}, 'exchange_form': {'force_exchange': True}, 'one_graph_gradient_buffer': {'fused_apply': False}}[form]
+    tables, small, st = _run_stepper(full, small0, i2e, batches, 'adagrad', 0.05, 1e-4, 0.5, 0, 1, torch.device(DEV), **kw)
+    _check(tables, small, Wd, 0, 1)
+    np.testing.assert_allclose(float(st.loss_sum[0]), sum(losses), rtol=1e-4)
 
 
 @pytest.mark.parametrize('l1,orth,pad_every', [(True, False, 0), (False, True, 5), (False, False, 0)])

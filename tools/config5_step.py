@@ -43,7 +43,7 @@ def fused_main(args):
             dist.broadcast(p.data, src=0)
     item2ent = torch.randint(0, NE, (NI,), generator=torch.Generator(device=dev).manual_seed(7), device=dev).to(torch.int32)
     st = ShardedKtupStepper(Ut, It, Et, *small, item2ent, batch=B, kind='adagrad', lr=0.005, max_norm=5.0, use_graphs=not args.no_graphs,
-                            force_exchange=args.exchange, direct=False if (args.no_direct or args.exchange or world > 1) else None)
+                            force_exchange=args.exchange, overlap_route=not args.no_overlap, fused_apply=not args.gradient_buffer, direct=False if (args.no_direct or args.exchange or world > 1) else None)
 
     def draw(n_rows):
         if args.zipf <= 0:
@@ -98,6 +98,8 @@ def main():
     ap.add_argument('--exchange', action='store_true', help='one rank in exchange form: the several-ranks route (five segments, all-to-alls) talking to itself')
     ap.add_argument('--no-graphs', action='store_true')
     ap.add_argument('--copy-batches', action='store_true', help='hand every batch over as three tensors (three device copies per step) instead of device-fed columns')
+    ap.add_argument('--no-overlap', action='store_true', help='one rank, direct gathers: keep the route on the step kernel\'s stream (no second stream in the graph)')
+    ap.add_argument('--gradient-buffer', action='store_true', help='reduce -> norm -> apply through a W x d gradient buffer (three launches) instead of two walks over the per-pair gradients')
     ap.add_argument('--no-direct', action='store_true', help='one rank: pack the rows into the compact wire table first (what several ranks do)')
     args = ap.parse_args()
     if not args.legacy:

@@ -610,14 +610,16 @@ def dp_train_leg(device, world, rank, steps=100, warmup=20):
     return out
 
 
-def config5_leg(device, world, rank, steps=10, warmup=3, batch=8192, full=True):
+def config5_leg(device, world, rank, steps=100, warmup=10, batch=8192, full=True):
     """BASELINE config 5: KTUP at d=256 on 10 M users x 1 M items x 5 M entities, tables row-sharded over the N ranks
-    (row % N), B = 8192 (u, pos, neg) per rank and step: device-side dedupe, ONE id and ONE row all-to-all for the three
-    tables, the matrix-core scorer on the compact tables, row gradients back in ONE all-to-all, global clip, row-sparse Adagrad
-    (parallel.ShardedStep).  With fewer than 8 ranks the same tables simply give bigger shards (16.4 GB of tables + as much
-    optimizer state in total)."""
+    (row % N), B = 8192 (u, pos, neg) per rank and step, through jTransUP/sharded_ktup.py: every buffer of the step has a
+    fixed shape, so the step is graph replays with no host synchronisation -- device-side routing of the batch's distinct ids
+    into fixed-capacity wire rows, (N > 1: an id, a row and a gradient all-to-all with EQUAL splits + one fp64 all-reduce), the fused
+    KTUP forward / BPR / backward kernel with per-pair row gradients, the segment reduction run twice (norm, then clip +
+    row-sparse Adagrad straight from registers).  `ms_per_step` is the host clock around `steps` steps, `ms_per_step_device` the
+    time between two HIP events around the same steps.  With fewer than 8 ranks the same tables simply give bigger shards."""
     from jTransUP import parallel
-    from jTransUP.hip import ops
+    from jTransUP.sharded_ktup import ShardedKtupStepper
     d, P, B = 256, 20, batch
     NUs, NIs, NEs = (10_000_000, 1_000_000, 5_000_000) if full else (1_250_000 * world, 125_000 * world, 625_000 * world)
     free, _ = torch.cuda.mem_get_info(device)
@@ -636,38 +638,49 @@ def config5_leg(device, world, rank, steps=10, warmup=3, batch=8192, full=True):
     if world > 1:
         for p in small:
             dist.broadcast(p.data, src=0)
-    item2ent = torch.randint(0, NEs, (NIs,), generator=torch.Generator(device=device).manual_seed(7), device=device)
-    step = parallel.ShardedStep('adagrad', lr=0.005, max_norm=5.0)
-    times = {'lookup': 0.0, 'score_fwd_bwd': 0.0, 'apply': 0.0}
+    item2ent = torch.randint(0, NEs, (NIs,), generator=torch.Generator(device=device).manual_seed(7), device=device).to(torch.int32)
+    out = {'backend': dist.get_backend() if world > 1 else 'single process', 'world': world, 'batch_per_rank': B,
+           'rows': {'users': NUs, 'items': NIs, 'entities': NEs}, 'd': d, 'tables_GB_per_rank': (NUs + NIs + NEs) * d * 4 / world / 1e9}
 
-    def tick():
+    def run(label, **kw):
+        st = ShardedKtupStepper(Ut, It, Et, *small, item2ent, batch=B, kind='adagrad', lr=0.005, max_norm=5.0, **kw)
+        n = steps + warmup
+        cols = [torch.randint(0, hi, (n, B), generator=gen, device=device) for hi in (NUs, NIs, NIs)]
+        st.set_feed(cols)                                              # device-fed: the step's own launches walk the columns
+        for _ in range(warmup):
+            st.run()
         torch.cuda.synchronize(device)
-        return time.perf_counter()
-    for s in range(steps + warmup):
-        u = torch.randint(0, NUs, (B,), generator=gen, device=device)
-        pi = torch.randint(0, NIs, (B,), generator=gen, device=device); ni = torch.randint(0, NIs, (B,), generator=gen, device=device)
         if world > 1:
             dist.barrier()
-        t0 = tick()
-        items = torch.cat([pi, ni])
-        (u_rows, u_at), (i_rows, i_at), (e_rows, e_at) = step.lookup_many([(Ut, u), (It, items), (Et, item2ent[items])])
-        t1 = tick()
-        i2e_c = torch.zeros(i_rows.shape[0], dtype=torch.int32, device=device)
-        i2e_c[i_at] = e_at.to(torch.int32)
-        score = ops.score_ktup(u_rows, i_rows, e_rows, *small, i2e_c, torch.cat([u_at, u_at]), i_at, False, ent_pad=-1)
-        (torch.nn.functional.softplus(score[:B] - score[B:]).mean() / world).backward()
-        t2 = tick()
-        step.apply(replicated=small)
-        t3 = tick()
-        if s >= warmup:
-            times['lookup'] += t1 - t0; times['score_fwd_bwd'] += t2 - t1; times['apply'] += t3 - t2
-    total = _max_over_ranks(sum(times.values()), device, world)
-    return {'backend': dist.get_backend() if world > 1 else 'single process', 'world': world, 'batch_per_rank': B,
-            'rows': {'users': NUs, 'items': NIs, 'entities': NEs}, 'd': d, 'tables_GB_per_rank': (NUs + NIs + NEs) * d * 4 / world / 1e9,
-            'ms_per_step': 1e3 * total / steps, 'ms_rank0': {k: 1e3 * v / steps for k, v in times.items()},
-            'scored_rows_per_s': 2 * B * world * steps / total,
-            'note': 'lookup = dedupe + (N > 1: one count, one id, one row all-to-all) + owner-side pack; apply = gradient rows back '
-                    '(one all-to-all), duplicate combine, one all-reduce (small tables + norm), row-sparse Adagrad on the touched rows'}
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record()
+        for _ in range(steps):
+            st.run()
+        e1.record()
+        torch.cuda.synchronize(device)
+        wall = _max_over_ranks(1e3 * (time.perf_counter() - t0) / steps, device, world)
+        st.check()
+        leg = {'ms_per_step': wall, 'ms_per_step_device': e0.elapsed_time(e1) / steps, 'scored_rows_per_s': 2 * B * world / (wall * 1e-3),
+               'wire_rows_per_rank': st.W, 'graph_segments': len(st._graphs) if st._graphs else 0}
+        # train-step bytes per scored row = forward (12 d + 24 B ... = 3096 B at d = 256) + 3 gathered rows x 4 d x 3
+        alg = 2 * B * (3096 + 3 * 4 * d * 3)
+        # what a step must move at least on top of that: parameter + Adagrad state, read and written, of every distinct row
+        moved = alg + st.W * d * 4 * 4
+        leg['algorithmic_MB'] = alg / 1e6
+        leg['hbm_frac_algorithmic'] = alg / (leg['ms_per_step_device'] * 1e-3) / 1e9 / HBM_PEAK_GBS
+        leg['hbm_frac_with_optimizer_rows'] = moved / (leg['ms_per_step_device'] * 1e-3) / 1e9 / HBM_PEAK_GBS
+        del st
+        return leg
+    out.update(run('default'))
+    if world == 1:
+        out['exchange_form'] = run('exchange', force_exchange=True)   # what ONE rank of a bigger job runs, minus the wire
+        out['exchange_form']['note'] = ('the several-ranks route on one rank: five graph segments, rows packed into the wire '
+                                        'buffer, the three all-to-alls as device copies')
+    out['note'] = ('one rank: ONE graph of 10 launches (route 5, fused step 1, reduce+norm 2, reduce+apply 2), the route on a second '
+                   'graph branch beside the step kernel; N > 1: five graph segments around three equal-split all-to-alls and one '
+                   'fp64 all-reduce (small tables + norm + overflow flag); round 2 ran this step at 0.82-0.89 ms through autograd')
+    return out
 
 
 def roofline(rec_ms, kg_ms):

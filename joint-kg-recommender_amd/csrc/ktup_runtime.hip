@@ -42,6 +42,7 @@ Option g_opts[] = {
     {"seg_bwd_min", "KTUP_SEG_BWD_MIN", {env_int("KTUP_SEG_BWD_MIN", 8192)}},   // rows from which the backward kernels reduce row gradients by segments (0: never)
     {"bwd_wide_max", "KTUP_BWD_WIDE_MAX", {env_int("KTUP_BWD_WIDE_MAX", 4096)}},   // K5-K7 backward: pairs up to which four waves share a 16-pair tile (d <= 128)
     {"side_sort", "KTUP_SIDE_SORT", {env_int("KTUP_SIDE_SORT", 1)}},    // 0: the id sorts of the segment reductions stay on the caller's stream
+    {"shard_chunk", "KTUP_SHARD_CHUNK", {env_int("KTUP_SHARD_CHUNK", 0)}},   // > 0: sorted entries per lane group in the sharded step's two reduction walks (0: by batch size)
     {"dbg_noflush", "KTUP_DBG_NOFLUSH", {env_int("KTUP_DBG_NOFLUSH", 0)}},  // MEASUREMENT ONLY (wrong results): the fused step kernels skip the small-table gradient flush
 };
 Option* find(const char* name) {
@@ -56,7 +57,8 @@ int opt_eval_mc() { return g_opts[1].value.load(std::memory_order_relaxed); }
 int opt_rank_chunk() { return g_opts[2].value.load(std::memory_order_relaxed); }
 int opt_seg_bwd_min() { return g_opts[3].value.load(std::memory_order_relaxed); }
 int opt_bwd_wide_max() { return g_opts[4].value.load(std::memory_order_relaxed); }
-int opt_dbg_noflush() { return g_opts[6].value.load(std::memory_order_relaxed); }
+int opt_shard_chunk() { return g_opts[6].value.load(std::memory_order_relaxed); }
+int opt_dbg_noflush() { return g_opts[7].value.load(std::memory_order_relaxed); }
 
 // A library-owned second stream for work that depends only on a call's INPUTS (the counting sorts of the segment reductions)
 // while the caller's stream runs the kernel that produces the data: fork_side makes it wait for everything enqueued on `st` so far,

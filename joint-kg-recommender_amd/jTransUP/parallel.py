@@ -41,6 +41,24 @@ def _world(group=None):
     return dist.get_world_size(group) if dist.is_initialized() else 1
 
 
+_FORCE = [False]
+
+
+def force_collectives(on=True):
+    """Test / measurement hook: with an initialised process group of ONE rank, still issue every collective of the N > 1 paths
+    (all-reduce of the gradient bucket, the all-to-alls of the sharded lookups, the all-gathers of the merged rankings) instead of
+    short-cutting them -- a 1-GPU box then runs RCCL's device-tensor branches and their stream ordering, degenerately but for
+    real.  Returns the previous setting."""
+    old = _FORCE[0]
+    _FORCE[0] = bool(on)
+    return old
+
+
+def _exchanging(group=None):
+    """True when the collectives of the N > 1 paths must be issued: several ranks, or one rank under force_collectives()."""
+    return dist.is_initialized() and (dist.get_world_size(group) > 1 or _FORCE[0])
+
+
 # ------------------------------------------------------------------------------------------ config 4: replicas
 class ReplicaGradSync(object):
     """Gradient exchange for data-parallel replicas.
@@ -80,7 +98,7 @@ class ReplicaGradSync(object):
     @torch.no_grad()
     def all_reduce_grads(self):
         """ONE all-reduce(sum) of the flat bucket: no gather / scatter copies, the gradients are views into it."""
-        if self.world == 1:
+        if not _exchanging(self.group):
             return
         for p in self.params:                 # autograd may have replaced a view by its own tensor (set_to_none, first backward)
             if p.grad is None or p.grad.data_ptr() < self.flat.data_ptr() or \
@@ -103,7 +121,7 @@ class ReplicaGradSync(object):
             off += n + ((-n) % 4)
 
     def broadcast_params(self, src=0):
-        if self.world > 1:
+        if _exchanging(self.group):
             for p in self.params:
                 dist.broadcast(p.data, src=src, group=self.group)
 
@@ -266,7 +284,7 @@ class ShardedTable(torch.nn.Module):
         """Autograd form (dense shard gradient): for code that wants `.grad` on the shard.  The training step uses
         ShardedStep.lookup, which never materialises a shard-sized gradient."""
         uniq, inverse = torch.unique(ids, return_inverse=True)
-        if self.world == 1:
+        if not _exchanging(self.group):
             return _LocalGather.apply(self.weight, uniq, self), inverse
         return _ShardedLookup.apply(self.weight, uniq, self), inverse
 
@@ -350,7 +368,7 @@ class ShardedStep(object):
         with torch.no_grad():
             ded = [self.ops.dedupe(ids) for _, ids in pairs]                     # (uniq padded with -1, inverse)
             uniqs = [u for u, _ in ded]
-            if self.world == 1:
+            if not _exchanging(self.group):
                 route = None
                 rows = [t.pack(t.weight.data, u) for t, u in zip(tables, uniqs)]
             else:
@@ -402,7 +420,7 @@ class ShardedStep(object):
         reps = [p for p in replicated if p.grad is not None]
         sumsq = None
         local = ops.sumsq([g for _, _, g in work if g.numel()]) if self.max_norm > 0 else None   # every touched row once, at its owner
-        if self.world > 1 and (reps or local is not None):
+        if _exchanging(self.group) and (reps or local is not None):
             flat = torch.cat([p.grad.reshape(-1).double() for p in reps] + ([local.reshape(1)] if local is not None else []))
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)        # small tables' gradients + the norm, one bucket
             off = 0
@@ -442,7 +460,7 @@ def merge_topk(local_ids, local_scores, topn, descending=False, group=None):
     """Merge per-shard filtered top-n lists (global candidate ids, -1 padded) into the global top-n on every rank.
     Order: ascending score (descending=True negates), ties -> lower id: the same total order the ranking kernel uses."""
     world = _world(group)
-    if world > 1:
+    if _exchanging(group):
         stage = local_ids.is_cuda and dist.get_backend(group) == 'gloo'      # gloo test hook: no device all-gather there
         src_i, src_s = (local_ids.cpu(), local_scores.cpu()) if stage else (local_ids.contiguous(), local_scores.contiguous())
         ids_all = [torch.empty_like(src_i) for _ in range(world)]
@@ -506,10 +524,10 @@ def sharded_gold_ranks(local_scores, lo, descending, g_off, g_ids, g_rows, f_off
     if n_local and bool(n):
         picked = local_scores[g_rows[mine], col[mine]]
         gold_scores[mine] = picked
-    if _world(group) > 1:
+    if _exchanging(group):
         _all_reduce(gold_scores, group)
     counts = local_counts(local_scores, lo, descending, g_off, g_ids, gold_scores, f_off, f_ids)[:n].clone()
-    if _world(group) > 1:
+    if _exchanging(group):
         _all_reduce(counts, group)
     return torch.where(counts < 0, torch.full_like(counts, -1), counts)
 

@@ -79,7 +79,15 @@ class _StepperBase(object):
         if use_graphs is None:
             import os
             use_graphs = os.environ.get('KTUP_TRAIN_GRAPHS', '1') != '0'
-        self.use_graphs = bool(use_graphs) and self.world == 1
+        # Data-parallel replicas: the step is still ONE graph -- fused step kernel, the all-reduce of the flat bucket (RCCL
+        # collectives are capturable), clip + optimizer launch -- when the backend is nccl; under the gloo test hook the
+        # all-reduce is staged through the host and the launches are issued one by one (KTUP_DP_GRAPHS=0 forces that too)
+        import os as _os0
+        dp_ok = self.world == 1 or (dist.get_backend(group) == 'nccl' and _os0.environ.get('KTUP_DP_GRAPHS', '1') != '0')
+        if dist.is_initialized() and self.world == 1 and dist.get_backend(group) != 'nccl':
+            from jTransUP import parallel as _par
+            dp_ok = not _par._FORCE[0]              # forced collectives on gloo stage through the host: not capturable
+        self.use_graphs = bool(use_graphs) and dp_ok
         import os as _os
         self.want_fused = _os.environ.get('KTUP_FUSED_STEP', '1') != '0'
         self.out = {k: torch.zeros((), **f32) for k in self.KINDS}                       # fused steps: where the step's loss is published
@@ -244,7 +252,24 @@ class _StepperBase(object):
         self.gadv = torch.tensor([0, int(draws_per_step)], dtype=torch.int64, device=self.dev)
 
     def _gate_args(self):
+        if self.gstate is not None and getattr(self, 'guni', None) is not None:
+            return (ops.GUMBEL_INPUT, _p(self.guni))
         return (ops.GUMBEL_OFF, None) if self.gstate is None else (ops.GUMBEL_PHILOX_DEV, _p(self.gstate))
+
+    def set_gumbel_uniforms(self, uniforms):
+        """Parity hook (tests against the reference's goldens): the ST-Gumbel gate of the NEXT steps reads its uniforms -- one row
+        of n_pref values per scored pair, positives then negatives, as transUP.py:159-162 drew them -- from a fixed buffer that
+        this call fills, instead of drawing Philox numbers on the device.  None switches back."""
+        if self.gstate is None:
+            raise L.KtupError('the model has no ST-Gumbel gate')
+        if uniforms is None:
+            self.guni = None
+        else:
+            if getattr(self, 'guni', None) is None:
+                self.guni = torch.empty(2 * self.B, uniforms.shape[1], dtype=torch.float32, device=self.dev)
+                self._keys = None                      # re-bind the launches with the new gate arguments
+                self._graphs = {}
+            self.guni.copy_(uniforms)
 
     def _gumbel_advance(self):
         if self.gstate is not None:

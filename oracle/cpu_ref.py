@@ -223,6 +223,66 @@ def norm_loss(emb, dim=1):
     return torch.sum(torch.clamp(torch.sum(emb ** 2, dim=dim, keepdim=True) - 1.0, min=0.0))
 
 
+# ----------------------------------------------------------------------------- the drivers' step bodies (loss assembly + one step)
+def ktup_rec_step_loss(U, I, E, P, Pn, R, Rn, item2ent, u, pi, ni, l1=False, target=-1.0, uni_pos=None, uni_neg=None):
+    """models/knowledgable_recommendation.py:335-344 : bprLoss(pos, neg, target) + orthogonalLoss(pref, pref_norm)."""
+    pos = score_ktup_rec(U, I, E, P, Pn, R, Rn, item2ent, u, pi, l1, uni_pos)
+    neg = score_ktup_rec(U, I, E, P, Pn, R, Rn, item2ent, u, ni, l1, uni_neg)
+    return bpr_loss(pos, neg, target) + orthogonal_loss(P, Pn)
+
+
+def kg_step_loss(E, R, N, ph, pt, pr, nh, nt, nr, l1=False, margin=1.0, kg_lambda=1.0):
+    """models/knowledge_representation.py:189-204 (TransE: N is None; TransH) and knowledgable_recommendation.py:368-383 (KTUP's
+    kg branch = TransH on its own tables, times kg_lambda): marginLoss + orthogonalLoss(rel rows, norm rows) [TransH] +
+    normLoss(ent rows of ph, pt, nh, nt) + normLoss(rel rows of pr, nr)."""
+    if N is None:
+        pos, neg = score_transe(E, R, ph, pt, pr, l1), score_transe(E, R, nh, nt, nr, l1)
+    else:
+        pos, neg = score_transh(E, R, N, ph, pt, pr, l1), score_transh(E, R, N, nh, nt, nr, l1)
+    loss = margin_loss(pos, neg, margin)
+    rel_ids = torch.cat([pr, nr])
+    if N is not None:
+        loss = loss + orthogonal_loss(R[rel_ids], N[rel_ids])
+    loss = loss + norm_loss(E[torch.cat([ph, pt, nh, nt])]) + norm_loss(R[rel_ids])
+    return kg_lambda * loss
+
+
+def tup_rec_step_loss(U, I, P, Pn, u, pi, ni, l1=False, target=-1.0, uni_pos=None, uni_neg=None):
+    """models/item_recommendation.py:171-180 (transup): bprLoss + orthogonalLoss(pref, pref_norm) + normLoss(user rows) +
+    normLoss(item rows of pos and neg) + normLoss(pref)."""
+    pos, neg = score_tup(U, I, P, Pn, u, pi, l1, uni_pos), score_tup(U, I, P, Pn, u, ni, l1, uni_neg)
+    return bpr_loss(pos, neg, target) + orthogonal_loss(P, Pn) + norm_loss(U[u]) + norm_loss(I[torch.cat([pi, ni])]) + norm_loss(P)
+
+
+def make_optimizer(params, optimizer_type, lr, l2_lambda, momentum=0.9):
+    """utils/trainer.py:63-77 : torch.optim with weight_decay = l2_lambda (dense: every row of every table moves)."""
+    if optimizer_type == 'Adam':
+        return torch.optim.Adam(params, lr=lr, weight_decay=l2_lambda)
+    if optimizer_type == 'SGD':
+        return torch.optim.SGD(params, lr=lr, weight_decay=l2_lambda, momentum=momentum)
+    if optimizer_type == 'Adagrad':
+        return torch.optim.Adagrad(params, lr=lr, weight_decay=l2_lambda)
+    if optimizer_type == 'Rmsprop':
+        return torch.optim.RMSprop(params, lr=lr, weight_decay=l2_lambda, momentum=momentum)
+    raise ValueError(optimizer_type)
+
+
+def train_step(params, optimizer, loss_fn, clip_max, pad_row_of=None):
+    """One step as every driver ends it (e.g. knowledgable_recommendation.py:394-403): zero_grad, loss, backward,
+    clip_grad_norm over ALL parameters, optimizer.step -- with the zero-filling zero_grad of the torch 0.3 the reference targets
+    (the goldens are generated with the same shim, tests/golden/make_goldens.py #5).  pad_row_of: the entity table whose last row is nn.Embedding's
+    padding_idx (jTransUP.py:96) -- autograd on a plain tensor would give it a gradient, the reference's Embedding does not.
+    -> (loss value, pre-clip global gradient norm)."""
+    optimizer.zero_grad(set_to_none=False)     # torch 0.3's zero_grad zero-FILLS: a table that has had a gradient once keeps being
+    loss = loss_fn()                            # updated (weight decay, Adam moments) on steps that do not touch it
+    loss.backward()
+    if pad_row_of is not None and pad_row_of.grad is not None:
+        pad_row_of.grad[-1].zero_()
+    norm = torch.nn.utils.clip_grad_norm_(params, clip_max)
+    optimizer.step()
+    return float(loss.detach()), float(norm)
+
+
 # ----------------------------------------------------------------------------- ranking walk (integer work -> numpy)
 def dcg_at_k(r, k, method=1):
     """utils/evaluation.py:41-77 (np.asfarray replaced by its definition)."""

@@ -15,6 +15,11 @@ Harness-side shims (none touches reference files):
      rule (ascending score, then ascending id) the build declares; on tie-free rows it is a no-op.
   4. The Gumbel uniforms the reference draws from torch's global generator are recovered by re-seeding
      and re-drawing a tensor of the same shape (torch.manual_seed(s); torch.empty(shape).uniform_()).
+  5. (train_step_cases only) Optimizer.zero_grad() zero-FILLS, as it did in the torch 0.3 the reference is written for
+     (README.md:5-9): modern torch's default set_to_none=True would make torch.optim skip every table a step does not touch
+     (no weight decay, no Adam moment decay on the user / item tables during KTUP's kg steps), which is not what
+     utils/trainer.py:79-84 did when it was written.  A table whose gradient is still None (never touched) is skipped in
+     both.
 """
 import argparse
 import json
@@ -466,8 +471,244 @@ def transr_d256_case():
     save('transr_d256', **out)
 
 
+def train_step_cases():
+    """G4 (post-optimizer-step tables) + G8 (joint schedule), SURVEY.md 8(c): the step bodies of the three drivers replayed line by
+    line on the reference's own modules -- knowledgable_recommendation.py:335-403 (jtransup: rec and kg steps under the joint
+    schedule of :209,320), item_recommendation.py:160-192 (transup, soft and ST-Gumbel gate), knowledge_representation.py:176-216
+    (transe / transh) -- with the reference's own ModelTrainer (utils/trainer.py:20-81: optimizer construction with
+    weight_decay = l2_lambda, optimizer_zero_grad, optimizer_step) and nn.utils.clip_grad_norm.  The drivers themselves cannot be
+    imported (models/base.py:2 needs gflags; losses.data[0] raises on 0-dim tensors), so their lines are restated here; FLAGS is
+    a plain namespace with the fields ModelTrainer reads.  Own seeds, own file: the earlier fixtures keep their draws.
+    Stored per case: initial tables (once per model), the batches, recorded Gumbel uniforms, per-step losses and pre-clip global
+    gradient norms, and the tables after the last step."""
+    import logging
+    import types
+    from jTransUP.utils import trainer as rtrainer
+    real_zero_grad = torch.optim.Optimizer.zero_grad
+    torch.optim.Optimizer.zero_grad = lambda self, set_to_none=False: real_zero_grad(self, set_to_none=False)      # shim 5
+    clip = getattr(torch.nn.utils, 'clip_grad_norm', None) or torch.nn.utils.clip_grad_norm_
+    rng = np.random.RandomState(47)
+    gen = torch.Generator().manual_seed(53)
+    e_vocab, i_vocab, kg2i, new_map, e_remap, i_remap, n_aligned = make_alignment(rng)
+    i_map = IntKeyDict(i_remap)
+    d, NSTEP = 64, 3
+    log = logging.getLogger('goldens'); log.setLevel(logging.ERROR)
+    out = {}
+
+    def flags(model_type, opt, l2, lr):
+        return types.SimpleNamespace(model_type=model_type, optimizer_type=opt, l2_lambda=l2, learning_rate=lr,
+                                     learning_rate_decay_when_no_progress=1.0, momentum=0.9, eval_interval_steps=10,
+                                     ckpt_path='/tmp', experiment_name='goldens', eval_only_mode=False, load_experiment_name=None)
+
+    def ids(hi, n=B):
+        return torch.from_numpy(rng.randint(0, hi, n)).long()
+
+    def run(tag, model, FL, steps, clip_max):
+        """steps: list of callables(model, trainer) -> loss Variable (the driver's loss lines).  Returns nothing; fills `out`."""
+        tr = rtrainer.ModelTrainer(model, log, 10, FL)
+        losses, norms = [], []
+        for body in steps:
+            tr.optimizer_zero_grad()
+            l = body(model, tr)
+            l.backward()
+            gn = clip([p for _, p in model.named_parameters()], clip_max)
+            tr.optimizer_step()
+            losses.append(float(l)); norms.append(float(gn))
+        out[tag + 'losses'] = np.asarray(losses, dtype=np.float64)
+        out[tag + 'gradnorms'] = np.asarray(norms, dtype=np.float64)
+        for k, p in model.named_parameters():
+            out[tag + 'final.' + k] = npy(p.data)
+        assert tr.step == len(steps)
+
+    # ---------------- KTUP (jtransup), the joint schedule: step s is a rec step iff s % 10 < 10 * joint_ratio
+    sched = {}
+    for jr in (0.5, 0.7, 0.9):
+        step_to_switch = 10 * jr                                            # knowledgable_recommendation.py:209
+        sched[str(jr)] = [bool(s % 10 < step_to_switch) for s in range(30)]   # :320
+    kt_batches = []
+    for s in range(6):
+        kt_batches.append(dict(u=ids(NU), pi=ids(NI), ni=ids(NI), ph=ids(NE), pt=ids(NE), pr=ids(NR), nh=ids(NE), nt=ids(NE)))
+    for s, b in enumerate(kt_batches):
+        out.update({'ktup.batch%d.%s' % (s, k): npy(v) for k, v in b.items()})
+    kg_lambda, margin = 0.5, 1.0
+    base = jtup.jTransUPModel(False, d, NU, NI, NE, NR, i_map, new_map, False, False)
+    sd = set_weights(base, gen)
+    out.update({'ktup.init.' + k: v for k, v in sd.items()})
+    out['ktup.item2ent'] = np.asarray(base.paddingItems(torch.arange(NI), base.ent_total - 1), dtype=np.int64)
+    keep = {k: p.data.clone() for k, p in base.named_parameters()}
+    kinds6 = [True, True, False, True, False, False]                       # steps 5..10 of joint_ratio 0.7 would read R R K K K R; any mix serves
+
+    def ktup_rec(b):
+        def body(m, tr):
+            pos = m((V(b['u']), V(b['pi'])), None, is_rec=True)
+            neg = m((V(b['u']), V(b['ni'])), None, is_rec=True)
+            l = rloss.bprLoss(pos, neg, target=tr.model_target)
+            return l + rloss.orthogonalLoss(m.pref_embeddings.weight, m.pref_norm_embeddings.weight)
+        return body
+
+    def ktup_kg(b):
+        def body(m, tr):
+            pos = m(None, (V(b['ph']), V(b['pt']), V(b['pr'])), is_rec=False)
+            neg = m(None, (V(b['nh']), V(b['nt']), V(b['pr'])), is_rec=False)
+            l = rloss.marginLoss()(pos, neg, margin)
+            ent = m.ent_embeddings(V(torch.cat([b['ph'], b['pt'], b['nh'], b['nt']])))
+            rel = m.rel_embeddings(V(torch.cat([b['pr'], b['pr']])))
+            nrm = m.norm_embeddings(V(torch.cat([b['pr'], b['pr']])))
+            l = l + rloss.orthogonalLoss(rel, nrm)
+            l = l + rloss.normLoss(ent) + rloss.normLoss(rel)
+            return kg_lambda * l
+        return body
+    out['ktup.kinds'] = np.asarray(kinds6, dtype=np.int64)
+    out['ktup.kg_lambda'] = np.asarray([kg_lambda]); out['ktup.margin'] = np.asarray([margin])
+    for opt, lr in (('Adagrad', 0.05), ('Adam', 0.01), ('SGD', 0.05)):
+        for l2 in (0.0, 1e-5):
+            if opt == 'SGD' and l2 == 0.0:
+                continue
+            m = jtup.jTransUPModel(False, d, NU, NI, NE, NR, i_map, new_map, False, False)
+            for k, p in m.named_parameters():
+                p.data.copy_(keep[k])
+            steps = [ktup_rec(b) if r else ktup_kg(b) for r, b in zip(kinds6, kt_batches)]
+            run('ktup.%s.l2_%g.' % (opt, l2), m, flags('jtransup', opt, l2, lr), steps, 5.0)
+
+    # ---------------- TUP (transup), soft and ST-Gumbel gate, item_recommendation.py:160-192
+    tup_batches = [dict(u=ids(NU), pi=ids(NI), ni=ids(NI)) for _ in range(NSTEP)]
+    for s, b in enumerate(tup_batches):
+        out.update({'tup.batch%d.%s' % (s, k): npy(v) for k, v in b.items()})
+    base = transUP.TransUPModel(False, d, NU, NI, NP_TUP, False)
+    sd = set_weights(base, gen)
+    out.update({'tup.init.' + k: v for k, v in sd.items()})
+    keep = {k: p.data.clone() for k, p in base.named_parameters()}
+
+    def tup_rec(b, seeds=None):
+        def body(m, tr):
+            if seeds is not None:
+                torch.manual_seed(seeds[0])
+            pos = m(V(b['u']), V(b['pi']))
+            if seeds is not None:
+                torch.manual_seed(seeds[1])
+            neg = m(V(b['u']), V(b['ni']))
+            l = rloss.bprLoss(pos, neg, target=tr.model_target)
+            ue = m.user_embeddings(V(b['u'])); ie = m.item_embeddings(V(torch.cat([b['pi'], b['ni']])))
+            return l + rloss.orthogonalLoss(m.pref_embeddings.weight, m.pref_norm_embeddings.weight) + rloss.normLoss(ue) + \
+                rloss.normLoss(ie) + rloss.normLoss(m.pref_embeddings.weight)
+        return body
+    for gum in (False, True):
+        for opt, lr, cmax in (('Adagrad', 0.05, 5.0), ('Adam', 0.01, 0.05)):          # 0.05: a clip that certainly bites
+            m = transUP.TransUPModel(False, d, NU, NI, NP_TUP, gum)
+            for k, p in m.named_parameters():
+                p.data.copy_(keep[k])
+            tag = 'tup.%s.%s.' % ('hard' if gum else 'soft', opt)
+            steps = []
+            for s, b in enumerate(tup_batches):
+                seeds = None
+                if gum:
+                    seeds = (500 + 2 * s, 501 + 2 * s)
+                    out[tag + 'uni%d.pos' % s] = npy(uniforms(seeds[0], (B, NP_TUP)))
+                    out[tag + 'uni%d.neg' % s] = npy(uniforms(seeds[1], (B, NP_TUP)))
+                steps.append(tup_rec(b, seeds))
+            out[tag + 'clip'] = np.asarray([cmax])
+            run(tag, m, flags('transup', opt, 1e-5, lr), steps, cmax)
+
+    # ---------------- TransE / TransH, knowledge_representation.py:176-216
+    kg_batches = [dict(ph=ids(NE), pt=ids(NE), pr=ids(NR), nh=ids(NE), nt=ids(NE)) for _ in range(NSTEP)]
+    for s, b in enumerate(kg_batches):
+        out.update({'kg.batch%d.%s' % (s, k): npy(v) for k, v in b.items()})
+    for name, mod, cls in (('transe', transE, 'TransEModel'), ('transh', transH, 'TransHModel')):
+        base = getattr(mod, cls)(False, d, NE, NR)
+        sd = set_weights(base, gen)
+        out.update({name + '.init.' + k: v for k, v in sd.items()})
+        keep = {k: p.data.clone() for k, p in base.named_parameters()}
+
+        def kg_body(b, name=name):
+            def body(m, tr):
+                pos, neg = m(V(b['ph']), V(b['pt']), V(b['pr'])), m(V(b['nh']), V(b['nt']), V(b['pr']))
+                l = rloss.marginLoss()(pos, neg, margin)
+                ent = m.ent_embeddings(V(torch.cat([b['ph'], b['pt'], b['nh'], b['nt']])))
+                rel = m.rel_embeddings(V(torch.cat([b['pr'], b['pr']])))
+                if name == 'transh':
+                    l = l + rloss.orthogonalLoss(rel, m.norm_embeddings(V(torch.cat([b['pr'], b['pr']]))))
+                return l + rloss.normLoss(ent) + rloss.normLoss(rel)
+            return body
+        for opt, lr in (('Adagrad', 0.05), ('Adam', 0.01)):
+            m = getattr(mod, cls)(False, d, NE, NR)
+            for k, p in m.named_parameters():
+                p.data.copy_(keep[k])
+            run('%s.%s.' % (name, opt), m, flags(name, opt, 1e-5, lr), [kg_body(b) for b in kg_batches], 5.0)
+    torch.optim.Optimizer.zero_grad = real_zero_grad
+    save('train_steps', **out)
+    with open(os.path.join(args.out, 'train_steps.json'), 'w') as f:
+        json.dump({'joint_schedule': sched, 'B': B, 'd': d, 'NP_TUP': NP_TUP}, f, indent=0, sort_keys=True)
+
+
+
+def eval_pass_cases():
+    """The whole evaluation pass of the rec drivers (item_recommendation.py:27-53 / knowledgable_recommendation.py:50-104):
+    model.evaluate / evaluateRec for EVERY user in batches, the reference's own evalRecProcess (worker processes, filter = union
+    of all_dicts, sign flip for `descending`), and the mean of the metric columns -- at d = 64 and d = 100, where the build's
+    one-sweep evaluation (scores + filtered top-n without the score matrix) applies.  Stored: tables, the eval / filter
+    dictionaries, per-user (f1, p, r, hit, ndcg) and top ids, and the pass means.  np.argsort forced stable (shim 3).  Own seeds."""
+    rng = np.random.RandomState(61)
+    gen = torch.Generator().manual_seed(67)
+    e_vocab, i_vocab, kg2i, new_map, e_remap, i_remap, n_aligned = make_alignment(rng)
+    i_map = IntKeyDict(i_remap)
+    NIe = 230                                # enough items for a filtered top-10 to be a real selection (a few 16-item tiles per user)
+    i_map_big = IntKeyDict({i: i for i in range(NIe)})
+    new_map_big = {i: ((int(rng.randint(0, NE)) if i % 4 else -1), i) for i in range(NIe)}
+    out, meta = {}, {}
+    real_argsort = np.argsort
+    np.argsort = lambda a, *aa, **kw: real_argsort(a, *aa, **dict(kw, kind='stable'))
+    try:
+        for d in (64, 100):
+            for name in ('tup', 'ktup'):
+                if name == 'tup':
+                    m = transUP.TransUPModel(False, d, NU, NIe, NP_TUP, False)
+                else:
+                    m = jtup.jTransUPModel(False, d, NU, NIe, NE, NR, i_map_big, new_map_big, False, False)
+                sd = set_weights(m, gen)
+                tag = '%s.d%d.' % (name, d)
+                out.update({tag + k: v for k, v in sd.items()})
+                if name == 'ktup':
+                    out[tag + 'item2ent'] = np.asarray(m.paddingItems(torch.arange(NIe), m.ent_total - 1), dtype=np.int64)
+                eval_dict, train_dict, valid_dict = {}, {}, {}
+                for u in range(NU):
+                    if u % 9 == 8:
+                        continue                                         # a user without test items is skipped (misc.py:169)
+                    perm = rng.permutation(NIe)
+                    ng, nt, nv = rng.randint(1, 6), rng.randint(0, 40), rng.randint(0, 8)
+                    eval_dict[u] = set(int(x) for x in perm[:ng])
+                    train_dict[u] = set(int(x) for x in perm[ng:ng + nt])
+                    if nv:
+                        valid_dict[u] = set(int(x) for x in perm[ng + nt:ng + nt + nv])
+                all_dicts = [train_dict, valid_dict]
+                users = list(range(NU))
+                results = []
+                for b0 in range(0, NU, 16):                              # the eval iterator's batches
+                    u_ids = users[b0:b0 + 16]
+                    scores = m.evaluate(V(torch.LongTensor(u_ids))) if name == 'tup' else m.evaluateRec(V(torch.LongTensor(u_ids)))
+                    preds = zip(u_ids, scores.data.cpu().numpy())
+                    results.extend(rmisc.evalRecProcess(list(preds), eval_dict, all_dicts=all_dicts, descending=False, num_processes=2,
+                                                        topn=10, queue_limit=10))
+                results.sort(key=lambda r: r[-1][0])                     # worker order is arbitrary; key by user id
+                perf = np.array([r[:5] for r in results], dtype=np.float64)
+                meta[tag.rstrip('.')] = {
+                    'eval': {str(u): sorted(v) for u, v in eval_dict.items()},
+                    'train': {str(u): sorted(v) for u, v in train_dict.items()},
+                    'valid': {str(u): sorted(v) for u, v in valid_dict.items()},
+                    'users': [int(r[-1][0]) for r in results],
+                    'top_ids': [[int(x) for x in r[-1][1]] for r in results],
+                    'mean': [float(x) for x in perf.mean(axis=0)]}
+                out[tag + 'perf'] = perf
+    finally:
+        np.argsort = real_argsort
+    save('eval_pass', **out)
+    with open(os.path.join(args.out, 'eval_pass.json'), 'w') as f:
+        json.dump(meta, f, indent=0, sort_keys=True)
+
+
 if __name__ == '__main__':
     i_map, new_map = score_cases()
     eval_cases(i_map, new_map)
     baseline_cases()
     transr_d256_case()
+    train_step_cases()
+    eval_pass_cases()

@@ -1,0 +1,61 @@
+"""The drivers' one-sweep evaluation (ktup_eval_pref_topk: scores + filtered top-n without the users x items matrix, then K18b's
+per-user metrics on the device) against a whole pass of the REFERENCE: model.evaluate / evaluateRec for every user, its own
+evalRecProcess (worker processes, filter sets, stable argsort) and the metric means (tests/golden/make_goldens.py
+eval_pass_cases: item_recommendation.py:27-53, knowledgable_recommendation.py:50-104, utils/misc.py:148-248).  Ranked ids
+bit-exact, metrics to 1e-12."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+KTUP_NAMES = ['user_embeddings.weight', 'item_embeddings.weight', 'ent_embeddings.weight', 'pref_embeddings.weight',
+              'pref_norm_embeddings.weight', 'rel_embeddings.weight', 'norm_embeddings.weight']
+TUP_NAMES = ['user_embeddings.weight', 'item_embeddings.weight', 'pref_embeddings.weight', 'pref_norm_embeddings.weight']
+
+
+def _csr(dicts, users, dtype=torch.int32):
+    off, ids = [0], []
+    for u in users:
+        s = set()
+        for dct in dicts:
+            s |= set(dct.get(str(u), []))
+        ids += sorted(s)
+        off.append(len(ids))
+    return torch.tensor(off, dtype=torch.int64, device=DEV), torch.tensor(ids, dtype=dtype, device=DEV)
+
+
+@pytest.mark.parametrize('name,d', [('tup', 64), ('ktup', 64), ('tup', 100), ('ktup', 100)])
+@pytest.mark.parametrize('route', ['one_sweep', 'score_matrix'])
+def test_fused_eval_pass_reproduces_the_reference_pass(name, d, route):
+    from jTransUP.hip import ops
+    g = np.load(os.path.join(GOLDEN, 'eval_pass.npz'))
+    J = json.load(open(os.path.join(GOLDEN, 'eval_pass.json')))['%s.d%d' % (name, d)]
+    tag = '%s.d%d.' % (name, d)
+    t = lambda n: torch.from_numpy(g[tag + n]).to(DEV)
+    users = J['users']                                                   # the users that have test items, ascending
+    u = torch.tensor(users, dtype=torch.int64, device=DEV)
+    f_off, f_ids = _csr([J['train'], J['valid']], users)
+    g_off, g_ids = _csr([J['eval']], users)
+    if name == 'tup':
+        U, I, P, Pn = (t(n) for n in TUP_NAMES)
+        items = ops.eval_pref_items(I, None, P, Pn, None, None, None)
+        full = lambda: ops.eval_tup(U, I, P, Pn, u, False, items=items)
+    else:
+        U, I, E, P, Pn, R, Rn = (t(n) for n in KTUP_NAMES)
+        i2e = t('item2ent').to(torch.int32)
+        items = ops.eval_pref_items(I, E, P, Pn, R, Rn, i2e)
+        full = lambda: ops.eval_ktup(U, I, E, P, Pn, R, Rn, i2e, u, False, items=items)
+    if route == 'one_sweep':
+        top = ops.eval_pref_topk(U, u, items, False, 10, f_off, f_ids)
+        assert top is not None                                           # the fused pass covers d = 64 / 100, squared L2, soft gate
+    else:
+        top = ops.topk_filtered(full(), False, 10, f_off, f_ids)
+    assert top.cpu().tolist() == J['top_ids']
+    perf = ops.rec_metrics(top, g_off, g_ids).cpu().numpy()
+    np.testing.assert_allclose(perf, g[tag + 'perf'], rtol=1e-12, atol=0)
+    np.testing.assert_allclose(perf.mean(axis=0), J['mean'], rtol=1e-12)

@@ -1,0 +1,159 @@
+"""RCCL for real on a 1-GPU box: init_process_group('nccl', world_size=1) and parallel.force_collectives(), so that every
+collective of the N > 1 paths is ISSUED on device tensors (torch.distributed's nccl backend is RCCL on ROCm) instead of being
+short-cut or staged through the host as in the gloo tests: the flat gradient bucket's all-reduce inside the captured
+data-parallel step, the all-to-alls / all-reduce of the row-sharded lookups, the all-gathers of the merged rankings.  With one
+rank each collective is the identity, so every result must equal the single-process one; what is exercised is the device-tensor
+branch of jTransUP/parallel.py, RCCL's stream ordering against the HIP launches around it, and RCCL inside HIP-graph capture.
+The reference has no distributed code; its single-process step is knowledgable_recommendation.py:330-403.
+One worker process per test (a process group lives and dies with it)."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def _spawn(fn, *args):
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(fn, args=(port,) + args, nprocs=1, join=True)
+
+
+def _init(port):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1')
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=0, world_size=1)
+    from jTransUP import parallel
+    parallel.force_collectives(True)
+    return dist, parallel
+
+
+def _replica_worker(rank, port):
+    dist, parallel = _init(port)
+    try:
+        ps = [torch.nn.Parameter(torch.randn(n, 12, device=DEV)) for n in (7, 33, 5)]
+        sync = parallel.ReplicaGradSync(ps, extra=8)
+        assert all(p.grad.data_ptr() >= sync.flat.data_ptr() for p in ps)
+        for k, p in enumerate(ps):
+            p.grad.fill_(float(k + 1))
+        sync.extra.fill_(0.25)
+        before = sync.flat.clone()
+        sync.all_reduce_grads()                                    # RCCL all-reduce over one rank: the identity, on the device bucket
+        torch.cuda.synchronize()
+        assert torch.equal(sync.flat, before)
+        sync.broadcast_params()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_replica_grad_sync_all_reduce_on_the_device_bucket():
+    _spawn(_replica_worker)
+
+
+def _dp_graph_worker(rank, port, tmp, D):
+    """The data-parallel joint step as ONE HIP graph with the RCCL all-reduce captured inside it, against the same schedule in
+    the same process without a process group semantics (force off, eager) -- tables and losses must agree bit for bit: the
+    all-reduce over one rank changes nothing."""
+    dist, parallel = _init(port)
+    try:
+        import copy
+        from test_fast_train import build
+        from jTransUP.utils.fast_train import JointStepper
+        FLAGS, m1, tr1, (NU, NI, NE, NR) = build(os.path.join(tmp, 'a'), 'Adagrad', False, D)
+        _, m2, tr2, _ = build(os.path.join(tmp, 'b'), 'Adagrad', False, D)
+        m2.load_state_dict(copy.deepcopy(m1.state_dict()))
+        B = 64
+        fast = JointStepper(m1, tr1, FLAGS, B)                       # nccl + forced collectives: graph replay with the all-reduce inside
+        assert fast.use_graphs
+        parallel.force_collectives(False)
+        plain = JointStepper(m2, tr2, FLAGS, B, use_graphs=False)
+        gen = torch.Generator().manual_seed(9)
+        rnd = lambda hi: torch.randint(0, hi, (B,), generator=gen).to(DEV)
+        for is_rec in [True, True, False, True, False, False, True, True, False]:
+            if is_rec:
+                ids = (rnd(NU), rnd(NI), rnd(NI))
+                parallel.force_collectives(True); la = float(fast.rec_step(*ids))
+                parallel.force_collectives(False); lb = float(plain.rec_step(*ids))
+            else:
+                ph, pt, pr, nh, nt = rnd(NE), rnd(NE), rnd(NR), rnd(NE), rnd(NE)
+                parallel.force_collectives(True); la = float(fast.kg_step(ph, pt, pr, nh, nt, pr))
+                parallel.force_collectives(False); lb = float(plain.kg_step(ph, pt, pr, nh, nt, pr))
+            assert abs(la - lb) <= 1e-6 * max(1.0, abs(lb))
+        assert fast._graphs and not plain._graphs
+        for (k, a), (_, b) in zip(m1.state_dict().items(), m2.state_dict().items()):
+            err = (a - b).abs()
+            bad = err > 2e-6 + 2e-5 * b.abs()                       # atomics order differs between replays; same bound as test_fast_train
+            assert float(bad.float().mean()) <= 2e-3 and float(err.max()) <= 1e-3 * 0.05, k
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('D', [64, 36])
+def test_data_parallel_step_is_one_graph_with_the_all_reduce_inside(tmp_path, D):
+    for r in ('a', 'b'):
+        os.makedirs(os.path.join(str(tmp_path), r))
+    _spawn(_dp_graph_worker, str(tmp_path), D)
+
+
+def _sharded_step_worker(rank, port):
+    """parallel.ShardedStep (the autograd-facing generic step): count / id / row all-to-alls and the fp64 all-reduce on device
+    tensors, against the dense single-process reference of tests/_sharded_case.py."""
+    dist, parallel = _init(port)
+    try:
+        import _sharded_case as C
+        from jTransUP.parallel import RowOps
+        for kind, lr in (('sgd', 0.5), ('adagrad', 0.1)):
+            C.check_against_dense(kind, lr, 0.7, 3, torch.device(DEV), RowOps, 0, 1, many=True, rtol=1e-4, atol=1e-5)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_step_lookups_over_rccl():
+    _spawn(_sharded_step_worker)
+
+
+def _sharded_eval_worker(rank, port):
+    """sharded_topk / sharded_gold_ranks: all-gather of the local top-n lists and the two all-reduces of the rank counts on
+    device tensors; one rank holds the whole catalogue, so the results are the plain ranking kernels'."""
+    dist, parallel = _init(port)
+    try:
+        from jTransUP.hip import ops
+        g = torch.Generator().manual_seed(5)
+        nq, n, topn = 9, 700, 10
+        scores = torch.randn(nq, n, generator=g).to(DEV)
+        f_off = torch.arange(0, 4 * (nq + 1), 4, dtype=torch.int64, device=DEV)
+        f_ids = torch.randint(0, n, (4 * nq,), generator=g).to(torch.int32).to(DEV)
+        ids, sc = parallel.sharded_topk(scores, 0, topn, False, f_off, f_ids)
+        want = ops.topk_filtered(scores, False, topn, f_off, f_ids)
+        assert torch.equal(ids.to(torch.int64), want.to(torch.int64))
+        g_off = torch.arange(0, 2 * (nq + 1), 2, dtype=torch.int64, device=DEV)
+        g_ids = torch.randint(0, n, (2 * nq,), generator=g).to(torch.int32).to(DEV)
+        g_rows = torch.arange(nq, device=DEV).repeat_interleave(2)
+        ranks = parallel.sharded_gold_ranks(scores, 0, False, g_off, g_ids, g_rows, f_off, f_ids)
+        want_r = ops.gold_ranks(scores, False, g_off, g_ids, f_off, f_ids)
+        assert torch.equal(ranks.to(torch.int64).cpu(), want_r.to(torch.int64).cpu()[:ranks.numel()])
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_candidate_ranking_over_rccl():
+    _spawn(_sharded_eval_worker)
+
+
+def test_bench_line_under_a_one_rank_rccl_job():
+    """bench.py as the driver launches it, with WORLD_SIZE=1 in the environment of a torch.distributed.run job."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
+           '--master-port', '29557', os.path.join(root, 'bench.py'), '--gpus', '1', '--steps', '4', '--warmup', '2', '--no-extras']
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(line) == 1 and json.loads(line[0])['n_gpus'] == 1

@@ -255,3 +255,112 @@ def test_transr_d256_seeded_golden(golden):
         tag = 'L1.' if l1 else 'L2.'
         close(O.score_transr(E, R, M, ph, pt, pr, l1), g[tag + 'pos'], rtol=2e-5, atol=2e-5)
         close(O.score_transr(E, R, M, nh, nt, pr, l1), g[tag + 'neg'], rtol=2e-5, atol=2e-5)
+
+
+# ------------------------------------------------------------------------------------------------ G4 / G8: whole training steps
+def _steps_fixture():
+    return np.load(os.path.join(GOLDEN, 'train_steps.npz')), json.load(open(os.path.join(GOLDEN, 'train_steps.json')))
+
+
+def _params(g, prefix, names):
+    return [torch.nn.Parameter(T(g[prefix + n]).clone()) for n in names]
+
+
+KTUP_NAMES = ['user_embeddings.weight', 'item_embeddings.weight', 'ent_embeddings.weight', 'pref_embeddings.weight',
+              'pref_norm_embeddings.weight', 'rel_embeddings.weight', 'norm_embeddings.weight']
+TUP_NAMES = ['user_embeddings.weight', 'item_embeddings.weight', 'pref_embeddings.weight', 'pref_norm_embeddings.weight']
+STEP_TOL = dict(rtol=2e-5, atol=2e-6)        # several optimizer steps of fp32 sums in a different association order
+
+
+def test_joint_schedule_golden():
+    """G8: which branch runs at step s (knowledgable_recommendation.py:209,320), as the reference's own expression decided it."""
+    _, J = _steps_fixture()
+    for ratio, flags in J['joint_schedule'].items():
+        assert [bool(O.is_rec_step(s, float(ratio))) for s in range(len(flags))] == flags
+
+
+@pytest.mark.parametrize('opt,lr,l2', [('Adagrad', 0.05, 0.0), ('Adagrad', 0.05, 1e-5), ('Adam', 0.01, 0.0), ('Adam', 0.01, 1e-5),
+                                       ('SGD', 0.05, 1e-5)])
+def test_ktup_training_steps_golden(opt, lr, l2):
+    """G4: six consecutive KTUP steps (rec, rec, kg, rec, kg, kg) through the reference's ModelTrainer -- losses, pre-clip
+    gradient norms and the tables after the last step."""
+    g, _ = _steps_fixture()
+    W = _params(g, 'ktup.init.', KTUP_NAMES)
+    i2e = T(g['ktup.item2ent'])
+    optim = O.make_optimizer(W, opt, lr, l2)
+    tag = 'ktup.%s.l2_%g.' % (opt, l2)
+    kg_lambda, margin = float(g['ktup.kg_lambda'][0]), float(g['ktup.margin'][0])
+    for s, is_rec in enumerate(g['ktup.kinds']):
+        b = {k: T(g['ktup.batch%d.%s' % (s, k)]) for k in ('u', 'pi', 'ni', 'ph', 'pt', 'pr', 'nh', 'nt')}
+        if is_rec:
+            fn = lambda: O.ktup_rec_step_loss(*W, i2e, b['u'], b['pi'], b['ni'])
+        else:
+            fn = lambda: O.kg_step_loss(W[2], W[5], W[6], b['ph'], b['pt'], b['pr'], b['nh'], b['nt'], b['pr'], margin=margin, kg_lambda=kg_lambda)
+        loss, norm = O.train_step(W, optim, fn, 5.0, pad_row_of=W[2])
+        np.testing.assert_allclose(loss, g[tag + 'losses'][s], rtol=2e-5)
+        np.testing.assert_allclose(norm, g[tag + 'gradnorms'][s], rtol=2e-5)
+    for w, n in zip(W, KTUP_NAMES):
+        close(w.data, g[tag + 'final.' + n], **STEP_TOL)
+    assert float(W[2].data[-1].abs().sum()) == 0.0 or l2 > 0 or opt != 'Adagrad'      # the pad row only ever moves by weight decay
+
+
+@pytest.mark.parametrize('gum', [False, True])
+@pytest.mark.parametrize('opt,lr', [('Adagrad', 0.05), ('Adam', 0.01)])
+def test_tup_training_steps_golden(gum, opt, lr):
+    g, _ = _steps_fixture()
+    W = _params(g, 'tup.init.', TUP_NAMES)
+    optim = O.make_optimizer(W, opt, lr, 1e-5)
+    tag = 'tup.%s.%s.' % ('hard' if gum else 'soft', opt)
+    clip = float(g[tag + 'clip'][0])
+    for s in range(3):
+        b = {k: T(g['tup.batch%d.%s' % (s, k)]) for k in ('u', 'pi', 'ni')}
+        up = T(g[tag + 'uni%d.pos' % s]) if gum else None
+        un = T(g[tag + 'uni%d.neg' % s]) if gum else None
+        loss, norm = O.train_step(W, optim, lambda: O.tup_rec_step_loss(*W, b['u'], b['pi'], b['ni'], uni_pos=up, uni_neg=un), clip)
+        np.testing.assert_allclose(loss, g[tag + 'losses'][s], rtol=2e-5)
+        np.testing.assert_allclose(norm, g[tag + 'gradnorms'][s], rtol=2e-5)
+    for w, n in zip(W, TUP_NAMES):
+        close(w.data, g[tag + 'final.' + n], **STEP_TOL)
+
+
+@pytest.mark.parametrize('name', ['transe', 'transh'])
+@pytest.mark.parametrize('opt,lr', [('Adagrad', 0.05), ('Adam', 0.01)])
+def test_kg_training_steps_golden(name, opt, lr):
+    g, _ = _steps_fixture()
+    names = ['ent_embeddings.weight', 'rel_embeddings.weight'] + (['norm_embeddings.weight'] if name == 'transh' else [])
+    W = _params(g, name + '.init.', names)
+    optim = O.make_optimizer(W, opt, lr, 1e-5)
+    tag = '%s.%s.' % (name, opt)
+    for s in range(3):
+        b = {k: T(g['kg.batch%d.%s' % (s, k)]) for k in ('ph', 'pt', 'pr', 'nh', 'nt')}
+        N = W[2] if name == 'transh' else None
+        loss, norm = O.train_step(W, optim, lambda: O.kg_step_loss(W[0], W[1], N, b['ph'], b['pt'], b['pr'], b['nh'], b['nt'], b['pr']), 5.0)
+        np.testing.assert_allclose(loss, g[tag + 'losses'][s], rtol=2e-5)
+        np.testing.assert_allclose(norm, g[tag + 'gradnorms'][s], rtol=2e-5)
+    for w, n in zip(W, names):
+        close(w.data, g[tag + 'final.' + n], **STEP_TOL)
+
+
+# ------------------------------------------------------------------------------------------------ whole evaluation pass
+@pytest.mark.parametrize('name,d', [('tup', 64), ('ktup', 64), ('tup', 100), ('ktup', 100)])
+def test_eval_pass_golden(name, d):
+    """item_recommendation.py:27-53 / knowledgable_recommendation.py:50-104 through the reference's own evalRecProcess: the
+    oracle's all-item scores + ranking walk reproduce the per-user metric rows, the ranked ids and the pass means."""
+    g = np.load(os.path.join(GOLDEN, 'eval_pass.npz'))
+    J = json.load(open(os.path.join(GOLDEN, 'eval_pass.json')))['%s.d%d' % (name, d)]
+    tag = '%s.d%d.' % (name, d)
+    eval_dict = {int(u): set(v) for u, v in J['eval'].items()}
+    all_dicts = [{int(u): set(v) for u, v in J[k].items()} for k in ('train', 'valid')]
+    users = torch.arange(37)
+    if name == 'tup':
+        W = [T(g[tag + n]) for n in TUP_NAMES]
+        scores = O.eval_tup(*W, users, False)
+    else:
+        W = [T(g[tag + n]) for n in KTUP_NAMES]
+        scores = O.eval_ktup_rec(*W, T(g[tag + 'item2ent']), users, False)
+    rows = O.eval_rec_rows(list(zip(users.tolist(), scores.numpy())), eval_dict, all_dicts, descending=False, topn=10)
+    rows.sort(key=lambda r: r[-1][0])
+    assert [r[-1][0] for r in rows] == J['users']
+    assert [[int(x) for x in r[-1][1]] for r in rows] == J['top_ids']
+    np.testing.assert_allclose(np.array([r[:5] for r in rows]), g[tag + 'perf'], rtol=1e-12, atol=0)
+    np.testing.assert_allclose(np.array([r[:5] for r in rows]).mean(axis=0), J['mean'], rtol=1e-12)

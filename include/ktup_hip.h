@@ -554,6 +554,10 @@ int ktup_train_kg_step(int transh, const float* E, int64_t lde, const float* R, 
                        int d, const int64_t* h, const int64_t* t, const int64_t* r, int64_t B, int l1, float margin,
                        float gscale, int regs, float* loss, float* gE, float* gR, float* gN, void* stream);
 #define KTUP_OPTIM_WS_DOUBLES 784
+/* largest grid of ktup_optim_clip_step on the current device: its grid barrier needs every workgroup resident at once, so the
+ * launch is sized from the occupancy query x the CU count (one workgroup per CU short of it), at most 512; 0 = unknown (the
+ * one-launch entry point then refuses and the caller uses ktup_optim_gradnorm + ktup_optim_step).                           */
+int ktup_optim_clip_step_capacity(int kind);
 int ktup_optim_clip_step(int kind, int n_tensors, float* const* params, float* const* grads, float* const* state1,
                          float* const* state2, const int64_t* sizes, const int64_t* steps, const int64_t* steps_dev,
                          const int32_t* first, float lr, float weight_decay, float momentum, float beta1, float beta2, float eps,

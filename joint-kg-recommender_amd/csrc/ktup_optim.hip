@@ -478,6 +478,49 @@ extern "C" int ktup_optim_step(int kind, int n_tensors, float* const* params, fl
   return check_launch("ktup_optim_step");
 }
 
+namespace {
+
+// How many clip_step workgroups can be RESIDENT at once on the current device: the hand-rolled grid barrier needs them all.
+// occupancy query x compute units, one workgroup per CU short of it (MI355X_MICROARCH.md: the API answer can be one block per
+// CU too high when the kernel's SGPR count is 81-112, and a surplus block would strand the barrier), never more than
+// CS_MAX_WG.  Cached per (device, optimizer kind).  0 = the query failed: the caller keeps the two-launch route.
+template <int KIND>
+int cs_capacity() {
+  static int cached_dev = -1, cached = 0;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  if (dev == cached_dev) return cached;
+  int per_cu = 0, cus = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)clip_step_kernel<KIND>, 256, 0) != hipSuccess ||
+      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  if (per_cu > 8) per_cu = 8;
+  if (per_cu > 1) per_cu -= 1;
+  int cap = per_cu * cus;
+  cached_dev = dev;
+  cached = cap < CS_MAX_WG ? cap : CS_MAX_WG;
+  return cached;
+}
+
+int cs_capacity_of(int kind) {
+  switch (kind) {
+    case KTUP_OPT_SGD: return cs_capacity<KTUP_OPT_SGD>();
+    case KTUP_OPT_ADAGRAD: return cs_capacity<KTUP_OPT_ADAGRAD>();
+    case KTUP_OPT_ADAM: return cs_capacity<KTUP_OPT_ADAM>();
+    default: return cs_capacity<KTUP_OPT_RMSPROP>();
+  }
+}
+
+}  // namespace
+
+// The largest grid ktup_optim_clip_step will launch on the current device (all of it resident at once), 0 if unknown.
+extern "C" int ktup_optim_clip_step_capacity(int kind) {
+  if (kind < KTUP_OPT_SGD || kind > KTUP_OPT_RMSPROP) return 0;
+  return cs_capacity_of(kind);
+}
+
 // ktup_optim_gradnorm + ktup_optim_step as one launch (see clip_step_kernel); `ws`: KTUP_OPTIM_WS_DOUBLES doubles, zero-filled
 // ONCE by the caller and left consistent by every launch ([0] = the squared norm of the last clipped step).
 extern "C" int ktup_optim_clip_step(int kind, int n_tensors, float* const* params, float* const* grads, float* const* state1,
@@ -496,7 +539,10 @@ extern "C" int ktup_optim_clip_step(int kind, int n_tensors, float* const* param
   if (nunits == 0 && !loss_slots) return KTUP_OK;
   const Hyper h{lr, weight_decay, momentum, beta1, beta2, eps, alpha, max_norm, zero_grads};
   hipStream_t st = (hipStream_t)stream;
-  const dim3 grid((unsigned)(nunits < 1 ? 1 : nunits < CS_MAX_WG ? nunits : CS_MAX_WG)), block(256);
+  const int cap = cs_capacity_of(kind);
+  if (cap <= 0)
+    return set_error(KTUP_ERR_UNSUPPORTED, "%s: cannot size a resident grid on this device (occupancy query failed): use ktup_optim_gradnorm + ktup_optim_step", name);
+  const dim3 grid((unsigned)(nunits < 1 ? 1 : nunits < cap ? nunits : cap)), block(256);
   switch (kind) {
     case KTUP_OPT_SGD:
       hipLaunchKernelGGL(clip_step_kernel<KTUP_OPT_SGD>, grid, block, 0, st, T, h, ws, loss_slots, n_slots, loss_scale, loss_out, loss_acc, steps_dev);

@@ -39,9 +39,13 @@ class CFKG(nn.Module, GradToggle):
         E, R = self.ent_embeddings.weight, self.rel_embeddings.weight
         if is_rec and ratings is not None:
             u_ids, i_ids = ratings
-            stacked = torch.cat([self.user_embeddings.weight, E])
+            # CFKG.py:66-80 : user + buy - item-entity, on the batch's rows only (heads = the gathered user rows, tails = the
+            # gathered entity rows of one 2B-row table) instead of concatenating the two whole tables per step
+            n = u_ids.numel()
+            both = torch.cat([self.user_embeddings(u_ids), self.ent_embeddings(i_ids)])
+            at = torch.arange(n, device=u_ids.device)
             buy = torch.full_like(u_ids, self.rel_total - 1)
-            return ops.score_transe(stacked, R, u_ids, i_ids + self.user_total, buy, self.L1_flag)        # CFKG.py:66-80
+            return ops.score_transe(both, R, at, at + n, buy, self.L1_flag)
         if not is_rec and triples is not None:
             h, t, r = triples
             return ops.score_transe(E, R, h, t, r, self.L1_flag)                                             # CFKG.py:81-92

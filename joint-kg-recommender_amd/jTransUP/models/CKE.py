@@ -58,7 +58,10 @@ class CKE(nn.Module, GradToggle):
     def forward(self, ratings, triples, is_rec=True):
         if is_rec and ratings is not None:
             u_ids, i_ids = ratings
-            return ops.score_bprmf(self.user_embeddings.weight, self._item_side(), u_ids, i_ids)          # CKE.py:122-135
+            # CKE.py:122-135 on the BATCH's rows only: item row + aligned entity row (pad row = zero) gathered per pair, so a
+            # step costs O(batch) memory traffic, not a pass over the item table (the full table is built for evaluateRec only)
+            iv = self.item_embeddings(i_ids) + self.ent_embeddings(self._item2ent[i_ids])
+            return ops.score_bprmf(self.user_embeddings.weight, iv, u_ids, torch.arange(i_ids.numel(), device=i_ids.device))
         if not is_rec and triples is not None:
             h, t, r = triples
             return ops.score_transr(self.ent_embeddings.weight, self.rel_embeddings.weight, self.proj_embeddings.weight, h, t, r,

@@ -91,6 +91,8 @@ def rank_index(eval_iter, eval_dict, all_dicts):
     hit = _INDEX_CACHE.get(key)
     if hit is None or hit[0] is not eval_iter or hit[1] is not eval_dict:
         hit = (eval_iter, eval_dict, all_dicts, RankIndex(flat_keys(eval_iter), eval_dict, all_dicts, DEV))
+        if len(_INDEX_CACHE) > 16:                    # bounded like the graph / pinned-buffer caches: long-lived processes build many iterators
+            _INDEX_CACHE.clear()
         _INDEX_CACHE[key] = hit
     return hit[3]
 
@@ -215,6 +217,8 @@ def _rec_eval_fused(FLAGS, pass_fn, eval_iter, index, graph_key=None):
     from jTransUP.hip import ops
     hit = _PASS_IDS.get(id(eval_iter))
     if hit is None or hit[0] is not eval_iter:
+        if len(_PASS_IDS) > 16:
+            _PASS_IDS.clear()
         hit = _PASS_IDS[id(eval_iter)] = (eval_iter, ids([u for batch in eval_iter for u in batch]))
     users = hit[1]
     if users.numel() == 0:
@@ -290,6 +294,8 @@ def _kg_eval_fused(FLAGS, rank_fn, eval_iter, index, descending, remap, want_row
     hit = _KG_PASS_IDS.get(id(eval_iter))
     if hit is None or hit[0] is not eval_iter or hit[2] is not remap:
         keys = [k for batch in eval_iter for k in batch]
+        if len(_KG_PASS_IDS) > 16:
+            _KG_PASS_IDS.clear()
         hit = _KG_PASS_IDS[id(eval_iter)] = (eval_iter, (ids([k[0] if remap is None else remap[k[0]] for k in keys]), ids([k[1] for k in keys])), remap)
     q_dev, r_dev = hit[1]
     if q_dev.numel() == 0 or len(index.g_ids_h) == 0:
@@ -411,9 +417,25 @@ def clip_and_step(FLAGS, model, trainer):
     trainer.clip_and_step(FLAGS.clipping_max_value)
 
 
-def steps_before_pause(FLAGS, step):
-    """How many consecutive steps may run from `step` before the loop has to look again (next evaluation, end of training)."""
-    return min(FLAGS.eval_interval_steps - step % FLAGS.eval_interval_steps, FLAGS.training_steps - step)
+def steps_before_pause(FLAGS, step, best_step=None):
+    """How many consecutive steps may run from `step` before the loop has to look again: the next evaluation, the end of
+    training, or (best_step given) the step at which the reference loop's early-stopping test first fires
+    (step - best_step > early_stopping_steps_to_wait, e.g. knowledgable_recommendation.py:215-217)."""
+    n = min(FLAGS.eval_interval_steps - step % FLAGS.eval_interval_steps, FLAGS.training_steps - step)
+    if best_step is not None and FLAGS.early_stopping_steps_to_wait > 0:
+        n = min(n, max(1, best_step + FLAGS.early_stopping_steps_to_wait + 1 - step))
+    return n
+
+
+def _check_clip_barrier(trainer):
+    """The one-launch clip + optimizer kernel waits at a hand-rolled grid barrier; if its workgroups were ever not all resident
+    (a GPU shared with another job), the poll timed out and that step went unclipped -- not the reference's step.  Checked where
+    the loop syncs anyway; raises rather than training on."""
+    fused = getattr(trainer, 'fused', None)
+    if fused is not None and fused.barrier_timeouts():
+        from jTransUP.hip.lib import KtupError
+        raise KtupError('ktup_optim_clip_step timed out at its grid barrier (the GPU is shared or partitioned): at least one step was '
+                        'applied without the global-norm clip.  Re-run with KTUP_CLIP_STEP=0 (two launches, no barrier).')
 
 
 def training_loop(FLAGS, model, trainer, logger, do_step, do_eval, loss_names, on_train_mode=None, sampler=None, stepper=None):
@@ -439,6 +461,7 @@ def training_loop(FLAGS, model, trainer, logger, do_step, do_eval, loss_names, o
                     totals[k] = totals.get(k, 0.0) + v
             if sampler is not None:
                 sampler.check()
+            _check_clip_barrier(trainer)
             do_eval(totals)
             pbar = tqdm(total=FLAGS.eval_interval_steps, desc='Training')
             for v in sums.values():
@@ -453,3 +476,4 @@ def training_loop(FLAGS, model, trainer, logger, do_step, do_eval, loss_names, o
         pbar.close()
     if sampler is not None:
         sampler.check()
+    _check_clip_barrier(trainer)

@@ -79,7 +79,7 @@ def train_loop(FLAGS, model, trainer, train_dataset, eval_datasets, user_total, 
     def do_step(step):
         if feed is not None:
             if stepper.can_feed('rec'):                    # batch + negatives drawn inside the step's own graph
-                if D.steps_before_pause(FLAGS, step) >= 10 and stepper.fed_cycle(('rec',) * 10):
+                if D.steps_before_pause(FLAGS, step, trainer.best_step) >= 10 and stepper.fed_cycle(('rec',) * 10):
                     return 'rec', None                     # ten steps in one replay; losses are summed on the device
                 stepper.fed_step('rec')
                 return 'rec', None                         # (stepper.take_sums)

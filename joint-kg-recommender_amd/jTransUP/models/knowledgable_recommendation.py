@@ -163,7 +163,7 @@ def train_loop(FLAGS, model, trainer, rating_train_dataset, triple_train_dataset
         if stepper is not None and rec_feed is not None:
             kind = 'rec' if is_rec else 'kg'
             if stepper.can_feed(kind):                     # batch + negatives drawn inside the step's own graph
-                if step % 10 == 0 and D.steps_before_pause(FLAGS, step) >= 10 and stepper.fed_cycle(cycle10):
+                if step % 10 == 0 and D.steps_before_pause(FLAGS, step, trainer.best_step) >= 10 and stepper.fed_cycle(cycle10):
                     return kind, None                      # ten steps in one replay; losses are summed on the device
                 stepper.fed_step(kind)
                 return kind, None                          # (stepper.take_sums)

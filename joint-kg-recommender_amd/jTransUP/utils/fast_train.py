@@ -636,8 +636,11 @@ class DeviceFeeder(object):
         self.gen = torch.Generator(device=device)
         self.gen.manual_seed(int(seed))
         self.n = rows.shape[0]
-        if self.n * self.rep < self.B:
-            raise ValueError('fewer training examples (%d) than one batch (%d)' % (self.n * self.rep, self.B))
+        if self.n < self.B:
+            # the reference slices a batch out of the replicated order list even when n < B <= n * negtive_samples
+            # (data.py:87-110); here an epoch's columns hold the n distinct examples only, so a full batch must fit in them
+            raise ValueError('fewer distinct training examples (%d) than one batch (%d): lower -batch_size (negtive_samples does '
+                             'not add rows to an epoch of the device-resident feeder)' % (self.n, self.B))
         # column-major: a batch is then a contiguous SLICE of this epoch's shuffled columns (no per-step gather launches), and
         # the columns live in fixed storage, reshuffled in place -- what the feed kernels' graph-static arguments point at
         self.src = [rows[:, c].contiguous() for c in range(rows.shape[1])]

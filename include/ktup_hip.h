@@ -309,6 +309,15 @@ int ktup_eval_gold_ranks(const float* scores, int64_t lds, int64_t nq, int64_t n
  * per-batch route.  model: KTUP_KG_TRANSE (Nrm ignored) or KTUP_KG_TRANSH; head / l1 / C as in ktup_eval_trans{e,h}_scores. */
 #define KTUP_KG_TRANSE 0
 #define KTUP_KG_TRANSH 1
+/* TransR (transR.py:80-128): the same pass over the entity table; ents_ws = ktup_eval_transr_prepare's output for these tables
+ * (NULL: the entity side is recomputed per chunk).  The score matrix of a chunk is double-buffered and K18 of chunk c runs on a
+ * library-owned second stream beside the score kernel of chunk c + 1 (not during graph capture).                              */
+size_t ktup_eval_kg_ranks_transr_workspace_bytes(int d, int64_t n_ent, int n_rel, int64_t chunk);
+int ktup_eval_kg_ranks_transr(const float* E, int64_t lde, const float* R, int64_t ldr, const float* M, int64_t ldm, int d,
+                              int64_t n_ent, int n_rel, const float* ents_ws, const int64_t* q, const int64_t* r, int64_t nq,
+                              int l1, int head, int descending, const int64_t* filt_off, const int32_t* filt_ids,
+                              const int64_t* gold_off, const int32_t* gold_ids, int32_t* ranks, int64_t chunk, void* ws,
+                              void* stream);
 size_t ktup_eval_kg_ranks_workspace_bytes(int d, int64_t n_cand, int64_t chunk);
 int ktup_eval_kg_ranks(int model, const float* E, int64_t lde, const float* R, int64_t ldr, const float* Nrm, int64_t ldn, int d,
                        const float* C, int64_t ldc, int64_t n_cand, const int64_t* q, const int64_t* r, int64_t nq, int l1,

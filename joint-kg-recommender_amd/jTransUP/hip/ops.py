@@ -428,6 +428,25 @@ def eval_kg_ranks(E, R, N, q, r, l1, head, descending, gold_off, gold_ids, filt_
     return ranks
 
 
+@torch.no_grad()
+def eval_kg_ranks_transr(E, R, M, q, r, l1, head, descending, gold_off, gold_ids, filt_off=None, filt_ids=None, ents=None, chunk=512):
+    """eval_kg_ranks for TransR (ktup_eval_kg_ranks_transr): K14 per chunk of keys against the entity side `ents`
+    (eval_transr_entities, once per pass) + K18, the loop under the C ABI."""
+    dev = _dev(_table('entity table', E)); _table('relation table', R); _table('projection table', M)
+    nq = q.numel(); q = _ids('q', q, dev); r = _ids('r', r, dev, nq)
+    if gold_off.numel() != nq + 1 or (filt_off is not None and filt_off.numel() != nq + 1):
+        raise L.KtupError('eval_kg_ranks_transr: CSR offsets need len(q) + 1 entries')
+    if ents is not None and (ents.shape != (E.shape[0], E.shape[1], R.shape[0]) or ents.l1 != bool(l1)):
+        raise L.KtupError('prepared entity side does not match the tables / distance kind')
+    ranks = torch.empty(max(gold_ids.numel(), 1), dtype=torch.int32, device=dev)
+    chunk = max(1, min(int(chunk), max(nq, 1)))
+    ws = _scratch(L.load().ktup_eval_kg_ranks_transr_workspace_bytes(E.shape[1], E.shape[0], R.shape[0], chunk), dev)
+    L.call('ktup_eval_kg_ranks_transr', _p(E), E.stride(0), _p(R), R.stride(0), _p(M), M.stride(0), E.shape[1], E.shape[0], R.shape[0],
+           _p(None if ents is None else ents.ws), _p(q), _p(r), nq, int(l1), int(head), int(bool(descending)), _p(filt_off), _p(filt_ids),
+           _p(gold_off), _p(gold_ids), _p(ranks), chunk, _p(ws), _stream(dev))
+    return ranks
+
+
 class PreparedEntities(object):
     """Entity side of K14 for one evaluation pass (ktup_eval_transr_prepare): valid while the tables it was built from do not
     change, for the distance kind it was built for."""

@@ -22,11 +22,13 @@ def evaluate(FLAGS, model, entity_total, relation_total, eval_head_iter, eval_ta
     model.eval(); model.disable_grad()
     from jTransUP.models._shard_eval import kg_shard_fn
     head_fn, tail_fn = model.evaluateHead, model.evaluateTail
+    kw = {}
     if hasattr(model, 'prepare_entities'):           # TransR: the entity side of both passes, once (it does not depend on the queries)
         ents = model.prepare_entities()
         head_fn, tail_fn = (lambda t, r: model.evaluateHead(t, r, ents=ents)), (lambda h, r: model.evaluateTail(h, r, ents=ents))
-    # models with rank_entities (TransE, TransH): the whole pass -- scores and filtered gold ranks -- behind one call per direction
-    rank = (lambda head: (lambda q, r, desc, go, gi, fo, fi: model.rank_entities(q, r, head, desc, go, gi, fo, fi))) \
+        kw = {'ents': ents}
+    # models with rank_entities (TransE, TransH, TransR): the whole pass -- scores and filtered gold ranks -- behind one call per direction
+    rank = (lambda head: (lambda q, r, desc, go, gi, fo, fi: model.rank_entities(q, r, head, desc, go, gi, fo, fi, **kw))) \
         if hasattr(model, 'rank_entities') else (lambda head: None)
     head_results = D.kg_eval_pass(FLAGS, head_fn, eval_head_iter, eval_head_dict, all_head_dicts, eval_descending,
                                   want_rows=is_report, shard=kg_shard_fn(model, True), rank_fn=rank(True))

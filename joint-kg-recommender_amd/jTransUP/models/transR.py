@@ -50,3 +50,9 @@ class TransRModel(nn.Module, GradToggle):
         """K14 (transR.py:105-128)."""
         E, R, M = self._tables()
         return ops.eval_transr(E, R, M, h, r, self.L1_flag, head=False, ents=ents)
+
+    def rank_entities(self, q, r, head, descending, gold_off, gold_ids, filt_off=None, filt_ids=None, ents=None):
+        """A whole evaluateHead / evaluateTail pass + the filtered gold ranks of utils/misc.py:125-146 in one call (K14 + K18 per
+        chunk of 512 keys under the C ABI, the rank kernel of a chunk beside the score kernel of the next)."""
+        E, R, M = self._tables()
+        return ops.eval_kg_ranks_transr(E, R, M, q, r, self.L1_flag, head, descending, gold_off, gold_ids, filt_off, filt_ids, ents=ents)

@@ -530,6 +530,36 @@ def test_kg_ranks_whole_pass_equals_the_batch_walk(model):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('d,l1', [(64, False), (100, False), (36, False), (64, True)])
+def test_kg_ranks_whole_pass_transr(d, l1):
+    """ktup_eval_kg_ranks_transr (TransR's pass under the C ABI: K14 per chunk of 512 keys against the once-prepared entity side +
+    K18, the rank kernel of a chunk on a second stream beside the next chunk's scores) returns the integers of the per-batch
+    route: 1,300 keys = two full chunks + a ragged one, head and tail, with and without a prepared entity side."""
+    rng = np.random.RandomState(29)
+    ne, nr, nq = 500, 5, 1300
+    gen = torch.Generator().manual_seed(6)
+    E, R = O.make_table(ne, d, gen), O.make_table(nr, d, gen)
+    M = torch.randn(nr, d * d, generator=gen) * 0.1
+    q = torch.from_numpy(rng.randint(0, ne, size=nq)); r = torch.from_numpy(rng.randint(0, nr, size=nq))
+    _, filt, gold, f_off, f_ids, g_off, g_ids = _rank_case(rng, nq, ne, 40, 5, 0)
+    Ed, Rd, Md = dv(E.numpy()), dv(R.numpy()), dv(M.numpy())
+    qd, rd = q.to(DEV), r.to(DEV)
+    ents = ops().eval_transr_entities(Ed, Md, nr, l1)
+    for head in (True, False):
+        for use_ents in (True, False):
+            got = ops().eval_kg_ranks_transr(Ed, Rd, Md, qd, rd, l1, head, False, dv(g_off), dv(g_ids), dv(f_off), dv(f_ids),
+                                             ents=ents if use_ents else None)
+            want = []
+            for s in range(0, nq, 512):
+                e = min(nq, s + 512)
+                sc = ops().eval_transr(Ed, Rd, Md, qd[s:e], rd[s:e], l1, head, ents=ents if use_ents else None)
+                lo = int(g_off[s])
+                want.append(ops().gold_ranks(sc, False, dv(g_off[s:e + 1] - lo), dv(g_ids[lo:]), dv(f_off[s:e + 1] - f_off[s]),
+                                             dv(f_ids[int(f_off[s]):]))[:int(g_off[e]) - lo])
+            assert torch.equal(got[:len(g_ids)], torch.cat(want))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('want_rows', [False, True])
 def test_kg_eval_pass_whole_pass_route_equals_the_batch_walk(want_rows, monkeypatch):
     """_driver.kg_eval_pass with a model's rank_entities (scores + filtered gold ranks of the WHOLE pass behind one call) returns

@@ -12,8 +12,8 @@ from jTransUP.utils import flags as gflags
 
 # -model_type -> module under jTransUP.models that provides build_model(...)
 ACCELERATED = {'transup': 'transUP', 'bprmf': 'bprmf', 'transe': 'transE', 'transh': 'transH', 'transr': 'transR',
-               'jtransup': 'jTransUP', 'cke': 'CKE', 'cfkg': 'CFKG'}
-REFERENCE_ONLY = ('fm', 'transd', 'cofm')      # baselines of the reference outside the accelerated path (FM-family: no kernel here)
+               'jtransup': 'jTransUP', 'cke': 'CKE', 'cfkg': 'CFKG', 'fm': 'fm', 'cofm': 'cofm'}
+REFERENCE_ONLY = ('transd',)      # TransD: outside SURVEY.md section 8 (and its evaluateTail has a NameError in the reference, transD.py:127)
 MODEL_TYPES = ['transup', 'bprmf', 'fm', 'transe', 'transh', 'transr', 'transd', 'cfkg', 'cke', 'cofm', 'jtransup']
 DATASETS = ['ml1m', 'dbbook2014', 'amazon-book', 'last-fm', 'yelp2018']
 

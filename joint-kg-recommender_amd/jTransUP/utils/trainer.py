@@ -152,5 +152,10 @@ class ModelTrainer(object):
             new_ids = torch.tensor(list(remap.values()), dtype=torch.long)
             table[new_ids.to(table.device)] = rows[old_ids].to(table.device)
             self.logger.info('Restored ' + str(len(remap)) + ' ' + what + ' from checkpoint.')
+            if key == 'item_embeddings' and 'item_bias.weight' in merged and 'item_bias.weight' in wanted:      # coFM (trainer.py:202-211)
+                bias = merged.pop('item_bias.weight')
+                mine = self.model.item_bias.weight.data
+                mine[new_ids.to(mine.device)] = bias[old_ids].to(mine.device)
+                self.logger.info('Restored ' + str(len(remap)) + ' items bias from checkpoint.')
         self.model.load_state_dict(merged, strict=False)
         self.logger.info('Load Embeddings of {} from {}.'.format(', '.join(wanted), filename))

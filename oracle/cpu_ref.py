@@ -73,6 +73,16 @@ def score_bprmf(U, I, u, i):
     return torch.bmm(U[u].unsqueeze(1), I[i].unsqueeze(2)).reshape(-1)
 
 
+def score_fm(U, I, ub, ib, bias, u, i):
+    """fm.py:58-67 / cofm.py:99-108 : global bias + user bias + item bias + u . i."""
+    return bias + ub[u] + ib[i] + (U[u] * I[i]).sum(1)
+
+
+def eval_fm(U, I, ub, ib, bias, u):
+    """fm.py:69-80 / cofm.py:127-141 -> (len(u), n_items)."""
+    return bias + ub[u][:, None] + ib[None, :] + U[u] @ I.t()
+
+
 def score_transe(E, R, h, t, r, l1):
     """transE.py:51-63."""
     return _dist(E[h] + R[r] - E[t], l1, 1)

@@ -20,6 +20,10 @@ Harness-side shims (none touches reference files):
      (no weight decay, no Adam moment decay on the user / item tables during KTUP's kg steps), which is not what
      utils/trainer.py:79-84 did when it was written.  A table whose gradient is still None (never touched) is skipped in
      both.
+  6. (fm_cases only) fm.py / cofm.py do not construct on a modern torch: `nn.Parameter(bias, 1)` passes an int where a bool is
+     required now, and their bias tables are nn.Embedding modules whose weight is 1-D, which torch.embedding no longer accepts.
+     While those two models are built and run, nn.Parameter coerces requires_grad with bool() and F.embedding serves a 1-D weight
+     by weight.index_select(0, ids) (what the torch-0.3 backend did).  The models' own lines are untouched.
 """
 import argparse
 import json
@@ -705,6 +709,79 @@ def eval_pass_cases():
         json.dump(meta, f, indent=0, sort_keys=True)
 
 
+
+def fm_cases():
+    """FM (fm.py) and coFM (cofm.py, shared and separate item tables): scores, BPR (target +1, trainer.py:15-17) / margin losses with
+    the drivers' regularisers, gradients, and the all-candidate evaluation matrices.  Shim 6.  Own seeds, own file."""
+    import torch.nn as tnn
+    import torch.nn.functional as TF
+    real_new, real_emb = tnn.Parameter.__new__, TF.embedding
+
+    def param_new(cls, data=None, requires_grad=True):
+        return real_new(cls, data, bool(requires_grad))
+
+    def emb(input, weight, *a, **kw):
+        if weight.dim() == 1:
+            return weight.index_select(0, input.reshape(-1)).reshape(input.shape)
+        return real_emb(input, weight, *a, **kw)
+    tnn.Parameter.__new__ = staticmethod(param_new)
+    TF.embedding = emb
+    try:
+        from jTransUP.models import fm as rfm, cofm as rcofm
+        rng = np.random.RandomState(71)
+        gen = torch.Generator().manual_seed(73)
+        out = {}
+        BQ = 9
+        for d in (36, 64):
+            pre = 'd%d.' % d
+            u = torch.from_numpy(rng.randint(0, NU, B)).long()
+            pi = torch.from_numpy(rng.randint(0, NI, B)).long(); ni = torch.from_numpy(rng.randint(0, NI, B)).long()
+            ph = torch.from_numpy(rng.randint(0, NE, B)).long(); pt = torch.from_numpy(rng.randint(0, NE, B)).long()
+            pr = torch.from_numpy(rng.randint(0, NR, B)).long()
+            nh = torch.from_numpy(rng.randint(0, NE, B)).long(); nt = torch.from_numpy(rng.randint(0, NE, B)).long()
+            uq = torch.from_numpy(rng.randint(0, NU, BQ)).long(); eq = torch.from_numpy(rng.randint(0, NE, BQ)).long()
+            rq = torch.from_numpy(rng.randint(0, NR, BQ)).long()
+            out.update({pre + k: npy(v) for k, v in dict(u=u, pi=pi, ni=ni, ph=ph, pt=pt, pr=pr, nh=nh, nt=nt, uq=uq, eq=eq, rq=rq).items()})
+            m = rfm.FM(d, NU, NI)
+            sd = set_weights(m, gen)
+            out.update({pre + 'fm.' + k: v for k, v in sd.items()})
+            pos, neg = m(V(u), V(pi)), m(V(u), V(ni))
+            loss = rloss.bprLoss(pos, neg, target=1)
+            zero_grads(m); loss.backward()
+            out.update({pre + 'fm.pos': npy(pos), pre + 'fm.neg': npy(neg), pre + 'fm.loss': npy(loss), pre + 'fm.eval': npy(m.evaluate(V(uq)))})
+            out.update({pre + 'fm.' + k: v for k, v in grads_of(m).items()})
+            for share in (False, True):
+                for l1 in (False, True):
+                    n_items = NE if share else NI                      # shared: the item table IS the entity table (cofm.py:86-88)
+                    tag = pre + 'cofm.%s.%s.' % ('share' if share else 'own', 'L1' if l1 else 'L2')
+                    m = rcofm.coFM(l1, d, NU, n_items, NE, NR, share)
+                    if not l1:
+                        sd = set_weights(m, gen)
+                        out.update({pre + 'cofm.%s.' % ('share' if share else 'own') + k: v for k, v in sd.items()})
+                        keep = {k: p.data.clone() for k, p in m.named_parameters()}
+                    else:
+                        for k, p in m.named_parameters():
+                            p.data.copy_(keep[k])
+                    pos, neg = m((V(u), V(pi)), None, is_rec=True), m((V(u), V(ni)), None, is_rec=True)
+                    loss = rloss.bprLoss(pos, neg, target=1)
+                    zero_grads(m); loss.backward()
+                    out.update({tag + 'rec.pos': npy(pos), tag + 'rec.neg': npy(neg), tag + 'rec.loss': npy(loss)})
+                    out.update({tag + 'rec.' + k: v for k, v in grads_of(m).items()})
+                    pos, neg = m(None, (V(ph), V(pt), V(pr)), is_rec=False), m(None, (V(nh), V(nt), V(pr)), is_rec=False)
+                    loss = rloss.marginLoss()(pos, neg, 1.0)
+                    loss = loss + rloss.normLoss(m.ent_embeddings(V(torch.cat([ph, pt, nh, nt])))) + rloss.normLoss(m.rel_embeddings(V(torch.cat([pr, pr]))))
+                    zero_grads(m); loss.backward()
+                    out.update({tag + 'kg.pos': npy(pos), tag + 'kg.neg': npy(neg), tag + 'kg.loss': npy(loss)})
+                    out.update({tag + 'kg.' + k: v for k, v in grads_of(m).items()})
+                    out[tag + 'evalRec'] = npy(m.evaluateRec(V(uq)))
+                    out[tag + 'evalHead'] = npy(m.evaluateHead(V(eq), V(rq)))
+                    out[tag + 'evalTail'] = npy(m.evaluateTail(V(eq), V(rq)))
+        save('fm_cofm', **out)
+    finally:
+        tnn.Parameter.__new__ = real_new
+        TF.embedding = real_emb
+
+
 if __name__ == '__main__':
     i_map, new_map = score_cases()
     eval_cases(i_map, new_map)
@@ -712,3 +789,4 @@ if __name__ == '__main__':
     transr_d256_case()
     train_step_cases()
     eval_pass_cases()
+    fm_cases()

@@ -34,7 +34,7 @@ def dataset(tmp_path_factory):
     return tmp
 
 
-@pytest.mark.parametrize('model,extra', [('bprmf', []), ('transup', ['-num_preferences', '6', '-L1_flag']),
+@pytest.mark.parametrize('model,extra', [('bprmf', []), ('fm', []), ('transup', ['-num_preferences', '6', '-L1_flag']),
                                          ('transup', ['-num_preferences', '6', '-use_st_gumbel'])])
 def test_item_recommendation_cli(dataset, model, extra):
     name = 'rec-' + model + ('-g' if '-use_st_gumbel' in extra else '')
@@ -90,10 +90,11 @@ def test_joint_cli_training_routes(dataset, mode, monkeypatch):
     assert len(re.findall(r'f1:\d\.\d+', log)) >= 3 and len(re.findall(r'avg hit:', log)) >= 3
 
 
-@pytest.mark.parametrize('model', ['cke', 'cfkg'])
+@pytest.mark.parametrize('model', ['cke', 'cfkg', 'cofm'])
 def test_joint_cli_baselines(dataset, model):
     """The reference baselines that reuse the accelerated kernels run through the joint driver: CKE (own item / entity tables,
-    BPRMF + TransR) and CFKG (shared item-entity table, TransE + "buy" relation; -share_embeddings is forced like the reference)."""
+    BPRMF + TransR), CFKG (shared item-entity table, TransE + "buy" relation; -share_embeddings is forced like the reference) and
+    coFM (FM + TransE, own item table here, so the alignment term pNormLoss of knowledgable_recommendation.py:385-390 is active)."""
     log, logs = run_cli('run_knowledgable_recommendation.py', dataset, 'joint-' + model,
                         ['-model_type', model, '-rec_test_files', 'valid.dat', '-kg_test_files', 'valid.dat', '-joint_ratio', '0.5',
                          '-embedding_size', '36'])

@@ -116,3 +116,64 @@ def test_transr_d256_seeded_golden(golden, l1):
     close(E.grad, g[tag + 'grad.ent'], rtol=3e-4, atol=2e-4); close(R.grad, g[tag + 'grad.rel'], rtol=3e-4, atol=2e-4)
     close(M.grad.sum(1), g[tag + 'grad.proj.rowsum'], rtol=1e-3, atol=5e-3)
     close(M.grad[:, ::997], g[tag + 'grad.proj.sample'], rtol=3e-4, atol=2e-4)
+
+
+@pytest.mark.parametrize('d', [36, 64])
+def test_fm_golden(golden, d):
+    """fm.py: global + user + item bias + u . i, bprLoss with target +1 (trainer.py:15-17), gradients of all five parameters, and the
+    all-item evaluation matrix."""
+    from jTransUP.models import fm
+    from jTransUP.utils import loss
+    g = golden('fm_cofm')
+    p = 'd%d.' % d
+    m = fm.FM(d, NU, NI)
+    assert all(tuple(v.shape) == g[p + 'fm.' + k].shape for k, v in m.state_dict().items())      # biases are 1-D like the reference's
+    assert set(m.state_dict()) == {'user_embeddings.weight', 'item_embeddings.weight', 'user_bias.weight', 'item_bias.weight', 'bias'}
+    _load(m, g, p + 'fm.')
+    ids = {k: torch.from_numpy(g[p + k]).long().to(DEV) for k in ('u', 'pi', 'ni', 'uq')}
+    pos, neg = m(ids['u'], ids['pi']), m(ids['u'], ids['ni'])
+    close(pos, g[p + 'fm.pos']); close(neg, g[p + 'fm.neg'])
+    lo = loss.bprLoss(pos, neg, target=1)
+    close(lo, g[p + 'fm.loss'])
+    m.zero_grad(); lo.backward()
+    for k, prm in m.named_parameters():
+        close(prm.grad, g[p + 'fm.grad.' + k], rtol=2e-4, atol=3e-5)
+    close(m.evaluate(ids['uq']), g[p + 'fm.eval'])
+
+
+@pytest.mark.parametrize('d', [36, 64])
+@pytest.mark.parametrize('share', [False, True])
+@pytest.mark.parametrize('l1', [False, True])
+def test_cofm_golden(golden, d, share, l1):
+    """cofm.py: FM on the ratings, TransE on the triples, item table = entity table with -share_embeddings."""
+    from jTransUP.models import cofm
+    from jTransUP.utils import loss
+    g = golden('fm_cofm')
+    p = 'd%d.' % d
+    kind = 'share' if share else 'own'
+    tag = p + 'cofm.%s.%s.' % (kind, 'L1' if l1 else 'L2')
+    m = cofm.coFM(l1, d, NU, NE if share else NI, NE, NR, share)
+    _load(m, g, p + 'cofm.%s.' % kind)
+    assert (m.item_embeddings is m.ent_embeddings) == share
+    ids = {k: torch.from_numpy(g[p + k]).long().to(DEV) for k in ('u', 'pi', 'ni', 'ph', 'pt', 'pr', 'nh', 'nt', 'uq', 'eq', 'rq')}
+    pos, neg = m((ids['u'], ids['pi']), None, is_rec=True), m((ids['u'], ids['ni']), None, is_rec=True)
+    close(pos, g[tag + 'rec.pos']); close(neg, g[tag + 'rec.neg'])
+    lo = loss.bprLoss(pos, neg, target=1)
+    close(lo, g[tag + 'rec.loss'])
+    m.zero_grad(); lo.backward()
+    for k, prm in m.named_parameters():
+        key = tag + 'rec.grad.' + k
+        if key in g:
+            close(prm.grad, g[key], rtol=2e-4, atol=3e-5)
+    pos, neg = m(None, (ids['ph'], ids['pt'], ids['pr']), is_rec=False), m(None, (ids['nh'], ids['nt'], ids['pr']), is_rec=False)
+    close(pos, g[tag + 'kg.pos']); close(neg, g[tag + 'kg.neg'])
+    lo = _margin_and_norms(m, pos, neg, ids['ph'], ids['pt'], ids['nh'], ids['nt'], ids['pr'])
+    close(lo, g[tag + 'kg.loss'], rtol=2e-4)
+    m.zero_grad(); lo.backward()
+    for k, prm in m.named_parameters():
+        key = tag + 'kg.grad.' + k
+        if key in g and prm.grad is not None:
+            close(prm.grad, g[key], rtol=3e-4, atol=1e-4)
+    close(m.evaluateRec(ids['uq']), g[tag + 'evalRec'])
+    close(m.evaluateHead(ids['eq'], ids['rq']), g[tag + 'evalHead'])
+    close(m.evaluateTail(ids['eq'], ids['rq']), g[tag + 'evalTail'])

@@ -364,3 +364,33 @@ def test_eval_pass_golden(name, d):
     assert [[int(x) for x in r[-1][1]] for r in rows] == J['top_ids']
     np.testing.assert_allclose(np.array([r[:5] for r in rows]), g[tag + 'perf'], rtol=1e-12, atol=0)
     np.testing.assert_allclose(np.array([r[:5] for r in rows]).mean(axis=0), J['mean'], rtol=1e-12)
+
+
+# ------------------------------------------------------------------------------------------------ FM / coFM
+@pytest.mark.parametrize('d', [36, 64])
+def test_fm_cofm_golden(golden, d):
+    g = golden('fm_cofm')
+    p = 'd%d.' % d
+    ids = {k: T(g[p + k]).long() for k in ('u', 'pi', 'ni', 'ph', 'pt', 'pr', 'nh', 'nt', 'uq', 'eq', 'rq')}
+    W = {k: leaf(g, p + 'fm.' + k) for k in ('user_embeddings.weight', 'item_embeddings.weight', 'user_bias.weight', 'item_bias.weight', 'bias')}
+    args = (W['user_embeddings.weight'], W['item_embeddings.weight'], W['user_bias.weight'], W['item_bias.weight'], W['bias'])
+    pos, neg = O.score_fm(*args, ids['u'], ids['pi']), O.score_fm(*args, ids['u'], ids['ni'])
+    close(pos, g[p + 'fm.pos']); close(neg, g[p + 'fm.neg'])
+    lo = O.bpr_loss(pos, neg, 1.0)
+    close(lo, g[p + 'fm.loss'])
+    lo.backward()
+    for k, w in W.items():
+        close(w.grad, g[p + 'fm.grad.' + k], rtol=1e-4, atol=1e-6)
+    close(O.eval_fm(*[w.detach() for w in args], ids['uq']), g[p + 'fm.eval'])
+    for kind in ('own', 'share'):
+        for l1 in (False, True):
+            tag = p + 'cofm.%s.%s.' % (kind, 'L1' if l1 else 'L2')
+            q = p + 'cofm.%s.' % kind
+            E, R = T(g[q + 'ent_embeddings.weight']), T(g[q + 'rel_embeddings.weight'])
+            I = E if kind == 'share' else T(g[q + 'item_embeddings.weight'])
+            a = (T(g[q + 'user_embeddings.weight']), I, T(g[q + 'user_bias.weight']), T(g[q + 'item_bias.weight']), T(g[q + 'bias']))
+            close(O.score_fm(*a, ids['u'], ids['pi']), g[tag + 'rec.pos'])
+            close(O.score_transe(E, R, ids['ph'], ids['pt'], ids['pr'], l1), g[tag + 'kg.pos'])
+            close(O.eval_fm(*a, ids['uq']), g[tag + 'evalRec'])
+            close(O.eval_transe(E, R, ids['eq'], ids['rq'], l1, True), g[tag + 'evalHead'])
+            close(O.eval_transe(E, R, ids['eq'], ids['rq'], l1, False), g[tag + 'evalTail'])

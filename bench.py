@@ -489,7 +489,10 @@ def eval_kg_bench(device, nq=20480, batch=512, seed=13):
             done += cb
     torch.set_num_threads(before)
     n_cpu = len(cpu_rows)
-    agree = bool(n_cpu and np.array_equal(np.array(sorted(r[1] for r in cpu_rows)), np.sort(rows[:n_cpu, 1]).astype(np.int64)))
+    # the oracle sums (c - e)^2 directly, the device expands |c|^2 - 2 c.e + |e|^2 on the matrix cores: near-ties may swap neighbours
+    cr, dr = np.array(sorted(r[1] for r in cpu_rows), dtype=np.int64), np.sort(rows[:n_cpu, 1]).astype(np.int64)
+    agree = {'ranks_compared': int(n_cpu), 'frac_equal': float((cr == dr).mean()) if n_cpu else None,
+             'max_abs_rank_diff': int(np.abs(cr - dr).max()) if n_cpu else None}
     per_q = 1e3 * (t_score + t_rank) / max(done, 1)
     return {'model': 'TransE d=%d squared-L2 (BASELINE configs[1])' % D, 'keys': len(keys), 'entities': NE, 'batch': batch,
             'full_pass_ms': pass_ms, 'ms_per_512_keys': pass_ms / len(batches), 'gold_entries': int(rows.shape[0]),
@@ -497,7 +500,7 @@ def eval_kg_bench(device, nq=20480, batch=512, seed=13):
             'mrr_random_init': float((1.0 / (rows[:, 1] + 1.0)).mean()),
             'cpu_baseline': {'kind': 'port', 'cores': min(32, phys), 'keys_sampled': done, 'batch': cb, 'ms_per_key': per_q,
                              'ms_per_key_scoring': 1e3 * t_score / max(done, 1), 'ms_per_key_ranking': 1e3 * t_rank / max(done, 1),
-                             'full_pass_ms_extrapolated': per_q * len(keys), 'ranks_equal_device_on_sample': agree,
+                             'full_pass_ms_extrapolated': per_q * len(keys), 'ranks_vs_device_on_sample': agree,
                              'sample': 'first %d keys in batches of %d: oracle eval_transe (reference-shaped) + eval_kg_rows, %.1f s of CPU work'
                                        % (done, cb, t_score + t_rank)},
             'note': 'one direction (tails) of a link-prediction pass: K12 scores + K18 filtered gold ranks under ONE call per pass '

@@ -534,6 +534,14 @@ int kg_eval(int model, const char* name, const float* E, int64_t lde, const floa
 
 }  // namespace
 
+// the query side alone (ktup_eval_kg_fused.hip): QW[nq][3][round4(d)], slot 0 = c, slot 2 = w (TransH)
+int ktup::kg_query_prep(int model, const float* E, int64_t lde, const float* R, int64_t ldr, const float* X, int64_t ldx, int d,
+                        const int64_t* q, const int64_t* r, int64_t nq, int head, float* QW, hipStream_t st, const char* name) {
+  hipLaunchKernelGGL(kg_query_prep_kernel, dim3(grid_for((nq + 3) / 4)), dim3(256), 0, st, model, E, lde, R, ldr, X, ldx, d, round4(d), q, r,
+                     nq, head, QW);
+  return check_launch(name);
+}
+
 extern "C" size_t ktup_eval_kg_workspace_bytes(int d, int64_t nq) { return (size_t)nq * 3 * round4(d) * sizeof(float); }
 
 extern "C" size_t ktup_eval_pref_workspace_bytes(int d, int n_pref, int64_t nq, int64_t n_items) {

@@ -1,0 +1,405 @@
+// A link-prediction pass WITHOUT the (keys x entities) score matrix: squared-L2 TransE / TransH (transE.py:65-105, transH.py:73-121,
+// jTransUP.py:193-247) scored on the matrix cores exactly as ktup_eval_mc.hip's K12 / K13 do, with the filtered gold ranks of
+// utils/misc.py:125-146 taken from COUNTS formed in the score kernel's epilogue instead of from a matrix that is written and read
+// back (30 MB per 512 keys at ml1m-kg size: K12 / K13 + K18 were 59-74 us per chunk, most of it that round trip).
+//
+//   rank(g) = #{c : key(c) < key(g)} - #{c in filter(q) U gold(q), c != g : key(c) < key(g)},   key = (score image << 32 | id)
+//
+// (the reference's walk skips filtered ids and the other golds, so both are subtracted; a gold that is itself filtered is never
+// reached: rank -1).  Three launches after the query preparation:
+//   kg_list_scores  the scores of every (key, gold) and (key, filtered id) pair -- a few dozen per key -- computed with the SAME
+//                   instruction sequence as the sweep (per wave: 16 keys x 16 gathered candidates per MFMA tile, of which the
+//                   diagonal is kept), so that a candidate's key is bit-identical in both places;
+//   kg_count_mc     the sweep: a workgroup keeps 64 keys' query vectors in LDS and walks one eighth of the candidate table (one
+//                   band per XCD: its L2 then serves all the workgroups that walk it), 64 candidates per stage; each wave owns
+//                   a 16 x 16 tile per stage, turns its four scores per lane into keys and compares them with the (<= 8) gold
+//                   keys of its keys, counting in registers; one flush of int atomics per workgroup at the end;
+//   kg_rank_finalize  the subtraction above, per gold entry, from the list scores.
+// Covers d in {20, 36, 64, 100, 128}, at most GM = 8 golds per key (the caller checks; otherwise the chunked matrix route runs).
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "ktup_common.h"
+#include "ktup_lane_swap.h"
+#include "ktup_pref_geom.h"
+
+namespace ktup {
+namespace {
+
+constexpr int IB = 64, UB = 64, NW = 16, GM = 8, NBAND = 8;
+
+template <int NCH_, bool TRANSH_>
+struct FGeom {
+  static constexpr int NCH = NCH_, D = 4 * NCH;
+  static constexpr bool TRANSH = TRANSH_;
+  static constexpr int KG = (D + 15) / 16;
+  static constexpr bool TAIL1 = NCH - 4 * (KG - 1) == 1;
+  static constexpr int KGF = TAIL1 ? KG - 1 : KG;
+  static_assert(TAIL1 || NCH % 4 == 0, "k groups must be whole (d % 16 in {0, 4})");
+  static constexpr int P4 = NCH | 1;
+  static constexpr int QV = TRANSH ? 2 : 1;
+  // Q [UB][QV][P4] v4 | C [IB][P4] v4 | qs [UB][4] | cs [IB] | gkey [UB][GM] u64 | gn [UB]
+  static constexpr size_t LDS = (size_t)(UB * QV + IB) * P4 * 16 + (size_t)(UB * 4 + IB) * 4 + (size_t)UB * GM * 8 + (size_t)UB * 4;
+};
+
+KTUP_DEV uint64_t kg_key(float s, bool descending, uint32_t id) {      // = make_key of ktup_rank.hip
+  if (descending) s = -s;
+  if (s == 0.f) s = 0.f;
+  uint32_t u = __float_as_uint(s);
+  u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+  return ((uint64_t)u << 32) | id;
+}
+
+struct FArgs {
+  const float* QW; int dq;
+  const float* C; int64_t ldc;
+  int64_t nq, n_cand;
+  int descending;
+  const int64_t* gold_off; const int32_t* gold_ids; const float* gscore;
+  const int64_t* filt_off; const int32_t* filt_ids; float* fscore;
+  float* gscore_out;
+  int32_t* counts; int32_t* ranks;
+  int tiles_per_band;
+};
+
+// ---- pieces shared by the list kernel and the sweep: identical code => identical bits
+template <typename G>
+KTUP_DEV void stage_queries(const FArgs& a, v4* Q, int64_t u0, int nthreads) {
+  constexpr int NCH = G::NCH, QV = G::QV, P4 = G::P4;
+  for (int idx = threadIdx.x; idx < UB * QV * NCH; idx += nthreads) {
+    const int row = idx / (QV * NCH), rem = idx - row * (QV * NCH), vec = rem / NCH, c = rem - vec * NCH;
+    v4 val = (v4){0.f, 0.f, 0.f, 0.f};
+    if (u0 + row < a.nq) val = *reinterpret_cast<const v4*>(a.QW + ((u0 + row) * 3 + 2 * vec) * a.dq + 4 * c);
+    Q[(row * QV + vec) * P4 + c] = val;
+  }
+}
+
+// |c|^2, c.w, |w|^2 of a query row / |e|^2 of a candidate row: 8 lanes per row, chunks sub, sub + 8, ...
+template <typename G, bool QUERY>
+KTUP_DEV void row_scalars(const v4* r0, int sub, float& f0, float& f1, float& f2) {
+  constexpr int NCH = G::NCH, P4 = G::P4;
+  v4 s0 = (v4){0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0;
+  for (int c = sub; c < NCH; c += 8) {
+    const v4 x0 = r0[c];
+    s0 += x0 * x0;
+    if (QUERY && G::TRANSH) { const v4 x1 = r0[P4 + c]; s1 += x0 * x1; s2 += x1 * x1; }
+  }
+  f0 = (s0[0] + s0[1]) + (s0[2] + s0[3]); f1 = (s1[0] + s1[1]) + (s1[2] + s1[3]); f2 = (s2[0] + s2[1]) + (s2[2] + s2[3]);
+#pragma unroll
+  for (int m = 1; m < 8; m <<= 1) { f0 += __shfl_xor(f0, m, 64); f1 += __shfl_xor(f1, m, 64); f2 += __shfl_xor(f2, m, 64); }
+}
+
+// one 16 x 16 (keys x candidates) tile: qa = the wave's query rows (+ kq), cb = its candidate rows (+ kq)
+template <typename G>
+KTUP_DEV void tile_dots(const v4* qa, const v4* cb, v4& ce, v4& we) {
+  constexpr int KGF = G::KGF, P4 = G::P4;
+  ce = (v4){0.f, 0.f, 0.f, 0.f}; we = ce;
+#pragma unroll
+  for (int g = 0; g < KGF; ++g) {
+    const v4 ac = qa[4 * g], be = cb[4 * g];
+    v4 aw = ac;
+    if (G::TRANSH) aw = qa[P4 + 4 * g];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      ce = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[c], be[c], ce, 0, 0, 0);
+      if (G::TRANSH) we = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[c], be[c], we, 0, 0, 0);
+    }
+  }
+  if (G::TAIL1) {
+    const float* qf = reinterpret_cast<const float*>(qa - (threadIdx.x & 63) / 16 + 4 * KGF) + ((threadIdx.x & 63) >> 4);
+    const float be = (reinterpret_cast<const float*>(cb - (threadIdx.x & 63) / 16 + 4 * KGF) + ((threadIdx.x & 63) >> 4))[0];
+    ce = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[0], be, ce, 0, 0, 0);
+    if (G::TRANSH) we = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[4 * P4], be, we, 0, 0, 0);
+  }
+}
+
+template <typename G>
+KTUP_DEV float pair_score(float ce, float we, float cc, float en, float cw, float ww) {
+  float score = fmaf(-2.f, ce, cc + en);
+  if (G::TRANSH) score = fmaf(we, fmaf(we, ww - 2.f, 2.f * cw), score);
+  return score;
+}
+
+// ---- list scores: one wave per 16 keys; round s scores every key of the wave against the s-th entry of ITS OWN list (golds first,
+// then filtered ids): a 16 x 16 tile of which only the diagonal is wanted.  4 waves = 64 keys per workgroup share the query stage.
+template <typename G>
+__global__ __launch_bounds__(256) void kg_list_scores_kernel(FArgs a) {
+  constexpr int NCH = G::NCH, P4 = G::P4, QV = G::QV;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  v4* Q = reinterpret_cast<v4*>(smem);                         // [UB][QV][P4]
+  v4* Cd = Q + UB * QV * P4;                                   // [4 waves][16][P4]
+  float* qs = reinterpret_cast<float*>(Cd + IB * P4);          // [UB][4]
+  float* cs = qs + UB * 4;                                     // [4 waves][16]
+  const int tid = threadIdx.x, lane = tid & 63, kq = lane >> 4, j = lane & 15;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t u0 = (int64_t)blockIdx.x * UB;
+  stage_queries<G>(a, Q, u0, 256);
+  __syncthreads();
+  for (int row = tid >> 3; row < UB; row += 32) {
+    float f0, f1, f2;
+    row_scalars<G, true>(Q + row * QV * P4, tid & 7, f0, f1, f2);
+    if ((tid & 7) == 0) { qs[row * 4 + 0] = f0; qs[row * 4 + 1] = f1; qs[row * 4 + 2] = f2; }
+  }
+  __syncthreads();
+  // this lane's key (for gathering: lane = (row j of the wave, chunk group))
+  const int64_t key_j = u0 + 16 * w + j;
+  const bool key_on = key_j < a.nq;
+  const int64_t g0 = key_on ? a.gold_off[key_j] : 0, ng = key_on ? a.gold_off[key_j + 1] - g0 : 0;
+  const int64_t f0_ = (key_on && a.filt_off) ? a.filt_off[key_j] : 0, nf = (key_on && a.filt_off) ? a.filt_off[key_j + 1] - f0_ : 0;
+  int64_t len = ng + nf, maxlen = len;
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) { const int64_t o = __shfl_xor(maxlen, m, 64); maxlen = o > maxlen ? o : maxlen; }
+  v4* myC = Cd + w * 16 * P4;
+  float* mycs = cs + w * 16;
+  const v4* qa = Q + ((16 * w + j) * QV) * P4 + kq;
+  const v4* cb = myC + j * P4 + kq;
+  for (int64_t s = 0; s < maxlen; ++s) {
+    // gather: row j of the tile = the s-th list entry of key j (zeros when the list is shorter); 4 lanes (kq) share a row
+    const bool on = s < len;
+    const int32_t cid = !on ? 0 : (s < ng ? a.gold_ids[g0 + s] : a.filt_ids[f0_ + (s - ng)]);
+    const bool valid = on && cid >= 0 && cid < a.n_cand;
+    for (int c = kq; c < NCH; c += 4)
+      myC[j * P4 + c] = valid ? *reinterpret_cast<const v4*>(a.C + (int64_t)cid * a.ldc + 4 * c) : (v4){0.f, 0.f, 0.f, 0.f};
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int row = lane >> 3; row < 16; row += 8) {
+      float e0, e1, e2;
+      row_scalars<G, false>(myC + row * P4, lane & 7, e0, e1, e2);
+      if ((lane & 7) == 0) mycs[row] = e0;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    v4 ce, we;
+    tile_dots<G>(qa, cb, ce, we);
+    // diagonal: key (4 kq + reg) against candidate column j  <=>  j == 4 kq + reg
+    const int reg = j - 4 * kq;
+    if (reg >= 0 && reg < 4 && valid) {
+      const int ur = 16 * w + j;
+      const float sc = pair_score<G>(ce[reg], we[reg], qs[ur * 4 + 0], mycs[j], qs[ur * 4 + 1], qs[ur * 4 + 2]);
+      if (s < ng) a.gscore_out[g0 + s] = sc; else a.fscore[f0_ + (s - ng)] = sc;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// ---- the sweep
+template <typename G>
+__global__ __launch_bounds__(NW * 64) void kg_count_mc_kernel(FArgs a) {
+  constexpr int NCH = G::NCH, P4 = G::P4, QV = G::QV;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  v4* Q = reinterpret_cast<v4*>(smem);
+  v4* Cd = Q + UB * QV * P4;
+  float* qs = reinterpret_cast<float*>(Cd + IB * P4);
+  float* cs = qs + UB * 4;
+  uint64_t* gkey = reinterpret_cast<uint64_t*>(cs + IB);         // [UB][GM]  (8-byte aligned: every part before is a multiple of 16)
+  const int tid = threadIdx.x, lane = tid & 63, kq = lane >> 4, j = lane & 15;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int band = blockIdx.x;                                  // consecutive workgroup ids go round the 8 XCDs: band == XCD
+  const int64_t u0 = (int64_t)blockIdx.y * UB;
+  const bool desc = a.descending != 0;
+  stage_queries<G>(a, Q, u0, NW * 64);
+  for (int idx = tid; idx < UB * GM; idx += NW * 64) {           // gold keys of the 64 keys (0 = no gold: no key is below it)
+    const int row = idx / GM, g = idx - row * GM;
+    uint64_t k = 0;
+    if (u0 + row < a.nq) {
+      const int64_t g0 = a.gold_off[u0 + row], n = a.gold_off[u0 + row + 1] - g0;
+      if (g < n) k = kg_key(a.gscore[g0 + g], desc, (uint32_t)a.gold_ids[g0 + g]);
+    }
+    gkey[idx] = k;
+  }
+  __syncthreads();
+  for (int row = tid >> 3; row < UB; row += (NW * 64) >> 3) {
+    float f0, f1, f2;
+    row_scalars<G, true>(Q + row * QV * P4, tid & 7, f0, f1, f2);
+    if ((tid & 7) == 0) { qs[row * 4 + 0] = f0; qs[row * 4 + 1] = f1; qs[row * 4 + 2] = f2; }
+  }
+  const int ut = w >> 2, it = w & 3;
+  const v4* qa = Q + ((16 * ut + j) * QV) * P4 + kq;
+  const v4* cb = Cd + (16 * it + j) * P4 + kq;
+  int cnt[4][GM];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int g = 0; g < GM; ++g) cnt[r][g] = 0;
+  const int t0 = band * a.tiles_per_band;
+  // a thread's share of a 64-candidate stage (IB * NCH float4 over 1024 threads: at most NLD each), fetched one stage AHEAD into
+  // registers so that the global loads of stage t + 1 are in flight under the matrix work of stage t
+  constexpr int NLD = (IB * NCH + NW * 64 - 1) / (NW * 64);
+  v4 nx[NLD];
+  auto fetch = [&](int t) {
+    const int64_t i0 = (int64_t)t * IB;
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+      const int idx = tid + k * NW * 64;
+      const int row = idx / NCH, c = idx - row * NCH;
+      nx[k] = (v4){0.f, 0.f, 0.f, 0.f};
+      if (idx < IB * NCH && t < t0 + a.tiles_per_band && i0 + row < a.n_cand) nx[k] = *reinterpret_cast<const v4*>(a.C + (i0 + row) * a.ldc + 4 * c);
+    }
+  };
+  fetch(t0);
+  for (int t = t0; t < t0 + a.tiles_per_band; ++t) {
+    const int64_t i0 = (int64_t)t * IB;
+    if (i0 >= a.n_cand) break;
+    __syncthreads();                                            // the previous stage's tile has been consumed (and qs is complete)
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+      const int idx = tid + k * NW * 64;
+      if (idx < IB * NCH) Cd[(idx / NCH) * P4 + (idx % NCH)] = nx[k];
+    }
+    fetch(t + 1);
+    __syncthreads();
+    for (int row = tid >> 3; row < IB; row += (NW * 64) >> 3) {
+      float e0, e1, e2;
+      row_scalars<G, false>(Cd + row * P4, tid & 7, e0, e1, e2);
+      if ((tid & 7) == 0) cs[row] = e0;
+    }
+    __syncthreads();
+    v4 ce, we;
+    tile_dots<G>(qa, cb, ce, we);
+    const float ee = cs[16 * it + j];
+    const int64_t cand = i0 + 16 * it + j;
+    if (cand < a.n_cand) {
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int ur = 16 * ut + 4 * kq + reg;
+        const uint64_t k = kg_key(pair_score<G>(ce[reg], we[reg], qs[ur * 4 + 0], ee, qs[ur * 4 + 1], qs[ur * 4 + 2]), desc, (uint32_t)cand);
+#pragma unroll
+        for (int g = 0; g < GM; ++g) cnt[reg][g] += k < gkey[ur * GM + g] ? 1 : 0;
+      }
+    }
+  }
+  // 16 candidate lanes (j) of a key -> one sum; the lanes with j == 0 flush
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg)
+#pragma unroll
+    for (int g = 0; g < GM; ++g) {
+      int c = cnt[reg][g];
+#pragma unroll
+      for (int m = 1; m < 16; m <<= 1) c += __shfl_xor(c, m, 64);
+      cnt[reg][g] = c;
+    }
+  if (j == 0) {
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int64_t key = u0 + 16 * ut + 4 * kq + reg;
+      if (key < a.nq) {
+        const int64_t g0 = a.gold_off[key], n = a.gold_off[key + 1] - g0;
+#pragma unroll
+        for (int g = 0; g < GM; ++g)
+          if (g < n && cnt[reg][g] != 0) atomicAdd(a.counts + g0 + g, cnt[reg][g]);
+      }
+    }
+  }
+}
+
+// ---- per gold entry: rank = count - (filtered ids and other golds of the key that are ordered before it); -1 if itself filtered
+__global__ __launch_bounds__(256) void kg_rank_finalize_kernel(FArgs a, int64_t n_gold_total) {
+  const bool desc = a.descending != 0;
+  for (int64_t key = (int64_t)blockIdx.x * 256 + threadIdx.x; key < a.nq; key += (int64_t)gridDim.x * 256) {
+    const int64_t g0 = a.gold_off[key], g1 = a.gold_off[key + 1];
+    const int64_t f0 = a.filt_off ? a.filt_off[key] : 0, f1 = a.filt_off ? a.filt_off[key + 1] : 0;
+    for (int64_t gi = g0; gi < g1; ++gi) {
+      const int32_t gid = a.gold_ids[gi];
+      bool filtered = gid < 0 || gid >= a.n_cand;
+      for (int64_t f = f0; f < f1 && !filtered; ++f) filtered = a.filt_ids[f] == gid;
+      if (filtered) { a.ranks[gi] = -1; continue; }
+      const uint64_t gk = kg_key(a.gscore[gi], desc, (uint32_t)gid);
+      int sub = 0;
+      for (int64_t f = f0; f < f1; ++f) {
+        const int32_t c = a.filt_ids[f];
+        if (c < 0 || c >= a.n_cand) continue;
+        bool dup = false;                                      // a filter list is a set, but stay exact if it is not
+        for (int64_t e = f0; e < f && !dup; ++e) dup = a.filt_ids[e] == c;
+        if (!dup && kg_key(a.fscore[f], desc, (uint32_t)c) < gk) ++sub;
+      }
+      for (int64_t o = g0; o < g1; ++o) {
+        const int32_t c = a.gold_ids[o];
+        if (o == gi || c < 0 || c >= a.n_cand) continue;
+        bool dup = false;                                      // another gold that is also filtered was counted above
+        for (int64_t f = f0; f < f1 && !dup; ++f) dup = a.filt_ids[f] == c;
+        for (int64_t e = g0; e < o && !dup; ++e) dup = a.gold_ids[e] == c;
+        if (!dup && kg_key(a.gscore[o], desc, (uint32_t)c) < gk) ++sub;
+      }
+      a.ranks[gi] = a.counts[gi] - sub;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void kg_zero_counts_kernel(int32_t* counts, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) counts[i] = 0;
+}
+
+template <typename G>
+int run_fused(FArgs a, int64_t n_gold, hipStream_t st, const char* name) {
+  (void)hipFuncSetAttribute((const void*)kg_list_scores_kernel<G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS);
+  (void)hipFuncSetAttribute((const void*)kg_count_mc_kernel<G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS);
+  const unsigned qblocks = (unsigned)((a.nq + UB - 1) / UB);
+  hipLaunchKernelGGL(kg_zero_counts_kernel, dim3(grid_for((n_gold + 255) / 256, 1024)), dim3(256), 0, st, a.counts, n_gold);
+  a.gscore_out = const_cast<float*>(a.gscore);
+  hipLaunchKernelGGL((kg_list_scores_kernel<G>), dim3(qblocks), dim3(256), G::LDS, st, a);
+  const int64_t ntiles = (a.n_cand + IB - 1) / IB;
+  a.tiles_per_band = (int)((ntiles + NBAND - 1) / NBAND);
+  hipLaunchKernelGGL((kg_count_mc_kernel<G>), dim3(NBAND, qblocks), dim3(NW * 64), G::LDS, st, a);
+  hipLaunchKernelGGL(kg_rank_finalize_kernel, dim3(grid_for((a.nq + 255) / 256, 1024)), dim3(256), 0, st, a, n_gold);
+  return check_launch(name);
+}
+
+template <bool TRANSH>
+int dispatch_fused(const FArgs& a, int d, int64_t n_gold, hipStream_t st, const char* name) {
+  switch (d) {
+    case 20: return run_fused<FGeom<5, TRANSH>>(a, n_gold, st, name);
+    case 36: return run_fused<FGeom<9, TRANSH>>(a, n_gold, st, name);
+    case 64: return run_fused<FGeom<16, TRANSH>>(a, n_gold, st, name);
+    case 100: return run_fused<FGeom<25, TRANSH>>(a, n_gold, st, name);
+    case 128: return run_fused<FGeom<32, TRANSH>>(a, n_gold, st, name);
+    default: return 1;
+  }
+}
+
+size_t pad256(size_t n) { return (n + 255) & ~(size_t)255; }
+
+}  // namespace
+}  // namespace ktup
+
+extern "C" int ktup_eval_kg_ranks_fused_supported(int model, int d, int l1, int64_t max_golds) {
+  return (model == KTUP_KG_TRANSE || model == KTUP_KG_TRANSH) && !l1 && (d == 20 || d == 36 || d == 64 || d == 100 || d == 128) &&
+         max_golds <= ktup::GM && ktup::opt_eval_mc();
+}
+
+extern "C" size_t ktup_eval_kg_ranks_fused_workspace_bytes(int d, int64_t nq, int64_t n_gold, int64_t n_filt) {
+  if (d <= 0 || nq <= 0) return 0;
+  return ktup::pad256(ktup_eval_kg_workspace_bytes(d, nq)) + ktup::pad256((size_t)(n_gold > 0 ? n_gold : 1) * 4) * 2 +
+         ktup::pad256((size_t)(n_filt > 0 ? n_filt : 1) * 4);
+}
+
+extern "C" int ktup_eval_kg_ranks_fused(int model, const float* E, int64_t lde, const float* R, int64_t ldr, const float* Nrm, int64_t ldn,
+                                        int d, const float* C, int64_t ldc, int64_t n_cand, const int64_t* q, const int64_t* r, int64_t nq,
+                                        int head, int descending, const int64_t* filt_off, const int32_t* filt_ids, int64_t n_filt,
+                                        const int64_t* gold_off, const int32_t* gold_ids, int64_t n_gold, int64_t max_golds,
+                                        int32_t* ranks, void* ws, void* stream) {
+  const char* name = "ktup_eval_kg_ranks_fused";
+  using namespace ktup;
+  if (!ktup_eval_kg_ranks_fused_supported(model, d, 0, max_golds))
+    return set_error(KTUP_ERR_UNSUPPORTED, "%s: squared-L2 TransE / TransH, d in {20,36,64,100,128}, at most %d golds per key", name, GM);
+  KTUP_REQUIRE(nq >= 0 && n_cand > 0 && n_gold >= 0 && n_filt >= 0, "%s: bad sizes", name);
+  if (nq == 0 || n_gold == 0) return KTUP_OK;
+  KTUP_REQUIRE(E && R && C && q && r && gold_off && gold_ids && ranks && ws && (model == KTUP_KG_TRANSE || Nrm), "%s: null pointer argument", name);
+  KTUP_REQUIRE((filt_off == nullptr) || filt_ids, "%s: filter offsets without ids", name);
+  KTUP_REQUIRE(aligned16(C) && (ldc & 3) == 0 && n_cand < (1ll << 31) && (nq + UB - 1) / UB <= 65535, "%s: candidate table must be 16-byte aligned (pitch %% 4), sizes in range", name);
+  hipStream_t st = (hipStream_t)stream;
+  char* p = reinterpret_cast<char*>(ws);
+  float* QW = reinterpret_cast<float*>(p); p += pad256(ktup_eval_kg_workspace_bytes(d, nq));
+  float* gscore = reinterpret_cast<float*>(p); p += pad256((size_t)n_gold * 4);
+  int32_t* counts = reinterpret_cast<int32_t*>(p); p += pad256((size_t)n_gold * 4);
+  float* fscore = reinterpret_cast<float*>(p);
+  if (int e = kg_query_prep(model, E, lde, R, ldr, Nrm, ldn, d, q, r, nq, head, QW, st, name)) return e;
+  FArgs a{};
+  a.QW = QW; a.dq = (d + 3) & ~3; a.C = C; a.ldc = ldc; a.nq = nq; a.n_cand = n_cand; a.descending = descending;
+  a.gold_off = gold_off; a.gold_ids = gold_ids; a.gscore = gscore; a.filt_off = filt_off; a.filt_ids = filt_ids; a.fscore = fscore;
+  a.counts = counts; a.ranks = ranks;
+  const int rc = model == KTUP_KG_TRANSH ? dispatch_fused<true>(a, d, n_gold, st, name) : dispatch_fused<false>(a, d, n_gold, st, name);
+  if (rc == 1) return set_error(KTUP_ERR_UNSUPPORTED, "%s: d=%d is not an instantiated width", name, d);
+  return rc;
+}

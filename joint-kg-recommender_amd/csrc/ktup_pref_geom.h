@@ -67,6 +67,10 @@ int transr_bwd_mc(const float* E, int64_t lde, const float* R, int64_t ldr, cons
 int pairs_l2_mc(const float* QW, const float* C0, const float* C1, const float* C2, int d, int64_t nq, int64_t n_items, float* out,
                 int64_t ldo, hipStream_t st, const char* name);
 
+// ktup_eval.hip: query-side vectors of the KG evaluation kernels (model 0 TransE, 1 TransH, 2 TransR) for all nq keys
+int kg_query_prep(int model, const float* E, int64_t lde, const float* R, int64_t ldr, const float* X, int64_t ldx, int d,
+                  const int64_t* q, const int64_t* r, int64_t nq, int head, float* QW, hipStream_t st, const char* name);
+
 // ktup_eval_pass.hip: scores + filtered top-n of a whole evaluation pass in one launch (+ a merge launch).  1 = not covered.
 size_t eval_pass_pspace_bytes(int d, int n_pref, int64_t nq, int64_t n_items, int topn);
 int eval_pass_pspace(const float* U, int64_t ldu, const int64_t* u_ids, int64_t nq, const float* I, int64_t ldi, const float* E, int64_t lde,

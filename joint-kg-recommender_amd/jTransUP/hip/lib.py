@@ -89,6 +89,10 @@ SIGNATURES = {
     'ktup_eval_kg_ranks_workspace_bytes': [c_i, c_l, c_l],
     'ktup_eval_kg_ranks': [c_i, c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_p, c_l, c_l, c_p, c_p, c_l, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_l,
                            c_p, c_p],
+    'ktup_eval_kg_ranks_fused_supported': [c_i, c_i, c_i, c_l],
+    'ktup_eval_kg_ranks_fused_workspace_bytes': [c_i, c_l, c_l, c_l],
+    'ktup_eval_kg_ranks_fused': [c_i, c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_p, c_l, c_l, c_p, c_p, c_l, c_i, c_i, c_p, c_p, c_l, c_p, c_p,
+                                 c_l, c_l, c_p, c_p, c_p],
     'ktup_eval_kg_ranks_transr_workspace_bytes': [c_i, c_l, c_i, c_l],
     'ktup_eval_kg_ranks_transr': [c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_l, c_i, c_p, c_p, c_p, c_l, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p,
                                   c_l, c_p, c_p],
@@ -132,7 +136,7 @@ SIGNATURES = {
     'ktup_feed_kg': [c_p, c_p, c_p, c_l, c_l, c_p, c_p, c_l, c_l, c_p, c_l, c_u, c_p, c_p, c_p, c_p, c_p],
 }
 _RESTYPE = {'ktup_last_error': ctypes.c_char_p, 'ktup_shard_reduce_list_len': ctypes.c_int64, 'ktup_shard_route_workspace_bytes': ctypes.c_size_t,
-            'ktup_shard_route_sort_bytes': ctypes.c_size_t, 'ktup_pref_workspace_bytes': ctypes.c_size_t, 'ktup_eval_kg_ranks_workspace_bytes': ctypes.c_size_t, 'ktup_eval_kg_ranks_transr_workspace_bytes': ctypes.c_size_t,
+            'ktup_shard_route_sort_bytes': ctypes.c_size_t, 'ktup_pref_workspace_bytes': ctypes.c_size_t, 'ktup_eval_kg_ranks_workspace_bytes': ctypes.c_size_t, 'ktup_eval_kg_ranks_transr_workspace_bytes': ctypes.c_size_t, 'ktup_eval_kg_ranks_fused_workspace_bytes': ctypes.c_size_t,
             'ktup_eval_kg_workspace_bytes': ctypes.c_size_t, 'ktup_eval_transr_workspace_bytes': ctypes.c_size_t, 'ktup_eval_transr_entities_workspace_bytes': ctypes.c_size_t, 'ktup_score_transr_workspace_bytes': ctypes.c_size_t, 'ktup_score_transr_bwd_workspace_bytes': ctypes.c_size_t,
             'ktup_eval_pref_workspace_bytes': ctypes.c_size_t, 'ktup_eval_pref_items_workspace_bytes': ctypes.c_size_t, 'ktup_negsample_rec_workspace_bytes': ctypes.c_size_t,
             'ktup_score_pref_bwd_workspace_bytes': ctypes.c_size_t, 'ktup_segment_workspace_bytes': ctypes.c_size_t, 'ktup_shard_dedupe_workspace_bytes': ctypes.c_size_t,

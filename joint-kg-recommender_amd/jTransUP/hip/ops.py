@@ -405,8 +405,23 @@ def eval_transh(E, R, N, q, r, l1, head, candidates=None):
 KG_TRANSE, KG_TRANSH = 0, 1
 
 
+_MAX_GOLDS = {}
+
+
+def _max_golds(gold_off):
+    """Largest gold set of a pass's CSR index: one device read per index (the offsets of a pass live as long as the run)."""
+    key = (gold_off.data_ptr(), gold_off.numel())
+    hit = _MAX_GOLDS.get(key)
+    if hit is None or hit[0] is not gold_off:
+        if len(_MAX_GOLDS) > 64:
+            _MAX_GOLDS.clear()
+        hit = _MAX_GOLDS[key] = (gold_off, int((gold_off[1:] - gold_off[:-1]).max().item()) if gold_off.numel() > 1 else 0)
+    return hit[1]
+
+
 @torch.no_grad()
-def eval_kg_ranks(E, R, N, q, r, l1, head, descending, gold_off, gold_ids, filt_off=None, filt_ids=None, candidates=None, chunk=512):
+def eval_kg_ranks(E, R, N, q, r, l1, head, descending, gold_off, gold_ids, filt_off=None, filt_ids=None, candidates=None, chunk=512,
+                  fused=None):
     """A whole link-prediction pass in one call (ktup_eval_kg_ranks): the filtered 0-based rank of every gold entry of every key
     (q[i], r[i]) among all candidates -- K12 (N is None) or K13 scores `chunk` keys at a time + K18, the loop over the batches
     under the C ABI.  gold_off / filt_off: the pass's CSR offsets (len(q) + 1, absolute).  -> int32 [gold_off[-1]]; -1 = a gold
@@ -420,6 +435,18 @@ def eval_kg_ranks(E, R, N, q, r, l1, head, descending, gold_off, gold_ids, filt_
         raise L.KtupError('eval_kg_ranks: CSR offsets need len(q) + 1 entries')
     n_gold = gold_ids.numel()
     ranks = torch.empty(max(n_gold, 1), dtype=torch.int32, device=dev)
+    if fused is not False and nq > 0 and n_gold > 0 and not l1:
+        # the pass without the score matrix (ktup_eval_kg_ranks_fused): ranks from counts in the score kernel's epilogue
+        mg = _max_golds(gold_off)
+        lib = L.load()
+        if lib.ktup_eval_kg_ranks_fused_supported(KG_TRANSE if N is None else KG_TRANSH, E.shape[1], int(l1), mg) and C.stride(0) % 4 == 0:
+            n_filt = 0 if filt_ids is None else filt_ids.numel()
+            fws = _scratch(lib.ktup_eval_kg_ranks_fused_workspace_bytes(E.shape[1], nq, n_gold, n_filt), dev)
+            L.call('ktup_eval_kg_ranks_fused', KG_TRANSE if N is None else KG_TRANSH, _p(E), E.stride(0), _p(R), R.stride(0), _p(N),
+                   0 if N is None else N.stride(0), E.shape[1], _p(C), C.stride(0), C.shape[0], _p(q), _p(r), nq, int(head),
+                   int(bool(descending)), _p(filt_off), _p(filt_ids), n_filt, _p(gold_off), _p(gold_ids), n_gold, mg, _p(ranks), _p(fws),
+                   _stream(dev))
+            return ranks
     chunk = max(1, min(int(chunk), max(nq, 1)))
     ws = _scratch(L.load().ktup_eval_kg_ranks_workspace_bytes(E.shape[1], C.shape[0], chunk), dev)
     L.call('ktup_eval_kg_ranks', KG_TRANSE if N is None else KG_TRANSH, _p(E), E.stride(0), _p(R), R.stride(0), _p(N),

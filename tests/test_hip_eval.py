@@ -500,7 +500,7 @@ def test_kg_ranks_whole_pass_equals_the_batch_walk(model):
     gen = torch.Generator().manual_seed(4)
     E, R, N = O.make_table(ne, d, gen), O.make_table(nr, d, gen), O.make_table(nr, d, gen)
     q = torch.from_numpy(rng.randint(0, ne, size=nq)); r = torch.from_numpy(rng.randint(0, nr, size=nq))
-    _, filt, gold, f_off, f_ids, g_off, g_ids = _rank_case(rng, nq, ne, 60, 6, 0)
+    _, filt, gold, f_off, f_ids, g_off, g_ids = _rank_case(rng, nq, ne, 60, 5, 0)      # <= 8 golds per key: the fused pass applies
     Ed, Rd, Nd = dv(E.numpy()), dv(R.numpy()), dv(N.numpy())
     qd, rd = q.to(DEV), r.to(DEV)
     for head in (True, False):
@@ -509,6 +509,11 @@ def test_kg_ranks_whole_pass_equals_the_batch_walk(model):
                 for with_filter in (True, False):
                     fo, fi = (dv(f_off), dv(f_ids)) if with_filter else (None, None)
                     got = ops().eval_kg_ranks(Ed, Rd, Nd if model == 'transh' else None, qd, rd, l1, head, desc, dv(g_off), dv(g_ids), fo, fi)
+                    # squared L2 takes the pass without a score matrix (counts in the score kernel's epilogue); the chunked matrix
+                    # route stays reachable and must give the same integers
+                    got_chunked = ops().eval_kg_ranks(Ed, Rd, Nd if model == 'transh' else None, qd, rd, l1, head, desc, dv(g_off), dv(g_ids), fo, fi,
+                                                      fused=False)
+                    assert torch.equal(got, got_chunked)
                     want = []
                     for s in range(0, nq, 512):
                         e = min(nq, s + 512)
@@ -527,6 +532,33 @@ def test_kg_ranks_whole_pass_equals_the_batch_walk(model):
         got_sel = np.concatenate([got[int(g_off[i]):int(g_off[i + 1])] for i in sel])
         # the oracle's scores differ from the device's in the last bits: ranks may move by the number of near-ties only
         assert np.array_equal(got_sel < 0, want_ranks < 0) and np.abs(got_sel - want_ranks).max() <= 1 and (got_sel == want_ranks).mean() > 0.98
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('model', ['transe', 'transh'])
+@pytest.mark.parametrize('d', [20, 36, 64, 100, 128])
+def test_kg_ranks_without_score_matrix(model, d):
+    """ktup_eval_kg_ranks_fused at every instantiated width, at ml1m-kg's entity count (14,709: 230 candidate stages in 8 bands, the
+    last one ragged), keys whose gold is filtered, keys without golds, duplicate keys: the integers of the matrix route."""
+    lib = __import__('jTransUP.hip.lib', fromlist=['x'])
+    rng = np.random.RandomState(5 + d)
+    ne, nr, nq = 14709, 11, 333
+    gen = torch.Generator().manual_seed(d)
+    E, R, N = O.make_table(ne, d, gen), O.make_table(nr, d, gen), O.make_table(nr, d, gen)
+    q = torch.from_numpy(rng.randint(0, ne, size=nq)); r = torch.from_numpy(rng.randint(0, nr, size=nq))
+    q[7], r[7] = q[3], r[3]
+    _, filt, gold, f_off, f_ids, g_off, g_ids = _rank_case(rng, nq, ne, 40, 5, 0)      # + 3 filtered golds on key 1: 8 at most
+    assert lib.load().ktup_eval_kg_ranks_fused_supported(0 if model == 'transe' else 1, d, 0, int(np.diff(g_off).max())) == 1
+    Ed, Rd, Nd = dv(E.numpy()), dv(R.numpy()), dv(N.numpy())
+    Nn = Nd if model == 'transh' else None
+    for head in (True, False):
+        for desc in (False, True):
+            a = ops().eval_kg_ranks(Ed, Rd, Nn, q.to(DEV), r.to(DEV), False, head, desc, dv(g_off), dv(g_ids), dv(f_off), dv(f_ids))
+            b = ops().eval_kg_ranks(Ed, Rd, Nn, q.to(DEV), r.to(DEV), False, head, desc, dv(g_off), dv(g_ids), dv(f_off), dv(f_ids), fused=False)
+            assert torch.equal(a, b) and int((a[:len(g_ids)] >= 0).sum()) > nq // 2
+        a = ops().eval_kg_ranks(Ed, Rd, Nn, q.to(DEV), r.to(DEV), False, head, False, dv(g_off), dv(g_ids))          # no filter at all
+        b = ops().eval_kg_ranks(Ed, Rd, Nn, q.to(DEV), r.to(DEV), False, head, False, dv(g_off), dv(g_ids), fused=False)
+        assert torch.equal(a, b)
 
 
 @pytest.mark.gpu

@@ -82,7 +82,42 @@ float run(const float* table, int64_t pitch, int d, const int32_t* ids, int64_t 
   return ms / reps;
 }
 
+// `footprint`: ONE 9.7 GB (d = 100) / 24.8 GB (d = 256) allocation, the same 2,150,400 random rows drawn from a leading window of it
+// of growing size.  Every row is its own DRAM page miss at all of these footprints, so what separates them is (a) the 256 MB
+// Infinity Cache (gone by ~1 GB) and (b) address translation reach; a rate that keeps falling from 2.4 GB to the full table is
+// translation, a flat one is the HBM's random-row rate itself.
+template <int D>
+void footprint_sweep() {
+  const int64_t nrows = 2150400, trows = 24248000;
+  float* table; int32_t* ids; float* out;
+  if (hipMalloc(&table, trows * D * 4) != hipSuccess) { printf("d=%d: allocation of %.1f GB failed\n", D, trows * D * 4 / 1e9); return; }
+  hipMemset(table, 0, trows * D * 4);
+  hipMalloc(&ids, nrows * 4);
+  hipMalloc(&out, 256 * 2048 * 4);
+  std::vector<int32_t> h(nrows);
+  for (double frac : {0.0423, 0.125, 0.25, 0.5, 1.0}) {
+    const int64_t window = (int64_t)(trows * frac);
+    uint64_t s = 88172645463325252ull;
+    for (auto& x : h) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; x = (int32_t)(s % (uint64_t)window); }
+    hipMemcpy(ids, h.data(), nrows * 4, hipMemcpyHostToDevice);
+    const double bytes = (double)nrows * D * 4;
+    for (int nt = 0; nt < 2; ++nt) {
+      const float ms = D == 100 ? (nt ? run<4, 21, true>(table, D, D, ids, nrows, out, 1, 16) : run<4, 21, false>(table, D, D, ids, nrows, out, 1, 16))
+                                : (nt ? run<4, 16, true>(table, D, D, ids, nrows, out, 1, 16) : run<4, 16, false>(table, D, D, ids, nrows, out, 1, 16));
+      printf("d=%3d rows of %4d B  window %6.2f GB of %5.1f GB  %-12s %8.1f us  %7.1f GB/s of row bytes  (%4.1f %% of 8 TB/s)\n", D, D * 4,
+             window * (double)D * 4 / 1e9, trows * (double)D * 4 / 1e9, nt ? "nontemporal" : "default", ms * 1e3, bytes / ms / 1e6,
+             bytes / ms / 1e6 / 80.0);
+    }
+  }
+  hipFree(table); hipFree(ids); hipFree(out);
+}
+
 int main(int argc, char** argv) {
+  if (argc > 1 && std::string(argv[1]) == "footprint") {
+    footprint_sweep<100>();
+    footprint_sweep<256>();
+    return 0;
+  }
   const bool big = argc > 1 && std::string(argv[1]) == "big";   // working sets beyond L2 + Infinity Cache only
   const int d = 100;
   const int64_t nrows = 2150400;   // 3 x 716800 row reads, like one KTUP launch

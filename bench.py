@@ -601,7 +601,9 @@ def gather_stress_bench(device, scale=1000, reps=20):
                  ws.data_ptr(), NR, D, u.data_ptr(), i.data_ptr(), REC_ROWS, 0, ops.GUMBEL_OFF, None, 0, 0, s_rec.data_ptr(), st)
     kg = L.bind('ktup_score_transh_fwd', E.data_ptr(), E.stride(0), R.data_ptr(), R.stride(0), Rn.data_ptr(), Rn.stride(0), NR, D,
                 h.data_ptr(), t.data_ptr(), r.data_ptr(), KG_ROWS, 0, s_kg.data_ptr(), st)
-    for name, f, rows, bpr in (('ktup_rec_forward', rec, REC_ROWS, BYTES_REC), ('ktup_kg_forward', kg, KG_ROWS, BYTES_KG)):
+    for name, f, rows, bpr in (('ktup_rec_forward', rec, REC_ROWS, BYTES_REC), ('ktup_kg_forward', kg, KG_ROWS, BYTES_KG),
+                               ('ktup_rec_forward_nontemporal', rec, REC_ROWS, BYTES_REC)):
+        nt_before = L.set_option('nt_gather', 1) if name.endswith('nontemporal') else None
         for _ in range(3):
             f()
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
@@ -612,6 +614,8 @@ def gather_stress_bench(device, scale=1000, reps=20):
         ms = sorted(a.elapsed_time(b) for a, b in ev)[reps // 2]
         out[name] = {'ms_per_launch': ms, 'achieved_GBs': rows * bpr / (ms * 1e-3) / 1e9,
                      'frac_of_hbm_peak': rows * bpr / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        if nt_before is not None:
+            L.set_option('nt_gather', nt_before)
     out['note'] = 'algorithmic row bytes / median HIP-event time of the bound launch; tables HBM-resident, so traffic ~ algorithmic x 512/400'
     return out
 
@@ -631,7 +635,9 @@ def roofline_hbm_resident(gs):
             'traffic_frac_of_hbm_peak': None if traffic is None else traffic / t / 1e9 / HBM_PEAK_GBS,
             'traffic_over_algorithmic': None if traffic is None else traffic / (REC_ROWS * BYTES_REC),
             'expected_traffic_over_algorithmic': 512.0 / 400.0,
-            'scattered_row_ceiling_GBs': 4800.0, 'frac_of_scattered_row_ceiling': e['achieved_GBs'] / 4800.0,
+            'with_nontemporal_row_loads': gs.get('ktup_rec_forward_nontemporal'),
+            'scattered_row_ceiling_GBs': 4860.0, 'frac_of_scattered_row_ceiling': e['achieved_GBs'] / 4860.0,
+            'ceiling_source': 'profiles/r03_gather_footprint.txt: pure gather of the same 2,150,400 rows from a 9.7 GB table, 4.68 TB/s default / 4.86 TB/s nontemporal',
             'ms_per_launch': e['ms_per_launch'], 'rows_per_launch': REC_ROWS, 'bytes_per_row': BYTES_REC,
             'kg_kernel': gs.get('ktup_kg_forward'),
             'note': '400-byte rows at their natural pitch cost four 128-byte lines; the ceiling is the pure gather microbenchmark '

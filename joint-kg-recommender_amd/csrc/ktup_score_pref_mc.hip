@@ -75,6 +75,7 @@ struct McArgs {
   const int64_t *u_ids, *i_ids;
   int64_t n;
   float* score;
+  int nt;                        // row gathers with the nontemporal hint (option nt_gather: tables far beyond the Infinity Cache)
 };
 
 // L1: the distance is compile-time too -- with a run-time flag the compiler evaluates |z| AND z^2 for every coordinate and
@@ -177,11 +178,16 @@ __global__ __launch_bounds__(G::NW * 64) void pref_fwd_mc_kernel(McArgs a) {
         if (jj < J) {
           asm volatile("" : "+v"(gc[jj]));   // opaque per tile: LICM would hoist 3 x J 64-bit (table + chunk) bases and spill them
           const uint32_t idu = (uint32_t)sid[grow[jj]], idi = (uint32_t)sid[16 + grow[jj]];
-          uu[jb] = a.U[(uint64_t)idu * a.ldu4 + (uint32_t)gc[jj]];
-          vv[jb] = a.I[(uint64_t)idi * a.ldi4 + (uint32_t)gc[jj]];
+          const v4* pu = a.U + ((uint64_t)idu * a.ldu4 + (uint32_t)gc[jj]);
+          const v4* pv = a.I + ((uint64_t)idi * a.ldi4 + (uint32_t)gc[jj]);
+          // scattered rows of tables much larger than the caches: the default policy allocates every line it will never
+          // re-read (tools/gather_bench footprint: 4.68 vs 4.86 TB/s at 9.7 GB; the other way round below ~2 GB)
+          uu[jb] = a.nt ? __builtin_nontemporal_load(pu) : *pu;
+          vv[jb] = a.nt ? __builtin_nontemporal_load(pv) : *pv;
           if (HASE) {
             const uint32_t ide = (uint32_t)sid[32 + grow[jj]];
-            ee[jb] = a.E[(uint64_t)ide * a.lde4 + (uint32_t)gc[jj]];
+            const v4* pe = a.E + ((uint64_t)ide * a.lde4 + (uint32_t)gc[jj]);
+            ee[jb] = a.nt ? __builtin_nontemporal_load(pe) : *pe;
           }
         }
       }
@@ -480,7 +486,7 @@ int pref_fwd_mc(const float* U, int64_t ldu, const float* I, int64_t ldi, const 
   a.Alog = Alog; a.Ar = Ar; a.Cn = Cn;
   a.dp = dp; a.P = n_pref; a.l1 = l1;
   a.gumbel = gumbel_mode; a.uniform = uniform; a.seed = seed; a.offset = offset;
-  a.u_ids = u_ids; a.i_ids = i_ids; a.n = n; a.score = score;
+  a.u_ids = u_ids; a.i_ids = i_ids; a.n = n; a.score = score; a.nt = opt_nt_gather();
   const int np = (n_pref + 3) / 4;
   if (d == 64) return launch_mc_np<16>(a, np, st, name);
   if (d == 100) return launch_mc_np<25>(a, np, st, name);

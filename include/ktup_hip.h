@@ -316,7 +316,7 @@ int ktup_eval_gold_ranks(const float* scores, int64_t lds, int64_t nq, int64_t n
  * arrays, max_golds = the largest gold set of a key (host side).  ktup_eval_kg_ranks_fused_supported: l1 == 0, d in
  * {20, 36, 64, 100, 128}, max_golds <= 8 (else KTUP_ERR_UNSUPPORTED: use ktup_eval_kg_ranks).                                  */
 int ktup_eval_kg_ranks_fused_supported(int model, int d, int l1, int64_t max_golds);
-size_t ktup_eval_kg_ranks_fused_workspace_bytes(int d, int64_t nq, int64_t n_gold, int64_t n_filt);
+size_t ktup_eval_kg_ranks_fused_workspace_bytes(int d, int64_t nq, int64_t n_gold, int64_t n_filt, int64_t n_cand);
 int ktup_eval_kg_ranks_fused(int model, const float* E, int64_t lde, const float* R, int64_t ldr, const float* Nrm, int64_t ldn, int d,
                              const float* C, int64_t ldc, int64_t n_cand, const int64_t* q, const int64_t* r, int64_t nq, int head,
                              int descending, const int64_t* filt_off, const int32_t* filt_ids, int64_t n_filt,

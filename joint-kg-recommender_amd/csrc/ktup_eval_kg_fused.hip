@@ -27,7 +27,7 @@
 namespace ktup {
 namespace {
 
-constexpr int IB = 64, UB = 64, NW = 16, GM = 8, NBAND = 8;
+constexpr int IB = 64, UB = 64, NW = 16, GM = 8, NBAND = 8;      // GM: most golds per key (the sweep is instantiated for 4 and 8)
 
 template <int NCH_, bool TRANSH_>
 struct FGeom {
@@ -61,6 +61,7 @@ struct FArgs {
   float* gscore_out;
   int32_t* counts; int32_t* ranks;
   int tiles_per_band;
+  float* cnorm;                 // |e|^2 of every candidate, computed ONCE per pass (kg_cand_norms_kernel) and read by both kernels
 };
 
 // ---- pieces shared by the list kernel and the sweep: identical code => identical bits
@@ -114,6 +115,46 @@ KTUP_DEV void tile_dots(const v4* qa, const v4* cb, v4& ce, v4& we) {
   }
 }
 
+// the same tile with the query-side operands held in registers (the sweep re-uses them for every candidate stage): the MFMA
+// sequence and its operand VALUES are those of tile_dots, so the results are the same bits
+template <typename G>
+struct QRegs {
+  v4 ac[G::KGF], aw[G::KGF];
+  float ta, tw;
+  KTUP_DEV void load(const v4* qa) {
+    const int kq = (threadIdx.x & 63) >> 4;
+#pragma unroll
+    for (int g = 0; g < G::KGF; ++g) { ac[g] = qa[4 * g]; aw[g] = G::TRANSH ? qa[G::P4 + 4 * g] : ac[g]; }
+    ta = tw = 0.f;
+    if (G::TAIL1) {
+      const float* qf = reinterpret_cast<const float*>(qa - kq + 4 * G::KGF) + kq;
+      ta = qf[0];
+      if (G::TRANSH) tw = qf[4 * G::P4];
+    }
+  }
+};
+
+template <typename G>
+KTUP_DEV void tile_dots_q(const QRegs<G>& q, const v4* cb, v4& ce, v4& we) {
+  constexpr int KGF = G::KGF;
+  ce = (v4){0.f, 0.f, 0.f, 0.f}; we = ce;
+#pragma unroll
+  for (int g = 0; g < KGF; ++g) {
+    const v4 be = cb[4 * g];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      ce = __builtin_amdgcn_mfma_f32_16x16x4f32(q.ac[g][c], be[c], ce, 0, 0, 0);
+      if (G::TRANSH) we = __builtin_amdgcn_mfma_f32_16x16x4f32(q.aw[g][c], be[c], we, 0, 0, 0);
+    }
+  }
+  if (G::TAIL1) {
+    const int kq = (threadIdx.x & 63) >> 4;
+    const float be = (reinterpret_cast<const float*>(cb - kq + 4 * KGF) + kq)[0];
+    ce = __builtin_amdgcn_mfma_f32_16x16x4f32(q.ta, be, ce, 0, 0, 0);
+    if (G::TRANSH) we = __builtin_amdgcn_mfma_f32_16x16x4f32(q.tw, be, we, 0, 0, 0);
+  }
+}
+
 template <typename G>
 KTUP_DEV float pair_score(float ce, float we, float cc, float en, float cw, float ww) {
   float score = fmaf(-2.f, ce, cc + en);
@@ -130,7 +171,6 @@ __global__ __launch_bounds__(256) void kg_list_scores_kernel(FArgs a) {
   v4* Q = reinterpret_cast<v4*>(smem);                         // [UB][QV][P4]
   v4* Cd = Q + UB * QV * P4;                                   // [4 waves][16][P4]
   float* qs = reinterpret_cast<float*>(Cd + IB * P4);          // [UB][4]
-  float* cs = qs + UB * 4;                                     // [4 waves][16]
   const int tid = threadIdx.x, lane = tid & 63, kq = lane >> 4, j = lane & 15;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t u0 = (int64_t)blockIdx.x * UB;
@@ -151,7 +191,6 @@ __global__ __launch_bounds__(256) void kg_list_scores_kernel(FArgs a) {
 #pragma unroll
   for (int m = 1; m < 64; m <<= 1) { const int64_t o = __shfl_xor(maxlen, m, 64); maxlen = o > maxlen ? o : maxlen; }
   v4* myC = Cd + w * 16 * P4;
-  float* mycs = cs + w * 16;
   const v4* qa = Q + ((16 * w + j) * QV) * P4 + kq;
   const v4* cb = myC + j * P4 + kq;
   for (int64_t s = 0; s < maxlen; ++s) {
@@ -161,13 +200,7 @@ __global__ __launch_bounds__(256) void kg_list_scores_kernel(FArgs a) {
     const bool valid = on && cid >= 0 && cid < a.n_cand;
     for (int c = kq; c < NCH; c += 4)
       myC[j * P4 + c] = valid ? *reinterpret_cast<const v4*>(a.C + (int64_t)cid * a.ldc + 4 * c) : (v4){0.f, 0.f, 0.f, 0.f};
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    for (int row = lane >> 3; row < 16; row += 8) {
-      float e0, e1, e2;
-      row_scalars<G, false>(myC + row * P4, lane & 7, e0, e1, e2);
-      if ((lane & 7) == 0) mycs[row] = e0;
-    }
+    const float en = valid ? a.cnorm[cid] : 0.f;                 // the same |e|^2 the sweep reads
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     v4 ce, we;
@@ -176,7 +209,7 @@ __global__ __launch_bounds__(256) void kg_list_scores_kernel(FArgs a) {
     const int reg = j - 4 * kq;
     if (reg >= 0 && reg < 4 && valid) {
       const int ur = 16 * w + j;
-      const float sc = pair_score<G>(ce[reg], we[reg], qs[ur * 4 + 0], mycs[j], qs[ur * 4 + 1], qs[ur * 4 + 2]);
+      const float sc = pair_score<G>(ce[reg], we[reg], qs[ur * 4 + 0], en, qs[ur * 4 + 1], qs[ur * 4 + 2]);
       if (s < ng) a.gscore_out[g0 + s] = sc; else a.fscore[f0_ + (s - ng)] = sc;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -185,7 +218,7 @@ __global__ __launch_bounds__(256) void kg_list_scores_kernel(FArgs a) {
 }
 
 // ---- the sweep
-template <typename G>
+template <typename G, int GMX>
 __global__ __launch_bounds__(NW * 64) void kg_count_mc_kernel(FArgs a) {
   constexpr int NCH = G::NCH, P4 = G::P4, QV = G::QV;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -193,15 +226,15 @@ __global__ __launch_bounds__(NW * 64) void kg_count_mc_kernel(FArgs a) {
   v4* Cd = Q + UB * QV * P4;
   float* qs = reinterpret_cast<float*>(Cd + IB * P4);
   float* cs = qs + UB * 4;
-  uint64_t* gkey = reinterpret_cast<uint64_t*>(cs + IB);         // [UB][GM]  (8-byte aligned: every part before is a multiple of 16)
+  uint64_t* gkey = reinterpret_cast<uint64_t*>(cs + IB);         // [UB][GMX]  (8-byte aligned: every part before is a multiple of 16)
   const int tid = threadIdx.x, lane = tid & 63, kq = lane >> 4, j = lane & 15;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int band = blockIdx.x;                                  // consecutive workgroup ids go round the 8 XCDs: band == XCD
   const int64_t u0 = (int64_t)blockIdx.y * UB;
   const bool desc = a.descending != 0;
   stage_queries<G>(a, Q, u0, NW * 64);
-  for (int idx = tid; idx < UB * GM; idx += NW * 64) {           // gold keys of the 64 keys (0 = no gold: no key is below it)
-    const int row = idx / GM, g = idx - row * GM;
+  for (int idx = tid; idx < UB * GMX; idx += NW * 64) {          // gold keys of the 64 keys (0 = no gold: no key is below it)
+    const int row = idx / GMX, g = idx - row * GMX;
     uint64_t k = 0;
     if (u0 + row < a.nq) {
       const int64_t g0 = a.gold_off[u0 + row], n = a.gold_off[u0 + row + 1] - g0;
@@ -218,11 +251,13 @@ __global__ __launch_bounds__(NW * 64) void kg_count_mc_kernel(FArgs a) {
   const int ut = w >> 2, it = w & 3;
   const v4* qa = Q + ((16 * ut + j) * QV) * P4 + kq;
   const v4* cb = Cd + (16 * it + j) * P4 + kq;
-  int cnt[4][GM];
+  int cnt[4][GMX];
 #pragma unroll
   for (int r = 0; r < 4; ++r)
 #pragma unroll
-    for (int g = 0; g < GM; ++g) cnt[r][g] = 0;
+    for (int g = 0; g < GMX; ++g) cnt[r][g] = 0;
+  QRegs<G> qr;
+  if constexpr (!G::TRANSH) qr.load(qa);      // Q was staged before the gold keys' barrier
   const int t0 = band * a.tiles_per_band;
   // a thread's share of a 64-candidate stage (IB * NCH float4 over 1024 threads: at most NLD each), fetched one stage AHEAD into
   // registers so that the global loads of stage t + 1 are in flight under the matrix work of stage t
@@ -248,16 +283,12 @@ __global__ __launch_bounds__(NW * 64) void kg_count_mc_kernel(FArgs a) {
       const int idx = tid + k * NW * 64;
       if (idx < IB * NCH) Cd[(idx / NCH) * P4 + (idx % NCH)] = nx[k];
     }
+    if (tid < IB) cs[tid] = i0 + tid < a.n_cand ? a.cnorm[i0 + tid] : 0.f;
     fetch(t + 1);
     __syncthreads();
-    for (int row = tid >> 3; row < IB; row += (NW * 64) >> 3) {
-      float e0, e1, e2;
-      row_scalars<G, false>(Cd + row * P4, tid & 7, e0, e1, e2);
-      if ((tid & 7) == 0) cs[row] = e0;
-    }
-    __syncthreads();
     v4 ce, we;
-    tile_dots<G>(qa, cb, ce, we);
+    if constexpr (G::TRANSH) tile_dots<G>(qa, cb, ce, we);      // two query vectors per key do not fit the registers (measured: spills)
+    else tile_dots_q<G>(qr, cb, ce, we);
     const float ee = cs[16 * it + j];
     const int64_t cand = i0 + 16 * it + j;
     if (cand < a.n_cand) {
@@ -266,7 +297,7 @@ __global__ __launch_bounds__(NW * 64) void kg_count_mc_kernel(FArgs a) {
         const int ur = 16 * ut + 4 * kq + reg;
         const uint64_t k = kg_key(pair_score<G>(ce[reg], we[reg], qs[ur * 4 + 0], ee, qs[ur * 4 + 1], qs[ur * 4 + 2]), desc, (uint32_t)cand);
 #pragma unroll
-        for (int g = 0; g < GM; ++g) cnt[reg][g] += k < gkey[ur * GM + g] ? 1 : 0;
+        for (int g = 0; g < GMX; ++g) cnt[reg][g] += k < gkey[ur * GMX + g] ? 1 : 0;
       }
     }
   }
@@ -274,7 +305,7 @@ __global__ __launch_bounds__(NW * 64) void kg_count_mc_kernel(FArgs a) {
 #pragma unroll
   for (int reg = 0; reg < 4; ++reg)
 #pragma unroll
-    for (int g = 0; g < GM; ++g) {
+    for (int g = 0; g < GMX; ++g) {
       int c = cnt[reg][g];
 #pragma unroll
       for (int m = 1; m < 16; m <<= 1) c += __shfl_xor(c, m, 64);
@@ -287,7 +318,7 @@ __global__ __launch_bounds__(NW * 64) void kg_count_mc_kernel(FArgs a) {
       if (key < a.nq) {
         const int64_t g0 = a.gold_off[key], n = a.gold_off[key + 1] - g0;
 #pragma unroll
-        for (int g = 0; g < GM; ++g)
+        for (int g = 0; g < GMX; ++g)
           if (g < n && cnt[reg][g] != 0) atomicAdd(a.counts + g0 + g, cnt[reg][g]);
       }
     }
@@ -327,33 +358,51 @@ __global__ __launch_bounds__(256) void kg_rank_finalize_kernel(FArgs a, int64_t 
   }
 }
 
-__global__ __launch_bounds__(256) void kg_zero_counts_kernel(int32_t* counts, int64_t n) {
+// counts <- 0 and |e|^2 of every candidate (8 lanes per row; ONE value per candidate for the whole pass)
+__global__ __launch_bounds__(256) void kg_pass_init_kernel(int32_t* counts, int64_t n, const float* __restrict__ C, int64_t ldc, int nch,
+                                                           int64_t n_cand, float* __restrict__ cnorm) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) counts[i] = 0;
+  for (int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 3; row < n_cand; row += ((int64_t)gridDim.x * 256) >> 3) {
+    const v4* r0 = reinterpret_cast<const v4*>(C + row * ldc);
+    v4 s0 = (v4){0.f, 0.f, 0.f, 0.f};
+    for (int c = threadIdx.x & 7; c < nch; c += 8) { const v4 x0 = r0[c]; s0 += x0 * x0; }
+    float f0 = (s0[0] + s0[1]) + (s0[2] + s0[3]);
+#pragma unroll
+    for (int m = 1; m < 8; m <<= 1) f0 += __shfl_xor(f0, m, 64);
+    if ((threadIdx.x & 7) == 0) cnorm[row] = f0;
+  }
 }
 
 template <typename G>
-int run_fused(FArgs a, int64_t n_gold, hipStream_t st, const char* name) {
+int run_fused(FArgs a, int64_t n_gold, int64_t max_golds, hipStream_t st, const char* name) {
   (void)hipFuncSetAttribute((const void*)kg_list_scores_kernel<G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS);
-  (void)hipFuncSetAttribute((const void*)kg_count_mc_kernel<G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS);
   const unsigned qblocks = (unsigned)((a.nq + UB - 1) / UB);
-  hipLaunchKernelGGL(kg_zero_counts_kernel, dim3(grid_for((n_gold + 255) / 256, 1024)), dim3(256), 0, st, a.counts, n_gold);
+  const int64_t init_work = n_gold > (a.n_cand * 8) ? n_gold : a.n_cand * 8;
+  hipLaunchKernelGGL(kg_pass_init_kernel, dim3(grid_for((init_work + 255) / 256, 2048)), dim3(256), 0, st, a.counts, n_gold, a.C, a.ldc, G::NCH,
+                     a.n_cand, a.cnorm);
   a.gscore_out = const_cast<float*>(a.gscore);
   hipLaunchKernelGGL((kg_list_scores_kernel<G>), dim3(qblocks), dim3(256), G::LDS, st, a);
   const int64_t ntiles = (a.n_cand + IB - 1) / IB;
   a.tiles_per_band = (int)((ntiles + NBAND - 1) / NBAND);
-  hipLaunchKernelGGL((kg_count_mc_kernel<G>), dim3(NBAND, qblocks), dim3(NW * 64), G::LDS, st, a);
+  if (max_golds <= 4) {          // half the compares per candidate (typical link-prediction keys have one to three golds)
+    (void)hipFuncSetAttribute((const void*)kg_count_mc_kernel<G, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS);
+    hipLaunchKernelGGL((kg_count_mc_kernel<G, 4>), dim3(NBAND, qblocks), dim3(NW * 64), G::LDS, st, a);
+  } else {
+    (void)hipFuncSetAttribute((const void*)kg_count_mc_kernel<G, GM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS);
+    hipLaunchKernelGGL((kg_count_mc_kernel<G, GM>), dim3(NBAND, qblocks), dim3(NW * 64), G::LDS, st, a);
+  }
   hipLaunchKernelGGL(kg_rank_finalize_kernel, dim3(grid_for((a.nq + 255) / 256, 1024)), dim3(256), 0, st, a, n_gold);
   return check_launch(name);
 }
 
 template <bool TRANSH>
-int dispatch_fused(const FArgs& a, int d, int64_t n_gold, hipStream_t st, const char* name) {
+int dispatch_fused(const FArgs& a, int d, int64_t n_gold, int64_t max_golds, hipStream_t st, const char* name) {
   switch (d) {
-    case 20: return run_fused<FGeom<5, TRANSH>>(a, n_gold, st, name);
-    case 36: return run_fused<FGeom<9, TRANSH>>(a, n_gold, st, name);
-    case 64: return run_fused<FGeom<16, TRANSH>>(a, n_gold, st, name);
-    case 100: return run_fused<FGeom<25, TRANSH>>(a, n_gold, st, name);
-    case 128: return run_fused<FGeom<32, TRANSH>>(a, n_gold, st, name);
+    case 20: return run_fused<FGeom<5, TRANSH>>(a, n_gold, max_golds, st, name);
+    case 36: return run_fused<FGeom<9, TRANSH>>(a, n_gold, max_golds, st, name);
+    case 64: return run_fused<FGeom<16, TRANSH>>(a, n_gold, max_golds, st, name);
+    case 100: return run_fused<FGeom<25, TRANSH>>(a, n_gold, max_golds, st, name);
+    case 128: return run_fused<FGeom<32, TRANSH>>(a, n_gold, max_golds, st, name);
     default: return 1;
   }
 }
@@ -368,10 +417,10 @@ extern "C" int ktup_eval_kg_ranks_fused_supported(int model, int d, int l1, int6
          max_golds <= ktup::GM && ktup::opt_eval_mc();
 }
 
-extern "C" size_t ktup_eval_kg_ranks_fused_workspace_bytes(int d, int64_t nq, int64_t n_gold, int64_t n_filt) {
-  if (d <= 0 || nq <= 0) return 0;
+extern "C" size_t ktup_eval_kg_ranks_fused_workspace_bytes(int d, int64_t nq, int64_t n_gold, int64_t n_filt, int64_t n_cand) {
+  if (d <= 0 || nq <= 0 || n_cand <= 0) return 0;
   return ktup::pad256(ktup_eval_kg_workspace_bytes(d, nq)) + ktup::pad256((size_t)(n_gold > 0 ? n_gold : 1) * 4) * 2 +
-         ktup::pad256((size_t)(n_filt > 0 ? n_filt : 1) * 4);
+         ktup::pad256((size_t)(n_filt > 0 ? n_filt : 1) * 4) + ktup::pad256((size_t)n_cand * 4);
 }
 
 extern "C" int ktup_eval_kg_ranks_fused(int model, const float* E, int64_t lde, const float* R, int64_t ldr, const float* Nrm, int64_t ldn,
@@ -393,13 +442,14 @@ extern "C" int ktup_eval_kg_ranks_fused(int model, const float* E, int64_t lde, 
   float* QW = reinterpret_cast<float*>(p); p += pad256(ktup_eval_kg_workspace_bytes(d, nq));
   float* gscore = reinterpret_cast<float*>(p); p += pad256((size_t)n_gold * 4);
   int32_t* counts = reinterpret_cast<int32_t*>(p); p += pad256((size_t)n_gold * 4);
-  float* fscore = reinterpret_cast<float*>(p);
+  float* fscore = reinterpret_cast<float*>(p); p += pad256((size_t)(n_filt > 0 ? n_filt : 1) * 4);
+  float* cnorm = reinterpret_cast<float*>(p);
   if (int e = kg_query_prep(model, E, lde, R, ldr, Nrm, ldn, d, q, r, nq, head, QW, st, name)) return e;
   FArgs a{};
   a.QW = QW; a.dq = (d + 3) & ~3; a.C = C; a.ldc = ldc; a.nq = nq; a.n_cand = n_cand; a.descending = descending;
   a.gold_off = gold_off; a.gold_ids = gold_ids; a.gscore = gscore; a.filt_off = filt_off; a.filt_ids = filt_ids; a.fscore = fscore;
-  a.counts = counts; a.ranks = ranks;
-  const int rc = model == KTUP_KG_TRANSH ? dispatch_fused<true>(a, d, n_gold, st, name) : dispatch_fused<false>(a, d, n_gold, st, name);
+  a.counts = counts; a.ranks = ranks; a.cnorm = cnorm;
+  const int rc = model == KTUP_KG_TRANSH ? dispatch_fused<true>(a, d, n_gold, max_golds, st, name) : dispatch_fused<false>(a, d, n_gold, max_golds, st, name);
   if (rc == 1) return set_error(KTUP_ERR_UNSUPPORTED, "%s: d=%d is not an instantiated width", name, d);
   return rc;
 }

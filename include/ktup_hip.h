@@ -314,11 +314,14 @@ int ktup_eval_gold_ranks(const float* scores, int64_t lds, int64_t nq, int64_t n
  * other golds of the key ordered before g, whose scores come from a small launch that runs the sweep's own instruction sequence
  * (bit-identical keys).  Same arguments and results as ktup_eval_kg_ranks, all keys in one go; n_filt / n_gold = lengths of the id
  * arrays, max_golds = the largest gold set of a key (host side).  ktup_eval_kg_ranks_fused_supported: l1 == 0, d in
- * {20, 36, 64, 100, 128}, max_golds <= 8 (else KTUP_ERR_UNSUPPORTED: use ktup_eval_kg_ranks).                                  */
+ * {20, 36, 64, 100, 128}, max_golds <= 8 (else KTUP_ERR_UNSUPPORTED: use ktup_eval_kg_ranks).  n_rel = rows of R / Nrm: TransH's
+ * second product w.e depends on (relation, candidate) only and is computed once per pass into an n_rel x n_cand table in `ws`
+ * (n_rel = 0, option kg_wtab = 0 or a table beyond 1 GiB: both products in the sweep; the same integers either way).            */
 int ktup_eval_kg_ranks_fused_supported(int model, int d, int l1, int64_t max_golds);
-size_t ktup_eval_kg_ranks_fused_workspace_bytes(int d, int64_t nq, int64_t n_gold, int64_t n_filt, int64_t n_cand);
-int ktup_eval_kg_ranks_fused(int model, const float* E, int64_t lde, const float* R, int64_t ldr, const float* Nrm, int64_t ldn, int d,
-                             const float* C, int64_t ldc, int64_t n_cand, const int64_t* q, const int64_t* r, int64_t nq, int head,
+size_t ktup_eval_kg_ranks_fused_workspace_bytes(int model, int d, int64_t nq, int64_t n_gold, int64_t n_filt, int64_t n_cand,
+                                                int64_t n_rel);
+int ktup_eval_kg_ranks_fused(int model, const float* E, int64_t lde, const float* R, int64_t ldr, const float* Nrm, int64_t ldn,
+                             int64_t n_rel, int d, const float* C, int64_t ldc, int64_t n_cand, const int64_t* q, const int64_t* r, int64_t nq, int head,
                              int descending, const int64_t* filt_off, const int32_t* filt_ids, int64_t n_filt,
                              const int64_t* gold_off, const int32_t* gold_ids, int64_t n_gold, int64_t max_golds, int32_t* ranks,
                              void* ws, void* stream);

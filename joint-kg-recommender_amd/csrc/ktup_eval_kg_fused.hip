@@ -10,11 +10,18 @@
 //   kg_list_scores  the scores of every (key, gold) and (key, filtered id) pair -- a few dozen per key -- computed with the SAME
 //                   instruction sequence as the sweep (per wave: 16 keys x 16 gathered candidates per MFMA tile, of which the
 //                   diagonal is kept), so that a candidate's key is bit-identical in both places;
-//   kg_count_mc     the sweep: a workgroup keeps 64 keys' query vectors in LDS and walks one eighth of the candidate table (one
-//                   band per XCD: its L2 then serves all the workgroups that walk it), 64 candidates per stage; each wave owns
-//                   a 16 x 16 tile per stage, turns its four scores per lane into keys and compares them with the (<= 8) gold
-//                   keys of its keys, counting in registers; one flush of int atomics per workgroup at the end;
+//   kg_count_mc     the sweep: a workgroup keeps 64 keys' query vectors in LDS (registers where they fit) and walks one eighth of
+//                   the candidate table (one band per XCD: its L2 then serves all the workgroups that walk it), 64 candidates per
+//                   stage, double-buffered: ONE barrier per stage; each wave owns a 16 x 16 tile per stage and compares its four
+//                   scores per lane with the (<= 8) gold scores of its keys -- as FLOATS, two VALU instructions per (score, gold);
+//                   only when some lane sees a tie or a NaN (v_cmp_nlg: the gold itself, once per band) does the wave build the
+//                   64-bit keys, so the order is that of the keys in every case; counts in registers, one flush of int atomics
+//                   per workgroup at the end;
 //   kg_rank_finalize  the subtraction above, per gold entry, from the list scores.
+// TransH's second product w.e (w = the relation's hyperplane normal) depends on (relation, candidate) only: kg_wtab computes the
+// (relations x candidates) table once per pass with the same MFMA sequence (mode 2), and the sweep is TransE's plus four table
+// look-ups per lane and stage, fetched one stage ahead -- half the matrix instructions of mode 1 (both products in the sweep), which
+// stays for relation counts whose table would not fit.
 // Covers d in {20, 36, 64, 100, 128}, at most GM = 8 golds per key (the caller checks; otherwise the chunked matrix route runs).
 #include <hip/hip_runtime.h>
 
@@ -27,20 +34,22 @@
 namespace ktup {
 namespace {
 
-constexpr int IB = 64, UB = 64, NW = 16, GM = 8, NBAND = 8;      // GM: most golds per key (the sweep is instantiated for 4 and 8)
+constexpr int IB = 64, UB = 64, NW = 16, GM = 8, GS = 4, NBAND = 8;   // GM: most golds per key; GS: golds a sweep launch counts for (a second
+                                                                      // launch takes golds 4..7 of the few keys that have them)
 
-template <int NCH_, bool TRANSH_>
+// MODE 0: TransE; 1: TransH, both products in the sweep; 2: TransH, w.e from the (relations x candidates) table
+template <int NCH_, int MODE_>
 struct FGeom {
-  static constexpr int NCH = NCH_, D = 4 * NCH;
-  static constexpr bool TRANSH = TRANSH_;
+  static constexpr int NCH = NCH_, D = 4 * NCH, MODE = MODE_;
+  static constexpr bool TRANSH = MODE == 1, WTAB = MODE == 2;
   static constexpr int KG = (D + 15) / 16;
   static constexpr bool TAIL1 = NCH - 4 * (KG - 1) == 1;
   static constexpr int KGF = TAIL1 ? KG - 1 : KG;
   static_assert(TAIL1 || NCH % 4 == 0, "k groups must be whole (d % 16 in {0, 4})");
   static constexpr int P4 = NCH | 1;
   static constexpr int QV = TRANSH ? 2 : 1;
-  // Q [UB][QV][P4] v4 | C [IB][P4] v4 | qs [UB][4] | cs [IB] | gkey [UB][GM] u64 | gn [UB]
-  static constexpr size_t LDS = (size_t)(UB * QV + IB) * P4 * 16 + (size_t)(UB * 4 + IB) * 4 + (size_t)UB * GM * 8 + (size_t)UB * 4;
+  // Q [UB][QV][P4] v4 | C [2][IB][P4] v4 | qs [UB][4] | gth [UB][GS] | gkey [UB][GS] u64
+  static constexpr size_t LDS = (size_t)(UB * QV + 2 * IB) * P4 * 16 + (size_t)UB * 4 * 4 + (size_t)UB * GS * 4 + (size_t)UB * GS * 8;
 };
 
 KTUP_DEV uint64_t kg_key(float s, bool descending, uint32_t id) {      // = make_key of ktup_rank.hip
@@ -61,7 +70,11 @@ struct FArgs {
   float* gscore_out;
   int32_t* counts; int32_t* ranks;
   int tiles_per_band;
-  float* cnorm;                 // |e|^2 of every candidate, computed ONCE per pass (kg_cand_norms_kernel) and read by both kernels
+  int gbase;                    // the sweep launch counts for golds gbase .. gbase + GS - 1 of every key
+  float* cnorm;                 // |e|^2 of every candidate, computed ONCE per pass (kg_pass_init_kernel) and read by both kernels
+  const int64_t* rel;           // mode 2: the keys' relation ids, the normals' table and w.e of every (relation, candidate)
+  const float* Nrm; int64_t ldn; int n_rel;
+  float* wtab; int64_t ldw;
 };
 
 // ---- pieces shared by the list kernel and the sweep: identical code => identical bits
@@ -76,19 +89,34 @@ KTUP_DEV void stage_queries(const FArgs& a, v4* Q, int64_t u0, int nthreads) {
   }
 }
 
-// |c|^2, c.w, |w|^2 of a query row / |e|^2 of a candidate row: 8 lanes per row, chunks sub, sub + 8, ...
-template <typename G, bool QUERY>
-KTUP_DEV void row_scalars(const v4* r0, int sub, float& f0, float& f1, float& f2) {
-  constexpr int NCH = G::NCH, P4 = G::P4;
+// |c|^2, c.w, |w|^2 of a query row (w0: its normal, LDS in mode 1, the prepared query rows in global memory in mode 2): 8 lanes per
+// row, chunks sub, sub + 8, ...
+template <typename G>
+KTUP_DEV void row_scalars(const v4* c0, const v4* w0, int sub, float& f0, float& f1, float& f2) {
+  constexpr int NCH = G::NCH;
   v4 s0 = (v4){0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0;
   for (int c = sub; c < NCH; c += 8) {
-    const v4 x0 = r0[c];
+    const v4 x0 = c0[c];
     s0 += x0 * x0;
-    if (QUERY && G::TRANSH) { const v4 x1 = r0[P4 + c]; s1 += x0 * x1; s2 += x1 * x1; }
+    if (G::MODE != 0 && w0) { const v4 x1 = w0[c]; s1 += x0 * x1; s2 += x1 * x1; }
   }
   f0 = (s0[0] + s0[1]) + (s0[2] + s0[3]); f1 = (s1[0] + s1[1]) + (s1[2] + s1[3]); f2 = (s2[0] + s2[1]) + (s2[2] + s2[3]);
 #pragma unroll
   for (int m = 1; m < 8; m <<= 1) { f0 += __shfl_xor(f0, m, 64); f1 += __shfl_xor(f1, m, 64); f2 += __shfl_xor(f2, m, 64); }
+}
+
+// qs[row] = the three scalars of the workgroup's 64 keys (Q staged and visible)
+template <typename G>
+KTUP_DEV void query_scalars(const FArgs& a, const v4* Q, float* qs, int64_t u0, int nthreads) {
+  constexpr int P4 = G::P4, QV = G::QV;
+  for (int row = threadIdx.x >> 3; row < UB; row += nthreads >> 3) {
+    const v4* c0 = Q + row * QV * P4;
+    const v4* w0 = G::TRANSH ? c0 + P4 : nullptr;
+    if (G::WTAB && u0 + row < a.nq) w0 = reinterpret_cast<const v4*>(a.QW + ((u0 + row) * 3 + 2) * a.dq);
+    float f0, f1, f2;
+    row_scalars<G>(c0, w0, threadIdx.x & 7, f0, f1, f2);
+    if ((threadIdx.x & 7) == 0) { qs[row * 4 + 0] = f0; qs[row * 4 + 1] = f1; qs[row * 4 + 2] = f2; }
+  }
 }
 
 // one 16 x 16 (keys x candidates) tile: qa = the wave's query rows (+ kq), cb = its candidate rows (+ kq)
@@ -113,6 +141,26 @@ KTUP_DEV void tile_dots(const v4* qa, const v4* cb, v4& ce, v4& we) {
     ce = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[0], be, ce, 0, 0, 0);
     if (G::TRANSH) we = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[4 * P4], be, we, 0, 0, 0);
   }
+}
+
+// one product of the tile: the `ce` chain of tile_dots alone (the same instructions on the same operands: the same bits)
+template <typename G>
+KTUP_DEV v4 tile_dot1(const v4* qa, const v4* cb) {
+  constexpr int KGF = G::KGF;
+  v4 ce = (v4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int g = 0; g < KGF; ++g) {
+    const v4 ac = qa[4 * g], be = cb[4 * g];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) ce = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[c], be[c], ce, 0, 0, 0);
+  }
+  if (G::TAIL1) {
+    const int kq = (threadIdx.x & 63) >> 4;
+    const float qf = (reinterpret_cast<const float*>(qa - kq + 4 * KGF) + kq)[0];
+    const float be = (reinterpret_cast<const float*>(cb - kq + 4 * KGF) + kq)[0];
+    ce = __builtin_amdgcn_mfma_f32_16x16x4f32(qf, be, ce, 0, 0, 0);
+  }
+  return ce;
 }
 
 // the same tile with the query-side operands held in registers (the sweep re-uses them for every candidate stage): the MFMA
@@ -158,7 +206,7 @@ KTUP_DEV void tile_dots_q(const QRegs<G>& q, const v4* cb, v4& ce, v4& we) {
 template <typename G>
 KTUP_DEV float pair_score(float ce, float we, float cc, float en, float cw, float ww) {
   float score = fmaf(-2.f, ce, cc + en);
-  if (G::TRANSH) score = fmaf(we, fmaf(we, ww - 2.f, 2.f * cw), score);
+  if (G::MODE != 0) score = fmaf(we, fmaf(we, ww - 2.f, 2.f * cw), score);
   return score;
 }
 
@@ -170,23 +218,20 @@ __global__ __launch_bounds__(256) void kg_list_scores_kernel(FArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   v4* Q = reinterpret_cast<v4*>(smem);                         // [UB][QV][P4]
   v4* Cd = Q + UB * QV * P4;                                   // [4 waves][16][P4]
-  float* qs = reinterpret_cast<float*>(Cd + IB * P4);          // [UB][4]
+  float* qs = reinterpret_cast<float*>(Cd + 2 * IB * P4);      // [UB][4]
   const int tid = threadIdx.x, lane = tid & 63, kq = lane >> 4, j = lane & 15;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t u0 = (int64_t)blockIdx.x * UB;
   stage_queries<G>(a, Q, u0, 256);
   __syncthreads();
-  for (int row = tid >> 3; row < UB; row += 32) {
-    float f0, f1, f2;
-    row_scalars<G, true>(Q + row * QV * P4, tid & 7, f0, f1, f2);
-    if ((tid & 7) == 0) { qs[row * 4 + 0] = f0; qs[row * 4 + 1] = f1; qs[row * 4 + 2] = f2; }
-  }
+  query_scalars<G>(a, Q, qs, u0, 256);
   __syncthreads();
   // this lane's key (for gathering: lane = (row j of the wave, chunk group))
   const int64_t key_j = u0 + 16 * w + j;
   const bool key_on = key_j < a.nq;
   const int64_t g0 = key_on ? a.gold_off[key_j] : 0, ng = key_on ? a.gold_off[key_j + 1] - g0 : 0;
   const int64_t f0_ = (key_on && a.filt_off) ? a.filt_off[key_j] : 0, nf = (key_on && a.filt_off) ? a.filt_off[key_j + 1] - f0_ : 0;
+  const int64_t wrow = (G::WTAB && key_on) ? a.rel[key_j] * a.ldw : 0;
   int64_t len = ng + nf, maxlen = len;
 #pragma unroll
   for (int m = 1; m < 64; m <<= 1) { const int64_t o = __shfl_xor(maxlen, m, 64); maxlen = o > maxlen ? o : maxlen; }
@@ -201,10 +246,12 @@ __global__ __launch_bounds__(256) void kg_list_scores_kernel(FArgs a) {
     for (int c = kq; c < NCH; c += 4)
       myC[j * P4 + c] = valid ? *reinterpret_cast<const v4*>(a.C + (int64_t)cid * a.ldc + 4 * c) : (v4){0.f, 0.f, 0.f, 0.f};
     const float en = valid ? a.cnorm[cid] : 0.f;                 // the same |e|^2 the sweep reads
+    const float wt = (G::WTAB && valid) ? a.wtab[wrow + cid] : 0.f;   // and the same w.e
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     v4 ce, we;
-    tile_dots<G>(qa, cb, ce, we);
+    if constexpr (G::TRANSH) tile_dots<G>(qa, cb, ce, we);
+    else { ce = tile_dot1<G>(qa, cb); we = (v4){wt, wt, wt, wt}; }
     // diagonal: key (4 kq + reg) against candidate column j  <=>  j == 4 kq + reg
     const int reg = j - 4 * kq;
     if (reg >= 0 && reg < 4 && valid) {
@@ -217,52 +264,101 @@ __global__ __launch_bounds__(256) void kg_list_scores_kernel(FArgs a) {
   }
 }
 
+// ---- mode 2: w.e of every (relation, candidate): a wave = 16 relations x 16 candidates, the sweep's `we` chain
+template <typename G>
+__global__ __launch_bounds__(256) void kg_wtab_kernel(FArgs a) {
+  constexpr int NCH = G::NCH, P4 = G::P4;
+  __shared__ __attribute__((aligned(16))) v4 W[16 * P4];
+  __shared__ __attribute__((aligned(16))) v4 Cs[IB * P4];
+  const int tid = threadIdx.x, lane = tid & 63, kq = lane >> 4, j = lane & 15;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t i0 = (int64_t)blockIdx.x * IB;
+  const int r0 = blockIdx.y * 16;
+  for (int idx = tid; idx < 16 * NCH; idx += 256) {
+    const int row = idx / NCH, c = idx - row * NCH;
+    v4 val = (v4){0.f, 0.f, 0.f, 0.f};
+    if (r0 + row < a.n_rel) {                                   // the zero padding of kg_query_prep's slot 2 (d % 4 != 0 never gets here: d = 4 NCH)
+      const float* src = a.Nrm + (int64_t)(r0 + row) * a.ldn + 4 * c;
+      val = (v4){src[0], src[1], src[2], src[3]};
+    }
+    W[row * P4 + c] = val;
+  }
+  for (int idx = tid; idx < IB * NCH; idx += 256) {
+    const int row = idx / NCH, c = idx - row * NCH;
+    Cs[row * P4 + c] = i0 + row < a.n_cand ? *reinterpret_cast<const v4*>(a.C + (i0 + row) * a.ldc + 4 * c) : (v4){0.f, 0.f, 0.f, 0.f};
+  }
+  __syncthreads();
+  const v4 we = tile_dot1<G>(W + j * P4 + kq, Cs + (16 * w + j) * P4 + kq);
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg)
+    if (r0 + 4 * kq + reg < a.n_rel) a.wtab[(int64_t)(r0 + 4 * kq + reg) * a.ldw + i0 + 16 * w + j] = we[reg];
+}
+
 // ---- the sweep
-template <typename G, int GMX>
+template <typename G>
 __global__ __launch_bounds__(NW * 64) void kg_count_mc_kernel(FArgs a) {
-  constexpr int NCH = G::NCH, P4 = G::P4, QV = G::QV;
+  constexpr int NCH = G::NCH, P4 = G::P4, QV = G::QV, GMX = GS;
+  // what a lane keeps in registers across the stages (128 VGPRs per wave at 16 waves per CU): the gold scores and the three scalars
+  // of its four keys, and the query operands of its MFMAs unless the key has two vectors (mode 1) or the table look-ups of mode 2 at
+  // d >= 100 take the room (measured: the same pass time with the operands read from LDS, thresholds from LDS, or six spilled registers)
+  constexpr bool QREGS = !G::TRANSH && !(G::WTAB && NCH >= 25);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   v4* Q = reinterpret_cast<v4*>(smem);
-  v4* Cd = Q + UB * QV * P4;
-  float* qs = reinterpret_cast<float*>(Cd + IB * P4);
-  float* cs = qs + UB * 4;
-  uint64_t* gkey = reinterpret_cast<uint64_t*>(cs + IB);         // [UB][GMX]  (8-byte aligned: every part before is a multiple of 16)
+  v4* Cd = Q + UB * QV * P4;                                    // [2][IB][P4]
+  float* qs = reinterpret_cast<float*>(Cd + 2 * IB * P4);
+  float* gth = qs + UB * 4;                                     // [UB][GMX] gold scores as compared (sign-flipped when descending)
+  uint64_t* gkey = reinterpret_cast<uint64_t*>(gth + UB * GMX); // [UB][GMX]  (8-byte aligned: every part before is a multiple of 16)
   const int tid = threadIdx.x, lane = tid & 63, kq = lane >> 4, j = lane & 15;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int band = blockIdx.x;                                  // consecutive workgroup ids go round the 8 XCDs: band == XCD
   const int64_t u0 = (int64_t)blockIdx.y * UB;
   const bool desc = a.descending != 0;
+  const uint32_t flip = desc ? 0x80000000u : 0u;                // scores are compared as s ^ flip: ascending in every case
+  if (a.gbase > 0) {                                            // a later launch: only for workgroups with a key that has such golds
+    int more = 0;
+    if (tid < UB && u0 + tid < a.nq) more = a.gold_off[u0 + tid + 1] - a.gold_off[u0 + tid] > a.gbase;
+    if (!__syncthreads_or(more)) return;
+  }
   stage_queries<G>(a, Q, u0, NW * 64);
   for (int idx = tid; idx < UB * GMX; idx += NW * 64) {          // gold keys of the 64 keys (0 = no gold: no key is below it)
-    const int row = idx / GMX, g = idx - row * GMX;
+    const int row = idx / GMX, g = a.gbase + idx - row * GMX;
     uint64_t k = 0;
+    float th = -__builtin_inff();                               // nothing is below it; a tie with it goes to the key compare (false)
     if (u0 + row < a.nq) {
       const int64_t g0 = a.gold_off[u0 + row], n = a.gold_off[u0 + row + 1] - g0;
-      if (g < n) k = kg_key(a.gscore[g0 + g], desc, (uint32_t)a.gold_ids[g0 + g]);
+      if (g < n) {
+        k = kg_key(a.gscore[g0 + g], desc, (uint32_t)a.gold_ids[g0 + g]);
+        th = __uint_as_float(__float_as_uint(a.gscore[g0 + g]) ^ flip);
+      }
     }
-    gkey[idx] = k;
+    gkey[idx] = k; gth[idx] = th;
   }
   __syncthreads();
-  for (int row = tid >> 3; row < UB; row += (NW * 64) >> 3) {
-    float f0, f1, f2;
-    row_scalars<G, true>(Q + row * QV * P4, tid & 7, f0, f1, f2);
-    if ((tid & 7) == 0) { qs[row * 4 + 0] = f0; qs[row * 4 + 1] = f1; qs[row * 4 + 2] = f2; }
-  }
+  query_scalars<G>(a, Q, qs, u0, NW * 64);
+  __syncthreads();
   const int ut = w >> 2, it = w & 3;
   const v4* qa = Q + ((16 * ut + j) * QV) * P4 + kq;
-  const v4* cb = Cd + (16 * it + j) * P4 + kq;
   int cnt[4][GMX];
+  float th[4][GMX];
+  v4 qsr[4];
+  int32_t wo[4];
 #pragma unroll
-  for (int r = 0; r < 4; ++r)
+  for (int r = 0; r < 4; ++r) {
+    const int ur = 16 * ut + 4 * kq + r;
 #pragma unroll
-    for (int g = 0; g < GMX; ++g) cnt[r][g] = 0;
+    for (int g = 0; g < GMX; ++g) { cnt[r][g] = 0; th[r][g] = gth[ur * GMX + g]; }
+    qsr[r] = *reinterpret_cast<const v4*>(qs + ur * 4);
+    wo[r] = (G::WTAB && u0 + ur < a.nq) ? (int32_t)(a.rel[u0 + ur] * a.ldw) : 0;
+  }
   QRegs<G> qr;
-  if constexpr (!G::TRANSH) qr.load(qa);      // Q was staged before the gold keys' barrier
-  const int t0 = band * a.tiles_per_band;
-  // a thread's share of a 64-candidate stage (IB * NCH float4 over 1024 threads: at most NLD each), fetched one stage AHEAD into
-  // registers so that the global loads of stage t + 1 are in flight under the matrix work of stage t
+  if constexpr (QREGS) qr.load(qa);
+  const int t0 = band * a.tiles_per_band, t1 = t0 + a.tiles_per_band;
+  // a thread's share of a 64-candidate stage (IB * NCH float4 over 1024 threads: at most NLD each) and its candidate's |e|^2 (mode 2:
+  // and the four w.e of its keys), fetched one stage AHEAD into registers: the loads of stage t + 1 are in flight under the matrix
+  // work of stage t
   constexpr int NLD = (IB * NCH + NW * 64 - 1) / (NW * 64);
   v4 nx[NLD];
+  float en_nx = 0.f, we_nx[4] = {0.f, 0.f, 0.f, 0.f};
   auto fetch = [&](int t) {
     const int64_t i0 = (int64_t)t * IB;
 #pragma unroll
@@ -270,34 +366,67 @@ __global__ __launch_bounds__(NW * 64) void kg_count_mc_kernel(FArgs a) {
       const int idx = tid + k * NW * 64;
       const int row = idx / NCH, c = idx - row * NCH;
       nx[k] = (v4){0.f, 0.f, 0.f, 0.f};
-      if (idx < IB * NCH && t < t0 + a.tiles_per_band && i0 + row < a.n_cand) nx[k] = *reinterpret_cast<const v4*>(a.C + (i0 + row) * a.ldc + 4 * c);
+      if (idx < IB * NCH && t < t1 && i0 + row < a.n_cand) nx[k] = *reinterpret_cast<const v4*>(a.C + (i0 + row) * a.ldc + 4 * c);
+    }
+    const int64_t cand = i0 + 16 * it + j;
+    if (t < t1 && cand < a.n_cand) {
+      en_nx = a.cnorm[cand];
+      if constexpr (G::WTAB) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) we_nx[r] = a.wtab[wo[r] + cand];
+      }
     }
   };
   fetch(t0);
-  for (int t = t0; t < t0 + a.tiles_per_band; ++t) {
+  for (int t = t0; t < t1; ++t) {
     const int64_t i0 = (int64_t)t * IB;
     if (i0 >= a.n_cand) break;
-    __syncthreads();                                            // the previous stage's tile has been consumed (and qs is complete)
+    v4* Cs = Cd + ((t - t0) & 1) * IB * P4;                     // the other half was read in stage t - 1: every wave is past that barrier
 #pragma unroll
     for (int k = 0; k < NLD; ++k) {
       const int idx = tid + k * NW * 64;
-      if (idx < IB * NCH) Cd[(idx / NCH) * P4 + (idx % NCH)] = nx[k];
+      if (idx < IB * NCH) Cs[(idx / NCH) * P4 + (idx % NCH)] = nx[k];
     }
-    if (tid < IB) cs[tid] = i0 + tid < a.n_cand ? a.cnorm[i0 + tid] : 0.f;
+    const float ee = en_nx;
+    float wl[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) wl[r] = we_nx[r];
     fetch(t + 1);
     __syncthreads();
+    const v4* cb = Cs + (16 * it + j) * P4 + kq;
     v4 ce, we;
     if constexpr (G::TRANSH) tile_dots<G>(qa, cb, ce, we);      // two query vectors per key do not fit the registers (measured: spills)
-    else tile_dots_q<G>(qr, cb, ce, we);
-    const float ee = cs[16 * it + j];
+    else {
+      if constexpr (QREGS) tile_dots_q<G>(qr, cb, ce, we); else ce = tile_dot1<G>(qa, cb);
+      we = (v4){wl[0], wl[1], wl[2], wl[3]};
+    }
     const int64_t cand = i0 + 16 * it + j;
     if (cand < a.n_cand) {
+      float s[4];
+      bool tie = false;
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
-        const int ur = 16 * ut + 4 * kq + reg;
-        const uint64_t k = kg_key(pair_score<G>(ce[reg], we[reg], qs[ur * 4 + 0], ee, qs[ur * 4 + 1], qs[ur * 4 + 2]), desc, (uint32_t)cand);
+        const v4 qv = qsr[reg];
+        s[reg] = __uint_as_float(__float_as_uint(pair_score<G>(ce[reg], we[reg], qv[0], ee, qv[1], qv[2])) ^ flip);
 #pragma unroll
-        for (int g = 0; g < GMX; ++g) cnt[reg][g] += k < gkey[ur * GMX + g] ? 1 : 0;
+        for (int g = 0; g < GMX; ++g) {
+          const float tg = th[reg][g];
+          const bool lt = s[reg] < tg;
+          cnt[reg][g] += lt ? 1 : 0;
+          tie |= !lt && !(s[reg] > tg);                         // equal or unordered: the keys decide
+        }
+      }
+      if (__builtin_amdgcn_ballot_w64(tie) != 0) {               // rare: the gold itself (once per band), exact float ties, NaNs
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int ur = 16 * ut + 4 * kq + reg;
+          const uint64_t k = kg_key(s[reg], false, (uint32_t)cand);   // s is already flipped
+#pragma unroll
+          for (int g = 0; g < GMX; ++g) {
+            const float tg = th[reg][g];
+            if (!(s[reg] < tg) && !(s[reg] > tg)) cnt[reg][g] += k < gkey[ur * GMX + g] ? 1 : 0;
+          }
+        }
       }
     }
   }
@@ -319,7 +448,7 @@ __global__ __launch_bounds__(NW * 64) void kg_count_mc_kernel(FArgs a) {
         const int64_t g0 = a.gold_off[key], n = a.gold_off[key + 1] - g0;
 #pragma unroll
         for (int g = 0; g < GMX; ++g)
-          if (g < n && cnt[reg][g] != 0) atomicAdd(a.counts + g0 + g, cnt[reg][g]);
+          if (a.gbase + g < n && cnt[reg][g] != 0) atomicAdd(a.counts + g0 + a.gbase + g, cnt[reg][g]);
       }
     }
   }
@@ -380,34 +509,38 @@ int run_fused(FArgs a, int64_t n_gold, int64_t max_golds, hipStream_t st, const 
   const int64_t init_work = n_gold > (a.n_cand * 8) ? n_gold : a.n_cand * 8;
   hipLaunchKernelGGL(kg_pass_init_kernel, dim3(grid_for((init_work + 255) / 256, 2048)), dim3(256), 0, st, a.counts, n_gold, a.C, a.ldc, G::NCH,
                      a.n_cand, a.cnorm);
+  const int64_t ntiles = (a.n_cand + IB - 1) / IB;
+  if constexpr (G::WTAB) hipLaunchKernelGGL((kg_wtab_kernel<G>), dim3((unsigned)ntiles, (unsigned)((a.n_rel + 15) / 16)), dim3(256), 0, st, a);
   a.gscore_out = const_cast<float*>(a.gscore);
   hipLaunchKernelGGL((kg_list_scores_kernel<G>), dim3(qblocks), dim3(256), G::LDS, st, a);
-  const int64_t ntiles = (a.n_cand + IB - 1) / IB;
   a.tiles_per_band = (int)((ntiles + NBAND - 1) / NBAND);
-  if (max_golds <= 4) {          // half the compares per candidate (typical link-prediction keys have one to three golds)
-    (void)hipFuncSetAttribute((const void*)kg_count_mc_kernel<G, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS);
-    hipLaunchKernelGGL((kg_count_mc_kernel<G, 4>), dim3(NBAND, qblocks), dim3(NW * 64), G::LDS, st, a);
-  } else {
-    (void)hipFuncSetAttribute((const void*)kg_count_mc_kernel<G, GM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS);
-    hipLaunchKernelGGL((kg_count_mc_kernel<G, GM>), dim3(NBAND, qblocks), dim3(NW * 64), G::LDS, st, a);
-  }
+  (void)hipFuncSetAttribute((const void*)kg_count_mc_kernel<G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS);
+  for (a.gbase = 0; a.gbase < max_golds; a.gbase += GS)     // typical link-prediction keys have one to three golds: one launch; the
+    hipLaunchKernelGGL((kg_count_mc_kernel<G>), dim3(NBAND, qblocks), dim3(NW * 64), G::LDS, st, a);   // workgroups of a later one whose
+  a.gbase = 0;                                                                                          // keys have no such golds exit
   hipLaunchKernelGGL(kg_rank_finalize_kernel, dim3(grid_for((a.nq + 255) / 256, 1024)), dim3(256), 0, st, a, n_gold);
   return check_launch(name);
 }
 
-template <bool TRANSH>
+template <int MODE>
 int dispatch_fused(const FArgs& a, int d, int64_t n_gold, int64_t max_golds, hipStream_t st, const char* name) {
   switch (d) {
-    case 20: return run_fused<FGeom<5, TRANSH>>(a, n_gold, max_golds, st, name);
-    case 36: return run_fused<FGeom<9, TRANSH>>(a, n_gold, max_golds, st, name);
-    case 64: return run_fused<FGeom<16, TRANSH>>(a, n_gold, max_golds, st, name);
-    case 100: return run_fused<FGeom<25, TRANSH>>(a, n_gold, max_golds, st, name);
-    case 128: return run_fused<FGeom<32, TRANSH>>(a, n_gold, max_golds, st, name);
+    case 20: return run_fused<FGeom<5, MODE>>(a, n_gold, max_golds, st, name);
+    case 36: return run_fused<FGeom<9, MODE>>(a, n_gold, max_golds, st, name);
+    case 64: return run_fused<FGeom<16, MODE>>(a, n_gold, max_golds, st, name);
+    case 100: return run_fused<FGeom<25, MODE>>(a, n_gold, max_golds, st, name);
+    case 128: return run_fused<FGeom<32, MODE>>(a, n_gold, max_golds, st, name);
     default: return 1;
   }
 }
 
 size_t pad256(size_t n) { return (n + 255) & ~(size_t)255; }
+
+// mode 2's table: pitch (whole candidate stages) and whether it is used at all -- offsets stay 32-bit, the table below 1 GiB
+int64_t wtab_pitch(int64_t n_cand) { return ((n_cand + IB - 1) / IB) * IB; }
+bool wtab_on(int model, int64_t n_cand, int64_t n_rel) {
+  return model == KTUP_KG_TRANSH && n_rel > 0 && opt_kg_wtab() && n_rel * wtab_pitch(n_cand) <= (int64_t)(1ll << 28);
+}
 
 }  // namespace
 }  // namespace ktup
@@ -417,22 +550,24 @@ extern "C" int ktup_eval_kg_ranks_fused_supported(int model, int d, int l1, int6
          max_golds <= ktup::GM && ktup::opt_eval_mc();
 }
 
-extern "C" size_t ktup_eval_kg_ranks_fused_workspace_bytes(int d, int64_t nq, int64_t n_gold, int64_t n_filt, int64_t n_cand) {
+extern "C" size_t ktup_eval_kg_ranks_fused_workspace_bytes(int model, int d, int64_t nq, int64_t n_gold, int64_t n_filt, int64_t n_cand,
+                                                           int64_t n_rel) {
   if (d <= 0 || nq <= 0 || n_cand <= 0) return 0;
   return ktup::pad256(ktup_eval_kg_workspace_bytes(d, nq)) + ktup::pad256((size_t)(n_gold > 0 ? n_gold : 1) * 4) * 2 +
-         ktup::pad256((size_t)(n_filt > 0 ? n_filt : 1) * 4) + ktup::pad256((size_t)n_cand * 4);
+         ktup::pad256((size_t)(n_filt > 0 ? n_filt : 1) * 4) + ktup::pad256((size_t)n_cand * 4) +
+         (ktup::wtab_on(model, n_cand, n_rel) ? ktup::pad256((size_t)n_rel * ktup::wtab_pitch(n_cand) * 4) : 0);
 }
 
 extern "C" int ktup_eval_kg_ranks_fused(int model, const float* E, int64_t lde, const float* R, int64_t ldr, const float* Nrm, int64_t ldn,
-                                        int d, const float* C, int64_t ldc, int64_t n_cand, const int64_t* q, const int64_t* r, int64_t nq,
-                                        int head, int descending, const int64_t* filt_off, const int32_t* filt_ids, int64_t n_filt,
+                                        int64_t n_rel, int d, const float* C, int64_t ldc, int64_t n_cand, const int64_t* q, const int64_t* r,
+                                        int64_t nq, int head, int descending, const int64_t* filt_off, const int32_t* filt_ids, int64_t n_filt,
                                         const int64_t* gold_off, const int32_t* gold_ids, int64_t n_gold, int64_t max_golds,
                                         int32_t* ranks, void* ws, void* stream) {
   const char* name = "ktup_eval_kg_ranks_fused";
   using namespace ktup;
   if (!ktup_eval_kg_ranks_fused_supported(model, d, 0, max_golds))
     return set_error(KTUP_ERR_UNSUPPORTED, "%s: squared-L2 TransE / TransH, d in {20,36,64,100,128}, at most %d golds per key", name, GM);
-  KTUP_REQUIRE(nq >= 0 && n_cand > 0 && n_gold >= 0 && n_filt >= 0, "%s: bad sizes", name);
+  KTUP_REQUIRE(nq >= 0 && n_cand > 0 && n_gold >= 0 && n_filt >= 0 && n_rel >= 0, "%s: bad sizes", name);
   if (nq == 0 || n_gold == 0) return KTUP_OK;
   KTUP_REQUIRE(E && R && C && q && r && gold_off && gold_ids && ranks && ws && (model == KTUP_KG_TRANSE || Nrm), "%s: null pointer argument", name);
   KTUP_REQUIRE((filt_off == nullptr) || filt_ids, "%s: filter offsets without ids", name);
@@ -443,13 +578,18 @@ extern "C" int ktup_eval_kg_ranks_fused(int model, const float* E, int64_t lde, 
   float* gscore = reinterpret_cast<float*>(p); p += pad256((size_t)n_gold * 4);
   int32_t* counts = reinterpret_cast<int32_t*>(p); p += pad256((size_t)n_gold * 4);
   float* fscore = reinterpret_cast<float*>(p); p += pad256((size_t)(n_filt > 0 ? n_filt : 1) * 4);
-  float* cnorm = reinterpret_cast<float*>(p);
+  float* cnorm = reinterpret_cast<float*>(p); p += pad256((size_t)n_cand * 4);
   if (int e = kg_query_prep(model, E, lde, R, ldr, Nrm, ldn, d, q, r, nq, head, QW, st, name)) return e;
   FArgs a{};
   a.QW = QW; a.dq = (d + 3) & ~3; a.C = C; a.ldc = ldc; a.nq = nq; a.n_cand = n_cand; a.descending = descending;
   a.gold_off = gold_off; a.gold_ids = gold_ids; a.gscore = gscore; a.filt_off = filt_off; a.filt_ids = filt_ids; a.fscore = fscore;
   a.counts = counts; a.ranks = ranks; a.cnorm = cnorm;
-  const int rc = model == KTUP_KG_TRANSH ? dispatch_fused<true>(a, d, n_gold, max_golds, st, name) : dispatch_fused<false>(a, d, n_gold, max_golds, st, name);
+  int rc;
+  if (model == KTUP_KG_TRANSE) rc = dispatch_fused<0>(a, d, n_gold, max_golds, st, name);
+  else if (wtab_on(model, n_cand, n_rel)) {      // relation ids are bounds-checked by the caller's tables (r indexes R and Nrm already)
+    a.rel = r; a.Nrm = Nrm; a.ldn = ldn; a.n_rel = (int)n_rel; a.wtab = reinterpret_cast<float*>(p); a.ldw = wtab_pitch(n_cand);
+    rc = dispatch_fused<2>(a, d, n_gold, max_golds, st, name);
+  } else rc = dispatch_fused<1>(a, d, n_gold, max_golds, st, name);
   if (rc == 1) return set_error(KTUP_ERR_UNSUPPORTED, "%s: d=%d is not an instantiated width", name, d);
   return rc;
 }

@@ -441,9 +441,10 @@ def eval_kg_ranks(E, R, N, q, r, l1, head, descending, gold_off, gold_ids, filt_
         lib = L.load()
         if lib.ktup_eval_kg_ranks_fused_supported(KG_TRANSE if N is None else KG_TRANSH, E.shape[1], int(l1), mg) and C.stride(0) % 4 == 0:
             n_filt = 0 if filt_ids is None else filt_ids.numel()
-            fws = _scratch(lib.ktup_eval_kg_ranks_fused_workspace_bytes(E.shape[1], nq, n_gold, n_filt, C.shape[0]), dev)
-            L.call('ktup_eval_kg_ranks_fused', KG_TRANSE if N is None else KG_TRANSH, _p(E), E.stride(0), _p(R), R.stride(0), _p(N),
-                   0 if N is None else N.stride(0), E.shape[1], _p(C), C.stride(0), C.shape[0], _p(q), _p(r), nq, int(head),
+            model, n_rel = (KG_TRANSE, 0) if N is None else (KG_TRANSH, min(R.shape[0], N.shape[0]))
+            fws = _scratch(lib.ktup_eval_kg_ranks_fused_workspace_bytes(model, E.shape[1], nq, n_gold, n_filt, C.shape[0], n_rel), dev)
+            L.call('ktup_eval_kg_ranks_fused', model, _p(E), E.stride(0), _p(R), R.stride(0), _p(N),
+                   0 if N is None else N.stride(0), n_rel, E.shape[1], _p(C), C.stride(0), C.shape[0], _p(q), _p(r), nq, int(head),
                    int(bool(descending)), _p(filt_off), _p(filt_ids), n_filt, _p(gold_off), _p(gold_ids), n_gold, mg, _p(ranks), _p(fws),
                    _stream(dev))
             return ranks

@@ -562,6 +562,36 @@ def test_kg_ranks_without_score_matrix(model, d):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('model,wtab', [('transe', 1), ('transh', 1), ('transh', 0)])
+def test_kg_ranks_without_score_matrix_ties_and_modes(model, wtab):
+    """The fused pass compares scores as floats and falls back to the 64-bit keys where a lane sees equality or a NaN: an entity table
+    of 40 distinct rows repeated (every candidate ties with hundreds of others, golds included), one NaN row and one inf row, keys
+    with up to 8 golds (the second sweep launch) -- the integers of the matrix route, for TransH with w.e from the (relation x
+    candidate) table (option kg_wtab = 1) and computed in the sweep (0)."""
+    L = __import__('jTransUP.hip.lib', fromlist=['x'])
+    rng = np.random.RandomState(11)
+    ne, nr, nq, d = 3000, 37, 200, 100
+    gen = torch.Generator().manual_seed(3)
+    E = O.make_table(40, d, gen).repeat(75, 1).contiguous()
+    E[1234] = float('nan'); E[77] = float('inf')
+    R, N = O.make_table(nr, d, gen), O.make_table(nr, d, gen)
+    q = torch.from_numpy(rng.randint(0, ne, size=nq)); r = torch.from_numpy(rng.randint(0, nr, size=nq))
+    q[5] = 1234                                                       # a key whose own row is NaN: every score of it is
+    _, filt, gold, f_off, f_ids, g_off, g_ids = _rank_case(rng, nq, ne, 40, 5, 0)
+    Ed, Rd, Nd = dv(E.numpy()), dv(R.numpy()), dv(N.numpy())
+    Nn = Nd if model == 'transh' else None
+    old = L.set_option('kg_wtab', wtab)
+    try:
+        for head in (True, False):
+            for desc in (False, True):
+                a = ops().eval_kg_ranks(Ed, Rd, Nn, q.to(DEV), r.to(DEV), False, head, desc, dv(g_off), dv(g_ids), dv(f_off), dv(f_ids))
+                b = ops().eval_kg_ranks(Ed, Rd, Nn, q.to(DEV), r.to(DEV), False, head, desc, dv(g_off), dv(g_ids), dv(f_off), dv(f_ids), fused=False)
+                assert torch.equal(a, b)
+    finally:
+        L.set_option('kg_wtab', old)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('d,l1', [(64, False), (100, False), (36, False), (64, True)])
 def test_kg_ranks_whole_pass_transr(d, l1):
     """ktup_eval_kg_ranks_transr (TransR's pass under the C ABI: K14 per chunk of 512 keys against the once-prepared entity side +

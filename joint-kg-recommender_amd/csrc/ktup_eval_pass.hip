@@ -36,6 +36,11 @@ namespace {
 constexpr uint64_t PKEY_MAX = ~0ull;
 constexpr int IBT = 16;        // items per LDS tile
 constexpr int TOPN_MAX = 16;   // top-n list capacity per user: one element per lane of a 16-lane row
+constexpr int PCAP = 32;       // pending candidates per user between two merges (a merge is due at 16; one tile adds at most 16)
+// LDS per wave of the sweep: user scalars [16][4] | filter bits [16][bm_words] | pending candidates [16][PCAP] u64 | lists [16][16] u64 |
+// n-th keys [16] u64
+constexpr size_t WAVE_TAIL = (size_t)16 * PCAP * 8 + (size_t)16 * 16 * 8 + (size_t)16 * 8;
+constexpr size_t wave_lds_bytes(int bm_words) { return (((size_t)16 * 4 * 4 + (size_t)16 * bm_words * 4 + 7) & ~(size_t)7) + WAVE_TAIL; }
 
 KTUP_DEV uint64_t pass_key(float s, uint32_t id) {   // ktup_rank.hip make_key, ascending (lower score = better)
   if (s == 0.f) s = 0.f;
@@ -148,10 +153,14 @@ struct QGeom {
   static constexpr int KA = (D + 2 * P4 + 15) / 16, KS = (2 * P4 + 15) / 16, KN = (P4 + 15) / 16;   // 16-blocks of K
   static constexpr int NA = KA + 2 * KS + KN;                   // float4 A operands per lane: [AA | S | AN | NN]
   static constexpr int AROW = 16 * NA;                          // floats per user row
-  static constexpr int SUB = 2;                                 // 16-item sub-tiles per buffer = per workgroup barrier
+  static constexpr int SUB = 1;                                 // 16-item sub-tiles per buffer = per workgroup barrier (2: no faster, and the
+                                                                // pending-candidate buffers below need the LDS for three workgroups per CU)
   static constexpr int TILE_F4 = SUB * IBT * ROW4 + 4;          // + pad: the padded K blocks read a little past the last row
   static constexpr int LPT = (IBT * RB4 + IBT + 255) / 256;     // float4 loads per thread and SUB-tile
-  static constexpr int MINW = NA <= 18 ? 3 : 2;                 // waves per SIMD the register budget allows (= workgroups per CU)
+#ifndef KTUP_EVAL_MINW3
+#define KTUP_EVAL_MINW3 3
+#endif
+  static constexpr int MINW = NA <= 18 ? KTUP_EVAL_MINW3 : 2;                 // waves per SIMD the register budget allows (= workgroups per CU)
 };
 
 struct QArgs {
@@ -160,6 +169,7 @@ struct QArgs {
   int64_t nq, n_items;
   const int64_t* filt_off; const int32_t* filt_ids;
   int topn, nsplit; int64_t split_items; uint64_t* part; int bm_words;
+  int dbg;                       // MEASUREMENT ONLY (option dbg_eval): 1 no ranking epilogue, 2 no item loads, 4 no workgroup barrier per tile, 8 no tiles at all
 };
 
 template <typename G>
@@ -171,25 +181,49 @@ __global__ __launch_bounds__(256, G::MINW) void eval_pass_q_kernel(QArgs a) {
   float* isc = reinterpret_cast<float*>(Xb + 2 * G::TILE_F4);             // [2][SUB * IBT][4] item scalars
   const int tid = threadIdx.x, lane = tid & 63, kq = lane >> 4, j = lane & 15;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  char* wbase = reinterpret_cast<char*>(isc + 2 * SUB * IBT * 4) + (size_t)w * ((size_t)16 * 4 * 4 + (size_t)16 * a.bm_words * 4);
+  char* wbase = reinterpret_cast<char*>(isc + 2 * SUB * IBT * 4) + (size_t)w * wave_lds_bytes(a.bm_words);
   float* usc = reinterpret_cast<float*>(wbase);                           // [16][4] user scalars
   uint32_t* bm = reinterpret_cast<uint32_t*>(usc + 64);                   // [16][bm_words] filter bits of this split
-  uint64_t tkr[4] = {PKEY_MAX, PKEY_MAX, PKEY_MAX, PKEY_MAX};
+  uint64_t* pbuf = reinterpret_cast<uint64_t*>(wbase + wave_lds_bytes(a.bm_words) - WAVE_TAIL);   // [16][PCAP] pending candidates
+  uint64_t* tk = pbuf + 16 * PCAP;                                        // [16][16] the users' sorted lists (touched by merges only)
+  uint64_t* thrk = tk + 16 * 16;                                          // [16] their n-th keys (read where floats cannot decide)
   const int64_t u0 = (int64_t)blockIdx.x * 64 + 16 * w;
   const int64_t i_lo = (int64_t)blockIdx.y * a.split_items;
   const int64_t i_hi = min(a.n_items, i_lo + a.split_items);
   const int topn = a.topn;
   for (int idx = tid; idx < 2 * G::TILE_F4; idx += 256) Xb[idx] = (v4){0.f, 0.f, 0.f, 0.f};   // row pads stay finite (x 0 operands)
   for (int idx = lane; idx < 16 * a.bm_words; idx += 64) bm[idx] = 0u;
+  for (int idx = lane; idx < 16 * 16; idx += 64) tk[idx] = PKEY_MAX;
+  if (lane < 16) thrk[lane] = u0 + lane < a.nq ? PKEY_MAX : 0;            // rows past the end: nothing is ever below
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
-  if (a.filt_off) {
-    for (int r = 0; r < 16; ++r) {
-      if (u0 + r >= a.nq) break;
-      const int64_t f0 = a.filt_off[u0 + r], f1 = a.filt_off[u0 + r + 1];
-      for (int64_t f = f0 + lane; f < f1; f += 64) {
-        const int64_t id = (int64_t)a.filt_ids[f] - i_lo;
-        if (id >= 0 && id < i_hi - i_lo) atomicOr(bm + r * a.bm_words + (id >> 5), 1u << (id & 31));
+  if (a.filt_off && !(a.dbg & 16)) {
+    // The 16 users of a wave are consecutive, so their filter lists are ONE contiguous run of the CSR ids: all 64 lanes walk it together
+    // (sixteen independent loads in flight per lane) and find an entry's row by comparing its position with the 15 inner offsets.  (One list
+    // after the other -- 48 dependent round trips -- was 18 of the sweep's 200 us, every split's workgroups repeating it; now 11.)
+    const int64_t uo = u0 + (lane < 16 ? lane : 16);
+    const int64_t myoff = a.filt_off[uo < a.nq ? uo : a.nq];
+    const int64_t f_begin = __shfl(myoff, 0, 64), f_end = __shfl(myoff, 16, 64);
+    uint32_t rel[15];
+#pragma unroll
+    for (int k = 0; k < 15; ++k) rel[k] = (uint32_t)(__shfl(myoff, k + 1, 64) - f_begin);
+    const int64_t span = i_hi - i_lo;
+    constexpr int FB = 16;                                               // loads in flight per lane
+    for (int64_t base = f_begin; base < f_end; base += 64 * FB) {
+      int32_t ids[FB];
+#pragma unroll
+      for (int k = 0; k < FB; ++k) {
+        const int64_t f = base + lane + 64 * k;
+        ids[k] = f < f_end ? a.filt_ids[f] : -1;
+      }
+#pragma unroll
+      for (int k = 0; k < FB; ++k) {
+        const int64_t id = (int64_t)ids[k] - i_lo;
+        const uint32_t pos = (uint32_t)(base - f_begin) + lane + 64 * k;
+        int r = 0;
+#pragma unroll
+        for (int q = 0; q < 15; ++q) r += pos >= rel[q] ? 1 : 0;
+        if (ids[k] >= 0 && id >= 0 && id < span) atomicOr(bm + r * a.bm_words + (id >> 5), 1u << (id & 31));
       }
     }
   }
@@ -197,13 +231,13 @@ __global__ __launch_bounds__(256, G::MINW) void eval_pass_q_kernel(QArgs a) {
       u0 + lane < a.nq ? *reinterpret_cast<const v4*>(a.SCU + (u0 + lane) * 4) : (v4){0.f, 0.f, 0.f, 0.f};
   v4 aop[NA];                                                             // A operands of the whole pass: user j, k-quad kq of every block
   {
-    const bool ok = u0 + j < a.nq;
+    const bool ok = u0 + j < a.nq && !(a.dbg & 32);
     const v4* r0 = reinterpret_cast<const v4*>(a.A + (ok ? u0 + j : 0) * G::AROW);
 #pragma unroll
     for (int g = 0; g < NA; ++g) aop[g] = ok ? r0[4 * g + kq] : (v4){0.f, 0.f, 0.f, 0.f};
   }
   __syncthreads();                                                        // tiles zeroed, bitmaps and scalars in place
-  const int64_t ntile = (i_hi - i_lo + IBT - 1) / IBT;
+  const int64_t ntile = (a.dbg & 8) ? 0 : (i_hi - i_lo + IBT - 1) / IBT;    // (dbg 8: prologue and epilogue only)
   v4 pre[LPT];
   const float* fsrc[LPT];
   int frow[LPT], fdst[LPT];
@@ -243,34 +277,80 @@ __global__ __launch_bounds__(256, G::MINW) void eval_pass_q_kernel(QArgs a) {
     }
   };
   const int rowbase = 16 * kq;
-  uint64_t thr[4] = {PKEY_MAX, PKEY_MAX, PKEY_MAX, PKEY_MAX};
-  // (A split restarts its lists from nothing, so its first tiles insert nearly every item.  One ballot / bpermute round per
-  // candidate was a third of this kernel's time, more than half of it in a split's first two tiles; sharing each user's n-th key
-  // between the concurrent splits cut the rounds by 37 % and the time by nothing.  Now a fixed merge network per row.)
+  // A user's list is touched only when 16 candidates are pending for it.  A score is a candidate if it is below the user's n-th score
+  // -- compared as FLOATS (thrf; NaN while the list is short: every score then takes the key compare below); equality or a NaN sends
+  // the wave through the 64-bit key compare, so the order is that of the keys in every case.  Candidates are appended to the user's
+  // pending row in LDS at positions taken from a ballot (no atomics; `pend` is replicated over the row's 16 lanes); once a row of a
+  // register slot holds 16, that slot's four rows go through the merge network -- 16 real candidates per network pass instead of the
+  // ~2 a tile yields -- and the thresholds are renewed.  (The network per tile and slot was 400 of this kernel's ~670 VALU
+  // instructions per tile.)
+  float thrf[4];
+  int pend[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) thrf[reg] = u0 + 4 * kq + reg < a.nq ? __uint_as_float(0x7fffffffu) : -__builtin_inff();
+  const uint32_t lt_j = (1u << j) - 1u;
+  const int rsh = 16 * (kq & 1);
+  const bool rhi = (kq & 2) != 0;
+  auto flush = [&](bool all) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int n = pend[reg];
+      if (!__builtin_amdgcn_ballot_w64(all ? n > 0 : n >= 16)) continue;
+      const int ur = 4 * kq + reg;
+      const uint64_t* row = pbuf + ur * PCAP;
+      uint64_t merged = row_merge16(tk[ur * 16 + j], j < n ? row[j] : PKEY_MAX, j);   // all four rows of the slot at once
+      if (__builtin_amdgcn_ballot_w64(n > 16)) merged = row_merge16(j < topn ? merged : PKEY_MAX, 16 + j < n ? row[16 + j] : PKEY_MAX, j);
+      merged = j < topn ? merged : PKEY_MAX;
+      tk[ur * 16 + j] = merged;
+      pend[reg] = 0;
+      if (u0 + ur < a.nq) {                                                       // (rows past the end keep thrf = -inf, thrk = 0)
+        const uint32_t hi = (uint32_t)__shfl((int)(merged >> 32), rowbase + topn - 1, 64);
+        thrf[reg] = __uint_as_float((hi & 0x80000000u) ? (hi & 0x7fffffffu) : ~hi);   // inverse of the order-preserving image (NaN: list short)
+        if (j == topn - 1) thrk[ur] = merged;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  };
   auto compute = [&](int buf, int sub, int64_t t) {                       // 16 users x the 16 items of tile t
     const v4* ib = Xb + buf * G::TILE_F4 + (sub * IBT + j) * ROW4 + kq;   // lane (kq, item j): k-quad kq of every 16-block
     v4 accAA = (v4){0.f, 0.f, 0.f, 0.f}, accS = accAA, accAN = accAA, accNN = accAA;
+    // B operands one 16-block ahead of the MFMAs that use them (two register sets): left to itself the compiler re-uses ONE set and
+    // every group of four MFMAs waits out an LDS round trip (measured: the MFMAs + reads alone took 120 us of a 68 us pipe time)
+    constexpr int NB = KA + KS;
+    auto bsrc = [&](int i) { return i < KA ? ib[4 * i] : ib[G::SOFF4 + 4 * (i - KA)]; };
+    v4 bcur = bsrc(0);
 #pragma unroll
-    for (int g = 0; g < KA; ++g) {
-      const v4 b = ib[4 * g];
+    for (int i = 0; i < NB; ++i) {
+      v4 bnext = bcur;
+      if (i + 1 < NB) bnext = bsrc(i + 1);
+      __builtin_amdgcn_sched_barrier(0);                                   // the read stays ahead of the MFMAs below
+      if (i < KA) {
 #pragma unroll
-      for (int c = 0; c < 4; ++c) accAA = __builtin_amdgcn_mfma_f32_16x16x4f32(aop[g][c], b[c], accAA, 0, 0, 0);
-    }
+        for (int c = 0; c < 4; ++c) accAA = __builtin_amdgcn_mfma_f32_16x16x4f32(aop[i][c], bcur[c], accAA, 0, 0, 0);
+      } else {
+        const int g = i - KA;
 #pragma unroll
-    for (int g = 0; g < KS; ++g) {
-      const v4 b = ib[G::SOFF4 + 4 * g];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        accS = __builtin_amdgcn_mfma_f32_16x16x4f32(aop[KA + g][c], b[c], accS, 0, 0, 0);
-        accAN = __builtin_amdgcn_mfma_f32_16x16x4f32(aop[KA + KS + g][c], b[c], accAN, 0, 0, 0);
-        if (g < KN) accNN = __builtin_amdgcn_mfma_f32_16x16x4f32(aop[KA + 2 * KS + g][c], b[c], accNN, 0, 0, 0);
+        for (int c = 0; c < 4; ++c) {
+          accS = __builtin_amdgcn_mfma_f32_16x16x4f32(aop[KA + g][c], bcur[c], accS, 0, 0, 0);
+          accAN = __builtin_amdgcn_mfma_f32_16x16x4f32(aop[KA + KS + g][c], bcur[c], accAN, 0, 0, 0);
+          if (g < KN) accNN = __builtin_amdgcn_mfma_f32_16x16x4f32(aop[KA + 2 * KS + g][c], bcur[c], accNN, 0, 0, 0);
+        }
       }
+      __builtin_amdgcn_sched_barrier(0);
+      bcur = bnext;
     }
     const v4 is4 = *reinterpret_cast<const v4*>(isc + ((buf * SUB + sub) * IBT + j) * 4);
     const int64_t item = i_lo + t * IBT + j;
     const int64_t lid = item - i_lo;
-    uint64_t ck[4];
-    bool cand[4];
+    const bool iok = item < i_hi;
+    bool full = false;
+    if (a.dbg & 1) {                                                       // measurement: keep the MFMAs alive, skip the ranking
+      if (accS[0] + accAA[1] + accAN[2] + accNN[3] == 12345.f) thrf[0] = is4[0];
+      return;
+    }
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
       const int ur = 4 * kq + reg;
@@ -280,20 +360,22 @@ __global__ __launch_bounds__(256, G::MINW) void eval_pass_q_kernel(QArgs a) {
       const float an = (us4[2] + accAN[reg]) - is4[2];
       const float nn = (us4[3] + is4[3]) + accNN[reg];
       const float score = fmaf(sv * sv, nn, fmaf(-2.f * sv, an, aa));
-      ck[reg] = pass_key(score, (uint32_t)item);
-      bool c = item < i_hi && u0 + ur < a.nq && ck[reg] < thr[reg];
+      bool c = score < thrf[reg];
+      const bool tie = !c && !(score > thrf[reg]);
+      if (__builtin_amdgcn_ballot_w64(tie)) {                              // the keys decide (always while the list is short)
+        if (tie) c = pass_key(score, (uint32_t)item) < thrk[ur];
+      }
+      c = c && iok;
       if (c) c = ((bm[ur * a.bm_words + (lid >> 5)] >> (lid & 31)) & 1u) == 0u;
-      cand[reg] = c;
+      const uint64_t m = __builtin_amdgcn_ballot_w64(c);
+      if (m) {
+        const uint32_t rb = ((rhi ? (uint32_t)(m >> 32) : (uint32_t)m) >> rsh) & 0xffffu;   // the candidates of this lane's row
+        if (c) pbuf[ur * PCAP + pend[reg] + __popc(rb & lt_j)] = pass_key(score, (uint32_t)item);
+        pend[reg] += __popc(rb);
+      }
+      full |= pend[reg] >= 16;
     }
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-      const unsigned long long any = __ballot(cand[reg]);
-      if (!any) continue;
-      const uint64_t merged = row_merge16(tkr[reg], cand[reg] ? ck[reg] : PKEY_MAX, j);     // all four rows at once
-      tkr[reg] = j < topn ? merged : PKEY_MAX;
-      thr[reg] = ((uint64_t)(uint32_t)__shfl((int)(tkr[reg] >> 32), rowbase + topn - 1, 64) << 32) |
-                 (uint32_t)__shfl((int)(uint32_t)tkr[reg], rowbase + topn - 1, 64);
-    }
+    if (__builtin_amdgcn_ballot_w64(full)) flush(false);
   };
   if (ntile > 0) {
 #pragma unroll
@@ -309,17 +391,18 @@ __global__ __launch_bounds__(256, G::MINW) void eval_pass_q_kernel(QArgs a) {
     const bool more = t0 + SUB < ntile;
 #pragma unroll
     for (int sub = 0; sub < SUB; ++sub) {
-      if (more) fetch(t0 + SUB + sub);
-      if (t0 + sub < ntile) compute(buf, sub, t0 + sub);
-      if (more) stash(buf ^ 1, sub);
+      if (more && !(a.dbg & 2)) fetch(t0 + SUB + sub);
+      if (t0 + sub < ntile) compute((a.dbg & 2) ? 0 : buf, sub, t0 + sub);
+      if (more && !(a.dbg & 2)) stash(buf ^ 1, sub);
     }
-    __syncthreads();
+    if (!(a.dbg & 4)) __syncthreads();
   }
+  flush(true);
   if (j < topn) {
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
       const int64_t ur = u0 + 4 * kq + reg;
-      if (ur < a.nq) a.part[(ur * a.nsplit + blockIdx.y) * topn + j] = tkr[reg];
+      if (ur < a.nq) a.part[(ur * a.nsplit + blockIdx.y) * topn + j] = tk[(4 * kq + reg) * 16 + j];
     }
   }
 }
@@ -716,10 +799,11 @@ int launch_q(const float* U, int64_t ldu, const int64_t* u_ids, int64_t nq, cons
   if (int e = check_launch(name)) return e;
   QArgs a{};
   a.A = q.A; a.SCU = q.SCU; a.B = q.B; a.ISC = q.ISC; a.nq = nq; a.n_items = n_items;
-  a.filt_off = filt_off; a.filt_ids = filt_ids; a.topn = topn; a.part = q.part;
+  a.filt_off = filt_off; a.filt_ids = filt_ids; a.topn = topn; a.part = q.part; a.dbg = opt_dbg_eval();
   const int64_t ublocks = (nq + 63) / 64;
   int nsplit = (int)(256 * G::MINW / ublocks);                            // MINW workgroups per CU are resident: ONE round
   if (nsplit > 8) nsplit = 8;
+  if (opt_eval_nsplit() > 0 && opt_eval_nsplit() <= 8) nsplit = opt_eval_nsplit();   // measurement knob
   const int64_t tiles = (n_items + IBT - 1) / IBT;
   if (nsplit > tiles) nsplit = (int)tiles;
   if (nsplit < 1) nsplit = 1;
@@ -727,8 +811,7 @@ int launch_q(const float* U, int64_t ldu, const int64_t* u_ids, int64_t nq, cons
   nsplit = (int)((n_items + a.split_items - 1) / a.split_items);
   a.nsplit = nsplit;
   a.bm_words = (int)((a.split_items + 31) / 32);
-  const size_t wave_bytes = (size_t)16 * 4 * 4 + (size_t)16 * a.bm_words * 4;
-  const size_t lds = (size_t)2 * G::TILE_F4 * 16 + (size_t)2 * G::SUB * IBT * 4 * 4 + 4 * wave_bytes;
+  const size_t lds = (size_t)2 * G::TILE_F4 * 16 + (size_t)2 * G::SUB * IBT * 4 * 4 + 4 * wave_lds_bytes(a.bm_words);
   if (lds > 160 * 1024) return 1;
   (void)hipFuncSetAttribute((const void*)eval_pass_q_kernel<G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL((eval_pass_q_kernel<G>), dim3((unsigned)ublocks, (unsigned)nsplit), dim3(256), lds, st, a);

@@ -45,6 +45,8 @@ Option g_opts[] = {
     {"shard_chunk", "KTUP_SHARD_CHUNK", {env_int("KTUP_SHARD_CHUNK", 0)}},   // > 0: sorted entries per lane group in the sharded step's two reduction walks (0: by batch size)
     {"nt_gather", "KTUP_NT_GATHER", {env_int("KTUP_NT_GATHER", 0)}},         // 1: K5-K7 forward gathers its rows with the nontemporal hint (tables >> Infinity Cache)
     {"dbg_noflush", "KTUP_DBG_NOFLUSH", {env_int("KTUP_DBG_NOFLUSH", 0)}},  // MEASUREMENT ONLY (wrong results): the fused step kernels skip the small-table gradient flush
+    {"eval_nsplit", "KTUP_EVAL_NSPLIT", {env_int("KTUP_EVAL_NSPLIT", 0)}},  // > 0: catalogue splits of the one-sweep rec evaluation (0: by occupancy, at most 8)
+    {"dbg_eval", "KTUP_DBG_EVAL", {env_int("KTUP_DBG_EVAL", 0)}},           // MEASUREMENT ONLY (wrong results): bits switch phases of the rec evaluation sweep off
     {"kg_wtab", "KTUP_KG_WTAB", {env_int("KTUP_KG_WTAB", 1)}},              // 0: the fused TransH link-prediction pass computes w.e in the sweep instead of once per (relation, candidate)
 };
 Option* find(const char* name) {
@@ -62,7 +64,9 @@ int opt_bwd_wide_max() { return g_opts[4].value.load(std::memory_order_relaxed);
 int opt_shard_chunk() { return g_opts[6].value.load(std::memory_order_relaxed); }
 int opt_nt_gather() { return g_opts[7].value.load(std::memory_order_relaxed); }
 int opt_dbg_noflush() { return g_opts[8].value.load(std::memory_order_relaxed); }
-int opt_kg_wtab() { return g_opts[9].value.load(std::memory_order_relaxed); }
+int opt_eval_nsplit() { return g_opts[9].value.load(std::memory_order_relaxed); }
+int opt_dbg_eval() { return g_opts[10].value.load(std::memory_order_relaxed); }
+int opt_kg_wtab() { return g_opts[11].value.load(std::memory_order_relaxed); }
 
 // A library-owned second stream for work that depends only on a call's INPUTS (the counting sorts of the segment reductions)
 // while the caller's stream runs the kernel that produces the data: fork_side makes it wait for everything enqueued on `st` so far,

@@ -542,14 +542,18 @@ def eval_tup_hard_bench(device, batch=512, seed=17):
     items = m.prepare_items()
     score_fn = lambda u: m.evaluate(u, items=items)
     import contextlib
+    pass_fn = lambda u, fo, fi, n: m.evaluate_topk(u, m.prepare_items(), n, fo, fi)      # the drivers' route: the pass in one sweep
     with contextlib.redirect_stderr(open(os.devnull, 'w')):
-        rows = Dr.rec_eval_pass(FL, score_fn, batches, gold, [train], False, want_rows=False)
-        torch.cuda.synchronize(device)
-        reps = 5
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            rows = Dr.rec_eval_pass(FL, score_fn, batches, gold, [train], False, want_rows=False)
-        pass_ms = 1e3 * (time.perf_counter() - t0) / reps
+        def timed(**kw):
+            rows = Dr.rec_eval_pass(FL, score_fn, batches, gold, [train], False, want_rows=False, **kw)
+            torch.cuda.synchronize(device)
+            reps = 5
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                rows = Dr.rec_eval_pass(FL, score_fn, batches, gold, [train], False, want_rows=False, **kw)
+            return 1e3 * (time.perf_counter() - t0) / reps, rows
+        batched_ms, rows_b = timed()
+        pass_ms, rows = timed(pass_fn=pass_fn)
     W = {k: v.detach().cpu() for k, v in m.state_dict().items()}
     _, phys, _ = host_topology()
     before = torch.get_num_threads()
@@ -572,13 +576,16 @@ def eval_tup_hard_bench(device, batch=512, seed=17):
     per_u = 1e3 * (t_score + t_rank) / max(done, 1)
     return {'model': 'TUP d=%d, %d preferences, ST-Gumbel gate (BASELINE configs[2])' % (D, NR), 'users': NU, 'items': NI, 'batch': batch,
             'full_pass_ms': pass_ms, 'ms_per_512_users': pass_ms / len(batches), 'hit_at_10_random_init': float(rows[:, 3].mean()),
+            'batched_route': {'full_pass_ms': batched_ms, 'hit_at_10_random_init': float(rows_b[:, 3].mean())},
             'cpu_baseline': {'kind': 'port', 'cores': min(32, phys), 'users_sampled': done, 'batch': cb, 'ms_per_user': per_u,
                              'ms_per_user_scoring': 1e3 * t_score / max(done, 1), 'ms_per_user_ranking': 1e3 * t_rank / max(done, 1),
                              'full_pass_ms_extrapolated': per_u * len(users),
                              'sample': 'first %d users in batches of %d: oracle eval_tup with drawn uniforms (reference-shaped, B x N x P '
                                        'noise + B x N x d tensors) + eval_rec_rows, %.1f s of CPU work' % (done, cb, t_score + t_rank)},
-            'note': 'the gate draws fresh noise per (user, item) pair, so this pass has no preference-space shortcut: per 512 users the '
-                    'hard-gate pair kernel (K15 / K7), then filtered top-10 (K17) and metrics (K18b) on the device; one copy back per pass'}
+            'note': 'the gate draws fresh noise per (user, item) pair, so this pass has no preference-space shortcut.  full_pass_ms: the '
+                    'whole pass in one sweep (ktup_eval_pref_topk_hard: pair arithmetic + filtered top-10 where the scores are made, '
+                    'no score matrix) + metrics (K18b), one copy back; batched_route: per 512 users the hard-gate pair kernel, K17, K18b '
+                    '(fresh noise per pass in both, so the two hit rates differ by sampling)'}
 
 
 def gather_stress_bench(device, scale=1000, reps=20):

@@ -109,4 +109,56 @@ struct Philox {
 // 24-bit uniform in [0, 1), the same lattice torch's uniform_() draws from.
 KTUP_DEV float u01(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
 
+
+// ---- the hard (ST-Gumbel) gate's choice: arg max_p logit(p) + Gumbel(u_p), first maximum on ties (the one-hot of
+// transUP.py:45-60 st_gumbel_softmax).  u_p: Philox draw at stream position base + p (+ offset), or uniform[base + p] (parity mode).
+// With Philox draws the transform first runs on the hardware logarithm (v_log_f32): over EVERY uniform of the 24-bit lattice it is within
+// 1.94e-6 of the logf form (tools/gumbel_log_check.hip, exhaustive), so a winner that leads the runner-up by more than GATE_MARGIN is
+// the logf form's winner too; lanes with a closer call redo the choice with logf.  Input uniforms always take the logf form.
+KTUP_DEV float fast_gumbel_from_uniform(float u) {
+  constexpr float ln2 = 0.69314718055994530942f;
+  return -ln2 * __builtin_amdgcn_logf(-ln2 * __builtin_amdgcn_logf(u + 1e-20f) + 1e-20f);
+}
+// MAXP > 0: the loop over the preferences is unrolled to MAXP steps (logit(p) may then index registers)
+template <bool FAST, int MAXP, typename LogitFn>
+KTUP_DEV int gate_argmax_pass(int P, uint64_t base, bool input, const float* uniform, uint64_t seed, uint64_t offset, LogitFn logit, float& best,
+                              float& second) {
+  int ps = 0;
+  best = -__builtin_inff(); second = best;
+  uint64_t blk = ~0ull;              // the Philox block (4 draws) in hand: consecutive preferences share it
+  uint4 r = {0u, 0u, 0u, 0u};
+#pragma unroll
+  for (int p = 0; p < (MAXP > 0 ? MAXP : P); ++p) {
+    if (MAXP == 0 || p < P) {
+      float u;
+      if (input) {
+        u = uniform[base + p];
+      } else {
+        const uint64_t idx = base + p + offset;
+        if ((idx >> 2) != blk) {
+          blk = idx >> 2;
+          r = Philox(seed)(blk, 0x4b545550ull);
+        }
+        u = u01((idx & 3) == 0 ? r.x : (idx & 3) == 1 ? r.y : (idx & 3) == 2 ? r.z : r.w);
+      }
+      const float v = logit(p) + (FAST ? fast_gumbel_from_uniform(u) : gumbel_from_uniform(u));
+      if (v > best) { second = best; best = v; ps = p; }
+      else if (v > second) second = v;
+    }
+  }
+  return ps;
+}
+template <int MAXP = 0, typename LogitFn>
+KTUP_DEV int gate_argmax(int P, uint64_t base, bool input, const float* uniform, uint64_t seed, uint64_t offset, LogitFn logit) {
+  float best, second;
+  if (input) return gate_argmax_pass<false, MAXP>(P, base, true, uniform, seed, offset, logit, best, second);
+  int ps = gate_argmax_pass<true, MAXP>(P, base, false, uniform, seed, offset, logit, best, second);
+  // two sums off by <= 1.94e-6 + an ulp each: 4e-6 + 5e-7 |best| bounds the error of the lead; four times that decides
+  const bool close = !(best - second > 2e-5f + 2e-6f * fabsf(best));       // (NaNs land here too)
+  if (__builtin_amdgcn_ballot_w64(close)) {
+    if (close) ps = gate_argmax_pass<false, MAXP>(P, base, false, uniform, seed, offset, logit, best, second);
+  }
+  return ps;
+}
+
 }  // namespace ktup

@@ -292,26 +292,9 @@ __global__ __launch_bounds__(HARD_NT) void pairs_hard_kernel(HardArgs a) {
   const int64_t qlo = (int64_t)blockIdx.y * per, qhi = min(a.nq, qlo + per);
   for (int64_t b = qlo + w; b < qhi; b += HARD_NT / 64) {
     const float* ql = a.QL + b * a.P;  // wave-uniform -> scalar loads
-    int ps = 0;
-    float best = -INFINITY;
     const uint64_t base = ((uint64_t)b * (uint64_t)a.n_cand + (uint64_t)gj) * (uint64_t)a.P;
-    uint64_t blk = ~0ull;              // the Philox block (4 draws) in hand: consecutive preferences share it
-    uint4 r = {0u, 0u, 0u, 0u};
-    for (int p = 0; p < a.P; ++p) {
-      float u;
-      if (a.gumbel == KTUP_GUMBEL_INPUT) {
-        u = a.uniform[base + p];
-      } else {
-        const uint64_t idx = base + p + a.offset;
-        if ((idx >> 2) != blk) {
-          blk = idx >> 2;
-          r = Philox(a.seed)(blk, 0x4b545550ull);
-        }
-        u = u01((idx & 3) == 0 ? r.x : (idx & 3) == 1 ? r.y : (idx & 3) == 2 ? r.z : r.w);
-      }
-      const float v = (ql[p] + lv[p * CT + lane]) + gumbel_from_uniform(u);
-      if (v > best) { best = v; ps = p; }
-    }
+    const int ps = gate_argmax(a.P, base, a.gumbel == KTUP_GUMBEL_INPUT, a.uniform, a.seed, a.offset,
+                               [&](int p) { return ql[p] + lv[p * CT + lane]; });
     const sptr4 ub = QW + (b * 3 + 1) * nch4;   // slot 1 = u_b; one scalar base, the chunk index is the only offset
     const float4* cn = tabC + ps * dp4;
     const float4* ar = tabA + ps * dp4;
@@ -323,6 +306,168 @@ __global__ __launch_bounds__(HARD_NT) void pairs_hard_kernel(HardArgs a) {
       acc += dist4(fma4(-s, cn[c], q + ar[c]), l1);
     }
     if (j0 + lane < a.n_cand) a.out[b * a.ldo + j0 + lane] = acc;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// The hard gate's evaluation PASS in one sweep (transUP.py:84-102 / jTransUP.py:163-191 with use_st_gumbel + utils/misc.py:186-248):
+// pairs_hard_kernel's pair arithmetic, instruction for instruction (the scores are the batched route's bits, the noise its stream
+// positions), with the filtered top-n taken where the scores are made.  A wave owns 16 users and walks a split of the catalogue in
+// 64-item stages (lane <-> item; the user's vectors are wave-uniform scalar loads, as above); a user's sorted list (64-bit keys =
+// score image << 32 | item id) lives in the wave's LDS, a score is a candidate if it is below the user's n-th score (floats; the keys
+// decide ties), is not filtered (bitmap of the split, built once per wave from the CSR lists) and candidates are inserted one by
+// one by ballot position -- a few per user and stage once the list has warmed up.  The (users x items) matrix never exists: the
+// batched route wrote and re-read 78 MB per ml1m pass and ran K17 twelve times; what is left is the noise (20 Philox draws and
+// Gumbel transforms per pair) and the d-long distance.  The splits' partial lists are merged by ktup_eval_pass.hip's merge launch.
+constexpr uint64_t SKEY_MAX = ~0ull;
+constexpr int SW_NW = 8, SW_UW = 8;       // waves per workgroup, users per wave (LDS allows two workgroups per CU: 16 waves)
+
+KTUP_DEV uint64_t sweep_key(float s, uint32_t id) {    // ktup_rank.hip make_key, ascending
+  if (s == 0.f) s = 0.f;
+  uint32_t u = __float_as_uint(s);
+  u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+  return ((uint64_t)u << 32) | id;
+}
+
+struct SweepHardArgs {
+  HardArgs h;
+  const int64_t* filt_off; const int32_t* filt_ids;
+  int topn, nsplit; int64_t split_items; uint64_t* part; int bm_words;
+};
+
+__host__ __device__ inline size_t sweep_wave_bytes(int bm_words, int topn) { return (size_t)SW_UW * topn * 8 + (size_t)SW_UW * 8 + (size_t)SW_UW * 4 + (size_t)SW_UW * bm_words * 4 + 4; }
+
+template <bool L1, int MAXP>
+__global__ __launch_bounds__(SW_NW * 64) void sweep_hard_kernel(SweepHardArgs sa) {
+  HardArgs a = sa.h;
+  KTUP_RESOLVE_GUMBEL(a);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int nch4 = a.d / 4, dp4 = a.dp / 4;
+  float4* cand = reinterpret_cast<float4*>(smem);              // [nch4][CT]
+  float4* tabA = cand + nch4 * CT;                              // [P][dp4]
+  float4* tabC = tabA + a.P * dp4;                              // [P][dp4]
+  const int t = threadIdx.x, lane = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int topn = sa.topn;
+  char* wb = reinterpret_cast<char*>(tabC + a.P * dp4) + (size_t)w * ((sweep_wave_bytes(sa.bm_words, topn) + 7) & ~(size_t)7);
+  uint64_t* tk = reinterpret_cast<uint64_t*>(wb);               // [users][topn] sorted lists
+  uint64_t* thrk = tk + SW_UW * topn;                           // [users] n-th keys
+  float* thrf = reinterpret_cast<float*>(thrk + SW_UW);         // [16] n-th scores (NaN while a list is short)
+  uint32_t* bm = reinterpret_cast<uint32_t*>(thrf + SW_UW);     // [16][bm_words] filter bits of this split
+  const int64_t u0 = (int64_t)blockIdx.x * (SW_NW * SW_UW) + SW_UW * w;
+  const int64_t i_lo = (int64_t)blockIdx.y * sa.split_items;
+  const int64_t i_hi = min(a.n_cand, i_lo + sa.split_items);
+  for (int idx = lane; idx < SW_UW * topn; idx += 64) tk[idx] = SKEY_MAX;
+  if (lane < SW_UW) { thrk[lane] = u0 + lane < a.nq ? SKEY_MAX : 0; thrf[lane] = u0 + lane < a.nq ? __uint_as_float(0x7fffffffu) : -__builtin_inff(); }
+  for (int idx = lane; idx < SW_UW * sa.bm_words; idx += 64) bm[idx] = 0u;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  if (sa.filt_off) {   // the wave's 16 users are consecutive: their filter lists are one run of the CSR ids (as in ktup_eval_pass.hip)
+    const int64_t uo = u0 + (lane < SW_UW ? lane : SW_UW);
+    const int64_t myoff = sa.filt_off[uo < a.nq ? uo : a.nq];
+    const int64_t f_begin = __shfl(myoff, 0, 64), f_end = __shfl(myoff, SW_UW, 64);
+    uint32_t rel[SW_UW - 1];
+#pragma unroll
+    for (int k = 0; k < SW_UW - 1; ++k) rel[k] = (uint32_t)(__shfl(myoff, k + 1, 64) - f_begin);
+    const int64_t span = i_hi - i_lo;
+    constexpr int FB = 16;
+    for (int64_t base = f_begin; base < f_end; base += 64 * FB) {
+      int32_t ids[FB];
+#pragma unroll
+      for (int k = 0; k < FB; ++k) {
+        const int64_t f = base + lane + 64 * k;
+        ids[k] = f < f_end ? sa.filt_ids[f] : -1;
+      }
+#pragma unroll
+      for (int k = 0; k < FB; ++k) {
+        const int64_t id = (int64_t)ids[k] - i_lo;
+        const uint32_t pos = (uint32_t)(base - f_begin) + lane + 64 * k;
+        int r = 0;
+#pragma unroll
+        for (int q = 0; q < SW_UW - 1; ++q) r += pos >= rel[q] ? 1 : 0;
+        if (ids[k] >= 0 && id >= 0 && id < span) atomicOr(bm + r * sa.bm_words + (id >> 5), 1u << (id & 31));
+      }
+    }
+  }
+  {
+    const float4* Ar = reinterpret_cast<const float4*>(a.ws + (size_t)a.ppad * a.dp);
+    for (int idx = t; idx < 2 * a.P * dp4; idx += SW_NW * 64) tabA[idx] = Ar[idx];  // Ar then Cn are adjacent in ws
+  }
+  const sptr4 QW = as_scalar(a.QW);
+  constexpr bool l1 = L1;
+  for (int64_t j0 = i_lo; j0 < i_hi; j0 += CT) {
+    __syncthreads();                                                    // the previous stage has been consumed
+    for (int idx = t; idx < nch4 * CT; idx += SW_NW * 64) {
+      const int j = idx & (CT - 1), c = idx >> 6;
+      cand[c * CT + j] = reinterpret_cast<const float4*>(a.V + min(j0 + j, a.n_cand - 1) * a.d)[c];
+    }
+    __syncthreads();
+    const int64_t item = j0 + lane;
+    const int64_t gj = min(item, a.n_cand - 1);
+    float lvr[MAXP];                                                    // this lane's item logits: registers for the stage's users
+#pragma unroll
+    for (int p = 0; p < MAXP; ++p) lvr[p] = p < a.P ? a.LV[gj * a.P + p] : 0.f;
+    const bool iok = item < i_hi;
+    const int64_t lid = item - i_lo;
+    for (int r = 0; r < SW_UW; ++r) {
+      const int64_t b = u0 + r;
+      if (b >= a.nq) break;
+      const float* ql = a.QL + b * a.P;  // wave-uniform -> scalar loads
+      const uint64_t base = ((uint64_t)b * (uint64_t)a.n_cand + (uint64_t)gj) * (uint64_t)a.P;
+      const int ps = gate_argmax<MAXP>(a.P, base, a.gumbel == KTUP_GUMBEL_INPUT, a.uniform, a.seed, a.offset,
+                                       [&](int p) { return ql[p] + lvr[p]; });
+      const sptr4 ub = QW + (b * 3 + 1) * nch4;   // slot 1 = u_b
+      const float4* cn = tabC + ps * dp4;
+      const float4* ar = tabA + ps * dp4;
+      float s = 0.f;
+      for (uint32_t c = 0; c < (uint32_t)nch4; ++c) s += dot4(sldp(ub + c) - cand[c * CT + lane], cn[c]);
+      float acc = 0.f;
+      for (uint32_t c = 0; c < (uint32_t)nch4; ++c) {
+        const float4 q = sldp(ub + c) - cand[c * CT + lane];
+        acc += dist4(fma4(-s, cn[c], q + ar[c]), l1);
+      }
+      // ---- ranking: acc against user r's n-th score
+      const float tf = thrf[r];
+      bool c = acc < tf;
+      const bool tie = !c && !(acc > tf);
+      if (__builtin_amdgcn_ballot_w64(tie)) {
+        if (tie) c = sweep_key(acc, (uint32_t)item) < thrk[r];
+      }
+      c = c && iok;
+      if (c) c = ((bm[r * sa.bm_words + (lid >> 5)] >> (lid & 31)) & 1u) == 0u;
+      uint64_t m = __builtin_amdgcn_ballot_w64(c);
+      if (m) {
+        const uint64_t mine = sweep_key(acc, (uint32_t)item);
+        uint64_t list = lane < topn ? tk[r * topn + lane] : SKEY_MAX;     // lanes 0..topn-1: the sorted list
+        while (m) {
+          const int src = __builtin_ctzll(m);
+          m &= m - 1;
+          const uint64_t k = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mine >> 32), src) << 32) |
+                             (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mine, src);
+          const int pos = __popcll(__builtin_amdgcn_ballot_w64(list < k));  // entries below the newcomer (lanes >= 16 hold MAX)
+          if (pos < topn) {
+            const uint64_t up = ((uint64_t)(uint32_t)__shfl_up((int)(uint32_t)(list >> 32), 1, 64) << 32) | (uint32_t)__shfl_up((int)(uint32_t)list, 1, 64);
+            list = lane < pos ? list : (lane == pos ? k : up);
+            if (lane >= topn) list = SKEY_MAX;
+          }
+        }
+        if (lane < topn) tk[r * topn + lane] = list;
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(list >> 32), topn - 1);
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)list, topn - 1);
+        if (lane == 0) {
+          thrk[r] = ((uint64_t)hi << 32) | lo;
+          thrf[r] = __uint_as_float((hi & 0x80000000u) ? (hi & 0x7fffffffu) : ~hi);   // inverse image; NaN while the list is short
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+  }
+  if (lane < topn) {
+    for (int r = 0; r < SW_UW; ++r) {
+      const int64_t b = u0 + r;
+      if (b < a.nq) sa.part[(b * sa.nsplit + blockIdx.y) * topn + lane] = tk[r * topn + lane];
+    }
   }
 }
 
@@ -841,4 +986,69 @@ extern "C" int ktup_eval_pref_scores(const float* U, int64_t ldu, const float* I
   if (int e = pref_items_project(name, I, ldi, E, lde, item2ent, pref_ws, n_pref, d, n_items, it, (hipStream_t)stream)) return e;
   return pref_scores_tail(name, U, ldu, pref_ws, n_pref, d, u_ids, nq, n_items, l1, gumbel_mode, uniform, seed, offset, out, ldo, it,
                           ws, (hipStream_t)stream);
+}
+
+
+// ---- the hard gate's whole pass (see sweep_hard_kernel)
+extern "C" size_t ktup_eval_pref_topk_hard_workspace_bytes(int d, int n_pref, int64_t nq, int64_t n_items, int topn) {
+  if (d <= 0 || n_pref <= 0 || nq < 0 || n_items < 0 || topn <= 0) return 0;
+  return ktup_eval_pref_items_workspace_bytes(d, n_pref, n_items) + ((size_t)nq * 3 * d + pad4((size_t)nq * n_pref)) * sizeof(float) +
+         (size_t)nq * 8 * topn * sizeof(uint64_t) + 64;
+}
+
+extern "C" int ktup_eval_pref_topk_hard(const float* U, int64_t ldu, const float* I, int64_t ldi, const float* E, int64_t lde,
+                                        const int32_t* item2ent, const float* pref_ws, int n_pref, int d, const int64_t* u_ids, int64_t nq,
+                                        int64_t n_items, int l1, int gumbel_mode, const float* uniform, uint64_t seed, uint64_t offset,
+                                        const int64_t* filt_off, const int32_t* filt_ids, int topn, int32_t* top_ids, float* top_scores,
+                                        float* ws, void* stream) {
+  const char* name = "ktup_eval_pref_topk_hard";
+  KTUP_REQUIRE(nq >= 0 && n_items >= 0, "%s: bad sizes", name);
+  if (nq == 0) return KTUP_OK;
+  KTUP_REQUIRE(n_items > 0 && n_items < (1ll << 31) && topn >= 1 && topn <= 16 && n_pref <= 32, "%s: needs items, 32-bit item ids, topn <= 16 and at most 32 preferences", name);
+  KTUP_REQUIRE(gumbel_mode == KTUP_GUMBEL_INPUT || gumbel_mode == KTUP_GUMBEL_PHILOX || gumbel_mode == KTUP_GUMBEL_PHILOX_DEV,
+               "%s: the hard gate needs a noise source (the soft gate's pass is ktup_eval_pref_topk)", name);
+  KTUP_REQUIRE(U && I && pref_ws && u_ids && top_ids && ws && aligned16(ws), "%s: bad argument", name);
+  KTUP_REQUIRE((gumbel_mode == KTUP_GUMBEL_PHILOX) || uniform, "%s: KTUP_GUMBEL_INPUT / KTUP_GUMBEL_PHILOX_DEV need the `uniform` pointer", name);
+  KTUP_REQUIRE((filt_off == nullptr) || filt_ids, "%s: filter offsets without ids", name);
+  const PrefGeom g = pref_geom(d, n_pref);
+  if (!g.ok) return set_error(KTUP_ERR_UNSUPPORTED, "%s: embedding_size must be a multiple of 4 in [4, 256] (got %d)", name, d);
+  hipStream_t st = (hipStream_t)stream;
+  float* items_ws = ws;
+  const ItemSide it = item_side(items_ws, n_items, d);
+  if (int e = pref_items_project(name, I, ldi, E, lde, item2ent, pref_ws, n_pref, d, n_items, it, st)) return e;
+  float* QW = items_ws + ktup_eval_pref_items_workspace_bytes(d, n_pref, n_items) / sizeof(float);
+  float* QL = QW + (size_t)nq * 3 * d;
+  uint64_t* part = reinterpret_cast<uint64_t*>((reinterpret_cast<uintptr_t>(QL + pad4((size_t)nq * n_pref)) + 15) & ~(uintptr_t)15);
+  KTUP_REQUIRE(aligned16(U) && aligned16(pref_ws) && ldu % 4 == 0, "%s: tables must be 16-byte aligned with pitches %% 4 == 0", name);
+  hipLaunchKernelGGL(pref_project_kernel, dim3(grid_for((nq + 3) / 4)), dim3(256), 0, st, U, ldu, (const float*)nullptr,
+                     (int64_t)0, (const int32_t*)nullptr, u_ids, nq, d, n_pref, pref_ws, g.ppad, g.dp, 1.0f, (int64_t)3 * d, QW,
+                     QW + d, QW + 2 * d, QL);
+  if (int e = check_launch(name)) return e;
+  SweepHardArgs sa{};
+  HardArgs& h = sa.h;
+  h.V = it.CW1; h.LV = it.CL; h.QW = QW; h.QL = QL; h.ws = pref_ws; h.ppad = g.ppad; h.dp = g.dp; h.P = n_pref; h.d = d;
+  h.n_cand = n_items; h.nq = nq; h.l1 = l1; h.gumbel = gumbel_mode; h.uniform = uniform; h.seed = seed; h.offset = offset;
+  sa.filt_off = filt_off; sa.filt_ids = filt_ids; sa.topn = topn; sa.part = part;
+  const int64_t ublocks = (nq + SW_NW * SW_UW - 1) / (SW_NW * SW_UW);
+  int nsplit = (int)(768 / ublocks);                     // three workgroups per CU are resident (LDS): one round
+  if (nsplit > 8) nsplit = 8;
+  if (nsplit < 1) nsplit = 1;
+  const int64_t stages = (n_items + CT - 1) / CT;
+  if (nsplit > stages) nsplit = (int)stages;
+  sa.split_items = ((stages + nsplit - 1) / nsplit) * CT;
+  nsplit = (int)((n_items + sa.split_items - 1) / sa.split_items);
+  sa.nsplit = nsplit;
+  sa.bm_words = (int)((sa.split_items + 31) / 32);
+  const size_t lds = (size_t)(d / 4) * CT * 16 + (size_t)2 * n_pref * g.dp * 4 + SW_NW * ((sweep_wave_bytes(sa.bm_words, topn) + 7) & ~(size_t)7);
+  if (lds > 160 * 1024 || ublocks > 0x7fffffffll)
+    return set_error(KTUP_ERR_UNSUPPORTED, "%s: the stage needs %zu B of LDS (per-batch calls remain)", name, lds);
+  const dim3 grid((unsigned)ublocks, (unsigned)nsplit);
+  auto launch = [&](auto kern) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, grid, dim3(SW_NW * 64), lds, st, sa);
+  };
+  if (n_pref <= 20) { if (l1) launch(sweep_hard_kernel<true, 20>); else launch(sweep_hard_kernel<false, 20>); }
+  else { if (l1) launch(sweep_hard_kernel<true, 32>); else launch(sweep_hard_kernel<false, 32>); }
+  if (int e = check_launch(name)) return e;
+  return ktup::launch_topk_merge(part, nq, nsplit, topn, top_ids, top_scores, st, name);
 }

@@ -839,6 +839,13 @@ int launch_q_p(int n_pref, const float* U, int64_t ldu, const int64_t* u_ids, in
 
 namespace ktup {
 
+// the merge of the splits' partial lists, for the other sweeps (ktup_eval.hip: the hard gate's pass)
+int launch_topk_merge(const uint64_t* part, int64_t nq, int nsplit, int topn, int32_t* top_ids, float* top_scores, hipStream_t st, const char* name) {
+  hipLaunchKernelGGL(topk_merge_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(MERGE_T), 0, st, part, nq, nsplit, topn, (const float*)nullptr, top_ids,
+                     top_scores);
+  return check_launch(name);
+}
+
 // The preference-space pass (see QGeom): scratch for the Gram matrices, both operand tables, the scalars and the partial lists.
 size_t eval_pass_pspace_bytes(int d, int n_pref, int64_t nq, int64_t n_items, int topn) {
   const size_t p4 = n_pref <= 4 ? 4 : n_pref <= 20 ? 20 : 32;

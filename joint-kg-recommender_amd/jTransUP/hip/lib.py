@@ -83,6 +83,9 @@ SIGNATURES = {
     'ktup_eval_pref_scores_prepared': [c_p, c_l, c_p, c_i, c_i, c_p, c_l, c_l, c_i, c_i, c_p, c_u, c_u, c_p, c_l, c_p, c_p, c_p],
     'ktup_eval_pref_topk_workspace_bytes': [c_i, c_i, c_l, c_l, c_i],
     'ktup_eval_pref_topk': [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_p, c_i, c_i, c_p, c_l, c_l, c_i, c_p, c_p, c_i, c_p, c_p, c_p, c_p],
+    'ktup_eval_pref_topk_hard_workspace_bytes': [c_i, c_i, c_l, c_l, c_i],
+    'ktup_eval_pref_topk_hard': [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_p, c_i, c_i, c_p, c_l, c_l, c_i, c_i, c_p, c_u, c_u, c_p, c_p, c_i, c_p,
+                                 c_p, c_p, c_p],
     'ktup_eval_topk_filtered': [c_p, c_l, c_l, c_l, c_i, c_p, c_p, c_i, c_p, c_p, c_p],
     'ktup_eval_gold_rank_counts': [c_p, c_l, c_l, c_l, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
     'ktup_eval_gold_ranks': [c_p, c_l, c_l, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_p],
@@ -140,7 +143,7 @@ _RESTYPE = {'ktup_last_error': ctypes.c_char_p, 'ktup_shard_reduce_list_len': ct
             'ktup_eval_kg_workspace_bytes': ctypes.c_size_t, 'ktup_eval_transr_workspace_bytes': ctypes.c_size_t, 'ktup_eval_transr_entities_workspace_bytes': ctypes.c_size_t, 'ktup_score_transr_workspace_bytes': ctypes.c_size_t, 'ktup_score_transr_bwd_workspace_bytes': ctypes.c_size_t,
             'ktup_eval_pref_workspace_bytes': ctypes.c_size_t, 'ktup_eval_pref_items_workspace_bytes': ctypes.c_size_t, 'ktup_negsample_rec_workspace_bytes': ctypes.c_size_t,
             'ktup_score_pref_bwd_workspace_bytes': ctypes.c_size_t, 'ktup_segment_workspace_bytes': ctypes.c_size_t, 'ktup_shard_dedupe_workspace_bytes': ctypes.c_size_t,
-            'ktup_eval_pref_topk_workspace_bytes': ctypes.c_size_t,
+            'ktup_eval_pref_topk_workspace_bytes': ctypes.c_size_t, 'ktup_eval_pref_topk_hard_workspace_bytes': ctypes.c_size_t,
             'ktup_score_kg_bwd_workspace_bytes': ctypes.c_size_t, 'ktup_score_bprmf_bwd_workspace_bytes': ctypes.c_size_t}
 
 _lib = None

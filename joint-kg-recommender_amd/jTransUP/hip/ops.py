@@ -598,6 +598,37 @@ def eval_pref_topk(U, u, items, l1, topn, filt_off=None, filt_ids=None, with_sco
     return (top, ts) if with_scores else top
 
 
+@torch.no_grad()
+def eval_pref_topk_hard(U, u, items, l1, topn, gumbel_mode, uniform=None, seed=0, offset=0, filt_off=None, filt_ids=None, with_scores=False):
+    """The hard (ST-Gumbel) gate's whole evaluation pass in one sweep (ktup_eval_pref_topk_hard): the scores of eval_tup / eval_ktup
+    for the same noise source over ALL users of `u` at once (pair (b, j) draws at ((b n_items + j) P + p) + offset), L1 or squared
+    L2, with the filtered top-n taken where the scores are made.  -> int32 (len(u), topn) ids (-1 padded) [, scores]; None when
+    topn > 16 (keep eval_* + topk_filtered)."""
+    dev = _dev(_table('user table', U))
+    u = _ids('u_ids', u, dev)
+    nq, d, P, ni = u.numel(), items.d, items.P, items.n_items
+    if not (0 < topn <= 16) or nq == 0:
+        return None
+    if gumbel_mode == GUMBEL_INPUT:
+        if uniform is None or tuple(uniform.shape) != (nq, ni, P) or uniform.dtype != torch.float32 or uniform.device != dev:
+            raise L.KtupError('uniform must be an (n_users, n_items, n_pref) fp32 device tensor')
+        uniform = uniform.contiguous()
+    elif gumbel_mode != GUMBEL_PHILOX:
+        raise L.KtupError('eval_pref_topk_hard needs GUMBEL_INPUT or GUMBEL_PHILOX')
+    else:
+        uniform = None
+    if filt_ids is not None and filt_ids.numel() == 0:
+        filt_off = filt_ids = None
+    top = torch.empty(nq, topn, dtype=torch.int32, device=dev)
+    ts = torch.empty(nq, topn, dtype=torch.float32, device=dev) if with_scores else None
+    ws = _scratch(L.load().ktup_eval_pref_topk_hard_workspace_bytes(d, P, nq, ni, topn), dev)
+    I, E = items.I, items.E
+    L.call('ktup_eval_pref_topk_hard', _p(U), U.stride(0), _p(I), I.stride(0), _p(E), 0 if E is None else E.stride(0), _p(items.item2ent),
+           _p(items.pws), P, d, _p(u), nq, ni, int(l1), int(gumbel_mode), _p(uniform), int(seed), int(offset), _p(filt_off), _p(filt_ids),
+           int(topn), _p(top), _p(ts), _p(ws), _stream(dev))
+    return (top, ts) if with_scores else top
+
+
 def eval_tup(U, I, pref, pref_norm, u, l1, gumbel_mode=GUMBEL_OFF, uniform=None, seed=0, offset=0, items=None):
     """transUP.py:84-102 -> (len(u), n_items).  `items`: eval_pref_items(...) of the same tables (one per evaluation pass)."""
     return _eval_pref(U, I, None, pref, pref_norm, None, None, None, u, l1, gumbel_mode, uniform, seed, offset, items)

@@ -203,7 +203,10 @@ def _single_process():
 
 
 def model_graph_key(model):
-    """What a captured evaluation pass of `model` depends on besides the pass's own inputs: the addresses of its tables."""
+    """What a captured evaluation pass of `model` depends on besides the pass's own inputs: the addresses of its tables.  None for a
+    model whose pass draws noise (ST-Gumbel gate): a replay would repeat the captured stream position."""
+    if getattr(model, 'use_st_gumbel', False):
+        return None
     return (id(model),) + tuple(p.data_ptr() for p in model.parameters())
 
 

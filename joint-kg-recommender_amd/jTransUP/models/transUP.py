@@ -53,9 +53,12 @@ class TransUPModel(nn.Module, GradToggle):
 
     def evaluate_topk(self, u_ids, items, topn, filt_off=None, filt_ids=None):
         """K15 + K17 for a whole evaluation pass in one sweep (this build): filtered top-n item ids of every user of `u_ids`
-        without the (users x items) matrix.  None when the fused pass does not apply (ST-Gumbel gate, L1, unsupported width)."""
+        without the (users x items) matrix.  The ST-Gumbel gate takes the hard gate's sweep (fresh Philox noise per pass, as `evaluate`
+        draws it per batch); None when no fused pass applies (soft gate with L1 or an unsupported width)."""
         if self.use_st_gumbel:
-            return None
+            mode, uni, seed, off = self._gumbel.mode_and_stream(True, None, u_ids.numel() * items.n_items * items.P)
+            return ops.eval_pref_topk_hard(self.user_embeddings.weight, u_ids, items, self.L1_flag, topn, mode, uni, seed, off,
+                                           filt_off, filt_ids)
         return ops.eval_pref_topk(self.user_embeddings.weight, u_ids, items, self.L1_flag, topn, filt_off, filt_ids)
 
     def prepare_items(self):

@@ -202,6 +202,44 @@ def test_topk_properties_full_catalogue():
         np.testing.assert_array_equal(ts[b], scores[b][order])
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('l1', [False, True])
+@pytest.mark.parametrize('noise', ['philox', 'philox_odd_offset', 'input'])
+def test_hard_gate_pass_in_one_sweep(l1, noise):
+    """ktup_eval_pref_topk_hard (the ST-Gumbel gate's evaluation pass in one sweep, L1 and squared L2, TUP and KTUP): the ids AND
+    the scores of eval_tup / eval_ktup + topk_filtered for the same noise -- Philox stream positions of one call over all users,
+    with an offset that is and is not a multiple of a Philox block, or a given uniform tensor -- bit for bit; users repeated and in
+    any order, a user whose items are all filtered, one with none, several catalogue splits with a ragged last stage."""
+    d, nu, ni, nq, topn, P, ne = 100, 90, 700, 150, 10, 20, 200
+    if noise == 'input':
+        ni, nq = 200, 70                                                      # (nq x ni x P) uniforms
+    gen = torch.Generator().manual_seed(7 + ni)
+    mk = lambda r: O.make_table(r, d, gen).to(DEV)
+    U, I, E, Pm, Pn, R, Rn = mk(nu), mk(ni), torch.cat([O.make_table(ne, d, gen), torch.zeros(1, d)]).to(DEV), mk(P), mk(P), mk(P), mk(P)
+    i2e = torch.randint(0, ne + 1, (ni,), generator=gen).to(DEV, torch.int32)
+    u = torch.randint(0, nu, (nq,), generator=gen).to(DEV)
+    rng = np.random.RandomState(ni)
+    filt = [np.sort(rng.choice(ni, size=min(ni, int(rng.randint(0, 170))), replace=False)).astype(np.int32) for _ in range(nq)]
+    filt[1] = np.arange(ni, dtype=np.int32)
+    filt[2] = np.zeros(0, np.int32)
+    f_off = dv(np.concatenate([[0], np.cumsum([len(f) for f in filt])]).astype(np.int64))
+    f_ids = dv(np.concatenate(filt).astype(np.int32))
+    G = ops()
+    mode = G.GUMBEL_INPUT if noise == 'input' else G.GUMBEL_PHILOX
+    uni = torch.rand(nq, ni, P, generator=gen).to(DEV) if noise == 'input' else None
+    seed, off = 0x1234567, (4 * 977 if noise == 'philox' else 4 * 977 + 3)
+    for ktup in (True, False):
+        items = G.eval_pref_items(I, E if ktup else None, Pm, Pn, R if ktup else None, Rn if ktup else None, i2e if ktup else None)
+        got = G.eval_pref_topk_hard(U, u, items, l1, topn, mode, uni, seed, off, f_off, f_ids, with_scores=True)
+        mat = G.eval_ktup(U, I, E, Pm, Pn, R, Rn, i2e, u, l1, mode, uni, seed, off, items=items) if ktup else \
+            G.eval_tup(U, I, Pm, Pn, u, l1, mode, uni, seed, off, items=items)
+        want = G.topk_filtered(mat, False, topn, f_off, f_ids, with_scores=True)
+        assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+        assert got[0][1].tolist() == [-1] * topn
+        nf = G.eval_pref_topk_hard(U, u, items, l1, topn, mode, uni, seed, off)
+        assert torch.equal(nf, G.topk_filtered(mat, False, topn))
+
+
 def _rank_case(rng, nq, nc, nf, max_gold, quant):
     scores = (rng.randint(0, quant, size=(nq, nc)) / 7.0).astype(np.float32) if quant else rng.randn(nq, nc).astype(np.float32)
     scores[0, ::3] = -0.0

@@ -9,19 +9,24 @@
 //     except u.v contracted in PREFERENCE space (see QGeom below): 68 instead of 156 MFMAs per 16 x 16 tile at d = 100, P = 20.
 //     Scores agree with the matrix route to fp32 rounding (the same sums in another association);
 //   * a workgroup owns 64 users (4 waves x 16) and a contiguous split of the catalogue.  A wave keeps its 16 users' operand
-//     rows in REGISTERS for the whole pass (17 float4 per lane); items stream through a double-buffered LDS buffer of two
-//     16-item tiles (the B operands, 160 floats per item) that the next tiles' global loads refill under the MFMAs -- three
+//     rows in REGISTERS for the whole pass (17 float4 per lane); items stream through a double-buffered LDS buffer of
+//     16-item tiles (the B operands, 160 floats per item) that the next tile's global loads refill under the MFMAs -- three
 //     workgroups per CU;
 //   * ranking: a user's sorted top-n list (64-bit keys = order-preserving score image << 32 | item id, the order of
-//     ktup_rank.hip: ascending score, ties -> lower id) lives in REGISTERS, one element per lane of the 16-lane row that owns
-//     the user in the MFMA output layout (lane (kq, j) holds element j of users 4 kq + reg).  A score is a candidate only if its
-//     key beats the user's current n-th key and its bit in the wave's filter bitmap (built once from the CSR filter lists, for
-//     this workgroup's item split only: 16 users x (split / 32) words of LDS) is clear.  The four rows insert their candidates in
-//     parallel: the shift of the sorted list is one DPP row_shr per half key, the position a popcount of a ballot -- no LDS
-//     round trip (the first version kept the lists in LDS and inserted one candidate per wave at a time: 830 us per ml1m pass);
+//     ktup_rank.hip: ascending score, ties -> lower id) lives in the wave's LDS and is touched only when 16 candidates are pending
+//     for it.  A score is a candidate if it is below the user's n-th score -- compared as floats, the keys deciding equality --
+//     and its bit in the wave's filter bitmap (built once from the CSR filter lists, for this workgroup's item split only: 16 users
+//     x (split / 32) words of LDS) is clear; candidates go to the user's pending row at positions taken from a ballot, and a row
+//     that holds 16 is merged with the list by a fixed 16-lane network (bitonic sort of the candidates + merge: DPP exchanges on
+//     the four rows of a register slot at once).  (History: lists in LDS with one insertion per wave at a time: 830 us per ml1m
+//     pass; lists in registers with the network run per tile and slot: 212 us, 400 of its ~670 VALU instructions per tile in the
+//     network; deferred merges: ~380 per tile, 192 us.  What is left is the shared MFMA + VALU pipe at the clock the chip holds
+//     under this load (~2.1 GHz): option dbg_eval switches phases off to measure them -- 120 us without the ranking, 23 us of
+//     prologue per workgroup.);
 //   * both operand tables and the per-row scalars are built per pass by one small launch (pspace_rows_kernel) after the three
 //     P x P Gram matrices (pspace_gram_kernel); the splits' partial lists are merged by a last, tiny launch (topk_merge_kernel).
-// L1 distance and the ST-Gumbel gate do not decompose into bilinear terms: they keep the per-batch kernels of ktup_eval.hip.
+// L1 distance and the ST-Gumbel gate do not decompose into bilinear terms: the hard gate has its own sweep (ktup_eval.hip
+// sweep_hard_kernel, either distance); the soft gate with L1 keeps the per-batch kernels of ktup_eval.hip.
 #include <hip/hip_runtime.h>
 
 #include <cstdint>

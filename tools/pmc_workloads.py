@@ -5,6 +5,9 @@
     seg_bwd     the large-batch backwards by sorted segments: TransE (307,200 triples) and KTUP (716,800 pairs), 5 each
     kg_rank     the filtered gold ranks of one 512-query KG evaluation batch over 14,709 entities (ktup_eval_gold_ranks), 10 calls
     kg_pass     one direction of a link-prediction pass, 20,480 keys x 14,709 entities behind one call (ktup_eval_kg_ranks, TransH), 3 passes
+    kg_pass_e   the same for TransE
+    hard_pass   the ST-Gumbel gate's evaluation pass in one sweep (TUP, 6040 users x 3240 items, ktup_eval_pref_topk_hard), 3 passes,
+                then the batched route over the same users (pairs_hard_kernel + K17 per 512 users), once
 tools/pmc_summary.py turns the counter_collection.csv into per-kernel averages."""
 import os
 import sys
@@ -96,7 +99,7 @@ def kg_rank(dev):
     torch.cuda.synchronize()
 
 
-def kg_pass(dev):
+def kg_pass(dev, transe=False):
     from jTransUP.hip import ops
     gen = torch.Generator().manual_seed(7)
     nq = 20480
@@ -109,9 +112,27 @@ def kg_pass(dev):
     f_off = (torch.arange(nq + 1) * 20).to(dev)
     f_ids = torch.randint(0, B.NE, (nq * 20,), generator=gen).to(dev, torch.int32)
     for _ in range(3):
-        ops.eval_kg_ranks(E, R, N, q, r, False, False, False, g_off, g_ids, f_off, f_ids)
+        ops.eval_kg_ranks(E, R, None if transe else N, q, r, False, False, False, g_off, g_ids, f_off, f_ids)
+    torch.cuda.synchronize()
+
+
+def hard_pass(dev):
+    from jTransUP.hip import ops
+    from jTransUP.models import transUP as tu
+    torch.manual_seed(3)
+    m = tu.TransUPModel(False, B.D, B.NU, B.NI, B.NR, True).to(dev)
+    m.eval(); m.disable_grad()
+    u = torch.arange(B.NU, device=dev)
+    gen = torch.Generator().manual_seed(1)
+    f_off = (torch.arange(B.NU + 1) * 165).to(dev)
+    f_ids = torch.randint(0, B.NI, (B.NU * 165,), generator=gen).to(dev, torch.int32)
+    items = m.prepare_items()
+    for _ in range(3):
+        m.evaluate_topk(u, items, 10, f_off, f_ids)
+    for s in range(0, B.NU, 512):
+        ops.topk_filtered(m.evaluate(u[s:s + 512], items=items), False, 10, f_off[s:s + 513] - f_off[s], f_ids[int(f_off[s]):])
     torch.cuda.synchronize()
 
 
 if __name__ == '__main__':
-    {'kg_pass': kg_pass, 'kg_rank': kg_rank, 'eval_pass': eval_pass, 'train_step': train_step, 'fed_step': fed_step, 'seg_bwd': seg_bwd}[sys.argv[1]](torch.device('cuda'))
+    {'kg_pass': kg_pass, 'kg_pass_e': lambda d: kg_pass(d, True), 'hard_pass': hard_pass, 'kg_rank': kg_rank, 'eval_pass': eval_pass, 'train_step': train_step, 'fed_step': fed_step, 'seg_bwd': seg_bwd}[sys.argv[1]](torch.device('cuda'))

@@ -97,8 +97,9 @@ struct Philox {
     uint32_t a = k0, b = k1;
 #pragma unroll
     for (int i = 0; i < 10; ++i) {
-      const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-      const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+      // one 32 x 32 -> 64 multiply per product (v_mad_u64_u32) instead of a high and a low one
+      const uint64_t m0 = (uint64_t)0xD2511F53u * (uint64_t)c0, m1 = (uint64_t)0xCD9E8D57u * (uint64_t)c2;
+      const uint32_t hi0 = (uint32_t)(m0 >> 32), lo0 = (uint32_t)m0, hi1 = (uint32_t)(m1 >> 32), lo1 = (uint32_t)m1;
       const uint32_t n0 = hi1 ^ c1 ^ a, n1 = lo1, n2 = hi0 ^ c3 ^ b, n3 = lo0;
       c0 = n0; c1 = n1; c2 = n2; c3 = n3;
       a += 0x9E3779B9u; b += 0xBB67AE85u;
@@ -120,11 +121,33 @@ KTUP_DEV float fast_gumbel_from_uniform(float u) {
   return -ln2 * __builtin_amdgcn_logf(-ln2 * __builtin_amdgcn_logf(u + 1e-20f) + 1e-20f);
 }
 // MAXP > 0: the loop over the preferences is unrolled to MAXP steps (logit(p) may then index registers)
+struct GatePick { int ps; float best, second; };     // (returned by value: reference outputs kept best / second in scratch memory,
+                                                     //  a memory round trip per preference -- the waves waited 57 % of the time)
 template <bool FAST, int MAXP, typename LogitFn>
-KTUP_DEV int gate_argmax_pass(int P, uint64_t base, bool input, const float* uniform, uint64_t seed, uint64_t offset, LogitFn logit, float& best,
-                              float& second) {
+KTUP_DEV GatePick gate_argmax_pass(int P, uint64_t base, bool input, const float* uniform, uint64_t seed, uint64_t offset, LogitFn logit) {
   int ps = 0;
-  best = -__builtin_inff(); second = best;
+  float best = -__builtin_inff(), second = best;
+  auto take = [&](int p, float u) {
+    const float v = logit(p) + (FAST ? fast_gumbel_from_uniform(u) : gumbel_from_uniform(u));
+    if (v > best) { second = best; best = v; ps = p; }
+    else if (v > second) second = v;
+  };
+  if (!input && (P & 3) == 0 && MAXP == 0) {
+    // a pair's P draws start at stream position base + offset with base a multiple of P, hence of 4: every lane sits at the same place
+    // `sh` inside its first Philox block, and the walk goes block by block -- one 64-bit add per pair instead of one (plus a shift, a
+    // compare and a component select) per preference
+    const uint64_t first = base + offset;
+    const int sh = __builtin_amdgcn_readfirstlane((int)((uint32_t)offset & 3u));
+    uint64_t blk = first >> 2;
+    for (int p0 = -sh; p0 < P; p0 += 4, ++blk) {
+      const uint4 r = Philox(seed)(blk, 0x4b545550ull);
+      if (p0 >= 0) take(p0, u01(r.x));
+      if (p0 + 1 >= 0 && p0 + 1 < P) take(p0 + 1, u01(r.y));
+      if (p0 + 2 >= 0 && p0 + 2 < P) take(p0 + 2, u01(r.z));
+      if (p0 + 3 < P) take(p0 + 3, u01(r.w));
+    }
+    return GatePick{ps, best, second};
+  }
   uint64_t blk = ~0ull;              // the Philox block (4 draws) in hand: consecutive preferences share it
   uint4 r = {0u, 0u, 0u, 0u};
 #pragma unroll
@@ -141,22 +164,20 @@ KTUP_DEV int gate_argmax_pass(int P, uint64_t base, bool input, const float* uni
         }
         u = u01((idx & 3) == 0 ? r.x : (idx & 3) == 1 ? r.y : (idx & 3) == 2 ? r.z : r.w);
       }
-      const float v = logit(p) + (FAST ? fast_gumbel_from_uniform(u) : gumbel_from_uniform(u));
-      if (v > best) { second = best; best = v; ps = p; }
-      else if (v > second) second = v;
+      take(p, u);
     }
   }
-  return ps;
+  return GatePick{ps, best, second};
 }
 template <int MAXP = 0, typename LogitFn>
 KTUP_DEV int gate_argmax(int P, uint64_t base, bool input, const float* uniform, uint64_t seed, uint64_t offset, LogitFn logit) {
-  float best, second;
-  if (input) return gate_argmax_pass<false, MAXP>(P, base, true, uniform, seed, offset, logit, best, second);
-  int ps = gate_argmax_pass<true, MAXP>(P, base, false, uniform, seed, offset, logit, best, second);
+  if (input) return gate_argmax_pass<false, MAXP>(P, base, true, uniform, seed, offset, logit).ps;
+  const GatePick f = gate_argmax_pass<true, MAXP>(P, base, false, uniform, seed, offset, logit);
+  int ps = f.ps;
   // two sums off by <= 1.94e-6 + an ulp each: 4e-6 + 5e-7 |best| bounds the error of the lead; four times that decides
-  const bool close = !(best - second > 2e-5f + 2e-6f * fabsf(best));       // (NaNs land here too)
+  const bool close = !(f.best - f.second > 2e-5f + 2e-6f * fabsf(f.best));       // (NaNs land here too)
   if (__builtin_amdgcn_ballot_w64(close)) {
-    if (close) ps = gate_argmax_pass<false, MAXP>(P, base, false, uniform, seed, offset, logit, best, second);
+    if (close) ps = gate_argmax_pass<false, MAXP>(P, base, false, uniform, seed, offset, logit).ps;
   }
   return ps;
 }

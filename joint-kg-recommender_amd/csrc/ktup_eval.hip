@@ -67,13 +67,14 @@ __global__ __launch_bounds__(256) void kg_query_prep_kernel(int model, const flo
 
 // ---------------------------------------------------------------------------------------------------------
 // Preference projections of one table (users or items): logits L = (A x)/2, R = beta A^T L, N = beta C^T L.
-// Outputs (pitch d): O0 = x + sign*R, O1 = x, O2 = N, OL = L (n_pref per row).  One wave per row, lane = 16-B chunk.
+// Outputs (pitch d): O0 = x + sign*R, O1 = x, O2 = N, OL = L (n_pref per row), ON = x . Cn_p (n_pref per row; NULL = not wanted: the
+// hard gate's squared-L2 score reads it).  One wave per row, lane = 16-B chunk.
 __global__ __launch_bounds__(256) void pref_project_kernel(const float* __restrict__ X, int64_t ldx, const float* __restrict__ E,
                                                            int64_t lde, const int32_t* __restrict__ item2ent,
                                                            const int64_t* __restrict__ ids, int64_t nrows, int d, int P,
                                                            const float* __restrict__ ws, int ppad, int dp, float sign,
                                                            int64_t opitch, float* __restrict__ O0, float* __restrict__ O1,
-                                                           float* __restrict__ O2, float* __restrict__ OL) {
+                                                           float* __restrict__ O2, float* __restrict__ OL, float* __restrict__ ON) {
   const int lane = threadIdx.x & 63;
   const int nch = d / 4;
   const float4* Alog = reinterpret_cast<const float4*>(ws);
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(256) void pref_project_kernel(const float* __restri
     float4 racc = f4zero(), nacc = f4zero();
     for (int pb = 0; pb < P; pb += 64) {          // up to 64 logits per pass: lane l keeps logit pb + l
       const int pe = min(P, pb + 64);
-      float mylog = 0.f;
+      float mylog = 0.f, mydn = 0.f;
       // phase 1: the logits.  Four preferences per trip = four INDEPENDENT cross-lane reductions in flight (one dependent
       // reduction per preference, as a single loop had it, is a chain of ~20 x 6 shuffle latencies per row)
       for (int p = pb; p < pe; p += 4) {
@@ -102,8 +103,18 @@ __global__ __launch_bounds__(256) void pref_project_kernel(const float* __restri
 #pragma unroll
         for (int k = 0; k < 4; ++k)
           if (lane == p + k - pb) mylog = part[k];
+        if (ON) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) part[k] = (lane < nch && p + k < pe) ? dot4(x, Cn[min(p + k, pe - 1) * dp4 + lane]) : 0.f;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) part[k] = wave_sum(part[k]);
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            if (lane == p + k - pb) mydn = part[k];
+        }
       }
       if (pb + lane < pe) OL[row * P + pb + lane] = mylog;
+      if (ON && pb + lane < pe) ON[row * P + pb + lane] = mydn;
       // phase 2: R and N accumulate over the preferences; logit p comes from lane p - pb (uniform index -> v_readlane)
       for (int p = pb; p < pe; ++p) {
         const float lp = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mylog), p - pb));
@@ -248,6 +259,8 @@ __global__ __launch_bounds__(PairsWG<MODE>::NT) void pairs_kernel(PairsArgs a) {
 struct HardArgs {
   const float *V, *LV;  // candidate vectors v_j [N][d], logits [N][P]
   const float *QW, *QL; // query vectors (slot 1 = u_b), logits [nq][P]
+  const float *QN, *VN; // u_b . Cn_p [nq][P], v_j . Cn_p [N][P]   (squared L2)
+  const float* consts;  // [4][32]: |Ar_p|^2, Ar_p . Cn_p, |Cn_p|^2 - 2, {4 beta}   (squared L2)
   const float* ws;      // prepared tables
   int ppad, dp, P, d;
   int64_t n_cand, nq;
@@ -260,51 +273,117 @@ struct HardArgs {
 
 constexpr int HARD_NT = 512;   // 8 waves share a candidate tile + tables (47 KB at d = 100, P = 20): 3 workgroups per CU
 
+// The stage both hard-gate kernels score against: 64 candidates' vectors [nch4][CT] and logits [P][CT], then
+//   L1:          the tables Ar, Cn [P][dp4] (the chosen preference's rows are read per lane);
+//   squared L2:  v_j . Cn_p [P][CT] and the per-preference constants [4][32] -- no table rows at all:
+//       |q + r - (q.n) n|^2 = |q|^2 + 2 q.r + |r|^2 - 2 s (s + r.n) + s^2 |n|^2,   q = u - v, s = q.n = u.n - v.n,
+//     and q.r = 4 beta (LU - LV)/2... precisely r = Ar_p = 2 beta Alog_p (a power of two: exact), so u.r - v.r = 2 beta (LU_p - LV_p)
+//     comes from the logits the gate has already read.  One table-free pass over d (25 LDS reads and 8 VALU instructions per
+//     16-byte chunk instead of 125 reads -- 75 of them rows picked per lane, colliding in the banks -- and 24 instructions).
+struct HardStage {
+  float4* cand; float* lv; float4 *tabA, *tabC; float* vn; float* cst;
+};
+template <bool L1>
+__host__ __device__ inline size_t hard_stage_floats(int nch4, int P, int dp4) {
+  return (size_t)nch4 * CT * 4 + (size_t)P * CT + (L1 ? (size_t)2 * P * dp4 * 4 : (size_t)P * CT + 128);
+}
+template <bool L1>
+KTUP_DEV HardStage hard_stage_carve(char* smem, int nch4, int P, int dp4) {
+  HardStage h{};
+  h.cand = reinterpret_cast<float4*>(smem);
+  h.lv = reinterpret_cast<float*>(h.cand + nch4 * CT);
+  if (L1) { h.tabA = reinterpret_cast<float4*>(h.lv + P * CT); h.tabC = h.tabA + P * dp4; }
+  else { h.vn = h.lv + P * CT; h.cst = h.vn + P * CT; }
+  return h;
+}
+// what does not change with the candidate tile
+template <bool L1>
+KTUP_DEV void hard_stage_tables(const HardArgs& a, const HardStage& h, int t, int nt) {
+  const int dp4 = a.dp / 4;
+  if (L1) {
+    const float4* Ar = reinterpret_cast<const float4*>(a.ws + (size_t)a.ppad * a.dp);
+    for (int idx = t; idx < 2 * a.P * dp4; idx += nt) h.tabA[idx] = Ar[idx];  // Ar then Cn are adjacent in ws
+  } else {
+    for (int idx = t; idx < 128; idx += nt) h.cst[idx] = a.consts[idx];
+  }
+}
+template <bool L1>
+KTUP_DEV void hard_stage_tile(const HardArgs& a, const HardStage& h, int64_t j0, int t, int nt) {
+  const int nch4 = a.d / 4;
+  for (int idx = t; idx < nch4 * CT; idx += nt) {
+    const int j = idx & (CT - 1), c = idx >> 6;
+    h.cand[c * CT + j] = reinterpret_cast<const float4*>(a.V + min(j0 + j, a.n_cand - 1) * a.d)[c];
+  }
+  for (int idx = t; idx < a.P * CT; idx += nt) {
+    const int j = idx & (CT - 1), p = idx >> 6;
+    const int64_t row = min(j0 + j, a.n_cand - 1);
+    h.lv[p * CT + j] = a.LV[row * a.P + p];
+    if (!L1) h.vn[p * CT + j] = a.VN[row * a.P + p];
+  }
+}
+// the score of (user b, this lane's candidate) under the gate's choice ps
+// the user's logits (and normal products): a wave-uniform row of P floats, lane p holds entry p -- one vector load per user; the gate
+// reads entry p through v_readlane (a load inside its loop is a round trip per preference: the waves then wait on memory 57 % of
+// the time), the score picks the chosen entry across lanes
+struct UserRow { float ql, qn; };
+template <bool L1>
+KTUP_DEV UserRow hard_user_row(const HardArgs& a, int64_t b, int lane) {
+  const int pl = lane < a.P ? lane : a.P - 1;
+  UserRow u;
+  u.ql = a.QL[b * a.P + pl];
+  u.qn = L1 ? 0.f : a.QN[b * a.P + pl];
+  return u;
+}
+KTUP_DEV float lane_entry(float v, int p) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), p)); }
+
+template <bool L1>
+KTUP_DEV float hard_pair_score(const HardArgs& a, const HardStage& h, sptr4 QW, int64_t b, const UserRow& ur, int ps, int lane) {
+  const int nch4 = a.d / 4, dp4 = a.dp / 4;
+  const sptr4 ub = QW + (b * 3 + 1) * nch4;   // slot 1 = u_b; one scalar base, the chunk index is the only offset
+  if (L1) {
+    const float4* cn = h.tabC + ps * dp4;
+    const float4* ar = h.tabA + ps * dp4;
+    float s = 0.f;
+    for (uint32_t c = 0; c < (uint32_t)nch4; ++c) s += dot4(sldp(ub + c) - h.cand[c * CT + lane], cn[c]);
+    float acc = 0.f;
+    for (uint32_t c = 0; c < (uint32_t)nch4; ++c) {
+      const float4 q = sldp(ub + c) - h.cand[c * CT + lane];
+      acc += dist4(fma4(-s, cn[c], q + ar[c]), true);
+    }
+    return acc;
+  }
+  const float qls = __shfl(ur.ql, ps, 64), qns = __shfl(ur.qn, ps, 64);
+  float qq = 0.f;
+  for (uint32_t c = 0; c < (uint32_t)nch4; ++c) {
+    const float4 q = sldp(ub + c) - h.cand[c * CT + lane];
+    qq += dot4(q, q);
+  }
+  const float s = qns - h.vn[ps * CT + lane];
+  const float lin = fmaf(h.cst[96], qls - h.lv[ps * CT + lane], h.cst[ps]);          // 2 q.r + |r|^2
+  return fmaf(s, fmaf(s, h.cst[64 + ps], -2.f * h.cst[32 + ps]), qq + lin);           // + s (s (|n|^2 - 2) - 2 r.n)
+}
+
 template <bool L1>
 __global__ __launch_bounds__(HARD_NT) void pairs_hard_kernel(HardArgs a) {
   KTUP_RESOLVE_GUMBEL(a);
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int nch4 = a.d / 4, dp4 = a.dp / 4;
-  float4* cand = reinterpret_cast<float4*>(smem);              // [nch4][CT]
-  float4* tabA = cand + nch4 * CT;                              // [P][dp4]
-  float4* tabC = tabA + a.P * dp4;                              // [P][dp4]
-  float* lv = reinterpret_cast<float*>(tabC + a.P * dp4);      // [P][CT]
+  const HardStage h = hard_stage_carve<L1>(smem, a.d / 4, a.P, a.dp / 4);
   const int t = threadIdx.x, lane = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
   const int64_t j0 = (int64_t)blockIdx.x * CT;
   const int64_t gj = min(j0 + lane, a.n_cand - 1);
-  for (int idx = t; idx < nch4 * CT; idx += HARD_NT) {
-    const int j = idx & (CT - 1), c = idx >> 6;
-    cand[c * CT + j] = reinterpret_cast<const float4*>(a.V + min(j0 + j, a.n_cand - 1) * a.d)[c];
-  }
-  {
-    const float4* Ar = reinterpret_cast<const float4*>(a.ws + (size_t)a.ppad * a.dp);
-    for (int idx = t; idx < 2 * a.P * dp4; idx += HARD_NT) tabA[idx] = Ar[idx];  // Ar then Cn are adjacent in ws
-    for (int idx = t; idx < a.P * CT; idx += HARD_NT) {
-      const int j = idx & (CT - 1), p = idx >> 6;
-      lv[p * CT + j] = a.LV[min(j0 + j, a.n_cand - 1) * a.P + p];
-    }
-  }
+  hard_stage_tables<L1>(a, h, t, HARD_NT);
+  hard_stage_tile<L1>(a, h, j0, t, HARD_NT);
   __syncthreads();
   const sptr4 QW = as_scalar(a.QW);
-  constexpr bool l1 = L1;
   const int64_t per = (a.nq + gridDim.y - 1) / gridDim.y;
   const int64_t qlo = (int64_t)blockIdx.y * per, qhi = min(a.nq, qlo + per);
   for (int64_t b = qlo + w; b < qhi; b += HARD_NT / 64) {
-    const float* ql = a.QL + b * a.P;  // wave-uniform -> scalar loads
+    const UserRow ur = hard_user_row<L1>(a, b, lane);
     const uint64_t base = ((uint64_t)b * (uint64_t)a.n_cand + (uint64_t)gj) * (uint64_t)a.P;
     const int ps = gate_argmax(a.P, base, a.gumbel == KTUP_GUMBEL_INPUT, a.uniform, a.seed, a.offset,
-                               [&](int p) { return ql[p] + lv[p * CT + lane]; });
-    const sptr4 ub = QW + (b * 3 + 1) * nch4;   // slot 1 = u_b; one scalar base, the chunk index is the only offset
-    const float4* cn = tabC + ps * dp4;
-    const float4* ar = tabA + ps * dp4;
-    float s = 0.f;
-    for (uint32_t c = 0; c < (uint32_t)nch4; ++c) s += dot4(sldp(ub + c) - cand[c * CT + lane], cn[c]);
-    float acc = 0.f;
-    for (uint32_t c = 0; c < (uint32_t)nch4; ++c) {
-      const float4 q = sldp(ub + c) - cand[c * CT + lane];
-      acc += dist4(fma4(-s, cn[c], q + ar[c]), l1);
-    }
+                               [&](int p) { return lane_entry(ur.ql, p) + h.lv[p * CT + lane]; });
+    const float acc = hard_pair_score<L1>(a, h, QW, b, ur, ps, lane);
     if (j0 + lane < a.n_cand) a.out[b * a.ldo + j0 + lane] = acc;
   }
 }
@@ -337,23 +416,20 @@ struct SweepHardArgs {
 
 __host__ __device__ inline size_t sweep_wave_bytes(int bm_words, int topn) { return (size_t)SW_UW * topn * 8 + (size_t)SW_UW * 8 + (size_t)SW_UW * 4 + (size_t)SW_UW * bm_words * 4 + 4; }
 
-template <bool L1, int MAXP>
+template <bool L1>
 __global__ __launch_bounds__(SW_NW * 64) void sweep_hard_kernel(SweepHardArgs sa) {
   HardArgs a = sa.h;
   KTUP_RESOLVE_GUMBEL(a);
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int nch4 = a.d / 4, dp4 = a.dp / 4;
-  float4* cand = reinterpret_cast<float4*>(smem);              // [nch4][CT]
-  float4* tabA = cand + nch4 * CT;                              // [P][dp4]
-  float4* tabC = tabA + a.P * dp4;                              // [P][dp4]
+  const HardStage h = hard_stage_carve<L1>(smem, a.d / 4, a.P, a.dp / 4);
   const int t = threadIdx.x, lane = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
   const int topn = sa.topn;
-  char* wb = reinterpret_cast<char*>(tabC + a.P * dp4) + (size_t)w * ((sweep_wave_bytes(sa.bm_words, topn) + 7) & ~(size_t)7);
+  char* wb = smem + hard_stage_floats<L1>(a.d / 4, a.P, a.dp / 4) * 4 + (size_t)w * ((sweep_wave_bytes(sa.bm_words, topn) + 7) & ~(size_t)7);
   uint64_t* tk = reinterpret_cast<uint64_t*>(wb);               // [users][topn] sorted lists
   uint64_t* thrk = tk + SW_UW * topn;                           // [users] n-th keys
-  float* thrf = reinterpret_cast<float*>(thrk + SW_UW);         // [16] n-th scores (NaN while a list is short)
-  uint32_t* bm = reinterpret_cast<uint32_t*>(thrf + SW_UW);     // [16][bm_words] filter bits of this split
+  float* thrf = reinterpret_cast<float*>(thrk + SW_UW);         // [users] n-th scores (NaN while a list is short)
+  uint32_t* bm = reinterpret_cast<uint32_t*>(thrf + SW_UW);     // [users][bm_words] filter bits of this split
   const int64_t u0 = (int64_t)blockIdx.x * (SW_NW * SW_UW) + SW_UW * w;
   const int64_t i_lo = (int64_t)blockIdx.y * sa.split_items;
   const int64_t i_hi = min(a.n_cand, i_lo + sa.split_items);
@@ -389,43 +465,24 @@ __global__ __launch_bounds__(SW_NW * 64) void sweep_hard_kernel(SweepHardArgs sa
       }
     }
   }
-  {
-    const float4* Ar = reinterpret_cast<const float4*>(a.ws + (size_t)a.ppad * a.dp);
-    for (int idx = t; idx < 2 * a.P * dp4; idx += SW_NW * 64) tabA[idx] = Ar[idx];  // Ar then Cn are adjacent in ws
-  }
+  hard_stage_tables<L1>(a, h, t, SW_NW * 64);
   const sptr4 QW = as_scalar(a.QW);
-  constexpr bool l1 = L1;
   for (int64_t j0 = i_lo; j0 < i_hi; j0 += CT) {
     __syncthreads();                                                    // the previous stage has been consumed
-    for (int idx = t; idx < nch4 * CT; idx += SW_NW * 64) {
-      const int j = idx & (CT - 1), c = idx >> 6;
-      cand[c * CT + j] = reinterpret_cast<const float4*>(a.V + min(j0 + j, a.n_cand - 1) * a.d)[c];
-    }
+    hard_stage_tile<L1>(a, h, j0, t, SW_NW * 64);
     __syncthreads();
     const int64_t item = j0 + lane;
     const int64_t gj = min(item, a.n_cand - 1);
-    float lvr[MAXP];                                                    // this lane's item logits: registers for the stage's users
-#pragma unroll
-    for (int p = 0; p < MAXP; ++p) lvr[p] = p < a.P ? a.LV[gj * a.P + p] : 0.f;
     const bool iok = item < i_hi;
     const int64_t lid = item - i_lo;
     for (int r = 0; r < SW_UW; ++r) {
       const int64_t b = u0 + r;
       if (b >= a.nq) break;
-      const float* ql = a.QL + b * a.P;  // wave-uniform -> scalar loads
+      const UserRow ur = hard_user_row<L1>(a, b, lane);
       const uint64_t base = ((uint64_t)b * (uint64_t)a.n_cand + (uint64_t)gj) * (uint64_t)a.P;
-      const int ps = gate_argmax<MAXP>(a.P, base, a.gumbel == KTUP_GUMBEL_INPUT, a.uniform, a.seed, a.offset,
-                                       [&](int p) { return ql[p] + lvr[p]; });
-      const sptr4 ub = QW + (b * 3 + 1) * nch4;   // slot 1 = u_b
-      const float4* cn = tabC + ps * dp4;
-      const float4* ar = tabA + ps * dp4;
-      float s = 0.f;
-      for (uint32_t c = 0; c < (uint32_t)nch4; ++c) s += dot4(sldp(ub + c) - cand[c * CT + lane], cn[c]);
-      float acc = 0.f;
-      for (uint32_t c = 0; c < (uint32_t)nch4; ++c) {
-        const float4 q = sldp(ub + c) - cand[c * CT + lane];
-        acc += dist4(fma4(-s, cn[c], q + ar[c]), l1);
-      }
+      const int ps = gate_argmax(a.P, base, a.gumbel == KTUP_GUMBEL_INPUT, a.uniform, a.seed, a.offset,
+                                 [&](int p) { return lane_entry(ur.ql, p) + h.lv[p * CT + lane]; });
+      const float acc = hard_pair_score<L1>(a, h, QW, b, ur, ps, lane);
       // ---- ranking: acc against user r's n-th score
       const float tf = thrf[r];
       bool c = acc < tf;
@@ -651,6 +708,9 @@ int launch_pairs(const PairsArgs& a, hipStream_t st, const char* name, int nrel 
 
 inline int round4(int d) { return (d + 3) / 4 * 4; }
 inline size_t pad4(size_t x) { return (x + 3) & ~(size_t)3; }
+// the evaluation workspaces of the preference models: items CW0 | CW1 | CW2 [N][d] | CL | CN [N][P] | consts [4][32]; users QW [nq][3][d] | QL | QN [nq][P]
+inline size_t item_side_floats(int64_t n_items, int d, int P) { return (size_t)n_items * 3 * d + 2 * pad4((size_t)n_items * P) + 128; }
+inline size_t user_side_floats(int64_t nq, int d, int P) { return (size_t)nq * 3 * d + 2 * pad4((size_t)nq * P); }
 
 int kg_eval(int model, const char* name, const float* E, int64_t lde, const float* R, int64_t ldr, const float* X, int64_t ldx,
             int d, const float* C, int64_t ldc, int64_t n_cand, const int64_t* q, const int64_t* r, int64_t nq, int l1, int head,
@@ -690,8 +750,8 @@ int ktup::kg_query_prep(int model, const float* E, int64_t lde, const float* R, 
 extern "C" size_t ktup_eval_kg_workspace_bytes(int d, int64_t nq) { return (size_t)nq * 3 * round4(d) * sizeof(float); }
 
 extern "C" size_t ktup_eval_pref_workspace_bytes(int d, int n_pref, int64_t nq, int64_t n_items) {
-  // QW[nq][3][d] | QL[nq][P] (padded to 16 B) | CW0, CW1, CW2 [N][d] | CL[N][P]
-  return ((size_t)nq * 3 * d + pad4((size_t)nq * n_pref) + (size_t)n_items * 3 * d + pad4((size_t)n_items * n_pref)) * sizeof(float);
+  // QW[nq][3][d] | QL[nq][P] | QN[nq][P] (padded to 16 B) | the item side (item_side)
+  return (user_side_floats(nq, d, n_pref) + (n_items > 0 ? item_side_floats(n_items, d, n_pref) : 0)) * sizeof(float);
 }
 
 extern "C" int ktup_eval_bprmf_scores(const float* U, int64_t ldu, const float* I, int64_t ldi, int d, const int64_t* u_ids,
@@ -845,13 +905,33 @@ extern "C" int ktup_eval_transr_scores(const float* E, int64_t lde, const float*
 // ROW of I (the caller passes the evaluateRec pairing, jTransUP.py:174); `uniform` is (nq x n_items x n_pref).
 namespace {
 
-struct ItemSide { float *CW0, *CW1, *CW2, *CL; };
+struct ItemSide { float *CW0, *CW1, *CW2, *CL, *CN, *consts; };
 
-// items_ws layout: CW0 | CW1 | CW2 [N][d] | CL [N][P]  (v - RV, v, NV, item logits)
-ItemSide item_side(float* base, int64_t n_items, int d) {
+// items_ws layout: CW0 | CW1 | CW2 [N][d] | CL [N][P] | CN [N][P] | consts [4][32]
+// (v - RV, v, NV, item logits, v . Cn_p, and the hard gate's per-preference constants |Ar_p|^2, Ar_p . Cn_p, |Cn_p|^2 - 2, {4 beta})
+ItemSide item_side(float* base, int64_t n_items, int d, int P) {
   ItemSide s;
   s.CW0 = base; s.CW1 = s.CW0 + (size_t)n_items * d; s.CW2 = s.CW1 + (size_t)n_items * d; s.CL = s.CW2 + (size_t)n_items * d;
+  s.CN = s.CL + pad4((size_t)n_items * P); s.consts = s.CN + pad4((size_t)n_items * P);
   return s;
+}
+
+// |Ar_p|^2, Ar_p . Cn_p, |Cn_p|^2 - 2 of the prepared tables, and 4 beta (beta = 1/2 with an entity side: ktup_pref_prepare)
+__global__ __launch_bounds__(256) void pref_consts_kernel(const float* __restrict__ ws, int ppad, int dp, int P, int d, float beta4,
+                                                          float* __restrict__ consts) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const float* Ar = ws + (size_t)ppad * dp;
+  const float* Cn = ws + (size_t)(ppad + P) * dp;
+  for (int p = w; p < 32; p += 4) {
+    float rr = 0.f, rn = 0.f, nn = 0.f;
+    if (p < P)
+      for (int k = lane; k < d; k += 64) {
+        const float r = Ar[(size_t)p * dp + k], n = Cn[(size_t)p * dp + k];
+        rr = fmaf(r, r, rr); rn = fmaf(r, n, rn); nn = fmaf(n, n, nn);
+      }
+    rr = wave_sum(rr); rn = wave_sum(rn); nn = wave_sum(nn);
+    if (lane == 0) { consts[p] = rr; consts[32 + p] = rn; consts[64 + p] = nn - 2.f; consts[96 + p] = beta4; }
+  }
 }
 
 int pref_items_project(const char* name, const float* I, int64_t ldi, const float* E, int64_t lde, const int32_t* item2ent,
@@ -863,7 +943,8 @@ int pref_items_project(const char* name, const float* I, int64_t ldi, const floa
   KTUP_REQUIRE(aligned16(I) && aligned16(E) && aligned16(pref_ws) && aligned16(it.CW0) && ldi % 4 == 0 && (!E || lde % 4 == 0),
                "%s: tables must be 16-byte aligned with pitches %% 4 == 0", name);
   hipLaunchKernelGGL(pref_project_kernel, dim3(grid_for((n_items + 3) / 4)), dim3(256), 0, st, I, ldi, E, lde, item2ent,
-                     (const int64_t*)nullptr, n_items, d, n_pref, pref_ws, g.ppad, g.dp, -1.0f, (int64_t)d, it.CW0, it.CW1, it.CW2, it.CL);
+                     (const int64_t*)nullptr, n_items, d, n_pref, pref_ws, g.ppad, g.dp, -1.0f, (int64_t)d, it.CW0, it.CW1, it.CW2, it.CL, it.CN);
+  hipLaunchKernelGGL(pref_consts_kernel, dim3(1), dim3(256), 0, st, pref_ws, g.ppad, g.dp, n_pref < 32 ? n_pref : 32, d, E ? 2.0f : 4.0f, it.consts);
   return check_launch(name);
 }
 
@@ -880,11 +961,13 @@ int pref_scores_tail(const char* name, const float* U, int64_t ldu, const float*
                "%s: KTUP_GUMBEL_INPUT / KTUP_GUMBEL_PHILOX_DEV need the `uniform` pointer", name);
   float* QW = ws;
   float* QL = QW + (size_t)nq * 3 * d;
+  float* QN = QL + pad4((size_t)nq * n_pref);
+  const bool hard_l2 = gumbel_mode != KTUP_GUMBEL_OFF && !l1 && n_pref <= 32;      // the only reader of QN / CN / consts
   float *CW0 = it.CW0, *CW1 = it.CW1, *CW2 = it.CW2, *CL = it.CL;
   // users: slot 0 = u + RU, slot 1 = u, slot 2 = NU, rows of pitch 3d;   items: v - RV, v, NV, rows of pitch d
   hipLaunchKernelGGL(pref_project_kernel, dim3(grid_for((nq + 3) / 4)), dim3(256), 0, st, U, ldu, (const float*)nullptr,
                      (int64_t)0, (const int32_t*)nullptr, u_ids, nq, d, n_pref, pref_ws, g.ppad, g.dp, 1.0f, (int64_t)3 * d, QW,
-                     QW + d, QW + 2 * d, QL);
+                     QW + d, QW + 2 * d, QL, hard_l2 ? QN : (float*)nullptr);
   if (int e = check_launch(name)) return e;
   if (gumbel_mode == KTUP_GUMBEL_OFF) {
     if (!l1) {     // squared L2: six (users x items) GEMMs on the matrix cores (ktup_eval_mc.hip); option eval_mc = 0 for A/B runs
@@ -901,8 +984,9 @@ int pref_scores_tail(const char* name, const float* U, int64_t ldu, const float*
   HardArgs h{};
   h.V = CW1; h.LV = CL; h.QW = QW; h.QL = QL; h.ws = pref_ws; h.ppad = g.ppad; h.dp = g.dp; h.P = n_pref; h.d = d;
   h.n_cand = n_items; h.nq = nq; h.l1 = l1; h.gumbel = gumbel_mode; h.uniform = uniform; h.seed = seed; h.offset = offset;
-  h.out = out; h.ldo = ldo;
-  const size_t lds = (size_t)(d / 4) * CT * 16 + (size_t)2 * n_pref * g.dp * 4 + (size_t)n_pref * CT * 4;
+  h.out = out; h.ldo = ldo; h.QN = QN; h.VN = it.CN; h.consts = it.consts;
+  KTUP_REQUIRE(l1 || n_pref <= 32, "%s: the hard gate's squared-L2 score covers at most 32 preferences", name);
+  const size_t lds = (l1 ? hard_stage_floats<true>(d / 4, n_pref, g.dp / 4) : hard_stage_floats<false>(d / 4, n_pref, g.dp / 4)) * 4;
   if (lds > 160 * 1024) return set_error(KTUP_ERR_UNSUPPORTED, "%s: hard-gate tile needs %zu B of LDS", name, lds);
   const int64_t tiles = (n_items + CT - 1) / CT;
   int64_t ysplit = (768 + tiles - 1) / tiles;    // ~ the resident workgroups (3 per CU): each stages 47 KB, so not many more
@@ -924,7 +1008,7 @@ int pref_scores_tail(const char* name, const float* U, int64_t ldu, const float*
 }  // namespace
 
 extern "C" size_t ktup_eval_pref_items_workspace_bytes(int d, int n_pref, int64_t n_items) {
-  return ((size_t)n_items * 3 * d + pad4((size_t)n_items * n_pref)) * sizeof(float);
+  return item_side_floats(n_items, d, n_pref) * sizeof(float);
 }
 
 extern "C" int ktup_eval_pref_items_prepare(const float* I, int64_t ldi, const float* E, int64_t lde, const int32_t* item2ent,
@@ -932,7 +1016,7 @@ extern "C" int ktup_eval_pref_items_prepare(const float* I, int64_t ldi, const f
   const char* name = "ktup_eval_pref_items_prepare";
   KTUP_REQUIRE(n_items >= 0, "%s: bad sizes", name);
   if (n_items == 0) return KTUP_OK;
-  return pref_items_project(name, I, ldi, E, lde, item2ent, pref_ws, n_pref, d, n_items, item_side(items_ws, n_items, d), (hipStream_t)stream);
+  return pref_items_project(name, I, ldi, E, lde, item2ent, pref_ws, n_pref, d, n_items, item_side(items_ws, n_items, d, n_pref), (hipStream_t)stream);
 }
 
 extern "C" int ktup_eval_pref_scores_prepared(const float* U, int64_t ldu, const float* pref_ws, int n_pref, int d,
@@ -944,7 +1028,7 @@ extern "C" int ktup_eval_pref_scores_prepared(const float* U, int64_t ldu, const
   if (nq == 0 || n_items == 0) return KTUP_OK;
   KTUP_REQUIRE(items_ws && aligned16(items_ws), "%s: item-side workspace missing or unaligned", name);
   return pref_scores_tail(name, U, ldu, pref_ws, n_pref, d, u_ids, nq, n_items, l1, gumbel_mode, uniform, seed, offset, out, ldo,
-                          item_side(const_cast<float*>(items_ws), n_items, d), ws, (hipStream_t)stream);
+                          item_side(const_cast<float*>(items_ws), n_items, d, n_pref), ws, (hipStream_t)stream);
 }
 
 // K16 + K17 for a whole evaluation pass in one sweep (ktup_eval_pass.hip): operand rows in preference space, then the fused score +
@@ -982,7 +1066,7 @@ extern "C" int ktup_eval_pref_scores(const float* U, int64_t ldu, const float* I
   if (nq == 0 || n_items == 0) return KTUP_OK;
   KTUP_REQUIRE(ws && aligned16(ws), "%s: bad argument", name);
   // QW[nq][3][d] | QL[nq][P] (padded to 16 B) | the item side
-  const ItemSide it = item_side(ws + (size_t)nq * 3 * d + pad4((size_t)nq * n_pref), n_items, d);
+  const ItemSide it = item_side(ws + user_side_floats(nq, d, n_pref), n_items, d, n_pref);
   if (int e = pref_items_project(name, I, ldi, E, lde, item2ent, pref_ws, n_pref, d, n_items, it, (hipStream_t)stream)) return e;
   return pref_scores_tail(name, U, ldu, pref_ws, n_pref, d, u_ids, nq, n_items, l1, gumbel_mode, uniform, seed, offset, out, ldo, it,
                           ws, (hipStream_t)stream);
@@ -992,8 +1076,7 @@ extern "C" int ktup_eval_pref_scores(const float* U, int64_t ldu, const float* I
 // ---- the hard gate's whole pass (see sweep_hard_kernel)
 extern "C" size_t ktup_eval_pref_topk_hard_workspace_bytes(int d, int n_pref, int64_t nq, int64_t n_items, int topn) {
   if (d <= 0 || n_pref <= 0 || nq < 0 || n_items < 0 || topn <= 0) return 0;
-  return ktup_eval_pref_items_workspace_bytes(d, n_pref, n_items) + ((size_t)nq * 3 * d + pad4((size_t)nq * n_pref)) * sizeof(float) +
-         (size_t)nq * 8 * topn * sizeof(uint64_t) + 64;
+  return (item_side_floats(n_items, d, n_pref) + user_side_floats(nq, d, n_pref)) * sizeof(float) + (size_t)nq * 8 * topn * sizeof(uint64_t) + 64;
 }
 
 extern "C" int ktup_eval_pref_topk_hard(const float* U, int64_t ldu, const float* I, int64_t ldi, const float* E, int64_t lde,
@@ -1014,20 +1097,22 @@ extern "C" int ktup_eval_pref_topk_hard(const float* U, int64_t ldu, const float
   if (!g.ok) return set_error(KTUP_ERR_UNSUPPORTED, "%s: embedding_size must be a multiple of 4 in [4, 256] (got %d)", name, d);
   hipStream_t st = (hipStream_t)stream;
   float* items_ws = ws;
-  const ItemSide it = item_side(items_ws, n_items, d);
+  const ItemSide it = item_side(items_ws, n_items, d, n_pref);
   if (int e = pref_items_project(name, I, ldi, E, lde, item2ent, pref_ws, n_pref, d, n_items, it, st)) return e;
-  float* QW = items_ws + ktup_eval_pref_items_workspace_bytes(d, n_pref, n_items) / sizeof(float);
+  float* QW = items_ws + item_side_floats(n_items, d, n_pref);
   float* QL = QW + (size_t)nq * 3 * d;
-  uint64_t* part = reinterpret_cast<uint64_t*>((reinterpret_cast<uintptr_t>(QL + pad4((size_t)nq * n_pref)) + 15) & ~(uintptr_t)15);
+  float* QN = QL + pad4((size_t)nq * n_pref);
+  uint64_t* part = reinterpret_cast<uint64_t*>((reinterpret_cast<uintptr_t>(QN + pad4((size_t)nq * n_pref)) + 15) & ~(uintptr_t)15);
   KTUP_REQUIRE(aligned16(U) && aligned16(pref_ws) && ldu % 4 == 0, "%s: tables must be 16-byte aligned with pitches %% 4 == 0", name);
   hipLaunchKernelGGL(pref_project_kernel, dim3(grid_for((nq + 3) / 4)), dim3(256), 0, st, U, ldu, (const float*)nullptr,
                      (int64_t)0, (const int32_t*)nullptr, u_ids, nq, d, n_pref, pref_ws, g.ppad, g.dp, 1.0f, (int64_t)3 * d, QW,
-                     QW + d, QW + 2 * d, QL);
+                     QW + d, QW + 2 * d, QL, l1 ? (float*)nullptr : QN);
   if (int e = check_launch(name)) return e;
   SweepHardArgs sa{};
   HardArgs& h = sa.h;
   h.V = it.CW1; h.LV = it.CL; h.QW = QW; h.QL = QL; h.ws = pref_ws; h.ppad = g.ppad; h.dp = g.dp; h.P = n_pref; h.d = d;
   h.n_cand = n_items; h.nq = nq; h.l1 = l1; h.gumbel = gumbel_mode; h.uniform = uniform; h.seed = seed; h.offset = offset;
+  h.QN = QN; h.VN = it.CN; h.consts = it.consts;
   sa.filt_off = filt_off; sa.filt_ids = filt_ids; sa.topn = topn; sa.part = part;
   const int64_t ublocks = (nq + SW_NW * SW_UW - 1) / (SW_NW * SW_UW);
   int nsplit = (int)(768 / ublocks);                     // three workgroups per CU are resident (LDS): one round
@@ -1039,7 +1124,8 @@ extern "C" int ktup_eval_pref_topk_hard(const float* U, int64_t ldu, const float
   nsplit = (int)((n_items + sa.split_items - 1) / sa.split_items);
   sa.nsplit = nsplit;
   sa.bm_words = (int)((sa.split_items + 31) / 32);
-  const size_t lds = (size_t)(d / 4) * CT * 16 + (size_t)2 * n_pref * g.dp * 4 + SW_NW * ((sweep_wave_bytes(sa.bm_words, topn) + 7) & ~(size_t)7);
+  const size_t lds = (l1 ? hard_stage_floats<true>(d / 4, n_pref, g.dp / 4) : hard_stage_floats<false>(d / 4, n_pref, g.dp / 4)) * 4 +
+                     SW_NW * ((sweep_wave_bytes(sa.bm_words, topn) + 7) & ~(size_t)7);
   if (lds > 160 * 1024 || ublocks > 0x7fffffffll)
     return set_error(KTUP_ERR_UNSUPPORTED, "%s: the stage needs %zu B of LDS (per-batch calls remain)", name, lds);
   const dim3 grid((unsigned)ublocks, (unsigned)nsplit);
@@ -1047,8 +1133,7 @@ extern "C" int ktup_eval_pref_topk_hard(const float* U, int64_t ldu, const float
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, grid, dim3(SW_NW * 64), lds, st, sa);
   };
-  if (n_pref <= 20) { if (l1) launch(sweep_hard_kernel<true, 20>); else launch(sweep_hard_kernel<false, 20>); }
-  else { if (l1) launch(sweep_hard_kernel<true, 32>); else launch(sweep_hard_kernel<false, 32>); }
+  if (l1) launch(sweep_hard_kernel<true>); else launch(sweep_hard_kernel<false>);
   if (int e = check_launch(name)) return e;
   return ktup::launch_topk_merge(part, nq, nsplit, topn, top_ids, top_scores, st, name);
 }

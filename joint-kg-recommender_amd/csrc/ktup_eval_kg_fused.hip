@@ -71,6 +71,7 @@ struct FArgs {
   int32_t* counts; int32_t* ranks;
   int tiles_per_band;
   int gbase;                    // the sweep launch counts for golds gbase .. gbase + GS - 1 of every key
+  int dbg;                      // MEASUREMENT ONLY (option dbg_eval): 1 no compares, 2 no candidate loads, 4 no barrier per stage
   float* cnorm;                 // |e|^2 of every candidate, computed ONCE per pass (kg_pass_init_kernel) and read by both kernels
   const int64_t* rel;           // mode 2: the keys' relation ids, the normals' table and w.e of every (relation, candidate)
   const float* Nrm; int64_t ldn; int n_rel;
@@ -359,25 +360,40 @@ __global__ __launch_bounds__(NW * 64) void kg_count_mc_kernel(FArgs a) {
   constexpr int NLD = (IB * NCH + NW * 64 - 1) / (NW * 64);
   v4 nx[NLD];
   float en_nx = 0.f, we_nx[4] = {0.f, 0.f, 0.f, 0.f};
-  auto fetch = [&](int t) {
-    const int64_t i0 = (int64_t)t * IB;
+  // BUFFER loads: a per-thread byte offset fixed for the whole sweep + the stage's offset (one 32-bit add per load), bounds checked by
+  // the descriptor (rows past the band's end and stages past the sweep's read as zeros) -- no 64-bit address arithmetic or range tests
+  // per stage (they were ~47 of the ~130 VALU instructions a wave issued per stage beside its 25 MFMAs)
+  const int64_t band_row0 = (int64_t)t0 * IB;
+  const int64_t band_rows = max((int64_t)0, min((int64_t)a.tiles_per_band * IB, a.n_cand - band_row0));
+  const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.C + band_row0 * a.ldc), 0,
+                                                                         (int)(band_rows * a.ldc * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsN = __builtin_amdgcn_make_buffer_rsrc(a.cnorm + band_row0, 0, (int)(band_rows * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(G::WTAB ? a.wtab : a.cnorm, 0, G::WTAB ? (int)((int64_t)a.n_rel * a.ldw * 4) : 0,
+                                                                         0x00020000);
+  int voC[NLD];
 #pragma unroll
-    for (int k = 0; k < NLD; ++k) {
-      const int idx = tid + k * NW * 64;
-      const int row = idx / NCH, c = idx - row * NCH;
-      nx[k] = (v4){0.f, 0.f, 0.f, 0.f};
-      if (idx < IB * NCH && t < t1 && i0 + row < a.n_cand) nx[k] = *reinterpret_cast<const v4*>(a.C + (i0 + row) * a.ldc + 4 * c);
-    }
-    const int64_t cand = i0 + 16 * it + j;
-    if (t < t1 && cand < a.n_cand) {
-      en_nx = a.cnorm[cand];
-      if constexpr (G::WTAB) {
+  for (int k = 0; k < NLD; ++k) {
+    const int idx = tid + k * NW * 64;
+    const int row = idx / NCH, c = idx - row * NCH;
+    voC[k] = idx < IB * NCH ? (int)((row * a.ldc + 4 * c) * 4) : -16;             // (as unsigned: out of range for every stage -> zeros)
+  }
+  const int voN = (16 * it + j) * 4;
+  int voW[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) we_nx[r] = a.wtab[wo[r] + cand];
-      }
+  for (int r = 0; r < 4; ++r) voW[r] = (wo[r] + (int)band_row0 + 16 * it + j) * 4;
+  const int stepC = (int)(IB * a.ldc * 4);
+  auto fetch = [&](int s) {                                     // s = stage index inside the band (uniform)
+    const int soC = s * stepC, soN = s * IB * 4;
+#pragma unroll
+    for (int k = 0; k < NLD; ++k)
+      nx[k] = __builtin_bit_cast(v4, __builtin_amdgcn_raw_buffer_load_b128(rsC, voC[k] < 0 ? voC[k] : voC[k] + soC, 0, 0));
+    en_nx = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsN, voN + soN, 0, 0));
+    if constexpr (G::WTAB) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) we_nx[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsW, voW[r] + soN, 0, 0));
     }
   };
-  fetch(t0);
+  fetch(0);
   for (int t = t0; t < t1; ++t) {
     const int64_t i0 = (int64_t)t * IB;
     if (i0 >= a.n_cand) break;
@@ -391,8 +407,8 @@ __global__ __launch_bounds__(NW * 64) void kg_count_mc_kernel(FArgs a) {
     float wl[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) wl[r] = we_nx[r];
-    fetch(t + 1);
-    __syncthreads();
+    if (!(a.dbg & 2)) fetch(t + 1 - t0);
+    if (!(a.dbg & 4)) __syncthreads();
     const v4* cb = Cs + (16 * it + j) * P4 + kq;
     v4 ce, we;
     if constexpr (G::TRANSH) tile_dots<G>(qa, cb, ce, we);      // two query vectors per key do not fit the registers (measured: spills)
@@ -401,6 +417,7 @@ __global__ __launch_bounds__(NW * 64) void kg_count_mc_kernel(FArgs a) {
       we = (v4){wl[0], wl[1], wl[2], wl[3]};
     }
     const int64_t cand = i0 + 16 * it + j;
+    if (a.dbg & 1) { if (ce[0] + we[1] == 12345.f) cnt[0][0] += 1; continue; }
     if (cand < a.n_cand) {
       float s[4];
       bool tie = false;
@@ -572,6 +589,9 @@ extern "C" int ktup_eval_kg_ranks_fused(int model, const float* E, int64_t lde, 
   KTUP_REQUIRE(E && R && C && q && r && gold_off && gold_ids && ranks && ws && (model == KTUP_KG_TRANSE || Nrm), "%s: null pointer argument", name);
   KTUP_REQUIRE((filt_off == nullptr) || filt_ids, "%s: filter offsets without ids", name);
   KTUP_REQUIRE(aligned16(C) && (ldc & 3) == 0 && n_cand < (1ll << 31) && (nq + UB - 1) / UB <= 65535, "%s: candidate table must be 16-byte aligned (pitch %% 4), sizes in range", name);
+  if (((n_cand + IB * NBAND - 1) / (IB * NBAND) + 1) * IB * ldc * 4 >= (1ll << 31))      // a band is addressed through one 32-bit buffer descriptor
+    return set_error(KTUP_ERR_UNSUPPORTED, "%s: a candidate band of %lld bytes does not fit a buffer descriptor (use ktup_eval_kg_ranks)", name,
+                     (long long)(((n_cand + IB * NBAND - 1) / (IB * NBAND)) * IB * ldc * 4));
   hipStream_t st = (hipStream_t)stream;
   char* p = reinterpret_cast<char*>(ws);
   float* QW = reinterpret_cast<float*>(p); p += pad256(ktup_eval_kg_workspace_bytes(d, nq));
@@ -583,7 +603,7 @@ extern "C" int ktup_eval_kg_ranks_fused(int model, const float* E, int64_t lde, 
   FArgs a{};
   a.QW = QW; a.dq = (d + 3) & ~3; a.C = C; a.ldc = ldc; a.nq = nq; a.n_cand = n_cand; a.descending = descending;
   a.gold_off = gold_off; a.gold_ids = gold_ids; a.gscore = gscore; a.filt_off = filt_off; a.filt_ids = filt_ids; a.fscore = fscore;
-  a.counts = counts; a.ranks = ranks; a.cnorm = cnorm;
+  a.counts = counts; a.ranks = ranks; a.cnorm = cnorm; a.dbg = opt_dbg_eval();
   int rc;
   if (model == KTUP_KG_TRANSE) rc = dispatch_fused<0>(a, d, n_gold, max_golds, st, name);
   else if (wtab_on(model, n_cand, n_rel)) {      // relation ids are bounds-checked by the caller's tables (r indexes R and Nrm already)

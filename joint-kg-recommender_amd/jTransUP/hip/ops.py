@@ -439,7 +439,8 @@ def eval_kg_ranks(E, R, N, q, r, l1, head, descending, gold_off, gold_ids, filt_
         # the pass without the score matrix (ktup_eval_kg_ranks_fused): ranks from counts in the score kernel's epilogue
         mg = _max_golds(gold_off)
         lib = L.load()
-        if lib.ktup_eval_kg_ranks_fused_supported(KG_TRANSE if N is None else KG_TRANSH, E.shape[1], int(l1), mg) and C.stride(0) % 4 == 0:
+        if lib.ktup_eval_kg_ranks_fused_supported(KG_TRANSE if N is None else KG_TRANSH, E.shape[1], int(l1), mg) and C.stride(0) % 4 == 0 \
+                and C.shape[0] * C.stride(0) * 4 < 8 * (2 ** 31 - 2 ** 24):      # (a candidate band goes through one 32-bit buffer descriptor)
             n_filt = 0 if filt_ids is None else filt_ids.numel()
             model, n_rel = (KG_TRANSE, 0) if N is None else (KG_TRANSH, min(R.shape[0], N.shape[0]))
             fws = _scratch(lib.ktup_eval_kg_ranks_fused_workspace_bytes(model, E.shape[1], nq, n_gold, n_filt, C.shape[0], n_rel), dev)

@@ -274,8 +274,9 @@ struct HardArgs {
 constexpr int HARD_NT = 512;   // 8 waves share a candidate tile + tables (47 KB at d = 100, P = 20): 3 workgroups per CU
 
 // The stage both hard-gate kernels score against: 64 candidates' vectors [nch4][CT] and logits [P][CT], then
-//   L1:          the tables Ar, Cn [P][dp4] (the chosen preference's rows are read per lane);
-//   squared L2:  v_j . Cn_p [P][CT] and the per-preference constants [4][32] -- no table rows at all:
+//   MODE 1 (L1) and MODE 2 (squared L2 with more than 32 preferences): the tables Ar, Cn [P][dp4] (the chosen preference's rows are
+//                read per lane), two passes over d;
+//   MODE 0 (squared L2):  v_j . Cn_p [P][CT] and the per-preference constants [4][32] -- no table rows at all:
 //       |q + r - (q.n) n|^2 = |q|^2 + 2 q.r + |r|^2 - 2 s (s + r.n) + s^2 |n|^2,   q = u - v, s = q.n = u.n - v.n,
 //     and q.r = 4 beta (LU - LV)/2... precisely r = Ar_p = 2 beta Alog_p (a power of two: exact), so u.r - v.r = 2 beta (LU_p - LV_p)
 //     comes from the logits the gate has already read.  One table-free pass over d (25 LDS reads and 8 VALU instructions per
@@ -283,31 +284,31 @@ constexpr int HARD_NT = 512;   // 8 waves share a candidate tile + tables (47 KB
 struct HardStage {
   float4* cand; float* lv; float4 *tabA, *tabC; float* vn; float* cst;
 };
-template <bool L1>
+template <int MODE>
 __host__ __device__ inline size_t hard_stage_floats(int nch4, int P, int dp4) {
-  return (size_t)nch4 * CT * 4 + (size_t)P * CT + (L1 ? (size_t)2 * P * dp4 * 4 : (size_t)P * CT + 128);
+  return (size_t)nch4 * CT * 4 + (size_t)P * CT + (MODE != 0 ? (size_t)2 * P * dp4 * 4 : (size_t)P * CT + 128);
 }
-template <bool L1>
+template <int MODE>
 KTUP_DEV HardStage hard_stage_carve(char* smem, int nch4, int P, int dp4) {
   HardStage h{};
   h.cand = reinterpret_cast<float4*>(smem);
   h.lv = reinterpret_cast<float*>(h.cand + nch4 * CT);
-  if (L1) { h.tabA = reinterpret_cast<float4*>(h.lv + P * CT); h.tabC = h.tabA + P * dp4; }
+  if (MODE != 0) { h.tabA = reinterpret_cast<float4*>(h.lv + P * CT); h.tabC = h.tabA + P * dp4; }
   else { h.vn = h.lv + P * CT; h.cst = h.vn + P * CT; }
   return h;
 }
 // what does not change with the candidate tile
-template <bool L1>
+template <int MODE>
 KTUP_DEV void hard_stage_tables(const HardArgs& a, const HardStage& h, int t, int nt) {
   const int dp4 = a.dp / 4;
-  if (L1) {
+  if (MODE != 0) {
     const float4* Ar = reinterpret_cast<const float4*>(a.ws + (size_t)a.ppad * a.dp);
     for (int idx = t; idx < 2 * a.P * dp4; idx += nt) h.tabA[idx] = Ar[idx];  // Ar then Cn are adjacent in ws
   } else {
     for (int idx = t; idx < 128; idx += nt) h.cst[idx] = a.consts[idx];
   }
 }
-template <bool L1>
+template <int MODE>
 KTUP_DEV void hard_stage_tile(const HardArgs& a, const HardStage& h, int64_t j0, int t, int nt) {
   const int nch4 = a.d / 4;
   for (int idx = t; idx < nch4 * CT; idx += nt) {
@@ -318,7 +319,7 @@ KTUP_DEV void hard_stage_tile(const HardArgs& a, const HardStage& h, int64_t j0,
     const int j = idx & (CT - 1), p = idx >> 6;
     const int64_t row = min(j0 + j, a.n_cand - 1);
     h.lv[p * CT + j] = a.LV[row * a.P + p];
-    if (!L1) h.vn[p * CT + j] = a.VN[row * a.P + p];
+    if (MODE == 0) h.vn[p * CT + j] = a.VN[row * a.P + p];
   }
 }
 // the score of (user b, this lane's candidate) under the gate's choice ps
@@ -326,21 +327,21 @@ KTUP_DEV void hard_stage_tile(const HardArgs& a, const HardStage& h, int64_t j0,
 // reads entry p through v_readlane (a load inside its loop is a round trip per preference: the waves then wait on memory 57 % of
 // the time), the score picks the chosen entry across lanes
 struct UserRow { float ql, qn; };
-template <bool L1>
+template <int MODE>
 KTUP_DEV UserRow hard_user_row(const HardArgs& a, int64_t b, int lane) {
   const int pl = lane < a.P ? lane : a.P - 1;
   UserRow u;
   u.ql = a.QL[b * a.P + pl];
-  u.qn = L1 ? 0.f : a.QN[b * a.P + pl];
+  u.qn = MODE != 0 ? 0.f : a.QN[b * a.P + pl];
   return u;
 }
 KTUP_DEV float lane_entry(float v, int p) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), p)); }
 
-template <bool L1>
+template <int MODE>
 KTUP_DEV float hard_pair_score(const HardArgs& a, const HardStage& h, sptr4 QW, int64_t b, const UserRow& ur, int ps, int lane) {
   const int nch4 = a.d / 4, dp4 = a.dp / 4;
   const sptr4 ub = QW + (b * 3 + 1) * nch4;   // slot 1 = u_b; one scalar base, the chunk index is the only offset
-  if (L1) {
+  if (MODE != 0) {
     const float4* cn = h.tabC + ps * dp4;
     const float4* ar = h.tabA + ps * dp4;
     float s = 0.f;
@@ -348,7 +349,7 @@ KTUP_DEV float hard_pair_score(const HardArgs& a, const HardStage& h, sptr4 QW, 
     float acc = 0.f;
     for (uint32_t c = 0; c < (uint32_t)nch4; ++c) {
       const float4 q = sldp(ub + c) - h.cand[c * CT + lane];
-      acc += dist4(fma4(-s, cn[c], q + ar[c]), true);
+      acc += dist4(fma4(-s, cn[c], q + ar[c]), MODE == 1);
     }
     return acc;
   }
@@ -363,27 +364,27 @@ KTUP_DEV float hard_pair_score(const HardArgs& a, const HardStage& h, sptr4 QW, 
   return fmaf(s, fmaf(s, h.cst[64 + ps], -2.f * h.cst[32 + ps]), qq + lin);           // + s (s (|n|^2 - 2) - 2 r.n)
 }
 
-template <bool L1>
+template <int MODE>
 __global__ __launch_bounds__(HARD_NT) void pairs_hard_kernel(HardArgs a) {
   KTUP_RESOLVE_GUMBEL(a);
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const HardStage h = hard_stage_carve<L1>(smem, a.d / 4, a.P, a.dp / 4);
+  const HardStage h = hard_stage_carve<MODE>(smem, a.d / 4, a.P, a.dp / 4);
   const int t = threadIdx.x, lane = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
   const int64_t j0 = (int64_t)blockIdx.x * CT;
   const int64_t gj = min(j0 + lane, a.n_cand - 1);
-  hard_stage_tables<L1>(a, h, t, HARD_NT);
-  hard_stage_tile<L1>(a, h, j0, t, HARD_NT);
+  hard_stage_tables<MODE>(a, h, t, HARD_NT);
+  hard_stage_tile<MODE>(a, h, j0, t, HARD_NT);
   __syncthreads();
   const sptr4 QW = as_scalar(a.QW);
   const int64_t per = (a.nq + gridDim.y - 1) / gridDim.y;
   const int64_t qlo = (int64_t)blockIdx.y * per, qhi = min(a.nq, qlo + per);
   for (int64_t b = qlo + w; b < qhi; b += HARD_NT / 64) {
-    const UserRow ur = hard_user_row<L1>(a, b, lane);
+    const UserRow ur = hard_user_row<MODE>(a, b, lane);
     const uint64_t base = ((uint64_t)b * (uint64_t)a.n_cand + (uint64_t)gj) * (uint64_t)a.P;
     const int ps = gate_argmax(a.P, base, a.gumbel == KTUP_GUMBEL_INPUT, a.uniform, a.seed, a.offset,
                                [&](int p) { return lane_entry(ur.ql, p) + h.lv[p * CT + lane]; });
-    const float acc = hard_pair_score<L1>(a, h, QW, b, ur, ps, lane);
+    const float acc = hard_pair_score<MODE>(a, h, QW, b, ur, ps, lane);
     if (j0 + lane < a.n_cand) a.out[b * a.ldo + j0 + lane] = acc;
   }
 }
@@ -416,16 +417,16 @@ struct SweepHardArgs {
 
 __host__ __device__ inline size_t sweep_wave_bytes(int bm_words, int topn) { return (size_t)SW_UW * topn * 8 + (size_t)SW_UW * 8 + (size_t)SW_UW * 4 + (size_t)SW_UW * bm_words * 4 + 4; }
 
-template <bool L1>
+template <int MODE>
 __global__ __launch_bounds__(SW_NW * 64) void sweep_hard_kernel(SweepHardArgs sa) {
   HardArgs a = sa.h;
   KTUP_RESOLVE_GUMBEL(a);
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const HardStage h = hard_stage_carve<L1>(smem, a.d / 4, a.P, a.dp / 4);
+  const HardStage h = hard_stage_carve<MODE>(smem, a.d / 4, a.P, a.dp / 4);
   const int t = threadIdx.x, lane = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
   const int topn = sa.topn;
-  char* wb = smem + hard_stage_floats<L1>(a.d / 4, a.P, a.dp / 4) * 4 + (size_t)w * ((sweep_wave_bytes(sa.bm_words, topn) + 7) & ~(size_t)7);
+  char* wb = smem + hard_stage_floats<MODE>(a.d / 4, a.P, a.dp / 4) * 4 + (size_t)w * ((sweep_wave_bytes(sa.bm_words, topn) + 7) & ~(size_t)7);
   uint64_t* tk = reinterpret_cast<uint64_t*>(wb);               // [users][topn] sorted lists
   uint64_t* thrk = tk + SW_UW * topn;                           // [users] n-th keys
   float* thrf = reinterpret_cast<float*>(thrk + SW_UW);         // [users] n-th scores (NaN while a list is short)
@@ -465,11 +466,11 @@ __global__ __launch_bounds__(SW_NW * 64) void sweep_hard_kernel(SweepHardArgs sa
       }
     }
   }
-  hard_stage_tables<L1>(a, h, t, SW_NW * 64);
+  hard_stage_tables<MODE>(a, h, t, SW_NW * 64);
   const sptr4 QW = as_scalar(a.QW);
   for (int64_t j0 = i_lo; j0 < i_hi; j0 += CT) {
     __syncthreads();                                                    // the previous stage has been consumed
-    hard_stage_tile<L1>(a, h, j0, t, SW_NW * 64);
+    hard_stage_tile<MODE>(a, h, j0, t, SW_NW * 64);
     __syncthreads();
     const int64_t item = j0 + lane;
     const int64_t gj = min(item, a.n_cand - 1);
@@ -478,11 +479,11 @@ __global__ __launch_bounds__(SW_NW * 64) void sweep_hard_kernel(SweepHardArgs sa
     for (int r = 0; r < SW_UW; ++r) {
       const int64_t b = u0 + r;
       if (b >= a.nq) break;
-      const UserRow ur = hard_user_row<L1>(a, b, lane);
+      const UserRow ur = hard_user_row<MODE>(a, b, lane);
       const uint64_t base = ((uint64_t)b * (uint64_t)a.n_cand + (uint64_t)gj) * (uint64_t)a.P;
       const int ps = gate_argmax(a.P, base, a.gumbel == KTUP_GUMBEL_INPUT, a.uniform, a.seed, a.offset,
                                  [&](int p) { return lane_entry(ur.ql, p) + h.lv[p * CT + lane]; });
-      const float acc = hard_pair_score<L1>(a, h, QW, b, ur, ps, lane);
+      const float acc = hard_pair_score<MODE>(a, h, QW, b, ur, ps, lane);
       // ---- ranking: acc against user r's n-th score
       const float tf = thrf[r];
       bool c = acc < tf;
@@ -962,7 +963,7 @@ int pref_scores_tail(const char* name, const float* U, int64_t ldu, const float*
   float* QW = ws;
   float* QL = QW + (size_t)nq * 3 * d;
   float* QN = QL + pad4((size_t)nq * n_pref);
-  const bool hard_l2 = gumbel_mode != KTUP_GUMBEL_OFF && !l1 && n_pref <= 32;      // the only reader of QN / CN / consts
+  const bool hard_l2 = gumbel_mode != KTUP_GUMBEL_OFF && !l1 && n_pref <= 32;      // the only reader of QN / CN / consts (mode 0)
   float *CW0 = it.CW0, *CW1 = it.CW1, *CW2 = it.CW2, *CL = it.CL;
   // users: slot 0 = u + RU, slot 1 = u, slot 2 = NU, rows of pitch 3d;   items: v - RV, v, NV, rows of pitch d
   hipLaunchKernelGGL(pref_project_kernel, dim3(grid_for((nq + 3) / 4)), dim3(256), 0, st, U, ldu, (const float*)nullptr,
@@ -985,23 +986,19 @@ int pref_scores_tail(const char* name, const float* U, int64_t ldu, const float*
   h.V = CW1; h.LV = CL; h.QW = QW; h.QL = QL; h.ws = pref_ws; h.ppad = g.ppad; h.dp = g.dp; h.P = n_pref; h.d = d;
   h.n_cand = n_items; h.nq = nq; h.l1 = l1; h.gumbel = gumbel_mode; h.uniform = uniform; h.seed = seed; h.offset = offset;
   h.out = out; h.ldo = ldo; h.QN = QN; h.VN = it.CN; h.consts = it.consts;
-  KTUP_REQUIRE(l1 || n_pref <= 32, "%s: the hard gate's squared-L2 score covers at most 32 preferences", name);
-  const size_t lds = (l1 ? hard_stage_floats<true>(d / 4, n_pref, g.dp / 4) : hard_stage_floats<false>(d / 4, n_pref, g.dp / 4)) * 4;
+  const int mode = l1 ? 1 : (n_pref <= 32 ? 0 : 2);
+  const size_t lds = (mode ? hard_stage_floats<1>(d / 4, n_pref, g.dp / 4) : hard_stage_floats<0>(d / 4, n_pref, g.dp / 4)) * 4;
   if (lds > 160 * 1024) return set_error(KTUP_ERR_UNSUPPORTED, "%s: hard-gate tile needs %zu B of LDS", name, lds);
   const int64_t tiles = (n_items + CT - 1) / CT;
   int64_t ysplit = (768 + tiles - 1) / tiles;    // ~ the resident workgroups (3 per CU): each stages 47 KB, so not many more
   if (ysplit > (nq + HARD_NT / 64 - 1) / (HARD_NT / 64)) ysplit = (nq + HARD_NT / 64 - 1) / (HARD_NT / 64);
   if (ysplit < 1) ysplit = 1;
   const dim3 hgrid((unsigned)tiles, (unsigned)ysplit);
-  if (l1) {
-    if (lds > 64 * 1024)
-      (void)hipFuncSetAttribute((const void*)pairs_hard_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(pairs_hard_kernel<true>, hgrid, dim3(HARD_NT), lds, st, h);
-  } else {
-    if (lds > 64 * 1024)
-      (void)hipFuncSetAttribute((const void*)pairs_hard_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(pairs_hard_kernel<false>, hgrid, dim3(HARD_NT), lds, st, h);
-  }
+  auto launch = [&](auto kern) {
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, hgrid, dim3(HARD_NT), lds, st, h);
+  };
+  if (mode == 0) launch(pairs_hard_kernel<0>); else if (mode == 1) launch(pairs_hard_kernel<1>); else launch(pairs_hard_kernel<2>);
   return check_launch(name);
 }
 
@@ -1124,7 +1121,7 @@ extern "C" int ktup_eval_pref_topk_hard(const float* U, int64_t ldu, const float
   nsplit = (int)((n_items + sa.split_items - 1) / sa.split_items);
   sa.nsplit = nsplit;
   sa.bm_words = (int)((sa.split_items + 31) / 32);
-  const size_t lds = (l1 ? hard_stage_floats<true>(d / 4, n_pref, g.dp / 4) : hard_stage_floats<false>(d / 4, n_pref, g.dp / 4)) * 4 +
+  const size_t lds = (l1 ? hard_stage_floats<1>(d / 4, n_pref, g.dp / 4) : hard_stage_floats<0>(d / 4, n_pref, g.dp / 4)) * 4 +
                      SW_NW * ((sweep_wave_bytes(sa.bm_words, topn) + 7) & ~(size_t)7);
   if (lds > 160 * 1024 || ublocks > 0x7fffffffll)
     return set_error(KTUP_ERR_UNSUPPORTED, "%s: the stage needs %zu B of LDS (per-batch calls remain)", name, lds);
@@ -1133,7 +1130,7 @@ extern "C" int ktup_eval_pref_topk_hard(const float* U, int64_t ldu, const float
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, grid, dim3(SW_NW * 64), lds, st, sa);
   };
-  if (l1) launch(sweep_hard_kernel<true>); else launch(sweep_hard_kernel<false>);
+  if (l1) launch(sweep_hard_kernel<1>); else launch(sweep_hard_kernel<0>);
   if (int e = check_launch(name)) return e;
   return ktup::launch_topk_merge(part, nq, nsplit, topn, top_ids, top_scores, st, name);
 }

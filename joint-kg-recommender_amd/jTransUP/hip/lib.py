@@ -150,7 +150,10 @@ _lib = None
 
 
 class KtupError(RuntimeError):
-    pass
+    code = None                    # the library's status (KTUP_ERR_*) when the error came from an entry point
+
+
+ERR_UNSUPPORTED = -3               # KTUP_ERR_UNSUPPORTED (include/ktup_hip.h): the entry point does not cover this shape
 
 
 def load():
@@ -175,7 +178,9 @@ def call(name, *args):
     lib = load()
     rc = getattr(lib, name)(*args)
     if rc != 0:
-        raise KtupError('%s failed (%d): %s' % (name, rc, lib.ktup_last_error().decode('utf-8', 'replace')))
+        err = KtupError('%s failed (%d): %s' % (name, rc, lib.ktup_last_error().decode('utf-8', 'replace')))
+        err.code = rc
+        raise err
 
 
 def get_option(name):

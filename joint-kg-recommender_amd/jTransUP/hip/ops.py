@@ -604,11 +604,11 @@ def eval_pref_topk_hard(U, u, items, l1, topn, gumbel_mode, uniform=None, seed=0
     """The hard (ST-Gumbel) gate's whole evaluation pass in one sweep (ktup_eval_pref_topk_hard): the scores of eval_tup / eval_ktup
     for the same noise source over ALL users of `u` at once (pair (b, j) draws at ((b n_items + j) P + p) + offset), L1 or squared
     L2, with the filtered top-n taken where the scores are made.  -> int32 (len(u), topn) ids (-1 padded) [, scores]; None when
-    topn > 16 (keep eval_* + topk_filtered)."""
+    topn > 16 or the library declines the shape (keep eval_* + topk_filtered)."""
     dev = _dev(_table('user table', U))
     u = _ids('u_ids', u, dev)
     nq, d, P, ni = u.numel(), items.d, items.P, items.n_items
-    if not (0 < topn <= 16) or nq == 0:
+    if not (0 < topn <= 16) or nq == 0 or P > 32:
         return None
     if gumbel_mode == GUMBEL_INPUT:
         if uniform is None or tuple(uniform.shape) != (nq, ni, P) or uniform.dtype != torch.float32 or uniform.device != dev:
@@ -624,9 +624,14 @@ def eval_pref_topk_hard(U, u, items, l1, topn, gumbel_mode, uniform=None, seed=0
     ts = torch.empty(nq, topn, dtype=torch.float32, device=dev) if with_scores else None
     ws = _scratch(L.load().ktup_eval_pref_topk_hard_workspace_bytes(d, P, nq, ni, topn), dev)
     I, E = items.I, items.E
-    L.call('ktup_eval_pref_topk_hard', _p(U), U.stride(0), _p(I), I.stride(0), _p(E), 0 if E is None else E.stride(0), _p(items.item2ent),
-           _p(items.pws), P, d, _p(u), nq, ni, int(l1), int(gumbel_mode), _p(uniform), int(seed), int(offset), _p(filt_off), _p(filt_ids),
-           int(topn), _p(top), _p(ts), _p(ws), _stream(dev))
+    try:
+        L.call('ktup_eval_pref_topk_hard', _p(U), U.stride(0), _p(I), I.stride(0), _p(E), 0 if E is None else E.stride(0), _p(items.item2ent),
+               _p(items.pws), P, d, _p(u), nq, ni, int(l1), int(gumbel_mode), _p(uniform), int(seed), int(offset), _p(filt_off), _p(filt_ids),
+               int(topn), _p(top), _p(ts), _p(ws), _stream(dev))
+    except L.KtupError as e:
+        if e.code == L.ERR_UNSUPPORTED:          # a shape the sweep does not cover (a catalogue split whose filter bitmap passes the LDS):
+            return None                          # the caller keeps the per-batch calls
+        raise
     return (top, ts) if with_scores else top
 
 

@@ -76,9 +76,10 @@ def world(seed, nu, ni, ne, nr, d):
     return W, i2e, gen
 
 
-@pytest.mark.parametrize('d,ni,nq,npref', [(100, 3240, 70, 20), (64, 130, 33, 4), (128, 1000, 5, 13), (100, 63, 1, 20)])
+@pytest.mark.parametrize('d,ni,nq,npref', [(100, 3240, 70, 20), (64, 130, 33, 4), (128, 1000, 5, 13), (100, 63, 1, 20), (36, 200, 9, 40)])
 def test_pref_eval_vs_oracle(d, ni, nq, npref):
-    """TUP / KTUP all-item scores at the ml1m catalogue size (3240 items) and ragged small shapes, soft and hard gate."""
+    """TUP / KTUP all-item scores at the ml1m catalogue size (3240 items) and ragged small shapes, soft and hard gate (40 preferences:
+    the hard gate's squared-L2 score takes its two-pass form beyond 32)."""
     W, i2e, gen = world(d + ni, 300, ni, 500, npref, d)
     u = torch.randint(0, 300, (nq,), generator=gen)
     D = {k: v.to(DEV) for k, v in W.items()}

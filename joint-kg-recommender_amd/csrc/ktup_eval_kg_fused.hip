@@ -471,32 +471,60 @@ __global__ __launch_bounds__(NW * 64) void kg_count_mc_kernel(FArgs a) {
   }
 }
 
-// ---- per gold entry: rank = count - (filtered ids and other golds of the key that are ordered before it); -1 if itself filtered
+// ---- per gold entry: rank = count - (filtered ids and other golds of the key that are ordered before it); -1 if itself filtered.
+// The drivers' filter and gold lists are sorted sets; a key whose lists are strictly increasing (checked in one pass) needs no
+// duplicate tests -- membership of a gold in the filter list is a binary search, "another gold that is also filtered" likewise.
+// Lists in any other order take the quadratic tests (exact for multisets): that form was 63 us per 20,480-key pass for every key.
+KTUP_DEV bool in_sorted(const int32_t* __restrict__ a, int64_t lo, int64_t hi, int32_t x) {
+  const int64_t end = hi;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (a[mid] < x) lo = mid + 1; else hi = mid;
+  }
+  return lo < end && a[lo] == x;
+}
 __global__ __launch_bounds__(256) void kg_rank_finalize_kernel(FArgs a, int64_t n_gold_total) {
   const bool desc = a.descending != 0;
   for (int64_t key = (int64_t)blockIdx.x * 256 + threadIdx.x; key < a.nq; key += (int64_t)gridDim.x * 256) {
     const int64_t g0 = a.gold_off[key], g1 = a.gold_off[key + 1];
     const int64_t f0 = a.filt_off ? a.filt_off[key] : 0, f1 = a.filt_off ? a.filt_off[key + 1] : 0;
+    bool sorted = true;
+    for (int64_t f = f0 + 1; f < f1 && sorted; ++f) sorted = a.filt_ids[f - 1] < a.filt_ids[f];
+    for (int64_t o = g0 + 1; o < g1 && sorted; ++o) sorted = a.gold_ids[o - 1] < a.gold_ids[o];
     for (int64_t gi = g0; gi < g1; ++gi) {
       const int32_t gid = a.gold_ids[gi];
       bool filtered = gid < 0 || gid >= a.n_cand;
-      for (int64_t f = f0; f < f1 && !filtered; ++f) filtered = a.filt_ids[f] == gid;
+      if (!filtered) {
+        if (sorted) filtered = in_sorted(a.filt_ids, f0, f1, gid);
+        else for (int64_t f = f0; f < f1 && !filtered; ++f) filtered = a.filt_ids[f] == gid;
+      }
       if (filtered) { a.ranks[gi] = -1; continue; }
       const uint64_t gk = kg_key(a.gscore[gi], desc, (uint32_t)gid);
       int sub = 0;
-      for (int64_t f = f0; f < f1; ++f) {
-        const int32_t c = a.filt_ids[f];
-        if (c < 0 || c >= a.n_cand) continue;
-        bool dup = false;                                      // a filter list is a set, but stay exact if it is not
-        for (int64_t e = f0; e < f && !dup; ++e) dup = a.filt_ids[e] == c;
-        if (!dup && kg_key(a.fscore[f], desc, (uint32_t)c) < gk) ++sub;
+      if (sorted) {
+#pragma unroll 8
+        for (int64_t f = f0; f < f1; ++f) {                   // independent loads: eight in flight
+          const int32_t c = a.filt_ids[f];
+          sub += (c >= 0 && c < a.n_cand && kg_key(a.fscore[f], desc, (uint32_t)c) < gk) ? 1 : 0;
+        }
+      } else {
+        for (int64_t f = f0; f < f1; ++f) {
+          const int32_t c = a.filt_ids[f];
+          if (c < 0 || c >= a.n_cand) continue;
+          bool dup = false;                                    // a filter list is a set, but stay exact if it is not
+          for (int64_t e = f0; e < f && !dup; ++e) dup = a.filt_ids[e] == c;
+          if (!dup && kg_key(a.fscore[f], desc, (uint32_t)c) < gk) ++sub;
+        }
       }
       for (int64_t o = g0; o < g1; ++o) {
         const int32_t c = a.gold_ids[o];
         if (o == gi || c < 0 || c >= a.n_cand) continue;
         bool dup = false;                                      // another gold that is also filtered was counted above
-        for (int64_t f = f0; f < f1 && !dup; ++f) dup = a.filt_ids[f] == c;
-        for (int64_t e = g0; e < o && !dup; ++e) dup = a.gold_ids[e] == c;
+        if (sorted) dup = in_sorted(a.filt_ids, f0, f1, c);
+        else {
+          for (int64_t f = f0; f < f1 && !dup; ++f) dup = a.filt_ids[f] == c;
+          for (int64_t e = g0; e < o && !dup; ++e) dup = a.gold_ids[e] == c;
+        }
         if (!dup && kg_key(a.gscore[o], desc, (uint32_t)c) < gk) ++sub;
       }
       a.ranks[gi] = a.counts[gi] - sub;

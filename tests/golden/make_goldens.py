@@ -662,14 +662,17 @@ def eval_pass_cases():
     real_argsort = np.argsort
     np.argsort = lambda a, *aa, **kw: real_argsort(a, *aa, **dict(kw, kind='stable'))
     try:
-        for d in (64, 100):
-            for name in ('tup', 'ktup'):
+        # (d, model, L1_flag, use_st_gumbel): the soft gate at both widths; the hard gate (noise per (user, item, preference), drawn by
+        # the reference from torch's global generator: re-seeded per batch and recovered by shim 4) with both distances at d = 100
+        cases = [(d, name, False, False) for d in (64, 100) for name in ('tup', 'ktup')] + \
+                [(100, name, l1, True) for name in ('tup', 'ktup') for l1 in (False, True)]
+        for ci, (d, name, l1, gum) in enumerate(cases):
                 if name == 'tup':
-                    m = transUP.TransUPModel(False, d, NU, NIe, NP_TUP, False)
+                    m = transUP.TransUPModel(l1, d, NU, NIe, NP_TUP, gum)
                 else:
-                    m = jtup.jTransUPModel(False, d, NU, NIe, NE, NR, i_map_big, new_map_big, False, False)
+                    m = jtup.jTransUPModel(l1, d, NU, NIe, NE, NR, i_map_big, new_map_big, False, gum)
                 sd = set_weights(m, gen)
-                tag = '%s.d%d.' % (name, d)
+                tag = '%s.d%d.' % (name, d) if not gum else '%s.hard.%s.d%d.' % (name, 'L1' if l1 else 'L2', d)
                 out.update({tag + k: v for k, v in sd.items()})
                 if name == 'ktup':
                     out[tag + 'item2ent'] = np.asarray(m.paddingItems(torch.arange(NIe), m.ent_total - 1), dtype=np.int64)
@@ -685,9 +688,12 @@ def eval_pass_cases():
                         valid_dict[u] = set(int(x) for x in perm[ng + nt:ng + nt + nv])
                 all_dicts = [train_dict, valid_dict]
                 users = list(range(NU))
-                results = []
+                results, seeds = [], []
                 for b0 in range(0, NU, 16):                              # the eval iterator's batches
                     u_ids = users[b0:b0 + 16]
+                    if gum:
+                        seeds.append([b0, len(u_ids), 5000 + 100 * ci + b0])
+                        torch.manual_seed(seeds[-1][2])                  # the batch's noise = uniforms(seed, (len(u_ids), NIe, P))
                     scores = m.evaluate(V(torch.LongTensor(u_ids))) if name == 'tup' else m.evaluateRec(V(torch.LongTensor(u_ids)))
                     preds = zip(u_ids, scores.data.cpu().numpy())
                     results.extend(rmisc.evalRecProcess(list(preds), eval_dict, all_dicts=all_dicts, descending=False, num_processes=2,
@@ -701,6 +707,9 @@ def eval_pass_cases():
                     'users': [int(r[-1][0]) for r in results],
                     'top_ids': [[int(x) for x in r[-1][1]] for r in results],
                     'mean': [float(x) for x in perf.mean(axis=0)]}
+                if gum:
+                    meta[tag.rstrip('.')]['gumbel_seeds'] = seeds        # [first user, users, seed] per batch
+                    meta[tag.rstrip('.')]['n_pref'] = NP_TUP if name == 'tup' else NR
                 out[tag + 'perf'] = perf
     finally:
         np.argsort = real_argsort

@@ -59,3 +59,44 @@ def test_fused_eval_pass_reproduces_the_reference_pass(name, d, route):
     perf = ops.rec_metrics(top, g_off, g_ids).cpu().numpy()
     np.testing.assert_allclose(perf, g[tag + 'perf'], rtol=1e-12, atol=0)
     np.testing.assert_allclose(perf.mean(axis=0), J['mean'], rtol=1e-12)
+
+
+@pytest.mark.parametrize('name', ['tup', 'ktup'])
+@pytest.mark.parametrize('l1', [False, True])
+@pytest.mark.parametrize('route', ['one_sweep', 'score_matrix'])
+def test_hard_gate_eval_pass_reproduces_the_reference_pass(name, l1, route):
+    """-use_st_gumbel: the reference's whole pass with its noise recovered batch by batch (make_goldens.py shim 4) against the hard
+    gate's one-sweep pass (ktup_eval_pref_topk_hard, given uniforms) and the per-batch route: ranked ids bit-exact, metrics to 1e-12."""
+    from jTransUP.hip import ops
+    g = np.load(os.path.join(GOLDEN, 'eval_pass.npz'))
+    key = '%s.hard.%s.d100' % (name, 'L1' if l1 else 'L2')
+    J = json.load(open(os.path.join(GOLDEN, 'eval_pass.json')))[key]
+    tag = key + '.'
+    t = lambda n: torch.from_numpy(g[tag + n]).to(DEV)
+    users = J['users']
+    u = torch.tensor(users, dtype=torch.int64, device=DEV)
+    f_off, f_ids = _csr([J['train'], J['valid']], users)
+    g_off, g_ids = _csr([J['eval']], users)
+    n_items = g[tag + 'item_embeddings.weight'].shape[0]
+    parts = []
+    for first, n, seed in J['gumbel_seeds']:                             # the reference re-seeded before every batch of 16 users
+        torch.manual_seed(seed)
+        parts.append(torch.empty(n, n_items, J['n_pref']).uniform_())
+    uni = torch.cat(parts)[users].contiguous().to(DEV)                   # rows of the users that have test items
+    if name == 'tup':
+        U, I, P, Pn = (t(n) for n in TUP_NAMES)
+        items = ops.eval_pref_items(I, None, P, Pn, None, None, None)
+        full = lambda: ops.eval_tup(U, I, P, Pn, u, l1, ops.GUMBEL_INPUT, uni, items=items)
+    else:
+        U, I, E, P, Pn, R, Rn = (t(n) for n in KTUP_NAMES)
+        i2e = t('item2ent').to(torch.int32)
+        items = ops.eval_pref_items(I, E, P, Pn, R, Rn, i2e)
+        full = lambda: ops.eval_ktup(U, I, E, P, Pn, R, Rn, i2e, u, l1, ops.GUMBEL_INPUT, uni, items=items)
+    if route == 'one_sweep':
+        top = ops.eval_pref_topk_hard(U, u, items, l1, 10, ops.GUMBEL_INPUT, uni, 0, 0, f_off, f_ids)
+        assert top is not None
+    else:
+        top = ops.topk_filtered(full(), False, 10, f_off, f_ids)
+    assert top.cpu().tolist() == J['top_ids']
+    perf = ops.rec_metrics(top, g_off, g_ids).cpu().numpy()
+    np.testing.assert_allclose(perf, g[tag + 'perf'], rtol=1e-12, atol=0)

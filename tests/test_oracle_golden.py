@@ -366,6 +366,43 @@ def test_eval_pass_golden(name, d):
     np.testing.assert_allclose(np.array([r[:5] for r in rows]).mean(axis=0), J['mean'], rtol=1e-12)
 
 
+def _pass_uniforms(J, n_items):
+    """The noise of a hard-gate pass: the reference re-seeded torch's global generator before every batch of users (make_goldens.py
+    shim 4), so the uniforms of batch (first, n, seed) are torch.manual_seed(seed); torch.empty(n, n_items, P).uniform_()."""
+    parts = []
+    for first, n, seed in J['gumbel_seeds']:
+        torch.manual_seed(seed)
+        parts.append(torch.empty(n, n_items, J['n_pref']).uniform_())
+    return torch.cat(parts)
+
+
+@pytest.mark.parametrize('name', ['tup', 'ktup'])
+@pytest.mark.parametrize('l1', [False, True])
+def test_eval_pass_hard_gate_golden(name, l1):
+    """The same pass with -use_st_gumbel (transUP.py:92,143-170: noise per (user, item, preference)), both distances: the oracle's
+    scores for the recorded uniforms + the ranking walk reproduce the reference's ranked ids and metric rows."""
+    g = np.load(os.path.join(GOLDEN, 'eval_pass.npz'))
+    key = '%s.hard.%s.d100' % (name, 'L1' if l1 else 'L2')
+    J = json.load(open(os.path.join(GOLDEN, 'eval_pass.json')))[key]
+    tag = key + '.'
+    eval_dict = {int(u): set(v) for u, v in J['eval'].items()}
+    all_dicts = [{int(u): set(v) for u, v in J[k].items()} for k in ('train', 'valid')]
+    users = torch.arange(37)
+    n_items = g[tag + 'item_embeddings.weight'].shape[0]
+    uni = _pass_uniforms(J, n_items)
+    if name == 'tup':
+        W = [T(g[tag + n]) for n in TUP_NAMES]
+        scores = O.eval_tup(*W, users, l1, uni)
+    else:
+        W = [T(g[tag + n]) for n in KTUP_NAMES]
+        scores = O.eval_ktup_rec(*W, T(g[tag + 'item2ent']), users, l1, uni)
+    rows = O.eval_rec_rows(list(zip(users.tolist(), scores.numpy())), eval_dict, all_dicts, descending=False, topn=10)
+    rows.sort(key=lambda r: r[-1][0])
+    assert [r[-1][0] for r in rows] == J['users']
+    assert [[int(x) for x in r[-1][1]] for r in rows] == J['top_ids']
+    np.testing.assert_allclose(np.array([r[:5] for r in rows]), g[tag + 'perf'], rtol=1e-12, atol=0)
+
+
 # ------------------------------------------------------------------------------------------------ FM / coFM
 @pytest.mark.parametrize('d', [36, 64])
 def test_fm_cofm_golden(golden, d):

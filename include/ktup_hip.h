@@ -321,19 +321,20 @@ int ktup_eval_gold_ranks(const float* scores, int64_t lds, int64_t nq, int64_t n
  * per-batch route.  model: KTUP_KG_TRANSE (Nrm ignored) or KTUP_KG_TRANSH; head / l1 / C as in ktup_eval_trans{e,h}_scores. */
 #define KTUP_KG_TRANSE 0
 #define KTUP_KG_TRANSH 1
-/* The pass WITHOUT the (keys x candidates) score matrix (csrc/ktup_eval_kg_fused.hip): squared-L2 TransE / TransH on the matrix
- * cores, ranks from counts formed in the score kernel's epilogue -- rank(g) = #{c : key(c) < key(g)} minus the filtered ids and
- * other golds of the key ordered before g, whose scores come from a small launch that runs the sweep's own instruction sequence
- * (bit-identical keys).  Same arguments and results as ktup_eval_kg_ranks, all keys in one go; n_filt / n_gold = lengths of the id
- * arrays, max_golds = the largest gold set of a key (host side).  ktup_eval_kg_ranks_fused_supported: l1 == 0, d in
- * {20, 36, 64, 100, 128}, max_golds <= 8 (else KTUP_ERR_UNSUPPORTED: use ktup_eval_kg_ranks).  n_rel = rows of R / Nrm: TransH's
- * second product w.e depends on (relation, candidate) only and is computed once per pass into an n_rel x n_cand table in `ws`
- * (n_rel = 0, option kg_wtab = 0 or a table beyond 1 GiB: both products in the sweep; the same integers either way).            */
+/* The pass WITHOUT the (keys x candidates) score matrix (csrc/ktup_eval_kg_fused.hip), TransE / TransH: the ranks are counts formed
+ * where the scores are made -- rank(g) = #{c : key(c) < key(g)} minus the filtered ids and other golds of the key ordered before g,
+ * whose scores come from a small launch that runs the sweep's own instruction sequence (bit-identical keys).  Squared L2 at d in
+ * {20, 36, 64, 100, 128} with at most 8 golds per key sweeps on the matrix cores; L1, other widths and larger gold sets score the
+ * tiles with the pair kernels of the per-batch entry points (any d) and count in their epilogue.  Same arguments and results as
+ * ktup_eval_kg_ranks, all keys in one go; n_filt / n_gold = lengths of the id arrays, max_golds = the largest gold set of a key
+ * (host side).  n_rel = rows of R / Nrm: the matrix-core sweep takes TransH's second product w.e, which depends on (relation,
+ * candidate) only, from an n_rel x n_cand table computed once per pass in `ws` (n_rel = 0, option kg_wtab = 0 or a table beyond
+ * 1 GiB: both products in the sweep; the same integers either way).                                                            */
 int ktup_eval_kg_ranks_fused_supported(int model, int d, int l1, int64_t max_golds);
 size_t ktup_eval_kg_ranks_fused_workspace_bytes(int model, int d, int64_t nq, int64_t n_gold, int64_t n_filt, int64_t n_cand,
                                                 int64_t n_rel);
 int ktup_eval_kg_ranks_fused(int model, const float* E, int64_t lde, const float* R, int64_t ldr, const float* Nrm, int64_t ldn,
-                             int64_t n_rel, int d, const float* C, int64_t ldc, int64_t n_cand, const int64_t* q, const int64_t* r, int64_t nq, int head,
+                             int64_t n_rel, int d, const float* C, int64_t ldc, int64_t n_cand, const int64_t* q, const int64_t* r, int64_t nq, int l1, int head,
                              int descending, const int64_t* filt_off, const int32_t* filt_ids, int64_t n_filt,
                              const int64_t* gold_off, const int32_t* gold_ids, int64_t n_gold, int64_t max_golds, int32_t* ranks,
                              void* ws, void* stream);

@@ -146,6 +146,13 @@ struct PairsArgs {
   const int32_t* qperm;       // query order sorted by relation (NULL otherwise)
   const int32_t* rel_off;     // [n_rel + 1] bucket offsets into qperm
   int64_t rel_stride;         // elements between the projected-candidate tables of consecutive relations
+  // COUNT kernels (the link-prediction pass without the score matrix, any distance): per gold entry of a query the number of
+  // candidates ordered before it, from the scores where they are made; LIST kernel: the scores of the queries' own list entries
+  const int64_t *gold_off, *filt_off;
+  const int32_t *gold_ids, *filt_ids;
+  float *gscore, *fscore;
+  int32_t* counts;
+  int descending;
 };
 
 KTUP_DEV float4 load_cand4(const float* base, int64_t ld, int64_t row, int c, int d, bool vec) {
@@ -165,7 +172,53 @@ KTUP_DEV float4 load_cand4(const float* base, int64_t ld, int64_t row, int c, in
 template <int MODE>
 struct PairsWG { static constexpr int NWV = MODE == 2 ? 8 : 4, NT = NWV * 64; };
 
-template <int MODE, bool L1>
+// the scores of NQ queries (wave-uniform vectors through scalar loads) against the lane's candidate of the staged tile.  ONE function
+// for the score kernel, its COUNT form and the list kernel: the same instructions on the same operands, so a (query, candidate) pair
+// has the same bits wherever it is scored
+template <int MODE, bool L1, int NQ>
+KTUP_DEV void pair_group_scores(const float4* cand, int nch4, const sptr4 (&qa)[NQ], const sptr4 (&qn)[NQ], const sptr4 (&q1p)[NQ], int lane,
+                                float (&acc)[NQ]) {
+  constexpr bool l1 = L1;
+  float s[NQ];
+#pragma unroll
+  for (int qi = 0; qi < NQ; ++qi) { s[qi] = 0.f; acc[qi] = 0.f; }
+  if (MODE >= 1) {
+    for (uint32_t c = 0; c < (uint32_t)nch4; ++c) {
+      const float4 c1 = cand[((MODE == 2 ? 1 : 0) * nch4 + c) * CT + lane];
+      const float4 nc = MODE == 2 ? cand[(2 * nch4 + c) * CT + lane] : f4zero();
+#pragma unroll
+      for (int qi = 0; qi < NQ; ++qi) {
+        const float4 nqv = sldp(qn[qi] + c);
+        if constexpr (MODE == 2) {
+          s[qi] += dot4(sldp(q1p[qi] + c) - c1, nqv + nc);
+        } else {                      // TransH: s = -(e . w); no zero operands for the compiler to keep (x + 0 is not x for -0)
+          s[qi] -= dot4(c1, nqv);
+        }
+      }
+    }
+  }
+  for (uint32_t c = 0; c < (uint32_t)nch4; ++c) {
+    const float4 c0 = cand[c * CT + lane];
+    const float4 nc = MODE == 2 ? cand[(2 * nch4 + c) * CT + lane] : f4zero();
+#pragma unroll
+    for (int qi = 0; qi < NQ; ++qi) {
+      const float4 av = sldp(qa[qi] + c);
+      float4 z = av - c0;
+      if constexpr (MODE == 2) z = fma4(-s[qi], sldp(qn[qi] + c) + nc, z);
+      if constexpr (MODE == 1) z = fma4(-s[qi], sldp(qn[qi] + c), z);
+      acc[qi] += dist4(z, l1);
+    }
+  }
+}
+
+KTUP_DEV uint64_t count_key(float s, uint32_t id) {    // ktup_rank.hip make_key (ascending)
+  if (s == 0.f) s = 0.f;
+  uint32_t u = __float_as_uint(s);
+  u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+  return ((uint64_t)u << 32) | id;
+}
+
+template <int MODE, bool L1, bool COUNT = false>
 __global__ __launch_bounds__(PairsWG<MODE>::NT) void pairs_kernel(PairsArgs a) {
   constexpr int NWV = PairsWG<MODE>::NWV, NT = PairsWG<MODE>::NT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -214,35 +267,53 @@ __global__ __launch_bounds__(PairsWG<MODE>::NT) void pairs_kernel(PairsArgs a) {
       q1p[qi] = qa[qi] + dq4;
       qn[qi] = qa[qi] + 2 * dq4;
     }
-    float s[QB], acc[QB];
-#pragma unroll
-    for (int qi = 0; qi < QB; ++qi) { s[qi] = 0.f; acc[qi] = 0.f; }
-    if (MODE >= 1) {
-      for (uint32_t c = 0; c < (uint32_t)nch4; ++c) {
-        const float4 c1 = cand[((MODE == 2 ? 1 : 0) * nch4 + c) * CT + lane];
-        const float4 nc = MODE == 2 ? cand[(2 * nch4 + c) * CT + lane] : f4zero();
-#pragma unroll
-        for (int qi = 0; qi < QB; ++qi) {
-          const float4 nqv = sldp(qn[qi] + c);
-          if constexpr (MODE == 2) {
-            s[qi] += dot4(sldp(q1p[qi] + c) - c1, nqv + nc);
-          } else {                      // TransH: s = -(e . w); no zero operands for the compiler to keep (x + 0 is not x for -0)
-            s[qi] -= dot4(c1, nqv);
-          }
-        }
-      }
-    }
-    for (uint32_t c = 0; c < (uint32_t)nch4; ++c) {
-      const float4 c0 = cand[c * CT + lane];
-      const float4 nc = MODE == 2 ? cand[(2 * nch4 + c) * CT + lane] : f4zero();
+    // COUNT: the queries' gold lists (offsets, the first TH scores and ids: wave-uniform scalar loads) are requested BEFORE the
+    // scores are computed -- after them they were three dependent round trips per query with nothing to hide behind
+    constexpr int TH = 4;
+    int64_t cg0[QB];
+    int cng[QB];
+    float cth[QB][TH];
+    uint32_t cgid[QB][TH];
+    if constexpr (COUNT) {
 #pragma unroll
       for (int qi = 0; qi < QB; ++qi) {
-        const float4 av = sldp(qa[qi] + c);
-        float4 z = av - c0;
-        if constexpr (MODE == 2) z = fma4(-s[qi], sldp(qn[qi] + c) + nc, z);
-        if constexpr (MODE == 1) z = fma4(-s[qi], sldp(qn[qi] + c), z);
-        acc[qi] += dist4(z, l1);
+        cg0[qi] = a.gold_off[qid[qi]];
+        cng[qi] = b0 + qi < qhi ? (int)(a.gold_off[qid[qi] + 1] - cg0[qi]) : 0;
       }
+#pragma unroll
+      for (int qi = 0; qi < QB; ++qi)
+#pragma unroll
+        for (int k = 0; k < TH; ++k) {
+          cth[qi][k] = k < cng[qi] ? a.gscore[cg0[qi] + k] : 0.f;
+          cgid[qi][k] = k < cng[qi] ? (uint32_t)a.gold_ids[cg0[qi] + k] : 0u;
+        }
+    }
+    float acc[QB];
+    pair_group_scores<MODE, L1, QB>(cand, nch4, qa, qn, q1p, lane, acc);
+    if constexpr (COUNT) {
+      // per gold entry of each query: the candidates of this tile ordered before it -- (score, id) order of ktup_rank.hip's keys: a
+      // lower score, or the same score and a lower id; NaNs on either side (uniform tests) go through the keys themselves
+      const bool in = j0 + lane < a.n_cand;
+      const uint32_t cid = (uint32_t)(j0 + lane);
+      const bool desc = a.descending != 0;
+#pragma unroll
+      for (int qi = 0; qi < QB; ++qi) {
+        const float sc = desc ? -acc[qi] : acc[qi];
+        const bool any_nan = __builtin_amdgcn_ballot_w64(sc != sc) != 0;
+        auto count = [&](float th0, uint32_t gid, int64_t g) {
+          const float th = desc ? -th0 : th0;
+          bool lt;
+          if (any_nan || th != th) lt = in && count_key(sc, cid) < count_key(th, gid);
+          else lt = in && (sc < th || (sc == th && cid < gid));
+          const int n = __popcll(__builtin_amdgcn_ballot_w64(lt));
+          if (n != 0 && lane == 0) atomicAdd(a.counts + g, n);
+        };
+#pragma unroll
+        for (int k = 0; k < TH; ++k)
+          if (k < cng[qi]) count(cth[qi][k], cgid[qi][k], cg0[qi] + k);
+        for (int k = TH; k < cng[qi]; ++k) count(a.gscore[cg0[qi] + k], (uint32_t)a.gold_ids[cg0[qi] + k], cg0[qi] + k);
+      }
+      continue;
     }
     if (j0 + lane < a.n_cand) {
 #pragma unroll
@@ -707,6 +778,53 @@ int launch_pairs(const PairsArgs& a, hipStream_t st, const char* name, int nrel 
   return check_launch(name);
 }
 
+// ---- the scores of every query's OWN list entries (golds, then filtered ids) with pair_group_scores: a wave takes one query at a
+// time, gathers up to 64 of its entries' rows into its LDS tile (lane <-> entry) and scores them -- the thresholds and the subtrahend of
+// the COUNT form's ranks (ktup_eval_kg_fused.hip), bit-identical to what the sweep computes for the same (query, candidate)
+constexpr int LIST_NW = 2;
+template <int MODE, bool L1>
+__global__ __launch_bounds__(LIST_NW * 64) void pairs_list_kernel(PairsArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int t = threadIdx.x, lane = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int nch4 = a.dq / 4;
+  float4* cand = reinterpret_cast<float4*>(smem) + (size_t)w * nch4 * CT;
+  const sptr4 QW = as_scalar(a.QW);
+  for (int64_t key = (int64_t)blockIdx.x * LIST_NW + w; key < a.nq; key += (int64_t)gridDim.x * LIST_NW) {
+    const int64_t g0 = a.gold_off[key], ng = a.gold_off[key + 1] - g0;
+    const int64_t f0 = a.filt_off ? a.filt_off[key] : 0, nf = a.filt_off ? a.filt_off[key + 1] - f0 : 0;
+    const sptr4 qa[1] = {QW + key * 3 * nch4}, q1p[1] = {qa[0] + nch4}, qn[1] = {qa[0] + 2 * nch4};
+    for (int64_t base = 0; base < ng + nf; base += 64) {
+      const int64_t e = base + lane;
+      const bool on = e < ng + nf;
+      const int32_t cid = !on ? 0 : (e < ng ? a.gold_ids[g0 + e] : a.filt_ids[f0 + (e - ng)]);
+      const bool valid = on && cid >= 0 && cid < a.n_cand;
+      for (int c = 0; c < nch4; ++c) cand[c * CT + lane] = load_cand4(a.C0, a.ldc0, valid ? cid : 0, c, a.d, a.cvec);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      float acc[1];
+      pair_group_scores<MODE, L1, 1>(cand, nch4, qa, qn, q1p, lane, acc);
+      if (valid) {
+        if (e < ng) a.gscore[g0 + e] = acc[0]; else a.fscore[f0 + (e - ng)] = acc[0];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
+template <int MODE, bool L1>
+int launch_pairs_count(const PairsArgs& a, hipStream_t st, const char* name) {
+  const size_t tile = (size_t)(a.dq / 4) * CT * 16;
+  if (tile * LIST_NW > 160 * 1024) return set_error(KTUP_ERR_UNSUPPORTED, "%s: embedding_size %d needs %zu B of LDS", name, a.d, tile * LIST_NW);
+  (void)hipFuncSetAttribute((const void*)pairs_list_kernel<MODE, L1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(tile * LIST_NW));
+  hipLaunchKernelGGL((pairs_list_kernel<MODE, L1>), dim3(grid_for((a.nq + LIST_NW - 1) / LIST_NW, 4096)), dim3(LIST_NW * 64), tile * LIST_NW, st, a);
+  const dim3 grid = pairs_grid(a.n_cand, a.nq, PairsWG<MODE>::NWV, 2048);
+  if (tile > 64 * 1024) (void)hipFuncSetAttribute((const void*)pairs_kernel<MODE, L1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile);
+  hipLaunchKernelGGL((pairs_kernel<MODE, L1, true>), grid, dim3(PairsWG<MODE>::NT), tile, st, a);
+  return check_launch(name);
+}
+
 inline int round4(int d) { return (d + 3) / 4 * 4; }
 inline size_t pad4(size_t x) { return (x + 3) & ~(size_t)3; }
 // the evaluation workspaces of the preference models: items CW0 | CW1 | CW2 [N][d] | CL | CN [N][P] | consts [4][32]; users QW [nq][3][d] | QL | QN [nq][P]
@@ -746,6 +864,20 @@ int ktup::kg_query_prep(int model, const float* E, int64_t lde, const float* R, 
   hipLaunchKernelGGL(kg_query_prep_kernel, dim3(grid_for((nq + 3) / 4)), dim3(256), 0, st, model, E, lde, R, ldr, X, ldx, d, round4(d), q, r,
                      nq, head, QW);
   return check_launch(name);
+}
+
+// the link-prediction pass's counts on the VALU route (any distance, any width, any number of golds per key): list scores, then the
+// pair kernel in its COUNT form.  QW: kg_query_prep's rows; counts must be zero on entry.
+int ktup::kg_valu_counts(int model, const float* QW, int d, const float* C, int64_t ldc, int64_t n_cand, int64_t nq, int l1, int descending,
+                         const int64_t* gold_off, const int32_t* gold_ids, const int64_t* filt_off, const int32_t* filt_ids, float* gscore,
+                         float* fscore, int32_t* counts, hipStream_t st, const char* name) {
+  PairsArgs a{};
+  a.C0 = C; a.ldc0 = ldc; a.QW = QW; a.n_cand = n_cand; a.nq = nq; a.d = d; a.dq = round4(d); a.l1 = l1;
+  a.cvec = (d % 4 == 0) && aligned16(C) && (ldc % 4 == 0);
+  a.gold_off = gold_off; a.gold_ids = gold_ids; a.filt_off = filt_off; a.filt_ids = filt_ids; a.gscore = gscore; a.fscore = fscore;
+  a.counts = counts; a.descending = descending;
+  if (model == 1) return l1 ? launch_pairs_count<1, true>(a, st, name) : launch_pairs_count<1, false>(a, st, name);
+  return l1 ? launch_pairs_count<0, true>(a, st, name) : launch_pairs_count<0, false>(a, st, name);
 }
 
 extern "C" size_t ktup_eval_kg_workspace_bytes(int d, int64_t nq) { return (size_t)nq * 3 * round4(d) * sizeof(float); }

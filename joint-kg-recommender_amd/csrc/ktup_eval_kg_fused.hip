@@ -612,9 +612,15 @@ bool wtab_on(int model, int64_t n_cand, int64_t n_rel) {
 }  // namespace
 }  // namespace ktup
 
+// the matrix-core sweep applies; everything else TransE / TransH takes the VALU count route (ktup_eval.hip kg_valu_counts)
+static bool fused_mfma(int d, int l1, int64_t max_golds) {
+  (void)max_golds;      // (golds beyond the first four of a key: further sweep launches whose other workgroups exit at once)
+  return !l1 && (d == 20 || d == 36 || d == 64 || d == 100 || d == 128) && ktup::opt_eval_mc();
+}
+
 extern "C" int ktup_eval_kg_ranks_fused_supported(int model, int d, int l1, int64_t max_golds) {
-  return (model == KTUP_KG_TRANSE || model == KTUP_KG_TRANSH) && !l1 && (d == 20 || d == 36 || d == 64 || d == 100 || d == 128) &&
-         max_golds <= ktup::GM && ktup::opt_eval_mc();
+  (void)l1; (void)max_golds;
+  return (model == KTUP_KG_TRANSE || model == KTUP_KG_TRANSH) && d > 0 && d <= 1024;
 }
 
 extern "C" size_t ktup_eval_kg_ranks_fused_workspace_bytes(int model, int d, int64_t nq, int64_t n_gold, int64_t n_filt, int64_t n_cand,
@@ -627,21 +633,20 @@ extern "C" size_t ktup_eval_kg_ranks_fused_workspace_bytes(int model, int d, int
 
 extern "C" int ktup_eval_kg_ranks_fused(int model, const float* E, int64_t lde, const float* R, int64_t ldr, const float* Nrm, int64_t ldn,
                                         int64_t n_rel, int d, const float* C, int64_t ldc, int64_t n_cand, const int64_t* q, const int64_t* r,
-                                        int64_t nq, int head, int descending, const int64_t* filt_off, const int32_t* filt_ids, int64_t n_filt,
-                                        const int64_t* gold_off, const int32_t* gold_ids, int64_t n_gold, int64_t max_golds,
+                                        int64_t nq, int l1, int head, int descending, const int64_t* filt_off, const int32_t* filt_ids,
+                                        int64_t n_filt, const int64_t* gold_off, const int32_t* gold_ids, int64_t n_gold, int64_t max_golds,
                                         int32_t* ranks, void* ws, void* stream) {
   const char* name = "ktup_eval_kg_ranks_fused";
   using namespace ktup;
-  if (!ktup_eval_kg_ranks_fused_supported(model, d, 0, max_golds))
-    return set_error(KTUP_ERR_UNSUPPORTED, "%s: squared-L2 TransE / TransH, d in {20,36,64,100,128}, at most %d golds per key", name, GM);
+  if (!ktup_eval_kg_ranks_fused_supported(model, d, l1, max_golds))
+    return set_error(KTUP_ERR_UNSUPPORTED, "%s: TransE / TransH (TransR: ktup_eval_kg_ranks_transr)", name);
   KTUP_REQUIRE(nq >= 0 && n_cand > 0 && n_gold >= 0 && n_filt >= 0 && n_rel >= 0, "%s: bad sizes", name);
   if (nq == 0 || n_gold == 0) return KTUP_OK;
   KTUP_REQUIRE(E && R && C && q && r && gold_off && gold_ids && ranks && ws && (model == KTUP_KG_TRANSE || Nrm), "%s: null pointer argument", name);
   KTUP_REQUIRE((filt_off == nullptr) || filt_ids, "%s: filter offsets without ids", name);
-  KTUP_REQUIRE(aligned16(C) && (ldc & 3) == 0 && n_cand < (1ll << 31) && (nq + UB - 1) / UB <= 65535, "%s: candidate table must be 16-byte aligned (pitch %% 4), sizes in range", name);
-  if (((n_cand + IB * NBAND - 1) / (IB * NBAND) + 1) * IB * ldc * 4 >= (1ll << 31))      // a band is addressed through one 32-bit buffer descriptor
-    return set_error(KTUP_ERR_UNSUPPORTED, "%s: a candidate band of %lld bytes does not fit a buffer descriptor (use ktup_eval_kg_ranks)", name,
-                     (long long)(((n_cand + IB * NBAND - 1) / (IB * NBAND)) * IB * ldc * 4));
+  KTUP_REQUIRE(n_cand < (1ll << 31) && (nq + UB - 1) / UB <= 65535, "%s: sizes out of range", name);
+  const bool mfma = fused_mfma(d, l1, max_golds) && aligned16(C) && (ldc & 3) == 0 &&
+                    ((n_cand + IB * NBAND - 1) / (IB * NBAND) + 1) * IB * ldc * 4 < (1ll << 31);   // a band goes through one 32-bit buffer descriptor
   hipStream_t st = (hipStream_t)stream;
   char* p = reinterpret_cast<char*>(ws);
   float* QW = reinterpret_cast<float*>(p); p += pad256(ktup_eval_kg_workspace_bytes(d, nq));
@@ -654,6 +659,16 @@ extern "C" int ktup_eval_kg_ranks_fused(int model, const float* E, int64_t lde, 
   a.QW = QW; a.dq = (d + 3) & ~3; a.C = C; a.ldc = ldc; a.nq = nq; a.n_cand = n_cand; a.descending = descending;
   a.gold_off = gold_off; a.gold_ids = gold_ids; a.gscore = gscore; a.filt_off = filt_off; a.filt_ids = filt_ids; a.fscore = fscore;
   a.counts = counts; a.ranks = ranks; a.cnorm = cnorm; a.dbg = opt_dbg_eval();
+  if (!mfma) {
+    // L1, widths without a matrix-core instantiation, keys with more than 8 golds: the pair kernels of ktup_eval.hip score the tiles
+    // on the VALU and count where the scores are made (no score matrix either); list scores by the same function
+    hipLaunchKernelGGL(kg_pass_init_kernel, dim3(grid_for((n_gold + 255) / 256, 2048)), dim3(256), 0, st, counts, n_gold, C, ldc, 0, (int64_t)0, cnorm);
+    if (int e = kg_valu_counts(model, QW, d, C, ldc, n_cand, nq, l1, descending, gold_off, gold_ids, filt_off, filt_ids, gscore, fscore, counts,
+                               st, name))
+      return e;
+    hipLaunchKernelGGL(kg_rank_finalize_kernel, dim3(grid_for((nq + 255) / 256, 1024)), dim3(256), 0, st, a, n_gold);
+    return check_launch(name);
+  }
   int rc;
   if (model == KTUP_KG_TRANSE) rc = dispatch_fused<0>(a, d, n_gold, max_golds, st, name);
   else if (wtab_on(model, n_cand, n_rel)) {      // relation ids are bounds-checked by the caller's tables (r indexes R and Nrm already)

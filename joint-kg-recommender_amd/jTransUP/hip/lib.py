@@ -94,7 +94,7 @@ SIGNATURES = {
                            c_p, c_p],
     'ktup_eval_kg_ranks_fused_supported': [c_i, c_i, c_i, c_l],
     'ktup_eval_kg_ranks_fused_workspace_bytes': [c_i, c_i, c_l, c_l, c_l, c_l, c_l],
-    'ktup_eval_kg_ranks_fused': [c_i, c_p, c_l, c_p, c_l, c_p, c_l, c_l, c_i, c_p, c_l, c_l, c_p, c_p, c_l, c_i, c_i, c_p, c_p, c_l, c_p, c_p,
+    'ktup_eval_kg_ranks_fused': [c_i, c_p, c_l, c_p, c_l, c_p, c_l, c_l, c_i, c_p, c_l, c_l, c_p, c_p, c_l, c_i, c_i, c_i, c_p, c_p, c_l, c_p, c_p,
                                  c_l, c_l, c_p, c_p, c_p],
     'ktup_eval_kg_ranks_transr_workspace_bytes': [c_i, c_l, c_i, c_l],
     'ktup_eval_kg_ranks_transr': [c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_l, c_i, c_p, c_p, c_p, c_l, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p,

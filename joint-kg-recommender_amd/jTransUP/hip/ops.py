@@ -435,17 +435,17 @@ def eval_kg_ranks(E, R, N, q, r, l1, head, descending, gold_off, gold_ids, filt_
         raise L.KtupError('eval_kg_ranks: CSR offsets need len(q) + 1 entries')
     n_gold = gold_ids.numel()
     ranks = torch.empty(max(n_gold, 1), dtype=torch.int32, device=dev)
-    if fused is not False and nq > 0 and n_gold > 0 and not l1:
-        # the pass without the score matrix (ktup_eval_kg_ranks_fused): ranks from counts in the score kernel's epilogue
+    if fused is not False and nq > 0 and n_gold > 0:
+        # the pass without the score matrix (ktup_eval_kg_ranks_fused): ranks from counts formed where the scores are made -- the
+        # matrix-core sweep for squared L2 at its widths, the pair kernels' COUNT form for L1 / other widths / large gold sets
         mg = _max_golds(gold_off)
         lib = L.load()
-        if lib.ktup_eval_kg_ranks_fused_supported(KG_TRANSE if N is None else KG_TRANSH, E.shape[1], int(l1), mg) and C.stride(0) % 4 == 0 \
-                and C.shape[0] * C.stride(0) * 4 < 8 * (2 ** 31 - 2 ** 24):      # (a candidate band goes through one 32-bit buffer descriptor)
+        model, n_rel = (KG_TRANSE, 0) if N is None else (KG_TRANSH, min(R.shape[0], N.shape[0]))
+        if lib.ktup_eval_kg_ranks_fused_supported(model, E.shape[1], int(bool(l1)), mg):
             n_filt = 0 if filt_ids is None else filt_ids.numel()
-            model, n_rel = (KG_TRANSE, 0) if N is None else (KG_TRANSH, min(R.shape[0], N.shape[0]))
             fws = _scratch(lib.ktup_eval_kg_ranks_fused_workspace_bytes(model, E.shape[1], nq, n_gold, n_filt, C.shape[0], n_rel), dev)
             L.call('ktup_eval_kg_ranks_fused', model, _p(E), E.stride(0), _p(R), R.stride(0), _p(N),
-                   0 if N is None else N.stride(0), n_rel, E.shape[1], _p(C), C.stride(0), C.shape[0], _p(q), _p(r), nq, int(head),
+                   0 if N is None else N.stride(0), n_rel, E.shape[1], _p(C), C.stride(0), C.shape[0], _p(q), _p(r), nq, int(bool(l1)), int(head),
                    int(bool(descending)), _p(filt_off), _p(filt_ids), n_filt, _p(gold_off), _p(gold_ids), n_gold, mg, _p(ranks), _p(fws),
                    _stream(dev))
             return ranks

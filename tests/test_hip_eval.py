@@ -601,6 +601,35 @@ def test_kg_ranks_without_score_matrix(model, d):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('model,d,l1', [('transe', 100, True), ('transh', 100, True), ('transe', 50, False), ('transh', 36, True),
+                                         ('transe', 256, True), ('transh', 64, False)])
+def test_kg_ranks_count_route(model, d, l1):
+    """The pass without the score matrix on the VALU route (ktup_eval_kg_ranks_fused for L1, for widths without a matrix-core sweep
+    -- d = 50 is not even a multiple of 4 -- and for keys with more than 8 golds): the pair kernels count where they score, the
+    list scores come from the same function; repeated entity rows (ties everywhere), a NaN row, keys whose gold is filtered, keys
+    without golds -- the integers of the matrix route."""
+    rng = np.random.RandomState(17 + d)
+    ne, nr, nq = 3100, 9, 150
+    gen = torch.Generator().manual_seed(d)
+    E = O.make_table(ne, d, gen)
+    E[2000:] = E[:1100]                                               # a third of the table repeats another third: exact ties
+    E[1500] = float('nan')
+    R, N = O.make_table(nr, d, gen), O.make_table(nr, d, gen)
+    q = torch.from_numpy(rng.randint(0, ne, size=nq)); r = torch.from_numpy(rng.randint(0, nr, size=nq))
+    _, filt, gold, f_off, f_ids, g_off, g_ids = _rank_case(rng, nq, ne, 40, 12 if d == 64 else 5, 0)    # d = 64: up to 15 golds per key
+    Ed, Rd, Nd = dv(E.numpy()), dv(R.numpy()), dv(N.numpy())
+    Nn = Nd if model == 'transh' else None
+    for head in (True, False):
+        for desc in (False, True):
+            a = ops().eval_kg_ranks(Ed, Rd, Nn, q.to(DEV), r.to(DEV), l1, head, desc, dv(g_off), dv(g_ids), dv(f_off), dv(f_ids))
+            b = ops().eval_kg_ranks(Ed, Rd, Nn, q.to(DEV), r.to(DEV), l1, head, desc, dv(g_off), dv(g_ids), dv(f_off), dv(f_ids), fused=False)
+            assert torch.equal(a, b)
+        a = ops().eval_kg_ranks(Ed, Rd, Nn, q.to(DEV), r.to(DEV), l1, head, False, dv(g_off), dv(g_ids))
+        b = ops().eval_kg_ranks(Ed, Rd, Nn, q.to(DEV), r.to(DEV), l1, head, False, dv(g_off), dv(g_ids), fused=False)
+        assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('model,wtab', [('transe', 1), ('transh', 1), ('transh', 0)])
 def test_kg_ranks_without_score_matrix_ties_and_modes(model, wtab):
     """The fused pass compares scores as floats and falls back to the 64-bit keys where a lane sees equality or a NaN: an entity table

@@ -23,7 +23,8 @@ def main():
     torch.manual_seed(1)
     ne, nr, d, nq = 14709, 20, 100, 20480
     model = sys.argv[1] if len(sys.argv) > 1 else 'transh'
-    m = (transE.TransEModel if model == 'transe' else transH.TransHModel)(False, d, ne, nr).to(dev)
+    l1 = len(sys.argv) > 2 and sys.argv[2] == 'l1'
+    m = (transE.TransEModel if model == 'transe' else transH.TransHModel)(l1, d, ne, nr).to(dev)
     m.eval(); m.disable_grad()
     FL = types.SimpleNamespace(topn=10)
     keys = list(dict.fromkeys((int(rng.randint(ne)), int(rng.randint(nr))) for _ in range(nq + 2000)))[:nq]
@@ -45,7 +46,7 @@ def main():
     walk_ms, a = timed()
     pass_ms, b = timed(rank_fn=rank_fn)
     assert np.array_equal(a, b)
-    print('KG evaluation pass, %d keys x %d entities (%s, d=%d), %d gold entries:' % (len(keys), ne, model, d, a.shape[0]))
+    print('KG evaluation pass, %d keys x %d entities (%s%s, d=%d), %d gold entries:' % (len(keys), ne, model, ' L1' if l1 else '', d, a.shape[0]))
     print('  walk over %d batches (K13 + K18 per batch from python): %8.2f ms per pass   mean rank %.2f' % (len(batches), walk_ms, a[:, 1].mean()))
     print('  whole pass behind one call (ktup_eval_kg_ranks):        %8.2f ms per pass   mean rank %.2f' % (pass_ms, b[:, 1].mean()))
 

@@ -5,7 +5,7 @@
     seg_bwd     the large-batch backwards by sorted segments: TransE (307,200 triples) and KTUP (716,800 pairs), 5 each
     kg_rank     the filtered gold ranks of one 512-query KG evaluation batch over 14,709 entities (ktup_eval_gold_ranks), 10 calls
     kg_pass     one direction of a link-prediction pass, 20,480 keys x 14,709 entities behind one call (ktup_eval_kg_ranks, TransH), 3 passes
-    kg_pass_e   the same for TransE
+    kg_pass_e   the same for TransE;  kg_pass_l1 / kg_pass_e_l1: with the L1 distance (the pair kernels' COUNT form)
     hard_pass   the ST-Gumbel gate's evaluation pass in one sweep (TUP, 6040 users x 3240 items, ktup_eval_pref_topk_hard), 3 passes,
                 then the batched route over the same users (pairs_hard_kernel + K17 per 512 users), once
 tools/pmc_summary.py turns the counter_collection.csv into per-kernel averages."""
@@ -99,7 +99,7 @@ def kg_rank(dev):
     torch.cuda.synchronize()
 
 
-def kg_pass(dev, transe=False):
+def kg_pass(dev, transe=False, l1=False):
     from jTransUP.hip import ops
     gen = torch.Generator().manual_seed(7)
     nq = 20480
@@ -114,7 +114,7 @@ def kg_pass(dev, transe=False):
     f_off = (torch.arange(nq + 1) * 20).to(dev)
     f_ids = strict(20).to(dev, torch.int32)
     for _ in range(3):
-        ops.eval_kg_ranks(E, R, None if transe else N, q, r, False, False, False, g_off, g_ids, f_off, f_ids)
+        ops.eval_kg_ranks(E, R, None if transe else N, q, r, l1, False, False, g_off, g_ids, f_off, f_ids)
     torch.cuda.synchronize()
 
 
@@ -137,4 +137,4 @@ def hard_pass(dev):
 
 
 if __name__ == '__main__':
-    {'kg_pass': kg_pass, 'kg_pass_e': lambda d: kg_pass(d, True), 'hard_pass': hard_pass, 'kg_rank': kg_rank, 'eval_pass': eval_pass, 'train_step': train_step, 'fed_step': fed_step, 'seg_bwd': seg_bwd}[sys.argv[1]](torch.device('cuda'))
+    {'kg_pass': kg_pass, 'kg_pass_e': lambda d: kg_pass(d, True), 'kg_pass_e_l1': lambda d: kg_pass(d, True, True), 'kg_pass_l1': lambda d: kg_pass(d, False, True), 'hard_pass': hard_pass, 'kg_rank': kg_rank, 'eval_pass': eval_pass, 'train_step': train_step, 'fed_step': fed_step, 'seg_bwd': seg_bwd}[sys.argv[1]](torch.device('cuda'))

@@ -22,7 +22,8 @@
 // (relations x candidates) table once per pass with the same MFMA sequence (mode 2), and the sweep is TransE's plus four table
 // look-ups per lane and stage, fetched one stage ahead -- half the matrix instructions of mode 1 (both products in the sweep), which
 // stays for relation counts whose table would not fit.
-// Covers d in {20, 36, 64, 100, 128}, at most GM = 8 golds per key (the caller checks; otherwise the chunked matrix route runs).
+// The sweep covers squared L2 at d in {20, 36, 64, 100, 128}; L1 and every other width take the pair kernels' COUNT form
+// (ktup_eval.hip kg_valu_counts) behind the same entry point, with this file's finalize step.
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -34,8 +35,8 @@
 namespace ktup {
 namespace {
 
-constexpr int IB = 64, UB = 64, NW = 16, GM = 8, GS = 4, NBAND = 8;   // GM: most golds per key; GS: golds a sweep launch counts for (a second
-                                                                      // launch takes golds 4..7 of the few keys that have them)
+constexpr int IB = 64, UB = 64, NW = 16, GS = 4, NBAND = 8;   // GS: golds a sweep launch counts for (further launches take golds
+                                                              // 4.., 8.. of the few keys that have them)
 
 // MODE 0: TransE; 1: TransH, both products in the sweep; 2: TransH, w.e from the (relations x candidates) table
 template <int NCH_, int MODE_>

@@ -320,9 +320,57 @@ __global__ __launch_bounds__(256) void gold_ranks_chunked_kernel(const float* __
 // the gold set, precision = hits / len(list), recall = hits / |gold|, F1, hit flag and NDCG with method-0 weights
 // (1, 1, 1/log2(3), ...) whose ideal is the best ordering of the OBSERVED hits.  One thread per query, float64 like the
 // reference; the gold ids of a query are ascending (binary search).
+// Sixteen lanes per query (topn <= 16: lane r looks entry r up, the four dependent loads of its binary search beside the others');
+// the float64 sums are then formed by the group's first lane in list order, as one thread per query formed them (that form was a chain of
+// ~40 dependent loads per query: 10 us for the 6040 users of an ml1m pass); longer lists keep the one-thread loop.
 __global__ __launch_bounds__(64) void rec_metrics_kernel(const int32_t* __restrict__ top_ids, int64_t nq, int topn,
                                                          const int64_t* __restrict__ gold_off,
                                                          const int32_t* __restrict__ gold_ids, double* __restrict__ out) {
+  auto lookup = [&](int32_t id, int64_t g0, int64_t g1) {
+    int64_t lo = g0, hi = g1;
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (gold_ids[mid] < id) lo = mid + 1; else hi = mid;
+    }
+    return lo < g1 && gold_ids[lo] == id;
+  };
+  auto finish = [&](int64_t b, int k, int hc, double dcg, int64_t ngold) {
+    double f1 = 0.0, p = 0.0, rc = 0.0, ndcg = 0.0;
+    if (hc > 0) {
+      p = (double)hc / (double)k;
+      rc = (double)hc / (double)ngold;
+      f1 = 2.0 * p * rc / (p + rc);
+      double ideal = 1.0;                         // hc hits in the first hc positions
+      for (int c = 1; c < hc; ++c) ideal += 1.0 / log2((double)(c + 1));
+      ndcg = dcg / ideal;
+    }
+    double* o = out + b * 5;
+    o[0] = f1; o[1] = p; o[2] = rc; o[3] = hc > 0 ? 1.0 : 0.0; o[4] = ndcg;
+  };
+  if (topn <= 16) {
+    const int lane = threadIdx.x, r = lane & 15, grp = lane >> 4;
+    const int64_t b = (int64_t)blockIdx.x * 4 + grp;
+    const bool on = b < nq;
+    const int64_t g0 = on ? gold_off[b] : 0, g1 = on ? gold_off[b + 1] : 0;
+    const int32_t id = (on && r < topn) ? top_ids[b * topn + r] : -1;
+    const bool valid = id >= 0;                    // -1 padding: the reference's list is simply shorter
+    const bool hit = valid && lookup(id, g0, g1);
+    const uint32_t vmask = (uint32_t)(__builtin_amdgcn_ballot_w64(valid) >> (16 * grp)) & 0xffffu;
+    uint32_t hmask = (uint32_t)(__builtin_amdgcn_ballot_w64(hit) >> (16 * grp)) & 0xffffu;
+    if (on && r == 0) {
+      int hc = 0;
+      double dcg = 0.0;
+      while (hmask) {                              // hits in list order; position = valid entries before it
+        const int pos = __builtin_ctz(hmask);
+        hmask &= hmask - 1;
+        const int k = __popc(vmask & ((1u << pos) - 1u));
+        hc += 1;
+        dcg += k == 0 ? 1.0 : 1.0 / log2((double)(k + 1));
+      }
+      finish(b, __popc(vmask), hc, dcg, g1 - g0);
+    }
+    return;
+  }
   const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
   if (b >= nq) return;
   const int64_t g0 = gold_off[b], g1 = gold_off[b + 1];
@@ -330,31 +378,15 @@ __global__ __launch_bounds__(64) void rec_metrics_kernel(const int32_t* __restri
   double dcg = 0.0;
   for (int r = 0; r < topn; ++r) {
     const int32_t id = top_ids[b * topn + r];
-    if (id < 0) continue;                       // -1 padding: the reference's list is simply shorter
+    if (id < 0) continue;
     // position in the reference's (shorter) list = number of valid entries before it; padding only ever trails
-    int64_t lo = g0, hi = g1;
-    while (lo < hi) {
-      const int64_t mid = (lo + hi) >> 1;
-      if (gold_ids[mid] < id) lo = mid + 1; else hi = mid;
-    }
-    const bool hit = lo < g1 && gold_ids[lo] == id;
-    if (hit) {
+    if (lookup(id, g0, g1)) {
       hc += 1;
       dcg += k == 0 ? 1.0 : 1.0 / log2((double)(k + 1));
     }
     k += 1;
   }
-  double f1 = 0.0, p = 0.0, rc = 0.0, ndcg = 0.0;
-  if (hc > 0) {
-    p = (double)hc / (double)k;
-    rc = (double)hc / (double)(g1 - g0);
-    f1 = 2.0 * p * rc / (p + rc);
-    double ideal = 1.0;                         // hc hits in the first hc positions
-    for (int c = 1; c < hc; ++c) ideal += 1.0 / log2((double)(c + 1));
-    ndcg = dcg / ideal;
-  }
-  double* o = out + b * 5;
-  o[0] = f1; o[1] = p; o[2] = rc; o[3] = hc > 0 ? 1.0 : 0.0; o[4] = ndcg;
+  finish(b, k, hc, dcg, g1 - g0);
 }
 
 constexpr int CHUNK_KEYS = 16384;  // 128 KB of keys per chunk
@@ -512,7 +544,7 @@ extern "C" int ktup_eval_rec_metrics(const int32_t* top_ids, int64_t nq, int top
   KTUP_REQUIRE(nq >= 0 && topn > 0, "%s: bad sizes", name);
   if (nq == 0) return KTUP_OK;
   KTUP_REQUIRE(top_ids && gold_off && gold_ids && out, "%s: null pointer argument", name);
-  hipLaunchKernelGGL(rec_metrics_kernel, dim3((unsigned)((nq + 63) / 64)), dim3(64), 0, (hipStream_t)stream, top_ids, nq, topn,
-                     gold_off, gold_ids, out);
+  hipLaunchKernelGGL(rec_metrics_kernel, dim3((unsigned)(topn <= 16 ? (nq + 3) / 4 : (nq + 63) / 64)), dim3(64), 0, (hipStream_t)stream, top_ids, nq,
+                     topn, gold_off, gold_ids, out);
   return check_launch(name);
 }

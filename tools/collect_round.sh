@@ -7,7 +7,7 @@ R=$(pwd)
 P=$R/gpurun_out/profiles
 mkdir -p $P
 timeout 900 python tools/collect_profiles.py $TAG > $R/gpurun_out/${TAG}_collect.log 2>&1
-for W in train_step fed_step eval_pass seg_bwd kg_rank kg_pass kg_pass_e hard_pass; do
+for W in train_step fed_step eval_pass seg_bwd kg_rank kg_pass kg_pass_e kg_pass_e_l1 hard_pass; do
   rm -rf /tmp/kp_$W
   (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kp_$W -- python $R/tools/pmc_workloads.py $W > /dev/null 2>&1)
   F=$(find /tmp/kp_$W -name "*kernel_stats.csv" | head -1)
@@ -38,6 +38,8 @@ timeout 600 python tools/kernel_times.py > $P/${TAG}_kernel_times.txt 2>/dev/nul
 timeout 400 python tools/cli_throughput.py > $P/${TAG}_cli_throughput.txt 2>/dev/null
 timeout 300 python tools/kg_eval_pass.py transh > $P/${TAG}_kg_eval_pass.txt 2>/dev/null
 timeout 300 python tools/kg_eval_pass.py transe >> $P/${TAG}_kg_eval_pass.txt 2>/dev/null
+timeout 300 python tools/kg_eval_pass.py transe l1 >> $P/${TAG}_kg_eval_pass.txt 2>/dev/null
+timeout 300 python tools/kg_eval_pass.py transh l1 >> $P/${TAG}_kg_eval_pass.txt 2>/dev/null
 (T=$(python -c 'import torch,os;print(os.path.dirname(torch.__file__))')/lib; echo "== LD_PRELOAD=torch/lib/libamdhip64.so"; LD_PRELOAD=$T/libamdhip64.so timeout 300 tools/graph_memset_repro; echo "== /opt/rocm/lib"; timeout 300 tools/graph_memset_repro) > $P/${TAG}_graph_memset_repro.txt 2>/dev/null
 timeout 300 python tools/graph_memset_repro.py > $P/${TAG}_graph_memset_repro_torch.txt 2>/dev/null
 timeout 120 tools/gumbel_log_check > $P/${TAG}_gumbel_log_check.txt 2>/dev/null

@@ -241,6 +241,44 @@ def test_hard_gate_pass_in_one_sweep(l1, noise):
         assert torch.equal(nf, G.topk_filtered(mat, False, topn))
 
 
+def _host_philox_uniforms(seed, first, count):
+    """u01 of the library's Philox4x32-10 stream (csrc/ktup_common.h: counter = (block, 0x4b545550), key = seed; draw i is word i & 3 of
+    block i >> 2; 24-bit lattice) at positions first .. first + count - 1, in numpy."""
+    idx = np.arange(first, first + count, dtype=np.uint64)
+    blk = idx >> np.uint64(2)
+    c = [(blk & np.uint64(0xffffffff)).astype(np.uint64), (blk >> np.uint64(32)).astype(np.uint64),
+         np.full(count, 0x4b545550, np.uint64), np.zeros(count, np.uint64)]
+    a, b = np.uint64(seed & 0xffffffff), np.uint64((seed >> 32) & 0xffffffff)
+    M = np.uint64(0xffffffff)
+    for _ in range(10):
+        m0, m1 = np.uint64(0xD2511F53) * c[0], np.uint64(0xCD9E8D57) * c[2]
+        hi0, lo0, hi1, lo1 = m0 >> np.uint64(32), m0 & M, m1 >> np.uint64(32), m1 & M
+        c = [(hi1 ^ c[1] ^ a) & M, lo1, (hi0 ^ c[3] ^ b) & M, lo0]
+        a, b = (a + np.uint64(0x9E3779B9)) & M, (b + np.uint64(0xBB67AE85)) & M
+    words = np.stack(c, axis=1)[np.arange(count), (idx & np.uint64(3)).astype(np.int64)]
+    return ((words >> np.uint64(8)).astype(np.float32) * np.float32(1.0 / 16777216.0)).astype(np.float32)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('P,offset', [(20, 0), (20, 4 * 555 + 3), (13, 7), (4, 1)])
+def test_eval_philox_stream_is_the_documented_one(P, offset):
+    """The hard gate's device noise: pair (b, j), preference p draws at stream position ((b n_items + j) P + p) + offset of
+    Philox4x32-10(seed) -- the scores of a Philox call equal those of the same call fed the uniforms a host Philox produces for those
+    positions (P % 4 == 0 walks the stream block by block, other P index by index: both against the same host stream)."""
+    d, nu, ni, nq = 64, 40, 90, 11
+    gen = torch.Generator().manual_seed(P)
+    mk = lambda r: O.make_table(r, d, gen).to(DEV)
+    U, I, Pm, Pn = mk(nu), mk(ni), mk(P), mk(P)
+    u = torch.randint(0, nu, (nq,), generator=gen).to(DEV)
+    seed = 0x0123456789abcdef
+    uni = torch.from_numpy(_host_philox_uniforms(seed, offset, nq * ni * P).reshape(nq, ni, P)).to(DEV)
+    G = ops()
+    for l1 in (False, True):
+        a = G.eval_tup(U, I, Pm, Pn, u, l1, G.GUMBEL_PHILOX, None, seed, offset)
+        b = G.eval_tup(U, I, Pm, Pn, u, l1, G.GUMBEL_INPUT, uni)
+        assert torch.equal(a, b)
+
+
 def _rank_case(rng, nq, nc, nf, max_gold, quant):
     scores = (rng.randint(0, quant, size=(nq, nc)) / 7.0).astype(np.float32) if quant else rng.randn(nq, nc).astype(np.float32)
     scores[0, ::3] = -0.0

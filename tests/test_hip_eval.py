@@ -279,6 +279,21 @@ def test_eval_philox_stream_is_the_documented_one(P, offset):
         assert torch.equal(a, b)
 
 
+@pytest.mark.gpu
+def test_fast_gate_choice_equals_the_logf_choice_at_scale():
+    """207,360 (user, item) pairs at ml1m's item count: the Philox mode (hardware logarithm + a logf redo inside the proven margin) against
+    the given-uniforms mode (logf throughout) on the same stream -- every score identical, i.e. every gate choice."""
+    d, nu, ni, nq, P = 100, 64, 3240, 64, 20
+    gen = torch.Generator().manual_seed(99)
+    mk = lambda r: O.make_table(r, d, gen).to(DEV)
+    U, I, Pm, Pn = mk(nu), mk(ni), mk(P), mk(P)
+    u = torch.arange(nq).to(DEV)
+    seed, offset = 0xfeedface12345678, 4 * 123456 + 2
+    uni = torch.from_numpy(_host_philox_uniforms(seed, offset, nq * ni * P).reshape(nq, ni, P)).to(DEV)
+    G = ops()
+    assert torch.equal(G.eval_tup(U, I, Pm, Pn, u, False, G.GUMBEL_PHILOX, None, seed, offset), G.eval_tup(U, I, Pm, Pn, u, False, G.GUMBEL_INPUT, uni))
+
+
 def _rank_case(rng, nq, nc, nf, max_gold, quant):
     scores = (rng.randint(0, quant, size=(nq, nc)) / 7.0).astype(np.float32) if quant else rng.randn(nq, nc).astype(np.float32)
     scores[0, ::3] = -0.0

@@ -289,8 +289,10 @@ int ktup_eval_pref_topk(const float* U, int64_t ldu, const float* I, int64_t ldi
 /* The same pass for the HARD (ST-Gumbel) gate and for L1 (transUP.py:84-102 with use_st_gumbel; csrc/ktup_eval.hip
  * sweep_hard_kernel): the pair arithmetic and the noise stream positions of ktup_eval_pref_scores -- the scores are that call's
  * bits for the same (gumbel_mode, uniform, seed, offset) over all nq users at once, i.e. pair (b, j) draws at
- * ((b * n_items + j) * n_pref + p) + offset -- with the filtered top-n taken where the scores are made.  gumbel_mode must name a
- * noise source (KTUP_GUMBEL_INPUT: uniform is (nq x n_items x n_pref)); any d % 4 == 0, n_pref <= 32, topn <= 16.            */
+ * ((b * n_items + j) * n_pref + p) + offset -- with the filtered top-n taken where the scores are made (KTUP_GUMBEL_INPUT: uniform
+ * is (nq x n_items x n_pref)); any d % 4 == 0, n_pref <= 32, topn <= 16.  gumbel_mode == KTUP_GUMBEL_OFF: the SOFT gate scored pair
+ * by pair (the arithmetic of ktup_eval_pref_scores, its bits) with the same epilogue -- the one-sweep pass for L1 and for widths
+ * ktup_eval_pref_topk does not cover (d <= 168); KTUP_ERR_UNSUPPORTED where the stage does not fit the LDS.                    */
 size_t ktup_eval_pref_topk_hard_workspace_bytes(int d, int n_pref, int64_t nq, int64_t n_items, int topn);
 int ktup_eval_pref_topk_hard(const float* U, int64_t ldu, const float* I, int64_t ldi, const float* E, int64_t lde,
                              const int32_t* item2ent, const float* pref_ws, int n_pref, int d, const int64_t* u_ids, int64_t nq,

@@ -486,7 +486,102 @@ struct SweepHardArgs {
   int topn, nsplit; int64_t split_items; uint64_t* part; int bm_words;
 };
 
-__host__ __device__ inline size_t sweep_wave_bytes(int bm_words, int topn) { return (size_t)SW_UW * topn * 8 + (size_t)SW_UW * 8 + (size_t)SW_UW * 4 + (size_t)SW_UW * bm_words * 4 + 4; }
+// ---- what every sweep keeps per wave in LDS for its UW users: sorted lists [UW][topn] u64 | n-th keys [UW] u64 | n-th scores [UW]
+// (NaN while a list is short) | filter bits of the workgroup's catalogue split [UW][bm_words]
+__host__ __device__ inline size_t sweep_wave_bytes(int uw, int bm_words, int topn) {
+  return (((size_t)uw * topn * 8 + (size_t)uw * 8 + (size_t)uw * 4 + (size_t)uw * bm_words * 4) + 7) & ~(size_t)7;
+}
+struct SweepState { uint64_t *tk, *thrk; float* thrf; uint32_t* bm; int topn, bm_words; };
+
+// lists empty, thresholds open (rows past the end: closed), the filter bitmap of items [i_lo, i_hi) from the CSR lists -- the wave's UW
+// users are consecutive, so their lists are one run of ids that all 64 lanes walk together (sixteen loads in flight per lane)
+template <int UW>
+KTUP_DEV SweepState sweep_state_init(char* wb, int topn, int bm_words, int64_t u0, int64_t nq, const int64_t* __restrict__ filt_off,
+                                     const int32_t* __restrict__ filt_ids, int64_t i_lo, int64_t i_hi, int lane) {
+  SweepState st;
+  st.tk = reinterpret_cast<uint64_t*>(wb); st.thrk = st.tk + UW * topn; st.thrf = reinterpret_cast<float*>(st.thrk + UW);
+  st.bm = reinterpret_cast<uint32_t*>(st.thrf + UW); st.topn = topn; st.bm_words = bm_words;
+  for (int idx = lane; idx < UW * topn; idx += 64) st.tk[idx] = SKEY_MAX;
+  if (lane < UW) { st.thrk[lane] = u0 + lane < nq ? SKEY_MAX : 0; st.thrf[lane] = u0 + lane < nq ? __uint_as_float(0x7fffffffu) : -__builtin_inff(); }
+  for (int idx = lane; idx < UW * bm_words; idx += 64) st.bm[idx] = 0u;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  if (filt_off) {
+    const int64_t uo = u0 + (lane < UW ? lane : UW);
+    const int64_t myoff = filt_off[uo < nq ? uo : nq];
+    const int64_t f_begin = __shfl(myoff, 0, 64), f_end = __shfl(myoff, UW, 64);
+    uint32_t rel[UW > 1 ? UW - 1 : 1];
+#pragma unroll
+    for (int k = 0; k < UW - 1; ++k) rel[k] = (uint32_t)(__shfl(myoff, k + 1, 64) - f_begin);
+    const int64_t span = i_hi - i_lo;
+    constexpr int FB = 16;
+    for (int64_t base = f_begin; base < f_end; base += 64 * FB) {
+      int32_t ids[FB];
+#pragma unroll
+      for (int k = 0; k < FB; ++k) {
+        const int64_t f = base + lane + 64 * k;
+        ids[k] = f < f_end ? filt_ids[f] : -1;
+      }
+#pragma unroll
+      for (int k = 0; k < FB; ++k) {
+        const int64_t id = (int64_t)ids[k] - i_lo;
+        const uint32_t pos = (uint32_t)(base - f_begin) + lane + 64 * k;
+        int r = 0;
+#pragma unroll
+        for (int q = 0; q < UW - 1; ++q) r += pos >= rel[q] ? 1 : 0;
+        if (ids[k] >= 0 && id >= 0 && id < span) atomicOr(st.bm + r * bm_words + (id >> 5), 1u << (id & 31));
+      }
+    }
+  }
+  return st;
+}
+
+// the lane's score of (user r of the wave, item): a candidate if it is below the user's n-th score (floats; the keys decide equality and
+// NaNs) and its filter bit is clear; the wave inserts its candidates into the user's sorted list one by one at ballot positions
+KTUP_DEV void sweep_rank(const SweepState& st, int r, float acc, int64_t item, bool iok, int64_t lid, int lane) {
+  const int topn = st.topn;
+  const float tf = st.thrf[r];
+  bool c = acc < tf;
+  const bool tie = !c && !(acc > tf);
+  if (__builtin_amdgcn_ballot_w64(tie)) {
+    if (tie) c = sweep_key(acc, (uint32_t)item) < st.thrk[r];
+  }
+  c = c && iok;
+  if (c) c = ((st.bm[r * st.bm_words + (lid >> 5)] >> (lid & 31)) & 1u) == 0u;
+  uint64_t m = __builtin_amdgcn_ballot_w64(c);
+  if (m) {
+    const uint64_t mine = sweep_key(acc, (uint32_t)item);
+    uint64_t list = lane < topn ? st.tk[r * topn + lane] : SKEY_MAX;     // lanes 0..topn-1: the sorted list
+    while (m) {
+      const int src = __builtin_ctzll(m);
+      m &= m - 1;
+      const uint64_t k = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mine >> 32), src) << 32) |
+                         (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mine, src);
+      const int pos = __popcll(__builtin_amdgcn_ballot_w64(list < k));  // entries below the newcomer (lanes >= topn hold MAX)
+      if (pos < topn) {
+        const uint64_t up = ((uint64_t)(uint32_t)__shfl_up((int)(uint32_t)(list >> 32), 1, 64) << 32) | (uint32_t)__shfl_up((int)(uint32_t)list, 1, 64);
+        list = lane < pos ? list : (lane == pos ? k : up);
+        if (lane >= topn) list = SKEY_MAX;
+      }
+    }
+    if (lane < topn) st.tk[r * topn + lane] = list;
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(list >> 32), topn - 1);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)list, topn - 1);
+    if (lane == 0) {
+      st.thrk[r] = ((uint64_t)hi << 32) | lo;
+      st.thrf[r] = __uint_as_float((hi & 0x80000000u) ? (hi & 0x7fffffffu) : ~hi);   // inverse image; NaN while the list is short
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+template <int UW>
+KTUP_DEV void sweep_store(const SweepState& st, uint64_t* __restrict__ part, int nsplit, int split, int64_t u0, int64_t nq, int lane) {
+  if (lane < st.topn)
+    for (int r = 0; r < UW; ++r)
+      if (u0 + r < nq) part[((u0 + r) * nsplit + split) * st.topn + lane] = st.tk[r * st.topn + lane];
+}
 
 template <int MODE>
 __global__ __launch_bounds__(SW_NW * 64) void sweep_hard_kernel(SweepHardArgs sa) {
@@ -496,47 +591,11 @@ __global__ __launch_bounds__(SW_NW * 64) void sweep_hard_kernel(SweepHardArgs sa
   const HardStage h = hard_stage_carve<MODE>(smem, a.d / 4, a.P, a.dp / 4);
   const int t = threadIdx.x, lane = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int topn = sa.topn;
-  char* wb = smem + hard_stage_floats<MODE>(a.d / 4, a.P, a.dp / 4) * 4 + (size_t)w * ((sweep_wave_bytes(sa.bm_words, topn) + 7) & ~(size_t)7);
-  uint64_t* tk = reinterpret_cast<uint64_t*>(wb);               // [users][topn] sorted lists
-  uint64_t* thrk = tk + SW_UW * topn;                           // [users] n-th keys
-  float* thrf = reinterpret_cast<float*>(thrk + SW_UW);         // [users] n-th scores (NaN while a list is short)
-  uint32_t* bm = reinterpret_cast<uint32_t*>(thrf + SW_UW);     // [users][bm_words] filter bits of this split
   const int64_t u0 = (int64_t)blockIdx.x * (SW_NW * SW_UW) + SW_UW * w;
   const int64_t i_lo = (int64_t)blockIdx.y * sa.split_items;
   const int64_t i_hi = min(a.n_cand, i_lo + sa.split_items);
-  for (int idx = lane; idx < SW_UW * topn; idx += 64) tk[idx] = SKEY_MAX;
-  if (lane < SW_UW) { thrk[lane] = u0 + lane < a.nq ? SKEY_MAX : 0; thrf[lane] = u0 + lane < a.nq ? __uint_as_float(0x7fffffffu) : -__builtin_inff(); }
-  for (int idx = lane; idx < SW_UW * sa.bm_words; idx += 64) bm[idx] = 0u;
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  if (sa.filt_off) {   // the wave's 16 users are consecutive: their filter lists are one run of the CSR ids (as in ktup_eval_pass.hip)
-    const int64_t uo = u0 + (lane < SW_UW ? lane : SW_UW);
-    const int64_t myoff = sa.filt_off[uo < a.nq ? uo : a.nq];
-    const int64_t f_begin = __shfl(myoff, 0, 64), f_end = __shfl(myoff, SW_UW, 64);
-    uint32_t rel[SW_UW - 1];
-#pragma unroll
-    for (int k = 0; k < SW_UW - 1; ++k) rel[k] = (uint32_t)(__shfl(myoff, k + 1, 64) - f_begin);
-    const int64_t span = i_hi - i_lo;
-    constexpr int FB = 16;
-    for (int64_t base = f_begin; base < f_end; base += 64 * FB) {
-      int32_t ids[FB];
-#pragma unroll
-      for (int k = 0; k < FB; ++k) {
-        const int64_t f = base + lane + 64 * k;
-        ids[k] = f < f_end ? sa.filt_ids[f] : -1;
-      }
-#pragma unroll
-      for (int k = 0; k < FB; ++k) {
-        const int64_t id = (int64_t)ids[k] - i_lo;
-        const uint32_t pos = (uint32_t)(base - f_begin) + lane + 64 * k;
-        int r = 0;
-#pragma unroll
-        for (int q = 0; q < SW_UW - 1; ++q) r += pos >= rel[q] ? 1 : 0;
-        if (ids[k] >= 0 && id >= 0 && id < span) atomicOr(bm + r * sa.bm_words + (id >> 5), 1u << (id & 31));
-      }
-    }
-  }
+  char* wb = smem + hard_stage_floats<MODE>(a.d / 4, a.P, a.dp / 4) * 4 + (size_t)w * sweep_wave_bytes(SW_UW, sa.bm_words, sa.topn);
+  const SweepState st = sweep_state_init<SW_UW>(wb, sa.topn, sa.bm_words, u0, a.nq, sa.filt_off, sa.filt_ids, i_lo, i_hi, lane);
   hard_stage_tables<MODE>(a, h, t, SW_NW * 64);
   const sptr4 QW = as_scalar(a.QW);
   for (int64_t j0 = i_lo; j0 < i_hi; j0 += CT) {
@@ -554,50 +613,80 @@ __global__ __launch_bounds__(SW_NW * 64) void sweep_hard_kernel(SweepHardArgs sa
       const uint64_t base = ((uint64_t)b * (uint64_t)a.n_cand + (uint64_t)gj) * (uint64_t)a.P;
       const int ps = gate_argmax(a.P, base, a.gumbel == KTUP_GUMBEL_INPUT, a.uniform, a.seed, a.offset,
                                  [&](int p) { return lane_entry(ur.ql, p) + h.lv[p * CT + lane]; });
-      const float acc = hard_pair_score<MODE>(a, h, QW, b, ur, ps, lane);
-      // ---- ranking: acc against user r's n-th score
-      const float tf = thrf[r];
-      bool c = acc < tf;
-      const bool tie = !c && !(acc > tf);
-      if (__builtin_amdgcn_ballot_w64(tie)) {
-        if (tie) c = sweep_key(acc, (uint32_t)item) < thrk[r];
-      }
-      c = c && iok;
-      if (c) c = ((bm[r * sa.bm_words + (lid >> 5)] >> (lid & 31)) & 1u) == 0u;
-      uint64_t m = __builtin_amdgcn_ballot_w64(c);
-      if (m) {
-        const uint64_t mine = sweep_key(acc, (uint32_t)item);
-        uint64_t list = lane < topn ? tk[r * topn + lane] : SKEY_MAX;     // lanes 0..topn-1: the sorted list
-        while (m) {
-          const int src = __builtin_ctzll(m);
-          m &= m - 1;
-          const uint64_t k = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mine >> 32), src) << 32) |
-                             (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mine, src);
-          const int pos = __popcll(__builtin_amdgcn_ballot_w64(list < k));  // entries below the newcomer (lanes >= 16 hold MAX)
-          if (pos < topn) {
-            const uint64_t up = ((uint64_t)(uint32_t)__shfl_up((int)(uint32_t)(list >> 32), 1, 64) << 32) | (uint32_t)__shfl_up((int)(uint32_t)list, 1, 64);
-            list = lane < pos ? list : (lane == pos ? k : up);
-            if (lane >= topn) list = SKEY_MAX;
-          }
-        }
-        if (lane < topn) tk[r * topn + lane] = list;
-        const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(list >> 32), topn - 1);
-        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)list, topn - 1);
-        if (lane == 0) {
-          thrk[r] = ((uint64_t)hi << 32) | lo;
-          thrf[r] = __uint_as_float((hi & 0x80000000u) ? (hi & 0x7fffffffu) : ~hi);   // inverse image; NaN while the list is short
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-      }
+      sweep_rank(st, r, hard_pair_score<MODE>(a, h, QW, b, ur, ps, lane), item, iok, lid, lane);
     }
   }
-  if (lane < topn) {
-    for (int r = 0; r < SW_UW; ++r) {
-      const int64_t b = u0 + r;
-      if (b < a.nq) sa.part[(b * sa.nsplit + blockIdx.y) * topn + lane] = tk[r * topn + lane];
-    }
+  sweep_store<SW_UW>(st, sa.part, sa.nsplit, blockIdx.y, u0, a.nq, lane);
+}
+
+// ---- the SOFT gate's pass with the pair arithmetic of pairs_kernel<2> (pair_group_scores: the scores are that route's bits), for L1
+// and for widths the preference-space pass (ktup_eval_pass.hip) does not cover.  16 waves x 3 users share a 64-item stage of the three
+// item arrays (v - RV, v, NV: 77 KB at d = 100, one workgroup per CU); the next stage's rows are in flight (registers) under the
+// scores of this one -- the per-batch kernel restages 77 KB per 52 users and spends more time staging than scoring.
+constexpr int SS_NW = 16, SS_UW = 3;
+struct SweepSoftArgs {
+  PairsArgs p;
+  const int64_t* filt_off; const int32_t* filt_ids;
+  int topn, nsplit; int64_t split_items; uint64_t* part; int bm_words;
+};
+template <bool L1>
+__global__ __launch_bounds__(SS_NW * 64) void sweep_soft_kernel(SweepSoftArgs sa) {
+  const PairsArgs& a = sa.p;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float4* cand = reinterpret_cast<float4*>(smem);                       // [3][nch4][CT]
+  const int t = threadIdx.x, lane = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int nch4 = a.dq / 4;
+  const int64_t u0 = (int64_t)blockIdx.x * (SS_NW * SS_UW) + SS_UW * w;
+  const int64_t i_lo = (int64_t)blockIdx.y * sa.split_items;
+  const int64_t i_hi = min(a.n_cand, i_lo + sa.split_items);
+  char* wb = smem + (size_t)3 * nch4 * CT * 16 + (size_t)w * sweep_wave_bytes(SS_UW, sa.bm_words, sa.topn);
+  const SweepState st = sweep_state_init<SS_UW>(wb, sa.topn, sa.bm_words, u0, a.nq, sa.filt_off, sa.filt_ids, i_lo, i_hi, lane);
+  const sptr4 QW = as_scalar(a.QW);
+  sptr4 qa[SS_UW], qn[SS_UW], q1p[SS_UW];
+#pragma unroll
+  for (int qi = 0; qi < SS_UW; ++qi) {
+    const int64_t b = min(u0 + qi, a.nq - 1);
+    qa[qi] = QW + b * 3 * nch4; q1p[qi] = qa[qi] + nch4; qn[qi] = qa[qi] + 2 * nch4;
   }
+  // a thread's share of a stage: 3 arrays x nch4 x 64 float4 over 1024 threads (at most PF each: d <= 168, the host side checks),
+  // fetched one stage ahead into registers
+  const int total = 3 * nch4 * CT;
+  constexpr int PF = 8;
+  float4 pre[PF];
+  const float* src[PF];
+  int dst[PF];
+#pragma unroll
+  for (int k = 0; k < PF; ++k) {
+    const int idx = t + k * SS_NW * 64;
+    const int arr = idx / (nch4 * CT), rem = idx - arr * nch4 * CT, c = rem >> 6;
+    const bool on = idx < total;
+    dst[k] = on ? (rem & (CT - 1)) : 0;                                  // the row inside the stage (slots past the end reload row 0: unused)
+    src[k] = on ? (arr == 0 ? a.C0 : (arr == 1 ? a.C1 : a.C2)) + 4 * c : a.C0;
+    pre[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+#define KTUP_SS_FETCH(J0)                                                                                                   \
+  _Pragma("unroll") for (int k = 0; k < PF; ++k)                                                                            \
+    pre[k] = *reinterpret_cast<const float4*>(src[k] + min((J0) + dst[k], a.n_cand - 1) * a.d);
+  KTUP_SS_FETCH(i_lo)
+  for (int64_t j0 = i_lo; j0 < i_hi; j0 += CT) {
+    __syncthreads();                                                    // the previous stage has been consumed
+#pragma unroll
+    for (int k = 0; k < PF; ++k)
+      if (t + k * SS_NW * 64 < total) cand[t + k * SS_NW * 64] = pre[k];
+    __syncthreads();
+    if (j0 + CT < i_hi) { KTUP_SS_FETCH(j0 + CT) }                      // in flight under the scores below
+    float acc[SS_UW];
+    pair_group_scores<2, L1, SS_UW>(cand, nch4, qa, qn, q1p, lane, acc);
+    const int64_t item = j0 + lane;
+    const bool iok = item < i_hi;
+    const int64_t lid = item - i_lo;
+#pragma unroll
+    for (int r = 0; r < SS_UW; ++r)
+      if (u0 + r < a.nq) sweep_rank(st, r, acc[r], item, iok, lid, lane);
+  }
+#undef KTUP_SS_FETCH
+  sweep_store<SS_UW>(st, sa.part, sa.nsplit, blockIdx.y, u0, a.nq, lane);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1217,10 +1306,9 @@ extern "C" int ktup_eval_pref_topk_hard(const float* U, int64_t ldu, const float
   KTUP_REQUIRE(nq >= 0 && n_items >= 0, "%s: bad sizes", name);
   if (nq == 0) return KTUP_OK;
   KTUP_REQUIRE(n_items > 0 && n_items < (1ll << 31) && topn >= 1 && topn <= 16 && n_pref <= 32, "%s: needs items, 32-bit item ids, topn <= 16 and at most 32 preferences", name);
-  KTUP_REQUIRE(gumbel_mode == KTUP_GUMBEL_INPUT || gumbel_mode == KTUP_GUMBEL_PHILOX || gumbel_mode == KTUP_GUMBEL_PHILOX_DEV,
-               "%s: the hard gate needs a noise source (the soft gate's pass is ktup_eval_pref_topk)", name);
+  KTUP_REQUIRE(gumbel_mode >= KTUP_GUMBEL_OFF && gumbel_mode <= KTUP_GUMBEL_PHILOX_DEV, "%s: bad gumbel_mode", name);
   KTUP_REQUIRE(U && I && pref_ws && u_ids && top_ids && ws && aligned16(ws), "%s: bad argument", name);
-  KTUP_REQUIRE((gumbel_mode == KTUP_GUMBEL_PHILOX) || uniform, "%s: KTUP_GUMBEL_INPUT / KTUP_GUMBEL_PHILOX_DEV need the `uniform` pointer", name);
+  KTUP_REQUIRE(gumbel_mode == KTUP_GUMBEL_OFF || gumbel_mode == KTUP_GUMBEL_PHILOX || uniform, "%s: KTUP_GUMBEL_INPUT / KTUP_GUMBEL_PHILOX_DEV need the `uniform` pointer", name);
   KTUP_REQUIRE((filt_off == nullptr) || filt_ids, "%s: filter offsets without ids", name);
   const PrefGeom g = pref_geom(d, n_pref);
   if (!g.ok) return set_error(KTUP_ERR_UNSUPPORTED, "%s: embedding_size must be a multiple of 4 in [4, 256] (got %d)", name, d);
@@ -1235,8 +1323,34 @@ extern "C" int ktup_eval_pref_topk_hard(const float* U, int64_t ldu, const float
   KTUP_REQUIRE(aligned16(U) && aligned16(pref_ws) && ldu % 4 == 0, "%s: tables must be 16-byte aligned with pitches %% 4 == 0", name);
   hipLaunchKernelGGL(pref_project_kernel, dim3(grid_for((nq + 3) / 4)), dim3(256), 0, st, U, ldu, (const float*)nullptr,
                      (int64_t)0, (const int32_t*)nullptr, u_ids, nq, d, n_pref, pref_ws, g.ppad, g.dp, 1.0f, (int64_t)3 * d, QW,
-                     QW + d, QW + 2 * d, QL, l1 ? (float*)nullptr : QN);
+                     QW + d, QW + 2 * d, QL, (l1 || gumbel_mode == KTUP_GUMBEL_OFF) ? (float*)nullptr : QN);
   if (int e = check_launch(name)) return e;
+  if (gumbel_mode == KTUP_GUMBEL_OFF) {           // the soft gate's pair arithmetic (pairs_kernel<2>) with the top-n in its epilogue
+    SweepSoftArgs ss{};
+    PairsArgs& pa = ss.p;
+    pa.C0 = it.CW0; pa.C1 = it.CW1; pa.C2 = it.CW2; pa.ldc0 = pa.ldc1 = pa.ldc2 = d;
+    pa.QW = QW; pa.n_cand = n_items; pa.nq = nq; pa.d = d; pa.dq = d; pa.l1 = l1; pa.cvec = 1;
+    ss.filt_off = filt_off; ss.filt_ids = filt_ids; ss.topn = topn; ss.part = part;
+    const int64_t ub = (nq + SS_NW * SS_UW - 1) / (SS_NW * SS_UW);
+    int ns = (int)(256 / ub);                       // one workgroup per CU is resident (the stage is 77 KB at d = 100): one round
+    if (ns > 8) ns = 8;
+    if (ns < 1) ns = 1;
+    const int64_t stg = (n_items + CT - 1) / CT;
+    if (ns > stg) ns = (int)stg;
+    ss.split_items = ((stg + ns - 1) / ns) * CT;
+    ns = (int)((n_items + ss.split_items - 1) / ss.split_items);
+    ss.nsplit = ns;
+    ss.bm_words = (int)((ss.split_items + 31) / 32);
+    const size_t sl = (size_t)3 * (d / 4) * CT * 16 + SS_NW * sweep_wave_bytes(SS_UW, ss.bm_words, topn);
+    if (sl > 160 * 1024 || 3 * (d / 4) * CT > 8 * SS_NW * 64) return set_error(KTUP_ERR_UNSUPPORTED, "%s: the stage needs %zu B of LDS (per-batch calls remain)", name, sl);
+    auto go = [&](auto kern) {
+      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sl);
+      hipLaunchKernelGGL(kern, dim3((unsigned)ub, (unsigned)ns), dim3(SS_NW * 64), sl, st, ss);
+    };
+    if (l1) go(sweep_soft_kernel<true>); else go(sweep_soft_kernel<false>);
+    if (int e = check_launch(name)) return e;
+    return ktup::launch_topk_merge(part, nq, ns, topn, top_ids, top_scores, st, name);
+  }
   SweepHardArgs sa{};
   HardArgs& h = sa.h;
   h.V = it.CW1; h.LV = it.CL; h.QW = QW; h.QL = QL; h.ws = pref_ws; h.ppad = g.ppad; h.dp = g.dp; h.P = n_pref; h.d = d;
@@ -1254,7 +1368,7 @@ extern "C" int ktup_eval_pref_topk_hard(const float* U, int64_t ldu, const float
   sa.nsplit = nsplit;
   sa.bm_words = (int)((sa.split_items + 31) / 32);
   const size_t lds = (l1 ? hard_stage_floats<1>(d / 4, n_pref, g.dp / 4) : hard_stage_floats<0>(d / 4, n_pref, g.dp / 4)) * 4 +
-                     SW_NW * ((sweep_wave_bytes(sa.bm_words, topn) + 7) & ~(size_t)7);
+                     SW_NW * sweep_wave_bytes(SW_UW, sa.bm_words, topn);
   if (lds > 160 * 1024 || ublocks > 0x7fffffffll)
     return set_error(KTUP_ERR_UNSUPPORTED, "%s: the stage needs %zu B of LDS (per-batch calls remain)", name, lds);
   const dim3 grid((unsigned)ublocks, (unsigned)nsplit);

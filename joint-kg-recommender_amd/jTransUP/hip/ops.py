@@ -581,13 +581,18 @@ def _eval_pref(U, I, E, pref, pref_norm, rel, norm, item2ent, u, l1, gumbel_mode
 @torch.no_grad()
 def eval_pref_topk(U, u, items, l1, topn, filt_off=None, filt_ids=None, with_scores=False):
     """Scores + filtered top-n of a whole evaluation pass in one sweep (ktup_eval_pref_topk): every user of `u` against the
-    item tables of `items`, no (users x items) matrix, no per-item projections.  -> int32 (len(u), topn) ids (-1 padded) [, scores], or None when the
-    fused pass does not cover the shape (L1, d outside {64, 100, 128}, topn > 16): keep eval_tup / eval_ktup + topk_filtered."""
+    item tables of `items`, no (users x items) matrix.  Squared L2 at d in {64, 100, 128}: the preference-space pass on the matrix cores;
+    L1 and other widths: the pair kernel's arithmetic swept with the top-n in its epilogue (the per-batch scores' bits).  -> int32
+    (len(u), topn) ids (-1 padded) [, scores], or None when no sweep covers the shape (topn > 16, very wide rows): keep eval_tup /
+    eval_ktup + topk_filtered."""
     dev = _dev(_table('user table', U))
     u = _ids('u_ids', u, dev)
     nq, d, P = u.numel(), items.d, items.P
-    if l1 or d not in (64, 100, 128) or not (0 < topn <= 16) or nq == 0 or not L.get_option('eval_mc'):
+    if not (0 < topn <= 16) or nq == 0:
         return None
+    if l1 or d not in (64, 100, 128) or not L.get_option('eval_mc'):
+        # no preference-space pass for this shape: the pair kernel's arithmetic with the top-n in its epilogue (or None: per-batch calls)
+        return eval_pref_topk_hard(U, u, items, l1, topn, GUMBEL_OFF, None, 0, 0, filt_off, filt_ids, with_scores)
     if filt_ids is not None and filt_ids.numel() == 0:
         filt_off = filt_ids = None
     top = torch.empty(nq, topn, dtype=torch.int32, device=dev)
@@ -614,8 +619,8 @@ def eval_pref_topk_hard(U, u, items, l1, topn, gumbel_mode, uniform=None, seed=0
         if uniform is None or tuple(uniform.shape) != (nq, ni, P) or uniform.dtype != torch.float32 or uniform.device != dev:
             raise L.KtupError('uniform must be an (n_users, n_items, n_pref) fp32 device tensor')
         uniform = uniform.contiguous()
-    elif gumbel_mode != GUMBEL_PHILOX:
-        raise L.KtupError('eval_pref_topk_hard needs GUMBEL_INPUT or GUMBEL_PHILOX')
+    elif gumbel_mode not in (GUMBEL_PHILOX, GUMBEL_OFF):
+        raise L.KtupError('eval_pref_topk_hard takes GUMBEL_INPUT, GUMBEL_PHILOX or GUMBEL_OFF (the soft gate scored pair by pair)')
     else:
         uniform = None
     if filt_ids is not None and filt_ids.numel() == 0:

@@ -557,7 +557,13 @@ def _fused_pass_case(d, nu, ni, nq, topn, pspace):
             a, b = ops().topk_filtered(mat, False, topn, with_scores=True)
             sc = torch.gather(mat, 1, nf[:64].clamp(min=0).long())
             _same_lists_up_to_rounding(nf[:64], sc, a, b, None, ni)
-    assert ops().eval_pref_topk(U, u, items, True, topn) is None              # L1 does not decompose: the caller keeps the matrix route
+    # L1 does not decompose into preference space: the pair kernel's arithmetic swept with the top-n in its epilogue -- that route's bits
+    for ktup in (True, False):
+        items = ops().eval_pref_items(I, E if ktup else None, Pm, Pn, R if ktup else None, Rn if ktup else None, i2e if ktup else None)
+        got = ops().eval_pref_topk(U, u, items, True, topn, f_off, f_ids, with_scores=True)
+        mat = ops().eval_ktup(U, I, E, Pm, Pn, R, Rn, i2e, u, True, items=items) if ktup else ops().eval_tup(U, I, Pm, Pn, u, True, items=items)
+        want = ops().topk_filtered(mat, False, topn, f_off, f_ids, with_scores=True)
+        assert got is not None and torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
 
 
 @pytest.mark.parametrize('d,ne,nrel', [(100, 3000, 20), (36, 500, 5), (64, 2049, 7)])

@@ -519,6 +519,46 @@ def eval_kg_bench(device, nq=20480, batch=512, seed=13):
                     '(ktup_eval_kg_ranks), one copy back of the ranks'}
 
 
+def eval_ktup_l1_bench(device, batch=512, seed=19):
+    """The reference's own run scripts evaluate KTUP / TUP with -L1_flag (ktup.sh, transup.sh): the whole 6040-user pass with the L1
+    distance, soft gate -- in one sweep (the pair kernel's arithmetic, top-10 in its epilogue) and batch by batch."""
+    import types
+    import numpy as np
+    from jTransUP.models import _driver as Dr
+    from jTransUP.models import jTransUP as jt
+    rng = np.random.RandomState(seed)
+    torch.manual_seed(seed)
+    i_map = {i: i for i in range(NI)}
+    new_map = {i: ((i * 4) % NE if i < ALIGNED else -1, i) for i in range(NI)}
+    m = jt.jTransUPModel(True, D, NU, NI, NE, NR, i_map, new_map, False, False).to(device)
+    m.eval(); m.disable_grad()
+    FL = types.SimpleNamespace(topn=10, shard_eval_candidates=False)
+    users = list(range(NU))
+    train = {u: set(rng.randint(0, NI, size=165).tolist()) for u in users}
+    gold = {u: set(rng.randint(0, NI, size=rng.randint(1, 31)).tolist()) - train[u] or {int(rng.randint(NI))} for u in users}
+    batches = [users[s_:s_ + batch] for s_ in range(0, NU, batch)]
+    items = m.prepare_items()
+    score_fn = lambda u: m.evaluateRec(u, items=items)
+    pass_fn = lambda u, fo, fi, n: m.evaluate_topk(u, m.prepare_items(), n, fo, fi)
+    import contextlib
+    with contextlib.redirect_stderr(open(os.devnull, 'w')):
+        def timed(**kw):
+            rows = Dr.rec_eval_pass(FL, score_fn, batches, gold, [train], False, want_rows=False, **kw)
+            torch.cuda.synchronize(device)
+            reps = 5
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                rows = Dr.rec_eval_pass(FL, score_fn, batches, gold, [train], False, want_rows=False, **kw)
+            return 1e3 * (time.perf_counter() - t0) / reps, rows
+        batched_ms, rows_b = timed()
+        pass_ms, rows = timed(pass_fn=pass_fn)
+    return {'model': 'KTUP d=%d, L1 distance, soft gate (the reference run scripts\' -L1_flag)' % D, 'users': NU, 'items': NI,
+            'full_pass_ms': pass_ms, 'batched_route': {'full_pass_ms': batched_ms},
+            'metric_rows_max_abs_diff_vs_batched_route': float(np.abs(rows - rows_b).max()) if rows.shape == rows_b.shape else None,
+            'note': 'full_pass_ms: one sweep (ktup_eval_pref_topk_hard with KTUP_GUMBEL_OFF: the pair kernel\'s arithmetic, filtered '
+                    'top-10 where the scores are made) + metrics; batched_route: K16 (VALU pair kernel) + K17 + K18b per 512 users'}
+
+
 def eval_tup_hard_bench(device, batch=512, seed=17):
     """BASELINE config 3's evaluation: TUP (transup) at d = 100, 20 preferences, -use_st_gumbel -- every one of the 6040 users
     against all 3240 items with the ST-Gumbel gate drawn per (user, item) pair (transUP.py:84-102,143-170: stochastic in the
@@ -1113,6 +1153,7 @@ def main():
         out['train_step_b512']['cpu_baseline'] = cpu_train_step_baseline(out['cpu_baseline']['cores'])
         out['eval_kg_transe'] = eval_kg_bench(device)
         out['eval_tup_hard_gate'] = eval_tup_hard_bench(device)
+        out['eval_ktup_l1'] = eval_ktup_l1_bench(device)
         out['eval_all_item_hit10']['cpu_baseline'] = cpu_eval_baseline(keep['m'], keep['users'], keep['gold'], keep['train'], keep['rows'])
     elif rank == 0:
         out['cpu_baseline'] = None

@@ -175,13 +175,20 @@ struct PairsWG { static constexpr int NWV = MODE == 2 ? 8 : 4, NT = NWV * 64; };
 // the scores of NQ queries (wave-uniform vectors through scalar loads) against the lane's candidate of the staged tile.  ONE function
 // for the score kernel, its COUNT form and the list kernel: the same instructions on the same operands, so a (query, candidate) pair
 // has the same bits wherever it is scored
+// The arithmetic is written on float PAIRS (v_pk_add_f32 / v_pk_fma_f32: two elements per ~5-clock issue against one per 4): these
+// kernels are bound by the vector pipe's issue rate, and every operand pair is naturally aligned (float4 chunks from s_load_dwordx4 /
+// ds_read_b128).  Dot products keep one partial sum per pair half; sum |z| has no packed form (no |.| modifier on packed operands).
+typedef float v2f __attribute__((ext_vector_type(2)));
+KTUP_DEV v2f lo2(float4 a) { return v2f{a.x, a.y}; }
+KTUP_DEV v2f hi2(float4 a) { return v2f{a.z, a.w}; }
+KTUP_DEV v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+
 template <int MODE, bool L1, int NQ>
 KTUP_DEV void pair_group_scores(const float4* cand, int nch4, const sptr4 (&qa)[NQ], const sptr4 (&qn)[NQ], const sptr4 (&q1p)[NQ], int lane,
                                 float (&acc)[NQ]) {
-  constexpr bool l1 = L1;
-  float s[NQ];
+  v2f s2[NQ], a2[NQ];
 #pragma unroll
-  for (int qi = 0; qi < NQ; ++qi) { s[qi] = 0.f; acc[qi] = 0.f; }
+  for (int qi = 0; qi < NQ; ++qi) { s2[qi] = v2f{0.f, 0.f}; a2[qi] = v2f{0.f, 0.f}; acc[qi] = 0.f; }
   if (MODE >= 1) {
     for (uint32_t c = 0; c < (uint32_t)nch4; ++c) {
       const float4 c1 = cand[((MODE == 2 ? 1 : 0) * nch4 + c) * CT + lane];
@@ -190,24 +197,47 @@ KTUP_DEV void pair_group_scores(const float4* cand, int nch4, const sptr4 (&qa)[
       for (int qi = 0; qi < NQ; ++qi) {
         const float4 nqv = sldp(qn[qi] + c);
         if constexpr (MODE == 2) {
-          s[qi] += dot4(sldp(q1p[qi] + c) - c1, nqv + nc);
-        } else {                      // TransH: s = -(e . w); no zero operands for the compiler to keep (x + 0 is not x for -0)
-          s[qi] -= dot4(c1, nqv);
+          const float4 q1 = sldp(q1p[qi] + c);
+          s2[qi] = fma2(lo2(q1) - lo2(c1), lo2(nqv) + lo2(nc), s2[qi]);
+          s2[qi] = fma2(hi2(q1) - hi2(c1), hi2(nqv) + hi2(nc), s2[qi]);
+        } else {                      // TransH: s = -(e . w)
+          s2[qi] = fma2(-lo2(c1), lo2(nqv), s2[qi]);
+          s2[qi] = fma2(-hi2(c1), hi2(nqv), s2[qi]);
         }
       }
     }
   }
+  v2f ms[NQ];
+#pragma unroll
+  for (int qi = 0; qi < NQ; ++qi) { const float s = s2[qi].x + s2[qi].y; ms[qi] = v2f{-s, -s}; }
   for (uint32_t c = 0; c < (uint32_t)nch4; ++c) {
     const float4 c0 = cand[c * CT + lane];
     const float4 nc = MODE == 2 ? cand[(2 * nch4 + c) * CT + lane] : f4zero();
 #pragma unroll
     for (int qi = 0; qi < NQ; ++qi) {
       const float4 av = sldp(qa[qi] + c);
-      float4 z = av - c0;
-      if constexpr (MODE == 2) z = fma4(-s[qi], sldp(qn[qi] + c) + nc, z);
-      if constexpr (MODE == 1) z = fma4(-s[qi], sldp(qn[qi] + c), z);
-      acc[qi] += dist4(z, l1);
+      v2f zl = lo2(av) - lo2(c0), zh = hi2(av) - hi2(c0);
+      if constexpr (MODE == 2) {
+        const float4 nqv = sldp(qn[qi] + c);
+        zl = fma2(ms[qi], lo2(nqv) + lo2(nc), zl);
+        zh = fma2(ms[qi], hi2(nqv) + hi2(nc), zh);
+      }
+      if constexpr (MODE == 1) {
+        const float4 nqv = sldp(qn[qi] + c);
+        zl = fma2(ms[qi], lo2(nqv), zl);
+        zh = fma2(ms[qi], hi2(nqv), zh);
+      }
+      if constexpr (L1) {
+        acc[qi] += (fabsf(zl.x) + fabsf(zl.y)) + (fabsf(zh.x) + fabsf(zh.y));
+      } else {
+        a2[qi] = fma2(zl, zl, a2[qi]);
+        a2[qi] = fma2(zh, zh, a2[qi]);
+      }
     }
+  }
+  if constexpr (!L1) {
+#pragma unroll
+    for (int qi = 0; qi < NQ; ++qi) acc[qi] = a2[qi].x + a2[qi].y;
   }
 }
 
@@ -293,25 +323,46 @@ __global__ __launch_bounds__(PairsWG<MODE>::NT) void pairs_kernel(PairsArgs a) {
     if constexpr (COUNT) {
       // per gold entry of each query: the candidates of this tile ordered before it -- (score, id) order of ktup_rank.hip's keys: a
       // lower score, or the same score and a lower id; NaNs on either side (uniform tests) go through the keys themselves
-      const bool in = j0 + lane < a.n_cand;
+      // Branch-free per gold: three compares into lane masks, mask arithmetic and a population count on the scalar unit; the counts
+      // of the group's first TH golds per query collect in one register (lane qi * TH + k) and leave as ONE atomic instruction
+      // (written with short-circuit tests and an atomic per gold, the epilogue was ~45 instructions and 8 branches per gold:
+      // a third of the kernel at d = 100)
+      const uint64_t inm = __builtin_amdgcn_ballot_w64(j0 + lane < a.n_cand);
       const uint32_t cid = (uint32_t)(j0 + lane);
       const bool desc = a.descending != 0;
+      int cntv = 0;
 #pragma unroll
       for (int qi = 0; qi < QB; ++qi) {
         const float sc = desc ? -acc[qi] : acc[qi];
         const bool any_nan = __builtin_amdgcn_ballot_w64(sc != sc) != 0;
-        auto count = [&](float th0, uint32_t gid, int64_t g) {
-          const float th = desc ? -th0 : th0;
-          bool lt;
-          if (any_nan || th != th) lt = in && count_key(sc, cid) < count_key(th, gid);
-          else lt = in && (sc < th || (sc == th && cid < gid));
-          const int n = __popcll(__builtin_amdgcn_ballot_w64(lt));
-          if (n != 0 && lane == 0) atomicAdd(a.counts + g, n);
+        auto before = [&](float th0, uint32_t gid0) {
+          const float th = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(desc ? -th0 : th0)));
+          const uint32_t gid = (uint32_t)__builtin_amdgcn_readfirstlane((int)gid0);
+          uint64_t m;
+          if (any_nan || th != th) {
+            m = __builtin_amdgcn_ballot_w64(count_key(sc, cid) < count_key(th, gid));
+          } else {
+            const uint64_t lt = __builtin_amdgcn_ballot_w64(sc < th), eq = __builtin_amdgcn_ballot_w64(sc == th);
+            m = lt | (eq & __builtin_amdgcn_ballot_w64(cid < gid));
+          }
+          return (int)__popcll(m & inm);
         };
 #pragma unroll
         for (int k = 0; k < TH; ++k)
-          if (k < cng[qi]) count(cth[qi][k], cgid[qi][k], cg0[qi] + k);
-        for (int k = TH; k < cng[qi]; ++k) count(a.gscore[cg0[qi] + k], (uint32_t)a.gold_ids[cg0[qi] + k], cg0[qi] + k);
+          if (k < cng[qi]) {
+            const int n = before(cth[qi][k], cgid[qi][k]);
+            asm("v_writelane_b32 %0, %1, %2" : "+v"(cntv) : "s"(n), "i"(qi * TH + k));   // (no builtin for it in this compiler)
+          }
+        for (int k = TH; k < cng[qi]; ++k) {
+          const int n = before(a.gscore[cg0[qi] + k], (uint32_t)a.gold_ids[cg0[qi] + k]);
+          if (n != 0 && lane == 0) atomicAdd(a.counts + cg0[qi] + k, n);
+        }
+      }
+      {
+        static_assert(QB == 4 && TH == 4, "one lane per (query of the group, gold slot)");
+        const int sq = (lane >> 2) & 3;
+        const int64_t g = (sq == 0 ? cg0[0] : sq == 1 ? cg0[1] : sq == 2 ? cg0[2] : cg0[3]) + (lane & 3);
+        if (lane < QB * TH && cntv != 0) atomicAdd(a.counts + g, cntv);
       }
       continue;
     }
@@ -415,21 +466,37 @@ KTUP_DEV float hard_pair_score(const HardArgs& a, const HardStage& h, sptr4 QW, 
   if (MODE != 0) {
     const float4* cn = h.tabC + ps * dp4;
     const float4* ar = h.tabA + ps * dp4;
-    float s = 0.f;
-    for (uint32_t c = 0; c < (uint32_t)nch4; ++c) s += dot4(sldp(ub + c) - h.cand[c * CT + lane], cn[c]);
+    v2f s2 = v2f{0.f, 0.f};                         // float pairs, as in pair_group_scores
+    for (uint32_t c = 0; c < (uint32_t)nch4; ++c) {
+      const float4 u = sldp(ub + c), e = h.cand[c * CT + lane], n = cn[c];
+      s2 = fma2(lo2(u) - lo2(e), lo2(n), s2);
+      s2 = fma2(hi2(u) - hi2(e), hi2(n), s2);
+    }
+    const float s = s2.x + s2.y;
+    const v2f ms = v2f{-s, -s};
+    v2f a2 = v2f{0.f, 0.f};
     float acc = 0.f;
     for (uint32_t c = 0; c < (uint32_t)nch4; ++c) {
-      const float4 q = sldp(ub + c) - h.cand[c * CT + lane];
-      acc += dist4(fma4(-s, cn[c], q + ar[c]), MODE == 1);
+      const float4 u = sldp(ub + c), e = h.cand[c * CT + lane], n = cn[c], r = ar[c];
+      const v2f zl = fma2(ms, lo2(n), (lo2(u) - lo2(e)) + lo2(r)), zh = fma2(ms, hi2(n), (hi2(u) - hi2(e)) + hi2(r));
+      if constexpr (MODE == 1) {
+        acc += (fabsf(zl.x) + fabsf(zl.y)) + (fabsf(zh.x) + fabsf(zh.y));
+      } else {
+        a2 = fma2(zl, zl, a2);
+        a2 = fma2(zh, zh, a2);
+      }
     }
-    return acc;
+    return MODE == 1 ? acc : a2.x + a2.y;
   }
   const float qls = __shfl(ur.ql, ps, 64), qns = __shfl(ur.qn, ps, 64);
-  float qq = 0.f;
+  v2f q2 = v2f{0.f, 0.f};
   for (uint32_t c = 0; c < (uint32_t)nch4; ++c) {
-    const float4 q = sldp(ub + c) - h.cand[c * CT + lane];
-    qq += dot4(q, q);
+    const float4 u = sldp(ub + c), e = h.cand[c * CT + lane];
+    const v2f ql = lo2(u) - lo2(e), qh = hi2(u) - hi2(e);
+    q2 = fma2(ql, ql, q2);
+    q2 = fma2(qh, qh, q2);
   }
+  const float qq = q2.x + q2.y;
   const float s = qns - h.vn[ps * CT + lane];
   const float lin = fmaf(h.cst[96], qls - h.lv[ps * CT + lane], h.cst[ps]);          // 2 q.r + |r|^2
   return fmaf(s, fmaf(s, h.cst[64 + ps], -2.f * h.cst[32 + ps]), qq + lin);           // + s (s (|n|^2 - 2) - 2 r.n)
@@ -834,13 +901,18 @@ __global__ __launch_bounds__(256) void rel_bucket_kernel(const int64_t* __restri
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// grid.y splits the queries: enough workgroups to fill the chip (`target`: ~2 rounds of the resident workgroups), but
-// every split a whole number of NWV x QB query groups and none of them empty.
-dim3 pairs_grid(int64_t n_cand, int64_t nq, int nwv, int64_t target) {
+// grid.y splits the queries: enough workgroups to fill the chip, every split a whole number of NWV x QB query groups and none of
+// them empty.  `slots` = the workgroups the chip holds at once (256 CUs x 6 at one staged vector, x 2 at three).  A short call gets
+// about one round of them (`target`); a long one (a whole link-prediction pass: 230 tiles x 1280 groups) gets up to 8 rounds of
+// workgroups with >= 6 query groups each -- at 2070 workgroups for 1536 slots the second round ran a third full and the kernel
+// held 55 % of the vector pipe's issue rate.
+dim3 pairs_grid(int64_t n_cand, int64_t nq, int nwv, int64_t target, int64_t slots) {
   const int64_t tiles = (n_cand + CT - 1) / CT;
   const int64_t group = (int64_t)nwv * QB;
-  int64_t ysplit = (target + tiles - 1) / tiles;
   const int64_t ymax = (nq + group - 1) / group;
+  const int64_t fine = tiles * ymax / 6;
+  if (fine > target) target = fine < 8 * slots ? fine : 8 * slots;
+  int64_t ysplit = (target + tiles - 1) / tiles;
   if (ysplit > ymax) ysplit = ymax;
   if (ysplit < 1) ysplit = 1;
   const int64_t per = ((nq + ysplit - 1) / ysplit + group - 1) / group * group;   // what the kernel computes from gridDim.y
@@ -853,7 +925,7 @@ int launch_pairs(const PairsArgs& a, hipStream_t st, const char* name, int nrel 
   const int ncv = MODE == 2 ? 3 : 1;
   const size_t lds = (size_t)ncv * (a.dq / 4) * CT * 16;
   if (lds > 160 * 1024) return set_error(KTUP_ERR_UNSUPPORTED, "%s: embedding_size %d needs %zu B of LDS", name, a.d, lds);
-  dim3 grid = pairs_grid(a.n_cand, a.nq, PairsWG<MODE>::NWV, MODE == 2 ? 512 : 2048);
+  dim3 grid = pairs_grid(a.n_cand, a.nq, PairsWG<MODE>::NWV, MODE == 2 ? 512 : 2048, MODE == 2 ? 512 : 1536);
   if (a.qperm) grid.z = (unsigned)nrel;
   if (a.l1) {
     if (lds > 64 * 1024)
@@ -908,7 +980,7 @@ int launch_pairs_count(const PairsArgs& a, hipStream_t st, const char* name) {
   if (tile * LIST_NW > 160 * 1024) return set_error(KTUP_ERR_UNSUPPORTED, "%s: embedding_size %d needs %zu B of LDS", name, a.d, tile * LIST_NW);
   (void)hipFuncSetAttribute((const void*)pairs_list_kernel<MODE, L1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(tile * LIST_NW));
   hipLaunchKernelGGL((pairs_list_kernel<MODE, L1>), dim3(grid_for((a.nq + LIST_NW - 1) / LIST_NW, 4096)), dim3(LIST_NW * 64), tile * LIST_NW, st, a);
-  const dim3 grid = pairs_grid(a.n_cand, a.nq, PairsWG<MODE>::NWV, 2048);
+  const dim3 grid = pairs_grid(a.n_cand, a.nq, PairsWG<MODE>::NWV, 2048, 1536);
   if (tile > 64 * 1024) (void)hipFuncSetAttribute((const void*)pairs_kernel<MODE, L1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile);
   hipLaunchKernelGGL((pairs_kernel<MODE, L1, true>), grid, dim3(PairsWG<MODE>::NT), tile, st, a);
   return check_launch(name);

@@ -7,7 +7,7 @@ R=$(pwd)
 P=$R/gpurun_out/profiles
 mkdir -p $P
 timeout 900 python tools/collect_profiles.py $TAG > $R/gpurun_out/${TAG}_collect.log 2>&1
-for W in train_step fed_step eval_pass seg_bwd kg_rank kg_pass kg_pass_e kg_pass_e_l1 hard_pass; do
+for W in train_step fed_step eval_pass seg_bwd kg_rank kg_pass kg_pass_e kg_pass_e_l1 hard_pass soft_l1_pass; do
   rm -rf /tmp/kp_$W
   (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kp_$W -- python $R/tools/pmc_workloads.py $W > /dev/null 2>&1)
   F=$(find /tmp/kp_$W -name "*kernel_stats.csv" | head -1)
@@ -25,13 +25,13 @@ for V in default exchange; do
   F=$(find /tmp/c5 -name "*kernel_stats.csv" | head -1)
   [ -n "$F" ] && cp $F $P/${TAG}_config5_${V}_kernel_stats.csv
 done
-for W in fed_step eval_pass kg_pass hard_pass; do
+for W in fed_step eval_pass kg_pass hard_pass soft_l1_pass; do
   : > $P/${TAG}_${W}_pmc.txt
   for SET in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_ANY" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT"; do
     rm -rf /tmp/pm_$W
     (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $SET --output-format csv -d /tmp/pm_$W -- python $R/tools/pmc_workloads.py $W > /dev/null 2>&1)
     F=$(find /tmp/pm_$W -name "*counter_collection.csv" | head -1)
-    [ -n "$F" ] && python tools/pmc_summary.py $F eval_pass pspace_ topk_merge clip_step_kernel pref_bwd_wide_kernel kg_step_kernel feed_ kg_count_mc kg_list_scores kg_rank_finalize kg_wtab sweep_hard pairs_hard >> $P/${TAG}_${W}_pmc.txt
+    [ -n "$F" ] && python tools/pmc_summary.py $F eval_pass pspace_ topk_merge clip_step_kernel pref_bwd_wide_kernel kg_step_kernel feed_ kg_count_mc kg_list_scores kg_rank_finalize kg_wtab sweep_hard sweep_soft pairs_hard pairs_kernel >> $P/${TAG}_${W}_pmc.txt
   done
 done
 timeout 600 python tools/kernel_times.py > $P/${TAG}_kernel_times.txt 2>/dev/null

@@ -136,5 +136,26 @@ def hard_pass(dev):
     torch.cuda.synchronize()
 
 
+def soft_l1_pass(dev):
+    """KTUP with -L1_flag (the reference's run scripts), soft gate: the whole pass in one sweep, then batch by batch."""
+    from jTransUP.hip import ops
+    from jTransUP.models import jTransUP as jt
+    torch.manual_seed(3)
+    i_map = {i: i for i in range(B.NI)}
+    new_map = {i: ((i * 4) % B.NE if i < B.ALIGNED else -1, i) for i in range(B.NI)}
+    m = jt.jTransUPModel(True, B.D, B.NU, B.NI, B.NE, B.NR, i_map, new_map, False, False).to(dev)
+    m.eval(); m.disable_grad()
+    u = torch.arange(B.NU, device=dev)
+    gen = torch.Generator().manual_seed(1)
+    f_off = (torch.arange(B.NU + 1) * 165).to(dev)
+    f_ids = torch.randint(0, B.NI, (B.NU * 165,), generator=gen).to(dev, torch.int32)
+    items = m.prepare_items()
+    for _ in range(3):
+        m.evaluate_topk(u, items, 10, f_off, f_ids)
+    for s in range(0, B.NU, 512):
+        ops.topk_filtered(m.evaluateRec(u[s:s + 512], items=items), False, 10, f_off[s:s + 513] - f_off[s], f_ids[int(f_off[s]):])
+    torch.cuda.synchronize()
+
+
 if __name__ == '__main__':
-    {'kg_pass': kg_pass, 'kg_pass_e': lambda d: kg_pass(d, True), 'kg_pass_e_l1': lambda d: kg_pass(d, True, True), 'kg_pass_l1': lambda d: kg_pass(d, False, True), 'hard_pass': hard_pass, 'kg_rank': kg_rank, 'eval_pass': eval_pass, 'train_step': train_step, 'fed_step': fed_step, 'seg_bwd': seg_bwd}[sys.argv[1]](torch.device('cuda'))
+    {'soft_l1_pass': soft_l1_pass, 'kg_pass': kg_pass, 'kg_pass_e': lambda d: kg_pass(d, True), 'kg_pass_e_l1': lambda d: kg_pass(d, True, True), 'kg_pass_l1': lambda d: kg_pass(d, False, True), 'hard_pass': hard_pass, 'kg_rank': kg_rank, 'eval_pass': eval_pass, 'train_step': train_step, 'fed_step': fed_step, 'seg_bwd': seg_bwd}[sys.argv[1]](torch.device('cuda'))

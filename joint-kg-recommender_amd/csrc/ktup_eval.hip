@@ -183,16 +183,22 @@ KTUP_DEV v2f lo2(float4 a) { return v2f{a.x, a.y}; }
 KTUP_DEV v2f hi2(float4 a) { return v2f{a.z, a.w}; }
 KTUP_DEV v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 
-template <int MODE, bool L1, int NQ>
-KTUP_DEV void pair_group_scores(const float4* cand, int nch4, const sptr4 (&qa)[NQ], const sptr4 (&qn)[NQ], const sptr4 (&q1p)[NQ], int lane,
-                                float (&acc)[NQ]) {
+// CF: the candidate's chunk c of staged vector v -- the LDS tile (StagedCand) or the row itself (the list kernel's RowCand)
+struct StagedCand {
+  static constexpr int UNROLL = 2;
+  const float4* cand; int nch4, lane;
+  KTUP_DEV float4 operator()(int v, uint32_t c) const { return cand[(v * nch4 + c) * CT + lane]; }
+};
+template <int MODE, bool L1, int NQ, class CF>
+KTUP_DEV void pair_group_scores(const CF& cf, int nch4, const sptr4 (&qa)[NQ], const sptr4 (&qn)[NQ], const sptr4 (&q1p)[NQ], float (&acc)[NQ]) {
   v2f s2[NQ], a2[NQ];
 #pragma unroll
   for (int qi = 0; qi < NQ; ++qi) { s2[qi] = v2f{0.f, 0.f}; a2[qi] = v2f{0.f, 0.f}; acc[qi] = 0.f; }
   if (MODE >= 1) {
+#pragma unroll(CF::UNROLL)
     for (uint32_t c = 0; c < (uint32_t)nch4; ++c) {
-      const float4 c1 = cand[((MODE == 2 ? 1 : 0) * nch4 + c) * CT + lane];
-      const float4 nc = MODE == 2 ? cand[(2 * nch4 + c) * CT + lane] : f4zero();
+      const float4 c1 = cf(MODE == 2 ? 1 : 0, c);
+      const float4 nc = MODE == 2 ? cf(2, c) : f4zero();
 #pragma unroll
       for (int qi = 0; qi < NQ; ++qi) {
         const float4 nqv = sldp(qn[qi] + c);
@@ -210,9 +216,10 @@ KTUP_DEV void pair_group_scores(const float4* cand, int nch4, const sptr4 (&qa)[
   v2f ms[NQ];
 #pragma unroll
   for (int qi = 0; qi < NQ; ++qi) { const float s = s2[qi].x + s2[qi].y; ms[qi] = v2f{-s, -s}; }
+#pragma unroll(CF::UNROLL)
   for (uint32_t c = 0; c < (uint32_t)nch4; ++c) {
-    const float4 c0 = cand[c * CT + lane];
-    const float4 nc = MODE == 2 ? cand[(2 * nch4 + c) * CT + lane] : f4zero();
+    const float4 c0 = cf(0, c);
+    const float4 nc = MODE == 2 ? cf(2, c) : f4zero();
 #pragma unroll
     for (int qi = 0; qi < NQ; ++qi) {
       const float4 av = sldp(qa[qi] + c);
@@ -240,6 +247,10 @@ KTUP_DEV void pair_group_scores(const float4* cand, int nch4, const sptr4 (&qa)[
     for (int qi = 0; qi < NQ; ++qi) acc[qi] = a2[qi].x + a2[qi].y;
   }
 }
+
+// a wave-uniform address read through the scalar cache (data written by an earlier kernel)
+template <class T>
+KTUP_DEV T uload(const T* p) { return *(const __attribute__((address_space(4))) T*)(uintptr_t)p; }
 
 KTUP_DEV uint64_t count_key(float s, uint32_t id) {    // ktup_rank.hip make_key (ascending)
   if (s == 0.f) s = 0.f;
@@ -300,26 +311,27 @@ __global__ __launch_bounds__(PairsWG<MODE>::NT) void pairs_kernel(PairsArgs a) {
     // COUNT: the queries' gold lists (offsets, the first TH scores and ids: wave-uniform scalar loads) are requested BEFORE the
     // scores are computed -- after them they were three dependent round trips per query with nothing to hide behind
     constexpr int TH = 4;
+    static_assert(QB == 4 && TH == 4, "lane qi * TH + k <-> (query of the group, gold slot)");
     int64_t cg0[QB];
     int cng[QB];
-    float cth[QB][TH];
-    uint32_t cgid[QB][TH];
+    float thv = 0.f;            // lane qi * TH + k: the k-th gold's score / id of the group's query qi -- two registers for the whole
+    uint32_t gidv = 0;          // group, read back lane by lane (v_readlane) where a threshold is needed
+    int64_t slot_g = 0;
     if constexpr (COUNT) {
 #pragma unroll
       for (int qi = 0; qi < QB; ++qi) {
-        cg0[qi] = a.gold_off[qid[qi]];
-        cng[qi] = b0 + qi < qhi ? (int)(a.gold_off[qid[qi] + 1] - cg0[qi]) : 0;
+        cg0[qi] = uload(a.gold_off + qid[qi]);
+        cng[qi] = b0 + qi < qhi ? (int)(uload(a.gold_off + qid[qi] + 1) - cg0[qi]) : 0;
       }
-#pragma unroll
-      for (int qi = 0; qi < QB; ++qi)
-#pragma unroll
-        for (int k = 0; k < TH; ++k) {
-          cth[qi][k] = k < cng[qi] ? a.gscore[cg0[qi] + k] : 0.f;
-          cgid[qi][k] = k < cng[qi] ? (uint32_t)a.gold_ids[cg0[qi] + k] : 0u;
-        }
+      const int sq = (lane >> 2) & 3, sk = lane & 3;
+      slot_g = (sq == 0 ? cg0[0] : sq == 1 ? cg0[1] : sq == 2 ? cg0[2] : cg0[3]) + sk;
+      if (lane < QB * TH && sk < (sq == 0 ? cng[0] : sq == 1 ? cng[1] : sq == 2 ? cng[2] : cng[3])) {
+        thv = a.gscore[slot_g];
+        gidv = (uint32_t)a.gold_ids[slot_g];
+      }
     }
     float acc[QB];
-    pair_group_scores<MODE, L1, QB>(cand, nch4, qa, qn, q1p, lane, acc);
+    pair_group_scores<MODE, L1, QB>(StagedCand{cand, nch4, lane}, nch4, qa, qn, q1p, acc);
     if constexpr (COUNT) {
       // per gold entry of each query: the candidates of this tile ordered before it -- (score, id) order of ktup_rank.hip's keys: a
       // lower score, or the same score and a lower id; NaNs on either side (uniform tests) go through the keys themselves
@@ -334,36 +346,50 @@ __global__ __launch_bounds__(PairsWG<MODE>::NT) void pairs_kernel(PairsArgs a) {
 #pragma unroll
       for (int qi = 0; qi < QB; ++qi) {
         const float sc = desc ? -acc[qi] : acc[qi];
-        const bool any_nan = __builtin_amdgcn_ballot_w64(sc != sc) != 0;
-        auto before = [&](float th0, uint32_t gid0) {
-          const float th = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(desc ? -th0 : th0)));
-          const uint32_t gid = (uint32_t)__builtin_amdgcn_readfirstlane((int)gid0);
+        // the thresholds are wave-uniform (scalar loads): their sign flip and NaN tests run on the scalar unit, and a query with a NaN
+        // on either side (rare) takes the key compares for all its golds -- nothing of that path is computed otherwise
+        bool slow = __builtin_amdgcn_ballot_w64(sc != sc) != 0;
+        uint32_t thb[TH], gid[TH];
+#pragma unroll
+        for (int k = 0; k < TH; ++k) {
+          thb[k] = (uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(thv), qi * TH + k) ^ (desc ? 0x80000000u : 0u);
+          gid[k] = (uint32_t)__builtin_amdgcn_readlane((int)gidv, qi * TH + k);
+          slow |= k < cng[qi] && (thb[k] & 0x7fffffffu) > 0x7f800000u;
+        }
+        if (!slow) {
+#pragma unroll
+          for (int k = 0; k < TH; ++k)
+            if (k < cng[qi]) {
+              const float th = __uint_as_float(thb[k]);
+              const uint64_t lt = __builtin_amdgcn_ballot_w64(sc < th), eq = __builtin_amdgcn_ballot_w64(sc == th);
+              const int n = (int)__popcll((lt | (eq & __builtin_amdgcn_ballot_w64(cid < gid[k]))) & inm);
+              asm("v_writelane_b32 %0, %1, %2" : "+v"(cntv) : "s"(n), "i"(qi * TH + k));   // (no builtin for it in this compiler)
+            }
+        } else {
+          const uint64_t key = count_key(sc, cid);
+#pragma unroll
+          for (int k = 0; k < TH; ++k)
+            if (k < cng[qi]) {
+              const int n = (int)__popcll(__builtin_amdgcn_ballot_w64(key < count_key(__uint_as_float(thb[k]), gid[k])) & inm);
+              asm("v_writelane_b32 %0, %1, %2" : "+v"(cntv) : "s"(n), "i"(qi * TH + k));
+            }
+        }
+        for (int k = TH; k < cng[qi]; ++k) {    // beyond TH golds: one at a time
+          const float th0 = uload(a.gscore + cg0[qi] + k);
+          const float th = desc ? -th0 : th0;
+          const uint32_t gid = (uint32_t)uload(a.gold_ids + cg0[qi] + k);
           uint64_t m;
-          if (any_nan || th != th) {
+          if (slow || th != th) {
             m = __builtin_amdgcn_ballot_w64(count_key(sc, cid) < count_key(th, gid));
           } else {
             const uint64_t lt = __builtin_amdgcn_ballot_w64(sc < th), eq = __builtin_amdgcn_ballot_w64(sc == th);
             m = lt | (eq & __builtin_amdgcn_ballot_w64(cid < gid));
           }
-          return (int)__popcll(m & inm);
-        };
-#pragma unroll
-        for (int k = 0; k < TH; ++k)
-          if (k < cng[qi]) {
-            const int n = before(cth[qi][k], cgid[qi][k]);
-            asm("v_writelane_b32 %0, %1, %2" : "+v"(cntv) : "s"(n), "i"(qi * TH + k));   // (no builtin for it in this compiler)
-          }
-        for (int k = TH; k < cng[qi]; ++k) {
-          const int n = before(a.gscore[cg0[qi] + k], (uint32_t)a.gold_ids[cg0[qi] + k]);
+          const int n = (int)__popcll(m & inm);
           if (n != 0 && lane == 0) atomicAdd(a.counts + cg0[qi] + k, n);
         }
       }
-      {
-        static_assert(QB == 4 && TH == 4, "one lane per (query of the group, gold slot)");
-        const int sq = (lane >> 2) & 3;
-        const int64_t g = (sq == 0 ? cg0[0] : sq == 1 ? cg0[1] : sq == 2 ? cg0[2] : cg0[3]) + (lane & 3);
-        if (lane < QB * TH && cntv != 0) atomicAdd(a.counts + g, cntv);
-      }
+      if (lane < QB * TH && cntv != 0) atomicAdd(a.counts + slot_g, cntv);
       continue;
     }
     if (j0 + lane < a.n_cand) {
@@ -744,7 +770,7 @@ __global__ __launch_bounds__(SS_NW * 64) void sweep_soft_kernel(SweepSoftArgs sa
     __syncthreads();
     if (j0 + CT < i_hi) { KTUP_SS_FETCH(j0 + CT) }                      // in flight under the scores below
     float acc[SS_UW];
-    pair_group_scores<2, L1, SS_UW>(cand, nch4, qa, qn, q1p, lane, acc);
+    pair_group_scores<2, L1, SS_UW>(StagedCand{cand, nch4, lane}, nch4, qa, qn, q1p, acc);
     const int64_t item = j0 + lane;
     const bool iok = item < i_hi;
     const int64_t lid = item - i_lo;
@@ -940,16 +966,26 @@ int launch_pairs(const PairsArgs& a, hipStream_t st, const char* name, int nrel 
 }
 
 // ---- the scores of every query's OWN list entries (golds, then filtered ids) with pair_group_scores: a wave takes one query at a
-// time, gathers up to 64 of its entries' rows into its LDS tile (lane <-> entry) and scores them -- the thresholds and the subtrahend of
-// the COUNT form's ranks (ktup_eval_kg_fused.hip), bit-identical to what the sweep computes for the same (query, candidate)
-constexpr int LIST_NW = 2;
+// time and scores up to 64 of its entries (lane <-> entry), every lane reading its entry's row where it lies (L2-resident: the sweep
+// is streaming the same table) -- the thresholds and the subtrahend of the COUNT form's ranks (ktup_eval_kg_fused.hip), bit-identical
+// to what the sweep computes for the same (query, candidate).  No LDS tile: staged through one, a CU held 6 waves and the kernel was
+// a chain of exposed latencies (offsets -> ids -> rows -> LDS -> scores: 166 us per 20,480 keys of 22 entries).
+constexpr int LIST_NW = 4;
+template <bool VEC>
+struct RowCand {              // UNROLL: the row loads of that many chunks are in flight together (one exposed latency per 5 chunks, not per chunk)
+  static constexpr int UNROLL = 5;
+  const float* row; int d;
+  KTUP_DEV float4 operator()(int, uint32_t c) const {
+    if constexpr (VEC) return *reinterpret_cast<const float4*>(row + 4 * c);
+    return load_cand4(row, 0, 0, (int)c, d, false);
+  }
+};
 template <int MODE, bool L1>
 __global__ __launch_bounds__(LIST_NW * 64) void pairs_list_kernel(PairsArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+  static_assert(MODE != 2, "one staged vector per candidate");
   const int t = threadIdx.x, lane = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
   const int nch4 = a.dq / 4;
-  float4* cand = reinterpret_cast<float4*>(smem) + (size_t)w * nch4 * CT;
   const sptr4 QW = as_scalar(a.QW);
   for (int64_t key = (int64_t)blockIdx.x * LIST_NW + w; key < a.nq; key += (int64_t)gridDim.x * LIST_NW) {
     const int64_t g0 = a.gold_off[key], ng = a.gold_off[key + 1] - g0;
@@ -960,16 +996,13 @@ __global__ __launch_bounds__(LIST_NW * 64) void pairs_list_kernel(PairsArgs a) {
       const bool on = e < ng + nf;
       const int32_t cid = !on ? 0 : (e < ng ? a.gold_ids[g0 + e] : a.filt_ids[f0 + (e - ng)]);
       const bool valid = on && cid >= 0 && cid < a.n_cand;
-      for (int c = 0; c < nch4; ++c) cand[c * CT + lane] = load_cand4(a.C0, a.ldc0, valid ? cid : 0, c, a.d, a.cvec);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
+      const float* row = a.C0 + (int64_t)(valid ? cid : 0) * a.ldc0;
       float acc[1];
-      pair_group_scores<MODE, L1, 1>(cand, nch4, qa, qn, q1p, lane, acc);
+      if (a.cvec) pair_group_scores<MODE, L1, 1>(RowCand<true>{row, a.d}, nch4, qa, qn, q1p, acc);
+      else pair_group_scores<MODE, L1, 1>(RowCand<false>{row, a.d}, nch4, qa, qn, q1p, acc);
       if (valid) {
         if (e < ng) a.gscore[g0 + e] = acc[0]; else a.fscore[f0 + (e - ng)] = acc[0];
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
     }
   }
 }
@@ -977,9 +1010,8 @@ __global__ __launch_bounds__(LIST_NW * 64) void pairs_list_kernel(PairsArgs a) {
 template <int MODE, bool L1>
 int launch_pairs_count(const PairsArgs& a, hipStream_t st, const char* name) {
   const size_t tile = (size_t)(a.dq / 4) * CT * 16;
-  if (tile * LIST_NW > 160 * 1024) return set_error(KTUP_ERR_UNSUPPORTED, "%s: embedding_size %d needs %zu B of LDS", name, a.d, tile * LIST_NW);
-  (void)hipFuncSetAttribute((const void*)pairs_list_kernel<MODE, L1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(tile * LIST_NW));
-  hipLaunchKernelGGL((pairs_list_kernel<MODE, L1>), dim3(grid_for((a.nq + LIST_NW - 1) / LIST_NW, 4096)), dim3(LIST_NW * 64), tile * LIST_NW, st, a);
+  if (tile > 160 * 1024) return set_error(KTUP_ERR_UNSUPPORTED, "%s: embedding_size %d needs %zu B of LDS", name, a.d, tile);
+  hipLaunchKernelGGL((pairs_list_kernel<MODE, L1>), dim3(grid_for((a.nq + LIST_NW - 1) / LIST_NW, 8192)), dim3(LIST_NW * 64), 0, st, a);
   const dim3 grid = pairs_grid(a.n_cand, a.nq, PairsWG<MODE>::NWV, 2048, 1536);
   if (tile > 64 * 1024) (void)hipFuncSetAttribute((const void*)pairs_kernel<MODE, L1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile);
   hipLaunchKernelGGL((pairs_kernel<MODE, L1, true>), grid, dim3(PairsWG<MODE>::NT), tile, st, a);

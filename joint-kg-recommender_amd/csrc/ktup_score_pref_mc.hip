@@ -153,11 +153,13 @@ __global__ __launch_bounds__(G::NW * 64) void pref_fwd_mc_kernel(McArgs a) {
   const int64_t wstride = (int64_t)gridDim.x * nwr;
   bool first = true;
   for (int64_t tile_id = (int64_t)blockIdx.x * nwr + w; tile_id < ntiles; tile_id += wstride) {
+    // wave-uniform 64-bit tile origin (scalar registers) + 32-bit lane offsets: kept as 64-bit per-lane row indices, these were
+    // six registers the kernel had to spill at 128 -- with scratch reloads in front of the id loads and inside the matrix phases
     const int64_t row0 = tile_id * 16;
+    const int rem = (int)(a.n - row0 < 16 ? a.n - row0 : 16);
     if (first && lane < 16) {
-      const int64_t gr = row0 + lane;
-      const bool ok = gr < a.n;
-      const int64_t uid = ok ? a.u_ids[gr] : 0, iid = ok ? a.i_ids[gr] : 0;
+      const bool ok = lane < rem;
+      const int64_t uid = ok ? (a.u_ids + row0)[lane] : 0, iid = ok ? (a.i_ids + row0)[lane] : 0;
       sid[lane] = (int32_t)uid;
       sid[16 + lane] = (int32_t)iid;
       sid[32 + lane] = HASE ? a.item2ent[iid] : 0;
@@ -207,9 +209,9 @@ __global__ __launch_bounds__(G::NW * 64) void pref_fwd_mc_kernel(McArgs a) {
     int32_t nx_u = 0, nx_i = 0, nx_e = 0;
     const bool pre = lane < 16 && tile_id + wstride < ntiles;
     if (pre) {
-      const int64_t gr = (tile_id + wstride) * 16 + lane;
-      const bool ok = gr < a.n;
-      const int64_t uid = ok ? a.u_ids[gr] : 0, iid = ok ? a.i_ids[gr] : 0;
+      const int64_t row1 = (tile_id + wstride) * 16;
+      const bool ok = lane < a.n - row1;
+      const int64_t uid = ok ? (a.u_ids + row1)[lane] : 0, iid = ok ? (a.i_ids + row1)[lane] : 0;
       nx_u = (int32_t)uid; nx_i = (int32_t)iid;
       nx_e = HASE ? a.item2ent[iid] : 0;
     }
@@ -419,7 +421,7 @@ __global__ __launch_bounds__(G::NW * 64) void pref_fwd_mc_kernel(McArgs a) {
     }
     }
     const float score = allsum_kq((dacc[0] + dacc[1]) + (dacc[2] + dacc[3]));
-    if (kq == 0 && row0 + j < a.n) a.score[row0 + j] = score;
+    if (kq == 0 && j < rem) (a.score + row0)[j] = score;
     if (pre) { sid[lane] = nx_u; sid[16 + lane] = nx_i; sid[32 + lane] = nx_e; }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();

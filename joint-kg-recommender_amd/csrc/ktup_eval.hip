@@ -153,6 +153,14 @@ struct PairsArgs {
   float *gscore, *fscore;
   int32_t* counts;
   int descending;
+  // MODE 3 (TransH with the pass's table of e . w): the keys' relation ids, the table [n_rel][ldw] of s = -(e . w_rel) in
+  // pair_group_scores' own operation order (transh_dots), and -- for the kernel that fills it -- the relation normals
+  const int64_t* rel;
+  float* wtab;
+  int64_t ldw;
+  const float* Nrm;
+  int64_t ldn;
+  int n_rel;
 };
 
 KTUP_DEV float4 load_cand4(const float* base, int64_t ld, int64_t row, int c, int d, bool vec) {
@@ -166,7 +174,7 @@ KTUP_DEV float4 load_cand4(const float* base, int64_t ld, int64_t row, int c, in
   return v;
 }
 
-// MODE 0: z = A - C0 (TransE / TransR-projected)   MODE 1: TransH   MODE 2: TUP / KTUP soft gate
+// MODE 0: z = A - C0 (TransE / TransR-projected)   MODE 1: TransH   MODE 2: TUP / KTUP soft gate   MODE 3: TransH, e . w from the pass's table
 // L1: the distance kind is compile-time -- a run-time flag makes the compiler evaluate |z| AND z^2 per element and select.
 // MODE 2 keeps three candidate vectors in LDS (77 KB at d = 100: two workgroups per CU), so its workgroups are 8 waves.
 template <int MODE>
@@ -189,34 +197,62 @@ struct StagedCand {
   const float4* cand; int nch4, lane;
   KTUP_DEV float4 operator()(int v, uint32_t c) const { return cand[(v * nch4 + c) * CT + lane]; }
 };
-template <int MODE, bool L1, int NQ, class CF>
-KTUP_DEV void pair_group_scores(const CF& cf, int nch4, const sptr4 (&qa)[NQ], const sptr4 (&qn)[NQ], const sptr4 (&q1p)[NQ], float (&acc)[NQ]) {
-  v2f s2[NQ], a2[NQ];
+// TransH's s = -(e . w) of the lane's candidate against NQ wave-uniform normals.  ONE function for the pair kernels' first pass and for
+// the kernel that tabulates s per (relation, candidate) once per pass: the same operations in the same order, so a table entry has
+// the bits the two-pass kernels compute
+template <int NQ, class CF>
+KTUP_DEV void transh_dots(const CF& cf, int nch4, const sptr4 (&qn)[NQ], float (&s)[NQ]) {
+  v2f s2[NQ];
 #pragma unroll
-  for (int qi = 0; qi < NQ; ++qi) { s2[qi] = v2f{0.f, 0.f}; a2[qi] = v2f{0.f, 0.f}; acc[qi] = 0.f; }
-  if (MODE >= 1) {
-#pragma unroll(CF::UNROLL)
+  for (int qi = 0; qi < NQ; ++qi) s2[qi] = v2f{0.f, 0.f};
+#pragma unroll CF::UNROLL
+  for (uint32_t c = 0; c < (uint32_t)nch4; ++c) {
+    const float4 c1 = cf(0, c);
+#pragma unroll
+    for (int qi = 0; qi < NQ; ++qi) {
+      const float4 nqv = sldp(qn[qi] + c);
+      s2[qi] = fma2(-lo2(c1), lo2(nqv), s2[qi]);
+      s2[qi] = fma2(-hi2(c1), hi2(nqv), s2[qi]);
+    }
+  }
+#pragma unroll
+  for (int qi = 0; qi < NQ; ++qi) s[qi] = s2[qi].x + s2[qi].y;
+}
+
+// MODE 3 = MODE 1 with s read from the pass's table (stab: this lane's candidate against each query's relation)
+template <int MODE, bool L1, int NQ, class CF>
+KTUP_DEV void pair_group_scores(const CF& cf, int nch4, const sptr4 (&qa)[NQ], const sptr4 (&qn)[NQ], const sptr4 (&q1p)[NQ], float (&acc)[NQ],
+                                const float* stab = nullptr) {
+  constexpr bool TRANSH = MODE == 1 || MODE == 3;
+  v2f s2[NQ], a2[NQ];
+  float s[NQ];
+#pragma unroll
+  for (int qi = 0; qi < NQ; ++qi) { s2[qi] = v2f{0.f, 0.f}; a2[qi] = v2f{0.f, 0.f}; acc[qi] = 0.f; s[qi] = 0.f; }
+  if constexpr (MODE == 1) transh_dots<NQ>(cf, nch4, qn, s);
+  if constexpr (MODE == 3) {
+#pragma unroll
+    for (int qi = 0; qi < NQ; ++qi) s[qi] = stab[qi];
+  }
+  if constexpr (MODE == 2) {
+#pragma unroll CF::UNROLL
     for (uint32_t c = 0; c < (uint32_t)nch4; ++c) {
-      const float4 c1 = cf(MODE == 2 ? 1 : 0, c);
-      const float4 nc = MODE == 2 ? cf(2, c) : f4zero();
+      const float4 c1 = cf(1, c);
+      const float4 nc = cf(2, c);
 #pragma unroll
       for (int qi = 0; qi < NQ; ++qi) {
         const float4 nqv = sldp(qn[qi] + c);
-        if constexpr (MODE == 2) {
-          const float4 q1 = sldp(q1p[qi] + c);
-          s2[qi] = fma2(lo2(q1) - lo2(c1), lo2(nqv) + lo2(nc), s2[qi]);
-          s2[qi] = fma2(hi2(q1) - hi2(c1), hi2(nqv) + hi2(nc), s2[qi]);
-        } else {                      // TransH: s = -(e . w)
-          s2[qi] = fma2(-lo2(c1), lo2(nqv), s2[qi]);
-          s2[qi] = fma2(-hi2(c1), hi2(nqv), s2[qi]);
-        }
+        const float4 q1 = sldp(q1p[qi] + c);
+        s2[qi] = fma2(lo2(q1) - lo2(c1), lo2(nqv) + lo2(nc), s2[qi]);
+        s2[qi] = fma2(hi2(q1) - hi2(c1), hi2(nqv) + hi2(nc), s2[qi]);
       }
     }
+#pragma unroll
+    for (int qi = 0; qi < NQ; ++qi) s[qi] = s2[qi].x + s2[qi].y;
   }
   v2f ms[NQ];
 #pragma unroll
-  for (int qi = 0; qi < NQ; ++qi) { const float s = s2[qi].x + s2[qi].y; ms[qi] = v2f{-s, -s}; }
-#pragma unroll(CF::UNROLL)
+  for (int qi = 0; qi < NQ; ++qi) ms[qi] = v2f{-s[qi], -s[qi]};
+#pragma unroll CF::UNROLL
   for (uint32_t c = 0; c < (uint32_t)nch4; ++c) {
     const float4 c0 = cf(0, c);
     const float4 nc = MODE == 2 ? cf(2, c) : f4zero();
@@ -229,7 +265,7 @@ KTUP_DEV void pair_group_scores(const CF& cf, int nch4, const sptr4 (&qa)[NQ], c
         zl = fma2(ms[qi], lo2(nqv) + lo2(nc), zl);
         zh = fma2(ms[qi], hi2(nqv) + hi2(nc), zh);
       }
-      if constexpr (MODE == 1) {
+      if constexpr (TRANSH) {
         const float4 nqv = sldp(qn[qi] + c);
         zl = fma2(ms[qi], lo2(nqv), zl);
         zh = fma2(ms[qi], hi2(nqv), zh);
@@ -289,7 +325,6 @@ __global__ __launch_bounds__(PairsWG<MODE>::NT) void pairs_kernel(PairsArgs a) {
   __syncthreads();
   const sptr4 QW = as_scalar(a.QW);
   const int dq4 = nch4;
-  constexpr bool l1 = L1;
   // this workgroup's slice of the queries (grid.y splits them), QB at a time per wave
   const int64_t nrange = range_hi - range_lo;
   const int64_t per = ((nrange + gridDim.y - 1) / gridDim.y + NWV * QB - 1) / (NWV * QB) * (NWV * QB);
@@ -330,8 +365,13 @@ __global__ __launch_bounds__(PairsWG<MODE>::NT) void pairs_kernel(PairsArgs a) {
         gidv = (uint32_t)a.gold_ids[slot_g];
       }
     }
+    float stab[QB];
+    if constexpr (MODE == 3) {            // s of (this lane's candidate, each query's relation): one coalesced table read per query
+#pragma unroll
+      for (int qi = 0; qi < QB; ++qi) stab[qi] = a.wtab[uload(a.rel + qid[qi]) * a.ldw + j0 + lane];
+    }
     float acc[QB];
-    pair_group_scores<MODE, L1, QB>(StagedCand{cand, nch4, lane}, nch4, qa, qn, q1p, acc);
+    pair_group_scores<MODE, L1, QB>(StagedCand{cand, nch4, lane}, nch4, qa, qn, q1p, acc, stab);
     if constexpr (COUNT) {
       // per gold entry of each query: the candidates of this tile ordered before it -- (score, id) order of ktup_rank.hip's keys: a
       // lower score, or the same score and a lower id; NaNs on either side (uniform tests) go through the keys themselves
@@ -997,9 +1037,10 @@ __global__ __launch_bounds__(LIST_NW * 64) void pairs_list_kernel(PairsArgs a) {
       const int32_t cid = !on ? 0 : (e < ng ? a.gold_ids[g0 + e] : a.filt_ids[f0 + (e - ng)]);
       const bool valid = on && cid >= 0 && cid < a.n_cand;
       const float* row = a.C0 + (int64_t)(valid ? cid : 0) * a.ldc0;
-      float acc[1];
-      if (a.cvec) pair_group_scores<MODE, L1, 1>(RowCand<true>{row, a.d}, nch4, qa, qn, q1p, acc);
-      else pair_group_scores<MODE, L1, 1>(RowCand<false>{row, a.d}, nch4, qa, qn, q1p, acc);
+      float acc[1], stab[1] = {0.f};
+      if constexpr (MODE == 3) stab[0] = a.wtab[a.rel[key] * a.ldw + (valid ? cid : 0)];
+      if (a.cvec) pair_group_scores<MODE, L1, 1>(RowCand<true>{row, a.d}, nch4, qa, qn, q1p, acc, stab);
+      else pair_group_scores<MODE, L1, 1>(RowCand<false>{row, a.d}, nch4, qa, qn, q1p, acc, stab);
       if (valid) {
         if (e < ng) a.gscore[g0 + e] = acc[0]; else a.fscore[f0 + (e - ng)] = acc[0];
       }
@@ -1007,10 +1048,41 @@ __global__ __launch_bounds__(LIST_NW * 64) void pairs_list_kernel(PairsArgs a) {
   }
 }
 
+// ---- MODE 3's table: s = -(e . w_rel) for every (relation, candidate), once per pass (20 x 14,709 at ml1m-kg: a few microseconds)
+// instead of once per (key, candidate) in the count kernel's first pass -- a fifth of TransH's pair arithmetic.  The pair kernels'
+// stage (64 candidates in LDS, lane <-> candidate) with the relation normals in the queries' place, through transh_dots.
+__global__ __launch_bounds__(256) void pairs_wtab_kernel(PairsArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float4* cand = reinterpret_cast<float4*>(smem);
+  const int t = threadIdx.x, lane = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int nch4 = a.dq / 4;
+  const int64_t j0 = (int64_t)blockIdx.x * CT;
+  for (int idx = t; idx < nch4 * CT; idx += 256) {
+    const int j = idx & (CT - 1), c = idx >> 6;
+    cand[c * CT + j] = load_cand4(a.C0, a.ldc0, min(j0 + j, a.n_cand - 1), c, a.d, a.cvec);
+  }
+  __syncthreads();
+  const sptr4 N4 = as_scalar(a.Nrm);
+  const int64_t ldn4 = a.ldn / 4;
+  for (int r0 = w * QB; r0 < a.n_rel; r0 += 4 * QB) {
+    sptr4 qn[QB];
+#pragma unroll
+    for (int qi = 0; qi < QB; ++qi) qn[qi] = N4 + (int64_t)min(r0 + qi, a.n_rel - 1) * ldn4;
+    float s[QB];
+    transh_dots<QB>(StagedCand{cand, nch4, lane}, nch4, qn, s);
+#pragma unroll
+    for (int qi = 0; qi < QB; ++qi)
+      if (r0 + qi < a.n_rel) a.wtab[(int64_t)(r0 + qi) * a.ldw + j0 + lane] = s[qi];
+  }
+}
+
 template <int MODE, bool L1>
 int launch_pairs_count(const PairsArgs& a, hipStream_t st, const char* name) {
   const size_t tile = (size_t)(a.dq / 4) * CT * 16;
   if (tile > 160 * 1024) return set_error(KTUP_ERR_UNSUPPORTED, "%s: embedding_size %d needs %zu B of LDS", name, a.d, tile);
+  if constexpr (MODE == 3)
+    hipLaunchKernelGGL(pairs_wtab_kernel, dim3((unsigned)((a.n_cand + CT - 1) / CT)), dim3(256), tile, st, a);
   hipLaunchKernelGGL((pairs_list_kernel<MODE, L1>), dim3(grid_for((a.nq + LIST_NW - 1) / LIST_NW, 8192)), dim3(LIST_NW * 64), 0, st, a);
   const dim3 grid = pairs_grid(a.n_cand, a.nq, PairsWG<MODE>::NWV, 2048, 1536);
   if (tile > 64 * 1024) (void)hipFuncSetAttribute((const void*)pairs_kernel<MODE, L1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile);
@@ -1063,12 +1135,19 @@ int ktup::kg_query_prep(int model, const float* E, int64_t lde, const float* R, 
 // pair kernel in its COUNT form.  QW: kg_query_prep's rows; counts must be zero on entry.
 int ktup::kg_valu_counts(int model, const float* QW, int d, const float* C, int64_t ldc, int64_t n_cand, int64_t nq, int l1, int descending,
                          const int64_t* gold_off, const int32_t* gold_ids, const int64_t* filt_off, const int32_t* filt_ids, float* gscore,
-                         float* fscore, int32_t* counts, hipStream_t st, const char* name) {
+                         float* fscore, int32_t* counts, const int64_t* rel, const float* Nrm, int64_t ldn, int64_t n_rel, float* wtab,
+                         int64_t ldw, hipStream_t st, const char* name) {
   PairsArgs a{};
   a.C0 = C; a.ldc0 = ldc; a.QW = QW; a.n_cand = n_cand; a.nq = nq; a.d = d; a.dq = round4(d); a.l1 = l1;
   a.cvec = (d % 4 == 0) && aligned16(C) && (ldc % 4 == 0);
   a.gold_off = gold_off; a.gold_ids = gold_ids; a.filt_off = filt_off; a.filt_ids = filt_ids; a.gscore = gscore; a.fscore = fscore;
   a.counts = counts; a.descending = descending;
+  // TransH with room for the pass's table of e . w (wtab: [n_rel][ldw], ldw >= the candidates rounded up to whole tiles) and rows the
+  // table kernel can read as the pair kernels do: the count and list kernels skip their first pass
+  if (model == 1 && wtab && rel && Nrm && n_rel > 0 && a.cvec && aligned16(Nrm) && (ldn % 4 == 0) && ldw >= (n_cand + CT - 1) / CT * CT) {
+    a.rel = rel; a.wtab = wtab; a.ldw = ldw; a.Nrm = Nrm; a.ldn = ldn; a.n_rel = (int)n_rel;
+    return l1 ? launch_pairs_count<3, true>(a, st, name) : launch_pairs_count<3, false>(a, st, name);
+  }
   if (model == 1) return l1 ? launch_pairs_count<1, true>(a, st, name) : launch_pairs_count<1, false>(a, st, name);
   return l1 ? launch_pairs_count<0, true>(a, st, name) : launch_pairs_count<0, false>(a, st, name);
 }

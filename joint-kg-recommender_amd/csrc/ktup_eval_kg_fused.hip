@@ -676,8 +676,9 @@ extern "C" int ktup_eval_kg_ranks_fused(int model, const float* E, int64_t lde, 
     // L1, widths without a matrix-core instantiation, keys with more than 8 golds: the pair kernels of ktup_eval.hip score the tiles
     // on the VALU and count where the scores are made (no score matrix either); list scores by the same function
     hipLaunchKernelGGL(kg_pass_init_kernel, dim3(grid_for((n_gold + 255) / 256, 2048)), dim3(256), 0, st, counts, n_gold, C, ldc, 0, (int64_t)0, cnorm);
+    const bool tab = wtab_on(model, n_cand, n_rel);   // (the workspace holds the table exactly then)
     if (int e = kg_valu_counts(model, QW, d, C, ldc, n_cand, nq, l1, descending, gold_off, gold_ids, filt_off, filt_ids, gscore, fscore, counts,
-                               st, name))
+                               tab ? r : nullptr, Nrm, ldn, n_rel, tab ? reinterpret_cast<float*>(p) : nullptr, wtab_pitch(n_cand), st, name))
       return e;
     hipLaunchKernelGGL(kg_rank_finalize_kernel, dim3(grid_for((nq + 255) / 256, 1024)), dim3(256), 0, st, a, n_gold);
     return check_launch(name);

@@ -75,7 +75,8 @@ int kg_query_prep(int model, const float* E, int64_t lde, const float* R, int64_
 size_t eval_pass_pspace_bytes(int d, int n_pref, int64_t nq, int64_t n_items, int topn);
 int kg_valu_counts(int model, const float* QW, int d, const float* C, int64_t ldc, int64_t n_cand, int64_t nq, int l1, int descending,
                    const int64_t* gold_off, const int32_t* gold_ids, const int64_t* filt_off, const int32_t* filt_ids, float* gscore,
-                   float* fscore, int32_t* counts, hipStream_t st, const char* name);
+                   float* fscore, int32_t* counts, const int64_t* rel, const float* Nrm, int64_t ldn, int64_t n_rel, float* wtab, int64_t ldw,
+                   hipStream_t st, const char* name);
 int launch_topk_merge(const uint64_t* part, int64_t nq, int nsplit, int topn, int32_t* top_ids, float* top_scores, hipStream_t st, const char* name);
 int eval_pass_pspace(const float* U, int64_t ldu, const int64_t* u_ids, int64_t nq, const float* I, int64_t ldi, const float* E, int64_t lde,
                      const int32_t* item2ent, int64_t n_items, const float* pref_ws,

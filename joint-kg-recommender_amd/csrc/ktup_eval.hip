@@ -13,6 +13,10 @@
 // Pair-kernel mapping: lane <-> candidate (64-candidate tile staged once in LDS as [k/4][lane] float4, conflict-free
 // ds_read_b128); the 4 waves of a workgroup take different queries, QB = 4 queries at a time, whose vectors are
 // wave-uniform and therefore come through scalar loads into SGPRs.  The (B x N) score row is written coalesced.
+// These kernels are bound by the vector pipe's issue rate, so the arithmetic is written on float pairs (v_pk_add_f32 / v_pk_fma_f32).
+// Whole-pass forms of the same arithmetic (no score matrix): the COUNT form of the pair kernel + pairs_list_kernel (link prediction:
+// counts of candidates ordered before each gold; TransH reads e . w from a per-pass table, pairs_wtab_kernel), sweep_soft_kernel
+// (soft gate, L1) and sweep_hard_kernel (ST-Gumbel gate) with the filtered top-n in their epilogues.
 #include <cstdlib>
 
 #include "ktup_pref_geom.h"

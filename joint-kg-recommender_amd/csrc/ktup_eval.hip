@@ -347,8 +347,9 @@ __global__ __launch_bounds__(PairsWG<MODE>::NT) void pairs_kernel(PairsArgs a) {
       q1p[qi] = qa[qi] + dq4;
       qn[qi] = qa[qi] + 2 * dq4;
     }
-    // COUNT: the queries' gold lists (offsets, the first TH scores and ids: wave-uniform scalar loads) are requested BEFORE the
-    // scores are computed -- after them they were three dependent round trips per query with nothing to hide behind
+    // COUNT: the queries' gold lists (offsets through scalar loads, then the first TH scores and ids of all QB queries with ONE vector
+    // load each: lane qi * TH + k takes slot k of query qi) are requested BEFORE the scores are computed -- after them they were
+    // three dependent round trips per query with nothing to hide behind
     constexpr int TH = 4;
     static_assert(QB == 4 && TH == 4, "lane qi * TH + k <-> (query of the group, gold slot)");
     int64_t cg0[QB];
@@ -390,8 +391,8 @@ __global__ __launch_bounds__(PairsWG<MODE>::NT) void pairs_kernel(PairsArgs a) {
 #pragma unroll
       for (int qi = 0; qi < QB; ++qi) {
         const float sc = desc ? -acc[qi] : acc[qi];
-        // the thresholds are wave-uniform (scalar loads): their sign flip and NaN tests run on the scalar unit, and a query with a NaN
-        // on either side (rare) takes the key compares for all its golds -- nothing of that path is computed otherwise
+        // a threshold read back from its lane (v_readlane) is a scalar: its sign flip and NaN test run on the scalar unit, and a
+        // query with a NaN on either side (rare) takes the key compares for all its golds -- nothing of that path is computed otherwise
         bool slow = __builtin_amdgcn_ballot_w64(sc != sc) != 0;
         uint32_t thb[TH], gid[TH];
 #pragma unroll

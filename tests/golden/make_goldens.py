@@ -664,15 +664,18 @@ def eval_pass_cases():
     try:
         # (d, model, L1_flag, use_st_gumbel): the soft gate at both widths; the hard gate (noise per (user, item, preference), drawn by
         # the reference from torch's global generator: re-seeded per batch and recovered by shim 4) with both distances at d = 100
+        # ... and, appended last so that the earlier cases keep their random draws, the soft gate with the L1 distance: what the
+        # reference's own run scripts evaluate (ktup.sh / transup.sh: -L1_flag -nouse_st_gumbel)
         cases = [(d, name, False, False) for d in (64, 100) for name in ('tup', 'ktup')] + \
-                [(100, name, l1, True) for name in ('tup', 'ktup') for l1 in (False, True)]
+                [(100, name, l1, True) for name in ('tup', 'ktup') for l1 in (False, True)] + \
+                [(100, name, True, False) for name in ('tup', 'ktup')]
         for ci, (d, name, l1, gum) in enumerate(cases):
                 if name == 'tup':
                     m = transUP.TransUPModel(l1, d, NU, NIe, NP_TUP, gum)
                 else:
                     m = jtup.jTransUPModel(l1, d, NU, NIe, NE, NR, i_map_big, new_map_big, False, gum)
                 sd = set_weights(m, gen)
-                tag = '%s.d%d.' % (name, d) if not gum else '%s.hard.%s.d%d.' % (name, 'L1' if l1 else 'L2', d)
+                tag = '%s.hard.%s.d%d.' % (name, 'L1' if l1 else 'L2', d) if gum else ('%s.L1.d%d.' if l1 else '%s.d%d.') % (name, d)
                 out.update({tag + k: v for k, v in sd.items()})
                 if name == 'ktup':
                     out[tag + 'item2ent'] = np.asarray(m.paddingItems(torch.arange(NIe), m.ent_total - 1), dtype=np.int64)

@@ -29,13 +29,16 @@ def _csr(dicts, users, dtype=torch.int32):
     return torch.tensor(off, dtype=torch.int64, device=DEV), torch.tensor(ids, dtype=dtype, device=DEV)
 
 
-@pytest.mark.parametrize('name,d', [('tup', 64), ('ktup', 64), ('tup', 100), ('ktup', 100)])
+@pytest.mark.parametrize('name,d,l1', [('tup', 64, False), ('ktup', 64, False), ('tup', 100, False), ('ktup', 100, False),
+                                       ('tup', 100, True), ('ktup', 100, True)])
 @pytest.mark.parametrize('route', ['one_sweep', 'score_matrix'])
-def test_fused_eval_pass_reproduces_the_reference_pass(name, d, route):
+def test_fused_eval_pass_reproduces_the_reference_pass(name, d, l1, route):
+    """l1: the soft gate with the L1 distance -- the reference's own run scripts (ktup.sh / transup.sh); its one-sweep pass is
+    sweep_soft_kernel (the pair kernel's arithmetic), the squared-L2 one the preference-space sweep."""
     from jTransUP.hip import ops
     g = np.load(os.path.join(GOLDEN, 'eval_pass.npz'))
-    J = json.load(open(os.path.join(GOLDEN, 'eval_pass.json')))['%s.d%d' % (name, d)]
-    tag = '%s.d%d.' % (name, d)
+    tag = ('%s.L1.d%d.' if l1 else '%s.d%d.') % (name, d)
+    J = json.load(open(os.path.join(GOLDEN, 'eval_pass.json')))[tag.rstrip('.')]
     t = lambda n: torch.from_numpy(g[tag + n]).to(DEV)
     users = J['users']                                                   # the users that have test items, ascending
     u = torch.tensor(users, dtype=torch.int64, device=DEV)
@@ -44,15 +47,15 @@ def test_fused_eval_pass_reproduces_the_reference_pass(name, d, route):
     if name == 'tup':
         U, I, P, Pn = (t(n) for n in TUP_NAMES)
         items = ops.eval_pref_items(I, None, P, Pn, None, None, None)
-        full = lambda: ops.eval_tup(U, I, P, Pn, u, False, items=items)
+        full = lambda: ops.eval_tup(U, I, P, Pn, u, l1, items=items)
     else:
         U, I, E, P, Pn, R, Rn = (t(n) for n in KTUP_NAMES)
         i2e = t('item2ent').to(torch.int32)
         items = ops.eval_pref_items(I, E, P, Pn, R, Rn, i2e)
-        full = lambda: ops.eval_ktup(U, I, E, P, Pn, R, Rn, i2e, u, False, items=items)
+        full = lambda: ops.eval_ktup(U, I, E, P, Pn, R, Rn, i2e, u, l1, items=items)
     if route == 'one_sweep':
-        top = ops.eval_pref_topk(U, u, items, False, 10, f_off, f_ids)
-        assert top is not None                                           # the fused pass covers d = 64 / 100, squared L2, soft gate
+        top = ops.eval_pref_topk(U, u, items, l1, 10, f_off, f_ids)
+        assert top is not None                                           # a one-sweep pass covers d = 64 / 100, soft gate, both distances
     else:
         top = ops.topk_filtered(full(), False, 10, f_off, f_ids)
     assert top.cpu().tolist() == J['top_ids']

@@ -342,22 +342,24 @@ def test_kg_training_steps_golden(name, opt, lr):
 
 
 # ------------------------------------------------------------------------------------------------ whole evaluation pass
-@pytest.mark.parametrize('name,d', [('tup', 64), ('ktup', 64), ('tup', 100), ('ktup', 100)])
-def test_eval_pass_golden(name, d):
+@pytest.mark.parametrize('name,d,l1', [('tup', 64, False), ('ktup', 64, False), ('tup', 100, False), ('ktup', 100, False),
+                                       ('tup', 100, True), ('ktup', 100, True)])
+def test_eval_pass_golden(name, d, l1):
     """item_recommendation.py:27-53 / knowledgable_recommendation.py:50-104 through the reference's own evalRecProcess: the
-    oracle's all-item scores + ranking walk reproduce the per-user metric rows, the ranked ids and the pass means."""
+    oracle's all-item scores + ranking walk reproduce the per-user metric rows, the ranked ids and the pass means.  L1 = the distance
+    of the reference's own run scripts (ktup.sh / transup.sh: -L1_flag with the soft gate)."""
     g = np.load(os.path.join(GOLDEN, 'eval_pass.npz'))
-    J = json.load(open(os.path.join(GOLDEN, 'eval_pass.json')))['%s.d%d' % (name, d)]
-    tag = '%s.d%d.' % (name, d)
+    tag = ('%s.L1.d%d.' if l1 else '%s.d%d.') % (name, d)
+    J = json.load(open(os.path.join(GOLDEN, 'eval_pass.json')))[tag.rstrip('.')]
     eval_dict = {int(u): set(v) for u, v in J['eval'].items()}
     all_dicts = [{int(u): set(v) for u, v in J[k].items()} for k in ('train', 'valid')]
     users = torch.arange(37)
     if name == 'tup':
         W = [T(g[tag + n]) for n in TUP_NAMES]
-        scores = O.eval_tup(*W, users, False)
+        scores = O.eval_tup(*W, users, l1)
     else:
         W = [T(g[tag + n]) for n in KTUP_NAMES]
-        scores = O.eval_ktup_rec(*W, T(g[tag + 'item2ent']), users, False)
+        scores = O.eval_ktup_rec(*W, T(g[tag + 'item2ent']), users, l1)
     rows = O.eval_rec_rows(list(zip(users.tolist(), scores.numpy())), eval_dict, all_dicts, descending=False, topn=10)
     rows.sort(key=lambda r: r[-1][0])
     assert [r[-1][0] for r in rows] == J['users']

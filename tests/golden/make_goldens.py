@@ -722,6 +722,63 @@ def eval_pass_cases():
 
 
 
+def kg_pass_cases():
+    """A whole link-prediction evaluation pass of the REFERENCE (knowledge_representation.py:28-75): evaluateHead / evaluateTail for every
+    (t, r) / (h, r) key in the eval iterator's batches and its own evalKGProcess (worker processes, filter sets; stable argsort, shim 3):
+    hit and filtered rank per (key, gold entity) and the pass means -- TransE and TransH with both distances (L1 is what transe.sh /
+    transh.sh / ktup.sh run) at d = 100 on 230 entities.  Own seeds, own files (kg_pass.npz / kg_pass.json)."""
+    rng = np.random.RandomState(81)
+    gen = torch.Generator().manual_seed(83)
+    NEk, d, NKEY = 230, 100, 60
+    out, meta = {}, {}
+    real_argsort = np.argsort
+    np.argsort = lambda a, *aa, **kw: real_argsort(a, *aa, **dict(kw, kind='stable'))
+    try:
+        for name, mod, cls in (('transe', transE, 'TransEModel'), ('transh', transH, 'TransHModel')):
+            for l1 in (True, False):
+                m = getattr(mod, cls)(l1, d, NEk, NR)
+                sd = set_weights(m, gen)
+                tag = '%s.%s.' % (name, 'L1' if l1 else 'L2')
+                out.update({tag + k: v for k, v in sd.items()})
+                meta[tag.rstrip('.')] = {}
+                for side in ('head', 'tail'):                           # head prediction: keys (t, r), golds are heads
+                    keys = []
+                    while len(keys) < NKEY:
+                        k = (int(rng.randint(NEk)), int(rng.randint(NR)))
+                        if k not in keys:
+                            keys.append(k)
+                    eval_dict, train_dict, valid_dict = {}, {}, {}
+                    for k in keys:
+                        perm = rng.permutation(NEk)
+                        ng, nt, nv = rng.randint(1, 5), rng.randint(0, 26), rng.randint(0, 6)
+                        eval_dict[k] = set(int(x) for x in perm[:ng])
+                        if nt:
+                            train_dict[k] = set(int(x) for x in perm[ng:ng + nt])
+                        if nv:
+                            valid_dict[k] = set(int(x) for x in perm[ng + nt:ng + nt + nv])
+                    results = []
+                    for b0 in range(0, NKEY, 16):                       # the eval iterator's batches
+                        batch = keys[b0:b0 + 16]
+                        e = V(torch.LongTensor([k[0] for k in batch]))
+                        r = V(torch.LongTensor([k[1] for k in batch]))
+                        scores = m.evaluateHead(e, r) if side == 'head' else m.evaluateTail(e, r)
+                        preds = zip(batch, scores.data.cpu().numpy())
+                        results.extend(rmisc.evalKGProcess(list(preds), eval_dict, all_dicts=[train_dict, valid_dict], descending=False,
+                                                           num_processes=2, topn=10, queue_limit=10))
+                    results = sorted((tuple(int(x) for x in r[2]), int(r[3]), int(r[1]), int(r[0])) for r in results)   # worker order is arbitrary
+                    perf = np.array([[r[3], r[2]] for r in results], dtype=np.float64)
+                    ser = lambda dct: [[k[0], k[1], sorted(v)] for k, v in sorted(dct.items())]
+                    meta[tag.rstrip('.')][side] = {
+                        'keys': [list(k) for k in keys], 'eval': ser(eval_dict), 'train': ser(train_dict), 'valid': ser(valid_dict),
+                        'rows': [[r[0][0], r[0][1], r[1], r[2], r[3]] for r in results],   # entity, relation, gold id, filtered rank, hit
+                        'mean': [float(x) for x in perf.mean(axis=0)]}                     # (hit ratio, mean rank): knowledge_representation.py:73-75
+    finally:
+        np.argsort = real_argsort
+    save('kg_pass', **out)
+    with open(os.path.join(args.out, 'kg_pass.json'), 'w') as f:
+        json.dump(meta, f, indent=0, sort_keys=True)
+
+
 def fm_cases():
     """FM (fm.py) and coFM (cofm.py, shared and separate item tables): scores, BPR (target +1, trainer.py:15-17) / margin losses with
     the drivers' regularisers, gradients, and the all-candidate evaluation matrices.  Shim 6.  Own seeds, own file."""
@@ -802,3 +859,4 @@ if __name__ == '__main__':
     train_step_cases()
     eval_pass_cases()
     fm_cases()
+    kg_pass_cases()

@@ -103,3 +103,45 @@ def test_hard_gate_eval_pass_reproduces_the_reference_pass(name, l1, route):
     assert top.cpu().tolist() == J['top_ids']
     perf = ops.rec_metrics(top, g_off, g_ids).cpu().numpy()
     np.testing.assert_allclose(perf, g[tag + 'perf'], rtol=1e-12, atol=0)
+
+
+@pytest.mark.parametrize('name', ['transe', 'transh'])
+@pytest.mark.parametrize('l1', [True, False])
+@pytest.mark.parametrize('route', ['one_call', 'chunked'])
+def test_kg_pass_reproduces_the_reference_pass(name, l1, route):
+    """The link-prediction pass behind one call (ktup_eval_kg_ranks_fused: no score matrix; the pair kernels' COUNT form for L1, the
+    matrix-core sweep for squared L2) and the chunked route (K12 / K13 + K18 per chunk) against a whole pass of the REFERENCE:
+    evaluateHead / evaluateTail for every key and its own evalKGProcess (tests/golden/make_goldens.py kg_pass_cases;
+    knowledge_representation.py:28-75, utils/misc.py:61-146), head and tail prediction, L1 (the distance of transe.sh / transh.sh /
+    ktup.sh) and squared L2: every filtered rank and the pass's (hit ratio, mean rank) equal the reference's.  (Squared L2 runs as
+    |c|^2 - 2 c.e + |e|^2 on the matrix cores -- DESIGN.md section 4's declared deviation for fp32 near-ties; none occurs in these 1208
+    (key, gold) entries.)"""
+    from jTransUP.hip import ops
+    g = np.load(os.path.join(GOLDEN, 'kg_pass.npz'))
+    tag = '%s.%s' % (name, 'L1' if l1 else 'L2')
+    J = json.load(open(os.path.join(GOLDEN, 'kg_pass.json')))[tag]
+    t = lambda n: torch.from_numpy(g[tag + '.' + n]).to(DEV)
+    E, R = t('ent_embeddings.weight'), t('rel_embeddings.weight')
+    N = t('norm_embeddings.weight') if name == 'transh' else None
+    for side in ('head', 'tail'):
+        S = J[side]
+        keys = [(int(e), int(r)) for e, r in S['keys']]
+        gold = {(int(e), int(r)): sorted(v) for e, r, v in S['eval']}
+        filt = {}
+        for k in ('train', 'valid'):
+            for e, r, v in S[k]:
+                filt.setdefault((int(e), int(r)), set()).update(v)
+        want = {(int(e), int(r), int(gid)): (int(rank), int(hit)) for e, r, gid, rank, hit in S['rows']}
+        g_off, g_ids, f_off, f_ids, expect = [0], [], [0], [], []
+        for k in keys:
+            g_ids += gold[k]; g_off.append(len(g_ids))
+            f_ids += sorted(filt.get(k, ())); f_off.append(len(f_ids))
+            expect += [want[k + (gid,)][0] for gid in gold[k]]
+        dv = lambda a, dt: torch.tensor(a, dtype=dt, device=DEV)
+        q, r = dv([k[0] for k in keys], torch.int64), dv([k[1] for k in keys], torch.int64)
+        ranks = ops.eval_kg_ranks(E, R, N, q, r, l1, side == 'head', False, dv(g_off, torch.int64), dv(g_ids, torch.int32),
+                                  dv(f_off, torch.int64), dv(f_ids, torch.int32), chunk=16, fused=None if route == 'one_call' else False)
+        got = ranks.cpu().numpy()[:len(expect)].astype(np.int64)
+        expect = np.asarray(expect, dtype=np.int64)
+        assert got.tolist() == expect.tolist()
+        np.testing.assert_allclose([float((got < 10).mean()), float(got.mean())], S['mean'], rtol=1e-12)

@@ -433,3 +433,32 @@ def test_fm_cofm_golden(golden, d):
             close(O.eval_fm(*a, ids['uq']), g[tag + 'evalRec'])
             close(O.eval_transe(E, R, ids['eq'], ids['rq'], l1, True), g[tag + 'evalHead'])
             close(O.eval_transe(E, R, ids['eq'], ids['rq'], l1, False), g[tag + 'evalTail'])
+
+
+# ------------------------------------------------------------------------------------------------ whole link-prediction pass
+def _kg_side(S):
+    key = lambda e, r: (int(e), int(r))
+    eval_dict = {key(e, r): set(v) for e, r, v in S['eval']}
+    all_dicts = [{key(e, r): set(v) for e, r, v in S[k]} for k in ('train', 'valid')]
+    return [key(e, r) for e, r in S['keys']], eval_dict, all_dicts
+
+
+@pytest.mark.parametrize('name', ['transe', 'transh'])
+@pytest.mark.parametrize('l1', [True, False])
+def test_kg_pass_golden(name, l1):
+    """knowledge_representation.py:28-75 through the reference's own evalKGProcess (tests/golden/make_goldens.py kg_pass_cases): the
+    oracle's all-entity scores + ranking walk reproduce hit and filtered rank of every (key, gold entity) and the pass means, head and
+    tail prediction, both distances (L1 = transe.sh / transh.sh / ktup.sh)."""
+    g = np.load(os.path.join(GOLDEN, 'kg_pass.npz'))
+    tag = '%s.%s' % (name, 'L1' if l1 else 'L2')
+    J = json.load(open(os.path.join(GOLDEN, 'kg_pass.json')))[tag]
+    E, R = T(g[tag + '.ent_embeddings.weight']), T(g[tag + '.rel_embeddings.weight'])
+    N = T(g[tag + '.norm_embeddings.weight']) if name == 'transh' else None
+    for side in ('head', 'tail'):
+        keys, eval_dict, all_dicts = _kg_side(J[side])
+        q, r = torch.tensor([k[0] for k in keys]), torch.tensor([k[1] for k in keys])
+        scores = O.eval_transe(E, R, q, r, l1, side == 'head') if N is None else O.eval_transh(E, R, N, q, r, l1, side == 'head')
+        rows = O.eval_kg_rows(list(zip(keys, scores.numpy())), eval_dict, all_dicts, descending=False, topn=10)
+        got = sorted([k[0], k[1], int(gid), int(rank), int(hit)] for hit, rank, k, gid in rows)
+        assert got == J[side]['rows']
+        np.testing.assert_allclose(np.array([[r_[4], r_[3]] for r_ in got], dtype=np.float64).mean(axis=0), J[side]['mean'], rtol=1e-12)

@@ -164,6 +164,21 @@ def world(rng, gen, wi):
                 note('ktup.eval', O.eval_transh(E, R, Rn, eq, rq, l1, True), npy(m.evaluateHead(V(eq), V(rq))))
                 note('ktup.eval', O.eval_transh(E, R, Rn, eq, rq, l1, False), npy(m.evaluateTail(V(eq), V(rq))))
 
+    # the two baselines that share this path's kernels (CKE.py, CFKG.py): rec scores and all-item evaluation
+    from jTransUP.models import CKE as rcke, CFKG as rcfkg           # (the REFERENCE's, like every jTransUP import here)
+    for l1 in (False, True):
+        if d <= 64:                                              # CKE carries TransR's d x d projections
+            m = rcke.CKE(l1, d, NU, NI, NE, NR, i_map, new_map); MG.set_weights(m, gen)
+            U_, I_, E_ = params(m, ['user_embeddings.weight', 'item_embeddings.weight', 'ent_embeddings.weight'])
+            i2e = torch.from_numpy(np.asarray(m.paddingItems(torch.arange(NI), m.ent_total - 1), dtype=np.int64))
+            note('cke.score', O.score_cke_rec(U_, I_, E_, i2e, u, pi), npy(m((V(u), V(pi)), None, is_rec=True)))
+            note('cke.eval', O.eval_cke_rec(U_, I_, E_, i2e, uq), npy(m.evaluateRec(V(uq))))
+        n_ent = max(NE, NI)                                      # CFKG: item ids index the shared entity table
+        m = rcfkg.CFKG(l1, d, NU, NI, n_ent, NR); MG.set_weights(m, gen)
+        U_, E_, R_ = params(m, ['user_embeddings.weight', 'ent_embeddings.weight', 'rel_embeddings.weight'])
+        note('cfkg.score', O.score_cfkg_rec(U_, E_, R_, u, pi, l1), npy(m((V(u), V(pi)), None, is_rec=True)))
+        note('cfkg.eval', O.eval_cfkg_rec(U_, E_, R_, uq, l1), npy(m.evaluateRec(V(uq))))
+
     # the ranking walks on random rows with repeated scores (stable argsort: shim 3, the tie rule the build declares)
     real_argsort = np.argsort
     np.argsort = lambda a, *aa, **kw: real_argsort(a, *aa, **dict(kw, kind='stable'))

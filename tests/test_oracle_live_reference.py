@@ -23,6 +23,6 @@ def test_oracle_matches_the_live_reference_on_random_worlds(seed):
     rep = json.loads(out.stdout.strip().splitlines()[-1])
     worst = rep['worst_excess_over_bar']
     assert worst.pop('ranking.mismatches') == 0
-    assert len(worst) == 20                                      # every family ran: scores / evaluation matrices of six model kinds, step loss + gradients of four
+    assert len(worst) == 24                                      # every family ran: scores / evaluation matrices of eight model kinds, step loss + gradients of four
     # 1.0 = the goldens' bars (|diff| <= 1e-6 + 1e-5 |reference|; TransR 1e-5 + 1e-4; gradients 1e-6 + 1e-4)
     assert all(v <= 1.0 for v in worst.values()), worst

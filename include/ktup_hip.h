@@ -329,9 +329,10 @@ int ktup_eval_gold_ranks(const float* scores, int64_t lds, int64_t nq, int64_t n
  * {20, 36, 64, 100, 128} with at most 8 golds per key sweeps on the matrix cores; L1, other widths and larger gold sets score the
  * tiles with the pair kernels of the per-batch entry points (any d) and count in their epilogue.  Same arguments and results as
  * ktup_eval_kg_ranks, all keys in one go; n_filt / n_gold = lengths of the id arrays, max_golds = the largest gold set of a key
- * (host side).  n_rel = rows of R / Nrm: the matrix-core sweep takes TransH's second product w.e, which depends on (relation,
- * candidate) only, from an n_rel x n_cand table computed once per pass in `ws` (n_rel = 0, option kg_wtab = 0 or a table beyond
- * 1 GiB: both products in the sweep; the same integers either way).                                                            */
+ * (host side).  n_rel = rows of R / Nrm: TransH's product w.e depends on (relation, candidate) only and comes from an
+ * n_rel x n_cand table computed once per pass in `ws` -- by the matrix-core sweep and, filled with the pair kernels' own first-pass
+ * operations (the same bits), by the pair-kernel route (n_rel = 0, option kg_wtab = 0, a table beyond 1 GiB or rows that are not
+ * 16-byte aligned: the product is recomputed per pair; the same integers either way).                                           */
 int ktup_eval_kg_ranks_fused_supported(int model, int d, int l1, int64_t max_golds);
 size_t ktup_eval_kg_ranks_fused_workspace_bytes(int model, int d, int64_t nq, int64_t n_gold, int64_t n_filt, int64_t n_cand,
                                                 int64_t n_rel);

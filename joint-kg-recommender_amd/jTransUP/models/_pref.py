@@ -16,6 +16,24 @@ def st_gumbel_softmax(logits, temperature=1.0, uniform=None):
     return (y_hard - y).detach() + y
 
 
+class GateHelpers(object):
+    """The gate's helper methods the reference's preference models expose (transUP.py:118-170, jTransUP.py:262-314), for callers
+    that use them directly; cold path like getPreferences."""
+
+    def convert_to_one_hot(self, indices, num_classes):
+        """transUP.py:118-135: (...,) integer indices -> (..., num_classes) one-hot of the indices' dtype."""
+        shape = tuple(indices.shape) + (int(num_classes),)
+        return indices.new_zeros(shape).scatter_(indices.dim(), indices.unsqueeze(indices.dim()), 1)
+
+    def masked_softmax(self, logits):
+        """transUP.py:138-141: a softmax over the last dimension (the reference's version masks nothing either)."""
+        return F.softmax(logits, dim=logits.dim() - 1)
+
+    def st_gumbel_softmax(self, logits, temperature=1.0):
+        """transUP.py:143-170: one-hot forward value, softmax backward; noise from torch's generator like the reference's."""
+        return st_gumbel_softmax(logits, temperature)
+
+
 class GumbelState(object):
     """Production ST-Gumbel draws come from Philox4x32-10 on the device; (seed, offset) advance per call so
     forward and backward of one call see the same noise while successive calls are independent."""

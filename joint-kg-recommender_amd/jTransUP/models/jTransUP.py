@@ -4,7 +4,7 @@ import torch.nn as nn
 
 from jTransUP.hip import ops
 from jTransUP.models._init import GradToggle, make_embedding, xavier_table
-from jTransUP.models._pref import GumbelState, st_gumbel_softmax
+from jTransUP.models._pref import GateHelpers, GumbelState, st_gumbel_softmax
 from jTransUP.utils.misc import to_gpu
 
 
@@ -14,7 +14,7 @@ def build_model(FLAGS, user_total, item_total, entity_total, relation_total, i_m
                          new_map=new_map, isShare=FLAGS.share_embeddings, use_st_gumbel=FLAGS.use_st_gumbel)
 
 
-class jTransUPModel(nn.Module, GradToggle):
+class jTransUPModel(nn.Module, GradToggle, GateHelpers):
     def __init__(self, L1_flag, embedding_size, user_total, item_total, entity_total, relation_total, i_map, new_map,
                  isShare, use_st_gumbel):
         super(jTransUPModel, self).__init__()

@@ -4,7 +4,7 @@ import torch.nn as nn
 
 from jTransUP.hip import ops
 from jTransUP.models._init import GradToggle, make_embedding, xavier_table
-from jTransUP.models._pref import GumbelState, st_gumbel_softmax
+from jTransUP.models._pref import GateHelpers, GumbelState, st_gumbel_softmax
 from jTransUP.utils.misc import to_gpu
 
 
@@ -13,7 +13,7 @@ def build_model(FLAGS, user_total, item_total, entity_total, relation_total, i_m
                         item_total=item_total, preference_total=FLAGS.num_preferences, use_st_gumbel=FLAGS.use_st_gumbel)
 
 
-class TransUPModel(nn.Module, GradToggle):
+class TransUPModel(nn.Module, GradToggle, GateHelpers):
     def __init__(self, L1_flag, embedding_size, user_total, item_total, preference_total, use_st_gumbel):
         super(TransUPModel, self).__init__()
         self.L1_flag = L1_flag

@@ -94,3 +94,36 @@ def test_the_reference_scripts_command_lines_parse_to_the_same_values():
         seen += 1
     assert seen >= 10                                                     # bprmf, fm, cofm, cke, ktup, ktup_eval, transe, transh, transr, transup ...
     FLAGS.reset()
+
+
+def test_module_class_surface_matches_the_reference():
+    """Every model class of the reference's jTransUP/models (tests/golden/live_surface.py, in a subprocess: both packages are called
+    jTransUP): same module, class, constructor arguments and public methods with the same leading argument names in the same order;
+    what this build adds to a signature comes after them and is optional."""
+    import importlib
+    import inspect
+    import json
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE='1')
+    env.pop('PYTHONPATH', None)
+    out = subprocess.run([sys.executable, os.path.join(here, 'golden', 'live_surface.py'), '--ref', REF], capture_output=True, text=True,
+                         timeout=300, env=env, cwd=os.path.dirname(here))
+    assert out.returncode == 0, out.stderr[-2000:]
+    ref = json.loads(out.stdout.strip().splitlines()[-1])
+    assert len(ref) == 10
+    checked = 0
+    for key, methods in ref.items():
+        mod, cname = key.split('.')
+        cls = getattr(importlib.import_module('jTransUP.models.' + mod), cname)
+        for name, args in methods.items():
+            assert hasattr(cls, name), (key, name)
+            sig = inspect.signature(getattr(cls, name))
+            ours = list(sig.parameters)
+            assert ours[:len(args)] == args, (key, name, ours, args)
+            for extra in ours[len(args):]:
+                p = sig.parameters[extra]
+                assert p.default is not inspect.Parameter.empty or p.kind in (p.VAR_POSITIONAL, p.VAR_KEYWORD), (key, name, extra)
+            checked += 1
+    assert checked >= 60

@@ -305,3 +305,32 @@ def test_wave_model_counts_the_waits_a_lone_wave_cannot_hide():
     assert chain['clocks'] >= 4 * 32 and chain['stall_mfma_dep'] > 0
     thin = W.model(['v_mfma_f32_4x4x1_16b_f32 a[0:3], v1, v2, a[0:3]'] * 4)
     assert thin['clocks'] < W.model(['v_mfma_f32_16x16x4_f32 a[0:3], v1, v2, a[0:3]'] * 4)['clocks']
+
+
+def test_gate_helper_methods_of_the_preference_models():
+    """transUP.py:118-170 / jTransUP.py:262-314: convert_to_one_hot, masked_softmax, st_gumbel_softmax exist on both preference
+    models with the reference's semantics (one-hot forward value, softmax gradient, noise from torch's global generator)."""
+    import torch
+    import torch.nn.functional as F
+    from oracle import cpu_ref as O
+    from jTransUP.models.transUP import TransUPModel
+    from jTransUP.models.jTransUP import jTransUPModel
+    tup = TransUPModel(False, 8, 5, 6, 3, True)
+    ktup = jTransUPModel(False, 8, 5, 6, 7, 3, {i: i for i in range(6)}, {i: (i, i) for i in range(6)}, False, True)
+    for m in (tup, ktup):
+        idx = torch.tensor([[2, 0], [1, 3]])
+        assert torch.equal(m.convert_to_one_hot(idx, 4), F.one_hot(idx, 4)) and m.convert_to_one_hot(idx, 4).dtype == idx.dtype
+        logits = torch.randn(4, 7, 5, requires_grad=True)
+        assert torch.allclose(m.masked_softmax(logits), F.softmax(logits, dim=2))
+        torch.manual_seed(11)
+        y = m.st_gumbel_softmax(logits, temperature=0.7)
+        torch.manual_seed(11)
+        uni = torch.empty(4, 7, 5).uniform_()                       # the draw the method makes (shim 4 of tests/golden/make_goldens.py)
+        eps = 1e-20
+        soft = F.softmax((logits + (-torch.log(-torch.log(uni + eps) + eps))) / 0.7, dim=2)
+        assert torch.equal(y.detach(), F.one_hot(soft.argmax(2), 5).float())          # forward value: the one-hot
+        g, = torch.autograd.grad((y * torch.arange(5.)).sum(), logits)
+        g_soft, = torch.autograd.grad((soft * torch.arange(5.)).sum(), logits)
+        assert torch.allclose(g, g_soft)                            # backward: the softmax's
+        torch.manual_seed(11)
+        assert torch.equal(m.st_gumbel_softmax(logits).detach(), O.st_gumbel_softmax(logits.detach(), uni))

@@ -65,6 +65,14 @@ def getNegRatings(ratingList, itemTotal, all_dicts=None):
     return [r[0] for r in ratingList], [r[1] for r in ratingList], ni
 
 
+def getTrainRatingBatch(rating_batch, item_total, all_dicts=None):
+    """data.py:5-10: (users, positive items, one sampled negative each) of a batch of ratings.  The reference's body calls an
+    `addNegRatings` that its module does not define (the drivers call getNegRatings themselves); this one returns what that
+    call was meant to: getNegRatings of the batch."""
+    batch = rating_batch.tolist() if hasattr(rating_batch, 'tolist') else list(rating_batch)
+    return getNegRatings(batch, item_total, all_dicts=all_dicts)
+
+
 def MakeTrainIterator(train_data, batch_size, negtive_samples=1):
     """data.py:87-110: endless iterator; shuffles an index list each epoch and DROPS the tail partial batch."""
     train_list = np.array(train_data)

@@ -12,6 +12,47 @@ def to_gpu(var):
     return var
 
 
+# ---- the projection helpers the reference's models call (utils/misc.py:18-37).  Plain tensor expressions for callers that use them
+# directly; the models of this build do not come through here (their projections are fused into the HIP kernels).
+def projection_transH_pytorch(original, norm):
+    """utils/misc.py:18-19: the component of `original` inside the hyperplane with normal `norm` (last dimension)."""
+    return original - torch.sum(original * norm, dim=original.dim() - 1, keepdim=True) * norm
+
+
+def projection_transR_pytorch(original, proj_matrix):
+    """utils/misc.py:21-26: rows (B, d_e) through their own (d_r x d_e) matrices given flat as (B, d_r * d_e) -> (B, d_r)."""
+    d_e = original.shape[1]
+    d_r = proj_matrix.shape[1] // d_e
+    return torch.matmul(proj_matrix.view(-1, d_r, d_e), original.view(-1, d_e, 1)).view(-1, d_r)
+
+
+def projection_transR_pytorch_batch(original, proj_matrix):
+    """utils/misc.py:29-33: every row of `original` (E, d_e) through each of B matrices (B, d_r * d_e) -> (B, E, d_r)."""
+    d_e = original.shape[1]
+    d_r = proj_matrix.shape[1] // d_e
+    return torch.matmul(proj_matrix.view(-1, d_r, d_e), original.transpose(0, 1)).transpose(1, 2)
+
+
+def projection_transD_pytorch_samesize(entity_embedding, entity_projection, relation_projection):
+    """utils/misc.py:36-37 (TransD itself is out of scope here: `init_model` refuses it; the helper is kept for callers)."""
+    return entity_embedding + torch.sum(entity_embedding * entity_projection, dim=entity_embedding.dim() - 1, keepdim=True) * relation_projection
+
+
+def recursively_set_device(inp, gpu=USE_CUDA):
+    """utils/misc.py:250-263, including its quirks: dict values are replaced in place, a tuple comes back as a generator, and the
+    `gpu` argument is ignored in favour of USE_CUDA."""
+    if hasattr(inp, 'keys'):
+        for k in list(inp.keys()):
+            inp[k] = recursively_set_device(inp[k], USE_CUDA)
+    elif isinstance(inp, list):
+        return [recursively_set_device(ii, USE_CUDA) for ii in inp]
+    elif isinstance(inp, tuple):
+        return (recursively_set_device(ii, USE_CUDA) for ii in inp)
+    elif hasattr(inp, 'cpu'):
+        inp = inp.cuda() if USE_CUDA else inp.cpu()
+    return inp
+
+
 class Accumulator(object):
     """utils/misc.py:39-59 -- trailing statistics."""
 
@@ -34,14 +75,18 @@ class Accumulator(object):
 
 
 # ---- ranking entry points (utils/misc.py:61-248 of the reference), device-backed: see jTransUP/utils/ranking.py
-def evalRecProcess(*args, **kwargs):
+def evalRecProcess(pred_scores, eval_dict, all_dicts=None, descending=True, num_processes=None, topn=10, queue_limit=10, **kwargs):
+    """utils/misc.py:186-210 (`num_processes` / `queue_limit` accepted and ignored: no process fan-out)."""
     from jTransUP.utils.ranking import evalRecProcess as f
-    return f(*args, **kwargs)
+    return f(pred_scores, eval_dict, all_dicts=all_dicts, descending=descending, num_processes=num_processes, topn=topn,
+             queue_limit=queue_limit, **kwargs)
 
 
-def evalKGProcess(*args, **kwargs):
+def evalKGProcess(pred_scores, eval_dict, all_dicts=None, descending=True, num_processes=None, topn=10, queue_limit=10, **kwargs):
+    """utils/misc.py:98-122."""
     from jTransUP.utils.ranking import evalKGProcess as f
-    return f(*args, **kwargs)
+    return f(pred_scores, eval_dict, all_dicts=all_dicts, descending=descending, num_processes=num_processes, topn=topn,
+             queue_limit=queue_limit, **kwargs)
 
 
 def getRecPerformance(pred, gold, fliter_samples=None, topn=10):

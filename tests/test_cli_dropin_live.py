@@ -96,34 +96,58 @@ def test_the_reference_scripts_command_lines_parse_to_the_same_values():
     FLAGS.reset()
 
 
-def test_module_class_surface_matches_the_reference():
-    """Every model class of the reference's jTransUP/models (tests/golden/live_surface.py, in a subprocess: both packages are called
-    jTransUP): same module, class, constructor arguments and public methods with the same leading argument names in the same order;
-    what this build adds to a signature comes after them and is optional."""
+IN_SCOPE = ['models/base', 'models/bprmf', 'models/fm', 'models/transE', 'models/transH', 'models/transR', 'models/transUP', 'models/jTransUP',
+            'models/CKE', 'models/CFKG', 'models/cofm', 'models/item_recommendation', 'models/knowledge_representation',
+            'models/knowledgable_recommendation', 'utils/loss', 'utils/misc', 'utils/trainer', 'utils/evaluation', 'utils/data',
+            'data/load_rating_data', 'data/load_triple_data', 'data/load_kg_rating_data']
+# the reference's multiprocessing worker classes behind evalRecProcess / evalKGProcess: this build ranks on the device, there is no
+# process fan-out to mirror
+NOT_MIRRORED = {'utils/misc': {'MyEvalKGProcess', 'MyEvalRecProcess'}}
+
+
+def _surface(path):
+    """Top-level functions and classes' public methods of a source file: name -> (positional argument names, number with defaults,
+    takes *args / **kwargs); classes also list their bases.  Read with ast: nothing is imported or executed."""
+    tree = ast.parse(open(path).read())
+    sig = lambda fn: ([a.arg for a in fn.args.args], len(fn.args.defaults), fn.args.vararg is not None or fn.args.kwarg is not None)
+    funcs, classes = {}, {}
+    for node in tree.body:
+        if isinstance(node, ast.FunctionDef):
+            funcs[node.name] = sig(node)
+        elif isinstance(node, ast.ClassDef):
+            methods = {m.name: sig(m) for m in node.body if isinstance(m, ast.FunctionDef) and (not m.name.startswith('_') or m.name == '__init__')}
+            classes[node.name] = methods
+    return funcs, classes
+
+
+def test_module_surface_matches_the_reference():
+    """Every in-scope module of the reference's package (SURVEY.md section 2 minus the rows DESIGN.md section 0 puts out of scope: transD,
+    log parsers, preprocessing, plotting, the visdom UI): each of its top-level functions and each public method of its classes exists
+    here under the same name with the same leading argument names in the same order; whatever this build adds to a signature comes
+    after them and is optional.  Methods may live in a base class here (GradToggle, GateHelpers): resolved through the imported class."""
     import importlib
     import inspect
-    import json
-    import subprocess
-    import sys
-    here = os.path.dirname(os.path.abspath(__file__))
-    env = dict(os.environ, PYTHONDONTWRITEBYTECODE='1')
-    env.pop('PYTHONPATH', None)
-    out = subprocess.run([sys.executable, os.path.join(here, 'golden', 'live_surface.py'), '--ref', REF], capture_output=True, text=True,
-                         timeout=300, env=env, cwd=os.path.dirname(here))
-    assert out.returncode == 0, out.stderr[-2000:]
-    ref = json.loads(out.stdout.strip().splitlines()[-1])
-    assert len(ref) == 10
+    ours_root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'joint-kg-recommender_amd', 'jTransUP')
     checked = 0
-    for key, methods in ref.items():
-        mod, cname = key.split('.')
-        cls = getattr(importlib.import_module('jTransUP.models.' + mod), cname)
-        for name, args in methods.items():
-            assert hasattr(cls, name), (key, name)
-            sig = inspect.signature(getattr(cls, name))
-            ours = list(sig.parameters)
-            assert ours[:len(args)] == args, (key, name, ours, args)
-            for extra in ours[len(args):]:
-                p = sig.parameters[extra]
-                assert p.default is not inspect.Parameter.empty or p.kind in (p.VAR_POSITIONAL, p.VAR_KEYWORD), (key, name, extra)
+    for mod in IN_SCOPE:
+        rfuncs, rclasses = _surface(os.path.join(REF, 'jTransUP', mod + '.py'))
+        ofuncs, oclasses = _surface(os.path.join(ours_root, mod + '.py'))
+        for name, (args, ndef, star) in rfuncs.items():
+            assert name in ofuncs, (mod, name)
+            oargs, ondef, ostar = ofuncs[name]
+            assert oargs[:len(args)] == args, (mod, name, oargs, args)
+            assert ostar or ondef >= len(oargs) - len(args), (mod, name, oargs, args)      # the extras are optional
             checked += 1
-    assert checked >= 60
+        for cname, methods in rclasses.items():
+            if cname in NOT_MIRRORED.get(mod, ()):
+                continue
+            assert cname in oclasses, (mod, cname)
+            cls = getattr(importlib.import_module('jTransUP.' + mod.replace('/', '.')), cname)
+            for name, (args, ndef, star) in methods.items():
+                assert hasattr(cls, name), (mod, cname, name)
+                p = inspect.signature(getattr(cls, name)).parameters
+                oargs = [k for k, v in p.items() if v.kind in (v.POSITIONAL_ONLY, v.POSITIONAL_OR_KEYWORD)]
+                assert oargs[:len(args)] == args, (mod, cname, name, oargs, args)
+                assert all(p[k].default is not inspect.Parameter.empty for k in oargs[len(args):]), (mod, cname, name, oargs, args)
+                checked += 1
+    assert checked >= 150

@@ -1,0 +1,103 @@
+#!/usr/bin/env python3
+"""One seeded scenario over the HOST-side functions of the path's callers, run against either package:
+
+    python tests/golden/live_host.py --pkg /root/reference            # the reference's jTransUP
+    python tests/golden/live_host.py --pkg joint-kg-recommender_amd   # this build's mirror of the same interface
+
+and printed as one JSON document.  tests/test_cli_dropin_live.py runs both (two subprocesses: the packages share their name) and
+requires equal documents: the loaders on the same synthetic dataset files (vocabularies, rating / triple lists, the per-key dicts,
+the entity-item alignment of rebuildEntityItemVocab), the train / eval iterators and the negative samplers under the same
+`random.seed` (same draws in the same order), and the metric helpers of utils/evaluation.py."""
+import json
+import os
+import random
+import sys
+import tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PKG = sys.argv[sys.argv.index('--pkg') + 1]
+sys.path.insert(0, os.path.abspath(PKG))
+sys.path.insert(0, os.path.dirname(HERE))                        # tests/: synth.py
+import numpy as np                                               # noqa: E402
+
+if not hasattr(np, 'asfarray'):
+    np.asfarray = lambda a: np.asarray(a, dtype=np.float64)      # removed in NumPy 2 (the reference's utils/evaluation.py:69 uses it)
+
+from synth import make_dataset                                   # noqa: E402
+from jTransUP.data import load_kg_rating_data, load_rating_data, load_triple_data   # noqa: E402
+from jTransUP.utils import data as udata                         # noqa: E402
+from jTransUP.utils import evaluation as ueval                   # noqa: E402
+
+
+def plain(x):
+    """JSON-able, order-stable image of the loaders' structures (dicts keyed by ints / tuples, sets, numpy scalars)."""
+    if hasattr(x, '__next__'):
+        return '<iterator>'                                      # a train iterator (endless): its batches are taken separately
+    if isinstance(x, dict):
+        return sorted([[plain(k), plain(v)] for k, v in x.items()], key=lambda kv: json.dumps(kv[0]))
+    if isinstance(x, (set, frozenset)):
+        return sorted(plain(v) for v in x)
+    if isinstance(x, (list, tuple)):
+        return [plain(v) for v in x]
+    if isinstance(x, np.ndarray):
+        return plain(x.tolist())
+    if isinstance(x, (np.integer,)):
+        return int(x)
+    if isinstance(x, (np.floating, float)):
+        return repr(float(x))
+    return x
+
+
+def take(it, n):
+    return [plain(next(it)) for _ in range(n)]
+
+
+def main():
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        d = make_dataset(tmp)
+        # ---- loaders: (train iterator, total, list, dict[, dict]), [(eval iterator, total, dict, ...)], maps
+        random.seed(5)
+        rating = load_rating_data.load_data(d, ['valid.dat', 'test.dat'], 16)
+        out['rating'] = plain(rating)
+        out['rating.train.batches'] = take(rating[0][0], 3)
+        random.seed(6)
+        triple = load_triple_data.load_data(os.path.join(d, 'kg'), ['valid.dat'], 16)
+        out['triple'] = plain(triple)
+        out['triple.train.batches'] = take(triple[0][0], 3)
+        random.seed(7)
+        joint = load_kg_rating_data.load_data(d, ['valid.dat'], ['valid.dat'], 16)
+        out['joint'] = plain(joint)
+        out['joint.train.batches'] = [take(joint[0][0], 2), take(joint[4][0], 2)] if hasattr(joint[0][0], '__next__') and hasattr(joint[4][0], '__next__') else None
+    # ---- iterators and samplers under the same seed
+    random.seed(11)
+    it = udata.MakeTrainIterator([(u, u % 7) for u in range(23)], 5, negtive_samples=2)
+    out['MakeTrainIterator'] = take(it, 12)                      # wraps into a second epoch (another shuffle)
+    out['MakeEvalIterator'] = plain(udata.MakeEvalIterator([(i, i + 1) for i in range(11)], np.int64, 4))
+    head_dicts = [{(t, r): {h for h in range(9) if (h + t + r) % 3 == 0} for t in range(9) for r in range(3)}]
+    tail_dicts = [{(h, r): {t for t in range(9) if (h + 2 * t + r) % 5 == 0} for h in range(9) for r in range(3)}]   # (sparse: a free tail always exists)
+    triples = [(h, (h * 5 + 2) % 9, h % 3) for h in range(9)] * 3
+    random.seed(12)
+    out['corrupt_head_filter'] = [plain(udata.corrupt_head_filter(t, 9, headDicts=head_dicts)) for t in triples]
+    out['corrupt_tail_filter'] = [plain(udata.corrupt_tail_filter(t, 9, tailDicts=tail_dicts)) for t in triples]
+    out['corrupt_no_filter'] = [plain(udata.corrupt_head_filter(t, 9)) for t in triples[:5]]
+    out['getTrainTripleBatch'] = plain(udata.getTrainTripleBatch(triples, 9, all_head_dicts=head_dicts, all_tail_dicts=tail_dicts))
+    out['getTripleElements'] = plain(udata.getTripleElements(triples[:4]))
+    rated = [{u: {(u + k) % 13 for k in range(4)} for u in range(6)}]
+    random.seed(13)
+    out['getNegRatings'] = plain(udata.getNegRatings([(u % 6, (u * 3) % 13) for u in range(8)], 13, all_dicts=rated))
+    # ---- metric helpers
+    rng = np.random.RandomState(3)
+    rows = []
+    for _ in range(12):
+        r = rng.randint(0, 2, size=int(rng.randint(1, 12))).tolist()
+        k = int(rng.randint(1, 12))
+        rows.append([plain(ueval.dcg_at_k(r, k)), plain(ueval.dcg_at_k(r, k, 0)), plain(ueval.ndcg_at_k(r, k)), plain(ueval.ndcg_at_k(r, k, 1))])
+    out['ndcg'] = rows
+    rec, gold = [3, 7, 1, 9, 4], [7, 4, 8]
+    out['get_performance'] = plain(list(ueval.get_performance(rec, gold)))
+    print(json.dumps(out, sort_keys=True))
+
+
+if __name__ == '__main__':
+    main()

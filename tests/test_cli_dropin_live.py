@@ -151,3 +151,27 @@ def test_module_surface_matches_the_reference():
                 assert all(p[k].default is not inspect.Parameter.empty for k in oargs[len(args):]), (mod, cname, name, oargs, args)
                 checked += 1
     assert checked >= 150
+
+
+def test_host_side_functions_behave_like_the_reference():
+    """tests/golden/live_host.py once against the reference's package and once against this build's (two subprocesses: both are called
+    jTransUP): the loaders on the same synthetic dataset files, the train / eval iterators and negative samplers under the same
+    random.seed (the same draws in the same order), the metric helpers -- equal JSON documents, and the same lines on stdout."""
+    import json
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    root = os.path.dirname(here)
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE='1')
+    env.pop('PYTHONPATH', None)
+    docs = []
+    for pkg in (REF, os.path.join(root, 'joint-kg-recommender_amd')):
+        out = subprocess.run([sys.executable, os.path.join(here, 'golden', 'live_host.py'), '--pkg', pkg], capture_output=True, text=True,
+                             timeout=120, env=env, cwd=root)
+        assert out.returncode == 0, (pkg, out.stderr[-2000:])
+        docs.append(out.stdout.strip().splitlines())
+    assert docs[0][:-1] == docs[1][:-1]                                   # what the loaders print
+    ref, ours = json.loads(docs[0][-1]), json.loads(docs[1][-1])
+    assert sorted(ref) == sorted(ours) and len(ref) == 16
+    for key in ref:
+        assert ref[key] == ours[key], key

@@ -95,9 +95,12 @@ class ModelTrainer(object):
         learning_rate_decay_when_no_progress once a whole epoch has gone by without an improvement."""
         improved = dev_performance[0] > check_rho * self.best_dev_performance
         if improved:
-            self.best_step, self.best_dev_performance, self.best_performances = self.step, dev_performance[0], performances
+            # order of trainer.py:94-99: the file is written BEFORE best_dev_performance moves, so a checkpoint carries the best value
+            # before this improvement (0.0 for a run's first one) -- what a run resumed from it prints and compares against
+            self.best_step = self.step
             self.logger.info('Checkpointing ...')
             self.save(self.checkpoint_path)
+            self.best_performances, self.best_dev_performance = performances, dev_performance[0]
         if self.learning_rate_decay_when_no_progress != 1.0:
             epoch_start = self.step - self.step % self.epoch_length
             first_eval_of_epoch = self.step - epoch_start <= self.eval_interval_steps

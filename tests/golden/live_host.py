@@ -52,6 +52,64 @@ def take(it, n):
     return [plain(next(it)) for _ in range(n)]
 
 
+def trainer_scenario():
+    """utils/trainer.py: ModelTrainer's bookkeeping over a run -- steps, best step, checkpoint-on-improvement, the learning-rate decay
+    after an epoch without progress, what a checkpoint file holds and what load() restores -- with hand-set gradients, so only the
+    trainer and torch.optim act."""
+    import types
+    import torch
+    from jTransUP.models import transE
+    from jTransUP.utils import trainer as utrainer
+    out = {}
+
+    class Log(object):
+        def __init__(self):
+            self.lines = []
+
+        def info(self, msg, *a):
+            self.lines.append(str(msg))
+
+    def model():
+        m = transE.TransEModel(False, 6, 9, 3)
+        for k, (_, p) in enumerate(sorted(m.named_parameters())):
+            p.data.copy_(torch.linspace(-0.5 + 0.1 * k, 0.5, p.numel()).reshape(p.shape))
+        return m
+
+    with tempfile.TemporaryDirectory() as tmp:
+        for opt in ('Adagrad', 'SGD', 'Adam', 'Rmsprop'):
+            F = types.SimpleNamespace(model_type='transe', optimizer_type=opt, l2_lambda=1e-3, learning_rate_decay_when_no_progress=0.5,
+                                      momentum=0.9, eval_interval_steps=2, learning_rate=0.1, ckpt_path=tmp, experiment_name='run_' + opt,
+                                      eval_only_mode=False, load_experiment_name='')
+            log = Log()
+            m = model()
+            tr = utrainer.ModelTrainer(m, log, 4, F)
+            perf = {2: 0.10, 4: 0.30, 6: 0.30, 8: 0.20, 10: 0.25, 12: 0.28, 14: 0.31}
+            events = []
+            for step in range(1, 15):
+                tr.optimizer_zero_grad()
+                for k, (_, p) in enumerate(sorted(m.named_parameters())):
+                    p.grad = torch.cos(torch.arange(p.numel(), dtype=torch.float32) * (0.37 + 0.05 * k) + step).reshape(p.shape) * 0.1
+                tr.optimizer_step()
+                if step in perf:
+                    best = tr.new_performance([perf[step], 0.0], [[perf[step], 0.0]])
+                    events.append([step, bool(best), tr.step, tr.best_step, repr(float(tr.learning_rate)), repr(float(tr.best_dev_performance)),
+                                   plain(tr.best_performances)])
+            ck = torch.load(tr.checkpoint_path, map_location='cpu', weights_only=False)
+            tr2 = utrainer.ModelTrainer(model(), Log(), 4, F)
+            tr2.load(tr.checkpoint_path, cpu=True)
+            out['trainer.' + opt] = {
+                'events': events, 'log': log.lines, 'path': os.path.relpath(tr.checkpoint_path, tmp),
+                'ckpt.keys': sorted(ck), 'ckpt.scalars': [ck['step'], ck['best_step'], repr(float(ck['best_dev_performance']))],
+                'ckpt.model': sorted(ck['model_state_dict']), 'ckpt.opt': sorted(ck['optimizer_state_dict']),
+                'params': [[n, [repr(round(float(x), 6)) for x in p.detach().reshape(-1)[:5]]] for n, p in sorted(m.named_parameters())],
+                'ckpt.params': [[n, [repr(round(float(x), 6)) for x in t.reshape(-1)[:5]]] for n, t in sorted(ck['model_state_dict'].items())],
+                'loaded': [tr2.step, tr2.best_step, repr(float(tr2.best_dev_performance))]}
+        F.ckpt_path = os.path.join(tmp, 'given.ckpt')
+        out['trainer.paths'] = [os.path.relpath(utrainer.get_checkpoint_path(F), tmp), os.path.relpath(utrainer.get_checkpoint_path(F, '.x'), tmp)]
+    out['trainer.targets'] = [[t, utrainer.get_model_target(t)] for t in ('bprmf', 'fm', 'cofm', 'transup', 'jtransup', 'transe', 'transh', 'transr', 'cke', 'cfkg')]
+    return out
+
+
 def main():
     out = {}
     with tempfile.TemporaryDirectory() as tmp:
@@ -96,6 +154,7 @@ def main():
     out['ndcg'] = rows
     rec, gold = [3, 7, 1, 9, 4], [7, 4, 8]
     out['get_performance'] = plain(list(ueval.get_performance(rec, gold)))
+    out.update(trainer_scenario())
     print(json.dumps(out, sort_keys=True))
 
 

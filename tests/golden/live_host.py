@@ -110,6 +110,67 @@ def trainer_scenario():
     return out
 
 
+def base_scenario():
+    """models/base.py: get_flags + flag_defaults (experiment name, default paths, the share_embeddings rules, the seed) and init_model's
+    choice, log lines and the module it builds (its repr: class, table names, shapes, padding rows, order) for the model types of the path.
+    The reference's base.py needs python-gflags, which is not installable here: on that side `gflags` is this build's own compatible
+    registry (jTransUP/utils/flags.py, loaded from its file) -- the registry is the thing under test in test_cli_dropin_live.py's other
+    cases, base.py's logic the thing compared here."""
+    import importlib.util
+    import time
+    import torch
+    if 'reference' in os.path.abspath(PKG):
+        spec = importlib.util.spec_from_file_location('gflags', os.path.join(os.path.dirname(os.path.dirname(HERE)), 'joint-kg-recommender_amd', 'jTransUP',
+                                                                             'utils', 'flags.py'))
+        mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+        sys.modules['gflags'] = mod
+        import torch.nn as tnn                                    # transD.py (imported by base.py, out of scope) needs nothing else
+        flags = mod
+    else:
+        from jTransUP.utils import flags
+    from jTransUP.models import base
+    out = {}
+
+    class Log(object):
+        def __init__(self):
+            self.lines = []
+
+        def info(self, msg, *a):
+            self.lines.append(str(msg))
+
+    base.get_flags()
+    FLAGS = flags.FLAGS
+    real_time = time.time
+    time.time = lambda: 1234567890.7
+    try:
+        for argv in (['-model_type', 'jtransup', '-dataset', 'ml1m', '-share_embeddings', '-seed', '3'],
+                     ['-model_type', 'cfkg', '-noshare_embeddings', '-log_path', '/x/log/', '-data_path', '/x/d/'],
+                     ['-model_type', 'transe', '-experiment_name', 'mine', '-ckpt_path', '/x/ck/', '-seed', '0'],
+                     ['-model_type', 'cke', '-share_embeddings']):
+            FLAGS.reset() if hasattr(FLAGS, 'reset') else None
+            FLAGS(['prog'] + argv)
+            torch.manual_seed(99)
+            base.flag_defaults(FLAGS)
+            out['flag_defaults ' + ' '.join(argv)] = [FLAGS.experiment_name, FLAGS.data_path, FLAGS.log_path, FLAGS.ckpt_path, FLAGS.share_embeddings,
+                                                      [repr(float(x)) for x in torch.rand(3)]]
+    finally:
+        time.time = real_time
+    i_map = {i: i for i in range(7)}
+    new_map = {i: ((i * 2) % 9 if i % 3 else -1, i) for i in range(7)}
+    for mt, extra in (('bprmf', []), ('transup', ['-num_preferences', '3']), ('transup', ['-use_st_gumbel', '-L1_flag']), ('transe', []),
+                      ('transh', ['-L1_flag']), ('transr', []), ('jtransup', []), ('cke', []), ('cfkg', [])):
+        FLAGS.reset() if hasattr(FLAGS, 'reset') else None
+        FLAGS(['prog', '-model_type', mt, '-embedding_size', '8'] + extra)
+        base.flag_defaults(FLAGS)
+        log = Log()
+        torch.manual_seed(1)
+        m = base.init_model(FLAGS, 5, 7, 9, 4, log, i_map=i_map, e_map=None, new_map=new_map)
+        out['init_model %s %s' % (mt, ' '.join(extra))] = {
+            'log': log.lines, 'class': type(m).__name__, 'params': [[n, list(p.shape)] for n, p in m.named_parameters()],
+            'state': sorted(m.state_dict())}
+    return out
+
+
 def main():
     out = {}
     with tempfile.TemporaryDirectory() as tmp:
@@ -155,6 +216,7 @@ def main():
     rec, gold = [3, 7, 1, 9, 4], [7, 4, 8]
     out['get_performance'] = plain(list(ueval.get_performance(rec, gold)))
     out.update(trainer_scenario())
+    out.update(base_scenario())
     print(json.dumps(out, sort_keys=True))
 
 

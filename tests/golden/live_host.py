@@ -167,7 +167,9 @@ def base_scenario():
         m = base.init_model(FLAGS, 5, 7, 9, 4, log, i_map=i_map, e_map=None, new_map=new_map)
         out['init_model %s %s' % (mt, ' '.join(extra))] = {
             'log': log.lines, 'class': type(m).__name__, 'params': [[n, list(p.shape)] for n, p in m.named_parameters()],
-            'state': sorted(m.state_dict())}
+            'state': sorted(m.state_dict()),
+            # the initial tables under torch.manual_seed(1): same seed, same model
+            'init': [[n, repr(float(p.detach().double().sum())), [repr(float(x)) for x in p.detach().reshape(-1)[:3]]] for n, p in m.named_parameters()]}
     return out
 
 

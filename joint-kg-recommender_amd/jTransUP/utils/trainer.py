@@ -153,7 +153,15 @@ class ModelTrainer(object):
             table = getattr(self.model, key).weight.data
             old_ids = torch.tensor(list(remap.keys()), dtype=torch.long)
             new_ids = torch.tensor(list(remap.values()), dtype=torch.long)
-            table[new_ids.to(table.device)] = rows[old_ids].to(table.device)
+            if rows.data_ptr() == table.data_ptr():
+                # the checkpoint holds no such table, so `rows` IS the model's own (state_dict aliases the parameters): the reference's
+                # loop (trainer.py:176-200) then moves rows one at a time inside the table it reads from, later moves seeing earlier
+                # ones -- what happens to the item table when the second of two checkpoints is loaded with the remaps
+                # (knowledgable_recommendation.py:478).  Same order, same result.
+                for old, new in zip(old_ids.tolist(), new_ids.tolist()):
+                    table[new] = table[old]
+            else:
+                table[new_ids.to(table.device)] = rows[old_ids].to(table.device)
             self.logger.info('Restored ' + str(len(remap)) + ' ' + what + ' from checkpoint.')
             if key == 'item_embeddings' and 'item_bias.weight' in merged and 'item_bias.weight' in wanted:      # coFM (trainer.py:202-211)
                 bias = merged.pop('item_bias.weight')

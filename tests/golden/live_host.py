@@ -106,6 +106,51 @@ def trainer_scenario():
                 'loaded': [tr2.step, tr2.best_step, repr(float(tr2.best_dev_performance))]}
         F.ckpt_path = os.path.join(tmp, 'given.ckpt')
         out['trainer.paths'] = [os.path.relpath(utrainer.get_checkpoint_path(F), tmp), os.path.relpath(utrainer.get_checkpoint_path(F, '.x'), tmp)]
+        # ---- loadEmbedding: pre-trained tables into a joint model (knowledgable_recommendation.py:470-484), with and without the remaps,
+        # and the padded-table rules (a checkpoint with E entity rows into a model with E + 1; R relation rows into R + 1)
+        from jTransUP.models import transUP as m_tup, transH as m_th, transR as m_tr, jTransUP as m_joint, CKE as m_cke, CFKG as m_cfkg
+        F = types.SimpleNamespace(model_type='jtransup', optimizer_type='Adagrad', l2_lambda=0.0, learning_rate_decay_when_no_progress=1.0,
+                                  momentum=0.9, eval_interval_steps=2, learning_rate=0.1, ckpt_path=tmp, experiment_name='pre',
+                                  eval_only_mode=False, load_experiment_name='')
+
+        def filled(m, base):
+            for k, (_, p) in enumerate(sorted(m.named_parameters())):
+                p.data.copy_((torch.arange(p.numel(), dtype=torch.float32) * 0.01 + base + k).reshape(p.shape))
+            return m
+
+        def saved(m, name):
+            t = utrainer.ModelTrainer(m, Log(), 4, F)
+            path = os.path.join(tmp, name + '.ckpt')
+            t.save(path)
+            return path
+
+        def dump(m):
+            return [[n, [repr(round(float(x), 4)) for x in t.reshape(-1)]] for n, t in sorted(m.state_dict().items())]
+
+        p_tup = saved(filled(m_tup.TransUPModel(False, 4, 5, 7, 4, False), 100.0), 'tup')
+        p_th = saved(filled(m_th.TransHModel(False, 4, 9, 4), 200.0), 'th')
+        p_tr = saved(filled(m_tr.TransRModel(False, 4, 9, 4), 300.0), 'tr')
+        i_map = {i: i for i in range(7)}
+        new_map = {i: ((i * 2) % 9 if i % 3 else -1, i) for i in range(7)}
+        e_remap = {i: (i * 4) % 9 for i in range(9)}
+        i_remap = {i: (i * 3) % 7 for i in range(7)}
+        for tag, remaps in (('remapped', dict(e_remap=e_remap, i_remap=i_remap)), ('plain', {})):
+            joint = filled(m_joint.jTransUPModel(False, 4, 5, 7, 9, 4, i_map, new_map, False, False), 0.0)
+            log = Log()
+            t = utrainer.ModelTrainer(joint, log, 4, F)
+            for path in (p_tup, p_th):
+                t.loadEmbedding(path, joint.state_dict(), cpu=True, **remaps)
+            out['loadEmbedding.jtransup.' + tag] = {'log': [l.replace(tmp, '<tmp>') for l in log.lines], 'state': dump(joint)}
+        cke = filled(m_cke.CKE(False, 4, 5, 7, 9, 4, i_map, new_map), 0.0)
+        log = Log()
+        t = utrainer.ModelTrainer(cke, log, 4, F)
+        t.loadEmbedding(p_tr, cke.state_dict(), cpu=True)
+        out['loadEmbedding.cke'] = {'log': [l.replace(tmp, '<tmp>') for l in log.lines], 'state': dump(cke)}
+        cfkg = filled(m_cfkg.CFKG(False, 4, 5, 7, 9, 4), 0.0)
+        log = Log()
+        t = utrainer.ModelTrainer(cfkg, log, 4, F)
+        t.loadEmbedding(p_th, cfkg.state_dict(), cpu=True)
+        out['loadEmbedding.cfkg'] = {'log': [l.replace(tmp, '<tmp>') for l in log.lines], 'state': dump(cfkg)}
     out['trainer.targets'] = [[t, utrainer.get_model_target(t)] for t in ('bprmf', 'fm', 'cofm', 'transup', 'jtransup', 'transe', 'transh', 'transr', 'cke', 'cfkg')]
     return out
 

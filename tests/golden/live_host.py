@@ -215,6 +215,36 @@ def base_scenario():
             'state': sorted(m.state_dict()),
             # the initial tables under torch.manual_seed(1): same seed, same model
             'init': [[n, repr(float(p.detach().double().sum())), [repr(float(x)) for x in p.detach().reshape(-1)[:3]]] for n, p in m.named_parameters()]}
+    # ---- the preference models' reporting path on the host (transUP.py:105-180, jTransUP.py:114-120,250-329): getPreferences on
+    # gathered rows (soft gate, and the ST-Gumbel gate under a seed), reportPreference, paddingItems, and the gradient switches
+    from jTransUP.models import transUP as m_tup, jTransUP as m_joint
+
+    def filled(m):
+        for k, (_, p) in enumerate(sorted(m.named_parameters())):
+            p.data.copy_(torch.sin(torch.arange(p.numel(), dtype=torch.float32) * (0.7 + 0.1 * k)).reshape(p.shape) * 0.5)
+        return m
+
+    class IntKeys(dict):                                         # the reference looks items up with LongTensor elements (jTransUP.py:116-117),
+        def __getitem__(self, k):                                # which hashed like ints in the torch it was written for
+            return dict.__getitem__(self, int(k))
+
+    tens = lambda t: [repr(round(float(x), 5)) for x in t.detach().reshape(-1)]
+    for gum in (False, True):
+        for name, m in (('tup', filled(m_tup.TransUPModel(False, 6, 5, 7, 3, gum))),
+                        ('ktup', filled(m_joint.jTransUPModel(True, 6, 5, 7, 9, 4, IntKeys({i: i for i in range(7)}),
+                                                              {i: ((i * 2) % 9 if i % 3 else -1, i) for i in range(7)}, False, gum)))):
+            key = 'pref.%s.%s' % (name, 'hard' if gum else 'soft')
+            u_e = m.user_embeddings(torch.tensor([0, 3, 4])); i_e = m.item_embeddings(torch.tensor([6, 1, 2]))
+            torch.manual_seed(21)
+            a = m.getPreferences(u_e, i_e, use_st_gumbel=gum)
+            torch.manual_seed(22)
+            b = m.reportPreference(torch.tensor([2]), torch.tensor([0, 5, 6, 3]))
+            doc = {'getPreferences': [tens(x) for x in a], 'reportPreference': [tens(x) for x in b]}
+            if name == 'ktup':
+                doc['paddingItems'] = plain(m.paddingItems(torch.tensor([0, 1, 2, 3, 6]), m.ent_total - 1))
+            m.disable_grad(); doc['disable_grad'] = [bool(p.requires_grad) for p in m.parameters()]
+            m.enable_grad(); doc['enable_grad'] = [bool(p.requires_grad) for p in m.parameters()]
+            out[key] = doc
     return out
 
 

@@ -292,6 +292,10 @@ def main():
     out['ndcg'] = rows
     rec, gold = [3, 7, 1, 9, 4], [7, 4, 8]
     out['get_performance'] = plain(list(ueval.get_performance(rec, gold)))
+    recs = [rng.permutation(20)[:int(rng.randint(1, 9))].tolist() for _ in range(6)]
+    golds = [rng.permutation(20)[:int(rng.randint(1, 7))].tolist() for _ in range(6)]
+    out['get_performance.many'] = [plain(list(ueval.get_performance(a, b))) for a, b in zip(recs, golds)]
+    out['evalAll'] = plain(list(ueval.evalAll(recs, golds)))
     out.update(trainer_scenario())
     out.update(base_scenario())
     print(json.dumps(out, sort_keys=True))

@@ -172,6 +172,6 @@ def test_host_side_functions_behave_like_the_reference():
         docs.append(out.stdout.strip().splitlines())
     assert docs[0][:-1] == docs[1][:-1]                                   # what the loaders print
     ref, ours = json.loads(docs[0][-1]), json.loads(docs[1][-1])
-    assert sorted(ref) == sorted(ours) and len(ref) == 43
+    assert sorted(ref) == sorted(ours) and len(ref) == 45
     for key in ref:
         assert ref[key] == ours[key], key

@@ -429,7 +429,9 @@ int ktup_shard_sparse_step(int kind, float* table, int64_t ldt, float* state, in
  *   small_rows x d each: gradient k updates small_p0[k] (and small_p1[k] if not NULL -- the two summands of a mixed table share
  *   one gradient); with small_g64 the small gradients are read from that fp64 array (the all-reduced bucket) instead.  Consumed
  *   gradient rows are zero-filled.  If *skip_count != 0 or *skip_value != 0 (either may be NULL) nothing is updated, gradients are
- *   still cleared.
+ *   still cleared.  The launch also closes the step's books (all four may be NULL / 0): the step kernels accumulate their loss
+ *   terms into loss_step[0 .. n_loss); here loss_sum[k] += loss_step[k] unless the step is skipped, loss_step := 0, and a skipped
+ *   step adds 1 to *skipped_steps -- a counter no launch ever clears, so a run can be checked once at its end.
  * ktup_shard_bucket: mode 0: bucket = [small gradients as doubles | sum of sumsq_local[0 .. sumsq_slots) | *overflow]; mode 1 (after the all-reduce):
  *   *sumsq_total = bucket[n] + small_weight * sum of squares of bucket[0 .. n) (2 when every small gradient feeds two tables).
  * ktup_zero_async: zero-fill by a kernel (16-byte aligned, multiple of 16 bytes).                                          */
@@ -451,6 +453,13 @@ int ktup_shard_route_ktup(const int64_t* u, const int64_t* pos_items, const int6
                           int64_t* cursor, const int32_t* item2ent, int64_t ent_pad, int64_t* entries, int world,
                           const int64_t* cap, int64_t* inverse, int64_t* send_ids, int32_t* pair_map, int32_t* sort_ws,
                           int32_t* counters, double* zero_doubles, int n_zero_doubles, void* ws, int phase, void* stream);
+/* The same for the KTUP kg step (knowledgable_recommendation.py:346-383): batch (*cursor mod n_batches) of the six triple columns
+ * -> entries = [ph ; pt ; nh ; nt] (4B int64, written), ONE table (entities; cap: one value); rels = [pr ; nr] (2B, written): the
+ * relation ids ktup_train_kg_step_rows reads.  phase as above.                                                                */
+int ktup_shard_route_kg(const int64_t* ph, const int64_t* pt, const int64_t* pr, const int64_t* nh, const int64_t* nt,
+                        const int64_t* nr, int64_t B, int64_t n_batches, int64_t* cursor, int64_t* entries, int64_t* rels,
+                        int world, const int64_t* cap, int64_t* inverse, int64_t* send_ids, int32_t* sort_ws, int32_t* counters,
+                        double* zero_doubles, int n_zero_doubles, void* ws, int phase, void* stream);
 int ktup_shard_reduce_rows(const float* G, int64_t ldg, int d, int64_t n_src, int64_t src_off, const int32_t* sort_ws,
                            int64_t n_entries, int64_t n_wire_rows, float* gwire, int64_t ldw, void* stream);
 int ktup_shard_ktup_entries(const int64_t* u, const int64_t* pos_items, const int64_t* neg_items, int64_t B,
@@ -462,7 +471,7 @@ int ktup_shard_apply(int kind, int n_tables, float* const* tables, const int64_t
                      int small_rows, float* const* small_grads, float* const* small_p0, float* const* small_s0,
                      float* const* small_p1, float* const* small_s1, const double* small_g64, float lr, float eps,
                      const double* sumsq, int sumsq_slots, float max_norm, const int32_t* skip_count, const double* skip_value,
-                     void* stream);
+                     float* loss_step, int n_loss, float* loss_sum, int32_t* skipped_steps, void* stream);
 int ktup_shard_bucket(int mode, int n_small, float* const* small_grads, int64_t small_elems, double* bucket,
                       const double* sumsq_local, int sumsq_slots, const int32_t* overflow, double* sumsq_total, double small_weight,
                       void* stream);
@@ -486,7 +495,8 @@ int ktup_shard_reduce_apply(int kind, int n_tables, float* const* tables, const 
                             float* gwire, int64_t ldw, const int32_t* xkeys, int n_small, int small_rows,
                             float* const* small_grads, float* const* small_p0, float* const* small_s0, float* const* small_p1,
                             float* const* small_s1, const double* small_g64, float lr, float eps, const double* sumsq,
-                            int sumsq_slots, float max_norm, const int32_t* skip_count, const double* skip_value, void* stream);
+                            int sumsq_slots, float max_norm, const int32_t* skip_count, const double* skip_value,
+                            float* loss_step, int n_loss, float* loss_sum, int32_t* skipped_steps, void* stream);
 
 /* ------------------------------------------- K19  negative sampling on the device  utils/data.py:12-85
  * rec: one uniform negative item per (u, positive): != positive, bit not set in the user's row of
@@ -594,6 +604,16 @@ int ktup_train_rec_step_rows(const float* U, int64_t ldu, const float* I, int64_
 int ktup_train_kg_step(int transh, const float* E, int64_t lde, const float* R, int64_t ldr, const float* Nrm, int64_t ldn,
                        int d, const int64_t* h, const int64_t* t, const int64_t* r, int64_t B, int l1, float margin,
                        float gscale, int regs, float* loss, float* gE, float* gR, float* gN, void* stream);
+/* ktup_train_kg_step for row-sharded entity tables (config 5's kg steps; csrc/ktup_shard_kg.hip): ent_ids = [ph ; pt ; nh ; nt]
+ * (4B rows of E: a shard's rows, or wire rows of a compact table), rel_ids = [pr ; nr] (2B); the entity-row gradients of triple k
+ * are STORED as rows k, B + k, 2B + k, 3B + k of GE (4B x d, pitch d) for ktup_shard_reduce_norm / _apply instead of accumulated
+ * into a table-shaped gradient; gR / gN (relation-side, replicated) are accumulated.  `order` (may be NULL): the triples' indices
+ * sorted by relation (ktup_shard_kg_rel_order) -- consecutive triples of one relation then share ONE flush of its gradient rows.
+ * ktup_shard_kg_rel_order: order[0 .. B) = a counting sort of rel[0 .. B) over [0, n_rel) in one launch (n_rel > 16384: identity). */
+int ktup_shard_kg_rel_order(const int64_t* rel, int64_t B, int64_t n_rel, int32_t* order, void* stream);
+int ktup_train_kg_step_rows(int transh, const float* E, int64_t lde, const float* R, int64_t ldr, const float* Nrm, int64_t ldn,
+                            int d, const int64_t* ent_ids, const int64_t* rel_ids, const int32_t* order, int64_t B, int l1,
+                            float margin, float gscale, int regs, float* loss, float* GE, float* gR, float* gN, void* stream);
 #define KTUP_OPTIM_WS_DOUBLES 784
 /* largest grid of ktup_optim_clip_step on the current device: its grid barrier needs every workgroup resident at once, so the
  * launch is sized from the occupancy query x the CU count (one workgroup per CU short of it), at most 512; 0 = unknown (the

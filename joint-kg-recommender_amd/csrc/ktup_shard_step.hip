@@ -41,6 +41,9 @@ struct RouteArgs {
   // (*cursor mod n_batches) of the id columns, and the NEXT launch moves the cursor on
   const int64_t *src_u, *src_pos, *src_neg; int64_t B, n_batches; const int32_t* item2ent; int64_t ent_pad; int64_t* cursor;
   int64_t* ids_out;
+  // KG source (ktup_shard_route_kg): ids = [ph ; pt ; nh ; nt] from the six triple columns (src_u / src_pos / src_neg / src_nt =
+  // ph / pt / nh / nt), and the batch's relation ids [pr ; nr] copied to rel_out for the step kernel
+  const int64_t *src_nt, *src_pr, *src_nr; int64_t* rel_out;
 };
 
 constexpr int TILE = 1024;                             // histogram counters per scan tile (256 threads x 4)
@@ -68,7 +71,17 @@ __global__ __launch_bounds__(256) void route_init_kernel(RouteArgs a) {
   for (int64_t i = tid; i <= a.W; i += nth) a.start[i] = 0;
   for (int64_t i = tid; i <= (int64_t)a.world * a.T; i += nth) a.counters[i] = 0;          // + the overflow word
   for (int64_t i = tid; i < a.n_zero_d; i += nth) a.zero_d[i] = 0.0;
-  if (a.src_u) {                                         // jTransUP.py:122-130: paddingItems as a table lookup
+  if (a.src_nt) {                                        // kg step: the triple columns of the cursor's batch
+    const int64_t b0 = a.cursor ? ((*a.cursor) % a.n_batches) * a.B : 0;
+    for (int64_t k = tid; k < a.B; k += nth) {
+      a.ids_out[k] = a.src_u[b0 + k];
+      a.ids_out[a.B + k] = a.src_pos[b0 + k];
+      a.ids_out[2 * a.B + k] = a.src_neg[b0 + k];
+      a.ids_out[3 * a.B + k] = a.src_nt[b0 + k];
+      a.rel_out[k] = a.src_pr[b0 + k];
+      a.rel_out[a.B + k] = a.src_nr[b0 + k];
+    }
+  } else if (a.src_u) {                                  // jTransUP.py:122-130: paddingItems as a table lookup
     const int64_t b0 = a.cursor ? ((*a.cursor) % a.n_batches) * a.B : 0;
     for (int64_t k = tid; k < 2 * a.B; k += nth) {
       const int64_t kk = k < a.B ? k : k - a.B;
@@ -319,6 +332,8 @@ struct ApplyRows {
   int d;
   float lr, eps, max_norm; const double* sumsq; int sumsq_slots; const int32_t* skip_i; const double* skip_d; bool adagrad;
   const int32_t* xkeys;        // non-null: rows [0, W) are LIST entries -- the wire row is xkeys[row], taken at its first occurrence only
+  // end of step (may be null): loss_sum[k] += loss_step[k] unless the step is skipped, loss_step := 0; *skipped += 1 if it is
+  float* loss_step; int n_loss; float* loss_sum; int32_t* skipped;
 
   template <typename V, int G, int CPL>
   KTUP_DEV void one(const RowCtx<V, G, CPL>& cx, float* prow, float* srow, const V (&gr)[CPL], float coef) const {
@@ -341,6 +356,14 @@ struct ApplyRows {
   template <typename V, int G, int CPL>
   KTUP_DEV void run(const RowCtx<V, G, CPL>& cx, int64_t row) const {
     const bool skip = (skip_i && *skip_i != 0) || (skip_d && *skip_d != 0.0);
+    if (row == 0 && cx.lane == 0) {                      // one lane of the launch closes the step's books
+      if (skip && skipped) *skipped = *skipped + 1;
+      for (int k = 0; k < n_loss; ++k) {
+        const float v = loss_step[k];
+        if (!skip) loss_sum[k] += v;
+        loss_step[k] = 0.f;
+      }
+    }
     const float coef = clip_coef(max_norm, sumsq, sumsq_slots);
     V gr[CPL], zero[CPL];
 #pragma unroll
@@ -800,6 +823,23 @@ extern "C" int ktup_shard_route_ktup(const int64_t* u, const int64_t* pos_items,
                     (hipStream_t)stream, phase);
 }
 
+// The KTUP kg step's route (knowledgable_recommendation.py:346-362: the entity ids of a triple batch and of its corrupted twin):
+// batch (*cursor mod n_batches) of the six triple columns -> entries = [ph ; pt ; nh ; nt] (4B, written), one table (entities);
+// rels = [pr ; nr] (2B, written) for ktup_train_kg_step_rows.  *cursor is incremented by the call.
+extern "C" int ktup_shard_route_kg(const int64_t* ph, const int64_t* pt, const int64_t* pr, const int64_t* nh, const int64_t* nt,
+                                   const int64_t* nr, int64_t B, int64_t n_batches, int64_t* cursor, int64_t* entries, int64_t* rels,
+                                   int world, const int64_t* cap, int64_t* inverse, int64_t* send_ids, int32_t* sort_ws,
+                                   int32_t* counters, double* zero_doubles, int n_zero_doubles, void* ws, int phase, void* stream) {
+  const char* name = "ktup_shard_route_kg";
+  KTUP_REQUIRE(B > 0 && n_batches > 0 && ph && pt && pr && nh && nt && nr && entries && rels, "%s: null pointer argument or empty batch", name);
+  const int64_t eoff[2] = {0, 4 * B};
+  RouteArgs a{};
+  if (int e = fill_route(name, a, entries, 4 * B, 4 * B, 1, eoff, world, cap)) return e;
+  a.src_u = ph; a.src_pos = pt; a.src_neg = nh; a.src_nt = nt; a.src_pr = pr; a.src_nr = nr; a.rel_out = rels;
+  a.B = B; a.n_batches = n_batches; a.cursor = cursor; a.ids_out = entries;
+  return route_impl(name, a, 0, 0, inverse, send_ids, nullptr, sort_ws, counters, zero_doubles, n_zero_doubles, ws, (hipStream_t)stream, phase);
+}
+
 extern "C" int ktup_shard_reduce_rows(const float* G, int64_t ldg, int d, int64_t n_src, int64_t src_off, const int32_t* sort_ws,
                                       int64_t n_entries, int64_t n_wire_rows, float* gwire, int64_t ldw, void* stream) {
   const char* name = "ktup_shard_reduce_rows";
@@ -838,8 +878,10 @@ extern "C" int ktup_shard_apply(int kind, int n_tables, float* const* tables, co
                                 const int64_t* cap, int d, const int64_t* ids, int64_t n_blocks, float* grads, int64_t ldg, int n_small,
                                 int small_rows, float* const* small_grads, float* const* small_p0, float* const* small_s0,
                                 float* const* small_p1, float* const* small_s1, const double* small_g64, float lr, float eps,
-                                const double* sumsq, int sumsq_slots, float max_norm, const int32_t* skip_count, const double* skip_value, void* stream) {
+                                const double* sumsq, int sumsq_slots, float max_norm, const int32_t* skip_count, const double* skip_value,
+                                float* loss_step, int n_loss, float* loss_sum, int32_t* skipped_steps, void* stream) {
   const char* name = "ktup_shard_apply";
+  KTUP_REQUIRE(n_loss >= 0 && (n_loss == 0 || (loss_step && loss_sum)), "%s: the loss slots need both arrays", name);
   KTUP_REQUIRE(kind == KTUP_OPT_SGD || kind == KTUP_OPT_ADAGRAD, "%s: only plain SGD and Adagrad have an exact row-sparse form", name);
   ApplyRows op{};
   if (int e = fill_wire(name, op.w, n_tables, tables, ld, states, lds, cap, d)) return e;
@@ -862,6 +904,7 @@ extern "C" int ktup_shard_apply(int kind, int n_tables, float* const* tables, co
   op.ids = ids; op.W = n_blocks * op.w.capsum; op.g = grads; op.ldg = ldg;
   op.n_small = n_small; op.small_rows = small_rows > 0 ? small_rows : 1; op.small_g64 = small_g64; op.d = d;
   op.lr = lr; op.eps = eps; op.max_norm = max_norm; op.sumsq = sumsq; op.sumsq_slots = sumsq_slots; op.skip_i = skip_count; op.skip_d = skip_value; op.adagrad = adagrad;
+  op.loss_step = loss_step; op.n_loss = n_loss; op.loss_sum = loss_sum; op.skipped = skipped_steps;
   return launch_rows(op, d, v4, op.W + (int64_t)n_small * op.small_rows, (hipStream_t)stream, name);
 }
 
@@ -903,8 +946,10 @@ extern "C" int ktup_shard_reduce_apply(int kind, int n_tables, float* const* tab
                                        float* gwire, int64_t ldw, const int32_t* xkeys, int n_small, int small_rows,
                                        float* const* small_grads, float* const* small_p0, float* const* small_s0, float* const* small_p1,
                                        float* const* small_s1, const double* small_g64, float lr, float eps, const double* sumsq,
-                                       int sumsq_slots, float max_norm, const int32_t* skip_count, const double* skip_value, void* stream) {
+                                       int sumsq_slots, float max_norm, const int32_t* skip_count, const double* skip_value,
+                                       float* loss_step, int n_loss, float* loss_sum, int32_t* skipped_steps, void* stream) {
   const char* name = "ktup_shard_reduce_apply";
+  KTUP_REQUIRE(n_loss >= 0 && (n_loss == 0 || (loss_step && loss_sum)), "%s: the loss slots need both arrays", name);
   KTUP_REQUIRE(kind == KTUP_OPT_SGD || kind == KTUP_OPT_ADAGRAD, "%s: only plain SGD and Adagrad have an exact row-sparse form", name);
   ApplyRows op{};
   if (int e = fill_wire(name, op.w, n_tables, tables, ld, states, lds, cap, d)) return e;
@@ -938,6 +983,7 @@ extern "C" int ktup_shard_reduce_apply(int kind, int n_tables, float* const* tab
   op.n_small = n_small; op.small_rows = small_rows > 0 ? small_rows : 1; op.small_g64 = small_g64; op.d = d;
   op.lr = lr; op.eps = eps; op.max_norm = max_norm; op.sumsq = sumsq; op.sumsq_slots = sumsq_slots; op.skip_i = skip_count; op.skip_d = skip_value;
   op.adagrad = adagrad;
+  op.loss_step = loss_step; op.n_loss = n_loss; op.loss_sum = loss_sum; op.skipped = skipped_steps;
   return launch_rows(op, d, true, op.W + (int64_t)n_small * op.small_rows, st, name);
 }
 

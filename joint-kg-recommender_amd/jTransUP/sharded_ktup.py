@@ -20,10 +20,18 @@ Several ranks: the same launches as five graph segments around three all-to-alls
 gradients out) and one fp64 all-reduce (small tables' gradients + the sum of squares + the overflow flag); the owner combines the
 rows several peers asked for with the same route + reduce (a row asked for by k peers is k entries of one key).
 
+The KG half of the joint schedule (knowledgable_recommendation.py:345-383 over jTransUP.py:144-157; three of every ten steps at
+joint_ratio 0.7) is ShardedKgStepper: the same fixed-shape form over the entity shard alone -- route of [ph ; pt ; nh ; nt],
+ktup_train_kg_step_rows (TransH forward x 2, marginLoss, orthogonalLoss / normLoss on the gathered rows, backward; entity-row
+gradients stored per triple, relation-side gradients accumulated in relation-sorted order), the same reduce -> norm -> apply.
+ShardedKtupJoint runs the two steppers on the reference's 10-step cycle over shared tables and optimizer state.
+
 Fixed capacity: a rank may ask one owner for at most cap = ceil(capacity_factor * n / world) + 64 distinct rows of a table per
 step (n = batch entries of that table).  Owners are `id % world`, so distinct ids spread like a binomial(n, 1 / world): at
 n = 16384, world = 8 the default factor 1.25 is 10 standard deviations out.  A step that does overflow is SKIPPED on every rank
-(the flag rides in the all-reduce) and counted; `check()` raises.  capacity_factor = world can never overflow.
+(the flag rides in the all-reduce): no table moves, its loss terms are dropped, and a device counter that no launch clears
+(`skipped`) takes note -- `overflowed_steps()` reads it, `check()` raises when it is non-zero, however long ago the step was.
+capacity_factor = world can never overflow.
 """
 import ctypes
 import math
@@ -49,11 +57,105 @@ def _i64s(vs):
     return (ctypes.c_int64 * len(vs))(*[int(v) for v in vs])
 
 
-class ShardedKtupStepper(object):
+class _ShardedStepBase(object):
+    """What the rec and the kg stepper share: eager warm-up, capture of the segments as HIP graphs, replay, the collectives
+    between the segments, the skipped-step counter.  A subclass provides `_bind(stream, side)` -> list of segments (lists of
+    pre-bound launches; ('fork', [...]) / ('join',) around launches bound to the side stream) and the buffers `_exchange` names."""
+
+    def _exchange(self, k):
+        """The collective after segment k (several ranks only)."""
+        from jTransUP.parallel import _a2a, _all_reduce
+        if not dist.is_initialized():                        # force_exchange without a process group: one rank talks to itself
+            if k == 0:
+                self.recv_ids.copy_(self.send_ids)
+            elif k == 1:
+                self.X[:self.W].copy_(self.Xsend)
+            elif k == 2:
+                self.Grecv.copy_(self.Gwire)
+            return
+        if k == 0:
+            _a2a(self.recv_ids, self.send_ids, None, None, self.group)            # ids to their owners
+        elif k == 1:
+            _a2a(self.X[:self.W], self.Xsend, None, None, self.group)             # rows back
+        elif k == 2:
+            _a2a(self.Grecv, self.Gwire, None, None, self.group)                  # row gradients to the owners
+        elif k == 3:
+            _all_reduce(self.bucket, self.group)                                  # small gradients + norm + overflow flag
+
+    def run(self):
+        """One step on the ids in the static buffers (or the cursor's batch of the feed columns).  The first two steps issue the
+        launches directly (warm-up), then the segments are captured once and replayed."""
+        stream = torch.cuda.current_stream(self.dev).cuda_stream
+        if not self.use_graphs or self.steps < 2:
+            if self._eager is None or self._eager[0] != stream:
+                side = self._side if (self.direct and self.overlap_route) else None
+                self._eager = (stream, self._bind(stream, None if side is None else side.cuda_stream), self._keep)
+            for k, seg in enumerate(self._eager[1]):
+                self._issue(seg, self._side)
+                if self.multi:
+                    self._exchange(k)
+            self.steps += 1
+            return
+        if self._graphs is None:
+            self._capture()
+        for k, g in enumerate(self._graphs):
+            g.replay()
+            if self.multi:
+                self._exchange(k)
+        self.steps += 1
+
+    def _issue(self, seg, side):
+        for item in seg:
+            if callable(item):
+                item()
+            elif item[0] == 'fork':                           # launches bound to the side stream, ordered after everything so far
+                side.wait_stream(torch.cuda.current_stream(self.dev))
+                for launch in item[1]:
+                    launch()
+            elif item[0] == 'join':
+                torch.cuda.current_stream(self.dev).wait_stream(side)
+
+    def _capture(self):
+        """Each segment becomes one HIP graph (the collectives between them are issued by torch.distributed).  A captured segment
+        also RUNS nothing: the step that triggers the capture replays the fresh graphs."""
+        graphs, keeps = [], []
+        n_seg = 5 if self.multi else 1
+        for k in range(n_seg):
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                cs = torch.cuda.current_stream(self.dev).cuda_stream
+                side = self._side if (self.direct and self.overlap_route) else None
+                segs = self._bind(cs, None if side is None else side.cuda_stream)
+                keeps.append(self._keep)
+                self._issue(segs[k], side)
+            graphs.append(graph)
+        self._graphs, self._graph_keep = graphs, keeps
+
+    # ------------------------------------------------------------------------------------------------ reporting
+    def overflowed_steps(self):
+        """Steps skipped so far because an exchange buffer overflowed (a device counter no launch clears; one device read -- call
+        it rarely)."""
+        return int(self.skipped.item())
+
+    def last_step_unplaced(self):
+        """Ids of the LAST step that found no slot on this job (0 = it ran)."""
+        if not self.multi:
+            return int(self.counters[-1].item())
+        return int(self.bucket[-1].item())
+
+    def check(self):
+        n = self.overflowed_steps()
+        if n:
+            raise L.KtupError('%d sharded step(s) asked one owner for more distinct rows than capacity_factor=%.2f allows and were '
+                              'skipped on every rank (tables untouched, losses dropped) -- raise capacity_factor (world = always safe)'
+                              % (n, self.capacity_factor))
+
+
+class ShardedKtupStepper(_ShardedStepBase):
     """step = ShardedKtupStepper(Ut, It, Et, pref, pref_norm, rel, norm, item2ent, batch=8192, kind='adagrad', lr=0.005, max_norm=5.0)
     step(u, pos_items, neg_items)      # int64 device tensors of `batch` ids; returns nothing, syncs nothing
     step.loss_sum[0]                   # running sum of the steps' batch-mean BPR losses of THIS rank (a device float)
-    step.check()                       # raises if a step overflowed its exchange capacity (and was therefore skipped)
+    step.check()                       # raises if ANY step so far overflowed its exchange capacity (and was therefore skipped)
 
     Ut / It / Et: parallel.ShardedTable (rows {g : g % world == rank}); pref, pref_norm, rel, norm: replicated (P, d) parameters;
     item2ent: int32 device table, global item -> global entity (negative or `ent_pad`: no aligned entity).  Exact w.r.t. the
@@ -132,7 +234,9 @@ class ShardedKtupStepper(object):
         self.Gwire = f32(W, d)
         self.xkeys = i32(max(2, lib.ktup_shard_reduce_list_len(E, d)))
         self.acc = torch.zeros(SLOTS + 1, dtype=torch.float64, device=dev)  # [SLOTS partial sums of squares | the job-wide total]
-        self.loss_sum = f32(2)                                # [sum of batch-mean BPR terms, sum of orthogonalLoss values]
+        self.loss_sum = f32(2)                                # [sum of batch-mean BPR terms, sum of orthogonalLoss values] of the steps that ran
+        self.loss_step = f32(2)                               # the current step's terms (the apply launch folds and clears them)
+        self.skipped = i32(1)                                 # steps skipped for overflow: never cleared by a launch
         n_g = 4 if self.orth else 2
         self.small_g = [f32(P, d) for _ in range(n_g)]        # orth: gP, gPn, gR, gRn; else gA (pref & rel), gC (pref_norm & norm)
         self.small_state = [torch.zeros_like(s.data) for s in self.small] if kind == 'adagrad' else [None] * 4
@@ -197,6 +301,7 @@ class ShardedKtupStepper(object):
         sp1p = arr(_ptrs(sp1)) if not self.orth else None
         ss1p = arr(_ptrs(ss1)) if (not self.orth and self.kind == 'adagrad') else None
         X, inv = self.X, self.inverse
+        close = (_p(self.loss_step), 2, _p(self.loss_sum), _p(self.skipped))
         bind = L.bind
         fu, fp, fn, nb = self._feed
         def route_phase(phase, on):
@@ -209,11 +314,11 @@ class ShardedKtupStepper(object):
             step = bind('ktup_train_rec_step_rows', _p(Ut.weight.data), Ut.weight.data.stride(0), _p(It.weight.data), It.weight.data.stride(0),
                         _p(Et.weight.data), Et.weight.data.stride(0), _p(self.item2ent), self.ent_pad, _p(pref), _p(pref_norm), _p(rel),
                         _p(norm), d, P, d, _p(ent), ent.data_ptr() + 2 * B * 8, B, int(self.l1), self.target, gscale, int(self.orth),
-                        _p(self.loss_sum), _p(self.Gcat), self.Gcat.data_ptr() + 2 * B * d * 4, _p(gP), _p(gPn), _p(gR), _p(gRn), stream)
+                        _p(self.loss_step), _p(self.Gcat), self.Gcat.data_ptr() + 2 * B * d * 4, _p(gP), _p(gPn), _p(gR), _p(gRn), stream)
         else:
             step = bind('ktup_train_rec_step_rows', _p(X), d, _p(X), d, _p(X), d, _p(self.pair_map), W, _p(pref), _p(pref_norm), _p(rel),
                         _p(norm), d, P, d, _p(inv), inv.data_ptr() + 2 * B * 8, B, int(self.l1), self.target, gscale, int(self.orth),
-                        _p(self.loss_sum), _p(self.Gcat), self.Gcat.data_ptr() + 2 * B * d * 4, _p(gP), _p(gPn), _p(gR), _p(gRn), stream)
+                        _p(self.loss_step), _p(self.Gcat), self.Gcat.data_ptr() + 2 * B * d * 4, _p(gP), _p(gPn), _p(gR), _p(gRn), stream)
         reduce_ = bind('ktup_shard_reduce_rows', _p(self.Gcat), d, d, 4 * B, 2 * B, _p(self.sort_ws), E, W, _p(self.Gwire), d, stream)
         if not self.multi:
             pack = bind('ktup_shard_pack_wire', 3, tabs, lds, cap, d, _p(self.send_ids), 1, _p(X), d, stream)
@@ -222,7 +327,7 @@ class ShardedKtupStepper(object):
             gnorm = bind('ktup_optim_gradnorm_acc', len(nl), nptr, nsz, _p(self.acc), SLOTS, stream)
             apply_ = bind('ktup_shard_apply', kind, 3, tabs, lds, states, lds, cap, d, _p(self.send_ids), 1, _p(self.Gwire), d, n_small, P,
                           sgp, sp0p, ss0p, sp1p, ss1p, None, self.lr, self.eps, _p(self.acc), SLOTS, self.max_norm,
-                          self.counters.data_ptr() + 4 * (Wn * 3), None, stream)
+                          self.counters.data_ptr() + 4 * (Wn * 3), None, *close, stream)
             if self.fused_apply:
                 nw = arr(_ptrs(sg_list))
                 rnorm = bind('ktup_shard_reduce_norm', _p(self.Gcat), d, d, 4 * B, 2 * B, _p(self.sort_ws), E, W, _p(self.Gwire), d,
@@ -230,7 +335,7 @@ class ShardedKtupStepper(object):
                 rapply = bind('ktup_shard_reduce_apply', kind, 3, tabs, lds, states, lds, cap, _p(self.send_ids), 1, _p(self.Gcat), d, d,
                               4 * B, 2 * B, _p(self.sort_ws), E, _p(self.Gwire), d, _p(self.xkeys), n_small, P, sgp, sp0p, ss0p, sp1p, ss1p,
                               None, self.lr, self.eps, _p(self.acc), SLOTS, self.max_norm, self.counters.data_ptr() + 4 * (Wn * 3), None,
-                              stream)
+                              *close, stream)
                 tail = [rnorm, rapply]
             else:
                 tail = [reduce_, gnorm, apply_]
@@ -252,36 +357,16 @@ class ShardedKtupStepper(object):
         fin_b = bind('ktup_shard_bucket', 1, n_small, None, P * d, _p(self.bucket), None, 0, None, self.acc.data_ptr() + 8 * SLOTS, small_weight, stream)
         apply_ = bind('ktup_shard_apply', kind, 3, tabs, lds, states, lds, capo, d, _p(self.own_ids), 1, _p(self.Gown), d, n_small, P,
                       sgp, sp0p, ss0p, sp1p, ss1p, _p(self.bucket), self.lr, self.eps, self.acc.data_ptr() + 8 * SLOTS, 1, self.max_norm,
-                      None, self.bucket.data_ptr() + 8 * (N + 1), stream)
+                      None, self.bucket.data_ptr() + 8 * (N + 1), *close, stream)
         if self.fused_apply:
             onorm = bind('ktup_shard_reduce_norm', _p(self.Grecv), d, d, W, 0, _p(self.own_sort), W, self.W_own, _p(self.Gown), d,
                          _p(self.own_xkeys), 0, None, 0, 1.0, _p(self.acc), SLOTS, stream)
             oapply = bind('ktup_shard_reduce_apply', kind, 3, tabs, lds, states, lds, capo, _p(self.own_ids), 1, _p(self.Grecv), d, d, W, 0,
                           _p(self.own_sort), W, _p(self.Gown), d, _p(self.own_xkeys), n_small, P, sgp, sp0p, ss0p, sp1p, ss1p,
                           _p(self.bucket), self.lr, self.eps, self.acc.data_ptr() + 8 * SLOTS, 1, self.max_norm, None,
-                          self.bucket.data_ptr() + 8 * (N + 1), stream)
+                          self.bucket.data_ptr() + 8 * (N + 1), *close, stream)
             return [[route], [pack], [step, reduce_], [zero, oroute, onorm, pack_b], [fin_b, oapply]]
         return [[route], [pack], [step, reduce_], [zero, oroute, oreduce, gnorm, pack_b], [fin_b, apply_]]
-
-    def _exchange(self, k):
-        """The collective after segment k (several ranks only)."""
-        from jTransUP.parallel import _a2a, _all_reduce
-        if not dist.is_initialized():                        # force_exchange without a process group: one rank talks to itself
-            if k == 0:
-                self.recv_ids.copy_(self.send_ids)
-            elif k == 1:
-                self.X[:self.W].copy_(self.Xsend)
-            elif k == 2:
-                self.Grecv.copy_(self.Gwire)
-            return
-        if k == 0:
-            _a2a(self.recv_ids, self.send_ids, None, None, self.group)            # ids to their owners
-        elif k == 1:
-            _a2a(self.X[:self.W], self.Xsend, None, None, self.group)             # rows back
-        elif k == 2:
-            _a2a(self.Grecv, self.Gwire, None, None, self.group)                  # row gradients to the owners
-        elif k == 3:
-            _all_reduce(self.bucket, self.group)                                  # small gradients + norm + overflow flag
 
     # ------------------------------------------------------------------------------------------------ the step
     def load_batch(self, u, pos_items, neg_items):
@@ -312,63 +397,226 @@ class ShardedKtupStepper(object):
             self.load_batch(u, pos_items, neg_items)
         self.run()
 
+
+class ShardedKgStepper(_ShardedStepBase):
+    """KTUP's kg step (knowledgable_recommendation.py:345-383, 394-403) on the row-sharded entity table:
+        kg_lambda * ( marginLoss(pos, neg, margin) + orthogonalLoss(rel[r], norm[r]) + normLoss(ent[h, t of pos and neg]) + normLoss(rel[r]) )
+    with the scores of jTransUP.py:144-157 (TransH on the entity / rel / norm tables; transh=False: TransE, no norm table), backward,
+    clip_grad_norm, optimizer.step.
+
+    step = ShardedKgStepper(Et, rel, norm, batch=8192, kind='adagrad', lr=0.005, max_norm=5.0, margin=1.0, kg_lambda=1.0)
+    step(ph, pt, pr, nh, nt, nr)       # int64 device tensors of `batch` ids each; returns nothing, syncs nothing
+    step.loss_sum                      # running sums of [margin term, orthogonalLoss, normLoss(ent), normLoss(rel)] of THIS rank's triples,
+                                       # un-weighted: kg_lambda x their sum is the reference's loss scalar
+
+    Et: parallel.ShardedTable; rel, norm: replicated (R, d) parameters.  small_state: the Adagrad sums of [rel, norm] when another
+    stepper (the rec step of the joint schedule) already owns them.  marginLoss and the row regularisers are SUMS over the batch:
+    every rank contributes its own triples' terms as they are (SURVEY.md Appendix A #12), the gradients add up across ranks."""
+
+    def __init__(self, Et, rel, norm, batch, kind='adagrad', lr=0.005, eps=1e-10, max_norm=0.0, l1=False, margin=1.0, kg_lambda=1.0,
+                 transh=True, regs=7, small_state=None, group=None, capacity_factor=1.25, use_graphs=True, force_exchange=False,
+                 direct=None, overlap_route=True):
+        if kind not in KINDS:
+            raise ValueError('row-sparse steps exist for plain SGD and Adagrad only')
+        self.tables = [Et]
+        self.transh = bool(transh)
+        self.small = [rel, norm] if self.transh else [rel]
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        if Et.world != self.world or Et.rank != self.rank:
+            raise ValueError('the entity table must be sharded over the stepper\'s process group')
+        self.kind, self.lr, self.eps, self.max_norm = kind, float(lr), float(eps), float(max_norm)
+        self.l1, self.margin, self.kg_lambda, self.regs = bool(l1), float(margin), float(kg_lambda), int(regs)
+        self.B = B = int(batch)
+        self.d = d = Et.d
+        self.P = P = rel.shape[0]
+        dev = self.dev = Et.weight.device
+        if dev.type != 'cuda':
+            raise L.KtupError('ShardedKgStepper runs the HIP kernels: the tables must live on the GPU (no CPU fallback)')
+        if any(tuple(s.shape) != (P, d) or not s.is_contiguous() for s in self.small):
+            raise ValueError('rel / norm are contiguous (R, d) tables of the entity table\'s width')
+        lib = L.load()
+        if not lib.ktup_train_step_supported(1 if self.transh else 2, d, P):
+            raise L.KtupError('no fused kg step kernel for d=%d (ktup_train_step_supported)' % d)
+        self.use_graphs = bool(use_graphs)
+        self.overlap_route = bool(overlap_route)
+        self._side = torch.cuda.Stream(device=dev) if self.overlap_route else None
+        self.multi = self.world > 1 or bool(force_exchange)
+        self.capacity_factor = float(capacity_factor)
+        can_direct = not self.multi
+        if direct and not can_direct:
+            raise ValueError('direct gathers need a single rank')
+        self.direct = can_direct if direct is None else bool(direct)
+        W_ = self.world
+        n_dist = 4 * B
+        cap = [n_dist if W_ == 1 else min(n_dist, int(math.ceil(self.capacity_factor * n_dist / W_)) + 64)]
+        self.cap, self.capsum = cap, cap[0]
+        self.W = W = W_ * self.capsum
+        self.E = E = 4 * B
+        i64 = lambda n, fill=None: torch.empty(n, dtype=torch.int64, device=dev) if fill is None else torch.full((n,), fill, dtype=torch.int64, device=dev)
+        i32 = lambda n: torch.zeros(n, dtype=torch.int32, device=dev)
+        f32 = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
+        self.cols = [i64(B, 0) for _ in range(6)]                        # ph, pt, pr, nh, nt, nr
+        self.cursor = torch.zeros(1, dtype=torch.int64, device=dev)
+        self._feed = tuple(self.cols) + (1,)
+        self.entries, self.rels, self.inverse = i64(E, 0), i64(2 * B, 0), i64(E, 0)
+        self.order = i32(B)
+        self.send_ids = i64(W, -1)
+        self.sort_ws = i32((lib.ktup_shard_route_sort_bytes(E, W) + 3) // 4)
+        self.counters = i32(W_ + 1)
+        self.route_ws = torch.empty((lib.ktup_shard_route_workspace_bytes(E) + 7) // 8, dtype=torch.int64, device=dev)
+        self.X = f32(W + 1, d)
+        self.GE = f32(E, d)
+        self.Gwire = f32(W, d)
+        self.xkeys = i32(max(2, lib.ktup_shard_reduce_list_len(E, d)))
+        self.acc = torch.zeros(SLOTS + 1, dtype=torch.float64, device=dev)
+        self.loss_sum, self.loss_step = f32(4), f32(4)
+        self.skipped = i32(1)
+        self.small_g = [f32(P, d) for _ in self.small]
+        if kind == 'adagrad':
+            self.small_state = list(small_state) if small_state is not None else [torch.zeros_like(s.data) for s in self.small]
+            if Et.state is None:
+                Et.state = torch.zeros_like(Et.weight.data)
+        else:
+            self.small_state = [None] * len(self.small)
+        self.steps = 0
+        if self.multi:
+            self.recv_ids = i64(W, -1)
+            self.Xsend = f32(W, d)
+            self.Grecv = f32(W, d)
+            self.cap_own = [max(1, min(W_ * cap[0], Et.weight.shape[0]))]
+            self.W_own = Wo = self.cap_own[0]
+            self.own_inverse = i64(W, 0)
+            self.own_ids = i64(Wo, -1)
+            self.own_sort = i32((lib.ktup_shard_route_sort_bytes(W, Wo) + 3) // 4)
+            self.own_counters = i32(1 + 1)
+            self.own_ws = torch.empty((lib.ktup_shard_route_workspace_bytes(W) + 7) // 8, dtype=torch.int64, device=dev)
+            self.Gown = f32(Wo, d)
+            self.own_xkeys = i32(max(2, lib.ktup_shard_reduce_list_len(W, d)))
+            self.bucket = torch.zeros(len(self.small) * P * d + 2, dtype=torch.float64, device=dev)
+        self._eager = None
+        self._graphs = None
+
+    def _bind(self, stream, side=None):
+        B, d, P, W, E, Wn = self.B, self.d, self.P, self.W, self.E, self.world
+        Et = self.tables[0]
+        keep = self._keep = []
+
+        def arr(x):
+            keep.append(x)
+            return ctypes.addressof(x)
+        tabs = arr(_ptrs([Et.weight.data]))
+        lds = arr(_i64s([Et.weight.data.stride(0)]))
+        states = arr(_ptrs([Et.state])) if self.kind == 'adagrad' else None
+        cap = arr(_i64s(self.cap))
+        kind = KINDS[self.kind]
+        n_small = len(self.small)
+        sgp = arr(_ptrs(self.small_g))
+        sp0p = arr(_ptrs([s.data for s in self.small]))
+        ss0p = arr(_ptrs(self.small_state)) if self.kind == 'adagrad' else None
+        rel = self.small[0].data
+        norm = self.small[1].data if self.transh else None
+        gR, gN = self.small_g[0], (self.small_g[1] if self.transh else None)
+        close = (_p(self.loss_step), 4, _p(self.loss_sum), _p(self.skipped))
+        skip_i = self.counters.data_ptr() + 4 * Wn
+        bind = L.bind
+        f = self._feed
+
+        def route_phase(phase, on):
+            return bind('ktup_shard_route_kg', _p(f[0]), _p(f[1]), _p(f[2]), _p(f[3]), _p(f[4]), _p(f[5]), B, f[6], _p(self.cursor),
+                        _p(self.entries), _p(self.rels), Wn, cap, _p(self.inverse), _p(self.send_ids), _p(self.sort_ws), _p(self.counters),
+                        _p(self.acc), SLOTS + 1, _p(self.route_ws), phase, on)
+        order = bind('ktup_shard_kg_rel_order', _p(self.rels), B, P, _p(self.order), stream)
+        if self.direct:
+            Esrc, lde, ent_ids = Et.weight.data, Et.weight.data.stride(0), self.entries
+        else:
+            Esrc, lde, ent_ids = self.X, d, self.inverse
+        step = bind('ktup_train_kg_step_rows', int(self.transh), _p(Esrc), lde, _p(rel), d, _p(norm), d, d, _p(ent_ids), _p(self.rels),
+                    _p(self.order), B, int(self.l1), self.margin, self.kg_lambda, self.regs, _p(self.loss_step), _p(self.GE), _p(gR), _p(gN), stream)
+        if not self.multi:
+            pack = bind('ktup_shard_pack_wire', 1, tabs, lds, cap, d, _p(self.send_ids), 1, _p(self.X), d, stream)
+            rnorm = bind('ktup_shard_reduce_norm', _p(self.GE), d, d, E, 0, _p(self.sort_ws), E, W, _p(self.Gwire), d, _p(self.xkeys), n_small,
+                         sgp, P * d, 1.0, _p(self.acc), SLOTS, stream)
+            rapply = bind('ktup_shard_reduce_apply', kind, 1, tabs, lds, states, lds, cap, _p(self.send_ids), 1, _p(self.GE), d, d, E, 0,
+                          _p(self.sort_ws), E, _p(self.Gwire), d, _p(self.xkeys), n_small, P, sgp, sp0p, ss0p, None, None, None, self.lr,
+                          self.eps, _p(self.acc), SLOTS, self.max_norm, skip_i, None, *close, stream)
+            if self.direct and side is not None:
+                return [[route_phase(1, stream), ('fork', [route_phase(2, side)]), order, step, ('join',), rnorm, rapply]]
+            return [[route_phase(0, stream)] + ([] if self.direct else [pack]) + [order, step, rnorm, rapply]]
+        capo = arr(_i64s(self.cap_own))
+        eoff_o = arr(_i64s([0, self.capsum]))
+        pack = bind('ktup_shard_pack_wire', 1, tabs, lds, cap, d, _p(self.recv_ids), Wn, _p(self.Xsend), d, stream)
+        reduce_ = bind('ktup_shard_reduce_rows', _p(self.GE), d, d, E, 0, _p(self.sort_ws), E, W, _p(self.Gwire), d, stream)
+        zero = bind('ktup_zero_async', _p(self.Gwire), self.Gwire.numel() * 4, stream)
+        oroute = bind('ktup_shard_route', _p(self.recv_ids), W, self.capsum, 1, eoff_o, 1, capo, 0, 0, _p(self.own_inverse),
+                      _p(self.own_ids), None, _p(self.own_sort), _p(self.own_counters), None, 0, _p(self.own_ws), stream)
+        N = n_small * P * d
+        onorm = bind('ktup_shard_reduce_norm', _p(self.Grecv), d, d, W, 0, _p(self.own_sort), W, self.W_own, _p(self.Gown), d,
+                     _p(self.own_xkeys), 0, None, 0, 1.0, _p(self.acc), SLOTS, stream)
+        pack_b = bind('ktup_shard_bucket', 0, n_small, sgp, P * d, _p(self.bucket), _p(self.acc), SLOTS, skip_i, None, 1.0, stream)
+        fin_b = bind('ktup_shard_bucket', 1, n_small, None, P * d, _p(self.bucket), None, 0, None, self.acc.data_ptr() + 8 * SLOTS, 1.0, stream)
+        oapply = bind('ktup_shard_reduce_apply', kind, 1, tabs, lds, states, lds, capo, _p(self.own_ids), 1, _p(self.Grecv), d, d, W, 0,
+                      _p(self.own_sort), W, _p(self.Gown), d, _p(self.own_xkeys), n_small, P, sgp, sp0p, ss0p, None, None, _p(self.bucket),
+                      self.lr, self.eps, self.acc.data_ptr() + 8 * SLOTS, 1, self.max_norm, None, self.bucket.data_ptr() + 8 * (N + 1),
+                      *close, stream)
+        return [[route_phase(0, stream)], [pack], [order, step, reduce_], [zero, oroute, onorm, pack_b], [fin_b, oapply]]
+
+    def load_batch(self, ph, pt, pr, nh, nt, nr):
+        if self._feed[0] is not self.cols[0]:
+            self.set_feed(None)
+        for dst, src in zip(self.cols, (ph, pt, pr, nh, nt, nr)):
+            dst.copy_(src, non_blocking=True)
+
+    def set_feed(self, columns):
+        """columns = (ph, pt, pr, nh, nt, nr): contiguous int64 device tensors of n_batches x B ids each; step s reads batch
+        (cursor mod n_batches) and moves the device cursor on.  None: back to the static buffers load_batch fills."""
+        if columns is None:
+            self._feed = tuple(self.cols) + (1,)
+        else:
+            cs = tuple(columns)
+            for c in cs:
+                if c.dtype != torch.int64 or c.device != self.dev or not c.is_contiguous() or c.numel() % self.B or c.numel() != cs[0].numel():
+                    raise L.KtupError('feed columns are contiguous int64 device tensors of n_batches x B ids each')
+            self._feed = cs + (cs[0].numel() // self.B,)
+        self.cursor.zero_()
+        self._eager = None
+        self._graphs = None
+
+    def __call__(self, *ids):
+        if ids:
+            self.load_batch(*ids)
+        self.run()
+
+
+class ShardedKtupJoint(object):
+    """The joint schedule of knowledgable_recommendation.py:209,320: step s is a rec step iff s % 10 < 10 * joint_ratio, else a
+    kg step -- each stepper replays its own graphs; the entity shard, the rel / norm tables and every Adagrad sum are shared.
+
+    joint = ShardedKtupJoint.build(Ut, It, Et, pref, pref_norm, rel, norm, item2ent, batch=8192, joint_ratio=0.7, ...)
+    joint.rec.set_feed((u, pos, neg)); joint.kg.set_feed((ph, pt, pr, nh, nt, nr)); joint.run() ...; joint.check()"""
+
+    def __init__(self, rec, kg, joint_ratio=0.7):
+        self.rec, self.kg = rec, kg
+        self.switch = 10 * float(joint_ratio)
+        self.steps = 0
+
+    @classmethod
+    def build(cls, Ut, It, Et, pref, pref_norm, rel, norm, item2ent, batch, joint_ratio=0.7, margin=1.0, kg_lambda=1.0, kg_batch=None,
+              orth=True, **kw):
+        rec = ShardedKtupStepper(Ut, It, Et, pref, pref_norm, rel, norm, item2ent, batch=batch, orth=orth, **kw)
+        kw_kg = {k: v for k, v in kw.items() if k not in ('target', 'ent_pad', 'fused_apply')}
+        kg = ShardedKgStepper(Et, rel, norm, batch=kg_batch or batch, margin=margin, kg_lambda=kg_lambda,
+                              small_state=rec.small_state[2:4] if rec.kind == 'adagrad' else None, **kw_kg)
+        return cls(rec, kg, joint_ratio)
+
+    def is_rec(self, step=None):
+        return (self.steps if step is None else step) % 10 < self.switch
+
     def run(self):
-        """One step on the ids in the static buffers.  The first two steps issue the launches directly (warm-up), then the
-        segments are captured once and replayed."""
-        stream = torch.cuda.current_stream(self.dev).cuda_stream
-        if not self.use_graphs or self.steps < 2:
-            if self._eager is None or self._eager[0] != stream:
-                self._eager = (stream, self._bind(stream), self._keep)
-            for k, seg in enumerate(self._eager[1]):
-                self._issue(seg, None)
-                if self.multi:
-                    self._exchange(k)
-            self.steps += 1
-            return
-        if self._graphs is None:
-            self._capture()
-        for k, g in enumerate(self._graphs):
-            g.replay()
-            if self.multi:
-                self._exchange(k)
+        (self.rec if self.is_rec() else self.kg).run()
         self.steps += 1
 
-    def _issue(self, seg, side):
-        for item in seg:
-            if callable(item):
-                item()
-            elif item[0] == 'fork':                           # launches bound to the side stream, ordered after everything so far
-                side.wait_stream(torch.cuda.current_stream(self.dev))
-                for launch in item[1]:
-                    launch()
-            elif item[0] == 'join':
-                torch.cuda.current_stream(self.dev).wait_stream(side)
-
-    def _capture(self):
-        """Each segment becomes one HIP graph (the collectives between them are issued by torch.distributed).  A captured segment
-        also RUNS nothing: the step that triggers the capture replays the fresh graphs."""
-        graphs, keeps = [], []
-        n_seg = 5 if self.multi else 1
-        for k in range(n_seg):
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                cs = torch.cuda.current_stream(self.dev).cuda_stream
-                side = self._side if (self.direct and self.overlap_route) else None
-                segs = self._bind(cs, None if side is None else side.cuda_stream)
-                keeps.append(self._keep)
-                self._issue(segs[k], side)
-            graphs.append(graph)
-        self._graphs, self._graph_keep = graphs, keeps
-
-    # ------------------------------------------------------------------------------------------------ reporting
-    def overflowed_steps(self):
-        """Cheap only when called rarely: one device read.  The counter of the LAST step's unplaced ids (0 = fine)."""
-        if not self.multi:
-            return int(self.counters[-1].item())
-        return int(self.bucket[-1].item())
-
     def check(self):
-        n = self.overflowed_steps()
-        if n:
-            raise L.KtupError('the last sharded step asked one owner for more distinct rows than capacity_factor=%.2f allows (%d ids '
-                              'unplaced on the job); the step was skipped -- raise capacity_factor (world = always safe)' % (self.capacity_factor, n))
+        self.rec.check()
+        self.kg.check()

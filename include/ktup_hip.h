@@ -418,9 +418,9 @@ int ktup_shard_sparse_step(int kind, float* table, int64_t ldt, float* state, in
  *   No memset, no host read: five launches, capturable; sort_ws 16-byte aligned.  On the owner side of a multi-rank step the same call with world = 1 and
  *   block = capsum groups the rows several peers asked for.
  * ktup_shard_reduce_rows: gwire[w] += sum of G rows of the entries sorted to wire row w; entry e reads row e of G for e < n_src,
- *   row e - src_off otherwise (KTUP: G = [GU ; GV] of ktup_train_rec_step_rows, 4B rows; the 2B entity entries re-read GV:
- *   n_src = 4B, src_off = 2B).  Sorted segments (csrc/ktup_segreduce.hip), no per-element atomics.
- * ktup_shard_ktup_entries: entries = [u ; u | pos ; neg | item2ent[pos ; neg]] (6B, or 4B when item2ent is NULL), an entity of
+ *   row e - src_off otherwise (KTUP: entries [u | pos ; neg | entities], G = [GU ; GV] of ktup_train_rec_step_rows, 3B rows; the 2B
+ *   entity entries re-read GV: n_src = 3B, src_off = 2B).  Sorted segments (csrc/ktup_segreduce.hip), no per-element atomics.
+ * ktup_shard_ktup_entries: entries = [u | pos ; neg | item2ent[pos ; neg]] (5B, or 3B when item2ent is NULL), an entity of
  *   value < 0 or == ent_pad becoming padding.
  * ktup_shard_pack_wire: out[w] = table_t[ids[w]] for the n_blocks * capsum rows of a wire buffer (t from w's place in its block;
  *   rows with ids[w] < 0 are left untouched).  tables / ld / cap: HOST arrays of n_tables device pointers / pitches / capacities.
@@ -444,8 +444,8 @@ int ktup_shard_route(const int64_t* ids, int64_t n_entries, int64_t block, int n
                      const int64_t* cap, int pair_a, int pair_b, int64_t* inverse, int64_t* send_ids, int32_t* pair_map,
                      int32_t* sort_ws, int32_t* counters, double* zero_doubles, int n_zero_doubles, void* ws, void* stream);
 /* ktup_shard_route for the KTUP rec step with the entry list built by its first launch: batch (*cursor mod n_batches) of the id
- * columns u / pos_items / neg_items (n_batches x B each; cursor NULL: batch 0) -> entries = [u ; u | pos ; neg | item2ent[pos ; neg]]
- * (6B int64, written; 4B / two tables when item2ent is NULL), tables 0 / 1 / 2 = users / items / entities, pair_map = item wire row
+ * columns u / pos_items / neg_items (n_batches x B each; cursor NULL: batch 0) -> entries = [u | pos ; neg | item2ent[pos ; neg]]
+ * (5B int64, written; 3B / two tables when item2ent is NULL; a user is one entry, shared by its positive and its negative pair), tables 0 / 1 / 2 = users / items / entities, pair_map = item wire row
  * -> entity wire row.  *cursor (device) is incremented by the call: a replayed graph walks through the columns by itself.
  * phase: 0 = the whole route; 1 = its first launch only (scratch init + the entry list); 2 = the remaining four launches -- a
  * scorer that needs nothing but the entry list (global ids) can then run beside phase 2 on another stream.                    */
@@ -592,9 +592,10 @@ int ktup_train_rec_step(const float* U, int64_t ldu, const float* I, int64_t ldi
                         const int64_t* i_ids, int64_t B, int l1, int gumbel_mode, const float* uniform, uint64_t seed,
                         uint64_t offset, float target, float gscale, int orth, float* loss, float* gU, float* gI, float* gE,
                         float* gP, float* gPn, float* gR, float* gRn, void* stream);
-/* ktup_train_rec_step with the row gradients of pair k (k in [0, 2B): positives then negatives) stored as rows k of GU / GV (GV: the
- * item row's gradient, which is also its entity row's) instead of accumulated by atomics -- for ktup_shard_reduce_rows / large
- * batches.  Soft gate only.  gR / gRn may be NULL although rel / norm are given (then orth must be 0): gP / gPn are the gradients
+/* ktup_train_rec_step with the row gradients STORED instead of accumulated by atomics -- for ktup_shard_reduce_rows / large
+ * batches: u_ids holds B ids (example k's user: a BPR example's positive and negative pair share it), i_ids 2B (positives then
+ * negatives); row k of GU (B x d) = the user-row gradient of example k from BOTH pairs, row k of GV (2B x d) = the item-row
+ * gradient of pair k (which is also its entity row's).  Soft gate only.  gR / gRn may be NULL although rel / norm are given (then orth must be 0): gP / gPn are the gradients
  * of both summands of the mixed tables.                                                                                   */
 int ktup_train_rec_step_rows(const float* U, int64_t ldu, const float* I, int64_t ldi, const float* E, int64_t lde,
                              const int32_t* item2ent, int64_t ent_pad, const float* pref, const float* pref_norm,

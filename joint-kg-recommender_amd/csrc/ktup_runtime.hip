@@ -44,10 +44,12 @@ Option g_opts[] = {
     {"side_sort", "KTUP_SIDE_SORT", {env_int("KTUP_SIDE_SORT", 1)}},    // 0: the id sorts of the segment reductions stay on the caller's stream
     {"shard_chunk", "KTUP_SHARD_CHUNK", {env_int("KTUP_SHARD_CHUNK", 0)}},   // > 0: sorted entries per lane group in the sharded step's two reduction walks (0: by batch size)
     {"nt_gather", "KTUP_NT_GATHER", {env_int("KTUP_NT_GATHER", 0)}},         // 1: K5-K7 forward gathers its rows with the nontemporal hint (tables >> Infinity Cache)
-    {"dbg_noflush", "KTUP_DBG_NOFLUSH", {env_int("KTUP_DBG_NOFLUSH", 0)}},  // MEASUREMENT ONLY (wrong results): the fused step kernels skip the small-table gradient flush
+    // the two MEASUREMENT-ONLY knobs (wrong results) are never seeded from the environment: only ktup_set_option turns them on, and it says so on stderr
+    {"dbg_noflush", "", {0}},                                              // the fused step kernels skip the small-table gradient flush
     {"eval_nsplit", "KTUP_EVAL_NSPLIT", {env_int("KTUP_EVAL_NSPLIT", 0)}},  // > 0: catalogue splits of the one-sweep rec evaluation (0: by occupancy, at most 8)
-    {"dbg_eval", "KTUP_DBG_EVAL", {env_int("KTUP_DBG_EVAL", 0)}},           // MEASUREMENT ONLY (wrong results): bits switch phases of the rec evaluation sweep off
+    {"dbg_eval", "", {0}},                                                  // bits switch phases of the rec evaluation sweep off
     {"kg_wtab", "KTUP_KG_WTAB", {env_int("KTUP_KG_WTAB", 1)}},              // 0: the fused TransH link-prediction pass computes w.e in the sweep instead of once per (relation, candidate)
+    {"wide_waves", "KTUP_WIDE_WAVES", {env_int("KTUP_WIDE_WAVES", 8)}},     // d = 256 coordinate-sliced K5-K7 backward / fused step: waves that share a 16-pair tile (8, or 4: the round-3 form)
 };
 Option* find(const char* name) {
   for (auto& o : g_opts)
@@ -67,6 +69,7 @@ int opt_dbg_noflush() { return g_opts[8].value.load(std::memory_order_relaxed); 
 int opt_eval_nsplit() { return g_opts[9].value.load(std::memory_order_relaxed); }
 int opt_dbg_eval() { return g_opts[10].value.load(std::memory_order_relaxed); }
 int opt_kg_wtab() { return g_opts[11].value.load(std::memory_order_relaxed); }
+int opt_wide_waves() { return g_opts[12].value.load(std::memory_order_relaxed); }
 
 // A library-owned second stream for work that depends only on a call's INPUTS (the counting sorts of the segment reductions)
 // while the caller's stream runs the kernel that produces the data: fork_side makes it wait for everything enqueued on `st` so far,
@@ -118,6 +121,8 @@ extern "C" const char* ktup_last_error(void) { return ktup::g_err; }
 extern "C" int ktup_set_option(const char* name, int value) {
   ktup::Option* o = ktup::find(name);
   if (!o) return ktup::set_error(KTUP_ERR_INVALID_ARG, "ktup_set_option: unknown option '%s'", name ? name : "(null)");
+  if (value != 0 && strncmp(o->name, "dbg_", 4) == 0)
+    fprintf(stderr, "libktup_hip: option %s = %d is a MEASUREMENT-ONLY knob: kernels now skip work and produce WRONG results until it is set back to 0\n", o->name, value);
   o->value.store(value, std::memory_order_relaxed);
   return KTUP_OK;
 }

@@ -35,11 +35,12 @@
 namespace ktup {
 namespace {
 
-template <int NCH_, int CTW_, int NP_, bool HASE_, bool HARD_>
+template <int NCH_, int CTW_, int NP_, bool HASE_, bool HARD_, int NWC_ = 4>
 struct WGeom {
   static constexpr int NP = NP_;
   static constexpr bool HASE = HASE_, HARD = HARD_;
-  static constexpr int NCH = NCH_, D = 4 * NCH, NWC = 4, CTW = CTW_, NCW = 4 * CTW;   // 4 waves x CTW coordinate tiles of 16 = NCW chunks each
+  static constexpr int NCH = NCH_, D = 4 * NCH, NWC = NWC_, CTW = CTW_, NCW = 4 * CTW;   // NWC waves x CTW coordinate tiles of 16 = NCW chunks each
+  static constexpr int NT = 64 * NWC;                     // threads of a workgroup
   static constexpr int NCHP = NWC * NCW;                  // padded chunk count (>= NCH; tables / tiles are zero beyond NCH)
   static_assert(NCHP >= NCH && NCHP - NCH < NCW, "the last wave must own at least one real chunk");
   static constexpr int PT = (NP + 3) / 4, TROW = 16 * PT;
@@ -52,8 +53,10 @@ struct WGeom {
   static constexpr int LT_F = TROW * 17;
   static constexpr int NOISE_F = HARD ? 16 * TROW : 0;
   static constexpr int RED_F = NWC * 64 * PT * 4;         // cross-wave partials of lg / gl
-  static constexpr size_t SHARED_BYTES = (size_t)3 * TAB_F4 * 16 + (size_t)RED_F * 4 + 3 * NWC * 16 * 4;
-  static constexpr size_t WAVE_BYTES = ((size_t)3 * TILE_F4 * 16 + (size_t)2 * LT_F * 4 + 3 * 16 * 4 + (size_t)NOISE_F * 4 + 15) & ~(size_t)15;
+  // LT / GLT (beta w and gL / 2, preference major) hold the SAME numbers in every wave -- all waves carry the full logits after the
+  // cross-wave sum -- so the workgroup keeps one copy: every wave writes all of it (equal values) before it reads it
+  static constexpr size_t SHARED_BYTES = (size_t)3 * TAB_F4 * 16 + (size_t)RED_F * 4 + 3 * NWC * 16 * 4 + (size_t)2 * LT_F * 4;
+  static constexpr size_t WAVE_BYTES = ((size_t)3 * TILE_F4 * 16 + 2 * 3 * 16 * 4 + (size_t)NOISE_F * 4 + 15) & ~(size_t)15;
   static constexpr size_t LDS = SHARED_BYTES + NWC * WAVE_BYTES;
 };
 
@@ -76,6 +79,7 @@ struct WArgs {
   float* loss;                   // loss[0] += mean_k -logsigmoid(target (pos_k - neg_k)); loss[1] += orthogonalLoss(pref, pnorm)
   float *gP, *gPn, *gR, *gRn;    // gradients of the raw tables, pitch D
   int orth;
+  int u_once;                    // STEP + ROWOUT: u_ids holds B ids (example k's user, shared by its two pairs) and GU B rows (the sum)
   int noflush;                   // measurement knob (option dbg_noflush)
   int gumbel;
   const float* uniform;
@@ -86,7 +90,7 @@ KTUP_DEV float wstep_neg_logsigmoid(float x) { return fmaxf(-x, 0.f) + log1pf(ex
 KTUP_DEV float wstep_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
 
 template <typename G, bool ROWOUT, bool STEP>
-__global__ __launch_bounds__(256) void pref_bwd_wide_kernel(WArgs a) {
+__global__ __launch_bounds__(G::NT) void pref_bwd_wide_kernel(WArgs a) {
   KTUP_RESOLVE_GUMBEL(a);
   constexpr int NP = G::NP, D = G::D, NCH = G::NCH, NCW = G::NCW, CTW = G::CTW, PT = G::PT, TROW = G::TROW;
   constexpr int RP4 = G::RP4, RPF = G::RPF, TP4 = G::TP4, TPF = G::TPF;
@@ -105,15 +109,21 @@ __global__ __launch_bounds__(256) void pref_bwd_wide_kernel(WArgs a) {
   const float* Cn2 = reinterpret_cast<const float*>(CnT);
   const int tid = threadIdx.x, lane = tid & 63, kq = lane >> 4, j = lane & 15;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);     // this wave's coordinate slice: [64 w, 64 w + 64)
-  char* wbase = reinterpret_cast<char*>(redsc + G::NWC * 16) + (size_t)w * G::WAVE_BYTES;
+  float* LT = redsc + G::NWC * 16;                            // [TROW][17]  beta * w   (preference major; one copy per workgroup)
+  float* GLT = LT + G::LT_F;                                  // [TROW][17]  gL / 2
+  char* wbase = reinterpret_cast<char*>(GLT + G::LT_F) + (size_t)w * G::WAVE_BYTES;
   v4* XT = reinterpret_cast<v4*>(wbase);                      // x    [16 pairs][TP4]   (this wave's 16 chunks)
   v4* QT = XT + G::TILE_F4;                                   // q, later gn (a lane overwrites exactly what it read)
   v4* GRT = QT + G::TILE_F4;                                  // gr = gz
-  float* LT = reinterpret_cast<float*>(GRT + G::TILE_F4);     // [TROW][17]  beta * w   (preference major)
-  float* GLT = LT + G::LT_F;                                  // [TROW][17]  gL / 2
-  int32_t* sid = reinterpret_cast<int32_t*>(GLT + G::LT_F);   // [3][16]
-  float* noise = reinterpret_cast<float*>(sid + 48);          // HARD: [16][TROW]
+  int32_t* sid0 = reinterpret_cast<int32_t*>(GRT + G::TILE_F4);   // [2][3][16]: the ids of this tile and of the next one
+  float* noise = reinterpret_cast<float*>(sid0 + 96);         // HARD: [16][TROW]
   const int P = a.P;
+  auto wsum16 = [](const float* r, int jj) {                  // the waves' partials of slot jj, always summed in wave order
+    float t = (r[jj] + r[16 + jj]) + (r[32 + jj] + r[48 + jj]);
+#pragma unroll
+    for (int ww = 4; ww < G::NWC; ww += 4) t += (r[16 * ww + jj] + r[16 * ww + 16 + jj]) + (r[16 * ww + 32 + jj] + r[16 * ww + 48 + jj]);
+    return t;
+  };
   int nblk = gridDim.x;                                       // workgroups that walk tiles
   if constexpr (STEP) {
     if (a.orth) {
@@ -146,17 +156,55 @@ __global__ __launch_bounds__(256) void pref_bwd_wide_kernel(WArgs a) {
       }
     }
   }
+  const int grow_l = lane / NCW, gch = lane % NCW;            // gather: row grow_l + GR jj, chunk gch of the wave's slice
+  const bool gok = !RAGGED || NCW * w + gch < NCH;            // chunks past the row stay zero in the tiles
+  const int64_t ntiles = STEP ? (a.B + 7) / 8 : (a.n + 15) / 16;
+  // ---- the gather runs ONE TILE AHEAD: while tile t goes through its phases (a chain of eight workgroup barriers on a wave that is
+  // alone on its SIMD), the rows of the workgroup's next tile are in flight into registers, its ids already in the other id buffer
+  constexpr int GJ = G::GJ, GR = G::GR;
+  v4 uu[GJ], vv[GJ], ee[GJ];
+  int32_t nuid = 0, niid = 0, neid = 0;                         // lanes 0-15: the ids that are staged next (fetched a whole tile earlier)
+  auto fetch_ids = [&](int64_t tile) {
+    if (lane < 16) {
+      const int64_t gr = STEP ? tile * 8 + (lane & 7) + (lane >> 3) * a.B : tile * 16 + lane;
+      const bool ok = tile < ntiles && (STEP ? tile * 8 + (lane & 7) < a.B : gr < a.n);
+      const int64_t uid = ok ? a.u_ids[(STEP && a.u_once) ? tile * 8 + (lane & 7) : gr] : 0, iid = ok ? a.i_ids[gr] : 0;
+      nuid = (int32_t)uid; niid = (int32_t)iid;
+      neid = HASE ? a.item2ent[iid] : 0;
+    }
+  };
+  auto stage_ids = [&](int32_t* dst) {
+    if (lane < 16) { dst[lane] = nuid; dst[16 + lane] = niid; dst[32 + lane] = neid; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  };
+  auto load_rows = [&](const int32_t* src) {
+#pragma unroll
+    for (int jj = 0; jj < GJ; ++jj) {
+      const int r = grow_l + GR * jj;
+      const uint32_t idu = (uint32_t)src[r], idi = (uint32_t)src[16 + r];
+      const v4 zero = (v4){0.f, 0.f, 0.f, 0.f};
+      uu[jj] = gok ? a.U[(uint64_t)idu * a.ldu4 + (uint32_t)(NCW * w + gch)] : zero;
+      vv[jj] = gok ? a.I[(uint64_t)idi * a.ldi4 + (uint32_t)(NCW * w + gch)] : zero;
+      if (HASE) {
+        const uint32_t ide = (uint32_t)src[32 + r];
+        ee[jj] = gok ? a.E[(uint64_t)ide * a.lde4 + (uint32_t)(NCW * w + gch)] : zero;
+      }
+    }
+  };
+  // the first tile's ids (two dependent loads: the item id, then its entity) fly under the table staging
+  if ((int64_t)blockIdx.x < ntiles) fetch_ids(blockIdx.x);
   // ---- stage the three tables: row p = preference p (zero beyond P), odd float4 row pitch.  All of a thread's loads are issued
   // before the first store: a B = 512 step is ONE tile per workgroup, so this prologue is on the step's critical path (with a
   // load -> store loop it cost ~8 dependent L2 round trips)
   {
-    constexpr int NIT = (G::TAB_F4 + 255) / 256;
+    constexpr int NIT = (G::TAB_F4 + G::NT - 1) / G::NT;
     const int dp = a.dp;
     const v4 zero = (v4){0.f, 0.f, 0.f, 0.f};
     v4 t0[NIT], t1[NIT], t2[NIT], t3[NIT];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-      const int idx = tid + 256 * it;
+      const int idx = tid + G::NT * it;
       const int row = idx / RP4, c = idx - row * RP4;
       const bool ok = idx < G::TAB_F4 && row < P && c < NCH;
       t0[it] = t1[it] = t2[it] = t3[it] = zero;
@@ -177,7 +225,7 @@ __global__ __launch_bounds__(256) void pref_bwd_wide_kernel(WArgs a) {
     }
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-      const int idx = tid + 256 * it;
+      const int idx = tid + G::NT * it;
       if (idx < G::TAB_F4) {
         if constexpr (STEP) {
           const v4 A = t0[it] + t2[it], C = t1[it] + t3[it];
@@ -189,6 +237,11 @@ __global__ __launch_bounds__(256) void pref_bwd_wide_kernel(WArgs a) {
         }
       }
     }
+  }
+  if ((int64_t)blockIdx.x < ntiles) {
+    stage_ids(sid0);
+    load_rows(sid0);
+    fetch_ids((int64_t)blockIdx.x + nblk);
   }
   __syncthreads();
   // ---- loop-invariant lane geometry
@@ -206,8 +259,6 @@ __global__ __launch_bounds__(256) void pref_bwd_wide_kernel(WArgs a) {
     const int p = 4 * m + kq;
     rb[m] = (p < P ? p : P) * RPF + 4 * NCW * w + j;          // float index; + 16 ct per coordinate tile
   }
-  const int grow_l = lane / NCW, gch = lane % NCW;            // gather: row grow_l + GR jj, chunk gch of the wave's slice
-  const bool gok = !RAGGED || NCW * w + gch < NCH;            // chunks past the row stay zero in the tiles
   float lpart = 0.f;                                          // STEP: this lane's share of the BPR loss value
   const bool l1 = a.l1 != 0;
   const float beta = a.beta;
@@ -216,46 +267,26 @@ __global__ __launch_bounds__(256) void pref_bwd_wide_kernel(WArgs a) {
   for (int pt = 0; pt < PT; ++pt)
 #pragma unroll
     for (int ct = 0; ct < CTW; ++ct) { accA[pt][ct] = (v4){0.f, 0.f, 0.f, 0.f}; accC[pt][ct] = accA[pt][ct]; }
-  const int64_t ntiles = STEP ? (a.B + 7) / 8 : (a.n + 15) / 16;
-  for (int64_t tile_id = blockIdx.x; tile_id < ntiles; tile_id += nblk) {
+  int cur = 0;
+  for (int64_t tile_id = blockIdx.x; tile_id < ntiles; tile_id += nblk, cur ^= 1) {
     const int64_t row0 = tile_id * 16;
     // STEP: slot j holds example k = 8 tile + (j & 7); slots 8-15 are the negatives (rows k + B of the id arrays)
     const int64_t kpair = STEP ? tile_id * 8 + (j & 7) : row0 + j;
     const bool live_j = STEP ? kpair < a.B : kpair < a.n;
     const int64_t row_j = STEP ? kpair + (j >> 3) * a.B : kpair;          // row in the [pos ; neg] id / draw order
-    if (lane < 16) {
-      const int64_t gr = STEP ? tile_id * 8 + (lane & 7) + (lane >> 3) * a.B : row0 + lane;
-      const bool ok = STEP ? tile_id * 8 + (lane & 7) < a.B : gr < a.n;
-      const int64_t uid = ok ? a.u_ids[gr] : 0, iid = ok ? a.i_ids[gr] : 0;
-      sid[lane] = (int32_t)uid;
-      sid[16 + lane] = (int32_t)iid;
-      sid[32 + lane] = HASE ? a.item2ent[iid] : 0;
+    const int32_t* sid = sid0 + 48 * cur;
+    // ---- this wave's coordinate slice of the 16 pairs (gathered during the previous tile): x and q tiles
+#pragma unroll
+    for (int jj = 0; jj < GJ; ++jj) {
+      const int r = grow_l + GR * jj;
+      const v4 ve = HASE ? vv[jj] + ee[jj] : vv[jj];
+      XT[r * TP4 + gch] = uu[jj] + ve;
+      QT[r * TP4 + gch] = uu[jj] + (-ve);
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    // ---- gather this wave's coordinate slice of the 16 pairs: x and q tiles
-    {
-      constexpr int GJ = G::GJ, GR = G::GR;
-      v4 uu[GJ], vv[GJ], ee[GJ];
-#pragma unroll
-      for (int jj = 0; jj < GJ; ++jj) {
-        const int r = grow_l + GR * jj;
-        const uint32_t idu = (uint32_t)sid[r], idi = (uint32_t)sid[16 + r];
-        const v4 zero = (v4){0.f, 0.f, 0.f, 0.f};
-        uu[jj] = gok ? a.U[(uint64_t)idu * a.ldu4 + (uint32_t)(NCW * w + gch)] : zero;
-        vv[jj] = gok ? a.I[(uint64_t)idi * a.ldi4 + (uint32_t)(NCW * w + gch)] : zero;
-        if (HASE) {
-          const uint32_t ide = (uint32_t)sid[32 + r];
-          ee[jj] = gok ? a.E[(uint64_t)ide * a.lde4 + (uint32_t)(NCW * w + gch)] : zero;
-        }
-      }
-#pragma unroll
-      for (int jj = 0; jj < GJ; ++jj) {
-        const int r = grow_l + GR * jj;
-        const v4 ve = HASE ? vv[jj] + ee[jj] : vv[jj];
-        XT[r * TP4 + gch] = uu[jj] + ve;
-        QT[r * TP4 + gch] = uu[jj] + (-ve);
-      }
+    if (tile_id + nblk < ntiles) {                                        // uniform over the workgroup
+      stage_ids(sid0 + 48 * (cur ^ 1));
+      load_rows(sid0 + 48 * (cur ^ 1));
+      fetch_ids(tile_id + 2 * (int64_t)nblk);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -369,7 +400,7 @@ __global__ __launch_bounds__(256) void pref_bwd_wide_kernel(WArgs a) {
     float s = allsum_kq((sacc[0] + sacc[1]) + (sacc[2] + sacc[3]));
     if (kq == 0) reds[w * 16 + j] = s;
     __syncthreads();
-    s = (reds[j] + reds[16 + j]) + (reds[32 + j] + reds[48 + j]);
+    s = wsum16(reds, j);
     float g;                                                      // upstream gradient of this slot's score; 0 for tail slots
 #pragma unroll
     for (int ct = 0; ct < CTW; ++ct) zz[ct] = zz[ct] - s * nn[ct];    // z
@@ -385,8 +416,8 @@ __global__ __launch_bounds__(256) void pref_bwd_wide_kernel(WArgs a) {
       float score = allsum_kq((dacc[0] + dacc[1]) + (dacc[2] + dacc[3]));
       if (kq == 0) redsc[w * 16 + j] = score;
       __syncthreads();
-      score = (redsc[j] + redsc[16 + j]) + (redsc[32 + j] + redsc[48 + j]);
-      const float other = (redsc[j ^ 8] + redsc[16 + (j ^ 8)]) + (redsc[32 + (j ^ 8)] + redsc[48 + (j ^ 8)]);
+      score = wsum16(redsc, j);
+      const float other = wsum16(redsc, j ^ 8);
       const bool negh = (j >> 3) != 0;
       const float diff = negh ? other - score : score - other;   // pos - neg
       const float g0 = a.gscale * (1.f / (float)a.B);
@@ -409,7 +440,7 @@ __global__ __launch_bounds__(256) void pref_bwd_wide_kernel(WArgs a) {
     float av = allsum_kq((aacc[0] + aacc[1]) + (aacc[2] + aacc[3]));
     if (kq == 0) redav[w * 16 + j] = av;
     __syncthreads();
-    av = (redav[j] + redav[16 + j]) + (redav[32 + j] + redav[48 + j]);
+    av = wsum16(redav, j);
     v4 gq[CTW];
 #pragma unroll
     for (int ct = 0; ct < CTW; ++ct) {
@@ -482,7 +513,7 @@ __global__ __launch_bounds__(256) void pref_bwd_wide_kernel(WArgs a) {
         v4 gu = gq[ct] + gx;
         const v4 gv = gx - gq[ct];
         bool u_mine = true;
-        if constexpr (STEP && !ROWOUT) {
+        if constexpr (STEP) {
           // slots j and j ^ 8 hold a positive and its negative -- the same user in a BPR batch: their user-row gradients are summed
           // through one DPP rotate (row_ror:8, every lane of the wave active here) and slot j < 8 issues ONE atomic for both instead
           // of two on the same address (a third of the step's row atomics)
@@ -493,14 +524,14 @@ __global__ __launch_bounds__(256) void pref_bwd_wide_kernel(WArgs a) {
             const int x = __float_as_int(gu[c]);
             go[c] = __int_as_float(__builtin_amdgcn_update_dpp(x, x, 0x128, 0xf, 0xf, false));
           }
-          if (uo == ur) {
+          if (ROWOUT ? a.u_once != 0 : uo == ur) {
             u_mine = j < 8;
             gu = gu + go;
           }
         }
         if (live && (!RAGGED || c0 < D)) {
           if constexpr (ROWOUT) {
-            *reinterpret_cast<v4*>(a.GU + gr * D + c0) = gu;
+            if (u_mine) *reinterpret_cast<v4*>(a.GU + ((STEP && a.u_once) ? kpair : gr) * D + c0) = gu;
             *reinterpret_cast<v4*>(a.GV + gr * D + c0) = gv;
           } else {
             if (u_mine) atomic_add4(pu + c0, make_float4(gu[0], gu[1], gu[2], gu[3]));
@@ -571,7 +602,7 @@ int launch_r(const WArgs& a, hipStream_t st, const char* name) {
   // d = 256: one workgroup (4 waves) per CU is all the LDS allows; narrower tables: two or three fit
   const int per_cu = (int)((160 * 1024) / G::LDS) < 1 ? 1 : (int)((160 * 1024) / G::LDS);
   const int grid = grid_for(ntiles, 256 * per_cu) + ((STEP && a.orth) ? 1 : 0);
-  hipLaunchKernelGGL((pref_bwd_wide_kernel<G, ROWOUT, STEP>), dim3(grid), dim3(256), G::LDS, st, a);
+  hipLaunchKernelGGL((pref_bwd_wide_kernel<G, ROWOUT, STEP>), dim3(grid), dim3(G::NT), G::LDS, st, a);
   return check_launch(name);
 }
 
@@ -581,21 +612,26 @@ int launch(const WArgs& a, hipStream_t st, const char* name) {
   return a.GU ? launch_r<G, true, false>(a, st, name) : launch_r<G, false, false>(a, st, name);
 }
 
-template <int NCH, int CTW, int NP>
+template <int NCH, int CTW, int NP, int NWC = 4>
 int launch_e(const WArgs& a, hipStream_t st, const char* name) {
   if (a.gumbel != KTUP_GUMBEL_OFF) {
-    if (a.E) return launch<WGeom<NCH, CTW, NP, true, true>>(a, st, name);
-    return launch<WGeom<NCH, CTW, NP, false, true>>(a, st, name);
+    if (a.E) return launch<WGeom<NCH, CTW, NP, true, true, NWC>>(a, st, name);
+    return launch<WGeom<NCH, CTW, NP, false, true, NWC>>(a, st, name);
   }
-  if (a.E) return launch<WGeom<NCH, CTW, NP, true, false>>(a, st, name);
-  return launch<WGeom<NCH, CTW, NP, false, false>>(a, st, name);
+  if (a.E) return launch<WGeom<NCH, CTW, NP, true, false, NWC>>(a, st, name);
+  return launch<WGeom<NCH, CTW, NP, false, false, NWC>>(a, st, name);
 }
 
 // P <= 20 everywhere (NP in {4, 5}); the narrower widths also take P <= 32 (NP = 8), which d = 256 has no LDS for
 int launch_d(const WArgs& a, int d, int np, hipStream_t st, const char* name) {
-  if (d == 256) {
-    if (np <= 4) return launch_e<64, 4, 4>(a, st, name);
-    if (np <= 5) return launch_e<64, 4, 5>(a, st, name);
+  if (d == 256) {                    // eight waves x 32 coordinates: two waves per SIMD (four x 64 left one wave alone with its latencies)
+    if (opt_wide_waves() == 4) {
+      if (np <= 4) return launch_e<64, 4, 4>(a, st, name);
+      if (np <= 5) return launch_e<64, 4, 5>(a, st, name);
+      return 1;
+    }
+    if (np <= 4) return launch_e<64, 2, 4, 8>(a, st, name);
+    if (np <= 5) return launch_e<64, 2, 5, 8>(a, st, name);
     return 1;
   }
   if (d == 64) {
@@ -661,7 +697,8 @@ int pref_step_mc(const float* U, int64_t ldu, const float* I, int64_t ldi, const
   a.pref = pref; a.pnorm = pnorm; a.rel = rel; a.norm = norm; a.ldp = ldp; a.B = B;
   a.target = target; a.gscale = gscale; a.loss = loss; a.gP = gP; a.gPn = gPn; a.gR = gR; a.gRn = gRn; a.orth = orth;
   a.noflush = opt_dbg_noflush();
-  a.GU = GU; a.GV = GV;          // both set: the row gradients of pair k leave as rows k of GU / GV (plain stores) instead of atomics
+  a.GU = GU; a.GV = GV;          // both set: the row gradients leave as rows of GU (example k: both pairs) / GV (pair k) instead of atomics
+  a.u_once = GU != nullptr;
   return launch_d(a, d, (n_pref + 3) / 4, st, name);
 }
 

@@ -37,7 +37,7 @@ struct RouteArgs {
   int32_t *start, *rank, *perm, *skey, *counters;
   double* zero_d; int n_zero_d;
   int32_t* tile_tot; int n_tiles;                      // two-level scan of the histogram (TILE counters per tile); n_tiles = 0: one-workgroup scan
-  // KTUP source (ktup_shard_route_ktup): the init launch also BUILDS ids = [u ; u | pos ; neg | item2ent[pos ; neg]] from batch
+  // KTUP source (ktup_shard_route_ktup): the init launch also BUILDS ids = [u | pos ; neg | item2ent[pos ; neg]] from batch
   // (*cursor mod n_batches) of the id columns, and the NEXT launch moves the cursor on
   const int64_t *src_u, *src_pos, *src_neg; int64_t B, n_batches; const int32_t* item2ent; int64_t ent_pad; int64_t* cursor;
   int64_t* ids_out;
@@ -83,14 +83,14 @@ __global__ __launch_bounds__(256) void route_init_kernel(RouteArgs a) {
     }
   } else if (a.src_u) {                                  // jTransUP.py:122-130: paddingItems as a table lookup
     const int64_t b0 = a.cursor ? ((*a.cursor) % a.n_batches) * a.B : 0;
-    for (int64_t k = tid; k < 2 * a.B; k += nth) {
+    for (int64_t k = tid; k < 2 * a.B; k += nth) {              // a user is ONE entry: its positive and its negative pair share the row
       const int64_t kk = k < a.B ? k : k - a.B;
       const int64_t item = k < a.B ? a.src_pos[b0 + kk] : a.src_neg[b0 + kk];
-      a.ids_out[k] = a.src_u[b0 + kk];
-      a.ids_out[2 * a.B + k] = item;
+      if (k < a.B) a.ids_out[k] = a.src_u[b0 + k];
+      a.ids_out[a.B + k] = item;
       if (a.item2ent) {
         const int64_t ent = a.item2ent[item];
-        a.ids_out[4 * a.B + k] = (ent < 0 || ent == a.ent_pad) ? -1 : ent;
+        a.ids_out[3 * a.B + k] = (ent < 0 || ent == a.ent_pad) ? -1 : ent;
       }
     }
   }
@@ -244,17 +244,17 @@ uint64_t route_slots(int64_t n) {
   return s;
 }
 
-// ---- [u ; u], [pos ; neg], item2ent[pos ; neg]: the entry list of a KTUP rec step (jTransUP.py:122-130 paddingItems as a table)
+// ---- [u], [pos ; neg], item2ent[pos ; neg]: the entry list of a KTUP rec step (jTransUP.py:122-130 paddingItems as a table)
 __global__ __launch_bounds__(256) void ktup_entries_kernel(const int64_t* __restrict__ u, const int64_t* __restrict__ pi,
                                                            const int64_t* __restrict__ ni, int64_t B, const int32_t* __restrict__ item2ent,
                                                            int64_t ent_pad, int64_t* __restrict__ out) {
   for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < 2 * B; k += (int64_t)gridDim.x * 256) {
     const int64_t item = k < B ? pi[k] : ni[k - B];
-    out[k] = u[k < B ? k : k - B];
-    out[2 * B + k] = item;
+    if (k < B) out[k] = u[k];
+    out[B + k] = item;
     if (item2ent) {
       const int64_t ent = item2ent[item];
-      out[4 * B + k] = (ent < 0 || ent == ent_pad) ? -1 : ent;
+      out[3 * B + k] = (ent < 0 || ent == ent_pad) ? -1 : ent;
     }
   }
 }
@@ -804,8 +804,8 @@ extern "C" int ktup_shard_route(const int64_t* ids, int64_t n_entries, int64_t b
 }
 
 // The KTUP rec step's route with its entry list built by the first launch (no separate entries launch): batch (*cursor mod
-// n_batches) of the id columns u / pos / neg (n_batches x B each; cursor may be NULL: batch 0), entries = [u ; u | pos ; neg |
-// item2ent[pos ; neg]] written to `entries` (6B; 4B and two tables when item2ent is NULL), tables 0 / 1 / 2 = users / items /
+// n_batches) of the id columns u / pos / neg (n_batches x B each; cursor may be NULL: batch 0), entries = [u | pos ; neg |
+// item2ent[pos ; neg]] written to `entries` (5B; 3B and two tables when item2ent is NULL), tables 0 / 1 / 2 = users / items /
 // entities, pair_map = item wire row -> entity wire row.  *cursor is incremented by the call.
 extern "C" int ktup_shard_route_ktup(const int64_t* u, const int64_t* pos_items, const int64_t* neg_items, int64_t B, int64_t n_batches,
                                      int64_t* cursor, const int32_t* item2ent, int64_t ent_pad, int64_t* entries, int world,
@@ -814,9 +814,9 @@ extern "C" int ktup_shard_route_ktup(const int64_t* u, const int64_t* pos_items,
   const char* name = "ktup_shard_route_ktup";
   KTUP_REQUIRE(B > 0 && n_batches > 0 && u && pos_items && neg_items && entries, "%s: null pointer argument or empty batch", name);
   const int T = item2ent ? 3 : 2;
-  const int64_t eoff[4] = {0, 2 * B, 4 * B, 6 * B};
+  const int64_t eoff[4] = {0, B, 3 * B, 5 * B};
   RouteArgs a{};
-  if (int e = fill_route(name, a, entries, 2 * B * T, 2 * B * T, T, eoff, world, cap)) return e;
+  if (int e = fill_route(name, a, entries, eoff[T], eoff[T], T, eoff, world, cap)) return e;
   a.src_u = u; a.src_pos = pos_items; a.src_neg = neg_items; a.B = B; a.n_batches = n_batches; a.cursor = cursor;
   a.item2ent = item2ent; a.ent_pad = ent_pad; a.ids_out = entries;
   return route_impl(name, a, 1, 2, inverse, send_ids, item2ent ? pair_map : nullptr, sort_ws, counters, zero_doubles, n_zero_doubles, ws,

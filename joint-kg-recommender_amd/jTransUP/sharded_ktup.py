@@ -5,13 +5,15 @@ torch op, no autograd in the step; the launches go through the C ABI with pre-bo
 The reference is single-device: everything here is new.
 
 One rank (the whole step is one graph of 9-10 launches):
-    route      entries [u ; u | pos ; neg | item2ent[pos ; neg]] of the cursor's batch; distinct ids -> wire rows (owner-major,
+    route      entries [u | pos ; neg | item2ent[pos ; neg]] of the cursor's batch (a user is ONE entry: its positive and its
+               negative pair share the row, and the step kernel hands back the sum of both); distinct ids -> wire rows (owner-major,
                fixed capacity), inverse, item -> entity map on the wire rows, and the counting sort of the entries by wire row
                as a by-product                                                                ktup_shard_route_ktup (5 launches)
     pack       X[w] = table[ids[w]] for all three tables (skipped on one rank when every item has an entity row: the step
                kernel then gathers straight from the shards by global id)                     ktup_shard_pack_wire
-    step       forward of [pos ; neg], BPR term, backward; the row gradient of pair k is row k of GU / GV, the small tables'
-               gradients accumulate in gA / gC                                                ktup_train_rec_step_rows
+    step       forward of [pos ; neg], BPR term, backward; the user-row gradient of example k is row k of GU (B rows), the item-row
+               gradient of pair k row k of GV (2B rows), the small tables' gradients accumulate in gA / gC
+                                                                                              ktup_train_rec_step_rows
     reduce     Gwire[w] += rows of the entries sorted to w (users | items | entities)         ktup_shard_reduce_rows
     norm       sum of squares of every gradient of the step                                   ktup_optim_gradnorm_acc
     apply      clip + row-sparse SGD / Adagrad on the touched rows of the three shards and on the four small tables; the
@@ -207,15 +209,14 @@ class ShardedKtupStepper(_ShardedStepBase):
             raise ValueError('direct gathers need a single rank and an item2ent without negative entries')
         self.direct = can_direct if direct is None else bool(direct)
         W_ = self.world
-        n_ent = [2 * B, 2 * B, 2 * B]                          # entries per table: [u ; u], [pos ; neg], their entities
-        n_dist = [B, 2 * B, 2 * B]                             # at most this many DISTINCT ids per table
+        n_dist = [B, 2 * B, 2 * B]                             # entries per table ([u], [pos ; neg], their entities) = at most this many DISTINCT ids
         if W_ == 1:
             cap = list(n_dist)
         else:
             cap = [min(n, int(math.ceil(self.capacity_factor * n / W_)) + 64) for n in n_dist]
         self.cap, self.capsum = cap, sum(cap)
         self.W = W = W_ * self.capsum
-        self.E = E = 6 * B
+        self.E = E = 5 * B
         i64 = lambda n, fill=None: torch.empty(n, dtype=torch.int64, device=dev) if fill is None else torch.full((n,), fill, dtype=torch.int64, device=dev)
         i32 = lambda n: torch.zeros(n, dtype=torch.int32, device=dev)
         f32 = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
@@ -230,7 +231,7 @@ class ShardedKtupStepper(_ShardedStepBase):
         self.counters = i32(W_ * 3 + 1)
         self.route_ws = torch.empty((lib.ktup_shard_route_workspace_bytes(E) + 7) // 8, dtype=torch.int64, device=dev)
         self.X = f32(W + 1, d)                                # row W stays zero: "no entity" (jTransUP.py:96 padding_idx)
-        self.Gcat = f32(4 * B, d)                             # [GU ; GV]
+        self.Gcat = f32(3 * B, d)                             # [GU (B) ; GV (2B)]
         self.Gwire = f32(W, d)
         self.xkeys = i32(max(2, lib.ktup_shard_reduce_list_len(E, d)))
         self.acc = torch.zeros(SLOTS + 1, dtype=torch.float64, device=dev)  # [SLOTS partial sums of squares | the job-wide total]
@@ -279,8 +280,8 @@ class ShardedKtupStepper(_ShardedStepBase):
         tabs = arr(_ptrs([t.weight.data for t in self.tables]))
         lds = arr(_i64s([t.weight.data.stride(0) for t in self.tables]))
         states = arr(_ptrs([t.state for t in self.tables])) if self.kind == 'adagrad' else None
+        slds = arr(_i64s([t.state.stride(0) for t in self.tables])) if self.kind == 'adagrad' else lds      # interleaved tables: pitch 2d
         cap = arr(_i64s(self.cap))
-        eoff = arr(_i64s([0, 2 * B, 4 * B, 6 * B]))
         kind = KINDS[self.kind]
         gscale = 1.0 / Wn
         g = self.small_g
@@ -309,31 +310,31 @@ class ShardedKtupStepper(_ShardedStepBase):
                         _p(self.entries), Wn, cap, _p(inv), _p(self.send_ids), _p(self.pair_map), _p(self.sort_ws), _p(self.counters),
                         _p(self.acc), SLOTS + 1, _p(self.route_ws), phase, on)
         route = route_phase(0, stream)
-        if self.direct:                                      # global ids straight into the shards (entries = [u ; u | pos ; neg | ...])
+        if self.direct:                                      # global ids straight into the shards (entries = [u | pos ; neg | ...])
             ent = self.entries
             step = bind('ktup_train_rec_step_rows', _p(Ut.weight.data), Ut.weight.data.stride(0), _p(It.weight.data), It.weight.data.stride(0),
                         _p(Et.weight.data), Et.weight.data.stride(0), _p(self.item2ent), self.ent_pad, _p(pref), _p(pref_norm), _p(rel),
-                        _p(norm), d, P, d, _p(ent), ent.data_ptr() + 2 * B * 8, B, int(self.l1), self.target, gscale, int(self.orth),
-                        _p(self.loss_step), _p(self.Gcat), self.Gcat.data_ptr() + 2 * B * d * 4, _p(gP), _p(gPn), _p(gR), _p(gRn), stream)
+                        _p(norm), d, P, d, _p(ent), ent.data_ptr() + B * 8, B, int(self.l1), self.target, gscale, int(self.orth),
+                        _p(self.loss_step), _p(self.Gcat), self.Gcat.data_ptr() + B * d * 4, _p(gP), _p(gPn), _p(gR), _p(gRn), stream)
         else:
             step = bind('ktup_train_rec_step_rows', _p(X), d, _p(X), d, _p(X), d, _p(self.pair_map), W, _p(pref), _p(pref_norm), _p(rel),
-                        _p(norm), d, P, d, _p(inv), inv.data_ptr() + 2 * B * 8, B, int(self.l1), self.target, gscale, int(self.orth),
-                        _p(self.loss_step), _p(self.Gcat), self.Gcat.data_ptr() + 2 * B * d * 4, _p(gP), _p(gPn), _p(gR), _p(gRn), stream)
-        reduce_ = bind('ktup_shard_reduce_rows', _p(self.Gcat), d, d, 4 * B, 2 * B, _p(self.sort_ws), E, W, _p(self.Gwire), d, stream)
+                        _p(norm), d, P, d, _p(inv), inv.data_ptr() + B * 8, B, int(self.l1), self.target, gscale, int(self.orth),
+                        _p(self.loss_step), _p(self.Gcat), self.Gcat.data_ptr() + B * d * 4, _p(gP), _p(gPn), _p(gR), _p(gRn), stream)
+        reduce_ = bind('ktup_shard_reduce_rows', _p(self.Gcat), d, d, 3 * B, 2 * B, _p(self.sort_ws), E, W, _p(self.Gwire), d, stream)
         if not self.multi:
             pack = bind('ktup_shard_pack_wire', 3, tabs, lds, cap, d, _p(self.send_ids), 1, _p(X), d, stream)
             nl = [self.Gwire] + norm_list
             nptr, nsz = arr(_ptrs(nl)), arr(_i64s([t.numel() for t in nl]))
             gnorm = bind('ktup_optim_gradnorm_acc', len(nl), nptr, nsz, _p(self.acc), SLOTS, stream)
-            apply_ = bind('ktup_shard_apply', kind, 3, tabs, lds, states, lds, cap, d, _p(self.send_ids), 1, _p(self.Gwire), d, n_small, P,
+            apply_ = bind('ktup_shard_apply', kind, 3, tabs, lds, states, slds, cap, d, _p(self.send_ids), 1, _p(self.Gwire), d, n_small, P,
                           sgp, sp0p, ss0p, sp1p, ss1p, None, self.lr, self.eps, _p(self.acc), SLOTS, self.max_norm,
                           self.counters.data_ptr() + 4 * (Wn * 3), None, *close, stream)
             if self.fused_apply:
                 nw = arr(_ptrs(sg_list))
-                rnorm = bind('ktup_shard_reduce_norm', _p(self.Gcat), d, d, 4 * B, 2 * B, _p(self.sort_ws), E, W, _p(self.Gwire), d,
+                rnorm = bind('ktup_shard_reduce_norm', _p(self.Gcat), d, d, 3 * B, 2 * B, _p(self.sort_ws), E, W, _p(self.Gwire), d,
                              _p(self.xkeys), n_small, nw, P * d, small_weight, _p(self.acc), SLOTS, stream)
-                rapply = bind('ktup_shard_reduce_apply', kind, 3, tabs, lds, states, lds, cap, _p(self.send_ids), 1, _p(self.Gcat), d, d,
-                              4 * B, 2 * B, _p(self.sort_ws), E, _p(self.Gwire), d, _p(self.xkeys), n_small, P, sgp, sp0p, ss0p, sp1p, ss1p,
+                rapply = bind('ktup_shard_reduce_apply', kind, 3, tabs, lds, states, slds, cap, _p(self.send_ids), 1, _p(self.Gcat), d, d,
+                              3 * B, 2 * B, _p(self.sort_ws), E, _p(self.Gwire), d, _p(self.xkeys), n_small, P, sgp, sp0p, ss0p, sp1p, ss1p,
                               None, self.lr, self.eps, _p(self.acc), SLOTS, self.max_norm, self.counters.data_ptr() + 4 * (Wn * 3), None,
                               *close, stream)
                 tail = [rnorm, rapply]
@@ -355,13 +356,13 @@ class ShardedKtupStepper(_ShardedStepBase):
         pack_b = bind('ktup_shard_bucket', 0, n_small, sgp, P * d, _p(self.bucket), _p(self.acc), SLOTS, self.counters.data_ptr() + 4 * (Wn * 3),
                       None, 1.0, stream)
         fin_b = bind('ktup_shard_bucket', 1, n_small, None, P * d, _p(self.bucket), None, 0, None, self.acc.data_ptr() + 8 * SLOTS, small_weight, stream)
-        apply_ = bind('ktup_shard_apply', kind, 3, tabs, lds, states, lds, capo, d, _p(self.own_ids), 1, _p(self.Gown), d, n_small, P,
+        apply_ = bind('ktup_shard_apply', kind, 3, tabs, lds, states, slds, capo, d, _p(self.own_ids), 1, _p(self.Gown), d, n_small, P,
                       sgp, sp0p, ss0p, sp1p, ss1p, _p(self.bucket), self.lr, self.eps, self.acc.data_ptr() + 8 * SLOTS, 1, self.max_norm,
                       None, self.bucket.data_ptr() + 8 * (N + 1), *close, stream)
         if self.fused_apply:
             onorm = bind('ktup_shard_reduce_norm', _p(self.Grecv), d, d, W, 0, _p(self.own_sort), W, self.W_own, _p(self.Gown), d,
                          _p(self.own_xkeys), 0, None, 0, 1.0, _p(self.acc), SLOTS, stream)
-            oapply = bind('ktup_shard_reduce_apply', kind, 3, tabs, lds, states, lds, capo, _p(self.own_ids), 1, _p(self.Grecv), d, d, W, 0,
+            oapply = bind('ktup_shard_reduce_apply', kind, 3, tabs, lds, states, slds, capo, _p(self.own_ids), 1, _p(self.Grecv), d, d, W, 0,
                           _p(self.own_sort), W, _p(self.Gown), d, _p(self.own_xkeys), n_small, P, sgp, sp0p, ss0p, sp1p, ss1p,
                           _p(self.bucket), self.lr, self.eps, self.acc.data_ptr() + 8 * SLOTS, 1, self.max_norm, None,
                           self.bucket.data_ptr() + 8 * (N + 1), *close, stream)
@@ -509,6 +510,7 @@ class ShardedKgStepper(_ShardedStepBase):
         tabs = arr(_ptrs([Et.weight.data]))
         lds = arr(_i64s([Et.weight.data.stride(0)]))
         states = arr(_ptrs([Et.state])) if self.kind == 'adagrad' else None
+        slds = arr(_i64s([Et.state.stride(0)])) if self.kind == 'adagrad' else lds
         cap = arr(_i64s(self.cap))
         kind = KINDS[self.kind]
         n_small = len(self.small)
@@ -538,7 +540,7 @@ class ShardedKgStepper(_ShardedStepBase):
             pack = bind('ktup_shard_pack_wire', 1, tabs, lds, cap, d, _p(self.send_ids), 1, _p(self.X), d, stream)
             rnorm = bind('ktup_shard_reduce_norm', _p(self.GE), d, d, E, 0, _p(self.sort_ws), E, W, _p(self.Gwire), d, _p(self.xkeys), n_small,
                          sgp, P * d, 1.0, _p(self.acc), SLOTS, stream)
-            rapply = bind('ktup_shard_reduce_apply', kind, 1, tabs, lds, states, lds, cap, _p(self.send_ids), 1, _p(self.GE), d, d, E, 0,
+            rapply = bind('ktup_shard_reduce_apply', kind, 1, tabs, lds, states, slds, cap, _p(self.send_ids), 1, _p(self.GE), d, d, E, 0,
                           _p(self.sort_ws), E, _p(self.Gwire), d, _p(self.xkeys), n_small, P, sgp, sp0p, ss0p, None, None, None, self.lr,
                           self.eps, _p(self.acc), SLOTS, self.max_norm, skip_i, None, *close, stream)
             if self.direct and side is not None:
@@ -556,7 +558,7 @@ class ShardedKgStepper(_ShardedStepBase):
                      _p(self.own_xkeys), 0, None, 0, 1.0, _p(self.acc), SLOTS, stream)
         pack_b = bind('ktup_shard_bucket', 0, n_small, sgp, P * d, _p(self.bucket), _p(self.acc), SLOTS, skip_i, None, 1.0, stream)
         fin_b = bind('ktup_shard_bucket', 1, n_small, None, P * d, _p(self.bucket), None, 0, None, self.acc.data_ptr() + 8 * SLOTS, 1.0, stream)
-        oapply = bind('ktup_shard_reduce_apply', kind, 1, tabs, lds, states, lds, capo, _p(self.own_ids), 1, _p(self.Grecv), d, d, W, 0,
+        oapply = bind('ktup_shard_reduce_apply', kind, 1, tabs, lds, states, slds, capo, _p(self.own_ids), 1, _p(self.Grecv), d, d, W, 0,
                       _p(self.own_sort), W, _p(self.Gown), d, _p(self.own_xkeys), n_small, P, sgp, sp0p, ss0p, None, None, _p(self.bucket),
                       self.lr, self.eps, self.acc.data_ptr() + 8 * SLOTS, 1, self.max_norm, None, self.bucket.data_ptr() + 8 * (N + 1),
                       *close, stream)

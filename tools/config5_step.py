@@ -24,7 +24,7 @@ def fused_main(args):
     """jTransUP/sharded_ktup.py: the step as HIP-graph replays, no host sync.  Reports wall time per step (host clock around
     `steps` replays, one synchronize at the end) and the device time between HIP events around the same replays."""
     from jTransUP import parallel
-    from jTransUP.sharded_ktup import ShardedKtupStepper
+    from jTransUP.sharded_ktup import ShardedKgStepper, ShardedKtupJoint, ShardedKtupStepper
     rank, world = parallel.init_distributed()
     dev = torch.device('cuda', torch.cuda.current_device())
     scale = 1 if args.full else 8
@@ -43,7 +43,15 @@ def fused_main(args):
             dist.broadcast(p.data, src=0)
     item2ent = torch.randint(0, NE, (NI,), generator=torch.Generator(device=dev).manual_seed(7), device=dev).to(torch.int32)
     st = ShardedKtupStepper(Ut, It, Et, *small, item2ent, batch=B, kind='adagrad', lr=0.005, max_norm=5.0, use_graphs=not args.no_graphs,
-                            force_exchange=args.exchange, overlap_route=not args.no_overlap, fused_apply=not args.gradient_buffer, direct=False if (args.no_direct or args.exchange or world > 1) else None)
+                            force_exchange=args.exchange, overlap_route=not args.no_overlap, fused_apply=not args.gradient_buffer, direct=False if (args.no_direct or args.exchange or world > 1) else None,
+                            orth=args.kind != 'rec')
+    rec = st
+    kg = None
+    if args.kind != 'rec':             # the kg half of the joint schedule (knowledgable_recommendation.py:345-383) on the same entity shard
+        kg = ShardedKgStepper(Et, small[2], small[3], batch=B, kind='adagrad', lr=0.005, max_norm=5.0, margin=1.0, kg_lambda=1.0,
+                              small_state=rec.small_state[2:4], use_graphs=not args.no_graphs, force_exchange=args.exchange,
+                              overlap_route=not args.no_overlap, direct=False if (args.no_direct or args.exchange or world > 1) else None)
+        st = kg if args.kind == 'kg' else ShardedKtupJoint(rec, kg, 0.7)
 
     def draw(n_rows):
         if args.zipf <= 0:
@@ -53,22 +61,34 @@ def fused_main(args):
         top = float(n_rows) ** (-a1)
         r = (1.0 - uu * (1.0 - top)) ** (-1.0 / a1)
         return (r.clamp(1, n_rows) - 1).to(torch.int64)
-    n = args.steps + 5
+    n = args.steps + 10
     batches = [(draw(NU), draw(NI), draw(NI)) for _ in range(n)]
-    if not args.copy_batches:                                # device-fed: the step's own launches walk the pre-drawn columns
-        st.set_feed([torch.stack([b[c] for b in batches]).contiguous() for c in range(3)])
+    if kg is not None:
+        kb = []
+        for _ in range(n):
+            ph, pt, other = draw(NE), draw(NE), draw(NE)
+            pr = torch.randint(0, P, (B,), generator=gen, device=dev)
+            flip = torch.rand(B, generator=gen, device=dev) < 0.5
+            kb.append((ph, pt, pr, torch.where(flip, other, ph), torch.where(flip, pt, other), pr))
+        kg.set_feed([torch.stack([b[c] for b in kb]).contiguous() for c in range(6)])
+    if not args.copy_batches or kg is not None:              # device-fed: the step's own launches walk the pre-drawn columns
+        rec.set_feed([torch.stack([b[c] for b in batches]).contiguous() for c in range(3)])
         batches = [()] * n
-    for s in range(5):
-        st(*batches[s])
+    if kg is not None:
+        run = st.run
+    else:
+        run = None
+    for s in range(10):
+        run() if run else st(*batches[s])
     torch.cuda.synchronize(dev)
-    l0 = float(st.loss_sum[0])
+    l0 = float(rec.loss_sum[0])
     if world > 1:
         dist.barrier()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()
-    for s in range(5, n):
-        st(*batches[s])
+    for s in range(10, n):
+        run() if run else st(*batches[s])
     ev1.record()
     torch.cuda.synchronize(dev)
     wall = time.perf_counter() - t0
@@ -78,11 +98,12 @@ def fused_main(args):
     st.check()
     if rank == 0:
         print(json.dumps({'config': 'KTUP d=%d, %d/%d/%d rows (users/items/entities) over %d rank(s), B=%d per rank, ids %s' % (d, NU, NI, NE, world, B, 'Zipf(%.2f)' % args.zipf if args.zipf > 0 else 'uniform'),
+                          'kind': args.kind,
                           'route': 'sharded_ktup.ShardedKtupStepper (%s%s%s%s)' % ('eager launches' if args.no_graphs else 'graph replay', ', exchange form' if args.exchange else '',
-                                                                                    ', direct gathers' if st.direct else ', packed rows', ', batches copied in' if args.copy_batches else ', device-fed'),
+                                                                                    ', direct gathers' if rec.direct else ', packed rows', ', batches copied in' if args.copy_batches else ', device-fed'),
                           'ms_per_step': 1e3 * wall / args.steps, 'ms_per_step_device': devms,
-                          'scored_rows_per_s': 2 * B * world * args.steps / wall, 'wire_rows': st.W,
-                          'mean_loss': (float(st.loss_sum[0]) - l0) / args.steps}))
+                          'scored_rows_per_s': 2 * B * world * args.steps / wall, 'wire_rows': (kg if args.kind == 'kg' else rec).W,
+                          'mean_loss': (float(rec.loss_sum[0]) - l0) / args.steps}))
     if world > 1:
         dist.destroy_process_group()
 
@@ -92,6 +113,7 @@ def main():
     ap.add_argument('--batch', type=int, default=8192)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--d', type=int, default=256)
+    ap.add_argument('--kind', default='rec', choices=['rec', 'kg', 'joint'], help='rec: the rec step alone (the round-3 figure); kg: the kg step alone; joint: the 7 : 3 cycle of knowledgable_recommendation.py:320')
     ap.add_argument('--zipf', type=float, default=0.0, help='draw ids from Zipf(a) (hot rows: contention in the row-gradient atomics) instead of uniformly, e.g. 1.05')
     ap.add_argument('--full', action='store_true', help='the whole 10M / 1M / 5M tables on this rank set (needs ~17 GB per rank at world 1)')
     ap.add_argument('--legacy', action='store_true', help="round 2's route: parallel.ShardedStep through autograd (eager torch ops around the kernels)")

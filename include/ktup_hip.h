@@ -480,7 +480,9 @@ int ktup_zero_async(void* ptr, int64_t nbytes, void* stream);
  * ktup_shard_reduce_norm: the squared norm of every reduced row (and of the n_small small gradients, weighted by small_weight) is
  *   ADDED to sumsq[0 .. n_slots) (n_slots = 1 or KTUP_SHARD_SUMSQ_SLOTS); nothing else is written, except that the few rows whose
  *   entries straddle two workgroups are summed into gwire (all-zero before the call) and listed in xkeys
- *   (ktup_shard_reduce_list_len(n_entries, d) int32).  Two launches.
+ *   (ktup_shard_reduce_list_len(n_entries, d) int32).  Two launches.  dup_only != 0: the kernel that wrote G has already added
+ *   |G row|^2 for every ENTRY (ktup_train_rec_step_rows / ktup_train_kg_step_rows with `sumsq`), so the walk adds only what rows
+ *   shared by several entries change -- |sum of the rows|^2 - sum of |row|^2 -- and never reads an entry that is alone on its row.
  * ktup_shard_reduce_apply: the same walk again; every reduced row goes straight from registers through the clipped row-sparse
  *   SGD / Adagrad rule of ktup_shard_apply into table_t[ids[w]]; the listed rows are applied from gwire, which is left all-zero
  *   again; small tables as in ktup_shard_apply.  Two launches.  Same arguments, same G, same sort_ws as the norm call.        */
@@ -488,7 +490,7 @@ int64_t ktup_shard_reduce_list_len(int64_t n_entries, int d);
 int ktup_shard_reduce_norm(const float* G, int64_t ldg, int d, int64_t n_src, int64_t src_off, const int32_t* sort_ws,
                            int64_t n_entries, int64_t n_wire_rows, float* gwire, int64_t ldw, int32_t* xkeys, int n_small,
                            float* const* small_grads, int64_t small_elems, float small_weight, double* sumsq, int n_slots,
-                           void* stream);
+                           int dup_only, void* stream);
 int ktup_shard_reduce_apply(int kind, int n_tables, float* const* tables, const int64_t* ld, float* const* states,
                             const int64_t* lds, const int64_t* cap, const int64_t* ids, int64_t n_blocks, const float* G,
                             int64_t ldg, int d, int64_t n_src, int64_t src_off, const int32_t* sort_ws, int64_t n_entries,
@@ -595,13 +597,16 @@ int ktup_train_rec_step(const float* U, int64_t ldu, const float* I, int64_t ldi
 /* ktup_train_rec_step with the row gradients STORED instead of accumulated by atomics -- for ktup_shard_reduce_rows / large
  * batches: u_ids holds B ids (example k's user: a BPR example's positive and negative pair share it), i_ids 2B (positives then
  * negatives); row k of GU (B x d) = the user-row gradient of example k from BOTH pairs, row k of GV (2B x d) = the item-row
- * gradient of pair k (which is also its entity row's).  Soft gate only.  gR / gRn may be NULL although rel / norm are given (then orth must be 0): gP / gPn are the gradients
+ * gradient of pair k (which is also its entity row's).  sumsq (may be NULL): n_slots doubles to which the launch ADDS
+ * sum_k |GU row k|^2 + sum_k |GV row k|^2 x (1 + [pair k's item has an entity row]) -- the squared norm of the row gradients as if
+ * every entry of the route had its own table row (ktup_shard_reduce_norm with dup_only corrects for shared rows).  Soft gate only.  gR / gRn may be NULL although rel / norm are given (then orth must be 0): gP / gPn are the gradients
  * of both summands of the mixed tables.                                                                                   */
 int ktup_train_rec_step_rows(const float* U, int64_t ldu, const float* I, int64_t ldi, const float* E, int64_t lde,
                              const int32_t* item2ent, int64_t ent_pad, const float* pref, const float* pref_norm,
                              const float* rel, const float* norm, int64_t ldp, int n_pref, int d, const int64_t* u_ids,
                              const int64_t* i_ids, int64_t B, int l1, float target, float gscale, int orth, float* loss,
-                             float* GU, float* GV, float* gP, float* gPn, float* gR, float* gRn, void* stream);
+                             float* GU, float* GV, float* gP, float* gPn, float* gR, float* gRn, double* sumsq, int n_slots,
+                             void* stream);
 int ktup_train_kg_step(int transh, const float* E, int64_t lde, const float* R, int64_t ldr, const float* Nrm, int64_t ldn,
                        int d, const int64_t* h, const int64_t* t, const int64_t* r, int64_t B, int l1, float margin,
                        float gscale, int regs, float* loss, float* gE, float* gR, float* gN, void* stream);
@@ -610,11 +615,13 @@ int ktup_train_kg_step(int transh, const float* E, int64_t lde, const float* R, 
  * are STORED as rows k, B + k, 2B + k, 3B + k of GE (4B x d, pitch d) for ktup_shard_reduce_norm / _apply instead of accumulated
  * into a table-shaped gradient; gR / gN (relation-side, replicated) are accumulated.  `order` (may be NULL): the triples' indices
  * sorted by relation (ktup_shard_kg_rel_order) -- consecutive triples of one relation then share ONE flush of its gradient rows.
+ * sumsq / n_slots (may be NULL): += the sum of |row|^2 over the 4B stored rows, as in ktup_train_rec_step_rows.
  * ktup_shard_kg_rel_order: order[0 .. B) = a counting sort of rel[0 .. B) over [0, n_rel) in one launch (n_rel > 16384: identity). */
 int ktup_shard_kg_rel_order(const int64_t* rel, int64_t B, int64_t n_rel, int32_t* order, void* stream);
 int ktup_train_kg_step_rows(int transh, const float* E, int64_t lde, const float* R, int64_t ldr, const float* Nrm, int64_t ldn,
                             int d, const int64_t* ent_ids, const int64_t* rel_ids, const int32_t* order, int64_t B, int l1,
-                            float margin, float gscale, int regs, float* loss, float* GE, float* gR, float* gN, void* stream);
+                            float margin, float gscale, int regs, float* loss, float* GE, float* gR, float* gN, double* sumsq,
+                            int n_slots, void* stream);
 #define KTUP_OPTIM_WS_DOUBLES 784
 /* largest grid of ktup_optim_clip_step on the current device: its grid barrier needs every workgroup resident at once, so the
  * launch is sized from the occupancy query x the CU count (one workgroup per CU short of it), at most 512; 0 = unknown (the

@@ -79,6 +79,9 @@ struct WArgs {
   float* loss;                   // loss[0] += mean_k -logsigmoid(target (pos_k - neg_k)); loss[1] += orthogonalLoss(pref, pnorm)
   float *gP, *gPn, *gR, *gRn;    // gradients of the raw tables, pitch D
   int orth;
+  double* sumsq; int sumsq_slots; // STEP + ROWOUT (may be null): += sum over the stored rows of |row|^2 x (entries that read the row): GU rows
+                                 // once, GV rows once for the item and once more for its entity -- the squared norm of the step's row
+                                 // gradients if no two entries shared a table row (ktup_shard_reduce_norm's dup_only walk corrects the rest)
   int u_once;                    // STEP + ROWOUT: u_ids holds B ids (example k's user, shared by its two pairs) and GU B rows (the sum)
   int noflush;                   // measurement knob (option dbg_noflush)
   int gumbel;
@@ -260,6 +263,7 @@ __global__ __launch_bounds__(G::NT) void pref_bwd_wide_kernel(WArgs a) {
     rb[m] = (p < P ? p : P) * RPF + 4 * NCW * w + j;          // float index; + 16 ct per coordinate tile
   }
   float lpart = 0.f;                                          // STEP: this lane's share of the BPR loss value
+  float ssq = 0.f;                                            // STEP + ROWOUT: this lane's share of the stored rows' squared norms
   const bool l1 = a.l1 != 0;
   const float beta = a.beta;
   v4 accA[PT][CTW], accC[PT][CTW];
@@ -533,6 +537,11 @@ __global__ __launch_bounds__(G::NT) void pref_bwd_wide_kernel(WArgs a) {
           if constexpr (ROWOUT) {
             if (u_mine) *reinterpret_cast<v4*>(a.GU + ((STEP && a.u_once) ? kpair : gr) * D + c0) = gu;
             *reinterpret_cast<v4*>(a.GV + gr * D + c0) = gv;
+            if constexpr (STEP) {
+              const v4 g2 = gu * gu, v2 = gv * gv;
+              const float su = (g2[0] + g2[1]) + (g2[2] + g2[3]), sv = (v2[0] + v2[1]) + (v2[2] + v2[3]);
+              ssq += (u_mine ? su : 0.f) + ((HASE && er != a.ent_pad) ? 2.f * sv : sv);
+            }
           } else {
             if (u_mine) atomic_add4(pu + c0, make_float4(gu[0], gu[1], gu[2], gu[3]));
             atomic_add4(pi + c0, make_float4(gv[0], gv[1], gv[2], gv[3]));
@@ -591,6 +600,19 @@ __global__ __launch_bounds__(G::NT) void pref_bwd_wide_kernel(WArgs a) {
   if constexpr (STEP) {
     lpart = group_sum<64>(lpart);
     if (lane == 0 && lpart != 0.f) atomicAdd(a.loss, lpart * (1.f / (float)a.B));
+    if constexpr (ROWOUT) {
+      if (a.sumsq) {            // ONE double atomic per workgroup (one per wave cost 11 us: ~2000 of them queue on 16 addresses)
+        ssq = group_sum<64>(ssq);
+        __syncthreads();
+        if (lane == 0) reds[w] = ssq;
+        __syncthreads();
+        if (tid == 0) {
+          double t = 0.0;
+          for (int ww = 0; ww < G::NWC; ++ww) t += (double)reds[ww];
+          if (t != 0.0) atomicAdd(a.sumsq + (a.sumsq_slots > 1 ? blockIdx.x % a.sumsq_slots : 0), t);
+        }
+      }
+    }
   }
 }
 
@@ -682,7 +704,7 @@ int pref_step_mc(const float* U, int64_t ldu, const float* I, int64_t ldi, const
                  int d, const int64_t* u_ids, const int64_t* i_ids, int64_t B, int l1, int gumbel_mode, const float* uniform,
                  uint64_t seed, uint64_t offset, float target, float gscale, int orth, float* loss, float* gU, float* gI, float* gE,
                  float* gP, float* gPn, float* gR, float* gRn, hipStream_t st,
-                 const char* name, float* GU, float* GV) {
+                 const char* name, float* GU, float* GV, double* sumsq, int sumsq_slots) {
   if (n_pref > 32 || (d == 256 && n_pref > 20)) return 1;
   if ((ldu | ldi | lde | ldp) & 3) return 1;
   if ((ldu >> 2) > 0xffffffffll || (ldi >> 2) > 0xffffffffll || (lde >> 2) > 0xffffffffll) return 1;
@@ -699,6 +721,7 @@ int pref_step_mc(const float* U, int64_t ldu, const float* I, int64_t ldi, const
   a.noflush = opt_dbg_noflush();
   a.GU = GU; a.GV = GV;          // both set: the row gradients leave as rows of GU (example k: both pairs) / GV (pair k) instead of atomics
   a.u_once = GU != nullptr;
+  a.sumsq = sumsq; a.sumsq_slots = sumsq_slots;
   return launch_d(a, d, (n_pref + 3) / 4, st, name);
 }
 

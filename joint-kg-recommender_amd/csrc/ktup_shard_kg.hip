@@ -75,6 +75,7 @@ struct KgRowsArgs {
   float* loss;                   // [4]: margin sum, orth, normE, normR  (accumulated)
   float* GE;                     // 4B x d, row x B + k = gradient of ent[x B + k]'s row from triple k
   float *gR, *gN;
+  double* sumsq; int sumsq_slots; // may be null: += sum of |row|^2 over the 4B stored rows
 };
 
 struct KgTriple {
@@ -95,6 +96,7 @@ __global__ __launch_bounds__(256) void kg_step_rows_kernel(KgRowsArgs a) {
   for (int i = threadIdx.x; i < 2 * 4 * GL; i += 256) (&home[0][0])[i] = 0.f;
   __syncthreads();
   float part[4] = {0.f, 0.f, 0.f, 0.f};
+  float ssq = 0.f;
   const float g1 = a.gscale;
   const int64_t p0 = p_wg + (int64_t)grp * a.chunk, p1 = min(a.B, p0 + (int64_t)a.chunk);
   float4 accR = f4zero(), accN = f4zero();
@@ -200,6 +202,8 @@ __global__ __launch_bounds__(256) void kg_step_rows_kernel(KgRowsArgs a) {
 #pragma unroll
       for (int x = 0; x < 4; ++x)
         reinterpret_cast<float4*>(a.GE + ((int64_t)x * a.B + t.k) * (4 * (int64_t)a.nch))[lane] = ge[x];
+#pragma unroll
+      for (int x = 0; x < 4; ++x) ssq += dot4(ge[x], ge[x]);
     }
 #pragma unroll
     for (int x = 0; x < 2; ++x) {
@@ -227,6 +231,16 @@ __global__ __launch_bounds__(256) void kg_step_rows_kernel(KgRowsArgs a) {
   if (threadIdx.x < 4) {
     const float v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
     if (v != 0.f) atomicAdd(a.loss + threadIdx.x, v);
+  }
+  if (a.sumsq) {                  // one double atomic per workgroup
+    ssq = group_sum<64>(ssq);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[0][threadIdx.x >> 6] = ssq;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const double t = ((double)red[0][0] + (double)red[0][1]) + ((double)red[0][2] + (double)red[0][3]);
+      if (t != 0.0) atomicAdd(a.sumsq + (a.sumsq_slots > 1 ? blockIdx.x % a.sumsq_slots : 0), t);
+    }
   }
 }
 
@@ -258,14 +272,16 @@ extern "C" int ktup_shard_kg_rel_order(const int64_t* rel, int64_t B, int64_t n_
 
 extern "C" int ktup_train_kg_step_rows(int transh, const float* E, int64_t lde, const float* R, int64_t ldr, const float* Nrm, int64_t ldn,
                                        int d, const int64_t* ent_ids, const int64_t* rel_ids, const int32_t* order, int64_t B, int l1,
-                                       float margin, float gscale, int regs, float* loss, float* GE, float* gR, float* gN, void* stream) {
+                                       float margin, float gscale, int regs, float* loss, float* GE, float* gR, float* gN, double* sumsq,
+                                       int n_slots, void* stream) {
   const char* name = "ktup_train_kg_step_rows";
+  KTUP_REQUIRE(!sumsq || n_slots >= 1, "%s: the sum of squares needs at least one slot", name);
   KTUP_REQUIRE(B >= 0, "%s: negative batch", name);
   if (B == 0) return KTUP_OK;
   KTUP_REQUIRE(E && R && ent_ids && rel_ids && loss && GE && gR && (!transh || (Nrm && gN)), "%s: null pointer argument", name);
   if (d <= 0 || d % 4 || d > 256 || (lde | ldr | (transh ? ldn : 0)) % 4 || !aligned16(E) || !aligned16(R) || !aligned16(GE) || !aligned16(gR) ||
       (transh && (!aligned16(Nrm) || !aligned16(gN))))
     return set_error(KTUP_ERR_UNSUPPORTED, "%s: needs d %% 4 == 0 (<= 256) and 16-byte aligned rows", name);
-  KgRowsArgs a{E, R, Nrm, lde, ldr, ldn, ent_ids, rel_ids, order, B, d / 4, l1 != 0, margin, gscale, regs, 1, loss, GE, gR, gN};
+  KgRowsArgs a{E, R, Nrm, lde, ldr, ldn, ent_ids, rel_ids, order, B, d / 4, l1 != 0, margin, gscale, regs, 1, loss, GE, gR, gN, sumsq, n_slots};
   return transh ? launch_kg_rows<true>(a, (hipStream_t)stream, name) : launch_kg_rows<false>(a, (hipStream_t)stream, name);
 }

@@ -432,6 +432,8 @@ struct FusedArgs {
   const int32_t *perm, *skey; const int32_t* m_dev; int chunk;
   float* gw; int64_t ldw; int32_t* xkeys;
   double* sumsq; int slots;                         // MODE 0: accumulated; MODE 1: read
+  bool dup_only;                                    // MODE 0: the step kernel has already added |G row|^2 for every entry: add only what rows SHARED
+                                                    // by several entries change, |sum|^2 - sum |.|^2 -- an entry alone on its row is not even read
   WireTables w; const int64_t* ids; float lr, eps, max_norm; bool adagrad; const int32_t* skip_i; const double* skip_d;
 };
 
@@ -524,10 +526,16 @@ __global__ __launch_bounds__(256) void seg_fused_kernel(FusedArgs a) {
       for (int64_t k = k0; k < k1; k += UNR) {
         int32_t key[UNR], e[UNR];
         float4 v[UNR][CPL];
+        int32_t kprev = (MODE == 0 && a.dup_only && k > 0) ? a.skey[k - 1] : -1;
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
-          const bool on = k + u < k1;
+          bool on = k + u < k1;
           key[u] = on ? a.skey[k + u] : -1;
+          if (MODE == 0 && a.dup_only) {                                 // (the neighbours may lie in another chunk: only the keys matter)
+            const int32_t knext = (on && k + u + 1 < m) ? a.skey[k + u + 1] : -1;
+            on = on && (key[u] == kprev || key[u] == knext);
+            kprev = key[u];
+          }
           e[u] = on ? a.perm[k + u] : 0;
           const int64_t src = e[u] >= a.n_src ? e[u] - a.src_off : e[u];
           const float4* row = a.G + src * a.ldg4;
@@ -543,6 +551,10 @@ __global__ __launch_bounds__(256) void seg_fused_kernel(FusedArgs a) {
           if (key[u] != cur) { flush(cur, false); cur = key[u]; }
 #pragma unroll
           for (int j = 0; j < CPL; ++j) acc[j] = acc[j] + v[u][j];
+          if (MODE == 0 && a.dup_only) {
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) ss -= dot4(v[u][j], v[u][j]);
+          }
         }
       }
       flush(cur, true);
@@ -917,13 +929,13 @@ extern "C" int64_t ktup_shard_reduce_list_len(int64_t n_entries, int d) {
 extern "C" int ktup_shard_reduce_norm(const float* G, int64_t ldg, int d, int64_t n_src, int64_t src_off, const int32_t* sort_ws,
                                       int64_t n_entries, int64_t n_wire_rows, float* gwire, int64_t ldw, int32_t* xkeys, int n_small,
                                       float* const* small_grads, int64_t small_elems, float small_weight, double* sumsq, int n_slots,
-                                      void* stream) {
+                                      int dup_only, void* stream) {
   const char* name = "ktup_shard_reduce_norm";
   FusedArgs a{};
   if (int e = fill_fused(name, a, G, ldg, d, n_src, src_off, sort_ws, n_entries, n_wire_rows, gwire, ldw, xkeys)) return e;
   KTUP_REQUIRE(sumsq && (n_slots == 1 || n_slots == NSLOT), "%s: the sum of squares lives in 1 or %d words", name, NSLOT);
   KTUP_REQUIRE(n_small >= 0 && n_small <= MAXS && (n_small == 0 || (small_grads && small_elems > 0)), "%s: bad small-gradient list", name);
-  a.sumsq = sumsq; a.slots = n_slots;
+  a.sumsq = sumsq; a.slots = n_slots; a.dup_only = dup_only != 0;
   hipStream_t st = (hipStream_t)stream;
   const int64_t grid = fused_grid(n_entries, d);
   if (int e = launch_fused<0>(a, grid, st, name)) return e;

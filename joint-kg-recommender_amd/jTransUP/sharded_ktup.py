@@ -303,6 +303,11 @@ class ShardedKtupStepper(_ShardedStepBase):
         ss1p = arr(_ptrs(ss1)) if (not self.orth and self.kind == 'adagrad') else None
         X, inv = self.X, self.inverse
         close = (_p(self.loss_step), 2, _p(self.loss_sum), _p(self.skipped))
+        # one rank, two-walk form: the step kernel adds the stored rows' squared norms itself and the norm walk only corrects for
+        # rows that several entries share (dup_only) -- with ids spread over millions of rows it reads almost nothing
+        import os as _os
+        dup = (not self.multi) and self.fused_apply and _os.environ.get('KTUP_C5_DUP','1') != '0'
+        ssq = (_p(self.acc), SLOTS) if dup else (None, 0)
         bind = L.bind
         fu, fp, fn, nb = self._feed
         def route_phase(phase, on):
@@ -315,11 +320,11 @@ class ShardedKtupStepper(_ShardedStepBase):
             step = bind('ktup_train_rec_step_rows', _p(Ut.weight.data), Ut.weight.data.stride(0), _p(It.weight.data), It.weight.data.stride(0),
                         _p(Et.weight.data), Et.weight.data.stride(0), _p(self.item2ent), self.ent_pad, _p(pref), _p(pref_norm), _p(rel),
                         _p(norm), d, P, d, _p(ent), ent.data_ptr() + B * 8, B, int(self.l1), self.target, gscale, int(self.orth),
-                        _p(self.loss_step), _p(self.Gcat), self.Gcat.data_ptr() + B * d * 4, _p(gP), _p(gPn), _p(gR), _p(gRn), stream)
+                        _p(self.loss_step), _p(self.Gcat), self.Gcat.data_ptr() + B * d * 4, _p(gP), _p(gPn), _p(gR), _p(gRn), *ssq, stream)
         else:
             step = bind('ktup_train_rec_step_rows', _p(X), d, _p(X), d, _p(X), d, _p(self.pair_map), W, _p(pref), _p(pref_norm), _p(rel),
                         _p(norm), d, P, d, _p(inv), inv.data_ptr() + B * 8, B, int(self.l1), self.target, gscale, int(self.orth),
-                        _p(self.loss_step), _p(self.Gcat), self.Gcat.data_ptr() + B * d * 4, _p(gP), _p(gPn), _p(gR), _p(gRn), stream)
+                        _p(self.loss_step), _p(self.Gcat), self.Gcat.data_ptr() + B * d * 4, _p(gP), _p(gPn), _p(gR), _p(gRn), *ssq, stream)
         reduce_ = bind('ktup_shard_reduce_rows', _p(self.Gcat), d, d, 3 * B, 2 * B, _p(self.sort_ws), E, W, _p(self.Gwire), d, stream)
         if not self.multi:
             pack = bind('ktup_shard_pack_wire', 3, tabs, lds, cap, d, _p(self.send_ids), 1, _p(X), d, stream)
@@ -332,7 +337,7 @@ class ShardedKtupStepper(_ShardedStepBase):
             if self.fused_apply:
                 nw = arr(_ptrs(sg_list))
                 rnorm = bind('ktup_shard_reduce_norm', _p(self.Gcat), d, d, 3 * B, 2 * B, _p(self.sort_ws), E, W, _p(self.Gwire), d,
-                             _p(self.xkeys), n_small, nw, P * d, small_weight, _p(self.acc), SLOTS, stream)
+                             _p(self.xkeys), n_small, nw, P * d, small_weight, _p(self.acc), SLOTS, int(dup), stream)
                 rapply = bind('ktup_shard_reduce_apply', kind, 3, tabs, lds, states, slds, cap, _p(self.send_ids), 1, _p(self.Gcat), d, d,
                               3 * B, 2 * B, _p(self.sort_ws), E, _p(self.Gwire), d, _p(self.xkeys), n_small, P, sgp, sp0p, ss0p, sp1p, ss1p,
                               None, self.lr, self.eps, _p(self.acc), SLOTS, self.max_norm, self.counters.data_ptr() + 4 * (Wn * 3), None,
@@ -361,7 +366,7 @@ class ShardedKtupStepper(_ShardedStepBase):
                       None, self.bucket.data_ptr() + 8 * (N + 1), *close, stream)
         if self.fused_apply:
             onorm = bind('ktup_shard_reduce_norm', _p(self.Grecv), d, d, W, 0, _p(self.own_sort), W, self.W_own, _p(self.Gown), d,
-                         _p(self.own_xkeys), 0, None, 0, 1.0, _p(self.acc), SLOTS, stream)
+                         _p(self.own_xkeys), 0, None, 0, 1.0, _p(self.acc), SLOTS, 0, stream)
             oapply = bind('ktup_shard_reduce_apply', kind, 3, tabs, lds, states, slds, capo, _p(self.own_ids), 1, _p(self.Grecv), d, d, W, 0,
                           _p(self.own_sort), W, _p(self.Gown), d, _p(self.own_xkeys), n_small, P, sgp, sp0p, ss0p, sp1p, ss1p,
                           _p(self.bucket), self.lr, self.eps, self.acc.data_ptr() + 8 * SLOTS, 1, self.max_norm, None,
@@ -535,11 +540,12 @@ class ShardedKgStepper(_ShardedStepBase):
         else:
             Esrc, lde, ent_ids = self.X, d, self.inverse
         step = bind('ktup_train_kg_step_rows', int(self.transh), _p(Esrc), lde, _p(rel), d, _p(norm), d, d, _p(ent_ids), _p(self.rels),
-                    _p(self.order), B, int(self.l1), self.margin, self.kg_lambda, self.regs, _p(self.loss_step), _p(self.GE), _p(gR), _p(gN), stream)
+                    _p(self.order), B, int(self.l1), self.margin, self.kg_lambda, self.regs, _p(self.loss_step), _p(self.GE), _p(gR), _p(gN),
+                    *((None, 0) if self.multi else (_p(self.acc), SLOTS)), stream)
         if not self.multi:
             pack = bind('ktup_shard_pack_wire', 1, tabs, lds, cap, d, _p(self.send_ids), 1, _p(self.X), d, stream)
             rnorm = bind('ktup_shard_reduce_norm', _p(self.GE), d, d, E, 0, _p(self.sort_ws), E, W, _p(self.Gwire), d, _p(self.xkeys), n_small,
-                         sgp, P * d, 1.0, _p(self.acc), SLOTS, stream)
+                         sgp, P * d, 1.0, _p(self.acc), SLOTS, 1, stream)
             rapply = bind('ktup_shard_reduce_apply', kind, 1, tabs, lds, states, slds, cap, _p(self.send_ids), 1, _p(self.GE), d, d, E, 0,
                           _p(self.sort_ws), E, _p(self.Gwire), d, _p(self.xkeys), n_small, P, sgp, sp0p, ss0p, None, None, None, self.lr,
                           self.eps, _p(self.acc), SLOTS, self.max_norm, skip_i, None, *close, stream)
@@ -555,7 +561,7 @@ class ShardedKgStepper(_ShardedStepBase):
                       _p(self.own_ids), None, _p(self.own_sort), _p(self.own_counters), None, 0, _p(self.own_ws), stream)
         N = n_small * P * d
         onorm = bind('ktup_shard_reduce_norm', _p(self.Grecv), d, d, W, 0, _p(self.own_sort), W, self.W_own, _p(self.Gown), d,
-                     _p(self.own_xkeys), 0, None, 0, 1.0, _p(self.acc), SLOTS, stream)
+                     _p(self.own_xkeys), 0, None, 0, 1.0, _p(self.acc), SLOTS, 0, stream)
         pack_b = bind('ktup_shard_bucket', 0, n_small, sgp, P * d, _p(self.bucket), _p(self.acc), SLOTS, skip_i, None, 1.0, stream)
         fin_b = bind('ktup_shard_bucket', 1, n_small, None, P * d, _p(self.bucket), None, 0, None, self.acc.data_ptr() + 8 * SLOTS, 1.0, stream)
         oapply = bind('ktup_shard_reduce_apply', kind, 1, tabs, lds, states, slds, capo, _p(self.own_ids), 1, _p(self.Grecv), d, d, W, 0,

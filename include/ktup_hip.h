@@ -454,7 +454,7 @@ int ktup_shard_route_ktup(const int64_t* u, const int64_t* pos_items, const int6
                           const int64_t* cap, int64_t* inverse, int64_t* send_ids, int32_t* pair_map, int32_t* sort_ws,
                           int32_t* counters, double* zero_doubles, int n_zero_doubles, void* ws, int phase, void* stream);
 /* The same for the KTUP kg step (knowledgable_recommendation.py:346-383): batch (*cursor mod n_batches) of the six triple columns
- * -> entries = [ph ; pt ; nh ; nt] (4B int64, written), ONE table (entities; cap: one value); rels = [pr ; nr] (2B, written): the
+ * -> entries = [ph ; pt ; nh ; nt] (4B int64, written; nh / nt = -1 where it equals ph / pt), ONE table (entities; cap: one value); rels = [pr ; nr] (2B, written): the
  * relation ids ktup_train_kg_step_rows reads.  phase as above.                                                                */
 int ktup_shard_route_kg(const int64_t* ph, const int64_t* pt, const int64_t* pr, const int64_t* nh, const int64_t* nt,
                         const int64_t* nr, int64_t B, int64_t n_batches, int64_t* cursor, int64_t* entries, int64_t* rels,
@@ -485,7 +485,7 @@ int ktup_zero_async(void* ptr, int64_t nbytes, void* stream);
  *   shared by several entries change -- |sum of the rows|^2 - sum of |row|^2 -- and never reads an entry that is alone on its row.
  * ktup_shard_reduce_apply: the same walk again; every reduced row goes straight from registers through the clipped row-sparse
  *   SGD / Adagrad rule of ktup_shard_apply into table_t[ids[w]]; the listed rows are applied from gwire, which is left all-zero
- *   again; small tables as in ktup_shard_apply.  Two launches.  Same arguments, same G, same sort_ws as the norm call.        */
+ *   again; small tables as in ktup_shard_apply -- both as extra workgroups of the ONE launch.  Same arguments, same G, same sort_ws as the norm call. */
 int64_t ktup_shard_reduce_list_len(int64_t n_entries, int d);
 int ktup_shard_reduce_norm(const float* G, int64_t ldg, int d, int64_t n_src, int64_t src_off, const int32_t* sort_ws,
                            int64_t n_entries, int64_t n_wire_rows, float* gwire, int64_t ldw, int32_t* xkeys, int n_small,
@@ -613,13 +613,15 @@ int ktup_train_kg_step(int transh, const float* E, int64_t lde, const float* R, 
 /* ktup_train_kg_step for row-sharded entity tables (config 5's kg steps; csrc/ktup_shard_kg.hip): ent_ids = [ph ; pt ; nh ; nt]
  * (4B rows of E: a shard's rows, or wire rows of a compact table), rel_ids = [pr ; nr] (2B); the entity-row gradients of triple k
  * are STORED as rows k, B + k, 2B + k, 3B + k of GE (4B x d, pitch d) for ktup_shard_reduce_norm / _apply instead of accumulated
- * into a table-shaped gradient; gR / gN (relation-side, replicated) are accumulated.  `order` (may be NULL): the triples' indices
+ * into a table-shaped gradient; gR / gN (relation-side, replicated) are accumulated.  An nh / nt that is negative or == ent_pad
+ * says "the same entry as ph / pt" (a corrupted triple keeps its head or its tail; ktup_shard_route_kg writes -1 there): the twin's
+ * gradient is added to the positive's stored row and the twin's own row is not written.  `order` (may be NULL): the triples' indices
  * sorted by relation (ktup_shard_kg_rel_order) -- consecutive triples of one relation then share ONE flush of its gradient rows.
  * sumsq / n_slots (may be NULL): += the sum of |row|^2 over the 4B stored rows, as in ktup_train_rec_step_rows.
  * ktup_shard_kg_rel_order: order[0 .. B) = a counting sort of rel[0 .. B) over [0, n_rel) in one launch (n_rel > 16384: identity). */
 int ktup_shard_kg_rel_order(const int64_t* rel, int64_t B, int64_t n_rel, int32_t* order, void* stream);
 int ktup_train_kg_step_rows(int transh, const float* E, int64_t lde, const float* R, int64_t ldr, const float* Nrm, int64_t ldn,
-                            int d, const int64_t* ent_ids, const int64_t* rel_ids, const int32_t* order, int64_t B, int l1,
+                            int d, const int64_t* ent_ids, int64_t ent_pad, const int64_t* rel_ids, const int32_t* order, int64_t B, int l1,
                             float margin, float gscale, int regs, float* loss, float* GE, float* gR, float* gN, double* sumsq,
                             int n_slots, void* stream);
 #define KTUP_OPTIM_WS_DOUBLES 784

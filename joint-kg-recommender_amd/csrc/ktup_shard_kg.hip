@@ -65,7 +65,9 @@ __global__ __launch_bounds__(ORD_T) void kg_rel_order_kernel(const int64_t* __re
 
 struct KgRowsArgs {
   const float *E, *R, *Nm; int64_t lde, ldr, ldn;
-  const int64_t* ent;            // [ph ; pt ; nh ; nt], B each: rows of E (global ids of a shard, or wire rows of a compact table)
+  const int64_t* ent;            // [ph ; pt ; nh ; nt], B each: rows of E (global ids of a shard, or wire rows of a compact table); an nh / nt
+                                 // that is negative or == pad: the corrupted triple shares that entity with the positive one
+  int64_t pad;
   const int64_t* rel;            // [pr ; nr]
   const int32_t* order;          // relation-sorted order of the triples (nullptr: as given)
   int64_t B; int nch; bool l1;
@@ -80,6 +82,7 @@ struct KgRowsArgs {
 
 struct KgTriple {
   int64_t k, id[4], rid[2];
+  bool same[2];                  // the corrupted triple's head / tail IS the positive one's entry
   float4 e[4];
 };
 
@@ -121,6 +124,11 @@ __global__ __launch_bounds__(256) void kg_step_rows_kernel(KgRowsArgs a) {
     t.k = a.order ? a.order[p] : p;
 #pragma unroll
     for (int x = 0; x < 4; ++x) t.id[x] = a.ent[(int64_t)x * a.B + t.k];
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+      t.same[x] = t.id[2 + x] < 0 || t.id[2 + x] == a.pad;
+      if (t.same[x]) t.id[2 + x] = t.id[x];
+    }
     t.rid[0] = a.rel[t.k]; t.rid[1] = a.rel[a.B + t.k];
 #pragma unroll
     for (int x = 0; x < 4; ++x) t.e[x] = on ? reinterpret_cast<const float4*>(a.E + t.id[x] * a.lde)[lane] : f4zero();
@@ -200,10 +208,13 @@ __global__ __launch_bounds__(256) void kg_step_rows_kernel(KgRowsArgs a) {
     }
     if (on) {
 #pragma unroll
-      for (int x = 0; x < 4; ++x)
-        reinterpret_cast<float4*>(a.GE + ((int64_t)x * a.B + t.k) * (4 * (int64_t)a.nch))[lane] = ge[x];
+      for (int x = 0; x < 2; ++x)
+        if (t.same[x]) { ge[x] = ge[x] + ge[2 + x]; ge[2 + x] = f4zero(); }
 #pragma unroll
-      for (int x = 0; x < 4; ++x) ssq += dot4(ge[x], ge[x]);
+      for (int x = 0; x < 4; ++x) {
+        if (x < 2 || !t.same[x - 2]) reinterpret_cast<float4*>(a.GE + ((int64_t)x * a.B + t.k) * (4 * (int64_t)a.nch))[lane] = ge[x];
+        ssq += dot4(ge[x], ge[x]);
+      }
     }
 #pragma unroll
     for (int x = 0; x < 2; ++x) {
@@ -271,7 +282,7 @@ extern "C" int ktup_shard_kg_rel_order(const int64_t* rel, int64_t B, int64_t n_
 }
 
 extern "C" int ktup_train_kg_step_rows(int transh, const float* E, int64_t lde, const float* R, int64_t ldr, const float* Nrm, int64_t ldn,
-                                       int d, const int64_t* ent_ids, const int64_t* rel_ids, const int32_t* order, int64_t B, int l1,
+                                       int d, const int64_t* ent_ids, int64_t ent_pad, const int64_t* rel_ids, const int32_t* order, int64_t B, int l1,
                                        float margin, float gscale, int regs, float* loss, float* GE, float* gR, float* gN, double* sumsq,
                                        int n_slots, void* stream) {
   const char* name = "ktup_train_kg_step_rows";
@@ -282,6 +293,6 @@ extern "C" int ktup_train_kg_step_rows(int transh, const float* E, int64_t lde, 
   if (d <= 0 || d % 4 || d > 256 || (lde | ldr | (transh ? ldn : 0)) % 4 || !aligned16(E) || !aligned16(R) || !aligned16(GE) || !aligned16(gR) ||
       (transh && (!aligned16(Nrm) || !aligned16(gN))))
     return set_error(KTUP_ERR_UNSUPPORTED, "%s: needs d %% 4 == 0 (<= 256) and 16-byte aligned rows", name);
-  KgRowsArgs a{E, R, Nrm, lde, ldr, ldn, ent_ids, rel_ids, order, B, d / 4, l1 != 0, margin, gscale, regs, 1, loss, GE, gR, gN, sumsq, n_slots};
+  KgRowsArgs a{E, R, Nrm, lde, ldr, ldn, ent_ids, ent_pad, rel_ids, order, B, d / 4, l1 != 0, margin, gscale, regs, 1, loss, GE, gR, gN, sumsq, n_slots};
   return transh ? launch_kg_rows<true>(a, (hipStream_t)stream, name) : launch_kg_rows<false>(a, (hipStream_t)stream, name);
 }

@@ -74,10 +74,13 @@ __global__ __launch_bounds__(256) void route_init_kernel(RouteArgs a) {
   if (a.src_nt) {                                        // kg step: the triple columns of the cursor's batch
     const int64_t b0 = a.cursor ? ((*a.cursor) % a.n_batches) * a.B : 0;
     for (int64_t k = tid; k < a.B; k += nth) {
-      a.ids_out[k] = a.src_u[b0 + k];
-      a.ids_out[a.B + k] = a.src_pos[b0 + k];
-      a.ids_out[2 * a.B + k] = a.src_neg[b0 + k];
-      a.ids_out[3 * a.B + k] = a.src_nt[b0 + k];
+      // a corrupted triple keeps its head or its tail (utils/data.py:12-18): that entity is ONE entry -- the twin's slot is padding
+      // and ktup_train_kg_step_rows adds the twin's gradient to the positive's stored row
+      const int64_t ph = a.src_u[b0 + k], pt = a.src_pos[b0 + k], nh = a.src_neg[b0 + k], nt = a.src_nt[b0 + k];
+      a.ids_out[k] = ph;
+      a.ids_out[a.B + k] = pt;
+      a.ids_out[2 * a.B + k] = nh == ph ? -1 : nh;
+      a.ids_out[3 * a.B + k] = nt == pt ? -1 : nt;
       a.rel_out[k] = a.src_pr[b0 + k];
       a.rel_out[a.B + k] = a.src_nr[b0 + k];
     }
@@ -437,10 +440,19 @@ struct FusedArgs {
   WireTables w; const int64_t* ids; float lr, eps, max_norm; bool adagrad; const int32_t* skip_i; const double* skip_d;
 };
 
+// MODE 1 carries the step's LAST launch along as extra workgroups [walk_grid, gridDim.x): the listed boundary rows (from gw, then
+// zero-filled), the small replicated tables and the step's bookkeeping (ApplyRows over op_rows rows) depend on the norm only, not on
+// this walk -- as a launch of their own they were 6 us of dependent latencies at the very end of every step.
 template <int GL, int CPL, int MODE>
-__global__ __launch_bounds__(256) void seg_fused_kernel(FusedArgs a) {
+__global__ __launch_bounds__(256) void seg_fused_kernel(FusedArgs a, ApplyRows op, int64_t op_rows, int walk_grid) {
   const int lane = threadIdx.x % GL, grp = threadIdx.x / GL;
   constexpr int GPB = 256 / GL;
+  if (MODE == 1 && (int)blockIdx.x >= walk_grid) {
+    const RowCtx<float4, GL, CPL> cx{a.nch, lane};
+    for (int64_t row = (int64_t)((int)blockIdx.x - walk_grid) * GPB + grp; row < op_rows; row += (int64_t)((int)gridDim.x - walk_grid) * GPB)
+      op.template run<float4, GL, CPL>(cx, row);
+    return;
+  }
   constexpr int ROW4 = GL * CPL;
   __shared__ float4 edge[2 * GPB * ROW4];
   __shared__ int32_t ekey[2 * GPB];
@@ -646,10 +658,13 @@ int64_t fused_grid(int64_t m_max, int d) {
 }
 
 template <int MODE>
-int launch_fused(const FusedArgs& a, int64_t grid, hipStream_t st, const char* name) {
+int launch_fused(const FusedArgs& a, int64_t grid, hipStream_t st, const char* name, const ApplyRows* op = nullptr, int64_t op_rows = 0) {
+  const ApplyRows none{};
 #define KTUP_F(GL, CPL)                                                                                  \
   {                                                                                                      \
-    hipLaunchKernelGGL((seg_fused_kernel<GL, CPL, MODE>), dim3((unsigned)grid), dim3(256), 0, st, a);    \
+    const int64_t extra = op ? grid_for((op_rows + (256 / GL) - 1) / (256 / GL), 256) : 0;               \
+    hipLaunchKernelGGL((seg_fused_kernel<GL, CPL, MODE>), dim3((unsigned)(grid + extra)), dim3(256), 0, st, a, op ? *op : none, op_rows, \
+                       (int)grid);                                                                       \
     return check_launch(name);                                                                           \
   }
   if (a.nch <= 16) KTUP_F(16, 1)
@@ -989,14 +1004,13 @@ extern "C" int ktup_shard_reduce_apply(int kind, int n_tables, float* const* tab
   a.adagrad = adagrad; a.skip_i = skip_count; a.skip_d = skip_value;
   hipStream_t st = (hipStream_t)stream;
   const int64_t grid = fused_grid(n_entries, d);
-  if (int e = launch_fused<1>(a, grid, st, name)) return e;
-  // the listed boundary rows from gw (then zero-filled) and the small tables
+  // the listed boundary rows from gw (then zero-filled) and the small tables ride in the same launch
   op.ids = ids; op.W = 2 * grid; op.g = gwire; op.ldg = ldw; op.xkeys = xkeys;
   op.n_small = n_small; op.small_rows = small_rows > 0 ? small_rows : 1; op.small_g64 = small_g64; op.d = d;
   op.lr = lr; op.eps = eps; op.max_norm = max_norm; op.sumsq = sumsq; op.sumsq_slots = sumsq_slots; op.skip_i = skip_count; op.skip_d = skip_value;
   op.adagrad = adagrad;
   op.loss_step = loss_step; op.n_loss = n_loss; op.loss_sum = loss_sum; op.skipped = skipped_steps;
-  return launch_rows(op, d, true, op.W + (int64_t)n_small * op.small_rows, st, name);
+  return launch_fused<1>(a, grid, st, name, &op, op.W + (int64_t)n_small * op.small_rows);
 }
 
 extern "C" int ktup_shard_bucket(int mode, int n_small, float* const* small_grads, int64_t small_elems, double* bucket,

@@ -114,7 +114,7 @@ SIGNATURES = {
                          c_p, c_i, c_f, c_p, c_p, c_p, c_i, c_p, c_p, c_p],
     'ktup_shard_route_kg': [c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_l, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_p],
     'ktup_shard_kg_rel_order': [c_p, c_l, c_l, c_p, c_p],
-    'ktup_train_kg_step_rows': [c_i, c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_p, c_p, c_p, c_l, c_i, c_f, c_f, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_p],
+    'ktup_train_kg_step_rows': [c_i, c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_p, c_l, c_p, c_p, c_l, c_i, c_f, c_f, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_p],
     'ktup_shard_bucket': [c_i, c_i, c_p, c_l, c_p, c_p, c_i, c_p, c_p, ctypes.c_double, c_p],
     'ktup_zero_async': [c_p, c_l, c_p],
     'ktup_shard_reduce_list_len': [c_l, c_i],

@@ -536,10 +536,10 @@ class ShardedKgStepper(_ShardedStepBase):
                         _p(self.acc), SLOTS + 1, _p(self.route_ws), phase, on)
         order = bind('ktup_shard_kg_rel_order', _p(self.rels), B, P, _p(self.order), stream)
         if self.direct:
-            Esrc, lde, ent_ids = Et.weight.data, Et.weight.data.stride(0), self.entries
+            Esrc, lde, ent_ids, ent_pad = Et.weight.data, Et.weight.data.stride(0), self.entries, -1
         else:
-            Esrc, lde, ent_ids = self.X, d, self.inverse
-        step = bind('ktup_train_kg_step_rows', int(self.transh), _p(Esrc), lde, _p(rel), d, _p(norm), d, d, _p(ent_ids), _p(self.rels),
+            Esrc, lde, ent_ids, ent_pad = self.X, d, self.inverse, W                  # padding entries route to the zero row W
+        step = bind('ktup_train_kg_step_rows', int(self.transh), _p(Esrc), lde, _p(rel), d, _p(norm), d, d, _p(ent_ids), ent_pad, _p(self.rels),
                     _p(self.order), B, int(self.l1), self.margin, self.kg_lambda, self.regs, _p(self.loss_step), _p(self.GE), _p(gR), _p(gN),
                     *((None, 0) if self.multi else (_p(self.acc), SLOTS)), stream)
         if not self.multi:

@@ -56,6 +56,9 @@ FLAG_TABLE = [
     ('device_sampling', 'bool', True, 'keep training data and negative sampling on the GPU (K19); -nodevice_sampling runs the python samplers'),
     ('shard_eval_candidates', 'bool', False, 'torchrun only: every rank scores its slice of the item / entity catalogue for ALL queries '
                                              '(top-n lists merged, KG rank counts all-reduced) instead of whole batches being dealt to the ranks'),
+    ('shard_tables', 'bool', False, 'jtransup with its own tables: the user / item / entity tables and their Adagrad sums are partitioned by row over '
+                                    'the ranks (row % world) and a step exchanges only the rows its batch touches (BASELINE config 5; one process: the '
+                                    'same row-sparse step without an exchange); needs -optimizer_type Adagrad (or SGD -momentum 0) and -l2_lambda 0'),
     # files
     ('data_path', 'str', None, 'root of the datasets'),
     ('log_path', 'str', None, 'logs (and, by default, checkpoints)'),

@@ -105,7 +105,14 @@ def train_loop(FLAGS, model, trainer, rating_train_dataset, triple_train_dataset
     # KTUP with its own tables: the step body below runs as ~a dozen C-ABI launches (utils/fast_train.py) instead of through
     # autograd; with -device_sampling the batches and their negatives never leave the GPU either.
     stepper = rec_feed = kg_feed = sampler = None
-    if D.USE_CUDA and FLAGS.model_type == 'jtransup' and not FLAGS.share_embeddings and trainer.fused is not None \
+    sharded = bool(getattr(FLAGS, 'shard_tables', False))
+    if sharded:
+        # BASELINE config 5: row-sharded user / item / entity tables, fixed-shape exchange, row-sparse Adagrad (utils/sharded_train.py)
+        from jTransUP.utils.sharded_train import ShardedJointDriver
+        stepper = ShardedJointDriver(model, trainer, FLAGS, FLAGS.batch_size, logger)
+        logger.info('Row-sharded training step enabled (-shard_tables): rank %d of %d owns rows r %% %d == %d of the user / item / entity tables.'
+                    % (stepper.rank, stepper.world, stepper.world, stepper.rank))
+    elif D.USE_CUDA and FLAGS.model_type == 'jtransup' and not FLAGS.share_embeddings and trainer.fused is not None \
             and os.environ.get('KTUP_FAST_TRAIN', '1') != '0':
         from jTransUP.utils.fast_train import DeviceFeeder, JointStepper
         stepper = JointStepper(model, trainer, FLAGS, FLAGS.batch_size)
@@ -126,6 +133,8 @@ def train_loop(FLAGS, model, trainer, rating_train_dataset, triple_train_dataset
     logger.info('Training.')
 
     def do_eval(totals):
+        if sharded:
+            stepper.sync_model()                           # the evaluation reads whole tables: gather the shards
         rec_loss = totals['rec'] / (FLAGS.eval_interval_steps * FLAGS.joint_ratio)
         kg_loss = totals['kg'] / (FLAGS.eval_interval_steps * (1 - FLAGS.joint_ratio)) if FLAGS.joint_ratio < 1 else 0.0
         logger.info('rec train loss:{:.4f}, kg train loss:{:.4f}!'.format(rec_loss, kg_loss))

@@ -189,3 +189,77 @@ def test_single_task_cli_data_parallel_torchrun(dataset, script, extra, metric, 
     m0, m1 = re.findall(metric, log0), re.findall(metric, log1)
     assert len(m0) >= 3 and m0 == m1
     assert re.findall(r'train loss:\d+\.\d+', log0) == re.findall(r'train loss:\d+\.\d+', log1)
+
+
+def _loss_lines(log):
+    return [(float(a), float(b)) for a, b in re.findall(r'rec train loss:(\d+\.\d+), kg train loss:(\d+\.\d+)', log)]
+
+
+def _metric_rows(log):
+    return [tuple(float(x) for x in m) for m in re.findall(r'f1:(\d\.\d+), p:(\d\.\d+), r:(\d\.\d+), hit:(\d\.\d+), ndcg:(\d\.\d+)', log)]
+
+
+def test_joint_cli_shard_tables_single_process(dataset):
+    """-shard_tables (BASELINE config 5's step: row-sharded tables, row-sparse Adagrad) in one process against the replicated
+    fused route on the same batches (-nodevice_sampling: the reference's python samplers under the same -seed): without weight
+    decay a row no batch touches does not move under dense Adagrad either, so both runs log the same losses and metrics; every
+    checkpoint comes with the rank's shard file (rows + Adagrad sums)."""
+    common = ['-model_type', 'jtransup', '-rec_test_files', 'valid.dat', '-kg_test_files', 'valid.dat', '-joint_ratio', '0.7',
+              '-noshare_embeddings', '-nodevice_sampling', '-embedding_size', '64', '-l2_lambda', '0', '-optimizer_type', 'Adagrad',
+              '-training_steps', '45', '-kg_lambda', '0.5']
+    dense, _ = run_cli('run_knowledgable_recommendation.py', dataset, 'ktup-dense64', common)
+    shard, logs = run_cli('run_knowledgable_recommendation.py', dataset, 'ktup-shard64', common + ['-shard_tables'])
+    assert 'Row-sharded training step enabled (-shard_tables): rank 0 of 1' in shard and 'GPU-resident training step enabled' in dense
+    la, lb = _loss_lines(dense), _loss_lines(shard)
+    assert len(la) >= 4 and len(la) == len(lb)
+    for (ra, ka), (rb, kb) in zip(la[1:], lb[1:]):                      # [0] is the step-0 evaluation: no step yet
+        assert abs(ra - rb) <= 2e-3 * max(1.0, abs(ra)) and abs(ka - kb) <= 2e-3 * max(1.0, abs(ka)), (la, lb)
+    ma, mb = _metric_rows(dense), _metric_rows(shard)
+    assert len(ma) >= 4 and len(ma) == len(mb)
+    assert all(abs(x - y) <= 0.03 for a, b in zip(ma, mb) for x, y in zip(a, b)), (ma, mb)      # (a rank flip moves hit@10 of 40 users by 0.025)
+    assert ma[0] == mb[0]                                                # before any step the tables are the same bits
+    assert os.path.isfile(os.path.join(logs, 'ktup-shard64.ckpt')) and os.path.isfile(os.path.join(logs, 'ktup-shard64.ckpt.shard0of1'))
+    log2, _ = run_cli('run_knowledgable_recommendation.py', dataset, 'ktup-shard64-eval',
+                      common + ['-eval_only_mode', '-load_experiment_name', os.path.join(logs, 'ktup-shard64.ckpt')])
+    assert 'Found checkpoint, restoring.' in log2 and len(_metric_rows(log2)) >= 1
+
+
+def test_joint_cli_shard_tables_refuses_what_it_cannot_do(dataset):
+    data = str(dataset)
+    logs = os.path.join(data, 'log')
+    cmd = [sys.executable, os.path.join(PKG, 'run_knowledgable_recommendation.py'), '-data_path', data, '-log_path', logs, '-dataset', 'ml1m',
+           '-experiment_name', 'ktup-shard-bad', '-nohas_visualization', '-batch_size', '32', '-embedding_size', '64', '-seed', '3',
+           '-training_steps', '5', '-model_type', 'jtransup', '-rec_test_files', 'valid.dat', '-kg_test_files', 'valid.dat',
+           '-noshare_embeddings', '-shard_tables']                       # default -l2_lambda 1e-5: weight decay moves every row
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and '-l2_lambda 0' in (r.stdout + r.stderr)
+
+
+def test_joint_cli_shard_tables_torchrun(dataset):
+    """Two ranks (gloo test hook: both share this box's GPU), rows r % 2 on rank r: the exchange form with real all-to-alls.  Both
+    ranks log the same losses and metrics, equal to the one-process sharded run on the same global batches; each writes its shard."""
+    data = str(dataset)
+    logs = os.path.join(data, 'log')
+    env = dict(os.environ, KTUP_DIST_BACKEND='gloo')
+    tail = ['-nohas_visualization', '-batch_size', '32', '-embedding_size', '64', '-seed', '3', '-eval_interval_steps', '10',
+            '-training_steps', '25', '-early_stopping_steps_to_wait', '0', '-learning_rate', '0.05', '-topn', '10', '-model_type', 'jtransup',
+            '-rec_test_files', 'valid.dat', '-kg_test_files', 'valid.dat', '-joint_ratio', '0.7', '-noshare_embeddings', '-nodevice_sampling',
+            '-l2_lambda', '0', '-shard_tables', '-shard_eval_candidates']
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', '29551', os.path.join(PKG, 'run_knowledgable_recommendation.py'), '-data_path', data, '-log_path', logs,
+           '-dataset', 'ml1m', '-experiment_name', 'ktup-shard2'] + tail
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    log0 = open(os.path.join(logs, 'ktup-shard2.log')).read()
+    log1 = open(os.path.join(logs, 'ktup-shard2.rank1.log')).read()
+    assert 'rank 0 of 2' in log0 and 'rank 1 of 2' in log1
+    assert _loss_lines(log0) == _loss_lines(log1) and len(_loss_lines(log0)) >= 3
+    assert _metric_rows(log0) == _metric_rows(log1) and len(_metric_rows(log0)) >= 3
+    assert os.path.isfile(os.path.join(logs, 'ktup-shard2.ckpt.shard0of2')) and os.path.isfile(os.path.join(logs, 'ktup-shard2.rank1.ckpt.shard1of2'))
+    one = subprocess.run([sys.executable, os.path.join(PKG, 'run_knowledgable_recommendation.py'), '-data_path', data, '-log_path', logs,
+                          '-dataset', 'ml1m', '-experiment_name', 'ktup-shard1'] + tail[:-1], capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stdout[-3000:] + one.stderr[-3000:]
+    log = open(os.path.join(logs, 'ktup-shard1.log')).read()
+    for (ra, ka), (rb, kb) in zip(_loss_lines(log)[1:], _loss_lines(log0)[1:]):
+        assert abs(ra - rb) <= 2e-3 * max(1.0, abs(ra)) and abs(ka - kb) <= 2e-3 * max(1.0, abs(ka))
+    assert all(abs(x - y) <= 0.03 for a, b in zip(_metric_rows(log), _metric_rows(log0)) for x, y in zip(a, b))

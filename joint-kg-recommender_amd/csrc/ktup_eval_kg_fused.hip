@@ -22,6 +22,20 @@
 // (relations x candidates) table once per pass with the same MFMA sequence (mode 2), and the sweep is TransE's plus four table
 // look-ups per lane and stage, fetched one stage ahead -- half the matrix instructions of mode 1 (both products in the sweep), which
 // stays for relation counts whose table would not fit.
+// EXACT ORDER NEAR THE GOLDS.  The sweep's score is |c|^2 - 2 c.e + |e|^2 (+ the TransH terms) from dot products, the reference's
+// sum_k (c_k - e_k)^2 (transE.py:65-105, utils/misc.py:125-146 ranks by it): the two round differently, ~1e-6 on scores of O(1), and a
+// candidate that close to a gold could land on the other side of it (8 of 3,478 ranks off by one at ml1m size).  So a comparison only
+// COUNTS when it is safe: score < gold - T or score > gold + T, with T = 2 kappa (|c|^2 + max_e |e|^2), kappa = 2 (d + 8) 2^-24
+// (1 + |w|^2)^2: the forward error of an n-term fp32 dot product is <= gamma_n |x||y| in any summation order, so a score is off by
+// <= gamma_d (|c|^2 + |e|^2 + 2 |c||e|) <= 2 gamma_d (|c|^2 + |e|^2) (+ 8 for the additions and the rounding of c itself), and a
+// comparison involves two scores.  A candidate inside the window goes to a list (one segment per workgroup, so the
+// slot counters are uncontended; ~1e-4 of the pairs) -- and so do the filtered ids and other golds of a key that the finalize step
+// finds inside the window, with the opposite sign.  kg_unc_resolve_kernel, the pass's LAST launch, decides every listed comparison
+// in fp64 from the tables themselves -- sum_k ((q_k -+ r_k) - e_k)^2, TransH with both projections, ids break exact ties -- and
+// adds +-1 to the rank.  The ranks are then those of the exact scores of the fp32 tables; where the fp32 sum of the reference's own
+// formula disagrees, fp64 is the referee (tests/test_hip_eval.py).  A segment that overflows (an entity table made of equal rows:
+// everything ties) switches the WHOLE pass back to the keys of the sweep's own scores -- sweep, finalize and list alike, so the
+// counts stay consistent.
 // The sweep covers squared L2 at d in {20, 36, 64, 100, 128}; L1 and every other width take the pair kernels' COUNT form
 // (ktup_eval.hip kg_valu_counts) behind the same entry point, with this file's finalize step.
 #include <hip/hip_runtime.h>
@@ -62,6 +76,7 @@ KTUP_DEV uint64_t kg_key(float s, bool descending, uint32_t id) {      // = make
   return ((uint64_t)u << 32) | id;
 }
 
+struct Unc;
 struct FArgs {
   const float* QW; int dq;
   const float* C; int64_t ldc;
@@ -78,7 +93,83 @@ struct FArgs {
   const int64_t* rel;           // mode 2: the keys' relation ids, the normals' table and w.e of every (relation, candidate)
   const float* Nrm; int64_t ldn; int n_rel;
   float* wtab; int64_t ldw;
+  // exact order near the golds: the raw inputs of the fp64 re-score, the per-key window and the list of undecided comparisons
+  int model, d, head;
+  const float* E; int64_t lde; const float* R; int64_t ldr; const int64_t* q;
+  float* ktol;                  // [nq] T of every key (kg_list_scores writes it; nullptr: no window, the keys of the scores decide)
+  uint32_t* enmax;              // [1] max |e|^2 over the candidates, as float bits
+  float kappa0;
+  Unc* unc; int32_t* unc_count; int unc_cap, unc_nseg;   // [unc_nseg][unc_cap] entries; [unc_nseg] counts, [unc_nseg] = 1 once a segment overflowed
+  int unc_sweep_segs;                                    // segments of the sweep's workgroups (blockIdx.y * NBAND + band); the finalize blocks' follow
 };
+
+// key index; the gold: its position in the key's list (a candidate the sweep did not count: +1 if it is before the gold) or ~gi, gi its
+// entry (a filtered id / other gold the finalize step did not subtract: -1 if it is); candidate id; its fp32 score (unflipped)
+struct Unc { int32_t key, gi, cand; float s; };
+
+// sum_k (c_k - e_k)^2 of key `key` against candidate `cand` in fp64 from the tables (GL lanes share the row; all of them get the sum)
+template <int GL>
+KTUP_DEV double precise_score(const FArgs& a, int64_t key, int32_t cand, int sub) {
+  const float* e = a.E + a.q[key] * a.lde;
+  const float* rl = a.R + a.rel[key] * a.ldr;
+  const float* c = a.C + (int64_t)cand * a.ldc;
+  const double sgn = a.head ? -1.0 : 1.0;                       // head: c = proj(t) - r; tail: c = proj(h) + r  (kg_query_prep_kernel)
+  double de = 0.0, dc = 0.0;
+  const float* w = nullptr;
+  if (a.model == KTUP_KG_TRANSH) {
+    w = a.Nrm + a.rel[key] * a.ldn;
+    for (int k = sub; k < a.d; k += GL) { de += (double)e[k] * (double)w[k]; dc += (double)c[k] * (double)w[k]; }
+#pragma unroll
+    for (int m = 1; m < GL; m <<= 1) { de += __shfl_xor(de, m, 64); dc += __shfl_xor(dc, m, 64); }
+  }
+  double acc = 0.0;
+  for (int k = sub; k < a.d; k += GL) {
+    double qv = (double)e[k], cv = (double)c[k];
+    if (w) { qv -= de * (double)w[k]; cv -= dc * (double)w[k]; }
+    const double z = (qv + sgn * (double)rl[k]) - cv;
+    acc += z * z;
+  }
+#pragma unroll
+  for (int m = 1; m < GL; m <<= 1) acc += __shfl_xor(acc, m, 64);
+  return acc;
+}
+// the same for TWO candidates of one key (a listed candidate and its gold): the key's rows are read once
+template <int GL>
+KTUP_DEV void precise_pair(const FArgs& a, int64_t key, int32_t c0, int32_t c1, int sub, double& s0, double& s1) {
+  const float* e = a.E + a.q[key] * a.lde;
+  const float* rl = a.R + a.rel[key] * a.ldr;
+  const float* x0 = a.C + (int64_t)c0 * a.ldc;
+  const float* x1 = a.C + (int64_t)c1 * a.ldc;
+  const double sgn = a.head ? -1.0 : 1.0;
+  double de = 0.0, d0 = 0.0, d1 = 0.0;
+  const float* w = nullptr;
+  if (a.model == KTUP_KG_TRANSH) {
+    w = a.Nrm + a.rel[key] * a.ldn;
+    for (int k = sub; k < a.d; k += GL) {
+      const double wk = (double)w[k];
+      de += (double)e[k] * wk; d0 += (double)x0[k] * wk; d1 += (double)x1[k] * wk;
+    }
+#pragma unroll
+    for (int m = 1; m < GL; m <<= 1) { de += __shfl_xor(de, m, 64); d0 += __shfl_xor(d0, m, 64); d1 += __shfl_xor(d1, m, 64); }
+  }
+  double a0 = 0.0, a1 = 0.0;
+  for (int k = sub; k < a.d; k += GL) {
+    double qv = (double)e[k], v0 = (double)x0[k], v1 = (double)x1[k];
+    if (w) { const double wk = (double)w[k]; qv -= de * wk; v0 -= d0 * wk; v1 -= d1 * wk; }
+    qv += sgn * (double)rl[k];
+    const double z0 = qv - v0, z1 = qv - v1;
+    a0 += z0 * z0; a1 += z1 * z1;
+  }
+#pragma unroll
+  for (int m = 1; m < GL; m <<= 1) { a0 += __shfl_xor(a0, m, 64); a1 += __shfl_xor(a1, m, 64); }
+  s0 = a0; s1 = a1;
+}
+// is candidate (sc, cid) ordered before gold (sg, gid)?  exact scores first, ids on exact ties; an unordered pair (NaN) -> the keys
+KTUP_DEV bool precise_before(double sc, int32_t cid, double sg, int32_t gid, bool desc, float fsc, float fsg) {
+  if (sc != sc || sg != sg) return kg_key(fsc, desc, (uint32_t)cid) < kg_key(fsg, desc, (uint32_t)gid);
+  if (desc) { sc = -sc; sg = -sg; }
+  return sc < sg || (sc == sg && (uint32_t)cid < (uint32_t)gid);
+}
 
 // ---- pieces shared by the list kernel and the sweep: identical code => identical bits
 template <typename G>
@@ -229,6 +320,10 @@ __global__ __launch_bounds__(256) void kg_list_scores_kernel(FArgs a) {
   __syncthreads();
   query_scalars<G>(a, Q, qs, u0, 256);
   __syncthreads();
+  if (a.ktol && tid < UB && u0 + tid < a.nq) {                  // T = 2 kappa (|c|^2 + max |e|^2): see the file header
+    const float ww = G::MODE != 0 ? qs[tid * 4 + 2] : 0.f;
+    a.ktol[u0 + tid] = 2.f * a.kappa0 * (1.f + ww) * (1.f + ww) * (qs[tid * 4 + 0] + __uint_as_float(*a.enmax));
+  }
   // this lane's key (for gathering: lane = (row j of the wave, chunk group))
   const int64_t key_j = u0 + 16 * w + j;
   const bool key_on = key_j < a.nq;
@@ -333,6 +428,7 @@ __global__ __launch_bounds__(NW * 64) void kg_count_mc_kernel(FArgs a) {
   float* qs = reinterpret_cast<float*>(Cd + 2 * IB * P4);
   float* gth = qs + UB * 4;                                     // [UB][GMX] gold scores as compared (sign-flipped when descending)
   uint64_t* gkey = reinterpret_cast<uint64_t*>(gth + UB * GMX); // [UB][GMX]  (8-byte aligned: every part before is a multiple of 16)
+  __shared__ int unc_n;                                         // entries of this workgroup's list segment (earlier launches' included)
   const int tid = threadIdx.x, lane = tid & 63, kq = lane >> 4, j = lane & 15;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int band = blockIdx.x;                                  // consecutive workgroup ids go round the 8 XCDs: band == XCD
@@ -348,6 +444,8 @@ __global__ __launch_bounds__(NW * 64) void kg_count_mc_kernel(FArgs a) {
   if (tid < UB && u0 + tid < a.nq) most = (int)min((int64_t)GMX, a.gold_off[u0 + tid + 1] - a.gold_off[u0 + tid] - a.gbase);
   const bool wg_one = !__syncthreads_or(most > 1), wg_two = !__syncthreads_or(most > 2);
   stage_queries<G>(a, Q, u0, NW * 64);
+  const int seg = (int)blockIdx.y * NBAND + band;
+  if (tid == 0) unc_n = a.ktol ? a.unc_count[seg] : 0;
   for (int idx = tid; idx < UB * GMX; idx += NW * 64) {          // gold keys of the 64 keys (0 = no gold: no key is below it)
     const int row = idx / GMX, g = a.gbase + idx - row * GMX;
     uint64_t k = 0;
@@ -371,14 +469,15 @@ __global__ __launch_bounds__(NW * 64) void kg_count_mc_kernel(FArgs a) {
   auto run = [&](auto gn_c) {
   constexpr int GN = decltype(gn_c)::value;
   int cnt[4][GN];
-  float th[4][GN];
+  float lo[4][GN], hi[4][GN];                                   // a score counts below lo, is out above hi; in between: the list
   v4 qsr[4];
   int32_t wo[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int ur = 16 * ut + 4 * kq + r;
+    const float T = (a.ktol && u0 + ur < a.nq) ? a.ktol[u0 + ur] : 0.f;
 #pragma unroll
-    for (int g = 0; g < GN; ++g) { cnt[r][g] = 0; th[r][g] = gth[ur * GMX + g]; }
+    for (int g = 0; g < GN; ++g) { cnt[r][g] = 0; lo[r][g] = gth[ur * GMX + g] - T; hi[r][g] = gth[ur * GMX + g] + T; }
     qsr[r] = *reinterpret_cast<const v4*>(qs + ur * 4);
     wo[r] = (G::WTAB && u0 + ur < a.nq) ? (int32_t)(a.rel[u0 + ur] * a.ldw) : 0;
   }
@@ -458,21 +557,27 @@ __global__ __launch_bounds__(NW * 64) void kg_count_mc_kernel(FArgs a) {
         s[reg] = __uint_as_float(__float_as_uint(pair_score<G>(ce[reg], we[reg], qv[0], ee, qv[1], qv[2])) ^ flip);
 #pragma unroll
         for (int g = 0; g < GN; ++g) {
-          const float tg = th[reg][g];
-          const bool lt = s[reg] < tg;
+          const bool lt = s[reg] < lo[reg][g];
           cnt[reg][g] += lt ? 1 : 0;
-          tie |= !lt && !(s[reg] > tg);                         // equal or unordered: the keys decide
+          tie |= !lt && !(s[reg] > hi[reg][g]);                 // inside the window, or unordered: decided elsewhere
         }
       }
-      if (__builtin_amdgcn_ballot_w64(tie) != 0) {               // rare: the gold itself (once per band), exact float ties, NaNs
+      if (__builtin_amdgcn_ballot_w64(tie) != 0) {               // rare: the gold itself (once per band), near ties, NaNs
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
           const int ur = 16 * ut + 4 * kq + reg;
-          const uint64_t k = kg_key(s[reg], false, (uint32_t)cand);   // s is already flipped
 #pragma unroll
           for (int g = 0; g < GN; ++g) {
-            const float tg = th[reg][g];
-            if (!(s[reg] < tg) && !(s[reg] > tg)) cnt[reg][g] += k < gkey[ur * GMX + g] ? 1 : 0;
+            if (s[reg] < lo[reg][g] || s[reg] > hi[reg][g]) continue;
+            const uint64_t gk = gkey[ur * GMX + g];
+            if (gk == 0 || (uint32_t)gk == (uint32_t)cand) continue;          // no such gold; the gold itself is not before itself
+            const int slot = a.ktol ? atomicAdd(&unc_n, 1) : a.unc_cap;      // an LDS counter: the segment is this workgroup's alone
+            if (slot < a.unc_cap) {
+              a.unc[(int64_t)seg * a.unc_cap + slot] = Unc{(int32_t)(u0 + ur), a.gbase + g, (int32_t)cand, __uint_as_float(__float_as_uint(s[reg]) ^ flip)};
+            } else {                                             // no window / the segment is full: the keys of the sweep's own scores decide
+              if (a.ktol) a.unc_count[a.unc_nseg] = 1;
+              cnt[reg][g] += kg_key(s[reg], false, (uint32_t)cand) < gk ? 1 : 0;      // s is already flipped
+            }
           }
         }
       }
@@ -504,6 +609,10 @@ __global__ __launch_bounds__(NW * 64) void kg_count_mc_kernel(FArgs a) {
   if (wg_one) run(std::integral_constant<int, 1>{});
   else if (wg_two) run(std::integral_constant<int, 2>{});
   else run(std::integral_constant<int, GMX>{});
+  if (a.ktol) {
+    __syncthreads();
+    if (tid == 0) a.unc_count[seg] = unc_n < a.unc_cap ? unc_n : a.unc_cap;
+  }
 }
 
 // ---- per gold entry: rank = count - (filtered ids and other golds of the key that are ordered before it); -1 if itself filtered.
@@ -518,8 +627,36 @@ KTUP_DEV bool in_sorted(const int32_t* __restrict__ a, int64_t lo, int64_t hi, i
   }
   return lo < end && a[lo] == x;
 }
+// the listed comparisons, 16 lanes per entry, a workgroup per segment: fp64 from the tables; after an overflow the keys of the fp32
+// scores for all of them.  counts[gi] < 0 marks a gold that is itself filtered (rank -1: nothing to adjust).
+__global__ __launch_bounds__(256) void kg_unc_resolve_kernel(FArgs a) {
+  const bool desc = a.descending != 0;
+  const bool approx = a.unc_count[a.unc_nseg] != 0;
+  const int sub = threadIdx.x & 15;
+  for (int seg = blockIdx.x; seg < a.unc_nseg; seg += gridDim.x) {
+    const int n = min(a.unc_count[seg], a.unc_cap);
+    for (int i = threadIdx.x >> 4; i < n; i += 16) {
+      const Unc u = a.unc[(int64_t)seg * a.unc_cap + i];
+      const int32_t gi = u.gi < 0 ? ~u.gi : (int32_t)a.gold_off[u.key] + u.gi;
+      if (a.counts[gi] < 0) continue;
+      const int32_t gid = a.gold_ids[gi];
+      bool before;
+      if (approx) {
+        before = kg_key(u.s, desc, (uint32_t)u.cand) < kg_key(a.gscore[gi], desc, (uint32_t)gid);
+      } else {
+        double sc, sg;
+        precise_pair<16>(a, u.key, u.cand, gid, sub, sc, sg);
+        before = precise_before(sc, u.cand, sg, gid, desc, u.s, a.gscore[gi]);
+      }
+      if (sub == 0 && before) atomicAdd(a.ranks + gi, u.gi < 0 ? -1 : 1);
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void kg_rank_finalize_kernel(FArgs a, int64_t n_gold_total) {
   const bool desc = a.descending != 0;
+  const bool windowed = a.ktol != nullptr;
+  const int seg = a.unc_sweep_segs + (int)blockIdx.x;
   for (int64_t key = (int64_t)blockIdx.x * 256 + threadIdx.x; key < a.nq; key += (int64_t)gridDim.x * 256) {
     const int64_t g0 = a.gold_off[key], g1 = a.gold_off[key + 1];
     const int64_t f0 = a.filt_off ? a.filt_off[key] : 0, f1 = a.filt_off ? a.filt_off[key + 1] : 0;
@@ -533,14 +670,24 @@ __global__ __launch_bounds__(256) void kg_rank_finalize_kernel(FArgs a, int64_t 
         if (sorted) filtered = in_sorted(a.filt_ids, f0, f1, gid);
         else for (int64_t f = f0; f < f1 && !filtered; ++f) filtered = a.filt_ids[f] == gid;
       }
-      if (filtered) { a.ranks[gi] = -1; continue; }
+      if (filtered) { a.ranks[gi] = -1; a.counts[gi] = -1; continue; }
       const uint64_t gk = kg_key(a.gscore[gi], desc, (uint32_t)gid);
+      const float gs = a.gscore[gi], T = windowed ? a.ktol[key] : 0.f;
+      // list entry (score fs, id c) before this gold?  outside the window the float scores decide; inside it the comparison joins the
+      // sweep's list (sign -1) and kg_unc_resolve_kernel decides it
+      auto before = [&](float fs, int32_t c) {
+        if (!windowed || fs < gs - T || fs > gs + T) return kg_key(fs, desc, (uint32_t)c) < gk;
+        const int slot = atomicAdd(a.unc_count + seg, 1);
+        if (slot < a.unc_cap) { a.unc[(int64_t)seg * a.unc_cap + slot] = Unc{(int32_t)key, ~(int32_t)gi, c, fs}; return false; }
+        a.unc_count[a.unc_nseg] = 1;                           // full: the whole pass falls back to the keys (the resolve step reads this)
+        return kg_key(fs, desc, (uint32_t)c) < gk;
+      };
       int sub = 0;
       if (sorted) {
 #pragma unroll 8
         for (int64_t f = f0; f < f1; ++f) {                   // independent loads: eight in flight
           const int32_t c = a.filt_ids[f];
-          sub += (c >= 0 && c < a.n_cand && kg_key(a.fscore[f], desc, (uint32_t)c) < gk) ? 1 : 0;
+          sub += (c >= 0 && c < a.n_cand && before(a.fscore[f], c)) ? 1 : 0;
         }
       } else {
         for (int64_t f = f0; f < f1; ++f) {
@@ -548,7 +695,7 @@ __global__ __launch_bounds__(256) void kg_rank_finalize_kernel(FArgs a, int64_t 
           if (c < 0 || c >= a.n_cand) continue;
           bool dup = false;                                    // a filter list is a set, but stay exact if it is not
           for (int64_t e = f0; e < f && !dup; ++e) dup = a.filt_ids[e] == c;
-          if (!dup && kg_key(a.fscore[f], desc, (uint32_t)c) < gk) ++sub;
+          if (!dup && before(a.fscore[f], c)) ++sub;
         }
       }
       for (int64_t o = g0; o < g1; ++o) {
@@ -560,17 +707,24 @@ __global__ __launch_bounds__(256) void kg_rank_finalize_kernel(FArgs a, int64_t 
           for (int64_t f = f0; f < f1 && !dup; ++f) dup = a.filt_ids[f] == c;
           for (int64_t e = g0; e < o && !dup; ++e) dup = a.gold_ids[e] == c;
         }
-        if (!dup && kg_key(a.gscore[o], desc, (uint32_t)c) < gk) ++sub;
+        if (!dup && before(a.gscore[o], c)) ++sub;
       }
       a.ranks[gi] = a.counts[gi] - sub;
+      a.counts[gi] = 0;
     }
   }
 }
 
 // counts <- 0 and |e|^2 of every candidate (8 lanes per row; ONE value per candidate for the whole pass)
+__global__ __launch_bounds__(256) void kg_unc_reset_kernel(uint32_t* enmax, int32_t* unc_count, int nseg) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) *enmax = 0u;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i <= nseg; i += gridDim.x * 256) unc_count[i] = 0;
+}
+
 __global__ __launch_bounds__(256) void kg_pass_init_kernel(int32_t* counts, int64_t n, const float* __restrict__ C, int64_t ldc, int nch,
-                                                           int64_t n_cand, float* __restrict__ cnorm) {
+                                                           int64_t n_cand, float* __restrict__ cnorm, uint32_t* enmax) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) counts[i] = 0;
+  float mx = 0.f;
   for (int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 3; row < n_cand; row += ((int64_t)gridDim.x * 256) >> 3) {
     const v4* r0 = reinterpret_cast<const v4*>(C + row * ldc);
     v4 s0 = (v4){0.f, 0.f, 0.f, 0.f};
@@ -579,16 +733,30 @@ __global__ __launch_bounds__(256) void kg_pass_init_kernel(int32_t* counts, int6
 #pragma unroll
     for (int m = 1; m < 8; m <<= 1) f0 += __shfl_xor(f0, m, 64);
     if ((threadIdx.x & 7) == 0) cnorm[row] = f0;
+    mx = f0 > mx ? f0 : mx;                                     // (a NaN norm does not raise the window: its rows tie by keys anyway)
+  }
+  if (enmax) {
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) { const float o = __shfl_xor(mx, m, 64); mx = o > mx ? o : mx; }
+    if ((threadIdx.x & 63) == 0 && mx > 0.f) atomicMax(enmax, __float_as_uint(mx));     // non-negative floats order like their bits
   }
 }
+
+// undecided comparisons: one list segment per sweep workgroup (64 keys x one band of candidates: ~1e-4 of its 120 k pairs per gold
+// land in a window) and per finalize block (256 keys' filter lists), UNC_CAP entries each
+constexpr int UNC_CAP = 1024;
+int fin_blocks(int64_t nq) { return grid_for((nq + 255) / 256, 1024); }
+int64_t unc_sweep_segs(int64_t nq) { return ((nq + UB - 1) / UB) * NBAND; }
+int64_t unc_segs(int64_t nq) { return unc_sweep_segs(nq) + fin_blocks(nq); }
 
 template <typename G>
 int run_fused(FArgs a, int64_t n_gold, int64_t max_golds, hipStream_t st, const char* name) {
   (void)hipFuncSetAttribute((const void*)kg_list_scores_kernel<G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS);
   const unsigned qblocks = (unsigned)((a.nq + UB - 1) / UB);
   const int64_t init_work = n_gold > (a.n_cand * 8) ? n_gold : a.n_cand * 8;
+  hipLaunchKernelGGL(kg_unc_reset_kernel, dim3(grid_for((a.unc_nseg + 256) / 256, 64)), dim3(256), 0, st, a.enmax, a.unc_count, a.unc_nseg);
   hipLaunchKernelGGL(kg_pass_init_kernel, dim3(grid_for((init_work + 255) / 256, 2048)), dim3(256), 0, st, a.counts, n_gold, a.C, a.ldc, G::NCH,
-                     a.n_cand, a.cnorm);
+                     a.n_cand, a.cnorm, a.enmax);
   const int64_t ntiles = (a.n_cand + IB - 1) / IB;
   if constexpr (G::WTAB) hipLaunchKernelGGL((kg_wtab_kernel<G>), dim3((unsigned)ntiles, (unsigned)((a.n_rel + 15) / 16)), dim3(256), 0, st, a);
   a.gscore_out = const_cast<float*>(a.gscore);
@@ -598,7 +766,8 @@ int run_fused(FArgs a, int64_t n_gold, int64_t max_golds, hipStream_t st, const 
   for (a.gbase = 0; a.gbase < max_golds; a.gbase += GS)     // typical link-prediction keys have one to three golds: one launch; the
     hipLaunchKernelGGL((kg_count_mc_kernel<G>), dim3(NBAND, qblocks), dim3(NW * 64), G::LDS, st, a);   // workgroups of a later one whose
   a.gbase = 0;                                                                                          // keys have no such golds exit
-  hipLaunchKernelGGL(kg_rank_finalize_kernel, dim3(grid_for((a.nq + 255) / 256, 1024)), dim3(256), 0, st, a, n_gold);
+  hipLaunchKernelGGL(kg_rank_finalize_kernel, dim3(fin_blocks(a.nq)), dim3(256), 0, st, a, n_gold);
+  if (a.ktol) hipLaunchKernelGGL(kg_unc_resolve_kernel, dim3(grid_for(a.unc_nseg, 4096)), dim3(256), 0, st, a);
   return check_launch(name);
 }
 
@@ -615,6 +784,7 @@ int dispatch_fused(const FArgs& a, int d, int64_t n_gold, int64_t max_golds, hip
 }
 
 size_t pad256(size_t n) { return (n + 255) & ~(size_t)255; }
+
 
 // mode 2's table: pitch (whole candidate stages) and whether it is used at all -- offsets stay 32-bit, the table below 1 GiB
 int64_t wtab_pitch(int64_t n_cand) { return ((n_cand + IB - 1) / IB) * IB; }
@@ -640,7 +810,8 @@ extern "C" size_t ktup_eval_kg_ranks_fused_workspace_bytes(int model, int d, int
                                                            int64_t n_rel) {
   if (d <= 0 || nq <= 0 || n_cand <= 0) return 0;
   return ktup::pad256(ktup_eval_kg_workspace_bytes(d, nq)) + ktup::pad256((size_t)(n_gold > 0 ? n_gold : 1) * 4) * 2 +
-         ktup::pad256((size_t)(n_filt > 0 ? n_filt : 1) * 4) + ktup::pad256((size_t)n_cand * 4) +
+         ktup::pad256((size_t)(n_filt > 0 ? n_filt : 1) * 4) + ktup::pad256((size_t)n_cand * 4) + ktup::pad256((size_t)nq * 4) + 256 +
+         ktup::pad256((size_t)(ktup::unc_segs(nq) + 1) * 4) + ktup::pad256((size_t)ktup::unc_segs(nq) * ktup::UNC_CAP * sizeof(ktup::Unc)) +
          (ktup::wtab_on(model, n_cand, n_rel) ? ktup::pad256((size_t)n_rel * ktup::wtab_pitch(n_cand) * 4) : 0);
 }
 
@@ -667,15 +838,24 @@ extern "C" int ktup_eval_kg_ranks_fused(int model, const float* E, int64_t lde, 
   int32_t* counts = reinterpret_cast<int32_t*>(p); p += pad256((size_t)n_gold * 4);
   float* fscore = reinterpret_cast<float*>(p); p += pad256((size_t)(n_filt > 0 ? n_filt : 1) * 4);
   float* cnorm = reinterpret_cast<float*>(p); p += pad256((size_t)n_cand * 4);
+  float* ktol = reinterpret_cast<float*>(p); p += pad256((size_t)nq * 4);
+  uint32_t* enmax = reinterpret_cast<uint32_t*>(p); p += 256;
+  int32_t* unc_count = reinterpret_cast<int32_t*>(p); p += pad256((size_t)(unc_segs(nq) + 1) * 4);
+  Unc* unc = reinterpret_cast<Unc*>(p); p += pad256((size_t)unc_segs(nq) * UNC_CAP * sizeof(Unc));
   if (int e = kg_query_prep(model, E, lde, R, ldr, Nrm, ldn, d, q, r, nq, head, QW, st, name)) return e;
   FArgs a{};
   a.QW = QW; a.dq = (d + 3) & ~3; a.C = C; a.ldc = ldc; a.nq = nq; a.n_cand = n_cand; a.descending = descending;
   a.gold_off = gold_off; a.gold_ids = gold_ids; a.gscore = gscore; a.filt_off = filt_off; a.filt_ids = filt_ids; a.fscore = fscore;
   a.counts = counts; a.ranks = ranks; a.cnorm = cnorm; a.dbg = opt_dbg_eval();
+  a.model = model; a.d = d; a.head = head; a.E = E; a.lde = lde; a.R = R; a.ldr = ldr; a.q = q; a.rel = r; a.Nrm = Nrm; a.ldn = ldn;
+  a.enmax = enmax; a.unc = unc; a.unc_count = unc_count; a.unc_cap = UNC_CAP; a.unc_nseg = (int)unc_segs(nq);
+  a.unc_sweep_segs = (int)unc_sweep_segs(nq);
+  a.kappa0 = 2.f * (float)(d + 8) * 5.9604645e-8f;             // 2 (d + 8) 2^-24
+  a.ktol = (mfma && opt_kg_exact()) ? ktol : nullptr;          // the VALU routes score by the reference's own formula: no window
   if (!mfma) {
     // L1, widths without a matrix-core instantiation, keys with more than 8 golds: the pair kernels of ktup_eval.hip score the tiles
     // on the VALU and count where the scores are made (no score matrix either); list scores by the same function
-    hipLaunchKernelGGL(kg_pass_init_kernel, dim3(grid_for((n_gold + 255) / 256, 2048)), dim3(256), 0, st, counts, n_gold, C, ldc, 0, (int64_t)0, cnorm);
+    hipLaunchKernelGGL(kg_pass_init_kernel, dim3(grid_for((n_gold + 255) / 256, 2048)), dim3(256), 0, st, counts, n_gold, C, ldc, 0, (int64_t)0, cnorm, (uint32_t*)nullptr);
     const bool tab = wtab_on(model, n_cand, n_rel);   // (the workspace holds the table exactly then)
     if (int e = kg_valu_counts(model, QW, d, C, ldc, n_cand, nq, l1, descending, gold_off, gold_ids, filt_off, filt_ids, gscore, fscore, counts,
                                tab ? r : nullptr, Nrm, ldn, n_rel, tab ? reinterpret_cast<float*>(p) : nullptr, wtab_pitch(n_cand), st, name))

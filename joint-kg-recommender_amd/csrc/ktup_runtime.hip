@@ -49,6 +49,7 @@ Option g_opts[] = {
     {"eval_nsplit", "KTUP_EVAL_NSPLIT", {env_int("KTUP_EVAL_NSPLIT", 0)}},  // > 0: catalogue splits of the one-sweep rec evaluation (0: by occupancy, at most 8)
     {"dbg_eval", "", {0}},                                                  // bits switch phases of the rec evaluation sweep off
     {"kg_wtab", "KTUP_KG_WTAB", {env_int("KTUP_KG_WTAB", 1)}},              // 0: the fused TransH link-prediction pass computes w.e in the sweep instead of once per (relation, candidate)
+    {"kg_exact", "KTUP_KG_EXACT", {env_int("KTUP_KG_EXACT", 1)}},            // 0: the fused squared-L2 link-prediction pass ranks by its own fp32 scores alone (no fp64 referee near the golds)
     {"wide_waves", "KTUP_WIDE_WAVES", {env_int("KTUP_WIDE_WAVES", 8)}},     // d = 256 coordinate-sliced K5-K7 backward / fused step: waves that share a 16-pair tile (8, or 4: the round-3 form)
 };
 Option* find(const char* name) {
@@ -69,7 +70,8 @@ int opt_dbg_noflush() { return g_opts[8].value.load(std::memory_order_relaxed); 
 int opt_eval_nsplit() { return g_opts[9].value.load(std::memory_order_relaxed); }
 int opt_dbg_eval() { return g_opts[10].value.load(std::memory_order_relaxed); }
 int opt_kg_wtab() { return g_opts[11].value.load(std::memory_order_relaxed); }
-int opt_wide_waves() { return g_opts[12].value.load(std::memory_order_relaxed); }
+int opt_kg_exact() { return g_opts[12].value.load(std::memory_order_relaxed); }
+int opt_wide_waves() { return g_opts[13].value.load(std::memory_order_relaxed); }
 
 // A library-owned second stream for work that depends only on a call's INPUTS (the counting sorts of the segment reductions)
 // while the caller's stream runs the kernel that produces the data: fork_side makes it wait for everything enqueued on `st` so far,

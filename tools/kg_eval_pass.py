@@ -43,12 +43,20 @@ def main():
             out = D.kg_eval_pass(FL, score_fn, batches, gold, [filt], False, want_rows=False, **kw)
         return 1e3 * (time.perf_counter() - t0) / reps, out
 
+    from jTransUP.hip import lib as L
     walk_ms, a = timed()
     pass_ms, b = timed(rank_fn=rank_fn)
-    assert np.array_equal(a, b)
+    # squared L2: the pass decides comparisons near a gold in fp64 (option kg_exact); the walk ranks by its fp32 score matrix alone
+    differ = int((a[:, 1] != b[:, 1]).sum())
+    assert differ <= a.shape[0] // 100 and np.abs(a[:, 1] - b[:, 1]).max() <= 2
+    old = L.set_option('kg_exact', 0)
+    raw_ms, c = timed(rank_fn=rank_fn)
+    L.set_option('kg_exact', old)
+    assert np.array_equal(a, c)
     print('KG evaluation pass, %d keys x %d entities (%s%s, d=%d), %d gold entries:' % (len(keys), ne, model, ' L1' if l1 else '', d, a.shape[0]))
     print('  walk over %d batches (K13 + K18 per batch from python): %8.2f ms per pass   mean rank %.2f' % (len(batches), walk_ms, a[:, 1].mean()))
-    print('  whole pass behind one call (ktup_eval_kg_ranks):        %8.2f ms per pass   mean rank %.2f' % (pass_ms, b[:, 1].mean()))
+    print('  whole pass behind one call (ktup_eval_kg_ranks):        %8.2f ms per pass   mean rank %.2f   (%d ranks moved by the fp64 referee near a gold)' % (pass_ms, b[:, 1].mean(), differ))
+    print('  the same with option kg_exact = 0 (fp32 scores alone):   %8.2f ms per pass   mean rank %.2f' % (raw_ms, c[:, 1].mean()))
 
 
 if __name__ == '__main__':

@@ -475,8 +475,10 @@ def transr_d256_case():
     save('transr_d256', **out)
 
 
-def train_step_cases():
-    """G4 (post-optimizer-step tables) + G8 (joint schedule), SURVEY.md 8(c): the step bodies of the three drivers replayed line by
+def train_step_cases(d=64, out_name='train_steps', seeds=(47, 53), ktup_cases=None, tup_cases=None, kg_cases=None):
+    """(d, out_name, seeds and the case filters: the defaults write train_steps.npz exactly as before; train_steps_d100 / _d256 are the
+    same step bodies at BASELINE's widths -- the fused step kernels are per-width templates -- with their own draws.)
+    G4 (post-optimizer-step tables) + G8 (joint schedule), SURVEY.md 8(c): the step bodies of the three drivers replayed line by
     line on the reference's own modules -- knowledgable_recommendation.py:335-403 (jtransup: rec and kg steps under the joint
     schedule of :209,320), item_recommendation.py:160-192 (transup, soft and ST-Gumbel gate), knowledge_representation.py:176-216
     (transe / transh) -- with the reference's own ModelTrainer (utils/trainer.py:20-81: optimizer construction with
@@ -491,11 +493,11 @@ def train_step_cases():
     real_zero_grad = torch.optim.Optimizer.zero_grad
     torch.optim.Optimizer.zero_grad = lambda self, set_to_none=False: real_zero_grad(self, set_to_none=False)      # shim 5
     clip = getattr(torch.nn.utils, 'clip_grad_norm', None) or torch.nn.utils.clip_grad_norm_
-    rng = np.random.RandomState(47)
-    gen = torch.Generator().manual_seed(53)
+    rng = np.random.RandomState(seeds[0])
+    gen = torch.Generator().manual_seed(seeds[1])
     e_vocab, i_vocab, kg2i, new_map, e_remap, i_remap, n_aligned = make_alignment(rng)
     i_map = IntKeyDict(i_remap)
-    d, NSTEP = 64, 3
+    NSTEP = 3
     log = logging.getLogger('goldens'); log.setLevel(logging.ERROR)
     out = {}
 
@@ -568,6 +570,8 @@ def train_step_cases():
         for l2 in (0.0, 1e-5):
             if opt == 'SGD' and l2 == 0.0:
                 continue
+            if ktup_cases is not None and (opt, l2) not in ktup_cases:
+                continue
             m = jtup.jTransUPModel(False, d, NU, NI, NE, NR, i_map, new_map, False, False)
             for k, p in m.named_parameters():
                 p.data.copy_(keep[k])
@@ -598,6 +602,8 @@ def train_step_cases():
         return body
     for gum in (False, True):
         for opt, lr, cmax in (('Adagrad', 0.05, 5.0), ('Adam', 0.01, 0.05)):          # 0.05: a clip that certainly bites
+            if tup_cases is not None and (gum, opt) not in tup_cases:
+                continue
             m = transUP.TransUPModel(False, d, NU, NI, NP_TUP, gum)
             for k, p in m.named_parameters():
                 p.data.copy_(keep[k])
@@ -634,14 +640,17 @@ def train_step_cases():
                 return l + rloss.normLoss(ent) + rloss.normLoss(rel)
             return body
         for opt, lr in (('Adagrad', 0.05), ('Adam', 0.01)):
+            if kg_cases is not None and (name, opt) not in kg_cases:
+                continue
             m = getattr(mod, cls)(False, d, NE, NR)
             for k, p in m.named_parameters():
                 p.data.copy_(keep[k])
             run('%s.%s.' % (name, opt), m, flags(name, opt, 1e-5, lr), [kg_body(b) for b in kg_batches], 5.0)
     torch.optim.Optimizer.zero_grad = real_zero_grad
-    save('train_steps', **out)
-    with open(os.path.join(args.out, 'train_steps.json'), 'w') as f:
-        json.dump({'joint_schedule': sched, 'B': B, 'd': d, 'NP_TUP': NP_TUP}, f, indent=0, sort_keys=True)
+    save(out_name, **out)
+    if out_name == 'train_steps':
+        with open(os.path.join(args.out, 'train_steps.json'), 'w') as f:
+            json.dump({'joint_schedule': sched, 'B': B, 'd': d, 'NP_TUP': NP_TUP}, f, indent=0, sort_keys=True)
 
 
 
@@ -857,6 +866,12 @@ if __name__ == '__main__':
     baseline_cases()
     transr_d256_case()
     train_step_cases()
+    # the same step bodies at BASELINE's widths (configs[1]-[3]: d = 100; config 5: d = 256)
+    train_step_cases(d=100, out_name='train_steps_d100', seeds=(59, 61),
+                     ktup_cases=[('Adagrad', 0.0), ('Adagrad', 1e-5), ('Adam', 0.0), ('Adam', 1e-5)],
+                     tup_cases=[(True, 'Adagrad'), (True, 'Adam'), (False, 'Adagrad')], kg_cases=[('transh', 'Adagrad'), ('transh', 'Adam')])
+    train_step_cases(d=256, out_name='train_steps_d256', seeds=(67, 71), ktup_cases=[('Adagrad', 0.0), ('Adam', 1e-5)],
+                     tup_cases=[(False, 'Adagrad')], kg_cases=[('transh', 'Adagrad')])
     eval_pass_cases()
     fm_cases()
     kg_pass_cases()

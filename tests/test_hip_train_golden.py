@@ -3,8 +3,15 @@ clip + optimizer, HIP-graph replay) -- against goldens produced by the REFERENCE
 (tests/golden/make_goldens.py train_step_cases: knowledgable_recommendation.py:335-403, item_recommendation.py:160-192,
 knowledge_representation.py:176-216, utils/trainer.py:63-81): per-step losses, and every table after the last step.  Not a
 comparison with this repo's own autograd route (tests/test_fast_train.py does that): the other end of this one is the reference.
-Tolerance: 1e-4 on the tables (north_star), with the same stray-element allowance as test_fast_train for Adagrad / Adam elements
-whose accumulated gradient is itself rounding noise."""
+Three worlds: d = 64 (train_steps.npz: every optimizer), and BASELINE's widths d = 100 (configs[1]-[3]) and d = 256 (config 5) --
+the fused step kernels are per-width templates, so each width is pinned to the reference on its own.
+Tolerance: 1e-4 on the tables (north_star): |got - want| <= 2e-5 + 1e-4 |want| for EVERY element, with one exemption that is named,
+counted and printed per table: an element whose second-moment state is tiny -- Adagrad's sum < 1e-5 (accumulated |g| < 3e-3) or
+Adam's exp_avg_sq < 1e-10 (|g| < 3e-4 after a few steps) -- where the gradient is the small difference of O(1) summands and
+lr * m / (sqrt(v) + eps) turns its last bits into a visible step.  Such elements may leave the band (at most 0.2 % of a table, none by
+more than 5e-4).  The thresholds come from the offenders themselves: with the state cut at 1e-12 five of the 27 cases failed on one
+or two elements each, of state 3e-12 (Adam), 1.5e-7, 6e-7, 1.3e-6, 2.1e-6 (Adagrad; errors 1.4e-5 .. 1.4e-4) and one of state 1.4e-3
+whose error 1.41e-5 sat just outside a 1e-5 floor."""
 import json
 import logging
 import os
@@ -16,12 +23,21 @@ import torch
 pytestmark = pytest.mark.gpu
 DEV = torch.device('cuda', 0)
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
-NU, NI, NE, NR, NP_TUP, B, D = 37, 45, 53, 7, 5, 48, 64
+NU, NI, NE, NR, NP_TUP, B = 37, 45, 53, 7, 5, 48
+FILES = {64: 'train_steps.npz', 100: 'train_steps_d100.npz', 256: 'train_steps_d256.npz'}
+_CACHE = {}
 
 
-@pytest.fixture(scope='module')
-def G():
-    return np.load(os.path.join(GOLDEN, 'train_steps.npz')), json.load(open(os.path.join(GOLDEN, 'train_steps.json')))
+def _golden(d):
+    if d not in _CACHE:
+        _CACHE[d] = np.load(os.path.join(GOLDEN, FILES[d]))
+    return _CACHE[d]
+
+
+def test_joint_schedule_golden_is_the_drivers_rule():
+    sched = json.load(open(os.path.join(GOLDEN, 'train_steps.json')))['joint_schedule']
+    for jr, want in sched.items():
+        assert [bool(s % 10 < 10 * float(jr)) for s in range(30)] == want
 
 
 def _flags(tmp_path, model_type, opt, lr, l2, clip, extra=()):
@@ -39,30 +55,49 @@ def _load(model, g, prefix):
     model.load_state_dict(sd)
 
 
-def _compare(model, g, tag, opt):
-    for k, v in model.state_dict().items():
+def _compare(model, g, tag, opt, trainer):
+    """Every element inside 2e-5 + 1e-4 |want|, except -- counted and reported per table -- those whose second-moment state is tiny
+    (see the module docstring); even those stay within 5e-4.  Plain SGD has no such state: no exemption."""
+    trainer.fused._flush_steps() if trainer.fused is not None else None
+    state_key = {'Adam': 'exp_avg_sq', 'Adagrad': 'sum'}.get(opt)
+    report = []
+    for (k, v), p in zip(model.state_dict().items(), model.parameters()):
         want = torch.from_numpy(g[tag + 'final.' + k])
         got = v.detach().cpu()
         err = (got - want).abs()
-        bad = err > 1e-5 + 1e-4 * want.abs()
-        # a last-bit difference of an accumulated gradient becomes visible where Adagrad's sum / Adam's v is ~eps^2
-        assert float(bad.float().mean()) <= (2e-2 if opt == 'Adam' else 2e-3) and float(err.max()) <= 5e-4, \
-            '%s: %d of %d elements off, max %.3g' % (k, int(bad.sum()), bad.numel(), float(err.max()))
+        bad = err > 2e-5 + 1e-4 * want.abs()
+        exempt = torch.zeros_like(bad)
+        if state_key is not None:
+            st = trainer.optimizer.state.get(p, {})
+            if state_key in st:
+                exempt = st[state_key].detach().cpu() < (1e-10 if opt == 'Adam' else 1e-5)
+        report.append('%s: %d of %d with a tiny state, %d of them outside the band' % (k, int(exempt.sum()), exempt.numel(), int((bad & exempt).sum())))
+        assert int((bad & exempt).sum()) <= max(2, exempt.numel() // 500), report[-1]
+        off = bad & ~exempt
+        detail = ''
+        if int(off.sum()) and state_key is not None and state_key in trainer.optimizer.state.get(p, {}):
+            sv = trainer.optimizer.state[p][state_key].detach().cpu()[off]
+            detail = ' states of the offenders: %s errors: %s' % (sv[:8].tolist(), err[off][:8].tolist())
+        assert int(off.sum()) == 0 and float(err.max()) <= 5e-4, \
+            '%s: %d of %d well-conditioned elements off, max %.3g (%d exempt)%s' % (k, int(off.sum()), bad.numel(), float(err.max()),
+                                                                                   int(exempt.sum()), detail)
+    print(tag, '; '.join(report))
 
 
 def _t(g, key):
     return torch.from_numpy(g[key]).to(DEV)
 
 
-@pytest.mark.parametrize('opt,lr,l2', [('Adagrad', 0.05, 0.0), ('Adagrad', 0.05, 1e-5), ('Adam', 0.01, 0.0), ('Adam', 0.01, 1e-5),
-                                       ('SGD', 0.05, 1e-5)])
-def test_joint_stepper_reproduces_the_reference_steps(tmp_path, G, opt, lr, l2):
+@pytest.mark.parametrize('D,opt,lr,l2', [(64, 'Adagrad', 0.05, 0.0), (64, 'Adagrad', 0.05, 1e-5), (64, 'Adam', 0.01, 0.0), (64, 'Adam', 0.01, 1e-5),
+                                         (64, 'SGD', 0.05, 1e-5), (100, 'Adagrad', 0.05, 0.0), (100, 'Adagrad', 0.05, 1e-5), (100, 'Adam', 0.01, 0.0),
+                                         (100, 'Adam', 0.01, 1e-5), (256, 'Adagrad', 0.05, 0.0), (256, 'Adam', 0.01, 1e-5)])
+def test_joint_stepper_reproduces_the_reference_steps(tmp_path, D, opt, lr, l2):
     """KTUP: rec, rec, kg, rec, kg, kg -- the fused rec and kg step kernels + ktup_optim_clip_step, replayed from graphs from the
     third step of each kind on."""
     from jTransUP.models import jTransUP as jt
     from jTransUP.utils.fast_train import JointStepper
     from jTransUP.utils.trainer import ModelTrainer
-    g, _ = G
+    g = _golden(D)
     FLAGS = _flags(tmp_path, 'jtransup', opt, lr, l2, 5.0, ['-noshare_embeddings', '-kg_lambda', str(float(g['ktup.kg_lambda'][0]))])
     i2e = g['ktup.item2ent']
     i_map = {i: i for i in range(NI)}
@@ -78,17 +113,18 @@ def test_joint_stepper_reproduces_the_reference_steps(tmp_path, G, opt, lr, l2):
         loss = st.rec_step(b['u'], b['pi'], b['ni']) if is_rec else st.kg_step(b['ph'], b['pt'], b['pr'], b['nh'], b['nt'], b['pr'])
         np.testing.assert_allclose(float(loss), g[tag + 'losses'][s], rtol=1e-4)
     assert st.fused_step and tr.step == 6
-    _compare(m, g, tag, opt)
+    _compare(m, g, tag, opt, tr)
 
 
-@pytest.mark.parametrize('gum', [False, True])
-@pytest.mark.parametrize('opt,lr', [('Adagrad', 0.05), ('Adam', 0.01)])
-def test_rec_stepper_reproduces_the_reference_steps(tmp_path, G, gum, opt, lr):
+@pytest.mark.parametrize('D,gum,opt,lr', [(64, False, 'Adagrad', 0.05), (64, False, 'Adam', 0.01), (64, True, 'Adagrad', 0.05), (64, True, 'Adam', 0.01),
+                                          (100, True, 'Adagrad', 0.05), (100, True, 'Adam', 0.01), (100, False, 'Adagrad', 0.05),
+                                          (256, False, 'Adagrad', 0.05)])
+def test_rec_stepper_reproduces_the_reference_steps(tmp_path, D, gum, opt, lr):
     """TUP, soft gate and ST-Gumbel gate (the reference's recorded uniforms fed through the parity hook), three steps."""
     from jTransUP.models import transUP as tu
     from jTransUP.utils.fast_train import RecStepper
     from jTransUP.utils.trainer import ModelTrainer
-    g, _ = G
+    g = _golden(D)
     tag = 'tup.%s.%s.' % ('hard' if gum else 'soft', opt)
     FLAGS = _flags(tmp_path, 'transup', opt, lr, 1e-5, float(g[tag + 'clip'][0]), ['-num_preferences', str(NP_TUP)] + (['-use_st_gumbel'] if gum else []))
     m = tu.TransUPModel(False, D, NU, NI, NP_TUP, gum)
@@ -102,16 +138,17 @@ def test_rec_stepper_reproduces_the_reference_steps(tmp_path, G, gum, opt, lr):
         loss = st.rec_step(b['u'], b['pi'], b['ni'])
         np.testing.assert_allclose(float(loss), g[tag + 'losses'][s], rtol=1e-4)
     assert st.fused_step
-    _compare(m, g, tag, opt)
+    _compare(m, g, tag, opt, tr)
 
 
-@pytest.mark.parametrize('name', ['transe', 'transh'])
-@pytest.mark.parametrize('opt,lr', [('Adagrad', 0.05), ('Adam', 0.01)])
-def test_kg_stepper_reproduces_the_reference_steps(tmp_path, G, name, opt, lr):
+@pytest.mark.parametrize('D,name,opt,lr', [(64, 'transe', 'Adagrad', 0.05), (64, 'transe', 'Adam', 0.01), (64, 'transh', 'Adagrad', 0.05),
+                                           (64, 'transh', 'Adam', 0.01), (100, 'transh', 'Adagrad', 0.05), (100, 'transh', 'Adam', 0.01),
+                                           (256, 'transh', 'Adagrad', 0.05)])
+def test_kg_stepper_reproduces_the_reference_steps(tmp_path, D, name, opt, lr):
     from jTransUP.models import transE, transH
     from jTransUP.utils.fast_train import KGStepper
     from jTransUP.utils.trainer import ModelTrainer
-    g, _ = G
+    g = _golden(D)
     FLAGS = _flags(tmp_path, name, opt, lr, 1e-5, 5.0)
     m = (transE.TransEModel if name == 'transe' else transH.TransHModel)(False, D, NE, NR)
     _load(m, g, name + '.init.')
@@ -123,4 +160,4 @@ def test_kg_stepper_reproduces_the_reference_steps(tmp_path, G, name, opt, lr):
         loss = st.kg_step(b['ph'], b['pt'], b['pr'], b['nh'], b['nt'], b['pr'])
         np.testing.assert_allclose(float(loss), g[tag + 'losses'][s], rtol=1e-4)
     assert st.fused_step
-    _compare(m, g, tag, opt)
+    _compare(m, g, tag, opt, tr)

@@ -272,6 +272,32 @@ TUP_NAMES = ['user_embeddings.weight', 'item_embeddings.weight', 'pref_embedding
 STEP_TOL = dict(rtol=2e-5, atol=2e-6)        # several optimizer steps of fp32 sums in a different association order
 
 
+@pytest.mark.parametrize('fname,opt,lr,l2', [('train_steps_d100.npz', 'Adagrad', 0.05, 0.0), ('train_steps_d100.npz', 'Adam', 0.01, 1e-5),
+                                             ('train_steps_d256.npz', 'Adagrad', 0.05, 0.0), ('train_steps_d256.npz', 'Adam', 0.01, 1e-5)])
+def test_ktup_training_steps_golden_at_baseline_widths(fname, opt, lr, l2):
+    """The same six KTUP steps at d = 100 (BASELINE configs[1]-[3]) and d = 256 (config 5): the oracle is pinned at the widths the
+    fused step kernels are instantiated for, not only at the toy world's d = 64."""
+    g = np.load(os.path.join(GOLDEN, fname))
+    W = _params(g, 'ktup.init.', KTUP_NAMES)
+    i2e = T(g['ktup.item2ent'])
+    optim = O.make_optimizer(W, opt, lr, l2)
+    tag = 'ktup.%s.l2_%g.' % (opt, l2)
+    kg_lambda, margin = float(g['ktup.kg_lambda'][0]), float(g['ktup.margin'][0])
+    for s, is_rec in enumerate(g['ktup.kinds']):
+        b = {k: T(g['ktup.batch%d.%s' % (s, k)]) for k in ('u', 'pi', 'ni', 'ph', 'pt', 'pr', 'nh', 'nt')}
+        if is_rec:
+            fn = lambda: O.ktup_rec_step_loss(*W, i2e, b['u'], b['pi'], b['ni'])
+        else:
+            fn = lambda: O.kg_step_loss(W[2], W[5], W[6], b['ph'], b['pt'], b['pr'], b['nh'], b['nt'], b['pr'], margin=margin, kg_lambda=kg_lambda)
+        loss, norm = O.train_step(W, optim, fn, 5.0, pad_row_of=W[2])
+        np.testing.assert_allclose(loss, g[tag + 'losses'][s], rtol=2e-5)
+        np.testing.assert_allclose(norm, g[tag + 'gradnorms'][s], rtol=2e-5)
+    for w, n in zip(W, KTUP_NAMES):
+        got, want = w.data, T(g[tag + 'final.' + n])
+        bad = (got - want).abs() > 2e-5 + 1e-4 * want.abs()              # (the band of tests/test_hip_train_golden.py)
+        assert int(bad.sum()) <= max(2, bad.numel() // 500), (n, int(bad.sum()))
+
+
 def test_joint_schedule_golden():
     """G8: which branch runs at step s (knowledgable_recommendation.py:209,320), as the reference's own expression decided it."""
     _, J = _steps_fixture()

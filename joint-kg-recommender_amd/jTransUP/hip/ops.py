@@ -171,6 +171,24 @@ def score_transr(E, R, M, h, t, r, l1):
 
 
 # ------------------------------------------------------------------------------------------ K5-K7 TUP / KTUP
+# Any -embedding_size (models/base.py:52 takes any integer): the TUP / KTUP kernels read rows as 16-byte chunks, so a width that is
+# not a multiple of 4 is staged with a zero tail -- zero coordinates add nothing to a logit, a projection, a distance or a gradient of
+# the real ones.  The staging is a torch pad (its backward slices the gradients back): whole tables for the scoring calls, the
+# queried user rows and the catalogue for evaluation.  The arithmetic stays in the HIP kernels.
+def _pad4(t):
+    if t is None or t.shape[1] % 4 == 0:
+        return t
+    return torch.nn.functional.pad(t, (0, (-t.shape[1]) % 4))
+
+
+def _pad_users(U, u):
+    """(zero-padded rows U[u], ids 0 .. len(u) - 1) for a user table whose width is not a multiple of 4; (U, u) otherwise."""
+    if U.shape[1] % 4 == 0:
+        return U, u
+    u = _ids('u_ids', u, _dev(_table('user table', U)))
+    return _pad4(U.index_select(0, u)), torch.arange(u.numel(), dtype=torch.int64, device=U.device)
+
+
 def pref_workspace(pref, pref_norm, rel=None, norm=None):
     """Mixed, pre-scaled preference tables (ktup_pref_prepare) for the CURRENT table contents.
 
@@ -186,7 +204,8 @@ def pref_workspace(pref, pref_norm, rel=None, norm=None):
     P, d = pref.shape
     nbytes = L.load().ktup_pref_workspace_bytes(d, P)
     if nbytes == 0:
-        raise L.KtupError('TUP/KTUP kernels need embedding_size %% 4 == 0 and <= 256 (got %d)' % d)
+        raise L.KtupError('TUP / KTUP: -embedding_size %d is beyond the kernels\' 256 columns (models/base.py checks the flag)' % d
+                          if d > 256 else 'TUP / KTUP kernels take rows of whole 16-byte chunks (ops stages other widths with a zero tail); got d=%d' % d)
     ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
     L.call('ktup_pref_prepare', _p(pref), _p(pref_norm), _p(rel), _p(norm), pref.stride(0), P, d, _p(ws), _stream(dev))
     return ws
@@ -263,6 +282,8 @@ def score_tup(U, I, pref, pref_norm, u, i, l1, gumbel_mode=GUMBEL_OFF, uniform=N
     """transUP.py:69-82 (forward) with getPreferences / st_gumbel_softmax fused (transUP.py:105-170).
     `ws`: a pref_workspace(...) of the CURRENT table contents, to share one ktup_pref_prepare between several calls
     (pos / neg batches of a step); None prepares one here."""
+    if pref.shape[1] % 4:
+        U, I, pref, pref_norm, ws = _pad4(U), _pad4(I), _pad4(pref), _pad4(pref_norm), None
     return _ScorePref.apply(U, I, None, pref, pref_norm, None, None, None, u, i, l1, gumbel_mode, uniform, seed, offset, -1, ws)
 
 
@@ -270,6 +291,8 @@ def score_ktup(U, I, E, pref, pref_norm, rel, norm, item2ent, u, i, l1, gumbel_m
                offset=0, ent_pad=-1, ws=None):
     """jTransUP.py:122-143 (is_rec branch) with paddingItems replaced by the int32 `item2ent` device table.  `ws` as in
     score_tup."""
+    if pref.shape[1] % 4:
+        U, I, E, pref, pref_norm, rel, norm, ws = _pad4(U), _pad4(I), _pad4(E), _pad4(pref), _pad4(pref_norm), _pad4(rel), _pad4(norm), None
     return _ScorePref.apply(U, I, E, pref, pref_norm, rel, norm, item2ent, u, i, l1, gumbel_mode, uniform, seed, offset, ent_pad,
                             ws)
 
@@ -528,6 +551,7 @@ class PreparedItems(object):
 
 @torch.no_grad()
 def eval_pref_items(I, E, pref, pref_norm, rel, norm, item2ent):
+    I, E, pref, pref_norm, rel, norm = (_pad4(t) for t in (I, E, pref, pref_norm, rel, norm))
     dev = _dev(_table('item table', I))
     ni = I.shape[0]
     P, d = pref.shape
@@ -541,6 +565,9 @@ def eval_pref_items(I, E, pref, pref_norm, rel, norm, item2ent):
 
 @torch.no_grad()
 def _eval_pref(U, I, E, pref, pref_norm, rel, norm, item2ent, u, l1, gumbel_mode, uniform, seed, offset, items=None):
+    if pref.shape[1] % 4:
+        U, u = _pad_users(U, u)
+        I, E, pref, pref_norm, rel, norm = (_pad4(t) for t in (I, E, pref, pref_norm, rel, norm))
     dev = _dev(_table('user table', U)); _table('item table', I)
     u = _ids('u_ids', u, dev)
     nq, ni = u.numel(), I.shape[0]
@@ -585,6 +612,7 @@ def eval_pref_topk(U, u, items, l1, topn, filt_off=None, filt_ids=None, with_sco
     L1 and other widths: the pair kernel's arithmetic swept with the top-n in its epilogue (the per-batch scores' bits).  -> int32
     (len(u), topn) ids (-1 padded) [, scores], or None when no sweep covers the shape (topn > 16, very wide rows): keep eval_tup /
     eval_ktup + topk_filtered."""
+    U, u = _pad_users(U, u)
     dev = _dev(_table('user table', U))
     u = _ids('u_ids', u, dev)
     nq, d, P = u.numel(), items.d, items.P
@@ -610,6 +638,7 @@ def eval_pref_topk_hard(U, u, items, l1, topn, gumbel_mode, uniform=None, seed=0
     for the same noise source over ALL users of `u` at once (pair (b, j) draws at ((b n_items + j) P + p) + offset), L1 or squared
     L2, with the filtered top-n taken where the scores are made.  -> int32 (len(u), topn) ids (-1 padded) [, scores]; None when
     topn > 16 or the library declines the shape (keep eval_* + topk_filtered)."""
+    U, u = _pad_users(U, u)
     dev = _dev(_table('user table', U))
     u = _ids('u_ids', u, dev)
     nq, d, P, ni = u.numel(), items.d, items.P, items.n_items

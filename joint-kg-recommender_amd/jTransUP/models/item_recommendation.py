@@ -46,7 +46,8 @@ def train_loop(FLAGS, model, trainer, train_dataset, eval_datasets, user_total, 
     # training data and the negative sampling on the device (-device_sampling)
     stepper = feed = sampler = None
     if D.USE_CUDA and FLAGS.model_type in ('transup', 'bprmf') and trainer.fused is not None \
-            and os.environ.get('KTUP_FAST_TRAIN', '1') != '0':
+            and (FLAGS.model_type == 'bprmf' or FLAGS.embedding_size % 4 == 0) \
+            and os.environ.get('KTUP_FAST_TRAIN', '1') != '0':             # (a TUP width that is not a multiple of 4: the autograd route)
         from jTransUP.utils.fast_train import DeviceFeeder, RecStepper
         stepper = RecStepper(model, trainer, FLAGS, FLAGS.batch_size)
         logger.info('GPU-resident training step enabled (KTUP_FAST_TRAIN=0 selects the autograd route).')

@@ -113,6 +113,7 @@ def train_loop(FLAGS, model, trainer, rating_train_dataset, triple_train_dataset
         logger.info('Row-sharded training step enabled (-shard_tables): rank %d of %d owns rows r %% %d == %d of the user / item / entity tables.'
                     % (stepper.rank, stepper.world, stepper.world, stepper.rank))
     elif D.USE_CUDA and FLAGS.model_type == 'jtransup' and not FLAGS.share_embeddings and trainer.fused is not None \
+            and FLAGS.embedding_size % 4 == 0 \
             and os.environ.get('KTUP_FAST_TRAIN', '1') != '0':
         from jTransUP.utils.fast_train import DeviceFeeder, JointStepper
         stepper = JointStepper(model, trainer, FLAGS, FLAGS.batch_size)

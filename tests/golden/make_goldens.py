@@ -128,7 +128,7 @@ def score_cases():
     i_map = IntKeyDict(i_remap)
     pad = NE
 
-    for d in (64, 100, 36, 256):          # 256 (config 5's size) last: the earlier files keep their random draws
+    for d in (64, 100, 36, 256, 50):      # 256 (config 5's size), then 50 (not a multiple of 4) last: the earlier files keep their random draws
         out = {}
         u = torch.from_numpy(rng.randint(0, NU, B)).long()
         pi = torch.from_numpy(rng.randint(0, NI, B)).long()

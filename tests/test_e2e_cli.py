@@ -263,3 +263,24 @@ def test_joint_cli_shard_tables_torchrun(dataset):
     for (ra, ka), (rb, kb) in zip(_loss_lines(log)[1:], _loss_lines(log0)[1:]):
         assert abs(ra - rb) <= 2e-3 * max(1.0, abs(ra)) and abs(ka - kb) <= 2e-3 * max(1.0, abs(ka))
     assert all(abs(x - y) <= 0.03 for a, b in zip(_metric_rows(log), _metric_rows(log0)) for x, y in zip(a, b))
+
+
+@pytest.mark.parametrize('script,extra', [
+    ('run_item_recommendation.py', ['-model_type', 'transup', '-num_preferences', '6', '-rec_test_files', 'valid.dat']),
+    ('run_knowledgable_recommendation.py', ['-model_type', 'jtransup', '-rec_test_files', 'valid.dat', '-kg_test_files', 'valid.dat',
+                                            '-joint_ratio', '0.7', '-noshare_embeddings']),
+])
+def test_cli_any_embedding_size(dataset, script, extra):
+    """-embedding_size 50: the reference takes any integer (models/base.py:52); the TUP / KTUP kernels read 16-byte chunks, so the
+    rows are staged with a zero tail and training takes the autograd route.  -embedding_size 300 is refused by name for the models
+    whose preference gate has no layout beyond 256 columns (there is no CPU path to fall back to)."""
+    log, _ = run_cli(script, dataset, 'odd-' + extra[1], extra + ['-embedding_size', '50'])
+    losses = [float(x) for x in re.findall(r'train loss:(\d+\.\d+)', log)]
+    assert len(losses) >= 2 and all(l == l and l < 1e4 for l in losses)
+    assert len(re.findall(r'f1:\d\.\d+', log)) >= 3
+    data = str(dataset)
+    cmd = [sys.executable, os.path.join(PKG, script), '-data_path', data, '-log_path', os.path.join(data, 'log'), '-dataset', 'ml1m',
+           '-experiment_name', 'wide-' + extra[1], '-nohas_visualization', '-batch_size', '32', '-training_steps', '5', '-seed', '3'] + extra + \
+          ['-embedding_size', '300']
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and '-embedding_size 300' in (r.stdout + r.stderr)

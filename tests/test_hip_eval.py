@@ -76,7 +76,8 @@ def world(seed, nu, ni, ne, nr, d):
     return W, i2e, gen
 
 
-@pytest.mark.parametrize('d,ni,nq,npref', [(100, 3240, 70, 20), (64, 130, 33, 4), (128, 1000, 5, 13), (100, 63, 1, 20), (36, 200, 9, 40)])
+@pytest.mark.parametrize('d,ni,nq,npref', [(100, 3240, 70, 20), (64, 130, 33, 4), (128, 1000, 5, 13), (100, 63, 1, 20), (36, 200, 9, 40), (50, 301, 17, 6),
+                                           (7, 40, 5, 3)])     # 50 and 7: widths that are not a multiple of 4 (ops stages them with a zero tail)
 def test_pref_eval_vs_oracle(d, ni, nq, npref):
     """TUP / KTUP all-item scores at the ml1m catalogue size (3240 items) and ragged small shapes, soft and hard gate (40 preferences:
     the hard gate's squared-L2 score takes its two-pass form beyond 32)."""
@@ -930,3 +931,32 @@ def test_fused_rec_pass_replayed_as_a_graph_follows_the_tables(monkeypatch):
     n = len(D._EVAL_GRAPHS)
     D._rec_eval_fused(FL, pass_fn, batches, index, ('other',))
     assert len(D._EVAL_GRAPHS) == n
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('ktup', [False, True])
+@pytest.mark.parametrize('l1', [False, True])
+def test_pref_eval_pass_any_embedding_size(ktup, l1):
+    """-embedding_size 50 (the reference takes any integer, models/base.py:52): the item side prepared once per pass, the per-batch
+    scores and the one-sweep filtered top-n all run on rows staged with a zero tail -- the oracle's scores, and the ids of the
+    matrix route."""
+    d, nu, ni, ne, P, nq, topn = 50, 90, 211, 150, 6, 37, 10
+    W, i2e, gen = world(5, nu, ni, ne, P, d)
+    D = {k: v.to(DEV) for k, v in W.items()}
+    u = torch.randint(0, nu, (nq,), generator=gen)
+    rng = np.random.RandomState(3)
+    filt = [np.sort(rng.choice(ni, size=rng.randint(0, 20), replace=False)).astype(np.int32) for _ in range(nq)]
+    f_off = dv(np.concatenate([[0], np.cumsum([len(x) for x in filt])]).astype(np.int64)); f_ids = dv(np.concatenate(filt).astype(np.int32))
+    i2e_d = i2e.to(DEV, torch.int32)
+    items = ops().eval_pref_items(D['I'], D['E'] if ktup else None, D['P'], D['Pn'], D['R'] if ktup else None, D['Rn'] if ktup else None,
+                                  i2e_d if ktup else None)
+    if ktup:
+        mat = ops().eval_ktup(D['U'], D['I'], D['E'], D['P'], D['Pn'], D['R'], D['Rn'], i2e_d, u.to(DEV), l1, items=items)
+        want = O.eval_ktup_rec(W['U'], W['I'], W['E'], W['P'], W['Pn'], W['R'], W['Rn'], i2e, u, l1)
+    else:
+        mat = ops().eval_tup(D['U'], D['I'], D['P'], D['Pn'], u.to(DEV), l1, items=items)
+        want = O.eval_tup(W['U'], W['I'], W['P'], W['Pn'], u, l1)
+    close(mat, want)
+    ids = ops().topk_filtered(mat, False, topn, f_off, f_ids)
+    got = ops().eval_pref_topk(D['U'], u.to(DEV), items, l1, topn, f_off, f_ids)
+    assert got is not None and torch.equal(got, ids)

@@ -19,7 +19,7 @@ def close(got, want, rtol=1e-4, atol=1e-5):
     np.testing.assert_allclose(got, want, rtol=rtol, atol=atol)
 
 
-@pytest.mark.parametrize('d', [36, 64, 100, 256])
+@pytest.mark.parametrize('d', [36, 50, 64, 100, 256])
 @pytest.mark.parametrize('l1', [False, True])
 def test_full_transh_loss_and_grads_golden(golden, d, l1):
     """marginLoss + orthogonalLoss + normLoss x2 exactly as knowledge_representation.py:189-204, all through HIP."""
@@ -40,7 +40,7 @@ def test_full_transh_loss_and_grads_golden(golden, d, l1):
     close(N.grad, g[tag + 'grad.norm_embeddings.weight'], atol=3e-5)
 
 
-@pytest.mark.parametrize('d', [36, 64, 100, 256])
+@pytest.mark.parametrize('d', [36, 50, 64, 100, 256])
 @pytest.mark.parametrize('gum', [False, True])
 def test_full_tup_loss_and_grads_golden(golden, d, gum):
     """bprLoss(target=-1) + orthogonalLoss(P, Pn) + normLoss(users) + normLoss(items) + normLoss(P), item_recommendation.py:175-180."""

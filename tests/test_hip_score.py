@@ -46,7 +46,7 @@ def t_orth_loss(rel, nrm):
     return torch.sum(torch.sum(nrm * rel, dim=1, keepdim=True) ** 2 / torch.sum(rel ** 2, dim=1, keepdim=True))
 
 
-@pytest.mark.parametrize('d', [36, 64, 100, 256])
+@pytest.mark.parametrize('d', [36, 50, 64, 100, 256])
 def test_bprmf_golden(golden, d):
     g = golden('score_d%d' % d)
     U, I = leaf(g['bprmf.user_embeddings.weight']), leaf(g['bprmf.item_embeddings.weight'])
@@ -58,7 +58,7 @@ def test_bprmf_golden(golden, d):
     close(I.grad, g['bprmf.grad.item_embeddings.weight'], atol=GAT)
 
 
-@pytest.mark.parametrize('d', [36, 64, 100, 256])
+@pytest.mark.parametrize('d', [36, 50, 64, 100, 256])
 @pytest.mark.parametrize('l1', [False, True])
 @pytest.mark.parametrize('name', ['transe', 'transh', 'transr'])
 def test_kg_golden(golden, d, l1, name):
@@ -95,7 +95,7 @@ def test_kg_golden(golden, d, l1, name):
         close(X.grad, g[tag + 'grad.proj_embeddings.weight'], atol=gat)
 
 
-@pytest.mark.parametrize('d', [36, 64, 100, 256])
+@pytest.mark.parametrize('d', [36, 50, 64, 100, 256])
 @pytest.mark.parametrize('l1', [False, True])
 @pytest.mark.parametrize('gum', [False, True])
 def test_tup_golden(golden, d, l1, gum):
@@ -123,7 +123,7 @@ KT = ['user_embeddings', 'item_embeddings', 'ent_embeddings', 'pref_embeddings',
       'norm_embeddings']
 
 
-@pytest.mark.parametrize('d', [36, 64, 100, 256])
+@pytest.mark.parametrize('d', [36, 50, 64, 100, 256])
 @pytest.mark.parametrize('l1', [False, True])
 @pytest.mark.parametrize('gum', [False, True])
 def test_ktup_golden(golden, d, l1, gum):

@@ -26,7 +26,7 @@ def leaf(g, key):
     return T(g[key]).clone().requires_grad_(True)
 
 
-@pytest.mark.parametrize('d', [36, 64, 100, 256])
+@pytest.mark.parametrize('d', [36, 50, 64, 100, 256])
 def test_bprmf_scores_loss_grads(golden, d):
     g = golden('score_d%d' % d)
     U, I = leaf(g, 'bprmf.user_embeddings.weight'), leaf(g, 'bprmf.item_embeddings.weight')
@@ -39,7 +39,7 @@ def test_bprmf_scores_loss_grads(golden, d):
     close(U.grad, g['bprmf.grad.user_embeddings.weight']); close(I.grad, g['bprmf.grad.item_embeddings.weight'])
 
 
-@pytest.mark.parametrize('d', [36, 64, 100, 256])
+@pytest.mark.parametrize('d', [36, 50, 64, 100, 256])
 @pytest.mark.parametrize('l1', [False, True])
 @pytest.mark.parametrize('name', ['transe', 'transh', 'transr'])
 def test_kg_scorers(golden, d, l1, name):
@@ -75,7 +75,7 @@ def test_kg_scorers(golden, d, l1, name):
         close(extra.grad, g[tag + 'grad.proj_embeddings.weight'], atol=1e-5)
 
 
-@pytest.mark.parametrize('d', [36, 64, 100, 256])
+@pytest.mark.parametrize('d', [36, 50, 64, 100, 256])
 @pytest.mark.parametrize('l1', [False, True])
 @pytest.mark.parametrize('gum', [False, True])
 def test_tup(golden, d, l1, gum):
@@ -99,7 +99,7 @@ def test_tup(golden, d, l1, gum):
         close(pr_, g[tag + 'pref.probs']); close(re_, g[tag + 'pref.r_e']); close(no_, g[tag + 'pref.norm'])
 
 
-@pytest.mark.parametrize('d', [36, 64, 100, 256])
+@pytest.mark.parametrize('d', [36, 50, 64, 100, 256])
 @pytest.mark.parametrize('l1', [False, True])
 @pytest.mark.parametrize('gum', [False, True])
 def test_ktup(golden, d, l1, gum):

@@ -1086,8 +1086,10 @@ template <int MODE, bool L1>
 int launch_pairs_count(const PairsArgs& a, hipStream_t st, const char* name) {
   const size_t tile = (size_t)(a.dq / 4) * CT * 16;
   if (tile > 160 * 1024) return set_error(KTUP_ERR_UNSUPPORTED, "%s: embedding_size %d needs %zu B of LDS", name, a.d, tile);
-  if constexpr (MODE == 3)
+  if constexpr (MODE == 3) {                                    // (rows wider than 256 columns need more than the default 64 KB of LDS)
+    if (tile > 64 * 1024) (void)hipFuncSetAttribute((const void*)pairs_wtab_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile);
     hipLaunchKernelGGL(pairs_wtab_kernel, dim3((unsigned)((a.n_cand + CT - 1) / CT)), dim3(256), tile, st, a);
+  }
   hipLaunchKernelGGL((pairs_list_kernel<MODE, L1>), dim3(grid_for((a.nq + LIST_NW - 1) / LIST_NW, 8192)), dim3(LIST_NW * 64), 0, st, a);
   const dim3 grid = pairs_grid(a.n_cand, a.nq, PairsWG<MODE>::NWV, 2048, 1536);
   if (tile > 64 * 1024) (void)hipFuncSetAttribute((const void*)pairs_kernel<MODE, L1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile);

@@ -467,11 +467,15 @@ def eval_kg_ranks(E, R, N, q, r, l1, head, descending, gold_off, gold_ids, filt_
         if lib.ktup_eval_kg_ranks_fused_supported(model, E.shape[1], int(bool(l1)), mg):
             n_filt = 0 if filt_ids is None else filt_ids.numel()
             fws = _scratch(lib.ktup_eval_kg_ranks_fused_workspace_bytes(model, E.shape[1], nq, n_gold, n_filt, C.shape[0], n_rel), dev)
-            L.call('ktup_eval_kg_ranks_fused', model, _p(E), E.stride(0), _p(R), R.stride(0), _p(N),
-                   0 if N is None else N.stride(0), n_rel, E.shape[1], _p(C), C.stride(0), C.shape[0], _p(q), _p(r), nq, int(bool(l1)), int(head),
-                   int(bool(descending)), _p(filt_off), _p(filt_ids), n_filt, _p(gold_off), _p(gold_ids), n_gold, mg, _p(ranks), _p(fws),
-                   _stream(dev))
-            return ranks
+            try:
+                L.call('ktup_eval_kg_ranks_fused', model, _p(E), E.stride(0), _p(R), R.stride(0), _p(N),
+                       0 if N is None else N.stride(0), n_rel, E.shape[1], _p(C), C.stride(0), C.shape[0], _p(q), _p(r), nq, int(bool(l1)), int(head),
+                       int(bool(descending)), _p(filt_off), _p(filt_ids), n_filt, _p(gold_off), _p(gold_ids), n_gold, mg, _p(ranks), _p(fws),
+                       _stream(dev))
+                return ranks
+            except L.KtupError as e:
+                if e.code != L.ERR_UNSUPPORTED:        # a shape the pass declines (rows too wide for its LDS tile): the chunked route below
+                    raise
     chunk = max(1, min(int(chunk), max(nq, 1)))
     ws = _scratch(L.load().ktup_eval_kg_ranks_workspace_bytes(E.shape[1], C.shape[0], chunk), dev)
     L.call('ktup_eval_kg_ranks', KG_TRANSE if N is None else KG_TRANSH, _p(E), E.stride(0), _p(R), R.stride(0), _p(N),

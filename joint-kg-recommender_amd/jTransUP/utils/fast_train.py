@@ -83,7 +83,10 @@ class _StepperBase(object):
         # collectives are capturable), clip + optimizer launch -- when the backend is nccl; under the gloo test hook the
         # all-reduce is staged through the host and the launches are issued one by one (KTUP_DP_GRAPHS=0 forces that too)
         import os as _os0
-        dp_ok = self.world == 1 or (dist.get_backend(group) == 'nccl' and _os0.environ.get('KTUP_DP_GRAPHS', '1') != '0')
+        # Several ranks: capturing the all-reduce inside the step's graph is exercised over RCCL at world 1 only (this repo's boxes
+        # have one GPU), so it is opt-in there (KTUP_DP_GRAPHS=1) and the default issues the launches and the collective one by
+        # one; every rank takes the same route (same environment, same step counts).
+        dp_ok = self.world == 1 or (dist.get_backend(group) == 'nccl' and _os0.environ.get('KTUP_DP_GRAPHS', '0') == '1')
         if dist.is_initialized() and self.world == 1 and dist.get_backend(group) != 'nccl':
             from jTransUP import parallel as _par
             dp_ok = not _par._FORCE[0]              # forced collectives on gloo stage through the host: not capturable
@@ -263,6 +266,10 @@ class _StepperBase(object):
         if self.gstate is None:
             raise L.KtupError('the model has no ST-Gumbel gate')
         if uniforms is None:
+            if getattr(self, 'guni', None) is not None:    # bound launches and captured graphs still point at the uniform buffer
+                self._keys = None
+                self._graphs = {}
+                self._eager_steps = {k: 0 for k in self.KINDS}
             self.guni = None
         else:
             if getattr(self, 'guni', None) is None:

@@ -680,7 +680,7 @@ def test_kg_ranks_without_score_matrix(model, d):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('model,d,l1', [('transe', 100, True), ('transh', 100, True), ('transe', 50, False), ('transh', 36, True),
-                                         ('transe', 256, True), ('transh', 64, False)])
+                                         ('transe', 256, True), ('transh', 64, False), ('transh', 300, True), ('transh', 300, False)])
 def test_kg_ranks_count_route(model, d, l1):
     """The pass without the score matrix on the VALU route (ktup_eval_kg_ranks_fused for L1, for widths without a matrix-core sweep
     -- d = 50 is not even a multiple of 4 -- and for keys with more than 8 golds): the pair kernels count where they score, the

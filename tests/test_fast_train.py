@@ -73,7 +73,9 @@ def test_fast_steps_match_the_autograd_route(tmp_path, optimizer, D):
             err = (b - a).abs()
             bad = err > 2e-6 + 2e-5 * a.abs()
             # (Adam's m / sqrt(v) does the same wherever a gradient is itself rounding noise: a few more strays, same bound)
-            assert float(bad.float().mean()) <= (2e-2 if optimizer == 'Adam' else 2e-3) and float(err.max()) <= 1e-3 * 0.05, \
+            # (the count has a floor: on a 1,440-element table 0.2 % is two elements, and which elements stray depends on the order in
+            #  which the generic kernels' float atomics land -- 4 of 1,440 was seen once in four runs)
+            assert int(bad.sum()) <= max(6, int((2e-2 if optimizer == 'Adam' else 2e-3) * bad.numel())) and float(err.max()) <= 1e-3 * 0.05, \
                 '%s after step %d: %d elements off, max %.3g' % (k, step, int(bad.sum()), float(err.max()))
     assert fast._graphs                      # every optimizer kind replays from graphs (Adam: device-resident step counts)
     assert fast.fused_step == (D != 36)

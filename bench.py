@@ -1069,6 +1069,56 @@ def config5_leg(device, world, rank, steps=100, warmup=10, batch=8192, full=True
     return out
 
 
+def config4_sharded_leg(device, world, rank, steps=200, warmup=20):
+    """BASELINE config 4 (KTUP, ml1m shape, d = 100, global batch 512, 7 rec : 3 kg) through the ROW-SHARDED steppers instead of
+    replicas (-shard_tables at ml1m scale): the replicated route exchanges the dense 9.6 MB gradient bucket per step whatever the batch
+    (dp_train_step), this one only the rows a step touches -- ~3,000 distinct rows of 400 B in, out and back over equal-split
+    all-to-alls that use all links at once, plus the fp64 bucket of the four 20-row tables.  Exact for Adagrad / plain SGD without
+    weight decay (what the row-sparse update can reproduce).  One rank: the same launches without the wire -- a latency chain of ~9
+    launches on 64 pairs' worth of tiles, slower than the dense 2-launch step; the point of the leg is its curve over N."""
+    from jTransUP import parallel
+    from jTransUP.sharded_ktup import ShardedKtupJoint
+    if 512 % world:
+        return {'skipped': 'global batch 512 is not divisible by %d ranks' % world}
+    d, P, B = D, NR, 512 // world
+    gen = torch.Generator(device=device); gen.manual_seed(3)          # the same tables on every rank's generator: shards of ONE model
+
+    def table(n, pad_last=False):
+        full = torch.nn.functional.normalize(torch.randn(n, d, generator=gen, device=device), dim=1)
+        if pad_last:
+            full[-1].zero_()                                       # the entity table's pad row (jTransUP.py:46,96): items without an entity
+        return parallel.ShardedTable(n, d, rank=rank, world=world, device=device, init=lambda g: full[g.to(device)])
+    Ut, It, Et = table(NU), table(NI), table(NE + 1, pad_last=True)
+    small = [torch.nn.Parameter(torch.nn.functional.normalize(torch.randn(P, d, generator=gen, device=device), dim=1)) for _ in range(4)]
+    item2ent = torch.where(torch.arange(NI, device=device) < ALIGNED, (torch.arange(NI, device=device) * 4) % NE,
+                           torch.full((NI,), NE, device=device)).to(torch.int32)
+    joint = ShardedKtupJoint.build(Ut, It, Et, *small, item2ent, batch=B, joint_ratio=0.7, margin=1.0, kg_lambda=1.0, kind='adagrad', lr=0.005,
+                                   max_norm=5.0, ent_pad=NE)
+    n = steps + warmup
+    g2 = torch.Generator(device=device); g2.manual_seed(11 + rank)
+    joint.rec.set_feed([torch.randint(0, hi, (n, B), generator=g2, device=device) for hi in (NU, NI, NI)])
+    ph, pt, oth = (torch.randint(0, NE, (n, B), generator=g2, device=device) for _ in range(3))
+    pr = torch.randint(0, P, (n, B), generator=g2, device=device)
+    flip = torch.rand(n, B, generator=g2, device=device) < 0.5
+    joint.kg.set_feed([ph, pt, pr, torch.where(flip, oth, ph), torch.where(flip, pt, oth), pr])
+    for _ in range(warmup):
+        joint.run()
+    ramp_clocks(joint.run, device)
+    torch.cuda.synchronize(device)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        joint.run()
+    torch.cuda.synchronize(device)
+    wall = _max_over_ranks(1e3 * (time.perf_counter() - t0) / steps, device, world)
+    joint.check()
+    return {'backend': dist.get_backend() if world > 1 else 'single process', 'world': world, 'global_batch': 512, 'per_rank_batch': B,
+            'ms_per_step': wall, 'scored_rows_per_s': 2 * 512 / (wall * 1e-3), 'wire_rows_per_rank': {'rec': joint.rec.W, 'kg': joint.kg.W},
+            'optimizer': 'row-sparse Adagrad, l2_lambda 0 (the replicated route of dp_train_step runs dense Adagrad with weight decay)',
+            'note': 'strong scaling of the reference batch: B = 512 / N pairs or triples per rank and step'}
+
+
 def roofline(rec_ms, kg_ms, step_ms=None, live_traffic=None):
     """The dominant kernel (K6, KTUP rec forward) against the ceiling that actually binds it.
 
@@ -1306,7 +1356,7 @@ def main():
         def give_up():          # a rank stuck in a leg's collective must not take the headline line down with it
             if rank == 0:
                 done = dict(out)
-                for name in ('dp_train_step', 'config5_step'):
+                for name in ('dp_train_step', 'config4_sharded_step', 'config5_step'):
                     done[name] = legs.get(name, {'error': 'timeout after %d s' % LEG_TIMEOUT_S})
                 print(json.dumps(done), flush=True)
             os._exit(0)
@@ -1314,7 +1364,7 @@ def main():
         watchdog = threading.Timer(LEG_TIMEOUT_S, give_up)
         watchdog.daemon = True
         watchdog.start()
-        for name, fn in (('dp_train_step', dp_train_leg), ('config5_step', config5_leg)):
+        for name, fn in (('dp_train_step', dp_train_leg), ('config4_sharded_step', config4_sharded_leg), ('config5_step', config5_leg)):
             try:
                 legs[name] = fn(device, world, rank)
             except Exception as e:      # noqa: BLE001 -- a leg must not take the headline line down with it

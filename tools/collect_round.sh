@@ -1,7 +1,7 @@
 #!/bin/bash
 # Everything under profiles/<tag>_* in one GPU job (run from the repo root on an MI355X box):  bash tools/collect_round.sh r03
 # rocprofv3 runs from /tmp; counter passes are separate from the kernel-trace / stats pass (MI355X_MICROARCH.md).
-TAG=${1:-r03}
+TAG=${1:-r04}
 export TMPDIR=/tmp
 R=$(pwd)
 P=$R/gpurun_out/profiles
@@ -13,15 +13,16 @@ for W in train_step fed_step eval_pass seg_bwd kg_rank kg_pass kg_pass_e kg_pass
   F=$(find /tmp/kp_$W -name "*kernel_stats.csv" | head -1)
   [ -n "$F" ] && cp $F $P/${TAG}_${W}_kernel_stats.csv
 done
-# config 5's step (the fixed-shape stepper): kernel-level profile of one rank in its three forms, and wall / device time of each
-for V in "" "--zipf 1.05" "--no-overlap" "--gradient-buffer --no-overlap" "--exchange" "--full"; do
-  timeout 200 python tools/config5_step.py --steps 100 $V 2>/dev/null | grep config
+# config 5's step (the fixed-shape steppers, full-size tables): wall / device time of the rec step, the kg step and the 7 : 3 joint
+# cycle in their forms, and the kernel-level profile of one rank (rec and kg, one-graph and exchange form)
+for V in "--kind rec" "--kind kg" "--kind joint" "--kind rec --zipf 1.05" "--kind rec --no-overlap" "--kind rec --gradient-buffer --no-overlap" "--kind rec --exchange" "--kind joint --exchange"; do
+  timeout 200 python tools/config5_step.py --steps 200 --full $V 2>/dev/null | grep config
 done > $P/${TAG}_config5_step.txt
-timeout 200 python tools/config5_step.py --steps 50 --legacy 2>/dev/null | grep config >> $P/${TAG}_config5_step.txt
-for V in default exchange; do
+KTUP_WIDE_WAVES=4 timeout 200 python tools/config5_step.py --steps 200 --full --kind rec 2>/dev/null | grep config | sed 's/^/KTUP_WIDE_WAVES=4 /' >> $P/${TAG}_config5_step.txt
+for V in rec kg rec_exchange; do
   rm -rf /tmp/c5
-  A=""; [ $V = exchange ] && A="--exchange"
-  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/c5 -- python $R/tools/config5_step.py --steps 100 --no-overlap $A > /dev/null 2>&1)
+  A="--kind rec"; [ $V = kg ] && A="--kind kg"; [ $V = rec_exchange ] && A="--kind rec --exchange"
+  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/c5 -- python $R/tools/config5_step.py --steps 100 --full --no-overlap $A > /dev/null 2>&1)
   F=$(find /tmp/c5 -name "*kernel_stats.csv" | head -1)
   [ -n "$F" ] && cp $F $P/${TAG}_config5_${V}_kernel_stats.csv
 done
@@ -45,4 +46,6 @@ timeout 300 python tools/graph_memset_repro.py > $P/${TAG}_graph_memset_repro_to
 timeout 120 tools/gumbel_log_check > $P/${TAG}_gumbel_log_check.txt 2>/dev/null
 timeout 300 tools/gather_bench footprint > $P/${TAG}_gather_footprint.txt 2>/dev/null
 timeout 900 python bench.py > $P/${TAG}_bench.json 2>/dev/null
+# the numbers a reader is shown come from the files themselves; the stamp ties them to the kernel sources they were measured on
+python tools/profile_summary.py $TAG $P
 ls -la $P

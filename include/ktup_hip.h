@@ -448,7 +448,9 @@ int ktup_shard_route(const int64_t* ids, int64_t n_entries, int64_t block, int n
  * (5B int64, written; 3B / two tables when item2ent is NULL; a user is one entry, shared by its positive and its negative pair), tables 0 / 1 / 2 = users / items / entities, pair_map = item wire row
  * -> entity wire row.  *cursor (device) is incremented by the call: a replayed graph walks through the columns by itself.
  * phase: 0 = the whole route; 1 = its first launch only (scratch init + the entry list); 2 = the remaining four launches -- a
- * scorer that needs nothing but the entry list (global ids) can then run beside phase 2 on another stream.                    */
+ * scorer that needs nothing but the entry list (global ids) can then run beside phase 2 on another stream; 3 = the whole route
+ * WITHOUT moving the cursor -- for a scorer that reads the id columns itself and runs beside ALL of it (ktup_shard_reduce_norm moves
+ * the cursor once both are done).                                                                                              */
 int ktup_shard_route_ktup(const int64_t* u, const int64_t* pos_items, const int64_t* neg_items, int64_t B, int64_t n_batches,
                           int64_t* cursor, const int32_t* item2ent, int64_t ent_pad, int64_t* entries, int world,
                           const int64_t* cap, int64_t* inverse, int64_t* send_ids, int32_t* pair_map, int32_t* sort_ws,
@@ -483,6 +485,9 @@ int ktup_zero_async(void* ptr, int64_t nbytes, void* stream);
  *   (ktup_shard_reduce_list_len(n_entries, d) int32).  Two launches.  dup_only != 0: the kernel that wrote G has already added
  *   |G row|^2 for every ENTRY (ktup_train_rec_step_rows / ktup_train_kg_step_rows with `sumsq`), so the walk adds only what rows
  *   shared by several entries change -- |sum of the rows|^2 - sum of |row|^2 -- and never reads an entry that is alone on its row.
+ *   fold / n_fold (may be NULL / 0): accumulators that a kernel on ANOTHER branch of the step's graph filled while sumsq was being
+ *   cleared (the step kernel beside the route): their sum is added to sumsq and they are left zero.  cursor (may be NULL): the batch
+ *   position of ktup_shard_route_ktup / _kg with phase 3, moved on here, after every reader of it.
  * ktup_shard_reduce_apply: the same walk again; every reduced row goes straight from registers through the clipped row-sparse
  *   SGD / Adagrad rule of ktup_shard_apply into table_t[ids[w]]; the listed rows are applied from gwire, which is left all-zero
  *   again; small tables as in ktup_shard_apply -- both as extra workgroups of the ONE launch.  Same arguments, same G, same sort_ws as the norm call. */
@@ -490,7 +495,7 @@ int64_t ktup_shard_reduce_list_len(int64_t n_entries, int d);
 int ktup_shard_reduce_norm(const float* G, int64_t ldg, int d, int64_t n_src, int64_t src_off, const int32_t* sort_ws,
                            int64_t n_entries, int64_t n_wire_rows, float* gwire, int64_t ldw, int32_t* xkeys, int n_small,
                            float* const* small_grads, int64_t small_elems, float small_weight, double* sumsq, int n_slots,
-                           int dup_only, void* stream);
+                           int dup_only, double* fold, int n_fold, int64_t* cursor, void* stream);
 int ktup_shard_reduce_apply(int kind, int n_tables, float* const* tables, const int64_t* ld, float* const* states,
                             const int64_t* lds, const int64_t* cap, const int64_t* ids, int64_t n_blocks, const float* G,
                             int64_t ldg, int d, int64_t n_src, int64_t src_off, const int32_t* sort_ws, int64_t n_entries,
@@ -599,14 +604,16 @@ int ktup_train_rec_step(const float* U, int64_t ldu, const float* I, int64_t ldi
  * negatives); row k of GU (B x d) = the user-row gradient of example k from BOTH pairs, row k of GV (2B x d) = the item-row
  * gradient of pair k (which is also its entity row's).  sumsq (may be NULL): n_slots doubles to which the launch ADDS
  * sum_k |GU row k|^2 + sum_k |GV row k|^2 x (1 + [pair k's item has an entity row]) -- the squared norm of the row gradients as if
- * every entry of the route had its own table row (ktup_shard_reduce_norm with dup_only corrects for shared rows).  Soft gate only.  gR / gRn may be NULL although rel / norm are given (then orth must be 0): gP / gPn are the gradients
+ * every entry of the route had its own table row (ktup_shard_reduce_norm with dup_only corrects for shared rows).  neg_ids (may be
+ * NULL): u_ids / i_ids / neg_ids are then the id COLUMNS of ktup_shard_route_ktup (n_batches x B each) and the kernel reads batch
+ * (*cursor mod n_batches) of them itself (cursor NULL: batch 0): it does not wait for an entry list.  Soft gate only.  gR / gRn may be NULL although rel / norm are given (then orth must be 0): gP / gPn are the gradients
  * of both summands of the mixed tables.                                                                                   */
 int ktup_train_rec_step_rows(const float* U, int64_t ldu, const float* I, int64_t ldi, const float* E, int64_t lde,
                              const int32_t* item2ent, int64_t ent_pad, const float* pref, const float* pref_norm,
                              const float* rel, const float* norm, int64_t ldp, int n_pref, int d, const int64_t* u_ids,
                              const int64_t* i_ids, int64_t B, int l1, float target, float gscale, int orth, float* loss,
                              float* GU, float* GV, float* gP, float* gPn, float* gR, float* gRn, double* sumsq, int n_slots,
-                             void* stream);
+                             const int64_t* neg_ids, const int64_t* cursor, int64_t n_batches, void* stream);
 int ktup_train_kg_step(int transh, const float* E, int64_t lde, const float* R, int64_t ldr, const float* Nrm, int64_t ldn,
                        int d, const int64_t* h, const int64_t* t, const int64_t* r, int64_t B, int l1, float margin,
                        float gscale, int regs, float* loss, float* gE, float* gR, float* gN, void* stream);

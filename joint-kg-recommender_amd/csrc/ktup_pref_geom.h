@@ -97,7 +97,8 @@ int pref_step_mc(const float* U, int64_t ldu, const float* I, int64_t ldi, const
                  int d, const int64_t* u_ids, const int64_t* i_ids, int64_t B, int l1, int gumbel_mode, const float* uniform,
                  uint64_t seed, uint64_t offset, float target, float gscale, int orth, float* loss, float* gU, float* gI, float* gE,
                  float* gP, float* gPn, float* gR, float* gRn, hipStream_t st,
-                 const char* name, float* GU = nullptr, float* GV = nullptr, double* sumsq = nullptr, int sumsq_slots = 0);
+                 const char* name, float* GU = nullptr, float* GV = nullptr, double* sumsq = nullptr, int sumsq_slots = 0,
+                 const int64_t* neg_ids = nullptr, const int64_t* cursor = nullptr, int64_t n_batches = 1);
 // ktup_score_pref_bwd_wide.hip: the same backward for d = 256 (config 5): four waves share a 16-pair tile, 64 coordinates each.
 int pref_bwd_mc_wide(const float* U, int64_t ldu, const float* I, int64_t ldi, const float* E, int64_t lde, const int32_t* item2ent,
                      int64_t ent_pad, const float* Alog, const float* Ar, const float* Cn, int dp, float beta, int n_pref, int d,

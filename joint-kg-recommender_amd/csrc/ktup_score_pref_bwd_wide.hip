@@ -82,6 +82,8 @@ struct WArgs {
   double* sumsq; int sumsq_slots; // STEP + ROWOUT (may be null): += sum over the stored rows of |row|^2 x (entries that read the row): GU rows
                                  // once, GV rows once for the item and once more for its entity -- the squared norm of the step's row
                                  // gradients if no two entries shared a table row (ktup_shard_reduce_norm's dup_only walk corrects the rest)
+  const int64_t* neg_ids;        // STEP + ROWOUT (may be null): u_ids / i_ids / neg_ids are the id COLUMNS (n_batches x B each) and the kernel
+  const int64_t* cursor; int64_t n_batches;   // reads batch (*cursor mod n_batches) itself -- no entry list has to exist before it starts
   int u_once;                    // STEP + ROWOUT: u_ids holds B ids (example k's user, shared by its two pairs) and GU B rows (the sum)
   int noflush;                   // measurement knob (option dbg_noflush)
   int gumbel;
@@ -166,12 +168,22 @@ __global__ __launch_bounds__(G::NT) void pref_bwd_wide_kernel(WArgs a) {
   // alone on its SIMD), the rows of the workgroup's next tile are in flight into registers, its ids already in the other id buffer
   constexpr int GJ = G::GJ, GR = G::GR;
   v4 uu[GJ], vv[GJ], ee[GJ];
+  int64_t b0 = 0;                                               // id columns: the batch's first row
+  if constexpr (STEP) { if (a.neg_ids) b0 = a.cursor ? ((*a.cursor) % a.n_batches) * a.B : 0; }
   int32_t nuid = 0, niid = 0, neid = 0;                         // lanes 0-15: the ids that are staged next (fetched a whole tile earlier)
   auto fetch_ids = [&](int64_t tile) {
     if (lane < 16) {
       const int64_t gr = STEP ? tile * 8 + (lane & 7) + (lane >> 3) * a.B : tile * 16 + lane;
       const bool ok = tile < ntiles && (STEP ? tile * 8 + (lane & 7) < a.B : gr < a.n);
-      const int64_t uid = ok ? a.u_ids[(STEP && a.u_once) ? tile * 8 + (lane & 7) : gr] : 0, iid = ok ? a.i_ids[gr] : 0;
+      int64_t uid = 0, iid = 0;
+      if (ok) {
+        if (STEP && a.neg_ids) {
+          const int64_t k = b0 + tile * 8 + (lane & 7);
+          uid = a.u_ids[k]; iid = (lane >> 3) ? a.neg_ids[k] : a.i_ids[k];
+        } else {
+          uid = a.u_ids[(STEP && a.u_once) ? tile * 8 + (lane & 7) : gr]; iid = a.i_ids[gr];
+        }
+      }
       nuid = (int32_t)uid; niid = (int32_t)iid;
       neid = HASE ? a.item2ent[iid] : 0;
     }
@@ -704,7 +716,8 @@ int pref_step_mc(const float* U, int64_t ldu, const float* I, int64_t ldi, const
                  int d, const int64_t* u_ids, const int64_t* i_ids, int64_t B, int l1, int gumbel_mode, const float* uniform,
                  uint64_t seed, uint64_t offset, float target, float gscale, int orth, float* loss, float* gU, float* gI, float* gE,
                  float* gP, float* gPn, float* gR, float* gRn, hipStream_t st,
-                 const char* name, float* GU, float* GV, double* sumsq, int sumsq_slots) {
+                 const char* name, float* GU, float* GV, double* sumsq, int sumsq_slots, const int64_t* neg_ids, const int64_t* cursor,
+                 int64_t n_batches) {
   if (n_pref > 32 || (d == 256 && n_pref > 20)) return 1;
   if ((ldu | ldi | lde | ldp) & 3) return 1;
   if ((ldu >> 2) > 0xffffffffll || (ldi >> 2) > 0xffffffffll || (lde >> 2) > 0xffffffffll) return 1;
@@ -722,6 +735,7 @@ int pref_step_mc(const float* U, int64_t ldu, const float* I, int64_t ldi, const
   a.GU = GU; a.GV = GV;          // both set: the row gradients leave as rows of GU (example k: both pairs) / GV (pair k) instead of atomics
   a.u_once = GU != nullptr;
   a.sumsq = sumsq; a.sumsq_slots = sumsq_slots;
+  a.neg_ids = neg_ids; a.cursor = cursor; a.n_batches = n_batches > 0 ? n_batches : 1;
   return launch_d(a, d, (n_pref + 3) / 4, st, name);
 }
 

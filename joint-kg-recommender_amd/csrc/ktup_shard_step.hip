@@ -44,6 +44,7 @@ struct RouteArgs {
   // KG source (ktup_shard_route_kg): ids = [ph ; pt ; nh ; nt] from the six triple columns (src_u / src_pos / src_neg / src_nt =
   // ph / pt / nh / nt), and the batch's relation ids [pr ; nr] copied to rel_out for the step kernel
   const int64_t *src_nt, *src_pr, *src_nr; int64_t* rel_out;
+  bool keep_cursor;                                    // phase 3: the caller moves the cursor itself (ktup_shard_reduce_norm), after every reader of it
 };
 
 constexpr int TILE = 1024;                             // histogram counters per scan tile (256 threads x 4)
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(256) void route_init_kernel(RouteArgs a) {
 
 __global__ __launch_bounds__(256) void route_insert_kernel(RouteArgs a) {
   const int lane = threadIdx.x & 63;
-  if (a.cursor && blockIdx.x == 0 && threadIdx.x == 0) *a.cursor = *a.cursor + 1;     // the init launch has read it
+  if (a.cursor && !a.keep_cursor && blockIdx.x == 0 && threadIdx.x == 0) *a.cursor = *a.cursor + 1;     // the init launch has read it
   const uint64_t mask = a.slots - 1;
   for (int64_t base = (int64_t)blockIdx.x * 256; base < a.n; base += (int64_t)gridDim.x * 256) {
     const int64_t e = base + threadIdx.x;
@@ -613,10 +614,20 @@ struct XNormArgs {
   const int32_t* xkeys; int64_t nx; const float* gw; int64_t ldw; int d;
   int n_small; const float* sg[MAXS]; int64_t small_elems; float small_weight;
   double* sumsq; int slots;
+  double* fold; int n_fold;          // accumulators another stream filled while `sumsq` was being cleared: added in, left zero
+  int64_t* cursor;                   // moved on here: every reader of the step's batch position is done
 };
 
 __global__ __launch_bounds__(256) void xnorm_kernel(XNormArgs a) {
   const int lane = threadIdx.x & 63;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (a.fold) {
+      double t = 0.0;
+      for (int k = 0; k < a.n_fold; ++k) { t += a.fold[k]; a.fold[k] = 0.0; }
+      if (t != 0.0) atomicAdd(a.sumsq, t);
+    }
+    if (a.cursor) *a.cursor = *a.cursor + 1;
+  }
   const int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * 256) >> 6;
   float ss = 0.f;
   for (int64_t i = wave; i < a.nx; i += nwaves) {
@@ -782,7 +793,9 @@ namespace {
 // scorer needs nothing but the entry list can run the rest of the route on a second stream beside it
 int route_impl(const char* name, RouteArgs& a, int pair_a, int pair_b, int64_t* inverse, int64_t* send_ids, int32_t* pair_map,
                int32_t* sort_ws, int32_t* counters, double* zero_doubles, int n_zero_doubles, void* ws, hipStream_t st, int phase = 0) {
-  KTUP_REQUIRE(phase >= 0 && phase <= 2, "%s: phase must be 0 (all), 1 (first launch) or 2 (the rest)", name);
+  KTUP_REQUIRE(phase >= 0 && phase <= 3, "%s: phase must be 0 (all), 1 (first launch), 2 (the rest) or 3 (all, the cursor stays)", name);
+  a.keep_cursor = phase == 3;
+  if (phase == 3) phase = 0;
   KTUP_REQUIRE(inverse && send_ids && sort_ws && counters && ws, "%s: null pointer argument", name);
   KTUP_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 7u) == 0 && (reinterpret_cast<uintptr_t>(sort_ws) & 15u) == 0,
                "%s: workspace must be 8-byte, sort_ws 16-byte aligned", name);
@@ -944,7 +957,7 @@ extern "C" int64_t ktup_shard_reduce_list_len(int64_t n_entries, int d) {
 extern "C" int ktup_shard_reduce_norm(const float* G, int64_t ldg, int d, int64_t n_src, int64_t src_off, const int32_t* sort_ws,
                                       int64_t n_entries, int64_t n_wire_rows, float* gwire, int64_t ldw, int32_t* xkeys, int n_small,
                                       float* const* small_grads, int64_t small_elems, float small_weight, double* sumsq, int n_slots,
-                                      int dup_only, void* stream) {
+                                      int dup_only, double* fold, int n_fold, int64_t* cursor, void* stream) {
   const char* name = "ktup_shard_reduce_norm";
   FusedArgs a{};
   if (int e = fill_fused(name, a, G, ldg, d, n_src, src_off, sort_ws, n_entries, n_wire_rows, gwire, ldw, xkeys)) return e;
@@ -962,6 +975,8 @@ extern "C" int ktup_shard_reduce_norm(const float* G, int64_t ldg, int d, int64_
     x.sg[k] = small_grads[k];
   }
   x.sumsq = sumsq; x.slots = n_slots;
+  KTUP_REQUIRE(n_fold >= 0 && (n_fold == 0 || fold), "%s: fold needs its array", name);
+  x.fold = n_fold > 0 ? fold : nullptr; x.n_fold = n_fold; x.cursor = cursor;
   const int64_t work = (2 * grid + 3) / 4 + ((int64_t)n_small * x.small_elems + 255) / 256;
   hipLaunchKernelGGL(xnorm_kernel, dim3(grid_for(work, 256)), dim3(256), 0, st, x);
   return check_launch(name);

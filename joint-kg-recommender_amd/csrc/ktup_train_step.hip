@@ -191,7 +191,7 @@ extern "C" int ktup_train_rec_step_rows(const float* U, int64_t ldu, const float
                                         const float* rel, const float* norm, int64_t ldp, int n_pref, int d, const int64_t* u_ids,
                                         const int64_t* i_ids, int64_t B, int l1, float target, float gscale, int orth, float* loss,
                                         float* GU, float* GV, float* gP, float* gPn, float* gR, float* gRn, double* sumsq, int n_slots,
-                                        void* stream) {
+                                        const int64_t* neg_ids, const int64_t* cursor, int64_t n_batches, void* stream) {
   const char* name = "ktup_train_rec_step_rows";
   KTUP_REQUIRE(B >= 0, "%s: negative batch", name);
   if (B == 0) return KTUP_OK;
@@ -201,12 +201,13 @@ extern "C" int ktup_train_rec_step_rows(const float* U, int64_t ldu, const float
   KTUP_REQUIRE(!orth || !rel || gR, "%s: orthogonalLoss(pref, pref_norm) needs separate gradients for pref and rel", name);
   KTUP_REQUIRE(ldp == d, "%s: preference-side tables and their gradients must be contiguous (pitch d)", name);
   KTUP_REQUIRE(!sumsq || n_slots >= 1, "%s: the sum of squares needs at least one slot", name);
+  KTUP_REQUIRE(!neg_ids || n_batches > 0, "%s: id columns need n_batches > 0", name);
   KTUP_REQUIRE(aligned16(U) && aligned16(I) && aligned16(E) && aligned16(pref) && aligned16(pref_norm) && aligned16(rel) && aligned16(norm) &&
                    aligned16(GU) && aligned16(GV) && aligned16(gP) && aligned16(gPn) && aligned16(gR) && aligned16(gRn),
                "%s: tables and gradients must be 16-byte aligned", name);
   const int rc = pref_step_mc(U, ldu, I, ldi, E, lde, item2ent, ent_pad, pref, pref_norm, rel, norm, ldp, n_pref, d, u_ids, i_ids, B, l1,
                               KTUP_GUMBEL_OFF, nullptr, 0, 0, target, gscale, orth, loss, nullptr, nullptr, nullptr, gP, gPn, gR, gRn,
-                              (hipStream_t)stream, name, GU, GV, sumsq, n_slots);
+                              (hipStream_t)stream, name, GU, GV, sumsq, n_slots, neg_ids, cursor, n_batches);
   if (rc == 1) return set_error(KTUP_ERR_UNSUPPORTED, "%s: no fused kernel for d=%d, n_pref=%d (see ktup_train_step_supported)", name, d, n_pref);
   return rc;
 }

@@ -165,9 +165,10 @@ class ShardedKtupStepper(_ShardedStepBase):
 
     def __init__(self, Ut, It, Et, pref, pref_norm, rel, norm, item2ent, batch, kind='adagrad', lr=0.005, eps=1e-10, max_norm=0.0,
                  l1=False, target=-1.0, orth=False, ent_pad=-1, group=None, capacity_factor=1.25, use_graphs=True, force_exchange=False,
-                 direct=None, overlap_route=True, fused_apply=True):
+                 direct=None, overlap_route=True, fused_apply=True, route_beside=False):
         if kind not in KINDS:
             raise ValueError('row-sparse steps exist for plain SGD and Adagrad only')
+        self.route_beside = bool(route_beside)
         self.tables = [Ut, It, Et]
         self.small = [pref, pref_norm, rel, norm]
         self.group = group
@@ -235,6 +236,7 @@ class ShardedKtupStepper(_ShardedStepBase):
         self.Gwire = f32(W, d)
         self.xkeys = i32(max(2, lib.ktup_shard_reduce_list_len(E, d)))
         self.acc = torch.zeros(SLOTS + 1, dtype=torch.float64, device=dev)  # [SLOTS partial sums of squares | the job-wide total]
+        self.acc_step = torch.zeros(SLOTS, dtype=torch.float64, device=dev)  # the step kernel's share, when it runs beside the route's init
         self.loss_sum = f32(2)                                # [sum of batch-mean BPR terms, sum of orthogonalLoss values] of the steps that ran
         self.loss_step = f32(2)                               # the current step's terms (the apply launch folds and clears them)
         self.skipped = i32(1)                                 # steps skipped for overflow: never cleared by a launch
@@ -308,6 +310,17 @@ class ShardedKtupStepper(_ShardedStepBase):
         import os as _os
         dup = (not self.multi) and self.fused_apply and _os.environ.get('KTUP_C5_DUP','1') != '0'
         ssq = (_p(self.acc), SLOTS) if dup else (None, 0)
+        # one rank, direct gathers, a second stream: the step kernel reads the id columns itself and runs beside the WHOLE route (its
+        # init launch included); its squared norms go to accumulators of their own that the boundary-norm launch folds in, and that
+        # launch moves the cursor once both branches are done
+        # (measured at config 5: 0.151 ms per step against 0.141 with only the route's last four launches beside the kernel -- the init
+        # launch's 1,024 workgroups delay the step kernel's first tiles -- so it is an option, off by default)
+        beside = dup and self.direct and side is not None and self.route_beside
+        cols = (None, None, 0)
+        fold = (None, 0, None)
+        if beside:
+            ssq = (_p(self.acc_step), SLOTS)
+            fold = (_p(self.acc_step), SLOTS, _p(self.cursor))
         bind = L.bind
         fu, fp, fn, nb = self._feed
         def route_phase(phase, on):
@@ -317,14 +330,16 @@ class ShardedKtupStepper(_ShardedStepBase):
         route = route_phase(0, stream)
         if self.direct:                                      # global ids straight into the shards (entries = [u | pos ; neg | ...])
             ent = self.entries
+            uid_p, iid_p = (_p(fu), _p(fp)) if beside else (_p(ent), ent.data_ptr() + B * 8)
+            cols = (_p(fn), _p(self.cursor), nb) if beside else (None, None, 0)
             step = bind('ktup_train_rec_step_rows', _p(Ut.weight.data), Ut.weight.data.stride(0), _p(It.weight.data), It.weight.data.stride(0),
                         _p(Et.weight.data), Et.weight.data.stride(0), _p(self.item2ent), self.ent_pad, _p(pref), _p(pref_norm), _p(rel),
-                        _p(norm), d, P, d, _p(ent), ent.data_ptr() + B * 8, B, int(self.l1), self.target, gscale, int(self.orth),
-                        _p(self.loss_step), _p(self.Gcat), self.Gcat.data_ptr() + B * d * 4, _p(gP), _p(gPn), _p(gR), _p(gRn), *ssq, stream)
+                        _p(norm), d, P, d, uid_p, iid_p, B, int(self.l1), self.target, gscale, int(self.orth),
+                        _p(self.loss_step), _p(self.Gcat), self.Gcat.data_ptr() + B * d * 4, _p(gP), _p(gPn), _p(gR), _p(gRn), *ssq, *cols, stream)
         else:
             step = bind('ktup_train_rec_step_rows', _p(X), d, _p(X), d, _p(X), d, _p(self.pair_map), W, _p(pref), _p(pref_norm), _p(rel),
                         _p(norm), d, P, d, _p(inv), inv.data_ptr() + B * 8, B, int(self.l1), self.target, gscale, int(self.orth),
-                        _p(self.loss_step), _p(self.Gcat), self.Gcat.data_ptr() + B * d * 4, _p(gP), _p(gPn), _p(gR), _p(gRn), *ssq, stream)
+                        _p(self.loss_step), _p(self.Gcat), self.Gcat.data_ptr() + B * d * 4, _p(gP), _p(gPn), _p(gR), _p(gRn), *ssq, None, None, 0, stream)
         reduce_ = bind('ktup_shard_reduce_rows', _p(self.Gcat), d, d, 3 * B, 2 * B, _p(self.sort_ws), E, W, _p(self.Gwire), d, stream)
         if not self.multi:
             pack = bind('ktup_shard_pack_wire', 3, tabs, lds, cap, d, _p(self.send_ids), 1, _p(X), d, stream)
@@ -337,7 +352,7 @@ class ShardedKtupStepper(_ShardedStepBase):
             if self.fused_apply:
                 nw = arr(_ptrs(sg_list))
                 rnorm = bind('ktup_shard_reduce_norm', _p(self.Gcat), d, d, 3 * B, 2 * B, _p(self.sort_ws), E, W, _p(self.Gwire), d,
-                             _p(self.xkeys), n_small, nw, P * d, small_weight, _p(self.acc), SLOTS, int(dup), stream)
+                             _p(self.xkeys), n_small, nw, P * d, small_weight, _p(self.acc), SLOTS, int(dup), *fold, stream)
                 rapply = bind('ktup_shard_reduce_apply', kind, 3, tabs, lds, states, slds, cap, _p(self.send_ids), 1, _p(self.Gcat), d, d,
                               3 * B, 2 * B, _p(self.sort_ws), E, _p(self.Gwire), d, _p(self.xkeys), n_small, P, sgp, sp0p, ss0p, sp1p, ss1p,
                               None, self.lr, self.eps, _p(self.acc), SLOTS, self.max_norm, self.counters.data_ptr() + 4 * (Wn * 3), None,
@@ -345,6 +360,8 @@ class ShardedKtupStepper(_ShardedStepBase):
                 tail = [rnorm, rapply]
             else:
                 tail = [reduce_, gnorm, apply_]
+            if beside:
+                return [[('fork', [route_phase(3, side)]), step, ('join',)] + tail]
             if self.direct and side is not None:
                 return [[route_phase(1, stream), ('fork', [route_phase(2, side)]), step, ('join',)] + tail]
             return [([route, step] if self.direct else [route, pack, step]) + tail]
@@ -366,7 +383,7 @@ class ShardedKtupStepper(_ShardedStepBase):
                       None, self.bucket.data_ptr() + 8 * (N + 1), *close, stream)
         if self.fused_apply:
             onorm = bind('ktup_shard_reduce_norm', _p(self.Grecv), d, d, W, 0, _p(self.own_sort), W, self.W_own, _p(self.Gown), d,
-                         _p(self.own_xkeys), 0, None, 0, 1.0, _p(self.acc), SLOTS, 0, stream)
+                         _p(self.own_xkeys), 0, None, 0, 1.0, _p(self.acc), SLOTS, 0, None, 0, None, stream)
             oapply = bind('ktup_shard_reduce_apply', kind, 3, tabs, lds, states, slds, capo, _p(self.own_ids), 1, _p(self.Grecv), d, d, W, 0,
                           _p(self.own_sort), W, _p(self.Gown), d, _p(self.own_xkeys), n_small, P, sgp, sp0p, ss0p, sp1p, ss1p,
                           _p(self.bucket), self.lr, self.eps, self.acc.data_ptr() + 8 * SLOTS, 1, self.max_norm, None,
@@ -545,7 +562,7 @@ class ShardedKgStepper(_ShardedStepBase):
         if not self.multi:
             pack = bind('ktup_shard_pack_wire', 1, tabs, lds, cap, d, _p(self.send_ids), 1, _p(self.X), d, stream)
             rnorm = bind('ktup_shard_reduce_norm', _p(self.GE), d, d, E, 0, _p(self.sort_ws), E, W, _p(self.Gwire), d, _p(self.xkeys), n_small,
-                         sgp, P * d, 1.0, _p(self.acc), SLOTS, 1, stream)
+                         sgp, P * d, 1.0, _p(self.acc), SLOTS, 1, None, 0, None, stream)
             rapply = bind('ktup_shard_reduce_apply', kind, 1, tabs, lds, states, slds, cap, _p(self.send_ids), 1, _p(self.GE), d, d, E, 0,
                           _p(self.sort_ws), E, _p(self.Gwire), d, _p(self.xkeys), n_small, P, sgp, sp0p, ss0p, None, None, None, self.lr,
                           self.eps, _p(self.acc), SLOTS, self.max_norm, skip_i, None, *close, stream)
@@ -561,7 +578,7 @@ class ShardedKgStepper(_ShardedStepBase):
                       _p(self.own_ids), None, _p(self.own_sort), _p(self.own_counters), None, 0, _p(self.own_ws), stream)
         N = n_small * P * d
         onorm = bind('ktup_shard_reduce_norm', _p(self.Grecv), d, d, W, 0, _p(self.own_sort), W, self.W_own, _p(self.Gown), d,
-                     _p(self.own_xkeys), 0, None, 0, 1.0, _p(self.acc), SLOTS, 0, stream)
+                     _p(self.own_xkeys), 0, None, 0, 1.0, _p(self.acc), SLOTS, 0, None, 0, None, stream)
         pack_b = bind('ktup_shard_bucket', 0, n_small, sgp, P * d, _p(self.bucket), _p(self.acc), SLOTS, skip_i, None, 1.0, stream)
         fin_b = bind('ktup_shard_bucket', 1, n_small, None, P * d, _p(self.bucket), None, 0, None, self.acc.data_ptr() + 8 * SLOTS, 1.0, stream)
         oapply = bind('ktup_shard_reduce_apply', kind, 1, tabs, lds, states, slds, capo, _p(self.own_ids), 1, _p(self.Grecv), d, d, W, 0,

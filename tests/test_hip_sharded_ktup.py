@@ -133,10 +133,11 @@ def test_stepper_l1_distance_and_orthogonal_regulariser(l1, orth, pad_every):
     np.testing.assert_allclose(float(st.loss_sum[0] + st.loss_sum[1]), sum(losses), rtol=1e-4)
 
 
-@pytest.mark.parametrize('direct', [True, False])
+@pytest.mark.parametrize('direct', [True, False, 'beside'])
 def test_stepper_device_fed_batches_walk_the_columns(direct):
     """set_feed: an epoch of pre-drawn batches in device columns, the step's own launches move the cursor (no per-step copy or
-    argument); 5 steps over 3 batches wrap around."""
+    argument); 5 steps over 3 batches wrap around.  'beside': the step kernel reads the id columns itself and the WHOLE route runs
+    on the second graph branch (route_beside)."""
     from jTransUP import parallel
     from jTransUP.sharded_ktup import ShardedKtupStepper
     nu, ni, ne, b, d, P = 700, 250, 500, 256, 128, 20
@@ -148,7 +149,8 @@ def test_stepper_device_fed_batches_walk_the_columns(direct):
     mk = lambda key: parallel.ShardedTable(full[key].shape[0], d, rank=0, world=1, device=dev, init=lambda g: full[key][g].to(dev))
     Ut, It, Et = mk('U'), mk('I'), mk('E')
     small = [torch.nn.Parameter(t.clone().to(dev)) for t in small0]
-    st = ShardedKtupStepper(Ut, It, Et, *small, i2e.to(torch.int32).to(dev), batch=b, kind='adagrad', lr=0.05, eps=1e-4, max_norm=0.5, direct=direct)
+    st = ShardedKtupStepper(Ut, It, Et, *small, i2e.to(torch.int32).to(dev), batch=b, kind='adagrad', lr=0.05, eps=1e-4, max_norm=0.5,
+                            direct=bool(direct), route_beside=direct == 'beside')
     cols = [torch.stack([three[k][0][c] for k in range(3)]).to(dev) for c in range(3)]
     st.set_feed(cols)
     for _ in order:

@@ -361,7 +361,8 @@ def forward_b512_bench(device, D_, i2e_d, X, reps=50):
     torch.cuda.synchronize(device)
     ms_eager = 1e3 * (time.perf_counter() - t0) / reps
     graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
+    from jTransUP.hip.lib import capture as _capture
+    with _capture(graph):
         for f in bound(torch.cuda.current_stream(device).cuda_stream):
             f()
     graph.replay()
@@ -852,11 +853,12 @@ def variants_bench(device, D_, i2e_d, X, reps=10, inner=8):
     ]
     cases += [(name, f, pairs, 0) for name, f, pairs in evals]
     out = {}
+    from jTransUP.hip.lib import capture as _cap
     with torch.no_grad():
         for name, f, rows, bpr in cases:
             f(); torch.cuda.synchronize(device)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with _cap(g):
                 for _ in range(inner):
                     f()
             g.replay(); torch.cuda.synchronize(device)

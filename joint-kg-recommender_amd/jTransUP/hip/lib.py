@@ -217,3 +217,24 @@ def bind(name, *args):
         if rc != 0:
             raise KtupError('%s failed (%d): %s' % (name, rc, lib.ktup_last_error().decode('utf-8', 'replace')))
     return run
+
+
+import contextlib as _contextlib
+import gc as _gc
+
+
+@_contextlib.contextmanager
+def capture(graph, **kw):
+    """`with torch.cuda.graph(graph)` with Python's cyclic garbage collector held off.  A collection that happens to run INSIDE a
+    capture (binding a step's launches allocates thousands of ctypes objects) may finalise garbage of earlier steppers -- an older
+    CUDAGraph, tensors whose blocks go back to the driver -- and the HIP runtime refuses those calls while a stream is capturing:
+    the process aborts (seen once in three runs of the GPU suite, in whichever test captured when the collector's turn came)."""
+    _gc.collect()
+    was = _gc.isenabled()
+    _gc.disable()
+    try:
+        with torch.cuda.graph(graph, **kw):
+            yield
+    finally:
+        if was:
+            _gc.enable()

@@ -248,7 +248,8 @@ def _rec_eval_fused(FLAGS, pass_fn, eval_iter, index, graph_key=None):
         return _present_rows(_to_host(cols, copy=False), index)
     if entry[0] is None:                                # second pass: capture (allocations land in the graph's own pool), then replay
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        from jTransUP.hip.lib import capture as _capture
+        with _capture(graph):
             cols = body()
         entry = _EVAL_GRAPHS[key] = (graph, cols, eval_iter, index)
     entry[0].replay()

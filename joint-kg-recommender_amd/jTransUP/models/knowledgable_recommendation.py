@@ -112,6 +112,18 @@ def train_loop(FLAGS, model, trainer, rating_train_dataset, triple_train_dataset
         stepper = ShardedJointDriver(model, trainer, FLAGS, FLAGS.batch_size, logger)
         logger.info('Row-sharded training step enabled (-shard_tables): rank %d of %d owns rows r %% %d == %d of the user / item / entity tables.'
                     % (stepper.rank, stepper.world, stepper.world, stepper.rank))
+        if FLAGS.device_sampling:                          # batches and negatives drawn on the device (every rank draws the same global batch)
+            from jTransUP.utils.device_sampler import DeviceSampler
+            from jTransUP.utils.fast_train import DeviceFeeder
+            sampler = DeviceSampler(D.DEV, seed=FLAGS.seed)
+            sampler.set_rating_dicts(model.user_total, item_total, all_rating_dicts)
+            known = None
+            if FLAGS.filter_wrong_corrupted:
+                known = [triple_train_list] + [[(h, t, r) for (t, r), hs in d[4].items() for h in hs] for d in triple_eval_datasets]
+            sampler.set_triples(entity_total, model.rel_total, known)
+            rec_feed = DeviceFeeder(rating_train_list, FLAGS.batch_size, D.DEV, FLAGS.negtive_samples, seed=FLAGS.seed)
+            kg_feed = DeviceFeeder(triple_train_list, FLAGS.batch_size, D.DEV, FLAGS.negtive_samples, seed=FLAGS.seed + 1)
+            logger.info('Training data and negative sampling are device-resident (-device_sampling).')
     elif D.USE_CUDA and FLAGS.model_type == 'jtransup' and not FLAGS.share_embeddings and trainer.fused is not None \
             and FLAGS.embedding_size % 4 == 0 \
             and os.environ.get('KTUP_FAST_TRAIN', '1') != '0':

@@ -124,7 +124,7 @@ class _ShardedStepBase(object):
         n_seg = 5 if self.multi else 1
         for k in range(n_seg):
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with L.capture(graph):
                 cs = torch.cuda.current_stream(self.dev).cuda_stream
                 side = self._side if (self.direct and self.overlap_route) else None
                 segs = self._bind(cs, None if side is None else side.cuda_stream)

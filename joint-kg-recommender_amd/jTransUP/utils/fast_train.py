@@ -171,7 +171,7 @@ class _StepperBase(object):
             entry = None
         if entry is None:
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with L.capture(graph):
                 self._acc_on = True
                 try:
                     for kind in kinds:
@@ -229,7 +229,7 @@ class _StepperBase(object):
             return out
         if entry is None:
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with L.capture(graph):
                 out = fed_eager()
             self._keys = None                                 # plans were bound to the capture stream: rebind for eager use
             fused._plan = None
@@ -330,7 +330,7 @@ class _StepperBase(object):
         self._pack(kind, args)                                   # ids -> the persistent [pos ; neg] buffers (outside the graph)
         if entry is None:
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with L.capture(graph):
                 out = eager(*([None] * len(args)))               # None: ids are already packed
             self._keys = None                                    # plans were bound to the capture stream: rebind for eager use
             fused._plan = None

@@ -284,3 +284,15 @@ def test_cli_any_embedding_size(dataset, script, extra):
           ['-embedding_size', '300']
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert r.returncode != 0 and '-embedding_size 300' in (r.stdout + r.stderr)
+
+
+def test_joint_cli_shard_tables_device_sampling(dataset):
+    """-shard_tables with the default -device_sampling: the epoch's columns and the negative sampling stay on the device (K19), the
+    sharded steppers take the batches from there."""
+    log, logs = run_cli('run_knowledgable_recommendation.py', dataset, 'ktup-shard-ds',
+                        ['-model_type', 'jtransup', '-rec_test_files', 'valid.dat', '-kg_test_files', 'valid.dat', '-joint_ratio', '0.7',
+                         '-noshare_embeddings', '-embedding_size', '64', '-l2_lambda', '0', '-shard_tables'])
+    assert 'Row-sharded training step enabled' in log and 'device-resident' in log
+    losses = _loss_lines(log)
+    assert len(losses) >= 3 and all(a == a and b == b and a < 1e3 and b < 1e4 for a, b in losses)
+    assert len(_metric_rows(log)) >= 3 and os.path.isfile(os.path.join(logs, 'ktup-shard-ds.ckpt.shard0of1'))

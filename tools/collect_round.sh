@@ -32,7 +32,7 @@ for W in fed_step eval_pass kg_pass hard_pass soft_l1_pass; do
     rm -rf /tmp/pm_$W
     (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $SET --output-format csv -d /tmp/pm_$W -- python $R/tools/pmc_workloads.py $W > /dev/null 2>&1)
     F=$(find /tmp/pm_$W -name "*counter_collection.csv" | head -1)
-    [ -n "$F" ] && python tools/pmc_summary.py $F eval_pass pspace_ topk_merge clip_step_kernel pref_bwd_wide_kernel kg_step_kernel feed_ kg_count_mc kg_list_scores kg_rank_finalize kg_wtab sweep_hard sweep_soft pairs_hard pairs_kernel >> $P/${TAG}_${W}_pmc.txt
+    [ -n "$F" ] && python tools/pmc_summary.py $F eval_pass pspace_ topk_merge clip_step_kernel pref_bwd_wide_kernel kg_step_kernel feed_ kg_count_mc kg_list_scores kg_rank_finalize kg_unc_resolve kg_wtab sweep_hard sweep_soft pairs_hard pairs_kernel >> $P/${TAG}_${W}_pmc.txt
   done
 done
 timeout 600 python tools/kernel_times.py > $P/${TAG}_kernel_times.txt 2>/dev/null

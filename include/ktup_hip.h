@@ -482,7 +482,9 @@ int ktup_zero_async(void* ptr, int64_t nbytes, void* stream);
  * ktup_shard_reduce_norm: the squared norm of every reduced row (and of the n_small small gradients, weighted by small_weight) is
  *   ADDED to sumsq[0 .. n_slots) (n_slots = 1 or KTUP_SHARD_SUMSQ_SLOTS); nothing else is written, except that the few rows whose
  *   entries straddle two workgroups are summed into gwire (all-zero before the call) and listed in xkeys
- *   (ktup_shard_reduce_list_len(n_entries, d) int32).  Two launches.  dup_only != 0: the kernel that wrote G has already added
+ *   (ktup_shard_reduce_list_len(n_entries, d) int32) -- their squared norm is accumulated by the adds themselves (an add of v onto
+ *   `old` raises the square by 2 old v + v^2, and the atomic returns old).  One launch (the small gradients, `fold` and `cursor` ride in
+ *   extra workgroups).  dup_only != 0: the kernel that wrote G has already added
  *   |G row|^2 for every ENTRY (ktup_train_rec_step_rows / ktup_train_kg_step_rows with `sumsq`), so the walk adds only what rows
  *   shared by several entries change -- |sum of the rows|^2 - sum of |row|^2 -- and never reads an entry that is alone on its row.
  *   fold / n_fold (may be NULL / 0): accumulators that a kernel on ANOTHER branch of the step's graph filled while sumsq was being

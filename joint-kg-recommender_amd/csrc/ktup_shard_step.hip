@@ -441,13 +441,52 @@ struct FusedArgs {
   WireTables w; const int64_t* ids; float lr, eps, max_norm; bool adagrad; const int32_t* skip_i; const double* skip_d;
 };
 
+// What the norm walk's EXTRA workgroups add (blocks [walk_grid, gridDim.x) of its launch): the small replicated gradients' squares,
+// accumulators another graph branch filled, and the batch cursor's move.  (Round 3 ran a second launch for this and for the boundary
+// rows; those now account for themselves: see boundary() below.)
+struct XNormArgs {
+  int n_small; const float* sg[MAXS]; int64_t small_elems; float small_weight;
+  double* sumsq; int slots;
+  double* fold; int n_fold;          // accumulators another stream filled while `sumsq` was being cleared: added in, left zero
+  int64_t* cursor;                   // moved on here: every reader of the step's batch position is done
+};
+
+KTUP_DEV void xnorm_blocks(const XNormArgs& a, int blk, int nblk) {
+  if (blk == 0 && threadIdx.x == 0) {
+    if (a.fold) {
+      double t = 0.0;
+      for (int k = 0; k < a.n_fold; ++k) { t += a.fold[k]; a.fold[k] = 0.0; }
+      if (t != 0.0) atomicAdd(a.sumsq, t);
+    }
+    if (a.cursor) *a.cursor = *a.cursor + 1;
+  }
+  float ss = 0.f;
+  const int64_t N = (int64_t)a.n_small * a.small_elems;
+  for (int64_t i = (int64_t)blk * 256 + threadIdx.x; i < N; i += (int64_t)nblk * 256) {
+    const float v = a.sg[i / a.small_elems][i % a.small_elems];
+    ss = fmaf(a.small_weight * v, v, ss);
+  }
+  __shared__ float xred[4];
+  ss = group_sum<64>(ss);
+  if ((threadIdx.x & 63) == 0) xred[threadIdx.x >> 6] = ss;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double t = ((double)xred[0] + (double)xred[1]) + ((double)xred[2] + (double)xred[3]);
+    if (t != 0.0) atomicAdd(a.sumsq + (a.slots > 1 ? blk % a.slots : 0), t);
+  }
+}
+
 // MODE 1 carries the step's LAST launch along as extra workgroups [walk_grid, gridDim.x): the listed boundary rows (from gw, then
 // zero-filled), the small replicated tables and the step's bookkeeping (ApplyRows over op_rows rows) depend on the norm only, not on
 // this walk -- as a launch of their own they were 6 us of dependent latencies at the very end of every step.
 template <int GL, int CPL, int MODE>
-__global__ __launch_bounds__(256) void seg_fused_kernel(FusedArgs a, ApplyRows op, int64_t op_rows, int walk_grid) {
+__global__ __launch_bounds__(256) void seg_fused_kernel(FusedArgs a, ApplyRows op, int64_t op_rows, int walk_grid, XNormArgs xn) {
   const int lane = threadIdx.x % GL, grp = threadIdx.x / GL;
   constexpr int GPB = 256 / GL;
+  if (MODE == 0 && (int)blockIdx.x >= walk_grid) {
+    xnorm_blocks(xn, (int)blockIdx.x - walk_grid, (int)gridDim.x - walk_grid);
+    return;
+  }
   if (MODE == 1 && (int)blockIdx.x >= walk_grid) {
     const RowCtx<float4, GL, CPL> cx{a.nch, lane};
     for (int64_t row = (int64_t)((int)blockIdx.x - walk_grid) * GPB + grp; row < op_rows; row += (int64_t)((int)gridDim.x - walk_grid) * GPB)
@@ -498,12 +537,20 @@ __global__ __launch_bounds__(256) void seg_fused_kernel(FusedArgs a, ApplyRows o
     }
   };
   auto boundary = [&](int32_t key, const float4* acc, bool head, bool tail) {
-    if (MODE != 0) return;                                               // MODE 0 put it into gw; the list launch applies it
+    if (MODE != 0) return;                                               // MODE 0 put it into gw; the apply launch's extra workgroups apply it
+    // A boundary row is the sum of several workgroups' partials, added to gw by float atomics in any order.  Its squared norm needs no
+    // pass of its own: an add of v onto `old` raises the row's square by (old + v)^2 - old^2 = 2 old v + v^2, and the atomic RETURNS old --
+    // summed over all the adds that telescopes to |final row|^2 whatever the order
     float* row = a.gw + (int64_t)key * a.ldw;
 #pragma unroll
     for (int j = 0; j < CPL; ++j) {
       const int ch = lane + j * GL;
-      if (ch < a.nch) atomic_add4(row + 4 * ch, acc[j]);
+      if (ch < a.nch) {
+        float* p = row + 4 * ch;
+        const float4 v = acc[j];
+        const float ox = atomicAdd(p + 0, v.x), oy = atomicAdd(p + 1, v.y), oz = atomicAdd(p + 2, v.z), ow = atomicAdd(p + 3, v.w);
+        ss += fmaf(2.f * ox, v.x, v.x * v.x) + fmaf(2.f * oy, v.y, v.y * v.y) + fmaf(2.f * oz, v.z, v.z * v.z) + fmaf(2.f * ow, v.w, v.w * v.w);
+      }
     }
     // a workgroup that lies wholly inside one hot row lists it on BOTH sides: equal keys must stay adjacent in the list
     if (lane == 0 && head) a.xkeys[2 * (int64_t)blockIdx.x] = key;
@@ -609,48 +656,6 @@ __global__ __launch_bounds__(256) void seg_fused_kernel(FusedArgs a, ApplyRows o
   }
 }
 
-// the listed boundary rows (each at its first occurrence) and the small replicated gradients join the sum of squares
-struct XNormArgs {
-  const int32_t* xkeys; int64_t nx; const float* gw; int64_t ldw; int d;
-  int n_small; const float* sg[MAXS]; int64_t small_elems; float small_weight;
-  double* sumsq; int slots;
-  double* fold; int n_fold;          // accumulators another stream filled while `sumsq` was being cleared: added in, left zero
-  int64_t* cursor;                   // moved on here: every reader of the step's batch position is done
-};
-
-__global__ __launch_bounds__(256) void xnorm_kernel(XNormArgs a) {
-  const int lane = threadIdx.x & 63;
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    if (a.fold) {
-      double t = 0.0;
-      for (int k = 0; k < a.n_fold; ++k) { t += a.fold[k]; a.fold[k] = 0.0; }
-      if (t != 0.0) atomicAdd(a.sumsq, t);
-    }
-    if (a.cursor) *a.cursor = *a.cursor + 1;
-  }
-  const int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * 256) >> 6;
-  float ss = 0.f;
-  for (int64_t i = wave; i < a.nx; i += nwaves) {
-    const int32_t key = a.xkeys[i];
-    if (key < 0 || (i > 0 && a.xkeys[i - 1] == key)) continue;
-    const float* row = a.gw + (int64_t)key * a.ldw;
-    for (int c = lane; c < a.d; c += 64) ss = fmaf(row[c], row[c], ss);
-  }
-  const int64_t N = (int64_t)a.n_small * a.small_elems;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < N; i += (int64_t)gridDim.x * 256) {
-    const float v = a.sg[i / a.small_elems][i % a.small_elems];
-    ss = fmaf(a.small_weight * v, v, ss);
-  }
-  __shared__ float red[4];
-  ss = group_sum<64>(ss);
-  if (lane == 0) red[threadIdx.x >> 6] = ss;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const double t = ((double)red[0] + (double)red[1]) + ((double)red[2] + (double)red[3]);
-    if (t != 0.0) atomicAdd(a.sumsq + (a.slots > 1 ? blockIdx.x % a.slots : 0), t);
-  }
-}
-
 // Sorted entries per lane group.  Measured at config 5 (49,152 entries, d = 256): 8 -> 0.171 ms per step, 16 -> 0.173, 24 -> 0.189,
 // 32 -> 0.205, 64 -> 0.275: the two walks live on memory-level parallelism (many lane groups with a few rows each), so the
 // chunk stays small until the batch is large enough to fill the chip anyway.
@@ -669,13 +674,16 @@ int64_t fused_grid(int64_t m_max, int d) {
 }
 
 template <int MODE>
-int launch_fused(const FusedArgs& a, int64_t grid, hipStream_t st, const char* name, const ApplyRows* op = nullptr, int64_t op_rows = 0) {
+int launch_fused(const FusedArgs& a, int64_t grid, hipStream_t st, const char* name, const ApplyRows* op = nullptr, int64_t op_rows = 0,
+                 const XNormArgs* xn = nullptr) {
   const ApplyRows none{};
+  const XNormArgs xnone{};
 #define KTUP_F(GL, CPL)                                                                                  \
   {                                                                                                      \
-    const int64_t extra = op ? grid_for((op_rows + (256 / GL) - 1) / (256 / GL), 256) : 0;               \
+    int64_t extra = op ? grid_for((op_rows + (256 / GL) - 1) / (256 / GL), 256) : 0;                     \
+    if (xn) extra = grid_for(((int64_t)xn->n_small * xn->small_elems + 2047) / 2048, 64);                \
     hipLaunchKernelGGL((seg_fused_kernel<GL, CPL, MODE>), dim3((unsigned)(grid + extra)), dim3(256), 0, st, a, op ? *op : none, op_rows, \
-                       (int)grid);                                                                       \
+                       (int)grid, xn ? *xn : xnone);                                                     \
     return check_launch(name);                                                                           \
   }
   if (a.nch <= 16) KTUP_F(16, 1)
@@ -966,9 +974,7 @@ extern "C" int ktup_shard_reduce_norm(const float* G, int64_t ldg, int d, int64_
   a.sumsq = sumsq; a.slots = n_slots; a.dup_only = dup_only != 0;
   hipStream_t st = (hipStream_t)stream;
   const int64_t grid = fused_grid(n_entries, d);
-  if (int e = launch_fused<0>(a, grid, st, name)) return e;
   XNormArgs x{};
-  x.xkeys = xkeys; x.nx = 2 * grid; x.gw = gwire; x.ldw = ldw; x.d = d;
   x.n_small = n_small; x.small_elems = small_elems > 0 ? small_elems : 1; x.small_weight = small_weight;
   for (int k = 0; k < n_small; ++k) {
     KTUP_REQUIRE(small_grads[k], "%s: small gradient %d is null", name, k);
@@ -977,9 +983,7 @@ extern "C" int ktup_shard_reduce_norm(const float* G, int64_t ldg, int d, int64_
   x.sumsq = sumsq; x.slots = n_slots;
   KTUP_REQUIRE(n_fold >= 0 && (n_fold == 0 || fold), "%s: fold needs its array", name);
   x.fold = n_fold > 0 ? fold : nullptr; x.n_fold = n_fold; x.cursor = cursor;
-  const int64_t work = (2 * grid + 3) / 4 + ((int64_t)n_small * x.small_elems + 255) / 256;
-  hipLaunchKernelGGL(xnorm_kernel, dim3(grid_for(work, 256)), dim3(256), 0, st, x);
-  return check_launch(name);
+  return launch_fused<0>(a, grid, st, name, nullptr, 0, &x);     // the walk + (extra workgroups) the small gradients, the fold, the cursor
 }
 
 extern "C" int ktup_shard_reduce_apply(int kind, int n_tables, float* const* tables, const int64_t* ld, float* const* states,

@@ -50,7 +50,8 @@ Option g_opts[] = {
     {"dbg_eval", "", {0}},                                                  // bits switch phases of the rec evaluation sweep off
     {"kg_wtab", "KTUP_KG_WTAB", {env_int("KTUP_KG_WTAB", 1)}},              // 0: the fused TransH link-prediction pass computes w.e in the sweep instead of once per (relation, candidate)
     {"kg_exact", "KTUP_KG_EXACT", {env_int("KTUP_KG_EXACT", 1)}},            // 0: the fused squared-L2 link-prediction pass ranks by its own fp32 scores alone (no fp64 referee near the golds)
-    {"wide_waves", "KTUP_WIDE_WAVES", {env_int("KTUP_WIDE_WAVES", 8)}},     // d = 256 coordinate-sliced K5-K7 backward / fused step: waves that share a 16-pair tile (8, or 4: the round-3 form)
+    {"wide_waves", "KTUP_WIDE_WAVES", {env_int("KTUP_WIDE_WAVES", 4)}},     // d = 256 coordinate-sliced K5-K7 backward / fused step: waves that share a 16-pair tile: 4, or 8 (two per SIMD: 1 us faster alone,
+                                                                            // but its 2 x 240 registers per SIMD leave no room for the route's kernels beside it: 0.149 against 0.139 ms per config-5 step)
 };
 Option* find(const char* name) {
   for (auto& o : g_opts)

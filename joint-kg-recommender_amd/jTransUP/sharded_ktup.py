@@ -114,6 +114,15 @@ class _ShardedStepBase(object):
                 side.wait_stream(torch.cuda.current_stream(self.dev))
                 for launch in item[1]:
                     launch()
+            elif item[0] == 'beside':                         # (main launch, side launches): both ordered after everything so far.  The
+                main = torch.cuda.current_stream(self.dev)    # MAIN launch is enqueued first: a captured graph keeps the branch it meets first
+                ev = torch.cuda.Event()                       # on the queue of the launches around it, and the other branch pays the
+                ev.record(main)                               # cross-queue latency (~12 us each way) -- the route has 25 us to spare, the
+                for launch in item[1]:                        # step kernel none
+                    launch()
+                side.wait_event(ev)
+                for launch in item[2]:
+                    launch()
             elif item[0] == 'join':
                 torch.cuda.current_stream(self.dev).wait_stream(side)
 
@@ -361,9 +370,9 @@ class ShardedKtupStepper(_ShardedStepBase):
             else:
                 tail = [reduce_, gnorm, apply_]
             if beside:
-                return [[('fork', [route_phase(3, side)]), step, ('join',)] + tail]
+                return [[('beside', [step], [route_phase(3, side)]), ('join',)] + tail]
             if self.direct and side is not None:
-                return [[route_phase(1, stream), ('fork', [route_phase(2, side)]), step, ('join',)] + tail]
+                return [[route_phase(1, stream), ('beside', [step], [route_phase(2, side)]), ('join',)] + tail]
             return [([route, step] if self.direct else [route, pack, step]) + tail]
         capo = arr(_i64s(self.cap_own))
         eoff_o = arr(_i64s([0, self.cap[0], self.cap[0] + self.cap[1], self.capsum]))
@@ -567,7 +576,7 @@ class ShardedKgStepper(_ShardedStepBase):
                           _p(self.sort_ws), E, _p(self.Gwire), d, _p(self.xkeys), n_small, P, sgp, sp0p, ss0p, None, None, None, self.lr,
                           self.eps, _p(self.acc), SLOTS, self.max_norm, skip_i, None, *close, stream)
             if self.direct and side is not None:
-                return [[route_phase(1, stream), ('fork', [route_phase(2, side)]), order, step, ('join',), rnorm, rapply]]
+                return [[route_phase(1, stream), ('beside', [order, step], [route_phase(2, side)]), ('join',), rnorm, rapply]]
             return [[route_phase(0, stream)] + ([] if self.direct else [pack]) + [order, step, rnorm, rapply]]
         capo = arr(_i64s(self.cap_own))
         eoff_o = arr(_i64s([0, self.capsum]))

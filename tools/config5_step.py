@@ -44,7 +44,7 @@ def fused_main(args):
     item2ent = torch.randint(0, NE, (NI,), generator=torch.Generator(device=dev).manual_seed(7), device=dev).to(torch.int32)
     st = ShardedKtupStepper(Ut, It, Et, *small, item2ent, batch=B, kind='adagrad', lr=0.005, max_norm=5.0, use_graphs=not args.no_graphs,
                             force_exchange=args.exchange, overlap_route=not args.no_overlap, fused_apply=not args.gradient_buffer, direct=False if (args.no_direct or args.exchange or world > 1) else None,
-                            orth=args.kind != 'rec')
+                            orth=args.kind != 'rec', route_beside=args.route_beside)
     rec = st
     kg = None
     if args.kind != 'rec':             # the kg half of the joint schedule (knowledgable_recommendation.py:345-383) on the same entity shard
@@ -114,6 +114,7 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--d', type=int, default=256)
     ap.add_argument('--kind', default='rec', choices=['rec', 'kg', 'joint'], help='rec: the rec step alone (the round-3 figure); kg: the kg step alone; joint: the 7 : 3 cycle of knowledgable_recommendation.py:320')
+    ap.add_argument('--route-beside', action='store_true', help='rec step: the step kernel reads the id columns itself, the WHOLE route (init launch included) runs on the second graph branch')
     ap.add_argument('--zipf', type=float, default=0.0, help='draw ids from Zipf(a) (hot rows: contention in the row-gradient atomics) instead of uniformly, e.g. 1.05')
     ap.add_argument('--full', action='store_true', help='the whole 10M / 1M / 5M tables on this rank set (needs ~17 GB per rank at world 1)')
     ap.add_argument('--legacy', action='store_true', help="round 2's route: parallel.ShardedStep through autograd (eager torch ops around the kernels)")

@@ -1064,10 +1064,10 @@ def config5_leg(device, world, rank, steps=100, warmup=10, batch=8192, full=True
                                         'buffer, the three all-to-alls as device copies')
         out['exchange_form']['joint'] = run('exchange joint', what='joint', force_exchange=True)
     out['note'] = ('top level: the rec step (the round-3 figure); kg_step / joint: the kg half and the 7 : 3 cycle.  One rank: ONE graph of '
-                   '8 launches per step (route 5, fused step 1, norm walk + boundary norm 2... the apply walk carries the small tables and '
-                   'the bookkeeping), the route on a second graph branch beside the step kernel; N > 1: five graph segments around three '
-                   'equal-split all-to-alls and one fp64 all-reduce (small tables + norm + overflow flag); round 3: 0.171 ms per rec step, '
-                   'no kg step')
+                   '8 launches per step (route 5, fused step 1, norm walk 1, apply walk 1 -- the walks carry the small tables and the '
+                   'bookkeeping as extra workgroups), four of them dependent on one queue, the route\'s other four on a second graph branch '
+                   'beside the step kernel; N > 1: five graph segments around three equal-split all-to-alls and one fp64 all-reduce (small '
+                   'tables + norm + overflow flag); round 3: 0.171 ms per rec step, no kg step')
     return out
 
 

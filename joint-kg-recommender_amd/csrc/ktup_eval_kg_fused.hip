@@ -419,8 +419,7 @@ template <typename G>
 __global__ __launch_bounds__(NW * 64) void kg_count_mc_kernel(FArgs a) {
   constexpr int NCH = G::NCH, P4 = G::P4, QV = G::QV, GMX = GS;
   // what a lane keeps in registers across the stages (128 VGPRs per wave at 16 waves per CU): the gold scores and the three scalars
-  // of its four keys, and the query operands of its MFMAs unless the key has two vectors (mode 1) or the table look-ups of mode 2 at
-  // d >= 100 take the room (measured: the same pass time with the operands read from LDS, thresholds from LDS, or six spilled registers)
+  // of its four keys, and -- at the narrow widths, one vector per key -- the query operands of its MFMAs (see QR below)
   constexpr bool QREGS = !G::TRANSH && !(G::WTAB && NCH >= 25);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   v4* Q = reinterpret_cast<v4*>(smem);
@@ -442,7 +441,7 @@ __global__ __launch_bounds__(NW * 64) void kg_count_mc_kernel(FArgs a) {
   }
   int most = 0;
   if (tid < UB && u0 + tid < a.nq) most = (int)min((int64_t)GMX, a.gold_off[u0 + tid + 1] - a.gold_off[u0 + tid] - a.gbase);
-  const bool wg_one = !__syncthreads_or(most > 1), wg_two = !__syncthreads_or(most > 2);
+  const bool wg_one = !__syncthreads_or(most > 1), wg_two = !__syncthreads_or(most > 2), wg_three = !__syncthreads_or(most > 3);
   stage_queries<G>(a, Q, u0, NW * 64);
   const int seg = (int)blockIdx.y * NBAND + band;
   if (tid == 0) unc_n = a.ktol ? a.unc_count[seg] : 0;
@@ -468,6 +467,10 @@ __global__ __launch_bounds__(NW * 64) void kg_count_mc_kernel(FArgs a) {
   // runs the loop with one / two compares per score instead of four (the compares are a quarter of the sweep: 921 -> 829 us with two)
   auto run = [&](auto gn_c) {
   constexpr int GN = decltype(gn_c)::value;
+  // the query operands stay in registers only where they fit beside the counters and window bounds: at d >= 100 they do not for any
+  // number of golds (measured on the 1-3-gold pass of the drivers: 106-122 spilled registers, the TransE sweep 2.7 ms; 0.95 ms with
+  // the operands read from LDS like modes 1 / 2 do)
+  constexpr bool QR = QREGS && NCH < 25 && GN <= 2;
   int cnt[4][GN];
   float lo[4][GN], hi[4][GN];                                   // a score counts below lo, is out above hi; in between: the list
   v4 qsr[4];
@@ -482,7 +485,7 @@ __global__ __launch_bounds__(NW * 64) void kg_count_mc_kernel(FArgs a) {
     wo[r] = (G::WTAB && u0 + ur < a.nq) ? (int32_t)(a.rel[u0 + ur] * a.ldw) : 0;
   }
   QRegs<G> qr;
-  if constexpr (QREGS) qr.load(qa);
+  if constexpr (QR) qr.load(qa);
   const int t0 = band * a.tiles_per_band, t1 = t0 + a.tiles_per_band;
   // a thread's share of a 64-candidate stage (IB * NCH float4 over 1024 threads: at most NLD each) and its candidate's |e|^2 (mode 2:
   // and the four w.e of its keys), fetched one stage AHEAD into registers: the loads of stage t + 1 are in flight under the matrix
@@ -543,7 +546,7 @@ __global__ __launch_bounds__(NW * 64) void kg_count_mc_kernel(FArgs a) {
     v4 ce, we;
     if constexpr (G::TRANSH) tile_dots<G>(qa, cb, ce, we);      // two query vectors per key do not fit the registers (measured: spills)
     else {
-      if constexpr (QREGS) tile_dots_q<G>(qr, cb, ce, we); else ce = tile_dot1<G>(qa, cb);
+      if constexpr (QR) tile_dots_q<G>(qr, cb, ce, we); else ce = tile_dot1<G>(qa, cb);
       we = (v4){wl[0], wl[1], wl[2], wl[3]};
     }
     const int64_t cand = i0 + 16 * it + j;
@@ -608,6 +611,7 @@ __global__ __launch_bounds__(NW * 64) void kg_count_mc_kernel(FArgs a) {
   };
   if (wg_one) run(std::integral_constant<int, 1>{});
   else if (wg_two) run(std::integral_constant<int, 2>{});
+  else if (wg_three) run(std::integral_constant<int, 3>{});
   else run(std::integral_constant<int, GMX>{});
   if (a.ktol) {
     __syncthreads();

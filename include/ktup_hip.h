@@ -593,14 +593,24 @@ int ktup_optim_step(int kind, int n_tensors, float* const* params, float* const*
  *   the squared gradient norm of the last clipped step.  max_norm <= 0: no clipping, no barrier.  loss_slots (may be NULL):
  *   *loss_out = loss_scale * sum(loss_slots[0..n_slots)) (also added to *loss_acc, a running sum, if not NULL) and
  *   loss_slots := 0 for the next step -- the step kernels above accumulate into them.  The barrier's poll is bounded; after a timeout (never observed; a lost workgroup would otherwise
- *   hang the GPU) ws[KTUP_OPTIM_WS_DOUBLES - 1] reads non-zero (as a uint64) and that step was applied unclipped.          */
+ *   hang the GPU) ws[KTUP_OPTIM_WS_DOUBLES - 1] reads non-zero (as a uint64) and that step was applied unclipped.
+ *
+ * gnorm (may be NULL; KTUP_GNORM_WS_DOUBLES doubles, zero-filled ONCE by the caller, the same pointer to the step launch and to the
+ *   ktup_optim_clip_step that follows it): the gradient norm WITHOUT a pass over the gradients.  ktup_train_rec_step /
+ *   ktup_train_kg_step then issue every gradient add as a returning atomic and track the squared norm of the buffers they build
+ *   (adding v onto a cell that held `old` raises it by (2 old + v) v), one double atomic per workgroup into the workspace;
+ *   ktup_optim_clip_step reads the sum instead of running its norm pass and its grid barrier (utils/trainer.py:63-81
+ *   clip_grad_norm_ + step: same norm up to fp32 rounding of the tracked terms).  Requires that the gradient buffers were zero-filled
+ *   before the step launch (zero_grads of the previous ktup_optim_clip_step), that nothing else adds to them in between (one
+ *   process: an all-reduce of the gradients changes their norm) and that max_norm > 0.                                       */
+#define KTUP_GNORM_WS_DOUBLES 64
 int ktup_train_step_supported(int kind, int d, int n_pref);
 int ktup_train_rec_step(const float* U, int64_t ldu, const float* I, int64_t ldi, const float* E, int64_t lde,
                         const int32_t* item2ent, int64_t ent_pad, const float* pref, const float* pref_norm,
                         const float* rel, const float* norm, int64_t ldp, int n_pref, int d, const int64_t* u_ids,
                         const int64_t* i_ids, int64_t B, int l1, int gumbel_mode, const float* uniform, uint64_t seed,
                         uint64_t offset, float target, float gscale, int orth, float* loss, float* gU, float* gI, float* gE,
-                        float* gP, float* gPn, float* gR, float* gRn, void* stream);
+                        float* gP, float* gPn, float* gR, float* gRn, double* gnorm, void* stream);
 /* ktup_train_rec_step with the row gradients STORED instead of accumulated by atomics -- for ktup_shard_reduce_rows / large
  * batches: u_ids holds B ids (example k's user: a BPR example's positive and negative pair share it), i_ids 2B (positives then
  * negatives); row k of GU (B x d) = the user-row gradient of example k from BOTH pairs, row k of GV (2B x d) = the item-row
@@ -618,7 +628,7 @@ int ktup_train_rec_step_rows(const float* U, int64_t ldu, const float* I, int64_
                              const int64_t* neg_ids, const int64_t* cursor, int64_t n_batches, void* stream);
 int ktup_train_kg_step(int transh, const float* E, int64_t lde, const float* R, int64_t ldr, const float* Nrm, int64_t ldn,
                        int d, const int64_t* h, const int64_t* t, const int64_t* r, int64_t B, int l1, float margin,
-                       float gscale, int regs, float* loss, float* gE, float* gR, float* gN, void* stream);
+                       float gscale, int regs, float* loss, float* gE, float* gR, float* gN, double* gnorm, void* stream);
 /* ktup_train_kg_step for row-sharded entity tables (config 5's kg steps; csrc/ktup_shard_kg.hip): ent_ids = [ph ; pt ; nh ; nt]
  * (4B rows of E: a shard's rows, or wire rows of a compact table), rel_ids = [pr ; nr] (2B); the entity-row gradients of triple k
  * are STORED as rows k, B + k, 2B + k, 3B + k of GE (4B x d, pitch d) for ktup_shard_reduce_norm / _apply instead of accumulated
@@ -641,8 +651,8 @@ int ktup_optim_clip_step_capacity(int kind);
 int ktup_optim_clip_step(int kind, int n_tensors, float* const* params, float* const* grads, float* const* state1,
                          float* const* state2, const int64_t* sizes, const int64_t* steps, const int64_t* steps_dev,
                          const int32_t* first, float lr, float weight_decay, float momentum, float beta1, float beta2, float eps,
-                         float alpha, double* ws, float max_norm, int zero_grads, float* loss_slots, int n_slots, float loss_scale,
-                         float* loss_out, float* loss_acc, void* stream);
+                         float alpha, double* ws, double* gnorm, float max_norm, int zero_grads, float* loss_slots, int n_slots,
+                         float loss_scale, float* loss_out, float* loss_acc, void* stream);
 
 #ifdef __cplusplus
 }

@@ -75,6 +75,32 @@ KTUP_DEV void atomic_add4(float* p, float4 v) {
   atomicAdd(p + 3, v.w);
 }
 
+// ---- the gradient norm without a pass over the gradients (the B = 512 fused step).  A kernel that BUILDS zero-filled gradient buffers
+// with atomics can track the squared norm of what it builds: adding v onto a cell that held `old` raises the buffer's squared norm by
+// (2 old + v) v, and the returning form of the atomic hands `old` back.  Exact (up to fp32 rounding of the terms) as long as EVERY add
+// into the buffers goes through these.  The per-workgroup totals go to a small workspace the optimizer launch reads (gnorm_* below,
+// ktup_optim.hip clip_step_kernel): no grid barrier around a norm pass any more.
+// Issue first, use later: a wave that consumes each returned value right after its atomic pays one memory round trip (~0.35 us) per
+// atomic -- the rec step's ~40 dependent ones cost 13 us.  The callers collect the old values of a whole group of adds in registers
+// and fold them into their sum once, after the last add of the group was issued.
+KTUP_DEV float sq_gain(float old, float v) { return fmaf(2.f, old, v) * v; }
+KTUP_DEV float4 atomic_add4_old(float* p, float4 v) {
+  float4 o;
+  o.x = atomicAdd(p + 0, v.x); o.y = atomicAdd(p + 1, v.y); o.z = atomicAdd(p + 2, v.z); o.w = atomicAdd(p + 3, v.w);
+  return o;
+}
+KTUP_DEV float sq_gain4(float4 o, float4 v) { return (sq_gain(o.x, v.x) + sq_gain(o.y, v.y)) + (sq_gain(o.z, v.z) + sq_gain(o.w, v.w)); }
+// Workspace (KTUP_GNORM_WS_DOUBLES doubles, zero-filled once by the caller): word 0 = steps taken (its low bit picks the slot set the
+// NEXT building kernel adds to), word 1 = the set the last building kernel used, double 2 = the last squared norm (for the host),
+// doubles 8 .. 8 + 2 x 16 = two sets of 16 slots.  The building kernel adds to set (steps & 1); the optimizer launch sums that set,
+// clears the OTHER one (idle until the next building kernel) and bumps `steps` -- no set is ever cleared while someone adds to it.
+constexpr int GNORM_SLOTS = 16, GNORM_SET0 = 8;
+KTUP_DEV int gnorm_set(const double* ws) { return (int)(reinterpret_cast<const unsigned long long*>(ws)[0] & 1ull); }
+KTUP_DEV void gnorm_add(double* ws, int set, double wg_total) {      // one thread per workgroup
+  if (wg_total != 0.0) atomicAdd(ws + GNORM_SET0 + GNORM_SLOTS * set + (blockIdx.x % GNORM_SLOTS), wg_total);
+  if (blockIdx.x == 0) reinterpret_cast<unsigned long long*>(ws)[1] = (unsigned long long)set;
+}
+
 // ST-Gumbel noise, transUP.py:159-162 : g = -log(-log(u + 1e-20) + 1e-20)
 KTUP_DEV float gumbel_from_uniform(float u) { return -logf(-logf(u + 1e-20f) + 1e-20f); }
 

@@ -153,7 +153,15 @@ struct QGeom {
   static constexpr int NCH = NCH_, D = 4 * NCH, NP = NP_, P4 = 4 * NP;
   static constexpr int ROWB = D + 3 * P4;                       // item row: [x ; Rx ; L ; Nx]
   static constexpr int RB4 = ROWB / 4;
-  static constexpr int ROW4 = RB4 | 1;                          // odd float4 pitch in LDS: 16 rows x 4 k-quads tile the banks
+  // An item row is [x ; Rx ; L ; Nx | its 4 scalars (| one zero float4)] at an ODD float4 pitch (16 rows x 4 k-quads tile the LDS banks)
+  // -- in memory exactly as in LDS, so a tile of 16 consecutive items is ONE contiguous run of IBT * ROW4 float4 and travels by
+  // LDS-DMA (global_load_lds_dwordx4: destination = a wave-uniform LDS address + 16 B x lane): no staging registers (they were 12 of
+  // the lane's 168, with 9 more for the lane-constant source / destination addresses: 18 spilled), no ds_write pass (whose 16-lane
+  // groups straddled the row pads: ~16 two-way bank conflicts per tile)
+  static constexpr int ROW4 = (RB4 + 1) | 1;
+  static constexpr int GROW = 4 * ROW4;                         // floats per item row
+  static constexpr int TSLOTS = IBT * ROW4;                     // float4 per tile
+  static constexpr int DPW = ((TSLOTS + 63) / 64 + 3) / 4;      // DMA instructions per wave and tile (wave w issues pieces w, w + 4, ...)
   static constexpr int SOFF4 = (D + P4) / 4;                    // float4 offset of [L ; Nx] inside a row
   static constexpr int KA = (D + 2 * P4 + 15) / 16, KS = (2 * P4 + 15) / 16, KN = (P4 + 15) / 16;   // 16-blocks of K
   static constexpr int NA = KA + 2 * KS + KN;                   // float4 A operands per lane: [AA | S | AN | NN]
@@ -161,7 +169,6 @@ struct QGeom {
   static constexpr int SUB = 1;                                 // 16-item sub-tiles per buffer = per workgroup barrier (2: no faster, and the
                                                                 // pending-candidate buffers below need the LDS for three workgroups per CU)
   static constexpr int TILE_F4 = SUB * IBT * ROW4 + 4;          // + pad: the padded K blocks read a little past the last row
-  static constexpr int LPT = (IBT * RB4 + IBT + 255) / 256;     // float4 loads per thread and SUB-tile
 #ifndef KTUP_EVAL_MINW3
 #define KTUP_EVAL_MINW3 3
 #endif
@@ -170,7 +177,7 @@ struct QGeom {
 
 struct QArgs {
   const float *A, *SCU;          // users: AROW floats + 4 scalars each
-  const float *B, *ISC;          // items: ROWB floats + 4 scalars each
+  const float* B;                // items: rows of GROW floats (operands, then the 4 scalars)
   int64_t nq, n_items;
   const int64_t* filt_off; const int32_t* filt_ids;
   int topn, nsplit; int64_t split_items; uint64_t* part; int bm_words;
@@ -179,14 +186,13 @@ struct QArgs {
 
 template <typename G>
 __global__ __launch_bounds__(256, G::MINW) void eval_pass_q_kernel(QArgs a) {
-  constexpr int RB4 = G::RB4, ROW4 = G::ROW4, KA = G::KA, KS = G::KS, KN = G::KN, NA = G::NA, LPT = G::LPT;
+  constexpr int RB4 = G::RB4, ROW4 = G::ROW4, KA = G::KA, KS = G::KS, KN = G::KN, NA = G::NA, DPW = G::DPW;
+  static_assert(G::SUB == 1, "one 16-item tile per buffer");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   v4* Xb = reinterpret_cast<v4*>(smem);                                   // [2][TILE_F4] item tiles
-  constexpr int SUB = G::SUB;
-  float* isc = reinterpret_cast<float*>(Xb + 2 * G::TILE_F4);             // [2][SUB * IBT][4] item scalars
   const int tid = threadIdx.x, lane = tid & 63, kq = lane >> 4, j = lane & 15;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  char* wbase = reinterpret_cast<char*>(isc + 2 * SUB * IBT * 4) + (size_t)w * wave_lds_bytes(a.bm_words);
+  char* wbase = reinterpret_cast<char*>(Xb + 2 * G::TILE_F4) + (size_t)w * wave_lds_bytes(a.bm_words);
   float* usc = reinterpret_cast<float*>(wbase);                           // [16][4] user scalars
   uint32_t* bm = reinterpret_cast<uint32_t*>(usc + 64);                   // [16][bm_words] filter bits of this split
   uint64_t* pbuf = reinterpret_cast<uint64_t*>(wbase + wave_lds_bytes(a.bm_words) - WAVE_TAIL);   // [16][PCAP] pending candidates
@@ -243,42 +249,30 @@ __global__ __launch_bounds__(256, G::MINW) void eval_pass_q_kernel(QArgs a) {
   }
   __syncthreads();                                                        // tiles zeroed, bitmaps and scalars in place
   const int64_t ntile = (a.dbg & 8) ? 0 : (i_hi - i_lo + IBT - 1) / IBT;    // (dbg 8: prologue and epilogue only)
-  v4 pre[LPT];
-  const float* fsrc[LPT];
-  int frow[LPT], fdst[LPT];
+  // this lane's float4 of every DMA piece of its wave: byte offset inside a tile (tiles past the table's end re-read its last row:
+  // their items are masked out below, the operands only have to be finite)
+  uint32_t soff[DPW];
 #pragma unroll
-  for (int l = 0; l < LPT; ++l) {
-    const int idx = tid + 256 * l;
-    if (idx < IBT * RB4) {
-      const int row = idx / RB4, c = idx - row * RB4;
-      fsrc[l] = a.B + (i_lo + row) * G::ROWB + 4 * c;
-      frow[l] = row;
-      fdst[l] = row * ROW4 + c;
-    } else if (idx < IBT * RB4 + IBT) {
-      const int row = idx - IBT * RB4;
-      fsrc[l] = a.ISC + (i_lo + row) * 4;
-      frow[l] = row;
-      fdst[l] = -1 - row;
-    } else {
-      fsrc[l] = nullptr; frow[l] = IBT; fdst[l] = 0;
-    }
+  for (int k = 0; k < DPW; ++k) {
+    const int slot = 64 * (w + 4 * k) + lane;
+    soff[k] = slot < G::TSLOTS ? (uint32_t)slot * 16u : 0xffffffffu;
   }
-  auto fetch = [&](int64_t t) {
+  auto dma = [&](int64_t t, int buf) {                                    // tile t of this split -> LDS buffer `buf`
+    const int64_t row0 = i_lo + t * IBT;
+    const char* src = reinterpret_cast<const char*>(a.B + row0 * G::GROW);
+    v4* dst = Xb + buf * G::TILE_F4 + 64 * w;
+    const bool tail = row0 + IBT > a.n_items;                             // (uniform)
 #pragma unroll
-    for (int l = 0; l < LPT; ++l) {
-      v4 val = (v4){0.f, 0.f, 0.f, 0.f};
-      if (fsrc[l] && i_lo + t * IBT + frow[l] < i_hi) val = *reinterpret_cast<const v4*>(fsrc[l] + t * IBT * (fdst[l] >= 0 ? G::ROWB : 4));
-      pre[l] = val;
-    }
-  };
-  auto stash = [&](int buf, int sub) {                                    // registers -> sub-tile `sub` of LDS buffer `buf`
-    v4* X = Xb + buf * G::TILE_F4 + sub * IBT * ROW4;
-#pragma unroll
-    for (int l = 0; l < LPT; ++l) {
-      if (fsrc[l]) {
-        if (fdst[l] >= 0) X[fdst[l]] = pre[l];
-        else *reinterpret_cast<v4*>(isc + ((buf * SUB + sub) * IBT + (-1 - fdst[l])) * 4) = pre[l];
+    for (int k = 0; k < DPW; ++k) {
+      if (soff[k] == 0xffffffffu) continue;
+      const char* from = src + soff[k];
+      if (tail) {
+        const uint32_t slot = soff[k] >> 4, row = slot / ROW4, c = slot - row * ROW4;
+        const int64_t r = row0 + row < a.n_items ? row0 + row : a.n_items - 1;
+        from = reinterpret_cast<const char*>(a.B + r * G::GROW + 4 * c);
       }
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)from,
+                                       (__attribute__((address_space(3))) void*)(dst + 256 * k), 16, 0, 0);
     }
   };
   const int rowbase = 16 * kq;
@@ -347,7 +341,7 @@ __global__ __launch_bounds__(256, G::MINW) void eval_pass_q_kernel(QArgs a) {
       __builtin_amdgcn_sched_barrier(0);
       bcur = bnext;
     }
-    const v4 is4 = *reinterpret_cast<const v4*>(isc + ((buf * SUB + sub) * IBT + j) * 4);
+    const v4 is4 = Xb[buf * G::TILE_F4 + (sub * IBT + j) * ROW4 + RB4];      // the row's scalars ride in its tile slot
     const int64_t item = i_lo + t * IBT + j;
     const int64_t lid = item - i_lo;
     const bool iok = item < i_hi;
@@ -383,23 +377,15 @@ __global__ __launch_bounds__(256, G::MINW) void eval_pass_q_kernel(QArgs a) {
     if (__builtin_amdgcn_ballot_w64(full)) flush(false);
   };
   if (ntile > 0) {
-#pragma unroll
-    for (int sub = 0; sub < SUB; ++sub) {
-      fetch(sub);                                                          // (tiles past the split's end load zeros)
-      stash(0, sub);
-    }
-    __syncthreads();
+    if (!(a.dbg & 2)) dma(0, 0);
+    __syncthreads();                                                       // (carries the vmcnt(0) that lands the DMA)
   }
-  // SUB tiles per workgroup barrier; the next group's loads are in flight under each tile's MFMAs
-  for (int64_t t0 = 0; t0 < ntile; t0 += SUB) {
-    const int buf = (int)((t0 / SUB) & 1);
-    const bool more = t0 + SUB < ntile;
-#pragma unroll
-    for (int sub = 0; sub < SUB; ++sub) {
-      if (more && !(a.dbg & 2)) fetch(t0 + SUB + sub);
-      if (t0 + sub < ntile) compute((a.dbg & 2) ? 0 : buf, sub, t0 + sub);
-      if (more && !(a.dbg & 2)) stash(buf ^ 1, sub);
-    }
+  // one tile per workgroup barrier; the next tile's DMA is in flight under this tile's MFMAs.  Buffer buf ^ 1 was last read in the
+  // previous iteration, whose closing barrier every wave has passed; its new contents are read after this iteration's barrier.
+  for (int64_t t0 = 0; t0 < ntile; ++t0) {
+    const int buf = (int)(t0 & 1);
+    if (t0 + 1 < ntile && !(a.dbg & 2)) dma(t0 + 1, buf ^ 1);
+    compute((a.dbg & 2) ? 0 : buf, 0, t0);
     if (!(a.dbg & 4)) __syncthreads();
   }
   flush(true);
@@ -454,6 +440,7 @@ struct RowsSide {
   const float* X; int64_t ldx; const int64_t* ids;   // rows X[ids[row]] (ids == NULL: X[row])
   const float* E; int64_t lde; const int32_t* map;    // + E[map[row]] (KTUP items: the aligned entity, the pad row being zero); NULL = none
   int64_t nrows; float* out; int orow; float* scal; int blocks;
+  int opitch, spitch;                                 // floats between two rows of out / of scal (items: both G::GROW, scal = out + ROWB)
 };
 
 template <bool IS_USER, int NCH, int NP>
@@ -520,7 +507,7 @@ KTUP_DEV void pspace_rows(const RowsSide& sd, int block, int P, const float* __r
     d_nl = group_sum<64>(d_nl); d_rl = group_sum<64>(d_rl);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    float* o = out + row * (int64_t)orow;
+    float* o = out + row * (int64_t)sd.opitch;
     if (IS_USER) {
       // [AA: -2u ; -2L ; 2 (Ru + G_RR L) ; 0] [S: Nu ; -L ; 0] [AN: Nu + G_RN^T L + G_RN L ; -L ; 0] [NN: 2 G_NN L ; 0]
       const int oS = 16 * ka16, oAN = oS + 16 * ks16, oNN = oAN + 16 * ks16;
@@ -543,12 +530,15 @@ KTUP_DEV void pspace_rows(const RowsSide& sd, int block, int P, const float* __r
         o[k] = v;
       }
       // u.NU, |AU|^2, AU.NU, |NU|^2
-      if (lane == 0) *reinterpret_cast<float4*>(scal + row * 4) = make_float4(d_nl, sq + 2.f * d_rl + q_rr, d_nl + q_rn, q_nn);
+      if (lane == 0) *reinterpret_cast<float4*>(scal + row * (int64_t)sd.spitch) = make_float4(d_nl, sq + 2.f * d_rl + q_rr, d_nl + q_rn, q_nn);
     } else {
       // [x ; Rx ; L ; Nx]
       for (int k = lane; k < orow; k += 64) o[k] = k < d ? xs[k] : k < d + P4 ? Rx[k - d] : k < d + 2 * P4 ? L[k - d - P4] : Nx[k - d - 2 * P4];
       // v.NV, |C0|^2, C0.NV, |NV|^2
-      if (lane == 0) *reinterpret_cast<float4*>(scal + row * 4) = make_float4(d_nl, sq - 2.f * d_rl + q_rr, d_nl - q_rn, q_nn);
+      if (lane == 0) {
+        *reinterpret_cast<float4*>(scal + row * (int64_t)sd.spitch) = make_float4(d_nl, sq - 2.f * d_rl + q_rr, d_nl - q_rn, q_nn);
+        for (int k = orow + 4; k < sd.opitch; ++k) o[k] = 0.f;              // the pitch's spare float4 (padded K blocks may read it)
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -661,7 +651,7 @@ __global__ __launch_bounds__(256) void pspace_rows_mc_kernel(RowsSide users, Row
         const v4 v = xv[jj] + ev[jj];
         XT[e] = v;
         if (row0 + r < sd.nrows)                                  // the x part of the operand row: [-2u ...] | [x ...]
-          *reinterpret_cast<v4*>(sd.out + (row0 + r) * (int64_t)orow + 4 * c) = is_user ? -2.f * v : v;
+          *reinterpret_cast<v4*>(sd.out + (row0 + r) * (int64_t)sd.opitch + 4 * c) = is_user ? -2.f * v : v;
       }
     }
   }
@@ -714,7 +704,7 @@ __global__ __launch_bounds__(256) void pspace_rows_mc_kernel(RowsSide users, Row
   q_rr = allsum_kq(q_rr); q_rn = allsum_kq(q_rn); q_nn = allsum_kq(q_nn); d_nl = allsum_kq(d_nl); d_rl = allsum_kq(d_rl);
   const int64_t row = row0 + j;
   if (row >= sd.nrows) return;
-  float* o = sd.out + row * (int64_t)orow;
+  float* o = sd.out + row * (int64_t)sd.opitch;
   if (is_user) {
     // [AA: -2u ; -2L ; 2 (Ru + G_RR L) ; 0] [S: Nu ; -L ; 0] [AN: Nu + G_RN^T L + G_RN L ; -L ; 0] [NN: 2 G_NN L ; 0]
     const int oS = 16 * ka16, oAN = oS + 16 * ks16, oNN = oAN + 16 * ks16;
@@ -739,7 +729,7 @@ __global__ __launch_bounds__(256) void pspace_rows_mc_kernel(RowsSide users, Row
     for (int k = oAN + 2 * P4 + kq; k < oNN; k += 4) o[k] = 0.f;
     for (int k = oNN + P4 + kq; k < orow; k += 4) o[k] = 0.f;
     // u.NU, |AU|^2, AU.NU, |NU|^2
-    if (kq == 0) *reinterpret_cast<float4*>(sd.scal + row * 4) = make_float4(d_nl, sq + 2.f * d_rl + q_rr, d_nl + q_rn, q_nn);
+    if (kq == 0) *reinterpret_cast<float4*>(sd.scal + row * (int64_t)sd.spitch) = make_float4(d_nl, sq + 2.f * d_rl + q_rr, d_nl + q_rn, q_nn);
   } else {
     // [x ; Rx ; L ; Nx]
 #pragma unroll
@@ -754,11 +744,14 @@ __global__ __launch_bounds__(256) void pspace_rows_mc_kernel(RowsSide users, Row
         }
       }
     // v.NV, |C0|^2, C0.NV, |NV|^2
-    if (kq == 0) *reinterpret_cast<float4*>(sd.scal + row * 4) = make_float4(d_nl, sq - 2.f * d_rl + q_rr, d_nl - q_rn, q_nn);
+    if (kq == 0) {
+      *reinterpret_cast<float4*>(sd.scal + row * (int64_t)sd.spitch) = make_float4(d_nl, sq - 2.f * d_rl + q_rr, d_nl - q_rn, q_nn);
+      for (int k = orow + 4; k < sd.opitch; ++k) o[k] = 0.f;                // the pitch's spare float4 (padded K blocks may read it)
+    }
   }
 }
 
-struct QScratch { float *grams, *gs, *A, *SCU, *B, *ISC; uint64_t* part; };
+struct QScratch { float *grams, *gs, *A, *SCU, *B; uint64_t* part; };
 
 template <typename G>
 QScratch q_carve(void* scratch, int64_t nq, int64_t n_items) {
@@ -768,8 +761,7 @@ QScratch q_carve(void* scratch, int64_t nq, int64_t n_items) {
   s.gs = p; p += 4 * 2 * 8 * 64;                                 // RGeom::GS_F at its largest (PT = 2, NP = 8)
   s.A = p; p += (size_t)nq * G::AROW;
   s.SCU = p; p += (size_t)nq * 4;
-  s.B = p; p += (size_t)n_items * G::ROWB + 64;                  // + slack: the last tile fetch never reads past it, the pad keeps 16-B alignment
-  s.ISC = p; p += (size_t)n_items * 4;
+  s.B = p; p += (size_t)n_items * G::GROW + 64;                  // (eval_pass_pspace_bytes counts the same)
   s.part = reinterpret_cast<uint64_t*>(p);
   return s;
 }
@@ -790,8 +782,8 @@ int launch_q(const float* U, int64_t ldu, const int64_t* u_ids, int64_t nq, cons
                      rows_mc ? q.gs : nullptr, R::PT, G::NP);
   const size_t lds_rows = (size_t)4 * (G::D + 7 * G::P4) * sizeof(float);
   // many small workgroups: a row is a chain of dependent round trips (id -> row -> products -> store), hidden only by occupancy
-  RowsSide us{U, ldu, u_ids, nullptr, 0, nullptr, nq, q.A, G::AROW, q.SCU, grid_for((nq + 3) / 4, 2048)};
-  RowsSide is{I, ldi, nullptr, E, lde, item2ent, n_items, q.B, G::ROWB, q.ISC, grid_for((n_items + 3) / 4, 2048)};
+  RowsSide us{U, ldu, u_ids, nullptr, 0, nullptr, nq, q.A, G::AROW, q.SCU, grid_for((nq + 3) / 4, 2048), G::AROW, 4};
+  RowsSide is{I, ldi, nullptr, E, lde, item2ent, n_items, q.B, G::ROWB, q.B + G::ROWB, grid_for((n_items + 3) / 4, 2048), G::GROW, G::GROW};
   if (rows_mc) {    // 16 rows per wave on the matrix cores
     us.blocks = (int)((nq + 63) / 64); is.blocks = (int)((n_items + 63) / 64);
     (void)hipFuncSetAttribute((const void*)pspace_rows_mc_kernel<G::NCH, G::NP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)R::LDS);
@@ -803,7 +795,7 @@ int launch_q(const float* U, int64_t ldu, const int64_t* u_ids, int64_t nq, cons
   }
   if (int e = check_launch(name)) return e;
   QArgs a{};
-  a.A = q.A; a.SCU = q.SCU; a.B = q.B; a.ISC = q.ISC; a.nq = nq; a.n_items = n_items;
+  a.A = q.A; a.SCU = q.SCU; a.B = q.B; a.nq = nq; a.n_items = n_items;
   a.filt_off = filt_off; a.filt_ids = filt_ids; a.topn = topn; a.part = q.part; a.dbg = opt_dbg_eval();
   const int64_t ublocks = (nq + 63) / 64;
   int nsplit = (int)(256 * G::MINW / ublocks);                            // MINW workgroups per CU are resident: ONE round
@@ -816,7 +808,7 @@ int launch_q(const float* U, int64_t ldu, const int64_t* u_ids, int64_t nq, cons
   nsplit = (int)((n_items + a.split_items - 1) / a.split_items);
   a.nsplit = nsplit;
   a.bm_words = (int)((a.split_items + 31) / 32);
-  const size_t lds = (size_t)2 * G::TILE_F4 * 16 + (size_t)2 * G::SUB * IBT * 4 * 4 + 4 * wave_lds_bytes(a.bm_words);
+  const size_t lds = (size_t)2 * G::TILE_F4 * 16 + 4 * wave_lds_bytes(a.bm_words);
   if (lds > 160 * 1024) return 1;
   (void)hipFuncSetAttribute((const void*)eval_pass_q_kernel<G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL((eval_pass_q_kernel<G>), dim3((unsigned)ublocks, (unsigned)nsplit), dim3(256), lds, st, a);
@@ -855,8 +847,8 @@ int launch_topk_merge(const uint64_t* part, int64_t nq, int nsplit, int topn, in
 size_t eval_pass_pspace_bytes(int d, int n_pref, int64_t nq, int64_t n_items, int topn) {
   const size_t p4 = n_pref <= 4 ? 4 : n_pref <= 20 ? 20 : 32;
   const size_t ka = (d + 2 * p4 + 15) / 16, ks = (2 * p4 + 15) / 16, kn = (p4 + 15) / 16;
-  const size_t arow = 16 * (ka + 2 * ks + kn), rowb = d + 3 * p4;
-  return (3 * 32 * 32 + 4 * 2 * 8 * 64 + (size_t)nq * (arow + 4) + (size_t)n_items * (rowb + 4) + 64) * sizeof(float) + (size_t)nq * 8 * topn * sizeof(uint64_t);
+  const size_t arow = 16 * (ka + 2 * ks + kn), rowb = d + 3 * p4, grow = 4 * ((rowb / 4 + 1) | 1);      // QGeom::AROW, ROWB, GROW
+  return (3 * 32 * 32 + 4 * 2 * 8 * 64 + (size_t)nq * (arow + 4) + (size_t)n_items * grow + 64) * sizeof(float) + (size_t)nq * 8 * topn * sizeof(uint64_t);
 }
 
 // Items: I[row] (+ E[item2ent[row]] for KTUP; E == NULL for TUP); pref_ws: the prepared tables (ktup_pref_prepare; ppad / dp its

@@ -202,7 +202,7 @@ static_assert(GN_EPOCH + GN_SLOTS * GN_STRIDE <= GN_ERR, "workspace");
 constexpr int CS_UPT = 5, CS_MAX_WG = 512, CS_SPIN_LIMIT = 1 << 21;
 
 template <int KIND>
-__global__ __launch_bounds__(256, 4) void clip_step_kernel(OptTensors T, Hyper h, double* __restrict__ ws, float* __restrict__ slots,
+__global__ __launch_bounds__(256, 4) void clip_step_kernel(OptTensors T, Hyper h, double* __restrict__ ws, double* __restrict__ gn, float* __restrict__ slots,
                                                         int n_slots, float loss_scale, float* __restrict__ loss_out,
                                                         float* __restrict__ loss_acc, const int64_t* __restrict__ steps_dev) {
   __shared__ float dev_bc1[MAXT], dev_bc2s[MAXT];
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256, 4) void clip_step_kernel(OptTensors T, Hyper h
   const bool clip = h.max_norm > 0.f;
   unsigned long long e0 = 0;
   if (threadIdx.x == 0) {
-    if (clip) e0 = __hip_atomic_load(words + GN_EPOCH + slot * GN_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (clip && !gn) e0 = __hip_atomic_load(words + GN_EPOCH + slot * GN_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (slots && blockIdx.x == 0) {
       float s = 0.f;
       for (int i = 0; i < n_slots; ++i) { s += slots[i]; slots[i] = 0.f; }
@@ -245,7 +245,26 @@ __global__ __launch_bounds__(256, 4) void clip_step_kernel(OptTensors T, Hyper h
     }
   };
   float coef = 1.f;
-  if (clip) {
+  if (clip && gn) {
+    // the squared norm came with the gradients (ktup_common.h gnorm_*: the kernels that built them tracked it): every workgroup sums
+    // the 16 slots of the set in use for itself -- no norm pass, no barrier; workgroup 0 also clears the idle set and counts the step
+    if (threadIdx.x < 64) {
+      unsigned long long* gw = reinterpret_cast<unsigned long long*>(gn);
+      const int set = (int)(gw[1] & 1ull);
+      double v = threadIdx.x < ktup::GNORM_SLOTS ? gn[ktup::GNORM_SET0 + ktup::GNORM_SLOTS * set + threadIdx.x] : 0.0;
+#pragma unroll
+      for (int m = ktup::GNORM_SLOTS / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+      v = v > 0.0 ? v : 0.0;                                       // (rounding of the tracked terms can leave -1e-12 for a zero gradient)
+      if (threadIdx.x == 0) {
+        float c = h.max_norm / ((float)sqrt(v) + 1e-6f);
+        coef_s = c < 1.f ? c : 1.f;
+        if (blockIdx.x == 0) { ws[0] = v; gn[2] = v; gw[0] += 1ull; }
+      }
+      if (blockIdx.x == 0 && threadIdx.x < ktup::GNORM_SLOTS) gn[ktup::GNORM_SET0 + ktup::GNORM_SLOTS * (1 - set) + threadIdx.x] = 0.0;
+    }
+    __syncthreads();
+    coef = coef_s;
+  } else if (clip) {
     float acc = 0.f;
     for (int64_t base = blockIdx.x; base < nunits; base += stride) {
 #pragma unroll
@@ -330,7 +349,7 @@ __global__ __launch_bounds__(256, 4) void clip_step_kernel(OptTensors T, Hyper h
   } else {
     __syncthreads();                                              // dev_bc tables
   }
-  const bool in_regs = clip && resident;
+  const bool in_regs = clip && resident && !gn;
   for (int64_t base = blockIdx.x; base < nunits; base += stride) {
 #pragma unroll
     for (int q = 0; q < CS_UPT; ++q) {
@@ -526,11 +545,12 @@ extern "C" int ktup_optim_clip_step_capacity(int kind) {
 extern "C" int ktup_optim_clip_step(int kind, int n_tensors, float* const* params, float* const* grads, float* const* state1,
                                     float* const* state2, const int64_t* sizes, const int64_t* steps, const int64_t* steps_dev,
                                     const int32_t* first, float lr, float weight_decay, float momentum, float beta1, float beta2,
-                                    float eps, float alpha, double* ws, float max_norm, int zero_grads, float* loss_slots, int n_slots,
+                                    float eps, float alpha, double* ws, double* gnorm, float max_norm, int zero_grads, float* loss_slots, int n_slots,
                                     float loss_scale, float* loss_out, float* loss_acc, void* stream) {
   const char* name = "ktup_optim_clip_step";
   KTUP_REQUIRE(ws, "%s: null workspace", name);
   KTUP_REQUIRE(!loss_slots || (n_slots > 0 && loss_out), "%s: loss slots need a count and an output", name);
+  KTUP_REQUIRE(!gnorm || max_norm > 0.f, "%s: a tracked gradient norm without clipping", name);
   OptTensors T{};
   if (int e = prep_step(name, T, kind, n_tensors, params, grads, state1, state2, sizes, steps, steps_dev, first, momentum, beta1, beta2))
     return e;
@@ -545,16 +565,16 @@ extern "C" int ktup_optim_clip_step(int kind, int n_tensors, float* const* param
   const dim3 grid((unsigned)(nunits < 1 ? 1 : nunits < cap ? nunits : cap)), block(256);
   switch (kind) {
     case KTUP_OPT_SGD:
-      hipLaunchKernelGGL(clip_step_kernel<KTUP_OPT_SGD>, grid, block, 0, st, T, h, ws, loss_slots, n_slots, loss_scale, loss_out, loss_acc, steps_dev);
+      hipLaunchKernelGGL(clip_step_kernel<KTUP_OPT_SGD>, grid, block, 0, st, T, h, ws, gnorm, loss_slots, n_slots, loss_scale, loss_out, loss_acc, steps_dev);
       break;
     case KTUP_OPT_ADAGRAD:
-      hipLaunchKernelGGL(clip_step_kernel<KTUP_OPT_ADAGRAD>, grid, block, 0, st, T, h, ws, loss_slots, n_slots, loss_scale, loss_out, loss_acc, steps_dev);
+      hipLaunchKernelGGL(clip_step_kernel<KTUP_OPT_ADAGRAD>, grid, block, 0, st, T, h, ws, gnorm, loss_slots, n_slots, loss_scale, loss_out, loss_acc, steps_dev);
       break;
     case KTUP_OPT_ADAM:
-      hipLaunchKernelGGL(clip_step_kernel<KTUP_OPT_ADAM>, grid, block, 0, st, T, h, ws, loss_slots, n_slots, loss_scale, loss_out, loss_acc, steps_dev);
+      hipLaunchKernelGGL(clip_step_kernel<KTUP_OPT_ADAM>, grid, block, 0, st, T, h, ws, gnorm, loss_slots, n_slots, loss_scale, loss_out, loss_acc, steps_dev);
       break;
     default:
-      hipLaunchKernelGGL(clip_step_kernel<KTUP_OPT_RMSPROP>, grid, block, 0, st, T, h, ws, loss_slots, n_slots, loss_scale, loss_out, loss_acc, steps_dev);
+      hipLaunchKernelGGL(clip_step_kernel<KTUP_OPT_RMSPROP>, grid, block, 0, st, T, h, ws, gnorm, loss_slots, n_slots, loss_scale, loss_out, loss_acc, steps_dev);
       break;
   }
   return check_launch(name);

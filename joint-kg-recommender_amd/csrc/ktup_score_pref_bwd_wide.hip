@@ -84,6 +84,8 @@ struct WArgs {
                                  // gradients if no two entries shared a table row (ktup_shard_reduce_norm's dup_only walk corrects the rest)
   const int64_t* neg_ids;        // STEP + ROWOUT (may be null): u_ids / i_ids / neg_ids are the id COLUMNS (n_batches x B each) and the kernel
   const int64_t* cursor; int64_t n_batches;   // reads batch (*cursor mod n_batches) itself -- no entry list has to exist before it starts
+  double* gnorm;                 // STEP, gradients by atomics (may be null): the gradient-norm workspace of ktup_common.h -- every add of this
+                                 // launch tracks the squared norm of the buffers it builds
   int u_once;                    // STEP + ROWOUT: u_ids holds B ids (example k's user, shared by its two pairs) and GU B rows (the sum)
   int noflush;                   // measurement knob (option dbg_noflush)
   int gumbel;
@@ -136,7 +138,9 @@ __global__ __launch_bounds__(G::NT) void pref_bwd_wide_kernel(WArgs a) {
       if ((int)blockIdx.x == nblk) {
         // the extra workgroup: orthogonalLoss(pref, pref_norm) = sum_p (pn_p . p_p)^2 / |p_p|^2 (utils/loss.py:18-19), value and
         // gradient, rows dealt to the four waves; it touches no tile and leaves before any barrier
-        float lo = 0.f;
+        float lo = 0.f, sq = 0.f;
+        const bool track_o = !ROWOUT && a.gnorm != nullptr;
+        const int set_o = track_o ? gnorm_set(a.gnorm) : 0;
         for (int p = w; p < P; p += G::NWC) {
           float dot = 0.f, nr = 0.f;
           for (int c = lane; c < NCH; c += 64) {
@@ -151,12 +155,28 @@ __global__ __launch_bounds__(G::NT) void pref_bwd_wide_kernel(WArgs a) {
             const v4 r4 = *reinterpret_cast<const v4*>(a.pref + (int64_t)p * a.ldp + 4 * c);
             const v4 w4 = *reinterpret_cast<const v4*>(a.pnorm + (int64_t)p * a.ldp + 4 * c);
             const v4 gr4 = c1 * w4 - c2 * r4, gw4 = c1 * r4;
-            atomic_add4(a.gP + (int64_t)p * D + 4 * c, make_float4(gr4[0], gr4[1], gr4[2], gr4[3]));
-            atomic_add4(a.gPn + (int64_t)p * D + 4 * c, make_float4(gw4[0], gw4[1], gw4[2], gw4[3]));
+            if (track_o) {
+              const float4 g0 = make_float4(gr4[0], gr4[1], gr4[2], gr4[3]), g1 = make_float4(gw4[0], gw4[1], gw4[2], gw4[3]);
+              const float4 o0 = atomic_add4_old(a.gP + (int64_t)p * D + 4 * c, g0), o1 = atomic_add4_old(a.gPn + (int64_t)p * D + 4 * c, g1);
+              sq += sq_gain4(o0, g0) + sq_gain4(o1, g1);
+            } else {
+              atomic_add4(a.gP + (int64_t)p * D + 4 * c, make_float4(gr4[0], gr4[1], gr4[2], gr4[3]));
+              atomic_add4(a.gPn + (int64_t)p * D + 4 * c, make_float4(gw4[0], gw4[1], gw4[2], gw4[3]));
+            }
           }
           lo += dot * dot / nr;
         }
         if (lane == 0 && lo != 0.f) atomicAdd(a.loss + 1, lo);
+        if (track_o) {                                           // (no barrier was passed yet: every wave is still here)
+          sq = group_sum<64>(sq);
+          if (lane == 0) reds[w] = sq;
+          __syncthreads();
+          if (tid == 0) {
+            double t = 0.0;
+            for (int ww = 0; ww < G::NWC; ++ww) t += (double)reds[ww];
+            gnorm_add(a.gnorm, set_o, t);
+          }
+        }
         return;
       }
     }
@@ -276,6 +296,9 @@ __global__ __launch_bounds__(G::NT) void pref_bwd_wide_kernel(WArgs a) {
   }
   float lpart = 0.f;                                          // STEP: this lane's share of the BPR loss value
   float ssq = 0.f;                                            // STEP + ROWOUT: this lane's share of the stored rows' squared norms
+  constexpr bool TRK = STEP && !ROWOUT && NCH <= 32;          // (d = 256 has no registers left for the returned values: pref_step_mc refuses)
+  const bool track = TRK && a.gnorm != nullptr;               // STEP, atomics: ... of the squared norm of the buffers the adds build
+  const int gset = track ? gnorm_set(a.gnorm) : 0;
   const bool l1 = a.l1 != 0;
   const float beta = a.beta;
   v4 accA[PT][CTW], accC[PT][CTW];
@@ -511,6 +534,8 @@ __global__ __launch_bounds__(G::NT) void pref_bwd_wide_kernel(WArgs a) {
         LT[p * 17 + j] = beta * lg[tt][reg];
         GLT[p * 17 + j] = 0.5f * gl[tt][reg];
       }
+    float4 tu[TRK ? CTW : 1], tv[TRK ? CTW : 1], ou[TRK ? CTW : 1], oi[TRK ? CTW : 1], oe[TRK ? CTW : 1];   // tracked norm: values added / found
+    bool has_e = false;
     // ---- C: gx^T = Alog2^T . gL^T of this wave's coordinates, then the row gradients
     {
       const int64_t gr = STEP ? row_j : row0 + j;                // ROWOUT row: the pair's place in the [pos ; neg] order
@@ -519,6 +544,9 @@ __global__ __launch_bounds__(G::NT) void pref_bwd_wide_kernel(WArgs a) {
       float* pu = a.gU + (int64_t)ur * a.ldu4 * 4;
       float* pi = a.gI + (int64_t)ir * a.ldi4 * 4;
       float* pe = (HASE && er != a.ent_pad) ? a.gE + (int64_t)er * a.lde4 * 4 : nullptr;
+#pragma unroll
+      for (int ct = 0; ct < (TRK ? CTW : 0); ++ct) { tu[ct] = f4zero(); tv[ct] = f4zero(); ou[ct] = f4zero(); oi[ct] = f4zero(); oe[ct] = f4zero(); }
+      has_e = pe != nullptr;
 #pragma unroll
       for (int ct = 0; ct < CTW; ++ct) {
         v4 gx = (v4){0.f, 0.f, 0.f, 0.f};
@@ -555,9 +583,17 @@ __global__ __launch_bounds__(G::NT) void pref_bwd_wide_kernel(WArgs a) {
               ssq += (u_mine ? su : 0.f) + ((HASE && er != a.ent_pad) ? 2.f * sv : sv);
             }
           } else {
-            if (u_mine) atomic_add4(pu + c0, make_float4(gu[0], gu[1], gu[2], gu[3]));
-            atomic_add4(pi + c0, make_float4(gv[0], gv[1], gv[2], gv[3]));
-            if (pe) atomic_add4(pe + c0, make_float4(gv[0], gv[1], gv[2], gv[3]));
+            if (TRK && track) {          // the returned values wait in registers until the tile's table-gradient MFMAs are issued
+              const float4 fu = make_float4(gu[0], gu[1], gu[2], gu[3]), fv = make_float4(gv[0], gv[1], gv[2], gv[3]);
+              if (u_mine) { tu[ct] = fu; ou[ct] = atomic_add4_old(pu + c0, fu); }
+              tv[ct] = fv;
+              oi[ct] = atomic_add4_old(pi + c0, fv);
+              if (pe) oe[ct] = atomic_add4_old(pe + c0, fv);
+            } else {
+              if (u_mine) atomic_add4(pu + c0, make_float4(gu[0], gu[1], gu[2], gu[3]));
+              atomic_add4(pi + c0, make_float4(gv[0], gv[1], gv[2], gv[3]));
+              if (pe) atomic_add4(pe + c0, make_float4(gv[0], gv[1], gv[2], gv[3]));
+            }
           }
         }
       }
@@ -587,10 +623,42 @@ __global__ __launch_bounds__(G::NT) void pref_bwd_wide_kernel(WArgs a) {
         }
       }
     }
+    if (TRK && track) {
+#pragma unroll
+      for (int ct = 0; ct < (TRK ? CTW : 0); ++ct) ssq += sq_gain4(ou[ct], tu[ct]) + sq_gain4(oi[ct], tv[ct]) + (has_e ? sq_gain4(oe[ct], tv[ct]) : 0.f);
+    }
     __syncthreads();     // the next tile rewrites `red` and the wave tiles
   }
   // ---- flush the table gradients of this wave's coordinates
-  if (!a.noflush)
+  if (TRK && track && !a.noflush) {          // tracked norm: all adds issued, then the returned values folded in (ktup_common.h)
+    float fo[PT][CTW][4][4];
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+      for (int ct = 0; ct < CTW; ++ct)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int p = 16 * pt + 4 * kq + reg, c = 4 * NCW * w + 16 * ct + j;
+          const bool in = p < P && (!RAGGED || c < D);
+          const float va = accA[pt][ct][reg], vc = accC[pt][ct][reg];
+          fo[pt][ct][reg][0] = (in && va != 0.f) ? atomicAdd(a.gP + (int64_t)p * D + c, va) : 0.f;
+          fo[pt][ct][reg][1] = (in && va != 0.f && a.gR) ? atomicAdd(a.gR + (int64_t)p * D + c, va) : -0.5f * va;     // (gain 0)
+          fo[pt][ct][reg][2] = (in && vc != 0.f) ? atomicAdd(a.gPn + (int64_t)p * D + c, vc) : 0.f;
+          fo[pt][ct][reg][3] = (in && vc != 0.f && a.gRn) ? atomicAdd(a.gRn + (int64_t)p * D + c, vc) : -0.5f * vc;
+        }
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+      for (int ct = 0; ct < CTW; ++ct)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int p = 16 * pt + 4 * kq + reg, c = 4 * NCW * w + 16 * ct + j;
+          if (p < P && (!RAGGED || c < D)) {
+            const float va = accA[pt][ct][reg], vc = accC[pt][ct][reg];
+            ssq += (sq_gain(fo[pt][ct][reg][0], va) + sq_gain(fo[pt][ct][reg][1], va)) + (sq_gain(fo[pt][ct][reg][2], vc) + sq_gain(fo[pt][ct][reg][3], vc));
+          }
+        }
+  } else if (!a.noflush)
 #pragma unroll
   for (int pt = 0; pt < PT; ++pt)
 #pragma unroll
@@ -612,6 +680,19 @@ __global__ __launch_bounds__(G::NT) void pref_bwd_wide_kernel(WArgs a) {
   if constexpr (STEP) {
     lpart = group_sum<64>(lpart);
     if (lane == 0 && lpart != 0.f) atomicAdd(a.loss, lpart * (1.f / (float)a.B));
+    if constexpr (!ROWOUT) {
+      if (track) {
+        ssq = group_sum<64>(ssq);
+        __syncthreads();
+        if (lane == 0) reds[w] = ssq;
+        __syncthreads();
+        if (tid == 0) {
+          double t = 0.0;
+          for (int ww = 0; ww < G::NWC; ++ww) t += (double)reds[ww];
+          gnorm_add(a.gnorm, gset, t);
+        }
+      }
+    }
     if constexpr (ROWOUT) {
       if (a.sumsq) {            // ONE double atomic per workgroup (one per wave cost 11 us: ~2000 of them queue on 16 addresses)
         ssq = group_sum<64>(ssq);
@@ -717,7 +798,7 @@ int pref_step_mc(const float* U, int64_t ldu, const float* I, int64_t ldi, const
                  uint64_t seed, uint64_t offset, float target, float gscale, int orth, float* loss, float* gU, float* gI, float* gE,
                  float* gP, float* gPn, float* gR, float* gRn, hipStream_t st,
                  const char* name, float* GU, float* GV, double* sumsq, int sumsq_slots, const int64_t* neg_ids, const int64_t* cursor,
-                 int64_t n_batches) {
+                 int64_t n_batches, double* gnorm) {
   if (n_pref > 32 || (d == 256 && n_pref > 20)) return 1;
   if ((ldu | ldi | lde | ldp) & 3) return 1;
   if ((ldu >> 2) > 0xffffffffll || (ldi >> 2) > 0xffffffffll || (lde >> 2) > 0xffffffffll) return 1;
@@ -734,6 +815,8 @@ int pref_step_mc(const float* U, int64_t ldu, const float* I, int64_t ldi, const
   a.noflush = opt_dbg_noflush();
   a.GU = GU; a.GV = GV;          // both set: the row gradients leave as rows of GU (example k: both pairs) / GV (pair k) instead of atomics
   a.u_once = GU != nullptr;
+  if (gnorm && (GU || d > 128)) return set_error(KTUP_ERR_UNSUPPORTED, "%s: the tracked gradient norm exists for d <= 128, gradients by atomics", name);
+  a.gnorm = gnorm;
   a.sumsq = sumsq; a.sumsq_slots = sumsq_slots;
   a.neg_ids = neg_ids; a.cursor = cursor; a.n_batches = n_batches > 0 ? n_batches : 1;
   return launch_d(a, d, (n_pref + 3) / 4, st, name);

@@ -26,6 +26,7 @@ struct KgStepArgs {
   int regs;                      // bit 0 orthogonalLoss(rel, norm) rows, bit 1 normLoss(entity rows), bit 2 normLoss(relation rows)
   float* loss;                   // [4]: margin sum, orth, normE, normR  (accumulated)
   float *gE, *gR, *gN;
+  double* gnorm;                 // (may be null) the gradient-norm workspace of ktup_common.h: every add tracks the squared norm it builds
 };
 
 template <int GL, bool TRANSH>
@@ -35,6 +36,9 @@ __global__ __launch_bounds__(256) void kg_step_kernel(KgStepArgs a) {
   const bool on = lane < a.nch;
   float part[4] = {0.f, 0.f, 0.f, 0.f};
   const float g1 = a.gscale;
+  const bool track = a.gnorm != nullptr;
+  const int gset = track ? gnorm_set(a.gnorm) : 0;
+  float ssq = 0.f;
   for (int64_t k = (int64_t)blockIdx.x * GPB + threadIdx.x / GL; k < a.B; k += (int64_t)gridDim.x * GPB) {
     const int64_t id[4] = {a.h[k], a.t[k], a.h[k + a.B], a.t[k + a.B]};      // ph, pt, nh, nt
     const int64_t rid[2] = {a.r[k], a.r[k + a.B]};
@@ -109,7 +113,20 @@ __global__ __launch_bounds__(256) void kg_step_kernel(KgStepArgs a) {
         if (lane == 0) part[3] += fmaxf(s - 1.f, 0.f);
       }
     }
-    if (on) {
+    if (on && track) {                // every add issued before the first returned value is used (ktup_common.h)
+      float4 oe[4], orr[2], ow[2];
+#pragma unroll
+      for (int x = 0; x < 4; ++x) oe[x] = atomic_add4_old(a.gE + id[x] * a.lde + 4 * lane, ge[x]);
+#pragma unroll
+      for (int x = 0; x < 2; ++x) {
+        orr[x] = atomic_add4_old(a.gR + rid[x] * a.ldr + 4 * lane, gr[x]);
+        ow[x] = TRANSH ? atomic_add4_old(a.gN + rid[x] * a.ldn + 4 * lane, gw[x]) : f4zero();
+      }
+#pragma unroll
+      for (int x = 0; x < 4; ++x) ssq += sq_gain4(oe[x], ge[x]);
+#pragma unroll
+      for (int x = 0; x < 2; ++x) ssq += sq_gain4(orr[x], gr[x]) + (TRANSH ? sq_gain4(ow[x], gw[x]) : 0.f);
+    } else if (on) {
 #pragma unroll
       for (int x = 0; x < 4; ++x) atomic_add4(a.gE + id[x] * a.lde + 4 * lane, ge[x]);
 #pragma unroll
@@ -120,13 +137,18 @@ __global__ __launch_bounds__(256) void kg_step_kernel(KgStepArgs a) {
     }
   }
   // ---- the four loss values: wave sums -> one atomic per workgroup and slot
-  __shared__ float red[4][4];
+  __shared__ float red[4][5];
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     const float v = group_sum<64>(part[s]);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][s] = v;
   }
+  if (track) {
+    ssq = group_sum<64>(ssq);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][4] = ssq;
+  }
   __syncthreads();
+  if (track && threadIdx.x == 64) gnorm_add(a.gnorm, gset, ((double)red[0][4] + (double)red[1][4]) + ((double)red[2][4] + (double)red[3][4]));
   if (threadIdx.x < 4) {
     const float v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
     if (v != 0.f) atomicAdd(a.loss + threadIdx.x, v);
@@ -161,9 +183,9 @@ extern "C" int ktup_train_rec_step(const float* U, int64_t ldu, const float* I, 
                                    const float* rel, const float* norm, int64_t ldp, int n_pref, int d, const int64_t* u_ids,
                                    const int64_t* i_ids, int64_t B, int l1, int gumbel_mode, const float* uniform, uint64_t seed,
                                    uint64_t offset, float target, float gscale, int orth, float* loss, float* gU, float* gI, float* gE,
-                                   float* gP, float* gPn, float* gR, float* gRn, void* stream) {
+                                   float* gP, float* gPn, float* gR, float* gRn, double* gnorm, void* stream) {
   const char* name = "ktup_train_rec_step";
-  KTUP_REQUIRE(B >= 0, "%s: negative batch", name);
+  KTUP_REQUIRE(B >= 0 && (B > 0 || !gnorm), "%s: negative batch (or an empty one with a tracked norm)", name);
   if (B == 0) return KTUP_OK;
   KTUP_REQUIRE(U && I && pref && pref_norm && u_ids && i_ids && loss && gU && gI && gP && gPn, "%s: null pointer argument", name);
   KTUP_REQUIRE((E == nullptr) == (item2ent == nullptr) && (!E || gE), "%s: E, item2ent and gE go together", name);
@@ -177,7 +199,7 @@ extern "C" int ktup_train_rec_step(const float* U, int64_t ldu, const float* I, 
                "%s: KTUP_GUMBEL_INPUT / KTUP_GUMBEL_PHILOX_DEV need the `uniform` pointer", name);
   const int rc = pref_step_mc(U, ldu, I, ldi, E, lde, item2ent, ent_pad, pref, pref_norm, rel, norm, ldp, n_pref, d, u_ids, i_ids, B, l1,
                               gumbel_mode, uniform, seed, offset, target, gscale, orth, loss, gU, gI, gE, gP, gPn, gR, gRn,
-                              (hipStream_t)stream, name);
+                              (hipStream_t)stream, name, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 1, gnorm);
   if (rc == 1) return set_error(KTUP_ERR_UNSUPPORTED, "%s: no fused kernel for d=%d, n_pref=%d (see ktup_train_step_supported)", name, d, n_pref);
   return rc;
 }
@@ -214,14 +236,14 @@ extern "C" int ktup_train_rec_step_rows(const float* U, int64_t ldu, const float
 
 extern "C" int ktup_train_kg_step(int transh, const float* E, int64_t lde, const float* R, int64_t ldr, const float* Nrm, int64_t ldn,
                                   int d, const int64_t* h, const int64_t* t, const int64_t* r, int64_t B, int l1, float margin,
-                                  float gscale, int regs, float* loss, float* gE, float* gR, float* gN, void* stream) {
+                                  float gscale, int regs, float* loss, float* gE, float* gR, float* gN, double* gnorm, void* stream) {
   const char* name = "ktup_train_kg_step";
-  KTUP_REQUIRE(B >= 0, "%s: negative batch", name);
+  KTUP_REQUIRE(B >= 0 && (B > 0 || !gnorm), "%s: negative batch (or an empty one with a tracked norm)", name);
   if (B == 0) return KTUP_OK;
   KTUP_REQUIRE(E && R && h && t && r && loss && gE && gR && (!transh || (Nrm && gN)), "%s: null pointer argument", name);
   if (d <= 0 || d % 4 || d > 256 || (lde | ldr | (transh ? ldn : 0)) % 4 || !aligned16(E) || !aligned16(R) || !aligned16(gE) || !aligned16(gR) ||
       (transh && (!aligned16(Nrm) || !aligned16(gN))))
     return set_error(KTUP_ERR_UNSUPPORTED, "%s: needs d %% 4 == 0 (<= 256) and 16-byte aligned rows", name);
-  KgStepArgs a{E, R, Nrm, lde, ldr, ldn, h, t, r, B, d / 4, l1 != 0, margin, gscale, regs, loss, gE, gR, gN};
+  KgStepArgs a{E, R, Nrm, lde, ldr, ldn, h, t, r, B, d / 4, l1 != 0, margin, gscale, regs, loss, gE, gR, gN, gnorm};
   return transh ? launch_kg<true>(a, (hipStream_t)stream, name) : launch_kg<false>(a, (hipStream_t)stream, name);
 }

@@ -128,12 +128,12 @@ SIGNATURES = {
     'ktup_negsample_rec': [c_p, c_p, c_l, c_l, c_p, c_l, c_u, c_u, c_i, c_p, c_p, c_p, c_p],
     'ktup_optim_gradnorm': [c_i, c_p, c_p, c_p, c_p],
     'ktup_optim_clip_step_capacity': [c_i],
-    'ktup_optim_clip_step': [c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_p, c_f, c_i, c_p, c_i, c_f,
+    'ktup_optim_clip_step': [c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_p, c_p, c_f, c_i, c_p, c_i, c_f,
                              c_p, c_p, c_p],
     'ktup_train_step_supported': [c_i, c_i, c_i],
     'ktup_train_rec_step': [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_p, c_p, c_l, c_i, c_i, c_p, c_u, c_u,
-                            c_f, c_f, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
-    'ktup_train_kg_step': [c_i, c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_p, c_p, c_p, c_l, c_i, c_f, c_f, c_i, c_p, c_p, c_p, c_p, c_p],
+                            c_f, c_f, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
+    'ktup_train_kg_step': [c_i, c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_p, c_p, c_p, c_l, c_i, c_f, c_f, c_i, c_p, c_p, c_p, c_p, c_p, c_p],
     'ktup_optim_step': [c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_p, c_f, c_i, c_p],
     'ktup_eval_rec_metrics': [c_p, c_l, c_i, c_p, c_p, c_p, c_p],
     'ktup_shard_sparse_step': [c_i, c_p, c_l, c_p, c_l, c_i, c_p, c_l, c_p, c_l, c_f, c_f, c_p, c_f, c_p],

@@ -94,6 +94,13 @@ class _StepperBase(object):
         import os as _os
         self.want_fused = _os.environ.get('KTUP_FUSED_STEP', '1') != '0'
         self.out = {k: torch.zeros((), **f32) for k in self.KINDS}                       # fused steps: where the step's loss is published
+        # the gradient norm without a pass over the gradients (include/ktup_hip.h `gnorm`): the fused step kernels track the squared
+        # norm of the buffers their atomics build, ktup_optim_clip_step reads it -- one process only (an all-reduce of the gradients
+        # changes their norm), only with clipping on, and for d <= 128 (at d = 256 the rec step kernel has no registers left for the
+        # returned values).  KTUP_TRACKED_NORM=0: the norm pass + grid barrier of round 2.
+        self._gn = None
+        if self.world == 1 and self.max_norm > 0 and self.tabs[0].shape[1] <= 128 and _os.environ.get('KTUP_TRACKED_NORM', '1') != '0':
+            self._gn = torch.zeros(64, dtype=torch.float64, device=dev)                 # KTUP_GNORM_WS_DOUBLES
         self._graphs = {}
         self._eager_steps = {k: 0 for k in self.KINDS}
         self._feeds, self._sampler, self._feed_launch, self._feed_ok = {}, None, {}, {}
@@ -305,9 +312,13 @@ class _StepperBase(object):
             if self._feeds:
                 self._bind_feeds(st)
 
-    def _optimizer_launches(self, loss=None):
+    def _gn_ptr(self):
+        return None if self._gn is None else _p(self._gn)
+
+    def _optimizer_launches(self, loss=None, tracked=False):
+        """`tracked`: the launch before this one was a fused step bound with the gradient-norm workspace."""
         self.sync.all_reduce_grads()       # world > 1: gradients of all tables + the loss scalars, one bucket, one collective
-        self.trainer.fused.clip_and_step(self.max_norm, zero_grads=True, loss=loss)
+        self.trainer.fused.clip_and_step(self.max_norm, zero_grads=True, loss=loss, gnorm=self._gn_ptr() if tracked else None)
 
     def _fused_ok(self, kind, d, n_pref=0):
         return bool(self.want_fused and L.load().ktup_train_step_supported(kind, d, n_pref))
@@ -382,10 +393,10 @@ class JointStepper(_StepperBase):
             self._rec_fused = b('ktup_train_rec_step', _p(U), U.stride(0), _p(I), I.stride(0), _p(E), E.stride(0), _p(self.i2e), self.ent_pad,
                                 _p(P), _p(Pn), _p(R), _p(Rn), P.stride(0), n_pref, d, _p(self.u2), _p(self.i2), B, self.l1, gate, gptr, 0, 0,
                                 self.target, inv, 1, _p(self.loss), _p(U.grad), _p(I.grad), _p(E.grad), _p(P.grad), _p(Pn.grad),
-                                _p(R.grad), _p(Rn.grad), st)
+                                _p(R.grad), _p(Rn.grad), self._gn_ptr(), st)
             self._kg_fused = b('ktup_train_kg_step', 1, _p(E), E.stride(0), _p(R), R.stride(0), _p(Rn), Rn.stride(0), d, _p(self.h2),
                                _p(self.t2), _p(self.r2), B, self.l1, self.margin, self.kg_lambda, 7, _p(self.loss), _p(E.grad),
-                               _p(R.grad), _p(Rn.grad), st)
+                               _p(R.grad), _p(Rn.grad), self._gn_ptr(), st)
         self._rec_head = [
             b('ktup_pref_prepare', _p(P), _p(Pn), _p(R), _p(Rn), P.stride(0), n_pref, d, _p(self.ws), st)]
         self._rec_soft = [
@@ -424,7 +435,7 @@ class JointStepper(_StepperBase):
             self._gumbel_advance()
             if self.world > 1:
                 self.loss[:2].mul_(self.inv_world)
-            self._optimizer_launches(loss=(_p(self.loss), 2, 1.0, _p(self.out['rec']), self._acc_ptr('rec')))
+            self._optimizer_launches(loss=(_p(self.loss), 2, 1.0, _p(self.out['rec']), self._acc_ptr('rec')), tracked=True)
             return self.out['rec']
         self._rec_head[0]()
         self.gAC.zero_(); self.loss.zero_()
@@ -445,7 +456,7 @@ class JointStepper(_StepperBase):
             self._pack('kg', (ph, pt, pr, nh, nt, nr))
         if self.fused_step:              # one launch: both TransH scores, marginLoss, the three regularisers, every gradient
             self._kg_fused()
-            self._optimizer_launches(loss=(_p(self.loss), 4, self.kg_lambda, _p(self.out['kg']), self._acc_ptr('kg')))
+            self._optimizer_launches(loss=(_p(self.loss), 4, self.kg_lambda, _p(self.out['kg']), self._acc_ptr('kg')), tracked=True)
             return self.out['kg']
         self.loss.zero_()
         for launch in self._kg:
@@ -502,7 +513,8 @@ class RecStepper(_StepperBase):
         if self.fused_step:
             self._rec_fused = b('ktup_train_rec_step', _p(U), U.stride(0), _p(I), I.stride(0), None, 0, None, -1, _p(P), _p(Pn), None, None,
                                 P.stride(0), n_pref, d, _p(self.u2), _p(self.i2), B, self.l1, gate, gptr, 0, 0, self.target, 1.0 / self.world,
-                                1, _p(self.loss), _p(U.grad), _p(I.grad), None, _p(P.grad), _p(Pn.grad), None, None, st)
+                                1, _p(self.loss), _p(U.grad), _p(I.grad), None, _p(P.grad), _p(Pn.grad), None, None, None, st)   # (no tracked
+                                # norm: the row regularisers below add to the gradients after this launch)
         self._prep = b('ktup_pref_prepare', _p(P), _p(Pn), None, None, P.stride(0), n_pref, d, _p(self.ws), st)
         self._fwd = b('ktup_score_tup_fwd', _p(U), U.stride(0), _p(I), I.stride(0), _p(self.ws), n_pref, d, _p(self.u2), _p(self.i2),
                       2 * B, self.l1, gate, gptr, 0, 0, _p(self.score), st)
@@ -582,7 +594,8 @@ class KGStepper(_StepperBase):
             Rn_ = self.tabs[2] if self.transh else None
             self._kg_fused = b('ktup_train_kg_step', int(self.transh), _p(E), E.stride(0), _p(R), R.stride(0), _p(Rn_),
                                Rn_.stride(0) if self.transh else 0, d, _p(self.h2), _p(self.t2), _p(self.r2), B, self.l1, self.margin, 1.0,
-                               7 if self.transh else 6, _p(self.loss), _p(E.grad), _p(R.grad), _p(Rn_.grad) if self.transh else None, st)
+                               7 if self.transh else 6, _p(self.loss), _p(E.grad), _p(R.grad), _p(Rn_.grad) if self.transh else None,
+                               self._gn_ptr(), st)
         if self.transh:
             Rn = self.tabs[2]
             n_rel = min(R.shape[0], Rn.shape[0])
@@ -617,7 +630,7 @@ class KGStepper(_StepperBase):
             self._pack('kg', (ph, pt, pr, nh, nt, nr))
         if self.fused_step:
             self._kg_fused()
-            self._optimizer_launches(loss=(_p(self.loss), 4, 1.0, _p(self.out['kg']), self._acc_ptr('kg')))
+            self._optimizer_launches(loss=(_p(self.loss), 4, 1.0, _p(self.out['kg']), self._acc_ptr('kg')), tracked=True)
             return self.out['kg']
         self.loss.zero_()
         for launch in self._calls:

@@ -108,10 +108,12 @@ class FusedOptimizer(object):
         return 0 if self._sumsq is None else int(self._sumsq[OPTIM_WS_DOUBLES - 1:].view(torch.int64).item())
 
     @torch.no_grad()
-    def clip_and_step(self, max_norm, zero_grads=False, loss=None):
+    def clip_and_step(self, max_norm, zero_grads=False, loss=None, gnorm=None):
         """`zero_grads`: leave the gradients zero-filled (the next step's zero_grad folded into this pass) instead of
         clipped in place.  `loss` = (slots_ptr, n_slots, scale, out_ptr[, acc_ptr]): the fused training step's loss slots are folded
-        into *out (and added to the running sum *acc) and cleared by the same launch (needs the one-launch route)."""
+        into *out (and added to the running sum *acc) and cleared by the same launch (needs the one-launch route).  `gnorm`: pointer
+        to the gradient-norm workspace the step launch tracked the squared norm in (include/ktup_hip.h KTUP_GNORM_WS_DOUBLES): the
+        launch then has no norm pass and no grid barrier."""
         self._flush_steps()
         group = self.optimizer.param_groups[0]
         ps = [p for p in group['params'] if p.grad is not None]
@@ -144,9 +146,11 @@ class FusedOptimizer(object):
         hyper = (float(group['lr']), float(group['weight_decay']), float(group.get('momentum', 0.0)), float(betas[0]), float(betas[1]),
                  float(group.get('eps', 0.0)), float(group.get('alpha', 0.0)))
         head = (self.kind, n, params, grads, s1, s2, sizes, _arr(ctypes.c_int64, steps), steps_dev, _arr(ctypes.c_int32, firsts)) + hyper
-        if self.one_launch or loss is not None:
+        if gnorm is not None and not clip:
+            gnorm = None
+        if self.one_launch or loss is not None or gnorm is not None:
             lo = (None, 0, 0.0, None, None) if loss is None else (loss[0], int(loss[1]), float(loss[2]), loss[3], loss[4] if len(loss) > 4 else None)
-            L.call('ktup_optim_clip_step', *head, self.sumsq_ptr(dev), float(max_norm) if clip else 0.0, int(bool(zero_grads)), *lo, stream)
+            L.call('ktup_optim_clip_step', *head, self.sumsq_ptr(dev), gnorm, float(max_norm) if clip else 0.0, int(bool(zero_grads)), *lo, stream)
             return
         sumsq = None
         if clip:

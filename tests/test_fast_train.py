@@ -366,3 +366,36 @@ def test_fed_steps_match_the_host_driven_device_sampling(tmp_path, D):
         err = (b - a).abs()
         bad = err > 2e-6 + 2e-5 * a.abs()
         assert float(bad.float().mean()) <= 2e-3 and float(err.max()) <= 1e-3 * 0.05, (k, int(bad.sum()), float(err.max()))
+
+
+@pytest.mark.parametrize('D', [100, 64, 128])
+def test_tracked_gradient_norm_is_the_norm_pass(tmp_path, monkeypatch, D):
+    """The fused step kernels track the squared norm of the gradients their atomics build (include/ktup_hip.h `gnorm`) and the
+    optimizer launch reads it instead of running its norm pass + grid barrier: same norm, same clipped step as that pass
+    (KTUP_TRACKED_NORM=0), with a max_norm small enough that every step is clipped and ids that share rows (64 draws of 50 users),
+    eager steps and graph replays alike."""
+    from jTransUP.utils.fast_train import JointStepper
+    FLAGS, m1, tr1, (NU, NI, NE, NR) = build(tmp_path, 'Adagrad', False, D)
+    _, m2, tr2, _ = build(tmp_path, 'Adagrad', False, D)
+    m2.load_state_dict(copy.deepcopy(m1.state_dict()))
+    FLAGS.clipping_max_value = 0.05
+    B = 64
+    monkeypatch.setenv('KTUP_TRACKED_NORM', '0')
+    plain = JointStepper(m1, tr1, FLAGS, B)
+    monkeypatch.setenv('KTUP_TRACKED_NORM', '1')
+    tracked = JointStepper(m2, tr2, FLAGS, B)
+    assert plain._gn is None and tracked._gn is not None
+    gen = torch.Generator().manual_seed(11)
+    rnd = lambda hi: torch.randint(0, hi, (B,), generator=gen).to(DEV)
+    for step, is_rec in enumerate([True, True, True, False, False, False, True, False, True, True]):
+        if is_rec:
+            ids = (rnd(NU), rnd(NI), rnd(NI))
+            plain.rec_step(*ids); tracked.rec_step(*ids)
+        else:
+            ph, pt, pr, nh, nt = rnd(NE), rnd(NE), rnd(NR), rnd(NE), rnd(NE)
+            plain.kg_step(ph, pt, pr, nh, nt, pr); tracked.kg_step(ph, pt, pr, nh, nt, pr)
+        n1, n2 = tr1.fused.total_norm(), tr2.fused.total_norm()
+        assert n1 > FLAGS.clipping_max_value, 'the step was not clipped: the test would not see a wrong norm'
+        assert abs(n1 - n2) <= 2e-5 * n1, (step, n1, n2)
+        _assert_tables_close(m1, m2, step)
+    assert int(tracked._gn[:1].view(torch.int64).item()) == 10          # the workspace counted every step

@@ -232,8 +232,10 @@ def train_step_bench(device, steps=200, warmup=20):
     # (fused rec / kg kernel, norm + loss, optimizer) replayed from a HIP graph; KTUP_FUSED_STEP=0 = round 1's ~12 launches
     import types
     from jTransUP.utils.fast_train import JointStepper
-    for tag, env in (('gpu_resident_multilaunch', '0'), ('gpu_resident', '1')):
+    # (gpu_resident_norm_pass: the fused step with round 2's norm pass + grid barrier in the optimizer launch, KTUP_TRACKED_NORM=0)
+    for tag, env in (('gpu_resident_multilaunch', '0'), ('gpu_resident_norm_pass', '1'), ('gpu_resident', '1')):
         os.environ['KTUP_FUSED_STEP'] = env
+        os.environ['KTUP_TRACKED_NORM'] = '0' if tag == 'gpu_resident_norm_pass' else '1'
         torch.manual_seed(3)
         m = jt.jTransUPModel(False, D, NU, NI, NE, NR, i_map, new_map, False, False)
         opt = torch.optim.Adagrad(m.parameters(), lr=0.005, weight_decay=1e-5)
@@ -256,8 +258,9 @@ def train_step_bench(device, steps=200, warmup=20):
             fstep(s)
         torch.cuda.synchronize(device)
         out['ms_per_step_' + tag] = 1e3 * (time.perf_counter() - t0) / steps
-        if env == '1':
+        if tag == 'gpu_resident':
             out['fused_step'] = bool(js.fused_step)
+            out['tracked_norm'] = js._gn is not None
             # device time of the replayed graphs alone (HIP events around back-to-back replays of each step kind)
             for kind in ('rec', 'kg'):
                 g = js._graphs.get(kind)
@@ -271,6 +274,7 @@ def train_step_bench(device, steps=200, warmup=20):
                 b.record(); torch.cuda.synchronize(device)
                 out['device_ms_per_%s_step' % kind] = a.elapsed_time(b) / 50
     os.environ.pop('KTUP_FUSED_STEP', None)
+    os.environ.pop('KTUP_TRACKED_NORM', None)
     # device-fed steps (what -device_sampling runs): batch slice + negatives drawn by ktup_feed_* at the head of the step's graph;
     # one graph per step, and ten steps (7 rec + 3 kg) per graph -- what the joint driver replays between evaluations
     from jTransUP.utils.device_sampler import DeviceSampler
@@ -310,8 +314,8 @@ def train_step_bench(device, steps=200, warmup=20):
     out['scored_rows_per_s'] = 2 * B / (out['ms_per_step'] * 1e-3)
     out['note'] = ('fwd pos+neg, loss (+ regularisers on the gpu_resident route), bwd, global-norm clip, dense Adagrad with weight '
                    'decay. torch = autograd + clip_grad_norm_ + torch.optim; fused = autograd + K20; gpu_resident = JointStepper, the '
-                   'joint driver\'s default: 2 launches per step (ktup_train_rec_step / ktup_train_kg_step, then ktup_optim_clip_step: '
-                   'norm, clip and optimizer around a grid barrier) replayed from a HIP graph; gpu_resident_multilaunch = the same arithmetic as ~12 launches (round 1); '
+                   'joint driver\'s default: 2 launches per step (ktup_train_rec_step / ktup_train_kg_step, whose gradient atomics track the squared '
+                   'gradient norm, then ktup_optim_clip_step: clip + optimizer, no norm pass and no grid barrier since round 4) replayed from a HIP graph; gpu_resident_multilaunch = the same arithmetic as ~12 launches (round 1); '
                    'device_fed = the same step with its batch and negatives drawn by a third launch at the head of the graph (ktup_feed_*, -device_sampling), '
                    'device_fed_x10 = ten such steps per graph replay')
     return out

@@ -109,8 +109,12 @@ def kg_pass(dev, transe=False, l1=False):
     q = torch.randint(0, B.NE, (nq,), generator=gen).to(dev); r = torch.randint(0, B.NR, (nq,), generator=gen).to(dev)
     # sorted sets per key, as the drivers' evaluation index hands them over
     strict = lambda n: (torch.sort(torch.randint(0, B.NE - n, (nq, n), generator=gen), dim=1)[0] + torch.arange(n)).reshape(-1)
-    g_off = (torch.arange(nq + 1) * 2).to(dev)
-    g_ids = strict(2).to(dev, torch.int32)
+    # 1-3 golds per key, as in the drivers' passes (and bench.py's eval_kg_bench): nearly every 64-key workgroup then holds a key with
+    # three golds and runs the sweep's three-gold variant
+    n_g = torch.randint(1, 4, (nq,), generator=gen)
+    g_off = torch.cat([torch.zeros(1, dtype=torch.int64), torch.cumsum(n_g, 0)]).to(dev)
+    keep = (torch.arange(3)[None, :] < n_g[:, None]).reshape(-1)
+    g_ids = strict(3)[keep].to(dev, torch.int32)
     f_off = (torch.arange(nq + 1) * 20).to(dev)
     f_ids = strict(20).to(dev, torch.int32)
     for _ in range(3):

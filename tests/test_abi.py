@@ -82,3 +82,20 @@ def test_host_side_validation_of_the_newer_entry_points(lib):
     assert 'PHILOX_DEV' in str(e.value)
     with pytest.raises(lib.KtupError):                    # fused loss: null accumulator
         lib.call('ktup_loss_bpr_fused', d, d, 5, -1.0, d, None, d, d, None)
+
+
+def test_tracked_gradient_norm_arguments_are_validated_on_the_host(lib):
+    """include/ktup_hip.h `gnorm` (the B = 512 step's gradient norm from the step kernels' returning atomics): the combinations that
+    cannot work are refused before any launch."""
+    d = 16
+    with pytest.raises(lib.KtupError) as e:               # an empty batch would leave the optimizer launch a stale norm
+        lib.call('ktup_train_kg_step', 1, d, 100, d, 100, d, 100, 100, d, d, d, 0, 0, 1.0, 1.0, 7, d, d, d, d, d, None)
+    assert 'tracked norm' in str(e.value)
+    with pytest.raises(lib.KtupError) as e:               # d = 256: the rec step kernel has no registers for the returned values
+        lib.call('ktup_train_rec_step', d, 256, d, 256, d, 256, d, 9, d, d, d, d, 256, 20, 256, d, d, 8, 0, 0, None, 0, 0,
+                 -1.0, 1.0, 1, d, d, d, d, d, d, d, d, d, None)
+    assert 'tracked gradient norm' in str(e.value) and e.value.code == lib.ERR_UNSUPPORTED
+    with pytest.raises(lib.KtupError) as e:               # the optimizer launch reads the norm only to clip with it
+        lib.call('ktup_optim_clip_step', 1, 0, d, d, d, d, d, d, None, d, 0.1, 0.0, 0.0, 0.9, 0.999, 1e-10, 0.0, d, d, 0.0, 1,
+                 None, 0, 0.0, None, None, None)
+    assert 'without clipping' in str(e.value)

@@ -44,6 +44,25 @@ def check_flags(FLAGS, model):
         raise L.KtupError('-shard_tables: no fused step kernels for -embedding_size %d with %d preferences' % (d, P))
 
 
+@torch.no_grad()
+def gather_table(full, rows, total_rows, world, group=None):
+    """Rows {g : g % world == r} of a table live on rank r (`rows`: this rank's, in increasing g): write every rank's rows into
+    `full` (total_rows x d, the same on every rank afterwards).  One all-gather of equal-sized blocks -- the ranks with one row
+    fewer pad theirs.  Plain torch + torch.distributed: runs on CPU tensors over gloo as well (tests/test_parallel_gloo.py)."""
+    if world == 1:
+        full.copy_(rows)
+        return full
+    n_max = (total_rows + world - 1) // world
+    mine = torch.zeros(n_max, full.shape[1], dtype=full.dtype, device=full.device)
+    mine[:rows.shape[0]] = rows
+    parts = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine, group=group)
+    for r, part in enumerate(parts):
+        n_r = (total_rows - r + world - 1) // world
+        full[r::world] = part[:n_r]
+    return full
+
+
 class ShardedJointDriver(object):
     """The stepper interface of utils/fast_train.JointStepper (GB, rec_step, kg_step, take_sums, can_feed) over ShardedKtupJoint."""
 
@@ -145,18 +164,7 @@ class ShardedJointDriver(object):
         if not self._dirty:
             return
         for name, t in zip(BIG, self.tables):
-            full = getattr(self.m, name).weight.data
-            if self.world == 1:
-                full.copy_(t.weight.data)
-                continue
-            n_max = (t.total_rows + self.world - 1) // self.world
-            mine = torch.zeros(n_max, t.d, dtype=torch.float32, device=self.dev)
-            mine[:t.weight.shape[0]] = t.weight.data
-            parts = [torch.empty_like(mine) for _ in range(self.world)]
-            dist.all_gather(parts, mine, group=self.group)
-            for r, part in enumerate(parts):
-                n_r = (t.total_rows - r + self.world - 1) // self.world
-                full[r::self.world] = part[:n_r]
+            gather_table(getattr(self.m, name).weight.data, t.weight.data, t.total_rows, self.world, self.group)
         self._dirty = False
 
     @torch.no_grad()

@@ -145,9 +145,28 @@ def _shard_eval_worker(rank, world):
     C.run(rank, world, 'cpu', local_topk=C.np_local_topk, local_counts=C.np_local_counts)
 
 
-@pytest.mark.parametrize('worker', [_replica_worker, _sharded_worker, _sharded_step_worker, _merge_worker, _shard_eval_worker])
+def _gather_table_worker(rank, world):
+    """-shard_tables: before an evaluation or a checkpoint every rank rebuilds the whole tables from the shards
+    (utils/sharded_train.gather_table: rows g % world == r live on rank r) -- row counts that do and do not divide by the ranks,
+    a table with fewer rows than ranks, and the round trip back to the shards."""
+    from jTransUP.utils.sharded_train import gather_table
+    for total in (37, 40, 1, world, world + 1):
+        want = _init_rows(torch.arange(total))
+        mine = want[rank::world].clone()
+        full = torch.full((total, 8), float('nan'))
+        gather_table(full, mine, total, world)
+        assert torch.equal(full, want), (total, rank)
+        assert torch.equal(full[rank::world], mine)                         # load_from_model's slice is the shard again
+
+
+@pytest.mark.parametrize('worker', [_replica_worker, _sharded_worker, _sharded_step_worker, _merge_worker, _shard_eval_worker,
+                                    _gather_table_worker])
 def test_world_size_2_gloo(worker):
     _spawn(worker)
+
+
+def test_shard_gather_on_three_ranks():
+    _spawn(_gather_table_worker, world=3)
 
 
 def test_single_process_paths():

@@ -44,18 +44,39 @@ def getTrainTripleBatch(triple_batch, entity_total, all_head_dicts=None, all_tai
     return ph, pt, pr, nh, nt, nr
 
 
+_SEEN = []          # [(the dicts themselves, {user: union of the user's items over them})], most recent first, at most 4
+
+
+def _seen_sets(all_dicts):
+    """The per-user union of the rating dicts, built once per user and kept while the caller keeps handing over the SAME dict
+    objects (the drivers do: one list for the whole run).  The reference rebuilds the union for every rating of every batch
+    (data.py:70-75) -- 5.6 ms of a 512-rating batch; the membership tests and hence the draws are the same."""
+    for k, (dicts, seen) in enumerate(_SEEN):
+        if len(dicts) == len(all_dicts) and all(a is b for a, b in zip(dicts, all_dicts)):
+            if k:
+                _SEEN.insert(0, _SEEN.pop(k))
+            return seen
+    _SEEN.insert(0, (list(all_dicts), {}))
+    del _SEEN[4:]
+    return _SEEN[0][1]
+
+
 def getNegRatings(ratingList, itemTotal, all_dicts=None):
     """data.py:64-85: one negative per rating: != the positive, not rated by the user in any split, and not already
     used as a negative in this batch.  (Like the reference it requires all_dicts; `None` raises TypeError.)"""
     ni, used = [], set()
+    cache = _seen_sets(all_dicts) if all_dicts is not None else None
     for rating in ratingList:
         user, old_item = rating[0], rating[1]
         seen = None
-        if all_dicts is not None:
-            seen = set()
-            for dic in all_dicts:
-                if user in dic:
-                    seen.update(dic[user])
+        if cache is not None:
+            seen = cache.get(user)
+            if seen is None:
+                seen = set()
+                for dic in all_dicts:
+                    if user in dic:
+                        seen.update(dic[user])
+                cache[user] = seen
         while True:
             cand = random.randrange(itemTotal)
             if cand != old_item and cand not in seen and cand not in used:
@@ -80,14 +101,16 @@ def MakeTrainIterator(train_data, batch_size, negtive_samples=1):
     def data_iter():
         n = len(train_list)
         order = list(range(n)) * negtive_samples
-        random.shuffle(order)
+        random.shuffle(order)                                   # (python's shuffle of a list, like the reference: same permutation)
+        order_np = np.asarray(order)                            # a batch's rows are then one array slice, not a list -> array copy
         start = -batch_size
         while True:
             start += batch_size
             if start > n - batch_size:
                 start = 0
                 random.shuffle(order)
-            yield train_list[order[start:start + batch_size]].tolist()
+                order_np = np.asarray(order)
+            yield train_list[order_np[start:start + batch_size]].tolist()
 
     return data_iter()
 

@@ -233,6 +233,7 @@ def train_step_bench(device, steps=200, warmup=20):
     import types
     from jTransUP.utils.fast_train import JointStepper
     # (gpu_resident_norm_pass: the fused step with round 2's norm pass + grid barrier in the optimizer launch, KTUP_TRACKED_NORM=0)
+    outer_tracked = os.environ.get('KTUP_TRACKED_NORM')          # (an A/B run of tools/step_time.py sets it for the legs below)
     for tag, env in (('gpu_resident_multilaunch', '0'), ('gpu_resident_norm_pass', '1'), ('gpu_resident', '1')):
         os.environ['KTUP_FUSED_STEP'] = env
         os.environ['KTUP_TRACKED_NORM'] = '0' if tag == 'gpu_resident_norm_pass' else '1'
@@ -275,6 +276,8 @@ def train_step_bench(device, steps=200, warmup=20):
                 out['device_ms_per_%s_step' % kind] = a.elapsed_time(b) / 50
     os.environ.pop('KTUP_FUSED_STEP', None)
     os.environ.pop('KTUP_TRACKED_NORM', None)
+    if outer_tracked is not None:
+        os.environ['KTUP_TRACKED_NORM'] = outer_tracked
     # device-fed steps (what -device_sampling runs): batch slice + negatives drawn by ktup_feed_* at the head of the step's graph;
     # one graph per step, and ten steps (7 rec + 3 kg) per graph -- what the joint driver replays between evaluations
     from jTransUP.utils.device_sampler import DeviceSampler

@@ -52,7 +52,11 @@ const char* ktup_last_error(void);
  *   "bwd_wide_max" [KTUP_BWD_WIDE_MAX, 4096]  K5-K7 backward, d <= 128: pairs up to which four waves share a 16-pair tile
  *   "side_sort"   [KTUP_SIDE_SORT, 1]    0: the id sorts of those segment reductions stay on the caller's stream (default: a
  *                                        library-owned side stream, forked at entry and joined before the reduction; never
- *                                        while the caller's stream is being captured into a graph)                       */
+ *                                        while the caller's stream is being captured into a graph)
+ *   "deterministic" [KTUP_DETERMINISTIC, 0]  1: ktup_train_rec_step / ktup_train_kg_step (gradients by atomics) run on ONE
+ *                                        workgroup, so every gradient cell receives its adds from one wave in program order
+ *                                        and two runs of a step give the same bits (sums of float atomics issued by several
+ *                                        workgroups depend on the order they land in).  For parity runs: ~50x slower.        */
 int ktup_set_option(const char* name, int value);
 int ktup_get_option(const char* name, int* value);
 

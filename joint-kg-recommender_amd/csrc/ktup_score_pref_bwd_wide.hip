@@ -166,16 +166,17 @@ __global__ __launch_bounds__(G::NT) void pref_bwd_wide_kernel(WArgs a) {
           }
           lo += dot * dot / nr;
         }
-        if (lane == 0 && lo != 0.f) atomicAdd(a.loss + 1, lo);
-        if (track_o) {                                           // (no barrier was passed yet: every wave is still here)
-          sq = group_sum<64>(sq);
-          if (lane == 0) reds[w] = sq;
-          __syncthreads();
-          if (tid == 0) {
-            double t = 0.0;
-            for (int ww = 0; ww < G::NWC; ++ww) t += (double)reds[ww];
-            gnorm_add(a.gnorm, set_o, t);
-          }
+        // the waves' shares of the value summed in wave order by one thread (one atomic per wave landed in any order: the value's last bit
+        // changed from run to run); no barrier was passed yet: every wave is still here
+        sq = track_o ? group_sum<64>(sq) : 0.f;
+        if (lane == 0) { reds[w] = sq; reds[G::NWC + w] = lo; }
+        __syncthreads();
+        if (tid == 0) {
+          double t = 0.0;
+          float lsum = 0.f;
+          for (int ww = 0; ww < G::NWC; ++ww) { t += (double)reds[ww]; lsum += reds[G::NWC + ww]; }
+          if (lsum != 0.f) atomicAdd(a.loss + 1, lsum);
+          if (track_o) gnorm_add(a.gnorm, set_o, t);
         }
         return;
       }
@@ -716,7 +717,10 @@ int launch_r(const WArgs& a, hipStream_t st, const char* name) {
   const int64_t ntiles = STEP ? (a.B + 7) / 8 : (a.n + 15) / 16;
   // d = 256: one workgroup (4 waves) per CU is all the LDS allows; narrower tables: two or three fit
   const int per_cu = (int)((160 * 1024) / G::LDS) < 1 ? 1 : (int)((160 * 1024) / G::LDS);
-  const int grid = grid_for(ntiles, 256 * per_cu) + ((STEP && a.orth) ? 1 : 0);
+  // option `deterministic` (the fused step with gradients by atomics): ONE workgroup walks every tile -- a wave owns its coordinates of every
+  // row, so each gradient cell receives its adds from one wave in program order, and the table gradients are flushed once
+  const int tile_wgs = (STEP && !ROWOUT && opt_deterministic()) ? 1 : grid_for(ntiles, 256 * per_cu);
+  const int grid = tile_wgs + ((STEP && a.orth) ? 1 : 0);
   hipLaunchKernelGGL((pref_bwd_wide_kernel<G, ROWOUT, STEP>), dim3(grid), dim3(G::NT), G::LDS, st, a);
   return check_launch(name);
 }

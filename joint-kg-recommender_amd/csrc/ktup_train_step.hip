@@ -27,6 +27,8 @@ struct KgStepArgs {
   float* loss;                   // [4]: margin sum, orth, normE, normR  (accumulated)
   float *gE, *gR, *gN;
   double* gnorm;                 // (may be null) the gradient-norm workspace of ktup_common.h: every add tracks the squared norm it builds
+  int serial;                    // option `deterministic`: ONE lane group of one workgroup walks every pair, so that each gradient cell receives its
+                                 // adds in program order (the sums of float atomics from several waves depend on the order they land in)
 };
 
 template <int GL, bool TRANSH>
@@ -39,7 +41,9 @@ __global__ __launch_bounds__(256) void kg_step_kernel(KgStepArgs a) {
   const bool track = a.gnorm != nullptr;
   const int gset = track ? gnorm_set(a.gnorm) : 0;
   float ssq = 0.f;
-  for (int64_t k = (int64_t)blockIdx.x * GPB + threadIdx.x / GL; k < a.B; k += (int64_t)gridDim.x * GPB) {
+  const int64_t k0 = a.serial ? (threadIdx.x < GL ? 0 : a.B) : (int64_t)blockIdx.x * GPB + threadIdx.x / GL;
+  const int64_t kstep = a.serial ? 1 : (int64_t)gridDim.x * GPB;
+  for (int64_t k = k0; k < a.B; k += kstep) {
     const int64_t id[4] = {a.h[k], a.t[k], a.h[k + a.B], a.t[k + a.B]};      // ph, pt, nh, nt
     const int64_t rid[2] = {a.r[k], a.r[k + a.B]};
     float4 e[4], rr[2], ww[2];
@@ -159,7 +163,7 @@ template <bool TRANSH>
 int launch_kg(const KgStepArgs& a, hipStream_t st, const char* name) {
 #define KTUP_KG(GL)                                                                                            \
   {                                                                                                            \
-    const int grid = grid_for((a.B + (256 / GL) - 1) / (256 / GL), 1024);                                      \
+    const int grid = a.serial ? 1 : grid_for((a.B + (256 / GL) - 1) / (256 / GL), 1024);                       \
     hipLaunchKernelGGL((kg_step_kernel<GL, TRANSH>), dim3(grid), dim3(256), 0, st, a);                         \
     return check_launch(name);                                                                                 \
   }
@@ -244,6 +248,6 @@ extern "C" int ktup_train_kg_step(int transh, const float* E, int64_t lde, const
   if (d <= 0 || d % 4 || d > 256 || (lde | ldr | (transh ? ldn : 0)) % 4 || !aligned16(E) || !aligned16(R) || !aligned16(gE) || !aligned16(gR) ||
       (transh && (!aligned16(Nrm) || !aligned16(gN))))
     return set_error(KTUP_ERR_UNSUPPORTED, "%s: needs d %% 4 == 0 (<= 256) and 16-byte aligned rows", name);
-  KgStepArgs a{E, R, Nrm, lde, ldr, ldn, h, t, r, B, d / 4, l1 != 0, margin, gscale, regs, loss, gE, gR, gN, gnorm};
+  KgStepArgs a{E, R, Nrm, lde, ldr, ldn, h, t, r, B, d / 4, l1 != 0, margin, gscale, regs, loss, gE, gR, gN, gnorm, opt_deterministic() != 0};
   return transh ? launch_kg<true>(a, (hipStream_t)stream, name) : launch_kg<false>(a, (hipStream_t)stream, name);
 }

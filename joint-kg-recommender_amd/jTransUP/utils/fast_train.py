@@ -332,7 +332,12 @@ class _StepperBase(object):
         self.trainer.fused.clip_and_step(self.max_norm, zero_grads=True, loss=loss, gnorm=self._gn_ptr() if tracked else None)
 
     def _fused_ok(self, kind, d, n_pref=0):
-        return bool(self.want_fused and L.load().ktup_train_step_supported(kind, d, n_pref))
+        ok = bool(self.want_fused and L.load().ktup_train_step_supported(kind, d, n_pref))
+        if not ok and L.get_option('deterministic'):
+            # KTUP_DETERMINISTIC=1 (include/ktup_hip.h option "deterministic"): only the fused step kernels have the one-workgroup
+            # form whose gradient sums do not depend on the order atomics land in; the multi-launch route would silently not have it
+            raise L.KtupError('KTUP_DETERMINISTIC=1 needs a fused step kernel; this shape (kind %d, d=%d, n_pref=%d) has none' % (kind, d, n_pref))
+        return ok
 
     def _step(self, kind, eager, args):
         fused = self.trainer.fused
@@ -510,6 +515,7 @@ class RecStepper(_StepperBase):
                         _p(gneg), st)]
         self.fused_step = False
         if not self.tup:
+            self._fused_ok(-1, d)                          # (raises under KTUP_DETERMINISTIC=1: BPRMF steps are several launches with plain atomics)
             self._fwd = b('ktup_score_bprmf_fwd', _p(U), U.stride(0), _p(I), I.stride(0), d, _p(self.u2), _p(self.i2), 2 * B,
                           _p(self.score), st)
             self._bwd = b('ktup_score_bprmf_bwd', _p(U), U.stride(0), _p(I), I.stride(0), d, _p(self.u2), _p(self.i2), 2 * B,
@@ -597,7 +603,7 @@ class KGStepper(_StepperBase):
         d = E.shape[1]
         pos, neg, gpos, gneg = self.score[:B], self.score[B:], self.gscore[:B], self.gscore[B:]
         calls = []
-        self.fused_step = (not self.transr) and self._fused_ok(1 if self.transh else 2, d)
+        self.fused_step = self._fused_ok(-1 if self.transr else (1 if self.transh else 2), d)      # (-1: no fused kernel; TransR's step stays multi-launch)
         if self.fused_step:
             Rn_ = self.tabs[2] if self.transh else None
             self._kg_fused = b('ktup_train_kg_step', int(self.transh), _p(E), E.stride(0), _p(R), R.stride(0), _p(Rn_),

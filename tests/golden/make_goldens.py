@@ -37,6 +37,7 @@ sys.dont_write_bytecode = True
 ap = argparse.ArgumentParser()
 ap.add_argument('--ref', default='/root/reference')
 ap.add_argument('--out', default=os.path.dirname(os.path.abspath(__file__)))
+ap.add_argument('--only', default='', help="'train_steps': write only the three train_steps*.npz fixtures and their _cond files")
 args = ap.parse_args()
 sys.path.insert(0, args.ref)
 
@@ -500,6 +501,7 @@ def train_step_cases(d=64, out_name='train_steps', seeds=(47, 53), ktup_cases=No
     NSTEP = 3
     log = logging.getLogger('goldens'); log.setLevel(logging.ERROR)
     out = {}
+    cond_out = {}                        # <out_name>_cond.npz: conditioning of every final table (see conditioning() below)
 
     def flags(model_type, opt, l2, lr):
         return types.SimpleNamespace(model_type=model_type, optimizer_type=opt, l2_lambda=l2, learning_rate=lr,
@@ -509,14 +511,99 @@ def train_step_cases(d=64, out_name='train_steps', seeds=(47, 53), ktup_cases=No
     def ids(hi, n=B):
         return torch.from_numpy(rng.randint(0, hi, n)).long()
 
-    def run(tag, model, FL, steps, clip_max):
-        """steps: list of callables(model, trainer) -> loss Variable (the driver's loss lines).  Returns nothing; fills `out`."""
+    def replay(model, FL, steps, clip_max, after_backward=None, grads=None):
+        """The same loop as run() below on another copy of the model (conditioning replays): -> (final tables, gradient norms)."""
         tr = rtrainer.ModelTrainer(model, log, 10, FL)
-        losses, norms = [], []
+        norms = []
+        for t, body in enumerate(steps):
+            tr.optimizer_zero_grad()
+            l = body(model, tr)
+            l.backward()
+            if grads is not None:
+                grads.append({k: p.grad.data.double().numpy().copy() for k, p in model.named_parameters() if p.grad is not None})
+            if after_backward is not None:
+                after_backward(model, t)
+            norms.append(float(clip([p for _, p in model.named_parameters()], clip_max)))
+            tr.optimizer_step()
+        return {k: p.data.double().numpy().copy() for k, p in model.named_parameters()}, norms
+
+    def conditioning(tag, model0, FL, spec, clip_max, grads32):
+        """How far the tables after the last step move under changes that are mathematically (nearly) nothing -- the measure of which
+        elements a 1e-4 band can pin at all.  (An Adam element whose clipped gradient is of the size of eps = 1e-8 turns the last bits
+        of that gradient into a step of 1e-4; a gradient that is the small difference of large per-pair terms carries a rounding
+        error of several per cent in ANY fp32 evaluation, and each evaluation order rounds it differently.)  Samples, all through
+        the reference's own modules and ModelTrainer:
+          (1) the steps in fp64 (`.double()`; the ST-Gumbel uniforms are the fp32 draws);
+          (2) N_PERM fp32 replays with every batch in another order (the reference shuffles its batches every epoch,
+              utils/data.py:87-110: the sums over the batch and the embedding backward then round differently);
+          (3) N_NOISE fp64 replays in which, between backward() and clip_grad_norm, every gradient row receives Gaussian noise of
+              TWICE the size of the rounding error the reference's own fp32 step committed on that row at that step -- measured as
+              1.4826 x the median over the row of |fp32 gradient - fp64 gradient| (a robust scale: a few elements whose
+              trajectories already differ do not inflate it).  This is what another fp32 evaluation of the same step amounts to.
+        cond.<table> = max over the samples of |sample - final32|; d64.<table> = final64 - final32.  Entries below 1/64 of the band
+        2e-5 + 1e-4 |final32| are stored as 0 (they decide nothing; the file stays small)."""
+        import copy
+        import zlib
+        N_PERM, N_NOISE = 8, 16
+        prs = np.random.RandomState(zlib.crc32((out_name + ':' + tag).encode()) & 0x7fffffff)
+        final32 = {k: out[tag + 'final.' + k].astype(np.float64) for k, _ in model0.named_parameters()}
+        real_uniform = torch.Tensor.uniform_
+        ctx = {'perm': None}
+
+        def uniform_(self, *a, **kw):                         # the fp32 draws, whatever the table's dtype; rows follow the batch order
+            if self.dtype != torch.float64 and ctx['perm'] is None:
+                return real_uniform(self, *a, **kw)
+            tmp = real_uniform(torch.empty(self.shape, dtype=torch.float32), *a, **kw)
+            self.copy_(tmp if ctx['perm'] is None else tmp[ctx['perm']])
+            return self
+
+        def bodies(perm=None):
+            return [f(b if perm is None else {k: v[perm] for k, v in b.items()}, **kw) for f, b, kw in spec]
+
+        torch.Tensor.uniform_ = uniform_
+        try:
+            grads64 = []
+            f64, n64 = replay(copy.deepcopy(model0).double(), FL, bodies(), clip_max, grads=grads64)
+            sigma = [{k: 1.4826 * np.median(np.abs(g32[k] - g64[k]), axis=1, keepdims=True) for k in g64 if k in g32}
+                     for g32, g64 in zip(grads32, grads64)]
+
+            def noise(model, t):
+                for k, p in model.named_parameters():
+                    if p.grad is not None and k in sigma[t]:
+                        p.grad.data.add_(torch.from_numpy(2.0 * sigma[t][k] * prs.standard_normal(tuple(p.shape))))
+
+            samples = [f64]
+            for _ in range(N_PERM):
+                ctx['perm'] = torch.from_numpy(prs.permutation(B))
+                samples.append(replay(copy.deepcopy(model0), FL, bodies(ctx['perm']), clip_max)[0])
+                ctx['perm'] = None
+            for _ in range(N_NOISE):
+                samples.append(replay(copy.deepcopy(model0).double(), FL, bodies(), clip_max, after_backward=noise)[0])
+        finally:
+            torch.Tensor.uniform_ = real_uniform
+            ctx['perm'] = None
+        cond_out[tag + 'gradnorms64'] = np.asarray(n64, dtype=np.float64)
+        for k, w in final32.items():
+            floor = (2e-5 + 1e-4 * np.abs(w)) / 64.0
+            c = np.max(np.stack([np.abs(s[k] - w) for s in samples]), axis=0)
+            d64 = f64[k] - w
+            cond_out[tag + 'cond.' + k] = np.where(c < floor, 0.0, c).astype(np.float32)
+            cond_out[tag + 'd64.' + k] = np.where(np.abs(d64) < floor, 0.0, d64).astype(np.float32)
+
+    def run(tag, model, FL, steps, clip_max, spec=None):
+        """steps: list of callables(model, trainer) -> loss Variable (the driver's loss lines).  Returns nothing; fills `out`.
+        spec: the same steps as (factory, batch, keyword arguments) triples, for the conditioning replays."""
+        import copy
+        model0 = copy.deepcopy(model)
+        if spec is not None:
+            steps = [f(b, **kw) for f, b, kw in spec]
+        tr = rtrainer.ModelTrainer(model, log, 10, FL)
+        losses, norms, grads32 = [], [], []
         for body in steps:
             tr.optimizer_zero_grad()
             l = body(model, tr)
             l.backward()
+            grads32.append({k: p.grad.data.double().numpy().copy() for k, p in model.named_parameters() if p.grad is not None})
             gn = clip([p for _, p in model.named_parameters()], clip_max)
             tr.optimizer_step()
             losses.append(float(l)); norms.append(float(gn))
@@ -525,6 +612,8 @@ def train_step_cases(d=64, out_name='train_steps', seeds=(47, 53), ktup_cases=No
         for k, p in model.named_parameters():
             out[tag + 'final.' + k] = npy(p.data)
         assert tr.step == len(steps)
+        if spec is not None:
+            conditioning(tag, model0, FL, spec, clip_max, grads32)
 
     # ---------------- KTUP (jtransup), the joint schedule: step s is a rec step iff s % 10 < 10 * joint_ratio
     sched = {}
@@ -575,8 +664,8 @@ def train_step_cases(d=64, out_name='train_steps', seeds=(47, 53), ktup_cases=No
             m = jtup.jTransUPModel(False, d, NU, NI, NE, NR, i_map, new_map, False, False)
             for k, p in m.named_parameters():
                 p.data.copy_(keep[k])
-            steps = [ktup_rec(b) if r else ktup_kg(b) for r, b in zip(kinds6, kt_batches)]
-            run('ktup.%s.l2_%g.' % (opt, l2), m, flags('jtransup', opt, l2, lr), steps, 5.0)
+            spec = [(ktup_rec if r else ktup_kg, b, {}) for r, b in zip(kinds6, kt_batches)]
+            run('ktup.%s.l2_%g.' % (opt, l2), m, flags('jtransup', opt, l2, lr), None, 5.0, spec=spec)
 
     # ---------------- TUP (transup), soft and ST-Gumbel gate, item_recommendation.py:160-192
     tup_batches = [dict(u=ids(NU), pi=ids(NI), ni=ids(NI)) for _ in range(NSTEP)]
@@ -608,16 +697,16 @@ def train_step_cases(d=64, out_name='train_steps', seeds=(47, 53), ktup_cases=No
             for k, p in m.named_parameters():
                 p.data.copy_(keep[k])
             tag = 'tup.%s.%s.' % ('hard' if gum else 'soft', opt)
-            steps = []
+            spec = []
             for s, b in enumerate(tup_batches):
                 seeds = None
                 if gum:
                     seeds = (500 + 2 * s, 501 + 2 * s)
                     out[tag + 'uni%d.pos' % s] = npy(uniforms(seeds[0], (B, NP_TUP)))
                     out[tag + 'uni%d.neg' % s] = npy(uniforms(seeds[1], (B, NP_TUP)))
-                steps.append(tup_rec(b, seeds))
+                spec.append((tup_rec, b, dict(seeds=seeds)))
             out[tag + 'clip'] = np.asarray([cmax])
-            run(tag, m, flags('transup', opt, 1e-5, lr), steps, cmax)
+            run(tag, m, flags('transup', opt, 1e-5, lr), None, cmax, spec=spec)
 
     # ---------------- TransE / TransH, knowledge_representation.py:176-216
     kg_batches = [dict(ph=ids(NE), pt=ids(NE), pr=ids(NR), nh=ids(NE), nt=ids(NE)) for _ in range(NSTEP)]
@@ -645,9 +734,10 @@ def train_step_cases(d=64, out_name='train_steps', seeds=(47, 53), ktup_cases=No
             m = getattr(mod, cls)(False, d, NE, NR)
             for k, p in m.named_parameters():
                 p.data.copy_(keep[k])
-            run('%s.%s.' % (name, opt), m, flags(name, opt, 1e-5, lr), [kg_body(b) for b in kg_batches], 5.0)
+            run('%s.%s.' % (name, opt), m, flags(name, opt, 1e-5, lr), None, 5.0, spec=[(kg_body, b, {}) for b in kg_batches])
     torch.optim.Optimizer.zero_grad = real_zero_grad
     save(out_name, **out)
+    save(out_name + '_cond', **cond_out)
     if out_name == 'train_steps':
         with open(os.path.join(args.out, 'train_steps.json'), 'w') as f:
             json.dump({'joint_schedule': sched, 'B': B, 'd': d, 'NP_TUP': NP_TUP}, f, indent=0, sort_keys=True)
@@ -860,11 +950,7 @@ def fm_cases():
         TF.embedding = real_emb
 
 
-if __name__ == '__main__':
-    i_map, new_map = score_cases()
-    eval_cases(i_map, new_map)
-    baseline_cases()
-    transr_d256_case()
+def train_step_fixtures():
     train_step_cases()
     # the same step bodies at BASELINE's widths (configs[1]-[3]: d = 100; config 5: d = 256)
     train_step_cases(d=100, out_name='train_steps_d100', seeds=(59, 61),
@@ -872,6 +958,17 @@ if __name__ == '__main__':
                      tup_cases=[(True, 'Adagrad'), (True, 'Adam'), (False, 'Adagrad')], kg_cases=[('transh', 'Adagrad'), ('transh', 'Adam')])
     train_step_cases(d=256, out_name='train_steps_d256', seeds=(67, 71), ktup_cases=[('Adagrad', 0.0), ('Adam', 1e-5)],
                      tup_cases=[(False, 'Adagrad')], kg_cases=[('transh', 'Adagrad')])
+
+
+if __name__ == '__main__':
+    if args.only == 'train_steps':
+        train_step_fixtures()
+        sys.exit(0)
+    i_map, new_map = score_cases()
+    eval_cases(i_map, new_map)
+    baseline_cases()
+    transr_d256_case()
+    train_step_fixtures()
     eval_pass_cases()
     fm_cases()
     kg_pass_cases()

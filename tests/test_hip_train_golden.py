@@ -1,18 +1,28 @@
 """The DEFAULT training path of the three drivers -- the GPU-resident steppers of utils/fast_train.py (fused step kernels, one-launch
 clip + optimizer, HIP-graph replay) -- against goldens produced by the REFERENCE's own step lines and its own ModelTrainer
 (tests/golden/make_goldens.py train_step_cases: knowledgable_recommendation.py:335-403, item_recommendation.py:160-192,
-knowledge_representation.py:176-216, utils/trainer.py:63-81): per-step losses, and every table after the last step.  Not a
-comparison with this repo's own autograd route (tests/test_fast_train.py does that): the other end of this one is the reference.
+knowledge_representation.py:176-216, utils/trainer.py:63-81): per-step losses, per-step pre-clip gradient norms (what
+clip_grad_norm returned to the reference), and every table after the last step.  Not a comparison with this repo's own autograd
+route (tests/test_fast_train.py does that): the other end of this one is the reference.
 Three worlds: d = 64 (train_steps.npz: every optimizer), and BASELINE's widths d = 100 (configs[1]-[3]) and d = 256 (config 5) --
 the fused step kernels are per-width templates, so each width is pinned to the reference on its own.
-Tolerance: 1e-4 on the tables (north_star): |got - want| <= 2e-5 + 1e-4 |want| for every element (one stray element per table is
-tolerated: float atomics land in a different order on every run), with one exemption that is named,
-counted and printed per table: an element whose second-moment state is tiny -- Adagrad's sum < 1e-5 (accumulated |g| < 3e-3) or
-Adam's exp_avg_sq < 1e-10 (|g| < 3e-4 after a few steps) -- where the gradient is the small difference of O(1) summands and
-lr * m / (sqrt(v) + eps) turns its last bits into a visible step.  Such elements may leave the band (at most 0.2 % of a table, none by
-more than 5e-4).  The thresholds come from the offenders themselves: with the state cut at 1e-12 five of the 27 cases failed on one
-or two elements each, of state 3e-12 (Adam), 1.5e-7, 6e-7, 1.3e-6, 2.1e-6 (Adagrad; errors 1.4e-5 .. 1.4e-4) and one of state 1.4e-3
-whose error 1.41e-5 sat just outside a 1e-5 floor."""
+
+Tolerance on the tables: 1e-4 (north_star): |got - want| <= 2e-5 + 1e-4 |want| for EVERY element that a 1e-4 band can pin.  Which
+elements it cannot pin is decided by the fixture, from the reference alone, not by this test and not by the kernels: next to each
+<fixture>.npz lies <fixture>_cond.npz with, per case and table, `cond` = how far the reference's own final value moves under
+mathematically null changes -- the same steps in fp64, the same batches in eight other orders (fp32), and sixteen fp64 replays with
+gradient noise of twice the reference's own measured fp32 rounding error on that gradient row (make_goldens.py conditioning()).
+An element is ILL-CONDITIONED when cond > band / 4: Adam turns a clipped gradient of the size of its eps = 1e-8 (or Adagrad a first
+gradient that is the small difference of large per-pair terms: lr g / sqrt(g^2) = +-lr) into a visible step whose size any fp32
+evaluation order decides anew; the reference's fp32 result is itself up to 1.2e-4 from its fp64 result there.  Ill-conditioned
+elements are at most 0.9 % of a case's elements (asserted: <= 1.25 %; per table <= 4 % -- the largest is 2.8 %: one whole user row
+of 37 whose only pair of the first step is saturated), listed per table in the output, and held to band + 2 cond instead of the
+band; everything else -- 99 % of every case -- to the plain band with NO exemption and no stray-element allowance.
+
+Two modes (the `mode` fixture): the default launches (gradient sums by float atomics from many workgroups: their order, and with it
+the last bits of an ill-conditioned element, changes from run to run) and option "deterministic" (include/ktup_hip.h: one
+workgroup issues every add in program order), under which test_deterministic_steps_repeat_bit_for_bit asserts that two runs of a
+case give the same bits in every table."""
 import json
 import logging
 import os
@@ -56,34 +66,51 @@ def _load(model, g, prefix):
     model.load_state_dict(sd)
 
 
-def _compare(model, g, tag, opt, trainer):
-    """Every element inside 2e-5 + 1e-4 |want|, except -- counted and reported per table -- those whose second-moment state is tiny
-    (see the module docstring); even those stay within 5e-4.  Plain SGD has no such state: no exemption."""
+def _cond(d):
+    if ('c', d) not in _CACHE:
+        _CACHE[('c', d)] = np.load(os.path.join(GOLDEN, FILES[d].replace('.npz', '_cond.npz')))
+    return _CACHE[('c', d)]
+
+
+@pytest.fixture(params=['atomics', 'deterministic'])
+def mode(request):
+    from jTransUP.hip import lib as L
+    old = L.set_option('deterministic', int(request.param == 'deterministic'))
+    yield request.param
+    L.set_option('deterministic', old)
+
+
+def _check_norm(trainer, g, tag, s):
+    """The pre-clip global gradient norm of the step just taken (the tracked norm of the step kernels' returning atomics at
+    d <= 128, the optimizer launch's norm pass at d = 256) against what nn.utils.clip_grad_norm returned to the reference at that
+    step (utils/trainer.py:63-81; knowledgable_recommendation.py:399-401)."""
+    np.testing.assert_allclose(trainer.fused.total_norm(), g[tag + 'gradnorms'][s], rtol=1e-4, err_msg='gradient norm of step %d' % s)
+
+
+def _compare(model, g, c, tag, trainer):
+    """Every element inside 2e-5 + 1e-4 |want| + 2 cond (module docstring): cond is 0 for all but the ill-conditioned elements, which
+    are counted, bounded and printed per table."""
     trainer.fused._flush_steps() if trainer.fused is not None else None
-    state_key = {'Adam': 'exp_avg_sq', 'Adagrad': 'sum'}.get(opt)
     report = []
-    for (k, v), p in zip(model.state_dict().items(), model.parameters()):
+    n_ill = n_all = 0
+    for k, v in model.state_dict().items():
         want = torch.from_numpy(g[tag + 'final.' + k])
+        cond = torch.from_numpy(c[tag + 'cond.' + k])
         got = v.detach().cpu()
         err = (got - want).abs()
-        bad = err > 2e-5 + 1e-4 * want.abs()
-        exempt = torch.zeros_like(bad)
-        if state_key is not None:
-            st = trainer.optimizer.state.get(p, {})
-            if state_key in st:
-                exempt = st[state_key].detach().cpu() < (1e-10 if opt == 'Adam' else 1e-5)
-        report.append('%s: %d of %d with a tiny state, %d of them outside the band' % (k, int(exempt.sum()), exempt.numel(), int((bad & exempt).sum())))
-        assert int((bad & exempt).sum()) <= max(2, exempt.numel() // 500), report[-1]
-        off = bad & ~exempt
+        band = 2e-5 + 1e-4 * want.abs()
+        ill = cond > band / 4
+        n_ill += int(ill.sum()); n_all += ill.numel()
+        assert int(ill.sum()) <= max(2, ill.numel() // 25), '%s: the fixture marks %d of %d elements ill-conditioned' % (k, int(ill.sum()), ill.numel())
+        bad = err > band + 2 * cond
+        report.append('%s: %d of %d ill-conditioned, %d of them outside the plain band (max %.3g)' % (
+            k, int(ill.sum()), ill.numel(), int((ill & (err > band)).sum()), float((err * ill).max())))
         detail = ''
-        if int(off.sum()) and state_key is not None and state_key in trainer.optimizer.state.get(p, {}):
-            sv = trainer.optimizer.state[p][state_key].detach().cpu()[off]
-            detail = ' states of the offenders: %s errors: %s' % (sv[:8].tolist(), err[off][:8].tolist())
-        # (one element per table may stray: the gradients are sums of float atomics whose order changes from run to run -- one run in
-        #  about eight of the 27 cases showed a single such element, never the same one)
-        assert int(off.sum()) <= 1 and float(err.max()) <= 5e-4, \
-            '%s: %d of %d well-conditioned elements off, max %.3g (%d exempt)%s' % (k, int(off.sum()), bad.numel(), float(err.max()),
-                                                                                   int(exempt.sum()), detail)
+        if int(bad.sum()):
+            idx = bad.nonzero()[:8]
+            detail = ' offenders (index, error, band, cond): %s' % [(tuple(i.tolist()), float(err[tuple(i)]), float(band[tuple(i)]), float(cond[tuple(i)])) for i in idx]
+        assert int(bad.sum()) == 0, '%s: %d of %d elements off, max error %.3g.%s' % (k, int(bad.sum()), bad.numel(), float(err.max()), detail)
+    assert n_ill <= n_all // 80, 'the fixture marks %d of %d elements ill-conditioned' % (n_ill, n_all)
     print(tag, '; '.join(report))
 
 
@@ -91,12 +118,18 @@ def _t(g, key):
     return torch.from_numpy(g[key]).to(DEV)
 
 
-@pytest.mark.parametrize('D,opt,lr,l2', [(64, 'Adagrad', 0.05, 0.0), (64, 'Adagrad', 0.05, 1e-5), (64, 'Adam', 0.01, 0.0), (64, 'Adam', 0.01, 1e-5),
-                                         (64, 'SGD', 0.05, 1e-5), (100, 'Adagrad', 0.05, 0.0), (100, 'Adagrad', 0.05, 1e-5), (100, 'Adam', 0.01, 0.0),
-                                         (100, 'Adam', 0.01, 1e-5), (256, 'Adagrad', 0.05, 0.0), (256, 'Adam', 0.01, 1e-5)])
-def test_joint_stepper_reproduces_the_reference_steps(tmp_path, D, opt, lr, l2):
+JOINT = [(64, 'Adagrad', 0.05, 0.0), (64, 'Adagrad', 0.05, 1e-5), (64, 'Adam', 0.01, 0.0), (64, 'Adam', 0.01, 1e-5), (64, 'SGD', 0.05, 1e-5),
+         (100, 'Adagrad', 0.05, 0.0), (100, 'Adagrad', 0.05, 1e-5), (100, 'Adam', 0.01, 0.0), (100, 'Adam', 0.01, 1e-5),
+         (256, 'Adagrad', 0.05, 0.0), (256, 'Adam', 0.01, 1e-5)]
+REC = [(64, False, 'Adagrad', 0.05), (64, False, 'Adam', 0.01), (64, True, 'Adagrad', 0.05), (64, True, 'Adam', 0.01),
+       (100, True, 'Adagrad', 0.05), (100, True, 'Adam', 0.01), (100, False, 'Adagrad', 0.05), (256, False, 'Adagrad', 0.05)]
+KG = [(64, 'transe', 'Adagrad', 0.05), (64, 'transe', 'Adam', 0.01), (64, 'transh', 'Adagrad', 0.05), (64, 'transh', 'Adam', 0.01),
+      (100, 'transh', 'Adagrad', 0.05), (100, 'transh', 'Adam', 0.01), (256, 'transh', 'Adagrad', 0.05)]
+
+
+def _run_joint(tmp_path, D, opt, lr, l2):
     """KTUP: rec, rec, kg, rec, kg, kg -- the fused rec and kg step kernels + ktup_optim_clip_step, replayed from graphs from the
-    third step of each kind on."""
+    third step of each kind on.  -> (model, trainer, fixture tag, losses)"""
     from jTransUP.models import jTransUP as jt
     from jTransUP.utils.fast_train import JointStepper
     from jTransUP.utils.trainer import ModelTrainer
@@ -111,18 +144,18 @@ def test_joint_stepper_reproduces_the_reference_steps(tmp_path, D, opt, lr, l2):
     tr = ModelTrainer(m, logging.getLogger('g4'), 10, FLAGS)
     st = JointStepper(m, tr, FLAGS, B)
     tag = 'ktup.%s.l2_%g.' % (opt, l2)
+    losses = []
     for s, is_rec in enumerate(g['ktup.kinds']):
         b = {k: _t(g, 'ktup.batch%d.%s' % (s, k)) for k in ('u', 'pi', 'ni', 'ph', 'pt', 'pr', 'nh', 'nt')}
         loss = st.rec_step(b['u'], b['pi'], b['ni']) if is_rec else st.kg_step(b['ph'], b['pt'], b['pr'], b['nh'], b['nt'], b['pr'])
-        np.testing.assert_allclose(float(loss), g[tag + 'losses'][s], rtol=1e-4)
+        losses.append(float(loss))
+        np.testing.assert_allclose(losses[-1], g[tag + 'losses'][s], rtol=1e-4)
+        _check_norm(tr, g, tag, s)
     assert st.fused_step and tr.step == 6
-    _compare(m, g, tag, opt, tr)
+    return m, tr, tag, losses
 
 
-@pytest.mark.parametrize('D,gum,opt,lr', [(64, False, 'Adagrad', 0.05), (64, False, 'Adam', 0.01), (64, True, 'Adagrad', 0.05), (64, True, 'Adam', 0.01),
-                                          (100, True, 'Adagrad', 0.05), (100, True, 'Adam', 0.01), (100, False, 'Adagrad', 0.05),
-                                          (256, False, 'Adagrad', 0.05)])
-def test_rec_stepper_reproduces_the_reference_steps(tmp_path, D, gum, opt, lr):
+def _run_rec(tmp_path, D, gum, opt, lr):
     """TUP, soft gate and ST-Gumbel gate (the reference's recorded uniforms fed through the parity hook), three steps."""
     from jTransUP.models import transUP as tu
     from jTransUP.utils.fast_train import RecStepper
@@ -134,20 +167,20 @@ def test_rec_stepper_reproduces_the_reference_steps(tmp_path, D, gum, opt, lr):
     _load(m, g, 'tup.init.')
     tr = ModelTrainer(m, logging.getLogger('g4'), 10, FLAGS)
     st = RecStepper(m, tr, FLAGS, B)
+    losses = []
     for s in range(3):
         b = {k: _t(g, 'tup.batch%d.%s' % (s, k)) for k in ('u', 'pi', 'ni')}
         if gum:
             st.set_gumbel_uniforms(torch.cat([_t(g, tag + 'uni%d.pos' % s), _t(g, tag + 'uni%d.neg' % s)]))
         loss = st.rec_step(b['u'], b['pi'], b['ni'])
-        np.testing.assert_allclose(float(loss), g[tag + 'losses'][s], rtol=1e-4)
+        losses.append(float(loss))
+        np.testing.assert_allclose(losses[-1], g[tag + 'losses'][s], rtol=1e-4)
+        _check_norm(tr, g, tag, s)
     assert st.fused_step
-    _compare(m, g, tag, opt, tr)
+    return m, tr, tag, losses
 
 
-@pytest.mark.parametrize('D,name,opt,lr', [(64, 'transe', 'Adagrad', 0.05), (64, 'transe', 'Adam', 0.01), (64, 'transh', 'Adagrad', 0.05),
-                                           (64, 'transh', 'Adam', 0.01), (100, 'transh', 'Adagrad', 0.05), (100, 'transh', 'Adam', 0.01),
-                                           (256, 'transh', 'Adagrad', 0.05)])
-def test_kg_stepper_reproduces_the_reference_steps(tmp_path, D, name, opt, lr):
+def _run_kg(tmp_path, D, name, opt, lr):
     from jTransUP.models import transE, transH
     from jTransUP.utils.fast_train import KGStepper
     from jTransUP.utils.trainer import ModelTrainer
@@ -158,9 +191,54 @@ def test_kg_stepper_reproduces_the_reference_steps(tmp_path, D, name, opt, lr):
     tr = ModelTrainer(m, logging.getLogger('g4'), 10, FLAGS)
     st = KGStepper(m, tr, FLAGS, B)
     tag = '%s.%s.' % (name, opt)
+    losses = []
     for s in range(3):
         b = {k: _t(g, 'kg.batch%d.%s' % (s, k)) for k in ('ph', 'pt', 'pr', 'nh', 'nt')}
         loss = st.kg_step(b['ph'], b['pt'], b['pr'], b['nh'], b['nt'], b['pr'])
-        np.testing.assert_allclose(float(loss), g[tag + 'losses'][s], rtol=1e-4)
+        losses.append(float(loss))
+        np.testing.assert_allclose(losses[-1], g[tag + 'losses'][s], rtol=1e-4)
+        _check_norm(tr, g, tag, s)
     assert st.fused_step
-    _compare(m, g, tag, opt, tr)
+    return m, tr, tag, losses
+
+
+@pytest.mark.parametrize('D,opt,lr,l2', JOINT)
+def test_joint_stepper_reproduces_the_reference_steps(tmp_path, mode, D, opt, lr, l2):
+    m, tr, tag, _ = _run_joint(tmp_path, D, opt, lr, l2)
+    _compare(m, _golden(D), _cond(D), tag, tr)
+
+
+@pytest.mark.parametrize('D,gum,opt,lr', REC)
+def test_rec_stepper_reproduces_the_reference_steps(tmp_path, mode, D, gum, opt, lr):
+    m, tr, tag, _ = _run_rec(tmp_path, D, gum, opt, lr)
+    _compare(m, _golden(D), _cond(D), tag, tr)
+
+
+@pytest.mark.parametrize('D,name,opt,lr', KG)
+def test_kg_stepper_reproduces_the_reference_steps(tmp_path, mode, D, name, opt, lr):
+    m, tr, tag, _ = _run_kg(tmp_path, D, name, opt, lr)
+    _compare(m, _golden(D), _cond(D), tag, tr)
+
+
+@pytest.mark.parametrize('runner,case', [(_run_joint, JOINT[2]), (_run_joint, JOINT[6]), (_run_joint, JOINT[10]), (_run_rec, REC[3]),
+                                         (_run_rec, REC[6]), (_run_kg, KG[3]), (_run_kg, KG[6])],
+                         ids=lambda v: v.__name__ if callable(v) else '-'.join(str(x) for x in v))
+def test_deterministic_steps_repeat_bit_for_bit(tmp_path, runner, case):
+    """Option "deterministic": two runs of the same steps from the same tables end in the same bits -- every table, every loss --
+    because each gradient cell receives its adds from one wave in program order (the default launches' sums depend on the order
+    float atomics from many workgroups land in: there the comparison above holds, this one need not).  At d = 256 the norm comes
+    from the optimizer launch's pass, whose fp64 partial sums land in any order: a 1e-16 relative difference that reaches the fp32
+    clip factor about once in 1e9 steps."""
+    from jTransUP.hip import lib as L
+    old = L.set_option('deterministic', 1)
+    try:
+        m1, tr1, _, l1 = runner(tmp_path, *case)
+        tr1.fused._flush_steps()
+        sd1 = {k: v.detach().clone() for k, v in m1.state_dict().items()}
+        m2, tr2, _, l2 = runner(tmp_path, *case)
+        tr2.fused._flush_steps()
+    finally:
+        L.set_option('deterministic', old)
+    assert l1 == l2
+    for k, v in m2.state_dict().items():
+        assert torch.equal(v, sd1[k]), '%s: %d elements differ between two deterministic runs' % (k, int((v != sd1[k]).sum()))

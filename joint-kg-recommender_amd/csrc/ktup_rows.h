@@ -107,11 +107,15 @@ KTUP_DEV float block_sum_256(float v) {
 // Same row mapping, but every row contributes one float (returned by op.run, meaningful on the group's lane 0)
 // to a scalar: per-thread partials -> one block reduction -> ONE atomic per workgroup.
 template <typename V, int G, int CPL, typename Op>
-__global__ __launch_bounds__(256) void row_reduce_kernel(Op op, int nch, int64_t n, float* __restrict__ out) {
+__global__ __launch_bounds__(256) void row_reduce_kernel(Op op, int nch, int64_t n, float* __restrict__ out, int serial) {
   RowCtx<V, G, CPL> cx{nch, (int)(threadIdx.x % G)};
   constexpr int GPB = 256 / G;
   float part = 0.f;
-  for (int64_t row = (int64_t)blockIdx.x * GPB + threadIdx.x / G; row < n; row += (int64_t)gridDim.x * GPB) {
+  // serial (option `deterministic`): ONE lane group walks every row, so a row listed several times receives its gradient adds in
+  // program order and the value is summed in row order
+  const int64_t row0 = serial ? (threadIdx.x < G ? 0 : n) : (int64_t)blockIdx.x * GPB + threadIdx.x / G;
+  const int64_t rstep = serial ? 1 : (int64_t)gridDim.x * GPB;
+  for (int64_t row = row0; row < n; row += rstep) {
     const float v = op.template run<V, G, CPL>(cx, row);
     if (cx.lane == 0) part += v;
   }
@@ -126,8 +130,9 @@ int launch_rows_reduce(const Op& op, int d, bool vec4, int64_t n, float* out, hi
   const int nch = vec4 ? d / 4 : d;
 #define KTUP_L(V, G, CPL)                                                                                   \
   {                                                                                                         \
-    const int grid = grid_for((n + (256 / G) - 1) / (256 / G), 128);                                        \
-    hipLaunchKernelGGL((row_reduce_kernel<V, G, CPL, Op>), dim3(grid), dim3(256), 0, st, op, nch, n, out);  \
+    const int serial = opt_deterministic() != 0;                                                            \
+    const int grid = serial ? 1 : grid_for((n + (256 / G) - 1) / (256 / G), 128);                           \
+    hipLaunchKernelGGL((row_reduce_kernel<V, G, CPL, Op>), dim3(grid), dim3(256), 0, st, op, nch, n, out, serial);  \
     return check_launch(name);                                                                              \
   }
   if (vec4) {

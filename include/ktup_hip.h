@@ -657,26 +657,6 @@ int ktup_optim_clip_step(int kind, int n_tensors, float* const* params, float* c
                          const int32_t* first, float lr, float weight_decay, float momentum, float beta1, float beta2, float eps,
                          float alpha, double* ws, double* gnorm, float max_norm, int zero_grads, float* loss_slots, int n_slots,
                          float loss_scale, float* loss_out, float* loss_acc, void* stream);
-/* ktup_optim_clip_step in its tracked-norm form (gnorm; or max_norm <= 0) with the NEXT step's feed riding in one extra workgroup
- * of the same launch: the optimizer pass of step k and ktup_feed_rec / ktup_feed_kg for step k + 1 (same arguments, same draws --
- * the feed only has to come after step k's kernel, the last reader of the id buffers, and before step k + 1's).  A fed step is then
- * two launches (step kernel, this) instead of three; the first step of a graph still takes a plain ktup_feed_*.               */
-int ktup_optim_step_feed_rec(int kind, int n_tensors, float* const* params, float* const* grads, float* const* state1,
-                             float* const* state2, const int64_t* sizes, const int64_t* steps, const int64_t* steps_dev,
-                             const int32_t* first, float lr, float weight_decay, float momentum, float beta1, float beta2, float eps,
-                             float alpha, double* ws, double* gnorm, float max_norm, int zero_grads, float* loss_slots, int n_slots,
-                             float loss_scale, float* loss_out, float* loss_acc, const int64_t* col_u, const int64_t* col_i,
-                             int64_t n_rows, int64_t B, int64_t* cursor, uint64_t* offset_dev, int64_t n_items,
-                             const uint32_t* user_item_bitmap, int64_t words_per_user, uint64_t seed, int unique_in_batch, int64_t* u2,
-                             int64_t* i2, void* feed_ws, int32_t* fail_count, void* stream);
-int ktup_optim_step_feed_kg(int kind, int n_tensors, float* const* params, float* const* grads, float* const* state1,
-                            float* const* state2, const int64_t* sizes, const int64_t* steps, const int64_t* steps_dev,
-                            const int32_t* first, float lr, float weight_decay, float momentum, float beta1, float beta2, float eps,
-                            float alpha, double* ws, double* gnorm, float max_norm, int zero_grads, float* loss_slots, int n_slots,
-                            float loss_scale, float* loss_out, float* loss_acc, const int64_t* col_h, const int64_t* col_t,
-                            const int64_t* col_r, int64_t n_rows, int64_t B, int64_t* cursor, uint64_t* offset_dev, int64_t n_ent,
-                            int64_t n_rel, const uint64_t* sorted_keys, int64_t n_keys, uint64_t seed, int64_t* h2, int64_t* t2,
-                            int64_t* r2, int32_t* fail_count, void* stream);
 
 #ifdef __cplusplus
 }

@@ -15,7 +15,6 @@
 // owns the item (earlier rounds beat later ones, lower rows beat higher ones inside a round).  One workgroup runs all rounds
 // (a batch is <= a few thousand rows; n <= n_items or uniqueness is impossible anyway), so the barrier is __syncthreads.
 #include "ktup_common.h"
-#include "ktup_optim_body.h"
 
 using namespace ktup;
 
@@ -266,62 +265,53 @@ __global__ __launch_bounds__(256) void negsample_kg_kernel(const int64_t* __rest
 // utils/data.py:87-110 MakeTrainIterator + :64-85 / :12-56).  `cols`: this epoch's shuffled example columns (the host
 // reshuffles them in place once per epoch); *cursor: first row of the next batch; *offset_dev: the Philox counter the
 // host-driven samplers take as an argument -- the same (seed, offset) sequence, hence the same negatives.  One workgroup.
-struct FeedRec {
-  const int64_t *col_u, *col_i; int64_t n_rows, B; int64_t* cursor; uint64_t* offset_dev; int64_t n_items;
-  const uint32_t* bitmap; int64_t words; uint64_t seed; int unique; int64_t *u2, *i2; unsigned long long* owner; int32_t* fail;
-};
-struct FeedKg {
-  const int64_t *col_h, *col_t, *col_r; int64_t n_rows, B; int64_t* cursor; uint64_t* offset_dev; int64_t n_ent, n_rel;
-  const uint64_t* keys; int64_t nk; uint64_t seed; int64_t *h2, *t2, *r2; int32_t* fail;
-};
-
-// one workgroup of UNIQ_THREADS threads; lown: n_items u64 of LDS when the fast unique path applies (see ktup_feed_rec)
-KTUP_DEV void feed_rec_body(const FeedRec& f, unsigned long long* lown) {
-  const Philox ph(f.seed);
-  const int64_t B = f.B;
-  int64_t start = *f.cursor;
-  const uint64_t offset = *f.offset_dev;
-  if (start < 0 || start + B > f.n_rows) {                 // the host wraps before this can happen; never read out of bounds
-    if (threadIdx.x == 0 && f.fail) atomicAdd(f.fail, 1);
+__global__ __launch_bounds__(UNIQ_THREADS) void feed_rec_kernel(const int64_t* __restrict__ col_u, const int64_t* __restrict__ col_i,
+                                                                int64_t n_rows, int64_t B, int64_t* cursor, uint64_t* offset_dev,
+                                                                int64_t n_items, const uint32_t* __restrict__ bitmap, int64_t words,
+                                                                uint64_t seed, int unique, int64_t* u2, int64_t* i2,
+                                                                unsigned long long* owner, int32_t* __restrict__ fail) {
+  const Philox ph(seed);
+  int64_t start = *cursor;
+  const uint64_t offset = *offset_dev;
+  if (start < 0 || start + B > n_rows) {                   // the host wraps before this can happen; never read out of bounds
+    if (threadIdx.x == 0 && fail) atomicAdd(fail, 1);
     start = 0;
   }
   __syncthreads();                                         // everyone holds the cursor before thread 0 moves it
-  const int64_t *u = f.col_u + start, *pos = f.col_i + start;
-  int64_t* neg = f.i2 + B;
-  if (f.unique && B <= UNIQ_THREADS && f.n_items <= FAST_ITEMS) {
-    rec_unique_fast(ph, u, pos, B, f.n_items, f.bitmap, f.words, offset, neg, lown, f.fail);
+  const int64_t *u = col_u + start, *pos = col_i + start;
+  int64_t* neg = i2 + B;
+  extern __shared__ unsigned long long lown[];
+  if (unique && B <= UNIQ_THREADS && n_items <= FAST_ITEMS) {
+    rec_unique_fast(ph, u, pos, B, n_items, bitmap, words, offset, neg, lown, fail);
     __syncthreads();                                       // (the fallback's thread 0 may still have been writing neg[])
-  } else if (f.unique) {
-    rec_unique_rounds(ph, u, pos, B, f.n_items, f.bitmap, f.words, offset, neg, f.owner, f.fail, true);
+  } else if (unique) {
+    rec_unique_rounds(ph, u, pos, B, n_items, bitmap, words, offset, neg, owner, fail, true);
   } else {
-    for (int64_t b = threadIdx.x; b < B; b += UNIQ_THREADS) neg[b] = rec_pick(ph, offset, b, u[b], pos[b], f.n_items, f.bitmap, f.words, f.fail);
+    for (int64_t b = threadIdx.x; b < B; b += UNIQ_THREADS) neg[b] = rec_pick(ph, offset, b, u[b], pos[b], n_items, bitmap, words, fail);
   }
   for (int64_t b = threadIdx.x; b < B; b += UNIQ_THREADS) {
     const int64_t uu = u[b];
-    f.u2[b] = uu; f.u2[b + B] = uu; f.i2[b] = pos[b];
+    u2[b] = uu; u2[b + B] = uu; i2[b] = pos[b];
   }
-  if (threadIdx.x == 0) { *f.cursor = start + B; *f.offset_dev = offset + (uint64_t)B * MAX_TRIES; }
+  if (threadIdx.x == 0) { *cursor = start + B; *offset_dev = offset + (uint64_t)B * MAX_TRIES; }
 }
 
-__global__ __launch_bounds__(UNIQ_THREADS) void feed_rec_kernel(FeedRec f) {
-  extern __shared__ unsigned long long lown[];
-  feed_rec_body(f, lown);
-}
-
-// coarse: KG_COARSE u64 of LDS
-KTUP_DEV void feed_kg_body(const FeedKg& f, uint64_t* coarse) {
+__global__ __launch_bounds__(UNIQ_THREADS) void feed_kg_kernel(const int64_t* __restrict__ col_h, const int64_t* __restrict__ col_t,
+                                                               const int64_t* __restrict__ col_r, int64_t n_rows, int64_t B,
+                                                               int64_t* cursor, uint64_t* offset_dev, int64_t n_ent, int64_t n_rel,
+                                                               const uint64_t* __restrict__ keys, int64_t nk, uint64_t seed,
+                                                               int64_t* h2, int64_t* t2, int64_t* r2, int32_t* __restrict__ fail) {
   // every COARSE_STRIDE-th key in LDS: a membership test is a binary search in LDS + log2(stride) probes of the global list
   // instead of ~16 dependent L2 round trips (which were the whole 9 us of this launch)
-  const int64_t nk = f.nk, B = f.B;
-  const uint64_t* __restrict__ keys = f.keys;
+  __shared__ uint64_t coarse[KG_COARSE];
   const int64_t stride = nk > 0 ? max((int64_t)16, (nk + KG_COARSE - 1) / KG_COARSE) : 1;
   const int64_t nc = nk > 0 ? (nk + stride - 1) / stride : 0;
   for (int64_t i = threadIdx.x; i < nc; i += UNIQ_THREADS) coarse[i] = keys[i * stride];
-  const Philox ph(f.seed);
-  int64_t start = *f.cursor;
-  const uint64_t offset = *f.offset_dev;
-  if (start < 0 || start + B > f.n_rows) {
-    if (threadIdx.x == 0 && f.fail) atomicAdd(f.fail, 1);
+  const Philox ph(seed);
+  int64_t start = *cursor;
+  const uint64_t offset = *offset_dev;
+  if (start < 0 || start + B > n_rows) {
+    if (threadIdx.x == 0 && fail) atomicAdd(fail, 1);
     start = 0;
   }
   __syncthreads();
@@ -340,99 +330,13 @@ KTUP_DEV void feed_kg_body(const FeedKg& f, uint64_t* coarse) {
     return a < nk && keys[a] == key;
   };
   for (int64_t b = threadIdx.x; b < B; b += UNIQ_THREADS) {
-    const int64_t hh = f.col_h[start + b], tt = f.col_t[start + b], rr = f.col_r[start + b];
+    const int64_t hh = col_h[start + b], tt = col_t[start + b], rr = col_r[start + b];
     int64_t nh, nt;
-    kg_pick(ph, offset, b, hh, tt, rr, f.n_ent, f.n_rel, keys != nullptr, is_known, f.fail, nh, nt);
-    f.h2[b] = hh; f.t2[b] = tt; f.r2[b] = rr;
-    f.h2[b + B] = nh; f.t2[b + B] = nt; f.r2[b + B] = rr;
+    kg_pick(ph, offset, b, hh, tt, rr, n_ent, n_rel, keys != nullptr, is_known, fail, nh, nt);
+    h2[b] = hh; t2[b] = tt; r2[b] = rr;
+    h2[b + B] = nh; t2[b + B] = nt; r2[b + B] = rr;
   }
-  if (threadIdx.x == 0) { *f.cursor = start + B; *f.offset_dev = offset + (uint64_t)B * MAX_TRIES; }
-}
-
-__global__ __launch_bounds__(UNIQ_THREADS) void feed_kg_kernel(FeedKg f) {
-  __shared__ uint64_t coarse[KG_COARSE];
-  feed_kg_body(f, coarse);
-}
-
-// ---- the optimizer step of step k with the feed of step k + 1 riding in workgroup 0.  A fed training step is  feed -> step kernel ->
-// clip + optimizer; the feed is one workgroup's job (batch uniqueness) and a 9 us latency chain on an otherwise idle chip, and it needs
-// nothing of step k but to come after it in the sampler's own sequence -- so it runs BESIDE the optimizer pass instead of in front
-// of the next step kernel.  No second id buffer: this launch follows step k's kernel, which was the last reader of the ids.
-// The optimizer part is ktup_optim_step's arithmetic (step_chunk) on virtual workgroups of 256 threads, with the clip coefficient
-// from the tracked gradient norm (ktup_common.h gnorm_*: no norm pass, no barrier -- what makes a rider possible at all) and the
-// bookkeeping of ktup_optim_clip_step's tracked mode (loss slots, the idle slot set cleared, the step counted) in workgroup 1.
-template <int KIND, int FEED>
-__global__ __launch_bounds__(UNIQ_THREADS) void opt_feed_kernel(optb::OptTensors T, optb::Hyper h, double* __restrict__ ws, double* __restrict__ gn,
-                                                                float* __restrict__ slots, int n_slots, float loss_scale, float* __restrict__ loss_out,
-                                                                float* __restrict__ loss_acc, const int64_t* __restrict__ steps_dev, FeedRec fr, FeedKg fk) {
-  extern __shared__ unsigned long long dyn[];
-  if (blockIdx.x == 0) {
-    if (FEED == 1) feed_rec_body(fr, dyn);
-    else feed_kg_body(fk, reinterpret_cast<uint64_t*>(dyn));
-    return;
-  }
-  __shared__ float dev_bc1[optb::MAXT], dev_bc2s[optb::MAXT];
-  __shared__ float coef_s;
-  const bool clip = h.max_norm > 0.f;
-  const bool dev_bc = KIND == KTUP_OPT_ADAM && steps_dev != nullptr;
-  if (dev_bc && (int)threadIdx.x < T.count) {
-    const double t = (double)steps_dev[threadIdx.x];
-    dev_bc1[threadIdx.x] = (float)(1.0 - pow((double)h.beta1, t));
-    dev_bc2s[threadIdx.x] = (float)sqrt(1.0 - pow((double)h.beta2, t));
-  }
-  if (threadIdx.x < 64) {
-    if (slots && blockIdx.x == 1 && threadIdx.x == 0) {
-      float s = 0.f;
-      for (int i = 0; i < n_slots; ++i) { s += slots[i]; slots[i] = 0.f; }
-      *loss_out = loss_scale * s;
-      if (loss_acc) *loss_acc += loss_scale * s;
-    }
-    float c = 1.f;
-    if (clip) {
-      unsigned long long* gw = reinterpret_cast<unsigned long long*>(gn);
-      const int set = (int)(gw[1] & 1ull);
-      double v = threadIdx.x < GNORM_SLOTS ? gn[GNORM_SET0 + GNORM_SLOTS * set + threadIdx.x] : 0.0;
-#pragma unroll
-      for (int m = GNORM_SLOTS / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-      v = v > 0.0 ? v : 0.0;
-      c = h.max_norm / ((float)sqrt(v) + 1e-6f);
-      c = c < 1.f ? c : 1.f;
-      if (blockIdx.x == 1) {
-        if (threadIdx.x == 0) { ws[0] = v; gn[2] = v; gw[0] += 1ull; }
-        if (threadIdx.x < GNORM_SLOTS) gn[GNORM_SET0 + GNORM_SLOTS * (1 - set) + threadIdx.x] = 0.0;
-      }
-    }
-    if (threadIdx.x == 0) coef_s = c;
-  }
-  __syncthreads();
-  const float coef = coef_s;
-  const int t256 = threadIdx.x & 255;
-  const int64_t nvb = (int64_t)(gridDim.x - 1) * (UNIQ_THREADS / 256), nchunks = T.chunk0[T.count];
-  for (int64_t chunk = (int64_t)(blockIdx.x - 1) * (UNIQ_THREADS / 256) + (threadIdx.x >> 8); chunk < nchunks; chunk += nvb)
-    optb::step_chunk<KIND>(T, h, coef, chunk, t256, dev_bc, dev_bc1, dev_bc2s);
-}
-
-template <int FEED>
-int launch_opt_feed(int kind, const optb::OptTensors& T, const optb::Hyper& h, double* ws, double* gn, float* slots, int n_slots,
-                    float loss_scale, float* loss_out, float* loss_acc, const int64_t* steps_dev, const FeedRec& fr, const FeedKg& fk,
-                    size_t lds, hipStream_t st, const char* name) {
-  const int64_t nchunks = T.chunk0[T.count];
-  const dim3 grid((unsigned)(1 + grid_for((nchunks + 3) / 4, 1024))), block(UNIQ_THREADS);
-#define KTUP_OF(K)                                                                                                             \
-  {                                                                                                                            \
-    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)opt_feed_kernel<K, FEED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-    hipLaunchKernelGGL((opt_feed_kernel<K, FEED>), grid, block, lds, st, T, h, ws, gn, slots, n_slots, loss_scale, loss_out, loss_acc, \
-                       steps_dev, fr, fk);                                                                                     \
-    break;                                                                                                                     \
-  }
-  switch (kind) {
-    case KTUP_OPT_SGD: KTUP_OF(KTUP_OPT_SGD)
-    case KTUP_OPT_ADAGRAD: KTUP_OF(KTUP_OPT_ADAGRAD)
-    case KTUP_OPT_ADAM: KTUP_OF(KTUP_OPT_ADAM)
-    default: KTUP_OF(KTUP_OPT_RMSPROP)
-  }
-#undef KTUP_OF
-  return check_launch(name);
+  if (threadIdx.x == 0) { *cursor = start + B; *offset_dev = offset + (uint64_t)B * MAX_TRIES; }
 }
 
 }  // namespace
@@ -487,9 +391,8 @@ extern "C" int ktup_feed_rec(const int64_t* col_u, const int64_t* col_i, int64_t
                name);
   hipStream_t st = (hipStream_t)stream;
   const size_t lds = (unique_in_batch && B <= UNIQ_THREADS && n_items <= FAST_ITEMS) ? (size_t)n_items * sizeof(unsigned long long) : 0;
-  const FeedRec f{col_u, col_i, n_rows, B, cursor, offset_dev, n_items, user_item_bitmap, words_per_user, seed, unique_in_batch, u2, i2,
-                  (unsigned long long*)ws, fail_count};
-  hipLaunchKernelGGL(feed_rec_kernel, dim3(1), dim3(UNIQ_THREADS), lds, st, f);
+  hipLaunchKernelGGL(feed_rec_kernel, dim3(1), dim3(UNIQ_THREADS), lds, st, col_u, col_i, n_rows, B, cursor, offset_dev, n_items,
+                     user_item_bitmap, words_per_user, seed, unique_in_batch, u2, i2, (unsigned long long*)ws, fail_count);
   return check_launch(name);
 }
 
@@ -499,72 +402,7 @@ extern "C" int ktup_feed_kg(const int64_t* col_h, const int64_t* col_t, const in
   const char* name = "ktup_feed_kg";
   KTUP_REQUIRE(B > 0 && n_rows >= B && n_ent > 1 && n_rel > 0, "%s: bad sizes", name);
   KTUP_REQUIRE(col_h && col_t && col_r && cursor && offset_dev && h2 && t2 && r2, "%s: null pointer argument", name);
-  const FeedKg f{col_h, col_t, col_r, n_rows, B, cursor, offset_dev, n_ent, n_rel, sorted_keys, n_keys, seed, h2, t2, r2, fail_count};
-  hipLaunchKernelGGL(feed_kg_kernel, dim3(1), dim3(UNIQ_THREADS), 0, (hipStream_t)stream, f);
+  hipLaunchKernelGGL(feed_kg_kernel, dim3(1), dim3(UNIQ_THREADS), 0, (hipStream_t)stream, col_h, col_t, col_r, n_rows, B, cursor,
+                     offset_dev, n_ent, n_rel, sorted_keys, n_keys, seed, h2, t2, r2, fail_count);
   return check_launch(name);
-}
-
-// ---- ktup_optim_clip_step (tracked norm) + the NEXT step's feed in one launch: see opt_feed_kernel.
-namespace {
-int opt_feed_prepare(const char* name, optb::OptTensors& T, int kind, int n_tensors, float* const* params, float* const* grads,
-                     float* const* state1, float* const* state2, const int64_t* sizes, const int64_t* steps, const int64_t* steps_dev,
-                     const int32_t* first, float momentum, float beta1, float beta2, double* ws, double* gnorm, float max_norm,
-                     float* loss_slots, int n_slots, float* loss_out) {
-  KTUP_REQUIRE(ws, "%s: null workspace", name);
-  KTUP_REQUIRE(!loss_slots || (n_slots > 0 && loss_out), "%s: loss slots need a count and an output", name);
-  KTUP_REQUIRE(gnorm || max_norm <= 0.f, "%s: clipping here needs the tracked gradient norm (gnorm): there is no norm pass in this launch", name);
-  if (int e = optim_prepare(name, T, kind, n_tensors, params, grads, state1, state2, sizes, steps, steps_dev, first, momentum, beta1, beta2))
-    return e;
-  for (int i = 0; i < n_tensors; ++i) KTUP_REQUIRE(sizes[i] < (1ll << 32), "%s: tensor %d: 2^32 elements or more", name, i);
-  return KTUP_OK;
-}
-}  // namespace
-
-extern "C" int ktup_optim_step_feed_rec(int kind, int n_tensors, float* const* params, float* const* grads, float* const* state1,
-                                        float* const* state2, const int64_t* sizes, const int64_t* steps, const int64_t* steps_dev,
-                                        const int32_t* first, float lr, float weight_decay, float momentum, float beta1, float beta2,
-                                        float eps, float alpha, double* ws, double* gnorm, float max_norm, int zero_grads,
-                                        float* loss_slots, int n_slots, float loss_scale, float* loss_out, float* loss_acc,
-                                        const int64_t* col_u, const int64_t* col_i, int64_t n_rows, int64_t B, int64_t* cursor,
-                                        uint64_t* offset_dev, int64_t n_items, const uint32_t* user_item_bitmap, int64_t words_per_user,
-                                        uint64_t seed, int unique_in_batch, int64_t* u2, int64_t* i2, void* feed_ws, int32_t* fail_count,
-                                        void* stream) {
-  const char* name = "ktup_optim_step_feed_rec";
-  optb::OptTensors T{};
-  if (int e = opt_feed_prepare(name, T, kind, n_tensors, params, grads, state1, state2, sizes, steps, steps_dev, first, momentum, beta1, beta2,
-                               ws, gnorm, max_norm, loss_slots, n_slots, loss_out))
-    return e;
-  KTUP_REQUIRE(B > 0 && n_rows >= B && n_items > 1, "%s: bad feed sizes", name);
-  KTUP_REQUIRE(col_u && col_i && cursor && offset_dev && u2 && i2, "%s: null feed pointer", name);
-  KTUP_REQUIRE(!user_item_bitmap || words_per_user * 32 >= n_items, "%s: bitmap rows too short", name);
-  KTUP_REQUIRE(!unique_in_batch || (feed_ws && (reinterpret_cast<uintptr_t>(feed_ws) & 7u) == 0),
-               "%s: unique_in_batch needs the 8-byte aligned workspace", name);
-  const size_t lds = (unique_in_batch && B <= UNIQ_THREADS && n_items <= FAST_ITEMS) ? (size_t)n_items * sizeof(unsigned long long) : 0;
-  const optb::Hyper h{lr, weight_decay, momentum, beta1, beta2, eps, alpha, max_norm, zero_grads};
-  const FeedRec fr{col_u, col_i, n_rows, B, cursor, offset_dev, n_items, user_item_bitmap, words_per_user, seed, unique_in_batch, u2, i2,
-                   (unsigned long long*)feed_ws, fail_count};
-  return launch_opt_feed<1>(kind, T, h, ws, gnorm, loss_slots, n_slots, loss_scale, loss_out, loss_acc, steps_dev, fr, FeedKg{}, lds,
-                            (hipStream_t)stream, name);
-}
-
-extern "C" int ktup_optim_step_feed_kg(int kind, int n_tensors, float* const* params, float* const* grads, float* const* state1,
-                                       float* const* state2, const int64_t* sizes, const int64_t* steps, const int64_t* steps_dev,
-                                       const int32_t* first, float lr, float weight_decay, float momentum, float beta1, float beta2,
-                                       float eps, float alpha, double* ws, double* gnorm, float max_norm, int zero_grads,
-                                       float* loss_slots, int n_slots, float loss_scale, float* loss_out, float* loss_acc,
-                                       const int64_t* col_h, const int64_t* col_t, const int64_t* col_r, int64_t n_rows, int64_t B,
-                                       int64_t* cursor, uint64_t* offset_dev, int64_t n_ent, int64_t n_rel, const uint64_t* sorted_keys,
-                                       int64_t n_keys, uint64_t seed, int64_t* h2, int64_t* t2, int64_t* r2, int32_t* fail_count,
-                                       void* stream) {
-  const char* name = "ktup_optim_step_feed_kg";
-  optb::OptTensors T{};
-  if (int e = opt_feed_prepare(name, T, kind, n_tensors, params, grads, state1, state2, sizes, steps, steps_dev, first, momentum, beta1, beta2,
-                               ws, gnorm, max_norm, loss_slots, n_slots, loss_out))
-    return e;
-  KTUP_REQUIRE(B > 0 && n_rows >= B && n_ent > 1 && n_rel > 0, "%s: bad feed sizes", name);
-  KTUP_REQUIRE(col_h && col_t && col_r && cursor && offset_dev && h2 && t2 && r2, "%s: null feed pointer", name);
-  const optb::Hyper h{lr, weight_decay, momentum, beta1, beta2, eps, alpha, max_norm, zero_grads};
-  const FeedKg fk{col_h, col_t, col_r, n_rows, B, cursor, offset_dev, n_ent, n_rel, sorted_keys, n_keys, seed, h2, t2, r2, fail_count};
-  return launch_opt_feed<2>(kind, T, h, ws, gnorm, loss_slots, n_slots, loss_scale, loss_out, loss_acc, steps_dev, FeedRec{}, fk,
-                            (size_t)KG_COARSE * sizeof(uint64_t), (hipStream_t)stream, name);
 }

@@ -140,13 +140,6 @@ SIGNATURES = {
     'ktup_negsample_kg': [c_p, c_p, c_p, c_l, c_l, c_l, c_p, c_l, c_u, c_u, c_p, c_p, c_p, c_p],
     'ktup_feed_rec': [c_p, c_p, c_l, c_l, c_p, c_p, c_l, c_p, c_l, c_u, c_i, c_p, c_p, c_p, c_p, c_p],
     'ktup_feed_kg': [c_p, c_p, c_p, c_l, c_l, c_p, c_p, c_l, c_l, c_p, c_l, c_u, c_p, c_p, c_p, c_p, c_p],
-    # ktup_optim_clip_step's arguments without the stream, then ktup_feed_rec's / ktup_feed_kg's with it
-    'ktup_optim_step_feed_rec': [c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_p, c_p, c_f, c_i, c_p,
-                                 c_i, c_f, c_p, c_p,
-                                 c_p, c_p, c_l, c_l, c_p, c_p, c_l, c_p, c_l, c_u, c_i, c_p, c_p, c_p, c_p, c_p],
-    'ktup_optim_step_feed_kg': [c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_p, c_p, c_f, c_i, c_p,
-                                c_i, c_f, c_p, c_p,
-                                c_p, c_p, c_p, c_l, c_l, c_p, c_p, c_l, c_l, c_p, c_l, c_u, c_p, c_p, c_p, c_p, c_p],
 }
 _RESTYPE = {'ktup_last_error': ctypes.c_char_p, 'ktup_shard_reduce_list_len': ctypes.c_int64, 'ktup_shard_route_workspace_bytes': ctypes.c_size_t,
             'ktup_shard_route_sort_bytes': ctypes.c_size_t, 'ktup_pref_workspace_bytes': ctypes.c_size_t, 'ktup_eval_kg_ranks_workspace_bytes': ctypes.c_size_t, 'ktup_eval_kg_ranks_transr_workspace_bytes': ctypes.c_size_t, 'ktup_eval_kg_ranks_fused_workspace_bytes': ctypes.c_size_t,

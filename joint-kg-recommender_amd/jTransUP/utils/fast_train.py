@@ -29,11 +29,6 @@ from jTransUP.hip import lib as L
 from jTransUP.hip import ops
 
 
-def _os_env(name, default):
-    import os
-    return os.environ.get(name, default)
-
-
 def _p(t):
     return None if t is None else t.data_ptr()
 
@@ -103,7 +98,6 @@ class _StepperBase(object):
         # norm of the buffers their atomics build, ktup_optim_clip_step reads it -- one process only (an all-reduce of the gradients
         # changes their norm), only with clipping on, and for d <= 128 (at d = 256 the rec step kernel has no registers left for the
         # returned values).  KTUP_TRACKED_NORM=0: the norm pass + grid barrier of round 2.
-        self._rider = None
         self._gn = None
         if self.world == 1 and self.max_norm > 0 and self.tabs[0].shape[1] <= 128 and _os.environ.get('KTUP_TRACKED_NORM', '1') != '0':
             self._gn = torch.zeros(64, dtype=torch.float64, device=dev)                 # KTUP_GNORM_WS_DOUBLES
@@ -138,19 +132,15 @@ class _StepperBase(object):
         """Fed steps: the optimizer launch adds the step's loss to acc[kind] itself."""
         return _p(self.acc[kind]) if self._acc_on else None
 
-    def _feed_args(self, kind):
-        """ktup_feed_rec's / ktup_feed_kg's arguments without the stream (also what rides in ktup_optim_step_feed_*)."""
-        sm, feed = self._sampler, self._feeds[kind]
-        if kind == 'rec':
-            return (_p(feed.cols[0]), _p(feed.cols[1]), feed.n, self.B, _p(feed.cursor), _p(sm.offset_dev[0:]),
-                    sm.n_items, _p(sm.bitmap), sm.words if sm.bitmap is not None else 0, sm.seed, 1, _p(self.u2), _p(self.i2),
-                    _p(sm.rec_workspace()), _p(sm.fail))
-        return (_p(feed.cols[0]), _p(feed.cols[1]), _p(feed.cols[2]), feed.n, self.B, _p(feed.cursor),
-                _p(sm.offset_dev[1:]), sm.n_ent, sm.n_rel, _p(sm.keys), 0 if sm.keys is None else sm.keys.numel(), sm.seed,
-                _p(self.h2), _p(self.t2), _p(self.r2), _p(sm.fail))
-
     def _make_feed(self, kind, st):
-        return L.bind('ktup_feed_rec' if kind == 'rec' else 'ktup_feed_kg', *self._feed_args(kind), st)
+        b, sm, feed = L.bind, self._sampler, self._feeds[kind]
+        if kind == 'rec':
+            return b('ktup_feed_rec', _p(feed.cols[0]), _p(feed.cols[1]), feed.n, self.B, _p(feed.cursor), _p(sm.offset_dev[0:]),
+                     sm.n_items, _p(sm.bitmap), sm.words if sm.bitmap is not None else 0, sm.seed, 1, _p(self.u2), _p(self.i2),
+                     _p(sm.rec_workspace()), _p(sm.fail), st)
+        return b('ktup_feed_kg', _p(feed.cols[0]), _p(feed.cols[1]), _p(feed.cols[2]), feed.n, self.B, _p(feed.cursor),
+                 _p(sm.offset_dev[1:]), sm.n_ent, sm.n_rel, _p(sm.keys), 0 if sm.keys is None else sm.keys.numel(), sm.seed,
+                 _p(self.h2), _p(self.t2), _p(self.r2), _p(sm.fail), st)
 
     def _bind_feeds(self, st):
         self._feed_launch = {kind: self._make_feed(kind, st) for kind in self._feeds}
@@ -191,18 +181,12 @@ class _StepperBase(object):
             with L.capture(graph):
                 self._acc_on = True
                 try:
-                    # the first step's feed is a launch of its own; every later one comes with the optimizer launch of the step before
-                    # it (ktup_optim_step_feed_*: one extra workgroup; `_optimizer_launches`) -- two launches per step instead of three
-                    riders = _os_env('KTUP_FEED_RIDER', '1') != '0'
-                    for k, kind in enumerate(kinds):
+                    for kind in kinds:
                         self._plans()
-                        if k == 0 or not riders:
-                            self._feed_launch[kind]()
-                        self._rider = kinds[k + 1] if riders and k + 1 < len(kinds) else None
+                        self._feed_launch[kind]()
                         (self._rec_eager if kind == 'rec' else self._kg_eager)(*((None,) * self.N_IDS[kind]))
                 finally:
                     self._acc_on = False
-                    self._rider = None
             self._keys = None
             fused._plan = None
             entry = (graph, None, fused)
@@ -343,17 +327,9 @@ class _StepperBase(object):
         return None if self._gn is None else _p(self._gn)
 
     def _optimizer_launches(self, loss=None, tracked=False):
-        """`tracked`: the launch before this one was a fused step bound with the gradient-norm workspace.  `self._rider` (set by
-        fed_cycle): the kind of the NEXT step, whose feed comes with this optimizer launch -- inside it when the launch has no norm
-        pass (tracked norm, or nothing clipped), right behind it otherwise."""
+        """`tracked`: the launch before this one was a fused step bound with the gradient-norm workspace."""
         self.sync.all_reduce_grads()       # world > 1: gradients of all tables + the loss scalars, one bucket, one collective
-        gn = self._gn_ptr() if tracked else None
-        rider = self._rider
-        inside = rider is not None and (gn is not None or self.max_norm <= 0)
-        self.trainer.fused.clip_and_step(self.max_norm, zero_grads=True, loss=loss, gnorm=gn,
-                                         feed=((rider,) + self._feed_args(rider)) if inside else None)
-        if rider is not None and not inside:
-            self._feed_launch[rider]()
+        self.trainer.fused.clip_and_step(self.max_norm, zero_grads=True, loss=loss, gnorm=self._gn_ptr() if tracked else None)
 
     def _fused_ok(self, kind, d, n_pref=0):
         ok = bool(self.want_fused and L.load().ktup_train_step_supported(kind, d, n_pref))

@@ -108,13 +108,12 @@ class FusedOptimizer(object):
         return 0 if self._sumsq is None else int(self._sumsq[OPTIM_WS_DOUBLES - 1:].view(torch.int64).item())
 
     @torch.no_grad()
-    def clip_and_step(self, max_norm, zero_grads=False, loss=None, gnorm=None, feed=None):
+    def clip_and_step(self, max_norm, zero_grads=False, loss=None, gnorm=None):
         """`zero_grads`: leave the gradients zero-filled (the next step's zero_grad folded into this pass) instead of
         clipped in place.  `loss` = (slots_ptr, n_slots, scale, out_ptr[, acc_ptr]): the fused training step's loss slots are folded
         into *out (and added to the running sum *acc) and cleared by the same launch (needs the one-launch route).  `gnorm`: pointer
         to the gradient-norm workspace the step launch tracked the squared norm in (include/ktup_hip.h KTUP_GNORM_WS_DOUBLES): the
-        launch then has no norm pass and no grid barrier.  `feed` = ('rec' | 'kg', ktup_feed_*'s arguments without the stream): the NEXT
-        step's batch is drawn by one extra workgroup of this launch (ktup_optim_step_feed_*; needs `gnorm`, or no clipping)."""
+        launch then has no norm pass and no grid barrier."""
         self._flush_steps()
         group = self.optimizer.param_groups[0]
         ps = [p for p in group['params'] if p.grad is not None]
@@ -149,13 +148,6 @@ class FusedOptimizer(object):
         head = (self.kind, n, params, grads, s1, s2, sizes, _arr(ctypes.c_int64, steps), steps_dev, _arr(ctypes.c_int32, firsts)) + hyper
         if gnorm is not None and not clip:
             gnorm = None
-        if feed is not None:
-            if clip and gnorm is None:
-                raise L.KtupError('a feed can ride in the optimizer launch only when the gradient norm came with the gradients (gnorm) or nothing is clipped')
-            lo = (None, 0, 0.0, None, None) if loss is None else (loss[0], int(loss[1]), float(loss[2]), loss[3], loss[4] if len(loss) > 4 else None)
-            L.call('ktup_optim_step_feed_' + feed[0], *head, self.sumsq_ptr(dev), gnorm, float(max_norm) if clip else 0.0, int(bool(zero_grads)),
-                   *lo, *feed[1:], stream)
-            return
         if self.one_launch or loss is not None or gnorm is not None:
             lo = (None, 0, 0.0, None, None) if loss is None else (loss[0], int(loss[1]), float(loss[2]), loss[3], loss[4] if len(loss) > 4 else None)
             L.call('ktup_optim_clip_step', *head, self.sumsq_ptr(dev), gnorm, float(max_norm) if clip else 0.0, int(bool(zero_grads)), *lo, stream)

@@ -399,56 +399,3 @@ def test_tracked_gradient_norm_is_the_norm_pass(tmp_path, monkeypatch, D):
         assert abs(n1 - n2) <= 2e-5 * n1, (step, n1, n2)
         _assert_tables_close(m1, m2, step)
     assert int(tracked._gn[:1].view(torch.int64).item()) == 10          # the workspace counted every step
-
-
-@pytest.mark.parametrize('optimizer', ['Adagrad', 'Adam', 'SGD'])
-def test_feed_riding_in_the_optimizer_launch_changes_nothing(tmp_path, monkeypatch, optimizer):
-    """Ten-step graphs of device-fed steps, two ways: every step's feed as a launch of its own (KTUP_FEED_RIDER=0: feed -> step kernel ->
-    clip + optimizer) and the feed of step k + 1 as one extra workgroup of step k's optimizer launch (ktup_optim_step_feed_*, default).
-    Same sampler seeds -> the same batches in the same order (the id buffers after the last step are compared bit for bit), the same
-    losses and, up to the order of the gradient atomics, the same tables and optimizer state -- for every optimizer kind the rider
-    kernel instantiates, clipping on (so the coefficient comes from the tracked norm)."""
-    from jTransUP.utils.device_sampler import DeviceSampler
-    from jTransUP.utils.fast_train import DeviceFeeder, JointStepper
-    B, D = 16, 100
-    cyc = ('rec', 'rec', 'kg', 'rec', 'kg', 'kg', 'rec', 'rec', 'kg', 'rec')
-    runs = []
-    for rider in ('0', '1'):
-        monkeypatch.setenv('KTUP_FEED_RIDER', rider)
-        FLAGS, m, tr, (NU, NI, NE, NR) = build(tmp_path, optimizer, False, D)
-        FLAGS.clipping_max_value = 0.05
-        if runs:
-            m.load_state_dict(copy.deepcopy(runs[0][0]))
-        init = copy.deepcopy(m.state_dict())
-        gen = torch.Generator().manual_seed(33)
-        ratings = [(int(u), int(i)) for u, i in zip(torch.randint(0, NU, (900,), generator=gen), torch.randint(0, NI, (900,), generator=gen))]
-        triples = [(int(h), int(t), int(r)) for h, t, r in zip(torch.randint(0, NE, (900,), generator=gen),
-                                                               torch.randint(0, NE, (900,), generator=gen),
-                                                               torch.randint(0, NR, (900,), generator=gen))]
-        rated = {}
-        for u, i in ratings:
-            rated.setdefault(u, set()).add(i)
-        sampler = DeviceSampler(DEV, seed=6)
-        sampler.set_rating_dicts(NU, NI, [rated])
-        sampler.set_triples(NE, NR, [triples])
-        st = JointStepper(m, tr, FLAGS, B)
-        st.attach_feeds(sampler, rec=DeviceFeeder(ratings, B, DEV, seed=7), kg=DeviceFeeder(triples, B, DEV, seed=8))
-        for k in range(10):                                              # single steps first: eager, then each kind's own graph
-            st.fed_step(cyc[k])
-        for _ in range(3):                                               # captured once, replayed twice
-            assert st.fed_cycle(cyc) == 10
-        sampler.check()
-        assert tr.step == 40
-        sums = st.take_sums()
-        runs.append((init, sums, copy.deepcopy(m.state_dict()), st._ids_rec.clone(), st._ids_kg.clone(),
-                     {k: v.clone() for k, v in tr.fused.optimizer.state_dict()['state'].get(0, {}).items() if torch.is_tensor(v)}))
-    a, b = runs
-    assert torch.equal(a[3], b[3]) and torch.equal(a[4], b[4])           # the last rec / kg batches: same rows, same negatives
-    for k in a[1]:
-        assert abs(a[1][k] - b[1][k]) <= 1e-4 * abs(a[1][k]) + 1e-5, (k, a[1], b[1])
-    for (k, x), (_, y) in zip(a[2].items(), b[2].items()):
-        err = (y - x).abs()
-        bad = err > 2e-6 + 2e-5 * x.abs()
-        assert float(bad.float().mean()) <= 2e-3 and float(err.max()) <= 1e-3 * 0.05, (k, int(bad.sum()), float(err.max()))
-    for k in a[5]:
-        assert torch.allclose(a[5][k], b[5][k], rtol=2e-4, atol=1e-7), k

@@ -26,6 +26,7 @@ int opt_dbg_eval();
 int opt_wide_waves();
 int opt_kg_exact();
 int opt_deterministic();
+int opt_fwd_wide();
 hipStream_t fork_side(hipStream_t st);              // ktup_runtime.hip: second stream for input-only work (nullptr: stay on st)
 void join_side(hipStream_t st, hipStream_t side);
 

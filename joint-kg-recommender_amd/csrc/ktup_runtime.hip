@@ -52,6 +52,7 @@ Option g_opts[] = {
     {"kg_exact", "KTUP_KG_EXACT", {env_int("KTUP_KG_EXACT", 1)}},            // 0: the fused squared-L2 link-prediction pass ranks by its own fp32 scores alone (no fp64 referee near the golds)
     {"wide_waves", "KTUP_WIDE_WAVES", {env_int("KTUP_WIDE_WAVES", 4)}},     // d = 256 coordinate-sliced K5-K7 backward / fused step: waves that share a 16-pair tile: 4, or 8 (two per SIMD: 1 us faster alone,
                                                                             // but its 2 x 240 registers per SIMD leave no room for the route's kernels beside it: 0.149 against 0.139 ms per config-5 step)
+    {"fwd_wide", "KTUP_FWD_WIDE", {env_int("KTUP_FWD_WIDE", 1)}},          // 0: K5-K7 forward at d = 256 keeps one wave per 16-pair tile for every batch size
     {"deterministic", "KTUP_DETERMINISTIC", {env_int("KTUP_DETERMINISTIC", 0)}},   // 1: ktup_train_rec_step / ktup_train_kg_step issue every gradient add from ONE workgroup in program order (parity runs: the same
                                                                             // bits on every run; ~1 ms per B = 512 step instead of ~0.02)
 };
@@ -75,7 +76,8 @@ int opt_dbg_eval() { return g_opts[10].value.load(std::memory_order_relaxed); }
 int opt_kg_wtab() { return g_opts[11].value.load(std::memory_order_relaxed); }
 int opt_kg_exact() { return g_opts[12].value.load(std::memory_order_relaxed); }
 int opt_wide_waves() { return g_opts[13].value.load(std::memory_order_relaxed); }
-int opt_deterministic() { return g_opts[14].value.load(std::memory_order_relaxed); }
+int opt_fwd_wide() { return g_opts[14].value.load(std::memory_order_relaxed); }
+int opt_deterministic() { return g_opts[15].value.load(std::memory_order_relaxed); }
 
 // A library-owned second stream for work that depends only on a call's INPUTS (the counting sorts of the segment reductions)
 // while the caller's stream runs the kernel that produces the data: fork_side makes it wait for everything enqueued on `st` so far,

@@ -428,6 +428,237 @@ __global__ __launch_bounds__(G::NW * 64) void pref_fwd_mc_kernel(McArgs a) {
   }
 }
 
+// ---- d = 256 (config 5's width), soft gate, large batches: FOUR waves share a 16-pair tile, 64 coordinates each ----------------
+// The kernel above keeps a whole 16 x 256 tile per wave: 48 row loads of 16 bytes in flight per lane and the q tile in registers are
+// 256 VGPRs + 42 AGPRs, its x tiles fill the LDS at four waves per CU -- ONE wave per SIMD, which gathers, then computes, then
+// gathers: on HBM-resident tables 0.59 ms per 716,800 pairs = 0.47 of the HBM peak where the pure gather of the same 1 KB rows
+// reaches 0.73-0.79 (profiles/r04_gather_footprint.txt).  Here a wave owns 64 coordinates of the tile (the split of
+// ktup_score_pref_bwd_wide.hip): 12 row loads per lane, all of them for the NEXT tile and in flight under the current tile's matrix
+// phases; 12 waves per CU (three tiles in flight, three waves per SIMD).  The price: the three contractions over d -- logits, s = q.n,
+// the distance -- are per-wave partials summed across the four waves through LDS (three workgroup barriers per tile, partials
+// always added in wave order).
+template <int NP_, bool HASE_>
+struct FwGeom {
+  static constexpr int NP = NP_;                           // groups of four preferences: P <= 4 NP, NP in {4, 5}
+  static constexpr bool HASE = HASE_;
+  static constexpr int NCH = 64, NWC = 4, NCW = 16;        // float4 chunks per row; waves per tile; chunks per wave
+  static constexpr int PITCHA4 = 4 * 16 + 1;               // the slot-ordered logit table of McGeom (odd float4 pitch)
+  static constexpr int XP = NCW + 1;                       // odd float4 pitch of a wave's x / q tile
+  static constexpr int TROW = 4 * NP, TPITCH = 16 * 16 + 16;
+  static constexpr int A0_F4 = 16 * PITCHA4;               // preferences 0..15 (slot i = preference 4 (i & 3) + (i >> 2))
+  static constexpr int A1_F4 = NP > 4 ? 5 * PITCHA4 : 0;   // preferences 16..19 = slots 0, 4, 8, 12 of the second tile, and a zero row
+  static constexpr int T_F = TROW * TPITCH;
+  static constexpr size_t TABLE_BYTES = (size_t)(A0_F4 + A1_F4) * 16 + (size_t)2 * T_F * 4;
+  static constexpr int NLG = NP > 4 ? 5 : 4;               // live logit registers per lane (the second tile's only live one is reg 0)
+  static constexpr size_t WAVE_BYTES = (size_t)16 * XP * 16 + 48 * 4;
+  static constexpr size_t GROUP_BYTES = NWC * WAVE_BYTES + (size_t)NWC * NLG * 64 * 4 + (size_t)2 * NWC * 16 * 4;
+  static constexpr int TG_FIT = (int)((160 * 1024 - TABLE_BYTES) / GROUP_BYTES);
+  static constexpr int TG = TG_FIT >= 3 ? 3 : TG_FIT;      // tile groups (of four waves) per workgroup: three -- with four (128 VGPRs per lane) the KTUP variants spill 13-24 registers
+};
+
+template <typename G, bool L1>
+__global__ __launch_bounds__(768) void pref_fwd_wide_kernel(McArgs a) {
+  constexpr int NP = G::NP, NCH = G::NCH, NWC = G::NWC, XP = G::XP, PITCHA4 = G::PITCHA4, TPITCH = G::TPITCH, NLG = G::NLG;
+  constexpr bool HASE = G::HASE;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  v4* A0S = reinterpret_cast<v4*>(smem);
+  v4* A1S = A0S + G::A0_F4;                                      // [4 live rows + 1 zero row][PITCHA4]
+  float* CnS = reinterpret_cast<float*>(A1S + G::A1_F4);         // [TROW][TPITCH]
+  float* ArS = CnS + G::T_F;
+  const int t = threadIdx.x, lane = t & 63, kq = lane >> 4, j = lane & 15;
+  const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int grp = wv >> 2, w = wv & 3;                           // tile group; coordinate slice [64 w, 64 w + 64)
+  const int nthr = blockDim.x, ngrp = nthr >> 8;
+  char* gbase = reinterpret_cast<char*>(ArS + G::T_F) + (size_t)grp * G::GROUP_BYTES;
+  v4* xt = reinterpret_cast<v4*>(gbase + (size_t)w * G::WAVE_BYTES);   // [16 pairs][XP]: this wave's 16 chunks of x, later of q
+  int32_t* sid = reinterpret_cast<int32_t*>(xt + 16 * XP);       // [3][16]: ids of the tile whose rows are fetched next
+  float* red = reinterpret_cast<float*>(gbase + NWC * G::WAVE_BYTES);  // [NWC][NLG][64] logit partials
+  float* sred = red + NWC * NLG * 64;                            // [NWC][16]  q . n partials
+  float* dred = sred + NWC * 16;                                 // [NWC][16]  distance partials
+  {
+    const int P = a.P, dp = a.dp;
+    const v4 zero = (v4){0.f, 0.f, 0.f, 0.f};
+    for (int idx = t; idx < G::A0_F4; idx += nthr) {
+      const int i = idx / PITCHA4, c = idx - i * PITCHA4;
+      const int p = 4 * (i & 3) + (i >> 2);
+      A0S[idx] = (p < P && c < NCH) ? *reinterpret_cast<const v4*>(a.Alog + p * dp + 4 * c) : zero;
+    }
+    for (int idx = t; idx < G::A1_F4; idx += nthr) {
+      const int r = idx / PITCHA4, c = idx - r * PITCHA4;
+      A1S[idx] = (r < 4 && 16 + r < P && c < NCH) ? *reinterpret_cast<const v4*>(a.Alog + (16 + r) * dp + 4 * c) : zero;
+    }
+    v4* Cn4 = reinterpret_cast<v4*>(CnS);
+    v4* Ar4 = reinterpret_cast<v4*>(ArS);
+    for (int idx = t; idx < G::T_F / 4; idx += nthr) {
+      const int p = idx / (TPITCH / 4), c = idx - p * (TPITCH / 4);
+      const bool ok = p < P && c < NCH;
+      Cn4[idx] = ok ? *reinterpret_cast<const v4*>(a.Cn + p * dp + 4 * c) : zero;
+      Ar4[idx] = ok ? *reinterpret_cast<const v4*>(a.Ar + p * dp + 4 * c) : zero;
+    }
+  }
+  __syncthreads();
+  const uint32_t gc = 16u * (uint32_t)w + (uint32_t)j;           // this lane's chunk of every row it fetches (rows kq, kq + 4, ..)
+  const v4* xb = xt + j * XP + kq;                               // MFMA operand view: chunk 4 g + kq of pair j
+  const v4* tab0 = A0S + j * PITCHA4 + kq + 16 * w;
+  const v4* tab1 = A1S + ((j & 3) == 0 ? (j >> 2) : 4) * PITCHA4 + kq + 16 * w;
+  const float* tn0 = CnS + kq * TPITCH + j + 64 * w;
+  const float* tr0 = ArS + kq * TPITCH + j + 64 * w;
+  const int64_t ntiles = (a.n + 15) / 16;
+  const int64_t tstride = (int64_t)gridDim.x * ngrp;
+  const int64_t tfirst = (int64_t)blockIdx.x * ngrp;             // < ntiles (grid sizing)
+  const int niter = (int)((ntiles - tfirst + tstride - 1) / tstride);   // the same for every wave of the workgroup (barriers)
+  int32_t nx_u = 0, nx_i = 0, nx_e = 0;
+  auto fetch_ids = [&](int64_t tile) {
+    nx_u = 0; nx_i = 0; nx_e = 0;
+    if (lane < 16 && tile < ntiles) {
+      const int64_t row = tile * 16 + lane;
+      const bool ok = row < a.n;
+      const int64_t uid = ok ? a.u_ids[row] : 0, iid = ok ? a.i_ids[row] : 0;
+      nx_u = (int32_t)uid; nx_i = (int32_t)iid;
+      nx_e = HASE ? a.item2ent[iid] : 0;
+    }
+  };
+  v4 uu[4], vv[4], ee[4];
+  auto issue_rows = [&]() {
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const int row = kq + 4 * jj;
+      const uint32_t idu = (uint32_t)sid[row], idi = (uint32_t)sid[16 + row];
+      const v4* pu = a.U + ((uint64_t)idu * a.ldu4 + gc);
+      const v4* pv = a.I + ((uint64_t)idi * a.ldi4 + gc);
+      uu[jj] = a.nt ? __builtin_nontemporal_load(pu) : *pu;
+      vv[jj] = a.nt ? __builtin_nontemporal_load(pv) : *pv;
+      if (HASE) {
+        const uint32_t ide = (uint32_t)sid[32 + row];
+        const v4* pe = a.E + ((uint64_t)ide * a.lde4 + gc);
+        ee[jj] = a.nt ? __builtin_nontemporal_load(pe) : *pe;
+      }
+    }
+  };
+  // ---- prologue: ids and rows of the first tile, ids of the second
+  fetch_ids(tfirst + grp);
+  if (lane < 16) { sid[lane] = nx_u; sid[16 + lane] = nx_i; sid[32 + lane] = nx_e; }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  if (tfirst + grp < ntiles) issue_rows();
+  fetch_ids(tfirst + grp + tstride);
+  for (int it = 0; it < niter; ++it) {
+    const int64_t tile_id = tfirst + grp + (int64_t)it * tstride;
+    const bool live = tile_id < ntiles;                          // wave-uniform
+    v4 q[4];
+    v4 lg0 = (v4){0.f, 0.f, 0.f, 0.f}, lg1 = lg0;
+    if (live) {
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const v4 ve = HASE ? vv[jj] + ee[jj] : vv[jj];
+        xt[(kq + 4 * jj) * XP + j] = uu[jj] + ve;
+        q[jj] = uu[jj] + (-ve);
+      }
+    }
+    if (lane < 16) { sid[lane] = nx_u; sid[16 + lane] = nx_i; sid[32 + lane] = nx_e; }   // (the rows of THIS tile were addressed before)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // ---- the next tile's rows travel under this tile's phases, the ids of the tile after it too
+    if (tile_id + tstride < ntiles) issue_rows();
+    fetch_ids(tile_id + 2 * tstride);
+    if (live) {
+      // ---- stage 1: this wave's 64 coordinates of logits^T (layout of the kernel above: lg[reg] of lane (kq, pair j) = preference 4 reg + kq)
+#pragma unroll
+      for (int gk = 0; gk < 4; ++gk) {
+        const v4 bv = xb[4 * gk];
+        const v4 av0 = tab0[4 * gk];
+        v4 av1 = (v4){0.f, 0.f, 0.f, 0.f};
+        if (NP > 4) av1 = tab1[4 * gk];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          lg0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av0[c], bv[c], lg0, 0, 0, 0);
+          if (NP > 4) lg1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av1[c], bv[c], lg1, 0, 0, 0);
+        }
+      }
+      float* rw = red + w * NLG * 64 + lane;
+      rw[0] = lg0[0]; rw[64] = lg0[1]; rw[128] = lg0[2]; rw[192] = lg0[3];
+      if (NP > 4) rw[256] = lg1[0];
+      // ---- q overwrites x (this wave's own slice: its stage-1 reads are behind it)
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) xt[(kq + 4 * jj) * XP + j] = q[jj];
+    }
+    __syncthreads();
+    v4 accN[4];
+    float lgs[NLG];
+    if (live) {
+#pragma unroll
+      for (int k = 0; k < NLG; ++k) {
+        const float* r0 = red + k * 64 + lane;
+        lgs[k] = (r0[0] + r0[NLG * 64]) + (r0[2 * NLG * 64] + r0[3 * NLG * 64]);
+      }
+      // ---- stage 2a: n^T for this wave's coordinates, s partial
+      v4 sacc = (v4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) {
+        accN[ct] = (v4){0.f, 0.f, 0.f, 0.f};
+        float ta[NP];
+#pragma unroll
+        for (int m = 0; m < NP; ++m) ta[m] = tn0[(16 * (m >> 2) + 4 * (m & 3)) * TPITCH + 16 * ct];
+#pragma unroll
+        for (int m = 0; m < NP; ++m) accN[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(ta[m], lgs[m], accN[ct], 0, 0, 0);
+        sacc += xb[4 * ct] * accN[ct];
+      }
+      const float sp = allsum_kq((sacc[0] + sacc[1]) + (sacc[2] + sacc[3]));
+      if (kq == 0) sred[w * 16 + j] = sp;
+    }
+    __syncthreads();
+    if (live) {
+      const float sfull = (sred[j] + sred[16 + j]) + (sred[32 + j] + sred[48 + j]);
+      const v4 ms = (v4){-sfull, -sfull, -sfull, -sfull};
+      v4 dacc = (v4){0.f, 0.f, 0.f, 0.f};
+      // ---- stage 2b: r^T tiles and the distance
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) {
+        float ta[NP];
+#pragma unroll
+        for (int m = 0; m < NP; ++m) ta[m] = tr0[(16 * (m >> 2) + 4 * (m & 3)) * TPITCH + 16 * ct];
+        v4 accR = xb[4 * ct];                                     // q + r: start the accumulator at q
+#pragma unroll
+        for (int m = 0; m < NP; ++m) accR = __builtin_amdgcn_mfma_f32_16x16x4f32(ta[m], lgs[m], accR, 0, 0, 0);
+        const v4 tv = __builtin_elementwise_fma(ms, accN[ct], accR);
+        if (L1) dacc += __builtin_elementwise_abs(tv);
+        else dacc = __builtin_elementwise_fma(tv, tv, dacc);
+      }
+      const float dp_ = allsum_kq((dacc[0] + dacc[1]) + (dacc[2] + dacc[3]));
+      if (kq == 0) dred[w * 16 + j] = dp_;
+    }
+    __syncthreads();
+    if (live && w == 0 && kq == 0) {
+      const int64_t row0 = tile_id * 16;
+      if (row0 + j < a.n) (a.score + row0)[j] = (dred[j] + dred[16 + j]) + (dred[32 + j] + dred[48 + j]);
+    }
+  }
+}
+
+template <typename G, bool L1>
+int launch_fwd_wide_l(const McArgs& a, hipStream_t st, const char* name) {
+  static_assert(G::TG >= 1, "LDS budget");
+  const int64_t ntiles = (a.n + 15) / 16;
+  int tg = ntiles >= 256 * 3 ? 3 : ntiles >= 256 * 2 ? 2 : 1;
+  if (tg > G::TG) tg = G::TG;
+  const size_t lds = G::TABLE_BYTES + (size_t)tg * G::GROUP_BYTES;
+  (void)hipFuncSetAttribute((const void*)pref_fwd_wide_kernel<G, L1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(G::TABLE_BYTES + (size_t)G::TG * G::GROUP_BYTES));
+  const int grid = grid_for((ntiles + tg - 1) / tg, 256);
+  hipLaunchKernelGGL((pref_fwd_wide_kernel<G, L1>), dim3(grid), dim3(tg * 256), lds, st, a);
+  return check_launch(name);
+}
+
+int launch_fwd_wide(const McArgs& a, int np, hipStream_t st, const char* name) {
+#define KTUP_FW(NPV)                                                                                                  \
+  {                                                                                                                   \
+    if (a.E) return a.l1 ? launch_fwd_wide_l<FwGeom<NPV, true>, true>(a, st, name) : launch_fwd_wide_l<FwGeom<NPV, true>, false>(a, st, name);    \
+    return a.l1 ? launch_fwd_wide_l<FwGeom<NPV, false>, true>(a, st, name) : launch_fwd_wide_l<FwGeom<NPV, false>, false>(a, st, name);           \
+  }
+  if (np <= 4) KTUP_FW(4)
+  KTUP_FW(5)
+#undef KTUP_FW
+}
+
 template <typename G, bool L1>
 int launch_mc_l(const McArgs& a, hipStream_t st, const char* name) {
   static_assert(G::NW >= 2, "LDS budget");
@@ -492,7 +723,11 @@ int pref_fwd_mc(const float* U, int64_t ldu, const float* I, int64_t ldi, const 
   const int np = (n_pref + 3) / 4;
   if (d == 64) return launch_mc_np<16>(a, np, st, name);
   if (d == 100) return launch_mc_np<25>(a, np, st, name);
-  if (d == 256) return launch_mc_np<64>(a, np, st, name);     // config 5: 4 waves per CU (the x tiles fill the LDS)
+  if (d == 256) {
+    // soft gate, P <= 20, more than a chip-load of tiles: the coordinate-split kernel (option fwd_wide); else 4 waves per CU, a tile each
+    if (gumbel_mode == KTUP_GUMBEL_OFF && np <= 5 && n >= 16 * 256 && opt_fwd_wide()) return launch_fwd_wide(a, np, st, name);
+    return launch_mc_np<64>(a, np, st, name);
+  }
   return launch_mc_np<32>(a, np, st, name);
 }
 

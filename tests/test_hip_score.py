@@ -345,3 +345,30 @@ def test_philox_stream_position_in_device_memory(d, P):
     a = o.score_tup(D['U'], D['I'], D['P'], D['Pn'], u, i, False, o.GUMBEL_PHILOX_DEV, state)
     b = o.score_tup(D['U'], D['I'], D['P'], D['Pn'], u, i, False, o.GUMBEL_PHILOX, None, seed, off + n * P)
     assert torch.equal(a, b) and not torch.equal(a, outs[0][0])
+
+
+@pytest.mark.parametrize('npref', [20, 13, 7])
+@pytest.mark.parametrize('n', [4096, 16 * 256 * 3 + 5, 20011])
+def test_wide_forward_d256_vs_oracle(n, npref):
+    """d = 256 with 4096 pairs or more: the coordinate-split forward (pref_fwd_wide_kernel: four waves share a 16-pair tile, the three
+    contractions over d summed across them through LDS) against the oracle -- KTUP and TUP, both distances, one / two / three tile
+    groups per workgroup, a ragged last tile, P on and off a four-preference group -- and against the one-wave-per-tile kernel
+    (option fwd_wide = 0) on the same inputs."""
+    from jTransUP.hip import lib as L
+    nu, ni, ne, d = 700, 400, 900, 256
+    W, i2e, gen = rand_world(11 + npref, nu, ni, ne, npref, d)
+    u = torch.randint(0, nu, (n,), generator=gen); i = torch.randint(0, ni, (n,), generator=gen)
+    D = {k: v.to(DEV) for k, v in W.items()}
+    for l1 in (False, True):
+        want_k = O.score_ktup_rec(W['U'], W['I'], W['E'], W['P'], W['Pn'], W['R'], W['Rn'], i2e, u, i, l1)
+        want_t = O.score_tup(W['U'], W['I'], W['P'], W['Pn'], u, i, l1)
+        got = {}
+        for wide in (1, 0):
+            old = L.set_option('fwd_wide', wide)
+            try:
+                got[wide] = (ops().score_ktup(D['U'], D['I'], D['E'], D['P'], D['Pn'], D['R'], D['Rn'], i2e.to(DEV, torch.int32), u.to(DEV), i.to(DEV), l1).cpu(),
+                             ops().score_tup(D['U'], D['I'], D['P'], D['Pn'], u.to(DEV), i.to(DEV), l1).cpu())
+            finally:
+                L.set_option('fwd_wide', old)
+            close(got[wide][0], want_k); close(got[wide][1], want_t)
+        close(got[1][0], got[0][0], rtol=2e-5, atol=2e-6); close(got[1][1], got[0][1], rtol=2e-5, atol=2e-6)

@@ -787,7 +787,7 @@ def gather_stress_bench(device, scale=1000, reps=20, only_rec=False):
     ms = sorted(a.elapsed_time(b) for a, b in ev)[reps // 2]
     out['ktup_rec_forward_d256'] = {'ms_per_launch': ms, 'rows_per_launch': REC_ROWS, 'bytes_per_row': bpr2, 'tables_GB': (nu + ni + ne) * d2 * 4 / 1e9,
                                     'achieved_GBs': REC_ROWS * bpr2 / (ms * 1e-3) / 1e9, 'frac_of_hbm_peak': REC_ROWS * bpr2 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                    'kernel': 'pref_fwd_mc_kernel<McGeom<64,5,true,false>,false> (K6 at config 5 width; 1 KB line-aligned rows)'}
+                                    'kernel': 'pref_fwd_wide_kernel<FwGeom<5,true>,false> (K6 at config 5 width; 1 KB line-aligned rows; four waves per 16-pair tile, three tiles per CU)'}
     return out
 
 

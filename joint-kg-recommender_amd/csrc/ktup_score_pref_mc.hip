@@ -446,7 +446,8 @@ struct FwGeom {
   static constexpr int XP = NCW + 1;                       // odd float4 pitch of a wave's x / q tile
   static constexpr int TROW = 4 * NP, TPITCH = 16 * 16 + 16;
   static constexpr int A0_F4 = 16 * PITCHA4;               // preferences 0..15 (slot i = preference 4 (i & 3) + (i >> 2))
-  static constexpr int A1_F4 = NP > 4 ? 5 * PITCHA4 : 0;   // preferences 16..19 = slots 0, 4, 8, 12 of the second tile, and a zero row
+  static constexpr int A1_F4 = NP > 4 ? 4 * PITCHA4 : 0;   // preferences 16..19, row-major: their logits come from 4x4x1 blocks (a 16x16x4 tile
+                                                           // would be fifteen sixteenths padding: 512 of a wave's 2,300 matrix clocks per tile)
   static constexpr int T_F = TROW * TPITCH;
   static constexpr size_t TABLE_BYTES = (size_t)(A0_F4 + A1_F4) * 16 + (size_t)2 * T_F * 4;
   static constexpr int NLG = NP > 4 ? 5 : 4;               // live logit registers per lane (the second tile's only live one is reg 0)
@@ -462,7 +463,7 @@ __global__ __launch_bounds__(768) void pref_fwd_wide_kernel(McArgs a) {
   constexpr bool HASE = G::HASE;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   v4* A0S = reinterpret_cast<v4*>(smem);
-  v4* A1S = A0S + G::A0_F4;                                      // [4 live rows + 1 zero row][PITCHA4]
+  v4* A1S = A0S + G::A0_F4;                                      // [4][PITCHA4]
   float* CnS = reinterpret_cast<float*>(A1S + G::A1_F4);         // [TROW][TPITCH]
   float* ArS = CnS + G::T_F;
   const int t = threadIdx.x, lane = t & 63, kq = lane >> 4, j = lane & 15;
@@ -485,7 +486,7 @@ __global__ __launch_bounds__(768) void pref_fwd_wide_kernel(McArgs a) {
     }
     for (int idx = t; idx < G::A1_F4; idx += nthr) {
       const int r = idx / PITCHA4, c = idx - r * PITCHA4;
-      A1S[idx] = (r < 4 && 16 + r < P && c < NCH) ? *reinterpret_cast<const v4*>(a.Alog + (16 + r) * dp + 4 * c) : zero;
+      A1S[idx] = (16 + r < P && c < NCH) ? *reinterpret_cast<const v4*>(a.Alog + (16 + r) * dp + 4 * c) : zero;
     }
     v4* Cn4 = reinterpret_cast<v4*>(CnS);
     v4* Ar4 = reinterpret_cast<v4*>(ArS);
@@ -500,7 +501,10 @@ __global__ __launch_bounds__(768) void pref_fwd_wide_kernel(McArgs a) {
   const uint32_t gc = 16u * (uint32_t)w + (uint32_t)j;           // this lane's chunk of every row it fetches (rows kq, kq + 4, ..)
   const v4* xb = xt + j * XP + kq;                               // MFMA operand view: chunk 4 g + kq of pair j
   const v4* tab0 = A0S + j * PITCHA4 + kq + 16 * w;
-  const v4* tab1 = A1S + ((j & 3) == 0 ? (j >> 2) : 4) * PITCHA4 + kq + 16 * w;
+  // preferences 16..19 on v_mfma_f32_4x4x1 (16 blocks): block (quarter kq of this wave's coordinates, pair group) -- lane (kq, pair j)
+  // supplies A = preference 16 + (j & 3) and B = pair j at chunks 4 kq .. 4 kq + 3 of the slice
+  const v4* tab1 = A1S + (j & 3) * PITCHA4 + 4 * kq + 16 * w;
+  const v4* xb4 = xt + j * XP + 4 * kq;
   const float* tn0 = CnS + kq * TPITCH + j + 64 * w;
   const float* tr0 = ArS + kq * TPITCH + j + 64 * w;
   const int64_t ntiles = (a.n + 15) / 16;
@@ -546,7 +550,7 @@ __global__ __launch_bounds__(768) void pref_fwd_wide_kernel(McArgs a) {
     const int64_t tile_id = tfirst + grp + (int64_t)it * tstride;
     const bool live = tile_id < ntiles;                          // wave-uniform
     v4 q[4];
-    v4 lg0 = (v4){0.f, 0.f, 0.f, 0.f}, lg1 = lg0;
+    v4 lg0 = (v4){0.f, 0.f, 0.f, 0.f};
     if (live) {
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) {
@@ -567,22 +571,35 @@ __global__ __launch_bounds__(768) void pref_fwd_wide_kernel(McArgs a) {
       for (int gk = 0; gk < 4; ++gk) {
         const v4 bv = xb[4 * gk];
         const v4 av0 = tab0[4 * gk];
-        v4 av1 = (v4){0.f, 0.f, 0.f, 0.f};
-        if (NP > 4) av1 = tab1[4 * gk];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          lg0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av0[c], bv[c], lg0, 0, 0, 0);
-          if (NP > 4) lg1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av1[c], bv[c], lg1, 0, 0, 0);
-        }
+        for (int c = 0; c < 4; ++c) lg0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av0[c], bv[c], lg0, 0, 0, 0);
       }
       float* rw = red + w * NLG * 64 + lane;
       rw[0] = lg0[0]; rw[64] = lg0[1]; rw[128] = lg0[2]; rw[192] = lg0[3];
-      if (NP > 4) rw[256] = lg1[0];
+      if (NP > 4) {
+        v4 acc = (v4){0.f, 0.f, 0.f, 0.f}, acc1 = acc;               // two chains: a 4x4x1 result is not ready for the next issue slot
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          const v4 av = tab1[kk], bv = xb4[kk];
+          acc = __builtin_amdgcn_mfma_f32_4x4x1f32(av[0], bv[0], acc, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(av[1], bv[1], acc1, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_4x4x1f32(av[2], bv[2], acc, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(av[3], bv[3], acc1, 0, 0, 0);
+        }
+        acc += acc1;
+        rw[256] = scatter_kq(acc);                                  // lane (kq, pair j): preference 16 + kq, summed over the four quarters
+      }
       // ---- q overwrites x (this wave's own slice: its stage-1 reads are behind it)
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) xt[(kq + 4 * jj) * XP + j] = q[jj];
     }
     __syncthreads();
+    // the PREVIOUS tile's score: its distance partials were written before this barrier and are rewritten after the next one (a third
+    // barrier per tile only for this store cost 2-3 % of the kernel)
+    if (it > 0 && w == 0 && kq == 0) {
+      const int64_t row0 = (tile_id - tstride) * 16;
+      if (row0 + j < a.n) (a.score + row0)[j] = (dred[j] + dred[16 + j]) + (dred[32 + j] + dred[48 + j]);
+    }
     v4 accN[4];
     float lgs[NLG];
     if (live) {
@@ -627,11 +644,11 @@ __global__ __launch_bounds__(768) void pref_fwd_wide_kernel(McArgs a) {
       const float dp_ = allsum_kq((dacc[0] + dacc[1]) + (dacc[2] + dacc[3]));
       if (kq == 0) dred[w * 16 + j] = dp_;
     }
-    __syncthreads();
-    if (live && w == 0 && kq == 0) {
-      const int64_t row0 = tile_id * 16;
-      if (row0 + j < a.n) (a.score + row0)[j] = (dred[j] + dred[16 + j]) + (dred[32 + j] + dred[48 + j]);
-    }
+  }
+  __syncthreads();
+  if (w == 0 && kq == 0) {                                       // the last tile's score
+    const int64_t row0 = (tfirst + grp + (int64_t)(niter - 1) * tstride) * 16;
+    if (row0 + j < a.n) (a.score + row0)[j] = (dred[j] + dred[16 + j]) + (dred[32 + j] + dred[48 + j]);
   }
 }
 
@@ -641,6 +658,7 @@ int launch_fwd_wide_l(const McArgs& a, hipStream_t st, const char* name) {
   const int64_t ntiles = (a.n + 15) / 16;
   int tg = ntiles >= 256 * 3 ? 3 : ntiles >= 256 * 2 ? 2 : 1;
   if (tg > G::TG) tg = G::TG;
+  if (opt_fwd_wide() >= 2 && opt_fwd_wide() < tg) tg = opt_fwd_wide();      // (A/B: option fwd_wide = 2: two tile groups per workgroup)
   const size_t lds = G::TABLE_BYTES + (size_t)tg * G::GROUP_BYTES;
   (void)hipFuncSetAttribute((const void*)pref_fwd_wide_kernel<G, L1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(G::TABLE_BYTES + (size_t)G::TG * G::GROUP_BYTES));
   const int grid = grid_for((ntiles + tg - 1) / tg, 256);

@@ -17,7 +17,7 @@ from jTransUP.hip import ops
 
 dev = torch.device('cuda')
 gen = torch.Generator(device=dev); gen.manual_seed(3)
-d2, sc2, reps = 256, 400, 20
+d2, sc2, reps = 256, 400, 40
 nu, ni, ne = B.NU * sc2, B.NI * sc2, B.NE * sc2
 mk2 = lambda rows: torch.randn(rows, d2, generator=gen, device=dev).mul_(1.0 / 16.0)
 U, I, E = mk2(nu), mk2(ni), mk2(ne + 1)
@@ -33,7 +33,7 @@ for l1 in (0, 1):
         L.set_option('nt_gather', nt)
         rec2 = L.bind('ktup_score_ktup_fwd', U.data_ptr(), U.stride(0), I.data_ptr(), I.stride(0), E.data_ptr(), E.stride(0), i2e.data_ptr(),
                       ws2.data_ptr(), B.NR, d2, u.data_ptr(), i.data_ptr(), B.REC_ROWS, l1, ops.GUMBEL_OFF, None, 0, 0, s_rec.data_ptr(), st)
-        for _ in range(3):
+        for _ in range(25):
             rec2()
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
         torch.cuda.synchronize(dev)

@@ -472,12 +472,27 @@ int ktup_shard_ktup_entries(const int64_t* u, const int64_t* pos_items, const in
                             const int32_t* item2ent, int64_t ent_pad, int64_t* entries, void* stream);
 int ktup_shard_pack_wire(int n_tables, float* const* tables, const int64_t* ld, const int64_t* cap, int d, const int64_t* ids,
                          int64_t n_blocks, float* out, int64_t ldo, void* stream);
+/* Row-sparse ADAM (kind = KTUP_OPT_ADAM in ktup_shard_apply / ktup_shard_reduce_apply) that equals the reference's DENSE Adam
+ * (utils/trainer.py:63-66: torch.optim.Adam over whole tables, weight_decay = l2_lambda = 0; the configuration of the published
+ * recipe, ktup.sh:1): a dense Adam step moves every row that ever had a gradient -- m <- beta1 m, v <- beta2 v,
+ * p <- p - lr / (1 - beta1^s) m / (sqrt(v) / sqrt(1 - beta2^s) + eps) -- whether the batch touches it or not.  A state row is
+ * [m (d) | v (d) | last (int32) | 3 words of padding], KTUP_SHARD_ADAM_STATE_PITCH(d) floats; `last` = the step the row's state was
+ * written at (0: never).  Touching a row at step t first REPLAYS the zero-gradient steps last + 1 .. t - 1 in registers (the dense
+ * recurrence, step by step; after `replay` steps, when the increments have fallen below ~1e-6 of the first, only m and v keep
+ * decaying in closed form), then applies step t.  *step = the number of the step being applied: ktup_shard_step_count moves it
+ * (+1 unless the step is skipped) as the launch before the apply launch.  ktup_shard_adam_flush replays every row of a shard up to
+ * *step (before an evaluation or a checkpoint reads the table).                                                               */
+typedef struct ktup_adam_t { float beta1, beta2; int32_t replay; int32_t reserved; const int64_t* step; } ktup_adam_t;
+#define KTUP_SHARD_ADAM_STATE_PITCH(d) (2 * (d) + 4)
+int ktup_shard_step_count(int64_t* step, const int32_t* skip_count, const double* skip_value, void* stream);
+int ktup_shard_adam_flush(float* table, int64_t ldt, float* state, int64_t lds, int d, int64_t n_rows, float lr, float eps,
+                          const ktup_adam_t* adam_rule, void* stream);
 int ktup_shard_apply(int kind, int n_tables, float* const* tables, const int64_t* ld, float* const* states, const int64_t* lds,
                      const int64_t* cap, int d, const int64_t* ids, int64_t n_blocks, float* grads, int64_t ldg, int n_small,
                      int small_rows, float* const* small_grads, float* const* small_p0, float* const* small_s0,
                      float* const* small_p1, float* const* small_s1, const double* small_g64, float lr, float eps,
                      const double* sumsq, int sumsq_slots, float max_norm, const int32_t* skip_count, const double* skip_value,
-                     float* loss_step, int n_loss, float* loss_sum, int32_t* skipped_steps, void* stream);
+                     float* loss_step, int n_loss, float* loss_sum, int32_t* skipped_steps, const ktup_adam_t* adam_rule, void* stream);
 int ktup_shard_bucket(int mode, int n_small, float* const* small_grads, int64_t small_elems, double* bucket,
                       const double* sumsq_local, int sumsq_slots, const int32_t* overflow, double* sumsq_total, double small_weight,
                       void* stream);
@@ -509,7 +524,8 @@ int ktup_shard_reduce_apply(int kind, int n_tables, float* const* tables, const 
                             float* const* small_grads, float* const* small_p0, float* const* small_s0, float* const* small_p1,
                             float* const* small_s1, const double* small_g64, float lr, float eps, const double* sumsq,
                             int sumsq_slots, float max_norm, const int32_t* skip_count, const double* skip_value,
-                            float* loss_step, int n_loss, float* loss_sum, int32_t* skipped_steps, void* stream);
+                            float* loss_step, int n_loss, float* loss_sum, int32_t* skipped_steps, const ktup_adam_t* adam_rule,
+                            void* stream);
 
 /* ------------------------------------------- K19  negative sampling on the device  utils/data.py:12-85
  * rec: one uniform negative item per (u, positive): != positive, bit not set in the user's row of

@@ -312,6 +312,86 @@ KTUP_DEV void vfrom(float4& o, const double* p) { o = make_float4((float)p[0], (
 constexpr int MAXS = KTUP_SHARD_MAX_SMALL;
 constexpr int NSLOT = KTUP_SHARD_SUMSQ_SLOTS;
 
+// ---- row-sparse ADAM that equals the reference's DENSE Adam (utils/trainer.py:63-66: torch.optim.Adam over every table, l2_lambda = 0)
+// A dense Adam step moves EVERY row that has ever received a gradient -- a row the batch does not touch still takes
+//     m <- beta1 m,  v <- beta2 v,  p <- p - lr / (1 - beta1^s) * m / (sqrt(v) / sqrt(1 - beta2^s) + eps)
+// at every step s.  A row's state is kept as [m (d) | v (d) | last (int32) + 3 words of padding] (KTUP_SHARD_ADAM_STATE_PITCH(d) floats);
+// `last` = the step its state was written at (0: never touched: m = v = 0 and the row has not moved).  Whoever touches a row at step t
+// first REPLAYS the zero-gradient steps last + 1 .. t - 1 in registers -- exactly the dense recurrence, one step after the other --
+// then applies step t.  The replayed increments fall like (beta1 / sqrt(beta2))^k, so the replay stops after `replay` steps (the host
+// picks it so that what is dropped is below 1e-6 of the first increment, i.e. < 1e-7 absolute at the learning rates in use) and the
+// remaining steps only decay m and v (closed form).  ktup_shard_adam_flush brings every row of a shard up to the current step (before an
+// evaluation or a checkpoint reads the tables).
+struct AdamRule {
+  float b1, b2; int replay; const int64_t* step;       // *step = number of the step being applied (>= 1; ktup_shard_step_count moves it)
+};
+
+KTUP_DEV void adam_zero_steps(float4& p, float4& m, float4& v, float c1, float inv_bc2s, float eps, float b1, float b2) {
+#define KTUP_AZ(c)                                                                            \
+  m.c = fmaf(-m.c, 1.f - b1, m.c); v.c = b2 * v.c;                                            \
+  p.c = fmaf(-c1 * m.c, __builtin_amdgcn_rcpf(fmaf(__builtin_amdgcn_sqrtf(v.c), inv_bc2s, eps)), p.c);
+  KTUP_AZ(x) KTUP_AZ(y) KTUP_AZ(z) KTUP_AZ(w)
+#undef KTUP_AZ
+}
+KTUP_DEV void adam_step1(float& p, float& m, float& v, float g, float c1, float bc2s, float eps, float b1, float b2) {
+  m = m + (g - m) * (1.f - b1);                      // exp_avg.lerp_(grad, 1 - beta1)          (adam.py _single_tensor_adam, as ktup_optim.hip)
+  v = fmaf(1.f - b2, g * g, b2 * v);
+  p = p - c1 * (m / (sqrtf(v) / bc2s + eps));
+}
+// One row's CPL float4 chunks per lane: replay the zero-gradient steps last + 1 .. upto, then (has_g) step t = upto + 1 with gradient g.
+template <int CPL>
+KTUP_DEV void adam_row(float4 (&p)[CPL], float4 (&m)[CPL], float4 (&v)[CPL], const float4 (&g)[CPL], bool has_g, int upto, int last,
+                       float lr, float eps, const AdamRule& r) {
+  const int miss = upto - last;
+  if (last > 0 && miss > 0) {
+    const int K = miss < r.replay ? miss : r.replay;
+    double b1p = pow((double)r.b1, (double)last), b2p = pow((double)r.b2, (double)last);
+    for (int k = 0; k < K; ++k) {
+      b1p *= (double)r.b1; b2p *= (double)r.b2;
+      const float c1 = lr * __builtin_amdgcn_rcpf((float)(1.0 - b1p));
+      const float ib = __builtin_amdgcn_rsqf((float)(1.0 - b2p));
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) adam_zero_steps(p[j], m[j], v[j], c1, ib, eps, r.b1, r.b2);
+    }
+    if (miss > K) {
+      const float f1 = (float)pow((double)r.b1, (double)(miss - K)), f2 = (float)pow((double)r.b2, (double)(miss - K));
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) { m[j] = f1 * m[j]; v[j] = f2 * v[j]; }
+    }
+  }
+  if (has_g) {
+    const double t = (double)(upto + 1);
+    const float c1 = lr / (float)(1.0 - pow((double)r.b1, t)), bc2s = (float)sqrt(1.0 - pow((double)r.b2, t));
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+      adam_step1(p[j].x, m[j].x, v[j].x, g[j].x, c1, bc2s, eps, r.b1, r.b2); adam_step1(p[j].y, m[j].y, v[j].y, g[j].y, c1, bc2s, eps, r.b1, r.b2);
+      adam_step1(p[j].z, m[j].z, v[j].z, g[j].z, c1, bc2s, eps, r.b1, r.b2); adam_step1(p[j].w, m[j].w, v[j].w, g[j].w, c1, bc2s, eps, r.b1, r.b2);
+    }
+  }
+}
+// the same on a row in memory: lane `lane` of a group of GL owns chunks lane, lane + GL, ...; srow = [m | v | last]
+template <int GL, int CPL>
+KTUP_DEV void adam_row_mem(float4* prow, float4* srow, int nch, int lane, const float4 (&g)[CPL], bool has_g, int t, float lr, float eps,
+                           const AdamRule& r) {
+  int32_t* lastp = reinterpret_cast<int32_t*>(srow + 2 * nch);
+  const int last = *lastp;
+  const int upto = has_g ? t - 1 : t;
+  if (!has_g && (last <= 0 || last >= t)) return;
+  float4 p[CPL], m[CPL], v[CPL];
+#pragma unroll
+  for (int j = 0; j < CPL; ++j) {
+    const int ch = lane + j * GL;
+    if (ch < nch) { p[j] = prow[ch]; m[j] = srow[ch]; v[j] = srow[nch + ch]; } else { p[j] = f4zero(); m[j] = f4zero(); v[j] = f4zero(); }
+  }
+  adam_row<CPL>(p, m, v, g, has_g, upto, last, lr, eps, r);
+#pragma unroll
+  for (int j = 0; j < CPL; ++j) {
+    const int ch = lane + j * GL;
+    if (ch < nch) { prow[ch] = p[j]; srow[ch] = m[j]; srow[nch + ch] = v[j]; }
+  }
+  if (lane == 0) *lastp = t;
+}
+
 // min(1, max_norm / (||g|| + 1e-6)) with ||g||^2 spread over 1 or NSLOT accumulator words (independent loads, one latency)
 KTUP_DEV float clip_coef(float max_norm, const double* __restrict__ sumsq, int slots) {
   if (!(max_norm > 0.f)) return 1.f;
@@ -335,12 +415,24 @@ struct ApplyRows {
   const double* small_g64;     // non-null: the all-reduced small gradients (fp64 bucket, entries in sg order) replace sg's values
   int d;
   float lr, eps, max_norm; const double* sumsq; int sumsq_slots; const int32_t* skip_i; const double* skip_d; bool adagrad;
+  bool adam; AdamRule ar; int64_t small_lds;       // adam: `adagrad` is set too (= the rows have a state); small_lds: pitch of the small tables' states
   const int32_t* xkeys;        // non-null: rows [0, W) are LIST entries -- the wire row is xkeys[row], taken at its first occurrence only
   // end of step (may be null): loss_sum[k] += loss_step[k] unless the step is skipped, loss_step := 0; *skipped += 1 if it is
   float* loss_step; int n_loss; float* loss_sum; int32_t* skipped;
 
+  template <int G, int CPL>
+  KTUP_DEV void one_adam(const RowCtx<float4, G, CPL>& cx, float* prow, float* srow, const float4 (&gr)[CPL], float coef) const {
+    float4 g[CPL];
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) g[j] = coef * gr[j];
+    adam_row_mem<G, CPL>(reinterpret_cast<float4*>(prow), reinterpret_cast<float4*>(srow), cx.nch, cx.lane, g, true, (int)*ar.step, lr, eps, ar);
+  }
+  template <int G, int CPL>
+  KTUP_DEV void one_adam(const RowCtx<float, G, CPL>&, float*, float*, const float (&)[CPL], float) const {}   // (refused on the host: Adam rows are float4)
+
   template <typename V, int G, int CPL>
   KTUP_DEV void one(const RowCtx<V, G, CPL>& cx, float* prow, float* srow, const V (&gr)[CPL], float coef) const {
+    if (adam) { one_adam<G, CPL>(cx, prow, srow, gr, coef); return; }
     V p[CPL], st[CPL];
     cx.load(p, prow);
     if (adagrad) cx.load(st, srow);
@@ -409,8 +501,8 @@ struct ApplyRows {
       } else {
         cx.load(gr, grow);
       }
-      one(cx, sp0[k] + sr * d, adagrad ? ss0[k] + sr * d : nullptr, gr, coef);
-      if (sp1[k]) one(cx, sp1[k] + sr * d, adagrad ? ss1[k] + sr * d : nullptr, gr, coef);
+      one(cx, sp0[k] + sr * d, adagrad ? ss0[k] + sr * small_lds : nullptr, gr, coef);
+      if (sp1[k]) one(cx, sp1[k] + sr * d, adagrad ? ss1[k] + sr * small_lds : nullptr, gr, coef);
     }
     V* go = reinterpret_cast<V*>(grow);
 #pragma unroll
@@ -439,6 +531,7 @@ struct FusedArgs {
   bool dup_only;                                    // MODE 0: the step kernel has already added |G row|^2 for every entry: add only what rows SHARED
                                                     // by several entries change, |sum|^2 - sum |.|^2 -- an entry alone on its row is not even read
   WireTables w; const int64_t* ids; float lr, eps, max_norm; bool adagrad; const int32_t* skip_i; const double* skip_d;
+  bool adam; AdamRule ar;
 };
 
 // What the norm walk's EXTRA workgroups add (blocks [walk_grid, gridDim.x) of its launch): the small replicated gradients' squares,
@@ -520,6 +613,13 @@ __global__ __launch_bounds__(256) void seg_fused_kernel(FusedArgs a, ApplyRows o
     const int t = wire_table(a.w, key);
     float4* prow = reinterpret_cast<float4*>(a.w.tab[t] + id * a.w.ldt[t]);
     float4* srow = a.adagrad ? reinterpret_cast<float4*>(a.w.st[t] + id * a.w.lds[t]) : nullptr;
+    if (a.adam) {
+      float4 g[CPL];
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) g[j] = coef * acc[j];
+      adam_row_mem<GL, CPL>(prow, srow, a.nch, lane, g, true, (int)*a.ar.step, a.lr, a.eps, a.ar);
+      return;
+    }
     float4 p[CPL], st[CPL];
 #pragma unroll
     for (int j = 0; j < CPL; ++j) {
@@ -783,7 +883,72 @@ int fill_wire(const char* name, WireTables& w, int n_tables, float* const* table
   return KTUP_OK;
 }
 
+int check_kind(const char* name, int kind, const ktup_adam_t* adam, int d) {
+  KTUP_REQUIRE(kind == KTUP_OPT_SGD || kind == KTUP_OPT_ADAGRAD || kind == KTUP_OPT_ADAM,
+               "%s: row-sparse steps exist for plain SGD, Adagrad and Adam (with catch-up of the untouched steps)", name);
+  if (kind == KTUP_OPT_ADAM) {
+    KTUP_REQUIRE(adam && adam->step, "%s: Adam needs its rule (betas, replay length, the device step counter)", name);
+    KTUP_REQUIRE(adam->beta1 >= 0.f && adam->beta1 < 1.f && adam->beta2 > 0.f && adam->beta2 < 1.f && adam->replay >= 0, "%s: bad Adam rule", name);
+    KTUP_REQUIRE(d % 4 == 0, "%s: Adam rows need d %% 4 == 0", name);
+  }
+  return KTUP_OK;
+}
+
+// *step += 1 unless the step is skipped (the same two flags the apply launch reads): the launch BEFORE the apply launch of a step
+__global__ void step_count_kernel(int64_t* step, const int32_t* skip_i, const double* skip_d) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const bool skip = (skip_i && *skip_i != 0) || (skip_d && *skip_d != 0.0);
+    if (!skip) *step = *step + 1;
+  }
+}
+
+template <int GL, int CPL>
+__global__ __launch_bounds__(256) void adam_flush_kernel(float* table, int64_t ldt, float* state, int64_t lds, int nch, int64_t n_rows, float lr,
+                                                         float eps, AdamRule r) {
+  constexpr int GPB = 256 / GL;
+  const int lane = threadIdx.x % GL;
+  const int t = (int)*r.step;
+  float4 none[CPL];
+#pragma unroll
+  for (int j = 0; j < CPL; ++j) none[j] = f4zero();
+  for (int64_t row = (int64_t)blockIdx.x * GPB + threadIdx.x / GL; row < n_rows; row += (int64_t)gridDim.x * GPB)
+    adam_row_mem<GL, CPL>(reinterpret_cast<float4*>(table + row * ldt), reinterpret_cast<float4*>(state + row * lds), nch, lane, none, false, t,
+                          lr, eps, r);
+}
+
 }  // namespace
+
+extern "C" int ktup_shard_step_count(int64_t* step, const int32_t* skip_count, const double* skip_value, void* stream) {
+  KTUP_REQUIRE(step, "ktup_shard_step_count: null counter");
+  hipLaunchKernelGGL(step_count_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, step, skip_count, skip_value);
+  return check_launch("ktup_shard_step_count");
+}
+
+extern "C" int ktup_shard_adam_flush(float* table, int64_t ldt, float* state, int64_t lds, int d, int64_t n_rows, float lr, float eps,
+                                     const ktup_adam_t* adam_rule, void* stream) {
+  const char* name = "ktup_shard_adam_flush";
+  if (int e = check_kind(name, KTUP_OPT_ADAM, adam_rule, d)) return e;
+  KTUP_REQUIRE(table && state && n_rows >= 0 && d > 0 && ldt >= d && lds >= KTUP_SHARD_ADAM_STATE_PITCH(d), "%s: null pointer or bad sizes", name);
+  if (ldt % 4 || lds % 4 || !aligned16(table) || !aligned16(state))
+    return set_error(KTUP_ERR_UNSUPPORTED, "%s: needs 16-byte aligned rows", name);
+  if (n_rows == 0) return KTUP_OK;
+  const AdamRule r{adam_rule->beta1, adam_rule->beta2, adam_rule->replay, adam_rule->step};
+  const int nch = d / 4;
+  hipStream_t st = (hipStream_t)stream;
+#define KTUP_AF(GL, CPL)                                                                                                          \
+  {                                                                                                                               \
+    const int grid = grid_for((n_rows + (256 / GL) - 1) / (256 / GL), 256 * 8);                                                   \
+    hipLaunchKernelGGL((adam_flush_kernel<GL, CPL>), dim3(grid), dim3(256), 0, st, table, ldt, state, lds, nch, n_rows, lr, eps, r);  \
+    return check_launch(name);                                                                                                    \
+  }
+  if (nch <= 16) KTUP_AF(16, 1)
+  if (nch <= 32) KTUP_AF(32, 1)
+  if (nch <= 64) KTUP_AF(64, 1)
+  if (nch <= 128) KTUP_AF(64, 2)
+  if (nch <= 256) KTUP_AF(64, 4)
+#undef KTUP_AF
+  return set_error(KTUP_ERR_UNSUPPORTED, "%s: embedding_size %d too large", name, d);
+}
 
 extern "C" size_t ktup_shard_route_workspace_bytes(int64_t n_entries) {
   if (n_entries <= 0) return 0;
@@ -927,16 +1092,17 @@ extern "C" int ktup_shard_apply(int kind, int n_tables, float* const* tables, co
                                 int small_rows, float* const* small_grads, float* const* small_p0, float* const* small_s0,
                                 float* const* small_p1, float* const* small_s1, const double* small_g64, float lr, float eps,
                                 const double* sumsq, int sumsq_slots, float max_norm, const int32_t* skip_count, const double* skip_value,
-                                float* loss_step, int n_loss, float* loss_sum, int32_t* skipped_steps, void* stream) {
+                                float* loss_step, int n_loss, float* loss_sum, int32_t* skipped_steps, const ktup_adam_t* adam_rule, void* stream) {
   const char* name = "ktup_shard_apply";
   KTUP_REQUIRE(n_loss >= 0 && (n_loss == 0 || (loss_step && loss_sum)), "%s: the loss slots need both arrays", name);
-  KTUP_REQUIRE(kind == KTUP_OPT_SGD || kind == KTUP_OPT_ADAGRAD, "%s: only plain SGD and Adagrad have an exact row-sparse form", name);
+  if (int e = check_kind(name, kind, adam_rule, d)) return e;
   ApplyRows op{};
   if (int e = fill_wire(name, op.w, n_tables, tables, ld, states, lds, cap, d)) return e;
   KTUP_REQUIRE(ids && grads && n_blocks > 0 && ldg >= d && d > 0, "%s: null pointer argument or bad sizes", name);
   KTUP_REQUIRE(n_small >= 0 && n_small <= MAXS && (n_small == 0 || (small_rows > 0 && small_grads && small_p0)), "%s: bad small-table list", name);
   KTUP_REQUIRE(max_norm <= 0.f || (sumsq && (sumsq_slots == 1 || sumsq_slots == NSLOT)), "%s: clipping needs the sum of squared gradients (1 or %d words)", name, NSLOT);
-  const bool adagrad = kind == KTUP_OPT_ADAGRAD;
+  const bool adam = kind == KTUP_OPT_ADAM;
+  const bool adagrad = kind == KTUP_OPT_ADAGRAD || adam;          // "the rows have a state" (Adam: [m | v | last], pitch >= 2 d + 4)
   bool v4 = d % 4 == 0 && aligned16(grads) && ldg % 4 == 0;
   for (int t = 0; t < n_tables; ++t) {
     KTUP_REQUIRE(!adagrad || (states && states[t]), "%s: table %d: Adagrad state missing", name, t);
@@ -953,6 +1119,12 @@ extern "C" int ktup_shard_apply(int kind, int n_tables, float* const* tables, co
   op.n_small = n_small; op.small_rows = small_rows > 0 ? small_rows : 1; op.small_g64 = small_g64; op.d = d;
   op.lr = lr; op.eps = eps; op.max_norm = max_norm; op.sumsq = sumsq; op.sumsq_slots = sumsq_slots; op.skip_i = skip_count; op.skip_d = skip_value; op.adagrad = adagrad;
   op.loss_step = loss_step; op.n_loss = n_loss; op.loss_sum = loss_sum; op.skipped = skipped_steps;
+  op.adam = adam; op.small_lds = adam ? KTUP_SHARD_ADAM_STATE_PITCH(d) : d;
+  if (adam) {
+    op.ar = AdamRule{adam_rule->beta1, adam_rule->beta2, adam_rule->replay, adam_rule->step};
+    for (int t = 0; t < n_tables; ++t) KTUP_REQUIRE(op.w.lds[t] >= KTUP_SHARD_ADAM_STATE_PITCH(d), "%s: table %d: an Adam state row is [m | v | last]: pitch >= 2 d + 4", name, t);
+    if (!v4) return set_error(KTUP_ERR_UNSUPPORTED, "%s: Adam rows need d %% 4 == 0 and 16-byte aligned tables, states and gradients", name);
+  }
   return launch_rows(op, d, v4, op.W + (int64_t)n_small * op.small_rows, (hipStream_t)stream, name);
 }
 
@@ -993,10 +1165,11 @@ extern "C" int ktup_shard_reduce_apply(int kind, int n_tables, float* const* tab
                                        float* const* small_grads, float* const* small_p0, float* const* small_s0, float* const* small_p1,
                                        float* const* small_s1, const double* small_g64, float lr, float eps, const double* sumsq,
                                        int sumsq_slots, float max_norm, const int32_t* skip_count, const double* skip_value,
-                                       float* loss_step, int n_loss, float* loss_sum, int32_t* skipped_steps, void* stream) {
+                                       float* loss_step, int n_loss, float* loss_sum, int32_t* skipped_steps, const ktup_adam_t* adam_rule,
+                                       void* stream) {
   const char* name = "ktup_shard_reduce_apply";
   KTUP_REQUIRE(n_loss >= 0 && (n_loss == 0 || (loss_step && loss_sum)), "%s: the loss slots need both arrays", name);
-  KTUP_REQUIRE(kind == KTUP_OPT_SGD || kind == KTUP_OPT_ADAGRAD, "%s: only plain SGD and Adagrad have an exact row-sparse form", name);
+  if (int e = check_kind(name, kind, adam_rule, d)) return e;
   ApplyRows op{};
   if (int e = fill_wire(name, op.w, n_tables, tables, ld, states, lds, cap, d)) return e;
   KTUP_REQUIRE(ids && n_blocks > 0, "%s: null pointer argument or bad sizes", name);
@@ -1005,7 +1178,8 @@ extern "C" int ktup_shard_reduce_apply(int kind, int n_tables, float* const* tab
   if (int e = fill_fused(name, a, G, ldg, d, n_src, src_off, sort_ws, n_entries, W, gwire, ldw, const_cast<int32_t*>(xkeys))) return e;
   KTUP_REQUIRE(n_small >= 0 && n_small <= MAXS && (n_small == 0 || (small_rows > 0 && small_grads && small_p0)), "%s: bad small-table list", name);
   KTUP_REQUIRE(max_norm <= 0.f || (sumsq && (sumsq_slots == 1 || sumsq_slots == NSLOT)), "%s: clipping needs the sum of squared gradients (1 or %d words)", name, NSLOT);
-  const bool adagrad = kind == KTUP_OPT_ADAGRAD;
+  const bool adam = kind == KTUP_OPT_ADAM;
+  const bool adagrad = kind == KTUP_OPT_ADAGRAD || adam;          // "the rows have a state" (Adam: [m | v | last], pitch >= 2 d + 4)
   bool v4 = true;
   for (int t = 0; t < n_tables; ++t) {
     KTUP_REQUIRE(!adagrad || (states && states[t]), "%s: table %d: Adagrad state missing", name, t);
@@ -1021,6 +1195,11 @@ extern "C" int ktup_shard_reduce_apply(int kind, int n_tables, float* const* tab
   if (!v4) return set_error(KTUP_ERR_UNSUPPORTED, "%s: tables, states and gradients must be 16-byte aligned with pitches %% 4 == 0", name);
   a.sumsq = const_cast<double*>(sumsq); a.slots = sumsq_slots; a.w = op.w; a.ids = ids; a.lr = lr; a.eps = eps; a.max_norm = max_norm;
   a.adagrad = adagrad; a.skip_i = skip_count; a.skip_d = skip_value;
+  a.adam = adam; op.adam = adam; op.small_lds = adam ? KTUP_SHARD_ADAM_STATE_PITCH(d) : d;
+  if (adam) {
+    a.ar = op.ar = AdamRule{adam_rule->beta1, adam_rule->beta2, adam_rule->replay, adam_rule->step};
+    for (int t = 0; t < n_tables; ++t) KTUP_REQUIRE(op.w.lds[t] >= KTUP_SHARD_ADAM_STATE_PITCH(d), "%s: table %d: an Adam state row is [m | v | last]: pitch >= 2 d + 4", name, t);
+  }
   hipStream_t st = (hipStream_t)stream;
   const int64_t grid = fused_grid(n_entries, d);
   // the listed boundary rows from gw (then zero-filled) and the small tables ride in the same launch

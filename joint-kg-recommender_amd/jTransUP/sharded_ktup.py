@@ -43,8 +43,43 @@ import torch.distributed as dist
 
 from jTransUP.hip import lib as L
 
-KINDS = {'sgd': 0, 'adagrad': 1}
+KINDS = {'sgd': 0, 'adagrad': 1, 'adam': 2}
 SLOTS = 16          # the sum of squares is accumulated in this many words (one atomic per workgroup, ~20 ns each on one address)
+
+
+class AdamRule(ctypes.Structure):
+    """ktup_adam_t of include/ktup_hip.h: the row-sparse Adam that equals the reference's dense one (catch-up of the untouched steps)."""
+    _fields_ = [('beta1', ctypes.c_float), ('beta2', ctypes.c_float), ('replay', ctypes.c_int32), ('reserved', ctypes.c_int32),
+                ('step', ctypes.c_void_p)]
+
+
+def adam_state_pitch(d):
+    return 2 * d + 4            # KTUP_SHARD_ADAM_STATE_PITCH: [m (d) | v (d) | last (int32) + padding]
+
+
+def adam_replay(betas, tol=1e-6):
+    """Zero-gradient steps replayed one by one when a row is touched again: the replayed increments fall like (beta1 / sqrt(beta2))^k, so
+    after this many the rest of the series is below `tol` of its first term (< 1e-7 absolute at the learning rates in use)."""
+    r = float(betas[0]) / math.sqrt(float(betas[1]))
+    if r <= 0.0:
+        return 0
+    if r >= 1.0:
+        return 1 << 20
+    return min(1 << 20, int(math.ceil(math.log(tol) / math.log(r))))
+
+
+def row_state(weight, kind):
+    """Optimizer state of a table (or shard) for `kind`: None (sgd), the Adagrad sums, or Adam's [m | v | last] rows."""
+    if kind == 'adagrad':
+        return torch.zeros_like(weight)
+    if kind == 'adam':
+        return torch.zeros(weight.shape[0], adam_state_pitch(weight.shape[1]), dtype=torch.float32, device=weight.device)
+    return None
+
+
+def _check_state(state, weight, kind):
+    want = None if kind == 'sgd' else (weight.shape[0], weight.shape[1] if kind == 'adagrad' else adam_state_pitch(weight.shape[1]))
+    return (state is None and want is None) or (state is not None and want is not None and tuple(state.shape) == want)
 
 
 def _p(t):
@@ -142,6 +177,18 @@ class _ShardedStepBase(object):
             graphs.append(graph)
         self._graphs, self._graph_keep = graphs, keeps
 
+    def flush(self):
+        """Adam: bring EVERY row of this stepper's shards and small tables up to the current step (the zero-gradient steps a row has not
+        been touched for; ktup_shard_adam_flush), so that what an evaluation, a gather or a checkpoint reads is what the reference's
+        dense optimizer would hold.  Stream-ordered, no synchronisation; a no-op for the other optimizers."""
+        if self.kind != 'adam':
+            return
+        st = torch.cuda.current_stream(self.dev).cuda_stream
+        rule = AdamRule(self.betas[0], self.betas[1], adam_replay(self.betas), 0, self.opt_step.data_ptr())
+        for w, s in [(t.weight.data, t.state) for t in self.tables] + [(p.data, s) for p, s in zip(self.small, self.small_state)]:
+            L.call('ktup_shard_adam_flush', w.data_ptr(), w.stride(0), s.data_ptr(), s.stride(0), self.d, w.shape[0], self.lr, self.eps,
+                   ctypes.addressof(rule), st)
+
     # ------------------------------------------------------------------------------------------------ reporting
     def overflowed_steps(self):
         """Steps skipped so far because an exchange buffer overflowed (a device counter no launch clears; one device read -- call
@@ -174,9 +221,11 @@ class ShardedKtupStepper(_ShardedStepBase):
 
     def __init__(self, Ut, It, Et, pref, pref_norm, rel, norm, item2ent, batch, kind='adagrad', lr=0.005, eps=1e-10, max_norm=0.0,
                  l1=False, target=-1.0, orth=False, ent_pad=-1, group=None, capacity_factor=1.25, use_graphs=True, force_exchange=False,
-                 direct=None, overlap_route=True, fused_apply=True, route_beside=False):
+                 direct=None, overlap_route=True, fused_apply=True, route_beside=False, betas=(0.9, 0.999), opt_step=None):
         if kind not in KINDS:
-            raise ValueError('row-sparse steps exist for plain SGD and Adagrad only')
+            raise ValueError('row-sparse steps exist for plain SGD, Adagrad and Adam')
+        self.betas = (float(betas[0]), float(betas[1]))
+        self.has_state = kind != 'sgd'
         self.route_beside = bool(route_beside)
         self.tables = [Ut, It, Et]
         self.small = [pref, pref_norm, rel, norm]
@@ -251,10 +300,13 @@ class ShardedKtupStepper(_ShardedStepBase):
         self.skipped = i32(1)                                 # steps skipped for overflow: never cleared by a launch
         n_g = 4 if self.orth else 2
         self.small_g = [f32(P, d) for _ in range(n_g)]        # orth: gP, gPn, gR, gRn; else gA (pref & rel), gC (pref_norm & norm)
-        self.small_state = [torch.zeros_like(s.data) for s in self.small] if kind == 'adagrad' else [None] * 4
+        self.small_state = [row_state(s.data, kind) for s in self.small]
         for t in self.tables:
-            if kind == 'adagrad' and t.state is None:
-                t.state = torch.zeros_like(t.weight.data)
+            if not _check_state(t.state, t.weight.data, kind):
+                t.state = row_state(t.weight.data, kind)
+        # Adam: the number of the step being applied, in device memory (the launches are replayed from graphs); shared by the steppers
+        # of a joint schedule.  ktup_shard_step_count moves it just before every apply launch.
+        self.opt_step = opt_step if opt_step is not None else torch.zeros(1, dtype=torch.int64, device=dev)
         self.steps = 0
         if self.multi:
             self.recv_ids = i64(W, -1)
@@ -290,8 +342,9 @@ class ShardedKtupStepper(_ShardedStepBase):
             return ctypes.addressof(x)
         tabs = arr(_ptrs([t.weight.data for t in self.tables]))
         lds = arr(_i64s([t.weight.data.stride(0) for t in self.tables]))
-        states = arr(_ptrs([t.state for t in self.tables])) if self.kind == 'adagrad' else None
-        slds = arr(_i64s([t.state.stride(0) for t in self.tables])) if self.kind == 'adagrad' else lds      # interleaved tables: pitch 2d
+        states = arr(_ptrs([t.state for t in self.tables])) if self.has_state else None
+        slds = arr(_i64s([t.state.stride(0) for t in self.tables])) if self.has_state else lds      # interleaved tables: pitch 2d
+        adam = arr(AdamRule(self.betas[0], self.betas[1], adam_replay(self.betas), 0, self.opt_step.data_ptr())) if self.kind == 'adam' else None
         cap = arr(_i64s(self.cap))
         kind = KINDS[self.kind]
         gscale = 1.0 / Wn
@@ -309,9 +362,9 @@ class ShardedKtupStepper(_ShardedStepBase):
             sp1, ss1 = [rel, norm], [self.small_state[2], self.small_state[3]]
             norm_list, small_weight = [g[0], g[0], g[1], g[1]], 2.0      # the norm runs over all four tables' gradients
         n_small = len(sg_list)
-        sgp, sp0p, ss0p = arr(_ptrs(sg_list)), arr(_ptrs(sp0)), (arr(_ptrs(ss0)) if self.kind == 'adagrad' else None)
+        sgp, sp0p, ss0p = arr(_ptrs(sg_list)), arr(_ptrs(sp0)), (arr(_ptrs(ss0)) if self.has_state else None)
         sp1p = arr(_ptrs(sp1)) if not self.orth else None
-        ss1p = arr(_ptrs(ss1)) if (not self.orth and self.kind == 'adagrad') else None
+        ss1p = arr(_ptrs(ss1)) if (not self.orth and self.has_state) else None
         X, inv = self.X, self.inverse
         close = (_p(self.loss_step), 2, _p(self.loss_sum), _p(self.skipped))
         # one rank, two-walk form: the step kernel adds the stored rows' squared norms itself and the norm walk only corrects for
@@ -357,7 +410,8 @@ class ShardedKtupStepper(_ShardedStepBase):
             gnorm = bind('ktup_optim_gradnorm_acc', len(nl), nptr, nsz, _p(self.acc), SLOTS, stream)
             apply_ = bind('ktup_shard_apply', kind, 3, tabs, lds, states, slds, cap, d, _p(self.send_ids), 1, _p(self.Gwire), d, n_small, P,
                           sgp, sp0p, ss0p, sp1p, ss1p, None, self.lr, self.eps, _p(self.acc), SLOTS, self.max_norm,
-                          self.counters.data_ptr() + 4 * (Wn * 3), None, *close, stream)
+                          self.counters.data_ptr() + 4 * (Wn * 3), None, *close, adam, stream)
+            count = [bind('ktup_shard_step_count', _p(self.opt_step), self.counters.data_ptr() + 4 * (Wn * 3), None, stream)] if adam else []
             if self.fused_apply:
                 nw = arr(_ptrs(sg_list))
                 rnorm = bind('ktup_shard_reduce_norm', _p(self.Gcat), d, d, 3 * B, 2 * B, _p(self.sort_ws), E, W, _p(self.Gwire), d,
@@ -365,10 +419,10 @@ class ShardedKtupStepper(_ShardedStepBase):
                 rapply = bind('ktup_shard_reduce_apply', kind, 3, tabs, lds, states, slds, cap, _p(self.send_ids), 1, _p(self.Gcat), d, d,
                               3 * B, 2 * B, _p(self.sort_ws), E, _p(self.Gwire), d, _p(self.xkeys), n_small, P, sgp, sp0p, ss0p, sp1p, ss1p,
                               None, self.lr, self.eps, _p(self.acc), SLOTS, self.max_norm, self.counters.data_ptr() + 4 * (Wn * 3), None,
-                              *close, stream)
-                tail = [rnorm, rapply]
+                              *close, adam, stream)
+                tail = [rnorm] + count + [rapply]
             else:
-                tail = [reduce_, gnorm, apply_]
+                tail = [reduce_, gnorm] + count + [apply_]
             if beside:
                 return [[('beside', [step], [route_phase(3, side)]), ('join',)] + tail]
             if self.direct and side is not None:
@@ -389,16 +443,17 @@ class ShardedKtupStepper(_ShardedStepBase):
         fin_b = bind('ktup_shard_bucket', 1, n_small, None, P * d, _p(self.bucket), None, 0, None, self.acc.data_ptr() + 8 * SLOTS, small_weight, stream)
         apply_ = bind('ktup_shard_apply', kind, 3, tabs, lds, states, slds, capo, d, _p(self.own_ids), 1, _p(self.Gown), d, n_small, P,
                       sgp, sp0p, ss0p, sp1p, ss1p, _p(self.bucket), self.lr, self.eps, self.acc.data_ptr() + 8 * SLOTS, 1, self.max_norm,
-                      None, self.bucket.data_ptr() + 8 * (N + 1), *close, stream)
+                      None, self.bucket.data_ptr() + 8 * (N + 1), *close, adam, stream)
+        count = [bind('ktup_shard_step_count', _p(self.opt_step), None, self.bucket.data_ptr() + 8 * (N + 1), stream)] if adam else []
         if self.fused_apply:
             onorm = bind('ktup_shard_reduce_norm', _p(self.Grecv), d, d, W, 0, _p(self.own_sort), W, self.W_own, _p(self.Gown), d,
                          _p(self.own_xkeys), 0, None, 0, 1.0, _p(self.acc), SLOTS, 0, None, 0, None, stream)
             oapply = bind('ktup_shard_reduce_apply', kind, 3, tabs, lds, states, slds, capo, _p(self.own_ids), 1, _p(self.Grecv), d, d, W, 0,
                           _p(self.own_sort), W, _p(self.Gown), d, _p(self.own_xkeys), n_small, P, sgp, sp0p, ss0p, sp1p, ss1p,
                           _p(self.bucket), self.lr, self.eps, self.acc.data_ptr() + 8 * SLOTS, 1, self.max_norm, None,
-                          self.bucket.data_ptr() + 8 * (N + 1), *close, stream)
-            return [[route], [pack], [step, reduce_], [zero, oroute, onorm, pack_b], [fin_b, oapply]]
-        return [[route], [pack], [step, reduce_], [zero, oroute, oreduce, gnorm, pack_b], [fin_b, apply_]]
+                          self.bucket.data_ptr() + 8 * (N + 1), *close, adam, stream)
+            return [[route], [pack], [step, reduce_], [zero, oroute, onorm, pack_b], [fin_b] + count + [oapply]]
+        return [[route], [pack], [step, reduce_], [zero, oroute, oreduce, gnorm, pack_b], [fin_b] + count + [apply_]]
 
     # ------------------------------------------------------------------------------------------------ the step
     def load_batch(self, u, pos_items, neg_items):
@@ -447,9 +502,12 @@ class ShardedKgStepper(_ShardedStepBase):
 
     def __init__(self, Et, rel, norm, batch, kind='adagrad', lr=0.005, eps=1e-10, max_norm=0.0, l1=False, margin=1.0, kg_lambda=1.0,
                  transh=True, regs=7, small_state=None, group=None, capacity_factor=1.25, use_graphs=True, force_exchange=False,
-                 direct=None, overlap_route=True):
+                 direct=None, overlap_route=True, betas=(0.9, 0.999), opt_step=None):
         if kind not in KINDS:
-            raise ValueError('row-sparse steps exist for plain SGD and Adagrad only')
+            raise ValueError('row-sparse steps exist for plain SGD, Adagrad and Adam')
+        self.betas = (float(betas[0]), float(betas[1]))
+        self.has_state = kind != 'sgd'
+
         self.tables = [Et]
         self.transh = bool(transh)
         self.small = [rel, norm] if self.transh else [rel]
@@ -506,12 +564,13 @@ class ShardedKgStepper(_ShardedStepBase):
         self.loss_sum, self.loss_step = f32(4), f32(4)
         self.skipped = i32(1)
         self.small_g = [f32(P, d) for _ in self.small]
-        if kind == 'adagrad':
-            self.small_state = list(small_state) if small_state is not None else [torch.zeros_like(s.data) for s in self.small]
-            if Et.state is None:
-                Et.state = torch.zeros_like(Et.weight.data)
+        if self.has_state:
+            self.small_state = list(small_state) if small_state is not None else [row_state(s.data, kind) for s in self.small]
+            if not _check_state(Et.state, Et.weight.data, kind):
+                Et.state = row_state(Et.weight.data, kind)
         else:
             self.small_state = [None] * len(self.small)
+        self.opt_step = opt_step if opt_step is not None else torch.zeros(1, dtype=torch.int64, device=dev)
         self.steps = 0
         if self.multi:
             self.recv_ids = i64(W, -1)
@@ -540,14 +599,15 @@ class ShardedKgStepper(_ShardedStepBase):
             return ctypes.addressof(x)
         tabs = arr(_ptrs([Et.weight.data]))
         lds = arr(_i64s([Et.weight.data.stride(0)]))
-        states = arr(_ptrs([Et.state])) if self.kind == 'adagrad' else None
-        slds = arr(_i64s([Et.state.stride(0)])) if self.kind == 'adagrad' else lds
+        states = arr(_ptrs([Et.state])) if self.has_state else None
+        slds = arr(_i64s([Et.state.stride(0)])) if self.has_state else lds
+        adam = arr(AdamRule(self.betas[0], self.betas[1], adam_replay(self.betas), 0, self.opt_step.data_ptr())) if self.kind == 'adam' else None
         cap = arr(_i64s(self.cap))
         kind = KINDS[self.kind]
         n_small = len(self.small)
         sgp = arr(_ptrs(self.small_g))
         sp0p = arr(_ptrs([s.data for s in self.small]))
-        ss0p = arr(_ptrs(self.small_state)) if self.kind == 'adagrad' else None
+        ss0p = arr(_ptrs(self.small_state)) if self.has_state else None
         rel = self.small[0].data
         norm = self.small[1].data if self.transh else None
         gR, gN = self.small_g[0], (self.small_g[1] if self.transh else None)
@@ -574,10 +634,11 @@ class ShardedKgStepper(_ShardedStepBase):
                          sgp, P * d, 1.0, _p(self.acc), SLOTS, 1, None, 0, None, stream)
             rapply = bind('ktup_shard_reduce_apply', kind, 1, tabs, lds, states, slds, cap, _p(self.send_ids), 1, _p(self.GE), d, d, E, 0,
                           _p(self.sort_ws), E, _p(self.Gwire), d, _p(self.xkeys), n_small, P, sgp, sp0p, ss0p, None, None, None, self.lr,
-                          self.eps, _p(self.acc), SLOTS, self.max_norm, skip_i, None, *close, stream)
+                          self.eps, _p(self.acc), SLOTS, self.max_norm, skip_i, None, *close, adam, stream)
+            count = [bind('ktup_shard_step_count', _p(self.opt_step), skip_i, None, stream)] if adam else []
             if self.direct and side is not None:
-                return [[route_phase(1, stream), ('beside', [order, step], [route_phase(2, side)]), ('join',), rnorm, rapply]]
-            return [[route_phase(0, stream)] + ([] if self.direct else [pack]) + [order, step, rnorm, rapply]]
+                return [[route_phase(1, stream), ('beside', [order, step], [route_phase(2, side)]), ('join',), rnorm] + count + [rapply]]
+            return [[route_phase(0, stream)] + ([] if self.direct else [pack]) + [order, step, rnorm] + count + [rapply]]
         capo = arr(_i64s(self.cap_own))
         eoff_o = arr(_i64s([0, self.capsum]))
         pack = bind('ktup_shard_pack_wire', 1, tabs, lds, cap, d, _p(self.recv_ids), Wn, _p(self.Xsend), d, stream)
@@ -593,8 +654,9 @@ class ShardedKgStepper(_ShardedStepBase):
         oapply = bind('ktup_shard_reduce_apply', kind, 1, tabs, lds, states, slds, capo, _p(self.own_ids), 1, _p(self.Grecv), d, d, W, 0,
                       _p(self.own_sort), W, _p(self.Gown), d, _p(self.own_xkeys), n_small, P, sgp, sp0p, ss0p, None, None, _p(self.bucket),
                       self.lr, self.eps, self.acc.data_ptr() + 8 * SLOTS, 1, self.max_norm, None, self.bucket.data_ptr() + 8 * (N + 1),
-                      *close, stream)
-        return [[route_phase(0, stream)], [pack], [order, step, reduce_], [zero, oroute, onorm, pack_b], [fin_b, oapply]]
+                      *close, adam, stream)
+        count = [bind('ktup_shard_step_count', _p(self.opt_step), None, self.bucket.data_ptr() + 8 * (N + 1), stream)] if adam else []
+        return [[route_phase(0, stream)], [pack], [order, step, reduce_], [zero, oroute, onorm, pack_b], [fin_b] + count + [oapply]]
 
     def load_batch(self, ph, pt, pr, nh, nt, nr):
         if self._feed[0] is not self.cols[0]:
@@ -639,10 +701,14 @@ class ShardedKtupJoint(object):
     def build(cls, Ut, It, Et, pref, pref_norm, rel, norm, item2ent, batch, joint_ratio=0.7, margin=1.0, kg_lambda=1.0, kg_batch=None,
               orth=True, **kw):
         rec = ShardedKtupStepper(Ut, It, Et, pref, pref_norm, rel, norm, item2ent, batch=batch, orth=orth, **kw)
-        kw_kg = {k: v for k, v in kw.items() if k not in ('target', 'ent_pad', 'fused_apply')}
+        kw_kg = {k: v for k, v in kw.items() if k not in ('target', 'ent_pad', 'fused_apply', 'opt_step')}
         kg = ShardedKgStepper(Et, rel, norm, batch=kg_batch or batch, margin=margin, kg_lambda=kg_lambda,
-                              small_state=rec.small_state[2:4] if rec.kind == 'adagrad' else None, **kw_kg)
+                              small_state=rec.small_state[2:4] if rec.has_state else None, opt_step=rec.opt_step, **kw_kg)
         return cls(rec, kg, joint_ratio)
+
+    def flush(self):
+        """Adam: every row of the three shards and of the four small tables up to the current step (the rec stepper holds them all)."""
+        self.rec.flush()
 
     def is_rec(self, step=None):
         return (self.steps if step is None else step) % 10 < self.switch

@@ -33,8 +33,9 @@ def check_flags(FLAGS, model):
     """Everything -shard_tables cannot do is refused here, by the reference's flag names."""
     if FLAGS.model_type != 'jtransup' or FLAGS.share_embeddings:
         raise L.KtupError('-shard_tables trains jtransup with its own tables (-model_type jtransup -noshare_embeddings)')
-    if FLAGS.optimizer_type not in ('Adagrad', 'SGD') or (FLAGS.optimizer_type == 'SGD' and FLAGS.momentum != 0):
-        raise L.KtupError('-shard_tables updates only the rows a batch touches: exact for -optimizer_type Adagrad, or SGD with -momentum 0')
+    if FLAGS.optimizer_type not in ('Adagrad', 'SGD', 'Adam') or (FLAGS.optimizer_type == 'SGD' and FLAGS.momentum != 0):
+        raise L.KtupError('-shard_tables updates only the rows a batch touches: exact for -optimizer_type Adagrad, SGD with -momentum 0, '
+                          'or Adam (whose untouched steps are replayed when a row is touched again)')
     if FLAGS.l2_lambda != 0:
         raise L.KtupError('-shard_tables needs -l2_lambda 0 (weight decay moves every row of every table on every step)')
     if FLAGS.use_st_gumbel:
@@ -97,6 +98,7 @@ class ShardedJointDriver(object):
         F = self.FLAGS
         self.joint = ShardedKtupJoint.build(*self.tables, *self.small, self.m._item2ent, batch=self.B, joint_ratio=F.joint_ratio,
                                             margin=F.margin, kg_lambda=F.kg_lambda, kind=self.kind, lr=lr, max_norm=F.clipping_max_value,
+                                            eps=1e-8 if self.kind == 'adam' else 1e-10,       # torch.optim's defaults (utils/trainer.py:63-77 passes none)
                                             l1=bool(F.L1_flag), target=float(self.trainer.model_target), orth=True,
                                             ent_pad=self.m.ent_total - 1, group=self.group)
         self._lr = lr
@@ -163,6 +165,7 @@ class ShardedJointDriver(object):
         """Gather every shard into the model's whole tables (before an evaluation or a checkpoint)."""
         if not self._dirty:
             return
+        self.joint.flush()                           # Adam: every row up to the current step, as the dense optimizer would hold it
         for name, t in zip(BIG, self.tables):
             gather_table(getattr(self.m, name).weight.data, t.weight.data, t.total_rows, self.world, self.group)
         self._dirty = False
@@ -179,7 +182,9 @@ class ShardedJointDriver(object):
 
     def save_shards(self, filename):
         j = self.joint
+        j.flush()
         torch.save({'rank': self.rank, 'world': self.world, 'step': self.trainer.step, 'joint_steps': j.steps, 'lr': self._lr,
+                    'opt_step': int(j.rec.opt_step.item()),
                     'rows': {n: t.weight.data.cpu() for n, t in zip(BIG, self.tables)},
                     'row_state': {n: (None if t.state is None else t.state.cpu()) for n, t in zip(BIG, self.tables)},
                     'small': {n: p.data.cpu() for n, p in zip(SMALL, self.small)},
@@ -201,6 +206,7 @@ class ShardedJointDriver(object):
         for s, v in zip(self.joint.rec.small_state, ck['small_state']):
             if s is not None and v is not None:
                 s.copy_(v)                           # (the kg stepper shares the rel / norm sums)
+        self.joint.rec.opt_step.fill_(int(ck.get('opt_step', 0)))
         self.joint.steps = ck['joint_steps']
         self.trainer.step = ck['step']
         self._dirty = True

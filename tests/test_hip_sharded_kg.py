@@ -54,10 +54,10 @@ def _dense(full, small0, i2e, schedule, kind, lr, eps, max_norm, l1=False, margi
     """schedule: list of ('rec', per-rank batches) / ('kg', per-rank batches).  -> tables after the steps, per-step losses."""
     W = [torch.nn.Parameter(full[k].clone()) for k in ('U', 'I', 'E')] + [torch.nn.Parameter(t.clone()) for t in small0]
     U, I, E, Pf, Pn, R, Rn = W
-    opt = torch.optim.Adagrad(W, lr=lr, eps=eps) if kind == 'adagrad' else torch.optim.SGD(W, lr=lr)
+    opt = torch.optim.Adagrad(W, lr=lr, eps=eps) if kind == 'adagrad' else torch.optim.Adam(W, lr=lr, eps=eps) if kind == 'adam' else torch.optim.SGD(W, lr=lr)
     losses = []
     for what, per in schedule:
-        opt.zero_grad()
+        opt.zero_grad(set_to_none=False)      # zero-FILL (torch 0.3): a table keeps being stepped on the steps that do not touch it
         cat = [torch.cat([x[c] for x in per]) for c in range(len(per[0]))]
         if what == 'rec':
             pos = O.score_ktup_rec(U, I, E, Pf, Pn, R, Rn, i2e, cat[0], cat[1], l1)
@@ -187,7 +187,7 @@ def _joint_schedule(gen, world, steps, nu, ni, ne, P, b, joint_ratio):
     return sched
 
 
-@pytest.mark.parametrize('kind', ['adagrad', 'sgd'])
+@pytest.mark.parametrize('kind', ['adagrad', 'sgd', 'adam'])
 @pytest.mark.parametrize('form', ['one_graph', 'exchange_form'])
 def test_joint_schedule_equals_the_dense_reference(kind, form):
     """Twelve steps of the 7 : 3 cycle (rec x 7, kg x 3, rec x 2) over shared entity / rel / norm tables and Adagrad sums."""
@@ -197,17 +197,19 @@ def test_joint_schedule_equals_the_dense_reference(kind, form):
     full, small0, i2e, gen = _tables(nu, ni, ne, P, d, seed=43, scale=1.05)
     sched = _joint_schedule(gen, 1, steps, nu, ni, ne, P, b, 0.7)
     assert [w for w, _ in sched] == ['rec'] * 7 + ['kg'] * 3 + ['rec'] * 2
-    lr, max_norm = (0.05, 0.5) if kind == 'adagrad' else (0.02, 0.5)
-    Wd, losses = _dense(full, small0, i2e, sched, kind, lr, 1e-4, max_norm, kg_lambda=0.5)
+    lr, max_norm = (0.05, 0.5) if kind == 'adagrad' else (0.01, 0.5) if kind == 'adam' else (0.02, 0.5)
+    eps = 1e-5 if kind == 'adam' else 1e-4     # Adam: the user / item tables decay through the three kg steps, pref / pref_norm too (dense semantics)
+    Wd, losses = _dense(full, small0, i2e, sched, kind, lr, eps, max_norm, kg_lambda=0.5)
     tabs = _sharded(full, dev, 0, 1)
     small = [torch.nn.Parameter(t.clone().to(dev)) for t in small0]
     kw = {'one_graph': {}, 'exchange_form': {'force_exchange': True}}[form]
     joint = ShardedKtupJoint.build(*tabs, *small, i2e.to(torch.int32).to(dev), batch=b, joint_ratio=0.7, kg_lambda=0.5, kind=kind, lr=lr,
-                                   eps=1e-4, max_norm=max_norm, **kw)
+                                   eps=eps, max_norm=max_norm, **kw)
     for what, per in sched:
         assert joint.is_rec() == (what == 'rec')
         (joint.rec if what == 'rec' else joint.kg).load_batch(*(x.to(dev) for x in per[0]))
         joint.run()
+    joint.flush()
     torch.cuda.synchronize()
     _check(tabs, 'UIE', small, Wd, 0, 1)
     np.testing.assert_allclose(float(joint.rec.loss_sum.sum()), sum(v for w, v in losses if w == 'rec'), rtol=1e-4)

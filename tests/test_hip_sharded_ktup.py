@@ -36,10 +36,10 @@ def _dense_reference(full, small0, i2e, batches, kind, lr, eps, max_norm, l1=Fal
     W = [torch.nn.Parameter(full['U'].clone()), torch.nn.Parameter(full['I'].clone()), torch.nn.Parameter(E_pad)] + \
         [torch.nn.Parameter(t.clone()) for t in small0]
     i2e_pad = torch.where(i2e < 0, torch.full_like(i2e, ne), i2e)
-    opt = torch.optim.Adagrad(W, lr=lr, eps=eps) if kind == 'adagrad' else torch.optim.SGD(W, lr=lr)
+    opt = torch.optim.Adagrad(W, lr=lr, eps=eps) if kind == 'adagrad' else torch.optim.Adam(W, lr=lr, eps=eps) if kind == 'adam' else torch.optim.SGD(W, lr=lr)
     losses = []
     for step in batches:
-        opt.zero_grad()
+        opt.zero_grad(set_to_none=False)      # zero-FILL, like the torch 0.3 of the reference: Adam keeps moving every table it has ever stepped
         u = torch.cat([x[0] for x in step]); pi = torch.cat([x[1] for x in step]); ni_ = torch.cat([x[2] for x in step])
         pos = O.score_ktup_rec(*W, i2e_pad, u, pi, l1); neg = O.score_ktup_rec(*W, i2e_pad, u, ni_, l1)
         loss = torch.nn.functional.softplus(pos - neg).mean()
@@ -67,6 +67,7 @@ def _run_stepper(full, small0, i2e, batches, kind, lr, eps, max_norm, rank, worl
                             l1=l1, orth=orth, **kw)
     for step in batches:
         st(*(x.to(dev) for x in step[rank]))
+    st.flush()                                # Adam: the rows the last steps did not touch, up to the last step
     torch.cuda.synchronize()
     return (Ut, It, Et), small, st
 
@@ -277,3 +278,72 @@ def test_stepper_at_one_ranks_share_of_config5(zipf):
     for p, w in zip(small, Wd[3:]):
         torch.testing.assert_close(p.data.cpu(), w, rtol=1e-4, atol=2e-5)
     np.testing.assert_allclose(float(st.loss_sum[0]), sum(losses), rtol=1e-4)
+
+
+# Adam's eps = 1e-5 here for the same reason as Adagrad's 1e-4 above (the default 1e-8 turns a gradient element of that size into a
+# step of lr / 2 that fp32 rounding decides); the catch-up arithmetic is the same for any eps.
+@pytest.mark.parametrize('d,P', [(256, 20), (100, 20), (64, 4)])
+@pytest.mark.parametrize('form', ['one_graph', 'exchange_form', 'eager', 'one_graph_gradient_buffer'])
+def test_stepper_adam_equals_the_dense_adam(d, P, form):
+    """Row-sparse Adam with catch-up (include/ktup_hip.h ktup_adam_t) against torch.optim.Adam over WHOLE tables with zero-filled
+    gradients -- what utils/trainer.py:63-66 builds for ktup.sh's `-optimizer_type Adam -l2_lambda 0`: nine steps on 900 users with
+    128-row batches, so most rows are touched at some steps and not at others (gaps of 1-8 steps replayed on the next touch, the
+    rest by the flush)."""
+    nu, ni, ne, b, steps = 900, 300, 700, 128, 9
+    full, small0, i2e, gen = _world_tables(nu, ni, ne, P, d, seed=5 + d, pad_every=7)
+    batches = _batches(gen, 1, steps, nu, ni, b)
+    lr, max_norm = 0.01, 0.5
+    Wd, losses = _dense_reference(full, small0, i2e, batches, 'adam', lr, 1e-5, max_norm, orth=True)
+    kw = {'one_graph': {}, 'exchange_form': {'force_exchange': True}, 'eager': {'use_graphs': False},
+          'one_graph_gradient_buffer': {'fused_apply': False}}[form]
+    tables, small, st = _run_stepper(full, small0, i2e, batches, 'adam', lr, 1e-5, max_norm, 0, 1, torch.device(DEV), orth=True, **kw)
+    assert st.steps == steps and int(st.opt_step.item()) == steps
+    _check(tables, small, Wd, 0, 1)
+    np.testing.assert_allclose(float(st.loss_sum.sum()), sum(losses), rtol=1e-4)
+    # every touched row of every shard was written at the last step or brought up to it; untouched rows never moved
+    for t, key in zip(tables, 'UIE'):
+        last = t.state[:, 2 * d].view(torch.int32)
+        touched = last > 0
+        assert bool((last[touched] == steps).all()) and torch.equal(t.weight.data[~touched].cpu(), full[key][~touched.cpu()])
+    st.check()
+
+
+@pytest.mark.parametrize('gap', [1, 7, 131, 132, 133, 400])
+def test_adam_flush_replays_the_untouched_steps(gap):
+    """ktup_shard_adam_flush against the dense recurrence written out in float64: a row whose state was written at step `last` is
+    taken through steps last + 1 .. t with a zero gradient -- m <- beta1 m, v <- beta2 v, p <- p - lr / (1 - beta1^s) m / (sqrt(v /
+    (1 - beta2^s)) + eps) -- one after the other; beyond 132 replayed steps (adam_replay: the increments have fallen below 1e-6 of
+    the first) only m and v keep decaying.  Rows never touched (last = 0) stay as they are."""
+    import ctypes
+    from jTransUP.hip import lib as L
+    from jTransUP.sharded_ktup import AdamRule, adam_replay, adam_state_pitch
+    gen = torch.Generator().manual_seed(gap)
+    n, d, lr, eps, b1, b2 = 96, 100, 0.01, 1e-8, 0.9, 0.999
+    p0 = torch.randn(n, d, generator=gen)
+    m0 = 1e-2 * torch.randn(n, d, generator=gen)
+    v0 = (m0 ** 2) * (0.2 + 3 * torch.rand(n, d, generator=gen)) + 1e-12
+    v0[:, :7] = 1e-17                                          # elements where eps carries the denominator
+    last = torch.randint(1, 60, (n,), generator=gen).to(torch.int32)
+    last[::9] = 0
+    m0[last == 0] = 0; v0[last == 0] = 0
+    t = int(last.max()) + gap
+    state = torch.zeros(n, adam_state_pitch(d))
+    state[:, :d] = m0; state[:, d:2 * d] = v0
+    state[:, 2 * d] = last.view(torch.float32)
+    P, S = p0.to(DEV), state.to(DEV)
+    step = torch.tensor([t], dtype=torch.int64, device=DEV)
+    rule = AdamRule(b1, b2, adam_replay((b1, b2)), 0, step.data_ptr())
+    L.call('ktup_shard_adam_flush', P.data_ptr(), P.stride(0), S.data_ptr(), S.stride(0), d, n, lr, eps, ctypes.addressof(rule),
+           torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    p, m, v = p0.double().clone(), m0.double().clone(), v0.double().clone()
+    for s in range(1, t + 1):
+        on = (last.long() > 0) & (last.long() < s)
+        m[on] *= b1; v[on] *= b2
+        p[on] -= lr / (1 - b1 ** s) * m[on] / (v[on].sqrt() / (1 - b2 ** s) ** 0.5 + eps)
+    got_p, got_s = P.cpu(), S.cpu()
+    torch.testing.assert_close(got_p.double(), p, rtol=2e-6, atol=2e-7)
+    torch.testing.assert_close(got_s[:, :d].double(), m, rtol=1e-5, atol=1e-30)
+    torch.testing.assert_close(got_s[:, d:2 * d].double(), v, rtol=1e-5, atol=1e-30)
+    want_last = torch.where(last > 0, torch.full_like(last, t), last)
+    assert torch.equal(got_s[:, 2 * d].view(torch.int32), want_last)

@@ -487,6 +487,15 @@ typedef struct ktup_adam_t { float beta1, beta2; int32_t replay; int32_t reserve
 int ktup_shard_step_count(int64_t* step, const int32_t* skip_count, const double* skip_value, void* stream);
 int ktup_shard_adam_flush(float* table, int64_t ldt, float* state, int64_t lds, int d, int64_t n_rows, float lr, float eps,
                           const ktup_adam_t* adam_rule, void* stream);
+/* The catch-up has to come BEFORE a step reads a row (the pending zero-gradient moves are part of the weights the reference's forward
+ * sees): ktup_shard_adam_catchup replays, in ONE launch, the rows ids[k][0 .. n_rows[k]) of table k for up to KTUP_SHARD_ADAM_MAX_SEG
+ * tables (owner-local row numbers, DISTINCT within a segment, negative = padding; ids == NULL or ids[k] == NULL: rows 0 .. n_rows[k] - 1)
+ * up to *step -- after the route has named the step's distinct rows, before the pack launch / the step kernel gathers them.  The apply
+ * launch of the step then finds last == step - 1 on every row it touches.                                                       */
+#define KTUP_SHARD_ADAM_MAX_SEG 8
+int ktup_shard_adam_catchup(int n_seg, float* const* tables, const int64_t* ld, float* const* states, const int64_t* lds,
+                            const int64_t* const* ids, const int64_t* n_rows, int d, float lr, float eps,
+                            const ktup_adam_t* adam_rule, void* stream);
 int ktup_shard_apply(int kind, int n_tables, float* const* tables, const int64_t* ld, float* const* states, const int64_t* lds,
                      const int64_t* cap, int d, const int64_t* ids, int64_t n_blocks, float* grads, int64_t ldg, int n_small,
                      int small_rows, float* const* small_grads, float* const* small_p0, float* const* small_s0,

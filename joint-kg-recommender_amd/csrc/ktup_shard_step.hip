@@ -902,18 +902,33 @@ __global__ void step_count_kernel(int64_t* step, const int32_t* skip_i, const do
   }
 }
 
+// Rows of up to KTUP_SHARD_ADAM_MAX_SEG tables brought up to step *r.step (zero-gradient steps replayed): segment k = rows ids[k][0 .. n[k])
+// of table k (negative ids: padding), or rows 0 .. n[k] - 1 when ids[k] is null.  The ids of a segment are DISTINCT.
+struct CatchupArgs {
+  int n_seg; float* tab[KTUP_SHARD_ADAM_MAX_SEG]; int64_t ldt[KTUP_SHARD_ADAM_MAX_SEG]; float* st[KTUP_SHARD_ADAM_MAX_SEG];
+  int64_t lds[KTUP_SHARD_ADAM_MAX_SEG]; const int64_t* ids[KTUP_SHARD_ADAM_MAX_SEG]; int64_t end[KTUP_SHARD_ADAM_MAX_SEG];   // end: prefix sums of n
+  int nch; float lr, eps; AdamRule r;
+};
+
 template <int GL, int CPL>
-__global__ __launch_bounds__(256) void adam_flush_kernel(float* table, int64_t ldt, float* state, int64_t lds, int nch, int64_t n_rows, float lr,
-                                                         float eps, AdamRule r) {
+__global__ __launch_bounds__(256) void adam_catchup_kernel(CatchupArgs a) {
   constexpr int GPB = 256 / GL;
   const int lane = threadIdx.x % GL;
-  const int t = (int)*r.step;
+  const int t = (int)*a.r.step;
   float4 none[CPL];
 #pragma unroll
   for (int j = 0; j < CPL; ++j) none[j] = f4zero();
-  for (int64_t row = (int64_t)blockIdx.x * GPB + threadIdx.x / GL; row < n_rows; row += (int64_t)gridDim.x * GPB)
-    adam_row_mem<GL, CPL>(reinterpret_cast<float4*>(table + row * ldt), reinterpret_cast<float4*>(state + row * lds), nch, lane, none, false, t,
-                          lr, eps, r);
+  const int64_t total = a.end[a.n_seg - 1];
+  for (int64_t e = (int64_t)blockIdx.x * GPB + threadIdx.x / GL; e < total; e += (int64_t)gridDim.x * GPB) {
+    int k = 0;
+#pragma unroll
+    for (int i = 0; i < KTUP_SHARD_ADAM_MAX_SEG - 1; ++i) k += (i < a.n_seg - 1 && e >= a.end[i]) ? 1 : 0;
+    const int64_t pos = e - (k > 0 ? a.end[k - 1] : 0);
+    const int64_t row = a.ids[k] ? a.ids[k][pos] : pos;
+    if (row < 0) continue;
+    adam_row_mem<GL, CPL>(reinterpret_cast<float4*>(a.tab[k] + row * a.ldt[k]), reinterpret_cast<float4*>(a.st[k] + row * a.lds[k]), a.nch, lane,
+                          none, false, t, a.lr, a.eps, a.r);
+  }
 }
 
 }  // namespace
@@ -924,30 +939,47 @@ extern "C" int ktup_shard_step_count(int64_t* step, const int32_t* skip_count, c
   return check_launch("ktup_shard_step_count");
 }
 
-extern "C" int ktup_shard_adam_flush(float* table, int64_t ldt, float* state, int64_t lds, int d, int64_t n_rows, float lr, float eps,
-                                     const ktup_adam_t* adam_rule, void* stream) {
-  const char* name = "ktup_shard_adam_flush";
+extern "C" int ktup_shard_adam_catchup(int n_seg, float* const* tables, const int64_t* ld, float* const* states, const int64_t* lds,
+                                       const int64_t* const* ids, const int64_t* n_rows, int d, float lr, float eps,
+                                       const ktup_adam_t* adam_rule, void* stream) {
+  const char* name = "ktup_shard_adam_catchup";
   if (int e = check_kind(name, KTUP_OPT_ADAM, adam_rule, d)) return e;
-  KTUP_REQUIRE(table && state && n_rows >= 0 && d > 0 && ldt >= d && lds >= KTUP_SHARD_ADAM_STATE_PITCH(d), "%s: null pointer or bad sizes", name);
-  if (ldt % 4 || lds % 4 || !aligned16(table) || !aligned16(state))
-    return set_error(KTUP_ERR_UNSUPPORTED, "%s: needs 16-byte aligned rows", name);
-  if (n_rows == 0) return KTUP_OK;
-  const AdamRule r{adam_rule->beta1, adam_rule->beta2, adam_rule->replay, adam_rule->step};
-  const int nch = d / 4;
-  hipStream_t st = (hipStream_t)stream;
-#define KTUP_AF(GL, CPL)                                                                                                          \
-  {                                                                                                                               \
-    const int grid = grid_for((n_rows + (256 / GL) - 1) / (256 / GL), 256 * 8);                                                   \
-    hipLaunchKernelGGL((adam_flush_kernel<GL, CPL>), dim3(grid), dim3(256), 0, st, table, ldt, state, lds, nch, n_rows, lr, eps, r);  \
-    return check_launch(name);                                                                                                    \
+  KTUP_REQUIRE(n_seg >= 1 && n_seg <= KTUP_SHARD_ADAM_MAX_SEG && tables && ld && states && lds && n_rows && d > 0, "%s: 1..%d segments with their arrays", name,
+               KTUP_SHARD_ADAM_MAX_SEG);
+  CatchupArgs a{};
+  a.n_seg = n_seg;
+  int64_t end = 0;
+  for (int k = 0; k < n_seg; ++k) {
+    KTUP_REQUIRE(tables[k] && states[k] && n_rows[k] >= 0 && ld[k] >= d && lds[k] >= KTUP_SHARD_ADAM_STATE_PITCH(d), "%s: segment %d: null pointer or bad sizes", name, k);
+    if (ld[k] % 4 || lds[k] % 4 || !aligned16(tables[k]) || !aligned16(states[k])) return set_error(KTUP_ERR_UNSUPPORTED, "%s: needs 16-byte aligned rows", name);
+    a.tab[k] = tables[k]; a.ldt[k] = ld[k]; a.st[k] = states[k]; a.lds[k] = lds[k]; a.ids[k] = ids ? ids[k] : nullptr;
+    end += n_rows[k]; a.end[k] = end;
   }
-  if (nch <= 16) KTUP_AF(16, 1)
-  if (nch <= 32) KTUP_AF(32, 1)
-  if (nch <= 64) KTUP_AF(64, 1)
-  if (nch <= 128) KTUP_AF(64, 2)
-  if (nch <= 256) KTUP_AF(64, 4)
+  if (end == 0) return KTUP_OK;
+  a.nch = d / 4; a.lr = lr; a.eps = eps;
+  a.r = AdamRule{adam_rule->beta1, adam_rule->beta2, adam_rule->replay, adam_rule->step};
+  hipStream_t st = (hipStream_t)stream;
+#define KTUP_AF(GL, CPL)                                                                                   \
+  {                                                                                                        \
+    const int grid = grid_for((end + (256 / GL) - 1) / (256 / GL), 256 * 8);                               \
+    hipLaunchKernelGGL((adam_catchup_kernel<GL, CPL>), dim3(grid), dim3(256), 0, st, a);                   \
+    return check_launch(name);                                                                             \
+  }
+  if (a.nch <= 16) KTUP_AF(16, 1)
+  if (a.nch <= 32) KTUP_AF(32, 1)
+  if (a.nch <= 64) KTUP_AF(64, 1)
+  if (a.nch <= 128) KTUP_AF(64, 2)
+  if (a.nch <= 256) KTUP_AF(64, 4)
 #undef KTUP_AF
   return set_error(KTUP_ERR_UNSUPPORTED, "%s: embedding_size %d too large", name, d);
+}
+
+extern "C" int ktup_shard_adam_flush(float* table, int64_t ldt, float* state, int64_t lds, int d, int64_t n_rows, float lr, float eps,
+                                     const ktup_adam_t* adam_rule, void* stream) {
+  float* tabs[1] = {table}; float* sts[1] = {state};
+  const int64_t l1[1] = {ldt}, l2[1] = {lds}, n[1] = {n_rows};
+  KTUP_REQUIRE(table && state, "ktup_shard_adam_flush: null pointer");
+  return ktup_shard_adam_catchup(1, tabs, l1, sts, l2, nullptr, n, d, lr, eps, adam_rule, stream);
 }
 
 extern "C" size_t ktup_shard_route_workspace_bytes(int64_t n_entries) {

@@ -177,6 +177,19 @@ class _ShardedStepBase(object):
             graphs.append(graph)
         self._graphs, self._graph_keep = graphs, keeps
 
+    def _catchup(self, ids, caps, adam, stream, arr):
+        """Adam: the launch that brings the step's rows up to date BEFORE anything reads them (ktup_shard_adam_catchup): the distinct
+        owner-local rows `ids` = [caps[0] of table 0 | caps[1] of table 1 | ...] the route named (negative = unused slot), and every
+        row of the small tables (pref / pref_norm rest during the kg steps and are read again by the next rec step)."""
+        tabs = [t.weight.data for t in self.tables] + [p.data for p in self.small]
+        sts = [t.state for t in self.tables] + list(self.small_state)
+        offs = [sum(caps[:k]) for k in range(len(caps))]
+        idp = [ids.data_ptr() + 8 * o for o in offs] + [None] * len(self.small)
+        ns = list(caps) + [p.shape[0] for p in self.small]
+        return L.bind('ktup_shard_adam_catchup', len(tabs), arr(_ptrs(tabs)), arr(_i64s([w.stride(0) for w in tabs])), arr(_ptrs(sts)),
+                      arr(_i64s([x.stride(0) for x in sts])), arr((ctypes.c_void_p * len(idp))(*idp)), arr(_i64s(ns)), self.d, self.lr, self.eps,
+                      adam, stream)
+
     def flush(self):
         """Adam: bring EVERY row of this stepper's shards and small tables up to the current step (the zero-gradient steps a row has not
         been touched for; ktup_shard_adam_flush), so that what an evaluation, a gather or a checkpoint reads is what the reference's
@@ -423,6 +436,9 @@ class ShardedKtupStepper(_ShardedStepBase):
                 tail = [rnorm] + count + [rapply]
             else:
                 tail = [reduce_, gnorm] + count + [apply_]
+            if adam:                                         # the whole route, then the catch-up of the rows it named, then whoever reads them
+                catch = self._catchup(self.send_ids, self.cap, adam, stream, arr)
+                return [([route, catch, step] if self.direct else [route, catch, pack, step]) + tail]
             if beside:
                 return [[('beside', [step], [route_phase(3, side)]), ('join',)] + tail]
             if self.direct and side is not None:
@@ -452,7 +468,13 @@ class ShardedKtupStepper(_ShardedStepBase):
                           _p(self.own_sort), W, _p(self.Gown), d, _p(self.own_xkeys), n_small, P, sgp, sp0p, ss0p, sp1p, ss1p,
                           _p(self.bucket), self.lr, self.eps, self.acc.data_ptr() + 8 * SLOTS, 1, self.max_norm, None,
                           self.bucket.data_ptr() + 8 * (N + 1), *close, adam, stream)
+            if adam:    # the owner's route of the requested rows moves in front of the pack launch: the catch-up needs its DISTINCT rows
+                catch = self._catchup(self.own_ids, self.cap_own, adam, stream, arr)
+                return [[route], [oroute, catch, pack], [step, reduce_], [zero, onorm, pack_b], [fin_b] + count + [oapply]]
             return [[route], [pack], [step, reduce_], [zero, oroute, onorm, pack_b], [fin_b] + count + [oapply]]
+        if adam:
+            catch = self._catchup(self.own_ids, self.cap_own, adam, stream, arr)
+            return [[route], [oroute, catch, pack], [step, reduce_], [zero, oreduce, gnorm, pack_b], [fin_b] + count + [apply_]]
         return [[route], [pack], [step, reduce_], [zero, oroute, oreduce, gnorm, pack_b], [fin_b] + count + [apply_]]
 
     # ------------------------------------------------------------------------------------------------ the step
@@ -636,6 +658,9 @@ class ShardedKgStepper(_ShardedStepBase):
                           _p(self.sort_ws), E, _p(self.Gwire), d, _p(self.xkeys), n_small, P, sgp, sp0p, ss0p, None, None, None, self.lr,
                           self.eps, _p(self.acc), SLOTS, self.max_norm, skip_i, None, *close, adam, stream)
             count = [bind('ktup_shard_step_count', _p(self.opt_step), skip_i, None, stream)] if adam else []
+            if adam:
+                catch = self._catchup(self.send_ids, self.cap, adam, stream, arr)
+                return [[route_phase(0, stream), catch] + ([] if self.direct else [pack]) + [order, step, rnorm] + count + [rapply]]
             if self.direct and side is not None:
                 return [[route_phase(1, stream), ('beside', [order, step], [route_phase(2, side)]), ('join',), rnorm] + count + [rapply]]
             return [[route_phase(0, stream)] + ([] if self.direct else [pack]) + [order, step, rnorm] + count + [rapply]]
@@ -656,6 +681,9 @@ class ShardedKgStepper(_ShardedStepBase):
                       self.lr, self.eps, self.acc.data_ptr() + 8 * SLOTS, 1, self.max_norm, None, self.bucket.data_ptr() + 8 * (N + 1),
                       *close, adam, stream)
         count = [bind('ktup_shard_step_count', _p(self.opt_step), None, self.bucket.data_ptr() + 8 * (N + 1), stream)] if adam else []
+        if adam:
+            catch = self._catchup(self.own_ids, self.cap_own, adam, stream, arr)
+            return [[route_phase(0, stream)], [oroute, catch, pack], [order, step, reduce_], [zero, onorm, pack_b], [fin_b] + count + [oapply]]
         return [[route_phase(0, stream)], [pack], [order, step, reduce_], [zero, oroute, onorm, pack_b], [fin_b] + count + [oapply]]
 
     def load_batch(self, ph, pt, pr, nh, nt, nr):

@@ -369,6 +369,12 @@ int ktup_eval_gold_rank_counts(const float* scores, int64_t lds, int64_t nq, int
                                int descending, const int64_t* filt_off, const int32_t* filt_ids,
                                const int64_t* gold_off, const int32_t* gold_ids, const float* gold_scores,
                                int32_t* counts, void* stream);
+/* the same for a shard that is a LATTICE of the catalogue: local candidate j has the global id cand_lo + cand_stride * j (the rows
+ * g % world == rank of a table sharded by row: cand_lo = rank, cand_stride = world) -- evaluation straight from the shards of -shard_tables */
+int ktup_eval_gold_rank_counts_strided(const float* scores, int64_t lds, int64_t nq, int64_t n_local, int64_t cand_lo,
+                                       int64_t cand_stride, int descending, const int64_t* filt_off, const int32_t* filt_ids,
+                                       const int64_t* gold_off, const int32_t* gold_ids, const float* gold_scores,
+                                       int32_t* counts, void* stream);
 
 /* K18b  utils/misc.py:232-248 + utils/evaluation.py:80-110 (ndcg_at_k, method 0): per query (f1, precision, recall,
  * hit, ndcg) as 5 float64 from its ranked id list (`topn` entries, -1 padded as ktup_eval_topk_filtered writes them)

@@ -470,7 +470,7 @@ extern "C" int ktup_eval_gold_ranks(const float* scores, int64_t lds, int64_t nq
 constexpr int32_t FILTERED_GOLD = -(1 << 20);
 
 __global__ __launch_bounds__(256) void gold_rank_counts_kernel(const float* __restrict__ scores, int64_t lds, int64_t n_local, int64_t c_lo,
-                                                               int descending, const int64_t* __restrict__ filt_off,
+                                                               int64_t c_stride, int descending, const int64_t* __restrict__ filt_off,
                                                                const int32_t* __restrict__ filt_ids,
                                                                const int64_t* __restrict__ gold_off,
                                                                const int32_t* __restrict__ gold_ids,
@@ -493,15 +493,19 @@ __global__ __launch_bounds__(256) void gold_rank_counts_kernel(const float* __re
   for (int64_t c0 = 0; c0 < n_local; c0 += CH) {
     const int len = (int)min((int64_t)CH, n_local - c0);
     __syncthreads();
-    for (int j = threadIdx.x; j < len; j += 256) keys[j] = make_key(row[c0 + j], descending != 0, (uint32_t)(c_lo + c0 + j));
+    // local candidate j has the global id c_lo + c_stride * j (c_stride = 1: a contiguous block; = world: rows g % world == rank of a
+    // row-sharded table); a listed id lies in this shard when it is on that lattice
+    for (int j = threadIdx.x; j < len; j += 256) keys[j] = make_key(row[c0 + j], descending != 0, (uint32_t)(c_lo + c_stride * (c0 + j)));
     __syncthreads();
     for (int64_t f = threadIdx.x; f < nf; f += 256) {                  // filtered candidates and the golds themselves do not count
-      const int64_t id = (int64_t)fids[f] - c_lo - c0;
-      if (id >= 0 && id < len) keys[id] = KEY_MAX;
+      const int64_t off = (int64_t)fids[f] - c_lo;
+      const int64_t id = off / c_stride - c0;
+      if (off >= 0 && off % c_stride == 0 && id >= 0 && id < len) keys[id] = KEY_MAX;
     }
     for (int64_t o = g0 + threadIdx.x; o < g1; o += 256) {
-      const int64_t id = (int64_t)gold_ids[o] - c_lo - c0;
-      if (id >= 0 && id < len) keys[id] = KEY_MAX;
+      const int64_t off = (int64_t)gold_ids[o] - c_lo;
+      const int64_t id = off / c_stride - c0;
+      if (off >= 0 && off % c_stride == 0 && id >= 0 && id < len) keys[id] = KEY_MAX;
     }
     __syncthreads();
     for (int64_t gi = g0; gi < g1; ++gi) {
@@ -524,17 +528,25 @@ extern "C" int ktup_eval_gold_rank_counts(const float* scores, int64_t lds, int6
                                           int descending, const int64_t* filt_off, const int32_t* filt_ids,
                                           const int64_t* gold_off, const int32_t* gold_ids, const float* gold_scores,
                                           int32_t* counts, void* stream) {
+  return ktup_eval_gold_rank_counts_strided(scores, lds, nq, n_local, cand_lo, 1, descending, filt_off, filt_ids, gold_off, gold_ids, gold_scores,
+                                            counts, stream);
+}
+
+extern "C" int ktup_eval_gold_rank_counts_strided(const float* scores, int64_t lds, int64_t nq, int64_t n_local, int64_t cand_lo,
+                                                  int64_t cand_stride, int descending, const int64_t* filt_off, const int32_t* filt_ids,
+                                                  const int64_t* gold_off, const int32_t* gold_ids, const float* gold_scores,
+                                                  int32_t* counts, void* stream) {
   const char* name = "ktup_eval_gold_rank_counts";
-  KTUP_REQUIRE(nq >= 0 && n_local >= 0 && cand_lo >= 0 && (n_local == 0 || lds >= n_local), "%s: bad sizes", name);
+  KTUP_REQUIRE(nq >= 0 && n_local >= 0 && cand_lo >= 0 && cand_stride >= 1 && (n_local == 0 || lds >= n_local), "%s: bad sizes", name);
   if (nq == 0) return KTUP_OK;
   KTUP_REQUIRE((scores || n_local == 0) && gold_off && gold_ids && gold_scores && counts && ((filt_off == nullptr) || filt_ids),
                "%s: null pointer argument", name);
-  KTUP_REQUIRE(cand_lo + n_local <= 0x7fffffffll, "%s: candidate ids are 32-bit", name);
+  KTUP_REQUIRE(cand_lo + cand_stride * n_local <= 0x7fffffffll + cand_stride, "%s: candidate ids are 32-bit", name);
   const int ch = (int)(n_local < 1 ? 64 : (n_local < CHUNK_KEYS ? ((n_local + 63) & ~63ll) : CHUNK_KEYS));
   const size_t lbytes = (size_t)ch * 8;
   allow_lds((const void*)gold_rank_counts_kernel, lbytes);
   hipLaunchKernelGGL(gold_rank_counts_kernel, dim3((unsigned)nq), dim3(256), lbytes, (hipStream_t)stream, scores, lds, n_local, cand_lo,
-                     descending, filt_off, filt_ids, gold_off, gold_ids, gold_scores, ch, counts);
+                     cand_stride, descending, filt_off, filt_ids, gold_off, gold_ids, gold_scores, ch, counts);
   return check_launch(name);
 }
 

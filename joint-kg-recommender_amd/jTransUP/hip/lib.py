@@ -88,6 +88,7 @@ SIGNATURES = {
                                  c_p, c_p, c_p],
     'ktup_eval_topk_filtered': [c_p, c_l, c_l, c_l, c_i, c_p, c_p, c_i, c_p, c_p, c_p],
     'ktup_eval_gold_rank_counts': [c_p, c_l, c_l, c_l, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
+    'ktup_eval_gold_rank_counts_strided': [c_p, c_l, c_l, c_l, c_l, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
     'ktup_eval_gold_ranks': [c_p, c_l, c_l, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_p],
     'ktup_eval_kg_ranks_workspace_bytes': [c_i, c_l, c_l],
     'ktup_eval_kg_ranks': [c_i, c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_p, c_l, c_l, c_p, c_p, c_l, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_l,

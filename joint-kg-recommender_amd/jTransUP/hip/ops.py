@@ -717,9 +717,10 @@ def gold_ranks(scores, descending, gold_off, gold_ids, filt_off=None, filt_ids=N
 
 
 @torch.no_grad()
-def gold_rank_counts(local_scores, cand_lo, descending, gold_off, gold_ids, gold_scores, filt_off=None, filt_ids=None):
+def gold_rank_counts(local_scores, cand_lo, descending, gold_off, gold_ids, gold_scores, filt_off=None, filt_ids=None, cand_stride=1):
     """Per gold entry: this candidate shard's unfiltered non-gold candidates ordered before it (ktup_eval_gold_rank_counts);
-    all-reduce(sum) over the shards gives the rank (negative -> the gold is itself filtered -> -1)."""
+    all-reduce(sum) over the shards gives the rank (negative -> the gold is itself filtered -> -1).  Local candidate j has the global
+    id cand_lo + cand_stride * j."""
     dev = _dev(local_scores)
     if local_scores.dtype != torch.float32 or local_scores.dim() != 2 or (local_scores.shape[1] and local_scores.stride(1) != 1):
         raise L.KtupError('scores must be a 2-D fp32 device matrix with unit inner stride')
@@ -727,8 +728,8 @@ def gold_rank_counts(local_scores, cand_lo, descending, gold_off, gold_ids, gold
     if filt_ids is not None and filt_ids.numel() == 0:
         filt_off = filt_ids = None
     counts = torch.empty(gold_ids.numel(), dtype=torch.int32, device=dev)
-    L.call('ktup_eval_gold_rank_counts', _p(local_scores) if nl else None, local_scores.stride(0) if nl else 0, nq, nl, int(cand_lo),
-           int(bool(descending)), _p(filt_off), _p(filt_ids), _p(gold_off), _p(gold_ids), _p(gold_scores.contiguous()), _p(counts),
+    L.call('ktup_eval_gold_rank_counts_strided', _p(local_scores) if nl else None, local_scores.stride(0) if nl else 0, nq, nl, int(cand_lo),
+           int(cand_stride), int(bool(descending)), _p(filt_off), _p(filt_ids), _p(gold_off), _p(gold_ids), _p(gold_scores.contiguous()), _p(counts),
            _stream(dev))
     return counts
 

@@ -119,8 +119,22 @@ def _gather_batches(per_batch, n_batches, world):
 def _shard_mode(FLAGS, shard, want_rows):
     """Candidate-sharded evaluation applies under torchrun with -shard_eval_candidates, for models with a sliceable candidate
     table, on the training-time path (metric columns only; the per-user report rows keep the whole-batch route)."""
+    if shard is not None and len(shard) == 3 and not want_rows:
+        return True                                  # -shard_tables: the candidates are the rows a rank owns, whatever the world size
     return shard is not None and not want_rows and getattr(FLAGS, 'shard_eval_candidates', False) \
         and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def _shard_layout(shard):
+    """(candidate scores of a batch, global id of local candidate 0, id stride) -- a contiguous block [lo, hi) of the catalogue
+    (models/_shard_eval.py: whole tables on every rank), or the lattice rank + world * j (utils/sharded_train.py: row-sharded tables)."""
+    from jTransUP import parallel
+    if len(shard) == 3:
+        n_cand, fn, (_, rank, world) = shard
+        return fn, rank, world
+    n_cand, fn = shard
+    lo, hi = parallel.shard_bounds(n_cand, dist.get_rank(), dist.get_world_size())
+    return (lambda *a: fn(*a, lo, hi)), lo, 1
 
 
 def _rec_eval_sharded(FLAGS, shard, eval_iter, index, descending):
@@ -128,13 +142,12 @@ def _rec_eval_sharded(FLAGS, shard, eval_iter, index, descending):
     filtered top-n lists are merged (parallel.sharded_topk); the metric columns are then identical on every rank."""
     from jTransUP import parallel
     from jTransUP.hip import ops
-    n_cand, fn = shard
-    lo, hi = parallel.shard_bounds(n_cand, dist.get_rank(), dist.get_world_size())
+    fn, lo, stride = _shard_layout(shard)
     cols = []
     for u_ids in eval_iter:
         s, e = index.rows_of(u_ids)
         f_off, f_ids = index.filter_slice(s, e)
-        top, _ = parallel.sharded_topk(fn(batch_ids(u_ids), lo, hi), lo, FLAGS.topn, descending, f_off, f_ids)
+        top, _ = parallel.sharded_topk(fn(batch_ids(u_ids)), lo, FLAGS.topn, descending, f_off, f_ids, stride=stride)
         g_off, g_ids = index.gold_slice(s, e)[:2]
         cols.append(ops.rec_metrics(top.to(torch.int32).contiguous(), g_off, g_ids))
     host = torch.cat(cols).cpu().numpy() if cols else np.zeros((0, 5))
@@ -145,8 +158,7 @@ def _rec_eval_sharded(FLAGS, shard, eval_iter, index, descending):
 def _kg_eval_sharded(FLAGS, shard, eval_iter, index, descending, remap):
     """kg_eval_pass with the entity catalogue split over the ranks: per-shard rank counts, all-reduced (parallel.sharded_gold_ranks)."""
     from jTransUP import parallel
-    n_cand, fn = shard
-    lo, hi = parallel.shard_bounds(n_cand, dist.get_rank(), dist.get_world_size())
+    fn, lo, stride = _shard_layout(shard)
     out = []
     for batch in eval_iter:
         q = ids([k[0] if remap is None else remap[k[0]] for k in batch])
@@ -159,7 +171,7 @@ def _kg_eval_sharded(FLAGS, shard, eval_iter, index, descending, remap):
         if n == 0:
             continue
         g_rows = torch.repeat_interleave(torch.arange(len(keys), device=DEV), (g_off[1:] - g_off[:-1]))
-        out.append(parallel.sharded_gold_ranks(fn(q, r, lo, hi), lo, descending, g_off, g_ids, g_rows, f_off, f_ids))
+        out.append(parallel.sharded_gold_ranks(fn(q, r), lo, descending, g_off, g_ids, g_rows, f_off, f_ids, stride=stride))
     ranks = torch.cat(out).cpu().numpy() if out else np.zeros(0, np.int32)
     ranks = ranks[ranks >= 0]
     return np.stack([(ranks < FLAGS.topn).astype(np.float64), ranks.astype(np.float64)], axis=1)

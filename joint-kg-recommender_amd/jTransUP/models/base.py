@@ -58,7 +58,10 @@ FLAG_TABLE = [
                                              '(top-n lists merged, KG rank counts all-reduced) instead of whole batches being dealt to the ranks'),
     ('shard_tables', 'bool', False, 'jtransup with its own tables: the user / item / entity tables and their Adagrad sums are partitioned by row over '
                                     'the ranks (row % world) and a step exchanges only the rows its batch touches (BASELINE config 5; one process: the '
-                                    'same row-sparse step without an exchange); needs -optimizer_type Adagrad (or SGD -momentum 0) and -l2_lambda 0'),
+                                    'same row-sparse step without an exchange); needs -optimizer_type Adagrad, Adam or SGD -momentum 0, and -l2_lambda 0; '
+                                    'the shards are the only resident copy: evaluation runs on them'),
+    ('shard_whole_checkpoint', 'bool', True, '-shard_tables: besides the per-rank shard files write the reference-layout whole-table checkpoint (tables '
+                                             'gathered transiently); -noshard_whole_checkpoint: shard files only'),
     # files
     ('data_path', 'str', None, 'root of the datasets'),
     ('log_path', 'str', None, 'logs (and, by default, checkpoints)'),

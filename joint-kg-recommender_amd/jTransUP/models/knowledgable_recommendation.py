@@ -59,8 +59,12 @@ def evaluateRec(FLAGS, model, eval_iter, eval_dict, all_dicts, i_map, logger, ev
     # the whole-pass route prepares its own item side, so that a captured pass (D._rec_eval_fused) recomputes it from the tables
     pass_fn = (lambda u, fo, fi, n: model.evaluate_topk(u, model.prepare_items(), n, fo, fi)) \
         if has_items and hasattr(model, 'evaluate_topk') and not FLAGS.share_embeddings else None
-    results = D.rec_eval_pass(FLAGS, score_fn, eval_iter, eval_dict, all_dicts, eval_descending, want_rows=is_report,
-                              shard=rec_shard_fn(model), pass_fn=pass_fn, graph_key=D.model_graph_key(model) if pass_fn else None)
+    native = getattr(model, '_shard_native', None)             # -shard_tables: the candidates are the rows this rank owns
+    if native is not None and not is_report:
+        results = D.rec_eval_pass(FLAGS, None, eval_iter, eval_dict, all_dicts, eval_descending, want_rows=False, shard=native.rec_shard())
+    else:
+        results = D.rec_eval_pass(FLAGS, score_fn, eval_iter, eval_dict, all_dicts, eval_descending, want_rows=is_report,
+                                  shard=rec_shard_fn(model), pass_fn=pass_fn, graph_key=D.model_graph_key(model) if pass_fn else None)
     perf = D.summarize_rec(FLAGS, results, logger)
     if is_report:
         D.report_rec(FLAGS, model, results, all_dicts, eval_dict, logger, FLAGS.model_type in ('transup', 'jtransup'))
@@ -78,12 +82,19 @@ def evaluateKG(FLAGS, model, eval_head_iter, eval_tail_iter, eval_head_dict, eva
     # jTransUP / CFKG: the whole pass -- scores and filtered gold ranks -- behind one call per direction (model.rank_entities)
     rank = (lambda head: (lambda q, r, desc, go, gi, fo, fi: model.rank_entities(q, r, head, desc, go, gi, fo, fi, all_e_ids=all_e_var))) \
         if hasattr(model, 'rank_entities') else (lambda head: None)
-    head_results = D.kg_eval_pass(FLAGS, lambda t, r: model.evaluateHead(t, r, all_e_ids=all_e_var, **kw), eval_head_iter, eval_head_dict,
-                                  all_head_dicts, eval_descending, remap=remap, want_rows=is_report, shard=kg_shard_fn(model, True),
-                                  rank_fn=rank(True))
-    tail_results = D.kg_eval_pass(FLAGS, lambda h, r: model.evaluateTail(h, r, all_e_ids=all_e_var, **kw), eval_tail_iter, eval_tail_dict,
-                                  all_tail_dicts, eval_descending, remap=remap, want_rows=is_report, shard=kg_shard_fn(model, False),
-                                  rank_fn=rank(False))
+    native = getattr(model, '_shard_native', None)
+    if native is not None and not is_report:
+        head_results = D.kg_eval_pass(FLAGS, None, eval_head_iter, eval_head_dict, all_head_dicts, eval_descending, remap=remap, want_rows=False,
+                                      shard=native.kg_shard(True))
+        tail_results = D.kg_eval_pass(FLAGS, None, eval_tail_iter, eval_tail_dict, all_tail_dicts, eval_descending, remap=remap, want_rows=False,
+                                      shard=native.kg_shard(False))
+    else:
+        head_results = D.kg_eval_pass(FLAGS, lambda t, r: model.evaluateHead(t, r, all_e_ids=all_e_var, **kw), eval_head_iter, eval_head_dict,
+                                      all_head_dicts, eval_descending, remap=remap, want_rows=is_report, shard=kg_shard_fn(model, True),
+                                      rank_fn=rank(True))
+        tail_results = D.kg_eval_pass(FLAGS, lambda h, r: model.evaluateTail(h, r, all_e_ids=all_e_var, **kw), eval_tail_iter, eval_tail_dict,
+                                      all_tail_dicts, eval_descending, remap=remap, want_rows=is_report, shard=kg_shard_fn(model, False),
+                                      rank_fn=rank(False))
     perf = D.summarize_kg(FLAGS, head_results, tail_results, logger)
     if is_report:
         D.report_kg(head_results, tail_results, logger)
@@ -147,7 +158,10 @@ def train_loop(FLAGS, model, trainer, rating_train_dataset, triple_train_dataset
 
     def do_eval(totals):
         if sharded:
-            stepper.sync_model()                           # the evaluation reads whole tables: gather the shards
+            if is_report:
+                stepper.sync_model()                       # the per-user report walks whole tables: gathered for this pass only
+            else:
+                stepper.begin_eval()                       # evaluation ON the shards: flush (Adam), the items' entity rows
         rec_loss = totals['rec'] / (FLAGS.eval_interval_steps * FLAGS.joint_ratio)
         kg_loss = totals['kg'] / (FLAGS.eval_interval_steps * (1 - FLAGS.joint_ratio)) if FLAGS.joint_ratio < 1 else 0.0
         logger.info('rec train loss:{:.4f}, kg train loss:{:.4f}!'.format(rec_loss, kg_loss))
@@ -175,6 +189,10 @@ def train_loop(FLAGS, model, trainer, rating_train_dataset, triple_train_dataset
                     vis.plot_many_stack({'KG Eval {} Hit'.format(i): p[0] for i, p in enumerate(kg_perfs)},
                                         win_name='KG Hit Ratio@{}'.format(FLAGS.topn))
                     vis.plot_many_stack({'KG Eval {} MeanRank'.format(i): p[1] for i, p in enumerate(kg_perfs)}, win_name='KG MeanRank')
+        if sharded:
+            stepper.end_eval()
+            if is_report:
+                stepper.release_model()
         return rec_perfs
 
     cycle10 = tuple('rec' if k < step_to_switch else 'kg' for k in range(10))

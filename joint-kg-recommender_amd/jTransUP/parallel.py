@@ -487,30 +487,34 @@ def _local_topk_hip(local_scores, descending, topn, f_off, f_ids_local):
     return ops.topk_filtered(local_scores, descending, topn, f_off, f_ids_local, with_scores=True)
 
 
-def _local_counts_hip(local_scores, lo, descending, g_off, g_ids, gold_scores, f_off, f_ids):
+def _local_counts_hip(local_scores, lo, descending, g_off, g_ids, gold_scores, f_off, f_ids, stride=1):
     from jTransUP.hip import ops
-    return ops.gold_rank_counts(local_scores, lo, descending, g_off, g_ids, gold_scores, f_off, f_ids)
+    return ops.gold_rank_counts(local_scores, lo, descending, g_off, g_ids, gold_scores, f_off, f_ids, cand_stride=stride)
 
 
 @torch.no_grad()
-def sharded_topk(local_scores, lo, topn, descending, f_off=None, f_ids=None, group=None, local_topk=None):
+def sharded_topk(local_scores, lo, topn, descending, f_off=None, f_ids=None, group=None, local_topk=None, stride=1):
     """Filtered top-n of a catalogue sharded over the ranks (utils/misc.py:213-248 on the union of the shards).
-    local_scores: (nq, n_local) scores of candidates [lo, lo + n_local); f_off / f_ids: the filter sets as CSR with GLOBAL
-    candidate ids (ids outside the shard are ignored by the ranking kernel).  Every rank returns the same (nq, topn) global ids
+    local_scores: (nq, n_local) scores of candidates lo + stride * j, j in [0, n_local) (stride 1: a contiguous block; stride = world,
+    lo = rank: the rows of a table sharded by `row % world`, whose order within the shard is the global id order, so ties fall the
+    same way); f_off / f_ids: the filter sets as CSR with GLOBAL candidate ids (ids outside the shard are ignored by the ranking kernel).  Every rank returns the same (nq, topn) global ids
     (-1 padded) and scores: local filtered top-n -> all-gather of (score, id) -> merge under the same (score, id) order."""
     local_topk = local_topk or _local_topk_hip
     if local_scores.shape[1] == 0:
         ids = torch.full((local_scores.shape[0], topn), -1, dtype=torch.int32, device=local_scores.device)
         sc = torch.zeros(local_scores.shape[0], topn, dtype=torch.float32, device=local_scores.device)
     else:
-        fl = None if f_ids is None else (f_ids.to(torch.int64) - lo).to(torch.int32)
+        fl = None
+        if f_ids is not None:
+            off = f_ids.to(torch.int64) - lo
+            fl = (off if stride == 1 else torch.where(off % stride == 0, torch.div(off, stride, rounding_mode='floor'), torch.full_like(off, -1))).to(torch.int32)
         ids, sc = local_topk(local_scores, descending, topn, f_off, fl)
-        ids = torch.where(ids >= 0, ids + int(lo), ids)
+        ids = torch.where(ids >= 0, ids * int(stride) + int(lo), ids)
     return merge_topk(ids, sc, topn, descending=descending, group=group)
 
 
 @torch.no_grad()
-def sharded_gold_ranks(local_scores, lo, descending, g_off, g_ids, g_rows, f_off=None, f_ids=None, group=None, local_counts=None):
+def sharded_gold_ranks(local_scores, lo, descending, g_off, g_ids, g_rows, f_off=None, f_ids=None, group=None, local_counts=None, stride=1):
     """0-based filtered ranks of the gold ids (utils/misc.py:125-146) when every rank holds the scores of one candidate shard
     [lo, lo + n_local).  g_off / g_ids: gold CSR (global ids), g_rows: the query row of every gold entry (int64, len(g_ids));
     -> int32 ranks per gold entry on every rank (-1: the gold is itself filtered).  Two small collectives: the golds' own
@@ -519,6 +523,8 @@ def sharded_gold_ranks(local_scores, lo, descending, g_off, g_ids, g_rows, f_off
     n_local = local_scores.shape[1]
     n = g_rows.numel()
     col = g_ids[:n].to(torch.int64) - lo
+    if stride != 1:                                          # a lattice shard: candidate lo + stride * j is local column j
+        col = torch.where(col % stride == 0, torch.div(col, stride, rounding_mode='floor'), torch.full_like(col, -1))
     mine = (col >= 0) & (col < n_local)
     gold_scores = torch.zeros(n, dtype=torch.float32, device=local_scores.device)
     if n_local and bool(n):
@@ -526,7 +532,8 @@ def sharded_gold_ranks(local_scores, lo, descending, g_off, g_ids, g_rows, f_off
         gold_scores[mine] = picked
     if _exchanging(group):
         _all_reduce(gold_scores, group)
-    counts = local_counts(local_scores, lo, descending, g_off, g_ids, gold_scores, f_off, f_ids)[:n].clone()
+    counts = (local_counts(local_scores, lo, descending, g_off, g_ids, gold_scores, f_off, f_ids) if stride == 1 else
+              local_counts(local_scores, lo, descending, g_off, g_ids, gold_scores, f_off, f_ids, stride=stride))[:n].clone()
     if _exchanging(group):
         _all_reduce(counts, group)
     return torch.where(counts < 0, torch.full_like(counts, -1), counts)

@@ -12,10 +12,17 @@ What the rows' owners do NOT keep is a dense gradient or a dense optimizer pass:
 equals the reference's dense step exactly for Adagrad / plain SGD without weight decay (l2_lambda = 0) -- other settings are
 refused by name.  Every rank draws the same global batches (same -seed, like the replicated route) and takes its slice.
 
-Evaluation and checkpoints see whole tables: before either, the shards are gathered into the model's own parameters
-(`sync_model`, one all-gather per table), so evaluateRec / evaluateKG (with -shard_eval_candidates: every rank scores its slice of
-the catalogue) and ModelTrainer.save run unchanged; next to every checkpoint each rank also writes `<file>.shard<rank>of<world>`
-with its rows AND their Adagrad sums (load_shards restores a run exactly; the whole-table file alone restarts the sums)."""
+Memory: the shards are the ONLY resident copy of the three big tables.  Once they are built the model's own whole tables are released
+(zero-row placeholders) and so is the dense optimizer's state for them; a rank holds rows/world x (table + optimizer state).
+Evaluation runs ON the shards (`rec_shard` / `kg_shard`): a rank's candidates are the rows it owns -- the lattice rank + world * j of the
+catalogue, ranked with the strided forms of parallel.sharded_topk / sharded_gold_ranks (order within a shard = global id order, so
+ties fall as in the whole-table walk) -- the B query rows of a batch come from their owners by one all-reduce of a (B x d) buffer that
+is zero elsewhere, and the entity rows of a rank's items are fetched once per evaluation.  Whole tables exist only transiently:
+for a whole-table checkpoint (`-shard_whole_checkpoint`, on by default so that `-load_experiment_name` / `-eval_only_mode` keep working;
+off: shard files only) and for the per-user report mode, gathered by `sync_model` and released right after.  The whole-table
+checkpoint carries the gathered optimizer state (Adagrad sums / Adam moments) in torch.optim's layout; next to every checkpoint each
+rank writes `<file>.shard<rank>of<world>` with its rows, their optimizer state and the step counter -- a run started with
+`-load_experiment_name <file>` picks its shard file up when there is one (exact resume), else shards the whole tables it loaded."""
 import os
 
 import torch
@@ -91,8 +98,24 @@ class ShardedJointDriver(object):
         self._lr = None
         self._build(float(trainer.learning_rate))
         self.acc = {'rec': 0.0, 'kg': 0.0}
-        self._dirty = False                          # the model's whole tables lag behind the shards
+        self._import_optimizer()                     # a whole-table checkpoint was loaded: its sums / moments go to the shards
+        self._whole = True                           # the model's own big tables are allocated ...
+        self._dirty = False                          # ... and equal the shards
+        self.release_model()
+        if logger is not None:
+            logger.info('The shards are the only resident copy of the big tables: rank %d holds %s of %s user / item / entity rows (and their '
+                        'optimizer state); the model\'s own tables are released.'
+                        % (self.rank, ' / '.join(str(t.weight.shape[0]) for t in self.tables), ' / '.join(str(t.total_rows) for t in self.tables)))
+        self._item_ent = None                        # (n_my_items + 1, d): the entity rows of this rank's items, per evaluation
+        model._shard_native = self                   # models/knowledgable_recommendation.py evaluates on the shards
         self._wrap_trainer()
+        resume = getattr(FLAGS, 'load_experiment_name', None)
+        if resume:
+            path = resume if os.path.isabs(resume) else os.path.join(FLAGS.log_path, resume)
+            if os.path.isfile(self.shard_file(path)):
+                self.load_shards(path)
+                if logger is not None:
+                    logger.info('Restored rank %d\'s shard (rows, optimizer state, step counter) from %s.' % (self.rank, self.shard_file(path)))
 
     def _build(self, lr):
         F = self.FLAGS
@@ -159,16 +182,143 @@ class ShardedJointDriver(object):
         out, self.acc = self.acc, {'rec': 0.0, 'kg': 0.0}
         return out
 
+    # ------------------------------------------------------------------------------------------------ evaluation on the shards
+    @torch.no_grad()
+    def rows_everywhere(self, t, ids):
+        """Rows `ids` (global, int64 device) of sharded table `t` on every rank: each rank fills the rows it owns into a zero buffer,
+        one all-reduce sums them (x + 0 = x exactly)."""
+        buf = torch.zeros(ids.numel(), t.d, dtype=torch.float32, device=self.dev)
+        if self.world == 1:
+            return t.weight.data.index_select(0, ids)
+        mine = (ids % self.world) == self.rank
+        buf[mine] = t.weight.data.index_select(0, torch.div(ids[mine], self.world, rounding_mode='floor'))
+        parallel._all_reduce(buf, self.group)
+        return buf
+
+    @torch.no_grad()
+    def begin_eval(self):
+        """Before an evaluation reads the shards: Adam's pending zero-gradient steps (flush), and the entity rows of this rank's items
+        -- E[item2ent[rank + world j]], the operand jTransUP.py:122-130 adds to the item row -- fetched from their owners once."""
+        self.joint.flush()
+        i2e = self.m._eval_item2ent.long()
+        Et = self.tables[2]
+        mine = None
+        for q in range(self.world):                  # rank q's items need entity rows from everywhere: one summed buffer per rank
+            rows = self.rows_everywhere(Et, i2e[q::self.world].contiguous())
+            if q == self.rank:
+                mine = rows
+        self._item_ent = torch.cat([mine, torch.zeros(1, Et.d, dtype=torch.float32, device=self.dev)])
+
+    def rec_shard(self):
+        """(n_items, f(u_ids) -> (B, n_my_items) scores, ('lattice', rank, world)) for models/_driver.rec_eval_pass: transUP / jTransUP's
+        evaluateRec (jTransUP.py:163-191) with this rank's item rows as the candidates."""
+        from jTransUP.hip import ops
+        m, (Ut, It, Et) = self.m, self.tables
+        P, Pn, R, Rn = [p.data for p in self.small]
+        n_my = It.weight.shape[0]
+        local_map = torch.arange(n_my, dtype=torch.int32, device=self.dev)       # item row j <-> row j of the fetched entity rows
+
+        def f(u_ids):
+            if self._item_ent is None:
+                self.begin_eval()
+            Uq = self.rows_everywhere(Ut, u_ids)
+            q = torch.arange(u_ids.numel(), dtype=torch.int64, device=self.dev)
+            return ops.eval_ktup(Uq, It.weight.data, self._item_ent, P, Pn, R, Rn, local_map, q, m.L1_flag, ops.GUMBEL_OFF, None, 0, 0)
+        return It.total_rows, f, ('lattice', self.rank, self.world)
+
+    def kg_shard(self, head):
+        """(n_entities, f(q_ids, r_ids) -> (B, n_my_entities) scores, lattice): evaluateHead / evaluateTail (jTransUP.py:193-247: TransH
+        over the entity table INCLUDING its pad row) with this rank's entity rows as the candidates."""
+        from jTransUP.hip import ops
+        m, Et = self.m, self.tables[2]
+        R, N = self.small[2].data, self.small[3].data
+
+        def f(q_ids, r_ids):
+            if self._item_ent is None:
+                self.begin_eval()
+            Eq = self.rows_everywhere(Et, q_ids)
+            q = torch.arange(q_ids.numel(), dtype=torch.int64, device=self.dev)
+            return ops.eval_transh(Eq, R, N, q, r_ids, m.L1_flag, head, candidates=Et.weight.data)
+        return Et.total_rows, f, ('lattice', self.rank, self.world)
+
+    def end_eval(self):
+        self._item_ent = None
+
     # ------------------------------------------------------------------------------------------------ whole tables <-> shards
     @torch.no_grad()
     def sync_model(self):
-        """Gather every shard into the model's whole tables (before an evaluation or a checkpoint)."""
-        if not self._dirty:
+        """Gather every shard into the model's whole tables -- TRANSIENTLY, for a whole-table checkpoint or the per-user report mode;
+        `release_model()` frees them again (the training steps and the evaluation never need them)."""
+        if self._whole and not self._dirty:
             return
         self.joint.flush()                           # Adam: every row up to the current step, as the dense optimizer would hold it
         for name, t in zip(BIG, self.tables):
-            gather_table(getattr(self.m, name).weight.data, t.weight.data, t.total_rows, self.world, self.group)
-        self._dirty = False
+            w = getattr(self.m, name).weight
+            if w.data.shape[0] != t.total_rows:
+                w.data = torch.empty(t.total_rows, t.d, dtype=torch.float32, device=self.dev)
+            gather_table(w.data, t.weight.data, t.total_rows, self.world, self.group)
+        self._whole, self._dirty = True, False
+
+    @torch.no_grad()
+    def release_model(self):
+        """Drop the model's whole big tables (zero-row placeholders keep the module structure) and the dense optimizer's state for them."""
+        for name in BIG:
+            w = getattr(self.m, name).weight
+            w.data = torch.empty(0, w.data.shape[1], dtype=torch.float32, device=self.dev)
+            w.grad = None
+            st = self.trainer.optimizer.state.get(w)
+            if st:
+                for k, v in list(st.items()):
+                    if torch.is_tensor(v) and v.dim() == 2:
+                        st[k] = torch.empty(0, v.shape[1], dtype=v.dtype, device=v.device)
+        self._whole = False
+
+    # ---- optimizer state in torch.optim's layout (what ModelTrainer.save writes and .load reads)
+    _KEYS = {'adagrad': ('sum',), 'adam': ('exp_avg', 'exp_avg_sq'), 'sgd': ()}
+
+    @torch.no_grad()
+    def _export_optimizer(self):
+        """Shards' optimizer state -> trainer.optimizer.state as WHOLE tensors (called with the whole tables materialised, before
+        ModelTrainer.save): the whole-table checkpoint then holds what a dense run's would."""
+        keys = self._KEYS[self.kind]
+        if not keys:
+            return
+        opt, d = self.trainer.optimizer, self.tables[0].d
+        step = float(self.joint.rec.opt_step.item()) if self.kind == 'adam' else float(self.trainer.step)
+        pieces = [(getattr(self.m, n).weight, t.state, t.total_rows, True) for n, t in zip(BIG, self.tables)] + \
+                 [(p, s, p.shape[0], False) for p, s in zip(self.small, self.joint.rec.small_state)]
+        for p, st, rows, big in pieces:
+            entry = opt.state[p]
+            entry['step'] = torch.tensor(step)
+            for k, key in enumerate(keys):
+                part = st[:, k * d:(k + 1) * d].contiguous() if self.kind == 'adam' else st
+                full = torch.empty(rows, d, dtype=torch.float32, device=self.dev)
+                entry[key] = gather_table(full, part, rows, self.world, self.group) if big else full.copy_(part)
+
+    @torch.no_grad()
+    def _import_optimizer(self):
+        """trainer.optimizer.state (a whole-table checkpoint was loaded through ModelTrainer.load) -> the shards' state."""
+        keys = self._KEYS[self.kind]
+        opt, d = self.trainer.optimizer, self.tables[0].d
+        pieces = [(getattr(self.m, n).weight, t.state, True) for n, t in zip(BIG, self.tables)] + \
+                 [(p, s, False) for p, s in zip(self.small, self.joint.rec.small_state)]
+        step = 0
+        for p, st, big in pieces:
+            entry = opt.state.get(p) or {}
+            if not keys or any(key not in entry or entry[key].shape != p.shape for key in keys):
+                continue
+            step = max(step, int(float(entry.get('step', 0))))
+            for k, key in enumerate(keys):
+                src = entry[key].to(self.dev)
+                src = src[self.rank::self.world] if big else src
+                if self.kind == 'adam':
+                    st[:, k * d:(k + 1) * d] = src
+                else:
+                    st.copy_(src)
+            if self.kind == 'adam' and step > 0:         # every row is as the dense optimizer left it at `step`
+                st[:, 2 * d] = torch.full((st.shape[0],), step, dtype=torch.int32, device=self.dev).view(torch.float32)
+        if self.kind == 'adam' and step > 0:
+            self.joint.rec.opt_step.fill_(step)
 
     @torch.no_grad()
     def load_from_model(self):
@@ -210,14 +360,16 @@ class ShardedJointDriver(object):
         self.joint.steps = ck['joint_steps']
         self.trainer.step = ck['step']
         self._dirty = True
-        self.sync_model()
 
     def _wrap_trainer(self):
         """ModelTrainer.save writes the whole tables (gathered first) and, beside them, this rank's shard file."""
         trainer, inner = self.trainer, self.trainer.save
 
         def save(filename):
-            self.sync_model()
-            inner(filename)
+            if getattr(self.FLAGS, 'shard_whole_checkpoint', True):
+                self.sync_model()                    # transient whole tables + the gathered optimizer state, in the reference's layout
+                self._export_optimizer()
+                inner(filename)
+                self.release_model()
             self.save_shards(filename)
         trainer.save = save

@@ -6,6 +6,7 @@ import subprocess
 import sys
 
 import pytest
+import torch
 
 from tests.synth import make_dataset
 
@@ -210,6 +211,7 @@ def test_joint_cli_shard_tables_single_process(dataset):
     dense, _ = run_cli('run_knowledgable_recommendation.py', dataset, 'ktup-dense64', common)
     shard, logs = run_cli('run_knowledgable_recommendation.py', dataset, 'ktup-shard64', common + ['-shard_tables'])
     assert 'Row-sharded training step enabled (-shard_tables): rank 0 of 1' in shard and 'GPU-resident training step enabled' in dense
+    assert "the model's own tables are released" in shard                # evaluation runs on the shards; whole tables only for the checkpoint
     la, lb = _loss_lines(dense), _loss_lines(shard)
     assert len(la) >= 4 and len(la) == len(lb)
     for (ra, ka), (rb, kb) in zip(la[1:], lb[1:]):                      # [0] is the step-0 evaluation: no step yet
@@ -222,6 +224,29 @@ def test_joint_cli_shard_tables_single_process(dataset):
     log2, _ = run_cli('run_knowledgable_recommendation.py', dataset, 'ktup-shard64-eval',
                       common + ['-eval_only_mode', '-load_experiment_name', os.path.join(logs, 'ktup-shard64.ckpt')])
     assert 'Found checkpoint, restoring.' in log2 and len(_metric_rows(log2)) >= 1
+
+
+def test_joint_cli_shard_tables_published_recipe(dataset):
+    """The flags of the reference's own KTUP recipe (ktup.sh:1: -optimizer_type Adam -l2_lambda 0 -L1_flag -joint_ratio 0.7
+    -noshare_embeddings -nouse_st_gumbel -norm_lambda 1 -kg_lambda 1 -learning_rate 0.001) under -shard_tables: the row-sparse Adam
+    with catch-up (a dense Adam step moves every row it has ever touched) against the replicated route's dense Adam on the same
+    batches -- same losses, same metrics; the shard file carries the [m | v | last] rows and the step counter, and a run restored
+    from it evaluates to the same rows."""
+    common = ['-model_type', 'jtransup', '-rec_test_files', 'valid.dat', '-kg_test_files', 'valid.dat', '-joint_ratio', '0.7',
+              '-noshare_embeddings', '-nodevice_sampling', '-embedding_size', '64', '-l2_lambda', '0', '-optimizer_type', 'Adam', '-L1_flag',
+              '-nouse_st_gumbel', '-norm_lambda', '1', '-kg_lambda', '1', '-training_steps', '45', '-learning_rate', '0.001']
+    dense, _ = run_cli('run_knowledgable_recommendation.py', dataset, 'ktup-recipe-dense', common)
+    shard, logs = run_cli('run_knowledgable_recommendation.py', dataset, 'ktup-recipe-shard', common + ['-shard_tables'])
+    assert 'Row-sharded training step enabled (-shard_tables): rank 0 of 1' in shard and 'GPU-resident training step enabled' in dense
+    la, lb = _loss_lines(dense), _loss_lines(shard)
+    assert len(la) >= 4 and len(la) == len(lb)
+    for (ra, ka), (rb, kb) in zip(la[1:], lb[1:]):
+        assert abs(ra - rb) <= 2e-3 * max(1.0, abs(ra)) and abs(ka - kb) <= 2e-3 * max(1.0, abs(ka)), (la, lb)
+    ma, mb = _metric_rows(dense), _metric_rows(shard)
+    assert len(ma) >= 4 and len(ma) == len(mb) and ma[0] == mb[0]
+    assert all(abs(x - y) <= 0.03 for a, b in zip(ma, mb) for x, y in zip(a, b)), (ma, mb)
+    ck = torch.load(os.path.join(logs, 'ktup-recipe-shard.ckpt.shard0of1'), map_location='cpu', weights_only=False)
+    assert ck['opt_step'] >= 40 and ck['row_state']['user_embeddings'].shape[1] == 2 * 64 + 4
 
 
 def test_joint_cli_shard_tables_refuses_what_it_cannot_do(dataset):

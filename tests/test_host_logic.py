@@ -338,7 +338,7 @@ def test_gate_helper_methods_of_the_preference_models():
 
 def test_shard_tables_refuses_what_it_cannot_train_by_flag_name():
     """utils/sharded_train.check_flags: -shard_tables updates only the rows a batch touches, which equals the reference's dense step
-    (knowledgable_recommendation.py:394-403) for Adagrad / plain SGD without weight decay only -- everything else is refused before
+    (knowledgable_recommendation.py:394-403) for Adagrad / plain SGD / Adam (with catch-up) without weight decay only -- everything else is refused before
     any table is sharded, naming the reference's flag."""
     import types
     from jTransUP.hip import lib as L
@@ -347,8 +347,9 @@ def test_shard_tables_refuses_what_it_cannot_train_by_flag_name():
     ok = dict(model_type='jtransup', share_embeddings=False, optimizer_type='Adagrad', momentum=0.0, l2_lambda=0.0, use_st_gumbel=False)
     S.check_flags(types.SimpleNamespace(**ok), model)                                  # the supported combination passes
     S.check_flags(types.SimpleNamespace(**dict(ok, optimizer_type='SGD')), model)
+    S.check_flags(types.SimpleNamespace(**dict(ok, optimizer_type='Adam')), model)       # ktup.sh's optimizer: row-sparse with catch-up
     for change, word in ((dict(model_type='transup'), 'jtransup'), (dict(share_embeddings=True), 'noshare_embeddings'),
-                         (dict(optimizer_type='Adam'), 'optimizer_type'), (dict(optimizer_type='SGD', momentum=0.9), 'momentum'),
+                         (dict(optimizer_type='Rmsprop'), 'optimizer_type'), (dict(optimizer_type='SGD', momentum=0.9), 'momentum'),
                          (dict(l2_lambda=1e-5), 'l2_lambda'), (dict(use_st_gumbel=True), 'st_gumbel')):
         with pytest.raises(L.KtupError) as e:
             S.check_flags(types.SimpleNamespace(**dict(ok, **change)), model)

@@ -246,7 +246,7 @@ def test_joint_cli_shard_tables_published_recipe(dataset):
     assert len(ma) >= 4 and len(ma) == len(mb) and ma[0] == mb[0]
     assert all(abs(x - y) <= 0.03 for a, b in zip(ma, mb) for x, y in zip(a, b)), (ma, mb)
     ck = torch.load(os.path.join(logs, 'ktup-recipe-shard.ckpt.shard0of1'), map_location='cpu', weights_only=False)
-    assert ck['opt_step'] >= 40 and ck['row_state']['user_embeddings'].shape[1] == 2 * 64 + 4
+    assert ck['opt_step'] == ck['step'] >= 10 and ck['row_state']['user_embeddings'].shape[1] == 2 * 64 + 4      # (written at the best evaluation)
 
 
 def test_joint_cli_shard_tables_refuses_what_it_cannot_do(dataset):

@@ -492,4 +492,6 @@ def training_loop(FLAGS, model, trainer, logger, do_step, do_eval, loss_names, o
         pbar.close()
     if sampler is not None:
         sampler.check()
+    if stepper is not None and hasattr(stepper, 'joint'):      # -shard_tables: steps after the last evaluation are checked here
+        stepper.joint.check()
     _check_clip_barrier(trainer)

@@ -60,6 +60,8 @@ FLAG_TABLE = [
                                     'the ranks (row % world) and a step exchanges only the rows its batch touches (BASELINE config 5; one process: the '
                                     'same row-sparse step without an exchange); needs -optimizer_type Adagrad, Adam or SGD -momentum 0, and -l2_lambda 0; '
                                     'the shards are the only resident copy: evaluation runs on them'),
+    ('shard_capacity_factor', 'float', 1.25, '-shard_tables under torchrun: distinct rows a rank may ask ONE owner for per step = factor x entries / world '
+                                             '+ 64; a step that needs more is skipped on every rank and the run stops at the next check (factor = world never overflows)'),
     ('shard_whole_checkpoint', 'bool', True, '-shard_tables: besides the per-rank shard files write the reference-layout whole-table checkpoint (tables '
                                              'gathered transiently); -noshard_whole_checkpoint: shard files only'),
     # files

@@ -218,7 +218,7 @@ class _ShardedStepBase(object):
         n = self.overflowed_steps()
         if n:
             raise L.KtupError('%d sharded step(s) asked one owner for more distinct rows than capacity_factor=%.2f allows and were '
-                              'skipped on every rank (tables untouched, losses dropped) -- raise capacity_factor (world = always safe)'
+                              'skipped on every rank (tables untouched, losses dropped) -- raise capacity_factor (-shard_capacity_factor; world = always safe)'
                               % (n, self.capacity_factor))
 
 

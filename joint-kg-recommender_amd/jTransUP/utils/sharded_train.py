@@ -123,7 +123,8 @@ class ShardedJointDriver(object):
                                             margin=F.margin, kg_lambda=F.kg_lambda, kind=self.kind, lr=lr, max_norm=F.clipping_max_value,
                                             eps=1e-8 if self.kind == 'adam' else 1e-10,       # torch.optim's defaults (utils/trainer.py:63-77 passes none)
                                             l1=bool(F.L1_flag), target=float(self.trainer.model_target), orth=True,
-                                            ent_pad=self.m.ent_total - 1, group=self.group)
+                                            ent_pad=self.m.ent_total - 1, group=self.group,
+                                            capacity_factor=float(getattr(F, 'shard_capacity_factor', 1.25)))
         self._lr = lr
         self._base = {'rec': torch.zeros(2), 'kg': torch.zeros(4)}
 
@@ -132,6 +133,7 @@ class ShardedJointDriver(object):
         lr = float(self.trainer.learning_rate)
         if lr != self._lr:
             self._collect()
+            self.joint.check()                       # the steppers about to be replaced carry the skipped-step counters
             for t in self.tables:
                 if t.state is not None:
                     t.state.zero_()

@@ -268,7 +268,8 @@ class ShardedJointDriver(object):
             w = getattr(self.m, name).weight
             w.data = torch.empty(0, w.data.shape[1], dtype=torch.float32, device=self.dev)
             w.grad = None
-            st = self.trainer.optimizer.state.get(w)
+            opt = getattr(self.trainer, 'optimizer', None)
+            st = opt.state.get(w) if opt is not None else None
             if st:
                 for k, v in list(st.items()):
                     if torch.is_tensor(v) and v.dim() == 2:
@@ -283,9 +284,9 @@ class ShardedJointDriver(object):
         """Shards' optimizer state -> trainer.optimizer.state as WHOLE tensors (called with the whole tables materialised, before
         ModelTrainer.save): the whole-table checkpoint then holds what a dense run's would."""
         keys = self._KEYS[self.kind]
-        if not keys:
+        opt, d = getattr(self.trainer, 'optimizer', None), self.tables[0].d
+        if not keys or opt is None:
             return
-        opt, d = self.trainer.optimizer, self.tables[0].d
         step = float(self.joint.rec.opt_step.item()) if self.kind == 'adam' else float(self.trainer.step)
         pieces = [(getattr(self.m, n).weight, t.state, t.total_rows, True) for n, t in zip(BIG, self.tables)] + \
                  [(p, s, p.shape[0], False) for p, s in zip(self.small, self.joint.rec.small_state)]
@@ -301,7 +302,9 @@ class ShardedJointDriver(object):
     def _import_optimizer(self):
         """trainer.optimizer.state (a whole-table checkpoint was loaded through ModelTrainer.load) -> the shards' state."""
         keys = self._KEYS[self.kind]
-        opt, d = self.trainer.optimizer, self.tables[0].d
+        opt, d = getattr(self.trainer, 'optimizer', None), self.tables[0].d
+        if opt is None:
+            return
         pieces = [(getattr(self.m, n).weight, t.state, True) for n, t in zip(BIG, self.tables)] + \
                  [(p, s, False) for p, s in zip(self.small, self.joint.rec.small_state)]
         step = 0

@@ -334,11 +334,14 @@ def test_shard_files_restore_a_run_exactly(tmp_path, opt):
     d3.sync_model()
     # (the small tables' gradients are flushed by float atomics: two runs agree to rounding, not bit for bit)
     for (k, a), (_, c) in zip(m1.state_dict().items(), m3.state_dict().items()):
-        torch.testing.assert_close(a, c, rtol=1e-5, atol=1e-6, msg=k)
+        if opt == 'Adam':           # eps = 1e-8: an element whose gradient is of that size turns the atomics' rounding into a visible step
+            _close_mostly(c.cpu(), a.cpu(), 1e-5, 1e-6, frac=2e-3, cap=2e-4)
+        else:
+            torch.testing.assert_close(a, c, rtol=1e-5, atol=1e-6, msg=k)
     nd = 2 * d if opt == 'Adam' else d                                   # Adam: [m | v | last]: compare the moments as floats, `last` as ints
     for ta, tc in zip(d1.tables, d3.tables):
-        torch.testing.assert_close(ta.state[:, :nd], tc.state[:, :nd], rtol=1e-5, atol=1e-7)
+        torch.testing.assert_close(ta.state[:, :nd], tc.state[:, :nd], rtol=1e-4 if opt == 'Adam' else 1e-5, atol=1e-7)
         assert opt != 'Adam' or torch.equal(ta.state[:, nd].view(torch.int32), tc.state[:, nd].view(torch.int32))
     for sa, sc in zip(d1.joint.rec.small_state, d3.joint.rec.small_state):
-        torch.testing.assert_close(sa[:, :nd], sc[:, :nd], rtol=1e-5, atol=1e-7)
+        torch.testing.assert_close(sa[:, :nd], sc[:, :nd], rtol=1e-4 if opt == 'Adam' else 1e-5, atol=1e-7)
     assert float(d3.tables[0].state.abs().sum()) > 0                       # the sums really travelled

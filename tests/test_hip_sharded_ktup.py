@@ -343,7 +343,8 @@ def test_adam_flush_replays_the_untouched_steps(gap):
         p[on] -= lr / (1 - b1 ** s) * m[on] / (v[on].sqrt() / (1 - b2 ** s) ** 0.5 + eps)
     got_p, got_s = P.cpu(), S.cpu()
     torch.testing.assert_close(got_p.double(), p, rtol=1e-5, atol=2e-6)       # fp32 running sums of up to 132 increments against float64
-    torch.testing.assert_close(got_s[:, :d].double(), m, rtol=1e-5, atol=1e-30)
-    torch.testing.assert_close(got_s[:, d:2 * d].double(), v, rtol=1e-5, atol=1e-30)
+    # (beta1 = 0.9 is 0.89999998 as the fp32 kernel argument: 2.6e-8 per step, 1e-5 after 400)
+    torch.testing.assert_close(got_s[:, :d].double(), m, rtol=5e-5, atol=1e-30)
+    torch.testing.assert_close(got_s[:, d:2 * d].double(), v, rtol=5e-5, atol=1e-30)
     want_last = torch.where(last > 0, torch.full_like(last, t), last)
     assert torch.equal(got_s[:, 2 * d].view(torch.int32), want_last)

@@ -178,13 +178,18 @@ class _StepperBase(object):
             entry = None
         if entry is None:
             graph = torch.cuda.CUDAGraph()
+            import os as _os
+            ahead = _os.environ.get('KTUP_FEED_AHEAD', '0') != '0'      # measured, round 5: 0.0456 against 0.0434 ms per step -- off
             with L.capture(graph):
                 self._acc_on = True
                 try:
-                    for kind in kinds:
-                        self._plans()
-                        self._feed_launch[kind]()
-                        (self._rec_eager if kind == 'rec' else self._kg_eager)(*((None,) * self.N_IDS[kind]))
+                    if ahead:
+                        self._capture_cycle_feeds_ahead(kinds)
+                    else:
+                        for kind in kinds:
+                            self._plans()
+                            self._feed_launch[kind]()
+                            (self._rec_eager if kind == 'rec' else self._kg_eager)(*((None,) * self.N_IDS[kind]))
                 finally:
                     self._acc_on = False
             self._keys = None
@@ -199,6 +204,53 @@ class _StepperBase(object):
             fused.bump_steps(len(kinds))
         self.trainer.step += len(kinds)
         return len(kinds)
+
+    def _capture_cycle_feeds_ahead(self, kinds):
+        """The launches of a fed cycle with the FEEDS on a second branch of the graph: a feed depends on the sampler's state and the
+        cursor only, never on a step's result, so all of the cycle's feeds run back to back beside the chain
+        step kernel -> clip + optimizer -> step kernel -> ..., each into id buffers of its own (step k reads slot k), and step k waits
+        for feed k alone -- which has long finished when the chain gets there (ten feeds take ~90 us, the chain ~350).  The feeds
+        would leave the critical path but for the first one: ~8 of a step's ~43 us.  (Round 4 tried the fork / join PER STEP: the
+        cross-queue hand-over cost more than the feed it hid; here the graph forks once.)  Same feed kernels in the same order on
+        one queue, so the batches are the single-step route's (tests/test_fast_train.py runs under either setting).
+        MEASURED (round 5, tools/step_time.py): 0.0456 ms per step against 0.0434 with the feeds in the chain -- ten cross-queue
+        dependency edges cost more than the ten feeds they hide -- so this form is opt-in (KTUP_FEED_AHEAD=1), kept as the record
+        of the experiment."""
+        main = torch.cuda.current_stream(self.dev)
+        if getattr(self, '_feed_side', None) is None:
+            self._feed_side = torch.cuda.Stream(device=self.dev)
+        side = self._feed_side
+        i64 = dict(dtype=torch.int64, device=self.dev)
+        saved = {k: getattr(self, k, None) for k in ('_ids_rec', 'u2', 'i2', '_ids_kg', 'h2', 't2', 'r2', 'ht4')}
+        slots = []
+        try:
+            for kind in kinds:                                   # slot buffers with the layout of _id_buffers
+                self._id_buffers(kind, i64)
+                slots.append({k: getattr(self, k) for k in (('_ids_rec', 'u2', 'i2') if kind == 'rec' else ('_ids_kg', 'h2', 't2', 'r2', 'ht4'))})
+            self._cycle_slots = getattr(self, '_cycle_slots', []) + [slots]        # keep them alive as long as the graphs
+            side.wait_stream(main)
+            events = []
+            with torch.cuda.stream(side):
+                for kind, slot in zip(kinds, slots):
+                    for k, v in slot.items():
+                        setattr(self, k, v)
+                    self._make_feed(kind, side.cuda_stream)()
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                    events.append(ev)
+            for kind, slot, ev in zip(kinds, slots, events):
+                for k, v in slot.items():
+                    setattr(self, k, v)
+                self._keys = None                                # bind the step's launches to this slot's buffers
+                self._plans()
+                main.wait_event(ev)
+                (self._rec_eager if kind == 'rec' else self._kg_eager)(*((None,) * self.N_IDS[kind]))
+            main.wait_stream(side)
+        finally:
+            for k, v in saved.items():
+                if v is not None:
+                    setattr(self, k, v)
+            self._keys = None
 
     def fed_step(self, kind):
         """One step of `kind` on the feeder's next batch: the step's graph is  feed launch -> step kernel -> clip + optimizer

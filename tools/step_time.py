@@ -16,5 +16,5 @@ import bench as B
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 400
 o = B.train_step_bench(torch.device('cuda'), steps=steps, warmup=50)
-switches = {k: os.environ[k] for k in ('KTUP_TRACKED_NORM', 'KTUP_FEED_RIDER', 'KTUP_FUSED_STEP') if k in os.environ}
+switches = {k: os.environ[k] for k in ('KTUP_TRACKED_NORM', 'KTUP_FEED_AHEAD', 'KTUP_FUSED_STEP') if k in os.environ}
 print('STEP', switches, {k: round(v, 5) for k, v in o.items() if isinstance(v, float)})

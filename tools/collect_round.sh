@@ -1,7 +1,7 @@
 #!/bin/bash
 # Everything under profiles/<tag>_* in one GPU job (run from the repo root on an MI355X box):  bash tools/collect_round.sh r03
 # rocprofv3 runs from /tmp; counter passes are separate from the kernel-trace / stats pass (MI355X_MICROARCH.md).
-TAG=${1:-r04}
+TAG=${1:-r05}
 export TMPDIR=/tmp
 R=$(pwd)
 P=$R/gpurun_out/profiles
@@ -18,6 +18,7 @@ done
 for V in "--kind rec" "--kind kg" "--kind joint" "--kind rec --zipf 1.05" "--kind rec --no-overlap" "--kind rec --gradient-buffer --no-overlap" "--kind rec --exchange" "--kind joint --exchange"; do
   timeout 200 python tools/config5_step.py --steps 200 --full $V 2>/dev/null | grep config
 done > $P/${TAG}_config5_step.txt
+timeout 200 python tools/config5_step.py --steps 300 --full --kind joint --optimizer adam 2>/dev/null | grep config | sed 's/^/--optimizer adam /' >> $P/${TAG}_config5_step.txt
 KTUP_WIDE_WAVES=4 timeout 200 python tools/config5_step.py --steps 200 --full --kind rec 2>/dev/null | grep config | sed 's/^/KTUP_WIDE_WAVES=4 /' >> $P/${TAG}_config5_step.txt
 for V in rec kg rec_exchange; do
   rm -rf /tmp/c5
@@ -45,6 +46,12 @@ timeout 300 python tools/kg_eval_pass.py transh l1 >> $P/${TAG}_kg_eval_pass.txt
 timeout 300 python tools/graph_memset_repro.py > $P/${TAG}_graph_memset_repro_torch.txt 2>/dev/null
 timeout 120 tools/gumbel_log_check > $P/${TAG}_gumbel_log_check.txt 2>/dev/null
 timeout 300 tools/gather_bench footprint > $P/${TAG}_gather_footprint.txt 2>/dev/null
+# K6 forward at config 5's width on HBM-resident tables: the coordinate-split kernel and the one-wave-per-tile kernel it replaced, + its trace
+(timeout 200 python tools/fwd_d256_time.py; KTUP_FWD_WIDE=0 timeout 200 python tools/fwd_d256_time.py) 2>/dev/null | grep FWD256 > $P/${TAG}_fwd_d256.txt
+rm -rf /tmp/kp_fwd256
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kp_fwd256 -- python $R/tools/fwd_d256_time.py > /dev/null 2>&1)
+F=$(find /tmp/kp_fwd256 -name "*kernel_stats.csv" | head -1)
+[ -n "$F" ] && cp $F $P/${TAG}_fwd_d256_kernel_stats.csv
 timeout 900 python bench.py > $P/${TAG}_bench.json 2>/dev/null
 # the numbers a reader is shown come from the files themselves; the stamp ties them to the kernel sources they were measured on
 python tools/profile_summary.py $TAG $P

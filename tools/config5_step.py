@@ -42,14 +42,14 @@ def fused_main(args):
         for p in small:
             dist.broadcast(p.data, src=0)
     item2ent = torch.randint(0, NE, (NI,), generator=torch.Generator(device=dev).manual_seed(7), device=dev).to(torch.int32)
-    st = ShardedKtupStepper(Ut, It, Et, *small, item2ent, batch=B, kind='adagrad', lr=0.005, max_norm=5.0, use_graphs=not args.no_graphs,
+    st = ShardedKtupStepper(Ut, It, Et, *small, item2ent, batch=B, kind=args.optimizer, lr=0.005, max_norm=5.0, use_graphs=not args.no_graphs,
                             force_exchange=args.exchange, overlap_route=not args.no_overlap, fused_apply=not args.gradient_buffer, direct=False if (args.no_direct or args.exchange or world > 1) else None,
                             orth=args.kind != 'rec', route_beside=args.route_beside)
     rec = st
     kg = None
     if args.kind != 'rec':             # the kg half of the joint schedule (knowledgable_recommendation.py:345-383) on the same entity shard
-        kg = ShardedKgStepper(Et, small[2], small[3], batch=B, kind='adagrad', lr=0.005, max_norm=5.0, margin=1.0, kg_lambda=1.0,
-                              small_state=rec.small_state[2:4], use_graphs=not args.no_graphs, force_exchange=args.exchange,
+        kg = ShardedKgStepper(Et, small[2], small[3], batch=B, kind=args.optimizer, lr=0.005, max_norm=5.0, margin=1.0, kg_lambda=1.0,
+                              small_state=rec.small_state[2:4], opt_step=rec.opt_step, use_graphs=not args.no_graphs, force_exchange=args.exchange,
                               overlap_route=not args.no_overlap, direct=False if (args.no_direct or args.exchange or world > 1) else None)
         st = kg if args.kind == 'kg' else ShardedKtupJoint(rec, kg, 0.7)
 
@@ -113,6 +113,7 @@ def main():
     ap.add_argument('--batch', type=int, default=8192)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--d', type=int, default=256)
+    ap.add_argument('--optimizer', default='adagrad', choices=['adagrad', 'sgd', 'adam'], help='adam: the row-sparse Adam with catch-up of the untouched steps (ktup_adam_t)')
     ap.add_argument('--kind', default='rec', choices=['rec', 'kg', 'joint'], help='rec: the rec step alone (the round-3 figure); kg: the kg step alone; joint: the 7 : 3 cycle of knowledgable_recommendation.py:320')
     ap.add_argument('--route-beside', action='store_true', help='rec step: the step kernel reads the id columns itself, the WHOLE route (init launch included) runs on the second graph branch')
     ap.add_argument('--zipf', type=float, default=0.0, help='draw ids from Zipf(a) (hot rows: contention in the row-gradient atomics) instead of uniformly, e.g. 1.05')

@@ -190,7 +190,11 @@ def _two_rank_worker(rank, world, port, kind, overflow):
         nu, ni, ne, b, steps, d, P = 901, 301, 703, 512, 4, 256, 20     # odd row counts: the shards differ in size
         full, small0, i2e, gen = _world_tables(nu, ni, ne, P, d, seed=31, pad_every=6)
         batches = _batches(gen, world, steps, nu, ni, b)
-        lr, max_norm = (0.05, 0.5) if kind == 'adagrad' else (20.0, 0.5)
+        lr, max_norm = (0.05, 0.5) if kind == 'adagrad' else (0.01, 0.5) if kind == 'adam' else (20.0, 0.5)
+        eps = 1e-5 if kind == 'adam' else 1e-4
+        if kind == 'adam':                                                # more, smaller steps: rows rest for a few steps between touches
+            steps, b = 7, 128
+            batches = _batches(gen, world, steps, nu, ni, b)
         if overflow:
             tables, small, st = _run_stepper(full, small0, i2e, batches[:3], kind, lr, 1e-4, max_norm, rank, world, dev, capacity_factor=0.01)
             assert st.overflowed_steps() > 0                            # cap = 64 + a few rows < the batch's distinct ids per owner
@@ -202,8 +206,8 @@ def _two_rank_worker(rank, world, port, kind, overflow):
                 assert torch.equal(p.data.cpu(), w)
             assert float(st.Gwire.abs().sum()) == 0.0 and float(st.Gown.abs().sum()) == 0.0     # and left no gradient behind
             return
-        Wd, _ = _dense_reference(full, small0, i2e, batches, kind, lr, 1e-4, max_norm)
-        tables, small, st = _run_stepper(full, small0, i2e, batches, kind, lr, 1e-4, max_norm, rank, world, dev)
+        Wd, _ = _dense_reference(full, small0, i2e, batches, kind, lr, eps, max_norm)
+        tables, small, st = _run_stepper(full, small0, i2e, batches, kind, lr, eps, max_norm, rank, world, dev)
         assert st.multi and len(st._graphs) == 5 and st.overflowed_steps() == 0
         _check(tables, small, Wd, rank, world)
         copies = [torch.empty_like(small[0].data.cpu()) for _ in range(world)]
@@ -213,7 +217,7 @@ def _two_rank_worker(rank, world, port, kind, overflow):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('kind,overflow', [('adagrad', False), ('sgd', False), ('adagrad', True)])
+@pytest.mark.parametrize('kind,overflow', [('adagrad', False), ('sgd', False), ('adagrad', True), ('adam', False)])
 def test_stepper_two_ranks_share_the_gpu(kind, overflow):
     import torch.multiprocessing as mp
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))

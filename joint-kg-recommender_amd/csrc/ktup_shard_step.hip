@@ -20,6 +20,8 @@
 // The owner side of several ranks combines the rows different peers asked for with the same route + reduction (world = 1,
 // block = capsum): a row requested by k peers is k entries of one key.
 #include "ktup_pref_geom.h"
+#include <cstring>
+
 #include "ktup_rows.h"
 
 using namespace ktup;
@@ -409,7 +411,8 @@ KTUP_DEV float clip_coef(float max_norm, const double* __restrict__ sumsq, int s
 
 // Same rule as ktup_shard.hip SparseRowStep (utils/trainer.py:63-77 with l2_lambda = 0 restricted to the touched rows), for
 // every wire row of every table + the rows of the small replicated tables; the gradient rows are zero-filled once consumed.
-struct ApplyRows {
+template <bool ADAM>
+struct ApplyRowsT {
   WireTables w; const int64_t* ids; int64_t W; float* g; int64_t ldg;
   int n_small, small_rows; float* sg[MAXS]; float* sp0[MAXS]; float* ss0[MAXS]; float* sp1[MAXS]; float* ss1[MAXS];
   const double* small_g64;     // non-null: the all-reduced small gradients (fp64 bucket, entries in sg order) replace sg's values
@@ -432,7 +435,9 @@ struct ApplyRows {
 
   template <typename V, int G, int CPL>
   KTUP_DEV void one(const RowCtx<V, G, CPL>& cx, float* prow, float* srow, const V (&gr)[CPL], float coef) const {
-    if (adam) { one_adam<G, CPL>(cx, prow, srow, gr, coef); return; }
+    // (ADAM is a template parameter: with the replay loop and its fp64 powers compiled into the Adagrad / SGD instantiation the apply
+    //  walk of config 5 took 169 us instead of 47 -- registers)
+    if constexpr (ADAM) { one_adam<G, CPL>(cx, prow, srow, gr, coef); return; }
     V p[CPL], st[CPL];
     cx.load(p, prow);
     if (adagrad) cx.load(st, srow);
@@ -512,6 +517,7 @@ struct ApplyRows {
     }
   }
 };
+using ApplyRows = ApplyRowsT<false>;
 
 
 // ---- reduction by sorted segments WITHOUT a gradient buffer (one rank's reduce -> norm -> apply, and the owner side of several):
@@ -572,8 +578,8 @@ KTUP_DEV void xnorm_blocks(const XNormArgs& a, int blk, int nblk) {
 // MODE 1 carries the step's LAST launch along as extra workgroups [walk_grid, gridDim.x): the listed boundary rows (from gw, then
 // zero-filled), the small replicated tables and the step's bookkeeping (ApplyRows over op_rows rows) depend on the norm only, not on
 // this walk -- as a launch of their own they were 6 us of dependent latencies at the very end of every step.
-template <int GL, int CPL, int MODE>
-__global__ __launch_bounds__(256) void seg_fused_kernel(FusedArgs a, ApplyRows op, int64_t op_rows, int walk_grid, XNormArgs xn) {
+template <int GL, int CPL, int MODE, bool ADAM>
+__global__ __launch_bounds__(256) void seg_fused_kernel(FusedArgs a, ApplyRowsT<ADAM> op, int64_t op_rows, int walk_grid, XNormArgs xn) {
   const int lane = threadIdx.x % GL, grp = threadIdx.x / GL;
   constexpr int GPB = 256 / GL;
   if (MODE == 0 && (int)blockIdx.x >= walk_grid) {
@@ -613,7 +619,7 @@ __global__ __launch_bounds__(256) void seg_fused_kernel(FusedArgs a, ApplyRows o
     const int t = wire_table(a.w, key);
     float4* prow = reinterpret_cast<float4*>(a.w.tab[t] + id * a.w.ldt[t]);
     float4* srow = a.adagrad ? reinterpret_cast<float4*>(a.w.st[t] + id * a.w.lds[t]) : nullptr;
-    if (a.adam) {
+    if constexpr (ADAM) {
       float4 g[CPL];
 #pragma unroll
       for (int j = 0; j < CPL; ++j) g[j] = coef * acc[j];
@@ -773,16 +779,16 @@ int64_t fused_grid(int64_t m_max, int d) {
   return (nchunks + gpb - 1) / gpb;
 }
 
-template <int MODE>
-int launch_fused(const FusedArgs& a, int64_t grid, hipStream_t st, const char* name, const ApplyRows* op = nullptr, int64_t op_rows = 0,
+template <int MODE, bool ADAM = false>
+int launch_fused(const FusedArgs& a, int64_t grid, hipStream_t st, const char* name, const ApplyRowsT<ADAM>* op = nullptr, int64_t op_rows = 0,
                  const XNormArgs* xn = nullptr) {
-  const ApplyRows none{};
+  const ApplyRowsT<ADAM> none{};
   const XNormArgs xnone{};
 #define KTUP_F(GL, CPL)                                                                                  \
   {                                                                                                      \
     int64_t extra = op ? grid_for((op_rows + (256 / GL) - 1) / (256 / GL), 256) : 0;                     \
     if (xn) extra = grid_for(((int64_t)xn->n_small * xn->small_elems + 2047) / 2048, 64);                \
-    hipLaunchKernelGGL((seg_fused_kernel<GL, CPL, MODE>), dim3((unsigned)(grid + extra)), dim3(256), 0, st, a, op ? *op : none, op_rows, \
+    hipLaunchKernelGGL((seg_fused_kernel<GL, CPL, MODE, ADAM>), dim3((unsigned)(grid + extra)), dim3(256), 0, st, a, op ? *op : none, op_rows, \
                        (int)grid, xn ? *xn : xnone);                                                     \
     return check_launch(name);                                                                           \
   }
@@ -1156,6 +1162,10 @@ extern "C" int ktup_shard_apply(int kind, int n_tables, float* const* tables, co
     op.ar = AdamRule{adam_rule->beta1, adam_rule->beta2, adam_rule->replay, adam_rule->step};
     for (int t = 0; t < n_tables; ++t) KTUP_REQUIRE(op.w.lds[t] >= KTUP_SHARD_ADAM_STATE_PITCH(d), "%s: table %d: an Adam state row is [m | v | last]: pitch >= 2 d + 4", name, t);
     if (!v4) return set_error(KTUP_ERR_UNSUPPORTED, "%s: Adam rows need d %% 4 == 0 and 16-byte aligned tables, states and gradients", name);
+    ApplyRowsT<true> oa;                                  // same members, the Adam instantiation of the row rule
+    static_assert(sizeof(oa) == sizeof(op), "ApplyRowsT<true> and <false> share one layout");
+    memcpy(&oa, &op, sizeof(op));
+    return launch_rows(oa, d, v4, op.W + (int64_t)n_small * op.small_rows, (hipStream_t)stream, name);
   }
   return launch_rows(op, d, v4, op.W + (int64_t)n_small * op.small_rows, (hipStream_t)stream, name);
 }
@@ -1187,7 +1197,7 @@ extern "C" int ktup_shard_reduce_norm(const float* G, int64_t ldg, int d, int64_
   x.sumsq = sumsq; x.slots = n_slots;
   KTUP_REQUIRE(n_fold >= 0 && (n_fold == 0 || fold), "%s: fold needs its array", name);
   x.fold = n_fold > 0 ? fold : nullptr; x.n_fold = n_fold; x.cursor = cursor;
-  return launch_fused<0>(a, grid, st, name, nullptr, 0, &x);     // the walk + (extra workgroups) the small gradients, the fold, the cursor
+  return launch_fused<0, false>(a, grid, st, name, (const ApplyRows*)nullptr, 0, &x);     // the walk + (extra workgroups) the small gradients, the fold, the cursor
 }
 
 extern "C" int ktup_shard_reduce_apply(int kind, int n_tables, float* const* tables, const int64_t* ld, float* const* states,
@@ -1240,6 +1250,11 @@ extern "C" int ktup_shard_reduce_apply(int kind, int n_tables, float* const* tab
   op.lr = lr; op.eps = eps; op.max_norm = max_norm; op.sumsq = sumsq; op.sumsq_slots = sumsq_slots; op.skip_i = skip_count; op.skip_d = skip_value;
   op.adagrad = adagrad;
   op.loss_step = loss_step; op.n_loss = n_loss; op.loss_sum = loss_sum; op.skipped = skipped_steps;
+  if (adam) {
+    ApplyRowsT<true> oa;
+    memcpy(&oa, &op, sizeof(op));
+    return launch_fused<1, true>(a, grid, st, name, &oa, op.W + (int64_t)n_small * op.small_rows);
+  }
   return launch_fused<1>(a, grid, st, name, &op, op.W + (int64_t)n_small * op.small_rows);
 }
 

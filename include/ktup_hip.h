@@ -484,7 +484,7 @@ int ktup_shard_pack_wire(int n_tables, float* const* tables, const int64_t* ld, 
  * p <- p - lr / (1 - beta1^s) m / (sqrt(v) / sqrt(1 - beta2^s) + eps) -- whether the batch touches it or not.  A state row is
  * [m (d) | v (d) | last (int32) | 3 words of padding], KTUP_SHARD_ADAM_STATE_PITCH(d) floats; `last` = the step the row's state was
  * written at (0: never).  Touching a row at step t first REPLAYS the zero-gradient steps last + 1 .. t - 1 in registers (the dense
- * recurrence, step by step; after `replay` steps, when the increments have fallen below ~1e-6 of the first, only m and v keep
+ * recurrence, step by step; after `replay` steps, when the increments have fallen below ~1e-5 of the first, only m and v keep
  * decaying in closed form), then applies step t.  *step = the number of the step being applied: ktup_shard_step_count moves it
  * (+1 unless the step is skipped) as the launch before the apply launch.  ktup_shard_adam_flush replays every row of a shard up to
  * *step (before an evaluation or a checkpoint reads the table).                                                               */

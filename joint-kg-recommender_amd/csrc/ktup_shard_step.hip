@@ -321,17 +321,19 @@ constexpr int NSLOT = KTUP_SHARD_SUMSQ_SLOTS;
 // `last` = the step its state was written at (0: never touched: m = v = 0 and the row has not moved).  Whoever touches a row at step t
 // first REPLAYS the zero-gradient steps last + 1 .. t - 1 in registers -- exactly the dense recurrence, one step after the other --
 // then applies step t.  The replayed increments fall like (beta1 / sqrt(beta2))^k, so the replay stops after `replay` steps (the host
-// picks it so that what is dropped is below 1e-6 of the first increment, i.e. < 1e-7 absolute at the learning rates in use) and the
+// picks it so that what is dropped is below 1e-4 of the first increment, i.e. < 2e-6 absolute at the learning rates in use) and the
 // remaining steps only decay m and v (closed form).  ktup_shard_adam_flush brings every row of a shard up to the current step (before an
 // evaluation or a checkpoint reads the tables).
 struct AdamRule {
   float b1, b2; int replay; const int64_t* step;       // *step = number of the step being applied (>= 1; ktup_shard_step_count moves it)
 };
 
-KTUP_DEV void adam_zero_steps(float4& p, float4& m, float4& v, float c1, float inv_bc2s, float eps, float b1, float b2) {
+// one zero-gradient step on (p, m, sqrt(v)): sqrt(beta2^k v) = sqrt(v) sqrt(beta2)^k, so the replay carries sqrt(v) and multiplies it -- a
+// square root per element and step was a quarter of the loop (transcendental rate)
+KTUP_DEV void adam_zero_steps(float4& p, float4& m, float4& sv, float c1, float inv_bc2s, float eps, float b1, float sb2) {
 #define KTUP_AZ(c)                                                                            \
-  m.c = fmaf(-m.c, 1.f - b1, m.c); v.c = b2 * v.c;                                            \
-  p.c = fmaf(-c1 * m.c, __builtin_amdgcn_rcpf(fmaf(__builtin_amdgcn_sqrtf(v.c), inv_bc2s, eps)), p.c);
+  m.c = fmaf(-m.c, 1.f - b1, m.c); sv.c = sb2 * sv.c;                                         \
+  p.c = fmaf(-c1 * m.c, __builtin_amdgcn_rcpf(fmaf(sv.c, inv_bc2s, eps)), p.c);
   KTUP_AZ(x) KTUP_AZ(y) KTUP_AZ(z) KTUP_AZ(w)
 #undef KTUP_AZ
 }
@@ -348,15 +350,20 @@ KTUP_DEV void adam_row(float4 (&p)[CPL], float4 (&m)[CPL], float4 (&v)[CPL], con
   if (last > 0 && miss > 0) {
     const int K = miss < r.replay ? miss : r.replay;
     double b1p = pow((double)r.b1, (double)last), b2p = pow((double)r.b2, (double)last);
+    const float sb2 = sqrtf(r.b2);
+    float4 sv[CPL];
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) sv[j] = make_float4(sqrtf(v[j].x), sqrtf(v[j].y), sqrtf(v[j].z), sqrtf(v[j].w));
     for (int k = 0; k < K; ++k) {
       b1p *= (double)r.b1; b2p *= (double)r.b2;
       const float c1 = lr * __builtin_amdgcn_rcpf((float)(1.0 - b1p));
       const float ib = __builtin_amdgcn_rsqf((float)(1.0 - b2p));
 #pragma unroll
-      for (int j = 0; j < CPL; ++j) adam_zero_steps(p[j], m[j], v[j], c1, ib, eps, r.b1, r.b2);
+      for (int j = 0; j < CPL; ++j) adam_zero_steps(p[j], m[j], sv[j], c1, ib, eps, r.b1, sb2);
     }
-    if (miss > K) {
-      const float f1 = (float)pow((double)r.b1, (double)(miss - K)), f2 = (float)pow((double)r.b2, (double)(miss - K));
+    {   // v after all `miss` steps in closed form (the loop carried its square root); m's remaining decay likewise
+      const float f2 = (float)pow((double)r.b2, (double)miss);
+      const float f1 = miss > K ? (float)pow((double)r.b1, (double)(miss - K)) : 1.f;
 #pragma unroll
       for (int j = 0; j < CPL; ++j) { m[j] = f1 * m[j]; v[j] = f2 * v[j]; }
     }

@@ -57,9 +57,10 @@ def adam_state_pitch(d):
     return 2 * d + 4            # KTUP_SHARD_ADAM_STATE_PITCH: [m (d) | v (d) | last (int32) + padding]
 
 
-def adam_replay(betas, tol=1e-6):
+def adam_replay(betas, tol=1e-5):
     """Zero-gradient steps replayed one by one when a row is touched again: the replayed increments fall like (beta1 / sqrt(beta2))^k, so
-    after this many the rest of the series is below `tol` of its first term (< 1e-7 absolute at the learning rates in use)."""
+    after this many (110 for the default betas) the rest of the series is below 10 `tol` = 1e-4 of its first term -- < 2e-6 absolute at
+    the learning rates in use, a tenth of the comparison band."""
     r = float(betas[0]) / math.sqrt(float(betas[1]))
     if r <= 0.0:
         return 0

@@ -312,11 +312,11 @@ def test_stepper_adam_equals_the_dense_adam(d, P, form):
     st.check()
 
 
-@pytest.mark.parametrize('gap', [1, 7, 131, 132, 133, 400])
+@pytest.mark.parametrize('gap', [1, 7, 109, 110, 111, 400])
 def test_adam_flush_replays_the_untouched_steps(gap):
     """ktup_shard_adam_flush against the dense recurrence written out in float64: a row whose state was written at step `last` is
     taken through steps last + 1 .. t with a zero gradient -- m <- beta1 m, v <- beta2 v, p <- p - lr / (1 - beta1^s) m / (sqrt(v /
-    (1 - beta2^s)) + eps) -- one after the other; beyond 132 replayed steps (adam_replay: the increments have fallen below 1e-6 of
+    (1 - beta2^s)) + eps) -- one after the other; beyond 110 replayed steps (adam_replay: the increments have fallen below 1e-5 of
     the first) only m and v keep decaying.  Rows never touched (last = 0) stay as they are."""
     import ctypes
     from jTransUP.hip import lib as L
@@ -346,7 +346,8 @@ def test_adam_flush_replays_the_untouched_steps(gap):
         m[on] *= b1; v[on] *= b2
         p[on] -= lr / (1 - b1 ** s) * m[on] / (v[on].sqrt() / (1 - b2 ** s) ** 0.5 + eps)
     got_p, got_s = P.cpu(), S.cpu()
-    torch.testing.assert_close(got_p.double(), p, rtol=1e-5, atol=2e-6)       # fp32 running sums of up to 132 increments against float64
+    # beyond the replay cap the dropped tail is < 1e-4 of a row's FIRST replayed increment (here up to 0.2: tiny `last`, large bias correction)
+    torch.testing.assert_close(got_p.double(), p, rtol=1e-5, atol=2e-6 if gap <= 110 else 3e-5)       # fp32 running sums of up to 110 increments against float64 (+ < 1e-4 of the first increment dropped)
     # (beta1 = 0.9 is 0.89999998 as the fp32 kernel argument: 2.6e-8 per step, 1e-5 after 400)
     torch.testing.assert_close(got_s[:, :d].double(), m, rtol=5e-5, atol=1e-30)
     torch.testing.assert_close(got_s[:, d:2 * d].double(), v, rtol=5e-5, atol=1e-30)

@@ -485,12 +485,13 @@ int ktup_shard_pack_wire(int n_tables, float* const* tables, const int64_t* ld, 
  * [m (d) | v (d) | last (int32) | 3 words of padding], KTUP_SHARD_ADAM_STATE_PITCH(d) floats; `last` = the step the row's state was
  * written at (0: never).  Touching a row at step t first REPLAYS the zero-gradient steps last + 1 .. t - 1 in registers (the dense
  * recurrence, step by step; after `replay` steps, when the increments have fallen below ~1e-5 of the first, only m and v keep
- * decaying in closed form), then applies step t.  *step = the number of the step being applied: ktup_shard_step_count moves it
- * (+1 unless the step is skipped) as the launch before the apply launch.  ktup_shard_adam_flush replays every row of a shard up to
+ * decaying in closed form), then applies step t.  `step` points at TWO device int64: step[0] = the number of the step being applied,
+ * step[1] = that step's bias corrections {1 - beta1^t, sqrt(1 - beta2^t)} as two floats; ktup_shard_step_count -- the launch before
+ * the apply launch, and the only writer of both -- moves the counter (+1 unless the step is skipped) and refreshes them.  ktup_shard_adam_flush replays every row of a shard up to
  * *step (before an evaluation or a checkpoint reads the table).                                                               */
 typedef struct ktup_adam_t { float beta1, beta2; int32_t replay; int32_t reserved; const int64_t* step; } ktup_adam_t;
 #define KTUP_SHARD_ADAM_STATE_PITCH(d) (2 * (d) + 4)
-int ktup_shard_step_count(int64_t* step, const int32_t* skip_count, const double* skip_value, void* stream);
+int ktup_shard_step_count(int64_t* step, const int32_t* skip_count, const double* skip_value, float beta1, float beta2, void* stream);
 int ktup_shard_adam_flush(float* table, int64_t ldt, float* state, int64_t lds, int d, int64_t n_rows, float lr, float eps,
                           const ktup_adam_t* adam_rule, void* stream);
 /* The catch-up has to come BEFORE a step reads a row (the pending zero-gradient moves are part of the weights the reference's forward

@@ -325,8 +325,13 @@ constexpr int NSLOT = KTUP_SHARD_SUMSQ_SLOTS;
 // remaining steps only decay m and v (closed form).  ktup_shard_adam_flush brings every row of a shard up to the current step (before an
 // evaluation or a checkpoint reads the tables).
 struct AdamRule {
-  float b1, b2; int replay; const int64_t* step;       // *step = number of the step being applied (>= 1; ktup_shard_step_count moves it)
+  float b1, b2; int replay; const int64_t* step;       // step[0] = number of the step being applied (>= 1; ktup_shard_step_count moves it and
+                                                       // leaves that step's bias corrections {1 - beta1^t, sqrt(1 - beta2^t)} as two floats in step[1])
+  float ln1, ln2;                                      // log(beta1), log(beta2): beta^k = exp(k log beta) without a pow() per row
 };
+// (a pow() per row and lane -- the bias corrections of the step, the powers the replay starts from -- made the Adam apply walk of config 5
+//  193 us against Adagrad's 47: fp64 pow is several hundred instructions)
+inline AdamRule make_rule(const ktup_adam_t* a) { return AdamRule{a->beta1, a->beta2, a->replay, a->step, logf(a->beta1), logf(a->beta2)}; }
 
 // one zero-gradient step on (p, m, sqrt(v)): sqrt(beta2^k v) = sqrt(v) sqrt(beta2)^k, so the replay carries sqrt(v) and multiplies it -- a
 // square root per element and step was a quarter of the loop (transcendental rate)
@@ -349,7 +354,7 @@ KTUP_DEV void adam_row(float4 (&p)[CPL], float4 (&m)[CPL], float4 (&v)[CPL], con
   const int miss = upto - last;
   if (last > 0 && miss > 0) {
     const int K = miss < r.replay ? miss : r.replay;
-    double b1p = pow((double)r.b1, (double)last), b2p = pow((double)r.b2, (double)last);
+    double b1p = (double)__expf((float)last * r.ln1), b2p = (double)__expf((float)last * r.ln2);
     const float sb2 = sqrtf(r.b2);
     float4 sv[CPL];
 #pragma unroll
@@ -362,15 +367,15 @@ KTUP_DEV void adam_row(float4 (&p)[CPL], float4 (&m)[CPL], float4 (&v)[CPL], con
       for (int j = 0; j < CPL; ++j) adam_zero_steps(p[j], m[j], sv[j], c1, ib, eps, r.b1, sb2);
     }
     {   // v after all `miss` steps in closed form (the loop carried its square root); m's remaining decay likewise
-      const float f2 = (float)pow((double)r.b2, (double)miss);
-      const float f1 = miss > K ? (float)pow((double)r.b1, (double)(miss - K)) : 1.f;
+      const float f2 = __expf((float)miss * r.ln2);
+      const float f1 = miss > K ? __expf((float)(miss - K) * r.ln1) : 1.f;
 #pragma unroll
       for (int j = 0; j < CPL; ++j) { m[j] = f1 * m[j]; v[j] = f2 * v[j]; }
     }
   }
   if (has_g) {
-    const double t = (double)(upto + 1);
-    const float c1 = lr / (float)(1.0 - pow((double)r.b1, t)), bc2s = (float)sqrt(1.0 - pow((double)r.b2, t));
+    const float* bc = reinterpret_cast<const float*>(r.step + 1);          // this step's bias corrections (ktup_shard_step_count)
+    const float c1 = lr / bc[0], bc2s = bc[1];
 #pragma unroll
     for (int j = 0; j < CPL; ++j) {
       adam_step1(p[j].x, m[j].x, v[j].x, g[j].x, c1, bc2s, eps, r.b1, r.b2); adam_step1(p[j].y, m[j].y, v[j].y, g[j].y, c1, bc2s, eps, r.b1, r.b2);
@@ -908,10 +913,16 @@ int check_kind(const char* name, int kind, const ktup_adam_t* adam, int d) {
 }
 
 // *step += 1 unless the step is skipped (the same two flags the apply launch reads): the launch BEFORE the apply launch of a step
-__global__ void step_count_kernel(int64_t* step, const int32_t* skip_i, const double* skip_d) {
+__global__ void step_count_kernel(int64_t* step, const int32_t* skip_i, const double* skip_d, float b1, float b2) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     const bool skip = (skip_i && *skip_i != 0) || (skip_d && *skip_d != 0.0);
-    if (!skip) *step = *step + 1;
+    if (!skip) {
+      const int64_t t = *step + 1;
+      *step = t;
+      float* bc = reinterpret_cast<float*>(step + 1);                       // adam.py: bias_correction1, sqrt(bias_correction2), as ktup_optim.hip
+      bc[0] = (float)(1.0 - pow((double)b1, (double)t));
+      bc[1] = (float)sqrt(1.0 - pow((double)b2, (double)t));
+    }
   }
 }
 
@@ -946,9 +957,9 @@ __global__ __launch_bounds__(256) void adam_catchup_kernel(CatchupArgs a) {
 
 }  // namespace
 
-extern "C" int ktup_shard_step_count(int64_t* step, const int32_t* skip_count, const double* skip_value, void* stream) {
+extern "C" int ktup_shard_step_count(int64_t* step, const int32_t* skip_count, const double* skip_value, float beta1, float beta2, void* stream) {
   KTUP_REQUIRE(step, "ktup_shard_step_count: null counter");
-  hipLaunchKernelGGL(step_count_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, step, skip_count, skip_value);
+  hipLaunchKernelGGL(step_count_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, step, skip_count, skip_value, beta1, beta2);
   return check_launch("ktup_shard_step_count");
 }
 
@@ -970,7 +981,7 @@ extern "C" int ktup_shard_adam_catchup(int n_seg, float* const* tables, const in
   }
   if (end == 0) return KTUP_OK;
   a.nch = d / 4; a.lr = lr; a.eps = eps;
-  a.r = AdamRule{adam_rule->beta1, adam_rule->beta2, adam_rule->replay, adam_rule->step};
+  a.r = make_rule(adam_rule);
   hipStream_t st = (hipStream_t)stream;
 #define KTUP_AF(GL, CPL)                                                                                   \
   {                                                                                                        \
@@ -1166,7 +1177,7 @@ extern "C" int ktup_shard_apply(int kind, int n_tables, float* const* tables, co
   op.loss_step = loss_step; op.n_loss = n_loss; op.loss_sum = loss_sum; op.skipped = skipped_steps;
   op.adam = adam; op.small_lds = adam ? KTUP_SHARD_ADAM_STATE_PITCH(d) : d;
   if (adam) {
-    op.ar = AdamRule{adam_rule->beta1, adam_rule->beta2, adam_rule->replay, adam_rule->step};
+    op.ar = make_rule(adam_rule);
     for (int t = 0; t < n_tables; ++t) KTUP_REQUIRE(op.w.lds[t] >= KTUP_SHARD_ADAM_STATE_PITCH(d), "%s: table %d: an Adam state row is [m | v | last]: pitch >= 2 d + 4", name, t);
     if (!v4) return set_error(KTUP_ERR_UNSUPPORTED, "%s: Adam rows need d %% 4 == 0 and 16-byte aligned tables, states and gradients", name);
     ApplyRowsT<true> oa;                                  // same members, the Adam instantiation of the row rule
@@ -1246,7 +1257,7 @@ extern "C" int ktup_shard_reduce_apply(int kind, int n_tables, float* const* tab
   a.adagrad = adagrad; a.skip_i = skip_count; a.skip_d = skip_value;
   a.adam = adam; op.adam = adam; op.small_lds = adam ? KTUP_SHARD_ADAM_STATE_PITCH(d) : d;
   if (adam) {
-    a.ar = op.ar = AdamRule{adam_rule->beta1, adam_rule->beta2, adam_rule->replay, adam_rule->step};
+    a.ar = op.ar = make_rule(adam_rule);
     for (int t = 0; t < n_tables; ++t) KTUP_REQUIRE(op.w.lds[t] >= KTUP_SHARD_ADAM_STATE_PITCH(d), "%s: table %d: an Adam state row is [m | v | last]: pitch >= 2 d + 4", name, t);
   }
   hipStream_t st = (hipStream_t)stream;

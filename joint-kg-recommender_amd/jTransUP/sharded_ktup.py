@@ -320,7 +320,7 @@ class ShardedKtupStepper(_ShardedStepBase):
                 t.state = row_state(t.weight.data, kind)
         # Adam: the number of the step being applied, in device memory (the launches are replayed from graphs); shared by the steppers
         # of a joint schedule.  ktup_shard_step_count moves it just before every apply launch.
-        self.opt_step = opt_step if opt_step is not None else torch.zeros(1, dtype=torch.int64, device=dev)
+        self.opt_step = opt_step if opt_step is not None else torch.zeros(2, dtype=torch.int64, device=dev)      # [step, two floats of bias corrections]
         self.steps = 0
         if self.multi:
             self.recv_ids = i64(W, -1)
@@ -425,7 +425,7 @@ class ShardedKtupStepper(_ShardedStepBase):
             apply_ = bind('ktup_shard_apply', kind, 3, tabs, lds, states, slds, cap, d, _p(self.send_ids), 1, _p(self.Gwire), d, n_small, P,
                           sgp, sp0p, ss0p, sp1p, ss1p, None, self.lr, self.eps, _p(self.acc), SLOTS, self.max_norm,
                           self.counters.data_ptr() + 4 * (Wn * 3), None, *close, adam, stream)
-            count = [bind('ktup_shard_step_count', _p(self.opt_step), self.counters.data_ptr() + 4 * (Wn * 3), None, stream)] if adam else []
+            count = [bind('ktup_shard_step_count', _p(self.opt_step), self.counters.data_ptr() + 4 * (Wn * 3), None, self.betas[0], self.betas[1], stream)] if adam else []
             if self.fused_apply:
                 nw = arr(_ptrs(sg_list))
                 rnorm = bind('ktup_shard_reduce_norm', _p(self.Gcat), d, d, 3 * B, 2 * B, _p(self.sort_ws), E, W, _p(self.Gwire), d,
@@ -461,7 +461,7 @@ class ShardedKtupStepper(_ShardedStepBase):
         apply_ = bind('ktup_shard_apply', kind, 3, tabs, lds, states, slds, capo, d, _p(self.own_ids), 1, _p(self.Gown), d, n_small, P,
                       sgp, sp0p, ss0p, sp1p, ss1p, _p(self.bucket), self.lr, self.eps, self.acc.data_ptr() + 8 * SLOTS, 1, self.max_norm,
                       None, self.bucket.data_ptr() + 8 * (N + 1), *close, adam, stream)
-        count = [bind('ktup_shard_step_count', _p(self.opt_step), None, self.bucket.data_ptr() + 8 * (N + 1), stream)] if adam else []
+        count = [bind('ktup_shard_step_count', _p(self.opt_step), None, self.bucket.data_ptr() + 8 * (N + 1), self.betas[0], self.betas[1], stream)] if adam else []
         if self.fused_apply:
             onorm = bind('ktup_shard_reduce_norm', _p(self.Grecv), d, d, W, 0, _p(self.own_sort), W, self.W_own, _p(self.Gown), d,
                          _p(self.own_xkeys), 0, None, 0, 1.0, _p(self.acc), SLOTS, 0, None, 0, None, stream)
@@ -593,7 +593,7 @@ class ShardedKgStepper(_ShardedStepBase):
                 Et.state = row_state(Et.weight.data, kind)
         else:
             self.small_state = [None] * len(self.small)
-        self.opt_step = opt_step if opt_step is not None else torch.zeros(1, dtype=torch.int64, device=dev)
+        self.opt_step = opt_step if opt_step is not None else torch.zeros(2, dtype=torch.int64, device=dev)      # [step, two floats of bias corrections]
         self.steps = 0
         if self.multi:
             self.recv_ids = i64(W, -1)
@@ -658,7 +658,7 @@ class ShardedKgStepper(_ShardedStepBase):
             rapply = bind('ktup_shard_reduce_apply', kind, 1, tabs, lds, states, slds, cap, _p(self.send_ids), 1, _p(self.GE), d, d, E, 0,
                           _p(self.sort_ws), E, _p(self.Gwire), d, _p(self.xkeys), n_small, P, sgp, sp0p, ss0p, None, None, None, self.lr,
                           self.eps, _p(self.acc), SLOTS, self.max_norm, skip_i, None, *close, adam, stream)
-            count = [bind('ktup_shard_step_count', _p(self.opt_step), skip_i, None, stream)] if adam else []
+            count = [bind('ktup_shard_step_count', _p(self.opt_step), skip_i, None, self.betas[0], self.betas[1], stream)] if adam else []
             if adam:
                 catch = self._catchup(self.send_ids, self.cap, adam, stream, arr)
                 return [[route_phase(0, stream), catch] + ([] if self.direct else [pack]) + [order, step, rnorm] + count + [rapply]]
@@ -681,7 +681,7 @@ class ShardedKgStepper(_ShardedStepBase):
                       _p(self.own_sort), W, _p(self.Gown), d, _p(self.own_xkeys), n_small, P, sgp, sp0p, ss0p, None, None, _p(self.bucket),
                       self.lr, self.eps, self.acc.data_ptr() + 8 * SLOTS, 1, self.max_norm, None, self.bucket.data_ptr() + 8 * (N + 1),
                       *close, adam, stream)
-        count = [bind('ktup_shard_step_count', _p(self.opt_step), None, self.bucket.data_ptr() + 8 * (N + 1), stream)] if adam else []
+        count = [bind('ktup_shard_step_count', _p(self.opt_step), None, self.bucket.data_ptr() + 8 * (N + 1), self.betas[0], self.betas[1], stream)] if adam else []
         if adam:
             catch = self._catchup(self.own_ids, self.cap_own, adam, stream, arr)
             return [[route_phase(0, stream)], [oroute, catch, pack], [order, step, reduce_], [zero, onorm, pack_b], [fin_b] + count + [oapply]]

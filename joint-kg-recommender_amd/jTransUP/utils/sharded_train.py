@@ -287,7 +287,7 @@ class ShardedJointDriver(object):
         opt, d = getattr(self.trainer, 'optimizer', None), self.tables[0].d
         if not keys or opt is None:
             return
-        step = float(self.joint.rec.opt_step.item()) if self.kind == 'adam' else float(self.trainer.step)
+        step = float(self.joint.rec.opt_step[0].item()) if self.kind == 'adam' else float(self.trainer.step)
         pieces = [(getattr(self.m, n).weight, t.state, t.total_rows, True) for n, t in zip(BIG, self.tables)] + \
                  [(p, s, p.shape[0], False) for p, s in zip(self.small, self.joint.rec.small_state)]
         for p, st, rows, big in pieces:
@@ -323,7 +323,7 @@ class ShardedJointDriver(object):
             if self.kind == 'adam' and step > 0:         # every row is as the dense optimizer left it at `step`
                 st[:, 2 * d] = torch.full((st.shape[0],), step, dtype=torch.int32, device=self.dev).view(torch.float32)
         if self.kind == 'adam' and step > 0:
-            self.joint.rec.opt_step.fill_(step)
+            self.joint.rec.opt_step[:1].fill_(step)
 
     @torch.no_grad()
     def load_from_model(self):
@@ -339,7 +339,7 @@ class ShardedJointDriver(object):
         j = self.joint
         j.flush()
         torch.save({'rank': self.rank, 'world': self.world, 'step': self.trainer.step, 'joint_steps': j.steps, 'lr': self._lr,
-                    'opt_step': int(j.rec.opt_step.item()),
+                    'opt_step': int(j.rec.opt_step[0].item()),
                     'rows': {n: t.weight.data.cpu() for n, t in zip(BIG, self.tables)},
                     'row_state': {n: (None if t.state is None else t.state.cpu()) for n, t in zip(BIG, self.tables)},
                     'small': {n: p.data.cpu() for n, p in zip(SMALL, self.small)},
@@ -361,7 +361,7 @@ class ShardedJointDriver(object):
         for s, v in zip(self.joint.rec.small_state, ck['small_state']):
             if s is not None and v is not None:
                 s.copy_(v)                           # (the kg stepper shares the rel / norm sums)
-        self.joint.rec.opt_step.fill_(int(ck.get('opt_step', 0)))
+        self.joint.rec.opt_step[:1].fill_(int(ck.get('opt_step', 0)))
         self.joint.steps = ck['joint_steps']
         self.trainer.step = ck['step']
         self._dirty = True

@@ -301,7 +301,7 @@ def test_stepper_adam_equals_the_dense_adam(d, P, form):
     kw = {'one_graph': {}, 'exchange_form': {'force_exchange': True}, 'eager': {'use_graphs': False},
           'one_graph_gradient_buffer': {'fused_apply': False}}[form]
     tables, small, st = _run_stepper(full, small0, i2e, batches, 'adam', lr, 1e-5, max_norm, 0, 1, torch.device(DEV), orth=True, **kw)
-    assert st.steps == steps and int(st.opt_step.item()) == steps
+    assert st.steps == steps and int(st.opt_step[0].item()) == steps
     _check(tables, small, Wd, 0, 1)
     np.testing.assert_allclose(float(st.loss_sum.sum()), sum(losses), rtol=1e-4)
     # every touched row of every shard was written at the last step or brought up to it; untouched rows never moved
@@ -335,7 +335,7 @@ def test_adam_flush_replays_the_untouched_steps(gap):
     state[:, :d] = m0; state[:, d:2 * d] = v0
     state[:, 2 * d] = last.view(torch.float32)
     P, S = p0.to(DEV), state.to(DEV)
-    step = torch.tensor([t], dtype=torch.int64, device=DEV)
+    step = torch.tensor([t, 0], dtype=torch.int64, device=DEV)
     rule = AdamRule(b1, b2, adam_replay((b1, b2)), 0, step.data_ptr())
     L.call('ktup_shard_adam_flush', P.data_ptr(), P.stride(0), S.data_ptr(), S.stride(0), d, n, lr, eps, ctypes.addressof(rule),
            torch.cuda.current_stream().cuda_stream)

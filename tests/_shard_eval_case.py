@@ -32,8 +32,9 @@ def np_local_topk(local_scores, descending, topn, f_off, f_ids_local):
     return torch.from_numpy(ids), torch.from_numpy(out)
 
 
-def np_local_counts(local_scores, lo, descending, g_off, g_ids, gold_scores, f_off, f_ids):
-    """Stand-in of ops.gold_rank_counts: per gold entry the shard's unfiltered non-gold candidates ordered before it."""
+def np_local_counts(local_scores, lo, descending, g_off, g_ids, gold_scores, f_off, f_ids, stride=1):
+    """Stand-in of ops.gold_rank_counts: per gold entry the shard's unfiltered non-gold candidates ordered before it (local candidate j
+    has the global id lo + stride * j)."""
     sc = local_scores.numpy()
     nq, n = sc.shape
     counts = np.zeros(len(g_ids), np.int32)
@@ -46,8 +47,8 @@ def np_local_counts(local_scores, lo, descending, g_off, g_ids, gold_scores, f_o
                 counts[e] = -(1 << 20)
                 continue
             gk = (_key(float(gold_scores[e]), descending), g)
-            counts[e] = sum(1 for j in range(n) if (lo + j) not in filt and (lo + j) not in golds
-                            and (_key(sc[b, j], descending), lo + j) < gk)
+            counts[e] = sum(1 for j in range(n) if (lo + stride * j) not in filt and (lo + stride * j) not in golds
+                            and (_key(sc[b, j], descending), lo + stride * j) < gk)
     return torch.from_numpy(counts)
 
 
@@ -57,8 +58,16 @@ def _csr(lists, dtype=np.int32):
     return torch.from_numpy(off), torch.from_numpy(ids.astype(dtype))
 
 
-def run(rank, world, device, local_topk=None, local_counts=None, group=None):
+def run(rank, world, device, local_topk=None, local_counts=None, group=None, layout='block'):
+    """layout 'block': a rank holds the contiguous slice shard_bounds gives it (-shard_eval_candidates: whole tables on every rank);
+    'lattice': candidates rank, rank + world, ... (-shard_tables: the rows of a table sharded by row % world are a rank's candidates)."""
     from jTransUP.parallel import shard_bounds, sharded_gold_ranks, sharded_topk
+
+    def part(mat):                                         # -> (this rank's columns, global id of local column 0, extra keyword arguments)
+        if layout == 'lattice':
+            return mat[:, rank::world].copy(), rank, {'stride': world}
+        lo, hi = shard_bounds(mat.shape[1], rank, world)
+        return mat[:, lo:hi].copy(), lo, {}
     g = dict(np.load(os.path.join(GOLDEN, 'ranking.npz')))
     J = json.load(open(os.path.join(GOLDEN, 'ranking.json')))
     dev = torch.device(device)
@@ -75,22 +84,22 @@ def run(rank, world, device, local_topk=None, local_counts=None, group=None):
         if not sel:
             continue
         mat = np.stack([rows[i] for i in sel]).astype(np.float32)
-        lo, hi = shard_bounds(mat.shape[1], rank, world)
+        loc, lo, kw = part(mat)
         f_off, f_ids = _csr([filts[i] for i in sel])
-        ids, _ = sharded_topk(torch.from_numpy(mat[:, lo:hi].copy()).to(dev), lo, 10, desc, f_off.to(dev), f_ids.to(dev), group=group,
-                              local_topk=local_topk)
+        ids, _ = sharded_topk(torch.from_numpy(loc).to(dev), lo, 10, desc, f_off.to(dev), f_ids.to(dev), group=group,
+                              local_topk=local_topk, **kw)
         for k, i in enumerate(sel):
             got = [x for x in ids[k].tolist() if x >= 0]
             assert got == want[i], (rank, i, got, want[i])
     # ---- kg: the reference's 0-based filtered ranks (utils/misc.py:125-146)
     mat = g['kg.rows'].astype(np.float32)
-    lo, hi = shard_bounds(mat.shape[1], rank, world)
+    loc, lo, kw = part(mat)
     golds = [c['gold'] for c in J['kg']]
     f_off, f_ids = _csr([c['filter'] for c in J['kg']])
     g_off, g_ids = _csr(golds)
     g_rows = torch.from_numpy(np.repeat(np.arange(len(golds)), [len(x) for x in golds]).astype(np.int64))
-    ranks = sharded_gold_ranks(torch.from_numpy(mat[:, lo:hi].copy()).to(dev), lo, False, g_off.to(dev), g_ids.to(dev), g_rows.to(dev),
-                               f_off.to(dev), f_ids.to(dev), group=group, local_counts=local_counts).cpu().numpy()
+    ranks = sharded_gold_ranks(torch.from_numpy(loc).to(dev), lo, False, g_off.to(dev), g_ids.to(dev), g_rows.to(dev),
+                               f_off.to(dev), f_ids.to(dev), group=group, local_counts=local_counts, **kw).cpu().numpy()
     for b, c in enumerate(J['kg']):
         seg = ranks[int(g_off[b]):int(g_off[b + 1])]
         ids_sorted = sorted(c['gold'])
@@ -103,14 +112,14 @@ def run(rank, world, device, local_topk=None, local_counts=None, group=None):
     filt = [sorted(rng.choice(nc, size=rng.randint(0, 200), replace=False).tolist()) for _ in range(nq)]
     gold = [sorted(rng.choice(nc, size=rng.randint(1, 9), replace=False).tolist()) for _ in range(nq)]
     gold[3] = sorted(set(gold[3]) | {filt[3][0]} if filt[3] else gold[3])        # a gold that is itself filtered -> -1
-    lo, hi = shard_bounds(nc, rank, world)
+    loc, lo, kw = part(sc)
     f_off, f_ids = _csr(filt); g_off, g_ids = _csr(gold)
     g_rows = torch.from_numpy(np.repeat(np.arange(nq), [len(x) for x in gold]).astype(np.int64))
     for desc in (False, True):
-        ids, scs = sharded_topk(torch.from_numpy(sc[:, lo:hi].copy()).to(dev), lo, 10, desc, f_off.to(dev), f_ids.to(dev), group=group,
-                                local_topk=local_topk)
-        ranks = sharded_gold_ranks(torch.from_numpy(sc[:, lo:hi].copy()).to(dev), lo, desc, g_off.to(dev), g_ids.to(dev), g_rows.to(dev),
-                                   f_off.to(dev), f_ids.to(dev), group=group, local_counts=local_counts).cpu().numpy()
+        ids, scs = sharded_topk(torch.from_numpy(loc).to(dev), lo, 10, desc, f_off.to(dev), f_ids.to(dev), group=group,
+                                local_topk=local_topk, **kw)
+        ranks = sharded_gold_ranks(torch.from_numpy(loc).to(dev), lo, desc, g_off.to(dev), g_ids.to(dev), g_rows.to(dev),
+                                   f_off.to(dev), f_ids.to(dev), group=group, local_counts=local_counts, **kw).cpu().numpy()
         for b in range(nq):
             fs, gs = set(filt[b]), set(gold[b])
             order = sorted((j for j in range(nc) if j not in fs), key=lambda j: (_key(sc[b, j], desc), j))

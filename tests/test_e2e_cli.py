@@ -260,31 +260,35 @@ def test_joint_cli_shard_tables_refuses_what_it_cannot_do(dataset):
     assert r.returncode != 0 and '-l2_lambda 0' in (r.stdout + r.stderr)
 
 
-def test_joint_cli_shard_tables_torchrun(dataset):
-    """Two ranks (gloo test hook: both share this box's GPU), rows r % 2 on rank r: the exchange form with real all-to-alls.  Both
-    ranks log the same losses and metrics, equal to the one-process sharded run on the same global batches; each writes its shard."""
+@pytest.mark.parametrize('opt,lr,port', [('Adagrad', '0.05', '29551'), ('Adam', '0.005', '29553')])
+def test_joint_cli_shard_tables_torchrun(dataset, opt, lr, port):
+    """Two ranks (gloo test hook: both share this box's GPU), rows r % 2 on rank r: the exchange form with real all-to-alls, the
+    evaluation on the two shards (a rank's candidates are its own rows; query rows by all-reduce).  Both ranks log the same losses and
+    metrics, equal to the one-process sharded run on the same global batches; each writes its shard.  Adagrad, and the published
+    recipe's Adam (owner-side catch-up before the rows are packed)."""
     data = str(dataset)
     logs = os.path.join(data, 'log')
     env = dict(os.environ, KTUP_DIST_BACKEND='gloo')
     tail = ['-nohas_visualization', '-batch_size', '32', '-embedding_size', '64', '-seed', '3', '-eval_interval_steps', '10',
-            '-training_steps', '25', '-early_stopping_steps_to_wait', '0', '-learning_rate', '0.05', '-topn', '10', '-model_type', 'jtransup',
+            '-training_steps', '25', '-early_stopping_steps_to_wait', '0', '-learning_rate', lr, '-topn', '10', '-model_type', 'jtransup',
             '-rec_test_files', 'valid.dat', '-kg_test_files', 'valid.dat', '-joint_ratio', '0.7', '-noshare_embeddings', '-nodevice_sampling',
-            '-l2_lambda', '0', '-shard_tables', '-shard_eval_candidates']
+            '-l2_lambda', '0', '-optimizer_type', opt, '-shard_tables', '-shard_eval_candidates']
+    n2, n1 = 'ktup-shard2-' + opt, 'ktup-shard1-' + opt
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-           '--master-port', '29551', os.path.join(PKG, 'run_knowledgable_recommendation.py'), '-data_path', data, '-log_path', logs,
-           '-dataset', 'ml1m', '-experiment_name', 'ktup-shard2'] + tail
+           '--master-port', port, os.path.join(PKG, 'run_knowledgable_recommendation.py'), '-data_path', data, '-log_path', logs,
+           '-dataset', 'ml1m', '-experiment_name', n2] + tail
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-    log0 = open(os.path.join(logs, 'ktup-shard2.log')).read()
-    log1 = open(os.path.join(logs, 'ktup-shard2.rank1.log')).read()
+    log0 = open(os.path.join(logs, n2 + '.log')).read()
+    log1 = open(os.path.join(logs, n2 + '.rank1.log')).read()
     assert 'rank 0 of 2' in log0 and 'rank 1 of 2' in log1
     assert _loss_lines(log0) == _loss_lines(log1) and len(_loss_lines(log0)) >= 3
     assert _metric_rows(log0) == _metric_rows(log1) and len(_metric_rows(log0)) >= 3
-    assert os.path.isfile(os.path.join(logs, 'ktup-shard2.ckpt.shard0of2')) and os.path.isfile(os.path.join(logs, 'ktup-shard2.rank1.ckpt.shard1of2'))
+    assert os.path.isfile(os.path.join(logs, n2 + '.ckpt.shard0of2')) and os.path.isfile(os.path.join(logs, n2 + '.rank1.ckpt.shard1of2'))
     one = subprocess.run([sys.executable, os.path.join(PKG, 'run_knowledgable_recommendation.py'), '-data_path', data, '-log_path', logs,
-                          '-dataset', 'ml1m', '-experiment_name', 'ktup-shard1'] + tail[:-1], capture_output=True, text=True, timeout=600)
+                          '-dataset', 'ml1m', '-experiment_name', n1] + tail[:-1], capture_output=True, text=True, timeout=600)
     assert one.returncode == 0, one.stdout[-3000:] + one.stderr[-3000:]
-    log = open(os.path.join(logs, 'ktup-shard1.log')).read()
+    log = open(os.path.join(logs, n1 + '.log')).read()
     for (ra, ka), (rb, kb) in zip(_loss_lines(log)[1:], _loss_lines(log0)[1:]):
         assert abs(ra - rb) <= 2e-3 * max(1.0, abs(ra)) and abs(ka - kb) <= 2e-3 * max(1.0, abs(ka))
     assert all(abs(x - y) <= 0.03 for a, b in zip(_metric_rows(log), _metric_rows(log0)) for x, y in zip(a, b))

@@ -121,6 +121,7 @@ def _shard_eval_worker(rank, world, port):
     try:
         import _shard_eval_case as C
         C.run(rank, world, DEV)                       # the HIP local kernels: ktup_eval_topk_filtered, ktup_eval_gold_rank_counts
+        C.run(rank, world, DEV, layout='lattice')     # candidates rank + world * j: ktup_eval_gold_rank_counts_strided (-shard_tables)
     finally:
         dist.destroy_process_group()
 

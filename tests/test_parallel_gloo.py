@@ -145,6 +145,13 @@ def _shard_eval_worker(rank, world):
     C.run(rank, world, 'cpu', local_topk=C.np_local_topk, local_counts=C.np_local_counts)
 
 
+def _shard_eval_lattice_worker(rank, world):
+    """The same with the candidates of a rank = the lattice rank + world * j (-shard_tables: evaluation straight from the row shards):
+    strided local ids for the filter lists, global ids back for the merge, strided rank counts -- the golden lists / ranks again."""
+    import _shard_eval_case as C
+    C.run(rank, world, 'cpu', local_topk=C.np_local_topk, local_counts=C.np_local_counts, layout='lattice')
+
+
 def _gather_table_worker(rank, world):
     """-shard_tables: before an evaluation or a checkpoint every rank rebuilds the whole tables from the shards
     (utils/sharded_train.gather_table: rows g % world == r live on rank r) -- row counts that do and do not divide by the ranks,
@@ -160,13 +167,17 @@ def _gather_table_worker(rank, world):
 
 
 @pytest.mark.parametrize('worker', [_replica_worker, _sharded_worker, _sharded_step_worker, _merge_worker, _shard_eval_worker,
-                                    _gather_table_worker])
+                                    _shard_eval_lattice_worker, _gather_table_worker])
 def test_world_size_2_gloo(worker):
     _spawn(worker)
 
 
 def test_shard_gather_on_three_ranks():
     _spawn(_gather_table_worker, world=3)
+
+
+def test_lattice_shard_evaluation_on_three_ranks():
+    _spawn(_shard_eval_lattice_worker, world=3)
 
 
 def test_single_process_paths():

@@ -175,9 +175,17 @@ def cpu_train_step_baseline(threads, budget_s=8.0):
                       '(losses + backward + clip_grad_norm_ + dense Adagrad, weight decay 1e-5)'}
 
 
-def ramp_clocks(fn, device, seconds=0.25):
+def ramp_clocks(fn, device, seconds=0.25, world=1, calls=20):
     """A device that sat idle while the host built a model needs ~50 ms of load to reach its clocks; a 10 ms timed loop started
-    cold measures the ramp, not the step (seen as a 7x outlier on one of the B=512 legs per run).  Untimed, like warm-up steps."""
+    cold measures the ramp, not the step (seen as a 7x outlier on one of the B=512 legs per run).  Untimed, like warm-up steps.
+    With several ranks and collectives inside `fn` the loop runs a FIXED number of calls: a wall-clock bound lets one rank leave
+    the loop a call earlier than its peer, which then waits in an all-to-all forever (round 5: the config-5 leg of the two-rank
+    bench test hit the 240 s watchdog once in three runs)."""
+    if world > 1:
+        for _ in range(calls):
+            fn()
+        torch.cuda.synchronize(device)
+        return
     t0 = time.perf_counter()
     while time.perf_counter() - t0 < seconds:
         fn()
@@ -1018,15 +1026,15 @@ def config5_leg(device, world, rank, steps=100, warmup=10, batch=8192, full=True
     out = {'backend': dist.get_backend() if world > 1 else 'single process', 'world': world, 'batch_per_rank': B,
            'rows': {'users': NUs, 'items': NIs, 'entities': NEs}, 'd': d, 'tables_GB_per_rank': (NUs + NIs + NEs) * d * 4 / world / 1e9}
 
-    def run(label, what='rec', **kw):
+    def run(label, what='rec', kind='adagrad', **kw):
         n = steps + warmup
-        rec = ShardedKtupStepper(Ut, It, Et, *small, item2ent, batch=B, kind='adagrad', lr=0.005, max_norm=5.0, orth=(what != 'rec'), **kw)
+        rec = ShardedKtupStepper(Ut, It, Et, *small, item2ent, batch=B, kind=kind, lr=0.005, max_norm=5.0, orth=(what != 'rec'), **kw)
         rec.set_feed([torch.randint(0, hi, (n, B), generator=gen, device=device) for hi in (NUs, NIs, NIs)])   # device-fed: the step's own launches walk the columns
         st = rec
         if what != 'rec':       # the kg half of the joint schedule (knowledgable_recommendation.py:345-383) on the same entity shard
             kkw = {k: v for k, v in kw.items() if k != 'fused_apply'}
-            kg = ShardedKgStepper(Et, small[2], small[3], batch=B, kind='adagrad', lr=0.005, max_norm=5.0, margin=1.0, kg_lambda=1.0,
-                                  small_state=rec.small_state[2:4], **kkw)
+            kg = ShardedKgStepper(Et, small[2], small[3], batch=B, kind=kind, lr=0.005, max_norm=5.0, margin=1.0, kg_lambda=1.0,
+                                  small_state=rec.small_state[2:4], opt_step=rec.opt_step, **kkw)
             ph, pt, oth = (torch.randint(0, NEs, (n, B), generator=gen, device=device) for _ in range(3))
             pr = torch.randint(0, P, (n, B), generator=gen, device=device)
             flip = torch.rand(n, B, generator=gen, device=device) < 0.5       # a corrupted triple keeps its head or its tail
@@ -1034,7 +1042,7 @@ def config5_leg(device, world, rank, steps=100, warmup=10, batch=8192, full=True
             st = kg if what == 'kg' else ShardedKtupJoint(rec, kg, 0.7)
         for _ in range(warmup):
             st.run()
-        ramp_clocks(st.run, device)
+        ramp_clocks(st.run, device, world=world)
         torch.cuda.synchronize(device)
         if world > 1:
             dist.barrier()
@@ -1071,6 +1079,17 @@ def config5_leg(device, world, rank, steps=100, warmup=10, batch=8192, full=True
         out['exchange_form']['note'] = ('the several-ranks route on one rank: five graph segments, rows packed into the wire '
                                         'buffer, the three all-to-alls as device copies')
         out['exchange_form']['joint'] = run('exchange joint', what='joint', force_exchange=True)
+    # the published recipe's optimizer (ktup.sh:1: Adam, l2_lambda 0) on the shards: row-sparse Adam with exact catch-up of the steps a row
+    # was not touched for (include/ktup_hip.h ktup_adam_t); last, so that a failure here cannot take the figures above with it
+    try:
+        free, _ = torch.cuda.mem_get_info(device)
+        if free > 2.3 * (NUs + NIs + NEs) * d * 4 / world:                # [m | v | last] rows: twice the tables
+            out['joint_adam'] = run('joint adam', what='joint', kind='adam')
+            out['joint_adam']['what'] = 'the 7 : 3 cycle with -optimizer_type Adam (row-sparse with catch-up = the dense Adam of utils/trainer.py:63-66)'
+        else:
+            out['joint_adam'] = {'skipped': 'not enough free device memory for the Adam state'}
+    except Exception as e:                                               # noqa: BLE001 -- reported, never fatal for the bench line
+        out['joint_adam'] = {'error': '%s: %s' % (type(e).__name__, e)}
     out['note'] = ('top level: the rec step (the round-3 figure); kg_step / joint: the kg half and the 7 : 3 cycle.  One rank: ONE graph of '
                    '8 launches per step (route 5, fused step 1, norm walk 1, apply walk 1 -- the walks carry the small tables and the '
                    'bookkeeping as extra workgroups), four of them dependent on one queue, the route\'s other four on a second graph branch '
@@ -1113,7 +1132,7 @@ def config4_sharded_leg(device, world, rank, steps=200, warmup=20):
     joint.kg.set_feed([ph, pt, pr, torch.where(flip, oth, ph), torch.where(flip, pt, oth), pr])
     for _ in range(warmup):
         joint.run()
-    ramp_clocks(joint.run, device)
+    ramp_clocks(joint.run, device, world=world)
     torch.cuda.synchronize(device)
     if world > 1:
         dist.barrier()

@@ -24,7 +24,15 @@ def build(tmp_path, optimizer, gumbel, D=36):
     new_map = {i: ((i * 3) % NE if i % 5 else -1, i) for i in range(NI)}
     torch.manual_seed(4)
     m = jt.jTransUPModel(False, D, NU, NI, NE, NR, i_map, new_map, False, gumbel)
-    return FLAGS, m, ModelTrainer(m, logging.getLogger('ft'), 10, FLAGS), (NU, NI, NE, NR)
+    tr = ModelTrainer(m, logging.getLogger('ft'), 10, FLAGS)
+    if optimizer == 'Adam':
+        # these tests compare two HIP routes whose gradient atomics land in different orders: with Adam's default eps = 1e-8 an element
+        # whose gradient is of that size turns a last-bit difference into a step of ~lr / 4, and how many such elements a draw holds
+        # decided whether a run passed (round 5's first full run: 5.3e-5 against a cap of 5e-5).  eps = 1e-5 keeps every element
+        # well-conditioned; the arithmetic under test is the same.  (Against the REFERENCE the default eps is kept and the
+        # ill-conditioned elements are named by the fixture: tests/test_hip_train_golden.py.)
+        tr.optimizer.param_groups[0]['eps'] = 1e-5
+    return FLAGS, m, tr, (NU, NI, NE, NR)
 
 
 @pytest.mark.parametrize('D', [36, 100, 64])

@@ -32,6 +32,8 @@ def build(tmp_path, optimizer, gumbel, D=36):
         # well-conditioned; the arithmetic under test is the same.  (Against the REFERENCE the default eps is kept and the
         # ill-conditioned elements are named by the fixture: tests/test_hip_train_golden.py.)
         tr.optimizer.param_groups[0]['eps'] = 1e-5
+    elif optimizer == 'Adagrad':
+        tr.optimizer.param_groups[0]['eps'] = 1e-5       # same reason: lr g / (sqrt(g^2) + 1e-10) is +-lr for a first gradient of ANY size
     return FLAGS, m, tr, (NU, NI, NE, NR)
 
 

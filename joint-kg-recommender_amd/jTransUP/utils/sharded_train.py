@@ -134,6 +134,7 @@ class ShardedJointDriver(object):
         if lr != self._lr:
             self._collect()
             self.joint.check()                       # the steppers about to be replaced carry the skipped-step counters
+            self.joint.flush()                       # Adam: the moves the old optimizer still owes the rows it has not touched lately
             for t in self.tables:
                 if t.state is not None:
                     t.state.zero_()

@@ -1,16 +1,19 @@
 """-shard_tables: KTUP's joint training loop (knowledgable_recommendation.py:319-403) on ROW-SHARDED user / item / entity tables
-(BASELINE config 5): every rank owns rows {g : g % world == rank} of the three big tables and their Adagrad sums, the four
+(BASELINE config 5): every rank owns rows {g : g % world == rank} of the three big tables and their optimizer state, the four
 preference-side tables (a few dozen rows) stay replicated; a step is sharded_ktup.ShardedKtupJoint's -- fixed-shape exchange,
 fused step kernels, row-sparse optimizer on exactly the touched rows, replayed as HIP graphs.  The reference is single-device:
 this module only adapts that stepper to the driver's loop (same batches, same step counting, same logging, evaluation and
 checkpointing as the replicated route of utils/fast_train.py).
 
     torchrun --nproc-per-node 8 run_knowledgable_recommendation.py -model_type jtransup -noshare_embeddings -shard_tables \
-        -optimizer_type Adagrad -l2_lambda 0 -seed 7 -shard_eval_candidates ...
+        -optimizer_type Adam -l2_lambda 0 -L1_flag -seed 7 ...                    # the recipe of the reference's ktup.sh
 
-What the rows' owners do NOT keep is a dense gradient or a dense optimizer pass: a row that no batch touches never moves, which
-equals the reference's dense step exactly for Adagrad / plain SGD without weight decay (l2_lambda = 0) -- other settings are
-refused by name.  Every rank draws the same global batches (same -seed, like the replicated route) and takes its slice.
+What the rows' owners do NOT keep is a dense gradient or a dense optimizer pass.  Under Adagrad / plain SGD without weight decay
+(l2_lambda = 0) a row that no batch touches never moves, so updating the touched rows IS the reference's dense step.  Under Adam a dense
+step moves every row that ever had a gradient; the steppers replay the zero-gradient steps a row has missed before the row is read
+again (sharded_ktup.py, include/ktup_hip.h ktup_adam_t), `flush()` does it for all rows before an evaluation or a checkpoint --
+the same tables as torch.optim.Adam over whole tables.  Other settings are refused by name.  Every rank draws the same global batches
+(same -seed, like the replicated route) and takes its slice.
 
 Memory: the shards are the ONLY resident copy of the three big tables.  Once they are built the model's own whole tables are released
 (zero-row placeholders) and so is the dense optimizer's state for them; a rank holds rows/world x (table + optimizer state).

@@ -128,3 +128,77 @@ def test_tracked_norm_identity_and_its_fp32_error():
             total += float(lane)                                     # (workgroup totals are fp64)
         exact = float((buf.astype(np.float64) ** 2).sum())
         assert abs(total - exact) <= 2e-6 * exact, (trial, total, exact)
+
+
+def test_sparse_adam_with_catch_up_is_the_dense_adam():
+    """The third claim (round 5; csrc/ktup_shard_step.hip adam_row, jTransUP/sharded_ktup.py): a row-sparse Adam that, BEFORE a row is read,
+    replays the zero-gradient steps the row has missed -- m <- beta1 m, sqrt(v) <- sqrt(beta2) sqrt(v), p <- p - lr / (1 - beta1^s) m /
+    (sqrt(v) / sqrt(1 - beta2^s) + eps), at most `replay` of them one by one, then m and v in closed form -- and only then applies the
+    step, holds the same tables as torch.optim.Adam stepping EVERY row with zero-filled gradients (what utils/trainer.py:63-66 builds).
+    Restated in numpy (fp32 state, the kernel's order of operations), on a loss whose gradient depends on the weights (so a row read
+    stale would show), rows touched at random with gaps from 1 to beyond the replay cap.  Also pins the cap the host computes."""
+    import math
+
+    import torch
+
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, 'joint-kg-recommender_amd'))
+    from jTransUP.sharded_ktup import adam_replay, adam_state_pitch
+    b1, b2, lr, eps = 0.9, 0.999, 0.001, 1e-8
+    K = adam_replay((b1, b2))
+    r = b1 / math.sqrt(b2)
+    assert K == 110 and r ** K / (1 - r) < 1e-4 and adam_state_pitch(100) == 204        # the dropped tail < 1e-4 of the first increment
+    rng = np.random.RandomState(7)
+    rows, d, T = 40, 12, 400
+    w0 = rng.standard_normal((rows, d)).astype(np.float32)
+    c = (0.5 + rng.rand(rows, d)).astype(np.float32)                   # loss = sum over touched rows of 0.5 c w^2 + b w  ->  g = c w + b
+    b = (rng.choice([-1.0, 1.0], (rows, d)) * (2.5 + rng.rand(rows, d))).astype(np.float32)   # |b| > |c w| over the run: no gradient near 0
+    touch_p = np.concatenate([np.full(10, 0.9), np.full(10, 0.2), np.full(10, 0.02), np.full(10, 0.004)])   # gaps of ~1, ~5, ~50, ~250 steps
+    touched = rng.rand(T, rows) < touch_p[None, :]
+    touched[0] = True                                                  # (every table gets a gradient at step 1, like the rec step)
+    # ---- dense reference
+    W = torch.nn.Parameter(torch.from_numpy(w0.copy()))
+    opt = torch.optim.Adam([W], lr=lr, betas=(b1, b2), eps=eps)
+    C, Bt = torch.from_numpy(c), torch.from_numpy(b)
+    for t in range(T):
+        opt.zero_grad(set_to_none=False)
+        mask = torch.from_numpy(touched[t].astype(np.float32))[:, None]
+        (mask * (0.5 * C * W * W + Bt * W)).sum().backward()
+        opt.step()
+    dense = W.detach().numpy()
+    # ---- the lazy form
+    f = np.float32
+    p, m, v = w0.copy(), np.zeros_like(w0), np.zeros_like(w0)
+    last = np.zeros(rows, np.int64)
+
+    def catch_up(i, upto):
+        miss = upto - last[i]
+        if last[i] > 0 and miss > 0:
+            k_run = min(miss, K)
+            b1p, b2p = b1 ** int(last[i]), b2 ** int(last[i])
+            sv = np.sqrt(v[i]).astype(f)
+            sb2 = f(math.sqrt(b2))
+            for _ in range(k_run):
+                b1p *= b1; b2p *= b2
+                c1 = f(lr / (1.0 - b1p)); ib = f(1.0 / math.sqrt(1.0 - b2p))
+                m[i] = (m[i] - m[i] * f(1 - b1)).astype(f)
+                sv = (sb2 * sv).astype(f)
+                p[i] = (p[i] - (c1 * m[i]) / (sv * ib + f(eps))).astype(f)
+            v[i] = (f(b2 ** int(miss)) * v[i]).astype(f)
+            if miss > k_run:
+                m[i] = (f(b1 ** int(miss - k_run)) * m[i]).astype(f)
+        if upto > last[i] and last[i] > 0:
+            last[i] = upto
+    for t in range(1, T + 1):
+        for i in np.nonzero(touched[t - 1])[0]:
+            catch_up(i, t - 1)                                         # BEFORE the row is read
+            g = (c[i] * p[i] + b[i]).astype(f)
+            m[i] = (m[i] + (g - m[i]) * f(1 - b1)).astype(f)
+            v[i] = (f(1 - b2) * g * g + f(b2) * v[i]).astype(f)
+            p[i] = (p[i] - f(lr / (1 - b1 ** t)) * (m[i] / (np.sqrt(v[i]) / f(math.sqrt(1 - b2 ** t)) + f(eps)))).astype(f)
+            last[i] = t
+    for i in range(rows):
+        catch_up(i, T)                                                 # the flush before an evaluation
+    np.testing.assert_allclose(p, dense, rtol=2e-5, atol=5e-6)
+    # and what a stale read costs (no catch-up before the gradient): far outside that band -- the test would see it
+    assert r ** 5 > 0.5                                                # (a row resting five steps still owes more than half its first move)

@@ -296,6 +296,12 @@ def run(only_forward=False):
                 trainer.loadEmbedding(os.path.join(FLAGS.log_path, filename), model.state_dict())
         model.is_pretrained = True
     if only_forward:
+        shards = None
+        if getattr(FLAGS, 'shard_tables', False):      # -eval_only_mode under -shard_tables: shard what was loaded (or pick this rank's
+            from jTransUP.utils.sharded_train import ShardedJointDriver      # shard file up) and evaluate ON the shards, like the training loop
+            shards = ShardedJointDriver(model, trainer, FLAGS, FLAGS.batch_size, logger)
+            logger.info('Row-sharded evaluation (-shard_tables): rank %d of %d.' % (shards.rank, shards.world))
+            shards.sync_model() if FLAGS.is_report else shards.begin_eval()
         for i, ed in enumerate(rating_eval_datasets):
             others = [rating_train_dict] + [d[3] for j, d in enumerate(rating_eval_datasets) if j != i] \
                 if FLAGS.filter_wrong_corrupted else None
@@ -308,6 +314,8 @@ def run(only_forward=False):
                 td = [tail_dict] + [d[5] for j, d in enumerate(triple_eval_datasets) if j != i]
             evaluateKG(FLAGS, model, ed[0], ed[1], ed[4], ed[5], hd, td, e_map, logger, eval_descending=False,
                        is_report=FLAGS.is_report)
+        if shards is not None:
+            shards.end_eval()
     else:
         train_loop(FLAGS, model, trainer, rating_train_dataset, triple_train_dataset, rating_eval_datasets, triple_eval_datasets,
                    e_map, i_map, ikg_map, logger, vis=vis, is_report=False)

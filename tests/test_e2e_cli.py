@@ -248,6 +248,13 @@ def test_joint_cli_shard_tables_published_recipe(dataset):
     assert all(abs(x - y) <= 0.055 for a, b in zip(ma, mb) for x, y in zip(a, b)), (ma, mb)
     ck = torch.load(os.path.join(logs, 'ktup-recipe-shard.ckpt.shard0of1'), map_location='cpu', weights_only=False)
     assert ck['opt_step'] == ck['step'] >= 10 and ck['row_state']['user_embeddings'].shape[1] == 2 * 64 + 4      # (written at the best evaluation)
+    # the checkpoint evaluated again under -shard_tables: whole tables from the reference-layout file, then this rank's shard file (rows,
+    # moments, step counter) picked up beside it; evaluated ON the shards it gives a metric row the training run logged at that step
+    log3, _ = run_cli('run_knowledgable_recommendation.py', dataset, 'ktup-recipe-shard-eval',
+                      common + ['-shard_tables', '-eval_only_mode', '-load_experiment_name', os.path.join(logs, 'ktup-recipe-shard.ckpt')])
+    assert 'Found checkpoint, restoring.' in log3 and "Restored rank 0's shard" in log3
+    again = _metric_rows(log3)
+    assert again and again[0] in mb, (again, mb)
 
 
 def test_joint_cli_shard_tables_refuses_what_it_cannot_do(dataset):

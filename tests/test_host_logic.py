@@ -357,3 +357,22 @@ def test_shard_tables_refuses_what_it_cannot_train_by_flag_name():
     with pytest.raises(L.KtupError) as e:                                              # a width without fused step kernels
         S.check_flags(types.SimpleNamespace(**ok), types.SimpleNamespace(embedding_size=36, rel_total=20))
     assert 'embedding_size 36' in str(e.value)
+
+
+def test_sparse_adam_host_side_layouts():
+    """jTransUP/sharded_ktup.py: what the host hands the row-sparse Adam kernels (include/ktup_hip.h ktup_adam_t) -- the struct's C layout,
+    the state row [m | v | last], how many missed steps are replayed one by one for the betas in use, and which state a table needs."""
+    import ctypes
+    import math
+    from jTransUP.sharded_ktup import KINDS, AdamRule, _check_state, adam_replay, adam_state_pitch, row_state
+    assert KINDS == {'sgd': 0, 'adagrad': 1, 'adam': 2}                                   # KTUP_OPT_SGD / _ADAGRAD / _ADAM
+    assert ctypes.sizeof(AdamRule) == 24 and AdamRule.step.offset == 16 and AdamRule.replay.offset == 8      # {float, float, int32, int32, pointer}
+    assert adam_state_pitch(256) == 516 and adam_state_pitch(100) % 4 == 0                # rows stay 16-byte aligned
+    for betas in ((0.9, 0.999), (0.8, 0.99), (0.95, 0.999)):
+        k, r = adam_replay(betas), betas[0] / math.sqrt(betas[1])
+        assert r ** k <= 1e-5 < r ** (k - 1)                                              # the first k whose increment is below 1e-5 of the first
+    assert adam_replay((0.9, 0.999)) == 110 and adam_replay((0.0, 0.999)) == 0
+    w = torch.zeros(7, 12)
+    assert row_state(w, 'sgd') is None and row_state(w, 'adagrad').shape == (7, 12) and row_state(w, 'adam').shape == (7, 28)
+    assert _check_state(None, w, 'sgd') and _check_state(row_state(w, 'adam'), w, 'adam') and not _check_state(row_state(w, 'adagrad'), w, 'adam')
+    assert not _check_state(None, w, 'adagrad')                                           # a stepper of another kind re-creates the state

@@ -232,8 +232,10 @@ def capture(graph, **kw):
     """`with torch.cuda.graph(graph)` with Python's cyclic garbage collector held off.  A collection that happens to run INSIDE a
     capture (binding a step's launches allocates thousands of ctypes objects) may finalise garbage of earlier steppers -- an older
     CUDAGraph, tensors whose blocks go back to the driver -- and the HIP runtime refuses those calls while a stream is capturing:
-    the process aborts (seen once in three runs of the GPU suite, in whichever test captured when the collector's turn came)."""
-    _gc.collect()
+    the process aborts (seen once in three runs of the GPU suite, in whichever test captured when the collector's turn came).
+    Holding the collector off is all that needs: a full `gc.collect()` in front of every capture (rounds 4-5) walked the whole heap --
+    120 ms with an ml1m-size dataset's dicts on it, charged to the evaluation pass that captures (tools/cli_throughput.py: 20.4 k ->
+    11.5 k steps/s over the interval that holds it)."""
     was = _gc.isenabled()
     _gc.disable()
     try:

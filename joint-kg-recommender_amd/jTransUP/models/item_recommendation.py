@@ -118,6 +118,7 @@ def run(only_forward=False):
     train_iter, train_total, train_list, train_dict = train_dataset
     user_total = max(len(u_map), max(u_map.values()))
     item_total = max(len(i_map), max(i_map.values()))
+    D.freeze_heap()
     model = init_model(FLAGS, user_total, item_total, 0, 0, logger)
     trainer = ModelTrainer(model, logger, math.ceil(train_total / FLAGS.batch_size), FLAGS)
     if FLAGS.load_ckpt_file is not None:

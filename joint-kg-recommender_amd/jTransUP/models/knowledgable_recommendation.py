@@ -284,6 +284,7 @@ def run(only_forward=False):
     relation_total = max(len(r_map), max(r_map.values()))
     if FLAGS.share_embeddings:
         item_total = entity_total = len(ikg_map)
+    D.freeze_heap()
     model = init_model(FLAGS, user_total, item_total, entity_total, relation_total, logger, i_map=i_map, e_map=e_map, new_map=ikg_map)
     triple_epoch = math.ceil(float(triple_train_total) / (1 - FLAGS.joint_ratio) / FLAGS.batch_size) if FLAGS.joint_ratio < 1 else 0
     rating_epoch = math.ceil(float(rating_train_total) / FLAGS.joint_ratio / FLAGS.batch_size)

@@ -144,6 +144,7 @@ def run(only_forward=False):
     entity_total = max(len(e_map), max(e_map.values()))
     relation_total = max(len(r_map), max(r_map.values()))
     train_iter, train_total, train_list, train_head_dict, train_tail_dict = train_dataset
+    D.freeze_heap()
     model = init_model(FLAGS, 0, 0, entity_total, relation_total, logger)
     trainer = ModelTrainer(model, logger, math.ceil(train_total / FLAGS.batch_size), FLAGS)
     if FLAGS.load_ckpt_file is not None:

@@ -1068,6 +1068,7 @@ def config5_leg(device, world, rank, steps=100, warmup=10, batch=8192, full=True
         leg['algorithmic_MB'] = alg / 1e6
         leg['hbm_frac_algorithmic'] = alg / (leg['ms_per_step_device'] * 1e-3) / 1e9 / HBM_PEAK_GBS
         leg['hbm_frac_with_optimizer_rows'] = moved / (leg['ms_per_step_device'] * 1e-3) / 1e9 / HBM_PEAK_GBS
+        rec.close()
         del st
         return leg
     out.update(run('default'))
@@ -1141,6 +1142,7 @@ def config4_sharded_leg(device, world, rank, steps=200, warmup=20):
     torch.cuda.synchronize(device)
     wall = _max_over_ranks(1e3 * (time.perf_counter() - t0) / steps, device, world)
     joint.check()
+    joint.close()
     return {'backend': dist.get_backend() if world > 1 else 'single process', 'world': world, 'global_batch': 512, 'per_rank_batch': B,
             'ms_per_step': wall, 'scored_rows_per_s': 2 * 512 / (wall * 1e-3), 'wire_rows_per_rank': {'rec': joint.rec.W, 'kg': joint.kg.W},
             'optimizer': 'row-sparse Adagrad, l2_lambda 0 (the replicated route of dp_train_step runs dense Adagrad with weight decay)',

@@ -460,7 +460,9 @@ int ktup_shard_route(const int64_t* ids, int64_t n_entries, int64_t block, int n
  * phase: 0 = the whole route; 1 = its first launch only (scratch init + the entry list); 2 = the remaining four launches -- a
  * scorer that needs nothing but the entry list (global ids) can then run beside phase 2 on another stream; 3 = the whole route
  * WITHOUT moving the cursor -- for a scorer that reads the id columns itself and runs beside ALL of it (ktup_shard_reduce_norm moves
- * the cursor once both are done).                                                                                              */
+ * the cursor once both are done); 4 = the first three launches (send_ids, inverse, pair_map: what an id exchange and the scorer wait
+ * for); 5 = the last two (the counting sort's scan + scatter, read by the row-gradient reduction only) -- phase 5 may then run on
+ * another stream beside the id exchange and the pack launch.                                                                   */
 int ktup_shard_route_ktup(const int64_t* u, const int64_t* pos_items, const int64_t* neg_items, int64_t B, int64_t n_batches,
                           int64_t* cursor, const int32_t* item2ent, int64_t ent_pad, int64_t* entries, int world,
                           const int64_t* cap, int64_t* inverse, int64_t* send_ids, int32_t* pair_map, int32_t* sort_ws,
@@ -529,6 +531,17 @@ int ktup_zero_async(void* ptr, int64_t nbytes, void* stream);
  *   SGD / Adagrad rule of ktup_shard_apply into table_t[ids[w]]; the listed rows are applied from gwire, which is left all-zero
  *   again; small tables as in ktup_shard_apply -- both as extra workgroups of the ONE launch.  Same arguments, same G, same sort_ws as the norm call. */
 int64_t ktup_shard_reduce_list_len(int64_t n_entries, int d);
+/* The requester's side of the gradient exchange WITHOUT a zero-filled buffer and without a read-modify-write:
+ * ktup_shard_reduce_store: gwire[w] = sum of the G rows of the entries sorted to wire row w (arguments of ktup_shard_reduce_rows).  A row whose
+ *   entries lie inside one workgroup's stretch of the sorted order -- all rows with one entry, nearly all others -- is STORED; a row cut by a
+ *   workgroup's edge is summed by float atomics and must be zero beforehand, which is what
+ * ktup_shard_zero_shared_rows does: it zero-fills every wire row that has two or more entries (named by the entry of rank 1 in the row; any
+ *   time after ktup_shard_route's finish launch, phase 4).  Wire rows without an entry are not written at all (the owner never reads them:
+ *   their id is negative). */
+int ktup_shard_zero_shared_rows(const int32_t* sort_ws, int64_t n_entries, int64_t n_wire_rows, const int64_t* inverse, float* gwire,
+                                int64_t ldw, int d, void* stream);
+int ktup_shard_reduce_store(const float* G, int64_t ldg, int d, int64_t n_src, int64_t src_off, const int32_t* sort_ws,
+                            int64_t n_entries, int64_t n_wire_rows, float* gwire, int64_t ldw, void* stream);
 int ktup_shard_reduce_norm(const float* G, int64_t ldg, int d, int64_t n_src, int64_t src_off, const int32_t* sort_ws,
                            int64_t n_entries, int64_t n_wire_rows, float* gwire, int64_t ldw, int32_t* xkeys, int n_small,
                            float* const* small_grads, int64_t small_elems, float small_weight, double* sumsq, int n_slots,

@@ -620,6 +620,15 @@ __global__ __launch_bounds__(256) void seg_fused_kernel(FusedArgs a, ApplyRowsT<
   }
   if (c0 >= nchunks) return;
   auto interior = [&](int32_t key, const float4* acc) {
+    if (MODE == 2) {                                                     // the reduced row itself, stored (no read, no zero-fill before)
+      float4* row = reinterpret_cast<float4*>(a.gw + (int64_t)key * a.ldw);
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) {
+        const int ch = lane + j * GL;
+        if (ch < a.nch) row[ch] = acc[j];
+      }
+      return;
+    }
     if (MODE == 0) {
 #pragma unroll
       for (int j = 0; j < CPL; ++j) ss += dot4(acc[j], acc[j]);            // chunks past the row hold zeros
@@ -655,6 +664,15 @@ __global__ __launch_bounds__(256) void seg_fused_kernel(FusedArgs a, ApplyRowsT<
     }
   };
   auto boundary = [&](int32_t key, const float4* acc, bool head, bool tail) {
+    if (MODE == 2) {                                                     // several workgroups share the row: it was zero-filled beforehand
+      float* row = a.gw + (int64_t)key * a.ldw;                          // (ktup_shard_zero_shared_rows: every row with two or more entries)
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) {
+        const int ch = lane + j * GL;
+        if (ch < a.nch) atomic_add4(row + 4 * ch, acc[j]);
+      }
+      return;
+    }
     if (MODE != 0) return;                                               // MODE 0 put it into gw; the apply launch's extra workgroups apply it
     // A boundary row is the sum of several workgroups' partials, added to gw by float atomics in any order.  Its squared norm needs no
     // pass of its own: an add of v onto `old` raises the row's square by (old + v)^2 - old^2 = 2 old v + v^2, and the atomic RETURNS old --
@@ -865,6 +883,28 @@ __global__ __launch_bounds__(256) void zero_f4_kernel(float4* __restrict__ p, in
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) p[i] = f4zero();
 }
 
+
+// Rows of the wire-layout gradient buffer that SEVERAL entries share, zero-filled: the second entry of a row (rank 1 in its row: there is
+// exactly one per shared row) names it.  With that, ktup_shard_reduce_store needs no zero-filled buffer: a row with one entry or with all
+// its entries inside one workgroup is STORED, and only rows cut by a workgroup's edge are summed by atomics -- onto these zeros.
+__global__ __launch_bounds__(256) void zero_shared_rows_kernel(const int32_t* __restrict__ rank, const int64_t* __restrict__ inverse, int64_t n,
+                                                               float* __restrict__ gw, int64_t ldw, int nch) {
+  const int lane = threadIdx.x & 63;
+  for (int64_t base = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64; base < n; base += (int64_t)gridDim.x * 256) {
+    const int64_t e = base + lane;
+    const bool second = e < n && rank[e] == 1;
+    const int64_t w = second ? inverse[e] : 0;
+    unsigned long long m = __ballot(second);
+    while (m != 0ull) {                                             // the wave clears one listed row per round, a float4 per lane
+      const int src = __ffsll((long long)m) - 1;
+      m &= m - 1ull;
+      const int64_t row = __shfl(w, src, 64);
+      float4* dst = reinterpret_cast<float4*>(gw + row * ldw);
+      for (int ch = lane; ch < nch; ch += 64) dst[ch] = f4zero();
+    }
+  }
+}
+
 int fill_route(const char* name, RouteArgs& a, const int64_t* ids, int64_t n_entries, int64_t block, int n_tables, const int64_t* ent_off,
                int world, const int64_t* cap) {
   KTUP_REQUIRE(n_entries > 0 && n_entries < (1ll << 30) && block > 0 && n_entries % block == 0, "%s: bad entry count / block", name);
@@ -1019,10 +1059,12 @@ extern "C" size_t ktup_shard_route_sort_bytes(int64_t n_entries, int64_t n_wire_
 namespace {
 
 // phase 0: all five launches; 1: the first (scratch init + the KTUP entry list) only; 2: the other four -- so that a caller whose
-// scorer needs nothing but the entry list can run the rest of the route on a second stream beside it
+// scorer needs nothing but the entry list can run the rest of the route on a second stream beside it; 4: the first three (what an
+// id exchange waits for); 5: the last two (the sort), which only the row-gradient reduction waits for
 int route_impl(const char* name, RouteArgs& a, int pair_a, int pair_b, int64_t* inverse, int64_t* send_ids, int32_t* pair_map,
                int32_t* sort_ws, int32_t* counters, double* zero_doubles, int n_zero_doubles, void* ws, hipStream_t st, int phase = 0) {
-  KTUP_REQUIRE(phase >= 0 && phase <= 3, "%s: phase must be 0 (all), 1 (first launch), 2 (the rest) or 3 (all, the cursor stays)", name);
+  KTUP_REQUIRE(phase >= 0 && phase <= 5, "%s: phase must be 0 (all), 1 (first launch), 2 (the rest), 3 (all, the cursor stays), 4 (ids: init + "
+               "insert + finish) or 5 (the sort: scan + scatter)", name);
   a.keep_cursor = phase == 3;
   if (phase == 3) phase = 0;
   KTUP_REQUIRE(inverse && send_ids && sort_ws && counters && ws, "%s: null pointer argument", name);
@@ -1046,12 +1088,17 @@ int route_impl(const char* name, RouteArgs& a, int pair_a, int pair_b, int64_t* 
   a.n_tiles = n_tiles <= MAX_TILES ? (int)n_tiles : 0;
   a.counters = counters; a.zero_d = zero_doubles; a.n_zero_d = n_zero_doubles;
   const int64_t init_items = (int64_t)a.slots > a.W + 1 ? (int64_t)a.slots : a.W + 1;
-  if (phase != 2) hipLaunchKernelGGL(route_init_kernel, dim3(grid_for((init_items + 255) / 256, 1024)), dim3(256), 0, st, a);
+  if (phase != 2 && phase != 5) hipLaunchKernelGGL(route_init_kernel, dim3(grid_for((init_items + 255) / 256, 1024)), dim3(256), 0, st, a);
   if (phase == 1) return check_launch(name);
   const int grid = grid_for((a.n + 255) / 256, 1024);
-  hipLaunchKernelGGL(route_insert_kernel, dim3(grid), dim3(256), 0, st, a);
-  hipLaunchKernelGGL(route_finish_kernel, dim3(grid), dim3(256), 0, st, a);
-  if (int e = check_launch(name)) return e;
+  if (phase != 5) {
+    // everything the id exchange and the scorer need: send_ids, inverse, pair_map (+ the histogram and each entry's rank in its row)
+    hipLaunchKernelGGL(route_insert_kernel, dim3(grid), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(route_finish_kernel, dim3(grid), dim3(256), 0, st, a);
+    if (int e = check_launch(name)) return e;
+    if (phase == 4) return KTUP_OK;
+  }
+  // the counting sort's second half (only the row-gradient reduction reads it): it may run beside the id exchange and the pack launch
   if (a.n_tiles > 0) {
     hipLaunchKernelGGL(route_tile_scan_kernel, dim3(a.n_tiles), dim3(256), 0, st, a);
   } else if (int e = seg_scan_wide(a.start, a.W, st, name)) {
@@ -1274,6 +1321,27 @@ extern "C" int ktup_shard_reduce_apply(int kind, int n_tables, float* const* tab
     return launch_fused<1, true>(a, grid, st, name, &oa, op.W + (int64_t)n_small * op.small_rows);
   }
   return launch_fused<1>(a, grid, st, name, &op, op.W + (int64_t)n_small * op.small_rows);
+}
+
+extern "C" int ktup_shard_zero_shared_rows(const int32_t* sort_ws, int64_t n_entries, int64_t n_wire_rows, const int64_t* inverse, float* gwire,
+                                           int64_t ldw, int d, void* stream) {
+  const char* name = "ktup_shard_zero_shared_rows";
+  KTUP_REQUIRE(sort_ws && inverse && gwire && n_entries > 0 && n_wire_rows > 0 && d > 0 && ldw >= d, "%s: null pointer argument or bad sizes", name);
+  if (d % 4 || ldw % 4 || !aligned16(gwire)) return set_error(KTUP_ERR_UNSUPPORTED, "%s: needs d %% 4 == 0 and 16-byte aligned rows", name);
+  const int32_t* rank = sort_ws + ((n_wire_rows + 2) & ~(int64_t)1);
+  hipLaunchKernelGGL(zero_shared_rows_kernel, dim3(grid_for((n_entries + 255) / 256, 1024)), dim3(256), 0, (hipStream_t)stream, rank, inverse,
+                     n_entries, gwire, ldw, d / 4);
+  return check_launch(name);
+}
+
+extern "C" int ktup_shard_reduce_store(const float* G, int64_t ldg, int d, int64_t n_src, int64_t src_off, const int32_t* sort_ws,
+                                       int64_t n_entries, int64_t n_wire_rows, float* gwire, int64_t ldw, void* stream) {
+  const char* name = "ktup_shard_reduce_store";
+  FusedArgs a{};
+  int32_t none = 0;
+  if (int e = fill_fused(name, a, G, ldg, d, n_src, src_off, sort_ws, n_entries, n_wire_rows, gwire, ldw, &none)) return e;
+  a.xkeys = nullptr;
+  return launch_fused<2, false>(a, fused_grid(n_entries, d), (hipStream_t)stream, name);
 }
 
 extern "C" int ktup_shard_bucket(int mode, int n_small, float* const* small_grads, int64_t small_elems, double* bucket,

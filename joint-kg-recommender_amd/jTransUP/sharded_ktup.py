@@ -120,13 +120,34 @@ class _ShardedStepBase(object):
         elif k == 3:
             _all_reduce(self.bucket, self.group)                                  # small gradients + norm + overflow flag
 
+    def _whole_step_graph(self):
+        """Several ranks: the five segments AND the collectives between them as ONE graph -- when the collectives can be captured (RCCL, or
+        the device copies that stand for them when one rank talks to itself without a process group).  Under gloo (the CPU staging of the
+        two-ranks-share-the-GPU tests) every segment stays a graph of its own with the collectives issued between the replays."""
+        if not self.multi or not getattr(self, 'exchange_graph', True):
+            return False
+        return (not dist.is_initialized()) or dist.get_backend(self.group) == 'nccl'
+
+    def close(self):
+        """Drop the captured graphs and bound launches (stream-synchronised first).  A process group must not be destroyed while a graph
+        that holds its captured collectives is alive: `destroy_process_group()` then waits forever (seen with RCCL's all-to-all inside the
+        whole-step graph) -- call this (ShardedKtupJoint.close closes both steppers) before tearing the group down."""
+        torch.cuda.synchronize(self.dev)
+        self._graphs = None
+        self._graph_keep = None
+        self._eager = None
+
+    def _open_branch(self):
+        import os
+        return os.environ.get('KTUP_EXCHANGE_LAYOUT', 'open') == 'open'
+
     def run(self):
         """One step on the ids in the static buffers (or the cursor's batch of the feed columns).  The first two steps issue the
         launches directly (warm-up), then the segments are captured once and replayed."""
         stream = torch.cuda.current_stream(self.dev).cuda_stream
         if not self.use_graphs or self.steps < 2:
             if self._eager is None or self._eager[0] != stream:
-                side = self._side if (self.direct and self.overlap_route) else None
+                side = self._side if ((self.direct or self.multi) and self.overlap_route) else None
                 self._eager = (stream, self._bind(stream, None if side is None else side.cuda_stream), self._keep)
             for k, seg in enumerate(self._eager[1]):
                 self._issue(seg, self._side)
@@ -138,7 +159,7 @@ class _ShardedStepBase(object):
             self._capture()
         for k, g in enumerate(self._graphs):
             g.replay()
-            if self.multi:
+            if self.multi and len(self._graphs) > 1:
                 self._exchange(k)
         self.steps += 1
 
@@ -167,11 +188,22 @@ class _ShardedStepBase(object):
         also RUNS nothing: the step that triggers the capture replays the fresh graphs."""
         graphs, keeps = [], []
         n_seg = 5 if self.multi else 1
+        if self._whole_step_graph():
+            graph = torch.cuda.CUDAGraph()
+            with L.capture(graph):
+                cs = torch.cuda.current_stream(self.dev).cuda_stream
+                side = self._side if self.overlap_route else None
+                segs = self._bind(cs, None if side is None else side.cuda_stream)
+                for k, seg in enumerate(segs):
+                    self._issue(seg, side)
+                    self._exchange(k)
+            self._graphs, self._graph_keep = [graph], [self._keep]
+            return
         for k in range(n_seg):
             graph = torch.cuda.CUDAGraph()
             with L.capture(graph):
                 cs = torch.cuda.current_stream(self.dev).cuda_stream
-                side = self._side if (self.direct and self.overlap_route) else None
+                side = self._side if ((self.direct or self.multi) and self.overlap_route) else None
                 segs = self._bind(cs, None if side is None else side.cuda_stream)
                 keeps.append(self._keep)
                 self._issue(segs[k], side)
@@ -235,7 +267,8 @@ class ShardedKtupStepper(_ShardedStepBase):
 
     def __init__(self, Ut, It, Et, pref, pref_norm, rel, norm, item2ent, batch, kind='adagrad', lr=0.005, eps=1e-10, max_norm=0.0,
                  l1=False, target=-1.0, orth=False, ent_pad=-1, group=None, capacity_factor=1.25, use_graphs=True, force_exchange=False,
-                 direct=None, overlap_route=True, fused_apply=True, route_beside=False, betas=(0.9, 0.999), opt_step=None):
+                 direct=None, overlap_route=True, fused_apply=True, route_beside=False, betas=(0.9, 0.999), opt_step=None, exchange_graph=True):
+        self.exchange_graph = bool(exchange_graph)
         if kind not in KINDS:
             raise ValueError('row-sparse steps exist for plain SGD, Adagrad and Adam')
         self.betas = (float(betas[0]), float(betas[1]))
@@ -445,12 +478,25 @@ class ShardedKtupStepper(_ShardedStepBase):
             if self.direct and side is not None:
                 return [[route_phase(1, stream), ('beside', [step], [route_phase(2, side)]), ('join',)] + tail]
             return [([route, step] if self.direct else [route, pack, step]) + tail]
+        # ---- several ranks (or one in exchange form): five segments around the three all-to-alls and the all-reduce.  What does not lie on
+        # the path of the data rides on the second stream: the counting sort of the entries (only the gradient reduction reads it) and the
+        # zero-fill of the few wire rows that several entries share run beside the pack launch, the owner's route of the requested rows
+        # (only the owner's reduction reads it) beside the step kernel.  The requester's reduction STORES its rows (ktup_shard_reduce_store):
+        # no zero-filled 42 MB buffer, no read-modify-write.
+        on = side if side is not None else stream
+
+        def par(main, beside):
+            return [('beside', main, beside), ('join',)] if side is not None else beside + main
         capo = arr(_i64s(self.cap_own))
         eoff_o = arr(_i64s([0, self.cap[0], self.cap[0] + self.cap[1], self.capsum]))
         pack = bind('ktup_shard_pack_wire', 3, tabs, lds, cap, d, _p(self.recv_ids), Wn, _p(self.Xsend), d, stream)
-        zero = bind('ktup_zero_async', _p(self.Gwire), self.Gwire.numel() * 4, stream)
-        oroute = bind('ktup_shard_route', _p(self.recv_ids), W, self.capsum, 3, eoff_o, 1, capo, 0, 0, _p(self.own_inverse),
-                      _p(self.own_ids), None, _p(self.own_sort), _p(self.own_counters), None, 0, _p(self.own_ws), stream)
+        sort_ = route_phase(5, on)
+        zshared = bind('ktup_shard_zero_shared_rows', _p(self.sort_ws), E, W, _p(inv), _p(self.Gwire), d, d, on)
+        rstore = bind('ktup_shard_reduce_store', _p(self.Gcat), d, d, 3 * B, 2 * B, _p(self.sort_ws), E, W, _p(self.Gwire), d, stream)
+
+        def oroute_on(st_):
+            return bind('ktup_shard_route', _p(self.recv_ids), W, self.capsum, 3, eoff_o, 1, capo, 0, 0, _p(self.own_inverse),
+                        _p(self.own_ids), None, _p(self.own_sort), _p(self.own_counters), None, 0, _p(self.own_ws), st_)
         oreduce = bind('ktup_shard_reduce_rows', _p(self.Grecv), d, d, W, 0, _p(self.own_sort), W, self.W_own, _p(self.Gown), d, stream)
         nptr, nsz = arr(_ptrs([self.Gown])), arr(_i64s([self.Gown.numel()]))
         gnorm = bind('ktup_optim_gradnorm_acc', 1, nptr, nsz, _p(self.acc), SLOTS, stream)
@@ -469,14 +515,18 @@ class ShardedKtupStepper(_ShardedStepBase):
                           _p(self.own_sort), W, _p(self.Gown), d, _p(self.own_xkeys), n_small, P, sgp, sp0p, ss0p, sp1p, ss1p,
                           _p(self.bucket), self.lr, self.eps, self.acc.data_ptr() + 8 * SLOTS, 1, self.max_norm, None,
                           self.bucket.data_ptr() + 8 * (N + 1), *close, adam, stream)
-            if adam:    # the owner's route of the requested rows moves in front of the pack launch: the catch-up needs its DISTINCT rows
-                catch = self._catchup(self.own_ids, self.cap_own, adam, stream, arr)
-                return [[route], [oroute, catch, pack], [step, reduce_], [zero, onorm, pack_b], [fin_b] + count + [oapply]]
-            return [[route], [pack], [step, reduce_], [zero, oroute, onorm, pack_b], [fin_b] + count + [oapply]]
-        if adam:
+            own_tail = [[onorm, pack_b], [fin_b] + count + [oapply]]
+        else:
+            own_tail = [[oreduce, gnorm, pack_b], [fin_b] + count + [apply_]]
+        whole = side is not None and self._whole_step_graph() and self._open_branch()      # one graph: a branch may stay open across the exchanges
+        if adam:    # the owner's route of the requested rows moves in front of the pack launch: the catch-up needs its DISTINCT rows
             catch = self._catchup(self.own_ids, self.cap_own, adam, stream, arr)
-            return [[route], [oroute, catch, pack], [step, reduce_], [zero, oreduce, gnorm, pack_b], [fin_b] + count + [apply_]]
-        return [[route], [pack], [step, reduce_], [zero, oroute, oreduce, gnorm, pack_b], [fin_b] + count + [apply_]]
+            if whole:
+                return [[route_phase(4, stream)], [oroute_on(stream), catch, ('beside', [pack], [sort_, zshared])], [step, ('join',), rstore]] + own_tail
+            return [[route_phase(4, stream)], [oroute_on(stream), catch] + par([pack], [sort_, zshared]), [step, rstore]] + own_tail
+        if whole:   # sort, zero-fill and the owner's route: one branch from the id exchange to the end of the step kernel
+            return [[route_phase(4, stream)], [('beside', [pack], [sort_, zshared, oroute_on(on)])], [step, ('join',), rstore]] + own_tail
+        return [[route_phase(4, stream)], par([pack], [sort_, zshared]), par([step, rstore], [oroute_on(on)])] + own_tail
 
     # ------------------------------------------------------------------------------------------------ the step
     def load_batch(self, u, pos_items, neg_items):
@@ -525,7 +575,8 @@ class ShardedKgStepper(_ShardedStepBase):
 
     def __init__(self, Et, rel, norm, batch, kind='adagrad', lr=0.005, eps=1e-10, max_norm=0.0, l1=False, margin=1.0, kg_lambda=1.0,
                  transh=True, regs=7, small_state=None, group=None, capacity_factor=1.25, use_graphs=True, force_exchange=False,
-                 direct=None, overlap_route=True, betas=(0.9, 0.999), opt_step=None):
+                 direct=None, overlap_route=True, betas=(0.9, 0.999), opt_step=None, exchange_graph=True):
+        self.exchange_graph = bool(exchange_graph)
         if kind not in KINDS:
             raise ValueError('row-sparse steps exist for plain SGD, Adagrad and Adam')
         self.betas = (float(betas[0]), float(betas[1]))
@@ -665,13 +716,22 @@ class ShardedKgStepper(_ShardedStepBase):
             if self.direct and side is not None:
                 return [[route_phase(1, stream), ('beside', [order, step], [route_phase(2, side)]), ('join',), rnorm] + count + [rapply]]
             return [[route_phase(0, stream)] + ([] if self.direct else [pack]) + [order, step, rnorm] + count + [rapply]]
+        # several ranks: as ShardedKtupStepper._bind -- the sort and the shared rows' zero-fill beside the pack launch, the owner's route
+        # beside the step kernel, the requester's reduction storing its rows
+        on = side if side is not None else stream
+
+        def par(main, beside):
+            return [('beside', main, beside), ('join',)] if side is not None else beside + main
         capo = arr(_i64s(self.cap_own))
         eoff_o = arr(_i64s([0, self.capsum]))
         pack = bind('ktup_shard_pack_wire', 1, tabs, lds, cap, d, _p(self.recv_ids), Wn, _p(self.Xsend), d, stream)
-        reduce_ = bind('ktup_shard_reduce_rows', _p(self.GE), d, d, E, 0, _p(self.sort_ws), E, W, _p(self.Gwire), d, stream)
-        zero = bind('ktup_zero_async', _p(self.Gwire), self.Gwire.numel() * 4, stream)
-        oroute = bind('ktup_shard_route', _p(self.recv_ids), W, self.capsum, 1, eoff_o, 1, capo, 0, 0, _p(self.own_inverse),
-                      _p(self.own_ids), None, _p(self.own_sort), _p(self.own_counters), None, 0, _p(self.own_ws), stream)
+        sort_ = route_phase(5, on)
+        zshared = bind('ktup_shard_zero_shared_rows', _p(self.sort_ws), E, W, _p(self.inverse), _p(self.Gwire), d, d, on)
+        rstore = bind('ktup_shard_reduce_store', _p(self.GE), d, d, E, 0, _p(self.sort_ws), E, W, _p(self.Gwire), d, stream)
+
+        def oroute_on(st_):
+            return bind('ktup_shard_route', _p(self.recv_ids), W, self.capsum, 1, eoff_o, 1, capo, 0, 0, _p(self.own_inverse),
+                        _p(self.own_ids), None, _p(self.own_sort), _p(self.own_counters), None, 0, _p(self.own_ws), st_)
         N = n_small * P * d
         onorm = bind('ktup_shard_reduce_norm', _p(self.Grecv), d, d, W, 0, _p(self.own_sort), W, self.W_own, _p(self.Gown), d,
                      _p(self.own_xkeys), 0, None, 0, 1.0, _p(self.acc), SLOTS, 0, None, 0, None, stream)
@@ -682,10 +742,16 @@ class ShardedKgStepper(_ShardedStepBase):
                       self.lr, self.eps, self.acc.data_ptr() + 8 * SLOTS, 1, self.max_norm, None, self.bucket.data_ptr() + 8 * (N + 1),
                       *close, adam, stream)
         count = [bind('ktup_shard_step_count', _p(self.opt_step), None, self.bucket.data_ptr() + 8 * (N + 1), self.betas[0], self.betas[1], stream)] if adam else []
+        own_tail = [[onorm, pack_b], [fin_b] + count + [oapply]]
+        whole = side is not None and self._whole_step_graph() and self._open_branch()
         if adam:
             catch = self._catchup(self.own_ids, self.cap_own, adam, stream, arr)
-            return [[route_phase(0, stream)], [oroute, catch, pack], [order, step, reduce_], [zero, onorm, pack_b], [fin_b] + count + [oapply]]
-        return [[route_phase(0, stream)], [pack], [order, step, reduce_], [zero, oroute, onorm, pack_b], [fin_b] + count + [oapply]]
+            if whole:
+                return [[route_phase(4, stream)], [oroute_on(stream), catch, ('beside', [pack], [sort_, zshared])], [order, step, ('join',), rstore]] + own_tail
+            return [[route_phase(4, stream)], [oroute_on(stream), catch] + par([pack], [sort_, zshared]), [order, step, rstore]] + own_tail
+        if whole:
+            return [[route_phase(4, stream)], [('beside', [pack], [sort_, zshared, oroute_on(on)])], [order, step, ('join',), rstore]] + own_tail
+        return [[route_phase(4, stream)], par([pack], [sort_, zshared]), par([order, step, rstore], [oroute_on(on)])] + own_tail
 
     def load_batch(self, ph, pt, pr, nh, nt, nr):
         if self._feed[0] is not self.cols[0]:
@@ -738,6 +804,10 @@ class ShardedKtupJoint(object):
     def flush(self):
         """Adam: every row of the three shards and of the four small tables up to the current step (the rec stepper holds them all)."""
         self.rec.flush()
+
+    def close(self):
+        self.rec.close()
+        self.kg.close()
 
     def is_rec(self, step=None):
         return (self.steps if step is None else step) % 10 < self.switch

@@ -175,8 +175,9 @@ def test_stepper_exchange_form_over_rccl_at_world_one():
         batches = _batches(gen, 1, steps, nu, ni, b)
         Wd, _ = _dense_reference(full, small0, i2e, batches, 'adagrad', 0.05, 1e-4, 0.5)
         tables, small, st = _run_stepper(full, small0, i2e, batches, 'adagrad', 0.05, 1e-4, 0.5, 0, 1, torch.device(DEV), force_exchange=True)
-        assert st.multi and len(st._graphs) == 5
+        assert st.multi and len(st._graphs) == 1          # RCCL: the five segments and the collectives between them are ONE graph
         _check(tables, small, Wd, 0, 1)
+        st.close()                                        # the graph holds captured collectives: it goes before the group does
     finally:
         dist.destroy_process_group()
 
@@ -204,7 +205,7 @@ def _two_rank_worker(rank, world, port, kind, overflow):
                 assert torch.equal(t.weight.data.cpu(), full[key][torch.arange(rank, t.total_rows, world)])
             for p, w in zip(small, small0):
                 assert torch.equal(p.data.cpu(), w)
-            assert float(st.Gwire.abs().sum()) == 0.0 and float(st.Gown.abs().sum()) == 0.0     # and left no gradient behind
+            assert float(st.Gown.abs().sum()) == 0.0     # and left no gradient behind (the requester's buffer is stored into, never accumulated)
             return
         Wd, _ = _dense_reference(full, small0, i2e, batches, kind, lr, eps, max_norm)
         tables, small, st = _run_stepper(full, small0, i2e, batches, kind, lr, eps, max_norm, rank, world, dev)

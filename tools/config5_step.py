@@ -44,13 +44,13 @@ def fused_main(args):
     item2ent = torch.randint(0, NE, (NI,), generator=torch.Generator(device=dev).manual_seed(7), device=dev).to(torch.int32)
     st = ShardedKtupStepper(Ut, It, Et, *small, item2ent, batch=B, kind=args.optimizer, lr=0.005, max_norm=5.0, use_graphs=not args.no_graphs,
                             force_exchange=args.exchange, overlap_route=not args.no_overlap, fused_apply=not args.gradient_buffer, direct=False if (args.no_direct or args.exchange or world > 1) else None,
-                            orth=args.kind != 'rec', route_beside=args.route_beside)
+                            orth=args.kind != 'rec', route_beside=args.route_beside, exchange_graph=not args.segment_graphs)
     rec = st
     kg = None
     if args.kind != 'rec':             # the kg half of the joint schedule (knowledgable_recommendation.py:345-383) on the same entity shard
         kg = ShardedKgStepper(Et, small[2], small[3], batch=B, kind=args.optimizer, lr=0.005, max_norm=5.0, margin=1.0, kg_lambda=1.0,
                               small_state=rec.small_state[2:4], opt_step=rec.opt_step, use_graphs=not args.no_graphs, force_exchange=args.exchange,
-                              overlap_route=not args.no_overlap, direct=False if (args.no_direct or args.exchange or world > 1) else None)
+                              overlap_route=not args.no_overlap, direct=False if (args.no_direct or args.exchange or world > 1) else None, exchange_graph=not args.segment_graphs)
         st = kg if args.kind == 'kg' else ShardedKtupJoint(rec, kg, 0.7)
 
     def draw(n_rows):
@@ -104,6 +104,9 @@ def fused_main(args):
                           'ms_per_step': 1e3 * wall / args.steps, 'ms_per_step_device': devms,
                           'scored_rows_per_s': 2 * B * world * args.steps / wall, 'wire_rows': (kg if args.kind == 'kg' else rec).W,
                           'mean_loss': (float(rec.loss_sum[0]) - l0) / args.steps}))
+    rec.close()
+    if kg is not None:
+        kg.close()
     if world > 1:
         dist.destroy_process_group()
 
@@ -121,6 +124,7 @@ def main():
     ap.add_argument('--legacy', action='store_true', help="round 2's route: parallel.ShardedStep through autograd (eager torch ops around the kernels)")
     ap.add_argument('--exchange', action='store_true', help='one rank in exchange form: the several-ranks route (five segments, all-to-alls) talking to itself')
     ap.add_argument('--no-graphs', action='store_true')
+    ap.add_argument('--segment-graphs', action='store_true', help='exchange form: one graph per segment with the collectives issued between the replays (what gloo runs) instead of the whole step as one graph')
     ap.add_argument('--copy-batches', action='store_true', help='hand every batch over as three tensors (three device copies per step) instead of device-fed columns')
     ap.add_argument('--no-overlap', action='store_true', help='one rank, direct gathers: keep the route on the step kernel\'s stream (no second stream in the graph)')
     ap.add_argument('--gradient-buffer', action='store_true', help='reduce -> norm -> apply through a W x d gradient buffer (three launches) instead of two walks over the per-pair gradients')

@@ -55,7 +55,10 @@ struct WGeom {
   static constexpr int RED_F = NWC * 64 * PT * 4;         // cross-wave partials of lg / gl
   // LT / GLT (beta w and gL / 2, preference major) hold the SAME numbers in every wave -- all waves carry the full logits after the
   // cross-wave sum -- so the workgroup keeps one copy: every wave writes all of it (equal values) before it reads it
-  static constexpr size_t SHARED_BYTES = (size_t)3 * TAB_F4 * 16 + (size_t)RED_F * 4 + 3 * NWC * 16 * 4 + (size_t)2 * LT_F * 4;
+  // (`red` twice: tiles alternate between the copies, which is what lets a tile end without a workgroup barrier; 4 x NWC x 16 floats of
+  //  per-pair partials: reds | redav | redsc of the three-barrier path = the float4 per (wave, pair) of the merged one)
+  static constexpr int REDC = NWC_ <= 4 ? 2 : 1;          // (the opt-in eight-wave form at d = 256 has no LDS for the second copy: it keeps its end-of-tile barrier)
+  static constexpr size_t SHARED_BYTES = (size_t)3 * TAB_F4 * 16 + (size_t)REDC * RED_F * 4 + 4 * NWC * 16 * 4 + (size_t)2 * LT_F * 4;
   static constexpr size_t WAVE_BYTES = ((size_t)3 * TILE_F4 * 16 + 2 * 3 * 16 * 4 + (size_t)NOISE_F * 4 + 15) & ~(size_t)15;
   static constexpr size_t LDS = SHARED_BYTES + NWC * WAVE_BYTES;
 };
@@ -107,8 +110,8 @@ __global__ __launch_bounds__(G::NT) void pref_bwd_wide_kernel(WArgs a) {
   v4* AlogT = reinterpret_cast<v4*>(smem);                    // [ROWS][RP4]
   v4* ArT = AlogT + G::TAB_F4;
   v4* CnT = ArT + G::TAB_F4;
-  float* red = reinterpret_cast<float*>(CnT + G::TAB_F4);     // [4 waves][64 lanes][PT * 4]
-  float* reds = red + G::RED_F;                               // [4][16]
+  float* red0 = reinterpret_cast<float*>(CnT + G::TAB_F4);    // [2 copies][4 waves][64 lanes][PT * 4]
+  float* reds = red0 + G::REDC * G::RED_F;                    // [4][16]
   float* redav = reds + G::NWC * 16;                          // [4][16]
   float* redsc = redav + G::NWC * 16;                         // [4][16]  STEP: partial scores
   const float* Alog2 = reinterpret_cast<const float*>(AlogT);
@@ -116,7 +119,7 @@ __global__ __launch_bounds__(G::NT) void pref_bwd_wide_kernel(WArgs a) {
   const float* Cn2 = reinterpret_cast<const float*>(CnT);
   const int tid = threadIdx.x, lane = tid & 63, kq = lane >> 4, j = lane & 15;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);     // this wave's coordinate slice: [64 w, 64 w + 64)
-  float* LT = redsc + G::NWC * 16;                            // [TROW][17]  beta * w   (preference major; one copy per workgroup)
+  float* LT = reds + 4 * G::NWC * 16;                         // [TROW][17]  beta * w   (preference major; one copy per workgroup)
   float* GLT = LT + G::LT_F;                                  // [TROW][17]  gL / 2
   char* wbase = reinterpret_cast<char*>(GLT + G::LT_F) + (size_t)w * G::WAVE_BYTES;
   v4* XT = reinterpret_cast<v4*>(wbase);                      // x    [16 pairs][TP4]   (this wave's 16 chunks)
@@ -315,6 +318,7 @@ __global__ __launch_bounds__(G::NT) void pref_bwd_wide_kernel(WArgs a) {
     const bool live_j = STEP ? kpair < a.B : kpair < a.n;
     const int64_t row_j = STEP ? kpair + (j >> 3) * a.B : kpair;          // row in the [pos ; neg] id / draw order
     const int32_t* sid = sid0 + 48 * cur;
+    float* red = red0 + (G::REDC > 1 ? cur : 0) * G::RED_F;               // this tile's copy of the cross-wave scratch
     // ---- this wave's coordinate slice of the 16 pairs (gathered during the previous tile): x and q tiles
 #pragma unroll
     for (int jj = 0; jj < GJ; ++jj) {
@@ -425,6 +429,13 @@ __global__ __launch_bounds__(G::NT) void pref_bwd_wide_kernel(WArgs a) {
     // ---- A2: n^T, (q + r)^T of this wave's 4 coordinate tiles; lane (kq, j) owns coordinates 64 w + 16 ct + 4 kq + reg of pair j
     v4 nn[CTW], zz[CTW], qv[CTW];
     v4 sacc = (v4){0.f, 0.f, 0.f, 0.f};
+    // MERGED (squared L2, the fused step): s = q.n, the score |z|^2 of z = (q + r) - s n and av = gz.n = 2 g z.n are all functions of FOUR
+    // sums over the coordinates -- q.n, |q + r|^2, (q + r).n, |n|^2:  |z|^2 = |q + r|^2 - 2 s (q + r).n + s^2 |n|^2,  z.n = (q + r).n - s |n|^2 --
+    // so the three cross-wave reductions of the chain (s, then the score, then av: a store, a workgroup barrier and a read each) are one.
+    // The L1 distance needs z itself before it can be summed and keeps the three-step chain.
+    constexpr bool MERGED_OK = STEP;
+    const bool merged = MERGED_OK && !l1;
+    v4 p_q2 = (v4){0.f, 0.f, 0.f, 0.f}, p_qn = p_q2, p_n2 = p_q2;
 #pragma unroll
     for (int ct = 0; ct < CTW; ++ct) {
       qv[ct] = QT[j * TP4 + 4 * ct + kq];
@@ -436,12 +447,46 @@ __global__ __launch_bounds__(G::NT) void pref_bwd_wide_kernel(WArgs a) {
         zz[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(Ar2[rb[m] + 16 * ct], lg[m >> 2][m & 3], zz[ct], 0, 0, 0);
       }
       sacc += qv[ct] * nn[ct];
+      if (MERGED_OK && merged) {
+        p_q2 = __builtin_elementwise_fma(zz[ct], zz[ct], p_q2);
+        p_qn = __builtin_elementwise_fma(zz[ct], nn[ct], p_qn);
+        p_n2 = __builtin_elementwise_fma(nn[ct], nn[ct], p_n2);
+      }
     }
-    float s = allsum_kq((sacc[0] + sacc[1]) + (sacc[2] + sacc[3]));
+    float s, g, av;
+    if (MERGED_OK && merged) {
+      // lane (kq, j) ends up with component kq of pair j's four sums over this wave's coordinates; summed across the waves in wave order
+      const v4 part = (v4){(sacc[0] + sacc[1]) + (sacc[2] + sacc[3]), (p_q2[0] + p_q2[1]) + (p_q2[2] + p_q2[3]),
+                           (p_qn[0] + p_qn[1]) + (p_qn[2] + p_qn[3]), (p_n2[0] + p_n2[1]) + (p_n2[2] + p_n2[3])};
+      reds[(w * 16 + j) * 4 + kq] = scatter_kq(part);
+      __syncthreads();
+      const v4* r4 = reinterpret_cast<const v4*>(reds);
+      auto wsum4 = [&](int jj) {
+        v4 t = (r4[jj] + r4[16 + jj]) + (r4[32 + jj] + r4[48 + jj]);
+#pragma unroll
+        for (int ww = 4; ww < G::NWC; ww += 4) t += (r4[16 * ww + jj] + r4[16 * ww + 16 + jj]) + (r4[16 * ww + 32 + jj] + r4[16 * ww + 48 + jj]);
+        return t;
+      };
+      const v4 tj = wsum4(j), to = wsum4(j ^ 8);
+      s = tj[0];
+#pragma unroll
+      for (int ct = 0; ct < CTW; ++ct) zz[ct] = zz[ct] - s * nn[ct];    // z
+      const float score = fmaf(s, fmaf(s, tj[3], -2.f * tj[2]), tj[1]);
+      const float other = fmaf(to[0], fmaf(to[0], to[3], -2.f * to[2]), to[1]);
+      const bool negh = (j >> 3) != 0;
+      const float diff = negh ? other - score : score - other;   // pos - neg
+      const float g0 = a.gscale * (1.f / (float)a.B);
+      const float gd = -g0 * a.target * wstep_sigmoid(-a.target * diff);    // d/dpos of mean_k -logsigmoid(target diff_k)
+      g = live_j ? (negh ? -gd : gd) : 0.f;
+      if (w == 0 && live_j && !negh && kq == 0) lpart += wstep_neg_logsigmoid(a.target * diff);
+      av = 2.f * g * fmaf(-s, tj[3], tj[2]);                     // gz . n with gz = 2 g z
+#pragma unroll
+      for (int ct = 0; ct < CTW; ++ct) zz[ct] = (2.f * g) * zz[ct];
+    } else {
+    s = allsum_kq((sacc[0] + sacc[1]) + (sacc[2] + sacc[3]));
     if (kq == 0) reds[w * 16 + j] = s;
     __syncthreads();
     s = wsum16(reds, j);
-    float g;                                                      // upstream gradient of this slot's score; 0 for tail slots
 #pragma unroll
     for (int ct = 0; ct < CTW; ++ct) zz[ct] = zz[ct] - s * nn[ct];    // z
     if constexpr (STEP) {
@@ -477,10 +522,11 @@ __global__ __launch_bounds__(G::NT) void pref_bwd_wide_kernel(WArgs a) {
       zz[ct] = gz;
       aacc += gz * nn[ct];
     }
-    float av = allsum_kq((aacc[0] + aacc[1]) + (aacc[2] + aacc[3]));
+    av = allsum_kq((aacc[0] + aacc[1]) + (aacc[2] + aacc[3]));
     if (kq == 0) redav[w * 16 + j] = av;
     __syncthreads();
     av = wsum16(redav, j);
+    }
     v4 gq[CTW];
 #pragma unroll
     for (int ct = 0; ct < CTW; ++ct) {
@@ -628,7 +674,9 @@ __global__ __launch_bounds__(G::NT) void pref_bwd_wide_kernel(WArgs a) {
 #pragma unroll
       for (int ct = 0; ct < (TRK ? CTW : 0); ++ct) ssq += sq_gain4(ou[ct], tu[ct]) + sq_gain4(oi[ct], tv[ct]) + (has_e ? sq_gain4(oe[ct], tv[ct]) : 0.f);
     }
-    __syncthreads();     // the next tile rewrites `red` and the wave tiles
+    // (with two copies of `red` no workgroup barrier is needed here: the next tile's cross-wave scratch is the OTHER copy, the wave tiles are
+    //  private, and every other shared array is written after the next tile's first barrier and read before this tile's last one)
+    if constexpr (G::REDC == 1) __syncthreads();
   }
   // ---- flush the table gradients of this wave's coordinates
   if (TRK && track && !a.noflush) {          // tracked norm: all adds issued, then the returned values folded in (ktup_common.h)

@@ -976,22 +976,44 @@ struct CatchupArgs {
 
 template <int GL, int CPL>
 __global__ __launch_bounds__(256) void adam_catchup_kernel(CatchupArgs a) {
-  constexpr int GPB = 256 / GL;
+  // A lane group per row, RB rows per round: their ids, then their `last` stamps, are RB independent loads in flight per group -- every
+  // state row lies on another page, so a stamp is a TLB miss, and one row after the other the misses of a group queued up behind each
+  // other.  All lanes of a group read the SAME address (one translation per row).  One LANE per row -- 64 different pages per load
+  // instruction -- was measured too: 209 us against 76 for the 40,960 stamps of a config-5 step; the translations of one instruction
+  // are served one after the other.
+  constexpr int GPB = 256 / GL, RB = 4;
   const int lane = threadIdx.x % GL;
   const int t = (int)*a.r.step;
   float4 none[CPL];
 #pragma unroll
   for (int j = 0; j < CPL; ++j) none[j] = f4zero();
   const int64_t total = a.end[a.n_seg - 1];
-  for (int64_t e = (int64_t)blockIdx.x * GPB + threadIdx.x / GL; e < total; e += (int64_t)gridDim.x * GPB) {
-    int k = 0;
+  const int64_t ngrp = (int64_t)gridDim.x * GPB;
+  for (int64_t e0 = (int64_t)blockIdx.x * GPB + threadIdx.x / GL; e0 < total; e0 += ngrp * RB) {
+    int k[RB];
+    int64_t row[RB];
+    int last[RB];
 #pragma unroll
-    for (int i = 0; i < KTUP_SHARD_ADAM_MAX_SEG - 1; ++i) k += (i < a.n_seg - 1 && e >= a.end[i]) ? 1 : 0;
-    const int64_t pos = e - (k > 0 ? a.end[k - 1] : 0);
-    const int64_t row = a.ids[k] ? a.ids[k][pos] : pos;
-    if (row < 0) continue;
-    adam_row_mem<GL, CPL>(reinterpret_cast<float4*>(a.tab[k] + row * a.ldt[k]), reinterpret_cast<float4*>(a.st[k] + row * a.lds[k]), a.nch, lane,
-                          none, false, t, a.lr, a.eps, a.r);
+    for (int u = 0; u < RB; ++u) {
+      const int64_t e = e0 + u * ngrp;
+      k[u] = 0;
+#pragma unroll
+      for (int i = 0; i < KTUP_SHARD_ADAM_MAX_SEG - 1; ++i) k[u] += (i < a.n_seg - 1 && e >= a.end[i]) ? 1 : 0;
+      row[u] = -1;
+      if (e < total) {
+        const int64_t pos = e - (k[u] > 0 ? a.end[k[u] - 1] : 0);
+        row[u] = a.ids[k[u]] ? a.ids[k[u]][pos] : pos;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < RB; ++u)
+      last[u] = row[u] >= 0 ? *reinterpret_cast<const int32_t*>(a.st[k[u]] + row[u] * a.lds[k[u]] + 8 * a.nch) : 0;
+#pragma unroll
+    for (int u = 0; u < RB; ++u) {
+      if (last[u] > 0 && last[u] < t)
+        adam_row_mem<GL, CPL>(reinterpret_cast<float4*>(a.tab[k[u]] + row[u] * a.ldt[k[u]]), reinterpret_cast<float4*>(a.st[k[u]] + row[u] * a.lds[k[u]]),
+                              a.nch, lane, none, false, t, a.lr, a.eps, a.r);
+    }
   }
 }
 
@@ -1025,7 +1047,7 @@ extern "C" int ktup_shard_adam_catchup(int n_seg, float* const* tables, const in
   hipStream_t st = (hipStream_t)stream;
 #define KTUP_AF(GL, CPL)                                                                                   \
   {                                                                                                        \
-    const int grid = grid_for((end + (256 / GL) - 1) / (256 / GL), 256 * 8);                               \
+    const int grid = grid_for((end + 4 * (256 / GL) - 1) / (4 * (256 / GL)), 256 * 8);                     \
     hipLaunchKernelGGL((adam_catchup_kernel<GL, CPL>), dim3(grid), dim3(256), 0, st, a);                   \
     return check_launch(name);                                                                             \
   }

@@ -133,9 +133,27 @@ class _ShardedStepBase(object):
         that holds its captured collectives is alive: `destroy_process_group()` then waits forever (seen with RCCL's all-to-all inside the
         whole-step graph) -- call this (ShardedKtupJoint.close closes both steppers) before tearing the group down."""
         torch.cuda.synchronize(self.dev)
-        self._graphs = None
-        self._graph_keep = None
+        self._graphs = self._graphs1 = None
+        self._graph_keep = self._graph_keep1 = None
         self._eager = None
+
+    def _pipelined(self):
+        """Batches fed from device columns (set_feed): the route of step s + 1 -- the hash of its ids, the wire slots, the send buffer, the
+        counting sort: 30-35 us of small dependent launches that depend on nothing but the id columns -- runs on the second stream at the
+        END of step s, beside the (owner's) apply walk, instead of at the head of step s + 1.  (Not with load_batch: the next batch is
+        not there yet.)  The first step after set_feed routes itself (run()).  One rank: the walks of step s read the route's output
+        to their end, so the route's buffers exist TWICE (`_sets`) and steps alternate between them -- two graphs, `_graphs` and
+        `_graphs1`; several ranks: the requester's side of the route is free once the bucket launch has read the overflow word."""
+        return self._fed and getattr(self, 'pipeline_route', True) and not getattr(self, 'route_beside', False)
+
+    def _double(self):
+        return self._pipelined()
+
+    def _use(self, par):
+        """Point the attribute names of the route's buffers (entries, send_ids, sort_ws, ...) at buffer set `par`: what _bind bakes in."""
+        for k, v in self._sets[par].items():
+            setattr(self, k, v)
+        self._bind_par = par
 
     def _open_branch(self):
         import os
@@ -145,21 +163,34 @@ class _ShardedStepBase(object):
         """One step on the ids in the static buffers (or the cursor's batch of the feed columns).  The first two steps issue the
         launches directly (warm-up), then the segments are captured once and replayed."""
         stream = torch.cuda.current_stream(self.dev).cuda_stream
+        dbl = self._double()
+        par = self._par if dbl else 0
+        self._use(par)
+        if self._pipelined() and not self._routed:               # nobody has routed this step's batch yet
+            self._route_now = self._bind_route(stream)            # (kept: the ctypes arrays behind the bound launch)
+            self._route_now[0]()
+            self._routed = True
+        if dbl:
+            self._par ^= 1
         if not self.use_graphs or self.steps < 2:
-            if self._eager is None or self._eager[0] != stream:
-                side = self._side if ((self.direct or self.multi) and self.overlap_route) else None
-                self._eager = (stream, self._bind(stream, None if side is None else side.cuda_stream), self._keep)
-            for k, seg in enumerate(self._eager[1]):
+            if self._eager is None:
+                self._eager = {}
+            hit = self._eager.get(par)
+            if hit is None or hit[0] != stream:
+                side = self._side if ((self.direct or self.multi or dbl) and self.overlap_route) else None
+                hit = self._eager[par] = (stream, self._bind(stream, None if side is None else side.cuda_stream), self._keep)
+            for k, seg in enumerate(hit[1]):
                 self._issue(seg, self._side)
                 if self.multi:
                     self._exchange(k)
             self.steps += 1
             return
-        if self._graphs is None:
-            self._capture()
-        for k, g in enumerate(self._graphs):
+        graphs = self._graphs1 if par else self._graphs
+        if graphs is None:
+            graphs = self._capture(par)
+        for k, g in enumerate(graphs):
             g.replay()
-            if self.multi and len(self._graphs) > 1:
+            if self.multi and len(graphs) > 1:
                 self._exchange(k)
         self.steps += 1
 
@@ -171,11 +202,17 @@ class _ShardedStepBase(object):
                 side.wait_stream(torch.cuda.current_stream(self.dev))
                 for launch in item[1]:
                     launch()
+            elif item[0] == 'mark':                           # a point on the main stream a later ('beside', ..., ..., 'marked') branches off from
+                self._mark = torch.cuda.Event()
+                self._mark.record(torch.cuda.current_stream(self.dev))
             elif item[0] == 'beside':                         # (main launch, side launches): both ordered after everything so far.  The
                 main = torch.cuda.current_stream(self.dev)    # MAIN launch is enqueued first: a captured graph keeps the branch it meets first
-                ev = torch.cuda.Event()                       # on the queue of the launches around it, and the other branch pays the
-                ev.record(main)                               # cross-queue latency (~12 us each way) -- the route has 25 us to spare, the
-                for launch in item[1]:                        # step kernel none
+                if len(item) > 3 and item[3] == 'marked':     # on the queue of the launches around it, and the other branch pays the
+                    ev = self._mark                           # cross-queue latency (~12 us each way) -- the route has 25 us to spare, the
+                else:                                         # step kernel none
+                    ev = torch.cuda.Event()
+                    ev.record(main)
+                for launch in item[1]:
                     launch()
                 side.wait_event(ev)
                 for launch in item[2]:
@@ -183,9 +220,10 @@ class _ShardedStepBase(object):
             elif item[0] == 'join':
                 torch.cuda.current_stream(self.dev).wait_stream(side)
 
-    def _capture(self):
+    def _capture(self, par=0):
         """Each segment becomes one HIP graph (the collectives between them are issued by torch.distributed).  A captured segment
-        also RUNS nothing: the step that triggers the capture replays the fresh graphs."""
+        also RUNS nothing: the step that triggers the capture replays the fresh graphs.  `par`: the buffer set the launches are
+        bound to (`_use(par)` has been called)."""
         graphs, keeps = [], []
         n_seg = 5 if self.multi else 1
         if self._whole_step_graph():
@@ -197,18 +235,22 @@ class _ShardedStepBase(object):
                 for k, seg in enumerate(segs):
                     self._issue(seg, side)
                     self._exchange(k)
-            self._graphs, self._graph_keep = [graph], [self._keep]
-            return
-        for k in range(n_seg):
-            graph = torch.cuda.CUDAGraph()
-            with L.capture(graph):
-                cs = torch.cuda.current_stream(self.dev).cuda_stream
-                side = self._side if ((self.direct or self.multi) and self.overlap_route) else None
-                segs = self._bind(cs, None if side is None else side.cuda_stream)
-                keeps.append(self._keep)
-                self._issue(segs[k], side)
-            graphs.append(graph)
-        self._graphs, self._graph_keep = graphs, keeps
+            graphs, keeps = [graph], [self._keep]
+        else:
+            for k in range(n_seg):
+                graph = torch.cuda.CUDAGraph()
+                with L.capture(graph):
+                    cs = torch.cuda.current_stream(self.dev).cuda_stream
+                    side = self._side if ((self.direct or self.multi or self._double()) and self.overlap_route) else None
+                    segs = self._bind(cs, None if side is None else side.cuda_stream)
+                    keeps.append(self._keep)
+                    self._issue(segs[k], side)
+                graphs.append(graph)
+        if par:
+            self._graphs1, self._graph_keep1 = graphs, keeps
+        else:
+            self._graphs, self._graph_keep = graphs, keeps
+        return graphs
 
     def _catchup(self, ids, caps, adam, stream, arr):
         """Adam: the launch that brings the step's rows up to date BEFORE anything reads them (ktup_shard_adam_catchup): the distinct
@@ -244,7 +286,7 @@ class _ShardedStepBase(object):
     def last_step_unplaced(self):
         """Ids of the LAST step that found no slot on this job (0 = it ran)."""
         if not self.multi:
-            return int(self.counters[-1].item())
+            return int(self._sets[self._bind_par]['counters'][-1].item())
         return int(self.bucket[-1].item())
 
     def check(self):
@@ -330,17 +372,19 @@ class ShardedKtupStepper(_ShardedStepBase):
         self.u, self.pi, self.ni = i64(B, 0), i64(B, 0), i64(B, 0)
         self.cursor = torch.zeros(1, dtype=torch.int64, device=dev)       # batch the next step reads (device side, moves by itself)
         self._feed = (self.u, self.pi, self.ni, 1)
-        self.entries, self.inverse = i64(E, -1), i64(E, 0)
-        self.send_ids = i64(W, -1)
-        self.pair_map = i32(W + 1)
-        self.sort_ws = i32((lib.ktup_shard_route_sort_bytes(E, W) + 3) // 4)
-        self.counters = i32(W_ * 3 + 1)
+        # what a route writes and the step's launches read, TWICE: with batches fed from device columns on one rank, steps alternate between
+        # the sets and the route of step s + 1 fills the other set beside the walks of step s (_pipelined); otherwise set 0 is the only one
+        # in use.  The attribute names (self.entries, ...) point at the set of the step being bound / run (_use).
+        self._sets = [{'entries': i64(E, -1), 'inverse': i64(E, 0), 'send_ids': i64(W, -1), 'pair_map': i32(W + 1),
+                       'sort_ws': i32((lib.ktup_shard_route_sort_bytes(E, W) + 3) // 4), 'counters': i32(W_ * 3 + 1),
+                       'acc': torch.zeros(SLOTS + 1, dtype=torch.float64, device=dev)} for _ in range(2)]   # acc: [SLOTS partial sums of squares | the job-wide total]
+        self._par = 0
+        self._use(0)
         self.route_ws = torch.empty((lib.ktup_shard_route_workspace_bytes(E) + 7) // 8, dtype=torch.int64, device=dev)
         self.X = f32(W + 1, d)                                # row W stays zero: "no entity" (jTransUP.py:96 padding_idx)
         self.Gcat = f32(3 * B, d)                             # [GU (B) ; GV (2B)]
         self.Gwire = f32(W, d)
         self.xkeys = i32(max(2, lib.ktup_shard_reduce_list_len(E, d)))
-        self.acc = torch.zeros(SLOTS + 1, dtype=torch.float64, device=dev)  # [SLOTS partial sums of squares | the job-wide total]
         self.acc_step = torch.zeros(SLOTS, dtype=torch.float64, device=dev)  # the step kernel's share, when it runs beside the route's init
         self.loss_sum = f32(2)                                # [sum of batch-mean BPR terms, sum of orthogonalLoss values] of the steps that ran
         self.loss_step = f32(2)                               # the current step's terms (the apply launch folds and clears them)
@@ -370,8 +414,9 @@ class ShardedKtupStepper(_ShardedStepBase):
             self.own_xkeys = i32(max(2, lib.ktup_shard_reduce_list_len(W, d)))
             self.bucket = torch.zeros(n_g * P * d + 2, dtype=torch.float64, device=dev)
         self._eager = None
-        self._graphs = None
+        self._graphs = self._graphs1 = None
         self._graph_steps = 0
+        self._fed = self._routed = False
 
     # ------------------------------------------------------------------------------------------------ launch lists
     def _bind(self, stream, side=None):
@@ -433,9 +478,7 @@ class ShardedKtupStepper(_ShardedStepBase):
         bind = L.bind
         fu, fp, fn, nb = self._feed
         def route_phase(phase, on):
-            return bind('ktup_shard_route_ktup', _p(fu), _p(fp), _p(fn), B, nb, _p(self.cursor), _p(self.item2ent), self.ent_pad,
-                        _p(self.entries), Wn, cap, _p(inv), _p(self.send_ids), _p(self.pair_map), _p(self.sort_ws), _p(self.counters),
-                        _p(self.acc), SLOTS + 1, _p(self.route_ws), phase, on)
+            return self._route_launch(phase, on, keep)
         route = route_phase(0, stream)
         if self.direct:                                      # global ids straight into the shards (entries = [u | pos ; neg | ...])
             ent = self.entries
@@ -470,6 +513,12 @@ class ShardedKtupStepper(_ShardedStepBase):
                 tail = [rnorm] + count + [rapply]
             else:
                 tail = [reduce_, gnorm] + count + [apply_]
+            if self._double():     # this step's route ran beside the previous step's walks (into this buffer set); the next step's runs beside these
+                nxt = [self._route_launch(0, side if side is not None else stream, keep, 1 - self._bind_par)]
+                head = ([self._catchup(self.send_ids, self.cap, adam, stream, arr)] if adam else []) + ([step] if self.direct else [pack, step])
+                # the branch leaves at the step's first launch and is joined in front of its last one: a graph that ENDS in a join pays ~17 us
+                # before the next replay starts (measured), and a route that starts beside the walks ends after them
+                return [[('beside', head + tail[:-1], nxt), ('join',), tail[-1]] if side is not None else head + tail + nxt]
             if adam:                                         # the whole route, then the catch-up of the rows it named, then whoever reads them
                 catch = self._catchup(self.send_ids, self.cap, adam, stream, arr)
                 return [([route, catch, step] if self.direct else [route, catch, pack, step]) + tail]
@@ -519,14 +568,34 @@ class ShardedKtupStepper(_ShardedStepBase):
         else:
             own_tail = [[oreduce, gnorm, pack_b], [fin_b] + count + [apply_]]
         whole = side is not None and self._whole_step_graph() and self._open_branch()      # one graph: a branch may stay open across the exchanges
+        head, nxt = [route_phase(4, stream)], []
+        if self._pipelined():           # this step's route ran during the previous step (into this buffer set); the next step's rides on the
+            head = []                   # branch that carries the sort and the owner's route (or follows the step on one stream)
+            nxt = [self._route_launch(4, on, keep, 1 - self._bind_par)]
         if adam:    # the owner's route of the requested rows moves in front of the pack launch: the catch-up needs its DISTINCT rows
             catch = self._catchup(self.own_ids, self.cap_own, adam, stream, arr)
             if whole:
-                return [[route_phase(4, stream)], [oroute_on(stream), catch, ('beside', [pack], [sort_, zshared])], [step, ('join',), rstore]] + own_tail
-            return [[route_phase(4, stream)], [oroute_on(stream), catch] + par([pack], [sort_, zshared]), [step, rstore]] + own_tail
-        if whole:   # sort, zero-fill and the owner's route: one branch from the id exchange to the end of the step kernel
-            return [[route_phase(4, stream)], [('beside', [pack], [sort_, zshared, oroute_on(on)])], [step, ('join',), rstore]] + own_tail
-        return [[route_phase(4, stream)], par([pack], [sort_, zshared]), par([step, rstore], [oroute_on(on)])] + own_tail
+                return [head, [oroute_on(stream), catch, ('beside', [pack], [sort_, zshared] + nxt)], [step, ('join',), rstore]] + own_tail
+            return [head, [oroute_on(stream), catch] + par([pack], [sort_, zshared]), par([step, rstore], nxt) if nxt else [step, rstore]] + own_tail
+        if whole:   # sort, zero-fill, the owner's route (and the next step's route): one branch from the id exchange to the end of the step kernel
+            return [head, [('beside', [pack], [sort_, zshared, oroute_on(on)] + nxt)], [step, ('join',), rstore]] + own_tail
+        return [head, par([pack], [sort_, zshared]), par([step, rstore], [oroute_on(on)] + nxt)] + own_tail
+
+    def _route_launch(self, phase, on, keep, par=None):
+        """ktup_shard_route_ktup, pre-bound (phases: include/ktup_hip.h), writing buffer set `par` (default: the set in use).  Several
+        ranks: the launch clears the SLOTS partial sums of the norm but not the job-wide total behind them -- the owner's apply walk of
+        step s reads that word while the route of step s + 1 may already run beside it (_pipelined)."""
+        S = self._sets[self._bind_par if par is None else par]
+        cap = _i64s(self.cap)
+        keep.append(cap)
+        fu, fp, fn, nb = self._feed
+        return L.bind('ktup_shard_route_ktup', _p(fu), _p(fp), _p(fn), self.B, nb, _p(self.cursor), _p(self.item2ent), self.ent_pad,
+                      _p(S['entries']), self.world, ctypes.addressof(cap), _p(S['inverse']), _p(S['send_ids']), _p(S['pair_map']), _p(S['sort_ws']),
+                      _p(S['counters']), _p(S['acc']), SLOTS if self.multi else SLOTS + 1, _p(self.route_ws), phase, on)
+
+    def _bind_route(self, stream):
+        keep = []
+        return self._route_launch(0 if not self.multi else 4, stream, keep), keep
 
     # ------------------------------------------------------------------------------------------------ the step
     def load_batch(self, u, pos_items, neg_items):
@@ -548,9 +617,10 @@ class ShardedKtupStepper(_ShardedStepBase):
                 if c.dtype != torch.int64 or c.device != self.dev or not c.is_contiguous() or c.numel() % self.B or c.numel() != u.numel():
                     raise L.KtupError('feed columns are contiguous int64 device tensors of n_batches x B ids each')
             self._feed = (u, p, n, u.numel() // self.B)
+        self._fed, self._routed, self._par = columns is not None, False, 0
         self.cursor.zero_()
         self._eager = None
-        self._graphs = None                                   # the column addresses are baked into the bound launches
+        self._graphs = self._graphs1 = None                   # the column addresses are baked into the bound launches
 
     def __call__(self, u=None, pos_items=None, neg_items=None):
         if u is not None:
@@ -624,17 +694,18 @@ class ShardedKgStepper(_ShardedStepBase):
         self.cols = [i64(B, 0) for _ in range(6)]                        # ph, pt, pr, nh, nt, nr
         self.cursor = torch.zeros(1, dtype=torch.int64, device=dev)
         self._feed = tuple(self.cols) + (1,)
-        self.entries, self.rels, self.inverse = i64(E, 0), i64(2 * B, 0), i64(E, 0)
+        # the route's output twice (ShardedKtupStepper.__init__: steps fed from device columns alternate between the sets)
+        self._sets = [{'entries': i64(E, 0), 'rels': i64(2 * B, 0), 'inverse': i64(E, 0), 'send_ids': i64(W, -1),
+                       'sort_ws': i32((lib.ktup_shard_route_sort_bytes(E, W) + 3) // 4), 'counters': i32(W_ + 1),
+                       'acc': torch.zeros(SLOTS + 1, dtype=torch.float64, device=dev)} for _ in range(2)]
+        self._par = 0
+        self._use(0)
         self.order = i32(B)
-        self.send_ids = i64(W, -1)
-        self.sort_ws = i32((lib.ktup_shard_route_sort_bytes(E, W) + 3) // 4)
-        self.counters = i32(W_ + 1)
         self.route_ws = torch.empty((lib.ktup_shard_route_workspace_bytes(E) + 7) // 8, dtype=torch.int64, device=dev)
         self.X = f32(W + 1, d)
         self.GE = f32(E, d)
         self.Gwire = f32(W, d)
         self.xkeys = i32(max(2, lib.ktup_shard_reduce_list_len(E, d)))
-        self.acc = torch.zeros(SLOTS + 1, dtype=torch.float64, device=dev)
         self.loss_sum, self.loss_step = f32(4), f32(4)
         self.skipped = i32(1)
         self.small_g = [f32(P, d) for _ in self.small]
@@ -661,7 +732,8 @@ class ShardedKgStepper(_ShardedStepBase):
             self.own_xkeys = i32(max(2, lib.ktup_shard_reduce_list_len(W, d)))
             self.bucket = torch.zeros(len(self.small) * P * d + 2, dtype=torch.float64, device=dev)
         self._eager = None
-        self._graphs = None
+        self._graphs = self._graphs1 = None
+        self._fed = self._routed = False
 
     def _bind(self, stream, side=None):
         B, d, P, W, E, Wn = self.B, self.d, self.P, self.W, self.E, self.world
@@ -691,9 +763,7 @@ class ShardedKgStepper(_ShardedStepBase):
         f = self._feed
 
         def route_phase(phase, on):
-            return bind('ktup_shard_route_kg', _p(f[0]), _p(f[1]), _p(f[2]), _p(f[3]), _p(f[4]), _p(f[5]), B, f[6], _p(self.cursor),
-                        _p(self.entries), _p(self.rels), Wn, cap, _p(self.inverse), _p(self.send_ids), _p(self.sort_ws), _p(self.counters),
-                        _p(self.acc), SLOTS + 1, _p(self.route_ws), phase, on)
+            return self._route_launch(phase, on, keep)
         order = bind('ktup_shard_kg_rel_order', _p(self.rels), B, P, _p(self.order), stream)
         if self.direct:
             Esrc, lde, ent_ids, ent_pad = Et.weight.data, Et.weight.data.stride(0), self.entries, -1
@@ -710,6 +780,11 @@ class ShardedKgStepper(_ShardedStepBase):
                           _p(self.sort_ws), E, _p(self.Gwire), d, _p(self.xkeys), n_small, P, sgp, sp0p, ss0p, None, None, None, self.lr,
                           self.eps, _p(self.acc), SLOTS, self.max_norm, skip_i, None, *close, adam, stream)
             count = [bind('ktup_shard_step_count', _p(self.opt_step), skip_i, None, self.betas[0], self.betas[1], stream)] if adam else []
+            if self._double():     # routed beside the previous step's walks; the next step's route (the other buffer set) beside these
+                nxt = [self._route_launch(0, side if side is not None else stream, keep, 1 - self._bind_par)]
+                head = ([self._catchup(self.send_ids, self.cap, adam, stream, arr)] if adam else []) + ([] if self.direct else [pack]) + [order, step]
+                walks = [rnorm] + count + [rapply]
+                return [[('beside', head + walks[:-1], nxt), ('join',), walks[-1]] if side is not None else head + walks + nxt]
             if adam:
                 catch = self._catchup(self.send_ids, self.cap, adam, stream, arr)
                 return [[route_phase(0, stream), catch] + ([] if self.direct else [pack]) + [order, step, rnorm] + count + [rapply]]
@@ -744,14 +819,31 @@ class ShardedKgStepper(_ShardedStepBase):
         count = [bind('ktup_shard_step_count', _p(self.opt_step), None, self.bucket.data_ptr() + 8 * (N + 1), self.betas[0], self.betas[1], stream)] if adam else []
         own_tail = [[onorm, pack_b], [fin_b] + count + [oapply]]
         whole = side is not None and self._whole_step_graph() and self._open_branch()
+        head, nxt = [route_phase(4, stream)], []
+        if self._pipelined():
+            head = []
+            nxt = [self._route_launch(4, on, keep, 1 - self._bind_par)]
         if adam:
             catch = self._catchup(self.own_ids, self.cap_own, adam, stream, arr)
             if whole:
-                return [[route_phase(4, stream)], [oroute_on(stream), catch, ('beside', [pack], [sort_, zshared])], [order, step, ('join',), rstore]] + own_tail
-            return [[route_phase(4, stream)], [oroute_on(stream), catch] + par([pack], [sort_, zshared]), [order, step, rstore]] + own_tail
+                return [head, [oroute_on(stream), catch, ('beside', [pack], [sort_, zshared] + nxt)], [order, step, ('join',), rstore]] + own_tail
+            return [head, [oroute_on(stream), catch] + par([pack], [sort_, zshared]), par([order, step, rstore], nxt) if nxt else [order, step, rstore]] + own_tail
         if whole:
-            return [[route_phase(4, stream)], [('beside', [pack], [sort_, zshared, oroute_on(on)])], [order, step, ('join',), rstore]] + own_tail
-        return [[route_phase(4, stream)], par([pack], [sort_, zshared]), par([order, step, rstore], [oroute_on(on)])] + own_tail
+            return [head, [('beside', [pack], [sort_, zshared, oroute_on(on)] + nxt)], [order, step, ('join',), rstore]] + own_tail
+        return [head, par([pack], [sort_, zshared]), par([order, step, rstore], [oroute_on(on)] + nxt)] + own_tail
+
+    def _route_launch(self, phase, on, keep, par=None):
+        S = self._sets[self._bind_par if par is None else par]
+        cap = _i64s(self.cap)
+        keep.append(cap)
+        f = self._feed
+        return L.bind('ktup_shard_route_kg', _p(f[0]), _p(f[1]), _p(f[2]), _p(f[3]), _p(f[4]), _p(f[5]), self.B, f[6], _p(self.cursor),
+                      _p(S['entries']), _p(S['rels']), self.world, ctypes.addressof(cap), _p(S['inverse']), _p(S['send_ids']), _p(S['sort_ws']),
+                      _p(S['counters']), _p(S['acc']), SLOTS if self.multi else SLOTS + 1, _p(self.route_ws), phase, on)
+
+    def _bind_route(self, stream):
+        keep = []
+        return self._route_launch(0 if not self.multi else 4, stream, keep), keep
 
     def load_batch(self, ph, pt, pr, nh, nt, nr):
         if self._feed[0] is not self.cols[0]:
@@ -770,9 +862,10 @@ class ShardedKgStepper(_ShardedStepBase):
                 if c.dtype != torch.int64 or c.device != self.dev or not c.is_contiguous() or c.numel() % self.B or c.numel() != cs[0].numel():
                     raise L.KtupError('feed columns are contiguous int64 device tensors of n_batches x B ids each')
             self._feed = cs + (cs[0].numel() // self.B,)
+        self._fed, self._routed, self._par = columns is not None, False, 0
         self.cursor.zero_()
         self._eager = None
-        self._graphs = None
+        self._graphs = self._graphs1 = None
 
     def __call__(self, *ids):
         if ids:

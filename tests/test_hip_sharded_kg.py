@@ -154,24 +154,28 @@ def test_kg_stepper_transe_and_l1(transh, l1):
     np.testing.assert_allclose(float(st.loss_sum.sum()), sum(v for _, v in losses), rtol=1e-4)
 
 
-def test_kg_stepper_hot_entities_and_device_fed_columns():
+@pytest.mark.parametrize('form', ['one_graph', 'exchange_form', 'exchange_form_adam'])
+def test_kg_stepper_hot_entities_and_device_fed_columns(form):
     """30 entities under 512-triple batches: every row's sorted segment spans several workgroups of the reduction; the batches come
-    from device columns walked by the step's own cursor (5 steps over 3 batches wrap around)."""
+    from device columns walked by the step's own cursor (5 steps over 3 batches wrap around).  Exchange form: the route of step s + 1
+    runs at the end of step s (the cursor is one batch ahead), the requester's reduction stores its rows."""
     from jTransUP.sharded_ktup import ShardedKgStepper
     ne, P, d, b = 400, 20, 256, 512
     dev = torch.device(DEV)
     full, small0, i2e, gen = _tables(10, 10, ne, P, d, seed=29, scale=1.2)
     three = _kg_batches(gen, 1, 3, ne, P, b, hot=30)
     order = [0, 1, 2, 0, 1]
-    Wd, losses = _dense(full, small0, i2e, [('kg', three[k]) for k in order], 'adagrad', 0.05, 1e-4, 0.5)
+    kind, lr, eps = ('adam', 0.01, 1e-5) if form.endswith('adam') else ('adagrad', 0.05, 1e-4)
+    Wd, losses = _dense(full, small0, i2e, [('kg', three[k]) for k in order], kind, lr, eps, 0.5)
     _, _, Et = _sharded(full, dev, 0, 1)
     rel, norm = [torch.nn.Parameter(t.clone().to(dev)) for t in small0[2:]]
-    st = ShardedKgStepper(Et, rel, norm, batch=b, kind='adagrad', lr=0.05, eps=1e-4, max_norm=0.5)
+    st = ShardedKgStepper(Et, rel, norm, batch=b, kind=kind, lr=lr, eps=eps, max_norm=0.5, force_exchange=form != 'one_graph')
     st.set_feed([torch.stack([three[k][0][c] for k in range(3)]).to(dev) for c in range(6)])
     for _ in order:
         st.run()
+    st.flush()
     torch.cuda.synchronize()
-    assert int(st.cursor) == len(order) and st._graphs is not None
+    assert int(st.cursor) == len(order) + 1 and st._graphs is not None       # (the next step's route has already run)
     torch.testing.assert_close(Et.weight.data.cpu(), Wd[2], rtol=1e-4, atol=2e-5)
     torch.testing.assert_close(rel.data.cpu(), Wd[5], rtol=1e-4, atol=2e-5)
     np.testing.assert_allclose(float(st.loss_sum.sum()), sum(v for _, v in losses), rtol=1e-4)

@@ -134,11 +134,12 @@ def test_stepper_l1_distance_and_orthogonal_regulariser(l1, orth, pad_every):
     np.testing.assert_allclose(float(st.loss_sum[0] + st.loss_sum[1]), sum(losses), rtol=1e-4)
 
 
-@pytest.mark.parametrize('direct', [True, False, 'beside'])
+@pytest.mark.parametrize('direct', [True, False, 'beside', 'exchange', 'exchange_adam'])
 def test_stepper_device_fed_batches_walk_the_columns(direct):
     """set_feed: an epoch of pre-drawn batches in device columns, the step's own launches move the cursor (no per-step copy or
     argument); 5 steps over 3 batches wrap around.  'beside': the step kernel reads the id columns itself and the WHOLE route runs
-    on the second graph branch (route_beside)."""
+    on the second graph branch (route_beside).  'exchange': the several-ranks form, where the route of step s + 1 runs at the END of
+    step s beside the owner's apply walk (the cursor is then one batch ahead of the steps)."""
     from jTransUP import parallel
     from jTransUP.sharded_ktup import ShardedKtupStepper
     nu, ni, ne, b, d, P = 700, 250, 500, 256, 128, 20
@@ -146,18 +147,21 @@ def test_stepper_device_fed_batches_walk_the_columns(direct):
     full, small0, i2e, gen = _world_tables(nu, ni, ne, P, d, seed=41)
     three = _batches(gen, 1, 3, nu, ni, b)
     order = [0, 1, 2, 0, 1]
-    Wd, losses = _dense_reference(full, small0, i2e, [three[k] for k in order], 'adagrad', 0.05, 1e-4, 0.5)
+    exch = str(direct).startswith('exchange')
+    kind, lr, eps = ('adam', 0.01, 1e-5) if direct == 'exchange_adam' else ('adagrad', 0.05, 1e-4)
+    Wd, losses = _dense_reference(full, small0, i2e, [three[k] for k in order], kind, lr, eps, 0.5)
     mk = lambda key: parallel.ShardedTable(full[key].shape[0], d, rank=0, world=1, device=dev, init=lambda g: full[key][g].to(dev))
     Ut, It, Et = mk('U'), mk('I'), mk('E')
     small = [torch.nn.Parameter(t.clone().to(dev)) for t in small0]
-    st = ShardedKtupStepper(Ut, It, Et, *small, i2e.to(torch.int32).to(dev), batch=b, kind='adagrad', lr=0.05, eps=1e-4, max_norm=0.5,
-                            direct=bool(direct), route_beside=direct == 'beside')
+    st = ShardedKtupStepper(Ut, It, Et, *small, i2e.to(torch.int32).to(dev), batch=b, kind=kind, lr=lr, eps=eps, max_norm=0.5,
+                            direct=None if exch else bool(direct), route_beside=direct == 'beside', force_exchange=exch)
     cols = [torch.stack([three[k][0][c] for k in range(3)]).to(dev) for c in range(3)]
     st.set_feed(cols)
     for _ in order:
         st.run()
+    st.flush()
     torch.cuda.synchronize()
-    assert int(st.cursor) == len(order) and st._graphs is not None
+    assert int(st.cursor) == len(order) + (direct != 'beside') and st._graphs is not None       # (the next step's route has already run)
     _check((Ut, It, Et), small, Wd, 0, 1)
     np.testing.assert_allclose(float(st.loss_sum[0]), sum(losses), rtol=1e-4)
 

@@ -16,7 +16,7 @@ def main():
         path = sorted(glob.glob(os.path.join(path, '**', '*kernel_trace.csv'), recursive=True))[0]
     rows = list(csv.DictReader(open(path)))
     rows.sort(key=lambda r: int(r['Start_Timestamp']))
-    idx = [i for i, r in enumerate(rows) if anchor in r['Kernel_Name']]
+    idx = [i for i, r in enumerate(rows) if (anchor in r['Kernel_Name'] and 'count' not in r['Kernel_Name'])]
     # an anchor occurrence that follows another within 40 us belongs to the same step (the owner's route has an init launch too)
     firsts = [i for k, i in enumerate(idx) if k == 0 or int(rows[i]['Start_Timestamp']) - int(rows[idx[k - 1]]['Start_Timestamp']) > 40000]
     if len(firsts) < back + 1:

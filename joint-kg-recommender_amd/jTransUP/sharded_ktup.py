@@ -202,16 +202,10 @@ class _ShardedStepBase(object):
                 side.wait_stream(torch.cuda.current_stream(self.dev))
                 for launch in item[1]:
                     launch()
-            elif item[0] == 'mark':                           # a point on the main stream a later ('beside', ..., ..., 'marked') branches off from
-                self._mark = torch.cuda.Event()
-                self._mark.record(torch.cuda.current_stream(self.dev))
             elif item[0] == 'beside':                         # (main launch, side launches): both ordered after everything so far.  The
                 main = torch.cuda.current_stream(self.dev)    # MAIN launch is enqueued first: a captured graph keeps the branch it meets first
-                if len(item) > 3 and item[3] == 'marked':     # on the queue of the launches around it, and the other branch pays the
-                    ev = self._mark                           # cross-queue latency (~12 us each way) -- the route has 25 us to spare, the
-                else:                                         # step kernel none
-                    ev = torch.cuda.Event()
-                    ev.record(main)
+                ev = torch.cuda.Event()                       # on the queue of the launches around it, and the other branch pays the
+                ev.record(main)                               # cross-queue latency (~12 us each way)
                 for launch in item[1]:
                     launch()
                 side.wait_event(ev)
@@ -518,6 +512,9 @@ class ShardedKtupStepper(_ShardedStepBase):
                 head = ([self._catchup(self.send_ids, self.cap, adam, stream, arr)] if adam else []) + ([step] if self.direct else [pack, step])
                 # the branch leaves at the step's first launch and is joined in front of its last one: a graph that ENDS in a join pays ~17 us
                 # before the next replay starts (measured), and a route that starts beside the walks ends after them
+                # (joined at the graph's end instead: 0.1217 against 0.1205 ms; the next route on the second stream as a graph of its own with
+                #  events between the replays -- no branch inside the step's graph at all: 0.126; forked after the step kernel, beside the
+                #  walks only: 0.143 -- the branch then ends after the walks and a graph that ends in a late join pays ~17 us)
                 return [[('beside', head + tail[:-1], nxt), ('join',), tail[-1]] if side is not None else head + tail + nxt]
             if adam:                                         # the whole route, then the catch-up of the rows it named, then whoever reads them
                 catch = self._catchup(self.send_ids, self.cap, adam, stream, arr)

@@ -490,8 +490,14 @@ int ktup_shard_pack_wire(int n_tables, float* const* tables, const int64_t* ld, 
  * decaying in closed form), then applies step t.  `step` points at TWO device int64: step[0] = the number of the step being applied,
  * step[1] = that step's bias corrections {1 - beta1^t, sqrt(1 - beta2^t)} as two floats; ktup_shard_step_count -- the launch before
  * the apply launch, and the only writer of both -- moves the counter (+1 unless the step is skipped) and refreshes them.  ktup_shard_adam_flush replays every row of a shard up to
- * *step (before an evaluation or a checkpoint reads the table).                                                               */
-typedef struct ktup_adam_t { float beta1, beta2; int32_t replay; int32_t reserved; const int64_t* step; } ktup_adam_t;
+ * *step (before an evaluation or a checkpoint reads the table).
+ * WEIGHT DECAY (the reference builds every optimizer with weight_decay = l2_lambda, 1e-5 by default: utils/trainer.py:63-77, base.py:51): the
+ * dense step adds weight_decay * p to the gradient of EVERY row at EVERY step, touched or not.  The same state rows and the same three
+ * launches carry it: `rule` = 0 Adam, 1 Adagrad (its sum in the `v` half of the state row), 2 plain SGD; with weight_decay > 0 a touched row
+ * first takes the steps last + 1 .. t - 1 on g = weight_decay * p one by one (from step 1 on: `last` = 0 is a row never written), then step t
+ * on g + weight_decay * p; catch-up and flush likewise.  (Adagrad / SGD without weight decay keep their plain row-sparse forms, kind =
+ * KTUP_OPT_ADAGRAD / KTUP_OPT_SGD; kind = KTUP_OPT_ADAM means "state rows [m | v | last] and this rule".)                      */
+typedef struct ktup_adam_t { float beta1, beta2; int32_t replay; int32_t rule; const int64_t* step; float weight_decay; float reserved; } ktup_adam_t;
 #define KTUP_SHARD_ADAM_STATE_PITCH(d) (2 * (d) + 4)
 int ktup_shard_step_count(int64_t* step, const int32_t* skip_count, const double* skip_value, float beta1, float beta2, void* stream);
 int ktup_shard_adam_flush(float* table, int64_t ldt, float* state, int64_t lds, int d, int64_t n_rows, float lr, float eps,
@@ -668,13 +674,16 @@ int ktup_train_rec_step(const float* U, int64_t ldu, const float* I, int64_t ldi
  * every entry of the route had its own table row (ktup_shard_reduce_norm with dup_only corrects for shared rows).  neg_ids (may be
  * NULL): u_ids / i_ids / neg_ids are then the id COLUMNS of ktup_shard_route_ktup (n_batches x B each) and the kernel reads batch
  * (*cursor mod n_batches) of them itself (cursor NULL: batch 0): it does not wait for an entry list.  Soft gate only.  gR / gRn may be NULL although rel / norm are given (then orth must be 0): gP / gPn are the gradients
- * of both summands of the mixed tables.                                                                                   */
+ * of both summands of the mixed tables.                                                                                     gumbel_mode / gumbel: the preference gate -- KTUP_GUMBEL_OFF (soft, gumbel NULL), KTUP_GUMBEL_INPUT (gumbel = 2B x n_pref
+ * uniforms, positives then negatives, as transUP.py:159-162 draws them: the parity mode) or KTUP_GUMBEL_PHILOX_DEV (gumbel = device uint64
+ * {seed, offset}: draw (row k of [pos ; neg], preference p) is Philox number offset + k n_pref + p; the caller moves the offset on). */
 int ktup_train_rec_step_rows(const float* U, int64_t ldu, const float* I, int64_t ldi, const float* E, int64_t lde,
                              const int32_t* item2ent, int64_t ent_pad, const float* pref, const float* pref_norm,
                              const float* rel, const float* norm, int64_t ldp, int n_pref, int d, const int64_t* u_ids,
                              const int64_t* i_ids, int64_t B, int l1, float target, float gscale, int orth, float* loss,
                              float* GU, float* GV, float* gP, float* gPn, float* gR, float* gRn, double* sumsq, int n_slots,
-                             const int64_t* neg_ids, const int64_t* cursor, int64_t n_batches, void* stream);
+                             const int64_t* neg_ids, const int64_t* cursor, int64_t n_batches, int gumbel_mode, const void* gumbel,
+                             void* stream);
 int ktup_train_kg_step(int transh, const float* E, int64_t lde, const float* R, int64_t ldr, const float* Nrm, int64_t ldn,
                        int d, const int64_t* h, const int64_t* t, const int64_t* r, int64_t B, int l1, float margin,
                        float gscale, int regs, float* loss, float* gE, float* gR, float* gN, double* gnorm, void* stream);

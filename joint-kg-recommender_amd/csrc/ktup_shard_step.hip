@@ -328,10 +328,18 @@ struct AdamRule {
   float b1, b2; int replay; const int64_t* step;       // step[0] = number of the step being applied (>= 1; ktup_shard_step_count moves it and
                                                        // leaves that step's bias corrections {1 - beta1^t, sqrt(1 - beta2^t)} as two floats in step[1])
   float ln1, ln2;                                      // log(beta1), log(beta2): beta^k = exp(k log beta) without a pow() per row
+  // WEIGHT DECAY (utils/trainer.py:63-77: every torch.optim optimizer is built with weight_decay = l2_lambda, 1e-5 by default): the dense
+  // step adds wd * p to the gradient of EVERY row of every table at every step -- also of rows no batch has touched yet.  A row then owes,
+  // for each step it was not touched, the optimizer's step on g = wd * p; whoever touches it replays those steps one by one (no
+  // closed form for Adagrad / Adam, no geometric tail to cut), from step 1 on (`last` = 0 is a row that has never been written).
+  // rule: which optimizer the replay and the step are: 0 Adam, 1 Adagrad (its sum lives in the `v` half of the state row), 2 plain SGD.
+  int rule; float wd;
 };
 // (a pow() per row and lane -- the bias corrections of the step, the powers the replay starts from -- made the Adam apply walk of config 5
 //  193 us against Adagrad's 47: fp64 pow is several hundred instructions)
-inline AdamRule make_rule(const ktup_adam_t* a) { return AdamRule{a->beta1, a->beta2, a->replay, a->step, logf(a->beta1), logf(a->beta2)}; }
+inline AdamRule make_rule(const ktup_adam_t* a) {
+  return AdamRule{a->beta1, a->beta2, a->replay, a->step, logf(a->beta1), logf(a->beta2), a->rule, a->weight_decay};
+}
 
 // one zero-gradient step on (p, m, sqrt(v)): sqrt(beta2^k v) = sqrt(v) sqrt(beta2)^k, so the replay carries sqrt(v) and multiplies it -- a
 // square root per element and step was a quarter of the loop (transcendental rate)
@@ -347,11 +355,59 @@ KTUP_DEV void adam_step1(float& p, float& m, float& v, float g, float c1, float 
   v = fmaf(1.f - b2, g * g, b2 * v);
   p = p - c1 * (m / (sqrtf(v) / bc2s + eps));
 }
-// One row's CPL float4 chunks per lane: replay the zero-gradient steps last + 1 .. upto, then (has_g) step t = upto + 1 with gradient g.
+// The three dense rules on one element, gradient g (weight decay already added): torch.optim's _single_tensor_* forms
+KTUP_DEV void lazy_step1(int rule, float& p, float& m, float& v, float g, float lr, float c1, float bc2s, float eps, float b1, float b2) {
+  if (rule == 0) { adam_step1(p, m, v, g, c1, bc2s, eps, b1, b2); return; }
+  if (rule == 1) {                                    // adagrad.py: state_sum.addcmul_(g, g); p.addcdiv_(g, sqrt(state_sum) + eps, value=-lr)
+    v = fmaf(g, g, v);
+    p = p - lr * (g / (sqrtf(v) + eps));
+    return;
+  }
+  p = fmaf(-lr, g, p);                                // sgd.py (momentum 0)
+}
+// One row's CPL float4 chunks per lane: replay the untouched steps last + 1 .. upto, then (has_g) step t = upto + 1 with gradient g.
 template <int CPL>
 KTUP_DEV void adam_row(float4 (&p)[CPL], float4 (&m)[CPL], float4 (&v)[CPL], const float4 (&g)[CPL], bool has_g, int upto, int last,
                        float lr, float eps, const AdamRule& r) {
   const int miss = upto - last;
+  if (r.wd != 0.f) {
+    // weight decay: the steps last + 1 .. upto on g = wd * p, exactly as the dense optimizer took them
+    if (miss > 0) {
+      if (r.rule == 2) {                              // p <- p (1 - lr wd), `miss` times
+        const float f = expf((float)miss * log1pf(-lr * r.wd));
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) p[j] = f * p[j];
+      } else {
+        double b1p = pow((double)r.b1, (double)last), b2p = pow((double)r.b2, (double)last);
+        for (int k = 0; k < miss; ++k) {
+          float c1 = lr, bc2s = 1.f;
+          if (r.rule == 0) {
+            b1p *= (double)r.b1; b2p *= (double)r.b2;
+            c1 = lr / (float)(1.0 - b1p); bc2s = (float)sqrt(1.0 - b2p);
+          }
+#pragma unroll
+          for (int j = 0; j < CPL; ++j) {
+            lazy_step1(r.rule, p[j].x, m[j].x, v[j].x, r.wd * p[j].x, lr, c1, bc2s, eps, r.b1, r.b2);
+            lazy_step1(r.rule, p[j].y, m[j].y, v[j].y, r.wd * p[j].y, lr, c1, bc2s, eps, r.b1, r.b2);
+            lazy_step1(r.rule, p[j].z, m[j].z, v[j].z, r.wd * p[j].z, lr, c1, bc2s, eps, r.b1, r.b2);
+            lazy_step1(r.rule, p[j].w, m[j].w, v[j].w, r.wd * p[j].w, lr, c1, bc2s, eps, r.b1, r.b2);
+          }
+        }
+      }
+    }
+    if (has_g) {
+      const float* bc = reinterpret_cast<const float*>(r.step + 1);
+      const float c1 = r.rule == 0 ? lr / bc[0] : lr, bc2s = r.rule == 0 ? bc[1] : 1.f;
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) {
+        lazy_step1(r.rule, p[j].x, m[j].x, v[j].x, fmaf(r.wd, p[j].x, g[j].x), lr, c1, bc2s, eps, r.b1, r.b2);
+        lazy_step1(r.rule, p[j].y, m[j].y, v[j].y, fmaf(r.wd, p[j].y, g[j].y), lr, c1, bc2s, eps, r.b1, r.b2);
+        lazy_step1(r.rule, p[j].z, m[j].z, v[j].z, fmaf(r.wd, p[j].z, g[j].z), lr, c1, bc2s, eps, r.b1, r.b2);
+        lazy_step1(r.rule, p[j].w, m[j].w, v[j].w, fmaf(r.wd, p[j].w, g[j].w), lr, c1, bc2s, eps, r.b1, r.b2);
+      }
+    }
+    return;
+  }
   if (last > 0 && miss > 0) {
     const int K = miss < r.replay ? miss : r.replay;
     double b1p = (double)__expf((float)last * r.ln1), b2p = (double)__expf((float)last * r.ln2);
@@ -390,7 +446,7 @@ KTUP_DEV void adam_row_mem(float4* prow, float4* srow, int nch, int lane, const 
   int32_t* lastp = reinterpret_cast<int32_t*>(srow + 2 * nch);
   const int last = *lastp;
   const int upto = has_g ? t - 1 : t;
-  if (!has_g && (last <= 0 || last >= t)) return;
+  if (!has_g && ((last <= 0 && r.wd == 0.f) || last >= t)) return;          // (weight decay moves rows that were never touched too)
   float4 p[CPL], m[CPL], v[CPL];
 #pragma unroll
   for (int j = 0; j < CPL; ++j) {
@@ -947,6 +1003,8 @@ int check_kind(const char* name, int kind, const ktup_adam_t* adam, int d) {
   if (kind == KTUP_OPT_ADAM) {
     KTUP_REQUIRE(adam && adam->step, "%s: Adam needs its rule (betas, replay length, the device step counter)", name);
     KTUP_REQUIRE(adam->beta1 >= 0.f && adam->beta1 < 1.f && adam->beta2 > 0.f && adam->beta2 < 1.f && adam->replay >= 0, "%s: bad Adam rule", name);
+    KTUP_REQUIRE(adam->rule >= 0 && adam->rule <= 2 && adam->weight_decay >= 0.f && (adam->rule == 0 || adam->weight_decay > 0.f),
+                 "%s: rule is 0 (Adam), or 1 (Adagrad) / 2 (SGD) with a weight decay > 0 (without one those two have plain row-sparse forms)", name);
     KTUP_REQUIRE(d % 4 == 0, "%s: Adam rows need d %% 4 == 0", name);
   }
   return KTUP_OK;
@@ -1010,7 +1068,7 @@ __global__ __launch_bounds__(256) void adam_catchup_kernel(CatchupArgs a) {
       last[u] = row[u] >= 0 ? *reinterpret_cast<const int32_t*>(a.st[k[u]] + row[u] * a.lds[k[u]] + 8 * a.nch) : 0;
 #pragma unroll
     for (int u = 0; u < RB; ++u) {
-      if (last[u] > 0 && last[u] < t)
+      if (row[u] >= 0 && (last[u] > 0 || a.r.wd != 0.f) && last[u] < t)
         adam_row_mem<GL, CPL>(reinterpret_cast<float4*>(a.tab[k[u]] + row[u] * a.ldt[k[u]]), reinterpret_cast<float4*>(a.st[k[u]] + row[u] * a.lds[k[u]]),
                               a.nch, lane, none, false, t, a.lr, a.eps, a.r);
     }

@@ -217,8 +217,12 @@ extern "C" int ktup_train_rec_step_rows(const float* U, int64_t ldu, const float
                                         const float* rel, const float* norm, int64_t ldp, int n_pref, int d, const int64_t* u_ids,
                                         const int64_t* i_ids, int64_t B, int l1, float target, float gscale, int orth, float* loss,
                                         float* GU, float* GV, float* gP, float* gPn, float* gR, float* gRn, double* sumsq, int n_slots,
-                                        const int64_t* neg_ids, const int64_t* cursor, int64_t n_batches, void* stream) {
+                                        const int64_t* neg_ids, const int64_t* cursor, int64_t n_batches, int gumbel_mode,
+                                        const void* gumbel, void* stream) {
   const char* name = "ktup_train_rec_step_rows";
+  KTUP_REQUIRE(gumbel_mode == KTUP_GUMBEL_OFF || ((gumbel_mode == KTUP_GUMBEL_INPUT || gumbel_mode == KTUP_GUMBEL_PHILOX_DEV) && gumbel),
+               "%s: the ST-Gumbel gate takes its uniforms (KTUP_GUMBEL_INPUT: 2B x n_pref floats, positives then negatives) or a device-resident "
+               "Philox position (KTUP_GUMBEL_PHILOX_DEV: uint64 {seed, offset})", name);
   KTUP_REQUIRE(B >= 0, "%s: negative batch", name);
   if (B == 0) return KTUP_OK;
   KTUP_REQUIRE(U && I && pref && pref_norm && u_ids && i_ids && loss && GU && GV && gP && gPn, "%s: null pointer argument", name);
@@ -232,7 +236,7 @@ extern "C" int ktup_train_rec_step_rows(const float* U, int64_t ldu, const float
                    aligned16(GU) && aligned16(GV) && aligned16(gP) && aligned16(gPn) && aligned16(gR) && aligned16(gRn),
                "%s: tables and gradients must be 16-byte aligned", name);
   const int rc = pref_step_mc(U, ldu, I, ldi, E, lde, item2ent, ent_pad, pref, pref_norm, rel, norm, ldp, n_pref, d, u_ids, i_ids, B, l1,
-                              KTUP_GUMBEL_OFF, nullptr, 0, 0, target, gscale, orth, loss, nullptr, nullptr, nullptr, gP, gPn, gR, gRn,
+                              gumbel_mode, reinterpret_cast<const float*>(gumbel), 0, 0, target, gscale, orth, loss, nullptr, nullptr, nullptr, gP, gPn, gR, gRn,
                               (hipStream_t)stream, name, GU, GV, sumsq, n_slots, neg_ids, cursor, n_batches);
   if (rc == 1) return set_error(KTUP_ERR_UNSUPPORTED, "%s: no fused kernel for d=%d, n_pref=%d (see ktup_train_step_supported)", name, d, n_pref);
   return rc;

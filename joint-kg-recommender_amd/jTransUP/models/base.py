@@ -58,7 +58,8 @@ FLAG_TABLE = [
                                              '(top-n lists merged, KG rank counts all-reduced) instead of whole batches being dealt to the ranks'),
     ('shard_tables', 'bool', False, 'jtransup with its own tables: the user / item / entity tables and their Adagrad sums are partitioned by row over '
                                     'the ranks (row % world) and a step exchanges only the rows its batch touches (BASELINE config 5; one process: the '
-                                    'same row-sparse step without an exchange); needs -optimizer_type Adagrad, Adam or SGD -momentum 0, and -l2_lambda 0; '
+                                    'same row-sparse step without an exchange); needs -optimizer_type Adagrad, Adam or SGD -momentum 0 (-l2_lambda > 0: the steps a row was not '
+                                    'touched for are replayed one by one when it is touched again -- fine at ml1m size, use -l2_lambda 0 for tables of millions of rows); '
                                     'the shards are the only resident copy: evaluation runs on them'),
     ('shard_capacity_factor', 'float', 1.25, '-shard_tables under torchrun: distinct rows a rank may ask ONE owner for per step = factor x entries / world '
                                              '+ 64; a step that needs more is skipped on every rank and the run stops at the next check (factor = world never overflows)'),

@@ -48,9 +48,19 @@ SLOTS = 16          # the sum of squares is accumulated in this many words (one 
 
 
 class AdamRule(ctypes.Structure):
-    """ktup_adam_t of include/ktup_hip.h: the row-sparse Adam that equals the reference's dense one (catch-up of the untouched steps)."""
-    _fields_ = [('beta1', ctypes.c_float), ('beta2', ctypes.c_float), ('replay', ctypes.c_int32), ('reserved', ctypes.c_int32),
-                ('step', ctypes.c_void_p)]
+    """ktup_adam_t of include/ktup_hip.h: the row-sparse rules that equal the reference's DENSE optimizers -- Adam (catch-up of the untouched
+    steps), and any of Adam / Adagrad / plain SGD with weight decay (`rule` 0 / 1 / 2: the untouched steps on g = weight_decay * p)."""
+    _fields_ = [('beta1', ctypes.c_float), ('beta2', ctypes.c_float), ('replay', ctypes.c_int32), ('rule', ctypes.c_int32),
+                ('step', ctypes.c_void_p), ('weight_decay', ctypes.c_float), ('reserved', ctypes.c_float)]
+
+
+RULES = {'adam': 0, 'adagrad': 1, 'sgd': 2}
+
+
+def is_lazy(kind, weight_decay=0.0):
+    """Does the row-sparse form of `kind` need the state rows [m | v | last] and the catch-up of untouched steps?  Adam always (a dense Adam
+    step moves every row that ever had a gradient), everything under weight decay (the dense step moves every row at every step)."""
+    return kind == 'adam' or float(weight_decay) != 0.0
 
 
 def adam_state_pitch(d):
@@ -69,8 +79,11 @@ def adam_replay(betas, tol=1e-5):
     return min(1 << 20, int(math.ceil(math.log(tol) / math.log(r))))
 
 
-def row_state(weight, kind):
-    """Optimizer state of a table (or shard) for `kind`: None (sgd), the Adagrad sums, or Adam's [m | v | last] rows."""
+def row_state(weight, kind, weight_decay=0.0):
+    """Optimizer state of a table (or shard) for `kind`: None (sgd), the Adagrad sums, or the [m | v | last] rows of Adam and of every
+    kind under weight decay (is_lazy; Adagrad's sum is then the `v` half)."""
+    if is_lazy(kind, weight_decay):
+        kind = 'adam'
     if kind == 'adagrad':
         return torch.zeros_like(weight)
     if kind == 'adam':
@@ -78,7 +91,9 @@ def row_state(weight, kind):
     return None
 
 
-def _check_state(state, weight, kind):
+def _check_state(state, weight, kind, weight_decay=0.0):
+    if is_lazy(kind, weight_decay):
+        kind = 'adam'
     want = None if kind == 'sgd' else (weight.shape[0], weight.shape[1] if kind == 'adagrad' else adam_state_pitch(weight.shape[1]))
     return (state is None and want is None) or (state is not None and want is not None and tuple(state.shape) == want)
 
@@ -259,14 +274,17 @@ class _ShardedStepBase(object):
                       arr(_i64s([x.stride(0) for x in sts])), arr((ctypes.c_void_p * len(idp))(*idp)), arr(_i64s(ns)), self.d, self.lr, self.eps,
                       adam, stream)
 
+    def _rule(self):
+        return AdamRule(self.betas[0], self.betas[1], adam_replay(self.betas), RULES[self.kind], self.opt_step.data_ptr(), self.weight_decay, 0.0)
+
     def flush(self):
         """Adam: bring EVERY row of this stepper's shards and small tables up to the current step (the zero-gradient steps a row has not
         been touched for; ktup_shard_adam_flush), so that what an evaluation, a gather or a checkpoint reads is what the reference's
         dense optimizer would hold.  Stream-ordered, no synchronisation; a no-op for the other optimizers."""
-        if self.kind != 'adam':
+        if not self.lazy:
             return
         st = torch.cuda.current_stream(self.dev).cuda_stream
-        rule = AdamRule(self.betas[0], self.betas[1], adam_replay(self.betas), 0, self.opt_step.data_ptr())
+        rule = self._rule()
         for w, s in [(t.weight.data, t.state) for t in self.tables] + [(p.data, s) for p, s in zip(self.small, self.small_state)]:
             L.call('ktup_shard_adam_flush', w.data_ptr(), w.stride(0), s.data_ptr(), s.stride(0), self.d, w.shape[0], self.lr, self.eps,
                    ctypes.addressof(rule), st)
@@ -303,12 +321,16 @@ class ShardedKtupStepper(_ShardedStepBase):
 
     def __init__(self, Ut, It, Et, pref, pref_norm, rel, norm, item2ent, batch, kind='adagrad', lr=0.005, eps=1e-10, max_norm=0.0,
                  l1=False, target=-1.0, orth=False, ent_pad=-1, group=None, capacity_factor=1.25, use_graphs=True, force_exchange=False,
-                 direct=None, overlap_route=True, fused_apply=True, route_beside=False, betas=(0.9, 0.999), opt_step=None, exchange_graph=True):
+                 direct=None, overlap_route=True, fused_apply=True, route_beside=False, betas=(0.9, 0.999), opt_step=None, exchange_graph=True,
+                 weight_decay=0.0, use_st_gumbel=False, gumbel_seed=0):
         self.exchange_graph = bool(exchange_graph)
+        self.weight_decay = float(weight_decay)
+        self.lazy = is_lazy(kind, weight_decay)
+        self.use_st_gumbel = bool(use_st_gumbel)
         if kind not in KINDS:
             raise ValueError('row-sparse steps exist for plain SGD, Adagrad and Adam')
         self.betas = (float(betas[0]), float(betas[1]))
-        self.has_state = kind != 'sgd'
+        self.has_state = kind != 'sgd' or self.lazy
         self.route_beside = bool(route_beside)
         self.tables = [Ut, It, Et]
         self.small = [pref, pref_norm, rel, norm]
@@ -385,14 +407,22 @@ class ShardedKtupStepper(_ShardedStepBase):
         self.skipped = i32(1)                                 # steps skipped for overflow: never cleared by a launch
         n_g = 4 if self.orth else 2
         self.small_g = [f32(P, d) for _ in range(n_g)]        # orth: gP, gPn, gR, gRn; else gA (pref & rel), gC (pref_norm & norm)
-        self.small_state = [row_state(s.data, kind) for s in self.small]
+        self.small_state = [row_state(s.data, kind, weight_decay) for s in self.small]
         for t in self.tables:
-            if not _check_state(t.state, t.weight.data, kind):
-                t.state = row_state(t.weight.data, kind)
+            if not _check_state(t.state, t.weight.data, kind, weight_decay):
+                t.state = row_state(t.weight.data, kind, weight_decay)
         # Adam: the number of the step being applied, in device memory (the launches are replayed from graphs); shared by the steppers
         # of a joint schedule.  ktup_shard_step_count moves it just before every apply launch.
         self.opt_step = opt_step if opt_step is not None else torch.zeros(2, dtype=torch.int64, device=dev)      # [step, two floats of bias corrections]
         self.steps = 0
+        # ST-Gumbel gate (transUP.py:118-170 / jTransUP.py:250-262, -use_st_gumbel): the draws of a step come from a Philox stream whose
+        # position lives in device memory (KTUP_GUMBEL_PHILOX_DEV: the step is a replayed graph) and moves by 2 B P per step -- every rank
+        # its own stream; set_gumbel_uniforms() feeds recorded uniforms instead (the parity mode of the tests)
+        self.gstate = self.gadv = self.guni = None
+        if self.use_st_gumbel:
+            seed = (int(gumbel_seed) * 6364136223846793005 + 1442695040888963407 + 7919 * self.rank) % (1 << 62)
+            self.gstate = torch.tensor([seed, 0], dtype=torch.int64, device=dev)
+            self.gadv = torch.tensor([0, 2 * B * P], dtype=torch.int64, device=dev)
         if self.multi:
             self.recv_ids = i64(W, -1)
             self.Xsend = f32(W, d)
@@ -430,9 +460,9 @@ class ShardedKtupStepper(_ShardedStepBase):
         lds = arr(_i64s([t.weight.data.stride(0) for t in self.tables]))
         states = arr(_ptrs([t.state for t in self.tables])) if self.has_state else None
         slds = arr(_i64s([t.state.stride(0) for t in self.tables])) if self.has_state else lds      # interleaved tables: pitch 2d
-        adam = arr(AdamRule(self.betas[0], self.betas[1], adam_replay(self.betas), 0, self.opt_step.data_ptr())) if self.kind == 'adam' else None
+        adam = arr(self._rule()) if self.lazy else None                 # (the lazy rules: Adam, or any kind under weight decay)
         cap = arr(_i64s(self.cap))
-        kind = KINDS[self.kind]
+        kind = KINDS['adam'] if self.lazy else KINDS[self.kind]      # (the C side: 'state rows [m | v | last] + the rule' or a plain form)
         gscale = 1.0 / Wn
         g = self.small_g
         if self.orth:
@@ -474,6 +504,9 @@ class ShardedKtupStepper(_ShardedStepBase):
         def route_phase(phase, on):
             return self._route_launch(phase, on, keep)
         route = route_phase(0, stream)
+        gate = (0, None)                                     # KTUP_GUMBEL_OFF / _INPUT (recorded uniforms) / _PHILOX_DEV (device-resident stream position)
+        if self.use_st_gumbel:
+            gate = (1, _p(self.guni)) if self.guni is not None else (3, _p(self.gstate))
         if self.direct:                                      # global ids straight into the shards (entries = [u | pos ; neg | ...])
             ent = self.entries
             uid_p, iid_p = (_p(fu), _p(fp)) if beside else (_p(ent), ent.data_ptr() + B * 8)
@@ -481,11 +514,17 @@ class ShardedKtupStepper(_ShardedStepBase):
             step = bind('ktup_train_rec_step_rows', _p(Ut.weight.data), Ut.weight.data.stride(0), _p(It.weight.data), It.weight.data.stride(0),
                         _p(Et.weight.data), Et.weight.data.stride(0), _p(self.item2ent), self.ent_pad, _p(pref), _p(pref_norm), _p(rel),
                         _p(norm), d, P, d, uid_p, iid_p, B, int(self.l1), self.target, gscale, int(self.orth),
-                        _p(self.loss_step), _p(self.Gcat), self.Gcat.data_ptr() + B * d * 4, _p(gP), _p(gPn), _p(gR), _p(gRn), *ssq, *cols, stream)
+                        _p(self.loss_step), _p(self.Gcat), self.Gcat.data_ptr() + B * d * 4, _p(gP), _p(gPn), _p(gR), _p(gRn), *ssq, *cols, *gate, stream)
         else:
             step = bind('ktup_train_rec_step_rows', _p(X), d, _p(X), d, _p(X), d, _p(self.pair_map), W, _p(pref), _p(pref_norm), _p(rel),
                         _p(norm), d, P, d, _p(inv), inv.data_ptr() + B * 8, B, int(self.l1), self.target, gscale, int(self.orth),
-                        _p(self.loss_step), _p(self.Gcat), self.Gcat.data_ptr() + B * d * 4, _p(gP), _p(gPn), _p(gR), _p(gRn), *ssq, None, None, 0, stream)
+                        _p(self.loss_step), _p(self.Gcat), self.Gcat.data_ptr() + B * d * 4, _p(gP), _p(gPn), _p(gR), _p(gRn), *ssq, None, None, 0, *gate, stream)
+        if self.use_st_gumbel and self.guni is None:         # the stream position moves past this step's draws (a torch op: captured with the rest)
+            launch_step, gstate, gadv = step, self.gstate, self.gadv
+
+            def step():
+                launch_step()
+                gstate.add_(gadv)
         reduce_ = bind('ktup_shard_reduce_rows', _p(self.Gcat), d, d, 3 * B, 2 * B, _p(self.sort_ws), E, W, _p(self.Gwire), d, stream)
         if not self.multi:
             pack = bind('ktup_shard_pack_wire', 3, tabs, lds, cap, d, _p(self.send_ids), 1, _p(X), d, stream)
@@ -578,6 +617,24 @@ class ShardedKtupStepper(_ShardedStepBase):
             return [head, [('beside', [pack], [sort_, zshared, oroute_on(on)] + nxt)], [step, ('join',), rstore]] + own_tail
         return [head, par([pack], [sort_, zshared]), par([step, rstore], [oroute_on(on)] + nxt)] + own_tail
 
+    def set_gumbel_uniforms(self, uniforms):
+        """Parity hook: the ST-Gumbel gate of the NEXT steps reads its uniforms -- (2B, n_pref): one row per scored pair, positives then
+        negatives, as transUP.py:159-162 draws them -- from a fixed buffer that this call fills, instead of drawing Philox numbers on
+        the device.  None switches back."""
+        if not self.use_st_gumbel:
+            raise L.KtupError('the stepper was built without the ST-Gumbel gate (use_st_gumbel=True)')
+        rebind = (uniforms is None) != (self.guni is None)
+        if uniforms is None:
+            self.guni = None
+        else:
+            if self.guni is None:
+                self.guni = torch.empty(2 * self.B, self.P, dtype=torch.float32, device=self.dev)
+            self.guni.copy_(uniforms)
+        if rebind:                                            # the gate's arguments are baked into the bound launches
+            torch.cuda.synchronize(self.dev)
+            self._eager = None
+            self._graphs = self._graphs1 = None
+
     def _route_launch(self, phase, on, keep, par=None):
         """ktup_shard_route_ktup, pre-bound (phases: include/ktup_hip.h), writing buffer set `par` (default: the set in use).  Several
         ranks: the launch clears the SLOTS partial sums of the norm but not the job-wide total behind them -- the owner's apply walk of
@@ -642,12 +699,14 @@ class ShardedKgStepper(_ShardedStepBase):
 
     def __init__(self, Et, rel, norm, batch, kind='adagrad', lr=0.005, eps=1e-10, max_norm=0.0, l1=False, margin=1.0, kg_lambda=1.0,
                  transh=True, regs=7, small_state=None, group=None, capacity_factor=1.25, use_graphs=True, force_exchange=False,
-                 direct=None, overlap_route=True, betas=(0.9, 0.999), opt_step=None, exchange_graph=True):
+                 direct=None, overlap_route=True, betas=(0.9, 0.999), opt_step=None, exchange_graph=True, weight_decay=0.0):
         self.exchange_graph = bool(exchange_graph)
+        self.weight_decay = float(weight_decay)
+        self.lazy = is_lazy(kind, weight_decay)
         if kind not in KINDS:
             raise ValueError('row-sparse steps exist for plain SGD, Adagrad and Adam')
         self.betas = (float(betas[0]), float(betas[1]))
-        self.has_state = kind != 'sgd'
+        self.has_state = kind != 'sgd' or self.lazy
 
         self.tables = [Et]
         self.transh = bool(transh)
@@ -707,9 +766,9 @@ class ShardedKgStepper(_ShardedStepBase):
         self.skipped = i32(1)
         self.small_g = [f32(P, d) for _ in self.small]
         if self.has_state:
-            self.small_state = list(small_state) if small_state is not None else [row_state(s.data, kind) for s in self.small]
-            if not _check_state(Et.state, Et.weight.data, kind):
-                Et.state = row_state(Et.weight.data, kind)
+            self.small_state = list(small_state) if small_state is not None else [row_state(s.data, kind, weight_decay) for s in self.small]
+            if not _check_state(Et.state, Et.weight.data, kind, weight_decay):
+                Et.state = row_state(Et.weight.data, kind, weight_decay)
         else:
             self.small_state = [None] * len(self.small)
         self.opt_step = opt_step if opt_step is not None else torch.zeros(2, dtype=torch.int64, device=dev)      # [step, two floats of bias corrections]
@@ -744,9 +803,9 @@ class ShardedKgStepper(_ShardedStepBase):
         lds = arr(_i64s([Et.weight.data.stride(0)]))
         states = arr(_ptrs([Et.state])) if self.has_state else None
         slds = arr(_i64s([Et.state.stride(0)])) if self.has_state else lds
-        adam = arr(AdamRule(self.betas[0], self.betas[1], adam_replay(self.betas), 0, self.opt_step.data_ptr())) if self.kind == 'adam' else None
+        adam = arr(self._rule()) if self.lazy else None                 # (the lazy rules: Adam, or any kind under weight decay)
         cap = arr(_i64s(self.cap))
-        kind = KINDS[self.kind]
+        kind = KINDS['adam'] if self.lazy else KINDS[self.kind]      # (the C side: 'state rows [m | v | last] + the rule' or a plain form)
         n_small = len(self.small)
         sgp = arr(_ptrs(self.small_g))
         sp0p = arr(_ptrs([s.data for s in self.small]))
@@ -886,7 +945,7 @@ class ShardedKtupJoint(object):
     def build(cls, Ut, It, Et, pref, pref_norm, rel, norm, item2ent, batch, joint_ratio=0.7, margin=1.0, kg_lambda=1.0, kg_batch=None,
               orth=True, **kw):
         rec = ShardedKtupStepper(Ut, It, Et, pref, pref_norm, rel, norm, item2ent, batch=batch, orth=orth, **kw)
-        kw_kg = {k: v for k, v in kw.items() if k not in ('target', 'ent_pad', 'fused_apply', 'opt_step')}
+        kw_kg = {k: v for k, v in kw.items() if k not in ('target', 'ent_pad', 'fused_apply', 'opt_step', 'use_st_gumbel', 'gumbel_seed')}
         kg = ShardedKgStepper(Et, rel, norm, batch=kg_batch or batch, margin=margin, kg_lambda=kg_lambda,
                               small_state=rec.small_state[2:4] if rec.has_state else None, opt_step=rec.opt_step, **kw_kg)
         return cls(rec, kg, joint_ratio)

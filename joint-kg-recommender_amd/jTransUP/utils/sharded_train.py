@@ -10,10 +10,14 @@ checkpointing as the replicated route of utils/fast_train.py).
 
 What the rows' owners do NOT keep is a dense gradient or a dense optimizer pass.  Under Adagrad / plain SGD without weight decay
 (l2_lambda = 0) a row that no batch touches never moves, so updating the touched rows IS the reference's dense step.  Under Adam a dense
-step moves every row that ever had a gradient; the steppers replay the zero-gradient steps a row has missed before the row is read
-again (sharded_ktup.py, include/ktup_hip.h ktup_adam_t), `flush()` does it for all rows before an evaluation or a checkpoint --
-the same tables as torch.optim.Adam over whole tables.  Other settings are refused by name.  Every rank draws the same global batches
-(same -seed, like the replicated route) and takes its slice.
+step moves every row that ever had a gradient, and under weight decay (-l2_lambda, 1e-5 by default: base.py:51) every optimizer moves
+every row at every step (g = l2_lambda * p): the steppers replay the steps a row has missed before the row is read again
+(sharded_ktup.py, include/ktup_hip.h ktup_adam_t: `rule` and `weight_decay`), `flush()` does it for all rows before an evaluation or a
+checkpoint -- the same tables as torch.optim's dense optimizers over whole tables.  (The replay under weight decay is one optimizer step
+per missed step and row: fine where rows come round every few steps -- ml1m --, the wrong tool for tables of millions of rows that a
+batch visits every thousand steps -- there -l2_lambda 0, like the published recipe.)  The ST-Gumbel gate (-use_st_gumbel, the gate of
+transup.sh) draws its noise on the device, every rank from its own Philox stream.  Other settings are refused by name.  Every
+rank draws the same global batches (same -seed, like the replicated route) and takes its slice.
 
 Memory: the shards are the ONLY resident copy of the three big tables.  Once they are built the model's own whole tables are released
 (zero-row placeholders) and so is the dense optimizer's state for them; a rank holds rows/world x (table + optimizer state).
@@ -46,10 +50,8 @@ def check_flags(FLAGS, model):
     if FLAGS.optimizer_type not in ('Adagrad', 'SGD', 'Adam') or (FLAGS.optimizer_type == 'SGD' and FLAGS.momentum != 0):
         raise L.KtupError('-shard_tables updates only the rows a batch touches: exact for -optimizer_type Adagrad, SGD with -momentum 0, '
                           'or Adam (whose untouched steps are replayed when a row is touched again)')
-    if FLAGS.l2_lambda != 0:
-        raise L.KtupError('-shard_tables needs -l2_lambda 0 (weight decay moves every row of every table on every step)')
-    if FLAGS.use_st_gumbel:
-        raise L.KtupError('-shard_tables has no ST-Gumbel step yet (-nouse_st_gumbel)')
+    if FLAGS.l2_lambda < 0:
+        raise L.KtupError('-l2_lambda must not be negative')
     d, P = model.embedding_size, model.rel_total
     if not L.load().ktup_train_step_supported(0, d, P) or not L.load().ktup_train_step_supported(1, d, P):
         raise L.KtupError('-shard_tables: no fused step kernels for -embedding_size %d with %d preferences' % (d, P))
@@ -98,6 +100,9 @@ class ShardedJointDriver(object):
             self.tables.append(t)
         self.small = [getattr(model, name).weight for name in SMALL]
         self.kind = FLAGS.optimizer_type.lower()
+        self.weight_decay = float(getattr(FLAGS, 'l2_lambda', 0.0) or 0.0)
+        from jTransUP.sharded_ktup import is_lazy
+        self.lazy = is_lazy(self.kind, self.weight_decay)          # state rows [m | v | last] + catch-up of the untouched steps
         self._lr = None
         self._build(float(trainer.learning_rate))
         self.acc = {'rec': 0.0, 'kg': 0.0}
@@ -114,11 +119,16 @@ class ShardedJointDriver(object):
         self._wrap_trainer()
         resume = getattr(FLAGS, 'load_experiment_name', None)
         if resume:
-            path = resume if os.path.isabs(resume) else os.path.join(FLAGS.log_path, resume)
+            # as given first -- what ModelTrainer does with the same flag (trainer.py:52) --, then under -log_path
+            path = resume if (os.path.isabs(resume) or os.path.isfile(self.shard_file(resume)) or os.path.isfile(resume)) \
+                else os.path.join(FLAGS.log_path, resume)
             if os.path.isfile(self.shard_file(path)):
                 self.load_shards(path)
                 if logger is not None:
                     logger.info('Restored rank %d\'s shard (rows, optimizer state, step counter) from %s.' % (self.rank, self.shard_file(path)))
+            elif getattr(FLAGS, 'eval_only_mode', False) and not os.path.isfile(path) and not os.path.isfile(resume):
+                raise L.KtupError('-eval_only_mode -load_experiment_name %s: neither that file nor %s exists -- randomly initialised tables would '
+                                  'be evaluated' % (resume, self.shard_file(path)))
 
     def _build(self, lr):
         F = self.FLAGS
@@ -127,7 +137,9 @@ class ShardedJointDriver(object):
                                             eps=1e-8 if self.kind == 'adam' else 1e-10,       # torch.optim's defaults (utils/trainer.py:63-77 passes none)
                                             l1=bool(F.L1_flag), target=float(self.trainer.model_target), orth=True,
                                             ent_pad=self.m.ent_total - 1, group=self.group,
-                                            capacity_factor=float(getattr(F, 'shard_capacity_factor', 1.25)))
+                                            capacity_factor=float(getattr(F, 'shard_capacity_factor', 1.25)),
+                                            weight_decay=self.weight_decay, use_st_gumbel=bool(getattr(F, 'use_st_gumbel', False)),
+                                            gumbel_seed=int(getattr(F, 'seed', 0) or 0))
         self._lr = lr
         self._base = {'rec': torch.zeros(2), 'kg': torch.zeros(4)}
 
@@ -229,7 +241,9 @@ class ShardedJointDriver(object):
                 self.begin_eval()
             Uq = self.rows_everywhere(Ut, u_ids)
             q = torch.arange(u_ids.numel(), dtype=torch.int64, device=self.dev)
-            return ops.eval_ktup(Uq, It.weight.data, self._item_ent, P, Pn, R, Rn, local_map, q, m.L1_flag, ops.GUMBEL_OFF, None, 0, 0)
+            # (-use_st_gumbel: the reference draws noise in evaluate too, transUP.py:92 -- here from the model's own Philox stream)
+            mode, uni, seed, off = m._gumbel.mode_and_stream(m.use_st_gumbel, None, u_ids.numel() * n_my * P.shape[0])
+            return ops.eval_ktup(Uq, It.weight.data, self._item_ent, P, Pn, R, Rn, local_map, q, m.L1_flag, mode, uni, seed, off)
         return It.total_rows, f, ('lattice', self.rank, self.world)
 
     def kg_shard(self, head):
@@ -291,14 +305,15 @@ class ShardedJointDriver(object):
         opt, d = getattr(self.trainer, 'optimizer', None), self.tables[0].d
         if not keys or opt is None:
             return
-        step = float(self.joint.rec.opt_step[0].item()) if self.kind == 'adam' else float(self.trainer.step)
+        step = float(self.joint.rec.opt_step[0].item()) if self.lazy else float(self.trainer.step)
+        block = {'adam': (0, 1), 'adagrad': (1,)}.get(self.kind, ())          # which d-wide block of a lazy state row [m | v | last] a key is
         pieces = [(getattr(self.m, n).weight, t.state, t.total_rows, True) for n, t in zip(BIG, self.tables)] + \
                  [(p, s, p.shape[0], False) for p, s in zip(self.small, self.joint.rec.small_state)]
         for p, st, rows, big in pieces:
             entry = opt.state[p]
             entry['step'] = torch.tensor(step)
             for k, key in enumerate(keys):
-                part = st[:, k * d:(k + 1) * d].contiguous() if self.kind == 'adam' else st
+                part = st[:, block[k] * d:(block[k] + 1) * d].contiguous() if self.lazy else st
                 full = torch.empty(rows, d, dtype=torch.float32, device=self.dev)
                 entry[key] = gather_table(full, part, rows, self.world, self.group) if big else full.copy_(part)
 
@@ -312,6 +327,7 @@ class ShardedJointDriver(object):
         pieces = [(getattr(self.m, n).weight, t.state, True) for n, t in zip(BIG, self.tables)] + \
                  [(p, s, False) for p, s in zip(self.small, self.joint.rec.small_state)]
         step = 0
+        block = {'adam': (0, 1), 'adagrad': (1,)}.get(self.kind, ())
         for p, st, big in pieces:
             entry = opt.state.get(p) or {}
             if not keys or any(key not in entry or entry[key].shape != p.shape for key in keys):
@@ -320,13 +336,13 @@ class ShardedJointDriver(object):
             for k, key in enumerate(keys):
                 src = entry[key].to(self.dev)
                 src = src[self.rank::self.world] if big else src
-                if self.kind == 'adam':
-                    st[:, k * d:(k + 1) * d] = src
+                if self.lazy:
+                    st[:, block[k] * d:(block[k] + 1) * d] = src
                 else:
                     st.copy_(src)
-            if self.kind == 'adam' and step > 0:         # every row is as the dense optimizer left it at `step`
+            if self.lazy and step > 0:                   # every row is as the dense optimizer left it at `step`
                 st[:, 2 * d] = torch.full((st.shape[0],), step, dtype=torch.int32, device=self.dev).view(torch.float32)
-        if self.kind == 'adam' and step > 0:
+        if self.lazy and step > 0:
             self.joint.rec.opt_step[:1].fill_(step)
 
     @torch.no_grad()
@@ -342,7 +358,10 @@ class ShardedJointDriver(object):
     def save_shards(self, filename):
         j = self.joint
         j.flush()
+        tr = self.trainer
         torch.save({'rank': self.rank, 'world': self.world, 'step': self.trainer.step, 'joint_steps': j.steps, 'lr': self._lr,
+                    'best_step': getattr(tr, 'best_step', 0), 'best_dev_performance': getattr(tr, 'best_dev_performance', 0.0),
+                    'best_performances': getattr(tr, 'best_performances', None),
                     'opt_step': int(j.rec.opt_step[0].item()),
                     'rows': {n: t.weight.data.cpu() for n, t in zip(BIG, self.tables)},
                     'row_state': {n: (None if t.state is None else t.state.cpu()) for n, t in zip(BIG, self.tables)},
@@ -355,6 +374,13 @@ class ShardedJointDriver(object):
         if ck['rank'] != self.rank or ck['world'] != self.world:
             raise L.KtupError('%s was written by rank %d of %d' % (self.shard_file(filename), ck['rank'], ck['world']))
         if ck['lr'] != self._lr:
+            # the run had lowered its learning rate: the trainer follows FIRST (a fresh torch optimizer at that rate, like the run's own
+            # decay), so that _follow_trainer sees no change on the next step and leaves the restored state alone
+            if hasattr(self.trainer, 'optimizer_reset'):
+                self.trainer.optimizer_reset(ck['lr'])
+                self.release_model()                 # (the new dense optimizer holds no state yet; keep it that way for the big tables)
+            else:
+                self.trainer.learning_rate = ck['lr']
             self._build(ck['lr'])
         for n, t in zip(BIG, self.tables):
             t.weight.data.copy_(ck['rows'][n])
@@ -368,6 +394,9 @@ class ShardedJointDriver(object):
         self.joint.rec.opt_step[:1].fill_(int(ck.get('opt_step', 0)))
         self.joint.steps = ck['joint_steps']
         self.trainer.step = ck['step']
+        for key in ('best_step', 'best_dev_performance', 'best_performances'):     # what ModelTrainer.load restores (trainer.py:146-150):
+            if key in ck and hasattr(self.trainer, key):                        # without it the first evaluation of a resumed run
+                setattr(self.trainer, key, ck[key])                            # overwrites the best checkpoint unconditionally
         self._dirty = True
 
     def _wrap_trainer(self):

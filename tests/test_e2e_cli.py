@@ -263,9 +263,34 @@ def test_joint_cli_shard_tables_refuses_what_it_cannot_do(dataset):
     cmd = [sys.executable, os.path.join(PKG, 'run_knowledgable_recommendation.py'), '-data_path', data, '-log_path', logs, '-dataset', 'ml1m',
            '-experiment_name', 'ktup-shard-bad', '-nohas_visualization', '-batch_size', '32', '-embedding_size', '64', '-seed', '3',
            '-training_steps', '5', '-model_type', 'jtransup', '-rec_test_files', 'valid.dat', '-kg_test_files', 'valid.dat',
-           '-noshare_embeddings', '-shard_tables']                       # default -l2_lambda 1e-5: weight decay moves every row
+           '-noshare_embeddings', '-shard_tables', '-optimizer_type', 'Rmsprop']      # no row-sparse form of RMSprop
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
-    assert r.returncode != 0 and '-l2_lambda 0' in (r.stdout + r.stderr)
+    assert r.returncode != 0 and '-optimizer_type Adagrad' in (r.stdout + r.stderr)
+
+
+def test_joint_cli_shard_tables_reference_defaults(dataset):
+    """-shard_tables under the reference's DEFAULT flags (base.py:51: -l2_lambda 1e-5; base.py:32: soft gate; -optimizer_type Adagrad):
+    weight decay by replay of the steps a row was not touched for, against the replicated route's dense optimizer on the same batches:
+    same losses, same metrics.  Then with -use_st_gumbel (transup.sh:1's gate; its noise comes from a different stream than the replicated
+    route's, so no comparison): the run trains and evaluates (noise in the evaluation too, transUP.py:92)."""
+    common = ['-model_type', 'jtransup', '-rec_test_files', 'valid.dat', '-kg_test_files', 'valid.dat', '-joint_ratio', '0.7',
+              '-noshare_embeddings', '-nodevice_sampling', '-embedding_size', '64', '-training_steps', '45', '-kg_lambda', '0.5']
+    dense, _ = run_cli('run_knowledgable_recommendation.py', dataset, 'ktup-wd-dense', common)
+    shard, logs = run_cli('run_knowledgable_recommendation.py', dataset, 'ktup-wd-shard', common + ['-shard_tables'])
+    assert '"l2_lambda": 1e-05' in shard and 'Row-sharded training step enabled' in shard
+    la, lb = _loss_lines(dense), _loss_lines(shard)
+    assert len(la) >= 4 and len(la) == len(lb)
+    for (ra, ka), (rb, kb) in zip(la[1:], lb[1:]):
+        assert abs(ra - rb) <= 2e-3 * max(1.0, abs(ra)) and abs(ka - kb) <= 2e-3 * max(1.0, abs(ka)), (la, lb)
+    ma, mb = _metric_rows(dense), _metric_rows(shard)
+    assert len(ma) >= 4 and len(ma) == len(mb) and ma[0] == mb[0]
+    assert all(abs(x - y) <= 0.03 for a, b in zip(ma, mb) for x, y in zip(a, b)), (ma, mb)
+    ck = torch.load(os.path.join(logs, 'ktup-wd-shard.ckpt.shard0of1'), map_location='cpu', weights_only=False)
+    assert ck['row_state']['user_embeddings'].shape[1] == 2 * 64 + 4 and ck['opt_step'] == ck['step'] >= 10      # lazy state rows, flushed
+    hard, _ = run_cli('run_knowledgable_recommendation.py', dataset, 'ktup-gumbel-shard', common + ['-shard_tables', '-use_st_gumbel'])
+    assert '"use_st_gumbel": true' in hard
+    losses = _loss_lines(hard)
+    assert len(losses) >= 4 and all(a == a and b == b and a < 1e3 and b < 1e4 for a, b in losses) and len(_metric_rows(hard)) >= 4
 
 
 @pytest.mark.parametrize('opt,lr,port', [('Adagrad', '0.05', '29551'), ('Adam', '0.005', '29553')])

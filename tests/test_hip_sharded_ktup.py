@@ -29,19 +29,22 @@ def _world_tables(nu, ni, ne, P, d, seed, pad_every=0):
     return full, small, i2e, gen
 
 
-def _dense_reference(full, small0, i2e, batches, kind, lr, eps, max_norm, l1=False, orth=False):
+def _dense_reference(full, small0, i2e, batches, kind, lr, eps, max_norm, l1=False, orth=False, weight_decay=0.0, uniforms=None):
     """One process, whole tables, the global batch: returns the tables after the steps and the per-step losses."""
     ne = full['E'].shape[0]
     E_pad = torch.cat([full['E'], torch.zeros(1, full['E'].shape[1])])           # pad row = ent_total - 1 (jTransUP.py:46,96)
     W = [torch.nn.Parameter(full['U'].clone()), torch.nn.Parameter(full['I'].clone()), torch.nn.Parameter(E_pad)] + \
         [torch.nn.Parameter(t.clone()) for t in small0]
     i2e_pad = torch.where(i2e < 0, torch.full_like(i2e, ne), i2e)
-    opt = torch.optim.Adagrad(W, lr=lr, eps=eps) if kind == 'adagrad' else torch.optim.Adam(W, lr=lr, eps=eps) if kind == 'adam' else torch.optim.SGD(W, lr=lr)
+    wd = weight_decay
+    opt = torch.optim.Adagrad(W, lr=lr, eps=eps, weight_decay=wd) if kind == 'adagrad' else \
+        torch.optim.Adam(W, lr=lr, eps=eps, weight_decay=wd) if kind == 'adam' else torch.optim.SGD(W, lr=lr, weight_decay=wd)
     losses = []
-    for step in batches:
+    for k_step, step in enumerate(batches):
         opt.zero_grad(set_to_none=False)      # zero-FILL, like the torch 0.3 of the reference: Adam keeps moving every table it has ever stepped
         u = torch.cat([x[0] for x in step]); pi = torch.cat([x[1] for x in step]); ni_ = torch.cat([x[2] for x in step])
-        pos = O.score_ktup_rec(*W, i2e_pad, u, pi, l1); neg = O.score_ktup_rec(*W, i2e_pad, u, ni_, l1)
+        un = (None, None) if uniforms is None else uniforms[k_step]        # (pos, neg): one row of n_pref uniforms per pair, as transUP.py:159-162 draws them
+        pos = O.score_ktup_rec(*W, i2e_pad, u, pi, l1, un[0]); neg = O.score_ktup_rec(*W, i2e_pad, u, ni_, l1, un[1])
         loss = torch.nn.functional.softplus(pos - neg).mean()
         if orth:
             loss = loss + O.orthogonal_loss(W[3], W[4])
@@ -54,7 +57,7 @@ def _dense_reference(full, small0, i2e, batches, kind, lr, eps, max_norm, l1=Fal
     return [w.data for w in W], losses
 
 
-def _run_stepper(full, small0, i2e, batches, kind, lr, eps, max_norm, rank, world, dev, l1=False, orth=False, **kw):
+def _run_stepper(full, small0, i2e, batches, kind, lr, eps, max_norm, rank, world, dev, l1=False, orth=False, uniforms=None, **kw):
     from jTransUP import parallel
     from jTransUP.sharded_ktup import ShardedKtupStepper
     d = full['U'].shape[1]
@@ -65,9 +68,11 @@ def _run_stepper(full, small0, i2e, batches, kind, lr, eps, max_norm, rank, worl
     B = batches[0][rank][0].numel()
     st = ShardedKtupStepper(Ut, It, Et, *small, i2e.to(torch.int32).to(dev), batch=B, kind=kind, lr=lr, eps=eps, max_norm=max_norm,
                             l1=l1, orth=orth, **kw)
-    for step in batches:
+    for k_step, step in enumerate(batches):
+        if uniforms is not None:              # this rank's rows of the recorded draws, positives then negatives
+            st.set_gumbel_uniforms(torch.cat([x[rank * B:(rank + 1) * B] for x in uniforms[k_step]]).to(dev))
         st(*(x.to(dev) for x in step[rank]))
-    st.flush()                                # Adam: the rows the last steps did not touch, up to the last step
+    st.flush()                                # the lazy rules (Adam, weight decay): the rows the last steps did not touch, up to the last step
     torch.cuda.synchronize()
     return (Ut, It, Et), small, st
 
@@ -358,3 +363,51 @@ def test_adam_flush_replays_the_untouched_steps(gap):
     torch.testing.assert_close(got_s[:, d:2 * d].double(), v, rtol=5e-5, atol=1e-30)
     want_last = torch.where(last > 0, torch.full_like(last, t), last)
     assert torch.equal(got_s[:, 2 * d].view(torch.int32), want_last)
+
+
+@pytest.mark.parametrize('form', ['one_graph', 'exchange_form'])
+@pytest.mark.parametrize('wd', [1e-5, 1e-2])
+@pytest.mark.parametrize('kind', ['adagrad', 'sgd', 'adam'])
+def test_stepper_weight_decay_equals_the_dense_step(kind, wd, form):
+    """-l2_lambda (utils/trainer.py:63-77: every optimizer is built with weight_decay = l2_lambda; base.py:51: 1e-5 by default): the dense
+    step moves EVERY row at every step by the optimizer's step on g = wd * p.  Row-sparse: a row owes those steps until it is touched
+    (or flushed) and then takes them one by one (ktup_adam_t rule / weight_decay).  Small batches over bigger tables, so that most rows
+    rest for several steps -- and many are never touched at all before the flush; 1e-2 makes the owed steps large against the band."""
+    nu, ni, ne, b, steps, d, P = 500, 260, 400, 64, 7, 100, 20
+    full, small0, i2e, gen = _world_tables(nu, ni, ne, P, d, seed=53, pad_every=7)
+    batches = _batches(gen, 1, steps, nu, ni, b)
+    lr, eps = (0.01, 1e-5) if kind == 'adam' else (0.05, 1e-4) if kind == 'adagrad' else (5.0, 1e-4)
+    Wd, losses = _dense_reference(full, small0, i2e, batches, kind, lr, eps, 0.5, weight_decay=wd)
+    kw = {'one_graph': {}, 'exchange_form': {'force_exchange': True}}[form]
+    tables, small, st = _run_stepper(full, small0, i2e, batches, kind, lr, eps, 0.5, 0, 1, torch.device(DEV), weight_decay=wd, **kw)
+    assert st.lazy and tables[0].state.shape[1] == 2 * d + 4
+    _check(tables, small, Wd, 0, 1)
+    np.testing.assert_allclose(float(st.loss_sum[0]), sum(losses), rtol=1e-4)
+    moved = (Wd[0] - full['U']).abs().max(dim=1).values > 0              # the dense run moved EVERY user row (decay), touched or not
+    assert bool(moved.all())
+
+
+@pytest.mark.parametrize('form', ['one_graph', 'exchange_form'])
+@pytest.mark.parametrize('d', [100, 256])
+def test_stepper_st_gumbel_gate_equals_the_dense_step(d, form):
+    """-use_st_gumbel (transup.sh:1's gate; transUP.py:118-170, jTransUP.py:250-262) in the sharded rec step: the forward takes the
+    one-hot of argmax(logits + Gumbel noise), the backward the softmax's Jacobian.  Parity mode: the uniforms the reference would draw
+    (one (B, n_pref) tensor for the positives, one for the negatives, per step) are recorded and handed to both sides."""
+    nu, ni, ne, b, steps, P = 300, 200, 250, 128, 4, 20
+    full, small0, i2e, gen = _world_tables(nu, ni, ne, P, d, seed=59, pad_every=5)
+    batches = _batches(gen, 1, steps, nu, ni, b)
+    uniforms = [(torch.rand(b, P, generator=gen), torch.rand(b, P, generator=gen)) for _ in range(steps)]
+    Wd, losses = _dense_reference(full, small0, i2e, batches, 'adagrad', 0.05, 1e-4, 0.5, uniforms=uniforms)
+    kw = {'one_graph': {}, 'exchange_form': {'force_exchange': True}}[form]
+    tables, small, st = _run_stepper(full, small0, i2e, batches, 'adagrad', 0.05, 1e-4, 0.5, 0, 1, torch.device(DEV), uniforms=uniforms,
+                                     use_st_gumbel=True, **kw)
+    _check(tables, small, Wd, 0, 1)
+    np.testing.assert_allclose(float(st.loss_sum[0]), sum(losses), rtol=1e-4)
+    # and the production mode: noise from the device-resident Philox stream, which moves by 2 B P draws per step
+    st.set_gumbel_uniforms(None)
+    before = int(st.gstate[1])
+    for step in batches[:3]:
+        st(*(x.to(DEV) for x in step[0]))
+    torch.cuda.synchronize()
+    assert int(st.gstate[1]) - before == 3 * 2 * b * P and st.overflowed_steps() == 0
+    assert all(bool(torch.isfinite(t.weight.data).all()) for t in tables)

@@ -338,8 +338,9 @@ def test_gate_helper_methods_of_the_preference_models():
 
 def test_shard_tables_refuses_what_it_cannot_train_by_flag_name():
     """utils/sharded_train.check_flags: -shard_tables updates only the rows a batch touches, which equals the reference's dense step
-    (knowledgable_recommendation.py:394-403) for Adagrad / plain SGD / Adam (with catch-up) without weight decay only -- everything else is refused before
-    any table is sharded, naming the reference's flag."""
+    (knowledgable_recommendation.py:394-403) for Adagrad / plain SGD / Adam -- with the steps a row was not touched for replayed where the
+    dense step moves untouched rows (Adam; any of them under -l2_lambda > 0) -- everything else is refused before any table is sharded,
+    naming the reference's flag."""
     import types
     from jTransUP.hip import lib as L
     from jTransUP.utils import sharded_train as S
@@ -348,9 +349,11 @@ def test_shard_tables_refuses_what_it_cannot_train_by_flag_name():
     S.check_flags(types.SimpleNamespace(**ok), model)                                  # the supported combination passes
     S.check_flags(types.SimpleNamespace(**dict(ok, optimizer_type='SGD')), model)
     S.check_flags(types.SimpleNamespace(**dict(ok, optimizer_type='Adam')), model)       # ktup.sh's optimizer: row-sparse with catch-up
+    S.check_flags(types.SimpleNamespace(**dict(ok, l2_lambda=1e-5)), model)              # the reference's default weight decay (base.py:51)
+    S.check_flags(types.SimpleNamespace(**dict(ok, use_st_gumbel=True)), model)          # transup.sh's gate
     for change, word in ((dict(model_type='transup'), 'jtransup'), (dict(share_embeddings=True), 'noshare_embeddings'),
                          (dict(optimizer_type='Rmsprop'), 'optimizer_type'), (dict(optimizer_type='SGD', momentum=0.9), 'momentum'),
-                         (dict(l2_lambda=1e-5), 'l2_lambda'), (dict(use_st_gumbel=True), 'st_gumbel')):
+                         (dict(l2_lambda=-1e-5), 'l2_lambda')):
         with pytest.raises(L.KtupError) as e:
             S.check_flags(types.SimpleNamespace(**dict(ok, **change)), model)
         assert word in str(e.value), (change, str(e.value))
@@ -364,9 +367,13 @@ def test_sparse_adam_host_side_layouts():
     the state row [m | v | last], how many missed steps are replayed one by one for the betas in use, and which state a table needs."""
     import ctypes
     import math
-    from jTransUP.sharded_ktup import KINDS, AdamRule, _check_state, adam_replay, adam_state_pitch, row_state
+    from jTransUP.sharded_ktup import KINDS, RULES, AdamRule, _check_state, adam_replay, adam_state_pitch, is_lazy, row_state
     assert KINDS == {'sgd': 0, 'adagrad': 1, 'adam': 2}                                   # KTUP_OPT_SGD / _ADAGRAD / _ADAM
-    assert ctypes.sizeof(AdamRule) == 24 and AdamRule.step.offset == 16 and AdamRule.replay.offset == 8      # {float, float, int32, int32, pointer}
+    assert RULES == {'adam': 0, 'adagrad': 1, 'sgd': 2}                                   # ktup_adam_t.rule
+    # {float, float, int32 replay, int32 rule, pointer, float weight_decay, float}
+    assert ctypes.sizeof(AdamRule) == 32 and AdamRule.step.offset == 16 and AdamRule.replay.offset == 8 and AdamRule.rule.offset == 12
+    assert AdamRule.weight_decay.offset == 24
+    assert is_lazy('adam') and is_lazy('adagrad', 1e-5) and is_lazy('sgd', 1e-5) and not is_lazy('adagrad') and not is_lazy('sgd', 0.0)
     assert adam_state_pitch(256) == 516 and adam_state_pitch(100) % 4 == 0                # rows stay 16-byte aligned
     for betas in ((0.9, 0.999), (0.8, 0.99), (0.95, 0.999)):
         k, r = adam_replay(betas), betas[0] / math.sqrt(betas[1])
@@ -376,3 +383,6 @@ def test_sparse_adam_host_side_layouts():
     assert row_state(w, 'sgd') is None and row_state(w, 'adagrad').shape == (7, 12) and row_state(w, 'adam').shape == (7, 28)
     assert _check_state(None, w, 'sgd') and _check_state(row_state(w, 'adam'), w, 'adam') and not _check_state(row_state(w, 'adagrad'), w, 'adam')
     assert not _check_state(None, w, 'adagrad')                                           # a stepper of another kind re-creates the state
+    # under weight decay every kind keeps the lazy rows [m | v | last] (Adagrad's sum in the v half)
+    assert row_state(w, 'adagrad', 1e-5).shape == (7, 28) and row_state(w, 'sgd', 1e-5).shape == (7, 28)
+    assert _check_state(row_state(w, 'sgd', 1e-5), w, 'sgd', 1e-5) and not _check_state(row_state(w, 'adagrad'), w, 'adagrad', 1e-5)

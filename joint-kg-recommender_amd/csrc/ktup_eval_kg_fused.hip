@@ -415,7 +415,12 @@ __global__ __launch_bounds__(256) void kg_wtab_kernel(FArgs a) {
 }
 
 // ---- the sweep
-template <typename G>
+// KMAX: the most golds per key (in this launch's window of GS) the instantiation carries a stage loop for.  The four-gold loop keeps 16
+// counters and 32 window bounds per lane beside the operands and does not fit the 128 registers a wave has at 16 waves per CU (38-96
+// spilled VGPRs, depending on the width); compiled into the same kernel it sets the register count and the scratch set-up of the loops
+// that DO fit.  The drivers' passes carry one to three golds per key: the host picks KMAX = 3 from the pass's largest gold list
+// (run_fused) and only a pass with longer lists launches the instantiation that holds the four-gold loop.
+template <typename G, int KMAX>
 __global__ __launch_bounds__(NW * 64) void kg_count_mc_kernel(FArgs a) {
   constexpr int NCH = G::NCH, P4 = G::P4, QV = G::QV, GMX = GS;
   // what a lane keeps in registers across the stages (128 VGPRs per wave at 16 waves per CU): the gold scores and the three scalars
@@ -611,8 +616,10 @@ __global__ __launch_bounds__(NW * 64) void kg_count_mc_kernel(FArgs a) {
   };
   if (wg_one) run(std::integral_constant<int, 1>{});
   else if (wg_two) run(std::integral_constant<int, 2>{});
-  else if (wg_three) run(std::integral_constant<int, 3>{});
-  else run(std::integral_constant<int, GMX>{});
+  else if (KMAX <= 3 || wg_three) run(std::integral_constant<int, 3>{});
+  else {
+    if constexpr (KMAX > 3) run(std::integral_constant<int, GMX>{});
+  }
   if (a.ktol) {
     __syncthreads();
     if (tid == 0) a.unc_count[seg] = unc_n < a.unc_cap ? unc_n : a.unc_cap;
@@ -766,10 +773,15 @@ int run_fused(FArgs a, int64_t n_gold, int64_t max_golds, hipStream_t st, const 
   a.gscore_out = const_cast<float*>(a.gscore);
   hipLaunchKernelGGL((kg_list_scores_kernel<G>), dim3(qblocks), dim3(256), G::LDS, st, a);
   a.tiles_per_band = (int)((ntiles + NBAND - 1) / NBAND);
-  (void)hipFuncSetAttribute((const void*)kg_count_mc_kernel<G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS);
-  for (a.gbase = 0; a.gbase < max_golds; a.gbase += GS)     // typical link-prediction keys have one to three golds: one launch; the
-    hipLaunchKernelGGL((kg_count_mc_kernel<G>), dim3(NBAND, qblocks), dim3(NW * 64), G::LDS, st, a);   // workgroups of a later one whose
-  a.gbase = 0;                                                                                          // keys have no such golds exit
+  (void)hipFuncSetAttribute((const void*)kg_count_mc_kernel<G, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS);
+  (void)hipFuncSetAttribute((const void*)kg_count_mc_kernel<G, GS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS);
+  for (a.gbase = 0; a.gbase < max_golds; a.gbase += GS) {   // typical link-prediction keys have one to three golds: one launch; the
+    if (max_golds - a.gbase <= 3)                           // workgroups of a later one whose keys have no such golds exit
+      hipLaunchKernelGGL((kg_count_mc_kernel<G, 3>), dim3(NBAND, qblocks), dim3(NW * 64), G::LDS, st, a);
+    else
+      hipLaunchKernelGGL((kg_count_mc_kernel<G, GS>), dim3(NBAND, qblocks), dim3(NW * 64), G::LDS, st, a);
+  }
+  a.gbase = 0;
   hipLaunchKernelGGL(kg_rank_finalize_kernel, dim3(fin_blocks(a.nq)), dim3(256), 0, st, a, n_gold);
   if (a.ktol) hipLaunchKernelGGL(kg_unc_resolve_kernel, dim3(grid_for(a.unc_nseg, 4096)), dim3(256), 0, st, a);
   return check_launch(name);

@@ -226,7 +226,9 @@ def test_ml1m_shape_vs_oracle_fwd_bwd(d, npref):
                 wg = Wc[k].grad.clone()
                 if k == 'E':
                     wg[-1].zero_()
-                close(Wd[k].grad, wg, rtol=2e-4, atol=1e-4)
+                # north_star's 1e-4, with the floor of test_tup_golden: a table gradient is an fp32 sum over the batch, whose rounding
+                # scales with the gradient's size (2e-6 of its largest element ~ sqrt(n) ulp of the summands), not with each element
+                close(Wd[k].grad, wg, rtol=RT, atol=max(GAT, 2e-6 * float(wg.abs().max())))
             # TUP on the same tables
             Wc = {k: v.clone().requires_grad_(True) for k, v in W.items()}
             Wd = {k: v.to(DEV).requires_grad_(True) for k, v in W.items()}
@@ -236,7 +238,7 @@ def test_ml1m_shape_vs_oracle_fwd_bwd(d, npref):
             close(got, want)
             want.backward(gs); got.backward(gs.to(DEV))
             for k in ('U', 'I', 'P', 'Pn'):
-                close(Wd[k].grad, Wc[k].grad, rtol=2e-4, atol=1e-4)
+                close(Wd[k].grad, Wc[k].grad, rtol=RT, atol=max(GAT, 2e-6 * float(Wc[k].grad.abs().max())))
 
 
 def test_philox_gate_is_deterministic_and_one_hot():

@@ -349,3 +349,56 @@ def test_shard_files_restore_a_run_exactly(tmp_path, opt):
     for sa, sc in zip(d1.joint.rec.small_state, d3.joint.rec.small_state):
         torch.testing.assert_close(sa[:, :nd], sc[:, :nd], rtol=1e-4 if opt == 'Adam' else 1e-5, atol=1e-7)
     assert float(d3.tables[0].state.abs().sum()) > 0                       # the sums really travelled
+
+
+def test_shard_files_restore_after_a_learning_rate_decay(tmp_path):
+    """A run that has LOWERED its learning rate (utils/trainer.py:107-110: a fresh optimizer at the new rate), stepped on, written its shard
+    file and is continued in a fresh driver: the restored trainer must carry the lowered rate, or the driver's first step would see a
+    "change" of rate, throw the restored sums away and go on at the original rate (round 5's advisor finding).  Also restored: best_step /
+    best_dev_performance, without which a resumed run's first evaluation overwrites the best checkpoint unconditionally."""
+    import logging
+    import types
+    from jTransUP.models import jTransUP as jt
+    from jTransUP.utils.sharded_train import ShardedJointDriver
+    nu, ni, ne, P, d, b = 120, 90, 150, 6, 64, 64
+    dev = torch.device(DEV)
+    gen = torch.Generator().manual_seed(73)
+    i_map = {i: i for i in range(ni)}
+    new_map = {i: ((i * 7) % ne if i % 5 else -1, i) for i in range(ni)}
+    FL = types.SimpleNamespace(model_type='jtransup', share_embeddings=False, optimizer_type='Adagrad', momentum=0.9, l2_lambda=0.0,
+                               use_st_gumbel=False, joint_ratio=0.7, margin=1.0, kg_lambda=0.5, clipping_max_value=0.5, L1_flag=False)
+    sched = _joint_schedule(gen, 1, 13, nu, ni, ne, P, b, 0.7)
+
+    def fresh():
+        torch.manual_seed(5)
+        m = jt.jTransUPModel(False, d, nu, ni, ne, P, i_map, new_map, False, False)
+        tr = types.SimpleNamespace(step=0, learning_rate=0.05, model_target=-1, save=lambda filename: None, best_step=0,
+                                   best_dev_performance=0.0, best_performances=None)
+        tr.optimizer_reset = lambda lr: setattr(tr, 'learning_rate', lr)
+        return m, tr, ShardedJointDriver(m, tr, FL, b, logging.getLogger('shards'))
+
+    def run(drv, steps):
+        for what, per in steps:
+            ids = [x.to(dev) for x in per[0]]
+            drv.rec_step(*ids) if what == 'rec' else drv.kg_step(*ids)
+    m1, tr1, d1 = fresh()
+    run(d1, sched[:5])
+    tr1.optimizer_reset(0.025)                                             # ModelTrainer.new_performance: no improvement for an epoch
+    tr1.best_step, tr1.best_dev_performance, tr1.best_performances = 3, 0.123, [(0.123, 0.1)]
+    run(d1, sched[5:9])
+    path = str(tmp_path / 'decayed.ckpt')
+    d1.save_shards(path)
+    run(d1, sched[9:])                                                     # the run that never stopped
+    d1.sync_model()
+    m2, tr2, d2 = fresh()                                                  # a fresh process: -learning_rate as on the command line
+    d2.load_shards(path)
+    assert tr2.learning_rate == 0.025 and d2._lr == 0.025 and tr2.step == 9
+    assert (tr2.best_step, tr2.best_dev_performance, tr2.best_performances) == (3, 0.123, [(0.123, 0.1)])
+    sums = d2.tables[2].state.clone()                                      # the entity shard: rec and kg steps both touch it
+    assert float(sums.abs().sum()) > 0 and float(d2.tables[0].state.abs().sum()) > 0
+    run(d2, sched[9:10])
+    assert d2._lr == 0.025 and bool((d2.tables[2].state >= sums).all()) and float((d2.tables[2].state - sums).abs().sum()) > 0   # grown, not reset
+    run(d2, sched[10:])
+    d2.sync_model()
+    for (k, a), (_, c) in zip(m1.state_dict().items(), m2.state_dict().items()):
+        torch.testing.assert_close(a, c, rtol=1e-5, atol=1e-6, msg=k)

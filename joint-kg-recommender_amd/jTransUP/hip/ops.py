@@ -49,6 +49,18 @@ def _stream(dev):
     return torch.cuda.current_stream(dev).cuda_stream
 
 
+def _zeros_like_many(*tables):
+    """Zero-filled gradient buffers for several tables out of ONE allocation and ONE fill launch (a backward through autograd is bound
+    by the host: ~8 us per torch call); every part starts on a 16-byte boundary."""
+    sizes = [(t.numel() + 3) & ~3 for t in tables]
+    flat = torch.zeros(sum(sizes), dtype=torch.float32, device=tables[0].device)
+    out, at = [], 0
+    for t, sz in zip(tables, sizes):
+        out.append(flat[at:at + t.numel()].view(t.shape))
+        at += sz
+    return out
+
+
 def _vec(t, n):
     t = t.contiguous()
     if t.dtype != torch.float32 or t.numel() != n:
@@ -71,7 +83,7 @@ class _ScoreBprmf(Function):
     def backward(ctx, gs):
         U, I, u, i = ctx.saved_tensors
         gs = _vec(gs, u.numel())
-        gU, gI = torch.zeros_like(U), torch.zeros_like(I)
+        gU, gI = _zeros_like_many(U, I)
         bws = _seg_ws(L.load().ktup_score_bprmf_bwd_workspace_bytes(u.numel(), U.shape[1], U.shape[0], I.shape[0]), U.device)
         L.call('ktup_score_bprmf_bwd_ws', _p(U), U.stride(0), _p(I), I.stride(0), U.shape[1], _p(u), _p(i), u.numel(), _p(gs),
                _p(gU), _p(gI), U.shape[0], I.shape[0], _p(bws), _stream(U.device))
@@ -99,7 +111,7 @@ class _ScoreTransE(Function):
     def backward(ctx, gs):
         E, R, h, t, r = ctx.saved_tensors
         gs = _vec(gs, h.numel())
-        gE, gR = torch.zeros_like(E), torch.zeros_like(R)
+        gE, gR = _zeros_like_many(E, R)
         bws = _seg_ws(L.load().ktup_score_kg_bwd_workspace_bytes(h.numel(), E.shape[1], E.shape[0]), E.device)
         L.call('ktup_score_transe_bwd_ws', _p(E), E.stride(0), _p(R), R.stride(0), E.shape[1], _p(h), _p(t), _p(r), h.numel(),
                ctx.l1, _p(gs), _p(gE), _p(gR), E.shape[0], R.shape[0], _p(bws), _stream(E.device))
@@ -121,7 +133,7 @@ class _ScoreTransH(Function):
     def backward(ctx, gs):
         E, R, N, h, t, r = ctx.saved_tensors
         gs = _vec(gs, h.numel())
-        gE, gR, gN = torch.zeros_like(E), torch.zeros_like(R), torch.zeros_like(N)
+        gE, gR, gN = _zeros_like_many(E, R, N)
         bws = _seg_ws(L.load().ktup_score_kg_bwd_workspace_bytes(h.numel(), E.shape[1], E.shape[0]), E.device)
         L.call('ktup_score_transh_bwd_ws', _p(E), E.stride(0), _p(R), R.stride(0), _p(N), N.stride(0), E.shape[1], _p(h), _p(t),
                _p(r), h.numel(), ctx.l1, _p(gs), _p(gE), _p(gR), _p(gN), E.shape[0], min(R.shape[0], N.shape[0]), _p(bws),
@@ -147,7 +159,7 @@ class _ScoreTransR(Function):
     def backward(ctx, gs):
         E, R, M, h, t, r = ctx.saved_tensors
         gs = _vec(gs, h.numel())
-        gE, gR, gM = torch.zeros_like(E), torch.zeros_like(R), torch.zeros_like(M)
+        gE, gR, gM = _zeros_like_many(E, R, M)
         n, n_rel = h.numel(), min(R.shape[0], M.shape[0])
         ws = _seg_ws(L.load().ktup_score_transr_bwd_workspace_bytes(n, E.shape[1], E.shape[0], n_rel), E.device)
         L.call('ktup_score_transr_bwd_ws', _p(E), E.stride(0), _p(R), R.stride(0), _p(M), M.stride(0), E.shape[1], _p(h), _p(t),
@@ -259,9 +271,16 @@ class _ScorePref(Function):
         l1, gumbel_mode, seed, offset, ent_pad = ctx.cfg
         n = u.numel(); P, d = pref.shape; dev = U.device
         gs = _vec(gs, n)
-        gU, gI = torch.zeros_like(U), torch.zeros_like(I)
-        gA = torch.zeros(P, d, dtype=torch.float32, device=dev)
-        gC = torch.zeros(P, d, dtype=torch.float32, device=dev)
+        # every gradient of the call out of ONE zero-filled buffer (one allocation and one fill launch instead of five: the step through
+        # autograd is bound by the host, ~8 us per torch call; every part starts on a 16-byte boundary)
+        shapes = [tuple(U.shape), tuple(I.shape), (P, d), (P, d)] + ([tuple(E.shape)] if E is not None else [])
+        sizes = [(a * b + 3) & ~3 for a, b in shapes]
+        flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+        parts, at = [], 0
+        for (a, b), sz in zip(shapes, sizes):
+            parts.append(flat[at:at + a * b].view(a, b))
+            at += sz
+        gU, gI, gA, gC = parts[:4]
         # large batches: per-pair row gradients + reduction by sorted segments instead of float atomics (the library decides:
         # 0 bytes = the atomics path)
         nbytes = L.load().ktup_score_pref_bwd_workspace_bytes(n, d, U.shape[0], I.shape[0])
@@ -270,7 +289,7 @@ class _ScorePref(Function):
             L.call('ktup_score_tup_bwd_ws', _p(U), U.stride(0), _p(I), I.stride(0), _p(ws), P, d, _p(u), _p(i), n, l1, gumbel_mode,
                    _p(uniform), seed, offset, _p(gs), _p(gU), _p(gI), _p(gA), _p(gC), U.shape[0], I.shape[0], _p(bws), _stream(dev))
             return gU, gI, None, gA, gC, None, None, None, None, None, None, None, None, None, None, None, None
-        gE = torch.zeros_like(E)
+        gE = parts[4]
         L.call('ktup_score_ktup_bwd_ws', _p(U), U.stride(0), _p(I), I.stride(0), _p(E), E.stride(0), _p(item2ent), ent_pad, _p(ws), P,
                d, _p(u), _p(i), n, l1, gumbel_mode, _p(uniform), seed, offset, _p(gs), _p(gU), _p(gI), _p(gE), _p(gA), _p(gC),
                U.shape[0], I.shape[0], _p(bws), _stream(dev))
@@ -366,7 +385,7 @@ class _OrthLoss(Function):
     @staticmethod
     def backward(ctx, gloss):
         R, N, ids = ctx.saved_tensors
-        gR, gN = torch.zeros_like(R), torch.zeros_like(N)
+        gR, gN = _zeros_like_many(R, N)
         gloss = gloss.contiguous().float()
         L.call('ktup_reg_orth_bwd', _p(R), R.stride(0), _p(N), N.stride(0), R.shape[1], _p(ids), ctx.n, _p(gloss), _p(gR), _p(gN),
                _stream(R.device))

@@ -1,0 +1,66 @@
+"""Where the host time of the autograd-facing training step goes (bench.py train_step_b512's `fused` mode: jTransUPModel.forward x 2,
+loss, backward through the custom Functions, K20): cProfile over 300 steps, top functions by own time.
+    python tools/step_profile.py [torch|fused]"""
+import cProfile
+import os
+import pstats
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'joint-kg-recommender_amd'))
+import torch
+import torch.nn.functional as F
+
+import bench
+from jTransUP.models import jTransUP as jt
+from jTransUP.utils.fused_optim import FusedOptimizer
+
+mode = sys.argv[1] if len(sys.argv) > 1 else 'fused'
+device = torch.device('cuda', 0)
+NU, NI, NE, NR, D, ALIGNED = bench.NU, bench.NI, bench.NE, bench.NR, bench.D, bench.ALIGNED
+B, steps = 512, 300
+gen = torch.Generator().manual_seed(5)
+mk = lambda hi: torch.randint(0, hi, (steps + 20, B), generator=gen).to(device)
+u, pi, ni_, h, t, nh, nt, r = mk(NU), mk(NI), mk(NI), mk(NE), mk(NE), mk(NE), mk(NE), mk(NR)
+torch.manual_seed(3)
+i_map = {i: i for i in range(NI)}
+new_map = {i: ((i * 4) % NE if i < ALIGNED else -1, i) for i in range(NI)}
+m = jt.jTransUPModel(False, D, NU, NI, NE, NR, i_map, new_map, False, False)
+opt = torch.optim.Adagrad(m.parameters(), lr=0.005, weight_decay=1e-5)
+fused = FusedOptimizer(opt) if mode == 'fused' else None
+params = list(m.parameters())
+
+
+def step(s):
+    opt.zero_grad(set_to_none=False)
+    if s % 10 < 7:
+        pos = m((u[s], pi[s]), None, is_rec=True); neg = m((u[s], ni_[s]), None, is_rec=True)
+        loss = (-F.logsigmoid(-(pos - neg))).mean()
+    else:
+        pos = m(None, (h[s], t[s], r[s]), is_rec=False); neg = m(None, (nh[s], nt[s], r[s]), is_rec=False)
+        loss = torch.sum(torch.clamp(pos - neg + 1.0, min=0.0))
+    loss.backward()
+    if fused is not None:
+        fused.clip_and_step(5.0)
+    else:
+        torch.nn.utils.clip_grad_norm_(params, 5.0)
+        opt.step()
+
+
+for s in range(20):
+    step(s)
+torch.cuda.synchronize()
+import time
+t0 = time.perf_counter()
+for s in range(20, 20 + steps):
+    step(s)
+torch.cuda.synchronize()
+print('STEP %s: %.3f ms per step (wall, unprofiled)' % (mode, 1e3 * (time.perf_counter() - t0) / steps))
+pr = cProfile.Profile()
+pr.enable()
+for s in range(20, 20 + steps):
+    step(s)
+torch.cuda.synchronize()
+pr.disable()
+st = pstats.Stats(pr)
+st.sort_stats('tottime').print_stats(28)

@@ -684,6 +684,14 @@ int ktup_train_rec_step_rows(const float* U, int64_t ldu, const float* I, int64_
                              float* GU, float* GV, float* gP, float* gPn, float* gR, float* gRn, double* sumsq, int n_slots,
                              const int64_t* neg_ids, const int64_t* cursor, int64_t n_batches, int gumbel_mode, const void* gumbel,
                              void* stream);
+/* TUP's row regularisers (item_recommendation.py:177-180: normLoss(user rows of the batch) + normLoss(item rows of [pos ; neg]) +
+ * normLoss(pref); normLoss(x) = sum_rows max(|x|^2 - 1, 0), utils/loss.py:21-23) for a step with STORED row gradients: after
+ * ktup_train_rec_step_rows and before the reduction, row k of GU (example k's user, id u_ids[k]) and row k of GV (pair k's item, id i_ids[k],
+ * k < 2B) take 2 scale_rows x for rows with |x|^2 > 1, gP likewise with scale_pref for the n_pref rows of `pref` (contiguous, pitch d);
+ * loss[0] += scale_rows x (the two row terms), loss[1] += scale_pref x normLoss(pref).  GU / GV: pitch d.                            */
+int ktup_train_rec_reg_rows(const float* U, int64_t ldu, const float* I, int64_t ldi, int d, const int64_t* u_ids, const int64_t* i_ids,
+                            int64_t B, float* GU, float* GV, const float* pref, int n_pref, float* gP, float scale_rows, float scale_pref,
+                            float* loss, void* stream);
 int ktup_train_kg_step(int transh, const float* E, int64_t lde, const float* R, int64_t ldr, const float* Nrm, int64_t ldn,
                        int d, const int64_t* h, const int64_t* t, const int64_t* r, int64_t B, int l1, float margin,
                        float gscale, int regs, float* loss, float* gE, float* gR, float* gN, double* gnorm, void* stream);

@@ -173,7 +173,82 @@ int launch_kg(const KgStepArgs& a, hipStream_t st, const char* name) {
 #undef KTUP_KG
 }
 
+// ---- the row regularisers of TUP's rec step (item_recommendation.py:177-180) for a step whose row gradients are STORED per pair
+// (ktup_train_rec_step_rows): normLoss(user rows of the B examples) + normLoss(item rows of the 2B pairs) + normLoss(pref), with
+// normLoss(x) = sum_rows max(|x|^2 - 1, 0) (utils/loss.py:21-23): a row with |x|^2 > 1 adds 2 x to its gradient.  Row k of GU is example
+// k's user, row k of GV pair k's item, so the terms go to the stored rows by plain read-modify-write (a lane group per row), after the step
+// kernel and before the reduction reads them.
+struct RegRowsArgs {
+  const float *U, *I; int64_t ldu, ldi; int nch;
+  const int64_t *u_ids, *i_ids; int64_t B;
+  float *GU, *GV; int64_t ldg;
+  const float* pref; int n_pref; float* gP;
+  float scale_rows, scale_pref;
+  float* loss;                     // [2]: normLoss(user rows) + normLoss(item rows), normLoss(pref)  (accumulated)
+};
+
+template <int GL>
+__global__ __launch_bounds__(256) void reg_rows_kernel(RegRowsArgs a) {
+  constexpr int GPB = 256 / GL;
+  const int lane = threadIdx.x % GL;
+  const bool on = lane < a.nch;
+  float part[2] = {0.f, 0.f};
+  const int64_t total = 3 * a.B + a.n_pref;
+  for (int64_t r = (int64_t)blockIdx.x * GPB + threadIdx.x / GL; r < total; r += (int64_t)gridDim.x * GPB) {
+    const float* src;
+    float* dst;
+    float scale = a.scale_rows;
+    int which = 0;
+    if (r < a.B) { src = a.U + a.u_ids[r] * a.ldu; dst = a.GU + r * a.ldg; }
+    else if (r < 3 * a.B) { const int64_t k = r - a.B; src = a.I + a.i_ids[k] * a.ldi; dst = a.GV + k * a.ldg; }
+    else { const int64_t p = r - 3 * a.B; src = a.pref + p * 4 * a.nch; dst = a.gP + p * 4 * a.nch; scale = a.scale_pref; which = 1; }
+    const float4 x = on ? reinterpret_cast<const float4*>(src)[lane] : f4zero();
+    const float n2 = group_sum<GL>(dot4(x, x));
+    if (n2 > 1.f) {
+      if (on) {
+        float4* g = reinterpret_cast<float4*>(dst) + lane;
+        float4 v = *g;
+        const float c = 2.f * scale;
+        v.x = fmaf(c, x.x, v.x); v.y = fmaf(c, x.y, v.y); v.z = fmaf(c, x.z, v.z); v.w = fmaf(c, x.w, v.w);
+        *g = v;
+      }
+      if (lane == 0) part[which] += scale * (n2 - 1.f);
+    }
+  }
+  __shared__ float red[2][256 / 16];
+  if (lane == 0) { red[0][threadIdx.x / GL] = part[0]; red[1][threadIdx.x / GL] = part[1]; }
+  __syncthreads();
+  if (threadIdx.x < 2) {
+    float t = 0.f;
+    for (int g = 0; g < GPB; ++g) t += red[threadIdx.x][g];
+    if (t != 0.f) atomicAdd(a.loss + threadIdx.x, t);
+  }
+}
+
 }  // namespace
+
+extern "C" int ktup_train_rec_reg_rows(const float* U, int64_t ldu, const float* I, int64_t ldi, int d, const int64_t* u_ids,
+                                       const int64_t* i_ids, int64_t B, float* GU, float* GV, const float* pref, int n_pref, float* gP,
+                                       float scale_rows, float scale_pref, float* loss, void* stream) {
+  const char* name = "ktup_train_rec_reg_rows";
+  KTUP_REQUIRE(B >= 0 && n_pref >= 0, "%s: negative sizes", name);
+  if (B == 0 && n_pref == 0) return KTUP_OK;
+  KTUP_REQUIRE(U && I && u_ids && i_ids && GU && GV && loss && (n_pref == 0 || (pref && gP)), "%s: null pointer argument", name);
+  if (d % 4 || d > 256 || (ldu | ldi) % 4 || !aligned16(U) || !aligned16(I) || !aligned16(GU) || !aligned16(GV) || !aligned16(pref) || !aligned16(gP))
+    return set_error(KTUP_ERR_UNSUPPORTED, "%s: needs d %% 4 == 0 (<= 256) and 16-byte aligned rows", name);
+  RegRowsArgs a{U, I, ldu, ldi, d / 4, u_ids, i_ids, B, GU, GV, (int64_t)d, pref, n_pref, gP, scale_rows, scale_pref, loss};
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t total = 3 * B + n_pref;
+#define KTUP_RR(GL)                                                                                                  \
+  {                                                                                                                  \
+    hipLaunchKernelGGL((reg_rows_kernel<GL>), dim3(grid_for((total + (256 / GL) - 1) / (256 / GL), 2048)), dim3(256), 0, st, a); \
+    return check_launch(name);                                                                                       \
+  }
+  if (a.nch <= 16) KTUP_RR(16)
+  if (a.nch <= 32) KTUP_RR(32)
+  KTUP_RR(64)
+#undef KTUP_RR
+}
 
 // 1 = this (step kind, d, n_pref) has a fused kernel; 0 = keep the multi-launch step.  kind: 0 rec (TUP / KTUP), 1 kg TransH, 2 kg TransE
 extern "C" int ktup_train_step_supported(int kind, int d, int n_pref) {

@@ -130,6 +130,7 @@ SIGNATURES = {
     'ktup_optim_gradnorm_acc': [c_i, c_p, c_p, c_p, c_i, c_p],
     'ktup_train_rec_step_rows': [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_p, c_p, c_l, c_i,
                                  c_f, c_f, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_l, c_i, c_p, c_p],
+    'ktup_train_rec_reg_rows': [c_p, c_l, c_p, c_l, c_i, c_p, c_p, c_l, c_p, c_p, c_p, c_i, c_p, c_f, c_f, c_p, c_p],
     'ktup_negsample_rec_workspace_bytes': [c_l],
     'ktup_negsample_rec': [c_p, c_p, c_l, c_l, c_p, c_l, c_u, c_u, c_i, c_p, c_p, c_p, c_p],
     'ktup_optim_gradnorm': [c_i, c_p, c_p, c_p, c_p],

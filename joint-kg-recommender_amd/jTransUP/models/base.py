@@ -56,7 +56,7 @@ FLAG_TABLE = [
     ('device_sampling', 'bool', True, 'keep training data and negative sampling on the GPU (K19); -nodevice_sampling runs the python samplers'),
     ('shard_eval_candidates', 'bool', False, 'torchrun only: every rank scores its slice of the item / entity catalogue for ALL queries '
                                              '(top-n lists merged, KG rank counts all-reduced) instead of whole batches being dealt to the ranks'),
-    ('shard_tables', 'bool', False, 'jtransup with its own tables: the user / item / entity tables and their Adagrad sums are partitioned by row over '
+    ('shard_tables', 'bool', False, 'transup, or jtransup with its own tables: the user / item (/ entity) tables and their optimizer state are partitioned by row over '
                                     'the ranks (row % world) and a step exchanges only the rows its batch touches (BASELINE config 5; one process: the '
                                     'same row-sparse step without an exchange); needs -optimizer_type Adagrad, Adam or SGD -momentum 0 (-l2_lambda > 0: the steps a row was not '
                                     'touched for are replayed one by one when it is touched again -- fine at ml1m size, use -l2_lambda 0 for tables of millions of rows); '

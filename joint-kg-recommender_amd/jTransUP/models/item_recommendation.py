@@ -30,6 +30,12 @@ def evaluate(FLAGS, model, eval_iter, eval_dict, all_dicts, logger, eval_descend
     from jTransUP.models._shard_eval import rec_shard_fn
     # the whole-pass route prepares its own item side, so that a captured pass (D._rec_eval_fused) recomputes it from the tables
     pass_fn = (lambda u, fo, fi, n: model.evaluate_topk(u, model.prepare_items(), n, fo, fi)) if hasattr(model, 'evaluate_topk') else None
+    native = getattr(model, '_shard_native', None)             # -shard_tables: the candidates are the item rows this rank owns
+    if native is not None and not is_report:
+        results = D.rec_eval_pass(FLAGS, None, eval_iter, eval_dict, all_dicts, eval_descending, want_rows=False, shard=native.rec_shard())
+        perf = D.summarize_rec(FLAGS, results, logger)
+        model.enable_grad()
+        return perf
     results = D.rec_eval_pass(FLAGS, score_fn, eval_iter, eval_dict, all_dicts, eval_descending, want_rows=is_report,
                               shard=rec_shard_fn(model), pass_fn=pass_fn, graph_key=D.model_graph_key(model) if pass_fn else None)
     perf = D.summarize_rec(FLAGS, results, logger)
@@ -45,7 +51,22 @@ def train_loop(FLAGS, model, trainer, train_dataset, eval_datasets, user_total, 
     # TUP / BPRMF: the step body below as a handful of C-ABI launches (utils/fast_train.py RecStepper), optionally with the
     # training data and the negative sampling on the device (-device_sampling)
     stepper = feed = sampler = None
-    if D.USE_CUDA and FLAGS.model_type in ('transup', 'bprmf') and trainer.fused is not None \
+    sharded = bool(getattr(FLAGS, 'shard_tables', False))
+    if sharded:
+        # config 3 at scale: TUP's user / item tables row-sharded over the ranks, fixed-shape exchange, row-sparse optimizer on the touched
+        # rows (utils/sharded_train.py; the stepper is sharded_ktup.ShardedKtupStepper without an entity table)
+        from jTransUP.utils.sharded_train import ShardedJointDriver
+        stepper = ShardedJointDriver(model, trainer, FLAGS, FLAGS.batch_size, logger)
+        logger.info('Row-sharded training step enabled (-shard_tables): rank %d of %d owns rows r %% %d == %d of the user / item tables.'
+                    % (stepper.rank, stepper.world, stepper.world, stepper.rank))
+        if FLAGS.device_sampling:
+            from jTransUP.utils.device_sampler import DeviceSampler
+            from jTransUP.utils.fast_train import DeviceFeeder
+            sampler = DeviceSampler(D.DEV, seed=FLAGS.seed)
+            sampler.set_rating_dicts(user_total, item_total, all_dicts)
+            feed = DeviceFeeder(train_list, FLAGS.batch_size, D.DEV, FLAGS.negtive_samples, seed=FLAGS.seed)
+            logger.info('Training data and negative sampling are device-resident (-device_sampling).')
+    elif D.USE_CUDA and FLAGS.model_type in ('transup', 'bprmf') and trainer.fused is not None \
             and (FLAGS.model_type == 'bprmf' or FLAGS.embedding_size % 4 == 0) \
             and os.environ.get('KTUP_FAST_TRAIN', '1') != '0':             # (a TUP width that is not a multiple of 4: the autograd route)
         from jTransUP.utils.fast_train import DeviceFeeder, RecStepper
@@ -62,6 +83,8 @@ def train_loop(FLAGS, model, trainer, train_dataset, eval_datasets, user_total, 
     logger.info('Training.')
 
     def do_eval(totals):
+        if sharded:
+            stepper.sync_model() if is_report else stepper.begin_eval()      # (report mode walks whole tables: gathered for this pass only)
         logger.info('train loss:{:.4f}!'.format(totals['rec'] / FLAGS.eval_interval_steps))
         perfs = []
         for i, ed in enumerate(eval_datasets):
@@ -75,6 +98,10 @@ def train_loop(FLAGS, model, trainer, train_dataset, eval_datasets, user_total, 
                 for name, col in (('F1', 0), ('Precision', 1), ('Recall', 2), ('Hit Ratio', 3), ('NDCG', 4)):
                     vis.plot_many_stack({'Rec Eval {} {}'.format(i, name): p[col] for i, p in enumerate(perfs)},
                                         win_name='Rec {}@{}'.format(name, FLAGS.topn))
+        if sharded:
+            stepper.end_eval()
+            if is_report:
+                stepper.release_model()
         return perfs
 
     def do_step(step):
@@ -125,10 +152,18 @@ def run(only_forward=False):
         trainer.loadEmbedding(os.path.join(FLAGS.log_path, FLAGS.load_ckpt_file), model.state_dict(), cpu=not D.USE_CUDA)
         model.is_pretrained = True
     if only_forward:
+        shards = None
+        if getattr(FLAGS, 'shard_tables', False):      # -eval_only_mode under -shard_tables: shard what was loaded, evaluate ON the shards
+            from jTransUP.utils.sharded_train import ShardedJointDriver
+            shards = ShardedJointDriver(model, trainer, FLAGS, FLAGS.batch_size, logger)
+            logger.info('Row-sharded evaluation (-shard_tables): rank %d of %d.' % (shards.rank, shards.world))
+            shards.sync_model() if FLAGS.is_report else shards.begin_eval()
         for i, ed in enumerate(eval_datasets):
             others = [train_dict] + [d[3] for j, d in enumerate(eval_datasets) if j != i] if FLAGS.filter_wrong_corrupted else None
             evaluate(FLAGS, model, ed[0], ed[3], others, logger, eval_descending=trainer.model_target == 1,
                      is_report=FLAGS.is_report)
+        if shards is not None:
+            shards.end_eval()
     else:
         train_loop(FLAGS, model, trainer, train_dataset, eval_datasets, user_total, item_total, logger, vis=vis, is_report=False)
     if vis is not None:

@@ -322,8 +322,13 @@ class ShardedKtupStepper(_ShardedStepBase):
     def __init__(self, Ut, It, Et, pref, pref_norm, rel, norm, item2ent, batch, kind='adagrad', lr=0.005, eps=1e-10, max_norm=0.0,
                  l1=False, target=-1.0, orth=False, ent_pad=-1, group=None, capacity_factor=1.25, use_graphs=True, force_exchange=False,
                  direct=None, overlap_route=True, fused_apply=True, route_beside=False, betas=(0.9, 0.999), opt_step=None, exchange_graph=True,
-                 weight_decay=0.0, use_st_gumbel=False, gumbel_seed=0):
+                 weight_decay=0.0, use_st_gumbel=False, gumbel_seed=0, row_regs=False):
         self.exchange_graph = bool(exchange_graph)
+        # TUP (transUP.py:69-82; run_item_recommendation.py -model_type transup): Et = rel = norm = item2ent = None -- two sharded tables,
+        # two small ones.  row_regs: TUP's row regularisers (item_recommendation.py:177-180: normLoss of the batch's user rows, of its
+        # [pos ; neg] item rows and of the preference table), added to the stored row gradients by a launch after the step kernel
+        self.tup = Et is None
+        self.row_regs = bool(row_regs)
         self.weight_decay = float(weight_decay)
         self.lazy = is_lazy(kind, weight_decay)
         self.use_st_gumbel = bool(use_st_gumbel)
@@ -332,8 +337,11 @@ class ShardedKtupStepper(_ShardedStepBase):
         self.betas = (float(betas[0]), float(betas[1]))
         self.has_state = kind != 'sgd' or self.lazy
         self.route_beside = bool(route_beside)
-        self.tables = [Ut, It, Et]
-        self.small = [pref, pref_norm, rel, norm]
+        if self.tup and (rel is not None or norm is not None or item2ent is not None):
+            raise ValueError('without an entity table there is no rel / norm / item2ent (TUP)')
+        self.tables = [Ut, It] if self.tup else [Ut, It, Et]
+        self.small = [pref, pref_norm] if self.tup else [pref, pref_norm, rel, norm]
+        self.T = T = len(self.tables)
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -352,9 +360,9 @@ class ShardedKtupStepper(_ShardedStepBase):
             raise ValueError('one row width for all tables; the small tables are contiguous (P, d)')
         if not L.load().ktup_train_step_supported(0, d, P):
             raise L.KtupError('no fused KTUP step kernel for d=%d, n_pref=%d (ktup_train_step_supported)' % (d, P))
-        if item2ent.dtype != torch.int32 or item2ent.device != dev:
+        if not self.tup and (item2ent.dtype != torch.int32 or item2ent.device != dev):
             raise L.KtupError('item2ent must be an int32 device table')
-        self.item2ent, self.ent_pad = item2ent.contiguous(), int(ent_pad)
+        self.item2ent, self.ent_pad = (None if self.tup else item2ent.contiguous()), int(ent_pad)
         self.use_graphs = bool(use_graphs)
         self.overlap_route = bool(overlap_route)
         # fused_apply: reduce -> norm -> apply as two walks over the per-pair gradients (no W x d gradient buffer in between);
@@ -368,19 +376,19 @@ class ShardedKtupStepper(_ShardedStepBase):
         self.capacity_factor = float(capacity_factor)
         # direct (one rank only): the step kernel gathers straight from the shards by global id -- no pack launch, no compact copy;
         # it needs every item's entity to be a row of Et (no negative map entries; `ent_pad`, if given, is Et's own zero row)
-        can_direct = not self.multi and not bool((self.item2ent < 0).any())
+        can_direct = not self.multi and (self.tup or not bool((self.item2ent < 0).any()))
         if direct and not can_direct:
             raise ValueError('direct gathers need a single rank and an item2ent without negative entries')
         self.direct = can_direct if direct is None else bool(direct)
         W_ = self.world
-        n_dist = [B, 2 * B, 2 * B]                             # entries per table ([u], [pos ; neg], their entities) = at most this many DISTINCT ids
+        n_dist = [B, 2 * B, 2 * B][:T]                         # entries per table ([u], [pos ; neg], their entities) = at most this many DISTINCT ids
         if W_ == 1:
             cap = list(n_dist)
         else:
             cap = [min(n, int(math.ceil(self.capacity_factor * n / W_)) + 64) for n in n_dist]
         self.cap, self.capsum = cap, sum(cap)
         self.W = W = W_ * self.capsum
-        self.E = E = 5 * B
+        self.E = E = (3 if self.tup else 5) * B
         i64 = lambda n, fill=None: torch.empty(n, dtype=torch.int64, device=dev) if fill is None else torch.full((n,), fill, dtype=torch.int64, device=dev)
         i32 = lambda n: torch.zeros(n, dtype=torch.int32, device=dev)
         f32 = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
@@ -392,7 +400,7 @@ class ShardedKtupStepper(_ShardedStepBase):
         # the sets and the route of step s + 1 fills the other set beside the walks of step s (_pipelined); otherwise set 0 is the only one
         # in use.  The attribute names (self.entries, ...) point at the set of the step being bound / run (_use).
         self._sets = [{'entries': i64(E, -1), 'inverse': i64(E, 0), 'send_ids': i64(W, -1), 'pair_map': i32(W + 1),
-                       'sort_ws': i32((lib.ktup_shard_route_sort_bytes(E, W) + 3) // 4), 'counters': i32(W_ * 3 + 1),
+                       'sort_ws': i32((lib.ktup_shard_route_sort_bytes(E, W) + 3) // 4), 'counters': i32(W_ * T + 1),
                        'acc': torch.zeros(SLOTS + 1, dtype=torch.float64, device=dev)} for _ in range(2)]   # acc: [SLOTS partial sums of squares | the job-wide total]
         self._par = 0
         self._use(0)
@@ -402,10 +410,11 @@ class ShardedKtupStepper(_ShardedStepBase):
         self.Gwire = f32(W, d)
         self.xkeys = i32(max(2, lib.ktup_shard_reduce_list_len(E, d)))
         self.acc_step = torch.zeros(SLOTS, dtype=torch.float64, device=dev)  # the step kernel's share, when it runs beside the route's init
-        self.loss_sum = f32(2)                                # [sum of batch-mean BPR terms, sum of orthogonalLoss values] of the steps that ran
-        self.loss_step = f32(2)                               # the current step's terms (the apply launch folds and clears them)
+        self.n_loss = 4 if self.row_regs else 2               # [batch-mean BPR terms, orthogonalLoss values (, normLoss of the rows, normLoss(pref))]
+        self.loss_sum = f32(self.n_loss)                      # ... summed over the steps that ran
+        self.loss_step = f32(self.n_loss)                     # the current step's terms (the apply launch folds and clears them)
         self.skipped = i32(1)                                 # steps skipped for overflow: never cleared by a launch
-        n_g = 4 if self.orth else 2
+        n_g = 4 if (self.orth and not self.tup) else 2
         self.small_g = [f32(P, d) for _ in range(n_g)]        # orth: gP, gPn, gR, gRn; else gA (pref & rel), gC (pref_norm & norm)
         self.small_state = [row_state(s.data, kind, weight_decay) for s in self.small]
         for t in self.tables:
@@ -432,7 +441,7 @@ class ShardedKtupStepper(_ShardedStepBase):
             self.own_inverse = i64(W, 0)
             self.own_ids = i64(Wo, -1)
             self.own_sort = i32((lib.ktup_shard_route_sort_bytes(W, Wo) + 3) // 4)
-            self.own_counters = i32(3 + 1)
+            self.own_counters = i32(T + 1)
             self.own_ws = torch.empty((lib.ktup_shard_route_workspace_bytes(W) + 7) // 8, dtype=torch.int64, device=dev)
             self.Gown = f32(Wo, d)
             self.own_xkeys = i32(max(2, lib.ktup_shard_reduce_list_len(W, d)))
@@ -449,8 +458,11 @@ class ShardedKtupStepper(_ShardedStepBase):
         counting sort: four small latency-bound launches -- is bound to `side` (a second stream) and runs beside it; the
         segment then reads [init, ('fork', [...]), step, ('join',), ...]."""
         B, d, P, W, E, Wn = self.B, self.d, self.P, self.W, self.E, self.world
-        Ut, It, Et = self.tables
-        pref, pref_norm, rel, norm = [s.data for s in self.small]
+        Ut, It = self.tables[0], self.tables[1]
+        Et = None if self.tup else self.tables[2]
+        T = self.T
+        pref, pref_norm = self.small[0].data, self.small[1].data
+        rel, norm = (None, None) if self.tup else (self.small[2].data, self.small[3].data)
         keep = self._keep = []                                 # ctypes arrays must outlive the bound launches
 
         def arr(x):
@@ -465,7 +477,13 @@ class ShardedKtupStepper(_ShardedStepBase):
         kind = KINDS['adam'] if self.lazy else KINDS[self.kind]      # (the C side: 'state rows [m | v | last] + the rule' or a plain form)
         gscale = 1.0 / Wn
         g = self.small_g
-        if self.orth:
+        if self.tup:                                         # two small tables, each with a gradient of its own
+            gP, gPn, gR, gRn = g[0], g[1], None, None
+            sg_list = [gP, gPn]
+            sp0, ss0 = [pref, pref_norm], list(self.small_state)
+            sp1, ss1 = [None] * 2, [None] * 2
+            norm_list, small_weight = [gP, gPn], 1.0
+        elif self.orth:
             gP, gPn, gR, gRn = g
             sg_list = [gP, gPn, gR, gRn]
             sp0, ss0 = [pref, pref_norm, rel, norm], list(self.small_state)
@@ -479,14 +497,16 @@ class ShardedKtupStepper(_ShardedStepBase):
             norm_list, small_weight = [g[0], g[0], g[1], g[1]], 2.0      # the norm runs over all four tables' gradients
         n_small = len(sg_list)
         sgp, sp0p, ss0p = arr(_ptrs(sg_list)), arr(_ptrs(sp0)), (arr(_ptrs(ss0)) if self.has_state else None)
-        sp1p = arr(_ptrs(sp1)) if not self.orth else None
-        ss1p = arr(_ptrs(ss1)) if (not self.orth and self.has_state) else None
+        two = not self.orth and not self.tup                 # a gradient shared by two tables (pref & rel, pref_norm & norm)
+        sp1p = arr(_ptrs(sp1)) if two else None
+        ss1p = arr(_ptrs(ss1)) if (two and self.has_state) else None
         X, inv = self.X, self.inverse
-        close = (_p(self.loss_step), 2, _p(self.loss_sum), _p(self.skipped))
+        close = (_p(self.loss_step), self.n_loss, _p(self.loss_sum), _p(self.skipped))
         # one rank, two-walk form: the step kernel adds the stored rows' squared norms itself and the norm walk only corrects for
         # rows that several entries share (dup_only) -- with ids spread over millions of rows it reads almost nothing
         import os as _os
-        dup = (not self.multi) and self.fused_apply and _os.environ.get('KTUP_C5_DUP','1') != '0'
+        # (not with row regularisers: they change the stored rows after the step kernel has summed their squares)
+        dup = (not self.multi) and self.fused_apply and not self.row_regs and _os.environ.get('KTUP_C5_DUP','1') != '0'
         ssq = (_p(self.acc), SLOTS) if dup else (None, 0)
         # one rank, direct gathers, a second stream: the step kernel reads the id columns itself and runs beside the WHOLE route (its
         # init launch included); its squared norms go to accumulators of their own that the boundary-norm launch folds in, and that
@@ -512,13 +532,26 @@ class ShardedKtupStepper(_ShardedStepBase):
             uid_p, iid_p = (_p(fu), _p(fp)) if beside else (_p(ent), ent.data_ptr() + B * 8)
             cols = (_p(fn), _p(self.cursor), nb) if beside else (None, None, 0)
             step = bind('ktup_train_rec_step_rows', _p(Ut.weight.data), Ut.weight.data.stride(0), _p(It.weight.data), It.weight.data.stride(0),
-                        _p(Et.weight.data), Et.weight.data.stride(0), _p(self.item2ent), self.ent_pad, _p(pref), _p(pref_norm), _p(rel),
+                        None if self.tup else _p(Et.weight.data), 0 if self.tup else Et.weight.data.stride(0), _p(self.item2ent), self.ent_pad, _p(pref), _p(pref_norm), _p(rel),
                         _p(norm), d, P, d, uid_p, iid_p, B, int(self.l1), self.target, gscale, int(self.orth),
                         _p(self.loss_step), _p(self.Gcat), self.Gcat.data_ptr() + B * d * 4, _p(gP), _p(gPn), _p(gR), _p(gRn), *ssq, *cols, *gate, stream)
         else:
-            step = bind('ktup_train_rec_step_rows', _p(X), d, _p(X), d, _p(X), d, _p(self.pair_map), W, _p(pref), _p(pref_norm), _p(rel),
+            step = bind('ktup_train_rec_step_rows', _p(X), d, _p(X), d, None if self.tup else _p(X), 0 if self.tup else d, None if self.tup else _p(self.pair_map), W, _p(pref), _p(pref_norm), _p(rel),
                         _p(norm), d, P, d, _p(inv), inv.data_ptr() + B * 8, B, int(self.l1), self.target, gscale, int(self.orth),
                         _p(self.loss_step), _p(self.Gcat), self.Gcat.data_ptr() + B * d * 4, _p(gP), _p(gPn), _p(gR), _p(gRn), *ssq, None, None, 0, *gate, stream)
+        if self.row_regs:                                    # TUP: normLoss of the gathered rows and of pref, onto the stored row gradients
+            if self.direct:
+                ru, ri, ldr_u, ldr_i, idu, idi = _p(Ut.weight.data), _p(It.weight.data), Ut.weight.data.stride(0), It.weight.data.stride(0), \
+                    _p(self.entries), self.entries.data_ptr() + B * 8
+            else:
+                ru, ri, ldr_u, ldr_i, idu, idi = _p(X), _p(X), d, d, _p(inv), inv.data_ptr() + B * 8
+            reg = bind('ktup_train_rec_reg_rows', ru, ldr_u, ri, ldr_i, d, idu, idi, B, _p(self.Gcat), self.Gcat.data_ptr() + B * d * 4,
+                       _p(pref), P, _p(gP), 1.0, gscale, self.loss_step.data_ptr() + 8, stream)   # (rows: every rank its own; pref: once over the job)
+            score_step = step
+
+            def step():
+                score_step()
+                reg()
         if self.use_st_gumbel and self.guni is None:         # the stream position moves past this step's draws (a torch op: captured with the rest)
             launch_step, gstate, gadv = step, self.gstate, self.gadv
 
@@ -527,21 +560,21 @@ class ShardedKtupStepper(_ShardedStepBase):
                 gstate.add_(gadv)
         reduce_ = bind('ktup_shard_reduce_rows', _p(self.Gcat), d, d, 3 * B, 2 * B, _p(self.sort_ws), E, W, _p(self.Gwire), d, stream)
         if not self.multi:
-            pack = bind('ktup_shard_pack_wire', 3, tabs, lds, cap, d, _p(self.send_ids), 1, _p(X), d, stream)
+            pack = bind('ktup_shard_pack_wire', T, tabs, lds, cap, d, _p(self.send_ids), 1, _p(X), d, stream)
             nl = [self.Gwire] + norm_list
             nptr, nsz = arr(_ptrs(nl)), arr(_i64s([t.numel() for t in nl]))
             gnorm = bind('ktup_optim_gradnorm_acc', len(nl), nptr, nsz, _p(self.acc), SLOTS, stream)
-            apply_ = bind('ktup_shard_apply', kind, 3, tabs, lds, states, slds, cap, d, _p(self.send_ids), 1, _p(self.Gwire), d, n_small, P,
+            apply_ = bind('ktup_shard_apply', kind, T, tabs, lds, states, slds, cap, d, _p(self.send_ids), 1, _p(self.Gwire), d, n_small, P,
                           sgp, sp0p, ss0p, sp1p, ss1p, None, self.lr, self.eps, _p(self.acc), SLOTS, self.max_norm,
-                          self.counters.data_ptr() + 4 * (Wn * 3), None, *close, adam, stream)
-            count = [bind('ktup_shard_step_count', _p(self.opt_step), self.counters.data_ptr() + 4 * (Wn * 3), None, self.betas[0], self.betas[1], stream)] if adam else []
+                          self.counters.data_ptr() + 4 * (Wn * T), None, *close, adam, stream)
+            count = [bind('ktup_shard_step_count', _p(self.opt_step), self.counters.data_ptr() + 4 * (Wn * T), None, self.betas[0], self.betas[1], stream)] if adam else []
             if self.fused_apply:
                 nw = arr(_ptrs(sg_list))
                 rnorm = bind('ktup_shard_reduce_norm', _p(self.Gcat), d, d, 3 * B, 2 * B, _p(self.sort_ws), E, W, _p(self.Gwire), d,
                              _p(self.xkeys), n_small, nw, P * d, small_weight, _p(self.acc), SLOTS, int(dup), *fold, stream)
-                rapply = bind('ktup_shard_reduce_apply', kind, 3, tabs, lds, states, slds, cap, _p(self.send_ids), 1, _p(self.Gcat), d, d,
+                rapply = bind('ktup_shard_reduce_apply', kind, T, tabs, lds, states, slds, cap, _p(self.send_ids), 1, _p(self.Gcat), d, d,
                               3 * B, 2 * B, _p(self.sort_ws), E, _p(self.Gwire), d, _p(self.xkeys), n_small, P, sgp, sp0p, ss0p, sp1p, ss1p,
-                              None, self.lr, self.eps, _p(self.acc), SLOTS, self.max_norm, self.counters.data_ptr() + 4 * (Wn * 3), None,
+                              None, self.lr, self.eps, _p(self.acc), SLOTS, self.max_norm, self.counters.data_ptr() + 4 * (Wn * T), None,
                               *close, adam, stream)
                 tail = [rnorm] + count + [rapply]
             else:
@@ -573,30 +606,30 @@ class ShardedKtupStepper(_ShardedStepBase):
         def par(main, beside):
             return [('beside', main, beside), ('join',)] if side is not None else beside + main
         capo = arr(_i64s(self.cap_own))
-        eoff_o = arr(_i64s([0, self.cap[0], self.cap[0] + self.cap[1], self.capsum]))
-        pack = bind('ktup_shard_pack_wire', 3, tabs, lds, cap, d, _p(self.recv_ids), Wn, _p(self.Xsend), d, stream)
+        eoff_o = arr(_i64s([0, self.cap[0], self.cap[0] + self.cap[1], self.capsum][:T] + [self.capsum]))
+        pack = bind('ktup_shard_pack_wire', T, tabs, lds, cap, d, _p(self.recv_ids), Wn, _p(self.Xsend), d, stream)
         sort_ = route_phase(5, on)
         zshared = bind('ktup_shard_zero_shared_rows', _p(self.sort_ws), E, W, _p(inv), _p(self.Gwire), d, d, on)
         rstore = bind('ktup_shard_reduce_store', _p(self.Gcat), d, d, 3 * B, 2 * B, _p(self.sort_ws), E, W, _p(self.Gwire), d, stream)
 
         def oroute_on(st_):
-            return bind('ktup_shard_route', _p(self.recv_ids), W, self.capsum, 3, eoff_o, 1, capo, 0, 0, _p(self.own_inverse),
+            return bind('ktup_shard_route', _p(self.recv_ids), W, self.capsum, T, eoff_o, 1, capo, 0, 0, _p(self.own_inverse),
                         _p(self.own_ids), None, _p(self.own_sort), _p(self.own_counters), None, 0, _p(self.own_ws), st_)
         oreduce = bind('ktup_shard_reduce_rows', _p(self.Grecv), d, d, W, 0, _p(self.own_sort), W, self.W_own, _p(self.Gown), d, stream)
         nptr, nsz = arr(_ptrs([self.Gown])), arr(_i64s([self.Gown.numel()]))
         gnorm = bind('ktup_optim_gradnorm_acc', 1, nptr, nsz, _p(self.acc), SLOTS, stream)
         N = n_small * P * d
-        pack_b = bind('ktup_shard_bucket', 0, n_small, sgp, P * d, _p(self.bucket), _p(self.acc), SLOTS, self.counters.data_ptr() + 4 * (Wn * 3),
+        pack_b = bind('ktup_shard_bucket', 0, n_small, sgp, P * d, _p(self.bucket), _p(self.acc), SLOTS, self.counters.data_ptr() + 4 * (Wn * T),
                       None, 1.0, stream)
         fin_b = bind('ktup_shard_bucket', 1, n_small, None, P * d, _p(self.bucket), None, 0, None, self.acc.data_ptr() + 8 * SLOTS, small_weight, stream)
-        apply_ = bind('ktup_shard_apply', kind, 3, tabs, lds, states, slds, capo, d, _p(self.own_ids), 1, _p(self.Gown), d, n_small, P,
+        apply_ = bind('ktup_shard_apply', kind, T, tabs, lds, states, slds, capo, d, _p(self.own_ids), 1, _p(self.Gown), d, n_small, P,
                       sgp, sp0p, ss0p, sp1p, ss1p, _p(self.bucket), self.lr, self.eps, self.acc.data_ptr() + 8 * SLOTS, 1, self.max_norm,
                       None, self.bucket.data_ptr() + 8 * (N + 1), *close, adam, stream)
         count = [bind('ktup_shard_step_count', _p(self.opt_step), None, self.bucket.data_ptr() + 8 * (N + 1), self.betas[0], self.betas[1], stream)] if adam else []
         if self.fused_apply:
             onorm = bind('ktup_shard_reduce_norm', _p(self.Grecv), d, d, W, 0, _p(self.own_sort), W, self.W_own, _p(self.Gown), d,
                          _p(self.own_xkeys), 0, None, 0, 1.0, _p(self.acc), SLOTS, 0, None, 0, None, stream)
-            oapply = bind('ktup_shard_reduce_apply', kind, 3, tabs, lds, states, slds, capo, _p(self.own_ids), 1, _p(self.Grecv), d, d, W, 0,
+            oapply = bind('ktup_shard_reduce_apply', kind, T, tabs, lds, states, slds, capo, _p(self.own_ids), 1, _p(self.Grecv), d, d, W, 0,
                           _p(self.own_sort), W, _p(self.Gown), d, _p(self.own_xkeys), n_small, P, sgp, sp0p, ss0p, sp1p, ss1p,
                           _p(self.bucket), self.lr, self.eps, self.acc.data_ptr() + 8 * SLOTS, 1, self.max_norm, None,
                           self.bucket.data_ptr() + 8 * (N + 1), *close, adam, stream)

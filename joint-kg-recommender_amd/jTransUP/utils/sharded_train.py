@@ -41,19 +41,23 @@ from jTransUP.sharded_ktup import ShardedKtupJoint
 
 BIG = ('user_embeddings', 'item_embeddings', 'ent_embeddings')
 SMALL = ('pref_embeddings', 'pref_norm_embeddings', 'rel_embeddings', 'norm_embeddings')
+TUP_BIG, TUP_SMALL = BIG[:2], SMALL[:2]            # -model_type transup (run_item_recommendation.py): no entity side
 
 
 def check_flags(FLAGS, model):
     """Everything -shard_tables cannot do is refused here, by the reference's flag names."""
-    if FLAGS.model_type != 'jtransup' or FLAGS.share_embeddings:
-        raise L.KtupError('-shard_tables trains jtransup with its own tables (-model_type jtransup -noshare_embeddings)')
+    if FLAGS.model_type == 'transup':
+        pass                                         # TUP: user / item tables sharded, the preference tables replicated
+    elif FLAGS.model_type != 'jtransup' or getattr(FLAGS, 'share_embeddings', False):
+        raise L.KtupError('-shard_tables trains transup, or jtransup with its own tables (-model_type jtransup -noshare_embeddings)')
     if FLAGS.optimizer_type not in ('Adagrad', 'SGD', 'Adam') or (FLAGS.optimizer_type == 'SGD' and FLAGS.momentum != 0):
         raise L.KtupError('-shard_tables updates only the rows a batch touches: exact for -optimizer_type Adagrad, SGD with -momentum 0, '
                           'or Adam (whose untouched steps are replayed when a row is touched again)')
     if FLAGS.l2_lambda < 0:
         raise L.KtupError('-l2_lambda must not be negative')
-    d, P = model.embedding_size, model.rel_total
-    if not L.load().ktup_train_step_supported(0, d, P) or not L.load().ktup_train_step_supported(1, d, P):
+    tup = FLAGS.model_type == 'transup'
+    d, P = model.embedding_size, (model.pref_embeddings.weight.shape[0] if tup else model.rel_total)
+    if not L.load().ktup_train_step_supported(0, d, P) or not (tup or L.load().ktup_train_step_supported(1, d, P)):
         raise L.KtupError('-shard_tables: no fused step kernels for -embedding_size %d with %d preferences' % (d, P))
 
 
@@ -76,12 +80,30 @@ def gather_table(full, rows, total_rows, world, group=None):
     return full
 
 
+class _RecOnly(object):
+    """What the driver needs of ShardedKtupJoint when there is no kg half (TUP)."""
+
+    def __init__(self, rec):
+        self.rec, self.kg, self.steps = rec, None, 0
+
+    def flush(self):
+        self.rec.flush()
+
+    def check(self):
+        self.rec.check()
+
+    def close(self):
+        self.rec.close()
+
+
 class ShardedJointDriver(object):
     """The stepper interface of utils/fast_train.JointStepper (GB, rec_step, kg_step, take_sums, can_feed) over ShardedKtupJoint."""
 
     def __init__(self, model, trainer, FLAGS, batch_size, logger=None, group=None):
         check_flags(FLAGS, model)
         self.m, self.trainer, self.FLAGS, self.group, self.logger = model, trainer, FLAGS, group, logger
+        self.tup = FLAGS.model_type == 'transup'
+        self.BIG, self.SMALL = (TUP_BIG, TUP_SMALL) if self.tup else (BIG, SMALL)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         if int(batch_size) % self.world:
@@ -93,12 +115,12 @@ class ShardedJointDriver(object):
             for p in model.parameters():
                 dist.broadcast(p.data, src=0, group=group)
         self.tables = []
-        for name in BIG:
+        for name in self.BIG:
             full = getattr(model, name).weight.data
             t = parallel.ShardedTable(full.shape[0], full.shape[1], rank=self.rank, world=self.world, group=group, device=dev,
                                       init=lambda g, full=full: full[g.to(full.device)])
             self.tables.append(t)
-        self.small = [getattr(model, name).weight for name in SMALL]
+        self.small = [getattr(model, name).weight for name in self.SMALL]
         self.kind = FLAGS.optimizer_type.lower()
         self.weight_decay = float(getattr(FLAGS, 'l2_lambda', 0.0) or 0.0)
         from jTransUP.sharded_ktup import is_lazy
@@ -132,6 +154,18 @@ class ShardedJointDriver(object):
 
     def _build(self, lr):
         F = self.FLAGS
+        if self.tup:     # TUP's rec step alone (item_recommendation.py:160-192), with its row regularisers
+            from jTransUP.sharded_ktup import ShardedKtupStepper
+            self.joint = _RecOnly(ShardedKtupStepper(self.tables[0], self.tables[1], None, self.small[0], self.small[1], None, None, None,
+                                                     batch=self.B, kind=self.kind, lr=lr, max_norm=F.clipping_max_value,
+                                                     eps=1e-8 if self.kind == 'adam' else 1e-10, l1=bool(F.L1_flag),
+                                                     target=float(self.trainer.model_target), orth=True, row_regs=True, group=self.group,
+                                                     capacity_factor=float(getattr(F, 'shard_capacity_factor', 1.25)),
+                                                     weight_decay=self.weight_decay, use_st_gumbel=bool(getattr(F, 'use_st_gumbel', False)),
+                                                     gumbel_seed=int(getattr(F, 'seed', 0) or 0)))
+            self._lr = lr
+            self._base = {'rec': torch.zeros(4), 'kg': torch.zeros(4)}
+            return
         self.joint = ShardedKtupJoint.build(*self.tables, *self.small, self.m._item2ent, batch=self.B, joint_ratio=F.joint_ratio,
                                             margin=F.margin, kg_lambda=F.kg_lambda, kind=self.kind, lr=lr, max_norm=F.clipping_max_value,
                                             eps=1e-8 if self.kind == 'adam' else 1e-10,       # torch.optim's defaults (utils/trainer.py:63-77 passes none)
@@ -184,9 +218,11 @@ class ShardedJointDriver(object):
         """Fold the steppers' device-side loss sums into the host totals (one sync).  rec: the batch-mean BPR term averaged over the
         ranks + orthogonalLoss(pref, pref_norm) (identical on every rank); kg: kg_lambda x the sum over all ranks' triples."""
         rec = self.joint.rec.loss_sum.detach().cpu() - self._base['rec']
-        kg = self.joint.kg.loss_sum.detach().cpu() - self._base['kg']
+        kg = torch.zeros(4) if self.joint.kg is None else self.joint.kg.loss_sum.detach().cpu() - self._base['kg']
         self._base['rec'] += rec; self._base['kg'] += kg
-        vals = torch.tensor([float(rec[0]) / self.world, float(kg.sum()) * self.FLAGS.kg_lambda], dtype=torch.float64)
+        # TUP's row regularisers: every rank's own rows' terms and its 1 / world share of normLoss(pref) -- both add up over the ranks
+        rows = float(rec[2]) + float(rec[3]) if rec.numel() > 2 else 0.0
+        vals = torch.tensor([float(rec[0]) / self.world + rows, float(kg.sum()) * getattr(self.FLAGS, 'kg_lambda', 1.0)], dtype=torch.float64)
         if self.world > 1:
             v = vals.to(self.dev)
             dist.all_reduce(v, group=self.group)
@@ -218,6 +254,9 @@ class ShardedJointDriver(object):
         """Before an evaluation reads the shards: Adam's pending zero-gradient steps (flush), and the entity rows of this rank's items
         -- E[item2ent[rank + world j]], the operand jTransUP.py:122-130 adds to the item row -- fetched from their owners once."""
         self.joint.flush()
+        if self.tup:
+            self._item_ent = True                    # (nothing to fetch: no entity side)
+            return
         i2e = self.m._eval_item2ent.long()
         Et = self.tables[2]
         mine = None
@@ -231,8 +270,9 @@ class ShardedJointDriver(object):
         """(n_items, f(u_ids) -> (B, n_my_items) scores, ('lattice', rank, world)) for models/_driver.rec_eval_pass: transUP / jTransUP's
         evaluateRec (jTransUP.py:163-191) with this rank's item rows as the candidates."""
         from jTransUP.hip import ops
-        m, (Ut, It, Et) = self.m, self.tables
-        P, Pn, R, Rn = [p.data for p in self.small]
+        m, Ut, It = self.m, self.tables[0], self.tables[1]
+        P, Pn = self.small[0].data, self.small[1].data
+        R, Rn = (None, None) if self.tup else (self.small[2].data, self.small[3].data)
         n_my = It.weight.shape[0]
         local_map = torch.arange(n_my, dtype=torch.int32, device=self.dev)       # item row j <-> row j of the fetched entity rows
 
@@ -243,6 +283,8 @@ class ShardedJointDriver(object):
             q = torch.arange(u_ids.numel(), dtype=torch.int64, device=self.dev)
             # (-use_st_gumbel: the reference draws noise in evaluate too, transUP.py:92 -- here from the model's own Philox stream)
             mode, uni, seed, off = m._gumbel.mode_and_stream(m.use_st_gumbel, None, u_ids.numel() * n_my * P.shape[0])
+            if self.tup:                             # transUP.py:84-102 with this rank's item rows as the candidates
+                return ops.eval_tup(Uq, It.weight.data, P, Pn, q, m.L1_flag, mode, uni, seed, off)
             return ops.eval_ktup(Uq, It.weight.data, self._item_ent, P, Pn, R, Rn, local_map, q, m.L1_flag, mode, uni, seed, off)
         return It.total_rows, f, ('lattice', self.rank, self.world)
 
@@ -272,7 +314,7 @@ class ShardedJointDriver(object):
         if self._whole and not self._dirty:
             return
         self.joint.flush()                           # Adam: every row up to the current step, as the dense optimizer would hold it
-        for name, t in zip(BIG, self.tables):
+        for name, t in zip(self.BIG, self.tables):
             w = getattr(self.m, name).weight
             if w.data.shape[0] != t.total_rows:
                 w.data = torch.empty(t.total_rows, t.d, dtype=torch.float32, device=self.dev)
@@ -282,7 +324,7 @@ class ShardedJointDriver(object):
     @torch.no_grad()
     def release_model(self):
         """Drop the model's whole big tables (zero-row placeholders keep the module structure) and the dense optimizer's state for them."""
-        for name in BIG:
+        for name in self.BIG:
             w = getattr(self.m, name).weight
             w.data = torch.empty(0, w.data.shape[1], dtype=torch.float32, device=self.dev)
             w.grad = None
@@ -307,7 +349,7 @@ class ShardedJointDriver(object):
             return
         step = float(self.joint.rec.opt_step[0].item()) if self.lazy else float(self.trainer.step)
         block = {'adam': (0, 1), 'adagrad': (1,)}.get(self.kind, ())          # which d-wide block of a lazy state row [m | v | last] a key is
-        pieces = [(getattr(self.m, n).weight, t.state, t.total_rows, True) for n, t in zip(BIG, self.tables)] + \
+        pieces = [(getattr(self.m, n).weight, t.state, t.total_rows, True) for n, t in zip(self.BIG, self.tables)] + \
                  [(p, s, p.shape[0], False) for p, s in zip(self.small, self.joint.rec.small_state)]
         for p, st, rows, big in pieces:
             entry = opt.state[p]
@@ -324,7 +366,7 @@ class ShardedJointDriver(object):
         opt, d = getattr(self.trainer, 'optimizer', None), self.tables[0].d
         if opt is None:
             return
-        pieces = [(getattr(self.m, n).weight, t.state, True) for n, t in zip(BIG, self.tables)] + \
+        pieces = [(getattr(self.m, n).weight, t.state, True) for n, t in zip(self.BIG, self.tables)] + \
                  [(p, s, False) for p, s in zip(self.small, self.joint.rec.small_state)]
         step = 0
         block = {'adam': (0, 1), 'adagrad': (1,)}.get(self.kind, ())
@@ -348,7 +390,7 @@ class ShardedJointDriver(object):
     @torch.no_grad()
     def load_from_model(self):
         """The model's whole tables -> this rank's rows (after pre-trained tables or a whole-table checkpoint were loaded)."""
-        for name, t in zip(BIG, self.tables):
+        for name, t in zip(self.BIG, self.tables):
             t.weight.data.copy_(getattr(self.m, name).weight.data[self.rank::self.world])
         self._dirty = False
 
@@ -363,9 +405,9 @@ class ShardedJointDriver(object):
                     'best_step': getattr(tr, 'best_step', 0), 'best_dev_performance': getattr(tr, 'best_dev_performance', 0.0),
                     'best_performances': getattr(tr, 'best_performances', None),
                     'opt_step': int(j.rec.opt_step[0].item()),
-                    'rows': {n: t.weight.data.cpu() for n, t in zip(BIG, self.tables)},
-                    'row_state': {n: (None if t.state is None else t.state.cpu()) for n, t in zip(BIG, self.tables)},
-                    'small': {n: p.data.cpu() for n, p in zip(SMALL, self.small)},
+                    'rows': {n: t.weight.data.cpu() for n, t in zip(self.BIG, self.tables)},
+                    'row_state': {n: (None if t.state is None else t.state.cpu()) for n, t in zip(self.BIG, self.tables)},
+                    'small': {n: p.data.cpu() for n, p in zip(self.SMALL, self.small)},
                     'small_state': [None if s is None else s.cpu() for s in j.rec.small_state]}, self.shard_file(filename))
 
     @torch.no_grad()
@@ -382,11 +424,11 @@ class ShardedJointDriver(object):
             else:
                 self.trainer.learning_rate = ck['lr']
             self._build(ck['lr'])
-        for n, t in zip(BIG, self.tables):
+        for n, t in zip(self.BIG, self.tables):
             t.weight.data.copy_(ck['rows'][n])
             if t.state is not None and ck['row_state'][n] is not None:
                 t.state.copy_(ck['row_state'][n])
-        for n, p in zip(SMALL, self.small):
+        for n, p in zip(self.SMALL, self.small):
             p.data.copy_(ck['small'][n])
         for s, v in zip(self.joint.rec.small_state, ck['small_state']):
             if s is not None and v is not None:

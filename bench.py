@@ -1076,8 +1076,9 @@ def config5_leg(device, world, rank, steps=100, warmup=10, batch=8192, full=True
     out['joint'] = run('joint', what='joint')
     if world == 1:
         out['exchange_form'] = run('exchange', force_exchange=True)   # what ONE rank of a bigger job runs, minus the wire
-        out['exchange_form']['note'] = ('the several-ranks route on one rank: five graph segments, rows packed into the wire '
-                                        'buffer, the three all-to-alls as device copies')
+        out['exchange_form']['note'] = ('the several-ranks route on one rank: the five segments AND the exchanges between them as ONE graph '
+                                        '(device copies stand for the three all-to-alls; with RCCL the collectives are captured the same way), '
+                                        'rows packed into the wire buffer, the requester reduction stores its rows, the next step\'s route on a second branch')
         out['exchange_form']['joint'] = run('exchange joint', what='joint', force_exchange=True)
     # the published recipe's optimizer (ktup.sh:1: Adam, l2_lambda 0) on the shards: row-sparse Adam with exact catch-up of the steps a row
     # was not touched for (include/ktup_hip.h ktup_adam_t); last, so that a failure here cannot take the figures above with it
@@ -1090,11 +1091,12 @@ def config5_leg(device, world, rank, steps=100, warmup=10, batch=8192, full=True
             out['joint_adam'] = {'skipped': 'not enough free device memory for the Adam state'}
     except Exception as e:                                               # noqa: BLE001 -- reported, never fatal for the bench line
         out['joint_adam'] = {'error': '%s: %s' % (type(e).__name__, e)}
-    out['note'] = ('top level: the rec step (the round-3 figure); kg_step / joint: the kg half and the 7 : 3 cycle.  One rank: ONE graph of '
-                   '8 launches per step (route 5, fused step 1, norm walk 1, apply walk 1 -- the walks carry the small tables and the '
-                   'bookkeeping as extra workgroups), four of them dependent on one queue, the route\'s other four on a second graph branch '
-                   'beside the step kernel; N > 1: five graph segments around three equal-split all-to-alls and one fp64 all-reduce (small '
-                   'tables + norm + overflow flag); round 3: 0.171 ms per rec step, no kg step')
+    out['note'] = ('top level: the rec step (the round-3 figure); kg_step / joint: the kg half and the 7 : 3 cycle.  One rank: ONE graph per step -- '
+                   'fused step, norm walk, apply walk on one queue (the walks carry the small tables and the bookkeeping as extra workgroups) and, '
+                   'on a second branch from the step\'s first launch to its last, the ROUTE OF THE NEXT STEP into the other of two buffer sets (two '
+                   'graphs alternate); N > 1: the five segments, three equal-split all-to-alls and one fp64 all-reduce (small tables + norm + '
+                   'overflow flag) as ONE graph where the collectives can be captured (RCCL), five graphs under gloo; round 3: 0.171, round 5: '
+                   '0.129 ms per rec step')
     return out
 
 
@@ -1147,6 +1149,61 @@ def config4_sharded_leg(device, world, rank, steps=200, warmup=20):
             'ms_per_step': wall, 'scored_rows_per_s': 2 * 512 / (wall * 1e-3), 'wire_rows_per_rank': {'rec': joint.rec.W, 'kg': joint.kg.W},
             'optimizer': 'row-sparse Adagrad, l2_lambda 0 (the replicated route of dp_train_step runs dense Adagrad with weight decay)',
             'note': 'strong scaling of the reference batch: B = 512 / N pairs or triples per rank and step'}
+
+
+def key_figures(out):
+    """The figures the rounds' targets are stated in, once more and compactly, as the LAST object of the JSON line (a reader who keeps
+    only the line's tail still sees them); every value is copied from the leg that measured it."""
+    def get(*path):
+        v = out
+        for k in path:
+            if not isinstance(v, dict) or k not in v:
+                return None
+            v = v[k]
+        return v
+    kf = {
+        'scoring_rows_per_s': out.get('value'), 'K6_frac_of_fp32_pipe': get('roofline', 'frac'),
+        'eval_full_pass_ms': get('eval_all_item_hit10', 'full_pass_ms'),
+        'eval_sweep_device_ms': get('eval_all_item_hit10', 'fused_pass', 'device_ms_scores_and_topk'),
+        'eval_sweep_frac_of_fp32_peak': get('eval_all_item_hit10', 'fused_pass', 'gemm_frac_of_fp32_peak'),
+        'train_step_b512_ms': {k: get('train_step_b512', 'ms_per_step_' + k) for k in ('gpu_resident', 'device_fed_x10', 'fused', 'torch')},
+        'forward_b512_rows_per_s': get('forward_b512', 'scored_rows_per_s'),
+        'cli_steps_per_s': get('cli_steps_per_s', 'steps_per_s'),
+        'config5_ms': {'rec': get('config5_step', 'ms_per_step'), 'kg': get('config5_step', 'kg_step', 'ms_per_step'),
+                       'joint': get('config5_step', 'joint', 'ms_per_step'), 'exchange_form': get('config5_step', 'exchange_form', 'ms_per_step'),
+                       'exchange_form_joint': get('config5_step', 'exchange_form', 'joint', 'ms_per_step'),
+                       'joint_adam': get('config5_step', 'joint_adam', 'ms_per_step')},
+        'config5_rec_hbm_frac_algorithmic': get('config5_step', 'hbm_frac_algorithmic'),
+        'K6_d256_hbm_resident_frac': get('roofline_hbm_resident', 'd256', 'frac_of_hbm_peak') or get('roofline_hbm_resident', 'frac'),
+        'kg_pass_transe_ms': get('eval_kg_transe', 'full_pass_ms'),
+        'dp_train_step_ms': get('dp_train_step', 'ms_per_step'),
+    }
+    return {k: v for k, v in kf.items() if v is not None}
+
+
+def cli_throughput_leg(steps=3000, timeout_s=300):
+    """The drop-in command line end to end (tools/cli_throughput.py): run_knowledgable_recommendation.py -model_type jtransup (d = 100, B = 512,
+    joint_ratio 0.7, -device_sampling) on an ml1m-SHAPED dataset written in the reference's file formats, training steps per second over an
+    interval between two periodic evaluations (one evaluation pass and a checkpoint included), in a process of its own.  Round 5's line did
+    not carry this figure and a 1.7 x regression of it went unnoticed for two rounds."""
+    import re
+    import subprocess
+    tool = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tools', 'cli_throughput.py')
+    try:
+        r = subprocess.run([sys.executable, tool, str(steps), 'dev'], capture_output=True, text=True, timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        return {'error': 'timeout after %d s' % timeout_s}
+    m = re.search(r'dev\s+sampling:\s+(\d+) steps/s', r.stdout)
+    b = re.search(r'fastest of (\d+) intervals\s+(\d+) steps/s; per interval \[total, rec pass, kg pass, checkpoint \+ steps\] s: (.*)', r.stdout)
+    if r.returncode != 0 or not m:
+        return {'error': (r.stdout + r.stderr)[-400:]}
+    out = {'steps_per_s': float(m.group(1)), 'scored_rows_per_s': float(m.group(1)) * 1024, 'steps_per_interval': steps,
+           'what': 'run_knowledgable_recommendation.py jtransup d=100 B=512 -device_sampling, first interval after the step-0 evaluation '
+                   '(evaluation passes + checkpoint included); round 3: 20,408, rounds 4-5: 11,450 / 11,765 (a full gc.collect() before every graph capture)'}
+    if b:
+        out['fastest_interval_steps_per_s'] = float(b.group(2))
+        out['intervals_s_total_rec_kg_rest'] = b.group(3)
+    return out
 
 
 def roofline(rec_ms, kg_ms, step_ms=None, live_traffic=None):
@@ -1376,6 +1433,7 @@ def main():
         out['eval_tup_hard_gate'] = eval_tup_hard_bench(device)
         out['eval_ktup_l1'] = eval_ktup_l1_bench(device)
         out['eval_all_item_hit10']['cpu_baseline'] = cpu_eval_baseline(keep['m'], keep['users'], keep['gold'], keep['train'], keep['rows'])
+        out['cli_steps_per_s'] = cli_throughput_leg()
     elif rank == 0:
         out['cpu_baseline'] = None
     if not args.no_extras:
@@ -1403,6 +1461,7 @@ def main():
         if rank == 0:
             out.update(legs)
     if rank == 0:
+        out['key_figures'] = key_figures(out)          # LAST: what a truncated tail of the line still shows
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -366,11 +366,15 @@ KTUP_DEV void lazy_step1(int rule, float& p, float& m, float& v, float g, float 
   p = fmaf(-lr, g, p);                                // sgd.py (momentum 0)
 }
 // One row's CPL float4 chunks per lane: replay the untouched steps last + 1 .. upto, then (has_g) step t = upto + 1 with gradient g.
-template <int CPL>
+// WD (weight decay) is a TEMPLATE parameter: compiled into the same instantiation, its replay (an optimizer step per missed step, fp64
+// bias corrections, a third rule) cost the plain Adam walk of config 5 23 registers, 488 bytes of scratch and a wave per SIMD
+// (seg_fused_kernel<64,1,1,...>: 115 -> 138 VGPRs; joint_adam 0.395 -> 0.474 ms in the bench line) -- the lesson of the Adagrad / Adam
+// split of round 5 once more.
+template <int CPL, bool WD>
 KTUP_DEV void adam_row(float4 (&p)[CPL], float4 (&m)[CPL], float4 (&v)[CPL], const float4 (&g)[CPL], bool has_g, int upto, int last,
                        float lr, float eps, const AdamRule& r) {
   const int miss = upto - last;
-  if (r.wd != 0.f) {
+  if constexpr (WD) {
     // weight decay: the steps last + 1 .. upto on g = wd * p, exactly as the dense optimizer took them
     if (miss > 0) {
       if (r.rule == 2) {                              // p <- p (1 - lr wd), `miss` times
@@ -378,7 +382,7 @@ KTUP_DEV void adam_row(float4 (&p)[CPL], float4 (&m)[CPL], float4 (&v)[CPL], con
 #pragma unroll
         for (int j = 0; j < CPL; ++j) p[j] = f * p[j];
       } else {
-        double b1p = pow((double)r.b1, (double)last), b2p = pow((double)r.b2, (double)last);
+        double b1p = (double)__expf((float)last * r.ln1), b2p = (double)__expf((float)last * r.ln2);     // (as the plain replay below)
         for (int k = 0; k < miss; ++k) {
           float c1 = lr, bc2s = 1.f;
           if (r.rule == 0) {
@@ -407,7 +411,7 @@ KTUP_DEV void adam_row(float4 (&p)[CPL], float4 (&m)[CPL], float4 (&v)[CPL], con
       }
     }
     return;
-  }
+  } else {
   if (last > 0 && miss > 0) {
     const int K = miss < r.replay ? miss : r.replay;
     double b1p = (double)__expf((float)last * r.ln1), b2p = (double)__expf((float)last * r.ln2);
@@ -438,22 +442,23 @@ KTUP_DEV void adam_row(float4 (&p)[CPL], float4 (&m)[CPL], float4 (&v)[CPL], con
       adam_step1(p[j].z, m[j].z, v[j].z, g[j].z, c1, bc2s, eps, r.b1, r.b2); adam_step1(p[j].w, m[j].w, v[j].w, g[j].w, c1, bc2s, eps, r.b1, r.b2);
     }
   }
+  }
 }
 // the same on a row in memory: lane `lane` of a group of GL owns chunks lane, lane + GL, ...; srow = [m | v | last]
-template <int GL, int CPL>
+template <int GL, int CPL, bool WD>
 KTUP_DEV void adam_row_mem(float4* prow, float4* srow, int nch, int lane, const float4 (&g)[CPL], bool has_g, int t, float lr, float eps,
                            const AdamRule& r) {
   int32_t* lastp = reinterpret_cast<int32_t*>(srow + 2 * nch);
   const int last = *lastp;
   const int upto = has_g ? t - 1 : t;
-  if (!has_g && ((last <= 0 && r.wd == 0.f) || last >= t)) return;          // (weight decay moves rows that were never touched too)
+  if (!has_g && ((last <= 0 && !WD) || last >= t)) return;          // (weight decay moves rows that were never touched too)
   float4 p[CPL], m[CPL], v[CPL];
 #pragma unroll
   for (int j = 0; j < CPL; ++j) {
     const int ch = lane + j * GL;
     if (ch < nch) { p[j] = prow[ch]; m[j] = srow[ch]; v[j] = srow[nch + ch]; } else { p[j] = f4zero(); m[j] = f4zero(); v[j] = f4zero(); }
   }
-  adam_row<CPL>(p, m, v, g, has_g, upto, last, lr, eps, r);
+  adam_row<CPL, WD>(p, m, v, g, has_g, upto, last, lr, eps, r);
 #pragma unroll
   for (int j = 0; j < CPL; ++j) {
     const int ch = lane + j * GL;
@@ -479,8 +484,10 @@ KTUP_DEV float clip_coef(float max_norm, const double* __restrict__ sumsq, int s
 
 // Same rule as ktup_shard.hip SparseRowStep (utils/trainer.py:63-77 with l2_lambda = 0 restricted to the touched rows), for
 // every wire row of every table + the rows of the small replicated tables; the gradient rows are zero-filled once consumed.
-template <bool ADAM>
+// LZ: 0 the plain row-sparse forms (SGD / Adagrad), 1 Adam with catch-up, 2 any rule under weight decay (ktup_adam_t)
+template <int LZ>
 struct ApplyRowsT {
+  static constexpr bool ADAM = LZ != 0;
   WireTables w; const int64_t* ids; int64_t W; float* g; int64_t ldg;
   int n_small, small_rows; float* sg[MAXS]; float* sp0[MAXS]; float* ss0[MAXS]; float* sp1[MAXS]; float* ss1[MAXS];
   const double* small_g64;     // non-null: the all-reduced small gradients (fp64 bucket, entries in sg order) replace sg's values
@@ -496,7 +503,7 @@ struct ApplyRowsT {
     float4 g[CPL];
 #pragma unroll
     for (int j = 0; j < CPL; ++j) g[j] = coef * gr[j];
-    adam_row_mem<G, CPL>(reinterpret_cast<float4*>(prow), reinterpret_cast<float4*>(srow), cx.nch, cx.lane, g, true, (int)*ar.step, lr, eps, ar);
+    adam_row_mem<G, CPL, LZ == 2>(reinterpret_cast<float4*>(prow), reinterpret_cast<float4*>(srow), cx.nch, cx.lane, g, true, (int)*ar.step, lr, eps, ar);
   }
   template <int G, int CPL>
   KTUP_DEV void one_adam(const RowCtx<float, G, CPL>&, float*, float*, const float (&)[CPL], float) const {}   // (refused on the host: Adam rows are float4)
@@ -585,7 +592,7 @@ struct ApplyRowsT {
     }
   }
 };
-using ApplyRows = ApplyRowsT<false>;
+using ApplyRows = ApplyRowsT<0>;
 
 
 // ---- reduction by sorted segments WITHOUT a gradient buffer (one rank's reduce -> norm -> apply, and the owner side of several):
@@ -646,8 +653,8 @@ KTUP_DEV void xnorm_blocks(const XNormArgs& a, int blk, int nblk) {
 // MODE 1 carries the step's LAST launch along as extra workgroups [walk_grid, gridDim.x): the listed boundary rows (from gw, then
 // zero-filled), the small replicated tables and the step's bookkeeping (ApplyRows over op_rows rows) depend on the norm only, not on
 // this walk -- as a launch of their own they were 6 us of dependent latencies at the very end of every step.
-template <int GL, int CPL, int MODE, bool ADAM>
-__global__ __launch_bounds__(256) void seg_fused_kernel(FusedArgs a, ApplyRowsT<ADAM> op, int64_t op_rows, int walk_grid, XNormArgs xn) {
+template <int GL, int CPL, int MODE, int LZ>
+__global__ __launch_bounds__(256) void seg_fused_kernel(FusedArgs a, ApplyRowsT<LZ> op, int64_t op_rows, int walk_grid, XNormArgs xn) {
   const int lane = threadIdx.x % GL, grp = threadIdx.x / GL;
   constexpr int GPB = 256 / GL;
   if (MODE == 0 && (int)blockIdx.x >= walk_grid) {
@@ -696,11 +703,11 @@ __global__ __launch_bounds__(256) void seg_fused_kernel(FusedArgs a, ApplyRowsT<
     const int t = wire_table(a.w, key);
     float4* prow = reinterpret_cast<float4*>(a.w.tab[t] + id * a.w.ldt[t]);
     float4* srow = a.adagrad ? reinterpret_cast<float4*>(a.w.st[t] + id * a.w.lds[t]) : nullptr;
-    if constexpr (ADAM) {
+    if constexpr (LZ != 0) {
       float4 g[CPL];
 #pragma unroll
       for (int j = 0; j < CPL; ++j) g[j] = coef * acc[j];
-      adam_row_mem<GL, CPL>(prow, srow, a.nch, lane, g, true, (int)*a.ar.step, a.lr, a.eps, a.ar);
+      adam_row_mem<GL, CPL, LZ == 2>(prow, srow, a.nch, lane, g, true, (int)*a.ar.step, a.lr, a.eps, a.ar);
       return;
     }
     float4 p[CPL], st[CPL];
@@ -865,16 +872,16 @@ int64_t fused_grid(int64_t m_max, int d) {
   return (nchunks + gpb - 1) / gpb;
 }
 
-template <int MODE, bool ADAM = false>
-int launch_fused(const FusedArgs& a, int64_t grid, hipStream_t st, const char* name, const ApplyRowsT<ADAM>* op = nullptr, int64_t op_rows = 0,
+template <int MODE, int LZ = 0>
+int launch_fused(const FusedArgs& a, int64_t grid, hipStream_t st, const char* name, const ApplyRowsT<LZ>* op = nullptr, int64_t op_rows = 0,
                  const XNormArgs* xn = nullptr) {
-  const ApplyRowsT<ADAM> none{};
+  const ApplyRowsT<LZ> none{};
   const XNormArgs xnone{};
 #define KTUP_F(GL, CPL)                                                                                  \
   {                                                                                                      \
     int64_t extra = op ? grid_for((op_rows + (256 / GL) - 1) / (256 / GL), 256) : 0;                     \
     if (xn) extra = grid_for(((int64_t)xn->n_small * xn->small_elems + 2047) / 2048, 64);                \
-    hipLaunchKernelGGL((seg_fused_kernel<GL, CPL, MODE, ADAM>), dim3((unsigned)(grid + extra)), dim3(256), 0, st, a, op ? *op : none, op_rows, \
+    hipLaunchKernelGGL((seg_fused_kernel<GL, CPL, MODE, LZ>), dim3((unsigned)(grid + extra)), dim3(256), 0, st, a, op ? *op : none, op_rows, \
                        (int)grid, xn ? *xn : xnone);                                                     \
     return check_launch(name);                                                                           \
   }
@@ -1032,7 +1039,7 @@ struct CatchupArgs {
   int nch; float lr, eps; AdamRule r;
 };
 
-template <int GL, int CPL>
+template <int GL, int CPL, bool WD>
 __global__ __launch_bounds__(256) void adam_catchup_kernel(CatchupArgs a) {
   // A lane group per row, RB rows per round: their ids, then their `last` stamps, are RB independent loads in flight per group -- every
   // state row lies on another page, so a stamp is a TLB miss, and one row after the other the misses of a group queued up behind each
@@ -1068,8 +1075,8 @@ __global__ __launch_bounds__(256) void adam_catchup_kernel(CatchupArgs a) {
       last[u] = row[u] >= 0 ? *reinterpret_cast<const int32_t*>(a.st[k[u]] + row[u] * a.lds[k[u]] + 8 * a.nch) : 0;
 #pragma unroll
     for (int u = 0; u < RB; ++u) {
-      if (row[u] >= 0 && (last[u] > 0 || a.r.wd != 0.f) && last[u] < t)
-        adam_row_mem<GL, CPL>(reinterpret_cast<float4*>(a.tab[k[u]] + row[u] * a.ldt[k[u]]), reinterpret_cast<float4*>(a.st[k[u]] + row[u] * a.lds[k[u]]),
+      if (row[u] >= 0 && (last[u] > 0 || WD) && last[u] < t)
+        adam_row_mem<GL, CPL, WD>(reinterpret_cast<float4*>(a.tab[k[u]] + row[u] * a.ldt[k[u]]), reinterpret_cast<float4*>(a.st[k[u]] + row[u] * a.lds[k[u]]),
                               a.nch, lane, none, false, t, a.lr, a.eps, a.r);
     }
   }
@@ -1106,7 +1113,8 @@ extern "C" int ktup_shard_adam_catchup(int n_seg, float* const* tables, const in
 #define KTUP_AF(GL, CPL)                                                                                   \
   {                                                                                                        \
     const int grid = grid_for((end + 4 * (256 / GL) - 1) / (4 * (256 / GL)), 256 * 8);                     \
-    hipLaunchKernelGGL((adam_catchup_kernel<GL, CPL>), dim3(grid), dim3(256), 0, st, a);                   \
+    if (a.r.wd != 0.f) hipLaunchKernelGGL((adam_catchup_kernel<GL, CPL, true>), dim3(grid), dim3(256), 0, st, a);  \
+    else hipLaunchKernelGGL((adam_catchup_kernel<GL, CPL, false>), dim3(grid), dim3(256), 0, st, a);            \
     return check_launch(name);                                                                             \
   }
   if (a.nch <= 16) KTUP_AF(16, 1)
@@ -1307,8 +1315,13 @@ extern "C" int ktup_shard_apply(int kind, int n_tables, float* const* tables, co
     op.ar = make_rule(adam_rule);
     for (int t = 0; t < n_tables; ++t) KTUP_REQUIRE(op.w.lds[t] >= KTUP_SHARD_ADAM_STATE_PITCH(d), "%s: table %d: an Adam state row is [m | v | last]: pitch >= 2 d + 4", name, t);
     if (!v4) return set_error(KTUP_ERR_UNSUPPORTED, "%s: Adam rows need d %% 4 == 0 and 16-byte aligned tables, states and gradients", name);
-    ApplyRowsT<true> oa;                                  // same members, the Adam instantiation of the row rule
-    static_assert(sizeof(oa) == sizeof(op), "ApplyRowsT<true> and <false> share one layout");
+    ApplyRowsT<1> oa;                                     // same members, the lazy instantiations of the row rule
+    ApplyRowsT<2> ow;
+    static_assert(sizeof(oa) == sizeof(op) && sizeof(ow) == sizeof(op), "the ApplyRowsT instantiations share one layout");
+    if (op.ar.wd != 0.f) {
+      memcpy(&ow, &op, sizeof(op));
+      return launch_rows(ow, d, v4, op.W + (int64_t)n_small * op.small_rows, (hipStream_t)stream, name);
+    }
     memcpy(&oa, &op, sizeof(op));
     return launch_rows(oa, d, v4, op.W + (int64_t)n_small * op.small_rows, (hipStream_t)stream, name);
   }
@@ -1342,7 +1355,7 @@ extern "C" int ktup_shard_reduce_norm(const float* G, int64_t ldg, int d, int64_
   x.sumsq = sumsq; x.slots = n_slots;
   KTUP_REQUIRE(n_fold >= 0 && (n_fold == 0 || fold), "%s: fold needs its array", name);
   x.fold = n_fold > 0 ? fold : nullptr; x.n_fold = n_fold; x.cursor = cursor;
-  return launch_fused<0, false>(a, grid, st, name, (const ApplyRows*)nullptr, 0, &x);     // the walk + (extra workgroups) the small gradients, the fold, the cursor
+  return launch_fused<0, 0>(a, grid, st, name, (const ApplyRows*)nullptr, 0, &x);     // the walk + (extra workgroups) the small gradients, the fold, the cursor
 }
 
 extern "C" int ktup_shard_reduce_apply(int kind, int n_tables, float* const* tables, const int64_t* ld, float* const* states,
@@ -1396,9 +1409,14 @@ extern "C" int ktup_shard_reduce_apply(int kind, int n_tables, float* const* tab
   op.adagrad = adagrad;
   op.loss_step = loss_step; op.n_loss = n_loss; op.loss_sum = loss_sum; op.skipped = skipped_steps;
   if (adam) {
-    ApplyRowsT<true> oa;
+    if (op.ar.wd != 0.f) {
+      ApplyRowsT<2> ow;
+      memcpy(&ow, &op, sizeof(op));
+      return launch_fused<1, 2>(a, grid, st, name, &ow, op.W + (int64_t)n_small * op.small_rows);
+    }
+    ApplyRowsT<1> oa;
     memcpy(&oa, &op, sizeof(op));
-    return launch_fused<1, true>(a, grid, st, name, &oa, op.W + (int64_t)n_small * op.small_rows);
+    return launch_fused<1, 1>(a, grid, st, name, &oa, op.W + (int64_t)n_small * op.small_rows);
   }
   return launch_fused<1>(a, grid, st, name, &op, op.W + (int64_t)n_small * op.small_rows);
 }
@@ -1421,7 +1439,7 @@ extern "C" int ktup_shard_reduce_store(const float* G, int64_t ldg, int d, int64
   int32_t none = 0;
   if (int e = fill_fused(name, a, G, ldg, d, n_src, src_off, sort_ws, n_entries, n_wire_rows, gwire, ldw, &none)) return e;
   a.xkeys = nullptr;
-  return launch_fused<2, false>(a, fused_grid(n_entries, d), (hipStream_t)stream, name);
+  return launch_fused<2, 0>(a, fused_grid(n_entries, d), (hipStream_t)stream, name);
 }
 
 extern "C" int ktup_shard_bucket(int mode, int n_small, float* const* small_grads, int64_t small_elems, double* bucket,

@@ -54,9 +54,12 @@ def run(data, name, steps, extra, intervals=4):
 
 def main():
     steps = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
+    only = sys.argv[2] if len(sys.argv) > 2 else None          # 'dev' / 'host': that sampling mode alone (bench.py's leg runs 'dev')
     with tempfile.TemporaryDirectory() as tmp:
         make_dataset(tmp, n_users=6040, n_items=3240, n_ent=14708, n_rel=20, n_ratings=120000, n_triples=60000, aligned=2934)
         for name, extra in (('dev', ['-device_sampling']), ('host', ['-nodevice_sampling'])):
+            if only and name != only:
+                continue
             n = steps if name == 'dev' else max(200, steps // 10)
             sps, dt, sps_best, rows = run(tmp, name, n, extra)
             print('%-5s sampling: %8.0f steps/s  (%d steps of B=512 in %.2f s incl. one evaluation pass) = %.2f M scored rows/s'

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Everything under profiles/<tag>_* in one GPU job (run from the repo root on an MI355X box):  bash tools/collect_round.sh r03
 # rocprofv3 runs from /tmp; counter passes are separate from the kernel-trace / stats pass (MI355X_MICROARCH.md).
-TAG=${1:-r05}
+TAG=${1:-r06}
 export TMPDIR=/tmp
 R=$(pwd)
 P=$R/gpurun_out/profiles
@@ -19,10 +19,21 @@ for V in "--kind rec" "--kind kg" "--kind joint" "--kind rec --zipf 1.05" "--kin
   timeout 200 python tools/config5_step.py --steps 200 --full $V 2>/dev/null | grep config
 done > $P/${TAG}_config5_step.txt
 timeout 200 python tools/config5_step.py --steps 300 --full --kind joint --optimizer adam 2>/dev/null | grep config | sed 's/^/--optimizer adam /' >> $P/${TAG}_config5_step.txt
+# Adam in its steady state (400 untimed steps first: nearly every item row then has a state and steps to replay whenever it is touched)
+for V in "--kind joint" "--kind rec" "--kind joint --exchange"; do
+  timeout 300 python tools/config5_step.py --steps 200 --full --optimizer adam --warm 400 $V 2>/dev/null | grep config | sed "s/^/--optimizer adam --warm 400 $V /"
+done >> $P/${TAG}_config5_step.txt
+timeout 200 python tools/config5_step.py --steps 200 --full --kind rec --exchange --segment-graphs 2>/dev/null | grep config | sed 's/^/--exchange --segment-graphs /' >> $P/${TAG}_config5_step.txt
+# what runs beside what in one replayed step (start offsets, durations, hardware queues), one rank and exchange form
+for V in "rec" "rec --exchange" "rec --optimizer adam --warm 400"; do
+  rm -rf /tmp/tl
+  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/tl -- python $R/tools/config5_step.py --steps 60 --full --kind $V > /dev/null 2>&1)
+  echo "=== config5_step.py --full --kind $V"; python tools/trace_timeline.py /tmp/tl pref_bwd_wide 3
+done > $P/${TAG}_config5_timeline.txt 2>&1
 KTUP_WIDE_WAVES=4 timeout 200 python tools/config5_step.py --steps 200 --full --kind rec 2>/dev/null | grep config | sed 's/^/KTUP_WIDE_WAVES=4 /' >> $P/${TAG}_config5_step.txt
-for V in rec kg rec_exchange; do
+for V in rec kg rec_exchange rec_adam; do
   rm -rf /tmp/c5
-  A="--kind rec"; [ $V = kg ] && A="--kind kg"; [ $V = rec_exchange ] && A="--kind rec --exchange"
+  A="--kind rec"; [ $V = kg ] && A="--kind kg"; [ $V = rec_exchange ] && A="--kind rec --exchange"; [ $V = rec_adam ] && A="--kind rec --optimizer adam --warm 400"
   (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/c5 -- python $R/tools/config5_step.py --steps 100 --full --no-overlap $A > /dev/null 2>&1)
   F=$(find /tmp/c5 -name "*kernel_stats.csv" | head -1)
   [ -n "$F" ] && cp $F $P/${TAG}_config5_${V}_kernel_stats.csv
@@ -38,6 +49,7 @@ for W in fed_step eval_pass kg_pass hard_pass soft_l1_pass; do
 done
 timeout 600 python tools/kernel_times.py > $P/${TAG}_kernel_times.txt 2>/dev/null
 timeout 400 python tools/cli_throughput.py > $P/${TAG}_cli_throughput.txt 2>/dev/null
+(timeout 200 python tools/step_profile.py fused; timeout 200 python tools/step_profile.py torch) 2>/dev/null | grep -A14 'STEP' | cut -c1-160 > $P/${TAG}_autograd_step_profile.txt
 timeout 300 python tools/kg_eval_pass.py transh > $P/${TAG}_kg_eval_pass.txt 2>/dev/null
 timeout 300 python tools/kg_eval_pass.py transe >> $P/${TAG}_kg_eval_pass.txt 2>/dev/null
 timeout 300 python tools/kg_eval_pass.py transe l1 >> $P/${TAG}_kg_eval_pass.txt 2>/dev/null

@@ -61,7 +61,7 @@ def fused_main(args):
         top = float(n_rows) ** (-a1)
         r = (1.0 - uu * (1.0 - top)) ** (-1.0 / a1)
         return (r.clamp(1, n_rows) - 1).to(torch.int64)
-    n = args.steps + 10
+    n = args.steps + args.warm
     batches = [(draw(NU), draw(NI), draw(NI)) for _ in range(n)]
     if kg is not None:
         kb = []
@@ -78,7 +78,7 @@ def fused_main(args):
         run = st.run
     else:
         run = None
-    for s in range(10):
+    for s in range(args.warm):
         run() if run else st(*batches[s])
     torch.cuda.synchronize(dev)
     l0 = float(rec.loss_sum[0])
@@ -87,7 +87,7 @@ def fused_main(args):
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()
-    for s in range(10, n):
+    for s in range(args.warm, n):
         run() if run else st(*batches[s])
     ev1.record()
     torch.cuda.synchronize(dev)
@@ -115,6 +115,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--batch', type=int, default=8192)
     ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warm', type=int, default=10, help='untimed steps before the timed ones (Adam / weight decay: a few hundred bring the item rows to their steady state -- every touched row then has steps to replay)')
     ap.add_argument('--d', type=int, default=256)
     ap.add_argument('--optimizer', default='adagrad', choices=['adagrad', 'sgd', 'adam'], help='adam: the row-sparse Adam with catch-up of the untouched steps (ktup_adam_t)')
     ap.add_argument('--kind', default='rec', choices=['rec', 'kg', 'joint'], help='rec: the rec step alone (the round-3 figure); kg: the kg step alone; joint: the 7 : 3 cycle of knowledgable_recommendation.py:320')

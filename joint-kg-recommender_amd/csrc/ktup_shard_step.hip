@@ -419,6 +419,9 @@ KTUP_DEV void adam_row(float4 (&p)[CPL], float4 (&m)[CPL], float4 (&v)[CPL], con
     float4 sv[CPL];
 #pragma unroll
     for (int j = 0; j < CPL; ++j) sv[j] = make_float4(sqrtf(v[j].x), sqrtf(v[j].y), sqrtf(v[j].z), sqrtf(v[j].w));
+    // (unrolled by four: the only loop-carried values are m, sqrt(v), the two powers and the running p -- one multiply each -- so four
+    //  steps' reciprocals and FMAs are in flight together instead of one step's; the steady-state catch-up of config 5 is bound by this loop)
+#pragma unroll 4
     for (int k = 0; k < K; ++k) {
       b1p *= (double)r.b1; b2p *= (double)r.b2;
       const float c1 = lr * __builtin_amdgcn_rcpf((float)(1.0 - b1p));

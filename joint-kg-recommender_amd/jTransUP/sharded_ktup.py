@@ -638,16 +638,26 @@ class ShardedKtupStepper(_ShardedStepBase):
             own_tail = [[oreduce, gnorm, pack_b], [fin_b] + count + [apply_]]
         whole = side is not None and self._whole_step_graph() and self._open_branch()      # one graph: a branch may stay open across the exchanges
         head, nxt = [route_phase(4, stream)], []
-        if self._pipelined():           # this step's route ran during the previous step (into this buffer set); the next step's rides on the
-            head = []                   # branch that carries the sort and the owner's route (or follows the step on one stream)
+        if self._pipelined():           # this step's route ran during the previous step (into this buffer set)
+            head = []
             nxt = [self._route_launch(4, on, keep, 1 - self._bind_par)]
+
+        def later(first):
+            """Whole-step graph: the NEXT step's route leaves the main stream at the requester's reduction and is joined after the bucket
+            launch (55 us of main-stream work -- reduction, gradient exchange, norm walk, bucket -- against ~30 of route).  On the branch
+            that carries the sort and the owner's route it ended 23 us after the step kernel and the reduction waited for it
+            (profiles/r06_config5_timeline.txt, first collection)."""
+            if not nxt:
+                return [first]
+            own_tail[0] = own_tail[0] + [('join',)]
+            return [('beside', [first], nxt)]
         if adam:    # the owner's route of the requested rows moves in front of the pack launch: the catch-up needs its DISTINCT rows
             catch = self._catchup(self.own_ids, self.cap_own, adam, stream, arr)
             if whole:
-                return [head, [oroute_on(stream), catch, ('beside', [pack], [sort_, zshared] + nxt)], [step, ('join',), rstore]] + own_tail
+                return [head, [oroute_on(stream), catch, ('beside', [pack], [sort_, zshared])], [step, ('join',)] + later(rstore)] + own_tail
             return [head, [oroute_on(stream), catch] + par([pack], [sort_, zshared]), par([step, rstore], nxt) if nxt else [step, rstore]] + own_tail
         if whole:   # sort, zero-fill, the owner's route (and the next step's route): one branch from the id exchange to the end of the step kernel
-            return [head, [('beside', [pack], [sort_, zshared, oroute_on(on)] + nxt)], [step, ('join',), rstore]] + own_tail
+            return [head, [('beside', [pack], [sort_, zshared, oroute_on(on)])], [step, ('join',)] + later(rstore)] + own_tail
         return [head, par([pack], [sort_, zshared]), par([step, rstore], [oroute_on(on)] + nxt)] + own_tail
 
     def set_gumbel_uniforms(self, uniforms):
@@ -912,13 +922,19 @@ class ShardedKgStepper(_ShardedStepBase):
         if self._pipelined():
             head = []
             nxt = [self._route_launch(4, on, keep, 1 - self._bind_par)]
+
+        def later(first):           # (ShardedKtupStepper._bind: the next step's route from the requester's reduction to the bucket launch)
+            if not nxt:
+                return [first]
+            own_tail[0] = own_tail[0] + [('join',)]
+            return [('beside', [first], nxt)]
         if adam:
             catch = self._catchup(self.own_ids, self.cap_own, adam, stream, arr)
             if whole:
-                return [head, [oroute_on(stream), catch, ('beside', [pack], [sort_, zshared] + nxt)], [order, step, ('join',), rstore]] + own_tail
+                return [head, [oroute_on(stream), catch, ('beside', [pack], [sort_, zshared])], [order, step, ('join',)] + later(rstore)] + own_tail
             return [head, [oroute_on(stream), catch] + par([pack], [sort_, zshared]), par([order, step, rstore], nxt) if nxt else [order, step, rstore]] + own_tail
         if whole:
-            return [head, [('beside', [pack], [sort_, zshared, oroute_on(on)] + nxt)], [order, step, ('join',), rstore]] + own_tail
+            return [head, [('beside', [pack], [sort_, zshared, oroute_on(on)])], [order, step, ('join',)] + later(rstore)] + own_tail
         return [head, par([pack], [sort_, zshared]), par([order, step, rstore], [oroute_on(on)] + nxt)] + own_tail
 
     def _route_launch(self, phase, on, keep, par=None):

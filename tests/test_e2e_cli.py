@@ -286,6 +286,36 @@ def test_item_cli_shard_tables_transup(dataset):
     assert 'device-resident' in dev_s and len(_metric_rows(dev_s)) >= 3
 
 
+def test_item_cli_shard_tables_transup_torchrun(dataset):
+    """TUP on two ranks (gloo test hook: both share this box's GPU), user / item rows r % 2 on rank r: the exchange form with real
+    all-to-alls and the evaluation on the two shards.  Both ranks log the same losses and metrics, equal to the one-process sharded run on
+    the same global batches."""
+    data = str(dataset)
+    logs = os.path.join(data, 'log')
+    env = dict(os.environ, KTUP_DIST_BACKEND='gloo')
+    tail = ['-nohas_visualization', '-batch_size', '32', '-embedding_size', '64', '-seed', '3', '-eval_interval_steps', '10',
+            '-training_steps', '25', '-early_stopping_steps_to_wait', '0', '-learning_rate', '0.05', '-topn', '10', '-model_type', 'transup',
+            '-num_preferences', '6', '-rec_test_files', 'valid.dat', '-nodevice_sampling', '-shard_tables', '-shard_eval_candidates']
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', '29561', os.path.join(PKG, 'run_item_recommendation.py'), '-data_path', data, '-log_path', logs,
+           '-dataset', 'ml1m', '-experiment_name', 'tup-shard2'] + tail
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    log0 = open(os.path.join(logs, 'tup-shard2.log')).read()
+    log1 = open(os.path.join(logs, 'tup-shard2.rank1.log')).read()
+    assert 'rank 0 of 2' in log0 and 'rank 1 of 2' in log1
+    tl = lambda log: [float(x) for x in re.findall(r'train loss:(\d+\.\d+)', log)]
+    assert tl(log0) == tl(log1) and len(tl(log0)) >= 3
+    assert _metric_rows(log0) == _metric_rows(log1) and len(_metric_rows(log0)) >= 3
+    assert os.path.isfile(os.path.join(logs, 'tup-shard2.ckpt.shard0of2')) and os.path.isfile(os.path.join(logs, 'tup-shard2.rank1.ckpt.shard1of2'))
+    one = subprocess.run([sys.executable, os.path.join(PKG, 'run_item_recommendation.py'), '-data_path', data, '-log_path', logs,
+                          '-dataset', 'ml1m', '-experiment_name', 'tup-shard1'] + tail[:-1], capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stdout[-3000:] + one.stderr[-3000:]
+    log = open(os.path.join(logs, 'tup-shard1.log')).read()
+    assert all(abs(a - b) <= 2e-3 * max(1.0, abs(a)) for a, b in zip(tl(log)[1:], tl(log0)[1:]))
+    assert all(abs(x - y) <= 0.03 for a, b in zip(_metric_rows(log), _metric_rows(log0)) for x, y in zip(a, b))
+
+
 def test_joint_cli_shard_tables_refuses_what_it_cannot_do(dataset):
     data = str(dataset)
     logs = os.path.join(data, 'log')

@@ -50,11 +50,13 @@ def _rec_batches(gen, world, steps, nu, ni, b):
               torch.randint(0, ni, (b,), generator=gen)) for _ in range(world)] for _ in range(steps)]
 
 
-def _dense(full, small0, i2e, schedule, kind, lr, eps, max_norm, l1=False, margin=1.0, kg_lambda=1.0, transh=True, orth=True):
+def _dense(full, small0, i2e, schedule, kind, lr, eps, max_norm, l1=False, margin=1.0, kg_lambda=1.0, transh=True, orth=True, weight_decay=0.0):
     """schedule: list of ('rec', per-rank batches) / ('kg', per-rank batches).  -> tables after the steps, per-step losses."""
     W = [torch.nn.Parameter(full[k].clone()) for k in ('U', 'I', 'E')] + [torch.nn.Parameter(t.clone()) for t in small0]
     U, I, E, Pf, Pn, R, Rn = W
-    opt = torch.optim.Adagrad(W, lr=lr, eps=eps) if kind == 'adagrad' else torch.optim.Adam(W, lr=lr, eps=eps) if kind == 'adam' else torch.optim.SGD(W, lr=lr)
+    wd = weight_decay
+    opt = torch.optim.Adagrad(W, lr=lr, eps=eps, weight_decay=wd) if kind == 'adagrad' else \
+        torch.optim.Adam(W, lr=lr, eps=eps, weight_decay=wd) if kind == 'adam' else torch.optim.SGD(W, lr=lr, weight_decay=wd)
     losses = []
     for what, per in schedule:
         opt.zero_grad(set_to_none=False)      # zero-FILL (torch 0.3): a table keeps being stepped on the steps that do not touch it
@@ -402,3 +404,34 @@ def test_shard_files_restore_after_a_learning_rate_decay(tmp_path):
     d2.sync_model()
     for (k, a), (_, c) in zip(m1.state_dict().items(), m2.state_dict().items()):
         torch.testing.assert_close(a, c, rtol=1e-5, atol=1e-6, msg=k)
+
+
+@pytest.mark.parametrize('form', ['one_graph', 'exchange_form'])
+@pytest.mark.parametrize('kind', ['adagrad', 'sgd', 'adam'])
+def test_joint_schedule_under_weight_decay(kind, form):
+    """The 7 : 3 cycle under -l2_lambda (utils/trainer.py:63-77: weight_decay on every table): the user / item / preference tables owe the
+    decay steps of the three kg steps that do not touch them, every row of every table the steps of the batches that miss it -- replayed
+    when the row is touched again or flushed (ktup_adam_t rule / weight_decay), against torch.optim's dense optimizers over whole tables
+    with zero-filled gradients."""
+    from jTransUP.sharded_ktup import ShardedKtupJoint
+    nu, ni, ne, P, d, b, steps, wd = 500, 250, 450, 20, 100, 96, 12, 1e-3
+    dev = torch.device(DEV)
+    full, small0, i2e, gen = _tables(nu, ni, ne, P, d, seed=47, scale=1.05)
+    sched = _joint_schedule(gen, 1, steps, nu, ni, ne, P, b, 0.7)
+    lr, max_norm = (0.05, 0.5) if kind == 'adagrad' else (0.01, 0.5) if kind == 'adam' else (0.02, 0.5)
+    eps = 1e-5 if kind == 'adam' else 1e-4
+    Wd, losses = _dense(full, small0, i2e, sched, kind, lr, eps, max_norm, kg_lambda=0.5, weight_decay=wd)
+    tabs = _sharded(full, dev, 0, 1)
+    small = [torch.nn.Parameter(t.clone().to(dev)) for t in small0]
+    kw = {'one_graph': {}, 'exchange_form': {'force_exchange': True}}[form]
+    joint = ShardedKtupJoint.build(*tabs, *small, i2e.to(torch.int32).to(dev), batch=b, joint_ratio=0.7, kg_lambda=0.5, kind=kind, lr=lr,
+                                   eps=eps, max_norm=max_norm, weight_decay=wd, **kw)
+    assert joint.rec.lazy and joint.kg.lazy and joint.kg.opt_step is joint.rec.opt_step
+    for what, per in sched:
+        (joint.rec if what == 'rec' else joint.kg).load_batch(*(x.to(dev) for x in per[0]))
+        joint.run()
+    joint.flush()
+    torch.cuda.synchronize()
+    _check(tabs, 'UIE', small, Wd, 0, 1)
+    np.testing.assert_allclose(float(joint.rec.loss_sum.sum()), sum(v for w, v in losses if w == 'rec'), rtol=1e-4)
+    joint.check()

@@ -480,7 +480,9 @@ int ktup_shard_ktup_entries(const int64_t* u, const int64_t* pos_items, const in
                             const int32_t* item2ent, int64_t ent_pad, int64_t* entries, void* stream);
 int ktup_shard_pack_wire(int n_tables, float* const* tables, const int64_t* ld, const int64_t* cap, int d, const int64_t* ids,
                          int64_t n_blocks, float* out, int64_t ldo, void* stream);
-/* Row-sparse ADAM (kind = KTUP_OPT_ADAM in ktup_shard_apply / ktup_shard_reduce_apply) that equals the reference's DENSE Adam
+/* Row-sparse ADAM (kind = KTUP_OPT_ADAM in ktup_shard_apply / ktup_shard_reduce_apply) that reproduces the reference's DENSE Adam
+ * to within ~1e-6 absolute per element (the replay is cut after `replay` steps and seeds its bias corrections from fp32 exponentials;
+ * plain SGD / Adagrad need no replay and are exact)
  * (utils/trainer.py:63-66: torch.optim.Adam over whole tables, weight_decay = l2_lambda = 0; the configuration of the published
  * recipe, ktup.sh:1): a dense Adam step moves every row that ever had a gradient -- m <- beta1 m, v <- beta2 v,
  * p <- p - lr / (1 - beta1^s) m / (sqrt(v) / sqrt(1 - beta2^s) + eps) -- whether the batch touches it or not.  A state row is

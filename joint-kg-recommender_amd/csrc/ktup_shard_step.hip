@@ -314,7 +314,9 @@ KTUP_DEV void vfrom(float4& o, const double* p) { o = make_float4((float)p[0], (
 constexpr int MAXS = KTUP_SHARD_MAX_SMALL;
 constexpr int NSLOT = KTUP_SHARD_SUMSQ_SLOTS;
 
-// ---- row-sparse ADAM that equals the reference's DENSE Adam (utils/trainer.py:63-66: torch.optim.Adam over every table, l2_lambda = 0)
+// ---- row-sparse ADAM that reproduces the reference's DENSE Adam (utils/trainer.py:63-66: torch.optim.Adam over every table, l2_lambda = 0)
+// to within ~1e-6 per element: the replay below is cut after r.replay steps and starts its bias corrections from __expf(last * log beta)
+// (~1e-4 relative on 1 - beta2^last for small `last`; the apply step itself takes the corrections ktup_shard_step_count computed in fp64)
 // A dense Adam step moves EVERY row that has ever received a gradient -- a row the batch does not touch still takes
 //     m <- beta1 m,  v <- beta2 v,  p <- p - lr / (1 - beta1^s) * m / (sqrt(v) / sqrt(1 - beta2^s) + eps)
 // at every step s.  A row's state is kept as [m (d) | v (d) | last (int32) + 3 words of padding] (KTUP_SHARD_ADAM_STATE_PITCH(d) floats);
@@ -451,6 +453,7 @@ KTUP_DEV void adam_row(float4 (&p)[CPL], float4 (&m)[CPL], float4 (&v)[CPL], con
 template <int GL, int CPL, bool WD>
 KTUP_DEV void adam_row_mem(float4* prow, float4* srow, int nch, int lane, const float4 (&g)[CPL], bool has_g, int t, float lr, float eps,
                            const AdamRule& r) {
+  static_assert(GL <= 64, "a lane group reads the row's stamp and lane 0 rewrites it without a barrier: the group must lie inside one wave64");
   int32_t* lastp = reinterpret_cast<int32_t*>(srow + 2 * nch);
   const int last = *lastp;
   const int upto = has_g ? t - 1 : t;

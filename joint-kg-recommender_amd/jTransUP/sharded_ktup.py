@@ -337,6 +337,9 @@ class ShardedKtupStepper(_ShardedStepBase):
         self.betas = (float(betas[0]), float(betas[1]))
         self.has_state = kind != 'sgd' or self.lazy
         self.route_beside = bool(route_beside)
+        if self.lazy and self.route_beside:      # the catch-up needs the route's distinct rows before the step kernel reads them
+            raise ValueError('route_beside (the step kernel beside the whole route) does not exist for the lazy rules (Adam, weight decay): '
+                             'the catch-up of the rows the route names comes before the step kernel')
         if self.tup and (rel is not None or norm is not None or item2ent is not None):
             raise ValueError('without an entity table there is no rel / norm / item2ent (TUP)')
         self.tables = [Ut, It] if self.tup else [Ut, It, Et]

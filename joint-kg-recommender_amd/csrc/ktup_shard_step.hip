@@ -336,13 +336,18 @@ struct AdamRule {
   // closed form for Adagrad / Adam, no geometric tail to cut), from step 1 on (`last` = 0 is a row that has never been written).
   // rule: which optimizer the replay and the step are: 0 Adam, 1 Adagrad (its sum lives in the `v` half of the state row), 2 plain SGD.
   int rule; float wd;
+  int istar;                                            // the step the series form of the replay expands around (make_rule)
 };
 // (a pow() per row and lane -- the bias corrections of the step, the powers the replay starts from -- made the Adam apply walk of config 5
 //  193 us against Adagrad's 47: fp64 pow is several hundred instructions)
 inline AdamRule make_rule(const ktup_adam_t* a) {
-  return AdamRule{a->beta1, a->beta2, a->replay, a->step, logf(a->beta1), logf(a->beta2), a->rule, a->weight_decay};
+  // the replayed increments fall like rho^i, rho = beta1 / sqrt(beta2): their weight sits around step 1 / (1 - rho)
+  const double rho = (double)a->beta1 / sqrt((double)a->beta2);
+  const int istar = rho < 1.0 ? (int)fmin(1048576.0, fmax(1.0, floor(1.0 / (1.0 - rho) + 0.5))) : 1;
+  return AdamRule{a->beta1, a->beta2, a->replay, a->step, logf(a->beta1), logf(a->beta2), a->rule, a->weight_decay, istar};
 }
 
+constexpr int ADAM_SERIES_MIN = 8;      // replays shorter than this stay step by step (the series costs ~a dozen steps of the loop)
 // one zero-gradient step on (p, m, sqrt(v)): sqrt(beta2^k v) = sqrt(v) sqrt(beta2)^k, so the replay carries sqrt(v) and multiplies it -- a
 // square root per element and step was a quarter of the loop (transcendental rate)
 KTUP_DEV void adam_zero_steps(float4& p, float4& m, float4& sv, float c1, float inv_bc2s, float eps, float b1, float sb2) {
@@ -351,6 +356,47 @@ KTUP_DEV void adam_zero_steps(float4& p, float4& m, float4& sv, float c1, float 
   p.c = fmaf(-c1 * m.c, __builtin_amdgcn_rcpf(fmaf(sv.c, inv_bc2s, eps)), p.c);
   KTUP_AZ(x) KTUP_AZ(y) KTUP_AZ(z) KTUP_AZ(w)
 #undef KTUP_AZ
+}
+// The K zero-gradient steps last + 1 .. last + K at once.  Step i moves an element by
+//     lr m0 c_i / (s + e_i),   s = sqrt(v0),   c_i = beta1^i sqrt(bc2_i) / (bc1_i beta2^(i/2)),   e_i = eps sqrt(bc2_i) / beta2^(i/2)
+// (bc1_i = 1 - beta1^(last+i), bc2_i = 1 - beta2^(last+i)): c_i and e_i are the same for every element of every row with this (last, K),
+// only s and m0 are the element's.  e_i drifts slowly (d ln e / di = -ln(beta2) / (2 bc2) = 5e-4 per step once bc2 ~ 1) while c_i falls like
+// 0.9^i, so around a reference E = e_(i*) the sum over i is a short series in U = E / (s + E) in (0, 1]:
+//     sum_i c_i / (s + e_i) = 1 / (s + E) * sum_n (-U)^n R_n,   R_n = sum_i c_i (e_i / E - 1)^n
+// The lanes of the row's group take the steps i (one each, then the next GL ...) and sum R_0 .. R_4 and the remainder's bound
+// R_5 = sum_i c_i |e_i / E - 1|^5 across the group; each element then costs a square root, a reciprocal and a degree-4 Horner form
+// instead of K steps of the recurrence (the steady-state catch-up of config 5 replays ~60 steps x 33 k rows: 95 us of the step's 312
+// were this loop).  The series is taken only when R_5 <= 1e-6 R_0 (the truncation error relative to the row's whole replayed
+// displacement, for every s >= 0); otherwise -- young steps, where bc2 still moves by percents per step -- the caller replays step by step.
+template <int GL, int CPL>
+KTUP_DEV bool adam_zero_series(float4 (&p)[CPL], const float4 (&m)[CPL], const float4 (&v)[CPL], int last, int K, float lr, float eps,
+                               const AdamRule& r, int lane) {
+  if (!(eps > 0.f)) return false;
+  const float tl = (float)last, lrho = fmaf(-0.5f, r.ln2, r.ln1);
+  const float fs = (float)(K < r.istar ? K : r.istar);
+  const float E = eps * sqrtf(-expm1f((tl + fs) * r.ln2)) * __expf(-0.5f * fs * r.ln2);
+  const float iE = 1.f / E;
+  float R0 = 0.f, R1 = 0.f, R2 = 0.f, R3 = 0.f, R4 = 0.f, R5 = 0.f;
+  for (int i = lane + 1; i <= K; i += GL) {
+    const float x = (float)i;
+    const float bc2s = sqrtf(-expm1f((tl + x) * r.ln2));
+    const float c = __expf(x * lrho) * bc2s / -expm1f((tl + x) * r.ln1);
+    const float q = fmaf(eps * bc2s * __expf(-0.5f * x * r.ln2), iE, -1.f), q2 = q * q;
+    R0 += c; R1 = fmaf(c, q, R1); R2 = fmaf(c, q2, R2); R3 = fmaf(c * q, q2, R3); R4 = fmaf(c * q2, q2, R4); R5 = fmaf(c * q2, q2 * fabsf(q), R5);
+  }
+  R0 = group_sum<GL>(R0); R5 = group_sum<GL>(R5);
+  if (!(R5 <= 1e-6f * R0)) return false;
+  R1 = group_sum<GL>(R1); R2 = group_sum<GL>(R2); R3 = group_sum<GL>(R3); R4 = group_sum<GL>(R4);
+#define KTUP_AS(c)                                                                              \
+  {                                                                                             \
+    const float u = __builtin_amdgcn_rcpf(sqrtf(v[j].c) + E), U = E * u;                        \
+    const float h = fmaf(-U, fmaf(-U, fmaf(-U, fmaf(-U, R4, R3), R2), R1), R0);                 \
+    p[j].c = fmaf(-lr * m[j].c, u * h, p[j].c);                                                 \
+  }
+#pragma unroll
+  for (int j = 0; j < CPL; ++j) { KTUP_AS(x) KTUP_AS(y) KTUP_AS(z) KTUP_AS(w) }
+#undef KTUP_AS
+  return true;
 }
 KTUP_DEV void adam_step1(float& p, float& m, float& v, float g, float c1, float bc2s, float eps, float b1, float b2) {
   m = m + (g - m) * (1.f - b1);                      // exp_avg.lerp_(grad, 1 - beta1)          (adam.py _single_tensor_adam, as ktup_optim.hip)
@@ -372,9 +418,9 @@ KTUP_DEV void lazy_step1(int rule, float& p, float& m, float& v, float g, float 
 // bias corrections, a third rule) cost the plain Adam walk of config 5 23 registers, 488 bytes of scratch and a wave per SIMD
 // (seg_fused_kernel<64,1,1,...>: 115 -> 138 VGPRs; joint_adam 0.395 -> 0.474 ms in the bench line) -- the lesson of the Adagrad / Adam
 // split of round 5 once more.
-template <int CPL, bool WD>
+template <int GL, int CPL, bool WD>
 KTUP_DEV void adam_row(float4 (&p)[CPL], float4 (&m)[CPL], float4 (&v)[CPL], const float4 (&g)[CPL], bool has_g, int upto, int last,
-                       float lr, float eps, const AdamRule& r) {
+                       float lr, float eps, const AdamRule& r, int lane) {
   const int miss = upto - last;
   if constexpr (WD) {
     // weight decay: the steps last + 1 .. upto on g = wd * p, exactly as the dense optimizer took them
@@ -416,6 +462,12 @@ KTUP_DEV void adam_row(float4 (&p)[CPL], float4 (&m)[CPL], float4 (&v)[CPL], con
   } else {
   if (last > 0 && miss > 0) {
     const int K = miss < r.replay ? miss : r.replay;
+    // (`last` and K are the row's: the whole lane group takes the same branch)
+    if (K >= ADAM_SERIES_MIN && adam_zero_series<GL, CPL>(p, m, v, last, K, lr, eps, r, lane)) {
+      const float fk = __expf((float)K * r.ln1);               // m as the K replayed steps leave it
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) m[j] = fk * m[j];
+    } else {
     double b1p = (double)__expf((float)last * r.ln1), b2p = (double)__expf((float)last * r.ln2);
     const float sb2 = sqrtf(r.b2);
     float4 sv[CPL];
@@ -430,6 +482,7 @@ KTUP_DEV void adam_row(float4 (&p)[CPL], float4 (&m)[CPL], float4 (&v)[CPL], con
       const float ib = __builtin_amdgcn_rsqf((float)(1.0 - b2p));
 #pragma unroll
       for (int j = 0; j < CPL; ++j) adam_zero_steps(p[j], m[j], sv[j], c1, ib, eps, r.b1, sb2);
+    }
     }
     {   // v after all `miss` steps in closed form (the loop carried its square root); m's remaining decay likewise
       const float f2 = __expf((float)miss * r.ln2);
@@ -464,7 +517,7 @@ KTUP_DEV void adam_row_mem(float4* prow, float4* srow, int nch, int lane, const 
     const int ch = lane + j * GL;
     if (ch < nch) { p[j] = prow[ch]; m[j] = srow[ch]; v[j] = srow[nch + ch]; } else { p[j] = f4zero(); m[j] = f4zero(); v[j] = f4zero(); }
   }
-  adam_row<CPL, WD>(p, m, v, g, has_g, upto, last, lr, eps, r);
+  adam_row<GL, CPL, WD>(p, m, v, g, has_g, upto, last, lr, eps, r, lane);
 #pragma unroll
   for (int j = 0; j < CPL; ++j) {
     const int ch = lane + j * GL;

@@ -322,12 +322,16 @@ def test_stepper_adam_equals_the_dense_adam(d, P, form):
     st.check()
 
 
-@pytest.mark.parametrize('gap', [1, 7, 109, 110, 111, 400])
-def test_adam_flush_replays_the_untouched_steps(gap):
+@pytest.mark.parametrize('base', [0, 300, 20000])
+@pytest.mark.parametrize('gap', [1, 7, 8, 60, 109, 110, 111, 400])
+def test_adam_flush_replays_the_untouched_steps(gap, base):
     """ktup_shard_adam_flush against the dense recurrence written out in float64: a row whose state was written at step `last` is
     taken through steps last + 1 .. t with a zero gradient -- m <- beta1 m, v <- beta2 v, p <- p - lr / (1 - beta1^s) m / (sqrt(v /
     (1 - beta2^s)) + eps) -- one after the other; beyond 110 replayed steps (adam_replay: the increments have fallen below 1e-5 of
-    the first) only m and v keep decaying.  Rows never touched (last = 0) stay as they are."""
+    the first) only m and v keep decaying.  Rows never touched (last = 0) stay as they are.
+    `base`: how old the rows' states are.  Young states (bias correction 1 - beta2^s still moving by percents per step) are replayed
+    step by step; from a few hundred steps on a replay of eight steps or more is the series form (ktup_shard_step.hip
+    adam_zero_series) -- the same float64 recurrence is the reference for both."""
     import ctypes
     from jTransUP.hip import lib as L
     from jTransUP.sharded_ktup import AdamRule, adam_replay, adam_state_pitch
@@ -337,7 +341,7 @@ def test_adam_flush_replays_the_untouched_steps(gap):
     m0 = 1e-2 * torch.randn(n, d, generator=gen)
     v0 = (m0 ** 2) * (0.2 + 3 * torch.rand(n, d, generator=gen)) + 1e-12
     m0[:, :7] *= 1e-7; v0[:, :7] = m0[:, :7] ** 2              # elements where eps carries the denominator (|g| ~ 1e-9 < eps)
-    last = torch.randint(1, 60, (n,), generator=gen).to(torch.int32)
+    last = (base + torch.randint(1, 60, (n,), generator=gen)).to(torch.int32)
     last[::9] = 0
     m0[last == 0] = 0; v0[last == 0] = 0
     t = int(last.max()) + gap
@@ -351,7 +355,7 @@ def test_adam_flush_replays_the_untouched_steps(gap):
            torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     p, m, v = p0.double().clone(), m0.double().clone(), v0.double().clone()
-    for s in range(1, t + 1):
+    for s in range(base + 1, t + 1):
         on = (last.long() > 0) & (last.long() < s)
         m[on] *= b1; v[on] *= b2
         p[on] -= lr / (1 - b1 ** s) * m[on] / (v[on].sqrt() / (1 - b2 ** s) ** 0.5 + eps)

@@ -488,8 +488,9 @@ int ktup_shard_pack_wire(int n_tables, float* const* tables, const int64_t* ld, 
  * p <- p - lr / (1 - beta1^s) m / (sqrt(v) / sqrt(1 - beta2^s) + eps) -- whether the batch touches it or not.  A state row is
  * [m (d) | v (d) | last (int32) | 3 words of padding], KTUP_SHARD_ADAM_STATE_PITCH(d) floats; `last` = the step the row's state was
  * written at (0: never).  Touching a row at step t first REPLAYS the zero-gradient steps last + 1 .. t - 1 in registers (the dense
- * recurrence, step by step; after `replay` steps, when the increments have fallen below ~1e-5 of the first, only m and v keep
- * decaying in closed form), then applies step t.  `step` points at TWO device int64: step[0] = the number of the step being applied,
+ * recurrence, step by step -- or, for eight steps or more of a state old enough that its bias corrections move slowly, as ONE series
+ * per row in eps / (sqrt(v) + eps) whose remainder is bounded below 1e-6 of the replayed displacement; after `replay` steps, when the
+ * increments have fallen below ~1e-5 of the first, only m and v keep decaying in closed form), then applies step t.  `step` points at TWO device int64: step[0] = the number of the step being applied,
  * step[1] = that step's bias corrections {1 - beta1^t, sqrt(1 - beta2^t)} as two floats; ktup_shard_step_count -- the launch before
  * the apply launch, and the only writer of both -- moves the counter (+1 unless the step is skipped) and refreshes them.  ktup_shard_adam_flush replays every row of a shard up to
  * *step (before an evaluation or a checkpoint reads the table).

@@ -22,6 +22,7 @@
 #include "ktup_pref_geom.h"
 #include <cstring>
 
+#include "ktup_lane_swap.h"
 #include "ktup_rows.h"
 
 using namespace ktup;
@@ -321,8 +322,8 @@ constexpr int NSLOT = KTUP_SHARD_SUMSQ_SLOTS;
 //     m <- beta1 m,  v <- beta2 v,  p <- p - lr / (1 - beta1^s) * m / (sqrt(v) / sqrt(1 - beta2^s) + eps)
 // at every step s.  A row's state is kept as [m (d) | v (d) | last (int32) + 3 words of padding] (KTUP_SHARD_ADAM_STATE_PITCH(d) floats);
 // `last` = the step its state was written at (0: never touched: m = v = 0 and the row has not moved).  Whoever touches a row at step t
-// first REPLAYS the zero-gradient steps last + 1 .. t - 1 in registers -- exactly the dense recurrence, one step after the other --
-// then applies step t.  The replayed increments fall like (beta1 / sqrt(beta2))^k, so the replay stops after `replay` steps (the host
+// first REPLAYS the zero-gradient steps last + 1 .. t - 1 in registers -- the dense recurrence, one step after the other, or (eight steps
+// or more of a state that is not young: adam_zero_series below) their sum as one short series per row -- then applies step t.  The replayed increments fall like (beta1 / sqrt(beta2))^k, so the replay stops after `replay` steps (the host
 // picks it so that what is dropped is below 1e-4 of the first increment, i.e. < 2e-6 absolute at the learning rates in use) and the
 // remaining steps only decay m and v (closed form).  ktup_shard_adam_flush brings every row of a shard up to the current step (before an
 // evaluation or a checkpoint reads the tables).
@@ -367,29 +368,49 @@ KTUP_DEV void adam_zero_steps(float4& p, float4& m, float4& sv, float c1, float 
 // R_5 = sum_i c_i |e_i / E - 1|^5 across the group; each element then costs a square root, a reciprocal and a degree-4 Horner form
 // instead of K steps of the recurrence (the steady-state catch-up of config 5 replays ~60 steps x 33 k rows: 95 us of the step's 312
 // were this loop).  The series is taken only when R_5 <= 1e-6 R_0 (the truncation error relative to the row's whole replayed
-// displacement, for every s >= 0); otherwise -- young steps, where bc2 still moves by percents per step -- the caller replays step by step.
+// displacement, for every s >= 0); otherwise -- young steps, where bc2 still moves by percents per step -- the caller replays step by step.  ~190 instructions per row at d = 256 (the first version, with expm1f / sqrtf / a division per
+// lane and step and shuffles through LDS for the six sums, was 540 and a third of the catch-up kernel's time).
+// Sum over the G lanes of a group, in all of them, without LDS: DPP inside a row of 16, the gfx950 lane swaps across rows.
+template <int G>
+KTUP_DEV float group_sum_dpp(float v) {
+#define KTUP_DPP_ADD(ctrl) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xf, 0xf, true));
+  KTUP_DPP_ADD(0xB1)      // quad_perm:[1,0,3,2]
+  KTUP_DPP_ADD(0x4E)      // quad_perm:[2,3,0,1]
+  KTUP_DPP_ADD(0x141)     // row_half_mirror
+  KTUP_DPP_ADD(0x140)     // row_mirror
+#undef KTUP_DPP_ADD
+  if constexpr (G >= 32) v = swap16_sum(v, v);
+  if constexpr (G >= 64) v = swap32_sum(v, v);
+  return v;
+}
+// 1 - e^x for x <= 0 without cancellation: the hardware exponential below -1/4, the Taylor polynomial (remainder < 2e-9 relative) above
+KTUP_DEV float one_minus_exp(float x) {
+  const float t = fmaf(x, fmaf(x, fmaf(x, fmaf(x, fmaf(x, fmaf(x, 1.f / 5040.f, 1.f / 720.f), 1.f / 120.f), 1.f / 24.f), 1.f / 6.f), 0.5f), 1.f);
+  return x > -0.25f ? -x * t : 1.f - __expf(x);
+}
 template <int GL, int CPL>
 KTUP_DEV bool adam_zero_series(float4 (&p)[CPL], const float4 (&m)[CPL], const float4 (&v)[CPL], int last, int K, float lr, float eps,
                                const AdamRule& r, int lane) {
+  const float tl = (float)last;
   if (!(eps > 0.f)) return false;
-  const float tl = (float)last, lrho = fmaf(-0.5f, r.ln2, r.ln1);
+  const float lrho = fmaf(-0.5f, r.ln2, r.ln1);
   const float fs = (float)(K < r.istar ? K : r.istar);
-  const float E = eps * sqrtf(-expm1f((tl + fs) * r.ln2)) * __expf(-0.5f * fs * r.ln2);
-  const float iE = 1.f / E;
+  const float E = eps * __builtin_amdgcn_sqrtf(one_minus_exp((tl + fs) * r.ln2)) * __expf(-0.5f * fs * r.ln2);
+  const float iE = __builtin_amdgcn_rcpf(E);
   float R0 = 0.f, R1 = 0.f, R2 = 0.f, R3 = 0.f, R4 = 0.f, R5 = 0.f;
   for (int i = lane + 1; i <= K; i += GL) {
     const float x = (float)i;
-    const float bc2s = sqrtf(-expm1f((tl + x) * r.ln2));
-    const float c = __expf(x * lrho) * bc2s / -expm1f((tl + x) * r.ln1);
+    const float bc2s = __builtin_amdgcn_sqrtf(one_minus_exp((tl + x) * r.ln2));
+    const float c = __expf(x * lrho) * bc2s * __builtin_amdgcn_rcpf(one_minus_exp((tl + x) * r.ln1));
     const float q = fmaf(eps * bc2s * __expf(-0.5f * x * r.ln2), iE, -1.f), q2 = q * q;
     R0 += c; R1 = fmaf(c, q, R1); R2 = fmaf(c, q2, R2); R3 = fmaf(c * q, q2, R3); R4 = fmaf(c * q2, q2, R4); R5 = fmaf(c * q2, q2 * fabsf(q), R5);
   }
-  R0 = group_sum<GL>(R0); R5 = group_sum<GL>(R5);
+  R0 = group_sum_dpp<GL>(R0); R5 = group_sum_dpp<GL>(R5);
   if (!(R5 <= 1e-6f * R0)) return false;
-  R1 = group_sum<GL>(R1); R2 = group_sum<GL>(R2); R3 = group_sum<GL>(R3); R4 = group_sum<GL>(R4);
+  R1 = group_sum_dpp<GL>(R1); R2 = group_sum_dpp<GL>(R2); R3 = group_sum_dpp<GL>(R3); R4 = group_sum_dpp<GL>(R4);
 #define KTUP_AS(c)                                                                              \
   {                                                                                             \
-    const float u = __builtin_amdgcn_rcpf(sqrtf(v[j].c) + E), U = E * u;                        \
+    const float u = __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v[j].c) + E), U = E * u;       \
     const float h = fmaf(-U, fmaf(-U, fmaf(-U, fmaf(-U, R4, R3), R2), R1), R0);                 \
     p[j].c = fmaf(-lr * m[j].c, u * h, p[j].c);                                                 \
   }
@@ -473,9 +494,9 @@ KTUP_DEV void adam_row(float4 (&p)[CPL], float4 (&m)[CPL], float4 (&v)[CPL], con
     float4 sv[CPL];
 #pragma unroll
     for (int j = 0; j < CPL; ++j) sv[j] = make_float4(sqrtf(v[j].x), sqrtf(v[j].y), sqrtf(v[j].z), sqrtf(v[j].w));
-    // (unrolled by four: the only loop-carried values are m, sqrt(v), the two powers and the running p -- one multiply each -- so four
-    //  steps' reciprocals and FMAs are in flight together instead of one step's; the steady-state catch-up of config 5 is bound by this loop)
-#pragma unroll 4
+    // (not unrolled: with the series above this loop only takes short replays and young states, and unrolled by four it cost the
+    //  catch-up kernel 21 registers = a wave per SIMD: steady-state config-5 step 0.238 -> 0.233 ms)
+#pragma unroll 1
     for (int k = 0; k < K; ++k) {
       b1p *= (double)r.b1; b2p *= (double)r.b2;
       const float c1 = lr * __builtin_amdgcn_rcpf((float)(1.0 - b1p));

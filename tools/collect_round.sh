@@ -19,13 +19,13 @@ for V in "--kind rec" "--kind kg" "--kind joint" "--kind rec --zipf 1.05" "--kin
   timeout 200 python tools/config5_step.py --steps 200 --full $V 2>/dev/null | grep config
 done > $P/${TAG}_config5_step.txt
 timeout 200 python tools/config5_step.py --steps 300 --full --kind joint --optimizer adam 2>/dev/null | grep config | sed 's/^/--optimizer adam /' >> $P/${TAG}_config5_step.txt
-# Adam in its steady state (400 untimed steps first: nearly every item row then has a state and steps to replay whenever it is touched)
+# Adam in its steady state (1,500 untimed steps first: every item and entity row then has a state and steps to replay whenever it is touched)
 for V in "--kind joint" "--kind rec" "--kind joint --exchange"; do
-  timeout 300 python tools/config5_step.py --steps 200 --full --optimizer adam --warm 400 $V 2>/dev/null | grep config | sed "s/^/--optimizer adam --warm 400 $V /"
+  timeout 300 python tools/config5_step.py --steps 200 --full --optimizer adam --warm 1500 $V 2>/dev/null | grep config | sed "s/^/--optimizer adam --warm 1500 $V /"
 done >> $P/${TAG}_config5_step.txt
 timeout 200 python tools/config5_step.py --steps 200 --full --kind rec --exchange --segment-graphs 2>/dev/null | grep config | sed 's/^/--exchange --segment-graphs /' >> $P/${TAG}_config5_step.txt
 # what runs beside what in one replayed step (start offsets, durations, hardware queues), one rank and exchange form
-for V in "rec" "rec --exchange" "rec --optimizer adam --warm 400"; do
+for V in "rec" "rec --exchange" "rec --optimizer adam --warm 1500"; do
   rm -rf /tmp/tl
   (cd /tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/tl -- python $R/tools/config5_step.py --steps 60 --full --kind $V > /dev/null 2>&1)
   echo "=== config5_step.py --full --kind $V"; python tools/trace_timeline.py /tmp/tl pref_bwd_wide 3
@@ -33,7 +33,7 @@ done > $P/${TAG}_config5_timeline.txt 2>&1
 KTUP_WIDE_WAVES=4 timeout 200 python tools/config5_step.py --steps 200 --full --kind rec 2>/dev/null | grep config | sed 's/^/KTUP_WIDE_WAVES=4 /' >> $P/${TAG}_config5_step.txt
 for V in rec kg rec_exchange rec_adam; do
   rm -rf /tmp/c5
-  A="--kind rec"; [ $V = kg ] && A="--kind kg"; [ $V = rec_exchange ] && A="--kind rec --exchange"; [ $V = rec_adam ] && A="--kind rec --optimizer adam --warm 400"
+  A="--kind rec"; [ $V = kg ] && A="--kind kg"; [ $V = rec_exchange ] && A="--kind rec --exchange"; [ $V = rec_adam ] && A="--kind rec --optimizer adam --warm 1500"
   (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/c5 -- python $R/tools/config5_step.py --steps 100 --full --no-overlap $A > /dev/null 2>&1)
   F=$(find /tmp/c5 -name "*kernel_stats.csv" | head -1)
   [ -n "$F" ] && cp $F $P/${TAG}_config5_${V}_kernel_stats.csv

@@ -29,7 +29,7 @@ def _world_tables(nu, ni, ne, P, d, seed, pad_every=0):
     return full, small, i2e, gen
 
 
-def _dense_reference(full, small0, i2e, batches, kind, lr, eps, max_norm, l1=False, orth=False, weight_decay=0.0, uniforms=None):
+def _dense_reference(full, small0, i2e, batches, kind, lr, eps, max_norm, l1=False, orth=False, weight_decay=0.0, uniforms=None, adam_init=None):
     """One process, whole tables, the global batch: returns the tables after the steps and the per-step losses."""
     ne = full['E'].shape[0]
     E_pad = torch.cat([full['E'], torch.zeros(1, full['E'].shape[1])])           # pad row = ent_total - 1 (jTransUP.py:46,96)
@@ -39,6 +39,12 @@ def _dense_reference(full, small0, i2e, batches, kind, lr, eps, max_norm, l1=Fal
     wd = weight_decay
     opt = torch.optim.Adagrad(W, lr=lr, eps=eps, weight_decay=wd) if kind == 'adagrad' else \
         torch.optim.Adam(W, lr=lr, eps=eps, weight_decay=wd) if kind == 'adam' else torch.optim.SGD(W, lr=lr, weight_decay=wd)
+    if adam_init is not None:                 # an optimizer that has already run t0 steps: (t0, first moments, second moments) per table
+        t0, M, V = adam_init
+        for w, m, v in zip(W, M, V):
+            pad = w.shape[0] - m.shape[0]     # (the entity table's pad row)
+            opt.state[w] = {'step': torch.tensor(float(t0)), 'exp_avg': torch.cat([m, torch.zeros(pad, m.shape[1])]).clone(),
+                            'exp_avg_sq': torch.cat([v, torch.zeros(pad, v.shape[1])]).clone()}
     losses = []
     for k_step, step in enumerate(batches):
         opt.zero_grad(set_to_none=False)      # zero-FILL, like the torch 0.3 of the reference: Adam keeps moving every table it has ever stepped
@@ -57,7 +63,7 @@ def _dense_reference(full, small0, i2e, batches, kind, lr, eps, max_norm, l1=Fal
     return [w.data for w in W], losses
 
 
-def _run_stepper(full, small0, i2e, batches, kind, lr, eps, max_norm, rank, world, dev, l1=False, orth=False, uniforms=None, **kw):
+def _run_stepper(full, small0, i2e, batches, kind, lr, eps, max_norm, rank, world, dev, l1=False, orth=False, uniforms=None, adam_init=None, **kw):
     from jTransUP import parallel
     from jTransUP.sharded_ktup import ShardedKtupStepper
     d = full['U'].shape[1]
@@ -68,6 +74,16 @@ def _run_stepper(full, small0, i2e, batches, kind, lr, eps, max_norm, rank, worl
     B = batches[0][rank][0].numel()
     st = ShardedKtupStepper(Ut, It, Et, *small, i2e.to(torch.int32).to(dev), batch=B, kind=kind, lr=lr, eps=eps, max_norm=max_norm,
                             l1=l1, orth=orth, **kw)
+    if adam_init is not None:                 # every row's state as written at step t0
+        t0, M, V = adam_init
+        for t, m, v in zip((Ut, It, Et), M[:3], V[:3]):
+            own = torch.arange(rank, t.total_rows, world)
+            t.state[:, :d] = m[own].to(dev); t.state[:, d:2 * d] = v[own].to(dev)
+            t.state[:, 2 * d] = torch.full((own.numel(),), t0, dtype=torch.int32).view(torch.float32).to(dev)
+        for sst, m, v in zip(st.small_state, M[3:], V[3:]):
+            sst[:, :d] = m.to(dev); sst[:, d:2 * d] = v.to(dev)
+            sst[:, 2 * d] = torch.full((m.shape[0],), t0, dtype=torch.int32).view(torch.float32).to(dev)
+        st.opt_step[0] = t0
     for k_step, step in enumerate(batches):
         if uniforms is not None:              # this rank's rows of the recorded draws, positives then negatives
             st.set_gumbel_uniforms(torch.cat([x[rank * B:(rank + 1) * B] for x in uniforms[k_step]]).to(dev))
@@ -319,6 +335,31 @@ def test_stepper_adam_equals_the_dense_adam(d, P, form):
         last = t.state[:, 2 * d].view(torch.int32)
         touched = last > 0
         assert bool((last[touched] == steps).all()) and torch.equal(t.weight.data[~touched].cpu(), full[key][~touched.cpu()])
+    st.check()
+
+
+@pytest.mark.parametrize('form', ['one_graph', 'exchange_form'])
+def test_stepper_adam_on_old_states_takes_the_series(form):
+    """The same comparison 5,000 steps into a run: every row carries first and second moments written at step 5,000, the batches are
+    small (32 pairs over 900 users / 300 items / 700 entities), so a row rests for 5-30 steps between two touches and its catch-up is
+    the SERIES form of the replay (ktup_shard_step.hip adam_zero_series: eight steps or more of a state whose bias corrections have
+    settled) -- inside the stepper's own launches, catch-up and apply walk, against torch.optim.Adam handed the same state."""
+    nu, ni, ne, b, steps, d, P, t0 = 900, 300, 700, 32, 40, 128, 20, 5000
+    full, small0, i2e, gen = _world_tables(nu, ni, ne, P, d, seed=77, pad_every=7)
+    batches = _batches(gen, 1, steps, nu, ni, b)
+    shapes = [full['U'].shape, full['I'].shape, full['E'].shape] + [t.shape for t in small0]
+    M = [1e-3 * torch.randn(*sh, generator=gen) for sh in shapes]
+    V = [(m ** 2) * (0.3 + 2 * torch.rand(*m.shape, generator=gen)) + 1e-14 for m in M]
+    # (no elements with sqrt(v) below eps here: the first gradient such an element sees moves it by ~3 lr whatever the gradient's size,
+    #  with the sign of a number that may be rounding noise -- test_adam_flush_replays_the_untouched_steps has them, without a model around)
+    lr, max_norm = 0.01, 0.5
+    init = (t0, M, V)
+    Wd, losses = _dense_reference(full, small0, i2e, batches, 'adam', lr, 1e-8, max_norm, orth=True, adam_init=init)
+    kw = {'one_graph': {}, 'exchange_form': {'force_exchange': True}}[form]
+    tables, small, st = _run_stepper(full, small0, i2e, batches, 'adam', lr, 1e-8, max_norm, 0, 1, torch.device(DEV), orth=True, adam_init=init, **kw)
+    assert int(st.opt_step[0].item()) == t0 + steps
+    _check(tables, small, Wd, 0, 1, atol=6e-5)                   # 40 steps of two float32 runs (the nine-step tests: 2e-5; measured here: 3.5e-5)
+    np.testing.assert_allclose(float(st.loss_sum.sum()), sum(losses), rtol=1e-4)
     st.check()
 
 

@@ -1025,9 +1025,9 @@ def config5_leg(device, world, rank, steps=100, warmup=10, batch=8192, full=True
     out = {'backend': dist.get_backend() if world > 1 else 'single process', 'world': world, 'batch_per_rank': B,
            'rows': {'users': NUs, 'items': NIs, 'entities': NEs}, 'd': d, 'tables_GB_per_rank': (NUs + NIs + NEs) * d * 4 / world / 1e9}
 
-    def run(label, what='rec', kind='adagrad', warm=None, **kw):
+    def run(label, what='rec', kind='adagrad', warm=None, cycle=0, **kw):
         warm = warmup if warm is None else warm
-        n = steps + warm
+        n = steps + warm + (steps + 2 * cycle if cycle else 0)
         rec = ShardedKtupStepper(Ut, It, Et, *small, item2ent, batch=B, kind=kind, lr=0.005, max_norm=5.0, orth=(what != 'rec'), **kw)
         rec.set_feed([torch.randint(0, hi, (n, B), generator=gen, device=device) for hi in (NUs, NIs, NIs)])   # device-fed: the step's own launches walk the columns
         st = rec
@@ -1054,9 +1054,20 @@ def config5_leg(device, world, rank, steps=100, warmup=10, batch=8192, full=True
         e1.record()
         torch.cuda.synchronize(device)
         wall = _max_over_ranks(1e3 * (time.perf_counter() - t0) / steps, device, world)
+        cyc = None
+        if cycle and world == 1:         # the same steps in graphs of `cycle` steps (run_cycle): one graph launch per cycle, the next route joined between steps
+            st.run_cycle(cycle); st.run_cycle(cycle)
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            for _ in range(steps // cycle):
+                st.run_cycle(cycle)
+            torch.cuda.synchronize(device)
+            cyc = 1e3 * (time.perf_counter() - t0) / (steps // cycle * cycle)
         st.check()
         leg = {'ms_per_step': wall, 'ms_per_step_device': e0.elapsed_time(e1) / steps, 'scored_rows_per_s': 2 * B * world / (wall * 1e-3),
                'wire_rows_per_rank': rec.W if what != 'kg' else st.W, 'graph_segments': len(rec._graphs) if rec._graphs else 0}
+        if cyc is not None:
+            leg['ms_per_step_in_%d_step_graphs' % cycle] = cyc
         if what != 'rec':
             leg['what'] = {'kg': 'kg steps only (TransH on the entity shard: 2B scored triples per step)',
                            'joint': 'the 7 rec : 3 kg cycle of knowledgable_recommendation.py:320 over shared tables and Adagrad sums'}[what]
@@ -1072,7 +1083,7 @@ def config5_leg(device, world, rank, steps=100, warmup=10, batch=8192, full=True
         rec.close()
         del st
         return leg
-    out.update(run('default'))
+    out.update(run('default', cycle=10))
     out['kg_step'] = run('kg', what='kg')
     out['joint'] = run('joint', what='joint')
     if world == 1:

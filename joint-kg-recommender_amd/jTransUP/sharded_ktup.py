@@ -148,7 +148,7 @@ class _ShardedStepBase(object):
         that holds its captured collectives is alive: `destroy_process_group()` then waits forever (seen with RCCL's all-to-all inside the
         whole-step graph) -- call this (ShardedKtupJoint.close closes both steppers) before tearing the group down."""
         torch.cuda.synchronize(self.dev)
-        self._graphs = self._graphs1 = None
+        self._graphs = self._graphs1 = self._cycles = None
         self._graph_keep = self._graph_keep1 = None
         self._eager = None
 
@@ -208,6 +208,41 @@ class _ShardedStepBase(object):
             if self.multi and len(graphs) > 1:
                 self._exchange(k)
         self.steps += 1
+
+    def run_cycle(self, n):
+        """`n` steps (even) on the next n batches of the feed columns as ONE graph replay.  One rank, device-fed, pipelined route: inside a
+        graph of several steps the route of step s + 1 -- forked at the first launch of step s -- is joined in front of step s + 1's
+        first launch instead of in front of step s's apply walk, where the main branch WAITED for it (the route beside the step kernel ends
+        ~5 us after the norm walk, and a cross-queue join that has to wait costs ~12 us on top: profiles/r06_config5_timeline.txt; a join
+        whose branch ended long ago costs ~6), and n steps pay for one graph launch.  Anything else (several ranks, host-fed batches, an
+        odd n, the warm-up steps) runs the steps one by one.  Same launches, same order per step, same results as n calls of run()."""
+        n = int(n)
+        if n <= 0:
+            return
+        ok = self.use_graphs and not self.multi and self._double() and self.overlap_route and self._routed and self.steps >= 2 and n % 2 == 0 \
+            and getattr(self, 'fused_apply', True)
+        if not ok:
+            for _ in range(n):
+                self.run()
+            return
+        par = self._par
+        if self._cycles is None:
+            self._cycles = {}
+        hit = self._cycles.get((n, par))
+        if hit is None:
+            graph, keeps = torch.cuda.CUDAGraph(), []
+            with L.capture(graph):
+                cs = torch.cuda.current_stream(self.dev).cuda_stream
+                for j in range(n):
+                    self._use(par ^ (j & 1))
+                    seg = self._bind(cs, self._side.cuda_stream)[0]
+                    keeps.append(self._keep)
+                    # the step's launches with the join moved behind its last one (= in front of the next step's first)
+                    self._issue([x for x in seg if x != ('join',)] + [('join',)], self._side)
+            hit = self._cycles[(n, par)] = (graph, keeps)
+        self._use(par)
+        hit[0].replay()
+        self.steps += n
 
     def _issue(self, seg, side):
         for item in seg:
@@ -450,7 +485,7 @@ class ShardedKtupStepper(_ShardedStepBase):
             self.own_xkeys = i32(max(2, lib.ktup_shard_reduce_list_len(W, d)))
             self.bucket = torch.zeros(n_g * P * d + 2, dtype=torch.float64, device=dev)
         self._eager = None
-        self._graphs = self._graphs1 = None
+        self._graphs = self._graphs1 = self._cycles = None
         self._graph_steps = 0
         self._fed = self._routed = False
 
@@ -679,7 +714,7 @@ class ShardedKtupStepper(_ShardedStepBase):
         if rebind:                                            # the gate's arguments are baked into the bound launches
             torch.cuda.synchronize(self.dev)
             self._eager = None
-            self._graphs = self._graphs1 = None
+            self._graphs = self._graphs1 = self._cycles = None
 
     def _route_launch(self, phase, on, keep, par=None):
         """ktup_shard_route_ktup, pre-bound (phases: include/ktup_hip.h), writing buffer set `par` (default: the set in use).  Several
@@ -720,7 +755,7 @@ class ShardedKtupStepper(_ShardedStepBase):
         self._fed, self._routed, self._par = columns is not None, False, 0
         self.cursor.zero_()
         self._eager = None
-        self._graphs = self._graphs1 = None                   # the column addresses are baked into the bound launches
+        self._graphs = self._graphs1 = self._cycles = None                   # the column addresses are baked into the bound launches
 
     def __call__(self, u=None, pos_items=None, neg_items=None):
         if u is not None:
@@ -834,7 +869,7 @@ class ShardedKgStepper(_ShardedStepBase):
             self.own_xkeys = i32(max(2, lib.ktup_shard_reduce_list_len(W, d)))
             self.bucket = torch.zeros(len(self.small) * P * d + 2, dtype=torch.float64, device=dev)
         self._eager = None
-        self._graphs = self._graphs1 = None
+        self._graphs = self._graphs1 = self._cycles = None
         self._fed = self._routed = False
 
     def _bind(self, stream, side=None):
@@ -973,7 +1008,7 @@ class ShardedKgStepper(_ShardedStepBase):
         self._fed, self._routed, self._par = columns is not None, False, 0
         self.cursor.zero_()
         self._eager = None
-        self._graphs = self._graphs1 = None
+        self._graphs = self._graphs1 = self._cycles = None
 
     def __call__(self, *ids):
         if ids:
@@ -1016,6 +1051,21 @@ class ShardedKtupJoint(object):
     def run(self):
         (self.rec if self.is_rec() else self.kg).run()
         self.steps += 1
+
+    def run_cycle(self, n):
+        """The next n steps of the schedule, every stretch of rec (kg) steps as one graph replay of its stepper (run_cycle: an even number
+        of steps per replay, an odd stretch's last step by itself)."""
+        left = int(n)
+        while left > 0:
+            rec, run = self.is_rec(), 0
+            while run < left and self.is_rec(self.steps + run) == rec:
+                run += 1
+            st = self.rec if rec else self.kg
+            st.run_cycle(run - (run & 1))
+            if run & 1:
+                st.run()
+            self.steps += run
+            left -= run
 
     def check(self):
         self.rec.check()

@@ -338,6 +338,38 @@ def test_stepper_adam_equals_the_dense_adam(d, P, form):
     st.check()
 
 
+@pytest.mark.parametrize('kind', ['adagrad', 'adam'])
+def test_run_cycle_is_the_same_steps_in_one_graph(kind):
+    """run_cycle(n): n device-fed steps as ONE graph replay (the next step's route joined in front of the next step instead of in front
+    of this step's apply walk) -- the same launches in the same order, so the same tables as step-by-step replays and as the dense
+    reference; ten steps over three batches: two by themselves (warm-up), then two cycles of four."""
+    from jTransUP import parallel
+    from jTransUP.sharded_ktup import ShardedKtupStepper
+    nu, ni, ne, b, d, P = 700, 250, 500, 256, 128, 20
+    dev = torch.device(DEV)
+    full, small0, i2e, gen = _world_tables(nu, ni, ne, P, d, seed=43)
+    three = _batches(gen, 1, 3, nu, ni, b)
+    order = [0, 1, 2, 0, 1, 2, 0, 1, 2, 0]
+    lr, eps = (0.01, 1e-5) if kind == 'adam' else (0.05, 1e-4)
+    Wd, losses = _dense_reference(full, small0, i2e, [three[k] for k in order], kind, lr, eps, 0.5)
+    mk = lambda key: parallel.ShardedTable(full[key].shape[0], d, rank=0, world=1, device=dev, init=lambda g: full[key][g].to(dev))
+    Ut, It, Et = mk('U'), mk('I'), mk('E')
+    small = [torch.nn.Parameter(t.clone().to(dev)) for t in small0]
+    st = ShardedKtupStepper(Ut, It, Et, *small, i2e.to(torch.int32).to(dev), batch=b, kind=kind, lr=lr, eps=eps, max_norm=0.5)
+    st.set_feed([torch.stack([three[k][0][c] for k in range(3)]).to(dev) for c in range(3)])
+    st.run(); st.run()
+    st.run_cycle(4); st.run_cycle(4)
+    st.run_cycle(3)                                            # (odd: step by step)
+    st.flush()
+    torch.cuda.synchronize()
+    assert st.steps == 13 and int(st.cursor) == 14 and st._cycles is not None and len(st._cycles) == 1
+    Wd13, losses13 = _dense_reference(full, small0, i2e, [three[k] for k in order + [1, 2, 0]], kind, lr, eps, 0.5)
+    _check((Ut, It, Et), small, Wd13, 0, 1)
+    np.testing.assert_allclose(float(st.loss_sum[0]), sum(losses13), rtol=1e-4)
+    st.check()
+    st.close()
+
+
 @pytest.mark.parametrize('form', ['one_graph', 'exchange_form'])
 def test_stepper_adam_on_old_states_takes_the_series(form):
     """The same comparison 5,000 steps into a run: every row carries first and second moments written at step 5,000, the batches are

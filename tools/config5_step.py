@@ -62,10 +62,11 @@ def fused_main(args):
         r = (1.0 - uu * (1.0 - top)) ** (-1.0 / a1)
         return (r.clamp(1, n_rows) - 1).to(torch.int64)
     n = args.steps + args.warm
-    batches = [(draw(NU), draw(NI), draw(NI)) for _ in range(n)]
+    n_draw = n + 2 * max(args.cycle, 0)
+    batches = [(draw(NU), draw(NI), draw(NI)) for _ in range(n_draw)]
     if kg is not None:
         kb = []
-        for _ in range(n):
+        for _ in range(n_draw):
             ph, pt, other = draw(NE), draw(NE), draw(NE)
             pr = torch.randint(0, P, (B,), generator=gen, device=dev)
             flip = torch.rand(B, generator=gen, device=dev) < 0.5
@@ -73,7 +74,7 @@ def fused_main(args):
         kg.set_feed([torch.stack([b[c] for b in kb]).contiguous() for c in range(6)])
     if not args.copy_batches or kg is not None:              # device-fed: the step's own launches walk the pre-drawn columns
         rec.set_feed([torch.stack([b[c] for b in batches]).contiguous() for c in range(3)])
-        batches = [()] * n
+        batches = [()] * n_draw
     if kg is not None:
         run = st.run
     else:
@@ -87,8 +88,18 @@ def fused_main(args):
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()
-    for s in range(args.warm, n):
-        run() if run else st(*batches[s])
+    if args.cycle > 0:
+        assert args.steps % args.cycle == 0 and not args.copy_batches
+        st.run_cycle(args.cycle); st.run_cycle(args.cycle)          # (capture + one replay, untimed: 2 x cycle more batches are drawn below)
+        torch.cuda.synchronize(dev)
+        l0 = float(rec.loss_sum[0])
+        t0 = time.perf_counter()
+        ev0.record()
+        for s in range(args.warm, n, args.cycle):
+            st.run_cycle(args.cycle)
+    else:
+        for s in range(args.warm, n):
+            run() if run else st(*batches[s])
     ev1.record()
     torch.cuda.synchronize(dev)
     wall = time.perf_counter() - t0
@@ -101,7 +112,7 @@ def fused_main(args):
                           'kind': args.kind,
                           'route': 'sharded_ktup.ShardedKtupStepper (%s%s%s%s)' % ('eager launches' if args.no_graphs else 'graph replay', ', exchange form' if args.exchange else '',
                                                                                     ', direct gathers' if rec.direct else ', packed rows', ', batches copied in' if args.copy_batches else ', device-fed'),
-                          'ms_per_step': 1e3 * wall / args.steps, 'ms_per_step_device': devms,
+                          'graph_steps': args.cycle if args.cycle > 0 else 1, 'ms_per_step': 1e3 * wall / args.steps, 'ms_per_step_device': devms,
                           'scored_rows_per_s': 2 * B * world * args.steps / wall, 'wire_rows': (kg if args.kind == 'kg' else rec).W,
                           'mean_loss': (float(rec.loss_sum[0]) - l0) / args.steps}))
     rec.close()
@@ -129,6 +140,7 @@ def main():
     ap.add_argument('--copy-batches', action='store_true', help='hand every batch over as three tensors (three device copies per step) instead of device-fed columns')
     ap.add_argument('--no-overlap', action='store_true', help='one rank, direct gathers: keep the route on the step kernel\'s stream (no second stream in the graph)')
     ap.add_argument('--gradient-buffer', action='store_true', help='reduce -> norm -> apply through a W x d gradient buffer (three launches) instead of two walks over the per-pair gradients')
+    ap.add_argument('--cycle', type=int, default=0, help='one rank, device-fed: the timed steps in graphs of this many steps each (run_cycle; even, a divisor of --steps)')
     ap.add_argument('--no-direct', action='store_true', help='one rank: pack the rows into the compact wire table first (what several ranks do)')
     args = ap.parse_args()
     if not args.legacy:

@@ -687,6 +687,20 @@ int ktup_train_rec_step_rows(const float* U, int64_t ldu, const float* I, int64_
                              float* GU, float* GV, float* gP, float* gPn, float* gR, float* gRn, double* sumsq, int n_slots,
                              const int64_t* neg_ids, const int64_t* cursor, int64_t n_batches, int gumbel_mode, const void* gumbel,
                              void* stream);
+/* The same with a workspace for the small tables' gradients (ktup_train_rec_step_rows_ws_bytes(B, n_pref, d) bytes, 16-byte aligned, its
+ * first 64 bytes ZERO before the first call; every call leaves them zero; NULL / too small = the call above).  Without it every tile
+ * workgroup of the launch adds its 2 x n_pref x d partial sums of the preference-table gradients to gP / gPn (/ gR / gRn) by float
+ * atomics at the kernel's end: 256 adds per address at config 5, 10 us of a 117 us step.  With it the partials are STORED into the
+ * workspace and extra workgroups of the same launch -- dispatched as the tile workgroups retire -- sum them in sixteen groups in
+ * workgroup order and add each group's sum: 16 adds per address.  Same values up to the order of the floating-point sums.        */
+size_t ktup_train_rec_step_rows_ws_bytes(int64_t B, int n_pref, int d);
+int ktup_train_rec_step_rows_ws(const float* U, int64_t ldu, const float* I, int64_t ldi, const float* E, int64_t lde,
+                                const int32_t* item2ent, int64_t ent_pad, const float* pref, const float* pref_norm,
+                                const float* rel, const float* norm, int64_t ldp, int n_pref, int d, const int64_t* u_ids,
+                                const int64_t* i_ids, int64_t B, int l1, float target, float gscale, int orth, float* loss,
+                                float* GU, float* GV, float* gP, float* gPn, float* gR, float* gRn, double* sumsq, int n_slots,
+                                const int64_t* neg_ids, const int64_t* cursor, int64_t n_batches, int gumbel_mode, const void* gumbel,
+                                void* small_ws, size_t small_ws_bytes, void* stream);
 /* TUP's row regularisers (item_recommendation.py:177-180: normLoss(user rows of the batch) + normLoss(item rows of [pos ; neg]) +
  * normLoss(pref); normLoss(x) = sum_rows max(|x|^2 - 1, 0), utils/loss.py:21-23) for a step with STORED row gradients: after
  * ktup_train_rec_step_rows and before the reduction, row k of GU (example k's user, id u_ids[k]) and row k of GV (pair k's item, id i_ids[k],

@@ -98,7 +98,9 @@ int pref_step_mc(const float* U, int64_t ldu, const float* I, int64_t ldi, const
                  uint64_t seed, uint64_t offset, float target, float gscale, int orth, float* loss, float* gU, float* gI, float* gE,
                  float* gP, float* gPn, float* gR, float* gRn, hipStream_t st,
                  const char* name, float* GU = nullptr, float* GV = nullptr, double* sumsq = nullptr, int sumsq_slots = 0,
-                 const int64_t* neg_ids = nullptr, const int64_t* cursor = nullptr, int64_t n_batches = 1, double* gnorm = nullptr);
+                 const int64_t* neg_ids = nullptr, const int64_t* cursor = nullptr, int64_t n_batches = 1, double* gnorm = nullptr,
+                 void* small_ws = nullptr, size_t small_ws_bytes = 0);
+size_t pref_step_small_ws_bytes(int64_t B, int n_pref, int d);
 // ktup_score_pref_bwd_wide.hip: the same backward for d = 256 (config 5): four waves share a 16-pair tile, 64 coordinates each.
 int pref_bwd_mc_wide(const float* U, int64_t ldu, const float* I, int64_t ldi, const float* E, int64_t lde, const int32_t* item2ent,
                      int64_t ent_pad, const float* Alog, const float* Ar, const float* Cn, int dp, float beta, int n_pref, int d,

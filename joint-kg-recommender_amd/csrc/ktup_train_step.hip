@@ -287,6 +287,8 @@ extern "C" int ktup_train_rec_step(const float* U, int64_t ldu, const float* I, 
 // the item row AND of its entity row) instead of float atomics into table-shaped buffers: for batches whose rows are then reduced
 // by sorted segments (config 5: ktup_shard_reduce_rows).  gR / gRn may be NULL with rel / norm given: the caller then applies
 // gP / gPn to both summands of the mixed tables itself (they are the same numbers).
+extern "C" size_t ktup_train_rec_step_rows_ws_bytes(int64_t B, int n_pref, int d) { return pref_step_small_ws_bytes(B, n_pref, d); }
+
 extern "C" int ktup_train_rec_step_rows(const float* U, int64_t ldu, const float* I, int64_t ldi, const float* E, int64_t lde,
                                         const int32_t* item2ent, int64_t ent_pad, const float* pref, const float* pref_norm,
                                         const float* rel, const float* norm, int64_t ldp, int n_pref, int d, const int64_t* u_ids,
@@ -294,6 +296,18 @@ extern "C" int ktup_train_rec_step_rows(const float* U, int64_t ldu, const float
                                         float* GU, float* GV, float* gP, float* gPn, float* gR, float* gRn, double* sumsq, int n_slots,
                                         const int64_t* neg_ids, const int64_t* cursor, int64_t n_batches, int gumbel_mode,
                                         const void* gumbel, void* stream) {
+  return ktup_train_rec_step_rows_ws(U, ldu, I, ldi, E, lde, item2ent, ent_pad, pref, pref_norm, rel, norm, ldp, n_pref, d, u_ids, i_ids, B, l1,
+                                     target, gscale, orth, loss, GU, GV, gP, gPn, gR, gRn, sumsq, n_slots, neg_ids, cursor, n_batches, gumbel_mode,
+                                     gumbel, nullptr, 0, stream);
+}
+
+extern "C" int ktup_train_rec_step_rows_ws(const float* U, int64_t ldu, const float* I, int64_t ldi, const float* E, int64_t lde,
+                                           const int32_t* item2ent, int64_t ent_pad, const float* pref, const float* pref_norm,
+                                           const float* rel, const float* norm, int64_t ldp, int n_pref, int d, const int64_t* u_ids,
+                                           const int64_t* i_ids, int64_t B, int l1, float target, float gscale, int orth, float* loss,
+                                           float* GU, float* GV, float* gP, float* gPn, float* gR, float* gRn, double* sumsq, int n_slots,
+                                           const int64_t* neg_ids, const int64_t* cursor, int64_t n_batches, int gumbel_mode,
+                                           const void* gumbel, void* small_ws, size_t small_ws_bytes, void* stream) {
   const char* name = "ktup_train_rec_step_rows";
   KTUP_REQUIRE(gumbel_mode == KTUP_GUMBEL_OFF || ((gumbel_mode == KTUP_GUMBEL_INPUT || gumbel_mode == KTUP_GUMBEL_PHILOX_DEV) && gumbel),
                "%s: the ST-Gumbel gate takes its uniforms (KTUP_GUMBEL_INPUT: 2B x n_pref floats, positives then negatives) or a device-resident "
@@ -312,7 +326,7 @@ extern "C" int ktup_train_rec_step_rows(const float* U, int64_t ldu, const float
                "%s: tables and gradients must be 16-byte aligned", name);
   const int rc = pref_step_mc(U, ldu, I, ldi, E, lde, item2ent, ent_pad, pref, pref_norm, rel, norm, ldp, n_pref, d, u_ids, i_ids, B, l1,
                               gumbel_mode, reinterpret_cast<const float*>(gumbel), 0, 0, target, gscale, orth, loss, nullptr, nullptr, nullptr, gP, gPn, gR, gRn,
-                              (hipStream_t)stream, name, GU, GV, sumsq, n_slots, neg_ids, cursor, n_batches);
+                              (hipStream_t)stream, name, GU, GV, sumsq, n_slots, neg_ids, cursor, n_batches, nullptr, small_ws, small_ws_bytes);
   if (rc == 1) return set_error(KTUP_ERR_UNSUPPORTED, "%s: no fused kernel for d=%d, n_pref=%d (see ktup_train_step_supported)", name, d, n_pref);
   return rc;
 }

@@ -130,6 +130,9 @@ SIGNATURES = {
     'ktup_optim_gradnorm_acc': [c_i, c_p, c_p, c_p, c_i, c_p],
     'ktup_train_rec_step_rows': [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_p, c_p, c_l, c_i,
                                  c_f, c_f, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_l, c_i, c_p, c_p],
+    'ktup_train_rec_step_rows_ws': [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_p, c_p, c_l, c_i,
+                                    c_f, c_f, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_l, c_i, c_p, c_p, ctypes.c_size_t, c_p],
+    'ktup_train_rec_step_rows_ws_bytes': [c_l, c_i, c_i],
     'ktup_train_rec_reg_rows': [c_p, c_l, c_p, c_l, c_i, c_p, c_p, c_l, c_p, c_p, c_p, c_i, c_p, c_f, c_f, c_p, c_p],
     'ktup_negsample_rec_workspace_bytes': [c_l],
     'ktup_negsample_rec': [c_p, c_p, c_l, c_l, c_p, c_l, c_u, c_u, c_i, c_p, c_p, c_p, c_p],
@@ -154,7 +157,8 @@ _RESTYPE = {'ktup_last_error': ctypes.c_char_p, 'ktup_shard_reduce_list_len': ct
             'ktup_eval_pref_workspace_bytes': ctypes.c_size_t, 'ktup_eval_pref_items_workspace_bytes': ctypes.c_size_t, 'ktup_negsample_rec_workspace_bytes': ctypes.c_size_t,
             'ktup_score_pref_bwd_workspace_bytes': ctypes.c_size_t, 'ktup_segment_workspace_bytes': ctypes.c_size_t, 'ktup_shard_dedupe_workspace_bytes': ctypes.c_size_t,
             'ktup_eval_pref_topk_workspace_bytes': ctypes.c_size_t, 'ktup_eval_pref_topk_hard_workspace_bytes': ctypes.c_size_t,
-            'ktup_score_kg_bwd_workspace_bytes': ctypes.c_size_t, 'ktup_score_bprmf_bwd_workspace_bytes': ctypes.c_size_t}
+            'ktup_score_kg_bwd_workspace_bytes': ctypes.c_size_t, 'ktup_score_bprmf_bwd_workspace_bytes': ctypes.c_size_t,
+            'ktup_train_rec_step_rows_ws_bytes': ctypes.c_size_t}
 
 _lib = None
 

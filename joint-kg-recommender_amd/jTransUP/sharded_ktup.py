@@ -569,14 +569,14 @@ class ShardedKtupStepper(_ShardedStepBase):
             ent = self.entries
             uid_p, iid_p = (_p(fu), _p(fp)) if beside else (_p(ent), ent.data_ptr() + B * 8)
             cols = (_p(fn), _p(self.cursor), nb) if beside else (None, None, 0)
-            step = bind('ktup_train_rec_step_rows', _p(Ut.weight.data), Ut.weight.data.stride(0), _p(It.weight.data), It.weight.data.stride(0),
+            step = bind('ktup_train_rec_step_rows_ws', _p(Ut.weight.data), Ut.weight.data.stride(0), _p(It.weight.data), It.weight.data.stride(0),
                         None if self.tup else _p(Et.weight.data), 0 if self.tup else Et.weight.data.stride(0), _p(self.item2ent), self.ent_pad, _p(pref), _p(pref_norm), _p(rel),
                         _p(norm), d, P, d, uid_p, iid_p, B, int(self.l1), self.target, gscale, int(self.orth),
-                        _p(self.loss_step), _p(self.Gcat), self.Gcat.data_ptr() + B * d * 4, _p(gP), _p(gPn), _p(gR), _p(gRn), *ssq, *cols, *gate, stream)
+                        _p(self.loss_step), _p(self.Gcat), self.Gcat.data_ptr() + B * d * 4, _p(gP), _p(gPn), _p(gR), _p(gRn), *ssq, *cols, *gate, *self._small_ws(), stream)
         else:
-            step = bind('ktup_train_rec_step_rows', _p(X), d, _p(X), d, None if self.tup else _p(X), 0 if self.tup else d, None if self.tup else _p(self.pair_map), W, _p(pref), _p(pref_norm), _p(rel),
+            step = bind('ktup_train_rec_step_rows_ws', _p(X), d, _p(X), d, None if self.tup else _p(X), 0 if self.tup else d, None if self.tup else _p(self.pair_map), W, _p(pref), _p(pref_norm), _p(rel),
                         _p(norm), d, P, d, _p(inv), inv.data_ptr() + B * 8, B, int(self.l1), self.target, gscale, int(self.orth),
-                        _p(self.loss_step), _p(self.Gcat), self.Gcat.data_ptr() + B * d * 4, _p(gP), _p(gPn), _p(gR), _p(gRn), *ssq, None, None, 0, *gate, stream)
+                        _p(self.loss_step), _p(self.Gcat), self.Gcat.data_ptr() + B * d * 4, _p(gP), _p(gPn), _p(gR), _p(gRn), *ssq, None, None, 0, *gate, *self._small_ws(), stream)
         if self.row_regs:                                    # TUP: normLoss of the gathered rows and of pref, onto the stored row gradients
             if self.direct:
                 ru, ri, ldr_u, ldr_i, idu, idi = _p(Ut.weight.data), _p(It.weight.data), Ut.weight.data.stride(0), It.weight.data.stride(0), \
@@ -697,6 +697,20 @@ class ShardedKtupStepper(_ShardedStepBase):
         if whole:   # sort, zero-fill, the owner's route (and the next step's route): one branch from the id exchange to the end of the step kernel
             return [head, [('beside', [pack], [sort_, zshared, oroute_on(on)])], [step, ('join',)] + later(rstore)] + own_tail
         return [head, par([pack], [sort_, zshared]), par([step, rstore], [oroute_on(on)] + nxt)] + own_tail
+
+    def _small_ws(self):
+        """(pointer, bytes) of the step kernel's workspace for the preference tables' gradients (ktup_train_rec_step_rows_ws: the tile
+        workgroups STORE their partial sums there and reducer workgroups of the same launch add them up -- 8 float atomics per address
+        instead of one per tile workgroup).  Zero-filled once: its head holds the launch's two counters.  KTUP_STEP_SMALL_WS=0: none."""
+        import os
+        if os.environ.get('KTUP_STEP_SMALL_WS', '1') == '0':
+            return None, 0
+        if getattr(self, '_small_ws_buf', None) is None:
+            n = int(L.load().ktup_train_rec_step_rows_ws_bytes(self.B, self.P, self.d))
+            self._small_ws_buf = torch.zeros((n + 3) // 4, dtype=torch.float32, device=self.dev) if n else None
+        if self._small_ws_buf is None:
+            return None, 0
+        return self._small_ws_buf.data_ptr(), self._small_ws_buf.numel() * 4
 
     def set_gumbel_uniforms(self, uniforms):
         """Parity hook: the ST-Gumbel gate of the NEXT steps reads its uniforms -- (2B, n_pref): one row per scored pair, positives then

@@ -551,10 +551,18 @@ int ktup_shard_zero_shared_rows(const int32_t* sort_ws, int64_t n_entries, int64
                                 int64_t ldw, int d, void* stream);
 int ktup_shard_reduce_store(const float* G, int64_t ldg, int d, int64_t n_src, int64_t src_off, const int32_t* sort_ws,
                             int64_t n_entries, int64_t n_wire_rows, float* gwire, int64_t ldw, void* stream);
+int ktup_shard_reduce_store_fold(const float* G, int64_t ldg, int d, int64_t n_src, int64_t src_off, const int32_t* sort_ws,
+                                 int64_t n_entries, int64_t n_wire_rows, float* gwire, int64_t ldw, float* rep, int n_rep,
+                                 int64_t rep_elems, float* const* rep_dst, void* stream);
 int ktup_shard_reduce_norm(const float* G, int64_t ldg, int d, int64_t n_src, int64_t src_off, const int32_t* sort_ws,
                            int64_t n_entries, int64_t n_wire_rows, float* gwire, int64_t ldw, int32_t* xkeys, int n_small,
                            float* const* small_grads, int64_t small_elems, float small_weight, double* sumsq, int n_slots,
                            int dup_only, double* fold, int n_fold, int64_t* cursor, void* stream);
+int ktup_shard_reduce_norm_fold(const float* G, int64_t ldg, int d, int64_t n_src, int64_t src_off, const int32_t* sort_ws,
+                                int64_t n_entries, int64_t n_wire_rows, float* gwire, int64_t ldw, int32_t* xkeys, int n_small,
+                                float* const* small_grads, int64_t small_elems, float small_weight, double* sumsq, int n_slots,
+                                int dup_only, double* fold, int n_fold, int64_t* cursor, float* rep, int n_rep,
+                                float* const* rep_dst, void* stream);
 int ktup_shard_reduce_apply(int kind, int n_tables, float* const* tables, const int64_t* ld, float* const* states,
                             const int64_t* lds, const int64_t* cap, const int64_t* ids, int64_t n_blocks, const float* G,
                             int64_t ldg, int d, int64_t n_src, int64_t src_off, const int32_t* sort_ws, int64_t n_entries,
@@ -687,12 +695,17 @@ int ktup_train_rec_step_rows(const float* U, int64_t ldu, const float* I, int64_
                              float* GU, float* GV, float* gP, float* gPn, float* gR, float* gRn, double* sumsq, int n_slots,
                              const int64_t* neg_ids, const int64_t* cursor, int64_t n_batches, int gumbel_mode, const void* gumbel,
                              void* stream);
-/* The same with a workspace for the small tables' gradients (ktup_train_rec_step_rows_ws_bytes(B, n_pref, d) bytes, 16-byte aligned, its
- * first 64 bytes ZERO before the first call; every call leaves them zero; NULL / too small = the call above).  Without it every tile
- * workgroup of the launch adds its 2 x n_pref x d partial sums of the preference-table gradients to gP / gPn (/ gR / gRn) by float
- * atomics at the kernel's end: 256 adds per address at config 5, 10 us of a 117 us step.  With it the partials are STORED into the
- * workspace and extra workgroups of the same launch -- dispatched as the tile workgroups retire -- sum them in sixteen groups in
- * workgroup order and add each group's sum: 16 adds per address.  Same values up to the order of the floating-point sums.        */
+/* The same with REPLICAS of the small tables' gradients (small_ws: ktup_train_rec_step_rows_ws_bytes(B, n_pref, d) bytes =
+ * KTUP_TRAIN_SMALL_REPLICAS x [A | C] x n_pref x d floats, 16-byte aligned, ZERO before the call; NULL / too small = the call above).
+ * Without them every tile workgroup of the launch adds its 2 x n_pref x d partial sums of the preference-table gradients to gP / gPn
+ * (/ gR / gRn) by float atomics as the workgroups end together: 256 adds per address at config 5, 10 us of a 117 us step (twice that when pref
+ * and rel have gradients of their own).  With them workgroup b adds to replica b mod KTUP_TRAIN_SMALL_REPLICAS -- 4 us -- and gP / gPn /
+ * gR / gRn receive NOTHING from the tile workgroups (orthogonalLoss's gradient still goes straight to gP / gPn): the caller's next
+ * launch must fold the replicas in -- ktup_shard_reduce_norm_fold (one rank: the norm walk's extra workgroups sum the replicas, add the sum
+ * to the gradients, take the folded values' squares for the norm) or ktup_shard_reduce_store_fold (several ranks: the same as extra
+ * workgroups of the requester's reduction, before the bucket launch reads the gradients); both leave the replicas zero.
+ * rep_dst = {gP, gPn, gR, gRn} (the last two NULL when rel / norm share gP / gPn); rep_elems = n_pref x d.                        */
+#define KTUP_TRAIN_SMALL_REPLICAS 8
 size_t ktup_train_rec_step_rows_ws_bytes(int64_t B, int n_pref, int d);
 int ktup_train_rec_step_rows_ws(const float* U, int64_t ldu, const float* I, int64_t ldi, const float* E, int64_t lde,
                                 const int32_t* item2ent, int64_t ent_pad, const float* pref, const float* pref_norm,

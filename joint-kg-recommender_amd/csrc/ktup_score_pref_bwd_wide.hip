@@ -91,11 +91,12 @@ struct WArgs {
                                  // launch tracks the squared norm of the buffers it builds
   int u_once;                    // STEP + ROWOUT: u_ids holds B ids (example k's user, shared by its two pairs) and GU B rows (the sum)
   int noflush;                   // measurement knob (option dbg_noflush)
-  // STEP + ROWOUT (may be null): the small tables' gradients leave the tile workgroups as STORED partials -- gpart[wg][A | C][P][D] -- and extra
-  // workgroups of the same launch sum them in `red_groups` groups and add each group's sum to gP / gPn (/ gR / gRn): every tile workgroup
-  // adding its 2 P D values itself is 256 float atomics per address, all at the kernel's end -- 10 us of a 117 us config-5 step, where
-  // plain stores of the same values cost 2 (measured: dbg_noflush 1 / atomics / stores).  gdone: [tile workgroups done, reducers done]
-  float* gpart; int32_t* gdone; int n_tile_wgs, red_groups;
+  // STEP + ROWOUT (may be null): the small tables' gradients go to n_rep REPLICAS -- grep[replica][A | C][P][D], workgroup b adds to replica
+  // b mod n_rep -- instead of straight to gP / gPn (/ gR / gRn), and the step's next launch folds the replicas into those
+  // (ktup_shard_reduce_norm_fold / _store_fold).  Every tile workgroup adding its 2 P D sums to ONE copy is 256 float atomics per address,
+  // all issued as the workgroups end together: 10 us of a 117 us config-5 step (dbg_noflush 1), twice that when pref and rel have
+  // gradients of their own; into 8, 16, 32 or 256 copies the same adds cost 4 (measured, all four alike).
+  float* grep; int n_rep;
   int gumbel;
   const float* uniform;
   uint64_t seed, offset;
@@ -103,53 +104,6 @@ struct WArgs {
 
 KTUP_DEV float wstep_neg_logsigmoid(float x) { return fmaxf(-x, 0.f) + log1pf(expf(-fabsf(x))); }   // as ktup_loss.hip / torch
 KTUP_DEV float wstep_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
-
-// device-scope (sc1) loads / stores: what one workgroup writes and another reads inside ONE launch (the XCDs' L2s are coherent for scoped
-// accesses, not for plain ones; a fence would write back and invalidate whole L2s under a kernel that streams its row gradients through them)
-template <typename V> KTUP_DEV V ld_dev(const V* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-template <typename V> KTUP_DEV void st_dev(V* p, V v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-// Reducer workgroup r of the step launch (blocks behind the tile workgroups: the dispatcher hands them CUs as tile workgroups retire, and
-// a tile workgroup never waits for one): element chunk r / groups (1024 of the 2 P D elements: a float4 per thread), partial group
-// r % groups.  Waits until every tile workgroup has stored its partials (bounded: a kernel must not hang), fetches its group's partials
-// -- up to sixteen 16-byte device-scope loads in flight per thread: one memory round trip -- sums them in workgroup order, adds the sum.
-template <int D>
-KTUP_DEV void small_grad_reduce(const WArgs& a, int r, int n_red) {
-  const int EL = 2 * a.P * D;
-  const int eb = r / a.red_groups, g = r % a.red_groups;
-  if (threadIdx.x == 0) {
-    int spins = 0;
-    while (ld_dev(a.gdone) < a.n_tile_wgs && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(2);
-    if (spins >= (1 << 22)) atomicAdd(a.loss, __builtin_nanf(""));      // gave up (never seen): the step's loss says so
-  }
-  __syncthreads();
-  const int e = eb * 1024 + 4 * (int)threadIdx.x;
-  if (e < EL) {
-    const int per = (a.n_tile_wgs + a.red_groups - 1) / a.red_groups;
-    const int lo = g * per, hi = lo + per < a.n_tile_wgs ? lo + per : a.n_tile_wgs;
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.gpart, 0, (int)((int64_t)a.n_tile_wgs * EL * 4), 0x00020000);
-    v4 t = (v4){0.f, 0.f, 0.f, 0.f};
-    for (int w0 = lo; w0 < hi; w0 += 16) {
-      v4 x[16];
-#pragma unroll
-      for (int k = 0; k < 16; ++k)      // (offsets past the buffer's end read zeros: the descriptor checks the range)
-        x[k] = __builtin_bit_cast(v4, __builtin_amdgcn_raw_buffer_load_b128(rs, w0 + k < hi ? ((w0 + k) * EL + e) * 4 : -16, 0, 17 /* sc0 sc1 */));
-#pragma unroll
-      for (int k = 0; k < 16; ++k) t += x[k];
-    }
-    const int which = e / (a.P * D), rem = e - which * a.P * D;
-    float* first = (which ? a.gPn : a.gP) + rem;
-    float* second = which ? a.gRn : a.gR;               // A = pref + rel, C = pref_norm + norm: the same numbers for both summands
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-      if (t[c] != 0.f) {
-        atomicAdd(first + c, t[c]);
-        if (second) atomicAdd(second + rem + c, t[c]);
-      }
-  }
-  __syncthreads();
-  if (threadIdx.x == 0 && atomicAdd(a.gdone + 1, 1) == n_red - 1) { st_dev(a.gdone, 0); st_dev(a.gdone + 1, 0); }      // the last one out: counters ready for the next launch
-}
 
 template <typename G, bool ROWOUT, bool STEP>
 __global__ __launch_bounds__(G::NT) void pref_bwd_wide_kernel(WArgs a) {
@@ -187,12 +141,6 @@ __global__ __launch_bounds__(G::NT) void pref_bwd_wide_kernel(WArgs a) {
     return t;
   };
   int nblk = gridDim.x;                                       // workgroups that walk tiles
-  if constexpr (STEP && ROWOUT) {
-    if (a.gpart) {                                            // [tile workgroups | the orth workgroup | reducers of the small gradients]
-      nblk = a.n_tile_wgs + (a.orth ? 1 : 0);
-      if ((int)blockIdx.x >= nblk) { small_grad_reduce<D>(a, (int)blockIdx.x - nblk, (int)gridDim.x - nblk); return; }
-    }
-  }
   if constexpr (STEP) {
     if (a.orth) {
       nblk = nblk - 1;
@@ -765,8 +713,8 @@ __global__ __launch_bounds__(G::NT) void pref_bwd_wide_kernel(WArgs a) {
             ssq += (sq_gain(fo[pt][ct][reg][0], va) + sq_gain(fo[pt][ct][reg][1], va)) + (sq_gain(fo[pt][ct][reg][2], vc) + sq_gain(fo[pt][ct][reg][3], vc));
           }
         }
-  } else if (STEP && ROWOUT && a.gpart && !a.noflush) {
-    float* mine = a.gpart + (int64_t)blockIdx.x * 2 * P * D;
+  } else if (STEP && ROWOUT && a.grep && !a.noflush) {
+    float* mine = a.grep + (int64_t)((int)blockIdx.x % a.n_rep) * 2 * P * D;
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt)
 #pragma unroll
@@ -775,14 +723,11 @@ __global__ __launch_bounds__(G::NT) void pref_bwd_wide_kernel(WArgs a) {
         for (int reg = 0; reg < 4; ++reg) {
           const int p = 16 * pt + 4 * kq + reg, c = 4 * NCW * w + 16 * ct + j;
           if (p < P && (!RAGGED || c < D)) {
-            st_dev(mine + p * D + c, accA[pt][ct][reg]);
-            st_dev(mine + (P + p) * D + c, accC[pt][ct][reg]);
+            const float va = accA[pt][ct][reg], vc = accC[pt][ct][reg];
+            if (va != 0.f) atomicAdd(mine + p * D + c, va);
+            if (vc != 0.f) atomicAdd(mine + (P + p) * D + c, vc);
           }
         }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_s_waitcnt(0);                              // this wave's partials have been acknowledged ...
-    __syncthreads();
-    if (tid == 0) atomicAdd(a.gdone, 1);                        // ... all four waves': the reducers may read them
   } else if (!a.noflush)
 #pragma unroll
   for (int pt = 0; pt < PT; ++pt)
@@ -844,16 +789,9 @@ int launch_r(const WArgs& a, hipStream_t st, const char* name) {
   // option `deterministic` (the fused step with gradients by atomics): ONE workgroup walks every tile -- a wave owns its coordinates of every
   // row, so each gradient cell receives its adds from one wave in program order, and the table gradients are flushed once
   const int tile_wgs = (STEP && !ROWOUT && opt_deterministic()) ? 1 : grid_for(ntiles, 256 * per_cu);
-  int grid = tile_wgs + ((STEP && a.orth) ? 1 : 0);
+  const int grid = tile_wgs + ((STEP && a.orth) ? 1 : 0);
   WArgs b = a;
-  if (STEP && ROWOUT && b.gpart) {
-    // the workspace was sized for the largest grid (pref_step_small_ws_bytes); [0, 64) its two counters
-    constexpr int GROUPS = 16;
-    b.n_tile_wgs = tile_wgs; b.red_groups = tile_wgs < GROUPS ? 1 : GROUPS;
-    grid += ((2 * b.P * G::D + 1023) / 1024) * b.red_groups;
-  } else {
-    b.gpart = nullptr;
-  }
+  if (!(STEP && ROWOUT)) b.grep = nullptr;
   hipLaunchKernelGGL((pref_bwd_wide_kernel<G, ROWOUT, STEP>), dim3(grid), dim3(G::NT), G::LDS, st, b);
   return check_launch(name);
 }
@@ -957,18 +895,15 @@ int pref_step_mc(const float* U, int64_t ldu, const float* I, int64_t ldi, const
   a.sumsq = sumsq; a.sumsq_slots = sumsq_slots;
   a.neg_ids = neg_ids; a.cursor = cursor; a.n_batches = n_batches > 0 ? n_batches : 1;
   if (small_ws && GU && small_ws_bytes >= pref_step_small_ws_bytes(B, n_pref, d) && (reinterpret_cast<uintptr_t>(small_ws) & 15u) == 0) {
-    a.gdone = reinterpret_cast<int32_t*>(small_ws);
-    a.gpart = reinterpret_cast<float*>(reinterpret_cast<char*>(small_ws) + 64);
+    a.grep = reinterpret_cast<float*>(small_ws); a.n_rep = KTUP_TRAIN_SMALL_REPLICAS;
   }
   return launch_d(a, d, (n_pref + 3) / 4, st, name);
 }
 
-// bytes of the small-gradient workspace of a rows step (0: the shape has no fused kernel): two counters + a partial per tile workgroup
+// bytes of the small-gradient replicas of a rows step (0: the shape has no fused kernel)
 size_t pref_step_small_ws_bytes(int64_t B, int n_pref, int d) {
   if (B <= 0 || n_pref <= 0 || !(d == 64 || d == 100 || d == 128 || d == 256)) return 0;
-  const int64_t ntiles = (B + 7) / 8;
-  const int64_t wgs = ntiles < 256 * 3 ? ntiles : 256 * 3;            // (launch_r: at most three workgroups per CU)
-  return 64 + (size_t)wgs * 2 * n_pref * d * sizeof(float);
+  return (size_t)KTUP_TRAIN_SMALL_REPLICAS * 2 * n_pref * d * sizeof(float);
 }
 
 }  // namespace ktup

@@ -700,7 +700,11 @@ struct FusedArgs {
 // rows; those now account for themselves: see boundary() below.)
 struct XNormArgs {
   int n_small; const float* sg[MAXS]; int64_t small_elems; float small_weight;
-  double* sumsq; int slots;
+  double* sumsq; int slots;         // (sumsq null: nothing is added -- the fold below alone, as extra workgroups of the store walk)
+  // the step kernel's REPLICAS of the preference-table gradients (ktup_train_rec_step_rows_ws): rep[r][A | C][rep_elems]; element j of A is
+  // added to rdst[0][j] (and rdst[2][j] if not null), of C to rdst[1][j] (rdst[3][j]); the replicas are left zero.  One thread owns an
+  // element: no atomics.  The squares added to sumsq are then those of the FOLDED values (rdst replaces sg as the list of small gradients).
+  float* rep; int n_rep; int64_t rep_elems; float* rdst[4];
   double* fold; int n_fold;          // accumulators another stream filled while `sumsq` was being cleared: added in, left zero
   int64_t* cursor;                   // moved on here: every reader of the step's batch position is done
 };
@@ -715,11 +719,30 @@ KTUP_DEV void xnorm_blocks(const XNormArgs& a, int blk, int nblk) {
     if (a.cursor) *a.cursor = *a.cursor + 1;
   }
   float ss = 0.f;
-  const int64_t N = (int64_t)a.n_small * a.small_elems;
-  for (int64_t i = (int64_t)blk * 256 + threadIdx.x; i < N; i += (int64_t)nblk * 256) {
-    const float v = a.sg[i / a.small_elems][i % a.small_elems];
-    ss = fmaf(a.small_weight * v, v, ss);
+  if (a.rep) {
+    for (int64_t i = (int64_t)blk * 256 + threadIdx.x; i < 2 * a.rep_elems; i += (int64_t)nblk * 256) {
+      const int which = i >= a.rep_elems ? 1 : 0;
+      const int64_t j = i - which * a.rep_elems;
+      float* r0 = a.rep + which * a.rep_elems + j;
+      float t = 0.f;
+      for (int r = 0; r < a.n_rep; ++r) { t += r0[(int64_t)r * 2 * a.rep_elems]; r0[(int64_t)r * 2 * a.rep_elems] = 0.f; }     // (independent loads: one round trip)
+      const float v1 = a.rdst[which][j] + t;
+      a.rdst[which][j] = v1;
+      ss = fmaf(a.small_weight * v1, v1, ss);
+      if (a.rdst[2 + which]) {
+        const float v2 = a.rdst[2 + which][j] + t;
+        a.rdst[2 + which][j] = v2;
+        ss = fmaf(a.small_weight * v2, v2, ss);
+      }
+    }
+  } else {
+    const int64_t N = (int64_t)a.n_small * a.small_elems;
+    for (int64_t i = (int64_t)blk * 256 + threadIdx.x; i < N; i += (int64_t)nblk * 256) {
+      const float v = a.sg[i / a.small_elems][i % a.small_elems];
+      ss = fmaf(a.small_weight * v, v, ss);
+    }
   }
+  if (!a.sumsq) return;
   __shared__ float xred[4];
   ss = group_sum<64>(ss);
   if ((threadIdx.x & 63) == 0) xred[threadIdx.x >> 6] = ss;
@@ -737,7 +760,7 @@ template <int GL, int CPL, int MODE, int LZ>
 __global__ __launch_bounds__(256) void seg_fused_kernel(FusedArgs a, ApplyRowsT<LZ> op, int64_t op_rows, int walk_grid, XNormArgs xn) {
   const int lane = threadIdx.x % GL, grp = threadIdx.x / GL;
   constexpr int GPB = 256 / GL;
-  if (MODE == 0 && (int)blockIdx.x >= walk_grid) {
+  if ((MODE == 0 || MODE == 2) && (int)blockIdx.x >= walk_grid) {
     xnorm_blocks(xn, (int)blockIdx.x - walk_grid, (int)gridDim.x - walk_grid);
     return;
   }
@@ -960,7 +983,8 @@ int launch_fused(const FusedArgs& a, int64_t grid, hipStream_t st, const char* n
 #define KTUP_F(GL, CPL)                                                                                  \
   {                                                                                                      \
     int64_t extra = op ? grid_for((op_rows + (256 / GL) - 1) / (256 / GL), 256) : 0;                     \
-    if (xn) extra = grid_for(((int64_t)xn->n_small * xn->small_elems + 2047) / 2048, 64);                \
+    if (xn) extra = xn->rep ? grid_for((2 * xn->rep_elems + 255) / 256, 256)                             \
+                            : grid_for(((int64_t)xn->n_small * xn->small_elems + 2047) / 2048, 64);         \
     hipLaunchKernelGGL((seg_fused_kernel<GL, CPL, MODE, LZ>), dim3((unsigned)(grid + extra)), dim3(256), 0, st, a, op ? *op : none, op_rows, \
                        (int)grid, xn ? *xn : xnone);                                                     \
     return check_launch(name);                                                                           \
@@ -1414,10 +1438,31 @@ extern "C" int64_t ktup_shard_reduce_list_len(int64_t n_entries, int d) {
   return 2 * fused_grid(n_entries, d);
 }
 
+namespace {
+// the replicas of ktup_train_rec_step_rows_ws and where their sums go: rep_dst = {gP, gPn, gR or NULL, gRn or NULL}
+int fill_rep(const char* name, XNormArgs& x, float* rep, int n_rep, int64_t rep_elems, float* const* rep_dst) {
+  if (!rep) return KTUP_OK;
+  KTUP_REQUIRE(n_rep >= 1 && rep_elems > 0 && rep_dst && rep_dst[0] && rep_dst[1] && (rep_dst[2] == nullptr) == (rep_dst[3] == nullptr),
+               "%s: the replicas need their count, their size and the gradients they fold into (gP, gPn, and gR / gRn together or not at all)", name);
+  x.rep = rep; x.n_rep = n_rep; x.rep_elems = rep_elems;
+  for (int k = 0; k < 4; ++k) x.rdst[k] = rep_dst[k];
+  return KTUP_OK;
+}
+}  // namespace
+
 extern "C" int ktup_shard_reduce_norm(const float* G, int64_t ldg, int d, int64_t n_src, int64_t src_off, const int32_t* sort_ws,
                                       int64_t n_entries, int64_t n_wire_rows, float* gwire, int64_t ldw, int32_t* xkeys, int n_small,
                                       float* const* small_grads, int64_t small_elems, float small_weight, double* sumsq, int n_slots,
                                       int dup_only, double* fold, int n_fold, int64_t* cursor, void* stream) {
+  return ktup_shard_reduce_norm_fold(G, ldg, d, n_src, src_off, sort_ws, n_entries, n_wire_rows, gwire, ldw, xkeys, n_small, small_grads,
+                                     small_elems, small_weight, sumsq, n_slots, dup_only, fold, n_fold, cursor, nullptr, 0, nullptr, stream);
+}
+
+extern "C" int ktup_shard_reduce_norm_fold(const float* G, int64_t ldg, int d, int64_t n_src, int64_t src_off, const int32_t* sort_ws,
+                                           int64_t n_entries, int64_t n_wire_rows, float* gwire, int64_t ldw, int32_t* xkeys, int n_small,
+                                           float* const* small_grads, int64_t small_elems, float small_weight, double* sumsq, int n_slots,
+                                           int dup_only, double* fold, int n_fold, int64_t* cursor, float* rep, int n_rep,
+                                           float* const* rep_dst, void* stream) {
   const char* name = "ktup_shard_reduce_norm";
   FusedArgs a{};
   if (int e = fill_fused(name, a, G, ldg, d, n_src, src_off, sort_ws, n_entries, n_wire_rows, gwire, ldw, xkeys)) return e;
@@ -1435,6 +1480,7 @@ extern "C" int ktup_shard_reduce_norm(const float* G, int64_t ldg, int d, int64_
   x.sumsq = sumsq; x.slots = n_slots;
   KTUP_REQUIRE(n_fold >= 0 && (n_fold == 0 || fold), "%s: fold needs its array", name);
   x.fold = n_fold > 0 ? fold : nullptr; x.n_fold = n_fold; x.cursor = cursor;
+  if (int e = fill_rep(name, x, rep, n_rep, small_elems, rep_dst)) return e;       // (the replicas' sums ARE the small gradients: same size)
   return launch_fused<0, 0>(a, grid, st, name, (const ApplyRows*)nullptr, 0, &x);     // the walk + (extra workgroups) the small gradients, the fold, the cursor
 }
 
@@ -1514,12 +1560,21 @@ extern "C" int ktup_shard_zero_shared_rows(const int32_t* sort_ws, int64_t n_ent
 
 extern "C" int ktup_shard_reduce_store(const float* G, int64_t ldg, int d, int64_t n_src, int64_t src_off, const int32_t* sort_ws,
                                        int64_t n_entries, int64_t n_wire_rows, float* gwire, int64_t ldw, void* stream) {
+  return ktup_shard_reduce_store_fold(G, ldg, d, n_src, src_off, sort_ws, n_entries, n_wire_rows, gwire, ldw, nullptr, 0, 0, nullptr, stream);
+}
+
+extern "C" int ktup_shard_reduce_store_fold(const float* G, int64_t ldg, int d, int64_t n_src, int64_t src_off, const int32_t* sort_ws,
+                                            int64_t n_entries, int64_t n_wire_rows, float* gwire, int64_t ldw, float* rep, int n_rep,
+                                            int64_t rep_elems, float* const* rep_dst, void* stream) {
   const char* name = "ktup_shard_reduce_store";
   FusedArgs a{};
   int32_t none = 0;
   if (int e = fill_fused(name, a, G, ldg, d, n_src, src_off, sort_ws, n_entries, n_wire_rows, gwire, ldw, &none)) return e;
   a.xkeys = nullptr;
-  return launch_fused<2, 0>(a, fused_grid(n_entries, d), (hipStream_t)stream, name);
+  XNormArgs x{};
+  x.small_weight = 1.f;
+  if (int e = fill_rep(name, x, rep, n_rep, rep_elems, rep_dst)) return e;
+  return launch_fused<2, 0>(a, fused_grid(n_entries, d), (hipStream_t)stream, name, (const ApplyRows*)nullptr, 0, rep ? &x : nullptr);
 }
 
 extern "C" int ktup_shard_bucket(int mode, int n_small, float* const* small_grads, int64_t small_elems, double* bucket,

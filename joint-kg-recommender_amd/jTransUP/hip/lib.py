@@ -121,10 +121,12 @@ SIGNATURES = {
     'ktup_shard_reduce_list_len': [c_l, c_i],
     'ktup_shard_zero_shared_rows': [c_p, c_l, c_l, c_p, c_p, c_l, c_i, c_p],
     'ktup_shard_reduce_store': [c_p, c_l, c_i, c_l, c_l, c_p, c_l, c_l, c_p, c_l, c_p],
+    'ktup_shard_reduce_store_fold': [c_p, c_l, c_i, c_l, c_l, c_p, c_l, c_l, c_p, c_l, c_p, c_i, c_l, c_p, c_p],
     'ktup_shard_step_count': [c_p, c_p, c_p, c_f, c_f, c_p],
     'ktup_shard_adam_flush': [c_p, c_l, c_p, c_l, c_i, c_l, c_f, c_f, c_p, c_p],
     'ktup_shard_adam_catchup': [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_f, c_f, c_p, c_p],
     'ktup_shard_reduce_norm': [c_p, c_l, c_i, c_l, c_l, c_p, c_l, c_l, c_p, c_l, c_p, c_i, c_p, c_l, c_f, c_p, c_i, c_i, c_p, c_i, c_p, c_p],
+    'ktup_shard_reduce_norm_fold': [c_p, c_l, c_i, c_l, c_l, c_p, c_l, c_l, c_p, c_l, c_p, c_i, c_p, c_l, c_f, c_p, c_i, c_i, c_p, c_i, c_p, c_p, c_i, c_p, c_p],
     'ktup_shard_reduce_apply': [c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_p, c_l, c_i, c_l, c_l, c_p, c_l, c_p, c_l, c_p, c_i, c_i,
                                 c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_f, c_p, c_i, c_f, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p],
     'ktup_optim_gradnorm_acc': [c_i, c_p, c_p, c_p, c_i, c_p],

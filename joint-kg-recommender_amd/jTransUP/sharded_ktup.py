@@ -608,8 +608,10 @@ class ShardedKtupStepper(_ShardedStepBase):
             count = [bind('ktup_shard_step_count', _p(self.opt_step), self.counters.data_ptr() + 4 * (Wn * T), None, self.betas[0], self.betas[1], stream)] if adam else []
             if self.fused_apply:
                 nw = arr(_ptrs(sg_list))
-                rnorm = bind('ktup_shard_reduce_norm', _p(self.Gcat), d, d, 3 * B, 2 * B, _p(self.sort_ws), E, W, _p(self.Gwire), d,
-                             _p(self.xkeys), n_small, nw, P * d, small_weight, _p(self.acc), SLOTS, int(dup), *fold, stream)
+                rep_p, rep_n = self._small_ws()
+                rnorm = bind('ktup_shard_reduce_norm_fold', _p(self.Gcat), d, d, 3 * B, 2 * B, _p(self.sort_ws), E, W, _p(self.Gwire), d,
+                             _p(self.xkeys), n_small, nw, P * d, small_weight, _p(self.acc), SLOTS, int(dup), *fold,
+                             rep_p, 8 if rep_p else 0, arr(_ptrs([gP, gPn, gR, gRn])) if rep_p else None, stream)
                 rapply = bind('ktup_shard_reduce_apply', kind, T, tabs, lds, states, slds, cap, _p(self.send_ids), 1, _p(self.Gcat), d, d,
                               3 * B, 2 * B, _p(self.sort_ws), E, _p(self.Gwire), d, _p(self.xkeys), n_small, P, sgp, sp0p, ss0p, sp1p, ss1p,
                               None, self.lr, self.eps, _p(self.acc), SLOTS, self.max_norm, self.counters.data_ptr() + 4 * (Wn * T), None,
@@ -648,7 +650,9 @@ class ShardedKtupStepper(_ShardedStepBase):
         pack = bind('ktup_shard_pack_wire', T, tabs, lds, cap, d, _p(self.recv_ids), Wn, _p(self.Xsend), d, stream)
         sort_ = route_phase(5, on)
         zshared = bind('ktup_shard_zero_shared_rows', _p(self.sort_ws), E, W, _p(inv), _p(self.Gwire), d, d, on)
-        rstore = bind('ktup_shard_reduce_store', _p(self.Gcat), d, d, 3 * B, 2 * B, _p(self.sort_ws), E, W, _p(self.Gwire), d, stream)
+        rep_p, rep_n = self._small_ws()
+        rstore = bind('ktup_shard_reduce_store_fold', _p(self.Gcat), d, d, 3 * B, 2 * B, _p(self.sort_ws), E, W, _p(self.Gwire), d,
+                      rep_p, 8 if rep_p else 0, P * d, arr(_ptrs([gP, gPn, gR, gRn])) if rep_p else None, stream)
 
         def oroute_on(st_):
             return bind('ktup_shard_route', _p(self.recv_ids), W, self.capsum, T, eoff_o, 1, capo, 0, 0, _p(self.own_inverse),
@@ -699,11 +703,12 @@ class ShardedKtupStepper(_ShardedStepBase):
         return [head, par([pack], [sort_, zshared]), par([step, rstore], [oroute_on(on)] + nxt)] + own_tail
 
     def _small_ws(self):
-        """(pointer, bytes) of the step kernel's workspace for the preference tables' gradients (ktup_train_rec_step_rows_ws: the tile
-        workgroups STORE their partial sums there and reducer workgroups of the same launch add them up -- 8 float atomics per address
-        instead of one per tile workgroup).  Zero-filled once: its head holds the launch's two counters.  KTUP_STEP_SMALL_WS=0: none."""
+        """(pointer, bytes) of the step kernel's REPLICAS of the preference tables' gradients (ktup_train_rec_step_rows_ws: tile workgroup b
+        adds its partial sums to replica b mod 8 instead of all 256 workgroups to one copy), or (None, 0): the launch that follows the step
+        kernel folds them into gP / gPn (/ gR / gRn) -- the norm walk on one rank, the requester's reduction on several -- so the forms
+        without such a launch (one rank through a gradient buffer) keep the plain flush.  KTUP_STEP_SMALL_WS=0: none."""
         import os
-        if os.environ.get('KTUP_STEP_SMALL_WS', '1') == '0':
+        if os.environ.get('KTUP_STEP_SMALL_WS', '1') == '0' or (not self.multi and not self.fused_apply):
             return None, 0
         if getattr(self, '_small_ws_buf', None) is None:
             n = int(L.load().ktup_train_rec_step_rows_ws_bytes(self.B, self.P, self.d))

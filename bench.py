@@ -1374,32 +1374,56 @@ def main():
         if world > 1:
             dist.barrier()
 
+    # The events of the timed region exist (and have been recorded once: torch creates the HIP event at its first record) BEFORE the
+    # ramp and the warm-up steps: whatever the host does between the warm-up and the timed region is idle time on the device, and the
+    # chip answers an idle gap of a few hundred microseconds with ~25 ms of lowered clocks (per-step event timeline, round 6: period
+    # 0.139 -> 0.155 -> 0.125 ms over the first 200 steps after a 0.4 ms gap, 0.1218 without one).
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    _dump = bool(os.environ.get('KTUP_DUMP_EV'))
+    evk = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)] if _dump else None
+    for a_, b_ in ev:
+        a_.record(); b_.record()
+    torch.cuda.synchronize(device)
     # clock ramp (untimed, like the warm-up steps, whatever --warmup says): a fresh device / process needs load before it holds its
     # clocks -- 80 ms was not enough on a box's FIRST run (0.1375 ms per step against 0.123 on the second and third): run windows of 40
     # steps until two in a row are within 1 % of the best seen, at least 0.25 s, at most 2 s
     t_ramp, best_w, settled = time.perf_counter(), None, 0
+    ramp_min_s = float(os.environ.get('KTUP_RAMP_MIN_S', '0.25'))
+    ramp_win = int(os.environ.get('KTUP_RAMP_WIN', '40'))
+    ramp_log = []
     while True:
         t_w = time.perf_counter()
-        for _ in range(40):
+        for _ in range(ramp_win):
             prep(); rec(); kg()
         torch.cuda.synchronize(device)
         w_ms = time.perf_counter() - t_w
+        ramp_log.append(round(1e3 * w_ms / ramp_win, 4))
         settled = settled + 1 if (best_w is not None and w_ms <= 1.01 * best_w) else 0
         best_w = w_ms if best_w is None else min(best_w, w_ms)
         el = time.perf_counter() - t_ramp
-        if (settled >= 2 and el > 0.25) or el > 2.0:
+        if (settled >= 2 and el > ramp_min_s) or el > max(2.0, 2 * ramp_min_s):
             break
+    if os.environ.get('KTUP_RAMP_LOG'):
+        print('ramp', len(ramp_log), ramp_log[:6], ramp_log[-12:], file=sys.stderr)
     for _ in range(args.warmup):
         prep(); rec(); kg()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     barrier(); torch.cuda.synchronize(device)
     t0 = time.perf_counter()
     for s in range(args.steps):                         # the timed region: exactly K steps
         prep()
         ev[s][0].record(); rec(); ev[s][1].record()     # HIP events around the dominant kernel's launch, on its stream
+        if _dump:
+            evk[s][0].record(side)
         kg()
+        if _dump:
+            evk[s][1].record(side)
     torch.cuda.synchronize(device); barrier()
     dt = time.perf_counter() - t0
+    if _dump:
+        z = ev[0][0]
+        for s in range(args.steps):
+            print('ev', s, round(z.elapsed_time(ev[s][0]), 4), round(z.elapsed_time(ev[s][1]), 4), round(z.elapsed_time(evk[s][0]), 4),
+                  round(z.elapsed_time(evk[s][1]), 4), file=sys.stderr)
     ek = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
     for a_, b_ in ek:                                   # the KG-branch kernel alone, timed after the region on its own stream
         a_.record(side); kg(); b_.record(side)

@@ -164,8 +164,15 @@ struct QGeom {
   static constexpr int DPW = ((TSLOTS + 63) / 64 + 3) / 4;      // DMA instructions per wave and tile (wave w issues pieces w, w + 4, ...)
   static constexpr int SOFF4 = (D + P4) / 4;                    // float4 offset of [L ; Nx] inside a row
   static constexpr int KA = (D + 2 * P4 + 15) / 16, KS = (2 * P4 + 15) / 16, KN = (P4 + 15) / 16;   // 16-blocks of K
-  static constexpr int NA = KA + 2 * KS + KN;                   // float4 A operands per lane: [AA | S | AN | NN]
+  static constexpr int NA = KA + 2 * KS + KN;                   // float4 per lane and 16-block of a user row in memory: [AA | S | AN | NN]
   static constexpr int AROW = 16 * NA;                          // floats per user row
+  // What the sweep multiplies is the REAL K of each product: whole 16-blocks (one ds_read_b128 and four MFMAs each, k = 16 g + 4 kq + c)
+  // and then the remaining k-quads one MFMA each (one ds_read_b32, k = 16 F + 4 m + kq) -- the zero padding of the last 16-blocks
+  // was 8 of 68 MFMAs per tile at d = 100, P = 20
+  static constexpr int FA = (D + 2 * P4) / 16, TA = ((D + 2 * P4) % 16) / 4;     // AA: [x ; Rx ; L]
+  static constexpr int FS = (2 * P4) / 16, TS = ((2 * P4) % 16) / 4;             // S and AN: [L ; Nx]
+  static constexpr int FN = P4 / 16, TN = (P4 % 16) / 4;                         // NN: [L]
+  static constexpr int NREG = 4 * FA + TA + 2 * (4 * FS + TS) + 4 * FN + TN;     // A-operand registers per lane
   static constexpr int SUB = 1;                                 // 16-item sub-tiles per buffer = per workgroup barrier (2: no faster, and the
                                                                 // pending-candidate buffers below need the LDS for three workgroups per CU)
   static constexpr int TILE_F4 = SUB * IBT * ROW4 + 4;          // + pad: the padded K blocks read a little past the last row
@@ -186,7 +193,8 @@ struct QArgs {
 
 template <typename G>
 __global__ __launch_bounds__(256, G::MINW) void eval_pass_q_kernel(QArgs a) {
-  constexpr int RB4 = G::RB4, ROW4 = G::ROW4, KA = G::KA, KS = G::KS, KN = G::KN, NA = G::NA, DPW = G::DPW;
+  constexpr int RB4 = G::RB4, ROW4 = G::ROW4, KA = G::KA, KS = G::KS, DPW = G::DPW;
+  constexpr int FA = G::FA, TA = G::TA, FS = G::FS, TS = G::TS, FN = G::FN, TN = G::TN;
   static_assert(G::SUB == 1, "one 16-item tile per buffer");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   v4* Xb = reinterpret_cast<v4*>(smem);                                   // [2][TILE_F4] item tiles
@@ -240,12 +248,27 @@ __global__ __launch_bounds__(256, G::MINW) void eval_pass_q_kernel(QArgs a) {
   }
   if (lane < 16) *reinterpret_cast<v4*>(usc + lane * 4) =
       u0 + lane < a.nq ? *reinterpret_cast<const v4*>(a.SCU + (u0 + lane) * 4) : (v4){0.f, 0.f, 0.f, 0.f};
-  v4 aop[NA];                                                             // A operands of the whole pass: user j, k-quad kq of every block
+  // A operands of the whole pass (user j): k-quad kq of every whole 16-block, then element kq of every remaining k-quad
+  v4 aAA[FA > 0 ? FA : 1], aS[FS > 0 ? FS : 1], aAN[FS > 0 ? FS : 1], aNN[FN > 0 ? FN : 1];
+  float tAA[TA > 0 ? TA : 1], tS[TS > 0 ? TS : 1], tAN[TS > 0 ? TS : 1], tNN[TN > 0 ? TN : 1];
   {
     const bool ok = u0 + j < a.nq && !(a.dbg & 32);
-    const v4* r0 = reinterpret_cast<const v4*>(a.A + (ok ? u0 + j : 0) * G::AROW);
+    const float* rf = a.A + (ok ? u0 + j : 0) * G::AROW;
+    const v4* r0 = reinterpret_cast<const v4*>(rf);
+    constexpr int oS = 16 * KA, oAN = oS + 16 * KS, oNN = oAN + 16 * KS;
+    const v4 z4 = (v4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int g = 0; g < NA; ++g) aop[g] = ok ? r0[4 * g + kq] : (v4){0.f, 0.f, 0.f, 0.f};
+    for (int g = 0; g < FA; ++g) aAA[g] = ok ? r0[4 * g + kq] : z4;
+#pragma unroll
+    for (int m = 0; m < TA; ++m) tAA[m] = ok ? rf[16 * FA + 4 * m + kq] : 0.f;
+#pragma unroll
+    for (int g = 0; g < FS; ++g) { aS[g] = ok ? r0[oS / 4 + 4 * g + kq] : z4; aAN[g] = ok ? r0[oAN / 4 + 4 * g + kq] : z4; }
+#pragma unroll
+    for (int m = 0; m < TS; ++m) { tS[m] = ok ? rf[oS + 16 * FS + 4 * m + kq] : 0.f; tAN[m] = ok ? rf[oAN + 16 * FS + 4 * m + kq] : 0.f; }
+#pragma unroll
+    for (int g = 0; g < FN; ++g) aNN[g] = ok ? r0[oNN / 4 + 4 * g + kq] : z4;
+#pragma unroll
+    for (int m = 0; m < TN; ++m) tNN[m] = ok ? rf[oNN + 16 * FN + 4 * m + kq] : 0.f;
   }
   __syncthreads();                                                        // tiles zeroed, bitmaps and scalars in place
   const int64_t ntile = (a.dbg & 8) ? 0 : (i_hi - i_lo + IBT - 1) / IBT;    // (dbg 8: prologue and epilogue only)
@@ -316,27 +339,44 @@ __global__ __launch_bounds__(256, G::MINW) void eval_pass_q_kernel(QArgs a) {
   auto compute = [&](int buf, int sub, int64_t t) {                       // 16 users x the 16 items of tile t
     const v4* ib = Xb + buf * G::TILE_F4 + (sub * IBT + j) * ROW4 + kq;   // lane (kq, item j): k-quad kq of every 16-block
     v4 accAA = (v4){0.f, 0.f, 0.f, 0.f}, accS = accAA, accAN = accAA, accNN = accAA;
-    // B operands one 16-block ahead of the MFMAs that use them (two register sets): left to itself the compiler re-uses ONE set and
-    // every group of four MFMAs waits out an LDS round trip (measured: the MFMAs + reads alone took 120 us of a 68 us pipe time)
-    constexpr int NB = KA + KS;
-    auto bsrc = [&](int i) { return i < KA ? ib[4 * i] : ib[G::SOFF4 + 4 * (i - KA)]; };
+    // B operands one step ahead of the MFMAs that use them (two register sets): left to itself the compiler re-uses ONE set and
+    // every group of MFMAs waits out an LDS round trip (measured: the MFMAs + reads alone took 120 us of a 68 us pipe time).
+    // Steps: AA's whole blocks, AA's remaining quads, the [L ; Nx] blocks (S, AN and -- the first FN -- NN), their remaining quads
+    // (S, AN), NN's remaining quads.
+    const float* ibf = reinterpret_cast<const float*>(Xb + buf * G::TILE_F4 + (sub * IBT + j) * ROW4) + kq;   // element kq of a k-quad
+    constexpr int S0 = FA, S1 = S0 + TA, S2 = S1 + FS, S3 = S2 + TS, NSTEP = S3 + TN;
+    constexpr int SF = 4 * G::SOFF4;                                       // float offset of [L ; Nx] inside a row
+    auto bsrc = [&](int s) -> v4 {
+      if (s < S0) return ib[4 * s];
+      if (s < S1) return (v4){ibf[16 * FA + 4 * (s - S0)], 0.f, 0.f, 0.f};
+      if (s < S2) return ib[G::SOFF4 + 4 * (s - S1)];
+      if (s < S3) return (v4){ibf[SF + 16 * FS + 4 * (s - S2)], 0.f, 0.f, 0.f};
+      return (v4){ibf[SF + 16 * FN + 4 * (s - S3)], 0.f, 0.f, 0.f};
+    };
     v4 bcur = bsrc(0);
 #pragma unroll
-    for (int i = 0; i < NB; ++i) {
+    for (int s = 0; s < NSTEP; ++s) {
       v4 bnext = bcur;
-      if (i + 1 < NB) bnext = bsrc(i + 1);
+      if (s + 1 < NSTEP) bnext = bsrc(s + 1);
       __builtin_amdgcn_sched_barrier(0);                                   // the read stays ahead of the MFMAs below
-      if (i < KA) {
+      if (s < S0) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) accAA = __builtin_amdgcn_mfma_f32_16x16x4f32(aop[i][c], bcur[c], accAA, 0, 0, 0);
-      } else {
-        const int g = i - KA;
+        for (int c = 0; c < 4; ++c) accAA = __builtin_amdgcn_mfma_f32_16x16x4f32(aAA[s][c], bcur[c], accAA, 0, 0, 0);
+      } else if (s < S1) {
+        accAA = __builtin_amdgcn_mfma_f32_16x16x4f32(tAA[s - S0], bcur[0], accAA, 0, 0, 0);
+      } else if (s < S2) {
+        const int g = s - S1;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          accS = __builtin_amdgcn_mfma_f32_16x16x4f32(aop[KA + g][c], bcur[c], accS, 0, 0, 0);
-          accAN = __builtin_amdgcn_mfma_f32_16x16x4f32(aop[KA + KS + g][c], bcur[c], accAN, 0, 0, 0);
-          if (g < KN) accNN = __builtin_amdgcn_mfma_f32_16x16x4f32(aop[KA + 2 * KS + g][c], bcur[c], accNN, 0, 0, 0);
+          accS = __builtin_amdgcn_mfma_f32_16x16x4f32(aS[g][c], bcur[c], accS, 0, 0, 0);
+          accAN = __builtin_amdgcn_mfma_f32_16x16x4f32(aAN[g][c], bcur[c], accAN, 0, 0, 0);
+          if (g < FN) accNN = __builtin_amdgcn_mfma_f32_16x16x4f32(aNN[g][c], bcur[c], accNN, 0, 0, 0);
         }
+      } else if (s < S3) {
+        accS = __builtin_amdgcn_mfma_f32_16x16x4f32(tS[s - S2], bcur[0], accS, 0, 0, 0);
+        accAN = __builtin_amdgcn_mfma_f32_16x16x4f32(tAN[s - S2], bcur[0], accAN, 0, 0, 0);
+      } else {
+        accNN = __builtin_amdgcn_mfma_f32_16x16x4f32(tNN[s - S3], bcur[0], accNN, 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
       bcur = bnext;

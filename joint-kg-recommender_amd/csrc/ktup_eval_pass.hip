@@ -135,6 +135,53 @@ __global__ __launch_bounds__(MERGE_T) void topk_merge_kernel(const uint64_t* __r
   }
 }
 
+// The filter lists of a pass as bits, built ONCE per pass instead of once per catalogue split inside the sweep (where the walk was 15 of
+// the sweep's 180 us: every split's workgroup of a user block repeated it, latency-bound, before its first tile): one wave per 16
+// consecutive users walks their contiguous run of the CSR ids -- all 64 lanes together, sixteen loads in flight per lane, an entry's
+// row found by comparing its position with the 15 inner offsets --, sets bit (id - split's first item) of word [row][split][.] in
+// LDS and stores the 16 rows as one contiguous run: out[(user * nsplit + split) * bm_words + word].  The waves ride as extra
+// workgroups of the Gram launch (which the sweep waits for anyway).
+struct FiltBm {
+  const int64_t* off; const int32_t* ids; int64_t nq, n_items; uint32_t* out; int nsplit, bm_words; uint32_t split_items; int gram_blocks;
+};
+
+KTUP_DEV void filter_bitmap_wave(const FiltBm& f, int64_t u0, uint32_t* lbm, int lane) {
+  const int wpu = f.nsplit * f.bm_words;
+  for (int idx = lane; idx < 16 * wpu; idx += 64) lbm[idx] = 0u;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const int64_t uo = u0 + (lane < 16 ? lane : 16);
+  const int64_t myoff = f.off[uo < f.nq ? uo : f.nq];
+  const int64_t f_begin = __shfl(myoff, 0, 64), f_end = __shfl(myoff, 16, 64);
+  uint32_t rel[15];
+#pragma unroll
+  for (int k = 0; k < 15; ++k) rel[k] = (uint32_t)(__shfl(myoff, k + 1, 64) - f_begin);
+  constexpr int FB = 16;                                               // loads in flight per lane
+  for (int64_t base = f_begin; base < f_end; base += 64 * FB) {
+    int32_t ids[FB];
+#pragma unroll
+    for (int k = 0; k < FB; ++k) {
+      const int64_t e = base + lane + 64 * k;
+      ids[k] = e < f_end ? f.ids[e] : -1;
+    }
+#pragma unroll
+    for (int k = 0; k < FB; ++k) {
+      const uint32_t pos = (uint32_t)(base - f_begin) + lane + 64 * k;
+      int r = 0;
+#pragma unroll
+      for (int q = 0; q < 15; ++q) r += pos >= rel[q] ? 1 : 0;
+      if (ids[k] >= 0 && ids[k] < f.n_items) {
+        const uint32_t id = (uint32_t)ids[k], sp = id / f.split_items, lid = id - sp * f.split_items;
+        atomicOr(lbm + r * wpu + sp * f.bm_words + (lid >> 5), 1u << (lid & 31));
+      }
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  uint32_t* o = f.out + u0 * wpu;                                      // (sized for whole 64-user blocks: rows past nq are all-zero)
+  for (int idx = lane; idx < 16 * wpu; idx += 64) o[idx] = lbm[idx];
+}
+
 // ================================================================================================ preference-space formulation
 // Six d-long products per pair (u.NV, NU.v, AU.C0, AU.NV, NU.C0, NU.NV: round 2's first fused pass, 0.39 ms per ml1m sweep) are
 // more work than the model needs.  With the soft gate every vector of the score lives in
@@ -188,6 +235,7 @@ struct QArgs {
   int64_t nq, n_items;
   const int64_t* filt_off; const int32_t* filt_ids;
   int topn, nsplit; int64_t split_items; uint64_t* part; int bm_words;
+  const uint32_t* bmg;           // the filter lists as bits, [user][split][bm_words] (filter_bitmap_wave); NULL: the sweep walks the lists itself
   int dbg;                       // MEASUREMENT ONLY (option dbg_eval): 1 no ranking epilogue, 2 no item loads, 4 no workgroup barrier per tile, 8 no tiles at all
 };
 
@@ -206,17 +254,44 @@ __global__ __launch_bounds__(256, G::MINW) void eval_pass_q_kernel(QArgs a) {
   uint64_t* pbuf = reinterpret_cast<uint64_t*>(wbase + wave_lds_bytes(a.bm_words) - WAVE_TAIL);   // [16][PCAP] pending candidates
   uint64_t* tk = pbuf + 16 * PCAP;                                        // [16][16] the users' sorted lists (touched by merges only)
   uint64_t* thrk = tk + 16 * 16;                                          // [16] their n-th keys (read where floats cannot decide)
-  const int64_t u0 = (int64_t)blockIdx.x * 64 + 16 * w;
-  const int64_t i_lo = (int64_t)blockIdx.y * a.split_items;
+  // Which (user block, split) this workgroup takes: workgroups go to the 8 XCDs round-robin in launch order and every XCD has an L2 of
+  // its own, so with (blockIdx.x, blockIdx.y) taken as they come the 8 splits of a user block sit on 8 different XCDs and EVERY L2
+  // fetches EVERY user row (8 x 6.6 MB over the fabric at ml1m size, ~10 us of prologue).  XCD x (launch-order ids x, x + 8, ...) takes
+  // a contiguous run of the pairs ordered user block major instead: its L2 then holds ~1/8 of the user rows (the item rows it needs
+  // entirely either way).
+  int ub, sp;
+  {
+    const uint32_t L = blockIdx.x + gridDim.x * blockIdx.y, total = gridDim.x * gridDim.y;
+    const uint32_t x = L & 7u, per = total >> 3, rem = total & 7u;
+    const uint32_t q = x * per + (x < rem ? x : rem) + (L >> 3);
+    ub = (int)(q / (uint32_t)a.nsplit);
+    sp = (int)(q - (uint32_t)ub * (uint32_t)a.nsplit);
+  }
+  const int64_t u0 = (int64_t)ub * 64 + 16 * w;
+  const int64_t i_lo = (int64_t)sp * a.split_items;
   const int64_t i_hi = min(a.n_items, i_lo + a.split_items);
   const int topn = a.topn;
+  // the wave's filter bits from the pass's bitmap (filter_bitmap_wave): requested first, stored after the other set-up work below
+  constexpr int BMR = 8;                                                  // words per lane held in flight (more: a second trip)
+  const bool use_bmg = a.bmg != nullptr && a.filt_off && !(a.dbg & 16);
+  uint32_t bmv[BMR];
+  if (use_bmg) {
+    const int nw = 16 * a.bm_words;
+#pragma unroll
+    for (int k = 0; k < BMR; ++k) {
+      const int idx = lane + 64 * k, r = idx / a.bm_words;
+      bmv[k] = idx < nw ? a.bmg[((u0 + r) * a.nsplit + sp) * a.bm_words + (idx - r * a.bm_words)] : 0u;
+    }
+  }
   for (int idx = tid; idx < 2 * G::TILE_F4; idx += 256) Xb[idx] = (v4){0.f, 0.f, 0.f, 0.f};   // row pads stay finite (x 0 operands)
-  for (int idx = lane; idx < 16 * a.bm_words; idx += 64) bm[idx] = 0u;
+  if (!use_bmg)
+    for (int idx = lane; idx < 16 * a.bm_words; idx += 64) bm[idx] = 0u;
   for (int idx = lane; idx < 16 * 16; idx += 64) tk[idx] = PKEY_MAX;
   if (lane < 16) thrk[lane] = u0 + lane < a.nq ? PKEY_MAX : 0;            // rows past the end: nothing is ever below
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
-  if (a.filt_off && !(a.dbg & 16)) {
+  if (a.filt_off && !use_bmg && !(a.dbg & 16)) {
+    // (No bitmap of the pass -- it would not fit the scratch cap: every split's workgroup walks the lists itself.)
     // The 16 users of a wave are consecutive, so their filter lists are ONE contiguous run of the CSR ids: all 64 lanes walk it together
     // (sixteen independent loads in flight per lane) and find an entry's row by comparing its position with the 15 inner offsets.  (One list
     // after the other -- 48 dependent round trips -- was 18 of the sweep's 200 us, every split's workgroups repeating it; now 11.)
@@ -269,6 +344,16 @@ __global__ __launch_bounds__(256, G::MINW) void eval_pass_q_kernel(QArgs a) {
     for (int g = 0; g < FN; ++g) aNN[g] = ok ? r0[oNN / 4 + 4 * g + kq] : z4;
 #pragma unroll
     for (int m = 0; m < TN; ++m) tNN[m] = ok ? rf[oNN + 16 * FN + 4 * m + kq] : 0.f;
+  }
+  if (use_bmg) {
+    const int nw = 16 * a.bm_words;
+#pragma unroll
+    for (int k = 0; k < BMR; ++k)
+      if (lane + 64 * k < nw) bm[lane + 64 * k] = bmv[k];
+    for (int idx = lane + 64 * BMR; idx < nw; idx += 64) {                // (splits of more than 1024 items)
+      const int r = idx / a.bm_words;
+      bm[idx] = a.bmg[((u0 + r) * a.nsplit + sp) * a.bm_words + (idx - r * a.bm_words)];
+    }
   }
   __syncthreads();                                                        // tiles zeroed, bitmaps and scalars in place
   const int64_t ntile = (a.dbg & 8) ? 0 : (i_hi - i_lo + IBT - 1) / IBT;    // (dbg 8: prologue and epilogue only)
@@ -433,7 +518,7 @@ __global__ __launch_bounds__(256, G::MINW) void eval_pass_q_kernel(QArgs a) {
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
       const int64_t ur = u0 + 4 * kq + reg;
-      if (ur < a.nq) a.part[(ur * a.nsplit + blockIdx.y) * topn + j] = tk[(4 * kq + reg) * 16 + j];
+      if (ur < a.nq) a.part[(ur * a.nsplit + sp) * topn + j] = tk[(4 * kq + reg) * 16 + j];
     }
   }
 }
@@ -448,9 +533,17 @@ KTUP_DEV int gs_index(int mtx, int p, int q, int PT, int NP) {
 }
 
 __global__ __launch_bounds__(256) void pspace_gram_kernel(const float* __restrict__ Ar, const float* __restrict__ Cn, int dp, int d, int P, int P4,
-                                                          float* __restrict__ grams, float* __restrict__ gs, int PT, int NP) {
+                                                          float* __restrict__ grams, float* __restrict__ gs, int PT, int NP, FiltBm fb) {
   const int lane = threadIdx.x & 63;
-  for (int idx = blockIdx.x * 4 + (threadIdx.x >> 6); idx < 3 * P4 * P4; idx += gridDim.x * 4) {
+  if ((int)blockIdx.x >= fb.gram_blocks) {                       // the pass's filter bitmap: four waves x 16 users per extra workgroup
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    filter_bitmap_wave(fb, ((int64_t)((int)blockIdx.x - fb.gram_blocks) * 4 + w) * 16,
+                       reinterpret_cast<uint32_t*>(smem) + (size_t)w * 16 * fb.nsplit * fb.bm_words, lane);
+    return;
+  }
+  const int gridx = fb.gram_blocks;
+  for (int idx = blockIdx.x * 4 + (threadIdx.x >> 6); idx < 3 * P4 * P4; idx += gridx * 4) {
     const int t = idx / (P4 * P4), rem = idx - t * P4 * P4, p = rem / P4, q = rem - p * P4;
     float acc = 0.f;
     if (p < P && q < P) {
@@ -468,7 +561,7 @@ __global__ __launch_bounds__(256) void pspace_gram_kernel(const float* __restric
     }
   }
   if (gs && 16 * PT > P4)                                        // rows P4 .. 16 PT - 1 of the last row tile: zero
-    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < 4 * (16 * PT - P4) * P4; idx += gridDim.x * 256) {
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < 4 * (16 * PT - P4) * P4; idx += gridx * 256) {
       const int mtx = idx / ((16 * PT - P4) * P4), rem = idx - mtx * (16 * PT - P4) * P4;
       gs[gs_index(mtx, P4 + rem / P4, rem % P4, PT, NP)] = 0.f;
     }
@@ -616,10 +709,16 @@ struct RGeom {
 template <int NCH, int NP>
 __global__ __launch_bounds__(256) void pspace_rows_mc_kernel(RowsSide users, RowsSide items, int P, const float* __restrict__ Alog,
                                                              const float* __restrict__ Ar, const float* __restrict__ Cn, int dp,
-                                                             const float* __restrict__ gs, int ka16, int ks16) {
+                                                             const float* __restrict__ gs, int ka16, int ks16, FiltBm fb) {
   using R = RGeom<NCH, NP>;
   constexpr int D = R::D, P4 = R::P4, PT = R::PT, KG = R::KG, PITCHA4 = R::PITCHA4, J = R::J;
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  if ((int)blockIdx.x >= users.blocks + items.blocks) {          // the pass's filter bitmap rides here: the walk is one wave's chain of
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // round trips (~10 us), as long as this launch and on CUs it leaves idle
+    filter_bitmap_wave(fb, ((int64_t)((int)blockIdx.x - users.blocks - items.blocks) * 4 + wv) * 16,
+                       reinterpret_cast<uint32_t*>(smem) + (size_t)wv * 16 * fb.nsplit * fb.bm_words, threadIdx.x & 63);
+    return;
+  }
   v4* Slot = reinterpret_cast<v4*>(smem);                         // [3][PT * 16 slots][PITCHA4]
   float* GS = reinterpret_cast<float*>(Slot + 3 * R::SLOT_F4);
   const int tid = threadIdx.x, lane = tid & 63, kq = lane >> 4, j = lane & 15;
@@ -791,7 +890,15 @@ __global__ __launch_bounds__(256) void pspace_rows_mc_kernel(RowsSide users, Row
   }
 }
 
-struct QScratch { float *grams, *gs, *A, *SCU, *B; uint64_t* part; };
+struct QScratch { float *grams, *gs, *A, *SCU, *B; uint64_t* part; uint32_t* bm; };
+
+// Words of the pass's filter bitmap per user for ANY split count <= 8 (nsplit x ceil(split_items / 32) with split_items = 16 x
+// ceil(tiles / nsplit)), and the cap under which the pass builds one (beyond it every split's workgroup walks the CSR lists itself)
+inline size_t filt_bm_words_per_user(int64_t n_items) { return (size_t)((n_items + IBT - 1) / IBT) / 2 + 13; }
+inline size_t filt_bm_bytes(int64_t nq, int64_t n_items) {
+  const size_t b = (size_t)((nq + 63) / 64) * 64 * filt_bm_words_per_user(n_items) * sizeof(uint32_t);
+  return b <= ((size_t)128 << 20) ? b : 0;
+}
 
 template <typename G>
 QScratch q_carve(void* scratch, int64_t nq, int64_t n_items) {
@@ -803,6 +910,7 @@ QScratch q_carve(void* scratch, int64_t nq, int64_t n_items) {
   s.SCU = p; p += (size_t)nq * 4;
   s.B = p; p += (size_t)n_items * G::GROW + 64;                  // (eval_pass_pspace_bytes counts the same)
   s.part = reinterpret_cast<uint64_t*>(p);
+  s.bm = reinterpret_cast<uint32_t*>(s.part + (size_t)nq * 8 * TOPN_MAX);   // (eval_pass_pspace_bytes: nq x 8 x topn keys, topn <= TOPN_MAX)
   return s;
 }
 
@@ -818,17 +926,38 @@ int launch_q(const float* U, int64_t ldu, const int64_t* u_ids, int64_t nq, cons
   const bool rows_mc = opt_eval_mc() && !((ldu | ldi | lde | dp) & 3) && aligned16(U) && aligned16(I) && (!E || aligned16(E)) && aligned16(pref_ws) &&
                        nq < (1ll << 31) && n_items < (1ll << 31);
   using R = RGeom<G::NCH, G::NP>;
-  hipLaunchKernelGGL(pspace_gram_kernel, dim3((3 * G::P4 * G::P4 + 3) / 4), dim3(256), 0, st, Ar, Cn, dp, G::D, n_pref, G::P4, q.grams,
-                     rows_mc ? q.gs : nullptr, R::PT, G::NP);
+  // the catalogue splits of the sweep (decided here: the filter bitmap is laid out by split)
+  const int64_t ublocks = (nq + 63) / 64;
+  int nsplit = (int)(256 * G::MINW / ublocks);                            // MINW workgroups per CU are resident: ONE round
+  if (nsplit > 8) nsplit = 8;
+  if (opt_eval_nsplit() > 0 && opt_eval_nsplit() <= 8) nsplit = opt_eval_nsplit();   // measurement knob
+  const int64_t tiles = (n_items + IBT - 1) / IBT;
+  if (nsplit > tiles) nsplit = (int)tiles;
+  if (nsplit < 1) nsplit = 1;
+  const int64_t split_items = ((tiles + nsplit - 1) / nsplit) * IBT;
+  nsplit = (int)((n_items + split_items - 1) / split_items);
+  const int bm_words = (int)((split_items + 31) / 32);
+  const size_t lds = (size_t)2 * G::TILE_F4 * 16 + 4 * wave_lds_bytes(bm_words);
+  if (lds > 160 * 1024) return 1;
+  const int gram_blocks = (3 * G::P4 * G::P4 + 3) / 4;
+  const size_t bm_lds = (size_t)4 * 16 * nsplit * bm_words * sizeof(uint32_t);
+  const bool use_bm = filt_off && filt_ids && filt_bm_bytes(nq, n_items) && (size_t)nsplit * bm_words <= filt_bm_words_per_user(n_items) &&
+                      bm_lds <= 64 * 1024;
+  FiltBm fb{filt_off, filt_ids, nq, n_items, q.bm, nsplit, bm_words, (uint32_t)split_items, gram_blocks};
+  // the bitmap's waves ride in the operand-row launch (16 us, 146 workgroups at ml1m size); without the matrix-core row kernel, in the Gram launch
+  const bool bm_in_gram = use_bm && !rows_mc;
+  hipLaunchKernelGGL(pspace_gram_kernel, dim3(gram_blocks + (bm_in_gram ? (unsigned)ublocks : 0u)), dim3(256), bm_in_gram ? bm_lds : 0, st, Ar, Cn, dp,
+                     G::D, n_pref, G::P4, q.grams, rows_mc ? q.gs : nullptr, R::PT, G::NP, fb);
   const size_t lds_rows = (size_t)4 * (G::D + 7 * G::P4) * sizeof(float);
   // many small workgroups: a row is a chain of dependent round trips (id -> row -> products -> store), hidden only by occupancy
   RowsSide us{U, ldu, u_ids, nullptr, 0, nullptr, nq, q.A, G::AROW, q.SCU, grid_for((nq + 3) / 4, 2048), G::AROW, 4};
   RowsSide is{I, ldi, nullptr, E, lde, item2ent, n_items, q.B, G::ROWB, q.B + G::ROWB, grid_for((n_items + 3) / 4, 2048), G::GROW, G::GROW};
   if (rows_mc) {    // 16 rows per wave on the matrix cores
     us.blocks = (int)((nq + 63) / 64); is.blocks = (int)((n_items + 63) / 64);
-    (void)hipFuncSetAttribute((const void*)pspace_rows_mc_kernel<G::NCH, G::NP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)R::LDS);
-    hipLaunchKernelGGL((pspace_rows_mc_kernel<G::NCH, G::NP>), dim3(us.blocks + is.blocks), dim3(256), R::LDS, st, us, is, n_pref, Alog, Ar, Cn, dp,
-                       q.gs, G::KA, G::KS);
+    const size_t rows_lds = use_bm && bm_lds > R::LDS ? bm_lds : R::LDS;
+    (void)hipFuncSetAttribute((const void*)pspace_rows_mc_kernel<G::NCH, G::NP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rows_lds);
+    hipLaunchKernelGGL((pspace_rows_mc_kernel<G::NCH, G::NP>), dim3(us.blocks + is.blocks + (use_bm ? (unsigned)ublocks : 0u)), dim3(256), rows_lds, st,
+                       us, is, n_pref, Alog, Ar, Cn, dp, q.gs, G::KA, G::KS, fb);
   } else {
     hipLaunchKernelGGL((pspace_rows_kernel<G::NCH, G::NP>), dim3(us.blocks + is.blocks), dim3(256), lds_rows, st, us, is, n_pref, Alog, Ar, Cn, dp,
                        q.grams, G::KA, G::KS);
@@ -837,19 +966,7 @@ int launch_q(const float* U, int64_t ldu, const int64_t* u_ids, int64_t nq, cons
   QArgs a{};
   a.A = q.A; a.SCU = q.SCU; a.B = q.B; a.nq = nq; a.n_items = n_items;
   a.filt_off = filt_off; a.filt_ids = filt_ids; a.topn = topn; a.part = q.part; a.dbg = opt_dbg_eval();
-  const int64_t ublocks = (nq + 63) / 64;
-  int nsplit = (int)(256 * G::MINW / ublocks);                            // MINW workgroups per CU are resident: ONE round
-  if (nsplit > 8) nsplit = 8;
-  if (opt_eval_nsplit() > 0 && opt_eval_nsplit() <= 8) nsplit = opt_eval_nsplit();   // measurement knob
-  const int64_t tiles = (n_items + IBT - 1) / IBT;
-  if (nsplit > tiles) nsplit = (int)tiles;
-  if (nsplit < 1) nsplit = 1;
-  a.split_items = ((tiles + nsplit - 1) / nsplit) * IBT;
-  nsplit = (int)((n_items + a.split_items - 1) / a.split_items);
-  a.nsplit = nsplit;
-  a.bm_words = (int)((a.split_items + 31) / 32);
-  const size_t lds = (size_t)2 * G::TILE_F4 * 16 + 4 * wave_lds_bytes(a.bm_words);
-  if (lds > 160 * 1024) return 1;
+  a.split_items = split_items; a.nsplit = nsplit; a.bm_words = bm_words; a.bmg = use_bm ? q.bm : nullptr;
   (void)hipFuncSetAttribute((const void*)eval_pass_q_kernel<G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL((eval_pass_q_kernel<G>), dim3((unsigned)ublocks, (unsigned)nsplit), dim3(256), lds, st, a);
   if (int e = check_launch(name)) return e;
@@ -888,7 +1005,9 @@ size_t eval_pass_pspace_bytes(int d, int n_pref, int64_t nq, int64_t n_items, in
   const size_t p4 = n_pref <= 4 ? 4 : n_pref <= 20 ? 20 : 32;
   const size_t ka = (d + 2 * p4 + 15) / 16, ks = (2 * p4 + 15) / 16, kn = (p4 + 15) / 16;
   const size_t arow = 16 * (ka + 2 * ks + kn), rowb = d + 3 * p4, grow = 4 * ((rowb / 4 + 1) | 1);      // QGeom::AROW, ROWB, GROW
-  return (3 * 32 * 32 + 4 * 2 * 8 * 64 + (size_t)nq * (arow + 4) + (size_t)n_items * grow + 64) * sizeof(float) + (size_t)nq * 8 * topn * sizeof(uint64_t);
+  (void)topn;
+  return (3 * 32 * 32 + 4 * 2 * 8 * 64 + (size_t)nq * (arow + 4) + (size_t)n_items * grow + 64) * sizeof(float) +
+         (size_t)nq * 8 * TOPN_MAX * sizeof(uint64_t) + filt_bm_bytes(nq, n_items);
 }
 
 // Items: I[row] (+ E[item2ent[row]] for KTUP; E == NULL for TUP); pref_ws: the prepared tables (ktup_pref_prepare; ppad / dp its

@@ -235,6 +235,8 @@ struct QArgs {
   int64_t nq, n_items;
   const int64_t* filt_off; const int32_t* filt_ids;
   int topn, nsplit; int64_t split_items; uint64_t* part; int bm_words;
+  int32_t* gthr;                 // [nq (+ pad to whole 64-user blocks)] the best n-th score any split of a user has reached, as the bits of a
+                                 // non-negative float (0x7fffffff: none yet); see the tile loop
   const uint32_t* bmg;           // the filter lists as bits, [user][split][bm_words] (filter_bitmap_wave); NULL: the sweep walks the lists itself
   int dbg;                       // MEASUREMENT ONLY (option dbg_eval): 1 no ranking epilogue, 2 no item loads, 4 no workgroup barrier per tile, 8 no tiles at all
 };
@@ -391,8 +393,15 @@ __global__ __launch_bounds__(256, G::MINW) void eval_pass_q_kernel(QArgs a) {
   // register slot holds 16, that slot's four rows go through the merge network -- 16 real candidates per network pass instead of the
   // ~2 a tile yields -- and the thresholds are renewed.  (The network per tile and slot was 400 of this kernel's ~670 VALU
   // instructions per tile.)
-  float thrf[4];
+  // The splits of a user share their bounds (a.gthr): any split's n-th score bounds the user's final n-th score from above, so a
+  // score above it is no candidate anywhere (a split's list may then end short: the merge pads).  Published at every merge, re-read
+  // once per tile -- requested before the tile's MFMAs (past the L1: the line changes under the kernel), used after them.  A stale
+  // value is an older bound, never a wrong one.  With the XCD-aware mapping above a user's splits share one L2.  Each split alone
+  // sends ~47 candidates per user through the append / merge path below, together ~4x fewer.
+  float thrf[4], gth[4];
   int pend[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) gth[reg] = __uint_as_float(0x7fffffffu);
 #pragma unroll
   for (int reg = 0; reg < 4; ++reg) thrf[reg] = u0 + 4 * kq + reg < a.nq ? __uint_as_float(0x7fffffffu) : -__builtin_inff();
   const uint32_t lt_j = (1u << j) - 1u;
@@ -414,14 +423,20 @@ __global__ __launch_bounds__(256, G::MINW) void eval_pass_q_kernel(QArgs a) {
       pend[reg] = 0;
       if (u0 + ur < a.nq) {                                                       // (rows past the end keep thrf = -inf, thrk = 0)
         const uint32_t hi = (uint32_t)__shfl((int)(merged >> 32), rowbase + topn - 1, 64);
-        thrf[reg] = __uint_as_float((hi & 0x80000000u) ? (hi & 0x7fffffffu) : ~hi);   // inverse of the order-preserving image (NaN: list short)
-        if (j == topn - 1) thrk[ur] = merged;
+        const float own = __uint_as_float((hi & 0x80000000u) ? (hi & 0x7fffffffu) : ~hi);   // inverse of the order-preserving image (NaN: list short)
+        thrf[reg] = __builtin_fminf(own, gth[reg]);                               // (the number where one of the two is a NaN)
+        if (j == topn - 1) {
+          thrk[ur] = merged;
+          // the splits of a user tell each other: non-negative floats order like their bits (a negative n-th score -- rounding of a
+          // squared distance -- is published as 0: a weaker bound, still one)
+          if (a.gthr && own == own) atomicMin(a.gthr + u0 + ur, __float_as_int(__builtin_fmaxf(own, 0.f)));
+        }
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
   };
-  auto compute = [&](int buf, int sub, int64_t t) {                       // 16 users x the 16 items of tile t
+  auto compute = [&](int buf, int sub, int64_t t, const int (&gl)[4]) {   // 16 users x the 16 items of tile t
     const v4* ib = Xb + buf * G::TILE_F4 + (sub * IBT + j) * ROW4 + kq;   // lane (kq, item j): k-quad kq of every 16-block
     v4 accAA = (v4){0.f, 0.f, 0.f, 0.f}, accS = accAA, accAN = accAA, accNN = accAA;
     // B operands one step ahead of the MFMAs that use them (two register sets): left to itself the compiler re-uses ONE set and
@@ -478,6 +493,8 @@ __global__ __launch_bounds__(256, G::MINW) void eval_pass_q_kernel(QArgs a) {
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
       const int ur = 4 * kq + reg;
+      gth[reg] = __int_as_float(gl[reg]);
+      thrf[reg] = __builtin_fminf(thrf[reg], gth[reg]);
       const v4 us4 = *reinterpret_cast<const v4*>(usc + ur * 4);
       const float sv = (us4[0] + accS[reg]) - is4[0];
       const float aa = (us4[1] + is4[1]) + accAA[reg];
@@ -510,7 +527,12 @@ __global__ __launch_bounds__(256, G::MINW) void eval_pass_q_kernel(QArgs a) {
   for (int64_t t0 = 0; t0 < ntile; ++t0) {
     const int buf = (int)(t0 & 1);
     if (t0 + 1 < ntile && !(a.dbg & 2)) dma(t0 + 1, buf ^ 1);
-    compute((a.dbg & 2) ? 0 : buf, 0, t0);
+    int gl[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
+    if (a.gthr) {
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) gl[reg] = __hip_atomic_load(a.gthr + u0 + 4 * kq + reg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    compute((a.dbg & 2) ? 0 : buf, 0, t0, gl);
     if (!(a.dbg & 4)) __syncthreads();
   }
   flush(true);
@@ -574,6 +596,7 @@ struct RowsSide {
   const float* E; int64_t lde; const int32_t* map;    // + E[map[row]] (KTUP items: the aligned entity, the pad row being zero); NULL = none
   int64_t nrows; float* out; int orow; float* scal; int blocks;
   int opitch, spitch;                                 // floats between two rows of out / of scal (items: both G::GROW, scal = out + ROWB)
+  int32_t* gthr;                                      // users: the sweep's shared n-th score per user, reset here (NULL: none / items)
 };
 
 template <bool IS_USER, int NCH, int NP>
@@ -664,6 +687,7 @@ KTUP_DEV void pspace_rows(const RowsSide& sd, int block, int P, const float* __r
       }
       // u.NU, |AU|^2, AU.NU, |NU|^2
       if (lane == 0) *reinterpret_cast<float4*>(scal + row * (int64_t)sd.spitch) = make_float4(d_nl, sq + 2.f * d_rl + q_rr, d_nl + q_rn, q_nn);
+      if (lane == 0 && sd.gthr) sd.gthr[row] = 0x7fffffff;
     } else {
       // [x ; Rx ; L ; Nx]
       for (int k = lane; k < orow; k += 64) o[k] = k < d ? xs[k] : k < d + P4 ? Rx[k - d] : k < d + 2 * P4 ? L[k - d - P4] : Nx[k - d - 2 * P4];
@@ -869,6 +893,7 @@ __global__ __launch_bounds__(256) void pspace_rows_mc_kernel(RowsSide users, Row
     for (int k = oNN + P4 + kq; k < orow; k += 4) o[k] = 0.f;
     // u.NU, |AU|^2, AU.NU, |NU|^2
     if (kq == 0) *reinterpret_cast<float4*>(sd.scal + row * (int64_t)sd.spitch) = make_float4(d_nl, sq + 2.f * d_rl + q_rr, d_nl + q_rn, q_nn);
+    if (kq == 0 && sd.gthr) sd.gthr[row] = 0x7fffffff;
   } else {
     // [x ; Rx ; L ; Nx]
 #pragma unroll
@@ -890,7 +915,7 @@ __global__ __launch_bounds__(256) void pspace_rows_mc_kernel(RowsSide users, Row
   }
 }
 
-struct QScratch { float *grams, *gs, *A, *SCU, *B; uint64_t* part; uint32_t* bm; };
+struct QScratch { float *grams, *gs, *A, *SCU, *B; uint64_t* part; uint32_t* bm; int32_t* gthr; };
 
 // Words of the pass's filter bitmap per user for ANY split count <= 8 (nsplit x ceil(split_items / 32) with split_items = 16 x
 // ceil(tiles / nsplit)), and the cap under which the pass builds one (beyond it every split's workgroup walks the CSR lists itself)
@@ -910,7 +935,8 @@ QScratch q_carve(void* scratch, int64_t nq, int64_t n_items) {
   s.SCU = p; p += (size_t)nq * 4;
   s.B = p; p += (size_t)n_items * G::GROW + 64;                  // (eval_pass_pspace_bytes counts the same)
   s.part = reinterpret_cast<uint64_t*>(p);
-  s.bm = reinterpret_cast<uint32_t*>(s.part + (size_t)nq * 8 * TOPN_MAX);   // (eval_pass_pspace_bytes: nq x 8 x topn keys, topn <= TOPN_MAX)
+  s.gthr = reinterpret_cast<int32_t*>(s.part + (size_t)nq * 8 * TOPN_MAX);  // (eval_pass_pspace_bytes: nq x 8 x topn keys, topn <= TOPN_MAX)
+  s.bm = reinterpret_cast<uint32_t*>(s.gthr + ((nq + 63) / 64) * 64);
   return s;
 }
 
@@ -950,8 +976,8 @@ int launch_q(const float* U, int64_t ldu, const int64_t* u_ids, int64_t nq, cons
                      G::D, n_pref, G::P4, q.grams, rows_mc ? q.gs : nullptr, R::PT, G::NP, fb);
   const size_t lds_rows = (size_t)4 * (G::D + 7 * G::P4) * sizeof(float);
   // many small workgroups: a row is a chain of dependent round trips (id -> row -> products -> store), hidden only by occupancy
-  RowsSide us{U, ldu, u_ids, nullptr, 0, nullptr, nq, q.A, G::AROW, q.SCU, grid_for((nq + 3) / 4, 2048), G::AROW, 4};
-  RowsSide is{I, ldi, nullptr, E, lde, item2ent, n_items, q.B, G::ROWB, q.B + G::ROWB, grid_for((n_items + 3) / 4, 2048), G::GROW, G::GROW};
+  RowsSide us{U, ldu, u_ids, nullptr, 0, nullptr, nq, q.A, G::AROW, q.SCU, grid_for((nq + 3) / 4, 2048), G::AROW, 4, q.gthr};
+  RowsSide is{I, ldi, nullptr, E, lde, item2ent, n_items, q.B, G::ROWB, q.B + G::ROWB, grid_for((n_items + 3) / 4, 2048), G::GROW, G::GROW, nullptr};
   if (rows_mc) {    // 16 rows per wave on the matrix cores
     us.blocks = (int)((nq + 63) / 64); is.blocks = (int)((n_items + 63) / 64);
     const size_t rows_lds = use_bm && bm_lds > R::LDS ? bm_lds : R::LDS;
@@ -967,6 +993,7 @@ int launch_q(const float* U, int64_t ldu, const int64_t* u_ids, int64_t nq, cons
   a.A = q.A; a.SCU = q.SCU; a.B = q.B; a.nq = nq; a.n_items = n_items;
   a.filt_off = filt_off; a.filt_ids = filt_ids; a.topn = topn; a.part = q.part; a.dbg = opt_dbg_eval();
   a.split_items = split_items; a.nsplit = nsplit; a.bm_words = bm_words; a.bmg = use_bm ? q.bm : nullptr;
+  a.gthr = nsplit > 1 && !(a.dbg & 64) ? q.gthr : nullptr;
   (void)hipFuncSetAttribute((const void*)eval_pass_q_kernel<G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL((eval_pass_q_kernel<G>), dim3((unsigned)ublocks, (unsigned)nsplit), dim3(256), lds, st, a);
   if (int e = check_launch(name)) return e;
@@ -1007,7 +1034,7 @@ size_t eval_pass_pspace_bytes(int d, int n_pref, int64_t nq, int64_t n_items, in
   const size_t arow = 16 * (ka + 2 * ks + kn), rowb = d + 3 * p4, grow = 4 * ((rowb / 4 + 1) | 1);      // QGeom::AROW, ROWB, GROW
   (void)topn;
   return (3 * 32 * 32 + 4 * 2 * 8 * 64 + (size_t)nq * (arow + 4) + (size_t)n_items * grow + 64) * sizeof(float) +
-         (size_t)nq * 8 * TOPN_MAX * sizeof(uint64_t) + filt_bm_bytes(nq, n_items);
+         (size_t)nq * 8 * TOPN_MAX * sizeof(uint64_t) + (size_t)((nq + 63) / 64) * 64 * sizeof(int32_t) + filt_bm_bytes(nq, n_items);
 }
 
 // Items: I[row] (+ E[item2ent[row]] for KTUP; E == NULL for TUP); pref_ws: the prepared tables (ktup_pref_prepare; ppad / dp its

@@ -469,10 +469,12 @@ def eval_bench(device, batch=512, seed=11, keep=None):
             m.evaluate_topk(all_u, items, 10, index.f_off, index.f_ids)
         b.record(); torch.cuda.synchronize(device)
         sweep_ms = a.elapsed_time(b) / 20
-        # matrix work of the sweep: every user x item cross term in preference space, K = (d + 2P) + 2P + 2P + P padded to
-        # 16-blocks = 272 multiply-adds per pair at d = 100, P = 20 (the six d-long products of the batched route: 600)
+        # matrix work of the sweep: every user x item cross term in preference space, K = (d + 2P) + 2P + 2P + P = 240 multiply-adds
+        # per pair at d = 100, P = 20 -- 60 MFMAs per 16 x 16 tile; until round 6 the sweep multiplied the zero padding of the last
+        # 16-blocks too (272, 68 MFMAs), and the round-5 fractions were quoted on those 544 flop (the six d-long products of the
+        # batched route: 600 multiply-adds)
         p4 = 4 if NR <= 4 else 20 if NR <= 20 else 32           # preferences = relations in KTUP
-        kpad = sum(-(-k // 16) * 16 for k in (D + 2 * p4, 2 * p4, 2 * p4, p4))
+        kpad = sum((D + 2 * p4, 2 * p4, 2 * p4, p4))
         flop = 2.0 * NU * NI * kpad
         fused = {'full_pass_ms_incl_metrics': fused_ms, 'device_ms_scores_and_topk': sweep_ms,
                  'mfma_flop_per_pair': 2 * kpad, 'gemm_tflops_over_sweep': flop / (sweep_ms * 1e-3) / 1e12,

@@ -226,7 +226,7 @@ struct QGeom {
 #ifndef KTUP_EVAL_MINW3
 #define KTUP_EVAL_MINW3 3
 #endif
-  static constexpr int MINW = NA <= 18 ? KTUP_EVAL_MINW3 : 2;                 // waves per SIMD the register budget allows (= workgroups per CU)
+  static constexpr int MINW = NREG <= 64 ? KTUP_EVAL_MINW3 : 2;                 // waves per SIMD the register budget allows (= workgroups per CU)
 };
 
 struct QArgs {
@@ -398,10 +398,8 @@ __global__ __launch_bounds__(256, G::MINW) void eval_pass_q_kernel(QArgs a) {
   // once per tile -- requested before the tile's MFMAs (past the L1: the line changes under the kernel), used after them.  A stale
   // value is an older bound, never a wrong one.  With the XCD-aware mapping above a user's splits share one L2.  Each split alone
   // sends ~47 candidates per user through the append / merge path below, together ~4x fewer.
-  float thrf[4], gth[4];
+  float thrf[4];
   int pend[4] = {0, 0, 0, 0};
-#pragma unroll
-  for (int reg = 0; reg < 4; ++reg) gth[reg] = __uint_as_float(0x7fffffffu);
 #pragma unroll
   for (int reg = 0; reg < 4; ++reg) thrf[reg] = u0 + 4 * kq + reg < a.nq ? __uint_as_float(0x7fffffffu) : -__builtin_inff();
   const uint32_t lt_j = (1u << j) - 1u;
@@ -424,7 +422,7 @@ __global__ __launch_bounds__(256, G::MINW) void eval_pass_q_kernel(QArgs a) {
       if (u0 + ur < a.nq) {                                                       // (rows past the end keep thrf = -inf, thrk = 0)
         const uint32_t hi = (uint32_t)__shfl((int)(merged >> 32), rowbase + topn - 1, 64);
         const float own = __uint_as_float((hi & 0x80000000u) ? (hi & 0x7fffffffu) : ~hi);   // inverse of the order-preserving image (NaN: list short)
-        thrf[reg] = __builtin_fminf(own, gth[reg]);                               // (the number where one of the two is a NaN)
+        thrf[reg] = own;                                                          // (the next tile's refresh brings the shared bound back)
         if (j == topn - 1) {
           thrk[ur] = merged;
           // the splits of a user tell each other: non-negative floats order like their bits (a negative n-th score -- rounding of a
@@ -493,18 +491,21 @@ __global__ __launch_bounds__(256, G::MINW) void eval_pass_q_kernel(QArgs a) {
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
       const int ur = 4 * kq + reg;
-      gth[reg] = __int_as_float(gl[reg]);
-      thrf[reg] = __builtin_fminf(thrf[reg], gth[reg]);
+      // (as integers: gl is a non-negative float's bits or 0x7fffffff, and a bound of this split that is negative, -inf or a NaN of
+      //  either sign keeps the meaning it has without the shared word)
+      thrf[reg] = __int_as_float(min(__float_as_int(thrf[reg]), gl[reg]));
       const v4 us4 = *reinterpret_cast<const v4*>(usc + ur * 4);
       const float sv = (us4[0] + accS[reg]) - is4[0];
       const float aa = (us4[1] + is4[1]) + accAA[reg];
       const float an = (us4[2] + accAN[reg]) - is4[2];
       const float nn = (us4[3] + is4[3]) + accNN[reg];
       const float score = fmaf(sv * sv, nn, fmaf(-2.f * sv, an, aa));
+      // one compare whose result stays a wave mask; with the shared bounds many 64-score slots have no candidate and leave here
+      const uint64_t m_ngt = __builtin_amdgcn_ballot_w64(!(score > thrf[reg]));   // below the bound, equal to it, or unordered
+      if (m_ngt == 0) continue;
       bool c = score < thrf[reg];
-      const bool tie = !c && !(score > thrf[reg]);
-      if (__builtin_amdgcn_ballot_w64(tie)) {                              // the keys decide (always while the list is short)
-        if (tie) c = pass_key(score, (uint32_t)item) < thrk[ur];
+      if (m_ngt != __builtin_amdgcn_ballot_w64(c)) {                       // the keys decide (always while the list is short)
+        if (!c && !(score > thrf[reg])) c = pass_key(score, (uint32_t)item) < thrk[ur];
       }
       c = c && iok;
       if (c) c = ((bm[ur * a.bm_words + (lid >> 5)] >> (lid & 31)) & 1u) == 0u;
@@ -513,8 +514,8 @@ __global__ __launch_bounds__(256, G::MINW) void eval_pass_q_kernel(QArgs a) {
         const uint32_t rb = ((rhi ? (uint32_t)(m >> 32) : (uint32_t)m) >> rsh) & 0xffffu;   // the candidates of this lane's row
         if (c) pbuf[ur * PCAP + pend[reg] + __popc(rb & lt_j)] = pass_key(score, (uint32_t)item);
         pend[reg] += __popc(rb);
+        full |= pend[reg] >= 16;
       }
-      full |= pend[reg] >= 16;
     }
     if (__builtin_amdgcn_ballot_w64(full)) flush(false);
   };

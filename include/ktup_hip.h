@@ -134,7 +134,10 @@ int ktup_score_bprmf_bwd_ws(const float* U, int64_t ldu, const float* I, int64_t
  * ktup_pref_prepare mixes and pre-scales the (tiny) preference tables once per table version into
  * caller scratch `ws` (ktup_pref_workspace_bytes): A = pref (+ rel), C = pref_norm (+ norm);
  * it stores A/2 (logit table), beta*A and beta*C with beta = 1 for TUP (rel == NULL) and 1/2 for
- * KTUP (jTransUP.py:253,257,258), zero-padded so the score kernels run without bounds checks.     */
+ * KTUP (jTransUP.py:253,257,258), zero-padded so the score kernels run without bounds checks.
+ * d: any positive multiple of 4 (models/base.py:52 takes any integer; callers stage other widths with a zero tail).  Up to 256
+ * columns the tile kernels run; beyond, the one-wave-per-pair kernels (ktup_score_pref_row.hip, n_pref <= 128) behind the same
+ * entry points: ktup_score_{tup,ktup}_{fwd,bwd,bwd_ws} and ktup_eval_pref_scores.  0 bytes = (d, n_pref) not covered.      */
 size_t ktup_pref_workspace_bytes(int d, int n_pref);
 int ktup_pref_prepare(const float* pref, const float* pref_norm, const float* rel, const float* norm, int64_t ld,
                       int n_pref, int d, float* ws, void* stream);

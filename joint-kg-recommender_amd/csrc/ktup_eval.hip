@@ -1163,6 +1163,7 @@ extern "C" size_t ktup_eval_kg_workspace_bytes(int d, int64_t nq) { return (size
 
 extern "C" size_t ktup_eval_pref_workspace_bytes(int d, int n_pref, int64_t nq, int64_t n_items) {
   // QW[nq][3][d] | QL[nq][P] | QN[nq][P] (padded to 16 B) | the item side (item_side)
+  if (pref_row_covers(d, n_pref)) return 64;      // the one-wave-per-pair forward stages nothing
   return (user_side_floats(nq, d, n_pref) + (n_items > 0 ? item_side_floats(n_items, d, n_pref) : 0)) * sizeof(float);
 }
 
@@ -1472,6 +1473,17 @@ extern "C" int ktup_eval_pref_scores(const float* U, int64_t ldu, const float* I
   const char* name = "ktup_eval_pref_scores";
   KTUP_REQUIRE(nq >= 0 && n_items >= 0, "%s: bad sizes", name);
   if (nq == 0 || n_items == 0) return KTUP_OK;
+  if (pref_row_covers(d, n_pref)) {       // rows beyond 256 columns: every (user, item) pair through the one-wave-per-pair forward
+    KTUP_REQUIRE(U && I && pref_ws && u_ids && out && ldo >= n_items, "%s: bad argument", name);
+    KTUP_REQUIRE((E == nullptr) == (item2ent == nullptr), "%s: E and item2ent must be given together", name);
+    KTUP_REQUIRE(aligned16(U) && aligned16(I) && aligned16(E) && aligned16(pref_ws) && ldu % 4 == 0 && ldi % 4 == 0 && (!E || lde % 4 == 0),
+                 "%s: tables must be 16-byte aligned with pitches %% 4 == 0", name);
+    KTUP_REQUIRE(gumbel_mode >= KTUP_GUMBEL_OFF && gumbel_mode <= KTUP_GUMBEL_PHILOX_DEV, "%s: bad gumbel_mode", name);
+    KTUP_REQUIRE((gumbel_mode != KTUP_GUMBEL_INPUT && gumbel_mode != KTUP_GUMBEL_PHILOX_DEV) || uniform,
+                 "%s: KTUP_GUMBEL_INPUT / KTUP_GUMBEL_PHILOX_DEV need the `uniform` pointer", name);
+    return pref_row(false, name, U, ldu, I, ldi, E, lde, item2ent, -1, pref_ws, n_pref, d, u_ids, nullptr, nq * n_items, n_items, ldo, l1,
+                    gumbel_mode, uniform, seed, offset, out, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, (hipStream_t)stream);
+  }
   KTUP_REQUIRE(ws && aligned16(ws), "%s: bad argument", name);
   // QW[nq][3][d] | QL[nq][P] (padded to 16 B) | the item side
   const ItemSide it = item_side(ws + user_side_floats(nq, d, n_pref), n_items, d, n_pref);

@@ -46,6 +46,16 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 typedef const __attribute__((address_space(4))) v16f* sptr16;  // 64-byte scalar loads (s_load_dwordx16)
 KTUP_DEV sptr16 as_scalar16(const float* p) { return (sptr16)(uintptr_t)p; }
 
+// ktup_score_pref_row.hip: rows wider than 256 columns (any multiple of 4): one wave per pair, nothing held per coordinate.  The
+// prepared tables of such a width are plain [P][d] blocks: Alog | Ar | Cn (ktup_pref_prepare with ppad = P, dp = d).  i_ids == nullptr:
+// the pairs are (u_ids[b], j), j in [0, n_items), scores to score[b * ldo + j] (the evaluation's all-item form; forward only).
+bool pref_row_covers(int d, int n_pref);
+inline size_t pref_row_ws_floats(int d, int n_pref) { return ((size_t)3 * n_pref * d + 15) & ~(size_t)15; }
+int pref_row(bool bwd, const char* name, const float* U, int64_t ldu, const float* I, int64_t ldi, const float* E, int64_t lde,
+             const int32_t* item2ent, int64_t ent_pad, const float* pref_ws, int n_pref, int d, const int64_t* u_ids, const int64_t* i_ids,
+             int64_t n, int64_t n_items, int64_t ldo, int l1, int gumbel_mode, const float* uniform, uint64_t seed, uint64_t offset,
+             float* score, const float* gscore, float* gU, float* gI, float* gE, float* gA, float* gC, hipStream_t st);
+
 // ktup_score_pref_mc.hip: compile-time-geometry matrix-core forward (soft gate and ST-Gumbel gate).  Returns 1 when (d, n_pref) is not an
 // instantiated geometry.
 int pref_fwd_mc(const float* U, int64_t ldu, const float* I, int64_t ldi, const float* E, int64_t lde, const int32_t* item2ent,

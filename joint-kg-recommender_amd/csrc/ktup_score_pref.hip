@@ -531,8 +531,9 @@ int run_pref(bool bwd, const char* name, const float* U, int64_t ldu, const floa
   KTUP_REQUIRE(n >= 0, "%s: negative row count", name);
   if (n == 0) return KTUP_OK;
   const PrefGeom g = pref_geom(d, n_pref);
-  if (!g.ok)
-    return set_error(KTUP_ERR_UNSUPPORTED, "%s: embedding_size must be a multiple of 4 in [4, 256] (got %d), n_pref > 0", name, d);
+  const bool rows = !g.ok && pref_row_covers(d, n_pref);      // wider than the tile kernels hold: one wave per pair (ktup_score_pref_row.hip)
+  if (!g.ok && !rows)
+    return set_error(KTUP_ERR_UNSUPPORTED, "%s: embedding_size must be a positive multiple of 4 (got %d), 0 < n_pref (<= 128 beyond 256 columns)", name, d);
   KTUP_REQUIRE(U && I && pref_ws && u_ids && i_ids, "%s: null pointer argument", name);
   KTUP_REQUIRE((E == nullptr) == (item2ent == nullptr), "%s: E and item2ent must be given together", name);
   KTUP_REQUIRE(aligned16(U) && aligned16(I) && aligned16(E) && aligned16(pref_ws), "%s: tables must be 16-byte aligned", name);
@@ -540,6 +541,12 @@ int run_pref(bool bwd, const char* name, const float* U, int64_t ldu, const floa
   KTUP_REQUIRE(gumbel_mode >= KTUP_GUMBEL_OFF && gumbel_mode <= KTUP_GUMBEL_PHILOX_DEV, "%s: bad gumbel_mode %d", name, gumbel_mode);
   KTUP_REQUIRE((gumbel_mode != KTUP_GUMBEL_INPUT && gumbel_mode != KTUP_GUMBEL_PHILOX_DEV) || uniform,
                "%s: KTUP_GUMBEL_INPUT / KTUP_GUMBEL_PHILOX_DEV need the `uniform` pointer", name);
+  if (rows) {
+    if (bwd) KTUP_REQUIRE(gscore && gU && gI && gA && gC && (!E || gE), "%s: null gradient pointer", name);
+    else KTUP_REQUIRE(score, "%s: null score pointer", name);
+    return pref_row(bwd, name, U, ldu, I, ldi, E, lde, item2ent, ent_pad, pref_ws, n_pref, d, u_ids, i_ids, n, 0, 0, l1, gumbel_mode,
+                    uniform, seed, offset, score, gscore, gU, gI, gE, gA, gC, (hipStream_t)stream);
+  }
   PrefArgs a{};
   a.U = reinterpret_cast<const float4*>(U); a.I = reinterpret_cast<const float4*>(I); a.E = reinterpret_cast<const float4*>(E);
   a.ldu4 = ldu / 4; a.ldi4 = ldi / 4; a.lde4 = lde / 4;
@@ -624,14 +631,16 @@ int run_pref(bool bwd, const char* name, const float* U, int64_t ldu, const floa
 
 extern "C" size_t ktup_pref_workspace_bytes(int d, int n_pref) {
   const PrefGeom g = pref_geom(d, n_pref);
-  return g.ok ? ws_floats(g, n_pref) * sizeof(float) : 0;
+  if (!g.ok) return pref_row_covers(d, n_pref) ? pref_row_ws_floats(d, n_pref) * sizeof(float) : 0;
+  return ws_floats(g, n_pref) * sizeof(float);
 }
 
 extern "C" int ktup_pref_prepare(const float* pref, const float* pref_norm, const float* rel, const float* norm, int64_t ld,
                                  int n_pref, int d, float* ws, void* stream) {
-  const PrefGeom g = pref_geom(d, n_pref);
+  PrefGeom g = pref_geom(d, n_pref);
+  if (!g.ok && pref_row_covers(d, n_pref)) { g.dp = d; g.ppad = n_pref; g.ok = true; }     // plain [P][d] blocks for the row kernels
   if (!g.ok)
-    return set_error(KTUP_ERR_UNSUPPORTED, "ktup_pref_prepare: embedding_size must be a multiple of 4 in [4, 256] (got %d)", d);
+    return set_error(KTUP_ERR_UNSUPPORTED, "ktup_pref_prepare: embedding_size must be a positive multiple of 4 (got %d), 0 < n_pref (<= 128 beyond 256 columns)", d);
   KTUP_REQUIRE(pref && pref_norm && ws, "ktup_pref_prepare: null pointer argument");
   KTUP_REQUIRE((rel == nullptr) == (norm == nullptr), "ktup_pref_prepare: rel and norm must be given together");
   KTUP_REQUIRE(ld >= d, "ktup_pref_prepare: pitch %lld < d", (long long)ld);

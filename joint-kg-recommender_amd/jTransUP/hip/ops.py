@@ -216,8 +216,8 @@ def pref_workspace(pref, pref_norm, rel=None, norm=None):
     P, d = pref.shape
     nbytes = L.load().ktup_pref_workspace_bytes(d, P)
     if nbytes == 0:
-        raise L.KtupError('TUP / KTUP: -embedding_size %d is beyond the kernels\' 256 columns (models/base.py checks the flag)' % d
-                          if d > 256 else 'TUP / KTUP kernels take rows of whole 16-byte chunks (ops stages other widths with a zero tail); got d=%d' % d)
+        raise L.KtupError('TUP / KTUP beyond 256 columns: at most 128 preferences (got %d)' % P
+                          if d > 256 and d % 4 == 0 else 'TUP / KTUP kernels take rows of whole 16-byte chunks (ops stages other widths with a zero tail); got d=%d' % d)
     ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
     L.call('ktup_pref_prepare', _p(pref), _p(pref_norm), _p(rel), _p(norm), pref.stride(0), P, d, _p(ws), _stream(dev))
     return ws
@@ -595,6 +595,10 @@ def _eval_pref(U, I, E, pref, pref_norm, rel, norm, item2ent, u, l1, gumbel_mode
     u = _ids('u_ids', u, dev)
     nq, ni = u.numel(), I.shape[0]
     P, d = pref.shape
+    if items is not None and d > 256:            # the one-wave-per-pair route (ktup_score_pref_row.hip) stages no item side
+        if (items.n_items, items.P, items.d) != (ni, P, d):
+            raise L.KtupError('prepared item side does not match the tables')
+        items = None
     if items is not None:                        # the pass prepared the item side once: users only here
         if (items.n_items, items.P, items.d) != (ni, P, d):
             raise L.KtupError('prepared item side does not match the tables')
@@ -639,7 +643,7 @@ def eval_pref_topk(U, u, items, l1, topn, filt_off=None, filt_ids=None, with_sco
     dev = _dev(_table('user table', U))
     u = _ids('u_ids', u, dev)
     nq, d, P = u.numel(), items.d, items.P
-    if not (0 < topn <= 16) or nq == 0:
+    if not (0 < topn <= 16) or nq == 0 or d > 256:
         return None
     if l1 or d not in (64, 100, 128) or not L.get_option('eval_mc'):
         # no preference-space pass for this shape: the pair kernel's arithmetic with the top-n in its epilogue (or None: per-batch calls)
@@ -665,7 +669,7 @@ def eval_pref_topk_hard(U, u, items, l1, topn, gumbel_mode, uniform=None, seed=0
     dev = _dev(_table('user table', U))
     u = _ids('u_ids', u, dev)
     nq, d, P, ni = u.numel(), items.d, items.P, items.n_items
-    if not (0 < topn <= 16) or nq == 0 or P > 32:
+    if not (0 < topn <= 16) or nq == 0 or P > 32 or d > 256:
         return None
     if gumbel_mode == GUMBEL_INPUT:
         if uniform is None or tuple(uniform.shape) != (nq, ni, P) or uniform.dtype != torch.float32 or uniform.device != dev:

@@ -113,11 +113,6 @@ def init_model(FLAGS, user_total, item_total, entity_total, relation_total, logg
                                   '(in scope: %s)' % (kind, ', '.join(sorted(ACCELERATED))))
     if kind not in ACCELERATED:
         raise NotImplementedError
-    if kind in ('transup', 'jtransup') and FLAGS.embedding_size > 256:
-        # any width up to 256 runs (widths that are not a multiple of 4 are staged with a zero tail: hip/ops.py); beyond it the
-        # preference-gate kernels have no LDS layout, and there is no CPU path to fall back to
-        raise ValueError('-embedding_size %d: the TUP / KTUP kernels hold rows of at most 256 columns (the reference, on CPU, takes any '
-                         'integer: models/base.py:52)' % FLAGS.embedding_size)
     module = importlib.import_module('jTransUP.models.' + ACCELERATED[kind])
     model = module.build_model(FLAGS, user_total, item_total, entity_total, relation_total, i_map=i_map, e_map=e_map, new_map=new_map)
     logger.info('Architecture: {}'.format(model))

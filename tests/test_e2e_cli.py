@@ -394,18 +394,13 @@ def test_joint_cli_shard_tables_torchrun(dataset, opt, lr, port):
 ])
 def test_cli_any_embedding_size(dataset, script, extra):
     """-embedding_size 50: the reference takes any integer (models/base.py:52); the TUP / KTUP kernels read 16-byte chunks, so the
-    rows are staged with a zero tail and training takes the autograd route.  -embedding_size 300 is refused by name for the models
-    whose preference gate has no layout beyond 256 columns (there is no CPU path to fall back to)."""
-    log, _ = run_cli(script, dataset, 'odd-' + extra[1], extra + ['-embedding_size', '50'])
-    losses = [float(x) for x in re.findall(r'train loss:(\d+\.\d+)', log)]
-    assert len(losses) >= 2 and all(l == l and l < 1e4 for l in losses)
-    assert len(re.findall(r'f1:\d\.\d+', log)) >= 3
-    data = str(dataset)
-    cmd = [sys.executable, os.path.join(PKG, script), '-data_path', data, '-log_path', os.path.join(data, 'log'), '-dataset', 'ml1m',
-           '-experiment_name', 'wide-' + extra[1], '-nohas_visualization', '-batch_size', '32', '-training_steps', '5', '-seed', '3'] + extra + \
-          ['-embedding_size', '300']
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
-    assert r.returncode != 0 and '-embedding_size 300' in (r.stdout + r.stderr)
+    rows are staged with a zero tail and training takes the autograd route.  -embedding_size 300 is beyond the tile kernels' 256
+    columns: the one-wave-per-pair kernels (ktup_score_pref_row.hip) score, differentiate and evaluate it."""
+    for width in ('50', '300'):
+        log, _ = run_cli(script, dataset, 'w%s-%s' % (width, extra[1]), extra + ['-embedding_size', width])
+        losses = [float(x) for x in re.findall(r'train loss:(\d+\.\d+)', log)]
+        assert len(losses) >= 2 and all(l == l and l < 1e4 for l in losses)
+        assert len(re.findall(r'f1:\d\.\d+', log)) >= 3
 
 
 def test_joint_cli_shard_tables_device_sampling(dataset):

@@ -203,9 +203,25 @@ def test_odd_and_unaligned_tables_vs_oracle(d):
         close(ops().score_bprmf(Ed, Ed, h.to(DEV), t.to(DEV)), O.score_bprmf(E, E, h, t))
 
 
-@pytest.mark.parametrize('d,npref', [(100, 20), (64, 4), (128, 13), (256, 20), (200, 20), (8, 33)])
+def _l1_knife_edge(W, i2e, u, i, uni, ktup, eps=1e-7):
+    """Pairs with a coordinate |z| < eps, z = proj(u) + r - proj(v) from the oracle's helpers in fp64 (transUP.py:69-82)."""
+    D = {k: v.double() for k, v in W.items()}
+    un = None if uni is None else uni.double()
+    u_e = D['U'][u]
+    if ktup:
+        v_e = D['I'][i] + D['E'][i2e[i]]
+        _, r_e, nrm = O.ktup_preferences(u_e, v_e, D['P'], D['Pn'], D['R'], D['Rn'], un)
+    else:
+        v_e = D['I'][i]
+        _, r_e, nrm = O.tup_preferences(u_e, v_e, D['P'], D['Pn'], un)
+    z = O.projection_transH(u_e, nrm) + r_e - O.projection_transH(v_e, nrm)
+    return z.abs().min(dim=1).values < eps
+
+
+@pytest.mark.parametrize('d,npref', [(100, 20), (64, 4), (128, 13), (256, 20), (200, 20), (8, 33), (320, 20), (516, 7), (1028, 3), (322, 5)])
 def test_ml1m_shape_vs_oracle_fwd_bwd(d, npref):
-    """ml1m-shape tables (scaled down in rows for d=256), B=512*3 pairs, forward and full backward."""
+    """ml1m-shape tables (scaled down in rows for d=256), B=512*3 pairs, forward and full backward.  Widths beyond 256 (any multiple
+    of 4; others staged with a zero tail) run the one-wave-per-pair kernels of ktup_score_pref_row.hip."""
     nu, ni, ne = (6040, 3240, 14708) if d <= 128 else (600, 300, 1500)
     W, i2e, gen = rand_world(7, nu, ni, ne, npref, d)
     n = 1536
@@ -214,6 +230,14 @@ def test_ml1m_shape_vs_oracle_fwd_bwd(d, npref):
     for l1 in (False, True):
         for gum in (False, True):
             uni = torch.rand(n, npref, generator=gen) if gum else None
+            if l1:
+                # |z| has no derivative at 0: a pair with a coordinate z below its fp32 rounding gets sign(z) = +1 from one summation
+                # order and -1 from another, and its three rows then differ by 2 g in that coordinate.  Such pairs (found with the
+                # oracle's own formulas in fp64, |z| < 1e-7: a handful of 1536 at most) leave the batch.
+                keep = ~(_l1_knife_edge(W, i2e, u, i, uni, True) | _l1_knife_edge(W, i2e, u, i, uni, False))
+                assert int((~keep).sum()) <= 8
+                u, i, gs, n = u[keep], i[keep], gs[keep], int(keep.sum())
+                uni = uni[keep] if gum else None
             Wc = {k: v.clone().requires_grad_(True) for k, v in W.items()}
             Wd = {k: v.to(DEV).requires_grad_(True) for k, v in W.items()}
             want = O.score_ktup_rec(Wc['U'], Wc['I'], Wc['E'], Wc['P'], Wc['Pn'], Wc['R'], Wc['Rn'], i2e, u, i, l1, uni)

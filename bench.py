@@ -213,16 +213,17 @@ def train_step_bench(device, steps=200, warmup=20):
         params = list(m.parameters())
 
         def step(s):
-            opt.zero_grad(set_to_none=False)
+            if fused is None:
+                opt.zero_grad(set_to_none=False)                     # (the K20 launch leaves the gradients zero-filled itself)
             if s % 10 < 7:
                 pos = m((u[s], pi[s]), None, is_rec=True); neg = m((u[s], ni_[s]), None, is_rec=True)
                 loss = (-F.logsigmoid(-(pos - neg))).mean()
             else:
                 pos = m(None, (h[s], t[s], r[s]), is_rec=False); neg = m(None, (nh[s], nt[s], r[s]), is_rec=False)
                 loss = torch.sum(torch.clamp(pos - neg + 1.0, min=0.0))
-            loss.backward()
+            loss.backward()                                          # (the score Functions add into the tables' .grad: ops._grad_targets)
             if fused is not None:
-                fused.clip_and_step(5.0)
+                fused.clip_and_step(5.0, zero_grads=True)
             else:
                 torch.nn.utils.clip_grad_norm_(params, 5.0)
                 opt.step()

@@ -61,6 +61,53 @@ def _zeros_like_many(*tables):
     return out
 
 
+_DIRECT_GRAD = [True]
+
+
+def set_direct_grad(on):
+    """Switch the gradient-accumulation fusion of the score Functions (see _grad_targets) on or off; returns the previous setting.
+    Off is needed only by code that calls torch.autograd.grad(...) on tables whose `.grad` is populated."""
+    was = _DIRECT_GRAD[0]
+    _DIRECT_GRAD[0] = bool(on)
+    return was
+
+
+def _takes_grad_directly(t):
+    if not (t.is_leaf and t.requires_grad):          # (.grad of a non-leaf warns)
+        return False
+    g = t.grad
+    return (g is not None and g.dtype == torch.float32 and g.layout == torch.strided
+            and g.device == t.device and g.shape == t.shape and g.is_contiguous() and t.dim() == 2 and t.stride(0) == t.shape[1]
+            and not t._backward_hooks and not getattr(t, '_post_accumulate_grad_hooks', None))
+
+
+def _grad_targets(*tables):
+    """Where a backward's kernels add the table gradients -> (buffers for the kernels, values for autograd).
+
+    The kernels build gradients by adding into zero-filled buffers.  A table that is a LEAF whose dense `.grad` already exists
+    (zero-filled by `zero_grad(set_to_none=False)` / FusedOptimizer.clip_and_step(zero_grads=True), or holding what earlier backward
+    calls of the step left) takes those adds straight into `.grad`, and the Function reports None for it: no zero-filled temporary,
+    no engine-side sum of the positive and the negative call's contributions, no AccumulateGrad add -- three whole-table passes and
+    launches per table and call (the B = 512 step through autograd is bound by its ~50 launches, not by arithmetic).  The same
+    trade as the gradient-accumulation fusion of large-model trainers (the weight gradient written into main_grad, None returned).
+    Everything else -- non-leaves (the zero-tail staged tables), leaves without a `.grad` yet, hooks on the tensor, create_graph
+    (grad mode on inside backward), set_direct_grad(False) -- gets zero-filled buffers out of ONE allocation and ONE fill launch and
+    the usual autograd hand-over.  `None` entries (absent tables) pass through."""
+    direct = _DIRECT_GRAD[0] and not torch.is_grad_enabled()
+    bufs, rets, fresh = [], [], []
+    for t in tables:
+        if t is None:
+            bufs.append(None); rets.append(None)
+        elif direct and _takes_grad_directly(t):
+            bufs.append(t.grad); rets.append(None)
+        else:
+            bufs.append(t); rets.append(t); fresh.append(len(bufs) - 1)
+    if fresh:
+        for k, z in zip(fresh, _zeros_like_many(*[bufs[k] for k in fresh])):
+            bufs[k] = rets[k] = z
+    return bufs, rets
+
+
 def _vec(t, n):
     t = t.contiguous()
     if t.dtype != torch.float32 or t.numel() != n:
@@ -83,11 +130,11 @@ class _ScoreBprmf(Function):
     def backward(ctx, gs):
         U, I, u, i = ctx.saved_tensors
         gs = _vec(gs, u.numel())
-        gU, gI = _zeros_like_many(U, I)
+        (gU, gI), rets = _grad_targets(U, I)
         bws = _seg_ws(L.load().ktup_score_bprmf_bwd_workspace_bytes(u.numel(), U.shape[1], U.shape[0], I.shape[0]), U.device)
         L.call('ktup_score_bprmf_bwd_ws', _p(U), U.stride(0), _p(I), I.stride(0), U.shape[1], _p(u), _p(i), u.numel(), _p(gs),
                _p(gU), _p(gI), U.shape[0], I.shape[0], _p(bws), _stream(U.device))
-        return gU, gI, None, None
+        return rets[0], rets[1], None, None
 
 
 def score_bprmf(U, I, u, i):
@@ -111,11 +158,11 @@ class _ScoreTransE(Function):
     def backward(ctx, gs):
         E, R, h, t, r = ctx.saved_tensors
         gs = _vec(gs, h.numel())
-        gE, gR = _zeros_like_many(E, R)
+        (gE, gR), rets = _grad_targets(E, R)
         bws = _seg_ws(L.load().ktup_score_kg_bwd_workspace_bytes(h.numel(), E.shape[1], E.shape[0]), E.device)
         L.call('ktup_score_transe_bwd_ws', _p(E), E.stride(0), _p(R), R.stride(0), E.shape[1], _p(h), _p(t), _p(r), h.numel(),
                ctx.l1, _p(gs), _p(gE), _p(gR), E.shape[0], R.shape[0], _p(bws), _stream(E.device))
-        return gE, gR, None, None, None, None
+        return rets[0], rets[1], None, None, None, None
 
 
 class _ScoreTransH(Function):
@@ -133,12 +180,12 @@ class _ScoreTransH(Function):
     def backward(ctx, gs):
         E, R, N, h, t, r = ctx.saved_tensors
         gs = _vec(gs, h.numel())
-        gE, gR, gN = _zeros_like_many(E, R, N)
+        (gE, gR, gN), rets = _grad_targets(E, R, N)
         bws = _seg_ws(L.load().ktup_score_kg_bwd_workspace_bytes(h.numel(), E.shape[1], E.shape[0]), E.device)
         L.call('ktup_score_transh_bwd_ws', _p(E), E.stride(0), _p(R), R.stride(0), _p(N), N.stride(0), E.shape[1], _p(h), _p(t),
                _p(r), h.numel(), ctx.l1, _p(gs), _p(gE), _p(gR), _p(gN), E.shape[0], min(R.shape[0], N.shape[0]), _p(bws),
                _stream(E.device))
-        return gE, gR, gN, None, None, None, None
+        return rets[0], rets[1], rets[2], None, None, None, None
 
 
 class _ScoreTransR(Function):
@@ -271,16 +318,17 @@ class _ScorePref(Function):
         l1, gumbel_mode, seed, offset, ent_pad = ctx.cfg
         n = u.numel(); P, d = pref.shape; dev = U.device
         gs = _vec(gs, n)
-        # every gradient of the call out of ONE zero-filled buffer (one allocation and one fill launch instead of five: the step through
-        # autograd is bound by the host, ~8 us per torch call; every part starts on a 16-byte boundary)
-        shapes = [tuple(U.shape), tuple(I.shape), (P, d), (P, d)] + ([tuple(E.shape)] if E is not None else [])
-        sizes = [(a * b + 3) & ~3 for a, b in shapes]
-        flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
-        parts, at = [], 0
-        for (a, b), sz in zip(shapes, sizes):
-            parts.append(flat[at:at + a * b].view(a, b))
-            at += sz
-        gU, gI, gA, gC = parts[:4]
+        # the row tables' gradients go where _grad_targets says (straight into `.grad` when it exists); the mixed tables A = pref + rel,
+        # C = pref_norm + norm of KTUP have ONE gradient each for two summands: the kernel builds it in a small zero-filled buffer
+        # and one multi-tensor add hands it to the summands that take their gradient directly
+        if E is None:
+            (gU, gI, gA, gC), rets = _grad_targets(U, I, pref, pref_norm)
+            gE, small = None, None
+        else:
+            (gU, gI, gE), rets = _grad_targets(U, I, E)
+            small = (pref, pref_norm, rel, norm)
+            direct = _DIRECT_GRAD[0] and not torch.is_grad_enabled() and all(_takes_grad_directly(t) for t in small)
+            gA, gC = _zeros_like_many(pref, pref_norm)
         # large batches: per-pair row gradients + reduction by sorted segments instead of float atomics (the library decides:
         # 0 bytes = the atomics path)
         nbytes = L.load().ktup_score_pref_bwd_workspace_bytes(n, d, U.shape[0], I.shape[0])
@@ -288,13 +336,15 @@ class _ScorePref(Function):
         if E is None:
             L.call('ktup_score_tup_bwd_ws', _p(U), U.stride(0), _p(I), I.stride(0), _p(ws), P, d, _p(u), _p(i), n, l1, gumbel_mode,
                    _p(uniform), seed, offset, _p(gs), _p(gU), _p(gI), _p(gA), _p(gC), U.shape[0], I.shape[0], _p(bws), _stream(dev))
-            return gU, gI, None, gA, gC, None, None, None, None, None, None, None, None, None, None, None, None
-        gE = parts[4]
+            return rets[0], rets[1], None, rets[2], rets[3], None, None, None, None, None, None, None, None, None, None, None, None
         L.call('ktup_score_ktup_bwd_ws', _p(U), U.stride(0), _p(I), I.stride(0), _p(E), E.stride(0), _p(item2ent), ent_pad, _p(ws), P,
                d, _p(u), _p(i), n, l1, gumbel_mode, _p(uniform), seed, offset, _p(gs), _p(gU), _p(gI), _p(gE), _p(gA), _p(gC),
                U.shape[0], I.shape[0], _p(bws), _stream(dev))
         # A = pref + rel and C = pref_norm + norm: the mixed-table gradient goes to both summands
-        return gU, gI, gE, gA, gC, gA.clone(), gC.clone(), None, None, None, None, None, None, None, None, None, None
+        if direct:
+            torch._foreach_add_([t.grad for t in small], [gA, gC, gA, gC])
+            return rets[0], rets[1], rets[2], None, None, None, None, None, None, None, None, None, None, None, None, None, None
+        return rets[0], rets[1], rets[2], gA, gC, gA.clone(), gC.clone(), None, None, None, None, None, None, None, None, None, None
 
 
 def score_tup(U, I, pref, pref_norm, u, i, l1, gumbel_mode=GUMBEL_OFF, uniform=None, seed=0, offset=0, ws=None):

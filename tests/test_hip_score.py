@@ -398,3 +398,44 @@ def test_wide_forward_d256_vs_oracle(n, npref):
                 L.set_option('fwd_wide', old)
             close(got[wide][0], want_k); close(got[wide][1], want_t)
         close(got[1][0], got[0][0], rtol=2e-5, atol=2e-6); close(got[1][1], got[0][1], rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize('d', [100, 50])
+def test_gradients_added_straight_into_grad_equal_the_autograd_handover(d):
+    """ops._grad_targets: leaves whose `.grad` exists receive the kernels' adds directly (the Functions report None for them).  Two
+    steps of the reference's loop shape -- positive and negative call, BPR / margin loss, gradients accumulated over both steps into
+    buffers that start NON-zero -- against the same with set_direct_grad(False) (zero-filled temporaries + AccumulateGrad).
+    d = 50: the zero-tail staged tables are not leaves and keep the hand-over in both runs."""
+    nu, ni, ne, P, n = 300, 200, 400, 7, 257
+    W, i2e, gen = rand_world(11, nu, ni, ne, P, d)
+    u = torch.randint(0, nu, (2, n), generator=gen); pi = torch.randint(0, ni, (2, n), generator=gen); nj = torch.randint(0, ni, (2, n), generator=gen)
+    h = torch.randint(0, ne, (2, n), generator=gen); t = torch.randint(0, ne, (2, n), generator=gen); r = torch.randint(0, P, (2, n), generator=gen)
+    start = {k: torch.randn(v.shape, generator=gen) for k, v in W.items()}
+    i2e_d = i2e.to(DEV, torch.int32)
+
+    def run(direct):
+        was = ops().set_direct_grad(direct)
+        try:
+            Wd = {k: v.to(DEV).requires_grad_(True) for k, v in W.items()}
+            for k in Wd:
+                Wd[k].grad = start[k].to(DEV).clone()
+            for s in range(2):
+                ud, pd, nd = u[s].to(DEV), pi[s].to(DEV), nj[s].to(DEV)
+                kt = lambda ii: ops().score_ktup(Wd['U'], Wd['I'], Wd['E'], Wd['P'], Wd['Pn'], Wd['R'], Wd['Rn'], i2e_d, ud, ii, False, ent_pad=ne)
+                tu = lambda ii: ops().score_tup(Wd['U'], Wd['I'], Wd['P'], Wd['Pn'], ud, ii, True)
+                th = lambda tt: ops().score_transh(Wd['E'], Wd['R'], Wd['Rn'], h[s].to(DEV), tt, r[s].to(DEV), False)
+                te = lambda tt: ops().score_transe(Wd['E'], Wd['R'], h[s].to(DEV), tt, r[s].to(DEV), True)
+                loss = (-F.logsigmoid(-(kt(pd) - kt(nd)))).mean() + (-F.logsigmoid(-(tu(pd) - tu(nd)))).mean() \
+                    + torch.sum(torch.clamp(th(t[s].to(DEV)) - th(h[s].to(DEV)) + 1.0, min=0.0)) * 1e-2 \
+                    + torch.sum(torch.clamp(te(t[s].to(DEV)) - te(h[s].to(DEV)) + 1.0, min=0.0)) * 1e-2 \
+                    + ops().score_bprmf(Wd['U'], Wd['I'], ud, pd).mean()
+                loss.backward()
+            return {k: v.grad.clone() for k, v in Wd.items()}
+        finally:
+            ops().set_direct_grad(was)
+
+    a, b = run(True), run(False)
+    for k in W:
+        moved = float((b[k].cpu() - start[k]).abs().max())
+        assert moved > 0
+        close(a[k], b[k], rtol=RT, atol=max(GAT, 2e-6 * moved))

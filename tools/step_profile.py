@@ -16,6 +16,9 @@ from jTransUP.models import jTransUP as jt
 from jTransUP.utils.fused_optim import FusedOptimizer
 
 mode = sys.argv[1] if len(sys.argv) > 1 else 'fused'
+if len(sys.argv) > 2 and sys.argv[2] == 'nodirect':        # A/B: the autograd hand-over of every gradient (ops.set_direct_grad)
+    from jTransUP.hip import ops as _ops
+    _ops.set_direct_grad(False)
 device = torch.device('cuda', 0)
 NU, NI, NE, NR, D, ALIGNED = bench.NU, bench.NI, bench.NE, bench.NR, bench.D, bench.ALIGNED
 B, steps = 512, 300
@@ -32,7 +35,8 @@ params = list(m.parameters())
 
 
 def step(s):
-    opt.zero_grad(set_to_none=False)
+    if fused is None:
+        opt.zero_grad(set_to_none=False)
     if s % 10 < 7:
         pos = m((u[s], pi[s]), None, is_rec=True); neg = m((u[s], ni_[s]), None, is_rec=True)
         loss = (-F.logsigmoid(-(pos - neg))).mean()
@@ -41,7 +45,7 @@ def step(s):
         loss = torch.sum(torch.clamp(pos - neg + 1.0, min=0.0))
     loss.backward()
     if fused is not None:
-        fused.clip_and_step(5.0)
+        fused.clip_and_step(5.0, zero_grads=True)
     else:
         torch.nn.utils.clip_grad_norm_(params, 5.0)
         opt.step()

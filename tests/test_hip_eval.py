@@ -740,7 +740,7 @@ def test_kg_ranks_without_score_matrix_ties_and_modes(model, wtab):
         L.set_option('kg_wtab', old)
 
 
-def _referee_ranks(E, R, N, q, r, head, g_off, g_ids, f_off, f_ids, dtype, chunk=32):
+def _referee_ranks(E, R, N, q, r, head, g_off, g_ids, f_off, f_ids, dtype, chunk=256):
     """Filtered gold ranks (utils/misc.py:125-146: filtered ids and the other golds are skipped) from the reference's OWN score formula
     -- sum_k (c_k - e_k)^2 with c = t - r / h + r (transE.py:65-105), both sides projected for TransH (transH.py:73-121) -- evaluated
     on the device in `dtype`, ascending, ids break exact ties.  float64: the referee; float32: what the reference's arithmetic gives."""

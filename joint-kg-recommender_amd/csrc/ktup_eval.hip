@@ -1377,6 +1377,22 @@ int pref_scores_tail(const char* name, const float* U, int64_t ldu, const float*
   float* QN = QL + pad4((size_t)nq * n_pref);
   const bool hard_l2 = gumbel_mode != KTUP_GUMBEL_OFF && !l1 && n_pref <= 32;      // the only reader of QN / CN / consts (mode 0)
   float *CW0 = it.CW0, *CW1 = it.CW1, *CW2 = it.CW2, *CL = it.CL;
+  {
+    // shapes whose staged item vectors pass the LDS of the pair kernels below (the soft gate beyond 212 columns unless the matrix
+    // cores take it, the hard gate's tile likewise: d = 256, config 5's width, among them): every (user, item) pair through the
+    // one-wave-per-pair forward, the items read from the projected item side (CW1 = v = i (+ e), pitch d)
+    bool fits;
+    if (gumbel_mode == KTUP_GUMBEL_OFF) {
+      const bool mc = !l1 && ktup::opt_eval_mc() && (d == 20 || d == 36 || d == 64 || d == 100 || d == 128);
+      fits = mc || (size_t)3 * (d / 4) * CT * 16 <= 160 * 1024;
+    } else {
+      const int mode = l1 ? 1 : (n_pref <= 32 ? 0 : 2);
+      fits = (mode ? hard_stage_floats<1>(d / 4, n_pref, g.dp / 4) : hard_stage_floats<0>(d / 4, n_pref, g.dp / 4)) * 4 <= 160 * 1024;
+    }
+    if (!fits)
+      return pref_row(false, name, U, ldu, CW1, d, nullptr, 0, nullptr, -1, pref_ws, n_pref, d, u_ids, nullptr, nq * n_items, n_items, ldo, l1,
+                      gumbel_mode, uniform, seed, offset, out, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, st, g.ppad, g.dp);
+  }
   // users: slot 0 = u + RU, slot 1 = u, slot 2 = NU, rows of pitch 3d;   items: v - RV, v, NV, rows of pitch d
   hipLaunchKernelGGL(pref_project_kernel, dim3(grid_for((nq + 3) / 4)), dim3(256), 0, st, U, ldu, (const float*)nullptr,
                      (int64_t)0, (const int32_t*)nullptr, u_ids, nq, d, n_pref, pref_ws, g.ppad, g.dp, 1.0f, (int64_t)3 * d, QW,

@@ -54,7 +54,8 @@ inline size_t pref_row_ws_floats(int d, int n_pref) { return ((size_t)3 * n_pref
 int pref_row(bool bwd, const char* name, const float* U, int64_t ldu, const float* I, int64_t ldi, const float* E, int64_t lde,
              const int32_t* item2ent, int64_t ent_pad, const float* pref_ws, int n_pref, int d, const int64_t* u_ids, const int64_t* i_ids,
              int64_t n, int64_t n_items, int64_t ldo, int l1, int gumbel_mode, const float* uniform, uint64_t seed, uint64_t offset,
-             float* score, const float* gscore, float* gU, float* gI, float* gE, float* gA, float* gC, hipStream_t st);
+             float* score, const float* gscore, float* gU, float* gI, float* gE, float* gA, float* gC, hipStream_t st, int ppad = 0,
+             int dp = 0);      // (ppad, dp): the tile kernels' padded table geometry when d <= 256 comes here (0: the plain blocks)
 
 // ktup_score_pref_mc.hip: compile-time-geometry matrix-core forward (soft gate and ST-Gumbel gate).  Returns 1 when (d, n_pref) is not an
 // instantiated geometry.

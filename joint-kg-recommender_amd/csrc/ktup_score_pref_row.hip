@@ -1,5 +1,7 @@
 // K5/K6/K7 for rows wider than the tile kernels hold (-embedding_size > 256): TUP / KTUP score, its backward, and the all-item
 // evaluation scores, for ANY width that is a multiple of 4 (ops stages other widths with a zero tail) and either gate / distance.
+// Also the per-batch all-item scores of the widths in (212, 256] whose three staged item vectors pass the LDS of the pair kernels
+// (ktup_eval.hip pref_scores_tail: BASELINE config 5's d = 256 among them).
 //   reference: jTransUP/models/transUP.py:69-102,105-170 ; jTransUP/models/jTransUP.py:122-143,163-191,250-315 ;
 //              jTransUP/models/base.py:52 (embedding_size is any integer)
 //
@@ -23,8 +25,8 @@ struct RowArgs {
   const float4 *U, *I, *E;
   int64_t ldu4, ldi4, lde4;
   const int32_t* item2ent;
-  const float4 *Alog, *Ar, *Cn;   // prepared tables, pitch nch (ktup_pref_prepare with ppad = P, dp = d)
-  int P, nch;
+  const float4 *Alog, *Ar, *Cn;   // prepared tables (ktup_pref_prepare), row pitch tp float4
+  int P, nch, tp;
   const int64_t *u_ids, *i_ids;   // i_ids null: the pairs are (u_ids[b], j) for j in [0, n_items), pair index b n_items + j
   int64_t n, n_items, ldo;
   int l1, gumbel;
@@ -79,7 +81,7 @@ KTUP_DEV int row_logits(const RowArgs& a, const Pair& k, int64_t pr, int lane, f
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     int row[4];
 #pragma unroll
-    for (int pp = 0; pp < 4; ++pp) row[pp] = min(p0 + pp, P - 1) * nch;
+    for (int pp = 0; pp < 4; ++pp) row[pp] = min(p0 + pp, P - 1) * a.tp;
     for (int c = lane; c < nch; c += 64) {
       const float4 x = k.pu[c] + k.v(c);
 #pragma unroll
@@ -107,15 +109,15 @@ KTUP_DEV int row_logits(const RowArgs& a, const Pair& k, int64_t pr, int lane, f
 // r and n of chunk c: the soft gate mixes every preference row with its logit, the hard gate takes row ps
 KTUP_DEV void row_mix(const RowArgs& a, const float* lg, int ps, int c, float4& r, float4& n) {
   if (a.gumbel != KTUP_GUMBEL_OFF) {
-    r = a.Ar[ps * a.nch + c];
-    n = a.Cn[ps * a.nch + c];
+    r = a.Ar[ps * a.tp + c];
+    n = a.Cn[ps * a.tp + c];
     return;
   }
   r = f4zero(); n = f4zero();
   for (int p = 0; p < a.P; ++p) {
     const float w = lg[p];
-    r = fma4(w, a.Ar[p * a.nch + c], r);
-    n = fma4(w, a.Cn[p * a.nch + c], n);
+    r = fma4(w, a.Ar[p * a.tp + c], r);
+    n = fma4(w, a.Cn[p * a.tp + c], n);
   }
 }
 
@@ -190,7 +192,7 @@ __global__ __launch_bounds__(NWV * 64) void pref_row_bwd_kernel(RowArgs a) {
       const float4 q = k.pu[c] - k.v(c);
       const float4 gz = g * ddist4(fma4(-s, n, q + r), l1);
       const float4 gn = fma4(-av, q, (-s) * gz);
-      for (int p = 0; p < P; ++p) part[p * 64 + lane] += dot4(a.Ar[p * nch + c], gz) + dot4(a.Cn[p * nch + c], gn);
+      for (int p = 0; p < P; ++p) part[p * 64 + lane] += dot4(a.Ar[p * a.tp + c], gz) + dot4(a.Cn[p * a.tp + c], gn);
     }
     for (int p = 0; p < P; ++p) {
       const float tot = wsum(part[p * 64 + lane]);
@@ -221,7 +223,7 @@ __global__ __launch_bounds__(NWV * 64) void pref_row_bwd_kernel(RowArgs a) {
       const float4 gq = fma4(-av, n, gz);
       const float4 gn = fma4(-av, q, (-s) * gz);
       float4 gx = f4zero();
-      for (int p = 0; p < P; ++p) gx = fma4(gl[p], a.Alog[p * nch + c], gx);       // Alog carries the 1/2
+      for (int p = 0; p < P; ++p) gx = fma4(gl[p], a.Alog[p * a.tp + c], gx);       // Alog carries the 1/2
       const float4 gv = gx - gq;
       atomic_add4(gu + 4 * c, gq + gx);
       atomic_add4(gi + 4 * c, gv);
@@ -246,15 +248,17 @@ bool pref_row_covers(int d, int n_pref) { return d > 256 && d % 4 == 0 && n_pref
 int pref_row(bool bwd, const char* name, const float* U, int64_t ldu, const float* I, int64_t ldi, const float* E, int64_t lde,
              const int32_t* item2ent, int64_t ent_pad, const float* pref_ws, int n_pref, int d, const int64_t* u_ids, const int64_t* i_ids,
              int64_t n, int64_t n_items, int64_t ldo, int l1, int gumbel_mode, const float* uniform, uint64_t seed, uint64_t offset,
-             float* score, const float* gscore, float* gU, float* gI, float* gE, float* gA, float* gC, hipStream_t st) {
-  if (!pref_row_covers(d, n_pref))
-    return set_error(KTUP_ERR_UNSUPPORTED, "%s: rows beyond 256 columns take a multiple of 4 and at most 128 preferences (d=%d, n_pref=%d)", name, d, n_pref);
+             float* score, const float* gscore, float* gU, float* gI, float* gE, float* gA, float* gC, hipStream_t st, int ppad, int dp) {
+  if (d <= 0 || d % 4 || n_pref <= 0 || n_pref > 128)
+    return set_error(KTUP_ERR_UNSUPPORTED, "%s: the one-wave-per-pair kernels take a multiple of 4 columns and at most 128 preferences (d=%d, n_pref=%d)", name, d, n_pref);
+  if (ppad <= 0) { ppad = n_pref; dp = d; }             // the plain [P][d] blocks of a width beyond 256
   RowArgs a{};
   a.U = reinterpret_cast<const float4*>(U); a.I = reinterpret_cast<const float4*>(I); a.E = reinterpret_cast<const float4*>(E);
   a.ldu4 = ldu / 4; a.ldi4 = ldi / 4; a.lde4 = lde / 4; a.item2ent = item2ent;
+  a.tp = dp / 4;
   a.Alog = reinterpret_cast<const float4*>(pref_ws);
-  a.Ar = a.Alog + (size_t)n_pref * (d / 4);
-  a.Cn = a.Ar + (size_t)n_pref * (d / 4);
+  a.Ar = a.Alog + (size_t)ppad * a.tp;
+  a.Cn = a.Ar + (size_t)n_pref * a.tp;
   a.P = n_pref; a.nch = d / 4; a.u_ids = u_ids; a.i_ids = i_ids; a.n = n; a.n_items = n_items; a.ldo = ldo;
   a.l1 = l1; a.gumbel = gumbel_mode; a.uniform = uniform; a.seed = seed; a.offset = offset; a.score = score;
   a.gscore = gscore; a.gU = gU; a.gI = gI; a.gE = gE; a.gA = gA; a.gC = gC; a.ent_pad = ent_pad; a.beta = E ? 0.5f : 1.0f;

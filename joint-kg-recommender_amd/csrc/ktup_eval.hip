@@ -477,6 +477,7 @@ constexpr int HARD_NT = 512;   // 8 waves share a candidate tile + tables (47 KB
 struct HardStage {
   float4* cand; float* lv; float4 *tabA, *tabC; float* vn; float* cst;
 };
+constexpr int HARD_PMAX = 64;   // hard_user_row: lane p holds the user's logit p (beyond it pref_scores_tail scores wave per pair)
 template <int MODE>
 __host__ __device__ inline size_t hard_stage_floats(int nch4, int P, int dp4) {
   return (size_t)nch4 * CT * 4 + (size_t)P * CT + (MODE != 0 ? (size_t)2 * P * dp4 * 4 : (size_t)P * CT + 128);
@@ -1388,6 +1389,7 @@ int pref_scores_tail(const char* name, const float* U, int64_t ldu, const float*
     } else {
       const int mode = l1 ? 1 : (n_pref <= 32 ? 0 : 2);
       fits = (mode ? hard_stage_floats<1>(d / 4, n_pref, g.dp / 4) : hard_stage_floats<0>(d / 4, n_pref, g.dp / 4)) * 4 <= 160 * 1024;
+      if (n_pref > HARD_PMAX) fits = false;
     }
     if (!fits)
       return pref_row(false, name, U, ldu, CW1, d, nullptr, 0, nullptr, -1, pref_ws, n_pref, d, u_ids, nullptr, nq * n_items, n_items, ldo, l1,

@@ -565,7 +565,9 @@ int run_pref(bool bwd, const char* name, const float* U, int64_t ldu, const floa
     const int nt = g.NW * 64;
     KTUP_REQUIRE(nt >= d, "%s: internal geometry error", name);
     const int ngrp = nt / d, pg = (n_pref + ngrp - 1) / ngrp;
-    if (pg > 16) return set_error(KTUP_ERR_UNSUPPORTED, "%s: n_pref %d too large for d=%d (max %d)", name, n_pref, d, 16 * ngrp);
+    if (pg > 16)     // more preferences than the table-gradient pass holds per thread (16 x the d-column groups of a workgroup: 32 at
+      return pref_row(true, name, U, ldu, I, ldi, E, lde, item2ent, ent_pad, pref_ws, n_pref, d, u_ids, i_ids, n, 0, 0, l1, gumbel_mode,
+                      uniform, seed, offset, nullptr, gscore, gU, gI, gE, gA, gC, (hipStream_t)stream, g.ppad, g.dp);   // d = 100): one wave per pair
   } else {
     KTUP_REQUIRE(score, "%s: null score pointer", name);
   }

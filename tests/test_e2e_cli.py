@@ -397,7 +397,8 @@ def test_cli_any_embedding_size(dataset, script, extra):
     rows are staged with a zero tail and training takes the autograd route.  -embedding_size 300 is beyond the tile kernels' 256
     columns: the one-wave-per-pair kernels (ktup_score_pref_row.hip) score, differentiate and evaluate it."""
     for width in ('50', '300'):
-        log, _ = run_cli(script, dataset, 'w%s-%s' % (width, extra[1]), extra + ['-embedding_size', width])
+        more = ['-num_preferences', '40'] if width == '300' and 'transup' in extra else []      # (and more preferences than a tile kernel holds)
+        log, _ = run_cli(script, dataset, 'w%s-%s' % (width, extra[1]), extra + ['-embedding_size', width] + more)
         losses = [float(x) for x in re.findall(r'train loss:(\d+\.\d+)', log)]
         assert len(losses) >= 2 and all(l == l and l < 1e4 for l in losses)
         assert len(re.findall(r'f1:\d\.\d+', log)) >= 3

@@ -78,7 +78,8 @@ def world(seed, nu, ni, ne, nr, d):
 
 @pytest.mark.parametrize('d,ni,nq,npref', [(100, 3240, 70, 20), (64, 130, 33, 4), (128, 1000, 5, 13), (100, 63, 1, 20), (36, 200, 9, 40), (50, 301, 17, 6),
                                            (7, 40, 5, 3),
-                                           (320, 211, 9, 20), (514, 70, 5, 6), (256, 300, 9, 20), (216, 130, 5, 6), (212, 130, 5, 6)])     # 50, 7, 514: not a multiple of 4 (ops stages them with a zero tail); > 256: the row kernels
+                                           (320, 211, 9, 20), (514, 70, 5, 6), (256, 300, 9, 20), (216, 130, 5, 6), (212, 130, 5, 6),
+                                           (64, 130, 9, 100)])     # 100 preferences: past the hard gate's lane-per-preference tile kernels     # 50, 7, 514: not a multiple of 4 (ops stages them with a zero tail); > 256: the row kernels
 def test_pref_eval_vs_oracle(d, ni, nq, npref):
     """TUP / KTUP all-item scores at the ml1m catalogue size (3240 items) and ragged small shapes, soft and hard gate (40 preferences:
     the hard gate's squared-L2 score takes its two-pass form beyond 32).  d = 256 (config 5's width) and 216: the pair kernels' staged

@@ -218,7 +218,8 @@ def _l1_knife_edge(W, i2e, u, i, uni, ktup, eps=1e-7):
     return z.abs().min(dim=1).values < eps
 
 
-@pytest.mark.parametrize('d,npref', [(100, 20), (64, 4), (128, 13), (256, 20), (200, 20), (8, 33), (320, 20), (516, 7), (1028, 3), (322, 5)])
+@pytest.mark.parametrize('d,npref', [(100, 20), (64, 4), (128, 13), (256, 20), (200, 20), (8, 33), (320, 20), (516, 7), (1028, 3), (322, 5),
+                                     (100, 40), (64, 100)])     # more preferences than the tile backward holds (32 at d = 100): the row kernels
 def test_ml1m_shape_vs_oracle_fwd_bwd(d, npref):
     """ml1m-shape tables (scaled down in rows for d=256), B=512*3 pairs, forward and full backward.  Widths beyond 256 (any multiple
     of 4; others staged with a zero tail) run the one-wave-per-pair kernels of ktup_score_pref_row.hip."""

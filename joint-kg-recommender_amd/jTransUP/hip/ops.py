@@ -523,6 +523,8 @@ def eval_kg_ranks(E, R, N, q, r, l1, head, descending, gold_off, gold_ids, filt_
         _table('norm table', N)
     C = E if candidates is None else _table('candidate table', candidates)
     nq = q.numel(); q = _ids('q', q, dev); r = _ids('r', r, dev, nq)
+    if filt_ids is not None and filt_ids.numel() == 0:       # an empty id list has no storage to point at: same as no filter
+        filt_off = filt_ids = None
     if gold_off.numel() != nq + 1 or (filt_off is not None and filt_off.numel() != nq + 1):
         raise L.KtupError('eval_kg_ranks: CSR offsets need len(q) + 1 entries')
     n_gold = gold_ids.numel()
@@ -559,6 +561,8 @@ def eval_kg_ranks_transr(E, R, M, q, r, l1, head, descending, gold_off, gold_ids
     (eval_transr_entities, once per pass) + K18, the loop under the C ABI."""
     dev = _dev(_table('entity table', E)); _table('relation table', R); _table('projection table', M)
     nq = q.numel(); q = _ids('q', q, dev); r = _ids('r', r, dev, nq)
+    if filt_ids is not None and filt_ids.numel() == 0:
+        filt_off = filt_ids = None
     if gold_off.numel() != nq + 1 or (filt_off is not None and filt_off.numel() != nq + 1):
         raise L.KtupError('eval_kg_ranks_transr: CSR offsets need len(q) + 1 entries')
     if ents is not None and (ents.shape != (E.shape[0], E.shape[1], R.shape[0]) or ents.l1 != bool(l1)):

@@ -201,6 +201,14 @@ struct StagedCand {
   const float4* cand; int nch4, lane;
   KTUP_DEV float4 operator()(int v, uint32_t c) const { return cand[(v * nch4 + c) * CT + lane]; }
 };
+// MODE 2 beyond 212 columns: three staged vectors pass the LDS (3 d x 256 B), two do not up to d = 320 -- v and NV stay staged, C0
+// (read once per chunk in the second pass, shared by the QB queries of a group) comes from the lane's own row in memory: a lane
+// streams its row, so a 128-byte line serves eight of its chunks
+struct HybridCand {
+  static constexpr int UNROLL = 2;
+  const float4* cand; const float4* row0; int nch4, lane;
+  KTUP_DEV float4 operator()(int v, uint32_t c) const { return v == 0 ? row0[c] : cand[((v - 1) * nch4 + c) * CT + lane]; }
+};
 // TransH's s = -(e . w) of the lane's candidate against NQ wave-uniform normals.  ONE function for the pair kernels' first pass and for
 // the kernel that tabulates s per (relation, candidate) once per pass: the same operations in the same order, so a table entry has
 // the bits the two-pass kernels compute
@@ -299,11 +307,12 @@ KTUP_DEV uint64_t count_key(float s, uint32_t id) {    // ktup_rank.hip make_key
   return ((uint64_t)u << 32) | id;
 }
 
-template <int MODE, bool L1, bool COUNT = false>
+template <int MODE, bool L1, bool COUNT = false, bool HYB = false>
 __global__ __launch_bounds__(PairsWG<MODE>::NT) void pairs_kernel(PairsArgs a) {
+  static_assert(!HYB || (MODE == 2 && !COUNT), "the hybrid stage is the soft gate's score kernel's");
   constexpr int NWV = PairsWG<MODE>::NWV, NT = PairsWG<MODE>::NT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float4* cand = reinterpret_cast<float4*>(smem);  // [NCV][nch4][CT]
+  float4* cand = reinterpret_cast<float4*>(smem);  // [NCV][nch4][CT]  (HYB: [2][nch4][CT], vectors 1 and 2)
   constexpr int NCV = MODE == 2 ? 3 : 1;
   const int t = threadIdx.x, lane = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -320,10 +329,10 @@ __global__ __launch_bounds__(PairsWG<MODE>::NT) void pairs_kernel(PairsArgs a) {
   for (int idx = t; idx < nch4 * CT; idx += NT) {
     const int j = idx & (CT - 1), c = idx >> 6;
     const int64_t gj = min(j0 + j, a.n_cand - 1);
-    cand[(0 * nch4 + c) * CT + j] = load_cand4(C0, a.ldc0, gj, c, a.d, a.cvec);
+    if (!HYB) cand[(0 * nch4 + c) * CT + j] = load_cand4(C0, a.ldc0, gj, c, a.d, a.cvec);
     if (NCV == 3) {
-      cand[(1 * nch4 + c) * CT + j] = load_cand4(a.C1, a.ldc1, gj, c, a.d, a.cvec);
-      cand[(2 * nch4 + c) * CT + j] = load_cand4(a.C2, a.ldc2, gj, c, a.d, a.cvec);
+      cand[((HYB ? 0 : 1) * nch4 + c) * CT + j] = load_cand4(a.C1, a.ldc1, gj, c, a.d, a.cvec);
+      cand[((HYB ? 1 : 2) * nch4 + c) * CT + j] = load_cand4(a.C2, a.ldc2, gj, c, a.d, a.cvec);
     }
   }
   __syncthreads();
@@ -376,7 +385,11 @@ __global__ __launch_bounds__(PairsWG<MODE>::NT) void pairs_kernel(PairsArgs a) {
       for (int qi = 0; qi < QB; ++qi) stab[qi] = a.wtab[uload(a.rel + qid[qi]) * a.ldw + j0 + lane];
     }
     float acc[QB];
-    pair_group_scores<MODE, L1, QB>(StagedCand{cand, nch4, lane}, nch4, qa, qn, q1p, acc, stab);
+    if constexpr (HYB)
+      pair_group_scores<MODE, L1, QB>(HybridCand{cand, reinterpret_cast<const float4*>(C0 + min(j0 + lane, a.n_cand - 1) * a.ldc0), nch4, lane},
+                                      nch4, qa, qn, q1p, acc, stab);
+    else
+      pair_group_scores<MODE, L1, QB>(StagedCand{cand, nch4, lane}, nch4, qa, qn, q1p, acc, stab);
     if constexpr (COUNT) {
       // per gold entry of each query: the candidates of this tile ordered before it -- (score, id) order of ktup_rank.hip's keys: a
       // lower score, or the same score and a lower id; NaNs on either side (uniform tests) go through the keys themselves
@@ -995,9 +1008,20 @@ dim3 pairs_grid(int64_t n_cand, int64_t nq, int nwv, int64_t target, int64_t slo
 template <int MODE>
 int launch_pairs(const PairsArgs& a, hipStream_t st, const char* name, int nrel = 1) {
   const int ncv = MODE == 2 ? 3 : 1;
-  const size_t lds = (size_t)ncv * (a.dq / 4) * CT * 16;
-  if (lds > 160 * 1024) return set_error(KTUP_ERR_UNSUPPORTED, "%s: embedding_size %d needs %zu B of LDS", name, a.d, lds);
+  size_t lds = (size_t)ncv * (a.dq / 4) * CT * 16;
   dim3 grid = pairs_grid(a.n_cand, a.nq, PairsWG<MODE>::NWV, MODE == 2 ? 512 : 2048, MODE == 2 ? 512 : 1536);
+  if constexpr (MODE == 2) {
+    if (lds > 160 * 1024 && lds / 3 * 2 <= 160 * 1024 && a.cvec && a.d == a.dq && !a.qperm) {      // two vectors staged, C0 from its rows
+      lds = lds / 3 * 2;
+      auto launch = [&](auto kern) {
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, grid, dim3(PairsWG<MODE>::NT), lds, st, a);
+      };
+      if (a.l1) launch(pairs_kernel<2, true, false, true>); else launch(pairs_kernel<2, false, false, true>);
+      return check_launch(name);
+    }
+  }
+  if (lds > 160 * 1024) return set_error(KTUP_ERR_UNSUPPORTED, "%s: embedding_size %d needs %zu B of LDS", name, a.d, lds);
   if (a.qperm) grid.z = (unsigned)nrel;
   if (a.l1) {
     if (lds > 64 * 1024)
@@ -1385,7 +1409,7 @@ int pref_scores_tail(const char* name, const float* U, int64_t ldu, const float*
     bool fits;
     if (gumbel_mode == KTUP_GUMBEL_OFF) {
       const bool mc = !l1 && ktup::opt_eval_mc() && (d == 20 || d == 36 || d == 64 || d == 100 || d == 128);
-      fits = mc || (size_t)3 * (d / 4) * CT * 16 <= 160 * 1024;
+      fits = mc || (size_t)2 * (d / 4) * CT * 16 <= 160 * 1024;          // (two of the three staged: launch_pairs<2>'s hybrid stage)
     } else {
       const int mode = l1 ? 1 : (n_pref <= 32 ? 0 : 2);
       fits = (mode ? hard_stage_floats<1>(d / 4, n_pref, g.dp / 4) : hard_stage_floats<0>(d / 4, n_pref, g.dp / 4)) * 4 <= 160 * 1024;

@@ -924,12 +924,20 @@ def _max_over_ranks(x, device, world):
     return float(t.item())
 
 
+def _leg_steps(steps, warmup):
+    """KTUP_BENCH_LEG_STEPS=<n>: a test hook (tests/test_bench_contract.py runs two ranks on ONE GPU over gloo, where a step of the
+    N-GPU legs stages through the host and takes ~100 x what it takes over RCCL): n timed steps, n // 4 + 1 warm-up steps per leg."""
+    n = int(os.environ.get('KTUP_BENCH_LEG_STEPS', '0') or 0)
+    return (n, n // 4 + 1) if n > 0 else (steps, warmup)
+
+
 def dp_train_leg(device, world, rank, steps=100, warmup=20):
     """BASELINE config 4 on N GPUs: the KTUP joint training step (ml1m shape, d=100, 7 rec : 3 kg, Adagrad + weight decay + clip)
     as data-parallel replicas -- every rank holds all tables, scores its slice of the global batch, ONE all-reduce of the flat
     gradient bucket (9.7 MB), then the identical clip + step (utils/fast_train.py JointStepper).  Weak scaling = global batch
     512 x N, strong = 512.  The comm / compute split: the same per-rank work without the exchange (a one-rank group: HIP-graph
     replay) and the bucket all-reduce alone."""
+    steps, warmup = _leg_steps(steps, warmup)
     import types
     from jTransUP.models import jTransUP as jt
     from jTransUP.utils.fast_train import JointStepper
@@ -1004,6 +1012,9 @@ def config5_leg(device, world, rank, steps=100, warmup=10, batch=8192, full=True
     KTUP forward / BPR / backward kernel with per-pair row gradients, the segment reduction run twice (norm, then clip +
     row-sparse Adagrad straight from registers).  `ms_per_step` is the host clock around `steps` steps, `ms_per_step_device` the
     time between two HIP events around the same steps.  With fewer than 8 ranks the same tables simply give bigger shards."""
+    steps, warmup = _leg_steps(steps, warmup)
+    if os.environ.get('KTUP_BENCH_LEG_STEPS'):
+        full = False                                   # (the same test hook: tables of 1.25 M / 125 K / 625 K rows per rank)
     from jTransUP import parallel
     from jTransUP.sharded_ktup import ShardedKgStepper, ShardedKtupJoint, ShardedKtupStepper
     d, P, B = 256, 20, batch
@@ -1030,6 +1041,8 @@ def config5_leg(device, world, rank, steps=100, warmup=10, batch=8192, full=True
 
     def run(label, what='rec', kind='adagrad', warm=None, cycle=0, **kw):
         warm = warmup if warm is None else warm
+        if os.environ.get('KTUP_BENCH_LEG_STEPS'):
+            warm = min(warm, warmup)                   # (test hook: no 1,500-step Adam warm-up at ~0.1 s per gloo step)
         n = steps + warm + (steps + 2 * cycle if cycle else 0)
         rec = ShardedKtupStepper(Ut, It, Et, *small, item2ent, batch=B, kind=kind, lr=0.005, max_norm=5.0, orth=(what != 'rec'), **kw)
         rec.set_feed([torch.randint(0, hi, (n, B), generator=gen, device=device) for hi in (NUs, NIs, NIs)])   # device-fed: the step's own launches walk the columns
@@ -1125,6 +1138,7 @@ def config4_sharded_leg(device, world, rank, steps=200, warmup=20):
     all-to-alls that use all links at once, plus the fp64 bucket of the four 20-row tables.  Exact for Adagrad / plain SGD without
     weight decay (what the row-sparse update can reproduce).  One rank: the same launches without the wire -- a latency chain of ~9
     launches on 64 pairs' worth of tiles, slower than the dense 2-launch step; the point of the leg is its curve over N."""
+    steps, warmup = _leg_steps(steps, warmup)
     from jTransUP import parallel
     from jTransUP.sharded_ktup import ShardedKtupJoint
     if 512 % world:
@@ -1139,8 +1153,10 @@ def config4_sharded_leg(device, world, rank, steps=200, warmup=20):
         return parallel.ShardedTable(n, d, rank=rank, world=world, device=device, init=lambda g: full[g.to(device)])
     Ut, It, Et = table(NU), table(NI), table(NE + 1, pad_last=True)
     small = [torch.nn.Parameter(torch.nn.functional.normalize(torch.randn(P, d, generator=gen, device=device), dim=1)) for _ in range(4)]
-    item2ent = torch.where(torch.arange(NI, device=device) < ALIGNED, (torch.arange(NI, device=device) * 4) % NE,
-                           torch.full((NI,), NE, device=device)).to(torch.int32)
+    # (4 i + i % 4, not the 4 i of the one-GPU legs: entity ids that are all multiples of 4 would all live on ONE of 2 or 4 owners of
+    #  a row % N sharding and overflow its wire rows -- a real item -> entity map has no such pattern)
+    ar = torch.arange(NI, device=device)
+    item2ent = torch.where(ar < ALIGNED, (ar * 4 + ar % 4) % NE, torch.full((NI,), NE, device=device)).to(torch.int32)
     joint = ShardedKtupJoint.build(Ut, It, Et, *small, item2ent, batch=B, joint_ratio=0.7, margin=1.0, kg_lambda=1.0, kind='adagrad', lr=0.005,
                                    max_norm=5.0, ent_pad=NE)
     n = steps + warmup
@@ -1496,7 +1512,10 @@ def main():
         watchdog.start()
         for name, fn in (('dp_train_step', dp_train_leg), ('config4_sharded_step', config4_sharded_leg), ('config5_step', config5_leg)):
             try:
+                t_leg = time.perf_counter()
                 legs[name] = fn(device, world, rank)
+                if isinstance(legs[name], dict):
+                    legs[name]['leg_wall_s'] = round(time.perf_counter() - t_leg, 1)      # set-up + ramp + timed steps of the whole leg
             except Exception as e:      # noqa: BLE001 -- a leg must not take the headline line down with it
                 legs[name] = {'error': '%s: %s' % (type(e).__name__, e)}
         watchdog.cancel()

@@ -40,7 +40,7 @@ def test_single_gpu_line():
 
 
 def test_two_ranks_as_the_driver_launches_them():
-    env = dict(os.environ, KTUP_BENCH_BACKEND='gloo')
+    env = dict(os.environ, KTUP_BENCH_BACKEND='gloo', KTUP_BENCH_LEG_STEPS='12')       # (short N-GPU legs: two ranks on one GPU stage every exchange through the host)
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
            '--master-port', '29551', os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '2']
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
@@ -56,5 +56,7 @@ def test_two_ranks_as_the_driver_launches_them():
     for leg, gb in (('weak', 1024), ('strong', 512)):
         assert dp[leg]['global_batch'] == gb and dp[leg]['ms_per_step'] > 0 and dp[leg]['ms_allreduce_only'] > 0
         assert 0 < dp[leg]['ms_per_step_compute_only'] < dp[leg]['ms_per_step']
+    c4 = out['config4_sharded_step']            # (an item -> entity map whose ids all fell on one owner overflowed this leg's wire rows until round 6)
+    assert 'error' not in c4 and (c4.get('skipped') or (c4['world'] == 2 and c4['ms_per_step'] > 0))
     c5 = out['config5_step']
     assert 'error' not in c5 and (c5.get('skipped') or (c5['world'] == 2 and c5['ms_per_step'] > 0 and c5['batch_per_rank'] == 8192))

@@ -781,18 +781,21 @@ struct SweepSoftArgs {
   const int64_t* filt_off; const int32_t* filt_ids;
   int topn, nsplit; int64_t split_items; uint64_t* part; int bm_words;
 };
-template <bool L1>
+// HYB: two of the three item arrays staged (v, NV) and v - RV streamed from the lane's row, as in pairs_kernel's hybrid stage: widths
+// beyond 168 up to 256 (the stage is then 128 KB at d = 256, a thread's share of it still PF float4).
+template <bool L1, bool HYB = false>
 __global__ __launch_bounds__(SS_NW * 64) void sweep_soft_kernel(SweepSoftArgs sa) {
   const PairsArgs& a = sa.p;
+  constexpr int NA = HYB ? 2 : 3;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float4* cand = reinterpret_cast<float4*>(smem);                       // [3][nch4][CT]
+  float4* cand = reinterpret_cast<float4*>(smem);                       // [NA][nch4][CT]
   const int t = threadIdx.x, lane = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
   const int nch4 = a.dq / 4;
   const int64_t u0 = (int64_t)blockIdx.x * (SS_NW * SS_UW) + SS_UW * w;
   const int64_t i_lo = (int64_t)blockIdx.y * sa.split_items;
   const int64_t i_hi = min(a.n_cand, i_lo + sa.split_items);
-  char* wb = smem + (size_t)3 * nch4 * CT * 16 + (size_t)w * sweep_wave_bytes(SS_UW, sa.bm_words, sa.topn);
+  char* wb = smem + (size_t)NA * nch4 * CT * 16 + (size_t)w * sweep_wave_bytes(SS_UW, sa.bm_words, sa.topn);
   const SweepState st = sweep_state_init<SS_UW>(wb, sa.topn, sa.bm_words, u0, a.nq, sa.filt_off, sa.filt_ids, i_lo, i_hi, lane);
   const sptr4 QW = as_scalar(a.QW);
   sptr4 qa[SS_UW], qn[SS_UW], q1p[SS_UW];
@@ -803,7 +806,7 @@ __global__ __launch_bounds__(SS_NW * 64) void sweep_soft_kernel(SweepSoftArgs sa
   }
   // a thread's share of a stage: 3 arrays x nch4 x 64 float4 over 1024 threads (at most PF each: d <= 168, the host side checks),
   // fetched one stage ahead into registers
-  const int total = 3 * nch4 * CT;
+  const int total = NA * nch4 * CT;
   constexpr int PF = 8;
   float4 pre[PF];
   const float* src[PF];
@@ -811,7 +814,8 @@ __global__ __launch_bounds__(SS_NW * 64) void sweep_soft_kernel(SweepSoftArgs sa
 #pragma unroll
   for (int k = 0; k < PF; ++k) {
     const int idx = t + k * SS_NW * 64;
-    const int arr = idx / (nch4 * CT), rem = idx - arr * nch4 * CT, c = rem >> 6;
+    const int slot = idx / (nch4 * CT), rem = idx - slot * nch4 * CT, c = rem >> 6;
+    const int arr = slot + (HYB ? 1 : 0);                                // (HYB: the staged slots hold arrays 1 and 2)
     const bool on = idx < total;
     dst[k] = on ? (rem & (CT - 1)) : 0;                                  // the row inside the stage (slots past the end reload row 0: unused)
     src[k] = on ? (arr == 0 ? a.C0 : (arr == 1 ? a.C1 : a.C2)) + 4 * c : a.C0;
@@ -829,7 +833,11 @@ __global__ __launch_bounds__(SS_NW * 64) void sweep_soft_kernel(SweepSoftArgs sa
     __syncthreads();
     if (j0 + CT < i_hi) { KTUP_SS_FETCH(j0 + CT) }                      // in flight under the scores below
     float acc[SS_UW];
-    pair_group_scores<2, L1, SS_UW>(StagedCand{cand, nch4, lane}, nch4, qa, qn, q1p, acc);
+    if constexpr (HYB)
+      pair_group_scores<2, L1, SS_UW>(HybridCand{cand, reinterpret_cast<const float4*>(a.C0 + min(j0 + lane, a.n_cand - 1) * a.d), nch4, lane},
+                                      nch4, qa, qn, q1p, acc);
+    else
+      pair_group_scores<2, L1, SS_UW>(StagedCand{cand, nch4, lane}, nch4, qa, qn, q1p, acc);
     const int64_t item = j0 + lane;
     const bool iok = item < i_hi;
     const int64_t lid = item - i_lo;
@@ -1585,13 +1593,20 @@ extern "C" int ktup_eval_pref_topk_hard(const float* U, int64_t ldu, const float
     ns = (int)((n_items + ss.split_items - 1) / ss.split_items);
     ss.nsplit = ns;
     ss.bm_words = (int)((ss.split_items + 31) / 32);
-    const size_t sl = (size_t)3 * (d / 4) * CT * 16 + SS_NW * sweep_wave_bytes(SS_UW, ss.bm_words, topn);
-    if (sl > 160 * 1024 || 3 * (d / 4) * CT > 8 * SS_NW * 64) return set_error(KTUP_ERR_UNSUPPORTED, "%s: the stage needs %zu B of LDS (per-batch calls remain)", name, sl);
+    const size_t wave_b = SS_NW * sweep_wave_bytes(SS_UW, ss.bm_words, topn);
+    size_t sl = (size_t)3 * (d / 4) * CT * 16 + wave_b;
+    const bool whole = sl <= 160 * 1024 && 3 * (d / 4) * CT <= 8 * SS_NW * 64;
+    if (!whole) {                                   // two arrays staged, the third streamed (d <= 256)
+      sl = (size_t)2 * (d / 4) * CT * 16 + wave_b;
+      if (sl > 160 * 1024 || 2 * (d / 4) * CT > 8 * SS_NW * 64)
+        return set_error(KTUP_ERR_UNSUPPORTED, "%s: the stage needs %zu B of LDS (per-batch calls remain)", name, sl);
+    }
     auto go = [&](auto kern) {
       (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sl);
       hipLaunchKernelGGL(kern, dim3((unsigned)ub, (unsigned)ns), dim3(SS_NW * 64), sl, st, ss);
     };
-    if (l1) go(sweep_soft_kernel<true>); else go(sweep_soft_kernel<false>);
+    if (whole) { if (l1) go(sweep_soft_kernel<true>); else go(sweep_soft_kernel<false>); }
+    else { if (l1) go(sweep_soft_kernel<true, true>); else go(sweep_soft_kernel<false, true>); }
     if (int e = check_launch(name)) return e;
     return ktup::launch_topk_merge(part, nq, ns, topn, top_ids, top_scores, st, name);
   }

@@ -99,7 +99,7 @@ for d in (20, 36, 50, 64, 100, 128, 200, 256, 300):
     print('kg d=%d done: %d cases, %d problems' % (d, ran[0], len(bad)), flush=True)
 
 # ---------------------------------------------------------------- recommendation top-n passes
-for d in (20, 36, 64, 100, 128, 168, 200):
+for d in (20, 36, 64, 100, 128, 168, 172, 200, 212, 216, 256, 260):
     for P in (1, 4, 20, 32):
         for ni, nq, topn in ((1, 3, 1), (7, 5, 10), (63, 37, 10), (64, 1, 16), (65, 300, 10), (500, 64, 5)):
             gen = torch.Generator().manual_seed(d + 31 * P + ni)

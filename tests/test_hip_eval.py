@@ -939,11 +939,12 @@ def test_fused_rec_pass_replayed_as_a_graph_follows_the_tables(monkeypatch):
 @pytest.mark.gpu
 @pytest.mark.parametrize('ktup', [False, True])
 @pytest.mark.parametrize('l1', [False, True])
-@pytest.mark.parametrize('d', [50, 300])
+@pytest.mark.parametrize('d', [50, 300, 256, 200])
 def test_pref_eval_pass_any_embedding_size(ktup, l1, d):
     """-embedding_size 50 (the reference takes any integer, models/base.py:52): the item side prepared once per pass, the per-batch
     scores and the one-sweep filtered top-n all run on rows staged with a zero tail -- the oracle's scores, and the ids of the
-    matrix route.  -embedding_size 300: the one-wave-per-pair forward (ktup_score_pref_row.hip) makes the per-batch scores."""
+    matrix route.  -embedding_size 300: the one-wave-per-pair forward (ktup_score_pref_row.hip) makes the per-batch scores.
+    200 / 256: the soft gate's sweep and the per-batch pair kernel with two of their three item arrays staged (HybridCand)."""
     nu, ni, ne, P, nq, topn = 90, 211, 150, 6, 37, 10
     W, i2e, gen = world(5, nu, ni, ne, P, d)
     D = {k: v.to(DEV) for k, v in W.items()}

@@ -45,4 +45,22 @@ for d in [int(x) for x in sys.argv[1:]] or [256, 320, 512, 1024]:
     uq = torch.arange(512, device=dev)
     with torch.no_grad():
         te = timed(lambda: ops.eval_ktup(U, I, E, A, C, R, Rn, i2e, uq, False), reps=5)
+    # a whole ml1m-size pass (6,040 users, filtered top-10): one sweep (d <= 256) against per-batch scores + topk_filtered
+    allu = torch.arange(NU, device=dev)
+    f_off = (torch.arange(NU + 1, device=dev) * 20)
+    f_ids = torch.randint(0, NI, (NU * 20,), generator=g).to(dev, torch.int32).view(NU, 20).sort(1).values.reshape(-1).contiguous()
+    ps = {}
+    with torch.no_grad():
+        for l1 in (True, False):
+            items = ops.eval_pref_items(I, E, A, C, R, Rn, i2e)
+            if ops.eval_pref_topk(U, allu[:64], items, l1, 10) is not None:
+                ps[('l1' if l1 else 'l2') + '_sweep'] = round(timed(lambda: ops.eval_pref_topk(U, allu, items, l1, 10, f_off, f_ids), reps=5), 3)
+
+            def batched():
+                for b0 in range(0, NU, 512):
+                    ub = allu[b0:b0 + 512]
+                    m = ops.eval_ktup(U, I, E, A, C, R, Rn, i2e, ub, l1, items=items)
+                    ops.topk_filtered(m, False, 10, f_off[b0:b0 + ub.numel() + 1] - f_off[b0], f_ids[int(f_off[b0]):int(f_off[min(b0 + 512, NU)])])
+            ps[('l1' if l1 else 'l2') + '_batched'] = round(timed(batched, reps=3), 3)
+    print('WIDEPASS d=%d  6040 x 3240 filtered top-10 pass ms %s' % (d, ps), flush=True)
     print('WIDEROW d=%d  fwd/bwd ms of 1024 pairs %s  eval 512 x 3240 all-item scores %.3f ms' % (d, out, te), flush=True)

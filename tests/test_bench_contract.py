@@ -42,7 +42,7 @@ def test_single_gpu_line():
 def test_two_ranks_as_the_driver_launches_them():
     env = dict(os.environ, KTUP_BENCH_BACKEND='gloo', KTUP_BENCH_LEG_STEPS='12')       # (short N-GPU legs: two ranks on one GPU stage every exchange through the host)
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-           '--master-port', '29551', os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '2']
+           '--master-port', '29571', os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '2']
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     out = _line(r.stdout)

@@ -388,3 +388,55 @@ def test_sparse_adam_host_side_layouts():
     # under weight decay every kind keeps the lazy rows [m | v | last] (Adagrad's sum in the v half)
     assert row_state(w, 'adagrad', 1e-5).shape == (7, 28) and row_state(w, 'sgd', 1e-5).shape == (7, 28)
     assert _check_state(row_state(w, 'sgd', 1e-5), w, 'sgd', 1e-5) and not _check_state(row_state(w, 'adagrad'), w, 'adagrad', 1e-5)
+
+
+def test_which_tables_take_their_gradient_directly():
+    """hip/ops.py _grad_targets: the score Functions add into an existing `.grad` only for dense contiguous fp32 LEAVES without hooks, outside
+    create_graph, and while set_direct_grad is on; everything else gets zero-filled buffers out of one allocation and the autograd
+    hand-over (the host-side decision, on CPU tensors: no kernel runs here)."""
+    from jTransUP.hip import ops
+    p = torch.nn.Parameter(torch.randn(6, 8))
+    assert not ops._takes_grad_directly(p)                                   # no .grad yet: autograd allocates (and steals) it
+    p.grad = torch.zeros(6, 8)
+    assert ops._takes_grad_directly(p)
+    assert not ops._takes_grad_directly(p * 2.0)                             # a non-leaf (the zero-tail staged tables)
+    frozen = torch.randn(6, 8)
+    assert not ops._takes_grad_directly(frozen)                              # requires_grad False
+    wide = torch.nn.Parameter(torch.randn(6, 16)[:, :8])                     # a view with a row pitch: the kernels' gradient pitch is the table's
+    wide.grad = torch.zeros(6, 8)
+    assert not ops._takes_grad_directly(wide)
+    half = torch.nn.Parameter(torch.randn(6, 8))
+    half.grad = torch.zeros(6, 8)
+    half.grad.data = half.grad.data.double()
+    assert not ops._takes_grad_directly(half)
+    hooked = torch.nn.Parameter(torch.randn(6, 8)); hooked.grad = torch.zeros(6, 8)
+    hooked.register_hook(lambda g: g)
+    assert not ops._takes_grad_directly(hooked)                              # a hook must see the gradient: hand-over
+    q = torch.nn.Parameter(torch.randn(3, 8)); q.grad = torch.ones(3, 8)
+    with torch.no_grad():                                                    # (backward without create_graph runs with grad mode off)
+        bufs, rets = ops._grad_targets(p, None, q, frozen)
+        assert bufs[0] is p.grad and rets[0] is None and bufs[1] is None and rets[1] is None and bufs[2] is q.grad and rets[2] is None
+        assert bufs[3] is rets[3] and bufs[3].shape == frozen.shape and float(bufs[3].abs().sum()) == 0.0
+        was = ops.set_direct_grad(False)
+        try:
+            bufs, rets = ops._grad_targets(p, q)
+            assert bufs[0] is rets[0] and bufs[0] is not p.grad and bufs[1] is rets[1] and float(bufs[0].abs().sum() + bufs[1].abs().sum()) == 0.0
+            assert bufs[0].data_ptr() % 16 == 0 and bufs[1].data_ptr() % 16 == 0     # one allocation, 16-byte aligned parts
+        finally:
+            assert ops.set_direct_grad(was) is False
+    bufs, rets = ops._grad_targets(p)                                        # grad mode on (create_graph): hand-over
+    assert bufs[0] is rets[0] and bufs[0] is not p.grad
+
+
+def test_bench_leg_steps_hook(monkeypatch):
+    """bench.py _leg_steps: KTUP_BENCH_LEG_STEPS shortens the N-GPU legs for the two-ranks-on-one-GPU contract test only."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location('bench_mod', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'bench.py'))
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    monkeypatch.delenv('KTUP_BENCH_LEG_STEPS', raising=False)
+    assert bench._leg_steps(100, 20) == (100, 20)
+    monkeypatch.setenv('KTUP_BENCH_LEG_STEPS', '12')
+    assert bench._leg_steps(100, 20) == (12, 4)
+    monkeypatch.setenv('KTUP_BENCH_LEG_STEPS', '0')
+    assert bench._leg_steps(200, 20) == (200, 20)

@@ -94,11 +94,14 @@ def _grad_targets(*tables):
     (grad mode on inside backward), set_direct_grad(False) -- gets zero-filled buffers out of ONE allocation and ONE fill launch and
     the usual autograd hand-over.  `None` entries (absent tables) pass through."""
     direct = _DIRECT_GRAD[0] and not torch.is_grad_enabled()
-    bufs, rets, fresh = [], [], []
+    bufs, rets, fresh, taken = [], [], [], set()
     for t in tables:
         if t is None:
             bufs.append(None); rets.append(None)
-        elif direct and _takes_grad_directly(t):
+        elif direct and _takes_grad_directly(t) and t.grad.data_ptr() not in taken:
+            # (one table passed twice keeps ONE direct buffer: the sorted-segment reductions of a large batch add without atomics and
+            #  must not meet in the same rows; the second role gets its own buffer and autograd adds it)
+            taken.add(t.grad.data_ptr())
             bufs.append(t.grad); rets.append(None)
         else:
             bufs.append(t); rets.append(t); fresh.append(len(bufs) - 1)

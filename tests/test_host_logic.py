@@ -424,6 +424,8 @@ def test_which_tables_take_their_gradient_directly():
             assert bufs[0].data_ptr() % 16 == 0 and bufs[1].data_ptr() % 16 == 0     # one allocation, 16-byte aligned parts
         finally:
             assert ops.set_direct_grad(was) is False
+        bufs, rets = ops._grad_targets(p, p)                                 # one table in two roles: one direct buffer, one of its own
+        assert bufs[0] is p.grad and rets[0] is None and bufs[1] is rets[1] and bufs[1] is not p.grad
     bufs, rets = ops._grad_targets(p)                                        # grad mode on (create_graph): hand-over
     assert bufs[0] is rets[0] and bufs[0] is not p.grad
 
